@@ -1,0 +1,160 @@
+"""Generate tests/golden/*.npz from the REAL reference modules (imported from /root/reference/src).
+
+Run in the build container only (the GPU box has no /root/reference):
+    python oracle/make_golden.py
+The reference ships no golden vectors of its own, so these files are what pins
+parity: inputs come from oracle/synth.py's NumPy streams (regenerated in the tests from the seeds
+stored in each file), outputs/gradients come from the reference's PyTorch-CPU fp32 forward/backward.
+"""
+from __future__ import annotations
+
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, "/root/reference/src")
+
+from models.fno.fno2d import Fno2d, SpectralConv2d_fast  # noqa: E402  (reference)
+from models.loss import MseLoss  # noqa: E402  (reference)
+
+from oracle import synth  # noqa: E402
+from oracle.make_golden_inputs import spectral_case  # noqa: E402
+
+OUT = REPO / "tests" / "golden"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def gen_spectral(name, seed, B, Cin, Cout, H, W, m1, m2):
+    x, gy, w1, w2 = spectral_case(seed, B, Cin, Cout, H, W, m1, m2)
+    mod = SpectralConv2d_fast(Cin, Cout, m1, m2)
+    with torch.no_grad():
+        mod.weights1.copy_(_t(w1))
+        mod.weights2.copy_(_t(w2))
+    xt = _t(x).requires_grad_(True)
+    y = mod(xt)
+    y.backward(_t(gy))
+    np.savez_compressed(
+        OUT / f"{name}.npz",
+        meta=np.array([seed, B, Cin, Cout, H, W, m1, m2]),
+        y=y.detach().numpy(), gx=xt.grad.numpy(),
+        gw1=mod.weights1.grad.numpy(), gw2=mod.weights2.grad.numpy(),
+    )
+    print(name, "ok", y.shape)
+
+
+def build_ref_model(params, C, L, m1, m2, p):
+    model = Fno2d(2, 2, p, MseLoss(normalize=True), L, m1, m2, C)
+    sd = {k: _t(v) for k, v in params.items()}
+    model.load_state_dict(sd)
+    return model
+
+
+def summarize(a: np.ndarray, idx_seed: int, n: int = 32):
+    flat = np.ascontiguousarray(a).reshape(-1)
+    rng = np.random.default_rng(idx_seed)
+    idx = rng.integers(0, flat.size, size=min(n, flat.size))
+    return dict(norm=np.sqrt(np.sum(np.abs(flat.astype(np.complex128)) ** 2)), sum=flat.sum(dtype=np.complex128),
+                idx=idx, vals=flat[idx])
+
+
+def gen_fno(name, pseed, bseed, B, C, L, H, W, p=5, border=False, full_grads=True, gain=1.0):
+    m1 = m2 = 12
+    params = synth.make_fno_params(pseed, C, L, m1, m2, p, spectral_gain=gain)
+    batch = synth.make_batch(bseed, B, H, W, p, border_mask=border)
+    model = build_ref_model(params, C, L, m1, m2, p)
+    tb = {k: _t(v) for k, v in batch.items()}
+    tb["inputs"].requires_grad_(True)
+    out = model(**tb)
+    out["loss"]["nmse"].backward()
+    save = dict(
+        meta=np.array([pseed, bseed, B, C, L, H, W, p, int(border)]), gain=np.array(gain),
+        preds=out["preds"].detach().numpy(),
+        **{f"loss_{k}": v.detach().numpy() for k, v in out["loss"].items()},
+        g_inputs=tb["inputs"].grad.numpy(),
+    )
+    for k, prm in model.named_parameters():
+        g = prm.grad.numpy()
+        if full_grads:
+            save[f"grad::{k}"] = g
+        else:
+            s = summarize(g, 7)
+            for kk, vv in s.items():
+                save[f"gsum::{k}::{kk}"] = vv
+    np.savez_compressed(OUT / f"{name}.npz", **save)
+    print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
+
+
+def gen_rollout(name, pseed, bseed, B, C, L, H, W, steps, p=5, border=False, gain=1.0):
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=gain)
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    if border:
+        batch["mask"][:, :, 0, :] = 0
+        batch["mask"][:, :, -1, :] = 0
+        batch["mask"][:, :, :, 0] = 0
+    model = build_ref_model(params, C, L, 12, 12, p).eval()
+    with torch.no_grad():
+        frames = model.generate_many(_t(batch["inputs"]), _t(batch["case_params"]), _t(batch["mask"]), steps)
+    frames = np.stack([f.numpy() for f in frames])  # (steps,B,2,H,W)
+    np.savez_compressed(
+        OUT / f"{name}.npz", meta=np.array([pseed, bseed, B, C, L, H, W, p, steps, int(border)]),
+        gain=np.array(gain),
+        last=frames[-1], first=frames[0], norms=np.sqrt((frames ** 2).mean(axis=(1, 2, 3, 4))),
+    )
+    print(name, "ok", frames.shape)
+
+
+def gen_adam(name, pseed, bseed, B, C, L, H, W, nsteps, lr, p=5, gain=1.0):
+    """train_auto.py:231-257: model(**batch) -> loss['nmse'].backward() -> Adam.step() -> zero_grad()."""
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=gain)
+    model = build_ref_model(params, C, L, 12, 12, p)
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    losses = []
+    for s in range(nsteps):
+        batch = synth.make_batch(bseed + s, B, H, W, p)
+        out = model(**{k: _t(v) for k, v in batch.items()})
+        opt.zero_grad()
+        out["loss"]["nmse"].backward()
+        opt.step()
+        losses.append(out["loss"]["nmse"].item())
+    save = dict(meta=np.array([pseed, bseed, B, C, L, H, W, p, nsteps]), lr=np.array(lr), gain=np.array(gain),
+                losses=np.array(losses))
+    for k, v in model.state_dict().items():
+        save[f"param::{k}"] = v.numpy()
+    np.savez_compressed(OUT / f"{name}.npz", **save)
+    print(name, "ok", losses)
+
+
+def gen_mseloss(name, seed):
+    rng = np.random.default_rng(seed)
+    p = rng.standard_normal((3, 2, 17, 19)).astype(np.float32)
+    l = rng.standard_normal((3, 2, 17, 19)).astype(np.float32)
+    r = MseLoss(normalize=True)(preds=_t(p), labels=_t(l))
+    np.savez_compressed(OUT / f"{name}.npz", meta=np.array([seed]), **{k: v.numpy() for k, v in r.items()})
+    print(name, "ok")
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    gen_spectral("spectral_64x64", 11, 2, 3, 4, 64, 64, 12, 12)
+    gen_spectral("spectral_66x65", 12, 2, 4, 3, 66, 65, 12, 12)
+    gen_spectral("spectral_c20_64x64", 13, 1, 20, 20, 64, 64, 12, 12)
+    gen_fno("fno_small_64x64", 21, 31, 2, 8, 2, 64, 64, gain=8.0)
+    gen_fno("fno_small_66x65", 22, 32, 2, 6, 2, 66, 65, border=True, gain=6.0)
+    gen_fno("fno_cfg1_b8", 23, 33, 8, 20, 4, 64, 64, full_grads=False)
+    gen_rollout("rollout_small_64x64", 24, 34, 2, 8, 2, 64, 64, steps=6, gain=8.0)
+    gen_rollout("rollout_small_66x65", 25, 35, 1, 6, 2, 66, 65, steps=4, border=True, gain=6.0)
+    gen_adam("adam_small_64x64", 26, 36, 2, 8, 2, 64, 64, nsteps=3, lr=1e-3, gain=8.0)
+    gen_mseloss("mseloss", 41)
+
+
+if __name__ == "__main__":
+    main()

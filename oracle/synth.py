@@ -1,0 +1,91 @@
+"""Deterministic synthetic weights / batches shared by the golden generator, the tests and bench.py.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).  NumPy's PCG64 stream is bit-stable across
+machines, so a fixture only needs to store the *outputs* the reference produced for these inputs.
+Shapes and distributions follow SURVEY.md section 8(d) ("Synthetic inputs").
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+
+
+def fno_param_shapes(C: int, L: int, m1: int, m2: int, p: int, in_chan: int = 2, out_chan: int = 2,
+                     head: int = 128) -> Dict[str, Tuple[Tuple[int, ...], bool]]:
+    """Reference state_dict layout of Fno2d (src/models/fno/fno2d.py:150-176); value = (shape, is_complex)."""
+    cin0 = in_chan + 1 + 2 + p
+    shapes: Dict[str, Tuple[Tuple[int, ...], bool]] = {}
+    shapes["fc0.weight"] = ((C, cin0, 1, 1), False)
+    shapes["fc0.bias"] = ((C,), False)
+    for l in range(L):
+        shapes[f"blocks.{l}.conv0.weights1"] = ((C, C, m1, m2), True)
+        shapes[f"blocks.{l}.conv0.weights2"] = ((C, C, m1, m2), True)
+        shapes[f"blocks.{l}.w0.weight"] = ((C, C, 1, 1), False)
+        shapes[f"blocks.{l}.w0.bias"] = ((C,), False)
+    shapes["fc1.weight"] = ((head, C, 1, 1), False)
+    shapes["fc1.bias"] = ((head,), False)
+    shapes["fc2.weight"] = ((out_chan, head, 1, 1), False)
+    shapes["fc2.bias"] = ((out_chan,), False)
+    return shapes
+
+
+def make_fno_params(seed: int, C: int = 20, L: int = 4, m1: int = 12, m2: int = 12, p: int = 5,
+                    dtype=np.float32, spectral_gain: float = 1.0) -> Dict[str, np.ndarray]:
+    """Weights with the reference's init *distributions* (conv: U(+-1/sqrt(fan_in)); spectral:
+    scale*U[0,1) re/im, scale = 1/(Cin*Cout), fno2d.py:31-51) drawn from a NumPy stream.
+    ``spectral_gain`` > 1 makes the spectral branch numerically visible next to the 1x1 branch."""
+    rng = np.random.default_rng(seed)
+    cd = np.complex64 if dtype == np.float32 else np.complex128
+    out: Dict[str, np.ndarray] = {}
+    for name, (shape, is_c) in fno_param_shapes(C, L, m1, m2, p).items():
+        if is_c:
+            scale = spectral_gain / (shape[0] * shape[1])
+            re = rng.random(shape)
+            im = rng.random(shape)
+            out[name] = (scale * (re + 1j * im)).astype(cd)
+        else:
+            fan_in = shape[1] if len(shape) == 4 else None
+            if fan_in is None:  # bias: fan_in of the matching weight
+                wname = name.replace("bias", "weight")
+                fan_in = out[wname].shape[1]
+            bound = 1.0 / np.sqrt(fan_in)
+            out[name] = rng.uniform(-bound, bound, size=shape).astype(dtype)
+    return out
+
+
+def make_batch(seed: int, B: int, H: int = 64, W: int = 64, p: int = 5, border_mask: bool = False,
+               dtype=np.float32) -> Dict[str, np.ndarray]:
+    """inputs=randn(B,2,H,W); label=inputs+0.1 randn; case_params=randn(B,p); mask=ones (cavity) or
+    zero top/bottom/left border (tube/dam style) -- SURVEY.md 8(d)."""
+    rng = np.random.default_rng(seed)
+    inputs = rng.standard_normal((B, 2, H, W))
+    label = inputs + 0.1 * rng.standard_normal((B, 2, H, W))
+    case_params = rng.standard_normal((B, p))
+    mask = np.ones((B, 1, H, W))
+    if border_mask:
+        mask[:, :, 0, :] = 0
+        mask[:, :, -1, :] = 0
+        mask[:, :, :, 0] = 0
+    return dict(inputs=inputs.astype(dtype), label=label.astype(dtype),
+                case_params=case_params.astype(dtype), mask=mask.astype(dtype))
+
+
+def make_smooth_batch(seed: int, B: int, H: int = 64, W: int = 64, p: int = 5, kmax: int = 4,
+                      dtype=np.float32) -> Dict[str, np.ndarray]:
+    """Band-limited fields (sum of |k|<=kmax sin/cos with 1/|k|^2 amplitudes) for rollout studies."""
+    rng = np.random.default_rng(seed)
+    xs = np.arange(H)[:, None] / H
+    ys = np.arange(W)[None, :] / W
+    f = np.zeros((B, 2, H, W))
+    for kx in range(-kmax, kmax + 1):
+        for ky in range(0, kmax + 1):
+            kk = max(1.0, float(kx * kx + ky * ky))
+            a = rng.standard_normal((B, 2, 1, 1)) / kk
+            b = rng.standard_normal((B, 2, 1, 1)) / kk
+            ph = 2 * np.pi * (kx * xs + ky * ys)
+            f += a * np.cos(ph) + b * np.sin(ph)
+    out = make_batch(seed + 1, B, H, W, p, dtype=dtype)
+    out["inputs"] = f.astype(dtype)
+    out["label"] = (f + 0.01 * rng.standard_normal(f.shape)).astype(dtype)
+    return out

@@ -1,0 +1,139 @@
+"""CPU: the oracle (oracle/fno_oracle.py) against fixtures produced by the real reference modules
+(oracle/make_golden.py).  This is what pins the oracle -- the reference has no tests of its own."""
+import numpy as np
+import pytest
+
+from oracle import fno_oracle as O
+from oracle import synth
+from oracle.make_golden_inputs import spectral_case
+
+TOL64 = 1e-11  # fp64 oracle vs fp32 reference output: bounded by the reference's own fp32 rounding
+TOL32 = 1e-10
+
+
+@pytest.mark.parametrize("name", ["spectral_64x64", "spectral_66x65", "spectral_c20_64x64"])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_spectral_forward_backward(golden_dir, name, dt):
+    g = np.load(golden_dir / f"{name}.npz")
+    seed, B, Cin, Cout, H, W, m1, m2 = [int(v) for v in g["meta"]]
+    x, gy, w1, w2 = spectral_case(seed, B, Cin, Cout, H, W, m1, m2)
+    cd = np.complex128 if dt == np.float64 else np.complex64
+    x, gy, w1, w2 = x.astype(dt), gy.astype(dt), w1.astype(cd), w2.astype(cd)
+    tol = TOL64 if dt == np.float64 else TOL32
+    y_fft = O.spectral_conv2d_fwd(x, w1, w2)
+    y_dft = O.spectral_conv2d_fwd_dft(x, w1, w2)
+    assert O.rel_nmse(y_fft, g["y"]) < tol
+    assert O.rel_nmse(y_dft, g["y"]) < tol
+    gx, gw1, gw2 = O.spectral_conv2d_bwd(gy, x, w1, w2)
+    assert O.rel_nmse(gx, g["gx"]) < tol
+    assert O.rel_nmse(gw1, g["gw1"]) < tol
+    assert O.rel_nmse(gw2, g["gw2"]) < tol
+
+
+def _run_fno(g, dt, use_fft):
+    pseed, bseed, B, C, L, H, W, p, border = [int(v) for v in g["meta"]]
+    gain = float(g["gain"]) if "gain" in g else 1.0
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=gain)
+    batch = synth.make_batch(bseed, B, H, W, p, border_mask=bool(border))
+    cd = np.complex128 if dt == np.float64 else np.complex64
+    params = {k: v.astype(cd if np.iscomplexobj(v) else dt) for k, v in params.items()}
+    batch = {k: v.astype(dt) for k, v in batch.items()}
+    out = O.fno_forward(params, batch["inputs"], batch["case_params"], batch["mask"], batch["label"], L,
+                        use_fft=use_fft)
+    gp = O.loss_grad_wrt_preds(out["cache"]["preds"], out["cache"]["label"], "nmse")
+    grads = O.fno_backward(params, out["cache"], gp, L)
+    return out, grads
+
+
+@pytest.mark.parametrize("name", ["fno_small_64x64", "fno_small_66x65"])
+@pytest.mark.parametrize("use_fft", [True, False])
+def test_fno_forward_backward_full_grads(golden_dir, name, use_fft):
+    g = np.load(golden_dir / f"{name}.npz")
+    out, grads = _run_fno(g, np.float64, use_fft)
+    assert O.rel_nmse(out["preds"], g["preds"]) < TOL64
+    for k in ("mse", "rmse", "mae", "nmse"):
+        assert abs(out["loss"][k] - float(g[f"loss_{k}"])) <= 2e-6 * abs(float(g[f"loss_{k}"]))
+    assert O.rel_nmse(grads["__inputs__"], g["g_inputs"]) < 1e-9
+    for key in g.files:
+        if key.startswith("grad::"):
+            k = key[len("grad::"):]
+            assert O.rel_nmse(grads[k], g[key]) < 1e-9, k
+
+
+def test_fno_cfg1_b8(golden_dir):
+    """BASELINE.json configs[0]: Auto-FNO, batch 8, 64x64, modes 12, width 20."""
+    g = np.load(golden_dir / "fno_cfg1_b8.npz")
+    out, grads = _run_fno(g, np.float64, True)
+    assert O.rel_nmse(out["preds"], g["preds"]) < TOL64
+    assert abs(out["loss"]["nmse"] - float(g["loss_nmse"])) < 2e-6
+    for key in g.files:
+        if key.startswith("gsum::") and key.endswith("::vals"):
+            k = key.split("::")[1]
+            idx = g[f"gsum::{k}::idx"]
+            vals = np.ascontiguousarray(grads[k]).reshape(-1)[idx]
+            assert O.rel_nmse(vals, g[key]) < 1e-8, k
+            nrm = np.sqrt(np.sum(np.abs(grads[k]) ** 2))
+            assert abs(nrm - abs(g[f"gsum::{k}::norm"])) <= 1e-4 * nrm, k
+
+
+@pytest.mark.parametrize("name", ["rollout_small_64x64", "rollout_small_66x65"])
+def test_rollout(golden_dir, name):
+    g = np.load(golden_dir / f"{name}.npz")
+    pseed, bseed, B, C, L, H, W, p, steps, border = [int(v) for v in g["meta"]]
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=float(g["gain"]))
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    if border:
+        batch["mask"][:, :, 0, :] = 0
+        batch["mask"][:, :, -1, :] = 0
+        batch["mask"][:, :, :, 0] = 0
+    frames = O.generate_many(params, batch["inputs"], batch["case_params"], batch["mask"], steps, L)
+    assert len(frames) == steps
+    assert O.rel_nmse(frames[0], g["first"]) < 1e-9
+    assert O.rel_nmse(frames[-1], g["last"]) < 1e-8
+
+
+def test_rollout_unbatched_adds_batch_dim():
+    params = synth.make_fno_params(3, 4, 1, 12, 12, 5)
+    b = synth.make_smooth_batch(4, 1, 64, 64, 5)
+    f = O.generate_many(params, b["inputs"][0], b["case_params"][0], b["mask"][0], 2, 1)
+    assert f[0].shape == (1, 2, 64, 64)
+
+
+def test_adam_three_steps(golden_dir):
+    g = np.load(golden_dir / "adam_small_64x64.npz")
+    pseed, bseed, B, C, L, H, W, p, nsteps = [int(v) for v in g["meta"]]
+    lr = float(g["lr"])
+    dt = np.float64
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=float(g["gain"]))
+    params = {k: v.astype(np.complex128 if np.iscomplexobj(v) else dt) for k, v in params.items()}
+    state = {k: (np.zeros(v.shape, v.dtype), np.zeros(v.shape, v.dtype)) for k, v in params.items()}
+    losses = []
+    for s in range(nsteps):
+        batch = {k: v.astype(dt) for k, v in synth.make_batch(bseed + s, B, H, W, p).items()}
+        out = O.fno_forward(params, batch["inputs"], batch["case_params"], batch["mask"], batch["label"], L)
+        losses.append(out["loss"]["nmse"])
+        gp = O.loss_grad_wrt_preds(out["cache"]["preds"], out["cache"]["label"], "nmse")
+        grads = O.fno_backward(params, out["cache"], gp, L)
+        for k in params:
+            rv = lambda a: a.view(np.float64) if np.iscomplexobj(a) else a  # noqa: E731
+            O.adam_step(rv(params[k]), rv(np.ascontiguousarray(grads[k])), rv(state[k][0]), rv(state[k][1]),
+                        s + 1, lr)
+    assert np.allclose(losses, g["losses"], rtol=2e-6)
+    for key in g.files:
+        if key.startswith("param::"):
+            k = key[len("param::"):]
+            # Adam's first steps move every weight by ~lr regardless of gradient size: compare the DELTA
+            p0 = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=float(g["gain"]))[k]
+            d_ref = g[key].astype(np.complex128) - p0
+            d_our = params[k] - p0
+            assert O.rel_nmse(d_our, d_ref) < 1e-4, k
+
+
+def test_mseloss(golden_dir):
+    g = np.load(golden_dir / "mseloss.npz")
+    rng = np.random.default_rng(int(g["meta"][0]))
+    p = rng.standard_normal((3, 2, 17, 19)).astype(np.float32)
+    l = rng.standard_normal((3, 2, 17, 19)).astype(np.float32)
+    r = O.mse_loss(p.astype(np.float64), l.astype(np.float64), True)
+    for k in ("mse", "rmse", "mae", "nmse"):
+        assert abs(r[k] - float(g[k])) < 1e-6 * abs(float(g[k]))
