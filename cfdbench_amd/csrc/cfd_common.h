@@ -1,0 +1,58 @@
+// Shared host/device helpers for the cfdbench_amd HIP sources.
+#pragma once
+#include <cfd_intrinsics.h>
+#include <hip/hip_runtime.h>
+
+#include "../../include/cfdbench_amd.h"
+
+void cfd_set_error(const char* fmt, ...);
+
+#define CFD_REQUIRE(cond, code, ...)      \
+    do {                                  \
+        if (!(cond)) {                    \
+            cfd_set_error(__VA_ARGS__);   \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+#define CFD_LAUNCH_CHECK(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            cfd_set_error("%s: HIP launch failed: %s", name, hipGetErrorString(e_));  \
+            return CFD_ERR_HIP;                                                       \
+        }                                                                             \
+    } while (0)
+
+#define CFD_TRY(expr)              \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != CFD_OK) return rc_; \
+    } while (0)
+
+// Operator tables of one (H,W,m1,m2); all d_* pointers are device memory, fragment-major ([step][lane]).
+struct cfd_plan {
+    int H, W, m1, m2;
+    int NJ;  // columns per lane = ceil(W/16)
+    int KX;  // forward stage-1 k-steps over folded rows: ceil((H/2+1)/4)
+    int T;   // inverse x tiles: ceil(H/16)
+    int SA;  // inverse stage-A k-steps: 4 (cos, kappa 0..15) + ceil(m1/4) (sin, kappa 1..m1)
+    int SB;  // inverse stage-B k-steps: ceil(2*m2/4)
+    int n_fwd, n_inv;
+    float* d_fwd;   // t1c[KX][64] | t1s[KX][64] | t2c[4*NJ][64] | t2s[4*NJ][64]
+    float* d_inv;   // ta[T][SA][64] | tb[SB][NJ][64]
+    float* d_clhw;  // [m2]  c_l / (H*W)
+    float* d_gx;    // [H]  np.linspace(0,1,H) as float32   (fno2d.py:251)
+    float* d_gy;    // [W]
+};
+
+static inline size_t cfd_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+#define CFD_SQRT1_2 0.70710678118654752440f
+#define CFD_INV_SQRT_2PI 0.39894228040143267794f
+
+// nn.GELU() exact-erf form (fno2d.py:147) and its derivative Phi(x) + x phi(x).
+__device__ __forceinline__ float cfd_gelu(float x) { return 0.5f * x * (1.0f + cfd_erff(x * CFD_SQRT1_2)); }
+__device__ __forceinline__ float cfd_gelu_grad(float x) {
+    return 0.5f * (1.0f + cfd_erff(x * CFD_SQRT1_2)) + x * CFD_INV_SQRT_2PI * cfd_expf(-0.5f * x * x);
+}

@@ -1,0 +1,23 @@
+// gfx950 (CDNA4) device intrinsics used by the cfdbench_amd kernels.  Wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fmaf chain; 32 cycles issue per SIMD).
+// Operand maps: a = A[i=lane&15][k=lane>>4]; b = B[k=lane>>4][j=lane&15];
+// c/d[r] = C[row=(lane>>4)*4+r][col=lane&15].
+__device__ __forceinline__ f32x4 cfd_mfma16x16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float cfd_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+
+__device__ __forceinline__ float cfd_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ float cfd_erff(float x) { return erff(x); }
+__device__ __forceinline__ float cfd_expf(float x) { return __expf(x); }

@@ -1,0 +1,132 @@
+// cfd_plan: host-built (double precision) pruned-DFT operator tables, laid out in MFMA fragment order.
+// Replaces the FFT plans behind torch.fft.rfft2/irfft2 (src/models/fno/fno2d.py:62,81) and the per-call
+// host np.linspace grids of Fno2d.get_coords (fno2d.py:244-255).
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+#include "cfd_common.h"
+
+static thread_local char g_err[512] = "";
+
+void cfd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* cfd_last_error(void) { return g_err; }
+extern "C" int cfd_version(void) { return 100; }
+
+static int upload(const std::vector<float>& h, float** d) {
+    if (hipMalloc((void**)d, h.size() * sizeof(float)) != hipSuccess) return CFD_ERR_HIP;
+    if (hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return CFD_ERR_HIP;
+    return CFD_OK;
+}
+
+extern "C" int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out) {
+    CFD_REQUIRE(out != nullptr, CFD_ERR_INVALID_ARG, "cfd_plan_create: out is NULL");
+    CFD_REQUIRE(H >= 2 && H <= 128 && W >= 2 && W <= 80, CFD_ERR_UNSUPPORTED,
+                "cfd_plan_create: grid %dx%d unsupported (need 2<=H<=128, 2<=W<=80)", H, W);
+    CFD_REQUIRE(m1 >= 1 && m1 <= 15 && 2 * m1 <= H, CFD_ERR_UNSUPPORTED,
+                "cfd_plan_create: modes1=%d unsupported (need 1<=m1<=15 and 2*m1<=H=%d)", m1, H);
+    CFD_REQUIRE(m2 >= 1 && m2 <= 16 && m2 <= W / 2 + 1, CFD_ERR_UNSUPPORTED,
+                "cfd_plan_create: modes2=%d unsupported (need 1<=m2<=16 and m2<=W/2+1, W=%d)", m2, W);
+    cfd_plan* p = new cfd_plan();
+    p->H = H; p->W = W; p->m1 = m1; p->m2 = m2;
+    p->NJ = (W + 15) / 16;
+    if (p->NJ < 4) p->NJ = 4;
+    p->KX = (H / 2 + 1 + 3) / 4;
+    p->T = (H + 15) / 16;
+    p->SA = 4 + (m1 + 3) / 4;
+    p->SB = (2 * m2 + 3) / 4;
+    const int NJ = p->NJ, KX = p->KX, T = p->T, SA = p->SA, SB = p->SB;
+    const double PI2 = 6.283185307179586476925286766559;
+
+    // ---- forward tables ----
+    std::vector<float> fwd((size_t)(2 * KX + 8 * NJ) * 64, 0.f);
+    float* t1c = fwd.data();
+    float* t1s = t1c + KX * 64;
+    float* t2c = t1s + KX * 64;
+    float* t2s = t2c + 4 * NJ * 64;
+    for (int s = 0; s < KX; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int xf = 4 * s + (lane >> 4), kap = lane & 15;
+            if (xf > H / 2 || kap > m1) continue;
+            const bool paired = (xf != 0) && (2 * xf != H);
+            const double th = PI2 * (double)((long)kap * xf % H) / H;
+            t1c[s * 64 + lane] = (float)std::cos(th);
+            t1s[s * 64 + lane] = paired ? (float)std::sin(th) : 0.f;
+        }
+    for (int j = 0; j < NJ; ++j)
+        for (int r = 0; r < 4; ++r)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int l = lane & 15, y = NJ * (4 * (lane >> 4) + r) + j;
+                if (l >= m2 || y >= W) continue;
+                const double ph = PI2 * (double)((long)l * y % W) / W;
+                t2c[(j * 4 + r) * 64 + lane] = (float)std::cos(ph);
+                t2s[(j * 4 + r) * 64 + lane] = (float)std::sin(ph);
+            }
+    // ---- inverse tables ----
+    std::vector<float> inv((size_t)(T * SA + SB * NJ) * 64, 0.f);
+    float* ta = inv.data();
+    float* tb = ta + T * SA * 64;
+    for (int t = 0; t < T; ++t)
+        for (int s = 0; s < SA; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int e = 4 * s + (lane >> 4), x = 16 * t + (lane & 15);
+                if (x >= H) continue;
+                const bool cosblk = e < 16;
+                const int kap = cosblk ? e : e - 15;
+                if (kap > m1) continue;
+                const double th = PI2 * (double)((long)kap * x % H) / H;
+                ta[(t * SA + s) * 64 + lane] = (float)(cosblk ? std::cos(th) : std::sin(th));
+            }
+    std::vector<float> clhw(m2);
+    for (int l = 0; l < m2; ++l) {
+        double c = (l == 0 || (W % 2 == 0 && l == W / 2)) ? 1.0 : 2.0;
+        clhw[l] = (float)(c / ((double)H * W));
+    }
+    for (int s = 0; s < SB; ++s)
+        for (int j = 0; j < NJ; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int c = 4 * s + (lane >> 4), y = NJ * (lane & 15) + j;
+                if (c >= 2 * m2 || y >= W) continue;
+                const bool im = c >= m2;
+                const int l = im ? c - m2 : c;
+                const double cl = ((l == 0 || (W % 2 == 0 && l == W / 2)) ? 1.0 : 2.0) / ((double)H * W);
+                const double ph = PI2 * (double)((long)l * y % W) / W;
+                tb[(s * NJ + j) * 64 + lane] = (float)(im ? -cl * std::sin(ph) : cl * std::cos(ph));
+            }
+    // ---- coordinate grids: np.linspace(0, 1, n) in float64, cast to float32 (fno2d.py:251,253) ----
+    std::vector<float> gx(H), gy(W);
+    for (int i = 0; i < H; ++i) gx[i] = (i == H - 1) ? 1.0f : (float)((double)i * (1.0 / (double)(H - 1)));
+    for (int i = 0; i < W; ++i) gy[i] = (i == W - 1) ? 1.0f : (float)((double)i * (1.0 / (double)(W - 1)));
+
+    p->n_fwd = (int)fwd.size();
+    p->n_inv = (int)inv.size();
+    int rc = upload(fwd, &p->d_fwd);
+    if (rc == CFD_OK) rc = upload(inv, &p->d_inv);
+    if (rc == CFD_OK) rc = upload(clhw, &p->d_clhw);
+    if (rc == CFD_OK) rc = upload(gx, &p->d_gx);
+    if (rc == CFD_OK) rc = upload(gy, &p->d_gy);
+    if (rc != CFD_OK) {
+        cfd_set_error("cfd_plan_create: device allocation/copy of operator tables failed");
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return CFD_OK;
+}
+
+extern "C" void cfd_plan_destroy(cfd_plan* p) {
+    if (!p) return;
+    hipFree(p->d_fwd);
+    hipFree(p->d_inv);
+    hipFree(p->d_clhw);
+    hipFree(p->d_gx);
+    hipFree(p->d_gy);
+    delete p;
+}

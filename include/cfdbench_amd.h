@@ -1,0 +1,175 @@
+/* cfdbench_amd -- C ABI of the MI355X-native (gfx950) hot path behind CFDBench's AutoCfdModel plugin surface.
+ *
+ * The reference (luo-yining/CFDBench) is pure Python/PyTorch and has NO native boundary of its own
+ * (SURVEY.md section 8b); its extension surface is the Python classes in src/models/base_model.py:41-81.  The entry
+ * points below are what a `torch.autograd.Function` under those classes binds (INTEGRATION.md shows the ctypes
+ * stub).  Each function names the reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain C, raw DEVICE pointers, explicit sizes, the HIP stream to enqueue on (void* = hipStream_t);
+ *   - every function only ENQUEUES work on `stream` and returns an int status: 0 = ok, <0 = error
+ *     (cfd_last_error() gives the text); no C++ exception crosses the boundary;
+ *   - all buffers are owned by the caller (PyTorch's caching allocator); any scratch is a caller-provided
+ *     workspace whose size the matching *_workspace_bytes() function reports;
+ *   - fp32 tensors are NCHW-contiguous; complex64 tensors are interleaved (re,im) float pairs, exactly
+ *     torch.view_as_real of the reference's parameters (state_dict ABI);
+ *   - functions are re-entrant; a cfd_plan is immutable after creation and may be shared between threads.
+ */
+#ifndef CFDBENCH_AMD_H
+#define CFDBENCH_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFD_OK 0
+#define CFD_ERR_INVALID_ARG (-1)
+#define CFD_ERR_UNSUPPORTED (-2)
+#define CFD_ERR_HIP (-3)
+#define CFD_ERR_WORKSPACE (-4)
+
+#define CFD_MAX_LAYERS 16
+
+int cfd_version(void);
+const char* cfd_last_error(void);
+
+/* ---- plan: pruned-DFT operator tables for one grid (H,W) and mode count (m1,m2) -------------------------
+ * Replaces the implicit FFT plans behind torch.fft.rfft2 / irfft2 (src/models/fno/fno2d.py:62,81) and the
+ * per-call host-side np.linspace coordinate grids of Fno2d.get_coords (fno2d.py:244-255).
+ * Allocates a few tens of KB of device memory; create once per (H,W,m1,m2), never inside stream capture. */
+typedef struct cfd_plan cfd_plan;
+int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out);
+void cfd_plan_destroy(cfd_plan* plan);
+
+/* ---- SpectralConv2d_fast pieces (src/models/fno/fno2d.py:59-82) ----------------------------------------
+ * Kept modes: rows K = [0,m1) U [H-m1,H) (2*m1 rows, in that order) x columns [0,m2).  M = 2*m1*m2.        */
+
+/* xh[img, row, l] = sum_{x,y} f(x[img,x,y]) e^{-2 pi i (K[row] x/H + l y/W)}   (== rfft2(x)[..., K, :m2], fno2d.py:62)
+ * x: (nimg,H,W) f32; xh: (nimg,2*m1,m2) c64.  act_in: 0 = identity, 1 = exact-erf GELU applied on load.   */
+int cfd_spectral_dft(const cfd_plan* plan, const float* x, float* xh, int nimg, int act_in, void* stream);
+
+/* conj_t = 0:  z[b,o,row,l] = sum_i xh[b,i,row,l] * Wsel[i,o,row,l]           (compl_mul2d, fno2d.py:54-57,73-78)
+ * conj_t = 1:  z[b,i,row,l] = sum_o conj(Wsel[i,o,row,l]) * xh[b,o,row,l]     (its adjoint w.r.t. the input)
+ * Wsel = w1 for rows < m1, w2 for rows >= m1; w1,w2: (Cin,Cout,m1,m2) c64.                                  */
+int cfd_spectral_mix(const cfd_plan* plan, const float* xh, const float* w1, const float* w2, float* z,
+                     int B, int Cin, int Cout, int conj_t, void* stream);
+
+/* out[img,x,y] = epi( (1/HW) Re sum_{row,l} c_l z[img,row,l] e^{+2 pi i (K[row] x/H + l y/W)} )
+ * (== irfft2 of the zero-filled spectrum, fno2d.py:65-81; c_0 = 1, c_l = 2).
+ * epi 0: value;  epi 1: value + addend;  epi 2: (value + addend) * gelu'(aprev).  addend may alias out.   */
+int cfd_spectral_idft(const cfd_plan* plan, const float* z, const float* addend, const float* aprev, float* out,
+                      int nimg, int epi, void* stream);
+
+/* gw{1,2}[i,o,rm,l] = sum_b conj(xh[b,i,row,l]) * (c_l/HW) * gh[b,o,row,l]   (autograd of fno2d.py:73-78)
+ * ws: cfd_spectral_wgrad_workspace_bytes() bytes.  Overwrites gw1, gw2.                                    */
+size_t cfd_spectral_wgrad_workspace_bytes(const cfd_plan* plan, int B, int Cin, int Cout);
+int cfd_spectral_wgrad(const cfd_plan* plan, const float* xh, const float* gh, float* gw1, float* gw2, void* ws,
+                       int B, int Cin, int Cout, void* stream);
+
+/* y = SpectralConv2d_fast(x) (fno2d.py:59-82).  xh_out (B,Cin,2*m1,m2) c64 receives the kept input modes (saved
+ * for the backward pass); z_ws (B,Cout,2*m1,m2) c64 is scratch.                                              */
+int cfd_spectral_conv2d_fwd(const cfd_plan* plan, const float* x, const float* w1, const float* w2, float* y,
+                            float* xh_out, float* z_ws, int B, int Cin, int Cout, void* stream);
+
+/* Backward of the above given gy: gx (B,Cin,H,W), gw1, gw2 (Cin,Cout,m1,m2) c64.  xh = modes saved by forward.
+ * ws: cfd_spectral_conv2d_bwd_workspace_bytes() bytes.  Any of gx / (gw1,gw2) may be NULL to skip it.       */
+size_t cfd_spectral_conv2d_bwd_workspace_bytes(const cfd_plan* plan, int B, int Cin, int Cout);
+int cfd_spectral_conv2d_bwd(const cfd_plan* plan, const float* gy, const float* xh, const float* w1, const float* w2,
+                            float* gx, float* gw1, float* gw2, void* ws, int B, int Cin, int Cout, void* stream);
+
+/* ---- pointwise / channel-mixing pieces -----------------------------------------------------------------*/
+
+/* out[b,o,p] = bias[o] + sum_i w[o,i] f(in[b,i,p])   (nn.Conv2d(k=1): fno2d.py:104,150; transpose=1 uses w[i,o]
+ * and is the input-gradient of the same conv).  in: (B,Ci,HW); out: (B,Co,HW); w: (Co,Ci) (or (Ci,Co) rows if
+ * transpose); bias may be NULL.  act_in as in cfd_spectral_dft.  Ci,Co <= 32.                              */
+int cfd_chanmix(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int HW,
+                int act_in, int transpose, void* stream);
+
+/* gw[o,i] = sum_{b,p} g[b,o,p] f(in[b,i,p]);  gb[o] = sum_{b,p} g[b,o,p]   (weight/bias grads of that conv).
+ * ws: cfd_chan_wgrad_workspace_bytes().  Overwrites gw, gb.                                                */
+size_t cfd_chan_wgrad_workspace_bytes(int B, int Ci, int Co, int HW);
+int cfd_chan_wgrad(const float* g, const float* in, float* gw, float* gb, void* ws, int B, int Ci, int Co, int HW,
+                   int act_in, void* stream);
+
+/* Fno2d input assembly + fc0 (fno2d.py:189-217): features [u, v, mask, grid_x, grid_y, props...] -> (B,C,H,W).
+ * inputs (B,in_chan,H,W); mask (B,1,H,W) or NULL (= ones, fno2d.py:189-191); case_params (B,P); w (C, in_chan+3+P). */
+int cfd_fno_stem_fwd(const cfd_plan* plan, const float* inputs, const float* mask, const float* case_params,
+                     const float* w, const float* bias, float* out, int B, int in_chan, int P, int C, void* stream);
+size_t cfd_fno_stem_bwd_workspace_bytes(const cfd_plan* plan, int B, int in_chan, int P, int C);
+int cfd_fno_stem_bwd(const cfd_plan* plan, const float* g, const float* inputs, const float* mask,
+                     const float* case_params, float* gw, float* gb, void* ws, int B, int in_chan, int P, int C,
+                     void* stream);
+
+/* Projection head + mask + MseLoss sums (fno2d.py:228-237, src/models/loss.py:22-37):
+ *   preds[b,c,p] = mask[b,p] * (b2[c] + sum_j w2[c,j] gelu(b1[j] + sum_i w1[j,i] f(a[b,i,p])))
+ *   if label: sums[0..3] = { sum (preds - label*mask)^2, sum |preds - label*mask|, sum (label*mask)^2, count }
+ * a: (B,C,HW); w1: (Hd,C); w2: (Co,Hd); Hd multiple of 16, <= 128; Co <= 2.  label/sums/ws may be NULL together. */
+size_t cfd_fno_head_workspace_bytes(int B, int C, int Hd, int Co, int HW);
+int cfd_fno_head_fwd(const float* a, const float* mask, const float* label, const float* w1, const float* b1,
+                     const float* w2, const float* b2, float* preds, float* sums, void* ws, int B, int C, int Hd,
+                     int Co, int HW, int act_in, void* stream);
+
+/* Backward of the head.  Upstream gradient on preds is  gpreds_ext[b,c,p] (may be NULL)
+ *   + coef[0] * 2 (preds - label*mask) + coef[1] * sign(preds - label*mask),   coef = 2 device floats
+ * (nmse: coef[0] = 1/sums[2]; mse: coef[0] = 1/count; mae: coef[1] = 1/count -- written by cfd_loss_coef).
+ * Outputs: ga (B,C,HW) = d/da (already multiplied by f'(a) when act_in=1); gw1,gb1,gw2,gb2 overwritten.     */
+int cfd_fno_head_bwd(const float* a, const float* mask, const float* label, const float* preds,
+                     const float* gpreds_ext, const float* coef, const float* w1, const float* b1, const float* w2,
+                     float* ga, float* gw1, float* gb1, float* gw2, float* gb2, void* ws, int B, int C, int Hd, int Co,
+                     int HW, int act_in, void* stream);
+
+/* MseLoss on arbitrary tensors (src/models/loss.py:22-37): sums = {sum (p-l)^2, sum |p-l|, sum l^2, n}.
+ * ws: cfd_loss_workspace_bytes(n).                                                                         */
+size_t cfd_loss_workspace_bytes(size_t n);
+int cfd_masked_loss_sums(const float* preds, const float* labels, float* sums, void* ws, size_t n, void* stream);
+/* scores[0..3] = {mse, rmse, mae, nmse} from sums (loss.py:27-35).                                           */
+int cfd_loss_scores(const float* sums, float* scores, void* stream);
+/* coef for cfd_fno_head_bwd: which = 0 mse, 1 nmse, 2 mae; scaled by `upstream` (d objective / d loss).       */
+int cfd_loss_coef(const float* sums, float* coef, int which, float upstream, void* stream);
+
+/* torch.optim.Adam step on one flat fp32 buffer (train_auto.py:213,256; complex params as (re,im) pairs --
+ * torch's view_as_real handling).  step >= 1.                                                               */
+int cfd_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ---- whole Auto-FNO (Fno2d.forward, fno2d.py:178-242; loss.backward() at train_auto.py:255) ---------------*/
+typedef struct {
+    int B, H, W;
+    int in_chan, out_chan, n_case_params;
+    int hidden, num_layers, modes1, modes2, head;
+} cfd_fno_shape;
+
+typedef struct { /* device pointers, reference state_dict order (SURVEY.md 8b "Checkpoint ABI") */
+    float* fc0_w;
+    float* fc0_b;
+    float* spec_w1[CFD_MAX_LAYERS]; /* blocks.{l}.conv0.weights1, c64 */
+    float* spec_w2[CFD_MAX_LAYERS];
+    float* w0_w[CFD_MAX_LAYERS];    /* blocks.{l}.w0.weight */
+    float* w0_b[CFD_MAX_LAYERS];
+    float* fc1_w;
+    float* fc1_b;
+    float* fc2_w;
+    float* fc2_b;
+} cfd_fno_params;
+
+/* Bytes of caller-provided workspace: activations kept for backward + scratch.  training=0: forward only.   */
+size_t cfd_fno_workspace_bytes(const cfd_plan* plan, const cfd_fno_shape* shape, int training);
+
+/* preds (B,out_chan,H,W); sums (4 floats) written iff label != NULL.  With training=1 the workspace keeps what
+ * cfd_fno_backward needs (same ws pointer must be passed to it, untouched in between).                      */
+int cfd_fno_forward(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,
+                    const float* inputs, const float* case_params, const float* mask, const float* label,
+                    float* preds, float* sums, void* ws, int training, void* stream);
+
+/* grads: same layout as params, every tensor overwritten.  coef/gpreds_ext as in cfd_fno_head_bwd.           */
+int cfd_fno_backward(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,
+                     const cfd_fno_params* grads, const float* inputs, const float* case_params, const float* mask,
+                     const float* label, const float* preds, const float* gpreds_ext, const float* coef, void* ws,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFDBENCH_AMD_H */
