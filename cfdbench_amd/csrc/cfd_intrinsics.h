@@ -19,5 +19,13 @@ __device__ __forceinline__ float cfd_wave_sum(float v) {
     return v;
 }
 
+// Orders LDS traffic between the lanes of ONE wave (each wave owns a private LDS region): LDS operations of a
+// wave execute in program order on CDNA, so only the compiler needs fencing -- no s_barrier, no waitcnt.
+__device__ __forceinline__ void cfd_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float cfd_erff(float x) { return erff(x); }
 __device__ __forceinline__ float cfd_expf(float x) { return __expf(x); }

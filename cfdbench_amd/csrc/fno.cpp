@@ -1,0 +1,130 @@
+// Whole Auto-FNO forward / backward as one C call each (Fno2d.forward, src/models/fno/fno2d.py:178-242, and the
+// autograd pass behind loss["nmse"].backward(), src/train_auto.py:255).  Only enqueues kernels on `stream`.
+//
+// Activation storage: block l keeps its PRE-activation a_{l+1} = spectral(h_l) + w0 h_l + b (h_0 = a_0 = fc0 output,
+// h_l = gelu(a_l) for l >= 1); consumers apply GELU on load (act_in=1) so every activation crosses HBM once per
+// producer/consumer instead of once more for a standalone GELU pass, and the backward pass reads the same buffers.
+#include "cfd_common.h"
+
+namespace {
+
+struct Layout {
+    size_t n_act;    // floats of one (B,C,H,W) activation
+    size_t n_modes;  // floats of one (B,C,2*m1,m2) complex tensor
+    size_t off_acts, off_xh, off_z, off_gA, off_gB, off_gh, off_scratch;
+    size_t scratch_bytes, total_bytes;
+    int n_acts, n_xh;
+};
+
+size_t max2(size_t a, size_t b) { return a > b ? a : b; }
+
+Layout make_layout(const cfd_plan* p, const cfd_fno_shape* s, int training) {
+    Layout L{};
+    const size_t HW = (size_t)s->H * s->W;
+    const int C = s->hidden, B = s->B;
+    L.n_act = (size_t)B * C * HW;
+    L.n_modes = (size_t)B * C * 2 * s->modes1 * s->modes2 * 2;
+    L.n_acts = training ? s->num_layers + 1 : 2;
+    L.n_xh = training ? s->num_layers : 1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += cfd_align_up(bytes, 256); return o; };
+    L.off_acts = take(L.n_act * sizeof(float) * L.n_acts);
+    L.off_xh = take(L.n_modes * sizeof(float) * L.n_xh);
+    L.off_z = take(L.n_modes * sizeof(float));
+    size_t scratch = cfd_fno_head_workspace_bytes(B, C, s->head, s->out_chan, (int)HW);
+    if (training) {
+        L.off_gA = take(L.n_act * sizeof(float));
+        L.off_gB = take(L.n_act * sizeof(float));
+        L.off_gh = take(L.n_modes * sizeof(float));
+        scratch = max2(scratch, cfd_spectral_wgrad_workspace_bytes(p, B, C, C));
+        scratch = max2(scratch, cfd_chan_wgrad_workspace_bytes(B, C, C, (int)HW));
+        scratch = max2(scratch, cfd_fno_stem_bwd_workspace_bytes(p, B, s->in_chan, s->n_case_params, C));
+    }
+    L.scratch_bytes = scratch;
+    L.off_scratch = take(scratch);
+    L.total_bytes = off;
+    return L;
+}
+
+int check_shape(const char* fn, const cfd_plan* p, const cfd_fno_shape* s) {
+    CFD_REQUIRE(p && s, CFD_ERR_INVALID_ARG, "%s: NULL plan/shape", fn);
+    CFD_REQUIRE(p->H == s->H && p->W == s->W && p->m1 == s->modes1 && p->m2 == s->modes2, CFD_ERR_INVALID_ARG,
+                "%s: plan is for %dx%d modes (%d,%d) but shape says %dx%d modes (%d,%d)", fn, p->H, p->W, p->m1, p->m2,
+                s->H, s->W, s->modes1, s->modes2);
+    CFD_REQUIRE(s->B >= 1, CFD_ERR_INVALID_ARG, "%s: empty batch", fn);
+    CFD_REQUIRE(s->num_layers >= 0 && s->num_layers <= CFD_MAX_LAYERS, CFD_ERR_UNSUPPORTED, "%s: num_layers=%d (max %d)", fn,
+                s->num_layers, CFD_MAX_LAYERS);
+    CFD_REQUIRE(s->hidden >= 1 && s->hidden <= 32, CFD_ERR_UNSUPPORTED, "%s: hidden=%d (max 32)", fn, s->hidden);
+    return CFD_OK;
+}
+
+}  // namespace
+
+extern "C" size_t cfd_fno_workspace_bytes(const cfd_plan* p, const cfd_fno_shape* s, int training) {
+    if (!p || !s || s->B < 1) return 0;
+    return make_layout(p, s, training).total_bytes;
+}
+
+extern "C" int cfd_fno_forward(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm, const float* inputs,
+                               const float* case_params, const float* mask, const float* label, float* preds,
+                               float* sums, void* ws, int training, void* stream) {
+    CFD_TRY(check_shape("cfd_fno_forward", p, s));
+    CFD_REQUIRE(prm && inputs && preds && ws, CFD_ERR_INVALID_ARG, "cfd_fno_forward: NULL pointer");
+    CFD_REQUIRE(!label || sums, CFD_ERR_INVALID_ARG, "cfd_fno_forward: label given without sums");
+    const Layout L = make_layout(p, s, training);
+    char* base = (char*)ws;
+    const int B = s->B, C = s->hidden, HW = s->H * s->W, NL = s->num_layers;
+    auto act_buf = [&](int l) { return (float*)(base + L.off_acts) + (size_t)(training ? l : (l & 1)) * L.n_act; };
+    auto xh_buf = [&](int l) { return (float*)(base + L.off_xh) + (size_t)(training ? l : 0) * L.n_modes; };
+    float* z = (float*)(base + L.off_z);
+    void* scratch = base + L.off_scratch;
+
+    CFD_TRY(cfd_fno_stem_fwd(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, act_buf(0), B, s->in_chan,
+                             s->n_case_params, C, stream));
+    for (int l = 0; l < NL; ++l) {  // FnoBlock.forward, fno2d.py:106-112
+        const int act = l > 0;
+        CFD_TRY(cfd_spectral_dft(p, act_buf(l), xh_buf(l), B * C, act, stream));
+        CFD_TRY(cfd_spectral_mix(p, xh_buf(l), prm->spec_w1[l], prm->spec_w2[l], z, B, C, C, 0, stream));
+        CFD_TRY(cfd_chanmix(act_buf(l), prm->w0_w[l], prm->w0_b[l], act_buf(l + 1), B, C, C, HW, act, 0, stream));
+        CFD_TRY(cfd_spectral_idft(p, z, act_buf(l + 1), nullptr, act_buf(l + 1), B * C, 1, stream));
+    }
+    CFD_TRY(cfd_fno_head_fwd(act_buf(NL), mask, label, prm->fc1_w, prm->fc1_b, prm->fc2_w, prm->fc2_b, preds, sums,
+                             scratch, B, C, s->head, s->out_chan, HW, NL > 0, stream));
+    return CFD_OK;
+}
+
+extern "C" int cfd_fno_backward(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm,
+                                const cfd_fno_params* g, const float* inputs, const float* case_params,
+                                const float* mask, const float* label, const float* preds, const float* gpreds_ext,
+                                const float* coef, void* ws, void* stream) {
+    CFD_TRY(check_shape("cfd_fno_backward", p, s));
+    CFD_REQUIRE(prm && g && inputs && ws, CFD_ERR_INVALID_ARG, "cfd_fno_backward: NULL pointer");
+    const Layout L = make_layout(p, s, 1);
+    char* base = (char*)ws;
+    const int B = s->B, C = s->hidden, HW = s->H * s->W, NL = s->num_layers;
+    auto act_buf = [&](int l) { return (float*)(base + L.off_acts) + (size_t)l * L.n_act; };
+    auto xh_buf = [&](int l) { return (float*)(base + L.off_xh) + (size_t)l * L.n_modes; };
+    float* z = (float*)(base + L.off_z);
+    float* gcur = (float*)(base + L.off_gA);
+    float* gnext = (float*)(base + L.off_gB);
+    float* gh = (float*)(base + L.off_gh);
+    void* scratch = base + L.off_scratch;
+
+    CFD_TRY(cfd_fno_head_bwd(act_buf(NL), mask, label, preds, gpreds_ext, coef, prm->fc1_w, prm->fc1_b, prm->fc2_w, gcur,
+                             g->fc1_w, g->fc1_b, g->fc2_w, g->fc2_b, scratch, B, C, s->head, s->out_chan, HW, NL > 0,
+                             stream));
+    for (int l = NL - 1; l >= 0; --l) {
+        const int act = l > 0;
+        // gcur = d loss / d a_{l+1}
+        CFD_TRY(cfd_spectral_dft(p, gcur, gh, B * C, 0, stream));
+        CFD_TRY(cfd_spectral_wgrad(p, xh_buf(l), gh, g->spec_w1[l], g->spec_w2[l], scratch, B, C, C, stream));
+        CFD_TRY(cfd_chan_wgrad(gcur, act_buf(l), g->w0_w[l], g->w0_b[l], scratch, B, C, C, HW, act, stream));
+        CFD_TRY(cfd_spectral_mix(p, gh, prm->spec_w1[l], prm->spec_w2[l], z, B, C, C, 1, stream));
+        CFD_TRY(cfd_chanmix(gcur, prm->w0_w[l], nullptr, gnext, B, C, C, HW, 0, 1, stream));
+        CFD_TRY(cfd_spectral_idft(p, z, gnext, act ? act_buf(l) : nullptr, gnext, B * C, act ? 2 : 1, stream));
+        float* t = gcur; gcur = gnext; gnext = t;
+    }
+    CFD_TRY(cfd_fno_stem_bwd(p, gcur, inputs, mask, case_params, g->fc0_w, g->fc0_b, scratch, B, s->in_chan,
+                             s->n_case_params, C, stream));
+    return CFD_OK;
+}

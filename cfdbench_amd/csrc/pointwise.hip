@@ -1,0 +1,481 @@
+// Channel-mixing (1x1 conv) kernels, the Fno2d input stem, MseLoss reductions and the flat Adam step.
+//   nn.Conv2d(k=1)            src/models/fno/fno2d.py:104,150      -> k_chanmix / k_chan_wgrad
+//   feature assembly + fc0    src/models/fno/fno2d.py:189-217      -> k_stem_fwd / k_chan_wgrad<STEM>
+//   MseLoss                   src/models/loss.py:22-37             -> k_loss_part / k_loss_final
+//   torch.optim.Adam          src/train_auto.py:213,256            -> k_adam
+#include "cfd_common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// stem: [u, v, mask, grid_x, grid_y, props...] -> fc0
+// ------------------------------------------------------------------------------------------------------
+template <int CP>
+__global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ inputs, const float* __restrict__ mask,
+                                                  const float* __restrict__ cp, const float* __restrict__ gx,
+                                                  const float* __restrict__ gy, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                  int in_chan, int P, int C, int H, int W) {
+    __shared__ float s_w[32 * CP];  // [feature][out], zero padded
+    __shared__ float s_b[CP];
+    const int F = in_chan + 3 + P;
+    for (int i = threadIdx.x; i < 32 * CP; i += blockDim.x) {
+        const int f = i / CP, o = i % CP;
+        s_w[i] = (f < F && o < C) ? w[o * F + f] : 0.f;
+    }
+    for (int i = threadIdx.x; i < CP; i += blockDim.x) s_b[i] = i < C ? bias[i] : 0.f;
+    __syncthreads();
+    const int HW = H * W;
+    const long total = (long)B * HW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / HW), p = (int)(idx - (long)b * HW);
+        const int row = p / W, col = p - row * W;
+        float acc[CP];
+#pragma unroll
+        for (int o = 0; o < CP; ++o) acc[o] = s_b[o];
+        auto add = [&](int f, float v) {
+#pragma unroll
+            for (int o = 0; o < CP; ++o) acc[o] = fmaf(s_w[f * CP + o], v, acc[o]);
+        };
+        for (int c = 0; c < in_chan; ++c) add(c, inputs[((size_t)b * in_chan + c) * HW + p]);
+        add(in_chan, mask ? mask[(size_t)b * HW + p] : 1.f);  // fno2d.py:189-195
+        add(in_chan + 1, gx[row]);                              // grid_x varies along rows, fno2d.py:251-252
+        add(in_chan + 2, gy[col]);
+        for (int k = 0; k < P; ++k) add(in_chan + 3 + k, cp[(size_t)b * P + k]);
+#pragma unroll
+        for (int o = 0; o < CP; ++o)
+            if (o < C) out[((size_t)b * C + o) * HW + p] = acc[o];
+    }
+}
+
+extern "C" int cfd_fno_stem_fwd(const cfd_plan* p, const float* inputs, const float* mask, const float* case_params,
+                                const float* w, const float* bias, float* out, int B, int in_chan, int P, int C,
+                                void* stream) {
+    CFD_REQUIRE(p && inputs && w && bias && out && (P == 0 || case_params), CFD_ERR_INVALID_ARG, "cfd_fno_stem_fwd: NULL pointer");
+    CFD_REQUIRE(B >= 0 && in_chan >= 1 && P >= 0 && C >= 1, CFD_ERR_INVALID_ARG, "cfd_fno_stem_fwd: bad sizes");
+    CFD_REQUIRE(in_chan + 3 + P <= 32 && C <= 32, CFD_ERR_UNSUPPORTED,
+                "cfd_fno_stem_fwd: features=%d (max 32) / hidden=%d (max 32) unsupported", in_chan + 3 + P, C);
+    if (B == 0) return CFD_OK;
+    const long total = (long)B * p->H * p->W;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+#define CFD_STEM(CPV)                                                                                              \
+    hipLaunchKernelGGL((k_stem_fwd<CPV>), dim3(blocks), dim3(256), 0, st, inputs, mask, case_params,               \
+                       (const float*)p->d_gx, (const float*)p->d_gy, w, bias, out, B, in_chan, P, C, p->H, p->W)
+    if (C <= 8) CFD_STEM(8);
+    else if (C <= 16) CFD_STEM(16);
+    else if (C <= 24) CFD_STEM(24);
+    else CFD_STEM(32);
+#undef CFD_STEM
+    CFD_LAUNCH_CHECK("cfd_fno_stem_fwd");
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 1x1 conv forward (and its input gradient with transpose=1)
+// ------------------------------------------------------------------------------------------------------
+template <int CPO, int VEC, bool ACT>
+__global__ __launch_bounds__(256) void k_chanmix(const float* __restrict__ in, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, float* __restrict__ out, int B, int Ci,
+                                                 int Co, int HW, int transpose) {
+    __shared__ float s_w[32 * CPO];  // [in][out], zero padded
+    __shared__ float s_b[CPO];
+    for (int i = threadIdx.x; i < 32 * CPO; i += blockDim.x) {
+        const int ci = i / CPO, o = i % CPO;
+        float v = 0.f;
+        if (ci < Ci && o < Co) v = transpose ? w[ci * Co + o] : w[o * Ci + ci];
+        s_w[i] = v;
+    }
+    for (int i = threadIdx.x; i < CPO; i += blockDim.x) s_b[i] = (bias && i < Co) ? bias[i] : 0.f;
+    __syncthreads();
+    const int units = HW / VEC;  // VEC divides HW (checked by the launcher)
+    const long total = (long)B * units;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / units), p = (int)(idx - (long)b * units) * VEC;
+        float acc[CPO][VEC];
+#pragma unroll
+        for (int o = 0; o < CPO; ++o)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[o][k] = s_b[o];
+        for (int ci = 0; ci < Ci; ++ci) {
+            float v[VEC];
+            const float* src = in + ((size_t)b * Ci + ci) * HW + p;
+            if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v[k] = src[k];
+            }
+            if constexpr (ACT) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v[k] = cfd_gelu(v[k]);
+            }
+#pragma unroll
+            for (int o = 0; o < CPO; ++o) {
+                const float wv = s_w[ci * CPO + o];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[o][k] = fmaf(wv, v[k], acc[o][k]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < CPO; ++o) {
+            if (o < Co) {
+                float* dst = out + ((size_t)b * Co + o) * HW + p;
+                if constexpr (VEC == 4) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) dst[k] = acc[o][k];
+                }
+            }
+        }
+    }
+}
+
+template <int CPO, int VEC>
+static int launch_chanmix(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int HW,
+                          int act, int transpose, hipStream_t st) {
+    const long total = (long)B * (HW / VEC);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (act)
+        hipLaunchKernelGGL((k_chanmix<CPO, VEC, true>), dim3(blocks), dim3(256), 0, st, in, w, bias, out, B, Ci, Co, HW, transpose);
+    else
+        hipLaunchKernelGGL((k_chanmix<CPO, VEC, false>), dim3(blocks), dim3(256), 0, st, in, w, bias, out, B, Ci, Co, HW, transpose);
+    CFD_LAUNCH_CHECK("cfd_chanmix");
+    return CFD_OK;
+}
+
+extern "C" int cfd_chanmix(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int HW,
+                           int act_in, int transpose, void* stream) {
+    CFD_REQUIRE(in && w && out, CFD_ERR_INVALID_ARG, "cfd_chanmix: NULL pointer");
+    CFD_REQUIRE(B >= 0 && Ci >= 1 && Co >= 1 && HW >= 1, CFD_ERR_INVALID_ARG, "cfd_chanmix: bad sizes");
+    CFD_REQUIRE(Ci <= 32 && Co <= 32, CFD_ERR_UNSUPPORTED, "cfd_chanmix: Ci=%d Co=%d (max 32) unsupported", Ci, Co);
+    if (B == 0) return CFD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool v4 = HW % 4 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0;
+#define CFD_CM(CPV)                                                                                   \
+    return v4 ? launch_chanmix<CPV, 4>(in, w, bias, out, B, Ci, Co, HW, act_in, transpose, st)       \
+              : launch_chanmix<CPV, 1>(in, w, bias, out, B, Ci, Co, HW, act_in, transpose, st)
+    if (Co <= 8) CFD_CM(8);
+    if (Co <= 16) CFD_CM(16);
+    if (Co <= 24) CFD_CM(24);
+    CFD_CM(32);
+#undef CFD_CM
+}
+
+// ------------------------------------------------------------------------------------------------------
+// weight/bias gradient of a 1x1 conv on the matrix pipe:  gw[o][i] = sum_{b,p} g[b,o,p] f(in[b,i,p])
+// M = out channel, N = in channel (+1 "ones" column that yields the bias gradient), K = pixels.
+// ------------------------------------------------------------------------------------------------------
+struct StemSrc {  // feature source for the fc0 weight gradient (features are never materialised)
+    const float* mask;
+    const float* cp;
+    const float* gx;
+    const float* gy;
+    int in_chan, P, W;
+};
+
+template <int MT, int NT, bool VEC4, bool ACT, bool STEM>
+__global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g, const float* __restrict__ in,
+                                                    StemSrc ss, float* __restrict__ part, int B, int Ci, int Co,
+                                                    int HW) {
+    __shared__ float s_red[4 * MT * NT * 4 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[a][c] = zero;
+    const int cpb = (HW + 15) / 16;  // 16-pixel chunks per batch entry
+    const long total = (long)B * cpb;
+    const int CiIn = STEM ? ss.in_chan : Ci;  // channels physically present in `in`
+    for (long ch = (long)blockIdx.x * 4 + wave; ch < total; ch += (long)gridDim.x * 4) {
+        const int b = (int)(ch / cpb);
+        const int px = (int)(ch - (long)b * cpb) * 16 + 4 * q;  // this lane's 4 pixels: px .. px+3
+        float av[MT][4], bv[NT][4];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int o = 16 * a + n;
+            const float* src = g + ((size_t)b * Co + o) * HW + px;
+            if (VEC4) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (o < Co && px < HW) t = *reinterpret_cast<const float4*>(src);
+                av[a][0] = t.x; av[a][1] = t.y; av[a][2] = t.z; av[a][3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[a][j] = (o < Co && px + j < HW) ? src[j] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const int i = 16 * c + n;
+            if (i < CiIn) {
+                const float* src = in + ((size_t)b * CiIn + i) * HW + px;
+                if (VEC4) {
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (px < HW) t = *reinterpret_cast<const float4*>(src);
+                    bv[c][0] = t.x; bv[c][1] = t.y; bv[c][2] = t.z; bv[c][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bv[c][j] = (px + j < HW) ? src[j] : 0.f;
+                }
+                if constexpr (ACT) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bv[c][j] = cfd_gelu(bv[c][j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pj = px + j;
+                    float v = 0.f;
+                    if (pj < HW) {
+                        if (i == Ci) v = 1.f;  // ones column -> bias gradient
+                        else if constexpr (STEM) {
+                            const int f = i - ss.in_chan;
+                            if (f == 0) v = ss.mask ? ss.mask[(size_t)b * HW + pj] : 1.f;
+                            else if (f == 1) v = ss.gx[pj / ss.W];
+                            else if (f == 2) v = ss.gy[pj % ss.W];
+                            else if (f < 3 + ss.P) v = ss.cp[(size_t)b * ss.P + (f - 3)];
+                        }
+                    }
+                    bv[c][j] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int c = 0; c < NT; ++c) acc[a][c] = cfd_mfma16x16x4(av[a][j], bv[c][j], acc[a][c]);
+    }
+    // block reduction of the 4 waves, then one partial tile per block
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_red[((wave * MT * NT + a * NT + c) * 4 + r) * 64 + lane] = acc[a][c][r];
+    __syncthreads();
+    const int NW = Ci + 1;
+    float* dst = part + (size_t)blockIdx.x * Co * NW;
+    for (int e = threadIdx.x; e < MT * NT * 4 * 64; e += blockDim.x) {
+        const int ln = e & 63, r = (e >> 6) & 3, tile = e >> 8;
+        const int a = tile / NT, c = tile % NT;
+        const int o = 16 * a + 4 * (ln >> 4) + r, i = 16 * c + (ln & 15);
+        if (o < Co && i < NW) {
+            float s = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) s += s_red[((wv * MT * NT + tile) * 4 + r) * 64 + ln];
+            dst[o * NW + i] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int nblk, float* __restrict__ gw,
+                                                      float* __restrict__ gb, int Co, int Ci) {
+    const int NW = Ci + 1;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Co * NW) return;
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * Co * NW + e];
+    const int o = e / NW, i = e - o * NW;
+    if (i < Ci) gw[o * Ci + i] = s;
+    else if (gb) gb[o] = s;
+}
+
+static int wgrad_blocks(int B, int HW) {
+    const long chunks = (long)B * ((HW + 15) / 16);
+    long blocks = (chunks + 31) / 32;  // >= 8 chunks per wave
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+extern "C" size_t cfd_chan_wgrad_workspace_bytes(int B, int Ci, int Co, int HW) {
+    if (B <= 0) return 0;
+    return (size_t)wgrad_blocks(B, HW) * Co * (Ci + 1) * sizeof(float);
+}
+
+template <bool STEM>
+static int launch_wgrad(const float* g, const float* in, StemSrc ss, float* gw, float* gb, void* ws, int B, int Ci,
+                        int Co, int HW, int act, hipStream_t st) {
+    const int blocks = wgrad_blocks(B, HW);
+    const int MT = (Co + 15) / 16, NT = (Ci + 1 + 15) / 16;
+    const bool v4 = HW % 4 == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)in % 16) == 0;
+    float* part = (float*)ws;
+#define CFD_WG(M_, N_, V_, A_)                                                                                   \
+    hipLaunchKernelGGL((k_chan_wgrad<M_, N_, V_, A_, STEM>), dim3(blocks), dim3(256), 0, st, g, in, ss, part, B, \
+                       Ci, Co, HW)
+#define CFD_WG_VA(M_, N_)                              \
+    do {                                               \
+        if (v4 && act) CFD_WG(M_, N_, true, true);     \
+        else if (v4) CFD_WG(M_, N_, true, false);      \
+        else if (act) CFD_WG(M_, N_, false, true);     \
+        else CFD_WG(M_, N_, false, false);             \
+    } while (0)
+    if (MT == 1 && NT == 1) CFD_WG_VA(1, 1);
+    else if (MT == 1 && NT == 2) CFD_WG_VA(1, 2);
+    else if (MT == 2 && NT == 1) CFD_WG_VA(2, 1);
+    else if (MT == 2 && NT == 2) CFD_WG_VA(2, 2);
+    else if (MT == 2 && NT == 3) CFD_WG_VA(2, 3);
+    else if (MT == 1 && NT == 3) CFD_WG_VA(1, 3);
+    else {
+        cfd_set_error("cfd_chan_wgrad: Co=%d Ci=%d unsupported tile shape", Co, Ci);
+        return CFD_ERR_UNSUPPORTED;
+    }
+#undef CFD_WG_VA
+#undef CFD_WG
+    CFD_LAUNCH_CHECK("cfd_chan_wgrad");
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((Co * (Ci + 1) + 255) / 256), dim3(256), 0, st, (const float*)part, blocks,
+                       gw, gb, Co, Ci);
+    CFD_LAUNCH_CHECK("cfd_chan_wgrad(reduce)");
+    return CFD_OK;
+}
+
+extern "C" int cfd_chan_wgrad(const float* g, const float* in, float* gw, float* gb, void* ws, int B, int Ci, int Co,
+                              int HW, int act_in, void* stream) {
+    CFD_REQUIRE(g && in && gw && ws, CFD_ERR_INVALID_ARG, "cfd_chan_wgrad: NULL pointer");
+    CFD_REQUIRE(B >= 1 && Ci >= 1 && Co >= 1 && HW >= 1, CFD_ERR_INVALID_ARG, "cfd_chan_wgrad: bad sizes");
+    CFD_REQUIRE(Ci <= 32 && Co <= 32, CFD_ERR_UNSUPPORTED, "cfd_chan_wgrad: Ci=%d Co=%d (max 32) unsupported", Ci, Co);
+    StemSrc ss{};
+    return launch_wgrad<false>(g, in, ss, gw, gb, ws, B, Ci, Co, HW, act_in, (hipStream_t)stream);
+}
+
+extern "C" size_t cfd_fno_stem_bwd_workspace_bytes(const cfd_plan* p, int B, int in_chan, int P, int C) {
+    if (!p) return 0;
+    return cfd_chan_wgrad_workspace_bytes(B, in_chan + 3 + P, C, p->H * p->W);
+}
+
+extern "C" int cfd_fno_stem_bwd(const cfd_plan* p, const float* g, const float* inputs, const float* mask,
+                                const float* case_params, float* gw, float* gb, void* ws, int B, int in_chan, int P,
+                                int C, void* stream) {
+    CFD_REQUIRE(p && g && inputs && gw && gb && ws && (P == 0 || case_params), CFD_ERR_INVALID_ARG, "cfd_fno_stem_bwd: NULL pointer");
+    CFD_REQUIRE(in_chan + 3 + P <= 32 && C <= 32, CFD_ERR_UNSUPPORTED, "cfd_fno_stem_bwd: too many features/channels");
+    StemSrc ss{mask, case_params, p->d_gx, p->d_gy, in_chan, P, p->W};
+    return launch_wgrad<true>(g, inputs, ss, gw, gb, ws, B, in_chan + 3 + P, C, p->H * p->W, 0, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// MseLoss sums  (src/models/loss.py:22-37)
+// ------------------------------------------------------------------------------------------------------
+#define CFD_LOSS_BLOCKS 256
+
+__global__ __launch_bounds__(256) void k_loss_part(const float* __restrict__ p, const float* __restrict__ l, size_t n,
+                                                   float* __restrict__ part) {
+    __shared__ float s_r[3 * 4];
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float lv = l[i], d = p[i] - lv;
+        a = fmaf(d, d, a);
+        b += fabsf(d);
+        c = fmaf(lv, lv, c);
+    }
+    a = cfd_wave_sum(a); b = cfd_wave_sum(b); c = cfd_wave_sum(c);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_r[wave] = a; s_r[4 + wave] = b; s_r[8 + wave] = c; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float* s = s_r + 4 * threadIdx.x;
+        part[blockIdx.x * 3 + threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+    }
+}
+
+// Deterministic final sum of per-block partials: sums = {sum sq err, sum abs err, sum sq label, count}.
+__global__ __launch_bounds__(64) void k_loss_final(const float* __restrict__ part, int nblk, float count,
+                                                   float* __restrict__ sums) {
+    const int lane = threadIdx.x;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int k = lane; k < nblk; k += 64) { a += part[k * 3]; b += part[k * 3 + 1]; c += part[k * 3 + 2]; }
+    a = cfd_wave_sum(a); b = cfd_wave_sum(b); c = cfd_wave_sum(c);
+    if (lane == 0) { sums[0] = a; sums[1] = b; sums[2] = c; sums[3] = count; }
+}
+
+extern "C" size_t cfd_loss_workspace_bytes(size_t n) { (void)n; return CFD_LOSS_BLOCKS * 3 * sizeof(float); }
+
+extern "C" int cfd_masked_loss_sums(const float* preds, const float* labels, float* sums, void* ws, size_t n,
+                                    void* stream) {
+    CFD_REQUIRE(preds && labels && sums && ws, CFD_ERR_INVALID_ARG, "cfd_masked_loss_sums: NULL pointer");
+    CFD_REQUIRE(n >= 1, CFD_ERR_INVALID_ARG, "cfd_masked_loss_sums: empty tensors (mean of nothing)");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_loss_part, dim3(CFD_LOSS_BLOCKS), dim3(256), 0, st, preds, labels, n, (float*)ws);
+    CFD_LAUNCH_CHECK("cfd_masked_loss_sums(part)");
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, st, (const float*)ws, CFD_LOSS_BLOCKS, (float)n, sums);
+    CFD_LAUNCH_CHECK("cfd_masked_loss_sums(final)");
+    return CFD_OK;
+}
+
+__global__ void k_loss_scores(const float* __restrict__ sums, float* __restrict__ scores) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float n = sums[3];
+        const float mse = sums[0] / n;              // loss.py:27
+        scores[0] = mse;
+        scores[1] = sqrtf(mse);                     // loss.py:31
+        scores[2] = sums[1] / n;                    // loss.py:28
+        scores[3] = mse / (sums[2] / n);            // loss.py:35
+    }
+}
+
+extern "C" int cfd_loss_scores(const float* sums, float* scores, void* stream) {
+    CFD_REQUIRE(sums && scores, CFD_ERR_INVALID_ARG, "cfd_loss_scores: NULL pointer");
+    hipLaunchKernelGGL(k_loss_scores, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, scores);
+    CFD_LAUNCH_CHECK("cfd_loss_scores");
+    return CFD_OK;
+}
+
+__global__ void k_loss_coef(const float* __restrict__ sums, float* __restrict__ coef, int which, float upstream) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float c0 = 0.f, c1 = 0.f;
+        if (which == 0) c0 = upstream / sums[3];        // d mse / d preds = 2 (p-l) / n
+        else if (which == 1) c0 = upstream / sums[2];   // d nmse / d preds = 2 (p-l) / sum l^2
+        else c1 = upstream / sums[3];                   // d mae / d preds = sign(p-l) / n
+        coef[0] = c0;
+        coef[1] = c1;
+    }
+}
+
+extern "C" int cfd_loss_coef(const float* sums, float* coef, int which, float upstream, void* stream) {
+    CFD_REQUIRE(sums && coef, CFD_ERR_INVALID_ARG, "cfd_loss_coef: NULL pointer");
+    CFD_REQUIRE(which >= 0 && which <= 2, CFD_ERR_INVALID_ARG, "cfd_loss_coef: which must be 0 (mse), 1 (nmse), 2 (mae)");
+    hipLaunchKernelGGL(k_loss_coef, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, coef, which, upstream);
+    CFD_LAUNCH_CHECK("cfd_loss_coef");
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Adam  (torch.optim.Adam defaults: amsgrad=False, maximize=False; train_auto.py:213)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                              float wd, float bc1, float rsqrt_bc2, float gscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * gscale;
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float mi = fmaf(1.f - b1, gi - m[i], m[i]);           // m.lerp_(g, 1-b1)
+        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);       // v.mul_(b2).addcmul_(g, g, 1-b2)
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;              // sqrt(v)/sqrt(bc2) + eps
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+extern "C" int cfd_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                             void* stream) {
+    CFD_REQUIRE(param && grad && exp_avg && exp_avg_sq, CFD_ERR_INVALID_ARG, "cfd_adam_flat: NULL pointer");
+    CFD_REQUIRE(step >= 1, CFD_ERR_INVALID_ARG, "cfd_adam_flat: step must be >= 1");
+    if (n == 0) return CFD_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)),
+                       grad_scale);
+    CFD_LAUNCH_CHECK("cfd_adam_flat");
+    return CFD_OK;
+}

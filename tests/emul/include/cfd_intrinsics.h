@@ -40,5 +40,7 @@ inline float cfd_wave_sum(float v) {
     return v;
 }
 
+inline void cfd_wave_lds_sync() { cfd_emul::wave_sync(); }
+
 inline float cfd_erff(float x) { return erff(x); }
 inline float cfd_expf(float x) { return expf(x); }

@@ -1,0 +1,322 @@
+"""Backend-agnostic parity checks of every C-ABI entry point against the oracle (oracle/fno_oracle.py).
+Used by tests/test_emul_kernels.py (CPU, SIMT emulator) and tests/test_gpu_kernels.py (MI355X)."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from cfdbench_amd._capi import FnoParams, FnoShape
+from oracle import fno_oracle as O
+from oracle import synth
+
+# north_star tolerance: relative nMSE <= 1e-5 (fp32).  The kernels are exact-fp32 MFMA/FMA chains, so the
+# checks hold them to a far tighter bound; TOL is what a fp32 pipeline of this depth can actually deliver.
+TOL = 1e-10
+NORTH_STAR_TOL = 1e-5
+
+f64 = np.float64
+c128 = np.complex128
+
+
+def nm(a, ref):
+    return O.rel_nmse(a, ref)
+
+
+def check_spectral(be, B, Cin, Cout, H, W, m1=12, m2=12, seed=0):
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    gy = rng.standard_normal((B, Cout, H, W)).astype(np.float32)
+    w1 = (rng.random((Cin, Cout, m1, m2)) + 1j * rng.random((Cin, Cout, m1, m2))).astype(np.complex64)
+    w2 = (rng.random((Cin, Cout, m1, m2)) + 1j * rng.random((Cin, Cout, m1, m2))).astype(np.complex64)
+    plan = api.plan_create(H, W, m1, m2)
+    try:
+        dx, dgy, dw1, dw2 = be.dev(x), be.dev(gy), be.dev(w1), be.dev(w2)
+        xh = be.zeros((B, Cin, 2 * m1, m2), np.complex64)
+        z = be.zeros((B, Cout, 2 * m1, m2), np.complex64)
+        y = be.zeros((B, Cout, H, W))
+        api.call("cfd_spectral_conv2d_fwd", plan, P(dx), P(dw1), P(dw2), P(y), P(xh), P(z), B, Cin, Cout, be.stream)
+        be.sync()
+        x64, w164, w264 = x.astype(f64), w1.astype(c128), w2.astype(c128)
+        res = {}
+        res["xh"] = nm(be.host(xh), O.pruned_dft_fwd(x64, m1, m2))
+        res["y"] = nm(be.host(y), O.spectral_conv2d_fwd(x64, w164, w264))
+        ws = be.bytes(api.size("cfd_spectral_conv2d_bwd_workspace_bytes", plan, B, Cin, Cout))
+        gx = be.zeros((B, Cin, H, W))
+        gw1 = be.zeros((Cin, Cout, m1, m2), np.complex64)
+        gw2 = be.zeros((Cin, Cout, m1, m2), np.complex64)
+        api.call("cfd_spectral_conv2d_bwd", plan, P(dgy), P(xh), P(dw1), P(dw2), P(gx), P(gw1), P(gw2), P(ws), B, Cin,
+                 Cout, be.stream)
+        be.sync()
+        rgx, rgw1, rgw2 = O.spectral_conv2d_bwd(gy.astype(f64), x64, w164, w264)
+        res["gx"] = nm(be.host(gx), rgx)
+        res["gw1"] = nm(be.host(gw1), rgw1)
+        res["gw2"] = nm(be.host(gw2), rgw2)
+        return res
+    finally:
+        api.plan_destroy(plan)
+
+
+def check_idft_epilogues(be, nimg, H, W, m1=12, m2=12, seed=1):
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    z = (rng.standard_normal((nimg, 1, 2 * m1, m2)) + 1j * rng.standard_normal((nimg, 1, 2 * m1, m2))).astype(np.complex64)
+    ad = rng.standard_normal((nimg, 1, H, W)).astype(np.float32)
+    ap = rng.standard_normal((nimg, 1, H, W)).astype(np.float32)
+    plan = api.plan_create(H, W, m1, m2)
+    try:
+        ref = O.pruned_idft(z.astype(c128), H, W)
+        dz, dap = be.dev(z), be.dev(ap)
+        res = {}
+        o1 = be.dev(ad)
+        api.call("cfd_spectral_idft", plan, P(dz), P(o1), None, P(o1), nimg, 1, be.stream)
+        be.sync()
+        res["epi1"] = nm(be.host(o1), ref + ad)
+        o2 = be.dev(ad)
+        api.call("cfd_spectral_idft", plan, P(dz), P(o2), P(dap), P(o2), nimg, 2, be.stream)
+        be.sync()
+        res["epi2"] = nm(be.host(o2), (ref + ad) * O.gelu_grad(ap.astype(f64)))
+        # GELU-on-load variant of the forward transform
+        xh = be.zeros((nimg, 1, 2 * m1, m2), np.complex64)
+        api.call("cfd_spectral_dft", plan, P(dap), P(xh), nimg, 1, be.stream)
+        be.sync()
+        res["dft_gelu"] = nm(be.host(xh), O.pruned_dft_fwd(O.gelu(ap.astype(f64)), m1, m2))
+        return res
+    finally:
+        api.plan_destroy(plan)
+
+
+def check_chanmix(be, B, Ci, Co, HW, act, seed=2):
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, Ci, HW)).astype(np.float32)
+    w = rng.standard_normal((Co, Ci)).astype(np.float32)
+    b = rng.standard_normal((Co,)).astype(np.float32)
+    g = rng.standard_normal((B, Co, HW)).astype(np.float32)
+    f = O.gelu(x.astype(f64)) if act else x.astype(f64)
+    res = {}
+    out = be.zeros((B, Co, HW))
+    dx, dw, db, dg = be.dev(x), be.dev(w), be.dev(b), be.dev(g)  # keep alive across the calls
+    api.call("cfd_chanmix", P(dx), P(dw), P(db), P(out), B, Ci, Co, HW, int(act), 0, be.stream)
+    be.sync()
+    res["fwd"] = nm(be.host(out), np.einsum("oi,bip->bop", w.astype(f64), f) + b[None, :, None])
+    gin = be.zeros((B, Ci, HW))
+    api.call("cfd_chanmix", P(dg), P(dw), None, P(gin), B, Co, Ci, HW, 0, 1, be.stream)
+    be.sync()
+    res["bwd_in"] = nm(be.host(gin), np.einsum("oi,bop->bip", w.astype(f64), g.astype(f64)))
+    ws = be.bytes(api.size("cfd_chan_wgrad_workspace_bytes", B, Ci, Co, HW))
+    gw, gb = be.zeros((Co, Ci)), be.zeros((Co,))
+    api.call("cfd_chan_wgrad", P(dg), P(dx), P(gw), P(gb), P(ws), B, Ci, Co, HW, int(act), be.stream)
+    be.sync()
+    res["gw"] = nm(be.host(gw), np.einsum("bop,bip->oi", g.astype(f64), f))
+    res["gb"] = nm(be.host(gb), g.astype(f64).sum(axis=(0, 2)))
+    return res
+
+
+def check_stem(be, B, H, W, P_, C, border, seed=3):
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    batch = synth.make_batch(seed, B, H, W, P_, border_mask=border)
+    F = 2 + 3 + P_
+    w = rng.standard_normal((C, F)).astype(np.float32)
+    b = rng.standard_normal((C,)).astype(np.float32)
+    g = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    plan = api.plan_create(H, W, 12, 12)
+    try:
+        feats = O.assemble_features(batch["inputs"].astype(f64), batch["case_params"].astype(f64), batch["mask"].astype(f64))
+        res = {}
+        out = be.zeros((B, C, H, W))
+        di, dm, dc = be.dev(batch["inputs"]), be.dev(batch["mask"]), be.dev(batch["case_params"])
+        dw, db, dg = be.dev(w), be.dev(b), be.dev(g)
+        api.call("cfd_fno_stem_fwd", plan, P(di), P(dm), P(dc), P(dw), P(db), P(out), B, 2, P_, C, be.stream)
+        be.sync()
+        res["fwd"] = nm(be.host(out), O.conv1x1(feats, w.astype(f64), b.astype(f64)))
+        out2 = be.zeros((B, C, H, W))
+        api.call("cfd_fno_stem_fwd", plan, P(di), None, P(dc), P(dw), P(db), P(out2), B, 2, P_, C, be.stream)
+        be.sync()
+        feats1 = O.assemble_features(batch["inputs"].astype(f64), batch["case_params"].astype(f64), np.ones_like(batch["mask"], dtype=f64))
+        res["fwd_nomask"] = nm(be.host(out2), O.conv1x1(feats1, w.astype(f64), b.astype(f64)))
+        ws = be.bytes(api.size("cfd_fno_stem_bwd_workspace_bytes", plan, B, 2, P_, C))
+        gw, gb = be.zeros((C, F)), be.zeros((C,))
+        api.call("cfd_fno_stem_bwd", plan, P(dg), P(di), P(dm), P(dc), P(gw), P(gb), P(ws), B, 2, P_, C, be.stream)
+        be.sync()
+        res["gw"] = nm(be.host(gw), np.einsum("bohw,bihw->oi", g.astype(f64), feats))
+        res["gb"] = nm(be.host(gb), g.astype(f64).sum(axis=(0, 2, 3)))
+        return res
+    finally:
+        api.plan_destroy(plan)
+
+
+def _head_ref(a, mask, label, w1, b1, w2, b2, act):
+    h = O.gelu(a) if act else a
+    z1 = np.einsum("ji,bip->bjp", w1, h) + b1[None, :, None]
+    a1 = O.gelu(z1)
+    raw = np.einsum("cj,bjp->bcp", w2, a1) + b2[None, :, None]
+    preds = raw * mask
+    return h, z1, a1, preds
+
+
+def check_head(be, B, C, HW, act, which="nmse", with_ext=False, border=True, seed=4):
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    Hd, Co = 128, 2
+    a = rng.standard_normal((B, C, HW)).astype(np.float32)
+    mask = np.ones((B, 1, HW), np.float32)
+    if border:
+        mask[:, :, ::7] = 0
+    label = rng.standard_normal((B, Co, HW)).astype(np.float32)
+    w1 = (rng.standard_normal((Hd, C)) / np.sqrt(C)).astype(np.float32)
+    b1 = rng.standard_normal((Hd,)).astype(np.float32) * 0.1
+    w2 = (rng.standard_normal((Co, Hd)) / np.sqrt(Hd)).astype(np.float32)
+    b2 = rng.standard_normal((Co,)).astype(np.float32) * 0.1
+    gext = rng.standard_normal((B, Co, HW)).astype(np.float32) if with_ext else None
+    A, M, Lb = a.astype(f64), mask.astype(f64), label.astype(f64)
+    h, z1, a1, preds_ref = _head_ref(A, M, Lb, w1.astype(f64), b1.astype(f64), w2.astype(f64), b2.astype(f64), act)
+    lab_m = Lb * M
+    res = {}
+    da, dm, dl = be.dev(a), be.dev(mask), be.dev(label)
+    dw1, db1, dw2, db2 = be.dev(w1), be.dev(b1), be.dev(w2), be.dev(b2)
+    ws = be.bytes(api.size("cfd_fno_head_workspace_bytes", B, C, Hd, Co, HW))
+    preds = be.zeros((B, Co, HW))
+    sums = be.zeros((4,))
+    api.call("cfd_fno_head_fwd", P(da), P(dm), P(dl), P(dw1), P(db1), P(dw2), P(db2), P(preds), P(sums), P(ws), B, C, Hd, Co,
+             HW, int(act), be.stream)
+    be.sync()
+    res["preds"] = nm(be.host(preds), preds_ref)
+    d = preds_ref - lab_m
+    sref = np.array([np.sum(d * d), np.sum(np.abs(d)), np.sum(lab_m * lab_m), d.size])
+    res["sums"] = float(np.max(np.abs(be.host(sums) - sref) / np.abs(sref)))
+    scores = be.zeros((4,))
+    api.call("cfd_loss_scores", P(sums), P(scores), be.stream)
+    be.sync()
+    lr = O.mse_loss(preds_ref, lab_m, True)
+    sc = be.host(scores)
+    res["scores"] = float(max(abs(sc[0] - lr["mse"]) / lr["mse"], abs(sc[1] - lr["rmse"]) / lr["rmse"],
+                              abs(sc[2] - lr["mae"]) / lr["mae"], abs(sc[3] - lr["nmse"]) / lr["nmse"]))
+    # backward
+    coef = be.zeros((2,))
+    api.call("cfd_loss_coef", P(sums), P(coef), {"mse": 0, "nmse": 1, "mae": 2}[which], 1.0, be.stream)
+    gp = O.loss_grad_wrt_preds(preds_ref, lab_m, which)
+    if with_ext:
+        gp = gp + gext.astype(f64)
+    graw = gp * M
+    ga1 = np.einsum("cj,bcp->bjp", w2.astype(f64), graw)
+    gz = ga1 * O.gelu_grad(z1)
+    gh = np.einsum("ji,bjp->bip", w1.astype(f64), gz)
+    ga_ref = gh * O.gelu_grad(A) if act else gh
+    ga = be.zeros((B, C, HW))
+    gw1, gb1, gw2, gb2 = be.zeros((Hd, C)), be.zeros((Hd,)), be.zeros((Co, Hd)), be.zeros((Co,))
+    dgext = be.dev(gext) if with_ext else None
+    api.call("cfd_fno_head_bwd", P(da), P(dm), P(dl), P(preds), P(dgext), P(coef), P(dw1),
+             P(db1), P(dw2), P(ga), P(gw1), P(gb1), P(gw2), P(gb2), P(ws), B, C, Hd, Co, HW, int(act), be.stream)
+    be.sync()
+    res["ga"] = nm(be.host(ga), ga_ref)
+    res["gw1"] = nm(be.host(gw1), np.einsum("bjp,bip->ji", gz, h))
+    res["gb1"] = nm(be.host(gb1), gz.sum(axis=(0, 2)))
+    res["gw2"] = nm(be.host(gw2), np.einsum("bcp,bjp->cj", graw, a1))
+    res["gb2"] = nm(be.host(gb2), graw.sum(axis=(0, 2)))
+    return res
+
+
+def check_loss_and_adam(be, n=10007, seed=5):
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    p = rng.standard_normal(n).astype(np.float32)
+    l = rng.standard_normal(n).astype(np.float32)
+    ws = be.bytes(api.size("cfd_loss_workspace_bytes", n))
+    sums = be.zeros((4,))
+    dpp, dll = be.dev(p), be.dev(l)
+    api.call("cfd_masked_loss_sums", P(dpp), P(dll), P(sums), P(ws), n, be.stream)
+    be.sync()
+    d = p.astype(f64) - l.astype(f64)
+    ref = np.array([np.sum(d * d), np.sum(np.abs(d)), np.sum(l.astype(f64) ** 2), n])
+    res = {"sums": float(np.max(np.abs(be.host(sums) - ref) / ref))}
+    # Adam, 3 steps against the oracle (itself pinned against torch.optim.Adam by tests/test_oracle_golden.py)
+    prm = rng.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    dp, dm_, dv = be.dev(prm), be.dev(m), be.dev(v)
+    p64, m64, v64 = prm.astype(f64), m.astype(f64), v.astype(f64)
+    for step in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32) * (10.0 ** rng.integers(-6, 1, size=n))
+        g = g.astype(np.float32)
+        dgr = be.dev(g)
+        api.call("cfd_adam_flat", P(dp), P(dgr), P(dm_), P(dv), n, 1e-3, 0.9, 0.999, 1e-8, 0.0, step, 1.0, be.stream)
+        be.sync()
+        O.adam_step(p64, g.astype(f64), m64, v64, step, 1e-3)
+    be.sync()
+    res["adam_delta"] = nm(be.host(dp).astype(f64) - prm, p64 - prm)
+    return res
+
+
+def make_param_struct(be, params_dev, L):
+    s = FnoParams()
+    P = be.ptr
+    s.fc0_w, s.fc0_b = P(params_dev["fc0.weight"]), P(params_dev["fc0.bias"])
+    for l in range(L):
+        s.spec_w1[l] = P(params_dev[f"blocks.{l}.conv0.weights1"])
+        s.spec_w2[l] = P(params_dev[f"blocks.{l}.conv0.weights2"])
+        s.w0_w[l] = P(params_dev[f"blocks.{l}.w0.weight"])
+        s.w0_b[l] = P(params_dev[f"blocks.{l}.w0.bias"])
+    s.fc1_w, s.fc1_b = P(params_dev["fc1.weight"]), P(params_dev["fc1.bias"])
+    s.fc2_w, s.fc2_b = P(params_dev["fc2.weight"]), P(params_dev["fc2.bias"])
+    return s
+
+
+def run_fno(be, params, batch, L, C, H, W, p, with_label=True, which="nmse"):
+    """Whole-model forward (+ backward) through cfd_fno_forward / cfd_fno_backward; returns host arrays."""
+    api, P = be.api, be.ptr
+    B = batch["inputs"].shape[0]
+    plan = api.plan_create(H, W, 12, 12)
+    try:
+        shape = FnoShape(B, H, W, 2, 2, p, C, L, 12, 12, 128)
+        pd = {k: be.dev(v) for k, v in params.items()}
+        gd = {k: be.zeros(v.shape, np.complex64 if np.iscomplexobj(v) else np.float32) for k, v in params.items()}
+        ps, gs = make_param_struct(be, pd, L), make_param_struct(be, gd, L)
+        ws = be.bytes(api.size("cfd_fno_workspace_bytes", plan, ctypes.byref(shape), 1))
+        di, dc, dm = be.dev(batch["inputs"]), be.dev(batch["case_params"]), be.dev(batch["mask"])
+        dl = be.dev(batch["label"]) if with_label else None
+        preds = be.zeros((B, 2, H, W))
+        sums = be.zeros((4,))
+        api.call("cfd_fno_forward", plan, ctypes.byref(shape), ctypes.byref(ps), P(di), P(dc), P(dm), P(dl), P(preds),
+                 P(sums), P(ws), 1, be.stream)
+        out = {}
+        if with_label:
+            coef = be.zeros((2,))
+            api.call("cfd_loss_coef", P(sums), P(coef), {"mse": 0, "nmse": 1, "mae": 2}[which], 1.0, be.stream)
+            api.call("cfd_fno_backward", plan, ctypes.byref(shape), ctypes.byref(ps), ctypes.byref(gs), P(di), P(dc), P(dm),
+                     P(dl), P(preds), None, P(coef), P(ws), be.stream)
+            scores = be.zeros((4,))
+            api.call("cfd_loss_scores", P(sums), P(scores), be.stream)
+            be.sync()
+            out["grads"] = {k: be.host(v) for k, v in gd.items()}
+            out["scores"] = be.host(scores)
+        be.sync()
+        out["preds"] = be.host(preds)
+        # inference-mode workspace (ping-pong activations) must give the same predictions
+        ws0 = be.bytes(api.size("cfd_fno_workspace_bytes", plan, ctypes.byref(shape), 0))
+        preds0 = be.zeros((B, 2, H, W))
+        api.call("cfd_fno_forward", plan, ctypes.byref(shape), ctypes.byref(ps), P(di), P(dc), P(dm), None, P(preds0), None,
+                 P(ws0), 0, be.stream)
+        be.sync()
+        out["preds_infer"] = be.host(preds0)
+        return out
+    finally:
+        api.plan_destroy(plan)
+
+
+def check_fno_vs_oracle(be, B, C, L, H, W, p=5, border=False, gain=4.0, pseed=7, bseed=8):
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=gain)
+    batch = synth.make_batch(bseed, B, H, W, p, border_mask=border)
+    out = run_fno(be, params, batch, L, C, H, W, p)
+    p64 = {k: v.astype(c128 if np.iscomplexobj(v) else f64) for k, v in params.items()}
+    b64 = {k: v.astype(f64) for k, v in batch.items()}
+    ref = O.fno_forward(p64, b64["inputs"], b64["case_params"], b64["mask"], b64["label"], L)
+    gp = O.loss_grad_wrt_preds(ref["cache"]["preds"], ref["cache"]["label"], "nmse")
+    rg = O.fno_backward(p64, ref["cache"], gp, L)
+    res = {"preds": nm(out["preds"], ref["preds"]), "preds_infer": nm(out["preds_infer"], ref["preds"])}
+    res["nmse_loss"] = abs(out["scores"][3] - ref["loss"]["nmse"]) / ref["loss"]["nmse"]
+    for k in params:
+        res["g:" + k] = nm(out["grads"][k], rg[k])
+    return res

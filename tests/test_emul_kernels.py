@@ -1,0 +1,79 @@
+"""CPU: every kernel of the product library, compiled UNMODIFIED against the SIMT emulator (tests/emul), checked
+against the oracle.  Catches index-math / layout bugs before a GPU minute is spent; the GPU twin of this file is
+tests/test_gpu_kernels.py."""
+import numpy as np
+import pytest
+
+from tests import kernel_checks as K
+from tests.backends import NumpyBackend
+
+
+@pytest.fixture(scope="module")
+def be():
+    return NumpyBackend()
+
+
+def _assert_all(res, tol=K.TOL):
+    bad = {k: v for k, v in res.items() if not (v < tol)}
+    assert not bad, f"parity failures (tol {tol}): {bad}; all: {res}"
+
+
+def test_symbols_exported(be):
+    assert be.api.missing == []
+    assert be.api.version() >= 100
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (66, 65)])
+def test_spectral_fwd_bwd(be, H, W):
+    _assert_all(K.check_spectral(be, 2, 3, 5, H, W))
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (66, 65)])
+def test_idft_epilogues(be, H, W):
+    _assert_all(K.check_idft_epilogues(be, 3, H, W))
+
+
+@pytest.mark.parametrize("Ci,Co,HW,act", [(20, 20, 256, True), (6, 8, 66 * 5, False), (32, 32, 64, True)])
+def test_chanmix_and_wgrad(be, Ci, Co, HW, act):
+    _assert_all(K.check_chanmix(be, 2, Ci, Co, HW, act))
+
+
+@pytest.mark.parametrize("H,W,border", [(64, 64, False), (66, 65, True)])
+def test_stem(be, H, W, border):
+    _assert_all(K.check_stem(be, 2, H, W, 5, 20, border))
+
+
+@pytest.mark.parametrize("C,HW,act,which,ext", [(20, 256, True, "nmse", False), (6, 330, False, "mse", True),
+                                                (32, 128, True, "mae", False)])
+def test_head(be, C, HW, act, which, ext):
+    res = K.check_head(be, 2, C, HW, act, which, ext)
+    _assert_all({k: v for k, v in res.items() if k not in ("sums", "scores")})
+    assert res["sums"] < 1e-5 and res["scores"] < 1e-5
+
+
+def test_loss_and_adam(be):
+    res = K.check_loss_and_adam(be)
+    assert res["sums"] < 1e-5
+    assert res["adam_delta"] < 1e-9
+
+
+@pytest.mark.parametrize("C,L,H,W,border", [(8, 2, 64, 64, False), (6, 2, 66, 65, True)])
+def test_fno_whole_model(be, C, L, H, W, border):
+    res = K.check_fno_vs_oracle(be, 1, C, L, H, W, border=border)
+    loss_err = res.pop("nmse_loss")
+    assert loss_err < 1e-5
+    _assert_all(res, 1e-9)
+
+
+def test_error_paths(be):
+    from cfdbench_amd._capi import CfdError
+    with pytest.raises(CfdError):
+        be.api.plan_create(64, 64, 40, 12)  # modes1 too large
+    plan = be.api.plan_create(64, 64, 12, 12)
+    with pytest.raises(CfdError):
+        be.api.call("cfd_spectral_dft", plan, None, None, 4, 0, None)
+    x = np.zeros((1, 64, 64), np.float32)
+    with pytest.raises(CfdError):
+        be.api.call("cfd_spectral_idft", plan, x.ctypes.data, None, None, x.ctypes.data, 1, 1, None)  # epi without addend
+    be.api.call("cfd_spectral_dft", plan, x.ctypes.data, x.ctypes.data, 0, 0, None)  # empty batch is a no-op
+    be.api.plan_destroy(plan)
