@@ -39,6 +39,8 @@ _Z = C.c_size_t
 _SIGS = {
     "cfd_version": (C.c_int, []),
     "cfd_last_error": (C.c_char_p, []),
+    "cfd_prof_begin": (_I, []),
+    "cfd_prof_end": (_I, [C.c_char_p, _Z]),
     "cfd_plan_create": (_I, [_I, _I, _I, _I, C.POINTER(_P)]),
     "cfd_plan_destroy": (None, [_P]),
     "cfd_spectral_dft": (_I, [_P, _P, _P, _I, _I, _P]),
@@ -60,8 +62,11 @@ _SIGS = {
     "cfd_fno_head_bwd": (_I, [_P] * 15 + [_I, _I, _I, _I, _I, _I, _P]),
     "cfd_loss_workspace_bytes": (_Z, [_Z]),
     "cfd_masked_loss_sums": (_I, [_P, _P, _P, _P, _Z, _P]),
+    "cfd_loss_sums_bwd": (_I, [_P, _P, _P, _P, _P, _Z, _P]),
     "cfd_loss_scores": (_I, [_P, _P, _P]),
     "cfd_loss_coef": (_I, [_P, _P, _I, _F, _P]),
+    "cfd_gelu_fwd": (_I, [_P, _P, _Z, _P]),
+    "cfd_gelu_bwd": (_I, [_P, _P, _P, _Z, _P]),
     "cfd_adam_flat": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P]),
     "cfd_fno_workspace_bytes": (_Z, [_P, C.POINTER(FnoShape), _I]),
     "cfd_fno_forward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), _P, _P, _P, _P, _P, _P, _P, _I, _P]),

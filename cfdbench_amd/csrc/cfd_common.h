@@ -30,6 +30,17 @@ void cfd_set_error(const char* fmt, ...);
         if (rc_ != CFD_OK) return rc_; \
     } while (0)
 
+// Per-kernel event timing (prof.cpp); a no-op unless cfd_prof_begin() was called.
+struct CfdProfScope {
+    hipStream_t st;
+    int idx;
+    CfdProfScope(const char* name, hipStream_t s);
+    ~CfdProfScope();
+};
+#define CFD_PROF_CAT2(a, b) a##b
+#define CFD_PROF_CAT(a, b) CFD_PROF_CAT2(a, b)
+#define CFD_PROF(name, st) CfdProfScope CFD_PROF_CAT(cfd_prof_scope_, __LINE__)(name, st)
+
 // Operator tables of one (H,W,m1,m2); all d_* pointers are device memory, fragment-major ([step][lane]).
 struct cfd_plan {
     int H, W, m1, m2;

@@ -27,5 +27,12 @@ __device__ __forceinline__ void cfd_wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Makes a value opaque to the optimiser (no instruction emitted).  Used on LDS table offsets inside a loop so the
+// loop-invariant table reads are NOT hoisted into hundreds of live VGPRs (which costs occupancy or spills).
+__device__ __forceinline__ int cfd_opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 __device__ __forceinline__ float cfd_erff(float x) { return erff(x); }
 __device__ __forceinline__ float cfd_expf(float x) { return __expf(x); }

@@ -53,7 +53,7 @@ __device__ __forceinline__ void head_build_w1f(float* s_w1f, const float* __rest
 }
 
 template <int KS, bool VEC4, bool ACT>
-__global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ a, const float* __restrict__ mask,
+__global__ __launch_bounds__(256, 2) void k_head_fwd(const float* __restrict__ a, const float* __restrict__ mask,
                                                   const float* __restrict__ label, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                                   const float* __restrict__ b2, float* __restrict__ preds,
@@ -77,34 +77,39 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ a, c
         const int px = (int)(tile - (long)b * tpb) * 64 + 4 * n;
         float h[KS][4];
         head_load_h<KS, VEC4, ACT>(a, b, C, HW, px, q, h);
-        float out0[4], out1[4];
-#pragma unroll
+        // The 4 pixel phases j run in a ROLLED loop (one 16-pixel sub-tile per trip keeps the live set at one
+        // z tile); the phase being processed always sits in h[s][0] / lands in out*[3], registers rotate each trip.
+        float out0[4] = {0.f, 0.f, 0.f, 0.f}, out1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
         for (int j = 0; j < 4; ++j) {
+            const int lo = cfd_opaque(lane), q4 = cfd_opaque(4 * q);  // keep the LDS table reads inside the loop
             f32x4 z[HEAD_MT];
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt) {
-                const int jb = 16 * mt + 4 * q;
+                const int jb = 16 * mt + q4;
                 z[mt] = f32x4{s_b1[jb], s_b1[jb + 1], s_b1[jb + 2], s_b1[jb + 3]};
             }
 #pragma unroll
             for (int s = 0; s < KS; ++s)
 #pragma unroll
                 for (int mt = 0; mt < HEAD_MT; ++mt)
-                    z[mt] = cfd_mfma16x16x4(s_w1f[(mt * KS + s) * 64 + lane], h[s][j], z[mt]);
+                    z[mt] = cfd_mfma16x16x4(s_w1f[(mt * KS + s) * 64 + lo], h[s][0], z[mt]);
             float o0 = 0.f, o1 = 0.f;
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int jh = 16 * mt + 4 * q + r;
+                    const int jh = 16 * mt + q4 + r;
                     const float gl = cfd_gelu(z[mt][r]);
                     o0 = fmaf(s_w2[jh], gl, o0);
                     o1 = fmaf(s_w2[HEAD_HD + jh], gl, o1);
                 }
             o0 += cfd_shfl_xor(o0, 16); o0 += cfd_shfl_xor(o0, 32);
             o1 += cfd_shfl_xor(o1, 16); o1 += cfd_shfl_xor(o1, 32);
-            out0[j] = o0;
-            out1[j] = o1;
+            out0[0] = out0[1]; out0[1] = out0[2]; out0[2] = out0[3]; out0[3] = o0;
+            out1[0] = out1[1]; out1[1] = out1[2]; out1[2] = out1[3]; out1[3] = o1;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { h[s][0] = h[s][1]; h[s][1] = h[s][2]; h[s][2] = h[s][3]; }
         }
         if (q < Co) {  // lane group q stores output channel q
             const int c = q;
@@ -184,6 +189,8 @@ extern "C" int cfd_fno_head_fwd(const float* a, const float* mask, const float* 
     const int blocks = head_blocks(B, HW);
     float* part = label ? (float*)ws : nullptr;
     const bool v4 = HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)preds % 16) == 0;
+    {
+    CFD_PROF("k_head_fwd", st);
 #define CFD_HF(K_, V_, A_)                                                                                      \
     hipLaunchKernelGGL((k_head_fwd<K_, V_, A_>), dim3(blocks), dim3(256), 0, st, a, mask, label, w1, b1, w2, b2, \
                        preds, part, B, C, Co, HW)
@@ -199,6 +206,7 @@ extern "C" int cfd_fno_head_fwd(const float* a, const float* mask, const float* 
     else CFD_HF_VA(8);
 #undef CFD_HF_VA
 #undef CFD_HF
+    }
     CFD_LAUNCH_CHECK("cfd_fno_head_fwd");
     if (label) {
         hipLaunchKernelGGL(k_head_loss_final, dim3(1), dim3(64), 0, st, (const float*)part, blocks,
@@ -212,7 +220,7 @@ extern "C" int cfd_fno_head_fwd(const float* a, const float* mask, const float* 
 // backward
 // ------------------------------------------------------------------------------------------------------
 template <int KS, bool VEC4, bool ACT>
-__global__ __launch_bounds__(256, (KS <= 5 ? 2 : 1)) void k_head_bwd(
+__global__ __launch_bounds__(256, 1) void k_head_bwd(
     const float* __restrict__ a, const float* __restrict__ mask, const float* __restrict__ label,
     const float* __restrict__ preds, const float* __restrict__ gext, const float* __restrict__ coef,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, float* __restrict__ ga,
@@ -289,25 +297,31 @@ __global__ __launch_bounds__(256, (KS <= 5 ? 2 : 1)) void k_head_bwd(
 #pragma unroll
             for (int j = 0; j < 4; ++j) { gb2a0 += gr0[j]; gb2a1 += gr1[j]; }
         }
+        // Rolled loop over the 4 pixel phases (see k_head_fwd): phase data sits in h[s][0] / gr*[0], the phase
+        // result is rotated into gh[mu][3].
         f32x4 gh[MU][4];
 #pragma unroll
         for (int mu = 0; mu < MU; ++mu)
 #pragma unroll
             for (int j = 0; j < 4; ++j) gh[mu][j] = zero;
-#pragma unroll
+#pragma unroll 1
         for (int j = 0; j < 4; ++j) {
+            const int lo = cfd_opaque(lane), q4 = cfd_opaque(4 * q);  // keep the LDS table reads inside the loop
+            f32x4 ghc[MU];
+#pragma unroll
+            for (int mu = 0; mu < MU; ++mu) ghc[mu] = zero;
             // 1. recompute the hidden pre-activation tile z[jh][pixel n]
             f32x4 z[HEAD_MT];
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt) {
-                const int jb = 16 * mt + 4 * q;
+                const int jb = 16 * mt + q4;
                 z[mt] = f32x4{s_b1[jb], s_b1[jb + 1], s_b1[jb + 2], s_b1[jb + 3]};
             }
 #pragma unroll
             for (int s = 0; s < KS; ++s)
 #pragma unroll
                 for (int mt = 0; mt < HEAD_MT; ++mt)
-                    z[mt] = cfd_mfma16x16x4(s_w1f[(mt * KS + s) * 64 + lane], h[s][j], z[mt]);
+                    z[mt] = cfd_mfma16x16x4(s_w1f[(mt * KS + s) * 64 + lo], h[s][0], z[mt]);
             // 2. transposed tiles: a1 = gelu(z) [jh][px], h [i | ones][px], graw [c][px]
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt)
@@ -315,11 +329,11 @@ __global__ __launch_bounds__(256, (KS <= 5 ? 2 : 1)) void k_head_bwd(
                 for (int r = 0; r < 4; ++r) s_x[(16 * mt + 4 * q + r) * HEAD_LD + n] = cfd_gelu(z[mt][r]);
 #pragma unroll
             for (int s = 0; s < KS; ++s)
-                if (4 * s + q < C) s_h[(4 * s + q) * HEAD_LD + n] = h[s][j];
+                if (4 * s + q < C) s_h[(4 * s + q) * HEAD_LD + n] = h[s][0];
             if (q == 0) {
                 s_h[C * HEAD_LD + n] = (px + j < HW) ? 1.f : 0.f;
-                s_g[n] = gr0[j];
-                s_g[HEAD_LD + n] = gr1[j];
+                s_g[n] = gr0[0];
+                s_g[HEAD_LD + n] = gr1[0];
             }
             cfd_wave_lds_sync();
             // 3. gw2[c][jh] += sum_px graw[c][px] a1[jh][px]
@@ -336,8 +350,8 @@ __global__ __launch_bounds__(256, (KS <= 5 ? 2 : 1)) void k_head_bwd(
             for (int mt = 0; mt < HEAD_MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int jh = 16 * mt + 4 * q + r;
-                    const float ga1 = fmaf(s_w2[jh], gr0[j], s_w2[HEAD_HD + jh] * gr1[j]);
+                    const int jh = 16 * mt + q4 + r;
+                    const float ga1 = fmaf(s_w2[jh], gr0[0], s_w2[HEAD_HD + jh] * gr1[0]);
                     const float gz = ga1 * cfd_gelu_grad(z[mt][r]);
                     z[mt][r] = gz;
                     s_x[jh * HEAD_LD + n] = gz;
@@ -350,7 +364,7 @@ __global__ __launch_bounds__(256, (KS <= 5 ? 2 : 1)) void k_head_bwd(
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int mu = 0; mu < MU; ++mu)
-                        gh[mu][j] = cfd_mfma16x16x4(s_w1t[(mu * 32 + mt * 4 + r) * 64 + lane], z[mt][r], gh[mu][j]);
+                        ghc[mu] = cfd_mfma16x16x4(s_w1t[(mu * 32 + mt * 4 + r) * 64 + lo], z[mt][r], ghc[mu]);
             // 6. gw1[jh][i] (+ gb1 through the ones column) += sum_px gz[jh][px] h[i][px]
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
@@ -365,6 +379,12 @@ __global__ __launch_bounds__(256, (KS <= 5 ? 2 : 1)) void k_head_bwd(
                 }
             }
             cfd_wave_lds_sync();
+#pragma unroll
+            for (int mu = 0; mu < MU; ++mu) { gh[mu][0] = gh[mu][1]; gh[mu][1] = gh[mu][2]; gh[mu][2] = gh[mu][3]; gh[mu][3] = ghc[mu]; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { h[s][0] = h[s][1]; h[s][1] = h[s][2]; h[s][2] = h[s][3]; }
+            gr0[0] = gr0[1]; gr0[1] = gr0[2]; gr0[2] = gr0[3];
+            gr1[0] = gr1[1]; gr1[1] = gr1[2]; gr1[2] = gr1[3];
         }
         // epilogue: ga[b][i][px..px+3] = d/dh * f'(a)
 #pragma unroll
@@ -461,6 +481,8 @@ extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* 
     const int blocks = head_blocks(B, HW);
     float* part = (float*)ws;
     const bool v4 = HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)ga % 16) == 0;
+    {
+    CFD_PROF("k_head_bwd", st);
 #define CFD_HB(K_, V_, A_)                                                                                         \
     hipLaunchKernelGGL((k_head_bwd<K_, V_, A_>), dim3(blocks), dim3(256), 0, st, a, mask, label, preds, gpreds_ext, \
                        coef, w1, b1, w2, ga, part, B, C, Co, HW)
@@ -476,6 +498,7 @@ extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* 
     else CFD_HB_VA(8);
 #undef CFD_HB_VA
 #undef CFD_HB
+    }
     CFD_LAUNCH_CHECK("cfd_fno_head_bwd");
     const int PS = (int)head_part_floats(C, Co);
     hipLaunchKernelGGL(k_head_reduce, dim3((PS + 255) / 256), dim3(256), 0, st, (const float*)part, blocks, PS, gw1,

@@ -28,12 +28,13 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ inpu
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int b = (int)(idx / HW), p = (int)(idx - (long)b * HW);
         const int row = p / W, col = p - row * W;
+        const int z0 = cfd_opaque(0);  // keeps the (loop-invariant) LDS weight reads from being hoisted into VGPRs
         float acc[CP];
 #pragma unroll
-        for (int o = 0; o < CP; ++o) acc[o] = s_b[o];
+        for (int o = 0; o < CP; ++o) acc[o] = s_b[z0 + o];
         auto add = [&](int f, float v) {
 #pragma unroll
-            for (int o = 0; o < CP; ++o) acc[o] = fmaf(s_w[f * CP + o], v, acc[o]);
+            for (int o = 0; o < CP; ++o) acc[o] = fmaf(s_w[z0 + f * CP + o], v, acc[o]);
         };
         for (int c = 0; c < in_chan; ++c) add(c, inputs[((size_t)b * in_chan + c) * HW + p]);
         add(in_chan, mask ? mask[(size_t)b * HW + p] : 1.f);  // fno2d.py:189-195
@@ -58,6 +59,7 @@ extern "C" int cfd_fno_stem_fwd(const cfd_plan* p, const float* inputs, const fl
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
+    CFD_PROF("k_stem_fwd", st);
 #define CFD_STEM(CPV)                                                                                              \
     hipLaunchKernelGGL((k_stem_fwd<CPV>), dim3(blocks), dim3(256), 0, st, inputs, mask, case_params,               \
                        (const float*)p->d_gx, (const float*)p->d_gy, w, bias, out, B, in_chan, P, C, p->H, p->W)
@@ -91,17 +93,21 @@ __global__ __launch_bounds__(256) void k_chanmix(const float* __restrict__ in, c
     const long total = (long)B * units;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int b = (int)(idx / units), p = (int)(idx - (long)b * units) * VEC;
+        const int z0 = cfd_opaque(0);  // see k_stem_fwd
         float acc[CPO][VEC];
 #pragma unroll
         for (int o = 0; o < CPO; ++o)
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[o][k] = s_b[o];
+            for (int k = 0; k < VEC; ++k) acc[o][k] = s_b[z0 + o];
         for (int ci = 0; ci < Ci; ++ci) {
             float v[VEC];
             const float* src = in + ((size_t)b * Ci + ci) * HW + p;
             if constexpr (VEC == 4) {
                 const float4 t = *reinterpret_cast<const float4*>(src);
                 v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else if constexpr (VEC == 2) {
+                const float2 t = *reinterpret_cast<const float2*>(src);
+                v[0] = t.x; v[1] = t.y;
             } else {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) v[k] = src[k];
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void k_chanmix(const float* __restrict__ in, c
             }
 #pragma unroll
             for (int o = 0; o < CPO; ++o) {
-                const float wv = s_w[ci * CPO + o];
+                const float wv = s_w[z0 + ci * CPO + o];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[o][k] = fmaf(wv, v[k], acc[o][k]);
             }
@@ -123,6 +129,8 @@ __global__ __launch_bounds__(256) void k_chanmix(const float* __restrict__ in, c
                 float* dst = out + ((size_t)b * Co + o) * HW + p;
                 if constexpr (VEC == 4) {
                     *reinterpret_cast<float4*>(dst) = make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
+                } else if constexpr (VEC == 2) {
+                    *reinterpret_cast<float2*>(dst) = make_float2(acc[o][0], acc[o][1]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) dst[k] = acc[o][k];
@@ -138,6 +146,7 @@ static int launch_chanmix(const float* in, const float* w, const float* bias, fl
     const long total = (long)B * (HW / VEC);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
+    CFD_PROF(transpose ? "k_chanmix_t" : (act ? "k_chanmix_act" : "k_chanmix"), st);
     if (act)
         hipLaunchKernelGGL((k_chanmix<CPO, VEC, true>), dim3(blocks), dim3(256), 0, st, in, w, bias, out, B, Ci, Co, HW, transpose);
     else
@@ -153,14 +162,17 @@ extern "C" int cfd_chanmix(const float* in, const float* w, const float* bias, f
     CFD_REQUIRE(Ci <= 32 && Co <= 32, CFD_ERR_UNSUPPORTED, "cfd_chanmix: Ci=%d Co=%d (max 32) unsupported", Ci, Co);
     if (B == 0) return CFD_OK;
     hipStream_t st = (hipStream_t)stream;
+    // pixels per thread: 4 (16-B accesses) while the accumulator tile stays small, 2 (8-B) for wide outputs
     const bool v4 = HW % 4 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0;
-#define CFD_CM(CPV)                                                                                   \
-    return v4 ? launch_chanmix<CPV, 4>(in, w, bias, out, B, Ci, Co, HW, act_in, transpose, st)       \
-              : launch_chanmix<CPV, 1>(in, w, bias, out, B, Ci, Co, HW, act_in, transpose, st)
-    if (Co <= 8) CFD_CM(8);
-    if (Co <= 16) CFD_CM(16);
-    if (Co <= 24) CFD_CM(24);
-    CFD_CM(32);
+    const bool v2 = HW % 2 == 0 && ((uintptr_t)in % 8) == 0 && ((uintptr_t)out % 8) == 0;
+#define CFD_CM(CPV, VW)                                                                               \
+    return (VW == 4 && v4) ? launch_chanmix<CPV, VW>(in, w, bias, out, B, Ci, Co, HW, act_in, transpose, st) \
+           : v2            ? launch_chanmix<CPV, 2>(in, w, bias, out, B, Ci, Co, HW, act_in, transpose, st)  \
+                           : launch_chanmix<CPV, 1>(in, w, bias, out, B, Ci, Co, HW, act_in, transpose, st)
+    if (Co <= 8) CFD_CM(8, 4);
+    if (Co <= 16) CFD_CM(16, 4);
+    if (Co <= 24) CFD_CM(24, 2);
+    CFD_CM(32, 2);
 #undef CFD_CM
 }
 
@@ -317,6 +329,8 @@ static int launch_wgrad(const float* g, const float* in, StemSrc ss, float* gw, 
         else if (act) CFD_WG(M_, N_, false, true);     \
         else CFD_WG(M_, N_, false, false);             \
     } while (0)
+    {
+    CFD_PROF(STEM ? "k_chan_wgrad_stem" : "k_chan_wgrad", st);
     if (MT == 1 && NT == 1) CFD_WG_VA(1, 1);
     else if (MT == 1 && NT == 2) CFD_WG_VA(1, 2);
     else if (MT == 2 && NT == 1) CFD_WG_VA(2, 1);
@@ -327,9 +341,11 @@ static int launch_wgrad(const float* g, const float* in, StemSrc ss, float* gw, 
         cfd_set_error("cfd_chan_wgrad: Co=%d Ci=%d unsupported tile shape", Co, Ci);
         return CFD_ERR_UNSUPPORTED;
     }
+    }
 #undef CFD_WG_VA
 #undef CFD_WG
     CFD_LAUNCH_CHECK("cfd_chan_wgrad");
+    CFD_PROF("k_wgrad_reduce", st);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((Co * (Ci + 1) + 255) / 256), dim3(256), 0, st, (const float*)part, blocks,
                        gw, gb, Co, Ci);
     CFD_LAUNCH_CHECK("cfd_chan_wgrad(reduce)");
@@ -408,6 +424,31 @@ extern "C" int cfd_masked_loss_sums(const float* preds, const float* labels, flo
     return CFD_OK;
 }
 
+__global__ __launch_bounds__(256) void k_loss_sums_bwd(const float* __restrict__ p, const float* __restrict__ l,
+                                                       const float* __restrict__ gs, float* __restrict__ gp,
+                                                       float* __restrict__ gl, size_t n) {
+    const float g0 = gs[0], g1 = gs[1], g2 = gs[2];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float lv = l[i], d = p[i] - lv;
+        const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        const float g = g0 * 2.f * d + g1 * sg;
+        if (gp) gp[i] = g;
+        if (gl) gl[i] = g2 * 2.f * lv - g;
+    }
+}
+
+extern "C" int cfd_loss_sums_bwd(const float* preds, const float* labels, const float* gsums, float* gp, float* gl,
+                                 size_t n, void* stream) {
+    CFD_REQUIRE(preds && labels && gsums, CFD_ERR_INVALID_ARG, "cfd_loss_sums_bwd: NULL pointer");
+    if (n == 0 || (!gp && !gl)) return CFD_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_loss_sums_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, preds, labels, gsums,
+                       gp, gl, n);
+    CFD_LAUNCH_CHECK("cfd_loss_sums_bwd");
+    return CFD_OK;
+}
+
 __global__ void k_loss_scores(const float* __restrict__ sums, float* __restrict__ scores) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const float n = sums[3];
@@ -446,6 +487,36 @@ extern "C" int cfd_loss_coef(const float* sums, float* coef, int which, float up
 }
 
 // ------------------------------------------------------------------------------------------------------
+// stand-alone GELU (only the stand-alone FnoBlock module needs it)
+// ------------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_gelu(const float* __restrict__ x, const float* __restrict__ gy,
+                                              float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = BWD ? gy[i] * cfd_gelu_grad(x[i]) : cfd_gelu(x[i]);
+}
+
+extern "C" int cfd_gelu_fwd(const float* x, float* y, size_t n, void* stream) {
+    CFD_REQUIRE(x && y, CFD_ERR_INVALID_ARG, "cfd_gelu_fwd: NULL pointer");
+    if (n == 0) return CFD_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((k_gelu<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, y, n);
+    CFD_LAUNCH_CHECK("cfd_gelu_fwd");
+    return CFD_OK;
+}
+
+extern "C" int cfd_gelu_bwd(const float* x, const float* gy, float* gx, size_t n, void* stream) {
+    CFD_REQUIRE(x && gy && gx, CFD_ERR_INVALID_ARG, "cfd_gelu_bwd: NULL pointer");
+    if (n == 0) return CFD_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((k_gelu<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, gy, gx, n);
+    CFD_LAUNCH_CHECK("cfd_gelu_bwd");
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Adam  (torch.optim.Adam defaults: amsgrad=False, maximize=False; train_auto.py:213)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -473,6 +544,7 @@ extern "C" int cfd_adam_flat(float* param, const float* grad, float* exp_avg, fl
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     size_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
+    CFD_PROF("k_adam", (hipStream_t)stream);
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)),
                        grad_scale);

@@ -109,6 +109,7 @@ template <int NJ, bool VEC4>
 static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, int act, hipStream_t st) {
     int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
     if (blocks > 2048) blocks = 2048;
+    CFD_PROF(act ? "k_dft_fwd_act" : "k_dft_fwd", st);
     if (act)
         hipLaunchKernelGGL((k_dft_fwd<NJ, VEC4, true>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
                            (const float*)p->d_fwd, p->n_fwd, nimg, p->H, p->W, p->m1, p->m2, p->KX);
@@ -181,6 +182,7 @@ extern "C" int cfd_spectral_mix(const cfd_plan* p, const float* xh, const float*
     const long total = (long)((B + BB - 1) / BB) * Cz * M;
     const int blocks = (int)((total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
+    CFD_PROF(conj_t ? "k_mix_adj" : "k_mix", st);
     if (conj_t)
         hipLaunchKernelGGL((k_mix<BB, true>), dim3(blocks), dim3(256), 0, st, (const float2*)xh, (const float2*)w1,
                            (const float2*)w2, (float2*)z, B, Cr, Cz, Cout, p->m1, p->m2);
@@ -250,9 +252,13 @@ extern "C" int cfd_spectral_wgrad(const cfd_plan* p, const float* xh, const floa
     const int nchunk = (B + CFD_WGRAD_BCHUNK - 1) / CFD_WGRAD_BCHUNK;
     const long total = (long)Cin * Cout * M;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_spec_wgrad_part, dim3((unsigned)((total + 255) / 256), nchunk), dim3(256), 0, st,
-                       (const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M);
+    {
+        CFD_PROF("k_spec_wgrad_part", st);
+        hipLaunchKernelGGL(k_spec_wgrad_part, dim3((unsigned)((total + 255) / 256), nchunk), dim3(256), 0, st,
+                           (const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M);
+    }
     CFD_LAUNCH_CHECK("cfd_spectral_wgrad(part)");
+    CFD_PROF("k_spec_wgrad_reduce", st);
     hipLaunchKernelGGL(k_spec_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        (const float2*)ws, (float2*)gw1, (float2*)gw2, (const float*)p->d_clhw, nchunk, Cin * Cout,
                        p->m1, p->m2);
@@ -383,6 +389,7 @@ static int launch_idft(const cfd_plan* p, const float* z, const float* addend, c
 #define CFD_IDFT_LAUNCH(E)                                                                                         \
     hipLaunchKernelGGL((k_idft<NJ, VEC4, E>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, z, addend, aprev, out,     \
                        (const float*)p->d_inv, p->n_inv, nimg, p->H, p->W, p->m1, p->m2, p->T, p->SA, p->SB)
+    CFD_PROF(epi == 0 ? "k_idft" : (epi == 1 ? "k_idft_add" : "k_idft_add_dgelu"), st);
     if (epi == 0) CFD_IDFT_LAUNCH(0);
     else if (epi == 1) CFD_IDFT_LAUNCH(1);
     else CFD_IDFT_LAUNCH(2);

@@ -1,0 +1,202 @@
+"""Fused training engine for Auto-FNO: the reference's step
+    model(**batch) -> loss["nmse"].backward() -> Adam.step() -> zero_grad()      (src/train_auto.py:231-257)
+as three C-ABI calls on one flat parameter / gradient / moment buffer, plus (world_size > 1) one RCCL all-reduce of
+the flat gradient between backward and Adam.  One process per GPU; nothing here syncs with the host.
+
+The engine re-points the model's parameters at slices of the flat buffer, so ``model.state_dict()`` (reference
+key names, complex64 spectral weights) always reflects the trained weights and checkpoints stay interchangeable.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from . import _lib
+from ._capi import FnoShape
+from .functional import _param_struct
+
+_LOSS_IDS = {"mse": 0, "nmse": 1, "mae": 2}
+
+
+def flatten_layout(params: Sequence[Tensor], align: int = 4) -> Tuple[List[int], int]:
+    """Offsets (in floats) of each tensor inside one flat fp32 buffer; complex tensors take 2 floats per element."""
+    offs, off = [], 0
+    for p in params:
+        n = p.numel() * (2 if p.is_complex() else 1)
+        offs.append(off)
+        off += (n + align - 1) // align * align
+    return offs, off
+
+
+class FlatParams:
+    """One contiguous fp32 buffer holding every parameter; the module's Parameters become views of it."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter]):
+        self.params = list(params)
+        dev = self.params[0].device
+        self.offsets, self.numel = flatten_layout(self.params)
+        self.data = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.views: List[Tensor] = []
+        self.grad_views: List[Tensor] = []
+        for p, off in zip(self.params, self.offsets):
+            n = p.numel() * (2 if p.is_complex() else 1)
+            sl = self.data[off:off + n]
+            gsl = self.grad[off:off + n]
+            if p.is_complex():
+                sl.view(*p.shape, 2).copy_(torch.view_as_real(p.detach().contiguous()))
+                p.data = torch.view_as_complex(sl.view(*p.shape, 2))
+            else:
+                sl.view(p.shape).copy_(p.detach())
+                p.data = sl.view(p.shape)
+            self.views.append(sl)
+            self.grad_views.append(gsl)
+
+    def ptrs(self, grad: bool = False) -> List[int]:
+        return [(g if grad else v).data_ptr() for v, g in zip(self.views, self.grad_views)]
+
+
+class GradSync:
+    """Data-parallel gradient exchange: SUM all-reduce of the flat gradient buffer (RCCL over xGMI on GPUs, gloo in
+    the CPU tests) in ``n_buckets`` contiguous slices; the 1/world_size factor is folded into the Adam kernel.
+    Semantics = DistributedDataParallel's (per-rank loss normalisers, averaged gradients)."""
+
+    def __init__(self, group=None, n_buckets: int = 1):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.n_buckets = max(1, n_buckets)
+
+    def bucket_slices(self, numel: int) -> List[Tuple[int, int]]:
+        per = (numel + self.n_buckets - 1) // self.n_buckets
+        per = (per + 3) // 4 * 4
+        return [(s, min(numel, s + per)) for s in range(0, numel, per)]
+
+    def all_reduce(self, flat_grad: Tensor) -> float:
+        """Returns the scale to apply to the reduced gradient (1/world)."""
+        if self.world == 1:
+            return 1.0
+        handles = [dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                   for a, b in self.bucket_slices(flat_grad.numel())]
+        for h in handles:
+            h.wait()
+        return 1.0 / self.world
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [start, stop) of the items owned by ``rank`` (sizes differ by at most one)."""
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class FnoTrainEngine:
+    def __init__(self, model, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, loss_name: str = "nmse", group=None, grad_buckets: int = 1):
+        if loss_name not in _LOSS_IDS:
+            raise ValueError(f"loss_name must be one of {sorted(_LOSS_IDS)}")
+        self.api = _lib.api()
+        self.model = model
+        params = model.abi_parameters()
+        if not params[0].is_cuda:
+            raise RuntimeError("FnoTrainEngine: move the model to the GPU first (no CPU fallback)")
+        self.device = params[0].device
+        self.flat = FlatParams(params)
+        self.cfg = model.abi_config()
+        self.L = self.cfg["num_layers"]
+        self.exp_avg = torch.zeros_like(self.flat.data)
+        self.exp_avg_sq = torch.zeros_like(self.flat.data)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.loss_id = _LOSS_IDS[loss_name]
+        self.step_count = 0
+        self.sync = GradSync(group, grad_buckets)
+        self.pstruct = _param_struct(self.flat.ptrs(False), self.L)
+        self.gstruct = _param_struct(self.flat.ptrs(True), self.L)
+        self.sums = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.coef = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self.scores_buf = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._shape_key = None
+        self._graph = None
+
+    # ------------------------------------------------------------------------------------------------
+    def _prepare(self, inputs: Tensor, case_params: Tensor):
+        B, in_chan, H, W = inputs.shape
+        key = (B, in_chan, H, W, case_params.shape[1])
+        if key == self._shape_key:
+            return
+        c = self.cfg
+        self.plan = _lib.plan(H, W, c["modes1"], c["modes2"], self.device.index)
+        self.shape = FnoShape(B, H, W, in_chan, c["out_chan"], case_params.shape[1], c["hidden"], self.L, c["modes1"],
+                              c["modes2"], c["head"])
+        nbytes = self.api.size("cfd_fno_workspace_bytes", self.plan, ctypes.byref(self.shape), 1)
+        self.ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+        self.preds = torch.empty((B, c["out_chan"], H, W), dtype=torch.float32, device=self.device)
+        self._shape_key = key
+        self._graph = None
+
+    def forward_backward(self, inputs: Tensor, label: Tensor, case_params: Tensor, mask: Optional[Tensor] = None):
+        """Enqueue forward + loss + backward into the flat gradient buffer (every gradient is overwritten)."""
+        for t in (inputs, label, case_params, mask):
+            if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
+                raise RuntimeError("FnoTrainEngine expects contiguous float32 CUDA tensors")
+        self._prepare(inputs, case_params)
+        st = torch.cuda.current_stream().cuda_stream
+        a, sp = self.api, ctypes.byref(self.shape)
+        mp = None if mask is None else mask.data_ptr()
+        a.call("cfd_fno_forward", self.plan, sp, ctypes.byref(self.pstruct), inputs.data_ptr(), case_params.data_ptr(), mp,
+               label.data_ptr(), self.preds.data_ptr(), self.sums.data_ptr(), self.ws.data_ptr(), 1, st)
+        a.call("cfd_loss_coef", self.sums.data_ptr(), self.coef.data_ptr(), self.loss_id, 1.0, st)
+        a.call("cfd_fno_backward", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct), inputs.data_ptr(),
+               case_params.data_ptr(), mp, label.data_ptr(), self.preds.data_ptr(), None, self.coef.data_ptr(),
+               self.ws.data_ptr(), st)
+
+    def optimizer_step(self, grad_scale: float = 1.0):
+        self.step_count += 1
+        self.api.call("cfd_adam_flat", self.flat.data.data_ptr(), self.flat.grad.data_ptr(), self.exp_avg.data_ptr(),
+                      self.exp_avg_sq.data_ptr(), self.flat.numel, self.lr, self.betas[0], self.betas[1], self.eps,
+                      self.weight_decay, self.step_count, grad_scale, torch.cuda.current_stream().cuda_stream)
+
+    def train_step(self, inputs: Tensor, label: Tensor, case_params: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+        """One optimisation step; returns the device tensor [sum sq err, sum abs err, sum sq label, n] of THIS rank's
+        batch (no host sync -- read it with .tolist() only when logging)."""
+        self.forward_backward(inputs, label, case_params, mask)
+        scale = self.sync.all_reduce(self.flat.grad)
+        self.optimizer_step(scale)
+        return self.sums
+
+    def scores(self) -> Dict[str, float]:
+        """{mse, rmse, mae, nmse} of the last step (loss.py:27-35).  Synchronises."""
+        self.api.call("cfd_loss_scores", self.sums.data_ptr(), self.scores_buf.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+        v = self.scores_buf.tolist()
+        return dict(mse=v[0], rmse=v[1], mae=v[2], nmse=v[3])
+
+    # ---- optional HIP-graph replay of forward+backward (static buffers) -------------------------------
+    def capture(self, inputs: Tensor, label: Tensor, case_params: Tensor, mask: Optional[Tensor] = None):
+        """Capture forward+loss+backward for this batch shape into a HIP graph.  Afterwards ``train_step_graph``
+        copies a batch into the static buffers and replays; the all-reduce and Adam stay outside the graph."""
+        self._static = [t.clone() if t is not None else None for t in (inputs, label, case_params, mask)]
+        self._prepare(inputs, case_params)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.forward_backward(*self._static)  # warm-up outside capture
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.forward_backward(*self._static)
+        self._graph = g
+
+    def train_step_graph(self, inputs: Tensor, label: Tensor, case_params: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+        if self._graph is None:
+            self.capture(inputs, label, case_params, mask)
+        for dst, src in zip(self._static, (inputs, label, case_params, mask)):
+            if dst is not None and src is not dst:
+                dst.copy_(src, non_blocking=True)
+        self._graph.replay()
+        scale = self.sync.all_reduce(self.flat.grad)
+        self.optimizer_step(scale)
+        return self.sums

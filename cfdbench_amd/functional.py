@@ -1,0 +1,277 @@
+"""torch.autograd.Function wrappers over the C ABI (include/cfdbench_amd.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator), the current stream and autograd's graph.
+All arithmetic on the tensors happens in the HIP kernels; nothing in this module has a CPU or ATen fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._capi import FnoParams, FnoShape
+
+
+def _require_cuda(*ts: Optional[Tensor]):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("cfdbench_amd runs on MI355X only: got a CPU tensor (there is no CPU fallback)")
+
+
+def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _bytes(n: int, device) -> Tensor:
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device=device)
+
+
+def _creal(t: Tensor) -> Tensor:
+    """complex64 parameter -> its contiguous interleaved storage (no copy when already contiguous)."""
+    return torch.view_as_real(t.contiguous())
+
+
+# ----------------------------------------------------------------------------------------------------
+# SpectralConv2d_fast  (src/models/fno/fno2d.py:59-82)
+# ----------------------------------------------------------------------------------------------------
+class SpectralConv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, w1: Tensor, w2: Tensor):
+        _require_cuda(x, w1, w2)
+        api = _lib.api()
+        x = _f32c(x)
+        B, Cin, H, W = x.shape
+        Cin_w, Cout, m1, m2 = w1.shape
+        if Cin_w != Cin:
+            raise RuntimeError(f"SpectralConv2d: input has {Cin} channels, weights expect {Cin_w}")
+        plan = _lib.plan(H, W, m1, m2, x.device.index)
+        w1r, w2r = _creal(w1.detach()), _creal(w2.detach())
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+        xh = torch.empty((B, Cin, 2 * m1, m2, 2), dtype=torch.float32, device=x.device)
+        z = torch.empty((B, Cout, 2 * m1, m2, 2), dtype=torch.float32, device=x.device)
+        api.call("cfd_spectral_conv2d_fwd", plan, _ptr(x), _ptr(w1r), _ptr(w2r), _ptr(y), _ptr(xh), _ptr(z), B, Cin, Cout,
+                 _stream())
+        ctx.save_for_backward(xh, w1r, w2r)
+        ctx.dims = (B, Cin, Cout, H, W, m1, m2, plan)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        api = _lib.api()
+        xh, w1r, w2r = ctx.saved_tensors
+        B, Cin, Cout, H, W, m1, m2, plan = ctx.dims
+        gy = _f32c(gy)
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        gx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=gy.device) if need_x else None
+        gw1 = torch.empty((Cin, Cout, m1, m2, 2), dtype=torch.float32, device=gy.device) if need_w else None
+        gw2 = torch.empty((Cin, Cout, m1, m2, 2), dtype=torch.float32, device=gy.device) if need_w else None
+        ws = _bytes(api.size("cfd_spectral_conv2d_bwd_workspace_bytes", plan, B, Cin, Cout), gy.device)
+        api.call("cfd_spectral_conv2d_bwd", plan, _ptr(gy), _ptr(xh), _ptr(w1r), _ptr(w2r), _ptr(gx), _ptr(gw1), _ptr(gw2),
+                 _ptr(ws), B, Cin, Cout, _stream())
+        return (gx, torch.view_as_complex(gw1) if need_w else None, torch.view_as_complex(gw2) if need_w else None)
+
+
+def spectral_conv2d(x: Tensor, w1: Tensor, w2: Tensor) -> Tensor:
+    return SpectralConv2dFn.apply(x, w1, w2)
+
+
+# ----------------------------------------------------------------------------------------------------
+# FnoBlock  (src/models/fno/fno2d.py:85-112) as a stand-alone module
+# ----------------------------------------------------------------------------------------------------
+class FnoBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, w1: Tensor, w2: Tensor, w0: Tensor, b0: Tensor, gelu: bool):
+        _require_cuda(x, w1, w2, w0, b0)
+        api = _lib.api()
+        x = _f32c(x)
+        B, Cin, H, W = x.shape
+        _, Cout, m1, m2 = w1.shape
+        plan = _lib.plan(H, W, m1, m2, x.device.index)
+        w1r, w2r = _creal(w1.detach()), _creal(w2.detach())
+        w0f, b0f = _f32c(w0.detach()), _f32c(b0.detach())
+        dev = x.device
+        xh = torch.empty((B, Cin, 2 * m1, m2, 2), dtype=torch.float32, device=dev)
+        z = torch.empty((B, Cout, 2 * m1, m2, 2), dtype=torch.float32, device=dev)
+        pre = torch.empty((B, Cout, H, W), dtype=torch.float32, device=dev)
+        st = _stream()
+        api.call("cfd_spectral_dft", plan, _ptr(x), _ptr(xh), B * Cin, 0, st)
+        api.call("cfd_spectral_mix", plan, _ptr(xh), _ptr(w1r), _ptr(w2r), _ptr(z), B, Cin, Cout, 0, st)
+        api.call("cfd_chanmix", _ptr(x), _ptr(w0f), _ptr(b0f), _ptr(pre), B, Cin, Cout, H * W, 0, 0, st)
+        api.call("cfd_spectral_idft", plan, _ptr(z), _ptr(pre), None, _ptr(pre), B * Cout, 1, st)
+        out = pre
+        if gelu:
+            out = torch.empty_like(pre)
+            api.call("cfd_gelu_fwd", _ptr(pre), _ptr(out), pre.numel(), st)
+        ctx.save_for_backward(x, xh, pre, w1r, w2r, w0f)
+        ctx.meta = (B, Cin, Cout, H, W, m1, m2, plan, gelu)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        api = _lib.api()
+        x, xh, pre, w1r, w2r, w0f = ctx.saved_tensors
+        B, Cin, Cout, H, W, m1, m2, plan, gelu = ctx.meta
+        dev, st = x.device, _stream()
+        g = _f32c(gout)
+        if gelu:
+            gp = torch.empty_like(g)
+            api.call("cfd_gelu_bwd", _ptr(pre), _ptr(g), _ptr(gp), g.numel(), st)
+            g = gp
+        gh = torch.empty((B, Cout, 2 * m1, m2, 2), dtype=torch.float32, device=dev)
+        api.call("cfd_spectral_dft", plan, _ptr(g), _ptr(gh), B * Cout, 0, st)
+        gw1 = torch.empty_like(w1r)
+        gw2 = torch.empty_like(w2r)
+        ws = _bytes(max(api.size("cfd_spectral_wgrad_workspace_bytes", plan, B, Cin, Cout),
+                        api.size("cfd_chan_wgrad_workspace_bytes", B, Cin, Cout, H * W)), dev)
+        api.call("cfd_spectral_wgrad", plan, _ptr(xh), _ptr(gh), _ptr(gw1), _ptr(gw2), _ptr(ws), B, Cin, Cout, st)
+        gw0 = torch.empty_like(w0f)
+        gb0 = torch.empty(Cout, dtype=torch.float32, device=dev)
+        api.call("cfd_chan_wgrad", _ptr(g), _ptr(x), _ptr(gw0), _ptr(gb0), _ptr(ws), B, Cin, Cout, H * W, 0, st)
+        gz = torch.empty((B, Cin, 2 * m1, m2, 2), dtype=torch.float32, device=dev)
+        api.call("cfd_spectral_mix", plan, _ptr(gh), _ptr(w1r), _ptr(w2r), _ptr(gz), B, Cin, Cout, 1, st)
+        gx = torch.empty_like(x)
+        api.call("cfd_chanmix", _ptr(g), _ptr(w0f), None, _ptr(gx), B, Cout, Cin, H * W, 0, 1, st)
+        api.call("cfd_spectral_idft", plan, _ptr(gz), _ptr(gx), None, _ptr(gx), B * Cin, 1, st)
+        return gx, torch.view_as_complex(gw1), torch.view_as_complex(gw2), gw0, gb0, None
+
+
+def fno_block(x: Tensor, w1: Tensor, w2: Tensor, w0: Tensor, b0: Tensor, gelu: bool = True) -> Tensor:
+    return FnoBlockFn.apply(x, w1, w2, w0, b0, gelu)
+
+
+# ----------------------------------------------------------------------------------------------------
+# MseLoss sums  (src/models/loss.py:22-37)
+# ----------------------------------------------------------------------------------------------------
+class LossSumsFn(torch.autograd.Function):
+    """sums = [sum (p-l)^2, sum |p-l|, sum l^2, n] as one device tensor."""
+
+    @staticmethod
+    def forward(ctx, preds: Tensor, labels: Tensor):
+        _require_cuda(preds, labels)
+        api = _lib.api()
+        if preds.shape != labels.shape:
+            raise RuntimeError(f"MseLoss: preds {tuple(preds.shape)} vs labels {tuple(labels.shape)}")
+        p, l = _f32c(preds), _f32c(labels)
+        n = p.numel()
+        sums = torch.empty(4, dtype=torch.float32, device=p.device)
+        ws = _bytes(api.size("cfd_loss_workspace_bytes", n), p.device)
+        api.call("cfd_masked_loss_sums", _ptr(p), _ptr(l), _ptr(sums), _ptr(ws), n, _stream())
+        ctx.save_for_backward(p, l)
+        return sums
+
+    @staticmethod
+    def backward(ctx, gs: Tensor):
+        api = _lib.api()
+        p, l = ctx.saved_tensors
+        gs = _f32c(gs)
+        gp = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        gl = torch.empty_like(l) if ctx.needs_input_grad[1] else None
+        api.call("cfd_loss_sums_bwd", _ptr(p), _ptr(l), _ptr(gs), _ptr(gp), _ptr(gl), p.numel(), _stream())
+        return gp, gl
+
+
+def scores_from_sums(sums: Tensor, normalize: bool) -> dict:
+    """loss.py:27-35 on the 4-float sums tensor (scalar plumbing; differentiable w.r.t. sums)."""
+    n = sums[3]
+    mse = sums[0] / n
+    out = dict(mse=mse, rmse=torch.sqrt(mse), mae=sums[1] / n)
+    if normalize:
+        out["nmse"] = mse / (sums[2] / n)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# whole Fno2d forward/backward  (src/models/fno/fno2d.py:178-242)
+# ----------------------------------------------------------------------------------------------------
+FNO_PARAM_ORDER_DOC = "fc0.weight, fc0.bias, [weights1, weights2, w0.weight, w0.bias] * L, fc1.weight, fc1.bias, fc2.weight, fc2.bias"
+
+
+def _param_struct(ptrs: Sequence[Optional[int]], L: int) -> FnoParams:
+    s = FnoParams()
+    s.fc0_w, s.fc0_b = ptrs[0], ptrs[1]
+    for l in range(L):
+        s.spec_w1[l], s.spec_w2[l], s.w0_w[l], s.w0_b[l] = ptrs[2 + 4 * l: 6 + 4 * l]
+    s.fc1_w, s.fc1_b, s.fc2_w, s.fc2_b = ptrs[2 + 4 * L: 6 + 4 * L]
+    return s
+
+
+class FnoForwardFn(torch.autograd.Function):
+    """(preds, sums) = Fno2d(inputs, case_params, mask, label); params in FNO_PARAM_ORDER_DOC order."""
+
+    @staticmethod
+    def forward(ctx, cfg: dict, inputs: Tensor, case_params: Tensor, mask: Optional[Tensor], label: Optional[Tensor],
+                *params: Tensor):
+        _require_cuda(inputs, case_params, mask, label, *params)
+        api = _lib.api()
+        L, C, m1, m2, head = cfg["num_layers"], cfg["hidden"], cfg["modes1"], cfg["modes2"], cfg["head"]
+        inputs, case_params, mask, label = _f32c(inputs), _f32c(case_params), _f32c(mask), _f32c(label)
+        B, in_chan, H, W = inputs.shape
+        out_chan = cfg["out_chan"]
+        P = case_params.shape[1]
+        if len(params) != 6 + 4 * L:
+            raise RuntimeError(f"FnoForwardFn: expected {6 + 4 * L} parameter tensors, got {len(params)}")
+        if params[0].shape[1] != in_chan + 3 + P:
+            raise RuntimeError(f"Fno2d: fc0 expects {params[0].shape[1]} features but inputs provide {in_chan}+3+{P}")
+        plan = _lib.plan(H, W, m1, m2, inputs.device.index)
+        shape = FnoShape(B, H, W, in_chan, out_chan, P, C, L, m1, m2, head)
+        flat = [(_creal(p.detach()) if p.is_complex() else _f32c(p.detach())) for p in params]
+        pstruct = _param_struct([t.data_ptr() for t in flat], L)
+        training = any(ctx.needs_input_grad[5:])
+        ws = _bytes(api.size("cfd_fno_workspace_bytes", plan, ctypes.byref(shape), int(training)), inputs.device)
+        preds = torch.empty((B, out_chan, H, W), dtype=torch.float32, device=inputs.device)
+        sums = torch.empty(4, dtype=torch.float32, device=inputs.device) if label is not None else None
+        api.call("cfd_fno_forward", plan, ctypes.byref(shape), ctypes.byref(pstruct), _ptr(inputs), _ptr(case_params),
+                 _ptr(mask), _ptr(label), _ptr(preds), _ptr(sums), _ptr(ws), int(training), _stream())
+        if training:
+            ctx.cfg, ctx.shape, ctx.plan, ctx.ws = cfg, shape, plan, ws
+            ctx.has_mask, ctx.has_label = mask is not None, label is not None
+            saved = [inputs, case_params, preds] + ([mask] if mask is not None else []) + ([label] if label is not None else [])
+            ctx.save_for_backward(*saved, *flat)
+            ctx.n_saved_head = len(saved)
+        ctx.set_materialize_grads(False)
+        return preds, sums
+
+    @staticmethod
+    def backward(ctx, gpreds: Optional[Tensor], gsums: Optional[Tensor]):
+        api = _lib.api()
+        saved = ctx.saved_tensors
+        head, flat = saved[:ctx.n_saved_head], saved[ctx.n_saved_head:]
+        inputs, case_params, preds = head[0], head[1], head[2]
+        k = 3
+        mask = head[k] if ctx.has_mask else None
+        k += int(ctx.has_mask)
+        label = head[k] if ctx.has_label else None
+        L = ctx.cfg["num_layers"]
+        dev = inputs.device
+        if gpreds is None and gsums is None:
+            return (None,) * (5 + len(flat))
+        use_label = label is not None and gsums is not None
+        coef = _f32c(gsums)[:2].contiguous() if use_label else None
+        gext = _f32c(gpreds) if gpreds is not None else None
+        if not use_label and gext is None:
+            return (None,) * (5 + len(flat))
+        grads = [torch.empty_like(t) for t in flat]
+        pstruct = _param_struct([t.data_ptr() for t in flat], L)
+        gstruct = _param_struct([t.data_ptr() for t in grads], L)
+        api.call("cfd_fno_backward", ctx.plan, ctypes.byref(ctx.shape), ctypes.byref(pstruct), ctypes.byref(gstruct),
+                 _ptr(inputs), _ptr(case_params), _ptr(mask), _ptr(label if use_label else None), _ptr(preds), _ptr(gext),
+                 _ptr(coef), _ptr(ctx.ws), _stream())
+        ctx.ws = None
+        out = [torch.view_as_complex(g) if (g.dim() == 5 and g.shape[-1] == 2) else g for g in grads]
+        # reshape 1x1 conv weights back to (out, in, 1, 1): empty_like(flat) already carries the parameter's shape
+        return (None, None, None, None, None, *out)

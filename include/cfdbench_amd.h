@@ -35,6 +35,11 @@ extern "C" {
 int cfd_version(void);
 const char* cfd_last_error(void);
 
+/* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  cfd_prof_end synchronises and
+ * writes "kernel_name launches total_ms\n" lines into buf.  Do not enable during stream capture.               */
+int cfd_prof_begin(void);
+int cfd_prof_end(char* buf, size_t cap);
+
 /* ---- plan: pruned-DFT operator tables for one grid (H,W) and mode count (m1,m2) -------------------------
  * Replaces the implicit FFT plans behind torch.fft.rfft2 / irfft2 (src/models/fno/fno2d.py:62,81) and the
  * per-call host-side np.linspace coordinate grids of Fno2d.get_coords (fno2d.py:244-255).
@@ -124,10 +129,19 @@ int cfd_fno_head_bwd(const float* a, const float* mask, const float* label, cons
  * ws: cfd_loss_workspace_bytes(n).                                                                         */
 size_t cfd_loss_workspace_bytes(size_t n);
 int cfd_masked_loss_sums(const float* preds, const float* labels, float* sums, void* ws, size_t n, void* stream);
+/* Gradient of the three sums: gp = gs[0]*2(p-l) + gs[1]*sign(p-l);  gl = -gp + gs[2]*2l.  gs: 3+ device floats.
+ * gp / gl may be NULL.                                                                                        */
+int cfd_loss_sums_bwd(const float* preds, const float* labels, const float* gsums, float* gp, float* gl, size_t n,
+                      void* stream);
 /* scores[0..3] = {mse, rmse, mae, nmse} from sums (loss.py:27-35).                                           */
 int cfd_loss_scores(const float* sums, float* scores, void* stream);
 /* coef for cfd_fno_head_bwd: which = 0 mse, 1 nmse, 2 mae; scaled by `upstream` (d objective / d loss).       */
 int cfd_loss_coef(const float* sums, float* coef, int which, float upstream, void* stream);
+
+/* nn.GELU() (exact erf, fno2d.py:147) as a standalone pass -- only used by the stand-alone FnoBlock module;
+ * inside Fno2d the activation is fused into the consumers.  bwd: gx = gy * gelu'(x).                          */
+int cfd_gelu_fwd(const float* x, float* y, size_t n, void* stream);
+int cfd_gelu_bwd(const float* x, const float* gy, float* gx, size_t n, void* stream);
 
 /* torch.optim.Adam step on one flat fp32 buffer (train_auto.py:213,256; complex params as (re,im) pairs --
  * torch's view_as_real handling).  step >= 1.                                                               */

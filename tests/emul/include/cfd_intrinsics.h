@@ -42,5 +42,7 @@ inline float cfd_wave_sum(float v) {
 
 inline void cfd_wave_lds_sync() { cfd_emul::wave_sync(); }
 
+inline int cfd_opaque(int x) { return x; }
+
 inline float cfd_erff(float x) { return erff(x); }
 inline float cfd_expf(float x) { return expf(x); }

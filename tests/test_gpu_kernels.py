@@ -1,0 +1,106 @@
+"""MI355X: every C-ABI entry point of the shipped library against the oracle (same checks as the CPU emulator run,
+tests/test_emul_kernels.py, at larger sizes)."""
+import numpy as np
+import pytest
+
+from tests import kernel_checks as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from tests.backends import TorchBackend
+    return TorchBackend()
+
+
+def _assert_all(res, tol=K.TOL):
+    bad = {k: v for k, v in res.items() if not (v < tol)}
+    assert not bad, f"parity failures (tol {tol}): {bad}; all: {res}"
+
+
+def test_library_is_the_hip_extension(be):
+    from cfdbench_amd import _lib
+    assert _lib.lib_path().exists()
+    assert be.api.missing == [] and be.api.version() >= 100
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 3, 5, 64, 64), (3, 4, 3, 66, 65), (4, 20, 20, 64, 64), (1, 32, 32, 64, 64)])
+def test_spectral_fwd_bwd(be, B, Cin, Cout, H, W):
+    _assert_all(K.check_spectral(be, B, Cin, Cout, H, W))
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (66, 65)])
+def test_idft_epilogues(be, H, W):
+    _assert_all(K.check_idft_epilogues(be, 37, H, W))
+
+
+@pytest.mark.parametrize("Ci,Co,HW,act", [(20, 20, 4096, True), (6, 8, 66 * 65, False), (32, 32, 4096, True),
+                                          (20, 20, 4290, True), (13, 20, 1001, False)])
+def test_chanmix_and_wgrad(be, Ci, Co, HW, act):
+    _assert_all(K.check_chanmix(be, 3, Ci, Co, HW, act))
+
+
+@pytest.mark.parametrize("H,W,border,C", [(64, 64, False, 20), (66, 65, True, 20), (64, 64, True, 32), (66, 65, False, 6)])
+def test_stem(be, H, W, border, C):
+    _assert_all(K.check_stem(be, 3, H, W, 5, C, border))
+
+
+@pytest.mark.parametrize("C,HW,act,which,ext", [(20, 4096, True, "nmse", False), (6, 4290, False, "mse", True),
+                                                (32, 4096, True, "mae", False), (20, 4290, True, "nmse", True),
+                                                (8, 1000, True, "nmse", False)])
+def test_head(be, C, HW, act, which, ext):
+    res = K.check_head(be, 3, C, HW, act, which, ext)
+    _assert_all({k: v for k, v in res.items() if k not in ("sums", "scores")})
+    assert res["sums"] < 1e-5 and res["scores"] < 1e-5
+
+
+def test_loss_and_adam(be):
+    res = K.check_loss_and_adam(be, n=1_000_003)
+    assert res["sums"] < 1e-5
+    assert res["adam_delta"] < 1e-9
+
+
+@pytest.mark.parametrize("B,C,L,H,W,border", [(2, 8, 2, 64, 64, False), (2, 6, 2, 66, 65, True), (4, 20, 4, 64, 64, False),
+                                              (2, 20, 4, 66, 65, True), (1, 32, 3, 64, 64, True)])
+def test_fno_whole_model_vs_oracle(be, B, C, L, H, W, border):
+    res = K.check_fno_vs_oracle(be, B, C, L, H, W, border=border)
+    loss_err = res.pop("nmse_loss")
+    assert loss_err < 1e-5
+    _assert_all(res, 1e-9)
+    assert max(res.values()) < K.NORTH_STAR_TOL
+
+
+def test_mfma_operand_layout_is_transpose_detecting(be):
+    """A = I against an ASYMMETRIC second operand: a swapped row/column map in any of the chained MFMA stages would
+    show up as a transposed spectrum (cdna_hip_programming.md section 3 'Always A=I-check with asymmetric B')."""
+    import torch
+    api = be.api
+    H = W = 64
+    plan = api.plan_create(H, W, 12, 12)
+    try:
+        x = np.zeros((1, 1, H, W), np.float32)
+        x[0, 0, 3, 5] = 1.0  # delta -> X^[k,l] = exp(-2 pi i (3k/H + 5l/W)): asymmetric in (k,l)
+        dx = be.dev(x)
+        xh = be.zeros((1, 1, 24, 12), np.complex64)
+        api.call("cfd_spectral_dft", plan, be.ptr(dx), be.ptr(xh), 1, 0, be.stream)
+        be.sync()
+        from oracle import fno_oracle as O
+        k = O.kept_rows(H, 12)[:, None]
+        l = np.arange(12)[None, :]
+        ref = np.exp(-2j * np.pi * (3 * k / H + 5 * l / W))
+        assert np.max(np.abs(be.host(xh)[0, 0] - ref)) < 1e-5
+    finally:
+        api.plan_destroy(plan)
+
+
+def test_error_paths(be):
+    from cfdbench_amd._capi import CfdError
+    with pytest.raises(CfdError):
+        be.api.plan_create(64, 64, 40, 12)
+    with pytest.raises(CfdError):
+        be.api.plan_create(64, 200, 12, 12)
+    plan = be.api.plan_create(64, 64, 12, 12)
+    with pytest.raises(CfdError):
+        be.api.call("cfd_spectral_dft", plan, None, None, 4, 0, be.stream)
+    be.api.plan_destroy(plan)

@@ -1,0 +1,267 @@
+"""MI355X: the drop-in Python surface (Fno2d / SpectralConv2d_fast / FnoBlock / MseLoss / FnoTrainEngine) against
+the golden fixtures produced by the REAL reference (tests/golden, oracle/make_golden.py) and against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import fno_oracle as O
+from oracle import synth
+from oracle.make_golden_inputs import spectral_case
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9            # what the fp32 kernels deliver
+NORTH_STAR_TOL = 1e-5  # BASELINE.json: outputs within 1e-5 relative nMSE of the reference (fp32)
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _model(torch, params, C, L, p=5):
+    from cfdbench_amd.models.fno.fno2d import Fno2d
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    m = Fno2d(2, 2, p, loss_name_to_fn("nmse"), L, 12, 12, C).cuda()
+    missing = m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()})
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m
+
+
+def _cuda(torch, batch):
+    return {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+
+
+def test_state_dict_keys_and_dtypes_match_reference(torch):
+    params = synth.make_fno_params(1, 20, 4, 12, 12, 5)
+    m = _model(torch, params, 20, 4)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(synth.fno_param_shapes(20, 4, 12, 12, 5).keys())
+    for k, (shape, is_c) in synth.fno_param_shapes(20, 4, 12, 12, 5).items():
+        assert tuple(sd[k].shape) == shape
+        assert sd[k].dtype == (torch.complex64 if is_c else torch.float32)
+    assert sum(p.numel() * (2 if p.is_complex() else 1) for p in m.parameters()) == 926446
+
+
+@pytest.mark.parametrize("name", ["spectral_64x64", "spectral_66x65", "spectral_c20_64x64"])
+def test_spectral_module_vs_reference_golden(torch, golden_dir, name):
+    from cfdbench_amd.models.fno.fno2d import SpectralConv2d_fast
+    g = np.load(golden_dir / f"{name}.npz")
+    seed, B, Cin, Cout, H, W, m1, m2 = [int(v) for v in g["meta"]]
+    x, gy, w1, w2 = spectral_case(seed, B, Cin, Cout, H, W, m1, m2)
+    mod = SpectralConv2d_fast(Cin, Cout, m1, m2).cuda()
+    with torch.no_grad():
+        mod.weights1.copy_(torch.from_numpy(w1))
+        mod.weights2.copy_(torch.from_numpy(w2))
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    y = mod(xt)
+    y.backward(torch.from_numpy(gy).cuda())
+    assert O.rel_nmse(y.detach().cpu().numpy(), g["y"]) < TOL
+    assert O.rel_nmse(xt.grad.cpu().numpy(), g["gx"]) < TOL
+    assert O.rel_nmse(mod.weights1.grad.cpu().numpy(), g["gw1"]) < TOL
+    assert O.rel_nmse(mod.weights2.grad.cpu().numpy(), g["gw2"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["fno_small_64x64", "fno_small_66x65", "fno_cfg1_b8"])
+def test_fno2d_forward_backward_vs_reference_golden(torch, golden_dir, name):
+    g = np.load(golden_dir / f"{name}.npz")
+    pseed, bseed, B, C, L, H, W, p, border = [int(v) for v in g["meta"]]
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=float(g["gain"]))
+    batch = synth.make_batch(bseed, B, H, W, p, border_mask=bool(border))
+    m = _model(torch, params, C, L, p)
+    out = m(**_cuda(torch, batch))
+    assert set(out["loss"].keys()) == {"mse", "rmse", "mae", "nmse"}
+    out["loss"]["nmse"].backward()
+    assert O.rel_nmse(out["preds"].detach().cpu().numpy(), g["preds"]) < TOL
+    for k in ("mse", "rmse", "mae", "nmse"):
+        assert abs(out["loss"][k].item() - float(g[f"loss_{k}"])) <= 5e-6 * abs(float(g[f"loss_{k}"]))
+    grads = dict(m.named_parameters())
+    for key in g.files:
+        if key.startswith("grad::"):
+            k = key[len("grad::"):]
+            err = O.rel_nmse(grads[k].grad.cpu().numpy(), g[key])
+            assert err < 1e-8 and err < NORTH_STAR_TOL, (k, err)
+        if key.startswith("gsum::") and key.endswith("::vals"):
+            k = key.split("::")[1]
+            got = grads[k].grad.cpu().numpy().reshape(-1)[g[f"gsum::{k}::idx"]]
+            assert O.rel_nmse(got, g[key]) < 1e-7, k
+
+
+def test_forward_without_label_has_no_loss_and_3d_mask(torch):
+    params = synth.make_fno_params(5, 8, 2, 12, 12, 5)
+    batch = synth.make_batch(6, 2, 64, 64, 5, border_mask=True)
+    m = _model(torch, params, 8, 2)
+    b = _cuda(torch, batch)
+    with torch.no_grad():
+        o4 = m(inputs=b["inputs"], case_params=b["case_params"], mask=b["mask"])
+        o3 = m(inputs=b["inputs"], case_params=b["case_params"], mask=b["mask"][:, 0])
+        o0 = m(inputs=b["inputs"], case_params=b["case_params"])
+    assert "loss" not in o4
+    assert torch.equal(o4["preds"], o3["preds"])
+    p64 = {k: v.astype(np.complex128 if np.iscomplexobj(v) else np.float64) for k, v in params.items()}
+    ref = O.fno_forward(p64, batch["inputs"].astype(np.float64), batch["case_params"].astype(np.float64), None, None, 2)
+    assert O.rel_nmse(o0["preds"].cpu().numpy(), ref["preds"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["rollout_small_64x64", "rollout_small_66x65"])
+def test_generate_many_vs_reference_golden(torch, golden_dir, name):
+    g = np.load(golden_dir / f"{name}.npz")
+    pseed, bseed, B, C, L, H, W, p, steps, border = [int(v) for v in g["meta"]]
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=float(g["gain"]))
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    if border:
+        batch["mask"][:, :, 0, :] = 0
+        batch["mask"][:, :, -1, :] = 0
+        batch["mask"][:, :, :, 0] = 0
+    m = _model(torch, params, C, L, p).eval()
+    b = _cuda(torch, batch)
+    with torch.no_grad():
+        frames = m.generate_many(b["inputs"], b["case_params"], b["mask"], steps)
+        assert len(frames) == steps and tuple(frames[0].shape) == (B, 2, H, W)
+        assert O.rel_nmse(frames[0].cpu().numpy(), g["first"]) < TOL
+        assert O.rel_nmse(frames[-1].cpu().numpy(), g["last"]) < 1e-7
+        # unbatched call adds the batch dimension (fno2d.py:281-285)
+        f1 = m.generate_many(b["inputs"][0], b["case_params"][0], b["mask"][0, 0], 2)
+        assert tuple(f1[0].shape) == (1, 2, H, W)
+        assert O.rel_nmse(f1[1].cpu().numpy(), frames[1][:1].cpu().numpy()) < 1e-10
+
+
+def test_mseloss_vs_reference_golden(torch, golden_dir):
+    from cfdbench_amd.models.loss import MseLoss, loss_name_to_fn
+    g = np.load(golden_dir / "mseloss.npz")
+    rng = np.random.default_rng(int(g["meta"][0]))
+    p = rng.standard_normal((3, 2, 17, 19)).astype(np.float32)
+    l = rng.standard_normal((3, 2, 17, 19)).astype(np.float32)
+    pt = torch.from_numpy(p).cuda().requires_grad_(True)
+    r = MseLoss(normalize=True)(preds=pt, labels=torch.from_numpy(l).cuda())
+    for k in ("mse", "rmse", "mae", "nmse"):
+        assert abs(r[k].item() - float(g[k])) < 2e-6 * abs(float(g[k]))
+    r["nmse"].backward()
+    ref = O.loss_grad_wrt_preds(p.astype(np.float64), l.astype(np.float64), "nmse")
+    assert O.rel_nmse(pt.grad.cpu().numpy(), ref) < 1e-10
+    assert loss_name_to_fn("mse").get_score_names() == ["mse", "rmse", "mae"]
+    with pytest.raises(NotImplementedError):
+        loss_name_to_fn("l1")
+
+
+def test_fno_block_module(torch):
+    from cfdbench_amd.models.fno.fno2d import FnoBlock
+    import torch.nn as nn
+    rng = np.random.default_rng(9)
+    blk = FnoBlock(6, 6, 12, 12, nn.GELU()).cuda()
+    x = rng.standard_normal((2, 6, 64, 64)).astype(np.float32)
+    gy = rng.standard_normal((2, 6, 64, 64)).astype(np.float32)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    y = blk(xt)
+    y.backward(torch.from_numpy(gy).cuda())
+    w1 = blk.conv0.weights1.detach().cpu().numpy().astype(np.complex128)
+    w2 = blk.conv0.weights2.detach().cpu().numpy().astype(np.complex128)
+    w0 = blk.w0.weight.detach().cpu().numpy().astype(np.float64)
+    b0 = blk.w0.bias.detach().cpu().numpy().astype(np.float64)
+    x64 = x.astype(np.float64)
+    pre = O.spectral_conv2d_fwd(x64, w1, w2) + O.conv1x1(x64, w0, b0)
+    assert O.rel_nmse(y.detach().cpu().numpy(), O.gelu(pre)) < TOL
+    gpre = gy.astype(np.float64) * O.gelu_grad(pre)
+    gx_s, gw1, gw2 = O.spectral_conv2d_bwd(gpre, x64, w1, w2)
+    gx = gx_s + np.einsum("oi,bohw->bihw", w0.reshape(6, 6), gpre)
+    assert O.rel_nmse(xt.grad.cpu().numpy(), gx) < TOL
+    assert O.rel_nmse(blk.conv0.weights1.grad.cpu().numpy(), gw1) < TOL
+    assert O.rel_nmse(blk.w0.weight.grad.cpu().numpy().reshape(6, 6), np.einsum("bohw,bihw->oi", gpre, x64)) < TOL
+
+
+def test_torch_adam_on_dropin_model_vs_reference_golden(torch, golden_dir):
+    """train_auto.py:231-257 with the stock torch.optim.Adam driving OUR module (compat path)."""
+    g = np.load(golden_dir / "adam_small_64x64.npz")
+    pseed, bseed, B, C, L, H, W, p, nsteps = [int(v) for v in g["meta"]]
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=float(g["gain"]))
+    m = _model(torch, params, C, L, p)
+    opt = torch.optim.Adam(m.parameters(), lr=float(g["lr"]))
+    losses = []
+    for s in range(nsteps):
+        out = m(**_cuda(torch, synth.make_batch(bseed + s, B, H, W, p)))
+        opt.zero_grad()
+        out["loss"]["nmse"].backward()
+        opt.step()
+        losses.append(out["loss"]["nmse"].item())
+    assert np.allclose(losses, g["losses"], rtol=5e-6)
+    for k, v in m.state_dict().items():
+        d_ref = g[f"param::{k}"].astype(np.complex128) - params[k]
+        d_our = v.cpu().numpy().astype(np.complex128) - params[k]
+        assert O.rel_nmse(d_our, d_ref) < 1e-3, k  # first Adam steps are ~ +-lr*sign(g): sensitive to 1-ulp grads
+
+
+def test_engine_train_steps_vs_reference_golden(torch, golden_dir):
+    """Fused engine (flat buffers + cfd_adam_flat) reproduces the reference's loss trajectory and weights."""
+    from cfdbench_amd.engine import FnoTrainEngine
+    g = np.load(golden_dir / "adam_small_64x64.npz")
+    pseed, bseed, B, C, L, H, W, p, nsteps = [int(v) for v in g["meta"]]
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=float(g["gain"]))
+    m = _model(torch, params, C, L, p)
+    eng = FnoTrainEngine(m, lr=float(g["lr"]))
+    losses = []
+    for s in range(nsteps):
+        b = _cuda(torch, synth.make_batch(bseed + s, B, H, W, p))
+        eng.train_step(b["inputs"], b["label"], b["case_params"], b["mask"])
+        losses.append(eng.scores()["nmse"])
+    assert np.allclose(losses, g["losses"], rtol=5e-6)
+    sd = m.state_dict()  # parameters are views of the engine's flat buffer
+    for k, v in sd.items():
+        d_ref = g[f"param::{k}"].astype(np.complex128) - params[k]
+        d_our = v.cpu().numpy().astype(np.complex128) - params[k]
+        assert O.rel_nmse(d_our, d_ref) < 1e-3, k
+
+
+def test_engine_graph_replay_matches_eager(torch):
+    from cfdbench_amd.engine import FnoTrainEngine
+    params = synth.make_fno_params(3, 8, 2, 12, 12, 5, spectral_gain=4.0)
+    ma, mb = _model(torch, params, 8, 2), _model(torch, params, 8, 2)
+    ea, eb = FnoTrainEngine(ma, lr=1e-3), FnoTrainEngine(mb, lr=1e-3)
+    for s in range(3):
+        b = _cuda(torch, synth.make_batch(50 + s, 4, 64, 64, 5))
+        ea.train_step(b["inputs"], b["label"], b["case_params"], b["mask"])
+        eb.train_step_graph(b["inputs"], b["label"], b["case_params"], b["mask"])
+    torch.cuda.synchronize()
+    assert torch.equal(ea.flat.data, eb.flat.data)
+
+
+def test_full_size_properties_b256(torch):
+    """BASELINE.json configs[1] size (B=256, C=20, 64x64, modes 12): size-independent properties instead of the oracle."""
+    from cfdbench_amd import functional as F_
+    rng = np.random.default_rng(77)
+    B, C, H, W = 256, 20, 64, 64
+    x = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32)).cuda()
+    w1 = torch.from_numpy((rng.random((C, C, 12, 12)) + 1j * rng.random((C, C, 12, 12))).astype(np.complex64)).cuda() / C
+    w2 = torch.from_numpy((rng.random((C, C, 12, 12)) + 1j * rng.random((C, C, 12, 12))).astype(np.complex64)).cuda() / C
+    with torch.no_grad():
+        fx, fy = F_.spectral_conv2d(x, w1, w2), F_.spectral_conv2d(y, w1, w2)
+        fl = F_.spectral_conv2d(2.0 * x - 3.0 * y, w1, w2)
+        lin = (fl - (2.0 * fx - 3.0 * fy)).pow(2).mean() / fl.pow(2).mean()
+        assert lin.item() < 1e-11  # linearity
+        # batch independence: the first 8 samples alone give the same rows
+        f8 = F_.spectral_conv2d(x[:8].contiguous(), w1, w2)
+        assert torch.equal(f8, fx[:8])
+        # band limit: the output only contains the kept modes -> applying an identity-weight layer reproduces it
+        eye = torch.zeros((C, C, 12, 12), dtype=torch.complex64, device="cuda")
+        eye[torch.arange(C), torch.arange(C)] = 1.0
+        proj = F_.spectral_conv2d(fx, eye, eye)
+        assert ((proj - fx).pow(2).mean() / fx.pow(2).mean()).item() < 1e-11
+    # adjoint identity <f(x), y> == <x, f^T(y)> through the backward kernels
+    xr = x.clone().requires_grad_(True)
+    out = F_.spectral_conv2d(xr, w1, w2)
+    out.backward(y)
+    lhs = (out.detach().double() * y.double()).sum()
+    rhs = (x.double() * xr.grad.double()).sum()
+    assert abs(lhs - rhs).item() <= 1e-6 * abs(lhs).item()
+    # sample 4 batch rows against the oracle
+    idx = [0, 17, 128, 255]
+    ref = O.spectral_conv2d_fwd(x[idx].cpu().numpy().astype(np.float64), w1.cpu().numpy().astype(np.complex128),
+                                w2.cpu().numpy().astype(np.complex128))
+    assert O.rel_nmse(fx[idx].cpu().numpy(), ref) < TOL
+
+
+def test_cpu_tensors_are_rejected(torch):
+    from cfdbench_amd.models.loss import MseLoss
+    with pytest.raises(RuntimeError):
+        MseLoss(True)(preds=torch.zeros(4), labels=torch.zeros(4))
