@@ -227,10 +227,18 @@ def main():
     # ---- CPU baseline leg (rank 0, N=1): the reference's ATen call sequence on the host cores ------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_port
-        cb = torch_port.time_train_steps(args.cpu_batch, args.cpu_steps, warmup=1, C=C, L=L, H=H, W=W, p=p)
-        result["cpu_baseline"] = dict(value=round(cb["frames_per_s"], 1), unit="frames/s", cores=cb["threads"], kind="port",
-                                      sample=f"same train step (fwd+nMSE+bwd+Adam) via oracle/torch_port.py (PyTorch-CPU ATen ops, "
-                                             f"fp32), batch {args.cpu_batch} x {args.cpu_steps} steps after 1 warm-up, median")
+        ncpu = os.cpu_count() or 1
+        # ATen's CPU kernels do not scale to every core at this size: probe a few thread counts briefly, keep the best
+        cands = sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu})
+        probe = {t: torch_port.time_train_steps(args.cpu_batch, 2, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=t)["frames_per_s"]
+                 for t in cands}
+        best_t = max(probe, key=probe.get)
+        cb = torch_port.time_train_steps(args.cpu_batch, args.cpu_steps, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=best_t)
+        result["cpu_baseline"] = dict(
+            value=round(cb["frames_per_s"], 1), unit="frames/s", cores=cb["threads"], kind="port",
+            sample=f"same train step (fwd+nMSE+bwd+Adam) via oracle/torch_port.py (PyTorch-CPU ATen ops, fp32), batch "
+                   f"{args.cpu_batch} x {args.cpu_steps} steps after 1 warm-up, median; best of thread counts "
+                   f"{ {t: round(v, 1) for t, v in probe.items()} } on {ncpu} host cores")
 
     if rank == 0:
         print(json.dumps(result), flush=True)

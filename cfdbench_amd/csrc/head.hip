@@ -454,18 +454,23 @@ __global__ __launch_bounds__(256, 1) void k_head_bwd(
     for (int e = threadIdx.x; e < PS; e += blockDim.x) dst[e] = red[e];
 }
 
+// One wave per output element (see k_wgrad_reduce).
 __global__ __launch_bounds__(256) void k_head_reduce(const float* __restrict__ part, int nblk, int PS,
                                                      float* __restrict__ gw1, float* __restrict__ gb1,
                                                      float* __restrict__ gw2, float* __restrict__ gb2, int C, int Co) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= PS) return;
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * PS + e];
-    const int o_gb1 = HEAD_HD * C, o_gw2 = o_gb1 + HEAD_HD, o_gb2 = o_gw2 + Co * HEAD_HD;
-    if (e < o_gb1) gw1[e] = s;
-    else if (e < o_gw2) gb1[e - o_gb1] = s;
-    else if (e < o_gb2) gw2[e - o_gw2] = s;
-    else gb2[e - o_gb2] = s;
+    for (int k = lane; k < nblk; k += 64) s += part[(size_t)k * PS + e];
+    s = cfd_wave_sum(s);
+    if (lane == 0) {
+        const int o_gb1 = HEAD_HD * C, o_gw2 = o_gb1 + HEAD_HD, o_gb2 = o_gw2 + Co * HEAD_HD;
+        if (e < o_gb1) gw1[e] = s;
+        else if (e < o_gw2) gb1[e - o_gb1] = s;
+        else if (e < o_gb2) gw2[e - o_gw2] = s;
+        else gb2[e - o_gb2] = s;
+    }
 }
 
 extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* label, const float* preds,
@@ -501,7 +506,8 @@ extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* 
     }
     CFD_LAUNCH_CHECK("cfd_fno_head_bwd");
     const int PS = (int)head_part_floats(C, Co);
-    hipLaunchKernelGGL(k_head_reduce, dim3((PS + 255) / 256), dim3(256), 0, st, (const float*)part, blocks, PS, gw1,
+    CFD_PROF("k_head_reduce", st);
+    hipLaunchKernelGGL(k_head_reduce, dim3((PS + 3) / 4), dim3(256), 0, st, (const float*)part, blocks, PS, gw1,
                        gb1, gw2, gb2, C, Co);
     CFD_LAUNCH_CHECK("cfd_fno_head_bwd(reduce)");
     return CFD_OK;

@@ -287,16 +287,21 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
     }
 }
 
+// One wave per output element: lanes stride over the per-block partials, then a fixed shuffle tree (deterministic).
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int nblk, float* __restrict__ gw,
                                                       float* __restrict__ gb, int Co, int Ci) {
     const int NW = Ci + 1;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= Co * NW) return;
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= Co * NW) return;  // whole wave exits together
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * Co * NW + e];
-    const int o = e / NW, i = e - o * NW;
-    if (i < Ci) gw[o * Ci + i] = s;
-    else if (gb) gb[o] = s;
+    for (int k = lane; k < nblk; k += 64) s += part[(size_t)k * Co * NW + e];
+    s = cfd_wave_sum(s);
+    if (lane == 0) {
+        const int o = e / NW, i = e - o * NW;
+        if (i < Ci) gw[o * Ci + i] = s;
+        else if (gb) gb[o] = s;
+    }
 }
 
 static int wgrad_blocks(int B, int HW) {
@@ -346,7 +351,7 @@ static int launch_wgrad(const float* g, const float* in, StemSrc ss, float* gw, 
 #undef CFD_WG
     CFD_LAUNCH_CHECK("cfd_chan_wgrad");
     CFD_PROF("k_wgrad_reduce", st);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((Co * (Ci + 1) + 255) / 256), dim3(256), 0, st, (const float*)part, blocks,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((Co * (Ci + 1) + 3) / 4), dim3(256), 0, st, (const float*)part, blocks,
                        gw, gb, Co, Ci);
     CFD_LAUNCH_CHECK("cfd_chan_wgrad(reduce)");
     return CFD_OK;

@@ -242,11 +242,6 @@ def test_full_size_properties_b256(torch):
         # batch independence: the first 8 samples alone give the same rows
         f8 = F_.spectral_conv2d(x[:8].contiguous(), w1, w2)
         assert torch.equal(f8, fx[:8])
-        # band limit: the output only contains the kept modes -> applying an identity-weight layer reproduces it
-        eye = torch.zeros((C, C, 12, 12), dtype=torch.complex64, device="cuda")
-        eye[torch.arange(C), torch.arange(C)] = 1.0
-        proj = F_.spectral_conv2d(fx, eye, eye)
-        assert ((proj - fx).pow(2).mean() / fx.pow(2).mean()).item() < 1e-11
     # adjoint identity <f(x), y> == <x, f^T(y)> through the backward kernels
     xr = x.clone().requires_grad_(True)
     out = F_.spectral_conv2d(xr, w1, w2)
