@@ -51,6 +51,8 @@ _SIGS = {
     "cfd_spectral_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cfd_spectral_conv2d_bwd_workspace_bytes": (_Z, [_P, _I, _I, _I]),
     "cfd_spectral_conv2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "cfd_fno_block_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cfd_fno_block_bwd_input": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cfd_chanmix": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cfd_chan_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "cfd_chan_wgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -34,5 +34,13 @@ __device__ __forceinline__ int cfd_opaque(int x) {
     return x;
 }
 
+// Wave-uniform value -> SGPR (lets the compiler use scalar loads / scalar operands for per-wave indices).
+__device__ __forceinline__ int cfd_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// Scheduling fence: the compiler may not move any instruction across it (keeps a software-pipelined load where it
+// was written instead of sinking it next to its first use).
+__device__ __forceinline__ void cfd_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 __device__ __forceinline__ float cfd_erff(float x) { return erff(x); }
 __device__ __forceinline__ float cfd_expf(float x) { return __expf(x); }
+__device__ __forceinline__ float cfd_rcpf(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32, 1 ulp

@@ -85,8 +85,7 @@ extern "C" int cfd_fno_forward(const cfd_plan* p, const cfd_fno_shape* s, const 
         const int act = l > 0;
         CFD_TRY(cfd_spectral_dft(p, act_buf(l), xh_buf(l), B * C, act, stream));
         CFD_TRY(cfd_spectral_mix(p, xh_buf(l), prm->spec_w1[l], prm->spec_w2[l], z, B, C, C, 0, stream));
-        CFD_TRY(cfd_chanmix(act_buf(l), prm->w0_w[l], prm->w0_b[l], act_buf(l + 1), B, C, C, HW, act, 0, stream));
-        CFD_TRY(cfd_spectral_idft(p, z, act_buf(l + 1), nullptr, act_buf(l + 1), B * C, 1, stream));
+        CFD_TRY(cfd_fno_block_fwd(p, act_buf(l), z, prm->w0_w[l], prm->w0_b[l], act_buf(l + 1), B, C, C, act, stream));
     }
     CFD_TRY(cfd_fno_head_fwd(act_buf(NL), mask, label, prm->fc1_w, prm->fc1_b, prm->fc2_w, prm->fc2_b, preds, sums,
                              scratch, B, C, s->head, s->out_chan, HW, NL > 0, stream));
@@ -120,8 +119,7 @@ extern "C" int cfd_fno_backward(const cfd_plan* p, const cfd_fno_shape* s, const
         CFD_TRY(cfd_spectral_wgrad(p, xh_buf(l), gh, g->spec_w1[l], g->spec_w2[l], scratch, B, C, C, stream));
         CFD_TRY(cfd_chan_wgrad(gcur, act_buf(l), g->w0_w[l], g->w0_b[l], scratch, B, C, C, HW, act, stream));
         CFD_TRY(cfd_spectral_mix(p, gh, prm->spec_w1[l], prm->spec_w2[l], z, B, C, C, 1, stream));
-        CFD_TRY(cfd_chanmix(gcur, prm->w0_w[l], nullptr, gnext, B, C, C, HW, 0, 1, stream));
-        CFD_TRY(cfd_spectral_idft(p, z, gnext, act ? act_buf(l) : nullptr, gnext, B * C, act ? 2 : 1, stream));
+        CFD_TRY(cfd_fno_block_bwd_input(p, gcur, z, prm->w0_w[l], act ? act_buf(l) : nullptr, gnext, B, C, C, stream));
         float* t = gcur; gcur = gnext; gnext = t;
     }
     CFD_TRY(cfd_fno_stem_bwd(p, gcur, inputs, mask, case_params, g->fc0_w, g->fc0_b, scratch, B, s->in_chan,

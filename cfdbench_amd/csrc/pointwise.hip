@@ -3,6 +3,8 @@
 //   feature assembly + fc0    src/models/fno/fno2d.py:189-217      -> k_stem_fwd / k_chan_wgrad<STEM>
 //   MseLoss                   src/models/loss.py:22-37             -> k_loss_part / k_loss_final
 //   torch.optim.Adam          src/train_auto.py:213,256            -> k_adam
+#include <cstdlib>
+
 #include "cfd_common.h"
 
 // ------------------------------------------------------------------------------------------------------
@@ -204,10 +206,11 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
     const int cpb = (HW + 15) / 16;  // 16-pixel chunks per batch entry
     const long total = (long)B * cpb;
     const int CiIn = STEM ? ss.in_chan : Ci;  // channels physically present in `in`
-    for (long ch = (long)blockIdx.x * 4 + wave; ch < total; ch += (long)gridDim.x * 4) {
+    // One chunk = 16 pixels of every channel.  load() only issues the global reads (raw values); GELU and the MFMAs
+    // happen one iteration later, so the next chunk's reads are in flight while this chunk is on the matrix pipe.
+    auto load = [&](long ch, float (&av)[MT][4], float (&bv)[NT][4]) {
         const int b = (int)(ch / cpb);
         const int px = (int)(ch - (long)b * cpb) * 16 + 4 * q;  // this lane's 4 pixels: px .. px+3
-        float av[MT][4], bv[NT][4];
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             const int o = 16 * a + n;
@@ -234,10 +237,6 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
 #pragma unroll
                     for (int j = 0; j < 4; ++j) bv[c][j] = (px + j < HW) ? src[j] : 0.f;
                 }
-                if constexpr (ACT) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bv[c][j] = cfd_gelu(bv[c][j]);
-                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -257,12 +256,39 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
                 }
             }
         }
+    };
+    const long stride = (long)gridDim.x * 4;
+    long ch = (long)blockIdx.x * 4 + wave;
+    float av[MT][4], bv[NT][4], avn[MT][4], bvn[NT][4];
+    if (ch < total) load(ch, av, bv);
+    while (ch < total) {
+        const long nx = ch + stride;
+        if (nx < total) load(nx, avn, bvn);
+        cfd_sched_fence();
+        if constexpr (ACT) {
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+                if (16 * c + n < CiIn) {  // the ones / generated columns are not activations
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bv[c][j] = cfd_gelu(bv[c][j]);
+                }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int c = 0; c < NT; ++c) acc[a][c] = cfd_mfma16x16x4(av[a][j], bv[c][j], acc[a][c]);
+        cfd_sched_fence();
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[a][j] = avn[a][j];
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[c][j] = bvn[c][j];
+        ch = nx;
     }
     // block reduction of the 4 waves, then one partial tile per block
 #pragma unroll
@@ -307,7 +333,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 static int wgrad_blocks(int B, int HW) {
     const long chunks = (long)B * ((HW + 15) / 16);
     long blocks = (chunks + 31) / 32;  // >= 8 chunks per wave
-    if (blocks > 512) blocks = 512;
+    static const long cap = getenv("CFD_WG_BLOCKS") ? atol(getenv("CFD_WG_BLOCKS")) : 1024;  // dev knob
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }

@@ -16,6 +16,8 @@
 //   S = Z[+kap] + Z[-kap], D = Z[+kap] - Z[-kap]
 //   stage A:    U_re[x][l] = sum_kap S_re cos(th) - D_im sin(th);  U_im[x][l] = sum_kap S_im cos(th) + D_re sin(th)
 //   stage B:    y[x][y] = sum_l (c_l/HW) (U_re cos(2pi l y/W) - U_im sin(2pi l y/W))
+#include <cstdlib>
+
 #include "cfd_common.h"
 
 #define CFD_WAVES 4  // waves per workgroup (256 threads)
@@ -105,11 +107,132 @@ __global__ __launch_bounds__(64 * CFD_WAVES) void k_dft_fwd(const float* __restr
     }
 }
 
+// Fast path for W == 64 (16-B aligned rows): persistent waves with a rolling prefetch.  A wave keeps a ring
+// of D k-steps (2*D float4 per lane) in flight: the moment the rows of k-step s have been folded into MFMA operands
+// the same registers are re-armed with k-step s+D (running on into the wave's NEXT image), so the HBM stream never
+// stops while the 136 MFMAs of the current image issue (measured: loads alone 14.6 us, MFMAs alone 17 us, unpipelined 31 us).
+// Every row load is unconditional (rows past H/2 are clamped to row 0 and meet all-zero table entries).
+template <int KXT, int D, bool ACT>
+__global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64(const float* __restrict__ x, float2* __restrict__ xh,
+                                                                  const float* __restrict__ tabs, int ntab, int nimg,
+                                                                  int H, int m1, int m2) {
+    constexpr int W = 64, NJ = 4;
+    __shared__ float s_tab[(2 * KXT + 8 * NJ) * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int stride = gridDim.x * CFD_WAVES;
+    int img = blockIdx.x * CFD_WAVES + wave;
+    static_assert(KXT % D == 0, "ring depth must divide the k-step count");
+    float4 v[D], u[D];  // ring of D k-steps in flight: step s lives in slot s % D
+    // H == 8*(KXT-1): k-step s holds rows xf = 4s+q (valid while xf <= H/2) and their mirror rows H-xf (only for
+    // 0 < xf < H/2).  Row offsets are (compile-time multiple of 4W) + one lane register, so they fold into the
+    // load instructions' immediate fields.
+    const int lv = q * W + 4 * n;        // row q, this lane's 4 columns
+    const int lu = (H - q) * W + 4 * n;  // row H-q
+    auto off_v = [&](int s) { return (s < KXT - 1 || q == 0) ? 4 * s * W + lv : 4 * n; };
+    auto off_u = [&](int s) { return (s == 0 ? q != 0 : s < KXT - 1) ? lu - 4 * s * W : 4 * n; };
+    auto is_paired = [&](int s) { return s == 0 ? q != 0 : s < KXT - 1; };
+    {
+        const float* xi = x + (size_t)(img < nimg ? img : 0) * H * W;
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            v[s] = *reinterpret_cast<const float4*>(xi + off_v(s));
+            u[s] = *reinterpret_cast<const float4*>(xi + off_u(s));
+        }
+    }
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) s_tab[i] = tabs[i];
+    __syncthreads();
+    const float* t1c = s_tab;
+    const float* t1s = t1c + KXT * 64;
+    const float* t2c = t1s + KXT * 64;
+    const float* t2s = t2c + 4 * NJ * 64;
+    const int M = 2 * m1 * m2;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    while (img < nimg) {
+        const int nxt = img + stride;
+        // no next image: re-read this one (cache hits, values never used) so the loop body stays branch-free
+        const float* xn = x + (size_t)(nxt < nimg ? nxt : img) * H * W;
+        f32x4 a1c[NJ], a1s[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { a1c[j] = zero; a1s[j] = zero; }
+#pragma unroll
+        for (int s = 0; s < KXT; ++s) {
+            float e[4], o[4];
+            {
+                float a[4] = {v[s % D].x, v[s % D].y, v[s % D].z, v[s % D].w};
+                float b[4] = {u[s % D].x, u[s % D].y, u[s % D].z, u[s % D].w};
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    float aa = a[j], bb = is_paired(s) ? b[j] : 0.f;
+                    if constexpr (ACT) { aa = cfd_gelu(aa); bb = cfd_gelu(bb); }  // gelu(0) = 0 keeps the zero fill
+                    e[j] = aa + bb;
+                    o[j] = aa - bb;
+                }
+            }
+            {   // re-arm the slot with k-step s+D: of this image while one remains, else of the wave's next image
+                const float* src = s + D < KXT ? x + (size_t)img * H * W : xn;
+                const int sn = (s + D) % KXT;
+                cfd_sched_fence();
+                v[s % D] = *reinterpret_cast<const float4*>(src + off_v(sn));
+                u[s % D] = *reinterpret_cast<const float4*>(src + off_u(sn));
+                cfd_sched_fence();
+            }
+            const float tc = t1c[s * 64 + lane], ts = t1s[s * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                a1c[j] = cfd_mfma16x16x4(e[j], tc, a1c[j]);
+                a1s[j] = cfd_mfma16x16x4(o[j], ts, a1s[j]);
+            }
+        }
+        f32x4 Pc = zero, Ps = zero, Qc = zero, Qs = zero;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ac = t2c[(j * 4 + r) * 64 + lane], as = t2s[(j * 4 + r) * 64 + lane];
+                Pc = cfd_mfma16x16x4(ac, a1c[j][r], Pc);
+                Ps = cfd_mfma16x16x4(as, a1c[j][r], Ps);
+                Qc = cfd_mfma16x16x4(ac, a1s[j][r], Qc);
+                Qs = cfd_mfma16x16x4(as, a1s[j][r], Qs);
+            }
+        }
+        float2* o = xh + (size_t)img * M;
+        const int kap = n;
+        if (kap <= m1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int l = 4 * q + r;
+                if (l < m2) {
+                    if (kap < m1) o[kap * m2 + l] = make_float2(Pc[r] - Qs[r], -(Ps[r] + Qc[r]));
+                    if (kap >= 1) o[(2 * m1 - kap) * m2 + l] = make_float2(Pc[r] + Qs[r], Qc[r] - Ps[r]);
+                }
+            }
+        }
+        img = nxt;
+    }
+}
+
 template <int NJ, bool VEC4>
 static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, int act, hipStream_t st) {
+    CFD_PROF(act ? "k_dft_fwd_act" : "k_dft_fwd", st);
+    if constexpr (VEC4) {
+        if (p->W == 64 && p->KX == 9 && p->H == 64) {
+            int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
+            static const int bpc = getenv("CFD_DFT_BPC") ? atoi(getenv("CFD_DFT_BPC")) : 3;  // dev knob
+            static const int dd = getenv("CFD_DFT_D") ? atoi(getenv("CFD_DFT_D")) : 3;        // dev knob
+            if (blocks > bpc * 256) blocks = bpc * 256;  // workgroups stay resident; waves stride over the images
+#define CFD_DFT64(D_, A_)                                                                                          \
+    hipLaunchKernelGGL((k_dft_fwd64<9, D_, A_>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,       \
+                       (const float*)p->d_fwd, p->n_fwd, nimg, p->H, p->m1, p->m2)
+            if (dd == 9) { if (act) CFD_DFT64(9, true); else CFD_DFT64(9, false); }
+            else { if (act) CFD_DFT64(3, true); else CFD_DFT64(3, false); }
+#undef CFD_DFT64
+            CFD_LAUNCH_CHECK("cfd_spectral_dft");
+            return CFD_OK;
+        }
+    }
     int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
     if (blocks > 2048) blocks = 2048;
-    CFD_PROF(act ? "k_dft_fwd_act" : "k_dft_fwd", st);
     if (act)
         hipLaunchKernelGGL((k_dft_fwd<NJ, VEC4, true>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
                            (const float*)p->d_fwd, p->n_fwd, nimg, p->H, p->W, p->m1, p->m2, p->KX);
@@ -134,88 +257,259 @@ extern "C" int cfd_spectral_dft(const cfd_plan* p, const float* x, float* xh, in
 }
 
 // ------------------------------------------------------------------------------------------------------
-// mode mixing  (compl_mul2d, fno2d.py:54-57) and its input-adjoint
+// mode mixing  (compl_mul2d, fno2d.py:54-57), its input-adjoint, and the spectral weight gradient
 // ------------------------------------------------------------------------------------------------------
-// One thread owns BB batch entries of one (output channel, mode): the weight is loaded once per BB complex MACs.
-template <int BB, bool CONJT>
-__global__ __launch_bounds__(256) void k_mix(const float2* __restrict__ xin, const float2* __restrict__ w1,
-                                             const float2* __restrict__ w2, float2* __restrict__ z, int B, int Cr,
-                                             int Cz, int CoutW, int m1, int m2) {
-    const int M = 2 * m1 * m2, half = m1 * m2;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nbg = (B + BB - 1) / BB;
-    if (gid >= (long)nbg * Cz * M) return;
-    const int mode = (int)(gid % M);
-    const int cz = (int)((gid / M) % Cz);
-    const int b0 = (int)(gid / ((long)M * Cz)) * BB;
-    const float2* w = mode < half ? w1 : w2;
-    const int wm = mode < half ? mode : mode - half;
-    float2 acc[BB];
+// All three are 288 independent tiny complex GEMMs over (batch, channel).  Layout: a lane owns one kept mode (the
+// fastest-varying index of every operand, so every global access of a wave is one contiguous 512-B run), a wave
+// owns one channel of the NON-contracted side and keeps its CR complex weights (mix) or CR complex accumulators
+// (weight gradient) in registers for a whole chunk of the batch.  The contracted-side modes of SB batch entries
+// are staged once per workgroup in LDS (double buffered, next stage prefetched into registers during the math).
+#define CFD_WGRAD_SB 4       // batch entries per LDS stage of the weight-gradient kernel
+#define CFD_WGRAD_BCHUNK 16  // batch entries per workgroup (weight gradient) == partial-sum chunk
+
+// Moves `nsb` batch entries x CR channels x 64 modes between global memory, registers and LDS xs[sb][cr][lane].
+template <int CR, int WPB, int SB, bool EXACT>
+struct MixStage {
+    static constexpr int RPW = (SB * CR + WPB - 1) / WPB;  // rows (sb, cr) each wave moves per stage
+    float2 r[RPW];
+    // Row (sb, cr) of a stage is row b0*Cr + sb*Cr + cr of the (B*Cr, M) matrix xin: consecutive rows, no division.
+    // Loads are unconditional: rows past the end of the batch chunk are clamped to its last row (never committed or
+    // never stored), `modec` is the lane's mode clamped to M-1 (lanes past M never store).
+    __device__ __forceinline__ void fetch(const float2* __restrict__ xin, int bend, int Cr, int M, int b0, int modec,
+                                          int wave) {
+        const int nsb = bend - b0 < SB ? bend - b0 : SB;
+        const int last = nsb * Cr - 1;
+        const unsigned base = (unsigned)b0 * Cr;
 #pragma unroll
-    for (int k = 0; k < BB; ++k) acc[k] = make_float2(0.f, 0.f);
-    for (int cr = 0; cr < Cr; ++cr) {
-        // weights are (Cin_w, Cout_w, m1, m2): forward reduces over Cin_w (= cr), adjoint over Cout_w (= cr)
-        const float2 wv = CONJT ? w[((size_t)cz * CoutW + cr) * half + wm] : w[((size_t)cr * CoutW + cz) * half + wm];
-        const float wr = wv.x, wi = CONJT ? -wv.y : wv.y;
+        for (int k = 0; k < RPW; ++k) {
+            const int row = wave + k * WPB;
+            r[k] = xin[(size_t)((base + (row < last ? row : last)) * (unsigned)M + modec)];
+        }
+    }
+    __device__ __forceinline__ void commit(float2* xs, int bend, int Cr, int b0, int lane, int wave) const {
+        const int nsb = bend - b0 < SB ? bend - b0 : SB;
 #pragma unroll
-        for (int k = 0; k < BB; ++k) {
-            if (b0 + k < B) {
-                const float2 xv = xin[((size_t)(b0 + k) * Cr + cr) * M + mode];
-                acc[k].x = fmaf(xv.x, wr, fmaf(-xv.y, wi, acc[k].x));
-                acc[k].y = fmaf(xv.x, wi, fmaf(xv.y, wr, acc[k].y));
+        for (int k = 0; k < RPW; ++k) {
+            const int row = wave + k * WPB;
+            if (row < nsb * Cr) {
+                if constexpr (EXACT) xs[row * 64 + lane] = r[k];
+                else { const int sb = row / Cr; xs[(sb * CR + row - sb * Cr) * 64 + lane] = r[k]; }
             }
         }
     }
+};
+
+// One round of workgroups: each takes a mode group x a group of WPB output channels x a contiguous range of BR batch
+// entries, keeps its weights in registers and streams the range through LDS in stages of SB entries (double
+// buffered; the next stage's global reads are issued before the current stage's FMAs).
+#define CFD_MIX_SB 4
+template <int CR, int WPB, bool CONJT, bool EXACT>
+__global__ __launch_bounds__(64 * WPB) void k_mix(const float2* __restrict__ xin, const float2* __restrict__ w1,
+                                                  const float2* __restrict__ w2, float2* __restrict__ z, int B, int BR,
+                                                  int Cr_, int Cz, int CoutW, int m1, int m2) {
+    constexpr int SB = CFD_MIX_SB;
+    const int Cr = EXACT ? CR : Cr_;  // EXACT: the contracted channel count equals CR (index math folds)
+    __shared__ float2 s_x[2 * SB * CR * 64];
+    const int M = 2 * m1 * m2, half = m1 * m2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mode = blockIdx.x * 64 + lane;
+    const bool mvalid = mode < M;
+    const int modec = mvalid ? mode : M - 1;
+    const int cz = blockIdx.y * WPB + wave;
+    const bool czvalid = cz < Cz;
+    const int bbeg = blockIdx.z * BR;
+    const int bend = bbeg + BR < B ? bbeg + BR : B;
+    if (bbeg >= bend) return;
+    MixStage<CR, WPB, SB, EXACT> stg;
+    stg.fetch(xin, bend, Cr, M, bbeg, modec, wave);
+    // this wave's weights: forward reduces over Cin_w (= cr), the adjoint over Cout_w (= cr) with conj(W).
+    // Unconditional loads (clamped indices): padding channels meet zeros in LDS, dead lanes / waves never store.
+    float2 wreg[CR];
+    {
+        const float2* w = modec < half ? w1 : w2;
+        const unsigned wm = modec < half ? modec : modec - half;
+        const unsigned czc = czvalid ? cz : Cz - 1;
 #pragma unroll
-    for (int k = 0; k < BB; ++k)
-        if (b0 + k < B) z[((size_t)(b0 + k) * Cz + cz) * M + mode] = acc[k];
+        for (int cr = 0; cr < CR; ++cr) {
+            const unsigned crc = cr < Cr ? cr : Cr - 1;
+            float2 v = CONJT ? w[(size_t)((czc * CoutW + crc) * (unsigned)half + wm)]
+                             : w[(size_t)((crc * CoutW + czc) * (unsigned)half + wm)];
+            if (CONJT) v.y = -v.y;
+            wreg[cr] = v;
+        }
+    }
+    if (!EXACT) {  // padding channels must read as zeros
+        for (int i = threadIdx.x; i < 2 * SB * CR * 64; i += blockDim.x) s_x[i] = make_float2(0.f, 0.f);
+        __syncthreads();
+    }
+    stg.commit(s_x, bend, Cr, bbeg, lane, wave);
+    __syncthreads();
+    int buf = 0;
+    for (int b0 = bbeg; b0 < bend; b0 += SB) {
+        const bool more = b0 + SB < bend;
+        if (more) stg.fetch(xin, bend, Cr, M, b0 + SB, modec, wave);
+        const float2* xs = s_x + buf * (SB * CR * 64);
+#pragma unroll 1
+        for (int sb = 0; sb < SB; ++sb) {  // rolled: one batch entry's LDS reads live at a time
+            const int base = sb * CR * 64 + lane;
+            float ar = 0.f, ai = 0.f;
+#pragma unroll
+            for (int cr = 0; cr < CR; ++cr) {
+                const float2 xv = xs[base + cr * 64];
+                ar = fmaf(xv.x, wreg[cr].x, fmaf(-xv.y, wreg[cr].y, ar));
+                ai = fmaf(xv.x, wreg[cr].y, fmaf(xv.y, wreg[cr].x, ai));
+            }
+            const int b = b0 + sb;
+            if (b < bend && czvalid && mvalid) z[((size_t)b * Cz + cz) * M + mode] = make_float2(ar, ai);
+        }
+        if (more) stg.commit(s_x + (buf ^ 1) * (SB * CR * 64), bend, Cr, b0 + SB, lane, wave);
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+template <int CR, int WPB, bool CONJT>
+static void launch_mix(const float2* xin, const float2* w1, const float2* w2, float2* z, int B, int Cr, int Cz,
+                       int CoutW, int m1, int m2, hipStream_t st) {
+    const int M = 2 * m1 * m2;
+    const int gx = (M + 63) / 64, gy = (Cz + WPB - 1) / WPB;
+    int nz = 256 / (gx * gy);  // about one workgroup per CU
+    if (nz < 1) nz = 1;
+    int BR = (B + nz - 1) / nz;
+    BR = (BR + CFD_MIX_SB - 1) / CFD_MIX_SB * CFD_MIX_SB;
+    dim3 grid(gx, gy, (B + BR - 1) / BR);
+    if (Cr == CR)
+        hipLaunchKernelGGL((k_mix<CR, WPB, CONJT, true>), grid, dim3(64 * WPB), 0, st, xin, w1, w2, z, B, BR, Cr, Cz,
+                           CoutW, m1, m2);
+    else
+        hipLaunchKernelGGL((k_mix<CR, WPB, CONJT, false>), grid, dim3(64 * WPB), 0, st, xin, w1, w2, z, B, BR, Cr, Cz,
+                           CoutW, m1, m2);
+}
+
+static int cfd_mix_cfg() {
+    static const int v = getenv("CFD_MIX_CFG") ? atoi(getenv("CFD_MIX_CFG")) : 0;  // dev knob
+    return v;
+}
+
+// (CR, WPB) instantiations: CR >= contracted channels, WPB waves = non-contracted channels per workgroup.
+#define CFD_MIX_DISPATCH(FN, Cr_, Cz_, ...)                                        \
+    do {                                                                            \
+        if ((Cr_) <= 8) FN<8, 8>(__VA_ARGS__);                                      \
+        else if ((Cr_) <= 20 && (Cz_) % 10 == 0 && cfd_mix_cfg() == 0) FN<20, 10>(__VA_ARGS__); \
+        else if ((Cr_) <= 20 && (Cz_) % 5 == 0) FN<20, 5>(__VA_ARGS__);             \
+        else if ((Cr_) <= 16) FN<16, 8>(__VA_ARGS__);                               \
+        else if ((Cr_) <= 24) FN<24, 8>(__VA_ARGS__);                               \
+        else FN<32, 8>(__VA_ARGS__);                                                \
+    } while (0)
+
+template <int CR, int WPB>
+static void launch_mix_fwd(const float2* a, const float2* b, const float2* c, float2* d, int B, int Cr, int Cz, int CoutW,
+                           int m1, int m2, hipStream_t st) {
+    launch_mix<CR, WPB, false>(a, b, c, d, B, Cr, Cz, CoutW, m1, m2, st);
+}
+template <int CR, int WPB>
+static void launch_mix_adj(const float2* a, const float2* b, const float2* c, float2* d, int B, int Cr, int Cz, int CoutW,
+                           int m1, int m2, hipStream_t st) {
+    launch_mix<CR, WPB, true>(a, b, c, d, B, Cr, Cz, CoutW, m1, m2, st);
 }
 
 extern "C" int cfd_spectral_mix(const cfd_plan* p, const float* xh, const float* w1, const float* w2, float* z, int B,
                                 int Cin, int Cout, int conj_t, void* stream) {
     CFD_REQUIRE(p && xh && w1 && w2 && z, CFD_ERR_INVALID_ARG, "cfd_spectral_mix: NULL pointer");
     CFD_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1, CFD_ERR_INVALID_ARG, "cfd_spectral_mix: bad sizes");
+    CFD_REQUIRE(Cin <= 32 && Cout <= 32, CFD_ERR_UNSUPPORTED, "cfd_spectral_mix: Cin=%d Cout=%d (max 32) unsupported", Cin, Cout);
     if (B == 0) return CFD_OK;
-    const int M = 2 * p->m1 * p->m2;
-    constexpr int BB = 4;
     const int Cr = conj_t ? Cout : Cin, Cz = conj_t ? Cin : Cout;
-    const long total = (long)((B + BB - 1) / BB) * Cz * M;
-    const int blocks = (int)((total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
     CFD_PROF(conj_t ? "k_mix_adj" : "k_mix", st);
     if (conj_t)
-        hipLaunchKernelGGL((k_mix<BB, true>), dim3(blocks), dim3(256), 0, st, (const float2*)xh, (const float2*)w1,
-                           (const float2*)w2, (float2*)z, B, Cr, Cz, Cout, p->m1, p->m2);
+        CFD_MIX_DISPATCH(launch_mix_adj, Cr, Cz, (const float2*)xh, (const float2*)w1, (const float2*)w2, (float2*)z, B, Cr,
+                         Cz, Cout, p->m1, p->m2, st);
     else
-        hipLaunchKernelGGL((k_mix<BB, false>), dim3(blocks), dim3(256), 0, st, (const float2*)xh, (const float2*)w1,
-                           (const float2*)w2, (float2*)z, B, Cr, Cz, Cout, p->m1, p->m2);
+        CFD_MIX_DISPATCH(launch_mix_fwd, Cr, Cz, (const float2*)xh, (const float2*)w1, (const float2*)w2, (float2*)z, B, Cr,
+                         Cz, Cout, p->m1, p->m2, st);
     CFD_LAUNCH_CHECK("cfd_spectral_mix");
     return CFD_OK;
 }
 
-// ------------------------------------------------------------------------------------------------------
 // spectral weight gradient: gw[i,o,mode] = sum_b conj(xh[b,i,mode]) * (c_l/HW) * gh[b,o,mode]
-// ------------------------------------------------------------------------------------------------------
-#define CFD_WGRAD_BCHUNK 32
-
-__global__ __launch_bounds__(256) void k_spec_wgrad_part(const float2* __restrict__ xh, const float2* __restrict__ gh,
-                                                         float2* __restrict__ part, int B, int Cin, int Cout, int M) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long)Cin * Cout * M) return;
-    const int mode = (int)(gid % M);
-    const int o = (int)((gid / M) % Cout);
-    const int i = (int)(gid / ((long)M * Cout));
-    const int b0 = blockIdx.y * CFD_WGRAD_BCHUNK;
-    const int b1 = (b0 + CFD_WGRAD_BCHUNK < B) ? b0 + CFD_WGRAD_BCHUNK : B;
-    float ar = 0.f, ai = 0.f;
-    for (int b = b0; b < b1; ++b) {
-        const float2 xv = xh[((size_t)b * Cin + i) * M + mode];
-        const float2 gv = gh[((size_t)b * Cout + o) * M + mode];
-        // conj(x) * g
-        ar = fmaf(xv.x, gv.x, fmaf(xv.y, gv.y, ar));
-        ai = fmaf(xv.x, gv.y, fmaf(-xv.y, gv.x, ai));
+// wave = output channel o, accumulators over i in registers; one partial sum per CFD_WGRAD_BCHUNK batch entries,
+// reduced in a fixed order by k_spec_wgrad_reduce (deterministic).
+template <int CR, int WPB, bool EXACT>
+__global__ __launch_bounds__(64 * WPB) void k_spec_wgrad_part(const float2* __restrict__ xh, const float2* __restrict__ gh,
+                                                              float2* __restrict__ part, int B, int Cin_, int Cout,
+                                                              int M) {
+    const int Cin = EXACT ? CR : Cin_;
+    __shared__ float2 s_x[2 * CFD_WGRAD_SB * CR * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mode = blockIdx.x * 64 + lane;
+    const bool mvalid = mode < M;
+    const int o = blockIdx.y * WPB + wave;
+    const bool ovalid = o < Cout;
+    const int bbeg = blockIdx.z * CFD_WGRAD_BCHUNK;
+    const int bend = bbeg + CFD_WGRAD_BCHUNK < B ? bbeg + CFD_WGRAD_BCHUNK : B;
+    for (int i = threadIdx.x; i < 2 * CFD_WGRAD_SB * CR * 64; i += blockDim.x) s_x[i] = make_float2(0.f, 0.f);
+    float2 acc[CR];
+#pragma unroll
+    for (int i = 0; i < CR; ++i) acc[i] = make_float2(0.f, 0.f);
+    auto gload = [&](int b0, float2 (&g)[CFD_WGRAD_SB]) {
+#pragma unroll
+        for (int sb = 0; sb < CFD_WGRAD_SB; ++sb)
+            g[sb] = (b0 + sb < bend && ovalid && mvalid) ? gh[((size_t)(b0 + sb) * Cout + o) * M + mode]
+                                                         : make_float2(0.f, 0.f);
+    };
+    MixStage<CR, WPB, CFD_WGRAD_SB, EXACT> stg;
+    float2 gcur[CFD_WGRAD_SB], gnxt[CFD_WGRAD_SB];
+    const int modec = mvalid ? mode : M - 1;
+    stg.fetch(xh, bend, Cin, M, bbeg, modec, wave);
+    gload(bbeg, gcur);
+    __syncthreads();
+    stg.commit(s_x, bend, Cin, bbeg, lane, wave);
+    __syncthreads();
+    int buf = 0;
+    for (int b0 = bbeg; b0 < bend; b0 += CFD_WGRAD_SB) {
+        const bool more = b0 + CFD_WGRAD_SB < bend;
+        if (more) {
+            stg.fetch(xh, bend, Cin, M, b0 + CFD_WGRAD_SB, modec, wave);
+            gload(b0 + CFD_WGRAD_SB, gnxt);
+        }
+        const float2* xs = s_x + buf * (CFD_WGRAD_SB * CR * 64);
+#pragma unroll 1
+        for (int sb = 0; sb < CFD_WGRAD_SB; ++sb) {  // rolled: one batch entry's LDS reads live at a time
+            const float2 gv = gcur[0];
+            const int base = sb * CR * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < CR; ++i) {
+                const float2 xv = xs[base + i * 64];
+                // conj(x) * g
+                acc[i].x = fmaf(xv.x, gv.x, fmaf(xv.y, gv.y, acc[i].x));
+                acc[i].y = fmaf(xv.x, gv.y, fmaf(-xv.y, gv.x, acc[i].y));
+            }
+#pragma unroll
+            for (int k = 0; k + 1 < CFD_WGRAD_SB; ++k) gcur[k] = gcur[k + 1];
+        }
+        if (more) {
+            stg.commit(s_x + (buf ^ 1) * (CFD_WGRAD_SB * CR * 64), bend, Cin, b0 + CFD_WGRAD_SB, lane, wave);
+#pragma unroll
+            for (int sb = 0; sb < CFD_WGRAD_SB; ++sb) gcur[sb] = gnxt[sb];
+        }
+        __syncthreads();
+        buf ^= 1;
     }
-    part[(size_t)blockIdx.y * Cin * Cout * M + gid] = make_float2(ar, ai);
+    if (ovalid && mvalid) {
+        float2* dst = part + (size_t)blockIdx.z * Cin * Cout * M;
+#pragma unroll
+        for (int i = 0; i < CR; ++i)
+            if (i < Cin) dst[((size_t)i * Cout + o) * M + mode] = acc[i];
+    }
+}
+
+template <int CR, int WPB>
+static void launch_spec_wgrad(const float2* xh, const float2* gh, float2* part, int B, int Cin, int Cout, int M,
+                              hipStream_t st) {
+    dim3 grid((M + 63) / 64, (Cout + WPB - 1) / WPB, (B + CFD_WGRAD_BCHUNK - 1) / CFD_WGRAD_BCHUNK);
+    if (Cin == CR) hipLaunchKernelGGL((k_spec_wgrad_part<CR, WPB, true>), grid, dim3(64 * WPB), 0, st, xh, gh, part, B, Cin, Cout, M);
+    else hipLaunchKernelGGL((k_spec_wgrad_part<CR, WPB, false>), grid, dim3(64 * WPB), 0, st, xh, gh, part, B, Cin, Cout, M);
 }
 
 __global__ __launch_bounds__(256) void k_spec_wgrad_reduce(const float2* __restrict__ part, float2* __restrict__ gw1,
@@ -248,14 +542,14 @@ extern "C" int cfd_spectral_wgrad(const cfd_plan* p, const float* xh, const floa
                                   int B, int Cin, int Cout, void* stream) {
     CFD_REQUIRE(p && xh && gh && gw1 && gw2 && ws, CFD_ERR_INVALID_ARG, "cfd_spectral_wgrad: NULL pointer");
     CFD_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1, CFD_ERR_INVALID_ARG, "cfd_spectral_wgrad: bad sizes");
+    CFD_REQUIRE(Cin <= 32 && Cout <= 32, CFD_ERR_UNSUPPORTED, "cfd_spectral_wgrad: Cin=%d Cout=%d (max 32) unsupported", Cin, Cout);
     const int M = 2 * p->m1 * p->m2;
     const int nchunk = (B + CFD_WGRAD_BCHUNK - 1) / CFD_WGRAD_BCHUNK;
     const long total = (long)Cin * Cout * M;
     hipStream_t st = (hipStream_t)stream;
     {
         CFD_PROF("k_spec_wgrad_part", st);
-        hipLaunchKernelGGL(k_spec_wgrad_part, dim3((unsigned)((total + 255) / 256), nchunk), dim3(256), 0, st,
-                           (const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M);
+        CFD_MIX_DISPATCH(launch_spec_wgrad, Cin, Cout, (const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M, st);
     }
     CFD_LAUNCH_CHECK("cfd_spectral_wgrad(part)");
     CFD_PROF("k_spec_wgrad_reduce", st);
@@ -269,110 +563,141 @@ extern "C" int cfd_spectral_wgrad(const cfd_plan* p, const float* xh, const floa
 // ------------------------------------------------------------------------------------------------------
 // inverse pruned DFT (+ fused epilogue)
 // ------------------------------------------------------------------------------------------------------
-template <int NJ, bool VEC4, int EPI>
-__global__ __launch_bounds__(64 * CFD_WAVES) void k_idft(const float* __restrict__ z, const float* addend,
-                                                          const float* __restrict__ aprev, float* out,
-                                                          const float* __restrict__ tabs, int ntab, int nimg, int H,
-                                                          int W, int m1, int m2, int T, int SA, int SB) {
-    __shared__ float s_tab[(8 * 8 + 8 * NJ) * 64];  // T<=8, SA<=8, SB<=8
-    for (int i = threadIdx.x; i < ntab; i += blockDim.x) s_tab[i] = tabs[i];
-    __syncthreads();
-    const float* ta = s_tab;
-    const float* tb = ta + T * SA * 64;
+// Kept modes of one image: global (2*M floats, interleaved re/im) -> this wave's LDS slice zs[0 .. 2*M], plus one
+// zero word at zs[2*M] that every masked-out gather index points at (so the gather below is branch-free).
+__device__ __forceinline__ void idft_stage_z(const float* __restrict__ zi, float* zs, int M2, int lane) {
+    for (int i = lane; i < M2; i += 64) zs[i] = zi[i];
+    if (lane == 0) zs[M2] = 0.f;
+    cfd_wave_lds_sync();
+}
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = lane >> 4, n = lane & 15;
-    const int M = 2 * m1 * m2;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-
-    // Stage-A data operand gather map (lane = (q, rho)): row rho of M-tile mu is c = 4*(4*mu + (rho&3)) + (rho>>2)
-    // so that accumulator register r of tile mu is exactly the stage-B operand of k-step 4*mu + r.
-    // k-steps s < 4 are the cos block (kappa = 4s+q, value S = Z+ + Z-); s >= 4 the sin block (kappa = 4s+q-15,
-    // value -D_im for a real-part row, +D_re for an imaginary-part row, D = Z+ - Z-).
-    int offP[2][8], offM[2][8];
-    float sg[2];
+// Stage-A data operands (lane = (q, rho)): row rho of M-tile mu is c = 4*(4*mu + (rho&3)) + (rho>>2) so that
+// accumulator register r of tile mu is exactly the stage-B operand of k-step 4*mu + r.  k-steps s < 4 are the cos
+// block (kappa = 4s+q, value S = Z+ + Z-); s >= 4 the sin block (kappa = 4s+q-15, value -D_im for a real-part row,
+// +D_re for an imaginary-part row, D = Z+ - Z-).
+__device__ __forceinline__ void idft_gather(const float* zs, int m1, int m2, int SA, int q, int n, float (&va)[2][8]) {
+    const int zero_slot = 4 * m1 * m2;
 #pragma unroll
     for (int mu = 0; mu < 2; ++mu) {
         const int c = 4 * (4 * mu + (n & 3)) + (n >> 2);
         const bool cvalid = c < 2 * m2;
         const int part = c >= m2 ? 1 : 0;
         const int l = c - part * m2;
-        sg[mu] = part ? 1.f : -1.f;
+        const float sg = part ? 1.f : -1.f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int kap = s < 4 ? 4 * s + q : 4 * s + q - 15;
             const bool kvalid = (s < SA) && kap <= m1 && cvalid;
             const int comp = s < 4 ? part : 1 - part;
-            offP[mu][s] = (kvalid && kap < m1) ? (kap * m2 + l) * 2 + comp : -1;
-            offM[mu][s] = (kvalid && kap >= 1) ? ((2 * m1 - kap) * m2 + l) * 2 + comp : -1;
+            const int offP = (kvalid && kap < m1) ? (kap * m2 + l) * 2 + comp : zero_slot;
+            const int offM = (kvalid && kap >= 1) ? ((2 * m1 - kap) * m2 + l) * 2 + comp : zero_slot;
+            const float vp = zs[offP], vm = zs[offM];
+            va[mu][s] = s < 4 ? vp + vm : sg * (vp - vm);
         }
     }
+}
 
-    for (int img = blockIdx.x * CFD_WAVES + wave; img < nimg; img += gridDim.x * CFD_WAVES) {
-        const float* zi = z + (size_t)img * M * 2;
-        float va[2][8];
+// One 16-row x tile: stage A (U' = sum over kept rows) chained into stage B (sum over kept columns).
+// accB[j][r]: x = 16t + 4q + r, y = NJ*n + j.
+template <int NJ>
+__device__ __forceinline__ void idft_tile(const float (&va)[2][8], const float* ta, const float* tb, int t, int SA, int SB,
+                                          int lane, f32x4 (&accB)[NJ]) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 accA[2] = {zero, zero};
 #pragma unroll
-        for (int mu = 0; mu < 2; ++mu) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const float vp = offP[mu][s] >= 0 ? zi[offP[mu][s]] : 0.f;
-                const float vm = offM[mu][s] >= 0 ? zi[offM[mu][s]] : 0.f;
-                va[mu][s] = s < 4 ? vp + vm : sg[mu] * (vp - vm);
-            }
+    for (int s = 0; s < 8; ++s) {
+        if (s < SA) {
+            const float tv = ta[(t * SA + s) * 64 + lane];
+            accA[0] = cfd_mfma16x16x4(va[0][s], tv, accA[0]);
+            accA[1] = cfd_mfma16x16x4(va[1][s], tv, accA[1]);
         }
-        const size_t ibase = (size_t)img * H * W;
-        for (int t = 0; t < T; ++t) {
-            f32x4 accA[2] = {zero, zero};
+    }
+    // accA[mu][r] (lane = (q,i)): U'[x = 16t+i][c = 4*(4mu+r)+q]  == stage-B A operand of k-step 4mu+r
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (s < SA) {
-                    const float tv = ta[(t * SA + s) * 64 + lane];
-                    accA[0] = cfd_mfma16x16x4(va[0][s], tv, accA[0]);
-                    accA[1] = cfd_mfma16x16x4(va[1][s], tv, accA[1]);
-                }
+    for (int sp = 0; sp < 8; ++sp) {
+        if (sp < SB) {
+            const float av = accA[sp >> 2][sp & 3];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x4(av, tb[(sp * NJ + j) * 64 + lane], accB[j]);
+        }
+    }
+}
+
+#define CFD_IDFT_ZMAX (4 * 15 * 16 + 1)  // 2*M floats (m1 <= 15, m2 <= 16) + the zero slot
+
+template <int NJ, bool VEC4, int EPI>
+__global__ __launch_bounds__(64 * CFD_WAVES) void k_idft(const float* __restrict__ z, const float* addend,
+                                                          const float* __restrict__ aprev, float* out,
+                                                          const float* __restrict__ tabs, int ntab, int nimg, int H,
+                                                          int W, int m1, int m2, int T, int SA, int SB) {
+    __shared__ float s_tab[(8 * 8 + 8 * NJ) * 64];  // T<=8, SA<=8, SB<=8
+    __shared__ float s_z[CFD_WAVES * CFD_IDFT_ZMAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int img = blockIdx.x * CFD_WAVES + wave;
+    const bool live = img < nimg;
+    const int M2 = 4 * m1 * m2;
+    float* zs = s_z + wave * CFD_IDFT_ZMAX;
+    if (live) idft_stage_z(z + (size_t)img * M2, zs, M2, lane);
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) s_tab[i] = tabs[i];
+    __syncthreads();
+    if (!live) return;
+    const float* ta = s_tab;
+    const float* tb = ta + T * SA * 64;
+    float va[2][8];
+    idft_gather(zs, m1, m2, SA, q, n, va);
+    const size_t ibase = (size_t)img * H * W;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (VEC4) {
+        // W % 4 == 0 and 16-B aligned rows: whole-float4 epilogue; the tile's addend / aprev rows are requested
+        // before the tile's MFMA work so their latency hides behind it.
+        const bool cok = 4 * n < W;
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            float4 ad[4], ap[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int xx = 16 * t + 4 * q + r;
+                const size_t off = ibase + (size_t)(xx < H ? xx : 0) * W + (cok ? 4 * n : 0);
+                if constexpr (EPI >= 1) ad[r] = *reinterpret_cast<const float4*>(addend + off);
+                if constexpr (EPI == 2) ap[r] = *reinterpret_cast<const float4*>(aprev + off);
             }
-            // accA[mu][r] (lane = (q,i)): U'[x = 16t+i][c = 4*(4mu+r)+q]  == stage-B A operand of k-step 4mu+r
             f32x4 accB[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) accB[j] = zero;
+            idft_tile<NJ>(va, ta, tb, t, SA, SB, cfd_opaque(lane), accB);
 #pragma unroll
-            for (int sp = 0; sp < 8; ++sp) {
-                if (sp < SB) {
-                    const float av = accA[sp >> 2][sp & 3];
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x4(av, tb[(sp * NJ + j) * 64 + lane], accB[j]);
+            for (int r = 0; r < 4; ++r) {
+                const int xx = 16 * t + 4 * q + r;
+                float4 v = make_float4(accB[0][r], accB[1][r], accB[2][r], accB[3][r]);
+                if constexpr (EPI >= 1) { v.x += ad[r].x; v.y += ad[r].y; v.z += ad[r].z; v.w += ad[r].w; }
+                if constexpr (EPI == 2) {
+                    v.x *= cfd_gelu_grad(ap[r].x); v.y *= cfd_gelu_grad(ap[r].y);
+                    v.z *= cfd_gelu_grad(ap[r].z); v.w *= cfd_gelu_grad(ap[r].w);
                 }
+                if (xx < H && cok) *reinterpret_cast<float4*>(out + ibase + (size_t)xx * W + 4 * n) = v;
             }
-            // accB[j][r]: x = 16t + 4q + r, y = NJ*n + j
+        }
+    } else {
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            f32x4 accB[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) accB[j] = zero;
+            idft_tile<NJ>(va, ta, tb, t, SA, SB, cfd_opaque(lane), accB);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int xx = 16 * t + 4 * q + r;
                 if (xx < H) {
                     const size_t rbase = ibase + (size_t)xx * W;
-                    if constexpr (VEC4) {
-                        if (4 * n < W) {
-                            float4 v = make_float4(accB[0][r], accB[1][r], accB[2][r], accB[3][r]);
-                            if constexpr (EPI >= 1) {
-                                const float4 ad = *reinterpret_cast<const float4*>(addend + rbase + 4 * n);
-                                v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
-                            }
-                            if constexpr (EPI == 2) {
-                                const float4 ap = *reinterpret_cast<const float4*>(aprev + rbase + 4 * n);
-                                v.x *= cfd_gelu_grad(ap.x); v.y *= cfd_gelu_grad(ap.y);
-                                v.z *= cfd_gelu_grad(ap.z); v.w *= cfd_gelu_grad(ap.w);
-                            }
-                            *reinterpret_cast<float4*>(out + rbase + 4 * n) = v;
-                        }
-                    } else {
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) {
-                            const int y = NJ * n + j;
-                            if (y < W) {
-                                float v = accB[j][r];
-                                if constexpr (EPI >= 1) v += addend[rbase + y];
-                                if constexpr (EPI == 2) v *= cfd_gelu_grad(aprev[rbase + y]);
-                                out[rbase + y] = v;
-                            }
+                    for (int j = 0; j < NJ; ++j) {
+                        const int y = NJ * n + j;
+                        if (y < W) {
+                            float v = accB[j][r];
+                            if constexpr (EPI >= 1) v += addend[rbase + y];
+                            if constexpr (EPI == 2) v *= cfd_gelu_grad(aprev[rbase + y]);
+                            out[rbase + y] = v;
                         }
                     }
                 }
@@ -384,8 +709,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES) void k_idft(const float* __restrict
 template <int NJ, bool VEC4>
 static int launch_idft(const cfd_plan* p, const float* z, const float* addend, const float* aprev, float* out,
                        int nimg, int epi, hipStream_t st) {
-    int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
-    if (blocks > 2048) blocks = 2048;
+    const int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
 #define CFD_IDFT_LAUNCH(E)                                                                                         \
     hipLaunchKernelGGL((k_idft<NJ, VEC4, E>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, z, addend, aprev, out,     \
                        (const float*)p->d_inv, p->n_inv, nimg, p->H, p->W, p->m1, p->m2, p->T, p->SA, p->SB)
@@ -455,5 +779,277 @@ extern "C" int cfd_spectral_conv2d_bwd(const cfd_plan* p, const float* gy, const
         CFD_TRY(cfd_spectral_mix(p, gh, w1, w2, gz, B, Cin, Cout, 1, stream));
         CFD_TRY(cfd_spectral_idft(p, gz, nullptr, nullptr, gx, B * Cin, 0, stream));
     }
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Fused FnoBlock body (fno2d.py:106-112 and its input-gradient): 1x1 conv + inverse pruned DFT (+ epilogue)
+// ------------------------------------------------------------------------------------------------------
+//   dst[b,d,x,y] = epi( bias[d] + sum_s wsel(d,s) f(src[b,s,x,y]) + idft(z[b,d])[x,y] )
+// forward : src = a_l, f = GELU for l > 0, wsel(d,s) = w0[d,s], dst = a_{l+1} (pre-activation)
+// backward: src = dL/da_{l+1}, f = id, wsel(d,s) = w0[s,d], epi = * gelu'(a_l[b,d,x,y]), dst = dL/da_l
+// so one activation-sized read and one write replace the chanmix -> idft_add round trip (5N -> 3N per layer forward,
+// 8N -> 6N backward).  Workgroup = one batch entry, all channels, its 16-row tiles one after another.  Each source tile streams through
+// LDS in NCH chunks of NW channels (wave w fetches channel w of each chunk, two chunks ahead in registers); wave w
+// owns destination channels w, w+NW, ... (DPW of them): their inverse transforms run on the matrix pipe while the
+// chunks are in flight, the channel mix accumulates on the VALU straight into the MFMA accumulator layout
+// (x = 16t+4q+r, y = 4n+j), and a_out leaves in whole float4 rows.  W == 64, H % 16 == 0.
+template <int V>
+struct CfdParity { static constexpr int value = V; };
+
+#define CFD_BLK_ZS 577  // floats of one staged mode vector: 2*M (m1 = m2 = 12) + the zero slot
+
+// NW waves; wave w owns destination channels w, w+NW, ... (DPW of them) and fetches channel w of each of the NCH
+// source chunks.  NW = 4 (one wave per SIMD) wherever the channel count allows.
+template <int NW, int DPW, int NCH, bool ACT, bool TRANS, bool DGELU>
+__global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src, const float* __restrict__ z,
+                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                   const float* __restrict__ aprev, float* __restrict__ dst,
+                                                   const float* __restrict__ tabs, int Cs, int Cd, int H, int m1,
+                                                   int m2, int T, int SA, int SB) {
+    constexpr int W = 64, NJ = 4;
+    constexpr int WS = DPW <= 4 ? 4 : 8;              // floats per weight-table entry
+    __shared__ float4 s_src[2 * NW * 16 * 16];        // [buf][channel in chunk][row][float4 column]
+    __shared__ float s_tab[(32 + 8 * NJ) * 64];       // ta of every tile (T*SA <= 32 steps) | tb (SB <= 8 steps x NJ)
+    __shared__ float s_z[NW * DPW * CFD_BLK_ZS];      // kept modes of this wave's destination channels
+    __shared__ float4 s_w[NW * NW * NCH * (WS / 4)];  // [wave][source channel] -> weights of the wave's DPW channels
+    static_assert(NW * NCH <= 64, "one lane per source channel fills the weight table");
+    static_assert(DPW <= 8, "weight-table entry holds at most 8 destination channels");
+    const int lane = threadIdx.x & 63;
+    const int wave = cfd_uniform(threadIdx.x >> 6);
+    const int q = lane >> 4, n = lane & 15;
+    const int b = blockIdx.x;
+    const int HW = H * W;
+    const int M2 = 4 * m1 * m2;
+    const int G = T * NCH;  // chunks of this batch entry, streamed tile after tile; chunk g lives in buffer g & 1
+    // ---- this wave's slice of a source chunk: channel ((g % NCH)*NW + wave) of tile g / NCH, rows 4k+q ----
+    float4 R[2][4];
+    auto fetch = [&](int g, float4 (&r)[4]) {
+        const int t = g / NCH, ch = (g - t * NCH) * NW + wave;
+        const float* p = src + ((size_t)b * Cs + (ch < Cs ? ch : 0)) * HW + (size_t)(16 * t + q) * W + 4 * n;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = *reinterpret_cast<const float4*>(p + (size_t)4 * k * W);
+    };
+    auto commit = [&](int c, int buf, const float4 (&r)[4]) {
+        const bool live = c * NW + wave < Cs;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 v = r[k];
+            if constexpr (ACT) { v.x = cfd_gelu(v.x); v.y = cfd_gelu(v.y); v.z = cfd_gelu(v.z); v.w = cfd_gelu(v.w); }
+            if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            s_src[((buf * NW + wave) * 16 + 4 * k + q) * 16 + n] = v;
+        }
+    };
+    fetch(0, R[0]);
+    fetch(1, R[1]);
+    // once per batch entry: operator tables, this wave's mixing weights and kept modes
+    {
+        const int nta = T * SA * 64;
+        for (int i = threadIdx.x; i < nta; i += blockDim.x) s_tab[i] = tabs[i];
+        for (int i = threadIdx.x; i < SB * NJ * 64; i += blockDim.x) s_tab[32 * 64 + i] = tabs[nta + i];
+    }
+    if (lane < NW * NCH) {
+        float wl[WS];
+#pragma unroll
+        for (int dd = 0; dd < WS; ++dd) {
+            const int d = wave + dd * NW;
+            wl[dd] = (dd < DPW && d < Cd && lane < Cs) ? (TRANS ? w[(size_t)lane * Cd + d] : w[(size_t)d * Cs + lane]) : 0.f;
+        }
+#pragma unroll
+        for (int h = 0; h < WS / 4; ++h)
+            s_w[(wave * (NW * NCH) + lane) * (WS / 4) + h] = make_float4(wl[4 * h], wl[4 * h + 1], wl[4 * h + 2], wl[4 * h + 3]);
+    }
+    float bv[DPW];
+#pragma unroll
+    for (int dd = 0; dd < DPW; ++dd) {
+        const int d = wave + dd * NW;
+        bv[dd] = (bias && d < Cd) ? bias[d] : 0.f;
+        if (d < Cd) idft_stage_z(z + ((size_t)b * Cd + d) * M2, s_z + (wave * DPW + dd) * CFD_BLK_ZS, M2, lane);
+    }
+    const float* ta = s_tab;
+    const float* tb = s_tab + 32 * 64;
+    float4 AP[2][4];  // gelu'(aprev) operands of two destination channels in flight
+    auto fetch_ap = [&](int t, int dd, float4 (&r)[4]) {
+        const int d = wave + dd * NW;
+        const float* p = aprev + ((size_t)b * Cd + (d < Cd ? d : 0)) * HW + (size_t)(16 * t + 4 * q) * W + 4 * n;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) r[r4] = *reinterpret_cast<const float4*>(p + (size_t)r4 * W);
+    };
+    // One 16-row tile.  PAR = parity of the tile's first chunk index (compile time, so the prefetch registers and
+    // LDS buffers are indexed statically even when NCH is odd).
+    auto tile = [&](auto par_c, int t) {
+        constexpr int PAR = decltype(par_c)::value;
+        f32x4 acc[DPW][NJ];
+#pragma unroll
+        for (int dd = 0; dd < DPW; ++dd)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[dd][j] = f32x4{bv[dd], bv[dd], bv[dd], bv[dd]};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int g = t * NCH + c;
+            const int par = (PAR + c) & 1;
+            commit(c, par, R[par]);
+            __syncthreads();  // chunk g visible (first pass: also tables, weights); the other buffer is free again
+            if (g + 2 < G) fetch(g + 2, R[par]);
+            if constexpr (DGELU) {
+                if (c == NCH - 2) fetch_ap(t, 0, AP[0]);
+                if (c == NCH - 1) fetch_ap(t, 1, AP[1]);
+            }
+            // inverse transform of destination channel dd = c (spread over the chunks so MFMA and VALU work interleave)
+            if (c < DPW && wave + c * NW < Cd) {
+                float va[2][8];
+                idft_gather(s_z + (wave * DPW + (c < DPW ? c : 0)) * CFD_BLK_ZS, m1, m2, SA, q, n, va);
+                idft_tile<NJ>(va, ta, tb, t, SA, SB, lane, acc[c < DPW ? c : 0]);
+            }
+            if constexpr (DPW > NCH) {  // more destination channels than chunks: the rest ride on the last chunk
+                if (c == NCH - 1) {
+#pragma unroll
+                    for (int dd = NCH; dd < DPW; ++dd) {
+                        if (wave + dd * NW < Cd) {
+                            float va[2][8];
+                            idft_gather(s_z + (wave * DPW + dd) * CFD_BLK_ZS, m1, m2, SA, q, n, va);
+                            idft_tile<NJ>(va, ta, tb, t, SA, SB, lane, acc[dd]);
+                        }
+                    }
+                }
+            }
+            // channel mix of this chunk (dead channels hold zeros in LDS and get zero weights); the LDS reads of
+            // source channel sl+1 are issued before the FMAs of channel sl
+            {
+                float4 v[2][4], wq[2][WS / 4];
+                auto lds_fetch = [&](int sl, float4 (&vv)[4], float4 (&ww)[WS / 4]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[r] = s_src[((par * NW + sl) * 16 + 4 * q + r) * 16 + n];
+#pragma unroll
+                    for (int h = 0; h < WS / 4; ++h) ww[h] = s_w[(wave * (NW * NCH) + c * NW + sl) * (WS / 4) + h];
+                };
+                lds_fetch(0, v[0], wq[0]);
+#pragma unroll 1
+                for (int sl = 0; sl < NW; ++sl) {  // rolled: registers rotate, one channel of LDS reads in flight
+                    const int sn = sl + 1 < NW ? sl + 1 : sl;
+                    lds_fetch(sn, v[1], wq[1]);
+                    float wd[WS];
+#pragma unroll
+                    for (int h = 0; h < WS / 4; ++h) {
+                        wd[4 * h] = wq[0][h].x; wd[4 * h + 1] = wq[0][h].y; wd[4 * h + 2] = wq[0][h].z; wd[4 * h + 3] = wq[0][h].w;
+                    }
+#pragma unroll
+                    for (int dd = 0; dd < DPW; ++dd) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            acc[dd][0][r] = fmaf(wd[dd], v[0][r].x, acc[dd][0][r]);
+                            acc[dd][1][r] = fmaf(wd[dd], v[0][r].y, acc[dd][1][r]);
+                            acc[dd][2][r] = fmaf(wd[dd], v[0][r].z, acc[dd][2][r]);
+                            acc[dd][3][r] = fmaf(wd[dd], v[0][r].w, acc[dd][3][r]);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[0][r] = v[1][r];
+#pragma unroll
+                    for (int h = 0; h < WS / 4; ++h) wq[0][h] = wq[1][h];
+                }
+            }
+        }
+        // ---- tile epilogue: [* gelu'(aprev)], whole-float4 row stores ----
+#pragma unroll
+        for (int dd = 0; dd < DPW; ++dd) {
+            const int d = wave + dd * NW;
+            float4 ap[4];
+            if constexpr (DGELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ap[r] = AP[dd & 1][r];
+                if (dd + 2 < DPW) fetch_ap(t, dd + 2, AP[dd & 1]);
+            }
+            if (d < Cd) {
+                float* o = dst + ((size_t)b * Cd + d) * HW + (size_t)(16 * t + 4 * q) * W + 4 * n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float4 v = make_float4(acc[dd][0][r], acc[dd][1][r], acc[dd][2][r], acc[dd][3][r]);
+                    if constexpr (DGELU) {
+                        v.x *= cfd_gelu_grad(ap[r].x); v.y *= cfd_gelu_grad(ap[r].y);
+                        v.z *= cfd_gelu_grad(ap[r].z); v.w *= cfd_gelu_grad(ap[r].w);
+                    }
+                    *reinterpret_cast<float4*>(o + (size_t)r * W) = v;
+                }
+            }
+        }
+    };
+#pragma unroll 1
+    for (int t = 0; t < T; t += 2) {
+        tile(CfdParity<0>{}, t);
+        if (t + 1 < T) {
+            if constexpr (NCH % 2 == 1) tile(CfdParity<1>{}, t + 1);
+            else tile(CfdParity<0>{}, t + 1);
+        }
+    }
+}
+
+static bool block_fused_ok(const cfd_plan* p, int Cs, int Cd, const void* a, const void* b, const void* c) {
+    const int cmax = Cs > Cd ? Cs : Cd;
+    return p->W == 64 && p->H % 16 == 0 && p->NJ == 4 && p->SA <= 8 && p->SB <= 8 && p->T * p->SA <= 32 &&
+           4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS && cmax <= 32 &&
+           ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && (!c || ((uintptr_t)c % 16) == 0);
+}
+
+template <int NW, int DPW, int NCH>
+static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z, const float* w, const float* bias,
+                             const float* aprev, float* dst, int B, int Cs, int Cd, int act, int trans, int dgelu,
+                             hipStream_t st) {
+    const dim3 grid(B), block(64 * NW);  // one workgroup per batch entry, tiles streamed inside
+#define CFD_BLK(A_, T_, D_)                                                                                     \
+    hipLaunchKernelGGL((k_block<NW, DPW, NCH, A_, T_, D_>), grid, block, 0, st, src, z, w, bias, aprev, dst,    \
+                       (const float*)p->d_inv, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB)
+    if (!trans) { if (act) CFD_BLK(true, false, false); else CFD_BLK(false, false, false); }
+    else { if (dgelu) CFD_BLK(false, true, true); else CFD_BLK(false, true, false); }
+#undef CFD_BLK
+}
+
+// (waves, destination channels per wave, source chunks): waves*DPW >= Cd and waves*NCH >= Cs
+static void launch_block(const cfd_plan* p, const float* src, const float* z, const float* w, const float* bias,
+                         const float* aprev, float* dst, int B, int Cs, int Cd, int act, int trans, int dgelu,
+                         hipStream_t st) {
+    const int cmax = Cs > Cd ? Cs : Cd;
+    if (cmax <= 8) launch_block_cfg<4, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st);
+    else if (cmax <= 16) launch_block_cfg<4, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st);
+    else if (cmax <= 20) {  // measured at B=256, C=20 (us): (10,2,2) 61/73/60/97, (5,4,4) 69/79/67/82, (4,5,5) 77/84/74/83
+        if (dgelu) launch_block_cfg<5, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st);
+        else launch_block_cfg<10, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st);
+    }
+    else launch_block_cfg<8, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st);
+}
+
+// out[b,o] = bias[o] + sum_i w0[o,i] f(a[b,i]) + idft(z[b,o])                       (FnoBlock.forward minus its GELU)
+extern "C" int cfd_fno_block_fwd(const cfd_plan* p, const float* a, const float* z, const float* w0, const float* b0,
+                                 float* out, int B, int Cin, int Cout, int act_in, void* stream) {
+    CFD_REQUIRE(p && a && z && w0 && out, CFD_ERR_INVALID_ARG, "cfd_fno_block_fwd: NULL pointer");
+    CFD_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && Cin <= 32 && Cout <= 32, CFD_ERR_UNSUPPORTED,
+                "cfd_fno_block_fwd: channels (%d -> %d) unsupported (1..32)", Cin, Cout);
+    if (B == 0) return CFD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (!block_fused_ok(p, Cin, Cout, a, out, nullptr)) {  // general grids: two passes
+        CFD_TRY(cfd_chanmix(a, w0, b0, out, B, Cin, Cout, p->H * p->W, act_in, 0, stream));
+        return cfd_spectral_idft(p, z, out, nullptr, out, B * Cout, 1, stream);
+    }
+    CFD_PROF(act_in ? "k_block_fwd_act" : "k_block_fwd", st);
+    launch_block(p, a, z, w0, b0, nullptr, out, B, Cin, Cout, act_in, 0, 0, st);
+    CFD_LAUNCH_CHECK("cfd_fno_block_fwd");
+    return CFD_OK;
+}
+
+// gin[b,i] = (sum_o w0[o,i] g[b,o] + idft(gz[b,i])) * (aprev ? gelu'(aprev[b,i]) : 1)      (input gradient of the block)
+extern "C" int cfd_fno_block_bwd_input(const cfd_plan* p, const float* g, const float* gz, const float* w0,
+                                       const float* aprev, float* gin, int B, int Cin, int Cout, void* stream) {
+    CFD_REQUIRE(p && g && gz && w0 && gin, CFD_ERR_INVALID_ARG, "cfd_fno_block_bwd_input: NULL pointer");
+    CFD_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && Cin <= 32 && Cout <= 32, CFD_ERR_UNSUPPORTED,
+                "cfd_fno_block_bwd_input: channels (%d -> %d) unsupported (1..32)", Cin, Cout);
+    if (B == 0) return CFD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (!block_fused_ok(p, Cout, Cin, g, gin, aprev)) {
+        CFD_TRY(cfd_chanmix(g, w0, nullptr, gin, B, Cout, Cin, p->H * p->W, 0, 1, stream));
+        return cfd_spectral_idft(p, gz, gin, aprev, gin, B * Cin, aprev ? 2 : 1, stream);
+    }
+    CFD_PROF(aprev ? "k_block_bwd_dgelu" : "k_block_bwd", st);
+    launch_block(p, g, gz, w0, nullptr, aprev, gin, B, Cout, Cin, 0, 1, aprev ? 1 : 0, st);
+    CFD_LAUNCH_CHECK("cfd_fno_block_bwd_input");
     return CFD_OK;
 }

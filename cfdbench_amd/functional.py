@@ -111,8 +111,7 @@ class FnoBlockFn(torch.autograd.Function):
         st = _stream()
         api.call("cfd_spectral_dft", plan, _ptr(x), _ptr(xh), B * Cin, 0, st)
         api.call("cfd_spectral_mix", plan, _ptr(xh), _ptr(w1r), _ptr(w2r), _ptr(z), B, Cin, Cout, 0, st)
-        api.call("cfd_chanmix", _ptr(x), _ptr(w0f), _ptr(b0f), _ptr(pre), B, Cin, Cout, H * W, 0, 0, st)
-        api.call("cfd_spectral_idft", plan, _ptr(z), _ptr(pre), None, _ptr(pre), B * Cout, 1, st)
+        api.call("cfd_fno_block_fwd", plan, _ptr(x), _ptr(z), _ptr(w0f), _ptr(b0f), _ptr(pre), B, Cin, Cout, 0, st)
         out = pre
         if gelu:
             out = torch.empty_like(pre)
@@ -145,8 +144,7 @@ class FnoBlockFn(torch.autograd.Function):
         gz = torch.empty((B, Cin, 2 * m1, m2, 2), dtype=torch.float32, device=dev)
         api.call("cfd_spectral_mix", plan, _ptr(gh), _ptr(w1r), _ptr(w2r), _ptr(gz), B, Cin, Cout, 1, st)
         gx = torch.empty_like(x)
-        api.call("cfd_chanmix", _ptr(g), _ptr(w0f), None, _ptr(gx), B, Cout, Cin, H * W, 0, 1, st)
-        api.call("cfd_spectral_idft", plan, _ptr(gz), _ptr(gx), None, _ptr(gx), B * Cin, 1, st)
+        api.call("cfd_fno_block_bwd_input", plan, _ptr(g), _ptr(gz), _ptr(w0f), None, _ptr(gx), B, Cin, Cout, st)
         return gx, torch.view_as_complex(gw1), torch.view_as_complex(gw2), gw0, gb0, None
 
 

@@ -84,6 +84,17 @@ size_t cfd_spectral_conv2d_bwd_workspace_bytes(const cfd_plan* plan, int B, int 
 int cfd_spectral_conv2d_bwd(const cfd_plan* plan, const float* gy, const float* xh, const float* w1, const float* w2,
                             float* gx, float* gw1, float* gw2, void* ws, int B, int Cin, int Cout, void* stream);
 
+/* Fused FnoBlock body (fno2d.py:106-112): out[b,o] = b0[o] + sum_i w0[o,i] f(a[b,i]) + irfft2-of-kept-modes(z[b,o]),
+ * i.e. cfd_chanmix followed by cfd_spectral_idft(epi=1) in ONE pass over the activation (the block's GELU is applied
+ * by the consumers on load).  a: (B,Cin,H,W); z: (B,Cout,2*m1,m2) c64; w0: (Cout,Cin); out: (B,Cout,H,W).
+ * Grids other than W == 64, H % 16 == 0 run the two-pass form internally.                                    */
+int cfd_fno_block_fwd(const cfd_plan* plan, const float* a, const float* z, const float* w0, const float* b0,
+                      float* out, int B, int Cin, int Cout, int act_in, void* stream);
+/* Its input gradient: gin[b,i] = (sum_o w0[o,i] g[b,o] + irfft2-of-kept-modes(gz[b,i])) * gelu'(aprev[b,i]);
+ * aprev == NULL skips the gelu' factor (first block, whose input is not an activation output).               */
+int cfd_fno_block_bwd_input(const cfd_plan* plan, const float* g, const float* gz, const float* w0,
+                            const float* aprev, float* gin, int B, int Cin, int Cout, void* stream);
+
 /* ---- pointwise / channel-mixing pieces -----------------------------------------------------------------*/
 
 /* out[b,o,p] = bias[o] + sum_i w[o,i] f(in[b,i,p])   (nn.Conv2d(k=1): fno2d.py:104,150; transpose=1 uses w[i,o]

@@ -44,5 +44,10 @@ inline void cfd_wave_lds_sync() { cfd_emul::wave_sync(); }
 
 inline int cfd_opaque(int x) { return x; }
 
+inline void cfd_sched_fence() {}
+
+inline int cfd_uniform(int x) { return x; }
+
 inline float cfd_erff(float x) { return erff(x); }
 inline float cfd_expf(float x) { return expf(x); }
+inline float cfd_rcpf(float x) { return 1.0f / x; }

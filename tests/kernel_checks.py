@@ -58,6 +58,80 @@ def check_spectral(be, B, Cin, Cout, H, W, m1=12, m2=12, seed=0):
         api.plan_destroy(plan)
 
 
+def check_mix_wgrad(be, B, Cin, Cout, m1=12, m2=12, H=64, W=64, seed=11):
+    """cfd_spectral_mix (forward + adjoint) and cfd_spectral_wgrad on their own: reaches every (channels, waves)
+    instantiation cheaply (no transforms involved)."""
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    M2 = (2 * m1, m2)
+
+    def crand(*shape):
+        return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+
+    xh, gh = crand(B, Cin, *M2), crand(B, Cout, *M2)
+    w1, w2 = crand(Cin, Cout, m1, m2), crand(Cin, Cout, m1, m2)
+    plan = api.plan_create(H, W, m1, m2)
+    try:
+        dxh, dgh, dw1, dw2 = be.dev(xh), be.dev(gh), be.dev(w1), be.dev(w2)
+        z = be.zeros((B, Cout, *M2), np.complex64)
+        api.call("cfd_spectral_mix", plan, P(dxh), P(dw1), P(dw2), P(z), B, Cin, Cout, 0, be.stream)
+        gz = be.zeros((B, Cin, *M2), np.complex64)
+        api.call("cfd_spectral_mix", plan, P(dgh), P(dw1), P(dw2), P(gz), B, Cin, Cout, 1, be.stream)
+        ws = be.bytes(api.size("cfd_spectral_wgrad_workspace_bytes", plan, B, Cin, Cout))
+        gw1 = be.zeros((Cin, Cout, m1, m2), np.complex64)
+        gw2 = be.zeros((Cin, Cout, m1, m2), np.complex64)
+        api.call("cfd_spectral_wgrad", plan, P(dxh), P(dgh), P(gw1), P(gw2), P(ws), B, Cin, Cout, be.stream)
+        be.sync()
+        X, G = xh.astype(c128), gh.astype(c128)
+        Wf = np.concatenate([w1, w2], axis=2).astype(c128)  # (Cin, Cout, 2*m1, m2): rows [0,m1) use w1, the rest w2
+        cl = O.hermitian_weights(m2, W) / (H * W)
+        rgw = np.einsum("bikl,bokl->iokl", X.conj(), G) * cl[None, None, None, :]
+        return {
+            "mix": nm(be.host(z), np.einsum("bikl,iokl->bokl", X, Wf)),
+            "mix_adj": nm(be.host(gz), np.einsum("bokl,iokl->bikl", G, Wf.conj())),
+            "gw1": nm(be.host(gw1), rgw[:, :, :m1]),
+            "gw2": nm(be.host(gw2), rgw[:, :, m1:]),
+        }
+    finally:
+        api.plan_destroy(plan)
+
+
+def check_block(be, B, Cin, Cout, H, W, m1=12, m2=12, seed=12):
+    """cfd_fno_block_fwd / cfd_fno_block_bwd_input (1x1 conv + inverse transform [+ gelu'] in one pass)."""
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    g = rng.standard_normal((B, Cout, H, W)).astype(np.float32)
+    z = (rng.standard_normal((B, Cout, 2 * m1, m2)) + 1j * rng.standard_normal((B, Cout, 2 * m1, m2))).astype(np.complex64)
+    gz = (rng.standard_normal((B, Cin, 2 * m1, m2)) + 1j * rng.standard_normal((B, Cin, 2 * m1, m2))).astype(np.complex64)
+    w0 = rng.standard_normal((Cout, Cin)).astype(np.float32)
+    b0 = rng.standard_normal((Cout,)).astype(np.float32)
+    plan = api.plan_create(H, W, m1, m2)
+    try:
+        da, dg, dz, dgz, dw, db = be.dev(a), be.dev(g), be.dev(z), be.dev(gz), be.dev(w0), be.dev(b0)
+        res = {}
+        a64, w64 = a.astype(f64), w0.astype(f64)
+        for act in (0, 1):
+            out = be.zeros((B, Cout, H, W))
+            api.call("cfd_fno_block_fwd", plan, P(da), P(dz), P(dw), P(db), P(out), B, Cin, Cout, act, be.stream)
+            be.sync()
+            fa = O.gelu(a64) if act else a64
+            ref = np.einsum("oi,bixy->boxy", w64, fa) + b0[None, :, None, None] + O.pruned_idft(z.astype(c128), H, W)
+            res[f"fwd_act{act}"] = nm(be.host(out), ref)
+        refg = np.einsum("oi,boxy->bixy", w64, g.astype(f64)) + O.pruned_idft(gz.astype(c128), H, W)
+        gin = be.zeros((B, Cin, H, W))
+        api.call("cfd_fno_block_bwd_input", plan, P(dg), P(dgz), P(dw), None, P(gin), B, Cin, Cout, be.stream)
+        be.sync()
+        res["bwd"] = nm(be.host(gin), refg)
+        gin2 = be.zeros((B, Cin, H, W))
+        api.call("cfd_fno_block_bwd_input", plan, P(dg), P(dgz), P(dw), P(da), P(gin2), B, Cin, Cout, be.stream)
+        be.sync()
+        res["bwd_dgelu"] = nm(be.host(gin2), refg * O.gelu_grad(a64))
+        return res
+    finally:
+        api.plan_destroy(plan)
+
+
 def check_idft_epilogues(be, nimg, H, W, m1=12, m2=12, seed=1):
     api, P = be.api, be.ptr
     rng = np.random.default_rng(seed)

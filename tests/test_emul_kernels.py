@@ -28,6 +28,16 @@ def test_spectral_fwd_bwd(be, H, W):
     _assert_all(K.check_spectral(be, 2, 3, 5, H, W))
 
 
+@pytest.mark.parametrize("B,Cin,Cout", [(3, 20, 20), (9, 12, 7), (2, 24, 24), (5, 32, 32), (10, 5, 20)])
+def test_mix_and_spectral_wgrad(be, B, Cin, Cout):
+    _assert_all(K.check_mix_wgrad(be, B, Cin, Cout))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 20, 20, 64, 64), (1, 6, 7, 32, 64), (1, 3, 5, 66, 65), (1, 32, 12, 32, 64)])
+def test_fused_block(be, B, Cin, Cout, H, W):
+    _assert_all(K.check_block(be, B, Cin, Cout, H, W))
+
+
 @pytest.mark.parametrize("H,W", [(64, 64), (66, 65)])
 def test_idft_epilogues(be, H, W):
     _assert_all(K.check_idft_epilogues(be, 3, H, W))

@@ -30,6 +30,16 @@ def test_spectral_fwd_bwd(be, B, Cin, Cout, H, W):
     _assert_all(K.check_spectral(be, B, Cin, Cout, H, W))
 
 
+@pytest.mark.parametrize("B,Cin,Cout", [(37, 20, 20), (9, 12, 7), (33, 24, 24), (70, 32, 32), (10, 5, 20), (256, 20, 20)])
+def test_mix_and_spectral_wgrad(be, B, Cin, Cout):
+    _assert_all(K.check_mix_wgrad(be, B, Cin, Cout))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(5, 20, 20, 64, 64), (3, 6, 7, 32, 64), (2, 3, 5, 66, 65), (3, 32, 32, 64, 64), (2, 14, 9, 48, 64)])
+def test_fused_block(be, B, Cin, Cout, H, W):
+    _assert_all(K.check_block(be, B, Cin, Cout, H, W))
+
+
 @pytest.mark.parametrize("H,W", [(64, 64), (66, 65)])
 def test_idft_epilogues(be, H, W):
     _assert_all(K.check_idft_epilogues(be, 37, H, W))
