@@ -64,6 +64,10 @@ def kernel_models(B, C, HW, L, M, head=128, co=2):
         "k_chanmix": dict(bytes=2 * N, flops=2 * px * C * C),
         "k_chanmix_act": dict(bytes=2 * N, flops=2 * px * C * C),
         "k_chanmix_t": dict(bytes=2 * N, flops=2 * px * C * C),
+        "k_block_fwd": dict(bytes=2 * N + Mb, flops=2 * px * C * C + 2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
+        "k_block_fwd_act": dict(bytes=2 * N + Mb, flops=2 * px * C * C + 2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
+        "k_block_bwd": dict(bytes=2 * N + Mb, flops=2 * px * C * C + 2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
+        "k_block_bwd_dgelu": dict(bytes=3 * N + Mb, flops=2 * px * C * C + 2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
         "k_idft": dict(bytes=N + Mb, flops=2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
         "k_idft_add": dict(bytes=2 * N + Mb, flops=2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
         "k_idft_add_dgelu": dict(bytes=3 * N + Mb, flops=2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),

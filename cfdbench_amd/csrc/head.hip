@@ -20,6 +20,14 @@ static int head_blocks(int B, int HW) {
     return (int)blocks;
 }
 
+// backward: the four waves of a block share each tile (see k_head_bwd)
+static int head_bwd_blocks(int B, int HW) {
+    const long tiles = (long)B * ((HW + 63) / 64);
+    long blocks = tiles < 512 ? tiles : 512;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
 template <int KS, bool VEC4, bool ACT>
 __device__ __forceinline__ void head_load_h(const float* __restrict__ a, int b, int C, int HW, int px, int q,
                                             float (&h)[KS][4]) {
@@ -164,9 +172,8 @@ static size_t head_part_floats(int C, int Co) { return (size_t)HEAD_HD * C + HEA
 extern "C" size_t cfd_fno_head_workspace_bytes(int B, int C, int Hd, int Co, int HW) {
     (void)Hd;
     if (B <= 0) return 0;
-    const size_t nb = (size_t)head_blocks(B, HW);
-    const size_t fwd = nb * 3 * sizeof(float);
-    const size_t bwd = nb * head_part_floats(C, Co) * sizeof(float);
+    const size_t fwd = (size_t)head_blocks(B, HW) * 3 * sizeof(float);
+    const size_t bwd = (size_t)head_bwd_blocks(B, HW) * head_part_floats(C, Co) * sizeof(float);
     return fwd > bwd ? fwd : bwd;
 }
 
@@ -219,54 +226,70 @@ extern "C" int cfd_fno_head_fwd(const float* a, const float* mask, const float* 
 // ------------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------------
+// The four waves of a workgroup share one 64-pixel tile and split the 128 hidden units: wave w owns hidden units
+// [32w, 32w+32) (two MFMA M-tiles).  Everything indexed by hidden unit -- the recomputed pre-activation, GELU and its
+// derivative, the fc2 weight gradient (per-lane VALU accumulators), the fc1 weight/bias gradient (MFMA, K = pixels,
+// operands transposed through a wave-private LDS tile) -- is wave-local, and all weight fragments of the slice are
+// loop-invariant registers.  Only d/dh = W1^T gz sums over hidden units: each wave contributes its partial through
+// LDS once per tile and the workgroup finishes ga = d/dh * f'(a) with coalesced float4 stores.
+// A wave issues 42 MFMAs per 16-pixel phase (10 recompute + 16 d/dh + 16 weight gradient) on ~150 registers, so
+// several waves per SIMD overlap MFMA with GELU/LDS work (the one-wave-owns-128-units version needed 450 registers).
 template <int KS, bool VEC4, bool ACT>
-__global__ __launch_bounds__(256, 1) void k_head_bwd(
+__global__ __launch_bounds__(256, 2) void k_head_bwd(
     const float* __restrict__ a, const float* __restrict__ mask, const float* __restrict__ label,
     const float* __restrict__ preds, const float* __restrict__ gext, const float* __restrict__ coef,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, float* __restrict__ ga,
     float* __restrict__ part, int B, int C, int Co, int HW) {
-    constexpr int MU = (4 * KS + 15) / 16;       // M tiles of the channel axis for d/dh
-    constexpr int NTI = (4 * KS + 1 + 15) / 16;  // N tiles of [channels | ones] for the fc1 weight/bias gradient
-    constexpr int XR = HEAD_HD * HEAD_LD;        // transposed hidden tile  [128][17]
-    constexpr int HR = 16 * NTI * HEAD_LD;       // transposed input tile   [16*NTI][17]
-    constexpr int GR = 16 * HEAD_LD;             // transposed output-grad tile [16][17]
-    constexpr int WAVE_LDS = XR + HR + GR;
-    __shared__ float s_w1f[HEAD_MT * KS * 64];
-    __shared__ float s_w1t[MU * 32 * 64];
-    __shared__ float s_b1[HEAD_HD];
-    __shared__ float s_w2[2 * HEAD_HD];
-    __shared__ float s_tile[4 * WAVE_LDS];
-    head_build_w1f<KS>(s_w1f, w1, C);
-    // A-operand fragments for d/dh = W1^T gz:  frag[mu][step=(mt,r)][lane=(q,i)] = w1[16mt+4q+r][16mu+i]
-    for (int idx = threadIdx.x; idx < MU * 32 * 64; idx += blockDim.x) {
-        const int ln = idx & 63, step = (idx >> 6) & 31, mu = idx >> 11;
-        const int jh = 16 * (step >> 2) + 4 * (ln >> 4) + (step & 3), i = 16 * mu + (ln & 15);
-        s_w1t[idx] = i < C ? w1[jh * C + i] : 0.f;
-    }
-    for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x) s_b1[i] = b1[i];
-    for (int i = threadIdx.x; i < 2 * HEAD_HD; i += blockDim.x) s_w2[i] = (i / HEAD_HD) < Co ? w2[i] : 0.f;
-    for (int i = threadIdx.x; i < 4 * WAVE_LDS; i += blockDim.x) s_tile[i] = 0.f;
-    __syncthreads();
-    const float c0 = label ? coef[0] : 0.f, c1 = label ? coef[1] : 0.f;
+    constexpr int CP = 4 * KS;                   // padded channel count
+    constexpr int MU = (CP + 15) / 16;           // M tiles of the channel axis for d/dh
+    constexpr int NTI = (CP + 1 + 15) / 16;      // N tiles of [channels | ones] for the fc1 weight/bias gradient
+    constexpr int XR = 32 * HEAD_LD;             // transposed gz tile of one wave   [32 hidden][17]
+    constexpr int HR = 16 * NTI * HEAD_LD;       // transposed input tile of one wave [16*NTI][17]
+    __shared__ float s_t[4 * (XR + HR)];
+    __shared__ float4 s_red[4 * CP * 16];        // [wave][channel][16 x float4 = 64 pixels] partial d/dh
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
-    float* s_x = s_tile + wave * WAVE_LDS;
+    for (int i = threadIdx.x; i < 4 * (XR + HR); i += blockDim.x) s_t[i] = 0.f;
+    float* s_x = s_t + wave * (XR + HR);
     float* s_h = s_x + XR;
-    float* s_g = s_h + HR;
+    // ---- loop-invariant fragments of this wave's hidden slice (global hidden tile mt = 2*wave + t) ----
+    float w1f[2][KS];   // A operand of z = W1 h:        w1[16mt + n][4s + q]
+    float w1t[MU][8];   // A operand of d/dh = W1^T gz:  w1[16mt + 4q + r][16mu + n], k-step 4t + r
+    float bz[2][4], w2a[2][4], w2b[2][4];  // b1, w2[0], w2[1] at hidden unit 16mt + 4q + r
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int mt = 2 * wave + t;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) w1f[t][s] = (4 * s + q < C) ? w1[(16 * mt + n) * C + 4 * s + q] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jh = 16 * mt + 4 * q + r;
+            bz[t][r] = b1[jh];
+            w2a[t][r] = w2[jh];
+            w2b[t][r] = Co > 1 ? w2[HEAD_HD + jh] : 0.f;
+#pragma unroll
+            for (int mu = 0; mu < MU; ++mu) w1t[mu][4 * t + r] = (16 * mu + n < C) ? w1[jh * C + 16 * mu + n] : 0.f;
+        }
+    }
+    const float c0 = label ? coef[0] : 0.f, c1 = label ? coef[1] : 0.f;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 aw1[HEAD_MT][NTI], aw2[HEAD_MT];
+    f32x4 aw1[2][NTI];
+    float acc2a[2][4], acc2b[2][4];
 #pragma unroll
-    for (int mt = 0; mt < HEAD_MT; ++mt) {
-        aw2[mt] = zero;
+    for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int v = 0; v < NTI; ++v) aw1[mt][v] = zero;
+        for (int v = 0; v < NTI; ++v) aw1[t][v] = zero;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc2a[t][r] = 0.f; acc2b[t][r] = 0.f; }
     }
     float gb2a0 = 0.f, gb2a1 = 0.f;
+    __syncthreads();
     const int tpb = (HW + 63) / 64;
     const long total = (long)B * tpb;
-    for (long tile = (long)blockIdx.x * 4 + wave; tile < total; tile += (long)gridDim.x * 4) {
+    for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {  // all four waves walk the same tiles
         const int b = (int)(tile / tpb);
-        const int px = (int)(tile - (long)b * tpb) * 64 + 4 * n;
+        const int px0 = (int)(tile - (long)b * tpb) * 64;
+        const int px = px0 + 4 * n;
         float h[KS][4];
         head_load_h<KS, VEC4, ACT>(a, b, C, HW, px, q, h);
         // upstream gradient on the raw head output for this lane's 4 pixels (same for every q)
@@ -293,165 +316,146 @@ __global__ __launch_bounds__(256, 1) void k_head_bwd(
                 }
             }
         }
-        if (q == 0) {
+        if (wave == 0 && q == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { gb2a0 += gr0[j]; gb2a1 += gr1[j]; }
         }
-        // Rolled loop over the 4 pixel phases (see k_head_fwd): phase data sits in h[s][0] / gr*[0], the phase
-        // result is rotated into gh[mu][3].
+        // The 4 pixel phases, unrolled (static register indices: no rotation moves).
         f32x4 gh[MU][4];
 #pragma unroll
         for (int mu = 0; mu < MU; ++mu)
 #pragma unroll
             for (int j = 0; j < 4; ++j) gh[mu][j] = zero;
-#pragma unroll 1
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int lo = cfd_opaque(lane), q4 = cfd_opaque(4 * q);  // keep the LDS table reads inside the loop
+            // 1. recompute this wave's slice of the hidden pre-activation z[hidden][pixel n]
+            f32x4 z[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) z[t] = f32x4{bz[t][0], bz[t][1], bz[t][2], bz[t][3]};
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x4(w1f[t][s], h[s][j], z[t]);
+            // 2. a1 = gelu(z) feeds the fc2 weight gradient; gz = (W2^T graw) * gelu'(z) replaces z
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float Phi, e;
+                    cfd_gelu_terms(z[t][r], Phi, e);
+                    const float a1 = z[t][r] * Phi;
+                    acc2a[t][r] = fmaf(gr0[j], a1, acc2a[t][r]);
+                    acc2b[t][r] = fmaf(gr1[j], a1, acc2b[t][r]);
+                    const float ga1 = fmaf(w2a[t][r], gr0[j], w2b[t][r] * gr1[j]);
+                    const float gz = ga1 * fmaf(z[t][r] * CFD_INV_SQRT_2PI, e, Phi);
+                    z[t][r] = gz;
+                    s_x[(16 * t + 4 * q + r) * HEAD_LD + n] = gz;
+                }
+            // 3. transposed input tile [channel | ones][pixel]
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                if (4 * s + q < C) s_h[(4 * s + q) * HEAD_LD + n] = h[s][j];
+            if (q == 0) s_h[C * HEAD_LD + n] = (px + j < HW) ? 1.f : 0.f;
+            cfd_wave_lds_sync();
+            // 4. partial d/dh[i][pixel] = sum over this wave's hidden units w1[jh][i] gz[jh][pixel]
             f32x4 ghc[MU];
 #pragma unroll
             for (int mu = 0; mu < MU; ++mu) ghc[mu] = zero;
-            // 1. recompute the hidden pre-activation tile z[jh][pixel n]
-            f32x4 z[HEAD_MT];
 #pragma unroll
-            for (int mt = 0; mt < HEAD_MT; ++mt) {
-                const int jb = 16 * mt + q4;
-                z[mt] = f32x4{s_b1[jb], s_b1[jb + 1], s_b1[jb + 2], s_b1[jb + 3]};
-            }
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int mt = 0; mt < HEAD_MT; ++mt)
-                    z[mt] = cfd_mfma16x16x4(s_w1f[(mt * KS + s) * 64 + lo], h[s][0], z[mt]);
-            // 2. transposed tiles: a1 = gelu(z) [jh][px], h [i | ones][px], graw [c][px]
-#pragma unroll
-            for (int mt = 0; mt < HEAD_MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s_x[(16 * mt + 4 * q + r) * HEAD_LD + n] = cfd_gelu(z[mt][r]);
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-                if (4 * s + q < C) s_h[(4 * s + q) * HEAD_LD + n] = h[s][0];
-            if (q == 0) {
-                s_h[C * HEAD_LD + n] = (px + j < HW) ? 1.f : 0.f;
-                s_g[n] = gr0[0];
-                s_g[HEAD_LD + n] = gr1[0];
-            }
-            cfd_wave_lds_sync();
-            // 3. gw2[c][jh] += sum_px graw[c][px] a1[jh][px]
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const float bg = s_g[n * HEAD_LD + 4 * s4 + q];
-#pragma unroll
-                for (int mt = 0; mt < HEAD_MT; ++mt)
-                    aw2[mt] = cfd_mfma16x16x4(s_x[(16 * mt + n) * HEAD_LD + 4 * s4 + q], bg, aw2[mt]);
-            }
-            cfd_wave_lds_sync();
-            // 4. gz = (W2^T graw) * gelu'(z)   (kept in z and written transposed)
-#pragma unroll
-            for (int mt = 0; mt < HEAD_MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int jh = 16 * mt + q4 + r;
-                    const float ga1 = fmaf(s_w2[jh], gr0[0], s_w2[HEAD_HD + jh] * gr1[0]);
-                    const float gz = ga1 * cfd_gelu_grad(z[mt][r]);
-                    z[mt][r] = gz;
-                    s_x[jh * HEAD_LD + n] = gz;
-                }
-            cfd_wave_lds_sync();
-            // 5. d/dh[i][px] += sum_jh w1[jh][i] gz[jh][px]   (gz registers are already the B operand)
-#pragma unroll
-            for (int mt = 0; mt < HEAD_MT; ++mt)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int mu = 0; mu < MU; ++mu)
-                        ghc[mu] = cfd_mfma16x16x4(s_w1t[(mu * 32 + mt * 4 + r) * 64 + lo], z[mt][r], ghc[mu]);
-            // 6. gw1[jh][i] (+ gb1 through the ones column) += sum_px gz[jh][px] h[i][px]
+                    for (int mu = 0; mu < MU; ++mu) ghc[mu] = cfd_mfma16x16x4(w1t[mu][4 * t + r], z[t][r], ghc[mu]);
+            // 5. gw1[jh][i] (+ gb1 through the ones column) += sum_pixel gz[jh][pixel] h[i][pixel]
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 float bh[NTI];
 #pragma unroll
                 for (int v = 0; v < NTI; ++v) bh[v] = s_h[(16 * v + n) * HEAD_LD + 4 * s4 + q];
 #pragma unroll
-                for (int mt = 0; mt < HEAD_MT; ++mt) {
-                    const float ax = s_x[(16 * mt + n) * HEAD_LD + 4 * s4 + q];
+                for (int t = 0; t < 2; ++t) {
+                    const float ax = s_x[(16 * t + n) * HEAD_LD + 4 * s4 + q];
 #pragma unroll
-                    for (int v = 0; v < NTI; ++v) aw1[mt][v] = cfd_mfma16x16x4(ax, bh[v], aw1[mt][v]);
+                    for (int v = 0; v < NTI; ++v) aw1[t][v] = cfd_mfma16x16x4(ax, bh[v], aw1[t][v]);
                 }
             }
             cfd_wave_lds_sync();
 #pragma unroll
-            for (int mu = 0; mu < MU; ++mu) { gh[mu][0] = gh[mu][1]; gh[mu][1] = gh[mu][2]; gh[mu][2] = gh[mu][3]; gh[mu][3] = ghc[mu]; }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) { h[s][0] = h[s][1]; h[s][1] = h[s][2]; h[s][2] = h[s][3]; }
-            gr0[0] = gr0[1]; gr0[1] = gr0[2]; gr0[2] = gr0[3];
-            gr1[0] = gr1[1]; gr1[1] = gr1[2]; gr1[2] = gr1[3];
+            for (int mu = 0; mu < MU; ++mu) gh[mu][j] = ghc[mu];
         }
-        // epilogue: ga[b][i][px..px+3] = d/dh * f'(a)
+        // this wave's partial d/dh of the tile: [channel][64 pixels], pixel = 4n + phase
 #pragma unroll
         for (int mu = 0; mu < MU; ++mu)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * mu + 4 * q + r;
-                if (i < C) {
-                    const size_t off = ((size_t)b * C + i) * HW + px;
-                    float v[4] = {gh[mu][0][r], gh[mu][1][r], gh[mu][2][r], gh[mu][3][r]};
-                    if constexpr (VEC4) {
-                        if (px < HW) {
-                            if constexpr (ACT) {
-                                const float4 av = *reinterpret_cast<const float4*>(a + off);
-                                v[0] *= cfd_gelu_grad(av.x); v[1] *= cfd_gelu_grad(av.y);
-                                v[2] *= cfd_gelu_grad(av.z); v[3] *= cfd_gelu_grad(av.w);
-                            }
-                            *reinterpret_cast<float4*>(ga + off) = make_float4(v[0], v[1], v[2], v[3]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (px + j < HW) {
-                                float vv = v[j];
-                                if constexpr (ACT) vv *= cfd_gelu_grad(a[off + j]);
-                                ga[off + j] = vv;
-                            }
-                    }
-                }
+                if (i < CP) s_red[(wave * CP + i) * 16 + n] = make_float4(gh[mu][0][r], gh[mu][1][r], gh[mu][2][r], gh[mu][3][r]);
             }
-    }
-    // ---- block reduction of the parameter-gradient accumulators (wave after wave, fixed order) ----
-    gb2a0 = cfd_wave_sum(gb2a0);
-    gb2a1 = cfd_wave_sum(gb2a1);
-    __syncthreads();
-    float* red = s_tile;  // [gw1 128*C | gb1 128 | gw2 Co*128 | gb2 Co]
-    const int o_gb1 = HEAD_HD * C, o_gw2 = o_gb1 + HEAD_HD, o_gb2 = o_gw2 + Co * HEAD_HD;
-    for (int wv = 0; wv < 4; ++wv) {
-        if (wave == wv) {
+        __syncthreads();
+        // ga[b][i][px0 .. px0+63] = (sum over the four hidden slices) * f'(a)
+        for (int e = threadIdx.x; e < C * 16; e += blockDim.x) {
+            const int i = e >> 4, n4 = e & 15;
+            float4 v = s_red[i * 16 + n4];
 #pragma unroll
-            for (int mt = 0; mt < HEAD_MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int jh = 16 * mt + 4 * q + r;
-#pragma unroll
-                    for (int v = 0; v < NTI; ++v) {
-                        const int i = 16 * v + n;
-                        if (i <= C) {
-                            const int off = i < C ? jh * C + i : o_gb1 + jh;
-                            red[off] = (wv == 0 ? 0.f : red[off]) + aw1[mt][v][r];
-                        }
+            for (int wv = 1; wv < 4; ++wv) {
+                const float4 u = s_red[(wv * CP + i) * 16 + n4];
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            const int p4 = px0 + 4 * n4;
+            const size_t off = ((size_t)b * C + i) * HW + p4;
+            if constexpr (VEC4) {
+                if (p4 < HW) {
+                    if constexpr (ACT) {
+                        const float4 av = *reinterpret_cast<const float4*>(a + off);
+                        v.x *= cfd_gelu_grad(av.x); v.y *= cfd_gelu_grad(av.y);
+                        v.z *= cfd_gelu_grad(av.z); v.w *= cfd_gelu_grad(av.w);
                     }
-                    if (n < Co) {
-                        const int off = o_gw2 + n * HEAD_HD + jh;
-                        red[off] = (wv == 0 ? 0.f : red[off]) + aw2[mt][r];
-                    }
+                    *reinterpret_cast<float4*>(ga + off) = v;
                 }
-            if (lane == 0) {
-                red[o_gb2] = (wv == 0 ? 0.f : red[o_gb2]) + gb2a0;
-                if (Co > 1) red[o_gb2 + 1] = (wv == 0 ? 0.f : red[o_gb2 + 1]) + gb2a1;
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (p4 + j < HW) {
+                        float x = vv[j];
+                        if constexpr (ACT) x *= cfd_gelu_grad(a[off + j]);
+                        ga[off + j] = x;
+                    }
             }
         }
         __syncthreads();
     }
-    const int PS = o_gb2 + Co;
-    float* dst = part + (size_t)blockIdx.x * PS;
-    for (int e = threadIdx.x; e < PS; e += blockDim.x) dst[e] = red[e];
+    // ---- this block's partial parameter gradients: [gw1 128*C | gb1 128 | gw2 Co*128 | gb2 Co] ----
+    const int o_gb1 = HEAD_HD * C, o_gw2 = o_gb1 + HEAD_HD, o_gb2 = o_gw2 + Co * HEAD_HD;
+    float* dst = part + (size_t)blockIdx.x * (o_gb2 + Co);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jh = 16 * (2 * wave + t) + 4 * q + r;
+#pragma unroll
+            for (int v = 0; v < NTI; ++v) {
+                const int i = 16 * v + n;
+                if (i < C) dst[jh * C + i] = aw1[t][v][r];
+                else if (i == C) dst[o_gb1 + jh] = aw1[t][v][r];
+            }
+            float sa = acc2a[t][r], sb = acc2b[t][r];  // sum over the 16 pixel lanes of this q group
+#pragma unroll
+            for (int m = 1; m <= 8; m <<= 1) { sa += cfd_shfl_xor(sa, m); sb += cfd_shfl_xor(sb, m); }
+            if (n == 0) {
+                dst[o_gw2 + jh] = sa;
+                if (Co > 1) dst[o_gw2 + HEAD_HD + jh] = sb;
+            }
+        }
+    if (wave == 0) {
+        gb2a0 = cfd_wave_sum(gb2a0);
+        gb2a1 = cfd_wave_sum(gb2a1);
+        if (lane == 0) {
+            dst[o_gb2] = gb2a0;
+            if (Co > 1) dst[o_gb2 + 1] = gb2a1;
+        }
+    }
 }
 
 // One wave per output element (see k_wgrad_reduce).
@@ -483,7 +487,7 @@ extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* 
     CFD_TRY(head_check("cfd_fno_head_bwd", B, C, Hd, Co, HW));
     CFD_REQUIRE(B >= 1, CFD_ERR_INVALID_ARG, "cfd_fno_head_bwd: empty batch");
     hipStream_t st = (hipStream_t)stream;
-    const int blocks = head_blocks(B, HW);
+    const int blocks = head_bwd_blocks(B, HW);
     float* part = (float*)ws;
     const bool v4 = HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)ga % 16) == 0;
     {
