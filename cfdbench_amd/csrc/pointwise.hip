@@ -238,17 +238,23 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
                     for (int j = 0; j < 4; ++j) bv[c][j] = (px + j < HW) ? src[j] : 0.f;
                 }
             } else {
+                // generated columns: ones (bias gradient) and, for the stem, mask / grid_x / grid_y / case parameters.
+                // One row/column split per lane and chunk (px .. px+3 share a row whenever W % 4 == 0).
+                const int f = STEM ? i - ss.in_chan : -1;
+                const int row0 = STEM ? px / ss.W : 0, col0 = STEM ? px - row0 * ss.W : 0;
+                const bool same_row = STEM && (ss.W % 4 == 0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int pj = px + j;
                     float v = 0.f;
                     if (pj < HW) {
-                        if (i == Ci) v = 1.f;  // ones column -> bias gradient
+                        if (i == Ci) v = 1.f;
                         else if constexpr (STEM) {
-                            const int f = i - ss.in_chan;
+                            int row = row0, col = col0 + j;
+                            if (!same_row && col >= ss.W) { row = pj / ss.W; col = pj - row * ss.W; }
                             if (f == 0) v = ss.mask ? ss.mask[(size_t)b * HW + pj] : 1.f;
-                            else if (f == 1) v = ss.gx[pj / ss.W];
-                            else if (f == 2) v = ss.gy[pj % ss.W];
+                            else if (f == 1) v = ss.gx[row];
+                            else if (f == 2) v = ss.gy[col];
                             else if (f < 3 + ss.P) v = ss.cp[(size_t)b * ss.P + (f - 3)];
                         }
                     }

@@ -21,6 +21,7 @@
 #include "cfd_common.h"
 
 #define CFD_WAVES 4  // waves per workgroup (256 threads)
+#define CFD_DFT_OS (2 * 15 * 16)  // complex modes of one image, m1 <= 15, m2 <= 16
 
 // ------------------------------------------------------------------------------------------------------
 // forward pruned DFT
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES) void k_dft_fwd(const float* __restr
                                                              const float* __restrict__ tabs, int ntab, int nimg,
                                                              int H, int W, int m1, int m2, int KX) {
     __shared__ float s_tab[(2 * 17 + 8 * NJ) * 64];
+    __shared__ float2 s_out[CFD_WAVES * CFD_DFT_OS];
     for (int i = threadIdx.x; i < ntab; i += blockDim.x) s_tab[i] = tabs[i];
     __syncthreads();
     const float* t1c = s_tab;
@@ -92,17 +94,24 @@ __global__ __launch_bounds__(64 * CFD_WAVES) void k_dft_fwd(const float* __restr
             }
         }
         // P*[r]: l = 4q + r, kap = n
-        float2* o = xh + (size_t)img * M;
-        const int kap = n;
-        if (kap <= m1) {
+        // modes -> this wave's LDS slice (scattered 8-byte writes are cheap there), then out in whole 512-byte runs
+        {
+            float2* so = s_out + wave * CFD_DFT_OS;
+            const int kap = n;
+            if (kap <= m1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int l = 4 * q + r;
-                if (l < m2) {
-                    if (kap < m1) o[kap * m2 + l] = make_float2(Pc[r] - Qs[r], -(Ps[r] + Qc[r]));
-                    if (kap >= 1) o[(2 * m1 - kap) * m2 + l] = make_float2(Pc[r] + Qs[r], Qc[r] - Ps[r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int l = 4 * q + r;
+                    if (l < m2) {
+                        if (kap < m1) so[kap * m2 + l] = make_float2(Pc[r] - Qs[r], -(Ps[r] + Qc[r]));
+                        if (kap >= 1) so[(2 * m1 - kap) * m2 + l] = make_float2(Pc[r] + Qs[r], Qc[r] - Ps[r]);
+                    }
                 }
             }
+            cfd_wave_lds_sync();
+            float2* o = xh + (size_t)img * M;
+            for (int i = lane; i < M; i += 64) o[i] = so[i];
+            cfd_wave_lds_sync();
         }
     }
 }
@@ -118,6 +127,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64(const float* __
                                                                   int H, int m1, int m2) {
     constexpr int W = 64, NJ = 4;
     __shared__ float s_tab[(2 * KXT + 8 * NJ) * 64];
+    __shared__ float2 s_out[CFD_WAVES * CFD_DFT_OS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
     const int stride = gridDim.x * CFD_WAVES;
@@ -196,17 +206,24 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64(const float* __
                 Qs = cfd_mfma16x16x4(as, a1s[j][r], Qs);
             }
         }
-        float2* o = xh + (size_t)img * M;
-        const int kap = n;
-        if (kap <= m1) {
+        // modes -> this wave's LDS slice (scattered 8-byte writes are cheap there), then out in whole 512-byte runs
+        {
+            float2* so = s_out + wave * CFD_DFT_OS;
+            const int kap = n;
+            if (kap <= m1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int l = 4 * q + r;
-                if (l < m2) {
-                    if (kap < m1) o[kap * m2 + l] = make_float2(Pc[r] - Qs[r], -(Ps[r] + Qc[r]));
-                    if (kap >= 1) o[(2 * m1 - kap) * m2 + l] = make_float2(Pc[r] + Qs[r], Qc[r] - Ps[r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int l = 4 * q + r;
+                    if (l < m2) {
+                        if (kap < m1) so[kap * m2 + l] = make_float2(Pc[r] - Qs[r], -(Ps[r] + Qc[r]));
+                        if (kap >= 1) so[(2 * m1 - kap) * m2 + l] = make_float2(Pc[r] + Qs[r], Qc[r] - Ps[r]);
+                    }
                 }
             }
+            cfd_wave_lds_sync();
+            float2* o = xh + (size_t)img * M;
+            for (int i = lane; i < M; i += 64) o[i] = so[i];
+            cfd_wave_lds_sync();
         }
         img = nxt;
     }
@@ -521,7 +538,15 @@ __global__ __launch_bounds__(256) void k_spec_wgrad_reduce(const float2* __restr
     const int mode = (int)(gid % M);
     const long io = gid / M;
     float ar = 0.f, ai = 0.f;
-    for (int c = 0; c < nchunk; ++c) {
+    int c = 0;
+    for (; c + 8 <= nchunk; c += 8) {  // 8 independent loads in flight, summed in a fixed order
+        float2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = part[(size_t)(c + k) * CC * M + gid];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ar += v[k].x; ai += v[k].y; }
+    }
+    for (; c < nchunk; ++c) {
         const float2 v = part[(size_t)c * CC * M + gid];
         ar += v.x;
         ai += v.y;
@@ -623,6 +648,11 @@ __device__ __forceinline__ void idft_tile(const float (&va)[2][8], const float* 
     }
 }
 
+#define CFD_BLK_ZS 577  // floats of one staged mode vector: 2*M (m1 = m2 = 12) + the zero slot
+
+template <int V>
+struct CfdParity { static constexpr int value = V; };
+
 #define CFD_IDFT_ZMAX (4 * 15 * 16 + 1)  // 2*M floats (m1 <= 15, m2 <= 16) + the zero slot
 
 template <int NJ, bool VEC4, int EPI>
@@ -706,10 +736,101 @@ __global__ __launch_bounds__(64 * CFD_WAVES) void k_idft(const float* __restrict
     }
 }
 
+// Persistent variant for W == 64 (float4 rows) with the 12x12-mode table sizes: each wave strides over images, the next
+// image's kept modes are requested before the current image's 152 MFMAs and parked in the other LDS slice, and
+// the operator tables are loaded once per workgroup instead of once per four images.
+template <int EPI>
+__global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __restrict__ z, const float* addend,
+                                                               const float* __restrict__ aprev, float* out,
+                                                               const float* __restrict__ tabs, int ntab, int nimg,
+                                                               int H, int m1, int m2, int T, int SA, int SB) {
+    constexpr int W = 64, NJ = 4;
+    __shared__ float s_tab[(32 + 8 * NJ) * 64];           // T*SA <= 32, SB <= 8
+    __shared__ float s_z[CFD_WAVES * 2 * CFD_BLK_ZS];    // two slices per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int M2 = 4 * m1 * m2;
+    const int stride = gridDim.x * CFD_WAVES;
+    int img = blockIdx.x * CFD_WAVES + wave;
+    float* zs0 = s_z + wave * 2 * CFD_BLK_ZS;
+    constexpr int ZR = (CFD_BLK_ZS - 1 + 63) / 64;  // dwords per lane of one mode vector
+    float zr[ZR];
+    auto zfetch = [&](int im) {
+        const float* zi = z + (size_t)im * M2;
+#pragma unroll
+        for (int k = 0; k < ZR; ++k) zr[k] = zi[lane + 64 * k < M2 ? lane + 64 * k : 0];
+    };
+    auto zcommit = [&](float* zs) {
+#pragma unroll
+        for (int k = 0; k < ZR; ++k)
+            if (lane + 64 * k < M2) zs[lane + 64 * k] = zr[k];
+        if (lane == 0) zs[M2] = 0.f;
+    };
+    zfetch(img < nimg ? img : 0);
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) s_tab[i < T * SA * 64 ? i : 32 * 64 + (i - T * SA * 64)] = tabs[i];
+    zcommit(zs0);
+    __syncthreads();
+    const float* ta = s_tab;
+    const float* tb = s_tab + 32 * 64;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    int cur = 0;
+    while (img < nimg) {
+        const int nxt = img + stride;
+        zfetch(nxt < nimg ? nxt : img);
+        cfd_sched_fence();
+        float va[2][8];
+        idft_gather(zs0 + cur * CFD_BLK_ZS, m1, m2, SA, q, n, va);
+        const size_t ibase = (size_t)img * H * W + 4 * n;
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            float4 ad[4], ap[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t off = ibase + (size_t)(16 * t + 4 * q + r) * W;
+                if constexpr (EPI >= 1) ad[r] = *reinterpret_cast<const float4*>(addend + off);
+                if constexpr (EPI == 2) ap[r] = *reinterpret_cast<const float4*>(aprev + off);
+            }
+            f32x4 accB[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) accB[j] = zero;
+            idft_tile<NJ>(va, ta, tb, t, SA, SB, cfd_opaque(lane), accB);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float4 v = make_float4(accB[0][r], accB[1][r], accB[2][r], accB[3][r]);
+                if constexpr (EPI >= 1) { v.x += ad[r].x; v.y += ad[r].y; v.z += ad[r].z; v.w += ad[r].w; }
+                if constexpr (EPI == 2) {
+                    v.x *= cfd_gelu_grad(ap[r].x); v.y *= cfd_gelu_grad(ap[r].y);
+                    v.z *= cfd_gelu_grad(ap[r].z); v.w *= cfd_gelu_grad(ap[r].w);
+                }
+                *reinterpret_cast<float4*>(out + ibase + (size_t)(16 * t + 4 * q + r) * W) = v;
+            }
+        }
+        cur ^= 1;
+        zcommit(zs0 + cur * CFD_BLK_ZS);  // the other slice was last read one image ago (same wave: program order)
+        cfd_wave_lds_sync();
+        img = nxt;
+    }
+}
+
 template <int NJ, bool VEC4>
 static int launch_idft(const cfd_plan* p, const float* z, const float* addend, const float* aprev, float* out,
                        int nimg, int epi, hipStream_t st) {
-    const int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
+    int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
+    if constexpr (VEC4) {
+        if (p->W == 64 && p->H % 16 == 0 && p->T * p->SA <= 32 && 4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS) {
+            if (blocks > 3 * 256) blocks = 3 * 256;  // resident workgroups; waves stride over the images
+#define CFD_IDFT64(E)                                                                                              \
+    hipLaunchKernelGGL((k_idft64<E>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, z, addend, aprev, out,             \
+                       (const float*)p->d_inv, p->n_inv, nimg, p->H, p->m1, p->m2, p->T, p->SA, p->SB)
+            CFD_PROF(epi == 0 ? "k_idft" : (epi == 1 ? "k_idft_add" : "k_idft_add_dgelu"), st);
+            if (epi == 0) CFD_IDFT64(0);
+            else if (epi == 1) CFD_IDFT64(1);
+            else CFD_IDFT64(2);
+#undef CFD_IDFT64
+            CFD_LAUNCH_CHECK("cfd_spectral_idft");
+            return CFD_OK;
+        }
+    }
 #define CFD_IDFT_LAUNCH(E)                                                                                         \
     hipLaunchKernelGGL((k_idft<NJ, VEC4, E>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, z, addend, aprev, out,     \
                        (const float*)p->d_inv, p->n_inv, nimg, p->H, p->W, p->m1, p->m2, p->T, p->SA, p->SB)
@@ -794,10 +915,6 @@ extern "C" int cfd_spectral_conv2d_bwd(const cfd_plan* p, const float* gy, const
 // owns destination channels w, w+NW, ... (DPW of them): their inverse transforms run on the matrix pipe while the
 // chunks are in flight, the channel mix accumulates on the VALU straight into the MFMA accumulator layout
 // (x = 16t+4q+r, y = 4n+j), and a_out leaves in whole float4 rows.  W == 64, H % 16 == 0.
-template <int V>
-struct CfdParity { static constexpr int value = V; };
-
-#define CFD_BLK_ZS 577  // floats of one staged mode vector: 2*M (m1 = m2 = 12) + the zero slot
 
 // NW waves; wave w owns destination channels w, w+NW, ... (DPW of them) and fetches channel w of each of the NCH
 // source chunks.  NW = 4 (one wave per SIMD) wherever the channel count allows.

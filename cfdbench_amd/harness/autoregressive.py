@@ -1,0 +1,36 @@
+"""``get_input_shapes`` / ``init_model``: the reference's plugin registration point (src/utils/autoregressive.py:19-125)."""
+from __future__ import annotations
+
+from typing import Tuple
+
+from ..models.base_model import AutoCfdModel
+from ..models.fno.fno2d import Fno2d
+from ..models.loss import loss_name_to_fn
+
+
+def get_input_shapes(args) -> Tuple[int, int, int]:
+    """(rows, cols, n_case_params) from data_name / num_rows / num_cols (autoregressive.py:19-38)."""
+    if any(x in args.data_name for x in ["tube", "dam", "cylinder"]):
+        n_rows, n_cols = args.num_rows + 2, args.num_cols + 1  # top/bottom and left boundaries
+    else:
+        assert "cavity" in args.data_name
+        n_rows, n_cols = args.num_rows, args.num_cols
+    if "cylinder" in args.data_name:
+        n_case_params = 8  # vel_in, density, viscosity, height, width, radius, center_x, center_y
+    else:
+        assert any(x in args.data_name for x in ["cavity", "tube", "dam"])
+        n_case_params = 5
+    return n_rows, n_cols, n_case_params
+
+
+def init_model(args) -> AutoCfdModel:
+    """Same ``elif`` chain as autoregressive.py:41-179; models whose kernels are not built yet name themselves."""
+    loss_fn = loss_name_to_fn(args.loss_name)
+    _, _, n_case_params = get_input_shapes(args)
+    if args.model == "fno":
+        return Fno2d(in_chan=args.in_chan, out_chan=args.out_chan, n_case_params=n_case_params, loss_fn=loss_fn,
+                     num_layers=args.fno_depth, hidden_dim=args.fno_hidden_dim, modes1=args.fno_modes_x,
+                     modes2=args.fno_modes_y)
+    if args.model in ("auto_ffn", "auto_deeponet", "auto_edeeponet", "auto_deeponet_cnn", "resnet", "unet"):
+        raise NotImplementedError(f"cfdbench_amd: model {args.model!r} has no MI355X kernels yet (DESIGN.md section 7)")
+    raise ValueError(f"Invalid model name: {args.model}")

@@ -1,0 +1,67 @@
+"""Dataset glue.  The on-disk format and preprocessing of CFDBench (src/dataset/*.py, ~2500 lines of NumPy) feed the hot
+path but are not part of it ("next" row 1): ``get_auto_dataset`` defers to the reference's own
+``dataset`` package when a CFDBench checkout is on ``sys.path`` and says so clearly when it is not.
+``SyntheticAutoDataset`` produces items of exactly the reference's shape -- ``(inputs (3,h,w), label (3,h,w),
+case_params dict)`` with the mask as the last channel (src/dataset/base.py, cavity.py:333-347) -- for smoke runs, tests
+and benchmarks without data on disk."""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+
+class SyntheticAutoDataset(Dataset):
+    """Smooth random velocity fields advected by a fixed linear map: learnable, deterministic, no files.
+
+    all_features: list over cases of (T, 3, h, w) float32 arrays [u, v, mask]; case_params: list of dicts in the
+    reference's key order (vel_top, density, viscosity, height, width) -- the attributes test_multistep.py:195-212 reads."""
+
+    def __init__(self, n_cases: int = 4, n_frames: int = 6, height: int = 64, width: int = 64, seed: int = 0,
+                 border_mask: bool = False):
+        rng = np.random.default_rng(seed)
+        yy, xx = np.meshgrid(np.linspace(0, 1, height), np.linspace(0, 1, width), indexing="ij")
+        self.all_features: List[np.ndarray] = []
+        self.case_params: List[Dict[str, float]] = []
+        mask = np.ones((height, width), np.float32)
+        if border_mask:
+            mask[0, :] = mask[-1, :] = mask[:, 0] = 0.0
+        for _ in range(n_cases):
+            vel, dens, visc = rng.uniform(0.5, 1.5), rng.uniform(0.5, 1.5), rng.uniform(0.5, 1.5)
+            amp = rng.standard_normal((2, 3, 3)) / (1.0 + np.arange(3)[None, :, None] + np.arange(3)[None, None, :])
+            frames = []
+            for t in range(n_frames):
+                ph = 0.15 * t * vel
+                u = sum(amp[0, k, l] * np.sin(2 * np.pi * (k * xx + l * yy) + ph) for k in range(3) for l in range(3))
+                v = sum(amp[1, k, l] * np.cos(2 * np.pi * (k * xx - l * yy) + ph * dens) for k in range(3) for l in range(3))
+                frames.append(np.stack([u * mask, v * mask, mask]).astype(np.float32))
+            self.all_features.append(np.stack(frames))
+            self.case_params.append(dict(vel_top=float(vel), density=float(dens), viscosity=float(visc),
+                                         height=1.0, width=1.0))
+        self.index: List[Tuple[int, int]] = [(c, t) for c in range(n_cases) for t in range(n_frames - 1)]
+
+    def __len__(self) -> int:
+        return len(self.index)
+
+    def __getitem__(self, i: int):
+        c, t = self.index[i]
+        f = self.all_features[c]
+        return torch.from_numpy(f[t]), torch.from_numpy(f[t + 1]), self.case_params[c]
+
+
+def get_auto_dataset(data_dir: Path, data_name: str, delta_time: float, norm_props: bool, norm_bc: bool,
+                     load_splits: Optional[List[str]] = None):
+    """(train, dev, test) CfdAutoDatasets via the reference's loaders (src/dataset/__init__.py:64)."""
+    try:
+        from dataset import get_auto_dataset as ref_get  # the CFDBench checkout's package
+    except Exception as e:  # noqa: BLE001
+        raise RuntimeError(
+            "cfdbench_amd ships the hot path, not CFDBench's dataset loaders: put the CFDBench `src/` directory on "
+            "PYTHONPATH so that `import dataset` resolves (its loaders are NumPy-only), or pass your own Dataset objects "
+            f"to train()/evaluate().  ({e})") from e
+    kw = {} if load_splits is None else dict(load_splits=load_splits)
+    return ref_get(data_dir=Path(data_dir), data_name=data_name, delta_time=delta_time, norm_props=norm_props,
+                   norm_bc=norm_bc, **kw)

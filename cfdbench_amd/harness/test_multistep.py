@@ -1,0 +1,101 @@
+"""Multi-step rollout inference with the reference's metric conventions (src/test_multistep.py:73-239):
+per step and per case, u channel only, ``preds*mask`` vs ``label*mask`` with prediction k (= frame k+1) compared
+against label frame k, averaged over cases -> multistep_metrics.json.
+
+    python -m cfdbench_amd.harness.test_multistep --model fno --data dam_prop_bc_geo --infer_steps 200
+
+Cases are independent, so ``infer`` rolls ALL cases out as one batch (one launch sequence per step instead of one per
+case and step); ``infer_case`` keeps the reference's one-case entry point.  Metrics are reduced on the device and
+fetched once at the end instead of three ``.item()`` syncs per case and step.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, List
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from .args import Args
+from .autoregressive import init_model
+from .common import dump_json, get_output_dir, load_best_ckpt
+
+
+def get_metrics(preds: Tensor, labels: Tensor) -> Dict[str, float]:  # test_multistep.py:73-82
+    assert preds.shape == labels.shape, f"{preds.shape}, {labels.shape}"
+    mse = ((preds - labels) ** 2).mean().detach().cpu().item()
+    nmse = mse / ((labels ** 2).mean()).detach().cpu().item()
+    mae = F.l1_loss(preds, labels).detach().cpu().item()
+    return dict(mse=mse, nmse=nmse, mae=mae)
+
+
+def case_params_to_tensor(case_params_dict: dict) -> Tensor:  # test_multistep.py:85-92
+    keys = [x for x in case_params_dict.keys() if x not in ["rotated", "dx", "dy"]]
+    return torch.tensor([case_params_dict[k] for k in keys], dtype=torch.float32)
+
+
+def infer_case(model, case_features: Tensor, case_params: Tensor, infer_steps: int) -> List[Tensor]:
+    """One case: start from frame 0 (channels [:-1]) with mask = last channel (test_multistep.py:102-132)."""
+    with torch.no_grad():
+        return model.generate_many(inputs=case_features[0, :-1], case_params=case_params, mask=case_features[0, -1],
+                                   steps=infer_steps)
+
+
+def infer(model, all_features: List[Tensor], all_case_params: List[Tensor], infer_steps: int) -> List[Dict[str, float]]:
+    """test_multistep.py:135-177 with the cases batched.  all_features[c]: (>=infer_steps, c+1, h, w) on the device."""
+    n_cases = len(all_features)
+    start = torch.stack([f[0, :-1] for f in all_features])          # (n, c, h, w)
+    mask = torch.stack([f[0, -1] for f in all_features])            # (n, h, w)
+    cps = torch.stack(list(all_case_params))                        # (n, p)
+    with torch.no_grad():
+        preds = model.generate_many(inputs=start, case_params=cps, mask=mask, steps=infer_steps)
+    sums = torch.empty(infer_steps, n_cases, 3, device=start.device)
+    for step in range(infer_steps):
+        lab = torch.stack([f[step, 0] * f[step, -1] for f in all_features])   # u channel of label frame `step`, masked
+        msk = torch.stack([f[step, -1] for f in all_features])
+        p = preds[step][:, 0] * msk
+        d = p - lab
+        n = float(d[0].numel())
+        sums[step, :, 0] = (d * d).flatten(1).sum(1) / n
+        sums[step, :, 1] = (lab * lab).flatten(1).sum(1) / n
+        sums[step, :, 2] = d.abs().flatten(1).sum(1) / n
+    s = sums.double().cpu().numpy()
+    all_metrics = []
+    for step in range(infer_steps):
+        mse, l2, mae = s[step, :, 0], s[step, :, 1], s[step, :, 2]
+        all_metrics.append(dict(mse=float(np.mean(mse)), nmse=float(np.mean(mse / l2)), mae=float(np.mean(mae))))
+    return all_metrics
+
+
+def prepare_cases(test_data, infer_steps: int, device="cuda"):
+    """Pad every case to >= infer_steps frames by repeating the last frame (steady state), move to the device
+    (test_multistep.py:201-218)."""
+    feats, cps = [], []
+    for case_features, case_params in zip(test_data.all_features, test_data.case_params):
+        case_features = np.asarray(case_features)
+        if case_features.shape[0] < infer_steps:
+            pad = np.repeat(case_features[-1:], infer_steps - case_features.shape[0], axis=0)
+            case_features = np.concatenate([case_features, pad], axis=0)
+        feats.append(torch.as_tensor(case_features, dtype=torch.float32).to(device))
+        cps.append(case_params_to_tensor(case_params).to(device))
+    return feats, cps
+
+
+def main(argv=None):
+    from .data import get_auto_dataset
+    args = Args().parse_args(argv)
+    print(args)
+    _, _, test_data = get_auto_dataset(data_dir=Path(args.data_dir), data_name=args.data_name, delta_time=args.delta_time,
+                                       norm_props=bool(args.norm_props), norm_bc=bool(args.norm_bc), load_splits=["test"])
+    feats, cps = prepare_cases(test_data, args.infer_steps)
+    model = init_model(args).cuda()
+    output_dir = get_output_dir(args, is_auto=True)
+    load_best_ckpt(model, output_dir)
+    all_metrics = infer(model, feats, cps, args.infer_steps)
+    dump_json(all_metrics, output_dir / "multistep_metrics.json")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,223 @@
+"""Autoregressive train / eval / test loop with the reference's behaviour and artefacts (src/train_auto.py:33-381).
+
+    python -m cfdbench_amd.harness.train_auto --model fno --data cavity_prop_bc_geo --loss_name nmse --fno_hidden_dim 20
+
+Two training paths:
+  * default -- the reference's own sequence ``model(**batch)`` -> ``loss["nmse"].backward()`` -> ``Adam.step()``
+    (train_auto.py:231-257) on the drop-in ``Fno2d`` (one autograd node over the HIP kernels);
+  * ``--fused 1`` -- ``FnoTrainEngine``: forward + nMSE + backward + flat Adam as C-ABI calls without autograd and
+    without the per-step ``.item()`` host sync (scores are read every ``log_interval`` steps only).
+Both use Adam(lr) + StepLR(lr_step_size, gamma) per epoch and write the same files: ckpt-{ep}/{model.pt,
+dev_scores.json, train_loss.json, scores.json}, train_losses.json, test/{preds.pt, scores.json}, args.json.
+Under torch.distributed (one process per GPU) each rank trains on its shard of the frames, gradients are summed over
+ranks (engine path), and rank 0 alone writes files.
+"""
+from __future__ import annotations
+
+import time
+from copy import deepcopy
+from pathlib import Path
+from shutil import copyfile
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import Tensor
+from torch.optim import Adam, lr_scheduler
+from torch.utils.data import DataLoader, Subset
+
+from ..engine import FnoTrainEngine, shard_range
+from ..models.base_model import AutoCfdModel
+from ..models.fno.fno2d import Fno2d
+from .args import Args
+from .autoregressive import init_model
+from .common import dump_json, get_output_dir, load_best_ckpt, plot, plot_loss, plot_predictions
+
+
+def collate_fn(batch: list, device: Optional[str] = "cuda"):
+    """list of (input (3,h,w), label (3,h,w), case_params dict) -> kwargs of the model's forward (train_auto.py:33-58):
+    the last channel is the mask; case_params = all case.json keys except rotated/dx/dy, in key order."""
+    inputs, labels, case_params = zip(*batch)
+    inputs = torch.stack(inputs)
+    labels = torch.stack(labels)
+    labels = labels[:, :-1]
+    mask = inputs[:, -1:]
+    inputs = inputs[:, :-1]
+    keys = [x for x in case_params[0].keys() if x not in ["rotated", "dx", "dy"]]
+    case_params_t = torch.tensor([[cp[k] for k in keys] for cp in case_params], dtype=torch.float32)
+    out = dict(inputs=inputs, label=labels, mask=mask, case_params=case_params_t)
+    if device is not None:
+        out = {k: v.to(device, non_blocking=True).contiguous() for k, v in out.items()}
+    return out
+
+
+def _rank_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def evaluate(model: AutoCfdModel, data, output_dir: Path, batch_size: int = 2, plot_interval: int = 1,
+             measure_time: bool = False):
+    """Single-step evaluation (train_auto.py:61-148): identity baseline + model scores per batch, predictions."""
+    loader = DataLoader(data, batch_size=batch_size, shuffle=False, collate_fn=collate_fn)
+    scores = {name: [] for name in model.loss_fn.get_score_names()}
+    input_scores = deepcopy(scores)
+    all_preds: List[Tensor] = []
+    start_time = time.time()
+    model.eval()
+    with torch.inference_mode():
+        for step, batch in enumerate(loader):
+            inputs, labels = batch["inputs"], batch["label"]
+            input_loss = model.loss_fn(labels=labels[:, :1], preds=inputs[:, :1])  # train_auto.py:93
+            for key in input_scores:
+                input_scores[key].append(input_loss[key].cpu().tolist())
+            outputs = model(**batch)
+            loss, preds = outputs["loss"], outputs["preds"]
+            height, width = labels.shape[2:]
+            preds = preds.view(-1, 1, height, width)  # train_auto.py:106
+            for key in scores:
+                scores[key].append(loss[key].cpu().tolist())
+            all_preds.append(preds.cpu().detach())
+            if plot_interval > 0 and step % plot_interval == 0 and not measure_time:
+                plot_predictions(inp=inputs[0][0], label=labels[0][0], pred=preds[0][0], out_dir=Path(output_dir) / "images",
+                                 step=step)
+    if measure_time:
+        print(f"Time (ms) per step: {1000 * (time.time() - start_time) / max(len(loader), 1):.3f}")
+    avg_scores = {}
+    for key in scores:
+        avg_scores[key] = float(np.mean(scores[key]))
+        avg_scores[f"input_{key}"] = float(np.mean(input_scores[key]))
+    if "nmse" in scores:
+        plot_loss(scores["nmse"], Path(output_dir) / "loss.png")
+    return dict(preds=torch.cat(all_preds, dim=0), scores=dict(mean=avg_scores, all=scores))
+
+
+def test(model: AutoCfdModel, data, output_dir: Path, infer_steps: int = 200, plot_interval: int = 10,
+         batch_size: int = 1, measure_time: bool = False):
+    """train_auto.py:151-178: evaluate on the test split, write preds.pt and scores.json."""
+    assert infer_steps > 0 and plot_interval > 0
+    output_dir = Path(output_dir)
+    output_dir.mkdir(exist_ok=True, parents=True)
+    result = evaluate(model, data, output_dir=output_dir, batch_size=batch_size, plot_interval=plot_interval,
+                      measure_time=measure_time)
+    torch.save(result["preds"], output_dir / "preds.pt")
+    dump_json(result["scores"], output_dir / "scores.json")
+    return result
+
+
+def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epochs: int = 400, lr: float = 1e-3,
+          lr_step_size: int = 1, lr_gamma: float = 0.9, batch_size: int = 2, eval_batch_size: int = 2,
+          log_interval: int = 10, eval_interval: int = 2, measure_time: bool = False, fused: bool = False,
+          plot_interval: int = 1):
+    """train_auto.py:181-313.  ``fused`` selects FnoTrainEngine (needs an Fno2d and the nmse loss)."""
+    rank, world = _rank_world()
+    output_dir = Path(output_dir)
+    if world > 1:  # shard the frames: each rank owns a contiguous 1/world of a fixed permutation
+        perm = torch.randperm(len(train_data), generator=torch.Generator().manual_seed(0)).tolist()
+        a, b = shard_range(len(perm), rank, world)
+        train_data = Subset(train_data, perm[a:b])
+    train_loader = DataLoader(train_data, batch_size=batch_size, shuffle=True, collate_fn=collate_fn,
+                              drop_last=world > 1)
+    if rank == 0:
+        output_dir.mkdir(exist_ok=True, parents=True)
+    engine = None
+    if fused:
+        if not isinstance(model, Fno2d):
+            raise NotImplementedError("--fused 1 needs the fno model")
+        engine = FnoTrainEngine(model, lr=lr, loss_name="nmse")
+    else:
+        optimizer = Adam(model.parameters(), lr=lr)
+        scheduler = lr_scheduler.StepLR(optimizer, step_size=lr_step_size, gamma=lr_gamma)
+    start_time = time.time()
+    global_step = 0
+    train_losses: List[float] = []
+    for ep in range(num_epochs):
+        ep_start_time = time.time()
+        cur_lr = lr * lr_gamma ** (ep // lr_step_size)  # what StepLR(step_size, gamma) yields in epoch ep
+        ep_train_losses: List = []
+        model.train()
+        for step, batch in enumerate(train_loader):
+            if engine is not None:
+                engine.lr = cur_lr
+                sums = engine.train_step(batch["inputs"], batch["label"], batch["case_params"], batch["mask"])
+                # nmse = sum sq err / sum sq label; kept on the device, fetched once per epoch (no per-step host sync)
+                ep_train_losses.append((sums[0] / sums[2]).clone())
+                loss_mse = loss_nmse = None
+            else:
+                outputs = model(**batch)
+                if step == 0 and not measure_time and rank == 0 and plot_interval > 0:
+                    plot(batch["inputs"][0][0], batch["label"][0][0], outputs["preds"][0][0].detach(), Path("example.png"))
+                loss = outputs["loss"]
+                loss["nmse"].backward()  # train_auto.py:255
+                optimizer.step()
+                optimizer.zero_grad()
+                ep_train_losses.append(loss["nmse"].item())  # train_auto.py:260
+                loss_mse, loss_nmse = loss["mse"], loss["nmse"]
+            global_step += 1
+            if global_step % log_interval == 0 and rank == 0:
+                if engine is not None:
+                    sc = engine.scores()
+                    mse_v, nmse_v = sc["mse"], sc["nmse"]
+                else:
+                    mse_v, nmse_v = loss_mse.item(), loss_nmse.item()
+                print(dict(ep=ep, step=step, mse=f"{mse_v:.3e}", nmse=f"{nmse_v:.3e}", lr=f"{cur_lr:.3e}",
+                           time=round(time.time() - start_time)))
+        if engine is not None:
+            ep_train_losses = torch.stack(ep_train_losses).tolist() if ep_train_losses else []
+        else:
+            scheduler.step()
+        if measure_time:
+            print("Time usage:", time.time() - ep_start_time)
+            return
+        train_losses += ep_train_losses
+        if (ep + 1) % eval_interval == 0 and rank == 0:
+            ckpt_dir = output_dir / f"ckpt-{ep}"
+            ckpt_dir.mkdir(exist_ok=True, parents=True)
+            result = evaluate(model, dev_data, ckpt_dir, batch_size=eval_batch_size, plot_interval=plot_interval)
+            dev_scores = result["scores"]
+            dump_json(dev_scores, ckpt_dir / "dev_scores.json")
+            dump_json(ep_train_losses, ckpt_dir / "train_loss.json")
+            ckpt_path = ckpt_dir / "model.pt"
+            if ckpt_path.exists():
+                copyfile(ckpt_path, ckpt_dir / "backup_model.pt")
+            torch.save(model.state_dict(), ckpt_path)  # bare state_dict, reference key names (train_auto.py:301)
+            dump_json(dict(ep=ep, train_loss=float(np.mean(ep_train_losses)), dev_loss=float(np.mean(dev_scores["all"]["nmse"])),
+                           time=time.time() - ep_start_time), ckpt_dir / "scores.json")
+        if world > 1:
+            dist.barrier()
+    if rank == 0:
+        dump_json(train_losses, output_dir / "train_losses.json")
+        plot_loss(train_losses, output_dir / "train_losses.png")
+    return train_losses
+
+
+def main(argv=None):
+    from .data import get_auto_dataset
+    args = Args().parse_args(argv)
+    print("#" * 80)
+    print(args)
+    print("#" * 80)
+    output_dir = get_output_dir(args, is_auto=True)
+    output_dir.mkdir(exist_ok=True, parents=True)
+    args.save(str(output_dir / "args.json"))
+    train_data, dev_data, test_data = get_auto_dataset(
+        data_dir=Path(args.data_dir), data_name=args.data_name, delta_time=args.delta_time,
+        norm_props=bool(args.norm_props), norm_bc=bool(args.norm_bc))
+    model = init_model(args).cuda()  # the reference forgets .cuda() for FNO
+    print(f"Model has {sum(p.numel() for p in model.parameters())} parameters")
+    if "train" in args.mode:
+        args.save(str(output_dir / "train_args.json"))
+        train(model, train_data=train_data, dev_data=dev_data, output_dir=output_dir, lr=args.lr,
+              lr_step_size=args.lr_step_size, lr_gamma=args.lr_gamma, num_epochs=args.num_epochs,
+              batch_size=args.batch_size, eval_batch_size=args.eval_batch_size, eval_interval=args.eval_interval,
+              log_interval=args.log_interval, fused=bool(args.fused), plot_interval=args.plot_interval)
+    if "test" in args.mode:
+        args.save(str(output_dir / "test_args.json"))
+        load_best_ckpt(model, output_dir)
+        test(model, test_data, output_dir / "test", batch_size=1, infer_steps=20, plot_interval=10)
+
+
+if __name__ == "__main__":
+    main()

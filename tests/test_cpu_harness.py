@@ -1,0 +1,83 @@
+"""CPU: host logic of the harness (flags, result tree, collate, checkpoint selection, case sharding) against the
+reference's conventions (src/args.py, src/utils/common.py, src/train_auto.py:33-58, src/test_multistep.py:85-92)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from cfdbench_amd.harness.args import Args
+from cfdbench_amd.harness.autoregressive import get_input_shapes
+from cfdbench_amd.harness.common import dump_json, get_best_ckpt, get_output_dir
+from cfdbench_amd.harness.data import SyntheticAutoDataset
+from cfdbench_amd.harness.test_multistep import case_params_to_tensor
+from cfdbench_amd.harness.train_auto import collate_fn
+
+
+def test_flag_defaults_match_reference():
+    a = Args()
+    # src/args.py:22-217 (values read from the reference source)
+    expect = dict(mode="train", seed=0, output_dir="result", lr=1e-4, weight_decay=1e-5, num_epochs=100, batch_size=8,
+                  eval_batch_size=16, loss_name="mse", log_interval=50, eval_interval=2, data_name="cylinder_geo",
+                  data_dir="../data", num_rows=64, num_cols=64, delta_time=0.1, norm_props=1, norm_bc=1,
+                  model="pixel_diffusion", in_chan=2, out_chan=2, fno_depth=4, fno_hidden_dim=32, fno_modes_x=12,
+                  fno_modes_y=12, unet_dim=12, unet_insert_case_params_at="input", resnet_depth=4, resnet_hidden_chan=16,
+                  resnet_kernel_size=7, deeponet_width=100, branch_depth=8, trunk_depth=8, act_fn="relu",
+                  act_scale_invariant=1, act_on_output=0, ffn_depth=8, ffn_width=100, autoffn_depth=8, autoffn_width=200)
+    for k, v in expect.items():
+        assert getattr(a, k) == v, k
+
+
+def test_cli_parsing_data_alias_and_save(tmp_path):
+    a = Args().parse_args(["--model", "fno", "--data", "cavity_prop_bc_geo", "--loss_name", "nmse", "--fno_hidden_dim", "20",
+                           "--lr", "0.001"])
+    assert a.data_name == "cavity_prop_bc_geo" and a.fno_hidden_dim == 20 and a.lr_step_size == 20
+    p = tmp_path / "args.json"
+    a.save(str(p))
+    d = json.loads(p.read_text())
+    assert d["model"] == "fno" and d["loss_name"] == "nmse"
+    with pytest.raises(SystemExit):
+        Args().parse_args(["--dat", "x"])  # no prefix matching: --data_name / --data_dir would be ambiguous
+
+
+def test_output_dir_scheme():
+    a = Args(model="fno", data_name="cavity_bc", lr=0.001, fno_hidden_dim=20)
+    assert str(get_output_dir(a, is_auto=True)) == "result/auto/cavity_bc/dt0.1/fno/lr0.001_d4_h20_m112_m212"
+    a = Args(model="unet", data_name="cylinder_prop_bc_geo")
+    assert str(get_output_dir(a, is_auto=True)) == "result/auto/cylinder_prop_bc_geo/dt0.1/unet/lr0.0001_d12_cpinput"
+    a = Args(model="deeponet", data_name="tube_prop_geo")
+    assert str(get_output_dir(a, is_auto=False)).endswith(
+        "non-auto/tube_prop_geo/dt0.1/deeponet/lr0.0001_width100_depthb8_deptht8_normprop1_actrelu-1-0")
+    a = Args(model="auto_deeponet", data_name="tube_prop_geo")
+    assert str(get_output_dir(a, True)).endswith("auto_deeponet/lr0.0001_width100_depthb8_deptht8_normprop1_actrelu")
+
+
+def test_input_shapes():
+    assert get_input_shapes(Args(data_name="cavity_prop_bc_geo")) == (64, 64, 5)
+    assert get_input_shapes(Args(data_name="dam_prop_bc_geo")) == (66, 65, 5)
+    assert get_input_shapes(Args(data_name="cylinder_geo")) == (66, 65, 8)
+
+
+def test_collate_splits_mask_and_orders_case_params():
+    ds = SyntheticAutoDataset(n_cases=2, n_frames=3, height=8, width=8, seed=1)
+    items = [ds[0], ds[3]]
+    # case.json may carry rotated/dx/dy, which the reference drops (train_auto.py:44-47)
+    items[0] = (items[0][0], items[0][1], dict(items[0][2], rotated=1, dx=0.1, dy=0.2))
+    items[1] = (items[1][0], items[1][1], dict(items[1][2], rotated=0, dx=0.1, dy=0.2))
+    b = collate_fn(items, device=None)
+    assert b["inputs"].shape == (2, 2, 8, 8) and b["label"].shape == (2, 2, 8, 8) and b["mask"].shape == (2, 1, 8, 8)
+    assert b["case_params"].shape == (2, 5)
+    np.testing.assert_allclose(b["case_params"][0].numpy(),
+                               [items[0][2][k] for k in ("vel_top", "density", "viscosity", "height", "width")], rtol=1e-6)
+    assert torch.equal(b["mask"][0, 0], items[0][0][-1]) and torch.equal(b["label"][1], items[1][1][:-1])
+    t = case_params_to_tensor(items[0][2])
+    assert torch.allclose(t, b["case_params"][0])
+
+
+def test_best_checkpoint_selection(tmp_path):
+    assert get_best_ckpt(tmp_path) is None
+    for ep, loss in ((1, 0.5), (3, 0.2), (5, 0.3)):
+        d = tmp_path / f"ckpt-{ep}"
+        d.mkdir()
+        dump_json(dict(ep=ep, train_loss=1.0, dev_loss=loss, time=1.0), d / "scores.json")
+    assert get_best_ckpt(tmp_path).name == "ckpt-3"

@@ -1,0 +1,145 @@
+"""MI355X: the harness end to end on a synthetic dataset (train both paths, checkpoint tree, test, multi-step inference)
+and the HIP-graph rollout against Fno2d.generate_many and the golden rollouts of the reference."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import fno_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _args(tmp_path, **kw):
+    from cfdbench_amd.harness.args import Args
+    return Args(model="fno", data_name="cavity_bc", loss_name="nmse", fno_hidden_dim=8, fno_depth=2, lr=2e-3,
+                output_dir=str(tmp_path), num_epochs=4, batch_size=4, eval_batch_size=4, eval_interval=2, log_interval=5,
+                plot_interval=0, **kw)
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+def test_train_eval_test_artifacts(torch, tmp_path, fused):
+    from cfdbench_amd.harness.autoregressive import init_model
+    from cfdbench_amd.harness.common import get_best_ckpt, get_output_dir, load_best_ckpt, load_json
+    from cfdbench_amd.harness.data import SyntheticAutoDataset
+    from cfdbench_amd.harness.train_auto import test, train
+    args = _args(tmp_path, fused=fused)
+    out = get_output_dir(args, is_auto=True)
+    tr = SyntheticAutoDataset(n_cases=6, n_frames=6, height=64, width=64, seed=0)
+    dev = SyntheticAutoDataset(n_cases=2, n_frames=4, height=64, width=64, seed=1)
+    torch.manual_seed(0)
+    model = init_model(args).cuda()
+    losses = train(model, tr, dev, out, num_epochs=args.num_epochs, lr=args.lr, lr_step_size=args.lr_step_size,
+                   lr_gamma=args.lr_gamma, batch_size=args.batch_size, eval_batch_size=args.eval_batch_size,
+                   log_interval=args.log_interval, eval_interval=args.eval_interval, fused=bool(fused), plot_interval=0)
+    assert len(losses) == 4 * ((len(tr) + 3) // 4)
+    assert np.mean(losses[-4:]) < 0.7 * np.mean(losses[:4]), "training does not reduce the nMSE"
+    for ep in (1, 3):
+        d = out / f"ckpt-{ep}"
+        assert (d / "model.pt").exists() and (d / "dev_scores.json").exists() and (d / "train_loss.json").exists()
+        sc = load_json(d / "scores.json")
+        assert set(sc) == {"ep", "train_loss", "dev_loss", "time"}
+        ds = load_json(d / "dev_scores.json")
+        assert set(ds) == {"mean", "all"} and set(ds["all"]) == {"mse", "rmse", "mae", "nmse"}
+        assert "input_nmse" in ds["mean"]
+    assert (out / "train_losses.json").exists()
+    # checkpoint = bare state_dict with the reference's keys / dtypes
+    sd = torch.load(get_best_ckpt(out) / "model.pt", map_location="cpu")
+    assert sd["blocks.0.conv0.weights1"].dtype == torch.complex64 and "fc2.bias" in sd
+    m2 = init_model(args).cuda()
+    load_best_ckpt(m2, out)
+    res = test(m2, dev, out / "test", batch_size=1, plot_interval=10)
+    assert (out / "test" / "preds.pt").exists() and (out / "test" / "scores.json").exists()
+    assert res["preds"].shape == (2 * len(dev), 1, 64, 64)
+
+
+def test_fused_and_autograd_paths_agree(torch, tmp_path):
+    """Same data order, same init: FnoTrainEngine's steps == autograd + torch.optim.Adam steps."""
+    from cfdbench_amd.engine import FnoTrainEngine
+    from cfdbench_amd.harness.autoregressive import init_model
+    from cfdbench_amd.harness.data import SyntheticAutoDataset
+    from cfdbench_amd.harness.train_auto import collate_fn
+    args = _args(tmp_path)
+    ds = SyntheticAutoDataset(n_cases=2, n_frames=5, height=64, width=64, seed=3)
+    batches = [collate_fn([ds[i] for i in range(k, k + 4)]) for k in (0, 4)]
+    torch.manual_seed(0)
+    ma = init_model(args).cuda()
+    mb = init_model(args).cuda()
+    mb.load_state_dict(ma.state_dict())
+    opt = torch.optim.Adam(ma.parameters(), lr=1e-3)
+    eng = FnoTrainEngine(mb, lr=1e-3, loss_name="nmse")
+    for b in batches * 2:
+        ma(**b)["loss"]["nmse"].backward()
+        opt.step()
+        opt.zero_grad()
+        eng.train_step(b["inputs"], b["label"], b["case_params"], b["mask"])
+    for (k, pa), (_, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        a = torch.view_as_real(pa) if pa.is_complex() else pa
+        bb = torch.view_as_real(pb) if pb.is_complex() else pb
+        assert O.rel_nmse(bb.cpu().numpy(), a.cpu().numpy()) < 1e-9, k
+
+
+def test_multistep_inference_metrics(torch, tmp_path):
+    from cfdbench_amd.harness.autoregressive import init_model
+    from cfdbench_amd.harness.data import SyntheticAutoDataset
+    from cfdbench_amd.harness.test_multistep import get_metrics, infer, infer_case, prepare_cases
+    args = _args(tmp_path)
+    torch.manual_seed(1)
+    model = init_model(args).cuda()
+    data = SyntheticAutoDataset(n_cases=3, n_frames=4, height=64, width=64, seed=5, border_mask=True)
+    steps = 6  # > n_frames: cases are padded with their last frame
+    feats, cps = prepare_cases(data, steps)
+    assert all(f.shape[0] == steps for f in feats)
+    metrics = infer(model, feats, cps, steps)
+    assert len(metrics) == steps and set(metrics[0]) == {"mse", "nmse", "mae"}
+    # the reference's per-case / per-step formulation (test_multistep.py:144-176)
+    ref = []
+    preds = [infer_case(model, f, c, steps) for f, c in zip(feats, cps)]
+    for s in range(steps):
+        ms = []
+        for c in range(3):
+            msk = feats[c][s][-1]
+            ms.append(get_metrics(preds[c][s][0][0] * msk, feats[c][s][0] * msk))
+        ref.append({k: float(np.mean([m[k] for m in ms])) for k in ms[0]})
+    for a, b in zip(metrics, ref):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-5 * abs(b[k]) + 1e-12, (k, a[k], b[k])
+
+
+@pytest.mark.parametrize("name", ["rollout_small_64x64", "rollout_small_66x65"])
+def test_graph_rollout_matches_generate_many_and_reference_golden(torch, golden_dir, name):
+    from cfdbench_amd.models.fno.fno2d import Fno2d
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    from cfdbench_amd.rollout import FnoRollout
+    from oracle import synth
+    g = np.load(golden_dir / f"{name}.npz")
+    pseed, bseed, B, C, L, H, W, p, steps, border = [int(v) for v in g["meta"]]
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=float(g["gain"]))
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    if border:
+        batch["mask"][:, :, 0, :] = 0
+        batch["mask"][:, :, -1, :] = 0
+        batch["mask"][:, :, :, 0] = 0
+    model = Fno2d(2, 2, p, loss_name_to_fn("nmse"), L, 12, 12, C).cuda()
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()})
+    x, cp, mask = (torch.from_numpy(batch[k]).cuda() for k in ("inputs", "case_params", "mask"))
+    with torch.no_grad():
+        plain = model.generate_many(x, cp, mask, steps)
+    ro = FnoRollout(model)
+    fast = ro.generate_many(x, cp, mask, steps)
+    again = ro.generate_many(x, cp, mask, steps)  # replay from the cached graph
+    for t in range(steps):
+        assert torch.equal(plain[t], fast[t]) and torch.equal(fast[t], again[t])
+    # vs the reference's own rollout (oracle/make_golden.py: gen_rollout), north-star tolerance and far tighter
+    assert O.rel_nmse(fast[0].cpu().numpy(), g["first"]) < 1e-9
+    assert O.rel_nmse(fast[-1].cpu().numpy(), g["last"]) < 1e-7
+    # unbatched entry point
+    one = ro.generate_many(x[0], cp[0], mask[0, 0], 2)
+    assert tuple(one[0].shape) == (1, 2, H, W) and O.rel_nmse(one[1].cpu().numpy(), fast[1][:1].cpu().numpy()) < 1e-10
