@@ -182,7 +182,9 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
             ckpt_path = ckpt_dir / "model.pt"
             if ckpt_path.exists():
                 copyfile(ckpt_path, ckpt_dir / "backup_model.pt")
-            torch.save(model.state_dict(), ckpt_path)  # bare state_dict, reference key names (train_auto.py:301)
+            # bare state_dict with the reference's key names (train_auto.py:301); cloned because under the fused engine
+            # the parameters are float/complex views of ONE flat buffer, which torch.save refuses to serialise as is
+            torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, ckpt_path)
             dump_json(dict(ep=ep, train_loss=float(np.mean(ep_train_losses)), dev_loss=float(np.mean(dev_scores["all"]["nmse"])),
                            time=time.time() - ep_start_time), ckpt_dir / "scores.json")
         if world > 1:
