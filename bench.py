@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward from a HIP graph")
+    ap.add_argument("--no-rollout", action="store_true")
+    ap.add_argument("--rollout-batch", type=int, default=64)
+    ap.add_argument("--rollout-steps", type=int, default=200)
     return ap.parse_args()
 
 
@@ -190,6 +193,16 @@ def main():
         result["kernels"] = kern
         dom = rows[0]
         result["roofline"] = roofline_of(dom[0], dom[2] / dom[1], model_bytes)
+        # HBM traffic per launch of the dominant kernel: rocprofv3 PMC passes of this same command
+        # (tools/profile_step.sh: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), committed under profiles/
+        try:
+            pmc = json.loads(sorted((REPO / "profiles").glob("r*_pmc_traffic.json"))[-1].read_text())
+            match = [v for k, v in pmc.items() if k.startswith(dom[0] + "<") or k == dom[0]]
+            if match and B == 256 and C == 20:
+                result["roofline"]["traffic"] = int(sum(m["traffic_bytes"] for m in match) / len(match))
+                result["roofline"]["traffic_source"] = "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch)"
+        except Exception:  # noqa: BLE001
+            pass
         # north-star kernel group: SpectralConv2d forward+backward alone, algorithmic bytes 5N + 3Wb
         plan = _lib.plan(H, W, 12, 12, dev.index)
         x = torch.randn(B, C, H, W, device=dev)
@@ -227,6 +240,27 @@ def main():
             what="SpectralConv2d fwd+bwd (dft, mix, idft | dft, wgrad, mix_adj, idft)", bound="hbm",
             algorithmic_bytes=alg, avg_us=round(us, 2), achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
             frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None)
+
+    # ---- rollout leg (rank 0): batched multi-step inference from one HIP graph (BASELINE metric's "rollout" half) ---
+    if rank == 0 and not args.no_rollout:
+        from cfdbench_amd.rollout import FnoRollout
+        Br, steps_r = args.rollout_batch, args.rollout_steps
+        ro = FnoRollout(model)
+        x0 = inputs[:Br].contiguous()
+        fr = ro.generate_many(x0, cp[:Br].contiguous(), mask[:Br].contiguous(), steps_r)  # builds + captures the graph
+        torch.cuda.synchronize()
+        t0r = time.perf_counter()
+        reps_r = 3
+        for _ in range(reps_r):
+            fr = ro.generate_many(x0, cp[:Br].contiguous(), mask[:Br].contiguous(), steps_r)
+        torch.cuda.synchronize()
+        dtr = (time.perf_counter() - t0r) / reps_r
+        with torch.no_grad():
+            plain = model.generate_many(x0, cp[:Br].contiguous(), mask[:Br].contiguous(), 3)
+        result["rollout"] = dict(
+            what=f"FnoRollout.generate_many: {Br} cases x {steps_r} steps, {H}x{W}, fp32, one HIP graph per horizon",
+            frames_per_s=round(Br * steps_r / dtr, 1), ms_per_step=round(dtr / steps_r * 1e3, 4),
+            bitwise_equal_to_generate_many=bool(all(torch.equal(a, b) for a, b in zip(plain, fr[:3]))))
 
     # ---- CPU baseline leg (rank 0, N=1): the reference's ATen call sequence on the host cores ------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
