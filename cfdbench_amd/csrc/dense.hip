@@ -1,0 +1,298 @@
+// Dense layers of the DeepONet family on the CDNA4 matrix pipe (exact-fp32 v_mfma_f32_16x16x4_f32):
+//   nn.Linear + activation stacks  (Ffn, src/models/ffn.py:12-35)             -> cfd_linear_fwd / cfd_linear_bwd
+//   branch x trunk inner product   (src/models/auto_deeponet.py:127-135,
+//                                   src/models/deeponet.py:204-205)           -> cfd_deeponet_inner_fwd / _bwd
+// The reference materialises the (b, k, p) broadcast product (879 MB at B=512 on the 66x65 lattice) and sums it; here
+// it is one GEMM whose epilogue adds the bias and gathers the residual u[b, query].  All of these are instances of
+// one LDS-tiled kernel C = epi(op(A) op(B)): 64x64 block tile, 4 waves x (2x2) MFMA tiles, K in slabs of 16 that are
+// prefetched into registers while the previous slab is on the matrix pipe.
+#include "cfd_common.h"
+
+#define GT 64   // block tile edge (M and N)
+#define GK 16   // K slab
+#define GLD 68  // LDS row stride in floats (64 + 4: keeps 16-B alignment for ds_write_b128, staggers banks)
+
+struct GemmEpi {
+    int mode;             // 0: store; 1: + bias[n], activation; 2: + bias[0] (+ resid[m*ldr + (qidx ? qidx[n] : n)])
+    int act;              // mode 1: 0 none, 1 relu, 2 tanh, 3 gelu (exact erf), 4 swish
+    const float* bias;
+    float* preact;        // mode 1: pre-activation copy (needed by the gelu / swish derivative), may be NULL
+    const float* resid;
+    const int* qidx;
+    int ldr;
+};
+
+__device__ __forceinline__ float cfd_act(float z, int act) {
+    switch (act) {
+        case 1: return z > 0.f ? z : 0.f;
+        case 2: return tanhf(z);
+        case 3: return cfd_gelu(z);
+        case 4: return z * cfd_rcpf(1.f + cfd_expf(-z));
+        default: return z;
+    }
+}
+
+// d act / d z from the layer output y (relu, tanh) or its pre-activation z (gelu, swish)
+__device__ __forceinline__ float cfd_act_grad(float y, float z, int act) {
+    switch (act) {
+        case 1: return y > 0.f ? 1.f : 0.f;
+        case 2: return 1.f - y * y;
+        case 3: return cfd_gelu_grad(z);
+        case 4: { const float s = cfd_rcpf(1.f + cfd_expf(-z)); return s * (1.f + z * (1.f - s)); }
+        default: return 1.f;
+    }
+}
+
+// One 64 x 16 slab of op(X) into registers.  KCONT: the source is k-contiguous (X stored [rows][K]); else it is
+// row-contiguous (X stored [K][rows]).  Either way s[k][row] is what lands in LDS.
+template <bool KCONT>
+struct SlabRegs {
+    float v[4];
+    __device__ __forceinline__ void load(const float* __restrict__ X, int ld, int rows, int K, int row0, int k0, int tid) {
+        if constexpr (KCONT) {
+            const int row = row0 + (tid >> 2), k = k0 + (tid & 3) * 4;
+            const float* p = X + (size_t)row * ld + k;
+            if (row < rows && k + 3 < K && ((((uintptr_t)p) & 15) == 0)) {
+                const float4 t = *reinterpret_cast<const float4*>(p);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (row < rows && k + j < K) ? p[j] : 0.f;
+            }
+        } else {
+            const int k = k0 + (tid >> 4), row = row0 + (tid & 15) * 4;
+            const float* p = X + (size_t)k * ld + row;
+            if (k < K && row + 3 < rows && ((((uintptr_t)p) & 15) == 0)) {
+                const float4 t = *reinterpret_cast<const float4*>(p);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (k < K && row + j < rows) ? p[j] : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* s, int tid) const {
+        if constexpr (KCONT) {
+            const int row = tid >> 2, k = (tid & 3) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[(k + j) * GLD + row] = v[j];
+        } else {
+            const int k = tid >> 4, row = (tid & 15) * 4;
+            *reinterpret_cast<float4*>(s + k * GLD + row) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+};
+
+// C[M][N] = epi( sum_k opA(m,k) opB(k,n) );  AT: A stored [K][M] (else [M][K]);  BT: B stored [N][K] (else [K][N]).
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, const float* __restrict__ B,
+                                              float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
+                                              GemmEpi epi) {
+    __shared__ __attribute__((aligned(16))) float s_a[2][GK * GLD];
+    __shared__ __attribute__((aligned(16))) float s_b[2][GK * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    SlabRegs<!AT> ra;  // A is k-contiguous unless transposed
+    SlabRegs<BT> rb;   // B is k-contiguous only when stored transposed
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][2] = {{zero, zero}, {zero, zero}};
+    const int nslab = (K + GK - 1) / GK;
+    ra.load(A, lda, M, K, m0, 0, tid);
+    rb.load(B, ldb, N, K, n0, 0, tid);
+    ra.store(s_a[0], tid);
+    rb.store(s_b[0], tid);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nslab) {  // next slab's global reads fly during this slab's MFMAs
+            ra.load(A, lda, M, K, m0, (s + 1) * GK, tid);
+            rb.load(B, ldb, N, K, n0, (s + 1) * GK, tid);
+        }
+        const float* sa = s_a[cur];
+        const float* sb = s_b[cur];
+#pragma unroll
+        for (int kk = 0; kk < GK / 4; ++kk) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                av[i] = sa[(4 * kk + q) * GLD + 32 * wm + 16 * i + n];
+                bv[i] = sb[(4 * kk + q) * GLD + 32 * wn + 16 * i + n];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = cfd_mfma16x16x4(av[i], bv[j], acc[i][j]);
+        }
+        if (s + 1 < nslab) {
+            ra.store(s_a[cur ^ 1], tid);  // the other buffer was last read before the previous barrier
+            rb.store(s_b[cur ^ 1], tid);
+        }
+        __syncthreads();
+    }
+    // acc[i][j][r] = C[m0 + 32wm + 16i + 4q + r][n0 + 32wn + 16j + n]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 32 * wn + 16 * j + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + 32 * wm + 16 * i + 4 * q + r;
+                if (row < M && col < N) {
+                    float v = acc[i][j][r];
+                    if (epi.mode == 1) {
+                        if (epi.bias) v += epi.bias[col];
+                        if (epi.preact) epi.preact[(size_t)row * ldc + col] = v;
+                        v = cfd_act(v, epi.act);
+                    } else if (epi.mode == 2) {
+                        v += epi.bias[0];
+                        if (epi.resid) v += epi.resid[(size_t)row * epi.ldr + (epi.qidx ? epi.qidx[col] : col)];
+                    }
+                    C[(size_t)row * ldc + col] = v;
+                }
+            }
+        }
+}
+
+static int launch_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int at,
+                       int bt, const GemmEpi& epi, hipStream_t st, const char* what) {
+    if (M == 0 || N == 0) return CFD_OK;
+    const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT);
+    CFD_PROF("k_gemm", st);
+    if (!at && !bt) hipLaunchKernelGGL((k_gemm<false, false>), grid, dim3(256), 0, st, A, B, C, M, N, K, lda, ldb, ldc, epi);
+    else if (!at && bt) hipLaunchKernelGGL((k_gemm<false, true>), grid, dim3(256), 0, st, A, B, C, M, N, K, lda, ldb, ldc, epi);
+    else if (at && !bt) hipLaunchKernelGGL((k_gemm<true, false>), grid, dim3(256), 0, st, A, B, C, M, N, K, lda, ldb, ldc, epi);
+    else hipLaunchKernelGGL((k_gemm<true, true>), grid, dim3(256), 0, st, A, B, C, M, N, K, lda, ldb, ldc, epi);
+    CFD_LAUNCH_CHECK(what);
+    return CFD_OK;
+}
+
+extern "C" int cfd_gemm(const float* a, const float* b, float* c, int M, int N, int K, int lda, int ldb, int ldc,
+                        int trans_a, int trans_b, void* stream) {
+    CFD_REQUIRE(a && b && c, CFD_ERR_INVALID_ARG, "cfd_gemm: NULL pointer");
+    CFD_REQUIRE(M >= 0 && N >= 0 && K >= 1 && lda >= 1 && ldb >= 1 && ldc >= N, CFD_ERR_INVALID_ARG, "cfd_gemm: bad sizes");
+    GemmEpi epi{};
+    return launch_gemm(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, epi, (hipStream_t)stream, "cfd_gemm");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// nn.Linear + activation  (ffn.py:23-31): y = act(x w^T + b), x (M,K), w (N,K), y (M,N)
+// ------------------------------------------------------------------------------------------------------
+extern "C" int cfd_linear_fwd(const float* x, const float* w, const float* bias, float* y, float* preact, int M, int K,
+                              int N, int act, void* stream) {
+    CFD_REQUIRE(x && w && y, CFD_ERR_INVALID_ARG, "cfd_linear_fwd: NULL pointer");
+    CFD_REQUIRE(M >= 0 && K >= 1 && N >= 1, CFD_ERR_INVALID_ARG, "cfd_linear_fwd: bad sizes");
+    CFD_REQUIRE(act >= 0 && act <= 4, CFD_ERR_INVALID_ARG, "cfd_linear_fwd: act must be 0 none, 1 relu, 2 tanh, 3 gelu, 4 swish");
+    CFD_REQUIRE(act < 3 || preact, CFD_ERR_INVALID_ARG, "cfd_linear_fwd: gelu / swish need the pre-activation buffer");
+    GemmEpi epi{};
+    epi.mode = 1; epi.act = act; epi.bias = bias; epi.preact = preact;
+    return launch_gemm(x, w, y, M, N, K, K, K, N, 0, 1, epi, (hipStream_t)stream, "cfd_linear_fwd");
+}
+
+__global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ gy, const float* __restrict__ y,
+                                                 const float* __restrict__ z, float* __restrict__ gz, size_t n, int act) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        gz[i] = gy[i] * cfd_act_grad(y ? y[i] : 0.f, z ? z[i] : 0.f, act);
+}
+
+// out[n] = sum_m g[m][n]: one wave per column, lanes stride over rows, fixed shuffle tree (deterministic)
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, float* __restrict__ out, int M, int N) {
+    const int lane = threadIdx.x & 63, col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= N) return;
+    float s = 0.f;
+    for (int m = lane; m < M; m += 64) s += g[(size_t)m * N + col];
+    s = cfd_wave_sum(s);
+    if (lane == 0) out[col] = s;
+}
+
+extern "C" size_t cfd_linear_bwd_workspace_bytes(int M, int K, int N) {
+    (void)K;
+    return cfd_align_up((size_t)(M > 0 ? M : 0) * N * sizeof(float), 256);
+}
+
+// gx (M,K) = gz w;  gw (N,K) = gz^T x;  gb (N) = column sums of gz;  gz = gy * act'.  gx / gb may be NULL.
+extern "C" int cfd_linear_bwd(const float* gy, const float* x, const float* w, const float* y, const float* preact,
+                              float* gx, float* gw, float* gb, void* ws, int M, int K, int N, int act, void* stream) {
+    CFD_REQUIRE(gy && x && w && gw, CFD_ERR_INVALID_ARG, "cfd_linear_bwd: NULL pointer");
+    CFD_REQUIRE(M >= 1 && K >= 1 && N >= 1, CFD_ERR_INVALID_ARG, "cfd_linear_bwd: bad sizes");
+    CFD_REQUIRE(act >= 0 && act <= 4, CFD_ERR_INVALID_ARG, "cfd_linear_bwd: bad act");
+    CFD_REQUIRE(act == 0 || ws, CFD_ERR_WORKSPACE, "cfd_linear_bwd: workspace needed");
+    CFD_REQUIRE(!(act == 1 || act == 2) || y, CFD_ERR_INVALID_ARG, "cfd_linear_bwd: relu / tanh need the layer output");
+    CFD_REQUIRE(act < 3 || preact, CFD_ERR_INVALID_ARG, "cfd_linear_bwd: gelu / swish need the pre-activation");
+    hipStream_t st = (hipStream_t)stream;
+    const float* gz = gy;
+    if (act != 0) {
+        const size_t nel = (size_t)M * N;
+        size_t blocks = (nel + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)blocks), dim3(256), 0, st, gy, y, preact, (float*)ws, nel, act);
+        CFD_LAUNCH_CHECK("cfd_linear_bwd(act)");
+        gz = (const float*)ws;
+    }
+    GemmEpi epi{};
+    if (gx) CFD_TRY(launch_gemm(gz, w, gx, M, K, N, N, K, K, 0, 0, epi, st, "cfd_linear_bwd(gx)"));
+    CFD_TRY(launch_gemm(gz, x, gw, N, K, M, N, K, K, 1, 0, epi, st, "cfd_linear_bwd(gw)"));
+    if (gb) {
+        hipLaunchKernelGGL(k_colsum, dim3((N + 3) / 4), dim3(256), 0, st, gz, gb, M, N);
+        CFD_LAUNCH_CHECK("cfd_linear_bwd(gb)");
+    }
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// DeepONet inner product + bias + residual  (auto_deeponet.py:127-135)
+// ------------------------------------------------------------------------------------------------------
+// preds[b][k] = sum_p branch[b][p] trunk[k][p] + bias[0] + (u ? u[b*HW + (qidx ? qidx[k] : k)] : 0)
+extern "C" int cfd_deeponet_inner_fwd(const float* branch, const float* trunk, const float* bias, const float* u,
+                                      const int* qidx, float* preds, int B, int P, int Kq, int HW, void* stream) {
+    CFD_REQUIRE(branch && trunk && bias && preds, CFD_ERR_INVALID_ARG, "cfd_deeponet_inner_fwd: NULL pointer");
+    CFD_REQUIRE(B >= 0 && P >= 1 && Kq >= 0, CFD_ERR_INVALID_ARG, "cfd_deeponet_inner_fwd: bad sizes");
+    CFD_REQUIRE(u || !qidx, CFD_ERR_INVALID_ARG, "cfd_deeponet_inner_fwd: query indices without a residual field");
+    CFD_REQUIRE(!u || qidx || Kq <= HW, CFD_ERR_INVALID_ARG, "cfd_deeponet_inner_fwd: more queries than lattice points");
+    GemmEpi epi{};
+    epi.mode = 2; epi.bias = bias; epi.resid = u; epi.qidx = qidx; epi.ldr = HW;  // u == NULL: bias only (deeponet.py:205)
+    return launch_gemm(branch, trunk, preds, B, Kq, P, P, P, Kq, 0, 1, epi, (hipStream_t)stream, "cfd_deeponet_inner_fwd");
+}
+
+__global__ __launch_bounds__(256) void k_sum_all(const float* __restrict__ g, size_t n, float* __restrict__ part) {
+    __shared__ float s_r[4];
+    float a = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a += g[i];
+    a = cfd_wave_sum(a);
+    if ((threadIdx.x & 63) == 0) s_r[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (s_r[0] + s_r[1]) + (s_r[2] + s_r[3]);
+}
+
+__global__ __launch_bounds__(64) void k_sum_final(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+    float a = 0.f;
+    for (int k = threadIdx.x; k < nblk; k += 64) a += part[k];
+    a = cfd_wave_sum(a);
+    if (threadIdx.x == 0) out[0] = a;
+}
+
+#define CFD_SUM_BLOCKS 128
+extern "C" size_t cfd_deeponet_inner_bwd_workspace_bytes(int B, int P, int Kq) {
+    (void)B; (void)P; (void)Kq;
+    return CFD_SUM_BLOCKS * sizeof(float);
+}
+
+// gbranch (B,P) = g trunk;  gtrunk (Kq,P) = g^T branch;  gbias = sum g   (the residual's gradient is g itself)
+extern "C" int cfd_deeponet_inner_bwd(const float* gpreds, const float* branch, const float* trunk, float* gbranch,
+                                      float* gtrunk, float* gbias, void* ws, int B, int P, int Kq, void* stream) {
+    CFD_REQUIRE(gpreds && branch && trunk && ws, CFD_ERR_INVALID_ARG, "cfd_deeponet_inner_bwd: NULL pointer");
+    CFD_REQUIRE(B >= 1 && P >= 1 && Kq >= 1, CFD_ERR_INVALID_ARG, "cfd_deeponet_inner_bwd: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    GemmEpi epi{};
+    if (gbranch) CFD_TRY(launch_gemm(gpreds, trunk, gbranch, B, P, Kq, Kq, P, P, 0, 0, epi, st, "cfd_deeponet_inner_bwd(gbranch)"));
+    if (gtrunk) CFD_TRY(launch_gemm(gpreds, branch, gtrunk, Kq, P, B, Kq, P, P, 1, 0, epi, st, "cfd_deeponet_inner_bwd(gtrunk)"));
+    if (gbias) {
+        hipLaunchKernelGGL(k_sum_all, dim3(CFD_SUM_BLOCKS), dim3(256), 0, st, gpreds, (size_t)B * Kq, (float*)ws);
+        CFD_LAUNCH_CHECK("cfd_deeponet_inner_bwd(sum)");
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64), 0, st, (const float*)ws, CFD_SUM_BLOCKS, gbias);
+        CFD_LAUNCH_CHECK("cfd_deeponet_inner_bwd(final)");
+    }
+    return CFD_OK;
+}

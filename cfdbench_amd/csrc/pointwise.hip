@@ -3,8 +3,6 @@
 //   feature assembly + fc0    src/models/fno/fno2d.py:189-217      -> k_stem_fwd / k_chan_wgrad<STEM>
 //   MseLoss                   src/models/loss.py:22-37             -> k_loss_part / k_loss_final
 //   torch.optim.Adam          src/train_auto.py:213,256            -> k_adam
-#include <cstdlib>
-
 #include "cfd_common.h"
 
 // ------------------------------------------------------------------------------------------------------
@@ -339,8 +337,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 static int wgrad_blocks(int B, int HW) {
     const long chunks = (long)B * ((HW + 15) / 16);
     long blocks = (chunks + 31) / 32;  // >= 8 chunks per wave
-    static const long cap = getenv("CFD_WG_BLOCKS") ? atol(getenv("CFD_WG_BLOCKS")) : 1024;  // dev knob
-    if (blocks > cap) blocks = cap;
+    if (blocks > 1024) blocks = 1024;  // 4 workgroups per CU (measured best of 512 / 1024 / 2048)
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }

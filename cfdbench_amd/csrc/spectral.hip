@@ -16,8 +16,6 @@
 //   S = Z[+kap] + Z[-kap], D = Z[+kap] - Z[-kap]
 //   stage A:    U_re[x][l] = sum_kap S_re cos(th) - D_im sin(th);  U_im[x][l] = sum_kap S_im cos(th) + D_re sin(th)
 //   stage B:    y[x][y] = sum_l (c_l/HW) (U_re cos(2pi l y/W) - U_im sin(2pi l y/W))
-#include <cstdlib>
-
 #include "cfd_common.h"
 
 #define CFD_WAVES 4  // waves per workgroup (256 threads)
@@ -235,15 +233,15 @@ static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, in
     if constexpr (VEC4) {
         if (p->W == 64 && p->KX == 9 && p->H == 64) {
             int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
-            static const int bpc = getenv("CFD_DFT_BPC") ? atoi(getenv("CFD_DFT_BPC")) : 3;  // dev knob
-            static const int dd = getenv("CFD_DFT_D") ? atoi(getenv("CFD_DFT_D")) : 3;        // dev knob
-            if (blocks > bpc * 256) blocks = bpc * 256;  // workgroups stay resident; waves stride over the images
-#define CFD_DFT64(D_, A_)                                                                                          \
-    hipLaunchKernelGGL((k_dft_fwd64<9, D_, A_>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,       \
-                       (const float*)p->d_fwd, p->n_fwd, nimg, p->H, p->m1, p->m2)
-            if (dd == 9) { if (act) CFD_DFT64(9, true); else CFD_DFT64(9, false); }
-            else { if (act) CFD_DFT64(3, true); else CFD_DFT64(3, false); }
-#undef CFD_DFT64
+            // 3 workgroups per CU stay resident and the waves stride over the images (measured best of 1..5; a ring of 3
+            // k-steps beats a whole image in flight: 23 vs 26 us at B*C = 5120)
+            if (blocks > 3 * 256) blocks = 3 * 256;
+            if (act)
+                hipLaunchKernelGGL((k_dft_fwd64<9, 3, true>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
+                                   (const float*)p->d_fwd, p->n_fwd, nimg, p->H, p->m1, p->m2);
+            else
+                hipLaunchKernelGGL((k_dft_fwd64<9, 3, false>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
+                                   (const float*)p->d_fwd, p->n_fwd, nimg, p->H, p->m1, p->m2);
             CFD_LAUNCH_CHECK("cfd_spectral_dft");
             return CFD_OK;
         }
@@ -403,17 +401,11 @@ static void launch_mix(const float2* xin, const float2* w1, const float2* w2, fl
                            CoutW, m1, m2);
 }
 
-static int cfd_mix_cfg() {
-    static const int v = getenv("CFD_MIX_CFG") ? atoi(getenv("CFD_MIX_CFG")) : 0;  // dev knob
-    return v;
-}
-
 // (CR, WPB) instantiations: CR >= contracted channels, WPB waves = non-contracted channels per workgroup.
 #define CFD_MIX_DISPATCH(FN, Cr_, Cz_, ...)                                        \
     do {                                                                            \
         if ((Cr_) <= 8) FN<8, 8>(__VA_ARGS__);                                      \
-        else if ((Cr_) <= 20 && (Cz_) % 10 == 0 && cfd_mix_cfg() == 0) FN<20, 10>(__VA_ARGS__); \
-        else if ((Cr_) <= 20 && (Cz_) % 5 == 0) FN<20, 5>(__VA_ARGS__);             \
+        else if ((Cr_) <= 20 && (Cz_) % 10 == 0) FN<20, 10>(__VA_ARGS__);           \
         else if ((Cr_) <= 16) FN<16, 8>(__VA_ARGS__);                               \
         else if ((Cr_) <= 24) FN<24, 8>(__VA_ARGS__);                               \
         else FN<32, 8>(__VA_ARGS__);                                                \

@@ -273,3 +273,98 @@ class FnoForwardFn(torch.autograd.Function):
         out = [torch.view_as_complex(g) if (g.dim() == 5 and g.shape[-1] == 2) else g for g in grads]
         # reshape 1x1 conv weights back to (out, in, 1, 1): empty_like(flat) already carries the parameter's shape
         return (None, None, None, None, None, *out)
+
+
+# ----------------------------------------------------------------------------------------------------
+# Dense layers of the DeepONet family  (src/models/ffn.py:12-35, src/models/auto_deeponet.py:127-135)
+# ----------------------------------------------------------------------------------------------------
+ACT_CODES = {None: 0, "none": 0, "relu": 1, "tanh": 2, "gelu": 3, "swish": 4}
+
+
+class LinearActFn(torch.autograd.Function):
+    """y = act(x w^T + b) as one MFMA GEMM with fused epilogue (nn.Linear followed by get_act_fn(name))."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor], act: int):
+        _require_cuda(x, w, b)
+        api = _lib.api()
+        lead = x.shape[:-1]
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        w, b = _f32c(w.detach()), _f32c(b.detach()) if b is not None else None
+        M, K = x2.shape
+        N = w.shape[0]
+        if w.shape[1] != K:
+            raise RuntimeError(f"Linear: input has {K} features, weight expects {w.shape[1]}")
+        y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+        pre = torch.empty_like(y) if act >= 3 else None
+        api.call("cfd_linear_fwd", _ptr(x2), _ptr(w), _ptr(b), _ptr(y), _ptr(pre), M, K, N, act, _stream())
+        ctx.save_for_backward(x2, w, y if act in (1, 2) else None, pre)
+        ctx.meta = (M, K, N, act, lead, b is not None)
+        return y.reshape(*lead, N)
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        api = _lib.api()
+        x2, w, y, pre = ctx.saved_tensors
+        M, K, N, act, lead, has_b = ctx.meta
+        gy2 = _f32c(gy).reshape(M, N)
+        dev = gy2.device
+        gx = torch.empty((M, K), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        gw = torch.empty((N, K), dtype=torch.float32, device=dev)
+        gb = torch.empty((N,), dtype=torch.float32, device=dev) if has_b else None
+        ws = _bytes(api.size("cfd_linear_bwd_workspace_bytes", M, K, N), dev)
+        api.call("cfd_linear_bwd", _ptr(gy2), _ptr(x2), _ptr(w), _ptr(y), _ptr(pre), _ptr(gx), _ptr(gw), _ptr(gb), _ptr(ws),
+                 M, K, N, act, _stream())
+        return (gx.reshape(*lead, K) if gx is not None else None), gw, gb, None
+
+
+def linear_act(x: Tensor, w: Tensor, b: Optional[Tensor], act: Optional[str]) -> Tensor:
+    return LinearActFn.apply(x, w, b, ACT_CODES[act])
+
+
+class DeepONetInnerFn(torch.autograd.Function):
+    """preds[b,k] = <branch[b], trunk[k]> + bias + u[b, query k]  (auto_deeponet.py:129-135) as one GEMM."""
+
+    @staticmethod
+    def forward(ctx, branch: Tensor, trunk: Tensor, bias: Tensor, u: Optional[Tensor], qidx: Optional[Tensor]):
+        _require_cuda(branch, trunk, bias, u, qidx)
+        api = _lib.api()
+        branch, trunk, bias = _f32c(branch), _f32c(trunk), _f32c(bias.detach())
+        B, P = branch.shape
+        Kq = trunk.shape[0]
+        u2 = _f32c(u).reshape(B, -1) if u is not None else None
+        HW = u2.shape[1] if u2 is not None else 0
+        qi = qidx.to(torch.int32).contiguous() if qidx is not None else None
+        preds = torch.empty((B, Kq), dtype=torch.float32, device=branch.device)
+        api.call("cfd_deeponet_inner_fwd", _ptr(branch), _ptr(trunk), _ptr(bias), _ptr(u2), _ptr(qi), _ptr(preds), B, P, Kq,
+                 HW, _stream())
+        ctx.save_for_backward(branch, trunk)
+        ctx.has_u = u is not None
+        ctx.u_shape = None if u is None else tuple(u.shape)
+        ctx.qidx = qi
+        return preds
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        api = _lib.api()
+        branch, trunk = ctx.saved_tensors
+        B, P = branch.shape
+        Kq = trunk.shape[0]
+        g = _f32c(g)
+        dev = g.device
+        gbr = torch.empty_like(branch) if ctx.needs_input_grad[0] else None
+        gtr = torch.empty_like(trunk) if ctx.needs_input_grad[1] else None
+        gbias = torch.empty(1, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+        ws = _bytes(api.size("cfd_deeponet_inner_bwd_workspace_bytes", B, P, Kq), dev)
+        api.call("cfd_deeponet_inner_bwd", _ptr(g), _ptr(branch), _ptr(trunk), _ptr(gbr), _ptr(gtr), _ptr(gbias), _ptr(ws),
+                 B, P, Kq, _stream())
+        gu = None
+        if ctx.has_u and ctx.needs_input_grad[3]:  # the residual's gradient is g scattered to the query points
+            if ctx.qidx is None and Kq == int(torch.tensor(ctx.u_shape[1:]).prod()):
+                gu = g.reshape(ctx.u_shape)
+            else:
+                gu2 = torch.zeros((B, int(torch.tensor(ctx.u_shape[1:]).prod())), dtype=torch.float32, device=dev)
+                idx = ctx.qidx.long() if ctx.qidx is not None else torch.arange(Kq, device=dev)
+                gu2.index_add_(1, idx, g)
+                gu = gu2.reshape(ctx.u_shape)
+        return gbr, gtr, gbias, gu, None

@@ -3,6 +3,7 @@ from __future__ import annotations
 
 from typing import Tuple
 
+from ..models.auto_deeponet import AutoDeepONet
 from ..models.base_model import AutoCfdModel
 from ..models.fno.fno2d import Fno2d
 from ..models.loss import loss_name_to_fn
@@ -26,11 +27,15 @@ def get_input_shapes(args) -> Tuple[int, int, int]:
 def init_model(args) -> AutoCfdModel:
     """Same ``elif`` chain as autoregressive.py:41-179; models whose kernels are not built yet name themselves."""
     loss_fn = loss_name_to_fn(args.loss_name)
-    _, _, n_case_params = get_input_shapes(args)
+    n_rows, n_cols, n_case_params = get_input_shapes(args)
     if args.model == "fno":
         return Fno2d(in_chan=args.in_chan, out_chan=args.out_chan, n_case_params=n_case_params, loss_fn=loss_fn,
                      num_layers=args.fno_depth, hidden_dim=args.fno_hidden_dim, modes1=args.fno_modes_x,
                      modes2=args.fno_modes_y)
-    if args.model in ("auto_ffn", "auto_deeponet", "auto_edeeponet", "auto_deeponet_cnn", "resnet", "unet"):
+    if args.model == "auto_deeponet":  # autoregressive.py:58-69
+        return AutoDeepONet(branch_dim=n_cols * n_rows + n_case_params, trunk_dim=2, loss_fn=loss_fn,
+                            width=args.deeponet_width, trunk_depth=args.trunk_depth, branch_depth=args.branch_depth,
+                            act_name=args.act_fn)
+    if args.model in ("auto_ffn", "auto_edeeponet", "auto_deeponet_cnn", "resnet", "unet"):
         raise NotImplementedError(f"cfdbench_amd: model {args.model!r} has no MI355X kernels yet (DESIGN.md section 7)")
     raise ValueError(f"Invalid model name: {args.model}")

@@ -1,0 +1,101 @@
+"""Auto-regressive DeepONet with the reference's constructor, ``state_dict`` keys (``branch_net.layers.*``,
+``trunk_net.layers.*``, ``bias``) and return conventions (src/models/auto_deeponet.py:19-200) on MFMA GEMMs.
+
+Differences that are pure cost, not behaviour: the query lattice ``list(product(range(h), range(w)))`` is built once
+per grid instead of per call on the host (auto_deeponet.py:119-124,161-165); ``branch * trunk`` is never broadcast to
+(b, k, p) (879 MB at B=512, 66x65) -- it is one GEMM whose epilogue adds the bias and the residual; in eval mode the
+trunk activations (a function of the lattice and the weights only) are cached across rollout steps."""
+from itertools import product
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from .. import functional as F_
+from .act_fn import get_act_fn
+from .base_model import AutoCfdModel
+from .ffn import Ffn
+from .loss import MseLoss
+
+
+class AutoDeepONet(AutoCfdModel):
+    def __init__(self, branch_dim: int, trunk_dim: int, loss_fn: MseLoss, num_label_samples: int = 1000,
+                 branch_depth: int = 4, trunk_depth: int = 4, width: int = 100, act_name="relu", act_norm: bool = False,
+                 act_on_output: bool = False):
+        super().__init__(loss_fn)
+        self.branch_dim = branch_dim
+        self.trunk_dim = trunk_dim
+        self.branch_depth = branch_depth
+        self.trunk_depth = trunk_depth
+        self.width = width
+        self.act_name = act_name
+        self.act_norm = act_norm
+        self.act_on_output = act_on_output
+        self.num_label_samples = num_label_samples
+        act_fn = get_act_fn(act_name, act_norm)
+        self.branch_dims = [branch_dim] + [width] * branch_depth
+        self.trunk_dims = [trunk_dim] + [width] * trunk_depth
+        self.branch_net = Ffn(self.branch_dims, act_fn=act_fn, act_on_output=act_on_output)
+        self.trunk_net = Ffn(self.trunk_dims, act_fn=act_fn)
+        self.bias = nn.Parameter(torch.zeros(1))
+        self._lattice: Dict[Tuple[int, int, int], Tensor] = {}
+        self._trunk_cache = None
+
+    def _full_lattice(self, height: int, width: int, device) -> Tensor:
+        key = (height, width, device.index if device.index is not None else -1)
+        if key not in self._lattice:
+            self._lattice[key] = torch.tensor(list(product(range(height), range(width))), dtype=torch.long, device=device)
+        return self._lattice[key]
+
+    def _trunk(self, query_idxs: Tensor, full: bool) -> Tensor:
+        """trunk_net((idx - 50) / 100), cached in eval mode for the full lattice (weights are frozen then)."""
+        ver = tuple(p._version for p in self.trunk_net.parameters())
+        if full and not self.training and not torch.is_grad_enabled() and self._trunk_cache is not None \
+                and self._trunk_cache[0] == (query_idxs.data_ptr(), ver):
+            return self._trunk_cache[1]
+        x_trunk = self.trunk_net((query_idxs.float() - 50) / 100)  # auto_deeponet.py:127-128
+        if full and not self.training and not torch.is_grad_enabled():
+            self._trunk_cache = ((query_idxs.data_ptr(), ver), x_trunk)
+        return x_trunk
+
+    def forward(self, inputs: Tensor, case_params: Tensor, label: Optional[Tensor] = None,
+                mask: Optional[Tensor] = None, query_idxs: Optional[Tensor] = None):
+        """inputs (b,c,h,w), case_params (b,p), label (b,c,h,w), query_idxs (k,2) -> preds (b,k) + loss if label, else
+        preds (b,1,h,w)   (auto_deeponet.py:76-147)."""
+        batch_size, num_chan, height, width = inputs.shape
+        u = inputs[:, 0]                                        # only the u channel (:109)
+        flat_inputs = torch.cat([u.reshape(batch_size, -1), case_params], dim=1)  # (:111-116)
+        x_branch = self.branch_net(flat_inputs)
+        full = query_idxs is None
+        if full:
+            query_idxs = self._full_lattice(height, width, inputs.device)
+        x_trunk = self._trunk(query_idxs, full)
+        qflat = None if full else (query_idxs[:, 0] * width + query_idxs[:, 1])
+        preds = F_.DeepONetInnerFn.apply(x_branch, x_trunk, self.bias, u, qflat)  # (:129-135)
+        if label is not None:
+            label = label[:, 0]
+            labels = label.reshape(batch_size, -1) if full else label[:, query_idxs[:, 0], query_idxs[:, 1]]
+            loss = self.loss_fn(labels=labels, preds=preds)
+            return dict(preds=preds, loss=loss)
+        return dict(preds=preds.view(-1, 1, height, width))
+
+    def generate(self, inputs: Tensor, case_params: Tensor, mask: Tensor) -> Tensor:
+        if inputs.dim() == 3:
+            inputs = inputs.unsqueeze(0)
+        batch_size, num_chan, height, width = inputs.shape
+        preds = self.forward(inputs, case_params=case_params, mask=mask)["preds"]
+        return preds.view(-1, 1, height, width)  # (b, 1, h, w): only u is predicted (auto_deeponet.py:171)
+
+    def generate_many(self, inputs: Tensor, case_params: Tensor, mask: Tensor, steps: int) -> List[Tensor]:
+        assert len(inputs.shape) == len(case_params.shape) + 2
+        if inputs.dim() == 3:
+            inputs = inputs.unsqueeze(0)
+            case_params = case_params.unsqueeze(0)
+            mask = mask.unsqueeze(0)
+        assert inputs.shape[0] == case_params.shape[0]
+        cur_frame = inputs
+        preds = []
+        for _ in range(steps):
+            cur_frame = self.generate(inputs=cur_frame, case_params=case_params, mask=mask)
+            preds.append(cur_frame)
+        return preds

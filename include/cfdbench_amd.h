@@ -159,6 +159,35 @@ int cfd_gelu_bwd(const float* x, const float* gy, float* gx, size_t n, void* str
 int cfd_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* ---- dense layers of the DeepONet family (exact-fp32 MFMA GEMMs) ----------------------------------------*/
+
+/* c (M,N) = op(a) op(b); trans_a: a stored (K,M) else (M,K); trans_b: b stored (N,K) else (K,N); row-major, leading
+ * dimensions in elements.                                                                                    */
+int cfd_gemm(const float* a, const float* b, float* c, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
+             int trans_b, void* stream);
+
+/* nn.Linear + activation (Ffn, src/models/ffn.py:23-31): y = act(x w^T + bias); x (M,K), w (N,K), y (M,N).
+ * act: 0 none, 1 relu, 2 tanh, 3 gelu (exact erf), 4 swish (get_act_fn, src/models/act_fn.py:5-18).
+ * preact (M,N) receives x w^T + bias when non-NULL (required for gelu / swish, whose derivative needs it).    */
+int cfd_linear_fwd(const float* x, const float* w, const float* bias, float* y, float* preact, int M, int K, int N,
+                   int act, void* stream);
+/* Backward of the above: gx (M,K), gw (N,K), gb (N) from gy (M,N); y = layer output (relu / tanh), preact (gelu /
+ * swish).  gx and gb may be NULL.  ws: cfd_linear_bwd_workspace_bytes().                                    */
+size_t cfd_linear_bwd_workspace_bytes(int M, int K, int N);
+int cfd_linear_bwd(const float* gy, const float* x, const float* w, const float* y, const float* preact, float* gx,
+                   float* gw, float* gb, void* ws, int M, int K, int N, int act, void* stream);
+
+/* DeepONet output (src/models/auto_deeponet.py:127-135, src/models/deeponet.py:204-205):
+ *   preds[b,k] = sum_p branch[b,p] trunk[k,p] + bias[0] + (u ? u[b*HW + (qidx ? qidx[k] : k)] : 0)
+ * branch (B,P); trunk (Kq,P); u (B,HW) = the u channel of the input frame (residual) or NULL; qidx (Kq) int32 flat
+ * lattice indices row*W+col of the query points, NULL = the full lattice in row-major order.                  */
+int cfd_deeponet_inner_fwd(const float* branch, const float* trunk, const float* bias, const float* u, const int* qidx,
+                           float* preds, int B, int P, int Kq, int HW, void* stream);
+/* gbranch (B,P) = g trunk; gtrunk (Kq,P) = g^T branch; gbias (1) = sum g.  Any output may be NULL.             */
+size_t cfd_deeponet_inner_bwd_workspace_bytes(int B, int P, int Kq);
+int cfd_deeponet_inner_bwd(const float* gpreds, const float* branch, const float* trunk, float* gbranch, float* gtrunk,
+                           float* gbias, void* ws, int B, int P, int Kq, void* stream);
+
 /* ---- whole Auto-FNO (Fno2d.forward, fno2d.py:178-242; loss.backward() at train_auto.py:255) ---------------*/
 typedef struct {
     int B, H, W;

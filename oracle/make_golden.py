@@ -111,6 +111,31 @@ def gen_rollout(name, pseed, bseed, B, C, L, H, W, steps, p=5, border=False, gai
     print(name, "ok", frames.shape)
 
 
+def gen_auto_deeponet(name, pseed, bseed, B, H, W, width, bdepth, tdepth, act_name="relu", p=5, steps=3):
+    """AutoDeepONet forward / loss / backward / rollout from the reference module (src/models/auto_deeponet.py)."""
+    from models.auto_deeponet import AutoDeepONet  # reference
+    from oracle import deeponet_oracle as D
+    params = D.make_params(pseed, H * W + p, width, bdepth, tdepth)
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    model = AutoDeepONet(H * W + p, 2, MseLoss(normalize=True), branch_depth=bdepth, trunk_depth=tdepth, width=width,
+                         act_name=act_name)
+    model.load_state_dict({k: _t(v) for k, v in params.items()})
+    x = _t(batch["inputs"]).requires_grad_(True)
+    out = model(inputs=x, case_params=_t(batch["case_params"]), label=_t(batch["label"]), mask=_t(batch["mask"]))
+    out["loss"]["nmse"].backward()
+    save = dict(meta=np.array([pseed, bseed, B, H, W, width, bdepth, tdepth, p, steps]), act=np.array(act_name),
+                preds=out["preds"].detach().numpy(), g_inputs=x.grad.numpy(),
+                **{f"loss_{k}": np.array(v.item()) for k, v in out["loss"].items()})
+    for k, prm in model.named_parameters():
+        save[f"grad::{k}"] = prm.grad.numpy()
+    model.eval()
+    with torch.no_grad():
+        frames = model.generate_many(_t(batch["inputs"]), _t(batch["case_params"]), _t(batch["mask"]), steps)
+    save["frames"] = np.stack([f.numpy() for f in frames])
+    np.savez_compressed(OUT / f"{name}.npz", **save)
+    print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
+
+
 def gen_adam(name, pseed, bseed, B, C, L, H, W, nsteps, lr, p=5, gain=1.0):
     """train_auto.py:231-257: model(**batch) -> loss['nmse'].backward() -> Adam.step() -> zero_grad()."""
     params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=gain)
@@ -152,6 +177,9 @@ def main():
     gen_fno("fno_cfg1_b8", 23, 33, 8, 20, 4, 64, 64, full_grads=False)
     gen_rollout("rollout_small_64x64", 24, 34, 2, 8, 2, 64, 64, steps=6, gain=8.0)
     gen_rollout("rollout_small_66x65", 25, 35, 1, 6, 2, 66, 65, steps=4, border=True, gain=6.0)
+    gen_auto_deeponet("auto_deeponet_small_16x16", 41, 51, 3, 16, 16, 24, 3, 3, "relu")
+    gen_auto_deeponet("auto_deeponet_tanh_18x17", 42, 52, 2, 18, 17, 20, 2, 3, "tanh")
+    gen_auto_deeponet("auto_deeponet_gelu_16x16", 43, 53, 2, 16, 16, 16, 2, 2, "gelu")
     gen_adam("adam_small_64x64", 26, 36, 2, 8, 2, 64, 64, nsteps=3, lr=1e-3, gain=8.0)
     gen_mseloss("mseloss", 41)
 

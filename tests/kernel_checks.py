@@ -394,3 +394,72 @@ def check_fno_vs_oracle(be, B, C, L, H, W, p=5, border=False, gain=4.0, pseed=7,
     for k in params:
         res["g:" + k] = nm(out["grads"][k], rg[k])
     return res
+
+
+# ---- dense layers of the DeepONet family (csrc/dense.hip) ---------------------------------------------------------
+def check_gemm(be, M, N, K, ta, tb, seed=21):
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    Bm = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    dA, dB, C = be.dev(A), be.dev(Bm), be.zeros((M, N))
+    api.call("cfd_gemm", P(dA), P(dB), P(C), M, N, K, A.shape[1], Bm.shape[1], N, int(ta), int(tb), be.stream)
+    be.sync()
+    ref = (A.T if ta else A).astype(f64) @ (Bm.T if tb else Bm).astype(f64)
+    return {"c": nm(be.host(C), ref)}
+
+
+def check_linear(be, M, K, N, act, seed=22):
+    from oracle import deeponet_oracle as D
+    api, P = be.api, be.ptr
+    code = {"none": 0, "relu": 1, "tanh": 2, "gelu": 3, "swish": 4}[act]
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal((N,)).astype(np.float32) * 0.3
+    gy = rng.standard_normal((M, N)).astype(np.float32)
+    dx, dw, db, dgy = be.dev(x), be.dev(w), be.dev(b), be.dev(gy)
+    y, pre = be.zeros((M, N)), be.zeros((M, N))
+    api.call("cfd_linear_fwd", P(dx), P(dw), P(db), P(y), P(pre), M, K, N, code, be.stream)
+    be.sync()
+    z = x.astype(f64) @ w.astype(f64).T + b
+    res = {"y": nm(be.host(y), D.act(z, act)), "pre": nm(be.host(pre), z)}
+    gx, gw, gb = be.zeros((M, K)), be.zeros((N, K)), be.zeros((N,))
+    ws = be.bytes(api.size("cfd_linear_bwd_workspace_bytes", M, K, N))
+    api.call("cfd_linear_bwd", P(dgy), P(dx), P(dw), P(y), P(pre), P(gx), P(gw), P(gb), P(ws), M, K, N, code, be.stream)
+    be.sync()
+    gz = gy.astype(f64) * D.act_grad(z, act)
+    res["gx"] = nm(be.host(gx), gz @ w.astype(f64))
+    res["gw"] = nm(be.host(gw), gz.T @ x.astype(f64))
+    res["gb"] = nm(be.host(gb), gz.sum(axis=0))
+    return res
+
+
+def check_deeponet_inner(be, B, P_, Kq, HW, with_q, seed=23):
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    br = rng.standard_normal((B, P_)).astype(np.float32)
+    tr = rng.standard_normal((Kq, P_)).astype(np.float32)
+    bias = np.array([0.37], np.float32)
+    u = rng.standard_normal((B, HW)).astype(np.float32)
+    q = rng.integers(0, HW, size=Kq).astype(np.int32) if with_q else None
+    g = rng.standard_normal((B, Kq)).astype(np.float32)
+    dbr, dtr, dbi, du, dg = be.dev(br), be.dev(tr), be.dev(bias), be.dev(u), be.dev(g)
+    dq = be.dev(q) if with_q else None
+    preds = be.zeros((B, Kq))
+    api.call("cfd_deeponet_inner_fwd", P(dbr), P(dtr), P(dbi), P(du), P(dq), P(preds), B, P_, Kq, HW, be.stream)
+    be.sync()
+    resid = u[:, q] if with_q else u[:, :Kq]
+    res = {"preds": nm(be.host(preds), br.astype(f64) @ tr.astype(f64).T + 0.37 + resid)}
+    p2 = be.zeros((B, Kq))
+    api.call("cfd_deeponet_inner_fwd", P(dbr), P(dtr), P(dbi), None, None, P(p2), B, P_, Kq, 0, be.stream)  # deeponet.py:205
+    be.sync()
+    res["preds_nores"] = nm(be.host(p2), br.astype(f64) @ tr.astype(f64).T + 0.37)
+    gbr, gtr, gbi = be.zeros((B, P_)), be.zeros((Kq, P_)), be.zeros((1,))
+    ws = be.bytes(api.size("cfd_deeponet_inner_bwd_workspace_bytes", B, P_, Kq))
+    api.call("cfd_deeponet_inner_bwd", P(dg), P(dbr), P(dtr), P(gbr), P(gtr), P(gbi), P(ws), B, P_, Kq, be.stream)
+    be.sync()
+    res["gbranch"] = nm(be.host(gbr), g.astype(f64) @ tr.astype(f64))
+    res["gtrunk"] = nm(be.host(gtr), g.astype(f64).T @ br.astype(f64))
+    res["gbias"] = float(abs(be.host(gbi)[0] - g.astype(f64).sum()) / abs(g.astype(f64).sum()))
+    return res

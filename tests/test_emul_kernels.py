@@ -87,3 +87,20 @@ def test_error_paths(be):
         be.api.call("cfd_spectral_idft", plan, x.ctypes.data, None, None, x.ctypes.data, 1, 1, None)  # epi without addend
     be.api.call("cfd_spectral_dft", plan, x.ctypes.data, x.ctypes.data, 0, 0, None)  # empty batch is a no-op
     be.api.plan_destroy(plan)
+
+
+@pytest.mark.parametrize("M,N,Kd,ta,tb", [(70, 45, 37, 0, 0), (33, 100, 19, 0, 1), (100, 21, 66, 1, 0), (17, 18, 5, 1, 1)])
+def test_gemm(be, M, N, Kd, ta, tb):
+    _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
+
+
+@pytest.mark.parametrize("M,K_in,N,act", [(37, 21, 24, "relu"), (9, 130, 100, "tanh"), (20, 7, 5, "gelu"), (5, 3, 70, "swish"), (66, 2, 16, "none")])
+def test_linear_act(be, M, K_in, N, act):
+    _assert_all(K.check_linear(be, M, K_in, N, act))
+
+
+@pytest.mark.parametrize("B,P,Kq,HW,with_q", [(3, 24, 256, 256, False), (5, 100, 77, 300, True)])
+def test_deeponet_inner(be, B, P, Kq, HW, with_q):
+    res = K.check_deeponet_inner(be, B, P, Kq, HW, with_q)
+    assert res.pop("gbias") < 1e-5  # a relative error of one fp32 sum, not an nMSE
+    _assert_all(res)

@@ -114,3 +114,20 @@ def test_error_paths(be):
     with pytest.raises(CfdError):
         be.api.call("cfd_spectral_dft", plan, None, None, 4, 0, be.stream)
     be.api.plan_destroy(plan)
+
+
+@pytest.mark.parametrize("M,N,Kd,ta,tb", [(512, 100, 4295, 0, 1), (4290, 100, 100, 0, 0), (100, 4295, 512, 1, 0), (100, 100, 4290, 1, 1), (70, 45, 37, 0, 0)])
+def test_gemm(be, M, N, Kd, ta, tb):
+    _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
+
+
+@pytest.mark.parametrize("M,K_in,N,act", [(512, 4295, 100, "relu"), (4290, 2, 100, "relu"), (4290, 100, 100, "tanh"), (300, 100, 100, "gelu"), (129, 33, 70, "swish"), (66, 100, 16, "none")])
+def test_linear_act(be, M, K_in, N, act):
+    _assert_all(K.check_linear(be, M, K_in, N, act))
+
+
+@pytest.mark.parametrize("B,P,Kq,HW,with_q", [(512, 100, 4290, 4290, False), (37, 100, 1000, 4290, True), (3, 24, 256, 256, False)])
+def test_deeponet_inner(be, B, P, Kq, HW, with_q):
+    res = K.check_deeponet_inner(be, B, P, Kq, HW, with_q)
+    assert res.pop("gbias") < 1e-5  # a relative error of one fp32 sum, not an nMSE
+    _assert_all(res)

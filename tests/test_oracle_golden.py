@@ -137,3 +137,28 @@ def test_mseloss(golden_dir):
     r = O.mse_loss(p.astype(np.float64), l.astype(np.float64), True)
     for k in ("mse", "rmse", "mae", "nmse"):
         assert abs(r[k] - float(g[k])) < 1e-6 * abs(float(g[k]))
+
+
+# ---- Auto-DeepONet (oracle/deeponet_oracle.py) against the reference module's outputs ------------------------
+@pytest.mark.parametrize("name", ["auto_deeponet_small_16x16", "auto_deeponet_tanh_18x17", "auto_deeponet_gelu_16x16"])
+def test_auto_deeponet_forward_backward_rollout(golden_dir, name):
+    from oracle import deeponet_oracle as D
+    g = np.load(golden_dir / f"{name}.npz")
+    pseed, bseed, B, H, W, width, bdepth, tdepth, p, steps = [int(v) for v in g["meta"]]
+    act = str(g["act"])
+    params = {k: v.astype(np.float64) for k, v in D.make_params(pseed, H * W + p, width, bdepth, tdepth).items()}
+    batch = {k: v.astype(np.float64) for k, v in synth.make_smooth_batch(bseed, B, H, W, p).items()}
+    out = D.auto_deeponet_forward(params, batch["inputs"], batch["case_params"], batch["label"], act)
+    assert O.rel_nmse(out["preds"], g["preds"]) < 1e-11
+    for k in ("mse", "rmse", "mae", "nmse"):
+        assert abs(out["loss"][k] - float(g[f"loss_{k}"])) <= 5e-6 * abs(float(g[f"loss_{k}"]))
+    gp = O.loss_grad_wrt_preds(out["preds"], out["cache"]["labels"], "nmse")
+    grads = D.auto_deeponet_backward(params, out["cache"], gp, act)
+    for key in g.files:
+        if key.startswith("grad::"):
+            assert O.rel_nmse(grads[key[len("grad::"):]], g[key]) < 1e-9, key
+    assert O.rel_nmse(grads["__u__"], g["g_inputs"][:, 0]) < 1e-9
+    cur = batch["inputs"]
+    for t in range(steps):  # generate_many, auto_deeponet.py:174-200: only u is predicted, frames are (b,1,h,w)
+        cur = D.auto_deeponet_forward(params, cur, batch["case_params"], None, act)["preds"]
+        assert O.rel_nmse(cur, g["frames"][t]) < 1e-10
