@@ -87,7 +87,7 @@ struct SlabRegs {
 template <bool AT, bool BT>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, const float* __restrict__ B,
                                               float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
-                                              GemmEpi epi) {
+                                              GemmEpi epi, int slabs_per_split) {
     __shared__ __attribute__((aligned(16))) float s_a[2][GK * GLD];
     __shared__ __attribute__((aligned(16))) float s_b[2][GK * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,17 +98,21 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, const
     SlabRegs<BT> rb;   // B is k-contiguous only when stored transposed
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[2][2] = {{zero, zero}, {zero, zero}};
-    const int nslab = (K + GK - 1) / GK;
-    ra.load(A, lda, M, K, m0, 0, tid);
-    rb.load(B, ldb, N, K, n0, 0, tid);
+    // split-K: blockIdx.z owns slabs [s0, s1) and writes its partial tile to C + z*M*ldc (epilogue in k_splitk_reduce)
+    const int nslab_all = (K + GK - 1) / GK;
+    const int s0 = blockIdx.z * slabs_per_split;
+    const int nslab = (s0 + slabs_per_split < nslab_all ? s0 + slabs_per_split : nslab_all) - s0;
+    C += (size_t)blockIdx.z * M * ldc;
+    ra.load(A, lda, M, K, m0, s0 * GK, tid);
+    rb.load(B, ldb, N, K, n0, s0 * GK, tid);
     ra.store(s_a[0], tid);
     rb.store(s_b[0], tid);
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
         const int cur = s & 1;
         if (s + 1 < nslab) {  // next slab's global reads fly during this slab's MFMAs
-            ra.load(A, lda, M, K, m0, (s + 1) * GK, tid);
-            rb.load(B, ldb, N, K, n0, (s + 1) * GK, tid);
+            ra.load(A, lda, M, K, m0, (s0 + s + 1) * GK, tid);
+            rb.load(B, ldb, N, K, n0, (s0 + s + 1) * GK, tid);
         }
         const float* sa = s_a[cur];
         const float* sb = s_b[cur];
@@ -156,39 +160,97 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, const
         }
 }
 
+// out[m][n] = epi( sum_z part[z][m][n] ), fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ part, float* __restrict__ C, int M, int N,
+                                                       int ldc, int splits, GemmEpi epi) {
+    const size_t total = (size_t)M * N;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(e / N), col = (int)(e - (size_t)row * N);
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += part[(size_t)z * total + e];
+        if (epi.mode == 1) {
+            if (epi.bias) v += epi.bias[col];
+            if (epi.preact) epi.preact[(size_t)row * ldc + col] = v;
+            v = cfd_act(v, epi.act);
+        } else if (epi.mode == 2) {
+            v += epi.bias[0];
+            if (epi.resid) v += epi.resid[(size_t)row * epi.ldr + (epi.qidx ? epi.qidx[col] : col)];
+        }
+        C[(size_t)row * ldc + col] = v;
+    }
+}
+
+// Skinny products (few 64x64 output tiles, long K -- e.g. the 100x100 weight gradients over 4290 lattice points) would
+// leave most CUs idle: K is split over blockIdx.z into partial tiles that a second kernel sums and finishes.
+static int gemm_splits(int M, int N, int K) {
+    const long tiles = (long)((M + GT - 1) / GT) * ((N + GT - 1) / GT);
+    const int nslab = (K + GK - 1) / GK;
+    if (tiles >= 128 || nslab < 8) return 1;
+    long s = (256 + tiles - 1) / tiles;
+    if (s > nslab / 4) s = nslab / 4;  // at least 4 slabs (64 k) per split
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : (int)s;
+}
+
+static size_t gemm_ws_bytes(int M, int N, int K) {
+    const int s = gemm_splits(M, N, K);
+    return s > 1 ? cfd_align_up((size_t)s * M * N * sizeof(float), 256) : 0;
+}
+
 static int launch_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int at,
-                       int bt, const GemmEpi& epi, hipStream_t st, const char* what) {
+                       int bt, const GemmEpi& epi, void* ws, hipStream_t st, const char* what) {
     if (M == 0 || N == 0) return CFD_OK;
-    const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT);
-    CFD_PROF("k_gemm", st);
-    if (!at && !bt) hipLaunchKernelGGL((k_gemm<false, false>), grid, dim3(256), 0, st, A, B, C, M, N, K, lda, ldb, ldc, epi);
-    else if (!at && bt) hipLaunchKernelGGL((k_gemm<false, true>), grid, dim3(256), 0, st, A, B, C, M, N, K, lda, ldb, ldc, epi);
-    else if (at && !bt) hipLaunchKernelGGL((k_gemm<true, false>), grid, dim3(256), 0, st, A, B, C, M, N, K, lda, ldb, ldc, epi);
-    else hipLaunchKernelGGL((k_gemm<true, true>), grid, dim3(256), 0, st, A, B, C, M, N, K, lda, ldb, ldc, epi);
+    int splits = ws ? gemm_splits(M, N, K) : 1;
+    const int nslab = (K + GK - 1) / GK;
+    const int per = (nslab + splits - 1) / splits;
+    splits = (nslab + per - 1) / per;
+    const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, splits);
+    GemmEpi e0{};
+    const GemmEpi& ek = splits > 1 ? e0 : epi;
+    float* Ck = splits > 1 ? (float*)ws : C;
+    const int ldk = splits > 1 ? N : ldc;
+    {
+        CFD_PROF("k_gemm", st);
+        if (!at && !bt) hipLaunchKernelGGL((k_gemm<false, false>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);
+        else if (!at && bt) hipLaunchKernelGGL((k_gemm<false, true>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);
+        else if (at && !bt) hipLaunchKernelGGL((k_gemm<true, false>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);
+        else hipLaunchKernelGGL((k_gemm<true, true>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);
+    }
     CFD_LAUNCH_CHECK(what);
+    if (splits > 1) {
+        CFD_PROF("k_splitk_reduce", st);
+        size_t blocks = ((size_t)M * N + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, C, M, N, ldc, splits, epi);
+        CFD_LAUNCH_CHECK(what);
+    }
     return CFD_OK;
 }
 
-extern "C" int cfd_gemm(const float* a, const float* b, float* c, int M, int N, int K, int lda, int ldb, int ldc,
+extern "C" size_t cfd_gemm_workspace_bytes(int M, int N, int K) { return gemm_ws_bytes(M, N, K); }
+
+extern "C" int cfd_gemm(const float* a, const float* b, float* c, void* ws, int M, int N, int K, int lda, int ldb, int ldc,
                         int trans_a, int trans_b, void* stream) {
     CFD_REQUIRE(a && b && c, CFD_ERR_INVALID_ARG, "cfd_gemm: NULL pointer");
     CFD_REQUIRE(M >= 0 && N >= 0 && K >= 1 && lda >= 1 && ldb >= 1 && ldc >= N, CFD_ERR_INVALID_ARG, "cfd_gemm: bad sizes");
     GemmEpi epi{};
-    return launch_gemm(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, epi, (hipStream_t)stream, "cfd_gemm");
+    return launch_gemm(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, epi, ws, (hipStream_t)stream, "cfd_gemm");
 }
 
 // ------------------------------------------------------------------------------------------------------
 // nn.Linear + activation  (ffn.py:23-31): y = act(x w^T + b), x (M,K), w (N,K), y (M,N)
 // ------------------------------------------------------------------------------------------------------
-extern "C" int cfd_linear_fwd(const float* x, const float* w, const float* bias, float* y, float* preact, int M, int K,
-                              int N, int act, void* stream) {
+extern "C" size_t cfd_linear_fwd_workspace_bytes(int M, int K, int N) { return gemm_ws_bytes(M, N, K); }
+
+extern "C" int cfd_linear_fwd(const float* x, const float* w, const float* bias, float* y, float* preact, void* ws, int M,
+                              int K, int N, int act, void* stream) {
     CFD_REQUIRE(x && w && y, CFD_ERR_INVALID_ARG, "cfd_linear_fwd: NULL pointer");
     CFD_REQUIRE(M >= 0 && K >= 1 && N >= 1, CFD_ERR_INVALID_ARG, "cfd_linear_fwd: bad sizes");
     CFD_REQUIRE(act >= 0 && act <= 4, CFD_ERR_INVALID_ARG, "cfd_linear_fwd: act must be 0 none, 1 relu, 2 tanh, 3 gelu, 4 swish");
     CFD_REQUIRE(act < 3 || preact, CFD_ERR_INVALID_ARG, "cfd_linear_fwd: gelu / swish need the pre-activation buffer");
     GemmEpi epi{};
     epi.mode = 1; epi.act = act; epi.bias = bias; epi.preact = preact;
-    return launch_gemm(x, w, y, M, N, K, K, K, N, 0, 1, epi, (hipStream_t)stream, "cfd_linear_fwd");
+    return launch_gemm(x, w, y, M, N, K, K, K, N, 0, 1, epi, ws, (hipStream_t)stream, "cfd_linear_fwd");
 }
 
 __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ gy, const float* __restrict__ y,
@@ -208,8 +270,10 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, flo
 }
 
 extern "C" size_t cfd_linear_bwd_workspace_bytes(int M, int K, int N) {
-    (void)K;
-    return cfd_align_up((size_t)(M > 0 ? M : 0) * N * sizeof(float), 256);
+    if (M <= 0) return 0;
+    const size_t gz = cfd_align_up((size_t)M * N * sizeof(float), 256);
+    const size_t a = gemm_ws_bytes(M, K, N), b = gemm_ws_bytes(N, K, M);  // input gradient, weight gradient
+    return gz + (a > b ? a : b);
 }
 
 // gx (M,K) = gz w;  gw (N,K) = gz^T x;  gb (N) = column sums of gz;  gz = gy * act'.  gx / gb may be NULL.
@@ -218,7 +282,7 @@ extern "C" int cfd_linear_bwd(const float* gy, const float* x, const float* w, c
     CFD_REQUIRE(gy && x && w && gw, CFD_ERR_INVALID_ARG, "cfd_linear_bwd: NULL pointer");
     CFD_REQUIRE(M >= 1 && K >= 1 && N >= 1, CFD_ERR_INVALID_ARG, "cfd_linear_bwd: bad sizes");
     CFD_REQUIRE(act >= 0 && act <= 4, CFD_ERR_INVALID_ARG, "cfd_linear_bwd: bad act");
-    CFD_REQUIRE(act == 0 || ws, CFD_ERR_WORKSPACE, "cfd_linear_bwd: workspace needed");
+    CFD_REQUIRE(ws, CFD_ERR_WORKSPACE, "cfd_linear_bwd: workspace needed");
     CFD_REQUIRE(!(act == 1 || act == 2) || y, CFD_ERR_INVALID_ARG, "cfd_linear_bwd: relu / tanh need the layer output");
     CFD_REQUIRE(act < 3 || preact, CFD_ERR_INVALID_ARG, "cfd_linear_bwd: gelu / swish need the pre-activation");
     hipStream_t st = (hipStream_t)stream;
@@ -232,8 +296,9 @@ extern "C" int cfd_linear_bwd(const float* gy, const float* x, const float* w, c
         gz = (const float*)ws;
     }
     GemmEpi epi{};
-    if (gx) CFD_TRY(launch_gemm(gz, w, gx, M, K, N, N, K, K, 0, 0, epi, st, "cfd_linear_bwd(gx)"));
-    CFD_TRY(launch_gemm(gz, x, gw, N, K, M, N, K, K, 1, 0, epi, st, "cfd_linear_bwd(gw)"));
+    void* skws = (char*)ws + cfd_align_up((size_t)M * N * sizeof(float), 256);
+    if (gx) CFD_TRY(launch_gemm(gz, w, gx, M, K, N, N, K, K, 0, 0, epi, skws, st, "cfd_linear_bwd(gx)"));
+    CFD_TRY(launch_gemm(gz, x, gw, N, K, M, N, K, K, 1, 0, epi, skws, st, "cfd_linear_bwd(gw)"));
     if (gb) {
         hipLaunchKernelGGL(k_colsum, dim3((N + 3) / 4), dim3(256), 0, st, gz, gb, M, N);
         CFD_LAUNCH_CHECK("cfd_linear_bwd(gb)");
@@ -253,7 +318,7 @@ extern "C" int cfd_deeponet_inner_fwd(const float* branch, const float* trunk, c
     CFD_REQUIRE(!u || qidx || Kq <= HW, CFD_ERR_INVALID_ARG, "cfd_deeponet_inner_fwd: more queries than lattice points");
     GemmEpi epi{};
     epi.mode = 2; epi.bias = bias; epi.resid = u; epi.qidx = qidx; epi.ldr = HW;  // u == NULL: bias only (deeponet.py:205)
-    return launch_gemm(branch, trunk, preds, B, Kq, P, P, P, Kq, 0, 1, epi, (hipStream_t)stream, "cfd_deeponet_inner_fwd");
+    return launch_gemm(branch, trunk, preds, B, Kq, P, P, P, Kq, 0, 1, epi, nullptr, (hipStream_t)stream, "cfd_deeponet_inner_fwd");
 }
 
 __global__ __launch_bounds__(256) void k_sum_all(const float* __restrict__ g, size_t n, float* __restrict__ part) {
@@ -275,8 +340,8 @@ __global__ __launch_bounds__(64) void k_sum_final(const float* __restrict__ part
 
 #define CFD_SUM_BLOCKS 128
 extern "C" size_t cfd_deeponet_inner_bwd_workspace_bytes(int B, int P, int Kq) {
-    (void)B; (void)P; (void)Kq;
-    return CFD_SUM_BLOCKS * sizeof(float);
+    const size_t a = gemm_ws_bytes(B, P, Kq), b = gemm_ws_bytes(Kq, P, B);
+    return cfd_align_up(CFD_SUM_BLOCKS * sizeof(float), 256) + (a > b ? a : b);
 }
 
 // gbranch (B,P) = g trunk;  gtrunk (Kq,P) = g^T branch;  gbias = sum g   (the residual's gradient is g itself)
@@ -286,8 +351,9 @@ extern "C" int cfd_deeponet_inner_bwd(const float* gpreds, const float* branch, 
     CFD_REQUIRE(B >= 1 && P >= 1 && Kq >= 1, CFD_ERR_INVALID_ARG, "cfd_deeponet_inner_bwd: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     GemmEpi epi{};
-    if (gbranch) CFD_TRY(launch_gemm(gpreds, trunk, gbranch, B, P, Kq, Kq, P, P, 0, 0, epi, st, "cfd_deeponet_inner_bwd(gbranch)"));
-    if (gtrunk) CFD_TRY(launch_gemm(gpreds, branch, gtrunk, Kq, P, B, Kq, P, P, 1, 0, epi, st, "cfd_deeponet_inner_bwd(gtrunk)"));
+    void* skws = (char*)ws + cfd_align_up(CFD_SUM_BLOCKS * sizeof(float), 256);
+    if (gbranch) CFD_TRY(launch_gemm(gpreds, trunk, gbranch, B, P, Kq, Kq, P, P, 0, 0, epi, skws, st, "cfd_deeponet_inner_bwd(gbranch)"));
+    if (gtrunk) CFD_TRY(launch_gemm(gpreds, branch, gtrunk, Kq, P, B, Kq, P, P, 1, 0, epi, skws, st, "cfd_deeponet_inner_bwd(gtrunk)"));
     if (gbias) {
         hipLaunchKernelGGL(k_sum_all, dim3(CFD_SUM_BLOCKS), dim3(256), 0, st, gpreds, (size_t)B * Kq, (float*)ws);
         CFD_LAUNCH_CHECK("cfd_deeponet_inner_bwd(sum)");

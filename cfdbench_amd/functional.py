@@ -297,7 +297,9 @@ class LinearActFn(torch.autograd.Function):
             raise RuntimeError(f"Linear: input has {K} features, weight expects {w.shape[1]}")
         y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
         pre = torch.empty_like(y) if act >= 3 else None
-        api.call("cfd_linear_fwd", _ptr(x2), _ptr(w), _ptr(b), _ptr(y), _ptr(pre), M, K, N, act, _stream())
+        nws = api.size("cfd_linear_fwd_workspace_bytes", M, K, N)
+        ws = _bytes(nws, x2.device) if nws else None
+        api.call("cfd_linear_fwd", _ptr(x2), _ptr(w), _ptr(b), _ptr(y), _ptr(pre), _ptr(ws), M, K, N, act, _stream())
         ctx.save_for_backward(x2, w, y if act in (1, 2) else None, pre)
         ctx.meta = (M, K, N, act, lead, b is not None)
         return y.reshape(*lead, N)

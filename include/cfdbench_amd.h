@@ -163,14 +163,17 @@ int cfd_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_av
 
 /* c (M,N) = op(a) op(b); trans_a: a stored (K,M) else (M,K); trans_b: b stored (N,K) else (K,N); row-major, leading
  * dimensions in elements.                                                                                    */
-int cfd_gemm(const float* a, const float* b, float* c, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
-             int trans_b, void* stream);
+size_t cfd_gemm_workspace_bytes(int M, int N, int K); /* split-K partial tiles of skinny products; 0 = none needed */
+int cfd_gemm(const float* a, const float* b, float* c, void* ws, int M, int N, int K, int lda, int ldb, int ldc,
+             int trans_a, int trans_b, void* stream);
 
 /* nn.Linear + activation (Ffn, src/models/ffn.py:23-31): y = act(x w^T + bias); x (M,K), w (N,K), y (M,N).
  * act: 0 none, 1 relu, 2 tanh, 3 gelu (exact erf), 4 swish (get_act_fn, src/models/act_fn.py:5-18).
- * preact (M,N) receives x w^T + bias when non-NULL (required for gelu / swish, whose derivative needs it).    */
-int cfd_linear_fwd(const float* x, const float* w, const float* bias, float* y, float* preact, int M, int K, int N,
-                   int act, void* stream);
+ * preact (M,N) receives x w^T + bias when non-NULL (required for gelu / swish, whose derivative needs it).
+ * ws: cfd_linear_fwd_workspace_bytes() bytes (may be NULL when that is 0).                                    */
+size_t cfd_linear_fwd_workspace_bytes(int M, int K, int N);
+int cfd_linear_fwd(const float* x, const float* w, const float* bias, float* y, float* preact, void* ws, int M, int K,
+                   int N, int act, void* stream);
 /* Backward of the above: gx (M,K), gw (N,K), gb (N) from gy (M,N); y = layer output (relu / tanh), preact (gelu /
  * swish).  gx and gb may be NULL.  ws: cfd_linear_bwd_workspace_bytes().                                    */
 size_t cfd_linear_bwd_workspace_bytes(int M, int K, int N);

@@ -403,7 +403,8 @@ def check_gemm(be, M, N, K, ta, tb, seed=21):
     A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
     Bm = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
     dA, dB, C = be.dev(A), be.dev(Bm), be.zeros((M, N))
-    api.call("cfd_gemm", P(dA), P(dB), P(C), M, N, K, A.shape[1], Bm.shape[1], N, int(ta), int(tb), be.stream)
+    ws = be.bytes(api.size("cfd_gemm_workspace_bytes", M, N, K))
+    api.call("cfd_gemm", P(dA), P(dB), P(C), P(ws), M, N, K, A.shape[1], Bm.shape[1], N, int(ta), int(tb), be.stream)
     be.sync()
     ref = (A.T if ta else A).astype(f64) @ (Bm.T if tb else Bm).astype(f64)
     return {"c": nm(be.host(C), ref)}
@@ -420,7 +421,8 @@ def check_linear(be, M, K, N, act, seed=22):
     gy = rng.standard_normal((M, N)).astype(np.float32)
     dx, dw, db, dgy = be.dev(x), be.dev(w), be.dev(b), be.dev(gy)
     y, pre = be.zeros((M, N)), be.zeros((M, N))
-    api.call("cfd_linear_fwd", P(dx), P(dw), P(db), P(y), P(pre), M, K, N, code, be.stream)
+    wsf = be.bytes(api.size("cfd_linear_fwd_workspace_bytes", M, K, N))
+    api.call("cfd_linear_fwd", P(dx), P(dw), P(db), P(y), P(pre), P(wsf), M, K, N, code, be.stream)
     be.sync()
     z = x.astype(f64) @ w.astype(f64).T + b
     res = {"y": nm(be.host(y), D.act(z, act)), "pre": nm(be.host(pre), z)}

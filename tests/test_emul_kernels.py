@@ -89,12 +89,12 @@ def test_error_paths(be):
     be.api.plan_destroy(plan)
 
 
-@pytest.mark.parametrize("M,N,Kd,ta,tb", [(70, 45, 37, 0, 0), (33, 100, 19, 0, 1), (100, 21, 66, 1, 0), (17, 18, 5, 1, 1)])
+@pytest.mark.parametrize("M,N,Kd,ta,tb", [(70, 45, 37, 0, 0), (33, 100, 19, 0, 1), (100, 21, 66, 1, 0), (17, 18, 5, 1, 1), (20, 30, 700, 1, 0), (40, 24, 330, 0, 1)])
 def test_gemm(be, M, N, Kd, ta, tb):
     _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
 
 
-@pytest.mark.parametrize("M,K_in,N,act", [(37, 21, 24, "relu"), (9, 130, 100, "tanh"), (20, 7, 5, "gelu"), (5, 3, 70, "swish"), (66, 2, 16, "none")])
+@pytest.mark.parametrize("M,K_in,N,act", [(37, 21, 24, "relu"), (9, 130, 100, "tanh"), (20, 7, 5, "gelu"), (5, 3, 70, "swish"), (66, 2, 16, "none"), (24, 520, 20, "relu")])
 def test_linear_act(be, M, K_in, N, act):
     _assert_all(K.check_linear(be, M, K_in, N, act))
 
