@@ -79,6 +79,18 @@ _SIGS = {
     "cfd_deeponet_inner_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfd_deeponet_inner_bwd_workspace_bytes": (_Z, [_I, _I, _I]),
     "cfd_deeponet_inner_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "cfd_conv2d_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cfd_conv2d_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "cfd_conv2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cfd_batchnorm_workspace_bytes": (_Z, [_I]),
+    "cfd_batchnorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _P]),
+    "cfd_batchnorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cfd_maxpool2_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "cfd_maxpool2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "cfd_convt2_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cfd_convt2_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "cfd_convt2_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cfd_residual_mask": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfd_fno_workspace_bytes": (_Z, [_P, C.POINTER(FnoShape), _I]),
     "cfd_fno_forward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "cfd_fno_backward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),

@@ -1,0 +1,741 @@
+// Convolution stack of the U-Net / ResNet baselines on the CDNA4 matrix pipe (exact-fp32 v_mfma_f32_16x16x4_f32):
+//   nn.Conv2d(k, padding=k/2, padding_mode="replicate")   src/models/unet.py:20-43 (k=3), src/models/resnet.py:35-55 (k=7)
+//   nn.BatchNorm2d + ReLU                                  src/models/unet.py:28-30,41-43
+//   nn.MaxPool2d(2), nn.ConvTranspose2d(k=2, s=2)          src/models/unet.py:59,80
+// All three convolution passes are implicit GEMMs whose data operand is gathered straight from the NCHW tensors
+// (replicate padding = index clamping; no im2col buffer):
+//   forward : out[o][p]   = sum_{(i,ky,kx)} w[o][(i,ky,kx)] * in[i][clamp(p + (ky,kx) - pad)]          M = Cout, N = pixels
+//   input gradient: the forward is V(P(in)) with P = replicate pad, V = valid convolution, so gin = P^T(V^T(g)):
+//             V^T(g) is the same gather kernel on the (H+2pad) x (W+2pad) extended grid with zero outside g, and
+//             P^T folds the pad ring back onto the border pixels (k_fold_pad) -- deterministic, no atomics
+//   weight gradient: gw[o][(i,ky,kx)] = sum_p g[o][p] * in[i][clamp(...)]                    M = Cout, N = Cin*k*k, K = pixels
+#include "cfd_common.h"
+
+#define CV_WAVES 4
+
+struct ConvGeom {
+    int B, Ci, Co, H, W, ks;  // ks = kernel size (odd), pad = ks/2
+};
+
+// (i, ky, kx) of flat index k over Ci*ks*ks
+__device__ __forceinline__ void conv_split_k(int k, int ks, int& i, int& ky, int& kx) {
+    const int kk = ks * ks;
+    i = k / kk;
+    const int r = k - i * kk;
+    ky = r / ks;
+    kx = r - ky * ks;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward / transposed-valid gather GEMM:  dst[b][m][p] = bias[m] + sum_k A(m,k) * src[b][c(k)][pos(p,k)]
+//   EXT = false: forward.    p over H x W, pos = clamp(p + (ky,kx) - pad);                A(m,k) = w[m][k]       (m = o)
+//   EXT = true : V^T(g).     p over (H+2pad) x (W+2pad), pos = p - (ky,kx), zero outside; A(m,k) = w[o][m][ky][kx] (m = i)
+// A wave owns 16 consecutive (linear) pixels of one batch entry and every output channel (MT tiles of 16).
+// ------------------------------------------------------------------------------------------------------
+template <int MT, bool EXT>
+__global__ __launch_bounds__(64 * CV_WAVES) void k_conv_gather(const float* __restrict__ src, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ dst,
+                                                               ConvGeom g, int tiles_per_b, long total_tiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int pad = g.ks / 2, kk = g.ks * g.ks;
+    const int Cs = EXT ? g.Co : g.Ci;       // channels of src (contracted)
+    const int Cm = EXT ? g.Ci : g.Co;       // channels of dst (M)
+    const int K = Cs * kk;
+    const int Hd = EXT ? g.H + 2 * pad : g.H, Wd = EXT ? g.W + 2 * pad : g.W;  // dst grid
+    const int HWd = Hd * Wd, HWs = g.H * g.W;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (long tile = (long)blockIdx.x * CV_WAVES + wave; tile < total_tiles; tile += (long)gridDim.x * CV_WAVES) {
+        const int b = (int)(tile / tiles_per_b);
+        const int p = (int)(tile - (long)b * tiles_per_b) * 16 + n;  // this lane's pixel (data operand column)
+        const bool pvalid = p < HWd;
+        const int py = pvalid ? p / Wd : 0, px = pvalid ? p - py * Wd : 0;
+        const float* sb = src + (size_t)b * Cs * HWs;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = zero;
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const int k = k0 + q;
+            int c, ky, kx;
+            conv_split_k(k < K ? k : 0, g.ks, c, ky, kx);
+            float bv = 0.f;
+            if (k < K && pvalid) {
+                if constexpr (EXT) {
+                    const int y = py - ky, x = px - kx;
+                    if (y >= 0 && y < g.H && x >= 0 && x < g.W) bv = sb[(size_t)c * HWs + y * g.W + x];
+                } else {
+                    int y = py + ky - pad, x = px + kx - pad;
+                    y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
+                    x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
+                    bv = sb[(size_t)c * HWs + y * g.W + x];
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = 16 * mt + n;  // A operand row
+                float av = 0.f;
+                if (m < Cm && k < K) av = EXT ? w[((size_t)c * g.Ci + m) * kk + ky * g.ks + kx] : w[(size_t)m * K + k];
+                acc[mt] = cfd_mfma16x16x4(av, bv, acc[mt]);
+            }
+        }
+        if (pvalid) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * mt + 4 * q + r;
+                    if (m < Cm) dst[((size_t)b * Cm + m) * HWd + p] = acc[mt][r] + (bias ? bias[m] : 0.f);
+                }
+        }
+    }
+}
+
+template <bool EXT>
+static int launch_conv_gather(const float* src, const float* w, const float* bias, float* dst, const ConvGeom& g,
+                              hipStream_t st, const char* what) {
+    const int pad = g.ks / 2;
+    const int HWd = EXT ? (g.H + 2 * pad) * (g.W + 2 * pad) : g.H * g.W;
+    const int tiles_per_b = (HWd + 15) / 16;
+    const long total = (long)g.B * tiles_per_b;
+    long blocks = (total + CV_WAVES - 1) / CV_WAVES;
+    if (blocks > 4096) blocks = 4096;
+    const int Cm = EXT ? g.Ci : g.Co, MT = (Cm + 15) / 16;
+#define CV_L(M_) hipLaunchKernelGGL((k_conv_gather<M_, EXT>), dim3((unsigned)blocks), dim3(64 * CV_WAVES), 0, st, src, w, bias, dst, g, tiles_per_b, total)
+    switch (MT) {
+        case 1: CV_L(1); break;
+        case 2: CV_L(2); break;
+        case 3: CV_L(3); break;
+        case 4: CV_L(4); break;
+        case 6: CV_L(6); break;
+        case 8: CV_L(8); break;
+        case 12: CV_L(12); break;
+        default:
+            if (MT <= 6) CV_L(6);
+            else if (MT <= 12) CV_L(12);
+            else {
+                cfd_set_error("%s: %d output channels unsupported (max 192)", what, Cm);
+                return CFD_ERR_UNSUPPORTED;
+            }
+    }
+#undef CV_L
+    CFD_LAUNCH_CHECK(what);
+    return CFD_OK;
+}
+
+static int conv_check(const char* fn, int B, int Ci, int Co, int H, int W, int ks) {
+    CFD_REQUIRE(B >= 0 && Ci >= 1 && Co >= 1 && H >= 1 && W >= 1, CFD_ERR_INVALID_ARG, "%s: bad sizes", fn);
+    CFD_REQUIRE(ks >= 1 && ks <= 7 && (ks & 1), CFD_ERR_UNSUPPORTED, "%s: kernel size %d unsupported (odd, <= 7)", fn, ks);
+    CFD_REQUIRE(Ci <= 192 && Co <= 192, CFD_ERR_UNSUPPORTED, "%s: channels (%d -> %d) unsupported (max 192)", fn, Ci, Co);
+    return CFD_OK;
+}
+
+// out (B,Co,H,W) = conv2d(in (B,Ci,H,W), w (Co,Ci,ks,ks), bias, padding=ks/2, padding_mode="replicate")
+extern "C" int cfd_conv2d_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int H,
+                              int W, int ks, void* stream) {
+    CFD_REQUIRE(in && w && out, CFD_ERR_INVALID_ARG, "cfd_conv2d_fwd: NULL pointer");
+    CFD_TRY(conv_check("cfd_conv2d_fwd", B, Ci, Co, H, W, ks));
+    if (B == 0) return CFD_OK;
+    const ConvGeom g{B, Ci, Co, H, W, ks};
+    CFD_PROF("k_conv_fwd", (hipStream_t)stream);
+    return launch_conv_gather<false>(in, w, bias, out, g, (hipStream_t)stream, "cfd_conv2d_fwd");
+}
+
+// gin[b][i][y][x] = sum over the extended positions that replicate padding maps to (y, x)
+__global__ __launch_bounds__(256) void k_fold_pad(const float* __restrict__ ext, float* __restrict__ gin, long nimg, int H,
+                                                  int W, int pad) {
+    const int He = H + 2 * pad, We = W + 2 * pad;
+    const long total = nimg * H * W;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long img = e / (H * W);
+        const int p = (int)(e - img * H * W), y = p / W, x = p - y * W;
+        const int y0 = y == 0 ? 0 : y + pad, y1 = y == H - 1 ? He - 1 : y + pad;
+        const int x0 = x == 0 ? 0 : x + pad, x1 = x == W - 1 ? We - 1 : x + pad;
+        const float* s = ext + img * He * We;
+        float acc = 0.f;
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) acc += s[yy * We + xx];
+        gin[e] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// weight gradient: gw[o][j] = sum_{b,p} g[b][o][p] * in[b][i(j)][clamp(p + (ky,kx)(j) - pad)],  j over Ci*ks*ks
+// Workgroup = one 32 x 64 block of the (o, j) plane x one chunk of pixels; partials are reduced in a fixed order.
+// ------------------------------------------------------------------------------------------------------
+#define CW_MT 2
+#define CW_NT 4
+__global__ __launch_bounds__(64 * CV_WAVES) void k_conv_wgrad(const float* __restrict__ gout, const float* __restrict__ in,
+                                                              float* __restrict__ part, ConvGeom g, int chunks_per_b,
+                                                              int nchunk_total, int chunk_px) {
+    __shared__ float s_red[CV_WAVES * CW_MT * CW_NT * 4 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int pad = g.ks / 2, kk = g.ks * g.ks, J = g.Ci * kk, HW = g.H * g.W;
+    const int o0 = blockIdx.y * 16 * CW_MT, j0 = blockIdx.z * 16 * CW_NT;
+    // this lane's B-operand columns: j = j0 + 16 nt + n -> (i, ky, kx)
+    int ci[CW_NT], dy[CW_NT], dx[CW_NT];
+    bool jv[CW_NT];
+#pragma unroll
+    for (int nt = 0; nt < CW_NT; ++nt) {
+        const int j = j0 + 16 * nt + n;
+        jv[nt] = j < J;
+        int ky, kx;
+        conv_split_k(jv[nt] ? j : 0, g.ks, ci[nt], ky, kx);
+        dy[nt] = ky - pad;
+        dx[nt] = kx - pad;
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[CW_MT][CW_NT];
+#pragma unroll
+    for (int a = 0; a < CW_MT; ++a)
+#pragma unroll
+        for (int c = 0; c < CW_NT; ++c) acc[a][c] = zero;
+    const int chunk = blockIdx.x;  // (b, pixel chunk)
+    const int b = chunk / chunks_per_b;
+    const int pbeg = (chunk - b * chunks_per_b) * chunk_px;
+    const int pend = pbeg + chunk_px < HW ? pbeg + chunk_px : HW;
+    const float* gb = gout + (size_t)b * g.Co * HW;
+    const float* ib = in + (size_t)b * g.Ci * HW;
+    for (int p0 = pbeg + 4 * wave; p0 < pend; p0 += 4 * CV_WAVES) {  // waves interleave 4-pixel k-steps
+        const int p = p0 + q;
+        const bool pv = p < pend;
+        const int y = pv ? p / g.W : 0, x = pv ? p - y * g.W : 0;
+        float av[CW_MT], bv[CW_NT];
+#pragma unroll
+        for (int a = 0; a < CW_MT; ++a) {
+            const int o = o0 + 16 * a + n;
+            av[a] = (pv && o < g.Co) ? gb[(size_t)o * HW + p] : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < CW_NT; ++c) {
+            float v = 0.f;
+            if (pv && jv[c]) {
+                int yy = y + dy[c], xx = x + dx[c];
+                yy = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy);
+                xx = xx < 0 ? 0 : (xx >= g.W ? g.W - 1 : xx);
+                v = ib[(size_t)ci[c] * HW + yy * g.W + xx];
+            }
+            bv[c] = v;
+        }
+#pragma unroll
+        for (int a = 0; a < CW_MT; ++a)
+#pragma unroll
+            for (int c = 0; c < CW_NT; ++c) acc[a][c] = cfd_mfma16x16x4(av[a], bv[c], acc[a][c]);
+    }
+    // block reduction of the 4 waves (fixed order), one partial tile per (chunk, o-block, j-block)
+#pragma unroll
+    for (int a = 0; a < CW_MT; ++a)
+#pragma unroll
+        for (int c = 0; c < CW_NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_red[(((wave * CW_MT + a) * CW_NT + c) * 4 + r) * 64 + lane] = acc[a][c][r];
+    __syncthreads();
+    float* dst = part + (size_t)chunk * g.Co * J;
+    for (int e = threadIdx.x; e < CW_MT * CW_NT * 4 * 64; e += blockDim.x) {
+        const int ln = e & 63, r = (e >> 6) & 3, tile = e >> 8;
+        const int a = tile / CW_NT, c = tile % CW_NT;
+        const int o = o0 + 16 * a + 4 * (ln >> 4) + r, j = j0 + 16 * c + (ln & 15);
+        if (o < g.Co && j < J) {
+            float s = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < CV_WAVES; ++wv) s += s_red[(((wv * CW_MT + a) * CW_NT + c) * 4 + r) * 64 + ln];
+            dst[(size_t)o * J + j] = s;
+        }
+    }
+    (void)nchunk_total;
+}
+
+// out[e] = sum_chunk part[chunk][e]  (8 loads in flight, fixed order)
+__global__ __launch_bounds__(256) void k_part_reduce(const float* __restrict__ part, float* __restrict__ out, long n, int nchunk) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        int c = 0;
+        for (; c + 8 <= nchunk; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = part[(size_t)(c + k) * n + e];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; c < nchunk; ++c) s += part[(size_t)c * n + e];
+        out[e] = s;
+    }
+}
+
+// per-channel sum over (B, H*W): one wave per channel, lanes stride over the elements, fixed tree
+__global__ __launch_bounds__(256) void k_chan_sum(const float* __restrict__ g, float* __restrict__ out, int B, int C, int HW) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* p = g + ((size_t)b * C + c) * HW;
+        for (int i = lane; i < HW; i += 64) s += p[i];
+    }
+    s = cfd_wave_sum(s);
+    if (lane == 0) out[c] = s;
+}
+
+static void conv_wgrad_plan(int B, int HW, int& chunk_px, int& chunks_per_b) {
+    // about 1024 (b, chunk) units, each at least 64 pixels
+    long target = 1024 / (B > 0 ? B : 1);
+    if (target < 1) target = 1;
+    chunk_px = (int)((HW + target - 1) / target);
+    if (chunk_px < 64) chunk_px = 64;
+    chunk_px = (chunk_px + 15) / 16 * 16;
+    chunks_per_b = (HW + chunk_px - 1) / chunk_px;
+}
+
+extern "C" size_t cfd_conv2d_bwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks) {
+    if (B <= 0) return 0;
+    const int pad = ks / 2;
+    const size_t ext = cfd_align_up((size_t)B * Ci * (H + 2 * pad) * (W + 2 * pad) * sizeof(float), 256);
+    int chunk_px, cpb;
+    conv_wgrad_plan(B, H * W, chunk_px, cpb);
+    const size_t part = cfd_align_up((size_t)B * cpb * Co * Ci * ks * ks * sizeof(float), 256);
+    return ext > part ? ext : part;
+}
+
+// gin (B,Ci,H,W), gw (Co,Ci,ks,ks), gb (Co) from gout (B,Co,H,W); any of gin / gw / gb may be NULL.
+extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws,
+                              int B, int Ci, int Co, int H, int W, int ks, void* stream) {
+    CFD_REQUIRE(gout && in && w && ws, CFD_ERR_INVALID_ARG, "cfd_conv2d_bwd: NULL pointer");
+    CFD_TRY(conv_check("cfd_conv2d_bwd", B, Ci, Co, H, W, ks));
+    CFD_REQUIRE(B >= 1, CFD_ERR_INVALID_ARG, "cfd_conv2d_bwd: empty batch");
+    hipStream_t st = (hipStream_t)stream;
+    const ConvGeom g{B, Ci, Co, H, W, ks};
+    const int HW = H * W, pad = ks / 2;
+    if (gin) {
+        float* ext = (float*)ws;
+        {
+            CFD_PROF("k_conv_dgrad", st);
+            CFD_TRY(launch_conv_gather<true>(gout, w, nullptr, ext, g, st, "cfd_conv2d_bwd(dgrad)"));
+        }
+        const long total = (long)B * Ci * HW;
+        long blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        CFD_PROF("k_fold_pad", st);
+        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ext, gin, (long)B * Ci, H, W, pad);
+        CFD_LAUNCH_CHECK("cfd_conv2d_bwd(fold)");
+    }
+    if (gw) {
+        int chunk_px, cpb;
+        conv_wgrad_plan(B, HW, chunk_px, cpb);
+        const int nchunk = B * cpb, J = Ci * ks * ks;
+        const dim3 grid(nchunk, (Co + 16 * CW_MT - 1) / (16 * CW_MT), (J + 16 * CW_NT - 1) / (16 * CW_NT));
+        {
+            CFD_PROF("k_conv_wgrad", st);
+            hipLaunchKernelGGL(k_conv_wgrad, grid, dim3(64 * CV_WAVES), 0, st, gout, in, (float*)ws, g, cpb, nchunk, chunk_px);
+        }
+        CFD_LAUNCH_CHECK("cfd_conv2d_bwd(wgrad)");
+        const long n = (long)Co * J;
+        long blocks = (n + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        CFD_PROF("k_part_reduce", st);
+        hipLaunchKernelGGL(k_part_reduce, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, gw, n, nchunk);
+        CFD_LAUNCH_CHECK("cfd_conv2d_bwd(reduce)");
+    }
+    if (gb) {
+        hipLaunchKernelGGL(k_chan_sum, dim3((Co + 3) / 4), dim3(256), 0, st, gout, gb, B, Co, HW);
+        CFD_LAUNCH_CHECK("cfd_conv2d_bwd(bias)");
+    }
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// BatchNorm2d (+ ReLU)   (src/models/unet.py:28-30; torch defaults eps = 1e-5, momentum = 0.1)
+// ------------------------------------------------------------------------------------------------------
+// Per-channel statistics over (B, H, W) in two deterministic stages: grid (C, nsplit) partials, then one wave per
+// channel.  Two passes (mean, then centred sum of squares) keep fp32 accurate when |mean| >> std.
+#define BN_SPLIT 32
+
+// MODE 0: sum x;  MODE 1: sum (x - mean[c])^2;  MODE 2: sums of gz and gz*xhat with gz = gy * (y > 0 if relu)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x, const float* __restrict__ aux,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    float* __restrict__ part, int B, int C, int HW, int relu) {
+    __shared__ float s_r[8];
+    const int c = blockIdx.x, sp = blockIdx.y;
+    const long n = (long)B * HW;
+    const long per = (n + BN_SPLIT - 1) / BN_SPLIT;
+    const long e0 = sp * per, e1 = e0 + per < n ? e0 + per : n;
+    const float mu = MODE >= 1 ? mean[c] : 0.f, rs = MODE == 2 ? rstd[c] : 0.f;
+    float s0 = 0.f, s1 = 0.f;
+    for (long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const long b = e / HW;
+        const size_t off = ((size_t)b * C + c) * HW + (e - b * HW);
+        const float v = x[off];
+        if (MODE == 0) s0 += v;
+        else if (MODE == 1) { const float d = v - mu; s0 = fmaf(d, d, s0); }
+        else {
+            // x = layer input, aux = upstream gradient; relu mask from the normalised output sign
+            const float xh = (v - mu) * rs;
+            float gz = aux[off];
+            if (relu) {
+                const float yv = fmaf(xh, mean[C + c], mean[2 * C + c]);  // gamma, beta packed behind mean
+                gz = yv > 0.f ? gz : 0.f;
+            }
+            s0 += gz;
+            s1 = fmaf(gz, xh, s1);
+        }
+    }
+    s0 = cfd_wave_sum(s0);
+    s1 = cfd_wave_sum(s1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_r[wave] = s0; s_r[4 + wave] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((size_t)c * BN_SPLIT + sp) * 2] = (s_r[0] + s_r[1]) + (s_r[2] + s_r[3]);
+        part[((size_t)c * BN_SPLIT + sp) * 2 + 1] = (s_r[4] + s_r[5]) + (s_r[6] + s_r[7]);
+    }
+}
+
+// stage 0 -> mean;  stage 1 -> rstd (+ running statistics);  stage 2 -> (gbeta, ggamma)
+__global__ __launch_bounds__(64) void k_bn_final(const float* __restrict__ part, int stage, float count, float eps,
+                                                 float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                                 float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                 float* __restrict__ gbeta, float* __restrict__ ggamma, int C) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float a = lane < BN_SPLIT ? part[((size_t)c * BN_SPLIT + lane) * 2] : 0.f;
+    float b = lane < BN_SPLIT ? part[((size_t)c * BN_SPLIT + lane) * 2 + 1] : 0.f;
+    a = cfd_wave_sum(a);
+    b = cfd_wave_sum(b);
+    if (lane != 0) return;
+    if (stage == 0) mean[c] = a / count;
+    else if (stage == 1) {
+        const float var = a / count;  // biased: what normalises (torch.nn.functional.batch_norm, training=True)
+        rstd[c] = 1.0f / sqrtf(var + eps);
+        if (run_mean) {
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean[c];
+            const float unb = count > 1.f ? a / (count - 1.f) : var;  // running_var tracks the unbiased estimate
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+        }
+    } else {
+        gbeta[c] = a;
+        ggamma[c] = b;
+    }
+    (void)C;
+}
+
+__global__ __launch_bounds__(256) void k_bn_eval_stats(const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                                       float eps, float* __restrict__ mean, float* __restrict__ rstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { mean[c] = run_mean[c]; rstd[c] = 1.0f / sqrtf(run_var[c] + eps); }
+}
+
+// y = [relu]((x - mean) * rstd * gamma + beta)
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float* __restrict__ y, long total, int C,
+                                                  int HW, int relu) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((e / HW) % C);
+        float v = fmaf((x[e] - mean[c]) * rstd[c], gamma[c], beta[c]);
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[e] = v;
+    }
+}
+
+// gx = gamma * rstd * (gz - [gbeta/N + xhat * ggamma/N] if training)
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ gy,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ gbeta, const float* __restrict__ ggamma,
+                                                      float* __restrict__ gx, long total, int C, int HW, float inv_count,
+                                                      int relu, int training) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((e / HW) % C);
+        const float xh = (x[e] - mean[c]) * rstd[c];
+        float gz = gy[e];
+        if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.f)) gz = 0.f;
+        float t = gz;
+        if (training) t -= (gbeta[c] + xh * ggamma[c]) * inv_count;
+        gx[e] = gamma[c] * rstd[c] * t;
+    }
+}
+
+static unsigned ew_blocks(long total) {
+    long b = (total + 255) / 256;
+    return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+extern "C" size_t cfd_batchnorm_workspace_bytes(int C) {
+    // [partials C*SPLIT*2 | packed (mean, gamma, beta) 3C] floats
+    return cfd_align_up(((size_t)C * BN_SPLIT * 2 + 3 * (size_t)C) * sizeof(float), 256);
+}
+
+// y = [relu](batch_norm(x)).  training != 0: batch statistics (saved into save_mean / save_rstd, running statistics
+// updated when non-NULL); training == 0: running statistics.  x, y: (B,C,H*W); everything else: (C).
+extern "C" int cfd_batchnorm_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                                 float* y, float* save_mean, float* save_rstd, void* ws, int B, int C, int HW, float eps,
+                                 float momentum, int training, int relu, void* stream) {
+    CFD_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && ws, CFD_ERR_INVALID_ARG, "cfd_batchnorm_fwd: NULL pointer");
+    CFD_REQUIRE(B >= 1 && C >= 1 && HW >= 1, CFD_ERR_INVALID_ARG, "cfd_batchnorm_fwd: bad sizes");
+    CFD_REQUIRE(training || (run_mean && run_var), CFD_ERR_INVALID_ARG, "cfd_batchnorm_fwd: eval mode needs running statistics");
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    const float count = (float)((double)B * HW);
+    if (training) {
+        CFD_PROF("k_bn_stats", st);
+        hipLaunchKernelGGL((k_bn_partial<0>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, part, B, C, HW, 0);
+        hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 0, count, eps, momentum, save_mean,
+                           save_rstd, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, C);
+        hipLaunchKernelGGL((k_bn_partial<1>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, (const float*)nullptr,
+                           (const float*)save_mean, (const float*)nullptr, part, B, C, HW, 0);
+        hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 1, count, eps, momentum, save_mean,
+                           save_rstd, run_mean, run_var, (float*)nullptr, (float*)nullptr, C);
+        CFD_LAUNCH_CHECK("cfd_batchnorm_fwd(stats)");
+    } else {
+        hipLaunchKernelGGL(k_bn_eval_stats, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)run_mean,
+                           (const float*)run_var, eps, save_mean, save_rstd, C);
+        CFD_LAUNCH_CHECK("cfd_batchnorm_fwd(eval stats)");
+    }
+    const long total = (long)B * C * HW;
+    CFD_PROF("k_bn_apply", st);
+    hipLaunchKernelGGL(k_bn_apply, dim3(ew_blocks(total)), dim3(256), 0, st, x, (const float*)save_mean,
+                       (const float*)save_rstd, gamma, beta, y, total, C, HW, relu);
+    CFD_LAUNCH_CHECK("cfd_batchnorm_fwd(apply)");
+    return CFD_OK;
+}
+
+__global__ __launch_bounds__(256) void k_pack3(const float* a, const float* b, const float* c, float* out, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) { out[i] = a[i]; out[C + i] = b[i]; out[2 * C + i] = c[i]; }
+}
+
+// gx, ggamma, gbeta from gy (gradient on the [relu]'d output), the layer input x and the saved statistics.
+extern "C" int cfd_batchnorm_bwd(const float* gy, const float* x, const float* gamma, const float* beta,
+                                 const float* save_mean, const float* save_rstd, float* gx, float* ggamma, float* gbeta,
+                                 void* ws, int B, int C, int HW, int training, int relu, void* stream) {
+    CFD_REQUIRE(gy && x && gamma && beta && save_mean && save_rstd && gx && ggamma && gbeta && ws, CFD_ERR_INVALID_ARG,
+                "cfd_batchnorm_bwd: NULL pointer");
+    CFD_REQUIRE(B >= 1 && C >= 1 && HW >= 1, CFD_ERR_INVALID_ARG, "cfd_batchnorm_bwd: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    float* packed = part + (size_t)C * BN_SPLIT * 2;  // (mean, gamma, beta) for the relu mask inside the reduction
+    hipLaunchKernelGGL(k_pack3, dim3((C + 255) / 256), dim3(256), 0, st, save_mean, gamma, beta, packed, C);
+    {
+        CFD_PROF("k_bn_bwd_reduce", st);
+        hipLaunchKernelGGL((k_bn_partial<2>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, gy, (const float*)packed, save_rstd,
+                           part, B, C, HW, relu);
+        hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 2, 1.f, 0.f, 0.f, (float*)nullptr,
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, gbeta, ggamma, C);
+    }
+    CFD_LAUNCH_CHECK("cfd_batchnorm_bwd(reduce)");
+    const long total = (long)B * C * HW;
+    CFD_PROF("k_bn_bwd_apply", st);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_blocks(total)), dim3(256), 0, st, x, gy, save_mean, save_rstd, gamma, beta,
+                       (const float*)gbeta, (const float*)ggamma, gx, total, C, HW, (float)(1.0 / ((double)B * HW)), relu,
+                       training);
+    CFD_LAUNCH_CHECK("cfd_batchnorm_bwd(apply)");
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// MaxPool2d(2)  (src/models/unet.py:59): floor mode, gradient to the FIRST maximum in row-major window order
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_maxpool2(const float* __restrict__ x, float* __restrict__ y, long nimg, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = nimg * Ho * Wo;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long img = e / (Ho * Wo);
+        const int p = (int)(e - img * Ho * Wo), yo = p / Wo, xo = p - yo * Wo;
+        const float* s = x + img * H * W + (2 * yo) * W + 2 * xo;
+        float m = s[0];
+        m = s[1] > m ? s[1] : m;
+        m = s[W] > m ? s[W] : m;
+        m = s[W + 1] > m ? s[W + 1] : m;
+        y[e] = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_maxpool2_bwd(const float* __restrict__ x, const float* __restrict__ gy,
+                                                      float* __restrict__ gx, long nimg, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = nimg * H * W;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long img = e / (H * W);
+        const int p = (int)(e - img * H * W), yy = p / W, xx = p - yy * W;
+        const int yo = yy / 2, xo = xx / 2;
+        float g = 0.f;
+        if (yo < Ho && xo < Wo) {  // rows / columns cut off by floor mode get no gradient
+            const float* s = x + img * H * W + (2 * yo) * W + 2 * xo;
+            int arg = 0;
+            float m = s[0];
+            if (s[1] > m) { m = s[1]; arg = 1; }
+            if (s[W] > m) { m = s[W]; arg = 2; }
+            if (s[W + 1] > m) { m = s[W + 1]; arg = 3; }
+            if (arg == (yy - 2 * yo) * 2 + (xx - 2 * xo)) g = gy[img * Ho * Wo + yo * Wo + xo];
+        }
+        gx[e] = g;
+    }
+}
+
+extern "C" int cfd_maxpool2_fwd(const float* x, float* y, int nimg, int H, int W, void* stream) {
+    CFD_REQUIRE(x && y && nimg >= 0 && H >= 2 && W >= 2, CFD_ERR_INVALID_ARG, "cfd_maxpool2_fwd: bad arguments");
+    if (nimg == 0) return CFD_OK;
+    hipLaunchKernelGGL(k_maxpool2, dim3(ew_blocks((long)nimg * (H / 2) * (W / 2))), dim3(256), 0, (hipStream_t)stream, x, y,
+                       (long)nimg, H, W);
+    CFD_LAUNCH_CHECK("cfd_maxpool2_fwd");
+    return CFD_OK;
+}
+
+extern "C" int cfd_maxpool2_bwd(const float* x, const float* gy, float* gx, int nimg, int H, int W, void* stream) {
+    CFD_REQUIRE(x && gy && gx && nimg >= 0 && H >= 2 && W >= 2, CFD_ERR_INVALID_ARG, "cfd_maxpool2_bwd: bad arguments");
+    if (nimg == 0) return CFD_OK;
+    hipLaunchKernelGGL(k_maxpool2_bwd, dim3(ew_blocks((long)nimg * H * W)), dim3(256), 0, (hipStream_t)stream, x, gy, gx,
+                       (long)nimg, H, W);
+    CFD_LAUNCH_CHECK("cfd_maxpool2_bwd");
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// ConvTranspose2d(kernel 2, stride 2)  (src/models/unet.py:80): out[b,o,2y+ky,2x+kx] = bias[o] + sum_i in[b,i,y,x] w[i,o,ky,kx]
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_convt2_fwd(const float* __restrict__ in, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int B, int Ci,
+                                                    int Co, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long total = (long)B * Co * Ho * Wo;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int xo = (int)(e % Wo), yo = (int)((e / Wo) % Ho), o = (int)((e / ((long)Wo * Ho)) % Co);
+        const int b = (int)(e / ((long)Wo * Ho * Co));
+        const int y = yo >> 1, x = xo >> 1, kidx = (yo & 1) * 2 + (xo & 1);
+        const float* ip = in + (size_t)b * Ci * H * W + y * W + x;
+        const float* wp = w + (size_t)o * 4 + kidx;
+        float acc = bias ? bias[o] : 0.f;
+        for (int i = 0; i < Ci; ++i) acc = fmaf(ip[(size_t)i * H * W], wp[(size_t)i * Co * 4], acc);
+        out[e] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_convt2_bwd_in(const float* __restrict__ g, const float* __restrict__ w,
+                                                       float* __restrict__ gin, int B, int Ci, int Co, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long total = (long)B * Ci * H * W;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(e % W), y = (int)((e / W) % H), i = (int)((e / ((long)W * H)) % Ci);
+        const int b = (int)(e / ((long)W * H * Ci));
+        const float* gp = g + (size_t)b * Co * Ho * Wo + (2 * y) * Wo + 2 * x;
+        const float* wp = w + (size_t)i * Co * 4;
+        float acc = 0.f;
+        for (int o = 0; o < Co; ++o) {
+            const float* go = gp + (size_t)o * Ho * Wo;
+            acc = fmaf(go[0], wp[o * 4], acc);
+            acc = fmaf(go[1], wp[o * 4 + 1], acc);
+            acc = fmaf(go[Wo], wp[o * 4 + 2], acc);
+            acc = fmaf(go[Wo + 1], wp[o * 4 + 3], acc);
+        }
+        gin[e] = acc;
+    }
+}
+
+// gw[i][o][ky][kx] = sum_{b,y,x} in[b,i,y,x] g[b,o,2y+ky,2x+kx]: grid (chunk of (b,pixels), i), thread = (o,ky,kx) slot
+__global__ __launch_bounds__(256) void k_convt2_wgrad(const float* __restrict__ in, const float* __restrict__ g,
+                                                      float* __restrict__ part, int B, int Ci, int Co, int H, int W,
+                                                      int chunk_px, int chunks_per_b) {
+    const int Ho = 2 * H, Wo = 2 * W, HW = H * W;
+    const int chunk = blockIdx.x, i = blockIdx.y;
+    const int b = chunk / chunks_per_b;
+    const int pbeg = (chunk - b * chunks_per_b) * chunk_px;
+    const int pend = pbeg + chunk_px < HW ? pbeg + chunk_px : HW;
+    const float* ip = in + ((size_t)b * Ci + i) * HW;
+    for (int slot = threadIdx.x; slot < Co * 4; slot += blockDim.x) {
+        const int o = slot >> 2, ky = (slot >> 1) & 1, kx = slot & 1;
+        const float* gp = g + ((size_t)b * Co + o) * Ho * Wo + ky * Wo + kx;
+        float acc = 0.f;
+        for (int p = pbeg; p < pend; ++p) {
+            const int y = p / W, x = p - y * W;
+            acc = fmaf(ip[p], gp[(2 * y) * Wo + 2 * x], acc);
+        }
+        part[((size_t)chunk * Ci + i) * Co * 4 + slot] = acc;
+    }
+}
+
+extern "C" int cfd_convt2_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int H,
+                              int W, void* stream) {
+    CFD_REQUIRE(in && w && out, CFD_ERR_INVALID_ARG, "cfd_convt2_fwd: NULL pointer");
+    CFD_REQUIRE(B >= 0 && Ci >= 1 && Co >= 1 && H >= 1 && W >= 1, CFD_ERR_INVALID_ARG, "cfd_convt2_fwd: bad sizes");
+    if (B == 0) return CFD_OK;
+    CFD_PROF("k_convt2_fwd", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_convt2_fwd, dim3(ew_blocks((long)B * Co * 4 * H * W)), dim3(256), 0, (hipStream_t)stream, in, w, bias,
+                       out, B, Ci, Co, H, W);
+    CFD_LAUNCH_CHECK("cfd_convt2_fwd");
+    return CFD_OK;
+}
+
+static void convt_plan(int B, int HW, int& chunk_px, int& cpb) {
+    long target = 256 / (B > 0 ? B : 1);
+    if (target < 1) target = 1;
+    chunk_px = (int)((HW + target - 1) / target);
+    if (chunk_px < 16) chunk_px = 16;
+    cpb = (HW + chunk_px - 1) / chunk_px;
+}
+
+extern "C" size_t cfd_convt2_bwd_workspace_bytes(int B, int Ci, int Co, int H, int W) {
+    if (B <= 0) return 0;
+    int chunk_px, cpb;
+    convt_plan(B, H * W, chunk_px, cpb);
+    return cfd_align_up((size_t)B * cpb * Ci * Co * 4 * sizeof(float), 256);
+}
+
+extern "C" int cfd_convt2_bwd(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws,
+                              int B, int Ci, int Co, int H, int W, void* stream) {
+    CFD_REQUIRE(gout && in && w && ws, CFD_ERR_INVALID_ARG, "cfd_convt2_bwd: NULL pointer");
+    CFD_REQUIRE(B >= 1 && Ci >= 1 && Co >= 1 && H >= 1 && W >= 1, CFD_ERR_INVALID_ARG, "cfd_convt2_bwd: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    if (gin) {
+        CFD_PROF("k_convt2_bwd_in", st);
+        hipLaunchKernelGGL(k_convt2_bwd_in, dim3(ew_blocks((long)B * Ci * H * W)), dim3(256), 0, st, gout, w, gin, B, Ci, Co, H, W);
+        CFD_LAUNCH_CHECK("cfd_convt2_bwd(input)");
+    }
+    if (gw) {
+        int chunk_px, cpb;
+        convt_plan(B, H * W, chunk_px, cpb);
+        const int nchunk = B * cpb;
+        {
+            CFD_PROF("k_convt2_wgrad", st);
+            hipLaunchKernelGGL(k_convt2_wgrad, dim3(nchunk, Ci), dim3(256), 0, st, in, gout, (float*)ws, B, Ci, Co, H, W,
+                               chunk_px, cpb);
+        }
+        CFD_LAUNCH_CHECK("cfd_convt2_bwd(wgrad)");
+        const long n = (long)Ci * Co * 4;
+        long blocks = (n + 255) / 256;
+        hipLaunchKernelGGL(k_part_reduce, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st,
+                           (const float*)ws, gw, n, nchunk);
+        CFD_LAUNCH_CHECK("cfd_convt2_bwd(reduce)");
+    }
+    if (gb) {
+        hipLaunchKernelGGL(k_chan_sum, dim3((Co + 3) / 4), dim3(256), 0, st, gout, gb, B, Co, 4 * H * W);
+        CFD_LAUNCH_CHECK("cfd_convt2_bwd(bias)");
+    }
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// output epilogue of the conv baselines: preds = (x + residual) * mask  (src/models/unet.py:206-208)
+// ------------------------------------------------------------------------------------------------------
+// x, out: (B,C,HW); resid: rows of (B,Cr,HW) with Cr >= C (the first C channels are used); mask: (B,HW) or NULL
+__global__ __launch_bounds__(256) void k_resid_mask(const float* __restrict__ x, const float* __restrict__ resid,
+                                                    const float* __restrict__ mask, float* __restrict__ out, long total, int C,
+                                                    int Cr, int HW) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(e % HW), c = (int)((e / HW) % C);
+        const long b = e / ((long)HW * C);
+        float v = x[e];
+        if (resid) v += resid[((size_t)b * Cr + c) * HW + p];
+        if (mask) v *= mask[b * HW + p];
+        out[e] = v;
+    }
+}
+
+extern "C" int cfd_residual_mask(const float* x, const float* resid, const float* mask, float* out, int B, int C, int Cr,
+                                 int HW, void* stream) {
+    CFD_REQUIRE(x && out && B >= 0 && C >= 1 && HW >= 1 && (!resid || Cr >= C), CFD_ERR_INVALID_ARG, "cfd_residual_mask: bad arguments");
+    if (B == 0) return CFD_OK;
+    const long total = (long)B * C * HW;
+    hipLaunchKernelGGL(k_resid_mask, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, resid, mask, out, total, C,
+                       Cr, HW);
+    CFD_LAUNCH_CHECK("cfd_residual_mask");
+    return CFD_OK;
+}

@@ -370,3 +370,159 @@ class DeepONetInnerFn(torch.autograd.Function):
                 gu2.index_add_(1, idx, g)
                 gu = gu2.reshape(ctx.u_shape)
         return gbr, gtr, gbias, gu, None
+
+
+# ----------------------------------------------------------------------------------------------------
+# Convolution stack of the U-Net / ResNet baselines  (src/models/unet.py, src/models/resnet.py)
+# ----------------------------------------------------------------------------------------------------
+class Conv2dReplicateFn(torch.autograd.Function):
+    """nn.Conv2d(k, padding=k//2, padding_mode='replicate') as an implicit GEMM on the matrix pipe."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor]):
+        _require_cuda(x, w, b)
+        api = _lib.api()
+        x, w = _f32c(x), _f32c(w.detach())
+        b = _f32c(b.detach()) if b is not None else None
+        B, Ci, H, W = x.shape
+        Co, Ci_w, ks, ks2 = w.shape
+        if Ci_w != Ci or ks != ks2:
+            raise RuntimeError(f"conv2d: input has {Ci} channels, weight is {tuple(w.shape)}")
+        out = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+        api.call("cfd_conv2d_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(out), B, Ci, Co, H, W, ks, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        api = _lib.api()
+        x, w = ctx.saved_tensors
+        B, Ci, H, W = x.shape
+        Co, _, ks, _ = w.shape
+        g = _f32c(g)
+        gin = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w)
+        gb = torch.empty(Co, dtype=torch.float32, device=g.device) if ctx.has_b else None
+        ws = _bytes(api.size("cfd_conv2d_bwd_workspace_bytes", B, Ci, Co, H, W, ks), g.device)
+        api.call("cfd_conv2d_bwd", _ptr(g), _ptr(x), _ptr(w), _ptr(gin), _ptr(gw), _ptr(gb), _ptr(ws), B, Ci, Co, H, W, ks,
+                 _stream())
+        return gin, gw, gb
+
+
+class BatchNormFn(torch.autograd.Function):
+    """[ReLU](BatchNorm2d(x)); running statistics are updated in place in training mode."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, run_mean: Optional[Tensor], run_var: Optional[Tensor],
+                training: bool, relu: bool, eps: float, momentum: float):
+        _require_cuda(x, gamma, beta, run_mean, run_var)
+        api = _lib.api()
+        x, gamma, beta = _f32c(x), _f32c(gamma.detach()), _f32c(beta.detach())
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        sm = torch.empty(C, dtype=torch.float32, device=x.device)
+        sr = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _bytes(api.size("cfd_batchnorm_workspace_bytes", C), x.device)
+        api.call("cfd_batchnorm_fwd", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(run_mean), _ptr(run_var), _ptr(y), _ptr(sm),
+                 _ptr(sr), _ptr(ws), B, C, H * W, float(eps), float(momentum), int(training), int(relu), _stream())
+        ctx.save_for_backward(x, gamma, beta, sm, sr)
+        ctx.meta = (B, C, H * W, bool(training), bool(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        api = _lib.api()
+        x, gamma, beta, sm, sr = ctx.saved_tensors
+        B, C, HW, training, relu = ctx.meta
+        gy = _f32c(gy)
+        gx = torch.empty_like(x)
+        gg = torch.empty(C, dtype=torch.float32, device=x.device)
+        gb = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _bytes(api.size("cfd_batchnorm_workspace_bytes", C), x.device)
+        api.call("cfd_batchnorm_bwd", _ptr(gy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(sm), _ptr(sr), _ptr(gx), _ptr(gg),
+                 _ptr(gb), _ptr(ws), B, C, HW, int(training), int(relu), _stream())
+        return gx, gg, gb, None, None, None, None, None, None
+
+
+class MaxPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        _require_cuda(x)
+        x = _f32c(x)
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        _lib.api().call("cfd_maxpool2_fwd", _ptr(x), _ptr(y), B * C, H, W, _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        (x,) = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        _lib.api().call("cfd_maxpool2_bwd", _ptr(x), _ptr(_f32c(gy)), _ptr(gx), B * C, H, W, _stream())
+        return gx
+
+
+class ConvTranspose2x2Fn(torch.autograd.Function):
+    """nn.ConvTranspose2d(kernel_size=2, stride=2)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor]):
+        _require_cuda(x, w, b)
+        x, w = _f32c(x), _f32c(w.detach())
+        b = _f32c(b.detach()) if b is not None else None
+        B, Ci, H, W = x.shape
+        Co = w.shape[1]
+        out = torch.empty((B, Co, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        _lib.api().call("cfd_convt2_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(out), B, Ci, Co, H, W, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        api = _lib.api()
+        x, w = ctx.saved_tensors
+        B, Ci, H, W = x.shape
+        Co = w.shape[1]
+        g = _f32c(g)
+        gin = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w)
+        gb = torch.empty(Co, dtype=torch.float32, device=g.device) if ctx.has_b else None
+        ws = _bytes(api.size("cfd_convt2_bwd_workspace_bytes", B, Ci, Co, H, W), g.device)
+        api.call("cfd_convt2_bwd", _ptr(g), _ptr(x), _ptr(w), _ptr(gin), _ptr(gw), _ptr(gb), _ptr(ws), B, Ci, Co, H, W, _stream())
+        return gin, gw, gb
+
+
+class ResidualMaskFn(torch.autograd.Function):
+    """(x + resid[:, :C]) * mask  (unet.py:206-208).  resid and mask are data (no gradient is taken for them)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, resid: Optional[Tensor], mask: Optional[Tensor]):
+        _require_cuda(x, resid, mask)
+        x, resid, mask = _f32c(x), _f32c(resid), _f32c(mask)
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        _lib.api().call("cfd_residual_mask", _ptr(x), _ptr(resid), _ptr(mask), _ptr(out), B, C,
+                        resid.shape[1] if resid is not None else C, H * W, _stream())
+        ctx.save_for_backward(mask)
+        ctx.has_mask = mask is not None
+        ctx.resid_shape = None if resid is None else tuple(resid.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        g = _f32c(g)
+        gx = g
+        if ctx.has_mask:
+            (mask,) = ctx.saved_tensors
+            B, C, H, W = g.shape
+            gx = torch.empty_like(g)
+            _lib.api().call("cfd_residual_mask", _ptr(g), None, _ptr(mask), _ptr(gx), B, C, C, H * W, _stream())
+        gres = None
+        if ctx.resid_shape is not None and ctx.needs_input_grad[1]:  # the residual frame's own gradient (copy of gx)
+            gres = torch.zeros(ctx.resid_shape, dtype=torch.float32, device=g.device)
+            gres[:, :g.shape[1]] = gx
+        return gx, gres, None

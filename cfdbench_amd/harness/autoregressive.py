@@ -7,6 +7,7 @@ from ..models.auto_deeponet import AutoDeepONet
 from ..models.base_model import AutoCfdModel
 from ..models.fno.fno2d import Fno2d
 from ..models.loss import loss_name_to_fn
+from ..models.unet import UNet
 
 
 def get_input_shapes(args) -> Tuple[int, int, int]:
@@ -36,6 +37,9 @@ def init_model(args) -> AutoCfdModel:
         return AutoDeepONet(branch_dim=n_cols * n_rows + n_case_params, trunk_dim=2, loss_fn=loss_fn,
                             width=args.deeponet_width, trunk_depth=args.trunk_depth, branch_depth=args.branch_depth,
                             act_name=args.act_fn)
-    if args.model in ("auto_ffn", "auto_edeeponet", "auto_deeponet_cnn", "resnet", "unet"):
+    if args.model == "unet":  # autoregressive.py:105-114
+        return UNet(in_chan=args.in_chan, out_chan=args.out_chan, loss_fn=loss_fn, n_case_params=n_case_params,
+                    insert_case_params_at=args.unet_insert_case_params_at, dim=args.unet_dim)
+    if args.model in ("auto_ffn", "auto_edeeponet", "auto_deeponet_cnn", "resnet"):
         raise NotImplementedError(f"cfdbench_amd: model {args.model!r} has no MI355X kernels yet (DESIGN.md section 7)")
     raise ValueError(f"Invalid model name: {args.model}")

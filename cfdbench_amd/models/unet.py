@@ -1,0 +1,154 @@
+"""U-Net with the reference's module tree, constructor and ``state_dict`` (136 tensors incl. BatchNorm buffers under
+``in_conv.conv{1,2}.{0,1}.*``, ``down{1-4}.maxpool_conv.1.*``, ``up{1-4}.{up,conv}.*``, ``out_conv.conv.*``;
+src/models/unet.py:11-263) on the gfx950 kernels of csrc/conv.hip.  The torch sub-modules (nn.Conv2d, nn.BatchNorm2d,
+nn.ConvTranspose2d) only hold parameters and buffers; the arithmetic runs in: implicit-GEMM replicate-padded conv (MFMA),
+fused BatchNorm+ReLU (batch statistics in training, running statistics in eval), 2x2 max-pool, 2x2/stride-2 transposed
+conv, 1x1 output conv and the (x + residual) * mask epilogue.  ``torch.cat`` / zero ``F.pad`` of skip connections are the
+only ATen calls (pure data movement).  ``bilinear=True`` and ``insert_case_params_at="hidden"`` are not built (init_model
+uses neither by default: src/utils/autoregressive.py:105-114, src/args.py:203)."""
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from .. import functional as F_
+from .base_model import AutoCfdModel
+
+
+def _conv_bn_relu(seq: nn.Sequential, x: Tensor) -> Tensor:
+    conv, bn = seq[0], seq[1]
+    x = F_.Conv2dReplicateFn.apply(x, conv.weight, conv.bias)
+    y = F_.BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, True, bn.eps,
+                             bn.momentum)
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return y
+
+
+class DoubleConv(nn.Module):
+    """(convolution => [BN] => ReLU) * 2  (unet.py:11-50)."""
+
+    def __init__(self, in_chan: int, out_chan: int, mid_chan: Optional[int] = None):
+        super().__init__()
+        if mid_chan is None:
+            mid_chan = out_chan
+        self.conv1 = nn.Sequential(
+            nn.Conv2d(in_chan, mid_chan, kernel_size=3, padding=1, bias=True, padding_mode="replicate"),
+            nn.BatchNorm2d(mid_chan), nn.ReLU(inplace=True))
+        self.conv2 = nn.Sequential(
+            nn.Conv2d(mid_chan, out_chan, kernel_size=3, padding=1, bias=True, padding_mode="replicate"),
+            nn.BatchNorm2d(out_chan), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return _conv_bn_relu(self.conv2, _conv_bn_relu(self.conv1, x))
+
+
+class Down(nn.Module):
+    """Downscaling with maxpool then double conv (unet.py:53-63)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels))
+
+    def forward(self, x):
+        return self.maxpool_conv[1](F_.MaxPool2Fn.apply(x))
+
+
+class Up(nn.Module):
+    """Upscaling then double conv (unet.py:66-99)."""
+
+    def __init__(self, in_channels, out_channels, bilinear=False):
+        super().__init__()
+        if bilinear:
+            raise NotImplementedError("cfdbench_amd.UNet: bilinear=True is not built (init_model uses bilinear=False)")
+        self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
+        self.conv = DoubleConv(in_channels, out_channels)
+
+    def forward(self, x1, x2):
+        x1 = F_.ConvTranspose2x2Fn.apply(x1, self.up.weight, self.up.bias)
+        diffY = x2.size()[2] - x1.size()[2]
+        diffX = x2.size()[3] - x1.size()[3]
+        if diffX or diffY:
+            x1 = F.pad(x1, [diffX // 2, diffX - diffX // 2, diffY // 2, diffY - diffY // 2])
+        return self.conv(torch.cat([x2, x1], dim=1))
+
+
+class OutConv(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return F_.Conv2dReplicateFn.apply(x, self.conv.weight, self.conv.bias)
+
+
+class UNet(AutoCfdModel):
+    def __init__(self, in_chan: int, out_chan: int, loss_fn: nn.Module, n_case_params: int,
+                 insert_case_params_at: str = "hidden", bilinear: bool = False, dim: int = 8):
+        assert insert_case_params_at in ["hidden", "input"]
+        super().__init__(loss_fn)
+        if insert_case_params_at == "hidden":
+            raise NotImplementedError("cfdbench_amd.UNet: insert_case_params_at='hidden' is not built "
+                                      "(the CLI default is 'input', src/args.py:203)")
+        self.in_chan = in_chan
+        self.out_chan = out_chan
+        self.n_case_params = n_case_params
+        self.insert_case_params_at = insert_case_params_at
+        self.bilinear = bilinear
+        self.dim = dim
+        self.in_conv = DoubleConv(in_chan + 1 + n_case_params, dim)  # + 1 for mask
+        self.down1 = Down(dim, dim * 2)
+        self.down2 = Down(dim * 2, dim * 4)
+        self.down3 = Down(dim * 4, dim * 8)
+        self.down4 = Down(dim * 8, dim * 16)
+        self.up1 = Up(dim * 16, dim * 8, bilinear)
+        self.up2 = Up(dim * 8, dim * 4, bilinear)
+        self.up3 = Up(dim * 4, dim * 2, bilinear)
+        self.up4 = Up(dim * 2, dim, bilinear)
+        self.out_conv = OutConv(dim, out_chan)
+
+    def forward(self, inputs: Tensor, case_params: Tensor, mask: Optional[Tensor] = None, label: Optional[Tensor] = None):
+        """inputs (B,c,h,w), mask (B,h,w)|(B,1,h,w), label (B,c,h,w), case_params (b,p)  (unet.py:153-223)."""
+        batch_size, n_chan, height, width = inputs.shape
+        residual = inputs
+        if mask is None:
+            mask = torch.ones((batch_size, 1, height, width), device=inputs.device)
+        elif mask.dim() == 3:
+            mask = mask.unsqueeze(1)
+        cp = case_params.unsqueeze(2).unsqueeze(3).expand(-1, -1, height, width)
+        x = torch.cat([inputs, mask, cp], dim=1)
+        x1 = self.in_conv(x)
+        x2 = self.down1(x1)
+        x3 = self.down2(x2)
+        x4 = self.down3(x3)
+        x5 = self.down4(x4)
+        x = self.up1(x5, x4)
+        x = self.up2(x, x3)
+        x = self.up3(x, x2)
+        x = self.up4(x, x1)
+        preds = F_.ResidualMaskFn.apply(self.out_conv(x), residual, mask)  # (out_conv + inputs[:, :out]) * mask
+        if label is not None:
+            label = F_.ResidualMaskFn.apply(label, None, mask)
+            return dict(preds=preds, loss=self.loss_fn(labels=label, preds=preds))
+        return dict(preds=preds)
+
+    def generate(self, inputs: Tensor, case_params: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+        return self.forward(inputs, case_params=case_params, mask=mask)["preds"]
+
+    def generate_many(self, inputs: Tensor, case_params: Tensor, mask: Tensor, steps: int) -> List[Tensor]:
+        """unet.py:225-252, including its quirk: ``mask.unsqueeze(0)`` is applied again after the batch dimension was
+        added, so a batched (B,h,w) mask becomes (1,B,h,w) -- i.e. the reference only works for B == 1 or an unbatched
+        call.  Reproduced for B == 1; larger batches take the (B,1,h,w) mask the rest of the harness uses."""
+        preds = []
+        if inputs.dim() == 3:
+            inputs = inputs.unsqueeze(0)
+            case_params = case_params.unsqueeze(0)
+            mask = mask.unsqueeze(0)
+        cur_frame = inputs
+        if mask.dim() == 3:
+            mask = mask.unsqueeze(1) if mask.shape[0] == inputs.shape[0] and inputs.shape[0] > 1 else mask.unsqueeze(0)
+        for _ in range(steps):
+            cur_frame = self.generate(cur_frame, case_params=case_params, mask=mask)
+            preds.append(cur_frame)
+        return preds

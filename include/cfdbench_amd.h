@@ -191,6 +191,43 @@ size_t cfd_deeponet_inner_bwd_workspace_bytes(int B, int P, int Kq);
 int cfd_deeponet_inner_bwd(const float* gpreds, const float* branch, const float* trunk, float* gbranch, float* gtrunk,
                            float* gbias, void* ws, int B, int P, int Kq, void* stream);
 
+/* ---- convolution stack of the U-Net / ResNet baselines (src/models/unet.py, src/models/resnet.py) ---------*/
+
+/* out (B,Co,H,W) = nn.Conv2d(Ci, Co, ks, padding=ks/2, padding_mode="replicate")(in); w (Co,Ci,ks,ks); ks odd <= 7
+ * (unet.py:20-27 ks=3, resnet.py:35-41 ks=7, unet.py:105 ks=1); bias may be NULL.                              */
+int cfd_conv2d_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int H, int W,
+                   int ks, void* stream);
+/* gin (B,Ci,H,W), gw (Co,Ci,ks,ks), gb (Co) from gout; any output may be NULL.  ws: cfd_conv2d_bwd_workspace_bytes(). */
+size_t cfd_conv2d_bwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);
+int cfd_conv2d_bwd(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws, int B,
+                   int Ci, int Co, int H, int W, int ks, void* stream);
+
+/* y = [relu](nn.BatchNorm2d(x)) (unet.py:28-30).  training: batch statistics, saved in save_mean / save_rstd for the
+ * backward pass, running_mean / running_var updated in place (momentum; unbiased variance) when non-NULL;
+ * otherwise the running statistics normalise.  x, y: (B,C,HW).  ws: cfd_batchnorm_workspace_bytes(C).           */
+size_t cfd_batchnorm_workspace_bytes(int C);
+int cfd_batchnorm_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float* y,
+                      float* save_mean, float* save_rstd, void* ws, int B, int C, int HW, float eps, float momentum,
+                      int training, int relu, void* stream);
+int cfd_batchnorm_bwd(const float* gy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                      const float* save_rstd, float* gx, float* ggamma, float* gbeta, void* ws, int B, int C, int HW,
+                      int training, int relu, void* stream);
+
+/* nn.MaxPool2d(2) (unet.py:59) on nimg = B*C images; the gradient goes to the first maximum of each window.     */
+int cfd_maxpool2_fwd(const float* x, float* y, int nimg, int H, int W, void* stream);
+int cfd_maxpool2_bwd(const float* x, const float* gy, float* gx, int nimg, int H, int W, void* stream);
+
+/* nn.ConvTranspose2d(Ci, Co, kernel_size=2, stride=2) (unet.py:80): in (B,Ci,H,W), w (Ci,Co,2,2), out (B,Co,2H,2W). */
+int cfd_convt2_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int H, int W,
+                   void* stream);
+size_t cfd_convt2_bwd_workspace_bytes(int B, int Ci, int Co, int H, int W);
+int cfd_convt2_bwd(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws, int B,
+                   int Ci, int Co, int H, int W, void* stream);
+
+/* out = (x + resid[:, :C]) * mask (unet.py:206-208): x, out (B,C,HW); resid (B,Cr,HW) or NULL; mask (B,HW) or NULL. */
+int cfd_residual_mask(const float* x, const float* resid, const float* mask, float* out, int B, int C, int Cr, int HW,
+                      void* stream);
+
 /* ---- whole Auto-FNO (Fno2d.forward, fno2d.py:178-242; loss.backward() at train_auto.py:255) ---------------*/
 typedef struct {
     int B, H, W;

@@ -136,6 +136,48 @@ def gen_auto_deeponet(name, pseed, bseed, B, H, W, width, bdepth, tdepth, act_na
     print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
 
 
+def gen_unet(name, seed, bseed, B, H, W, dim, p=8, steps=2):
+    """UNet (input-insert, ConvTranspose up path) train-mode forward/backward, running-stat update, eval forward and
+    rollout from the reference module (src/models/unet.py).  The state_dict itself is stored (torch's init stream)."""
+    from models.unet import UNet  # reference
+    torch.manual_seed(seed)
+    model = UNet(2, 2, MseLoss(normalize=True), p, insert_case_params_at="input", bilinear=False, dim=dim)
+    with torch.no_grad():  # non-trivial BatchNorm affine parameters and running statistics
+        g = torch.Generator().manual_seed(seed + 1)
+        for k, v in model.state_dict().items():
+            if k.endswith(".1.weight"):
+                v.copy_(1 + 0.2 * torch.randn(v.shape, generator=g))
+            elif k.endswith(".1.bias") or k.endswith("running_mean"):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            elif k.endswith("running_var"):
+                v.copy_(1 + 0.5 * torch.rand(v.shape, generator=g))
+    sd0 = {k: v.clone().numpy() for k, v in model.state_dict().items()}
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    batch["mask"][:, :, 0, :] = 0
+    batch["mask"][:, :, :, 0] = 0
+    model.train()
+    x = _t(batch["inputs"]).requires_grad_(True)
+    out = model(inputs=x, case_params=_t(batch["case_params"]), mask=_t(batch["mask"]), label=_t(batch["label"]))
+    out["loss"]["nmse"].backward()
+    save = dict(meta=np.array([seed, bseed, B, H, W, dim, p, steps]), preds_train=out["preds"].detach().numpy(),
+                g_inputs=x.grad.numpy(), **{f"loss_{k}": np.array(v.item()) for k, v in out["loss"].items()})
+    for k, v in sd0.items():
+        save[f"sd::{k}"] = v
+    for k, prm in model.named_parameters():
+        save[f"grad::{k}"] = prm.grad.numpy()
+    for k, v in model.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            save[f"after::{k}"] = v.numpy()
+    model.eval()
+    with torch.no_grad():
+        save["preds_eval"] = model(inputs=_t(batch["inputs"]), case_params=_t(batch["case_params"]),
+                                   mask=_t(batch["mask"]))["preds"].numpy()
+        frames = model.generate_many(_t(batch["inputs"][0]), _t(batch["case_params"][0]), _t(batch["mask"][0, 0]), steps)
+    save["frames"] = np.stack([f.numpy() for f in frames])
+    np.savez_compressed(OUT / f"{name}.npz", **save)
+    print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
+
+
 def gen_adam(name, pseed, bseed, B, C, L, H, W, nsteps, lr, p=5, gain=1.0):
     """train_auto.py:231-257: model(**batch) -> loss['nmse'].backward() -> Adam.step() -> zero_grad()."""
     params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=gain)
@@ -180,6 +222,8 @@ def main():
     gen_auto_deeponet("auto_deeponet_small_16x16", 41, 51, 3, 16, 16, 24, 3, 3, "relu")
     gen_auto_deeponet("auto_deeponet_tanh_18x17", 42, 52, 2, 18, 17, 20, 2, 3, "tanh")
     gen_auto_deeponet("auto_deeponet_gelu_16x16", 43, 53, 2, 16, 16, 16, 2, 2, "gelu")
+    gen_unet("unet_dim4_32x32", 61, 71, 3, 32, 32, 4)
+    gen_unet("unet_dim3_36x40", 62, 72, 2, 36, 40, 3, p=5)
     gen_adam("adam_small_64x64", 26, 36, 2, 8, 2, 64, 64, nsteps=3, lr=1e-3, gain=8.0)
     gen_mseloss("mseloss", 41)
 

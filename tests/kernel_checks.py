@@ -465,3 +465,92 @@ def check_deeponet_inner(be, B, P_, Kq, HW, with_q, seed=23):
     res["gtrunk"] = nm(be.host(gtr), g.astype(f64).T @ br.astype(f64))
     res["gbias"] = float(abs(be.host(gbi)[0] - g.astype(f64).sum()) / abs(g.astype(f64).sum()))
     return res
+
+
+# ---- convolution stack of the U-Net / ResNet baselines (csrc/conv.hip) ------------------------------------------
+def check_conv2d(be, B, Ci, Co, H, W, ks, seed=31):
+    from oracle import conv_oracle as CO
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, Ci, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, ks, ks)) / np.sqrt(Ci * ks * ks)).astype(np.float32)
+    b = rng.standard_normal((Co,)).astype(np.float32) * 0.2
+    g = rng.standard_normal((B, Co, H, W)).astype(np.float32)
+    dx, dw, db, dg = be.dev(x), be.dev(w), be.dev(b), be.dev(g)
+    out = be.zeros((B, Co, H, W))
+    api.call("cfd_conv2d_fwd", P(dx), P(dw), P(db), P(out), B, Ci, Co, H, W, ks, be.stream)
+    be.sync()
+    res = {"out": nm(be.host(out), CO.conv2d(x.astype(f64), w.astype(f64), b.astype(f64)))}
+    ws = be.bytes(api.size("cfd_conv2d_bwd_workspace_bytes", B, Ci, Co, H, W, ks))
+    gin, gw, gb = be.zeros((B, Ci, H, W)), be.zeros((Co, Ci, ks, ks)), be.zeros((Co,))
+    api.call("cfd_conv2d_bwd", P(dg), P(dx), P(dw), P(gin), P(gw), P(gb), P(ws), B, Ci, Co, H, W, ks, be.stream)
+    be.sync()
+    rgx, rgw, rgb = CO.conv2d_bwd(g.astype(f64), x.astype(f64), w.astype(f64))
+    res["gin"], res["gw"], res["gb"] = nm(be.host(gin), rgx), nm(be.host(gw), rgw), nm(be.host(gb), rgb)
+    return res
+
+
+def check_batchnorm(be, B, C, H, W, training, relu, seed=32):
+    from oracle import conv_oracle as CO
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((B, C, H, W)) * 1.7 + 3.0 * rng.standard_normal((1, C, 1, 1))).astype(np.float32)
+    gamma = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(C)).astype(np.float32)
+    rm = (0.5 * rng.standard_normal(C)).astype(np.float32)
+    rv = (1 + rng.random(C)).astype(np.float32)
+    gy = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    dx, dga, dbe, drm, drv, dgy = be.dev(x), be.dev(gamma), be.dev(beta), be.dev(rm), be.dev(rv), be.dev(gy)
+    y, sm, sr = be.zeros((B, C, H, W)), be.zeros((C,)), be.zeros((C,))
+    ws = be.bytes(api.size("cfd_batchnorm_workspace_bytes", C))
+    api.call("cfd_batchnorm_fwd", P(dx), P(dga), P(dbe), P(drm), P(drv), P(y), P(sm), P(sr), P(ws), B, C, H * W, 1e-5, 0.1,
+             int(training), int(relu), be.stream)
+    be.sync()
+    ry, cache, nrm, nrv = CO.batchnorm(x.astype(f64), gamma.astype(f64), beta.astype(f64), rm.astype(f64), rv.astype(f64),
+                                       training, relu=relu)
+    res = {"y": nm(be.host(y), ry), "run_mean": nm(be.host(drm), nrm), "run_var": nm(be.host(drv), nrv)}
+    gx, gga, gbe = be.zeros((B, C, H, W)), be.zeros((C,)), be.zeros((C,))
+    api.call("cfd_batchnorm_bwd", P(dgy), P(dx), P(dga), P(dbe), P(sm), P(sr), P(gx), P(gga), P(gbe), P(ws), B, C, H * W,
+             int(training), int(relu), be.stream)
+    be.sync()
+    rgx, rgg, rgb = CO.batchnorm_bwd(gy.astype(f64), cache)
+    res["gx"], res["ggamma"], res["gbeta"] = nm(be.host(gx), rgx), nm(be.host(gga), rgg), nm(be.host(gbe), rgb)
+    return res
+
+
+def check_pool_convt_resid(be, B, Ci, Co, H, W, seed=33):
+    from oracle import conv_oracle as CO
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    x = np.maximum(rng.standard_normal((B, Ci, H, W)), 0).astype(np.float32)  # ReLU-like input: ties at zero
+    dx = be.dev(x)
+    Ho, Wo = H // 2, W // 2
+    y = be.zeros((B, Ci, Ho, Wo))
+    api.call("cfd_maxpool2_fwd", P(dx), P(y), B * Ci, H, W, be.stream)
+    gy = rng.standard_normal((B, Ci, Ho, Wo)).astype(np.float32)
+    dgy, gx = be.dev(gy), be.zeros((B, Ci, H, W))
+    api.call("cfd_maxpool2_bwd", P(dx), P(dgy), P(gx), B * Ci, H, W, be.stream)
+    be.sync()
+    res = {"pool": float(np.abs(be.host(y) - CO.maxpool2(x)).max()),
+           "pool_bwd": float(np.abs(be.host(gx) - CO.maxpool2_bwd(x, gy)).max())}
+    w = (rng.standard_normal((Ci, Co, 2, 2)) / np.sqrt(Ci)).astype(np.float32)
+    b = rng.standard_normal((Co,)).astype(np.float32) * 0.1
+    g = rng.standard_normal((B, Co, 2 * H, 2 * W)).astype(np.float32)
+    dw, db, dg = be.dev(w), be.dev(b), be.dev(g)
+    out = be.zeros((B, Co, 2 * H, 2 * W))
+    api.call("cfd_convt2_fwd", P(dx), P(dw), P(db), P(out), B, Ci, Co, H, W, be.stream)
+    ws = be.bytes(api.size("cfd_convt2_bwd_workspace_bytes", B, Ci, Co, H, W))
+    gin, gw, gb = be.zeros((B, Ci, H, W)), be.zeros((Ci, Co, 2, 2)), be.zeros((Co,))
+    api.call("cfd_convt2_bwd", P(dg), P(dx), P(dw), P(gin), P(gw), P(gb), P(ws), B, Ci, Co, H, W, be.stream)
+    be.sync()
+    res["convt"] = nm(be.host(out), CO.convt2(x.astype(f64), w.astype(f64), b.astype(f64)))
+    rgx, rgw, rgb = CO.convt2_bwd(g.astype(f64), x.astype(f64), w.astype(f64))
+    res["convt_gin"], res["convt_gw"], res["convt_gb"] = nm(be.host(gin), rgx), nm(be.host(gw), rgw), nm(be.host(gb), rgb)
+    C2 = min(2, Ci)
+    mask = (rng.random((B, H * W)) > 0.2).astype(np.float32)
+    xs = rng.standard_normal((B, C2, H * W)).astype(np.float32)
+    dxs, dmask, o2 = be.dev(xs), be.dev(mask), be.zeros((B, C2, H * W))
+    api.call("cfd_residual_mask", P(dxs), P(dx), P(dmask), P(o2), B, C2, Ci, H * W, be.stream)
+    be.sync()
+    res["resid"] = nm(be.host(o2), (xs + x.reshape(B, Ci, -1)[:, :C2]) * mask[:, None])
+    return res

@@ -104,3 +104,20 @@ def test_deeponet_inner(be, B, P, Kq, HW, with_q):
     res = K.check_deeponet_inner(be, B, P, Kq, HW, with_q)
     assert res.pop("gbias") < 1e-5  # a relative error of one fp32 sum, not an nMSE
     _assert_all(res)
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(1, 5, 7, 9, 10, 3), (1, 3, 18, 5, 4, 3), (1, 2, 3, 8, 9, 7), (2, 4, 4, 6, 6, 1)])
+def test_conv2d_replicate(be, B, Ci, Co, H, W, ks):
+    _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, ks))
+
+
+@pytest.mark.parametrize("B,C,H,W,training,relu", [(2, 5, 6, 7, True, True), (2, 3, 4, 4, False, True), (3, 2, 5, 5, True, False)])
+def test_batchnorm_relu(be, B, C, H, W, training, relu):
+    _assert_all(K.check_batchnorm(be, B, C, H, W, training, relu))
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(1, 3, 5, 6, 8), (2, 2, 3, 5, 5)])
+def test_pool_convtranspose_residual(be, B, Ci, Co, H, W):
+    res = K.check_pool_convt_resid(be, B, Ci, Co, H, W)
+    assert res.pop("pool") == 0.0 and res.pop("pool_bwd") == 0.0  # selections, not arithmetic: exact
+    _assert_all(res)

@@ -131,3 +131,20 @@ def test_deeponet_inner(be, B, P, Kq, HW, with_q):
     res = K.check_deeponet_inner(be, B, P, Kq, HW, with_q)
     assert res.pop("gbias") < 1e-5  # a relative error of one fp32 sum, not an nMSE
     _assert_all(res)
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(3, 11, 12, 64, 64, 3), (2, 24, 12, 33, 32, 3), (2, 96, 192, 5, 4, 3), (2, 192, 96, 8, 8, 3), (1, 8, 64, 20, 21, 7), (1, 64, 16, 17, 16, 7), (2, 12, 2, 16, 16, 1)])
+def test_conv2d_replicate(be, B, Ci, Co, H, W, ks):
+    _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, ks))
+
+
+@pytest.mark.parametrize("B,C,H,W,training,relu", [(4, 12, 64, 64, True, True), (3, 192, 4, 4, True, True), (2, 24, 33, 32, False, True), (3, 5, 7, 9, True, False)])
+def test_batchnorm_relu(be, B, C, H, W, training, relu):
+    _assert_all(K.check_batchnorm(be, B, C, H, W, training, relu))
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 24, 12, 32, 32), (2, 192, 96, 4, 4), (1, 3, 5, 7, 9)])
+def test_pool_convtranspose_residual(be, B, Ci, Co, H, W):
+    res = K.check_pool_convt_resid(be, B, Ci, Co, H, W)
+    assert res.pop("pool") == 0.0 and res.pop("pool_bwd") == 0.0  # selections, not arithmetic: exact
+    _assert_all(res)

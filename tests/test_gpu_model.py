@@ -300,3 +300,47 @@ def test_auto_deeponet_vs_reference_golden(torch, golden_dir, name):
         full = m(inputs=b["inputs"], case_params=b["case_params"], label=b["label"])["preds"]
         idx = (q[:, 0] * W + q[:, 1]).long()
         assert O.rel_nmse(sub.cpu().numpy(), full[:, idx].cpu().numpy()) < 1e-10
+
+
+# ---- U-Net drop-in (cfdbench_amd/models/unet.py) vs the reference module's golden outputs ---------------------------
+@pytest.mark.parametrize("name", ["unet_dim4_32x32", "unet_dim3_36x40"])
+def test_unet_vs_reference_golden(torch, golden_dir, name):
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    from cfdbench_amd.models.unet import UNet
+    g = np.load(golden_dir / f"{name}.npz")
+    seed, bseed, B, H, W, dim, p, steps = [int(v) for v in g["meta"]]
+    m = UNet(2, 2, loss_name_to_fn("nmse"), p, insert_case_params_at="input", bilinear=False, dim=dim).cuda()
+    sd = {k[len("sd::"):]: torch.from_numpy(np.ascontiguousarray(g[k])) for k in g.files if k.startswith("sd::")}
+    assert list(sd.keys()) == list(m.state_dict().keys())  # the reference's 136-tensor checkpoint layout
+    m.load_state_dict(sd)
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    batch["mask"][:, :, 0, :] = 0
+    batch["mask"][:, :, :, 0] = 0
+    b = _cuda(torch, batch)
+    m.train()
+    x = b["inputs"].clone().requires_grad_(True)
+    out = m(inputs=x, case_params=b["case_params"], mask=b["mask"], label=b["label"])
+    assert O.rel_nmse(out["preds"].detach().cpu().numpy(), g["preds_train"]) < 1e-9
+    assert abs(out["loss"]["nmse"].item() - float(g["loss_nmse"])) <= 1e-5 * float(g["loss_nmse"])
+    out["loss"]["nmse"].backward()
+    for k, prm in m.named_parameters():
+        ref = g[f"grad::{k}"]
+        if np.abs(ref).max() < 1e-7:  # conv bias in front of a train-mode BatchNorm: the exact gradient is zero
+            assert float(prm.grad.abs().max()) < 1e-6, k
+        else:
+            assert O.rel_nmse(prm.grad.cpu().numpy(), ref) < 1e-7, k
+    assert O.rel_nmse(x.grad.cpu().numpy(), g["g_inputs"]) < 1e-7
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            assert O.rel_nmse(v.cpu().numpy(), g[f"after::{k}"]) < 1e-10, k
+        elif "num_batches" in k:
+            assert int(v) == int(g[f"after::{k}"])
+    m.load_state_dict(sd)  # the eval outputs of the fixture use the ORIGINAL running statistics
+    m.eval()
+    with torch.no_grad():
+        ev = m(inputs=b["inputs"], case_params=b["case_params"], mask=b["mask"])["preds"]
+        assert O.rel_nmse(ev.cpu().numpy(), g["preds_eval"]) < 1e-9
+        frames = m.generate_many(b["inputs"][0], b["case_params"][0], b["mask"][0, 0], steps)
+        for t in range(steps):
+            assert tuple(frames[t].shape) == (1, 2, H, W)
+            assert O.rel_nmse(frames[t].cpu().numpy(), g["frames"][t]) < 1e-8

@@ -162,3 +162,23 @@ def test_auto_deeponet_forward_backward_rollout(golden_dir, name):
     for t in range(steps):  # generate_many, auto_deeponet.py:174-200: only u is predicted, frames are (b,1,h,w)
         cur = D.auto_deeponet_forward(params, cur, batch["case_params"], None, act)["preds"]
         assert O.rel_nmse(cur, g["frames"][t]) < 1e-10
+
+
+# ---- U-Net (oracle/conv_oracle.py) against the reference module's outputs ------------------------------------------
+@pytest.mark.parametrize("name", ["unet_dim4_32x32", "unet_dim3_36x40"])
+def test_unet_forward_train_and_eval(golden_dir, name):
+    from oracle import conv_oracle as CO
+    g = np.load(golden_dir / f"{name}.npz")
+    seed, bseed, B, H, W, dim, p, steps = [int(v) for v in g["meta"]]
+    P = {k[len("sd::"):]: g[k].astype(np.float64) for k in g.files if k.startswith("sd::")}
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    batch["mask"][:, :, 0, :] = 0
+    batch["mask"][:, :, :, 0] = 0
+    b64 = {k: v.astype(np.float64) for k, v in batch.items()}
+    out = CO.unet_forward(P, b64["inputs"], b64["case_params"], b64["mask"], b64["label"], training=True)
+    assert O.rel_nmse(out["preds"], g["preds_train"]) < 1e-10
+    assert abs(out["loss"]["nmse"] - float(g["loss_nmse"])) <= 1e-5 * float(g["loss_nmse"])
+    for k, v in out["running"].items():
+        assert O.rel_nmse(v, g[f"after::{k}"]) < 1e-10, k
+    ev = CO.unet_forward(P, b64["inputs"], b64["case_params"], b64["mask"], None, training=False)
+    assert O.rel_nmse(ev["preds"], g["preds_eval"]) < 1e-10
