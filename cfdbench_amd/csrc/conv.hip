@@ -44,6 +44,7 @@ __global__ __launch_bounds__(64 * CV_WAVES) void k_conv_gather(const float* __re
     const int K = Cs * kk;
     const int Hd = EXT ? g.H + 2 * pad : g.H, Wd = EXT ? g.W + 2 * pad : g.W;  // dst grid
     const int HWd = Hd * Wd, HWs = g.H * g.W;
+    const int mbase = blockIdx.y * 16 * MT;  // this workgroup's slice of the output channels
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (long tile = (long)blockIdx.x * CV_WAVES + wave; tile < total_tiles; tile += (long)gridDim.x * CV_WAVES) {
         const int b = (int)(tile / tiles_per_b);
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(64 * CV_WAVES) void k_conv_gather(const float* __re
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int m = 16 * mt + n;  // A operand row
+                const int m = mbase + 16 * mt + n;  // A operand row
                 float av = 0.f;
                 if (m < Cm && k < K) av = EXT ? w[((size_t)c * g.Ci + m) * kk + ky * g.ks + kx] : w[(size_t)m * K + k];
                 acc[mt] = cfd_mfma16x16x4(av, bv, acc[mt]);
@@ -83,8 +84,105 @@ __global__ __launch_bounds__(64 * CV_WAVES) void k_conv_gather(const float* __re
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = 16 * mt + 4 * q + r;
+                    const int m = mbase + 16 * mt + 4 * q + r;
                     if (m < Cm) dst[((size_t)b * Cm + m) * HWd + p] = acc[mt][r] + (bias ? bias[m] : 0.f);
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LDS-tiled 3x3 variant for wide images (W >= 32): workgroup = 8 rows x 32 columns of the destination grid, every
+// output channel.  The source halo tile streams through LDS in chunks of 16 channels (each input element is fetched
+// from global memory once instead of nine times, the 3x3 gather becomes ds_read_b32), every wave owns 4 pixel tiles
+// so one weight fragment (global / L1) feeds 4 MFMAs.
+// ------------------------------------------------------------------------------------------------------
+#define CT_TH 8
+#define CT_TW 32
+#define CT_CC 16                 // channels per LDS chunk
+#define CT_LW 36                 // LDS row stride (32 + 2 halo + 2 pad)
+#define CT_LH (CT_TH + 2)
+template <int MT, bool EXT>
+__global__ __launch_bounds__(256) void k_conv3_tile(const float* __restrict__ src, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ dst, ConvGeom g) {
+    __shared__ float s_in[CT_CC * CT_LH * CT_LW];
+    __shared__ int s_koff[CT_CC * 9];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int Cs = EXT ? g.Co : g.Ci, Cm = EXT ? g.Ci : g.Co;
+    const int K = Cs * 9;
+    const int Hd = EXT ? g.H + 2 : g.H, Wd = EXT ? g.W + 2 : g.W;
+    const int HWd = Hd * Wd, HWs = g.H * g.W;
+    const int b = blockIdx.z, ty0 = blockIdx.y * CT_TH, tx0 = blockIdx.x * CT_TW;
+    // LDS offset of (channel, ky, kx) relative to a pixel's own tile position.  The staged tile starts one pixel up/left
+    // of the destination tile in the forward pass (pos = p + k - 1) and two in the transposed pass (pos = p - k).
+    for (int i = threadIdx.x; i < CT_CC * 9; i += blockDim.x) {
+        const int c = i / 9, r = i - 9 * c, ky = r / 3, kx = r - 3 * ky;
+        s_koff[i] = c * (CT_LH * CT_LW) + (EXT ? (2 - ky) * CT_LW + (2 - kx) : ky * CT_LW + kx);
+    }
+    // this wave's 4 pixel tiles: rows 2*wave + (t >> 1), columns 16 * (t & 1) + n
+    int poff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) poff[t] = (2 * wave + (t >> 1)) * CT_LW + 16 * (t & 1) + n;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[mt][t] = zero;
+    const float* sb = src + (size_t)b * Cs * HWs;
+    const int oy = EXT ? ty0 - 2 : ty0 - 1, ox = EXT ? tx0 - 2 : tx0 - 1;  // source coords of the staged tile origin
+    for (int c0 = 0; c0 < Cs; c0 += CT_CC) {
+        __syncthreads();  // previous chunk fully consumed (first pass: s_koff written)
+        for (int i = threadIdx.x; i < CT_CC * CT_LH * (CT_TW + 2); i += blockDim.x) {
+            const int c = i / (CT_LH * (CT_TW + 2)), r = i - c * (CT_LH * (CT_TW + 2));
+            const int ly = r / (CT_TW + 2), lx = r - ly * (CT_TW + 2);
+            int y = oy + ly, x = ox + lx;
+            float v = 0.f;
+            if (c0 + c < Cs) {
+                if constexpr (EXT) {
+                    if (y >= 0 && y < g.H && x >= 0 && x < g.W) v = sb[(size_t)(c0 + c) * HWs + y * g.W + x];
+                } else {
+                    y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
+                    x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
+                    v = sb[(size_t)(c0 + c) * HWs + y * g.W + x];
+                }
+            }
+            s_in[c * (CT_LH * CT_LW) + ly * CT_LW + lx] = v;
+        }
+        __syncthreads();
+        const int kc = (Cs - c0 < CT_CC ? Cs - c0 : CT_CC) * 9;  // k extent of this chunk
+        for (int k0 = 0; k0 < kc; k0 += 4) {
+            const int kl = k0 + q;                 // k within the chunk
+            const bool kv = kl < kc;
+            const int ko = s_koff[kv ? kl : 0];
+            float bv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bv[t] = kv ? s_in[ko + poff[t]] : 0.f;
+            const int kg = c0 * 9 + kl;            // global k = (channel, ky, kx)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = 16 * mt + n;
+                float av = 0.f;
+                if (kv && m < Cm) {
+                    if constexpr (EXT) { const int c = kg / 9, r = kg - 9 * c; av = w[((size_t)c * g.Ci + m) * 9 + r]; }
+                    else av = w[(size_t)m * K + kg];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[mt][t] = cfd_mfma16x16x4(av, bv[t], acc[mt][t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int y = ty0 + 2 * wave + (t >> 1), x = tx0 + 16 * (t & 1) + n;
+        if (y < Hd && x < Wd) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * mt + 4 * q + r;
+                    if (m < Cm) dst[((size_t)b * Cm + m) * HWd + y * Wd + x] = acc[mt][t][r] + (bias ? bias[m] : 0.f);
                 }
         }
     }
@@ -100,8 +198,24 @@ static int launch_conv_gather(const float* src, const float* w, const float* bia
     long blocks = (total + CV_WAVES - 1) / CV_WAVES;
     if (blocks > 4096) blocks = 4096;
     const int Cm = EXT ? g.Ci : g.Co, MT = (Cm + 15) / 16;
-#define CV_L(M_) hipLaunchKernelGGL((k_conv_gather<M_, EXT>), dim3((unsigned)blocks), dim3(64 * CV_WAVES), 0, st, src, w, bias, dst, g, tiles_per_b, total)
-    switch (MT) {
+    if (g.ks == 3 && g.W >= 32 && MT <= 3) {  // wide images: LDS-tiled kernel (64 accumulator registers at MT = 3... 4 tiles)
+        const int Hd = EXT ? g.H + 2 : g.H, Wd = EXT ? g.W + 2 : g.W;
+        const dim3 grid((Wd + CT_TW - 1) / CT_TW, (Hd + CT_TH - 1) / CT_TH, g.B);
+        if (MT == 1) hipLaunchKernelGGL((k_conv3_tile<1, EXT>), grid, dim3(256), 0, st, src, w, bias, dst, g);
+        else if (MT == 2) hipLaunchKernelGGL((k_conv3_tile<2, EXT>), grid, dim3(256), 0, st, src, w, bias, dst, g);
+        else hipLaunchKernelGGL((k_conv3_tile<3, EXT>), grid, dim3(256), 0, st, src, w, bias, dst, g);
+        CFD_LAUNCH_CHECK(what);
+        return CFD_OK;
+    }
+    // Few pixels (deep, wide layers): split the output channels over blockIdx.y so that the grid still fills the chip;
+    // many pixels: one wave keeps every output channel (the gathered data operand is then loaded once).
+    int mtw = MT;  // M tiles per wave
+    while (mtw > 1 && total * ((MT + mtw - 1) / mtw) < 2048) mtw = (mtw + 1) / 2;
+    if (mtw == 5) mtw = 6;
+    if (mtw > 6 && mtw < 12) mtw = 8;
+    const int mgroups = (MT + mtw - 1) / mtw;
+#define CV_L(M_) hipLaunchKernelGGL((k_conv_gather<M_, EXT>), dim3((unsigned)blocks, mgroups), dim3(64 * CV_WAVES), 0, st, src, w, bias, dst, g, tiles_per_b, total)
+    switch (mtw) {
         case 1: CV_L(1); break;
         case 2: CV_L(2); break;
         case 3: CV_L(3); break;
@@ -110,12 +224,8 @@ static int launch_conv_gather(const float* src, const float* w, const float* bia
         case 8: CV_L(8); break;
         case 12: CV_L(12); break;
         default:
-            if (MT <= 6) CV_L(6);
-            else if (MT <= 12) CV_L(12);
-            else {
-                cfd_set_error("%s: %d output channels unsupported (max 192)", what, Cm);
-                return CFD_ERR_UNSUPPORTED;
-            }
+            cfd_set_error("%s: %d output channels unsupported (max 192)", what, Cm);
+            return CFD_ERR_UNSUPPORTED;
     }
 #undef CV_L
     CFD_LAUNCH_CHECK(what);
@@ -164,25 +274,33 @@ __global__ __launch_bounds__(256) void k_fold_pad(const float* __restrict__ ext,
 // ------------------------------------------------------------------------------------------------------
 #define CW_MT 2
 #define CW_NT 4
-__global__ __launch_bounds__(64 * CV_WAVES) void k_conv_wgrad(const float* __restrict__ gout, const float* __restrict__ in,
-                                                              float* __restrict__ part, ConvGeom g, int chunks_per_b,
-                                                              int nchunk_total, int chunk_px) {
+// TRANSPOSED = false: convolution.     A rows = output channels of gout, B columns j = (i, ky, kx) gathered from `in` with
+//                                       replicate clamping.
+// TRANSPOSED = true : ConvTranspose2d(k=2, s=2) (w (Ci,Co,2,2)): A rows = input channels i of `in` (on the H x W grid),
+//                                       B columns j = (o, ky, kx) gathered from gout at (2y+ky, 2x+kx) on the 2H x 2W grid.
+// Pixels are one linear space over (batch, H*W); workgroup = one 32 x 64 block of the (row, j) plane x one chunk of it.
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(64 * CV_WAVES) void k_conv_wgrad(const float* __restrict__ arows, const float* __restrict__ bsrc,
+                                                              float* __restrict__ part, ConvGeom g, long chunk_px) {
     __shared__ float s_red[CV_WAVES * CW_MT * CW_NT * 4 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
-    const int pad = g.ks / 2, kk = g.ks * g.ks, J = g.Ci * kk, HW = g.H * g.W;
-    const int o0 = blockIdx.y * 16 * CW_MT, j0 = blockIdx.z * 16 * CW_NT;
-    // this lane's B-operand columns: j = j0 + 16 nt + n -> (i, ky, kx)
-    int ci[CW_NT], dy[CW_NT], dx[CW_NT];
+    const int ks = TRANSPOSED ? 2 : g.ks, pad = ks / 2, kk = ks * ks;
+    const int R = TRANSPOSED ? g.Ci : g.Co;          // rows of the result (A operand channels)
+    const int Cb = TRANSPOSED ? g.Co : g.Ci;         // channels of the gathered tensor
+    const int J = Cb * kk, HW = g.H * g.W;
+    const int HWb = TRANSPOSED ? 4 * HW : HW, Wb = TRANSPOSED ? 2 * g.W : g.W;
+    const int r0 = blockIdx.y * 16 * CW_MT, j0 = blockIdx.z * 16 * CW_NT;
+    int cj[CW_NT], dy[CW_NT], dx[CW_NT];
     bool jv[CW_NT];
 #pragma unroll
     for (int nt = 0; nt < CW_NT; ++nt) {
         const int j = j0 + 16 * nt + n;
         jv[nt] = j < J;
         int ky, kx;
-        conv_split_k(jv[nt] ? j : 0, g.ks, ci[nt], ky, kx);
-        dy[nt] = ky - pad;
-        dx[nt] = kx - pad;
+        conv_split_k(jv[nt] ? j : 0, ks, cj[nt], ky, kx);
+        dy[nt] = TRANSPOSED ? ky : ky - pad;
+        dx[nt] = TRANSPOSED ? kx : kx - pad;
     }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[CW_MT][CW_NT];
@@ -190,30 +308,35 @@ __global__ __launch_bounds__(64 * CV_WAVES) void k_conv_wgrad(const float* __res
     for (int a = 0; a < CW_MT; ++a)
 #pragma unroll
         for (int c = 0; c < CW_NT; ++c) acc[a][c] = zero;
-    const int chunk = blockIdx.x;  // (b, pixel chunk)
-    const int b = chunk / chunks_per_b;
-    const int pbeg = (chunk - b * chunks_per_b) * chunk_px;
-    const int pend = pbeg + chunk_px < HW ? pbeg + chunk_px : HW;
-    const float* gb = gout + (size_t)b * g.Co * HW;
-    const float* ib = in + (size_t)b * g.Ci * HW;
-    for (int p0 = pbeg + 4 * wave; p0 < pend; p0 += 4 * CV_WAVES) {  // waves interleave 4-pixel k-steps
-        const int p = p0 + q;
-        const bool pv = p < pend;
-        const int y = pv ? p / g.W : 0, x = pv ? p - y * g.W : 0;
+    const long total = (long)g.B * HW;
+    const long pbeg = (long)blockIdx.x * chunk_px;
+    const long pend = pbeg + chunk_px < total ? pbeg + chunk_px : total;
+    for (long p0 = pbeg + 4 * wave; p0 < pend; p0 += 4 * CV_WAVES) {  // waves interleave 4-pixel k-steps
+        const long P = p0 + q;
+        const bool pv = P < pend;
+        const int b = pv ? (int)(P / HW) : 0;
+        const int p = pv ? (int)(P - (long)b * HW) : 0;
+        const int y = p / g.W, x = p - y * g.W;
+        const float* ab = arows + (size_t)b * R * HW;
+        const float* bb = bsrc + (size_t)b * Cb * HWb;
         float av[CW_MT], bv[CW_NT];
 #pragma unroll
         for (int a = 0; a < CW_MT; ++a) {
-            const int o = o0 + 16 * a + n;
-            av[a] = (pv && o < g.Co) ? gb[(size_t)o * HW + p] : 0.f;
+            const int r = r0 + 16 * a + n;
+            av[a] = (pv && r < R) ? ab[(size_t)r * HW + p] : 0.f;
         }
 #pragma unroll
         for (int c = 0; c < CW_NT; ++c) {
             float v = 0.f;
             if (pv && jv[c]) {
-                int yy = y + dy[c], xx = x + dx[c];
-                yy = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy);
-                xx = xx < 0 ? 0 : (xx >= g.W ? g.W - 1 : xx);
-                v = ib[(size_t)ci[c] * HW + yy * g.W + xx];
+                int yy, xx;
+                if constexpr (TRANSPOSED) { yy = 2 * y + dy[c]; xx = 2 * x + dx[c]; }
+                else {
+                    yy = y + dy[c]; xx = x + dx[c];
+                    yy = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy);
+                    xx = xx < 0 ? 0 : (xx >= g.W ? g.W - 1 : xx);
+                }
+                v = bb[(size_t)cj[c] * HWb + yy * Wb + xx];
             }
             bv[c] = v;
         }
@@ -222,7 +345,7 @@ __global__ __launch_bounds__(64 * CV_WAVES) void k_conv_wgrad(const float* __res
 #pragma unroll
             for (int c = 0; c < CW_NT; ++c) acc[a][c] = cfd_mfma16x16x4(av[a], bv[c], acc[a][c]);
     }
-    // block reduction of the 4 waves (fixed order), one partial tile per (chunk, o-block, j-block)
+    // block reduction of the 4 waves (fixed order), one partial tile per (chunk, row block, j block)
 #pragma unroll
     for (int a = 0; a < CW_MT; ++a)
 #pragma unroll
@@ -230,19 +353,31 @@ __global__ __launch_bounds__(64 * CV_WAVES) void k_conv_wgrad(const float* __res
 #pragma unroll
             for (int r = 0; r < 4; ++r) s_red[(((wave * CW_MT + a) * CW_NT + c) * 4 + r) * 64 + lane] = acc[a][c][r];
     __syncthreads();
-    float* dst = part + (size_t)chunk * g.Co * J;
+    float* dst = part + (size_t)blockIdx.x * R * J;
     for (int e = threadIdx.x; e < CW_MT * CW_NT * 4 * 64; e += blockDim.x) {
         const int ln = e & 63, r = (e >> 6) & 3, tile = e >> 8;
         const int a = tile / CW_NT, c = tile % CW_NT;
-        const int o = o0 + 16 * a + 4 * (ln >> 4) + r, j = j0 + 16 * c + (ln & 15);
-        if (o < g.Co && j < J) {
-            float s = 0.f;
+        const int row = r0 + 16 * a + 4 * (ln >> 4) + r, j = j0 + 16 * c + (ln & 15);
+        if (row < R && j < J) {
+            float sum = 0.f;
 #pragma unroll
-            for (int wv = 0; wv < CV_WAVES; ++wv) s += s_red[(((wv * CW_MT + a) * CW_NT + c) * 4 + r) * 64 + ln];
-            dst[(size_t)o * J + j] = s;
+            for (int wv = 0; wv < CV_WAVES; ++wv) sum += s_red[(((wv * CW_MT + a) * CW_NT + c) * 4 + r) * 64 + ln];
+            dst[(size_t)row * J + j] = sum;
         }
     }
-    (void)nchunk_total;
+}
+
+// Chunks of the linear (batch, pixel) space: enough workgroups to fill the chip, but no more partial tiles than ~32 MB.
+static void wgrad_plan(long total_px, int R, int J, long& chunk_px, int& nchunk) {
+    const long tiles = (long)((R + 16 * CW_MT - 1) / (16 * CW_MT)) * ((J + 16 * CW_NT - 1) / (16 * CW_NT));
+    long want = (2048 + tiles - 1) / tiles;                      // workgroups ~ 2048
+    const long cap = (32L << 20) / ((long)R * J * 4 + 1);        // partial-sum bytes
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    chunk_px = (total_px + want - 1) / want;
+    if (chunk_px < 64) chunk_px = 64;
+    chunk_px = (chunk_px + 15) / 16 * 16;
+    nchunk = (int)((total_px + chunk_px - 1) / chunk_px);
 }
 
 // out[e] = sum_chunk part[chunk][e]  (8 loads in flight, fixed order)
@@ -262,37 +397,21 @@ __global__ __launch_bounds__(256) void k_part_reduce(const float* __restrict__ p
     }
 }
 
-// per-channel sum over (B, H*W): one wave per channel, lanes stride over the elements, fixed tree
-__global__ __launch_bounds__(256) void k_chan_sum(const float* __restrict__ g, float* __restrict__ out, int B, int C, int HW) {
-    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float* p = g + ((size_t)b * C + c) * HW;
-        for (int i = lane; i < HW; i += 64) s += p[i];
-    }
-    s = cfd_wave_sum(s);
-    if (lane == 0) out[c] = s;
-}
-
-static void conv_wgrad_plan(int B, int HW, int& chunk_px, int& chunks_per_b) {
-    // about 1024 (b, chunk) units, each at least 64 pixels
-    long target = 1024 / (B > 0 ? B : 1);
-    if (target < 1) target = 1;
-    chunk_px = (int)((HW + target - 1) / target);
-    if (chunk_px < 64) chunk_px = 64;
-    chunk_px = (chunk_px + 15) / 16 * 16;
-    chunks_per_b = (HW + chunk_px - 1) / chunk_px;
-}
+// per-channel sum over (B, HW) in two parallel stages (defined next to the BatchNorm reductions it shares)
+static int chan_sum(const float* g, float* out, void* ws, int B, int C, int HW, hipStream_t st, const char* what);
+static size_t chan_sum_ws_bytes(int C);
 
 extern "C" size_t cfd_conv2d_bwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks) {
     if (B <= 0) return 0;
     const int pad = ks / 2;
     const size_t ext = cfd_align_up((size_t)B * Ci * (H + 2 * pad) * (W + 2 * pad) * sizeof(float), 256);
-    int chunk_px, cpb;
-    conv_wgrad_plan(B, H * W, chunk_px, cpb);
-    const size_t part = cfd_align_up((size_t)B * cpb * Co * Ci * ks * ks * sizeof(float), 256);
-    return ext > part ? ext : part;
+    long chunk_px;
+    int nchunk;
+    wgrad_plan((long)B * H * W, Co, Ci * ks * ks, chunk_px, nchunk);
+    const size_t part = cfd_align_up((size_t)nchunk * Co * Ci * ks * ks * sizeof(float), 256);
+    const size_t cs = chan_sum_ws_bytes(Co);
+    const size_t m = ext > part ? ext : part;
+    return m > cs ? m : cs;
 }
 
 // gin (B,Ci,H,W), gw (Co,Ci,ks,ks), gb (Co) from gout (B,Co,H,W); any of gin / gw / gb may be NULL.
@@ -318,13 +437,14 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
         CFD_LAUNCH_CHECK("cfd_conv2d_bwd(fold)");
     }
     if (gw) {
-        int chunk_px, cpb;
-        conv_wgrad_plan(B, HW, chunk_px, cpb);
-        const int nchunk = B * cpb, J = Ci * ks * ks;
+        long chunk_px;
+        int nchunk;
+        const int J = Ci * ks * ks;
+        wgrad_plan((long)B * HW, Co, J, chunk_px, nchunk);
         const dim3 grid(nchunk, (Co + 16 * CW_MT - 1) / (16 * CW_MT), (J + 16 * CW_NT - 1) / (16 * CW_NT));
         {
             CFD_PROF("k_conv_wgrad", st);
-            hipLaunchKernelGGL(k_conv_wgrad, grid, dim3(64 * CV_WAVES), 0, st, gout, in, (float*)ws, g, cpb, nchunk, chunk_px);
+            hipLaunchKernelGGL((k_conv_wgrad<false>), grid, dim3(64 * CV_WAVES), 0, st, gout, in, (float*)ws, g, chunk_px);
         }
         CFD_LAUNCH_CHECK("cfd_conv2d_bwd(wgrad)");
         const long n = (long)Co * J;
@@ -334,10 +454,7 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
         hipLaunchKernelGGL(k_part_reduce, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, gw, n, nchunk);
         CFD_LAUNCH_CHECK("cfd_conv2d_bwd(reduce)");
     }
-    if (gb) {
-        hipLaunchKernelGGL(k_chan_sum, dim3((Co + 3) / 4), dim3(256), 0, st, gout, gb, B, Co, HW);
-        CFD_LAUNCH_CHECK("cfd_conv2d_bwd(bias)");
-    }
+    if (gb) CFD_TRY(chan_sum(gout, gb, ws, B, Co, HW, st, "cfd_conv2d_bwd(bias)"));
     return CFD_OK;
 }
 
@@ -414,6 +531,19 @@ __global__ __launch_bounds__(64) void k_bn_final(const float* __restrict__ part,
         ggamma[c] = b;
     }
     (void)C;
+}
+
+static size_t chan_sum_ws_bytes(int C) { return cfd_align_up(((size_t)C * BN_SPLIT * 2 + C) * sizeof(float), 256); }
+
+static int chan_sum(const float* g, float* out, void* ws, int B, int C, int HW, hipStream_t st, const char* what) {
+    float* part = (float*)ws;
+    float* dummy = part + (size_t)C * BN_SPLIT * 2;
+    hipLaunchKernelGGL((k_bn_partial<0>), dim3(C, BN_SPLIT), dim3(256), 0, st, g, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, part, B, C, HW, 0);
+    hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 2, 1.f, 0.f, 0.f, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, out, dummy, C);
+    CFD_LAUNCH_CHECK(what);
+    return CFD_OK;
 }
 
 __global__ __launch_bounds__(256) void k_bn_eval_stats(const float* __restrict__ run_mean, const float* __restrict__ run_var,
@@ -630,28 +760,6 @@ __global__ __launch_bounds__(256) void k_convt2_bwd_in(const float* __restrict__
     }
 }
 
-// gw[i][o][ky][kx] = sum_{b,y,x} in[b,i,y,x] g[b,o,2y+ky,2x+kx]: grid (chunk of (b,pixels), i), thread = (o,ky,kx) slot
-__global__ __launch_bounds__(256) void k_convt2_wgrad(const float* __restrict__ in, const float* __restrict__ g,
-                                                      float* __restrict__ part, int B, int Ci, int Co, int H, int W,
-                                                      int chunk_px, int chunks_per_b) {
-    const int Ho = 2 * H, Wo = 2 * W, HW = H * W;
-    const int chunk = blockIdx.x, i = blockIdx.y;
-    const int b = chunk / chunks_per_b;
-    const int pbeg = (chunk - b * chunks_per_b) * chunk_px;
-    const int pend = pbeg + chunk_px < HW ? pbeg + chunk_px : HW;
-    const float* ip = in + ((size_t)b * Ci + i) * HW;
-    for (int slot = threadIdx.x; slot < Co * 4; slot += blockDim.x) {
-        const int o = slot >> 2, ky = (slot >> 1) & 1, kx = slot & 1;
-        const float* gp = g + ((size_t)b * Co + o) * Ho * Wo + ky * Wo + kx;
-        float acc = 0.f;
-        for (int p = pbeg; p < pend; ++p) {
-            const int y = p / W, x = p - y * W;
-            acc = fmaf(ip[p], gp[(2 * y) * Wo + 2 * x], acc);
-        }
-        part[((size_t)chunk * Ci + i) * Co * 4 + slot] = acc;
-    }
-}
-
 extern "C" int cfd_convt2_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int H,
                               int W, void* stream) {
     CFD_REQUIRE(in && w && out, CFD_ERR_INVALID_ARG, "cfd_convt2_fwd: NULL pointer");
@@ -664,19 +772,13 @@ extern "C" int cfd_convt2_fwd(const float* in, const float* w, const float* bias
     return CFD_OK;
 }
 
-static void convt_plan(int B, int HW, int& chunk_px, int& cpb) {
-    long target = 256 / (B > 0 ? B : 1);
-    if (target < 1) target = 1;
-    chunk_px = (int)((HW + target - 1) / target);
-    if (chunk_px < 16) chunk_px = 16;
-    cpb = (HW + chunk_px - 1) / chunk_px;
-}
-
 extern "C" size_t cfd_convt2_bwd_workspace_bytes(int B, int Ci, int Co, int H, int W) {
     if (B <= 0) return 0;
-    int chunk_px, cpb;
-    convt_plan(B, H * W, chunk_px, cpb);
-    return cfd_align_up((size_t)B * cpb * Ci * Co * 4 * sizeof(float), 256);
+    long chunk_px;
+    int nchunk;
+    wgrad_plan((long)B * H * W, Ci, Co * 4, chunk_px, nchunk);
+    const size_t a = cfd_align_up((size_t)nchunk * Ci * Co * 4 * sizeof(float), 256), b = chan_sum_ws_bytes(Co);
+    return a > b ? a : b;
 }
 
 extern "C" int cfd_convt2_bwd(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws,
@@ -690,13 +792,15 @@ extern "C" int cfd_convt2_bwd(const float* gout, const float* in, const float* w
         CFD_LAUNCH_CHECK("cfd_convt2_bwd(input)");
     }
     if (gw) {
-        int chunk_px, cpb;
-        convt_plan(B, H * W, chunk_px, cpb);
-        const int nchunk = B * cpb;
+        long chunk_px;
+        int nchunk;
+        const int J = Co * 4;
+        wgrad_plan((long)B * H * W, Ci, J, chunk_px, nchunk);
+        const ConvGeom g{B, Ci, Co, H, W, 2};
+        const dim3 grid(nchunk, (Ci + 16 * CW_MT - 1) / (16 * CW_MT), (J + 16 * CW_NT - 1) / (16 * CW_NT));
         {
             CFD_PROF("k_convt2_wgrad", st);
-            hipLaunchKernelGGL(k_convt2_wgrad, dim3(nchunk, Ci), dim3(256), 0, st, in, gout, (float*)ws, B, Ci, Co, H, W,
-                               chunk_px, cpb);
+            hipLaunchKernelGGL((k_conv_wgrad<true>), grid, dim3(64 * CV_WAVES), 0, st, in, gout, (float*)ws, g, chunk_px);
         }
         CFD_LAUNCH_CHECK("cfd_convt2_bwd(wgrad)");
         const long n = (long)Ci * Co * 4;
@@ -705,10 +809,7 @@ extern "C" int cfd_convt2_bwd(const float* gout, const float* in, const float* w
                            (const float*)ws, gw, n, nchunk);
         CFD_LAUNCH_CHECK("cfd_convt2_bwd(reduce)");
     }
-    if (gb) {
-        hipLaunchKernelGGL(k_chan_sum, dim3((Co + 3) / 4), dim3(256), 0, st, gout, gb, B, Co, 4 * H * W);
-        CFD_LAUNCH_CHECK("cfd_convt2_bwd(bias)");
-    }
+    if (gb) CFD_TRY(chan_sum(gout, gb, ws, B, Co, 4 * H * W, st, "cfd_convt2_bwd(bias)"));
     return CFD_OK;
 }
 

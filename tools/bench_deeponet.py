@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--graph", action="store_true")
     a = ap.parse_args()
     from cfdbench_amd import _lib
     from cfdbench_amd.models.auto_deeponet import AutoDeepONet
@@ -26,7 +27,7 @@ def main():
     H, W, p, B = 66, 65, 5, a.batch
     torch.manual_seed(0)
     m = AutoDeepONet(H * W + p, 2, loss_name_to_fn("nmse"), branch_depth=8, trunk_depth=8, width=100).cuda()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=a.graph)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, 2, H, W, generator=g).cuda()
     y = (x.cpu() + 0.1 * torch.randn(B, 2, H, W, generator=g)).cuda()
@@ -40,6 +41,13 @@ def main():
         opt.zero_grad()
         return out["loss"]["nmse"]
 
+    if a.graph:
+        from cfdbench_amd.graph import GraphedTrainStep
+        gs = GraphedTrainStep(m, opt, dict(inputs=x, case_params=cp, label=y, mask=mask))
+        eager_step = step
+
+        def step():  # noqa: F811
+            return gs(inputs=x, case_params=cp, label=y, mask=mask)["nmse"]
     for _ in range(5):
         step()
     torch.cuda.synchronize()
@@ -51,11 +59,11 @@ def main():
     api = _lib.api()
     api.call("cfd_prof_begin")
     for _ in range(a.steps):
-        step()
+        (eager_step if a.graph else step)()
     buf = ctypes.create_string_buffer(1 << 16)
     api.call("cfd_prof_end", buf, len(buf))
     kern = {ln.split()[0]: round(float(ln.split()[2]) / a.steps * 1e3, 1) for ln in buf.value.decode().splitlines()}
-    res = dict(workload=f"Auto-DeepONet train step, B={B}, {H}x{W}, width 100, depth 8/8, fp32", frames_per_s=round(B / dt, 1),
+    res = dict(workload=f"Auto-DeepONet train step, B={B}, {H}x{W}, width 100, depth 8/8, fp32", frames_per_s=round(B / dt, 1), graph=bool(a.graph),
                ms_per_step=round(dt * 1e3, 3), final_nmse=round(l.item(), 5), hip_kernel_us_per_step=kern)
     if a.cpu:
         import torch.nn as nn

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--graph", action="store_true")
     a = ap.parse_args()
     from cfdbench_amd import _lib
     from cfdbench_amd.models.loss import loss_name_to_fn
@@ -25,7 +26,7 @@ def main():
     H, W, p, B = 64, 64, 8, a.batch
     torch.manual_seed(0)
     m = UNet(2, 2, loss_name_to_fn("nmse"), p, insert_case_params_at="input", dim=12).cuda()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=a.graph)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, 2, H, W, generator=g).cuda()
     y = (x.cpu() + 0.1 * torch.randn(B, 2, H, W, generator=g)).cuda()
@@ -39,6 +40,13 @@ def main():
         opt.zero_grad()
         return out["loss"]["nmse"]
 
+    if a.graph:
+        from cfdbench_amd.graph import GraphedTrainStep
+        gs = GraphedTrainStep(m, opt, dict(inputs=x, case_params=cp, label=y, mask=mask))
+        eager_step = step
+
+        def step():  # noqa: F811
+            return gs(inputs=x, case_params=cp, label=y, mask=mask)["nmse"]
     for _ in range(3):
         step()
     torch.cuda.synchronize()
@@ -50,11 +58,11 @@ def main():
     api = _lib.api()
     api.call("cfd_prof_begin")
     for _ in range(a.steps):
-        step()
+        (eager_step if a.graph else step)()
     buf = ctypes.create_string_buffer(1 << 16)
     api.call("cfd_prof_end", buf, len(buf))
     kern = {ln.split()[0]: round(float(ln.split()[2]) / a.steps * 1e3, 1) for ln in buf.value.decode().splitlines()}
-    res = dict(workload=f"U-Net(dim 12, p=8) train step, B={B}, {H}x{W}, fp32", frames_per_s=round(B / dt, 1),
+    res = dict(workload=f"U-Net(dim 12, p=8) train step, B={B}, {H}x{W}, fp32", frames_per_s=round(B / dt, 1), graph=bool(a.graph),
                ms_per_step=round(dt * 1e3, 3), final_nmse=round(l.item(), 5), hip_kernel_us_per_step=kern)
     if a.cpu:
         import torch.nn as nn
