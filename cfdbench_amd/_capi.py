@@ -91,6 +91,7 @@ _SIGS = {
     "cfd_convt2_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "cfd_convt2_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfd_residual_mask": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cfd_dropout": (_I, [_P, _P, _Z, _F, C.c_ulonglong, _P]),
     "cfd_fno_workspace_bytes": (_Z, [_P, C.POINTER(FnoShape), _I]),
     "cfd_fno_forward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "cfd_fno_backward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),

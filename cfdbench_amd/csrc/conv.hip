@@ -840,3 +840,34 @@ extern "C" int cfd_residual_mask(const float* x, const float* resid, const float
     CFD_LAUNCH_CHECK("cfd_residual_mask");
     return CFD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// nn.Dropout (src/models/resnet.py:45,76): y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) from a counter-based hash of
+// (seed, element index).  The reference draws from torch's Philox stream, which cannot be reproduced; parity of the
+// ResNet is therefore tested in eval mode (dropout = identity), and the training path is tested for its statistics
+// and for forward/backward consistency (the backward pass regenerates the same mask from the same seed).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned cfd_hash32(unsigned long long v) {
+    v ^= v >> 33; v *= 0xff51afd7ed558ccdULL;
+    v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL;
+    v ^= v >> 33;
+    return (unsigned)v;
+}
+
+__global__ __launch_bounds__(256) void k_dropout(const float* __restrict__ x, float* __restrict__ y, size_t n, float p,
+                                                 unsigned long long seed) {
+    const float scale = 1.0f / (1.0f - p);
+    const unsigned thresh = (unsigned)((double)p * 4294967296.0);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = cfd_hash32(seed * 0x9E3779B97F4A7C15ULL + i) >= thresh ? x[i] * scale : 0.f;
+}
+
+// forward and backward are the same map (applied to x resp. the upstream gradient) for the same (p, seed)
+extern "C" int cfd_dropout(const float* x, float* y, size_t n, float p, unsigned long long seed, void* stream) {
+    CFD_REQUIRE(x && y, CFD_ERR_INVALID_ARG, "cfd_dropout: NULL pointer");
+    CFD_REQUIRE(p >= 0.f && p < 1.f, CFD_ERR_INVALID_ARG, "cfd_dropout: p must be in [0, 1)");
+    if (n == 0) return CFD_OK;
+    hipLaunchKernelGGL(k_dropout, dim3(ew_blocks((long)n)), dim3(256), 0, (hipStream_t)stream, x, y, n, p, seed);
+    CFD_LAUNCH_CHECK("cfd_dropout");
+    return CFD_OK;
+}

@@ -526,3 +526,61 @@ class ResidualMaskFn(torch.autograd.Function):
             gres = torch.zeros(ctx.resid_shape, dtype=torch.float32, device=g.device)
             gres[:, :g.shape[1]] = gx
         return gx, gres, None
+
+
+class GeluFn(torch.autograd.Function):
+    """nn.GELU() (exact erf) as a stand-alone pass (resnet.py:46,77)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        _require_cuda(x)
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        _lib.api().call("cfd_gelu_fwd", _ptr(x), _ptr(y), x.numel(), _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        (x,) = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        _lib.api().call("cfd_gelu_bwd", _ptr(x), _ptr(_f32c(gy)), _ptr(gx), x.numel(), _stream())
+        return gx
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout in training mode: keep mask from a hash of (seed, index); backward regenerates the same mask."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, p: float, seed: int):
+        _require_cuda(x)
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        _lib.api().call("cfd_dropout", _ptr(x), _ptr(y), x.numel(), float(p), int(seed), _stream())
+        ctx.meta = (float(p), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        p, seed = ctx.meta
+        gy = _f32c(gy)
+        gx = torch.empty_like(gy)
+        _lib.api().call("cfd_dropout", _ptr(gy), _ptr(gx), gy.numel(), p, seed, _stream())
+        return gx, None, None
+
+
+class AddFn(torch.autograd.Function):
+    """x + y for equal shapes (the skip connection of a ResidualBlock, resnet.py:79)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, y: Tensor):
+        _require_cuda(x, y)
+        x, y = _f32c(x), _f32c(y)
+        B, C = x.shape[0], x.shape[1]
+        out = torch.empty_like(x)
+        _lib.api().call("cfd_residual_mask", _ptr(x), _ptr(y), None, _ptr(out), B, C, C, x[0, 0].numel(), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return g, g

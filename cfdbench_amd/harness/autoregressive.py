@@ -7,6 +7,7 @@ from ..models.auto_deeponet import AutoDeepONet
 from ..models.base_model import AutoCfdModel
 from ..models.fno.fno2d import Fno2d
 from ..models.loss import loss_name_to_fn
+from ..models.resnet import ResNet
 from ..models.unet import UNet
 
 
@@ -40,6 +41,10 @@ def init_model(args) -> AutoCfdModel:
     if args.model == "unet":  # autoregressive.py:105-114
         return UNet(in_chan=args.in_chan, out_chan=args.out_chan, loss_fn=loss_fn, n_case_params=n_case_params,
                     insert_case_params_at=args.unet_insert_case_params_at, dim=args.unet_dim)
-    if args.model in ("auto_ffn", "auto_edeeponet", "auto_deeponet_cnn", "resnet"):
+    if args.model == "resnet":  # autoregressive.py:93-104
+        return ResNet(in_chan=args.in_chan, out_chan=args.out_chan, n_case_params=n_case_params, loss_fn=loss_fn,
+                      hidden_chan=args.resnet_hidden_chan, num_blocks=args.resnet_depth,
+                      kernel_size=args.resnet_kernel_size, padding=args.resnet_kernel_size // 2)
+    if args.model in ("auto_ffn", "auto_edeeponet", "auto_deeponet_cnn"):
         raise NotImplementedError(f"cfdbench_amd: model {args.model!r} has no MI355X kernels yet (DESIGN.md section 7)")
     raise ValueError(f"Invalid model name: {args.model}")

@@ -1,0 +1,89 @@
+"""ResNet baseline with the reference's module tree and ``state_dict`` (including the never-called ``bn1`` / ``bn2`` of
+every block) on the gfx950 conv kernels (src/models/resnet.py:10-236): 7x7 replicate-padded implicit-GEMM
+convolutions, exact-erf GELU, hash-based dropout in training mode, 1x1 skip convolutions, (x + residual) * mask."""
+from typing import List, Optional
+
+import torch
+from torch import Tensor, nn
+
+from .. import functional as F_
+from .base_model import AutoCfdModel
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_chan: int, out_chan: int, hidden_chan: int, kernel_size: int, stride: int = 1, padding: int = 0,
+                 dropout_rate: float = 0.2, bias: bool = True, use_1x1conv: bool = False):
+        super().__init__()
+        if in_chan != out_chan:
+            assert use_1x1conv
+        if stride != 1 or padding != kernel_size // 2:
+            raise NotImplementedError("cfdbench_amd.ResidualBlock: only stride 1 with 'same' replicate padding is built "
+                                      "(what ResNet uses, resnet.py:95-96)")
+        self.in_chan, self.out_chan, self.hidden_chan = in_chan, out_chan, hidden_chan
+        self.kernel_size, self.stride, self.padding, self.bias = kernel_size, stride, padding, bias
+        self.conv1 = nn.Conv2d(in_chan, hidden_chan, kernel_size, stride, padding, bias=bias, padding_mode="replicate")
+        self.bn1 = nn.BatchNorm2d(hidden_chan)  # declared but never applied by the reference (resnet.py:44,70-80)
+        self.dropout = nn.Dropout(p=dropout_rate)
+        self.act = nn.GELU()
+        self.conv2 = nn.Conv2d(hidden_chan, out_chan, kernel_size, stride, padding, bias=bias, padding_mode="replicate")
+        self.bn2 = nn.BatchNorm2d(out_chan)
+        self.res_conv = nn.Conv2d(in_chan, out_chan, kernel_size=1, stride=stride, padding=0, bias=bias) if use_1x1conv else None
+        self._calls = 0
+
+    def forward(self, x: Tensor) -> Tensor:
+        residual = x if self.res_conv is None else F_.Conv2dReplicateFn.apply(x, self.res_conv.weight, self.res_conv.bias)
+        x = F_.Conv2dReplicateFn.apply(x, self.conv1.weight, self.conv1.bias)
+        if self.training and self.dropout.p > 0:
+            self._calls += 1
+            seed = (torch.initial_seed() * 1000003 + id(self) % 65521 * 7919 + self._calls) & 0xFFFFFFFFFFFF
+            x = F_.DropoutFn.apply(x, self.dropout.p, seed)
+        x = F_.GeluFn.apply(x)
+        x = F_.Conv2dReplicateFn.apply(x, self.conv2.weight, self.conv2.bias)
+        return F_.AddFn.apply(x, residual)
+
+
+class ResNet(AutoCfdModel):
+    def __init__(self, in_chan: int, out_chan: int, n_case_params: int, loss_fn: nn.Module, hidden_chan: int = 32,
+                 num_blocks: int = 4, kernel_size: int = 7, padding: int = 3, stride: int = 1):
+        super().__init__(loss_fn)
+        assert in_chan == out_chan
+        self.in_chan, self.out_chan, self.n_case_params = in_chan, out_chan, n_case_params
+        self.hidden_chan, self.num_blocks = hidden_chan, num_blocks
+        self.kernel_size, self.padding, self.stride = kernel_size, padding, stride
+        blocks = [ResidualBlock(in_chan + 1 + n_case_params, hidden_chan, 64, kernel_size, stride, padding, use_1x1conv=True)]
+        for _ in range(num_blocks):
+            blocks.append(ResidualBlock(hidden_chan, hidden_chan, 64, kernel_size, stride, padding, use_1x1conv=False))
+        blocks.append(ResidualBlock(hidden_chan, out_chan, 64, kernel_size, stride, padding, use_1x1conv=True))
+        self.blocks = nn.Sequential(*blocks)
+
+    def forward(self, inputs: Tensor, case_params: Tensor, mask: Optional[Tensor] = None, label: Optional[Tensor] = None) -> dict:
+        """inputs (B,c,h,w), case_params (B,p), mask (B,h,w)|(B,1,h,w), label (B,c,h,w)  (resnet.py:145-198)."""
+        residual = inputs
+        batch_size, n_chan, height, width = inputs.shape
+        if mask is None:
+            mask = torch.ones((batch_size, 1, height, width), device=inputs.device)
+        elif mask.dim() == 3:
+            mask = mask.unsqueeze(1)
+        cp = case_params.unsqueeze(-1).unsqueeze(-1).expand(-1, -1, height, width)
+        x = self.blocks(torch.cat([inputs, mask, cp], dim=1))
+        preds = F_.ResidualMaskFn.apply(x, residual, mask)  # (blocks + inputs[:, :out_chan]) * mask
+        if label is not None:
+            label = F_.ResidualMaskFn.apply(label, None, mask)
+            return dict(preds=preds, loss=self.loss_fn(preds=preds, labels=label))
+        return dict(preds=preds)
+
+    def generate(self, inputs: Tensor, case_params: Tensor, mask: Optional[Tensor] = None):
+        return self.forward(inputs, case_params=case_params, mask=mask)["preds"]
+
+    def generate_many(self, inputs: Tensor, case_params: Tensor, steps: int, mask: Tensor) -> List[Tensor]:
+        """steps + 1 frames: the reference prepends the input frame (resnet.py:210-236)."""
+        if inputs.dim() == 3:
+            inputs = inputs.unsqueeze(0)
+            case_params = case_params.unsqueeze(0)
+            mask = mask.unsqueeze(0)
+        cur_frame = inputs
+        frames = [cur_frame]
+        for _ in range(steps):
+            cur_frame = self.generate(cur_frame, case_params=case_params, mask=mask)
+            frames.append(cur_frame)
+        return frames

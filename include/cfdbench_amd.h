@@ -228,6 +228,10 @@ int cfd_convt2_bwd(const float* gout, const float* in, const float* w, float* gi
 int cfd_residual_mask(const float* x, const float* resid, const float* mask, float* out, int B, int C, int Cr, int HW,
                       void* stream);
 
+/* nn.Dropout (resnet.py:45,76): y = x * keep / (1-p) with keep from a counter-based hash of (seed, index).  The same
+ * call with the upstream gradient as x is the backward pass.  (torch's Philox stream is not reproducible here.)  */
+int cfd_dropout(const float* x, float* y, size_t n, float p, unsigned long long seed, void* stream);
+
 /* ---- whole Auto-FNO (Fno2d.forward, fno2d.py:178-242; loss.backward() at train_auto.py:255) ---------------*/
 typedef struct {
     int B, H, W;

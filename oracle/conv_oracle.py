@@ -162,3 +162,24 @@ def unet_forward(P: Dict[str, Array], inputs: Array, case_params: Array, mask: A
     if label is not None:
         out["loss"] = O.mse_loss(preds, label * mask, True)
     return out
+
+
+# ---- ResNet.forward in eval mode (src/models/resnet.py:70-80,145-198): dropout is the identity, bn1/bn2 are never applied ----
+def resnet_forward(P: Dict[str, Array], inputs: Array, case_params: Array, mask: Array, label: Optional[Array],
+                   out_chan: int = 2):
+    B, _, H, W = inputs.shape
+    if mask.ndim == 3:
+        mask = mask[:, None]
+    x = np.concatenate([inputs, mask, np.broadcast_to(case_params[:, :, None, None], (B, case_params.shape[1], H, W))], axis=1)
+    i = 0
+    while f"blocks.{i}.conv1.weight" in P:
+        pre = f"blocks.{i}"
+        res = conv2d(x, P[f"{pre}.res_conv.weight"], P[f"{pre}.res_conv.bias"]) if f"{pre}.res_conv.weight" in P else x
+        h = O.gelu(conv2d(x, P[f"{pre}.conv1.weight"], P[f"{pre}.conv1.bias"]))
+        x = conv2d(h, P[f"{pre}.conv2.weight"], P[f"{pre}.conv2.bias"]) + res
+        i += 1
+    preds = (x + inputs[:, :out_chan]) * mask
+    out = dict(preds=preds)
+    if label is not None:
+        out["loss"] = O.mse_loss(preds, label * mask, True)
+    return out

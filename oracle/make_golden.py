@@ -178,6 +178,33 @@ def gen_unet(name, seed, bseed, B, H, W, dim, p=8, steps=2):
     print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
 
 
+def gen_resnet(name, seed, bseed, B, H, W, hidden, nblocks, p=5, steps=2):
+    """ResNet in EVAL mode (dropout = identity; torch's dropout stream is not reproducible): forward, loss, backward and
+    rollout from the reference module (src/models/resnet.py)."""
+    from models.resnet import ResNet  # reference
+    torch.manual_seed(seed)
+    model = ResNet(2, 2, p, MseLoss(normalize=True), hidden_chan=hidden, num_blocks=nblocks, kernel_size=7, padding=3)
+    model.eval()
+    sd0 = {k: v.clone().numpy() for k, v in model.state_dict().items()}
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    batch["mask"][:, :, -1, :] = 0
+    x = _t(batch["inputs"]).requires_grad_(True)
+    out = model(inputs=x, case_params=_t(batch["case_params"]), mask=_t(batch["mask"]), label=_t(batch["label"]))
+    out["loss"]["nmse"].backward()
+    save = dict(meta=np.array([seed, bseed, B, H, W, hidden, nblocks, p, steps]), preds=out["preds"].detach().numpy(),
+                g_inputs=x.grad.numpy(), **{f"loss_{k}": np.array(v.item()) for k, v in out["loss"].items()})
+    for k, v in sd0.items():
+        save[f"sd::{k}"] = v
+    for k, prm in model.named_parameters():
+        if prm.grad is not None:
+            save[f"grad::{k}"] = prm.grad.numpy()
+    with torch.no_grad():
+        frames = model.generate_many(_t(batch["inputs"][0]), _t(batch["case_params"][0]), steps, _t(batch["mask"][0]))
+    save["frames"] = np.stack([f.numpy() for f in frames])
+    np.savez_compressed(OUT / f"{name}.npz", **save)
+    print(name, "ok", {k: float(v) for k, v in out["loss"].items()}, save["frames"].shape)
+
+
 def gen_adam(name, pseed, bseed, B, C, L, H, W, nsteps, lr, p=5, gain=1.0):
     """train_auto.py:231-257: model(**batch) -> loss['nmse'].backward() -> Adam.step() -> zero_grad()."""
     params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=gain)
@@ -224,6 +251,7 @@ def main():
     gen_auto_deeponet("auto_deeponet_gelu_16x16", 43, 53, 2, 16, 16, 16, 2, 2, "gelu")
     gen_unet("unet_dim4_32x32", 61, 71, 3, 32, 32, 4)
     gen_unet("unet_dim3_36x40", 62, 72, 2, 36, 40, 3, p=5)
+    gen_resnet("resnet_h4_20x24", 81, 91, 2, 20, 24, 4, 1)
     gen_adam("adam_small_64x64", 26, 36, 2, 8, 2, 64, 64, nsteps=3, lr=1e-3, gain=8.0)
     gen_mseloss("mseloss", 41)
 

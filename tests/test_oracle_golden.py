@@ -182,3 +182,16 @@ def test_unet_forward_train_and_eval(golden_dir, name):
         assert O.rel_nmse(v, g[f"after::{k}"]) < 1e-10, k
     ev = CO.unet_forward(P, b64["inputs"], b64["case_params"], b64["mask"], None, training=False)
     assert O.rel_nmse(ev["preds"], g["preds_eval"]) < 1e-10
+
+
+def test_resnet_eval_forward(golden_dir):
+    from oracle import conv_oracle as CO
+    g = np.load(golden_dir / "resnet_h4_20x24.npz")
+    seed, bseed, B, H, W, hidden, nblocks, p, steps = [int(v) for v in g["meta"]]
+    P = {k[len("sd::"):]: g[k].astype(np.float64) for k in g.files if k.startswith("sd::")}
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    batch["mask"][:, :, -1, :] = 0
+    b64 = {k: v.astype(np.float64) for k, v in batch.items()}
+    out = CO.resnet_forward(P, b64["inputs"], b64["case_params"], b64["mask"], b64["label"])
+    assert O.rel_nmse(out["preds"], g["preds"]) < 1e-10
+    assert abs(out["loss"]["nmse"] - float(g["loss_nmse"])) <= 1e-5 * float(g["loss_nmse"])
