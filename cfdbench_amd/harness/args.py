@@ -29,7 +29,7 @@ _FLAGS: Dict[str, Any] = dict(
     ffn_depth=8, ffn_width=100, autoffn_depth=8, autoffn_width=200, deeponet_width=100, branch_depth=8, trunk_depth=8,
     act_fn="relu", act_scale_invariant=1, act_on_output=0, autoedeeponet_width=100, autoedeeponet_depth=8,
     autoedeeponet_act_fn="relu", fno_depth=4, fno_hidden_dim=32, fno_modes_x=12, fno_modes_y=12, unet_dim=12,
-    unet_insert_case_params_at="input", resnet_depth=4, resnet_hidden_chan=16, resnet_kernel_size=7,
+    unet_insert_case_params_at="input", resnet_depth=4, resnet_hidden_chan=16, resnet_kernel_size=7, resnet_padding=3,
     # missing in the reference's Args but read by its trainers (train_auto.py:357, :188-189)
     lr_step_size=20, lr_gamma=0.9,
     # additions of this harness

@@ -44,7 +44,7 @@ def init_model(args) -> AutoCfdModel:
     if args.model == "resnet":  # autoregressive.py:93-104
         return ResNet(in_chan=args.in_chan, out_chan=args.out_chan, n_case_params=n_case_params, loss_fn=loss_fn,
                       hidden_chan=args.resnet_hidden_chan, num_blocks=args.resnet_depth,
-                      kernel_size=args.resnet_kernel_size, padding=args.resnet_kernel_size // 2)
+                      kernel_size=args.resnet_kernel_size, padding=args.resnet_padding)
     if args.model in ("auto_ffn", "auto_edeeponet", "auto_deeponet_cnn"):
         raise NotImplementedError(f"cfdbench_amd: model {args.model!r} has no MI355X kernels yet (DESIGN.md section 7)")
     raise ValueError(f"Invalid model name: {args.model}")
