@@ -86,6 +86,28 @@ class GradSync:
         return 1.0 / self.world
 
 
+def sync_gradients(params: Sequence[torch.nn.Parameter], group=None) -> None:
+    """Data-parallel gradient averaging for the autograd training path (any model): every ``.grad`` is packed into ONE
+    flat fp32 buffer (complex gradients as (re, im) pairs), summed over the ranks in a single all-reduce (RCCL over xGMI
+    on GPUs, gloo in the CPU tests), scaled by 1/world and scattered back.  Same semantics as DistributedDataParallel."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    grads = [torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.mul_(1.0 / world)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [start, stop) of the items owned by ``rank`` (sizes differ by at most one)."""
     base, rem = divmod(n, world)

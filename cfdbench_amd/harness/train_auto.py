@@ -27,7 +27,7 @@ from torch import Tensor
 from torch.optim import Adam, lr_scheduler
 from torch.utils.data import DataLoader, Subset
 
-from ..engine import FnoTrainEngine, shard_range
+from ..engine import FnoTrainEngine, shard_range, sync_gradients
 from ..models.base_model import AutoCfdModel
 from ..models.fno.fno2d import Fno2d
 from .args import Args
@@ -151,6 +151,8 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
                     plot(batch["inputs"][0][0], batch["label"][0][0], outputs["preds"][0][0].detach(), Path("example.png"))
                 loss = outputs["loss"]
                 loss["nmse"].backward()  # train_auto.py:255
+                if world > 1:
+                    sync_gradients(list(model.parameters()))  # one flat all-reduce, DDP semantics
                 optimizer.step()
                 optimizer.zero_grad()
                 ep_train_losses.append(loss["nmse"].item())  # train_auto.py:260

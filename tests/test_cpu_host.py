@@ -96,6 +96,50 @@ def test_data_parallel_gradient_exchange_gloo_world2():
     assert not np.allclose(res[0][2], res[1][2])  # the ranks really had different shards
 
 
+def _sync_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cfdbench_amd.engine import sync_gradients
+        g = torch.Generator().manual_seed(10 + rank)
+        params = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(2, 2, dtype=torch.cfloat)),
+                  torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(7))]
+        params[0].grad = torch.randn(3, 4, generator=g)
+        params[1].grad = torch.complex(torch.randn(2, 2, generator=g), torch.randn(2, 2, generator=g))
+        params[2].grad = torch.randn(5, generator=g)  # params[3] has no gradient (unused bn1/bn2-style parameter)
+        before = [p.grad.clone() for p in params[:3]]
+        sync_gradients(params)
+        q.put((rank, [torch.view_as_real(b).numpy() if b.is_complex() else b.numpy() for b in before],
+               [torch.view_as_real(p.grad).numpy() if p.grad.is_complex() else p.grad.numpy() for p in params[:3]],
+               params[3].grad is None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_autograd_path_gradient_averaging_gloo_world2():
+    """sync_gradients (the DP exchange of the autograd training path, any model) == mean of the per-rank gradients."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    for i in range(3):
+        mean = (res[0][1][i] + res[1][1][i]) / 2
+        for r in res:
+            assert np.allclose(r[2][i], mean, rtol=1e-6, atol=1e-7)
+    assert res[0][3] and res[1][3]
+
+
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     from cfdbench_amd import _lib
     from cfdbench_amd._capi import CfdError
