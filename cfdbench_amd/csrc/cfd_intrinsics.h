@@ -37,6 +37,9 @@ __device__ __forceinline__ int cfd_opaque(int x) {
 // Wave-uniform value -> SGPR (lets the compiler use scalar loads / scalar operands for per-wave indices).
 __device__ __forceinline__ int cfd_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
+// dynamic LDS (size given at launch)
+#define CFD_DYN_SHARED(T, name) extern __shared__ T name[]
+
 // Scheduling fence: the compiler may not move any instruction across it (keeps a software-pipelined load where it
 // was written instead of sinking it next to its first use).
 __device__ __forceinline__ void cfd_sched_fence() { __builtin_amdgcn_sched_barrier(0); }

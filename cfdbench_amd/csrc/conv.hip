@@ -92,100 +92,167 @@ __global__ __launch_bounds__(64 * CV_WAVES) void k_conv_gather(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------------
-// LDS-tiled 3x3 variant for wide images (W >= 32): workgroup = 8 rows x 32 columns of the destination grid, every
-// output channel.  The source halo tile streams through LDS in chunks of 16 channels (each input element is fetched
-// from global memory once instead of nine times, the 3x3 gather becomes ds_read_b32), every wave owns 4 pixel tiles
-// so one weight fragment (global / L1) feeds 4 MFMAs.
+// LDS-tiled variant (3x3 and 7x7): both MFMA operands come from LDS.
+// Workgroup = 256 destination pixels x up to 64 output channels: NB images x TH rows x TW columns with
+// NB*TH*TW == 256 (64x64: 1x8x32; 16x16: 1x16x16; 8x8: 4x8x8; 4x4: 16x4x4), so small images of the deep U-Net levels
+// still fill the MFMA N dimension.  The source halo tiles stream through LDS in chunks of CC channels (each input
+// element leaves global memory once instead of k*k times; the k x k gather becomes ds_read_b32 through a per-chunk
+// offset table), the chunk's weights are staged in MFMA fragment order, and every wave owns 4 pixel tiles so one
+// weight fragment feeds 4 MFMAs.  Output channels beyond 64 are split over blockIdx.y.
 // ------------------------------------------------------------------------------------------------------
-#define CT_TH 8
-#define CT_TW 32
-#define CT_CC 16                 // channels per LDS chunk
-#define CT_LW 36                 // LDS row stride (32 + 2 halo + 2 pad)
-#define CT_LH (CT_TH + 2)
-template <int MT, bool EXT>
-__global__ __launch_bounds__(256) void k_conv3_tile(const float* __restrict__ src, const float* __restrict__ w,
-                                                    const float* __restrict__ bias, float* __restrict__ dst, ConvGeom g) {
-    __shared__ float s_in[CT_CC * CT_LH * CT_LW];
-    __shared__ int s_koff[CT_CC * 9];
+struct ConvTile {
+    int TW, TH, NB;       // tile shape, NB*TH*TW == 256
+    int tiles_x, tiles_y; // tiles per image
+    int LW, LH;           // LDS halo tile: (TH + ks - 1) x (TW + ks - 1), row stride LW
+};
+
+template <int KS, int MT, int CC, bool EXT>
+__global__ __launch_bounds__(256) void k_conv_tile(const float* __restrict__ src, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ dst, ConvGeom g,
+                                                   ConvTile t) {
+    constexpr int KK = KS * KS, PAD = KS / 2;
+    constexpr int KSTEPS = (CC * KK + 3) / 4;               // k-steps of one chunk
+    CFD_DYN_SHARED(float, s_dyn);                           // [halo tiles NB*CC*LH*LW | weight fragments KSTEPS*MT*64]
+    __shared__ int s_koff[KSTEPS * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
     const int Cs = EXT ? g.Co : g.Ci, Cm = EXT ? g.Ci : g.Co;
-    const int K = Cs * 9;
-    const int Hd = EXT ? g.H + 2 : g.H, Wd = EXT ? g.W + 2 : g.W;
+    const int Hd = EXT ? g.H + 2 * PAD : g.H, Wd = EXT ? g.W + 2 * PAD : g.W;
     const int HWd = Hd * Wd, HWs = g.H * g.W;
-    const int b = blockIdx.z, ty0 = blockIdx.y * CT_TH, tx0 = blockIdx.x * CT_TW;
-    // LDS offset of (channel, ky, kx) relative to a pixel's own tile position.  The staged tile starts one pixel up/left
-    // of the destination tile in the forward pass (pos = p + k - 1) and two in the transposed pass (pos = p - k).
-    for (int i = threadIdx.x; i < CT_CC * 9; i += blockDim.x) {
-        const int c = i / 9, r = i - 9 * c, ky = r / 3, kx = r - 3 * ky;
-        s_koff[i] = c * (CT_LH * CT_LW) + (EXT ? (2 - ky) * CT_LW + (2 - kx) : ky * CT_LW + kx);
+    const int halo = t.LH * t.LW;
+    float* s_in = s_dyn;
+    float* s_w = s_dyn + t.NB * CC * halo;
+    const int mbase = blockIdx.y * 16 * MT;
+    // tile position: blockIdx.x enumerates (image group, tile row, tile column)
+    const int tpi = t.tiles_x * t.tiles_y;
+    const int bg = blockIdx.x / tpi, tr = blockIdx.x - bg * tpi;
+    const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
+    const int b0 = bg * t.NB;
+    // LDS offset of (channel-in-chunk, ky, kx) relative to a pixel's own position in its halo tile
+    for (int i = threadIdx.x; i < KSTEPS * 4; i += blockDim.x) {
+        const int c = i / KK, r = i - KK * c, ky = r / KS, kx = r - KS * ky;
+        s_koff[i] = i < CC * KK ? c * halo + (EXT ? (2 * PAD - ky) * t.LW + (2 * PAD - kx) : ky * t.LW + kx) : 0;
     }
-    // this wave's 4 pixel tiles: rows 2*wave + (t >> 1), columns 16 * (t & 1) + n
-    int poff[4];
+    // this wave's 4 pixel tiles: tile pixel pi = 64*wave + 16*tt + n -> (image bi, row, column)
+    int poff[4], pb[4], py[4], px[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) poff[t] = (2 * wave + (t >> 1)) * CT_LW + 16 * (t & 1) + n;
+    for (int tt = 0; tt < 4; ++tt) {
+        const int pi = 64 * wave + 16 * tt + n;
+        const int bi = pi / (t.TH * t.TW), rem = pi - bi * (t.TH * t.TW);
+        const int r = rem / t.TW, c = rem - r * t.TW;
+        pb[tt] = b0 + bi; py[tt] = ty0 + r; px[tt] = tx0 + c;
+        poff[tt] = bi * CC * halo + r * t.LW + c;
+    }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[mt][t] = zero;
-    const float* sb = src + (size_t)b * Cs * HWs;
-    const int oy = EXT ? ty0 - 2 : ty0 - 1, ox = EXT ? tx0 - 2 : tx0 - 1;  // source coords of the staged tile origin
-    for (int c0 = 0; c0 < Cs; c0 += CT_CC) {
+        for (int tt = 0; tt < 4; ++tt) acc[mt][tt] = zero;
+    const int oy = EXT ? ty0 - 2 * PAD : ty0 - PAD, ox = EXT ? tx0 - 2 * PAD : tx0 - PAD;  // source coords of the halo origin
+    const int hw_used = t.TW + KS - 1;
+    for (int c0 = 0; c0 < Cs; c0 += CC) {
         __syncthreads();  // previous chunk fully consumed (first pass: s_koff written)
-        for (int i = threadIdx.x; i < CT_CC * CT_LH * (CT_TW + 2); i += blockDim.x) {
-            const int c = i / (CT_LH * (CT_TW + 2)), r = i - c * (CT_LH * (CT_TW + 2));
-            const int ly = r / (CT_TW + 2), lx = r - ly * (CT_TW + 2);
+        // halo tiles of NB images x CC channels
+        for (int i = threadIdx.x; i < t.NB * CC * t.LH * hw_used; i += blockDim.x) {
+            const int lx = i % hw_used, r1 = i / hw_used, ly = r1 % t.LH, r2 = r1 / t.LH, c = r2 % CC, bi = r2 / CC;
             int y = oy + ly, x = ox + lx;
             float v = 0.f;
-            if (c0 + c < Cs) {
+            if (c0 + c < Cs && b0 + bi < g.B) {
+                const float* sb = src + ((size_t)(b0 + bi) * Cs + c0 + c) * HWs;
                 if constexpr (EXT) {
-                    if (y >= 0 && y < g.H && x >= 0 && x < g.W) v = sb[(size_t)(c0 + c) * HWs + y * g.W + x];
+                    if (y >= 0 && y < g.H && x >= 0 && x < g.W) v = sb[y * g.W + x];
                 } else {
                     y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
                     x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
-                    v = sb[(size_t)(c0 + c) * HWs + y * g.W + x];
+                    v = sb[y * g.W + x];
                 }
             }
-            s_in[c * (CT_LH * CT_LW) + ly * CT_LW + lx] = v;
+            s_in[(bi * CC + c) * halo + ly * t.LW + lx] = v;
+        }
+        // weight fragments of this chunk: frag[kstep][mt][lane (q, n)] = A[m = mbase + 16 mt + n][k = 4 kstep + q]
+        for (int i = threadIdx.x; i < KSTEPS * MT * 64; i += blockDim.x) {
+            const int ln = i & 63, mt = (i >> 6) % MT, ks_ = i / (64 * MT);
+            const int m = mbase + 16 * mt + (ln & 15), kl = 4 * ks_ + (ln >> 4);
+            const int c = kl / KK, r = kl - c * KK;
+            float v = 0.f;
+            if (m < Cm && kl < CC * KK && c0 + c < Cs)
+                v = EXT ? w[((size_t)(c0 + c) * g.Ci + m) * KK + r] : w[((size_t)m * Cs + c0 + c) * KK + r];
+            s_w[i] = v;
         }
         __syncthreads();
-        const int kc = (Cs - c0 < CT_CC ? Cs - c0 : CT_CC) * 9;  // k extent of this chunk
-        for (int k0 = 0; k0 < kc; k0 += 4) {
-            const int kl = k0 + q;                 // k within the chunk
-            const bool kv = kl < kc;
-            const int ko = s_koff[kv ? kl : 0];
-            float bv[4];
+#pragma unroll 2
+        for (int ks_ = 0; ks_ < KSTEPS; ++ks_) {
+            const int ko = s_koff[4 * ks_ + q];
+            float bv[4], av[MT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bv[t] = kv ? s_in[ko + poff[t]] : 0.f;
-            const int kg = c0 * 9 + kl;            // global k = (channel, ky, kx)
+            for (int tt = 0; tt < 4; ++tt) bv[tt] = s_in[ko + poff[tt]];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int m = 16 * mt + n;
-                float av = 0.f;
-                if (kv && m < Cm) {
-                    if constexpr (EXT) { const int c = kg / 9, r = kg - 9 * c; av = w[((size_t)c * g.Ci + m) * 9 + r]; }
-                    else av = w[(size_t)m * K + kg];
-                }
+            for (int mt = 0; mt < MT; ++mt) av[mt] = s_w[(ks_ * MT + mt) * 64 + lane];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[mt][t] = cfd_mfma16x16x4(av, bv[t], acc[mt][t]);
-            }
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[mt][tt] = cfd_mfma16x16x4(av[mt], bv[tt], acc[mt][tt]);
         }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int y = ty0 + 2 * wave + (t >> 1), x = tx0 + 16 * (t & 1) + n;
-        if (y < Hd && x < Wd) {
+    for (int tt = 0; tt < 4; ++tt) {
+        if (pb[tt] < g.B && py[tt] < Hd && px[tt] < Wd) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = 16 * mt + 4 * q + r;
-                    if (m < Cm) dst[((size_t)b * Cm + m) * HWd + y * Wd + x] = acc[mt][t][r] + (bias ? bias[m] : 0.f);
+                    const int m = mbase + 16 * mt + 4 * q + r;
+                    if (m < Cm) dst[((size_t)pb[tt] * Cm + m) * HWd + py[tt] * Wd + px[tt]] = acc[mt][tt][r] + (bias ? bias[m] : 0.f);
                 }
         }
     }
+}
+
+template <int KS, int CC, bool EXT>
+static int launch_conv_tile(const float* src, const float* w, const float* bias, float* dst, const ConvGeom& g,
+                            hipStream_t st, const char* what) {
+    constexpr int PAD = KS / 2, KK = KS * KS, KSTEPS = (CC * KK + 3) / 4;
+    const int Hd = EXT ? g.H + 2 * PAD : g.H, Wd = EXT ? g.W + 2 * PAD : g.W;
+    const int Cm = EXT ? g.Ci : g.Co, MTall = (Cm + 15) / 16;
+    ConvTile t{};
+    t.TW = Wd >= 32 ? 32 : (Wd > 8 ? 16 : (Wd > 4 ? 8 : 4));
+    int rows = 256 / t.TW;                       // rows available per workgroup
+    t.TH = Hd < rows ? Hd : rows;
+    int th = 1;
+    while (th < t.TH) th <<= 1;                  // power of two so that NB*TH*TW == 256 exactly
+    t.TH = th > rows ? rows : th;
+    t.NB = 256 / (t.TH * t.TW);
+    t.tiles_x = (Wd + t.TW - 1) / t.TW;
+    t.tiles_y = (Hd + t.TH - 1) / t.TH;
+    t.LH = t.TH + KS - 1;
+    t.LW = t.TW + KS - 1 + 1;                    // +1: odd-ish stride staggers LDS banks between rows
+    // output channels per workgroup: as many as 64, fewer while the grid would leave CUs idle; layers with too few
+    // pixel tiles even then (deep U-Net levels at small batch) go to the gather kernel, which parallelises finer
+    const long ptiles = (long)((g.B + t.NB - 1) / t.NB) * t.tiles_x * t.tiles_y;
+    int mtw = MTall >= 4 ? 4 : MTall;
+    while (mtw > 1 && ptiles * ((MTall + mtw - 1) / mtw) < 512) --mtw;
+    const int mgroups = (MTall + mtw - 1) / mtw;
+    if (ptiles * mgroups < 256) return CFD_ERR_UNSUPPORTED;
+    const size_t lds = ((size_t)t.NB * CC * t.LH * t.LW + (size_t)KSTEPS * mtw * 64) * sizeof(float);
+    if (lds > 120 * 1024) return CFD_ERR_UNSUPPORTED;  // caller falls back to the gather kernel
+    const dim3 grid((unsigned)ptiles, mgroups);
+#define CT_L(M_)                                                                                                      \
+    do {                                                                                                              \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)k_conv_tile<KS, M_, CC, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        hipLaunchKernelGGL((k_conv_tile<KS, M_, CC, EXT>), grid, dim3(256), lds, st, src, w, bias, dst, g, t);        \
+    } while (0)
+    if (mtw == 1) CT_L(1);
+    else if (mtw == 2) CT_L(2);
+    else if (mtw == 3) CT_L(3);
+    else CT_L(4);
+#undef CT_L
+    CFD_LAUNCH_CHECK(what);
+    return CFD_OK;
 }
 
 template <bool EXT>
@@ -198,14 +265,12 @@ static int launch_conv_gather(const float* src, const float* w, const float* bia
     long blocks = (total + CV_WAVES - 1) / CV_WAVES;
     if (blocks > 4096) blocks = 4096;
     const int Cm = EXT ? g.Ci : g.Co, MT = (Cm + 15) / 16;
-    if (g.ks == 3 && g.W >= 32 && MT <= 3) {  // wide images: LDS-tiled kernel (64 accumulator registers at MT = 3... 4 tiles)
-        const int Hd = EXT ? g.H + 2 : g.H, Wd = EXT ? g.W + 2 : g.W;
-        const dim3 grid((Wd + CT_TW - 1) / CT_TW, (Hd + CT_TH - 1) / CT_TH, g.B);
-        if (MT == 1) hipLaunchKernelGGL((k_conv3_tile<1, EXT>), grid, dim3(256), 0, st, src, w, bias, dst, g);
-        else if (MT == 2) hipLaunchKernelGGL((k_conv3_tile<2, EXT>), grid, dim3(256), 0, st, src, w, bias, dst, g);
-        else hipLaunchKernelGGL((k_conv3_tile<3, EXT>), grid, dim3(256), 0, st, src, w, bias, dst, g);
-        CFD_LAUNCH_CHECK(what);
-        return CFD_OK;
+    if (g.ks == 3) {
+        const int rc = launch_conv_tile<3, 16, EXT>(src, w, bias, dst, g, st, what);
+        if (rc != CFD_ERR_UNSUPPORTED) return rc;
+    } else if (g.ks == 7) {
+        const int rc = launch_conv_tile<7, 4, EXT>(src, w, bias, dst, g, st, what);
+        if (rc != CFD_ERR_UNSUPPORTED) return rc;
     }
     // Few pixels (deep, wide layers): split the output channels over blockIdx.y so that the grid still fills the chip;
     // many pixels: one wave keeps every output channel (the gathered data operand is then loaded once).

@@ -48,6 +48,9 @@ inline void cfd_sched_fence() {}
 
 inline int cfd_uniform(int x) { return x; }
 
+// dynamic LDS: the emulator's launch() sizes one buffer per launch
+#define CFD_DYN_SHARED(T, name) T* name = reinterpret_cast<T*>(cfd_emul::g_dyn_shared.data())
+
 inline float cfd_erff(float x) { return erff(x); }
 inline float cfd_expf(float x) { return expf(x); }
 inline float cfd_rcpf(float x) { return 1.0f / x; }

@@ -46,6 +46,8 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 
 struct dim3 {
     unsigned x, y, z;
@@ -76,6 +78,7 @@ struct WaveCtx {
 };
 inline std::vector<WaveCtx*> g_waves;
 inline pthread_barrier_t g_block_bar;
+inline std::vector<char> g_dyn_shared;  // dynamic LDS of the running launch (extern __shared__)
 
 inline WaveCtx& wave() { return *g_waves[t_lin >> 6]; }
 inline int lane() { return t_lin & 63; }
@@ -86,8 +89,9 @@ template <typename F, typename Tup, size_t... I>
 void call(F f, Tup& t, std::index_sequence<I...>) { f(std::get<I>(t)...); }
 
 template <typename... KArgs, typename... Args>
-void launch(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {
+void launch(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
     std::tuple<KArgs...> targs(static_cast<KArgs>(args)...);
+    g_dyn_shared.assign(shmem + 16, 0);
     g_blockDim = {block.x, block.y, block.z};
     g_gridDim = {grid.x, grid.y, grid.z};
     int nthreads = block.x * block.y * block.z;
