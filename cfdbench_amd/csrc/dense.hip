@@ -362,3 +362,196 @@ extern "C" int cfd_deeponet_inner_bwd(const float* gpreds, const float* branch, 
     }
     return CFD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// NormAct  (src/models/act_fn.py:21-47): per sample (everything but dim 0), x^ = (x - mean) / std (unbiased std, no eps),
+// y = act(x^) * std + mean.  One workgroup per sample; statistics in two passes (mean, then centred sum of squares).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* s_r) {
+    v = cfd_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_r[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s_r[0] + s_r[1]) + (s_r[2] + s_r[3]);
+}
+
+__global__ __launch_bounds__(256) void k_normact_fwd(const float* __restrict__ x, float* __restrict__ y,
+                                                     float* __restrict__ stats, long L, int act) {
+    __shared__ float s_r[4];
+    const float* xs = x + (size_t)blockIdx.x * L;
+    float* ys = y + (size_t)blockIdx.x * L;
+    float a = 0.f;
+    for (long i = threadIdx.x; i < L; i += blockDim.x) a += xs[i];
+    const float mean = block_sum_256(a, s_r) / (float)L;
+    float q = 0.f;
+    for (long i = threadIdx.x; i < L; i += blockDim.x) { const float d = xs[i] - mean; q = fmaf(d, d, q); }
+    const float sd = sqrtf(block_sum_256(q, s_r) / (float)(L - 1));
+    const float inv = 1.0f / sd;
+    for (long i = threadIdx.x; i < L; i += blockDim.x) ys[i] = fmaf(cfd_act((xs[i] - mean) * inv, act), sd, mean);
+    if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = sd; }
+}
+
+// gx_i = gu_i / sd + Gmu / L + Gsd * u_i / (L - 1),  u = x^, gu = g * sd * act'(u),
+// Gmu = sum g - sum gu / sd,  Gsd = sum g * act(u) - sum gu * u / sd
+__global__ __launch_bounds__(256) void k_normact_bwd(const float* __restrict__ x, const float* __restrict__ g,
+                                                     const float* __restrict__ stats, float* __restrict__ gx, long L, int act) {
+    __shared__ float s_r[4];
+    const float* xs = x + (size_t)blockIdx.x * L;
+    const float* gs = g + (size_t)blockIdx.x * L;
+    float* os = gx + (size_t)blockIdx.x * L;
+    const float mean = stats[2 * blockIdx.x], sd = stats[2 * blockIdx.x + 1], inv = 1.0f / sd;
+    float s_g = 0.f, s_gu = 0.f, s_ga = 0.f, s_guu = 0.f;
+    for (long i = threadIdx.x; i < L; i += blockDim.x) {
+        const float u = (xs[i] - mean) * inv, gi = gs[i];
+        const float av = cfd_act(u, act);
+        const float gu = gi * sd * cfd_act_grad(av, u, act);
+        s_g += gi; s_gu += gu; s_ga = fmaf(gi, av, s_ga); s_guu = fmaf(gu, u, s_guu);
+    }
+    s_g = block_sum_256(s_g, s_r);
+    s_gu = block_sum_256(s_gu, s_r);
+    s_ga = block_sum_256(s_ga, s_r);
+    s_guu = block_sum_256(s_guu, s_r);
+    const float Gmu = s_g - s_gu * inv, Gsd = s_ga - s_guu * inv;
+    const float c0 = Gmu / (float)L, c1 = Gsd / (float)(L - 1);
+    for (long i = threadIdx.x; i < L; i += blockDim.x) {
+        const float u = (xs[i] - mean) * inv;
+        const float gu = gs[i] * sd * cfd_act_grad(cfd_act(u, act), u, act);
+        os[i] = fmaf(gu, inv, fmaf(c1, u, c0));
+    }
+}
+
+// y (S,L) = NormAct(x); stats (S,2) receives (mean, std) for the backward pass.  act as in cfd_linear_fwd (1..4).
+extern "C" int cfd_normact_fwd(const float* x, float* y, float* stats, int S, long L, int act, void* stream) {
+    CFD_REQUIRE(x && y && stats, CFD_ERR_INVALID_ARG, "cfd_normact_fwd: NULL pointer");
+    CFD_REQUIRE(S >= 0 && L >= 2 && act >= 1 && act <= 4, CFD_ERR_INVALID_ARG, "cfd_normact_fwd: bad sizes / activation");
+    if (S == 0) return CFD_OK;
+    CFD_PROF("k_normact_fwd", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_normact_fwd, dim3(S), dim3(256), 0, (hipStream_t)stream, x, y, stats, L, act);
+    CFD_LAUNCH_CHECK("cfd_normact_fwd");
+    return CFD_OK;
+}
+
+extern "C" int cfd_normact_bwd(const float* x, const float* gy, const float* stats, float* gx, int S, long L, int act,
+                               void* stream) {
+    CFD_REQUIRE(x && gy && stats && gx, CFD_ERR_INVALID_ARG, "cfd_normact_bwd: NULL pointer");
+    CFD_REQUIRE(S >= 0 && L >= 2 && act >= 1 && act <= 4, CFD_ERR_INVALID_ARG, "cfd_normact_bwd: bad sizes / activation");
+    if (S == 0) return CFD_OK;
+    CFD_PROF("k_normact_bwd", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_normact_bwd, dim3(S), dim3(256), 0, (hipStream_t)stream, x, gy, stats, gx, L, act);
+    CFD_LAUNCH_CHECK("cfd_normact_bwd");
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// non-autoregressive DeepONet pieces (src/models/deeponet.py:184-205)
+//   trunk input   x[b,k,p] = ft[b,p] + fxy[k,p]                       (:188-192)
+//   output        preds[b,k] = sum_p branch[b,p] * trunk[b,k,p] + bias (:204-205)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bcast_add(const float* __restrict__ ft, const float* __restrict__ fxy,
+                                                   float* __restrict__ out, int B, int K, int P) {
+    const long total = (long)B * K * P;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(e % P), k = (int)((e / P) % K), b = (int)(e / ((long)P * K));
+        out[e] = ft[(size_t)b * P + p] + fxy[(size_t)k * P + p];
+    }
+}
+
+// gft[b,p] = sum_k g[b,k,p] (which = 0) or gfxy[k,p] = sum_b g[b,k,p] (which = 1): thread per output, coalesced along p
+__global__ __launch_bounds__(256) void k_bcast_add_bwd(const float* __restrict__ g, float* __restrict__ out, int B, int K, int P,
+                                                       int which) {
+    const long total = which == 0 ? (long)B * P : (long)K * P;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int p = (int)(e % P), o = (int)(e / P);
+    float s = 0.f;
+    if (which == 0) for (int k = 0; k < K; ++k) s += g[((size_t)o * K + k) * P + p];
+    else for (int b = 0; b < B; ++b) s += g[((size_t)b * K + o) * P + p];
+    out[e] = s;
+}
+
+extern "C" int cfd_bcast_add_fwd(const float* ft, const float* fxy, float* out, int B, int K, int P, void* stream) {
+    CFD_REQUIRE(ft && fxy && out && B >= 0 && K >= 0 && P >= 1, CFD_ERR_INVALID_ARG, "cfd_bcast_add_fwd: bad arguments");
+    const long total = (long)B * K * P;
+    if (total == 0) return CFD_OK;
+    long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(k_bcast_add, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, ft, fxy,
+                       out, B, K, P);
+    CFD_LAUNCH_CHECK("cfd_bcast_add_fwd");
+    return CFD_OK;
+}
+
+extern "C" int cfd_bcast_add_bwd(const float* g, float* gft, float* gfxy, int B, int K, int P, void* stream) {
+    CFD_REQUIRE(g && B >= 1 && K >= 1 && P >= 1, CFD_ERR_INVALID_ARG, "cfd_bcast_add_bwd: bad arguments");
+    if (gft) hipLaunchKernelGGL(k_bcast_add_bwd, dim3((unsigned)(((long)B * P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, gft, B, K, P, 0);
+    if (gfxy) hipLaunchKernelGGL(k_bcast_add_bwd, dim3((unsigned)(((long)K * P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, gfxy, B, K, P, 1);
+    CFD_LAUNCH_CHECK("cfd_bcast_add_bwd");
+    return CFD_OK;
+}
+
+// one wave per (b, k) row
+__global__ __launch_bounds__(256) void k_rowdot(const float* __restrict__ branch, const float* __restrict__ trunk,
+                                                const float* __restrict__ bias, float* __restrict__ preds, long rows, int K, int P) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* br = branch + (size_t)(row / K) * P;
+    const float* tr = trunk + (size_t)row * P;
+    float s = 0.f;
+    for (int p = lane; p < P; p += 64) s = fmaf(br[p], tr[p], s);
+    s = cfd_wave_sum(s);
+    if (lane == 0) preds[row] = s + bias[0];
+}
+
+// gtrunk[b,k,p] = g[b,k] * branch[b,p]
+__global__ __launch_bounds__(256) void k_rowdot_bwd_trunk(const float* __restrict__ g, const float* __restrict__ branch,
+                                                          float* __restrict__ gtrunk, int B, int K, int P) {
+    const long total = (long)B * K * P;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(e % P);
+        const long row = e / P;
+        gtrunk[e] = g[row] * branch[(size_t)(row / K) * P + p];
+    }
+}
+
+// gbranch[b,p] = sum_k g[b,k] * trunk[b,k,p]: thread per (b,p), coalesced along p
+__global__ __launch_bounds__(256) void k_rowdot_bwd_branch(const float* __restrict__ g, const float* __restrict__ trunk,
+                                                           float* __restrict__ gbranch, int B, int K, int P) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)B * P) return;
+    const int p = (int)(e % P), b = (int)(e / P);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s = fmaf(g[(size_t)b * K + k], trunk[((size_t)b * K + k) * P + p], s);
+    gbranch[e] = s;
+}
+
+// preds (B,K) = per-sample dot of branch (B,P) with trunk (B,K,P), + bias[0]
+extern "C" int cfd_rowdot_fwd(const float* branch, const float* trunk, const float* bias, float* preds, int B, int K, int P,
+                              void* stream) {
+    CFD_REQUIRE(branch && trunk && bias && preds && B >= 0 && K >= 0 && P >= 1, CFD_ERR_INVALID_ARG, "cfd_rowdot_fwd: bad arguments");
+    const long rows = (long)B * K;
+    if (rows == 0) return CFD_OK;
+    hipLaunchKernelGGL(k_rowdot, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, branch, trunk, bias, preds, rows, K, P);
+    CFD_LAUNCH_CHECK("cfd_rowdot_fwd");
+    return CFD_OK;
+}
+
+// gbranch (B,P), gtrunk (B,K,P), gbias (1) from g (B,K); ws: CFD_SUM_BLOCKS floats (cfd_rowdot_bwd_workspace_bytes)
+extern "C" size_t cfd_rowdot_bwd_workspace_bytes(void) { return CFD_SUM_BLOCKS * sizeof(float); }
+
+extern "C" int cfd_rowdot_bwd(const float* g, const float* branch, const float* trunk, float* gbranch, float* gtrunk,
+                              float* gbias, void* ws, int B, int K, int P, void* stream) {
+    CFD_REQUIRE(g && branch && trunk && B >= 1 && K >= 1 && P >= 1, CFD_ERR_INVALID_ARG, "cfd_rowdot_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (gbranch) hipLaunchKernelGGL(k_rowdot_bwd_branch, dim3((unsigned)(((long)B * P + 255) / 256)), dim3(256), 0, st, g, trunk, gbranch, B, K, P);
+    if (gtrunk) {
+        long blocks = ((long)B * K * P + 255) / 256;
+        hipLaunchKernelGGL(k_rowdot_bwd_trunk, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, g, branch, gtrunk, B, K, P);
+    }
+    if (gbias) {
+        CFD_REQUIRE(ws, CFD_ERR_WORKSPACE, "cfd_rowdot_bwd: workspace needed for the bias gradient");
+        hipLaunchKernelGGL(k_sum_all, dim3(CFD_SUM_BLOCKS), dim3(256), 0, st, g, (size_t)B * K, (float*)ws);
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64), 0, st, (const float*)ws, CFD_SUM_BLOCKS, gbias);
+    }
+    CFD_LAUNCH_CHECK("cfd_rowdot_bwd");
+    return CFD_OK;
+}

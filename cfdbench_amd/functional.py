@@ -584,3 +584,82 @@ class AddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g: Tensor):
         return g, g
+
+
+# ----------------------------------------------------------------------------------------------------
+# NormAct and the non-autoregressive DeepONet pieces  (src/models/act_fn.py:21-47, src/models/deeponet.py:184-205)
+# ----------------------------------------------------------------------------------------------------
+class NormActFn(torch.autograd.Function):
+    """Per-sample (all dims but the first) normalise -> activation -> de-normalise."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, act: int):
+        _require_cuda(x)
+        x = _f32c(x)
+        S = x.shape[0]
+        L = x[0].numel()
+        y = torch.empty_like(x)
+        stats = torch.empty((S, 2), dtype=torch.float32, device=x.device)
+        _lib.api().call("cfd_normact_fwd", _ptr(x), _ptr(y), _ptr(stats), S, L, act, _stream())
+        ctx.save_for_backward(x, stats)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x, stats = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        _lib.api().call("cfd_normact_bwd", _ptr(x), _ptr(_f32c(gy)), _ptr(stats), _ptr(gx), x.shape[0], x[0].numel(), ctx.act,
+                        _stream())
+        return gx, None
+
+
+class BcastAddFn(torch.autograd.Function):
+    """(b,p) + (k,p) -> (b,k,p)  (deeponet.py:190-192)."""
+
+    @staticmethod
+    def forward(ctx, ft: Tensor, fxy: Tensor):
+        _require_cuda(ft, fxy)
+        ft, fxy = _f32c(ft), _f32c(fxy)
+        B, P = ft.shape
+        K = fxy.shape[0]
+        out = torch.empty((B, K, P), dtype=torch.float32, device=ft.device)
+        _lib.api().call("cfd_bcast_add_fwd", _ptr(ft), _ptr(fxy), _ptr(out), B, K, P, _stream())
+        ctx.dims = (B, K, P)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        B, K, P = ctx.dims
+        g = _f32c(g)
+        gft = torch.empty((B, P), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+        gfxy = torch.empty((K, P), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
+        _lib.api().call("cfd_bcast_add_bwd", _ptr(g), _ptr(gft), _ptr(gfxy), B, K, P, _stream())
+        return gft, gfxy
+
+
+class RowDotFn(torch.autograd.Function):
+    """preds[b,k] = <branch[b], trunk[b,k]> + bias  (deeponet.py:204-205)."""
+
+    @staticmethod
+    def forward(ctx, branch: Tensor, trunk: Tensor, bias: Tensor):
+        _require_cuda(branch, trunk, bias)
+        branch, trunk, bias = _f32c(branch), _f32c(trunk), _f32c(bias.detach())
+        B, K, P = trunk.shape
+        preds = torch.empty((B, K), dtype=torch.float32, device=trunk.device)
+        _lib.api().call("cfd_rowdot_fwd", _ptr(branch), _ptr(trunk), _ptr(bias), _ptr(preds), B, K, P, _stream())
+        ctx.save_for_backward(branch, trunk)
+        return preds
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        api = _lib.api()
+        branch, trunk = ctx.saved_tensors
+        B, K, P = trunk.shape
+        g = _f32c(g)
+        gbr = torch.empty_like(branch) if ctx.needs_input_grad[0] else None
+        gtr = torch.empty_like(trunk) if ctx.needs_input_grad[1] else None
+        gb = torch.empty(1, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
+        ws = _bytes(api.size("cfd_rowdot_bwd_workspace_bytes"), g.device)
+        api.call("cfd_rowdot_bwd", _ptr(g), _ptr(branch), _ptr(trunk), _ptr(gbr), _ptr(gtr), _ptr(gb), _ptr(ws), B, K, P, _stream())
+        return gbr, gtr, gb

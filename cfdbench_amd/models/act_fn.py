@@ -32,6 +32,18 @@ def get_act_fn(name: str, norm: bool = False) -> nn.Module:
     fns = {"relu": ReLU, "tanh": Tanh, "gelu": GELU, "swish": SiLU}
     if name not in fns:
         raise ValueError(f"Unknown activation function: {name}")
-    if norm:
-        raise NotImplementedError("NormAct (act_scale_invariant=1, act_fn.py:21-47) has no MI355X kernel yet")
-    return fns[name]()
+    fn = fns[name]()
+    return NormAct(fn) if norm else fn
+
+
+class NormAct(nn.Module):
+    """Normalised activation (act_fn.py:21-47): per sample, normalise -> act -> transform back.  Marker for ``Ffn``
+    (which runs the preceding Linear without activation and then the fused NormAct kernel); also callable on its own."""
+
+    def __init__(self, act_fn: nn.Module):
+        super().__init__()
+        self.act_fn = act_fn
+
+    def forward(self, x):
+        from .. import functional as F_
+        return F_.NormActFn.apply(x, F_.ACT_CODES[self.act_fn.name])

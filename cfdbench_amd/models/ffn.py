@@ -4,7 +4,8 @@ running as ONE MFMA GEMM with a fused bias/activation epilogue."""
 from torch import Tensor, nn
 
 from .. import functional as F_
-from .act_fn import _Act
+from .act_fn import NormAct, _Act
+from .base_model import CfdModel
 
 
 class Ffn(nn.Module):
@@ -26,9 +27,65 @@ class Ffn(nn.Module):
         while i < len(mods):
             lin = mods[i]
             act = None
+            norm = None
             if i + 1 < len(mods) and isinstance(mods[i + 1], _Act):
                 act = mods[i + 1].name
                 i += 1
+            elif i + 1 < len(mods) and isinstance(mods[i + 1], NormAct):
+                norm = mods[i + 1]  # statistics span the whole sample, so the activation cannot ride in the GEMM epilogue
+                i += 1
             x = F_.linear_act(x, lin.weight, lin.bias, act)
+            if norm is not None:
+                x = norm(x)
             i += 1
         return x
+
+
+class FfnModel(CfdModel):
+    """Non-autoregressive FFN baseline (src/models/ffn.py:38-181): one Ffn over [case params, x, y, t] rows."""
+
+    def __init__(self, loss_fn, widths, act_name: str = "relu", act_norm: bool = True, act_on_output: bool = False,
+                 num_label_samples: int = 1000):
+        super().__init__(loss_fn)
+        from .act_fn import get_act_fn
+        self.loss_fn = loss_fn
+        self.widths = widths
+        self.act_name = act_name
+        self.act_norm = act_norm
+        self.act_on_output = act_on_output
+        self.num_label_samples = num_label_samples
+        self.ffn = Ffn(self.widths, act_fn=get_act_fn(act_name, act_norm), act_on_output=self.act_on_output)
+
+    def forward(self, case_params: Tensor, t: Tensor, label=None, query_idxs=None):
+        """case_params (b,p), t (b,1), label (b,c,h,w), query_idxs (k,2) -> preds (b,k) [+ loss]  (ffn.py:73-146)."""
+        import torch
+        batch_size, dim_in = case_params.shape
+        if query_idxs is None:
+            assert label is not None
+            height, width = label.shape[-2:]
+            query_idxs = torch.stack([torch.randint(0, height, (self.num_label_samples,), device=label.device),
+                                      torch.randint(0, width, (self.num_label_samples,), device=label.device)], dim=-1)
+        coords = query_idxs.unsqueeze(0).repeat(batch_size, 1, 1)
+        num_queries = coords.shape[1]
+        tt = t.unsqueeze(-1).repeat(1, num_queries, 1)
+        coords = torch.cat([coords, tt], dim=-1)
+        cp = case_params.unsqueeze(1).repeat(1, num_queries, 1)
+        inp = torch.cat([cp, coords], dim=-1).view(batch_size * num_queries, -1)
+        preds = self.ffn(inp).view(batch_size, num_queries)
+        if label is not None:
+            labels = label[:, 0][:, query_idxs[:, 0], query_idxs[:, 1]]
+            assert preds.shape == labels.shape, f"{preds.shape}, {labels.shape}"
+            return dict(preds=preds, loss=self.loss_fn(preds=preds, labels=labels))
+        return dict(preds=preds)
+
+    def generate_one(self, case_params: Tensor, t: Tensor, height: int, width: int) -> Tensor:
+        import torch
+        from itertools import product
+        if len(case_params.shape) == 1:
+            case_params = case_params.unsqueeze(0)
+        if len(t.shape) == 0:
+            t = t.unsqueeze(0).unsqueeze(0)
+        elif len(t.shape) == 1:
+            t = t.unsqueeze(0)
+        query_idxs = torch.tensor(list(product(range(height), range(width))), device=case_params.device)
+        return self.forward(case_params, t=t, query_idxs=query_idxs)["preds"].view(-1, 1, height, width)

@@ -191,6 +191,22 @@ size_t cfd_deeponet_inner_bwd_workspace_bytes(int B, int P, int Kq);
 int cfd_deeponet_inner_bwd(const float* gpreds, const float* branch, const float* trunk, float* gbranch, float* gtrunk,
                            float* gbias, void* ws, int B, int P, int Kq, void* stream);
 
+/* NormAct (src/models/act_fn.py:21-47): per sample (all dims but the first; x viewed as (S,L)): y = act((x-mean)/std) * std
+ * + mean with the unbiased std and no epsilon.  stats (S,2) keeps (mean, std) for the backward pass.  act 1..4. */
+int cfd_normact_fwd(const float* x, float* y, float* stats, int S, long L, int act, void* stream);
+int cfd_normact_bwd(const float* x, const float* gy, const float* stats, float* gx, int S, long L, int act, void* stream);
+
+/* Non-autoregressive DeepONet (src/models/deeponet.py:184-205):
+ *   trunk input  out[b,k,p] = ft[b,p] + fxy[k,p];   backward: gft = sum_k g, gfxy = sum_b g (either may be NULL)
+ *   output       preds[b,k] = sum_p branch[b,p] trunk[b,k,p] + bias[0]                                          */
+int cfd_bcast_add_fwd(const float* ft, const float* fxy, float* out, int B, int K, int P, void* stream);
+int cfd_bcast_add_bwd(const float* g, float* gft, float* gfxy, int B, int K, int P, void* stream);
+int cfd_rowdot_fwd(const float* branch, const float* trunk, const float* bias, float* preds, int B, int K, int P,
+                   void* stream);
+size_t cfd_rowdot_bwd_workspace_bytes(void);
+int cfd_rowdot_bwd(const float* g, const float* branch, const float* trunk, float* gbranch, float* gtrunk, float* gbias,
+                   void* ws, int B, int K, int P, void* stream);
+
 /* ---- convolution stack of the U-Net / ResNet baselines (src/models/unet.py, src/models/resnet.py) ---------*/
 
 /* out (B,Co,H,W) = nn.Conv2d(Ci, Co, ks, padding=ks/2, padding_mode="replicate")(in); w (Co,Ci,ks,ks); ks odd <= 7

@@ -132,3 +132,53 @@ def make_params(seed: int, branch_dim: int, width: int, branch_depth: int, trunk
             p[f"{prefix}.layers.{2 * i}.weight"] = rng.uniform(-bound, bound, (dims[i + 1], dims[i])).astype(dtype)
             p[f"{prefix}.layers.{2 * i}.bias"] = rng.uniform(-bound, bound, (dims[i + 1],)).astype(dtype)
     return p
+
+
+# ---- NormAct (src/models/act_fn.py:21-47) and the non-autoregressive DeepONet / FfnModel forward ----
+def normact(x: Array, name: str):
+    dims = tuple(range(1, x.ndim))
+    mean = x.mean(axis=dims, keepdims=True)
+    std = x.std(axis=dims, keepdims=True, ddof=1)
+    u = (x - mean) / std
+    return act(u, name) * std + mean, dict(u=u, std=std, name=name)
+
+
+def normact_bwd(g: Array, cache: dict) -> Array:
+    u, std, name = cache["u"], cache["std"], cache["name"]
+    dims = tuple(range(1, u.ndim))
+    L = u[0].size
+    gu = g * std * act_grad(u, name)
+    Gmu = g.sum(axis=dims, keepdims=True) - gu.sum(axis=dims, keepdims=True) / std
+    Gsd = (g * act(u, name)).sum(axis=dims, keepdims=True) - (gu * u).sum(axis=dims, keepdims=True) / std
+    return gu / std + Gmu / L + Gsd * u / (L - 1)
+
+
+def ffn_forward_norm(layers, x: Array, act_name: str, act_norm: bool, act_on_output: bool = False) -> Array:
+    n = len(layers)
+    for i, (w, b) in enumerate(layers):
+        x = x @ w.T + b
+        if i < n - 1 or act_on_output:
+            x = normact(x, act_name)[0] if act_norm else act(x, act_name)
+    return x
+
+
+def deeponet_forward(params: Dict[str, Array], case_params: Array, t: Array, query_idxs: Array, act_name: str = "relu",
+                     act_norm: bool = True) -> Array:
+    """DeepONet.forward, src/models/deeponet.py:153-223 (given query_idxs): preds (b,k)."""
+    xt = t @ params["fc_trunk_t.weight"].T + params["fc_trunk_t.bias"]                                   # (b,p)
+    xy = query_idxs.astype(t.dtype) @ params["fc_trunk_xy.weight"].T + params["fc_trunk_xy.bias"]        # (k,p)
+    x_trunk = xt[:, None, :] + xy[None, :, :]
+    xb = ffn_forward_norm(ffn_layers(params, "branch_net"), case_params, act_name, act_norm)
+    xtr = ffn_forward_norm(ffn_layers(params, "trunk_net"), x_trunk, act_name, act_norm)
+    return np.einsum("bp,bkp->bk", xb, xtr) + params["bias"][0]
+
+
+def ffnmodel_forward(params: Dict[str, Array], case_params: Array, t: Array, query_idxs: Array, act_name: str = "relu",
+                     act_norm: bool = True) -> Array:
+    """FfnModel.forward, src/models/ffn.py:73-146 (given query_idxs): preds (b,k)."""
+    B, K = case_params.shape[0], query_idxs.shape[0]
+    coords = np.broadcast_to(query_idxs.astype(t.dtype)[None], (B, K, 2))
+    tt = np.broadcast_to(t[:, None, :], (B, K, 1))
+    cp = np.broadcast_to(case_params[:, None, :], (B, K, case_params.shape[1]))
+    inp = np.concatenate([cp, coords, tt], axis=-1).reshape(B * K, -1)
+    return ffn_forward_norm(ffn_layers(params, "ffn"), inp, act_name, act_norm).reshape(B, K)

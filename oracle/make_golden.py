@@ -205,6 +205,41 @@ def gen_resnet(name, seed, bseed, B, H, W, hidden, nblocks, p=5, steps=2):
     print(name, "ok", {k: float(v) for k, v in out["loss"].items()}, save["frames"].shape)
 
 
+def gen_nonauto(name, kind, seed, B, K, H, W, width, act_name, act_norm, p=5):
+    """Non-autoregressive DeepONet / FfnModel (src/models/deeponet.py, ffn.py:38-181) with given query points:
+    forward, loss, backward, generate_one from the reference modules."""
+    from models.deeponet import DeepONet  # reference
+    from models.ffn import FfnModel  # reference
+    torch.manual_seed(seed)
+    if kind == "deeponet":
+        model = DeepONet(p, 3, MseLoss(normalize=True), branch_depth=3, trunk_depth=3, width=width, act_name=act_name,
+                         act_norm=act_norm)
+    else:
+        model = FfnModel(MseLoss(normalize=True), [p + 3, width, width, 1], act_name=act_name, act_norm=act_norm)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if k == "bias":
+                v.fill_(0.03)
+    rng = np.random.default_rng(seed)
+    cp = rng.standard_normal((B, p)).astype(np.float32)
+    t = rng.uniform(0, 2, (B, 1)).astype(np.float32)
+    label = rng.standard_normal((B, 2, H, W)).astype(np.float32)
+    q = np.stack([rng.integers(0, H, K), rng.integers(0, W, K)], axis=-1).astype(np.int64)
+    out = model(case_params=_t(cp), t=_t(t), label=_t(label), query_idxs=_t(q))
+    out["loss"]["nmse"].backward()
+    save = dict(meta=np.array([seed, B, K, H, W, width, p, int(act_norm)]), act=np.array(act_name), kind=np.array(kind),
+                cp=cp, t=t, label=label, q=q, preds=out["preds"].detach().numpy(),
+                **{f"loss_{k}": np.array(v.item()) for k, v in out["loss"].items()})
+    for k, v in model.state_dict().items():
+        save[f"sd::{k}"] = v.detach().numpy()
+    for k, prm in model.named_parameters():
+        save[f"grad::{k}"] = prm.grad.numpy()
+    with torch.no_grad():
+        save["frame"] = model.generate_one(_t(cp[0]), _t(t[0]), 6, 7).numpy()
+    np.savez_compressed(OUT / f"{name}.npz", **save)
+    print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
+
+
 def gen_adam(name, pseed, bseed, B, C, L, H, W, nsteps, lr, p=5, gain=1.0):
     """train_auto.py:231-257: model(**batch) -> loss['nmse'].backward() -> Adam.step() -> zero_grad()."""
     params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=gain)
@@ -252,6 +287,9 @@ def main():
     gen_unet("unet_dim4_32x32", 61, 71, 3, 32, 32, 4)
     gen_unet("unet_dim3_36x40", 62, 72, 2, 36, 40, 3, p=5)
     gen_resnet("resnet_h4_20x24", 81, 91, 2, 20, 24, 4, 1)
+    gen_nonauto("deeponet_normact_relu", "deeponet", 101, 3, 37, 16, 18, 24, "relu", True)
+    gen_nonauto("deeponet_plain_tanh", "deeponet", 102, 2, 50, 16, 18, 20, "tanh", False)
+    gen_nonauto("ffnmodel_normact_gelu", "ffn", 103, 3, 41, 16, 18, 24, "gelu", True)
     gen_adam("adam_small_64x64", 26, 36, 2, 8, 2, 64, 64, nsteps=3, lr=1e-3, gain=8.0)
     gen_mseloss("mseloss", 41)
 

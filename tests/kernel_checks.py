@@ -554,3 +554,48 @@ def check_pool_convt_resid(be, B, Ci, Co, H, W, seed=33):
     be.sync()
     res["resid"] = nm(be.host(o2), (xs + x.reshape(B, Ci, -1)[:, :C2]) * mask[:, None])
     return res
+
+
+# ---- NormAct and the non-autoregressive DeepONet pieces (csrc/dense.hip) ---------------------------------------------
+def check_normact(be, S, shape, act, seed=41):
+    from oracle import deeponet_oracle as D
+    api, P = be.api, be.ptr
+    code = {"relu": 1, "tanh": 2, "gelu": 3, "swish": 4}[act]
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((S,) + shape) * 1.3 + 0.4).astype(np.float32)
+    g = rng.standard_normal((S,) + shape).astype(np.float32)
+    L = int(np.prod(shape))
+    dx, dg = be.dev(x), be.dev(g)
+    y, stats, gx = be.zeros((S,) + shape), be.zeros((S, 2)), be.zeros((S,) + shape)
+    api.call("cfd_normact_fwd", P(dx), P(y), P(stats), S, L, code, be.stream)
+    api.call("cfd_normact_bwd", P(dx), P(dg), P(stats), P(gx), S, L, code, be.stream)
+    be.sync()
+    ry, cache = D.normact(x.astype(f64), act)
+    return {"y": nm(be.host(y), ry), "gx": nm(be.host(gx), D.normact_bwd(g.astype(f64), cache))}
+
+
+def check_bcast_rowdot(be, B, K, P_, seed=42):
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    ft, fxy = rng.standard_normal((B, P_)).astype(np.float32), rng.standard_normal((K, P_)).astype(np.float32)
+    g3 = rng.standard_normal((B, K, P_)).astype(np.float32)
+    dft, dfxy, dg3 = be.dev(ft), be.dev(fxy), be.dev(g3)
+    out, gft, gfxy = be.zeros((B, K, P_)), be.zeros((B, P_)), be.zeros((K, P_))
+    api.call("cfd_bcast_add_fwd", P(dft), P(dfxy), P(out), B, K, P_, be.stream)
+    api.call("cfd_bcast_add_bwd", P(dg3), P(gft), P(gfxy), B, K, P_, be.stream)
+    be.sync()
+    res = {"bcast": nm(be.host(out), ft[:, None, :].astype(f64) + fxy[None].astype(f64)),
+           "gft": nm(be.host(gft), g3.astype(f64).sum(axis=1)), "gfxy": nm(be.host(gfxy), g3.astype(f64).sum(axis=0))}
+    br, tr = rng.standard_normal((B, P_)).astype(np.float32), rng.standard_normal((B, K, P_)).astype(np.float32)
+    bias, g2 = np.array([0.21], np.float32), rng.standard_normal((B, K)).astype(np.float32)
+    dbr, dtr, dbi, dg2 = be.dev(br), be.dev(tr), be.dev(bias), be.dev(g2)
+    preds, gbr, gtr, gbi = be.zeros((B, K)), be.zeros((B, P_)), be.zeros((B, K, P_)), be.zeros((1,))
+    ws = be.bytes(api.size("cfd_rowdot_bwd_workspace_bytes"))
+    api.call("cfd_rowdot_fwd", P(dbr), P(dtr), P(dbi), P(preds), B, K, P_, be.stream)
+    api.call("cfd_rowdot_bwd", P(dg2), P(dbr), P(dtr), P(gbr), P(gtr), P(gbi), P(ws), B, K, P_, be.stream)
+    be.sync()
+    res["preds"] = nm(be.host(preds), np.einsum("bp,bkp->bk", br.astype(f64), tr.astype(f64)) + 0.21)
+    res["gbranch"] = nm(be.host(gbr), np.einsum("bk,bkp->bp", g2.astype(f64), tr.astype(f64)))
+    res["gtrunk"] = nm(be.host(gtr), g2.astype(f64)[:, :, None] * br.astype(f64)[:, None, :])
+    res["gbias"] = float(abs(be.host(gbi)[0] - g2.astype(f64).sum()) / abs(g2.astype(f64).sum()))
+    return res

@@ -121,3 +121,15 @@ def test_pool_convtranspose_residual(be, B, Ci, Co, H, W):
     res = K.check_pool_convt_resid(be, B, Ci, Co, H, W)
     assert res.pop("pool") == 0.0 and res.pop("pool_bwd") == 0.0  # selections, not arithmetic: exact
     _assert_all(res)
+
+
+@pytest.mark.parametrize("S,shape,act", [(5, (24,), "relu"), (2, (7, 20), "tanh"), (3, (33,), "gelu"), (2, (5, 6), "swish")])
+def test_normact(be, S, shape, act):
+    _assert_all(K.check_normact(be, S, shape, act))
+
+
+@pytest.mark.parametrize("B,Kq,P", [(2, 9, 20), (3, 5, 7)])
+def test_broadcast_add_and_rowdot(be, B, Kq, P):
+    res = K.check_bcast_rowdot(be, B, Kq, P)
+    assert res.pop("gbias") < 1e-5
+    _assert_all(res)

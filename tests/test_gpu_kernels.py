@@ -148,3 +148,15 @@ def test_pool_convtranspose_residual(be, B, Ci, Co, H, W):
     res = K.check_pool_convt_resid(be, B, Ci, Co, H, W)
     assert res.pop("pool") == 0.0 and res.pop("pool_bwd") == 0.0  # selections, not arithmetic: exact
     _assert_all(res)
+
+
+@pytest.mark.parametrize("S,shape,act", [(8000, (100,), "relu"), (8, (1000, 100), "tanh"), (37, (333,), "gelu"), (5, (40, 24), "swish")])
+def test_normact(be, S, shape, act):
+    _assert_all(K.check_normact(be, S, shape, act))
+
+
+@pytest.mark.parametrize("B,Kq,P", [(8, 1000, 100), (3, 37, 24)])
+def test_broadcast_add_and_rowdot(be, B, Kq, P):
+    res = K.check_bcast_rowdot(be, B, Kq, P)
+    assert res.pop("gbias") < 1e-5
+    _assert_all(res)

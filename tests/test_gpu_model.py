@@ -385,3 +385,35 @@ def test_resnet_vs_reference_golden(torch, golden_dir):
     assert torch.allclose(y[y != 0], (z / 0.8)[y != 0])
     y.sum().backward()
     assert torch.equal(z.grad != 0, y != 0)
+
+
+# ---- non-autoregressive DeepONet / FfnModel drop-ins vs the reference modules' golden outputs -----------------------
+@pytest.mark.parametrize("name", ["deeponet_normact_relu", "deeponet_plain_tanh", "ffnmodel_normact_gelu"])
+def test_nonauto_models_vs_reference_golden(torch, golden_dir, name):
+    from cfdbench_amd.models.deeponet import DeepONet
+    from cfdbench_amd.models.ffn import FfnModel
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    g = np.load(golden_dir / f"{name}.npz")
+    seed, B, K_, H, W, width, p, act_norm = [int(v) for v in g["meta"]]
+    act = str(g["act"])
+    if str(g["kind"]) == "deeponet":
+        m = DeepONet(p, 3, loss_name_to_fn("nmse"), branch_depth=3, trunk_depth=3, width=width, act_name=act,
+                     act_norm=bool(act_norm)).cuda()
+    else:
+        m = FfnModel(loss_name_to_fn("nmse"), [p + 3, width, width, 1], act_name=act, act_norm=bool(act_norm)).cuda()
+    sd = {k[len("sd::"):]: torch.from_numpy(np.ascontiguousarray(g[k])) for k in g.files if k.startswith("sd::")}
+    assert list(sd.keys()) == list(m.state_dict().keys())
+    m.load_state_dict(sd)
+    cp, t, label, q = (torch.from_numpy(g[k]).cuda() for k in ("cp", "t", "label", "q"))
+    out = m(case_params=cp, t=t, label=label, query_idxs=q)
+    assert O.rel_nmse(out["preds"].detach().cpu().numpy(), g["preds"]) < 1e-9
+    assert abs(out["loss"]["nmse"].item() - float(g["loss_nmse"])) <= 1e-5 * float(g["loss_nmse"])
+    out["loss"]["nmse"].backward()
+    for k, prm in m.named_parameters():
+        assert O.rel_nmse(prm.grad.cpu().numpy(), g[f"grad::{k}"]) < 1e-7, k
+    with torch.no_grad():
+        frame = m.generate_one(cp[0], t[0], 6, 7)
+        assert tuple(frame.shape) == (1, 1, 6, 7)
+        assert O.rel_nmse(frame.cpu().numpy(), g["frame"]) < 1e-9
+        rnd = m(case_params=cp, t=t, label=label)  # random query points (torch.randint), as in training
+        assert tuple(rnd["preds"].shape) == (B, m.num_label_samples)

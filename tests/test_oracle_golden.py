@@ -195,3 +195,13 @@ def test_resnet_eval_forward(golden_dir):
     out = CO.resnet_forward(P, b64["inputs"], b64["case_params"], b64["mask"], b64["label"])
     assert O.rel_nmse(out["preds"], g["preds"]) < 1e-10
     assert abs(out["loss"]["nmse"] - float(g["loss_nmse"])) <= 1e-5 * float(g["loss_nmse"])
+
+
+@pytest.mark.parametrize("name", ["deeponet_normact_relu", "deeponet_plain_tanh", "ffnmodel_normact_gelu"])
+def test_nonauto_deeponet_ffn_forward(golden_dir, name):
+    from oracle import deeponet_oracle as D
+    g = np.load(golden_dir / f"{name}.npz")
+    P = {k[len("sd::"):]: g[k].astype(np.float64) for k in g.files if k.startswith("sd::")}
+    fwd = D.deeponet_forward if str(g["kind"]) == "deeponet" else D.ffnmodel_forward
+    preds = fwd(P, g["cp"].astype(np.float64), g["t"].astype(np.float64), g["q"], str(g["act"]), bool(g["meta"][7]))
+    assert O.rel_nmse(preds, g["preds"]) < 1e-10
