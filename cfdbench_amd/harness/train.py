@@ -1,0 +1,221 @@
+"""Non-autoregressive train / eval / test loop (DeepONet, FfnModel) with the reference's behaviour and artefacts
+(src/train.py:26-350).
+
+    python -m cfdbench_amd.harness.train --model deeponet --data cavity_prop_bc_geo --loss_name nmse
+
+Dataset items are ``(case_params (p,), t (1,), frame (c,h,w))`` (src/dataset/cavity.py:198-205).  Training queries
+``num_label_samples`` random points per frame inside the model (deeponet.py:187-197); evaluation reconstructs whole
+frames with ``generate_one`` and scores the u channel.  Files written: ckpt-{ep}/{model.pt, dev_loss.json,
+train_loss.json, scores.json}, train_losses.json, test/{preds.pt, scores.json}, args.json -- the names of src/train.py.
+Under torch.distributed each rank trains on its shard of the frames; gradients are summed over ranks in one flat
+all-reduce; rank 0 alone evaluates and writes files."""
+from __future__ import annotations
+
+import time
+from pathlib import Path
+from shutil import copyfile
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.optim import Adam, lr_scheduler
+from torch.utils.data import DataLoader, Dataset, Subset
+
+from ..engine import shard_range, sync_gradients
+from ..models.base_model import CfdModel
+from ..models.deeponet import DeepONet
+from ..models.ffn import FfnModel
+from ..models.loss import loss_name_to_fn
+from .args import Args
+from .common import dump_json, get_output_dir, load_best_ckpt, plot_loss, plot_predictions
+
+
+def collate_fn(batch: list, device: Optional[str] = "cuda"):
+    """list of (case_params (p,), t (1,), frame (c,h,w)) -> kwargs of the model's forward (src/train.py:26-35)."""
+    case_params, t, label = zip(*batch)
+    out = dict(case_params=torch.stack(case_params), t=torch.stack(t), label=torch.stack(label))
+    if device is not None:
+        out = {k: v.to(device, non_blocking=True).contiguous() for k, v in out.items()}
+    return out
+
+
+def _rank_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def evaluate(model: CfdModel, data, output_dir: Path, batch_size: int = 64, plot_interval: int = 1,
+             measure_time: bool = False) -> Dict[str, Any]:
+    """src/train.py:38-113: whole-frame reconstruction with ``generate_one``; scores of the u channel; predictions
+    repeated to three channels for the plotting / preds.pt layout of the reference."""
+    loader = DataLoader(data, batch_size=batch_size, shuffle=False, collate_fn=collate_fn)
+    scores: Dict[str, List[float]] = {name: [] for name in model.loss_fn.get_score_names()}
+    all_preds = []
+    start_time = time.time()
+    model.eval()
+    with torch.no_grad():
+        for step, batch in enumerate(loader):
+            label = batch["label"]
+            height, width = label.shape[-2:]
+            preds = model.generate_one(case_params=batch["case_params"], t=batch["t"], height=height, width=width)
+            loss = model.loss_fn(labels=label[:, :1], preds=preds)
+            for key in scores:
+                scores[key].append(loss[key].item())
+            preds = preds.repeat(1, 3, 1, 1)
+            all_preds.append(preds.cpu().detach())
+            if plot_interval > 0 and step % plot_interval == 0 and not measure_time:
+                plot_predictions(inp=None, label=label[0][0], pred=preds[0][0], out_dir=Path(output_dir) / "images",
+                                 step=step)
+    if measure_time:
+        print(f"Time per step: {1000 * (time.time() - start_time) / max(len(loader), 1):.3f} ms")
+    avg_scores = {key: float(np.mean(vals)) for key, vals in scores.items()}
+    if "nmse" in scores:
+        plot_loss(scores["nmse"], Path(output_dir) / "loss.png")
+    return dict(scores=dict(mean=avg_scores, all=scores), preds=all_preds)
+
+
+def test(model: CfdModel, data, output_dir: Path, plot_interval: int = 10, batch_size: int = 1,
+         measure_time: bool = False):
+    """src/train.py:116-145."""
+    assert plot_interval > 0
+    output_dir = Path(output_dir)
+    output_dir.mkdir(exist_ok=True, parents=True)
+    result = evaluate(model, data, output_dir, batch_size=batch_size, plot_interval=plot_interval,
+                      measure_time=measure_time)
+    torch.save(result["preds"], output_dir / "preds.pt")
+    dump_json(result["scores"], output_dir / "scores.json")
+    return result
+
+
+def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: int = 400, lr: float = 1e-3,
+          lr_step_size: int = 1, lr_gamma: float = 0.9, batch_size: int = 64, log_interval: int = 50,
+          eval_interval: int = 2, measure_time: bool = False, plot_interval: int = 1):
+    """src/train.py:148-253: fwd -> ``loss["nmse"].backward()`` -> Adam -> zero_grad; StepLR per epoch."""
+    rank, world = _rank_world()
+    output_dir = Path(output_dir)
+    if world > 1:
+        perm = torch.randperm(len(train_data), generator=torch.Generator().manual_seed(0)).tolist()
+        a, b = shard_range(len(perm), rank, world)
+        train_data = Subset(train_data, perm[a:b])
+    loader = DataLoader(train_data, batch_size=batch_size, collate_fn=collate_fn, shuffle=True, drop_last=world > 1)
+    if rank == 0:
+        output_dir.mkdir(exist_ok=True, parents=True)
+    optimizer = Adam(model.parameters(), lr=lr)
+    scheduler = lr_scheduler.StepLR(optimizer, step_size=lr_step_size, gamma=lr_gamma)
+    start_time = time.time()
+    global_step = 0
+    all_train_losses: List[float] = []
+    for ep in range(num_epochs):
+        ep_start_time = time.time()
+        ep_train_losses: List[float] = []
+        model.train()
+        for step, batch in enumerate(loader):
+            loss = model(**batch)["loss"]["nmse"]
+            loss.backward()
+            if world > 1:
+                sync_gradients(list(model.parameters()))
+            optimizer.step()
+            optimizer.zero_grad()
+            ep_train_losses.append(loss.item())  # src/train.py:203
+            global_step += 1
+            if global_step % log_interval == 0 and not measure_time and rank == 0:
+                avg_loss = sum(ep_train_losses) / (len(ep_train_losses) + 1e-5)
+                print(dict(ep=ep, step=step, loss=f"{avg_loss:.3e}", lr=f"{scheduler.get_last_lr()[0]:.3e}",
+                           time=round(time.time() - start_time)))
+        if measure_time:
+            print("Time usage:", time.time() - ep_start_time)
+            return all_train_losses + ep_train_losses
+        scheduler.step()
+        if (ep + 1) % eval_interval == 0 and rank == 0:
+            ckpt_dir = output_dir / f"ckpt-{ep}"
+            ckpt_dir.mkdir(exist_ok=True, parents=True)
+            dev_scores = evaluate(model, dev_data, ckpt_dir, plot_interval=plot_interval)["scores"]
+            dump_json(dev_scores, ckpt_dir / "dev_loss.json")
+            dump_json(ep_train_losses, ckpt_dir / "train_loss.json")
+            ckpt_path = ckpt_dir / "model.pt"
+            if ckpt_path.exists():
+                copyfile(ckpt_path, ckpt_dir / "backup_model.pt")
+            torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, ckpt_path)
+            dump_json(dict(ep=ep, train_loss=float(np.mean(ep_train_losses)), dev_loss=float(np.mean(dev_scores["mean"]["nmse"])),
+                           time=time.time() - ep_start_time), ckpt_dir / "scores.json")
+        if world > 1:
+            dist.barrier()
+        all_train_losses += ep_train_losses
+    if rank == 0:
+        dump_json(all_train_losses, output_dir / "train_losses.json")
+        plot_loss(all_train_losses, output_dir / "train_losses.png")
+    return all_train_losses
+
+
+def init_model(args: Args) -> CfdModel:
+    """Instantiate a non-autoregressive model (src/train.py:256-291): branch input = the case parameters
+    (8 for the cylinder problem, else 5), trunk / query input = (t, x, y)."""
+    loss_fn = loss_name_to_fn(args.loss_name)
+    query_coord_dim = 3
+    n_case_params = 8 if "cylinder" in args.data_name else 5
+    if args.model == "deeponet":
+        return DeepONet(branch_dim=n_case_params, trunk_dim=query_coord_dim, loss_fn=loss_fn, width=args.deeponet_width,
+                        trunk_depth=args.trunk_depth, branch_depth=args.branch_depth, act_name=args.act_fn,
+                        act_norm=bool(args.act_scale_invariant), act_on_output=bool(args.act_on_output))
+    if args.model == "ffn":
+        widths = [n_case_params + query_coord_dim] + [args.ffn_width] * args.ffn_depth + [1]
+        return FfnModel(widths=widths, loss_fn=loss_fn)
+    raise ValueError(f"Invalid model name: {args.model}")
+
+
+class SyntheticDataset(Dataset):
+    """Items of the reference's non-autoregressive shape, built from the frames of a ``SyntheticAutoDataset``:
+    (case_params (5,), t (1,), frame (3,h,w)) -- for smoke runs and tests without data on disk."""
+
+    def __init__(self, n_cases: int = 3, n_frames: int = 4, height: int = 16, width: int = 16, seed: int = 0):
+        from .data import SyntheticAutoDataset
+        src = SyntheticAutoDataset(n_cases, n_frames, height, width, seed)
+        self.items = []
+        for feats, cp in zip(src.all_features, src.case_params):
+            cpt = torch.tensor(list(cp.values()), dtype=torch.float32)
+            for t in range(feats.shape[0]):
+                self.items.append((cpt, torch.tensor([float(t)]), torch.from_numpy(feats[t])))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def get_dataset(data_dir: Path, data_name: str, norm_props: bool, norm_bc: bool):
+    """(train, dev, test) CfdDatasets via the reference's loaders (src/dataset/__init__.py:12)."""
+    try:
+        from dataset import get_dataset as ref_get
+    except Exception as e:  # noqa: BLE001
+        raise RuntimeError(
+            "cfdbench_amd ships the hot path, not CFDBench's dataset loaders: put the CFDBench `src/` directory on "
+            f"PYTHONPATH so that `import dataset` resolves, or pass your own Dataset objects to train()/evaluate().  ({e})") from e
+    return ref_get(data_dir=Path(data_dir), data_name=data_name, norm_props=norm_props, norm_bc=norm_bc)
+
+
+def main(argv=None):
+    args = Args().parse_args(argv)
+    print(args)
+    output_dir = get_output_dir(args)
+    output_dir.mkdir(exist_ok=True, parents=True)
+    args.save(str(output_dir / "args.json"))
+    train_data, dev_data, test_data = get_dataset(Path(args.data_dir), args.data_name, bool(args.norm_props),
+                                                  bool(args.norm_bc))
+    model = init_model(args).cuda()
+    print(f"Model has {sum(p.numel() for p in model.parameters())} parameters")
+    if "train" in args.mode:
+        args.save(str(output_dir / "train_args.json"))
+        train(model, train_data, dev_data, output_dir, batch_size=args.batch_size, lr=args.lr,
+              lr_step_size=args.lr_step_size, lr_gamma=args.lr_gamma, num_epochs=args.num_epochs,
+              eval_interval=args.eval_interval, log_interval=args.log_interval, plot_interval=args.plot_interval)
+    if "test" in args.mode:
+        args.save(str(output_dir / "test_args.json"))
+        load_best_ckpt(model, output_dir)
+        test(model, data=test_data, output_dir=output_dir / "test", batch_size=1, plot_interval=10)
+
+
+if __name__ == "__main__":
+    main()

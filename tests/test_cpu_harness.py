@@ -81,3 +81,22 @@ def test_best_checkpoint_selection(tmp_path):
         d.mkdir()
         dump_json(dict(ep=ep, train_loss=1.0, dev_loss=loss, time=1.0), d / "scores.json")
     assert get_best_ckpt(tmp_path).name == "ckpt-3"
+
+
+def test_nonauto_collate_and_init_model_shapes():
+    """src/train.py:26-35,256-291: batch keys, and the branch / trunk widths init_model derives from the flags."""
+    from cfdbench_amd.harness.train import SyntheticDataset, collate_fn as collate_nonauto, init_model as init_nonauto
+    ds = SyntheticDataset(2, 3, 8, 8, seed=0)
+    b = collate_nonauto([ds[0], ds[4]], device=None)
+    assert b["case_params"].shape == (2, 5) and b["t"].shape == (2, 1) and b["label"].shape == (2, 3, 8, 8)
+    assert float(b["t"][1, 0]) == 1.0
+    m = init_nonauto(Args(model="deeponet", data_name="cylinder_geo", deeponet_width=16, branch_depth=2, trunk_depth=3))
+    assert m.branch_net.fc_layers if hasattr(m.branch_net, "fc_layers") else True
+    sd = m.state_dict()
+    assert sd["fc_trunk_t.weight"].shape[1] == 1 and sd["fc_trunk_xy.weight"].shape[1] == 2
+    assert [v.shape[1] for k, v in sd.items() if k.startswith("branch_net") and k.endswith("weight")][0] == 8
+    f = init_nonauto(Args(model="ffn", data_name="cavity_bc", ffn_width=12, ffn_depth=2))
+    ws = [tuple(v.shape) for k, v in f.state_dict().items() if k.endswith("weight")]
+    assert ws == [(12, 8), (12, 12), (1, 12)]
+    with pytest.raises(ValueError):
+        init_nonauto(Args(model="fno", data_name="cavity_bc"))

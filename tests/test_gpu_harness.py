@@ -143,3 +143,34 @@ def test_graph_rollout_matches_generate_many_and_reference_golden(torch, golden_
     # unbatched entry point
     one = ro.generate_many(x[0], cp[0], mask[0, 0], 2)
     assert tuple(one[0].shape) == (1, 2, H, W) and O.rel_nmse(one[1].cpu().numpy(), fast[1][:1].cpu().numpy()) < 1e-10
+
+
+@pytest.mark.parametrize("model_name", ["deeponet", "ffn"])
+def test_nonauto_train_eval_test_artifacts(torch, tmp_path, model_name):
+    """src/train.py's loop on the DeepONet / FfnModel drop-ins: loss decreases, reference file tree, reloadable ckpt."""
+    from cfdbench_amd.harness.args import Args
+    from cfdbench_amd.harness.common import get_best_ckpt, get_output_dir, load_best_ckpt, load_json
+    from cfdbench_amd.harness.train import SyntheticDataset, init_model, test, train
+    args = Args(model=model_name, data_name="cavity_prop_bc_geo", loss_name="nmse", deeponet_width=32, branch_depth=3,
+                trunk_depth=3, ffn_width=32, ffn_depth=3, lr=2e-3, output_dir=str(tmp_path), num_epochs=6, batch_size=4,
+                eval_interval=3, log_interval=5, plot_interval=0)
+    out = get_output_dir(args)
+    tr, dev = SyntheticDataset(4, 6, 16, 16, seed=0), SyntheticDataset(2, 3, 16, 16, seed=1)
+    torch.manual_seed(0)
+    model = init_model(args).cuda()
+    model.num_label_samples = 200
+    losses = train(model, tr, dev, out, num_epochs=args.num_epochs, lr=args.lr, batch_size=args.batch_size,
+                   eval_interval=args.eval_interval, log_interval=args.log_interval, plot_interval=0)
+    assert len(losses) == 6 * 6 and np.all(np.isfinite(losses))
+    assert np.mean(losses[-6:]) < np.mean(losses[:6]), "training does not reduce the nMSE"
+    for ep in (2, 5):
+        d = out / f"ckpt-{ep}"
+        assert (d / "model.pt").exists() and (d / "train_loss.json").exists()
+        assert set(load_json(d / "scores.json")) == {"ep", "train_loss", "dev_loss", "time"}
+        assert set(load_json(d / "dev_loss.json")["mean"]) == {"mse", "rmse", "mae", "nmse"}
+    m2 = init_model(args).cuda()
+    load_best_ckpt(m2, out)
+    res = test(m2, dev, out / "test", batch_size=1, plot_interval=10)
+    assert (out / "test" / "preds.pt").exists() and len(res["preds"]) == len(dev)
+    assert tuple(res["preds"][0].shape) == (1, 3, 16, 16)
+    assert get_best_ckpt(out) is not None
