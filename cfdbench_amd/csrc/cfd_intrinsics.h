@@ -11,6 +11,13 @@ __device__ __forceinline__ f32x4 cfd_mfma16x16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_16x16x32_bf16 (bf16 inputs, fp32 accumulate; ~17 cycles issue per SIMD, i.e. 15x the fp32 form's rate).
+// Operand maps: a = A[i=lane&15][k=8*(lane>>4)+v]; b = B[k=8*(lane>>4)+v][j=lane&15], v = 0..7; c/d as above.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 cfd_mfma16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float cfd_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 
 __device__ __forceinline__ float cfd_wave_sum(float v) {
@@ -47,3 +54,10 @@ __device__ __forceinline__ void cfd_sched_fence() { __builtin_amdgcn_sched_barri
 __device__ __forceinline__ float cfd_erff(float x) { return erff(x); }
 __device__ __forceinline__ float cfd_expf(float x) { return __expf(x); }
 __device__ __forceinline__ float cfd_rcpf(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float cfd_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32, no range fix-up
+
+// Two fp32 values in one 64-bit register pair: +, -, * and cfd_fma2 on it compile to the packed VALU instructions
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), which retire two lanes' worth of fp32 math per issue slot.
+typedef float cfd_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cfd_f2 cfd_fma2(cfd_f2 a, cfd_f2 b, cfd_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ cfd_f2 cfd_abs2(cfd_f2 a) { return __builtin_elementwise_abs(a); }

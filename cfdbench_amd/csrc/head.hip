@@ -1,21 +1,25 @@
 // Fno2d projection head fused with the mask and the MseLoss reductions (src/models/fno/fno2d.py:228-237,
 // src/models/loss.py:22-37):   preds = mask * fc2(gelu(fc1(h)))   with h = f(a), fc1: C -> 128, fc2: 128 -> out_chan.
 //
-// The (B,128,H,W) hidden tensor (537 MB at B=256, 64x64) never exists: each wave pushes 64-pixel tiles through
-// v_mfma_f32_16x16x4_f32 with the hidden units on the M axis (128 = 8 tiles, K = C channels), applies GELU on the
-// accumulator registers and folds fc2 + the loss sums in place.  The backward kernel recomputes the hidden tile and
-// produces d/da plus all four parameter gradients; the two contractions over PIXELS (weight gradients) need the tile
-// transposed, which goes through a wave-private LDS region (no workgroup barrier inside the tile loop).
+// The (B,128,H,W) hidden tensor (537 MB at B=256, 64x64) never exists: each wave pushes 64-pixel tiles through the
+// matrix cores with the hidden units on the M axis (128 = 8 tiles, K = channels), applies GELU on the accumulator
+// registers and folds fc2 + the loss sums in place.  The backward kernel recomputes the hidden tile and produces d/da
+// plus all four parameter gradients.  These kernels are compute-bound (17 GFLOP of fc1-shaped GEMMs + 134 M GELUs per
+// step at B=256), and fp32 MFMA on gfx950 only matches the VALU's fp32 rate without overlapping it, so the GEMMs run
+// as split-bf16 3-term products on v_mfma_f32_16x16x32_bf16 (cfd_common.h, relative error ~2^-16, fp32 accumulate).
 #include "cfd_common.h"
 
 #define HEAD_HD 128
 #define HEAD_MT 8
+#ifndef CFD_HEAD_FWD_BLOCKS
+#define CFD_HEAD_FWD_BLOCKS 1024  // 4 workgroups (16 waves) per CU: the kernel's 116 VGPRs allow 4 waves per SIMD
+#endif
 #define HEAD_LD 17  // LDS row stride of the transposed tiles (16 pixels + 1 pad -> conflict-free column reads)
 
 static int head_blocks(int B, int HW) {
     const long tiles = (long)B * ((HW + 63) / 64);
     long blocks = (tiles + 7) / 8;  // >= 2 tiles per wave
-    if (blocks > 512) blocks = 512;
+    if (blocks > CFD_HEAD_FWD_BLOCKS) blocks = CFD_HEAD_FWD_BLOCKS;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
@@ -28,51 +32,54 @@ static int head_bwd_blocks(int B, int HW) {
     return (int)blocks;
 }
 
-template <int KS, bool VEC4, bool ACT>
-__device__ __forceinline__ void head_load_h(const float* __restrict__ a, int b, int C, int HW, int px, int q,
-                                            float (&h)[KS][4]) {
+// Input tile in the K = 32 operand layout of v_mfma_f32_16x16x32_bf16: lane group q owns channels 8q .. 8q+7
+// (k-slot v <-> channel 8q + v, zero beyond C) of the lane's four pixels px .. px+3.
+template <bool VEC4, bool ACT>
+__device__ __forceinline__ void head_load_h8(const float* __restrict__ a, int b, int C, int HW, int px, int q,
+                                             float (&h)[8][4]) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int i = 4 * s + q;
+    for (int c = 0; c < 8; ++c) {
+        const int i = 8 * q + c;
         const float* src = a + ((size_t)b * C + i) * HW + px;
         if constexpr (VEC4) {
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < C && px < HW) t = *reinterpret_cast<const float4*>(src);
-            h[s][0] = t.x; h[s][1] = t.y; h[s][2] = t.z; h[s][3] = t.w;
+            h[c][0] = t.x; h[c][1] = t.y; h[c][2] = t.z; h[c][3] = t.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h[s][j] = (i < C && px + j < HW) ? src[j] : 0.f;
+            for (int j = 0; j < 4; ++j) h[c][j] = (i < C && px + j < HW) ? src[j] : 0.f;
         }
-        if constexpr (ACT) {
+        if constexpr (ACT) cfd_gelu4(h[c][0], h[c][1], h[c][2], h[c][3]);
+    }
+}
+
+// split-bf16 A-operand fragments of fc1 for z = W1 h:  frag[mt][lane=(q,i)][v] = w1[16mt+i][8q+v]
+__device__ __forceinline__ void head_build_w1f(bf16x8* s_hi, bf16x8* s_lo, const float* __restrict__ w1, int C) {
+    for (int idx = threadIdx.x; idx < HEAD_MT * 64; idx += blockDim.x) {
+        const int ln = idx & 63, mt = idx >> 6;
+        const int jh = 16 * mt + (ln & 15), c0 = 8 * (ln >> 4);
+        float x[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h[s][j] = cfd_gelu(h[s][j]);
-        }
+        for (int v = 0; v < 8; ++v) x[v] = c0 + v < C ? w1[jh * C + c0 + v] : 0.f;
+        const CfdSplit8 s = cfd_split8(x);
+        s_hi[idx] = s.hi;
+        s_lo[idx] = s.lo;
     }
 }
 
-// A-operand fragments of fc1 for z = W1 h:  frag[mt][s][lane=(q,i)] = w1[16mt+i][4s+q]
-template <int KS>
-__device__ __forceinline__ void head_build_w1f(float* s_w1f, const float* __restrict__ w1, int C) {
-    for (int idx = threadIdx.x; idx < HEAD_MT * KS * 64; idx += blockDim.x) {
-        const int ln = idx & 63, s = (idx >> 6) % KS, mt = idx / (64 * KS);
-        const int jh = 16 * mt + (ln & 15), i = 4 * s + (ln >> 4);
-        s_w1f[idx] = i < C ? w1[jh * C + i] : 0.f;
-    }
-}
-
-template <int KS, bool VEC4, bool ACT>
+template <bool VEC4, bool ACT>
 __global__ __launch_bounds__(256, 2) void k_head_fwd(const float* __restrict__ a, const float* __restrict__ mask,
                                                   const float* __restrict__ label, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                                   const float* __restrict__ b2, float* __restrict__ preds,
                                                   float* __restrict__ part, int B, int C, int Co, int HW) {
-    __shared__ float s_w1f[HEAD_MT * KS * 64];
+    __shared__ bf16x8 s_w1hi[HEAD_MT * 64], s_w1lo[HEAD_MT * 64];
     __shared__ float s_b1[HEAD_HD];
-    __shared__ float s_w2[2 * HEAD_HD];
+    __shared__ cfd_f2 s_w2[HEAD_HD];  // (w2[0][jh], w2[1][jh]) pairs: one packed FMA updates both outputs
     __shared__ float s_red[12];
-    head_build_w1f<KS>(s_w1f, w1, C);
+    head_build_w1f(s_w1hi, s_w1lo, w1, C);
     for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x) s_b1[i] = b1[i];
-    for (int i = threadIdx.x; i < 2 * HEAD_HD; i += blockDim.x) s_w2[i] = (i / HEAD_HD) < Co ? w2[i] : 0.f;
+    for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x) s_w2[i] = cfd_f2{w2[i], Co > 1 ? w2[HEAD_HD + i] : 0.f};
     __syncthreads();
     const float b2v0 = b2[0], b2v1 = Co > 1 ? b2[1] : 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -83,41 +90,50 @@ __global__ __launch_bounds__(256, 2) void k_head_fwd(const float* __restrict__ a
     for (long tile = (long)blockIdx.x * 4 + wave; tile < total; tile += (long)gridDim.x * 4) {
         const int b = (int)(tile / tpb);
         const int px = (int)(tile - (long)b * tpb) * 64 + 4 * n;
-        float h[KS][4];
-        head_load_h<KS, VEC4, ACT>(a, b, C, HW, px, q, h);
+        float h[8][4];
+        head_load_h8<VEC4, ACT>(a, b, C, HW, px, q, h);
         // The 4 pixel phases j run in a ROLLED loop (one 16-pixel sub-tile per trip keeps the live set at one
-        // z tile); the phase being processed always sits in h[s][0] / lands in out*[3], registers rotate each trip.
+        // z tile); the phase being processed always sits in h[c][0] / lands in out*[3], registers rotate each trip.
         float out0[4] = {0.f, 0.f, 0.f, 0.f}, out1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int j = 0; j < 4; ++j) {
             const int lo = cfd_opaque(lane), q4 = cfd_opaque(4 * q);  // keep the LDS table reads inside the loop
+            float xk[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xk[c] = h[c][0];
+            const CfdSplit8 bs = cfd_split8(xk);
             f32x4 z[HEAD_MT];
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt) {
                 const int jb = 16 * mt + q4;
                 z[mt] = f32x4{s_b1[jb], s_b1[jb + 1], s_b1[jb + 2], s_b1[jb + 3]};
             }
+            // z += W1 h as w_lo*h_hi + w_hi*h_lo + w_hi*h_hi (term-major: consecutive MFMAs hit different accumulators)
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
+            for (int mt = 0; mt < HEAD_MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(s_w1lo[mt * 64 + lo], bs.hi, z[mt]);
 #pragma unroll
-                for (int mt = 0; mt < HEAD_MT; ++mt)
-                    z[mt] = cfd_mfma16x16x4(s_w1f[(mt * KS + s) * 64 + lo], h[s][0], z[mt]);
-            float o0 = 0.f, o1 = 0.f;
+            for (int mt = 0; mt < HEAD_MT; ++mt) {
+                const bf16x8 whi = s_w1hi[mt * 64 + lo];
+                z[mt] = cfd_mfma16x16x32_bf16(whi, bs.lo, z[mt]);
+                z[mt] = cfd_mfma16x16x32_bf16(whi, bs.hi, z[mt]);
+            }
+            cfd_f2 o01 = {0.f, 0.f};
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 4; r += 2) {
                     const int jh = 16 * mt + q4 + r;
-                    const float gl = cfd_gelu(z[mt][r]);
-                    o0 = fmaf(s_w2[jh], gl, o0);
-                    o1 = fmaf(s_w2[HEAD_HD + jh], gl, o1);
+                    const cfd_f2 gl = cfd_gelu2(cfd_f2{z[mt][r], z[mt][r + 1]});
+                    o01 = cfd_fma2(s_w2[jh], (cfd_f2)(gl.x), o01);
+                    o01 = cfd_fma2(s_w2[jh + 1], (cfd_f2)(gl.y), o01);
                 }
+            float o0 = o01.x, o1 = o01.y;
             o0 += cfd_shfl_xor(o0, 16); o0 += cfd_shfl_xor(o0, 32);
             o1 += cfd_shfl_xor(o1, 16); o1 += cfd_shfl_xor(o1, 32);
             out0[0] = out0[1]; out0[1] = out0[2]; out0[2] = out0[3]; out0[3] = o0;
             out1[0] = out1[1]; out1[1] = out1[2]; out1[2] = out1[3]; out1[3] = o1;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) { h[s][0] = h[s][1]; h[s][1] = h[s][2]; h[s][2] = h[s][3]; }
+            for (int c = 0; c < 8; ++c) { h[c][0] = h[c][1]; h[c][1] = h[c][2]; h[c][2] = h[c][3]; }
         }
         if (q < Co) {  // lane group q stores output channel q
             const int c = q;
@@ -198,20 +214,13 @@ extern "C" int cfd_fno_head_fwd(const float* a, const float* mask, const float* 
     const bool v4 = HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)preds % 16) == 0;
     {
     CFD_PROF("k_head_fwd", st);
-#define CFD_HF(K_, V_, A_)                                                                                      \
-    hipLaunchKernelGGL((k_head_fwd<K_, V_, A_>), dim3(blocks), dim3(256), 0, st, a, mask, label, w1, b1, w2, b2, \
+#define CFD_HF(V_, A_)                                                                                      \
+    hipLaunchKernelGGL((k_head_fwd<V_, A_>), dim3(blocks), dim3(256), 0, st, a, mask, label, w1, b1, w2, b2, \
                        preds, part, B, C, Co, HW)
-#define CFD_HF_VA(K_)                              \
-    do {                                           \
-        if (v4 && act_in) CFD_HF(K_, true, true);  \
-        else if (v4) CFD_HF(K_, true, false);      \
-        else if (act_in) CFD_HF(K_, false, true);  \
-        else CFD_HF(K_, false, false);             \
-    } while (0)
-    if (C <= 8) CFD_HF_VA(2);
-    else if (C <= 20) CFD_HF_VA(5);
-    else CFD_HF_VA(8);
-#undef CFD_HF_VA
+    if (v4 && act_in) CFD_HF(true, true);
+    else if (v4) CFD_HF(true, false);
+    else if (act_in) CFD_HF(false, true);
+    else CFD_HF(false, false);
 #undef CFD_HF
     }
     CFD_LAUNCH_CHECK("cfd_fno_head_fwd");
@@ -228,59 +237,79 @@ extern "C" int cfd_fno_head_fwd(const float* a, const float* mask, const float* 
 // ------------------------------------------------------------------------------------------------------
 // The four waves of a workgroup share one 64-pixel tile and split the 128 hidden units: wave w owns hidden units
 // [32w, 32w+32) (two MFMA M-tiles).  Everything indexed by hidden unit -- the recomputed pre-activation, GELU and its
-// derivative, the fc2 weight gradient (per-lane VALU accumulators), the fc1 weight/bias gradient (MFMA, K = pixels,
-// operands transposed through a wave-private LDS tile) -- is wave-local, and all weight fragments of the slice are
-// loop-invariant registers.  Only d/dh = W1^T gz sums over hidden units: each wave contributes its partial through
-// LDS once per tile and the workgroup finishes ga = d/dh * f'(a) with coalesced float4 stores.
-// A wave issues 42 MFMAs per 16-pixel phase (10 recompute + 16 d/dh + 16 weight gradient) on ~150 registers, so
-// several waves per SIMD overlap MFMA with GELU/LDS work (the one-wave-owns-128-units version needed 450 registers).
+// derivative, the fc2 weight gradient and fc1 bias gradient (per-lane VALU accumulators), the fc1 weight gradient
+// (MFMA, K = pixels) -- is wave-local, and all weight fragments of the slice are loop-invariant registers.
+// All three GEMMs run as split-bf16 (3-term) MFMAs with K = 32:
+//   recompute   z[hidden][px]  = W1 h          K = channel slots (q, v) <-> channel 8q + v
+//   d/dh part   [channel][px]  = W1^T gz       K = this wave's 32 hidden units in ACCUMULATOR order: slot (q, v) <->
+//               hidden 16(v/4) + 4q + v%4, so the gz registers feed the B operand without any data movement
+//   gw1         [hidden][chan] += gz h^T       K = pixels, once per tile in two K = 32 steps; both operands are
+//               stored transposed in LDS as bf16 hi/lo planes [row][64 pixels] (one ds_read_b128 per fragment);
+//               the h^T planes are shared by the four waves (wave w stores pixel phase w)
+// d/dh sums over hidden units: each wave contributes its partial through LDS once per tile and the workgroup
+// finishes ga = d/dh * f'(a) with coalesced float4 stores.  72 bf16 MFMAs (~17 cycles each) per wave and tile replace
+// the 168 fp32 MFMAs (32 cycles each) of the exact-fp32 version.
 template <int KS, bool VEC4, bool ACT>
 __global__ __launch_bounds__(256, 2) void k_head_bwd(
     const float* __restrict__ a, const float* __restrict__ mask, const float* __restrict__ label,
     const float* __restrict__ preds, const float* __restrict__ gext, const float* __restrict__ coef,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, float* __restrict__ ga,
     float* __restrict__ part, int B, int C, int Co, int HW) {
-    constexpr int CP = 4 * KS;                   // padded channel count
-    constexpr int MU = (CP + 15) / 16;           // M tiles of the channel axis for d/dh
-    constexpr int NTI = (CP + 1 + 15) / 16;      // N tiles of [channels | ones] for the fc1 weight/bias gradient
-    constexpr int XR = 32 * HEAD_LD;             // transposed gz tile of one wave   [32 hidden][17]
-    constexpr int HR = 16 * NTI * HEAD_LD;       // transposed input tile of one wave [16*NTI][17]
-    __shared__ float s_t[4 * (XR + HR)];
-    __shared__ float4 s_red[4 * CP * 16];        // [wave][channel][16 x float4 = 64 pixels] partial d/dh
+    constexpr int CP = 4 * KS;          // padded channel count (rows of the d/dh exchange buffer)
+    constexpr int MU = (CP + 15) / 16;  // 16-channel tiles
+    constexpr int LDW = 72;             // bf16 row stride of the transposed planes: 64 pixels + 8 pad (144 B)
+    __shared__ __attribute__((aligned(16))) __bf16 s_xh[4 * 32 * LDW];   // per wave gz^T [32 hidden][64 px], hi
+    __shared__ __attribute__((aligned(16))) __bf16 s_xl[4 * 32 * LDW];   //                                   lo
+    __shared__ __attribute__((aligned(16))) __bf16 s_hh[16 * MU * LDW];  // shared h^T [channel][64 px], hi
+    __shared__ __attribute__((aligned(16))) __bf16 s_hl[16 * MU * LDW];  //                              lo
+    __shared__ float4 s_red[4 * CP * 16];  // [wave][channel][16 x float4 = 64 pixels] partial d/dh
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
-    for (int i = threadIdx.x; i < 4 * (XR + HR); i += blockDim.x) s_t[i] = 0.f;
-    float* s_x = s_t + wave * (XR + HR);
-    float* s_h = s_x + XR;
-    // ---- loop-invariant fragments of this wave's hidden slice (global hidden tile mt = 2*wave + t) ----
-    float w1f[2][KS];   // A operand of z = W1 h:        w1[16mt + n][4s + q]
-    float w1t[MU][8];   // A operand of d/dh = W1^T gz:  w1[16mt + 4q + r][16mu + n], k-step 4t + r
-    float bz[2][4], w2a[2][4], w2b[2][4];  // b1, w2[0], w2[1] at hidden unit 16mt + 4q + r
+    for (int i = threadIdx.x; i < 16 * MU * LDW; i += blockDim.x) { s_hh[i] = (__bf16)0.f; s_hl[i] = (__bf16)0.f; }
+    __bf16* s_xhw = s_xh + wave * 32 * LDW;
+    __bf16* s_xlw = s_xl + wave * 32 * LDW;
+    // ---- loop-invariant fragments of this wave's hidden slice ----
+    CfdSplit8 w1f[2];   // A operand of z = W1 h:        w1[32w + 16t + n][8q + v]
+    CfdSplit8 w1t[MU];  // A operand of d/dh = W1^T gz:  w1[32w + 16(v/4) + 4q + v%4][16mu + n]
+    float bz[2][4];                // b1 at hidden unit 32w + 16t + 4q + r
+    cfd_f2 w2a[2][2], w2b[2][2];   // w2[0], w2[1] at hidden units 32w + 16t + 4q + {2v, 2v+1}
+    {
+        float x[8];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int mt = 2 * wave + t;
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) w1f[t][s] = (4 * s + q < C) ? w1[(16 * mt + n) * C + 4 * s + q] : 0.f;
+            for (int v = 0; v < 8; ++v) x[v] = (8 * q + v < C) ? w1[(32 * wave + 16 * t + n) * C + 8 * q + v] : 0.f;
+            w1f[t] = cfd_split8(x);
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int jh = 16 * mt + 4 * q + r;
-            bz[t][r] = b1[jh];
-            w2a[t][r] = w2[jh];
-            w2b[t][r] = Co > 1 ? w2[HEAD_HD + jh] : 0.f;
+        for (int mu = 0; mu < MU; ++mu) {
 #pragma unroll
-            for (int mu = 0; mu < MU; ++mu) w1t[mu][4 * t + r] = (16 * mu + n < C) ? w1[jh * C + 16 * mu + n] : 0.f;
+            for (int v = 0; v < 8; ++v) {
+                const int jh = 32 * wave + 16 * (v >> 2) + 4 * q + (v & 3);
+                x[v] = (16 * mu + n < C) ? w1[jh * C + 16 * mu + n] : 0.f;
+            }
+            w1t[mu] = cfd_split8(x);
         }
     }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jh = 32 * wave + 16 * t + 4 * q + r;
+            bz[t][r] = b1[jh];
+            w2a[t][r >> 1][r & 1] = w2[jh];
+            w2b[t][r >> 1][r & 1] = Co > 1 ? w2[HEAD_HD + jh] : 0.f;
+        }
     const float c0 = label ? coef[0] : 0.f, c1 = label ? coef[1] : 0.f;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 aw1[2][NTI];
-    float acc2a[2][4], acc2b[2][4];
+    f32x4 aw1[2][MU];
+    cfd_f2 acc2a[2][2], acc2b[2][2], accb1[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int v = 0; v < NTI; ++v) aw1[t][v] = zero;
+        for (int v = 0; v < MU; ++v) aw1[t][v] = zero;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { acc2a[t][r] = 0.f; acc2b[t][r] = 0.f; }
+        for (int v = 0; v < 2; ++v) { acc2a[t][v] = cfd_f2{0.f, 0.f}; acc2b[t][v] = cfd_f2{0.f, 0.f}; accb1[t][v] = cfd_f2{0.f, 0.f}; }
     }
     float gb2a0 = 0.f, gb2a1 = 0.f;
     __syncthreads();
@@ -290,8 +319,8 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
         const int b = (int)(tile / tpb);
         const int px0 = (int)(tile - (long)b * tpb) * 64;
         const int px = px0 + 4 * n;
-        float h[KS][4];
-        head_load_h<KS, VEC4, ACT>(a, b, C, HW, px, q, h);
+        float h[8][4];
+        head_load_h8<VEC4, ACT>(a, b, C, HW, px, q, h);
         // upstream gradient on the raw head output for this lane's 4 pixels (same for every q)
         float gr0[4], gr1[4];
 #pragma unroll
@@ -320,79 +349,114 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
 #pragma unroll
             for (int j = 0; j < 4; ++j) { gb2a0 += gr0[j]; gb2a1 += gr1[j]; }
         }
-        // The 4 pixel phases, unrolled (static register indices: no rotation moves).
-        f32x4 gh[MU][4];
-#pragma unroll
-        for (int mu = 0; mu < MU; ++mu)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) gh[mu][j] = zero;
-#pragma unroll
+        // The 4 pixel phases (phase j of lane n is pixel 4n + j of the tile = column 16j + n of the LDS planes) run
+        // in a ROLLED loop: the phase being processed sits in h[c][0] / gr*[0] and the registers rotate each trip,
+        // which keeps the live set at one phase (the unrolled form spilled ~130 registers).
+        float* s_redf = reinterpret_cast<float*>(s_red);
+#pragma unroll 1
         for (int j = 0; j < 4; ++j) {
             // 1. recompute this wave's slice of the hidden pre-activation z[hidden][pixel n]
+            float xk[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xk[c] = h[c][0];
+            const CfdSplit8 hs = cfd_split8(xk);
             f32x4 z[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) z[t] = f32x4{bz[t][0], bz[t][1], bz[t][2], bz[t][3]};
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
+            for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].lo, hs.hi, z[t]);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x4(w1f[t][s], h[s][j], z[t]);
-            // 2. a1 = gelu(z) feeds the fc2 weight gradient; gz = (W2^T graw) * gelu'(z) replaces z
+            for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].hi, hs.lo, z[t]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].hi, hs.hi, z[t]);
+            const int col = 16 * j + n;
+            // wave w publishes pixel phase w of the (wave-independent) transposed input planes
+            if (j == wave) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (8 * q + c < C) {
+                        s_hh[(8 * q + c) * LDW + col] = hs.hi[c];
+                        s_hl[(8 * q + c) * LDW + col] = hs.lo[c];
+                    }
+            }
+            // 2. a1 = gelu(z) feeds the fc2 weight gradient; gz = (W2^T graw) * gelu'(z), k-slot 4t + r
+            float gzv[8];
+            const cfd_f2 g0 = (cfd_f2)(gr0[0]), g1 = (cfd_f2)(gr1[0]);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float Phi, e;
-                    cfd_gelu_terms(z[t][r], Phi, e);
-                    const float a1 = z[t][r] * Phi;
-                    acc2a[t][r] = fmaf(gr0[j], a1, acc2a[t][r]);
-                    acc2b[t][r] = fmaf(gr1[j], a1, acc2b[t][r]);
-                    const float ga1 = fmaf(w2a[t][r], gr0[j], w2b[t][r] * gr1[j]);
-                    const float gz = ga1 * fmaf(z[t][r] * CFD_INV_SQRT_2PI, e, Phi);
-                    z[t][r] = gz;
-                    s_x[(16 * t + 4 * q + r) * HEAD_LD + n] = gz;
+                for (int v = 0; v < 2; ++v) {  // packed pairs of hidden units r = 2v, 2v+1
+                    const cfd_f2 zz = {z[t][2 * v], z[t][2 * v + 1]};
+                    cfd_f2 Phi, e;
+                    cfd_gelu_terms2(zz, Phi, e);
+                    const cfd_f2 a1 = zz * Phi;
+                    acc2a[t][v] = cfd_fma2(g0, a1, acc2a[t][v]);
+                    acc2b[t][v] = cfd_fma2(g1, a1, acc2b[t][v]);
+                    const cfd_f2 ga1 = cfd_fma2(w2a[t][v], g0, w2b[t][v] * g1);
+                    const cfd_f2 gz = ga1 * cfd_fma2(zz * (cfd_f2)(CFD_INV_SQRT_2PI), e, Phi);
+                    accb1[t][v] = accb1[t][v] + gz;
+                    gzv[4 * t + 2 * v] = gz.x;
+                    gzv[4 * t + 2 * v + 1] = gz.y;
                 }
-            // 3. transposed input tile [channel | ones][pixel]
+            const CfdSplit8 gs = cfd_split8(gzv);
+            // 3. transposed gz planes of this wave: row = local hidden unit 16t + 4q + r, column 16j + n
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
-                if (4 * s + q < C) s_h[(4 * s + q) * HEAD_LD + n] = h[s][j];
-            if (q == 0) s_h[C * HEAD_LD + n] = (px + j < HW) ? 1.f : 0.f;
-            cfd_wave_lds_sync();
-            // 4. partial d/dh[i][pixel] = sum over this wave's hidden units w1[jh][i] gz[jh][pixel]
+            for (int v = 0; v < 8; ++v) {
+                const int row = 16 * (v >> 2) + 4 * q + (v & 3);
+                s_xhw[row * LDW + col] = gs.hi[v];
+                s_xlw[row * LDW + col] = gs.lo[v];
+            }
+            // 4. partial d/dh[channel][pixel] = sum over this wave's hidden units w1[jh][channel] gz[jh][pixel]
             f32x4 ghc[MU];
 #pragma unroll
-            for (int mu = 0; mu < MU; ++mu) ghc[mu] = zero;
+            for (int mu = 0; mu < MU; ++mu) ghc[mu] = cfd_mfma16x16x32_bf16(w1t[mu].lo, gs.hi, zero);
+#pragma unroll
+            for (int mu = 0; mu < MU; ++mu) ghc[mu] = cfd_mfma16x16x32_bf16(w1t[mu].hi, gs.lo, ghc[mu]);
+#pragma unroll
+            for (int mu = 0; mu < MU; ++mu) ghc[mu] = cfd_mfma16x16x32_bf16(w1t[mu].hi, gs.hi, ghc[mu]);
+            // this wave's partial d/dh of the tile: [channel][64 pixels], pixel = 4n + phase
+#pragma unroll
+            for (int mu = 0; mu < MU; ++mu)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * mu + 4 * q + r;
+                    if (i < CP) s_redf[((wave * CP + i) * 16 + n) * 4 + j] = ghc[mu][r];
+                }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { h[c][0] = h[c][1]; h[c][1] = h[c][2]; h[c][2] = h[c][3]; }
+            gr0[0] = gr0[1]; gr0[1] = gr0[2]; gr0[2] = gr0[3];
+            gr1[0] = gr1[1]; gr1[1] = gr1[2]; gr1[2] = gr1[3];
+        }
+        __syncthreads();
+        // 5. gw1[hidden][channel] += sum over the tile's 64 pixels gz[hidden][pixel] h[channel][pixel]  (2 K-steps)
+#pragma unroll
+        for (int kap = 0; kap < 2; ++kap) {
+            bf16x8 ah[2], al[2], bh[MU], bl[MU];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int o = (16 * t + n) * LDW + 32 * kap + 8 * q;
+                ah[t] = *reinterpret_cast<const bf16x8*>(s_xhw + o);
+                al[t] = *reinterpret_cast<const bf16x8*>(s_xlw + o);
+            }
+#pragma unroll
+            for (int mu = 0; mu < MU; ++mu) {
+                const int o = (16 * mu + n) * LDW + 32 * kap + 8 * q;
+                bh[mu] = *reinterpret_cast<const bf16x8*>(s_hh + o);
+                bl[mu] = *reinterpret_cast<const bf16x8*>(s_hl + o);
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int mu = 0; mu < MU; ++mu) aw1[t][mu] = cfd_mfma16x16x32_bf16(al[t], bh[mu], aw1[t][mu]);
 #pragma unroll
-                    for (int mu = 0; mu < MU; ++mu) ghc[mu] = cfd_mfma16x16x4(w1t[mu][4 * t + r], z[t][r], ghc[mu]);
-            // 5. gw1[jh][i] (+ gb1 through the ones column) += sum_pixel gz[jh][pixel] h[i][pixel]
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                float bh[NTI];
+                for (int mu = 0; mu < MU; ++mu) aw1[t][mu] = cfd_mfma16x16x32_bf16(ah[t], bl[mu], aw1[t][mu]);
 #pragma unroll
-                for (int v = 0; v < NTI; ++v) bh[v] = s_h[(16 * v + n) * HEAD_LD + 4 * s4 + q];
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const float ax = s_x[(16 * t + n) * HEAD_LD + 4 * s4 + q];
-#pragma unroll
-                    for (int v = 0; v < NTI; ++v) aw1[t][v] = cfd_mfma16x16x4(ax, bh[v], aw1[t][v]);
-                }
-            }
-            cfd_wave_lds_sync();
-#pragma unroll
-            for (int mu = 0; mu < MU; ++mu) gh[mu][j] = ghc[mu];
+                for (int mu = 0; mu < MU; ++mu) aw1[t][mu] = cfd_mfma16x16x32_bf16(ah[t], bh[mu], aw1[t][mu]);
         }
-        // this wave's partial d/dh of the tile: [channel][64 pixels], pixel = 4n + phase
-#pragma unroll
-        for (int mu = 0; mu < MU; ++mu)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * mu + 4 * q + r;
-                if (i < CP) s_red[(wave * CP + i) * 16 + n] = make_float4(gh[mu][0][r], gh[mu][1][r], gh[mu][2][r], gh[mu][3][r]);
-            }
-        __syncthreads();
         // ga[b][i][px0 .. px0+63] = (sum over the four hidden slices) * f'(a)
         for (int e = threadIdx.x; e < C * 16; e += blockDim.x) {
             const int i = e >> 4, n4 = e & 15;
@@ -407,9 +471,9 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
             if constexpr (VEC4) {
                 if (p4 < HW) {
                     if constexpr (ACT) {
-                        const float4 av = *reinterpret_cast<const float4*>(a + off);
-                        v.x *= cfd_gelu_grad(av.x); v.y *= cfd_gelu_grad(av.y);
-                        v.z *= cfd_gelu_grad(av.z); v.w *= cfd_gelu_grad(av.w);
+                        float4 gg = *reinterpret_cast<const float4*>(a + off);
+                        cfd_gelu_grad4(gg.x, gg.y, gg.z, gg.w);
+                        v.x *= gg.x; v.y *= gg.y; v.z *= gg.z; v.w *= gg.w;
                     }
                     *reinterpret_cast<float4*>(ga + off) = v;
                 }
@@ -433,17 +497,18 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int jh = 16 * (2 * wave + t) + 4 * q + r;
+            const int jh = 32 * wave + 16 * t + 4 * q + r;
 #pragma unroll
-            for (int v = 0; v < NTI; ++v) {
+            for (int v = 0; v < MU; ++v) {
                 const int i = 16 * v + n;
                 if (i < C) dst[jh * C + i] = aw1[t][v][r];
-                else if (i == C) dst[o_gb1 + jh] = aw1[t][v][r];
             }
-            float sa = acc2a[t][r], sb = acc2b[t][r];  // sum over the 16 pixel lanes of this q group
+            // sums over the 16 pixel lanes of this q group
+            float sa = acc2a[t][r >> 1][r & 1], sb = acc2b[t][r >> 1][r & 1], s1 = accb1[t][r >> 1][r & 1];
 #pragma unroll
-            for (int m = 1; m <= 8; m <<= 1) { sa += cfd_shfl_xor(sa, m); sb += cfd_shfl_xor(sb, m); }
+            for (int m = 1; m <= 8; m <<= 1) { sa += cfd_shfl_xor(sa, m); sb += cfd_shfl_xor(sb, m); s1 += cfd_shfl_xor(s1, m); }
             if (n == 0) {
+                dst[o_gb1 + jh] = s1;
                 dst[o_gw2 + jh] = sa;
                 if (Co > 1) dst[o_gw2 + HEAD_HD + jh] = sb;
             }

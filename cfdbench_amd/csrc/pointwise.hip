@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void k_chanmix(const float* __restrict__ in, c
             }
             if constexpr (ACT) {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) v[k] = cfd_gelu(v[k]);
+                for (int k = 0; k + 1 < VEC; k += 2) { const cfd_f2 g2 = cfd_gelu2(cfd_f2{v[k], v[k + 1]}); v[k] = g2.x; v[k + 1] = g2.y; }
+                if constexpr (VEC & 1) v[VEC - 1] = cfd_gelu(v[VEC - 1]);
             }
 #pragma unroll
             for (int o = 0; o < CPO; ++o) {
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
             for (int c = 0; c < NT; ++c)
                 if (16 * c + n < CiIn) {  // the ones / generated columns are not activations
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bv[c][j] = cfd_gelu(bv[c][j]);
+                    for (int j = 0; j < 4; j += 2) { const cfd_f2 g2 = cfd_gelu2(cfd_f2{bv[c][j], bv[c][j + 1]}); bv[c][j] = g2.x; bv[c][j + 1] = g2.y; }
                 }
         }
 #pragma unroll

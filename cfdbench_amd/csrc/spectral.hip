@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES) void k_dft_fwd(const float* __restr
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 float vv = v[j], uu = u[j];
-                if constexpr (ACT) { vv = cfd_gelu(vv); uu = cfd_gelu(uu); }  // gelu(0) = 0 keeps the zero fill
+                if constexpr (ACT) { const cfd_f2 g2 = cfd_gelu2(cfd_f2{vv, uu}); vv = g2.x; uu = g2.y; }  // gelu(0) = 0 keeps the zero fill
                 a1c[j] = cfd_mfma16x16x4(vv + uu, tc, a1c[j]);
                 a1s[j] = cfd_mfma16x16x4(vv - uu, ts, a1s[j]);
             }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64(const float* __
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     float aa = a[j], bb = is_paired(s) ? b[j] : 0.f;
-                    if constexpr (ACT) { aa = cfd_gelu(aa); bb = cfd_gelu(bb); }  // gelu(0) = 0 keeps the zero fill
+                    if constexpr (ACT) { const cfd_f2 g2 = cfd_gelu2(cfd_f2{aa, bb}); aa = g2.x; bb = g2.y; }  // gelu(0) = 0 keeps the zero fill
                     e[j] = aa + bb;
                     o[j] = aa - bb;
                 }
@@ -694,8 +694,9 @@ __global__ __launch_bounds__(64 * CFD_WAVES) void k_idft(const float* __restrict
                 float4 v = make_float4(accB[0][r], accB[1][r], accB[2][r], accB[3][r]);
                 if constexpr (EPI >= 1) { v.x += ad[r].x; v.y += ad[r].y; v.z += ad[r].z; v.w += ad[r].w; }
                 if constexpr (EPI == 2) {
-                    v.x *= cfd_gelu_grad(ap[r].x); v.y *= cfd_gelu_grad(ap[r].y);
-                    v.z *= cfd_gelu_grad(ap[r].z); v.w *= cfd_gelu_grad(ap[r].w);
+                    float4 gg = ap[r];
+                    cfd_gelu_grad4(gg.x, gg.y, gg.z, gg.w);
+                    v.x *= gg.x; v.y *= gg.y; v.z *= gg.z; v.w *= gg.w;
                 }
                 if (xx < H && cok) *reinterpret_cast<float4*>(out + ibase + (size_t)xx * W + 4 * n) = v;
             }
@@ -791,8 +792,9 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __res
                 float4 v = make_float4(accB[0][r], accB[1][r], accB[2][r], accB[3][r]);
                 if constexpr (EPI >= 1) { v.x += ad[r].x; v.y += ad[r].y; v.z += ad[r].z; v.w += ad[r].w; }
                 if constexpr (EPI == 2) {
-                    v.x *= cfd_gelu_grad(ap[r].x); v.y *= cfd_gelu_grad(ap[r].y);
-                    v.z *= cfd_gelu_grad(ap[r].z); v.w *= cfd_gelu_grad(ap[r].w);
+                    float4 gg = ap[r];
+                    cfd_gelu_grad4(gg.x, gg.y, gg.z, gg.w);
+                    v.x *= gg.x; v.y *= gg.y; v.z *= gg.z; v.w *= gg.w;
                 }
                 *reinterpret_cast<float4*>(out + ibase + (size_t)(16 * t + 4 * q + r) * W) = v;
             }
@@ -944,7 +946,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float4 v = r[k];
-            if constexpr (ACT) { v.x = cfd_gelu(v.x); v.y = cfd_gelu(v.y); v.z = cfd_gelu(v.z); v.w = cfd_gelu(v.w); }
+            if constexpr (ACT) cfd_gelu4(v.x, v.y, v.z, v.w);
             if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
             s_src[((buf * NW + wave) * 16 + 4 * k + q) * 16 + n] = v;
         }
@@ -1075,8 +1077,9 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                 for (int r = 0; r < 4; ++r) {
                     float4 v = make_float4(acc[dd][0][r], acc[dd][1][r], acc[dd][2][r], acc[dd][3][r]);
                     if constexpr (DGELU) {
-                        v.x *= cfd_gelu_grad(ap[r].x); v.y *= cfd_gelu_grad(ap[r].y);
-                        v.z *= cfd_gelu_grad(ap[r].z); v.w *= cfd_gelu_grad(ap[r].w);
+                        float4 gg = ap[r];
+                        cfd_gelu_grad4(gg.x, gg.y, gg.z, gg.w);
+                        v.x *= gg.x; v.y *= gg.y; v.z *= gg.z; v.w *= gg.w;
                     }
                     *reinterpret_cast<float4*>(o + (size_t)r * W) = v;
                 }

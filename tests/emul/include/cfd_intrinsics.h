@@ -25,6 +25,27 @@ inline f32x4 cfd_mfma16x16x4(float a, float b, f32x4 c) {
     return d;
 }
 
+// v_mfma_f32_16x16x32_bf16: a = A[i=lane&15][k=8*(lane>>4)+v], b = B[k=8*(lane>>4)+v][j=lane&15], v = 0..7;
+// c/d as the 16x16x4 form.  bf16 products are exact in fp32; the hardware's internal summation order is not
+// architected, so the emulator sums in k order in fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+inline f32x4 cfd_mfma16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    auto& w = cfd_emul::wave();
+    const int l = cfd_emul::lane();
+    for (int v = 0; v < 8; ++v) { w.fa8[l][v] = (float)a[v]; w.fb8[l][v] = (float)b[v]; }
+    cfd_emul::wave_sync();
+    f32x4 d = c;
+    const int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) acc += w.fa8[(k >> 3) * 16 + row][k & 7] * w.fb8[(k >> 3) * 16 + col][k & 7];
+        d[r] = acc;
+    }
+    cfd_emul::wave_sync();
+    return d;
+}
+
 inline float cfd_shfl_xor(float v, int mask) {
     auto& w = cfd_emul::wave();
     const int l = cfd_emul::lane();
@@ -54,3 +75,8 @@ inline int cfd_uniform(int x) { return x; }
 inline float cfd_erff(float x) { return erff(x); }
 inline float cfd_expf(float x) { return expf(x); }
 inline float cfd_rcpf(float x) { return 1.0f / x; }
+inline float cfd_exp2f(float x) { return exp2f(x); }
+
+typedef float cfd_f2 __attribute__((ext_vector_type(2)));
+inline cfd_f2 cfd_fma2(cfd_f2 a, cfd_f2 b, cfd_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+inline cfd_f2 cfd_abs2(cfd_f2 a) { return __builtin_elementwise_abs(a); }

@@ -73,6 +73,7 @@ inline int g_nthreads = 1;
 struct WaveCtx {
     pthread_barrier_t bar;
     float fa[64], fb[64];
+    float fa8[64][8], fb8[64][8];  // per-lane 8-element operands of the K=32 MFMA forms
     unsigned ua[64];
     int lanes;
 };
