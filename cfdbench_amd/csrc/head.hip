@@ -239,16 +239,19 @@ extern "C" int cfd_fno_head_fwd(const float* a, const float* mask, const float* 
 // [32w, 32w+32) (two MFMA M-tiles).  Everything indexed by hidden unit -- the recomputed pre-activation, GELU and its
 // derivative, the fc2 weight gradient and fc1 bias gradient (per-lane VALU accumulators), the fc1 weight gradient
 // (MFMA, K = pixels) -- is wave-local, and all weight fragments of the slice are loop-invariant registers.
-// All three GEMMs run as split-bf16 (3-term) MFMAs with K = 32:
-//   recompute   z[hidden][px]  = W1 h          K = channel slots (q, v) <-> channel 8q + v
+// The input tile h = f(a) is needed by every wave in two operand layouts, so the WORKGROUP stages it once per tile
+// (load, GELU, bf16 hi/lo split: 1/4 of the per-wave cost, and no padding lanes) into double-buffered LDS planes one
+// tile ahead, with the raw global loads issued two tiles ahead:
+//   s_hk [pixel column][channel]  -> B operand of the recompute (one ds_read_b128 per hi / lo fragment)
+//   s_ht [channel][pixel column]  -> B operand of the fc1 weight gradient
+// (pixel 4n + j of the tile lives in column 16j + n: phase j of lane n).  All three GEMMs are split-bf16 3-term MFMAs, K = 32:
+//   recompute   z[hidden][px]  = W1 h          K = channels
 //   d/dh part   [channel][px]  = W1^T gz       K = this wave's 32 hidden units in ACCUMULATOR order: slot (q, v) <->
 //               hidden 16(v/4) + 4q + v%4, so the gz registers feed the B operand without any data movement
-//   gw1         [hidden][chan] += gz h^T       K = pixels, once per tile in two K = 32 steps; both operands are
-//               stored transposed in LDS as bf16 hi/lo planes [row][64 pixels] (one ds_read_b128 per fragment);
-//               the h^T planes are shared by the four waves (wave w stores pixel phase w)
+//   gw1         [hidden][chan] += gz h^T       K = 32 pixels, after every second phase; gz^T goes through a
+//               wave-private LDS plane pair (wave-level sync only)
 // d/dh sums over hidden units: each wave contributes its partial through LDS once per tile and the workgroup
-// finishes ga = d/dh * f'(a) with coalesced float4 stores.  72 bf16 MFMAs (~17 cycles each) per wave and tile replace
-// the 168 fp32 MFMAs (32 cycles each) of the exact-fp32 version.
+// finishes ga = d/dh * f'(a) with coalesced float4 stores.  Two workgroup barriers per tile.
 template <int KS, bool VEC4, bool ACT>
 __global__ __launch_bounds__(256, 2) void k_head_bwd(
     const float* __restrict__ a, const float* __restrict__ mask, const float* __restrict__ label,
@@ -257,17 +260,20 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     float* __restrict__ part, int B, int C, int Co, int HW) {
     constexpr int CP = 4 * KS;          // padded channel count (rows of the d/dh exchange buffer)
     constexpr int MU = (CP + 15) / 16;  // 16-channel tiles
-    constexpr int LDW = 72;             // bf16 row stride of the transposed planes: 64 pixels + 8 pad (144 B)
-    __shared__ __attribute__((aligned(16))) __bf16 s_xh[4 * 32 * LDW];   // per wave gz^T [32 hidden][64 px], hi
-    __shared__ __attribute__((aligned(16))) __bf16 s_xl[4 * 32 * LDW];   //                                   lo
-    __shared__ __attribute__((aligned(16))) __bf16 s_hh[16 * MU * LDW];  // shared h^T [channel][64 px], hi
-    __shared__ __attribute__((aligned(16))) __bf16 s_hl[16 * MU * LDW];  //                              lo
+    constexpr int LDK = 40;             // bf16 row stride of s_hk: 32 channels + 8 pad (80 B: conflict-free b128 reads)
+    constexpr int LDT = 72;             // bf16 row stride of s_ht: 64 pixel columns + 8 pad (144 B)
+    constexpr int LDX = 40;             // bf16 row stride of the gz^T planes: 32 pixel columns + 8 pad
+    constexpr int NST = (CP * 16 + 255) / 256;  // float4 staging loads per thread and tile
+    __shared__ __attribute__((aligned(16))) __bf16 s_hk[2][2][64 * LDK];       // [buffer][hi/lo][column][channel]
+    __shared__ __attribute__((aligned(16))) __bf16 s_ht[2][2][16 * MU * LDT];  // [buffer][hi/lo][channel][column]
+    __shared__ __attribute__((aligned(16))) __bf16 s_x[4][2][32 * LDX];        // [wave][hi/lo][hidden][32 columns]
     __shared__ float4 s_red[4 * CP * 16];  // [wave][channel][16 x float4 = 64 pixels] partial d/dh
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
-    for (int i = threadIdx.x; i < 16 * MU * LDW; i += blockDim.x) { s_hh[i] = (__bf16)0.f; s_hl[i] = (__bf16)0.f; }
-    __bf16* s_xhw = s_xh + wave * 32 * LDW;
-    __bf16* s_xlw = s_xl + wave * 32 * LDW;
+    for (int i = threadIdx.x; i < 2 * 2 * 64 * LDK; i += blockDim.x) (&s_hk[0][0][0])[i] = (__bf16)0.f;
+    for (int i = threadIdx.x; i < 2 * 2 * 16 * MU * LDT; i += blockDim.x) (&s_ht[0][0][0])[i] = (__bf16)0.f;
+    __bf16* s_xhw = s_x[wave][0];
+    __bf16* s_xlw = s_x[wave][1];
     // ---- loop-invariant fragments of this wave's hidden slice ----
     CfdSplit8 w1f[2];   // A operand of z = W1 h:        w1[32w + 16t + n][8q + v]
     CfdSplit8 w1t[MU];  // A operand of d/dh = W1^T gz:  w1[32w + 16(v/4) + 4q + v%4][16mu + n]
@@ -312,15 +318,64 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
         for (int v = 0; v < 2; ++v) { acc2a[t][v] = cfd_f2{0.f, 0.f}; acc2b[t][v] = cfd_f2{0.f, 0.f}; accb1[t][v] = cfd_f2{0.f, 0.f}; }
     }
     float gb2a0 = 0.f, gb2a1 = 0.f;
-    __syncthreads();
     const int tpb = (HW + 63) / 64;
     const long total = (long)B * tpb;
-    for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {  // all four waves walk the same tiles
+    // ---- cooperative staging: element e = (channel e/16, pixel quad e%16) of a tile ----
+    float4 raw[NST];
+    auto fetch = [&](long tile) {  // raw activations of `tile` -> registers (zeros past the end of the work / image)
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int i = e >> 4, n4 = e & 15;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tile < total && i < C) {
+                const int b = (int)(tile / tpb);
+                const int p4 = (int)(tile - (long)b * tpb) * 64 + 4 * n4;
+                const float* src = a + ((size_t)b * C + i) * HW + p4;
+                if constexpr (VEC4) {
+                    if (p4 < HW) v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (p4 < HW) v.x = src[0];
+                    if (p4 + 1 < HW) v.y = src[1];
+                    if (p4 + 2 < HW) v.z = src[2];
+                    if (p4 + 3 < HW) v.w = src[3];
+                }
+            }
+            raw[k] = v;
+        }
+    };
+    auto stage = [&](int buf) {  // registers -> f(a) -> bf16 hi/lo -> both operand layouts of buffer `buf`
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int i = e >> 4, n4 = e & 15;
+            if (i < C) {
+                float4 v = raw[k];
+                if constexpr (ACT) cfd_gelu4(v.x, v.y, v.z, v.w);
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const __bf16 hi = (__bf16)vv[j];
+                    const __bf16 lo = (__bf16)(vv[j] - (float)hi);
+                    const int col = 16 * j + n4;
+                    s_hk[buf][0][col * LDK + i] = hi;
+                    s_hk[buf][1][col * LDK + i] = lo;
+                    s_ht[buf][0][i * LDT + col] = hi;
+                    s_ht[buf][1][i * LDT + col] = lo;
+                }
+            }
+        }
+    };
+    __syncthreads();  // planes zeroed
+    fetch(blockIdx.x);
+    stage(0);
+    fetch((long)blockIdx.x + gridDim.x);
+    __syncthreads();
+    int buf = 0;
+    for (long tile = blockIdx.x; tile < total; tile += gridDim.x, buf ^= 1) {  // all four waves walk the same tiles
         const int b = (int)(tile / tpb);
         const int px0 = (int)(tile - (long)b * tpb) * 64;
         const int px = px0 + 4 * n;
-        float h[8][4];
-        head_load_h8<VEC4, ACT>(a, b, C, HW, px, q, h);
         // upstream gradient on the raw head output for this lane's 4 pixels (same for every q)
         float gr0[4], gr1[4];
 #pragma unroll
@@ -349,36 +404,28 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
 #pragma unroll
             for (int j = 0; j < 4; ++j) { gb2a0 += gr0[j]; gb2a1 += gr1[j]; }
         }
-        // The 4 pixel phases (phase j of lane n is pixel 4n + j of the tile = column 16j + n of the LDS planes) run
-        // in a ROLLED loop: the phase being processed sits in h[c][0] / gr*[0] and the registers rotate each trip,
-        // which keeps the live set at one phase (the unrolled form spilled ~130 registers).
+        // The 4 pixel phases run in a ROLLED loop: the phase being processed sits in gr*[0], registers rotate each
+        // trip, which keeps the live set at one phase.
         float* s_redf = reinterpret_cast<float*>(s_red);
+        const __bf16* hk_hi = s_hk[buf][0];
+        const __bf16* hk_lo = s_hk[buf][1];
+        const __bf16* ht_hi = s_ht[buf][0];
+        const __bf16* ht_lo = s_ht[buf][1];
 #pragma unroll 1
         for (int j = 0; j < 4; ++j) {
             // 1. recompute this wave's slice of the hidden pre-activation z[hidden][pixel n]
-            float xk[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) xk[c] = h[c][0];
-            const CfdSplit8 hs = cfd_split8(xk);
+            const int col = 16 * j + n;
+            const bf16x8 hhi = *reinterpret_cast<const bf16x8*>(hk_hi + col * LDK + 8 * q);
+            const bf16x8 hlo = *reinterpret_cast<const bf16x8*>(hk_lo + col * LDK + 8 * q);
             f32x4 z[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) z[t] = f32x4{bz[t][0], bz[t][1], bz[t][2], bz[t][3]};
 #pragma unroll
-            for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].lo, hs.hi, z[t]);
+            for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].lo, hhi, z[t]);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].hi, hs.lo, z[t]);
+            for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].hi, hlo, z[t]);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].hi, hs.hi, z[t]);
-            const int col = 16 * j + n;
-            // wave w publishes pixel phase w of the (wave-independent) transposed input planes
-            if (j == wave) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    if (8 * q + c < C) {
-                        s_hh[(8 * q + c) * LDW + col] = hs.hi[c];
-                        s_hl[(8 * q + c) * LDW + col] = hs.lo[c];
-                    }
-            }
+            for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].hi, hhi, z[t]);
             // 2. a1 = gelu(z) feeds the fc2 weight gradient; gz = (W2^T graw) * gelu'(z), k-slot 4t + r
             float gzv[8];
             const cfd_f2 g0 = (cfd_f2)(gr0[0]), g1 = (cfd_f2)(gr1[0]);
@@ -399,12 +446,13 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                     gzv[4 * t + 2 * v + 1] = gz.y;
                 }
             const CfdSplit8 gs = cfd_split8(gzv);
-            // 3. transposed gz planes of this wave: row = local hidden unit 16t + 4q + r, column 16j + n
+            // 3. transposed gz planes of this wave: row = local hidden unit 16t + 4q + r, column 16(j&1) + n
+            const int xcol = 16 * (j & 1) + n;
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
                 const int row = 16 * (v >> 2) + 4 * q + (v & 3);
-                s_xhw[row * LDW + col] = gs.hi[v];
-                s_xlw[row * LDW + col] = gs.lo[v];
+                s_xhw[row * LDX + xcol] = gs.hi[v];
+                s_xlw[row * LDX + xcol] = gs.lo[v];
             }
             // 4. partial d/dh[channel][pixel] = sum over this wave's hidden units w1[jh][channel] gz[jh][pixel]
             f32x4 ghc[MU];
@@ -422,41 +470,43 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                     const int i = 16 * mu + 4 * q + r;
                     if (i < CP) s_redf[((wave * CP + i) * 16 + n) * 4 + j] = ghc[mu][r];
                 }
+            // 5. after each pair of phases: gw1[hidden][channel] += sum over 32 pixels gz[hidden][px] h[channel][px]
+            if (j & 1) {
+                cfd_wave_lds_sync();
+                bf16x8 ah[2], al[2], bh[MU], bl[MU];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { h[c][0] = h[c][1]; h[c][1] = h[c][2]; h[c][2] = h[c][3]; }
+                for (int t = 0; t < 2; ++t) {
+                    const int o = (16 * t + n) * LDX + 8 * q;
+                    ah[t] = *reinterpret_cast<const bf16x8*>(s_xhw + o);
+                    al[t] = *reinterpret_cast<const bf16x8*>(s_xlw + o);
+                }
+#pragma unroll
+                for (int mu = 0; mu < MU; ++mu) {
+                    const int o = (16 * mu + n) * LDT + 16 * (j - 1) + 8 * q;
+                    bh[mu] = *reinterpret_cast<const bf16x8*>(ht_hi + o);
+                    bl[mu] = *reinterpret_cast<const bf16x8*>(ht_lo + o);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int mu = 0; mu < MU; ++mu) aw1[t][mu] = cfd_mfma16x16x32_bf16(al[t], bh[mu], aw1[t][mu]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int mu = 0; mu < MU; ++mu) aw1[t][mu] = cfd_mfma16x16x32_bf16(ah[t], bl[mu], aw1[t][mu]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int mu = 0; mu < MU; ++mu) aw1[t][mu] = cfd_mfma16x16x32_bf16(ah[t], bh[mu], aw1[t][mu]);
+                cfd_wave_lds_sync();
+            }
             gr0[0] = gr0[1]; gr0[1] = gr0[2]; gr0[2] = gr0[3];
             gr1[0] = gr1[1]; gr1[1] = gr1[2]; gr1[2] = gr1[3];
         }
         __syncthreads();
-        // 5. gw1[hidden][channel] += sum over the tile's 64 pixels gz[hidden][pixel] h[channel][pixel]  (2 K-steps)
-#pragma unroll
-        for (int kap = 0; kap < 2; ++kap) {
-            bf16x8 ah[2], al[2], bh[MU], bl[MU];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int o = (16 * t + n) * LDW + 32 * kap + 8 * q;
-                ah[t] = *reinterpret_cast<const bf16x8*>(s_xhw + o);
-                al[t] = *reinterpret_cast<const bf16x8*>(s_xlw + o);
-            }
-#pragma unroll
-            for (int mu = 0; mu < MU; ++mu) {
-                const int o = (16 * mu + n) * LDW + 32 * kap + 8 * q;
-                bh[mu] = *reinterpret_cast<const bf16x8*>(s_hh + o);
-                bl[mu] = *reinterpret_cast<const bf16x8*>(s_hl + o);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int mu = 0; mu < MU; ++mu) aw1[t][mu] = cfd_mfma16x16x32_bf16(al[t], bh[mu], aw1[t][mu]);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int mu = 0; mu < MU; ++mu) aw1[t][mu] = cfd_mfma16x16x32_bf16(ah[t], bl[mu], aw1[t][mu]);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int mu = 0; mu < MU; ++mu) aw1[t][mu] = cfd_mfma16x16x32_bf16(ah[t], bh[mu], aw1[t][mu]);
-        }
+        // next tile's input planes (other buffer; its raw loads were issued one tile ago), then loads two tiles ahead
+        stage(buf ^ 1);
+        fetch(tile + 2 * (long)gridDim.x);
         // ga[b][i][px0 .. px0+63] = (sum over the four hidden slices) * f'(a)
         for (int e = threadIdx.x; e < C * 16; e += blockDim.x) {
             const int i = e >> 4, n4 = e & 15;
