@@ -148,3 +148,25 @@ __device__ __forceinline__ f32x4 cfd_mfma_bf16x3(const CfdSplit8& a, const CfdSp
     c = cfd_mfma16x16x32_bf16(a.hi, b.lo, c);
     return cfd_mfma16x16x32_bf16(a.hi, b.hi, c);
 }
+
+// Sum of a contiguous row of n floats by one wave (all lanes get the result): float4 loads when the row is 16-byte
+// aligned, all of a lane's loads issued before the adds, fixed order.
+__device__ __forceinline__ float cfd_row_sum(const float* __restrict__ row, int n, int lane) {
+    float s = 0.f;
+    if ((n & 3) == 0 && ((size_t)row & 15) == 0) {
+        const float4* r4 = reinterpret_cast<const float4*>(row);
+        const int n4 = n >> 2;
+        int k = lane;
+        for (; k + 192 < n4; k += 256) {  // four independent 1-KiB wave loads in flight
+            const float4 a = r4[k], b = r4[k + 64], c = r4[k + 128], d = r4[k + 192];
+            s += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w));
+        }
+        for (; k < n4; k += 64) {
+            const float4 a = r4[k];
+            s += (a.x + a.y) + (a.z + a.w);
+        }
+    } else {
+        for (int k = lane; k < n; k += 64) s += row[k];
+    }
+    return cfd_wave_sum(s);
+}

@@ -542,7 +542,9 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     }
     // ---- this block's partial parameter gradients: [gw1 128*C | gb1 128 | gw2 Co*128 | gb2 Co] ----
     const int o_gb1 = HEAD_HD * C, o_gw2 = o_gb1 + HEAD_HD, o_gb2 = o_gw2 + Co * HEAD_HD;
-    float* dst = part + (size_t)blockIdx.x * (o_gb2 + Co);
+    // element-major partials part[element][block] (see k_head_reduce)
+    float* dst = part + blockIdx.x;
+    const size_t nb = gridDim.x;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -551,38 +553,36 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
 #pragma unroll
             for (int v = 0; v < MU; ++v) {
                 const int i = 16 * v + n;
-                if (i < C) dst[jh * C + i] = aw1[t][v][r];
+                if (i < C) dst[(size_t)(jh * C + i) * nb] = aw1[t][v][r];
             }
             // sums over the 16 pixel lanes of this q group
             float sa = acc2a[t][r >> 1][r & 1], sb = acc2b[t][r >> 1][r & 1], s1 = accb1[t][r >> 1][r & 1];
 #pragma unroll
             for (int m = 1; m <= 8; m <<= 1) { sa += cfd_shfl_xor(sa, m); sb += cfd_shfl_xor(sb, m); s1 += cfd_shfl_xor(s1, m); }
             if (n == 0) {
-                dst[o_gb1 + jh] = s1;
-                dst[o_gw2 + jh] = sa;
-                if (Co > 1) dst[o_gw2 + HEAD_HD + jh] = sb;
+                dst[(size_t)(o_gb1 + jh) * nb] = s1;
+                dst[(size_t)(o_gw2 + jh) * nb] = sa;
+                if (Co > 1) dst[(size_t)(o_gw2 + HEAD_HD + jh) * nb] = sb;
             }
         }
     if (wave == 0) {
         gb2a0 = cfd_wave_sum(gb2a0);
         gb2a1 = cfd_wave_sum(gb2a1);
         if (lane == 0) {
-            dst[o_gb2] = gb2a0;
-            if (Co > 1) dst[o_gb2 + 1] = gb2a1;
+            dst[(size_t)o_gb2 * nb] = gb2a0;
+            if (Co > 1) dst[(size_t)(o_gb2 + 1) * nb] = gb2a1;
         }
     }
 }
 
-// One wave per output element (see k_wgrad_reduce).
+// One wave per output element, whose per-block partials are one contiguous row (see k_wgrad_reduce).
 __global__ __launch_bounds__(256) void k_head_reduce(const float* __restrict__ part, int nblk, int PS,
                                                      float* __restrict__ gw1, float* __restrict__ gb1,
                                                      float* __restrict__ gw2, float* __restrict__ gb2, int C, int Co) {
     const int lane = threadIdx.x & 63;
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= PS) return;
-    float s = 0.f;
-    for (int k = lane; k < nblk; k += 64) s += part[(size_t)k * PS + e];
-    s = cfd_wave_sum(s);
+    const float s = cfd_row_sum(part + (size_t)e * nblk, nblk, lane);
     if (lane == 0) {
         const int o_gb1 = HEAD_HD * C, o_gw2 = o_gb1 + HEAD_HD, o_gb2 = o_gw2 + Co * HEAD_HD;
         if (e < o_gb1) gw1[e] = s;

@@ -303,8 +303,11 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
 #pragma unroll
             for (int r = 0; r < 4; ++r) s_red[((wave * MT * NT + a * NT + c) * 4 + r) * 64 + lane] = acc[a][c][r];
     __syncthreads();
+    // partials are stored element-major, part[element][block]: the scattered 4-byte stores cost the producer nothing
+    // (fire and forget) and the reduction reads whole contiguous rows
     const int NW = Ci + 1;
-    float* dst = part + (size_t)blockIdx.x * Co * NW;
+    float* dst = part + blockIdx.x;
+    const size_t nb = gridDim.x;
     for (int e = threadIdx.x; e < MT * NT * 4 * 64; e += blockDim.x) {
         const int ln = e & 63, r = (e >> 6) & 3, tile = e >> 8;
         const int a = tile / NT, c = tile % NT;
@@ -313,21 +316,20 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
             float s = 0.f;
 #pragma unroll
             for (int wv = 0; wv < 4; ++wv) s += s_red[((wv * MT * NT + tile) * 4 + r) * 64 + ln];
-            dst[o * NW + i] = s;
+            dst[(size_t)(o * NW + i) * nb] = s;
         }
     }
 }
 
-// One wave per output element: lanes stride over the per-block partials, then a fixed shuffle tree (deterministic).
+// One wave per output element: its row of per-block partials is contiguous (part[element][block]); fixed summation
+// order (lane-strided float4 chunks, then a shuffle tree), so the result is deterministic.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int nblk, float* __restrict__ gw,
                                                       float* __restrict__ gb, int Co, int Ci) {
     const int NW = Ci + 1;
     const int lane = threadIdx.x & 63;
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= Co * NW) return;  // whole wave exits together
-    float s = 0.f;
-    for (int k = lane; k < nblk; k += 64) s += part[(size_t)k * Co * NW + e];
-    s = cfd_wave_sum(s);
+    const float s = cfd_row_sum(part + (size_t)e * nblk, nblk, lane);
     if (lane == 0) {
         const int o = e / NW, i = e - o * NW;
         if (i < Ci) gw[o * Ci + i] = s;
