@@ -79,6 +79,8 @@ _SIGS = {
     "cfd_deeponet_inner_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfd_deeponet_inner_bwd_workspace_bytes": (_Z, [_I, _I, _I]),
     "cfd_deeponet_inner_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "cfd_act_fwd": (_I, [_P, _P, _Z, _I, _P]),
+    "cfd_act_bwd": (_I, [_P, _P, _P, _P, _Z, _I, _P]),
     "cfd_normact_fwd": (_I, [_P, _P, _P, _I, C.c_long, _I, _P]),
     "cfd_normact_bwd": (_I, [_P, _P, _P, _P, _I, C.c_long, _I, _P]),
     "cfd_bcast_add_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -259,6 +259,35 @@ __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ gy, c
         gz[i] = gy[i] * cfd_act_grad(y ? y[i] : 0.f, z ? z[i] : 0.f, act);
 }
 
+__global__ __launch_bounds__(256) void k_act_fwd(const float* __restrict__ x, float* __restrict__ y, size_t n, int act) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = cfd_act(x[i], act);
+}
+
+// stand-alone activation (get_act_fn(name) applied to a tensor that is not a GEMM output, act_fn.py:8-18)
+extern "C" int cfd_act_fwd(const float* x, float* y, size_t n, int act, void* stream) {
+    CFD_REQUIRE(x && y, CFD_ERR_INVALID_ARG, "cfd_act_fwd: NULL pointer");
+    CFD_REQUIRE(act >= 0 && act <= 4, CFD_ERR_INVALID_ARG, "cfd_act_fwd: unknown activation %d", act);
+    if (n == 0) return CFD_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_act_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, n, act);
+    CFD_LAUNCH_CHECK("cfd_act_fwd");
+    return CFD_OK;
+}
+
+// gx = gy * act'(x)   (y = act(x) is used by relu / tanh, x by gelu / swish)
+extern "C" int cfd_act_bwd(const float* gy, const float* y, const float* x, float* gx, size_t n, int act, void* stream) {
+    CFD_REQUIRE(gy && gx && (y || x), CFD_ERR_INVALID_ARG, "cfd_act_bwd: NULL pointer");
+    CFD_REQUIRE(act >= 0 && act <= 4, CFD_ERR_INVALID_ARG, "cfd_act_bwd: unknown activation %d", act);
+    if (n == 0) return CFD_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gy, y, x, gx, n, act);
+    CFD_LAUNCH_CHECK("cfd_act_bwd");
+    return CFD_OK;
+}
+
 // out[n] = sum_m g[m][n]: one wave per column, lanes stride over rows, fixed shuffle tree (deterministic)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, float* __restrict__ out, int M, int N) {
     const int lane = threadIdx.x & 63, col = blockIdx.x * 4 + (threadIdx.x >> 6);

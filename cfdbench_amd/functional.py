@@ -320,6 +320,35 @@ class LinearActFn(torch.autograd.Function):
         return (gx.reshape(*lead, K) if gx is not None else None), gw, gb, None
 
 
+class ActFn(torch.autograd.Function):
+    """y = act(x) elementwise (get_act_fn(name), act_fn.py:8-18) for tensors that are not a GEMM output."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, act: int):
+        _require_cuda(x)
+        api = _lib.api()
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        api.call("cfd_act_fwd", _ptr(x), _ptr(y), x.numel(), act, _stream())
+        ctx.save_for_backward(y if act in (1, 2) else x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        api = _lib.api()
+        (s,) = ctx.saved_tensors
+        gy = _f32c(gy)
+        gx = torch.empty_like(gy)
+        yy, xx = (s, None) if ctx.act in (1, 2) else (None, s)
+        api.call("cfd_act_bwd", _ptr(gy), _ptr(yy), _ptr(xx), _ptr(gx), gy.numel(), ctx.act, _stream())
+        return gx, None
+
+
+def act(x: Tensor, name: Optional[str]) -> Tensor:
+    return x if name is None else ActFn.apply(x, ACT_CODES[name])
+
+
 def linear_act(x: Tensor, w: Tensor, b: Optional[Tensor], act: Optional[str]) -> Tensor:
     return LinearActFn.apply(x, w, b, ACT_CODES[act])
 

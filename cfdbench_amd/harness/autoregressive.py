@@ -4,6 +4,8 @@ from __future__ import annotations
 from typing import Tuple
 
 from ..models.auto_deeponet import AutoDeepONet
+from ..models.auto_edeeponet import AutoEDeepONet
+from ..models.auto_ffn import AutoFfn
 from ..models.base_model import AutoCfdModel
 from ..models.fno.fno2d import Fno2d
 from ..models.loss import loss_name_to_fn
@@ -45,6 +47,13 @@ def init_model(args) -> AutoCfdModel:
         return ResNet(in_chan=args.in_chan, out_chan=args.out_chan, n_case_params=n_case_params, loss_fn=loss_fn,
                       hidden_chan=args.resnet_hidden_chan, num_blocks=args.resnet_depth,
                       kernel_size=args.resnet_kernel_size, padding=args.resnet_padding)
-    if args.model in ("auto_ffn", "auto_edeeponet", "auto_deeponet_cnn"):
+    if args.model == "auto_ffn":  # autoregressive.py:48-57
+        return AutoFfn(input_field_dim=n_rows * n_cols, num_case_params=n_case_params, query_dim=2, loss_fn=loss_fn,
+                       width=args.autoffn_width, depth=args.autoffn_depth)
+    if args.model == "auto_edeeponet":  # autoregressive.py:70-81
+        return AutoEDeepONet(dim_branch1=n_rows * n_cols, dim_branch2=n_case_params, trunk_dim=2, loss_fn=loss_fn,
+                             width=args.autoedeeponet_width, trunk_depth=args.autoedeeponet_depth,
+                             branch_depth=args.autoedeeponet_depth, act_name=args.autoedeeponet_act_fn)
+    if args.model in ("auto_deeponet_cnn",):
         raise NotImplementedError(f"cfdbench_amd: model {args.model!r} has no MI355X kernels yet (DESIGN.md section 7)")
     raise ValueError(f"Invalid model name: {args.model}")

@@ -22,8 +22,23 @@ class Ffn(nn.Module):
         self.layers = nn.Sequential(*layers)  # parameter container only; forward() below fuses pairs
 
     def forward(self, x: Tensor) -> Tensor:
+        return self._run(x, 0)
+
+    def forward_from(self, z: Tensor, idx: int) -> Tensor:
+        """Continue after Linear ``layers[idx]`` whose output ``z`` the caller computed itself (its activation, if any,
+        is applied here as a stand-alone kernel)."""
         mods = list(self.layers)
-        i = 0
+        i = idx + 1
+        if i < len(mods) and isinstance(mods[i], _Act):
+            z = F_.act(z, mods[i].name)
+            i += 1
+        elif i < len(mods) and isinstance(mods[i], NormAct):
+            z = mods[i](z)
+            i += 1
+        return self._run(z, i)
+
+    def _run(self, x: Tensor, i: int) -> Tensor:
+        mods = list(self.layers)
         while i < len(mods):
             lin = mods[i]
             act = None

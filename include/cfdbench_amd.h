@@ -191,6 +191,12 @@ size_t cfd_deeponet_inner_bwd_workspace_bytes(int B, int P, int Kq);
 int cfd_deeponet_inner_bwd(const float* gpreds, const float* branch, const float* trunk, float* gbranch, float* gtrunk,
                            float* gbias, void* ws, int B, int P, int Kq, void* stream);
 
+/* Stand-alone activation get_act_fn(name) (src/models/act_fn.py:8-18) on n contiguous floats; act 0 none, 1 relu, 2 tanh,
+ * 3 gelu, 4 swish.  Backward: gx = gy * act'(x), reading y = act(x) for relu / tanh and x for gelu / swish (the other may
+ * be NULL). */
+int cfd_act_fwd(const float* x, float* y, size_t n, int act, void* stream);
+int cfd_act_bwd(const float* gy, const float* y, const float* x, float* gx, size_t n, int act, void* stream);
+
 /* NormAct (src/models/act_fn.py:21-47): per sample (all dims but the first; x viewed as (S,L)): y = act((x-mean)/std) * std
  * + mean with the unbiased std and no epsilon.  stats (S,2) keeps (mean, std) for the backward pass.  act 1..4. */
 int cfd_normact_fwd(const float* x, float* y, float* stats, int S, long L, int act, void* stream);

@@ -182,3 +182,35 @@ def ffnmodel_forward(params: Dict[str, Array], case_params: Array, t: Array, que
     cp = np.broadcast_to(case_params[:, None, :], (B, K, case_params.shape[1]))
     inp = np.concatenate([cp, coords, tt], axis=-1).reshape(B * K, -1)
     return ffn_forward_norm(ffn_layers(params, "ffn"), inp, act_name, act_norm).reshape(B, K)
+
+
+# ---- AutoEDeepONet / AutoFfn (forward only; their gradients are pinned by the golden files of the reference) --------
+def auto_edeeponet_forward(params: Dict[str, Array], inputs: Array, case_params: Array, act_name: str = "relu",
+                           query_idxs: Optional[Array] = None) -> Array:
+    """AutoEDeepONet.forward without a label, src/models/auto_edeeponet.py:66-131: (b, k) predictions."""
+    B, _, H, W = inputs.shape
+    u = inputs[:, 0]
+    b1, _ = ffn_forward(ffn_layers(params, "branch1"), u.reshape(B, -1), act_name)
+    b2, _ = ffn_forward(ffn_layers(params, "branch2"), case_params, act_name)
+    if query_idxs is None:
+        query_idxs = np.array([(i, j) for i in range(H) for j in range(W)], dtype=np.int64)
+    xt, _ = ffn_forward(ffn_layers(params, "trunk_net"), (query_idxs.astype(inputs.dtype) - 50) / 100, act_name)
+    preds = (b1 * b2) @ xt.T + params["bias"][0]                         # :93,107-109
+    return preds + u[:, query_idxs[:, 0], query_idxs[:, 1]]             # :111-112
+
+
+def auto_ffn_forward(params: Dict[str, Array], inputs: Array, case_params: Array, act_name: str = "relu",
+                     query_idxs: Optional[Array] = None) -> Array:
+    """AutoFfn.forward, src/models/auto_ffn.py:55-125, with the reference's own sample pairing: ``repeat`` tiles the b
+    frames k times and the k queries b times, so sample r pairs frame r % b with query r % k, and ``view(b, -1)`` then
+    reads the b*k rows frame-major."""
+    B, _, H, W = inputs.shape
+    u = inputs[:, 0]
+    flat = np.concatenate([u.reshape(B, -1), case_params], axis=1)
+    if query_idxs is None:
+        query_idxs = np.array([(i, j) for i in range(H) for j in range(W)], dtype=np.int64)
+    K = query_idxs.shape[0]
+    rows = np.concatenate([np.tile(flat, (K, 1)), np.tile(query_idxs.astype(inputs.dtype), (B, 1))], axis=1)  # :100-106
+    y, _ = ffn_forward(ffn_layers(params, "ffn"), rows, act_name)
+    preds = y.reshape(B, -1)                                              # :109
+    return preds + u[:, query_idxs[:, 0], query_idxs[:, 1]]             # :112-113

@@ -136,6 +136,43 @@ def gen_auto_deeponet(name, pseed, bseed, B, H, W, width, bdepth, tdepth, act_na
     print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
 
 
+def gen_auto_variants(name, kind, seed, bseed, B, H, W, width, depth, act_name="relu", p=5, steps=2, nq=37):
+    """AutoEDeepONet / AutoFfn from the reference modules (src/models/auto_edeeponet.py, auto_ffn.py): training forward
+    on random query points + loss + backward, full-lattice inference forward and a short rollout."""
+    torch.manual_seed(seed)
+    if kind == "auto_edeeponet":
+        from models.auto_edeeponet import AutoEDeepONet  # reference
+        model = AutoEDeepONet(H * W, p, 2, MseLoss(normalize=True), branch_depth=depth, trunk_depth=depth, width=width,
+                              act_name=act_name)
+        with torch.no_grad():
+            model.bias.fill_(0.03)
+    else:
+        from models.auto_ffn import AutoFfn  # reference
+        model = AutoFfn(H * W, p, 2, MseLoss(normalize=True), depth=depth, width=width, act_name=act_name)
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    g = torch.Generator().manual_seed(bseed + 7)
+    q = torch.stack([torch.randint(0, H, (nq,), generator=g), torch.randint(0, W, (nq,), generator=g)], dim=-1)
+    x = _t(batch["inputs"]).requires_grad_(True)
+    out = model(inputs=x, case_params=_t(batch["case_params"]), label=_t(batch["label"]), mask=_t(batch["mask"]),
+                query_idxs=q)
+    out["loss"]["nmse"].backward()
+    save = dict(meta=np.array([seed, bseed, B, H, W, width, depth, p, steps, nq]), act=np.array(act_name),
+                kind=np.array(kind), q=q.numpy(), preds=out["preds"].detach().numpy(), g_inputs=x.grad.numpy(),
+                **{f"loss_{k}": np.array(v.item()) for k, v in out["loss"].items()})
+    for k, v in model.state_dict().items():
+        save[f"sd::{k}"] = v.numpy().copy()
+    for k, prm in model.named_parameters():
+        save[f"grad::{k}"] = prm.grad.numpy()
+    model.eval()
+    with torch.no_grad():
+        full = model(inputs=_t(batch["inputs"]), case_params=_t(batch["case_params"]), mask=_t(batch["mask"]))["preds"]
+        save["preds_full"] = full.numpy()
+        frames = model.generate_many(_t(batch["inputs"]), _t(batch["case_params"]), _t(batch["mask"]), steps)
+    save["frames"] = np.stack([f.numpy() for f in frames])
+    np.savez_compressed(OUT / f"{name}.npz", **save)
+    print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
+
+
 def gen_unet(name, seed, bseed, B, H, W, dim, p=8, steps=2):
     """UNet (input-insert, ConvTranspose up path) train-mode forward/backward, running-stat update, eval forward and
     rollout from the reference module (src/models/unet.py).  The state_dict itself is stored (torch's init stream)."""
@@ -290,6 +327,10 @@ def main():
     gen_nonauto("deeponet_normact_relu", "deeponet", 101, 3, 37, 16, 18, 24, "relu", True)
     gen_nonauto("deeponet_plain_tanh", "deeponet", 102, 2, 50, 16, 18, 20, "tanh", False)
     gen_nonauto("ffnmodel_normact_gelu", "ffn", 103, 3, 41, 16, 18, 24, "gelu", True)
+    gen_auto_variants("auto_edeeponet_relu_16x18", "auto_edeeponet", 111, 121, 3, 16, 18, 24, 3, "relu")
+    gen_auto_variants("auto_edeeponet_gelu_12x12", "auto_edeeponet", 112, 122, 2, 12, 12, 16, 2, "gelu")
+    gen_auto_variants("auto_ffn_relu_16x18", "auto_ffn", 113, 123, 3, 16, 18, 24, 3, "relu")
+    gen_auto_variants("auto_ffn_tanh_10x12", "auto_ffn", 114, 124, 4, 10, 12, 16, 2, "tanh", nq=30)
     gen_adam("adam_small_64x64", 26, 36, 2, 8, 2, 64, 64, nsteps=3, lr=1e-3, gain=8.0)
     gen_mseloss("mseloss", 41)
 

@@ -599,3 +599,19 @@ def check_bcast_rowdot(be, B, K, P_, seed=42):
     res["gtrunk"] = nm(be.host(gtr), g2.astype(f64)[:, :, None] * br.astype(f64)[:, None, :])
     res["gbias"] = float(abs(be.host(gbi)[0] - g2.astype(f64).sum()) / abs(g2.astype(f64).sum()))
     return res
+
+
+def check_act(be, n, act, seed=43):
+    """stand-alone activation kernels vs the oracle's act / act_grad"""
+    from oracle import deeponet_oracle as D
+    api, P = be.api, be.ptr
+    code = {"relu": 1, "tanh": 2, "gelu": 3, "swish": 4}[act]
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(n) * 1.5).astype(np.float32)
+    g = rng.standard_normal(n).astype(np.float32)
+    dx, dg = be.dev(x), be.dev(g)
+    y, gx = be.zeros((n,)), be.zeros((n,))
+    api.call("cfd_act_fwd", P(dx), P(y), n, code, be.stream)
+    api.call("cfd_act_bwd", P(dg), P(y), P(dx), P(gx), n, code, be.stream)
+    be.sync()
+    return {"y": nm(be.host(y), D.act(x.astype(f64), act)), "gx": nm(be.host(gx), g.astype(f64) * D.act_grad(x.astype(f64), act))}

@@ -160,3 +160,8 @@ def test_broadcast_add_and_rowdot(be, B, Kq, P):
     res = K.check_bcast_rowdot(be, B, Kq, P)
     assert res.pop("gbias") < 1e-5
     _assert_all(res)
+
+
+@pytest.mark.parametrize("act", ["relu", "tanh", "gelu", "swish"])
+def test_standalone_activation(be, act):
+    _assert_all(K.check_act(be, 1000, act))

@@ -417,3 +417,41 @@ def test_nonauto_models_vs_reference_golden(torch, golden_dir, name):
         assert O.rel_nmse(frame.cpu().numpy(), g["frame"]) < 1e-9
         rnd = m(case_params=cp, t=t, label=label)  # random query points (torch.randint), as in training
         assert tuple(rnd["preds"].shape) == (B, m.num_label_samples)
+
+
+# ---- AutoEDeepONet / AutoFfn drop-ins (SURVEY 8f-3 "next" rows) vs the reference modules' golden outputs -------------
+@pytest.mark.parametrize("name", ["auto_edeeponet_relu_16x18", "auto_edeeponet_gelu_12x12", "auto_ffn_relu_16x18",
+                                  "auto_ffn_tanh_10x12"])
+def test_auto_edeeponet_auto_ffn_vs_reference_golden(torch, golden_dir, name):
+    from cfdbench_amd.models.auto_edeeponet import AutoEDeepONet
+    from cfdbench_amd.models.auto_ffn import AutoFfn
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    from oracle import synth
+    g = np.load(golden_dir / f"{name}.npz")
+    seed, bseed, B, H, W, width, depth, p, steps, nq = [int(v) for v in g["meta"]]
+    act = str(g["act"])
+    if str(g["kind"]) == "auto_edeeponet":
+        m = AutoEDeepONet(H * W, p, 2, loss_name_to_fn("nmse"), branch_depth=depth, trunk_depth=depth, width=width,
+                          act_name=act).cuda()
+    else:
+        m = AutoFfn(H * W, p, 2, loss_name_to_fn("nmse"), depth=depth, width=width, act_name=act).cuda()
+    sd = {k[len("sd::"):]: torch.from_numpy(np.ascontiguousarray(g[k])) for k in g.files if k.startswith("sd::")}
+    assert list(sd.keys()) == list(m.state_dict().keys())
+    m.load_state_dict(sd)
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    x = torch.from_numpy(batch["inputs"]).cuda().requires_grad_(True)
+    cp, label, mask = (torch.from_numpy(batch[k]).cuda() for k in ("case_params", "label", "mask"))
+    q = torch.from_numpy(g["q"]).cuda()
+    out = m(inputs=x, case_params=cp, label=label, mask=mask, query_idxs=q)
+    assert O.rel_nmse(out["preds"].detach().cpu().numpy(), g["preds"]) < 1e-9
+    assert abs(out["loss"]["nmse"].item() - float(g["loss_nmse"])) <= 1e-5 * float(g["loss_nmse"])
+    out["loss"]["nmse"].backward()
+    for k, prm in m.named_parameters():
+        assert O.rel_nmse(prm.grad.cpu().numpy(), g[f"grad::{k}"]) < 1e-7, k
+    assert O.rel_nmse(x.grad.cpu().numpy(), g["g_inputs"]) < 1e-7
+    m.eval()
+    with torch.no_grad():
+        full = m(inputs=x.detach(), case_params=cp, mask=mask)["preds"]
+        assert O.rel_nmse(full.cpu().numpy().reshape(g["preds_full"].shape), g["preds_full"]) < 1e-9
+        frames = m.generate_many(x.detach(), cp, mask, steps)
+        assert O.rel_nmse(torch.stack(frames).cpu().numpy(), g["frames"]) < 1e-8

@@ -205,3 +205,19 @@ def test_nonauto_deeponet_ffn_forward(golden_dir, name):
     fwd = D.deeponet_forward if str(g["kind"]) == "deeponet" else D.ffnmodel_forward
     preds = fwd(P, g["cp"].astype(np.float64), g["t"].astype(np.float64), g["q"], str(g["act"]), bool(g["meta"][7]))
     assert O.rel_nmse(preds, g["preds"]) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["auto_edeeponet_relu_16x18", "auto_edeeponet_gelu_12x12", "auto_ffn_relu_16x18",
+                                  "auto_ffn_tanh_10x12"])
+def test_auto_edeeponet_and_auto_ffn_forward(golden_dir, name):
+    """The restatements (incl. AutoFfn's frame/query pairing quirk) against the reference modules' outputs."""
+    from oracle import deeponet_oracle as D, synth
+    g = np.load(golden_dir / f"{name}.npz")
+    seed, bseed, B, H, W, width, depth, p, steps, nq = [int(v) for v in g["meta"]]
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    P = {k[len("sd::"):]: g[k].astype(np.float64) for k in g.files if k.startswith("sd::")}
+    fwd = D.auto_edeeponet_forward if str(g["kind"]) == "auto_edeeponet" else D.auto_ffn_forward
+    x, cp = batch["inputs"].astype(np.float64), batch["case_params"].astype(np.float64)
+    assert O.rel_nmse(fwd(P, x, cp, str(g["act"]), g["q"]), g["preds"]) < 1e-10
+    full = fwd(P, x, cp, str(g["act"]))
+    assert O.rel_nmse(full.reshape(g["preds_full"].shape), g["preds_full"]) < 1e-10
