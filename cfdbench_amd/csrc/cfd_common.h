@@ -52,6 +52,9 @@ struct cfd_plan {
     int n_fwd, n_inv;
     float* d_fwd;   // t1c[KX][64] | t1s[KX][64] | t2c[4*NJ][64] | t2s[4*NJ][64]
     float* d_inv;   // ta[T][SA][64] | tb[SB][NJ][64]
+    void* d_inv_b3; // split-bf16 form of the inverse tables for the K = 32 MFMA (NULL unless T <= 4, SA <= 8, SB <= 8,
+                    // NJ == 4): 16-byte vectors ta3[T][hi|lo][64 lanes] | tb3[NJ][hi|lo][64 lanes], element v of lane
+                    // vector = table value of k-step v (zero beyond SA / SB)
     float* d_clhw;  // [m2]  c_l / (H*W)
     float* d_gx;    // [H]  np.linspace(0,1,H) as float32   (fno2d.py:251)
     float* d_gy;    // [W]

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "cfd_common.h"
@@ -19,6 +20,20 @@ void cfd_set_error(const char* fmt, ...) {
 
 extern "C" const char* cfd_last_error(void) { return g_err; }
 extern "C" int cfd_version(void) { return 100; }
+
+// float -> bf16 bit pattern, round to nearest even (the device-side split uses the same rounding)
+static unsigned short bf16_rne(float x) {
+    unsigned int u;
+    memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static float bf16_to_float(unsigned short h) {
+    const unsigned int u = (unsigned int)h << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
 
 static int upload(const std::vector<float>& h, float** d) {
     if (hipMalloc((void**)d, h.size() * sizeof(float)) != hipSuccess) return CFD_ERR_HIP;
@@ -105,6 +120,23 @@ extern "C" int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out) {
     for (int i = 0; i < H; ++i) gx[i] = (i == H - 1) ? 1.0f : (float)((double)i * (1.0 / (double)(H - 1)));
     for (int i = 0; i < W; ++i) gy[i] = (i == W - 1) ? 1.0f : (float)((double)i * (1.0 / (double)(W - 1)));
 
+    // ---- split-bf16 inverse tables (K = 32 MFMA operand order: lane vector element v = k-step v) ----
+    std::vector<unsigned short> inv3;
+    if (T <= 4 && SA <= 8 && SB <= 8 && NJ == 4) {
+        inv3.assign((size_t)(2 * T + 2 * NJ) * 64 * 8, 0);
+        auto put = [&](size_t vec, int v, float x) {  // vec = index of the hi vector; the lo vector follows 64 later
+            const unsigned short hi = bf16_rne(x);
+            inv3[vec * 8 + v] = hi;
+            inv3[(vec + 64) * 8 + v] = bf16_rne(x - bf16_to_float(hi));
+        };
+        for (int t = 0; t < T; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int v = 0; v < SA; ++v) put((size_t)(2 * t) * 64 + lane, v, ta[(t * SA + v) * 64 + lane]);
+        for (int j = 0; j < NJ; ++j)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int v = 0; v < SB; ++v) put((size_t)(2 * T + 2 * j) * 64 + lane, v, tb[(v * NJ + j) * 64 + lane]);
+    }
+
     p->n_fwd = (int)fwd.size();
     p->n_inv = (int)inv.size();
     int rc = upload(fwd, &p->d_fwd);
@@ -112,6 +144,11 @@ extern "C" int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out) {
     if (rc == CFD_OK) rc = upload(clhw, &p->d_clhw);
     if (rc == CFD_OK) rc = upload(gx, &p->d_gx);
     if (rc == CFD_OK) rc = upload(gy, &p->d_gy);
+    p->d_inv_b3 = nullptr;
+    if (rc == CFD_OK && !inv3.empty()) {
+        if (hipMalloc(&p->d_inv_b3, inv3.size() * 2) != hipSuccess ||
+            hipMemcpy(p->d_inv_b3, inv3.data(), inv3.size() * 2, hipMemcpyHostToDevice) != hipSuccess) rc = CFD_ERR_HIP;
+    }
     if (rc != CFD_OK) {
         cfd_set_error("cfd_plan_create: device allocation/copy of operator tables failed");
         delete p;
@@ -125,6 +162,7 @@ extern "C" void cfd_plan_destroy(cfd_plan* p) {
     if (!p) return;
     hipFree(p->d_fwd);
     hipFree(p->d_inv);
+    if (p->d_inv_b3) hipFree(p->d_inv_b3);
     hipFree(p->d_clhw);
     hipFree(p->d_gx);
     hipFree(p->d_gy);

@@ -640,6 +640,43 @@ __device__ __forceinline__ void idft_tile(const float (&va)[2][8], const float* 
     }
 }
 
+// Split-bf16 form of the tile (cfd_common.h "bf16x3"): both stages have K <= 32 (stage A: SA <= 8 k-steps of 4 kept
+// rows, stage B: SB <= 8 k-steps of 4 kept columns), so each becomes ONE K = 32 MFMA per output tile and split term
+// -- 6 + 12 bf16 MFMAs (~17 cycles) instead of 14 + 24 fp32 ones (32 cycles).  k-slot (q, v) of the K = 32 operand
+// is (k-step v, k index q) of the fp32 form, so va[mu][0..7] and the stage-A accumulators feed the A operands as they
+// are; ta3 / tb3 point at the hi vectors of this tile's / column group's table (lo = +64 vectors).
+struct IdftSplitA {
+    CfdSplit8 a[2];
+};
+__device__ __forceinline__ IdftSplitA idft_split(const float (&va)[2][8]) {
+    IdftSplitA s;
+    s.a[0] = cfd_split8(va[0]);
+    s.a[1] = cfd_split8(va[1]);
+    return s;
+}
+template <int NJ>
+__device__ __forceinline__ void idft_tile_b3(const IdftSplitA& sa, const bf16x8* ta3, const bf16x8* tb3, int lane,
+                                             f32x4 (&accB)[NJ]) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const bf16x8 th = ta3[lane], tl = ta3[64 + lane];
+    f32x4 accA[2];
+    accA[0] = cfd_mfma16x16x32_bf16(sa.a[0].lo, th, zero);
+    accA[1] = cfd_mfma16x16x32_bf16(sa.a[1].lo, th, zero);
+    accA[0] = cfd_mfma16x16x32_bf16(sa.a[0].hi, tl, accA[0]);
+    accA[1] = cfd_mfma16x16x32_bf16(sa.a[1].hi, tl, accA[1]);
+    accA[0] = cfd_mfma16x16x32_bf16(sa.a[0].hi, th, accA[0]);
+    accA[1] = cfd_mfma16x16x32_bf16(sa.a[1].hi, th, accA[1]);
+    const float u[8] = {accA[0][0], accA[0][1], accA[0][2], accA[0][3], accA[1][0], accA[1][1], accA[1][2], accA[1][3]};
+    const CfdSplit8 us = cfd_split8(u);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x32_bf16(us.lo, tb3[(2 * j) * 64 + lane], accB[j]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x32_bf16(us.hi, tb3[(2 * j + 1) * 64 + lane], accB[j]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x32_bf16(us.hi, tb3[(2 * j) * 64 + lane], accB[j]);
+}
+#define CFD_B3_TABV ((2 * 4 + 2 * 4) * 64)  // 16-byte vectors of the split tables at T = 4, NJ = 4
+
 #define CFD_BLK_ZS 577  // floats of one staged mode vector: 2*M (m1 = m2 = 12) + the zero slot
 
 template <int V>
@@ -735,10 +772,10 @@ __global__ __launch_bounds__(64 * CFD_WAVES) void k_idft(const float* __restrict
 template <int EPI>
 __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __restrict__ z, const float* addend,
                                                                const float* __restrict__ aprev, float* out,
-                                                               const float* __restrict__ tabs, int ntab, int nimg,
+                                                               const bf16x8* __restrict__ tabs3, int nimg,
                                                                int H, int m1, int m2, int T, int SA, int SB) {
     constexpr int W = 64, NJ = 4;
-    __shared__ float s_tab[(32 + 8 * NJ) * 64];           // T*SA <= 32, SB <= 8
+    __shared__ bf16x8 s_tab3[CFD_B3_TABV];               // split-bf16 tables, T <= 4
     __shared__ float s_z[CFD_WAVES * 2 * CFD_BLK_ZS];    // two slices per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
@@ -760,11 +797,10 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __res
         if (lane == 0) zs[M2] = 0.f;
     };
     zfetch(img < nimg ? img : 0);
-    for (int i = threadIdx.x; i < ntab; i += blockDim.x) s_tab[i < T * SA * 64 ? i : 32 * 64 + (i - T * SA * 64)] = tabs[i];
+    for (int i = threadIdx.x; i < (2 * T + 2 * NJ) * 64; i += blockDim.x) s_tab3[i] = tabs3[i];
     zcommit(zs0);
     __syncthreads();
-    const float* ta = s_tab;
-    const float* tb = s_tab + 32 * 64;
+    const bf16x8* tb3 = s_tab3 + 2 * T * 64;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     int cur = 0;
     while (img < nimg) {
@@ -773,6 +809,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __res
         cfd_sched_fence();
         float va[2][8];
         idft_gather(zs0 + cur * CFD_BLK_ZS, m1, m2, SA, q, n, va);
+        const IdftSplitA sa = idft_split(va);  // once per image: the stage-A data does not depend on the row tile
         const size_t ibase = (size_t)img * H * W + 4 * n;
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
@@ -786,7 +823,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __res
             f32x4 accB[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) accB[j] = zero;
-            idft_tile<NJ>(va, ta, tb, t, SA, SB, cfd_opaque(lane), accB);
+            idft_tile_b3<NJ>(sa, s_tab3 + 2 * t * 64, tb3, cfd_opaque(lane), accB);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float4 v = make_float4(accB[0][r], accB[1][r], accB[2][r], accB[3][r]);
@@ -811,11 +848,11 @@ static int launch_idft(const cfd_plan* p, const float* z, const float* addend, c
                        int nimg, int epi, hipStream_t st) {
     int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
     if constexpr (VEC4) {
-        if (p->W == 64 && p->H % 16 == 0 && p->T * p->SA <= 32 && 4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS) {
+        if (p->W == 64 && p->H % 16 == 0 && p->d_inv_b3 && 4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS) {
             if (blocks > 3 * 256) blocks = 3 * 256;  // resident workgroups; waves stride over the images
 #define CFD_IDFT64(E)                                                                                              \
     hipLaunchKernelGGL((k_idft64<E>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, z, addend, aprev, out,             \
-                       (const float*)p->d_inv, p->n_inv, nimg, p->H, p->m1, p->m2, p->T, p->SA, p->SB)
+                       (const bf16x8*)p->d_inv_b3, nimg, p->H, p->m1, p->m2, p->T, p->SA, p->SB)
             CFD_PROF(epi == 0 ? "k_idft" : (epi == 1 ? "k_idft_add" : "k_idft_add_dgelu"), st);
             if (epi == 0) CFD_IDFT64(0);
             else if (epi == 1) CFD_IDFT64(1);
@@ -912,16 +949,19 @@ extern "C" int cfd_spectral_conv2d_bwd(const cfd_plan* p, const float* gy, const
 
 // NW waves; wave w owns destination channels w, w+NW, ... (DPW of them) and fetches channel w of each of the NCH
 // source chunks.  NW = 4 (one wave per SIMD) wherever the channel count allows.
+#ifndef CFD_EXP
+#define CFD_EXP 0  // dev switch: 1 skips the inverse transform, 2 the channel mix, 4 the input GELU (timing experiments)
+#endif
 template <int NW, int DPW, int NCH, bool ACT, bool TRANS, bool DGELU>
 __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src, const float* __restrict__ z,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
                                                    const float* __restrict__ aprev, float* __restrict__ dst,
-                                                   const float* __restrict__ tabs, int Cs, int Cd, int H, int m1,
+                                                   const bf16x8* __restrict__ tabs3, int Cs, int Cd, int H, int m1,
                                                    int m2, int T, int SA, int SB) {
     constexpr int W = 64, NJ = 4;
     constexpr int WS = DPW <= 4 ? 4 : 8;              // floats per weight-table entry
     __shared__ float4 s_src[2 * NW * 16 * 16];        // [buf][channel in chunk][row][float4 column]
-    __shared__ float s_tab[(32 + 8 * NJ) * 64];       // ta of every tile (T*SA <= 32 steps) | tb (SB <= 8 steps x NJ)
+    __shared__ bf16x8 s_tab3[CFD_B3_TABV];            // split-bf16 inverse tables: ta3 of every tile (T <= 4) | tb3
     __shared__ float s_z[NW * DPW * CFD_BLK_ZS];      // kept modes of this wave's destination channels
     __shared__ float4 s_w[NW * NW * NCH * (WS / 4)];  // [wave][source channel] -> weights of the wave's DPW channels
     static_assert(NW * NCH <= 64, "one lane per source channel fills the weight table");
@@ -946,7 +986,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float4 v = r[k];
-            if constexpr (ACT) cfd_gelu4(v.x, v.y, v.z, v.w);
+            if constexpr (ACT && !(CFD_EXP & 4)) cfd_gelu4(v.x, v.y, v.z, v.w);
             if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
             s_src[((buf * NW + wave) * 16 + 4 * k + q) * 16 + n] = v;
         }
@@ -954,11 +994,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     fetch(0, R[0]);
     fetch(1, R[1]);
     // once per batch entry: operator tables, this wave's mixing weights and kept modes
-    {
-        const int nta = T * SA * 64;
-        for (int i = threadIdx.x; i < nta; i += blockDim.x) s_tab[i] = tabs[i];
-        for (int i = threadIdx.x; i < SB * NJ * 64; i += blockDim.x) s_tab[32 * 64 + i] = tabs[nta + i];
-    }
+    for (int i = threadIdx.x; i < (2 * T + 2 * NJ) * 64; i += blockDim.x) s_tab3[i] = tabs3[i];
     if (lane < NW * NCH) {
         float wl[WS];
 #pragma unroll
@@ -977,8 +1013,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
         bv[dd] = (bias && d < Cd) ? bias[d] : 0.f;
         if (d < Cd) idft_stage_z(z + ((size_t)b * Cd + d) * M2, s_z + (wave * DPW + dd) * CFD_BLK_ZS, M2, lane);
     }
-    const float* ta = s_tab;
-    const float* tb = s_tab + 32 * 64;
+    const bf16x8* tb3 = s_tab3 + 2 * T * 64;
     float4 AP[2][4];  // gelu'(aprev) operands of two destination channels in flight
     auto fetch_ap = [&](int t, int dd, float4 (&r)[4]) {
         const int d = wave + dd * NW;
@@ -1007,19 +1042,19 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                 if (c == NCH - 1) fetch_ap(t, 1, AP[1]);
             }
             // inverse transform of destination channel dd = c (spread over the chunks so MFMA and VALU work interleave)
-            if (c < DPW && wave + c * NW < Cd) {
+            if (!(CFD_EXP & 1) && c < DPW && wave + c * NW < Cd) {
                 float va[2][8];
                 idft_gather(s_z + (wave * DPW + (c < DPW ? c : 0)) * CFD_BLK_ZS, m1, m2, SA, q, n, va);
-                idft_tile<NJ>(va, ta, tb, t, SA, SB, lane, acc[c < DPW ? c : 0]);
+                idft_tile_b3<NJ>(idft_split(va), s_tab3 + 2 * t * 64, tb3, lane, acc[c < DPW ? c : 0]);
             }
             if constexpr (DPW > NCH) {  // more destination channels than chunks: the rest ride on the last chunk
                 if (c == NCH - 1) {
 #pragma unroll
                     for (int dd = NCH; dd < DPW; ++dd) {
-                        if (wave + dd * NW < Cd) {
+                        if (!(CFD_EXP & 1) && wave + dd * NW < Cd) {
                             float va[2][8];
                             idft_gather(s_z + (wave * DPW + dd) * CFD_BLK_ZS, m1, m2, SA, q, n, va);
-                            idft_tile<NJ>(va, ta, tb, t, SA, SB, lane, acc[dd]);
+                            idft_tile_b3<NJ>(idft_split(va), s_tab3 + 2 * t * 64, tb3, lane, acc[dd]);
                         }
                     }
                 }
@@ -1036,7 +1071,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                 };
                 lds_fetch(0, v[0], wq[0]);
 #pragma unroll 1
-                for (int sl = 0; sl < NW; ++sl) {  // rolled: registers rotate, one channel of LDS reads in flight
+                for (int sl = 0; sl < ((CFD_EXP & 2) ? 1 : NW); ++sl) {  // rolled: registers rotate, one channel of LDS reads in flight
                     const int sn = sl + 1 < NW ? sl + 1 : sl;
                     lds_fetch(sn, v[1], wq[1]);
                     float wd[WS];
@@ -1098,7 +1133,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
 
 static bool block_fused_ok(const cfd_plan* p, int Cs, int Cd, const void* a, const void* b, const void* c) {
     const int cmax = Cs > Cd ? Cs : Cd;
-    return p->W == 64 && p->H % 16 == 0 && p->NJ == 4 && p->SA <= 8 && p->SB <= 8 && p->T * p->SA <= 32 &&
+    return p->W == 64 && p->H % 16 == 0 && p->NJ == 4 && p->d_inv_b3 &&
            4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS && cmax <= 32 &&
            ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && (!c || ((uintptr_t)c % 16) == 0);
 }
@@ -1110,7 +1145,7 @@ static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z
     const dim3 grid(B), block(64 * NW);  // one workgroup per batch entry, tiles streamed inside
 #define CFD_BLK(A_, T_, D_)                                                                                     \
     hipLaunchKernelGGL((k_block<NW, DPW, NCH, A_, T_, D_>), grid, block, 0, st, src, z, w, bias, aprev, dst,    \
-                       (const float*)p->d_inv, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB)
+                       (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB)
     if (!trans) { if (act) CFD_BLK(true, false, false); else CFD_BLK(false, false, false); }
     else { if (dgelu) CFD_BLK(false, true, true); else CFD_BLK(false, true, false); }
 #undef CFD_BLK

@@ -238,7 +238,9 @@ def test_full_size_properties_b256(torch):
         fx, fy = F_.spectral_conv2d(x, w1, w2), F_.spectral_conv2d(y, w1, w2)
         fl = F_.spectral_conv2d(2.0 * x - 3.0 * y, w1, w2)
         lin = (fl - (2.0 * fx - 3.0 * fy)).pow(2).mean() / fl.pow(2).mean()
-        assert lin.item() < 1e-11  # linearity
+        # linearity, to the accuracy of the split-bf16 (3-term) inverse transform: ~2^-16 per product, nMSE ~1e-10
+        # (the parity budget of BASELINE.json is 1e-5)
+        assert lin.item() < 1e-9
         # batch independence: the first 8 samples alone give the same rows
         f8 = F_.spectral_conv2d(x[:8].contiguous(), w1, w2)
         assert torch.equal(f8, fx[:8])
@@ -248,7 +250,10 @@ def test_full_size_properties_b256(torch):
     out.backward(y)
     lhs = (out.detach().double() * y.double()).sum()
     rhs = (x.double() * xr.grad.double()).sum()
-    assert abs(lhs - rhs).item() <= 1e-6 * abs(lhs).item()
+    # measured against the Cauchy-Schwarz scale |f(x)| |y| (the inner product itself is a heavily cancelling sum of
+    # 21M terms, so its own magnitude is not a stable yardstick for the ~2^-16 split-bf16 product error)
+    scale = out.detach().double().norm() * y.double().norm()
+    assert abs(lhs - rhs).item() <= 1e-6 * scale.item()
     # sample 4 batch rows against the oracle
     idx = [0, 17, 128, 255]
     ref = O.spectral_conv2d_fwd(x[idx].cpu().numpy().astype(np.float64), w1.cpu().numpy().astype(np.complex128),
