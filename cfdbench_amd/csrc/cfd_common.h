@@ -52,6 +52,9 @@ struct cfd_plan {
     int n_fwd, n_inv;
     float* d_fwd;   // t1c[KX][64] | t1s[KX][64] | t2c[4*NJ][64] | t2s[4*NJ][64]
     float* d_inv;   // ta[T][SA][64] | tb[SB][NJ][64]
+    void* d_fwd_b3; // split-bf16 forward tables for the K = 32 MFMA (NULL unless H == 64, W == 64): 16-byte vectors
+                    // [table][hi|lo][64 lanes], tables T1C, T1S, T1N (stage 1: rows 4v+q | Nyquist row), T2C0, T2C1,
+                    // T2S0, T2S1 (stage 2: columns 4(4q+r)+2h+jj, v = 4jj+r)
     void* d_inv_b3; // split-bf16 form of the inverse tables for the K = 32 MFMA (NULL unless T <= 4, SA <= 8, SB <= 8,
                     // NJ == 4): 16-byte vectors ta3[T][hi|lo][64 lanes] | tb3[NJ][hi|lo][64 lanes], element v of lane
                     // vector = table value of k-step v (zero beyond SA / SB)

@@ -120,6 +120,40 @@ extern "C" int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out) {
     for (int i = 0; i < H; ++i) gx[i] = (i == H - 1) ? 1.0f : (float)((double)i * (1.0 / (double)(H - 1)));
     for (int i = 0; i < W; ++i) gy[i] = (i == W - 1) ? 1.0f : (float)((double)i * (1.0 / (double)(W - 1)));
 
+    // ---- split-bf16 forward tables (64x64 grids): k-slot (q, v) of the K = 32 operand ----
+    std::vector<unsigned short> fwd3;
+    if (H == 64 && W == 64) {
+        fwd3.assign((size_t)7 * 2 * 64 * 8, 0);
+        auto putf = [&](int tbl, int lane, int v, double x) {
+            const float xf32 = (float)x;
+            const unsigned short hi = bf16_rne(xf32);
+            fwd3[((size_t)(2 * tbl) * 64 + lane) * 8 + v] = hi;
+            fwd3[((size_t)(2 * tbl + 1) * 64 + lane) * 8 + v] = bf16_rne(xf32 - bf16_to_float(hi));
+        };
+        for (int lane = 0; lane < 64; ++lane) {
+            const int q = lane >> 4, i = lane & 15;
+            for (int v = 0; v < 8; ++v) {
+                // stage 1, B operand: lane (q, kap = i), folded row xf = 4v + q (0..31: one load instruction of a wave
+                // covers four consecutive rows = 1 KiB); T1N: only slot (0,0) = row H/2
+                if (i <= m1) {
+                    const int xf = 4 * v + q;
+                    const double th = PI2 * (double)((long)i * xf % H) / H;
+                    putf(0, lane, v, std::cos(th));
+                    putf(1, lane, v, xf != 0 ? std::sin(th) : 0.0);
+                    if (q == 0 && v == 0) putf(2, lane, v, (i % 2 == 0) ? 1.0 : -1.0);
+                }
+                // stage 2, A operand: lane (q, l = i), column y = 4(4q + r) + 2h + jj with v = 4jj + r
+                if (i < m2) {
+                    for (int h = 0; h < 2; ++h) {
+                        const int jj = v >> 2, r = v & 3, y = 4 * (4 * q + r) + 2 * h + jj;
+                        const double ph = PI2 * (double)((long)i * y % W) / W;
+                        putf(3 + h, lane, v, std::cos(ph));
+                        putf(5 + h, lane, v, std::sin(ph));
+                    }
+                }
+            }
+        }
+    }
     // ---- split-bf16 inverse tables (K = 32 MFMA operand order: lane vector element v = k-step v) ----
     std::vector<unsigned short> inv3;
     if (T <= 4 && SA <= 8 && SB <= 8 && NJ == 4) {
@@ -145,6 +179,11 @@ extern "C" int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out) {
     if (rc == CFD_OK) rc = upload(gx, &p->d_gx);
     if (rc == CFD_OK) rc = upload(gy, &p->d_gy);
     p->d_inv_b3 = nullptr;
+    p->d_fwd_b3 = nullptr;
+    if (rc == CFD_OK && !fwd3.empty()) {
+        if (hipMalloc(&p->d_fwd_b3, fwd3.size() * 2) != hipSuccess ||
+            hipMemcpy(p->d_fwd_b3, fwd3.data(), fwd3.size() * 2, hipMemcpyHostToDevice) != hipSuccess) rc = CFD_ERR_HIP;
+    }
     if (rc == CFD_OK && !inv3.empty()) {
         if (hipMalloc(&p->d_inv_b3, inv3.size() * 2) != hipSuccess ||
             hipMemcpy(p->d_inv_b3, inv3.data(), inv3.size() * 2, hipMemcpyHostToDevice) != hipSuccess) rc = CFD_ERR_HIP;
@@ -163,6 +202,7 @@ extern "C" void cfd_plan_destroy(cfd_plan* p) {
     hipFree(p->d_fwd);
     hipFree(p->d_inv);
     if (p->d_inv_b3) hipFree(p->d_inv_b3);
+    if (p->d_fwd_b3) hipFree(p->d_fwd_b3);
     hipFree(p->d_clhw);
     hipFree(p->d_gx);
     hipFree(p->d_gy);

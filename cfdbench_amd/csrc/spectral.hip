@@ -18,6 +18,11 @@
 //   stage B:    y[x][y] = sum_l (c_l/HW) (U_re cos(2pi l y/W) - U_im sin(2pi l y/W))
 #include "cfd_common.h"
 
+#ifndef CFD_EXP
+#define CFD_EXP 0  // dev timing switches: k_block 1 skips the inverse transform, 2 the channel mix, 4 the input GELU;
+                   // k_dft_fwd64_b3 8 skips both contraction stages (streaming skeleton)
+#endif
+
 #define CFD_WAVES 4  // waves per workgroup (256 threads)
 #define CFD_DFT_OS (2 * 15 * 16)  // complex modes of one image, m1 <= 15, m2 <= 16
 
@@ -227,10 +232,175 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64(const float* __
     }
 }
 
+// Split-bf16 (3-term, cfd_common.h) form of the 64x64 fast path: the forward transform is MFMA-issue-bound in fp32
+// (136 MFMAs x 32 cycles per image against ~14 us of pure streaming for B*C = 5120 images), and both of its
+// contractions fit the K = 32 bf16 MFMA: stage 1 over the 32 folded rows xf = 4v + q (the unpaired Nyquist row H/2 rides
+// in a second, otherwise empty K block of the cosine sums), stage 2 over the 64 columns in two K = 32 halves.
+// 36 + 24 bf16 MFMAs (~17 cycles) per image.  The rows stream through the same rolling ring as in k_dft_fwd64 (a
+// slot is re-armed the moment its rows are folded, running on into the wave's next image); the folded values collect
+// in registers until the image's eight k-steps are in and the MFMAs issue in one burst.
+#define CFD_DFT3_TABV (7 * 2 * 64)  // 16-byte vectors of the split forward tables
+template <int D, bool ACT>
+__global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64_b3(const float* __restrict__ x, float2* __restrict__ xh,
+                                                                     const bf16x8* __restrict__ tabs3, int nimg, int m1,
+                                                                     int m2) {
+    constexpr int H = 64, W = 64, NJ = 4, KXT = 9;
+    __shared__ bf16x8 s_tab3[CFD_DFT3_TABV];
+    __shared__ float2 s_out[CFD_WAVES * CFD_DFT_OS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int stride = gridDim.x * CFD_WAVES;
+    int img = blockIdx.x * CFD_WAVES + wave;
+    static_assert(KXT % D == 0, "ring depth must divide the k-step count");
+    // Rolling prefetch exactly as k_dft_fwd64: k-step s holds rows xf = 4s+q (valid while xf <= H/2) and their mirror
+    // rows H-xf (only for 0 < xf < H/2); the ring slot of step s is re-armed with step s+D (running on into the wave's
+    // next image) the moment its rows have been folded.
+    float4 v[D], u[D];
+    const int lv = q * W + 4 * n;
+    const int lu = (H - q) * W + 4 * n;
+    auto off_v = [&](int s) { return (s < KXT - 1 || q == 0) ? 4 * s * W + lv : 4 * n; };
+    auto off_u = [&](int s) { return (s == 0 ? q != 0 : s < KXT - 1) ? lu - 4 * s * W : 4 * n; };
+    auto is_paired = [&](int s) { return s == 0 ? q != 0 : s < KXT - 1; };
+    {
+        const float* xi = x + (size_t)(img < nimg ? img : 0) * H * W;
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            v[s] = *reinterpret_cast<const float4*>(xi + off_v(s));
+            u[s] = *reinterpret_cast<const float4*>(xi + off_u(s));
+        }
+    }
+    for (int i = threadIdx.x; i < CFD_DFT3_TABV; i += blockDim.x) s_tab3[i] = tabs3[i];
+    __syncthreads();
+    const int M = 2 * m1 * m2;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    while (img < nimg) {
+        const int nxt = img + stride;
+        const float* xn = x + (size_t)(nxt < nimg ? nxt : img) * H * W;
+        // ---- fold the rows into the K = 32 operands: slot v of lane group q is k-step v, i.e. row xf = 4v + q ----
+        float e8[NJ][8], o8[NJ][8], ny[NJ];
+#pragma unroll
+        for (int s = 0; s < KXT; ++s) {
+            {
+                float a[4] = {v[s % D].x, v[s % D].y, v[s % D].z, v[s % D].w};
+                float b[4] = {u[s % D].x, u[s % D].y, u[s % D].z, u[s % D].w};
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    float aa = a[j], bb = is_paired(s) ? b[j] : 0.f;
+                    if constexpr (ACT) { const cfd_f2 g2 = cfd_gelu2(cfd_f2{aa, bb}); aa = g2.x; bb = g2.y; }  // gelu(0) = 0
+                    if (s < KXT - 1) { e8[j][s < 8 ? s : 0] = aa + bb; o8[j][s < 8 ? s : 0] = aa - bb; }
+                    else ny[j] = q == 0 ? aa : 0.f;  // k-step 8: only row H/2 (lanes q == 0), cosine sums only
+                }
+            }
+            {   // re-arm the slot with k-step s+D: of this image while one remains, else of the wave's next image
+                const float* src = s + D < KXT ? x + (size_t)img * H * W : xn;
+                const int sn = (s + D) % KXT;
+                cfd_sched_fence();
+                v[s % D] = *reinterpret_cast<const float4*>(src + off_v(sn));
+                u[s % D] = *reinterpret_cast<const float4*>(src + off_u(sn));
+                cfd_sched_fence();
+            }
+        }
+        // ---- stage 1: a1c[j] / a1s[j] = cosine / sine sums over the rows, for the lane's column 4n + j ----
+        f32x4 a1c[NJ], a1s[NJ];
+        if (CFD_EXP & 8) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float acc = ny[j];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += e8[j][k] + o8[j][k];
+                a1c[j] = f32x4{acc, acc, acc, acc};
+                a1s[j] = a1c[j];
+            }
+        } else {
+            const int lo = cfd_opaque(lane);
+            const bf16x8 tch = s_tab3[lo], tcl = s_tab3[64 + lo];
+            const bf16x8 tsh = s_tab3[128 + lo], tsl = s_tab3[192 + lo];
+            const bf16x8 tnh = s_tab3[256 + lo], tnl = s_tab3[320 + lo];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float nyv[8] = {ny[j], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const CfdSplit8 es = cfd_split8(e8[j]), os = cfd_split8(o8[j]), ns = cfd_split8(nyv);
+                f32x4 c = cfd_mfma16x16x32_bf16(es.lo, tch, zero);
+                f32x4 s = cfd_mfma16x16x32_bf16(os.lo, tsh, zero);
+                c = cfd_mfma16x16x32_bf16(es.hi, tcl, c);
+                s = cfd_mfma16x16x32_bf16(os.hi, tsl, s);
+                c = cfd_mfma16x16x32_bf16(ns.lo, tnh, c);
+                c = cfd_mfma16x16x32_bf16(ns.hi, tnl, c);
+                c = cfd_mfma16x16x32_bf16(ns.hi, tnh, c);
+                c = cfd_mfma16x16x32_bf16(es.hi, tch, c);
+                s = cfd_mfma16x16x32_bf16(os.hi, tsh, s);
+                a1c[j] = c;
+                a1s[j] = s;
+            }
+        }
+        // ---- stage 2: sums over the columns; k-slot (q, v = 4jj + r) of half h is column 4(4q+r) + 2h + jj ----
+        f32x4 Pc = zero, Ps = zero, Qc = zero, Qs = zero;
+        if (CFD_EXP & 8) {
+            Pc = a1c[0]; Ps = a1s[1]; Qc = a1c[2]; Qs = a1s[3];
+        } else {
+            const int lo = cfd_opaque(lane);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float cv[8] = {a1c[2 * h][0], a1c[2 * h][1], a1c[2 * h][2], a1c[2 * h][3],
+                                     a1c[2 * h + 1][0], a1c[2 * h + 1][1], a1c[2 * h + 1][2], a1c[2 * h + 1][3]};
+                const float sv[8] = {a1s[2 * h][0], a1s[2 * h][1], a1s[2 * h][2], a1s[2 * h][3],
+                                     a1s[2 * h + 1][0], a1s[2 * h + 1][1], a1s[2 * h + 1][2], a1s[2 * h + 1][3]};
+                const CfdSplit8 cs = cfd_split8(cv), ss = cfd_split8(sv);
+                const bf16x8 ch = s_tab3[(2 * (3 + h)) * 64 + lo], cl = s_tab3[(2 * (3 + h) + 1) * 64 + lo];
+                const bf16x8 sh = s_tab3[(2 * (5 + h)) * 64 + lo], sl = s_tab3[(2 * (5 + h) + 1) * 64 + lo];
+                Pc = cfd_mfma16x16x32_bf16(cl, cs.hi, Pc);
+                Ps = cfd_mfma16x16x32_bf16(sl, cs.hi, Ps);
+                Qc = cfd_mfma16x16x32_bf16(cl, ss.hi, Qc);
+                Qs = cfd_mfma16x16x32_bf16(sl, ss.hi, Qs);
+                Pc = cfd_mfma16x16x32_bf16(ch, cs.lo, Pc);
+                Ps = cfd_mfma16x16x32_bf16(sh, cs.lo, Ps);
+                Qc = cfd_mfma16x16x32_bf16(ch, ss.lo, Qc);
+                Qs = cfd_mfma16x16x32_bf16(sh, ss.lo, Qs);
+                Pc = cfd_mfma16x16x32_bf16(ch, cs.hi, Pc);
+                Ps = cfd_mfma16x16x32_bf16(sh, cs.hi, Ps);
+                Qc = cfd_mfma16x16x32_bf16(ch, ss.hi, Qc);
+                Qs = cfd_mfma16x16x32_bf16(sh, ss.hi, Qs);
+            }
+        }
+        // modes -> this wave's LDS slice (scattered 8-byte writes are cheap there), then out in whole 512-byte runs
+        {
+            float2* so = s_out + wave * CFD_DFT_OS;
+            const int kap = n;
+            if (kap <= m1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int l = 4 * q + r;
+                    if (l < m2) {
+                        if (kap < m1) so[kap * m2 + l] = make_float2(Pc[r] - Qs[r], -(Ps[r] + Qc[r]));
+                        if (kap >= 1) so[(2 * m1 - kap) * m2 + l] = make_float2(Pc[r] + Qs[r], Qc[r] - Ps[r]);
+                    }
+                }
+            }
+            cfd_wave_lds_sync();
+            float2* o = xh + (size_t)img * M;
+            for (int i = lane; i < M; i += 64) o[i] = so[i];
+            cfd_wave_lds_sync();
+        }
+        img = nxt;
+    }
+}
+
 template <int NJ, bool VEC4>
 static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, int act, hipStream_t st) {
     CFD_PROF(act ? "k_dft_fwd_act" : "k_dft_fwd", st);
     if constexpr (VEC4) {
+        if (p->W == 64 && p->H == 64 && p->d_fwd_b3) {
+            int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
+            if (blocks > 3 * 256) blocks = 3 * 256;  // 3 resident workgroups per CU; the waves stride over the images
+            if (act)
+                hipLaunchKernelGGL((k_dft_fwd64_b3<3, true>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
+                                   (const bf16x8*)p->d_fwd_b3, nimg, p->m1, p->m2);
+            else
+                hipLaunchKernelGGL((k_dft_fwd64_b3<3, false>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
+                                   (const bf16x8*)p->d_fwd_b3, nimg, p->m1, p->m2);
+            CFD_LAUNCH_CHECK("cfd_spectral_dft");
+            return CFD_OK;
+        }
         if (p->W == 64 && p->KX == 9 && p->H == 64) {
             int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
             // 3 workgroups per CU stay resident and the waves stride over the images (measured best of 1..5; a ring of 3
@@ -949,9 +1119,6 @@ extern "C" int cfd_spectral_conv2d_bwd(const cfd_plan* p, const float* gy, const
 
 // NW waves; wave w owns destination channels w, w+NW, ... (DPW of them) and fetches channel w of each of the NCH
 // source chunks.  NW = 4 (one wave per SIMD) wherever the channel count allows.
-#ifndef CFD_EXP
-#define CFD_EXP 0  // dev switch: 1 skips the inverse transform, 2 the channel mix, 4 the input GELU (timing experiments)
-#endif
 template <int NW, int DPW, int NCH, bool ACT, bool TRANS, bool DGELU>
 __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src, const float* __restrict__ z,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
