@@ -202,25 +202,29 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
     for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int c = 0; c < NT; ++c) acc[a][c] = zero;
-    const int cpb = (HW + 15) / 16;  // 16-pixel chunks per batch entry
+    const int cpb = (HW + 31) / 32;  // 32-pixel chunks per batch entry
     const long total = (long)B * cpb;
     const int CiIn = STEM ? ss.in_chan : Ci;  // channels physically present in `in`
-    // One chunk = 16 pixels of every channel.  load() only issues the global reads (raw values); GELU and the MFMAs
-    // happen one iteration later, so the next chunk's reads are in flight while this chunk is on the matrix pipe.
-    auto load = [&](long ch, float (&av)[MT][4], float (&bv)[NT][4]) {
+    // One chunk = 32 pixels of every channel = ONE K = 32 step of the split-bf16 MFMA (cfd_common.h): lane (q, n) holds
+    // pixels 8q .. 8q+7 of rows 16a + n (gradient) and 16c + n (input), straight from global memory in operand order.
+    // load() only issues the global reads (raw values); GELU, the bf16 split and the MFMAs happen one iteration later,
+    // so the next chunk's reads are in flight while this chunk is on the matrix pipe.
+    auto load = [&](long ch, float (&av)[MT][8], float (&bv)[NT][8]) {
         const int b = (int)(ch / cpb);
-        const int px = (int)(ch - (long)b * cpb) * 16 + 4 * q;  // this lane's 4 pixels: px .. px+3
+        const int px = (int)(ch - (long)b * cpb) * 32 + 8 * q;  // this lane's 8 pixels: px .. px+7
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             const int o = 16 * a + n;
             const float* src = g + ((size_t)b * Co + o) * HW + px;
             if (VEC4) {
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (o < Co && px < HW) t = *reinterpret_cast<const float4*>(src);
-                av[a][0] = t.x; av[a][1] = t.y; av[a][2] = t.z; av[a][3] = t.w;
+                float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+                if (o < Co && px < HW) t0 = *reinterpret_cast<const float4*>(src);
+                if (o < Co && px + 4 < HW) t1 = *reinterpret_cast<const float4*>(src + 4);
+                av[a][0] = t0.x; av[a][1] = t0.y; av[a][2] = t0.z; av[a][3] = t0.w;
+                av[a][4] = t1.x; av[a][5] = t1.y; av[a][6] = t1.z; av[a][7] = t1.w;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) av[a][j] = (o < Co && px + j < HW) ? src[j] : 0.f;
+                for (int j = 0; j < 8; ++j) av[a][j] = (o < Co && px + j < HW) ? src[j] : 0.f;
             }
         }
 #pragma unroll
@@ -229,21 +233,23 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
             if (i < CiIn) {
                 const float* src = in + ((size_t)b * CiIn + i) * HW + px;
                 if (VEC4) {
-                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (px < HW) t = *reinterpret_cast<const float4*>(src);
-                    bv[c][0] = t.x; bv[c][1] = t.y; bv[c][2] = t.z; bv[c][3] = t.w;
+                    float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+                    if (px < HW) t0 = *reinterpret_cast<const float4*>(src);
+                    if (px + 4 < HW) t1 = *reinterpret_cast<const float4*>(src + 4);
+                    bv[c][0] = t0.x; bv[c][1] = t0.y; bv[c][2] = t0.z; bv[c][3] = t0.w;
+                    bv[c][4] = t1.x; bv[c][5] = t1.y; bv[c][6] = t1.z; bv[c][7] = t1.w;
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bv[c][j] = (px + j < HW) ? src[j] : 0.f;
+                    for (int j = 0; j < 8; ++j) bv[c][j] = (px + j < HW) ? src[j] : 0.f;
                 }
             } else {
                 // generated columns: ones (bias gradient) and, for the stem, mask / grid_x / grid_y / case parameters.
-                // One row/column split per lane and chunk (px .. px+3 share a row whenever W % 4 == 0).
+                // One row/column split per lane and chunk (px .. px+7 share a row whenever W % 8 == 0).
                 const int f = STEM ? i - ss.in_chan : -1;
                 const int row0 = STEM ? px / ss.W : 0, col0 = STEM ? px - row0 * ss.W : 0;
-                const bool same_row = STEM && (ss.W % 4 == 0);
+                const bool same_row = STEM && (ss.W % 8 == 0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 8; ++j) {
                     const int pj = px + j;
                     float v = 0.f;
                     if (pj < HW) {
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
     };
     const long stride = (long)gridDim.x * 4;
     long ch = (long)blockIdx.x * 4 + wave;
-    float av[MT][4], bv[NT][4], avn[MT][4], bvn[NT][4];
+    float av[MT][8], bv[NT][8], avn[MT][8], bvn[NT][8];
     if (ch < total) load(ch, av, bv);
     while (ch < total) {
         const long nx = ch + stride;
@@ -275,24 +281,38 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
             for (int c = 0; c < NT; ++c)
                 if (16 * c + n < CiIn) {  // the ones / generated columns are not activations
 #pragma unroll
-                    for (int j = 0; j < 4; j += 2) { const cfd_f2 g2 = cfd_gelu2(cfd_f2{bv[c][j], bv[c][j + 1]}); bv[c][j] = g2.x; bv[c][j + 1] = g2.y; }
+                    for (int j = 0; j < 8; j += 2) { const cfd_f2 g2 = cfd_gelu2(cfd_f2{bv[c][j], bv[c][j + 1]}); bv[c][j] = g2.x; bv[c][j + 1] = g2.y; }
                 }
         }
+        {
+            CfdSplit8 as[MT], bs[NT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int a = 0; a < MT; ++a) as[a] = cfd_split8(av[a]);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) bs[c] = cfd_split8(bv[c]);
+            // term-major: consecutive MFMAs hit different accumulators
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
-                for (int c = 0; c < NT; ++c) acc[a][c] = cfd_mfma16x16x4(av[a][j], bv[c][j], acc[a][c]);
+                for (int c = 0; c < NT; ++c) acc[a][c] = cfd_mfma16x16x32_bf16(as[a].lo, bs[c].hi, acc[a][c]);
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int c = 0; c < NT; ++c) acc[a][c] = cfd_mfma16x16x32_bf16(as[a].hi, bs[c].lo, acc[a][c]);
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int c = 0; c < NT; ++c) acc[a][c] = cfd_mfma16x16x32_bf16(as[a].hi, bs[c].hi, acc[a][c]);
+        }
         cfd_sched_fence();
 #pragma unroll
         for (int a = 0; a < MT; ++a)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) av[a][j] = avn[a][j];
+            for (int j = 0; j < 8; ++j) av[a][j] = avn[a][j];
 #pragma unroll
         for (int c = 0; c < NT; ++c)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[c][j] = bvn[c][j];
+            for (int j = 0; j < 8; ++j) bv[c][j] = bvn[c][j];
         ch = nx;
     }
     // block reduction of the 4 waves, then one partial tile per block
@@ -338,7 +358,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 }
 
 static int wgrad_blocks(int B, int HW) {
-    const long chunks = (long)B * ((HW + 15) / 16);
+    const long chunks = (long)B * ((HW + 31) / 32);
     long blocks = (chunks + 31) / 32;  // >= 8 chunks per wave
     if (blocks > 1024) blocks = 1024;  // 4 workgroups per CU (measured best of 512 / 1024 / 2048)
     if (blocks < 1) blocks = 1;
