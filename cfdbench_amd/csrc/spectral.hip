@@ -391,7 +391,10 @@ static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, in
     if constexpr (VEC4) {
         if (p->W == 64 && p->H == 64 && p->d_fwd_b3) {
             int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
-            if (blocks > 3 * 256) blocks = 3 * 256;  // 3 resident workgroups per CU; the waves stride over the images
+#ifndef CFD_DFT_CAP
+#define CFD_DFT_CAP (3 * 256)
+#endif
+            if (blocks > CFD_DFT_CAP) blocks = CFD_DFT_CAP;  // 3 resident workgroups per CU; the waves stride over the images
             if (act)
                 hipLaunchKernelGGL((k_dft_fwd64_b3<3, true>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
                                    (const bf16x8*)p->d_fwd_b3, nimg, p->m1, p->m2);
@@ -1019,7 +1022,7 @@ static int launch_idft(const cfd_plan* p, const float* z, const float* addend, c
     int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
     if constexpr (VEC4) {
         if (p->W == 64 && p->H % 16 == 0 && p->d_inv_b3 && 4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS) {
-            if (blocks > 3 * 256) blocks = 3 * 256;  // resident workgroups; waves stride over the images
+            if (blocks > CFD_DFT_CAP) blocks = CFD_DFT_CAP;  // resident workgroups; waves stride over the images
 #define CFD_IDFT64(E)                                                                                              \
     hipLaunchKernelGGL((k_idft64<E>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, z, addend, aprev, out,             \
                        (const bf16x8*)p->d_inv_b3, nimg, p->H, p->m1, p->m2, p->T, p->SA, p->SB)

@@ -186,7 +186,11 @@ class SyntheticDataset(Dataset):
 
 
 def get_dataset(data_dir: Path, data_name: str, norm_props: bool, norm_bc: bool):
-    """(train, dev, test) CfdDatasets via the reference's loaders (src/dataset/__init__.py:12)."""
+    """(train, dev, test) CfdDatasets (src/dataset/__init__.py:12): cavity natively, the rest via the reference."""
+    if data_name.split("_")[0] == "cavity":
+        from .cavity import get_cavity_datasets
+        return get_cavity_datasets(Path(data_dir) / "cavity", case_name=data_name[len("cavity") + 1:],
+                                   norm_props=norm_props, norm_bc=norm_bc)
     try:
         from dataset import get_dataset as ref_get
     except Exception as e:  # noqa: BLE001

@@ -89,3 +89,33 @@ def make_smooth_batch(seed: int, B: int, H: int = 64, W: int = 64, p: int = 5, k
     out["inputs"] = f.astype(dtype)
     out["label"] = (f + 0.01 * rng.standard_normal(f.shape)).astype(dtype)
     return out
+
+
+def write_cavity_tree(root, seed: int = 0, h: int = 12, w: int = 12):
+    """A small deterministic CFDBench-layout cavity data set under ``root``/cavity/{prop,bc,geo}/case<NNNN>/ with
+    ``u.npy``, ``v.npy`` (float64, (T,h,w)) and ``case.json``: smooth fields relaxing exponentially towards a steady
+    state, fast enough in some cases to trigger the loaders' steady-state cut-off.  Test infrastructure (golden
+    generation + loader parity tests)."""
+    import json
+    from pathlib import Path
+    rng = np.random.default_rng(seed)
+    root = Path(root) / "cavity"
+    yy, xx = np.meshgrid(np.linspace(0, 1, h), np.linspace(0, 1, w), indexing="ij")
+    for subset, ids in (("prop", [0, 1, 2, 3, 10, 11, 12]), ("bc", [0, 2, 5, 7, 8, 9]), ("geo", [1, 3, 4, 20])):
+        for cid in ids:
+            d = root / subset / f"case{cid:04d}"
+            d.mkdir(parents=True, exist_ok=True)
+            T = int(rng.integers(6, 14))
+            tau = float(rng.uniform(0.3, 3.0))
+            vel, dens, visc = float(rng.uniform(1, 50)), float(rng.uniform(0.5, 10)), float(rng.uniform(1e-4, 1e-2))
+            hh, ww = (float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.5, 2.0))) if subset == "geo" else (1.0, 1.0)
+            pat_u = np.sin(np.pi * xx) * np.sin(np.pi * yy) ** 2 * (1 + 0.3 * rng.standard_normal())
+            pat_v = np.cos(np.pi * xx) * np.sin(2 * np.pi * yy) * 0.5
+            ramp = (1.0 - np.exp(-(np.arange(T) + 1.0) / tau))[:, None, None]
+            u = 0.2 * vel * ramp * pat_u[None]
+            v = 0.2 * vel * ramp * pat_v[None]
+            np.save(d / "u.npy", u)
+            np.save(d / "v.npy", v)
+            with open(d / "case.json", "w", encoding="utf8") as f:
+                json.dump(dict(vel_top=vel, density=dens, viscosity=visc, height=hh, width=ww), f)
+    return root.parent

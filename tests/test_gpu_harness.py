@@ -174,3 +174,24 @@ def test_nonauto_train_eval_test_artifacts(torch, tmp_path, model_name):
     assert (out / "test" / "preds.pt").exists() and len(res["preds"]) == len(dev)
     assert tuple(res["preds"][0].shape) == (1, 3, 16, 16)
     assert get_best_ckpt(out) is not None
+
+
+def test_train_on_native_cavity_loader_device_resident(torch, tmp_path):
+    """CFDBench-layout cavity files -> native loader with the frames resident on the GPU -> train_auto loop."""
+    from cfdbench_amd.harness.args import Args
+    from cfdbench_amd.harness.autoregressive import init_model
+    from cfdbench_amd.harness.cavity import get_cavity_auto_datasets
+    from cfdbench_amd.harness.common import get_output_dir
+    from cfdbench_amd.harness.train_auto import train
+    from oracle import synth
+    root = synth.write_cavity_tree(tmp_path / "data", 5, h=16, w=16)
+    tr, dev, te = get_cavity_auto_datasets(root / "cavity", "prop_bc_geo", norm_props=True, norm_bc=True, device="cuda")
+    assert tr.inputs.is_cuda and len(tr) > 50
+    args = Args(model="fno", data_name="cavity_prop_bc_geo", loss_name="nmse", fno_hidden_dim=8, fno_depth=2,
+                fno_modes_x=4, fno_modes_y=4, num_rows=16, num_cols=16, lr=3e-3, output_dir=str(tmp_path / "out"),
+                num_epochs=3, batch_size=8, eval_batch_size=8, eval_interval=3, log_interval=50, plot_interval=0)
+    torch.manual_seed(0)
+    model = init_model(args).cuda()
+    losses = train(model, tr, dev, get_output_dir(args, is_auto=True), num_epochs=3, lr=args.lr, batch_size=8,
+                   eval_batch_size=8, eval_interval=3, log_interval=50, plot_interval=0)
+    assert np.all(np.isfinite(losses)) and np.mean(losses[-5:]) < np.mean(losses[:5])
