@@ -177,12 +177,16 @@ def main():
     }
 
     # ---- roofline leg: the same K steps again with per-kernel HIP events on the launch stream -------------------
-    if rank == 0 and not args.no_roofline:
+    # EVERY rank runs these steps (they contain the gradient all-reduce, a collective); only rank 0 records events.
+    if not args.no_roofline:
         import ctypes
         api = _lib.api()
-        api.call("cfd_prof_begin")
+        if rank == 0:
+            api.call("cfd_prof_begin")
         for _ in range(args.steps):
             eng.train_step(inputs, label, cp, mask)
+        torch.cuda.synchronize()
+    if rank == 0 and not args.no_roofline:
         buf = ctypes.create_string_buffer(1 << 16)
         api.call("cfd_prof_end", buf, len(buf))
         rows = []
@@ -249,7 +253,7 @@ def main():
             frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None)
 
     # ---- rollout leg (rank 0): batched multi-step inference from one HIP graph (BASELINE metric's "rollout" half) ---
-    if rank == 0 and not args.no_rollout:
+    if rank == 0 and world == 1 and not args.no_rollout:  # N=1 only: keeps the multi-rank runs short
         from cfdbench_amd.rollout import FnoRollout
         Br, steps_r = args.rollout_batch, args.rollout_steps
         ro = FnoRollout(model)
@@ -293,6 +297,7 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
+        dist.barrier()  # the other ranks wait here while rank 0 finishes its (collective-free) extra legs
         dist.destroy_process_group()
 
 
