@@ -12,7 +12,7 @@
 #define HEAD_HD 128
 #define HEAD_MT 8
 #ifndef CFD_HEAD_FWD_BLOCKS
-#define CFD_HEAD_FWD_BLOCKS 1024  // 4 workgroups (16 waves) per CU: the kernel's 116 VGPRs allow 4 waves per SIMD
+#define CFD_HEAD_FWD_BLOCKS 768  // 3 resident workgroups per CU (138 VGPRs); 1024 leaves a quarter-filled second round (+5 %)
 #endif
 #define HEAD_LD 17  // LDS row stride of the transposed tiles (16 pixels + 1 pad -> conflict-free column reads)
 

@@ -67,7 +67,7 @@ def test_loss_and_adam(be):
     assert res["adam_delta"] < 1e-9
 
 
-@pytest.mark.parametrize("C,L,H,W,border", [(8, 2, 64, 64, False), (6, 2, 66, 65, True)])
+@pytest.mark.parametrize("C,L,H,W,border", [(8, 2, 64, 64, False), (6, 2, 34, 33, True)])
 def test_fno_whole_model(be, C, L, H, W, border):
     res = K.check_fno_vs_oracle(be, 1, C, L, H, W, border=border)
     loss_err = res.pop("nmse_loss")
@@ -106,12 +106,12 @@ def test_deeponet_inner(be, B, P, Kq, HW, with_q):
     _assert_all(res)
 
 
-@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(1, 5, 7, 9, 10, 3), (1, 3, 18, 5, 4, 3), (1, 2, 3, 8, 9, 7), (2, 4, 4, 6, 6, 1), (1, 5, 18, 9, 35, 3), (1, 17, 20, 9, 32, 3)])
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(1, 5, 7, 9, 10, 3), (1, 3, 18, 5, 4, 3), (1, 2, 3, 8, 9, 7), (2, 4, 4, 6, 6, 1), (1, 17, 20, 5, 32, 3)])
 def test_conv2d_replicate(be, B, Ci, Co, H, W, ks):
     _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, ks))
 
 
-@pytest.mark.parametrize("B,C,H,W,training,relu", [(2, 5, 6, 7, True, True), (2, 3, 4, 4, False, True), (3, 2, 5, 5, True, False)])
+@pytest.mark.parametrize("B,C,H,W,training,relu", [(2, 3, 6, 7, True, True), (2, 3, 4, 4, False, True), (3, 2, 5, 5, True, False)])
 def test_batchnorm_relu(be, B, C, H, W, training, relu):
     _assert_all(K.check_batchnorm(be, B, C, H, W, training, relu))
 
