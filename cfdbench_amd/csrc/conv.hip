@@ -153,22 +153,46 @@ __global__ __launch_bounds__(256) void k_conv_tile(const float* __restrict__ src
     const int hw_used = t.TW + KS - 1;
     for (int c0 = 0; c0 < Cs; c0 += CC) {
         __syncthreads();  // previous chunk fully consumed (first pass: s_koff written)
-        // halo tiles of NB images x CC channels
-        for (int i = threadIdx.x; i < t.NB * CC * t.LH * hw_used; i += blockDim.x) {
-            const int lx = i % hw_used, r1 = i / hw_used, ly = r1 % t.LH, r2 = r1 / t.LH, c = r2 % CC, bi = r2 / CC;
-            int y = oy + ly, x = ox + lx;
-            float v = 0.f;
-            if (c0 + c < Cs && b0 + bi < g.B) {
-                const float* sb = src + ((size_t)(b0 + bi) * Cs + c0 + c) * HWs;
-                if constexpr (EXT) {
-                    if (y >= 0 && y < g.H && x >= 0 && x < g.W) v = sb[y * g.W + x];
-                } else {
-                    y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
-                    x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
-                    v = sb[y * g.W + x];
+        // halo tiles of NB images x CC channels: one wave per halo row (lane = column), rows handed out round-robin
+        // four at a time.  The row -> (image, channel, halo row) split advances by carry (wave-uniform scalar work),
+        // the lane's clamped source column is loop-invariant, so an element costs one global load and one LDS store
+        // (the flat-index version spent ~150 VALU instructions per element on five runtime divisions: PMC showed 20
+        // VALU instructions per MFMA), and four rows of loads are in flight before the first store.
+        {
+            const int lx = lane;
+            const bool lane_on = lx < hw_used;
+            int xs = ox + lx;
+            bool xin = lane_on;
+            if constexpr (EXT) xin = xin && xs >= 0 && xs < g.W;
+            xs = xs < 0 ? 0 : (xs >= g.W ? g.W - 1 : xs);
+            int ly = cfd_uniform(wave), c = 0, bi = 0;
+            auto norm = [&]() {
+                while (ly >= t.LH) {
+                    ly -= t.LH;
+                    if (++c == CC) { c = 0; ++bi; }
                 }
+            };
+            norm();
+            while (bi < t.NB) {
+                float v[4];
+                int so[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool row_on = bi < t.NB;
+                    int y = oy + ly;
+                    bool ok = row_on && c0 + c < Cs && b0 + bi < g.B;
+                    if constexpr (EXT) ok = ok && y >= 0 && y < g.H;
+                    y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
+                    v[u] = 0.f;
+                    if (ok && xin) v[u] = src[((size_t)(b0 + bi) * Cs + c0 + c) * HWs + y * g.W + xs];
+                    so[u] = row_on ? (bi * CC + c) * halo + ly * t.LW + lx : -1;
+                    ly += 4;
+                    norm();
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (so[u] >= 0 && lane_on) s_in[so[u]] = v[u];
             }
-            s_in[(bi * CC + c) * halo + ly * t.LW + lx] = v;
         }
         // weight fragments of this chunk: frag[kstep][mt][lane (q, n)] = A[m = mbase + 16 mt + n][k = 4 kstep + q]
         for (int i = threadIdx.x; i < KSTEPS * MT * 64; i += blockDim.x) {
