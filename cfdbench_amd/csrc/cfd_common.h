@@ -176,3 +176,29 @@ __device__ __forceinline__ float cfd_row_sum(const float* __restrict__ row, int 
     }
     return cfd_wave_sum(s);
 }
+
+// ---- division of 31-bit indices by a launch-invariant divisor --------------------------------------------------
+// Element-wise kernels turn a flat index into (image, channel, pixel).  A 64-bit integer division costs ~100 VALU
+// instructions on gfx950 and the first versions of those kernels did several per element; with the magic number made on
+// the host (round-up method for 31-bit numerators: s = ceil(log2 d), m = ceil(2^(31+s) / d) < 2^32) it is one v_mul_hi
+// and one shift.  Callers guarantee n < 2^31.
+struct CfdDiv {
+    unsigned d, m, sh;
+};
+static inline CfdDiv cfd_div_make(unsigned d) {
+    CfdDiv r;
+    r.d = d;
+    r.m = 0;
+    r.sh = 0;
+    if (d <= 1) return r;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    r.m = (unsigned)((((unsigned long long)1 << (31 + s)) + d - 1) / d);
+    r.sh = s - 1;
+    return r;
+}
+__device__ __forceinline__ unsigned cfd_div(unsigned n, const CfdDiv& dv) {
+    return dv.d <= 1 ? n : (cfd_umulhi(n, dv.m) >> dv.sh);
+}
+#define CFD_REQUIRE_I31(total, fn) \
+    CFD_REQUIRE((total) < (1L << 31), CFD_ERR_UNSUPPORTED, "%s: %ld elements exceed the 2^31 index range of this kernel", fn, (long)(total))

@@ -54,6 +54,7 @@ __device__ __forceinline__ void cfd_sched_fence() { __builtin_amdgcn_sched_barri
 __device__ __forceinline__ float cfd_erff(float x) { return erff(x); }
 __device__ __forceinline__ float cfd_expf(float x) { return __expf(x); }
 __device__ __forceinline__ float cfd_rcpf(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32, 1 ulp
+__device__ __forceinline__ unsigned cfd_umulhi(unsigned a, unsigned b) { return __umulhi(a, b); }
 __device__ __forceinline__ float cfd_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32, no range fix-up
 
 // Two fp32 values in one 64-bit register pair: +, -, * and cfd_fma2 on it compile to the packed VALU instructions

@@ -153,46 +153,22 @@ __global__ __launch_bounds__(256) void k_conv_tile(const float* __restrict__ src
     const int hw_used = t.TW + KS - 1;
     for (int c0 = 0; c0 < Cs; c0 += CC) {
         __syncthreads();  // previous chunk fully consumed (first pass: s_koff written)
-        // halo tiles of NB images x CC channels: one wave per halo row (lane = column), rows handed out round-robin
-        // four at a time.  The row -> (image, channel, halo row) split advances by carry (wave-uniform scalar work),
-        // the lane's clamped source column is loop-invariant, so an element costs one global load and one LDS store
-        // (the flat-index version spent ~150 VALU instructions per element on five runtime divisions: PMC showed 20
-        // VALU instructions per MFMA), and four rows of loads are in flight before the first store.
-        {
-            const int lx = lane;
-            const bool lane_on = lx < hw_used;
-            int xs = ox + lx;
-            bool xin = lane_on;
-            if constexpr (EXT) xin = xin && xs >= 0 && xs < g.W;
-            xs = xs < 0 ? 0 : (xs >= g.W ? g.W - 1 : xs);
-            int ly = cfd_uniform(wave), c = 0, bi = 0;
-            auto norm = [&]() {
-                while (ly >= t.LH) {
-                    ly -= t.LH;
-                    if (++c == CC) { c = 0; ++bi; }
-                }
-            };
-            norm();
-            while (bi < t.NB) {
-                float v[4];
-                int so[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool row_on = bi < t.NB;
-                    int y = oy + ly;
-                    bool ok = row_on && c0 + c < Cs && b0 + bi < g.B;
-                    if constexpr (EXT) ok = ok && y >= 0 && y < g.H;
+        // halo tiles of NB images x CC channels
+        for (int i = threadIdx.x; i < t.NB * CC * t.LH * hw_used; i += blockDim.x) {
+            const int lx = i % hw_used, r1 = i / hw_used, ly = r1 % t.LH, r2 = r1 / t.LH, c = r2 % CC, bi = r2 / CC;
+            int y = oy + ly, x = ox + lx;
+            float v = 0.f;
+            if (c0 + c < Cs && b0 + bi < g.B) {
+                const float* sb = src + ((size_t)(b0 + bi) * Cs + c0 + c) * HWs;
+                if constexpr (EXT) {
+                    if (y >= 0 && y < g.H && x >= 0 && x < g.W) v = sb[y * g.W + x];
+                } else {
                     y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
-                    v[u] = 0.f;
-                    if (ok && xin) v[u] = src[((size_t)(b0 + bi) * Cs + c0 + c) * HWs + y * g.W + xs];
-                    so[u] = row_on ? (bi * CC + c) * halo + ly * t.LW + lx : -1;
-                    ly += 4;
-                    norm();
+                    x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
+                    v = sb[y * g.W + x];
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (so[u] >= 0 && lane_on) s_in[so[u]] = v[u];
             }
+            s_in[(bi * CC + c) * halo + ly * t.LW + lx] = v;
         }
         // weight fragments of this chunk: frag[kstep][mt][lane (q, n)] = A[m = mbase + 16 mt + n][k = 4 kstep + q]
         for (int i = threadIdx.x; i < KSTEPS * MT * 64; i += blockDim.x) {
@@ -340,16 +316,15 @@ extern "C" int cfd_conv2d_fwd(const float* in, const float* w, const float* bias
 }
 
 // gin[b][i][y][x] = sum over the extended positions that replicate padding maps to (y, x)
-__global__ __launch_bounds__(256) void k_fold_pad(const float* __restrict__ ext, float* __restrict__ gin, long nimg, int H,
-                                                  int W, int pad) {
+__global__ __launch_bounds__(256) void k_fold_pad(const float* __restrict__ ext, float* __restrict__ gin, unsigned total,
+                                                  int H, int W, int pad, CfdDiv dHW, CfdDiv dW) {
     const int He = H + 2 * pad, We = W + 2 * pad;
-    const long total = nimg * H * W;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long img = e / (H * W);
-        const int p = (int)(e - img * H * W), y = p / W, x = p - y * W;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned img = cfd_div(e, dHW);
+        const int p = (int)(e - img * (unsigned)(H * W)), y = (int)cfd_div((unsigned)p, dW), x = p - y * W;
         const int y0 = y == 0 ? 0 : y + pad, y1 = y == H - 1 ? He - 1 : y + pad;
         const int x0 = x == 0 ? 0 : x + pad, x1 = x == W - 1 ? We - 1 : x + pad;
-        const float* s = ext + img * He * We;
+        const float* s = ext + (size_t)img * He * We;
         float acc = 0.f;
         for (int yy = y0; yy <= y1; ++yy)
             for (int xx = x0; xx <= x1; ++xx) acc += s[yy * We + xx];
@@ -522,7 +497,9 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
         long blocks = (total + 255) / 256;
         if (blocks > 4096) blocks = 4096;
         CFD_PROF("k_fold_pad", st);
-        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ext, gin, (long)B * Ci, H, W, pad);
+        CFD_REQUIRE_I31(total, "cfd_conv2d_bwd");
+        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ext, gin, (unsigned)total, H, W,
+                           pad, cfd_div_make((unsigned)HW), cfd_div_make((unsigned)W));
         CFD_LAUNCH_CHECK("cfd_conv2d_bwd(fold)");
     }
     if (gw) {
@@ -552,30 +529,29 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
 // ------------------------------------------------------------------------------------------------------
 // Per-channel statistics over (B, H, W) in two deterministic stages: grid (C, nsplit) partials, then one wave per
 // channel.  Two passes (mean, then centred sum of squares) keep fp32 accurate when |mean| >> std.
-#define BN_SPLIT 32
+#define BN_SPLIT 64  // partial sums per channel (one lane of k_bn_final each)
 
 // MODE 0: sum x;  MODE 1: sum (x - mean[c])^2;  MODE 2: sums of gz and gz*xhat with gz = gy * (y > 0 if relu)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x, const float* __restrict__ aux,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                    float* __restrict__ part, int B, int C, int HW, int relu) {
+                                                    float* __restrict__ part, int B, int C, int HW, int relu,
+                                                    CfdDiv dHW) {
     __shared__ float s_r[8];
     const int c = blockIdx.x, sp = blockIdx.y;
-    const long n = (long)B * HW;
-    const long per = (n + BN_SPLIT - 1) / BN_SPLIT;
-    const long e0 = sp * per, e1 = e0 + per < n ? e0 + per : n;
+    const unsigned n = (unsigned)B * HW;  // < 2^31 (checked by the callers)
+    const unsigned per = (n + BN_SPLIT - 1) / BN_SPLIT;
+    const unsigned e0 = sp * per, e1 = e0 + per < n ? e0 + per : n;
     const float mu = MODE >= 1 ? mean[c] : 0.f, rs = MODE == 2 ? rstd[c] : 0.f;
     float s0 = 0.f, s1 = 0.f;
-    for (long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-        const long b = e / HW;
-        const size_t off = ((size_t)b * C + c) * HW + (e - b * HW);
-        const float v = x[off];
+    auto item = [&](unsigned e, float v, float a) {
+        (void)e;
         if (MODE == 0) s0 += v;
         else if (MODE == 1) { const float d = v - mu; s0 = fmaf(d, d, s0); }
         else {
             // x = layer input, aux = upstream gradient; relu mask from the normalised output sign
             const float xh = (v - mu) * rs;
-            float gz = aux[off];
+            float gz = a;
             if (relu) {
                 const float yv = fmaf(xh, mean[C + c], mean[2 * C + c]);  // gamma, beta packed behind mean
                 gz = yv > 0.f ? gz : 0.f;
@@ -583,6 +559,25 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
             s0 += gz;
             s1 = fmaf(gz, xh, s1);
         }
+    };
+    auto offset = [&](unsigned e) {
+        const unsigned b = cfd_div(e, dHW);
+        return ((size_t)b * C + c) * HW + (e - b * (unsigned)HW);
+    };
+    unsigned e = e0 + threadIdx.x;
+    for (; e + 3 * blockDim.x < e1; e += 4 * blockDim.x) {  // four independent loads in flight per thread
+        size_t o[4];
+        float v[4], a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = offset(e + k * blockDim.x);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = x[o[k]]; a[k] = MODE == 2 ? aux[o[k]] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) item(e + k * blockDim.x, v[k], a[k]);
+    }
+    for (; e < e1; e += blockDim.x) {
+        const size_t o = offset(e);
+        item(e, x[o], MODE == 2 ? aux[o] : 0.f);
     }
     s0 = cfd_wave_sum(s0);
     s1 = cfd_wave_sum(s1);
@@ -628,7 +623,7 @@ static int chan_sum(const float* g, float* out, void* ws, int B, int C, int HW, 
     float* part = (float*)ws;
     float* dummy = part + (size_t)C * BN_SPLIT * 2;
     hipLaunchKernelGGL((k_bn_partial<0>), dim3(C, BN_SPLIT), dim3(256), 0, st, g, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, part, B, C, HW, 0);
+                       (const float*)nullptr, (const float*)nullptr, part, B, C, HW, 0, cfd_div_make((unsigned)HW));
     hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 2, 1.f, 0.f, 0.f, (float*)nullptr,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, out, dummy, C);
     CFD_LAUNCH_CHECK(what);
@@ -644,10 +639,11 @@ __global__ __launch_bounds__(256) void k_bn_eval_stats(const float* __restrict__
 // y = [relu]((x - mean) * rstd * gamma + beta)
 __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                  const float* __restrict__ beta, float* __restrict__ y, long total, int C,
-                                                  int HW, int relu) {
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int c = (int)((e / HW) % C);
+                                                  const float* __restrict__ beta, float* __restrict__ y, unsigned total,
+                                                  int C, int relu, CfdDiv dHW, CfdDiv dC) {
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned row = cfd_div(e, dHW);
+        const int c = (int)(row - cfd_div(row, dC) * (unsigned)C);
         float v = fmaf((x[e] - mean[c]) * rstd[c], gamma[c], beta[c]);
         if (relu) v = v > 0.f ? v : 0.f;
         y[e] = v;
@@ -659,10 +655,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ gbeta, const float* __restrict__ ggamma,
-                                                      float* __restrict__ gx, long total, int C, int HW, float inv_count,
-                                                      int relu, int training) {
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int c = (int)((e / HW) % C);
+                                                      float* __restrict__ gx, unsigned total, int C, float inv_count,
+                                                      int relu, int training, CfdDiv dHW, CfdDiv dC) {
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned row = cfd_div(e, dHW);
+        const int c = (int)(row - cfd_div(row, dC) * (unsigned)C);
         const float xh = (x[e] - mean[c]) * rstd[c];
         float gz = gy[e];
         if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.f)) gz = 0.f;
@@ -689,6 +686,7 @@ extern "C" int cfd_batchnorm_fwd(const float* x, const float* gamma, const float
                                  float momentum, int training, int relu, void* stream) {
     CFD_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && ws, CFD_ERR_INVALID_ARG, "cfd_batchnorm_fwd: NULL pointer");
     CFD_REQUIRE(B >= 1 && C >= 1 && HW >= 1, CFD_ERR_INVALID_ARG, "cfd_batchnorm_fwd: bad sizes");
+    CFD_REQUIRE_I31((long)B * C * HW, "cfd_batchnorm_fwd");
     CFD_REQUIRE(training || (run_mean && run_var), CFD_ERR_INVALID_ARG, "cfd_batchnorm_fwd: eval mode needs running statistics");
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)ws;
@@ -696,11 +694,11 @@ extern "C" int cfd_batchnorm_fwd(const float* x, const float* gamma, const float
     if (training) {
         CFD_PROF("k_bn_stats", st);
         hipLaunchKernelGGL((k_bn_partial<0>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, (const float*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, part, B, C, HW, 0);
+                           (const float*)nullptr, (const float*)nullptr, part, B, C, HW, 0, cfd_div_make((unsigned)HW));
         hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 0, count, eps, momentum, save_mean,
                            save_rstd, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, C);
         hipLaunchKernelGGL((k_bn_partial<1>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, (const float*)nullptr,
-                           (const float*)save_mean, (const float*)nullptr, part, B, C, HW, 0);
+                           (const float*)save_mean, (const float*)nullptr, part, B, C, HW, 0, cfd_div_make((unsigned)HW));
         hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 1, count, eps, momentum, save_mean,
                            save_rstd, run_mean, run_var, (float*)nullptr, (float*)nullptr, C);
         CFD_LAUNCH_CHECK("cfd_batchnorm_fwd(stats)");
@@ -712,7 +710,8 @@ extern "C" int cfd_batchnorm_fwd(const float* x, const float* gamma, const float
     const long total = (long)B * C * HW;
     CFD_PROF("k_bn_apply", st);
     hipLaunchKernelGGL(k_bn_apply, dim3(ew_blocks(total)), dim3(256), 0, st, x, (const float*)save_mean,
-                       (const float*)save_rstd, gamma, beta, y, total, C, HW, relu);
+                       (const float*)save_rstd, gamma, beta, y, (unsigned)total, C, relu, cfd_div_make((unsigned)HW),
+                       cfd_div_make((unsigned)C));
     CFD_LAUNCH_CHECK("cfd_batchnorm_fwd(apply)");
     return CFD_OK;
 }
@@ -729,6 +728,7 @@ extern "C" int cfd_batchnorm_bwd(const float* gy, const float* x, const float* g
     CFD_REQUIRE(gy && x && gamma && beta && save_mean && save_rstd && gx && ggamma && gbeta && ws, CFD_ERR_INVALID_ARG,
                 "cfd_batchnorm_bwd: NULL pointer");
     CFD_REQUIRE(B >= 1 && C >= 1 && HW >= 1, CFD_ERR_INVALID_ARG, "cfd_batchnorm_bwd: bad sizes");
+    CFD_REQUIRE_I31((long)B * C * HW, "cfd_batchnorm_bwd");
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)ws;
     float* packed = part + (size_t)C * BN_SPLIT * 2;  // (mean, gamma, beta) for the relu mask inside the reduction
@@ -736,7 +736,7 @@ extern "C" int cfd_batchnorm_bwd(const float* gy, const float* x, const float* g
     {
         CFD_PROF("k_bn_bwd_reduce", st);
         hipLaunchKernelGGL((k_bn_partial<2>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, gy, (const float*)packed, save_rstd,
-                           part, B, C, HW, relu);
+                           part, B, C, HW, relu, cfd_div_make((unsigned)HW));
         hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 2, 1.f, 0.f, 0.f, (float*)nullptr,
                            (float*)nullptr, (float*)nullptr, (float*)nullptr, gbeta, ggamma, C);
     }
@@ -744,8 +744,8 @@ extern "C" int cfd_batchnorm_bwd(const float* gy, const float* x, const float* g
     const long total = (long)B * C * HW;
     CFD_PROF("k_bn_bwd_apply", st);
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_blocks(total)), dim3(256), 0, st, x, gy, save_mean, save_rstd, gamma, beta,
-                       (const float*)gbeta, (const float*)ggamma, gx, total, C, HW, (float)(1.0 / ((double)B * HW)), relu,
-                       training);
+                       (const float*)gbeta, (const float*)ggamma, gx, (unsigned)total, C, (float)(1.0 / ((double)B * HW)), relu,
+                       training, cfd_div_make((unsigned)HW), cfd_div_make((unsigned)C));
     CFD_LAUNCH_CHECK("cfd_batchnorm_bwd(apply)");
     return CFD_OK;
 }
@@ -753,13 +753,13 @@ extern "C" int cfd_batchnorm_bwd(const float* gy, const float* x, const float* g
 // ------------------------------------------------------------------------------------------------------
 // MaxPool2d(2)  (src/models/unet.py:59): floor mode, gradient to the FIRST maximum in row-major window order
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_maxpool2(const float* __restrict__ x, float* __restrict__ y, long nimg, int H, int W) {
+__global__ __launch_bounds__(256) void k_maxpool2(const float* __restrict__ x, float* __restrict__ y, unsigned total, int H,
+                                                  int W, CfdDiv dHWo, CfdDiv dWo) {
     const int Ho = H / 2, Wo = W / 2;
-    const long total = nimg * Ho * Wo;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long img = e / (Ho * Wo);
-        const int p = (int)(e - img * Ho * Wo), yo = p / Wo, xo = p - yo * Wo;
-        const float* s = x + img * H * W + (2 * yo) * W + 2 * xo;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned img = cfd_div(e, dHWo);
+        const int p = (int)(e - img * (unsigned)(Ho * Wo)), yo = (int)cfd_div((unsigned)p, dWo), xo = p - yo * Wo;
+        const float* s = x + (size_t)img * H * W + (2 * yo) * W + 2 * xo;
         float m = s[0];
         m = s[1] > m ? s[1] : m;
         m = s[W] > m ? s[W] : m;
@@ -769,22 +769,22 @@ __global__ __launch_bounds__(256) void k_maxpool2(const float* __restrict__ x, f
 }
 
 __global__ __launch_bounds__(256) void k_maxpool2_bwd(const float* __restrict__ x, const float* __restrict__ gy,
-                                                      float* __restrict__ gx, long nimg, int H, int W) {
+                                                      float* __restrict__ gx, unsigned total, int H, int W, CfdDiv dHW,
+                                                      CfdDiv dW) {
     const int Ho = H / 2, Wo = W / 2;
-    const long total = nimg * H * W;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long img = e / (H * W);
-        const int p = (int)(e - img * H * W), yy = p / W, xx = p - yy * W;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned img = cfd_div(e, dHW);
+        const int p = (int)(e - img * (unsigned)(H * W)), yy = (int)cfd_div((unsigned)p, dW), xx = p - yy * W;
         const int yo = yy / 2, xo = xx / 2;
         float g = 0.f;
         if (yo < Ho && xo < Wo) {  // rows / columns cut off by floor mode get no gradient
-            const float* s = x + img * H * W + (2 * yo) * W + 2 * xo;
+            const float* s = x + (size_t)img * H * W + (2 * yo) * W + 2 * xo;
             int arg = 0;
             float m = s[0];
             if (s[1] > m) { m = s[1]; arg = 1; }
             if (s[W] > m) { m = s[W]; arg = 2; }
             if (s[W + 1] > m) { m = s[W + 1]; arg = 3; }
-            if (arg == (yy - 2 * yo) * 2 + (xx - 2 * xo)) g = gy[img * Ho * Wo + yo * Wo + xo];
+            if (arg == (yy - 2 * yo) * 2 + (xx - 2 * xo)) g = gy[(size_t)img * Ho * Wo + yo * Wo + xo];
         }
         gx[e] = g;
     }
@@ -793,8 +793,10 @@ __global__ __launch_bounds__(256) void k_maxpool2_bwd(const float* __restrict__ 
 extern "C" int cfd_maxpool2_fwd(const float* x, float* y, int nimg, int H, int W, void* stream) {
     CFD_REQUIRE(x && y && nimg >= 0 && H >= 2 && W >= 2, CFD_ERR_INVALID_ARG, "cfd_maxpool2_fwd: bad arguments");
     if (nimg == 0) return CFD_OK;
+    CFD_REQUIRE_I31((long)nimg * H * W, "cfd_maxpool2_fwd");
     hipLaunchKernelGGL(k_maxpool2, dim3(ew_blocks((long)nimg * (H / 2) * (W / 2))), dim3(256), 0, (hipStream_t)stream, x, y,
-                       (long)nimg, H, W);
+                       (unsigned)((long)nimg * (H / 2) * (W / 2)), H, W, cfd_div_make((unsigned)((H / 2) * (W / 2))),
+                       cfd_div_make((unsigned)(W / 2)));
     CFD_LAUNCH_CHECK("cfd_maxpool2_fwd");
     return CFD_OK;
 }
@@ -802,8 +804,9 @@ extern "C" int cfd_maxpool2_fwd(const float* x, float* y, int nimg, int H, int W
 extern "C" int cfd_maxpool2_bwd(const float* x, const float* gy, float* gx, int nimg, int H, int W, void* stream) {
     CFD_REQUIRE(x && gy && gx && nimg >= 0 && H >= 2 && W >= 2, CFD_ERR_INVALID_ARG, "cfd_maxpool2_bwd: bad arguments");
     if (nimg == 0) return CFD_OK;
+    CFD_REQUIRE_I31((long)nimg * H * W, "cfd_maxpool2_bwd");
     hipLaunchKernelGGL(k_maxpool2_bwd, dim3(ew_blocks((long)nimg * H * W)), dim3(256), 0, (hipStream_t)stream, x, gy, gx,
-                       (long)nimg, H, W);
+                       (unsigned)((long)nimg * H * W), H, W, cfd_div_make((unsigned)(H * W)), cfd_div_make((unsigned)W));
     CFD_LAUNCH_CHECK("cfd_maxpool2_bwd");
     return CFD_OK;
 }
@@ -813,12 +816,12 @@ extern "C" int cfd_maxpool2_bwd(const float* x, const float* gy, float* gx, int 
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_convt2_fwd(const float* __restrict__ in, const float* __restrict__ w,
                                                     const float* __restrict__ bias, float* __restrict__ out, int B, int Ci,
-                                                    int Co, int H, int W) {
+                                                    int Co, int H, int W, CfdDiv dWo, CfdDiv dHo, CfdDiv dCo) {
     const int Ho = 2 * H, Wo = 2 * W;
-    const long total = (long)B * Co * Ho * Wo;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int xo = (int)(e % Wo), yo = (int)((e / Wo) % Ho), o = (int)((e / ((long)Wo * Ho)) % Co);
-        const int b = (int)(e / ((long)Wo * Ho * Co));
+    const unsigned total = (unsigned)B * Co * Ho * Wo;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned r1 = cfd_div(e, dWo), r2 = cfd_div(r1, dHo), b = cfd_div(r2, dCo);
+        const int xo = (int)(e - r1 * (unsigned)Wo), yo = (int)(r1 - r2 * (unsigned)Ho), o = (int)(r2 - b * (unsigned)Co);
         const int y = yo >> 1, x = xo >> 1, kidx = (yo & 1) * 2 + (xo & 1);
         const float* ip = in + (size_t)b * Ci * H * W + y * W + x;
         const float* wp = w + (size_t)o * 4 + kidx;
@@ -829,12 +832,13 @@ __global__ __launch_bounds__(256) void k_convt2_fwd(const float* __restrict__ in
 }
 
 __global__ __launch_bounds__(256) void k_convt2_bwd_in(const float* __restrict__ g, const float* __restrict__ w,
-                                                       float* __restrict__ gin, int B, int Ci, int Co, int H, int W) {
+                                                       float* __restrict__ gin, int B, int Ci, int Co, int H, int W,
+                                                       CfdDiv dW, CfdDiv dH, CfdDiv dCi) {
     const int Ho = 2 * H, Wo = 2 * W;
-    const long total = (long)B * Ci * H * W;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(e % W), y = (int)((e / W) % H), i = (int)((e / ((long)W * H)) % Ci);
-        const int b = (int)(e / ((long)W * H * Ci));
+    const unsigned total = (unsigned)B * Ci * H * W;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned r1 = cfd_div(e, dW), r2 = cfd_div(r1, dH), b = cfd_div(r2, dCi);
+        const int x = (int)(e - r1 * (unsigned)W), y = (int)(r1 - r2 * (unsigned)H), i = (int)(r2 - b * (unsigned)Ci);
         const float* gp = g + (size_t)b * Co * Ho * Wo + (2 * y) * Wo + 2 * x;
         const float* wp = w + (size_t)i * Co * 4;
         float acc = 0.f;
@@ -855,8 +859,10 @@ extern "C" int cfd_convt2_fwd(const float* in, const float* w, const float* bias
     CFD_REQUIRE(B >= 0 && Ci >= 1 && Co >= 1 && H >= 1 && W >= 1, CFD_ERR_INVALID_ARG, "cfd_convt2_fwd: bad sizes");
     if (B == 0) return CFD_OK;
     CFD_PROF("k_convt2_fwd", (hipStream_t)stream);
+    CFD_REQUIRE_I31((long)B * Co * 4 * H * W, "cfd_convt2_fwd");
     hipLaunchKernelGGL(k_convt2_fwd, dim3(ew_blocks((long)B * Co * 4 * H * W)), dim3(256), 0, (hipStream_t)stream, in, w, bias,
-                       out, B, Ci, Co, H, W);
+                       out, B, Ci, Co, H, W, cfd_div_make((unsigned)(2 * W)), cfd_div_make((unsigned)(2 * H)),
+                       cfd_div_make((unsigned)Co));
     CFD_LAUNCH_CHECK("cfd_convt2_fwd");
     return CFD_OK;
 }
@@ -874,10 +880,12 @@ extern "C" int cfd_convt2_bwd(const float* gout, const float* in, const float* w
                               int B, int Ci, int Co, int H, int W, void* stream) {
     CFD_REQUIRE(gout && in && w && ws, CFD_ERR_INVALID_ARG, "cfd_convt2_bwd: NULL pointer");
     CFD_REQUIRE(B >= 1 && Ci >= 1 && Co >= 1 && H >= 1 && W >= 1, CFD_ERR_INVALID_ARG, "cfd_convt2_bwd: bad sizes");
+    CFD_REQUIRE_I31((long)B * (Ci > 4 * Co ? Ci : 4 * Co) * H * W, "cfd_convt2_bwd");
     hipStream_t st = (hipStream_t)stream;
     if (gin) {
         CFD_PROF("k_convt2_bwd_in", st);
-        hipLaunchKernelGGL(k_convt2_bwd_in, dim3(ew_blocks((long)B * Ci * H * W)), dim3(256), 0, st, gout, w, gin, B, Ci, Co, H, W);
+        hipLaunchKernelGGL(k_convt2_bwd_in, dim3(ew_blocks((long)B * Ci * H * W)), dim3(256), 0, st, gout, w, gin, B, Ci, Co, H, W,
+                           cfd_div_make((unsigned)W), cfd_div_make((unsigned)H), cfd_div_make((unsigned)Ci));
         CFD_LAUNCH_CHECK("cfd_convt2_bwd(input)");
     }
     if (gw) {
@@ -907,14 +915,14 @@ extern "C" int cfd_convt2_bwd(const float* gout, const float* in, const float* w
 // ------------------------------------------------------------------------------------------------------
 // x, out: (B,C,HW); resid: rows of (B,Cr,HW) with Cr >= C (the first C channels are used); mask: (B,HW) or NULL
 __global__ __launch_bounds__(256) void k_resid_mask(const float* __restrict__ x, const float* __restrict__ resid,
-                                                    const float* __restrict__ mask, float* __restrict__ out, long total, int C,
-                                                    int Cr, int HW) {
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int p = (int)(e % HW), c = (int)((e / HW) % C);
-        const long b = e / ((long)HW * C);
+                                                    const float* __restrict__ mask, float* __restrict__ out, unsigned total,
+                                                    int C, int Cr, int HW, CfdDiv dHW, CfdDiv dC) {
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned row = cfd_div(e, dHW), b = cfd_div(row, dC);
+        const int p = (int)(e - row * (unsigned)HW), c = (int)(row - b * (unsigned)C);
         float v = x[e];
         if (resid) v += resid[((size_t)b * Cr + c) * HW + p];
-        if (mask) v *= mask[b * HW + p];
+        if (mask) v *= mask[(size_t)b * HW + p];
         out[e] = v;
     }
 }
@@ -924,8 +932,9 @@ extern "C" int cfd_residual_mask(const float* x, const float* resid, const float
     CFD_REQUIRE(x && out && B >= 0 && C >= 1 && HW >= 1 && (!resid || Cr >= C), CFD_ERR_INVALID_ARG, "cfd_residual_mask: bad arguments");
     if (B == 0) return CFD_OK;
     const long total = (long)B * C * HW;
-    hipLaunchKernelGGL(k_resid_mask, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, resid, mask, out, total, C,
-                       Cr, HW);
+    CFD_REQUIRE_I31(total, "cfd_residual_mask");
+    hipLaunchKernelGGL(k_resid_mask, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, resid, mask, out,
+                       (unsigned)total, C, Cr, HW, cfd_div_make((unsigned)HW), cfd_div_make((unsigned)C));
     CFD_LAUNCH_CHECK("cfd_residual_mask");
     return CFD_OK;
 }

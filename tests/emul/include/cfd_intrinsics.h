@@ -75,6 +75,7 @@ inline int cfd_uniform(int x) { return x; }
 inline float cfd_erff(float x) { return erff(x); }
 inline float cfd_expf(float x) { return expf(x); }
 inline float cfd_rcpf(float x) { return 1.0f / x; }
+inline unsigned cfd_umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline float cfd_exp2f(float x) { return exp2f(x); }
 
 typedef float cfd_f2 __attribute__((ext_vector_type(2)));
