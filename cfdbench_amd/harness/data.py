@@ -54,13 +54,14 @@ class SyntheticAutoDataset(Dataset):
 
 def get_auto_dataset(data_dir: Path, data_name: str, delta_time: float, norm_props: bool, norm_bc: bool,
                      load_splits: Optional[List[str]] = None):
-    """(train, dev, test) CfdAutoDatasets (src/dataset/__init__.py:64): the cavity problem through the native loader
-    (harness/cavity.py), tube / dam / cylinder via the reference's loaders."""
-    if data_name.split("_")[0] == "cavity" and (load_splits is None or list(load_splits) == ["train", "dev", "test"]):
-        from .cavity import get_cavity_auto_datasets
+    """(train, dev, test) CfdAutoDatasets (src/dataset/__init__.py:64): cavity, tube and dam through the native loaders
+    (harness/flow_data.py), cylinder via the reference's loaders."""
+    problem = data_name.split("_")[0]
+    if problem in ("cavity", "tube", "dam") and (load_splits is None or list(load_splits) == ["train", "dev", "test"]):
+        from .flow_data import get_flow_auto_datasets
         assert delta_time > 0
-        return get_cavity_auto_datasets(Path(data_dir) / "cavity", case_name=data_name[len("cavity") + 1:],
-                                        norm_props=norm_props, norm_bc=norm_bc, delta_time=delta_time)
+        return get_flow_auto_datasets(problem, Path(data_dir) / problem, data_name[len(problem) + 1:],
+                                      norm_props=norm_props, norm_bc=norm_bc, delta_time=delta_time)
     try:
         from dataset import get_auto_dataset as ref_get  # the CFDBench checkout's package
     except Exception as e:  # noqa: BLE001

@@ -1,0 +1,263 @@
+"""Native loaders for CFDBench's on-disk data (the data format feeding the hot path): layout
+``<data_dir>/<problem>/{prop,bc,geo}/case<NNNN>/{u.npy, v.npy, case.json}``, boundary padding, normalisation, split and
+item conventions of ``src/dataset/{cavity,tube,dam}.py`` -- so the harness runs ``--data cavity_* | tube_* | dam_*``
+without the reference's package.  Bit-exact against the reference's own loaders on synthetic data trees
+(tests/test_cpu_dataset.py), including their quirks: the autoregressive splits of tube / dam truncate (``int``) where
+every other split rounds; dam's barrier mask statement slices with a step and so masks nothing (dam.py:82-84); dam keeps
+only five case parameters; tube's non-autoregressive class has no ``all_features``.
+
+Differences that are cost, not behaviour: frames are stacked with NumPy and the steady-state cut-off
+(``stable_state_diff``) is found with one vectorised pass per case instead of a Python loop over frames; ``device=``
+keeps the stacked frames resident on the GPU so a training step does no host-to-device copy of fields (the reference's
+collate does four per step, train_auto.py:53-58).  The cylinder problem still goes through the reference's package
+(harness/data.py)."""
+from __future__ import annotations
+
+import json
+import random
+from bisect import bisect_right
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+from torch.utils.data import Dataset
+
+DATA_DELTA_TIME = 0.1  # seconds between two stored frames (cavity.py:65,240; tube.py:62; dam.py:121)
+
+
+def normalize_physics_props(case_params: Dict[str, float]) -> None:
+    """In place, src/dataset/utils.py:8-21."""
+    case_params["density"] = (case_params["density"] - 5) / 4
+    case_params["viscosity"] = (case_params["viscosity"] - 0.00238) / 0.005
+
+
+def normalize_bc(case_params: Dict[str, float], key: str) -> None:
+    """In place, src/dataset/utils.py:24-28."""
+    case_params[key] = case_params[key] / 50 - 0.5
+
+
+def _load_raw(case_dir: Path):
+    with open(Path(case_dir) / "case.json", "r", encoding="utf8") as f:
+        case_params = json.load(f)
+    return np.load(Path(case_dir) / "u.npy"), np.load(Path(case_dir) / "v.npy"), case_params
+
+
+def _pad_left_top_bottom(u, v, mask, left_u):
+    """Left column = inlet boundary (u = left_u, v = 0), then a zero row above and below; the mask is 0 on all of them."""
+    u = np.pad(u, ((0, 0), (0, 0), (1, 0)), mode="constant", constant_values=left_u)
+    v = np.pad(v, ((0, 0), (0, 0), (1, 0)), mode="constant", constant_values=0)
+    mask = np.pad(mask, ((0, 0), (0, 0), (1, 0)), mode="constant", constant_values=0)
+    u = np.pad(u, ((0, 0), (1, 1), (0, 0)), mode="constant", constant_values=0)
+    v = np.pad(v, ((0, 0), (1, 1), (0, 0)), mode="constant", constant_values=0)
+    mask = np.pad(mask, ((0, 0), (1, 1), (0, 0)), mode="constant", constant_values=0)
+    return u, v, mask
+
+
+def load_cavity_case(case_dir: Path) -> Tuple[np.ndarray, Dict[str, float]]:
+    """(T, 3, h, w) [u, v, mask = 1] and the case.json dict (cavity.py:15-37): closed box, nothing to pad."""
+    u, v, case_params = _load_raw(case_dir)
+    return np.stack([u, v, np.ones_like(u)], axis=1), case_params
+
+
+def load_tube_case(case_dir: Path) -> Tuple[np.ndarray, Dict[str, float]]:
+    """tube.py:15-50: inlet column u = vel_in on the left, wall rows top and bottom -> (T, 3, h+2, w+1)."""
+    u, v, case_params = _load_raw(case_dir)
+    u, v, mask = _pad_left_top_bottom(u, v, np.ones_like(u), case_params["vel_in"])
+    return np.stack([u, v, mask], axis=1), case_params
+
+
+def load_dam_case(case_dir: Path) -> Tuple[np.ndarray, Dict[str, float]]:
+    """dam.py:51-111: zero left column except u = velocity below the barrier top, wall rows, five case parameters kept."""
+    u, v, case_params = _load_raw(case_dir)
+    mask = np.ones_like(u)
+    barrier_left, barrier_bottom = 0.5, 0
+    left_idx = int(barrier_left / case_params["dx"])
+    right_idx = int((barrier_left + case_params["barrier_width"]) / case_params["dx"])
+    bottom_idx = int(barrier_bottom / case_params["dy"])
+    top_idx = int(case_params["barrier_height"] / case_params["dy"])
+    # the reference's statement as written (dam.py:82-84): a stepped slice of the TIME axis with stop 0 -- selects nothing
+    mask[:bottom_idx:top_idx, left_idx:right_idx] = 0
+    u = np.pad(u, ((0, 0), (0, 0), (1, 0)), mode="constant", constant_values=0)
+    u[:, :top_idx, :1] = case_params["velocity"]
+    v = np.pad(v, ((0, 0), (0, 0), (1, 0)), mode="constant", constant_values=0)
+    mask = np.pad(mask, ((0, 0), (0, 0), (1, 0)), mode="constant", constant_values=0)
+    u = np.pad(u, ((0, 0), (1, 1), (0, 0)), mode="constant", constant_values=0)
+    v = np.pad(v, ((0, 0), (1, 1), (0, 0)), mode="constant", constant_values=0)
+    mask = np.pad(mask, ((0, 0), (1, 1), (0, 0)), mode="constant", constant_values=0)
+    keys = ["velocity", "density", "viscosity", "height", "width"]
+    return np.stack([u, v, mask], axis=1), {k: case_params[k] for k in keys}
+
+
+@dataclass(frozen=True)
+class Problem:
+    name: str
+    load_case_data: Callable
+    bc_key: str
+    auto_cutoff: bool        # the autoregressive loader stops a case at its steady state
+    auto_split_trunc: bool   # autoregressive split sizes use int() instead of round()
+    point_mode: bool         # the non-autoregressive class supports sample_point_by_point
+    nonauto_all_features: bool
+
+    @property
+    def case_params_keys(self) -> List[str]:
+        return [self.bc_key, "density", "viscosity", "height", "width"]
+
+
+PROBLEMS = {
+    "cavity": Problem("cavity", load_cavity_case, "vel_top", True, False, True, True),
+    "tube": Problem("tube", load_tube_case, "vel_in", True, True, False, False),
+    "dam": Problem("dam", load_dam_case, "velocity", False, True, False, True),
+}
+
+
+def _prepared_params(pb: Problem, case_params: Dict[str, float], norm_props: bool, norm_bc: bool) -> Dict[str, float]:
+    if norm_props:
+        normalize_physics_props(case_params)
+    if norm_bc:
+        normalize_bc(case_params, pb.bc_key)
+    return case_params
+
+
+class FlowAutoDataset(Dataset):
+    """Items ``(input (3,h,w), label (3,h,w), case_params {key: 0-dim float32 tensor})``: frame t -> frame
+    t + delta_time/0.1 of every case, for cavity / tube up to (excluding) the first pair whose mean speed change drops
+    below ``stable_state_diff`` (cavity.py:262-355, tube.py:196-290, dam.py:246-330).  Attributes of the reference
+    classes are kept: ``all_features`` (list of (T,3,h,w) arrays, read by test_multistep.py), ``case_params`` (list of
+    dicts), ``inputs``, ``labels``, ``case_ids``."""
+
+    data_delta_time = DATA_DELTA_TIME
+
+    def __init__(self, problem: Problem, case_dirs: List[Path], norm_props: bool, norm_bc: bool, delta_time: float = 0.1,
+                 stable_state_diff: float = 0.001, device: Optional[str] = None):
+        self.problem = problem
+        self.case_dirs = case_dirs
+        self.norm_props = norm_props
+        self.norm_bc = norm_bc
+        self.delta_time = delta_time
+        self.stable_state_diff = stable_state_diff
+        self.time_step_size = int(self.delta_time / self.data_delta_time)
+        self.case_params: List[dict] = []
+        self.all_features: List[np.ndarray] = []
+        ins, outs, ids = [], [], []
+        step = self.time_step_size
+        for case_id, case_dir in enumerate(case_dirs):
+            feats, params = problem.load_case_data(case_dir)
+            self.all_features.append(feats)
+            self.case_params.append(_prepared_params(problem, params, norm_props, norm_bc))
+            f32 = feats.astype(np.float32)
+            inp, out = f32[:-step], f32[step:]
+            n = len(inp)
+            if problem.auto_cutoff:
+                # steady state: the reference compares float32 speed fields frame by frame and stops at the first hit
+                diff = np.abs(np.sqrt(inp[:, 0] ** 2 + inp[:, 1] ** 2) - np.sqrt(out[:, 0] ** 2 + out[:, 1] ** 2)) \
+                    .reshape(len(inp), -1).mean(axis=1, dtype=np.float32)
+                hit = np.nonzero(diff < np.float32(stable_state_diff))[0]
+                n = int(hit[0]) if len(hit) else len(inp)
+            if np.isnan(inp[:n]).any() or np.isnan(out[:n]).any():
+                raise AssertionError(f"NaN in {case_dir}")
+            ins.append(inp[:n])
+            outs.append(out[:n])
+            ids += [case_id] * n
+        self.inputs = torch.from_numpy(np.concatenate(ins))
+        self.labels = torch.from_numpy(np.concatenate(outs))
+        self.case_ids = ids
+        if device is not None:
+            self.inputs, self.labels = self.inputs.to(device), self.labels.to(device)
+
+    def __getitem__(self, idx: int):
+        case_params = {k: torch.tensor(v, dtype=torch.float32) for k, v in self.case_params[self.case_ids[idx]].items()}
+        return self.inputs[idx], self.labels[idx], case_params
+
+    def __len__(self) -> int:
+        return len(self.inputs)
+
+
+class FlowDataset(Dataset):
+    """Non-autoregressive view (cavity.py:34-217, tube.py:53-193, dam.py:114-243): items ``(case_params (5,), t (1,),
+    frame (3,h,w))`` for whole frames, or -- cavity only -- ``(case_params, (t,x,y), value)`` point samples."""
+
+    data_delta_time = DATA_DELTA_TIME
+
+    def __init__(self, problem: Problem, case_dirs: List[Path], norm_props: bool, norm_bc: bool,
+                 sample_point_by_point: bool = False, stable_state_diff: float = 0.001):
+        self.problem = problem
+        self.case_params_keys = problem.case_params_keys
+        self.case_dirs = case_dirs
+        self.norm_props = norm_props
+        self.norm_bc = norm_bc
+        self.sample_point_by_point = sample_point_by_point
+        self.stable_state_diff = stable_state_diff
+        self.case_params: List[Tensor] = []
+        self.num_features = 0
+        self.num_frames: List[int] = []
+        self.features: List[Tensor] = []
+        all_features: List[np.ndarray] = []
+        for case_dir in case_dirs:
+            feats, params = problem.load_case_data(case_dir)
+            params = _prepared_params(problem, params, norm_props, norm_bc)
+            T, c, h, w = feats.shape
+            self.num_features += T * h * w
+            all_features.append(feats)
+            self.case_params.append(torch.tensor([params[k] for k in self.case_params_keys], dtype=torch.float32))
+            self.features.append(torch.tensor(feats, dtype=torch.float32))
+            self.num_frames.append(T)
+        if problem.nonauto_all_features:
+            self.all_features = all_features
+        self.case_ids = torch.arange(len(case_dirs))
+        self.num_frames_before = list(np.cumsum(self.num_frames).tolist())
+
+    def idx_to_case_id_and_frame_idx(self, idx: int) -> Tuple[int, int]:
+        case_id = bisect_right(self.num_frames_before, idx)
+        return case_id, idx if case_id == 0 else idx - self.num_frames_before[case_id - 1]
+
+    def __getitem__(self, idx: int):
+        if self.sample_point_by_point and self.problem.point_mode:
+            h, w = self.features[0].shape[2:]
+            case_id, t = self.idx_to_case_id_and_frame_idx(idx // (h * w))
+            pix = idx % (h * w)
+            y, x = pix // w, pix % w
+            return self.case_params[case_id], torch.tensor([t, x, y]).float(), self.features[case_id][t, :, y, x].squeeze().float()
+        case_id, frame_idx = self.idx_to_case_id_and_frame_idx(idx)
+        return self.case_params[case_id], torch.tensor([frame_idx]).float(), self.features[case_id][frame_idx]
+
+    def __len__(self) -> int:
+        if self.sample_point_by_point and self.problem.point_mode:
+            return self.num_features
+        return self.num_frames_before[-1]
+
+
+def split_case_dirs(data_dir: Path, subset_name: str, seed: int, trunc: bool):
+    """Subsets named in ``subset_name`` in the fixed order prop, bc, geo; case<N> sorted by N; ``random.seed(seed)``
+    shuffle; 80 / 10 / 10 split with ``round`` (or ``int`` for the autoregressive tube / dam loaders)."""
+    case_dirs: List[Path] = []
+    for name in ["prop", "bc", "geo"]:
+        if name in subset_name:
+            case_dirs += sorted((Path(data_dir) / name).glob("case*"), key=lambda x: int(x.name[4:]))
+    assert case_dirs != [], f"no cases under {data_dir} for subset {subset_name!r}"
+    random.seed(seed)
+    random.shuffle(case_dirs)
+    n = len(case_dirs)
+    size = int if trunc else round
+    n_train, n_dev = size(n * 0.8), size(n * 0.1)
+    return case_dirs[:n_train], case_dirs[n_train:n_train + n_dev], case_dirs[n_train + n_dev:]
+
+
+def get_flow_auto_datasets(problem: str, data_dir: Path, subset_name: str, norm_props: bool, norm_bc: bool,
+                           delta_time: float = 0.1, stable_state_diff: float = 0.001, seed: int = 0,
+                           device: Optional[str] = None):
+    """(train, dev, test) of get_{cavity,tube,dam}_auto_datasets; ``data_dir`` is the problem's own directory."""
+    pb = PROBLEMS[problem]
+    splits = split_case_dirs(data_dir, subset_name, seed, pb.auto_split_trunc)
+    kw = dict(delta_time=delta_time, stable_state_diff=stable_state_diff, norm_props=norm_props, norm_bc=norm_bc,
+              device=device)
+    return tuple(FlowAutoDataset(pb, dirs, **kw) for dirs in splits)
+
+
+def get_flow_datasets(problem: str, data_dir: Path, subset_name: str, norm_props: bool, norm_bc: bool, seed: int = 0):
+    """(train, dev, test) of get_{cavity,tube,dam}_datasets."""
+    pb = PROBLEMS[problem]
+    splits = split_case_dirs(data_dir, subset_name, seed, False)
+    return tuple(FlowDataset(pb, dirs, norm_props=norm_props, norm_bc=norm_bc) for dirs in splits)

@@ -186,11 +186,12 @@ class SyntheticDataset(Dataset):
 
 
 def get_dataset(data_dir: Path, data_name: str, norm_props: bool, norm_bc: bool):
-    """(train, dev, test) CfdDatasets (src/dataset/__init__.py:12): cavity natively, the rest via the reference."""
-    if data_name.split("_")[0] == "cavity":
-        from .cavity import get_cavity_datasets
-        return get_cavity_datasets(Path(data_dir) / "cavity", case_name=data_name[len("cavity") + 1:],
-                                   norm_props=norm_props, norm_bc=norm_bc)
+    """(train, dev, test) CfdDatasets (src/dataset/__init__.py:12): cavity / tube / dam natively, cylinder via the reference."""
+    problem = data_name.split("_")[0]
+    if problem in ("cavity", "tube", "dam"):
+        from .flow_data import get_flow_datasets
+        return get_flow_datasets(problem, Path(data_dir) / problem, data_name[len(problem) + 1:], norm_props=norm_props,
+                                 norm_bc=norm_bc)
     try:
         from dataset import get_dataset as ref_get
     except Exception as e:  # noqa: BLE001

@@ -335,6 +335,46 @@ def gen_cavity_dataset(name, seed=5):
     print(name, "ok")
 
 
+def gen_flow_dataset(name, problem, seed=5):
+    """As gen_cavity_dataset for the tube / dam loaders of the reference (src/dataset/tube.py, dam.py)."""
+    import hashlib
+    import importlib
+    import json
+    import tempfile
+    mod = importlib.import_module(f"dataset.{problem}")  # reference
+    get_auto, get_nonauto = getattr(mod, f"get_{problem}_auto_datasets"), getattr(mod, f"get_{problem}_datasets")
+    digest = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    out = dict(seed=seed, problem=problem, auto={}, nonauto={})
+    with tempfile.TemporaryDirectory() as tmp:
+        root = synth.write_flow_tree(tmp, problem, seed)
+        for subset, dt, np_, nb in (("prop_bc_geo", 0.1, True, True), ("prop_geo", 0.2, False, True), ("prop_bc", 0.1, True, False)):
+            splits = get_auto(root / problem, subset, norm_props=np_, norm_bc=nb, delta_time=dt)
+            rec = []
+            for ds in splits:
+                i0, l0, cp0 = ds[len(ds) // 2]
+                rec.append(dict(cases=[f"{d.parent.name}/{d.name}" for d in ds.case_dirs], n=len(ds),
+                                case_ids=[int(v) for v in ds.case_ids], inputs=digest(ds.inputs.numpy()),
+                                labels=digest(ds.labels.numpy()), case_params=ds.case_params,
+                                shape=list(ds.inputs.shape[1:]),
+                                mid_item=dict(inp=digest(i0.numpy()), lab=digest(l0.numpy()),
+                                              cp={k: float(v) for k, v in cp0.items()}),
+                                n_features=[int(f.shape[0]) for f in ds.all_features]))
+            out["auto"][f"{subset}|{dt}|{int(np_)}|{int(nb)}"] = rec
+        splits = get_nonauto(root / problem, "prop_geo", norm_props=True, norm_bc=True)
+        rec = []
+        for ds in splits:
+            cp, t, frame = ds[len(ds) - 2]
+            rec.append(dict(cases=[f"{d.parent.name}/{d.name}" for d in ds.case_dirs], n=len(ds),
+                            num_frames_before=[int(v) for v in ds.num_frames_before], num_features=int(ds.num_features),
+                            case_params=[[float(x) for x in c] for c in ds.case_params],
+                            has_all_features=hasattr(ds, "all_features") and ds.all_features is not None,
+                            item=dict(cp=[float(x) for x in cp], t=float(t[0]), frame=digest(frame.numpy()))))
+        out["nonauto"]["prop_geo"] = rec
+    with open(OUT / f"{name}.json", "w", encoding="utf8") as f:
+        json.dump(out, f, indent=1)
+    print(name, "ok")
+
+
 def gen_mseloss(name, seed):
     rng = np.random.default_rng(seed)
     p = rng.standard_normal((3, 2, 17, 19)).astype(np.float32)
@@ -371,6 +411,8 @@ def main():
     gen_adam("adam_small_64x64", 26, 36, 2, 8, 2, 64, 64, nsteps=3, lr=1e-3, gain=8.0)
     gen_mseloss("mseloss", 41)
     gen_cavity_dataset("cavity_dataset")
+    gen_flow_dataset("tube_dataset", "tube")
+    gen_flow_dataset("dam_dataset", "dam")
 
 
 if __name__ == "__main__":

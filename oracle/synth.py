@@ -119,3 +119,37 @@ def write_cavity_tree(root, seed: int = 0, h: int = 12, w: int = 12):
             with open(d / "case.json", "w", encoding="utf8") as f:
                 json.dump(dict(vel_top=vel, density=dens, viscosity=visc, height=hh, width=ww), f)
     return root.parent
+
+
+def write_flow_tree(root, problem: str, seed: int = 0, h: int = 10, w: int = 12):
+    """Like write_cavity_tree for the tube and dam problems (their case.json keys: tube ``vel_in``; dam ``velocity``,
+    ``barrier_width``, ``barrier_height``, ``dx``, ``dy``): ``root``/<problem>/{prop,bc,geo}/case<NNNN>/."""
+    import json
+    from pathlib import Path
+    if problem == "cavity":
+        return write_cavity_tree(root, seed, h, w)
+    rng = np.random.default_rng(seed + (17 if problem == "tube" else 29))
+    base = Path(root) / problem
+    yy, xx = np.meshgrid(np.linspace(0, 1, h), np.linspace(0, 1, w), indexing="ij")
+    for subset, ids in (("prop", [0, 1, 2, 5, 6, 7, 8, 30]), ("bc", [0, 1, 3, 4, 9]), ("geo", [2, 3, 11, 12])):
+        for cid in ids:
+            d = base / subset / f"case{cid:04d}"
+            d.mkdir(parents=True, exist_ok=True)
+            T = int(rng.integers(5, 12))
+            tau = float(rng.uniform(0.3, 2.5))
+            vel, dens, visc = float(rng.uniform(0.5, 5)), float(rng.uniform(0.5, 10)), float(rng.uniform(1e-4, 1e-2))
+            hh, ww = (float(rng.uniform(0.2, 1.0)), float(rng.uniform(1.0, 8.0))) if subset == "geo" else (0.4, 5.0)
+            ramp = (1.0 - np.exp(-(np.arange(T) + 1.0) / tau))[:, None, None]
+            u = vel * ramp * (4 * yy * (1 - yy))[None] * (1 + 0.1 * np.sin(2 * np.pi * xx))[None]
+            v = 0.1 * vel * ramp * (np.sin(np.pi * yy) * np.cos(2 * np.pi * xx))[None]
+            np.save(d / "u.npy", u)
+            np.save(d / "v.npy", v)
+            if problem == "tube":
+                cp = dict(vel_in=vel, density=dens, viscosity=visc, height=hh, width=ww)
+            else:
+                cp = dict(velocity=vel, density=dens, viscosity=visc, height=hh, width=ww,
+                          barrier_width=float(rng.uniform(0.1, 0.4)), barrier_height=float(rng.uniform(0.05, 0.3)),
+                          dx=ww / w, dy=hh / h, extra_key_the_loader_drops=1.0)
+            with open(d / "case.json", "w", encoding="utf8") as f:
+                json.dump(cp, f)
+    return Path(root)
