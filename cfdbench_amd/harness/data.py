@@ -1,6 +1,6 @@
 """Dataset glue.  The on-disk format and preprocessing of CFDBench (src/dataset/*.py, ~2500 lines of NumPy) feed the hot
-path but are not part of it ("next" row 1): ``get_auto_dataset`` defers to the reference's own
-``dataset`` package when a CFDBench checkout is on ``sys.path`` and says so clearly when it is not.
+path but are not part of it ("next" row 1): ``get_auto_dataset`` routes every benchmark problem
+(cavity, tube, dam, cylinder) to the native loaders of harness/flow_data.py.
 ``SyntheticAutoDataset`` produces items of exactly the reference's shape -- ``(inputs (3,h,w), label (3,h,w),
 case_params dict)`` with the mask as the last channel (src/dataset/base.py, cavity.py:333-347) -- for smoke runs, tests
 and benchmarks without data on disk."""
@@ -54,21 +54,13 @@ class SyntheticAutoDataset(Dataset):
 
 def get_auto_dataset(data_dir: Path, data_name: str, delta_time: float, norm_props: bool, norm_bc: bool,
                      load_splits: Optional[List[str]] = None):
-    """(train, dev, test) CfdAutoDatasets (src/dataset/__init__.py:64): cavity, tube and dam through the native loaders
-    (harness/flow_data.py), cylinder via the reference's loaders."""
+    """(train, dev, test) CfdAutoDatasets (src/dataset/__init__.py:64) through the native loaders
+    (harness/flow_data.py); ``load_splits`` is honoured for the cylinder problem only, as in the reference."""
     problem = data_name.split("_")[0]
-    if problem in ("cavity", "tube", "dam") and (load_splits is None or list(load_splits) == ["train", "dev", "test"]):
+    if problem in ("cavity", "tube", "dam", "cylinder"):
         from .flow_data import get_flow_auto_datasets
         assert delta_time > 0
+        kw = dict(load_splits=tuple(load_splits)) if (problem == "cylinder" and load_splits is not None) else {}
         return get_flow_auto_datasets(problem, Path(data_dir) / problem, data_name[len(problem) + 1:],
-                                      norm_props=norm_props, norm_bc=norm_bc, delta_time=delta_time)
-    try:
-        from dataset import get_auto_dataset as ref_get  # the CFDBench checkout's package
-    except Exception as e:  # noqa: BLE001
-        raise RuntimeError(
-            "cfdbench_amd ships the hot path, not CFDBench's dataset loaders: put the CFDBench `src/` directory on "
-            "PYTHONPATH so that `import dataset` resolves (its loaders are NumPy-only), or pass your own Dataset objects "
-            f"to train()/evaluate().  ({e})") from e
-    kw = {} if load_splits is None else dict(load_splits=load_splits)
-    return ref_get(data_dir=Path(data_dir), data_name=data_name, delta_time=delta_time, norm_props=norm_props,
-                   norm_bc=norm_bc, **kw)
+                                      norm_props=norm_props, norm_bc=norm_bc, delta_time=delta_time, **kw)
+    raise ValueError(f'Invalid data name "{data_name}"')  # src/dataset/__init__.py:125

@@ -1,7 +1,7 @@
 """Native loaders for CFDBench's on-disk data (the data format feeding the hot path): layout
 ``<data_dir>/<problem>/{prop,bc,geo}/case<NNNN>/{u.npy, v.npy, case.json}``, boundary padding, normalisation, split and
-item conventions of ``src/dataset/{cavity,tube,dam}.py`` -- so the harness runs ``--data cavity_* | tube_* | dam_*``
-without the reference's package.  Bit-exact against the reference's own loaders on synthetic data trees
+item conventions of ``src/dataset/{cavity,tube,dam,cylinder}.py`` -- so the harness runs every ``--data`` name of the
+benchmark without the reference's package.  Bit-exact against the reference's own loaders on synthetic data trees
 (tests/test_cpu_dataset.py), including their quirks: the autoregressive splits of tube / dam truncate (``int``) where
 every other split rounds; dam's barrier mask statement slices with a step and so masks nothing (dam.py:82-84); dam keeps
 only five case parameters; tube's non-autoregressive class has no ``all_features``.
@@ -9,8 +9,8 @@ only five case parameters; tube's non-autoregressive class has no ``all_features
 Differences that are cost, not behaviour: frames are stacked with NumPy and the steady-state cut-off
 (``stable_state_diff``) is found with one vectorised pass per case instead of a Python loop over frames; ``device=``
 keeps the stacked frames resident on the GPU so a training step does no host-to-device copy of fields (the reference's
-collate does four per step, train_auto.py:53-58).  The cylinder problem still goes through the reference's package
-(harness/data.py)."""
+collate does four per step, train_auto.py:53-58).  Cylinder: the variant in use is ``load_case_data_fix`` (unpadded
+64x64 frames, cell-centre cylinder mask); its autoregressive class assumes 1-ms frames (``data_delta_time = 0.001``)."""
 from __future__ import annotations
 
 import json
@@ -25,7 +25,7 @@ import torch
 from torch import Tensor
 from torch.utils.data import Dataset
 
-DATA_DELTA_TIME = 0.1  # seconds between two stored frames (cavity.py:65,240; tube.py:62; dam.py:121)
+DATA_DELTA_TIME = 0.1  # seconds between two stored frames (cavity.py:65,240; tube.py:62; dam.py:121; cylinder auto: 0.001)
 
 
 def normalize_physics_props(case_params: Dict[str, float]) -> None:
@@ -91,6 +91,36 @@ def load_dam_case(case_dir: Path) -> Tuple[np.ndarray, Dict[str, float]]:
     return np.stack([u, v, mask], axis=1), {k: case_params[k] for k in keys}
 
 
+def load_cylinder_case(case_dir: Path) -> Tuple[np.ndarray, Dict[str, float]]:
+    """cylinder.py:194-283 (``load_case_data_fix``, the variant both cylinder classes call): the 64x64 frames are NOT
+    padded; the mask is 0 inside the cylinder (cell centres within ``radius`` of the centre given in case.json, or of the
+    origin) and on the top / bottom / left boundary cells; ``x_min .. y_max`` are replaced by ``height`` / ``width``."""
+    u, v, case_params = _load_raw(case_dir)
+    x_min, x_max, y_min, y_max = (case_params[k] for k in ("x_min", "x_max", "y_min", "y_max"))
+    radius = case_params["radius"]
+    if "center_x" in case_params and "center_y" in case_params:
+        center_x, center_y = case_params["center_x"], case_params["center_y"]
+    else:
+        center_x = center_y = 0.0
+        case_params["center_x"], case_params["center_y"] = center_x, center_y
+    height, width = y_max - y_min, x_max - x_min
+    case_params["height"], case_params["width"] = height, width
+    for key in ["x_min", "x_max", "y_min", "y_max"]:
+        if key in case_params:
+            del case_params[key]
+    mask = np.ones_like(u)
+    gh, gw = u.shape[1], u.shape[2]
+    dx, dy = width / gw, height / gh
+    xs = x_min + (np.arange(gw) + 0.5) * dx
+    ys = y_min + (np.arange(gh) + 0.5) * dy
+    inside = (xs[None, :] - center_x) ** 2 + (ys[:, None] - center_y) ** 2 <= radius ** 2
+    mask[:, inside] = 0
+    mask[:, 0, :] = 0
+    mask[:, -1, :] = 0
+    mask[:, :, 0] = 0
+    return np.stack([u, v, mask], axis=1), case_params
+
+
 @dataclass(frozen=True)
 class Problem:
     name: str
@@ -100,16 +130,21 @@ class Problem:
     auto_split_trunc: bool   # autoregressive split sizes use int() instead of round()
     point_mode: bool         # the non-autoregressive class supports sample_point_by_point
     nonauto_all_features: bool
+    auto_delta_time: float = DATA_DELTA_TIME  # seconds between stored frames as assumed by the autoregressive class
+    nonauto_split_trunc: bool = False
+    extra_keys: Tuple[str, ...] = ()
 
     @property
     def case_params_keys(self) -> List[str]:
-        return [self.bc_key, "density", "viscosity", "height", "width"]
+        return [self.bc_key, "density", "viscosity", "height", "width", *self.extra_keys]
 
 
 PROBLEMS = {
     "cavity": Problem("cavity", load_cavity_case, "vel_top", True, False, True, True),
     "tube": Problem("tube", load_tube_case, "vel_in", True, True, False, False),
     "dam": Problem("dam", load_dam_case, "velocity", False, True, False, True),
+    "cylinder": Problem("cylinder", load_cylinder_case, "vel_in", True, True, False, False, auto_delta_time=0.001,
+                        nonauto_split_trunc=True, extra_keys=("center_x", "center_y", "radius")),
 }
 
 
@@ -138,6 +173,7 @@ class FlowAutoDataset(Dataset):
         self.norm_bc = norm_bc
         self.delta_time = delta_time
         self.stable_state_diff = stable_state_diff
+        self.data_delta_time = problem.auto_delta_time
         self.time_step_size = int(self.delta_time / self.data_delta_time)
         self.case_params: List[dict] = []
         self.all_features: List[np.ndarray] = []
@@ -247,17 +283,20 @@ def split_case_dirs(data_dir: Path, subset_name: str, seed: int, trunc: bool):
 
 def get_flow_auto_datasets(problem: str, data_dir: Path, subset_name: str, norm_props: bool, norm_bc: bool,
                            delta_time: float = 0.1, stable_state_diff: float = 0.001, seed: int = 0,
-                           device: Optional[str] = None):
-    """(train, dev, test) of get_{cavity,tube,dam}_auto_datasets; ``data_dir`` is the problem's own directory."""
+                           device: Optional[str] = None, load_splits=("train", "dev", "test")):
+    """(train, dev, test) of get_{cavity,tube,dam,cylinder}_auto_datasets; ``data_dir`` is the problem's own directory.
+    Splits not named in ``load_splits`` come back as None (cylinder.py:606-672).  The reference's on-disk cache of the
+    cylinder tensors (``./dataset/cache``) is not reproduced: loading is one vectorised pass."""
     pb = PROBLEMS[problem]
     splits = split_case_dirs(data_dir, subset_name, seed, pb.auto_split_trunc)
     kw = dict(delta_time=delta_time, stable_state_diff=stable_state_diff, norm_props=norm_props, norm_bc=norm_bc,
               device=device)
-    return tuple(FlowAutoDataset(pb, dirs, **kw) for dirs in splits)
+    return tuple(FlowAutoDataset(pb, dirs, **kw) if name in load_splits else None
+                 for name, dirs in zip(("train", "dev", "test"), splits))
 
 
 def get_flow_datasets(problem: str, data_dir: Path, subset_name: str, norm_props: bool, norm_bc: bool, seed: int = 0):
     """(train, dev, test) of get_{cavity,tube,dam}_datasets."""
     pb = PROBLEMS[problem]
-    splits = split_case_dirs(data_dir, subset_name, seed, False)
+    splits = split_case_dirs(data_dir, subset_name, seed, pb.nonauto_split_trunc)
     return tuple(FlowDataset(pb, dirs, norm_props=norm_props, norm_bc=norm_bc) for dirs in splits)

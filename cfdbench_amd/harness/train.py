@@ -186,19 +186,13 @@ class SyntheticDataset(Dataset):
 
 
 def get_dataset(data_dir: Path, data_name: str, norm_props: bool, norm_bc: bool):
-    """(train, dev, test) CfdDatasets (src/dataset/__init__.py:12): cavity / tube / dam natively, cylinder via the reference."""
+    """(train, dev, test) CfdDatasets (src/dataset/__init__.py:12) through the native loaders (harness/flow_data.py)."""
     problem = data_name.split("_")[0]
-    if problem in ("cavity", "tube", "dam"):
+    if problem in ("cavity", "tube", "dam", "cylinder"):
         from .flow_data import get_flow_datasets
         return get_flow_datasets(problem, Path(data_dir) / problem, data_name[len(problem) + 1:], norm_props=norm_props,
                                  norm_bc=norm_bc)
-    try:
-        from dataset import get_dataset as ref_get
-    except Exception as e:  # noqa: BLE001
-        raise RuntimeError(
-            "cfdbench_amd ships the hot path, not CFDBench's dataset loaders: put the CFDBench `src/` directory on "
-            f"PYTHONPATH so that `import dataset` resolves, or pass your own Dataset objects to train()/evaluate().  ({e})") from e
-    return ref_get(data_dir=Path(data_dir), data_name=data_name, norm_props=norm_props, norm_bc=norm_bc)
+    raise ValueError(f"Invalid data name {data_name}!")  # src/dataset/__init__.py:60
 
 
 def main(argv=None):

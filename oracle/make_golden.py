@@ -345,9 +345,13 @@ def gen_flow_dataset(name, problem, seed=5):
     get_auto, get_nonauto = getattr(mod, f"get_{problem}_auto_datasets"), getattr(mod, f"get_{problem}_datasets")
     digest = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
     out = dict(seed=seed, problem=problem, auto={}, nonauto={})
+    cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)  # the cylinder loader of the reference writes a tensor cache under ./dataset/cache
         root = synth.write_flow_tree(tmp, problem, seed)
+        scale = 0.01 if problem == "cylinder" else 1.0  # its autoregressive class assumes 1-ms frames
         for subset, dt, np_, nb in (("prop_bc_geo", 0.1, True, True), ("prop_geo", 0.2, False, True), ("prop_bc", 0.1, True, False)):
+            dt = round(dt * scale, 6)
             splits = get_auto(root / problem, subset, norm_props=np_, norm_bc=nb, delta_time=dt)
             rec = []
             for ds in splits:
@@ -370,6 +374,7 @@ def gen_flow_dataset(name, problem, seed=5):
                             has_all_features=hasattr(ds, "all_features") and ds.all_features is not None,
                             item=dict(cp=[float(x) for x in cp], t=float(t[0]), frame=digest(frame.numpy()))))
         out["nonauto"]["prop_geo"] = rec
+        os.chdir(cwd)
     with open(OUT / f"{name}.json", "w", encoding="utf8") as f:
         json.dump(out, f, indent=1)
     print(name, "ok")
@@ -413,6 +418,7 @@ def main():
     gen_cavity_dataset("cavity_dataset")
     gen_flow_dataset("tube_dataset", "tube")
     gen_flow_dataset("dam_dataset", "dam")
+    gen_flow_dataset("cylinder_dataset", "cylinder")
 
 
 if __name__ == "__main__":

@@ -128,6 +128,8 @@ def write_flow_tree(root, problem: str, seed: int = 0, h: int = 10, w: int = 12)
     from pathlib import Path
     if problem == "cavity":
         return write_cavity_tree(root, seed, h, w)
+    if problem == "cylinder":
+        return write_cylinder_tree(root, seed)
     rng = np.random.default_rng(seed + (17 if problem == "tube" else 29))
     base = Path(root) / problem
     yy, xx = np.meshgrid(np.linspace(0, 1, h), np.linspace(0, 1, w), indexing="ij")
@@ -150,6 +152,36 @@ def write_flow_tree(root, problem: str, seed: int = 0, h: int = 10, w: int = 12)
                 cp = dict(velocity=vel, density=dens, viscosity=visc, height=hh, width=ww,
                           barrier_width=float(rng.uniform(0.1, 0.4)), barrier_height=float(rng.uniform(0.05, 0.3)),
                           dx=ww / w, dy=hh / h, extra_key_the_loader_drops=1.0)
+            with open(d / "case.json", "w", encoding="utf8") as f:
+                json.dump(cp, f)
+    return Path(root)
+
+
+def write_cylinder_tree(root, seed: int = 0, h: int = 12, w: int = 14):
+    """Synthetic cylinder-problem tree (case.json: vel_in, density, viscosity, radius, x_min, x_max, y_min, y_max and --
+    in some cases -- an explicit center_x / center_y): ``root``/cylinder/{prop,bc,geo}/case<NNNN>/."""
+    import json
+    from pathlib import Path
+    rng = np.random.default_rng(seed + 41)
+    base = Path(root) / "cylinder"
+    yy, xx = np.meshgrid(np.linspace(0, 1, h), np.linspace(0, 1, w), indexing="ij")
+    for subset, ids in (("prop", [0, 1, 2, 3, 4, 9, 21]), ("bc", [0, 5, 6, 7, 8]), ("geo", [1, 2, 3, 10])):
+        for cid in ids:
+            d = base / subset / f"case{cid:04d}"
+            d.mkdir(parents=True, exist_ok=True)
+            T = int(rng.integers(8, 16))
+            tau = float(rng.uniform(0.5, 3.0))
+            vel, dens, visc = float(rng.uniform(0.05, 0.15)), float(rng.uniform(900, 1100)), float(rng.uniform(5e-3, 1.5e-2))
+            ramp = (1.0 - np.exp(-(np.arange(T) + 1.0) / tau))[:, None, None]
+            u = 10 * vel * ramp * (1 + 0.3 * np.sin(2 * np.pi * xx) * np.cos(np.pi * yy))[None]
+            v = 3 * vel * ramp * (np.sin(2 * np.pi * yy) * np.sin(np.pi * xx))[None]
+            np.save(d / "u.npy", u)
+            np.save(d / "v.npy", v)
+            cp = dict(vel_in=vel, density=dens, viscosity=visc, radius=float(rng.uniform(0.05, 0.12)),
+                      x_min=-float(rng.uniform(0.3, 0.6)), x_max=float(rng.uniform(0.8, 1.4)),
+                      y_min=-float(rng.uniform(0.3, 0.5)), y_max=float(rng.uniform(0.3, 0.5)))
+            if cid % 2 == 1:
+                cp["center_x"], cp["center_y"] = float(rng.uniform(-0.05, 0.05)), float(rng.uniform(-0.05, 0.05))
             with open(d / "case.json", "w", encoding="utf8") as f:
                 json.dump(cp, f)
     return Path(root)
