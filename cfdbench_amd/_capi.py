@@ -105,6 +105,8 @@ _SIGS = {
     "cfd_fno_forward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "cfd_fno_backward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),
                               _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cfd_fno_backward_phase": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),
+                              _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
 }
 
 

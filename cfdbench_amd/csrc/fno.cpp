@@ -92,37 +92,54 @@ extern "C" int cfd_fno_forward(const cfd_plan* p, const cfd_fno_shape* s, const 
     return CFD_OK;
 }
 
+// One phase of the backward pass: 0 = projection head (+ loss gradient), 1 .. L = FnoBlock L-phase (the blocks in reverse
+// order), L+1 = lifting layer.  Phases must run in this order on one stream; the running input gradient alternates
+// between two workspace buffers, so a phase finds its operands from its index alone.  After phase k the gradients of
+// that phase's parameters are final -- a data-parallel trainer can start their all-reduce while later phases compute.
+extern "C" int cfd_fno_backward_phase(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm,
+                                      const cfd_fno_params* g, const float* inputs, const float* case_params,
+                                      const float* mask, const float* label, const float* preds,
+                                      const float* gpreds_ext, const float* coef, void* ws, int phase, void* stream) {
+    CFD_TRY(check_shape("cfd_fno_backward_phase", p, s));
+    CFD_REQUIRE(prm && g && inputs && ws, CFD_ERR_INVALID_ARG, "cfd_fno_backward_phase: NULL pointer");
+    const Layout L = make_layout(p, s, 1);
+    char* base = (char*)ws;
+    const int B = s->B, C = s->hidden, HW = s->H * s->W, NL = s->num_layers;
+    CFD_REQUIRE(phase >= 0 && phase <= NL + 1, CFD_ERR_INVALID_ARG, "cfd_fno_backward_phase: phase %d outside 0..%d", phase, NL + 1);
+    auto act_buf = [&](int l) { return (float*)(base + L.off_acts) + (size_t)l * L.n_act; };
+    auto xh_buf = [&](int l) { return (float*)(base + L.off_xh) + (size_t)l * L.n_modes; };
+    float* z = (float*)(base + L.off_z);
+    float* gA = (float*)(base + L.off_gA);
+    float* gB = (float*)(base + L.off_gB);
+    float* gh = (float*)(base + L.off_gh);
+    void* scratch = base + L.off_scratch;
+    if (phase == 0)
+        return cfd_fno_head_bwd(act_buf(NL), mask, label, preds, gpreds_ext, coef, prm->fc1_w, prm->fc1_b, prm->fc2_w, gA,
+                                g->fc1_w, g->fc1_b, g->fc2_w, g->fc2_b, scratch, B, C, s->head, s->out_chan, HW, NL > 0,
+                                stream);
+    const int done = phase - 1;  // blocks already processed: the gradient sits in gA after an even count
+    float* gcur = (done & 1) ? gB : gA;
+    float* gnext = (done & 1) ? gA : gB;
+    if (phase == NL + 1)
+        return cfd_fno_stem_bwd(p, gcur, inputs, mask, case_params, g->fc0_w, g->fc0_b, scratch, B, s->in_chan,
+                                s->n_case_params, C, stream);
+    const int l = NL - phase;
+    const int act = l > 0;
+    // gcur = d loss / d a_{l+1}
+    CFD_TRY(cfd_spectral_dft(p, gcur, gh, B * C, 0, stream));
+    CFD_TRY(cfd_spectral_wgrad(p, xh_buf(l), gh, g->spec_w1[l], g->spec_w2[l], scratch, B, C, C, stream));
+    CFD_TRY(cfd_chan_wgrad(gcur, act_buf(l), g->w0_w[l], g->w0_b[l], scratch, B, C, C, HW, act, stream));
+    CFD_TRY(cfd_spectral_mix(p, gh, prm->spec_w1[l], prm->spec_w2[l], z, B, C, C, 1, stream));
+    return cfd_fno_block_bwd_input(p, gcur, z, prm->w0_w[l], act ? act_buf(l) : nullptr, gnext, B, C, C, stream);
+}
+
 extern "C" int cfd_fno_backward(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm,
                                 const cfd_fno_params* g, const float* inputs, const float* case_params,
                                 const float* mask, const float* label, const float* preds, const float* gpreds_ext,
                                 const float* coef, void* ws, void* stream) {
     CFD_TRY(check_shape("cfd_fno_backward", p, s));
-    CFD_REQUIRE(prm && g && inputs && ws, CFD_ERR_INVALID_ARG, "cfd_fno_backward: NULL pointer");
-    const Layout L = make_layout(p, s, 1);
-    char* base = (char*)ws;
-    const int B = s->B, C = s->hidden, HW = s->H * s->W, NL = s->num_layers;
-    auto act_buf = [&](int l) { return (float*)(base + L.off_acts) + (size_t)l * L.n_act; };
-    auto xh_buf = [&](int l) { return (float*)(base + L.off_xh) + (size_t)l * L.n_modes; };
-    float* z = (float*)(base + L.off_z);
-    float* gcur = (float*)(base + L.off_gA);
-    float* gnext = (float*)(base + L.off_gB);
-    float* gh = (float*)(base + L.off_gh);
-    void* scratch = base + L.off_scratch;
-
-    CFD_TRY(cfd_fno_head_bwd(act_buf(NL), mask, label, preds, gpreds_ext, coef, prm->fc1_w, prm->fc1_b, prm->fc2_w, gcur,
-                             g->fc1_w, g->fc1_b, g->fc2_w, g->fc2_b, scratch, B, C, s->head, s->out_chan, HW, NL > 0,
-                             stream));
-    for (int l = NL - 1; l >= 0; --l) {
-        const int act = l > 0;
-        // gcur = d loss / d a_{l+1}
-        CFD_TRY(cfd_spectral_dft(p, gcur, gh, B * C, 0, stream));
-        CFD_TRY(cfd_spectral_wgrad(p, xh_buf(l), gh, g->spec_w1[l], g->spec_w2[l], scratch, B, C, C, stream));
-        CFD_TRY(cfd_chan_wgrad(gcur, act_buf(l), g->w0_w[l], g->w0_b[l], scratch, B, C, C, HW, act, stream));
-        CFD_TRY(cfd_spectral_mix(p, gh, prm->spec_w1[l], prm->spec_w2[l], z, B, C, C, 1, stream));
-        CFD_TRY(cfd_fno_block_bwd_input(p, gcur, z, prm->w0_w[l], act ? act_buf(l) : nullptr, gnext, B, C, C, stream));
-        float* t = gcur; gcur = gnext; gnext = t;
-    }
-    CFD_TRY(cfd_fno_stem_bwd(p, gcur, inputs, mask, case_params, g->fc0_w, g->fc0_b, scratch, B, s->in_chan,
-                             s->n_case_params, C, stream));
+    for (int phase = 0; phase <= s->num_layers + 1; ++phase)
+        CFD_TRY(cfd_fno_backward_phase(p, s, prm, g, inputs, case_params, mask, label, preds, gpreds_ext, coef, ws, phase,
+                                       stream));
     return CFD_OK;
 }

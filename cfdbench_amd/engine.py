@@ -75,6 +75,20 @@ class GradSync:
         per = (per + 3) // 4 * 4
         return [(s, min(numel, s + per)) for s in range(0, numel, per)]
 
+    def reduce_slice_async(self, flat_grad: Tensor, start: int, stop: int):
+        """Start the SUM all-reduce of flat_grad[start:stop] (ordered after the work already enqueued on the current
+        stream, running on the communicator's own stream); None when there is nothing to exchange."""
+        if self.world == 1 or stop <= start:
+            return None
+        return dist.all_reduce(flat_grad[start:stop], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait_all(self, handles) -> float:
+        """Make the current stream wait for the started reductions; returns the 1/world scale for Adam."""
+        for h in handles:
+            if h is not None:
+                h.wait()
+        return 1.0 / self.world
+
     def all_reduce(self, flat_grad: Tensor) -> float:
         """Returns the scale to apply to the reduced gradient (1/world)."""
         if self.world == 1:
@@ -84,6 +98,20 @@ class GradSync:
         for h in handles:
             h.wait()
         return 1.0 / self.world
+
+
+def backward_phase_slices(offsets: Sequence[int], numel: int, num_layers: int) -> List[Tuple[int, int]]:
+    """[start, stop) of the flat gradient buffer written by backward phase k (``cfd_fno_backward_phase``): phase 0 = head
+    (fc1, fc2: the last four tensors), phase 1 .. L = FnoBlock L-k (four tensors each), phase L+1 = fc0 (the first two).
+    ``Fno2d.abi_parameters`` order is fc0, blocks 0 .. L-1, fc1, fc2, so every phase owns one contiguous slice and the
+    slices tile the buffer."""
+    end = lambda i: offsets[i + 1] if i + 1 < len(offsets) else numel
+    sl = [(offsets[2 + 4 * num_layers], numel)]
+    for k in range(1, num_layers + 1):
+        l = num_layers - k
+        sl.append((offsets[2 + 4 * l], end(2 + 4 * l + 3)))
+    sl.append((0, end(1)))
+    return sl
 
 
 def sync_gradients(params: Sequence[torch.nn.Parameter], group=None) -> None:
@@ -117,7 +145,8 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 
 class FnoTrainEngine:
     def __init__(self, model, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, loss_name: str = "nmse", group=None, grad_buckets: int = 1):
+                 weight_decay: float = 0.0, loss_name: str = "nmse", group=None, grad_buckets: int = 1,
+                 overlap: bool = True):
         if loss_name not in _LOSS_IDS:
             raise ValueError(f"loss_name must be one of {sorted(_LOSS_IDS)}")
         self.api = _lib.api()
@@ -135,6 +164,7 @@ class FnoTrainEngine:
         self.loss_id = _LOSS_IDS[loss_name]
         self.step_count = 0
         self.sync = GradSync(group, grad_buckets)
+        self.overlap = overlap  # DP: reduce each backward phase's gradients while the next phase computes
         self.pstruct = _param_struct(self.flat.ptrs(False), self.L)
         self.gstruct = _param_struct(self.flat.ptrs(True), self.L)
         self.sums = torch.zeros(4, dtype=torch.float32, device=self.device)
@@ -175,6 +205,38 @@ class FnoTrainEngine:
                case_params.data_ptr(), mp, label.data_ptr(), self.preds.data_ptr(), None, self.coef.data_ptr(),
                self.ws.data_ptr(), st)
 
+    # ---- data-parallel step: backward phase by phase, each phase's gradient slice reduced while the next computes ----
+    def phase_slices(self) -> List[Tuple[int, int]]:
+        """[start, stop) of the flat gradient buffer written by backward phase k (cfd_fno_backward_phase): phase 0 = head
+        (fc1, fc2: the last four tensors), phase 1 .. L = FnoBlock L-k (four tensors each), phase L+1 = fc0 (the first
+        two).  ``abi_parameters`` order is fc0, blocks 0 .. L-1, fc1, fc2, so every phase owns one contiguous slice."""
+        return backward_phase_slices(self.flat.offsets, self.flat.numel, self.L)
+
+    def forward_backward_overlapped(self, inputs: Tensor, label: Tensor, case_params: Tensor,
+                                    mask: Optional[Tensor] = None) -> float:
+        """forward_backward with the gradient exchange overlapped: after each backward phase is enqueued, the SUM
+        all-reduce of that phase's (final) gradient slice is started asynchronously -- RCCL runs it on its own stream
+        while the following phases compute (the head's 12 KB first, then one 0.9-MB bucket per FnoBlock, during the next
+        block's DFT / mix / fused block kernels).  Returns the 1/world scale for Adam.  Bitwise the same gradients as
+        forward_backward + GradSync.all_reduce (same kernels, same reduction per element)."""
+        for t in (inputs, label, case_params, mask):
+            if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
+                raise RuntimeError("FnoTrainEngine expects contiguous float32 CUDA tensors")
+        self._prepare(inputs, case_params)
+        st = torch.cuda.current_stream().cuda_stream
+        a, sp = self.api, ctypes.byref(self.shape)
+        mp = None if mask is None else mask.data_ptr()
+        a.call("cfd_fno_forward", self.plan, sp, ctypes.byref(self.pstruct), inputs.data_ptr(), case_params.data_ptr(), mp,
+               label.data_ptr(), self.preds.data_ptr(), self.sums.data_ptr(), self.ws.data_ptr(), 1, st)
+        a.call("cfd_loss_coef", self.sums.data_ptr(), self.coef.data_ptr(), self.loss_id, 1.0, st)
+        handles = []
+        for phase, (s0, s1) in enumerate(self.phase_slices()):
+            a.call("cfd_fno_backward_phase", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
+                   inputs.data_ptr(), case_params.data_ptr(), mp, label.data_ptr(), self.preds.data_ptr(), None,
+                   self.coef.data_ptr(), self.ws.data_ptr(), phase, st)
+            handles.append(self.sync.reduce_slice_async(self.flat.grad, s0, s1))
+        return self.sync.wait_all(handles)
+
     def optimizer_step(self, grad_scale: float = 1.0):
         self.step_count += 1
         self.api.call("cfd_adam_flat", self.flat.data.data_ptr(), self.flat.grad.data_ptr(), self.exp_avg.data_ptr(),
@@ -184,8 +246,11 @@ class FnoTrainEngine:
     def train_step(self, inputs: Tensor, label: Tensor, case_params: Tensor, mask: Optional[Tensor] = None) -> Tensor:
         """One optimisation step; returns the device tensor [sum sq err, sum abs err, sum sq label, n] of THIS rank's
         batch (no host sync -- read it with .tolist() only when logging)."""
-        self.forward_backward(inputs, label, case_params, mask)
-        scale = self.sync.all_reduce(self.flat.grad)
+        if self.sync.world > 1 and self.overlap:
+            scale = self.forward_backward_overlapped(inputs, label, case_params, mask)
+        else:
+            self.forward_backward(inputs, label, case_params, mask)
+            scale = self.sync.all_reduce(self.flat.grad)
         self.optimizer_step(scale)
         return self.sums
 

@@ -289,6 +289,15 @@ int cfd_fno_backward(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd
                      const float* label, const float* preds, const float* gpreds_ext, const float* coef, void* ws,
                      void* stream);
 
+/* The same pass one phase at a time: 0 = head (+ loss gradient), 1 .. num_layers = the FnoBlocks in reverse order,
+ * num_layers + 1 = lifting layer; phases in this order on one stream.  After a phase returns (is enqueued) the gradients
+ * of its parameters are final, so a data-parallel trainer overlaps their all-reduce with the remaining phases
+ * (the reference has no DP; src/train_auto.py:255 is its single backward call).                                 */
+int cfd_fno_backward_phase(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,
+                           const cfd_fno_params* grads, const float* inputs, const float* case_params,
+                           const float* mask, const float* label, const float* preds, const float* gpreds_ext,
+                           const float* coef, void* ws, int phase, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

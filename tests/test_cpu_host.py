@@ -71,6 +71,17 @@ def _dp_worker(rank, world, port, q):
         flat = np.concatenate([np.ascontiguousarray(g[k]).view(np.float64).reshape(-1) for k in params])
         t = torch.from_numpy(flat.copy())
         scale = GradSync(None, n_buckets=3).all_reduce(t)
+        # the overlapped trainer's exchange: one asynchronous reduction per backward phase, in phase order
+        from cfdbench_amd.engine import backward_phase_slices
+        sizes = [np.ascontiguousarray(g[k]).view(np.float64).size for k in params]
+        offs = [int(v) for v in np.concatenate([[0], np.cumsum(sizes)[:-1]])]
+        slices = backward_phase_slices(offs, int(sum(sizes)), L)
+        assert sorted(slices) == [(a0, b0) for a0, b0 in sorted(slices)] and sum(b0 - a0 for a0, b0 in slices) == sum(sizes)
+        assert slices[0][1] == sum(sizes) and slices[-1][0] == 0 and len(slices) == L + 2
+        t2 = torch.from_numpy(flat.copy())
+        sync = GradSync(None)
+        scale2 = sync.wait_all([sync.reduce_slice_async(t2, a0, b0) for a0, b0 in slices])
+        assert scale2 == scale and torch.equal(t2, t)
         q.put((rank, (t * scale).numpy(), flat))
     finally:
         dist.destroy_process_group()

@@ -460,3 +460,23 @@ def test_auto_edeeponet_auto_ffn_vs_reference_golden(torch, golden_dir, name):
         assert O.rel_nmse(full.cpu().numpy().reshape(g["preds_full"].shape), g["preds_full"]) < 1e-9
         frames = m.generate_many(x.detach(), cp, mask, steps)
         assert O.rel_nmse(torch.stack(frames).cpu().numpy(), g["frames"]) < 1e-8
+
+
+def test_phased_backward_equals_monolithic(torch):
+    """cfd_fno_backward_phase x (L+2) == cfd_fno_backward bitwise, and the phase slices tile the flat gradient buffer
+    (what the data-parallel trainer reduces phase by phase while the next phase computes)."""
+    from cfdbench_amd.engine import FnoTrainEngine
+    params = synth.make_fno_params(5, 8, 3, 12, 12, 5, spectral_gain=4.0)
+    ma, mb = _model(torch, params, 8, 3), _model(torch, params, 8, 3)
+    ea, eb = FnoTrainEngine(ma, lr=1e-3), FnoTrainEngine(mb, lr=1e-3)
+    b = _cuda(torch, synth.make_batch(60, 4, 64, 64, 5))
+    ea.forward_backward(b["inputs"], b["label"], b["case_params"], b["mask"])
+    eb.flat.grad.fill_(float("nan"))  # every element must be (over)written by some phase
+    scale = eb.forward_backward_overlapped(b["inputs"], b["label"], b["case_params"], b["mask"])
+    torch.cuda.synchronize()
+    assert scale == 1.0
+    for ga, gb in zip(ea.flat.grad_views, eb.flat.grad_views):  # every parameter's gradient (alignment padding aside)
+        assert torch.equal(ga, gb)
+    sl = sorted(eb.phase_slices())
+    assert sl[0][0] == 0 and sl[-1][1] == eb.flat.numel and all(a[1] == c[0] for a, c in zip(sl, sl[1:]))
+    assert len(sl) == 3 + 2
