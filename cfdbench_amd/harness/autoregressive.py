@@ -4,6 +4,7 @@ from __future__ import annotations
 from typing import Tuple
 
 from ..models.auto_deeponet import AutoDeepONet
+from ..models.auto_deeponet_cnn import AutoDeepONetCnn
 from ..models.auto_edeeponet import AutoEDeepONet
 from ..models.auto_ffn import AutoFfn
 from ..models.base_model import AutoCfdModel
@@ -54,6 +55,7 @@ def init_model(args) -> AutoCfdModel:
         return AutoEDeepONet(dim_branch1=n_rows * n_cols, dim_branch2=n_case_params, trunk_dim=2, loss_fn=loss_fn,
                              width=args.autoedeeponet_width, trunk_depth=args.autoedeeponet_depth,
                              branch_depth=args.autoedeeponet_depth, act_name=args.autoedeeponet_act_fn)
-    if args.model in ("auto_deeponet_cnn",):
-        raise NotImplementedError(f"cfdbench_amd: model {args.model!r} has no MI355X kernels yet (DESIGN.md section 7)")
+    if args.model == "auto_deeponet_cnn":  # autoregressive.py:82-91
+        return AutoDeepONetCnn(in_chan=args.in_chan, height=n_rows, width=n_cols, num_case_params=n_case_params,
+                               query_dim=2, loss_fn=loss_fn)
     raise ValueError(f"Invalid model name: {args.model}")

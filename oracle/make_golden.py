@@ -173,6 +173,37 @@ def gen_auto_variants(name, kind, seed, bseed, B, H, W, width, depth, act_name="
     print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
 
 
+def gen_auto_deeponet_cnn(name, seed, bseed, B, trunk_depth=2, p=5, steps=2, nq=33):
+    """AutoDeepONetCnn (CNN branch with zero-padded 5x5 convs; needs 64x64 frames) from the reference module
+    (src/models/auto_deeponet_cnn.py): training forward on random query points + loss + backward, rollout."""
+    from models.auto_deeponet_cnn import AutoDeepONetCnn  # reference
+    H = W = 64
+    torch.manual_seed(seed)
+    model = AutoDeepONetCnn(2, 2, MseLoss(normalize=True), height=H, width=W, num_case_params=p, trunk_depth=trunk_depth)
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    batch["mask"][:, :, 0, :] = 0
+    g = torch.Generator().manual_seed(bseed + 7)
+    q = torch.stack([torch.randint(0, H, (nq,), generator=g), torch.randint(0, W, (nq,), generator=g)], dim=-1)
+    x = _t(batch["inputs"]).requires_grad_(True)
+    out = model(inputs=x, case_params=_t(batch["case_params"]), label=_t(batch["label"]), mask=_t(batch["mask"]),
+                query_idxs=q)
+    out["loss"]["nmse"].backward()
+    save = dict(meta=np.array([seed, bseed, B, trunk_depth, p, steps, nq]), q=q.numpy(),
+                preds=out["preds"].detach().numpy(), g_inputs=x.grad.numpy(),
+                **{f"loss_{k}": np.array(v.item()) for k, v in out["loss"].items()})
+    for k, v in model.state_dict().items():
+        save[f"sd::{k}"] = v.numpy().copy()
+    for k, prm in model.named_parameters():
+        if prm.grad is not None:
+            save[f"grad::{k}"] = prm.grad.numpy()
+    model.eval()
+    with torch.no_grad():
+        frames = model.generate_many(_t(batch["inputs"][:1]), _t(batch["case_params"][:1]), _t(batch["mask"][:1, 0]), steps)
+    save["frames"] = np.stack([f.numpy() for f in frames])
+    np.savez_compressed(OUT / f"{name}.npz", **save)
+    print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
+
+
 def gen_unet(name, seed, bseed, B, H, W, dim, p=8, steps=2):
     """UNet (input-insert, ConvTranspose up path) train-mode forward/backward, running-stat update, eval forward and
     rollout from the reference module (src/models/unet.py).  The state_dict itself is stored (torch's init stream)."""
@@ -413,6 +444,7 @@ def main():
     gen_auto_variants("auto_edeeponet_gelu_12x12", "auto_edeeponet", 112, 122, 2, 12, 12, 16, 2, "gelu")
     gen_auto_variants("auto_ffn_relu_16x18", "auto_ffn", 113, 123, 3, 16, 18, 24, 3, "relu")
     gen_auto_variants("auto_ffn_tanh_10x12", "auto_ffn", 114, 124, 4, 10, 12, 16, 2, "tanh", nq=30)
+    gen_auto_deeponet_cnn("auto_deeponet_cnn_64x64", 115, 125, 2)
     gen_adam("adam_small_64x64", 26, 36, 2, 8, 2, 64, 64, nsteps=3, lr=1e-3, gain=8.0)
     gen_mseloss("mseloss", 41)
     gen_cavity_dataset("cavity_dataset")

@@ -100,3 +100,16 @@ def test_nonauto_collate_and_init_model_shapes():
     assert ws == [(12, 8), (12, 12), (1, 12)]
     with pytest.raises(ValueError):
         init_nonauto(Args(model="fno", data_name="cavity_bc"))
+
+
+def test_init_model_resolves_every_autoregressive_name():
+    """Same ``--model`` names as src/utils/autoregressive.py:41-125 (construction only: no kernel runs on the CPU)."""
+    from cfdbench_amd.harness.autoregressive import init_model
+    names = {"fno": "Fno2d", "unet": "UNet", "resnet": "ResNet", "auto_deeponet": "AutoDeepONet",
+             "auto_edeeponet": "AutoEDeepONet", "auto_ffn": "AutoFfn", "auto_deeponet_cnn": "AutoDeepONetCnn"}
+    for name, cls in names.items():
+        m = init_model(Args(model=name, data_name="cavity_prop_bc_geo", num_rows=16, num_cols=16, deeponet_width=8,
+                            autoffn_width=8, autoedeeponet_width=8, fno_hidden_dim=4, unet_dim=2, resnet_hidden_chan=2))
+        assert type(m).__name__ == cls and hasattr(m, "generate_many")
+    with pytest.raises(ValueError):
+        init_model(Args(model="no_such_model", data_name="cavity_bc"))

@@ -480,3 +480,35 @@ def test_phased_backward_equals_monolithic(torch):
     sl = sorted(eb.phase_slices())
     assert sl[0][0] == 0 and sl[-1][1] == eb.flat.numel and all(a[1] == c[0] for a, c in zip(sl, sl[1:]))
     assert len(sl) == 3 + 2
+
+
+def test_auto_deeponet_cnn_vs_reference_golden(torch, golden_dir):
+    """AutoDeepONetCnn drop-in (zero-padded 5x5 CNN branch through the replicate-padding conv kernels) vs the reference
+    module: predictions on random query points, loss, every parameter gradient, input gradient, rollout."""
+    from cfdbench_amd.models.auto_deeponet_cnn import AutoDeepONetCnn
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    from oracle import synth
+    g = np.load(golden_dir / "auto_deeponet_cnn_64x64.npz")
+    seed, bseed, B, trunk_depth, p, steps, nq = [int(v) for v in g["meta"]]
+    m = AutoDeepONetCnn(2, 2, loss_name_to_fn("nmse"), height=64, width=64, num_case_params=p, trunk_depth=trunk_depth).cuda()
+    sd = {k[len("sd::"):]: torch.from_numpy(np.ascontiguousarray(g[k])) for k in g.files if k.startswith("sd::")}
+    assert list(sd.keys()) == list(m.state_dict().keys())
+    m.load_state_dict(sd)
+    batch = synth.make_smooth_batch(bseed, B, 64, 64, p)
+    batch["mask"][:, :, 0, :] = 0
+    x = torch.from_numpy(batch["inputs"]).cuda().requires_grad_(True)
+    cp, label, mask = (torch.from_numpy(batch[k]).cuda() for k in ("case_params", "label", "mask"))
+    out = m(inputs=x, case_params=cp, label=label, mask=mask, query_idxs=torch.from_numpy(g["q"]).cuda())
+    assert O.rel_nmse(out["preds"].detach().cpu().numpy(), g["preds"]) < 1e-9
+    assert abs(out["loss"]["nmse"].item() - float(g["loss_nmse"])) <= 1e-4 * float(g["loss_nmse"])
+    out["loss"]["nmse"].backward()
+    for k, prm in m.named_parameters():
+        if f"grad::{k}" in g.files:
+            assert O.rel_nmse(prm.grad.cpu().numpy(), g[f"grad::{k}"]) < 1e-7, k
+        else:
+            assert prm.grad is None  # `bias` takes no part in the forward (auto_deeponet_cnn.py:160)
+    assert O.rel_nmse(x.grad.cpu().numpy(), g["g_inputs"]) < 1e-7
+    m.eval()
+    with torch.no_grad():
+        frames = m.generate_many(x.detach()[:1], cp[:1], mask[:1, 0], steps)
+        assert O.rel_nmse(torch.stack(frames).cpu().numpy(), g["frames"]) < 1e-8
