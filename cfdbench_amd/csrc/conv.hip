@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256) void k_fold_pad(const float* __restrict__ ext,
 // Pixels are one linear space over (batch, H*W); workgroup = one 32 x 64 block of the (row, j) plane x one chunk of it.
 template <bool TRANSPOSED>
 __global__ __launch_bounds__(64 * CV_WAVES) void k_conv_wgrad(const float* __restrict__ arows, const float* __restrict__ bsrc,
-                                                              float* __restrict__ part, ConvGeom g, long chunk_px) {
+                                                              float* __restrict__ part, ConvGeom g, unsigned chunk_px,
+                                                              CfdDiv dHW, CfdDiv dW) {
     __shared__ float s_red[CV_WAVES * CW_MT * CW_NT * 4 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
@@ -372,15 +373,17 @@ __global__ __launch_bounds__(64 * CV_WAVES) void k_conv_wgrad(const float* __res
     for (int a = 0; a < CW_MT; ++a)
 #pragma unroll
         for (int c = 0; c < CW_NT; ++c) acc[a][c] = zero;
-    const long total = (long)g.B * HW;
-    const long pbeg = (long)blockIdx.x * chunk_px;
-    const long pend = pbeg + chunk_px < total ? pbeg + chunk_px : total;
-    for (long p0 = pbeg + 4 * wave; p0 < pend; p0 += 4 * CV_WAVES) {  // waves interleave 4-pixel k-steps
-        const long P = p0 + q;
+    // 31-bit pixel indices (checked by the callers) and magic-number division: the per-k-step index split used to be
+    // a 64-bit and a 32-bit hardware-less division, more VALU work than the eight MFMAs it feeds
+    const unsigned total = (unsigned)g.B * HW;
+    const unsigned pbeg = blockIdx.x * chunk_px;
+    const unsigned pend = pbeg + chunk_px < total ? pbeg + chunk_px : total;
+    for (unsigned p0 = pbeg + 4 * wave; p0 < pend; p0 += 4 * CV_WAVES) {  // waves interleave 4-pixel k-steps
+        const unsigned P = p0 + q;
         const bool pv = P < pend;
-        const int b = pv ? (int)(P / HW) : 0;
-        const int p = pv ? (int)(P - (long)b * HW) : 0;
-        const int y = p / g.W, x = p - y * g.W;
+        const int b = pv ? (int)cfd_div(P, dHW) : 0;
+        const int p = pv ? (int)(P - (unsigned)b * HW) : 0;
+        const int y = (int)cfd_div((unsigned)p, dW), x = p - y * g.W;
         const float* ab = arows + (size_t)b * R * HW;
         const float* bb = bsrc + (size_t)b * Cb * HWb;
         float av[CW_MT], bv[CW_NT];
@@ -510,7 +513,9 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
         const dim3 grid(nchunk, (Co + 16 * CW_MT - 1) / (16 * CW_MT), (J + 16 * CW_NT - 1) / (16 * CW_NT));
         {
             CFD_PROF("k_conv_wgrad", st);
-            hipLaunchKernelGGL((k_conv_wgrad<false>), grid, dim3(64 * CV_WAVES), 0, st, gout, in, (float*)ws, g, chunk_px);
+            CFD_REQUIRE_I31((long)B * HW, "cfd_conv2d_bwd");
+            hipLaunchKernelGGL((k_conv_wgrad<false>), grid, dim3(64 * CV_WAVES), 0, st, gout, in, (float*)ws, g,
+                               (unsigned)chunk_px, cfd_div_make((unsigned)HW), cfd_div_make((unsigned)W));
         }
         CFD_LAUNCH_CHECK("cfd_conv2d_bwd(wgrad)");
         const long n = (long)Co * J;
@@ -897,7 +902,8 @@ extern "C" int cfd_convt2_bwd(const float* gout, const float* in, const float* w
         const dim3 grid(nchunk, (Ci + 16 * CW_MT - 1) / (16 * CW_MT), (J + 16 * CW_NT - 1) / (16 * CW_NT));
         {
             CFD_PROF("k_convt2_wgrad", st);
-            hipLaunchKernelGGL((k_conv_wgrad<true>), grid, dim3(64 * CV_WAVES), 0, st, in, gout, (float*)ws, g, chunk_px);
+            hipLaunchKernelGGL((k_conv_wgrad<true>), grid, dim3(64 * CV_WAVES), 0, st, in, gout, (float*)ws, g,
+                               (unsigned)chunk_px, cfd_div_make((unsigned)(H * W)), cfd_div_make((unsigned)W));
         }
         CFD_LAUNCH_CHECK("cfd_convt2_bwd(wgrad)");
         const long n = (long)Ci * Co * 4;
