@@ -434,6 +434,149 @@ __global__ __launch_bounds__(64 * CV_WAVES) void k_conv_wgrad(const float* __res
     }
 }
 
+// LDS-tiled form of the convolution weight gradient (k = 3 and 7 on grids the forward tile kernel covers).  A workgroup
+// owns one chunk of CC input channels x one group of 16*MT output channels and walks pixel tiles (the forward kernel's
+// NB x TH x TW = 256-pixel tiles) in a grid-stride loop.  Per tile the replicate-clamped input halo [CC][LH][LW] and the
+// upstream-gradient tile [16 MT][256 pixels] are staged in LDS once -- every input element then feeds all k*k taps and
+// every output channel from LDS instead of one clamped global gather per MFMA operand (the gather kernel issued ~17
+// VALU instructions and a scattered load per MFMA).  GEMM view: M = output channels, N = (channel, ky, kx) columns of
+// the chunk in 16-column tiles dealt round-robin to the four waves, K = the tile's 256 pixels (64 k-steps).  The
+// accumulators live in registers across the workgroup's tiles; one partial [Co][Ci*k*k] slice per pixel group is
+// reduced by k_part_reduce in a fixed order.
+template <int KS, int MT, int CC>
+__global__ __launch_bounds__(256) void k_conv_wgrad_tile(const float* __restrict__ gout, const float* __restrict__ in,
+                                                         float* __restrict__ part, ConvGeom g, ConvTile t, int ptiles) {
+    constexpr int KK = KS * KS, PAD = KS / 2;
+    constexpr int NT = (CC * KK + 15) / 16;  // 16-column tiles of the chunk's (channel, tap) columns
+    constexpr int NTW = (NT + 3) / 4;        // per wave
+    constexpr int GS = 260;                  // row stride of the gradient tile (256 pixels + 4: conflict-free A reads)
+    CFD_DYN_SHARED(float, s_dyn);            // [halo tiles NB*CC*LH*LW | gradient tile 16*MT*GS]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int HW = g.H * g.W, halo = t.LH * t.LW;
+    float* s_in = s_dyn;
+    float* s_g = s_dyn + t.NB * CC * halo;
+    const int c0 = blockIdx.y * CC, mbase = blockIdx.z * 16 * MT;
+    const int tpi = t.tiles_x * t.tiles_y;
+    const int hw_used = t.TW + KS - 1;
+    // this wave's columns j = 16 (wave + 4 v) + n -> LDS offset of (channel, ky, kx) relative to a pixel of the halo tile
+    int koff[NTW];
+    bool jok[NTW];
+#pragma unroll
+    for (int v = 0; v < NTW; ++v) {
+        const int j = 16 * (wave + 4 * v) + n;
+        const int c = j / KK, r = j - KK * c, ky = r / KS, kx = r - KS * ky;
+        jok[v] = wave + 4 * v < NT && j < CC * KK;
+        koff[v] = jok[v] ? c * halo + ky * t.LW + kx : 0;
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int v = 0; v < NTW; ++v) acc[mt][v] = zero;
+    int tw_shift = 0;
+    while ((1 << tw_shift) < t.TW) ++tw_shift;  // TW and TH are powers of two
+    int th_shift = 0;
+    while ((1 << th_shift) < t.TH) ++th_shift;
+    for (int tile = blockIdx.x; tile < ptiles; tile += gridDim.x) {
+        const int bg = tile / tpi, tr = tile - bg * tpi;
+        const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
+        const int b0 = bg * t.NB;
+        const int oy = ty0 - PAD, ox = tx0 - PAD;
+        __syncthreads();  // previous tile fully consumed
+        for (int i = threadIdx.x; i < t.NB * CC * t.LH * hw_used; i += blockDim.x) {
+            const int lx = i % hw_used, r1 = i / hw_used, ly = r1 % t.LH, r2 = r1 / t.LH, c = r2 % CC, bi = r2 / CC;
+            int y = oy + ly, x = ox + lx;
+            float v = 0.f;
+            if (c0 + c < g.Ci && b0 + bi < g.B) {
+                y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
+                x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
+                v = in[((size_t)(b0 + bi) * g.Ci + c0 + c) * HW + y * g.W + x];
+            }
+            s_in[(bi * CC + c) * halo + ly * t.LW + lx] = v;
+        }
+        // upstream gradient of the tile's pixels (0 outside the image / batch / channel range: contributes nothing)
+        for (int i = threadIdx.x; i < 16 * MT * 256; i += blockDim.x) {
+            const int pi = i & 255, m = i >> 8;
+            const int bi = pi >> (th_shift + tw_shift), rem = pi & ((1 << (th_shift + tw_shift)) - 1);
+            const int y = ty0 + (rem >> tw_shift), x = tx0 + (rem & (t.TW - 1));
+            float v = 0.f;
+            if (mbase + m < g.Co && b0 + bi < g.B && y < g.H && x < g.W)
+                v = gout[((size_t)(b0 + bi) * g.Co + mbase + m) * HW + y * g.W + x];
+            s_g[m * GS + pi] = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int ks_ = 0; ks_ < 64; ++ks_) {
+            const int pi = 4 * ks_ + q;  // this lane's pixel of the k-step
+            const int bi = pi >> (th_shift + tw_shift), rem = pi & ((1 << (th_shift + tw_shift)) - 1);
+            const int po = bi * CC * halo + (rem >> tw_shift) * t.LW + (rem & (t.TW - 1));
+            float av[MT], bv[NTW];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = s_g[(16 * mt + n) * GS + pi];
+#pragma unroll
+            for (int v = 0; v < NTW; ++v) bv[v] = jok[v] ? s_in[koff[v] + po] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int v = 0; v < NTW; ++v) acc[mt][v] = cfd_mfma16x16x4(av[mt], bv[v], acc[mt][v]);
+        }
+    }
+    // partial slice of this pixel group: part[group][o][i][ky][kx]
+    float* dst = part + (size_t)blockIdx.x * g.Co * g.Ci * KK;
+#pragma unroll
+    for (int v = 0; v < NTW; ++v) {
+        const int j = 16 * (wave + 4 * v) + n;
+        const int c = j / KK, r = j - KK * c;
+        if (wave + 4 * v < NT && j < CC * KK && c0 + c < g.Ci) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int o = mbase + 16 * mt + 4 * q + rr;
+                    if (o < g.Co) dst[((size_t)o * g.Ci + c0 + c) * KK + r] = acc[mt][v][rr];
+                }
+        }
+    }
+}
+
+#ifndef CFD_WGRAD_TILE_MIN_WGS
+#define CFD_WGRAD_TILE_MIN_WGS 128  // fewer workgroups than this: the gather kernel parallelises finer (the CPU emulator
+                                    // build sets 1 so that small test shapes exercise the tiled kernel)
+#endif
+// Tile geometry shared with the forward kernel; returns false when the layer should use the gather kernel.
+template <int KS, int CC>
+static bool wgrad_tile_plan(const ConvGeom& g, ConvTile& t, int& ptiles, int& groups, int& mtw, size_t& lds) {
+    t = ConvTile{};
+    t.TW = g.W >= 32 ? 32 : (g.W > 8 ? 16 : (g.W > 4 ? 8 : 4));
+    const int rows = 256 / t.TW;
+    int th = 1;
+    while (th < (g.H < rows ? g.H : rows)) th <<= 1;
+    t.TH = th > rows ? rows : th;
+    t.NB = 256 / (t.TH * t.TW);
+    t.tiles_x = (g.W + t.TW - 1) / t.TW;
+    t.tiles_y = (g.H + t.TH - 1) / t.TH;
+    t.LH = t.TH + KS - 1;
+    t.LW = t.TW + KS - 1 + 1;
+    ptiles = ((g.B + t.NB - 1) / t.NB) * t.tiles_x * t.tiles_y;
+    const int MTall = (g.Co + 15) / 16, chunks = (g.Ci + CC - 1) / CC;
+    mtw = MTall >= 2 ? 2 : 1;
+    const int mgroups = (MTall + mtw - 1) / mtw;
+    // pixel groups: enough workgroups to fill the chip (~1024), at most one per tile, partials capped at ~32 MB
+    long want = 1024 / ((long)chunks * mgroups);
+    if (want < 1) want = 1;
+    const long cap = (32L << 20) / ((long)g.Co * g.Ci * KS * KS * 4 + 1);
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    groups = (int)(want < ptiles ? want : ptiles);
+    lds = ((size_t)t.NB * CC * t.LH * t.LW + (size_t)16 * mtw * 260) * sizeof(float);
+    // measured on the U-Net / ResNet layer shapes (tools/bench_conv_layers.py): the tiled form wins while a layer has few
+    // channel chunks (every chunk restages the gradient tile) -- all 7x7 layers and 3x3 layers with Ci <= 32
+    if (KS == 3 && chunks > 2 && CFD_WGRAD_TILE_MIN_WGS > 1) return false;
+    return lds <= 120 * 1024 && (long)groups * chunks * mgroups >= CFD_WGRAD_TILE_MIN_WGS;
+}
+
 // Chunks of the linear (batch, pixel) space: enough workgroups to fill the chip, but no more partial tiles than ~32 MB.
 static void wgrad_plan(long total_px, int R, int J, long& chunk_px, int& nchunk) {
     const long tiles = (long)((R + 16 * CW_MT - 1) / (16 * CW_MT)) * ((J + 16 * CW_NT - 1) / (16 * CW_NT));
@@ -475,6 +618,15 @@ extern "C" size_t cfd_conv2d_bwd_workspace_bytes(int B, int Ci, int Co, int H, i
     long chunk_px;
     int nchunk;
     wgrad_plan((long)B * H * W, Co, Ci * ks * ks, chunk_px, nchunk);
+    {   // the LDS-tiled weight gradient writes one partial slice per pixel group
+        const ConvGeom g{B, Ci, Co, H, W, ks};
+        ConvTile t;
+        int ptiles, groups = 0, mtw;
+        size_t lds;
+        const bool tiled = ks == 3 ? wgrad_tile_plan<3, 16>(g, t, ptiles, groups, mtw, lds)
+                                   : (ks == 7 ? wgrad_tile_plan<7, 4>(g, t, ptiles, groups, mtw, lds) : false);
+        if (tiled && groups > nchunk) nchunk = groups;
+    }
     const size_t part = cfd_align_up((size_t)nchunk * Co * Ci * ks * ks * sizeof(float), 256);
     const size_t cs = chan_sum_ws_bytes(Co);
     const size_t m = ext > part ? ext : part;
@@ -509,6 +661,35 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
         long chunk_px;
         int nchunk;
         const int J = Ci * ks * ks;
+        bool tiled = false;
+        {
+            ConvTile t;
+            int ptiles, groups, mtw;
+            size_t lds;
+            if (ks == 3) tiled = wgrad_tile_plan<3, 16>(g, t, ptiles, groups, mtw, lds);
+            else if (ks == 7) tiled = wgrad_tile_plan<7, 4>(g, t, ptiles, groups, mtw, lds);
+            if (tiled) {
+                const int CC = ks == 3 ? 16 : 4;
+                const dim3 grid(groups, (Ci + CC - 1) / CC, ((Co + 15) / 16 + mtw - 1) / mtw);
+                // channel chunks / output groups that a workgroup does not own are written by the others; rows of a
+                // partially filled last chunk are covered because every (o, i) pair belongs to exactly one workgroup
+                CFD_PROF("k_conv_wgrad", st);
+#define CW_T(K_, M_, C_)                                                                                                  \
+    do {                                                                                                                  \
+        static bool attr_set = false;                                                                                     \
+        if (!attr_set) {                                                                                                  \
+            (void)hipFuncSetAttribute((const void*)k_conv_wgrad_tile<K_, M_, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); \
+            attr_set = true;                                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((k_conv_wgrad_tile<K_, M_, C_>), grid, dim3(256), lds, st, gout, in, (float*)ws, g, t, ptiles); \
+    } while (0)
+                if (ks == 3) { if (mtw == 1) CW_T(3, 1, 16); else CW_T(3, 2, 16); }
+                else { if (mtw == 1) CW_T(7, 1, 4); else CW_T(7, 2, 4); }
+#undef CW_T
+                nchunk = groups;
+            }
+        }
+        if (!tiled) {
         wgrad_plan((long)B * HW, Co, J, chunk_px, nchunk);
         const dim3 grid(nchunk, (Co + 16 * CW_MT - 1) / (16 * CW_MT), (J + 16 * CW_NT - 1) / (16 * CW_NT));
         {
@@ -516,6 +697,7 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
             CFD_REQUIRE_I31((long)B * HW, "cfd_conv2d_bwd");
             hipLaunchKernelGGL((k_conv_wgrad<false>), grid, dim3(64 * CV_WAVES), 0, st, gout, in, (float*)ws, g,
                                (unsigned)chunk_px, cfd_div_make((unsigned)HW), cfd_div_make((unsigned)W));
+        }
         }
         CFD_LAUNCH_CHECK("cfd_conv2d_bwd(wgrad)");
         const long n = (long)Co * J;

@@ -31,7 +31,8 @@ def build(force: bool = False) -> Path:
     for src in sources():
         obj = OUT / (src.name + ".o")
         cmd = [CLANG, "-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-Wno-unused-value",
-               f"-I{HERE / 'include'}", f"-I{CSRC}", f"-I{REPO / 'include'}", "-c", str(src), "-o", str(obj)]
+               f"-I{HERE / 'include'}", f"-I{CSRC}", f"-I{REPO / 'include'}", "-DCFD_WGRAD_TILE_MIN_WGS=1", "-c", str(src), "-o",
+               str(obj)]
         subprocess.run(cmd, check=True)
         objs.append(str(obj))
     subprocess.run([CLANG, "-shared", "-pthread", "-o", str(lib)] + objs, check=True)
