@@ -104,6 +104,7 @@ struct ConvTile {
     int TW, TH, NB;       // tile shape, NB*TH*TW == 256
     int tiles_x, tiles_y; // tiles per image
     int LW, LH;           // LDS halo tile: (TH + ks - 1) x (TW + ks - 1), row stride LW
+    CfdDiv dUsed, dLH;    // magic-number dividers by the used halo width (TW + ks - 1) and by LH (staging index split)
 };
 
 template <int KS, int MT, int CC, bool EXT>
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(256) void k_conv_tile(const float* __restrict__ src
         __syncthreads();  // previous chunk fully consumed (first pass: s_koff written)
         // halo tiles of NB images x CC channels
         for (int i = threadIdx.x; i < t.NB * CC * t.LH * hw_used; i += blockDim.x) {
-            const int lx = i % hw_used, r1 = i / hw_used, ly = r1 % t.LH, r2 = r1 / t.LH, c = r2 % CC, bi = r2 / CC;
+            const int r1 = (int)cfd_div((unsigned)i, t.dUsed), lx = i - r1 * hw_used;
+            const int r2 = (int)cfd_div((unsigned)r1, t.dLH), ly = r1 - r2 * t.LH, c = r2 % CC, bi = r2 / CC;
             int y = oy + ly, x = ox + lx;
             float v = 0.f;
             if (c0 + c < Cs && b0 + bi < g.B) {
@@ -227,6 +229,8 @@ static int launch_conv_tile(const float* src, const float* w, const float* bias,
     t.tiles_y = (Hd + t.TH - 1) / t.TH;
     t.LH = t.TH + KS - 1;
     t.LW = t.TW + KS - 1 + 1;                    // +1: odd-ish stride staggers LDS banks between rows
+    t.dUsed = cfd_div_make((unsigned)(t.TW + KS - 1));
+    t.dLH = cfd_div_make((unsigned)t.LH);
     // output channels per workgroup: as many as 64, fewer while the grid would leave CUs idle; layers with too few
     // pixel tiles even then (deep U-Net levels at small batch) go to the gather kernel, which parallelises finer
     const long ptiles = (long)((g.B + t.NB - 1) / t.NB) * t.tiles_x * t.tiles_y;
@@ -486,7 +490,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_tile(const float* __restrict
         const int oy = ty0 - PAD, ox = tx0 - PAD;
         __syncthreads();  // previous tile fully consumed
         for (int i = threadIdx.x; i < t.NB * CC * t.LH * hw_used; i += blockDim.x) {
-            const int lx = i % hw_used, r1 = i / hw_used, ly = r1 % t.LH, r2 = r1 / t.LH, c = r2 % CC, bi = r2 / CC;
+            const int r1 = (int)cfd_div((unsigned)i, t.dUsed), lx = i - r1 * hw_used;
+            const int r2 = (int)cfd_div((unsigned)r1, t.dLH), ly = r1 - r2 * t.LH, c = r2 % CC, bi = r2 / CC;
             int y = oy + ly, x = ox + lx;
             float v = 0.f;
             if (c0 + c < g.Ci && b0 + bi < g.B) {
@@ -559,6 +564,8 @@ static bool wgrad_tile_plan(const ConvGeom& g, ConvTile& t, int& ptiles, int& gr
     t.tiles_y = (g.H + t.TH - 1) / t.TH;
     t.LH = t.TH + KS - 1;
     t.LW = t.TW + KS - 1 + 1;
+    t.dUsed = cfd_div_make((unsigned)(t.TW + KS - 1));
+    t.dLH = cfd_div_make((unsigned)t.LH);
     ptiles = ((g.B + t.NB - 1) / t.NB) * t.tiles_x * t.tiles_y;
     const int MTall = (g.Co + 15) / 16, chunks = (g.Ci + CC - 1) / CC;
     mtw = MTall >= 2 ? 2 : 1;
