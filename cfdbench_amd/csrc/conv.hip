@@ -55,10 +55,12 @@ __global__ __launch_bounds__(64 * CV_WAVES) void k_conv_gather(const float* __re
         f32x4 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = zero;
+        // (channel, ky, kx) of this lane's k = k0 + q advances by carry: two runtime integer divisions per k-step cost
+        // more VALU time than the MFMAs they feed
+        int c, ky, kx;
+        conv_split_k(q, g.ks, c, ky, kx);
         for (int k0 = 0; k0 < K; k0 += 4) {
             const int k = k0 + q;
-            int c, ky, kx;
-            conv_split_k(k < K ? k : 0, g.ks, c, ky, kx);
             float bv = 0.f;
             if (k < K && pvalid) {
                 if constexpr (EXT) {
@@ -78,6 +80,9 @@ __global__ __launch_bounds__(64 * CV_WAVES) void k_conv_gather(const float* __re
                 if (m < Cm && k < K) av = EXT ? w[((size_t)c * g.Ci + m) * kk + ky * g.ks + kx] : w[(size_t)m * K + k];
                 acc[mt] = cfd_mfma16x16x4(av, bv, acc[mt]);
             }
+            kx += 4;
+            while (kx >= g.ks) { kx -= g.ks; ++ky; }
+            while (ky >= g.ks) { ky -= g.ks; ++c; }
         }
         if (pvalid) {
 #pragma unroll
