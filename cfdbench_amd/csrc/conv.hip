@@ -761,10 +761,13 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
 // BatchNorm2d (+ ReLU)   (src/models/unet.py:28-30; torch defaults eps = 1e-5, momentum = 0.1)
 // ------------------------------------------------------------------------------------------------------
 // Per-channel statistics over (B, H, W) in two deterministic stages: grid (C, nsplit) partials, then one wave per
-// channel.  Two passes (mean, then centred sum of squares) keep fp32 accurate when |mean| >> std.
+// channel.  Mean and variance come from ONE pass over shifted values (x - x[first element of the channel]), which keeps
+// fp32 accurate when |mean| >> std without the second read of the two-pass form.
 #define BN_SPLIT 64  // partial sums per channel (one lane of k_bn_final each)
 
-// MODE 0: sum x;  MODE 1: sum (x - mean[c])^2;  MODE 2: sums of gz and gz*xhat with gz = gy * (y > 0 if relu)
+// MODE 0: sum x;  MODE 1: sum (x - mean[c])^2;  MODE 2: sums of gz and gz*xhat with gz = gy * (y > 0 if relu);
+// MODE 3: sum (x - K) and sum (x - K)^2 with the shift K = the channel's first element (one-pass mean + variance: the
+// shift is a sample of the channel, so |mean - K| ~ std and the cancellation in E[d^2] - E[d]^2 costs ~1 ulp)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x, const float* __restrict__ aux,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -775,12 +778,13 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
     const unsigned n = (unsigned)B * HW;  // < 2^31 (checked by the callers)
     const unsigned per = (n + BN_SPLIT - 1) / BN_SPLIT;
     const unsigned e0 = sp * per, e1 = e0 + per < n ? e0 + per : n;
-    const float mu = MODE >= 1 ? mean[c] : 0.f, rs = MODE == 2 ? rstd[c] : 0.f;
+    const float mu = MODE == 3 ? x[(size_t)c * HW] : (MODE >= 1 ? mean[c] : 0.f), rs = MODE == 2 ? rstd[c] : 0.f;
     float s0 = 0.f, s1 = 0.f;
     auto item = [&](unsigned e, float v, float a) {
         (void)e;
         if (MODE == 0) s0 += v;
         else if (MODE == 1) { const float d = v - mu; s0 = fmaf(d, d, s0); }
+        else if (MODE == 3) { const float d = v - mu; s0 += d; s1 = fmaf(d, d, s1); }
         else {
             // x = layer input, aux = upstream gradient; relu mask from the normalised output sign
             const float xh = (v - mu) * rs;
@@ -823,18 +827,33 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
     }
 }
 
-// stage 0 -> mean;  stage 1 -> rstd (+ running statistics);  stage 2 -> (gbeta, ggamma)
+// stage 0 -> mean;  stage 1 -> rstd (+ running statistics);  stage 2 -> (gbeta, ggamma);
+// stage 3 -> mean and rstd (+ running statistics) from the shifted sums of MODE 3 (shift[c] = x[c*HW])
 __global__ __launch_bounds__(64) void k_bn_final(const float* __restrict__ part, int stage, float count, float eps,
                                                  float momentum, float* __restrict__ mean, float* __restrict__ rstd,
                                                  float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                 float* __restrict__ gbeta, float* __restrict__ ggamma, int C) {
+                                                 float* __restrict__ gbeta, float* __restrict__ ggamma, int C,
+                                                 const float* __restrict__ x, int HW) {
     const int c = blockIdx.x, lane = threadIdx.x;
     float a = lane < BN_SPLIT ? part[((size_t)c * BN_SPLIT + lane) * 2] : 0.f;
     float b = lane < BN_SPLIT ? part[((size_t)c * BN_SPLIT + lane) * 2 + 1] : 0.f;
     a = cfd_wave_sum(a);
     b = cfd_wave_sum(b);
     if (lane != 0) return;
-    if (stage == 0) mean[c] = a / count;
+    if (stage == 3) {
+        const float d = a / count;
+        const float mu = x[(size_t)c * HW] + d;
+        float m2 = b - a * d;  // sum (x - mean)^2 = sum (x-K)^2 - n (mean-K)^2
+        m2 = m2 > 0.f ? m2 : 0.f;
+        const float var = m2 / count;
+        mean[c] = mu;
+        rstd[c] = 1.0f / sqrtf(var + eps);
+        if (run_mean) {
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+            const float unb = count > 1.f ? m2 / (count - 1.f) : var;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+        }
+    } else if (stage == 0) mean[c] = a / count;
     else if (stage == 1) {
         const float var = a / count;  // biased: what normalises (torch.nn.functional.batch_norm, training=True)
         rstd[c] = 1.0f / sqrtf(var + eps);
@@ -858,7 +877,7 @@ static int chan_sum(const float* g, float* out, void* ws, int B, int C, int HW, 
     hipLaunchKernelGGL((k_bn_partial<0>), dim3(C, BN_SPLIT), dim3(256), 0, st, g, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, part, B, C, HW, 0, cfd_div_make((unsigned)HW));
     hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 2, 1.f, 0.f, 0.f, (float*)nullptr,
-                       (float*)nullptr, (float*)nullptr, (float*)nullptr, out, dummy, C);
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, out, dummy, C, (const float*)nullptr, 0);
     CFD_LAUNCH_CHECK(what);
     return CFD_OK;
 }
@@ -926,14 +945,10 @@ extern "C" int cfd_batchnorm_fwd(const float* x, const float* gamma, const float
     const float count = (float)((double)B * HW);
     if (training) {
         CFD_PROF("k_bn_stats", st);
-        hipLaunchKernelGGL((k_bn_partial<0>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, (const float*)nullptr,
+        hipLaunchKernelGGL((k_bn_partial<3>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, part, B, C, HW, 0, cfd_div_make((unsigned)HW));
-        hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 0, count, eps, momentum, save_mean,
-                           save_rstd, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, C);
-        hipLaunchKernelGGL((k_bn_partial<1>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, (const float*)nullptr,
-                           (const float*)save_mean, (const float*)nullptr, part, B, C, HW, 0, cfd_div_make((unsigned)HW));
-        hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 1, count, eps, momentum, save_mean,
-                           save_rstd, run_mean, run_var, (float*)nullptr, (float*)nullptr, C);
+        hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 3, count, eps, momentum, save_mean,
+                           save_rstd, run_mean, run_var, (float*)nullptr, (float*)nullptr, C, x, HW);
         CFD_LAUNCH_CHECK("cfd_batchnorm_fwd(stats)");
     } else {
         hipLaunchKernelGGL(k_bn_eval_stats, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)run_mean,
@@ -971,7 +986,7 @@ extern "C" int cfd_batchnorm_bwd(const float* gy, const float* x, const float* g
         hipLaunchKernelGGL((k_bn_partial<2>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, gy, (const float*)packed, save_rstd,
                            part, B, C, HW, relu, cfd_div_make((unsigned)HW));
         hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 2, 1.f, 0.f, 0.f, (float*)nullptr,
-                           (float*)nullptr, (float*)nullptr, (float*)nullptr, gbeta, ggamma, C);
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, gbeta, ggamma, C, (const float*)nullptr, 0);
     }
     CFD_LAUNCH_CHECK("cfd_batchnorm_bwd(reduce)");
     const long total = (long)B * C * HW;
