@@ -1073,9 +1073,18 @@ __global__ __launch_bounds__(256) void k_convt2_fwd(const float* __restrict__ in
         const int y = yo >> 1, x = xo >> 1, kidx = (yo & 1) * 2 + (xo & 1);
         const float* ip = in + (size_t)b * Ci * H * W + y * W + x;
         const float* wp = w + (size_t)o * 4 + kidx;
-        float acc = bias ? bias[o] : 0.f;
-        for (int i = 0; i < Ci; ++i) acc = fmaf(ip[(size_t)i * H * W], wp[(size_t)i * Co * 4], acc);
-        out[e] = acc;
+        // four independent partial sums: the channel loop is a dependent FMA chain otherwise (latency-bound at Ci = 192)
+        float a0 = bias ? bias[o] : 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const size_t si = (size_t)H * W, sw = (size_t)Co * 4;
+        int i = 0;
+        for (; i + 3 < Ci; i += 4) {
+            a0 = fmaf(ip[i * si], wp[i * sw], a0);
+            a1 = fmaf(ip[(i + 1) * si], wp[(i + 1) * sw], a1);
+            a2 = fmaf(ip[(i + 2) * si], wp[(i + 2) * sw], a2);
+            a3 = fmaf(ip[(i + 3) * si], wp[(i + 3) * sw], a3);
+        }
+        for (; i < Ci; ++i) a0 = fmaf(ip[i * si], wp[i * sw], a0);
+        out[e] = (a0 + a1) + (a2 + a3);
     }
 }
 
@@ -1089,15 +1098,16 @@ __global__ __launch_bounds__(256) void k_convt2_bwd_in(const float* __restrict__
         const int x = (int)(e - r1 * (unsigned)W), y = (int)(r1 - r2 * (unsigned)H), i = (int)(r2 - b * (unsigned)Ci);
         const float* gp = g + (size_t)b * Co * Ho * Wo + (2 * y) * Wo + 2 * x;
         const float* wp = w + (size_t)i * Co * 4;
-        float acc = 0.f;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // one partial sum per tap: four independent FMA chains
+#pragma unroll 2
         for (int o = 0; o < Co; ++o) {
             const float* go = gp + (size_t)o * Ho * Wo;
-            acc = fmaf(go[0], wp[o * 4], acc);
-            acc = fmaf(go[1], wp[o * 4 + 1], acc);
-            acc = fmaf(go[Wo], wp[o * 4 + 2], acc);
-            acc = fmaf(go[Wo + 1], wp[o * 4 + 3], acc);
+            a0 = fmaf(go[0], wp[o * 4], a0);
+            a1 = fmaf(go[1], wp[o * 4 + 1], a1);
+            a2 = fmaf(go[Wo], wp[o * 4 + 2], a2);
+            a3 = fmaf(go[Wo + 1], wp[o * 4 + 3], a3);
         }
-        gin[e] = acc;
+        gin[e] = (a0 + a1) + (a2 + a3);
     }
 }
 
