@@ -146,8 +146,9 @@ __global__ __launch_bounds__(256) void k_conv_tile(const float* __restrict__ src
         const int pi = 64 * wave + 16 * tt + n;
         const int bi = pi / (t.TH * t.TW), rem = pi - bi * (t.TH * t.TW);
         const int r = rem / t.TW, c = rem - r * t.TW;
-        pb[tt] = b0 + bi; py[tt] = ty0 + r; px[tt] = tx0 + c;
-        poff[tt] = bi * CC * halo + r * t.LW + c;
+        const bool on = bi < t.NB;  // NB*TH*TW may be < 256 (tile shapes that are not powers of two): idle lanes
+        pb[tt] = on ? b0 + bi : g.B; py[tt] = ty0 + r; px[tt] = tx0 + c;
+        poff[tt] = on ? bi * CC * halo + r * t.LW + c : 0;
     }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[MT][4];
@@ -230,6 +231,27 @@ static int launch_conv_tile(const float* src, const float* w, const float* bias,
     while (th < t.TH) th <<= 1;                  // power of two so that NB*TH*TW == 256 exactly
     t.TH = th > rows ? rows : th;
     t.NB = 256 / (t.TH * t.TW);
+    {
+        // Grids that are not powers of two -- above all the (H+2pad) x (W+2pad) extended grid of the input-gradient
+        // pass -- waste whole workgroups on power-of-two tiles (66x66 on 32x8 tiles: 27 tiles per image for 17 tiles'
+        // worth of pixels).  Search the tile shapes with TW*TH <= 256 for the fewest workgroups per image (a partly
+        // filled workgroup costs as much as a full one); ties go to the wider tile (longer store runs).
+        const auto cost = [&](int tw, int thh) {
+            const int nb = 256 / (tw * thh);
+            return (double)((Wd + tw - 1) / tw) * ((Hd + thh - 1) / thh) / (double)(nb < g.B ? nb : g.B);
+        };
+        double best = cost(t.TW, t.TH) * 0.97;  // keep the power-of-two shape unless another one is clearly better
+        int btw = t.TW, bth = t.TH;
+        for (int tw = 4; tw <= 64 && tw <= Wd; ++tw)
+            for (int thh = 1; thh * tw <= 256 && thh <= Hd; ++thh) {
+                if (tw * thh < 128) continue;  // at least half of the lanes busy
+                const double c = cost(tw, thh);
+                if (c < best - 1e-9 || (c < best + 1e-9 && tw > btw)) { best = c; btw = tw; bth = thh; }
+            }
+        t.TW = btw;
+        t.TH = bth;
+        t.NB = 256 / (t.TW * t.TH);
+    }
     t.tiles_x = (Wd + t.TW - 1) / t.TW;
     t.tiles_y = (Hd + t.TH - 1) / t.TH;
     t.LH = t.TH + KS - 1;
