@@ -1,10 +1,12 @@
 // SpectralConv2d_fast (src/models/fno/fno2d.py:17-82) as pruned DFTs on the CDNA4 matrix pipe.
 //
 // Only rows K = [0,m1) U [H-m1,H) and columns [0,m2) of rfft2(x) are ever consumed (fno2d.py:73-78), i.e. 288 of
-// 2112 bins at 64x64 / modes 12, so both transforms are dense truncated DFTs evaluated with
-// v_mfma_f32_16x16x4_f32 (exact fp32).  One 64-lane wave owns one (batch, channel) image end to end; the
-// chained-MFMA operand maps below are arranged so that the accumulator of the first stage IS the operand of
-// the second (no LDS round trip for data, only the constant operator tables live in LDS).
+// 2112 bins at 64x64 / modes 12, so both transforms are dense truncated DFTs on the matrix cores: the 64-wide fast
+// paths (k_dft_fwd64_b3, k_idft64, k_block) as 3-term split-bf16 products on v_mfma_f32_16x16x32_bf16 (fp32-class,
+// cfd_common.h), the generic-width kernels (k_dft_fwd, k_idft, k_dft_fwd64) with v_mfma_f32_16x16x4_f32 (exact fp32).
+// One 64-lane wave owns one (batch, channel) image end to end; the chained-MFMA operand maps below are arranged so that
+// the accumulator of the first stage IS the operand of the second (no LDS round trip for data, only the constant
+// operator tables live in LDS).
 //
 // Forward (k_dft_fwd), image X[x][y]:
 //   fold rows:  E[xf] = X[xf] + X[H-xf], O[xf] = X[xf] - X[H-xf]            (xf = 0..H/2; cos even / sin odd in x)
