@@ -88,7 +88,8 @@ _SIGS = {
     "cfd_rowdot_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "cfd_rowdot_bwd_workspace_bytes": (_Z, []),
     "cfd_rowdot_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "cfd_conv2d_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cfd_conv2d_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "cfd_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cfd_conv2d_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "cfd_conv2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cfd_batchnorm_workspace_bytes": (_Z, [_I]),

@@ -105,6 +105,9 @@ __global__ __launch_bounds__(64 * CV_WAVES) void k_conv_gather(const float* __re
 // offset table), the chunk's weights are staged in MFMA fragment order, and every wave owns 4 pixel tiles so one
 // weight fragment feeds 4 MFMAs.  Output channels beyond 64 are split over blockIdx.y.
 // ------------------------------------------------------------------------------------------------------
+#ifndef CFD_CONV_TILE_MIN_WGS
+#define CFD_CONV_TILE_MIN_WGS 256  // fewer workgroups (after split-K) than this: use the gather kernel
+#endif
 struct ConvTile {
     int TW, TH, NB;       // tile shape, NB*TH*TW == 256
     int tiles_x, tiles_y; // tiles per image
@@ -158,7 +161,14 @@ __global__ __launch_bounds__(256) void k_conv_tile(const float* __restrict__ src
         for (int tt = 0; tt < 4; ++tt) acc[mt][tt] = zero;
     const int oy = EXT ? ty0 - 2 * PAD : ty0 - PAD, ox = EXT ? tx0 - 2 * PAD : tx0 - PAD;  // source coords of the halo origin
     const int hw_used = t.TW + KS - 1;
-    for (int c0 = 0; c0 < Cs; c0 += CC) {
+    // split-K: blockIdx.z owns a contiguous range of the channel chunks and writes its own partial output slice (summed,
+    // with the bias, by k_splitk_sum) -- the deep, narrow layers (4x4 / 8x8 images, 96-192 channels) have too few pixel
+    // tiles to fill the chip otherwise
+    const int nch = (Cs + CC - 1) / CC, per = (nch + gridDim.z - 1) / gridDim.z;
+    const int cbeg = blockIdx.z * per * CC, cend = (cbeg + per * CC) < Cs ? (cbeg + per * CC) : Cs;
+    const bool split = gridDim.z > 1;
+    if (split) dst += (size_t)blockIdx.z * g.B * Cm * HWd;
+    for (int c0 = cbeg; c0 < cend; c0 += CC) {
         __syncthreads();  // previous chunk fully consumed (first pass: s_koff written)
         // halo tiles of NB images x CC channels
         for (int i = threadIdx.x; i < t.NB * CC * t.LH * hw_used; i += blockDim.x) {
@@ -211,19 +221,44 @@ __global__ __launch_bounds__(256) void k_conv_tile(const float* __restrict__ src
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mbase + 16 * mt + 4 * q + r;
-                    if (m < Cm) dst[((size_t)pb[tt] * Cm + m) * HWd + py[tt] * Wd + px[tt]] = acc[mt][tt][r] + (bias ? bias[m] : 0.f);
+                    if (m < Cm)
+                        dst[((size_t)pb[tt] * Cm + m) * HWd + py[tt] * Wd + px[tt]] = acc[mt][tt][r] + ((bias && !split) ? bias[m] : 0.f);
                 }
         }
     }
 }
 
+// out[e] = bias[channel(e)] + sum_z part[z][e]   (fixed order; e over (B, Cm, HWd))
+__global__ __launch_bounds__(256) void k_splitk_sum(const float* __restrict__ part, const float* __restrict__ bias,
+                                                    float* __restrict__ out, unsigned n, int nz, int Cm, CfdDiv dHW, CfdDiv dC) {
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        if (bias) {
+            const unsigned row = cfd_div(e, dHW);
+            s = bias[row - cfd_div(row, dC) * (unsigned)Cm];
+        }
+        for (int z = 0; z < nz; ++z) s += part[(size_t)z * n + e];
+        out[e] = s;
+    }
+}
+
+struct ConvTilePlan {
+    ConvTile t;
+    long ptiles;
+    int mtw, mgroups, ksplit;
+    size_t lds;
+    bool ok;
+};
+
+// Tile shape, output-channel grouping and split-K factor of the LDS-tiled kernel for one layer (shared by the launcher
+// and the workspace-size functions so that both always agree).
 template <int KS, int CC, bool EXT>
-static int launch_conv_tile(const float* src, const float* w, const float* bias, float* dst, const ConvGeom& g,
-                            hipStream_t st, const char* what) {
+static ConvTilePlan plan_conv_tile(const ConvGeom& g, bool allow_split) {
     constexpr int PAD = KS / 2, KK = KS * KS, KSTEPS = (CC * KK + 3) / 4;
     const int Hd = EXT ? g.H + 2 * PAD : g.H, Wd = EXT ? g.W + 2 * PAD : g.W;
-    const int Cm = EXT ? g.Ci : g.Co, MTall = (Cm + 15) / 16;
-    ConvTile t{};
+    const int Cm = EXT ? g.Ci : g.Co, Cs = EXT ? g.Co : g.Ci, MTall = (Cm + 15) / 16;
+    ConvTilePlan P{};
+    ConvTile& t = P.t;
     t.TW = Wd >= 32 ? 32 : (Wd > 8 ? 16 : (Wd > 4 ? 8 : 4));
     int rows = 256 / t.TW;                       // rows available per workgroup
     t.TH = Hd < rows ? Hd : rows;
@@ -258,16 +293,48 @@ static int launch_conv_tile(const float* src, const float* w, const float* bias,
     t.LW = t.TW + KS - 1 + 1;                    // +1: odd-ish stride staggers LDS banks between rows
     t.dUsed = cfd_div_make((unsigned)(t.TW + KS - 1));
     t.dLH = cfd_div_make((unsigned)t.LH);
-    // output channels per workgroup: as many as 64, fewer while the grid would leave CUs idle; layers with too few
-    // pixel tiles even then (deep U-Net levels at small batch) go to the gather kernel, which parallelises finer
-    const long ptiles = (long)((g.B + t.NB - 1) / t.NB) * t.tiles_x * t.tiles_y;
+    // output channels per workgroup: as many as 64, fewer while the grid would leave CUs idle; if the pixel tiles x
+    // channel groups still cannot fill the chip, the channel chunks are split over blockIdx.z (split-K, needs the
+    // caller's workspace); layers too small even for that go to the gather kernel
+    P.ptiles = (long)((g.B + t.NB - 1) / t.NB) * t.tiles_x * t.tiles_y;
     int mtw = MTall >= 4 ? 4 : MTall;
-    while (mtw > 1 && ptiles * ((MTall + mtw - 1) / mtw) < 512) --mtw;
-    const int mgroups = (MTall + mtw - 1) / mtw;
-    if (ptiles * mgroups < 256) return CFD_ERR_UNSUPPORTED;
-    const size_t lds = ((size_t)t.NB * CC * t.LH * t.LW + (size_t)KSTEPS * mtw * 64) * sizeof(float);
-    if (lds > 120 * 1024) return CFD_ERR_UNSUPPORTED;  // caller falls back to the gather kernel
-    const dim3 grid((unsigned)ptiles, mgroups);
+    while (mtw > 1 && P.ptiles * ((MTall + mtw - 1) / mtw) < 512) --mtw;
+    P.mtw = mtw;
+    P.mgroups = (MTall + mtw - 1) / mtw;
+    const long wgs = P.ptiles * P.mgroups;
+    const int nch = (Cs + CC - 1) / CC;
+    P.ksplit = 1;
+    if (wgs < 256 && allow_split && nch > 1) {
+        long ks = (384 + wgs - 1) / wgs;
+        P.ksplit = (int)(ks < nch ? ks : nch);
+    }
+    P.lds = ((size_t)t.NB * CC * t.LH * t.LW + (size_t)KSTEPS * mtw * 64) * sizeof(float);
+    P.ok = wgs * P.ksplit >= CFD_CONV_TILE_MIN_WGS && P.lds <= 120 * 1024;
+    return P;
+}
+
+// bytes of split-K partial output the tile kernel needs for this layer (0: no split)
+template <bool EXT>
+static size_t conv_split_bytes(const ConvGeom& g) {
+    const int pad = g.ks / 2;
+    const size_t out = (size_t)g.B * (EXT ? g.Ci : g.Co) * (EXT ? (size_t)(g.H + 2 * pad) * (g.W + 2 * pad) : (size_t)g.H * g.W);
+    int ks = 1;
+    if (g.ks == 3) { const ConvTilePlan P = plan_conv_tile<3, 16, EXT>(g, true); ks = P.ok ? P.ksplit : 1; }
+    else if (g.ks == 7) { const ConvTilePlan P = plan_conv_tile<7, 4, EXT>(g, true); ks = P.ok ? P.ksplit : 1; }
+    return ks > 1 ? cfd_align_up(out * ks * sizeof(float), 256) : 0;
+}
+
+template <int KS, int CC, bool EXT>
+static int launch_conv_tile(const float* src, const float* w, const float* bias, float* dst, const ConvGeom& g,
+                            float* split_ws, hipStream_t st, const char* what) {
+    constexpr int PAD = KS / 2;
+    const ConvTilePlan P = plan_conv_tile<KS, CC, EXT>(g, split_ws != nullptr);
+    if (!P.ok) return CFD_ERR_UNSUPPORTED;  // caller falls back to the gather kernel
+    const ConvTile t = P.t;
+    const size_t lds = P.lds;
+    const int mtw = P.mtw;
+    const dim3 grid((unsigned)P.ptiles, P.mgroups, P.ksplit);
+    float* kdst = P.ksplit > 1 ? split_ws : dst;
 #define CT_L(M_)                                                                                                      \
     do {                                                                                                              \
         static bool attr_set = false;                                                                                 \
@@ -275,7 +342,7 @@ static int launch_conv_tile(const float* src, const float* w, const float* bias,
             (void)hipFuncSetAttribute((const void*)k_conv_tile<KS, M_, CC, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); \
             attr_set = true;                                                                                          \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_conv_tile<KS, M_, CC, EXT>), grid, dim3(256), lds, st, src, w, bias, dst, g, t);        \
+        hipLaunchKernelGGL((k_conv_tile<KS, M_, CC, EXT>), grid, dim3(256), lds, st, src, w, bias, kdst, g, t);       \
     } while (0)
     if (mtw == 1) CT_L(1);
     else if (mtw == 2) CT_L(2);
@@ -283,12 +350,23 @@ static int launch_conv_tile(const float* src, const float* w, const float* bias,
     else CT_L(4);
 #undef CT_L
     CFD_LAUNCH_CHECK(what);
+    if (P.ksplit > 1) {
+        const int Cm = EXT ? g.Ci : g.Co;
+        const long HWd = EXT ? (long)(g.H + 2 * PAD) * (g.W + 2 * PAD) : (long)g.H * g.W;
+        const long n = (long)g.B * Cm * HWd;
+        CFD_REQUIRE_I31(n, what);
+        long blocks = (n + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)split_ws, bias, dst,
+                           (unsigned)n, P.ksplit, Cm, cfd_div_make((unsigned)HWd), cfd_div_make((unsigned)Cm));
+        CFD_LAUNCH_CHECK(what);
+    }
     return CFD_OK;
 }
 
 template <bool EXT>
 static int launch_conv_gather(const float* src, const float* w, const float* bias, float* dst, const ConvGeom& g,
-                              hipStream_t st, const char* what) {
+                              float* split_ws, hipStream_t st, const char* what) {
     const int pad = g.ks / 2;
     const int HWd = EXT ? (g.H + 2 * pad) * (g.W + 2 * pad) : g.H * g.W;
     const int tiles_per_b = (HWd + 15) / 16;
@@ -297,10 +375,10 @@ static int launch_conv_gather(const float* src, const float* w, const float* bia
     if (blocks > 4096) blocks = 4096;
     const int Cm = EXT ? g.Ci : g.Co, MT = (Cm + 15) / 16;
     if (g.ks == 3) {
-        const int rc = launch_conv_tile<3, 16, EXT>(src, w, bias, dst, g, st, what);
+        const int rc = launch_conv_tile<3, 16, EXT>(src, w, bias, dst, g, split_ws, st, what);
         if (rc != CFD_ERR_UNSUPPORTED) return rc;
     } else if (g.ks == 7) {
-        const int rc = launch_conv_tile<7, 4, EXT>(src, w, bias, dst, g, st, what);
+        const int rc = launch_conv_tile<7, 4, EXT>(src, w, bias, dst, g, split_ws, st, what);
         if (rc != CFD_ERR_UNSUPPORTED) return rc;
     }
     // Few pixels (deep, wide layers): split the output channels over blockIdx.y so that the grid still fills the chip;
@@ -336,14 +414,21 @@ static int conv_check(const char* fn, int B, int Ci, int Co, int H, int W, int k
 }
 
 // out (B,Co,H,W) = conv2d(in (B,Ci,H,W), w (Co,Ci,ks,ks), bias, padding=ks/2, padding_mode="replicate")
-extern "C" int cfd_conv2d_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int H,
-                              int W, int ks, void* stream) {
+extern "C" size_t cfd_conv2d_fwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks) {
+    if (B <= 0 || Ci < 1 || Co < 1 || H < 1 || W < 1) return 0;
+    const ConvGeom g{B, Ci, Co, H, W, ks};
+    return conv_split_bytes<false>(g);
+}
+
+// ws: cfd_conv2d_fwd_workspace_bytes() bytes, or NULL (then the deep, narrow layers run without split-K)
+extern "C" int cfd_conv2d_fwd(const float* in, const float* w, const float* bias, float* out, void* ws, int B, int Ci, int Co,
+                              int H, int W, int ks, void* stream) {
     CFD_REQUIRE(in && w && out, CFD_ERR_INVALID_ARG, "cfd_conv2d_fwd: NULL pointer");
     CFD_TRY(conv_check("cfd_conv2d_fwd", B, Ci, Co, H, W, ks));
     if (B == 0) return CFD_OK;
     const ConvGeom g{B, Ci, Co, H, W, ks};
     CFD_PROF("k_conv_fwd", (hipStream_t)stream);
-    return launch_conv_gather<false>(in, w, bias, out, g, (hipStream_t)stream, "cfd_conv2d_fwd");
+    return launch_conv_gather<false>(in, w, bias, out, g, (float*)ws, (hipStream_t)stream, "cfd_conv2d_fwd");
 }
 
 // gin[b][i][y][x] = sum over the extended positions that replicate padding maps to (y, x)
@@ -699,7 +784,11 @@ extern "C" size_t cfd_conv2d_bwd_workspace_bytes(int B, int Ci, int Co, int H, i
     }
     const size_t part = cfd_align_up((size_t)nchunk * Co * Ci * ks * ks * sizeof(float), 256);
     const size_t cs = chan_sum_ws_bytes(Co);
-    const size_t m = ext > part ? ext : part;
+    // [extended input gradient | split-K partials of the input-gradient pass]; the weight-gradient partials and the
+    // bias sums reuse the front of the buffer afterwards
+    const ConvGeom gg{B, Ci, Co, H, W, ks};
+    const size_t dg = ext + conv_split_bytes<true>(gg);
+    const size_t m = dg > part ? dg : part;
     return m > cs ? m : cs;
 }
 
@@ -716,7 +805,9 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
         float* ext = (float*)ws;
         {
             CFD_PROF("k_conv_dgrad", st);
-            CFD_TRY(launch_conv_gather<true>(gout, w, nullptr, ext, g, st, "cfd_conv2d_bwd(dgrad)"));
+            const size_t ext_bytes = cfd_align_up((size_t)B * Ci * (H + 2 * pad) * (W + 2 * pad) * sizeof(float), 256);
+            float* split_ws = conv_split_bytes<true>(g) ? (float*)((char*)ws + ext_bytes) : nullptr;
+            CFD_TRY(launch_conv_gather<true>(gout, w, nullptr, ext, g, split_ws, st, "cfd_conv2d_bwd(dgrad)"));
         }
         const long total = (long)B * Ci * HW;
         long blocks = (total + 255) / 256;

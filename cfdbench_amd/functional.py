@@ -418,7 +418,9 @@ class Conv2dReplicateFn(torch.autograd.Function):
         if Ci_w != Ci or ks != ks2:
             raise RuntimeError(f"conv2d: input has {Ci} channels, weight is {tuple(w.shape)}")
         out = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
-        api.call("cfd_conv2d_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(out), B, Ci, Co, H, W, ks, _stream())
+        nws = api.size("cfd_conv2d_fwd_workspace_bytes", B, Ci, Co, H, W, ks)  # split-K partials of narrow, deep layers
+        ws = _bytes(nws, x.device) if nws else None
+        api.call("cfd_conv2d_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(out), _ptr(ws), B, Ci, Co, H, W, ks, _stream())
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
         return out

@@ -221,8 +221,9 @@ int cfd_rowdot_bwd(const float* g, const float* branch, const float* trunk, floa
 
 /* out (B,Co,H,W) = nn.Conv2d(Ci, Co, ks, padding=ks/2, padding_mode="replicate")(in); w (Co,Ci,ks,ks); ks odd <= 7
  * (unet.py:20-27 ks=3, resnet.py:35-41 ks=7, unet.py:105 ks=1); bias may be NULL.                              */
-int cfd_conv2d_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int H, int W,
-                   int ks, void* stream);
+size_t cfd_conv2d_fwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);
+int cfd_conv2d_fwd(const float* in, const float* w, const float* bias, float* out, void* ws, int B, int Ci, int Co, int H,
+                   int W, int ks, void* stream);
 /* gin (B,Ci,H,W), gw (Co,Ci,ks,ks), gb (Co) from gout; any output may be NULL.  ws: cfd_conv2d_bwd_workspace_bytes(). */
 size_t cfd_conv2d_bwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);
 int cfd_conv2d_bwd(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws, int B,

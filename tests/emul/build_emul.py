@@ -31,7 +31,7 @@ def build(force: bool = False) -> Path:
     for src in sources():
         obj = OUT / (src.name + ".o")
         cmd = [CLANG, "-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-Wno-unused-value",
-               f"-I{HERE / 'include'}", f"-I{CSRC}", f"-I{REPO / 'include'}", "-DCFD_WGRAD_TILE_MIN_WGS=1", "-c", str(src), "-o",
+               f"-I{HERE / 'include'}", f"-I{CSRC}", f"-I{REPO / 'include'}", "-DCFD_WGRAD_TILE_MIN_WGS=1", "-DCFD_CONV_TILE_MIN_WGS=2", "-c", str(src), "-o",
                str(obj)]
         subprocess.run(cmd, check=True)
         objs.append(str(obj))

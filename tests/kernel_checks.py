@@ -478,7 +478,9 @@ def check_conv2d(be, B, Ci, Co, H, W, ks, seed=31):
     g = rng.standard_normal((B, Co, H, W)).astype(np.float32)
     dx, dw, db, dg = be.dev(x), be.dev(w), be.dev(b), be.dev(g)
     out = be.zeros((B, Co, H, W))
-    api.call("cfd_conv2d_fwd", P(dx), P(dw), P(db), P(out), B, Ci, Co, H, W, ks, be.stream)
+    nws = api.size("cfd_conv2d_fwd_workspace_bytes", B, Ci, Co, H, W, ks)
+    fws = be.bytes(nws) if nws else None
+    api.call("cfd_conv2d_fwd", P(dx), P(dw), P(db), P(out), P(fws) if nws else None, B, Ci, Co, H, W, ks, be.stream)
     be.sync()
     res = {"out": nm(be.host(out), CO.conv2d(x.astype(f64), w.astype(f64), b.astype(f64)))}
     ws = be.bytes(api.size("cfd_conv2d_bwd_workspace_bytes", B, Ci, Co, H, W, ks))
