@@ -42,10 +42,16 @@ def main():
             yy = F_.Conv2dReplicateFn.apply(x, w, b)
             yy.backward(g)
         tb = timed(bwd) - tf
+        xd = x.detach()  # no input gradient: weight + bias gradient only
+
+        def bwd_w():
+            yy = F_.Conv2dReplicateFn.apply(xd, w, b)
+            yy.backward(g)
+        tw = timed(bwd_w) - tf
         gf = 2.0 * B * hw * hw * ci * co * ks * ks / 1e9
         byts = 4.0 * B * hw * hw * (ci + co) / 1e6
         print(f"{fam:6s} B={B:4d} {ci:4d}->{co:4d} {hw:3d}x{hw:<3d} k{ks}  fwd {tf:8.1f} us ({gf / tf * 1e3:6.1f} TF, {byts / tf:6.2f} TB/s)"
-              f"   bwd {tb:8.1f} us ({2 * gf / tb * 1e3:6.1f} TF)")
+              f"   bwd {tb:8.1f} us ({2 * gf / tb * 1e3:6.1f} TF)  of which wgrad+bias {tw:7.1f} us")
         if fam == "unet":
             tot[0] += tf
             tot[1] += tb
