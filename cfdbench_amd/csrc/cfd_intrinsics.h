@@ -62,3 +62,23 @@ __device__ __forceinline__ float cfd_exp2f(float x) { return __builtin_amdgcn_ex
 typedef float cfd_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cfd_f2 cfd_fma2(cfd_f2 a, cfd_f2 b, cfd_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ cfd_f2 cfd_abs2(cfd_f2 a) { return __builtin_elementwise_abs(a); }
+
+// Complex multiply-accumulate acc += x * w (cfd_cmla) and acc += conj(x) * w (cfd_cmla_conj) on (re, im) register
+// pairs: two v_pk_fma_f32 whose operand selects broadcast x.re / x.im and rotate w in the instruction itself.
+// Written in C the compiler materialises a rotated or broadcast copy of the loop-invariant operand (twice the
+// registers for a weight tile held in VGPRs).  Rounding: acc' = fma(x.re, w, acc), then fma(-+x.im, rot(w), acc').
+__device__ __forceinline__ cfd_f2 cfd_cmla(cfd_f2 acc, cfd_f2 x, cfd_f2 w) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(x), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(x), "v"(w));
+    return acc;
+}
+__device__ __forceinline__ cfd_f2 cfd_cmla_conj(cfd_f2 acc, cfd_f2 x, cfd_f2 w) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(x), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "+v"(acc) : "v"(x), "v"(w));
+    return acc;
+}
+
+// Waits for every outstanding vector-memory operation of the wave (s_waitcnt vmcnt(0), other counters untouched).
+// Placed in front of a software-pipelined loop so that the loop's own waits are computed from the loop body alone
+// (prologue loads still in flight at the loop header force a full wait on every iteration otherwise).
+__device__ __forceinline__ void cfd_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }

@@ -576,6 +576,147 @@ static void launch_mix(const float2* xin, const float2* w1, const float2* w2, fl
                            CoutW, m1, m2);
 }
 
+// ---- batch-in-lanes mode mixing --------------------------------------------------------------------------
+// lane = (b-lane j = lane >> 3, mode m = lane & 7): one wave-load covers 8 batch entries x 8 modes (eight contiguous
+// 64-B runs).  A wave owns ZT non-contracted channels and keeps their ZT x CR complex weights of its 8 modes in
+// registers (25.6 KB of weights per workgroup at C = 20 instead of the 102 KB of the lane = mode kernel); the
+// Cz / ZT waves of a workgroup share the contracted-side loads through the CU's vector L1.  No LDS, no barrier;
+// each wave prefetches its next 8 batch entries while it multiplies the current ones.  Workgroup id map as in
+// k_spec_wgrad_tile (the two mode groups of a 128-B line on one XCD).
+static inline void cfd_mix_tile_geometry(int B, int M, int want_wg, int* nmg, int* npair, int* BC, int* nchunk) {
+    *nmg = (M + 7) / 8;
+    *npair = (*nmg + 1) / 2;
+    int want = want_wg / *nmg;
+    if (want < 1) want = 1;
+    int bc = (B + want - 1) / want;
+    bc = (bc + 7) / 8 * 8;
+    if (bc < 8) bc = 8;
+    *BC = bc;
+    *nchunk = (B + bc - 1) / bc;
+}
+
+template <int CR, int ZT, int NW, bool CONJT, bool RING>
+__global__ __launch_bounds__(64 * NW) void k_mix_tile(const float2* __restrict__ xin, const float2* __restrict__ w1,
+                                                      const float2* __restrict__ w2, float2* __restrict__ z, int B,
+                                                      int BC, int Cz, int CoutW, int M, int half, int nmg, int npair,
+                                                      int nchunk) {
+    static_assert(CR % 2 == 0, "k_mix_tile: the contracted channels are streamed in two half blocks");
+    constexpr int HB = CR / 2;
+    const int L = blockIdx.x;
+    const int q = ((L >> 4) << 3) + (L & 7);
+    const int chunk = q / npair;
+    const int mg = 2 * (q - chunk * npair) + ((L >> 3) & 1);
+    if (chunk >= nchunk || mg >= nmg) return;
+    const int lane = threadIdx.x & 63, wave = cfd_uniform(threadIdx.x >> 6);
+    const int m = lane & 7, j = lane >> 3;
+    const int mode = mg * 8 + m;
+    const int modec = mode < M ? mode : M - 1;
+    const int cz0 = wave * ZT;
+    const int bbeg = chunk * BC;
+    const int bend = bbeg + BC < B ? bbeg + BC : B;
+    const float2* xp = xin + modec;
+    // one step = 8 batch entries (one per b-lane); rows past the chunk are clamped and never stored
+    auto load_half = [&](int b0, int h, float2 (&xv)[HB]) {
+        const int b = b0 + j;
+        const unsigned bc = (unsigned)(b < bend ? b : bend - 1);
+        const float2* xr = xp + (size_t)(bc * (unsigned)CR + (unsigned)(h * HB)) * M;
+#pragma unroll
+        for (int cr = 0; cr < HB; ++cr) xv[cr] = xr[(size_t)cr * M];
+    };
+    float2 xlo[HB], xhi[HB];
+    load_half(bbeg, 0, xlo);
+    load_half(bbeg, 1, xhi);
+    // forward reduces over Cin_w (= cr), the adjoint over Cout_w (= cr) with conj(W)
+    cfd_f2 wreg[ZT][CR];
+    {
+        const float2* w = modec < half ? w1 : w2;
+        const unsigned wm = modec < half ? modec : modec - half;
+#pragma unroll
+        for (int t = 0; t < ZT; ++t)
+#pragma unroll
+            for (int cr = 0; cr < CR; ++cr) {
+                const float2 v = CONJT ? w[(size_t)(((unsigned)(cz0 + t) * CoutW + cr) * (unsigned)half + wm)]
+                                       : w[(size_t)(((unsigned)cr * CoutW + (cz0 + t)) * (unsigned)half + wm)];
+                wreg[t][cr] = cfd_f2{v.x, CONJT ? -v.y : v.y};
+            }
+    }
+    // x * w per step: the two half blocks of the contracted channels one after the other, ZT outputs stored per lane
+    auto fma_half = [&](int h, const float2 (&xv)[HB], cfd_f2 (&acc)[ZT]) {
+#pragma unroll
+        for (int cr = 0; cr < HB; ++cr) {
+            const cfd_f2 x0 = {xv[cr].x, xv[cr].y};
+#pragma unroll
+            for (int t = 0; t < ZT; ++t) acc[t] = cfd_cmla(acc[t], x0, wreg[t][h * HB + cr]);
+        }
+    };
+    auto store = [&](int b0, const cfd_f2 (&acc)[ZT]) {
+        const int b = b0 + j;
+        if (b < bend && mode < M) {
+            float2* zr = z + ((size_t)((unsigned)b * Cz + cz0)) * M + mode;
+#pragma unroll
+            for (int t = 0; t < ZT; ++t) zr[(size_t)t * M] = make_float2(acc[t].x, acc[t].y);
+        }
+    };
+    // RING: each half block is re-armed with the next step's rows as soon as it has been consumed, so one half is
+    // always in flight behind the other half's FMAs; the loop body is branch-free (its waits stay partial) and the
+    // last step runs outside it with nothing left to re-arm.  !RING: the next step is loaded after the stores.
+    cfd_wait_vmem();
+    int b0 = bbeg;
+    for (; b0 + 8 < bend; b0 += 8) {
+        cfd_f2 acc[ZT];
+#pragma unroll
+        for (int t = 0; t < ZT; ++t) acc[t] = cfd_f2{0.f, 0.f};
+        fma_half(0, xlo, acc);
+        if (RING) { load_half(b0 + 8, 0, xlo); cfd_sched_fence(); }
+        fma_half(1, xhi, acc);
+        if (RING) { load_half(b0 + 8, 1, xhi); cfd_sched_fence(); }
+        store(b0, acc);
+        if (!RING) {
+            load_half(b0 + 8, 0, xlo);
+            load_half(b0 + 8, 1, xhi);
+        }
+    }
+    {
+        cfd_f2 acc[ZT];
+#pragma unroll
+        for (int t = 0; t < ZT; ++t) acc[t] = cfd_f2{0.f, 0.f};
+        fma_half(0, xlo, acc);
+        fma_half(1, xhi, acc);
+        store(b0, acc);
+    }
+}
+
+// Dev switches (timing experiments only): CFD_MIX_VARIANT=0 forces the lane = mode kernel, 2 the tile kernel without the
+// half-block ring; CFD_MIX_WG = workgroups aimed at.
+static int cfd_mix_variant() {
+    static const int v = [] { const char* e = getenv("CFD_MIX_VARIANT"); return e ? atoi(e) : -1; }();
+    return v;
+}
+static int cfd_mix_want_wg() {  // read per call: the tests shrink it to reach the multi-step loops at small batch sizes
+    const char* e = getenv("CFD_MIX_WG");
+    const int v = e ? atoi(e) : 256;
+    return v >= 1 ? v : 256;
+}
+
+template <bool CONJT>
+static bool launch_mix_tile(const float2* xin, const float2* w1, const float2* w2, float2* z, int B, int Cr, int Cz,
+                            int CoutW, int m1, int m2, hipStream_t st) {
+    constexpr int CR = 20, ZT = 2;
+    if (cfd_mix_variant() == 0 || Cr != CR || Cz % ZT || Cz / ZT > 10) return false;
+    const int nw = Cz / ZT, M = 2 * m1 * m2;
+    int nmg, npair, BC, nchunk;
+    cfd_mix_tile_geometry(B, M, cfd_mix_want_wg(), &nmg, &npair, &BC, &nchunk);
+    const unsigned grid = (unsigned)((npair * nchunk + 7) / 8) * 16u;
+    const bool ring = cfd_mix_variant() != 2;
+#define CFD_MIX_TILE_LAUNCH(NW_, RING_)                                                                               \
+    hipLaunchKernelGGL((k_mix_tile<CR, ZT, NW_, CONJT, RING_>), dim3(grid), dim3(64 * nw), 0, st, xin, w1, w2, z, B, BC, \
+                       Cz, CoutW, M, m1 * m2, nmg, npair, nchunk)
+    if (ring) CFD_MIX_TILE_LAUNCH(10, true);
+    else CFD_MIX_TILE_LAUNCH(10, false);
+#undef CFD_MIX_TILE_LAUNCH
+    return true;
+}
+
 // (CR, WPB) instantiations: CR >= contracted channels, WPB waves = non-contracted channels per workgroup.
 #define CFD_MIX_DISPATCH(FN, Cr_, Cz_, ...)                                        \
     do {                                                                            \
@@ -606,6 +747,13 @@ extern "C" int cfd_spectral_mix(const cfd_plan* p, const float* xh, const float*
     const int Cr = conj_t ? Cout : Cin, Cz = conj_t ? Cin : Cout;
     hipStream_t st = (hipStream_t)stream;
     CFD_PROF(conj_t ? "k_mix_adj" : "k_mix", st);
+    if (conj_t ? launch_mix_tile<true>((const float2*)xh, (const float2*)w1, (const float2*)w2, (float2*)z, B, Cr, Cz, Cout,
+                                       p->m1, p->m2, st)
+               : launch_mix_tile<false>((const float2*)xh, (const float2*)w1, (const float2*)w2, (float2*)z, B, Cr, Cz, Cout,
+                                        p->m1, p->m2, st)) {
+        CFD_LAUNCH_CHECK("cfd_spectral_mix(tile)");
+        return CFD_OK;
+    }
     if (conj_t)
         CFD_MIX_DISPATCH(launch_mix_adj, Cr, Cz, (const float2*)xh, (const float2*)w1, (const float2*)w2, (float2*)z, B, Cr,
                          Cz, Cout, p->m1, p->m2, st);
@@ -696,6 +844,137 @@ static void launch_spec_wgrad(const float2* xh, const float2* gh, float2* part, 
     else hipLaunchKernelGGL((k_spec_wgrad_part<CR, WPB, false>), grid, dim3(64 * WPB), 0, st, xh, gh, part, B, Cin, Cout, M);
 }
 
+// ---- register-tiled weight gradient -----------------------------------------------------------------------
+// The lane = mode kernel above needs one partial sum per 16 batch entries to fill the chip (its partial-sum round trip
+// is larger than its inputs) and reads the x modes once per output-channel group.  Here the BATCH is spread over
+// lanes as well: lane = (b-lane j = lane >> 3, mode m = lane & 7), so one wave-load covers 8 batch entries x 8
+// modes (eight contiguous 64-B runs), a wave owns an IT x OT tile of (input, output) channels with its IT*OT complex
+// accumulators in registers, and the (Cin/IT) x (Cout/OT) waves of a workgroup cover every channel pair of one
+// 8-mode group for a contiguous chunk of the batch.  No LDS and no barrier: the waves of a workgroup share their
+// operands through the CU's vector L1 and each wave software-pipelines its own loads one step ahead.  The 8 b-lanes
+// are summed by recursive halving (xor 32, 16, 8: each step exchanges half of the remaining accumulators), after
+// which every lane holds ~IT*OT/8 finished sums and the partial tile leaves in 64-B runs.  Workgroup ids are mapped
+// so that the two 8-mode groups sharing each 128-B line run on the same XCD (same L2) back to back.
+static int cfd_wgrad_want_wg() {  // dev / test switch, read per call (see cfd_mix_want_wg)
+    const char* e = getenv("CFD_WGRAD_WG");
+    const int v = e ? atoi(e) : 256;
+    return v >= 1 ? v : 256;
+}
+static inline void cfd_wgrad_tile_geometry(int B, int M, int* nmg, int* npair, int* BC, int* nchunk) {
+    *nmg = (M + 7) / 8;
+    *npair = (*nmg + 1) / 2;
+    int want = cfd_wgrad_want_wg() / *nmg;  // about one workgroup per CU
+    if (want < 1) want = 1;
+    int bc = (B + want - 1) / want;
+    bc = (bc + 7) / 8 * 8;
+    if (bc < 8) bc = 8;
+    *BC = bc;
+    *nchunk = (B + bc - 1) / bc;
+}
+
+template <int IT, int OT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_spec_wgrad_tile(const float2* __restrict__ xh, const float2* __restrict__ gh,
+                                                             float2* __restrict__ part, int B, int BC, int Cin, int Cout,
+                                                             int M, int nmg, int npair, int nchunk) {
+    constexpr int NA = IT * OT, NP = (NA + 7) / 8 * 8, H1 = NP / 2, H2 = NP / 4, H3 = NP / 8;
+    // XCD-aware id map: consecutive workgroup ids round-robin over the 8 XCDs; ids L and L + 8 (same XCD, adjacent
+    // in dispatch order) take the two mode groups of one 128-B line pair for the same batch chunk.
+    const int L = blockIdx.x;
+    const int q = ((L >> 4) << 3) + (L & 7);
+    const int chunk = q / npair;
+    const int mg = 2 * (q - chunk * npair) + ((L >> 3) & 1);
+    if (chunk >= nchunk || mg >= nmg) return;
+    const int lane = threadIdx.x & 63, wave = cfd_uniform(threadIdx.x >> 6);
+    const int m = lane & 7, j = lane >> 3;
+    const int nto = Cout / OT;
+    const int ti = wave / nto, to = wave - ti * nto;
+    const int i0 = ti * IT, o0 = to * OT;
+    const int mode = mg * 8 + m;
+    const int modec = mode < M ? mode : M - 1;
+    const int bbeg = chunk * BC;
+    const int bend = bbeg + BC < B ? bbeg + BC : B;
+    const float2* xp = xh + ((size_t)i0 * M + modec);
+    const float2* gp = gh + ((size_t)o0 * M + modec);
+    cfd_f2 acc[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) acc[a] = cfd_f2{0.f, 0.f};
+    // one step = 8 batch entries (one per b-lane); entries past the chunk read a clamped row and are masked at use
+    auto load = [&](int b0, float2 (&xv)[IT], float2 (&gv)[OT]) {
+        const int b = b0 + j;
+        const unsigned bc = (unsigned)(b < bend ? b : bend - 1);
+        const float2* xr = xp + (size_t)(bc * (unsigned)Cin) * M;
+        const float2* gr = gp + (size_t)(bc * (unsigned)Cout) * M;
+#pragma unroll
+        for (int ii = 0; ii < IT; ++ii) xv[ii] = xr[(size_t)ii * M];
+#pragma unroll
+        for (int oo = 0; oo < OT; ++oo) gv[oo] = gr[(size_t)oo * M];
+    };
+    auto fma_step = [&](int b0, const float2 (&xv)[IT], const float2 (&gv)[OT]) {
+        const bool ok = b0 + j < bend;
+#pragma unroll
+        for (int oo = 0; oo < OT; ++oo) {
+            const cfd_f2 g = {ok ? gv[oo].x : 0.f, ok ? gv[oo].y : 0.f};
+#pragma unroll
+            for (int ii = 0; ii < IT; ++ii)  // conj(x) * g
+                acc[ii * OT + oo] = cfd_cmla_conj(acc[ii * OT + oo], cfd_f2{xv[ii].x, xv[ii].y}, g);
+        }
+    };
+    // two register stages; the re-arm loads are unconditional (rows past the chunk are clamped and masked at use) so
+    // the loop body is branch-free and its waits stay partial: one stage is always in flight behind the other's FMAs
+    float2 xa[IT], ga[OT], xb[IT], gb[OT];
+    load(bbeg, xa, ga);
+    load(bbeg + 8, xb, gb);
+    cfd_wait_vmem();
+    int b0 = bbeg;
+    for (; b0 + 16 < bend; b0 += 16) {
+        fma_step(b0, xa, ga);
+        load(b0 + 16, xa, ga);
+        cfd_sched_fence();
+        fma_step(b0 + 8, xb, gb);
+        load(b0 + 24, xb, gb);
+        cfd_sched_fence();
+    }
+    fma_step(b0, xa, ga);  // last pair of steps: nothing left to re-arm
+    fma_step(b0 + 8, xb, gb);
+    // recursive halving over the b-lanes: after the three exchanges lane (j, m) holds the finished sums of the
+    // accumulators e = (j>>2&1)*H1 + (j>>1&1)*H2 + (j&1)*H3 + k, k < H3.
+    float2 v[NP];
+#pragma unroll
+    for (int a = 0; a < NP; ++a) v[a] = a < NA ? make_float2(acc[a].x, acc[a].y) : make_float2(0.f, 0.f);
+    {
+        const bool h = (lane & 32) != 0;
+#pragma unroll
+        for (int k = 0; k < H1; ++k) {
+            const float2 keep = h ? v[k + H1] : v[k], send = h ? v[k] : v[k + H1];
+            v[k] = make_float2(keep.x + cfd_shfl_xor(send.x, 32), keep.y + cfd_shfl_xor(send.y, 32));
+        }
+    }
+    {
+        const bool h = (lane & 16) != 0;
+#pragma unroll
+        for (int k = 0; k < H2; ++k) {
+            const float2 keep = h ? v[k + H2] : v[k], send = h ? v[k] : v[k + H2];
+            v[k] = make_float2(keep.x + cfd_shfl_xor(send.x, 16), keep.y + cfd_shfl_xor(send.y, 16));
+        }
+    }
+    {
+        const bool h = (lane & 8) != 0;
+#pragma unroll
+        for (int k = 0; k < H3; ++k) {
+            const float2 keep = h ? v[k + H3] : v[k], send = h ? v[k] : v[k + H3];
+            v[k] = make_float2(keep.x + cfd_shfl_xor(send.x, 8), keep.y + cfd_shfl_xor(send.y, 8));
+        }
+    }
+    const int ebase = ((lane >> 5) & 1) * H1 + ((lane >> 4) & 1) * H2 + ((lane >> 3) & 1) * H3;
+    float2* dst = part + (size_t)chunk * Cin * Cout * M + mode;
+#pragma unroll
+    for (int k = 0; k < H3; ++k) {
+        const int e = ebase + k;
+        const int ii = e / OT, oo = e - ii * OT;
+        if (e < NA && mode < M) dst[((size_t)(i0 + ii) * Cout + (o0 + oo)) * M] = v[k];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_spec_wgrad_reduce(const float2* __restrict__ part, float2* __restrict__ gw1,
                                                            float2* __restrict__ gw2, const float* __restrict__ clhw,
                                                            int nchunk, int CC, int m1, int m2) {
@@ -705,18 +984,13 @@ __global__ __launch_bounds__(256) void k_spec_wgrad_reduce(const float2* __restr
     const int mode = (int)(gid % M);
     const long io = gid / M;
     float ar = 0.f, ai = 0.f;
-    int c = 0;
-    for (; c + 8 <= nchunk; c += 8) {  // 8 independent loads in flight, summed in a fixed order
+    for (int c = 0; c < nchunk; c += 8) {  // 8 independent loads in flight (clamped past the end), fixed summation order
         float2 v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = part[(size_t)(c + k) * CC * M + gid];
+        for (int k = 0; k < 8; ++k) v[k] = part[(size_t)(c + k < nchunk ? c + k : nchunk - 1) * CC * M + gid];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { ar += v[k].x; ai += v[k].y; }
-    }
-    for (; c < nchunk; ++c) {
-        const float2 v = part[(size_t)c * CC * M + gid];
-        ar += v.x;
-        ai += v.y;
+        for (int k = 0; k < 8; ++k)
+            if (c + k < nchunk) { ar += v[k].x; ai += v[k].y; }
     }
     const float sc = clhw[mode % m2];
     const float2 r = make_float2(ar * sc, ai * sc);
@@ -726,8 +1000,35 @@ __global__ __launch_bounds__(256) void k_spec_wgrad_reduce(const float2* __restr
 
 extern "C" size_t cfd_spectral_wgrad_workspace_bytes(const cfd_plan* p, int B, int Cin, int Cout) {
     if (!p || B <= 0) return 0;
-    const size_t nchunk = (B + CFD_WGRAD_BCHUNK - 1) / CFD_WGRAD_BCHUNK;
+    size_t nchunk = (B + CFD_WGRAD_BCHUNK - 1) / CFD_WGRAD_BCHUNK;
+    int nmg, npair, BC, nct;
+    cfd_wgrad_tile_geometry(B, 2 * p->m1 * p->m2, &nmg, &npair, &BC, &nct);
+    if ((size_t)nct > nchunk) nchunk = (size_t)nct;  // either kernel may be dispatched
     return nchunk * (size_t)Cin * Cout * 2 * p->m1 * p->m2 * sizeof(float2);
+}
+
+// Dev switch (timing experiments only): CFD_WGRAD_VARIANT=0 forces the lane = mode kernel, 1 / 2 pick a tile shape.
+static int cfd_wgrad_variant() {
+    static const int v = [] { const char* e = getenv("CFD_WGRAD_VARIANT"); return e ? atoi(e) : -1; }();
+    return v;
+}
+
+template <int IT, int OT>
+static bool launch_spec_wgrad_tile(const float2* xh, const float2* gh, float2* part, int B, int Cin, int Cout, int M,
+                                   int* nchunk_out, hipStream_t st) {
+    if (Cin % IT || Cout % OT) return false;
+    const int nw = (Cin / IT) * (Cout / OT);
+    int nmg, npair, BC, nchunk;
+    cfd_wgrad_tile_geometry(B, M, &nmg, &npair, &BC, &nchunk);
+    const unsigned grid = (unsigned)((npair * nchunk + 7) / 8) * 16u;
+    if (nw <= 4) hipLaunchKernelGGL((k_spec_wgrad_tile<IT, OT, 4>), dim3(grid), dim3(64 * nw), 0, st, xh, gh, part, B, BC, Cin, Cout, M, nmg, npair, nchunk);
+    else if (nw <= 8) hipLaunchKernelGGL((k_spec_wgrad_tile<IT, OT, 8>), dim3(grid), dim3(64 * nw), 0, st, xh, gh, part, B, BC, Cin, Cout, M, nmg, npair, nchunk);
+    else if constexpr (IT * OT <= 32) {
+        if (nw > 16) return false;
+        hipLaunchKernelGGL((k_spec_wgrad_tile<IT, OT, 16>), dim3(grid), dim3(64 * nw), 0, st, xh, gh, part, B, BC, Cin, Cout, M, nmg, npair, nchunk);
+    } else return false;
+    *nchunk_out = nchunk;
+    return true;
 }
 
 extern "C" int cfd_spectral_wgrad(const cfd_plan* p, const float* xh, const float* gh, float* gw1, float* gw2, void* ws,
@@ -736,12 +1037,19 @@ extern "C" int cfd_spectral_wgrad(const cfd_plan* p, const float* xh, const floa
     CFD_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1, CFD_ERR_INVALID_ARG, "cfd_spectral_wgrad: bad sizes");
     CFD_REQUIRE(Cin <= 32 && Cout <= 32, CFD_ERR_UNSUPPORTED, "cfd_spectral_wgrad: Cin=%d Cout=%d (max 32) unsupported", Cin, Cout);
     const int M = 2 * p->m1 * p->m2;
-    const int nchunk = (B + CFD_WGRAD_BCHUNK - 1) / CFD_WGRAD_BCHUNK;
+    int nchunk = (B + CFD_WGRAD_BCHUNK - 1) / CFD_WGRAD_BCHUNK;
     const long total = (long)Cin * Cout * M;
     hipStream_t st = (hipStream_t)stream;
     {
         CFD_PROF("k_spec_wgrad_part", st);
-        CFD_MIX_DISPATCH(launch_spec_wgrad, Cin, Cout, (const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M, st);
+        // register-tiled kernel where the channel counts divide into its wave tiles (the FNO widths 10 / 20 / 40 ...),
+        // lane = mode kernel otherwise
+        const int var = cfd_wgrad_variant();
+        bool done = false;
+        if (var == 2) done = launch_spec_wgrad_tile<5, 5>((const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M, &nchunk, st);
+        else if (var != 0) done = launch_spec_wgrad_tile<5, 10>((const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M, &nchunk, st);
+        if (!done)
+            CFD_MIX_DISPATCH(launch_spec_wgrad, Cin, Cout, (const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M, st);
     }
     CFD_LAUNCH_CHECK("cfd_spectral_wgrad(part)");
     CFD_PROF("k_spec_wgrad_reduce", st);

@@ -81,3 +81,15 @@ inline float cfd_exp2f(float x) { return exp2f(x); }
 typedef float cfd_f2 __attribute__((ext_vector_type(2)));
 inline cfd_f2 cfd_fma2(cfd_f2 a, cfd_f2 b, cfd_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 inline cfd_f2 cfd_abs2(cfd_f2 a) { return __builtin_elementwise_abs(a); }
+
+// complex multiply-accumulate, same rounding sequence as the device form (two fused steps per component)
+inline cfd_f2 cfd_cmla(cfd_f2 acc, cfd_f2 x, cfd_f2 w) {
+    cfd_f2 r = {fmaf(x.x, w.x, acc.x), fmaf(x.x, w.y, acc.y)};
+    return cfd_f2{fmaf(-x.y, w.y, r.x), fmaf(x.y, w.x, r.y)};
+}
+inline cfd_f2 cfd_cmla_conj(cfd_f2 acc, cfd_f2 x, cfd_f2 w) {
+    cfd_f2 r = {fmaf(x.x, w.x, acc.x), fmaf(x.x, w.y, acc.y)};
+    return cfd_f2{fmaf(x.y, w.y, r.x), fmaf(-x.y, w.x, r.y)};
+}
+
+inline void cfd_wait_vmem() {}
