@@ -48,6 +48,7 @@ _SIGS = {
     "cfd_spectral_idft": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "cfd_spectral_wgrad_workspace_bytes": (_Z, [_P, _I, _I, _I]),
     "cfd_spectral_wgrad": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "cfd_spectral_mix_adj_wgrad": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cfd_spectral_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cfd_spectral_conv2d_bwd_workspace_bytes": (_Z, [_P, _I, _I, _I]),
     "cfd_spectral_conv2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -127,9 +127,9 @@ extern "C" int cfd_fno_backward_phase(const cfd_plan* p, const cfd_fno_shape* s,
     const int act = l > 0;
     // gcur = d loss / d a_{l+1}
     CFD_TRY(cfd_spectral_dft(p, gcur, gh, B * C, 0, stream));
-    CFD_TRY(cfd_spectral_wgrad(p, xh_buf(l), gh, g->spec_w1[l], g->spec_w2[l], scratch, B, C, C, stream));
+    CFD_TRY(cfd_spectral_mix_adj_wgrad(p, xh_buf(l), gh, prm->spec_w1[l], prm->spec_w2[l], z, g->spec_w1[l], g->spec_w2[l],
+                                       scratch, B, C, C, stream));
     CFD_TRY(cfd_chan_wgrad(gcur, act_buf(l), g->w0_w[l], g->w0_b[l], scratch, B, C, C, HW, act, stream));
-    CFD_TRY(cfd_spectral_mix(p, gh, prm->spec_w1[l], prm->spec_w2[l], z, B, C, C, 1, stream));
     return cfd_fno_block_bwd_input(p, gcur, z, prm->w0_w[l], act ? act_buf(l) : nullptr, gnext, B, C, C, stream);
 }
 

@@ -686,11 +686,97 @@ __global__ __launch_bounds__(64 * NW) void k_mix_tile(const float2* __restrict__
     }
 }
 
+// ---- batch-in-lanes mode mixing, weights in LDS -----------------------------------------------------------------
+// Same lane map as k_mix_tile (lane = (b-lane, mode of an 8-mode group)), but a wave owns 8 batch entries x ALL
+// channels: it loads its CR contracted-side values once (nothing is read twice anywhere in the grid), the workgroup
+// parks the Cz x CR weights of its 8 modes in LDS (25.6 KB at C = 20, pairs of contracted channels per 16-B word so
+// one ds_read_b128 feeds two complex FMAs; the 8 b-lanes of a mode read the same word: broadcast, conflict-free),
+// and every wave makes exactly ONE pass: loads in flight during the weight fill, Cz outputs, stores.  With 8 x NWV
+// batch entries per workgroup the whole batch is resident at once, so the kernel costs one memory latency plus the
+// LDS-fed FMAs instead of one latency per pipeline step.
+template <int CR, bool CONJT>
+__device__ __forceinline__ void mix_lds_body(float4* s_w, const int L, const float2* __restrict__ xin,
+                                             const float2* __restrict__ w1, const float2* __restrict__ w2,
+                                             float2* __restrict__ z, int B, int BC, int Cz, int CoutW, int M, int half,
+                                             int nmg, int npair, int nchunk) {
+    static_assert(CR % 2 == 0, "k_mix_lds: contracted channels are stored in pairs");
+    // s_w: [cz][cr / 2][m] -> (w[cr].re, w[cr].im, w[cr+1].re, w[cr+1].im)
+    const int q = ((L >> 4) << 3) + (L & 7);
+    const int chunk = q / npair;
+    const int mg = 2 * (q - chunk * npair) + ((L >> 3) & 1);
+    if (chunk >= nchunk || mg >= nmg) return;
+    const int lane = threadIdx.x & 63, wave = cfd_uniform(threadIdx.x >> 6);
+    const int m = lane & 7, j = lane >> 3;
+    const int mode = mg * 8 + m;
+    const int modec = mode < M ? mode : M - 1;
+    const int b = chunk * BC + wave * 8 + j;
+    const unsigned bc = (unsigned)(b < B ? b : B - 1);
+    cfd_f2 x[CR];
+    {
+        const float2* xr = xin + (size_t)(bc * (unsigned)CR) * M + modec;
+#pragma unroll
+        for (int cr = 0; cr < CR; ++cr) {
+            const float2 v = xr[(size_t)cr * M];
+            x[cr] = cfd_f2{v.x, v.y};
+        }
+    }
+    {   // weight fill: forward reduces over Cin_w (= cr), the adjoint over Cout_w (= cr) with conj(W).  16 loads per
+        // thread are issued back to back before the first LDS write (a load-wait-write loop costs one L2 latency each).
+        float2* s_w2 = reinterpret_cast<float2*>(s_w);
+        const int total = Cz * CR * 8;
+        constexpr int F = 16;
+        for (int base = threadIdx.x; base < total; base += F * blockDim.x) {
+            float2 v[F];
+            int dst[F];
+#pragma unroll
+            for (int k = 0; k < F; ++k) {
+                const int idx = base + k * blockDim.x;
+                const int idc = idx < total ? idx : total - 1;
+                const int mm = idc & 7, pr = idc >> 3;
+                const int cz = pr / CR, cr = pr - cz * CR;
+                const int md = mg * 8 + mm < M ? mg * 8 + mm : M - 1;
+                const float2* w = md < half ? w1 : w2;
+                const unsigned wm = md < half ? md : md - half;
+                v[k] = CONJT ? w[(size_t)(((unsigned)cz * CoutW + cr) * (unsigned)half + wm)]
+                             : w[(size_t)(((unsigned)cr * CoutW + cz) * (unsigned)half + wm)];
+                dst[k] = idx < total ? ((cz * (CR / 2) + (cr >> 1)) * 8 + mm) * 2 + (cr & 1) : -1;
+            }
+            cfd_sched_fence();
+#pragma unroll
+            for (int k = 0; k < F; ++k)
+                if (dst[k] >= 0) s_w2[dst[k]] = make_float2(v[k].x, CONJT ? -v[k].y : v[k].y);
+        }
+    }
+    __syncthreads();
+    const bool ok = b < B && b < chunk * BC + BC && mode < M;
+    float2* zr = z + (size_t)(bc * (unsigned)Cz) * M + mode;
+#pragma unroll 2
+    for (int cz = 0; cz < Cz; ++cz) {
+        const float4* wr = s_w + (cz * (CR / 2)) * 8 + m;
+        cfd_f2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int c2 = 0; c2 < CR / 2; ++c2) {
+            const float4 w = wr[c2 * 8];
+            acc = cfd_cmla(acc, x[2 * c2], cfd_f2{w.x, w.y});
+            acc = cfd_cmla(acc, x[2 * c2 + 1], cfd_f2{w.z, w.w});
+        }
+        if (ok) zr[(size_t)cz * M] = make_float2(acc.x, acc.y);
+    }
+}
+
+template <int CR, bool CONJT>
+__global__ __launch_bounds__(512) void k_mix_lds(const float2* __restrict__ xin, const float2* __restrict__ w1,
+                                                 const float2* __restrict__ w2, float2* __restrict__ z, int B, int BC,
+                                                 int Cz, int CoutW, int M, int half, int nmg, int npair, int nchunk) {
+    CFD_DYN_SHARED(float4, s_w);
+    mix_lds_body<CR, CONJT>(s_w, blockIdx.x, xin, w1, w2, z, B, BC, Cz, CoutW, M, half, nmg, npair, nchunk);
+}
+
 // Dev switches (timing experiments only): CFD_MIX_VARIANT=0 forces the lane = mode kernel, 2 the tile kernel without the
 // half-block ring; CFD_MIX_WG = workgroups aimed at.
 static int cfd_mix_variant() {
-    static const int v = [] { const char* e = getenv("CFD_MIX_VARIANT"); return e ? atoi(e) : -1; }();
-    return v;
+    const char* e = getenv("CFD_MIX_VARIANT");
+    return e ? atoi(e) : -1;
 }
 static int cfd_mix_want_wg() {  // read per call: the tests shrink it to reach the multi-step loops at small batch sizes
     const char* e = getenv("CFD_MIX_WG");
@@ -698,11 +784,35 @@ static int cfd_mix_want_wg() {  // read per call: the tests shrink it to reach t
     return v >= 1 ? v : 256;
 }
 
+static int cfd_mix_lds_waves() {  // dev switch: waves (= groups of 8 batch entries) per workgroup of k_mix_lds
+    const char* e = getenv("CFD_MIX_NWV");
+    const int v = e ? atoi(e) : 4;
+    return v >= 1 && v <= 8 ? v : 4;
+}
+
+template <bool CONJT>
+static bool launch_mix_lds(const float2* xin, const float2* w1, const float2* w2, float2* z, int B, int Cr, int Cz,
+                           int CoutW, int m1, int m2, hipStream_t st) {
+    const int var = cfd_mix_variant();
+    if (var == 0 || var == 1 || var == 2 || (Cr != 20 && Cr != 32)) return false;
+    const int M = 2 * m1 * m2, nwv = cfd_mix_lds_waves(), BC = 8 * nwv;
+    const int nmg = (M + 7) / 8, npair = (nmg + 1) / 2, nchunk = (B + BC - 1) / BC;
+    const unsigned grid = (unsigned)((npair * nchunk + 7) / 8) * 16u;
+    const size_t lds = (size_t)Cz * Cr * 8 * sizeof(float2);
+    if (Cr == 20)
+        hipLaunchKernelGGL((k_mix_lds<20, CONJT>), dim3(grid), dim3(64 * nwv), lds, st, xin, w1, w2, z, B, BC, Cz, CoutW, M,
+                           m1 * m2, nmg, npair, nchunk);
+    else
+        hipLaunchKernelGGL((k_mix_lds<32, CONJT>), dim3(grid), dim3(64 * nwv), lds, st, xin, w1, w2, z, B, BC, Cz, CoutW, M,
+                           m1 * m2, nmg, npair, nchunk);
+    return true;
+}
+
 template <bool CONJT>
 static bool launch_mix_tile(const float2* xin, const float2* w1, const float2* w2, float2* z, int B, int Cr, int Cz,
                             int CoutW, int m1, int m2, hipStream_t st) {
     constexpr int CR = 20, ZT = 2;
-    if (cfd_mix_variant() == 0 || Cr != CR || Cz % ZT || Cz / ZT > 10) return false;
+    if (cfd_mix_variant() == 0 || Cr != CR || Cz % ZT || Cz / ZT > 10) return false;  // variants 1 / 2 land here
     const int nw = Cz / ZT, M = 2 * m1 * m2;
     int nmg, npair, BC, nchunk;
     cfd_mix_tile_geometry(B, M, cfd_mix_want_wg(), &nmg, &npair, &BC, &nchunk);
@@ -747,6 +857,13 @@ extern "C" int cfd_spectral_mix(const cfd_plan* p, const float* xh, const float*
     const int Cr = conj_t ? Cout : Cin, Cz = conj_t ? Cin : Cout;
     hipStream_t st = (hipStream_t)stream;
     CFD_PROF(conj_t ? "k_mix_adj" : "k_mix", st);
+    if (conj_t ? launch_mix_lds<true>((const float2*)xh, (const float2*)w1, (const float2*)w2, (float2*)z, B, Cr, Cz, Cout,
+                                      p->m1, p->m2, st)
+               : launch_mix_lds<false>((const float2*)xh, (const float2*)w1, (const float2*)w2, (float2*)z, B, Cr, Cz, Cout,
+                                       p->m1, p->m2, st)) {
+        CFD_LAUNCH_CHECK("cfd_spectral_mix(lds)");
+        return CFD_OK;
+    }
     if (conj_t ? launch_mix_tile<true>((const float2*)xh, (const float2*)w1, (const float2*)w2, (float2*)z, B, Cr, Cz, Cout,
                                        p->m1, p->m2, st)
                : launch_mix_tile<false>((const float2*)xh, (const float2*)w1, (const float2*)w2, (float2*)z, B, Cr, Cz, Cout,
@@ -872,22 +989,22 @@ static inline void cfd_wgrad_tile_geometry(int B, int M, int* nmg, int* npair, i
     *nchunk = (B + bc - 1) / bc;
 }
 
-template <int IT, int OT, int NW>
-__global__ __launch_bounds__(64 * NW) void k_spec_wgrad_tile(const float2* __restrict__ xh, const float2* __restrict__ gh,
-                                                             float2* __restrict__ part, int B, int BC, int Cin, int Cout,
-                                                             int M, int nmg, int npair, int nchunk) {
+// `tile` = index of this wave's (input, output) channel tile, row-major over (Cin / IT) x (Cout / OT)
+template <int IT, int OT, int NS>
+__device__ __forceinline__ void wgrad_tile_body(const int L, const int tile, const float2* __restrict__ xh,
+                                                const float2* __restrict__ gh, float2* __restrict__ part, int B, int BC,
+                                                int Cin, int Cout, int M, int nmg, int npair, int nchunk) {
     constexpr int NA = IT * OT, NP = (NA + 7) / 8 * 8, H1 = NP / 2, H2 = NP / 4, H3 = NP / 8;
     // XCD-aware id map: consecutive workgroup ids round-robin over the 8 XCDs; ids L and L + 8 (same XCD, adjacent
     // in dispatch order) take the two mode groups of one 128-B line pair for the same batch chunk.
-    const int L = blockIdx.x;
     const int q = ((L >> 4) << 3) + (L & 7);
     const int chunk = q / npair;
     const int mg = 2 * (q - chunk * npair) + ((L >> 3) & 1);
     if (chunk >= nchunk || mg >= nmg) return;
-    const int lane = threadIdx.x & 63, wave = cfd_uniform(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     const int m = lane & 7, j = lane >> 3;
     const int nto = Cout / OT;
-    const int ti = wave / nto, to = wave - ti * nto;
+    const int ti = tile / nto, to = tile - ti * nto;
     const int i0 = ti * IT, o0 = to * OT;
     const int mode = mg * 8 + m;
     const int modec = mode < M ? mode : M - 1;
@@ -919,23 +1036,24 @@ __global__ __launch_bounds__(64 * NW) void k_spec_wgrad_tile(const float2* __res
                 acc[ii * OT + oo] = cfd_cmla_conj(acc[ii * OT + oo], cfd_f2{xv[ii].x, xv[ii].y}, g);
         }
     };
-    // two register stages; the re-arm loads are unconditional (rows past the chunk are clamped and masked at use) so
-    // the loop body is branch-free and its waits stay partial: one stage is always in flight behind the other's FMAs
-    float2 xa[IT], ga[OT], xb[IT], gb[OT];
-    load(bbeg, xa, ga);
-    load(bbeg + 8, xb, gb);
-    cfd_wait_vmem();
+    // NS register stages, all armed up front (NS x 8 batch entries in flight per wave); a stage is re-armed as soon as
+    // it has been consumed.  The re-arm loads are unconditional (rows past the chunk are clamped and masked at use) so
+    // the loop body is branch-free and its waits stay partial; the last NS steps run outside it, nothing left to arm.
+    float2 xs[NS][IT], gs[NS][OT];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) load(bbeg + 8 * t, xs[t], gs[t]);
     int b0 = bbeg;
-    for (; b0 + 16 < bend; b0 += 16) {
-        fma_step(b0, xa, ga);
-        load(b0 + 16, xa, ga);
-        cfd_sched_fence();
-        fma_step(b0 + 8, xb, gb);
-        load(b0 + 24, xb, gb);
-        cfd_sched_fence();
+    for (; b0 + 8 * NS < bend; b0 += 8 * NS) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            fma_step(b0 + 8 * t, xs[t], gs[t]);
+            load(b0 + 8 * (NS + t), xs[t], gs[t]);
+            cfd_sched_fence();
+        }
     }
-    fma_step(b0, xa, ga);  // last pair of steps: nothing left to re-arm
-    fma_step(b0 + 8, xb, gb);
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+        if (b0 + 8 * t < bend) fma_step(b0 + 8 * t, xs[t], gs[t]);
     // recursive halving over the b-lanes: after the three exchanges lane (j, m) holds the finished sums of the
     // accumulators e = (j>>2&1)*H1 + (j>>1&1)*H2 + (j&1)*H3 + k, k < H3.
     float2 v[NP];
@@ -975,6 +1093,37 @@ __global__ __launch_bounds__(64 * NW) void k_spec_wgrad_tile(const float2* __res
     }
 }
 
+template <int IT, int OT, int NW, int NS>
+__global__ __launch_bounds__(64 * NW) void k_spec_wgrad_tile(const float2* __restrict__ xh, const float2* __restrict__ gh,
+                                                             float2* __restrict__ part, int B, int BC, int Cin, int Cout,
+                                                             int M, int nmg, int npair, int nchunk) {
+    wgrad_tile_body<IT, OT, NS>(blockIdx.x, cfd_uniform(threadIdx.x >> 6), xh, gh, part, B, BC, Cin, Cout, M, nmg, npair,
+                                nchunk);
+}
+
+// ---- adjoint mix + weight gradient in ONE launch (horizontal fusion) ---------------------------------------------
+// Both consume the gradient modes gh and neither depends on the other; on this part every kernel costs ~4.5 us of
+// dispatch floor whatever it does, and both are latency-bound (one memory latency, little arithmetic).  The first
+// n_mix workgroups run the k_mix_lds body (adjoint), the rest the k_spec_wgrad_tile body; NSPLIT workgroups of 8
+// waves share the channel tiles of one (mode group, batch chunk).
+template <int C, int IT, int OT, int NS, int NSPLIT>
+__global__ __launch_bounds__(512) void k_mixadj_wgrad(const float2* __restrict__ xh, const float2* __restrict__ gh,
+                                                      const float2* __restrict__ w1, const float2* __restrict__ w2,
+                                                      float2* __restrict__ gz, float2* __restrict__ part, int B, int M,
+                                                      int half, int nmg, int npair, int n_mix, int mixBC, int mix_nchunk,
+                                                      int wgBC, int wg_nchunk) {
+    CFD_DYN_SHARED(float4, s_w);
+    static_assert((C / IT) * (C / OT) == 8 * NSPLIT, "k_mixadj_wgrad: 8 waves per workgroup");
+    if ((int)blockIdx.x < n_mix) {
+        mix_lds_body<C, true>(s_w, blockIdx.x, gh, w1, w2, gz, B, mixBC, C, C, M, half, nmg, npair, mix_nchunk);
+    } else {
+        const int Lw = (int)blockIdx.x - n_mix;
+        const int split = Lw % NSPLIT;
+        wgrad_tile_body<IT, OT, NS>(Lw / NSPLIT, split * 8 + cfd_uniform(threadIdx.x >> 6), xh, gh, part, B, wgBC, C, C, M,
+                                    nmg, npair, wg_nchunk);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_spec_wgrad_reduce(const float2* __restrict__ part, float2* __restrict__ gw1,
                                                            float2* __restrict__ gw2, const float* __restrict__ clhw,
                                                            int nchunk, int CC, int m1, int m2) {
@@ -1009,11 +1158,11 @@ extern "C" size_t cfd_spectral_wgrad_workspace_bytes(const cfd_plan* p, int B, i
 
 // Dev switch (timing experiments only): CFD_WGRAD_VARIANT=0 forces the lane = mode kernel, 1 / 2 pick a tile shape.
 static int cfd_wgrad_variant() {
-    static const int v = [] { const char* e = getenv("CFD_WGRAD_VARIANT"); return e ? atoi(e) : -1; }();
-    return v;
+    const char* e = getenv("CFD_WGRAD_VARIANT");
+    return e ? atoi(e) : -1;
 }
 
-template <int IT, int OT>
+template <int IT, int OT, int NS>
 static bool launch_spec_wgrad_tile(const float2* xh, const float2* gh, float2* part, int B, int Cin, int Cout, int M,
                                    int* nchunk_out, hipStream_t st) {
     if (Cin % IT || Cout % OT) return false;
@@ -1021,11 +1170,12 @@ static bool launch_spec_wgrad_tile(const float2* xh, const float2* gh, float2* p
     int nmg, npair, BC, nchunk;
     cfd_wgrad_tile_geometry(B, M, &nmg, &npair, &BC, &nchunk);
     const unsigned grid = (unsigned)((npair * nchunk + 7) / 8) * 16u;
-    if (nw <= 4) hipLaunchKernelGGL((k_spec_wgrad_tile<IT, OT, 4>), dim3(grid), dim3(64 * nw), 0, st, xh, gh, part, B, BC, Cin, Cout, M, nmg, npair, nchunk);
-    else if (nw <= 8) hipLaunchKernelGGL((k_spec_wgrad_tile<IT, OT, 8>), dim3(grid), dim3(64 * nw), 0, st, xh, gh, part, B, BC, Cin, Cout, M, nmg, npair, nchunk);
-    else if constexpr (IT * OT <= 32) {
+    if (nw <= 8) {
+        if (nw <= 4) hipLaunchKernelGGL((k_spec_wgrad_tile<IT, OT, 4, NS>), dim3(grid), dim3(64 * nw), 0, st, xh, gh, part, B, BC, Cin, Cout, M, nmg, npair, nchunk);
+        else hipLaunchKernelGGL((k_spec_wgrad_tile<IT, OT, 8, NS>), dim3(grid), dim3(64 * nw), 0, st, xh, gh, part, B, BC, Cin, Cout, M, nmg, npair, nchunk);
+    } else if constexpr (IT * OT <= 32) {  // 16 waves: 128 registers per lane
         if (nw > 16) return false;
-        hipLaunchKernelGGL((k_spec_wgrad_tile<IT, OT, 16>), dim3(grid), dim3(64 * nw), 0, st, xh, gh, part, B, BC, Cin, Cout, M, nmg, npair, nchunk);
+        hipLaunchKernelGGL((k_spec_wgrad_tile<IT, OT, 16, NS>), dim3(grid), dim3(64 * nw), 0, st, xh, gh, part, B, BC, Cin, Cout, M, nmg, npair, nchunk);
     } else return false;
     *nchunk_out = nchunk;
     return true;
@@ -1046,8 +1196,9 @@ extern "C" int cfd_spectral_wgrad(const cfd_plan* p, const float* xh, const floa
         // lane = mode kernel otherwise
         const int var = cfd_wgrad_variant();
         bool done = false;
-        if (var == 2) done = launch_spec_wgrad_tile<5, 5>((const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M, &nchunk, st);
-        else if (var != 0) done = launch_spec_wgrad_tile<5, 10>((const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M, &nchunk, st);
+        if (var == 2) done = launch_spec_wgrad_tile<5, 5, 3>((const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M, &nchunk, st);
+        else if (var == 1) done = launch_spec_wgrad_tile<5, 10, 2>((const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M, &nchunk, st);
+        else if (var != 0) done = launch_spec_wgrad_tile<5, 10, 4>((const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M, &nchunk, st);
         if (!done)
             CFD_MIX_DISPATCH(launch_spec_wgrad, Cin, Cout, (const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M, st);
     }
@@ -1057,6 +1208,63 @@ extern "C" int cfd_spectral_wgrad(const cfd_plan* p, const float* xh, const floa
                        (const float2*)ws, (float2*)gw1, (float2*)gw2, (const float*)p->d_clhw, nchunk, Cin * Cout,
                        p->m1, p->m2);
     CFD_LAUNCH_CHECK("cfd_spectral_wgrad(reduce)");
+    return CFD_OK;
+}
+
+// Adjoint mode mixing (gz = sum_o conj(W[i,o]) gh[b,o]) and the spectral weight gradient of the same gradient modes.
+// One launch for both where the fused kernel applies (Cin == Cout == 20), the two stand-alone entry points otherwise.
+static int cfd_fused_variant() {  // dev switch (timing experiments): 0 = two launches, 1..3 = tile shape / ring depth
+    const char* e = getenv("CFD_FUSED_VARIANT");
+    return e ? atoi(e) : -1;
+}
+
+template <int IT, int OT, int NS, int NSPLIT>
+static void launch_mixadj_wgrad(const float2* xh, const float2* gh, const float2* w1, const float2* w2, float2* gz,
+                                float2* part, int B, int m1, int m2, int* nchunk_out, hipStream_t st) {
+    constexpr int C = 20;
+    const int M = 2 * m1 * m2;
+    int nmg, npair, wgBC, wg_nchunk;
+    cfd_wgrad_tile_geometry(B, M, &nmg, &npair, &wgBC, &wg_nchunk);
+    const int mixBC = 64, mix_nchunk = (B + mixBC - 1) / mixBC;  // 8 waves x 8 batch entries per mix workgroup
+    const int n_mix = (npair * mix_nchunk + 7) / 8 * 16;
+    const int n_wg = (npair * wg_nchunk + 7) / 8 * 16 * NSPLIT;
+    hipLaunchKernelGGL((k_mixadj_wgrad<C, IT, OT, NS, NSPLIT>), dim3((unsigned)(n_mix + n_wg)), dim3(512),
+                       (size_t)C * C * 8 * sizeof(float2), st, xh, gh, w1, w2, gz, part, B, M, m1 * m2, nmg, npair, n_mix,
+                       mixBC, mix_nchunk, wgBC, wg_nchunk);
+    *nchunk_out = wg_nchunk;
+}
+
+extern "C" int cfd_spectral_mix_adj_wgrad(const cfd_plan* p, const float* xh, const float* gh, const float* w1,
+                                          const float* w2, float* gz, float* gw1, float* gw2, void* ws, int B, int Cin,
+                                          int Cout, void* stream) {
+    CFD_REQUIRE(p && xh && gh && w1 && w2 && gz && gw1 && gw2 && ws, CFD_ERR_INVALID_ARG, "cfd_spectral_mix_adj_wgrad: NULL pointer");
+    CFD_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1, CFD_ERR_INVALID_ARG, "cfd_spectral_mix_adj_wgrad: bad sizes");
+    const int var = cfd_fused_variant();
+    if (var == 0 || Cin != 20 || Cout != 20) {
+        CFD_TRY(cfd_spectral_wgrad(p, xh, gh, gw1, gw2, ws, B, Cin, Cout, stream));
+        return cfd_spectral_mix(p, gh, w1, w2, gz, B, Cin, Cout, 1, stream);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int M = 2 * p->m1 * p->m2;
+    int nchunk = 0;
+    {
+        CFD_PROF("k_mixadj_wgrad", st);
+        if (var == 2)
+            launch_mixadj_wgrad<5, 5, 3, 2>((const float2*)xh, (const float2*)gh, (const float2*)w1, (const float2*)w2,
+                                            (float2*)gz, (float2*)ws, B, p->m1, p->m2, &nchunk, st);
+        else if (var == 3)
+            launch_mixadj_wgrad<5, 10, 4, 1>((const float2*)xh, (const float2*)gh, (const float2*)w1, (const float2*)w2,
+                                             (float2*)gz, (float2*)ws, B, p->m1, p->m2, &nchunk, st);
+        else
+            launch_mixadj_wgrad<5, 10, 2, 1>((const float2*)xh, (const float2*)gh, (const float2*)w1, (const float2*)w2,
+                                             (float2*)gz, (float2*)ws, B, p->m1, p->m2, &nchunk, st);
+    }
+    CFD_LAUNCH_CHECK("cfd_spectral_mix_adj_wgrad(fused)");
+    CFD_PROF("k_spec_wgrad_reduce", st);
+    const long total = (long)Cin * Cout * M;
+    hipLaunchKernelGGL(k_spec_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float2*)ws,
+                       (float2*)gw1, (float2*)gw2, (const float*)p->d_clhw, nchunk, Cin * Cout, p->m1, p->m2);
+    CFD_LAUNCH_CHECK("cfd_spectral_mix_adj_wgrad(reduce)");
     return CFD_OK;
 }
 
@@ -1409,11 +1617,14 @@ extern "C" int cfd_spectral_conv2d_bwd(const cfd_plan* p, const float* gy, const
     float* gz = (float*)(base + cfd_align_up((size_t)B * Cout * M * 8, 256));
     void* wws = base + cfd_align_up((size_t)B * Cout * M * 8, 256) + cfd_align_up((size_t)B * Cin * M * 8, 256);
     CFD_TRY(cfd_spectral_dft(p, gy, gh, B * Cout, 0, stream));
-    if (gw1) CFD_TRY(cfd_spectral_wgrad(p, xh, gh, gw1, gw2, wws, B, Cin, Cout, stream));
-    if (gx) {
+    if (gw1 && gx) {
+        CFD_TRY(cfd_spectral_mix_adj_wgrad(p, xh, gh, w1, w2, gz, gw1, gw2, wws, B, Cin, Cout, stream));
+    } else if (gw1) {
+        CFD_TRY(cfd_spectral_wgrad(p, xh, gh, gw1, gw2, wws, B, Cin, Cout, stream));
+    } else if (gx) {
         CFD_TRY(cfd_spectral_mix(p, gh, w1, w2, gz, B, Cin, Cout, 1, stream));
-        CFD_TRY(cfd_spectral_idft(p, gz, nullptr, nullptr, gx, B * Cin, 0, stream));
     }
+    if (gx) CFD_TRY(cfd_spectral_idft(p, gz, nullptr, nullptr, gx, B * Cin, 0, stream));
     return CFD_OK;
 }
 

@@ -77,6 +77,13 @@ size_t cfd_spectral_wgrad_workspace_bytes(const cfd_plan* plan, int B, int Cin, 
 int cfd_spectral_wgrad(const cfd_plan* plan, const float* xh, const float* gh, float* gw1, float* gw2, void* ws,
                        int B, int Cin, int Cout, void* stream);
 
+/* Both mode-domain consumers of the gradient modes gh in one call (autograd of compl_mul2d, fno2d.py:54-57,73-78):
+ * gz = cfd_spectral_mix(gh, conj_t = 1) and gw{1,2} = cfd_spectral_wgrad(xh, gh).  One kernel launch for the pair
+ * where the fused kernel applies (Cin == Cout == 20), the two calls above otherwise; same results either way up to
+ * fp32 summation order.  ws: cfd_spectral_wgrad_workspace_bytes() bytes.                                     */
+int cfd_spectral_mix_adj_wgrad(const cfd_plan* plan, const float* xh, const float* gh, const float* w1, const float* w2,
+                               float* gz, float* gw1, float* gw2, void* ws, int B, int Cin, int Cout, void* stream);
+
 /* y = SpectralConv2d_fast(x) (fno2d.py:59-82).  xh_out (B,Cin,2*m1,m2) c64 receives the kept input modes (saved
  * for the backward pass); z_ws (B,Cout,2*m1,m2) c64 is scratch.                                              */
 int cfd_spectral_conv2d_fwd(const cfd_plan* plan, const float* x, const float* w1, const float* w2, float* y,

@@ -81,16 +81,26 @@ def check_mix_wgrad(be, B, Cin, Cout, m1=12, m2=12, H=64, W=64, seed=11):
         gw1 = be.zeros((Cin, Cout, m1, m2), np.complex64)
         gw2 = be.zeros((Cin, Cout, m1, m2), np.complex64)
         api.call("cfd_spectral_wgrad", plan, P(dxh), P(dgh), P(gw1), P(gw2), P(ws), B, Cin, Cout, be.stream)
+        # the two gradient-mode consumers in one call (one launch where the fused kernel applies)
+        fgz = be.zeros((B, Cin, *M2), np.complex64)
+        fgw1 = be.zeros((Cin, Cout, m1, m2), np.complex64)
+        fgw2 = be.zeros((Cin, Cout, m1, m2), np.complex64)
+        api.call("cfd_spectral_mix_adj_wgrad", plan, P(dxh), P(dgh), P(dw1), P(dw2), P(fgz), P(fgw1), P(fgw2), P(ws), B,
+                 Cin, Cout, be.stream)
         be.sync()
         X, G = xh.astype(c128), gh.astype(c128)
         Wf = np.concatenate([w1, w2], axis=2).astype(c128)  # (Cin, Cout, 2*m1, m2): rows [0,m1) use w1, the rest w2
         cl = O.hermitian_weights(m2, W) / (H * W)
         rgw = np.einsum("bikl,bokl->iokl", X.conj(), G) * cl[None, None, None, :]
+        rgz = np.einsum("bokl,iokl->bikl", G, Wf.conj())
         return {
             "mix": nm(be.host(z), np.einsum("bikl,iokl->bokl", X, Wf)),
-            "mix_adj": nm(be.host(gz), np.einsum("bokl,iokl->bikl", G, Wf.conj())),
+            "mix_adj": nm(be.host(gz), rgz),
             "gw1": nm(be.host(gw1), rgw[:, :, :m1]),
             "gw2": nm(be.host(gw2), rgw[:, :, m1:]),
+            "fused_mix_adj": nm(be.host(fgz), rgz),
+            "fused_gw1": nm(be.host(fgw1), rgw[:, :, :m1]),
+            "fused_gw2": nm(be.host(fgw2), rgw[:, :, m1:]),
         }
     finally:
         api.plan_destroy(plan)
