@@ -75,6 +75,7 @@ def kernel_models(B, C, HW, L, M, head=128, co=2):
         "k_idft_add": dict(bytes=2 * N + Mb, flops=2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
         "k_idft_add_dgelu": dict(bytes=3 * N + Mb, flops=2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
         "k_spec_wgrad_part": dict(bytes=2 * Mb + Wb, flops=8 * B * C * C * M),
+        "k_mixadj_wgrad": dict(bytes=3 * Mb + 2 * Wb, flops=16 * B * C * C * M),  # adjoint mix + weight gradient, one launch
         "k_spec_wgrad_reduce": dict(bytes=2 * Wb, flops=0),
         "k_chan_wgrad": dict(bytes=2 * N, flops=2 * px * C * C),
         "k_chan_wgrad_stem": dict(bytes=N + px * 12, flops=2 * px * C * 10),
@@ -248,7 +249,7 @@ def main():
         alg = 5 * Nb + 3 * Wb
         gbs = alg / (us * 1e-6) / 1e9
         result["roofline_spectral_conv2d"] = dict(
-            what="SpectralConv2d fwd+bwd (dft, mix, idft | dft, wgrad, mix_adj, idft)", bound="hbm",
+            what="SpectralConv2d fwd+bwd (dft, mix, idft | dft, mix_adj + wgrad in one launch, reduce, idft)", bound="hbm",
             algorithmic_bytes=alg, avg_us=round(us, 2), achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
             frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None)
 
