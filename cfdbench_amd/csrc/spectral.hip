@@ -542,15 +542,14 @@ __global__ __launch_bounds__(64 * WPB) void k_mix(const float2* __restrict__ xin
 #pragma unroll 1
         for (int sb = 0; sb < SB; ++sb) {  // rolled: one batch entry's LDS reads live at a time
             const int base = sb * CR * 64 + lane;
-            float ar = 0.f, ai = 0.f;
+            cfd_f2 acc = {0.f, 0.f};  // same product order as k_mix_lds: results do not depend on which kernel ran
 #pragma unroll
             for (int cr = 0; cr < CR; ++cr) {
                 const float2 xv = xs[base + cr * 64];
-                ar = fmaf(xv.x, wreg[cr].x, fmaf(-xv.y, wreg[cr].y, ar));
-                ai = fmaf(xv.x, wreg[cr].y, fmaf(xv.y, wreg[cr].x, ai));
+                acc = cfd_cmla(acc, cfd_f2{xv.x, xv.y}, cfd_f2{wreg[cr].x, wreg[cr].y});
             }
             const int b = b0 + sb;
-            if (b < bend && czvalid && mvalid) z[((size_t)b * Cz + cz) * M + mode] = make_float2(ar, ai);
+            if (b < bend && czvalid && mvalid) z[((size_t)b * Cz + cz) * M + mode] = make_float2(acc.x, acc.y);
         }
         if (more) stg.commit(s_x + (buf ^ 1) * (SB * CR * 64), bend, Cr, b0 + SB, lane, wave);
         __syncthreads();
@@ -668,12 +667,16 @@ __global__ __launch_bounds__(512) void k_mix_lds(const float2* __restrict__ xin,
 }
 
 // Waves (= groups of 8 batch entries) per k_mix_lds workgroup: as many as keep >= 128 workgroups in the grid (the
-// weight fill is per workgroup).  CFD_MIX_NWV overrides it (tests, timing experiments).
+// weight fill is per workgroup); 0 = use the lane = mode kernel.  CFD_MIX_NWV overrides it (tests, timing experiments).
 static int cfd_mix_lds_waves(int B, int nmg) {
     if (const char* e = getenv("CFD_MIX_NWV")) {
         const int v = atoi(e);
-        if (v >= 1 && v <= 8) return v;
+        if (v >= 0 && v <= 8) return v;  // 0: use the lane = mode kernel
     }
+    // The weight fill + barrier cost k_mix_lds a fixed ~5 us that the lane = mode kernel does not pay; its per-entry cost
+    // is lower.  Measured cross-over (C = 20, profiles/r01i_mode_variants_small_batch.txt): B = 16: 5.6 vs 8.8 us,
+    // 64: 6.1 vs 9.0, 128: 9.6 vs 9.6, 256: 13.9 vs 12.3.
+    if (B < 192) return 0;
     for (int nwv = 8; nwv > 1; nwv >>= 1)
         if (nmg * ((B + 8 * nwv - 1) / (8 * nwv)) >= 128) return nwv;
     return 1;
@@ -684,7 +687,9 @@ static bool launch_mix_lds(const float2* xin, const float2* w1, const float2* w2
                            int CoutW, int m1, int m2, hipStream_t st) {
     if (Cr != 20 && Cr != 32) return false;  // the contracted channel count is a template parameter
     const int M = 2 * m1 * m2, nmg = (M + 7) / 8, npair = (nmg + 1) / 2;
-    const int nwv = cfd_mix_lds_waves(B, nmg), BC = 8 * nwv, nchunk = (B + BC - 1) / BC;
+    const int nwv = cfd_mix_lds_waves(B, nmg);
+    if (nwv < 1) return false;
+    const int BC = 8 * nwv, nchunk = (B + BC - 1) / BC;
     const unsigned grid = (unsigned)((npair * nchunk + 7) / 8) * 16u;
     const size_t lds = (size_t)Cz * Cr * 8 * sizeof(float2);
     if (Cr == 20)
@@ -987,12 +992,38 @@ __global__ __launch_bounds__(512) void k_mixadj_wgrad(const float2* __restrict__
     }
 }
 
+// Sum of the nchunk partial weight gradients of one (i, o, mode) element, scaled by c_l / HW, split into gw1 / gw2.
+__device__ __forceinline__ void spec_wgrad_reduce_one(const long gid, const float2* __restrict__ part,
+                                                      float2* __restrict__ gw1, float2* __restrict__ gw2,
+                                                      const float* __restrict__ clhw, int nchunk, int CC, int m1, int m2);
+
+// The same reduction as extra workgroups of another kernel's launch (k_idft64 below): nblk workgroups of 256 threads
+// stride over the CC * M outputs.  nblk == 0: nothing to do.
+struct SpecWgradTail {
+    const float2* part;
+    float2* gw1;
+    float2* gw2;
+    const float* clhw;
+    int nchunk, CC, m1, m2, nblk;
+};
+__device__ __forceinline__ void spec_wgrad_reduce_tail(const SpecWgradTail& t, int blk) {
+    const long total = (long)t.CC * 2 * t.m1 * t.m2;
+    for (long gid = (long)blk * blockDim.x + threadIdx.x; gid < total; gid += (long)t.nblk * blockDim.x)
+        spec_wgrad_reduce_one(gid, t.part, t.gw1, t.gw2, t.clhw, t.nchunk, t.CC, t.m1, t.m2);
+}
+
 __global__ __launch_bounds__(256) void k_spec_wgrad_reduce(const float2* __restrict__ part, float2* __restrict__ gw1,
                                                            float2* __restrict__ gw2, const float* __restrict__ clhw,
                                                            int nchunk, int CC, int m1, int m2) {
-    const int M = 2 * m1 * m2, half = m1 * m2;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long)CC * M) return;
+    if (gid >= (long)CC * 2 * m1 * m2) return;
+    spec_wgrad_reduce_one(gid, part, gw1, gw2, clhw, nchunk, CC, m1, m2);
+}
+
+__device__ __forceinline__ void spec_wgrad_reduce_one(const long gid, const float2* __restrict__ part,
+                                                      float2* __restrict__ gw1, float2* __restrict__ gw2,
+                                                      const float* __restrict__ clhw, int nchunk, int CC, int m1, int m2) {
+    const int M = 2 * m1 * m2, half = m1 * m2;
     const int mode = (int)(gid % M);
     const long io = gid / M;
     float ar = 0.f, ai = 0.f;
@@ -1088,9 +1119,12 @@ static void launch_mixadj_wgrad(const float2* xh, const float2* gh, const float2
     *nchunk_out = wg_nchunk;
 }
 
-extern "C" int cfd_spectral_mix_adj_wgrad(const cfd_plan* p, const float* xh, const float* gh, const float* w1,
-                                          const float* w2, float* gz, float* gw1, float* gw2, void* ws, int B, int Cin,
-                                          int Cout, void* stream) {
+// `defer` (may be NULL): where the fused kernel ran, leave the partial-sum reduction to the caller's next launch
+// (defer->nblk > 0 describes it); otherwise the reduction kernel is launched here and defer->nblk == 0.
+static int mix_adj_wgrad_impl(const cfd_plan* p, const float* xh, const float* gh, const float* w1, const float* w2,
+                              float* gz, float* gw1, float* gw2, void* ws, int B, int Cin, int Cout, void* stream,
+                              SpecWgradTail* defer) {
+    if (defer) defer->nblk = 0;
     CFD_REQUIRE(p && xh && gh && w1 && w2 && gz && gw1 && gw2 && ws, CFD_ERR_INVALID_ARG, "cfd_spectral_mix_adj_wgrad: NULL pointer");
     CFD_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1, CFD_ERR_INVALID_ARG, "cfd_spectral_mix_adj_wgrad: bad sizes");
     if (cfd_fused_disabled() || Cin != 20 || Cout != 20) {
@@ -1108,12 +1142,24 @@ extern "C" int cfd_spectral_mix_adj_wgrad(const cfd_plan* p, const float* xh, co
                                         (float2*)gz, (float2*)ws, B, p->m1, p->m2, &nchunk, st);
     }
     CFD_LAUNCH_CHECK("cfd_spectral_mix_adj_wgrad(fused)");
-    CFD_PROF("k_spec_wgrad_reduce", st);
     const long total = (long)Cin * Cout * M;
+    if (defer) {
+        const long nb = (total + 255) / 256;
+        *defer = SpecWgradTail{(const float2*)ws, (float2*)gw1, (float2*)gw2, (const float*)p->d_clhw, nchunk, Cin * Cout,
+                               p->m1, p->m2, (int)(nb < 256 ? nb : 256)};
+        return CFD_OK;
+    }
+    CFD_PROF("k_spec_wgrad_reduce", st);
     hipLaunchKernelGGL(k_spec_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float2*)ws,
                        (float2*)gw1, (float2*)gw2, (const float*)p->d_clhw, nchunk, Cin * Cout, p->m1, p->m2);
     CFD_LAUNCH_CHECK("cfd_spectral_mix_adj_wgrad(reduce)");
     return CFD_OK;
+}
+
+extern "C" int cfd_spectral_mix_adj_wgrad(const cfd_plan* p, const float* xh, const float* gh, const float* w1,
+                                          const float* w2, float* gz, float* gw1, float* gw2, void* ws, int B, int Cin,
+                                          int Cout, void* stream) {
+    return mix_adj_wgrad_impl(p, xh, gh, w1, w2, gz, gw1, gw2, ws, B, Cin, Cout, stream, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1308,19 +1354,28 @@ __global__ __launch_bounds__(64 * CFD_WAVES) void k_idft(const float* __restrict
 // Persistent variant for W == 64 (float4 rows) with the 12x12-mode table sizes: each wave strides over images, the next
 // image's kept modes are requested before the current image's 152 MFMAs and parked in the other LDS slice, and
 // the operator tables are loaded once per workgroup instead of once per four images.
-template <int EPI>
+// TAIL: the first tail.nblk workgroups of the launch do not transform anything -- they sum the partial spectral weight
+// gradients of the preceding launch (spec_wgrad_reduce_tail).  That reduction is a ~0.5-us job which as a kernel of
+// its own costs the ~4.5-us dispatch floor plus a launch gap; here it rides in front of the resident transform waves.
+template <int EPI, bool TAIL>
 __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __restrict__ z, const float* addend,
                                                                const float* __restrict__ aprev, float* out,
                                                                const bf16x8* __restrict__ tabs3, int nimg,
-                                                               int H, int m1, int m2, int T, int SA, int SB) {
+                                                               int H, int m1, int m2, int T, int SA, int SB,
+                                                               const SpecWgradTail tail) {
     constexpr int W = 64, NJ = 4;
     __shared__ bf16x8 s_tab3[CFD_B3_TABV];               // split-bf16 tables, T <= 4
     __shared__ float s_z[CFD_WAVES * 2 * CFD_BLK_ZS];    // two slices per wave
+    const int nskip = TAIL ? tail.nblk : 0;
+    if (TAIL && (int)blockIdx.x < nskip) {
+        spec_wgrad_reduce_tail(tail, blockIdx.x);
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
     const int M2 = 4 * m1 * m2;
-    const int stride = gridDim.x * CFD_WAVES;
-    int img = blockIdx.x * CFD_WAVES + wave;
+    const int stride = (gridDim.x - nskip) * CFD_WAVES;
+    int img = (blockIdx.x - nskip) * CFD_WAVES + wave;
     float* zs0 = s_z + wave * 2 * CFD_BLK_ZS;
     constexpr int ZR = (CFD_BLK_ZS - 1 + 63) / 64;  // dwords per lane of one mode vector
     float zr[ZR];
@@ -1382,18 +1437,29 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __res
     }
 }
 
+static bool idft64_applies(const cfd_plan* p) {
+    return p->W == 64 && p->H % 16 == 0 && p->d_inv_b3 && 4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS;
+}
+
+// `tail` (may be NULL): a partial-sum reduction to run as extra workgroups of this launch; only the 64-wide kernel with
+// epi == 0 takes it (callers check idft64_applies and the alignment first).
 template <int NJ, bool VEC4>
 static int launch_idft(const cfd_plan* p, const float* z, const float* addend, const float* aprev, float* out,
-                       int nimg, int epi, hipStream_t st) {
+                       int nimg, int epi, hipStream_t st, const SpecWgradTail* tail = nullptr) {
     int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
     if constexpr (VEC4) {
-        if (p->W == 64 && p->H % 16 == 0 && p->d_inv_b3 && 4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS) {
+        if (idft64_applies(p)) {
             if (blocks > CFD_DFT_CAP) blocks = CFD_DFT_CAP;  // resident workgroups; waves stride over the images
+            SpecWgradTail none{};
 #define CFD_IDFT64(E)                                                                                              \
-    hipLaunchKernelGGL((k_idft64<E>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, z, addend, aprev, out,             \
-                       (const bf16x8*)p->d_inv_b3, nimg, p->H, p->m1, p->m2, p->T, p->SA, p->SB)
+    hipLaunchKernelGGL((k_idft64<E, false>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, z, addend, aprev, out,      \
+                       (const bf16x8*)p->d_inv_b3, nimg, p->H, p->m1, p->m2, p->T, p->SA, p->SB, none)
             CFD_PROF(epi == 0 ? "k_idft" : (epi == 1 ? "k_idft_add" : "k_idft_add_dgelu"), st);
-            if (epi == 0) CFD_IDFT64(0);
+            if (epi == 0 && tail && tail->nblk > 0)
+                hipLaunchKernelGGL((k_idft64<0, true>), dim3(blocks + tail->nblk), dim3(64 * CFD_WAVES), 0, st, z, addend,
+                                   aprev, out, (const bf16x8*)p->d_inv_b3, nimg, p->H, p->m1, p->m2, p->T, p->SA, p->SB,
+                                   *tail);
+            else if (epi == 0) CFD_IDFT64(0);
             else if (epi == 1) CFD_IDFT64(1);
             else CFD_IDFT64(2);
 #undef CFD_IDFT64
@@ -1465,14 +1531,21 @@ extern "C" int cfd_spectral_conv2d_bwd(const cfd_plan* p, const float* gy, const
     float* gz = (float*)(base + cfd_align_up((size_t)B * Cout * M * 8, 256));
     void* wws = base + cfd_align_up((size_t)B * Cout * M * 8, 256) + cfd_align_up((size_t)B * Cin * M * 8, 256);
     CFD_TRY(cfd_spectral_dft(p, gy, gh, B * Cout, 0, stream));
+    SpecWgradTail tail{};
     if (gw1 && gx) {
-        CFD_TRY(cfd_spectral_mix_adj_wgrad(p, xh, gh, w1, w2, gz, gw1, gw2, wws, B, Cin, Cout, stream));
+        // the partial-sum reduction of the weight gradient rides in the inverse transform's launch where that is the
+        // 64-wide kernel (one launch less on the critical path)
+        const bool ride = idft64_applies(p) && p->NJ == 4 && ((uintptr_t)gx % 16) == 0;
+        CFD_TRY(mix_adj_wgrad_impl(p, xh, gh, w1, w2, gz, gw1, gw2, wws, B, Cin, Cout, stream, ride ? &tail : nullptr));
     } else if (gw1) {
         CFD_TRY(cfd_spectral_wgrad(p, xh, gh, gw1, gw2, wws, B, Cin, Cout, stream));
     } else if (gx) {
         CFD_TRY(cfd_spectral_mix(p, gh, w1, w2, gz, B, Cin, Cout, 1, stream));
     }
-    if (gx) CFD_TRY(cfd_spectral_idft(p, gz, nullptr, nullptr, gx, B * Cin, 0, stream));
+    if (gx) {
+        if (tail.nblk > 0) CFD_TRY((launch_idft<4, true>(p, gz, nullptr, nullptr, gx, B * Cin, 0, (hipStream_t)stream, &tail)));
+        else CFD_TRY(cfd_spectral_idft(p, gz, nullptr, nullptr, gx, B * Cin, 0, stream));
+    }
     return CFD_OK;
 }
 

@@ -28,19 +28,24 @@ def test_spectral_fwd_bwd(be, H, W):
     _assert_all(K.check_spectral(be, 2, 3, 5, H, W))
 
 
+def test_spectral_fwd_bwd_fused_route(be):
+    """C = 20 at 64 x 64: adjoint mix + weight gradient in one launch, their reduction riding in the inverse transform's."""
+    _assert_all(K.check_spectral(be, 1, 20, 20, 64, 64))
+
+
 @pytest.mark.parametrize("B,Cin,Cout", [(3, 20, 20), (9, 12, 7), (2, 24, 24), (5, 32, 32), (10, 5, 20)])
 def test_mix_and_spectral_wgrad(be, B, Cin, Cout):
     _assert_all(K.check_mix_wgrad(be, B, Cin, Cout))
 
 
-@pytest.mark.parametrize("want_wg,nwv", [("36", "2"), ("80", "8")])
-def test_mix_and_spectral_wgrad_multi_step(be, want_wg, nwv, monkeypatch):
+@pytest.mark.parametrize("want_wg,nwv,B,C", [("36", "2", 27, 20), ("80", "8", 27, 20), ("256", "1", 5, 32)])
+def test_mix_and_spectral_wgrad_multi_step(be, want_wg, nwv, B, C, monkeypatch):
     """The batch-in-lanes kernels (k_mix_lds, k_spec_wgrad_tile, the fused k_mixadj_wgrad) at chunk sizes that reach
     the software-pipelined loops of the weight gradient (several 8-entry steps per workgroup, ragged last step) and
     several workgroup shapes of the mixing kernel, with a small batch."""
     monkeypatch.setenv("CFD_MIX_NWV", nwv)
     monkeypatch.setenv("CFD_WGRAD_WG", want_wg)
-    _assert_all(K.check_mix_wgrad(be, 27, 20, 20))
+    _assert_all(K.check_mix_wgrad(be, B, C, C))
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 20, 20, 64, 64), (1, 6, 7, 32, 64), (1, 3, 5, 66, 65), (1, 32, 12, 32, 64)])

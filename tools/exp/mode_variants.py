@@ -15,14 +15,13 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from cfdbench_amd import _lib  # noqa: E402
 
 CONFIGS = [
-    ("old lane=mode kernels", dict(CFD_MIX_VARIANT="0", CFD_WGRAD_VARIANT="0", CFD_FUSED_VARIANT="0")),
-    ("unfused: mix lds nwv8, wgrad 5x10 ns2", dict(CFD_FUSED_VARIANT="0", CFD_MIX_NWV="8", CFD_WGRAD_VARIANT="1")),
-    ("fused 5x10 ns2", dict(CFD_MIX_NWV="8")),
-    ("fused 5x5 ns3 split2", dict(CFD_MIX_NWV="8", CFD_FUSED_VARIANT="2")),
-    ("fused 5x10 ns4", dict(CFD_MIX_NWV="8", CFD_FUSED_VARIANT="3")),
-    ("fused 5x10 ns2, 6 chunks", dict(CFD_MIX_NWV="8", CFD_WGRAD_WG="216")),
-    ("fused 5x5 ns3, 5 chunks", dict(CFD_MIX_NWV="8", CFD_FUSED_VARIANT="2", CFD_WGRAD_WG="180")),
-    ("fused 5x5 ns3, 6 chunks", dict(CFD_MIX_NWV="8", CFD_FUSED_VARIANT="2", CFD_WGRAD_WG="216")),
+    ("lane=mode mix, unfused", dict(CFD_MIX_NWV="0", CFD_FUSED_VARIANT="0")),
+    ("default", dict()),
+    ("mix lds nwv1", dict(CFD_MIX_NWV="1")),
+    ("mix lds nwv2", dict(CFD_MIX_NWV="2")),
+    ("mix lds nwv4", dict(CFD_MIX_NWV="4")),
+    ("mix lds nwv8", dict(CFD_MIX_NWV="8")),
+    ("unfused", dict(CFD_FUSED_VARIANT="0")),
 ]
 KEYS = ("CFD_MIX_VARIANT", "CFD_WGRAD_VARIANT", "CFD_MIX_WG", "CFD_WGRAD_WG", "CFD_MIX_NWV", "CFD_FUSED_VARIANT")
 
