@@ -5,6 +5,7 @@
 // h_l = gelu(a_l) for l >= 1); consumers apply GELU on load (act_in=1) so every activation crosses HBM once per
 // producer/consumer instead of once more for a standalone GELU pass, and the backward pass reads the same buffers.
 #include "cfd_common.h"
+#include "cfd_tail.h"
 
 namespace {
 
@@ -36,8 +37,10 @@ Layout make_layout(const cfd_plan* p, const cfd_fno_shape* s, int training) {
         L.off_gA = take(L.n_act * sizeof(float));
         L.off_gB = take(L.n_act * sizeof(float));
         L.off_gh = take(L.n_modes * sizeof(float));
-        scratch = max2(scratch, cfd_spectral_wgrad_workspace_bytes(p, B, C, C));
-        scratch = max2(scratch, cfd_chan_wgrad_workspace_bytes(B, C, C, (int)HW));
+        // both weight-gradient partial buffers of a block are alive until the block's input-gradient kernel has reduced
+        // them (cfd_tail.h): spectral partials first, the 1x1-conv partials behind them
+        scratch = max2(scratch, cfd_align_up(cfd_spectral_wgrad_workspace_bytes(p, B, C, C), 256) +
+                                    cfd_chan_wgrad_workspace_bytes(B, C, C, (int)HW));
         scratch = max2(scratch, cfd_fno_stem_bwd_workspace_bytes(p, B, s->in_chan, s->n_case_params, C));
     }
     L.scratch_bytes = scratch;
@@ -127,10 +130,15 @@ extern "C" int cfd_fno_backward_phase(const cfd_plan* p, const cfd_fno_shape* s,
     const int act = l > 0;
     // gcur = d loss / d a_{l+1}
     CFD_TRY(cfd_spectral_dft(p, gcur, gh, B * C, 0, stream));
-    CFD_TRY(cfd_spectral_mix_adj_wgrad(p, xh_buf(l), gh, prm->spec_w1[l], prm->spec_w2[l], z, g->spec_w1[l], g->spec_w2[l],
-                                       scratch, B, C, C, stream));
-    CFD_TRY(cfd_chan_wgrad(gcur, act_buf(l), g->w0_w[l], g->w0_b[l], scratch, B, C, C, HW, act, stream));
-    return cfd_fno_block_bwd_input(p, gcur, z, prm->w0_w[l], act ? act_buf(l) : nullptr, gnext, B, C, C, stream);
+    // the reductions of both weight gradients ride in front of the input-gradient kernel's launch (cfd_tail.h); whatever
+    // a producer could not defer it has already reduced itself
+    CfdReduceTail tail{};
+    char* scratch2 = (char*)scratch + cfd_align_up(cfd_spectral_wgrad_workspace_bytes(p, B, C, C), 256);
+    CFD_TRY(cfd_int_spectral_mix_adj_wgrad(p, xh_buf(l), gh, prm->spec_w1[l], prm->spec_w2[l], z, g->spec_w1[l],
+                                           g->spec_w2[l], scratch, B, C, C, stream, &tail.spec));
+    CFD_TRY(cfd_int_chan_wgrad(gcur, act_buf(l), g->w0_w[l], g->w0_b[l], scratch2, B, C, C, HW, act, stream, &tail.chan));
+    tail.nblk = (tail.spec.part || tail.chan.part) ? 128 : 0;
+    return cfd_int_fno_block_bwd_input(p, gcur, z, prm->w0_w[l], act ? act_buf(l) : nullptr, gnext, B, C, C, stream, &tail);
 }
 
 extern "C" int cfd_fno_backward(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm,

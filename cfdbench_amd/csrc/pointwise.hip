@@ -4,6 +4,7 @@
 //   MseLoss                   src/models/loss.py:22-37             -> k_loss_part / k_loss_final
 //   torch.optim.Adam          src/train_auto.py:213,256            -> k_adam
 #include "cfd_common.h"
+#include "cfd_tail.h"
 
 // ------------------------------------------------------------------------------------------------------
 // stem: [u, v, mask, grid_x, grid_y, props...] -> fc0
@@ -345,16 +346,9 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
 // order (lane-strided float4 chunks, then a shuffle tree), so the result is deterministic.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int nblk, float* __restrict__ gw,
                                                       float* __restrict__ gb, int Co, int Ci) {
-    const int NW = Ci + 1;
-    const int lane = threadIdx.x & 63;
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (e >= Co * NW) return;  // whole wave exits together
-    const float s = cfd_row_sum(part + (size_t)e * nblk, nblk, lane);
-    if (lane == 0) {
-        const int o = e / NW, i = e - o * NW;
-        if (i < Ci) gw[o * Ci + i] = s;
-        else if (gb) gb[o] = s;
-    }
+    if (e >= Co * (Ci + 1)) return;  // whole wave exits together
+    chan_wgrad_reduce_one(e, threadIdx.x & 63, part, nblk, gw, gb, Co, Ci);
 }
 
 static int wgrad_blocks(int B, int HW) {
@@ -370,9 +364,10 @@ extern "C" size_t cfd_chan_wgrad_workspace_bytes(int B, int Ci, int Co, int HW) 
     return (size_t)wgrad_blocks(B, HW) * Co * (Ci + 1) * sizeof(float);
 }
 
+// `defer` (may be NULL): leave the partial-sum reduction to a later launch (cfd_tail.h) instead of launching it here
 template <bool STEM>
 static int launch_wgrad(const float* g, const float* in, StemSrc ss, float* gw, float* gb, void* ws, int B, int Ci,
-                        int Co, int HW, int act, hipStream_t st) {
+                        int Co, int HW, int act, hipStream_t st, ChanWgradTail* defer = nullptr) {
     const int blocks = wgrad_blocks(B, HW);
     const int MT = (Co + 15) / 16, NT = (Ci + 1 + 15) / 16;
     const bool v4 = HW % 4 == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)in % 16) == 0;
@@ -403,6 +398,10 @@ static int launch_wgrad(const float* g, const float* in, StemSrc ss, float* gw, 
 #undef CFD_WG_VA
 #undef CFD_WG
     CFD_LAUNCH_CHECK("cfd_chan_wgrad");
+    if (defer) {
+        *defer = ChanWgradTail{(const float*)part, gw, gb, blocks, Co, Ci};
+        return CFD_OK;
+    }
     CFD_PROF("k_wgrad_reduce", st);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((Co * (Ci + 1) + 3) / 4), dim3(256), 0, st, (const float*)part, blocks,
                        gw, gb, Co, Ci);
@@ -417,6 +416,16 @@ extern "C" int cfd_chan_wgrad(const float* g, const float* in, float* gw, float*
     CFD_REQUIRE(Ci <= 32 && Co <= 32, CFD_ERR_UNSUPPORTED, "cfd_chan_wgrad: Ci=%d Co=%d (max 32) unsupported", Ci, Co);
     StemSrc ss{};
     return launch_wgrad<false>(g, in, ss, gw, gb, ws, B, Ci, Co, HW, act_in, (hipStream_t)stream);
+}
+
+int cfd_int_chan_wgrad(const float* g, const float* in, float* gw, float* gb, void* ws, int B, int Ci, int Co, int HW,
+                       int act_in, void* stream, ChanWgradTail* defer) {
+    if (defer) defer->part = nullptr;
+    CFD_REQUIRE(g && in && gw && ws, CFD_ERR_INVALID_ARG, "cfd_chan_wgrad: NULL pointer");
+    CFD_REQUIRE(B >= 1 && Ci >= 1 && Co >= 1 && HW >= 1, CFD_ERR_INVALID_ARG, "cfd_chan_wgrad: bad sizes");
+    CFD_REQUIRE(Ci <= 32 && Co <= 32, CFD_ERR_UNSUPPORTED, "cfd_chan_wgrad: Ci=%d Co=%d (max 32) unsupported", Ci, Co);
+    StemSrc ss{};
+    return launch_wgrad<false>(g, in, ss, gw, gb, ws, B, Ci, Co, HW, act_in, (hipStream_t)stream, defer);
 }
 
 extern "C" size_t cfd_fno_stem_bwd_workspace_bytes(const cfd_plan* p, int B, int in_chan, int P, int C) {

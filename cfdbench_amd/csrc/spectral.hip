@@ -19,6 +19,7 @@
 //   stage A:    U_re[x][l] = sum_kap S_re cos(th) - D_im sin(th);  U_im[x][l] = sum_kap S_im cos(th) + D_re sin(th)
 //   stage B:    y[x][y] = sum_l (c_l/HW) (U_re cos(2pi l y/W) - U_im sin(2pi l y/W))
 #include "cfd_common.h"
+#include "cfd_tail.h"
 
 #ifndef CFD_EXP
 #define CFD_EXP 0  // dev timing switches: k_block 1 skips the inverse transform, 2 the channel mix, 4 the input GELU;
@@ -644,7 +645,7 @@ __device__ __forceinline__ void mix_lds_body(float4* s_w, const int L, const flo
     __syncthreads();
     const bool ok = b < B && b < chunk * BC + BC && mode < M;
     float2* zr = z + (size_t)(bc * (unsigned)Cz) * M + mode;
-#pragma unroll 2
+#pragma unroll 1
     for (int cz = 0; cz < Cz; ++cz) {
         const float4* wr = s_w + (cz * (CR / 2)) * 8 + m;
         cfd_f2 acc = {0.f, 0.f};
@@ -992,24 +993,11 @@ __global__ __launch_bounds__(512) void k_mixadj_wgrad(const float2* __restrict__
     }
 }
 
-// Sum of the nchunk partial weight gradients of one (i, o, mode) element, scaled by c_l / HW, split into gw1 / gw2.
-__device__ __forceinline__ void spec_wgrad_reduce_one(const long gid, const float2* __restrict__ part,
-                                                      float2* __restrict__ gw1, float2* __restrict__ gw2,
-                                                      const float* __restrict__ clhw, int nchunk, int CC, int m1, int m2);
-
-// The same reduction as extra workgroups of another kernel's launch (k_idft64 below): nblk workgroups of 256 threads
-// stride over the CC * M outputs.  nblk == 0: nothing to do.
-struct SpecWgradTail {
-    const float2* part;
-    float2* gw1;
-    float2* gw2;
-    const float* clhw;
-    int nchunk, CC, m1, m2, nblk;
-};
-__device__ __forceinline__ void spec_wgrad_reduce_tail(const SpecWgradTail& t, int blk) {
-    const long total = (long)t.CC * 2 * t.m1 * t.m2;
-    for (long gid = (long)blk * blockDim.x + threadIdx.x; gid < total; gid += (long)t.nblk * blockDim.x)
-        spec_wgrad_reduce_one(gid, t.part, t.gw1, t.gw2, t.clhw, t.nchunk, t.CC, t.m1, t.m2);
+// the 1x1-conv reduction as a kernel of its own (only where a deferred one cannot ride, see cfd_int_fno_block_bwd_input)
+__global__ __launch_bounds__(256) void k_chan_reduce_standalone(const ChanWgradTail t) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= t.Co * (t.Ci + 1)) return;
+    chan_wgrad_reduce_one(e, threadIdx.x & 63, t.part, t.nrow, t.gw, t.gb, t.Co, t.Ci);
 }
 
 __global__ __launch_bounds__(256) void k_spec_wgrad_reduce(const float2* __restrict__ part, float2* __restrict__ gw1,
@@ -1018,27 +1006,6 @@ __global__ __launch_bounds__(256) void k_spec_wgrad_reduce(const float2* __restr
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)CC * 2 * m1 * m2) return;
     spec_wgrad_reduce_one(gid, part, gw1, gw2, clhw, nchunk, CC, m1, m2);
-}
-
-__device__ __forceinline__ void spec_wgrad_reduce_one(const long gid, const float2* __restrict__ part,
-                                                      float2* __restrict__ gw1, float2* __restrict__ gw2,
-                                                      const float* __restrict__ clhw, int nchunk, int CC, int m1, int m2) {
-    const int M = 2 * m1 * m2, half = m1 * m2;
-    const int mode = (int)(gid % M);
-    const long io = gid / M;
-    float ar = 0.f, ai = 0.f;
-    for (int c = 0; c < nchunk; c += 8) {  // 8 independent loads in flight (clamped past the end), fixed summation order
-        float2 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = part[(size_t)(c + k < nchunk ? c + k : nchunk - 1) * CC * M + gid];
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (c + k < nchunk) { ar += v[k].x; ai += v[k].y; }
-    }
-    const float sc = clhw[mode % m2];
-    const float2 r = make_float2(ar * sc, ai * sc);
-    if (mode < half) gw1[io * half + mode] = r;
-    else gw2[io * half + (mode - half)] = r;
 }
 
 extern "C" size_t cfd_spectral_wgrad_workspace_bytes(const cfd_plan* p, int B, int Cin, int Cout) {
@@ -1120,11 +1087,11 @@ static void launch_mixadj_wgrad(const float2* xh, const float2* gh, const float2
 }
 
 // `defer` (may be NULL): where the fused kernel ran, leave the partial-sum reduction to the caller's next launch
-// (defer->nblk > 0 describes it); otherwise the reduction kernel is launched here and defer->nblk == 0.
-static int mix_adj_wgrad_impl(const cfd_plan* p, const float* xh, const float* gh, const float* w1, const float* w2,
+// (defer->part != NULL describes it, cfd_tail.h); otherwise the reduction kernel is launched here and defer->part == NULL.
+int cfd_int_spectral_mix_adj_wgrad(const cfd_plan* p, const float* xh, const float* gh, const float* w1, const float* w2,
                               float* gz, float* gw1, float* gw2, void* ws, int B, int Cin, int Cout, void* stream,
                               SpecWgradTail* defer) {
-    if (defer) defer->nblk = 0;
+    if (defer) defer->part = nullptr;
     CFD_REQUIRE(p && xh && gh && w1 && w2 && gz && gw1 && gw2 && ws, CFD_ERR_INVALID_ARG, "cfd_spectral_mix_adj_wgrad: NULL pointer");
     CFD_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1, CFD_ERR_INVALID_ARG, "cfd_spectral_mix_adj_wgrad: bad sizes");
     if (cfd_fused_disabled() || Cin != 20 || Cout != 20) {
@@ -1144,9 +1111,8 @@ static int mix_adj_wgrad_impl(const cfd_plan* p, const float* xh, const float* g
     CFD_LAUNCH_CHECK("cfd_spectral_mix_adj_wgrad(fused)");
     const long total = (long)Cin * Cout * M;
     if (defer) {
-        const long nb = (total + 255) / 256;
         *defer = SpecWgradTail{(const float2*)ws, (float2*)gw1, (float2*)gw2, (const float*)p->d_clhw, nchunk, Cin * Cout,
-                               p->m1, p->m2, (int)(nb < 256 ? nb : 256)};
+                               p->m1, p->m2};
         return CFD_OK;
     }
     CFD_PROF("k_spec_wgrad_reduce", st);
@@ -1159,7 +1125,7 @@ static int mix_adj_wgrad_impl(const cfd_plan* p, const float* xh, const float* g
 extern "C" int cfd_spectral_mix_adj_wgrad(const cfd_plan* p, const float* xh, const float* gh, const float* w1,
                                           const float* w2, float* gz, float* gw1, float* gw2, void* ws, int B, int Cin,
                                           int Cout, void* stream) {
-    return mix_adj_wgrad_impl(p, xh, gh, w1, w2, gz, gw1, gw2, ws, B, Cin, Cout, stream, nullptr);
+    return cfd_int_spectral_mix_adj_wgrad(p, xh, gh, w1, w2, gz, gw1, gw2, ws, B, Cin, Cout, stream, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1355,20 +1321,20 @@ __global__ __launch_bounds__(64 * CFD_WAVES) void k_idft(const float* __restrict
 // image's kept modes are requested before the current image's 152 MFMAs and parked in the other LDS slice, and
 // the operator tables are loaded once per workgroup instead of once per four images.
 // TAIL: the first tail.nblk workgroups of the launch do not transform anything -- they sum the partial spectral weight
-// gradients of the preceding launch (spec_wgrad_reduce_tail).  That reduction is a ~0.5-us job which as a kernel of
-// its own costs the ~4.5-us dispatch floor plus a launch gap; here it rides in front of the resident transform waves.
+// gradients of the preceding launch (cfd_reduce_tail, cfd_tail.h).  That reduction is a ~0.5-us job which as a kernel
+// of its own costs the ~4.5-us dispatch floor plus a launch gap; here it rides in front of the resident transform waves.
 template <int EPI, bool TAIL>
 __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __restrict__ z, const float* addend,
                                                                const float* __restrict__ aprev, float* out,
                                                                const bf16x8* __restrict__ tabs3, int nimg,
                                                                int H, int m1, int m2, int T, int SA, int SB,
-                                                               const SpecWgradTail tail) {
+                                                               const CfdReduceTail tail) {
     constexpr int W = 64, NJ = 4;
     __shared__ bf16x8 s_tab3[CFD_B3_TABV];               // split-bf16 tables, T <= 4
     __shared__ float s_z[CFD_WAVES * 2 * CFD_BLK_ZS];    // two slices per wave
     const int nskip = TAIL ? tail.nblk : 0;
     if (TAIL && (int)blockIdx.x < nskip) {
-        spec_wgrad_reduce_tail(tail, blockIdx.x);
+        cfd_reduce_tail(tail, blockIdx.x);
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1445,12 +1411,12 @@ static bool idft64_applies(const cfd_plan* p) {
 // epi == 0 takes it (callers check idft64_applies and the alignment first).
 template <int NJ, bool VEC4>
 static int launch_idft(const cfd_plan* p, const float* z, const float* addend, const float* aprev, float* out,
-                       int nimg, int epi, hipStream_t st, const SpecWgradTail* tail = nullptr) {
+                       int nimg, int epi, hipStream_t st, const CfdReduceTail* tail = nullptr) {
     int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
     if constexpr (VEC4) {
         if (idft64_applies(p)) {
             if (blocks > CFD_DFT_CAP) blocks = CFD_DFT_CAP;  // resident workgroups; waves stride over the images
-            SpecWgradTail none{};
+            CfdReduceTail none{};
 #define CFD_IDFT64(E)                                                                                              \
     hipLaunchKernelGGL((k_idft64<E, false>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, z, addend, aprev, out,      \
                        (const bf16x8*)p->d_inv_b3, nimg, p->H, p->m1, p->m2, p->T, p->SA, p->SB, none)
@@ -1531,12 +1497,17 @@ extern "C" int cfd_spectral_conv2d_bwd(const cfd_plan* p, const float* gy, const
     float* gz = (float*)(base + cfd_align_up((size_t)B * Cout * M * 8, 256));
     void* wws = base + cfd_align_up((size_t)B * Cout * M * 8, 256) + cfd_align_up((size_t)B * Cin * M * 8, 256);
     CFD_TRY(cfd_spectral_dft(p, gy, gh, B * Cout, 0, stream));
-    SpecWgradTail tail{};
+    CfdReduceTail tail{};
     if (gw1 && gx) {
         // the partial-sum reduction of the weight gradient rides in the inverse transform's launch where that is the
         // 64-wide kernel (one launch less on the critical path)
         const bool ride = idft64_applies(p) && p->NJ == 4 && ((uintptr_t)gx % 16) == 0;
-        CFD_TRY(mix_adj_wgrad_impl(p, xh, gh, w1, w2, gz, gw1, gw2, wws, B, Cin, Cout, stream, ride ? &tail : nullptr));
+        CFD_TRY(cfd_int_spectral_mix_adj_wgrad(p, xh, gh, w1, w2, gz, gw1, gw2, wws, B, Cin, Cout, stream,
+                                               ride ? &tail.spec : nullptr));
+        if (tail.spec.part) {
+            const long nb = ((long)Cin * Cout * M + 255) / 256;
+            tail.nblk = (int)(nb < 256 ? nb : 256);
+        }
     } else if (gw1) {
         CFD_TRY(cfd_spectral_wgrad(p, xh, gh, gw1, gw2, wws, B, Cin, Cout, stream));
     } else if (gx) {
@@ -1564,12 +1535,18 @@ extern "C" int cfd_spectral_conv2d_bwd(const cfd_plan* p, const float* gy, const
 
 // NW waves; wave w owns destination channels w, w+NW, ... (DPW of them) and fetches channel w of each of the NCH
 // source chunks.  NW = 4 (one wave per SIMD) wherever the channel count allows.
-template <int NW, int DPW, int NCH, bool ACT, bool TRANS, bool DGELU>
+// TAIL (backward only): the first tail.nblk workgroups of the launch run the reductions of this FnoBlock's two weight
+// gradients (cfd_tail.h) instead of a batch entry -- two kernel launches less per block and backward pass.
+template <int NW, int DPW, int NCH, bool ACT, bool TRANS, bool DGELU, bool TAIL>
 __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src, const float* __restrict__ z,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
                                                    const float* __restrict__ aprev, float* __restrict__ dst,
                                                    const bf16x8* __restrict__ tabs3, int Cs, int Cd, int H, int m1,
-                                                   int m2, int T, int SA, int SB) {
+                                                   int m2, int T, int SA, int SB, const CfdReduceTail tail) {
+    if (TAIL && (int)blockIdx.x < tail.nblk) {
+        cfd_reduce_tail(tail, blockIdx.x);
+        return;
+    }
     constexpr int W = 64, NJ = 4;
     constexpr int WS = DPW <= 4 ? 4 : 8;              // floats per weight-table entry
     __shared__ float4 s_src[2 * NW * 16 * 16];        // [buf][channel in chunk][row][float4 column]
@@ -1581,7 +1558,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     const int lane = threadIdx.x & 63;
     const int wave = cfd_uniform(threadIdx.x >> 6);
     const int q = lane >> 4, n = lane & 15;
-    const int b = blockIdx.x;
+    const int b = TAIL ? (int)blockIdx.x - tail.nblk : (int)blockIdx.x;
     const int HW = H * W;
     const int M2 = 4 * m1 * m2;
     const int G = T * NCH;  // chunks of this batch entry, streamed tile after tile; chunk g lives in buffer g & 1
@@ -1753,28 +1730,31 @@ static bool block_fused_ok(const cfd_plan* p, int Cs, int Cd, const void* a, con
 template <int NW, int DPW, int NCH>
 static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z, const float* w, const float* bias,
                              const float* aprev, float* dst, int B, int Cs, int Cd, int act, int trans, int dgelu,
-                             hipStream_t st) {
-    const dim3 grid(B), block(64 * NW);  // one workgroup per batch entry, tiles streamed inside
-#define CFD_BLK(A_, T_, D_)                                                                                     \
-    hipLaunchKernelGGL((k_block<NW, DPW, NCH, A_, T_, D_>), grid, block, 0, st, src, z, w, bias, aprev, dst,    \
-                       (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB)
-    if (!trans) { if (act) CFD_BLK(true, false, false); else CFD_BLK(false, false, false); }
-    else { if (dgelu) CFD_BLK(false, true, true); else CFD_BLK(false, true, false); }
+                             hipStream_t st, const CfdReduceTail* tail) {
+    const bool ride = trans && tail && tail->nblk > 0;
+    const CfdReduceTail tl = ride ? *tail : CfdReduceTail{};
+    const dim3 grid(B + tl.nblk), block(64 * NW);  // one workgroup per batch entry, tiles streamed inside
+#define CFD_BLK(A_, T_, D_, R_)                                                                                  \
+    hipLaunchKernelGGL((k_block<NW, DPW, NCH, A_, T_, D_, R_>), grid, block, 0, st, src, z, w, bias, aprev, dst, \
+                       (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB, tl)
+    if (!trans) { if (act) CFD_BLK(true, false, false, false); else CFD_BLK(false, false, false, false); }
+    else if (ride) { if (dgelu) CFD_BLK(false, true, true, true); else CFD_BLK(false, true, false, true); }
+    else { if (dgelu) CFD_BLK(false, true, true, false); else CFD_BLK(false, true, false, false); }
 #undef CFD_BLK
 }
 
 // (waves, destination channels per wave, source chunks): waves*DPW >= Cd and waves*NCH >= Cs
 static void launch_block(const cfd_plan* p, const float* src, const float* z, const float* w, const float* bias,
                          const float* aprev, float* dst, int B, int Cs, int Cd, int act, int trans, int dgelu,
-                         hipStream_t st) {
+                         hipStream_t st, const CfdReduceTail* tail = nullptr) {
     const int cmax = Cs > Cd ? Cs : Cd;
-    if (cmax <= 8) launch_block_cfg<4, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st);
-    else if (cmax <= 16) launch_block_cfg<4, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st);
+    if (cmax <= 8) launch_block_cfg<4, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
+    else if (cmax <= 16) launch_block_cfg<4, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
     else if (cmax <= 20) {  // measured at B=256, C=20 (us): (10,2,2) 61/73/60/97, (5,4,4) 69/79/67/82, (4,5,5) 77/84/74/83
-        if (dgelu) launch_block_cfg<5, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st);
-        else launch_block_cfg<10, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st);
+        if (dgelu) launch_block_cfg<5, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
+        else launch_block_cfg<10, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
     }
-    else launch_block_cfg<8, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st);
+    else launch_block_cfg<8, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
 }
 
 // out[b,o] = bias[o] + sum_i w0[o,i] f(a[b,i]) + idft(z[b,o])                       (FnoBlock.forward minus its GELU)
@@ -1796,19 +1776,47 @@ extern "C" int cfd_fno_block_fwd(const cfd_plan* p, const float* a, const float*
 }
 
 // gin[b,i] = (sum_o w0[o,i] g[b,o] + idft(gz[b,i])) * (aprev ? gelu'(aprev[b,i]) : 1)      (input gradient of the block)
-extern "C" int cfd_fno_block_bwd_input(const cfd_plan* p, const float* g, const float* gz, const float* w0,
-                                       const float* aprev, float* gin, int B, int Cin, int Cout, void* stream) {
+// `tail` (may be NULL): reductions to carry in this launch.  Where the fused kernel does not apply (general grids) or
+// the batch is empty they are launched as the kernels they replace, so the caller's gradients are final on return
+// either way.
+static int launch_reduce_tail_standalone(const CfdReduceTail* tail, hipStream_t st) {
+    if (!tail || tail->nblk <= 0) return CFD_OK;
+    if (tail->spec.part) {
+        const long total = (long)tail->spec.CC * 2 * tail->spec.m1 * tail->spec.m2;
+        CFD_PROF("k_spec_wgrad_reduce", st);
+        hipLaunchKernelGGL(k_spec_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tail->spec.part,
+                           tail->spec.gw1, tail->spec.gw2, tail->spec.clhw, tail->spec.nchunk, tail->spec.CC, tail->spec.m1,
+                           tail->spec.m2);
+        CFD_LAUNCH_CHECK("cfd_fno_block_bwd_input(spectral reduce)");
+    }
+    if (tail->chan.part) {
+        CFD_PROF("k_wgrad_reduce", st);
+        hipLaunchKernelGGL(k_chan_reduce_standalone, dim3((tail->chan.Co * (tail->chan.Ci + 1) + 3) / 4), dim3(256), 0, st,
+                           tail->chan);
+        CFD_LAUNCH_CHECK("cfd_fno_block_bwd_input(1x1 reduce)");
+    }
+    return CFD_OK;
+}
+
+int cfd_int_fno_block_bwd_input(const cfd_plan* p, const float* g, const float* gz, const float* w0, const float* aprev,
+                                float* gin, int B, int Cin, int Cout, void* stream, const CfdReduceTail* tail) {
     CFD_REQUIRE(p && g && gz && w0 && gin, CFD_ERR_INVALID_ARG, "cfd_fno_block_bwd_input: NULL pointer");
     CFD_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && Cin <= 32 && Cout <= 32, CFD_ERR_UNSUPPORTED,
                 "cfd_fno_block_bwd_input: channels (%d -> %d) unsupported (1..32)", Cin, Cout);
-    if (B == 0) return CFD_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (B == 0) return launch_reduce_tail_standalone(tail, st);
     if (!block_fused_ok(p, Cout, Cin, g, gin, aprev)) {
+        CFD_TRY(launch_reduce_tail_standalone(tail, st));
         CFD_TRY(cfd_chanmix(g, w0, nullptr, gin, B, Cout, Cin, p->H * p->W, 0, 1, stream));
         return cfd_spectral_idft(p, gz, gin, aprev, gin, B * Cin, aprev ? 2 : 1, stream);
     }
     CFD_PROF(aprev ? "k_block_bwd_dgelu" : "k_block_bwd", st);
-    launch_block(p, g, gz, w0, nullptr, aprev, gin, B, Cout, Cin, 0, 1, aprev ? 1 : 0, st);
+    launch_block(p, g, gz, w0, nullptr, aprev, gin, B, Cout, Cin, 0, 1, aprev ? 1 : 0, st, tail);
     CFD_LAUNCH_CHECK("cfd_fno_block_bwd_input");
     return CFD_OK;
+}
+
+extern "C" int cfd_fno_block_bwd_input(const cfd_plan* p, const float* g, const float* gz, const float* w0,
+                                       const float* aprev, float* gin, int B, int Cin, int Cout, void* stream) {
+    return cfd_int_fno_block_bwd_input(p, g, gz, w0, aprev, gin, B, Cin, Cout, stream, nullptr);
 }

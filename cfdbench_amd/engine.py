@@ -254,6 +254,21 @@ class FnoTrainEngine:
         self.optimizer_step(scale)
         return self.sums
 
+    # ---- optimiser state for full-state checkpoints (the reference saves weights only) ------------
+    def state_dict(self) -> Dict[str, object]:
+        """Adam moments (flat, in ``abi_parameters`` order), step count and learning rate.  The weights themselves live in
+        the model's ``state_dict`` (the flat buffer is what the model's parameters view)."""
+        return dict(exp_avg=self.exp_avg.detach().clone(), exp_avg_sq=self.exp_avg_sq.detach().clone(),
+                    step_count=int(self.step_count), lr=float(self.lr), numel=int(self.flat.numel))
+
+    def load_state_dict(self, state: Dict[str, object]) -> None:
+        if int(state["numel"]) != int(self.flat.numel):
+            raise ValueError(f"optimiser state is for {state['numel']} parameters, the model has {self.flat.numel}")
+        self.exp_avg.copy_(state["exp_avg"].to(self.device))
+        self.exp_avg_sq.copy_(state["exp_avg_sq"].to(self.device))
+        self.step_count = int(state["step_count"])
+        self.lr = float(state["lr"])
+
     def scores(self) -> Dict[str, float]:
         """{mse, rmse, mae, nmse} of the last step (loss.py:27-35).  Synchronises."""
         self.api.call("cfd_loss_scores", self.sums.data_ptr(), self.scores_buf.data_ptr(),

@@ -62,12 +62,15 @@ def evaluate(model: CfdModel, data, output_dir: Path, batch_size: int = 64, plot
             preds = model.generate_one(case_params=batch["case_params"], t=batch["t"], height=height, width=width)
             loss = model.loss_fn(labels=label[:, :1], preds=preds)
             for key in scores:
-                scores[key].append(loss[key].item())
+                scores[key].append(loss[key].detach().reshape(()))  # stays on the device: one transfer below
             preds = preds.repeat(1, 3, 1, 1)
-            all_preds.append(preds.cpu().detach())
+            all_preds.append(preds.detach())
             if plot_interval > 0 and step % plot_interval == 0 and not measure_time:
                 plot_predictions(inp=None, label=label[0][0], pred=preds[0][0], out_dir=Path(output_dir) / "images",
                                  step=step)
+    for key in scores:
+        scores[key] = torch.stack(scores[key]).cpu().tolist() if scores[key] else []
+    all_preds = [p_.cpu() for p_ in all_preds]  # same list-of-batches layout as the reference's preds.pt (src/train.py:143)
     if measure_time:
         print(f"Time per step: {1000 * (time.time() - start_time) / max(len(loader), 1):.3f} ms")
     avg_scores = {key: float(np.mean(vals)) for key, vals in scores.items()}
@@ -91,8 +94,9 @@ def test(model: CfdModel, data, output_dir: Path, plot_interval: int = 10, batch
 
 def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: int = 400, lr: float = 1e-3,
           lr_step_size: int = 1, lr_gamma: float = 0.9, batch_size: int = 64, log_interval: int = 50,
-          eval_interval: int = 2, measure_time: bool = False, plot_interval: int = 1):
-    """src/train.py:148-253: fwd -> ``loss["nmse"].backward()`` -> Adam -> zero_grad; StepLR per epoch."""
+          eval_interval: int = 2, measure_time: bool = False, plot_interval: int = 1, resume: bool = False):
+    """src/train.py:148-253: fwd -> ``loss["nmse"].backward()`` -> Adam -> zero_grad; StepLR per epoch.
+    ``resume``: continue from ``train_state.pt`` (see harness/train_auto.py:train)."""
     rank, world = _rank_world()
     output_dir = Path(output_dir)
     if world > 1:
@@ -107,7 +111,18 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
     start_time = time.time()
     global_step = 0
     all_train_losses: List[float] = []
-    for ep in range(num_epochs):
+    start_ep = 0
+    state_path = output_dir / "train_state.pt"
+    if resume and state_path.exists():
+        state = torch.load(state_path, map_location="cpu", weights_only=False)
+        model.load_state_dict(torch.load(output_dir / state["ckpt"] / "model.pt", map_location="cpu"))
+        optimizer.load_state_dict(state["optimizer"])
+        scheduler.load_state_dict(state["scheduler"])
+        start_ep, global_step, all_train_losses = state["ep"] + 1, state["global_step"], list(state["train_losses"])
+        torch.set_rng_state(state["rng"])
+        if rank == 0:
+            print(f"resuming after epoch {state['ep']} (step {global_step}) from {state_path}")
+    for ep in range(start_ep, num_epochs):
         ep_start_time = time.time()
         ep_train_losses: List[float] = []
         model.train()
@@ -140,6 +155,11 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
             torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, ckpt_path)
             dump_json(dict(ep=ep, train_loss=float(np.mean(ep_train_losses)), dev_loss=float(np.mean(dev_scores["mean"]["nmse"])),
                            time=time.time() - ep_start_time), ckpt_dir / "scores.json")
+            tmp = output_dir / "train_state.pt.tmp"
+            torch.save(dict(ep=ep, global_step=global_step, train_losses=all_train_losses + ep_train_losses,
+                            ckpt=ckpt_dir.name, optimizer=optimizer.state_dict(), scheduler=scheduler.state_dict(),
+                            rng=torch.get_rng_state(), world=world), tmp)
+            tmp.replace(state_path)
         if world > 1:
             dist.barrier()
         all_train_losses += ep_train_losses
@@ -209,7 +229,8 @@ def main(argv=None):
         args.save(str(output_dir / "train_args.json"))
         train(model, train_data, dev_data, output_dir, batch_size=args.batch_size, lr=args.lr,
               lr_step_size=args.lr_step_size, lr_gamma=args.lr_gamma, num_epochs=args.num_epochs,
-              eval_interval=args.eval_interval, log_interval=args.log_interval, plot_interval=args.plot_interval)
+              eval_interval=args.eval_interval, log_interval=args.log_interval, plot_interval=args.plot_interval,
+              resume=bool(args.resume))
     if "test" in args.mode:
         args.save(str(output_dir / "test_args.json"))
         load_best_ckpt(model, output_dir)

@@ -67,22 +67,29 @@ def evaluate(model: AutoCfdModel, data, output_dir: Path, batch_size: int = 2, p
     all_preds: List[Tensor] = []
     start_time = time.time()
     model.eval()
+    # the reference moves every score and every prediction to the host per batch (train_auto.py:96,
+    # :110-113), i.e. two device synchronisations per batch of 16.  Here the per-batch scores and predictions stay on the
+    # device and cross PCIe once at the end; the returned lists / tensors are the same.
     with torch.inference_mode():
         for step, batch in enumerate(loader):
             inputs, labels = batch["inputs"], batch["label"]
             input_loss = model.loss_fn(labels=labels[:, :1], preds=inputs[:, :1])  # train_auto.py:93
             for key in input_scores:
-                input_scores[key].append(input_loss[key].cpu().tolist())
+                input_scores[key].append(input_loss[key].detach().reshape(()))
             outputs = model(**batch)
             loss, preds = outputs["loss"], outputs["preds"]
             height, width = labels.shape[2:]
             preds = preds.view(-1, 1, height, width)  # train_auto.py:106
             for key in scores:
-                scores[key].append(loss[key].cpu().tolist())
-            all_preds.append(preds.cpu().detach())
+                scores[key].append(loss[key].detach().reshape(()))
+            all_preds.append(preds.detach())
             if plot_interval > 0 and step % plot_interval == 0 and not measure_time:
                 plot_predictions(inp=inputs[0][0], label=labels[0][0], pred=preds[0][0], out_dir=Path(output_dir) / "images",
                                  step=step)
+    for table in (scores, input_scores):
+        for key in table:
+            table[key] = torch.stack(table[key]).cpu().tolist() if table[key] else []
+    all_preds = [torch.cat(all_preds, dim=0).cpu()] if all_preds else []
     if measure_time:
         print(f"Time (ms) per step: {1000 * (time.time() - start_time) / max(len(loader), 1):.3f}")
     avg_scores = {}
@@ -110,8 +117,13 @@ def test(model: AutoCfdModel, data, output_dir: Path, infer_steps: int = 200, pl
 def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epochs: int = 400, lr: float = 1e-3,
           lr_step_size: int = 1, lr_gamma: float = 0.9, batch_size: int = 2, eval_batch_size: int = 2,
           log_interval: int = 10, eval_interval: int = 2, measure_time: bool = False, fused: bool = False,
-          plot_interval: int = 1):
-    """train_auto.py:181-313.  ``fused`` selects FnoTrainEngine (needs an Fno2d and the nmse loss)."""
+          plot_interval: int = 1, resume: bool = False):
+    """train_auto.py:181-313.  ``fused`` selects FnoTrainEngine (needs an Fno2d and the nmse loss).
+
+    ``resume`` (the reference saves weights only, train_auto.py:301, and cannot continue a run): every
+    checkpoint epoch also writes ``train_state.pt`` (optimiser moments / step, LR schedule, epoch, loss history, host RNG
+    state); with ``resume`` a run that finds it reloads the weights of that checkpoint and continues with the NEXT epoch,
+    reproducing the uninterrupted run step for step (same shuffles, same Adam state)."""
     rank, world = _rank_world()
     output_dir = Path(output_dir)
     if world > 1:  # shard the frames: each rank owns a contiguous 1/world of a fixed permutation (SURVEY.md 8e)
@@ -133,7 +145,21 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
     start_time = time.time()
     global_step = 0
     train_losses: List[float] = []
-    for ep in range(num_epochs):
+    start_ep = 0
+    state_path = output_dir / "train_state.pt"
+    if resume and state_path.exists():
+        state = torch.load(state_path, map_location="cpu", weights_only=False)
+        model.load_state_dict(torch.load(output_dir / state["ckpt"] / "model.pt", map_location="cpu"))
+        if engine is not None:
+            engine.load_state_dict(state["optimizer"])
+        else:
+            optimizer.load_state_dict(state["optimizer"])
+            scheduler.load_state_dict(state["scheduler"])
+        start_ep, global_step, train_losses = state["ep"] + 1, state["global_step"], list(state["train_losses"])
+        torch.set_rng_state(state["rng"])  # the DataLoader draws its shuffles from the host generator
+        if rank == 0:
+            print(f"resuming after epoch {state['ep']} (step {global_step}) from {state_path}")
+    for ep in range(start_ep, num_epochs):
         ep_start_time = time.time()
         cur_lr = lr * lr_gamma ** (ep // lr_step_size)  # what StepLR(step_size, gamma) yields in epoch ep
         ep_train_losses: List = []
@@ -189,6 +215,14 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
             torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, ckpt_path)
             dump_json(dict(ep=ep, train_loss=float(np.mean(ep_train_losses)), dev_loss=float(np.mean(dev_scores["all"]["nmse"])),
                            time=time.time() - ep_start_time), ckpt_dir / "scores.json")
+            # full training state next to the reference's artefacts (written last, atomically: a crash mid-checkpoint
+            # leaves the previous state in place)
+            opt_state = engine.state_dict() if engine is not None else optimizer.state_dict()
+            tmp = output_dir / "train_state.pt.tmp"
+            torch.save(dict(ep=ep, global_step=global_step, train_losses=train_losses, ckpt=ckpt_dir.name,
+                            optimizer=opt_state, scheduler=None if engine is not None else scheduler.state_dict(),
+                            rng=torch.get_rng_state(), fused=engine is not None, world=world), tmp)
+            tmp.replace(state_path)
         if world > 1:
             dist.barrier()
     if rank == 0:
@@ -216,7 +250,8 @@ def main(argv=None):
         train(model, train_data=train_data, dev_data=dev_data, output_dir=output_dir, lr=args.lr,
               lr_step_size=args.lr_step_size, lr_gamma=args.lr_gamma, num_epochs=args.num_epochs,
               batch_size=args.batch_size, eval_batch_size=args.eval_batch_size, eval_interval=args.eval_interval,
-              log_interval=args.log_interval, fused=bool(args.fused), plot_interval=args.plot_interval)
+              log_interval=args.log_interval, fused=bool(args.fused), plot_interval=args.plot_interval,
+              resume=bool(args.resume))
     if "test" in args.mode:
         args.save(str(output_dir / "test_args.json"))
         load_best_ckpt(model, output_dir)

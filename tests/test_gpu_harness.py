@@ -60,6 +60,39 @@ def test_train_eval_test_artifacts(torch, tmp_path, fused):
     assert res["preds"].shape == (2 * len(dev), 1, 64, 64)
 
 
+@pytest.mark.parametrize("fused", [0, 1])
+def test_resume_reproduces_the_uninterrupted_run(torch, tmp_path, fused):
+    """4 epochs in one go == 2 epochs, process 'restart', resume to 4 (weights, loss history, bitwise)."""
+    from cfdbench_amd.harness.autoregressive import init_model
+    from cfdbench_amd.harness.data import SyntheticAutoDataset
+    from cfdbench_amd.harness.train_auto import train
+    tr = SyntheticAutoDataset(n_cases=4, n_frames=5, height=64, width=64, seed=0)
+    dev = SyntheticAutoDataset(n_cases=1, n_frames=4, height=64, width=64, seed=1)
+
+    def run(out, num_epochs, resume):
+        args = _args(out, fused=fused)
+        torch.manual_seed(0)
+        model = init_model(args).cuda()
+        if resume:  # a restarted process knows nothing of the first run: different init, different generator state
+            torch.manual_seed(123)
+            for p_ in model.parameters():
+                p_.data.mul_(0.5)
+        losses = train(model, tr, dev, out, num_epochs=num_epochs, lr=args.lr, lr_step_size=1, lr_gamma=0.8,
+                       batch_size=4, eval_batch_size=4, log_interval=100, eval_interval=2, fused=bool(fused), plot_interval=0,
+                       resume=resume)
+        return model, losses
+
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    ma, la = run(tmp_path / "a", 4, False)
+    run(tmp_path / "b", 2, False)
+    assert (tmp_path / "b" / "train_state.pt").exists()
+    mb, lb = run(tmp_path / "b", 4, True)
+    assert la == lb
+    for (k, pa), (_, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        assert torch.equal(pa, pb), k
+
+
 def test_fused_and_autograd_paths_agree(torch, tmp_path):
     """Same data order, same init: FnoTrainEngine's steps == autograd + torch.optim.Adam steps."""
     from cfdbench_amd.engine import FnoTrainEngine
