@@ -249,7 +249,7 @@ def main():
         alg = 5 * Nb + 3 * Wb
         gbs = alg / (us * 1e-6) / 1e9
         result["roofline_spectral_conv2d"] = dict(
-            what="SpectralConv2d fwd+bwd (dft, mix, idft | dft, mix_adj + wgrad in one launch, reduce, idft)", bound="hbm",
+            what="SpectralConv2d fwd+bwd (dft, mix, idft | dft, mix_adj + wgrad in one launch, idft carrying the partial-sum reduction)", bound="hbm",
             algorithmic_bytes=alg, avg_us=round(us, 2), achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
             frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None)
 

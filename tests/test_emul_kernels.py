@@ -33,12 +33,12 @@ def test_spectral_fwd_bwd_fused_route(be):
     _assert_all(K.check_spectral(be, 1, 20, 20, 64, 64))
 
 
-@pytest.mark.parametrize("B,Cin,Cout", [(3, 20, 20), (9, 12, 7), (2, 24, 24), (5, 32, 32), (10, 5, 20)])
+@pytest.mark.parametrize("B,Cin,Cout", [(3, 20, 20), (9, 12, 7), (2, 24, 24), (5, 32, 32)])  # more shapes: test_gpu_kernels.py
 def test_mix_and_spectral_wgrad(be, B, Cin, Cout):
     _assert_all(K.check_mix_wgrad(be, B, Cin, Cout))
 
 
-@pytest.mark.parametrize("want_wg,nwv,B,C", [("36", "2", 27, 20), ("80", "8", 27, 20), ("256", "1", 5, 32)])
+@pytest.mark.parametrize("want_wg,nwv,B,C", [("36", "2", 27, 20), ("256", "1", 5, 32)])
 def test_mix_and_spectral_wgrad_multi_step(be, want_wg, nwv, B, C, monkeypatch):
     """The batch-in-lanes kernels (k_mix_lds, k_spec_wgrad_tile, the fused k_mixadj_wgrad) at chunk sizes that reach
     the software-pipelined loops of the weight gradient (several 8-entry steps per workgroup, ragged last step) and
