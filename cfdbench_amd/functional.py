@@ -559,6 +559,32 @@ class ResidualMaskFn(torch.autograd.Function):
         return gx, gres, None
 
 
+class ChannelBiasAddFn(torch.autograd.Function):
+    """x + s[:, :, None, None]  (UNet with ``insert_case_params_at="hidden"``, unet.py:198-204): the per-(sample, channel)
+    conditioning vector added to the bottleneck.  Forward = the residual-add kernel on the broadcast (a copy, pure data
+    movement); backward: gx = g, gs[b, c] = sum over pixels of g -- the row-dot kernel against a row of ones."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, s: Tensor):
+        _require_cuda(x, s)
+        x, s = _f32c(x), _f32c(s)
+        B, C, H, W = x.shape
+        se = s.reshape(B, C, 1, 1).expand(B, C, H, W).contiguous()
+        out = torch.empty_like(x)
+        _lib.api().call("cfd_residual_mask", _ptr(x), _ptr(se), None, _ptr(out), B, C, C, H * W, _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        g = _f32c(g)
+        B, C, H, W = g.shape
+        ones = torch.ones((B * C, 1, H * W), dtype=torch.float32, device=g.device)
+        zero = torch.zeros(1, dtype=torch.float32, device=g.device)
+        gs = torch.empty((B * C, 1), dtype=torch.float32, device=g.device)
+        _lib.api().call("cfd_rowdot_fwd", _ptr(g), _ptr(ones), _ptr(zero), _ptr(gs), B * C, 1, H * W, _stream())
+        return g, gs.reshape(B, C)
+
+
 class GeluFn(torch.autograd.Function):
     """nn.GELU() (exact erf) as a stand-alone pass (resnet.py:46,77)."""
 

@@ -4,7 +4,7 @@ src/models/unet.py:11-263) on the gfx950 kernels of csrc/conv.hip.  The torch su
 nn.ConvTranspose2d) only hold parameters and buffers; the arithmetic runs in: implicit-GEMM replicate-padded conv (MFMA),
 fused BatchNorm+ReLU (batch statistics in training, running statistics in eval), 2x2 max-pool, 2x2/stride-2 transposed
 conv, 1x1 output conv and the (x + residual) * mask epilogue.  ``torch.cat`` / zero ``F.pad`` of skip connections are the
-only ATen calls (pure data movement).  ``bilinear=True`` and ``insert_case_params_at="hidden"`` are not built (init_model
+only ATen calls (pure data movement).  ``bilinear=True`` is not built (init_model
 uses neither by default: src/utils/autoregressive.py:105-114, src/args.py:203)."""
 from typing import List, Optional
 
@@ -88,16 +88,17 @@ class UNet(AutoCfdModel):
                  insert_case_params_at: str = "hidden", bilinear: bool = False, dim: int = 8):
         assert insert_case_params_at in ["hidden", "input"]
         super().__init__(loss_fn)
-        if insert_case_params_at == "hidden":
-            raise NotImplementedError("cfdbench_amd.UNet: insert_case_params_at='hidden' is not built "
-                                      "(the CLI default is 'input', src/args.py:203)")
         self.in_chan = in_chan
         self.out_chan = out_chan
         self.n_case_params = n_case_params
         self.insert_case_params_at = insert_case_params_at
         self.bilinear = bilinear
         self.dim = dim
-        self.in_conv = DoubleConv(in_chan + 1 + n_case_params, dim)  # + 1 for mask
+        if insert_case_params_at == "hidden":  # registered first, like the reference (unet.py:132-133): state_dict order
+            self.case_params_fc = nn.Linear(n_case_params, dim * 16)
+            self.in_conv = DoubleConv(in_chan + 1, dim)  # + 1 for mask
+        else:
+            self.in_conv = DoubleConv(in_chan + 1 + n_case_params, dim)
         self.down1 = Down(dim, dim * 2)
         self.down2 = Down(dim * 2, dim * 4)
         self.down3 = Down(dim * 4, dim * 8)
@@ -116,13 +117,19 @@ class UNet(AutoCfdModel):
             mask = torch.ones((batch_size, 1, height, width), device=inputs.device)
         elif mask.dim() == 3:
             mask = mask.unsqueeze(1)
-        cp = case_params.unsqueeze(2).unsqueeze(3).expand(-1, -1, height, width)
-        x = torch.cat([inputs, mask, cp], dim=1)
+        if self.insert_case_params_at == "input":
+            cp = case_params.unsqueeze(2).unsqueeze(3).expand(-1, -1, height, width)
+            x = torch.cat([inputs, mask, cp], dim=1)
+        else:
+            x = torch.cat([inputs, mask], dim=1)
         x1 = self.in_conv(x)
         x2 = self.down1(x1)
         x3 = self.down2(x2)
         x4 = self.down3(x3)
         x5 = self.down4(x4)
+        if self.insert_case_params_at == "hidden":  # x5 + Linear(case_params)[:, :, None, None]  (unet.py:198-204)
+            conds = F_.linear_act(case_params, self.case_params_fc.weight, self.case_params_fc.bias, None)
+            x5 = F_.ChannelBiasAddFn.apply(x5, conds)
         x = self.up1(x5, x4)
         x = self.up2(x, x3)
         x = self.up3(x, x2)

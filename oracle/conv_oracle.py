@@ -127,7 +127,7 @@ def convt2_bwd(g: Array, x: Array, w: Array):
     return gx, gw, g.sum(axis=(0, 2, 3))
 
 
-# ---- UNet.forward (src/models/unet.py:153-223), insert_case_params_at="input", bilinear=False ----
+# ---- UNet.forward (src/models/unet.py:153-223), insert_case_params_at="input" | "hidden", bilinear=False ----
 def _double_conv(P, pre, x, training, stats):
     for j in (1, 2):
         x = conv2d(x, P[f"{pre}.conv{j}.0.weight"], P[f"{pre}.conv{j}.0.bias"])
@@ -142,7 +142,11 @@ def unet_forward(P: Dict[str, Array], inputs: Array, case_params: Array, mask: A
     B, _, H, W = inputs.shape
     if mask.ndim == 3:
         mask = mask[:, None]
-    x = np.concatenate([inputs, mask, np.broadcast_to(case_params[:, :, None, None], (B, case_params.shape[1], H, W))], axis=1)
+    hidden = "case_params_fc.weight" in P  # insert_case_params_at == "hidden" (unet.py:132-133, 198-204)
+    if hidden:
+        x = np.concatenate([inputs, mask], axis=1)
+    else:
+        x = np.concatenate([inputs, mask, np.broadcast_to(case_params[:, :, None, None], (B, case_params.shape[1], H, W))], axis=1)
     stats: Dict[str, Array] = {}
     x1 = _double_conv(P, "in_conv", x, training, stats)
     skips = [x1]
@@ -150,6 +154,10 @@ def unet_forward(P: Dict[str, Array], inputs: Array, case_params: Array, mask: A
     for d in (1, 2, 3, 4):
         cur = _double_conv(P, f"down{d}.maxpool_conv.1", maxpool2(cur), training, stats)
         skips.append(cur)
+    if hidden:  # x5 + Linear(case_params)[:, :, None, None]; the skip list keeps the un-conditioned x5 out of reach (it is
+        # only ever consumed by up1 as its input, unet.py:206)
+        conds = case_params @ P["case_params_fc.weight"].T + P["case_params_fc.bias"]
+        cur = cur + conds[:, :, None, None]
     for u, skip in zip((1, 2, 3, 4), (skips[3], skips[2], skips[1], skips[0])):
         up = convt2(cur, P[f"up{u}.up.weight"], P[f"up{u}.up.bias"])
         dy, dx = skip.shape[2] - up.shape[2], skip.shape[3] - up.shape[3]

@@ -204,12 +204,12 @@ def gen_auto_deeponet_cnn(name, seed, bseed, B, trunk_depth=2, p=5, steps=2, nq=
     print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
 
 
-def gen_unet(name, seed, bseed, B, H, W, dim, p=8, steps=2):
+def gen_unet(name, seed, bseed, B, H, W, dim, p=8, steps=2, insert="input"):
     """UNet (input-insert, ConvTranspose up path) train-mode forward/backward, running-stat update, eval forward and
     rollout from the reference module (src/models/unet.py).  The state_dict itself is stored (torch's init stream)."""
     from models.unet import UNet  # reference
     torch.manual_seed(seed)
-    model = UNet(2, 2, MseLoss(normalize=True), p, insert_case_params_at="input", bilinear=False, dim=dim)
+    model = UNet(2, 2, MseLoss(normalize=True), p, insert_case_params_at=insert, bilinear=False, dim=dim)
     with torch.no_grad():  # non-trivial BatchNorm affine parameters and running statistics
         g = torch.Generator().manual_seed(seed + 1)
         for k, v in model.state_dict().items():
@@ -436,6 +436,7 @@ def main():
     gen_auto_deeponet("auto_deeponet_gelu_16x16", 43, 53, 2, 16, 16, 16, 2, 2, "gelu")
     gen_unet("unet_dim4_32x32", 61, 71, 3, 32, 32, 4)
     gen_unet("unet_dim3_36x40", 62, 72, 2, 36, 40, 3, p=5)
+    gen_unet("unet_hidden_dim2_32x32", 63, 73, 3, 32, 32, 2, p=5, insert="hidden")
     gen_resnet("resnet_h4_20x24", 81, 91, 2, 20, 24, 4, 1)
     gen_nonauto("deeponet_normact_relu", "deeponet", 101, 3, 37, 16, 18, 24, "relu", True)
     gen_nonauto("deeponet_plain_tanh", "deeponet", 102, 2, 50, 16, 18, 20, "tanh", False)

@@ -165,7 +165,7 @@ def test_auto_deeponet_forward_backward_rollout(golden_dir, name):
 
 
 # ---- U-Net (oracle/conv_oracle.py) against the reference module's outputs ------------------------------------------
-@pytest.mark.parametrize("name", ["unet_dim4_32x32", "unet_dim3_36x40"])
+@pytest.mark.parametrize("name", ["unet_dim4_32x32", "unet_dim3_36x40", "unet_hidden_dim2_32x32"])
 def test_unet_forward_train_and_eval(golden_dir, name):
     from oracle import conv_oracle as CO
     g = np.load(golden_dir / f"{name}.npz")
