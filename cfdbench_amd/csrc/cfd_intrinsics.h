@@ -77,8 +77,3 @@ __device__ __forceinline__ cfd_f2 cfd_cmla_conj(cfd_f2 acc, cfd_f2 x, cfd_f2 w) 
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "+v"(acc) : "v"(x), "v"(w));
     return acc;
 }
-
-// Waits for every outstanding vector-memory operation of the wave (s_waitcnt vmcnt(0), other counters untouched).
-// Placed in front of a software-pipelined loop so that the loop's own waits are computed from the loop body alone
-// (prologue loads still in flight at the loop header force a full wait on every iteration otherwise).
-__device__ __forceinline__ void cfd_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }

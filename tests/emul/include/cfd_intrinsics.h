@@ -91,5 +91,3 @@ inline cfd_f2 cfd_cmla_conj(cfd_f2 acc, cfd_f2 x, cfd_f2 w) {
     cfd_f2 r = {fmaf(x.x, w.x, acc.x), fmaf(x.x, w.y, acc.y)};
     return cfd_f2{fmaf(x.y, w.y, r.x), fmaf(-x.y, w.x, r.y)};
 }
-
-inline void cfd_wait_vmem() {}

@@ -23,7 +23,7 @@ CONFIGS = [
     ("mix lds nwv8", dict(CFD_MIX_NWV="8")),
     ("unfused", dict(CFD_FUSED_VARIANT="0")),
 ]
-KEYS = ("CFD_MIX_VARIANT", "CFD_WGRAD_VARIANT", "CFD_MIX_WG", "CFD_WGRAD_WG", "CFD_MIX_NWV", "CFD_FUSED_VARIANT")
+KEYS = ("CFD_WGRAD_WG", "CFD_MIX_NWV", "CFD_FUSED_VARIANT")
 
 
 def main():
