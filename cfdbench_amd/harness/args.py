@@ -5,7 +5,8 @@ the same attribute table drives ``argparse``.  Differences, all documented in SU
   * ``lr_step_size`` / ``lr_gamma`` exist (train_auto.py:357 reads ``args.lr_step_size`` but the reference's Args lacks it);
   * ``--data`` is an explicit alias of ``--data_name`` (README.md:179 uses it; argparse prefix matching would be ambiguous);
   * additions: ``infer_steps`` (test_multistep.py:198 hard-codes 20), ``fused`` (FnoTrainEngine instead of autograd+Adam),
-    ``resume`` (continue from ``train_state.pt``: optimiser moments, schedule, epoch, RNG -- the reference saves weights only).
+    ``resume`` (continue from ``train_state.pt``: optimiser moments, schedule, epoch, RNG -- the reference saves weights only),
+    ``device_loader`` (frames resident in HBM, batches gathered on the device instead of DataLoader + collate_fn).
 Flags of models that are not built yet are carried so existing command lines and args.json files keep working.
 """
 from __future__ import annotations
@@ -34,7 +35,7 @@ _FLAGS: Dict[str, Any] = dict(
     # missing in the reference's Args but read by its trainers (train_auto.py:357, :188-189)
     lr_step_size=20, lr_gamma=0.9,
     # additions of this harness
-    infer_steps=20, fused=0, plot_interval=1, resume=0,
+    infer_steps=20, fused=0, plot_interval=1, resume=0, device_loader=0,
 )
 
 

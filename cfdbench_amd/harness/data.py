@@ -42,6 +42,10 @@ class SyntheticAutoDataset(Dataset):
             self.case_params.append(dict(vel_top=float(vel), density=float(dens), viscosity=float(visc),
                                          height=1.0, width=1.0))
         self.index: List[Tuple[int, int]] = [(c, t) for c in range(n_cases) for t in range(n_frames - 1)]
+        # the stacked view the reference's autoregressive datasets expose (cavity.py:345-355): frame t -> frame t + 1
+        self.inputs = torch.from_numpy(np.concatenate([f[:-1] for f in self.all_features]))
+        self.labels = torch.from_numpy(np.concatenate([f[1:] for f in self.all_features]))
+        self.case_ids: List[int] = [c for c, _ in self.index]
 
     def __len__(self) -> int:
         return len(self.index)
@@ -64,3 +68,47 @@ def get_auto_dataset(data_dir: Path, data_name: str, delta_time: float, norm_pro
         return get_flow_auto_datasets(problem, Path(data_dir) / problem, data_name[len(problem) + 1:],
                                       norm_props=norm_props, norm_bc=norm_bc, delta_time=delta_time, **kw)
     raise ValueError(f'Invalid data name "{data_name}"')  # src/dataset/__init__.py:125
+
+
+class DeviceBatchLoader:
+    """On-device batch assembly: the replacement for ``DataLoader(data, collate_fn=collate_fn)`` when the
+    frames of an autoregressive dataset fit in HBM (the whole interpolated CFDBench corpus is 13.4 GB).
+
+    The reference builds a batch item by item on the host -- ``__getitem__`` makes a dict of 0-dim tensors per sample,
+    ``collate_fn`` stacks the frames, rebuilds the case-parameter table from Python floats and copies four tensors to the
+    GPU (src/train_auto.py:33-58) -- which tops out at a few thousand frames/s, two orders of magnitude below the
+    training step.  Here the stacked frames ``data.inputs`` / ``data.labels`` (N, 3, h, w) and the per-frame parameter
+    table live on the device once; a batch is three ``index_select`` gathers with the epoch's permutation, and the
+    yielded dict is exactly ``collate_fn``'s: ``inputs`` = channels [:-1], ``mask`` = the last channel, ``label`` =
+    channels [:-1] of the next frame, ``case_params`` = every case.json key except rotated / dx / dy, in key order.
+
+    ``data`` needs the attributes of the reference's datasets: ``inputs``, ``labels``, ``case_ids``, ``case_params``.
+    ``indices`` restricts the loader to a subset (data-parallel shard).  The permutation is drawn from the host generator
+    (``torch.randperm``), so seeding / ``--resume`` behave as with a DataLoader."""
+
+    def __init__(self, data, batch_size: int, shuffle: bool = True, drop_last: bool = False, device: str = "cuda",
+                 indices=None, generator=None):
+        self.batch_size, self.shuffle, self.drop_last, self.generator = int(batch_size), shuffle, drop_last, generator
+        self.inputs = data.inputs.to(device)
+        self.labels = data.labels.to(device)
+        keys = [k for k in data.case_params[0].keys() if k not in ("rotated", "dx", "dy")]
+        table = torch.tensor([[float(cp[k]) for k in keys] for cp in data.case_params], dtype=torch.float32)
+        self.case_params = table[torch.as_tensor(data.case_ids, dtype=torch.long)].to(device)
+        n = len(self.inputs)
+        self.indices = torch.arange(n) if indices is None else torch.as_tensor(indices, dtype=torch.long)
+
+    def __len__(self) -> int:
+        n = len(self.indices)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        order = self.indices
+        if self.shuffle:
+            order = order[torch.randperm(len(order), generator=self.generator)]
+        order = order.to(self.inputs.device)
+        for k in range(len(self)):
+            idx = order[k * self.batch_size:(k + 1) * self.batch_size]
+            x = self.inputs.index_select(0, idx)
+            y = self.labels.index_select(0, idx)
+            yield dict(inputs=x[:, :-1].contiguous(), label=y[:, :-1].contiguous(), mask=x[:, -1:].contiguous(),
+                       case_params=self.case_params.index_select(0, idx))

@@ -117,7 +117,7 @@ def test(model: AutoCfdModel, data, output_dir: Path, infer_steps: int = 200, pl
 def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epochs: int = 400, lr: float = 1e-3,
           lr_step_size: int = 1, lr_gamma: float = 0.9, batch_size: int = 2, eval_batch_size: int = 2,
           log_interval: int = 10, eval_interval: int = 2, measure_time: bool = False, fused: bool = False,
-          plot_interval: int = 1, resume: bool = False):
+          plot_interval: int = 1, resume: bool = False, device_loader: bool = False):
     """train_auto.py:181-313.  ``fused`` selects FnoTrainEngine (needs an Fno2d and the nmse loss).
 
     ``resume`` (the reference saves weights only, train_auto.py:301, and cannot continue a run): every
@@ -130,8 +130,14 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
         perm = torch.randperm(len(train_data), generator=torch.Generator().manual_seed(0)).tolist()
         a, b = shard_range(len(perm), rank, world)
         train_data = Subset(train_data, perm[a:b])
-    train_loader = DataLoader(train_data, batch_size=batch_size, shuffle=True, collate_fn=collate_fn,
-                              drop_last=world > 1)
+    if device_loader:  # frames resident in HBM, batches gathered on the device (harness/data.py)
+        from .data import DeviceBatchLoader
+        base = train_data.dataset if isinstance(train_data, Subset) else train_data
+        train_loader = DeviceBatchLoader(base, batch_size, shuffle=True, drop_last=world > 1,
+                                         indices=train_data.indices if isinstance(train_data, Subset) else None)
+    else:
+        train_loader = DataLoader(train_data, batch_size=batch_size, shuffle=True, collate_fn=collate_fn,
+                                  drop_last=world > 1)
     if rank == 0:
         output_dir.mkdir(exist_ok=True, parents=True)
     engine = None
@@ -251,7 +257,7 @@ def main(argv=None):
               lr_step_size=args.lr_step_size, lr_gamma=args.lr_gamma, num_epochs=args.num_epochs,
               batch_size=args.batch_size, eval_batch_size=args.eval_batch_size, eval_interval=args.eval_interval,
               log_interval=args.log_interval, fused=bool(args.fused), plot_interval=args.plot_interval,
-              resume=bool(args.resume))
+              resume=bool(args.resume), device_loader=bool(args.device_loader))
     if "test" in args.mode:
         args.save(str(output_dir / "test_args.json"))
         load_best_ckpt(model, output_dir)

@@ -113,3 +113,31 @@ def test_init_model_resolves_every_autoregressive_name():
         assert type(m).__name__ == cls and hasattr(m, "generate_many")
     with pytest.raises(ValueError):
         init_model(Args(model="no_such_model", data_name="cavity_bc"))
+
+
+def test_device_batch_loader_equals_dataloader_plus_collate():
+    """batches gathered from the stacked frames == the reference's item-by-item collate (same order)."""
+    from functools import partial
+    from torch.utils.data import DataLoader
+    from cfdbench_amd.harness.data import DeviceBatchLoader
+    ds = SyntheticAutoDataset(n_cases=3, n_frames=5, height=8, width=9, seed=4, border_mask=True)
+    ref = list(DataLoader(ds, batch_size=5, shuffle=False, collate_fn=partial(collate_fn, device=None)))
+    got = list(DeviceBatchLoader(ds, 5, shuffle=False, device="cpu"))
+    assert len(ref) == len(got) == len(DeviceBatchLoader(ds, 5, shuffle=False, device="cpu")) == 3
+    for a, b in zip(ref, got):
+        assert set(a) == set(b) == {"inputs", "label", "mask", "case_params"}
+        for k in a:
+            assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+            assert b[k].is_contiguous()
+    # a shard (data-parallel subset) in shuffled order: every frame of the shard exactly once, drop_last honoured
+    idx = [11, 2, 7, 5, 0, 9, 3]
+    torch.manual_seed(5)
+    ld = DeviceBatchLoader(ds, 3, shuffle=True, drop_last=True, device="cpu", indices=idx)
+    batches = list(ld)
+    assert len(batches) == len(ld) == 2
+    seen = torch.cat([b["inputs"] for b in batches])
+    pool = ds.inputs[idx][:, :-1]
+    assert all(any(torch.equal(x, p) for p in pool) for x in seen) and len(seen) == 6
+    torch.manual_seed(5)
+    again = torch.cat([b["inputs"] for b in DeviceBatchLoader(ds, 3, shuffle=True, drop_last=True, device="cpu", indices=idx)])
+    assert torch.equal(seen, again)  # the permutation comes from the host generator: reproducible / resumable

@@ -93,6 +93,48 @@ def test_resume_reproduces_the_uninterrupted_run(torch, tmp_path, fused):
         assert torch.equal(pa, pb), k
 
 
+def test_train_with_device_batch_loader(torch, tmp_path):
+    """the fused trainer fed by on-device batch assembly (no DataLoader, no per-item host work)."""
+    import time
+    from torch.utils.data import DataLoader
+    from cfdbench_amd.harness.autoregressive import init_model
+    from cfdbench_amd.harness.data import DeviceBatchLoader, SyntheticAutoDataset
+    from cfdbench_amd.harness.train_auto import collate_fn, train
+    args = _args(tmp_path, fused=1)
+    tr = SyntheticAutoDataset(n_cases=6, n_frames=6, height=64, width=64, seed=0)
+    dev = SyntheticAutoDataset(n_cases=2, n_frames=4, height=64, width=64, seed=1)
+    torch.manual_seed(0)
+    model = init_model(args).cuda()
+    losses = train(model, tr, dev, tmp_path / "run", num_epochs=4, lr=args.lr, batch_size=4, eval_batch_size=4,
+                   log_interval=100, eval_interval=2, fused=True, plot_interval=0, device_loader=True)
+    assert len(losses) == 4 * ((len(tr) + 3) // 4)
+    assert np.mean(losses[-6:]) < 0.9 * np.mean(losses[:6])
+    # same batches as the reference's collate when the order is the same
+    ref = list(DataLoader(tr, batch_size=7, shuffle=False, collate_fn=collate_fn))
+    got = list(DeviceBatchLoader(tr, 7, shuffle=False))
+    for a, b in zip(ref, got):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    # loader-only rate (printed with -s): item-by-item collate vs on-device gathers
+    big = SyntheticAutoDataset(n_cases=16, n_frames=65, height=64, width=64, seed=2)  # 1024 frames
+    rates = {}
+    for name, mk in (("DataLoader+collate_fn", lambda: DataLoader(big, batch_size=256, shuffle=True, collate_fn=collate_fn)),
+                     ("DeviceBatchLoader", lambda: DeviceBatchLoader(big, 256, shuffle=True))):
+        ld = mk()
+        for b in ld:  # warm-up epoch
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for _ in range(5):
+            for b in ld:
+                n += b["inputs"].shape[0]
+        torch.cuda.synchronize()
+        rates[name] = n / (time.perf_counter() - t0)
+        print(f"{name}: {rates[name]:.0f} frames/s")
+    assert rates["DeviceBatchLoader"] > 5 * rates["DataLoader+collate_fn"]
+
+
 def test_fused_and_autograd_paths_agree(torch, tmp_path):
     """Same data order, same init: FnoTrainEngine's steps == autograd + torch.optim.Adam steps."""
     from cfdbench_amd.engine import FnoTrainEngine
