@@ -59,9 +59,13 @@ def _rank_world():
 
 
 def evaluate(model: AutoCfdModel, data, output_dir: Path, batch_size: int = 2, plot_interval: int = 1,
-             measure_time: bool = False):
+             measure_time: bool = False, device_loader: bool = False):
     """Single-step evaluation (train_auto.py:61-148): identity baseline + model scores per batch, predictions."""
-    loader = DataLoader(data, batch_size=batch_size, shuffle=False, collate_fn=collate_fn)
+    if device_loader:  # same batches, gathered on the device (harness/data.py)
+        from .data import DeviceBatchLoader
+        loader = DeviceBatchLoader(data, batch_size, shuffle=False)
+    else:
+        loader = DataLoader(data, batch_size=batch_size, shuffle=False, collate_fn=collate_fn)
     scores = {name: [] for name in model.loss_fn.get_score_names()}
     input_scores = deepcopy(scores)
     all_preds: List[Tensor] = []
@@ -209,7 +213,8 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
         if (ep + 1) % eval_interval == 0 and rank == 0:
             ckpt_dir = output_dir / f"ckpt-{ep}"
             ckpt_dir.mkdir(exist_ok=True, parents=True)
-            result = evaluate(model, dev_data, ckpt_dir, batch_size=eval_batch_size, plot_interval=plot_interval)
+            result = evaluate(model, dev_data, ckpt_dir, batch_size=eval_batch_size, plot_interval=plot_interval,
+                              device_loader=device_loader)
             dev_scores = result["scores"]
             dump_json(dev_scores, ckpt_dir / "dev_scores.json")
             dump_json(ep_train_losses, ckpt_dir / "train_loss.json")
