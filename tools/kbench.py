@@ -68,6 +68,8 @@ def main():
         "mix_adj": (lambda: api.call("cfd_spectral_mix", plan, P(gh), P(w1), P(w2), P(z), B, C, C, 1, st), 2 * Mb + Wb),
         "spec_wgrad": (lambda: api.call("cfd_spectral_wgrad", plan, P(xh), P(gh), P(gw1), P(gw2), P(ws), B, C, C, st),
                        2 * Mb + Wb),
+        "mix_adj_wgrad": (lambda: api.call("cfd_spectral_mix_adj_wgrad", plan, P(xh), P(gh), P(w1), P(w2), P(z), P(gw1), P(gw2),
+                                           P(ws), B, C, C, st), 3 * Mb + 2 * Wb),
         "idft": (lambda: api.call("cfd_spectral_idft", plan, P(z), None, None, P(out), B * C, 0, st), N + Mb),
         "idft_add": (lambda: api.call("cfd_spectral_idft", plan, P(z), P(out), None, P(out), B * C, 1, st), 2 * N + Mb),
         "idft_add_dgelu": (lambda: api.call("cfd_spectral_idft", plan, P(z), P(out), P(a2), P(out), B * C, 2, st),
