@@ -676,7 +676,7 @@ static int cfd_mix_lds_waves(int B, int nmg) {
     }
     // The weight fill + barrier cost k_mix_lds a fixed ~5 us that the lane = mode kernel does not pay; its per-entry cost
     // is lower.  Measured cross-over (C = 20, profiles/r01i_mode_variants_small_batch.txt): B = 16: 5.6 vs 8.8 us,
-    // 64: 6.1 vs 9.0, 128: 9.6 vs 9.6, 256: 13.9 vs 12.3.
+    // 64: 6.1 vs 9.0, 128: 9.6 vs 9.6, 256: 13.9 vs 12.3, 512: 26.8 vs 16.8; C = 32, B = 256: 32.2 vs 21.4.
     if (B < 192) return 0;
     for (int nwv = 8; nwv > 1; nwv >>= 1)
         if (nmg * ((B + 8 * nwv - 1) / (8 * nwv)) >= 128) return nwv;
