@@ -1064,16 +1064,15 @@ extern "C" int cfd_spectral_wgrad(const cfd_plan* p, const float* xh, const floa
 }
 
 // Adjoint mode mixing (gz = sum_o conj(W[i,o]) gh[b,o]) and the spectral weight gradient of the same gradient modes.
-// One launch for both where the fused kernel applies (Cin == Cout == 20), the two stand-alone entry points otherwise.
+// One launch for both where the fused kernel applies (Cin == Cout == 20 or 32), the two stand-alone entry points otherwise.
 static bool cfd_fused_disabled() {  // CFD_FUSED_VARIANT=0: two launches (tests compare both routes)
     const char* e = getenv("CFD_FUSED_VARIANT");
     return e && atoi(e) == 0;
 }
 
-template <int IT, int OT, int NS, int NSPLIT>
+template <int C, int IT, int OT, int NS, int NSPLIT>
 static void launch_mixadj_wgrad(const float2* xh, const float2* gh, const float2* w1, const float2* w2, float2* gz,
                                 float2* part, int B, int m1, int m2, int* nchunk_out, hipStream_t st) {
-    constexpr int C = 20;
     const int M = 2 * m1 * m2;
     int nmg, npair, wgBC, wg_nchunk;
     cfd_wgrad_tile_geometry(B, M, &nmg, &npair, &wgBC, &wg_nchunk);
@@ -1094,7 +1093,7 @@ int cfd_int_spectral_mix_adj_wgrad(const cfd_plan* p, const float* xh, const flo
     if (defer) defer->part = nullptr;
     CFD_REQUIRE(p && xh && gh && w1 && w2 && gz && gw1 && gw2 && ws, CFD_ERR_INVALID_ARG, "cfd_spectral_mix_adj_wgrad: NULL pointer");
     CFD_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1, CFD_ERR_INVALID_ARG, "cfd_spectral_mix_adj_wgrad: bad sizes");
-    if (cfd_fused_disabled() || Cin != 20 || Cout != 20) {
+    if (cfd_fused_disabled() || Cin != Cout || (Cin != 20 && Cin != 32)) {
         CFD_TRY(cfd_spectral_wgrad(p, xh, gh, gw1, gw2, ws, B, Cin, Cout, stream));
         return cfd_spectral_mix(p, gh, w1, w2, gz, B, Cin, Cout, 1, stream);
     }
@@ -1104,9 +1103,14 @@ int cfd_int_spectral_mix_adj_wgrad(const cfd_plan* p, const float* xh, const flo
     {
         // 5 x 5 accumulator tiles, 3-stage ring, two workgroups per (mode group, chunk): 122 registers, so two
         // workgroups per CU (measured: 19.1 us per launch against 20.9 / 22.8 us for 5 x 10 tiles with 2 / 4 stages)
+        // width 32 (the reference's default --fno_hidden_dim): 4 x 8 tiles, four workgroups per (mode group, chunk)
         CFD_PROF("k_mixadj_wgrad", st);
-        launch_mixadj_wgrad<5, 5, 3, 2>((const float2*)xh, (const float2*)gh, (const float2*)w1, (const float2*)w2,
-                                        (float2*)gz, (float2*)ws, B, p->m1, p->m2, &nchunk, st);
+        if (Cin == 20)
+            launch_mixadj_wgrad<20, 5, 5, 3, 2>((const float2*)xh, (const float2*)gh, (const float2*)w1, (const float2*)w2,
+                                                (float2*)gz, (float2*)ws, B, p->m1, p->m2, &nchunk, st);
+        else
+            launch_mixadj_wgrad<32, 4, 8, 3, 4>((const float2*)xh, (const float2*)gh, (const float2*)w1, (const float2*)w2,
+                                                (float2*)gz, (float2*)ws, B, p->m1, p->m2, &nchunk, st);
     }
     CFD_LAUNCH_CHECK("cfd_spectral_mix_adj_wgrad(fused)");
     const long total = (long)Cin * Cout * M;

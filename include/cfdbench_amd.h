@@ -79,7 +79,7 @@ int cfd_spectral_wgrad(const cfd_plan* plan, const float* xh, const float* gh, f
 
 /* Both mode-domain consumers of the gradient modes gh in one call (autograd of compl_mul2d, fno2d.py:54-57,73-78):
  * gz = cfd_spectral_mix(gh, conj_t = 1) and gw{1,2} = cfd_spectral_wgrad(xh, gh).  One kernel launch for the pair
- * where the fused kernel applies (Cin == Cout == 20), the two calls above otherwise; same results either way up to
+ * where the fused kernel applies (Cin == Cout == 20 or 32), the two calls above otherwise; same results either way up to
  * fp32 summation order.  ws: cfd_spectral_wgrad_workspace_bytes() bytes.                                     */
 int cfd_spectral_mix_adj_wgrad(const cfd_plan* plan, const float* xh, const float* gh, const float* w1, const float* w2,
                                float* gz, float* gw1, float* gw2, void* ws, int B, int Cin, int Cout, void* stream);
