@@ -249,6 +249,34 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
                 const int f = STEM ? i - ss.in_chan : -1;
                 const int row0 = STEM ? px / ss.W : 0, col0 = STEM ? px - row0 * ss.W : 0;
                 const bool same_row = STEM && (ss.W % 8 == 0);
+                if constexpr (STEM && VEC4) {
+                    // Fast path (W % 8 == 0: the lane's 8 pixels share a row, col0 is a multiple of 8): every generated
+                    // column is either 8 contiguous floats (mask, grid_y) -> two 16-byte loads like the field channels,
+                    // or one value for all 8 pixels (grid_x, case parameter, ones) -> one load.  The per-pixel form
+                    // below costs up to 8 scalar loads per lane and column, in five divergent branches.
+                    if (same_row && (((uintptr_t)ss.mask | (uintptr_t)ss.gy) % 16) == 0) {
+                        const float* p8 = nullptr;
+                        const float* p1 = nullptr;
+                        float s = 0.f;
+                        if (i == Ci) s = 1.f;
+                        else if (f == 0) { if (ss.mask) p8 = ss.mask + (size_t)b * HW + px; else s = 1.f; }
+                        else if (f == 1) p1 = ss.gx + row0;
+                        else if (f == 2) p8 = ss.gy + col0;
+                        else if (f < 3 + ss.P) p1 = ss.cp + (size_t)b * ss.P + (f - 3);
+                        float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+                        if (p8) {
+                            if (px < HW) t0 = *reinterpret_cast<const float4*>(p8);
+                            if (px + 4 < HW) t1 = *reinterpret_cast<const float4*>(p8 + 4);
+                        } else {
+                            if (p1) s = *p1;
+                            if (px < HW) t0 = make_float4(s, s, s, s);
+                            if (px + 4 < HW) t1 = make_float4(s, s, s, s);
+                        }
+                        bv[c][0] = t0.x; bv[c][1] = t0.y; bv[c][2] = t0.z; bv[c][3] = t0.w;
+                        bv[c][4] = t1.x; bv[c][5] = t1.y; bv[c][6] = t1.z; bv[c][7] = t1.w;
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int pj = px + j;
