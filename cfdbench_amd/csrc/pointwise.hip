@@ -48,6 +48,72 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ inpu
     }
 }
 
+// Four pixels of one row per thread (W % 4 == 0, 16-byte aligned tensors): 16-byte loads / stores, and every weight read
+// from LDS (one ds_read_b128 = four output channels) is used for four pixels -- the one-pixel form above issues 240
+// 4-byte LDS reads per pixel and is bound by that, not by its 84 MB of output.
+template <int CP>
+__global__ __launch_bounds__(256) void k_stem_fwd4(const float* __restrict__ inputs, const float* __restrict__ mask,
+                                                   const float* __restrict__ cp, const float* __restrict__ gx,
+                                                   const float* __restrict__ gy, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                   int in_chan, int P, int C, int H, int W) {
+    static_assert(CP % 4 == 0, "k_stem_fwd4: output channels are read four at a time");
+    __shared__ __attribute__((aligned(16))) float s_w[32 * CP];  // [feature][out], zero padded
+    __shared__ __attribute__((aligned(16))) float s_b[CP];
+    const int F = in_chan + 3 + P;
+    for (int i = threadIdx.x; i < 32 * CP; i += blockDim.x) {
+        const int f = i / CP, o = i % CP;
+        s_w[i] = (f < F && o < C) ? w[o * F + f] : 0.f;
+    }
+    for (int i = threadIdx.x; i < CP; i += blockDim.x) s_b[i] = i < C ? bias[i] : 0.f;
+    __syncthreads();
+    const int HW = H * W, Q = HW / 4;
+    const long total = (long)B * Q;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / Q), p = (int)(idx - (long)b * Q) * 4;
+        const int row = p / W, col = p - row * W;
+        const int z0 = cfd_opaque(0);  // keeps the (loop-invariant) LDS weight reads from being hoisted into VGPRs
+        const float4* w4 = reinterpret_cast<const float4*>(s_w + z0);
+        float4 acc[CP];
+#pragma unroll
+        for (int o4 = 0; o4 < CP / 4; ++o4) {
+            const float4 bb = reinterpret_cast<const float4*>(s_b + z0)[o4];
+            acc[4 * o4] = make_float4(bb.x, bb.x, bb.x, bb.x);
+            acc[4 * o4 + 1] = make_float4(bb.y, bb.y, bb.y, bb.y);
+            acc[4 * o4 + 2] = make_float4(bb.z, bb.z, bb.z, bb.z);
+            acc[4 * o4 + 3] = make_float4(bb.w, bb.w, bb.w, bb.w);
+        }
+        auto add = [&](int f, const float4 v) {
+#pragma unroll
+            for (int o4 = 0; o4 < CP / 4; ++o4) {
+                const float4 ww = w4[f * (CP / 4) + o4];
+                const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float4& a = acc[4 * o4 + k];
+                    a.x = fmaf(wv[k], v.x, a.x);
+                    a.y = fmaf(wv[k], v.y, a.y);
+                    a.z = fmaf(wv[k], v.z, a.z);
+                    a.w = fmaf(wv[k], v.w, a.w);
+                }
+            }
+        };
+        for (int c = 0; c < in_chan; ++c)
+            add(c, *reinterpret_cast<const float4*>(inputs + ((size_t)b * in_chan + c) * HW + p));
+        add(in_chan, mask ? *reinterpret_cast<const float4*>(mask + (size_t)b * HW + p) : make_float4(1.f, 1.f, 1.f, 1.f));
+        const float gxv = gx[row];
+        add(in_chan + 1, make_float4(gxv, gxv, gxv, gxv));
+        add(in_chan + 2, *reinterpret_cast<const float4*>(gy + col));
+        for (int k = 0; k < P; ++k) {
+            const float c1 = cp[(size_t)b * P + k];
+            add(in_chan + 3 + k, make_float4(c1, c1, c1, c1));
+        }
+#pragma unroll
+        for (int o = 0; o < CP; ++o)
+            if (o < C) *reinterpret_cast<float4*>(out + ((size_t)b * C + o) * HW + p) = acc[o];
+    }
+}
+
 extern "C" int cfd_fno_stem_fwd(const cfd_plan* p, const float* inputs, const float* mask, const float* case_params,
                                 const float* w, const float* bias, float* out, int B, int in_chan, int P, int C,
                                 void* stream) {
@@ -64,7 +130,21 @@ extern "C" int cfd_fno_stem_fwd(const cfd_plan* p, const float* inputs, const fl
 #define CFD_STEM(CPV)                                                                                              \
     hipLaunchKernelGGL((k_stem_fwd<CPV>), dim3(blocks), dim3(256), 0, st, inputs, mask, case_params,               \
                        (const float*)p->d_gx, (const float*)p->d_gy, w, bias, out, B, in_chan, P, C, p->H, p->W)
-    if (C <= 8) CFD_STEM(8);
+    const bool v4 = p->W % 4 == 0 && (((uintptr_t)inputs | (uintptr_t)mask | (uintptr_t)out | (uintptr_t)p->d_gy) % 16) == 0;
+    if (v4) {
+        const long quads = total / 4;
+        int blocks4 = (int)((quads + 255) / 256);
+        if (blocks4 > 2048) blocks4 = 2048;
+#define CFD_STEM4(CPV)                                                                                             \
+    hipLaunchKernelGGL((k_stem_fwd4<CPV>), dim3(blocks4), dim3(256), 0, st, inputs, mask, case_params,             \
+                       (const float*)p->d_gx, (const float*)p->d_gy, w, bias, out, B, in_chan, P, C, p->H, p->W)
+        if (C <= 8) CFD_STEM4(8);
+        else if (C <= 16) CFD_STEM4(16);
+        else if (C <= 24) CFD_STEM4(24);
+        else CFD_STEM4(32);
+#undef CFD_STEM4
+    }
+    else if (C <= 8) CFD_STEM(8);
     else if (C <= 16) CFD_STEM(16);
     else if (C <= 24) CFD_STEM(24);
     else CFD_STEM(32);
