@@ -39,6 +39,7 @@ _Z = C.c_size_t
 _SIGS = {
     "cfd_version": (C.c_int, []),
     "cfd_last_error": (C.c_char_p, []),
+    "cfd_tune_set": (_I, [C.c_char_p, _I]),
     "cfd_prof_begin": (_I, []),
     "cfd_prof_end": (_I, [C.c_char_p, _Z]),
     "cfd_plan_create": (_I, [_I, _I, _I, _I, C.POINTER(_P)]),

@@ -21,11 +21,6 @@
 #include "cfd_common.h"
 #include "cfd_tail.h"
 
-#ifndef CFD_EXP
-#define CFD_EXP 0  // dev timing switches: k_block 1 skips the inverse transform, 2 the channel mix, 4 the input GELU;
-                   // k_dft_fwd64_b3 8 skips both contraction stages (streaming skeleton)
-#endif
-
 #define CFD_WAVES 4  // waves per workgroup (256 threads)
 #define CFD_DFT_OS (2 * 15 * 16)  // complex modes of one image, m1 <= 15, m2 <= 16
 
@@ -305,16 +300,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64_b3(const float*
         }
         // ---- stage 1: a1c[j] / a1s[j] = cosine / sine sums over the rows, for the lane's column 4n + j ----
         f32x4 a1c[NJ], a1s[NJ];
-        if (CFD_EXP & 8) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                float acc = ny[j];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc += e8[j][k] + o8[j][k];
-                a1c[j] = f32x4{acc, acc, acc, acc};
-                a1s[j] = a1c[j];
-            }
-        } else {
+        {
             const int lo = cfd_opaque(lane);
             const bf16x8 tch = s_tab3[lo], tcl = s_tab3[64 + lo];
             const bf16x8 tsh = s_tab3[128 + lo], tsl = s_tab3[192 + lo];
@@ -338,9 +324,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64_b3(const float*
         }
         // ---- stage 2: sums over the columns; k-slot (q, v = 4jj + r) of half h is column 4(4q+r) + 2h + jj ----
         f32x4 Pc = zero, Ps = zero, Qc = zero, Qs = zero;
-        if (CFD_EXP & 8) {
-            Pc = a1c[0]; Ps = a1s[1]; Qc = a1c[2]; Qs = a1s[3];
-        } else {
+        {
             const int lo = cfd_opaque(lane);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -668,10 +652,10 @@ __global__ __launch_bounds__(512) void k_mix_lds(const float2* __restrict__ xin,
 }
 
 // Waves (= groups of 8 batch entries) per k_mix_lds workgroup: as many as keep >= 128 workgroups in the grid (the
-// weight fill is per workgroup); 0 = use the lane = mode kernel.  CFD_MIX_NWV overrides it (tests, timing experiments).
+// weight fill is per workgroup); 0 = use the lane = mode kernel.  The mix_nwv knob (tune.cpp) overrides it.
 static int cfd_mix_lds_waves(int B, int nmg) {
-    if (const char* e = getenv("CFD_MIX_NWV")) {
-        const int v = atoi(e);
+    {
+        const int v = cfd_tune_get(CFD_TUNE_MIX_NWV);
         if (v >= 0 && v <= 8) return v;  // 0: use the lane = mode kernel
     }
     // The weight fill + barrier cost k_mix_lds a fixed ~5 us that the lane = mode kernel does not pay; its per-entry cost
@@ -840,10 +824,9 @@ static void launch_spec_wgrad(const float2* xh, const float2* gh, float2* part, 
 // are summed by recursive halving (xor 32, 16, 8: each step exchanges half of the remaining accumulators), after
 // which every lane holds ~IT*OT/8 finished sums and the partial tile leaves in 64-B runs.  Workgroup ids are mapped
 // so that the two 8-mode groups sharing each 128-B line run on the same XCD (same L2) back to back.
-static int cfd_wgrad_want_wg() {  // workgroups aimed at; CFD_WGRAD_WG overrides it, read per call (the tests shrink it to
-                                  // reach the multi-step loops at small batch sizes)
-    const char* e = getenv("CFD_WGRAD_WG");
-    const int v = e ? atoi(e) : 256;
+static int cfd_wgrad_want_wg() {  // workgroups aimed at; the wgrad_wg knob overrides it (the tests shrink it to reach the
+                                  // multi-step loops at small batch sizes)
+    const int v = cfd_tune_get(CFD_TUNE_WGRAD_WG);
     return v >= 1 ? v : 256;
 }
 static inline void cfd_wgrad_tile_geometry(int B, int M, int* nmg, int* npair, int* BC, int* nchunk) {
@@ -1065,9 +1048,8 @@ extern "C" int cfd_spectral_wgrad(const cfd_plan* p, const float* xh, const floa
 
 // Adjoint mode mixing (gz = sum_o conj(W[i,o]) gh[b,o]) and the spectral weight gradient of the same gradient modes.
 // One launch for both where the fused kernel applies (Cin == Cout == 20 or 32), the two stand-alone entry points otherwise.
-static bool cfd_fused_disabled() {  // CFD_FUSED_VARIANT=0: two launches (tests compare both routes)
-    const char* e = getenv("CFD_FUSED_VARIANT");
-    return e && atoi(e) == 0;
+static bool cfd_fused_disabled() {  // fused_variant knob = 0: two launches (tests compare both routes)
+    return cfd_tune_get(CFD_TUNE_FUSED_VARIANT) == 0;
 }
 
 template <int C, int IT, int OT, int NS, int NSPLIT>
@@ -1579,7 +1561,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float4 v = r[k];
-            if constexpr (ACT && !(CFD_EXP & 4)) cfd_gelu4(v.x, v.y, v.z, v.w);
+            if constexpr (ACT) cfd_gelu4(v.x, v.y, v.z, v.w);
             if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
             s_src[((buf * NW + wave) * 16 + 4 * k + q) * 16 + n] = v;
         }
@@ -1635,7 +1617,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                 if (c == NCH - 1) fetch_ap(t, 1, AP[1]);
             }
             // inverse transform of destination channel dd = c (spread over the chunks so MFMA and VALU work interleave)
-            if (!(CFD_EXP & 1) && c < DPW && wave + c * NW < Cd) {
+            if (c < DPW && wave + c * NW < Cd) {
                 float va[2][8];
                 idft_gather(s_z + (wave * DPW + (c < DPW ? c : 0)) * CFD_BLK_ZS, m1, m2, SA, q, n, va);
                 idft_tile_b3<NJ>(idft_split(va), s_tab3 + 2 * t * 64, tb3, lane, acc[c < DPW ? c : 0]);
@@ -1644,7 +1626,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                 if (c == NCH - 1) {
 #pragma unroll
                     for (int dd = NCH; dd < DPW; ++dd) {
-                        if (!(CFD_EXP & 1) && wave + dd * NW < Cd) {
+                        if (wave + dd * NW < Cd) {
                             float va[2][8];
                             idft_gather(s_z + (wave * DPW + dd) * CFD_BLK_ZS, m1, m2, SA, q, n, va);
                             idft_tile_b3<NJ>(idft_split(va), s_tab3 + 2 * t * 64, tb3, lane, acc[dd]);
@@ -1664,7 +1646,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                 };
                 lds_fetch(0, v[0], wq[0]);
 #pragma unroll 1
-                for (int sl = 0; sl < ((CFD_EXP & 2) ? 1 : NW); ++sl) {  // rolled: registers rotate, one channel of LDS reads in flight
+                for (int sl = 0; sl < NW; ++sl) {  // rolled: registers rotate, one channel of LDS reads in flight
                     const int sn = sl + 1 < NW ? sl + 1 : sl;
                     lds_fetch(sn, v[1], wq[1]);
                     float wd[WS];

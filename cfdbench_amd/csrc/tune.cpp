@@ -1,0 +1,45 @@
+// Process-wide dispatch overrides (which kernel variant a launch helper picks).  The environment is read ONCE, the
+// first time any knob is looked up (the first versions called getenv() on every launch); afterwards cfd_tune_set() is
+// the only way to change a knob (tests and timing tools use it to reach every route).  -1 = the built-in choice.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "cfd_common.h"
+
+namespace {
+struct Knob {
+    const char* name;
+    const char* env;
+    std::atomic<int> value;
+};
+Knob g_knobs[CFD_TUNE_COUNT] = {
+    {"mix_nwv", "CFD_MIX_NWV", {-1}},            // waves per k_mix_lds workgroup; 0 = the lane = mode kernel
+    {"wgrad_wg", "CFD_WGRAD_WG", {-1}},          // workgroups the tiled spectral weight gradient aims at
+    {"fused_variant", "CFD_FUSED_VARIANT", {-1}},  // 0 = adjoint mix and weight gradient as two launches
+    {"block_fuse", "CFD_BLOCK_FUSE", {-1}},      // 0 = FnoBlock backward without the fused 1x1 weight gradient
+};
+std::once_flag g_once;
+void read_env() {
+    for (auto& k : g_knobs)
+        if (const char* e = getenv(k.env)) k.value.store(atoi(e), std::memory_order_relaxed);
+}
+}  // namespace
+
+int cfd_tune_get(int which) {
+    std::call_once(g_once, read_env);
+    return g_knobs[which].value.load(std::memory_order_relaxed);
+}
+
+extern "C" int cfd_tune_set(const char* name, int value) {
+    CFD_REQUIRE(name != nullptr, CFD_ERR_INVALID_ARG, "cfd_tune_set: NULL name");
+    std::call_once(g_once, read_env);
+    for (auto& k : g_knobs)
+        if (strcmp(k.name, name) == 0) {
+            k.value.store(value, std::memory_order_relaxed);
+            return CFD_OK;
+        }
+    cfd_set_error("cfd_tune_set: unknown knob '%s'", name);
+    return CFD_ERR_INVALID_ARG;
+}

@@ -293,8 +293,10 @@ class FnoTrainEngine:
         self._graph = g
 
     def train_step_graph(self, inputs: Tensor, label: Tensor, case_params: Tensor, mask: Optional[Tensor] = None) -> Tensor:
-        if self._graph is None:
+        key = (*inputs.shape, case_params.shape[1], mask is not None)
+        if self._graph is None or key != getattr(self, "_graph_key", None):  # a new batch shape needs a new capture
             self.capture(inputs, label, case_params, mask)
+            self._graph_key = key
         for dst, src in zip(self._static, (inputs, label, case_params, mask)):
             if dst is not None and src is not dst:
                 dst.copy_(src, non_blocking=True)

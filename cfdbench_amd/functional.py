@@ -229,7 +229,10 @@ class FnoForwardFn(torch.autograd.Function):
         shape = FnoShape(B, H, W, in_chan, out_chan, P, C, L, m1, m2, head)
         flat = [(_creal(p.detach()) if p.is_complex() else _f32c(p.detach())) for p in params]
         pstruct = _param_struct([t.data_ptr() for t in flat], L)
-        training = any(ctx.needs_input_grad[5:])
+        # needs_input_grad reflects requires_grad whatever the grad mode is (and grad mode is always off inside
+        # Function.forward), so the caller passes torch.is_grad_enabled(): under no_grad / inference_mode the forward-only
+        # workspace is used and nothing is saved.
+        training = bool(cfg.get("grad_enabled", True)) and any(ctx.needs_input_grad[5:])
         ws = _bytes(api.size("cfd_fno_workspace_bytes", plan, ctypes.byref(shape), int(training)), inputs.device)
         preds = torch.empty((B, out_chan, H, W), dtype=torch.float32, device=inputs.device)
         sums = torch.empty(4, dtype=torch.float32, device=inputs.device) if label is not None else None
@@ -255,7 +258,9 @@ class FnoForwardFn(torch.autograd.Function):
         k += int(ctx.has_mask)
         label = head[k] if ctx.has_label else None
         L = ctx.cfg["num_layers"]
-        dev = inputs.device
+        if ctx.ws is None:
+            raise RuntimeError("Fno2d: backward called twice on the same graph -- the activations live in a workspace that "
+                               "the first backward pass consumed (retain_graph is not supported; run forward again)")
         if gpreds is None and gsums is None:
             return (None,) * (5 + len(flat))
         use_label = label is not None and gsums is not None

@@ -71,5 +71,8 @@ class Args:
         return "Args(" + ", ".join(f"{k}={getattr(self, k)!r}" for k in _FLAGS) + ")"
 
 
-def is_args_valid(args: Args) -> bool:  # args.py:372-378
-    return args.model in ("fno",) or True
+def is_args_valid(args: Args) -> None:
+    """Validate argument values (src/args.py:372-378): asserts, like the reference; the model name is left to
+    ``init_model``."""
+    assert any(key in args.data_name for key in ["poiseuille", "cavity", "karman", "tube", "dam", "cylinder"])
+    assert args.batch_size > 0

@@ -5,8 +5,12 @@ against label frame k, averaged over cases -> multistep_metrics.j
     python -m cfdbench_amd.harness.test_multistep --model fno --data dam_prop_bc_geo --infer_steps 200
 
 Cases are independent, so ``infer`` rolls ALL cases out as one batch (one launch sequence per step instead of one per
-case and step); ``infer_case`` keeps the reference's one-case entry point.  Metrics are reduced on the device and
-fetched once at the end instead of three ``.item()`` syncs per case and step.
+case and step) -- for models whose forward is per-sample in the mode they are in.  The reference never calls
+``model.eval()`` here (test_multistep.py:180-239) and rolls out one case at a time, so a U-Net's BatchNorm normalises
+with the statistics of that ONE case and a ResNet's dropout stays active; batching such a model in training mode would
+pool the statistics over the cases and change the metrics.  ``infer`` therefore falls back to the reference's per-case
+loop (``infer_case``) whenever the model holds BatchNorm / Dropout layers in training mode.  Metrics are reduced on the
+device and fetched once at the end instead of three ``.item()`` syncs per case and step.
 """
 from __future__ import annotations
 
@@ -43,14 +47,31 @@ def infer_case(model, case_features: Tensor, case_params: Tensor, infer_steps: i
                                    steps=infer_steps)
 
 
+def batch_dependent(model) -> bool:
+    """True when a batched forward differs from per-sample forwards: BatchNorm with batch statistics or active dropout."""
+    for m in model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training:
+            return True
+        if isinstance(m, torch.nn.Dropout) and m.training and m.p > 0:
+            return True
+    return False
+
+
 def infer(model, all_features: List[Tensor], all_case_params: List[Tensor], infer_steps: int) -> List[Dict[str, float]]:
-    """test_multistep.py:135-177 with the cases batched.  all_features[c]: (>=infer_steps, c+1, h, w) on the device."""
+    """test_multistep.py:135-177.  all_features[c]: (>=infer_steps, c+1, h, w) on the device.  The cases run as one batch
+    unless the model is batch-dependent in its current mode (see the module docstring), in which case they run one by one
+    exactly as in the reference."""
     n_cases = len(all_features)
     start = torch.stack([f[0, :-1] for f in all_features])          # (n, c, h, w)
     mask = torch.stack([f[0, -1] for f in all_features])            # (n, h, w)
     cps = torch.stack(list(all_case_params))                        # (n, p)
-    with torch.no_grad():
-        preds = model.generate_many(inputs=start, case_params=cps, mask=mask, steps=infer_steps)
+    if batch_dependent(model):
+        per_case = [infer_case(model, f, cp, infer_steps) for f, cp in zip(all_features, all_case_params)]
+        n_frames = len(per_case[0])
+        preds = [torch.cat([pc[k] for pc in per_case], dim=0) for k in range(n_frames)]
+    else:
+        with torch.no_grad():
+            preds = model.generate_many(inputs=start, case_params=cps, mask=mask, steps=infer_steps)
     sums = torch.empty(infer_steps, n_cases, 3, device=start.device)
     for step in range(infer_steps):
         lab = torch.stack([f[step, 0] * f[step, -1] for f in all_features])   # u channel of label frame `step`, masked

@@ -22,13 +22,15 @@ import torch.distributed as dist
 from torch.optim import Adam, lr_scheduler
 from torch.utils.data import DataLoader, Dataset, Subset
 
-from ..engine import shard_range, sync_gradients
+from ..engine import sync_gradients
 from ..models.base_model import CfdModel
 from ..models.deeponet import DeepONet
 from ..models.ffn import FfnModel
 from ..models.loss import loss_name_to_fn
 from .args import Args
 from .common import dump_json, get_output_dir, load_best_ckpt, plot_loss, plot_predictions
+from .dist_util import (average_buffers, broadcast_model_state, check_resume_state, init_distributed, rank_world,
+                        shard_indices)
 
 
 def collate_fn(batch: list, device: Optional[str] = "cuda"):
@@ -99,10 +101,9 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
     ``resume``: continue from ``train_state.pt`` (see harness/train_auto.py:train)."""
     rank, world = _rank_world()
     output_dir = Path(output_dir)
-    if world > 1:
-        perm = torch.randperm(len(train_data), generator=torch.Generator().manual_seed(0)).tolist()
-        a, b = shard_range(len(perm), rank, world)
-        train_data = Subset(train_data, perm[a:b])
+    if world > 1:  # equal shards: every rank runs the same number of steps
+        train_data = Subset(train_data, shard_indices(len(train_data), rank, world, batch_size))
+        broadcast_model_state(model)
     loader = DataLoader(train_data, batch_size=batch_size, collate_fn=collate_fn, shuffle=True, drop_last=world > 1)
     if rank == 0:
         output_dir.mkdir(exist_ok=True, parents=True)
@@ -115,6 +116,7 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
     state_path = output_dir / "train_state.pt"
     if resume and state_path.exists():
         state = torch.load(state_path, map_location="cpu", weights_only=False)
+        check_resume_state(state, fused=False, world=world)
         model.load_state_dict(torch.load(output_dir / state["ckpt"] / "model.pt", map_location="cpu"))
         optimizer.load_state_dict(state["optimizer"])
         scheduler.load_state_dict(state["scheduler"])
@@ -143,6 +145,8 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
             print("Time usage:", time.time() - ep_start_time)
             return all_train_losses + ep_train_losses
         scheduler.step()
+        if world > 1 and (ep + 1) % eval_interval == 0:
+            average_buffers(model)
         if (ep + 1) % eval_interval == 0 and rank == 0:
             ckpt_dir = output_dir / f"ckpt-{ep}"
             ckpt_dir.mkdir(exist_ok=True, parents=True)
@@ -217,24 +221,31 @@ def get_dataset(data_dir: Path, data_name: str, norm_props: bool, norm_bc: bool)
 
 def main(argv=None):
     args = Args().parse_args(argv)
-    print(args)
+    rank, world = init_distributed()  # one process per GPU under torch.distributed.run; (0, 1) otherwise
     output_dir = get_output_dir(args)
-    output_dir.mkdir(exist_ok=True, parents=True)
-    args.save(str(output_dir / "args.json"))
+    if rank == 0:
+        print(args)
+        output_dir.mkdir(exist_ok=True, parents=True)
+        args.save(str(output_dir / "args.json"))
     train_data, dev_data, test_data = get_dataset(Path(args.data_dir), args.data_name, bool(args.norm_props),
                                                   bool(args.norm_bc))
     model = init_model(args).cuda()
-    print(f"Model has {sum(p.numel() for p in model.parameters())} parameters")
+    if rank == 0:
+        print(f"Model has {sum(p.numel() for p in model.parameters())} parameters")
     if "train" in args.mode:
-        args.save(str(output_dir / "train_args.json"))
+        if rank == 0:
+            args.save(str(output_dir / "train_args.json"))
         train(model, train_data, dev_data, output_dir, batch_size=args.batch_size, lr=args.lr,
               lr_step_size=args.lr_step_size, lr_gamma=args.lr_gamma, num_epochs=args.num_epochs,
               eval_interval=args.eval_interval, log_interval=args.log_interval, plot_interval=args.plot_interval,
               resume=bool(args.resume))
-    if "test" in args.mode:
+    if "test" in args.mode and rank == 0:
         args.save(str(output_dir / "test_args.json"))
         load_best_ckpt(model, output_dir)
         test(model, data=test_data, output_dir=output_dir / "test", batch_size=1, plot_interval=10)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

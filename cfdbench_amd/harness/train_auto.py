@@ -27,12 +27,14 @@ from torch import Tensor
 from torch.optim import Adam, lr_scheduler
 from torch.utils.data import DataLoader, Subset
 
-from ..engine import FnoTrainEngine, shard_range, sync_gradients
+from ..engine import FnoTrainEngine, sync_gradients
 from ..models.base_model import AutoCfdModel
 from ..models.fno.fno2d import Fno2d
 from .args import Args
 from .autoregressive import init_model
 from .common import dump_json, get_output_dir, load_best_ckpt, plot, plot_loss, plot_predictions
+from .dist_util import (average_buffers, broadcast_model_state, check_resume_state, init_distributed, rank_world,
+                        shard_indices)
 
 
 def collate_fn(batch: list, device: Optional[str] = "cuda"):
@@ -52,10 +54,7 @@ def collate_fn(batch: list, device: Optional[str] = "cuda"):
     return out
 
 
-def _rank_world():
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
-    return 0, 1
+_rank_world = rank_world
 
 
 def evaluate(model: AutoCfdModel, data, output_dir: Path, batch_size: int = 2, plot_interval: int = 1,
@@ -130,10 +129,9 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
     reproducing the uninterrupted run step for step (same shuffles, same Adam state)."""
     rank, world = _rank_world()
     output_dir = Path(output_dir)
-    if world > 1:  # shard the frames: each rank owns a contiguous 1/world of a fixed permutation (SURVEY.md 8e)
-        perm = torch.randperm(len(train_data), generator=torch.Generator().manual_seed(0)).tolist()
-        a, b = shard_range(len(perm), rank, world)
-        train_data = Subset(train_data, perm[a:b])
+    if world > 1:  # shard the frames: every rank owns an equal, contiguous part of a fixed permutation (SURVEY.md 8e)
+        train_data = Subset(train_data, shard_indices(len(train_data), rank, world, batch_size))
+        broadcast_model_state(model)  # identical replicas (weights, BatchNorm statistics) before the first step
     if device_loader:  # SURVEY.md 8f-1: frames resident in HBM, batches gathered on the device (harness/data.py)
         from .data import DeviceBatchLoader
         base = train_data.dataset if isinstance(train_data, Subset) else train_data
@@ -159,7 +157,10 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
     state_path = output_dir / "train_state.pt"
     if resume and state_path.exists():
         state = torch.load(state_path, map_location="cpu", weights_only=False)
+        check_resume_state(state, fused=engine is not None, world=world)
         model.load_state_dict(torch.load(output_dir / state["ckpt"] / "model.pt", map_location="cpu"))
+        if hasattr(model, "load_extra_train_state") and state.get("model_extra") is not None:
+            model.load_extra_train_state(state["model_extra"])  # e.g. ResNet's dropout step counter
         if engine is not None:
             engine.load_state_dict(state["optimizer"])
         else:
@@ -210,6 +211,8 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
             print("Time usage:", time.time() - ep_start_time)
             return
         train_losses += ep_train_losses
+        if world > 1 and (ep + 1) % eval_interval == 0:
+            average_buffers(model)  # BatchNorm running statistics of all shards go into the checkpoint
         if (ep + 1) % eval_interval == 0 and rank == 0:
             ckpt_dir = output_dir / f"ckpt-{ep}"
             ckpt_dir.mkdir(exist_ok=True, parents=True)
@@ -232,7 +235,8 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
             tmp = output_dir / "train_state.pt.tmp"
             torch.save(dict(ep=ep, global_step=global_step, train_losses=train_losses, ckpt=ckpt_dir.name,
                             optimizer=opt_state, scheduler=None if engine is not None else scheduler.state_dict(),
-                            rng=torch.get_rng_state(), fused=engine is not None, world=world), tmp)
+                            rng=torch.get_rng_state(), fused=engine is not None, world=world,
+                            model_extra=model.extra_train_state() if hasattr(model, "extra_train_state") else None), tmp)
             tmp.replace(state_path)
         if world > 1:
             dist.barrier()
@@ -245,28 +249,35 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
 def main(argv=None):
     from .data import get_auto_dataset
     args = Args().parse_args(argv)
-    print("#" * 80)
-    print(args)
-    print("#" * 80)
+    rank, world = init_distributed()  # one process per GPU under torch.distributed.run; (0, 1) otherwise
     output_dir = get_output_dir(args, is_auto=True)
-    output_dir.mkdir(exist_ok=True, parents=True)
-    args.save(str(output_dir / "args.json"))
+    if rank == 0:
+        print("#" * 80)
+        print(args)
+        print("#" * 80)
+        output_dir.mkdir(exist_ok=True, parents=True)
+        args.save(str(output_dir / "args.json"))
     train_data, dev_data, test_data = get_auto_dataset(
         data_dir=Path(args.data_dir), data_name=args.data_name, delta_time=args.delta_time,
         norm_props=bool(args.norm_props), norm_bc=bool(args.norm_bc))
     model = init_model(args).cuda()  # the reference forgets .cuda() for FNO
-    print(f"Model has {sum(p.numel() for p in model.parameters())} parameters")
+    if rank == 0:
+        print(f"Model has {sum(p.numel() for p in model.parameters())} parameters")
     if "train" in args.mode:
-        args.save(str(output_dir / "train_args.json"))
+        if rank == 0:
+            args.save(str(output_dir / "train_args.json"))
         train(model, train_data=train_data, dev_data=dev_data, output_dir=output_dir, lr=args.lr,
               lr_step_size=args.lr_step_size, lr_gamma=args.lr_gamma, num_epochs=args.num_epochs,
               batch_size=args.batch_size, eval_batch_size=args.eval_batch_size, eval_interval=args.eval_interval,
               log_interval=args.log_interval, fused=bool(args.fused), plot_interval=args.plot_interval,
               resume=bool(args.resume), device_loader=bool(args.device_loader))
-    if "test" in args.mode:
+    if "test" in args.mode and rank == 0:  # the test split is small: rank 0 evaluates it alone
         args.save(str(output_dir / "test_args.json"))
         load_best_ckpt(model, output_dir)
         test(model, test_data, output_dir / "test", batch_size=1, infer_steps=20, plot_interval=10)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

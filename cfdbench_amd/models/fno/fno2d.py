@@ -101,7 +101,8 @@ class Fno2d(AutoCfdModel):
         {"preds": (b,c,h,w)[, "loss": {mse,rmse,mae[,nmse]}]}   (fno2d.py:178-242)."""
         if mask is not None and mask.dim() == 3:  # fno2d.py:193-194
             mask = mask.unsqueeze(1)
-        preds, sums = F_.FnoForwardFn.apply(self.abi_config(), inputs, case_params, mask, label, *self.abi_parameters())
+        cfg = dict(self.abi_config(), grad_enabled=torch.is_grad_enabled())
+        preds, sums = F_.FnoForwardFn.apply(cfg, inputs, case_params, mask, label, *self.abi_parameters())
         if label is not None:
             normalize = bool(getattr(self.loss_fn, "normalize", True))
             return dict(preds=preds, loss=F_.scores_from_sums(sums, normalize))

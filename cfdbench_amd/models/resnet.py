@@ -28,14 +28,25 @@ class ResidualBlock(nn.Module):
         self.conv2 = nn.Conv2d(hidden_chan, out_chan, kernel_size, stride, padding, bias=bias, padding_mode="replicate")
         self.bn2 = nn.BatchNorm2d(out_chan)
         self.res_conv = nn.Conv2d(in_chan, out_chan, kernel_size=1, stride=stride, padding=0, bias=bias) if use_1x1conv else None
-        self._calls = 0
+        # Dropout stream: seed = mix(torch.initial_seed(), block index, step).  ResNet sets block_idx at construction and
+        # drop_step before every training forward; both are reproducible from --seed and the step counter is part of the
+        # saved training state (harness: train_state.pt), so a resumed run draws the masks the uninterrupted run would.
+        self.block_idx = 0
+        self.drop_step = 0
+
+    @staticmethod
+    def _mix64(x: int) -> int:  # splitmix64 finaliser
+        x &= 0xFFFFFFFFFFFFFFFF
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return x ^ (x >> 31)
 
     def forward(self, x: Tensor) -> Tensor:
         residual = x if self.res_conv is None else F_.Conv2dReplicateFn.apply(x, self.res_conv.weight, self.res_conv.bias)
         x = F_.Conv2dReplicateFn.apply(x, self.conv1.weight, self.conv1.bias)
         if self.training and self.dropout.p > 0:
-            self._calls += 1
-            seed = (torch.initial_seed() * 1000003 + id(self) % 65521 * 7919 + self._calls) & 0xFFFFFFFFFFFF
+            seed = self._mix64(self._mix64(torch.initial_seed()) + 0x9E3779B97F4A7C15 * (self.block_idx + 1)
+                               + self.drop_step) & 0xFFFFFFFFFFFF
             x = F_.DropoutFn.apply(x, self.dropout.p, seed)
         x = F_.GeluFn.apply(x)
         x = F_.Conv2dReplicateFn.apply(x, self.conv2.weight, self.conv2.bias)
@@ -55,6 +66,9 @@ class ResNet(AutoCfdModel):
             blocks.append(ResidualBlock(hidden_chan, hidden_chan, 64, kernel_size, stride, padding, use_1x1conv=False))
         blocks.append(ResidualBlock(hidden_chan, out_chan, 64, kernel_size, stride, padding, use_1x1conv=True))
         self.blocks = nn.Sequential(*blocks)
+        for i, blk in enumerate(self.blocks):
+            blk.block_idx = i
+        self._train_steps = 0  # training-mode forwards so far: the dropout stream's step counter
 
     def forward(self, inputs: Tensor, case_params: Tensor, mask: Optional[Tensor] = None, label: Optional[Tensor] = None) -> dict:
         """inputs (B,c,h,w), case_params (B,p), mask (B,h,w)|(B,1,h,w), label (B,c,h,w)  (resnet.py:145-198)."""
@@ -65,12 +79,23 @@ class ResNet(AutoCfdModel):
         elif mask.dim() == 3:
             mask = mask.unsqueeze(1)
         cp = case_params.unsqueeze(-1).unsqueeze(-1).expand(-1, -1, height, width)
+        if self.training:
+            self._train_steps += 1
+            for blk in self.blocks:
+                blk.drop_step = self._train_steps
         x = self.blocks(torch.cat([inputs, mask, cp], dim=1))
         preds = F_.ResidualMaskFn.apply(x, residual, mask)  # (blocks + inputs[:, :out_chan]) * mask
         if label is not None:
             label = F_.ResidualMaskFn.apply(label, None, mask)
             return dict(preds=preds, loss=self.loss_fn(preds=preds, labels=label))
         return dict(preds=preds)
+
+    # ---- training state beyond the state_dict (kept out of it: the reference's checkpoint keys must not change) ----
+    def extra_train_state(self) -> dict:
+        return dict(train_steps=int(self._train_steps))
+
+    def load_extra_train_state(self, state: dict) -> None:
+        self._train_steps = int(state.get("train_steps", 0))
 
     def generate(self, inputs: Tensor, case_params: Tensor, mask: Optional[Tensor] = None):
         return self.forward(inputs, case_params=case_params, mask=mask)["preds"]

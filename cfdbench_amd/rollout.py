@@ -65,7 +65,15 @@ class FnoRollout:
 
     @torch.no_grad()
     def generate_many(self, inputs: Tensor, case_params: Tensor, mask: Optional[Tensor], steps: int) -> List[Tensor]:
-        """Same argument conventions as Fno2d.generate_many (unbatched inputs get a batch dimension)."""
+        """Same argument conventions and return value as Fno2d.generate_many (unbatched inputs get a batch dimension):
+        ``steps`` frames, copied out of the graph's frame buffer in ONE device copy."""
+        frames = self.generate_frames(inputs, case_params, mask, steps)
+        return list(frames[1:].clone().unbind(0))
+
+    @torch.no_grad()
+    def generate_frames(self, inputs: Tensor, case_params: Tensor, mask: Optional[Tensor], steps: int) -> Tensor:
+        """The rollout as the graph's own (steps + 1, B, c, H, W) frame buffer (frame 0 = the input): no copy at all.  The
+        buffer is overwritten by the next call with the same shapes."""
         assert len(inputs.shape) == len(case_params.shape) + 2
         if inputs.dim() == 3:
             inputs, case_params = inputs.unsqueeze(0), case_params.unsqueeze(0)
@@ -85,4 +93,4 @@ class FnoRollout:
         if mask is not None:
             st["mask"].copy_(mask)
         st["graph"].replay()
-        return [st["frames"][t + 1].clone() for t in range(steps)]
+        return st["frames"]

@@ -39,6 +39,14 @@ extern "C" {
 int cfd_version(void);
 const char* cfd_last_error(void);
 
+/* Dispatch overrides for tests and timing tools: which kernel variant a launch helper picks.  Knobs: "mix_nwv" (waves per
+ * LDS-weight mixing workgroup, 0 = the lane = mode kernel), "wgrad_wg" (workgroups the tiled spectral weight gradient
+ * aims at), "fused_variant" (0 = adjoint mix and spectral weight gradient as two launches), "block_fuse" (0 = the 1x1
+ * weight gradient of a FnoBlock as its own kernel).  value -1 restores the built-in choice.  The environment variables
+ * CFD_MIX_NWV / CFD_WGRAD_WG / CFD_FUSED_VARIANT / CFD_BLOCK_FUSE are read once per process, at the first launch.  Every
+ * route computes the same function (the reference has no such switch: it has one ATen call per op).                */
+int cfd_tune_set(const char* name, int value);
+
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  cfd_prof_end synchronises and
  * writes "kernel_name launches total_ms\n" lines into buf.  Do not enable during stream capture.               */
 int cfd_prof_begin(void);

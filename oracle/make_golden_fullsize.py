@@ -1,0 +1,142 @@
+"""Golden fixtures at the BASELINE.json sizes, from the REAL reference modules (imported from /root/reference/src).
+
+Run in the build container only (the GPU box has no /root/reference):
+    python oracle/make_golden_fullsize.py [name ...]
+The fixtures keep seeds + fingerprints (norm, sum, sampled entries) instead of full tensors wherever a tensor is large
+(B = 256 predictions, the 1.1 M U-Net gradients, the 4295 x 100 branch weights): inputs and weights are regenerated in
+the tests from the NumPy streams of oracle/synth.py.
+
+  fno_cfg2_b256          Fno2d(hidden 20, L 4, modes 12, p 5), B = 256, 64x64: BASELINE configs[1]    fno2d.py:178-242
+  fno_cyl_p8_64x64       the same network with the 8 case parameters of the cylinder problem (13 input features)
+  unet_dim12_p8_64x64    UNet(dim 12, input-insert, p 8), 64x64, train-mode BatchNorm: configs[2]       unet.py:153-223
+  auto_deeponet_66x65    AutoDeepONet(branch 4295, width 100, depth 8/8, relu), 66x65: configs[3]       auto_deeponet.py:76-147
+  rollout200_c32_66x65   Fno2d(hidden 32, L 4) generate_many, 200 steps, 66x65, border mask: configs[4]  fno2d.py:269-295
+"""
+from __future__ import annotations
+
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, "/root/reference/src")
+
+from models.fno.fno2d import Fno2d  # noqa: E402  (reference)
+from models.loss import MseLoss  # noqa: E402  (reference)
+
+from oracle import synth  # noqa: E402
+
+OUT = REPO / "tests" / "golden"
+ROLLOUT_KEEP = (0, 1, 4, 19, 49, 99, 149, 199)  # frames stored in full by the 200-step fixture
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _grad_fingerprints(model, save, n=64):
+    for k, prm in model.named_parameters():
+        if prm.grad is None:
+            continue
+        for kk, vv in synth.summarize(prm.grad.numpy(), 7, n=n).items():
+            save[f"gsum::{k}::{kk}"] = vv
+
+
+def gen_fno_big(name, pseed, bseed, B, C, L, H, W, p):
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p)
+    batch = synth.make_batch(bseed, B, H, W, p)
+    model = Fno2d(2, 2, p, MseLoss(normalize=True), L, 12, 12, C)
+    model.load_state_dict({k: _t(v) for k, v in params.items()})
+    out = model(**{k: _t(v) for k, v in batch.items()})
+    out["loss"]["nmse"].backward()
+    preds = out["preds"].detach().numpy()
+    save = dict(meta=np.array([pseed, bseed, B, C, L, H, W, p]),
+                preds_sample_norms=np.sqrt((preds.astype(np.float64) ** 2).sum(axis=(1, 2, 3))),
+                preds_first=preds[:2], **{f"loss_{k}": v.detach().numpy() for k, v in out["loss"].items()})
+    for kk, vv in synth.summarize(preds, 11, n=4096).items():
+        save[f"psum::{kk}"] = vv
+    _grad_fingerprints(model, save, n=1024)
+    np.savez_compressed(OUT / f"{name}.npz", **save)
+    print(name, "ok", {k: float(v.detach()) for k, v in out["loss"].items()})
+
+
+def gen_unet_big(name, seed, bseed, B, H, W, dim, p):
+    from models.unet import UNet  # reference
+    model = UNet(2, 2, MseLoss(normalize=True), p, insert_case_params_at="input", bilinear=False, dim=dim)
+    sd = synth.make_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed)
+    model.load_state_dict({k: _t(v) for k, v in sd.items()})
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    batch["mask"][:, :, 0, :] = 0
+    batch["mask"][:, :, :, 0] = 0
+    model.train()
+    out = model(inputs=_t(batch["inputs"]), case_params=_t(batch["case_params"]), mask=_t(batch["mask"]), label=_t(batch["label"]))
+    out["loss"]["nmse"].backward()
+    save = dict(meta=np.array([seed, bseed, B, H, W, dim, p]), n_keys=np.array(len(sd)),
+                preds_train=out["preds"].detach().numpy(), **{f"loss_{k}": np.array(v.item()) for k, v in out["loss"].items()})
+    _grad_fingerprints(model, save, n=256)
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            save[f"after::{k}"] = v.numpy()
+    model.eval()
+    with torch.no_grad():
+        save["preds_eval"] = model(inputs=_t(batch["inputs"]), case_params=_t(batch["case_params"]), mask=_t(batch["mask"]))["preds"].numpy()
+    np.savez_compressed(OUT / f"{name}.npz", **save)
+    print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
+
+
+def gen_auto_deeponet_big(name, pseed, bseed, B, H, W, width, depth, p):
+    from models.auto_deeponet import AutoDeepONet  # reference
+    from oracle import deeponet_oracle as D
+    params = D.make_params(pseed, H * W + p, width, depth, depth)
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    model = AutoDeepONet(H * W + p, 2, MseLoss(normalize=True), branch_depth=depth, trunk_depth=depth, width=width, act_name="relu")
+    model.load_state_dict({k: _t(v) for k, v in params.items()})
+    out = model(inputs=_t(batch["inputs"]), case_params=_t(batch["case_params"]), label=_t(batch["label"]), mask=_t(batch["mask"]))
+    out["loss"]["nmse"].backward()
+    save = dict(meta=np.array([pseed, bseed, B, H, W, width, depth, p]), preds=out["preds"].detach().numpy(),
+                **{f"loss_{k}": np.array(v.item()) for k, v in out["loss"].items()})
+    _grad_fingerprints(model, save)
+    model.eval()
+    with torch.no_grad():
+        frames = model.generate_many(_t(batch["inputs"][:2]), _t(batch["case_params"][:2]), _t(batch["mask"][:2]), 3)
+    save["frames"] = np.stack([f.numpy() for f in frames])
+    np.savez_compressed(OUT / f"{name}.npz", **save)
+    print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
+
+
+def gen_rollout200(name, pseed, bseed, B, C, L, H, W, steps, p=5, eps=0.05, gain=30.0, decay=0.04):
+    params, batch = synth.make_rollout_case(pseed, bseed, B, C, L, H, W, p, eps, gain, decay)
+    model = Fno2d(2, 2, p, MseLoss(normalize=True), L, 12, 12, C).eval()
+    model.load_state_dict({k: _t(v) for k, v in params.items()})
+    with torch.no_grad():
+        frames = model.generate_many(_t(batch["inputs"]), _t(batch["case_params"]), _t(batch["mask"]), steps)
+    frames = np.stack([f.numpy() for f in frames])  # (steps, B, 2, H, W)
+    keep = [k for k in ROLLOUT_KEEP if k < steps]
+    np.savez_compressed(OUT / f"{name}.npz", meta=np.array([pseed, bseed, B, C, L, H, W, p, steps]),
+                        hyper=np.array([eps, gain, decay]), keep=np.array(keep), frames=frames[keep],
+                        norms=np.sqrt((frames.astype(np.float64) ** 2).mean(axis=(1, 2, 3, 4))))
+    print(name, "ok", frames.shape, "rms of frames 0 / 99 / 199:", [float(np.sqrt((frames[k] ** 2).mean())) for k in (0, 99, steps - 1)])
+
+
+GENERATORS = {
+    "fno_cfg2_b256": lambda: gen_fno_big("fno_cfg2_b256", 201, 211, 256, 20, 4, 64, 64, 5),
+    "fno_cyl_p8_64x64": lambda: gen_fno_big("fno_cyl_p8_64x64", 202, 212, 3, 20, 4, 64, 64, 8),
+    "unet_dim12_p8_64x64": lambda: gen_unet_big("unet_dim12_p8_64x64", 203, 213, 4, 64, 64, 12, 8),
+    "auto_deeponet_66x65": lambda: gen_auto_deeponet_big("auto_deeponet_66x65", 204, 214, 8, 66, 65, 100, 8, 5),
+    "rollout200_c32_66x65": lambda: gen_rollout200("rollout200_c32_66x65", 205, 215, 2, 32, 4, 66, 65, 200),
+}
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    for name in (sys.argv[1:] or list(GENERATORS)):
+        GENERATORS[name]()
+
+
+if __name__ == "__main__":
+    main()

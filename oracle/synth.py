@@ -54,6 +54,98 @@ def make_fno_params(seed: int, C: int = 20, L: int = 4, m1: int = 12, m2: int = 
     return out
 
 
+def make_fno_propagator_params(seed: int, C: int = 20, L: int = 4, m1: int = 12, m2: int = 12, p: int = 5, eps: float = 0.05,
+                               spectral_gain: float = 1.0, signal: float = 1.0, decay: float = 0.0,
+                               dtype=np.float32) -> Dict[str, np.ndarray]:
+    """Weights that make Fno2d a NEAR-IDENTITY map x_{t+1} = x_t + O(eps) -- a stand-in for a trained one-step propagator
+    in rollout studies (random-init weights collapse every input to one fixed point within five steps, so a 200-step
+    rollout of them exercises nothing).  Construction: gelu(x) - gelu(-x) = x exactly, so the pair of channels (+s u, -s u)
+    survives every GELU of the network when each following linear layer takes the difference of the pair:
+      fc0: ch0 = s u, ch1 = -s u, ch2 = s v, ch3 = -s v;  w0 of block 0 (no GELU before it): identity on those channels;
+      w0 of blocks >= 1: ch0' = h0 - h1, ch1' = h1 - h0, ... ;  fc1: hidden 0..3 likewise;  fc2: u' = (1 - decay) (g0 - g1) / s
+    (``decay`` balances the growth the random perturbation adds, so that 200-step rollouts stay O(1)).
+    Every other weight (incl. all biases and the spectral weights, which couple the pixels) is the usual random init
+    scaled by ``eps``.  Needs C >= 4."""
+    assert C >= 4
+    base = make_fno_params(seed, C, L, m1, m2, p, dtype=dtype, spectral_gain=spectral_gain)
+    out = {k: (v * eps).astype(v.dtype) for k, v in base.items()}
+    s = signal
+    sgn = np.array([1.0, -1.0])
+    for c in range(4):  # fc0 input features: [u, v, mask, grid_x, grid_y, props...]
+        out["fc0.weight"][c, :, 0, 0] *= 1.0
+        out["fc0.weight"][c, c // 2, 0, 0] += s * sgn[c % 2]
+    for l in range(L):
+        w = out[f"blocks.{l}.w0.weight"]
+        for c in range(4):
+            if l == 0:
+                w[c, c, 0, 0] += 1.0
+            else:
+                pair = 2 * (c // 2)
+                w[c, pair, 0, 0] += sgn[c % 2]
+                w[c, pair + 1, 0, 0] -= sgn[c % 2]
+    for c in range(4):
+        pair = 2 * (c // 2)
+        if L == 0:
+            out["fc1.weight"][c, c, 0, 0] += 1.0
+        else:
+            out["fc1.weight"][c, pair, 0, 0] += sgn[c % 2]
+            out["fc1.weight"][c, pair + 1, 0, 0] -= sgn[c % 2]
+    for o in range(2):
+        out["fc2.weight"][o, 2 * o, 0, 0] += (1.0 - decay) / s
+        out["fc2.weight"][o, 2 * o + 1, 0, 0] -= (1.0 - decay) / s
+    return out
+
+
+def make_state_dict(shapes, seed: int) -> Dict[str, np.ndarray]:
+    """Deterministic stand-in for a module's initial ``state_dict`` given its ordered (name, shape) list -- so that a golden
+    fixture of a LARGE model (U-Net dim 12: 1.1 M parameters) stores a seed instead of the weights.  Rules by name / rank:
+    num_batches_tracked -> 0 (int64); running_var -> 1 + U[0, 0.5); running_mean -> 0.1 N; 1-D ``weight`` (BatchNorm
+    gamma) -> 1 + 0.2 N; 1-D ``bias`` -> 0.1 N; 0-D / (1,) -> 0.03; everything else -> U(+-1/sqrt(fan_in)) with fan_in =
+    prod(shape[1:])."""
+    rng = np.random.default_rng(seed)
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in shapes:
+        shape = tuple(int(v) for v in shape)
+        if name.endswith("num_batches_tracked"):
+            out[name] = np.zeros(shape, np.int64)
+        elif name.endswith("running_var"):
+            out[name] = (1.0 + 0.5 * rng.random(shape)).astype(np.float32)
+        elif name.endswith("running_mean"):
+            out[name] = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        elif len(shape) == 0 or int(np.prod(shape)) == 1:
+            out[name] = np.full(shape, 0.03, np.float32)
+        elif len(shape) == 1 and name.endswith("weight"):
+            out[name] = (1.0 + 0.2 * rng.standard_normal(shape)).astype(np.float32)
+        elif len(shape) == 1:
+            out[name] = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        else:
+            bound = 1.0 / np.sqrt(float(np.prod(shape[1:])))
+            out[name] = rng.uniform(-bound, bound, size=shape).astype(np.float32)
+    return out
+
+
+def summarize(a: np.ndarray, idx_seed: int, n: int = 64) -> Dict[str, np.ndarray]:
+    """Compact fingerprint of a large tensor for a golden fixture: its l2 norm, its sum and ``n`` sampled entries."""
+    flat = np.ascontiguousarray(a).reshape(-1)
+    rng = np.random.default_rng(idx_seed)
+    idx = rng.integers(0, flat.size, size=min(n, flat.size))
+    return dict(norm=np.sqrt(np.sum(np.abs(flat.astype(np.complex128)) ** 2)), sum=flat.sum(dtype=np.complex128), idx=idx,
+                vals=flat[idx])
+
+
+def make_rollout_case(pseed: int, bseed: int, B: int, C: int, L: int, H: int, W: int, p: int, eps: float, gain: float,
+                      decay: float):
+    """Weights and start frame of the long-rollout fixtures / studies: the near-identity propagator above on a band-limited
+    field with the tube / dam style border mask (zero top / bottom rows and left column)."""
+    params = make_fno_propagator_params(pseed, C, L, 12, 12, p, eps=eps, spectral_gain=gain, decay=decay)
+    batch = make_smooth_batch(bseed, B, H, W, p)
+    batch["mask"][:, :, 0, :] = 0
+    batch["mask"][:, :, -1, :] = 0
+    batch["mask"][:, :, :, 0] = 0
+    batch["inputs"] = batch["inputs"] * batch["mask"]
+    return params, batch
+
+
 def make_batch(seed: int, B: int, H: int = 64, W: int = 64, p: int = 5, border_mask: bool = False,
                dtype=np.float32) -> Dict[str, np.ndarray]:
     """inputs=randn(B,2,H,W); label=inputs+0.1 randn; case_params=randn(B,p); mask=ones (cavity) or

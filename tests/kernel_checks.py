@@ -2,6 +2,7 @@
 Used by tests/test_emul_kernels.py (CPU, SIMT emulator) and tests/test_gpu_kernels.py (MI355X)."""
 from __future__ import annotations
 
+import contextlib
 import ctypes
 
 import numpy as np
@@ -21,6 +22,18 @@ c128 = np.complex128
 
 def nm(a, ref):
     return O.rel_nmse(a, ref)
+
+
+@contextlib.contextmanager
+def tuned(be, **knobs):
+    """Dispatch overrides (cfd_tune_set) for the duration of a check; -1 restores the built-in choice."""
+    for k, v in knobs.items():
+        be.api.call("cfd_tune_set", k.encode(), int(v))
+    try:
+        yield
+    finally:
+        for k in knobs:
+            be.api.call("cfd_tune_set", k.encode(), -1)
 
 
 def check_spectral(be, B, Cin, Cout, H, W, m1=12, m2=12, seed=0):

@@ -158,3 +158,69 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "_api", None)
     with pytest.raises(CfdError, match="no CPU/PyTorch fallback"):
         _lib.api()
+
+
+def test_shard_indices_give_every_rank_the_same_number_of_steps():
+    """with shards differing by one frame and drop_last, N = 31 / world 2 / batch 8 gave 2 steps on one rank and 1
+    on the other -- the extra gradient all-reduce then pairs with the other rank's barrier."""
+    from cfdbench_amd.harness.dist_util import shard_indices
+    for n, world, bs in [(31, 2, 8), (47, 2, 8), (256, 8, 16), (1000, 8, 16), (10, 4, 8), (7, 2, 1)]:
+        shards = [shard_indices(n, r, world, bs) for r in range(world)]
+        sizes = {len(s) for s in shards}
+        assert len(sizes) == 1, (n, world, bs, sizes)
+        assert len({len(s) // bs for s in shards}) == 1
+        flat = [i for s in shards for i in s]
+        assert len(flat) == len(set(flat)) and all(0 <= i < n for i in flat)
+        if n >= world * bs:
+            assert len(flat) == (n // (world * bs)) * world * bs and len(shards[0]) % bs == 0
+
+
+def _loop_worker(rank, world, port, n, bs, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch.utils.data import DataLoader, Subset, TensorDataset
+        from cfdbench_amd.harness.dist_util import average_buffers, broadcast_model_state, shard_indices
+        data = TensorDataset(torch.arange(n, dtype=torch.float32))
+        loader = DataLoader(Subset(data, shard_indices(n, rank, world, bs)), batch_size=bs, shuffle=True, drop_last=True)
+        model = torch.nn.Sequential(torch.nn.Linear(1, 1), torch.nn.BatchNorm1d(1))
+        with torch.no_grad():
+            model[0].weight.fill_(float(rank + 1))
+            model[1].running_mean.fill_(float(10 * rank))
+        broadcast_model_state(model)
+        w0, rm0 = float(model[0].weight), float(model[1].running_mean)
+        steps = 0
+        for _ in range(2):  # the epoch structure of harness/train_auto.py: one all-reduce per step, one barrier per epoch
+            for (x,) in loader:
+                t = x.sum().reshape(1)
+                dist.all_reduce(t)
+                steps += 1
+            dist.barrier()
+        with torch.no_grad():
+            model[1].running_mean.fill_(float(rank))
+        average_buffers(model)
+        q.put((rank, steps, w0, rm0, float(model[1].running_mean), int(model[1].num_batches_tracked)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_uneven_frame_count_runs_in_lockstep_gloo_world2():
+    """N % (world * batch) != 0: both ranks run the same number of steps (no collective is left unpaired), replicas start
+    from rank 0's weights and BatchNorm statistics, float buffers are averaged for the checkpoint."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, 31, 8, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == 2  # 31 frames -> 16 kept -> 8 per rank -> 1 step per epoch
+    assert res[0][2] == res[1][2] == 1.0 and res[0][3] == res[1][3] == 0.0  # rank 0's state everywhere
+    assert res[0][4] == res[1][4] == 0.5 and res[0][5] == res[1][5] == 0

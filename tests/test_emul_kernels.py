@@ -39,13 +39,12 @@ def test_mix_and_spectral_wgrad(be, B, Cin, Cout):
 
 
 @pytest.mark.parametrize("want_wg,nwv,B,C", [("36", "2", 27, 20), ("256", "1", 5, 32)])
-def test_mix_and_spectral_wgrad_multi_step(be, want_wg, nwv, B, C, monkeypatch):
+def test_mix_and_spectral_wgrad_multi_step(be, want_wg, nwv, B, C):
     """The batch-in-lanes kernels (k_mix_lds, k_spec_wgrad_tile, the fused k_mixadj_wgrad) at chunk sizes that reach
     the software-pipelined loops of the weight gradient (several 8-entry steps per workgroup, ragged last step) and
     several workgroup shapes of the mixing kernel, with a small batch."""
-    monkeypatch.setenv("CFD_MIX_NWV", nwv)
-    monkeypatch.setenv("CFD_WGRAD_WG", want_wg)
-    _assert_all(K.check_mix_wgrad(be, B, C, C))
+    with K.tuned(be, mix_nwv=int(nwv), wgrad_wg=int(want_wg)):
+        _assert_all(K.check_mix_wgrad(be, B, C, C))
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 20, 20, 64, 64), (1, 6, 7, 32, 64), (1, 3, 5, 66, 65), (1, 32, 12, 32, 64)])

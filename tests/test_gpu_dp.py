@@ -1,0 +1,102 @@
+"""MI355X: the data-parallel training step on the REAL engine.  Two processes share cuda:0 and exchange gradients through
+a host-staged (gloo) process group -- the only multi-rank set-up a 1-GPU box offers; on a multi-GPU node the same code
+runs over RCCL (backend "nccl").  What is checked is the engine's overlapped path: per-phase asynchronous all-reduce of
+slices of the flat gradient while later backward phases are still being enqueued (engine.forward_backward_overlapped)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+C, L, P, H, W, B_RANK, STEPS = 20, 2, 5, 64, 64, 4, 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make_model(torch):
+    from cfdbench_amd.models.fno.fno2d import Fno2d
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    params = synth.make_fno_params(301, C, L, 12, 12, P, spectral_gain=4.0)
+    m = Fno2d(2, 2, P, loss_name_to_fn("nmse"), L, 12, 12, C).cuda()
+    m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()})
+    return m
+
+
+def _batch(torch, step, rank, world):
+    b = synth.make_batch(311 + step, B_RANK * world, H, W, P, border_mask=True)
+    return {k: torch.from_numpy(v[rank * B_RANK:(rank + 1) * B_RANK].copy()).cuda() for k, v in b.items()}
+
+
+def _worker(rank, world, port, overlap, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cfdbench_amd.engine import FnoTrainEngine
+        eng = FnoTrainEngine(_make_model(torch), lr=1e-3, loss_name="nmse", overlap=overlap)
+        assert eng.sync.world == world
+        grads = []
+        for step in range(STEPS):
+            b = _batch(torch, step, rank, world)
+            eng.train_step(b["inputs"], b["label"], b["case_params"], b["mask"])
+            torch.cuda.synchronize()
+            grads.append(eng.flat.grad.cpu().numpy().copy())
+        q.put((rank, eng.flat.data.cpu().numpy().copy(), grads))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_world2(overlap):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return sorted(res, key=lambda r: r[0])
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_engine_train_step_world2_equals_ddp_emulation(overlap):
+    import torch
+    from cfdbench_amd.engine import FnoTrainEngine
+    assert torch.cuda.is_available()
+    res = _run_world2(overlap)
+    # single-process emulation of DistributedDataParallel on the concatenated batch: per-rank loss normaliser, the ranks'
+    # gradients summed, 1/world folded into the optimiser -- with the very same kernels
+    eng = FnoTrainEngine(_make_model(torch), lr=1e-3, loss_name="nmse")
+    for step in range(STEPS):
+        parts = []
+        for rank in range(2):
+            b = _batch(torch, step, rank, 2)
+            eng.forward_backward(b["inputs"], b["label"], b["case_params"], b["mask"])
+            parts.append(eng.flat.grad.clone())
+        eng.flat.grad.copy_(parts[0] + parts[1])
+        torch.cuda.synchronize()
+        expect = eng.flat.grad.cpu().numpy()
+        for rank in range(2):
+            assert np.array_equal(res[rank][2][step], expect), f"step {step}: rank {rank}'s reduced gradient"
+        eng.optimizer_step(0.5)
+    torch.cuda.synchronize()
+    final = eng.flat.data.cpu().numpy()
+    assert np.array_equal(res[0][1], res[1][1]), "replicas diverged"
+    assert np.array_equal(res[0][1], final)
+    assert not np.array_equal(parts[0].cpu().numpy(), parts[1].cpu().numpy())  # the ranks really had different shards

@@ -1,0 +1,202 @@
+"""MI355X: parity at the BASELINE.json sizes -- the drop-in models against fixtures made by the REAL reference modules
+(tests/golden, oracle/make_golden_fullsize.py) and against the fp64 oracle on the same seeded inputs.
+
+  configs[1]  Fno2d hidden 20 / L 4 / modes 12, B = 256, 64x64   whole forward + backward (every prediction and gradient
+              against the fp64 oracle; the reference's own fp32 outputs as fingerprints)
+  configs[2]  UNet dim 12, p = 8, 64x64, train-mode BatchNorm
+  configs[3]  AutoDeepONet branch 4295 / width 100 / depth 8+8, 66x65
+  configs[4]  Fno2d hidden 32 / L 4, 200-step rollout at 66x65 (eager generate_many and the one-graph FnoRollout)
+  cylinder    Fno2d with 8 case parameters (13 input features)
+"""
+import numpy as np
+import pytest
+
+from oracle import fno_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+NORTH_STAR_TOL = 1e-5  # BASELINE.json: outputs within 1e-5 relative nMSE of the reference (fp32)
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _fno(torch, params, C, L, p):
+    from cfdbench_amd.models.fno.fno2d import Fno2d
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    m = Fno2d(2, 2, p, loss_name_to_fn("nmse"), L, 12, 12, C).cuda()
+    m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()})
+    return m
+
+
+def _cuda(torch, batch):
+    return {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+
+
+def _check_fingerprints(g, grads, tol_vals, tol_norm=2e-4):
+    n = 0
+    for key in g.files:
+        if key.startswith("gsum::") and key.endswith("::vals"):
+            k = key.split("::")[1]
+            got = grads[k].reshape(-1)[g[f"gsum::{k}::idx"]]
+            ref = g[key]
+            if np.abs(ref).max() < 1e-7:  # conv bias in front of a train-mode BatchNorm: the exact gradient is zero
+                assert np.abs(got).max() < 1e-6, k
+            else:
+                assert O.rel_nmse(got, ref) < tol_vals, (k, O.rel_nmse(got, ref))
+                nrm = np.sqrt(np.sum(np.abs(grads[k]) ** 2))
+                assert abs(nrm - abs(g[f"gsum::{k}::norm"])) <= tol_norm * nrm, k
+            n += 1
+    assert n > 0
+
+
+def _named_grads(m):
+    return {k: (p.grad.detach().cpu().numpy()) for k, p in m.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("name", ["fno_cfg2_b256", "fno_cyl_p8_64x64"])
+def test_fno_whole_model_vs_reference_and_oracle(torch, golden_dir, name):
+    g = np.load(golden_dir / f"{name}.npz")
+    pseed, bseed, B, C, L, H, W, p = [int(v) for v in g["meta"]]
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p)
+    batch = synth.make_batch(bseed, B, H, W, p)
+    m = _fno(torch, params, C, L, p)
+    out = m(**_cuda(torch, batch))
+    out["loss"]["nmse"].backward()
+    preds = out["preds"].detach().cpu().numpy()
+    grads = _named_grads(m)
+    # -- the reference's own fp32 results
+    assert O.rel_nmse(preds[:2], g["preds_first"]) < 1e-9
+    assert O.rel_nmse(preds.reshape(-1)[g["psum::idx"]], g["psum::vals"]) < 1e-9
+    norms = np.sqrt((preds.astype(np.float64) ** 2).sum(axis=(1, 2, 3)))
+    assert np.max(np.abs(norms - g["preds_sample_norms"]) / g["preds_sample_norms"]) < 1e-5  # every sample of the batch
+    for k in ("mse", "rmse", "mae", "nmse"):
+        assert abs(out["loss"][k].item() - float(g[f"loss_{k}"])) <= 5e-6 * abs(float(g[f"loss_{k}"]))
+    _check_fingerprints(g, grads, tol_vals=1e-7)
+    # -- the fp64 oracle.  The forward pass is per-sample, so every 16th sample of the batch pins the predictions
+    # (NumPy needs ~0.7 s per sample and pass); CFD_FULL_ORACLE=1 runs the whole batch through the oracle forward AND
+    # backward and compares every gradient entry (~3 min; its log is committed under profiles/).
+    import os
+    full = os.environ.get("CFD_FULL_ORACLE") == "1" or B <= 16
+    sel = slice(None) if full else slice(0, None, 16)
+    p64 = {k: v.astype(np.complex128 if np.iscomplexobj(v) else np.float64) for k, v in params.items()}
+    b64 = {k: v.astype(np.float64)[sel] for k, v in batch.items()}
+    ref = O.fno_forward(p64, b64["inputs"], b64["case_params"], b64["mask"], b64["label"], L, keep_cache=full)
+    err = O.rel_nmse(preds[sel], ref["preds"])
+    print(f"{name}: preds nMSE vs the fp64 oracle {err:.2e} ({'whole batch' if full else 'every 16th sample'})")
+    assert err < 1e-9 and err < NORTH_STAR_TOL, err
+    if full:
+        rg = O.fno_backward(p64, ref["cache"], O.loss_grad_wrt_preds(ref["cache"]["preds"], ref["cache"]["label"], "nmse"), L)
+        for k, gk in grads.items():
+            e = O.rel_nmse(gk, rg[k])
+            print(f"{name}: grad {k} nMSE vs the fp64 oracle {e:.2e}")
+            assert e < 1e-8 and e < NORTH_STAR_TOL, (k, e)
+
+
+def test_engine_step_b256_matches_autograd_path(torch, golden_dir):
+    """The fused training engine (what bench.py times) at B = 256: same predictions, loss sums and gradients as the
+    autograd drop-in that the test above pins to the reference."""
+    from cfdbench_amd.engine import FnoTrainEngine
+    g = np.load(golden_dir / "fno_cfg2_b256.npz")
+    pseed, bseed, B, C, L, H, W, p = [int(v) for v in g["meta"]]
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p)
+    b = _cuda(torch, synth.make_batch(bseed, B, H, W, p))
+    m1 = _fno(torch, params, C, L, p)
+    out = m1(**b)
+    out["loss"]["nmse"].backward()
+    m2 = _fno(torch, params, C, L, p)
+    eng = FnoTrainEngine(m2, lr=1e-3, loss_name="nmse")
+    eng.forward_backward(b["inputs"], b["label"], b["case_params"], b["mask"])
+    torch.cuda.synchronize()
+    assert torch.equal(eng.preds, out["preds"].detach())
+    sums = eng.sums.tolist()
+    assert abs(sums[0] / sums[2] - float(g["loss_nmse"])) <= 5e-6 * float(g["loss_nmse"])
+    for p1, gv in zip(m1.abi_parameters(), eng.flat.grad_views):
+        a = torch.view_as_real(p1.grad).reshape(-1) if p1.grad.is_complex() else p1.grad.reshape(-1)
+        assert torch.equal(a, gv), "engine and autograd paths run the same kernels in the same order"
+
+
+def test_unet_dim12_p8_64x64_vs_reference_golden(torch, golden_dir):
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    from cfdbench_amd.models.unet import UNet
+    g = np.load(golden_dir / "unet_dim12_p8_64x64.npz")
+    seed, bseed, B, H, W, dim, p = [int(v) for v in g["meta"]]
+    m = UNet(2, 2, loss_name_to_fn("nmse"), p, insert_case_params_at="input", bilinear=False, dim=dim).cuda()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert len(shapes) == int(g["n_keys"]) == 136  # the reference's 136-tensor state_dict
+    assert sum(p_.numel() for p_ in m.parameters()) == 1095362
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(shapes, seed).items()}
+    m.load_state_dict(sd)
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    batch["mask"][:, :, 0, :] = 0
+    batch["mask"][:, :, :, 0] = 0
+    b = _cuda(torch, batch)
+    m.train()
+    out = m(inputs=b["inputs"], case_params=b["case_params"], mask=b["mask"], label=b["label"])
+    assert O.rel_nmse(out["preds"].detach().cpu().numpy(), g["preds_train"]) < 1e-9
+    assert abs(out["loss"]["nmse"].item() - float(g["loss_nmse"])) <= 1e-5 * float(g["loss_nmse"])
+    out["loss"]["nmse"].backward()
+    _check_fingerprints(g, _named_grads(m), tol_vals=1e-6, tol_norm=1e-3)
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            assert O.rel_nmse(v.cpu().numpy(), g[f"after::{k}"]) < 1e-10, k
+    m.load_state_dict(sd)
+    m.eval()
+    with torch.no_grad():
+        ev = m(inputs=b["inputs"], case_params=b["case_params"], mask=b["mask"])["preds"]
+    assert O.rel_nmse(ev.cpu().numpy(), g["preds_eval"]) < 1e-9
+
+
+def test_auto_deeponet_66x65_w100_d8_vs_reference_golden(torch, golden_dir):
+    from cfdbench_amd.models.auto_deeponet import AutoDeepONet
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    from oracle import deeponet_oracle as D
+    g = np.load(golden_dir / "auto_deeponet_66x65.npz")
+    pseed, bseed, B, H, W, width, depth, p = [int(v) for v in g["meta"]]
+    m = AutoDeepONet(H * W + p, 2, loss_name_to_fn("nmse"), branch_depth=depth, trunk_depth=depth, width=width,
+                     act_name="relu").cuda()
+    assert sum(p_.numel() for p_ in m.parameters()) == 571301
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in D.make_params(pseed, H * W + p, width, depth, depth).items()})
+    b = _cuda(torch, synth.make_smooth_batch(bseed, B, H, W, p))
+    out = m(inputs=b["inputs"], case_params=b["case_params"], label=b["label"], mask=b["mask"])
+    assert O.rel_nmse(out["preds"].detach().cpu().numpy(), g["preds"]) < 1e-9
+    assert abs(out["loss"]["nmse"].item() - float(g["loss_nmse"])) <= 1e-5 * float(g["loss_nmse"])
+    out["loss"]["nmse"].backward()
+    _check_fingerprints(g, _named_grads(m), tol_vals=1e-6, tol_norm=1e-3)
+    m.eval()
+    with torch.no_grad():
+        frames = m.generate_many(b["inputs"][:2], b["case_params"][:2], b["mask"][:2], 3)
+    for t in range(3):
+        assert O.rel_nmse(frames[t].cpu().numpy(), g["frames"][t]) < 1e-8
+
+
+def test_rollout_200_steps_c32_66x65_vs_reference_golden(torch, golden_dir):
+    """BASELINE configs[4] horizon: 200 autoregressive steps on the tube / dam grid at the reference's default width.  The
+    fixture's network is a near-identity propagator (oracle/synth.py), so round-off is carried from step to step instead
+    of being contracted away; the error against the reference's fp32 CPU rollout must stay far inside the 1e-5 budget at
+    EVERY stored step, and the one-graph FnoRollout must reproduce the eager loop bit for bit."""
+    from cfdbench_amd.rollout import FnoRollout
+    g = np.load(golden_dir / "rollout200_c32_66x65.npz")
+    pseed, bseed, B, C, L, H, W, p, steps = [int(v) for v in g["meta"]]
+    eps, gain, decay = [float(v) for v in g["hyper"]]
+    params, batch = synth.make_rollout_case(pseed, bseed, B, C, L, H, W, p, eps, gain, decay)
+    m = _fno(torch, params, C, L, p).eval()
+    b = _cuda(torch, batch)
+    with torch.no_grad():
+        frames = m.generate_many(b["inputs"], b["case_params"], b["mask"], steps)
+    assert len(frames) == steps
+    keep = [int(k) for k in g["keep"]]
+    errs = {k: O.rel_nmse(frames[k].cpu().numpy(), g["frames"][i]) for i, k in enumerate(keep)}
+    print("rollout nMSE vs the reference's fp32 frames:", {k: f"{v:.1e}" for k, v in errs.items()})
+    for k, e in errs.items():
+        assert e < 2e-7 and e < NORTH_STAR_TOL, (k, e)
+    norms = torch.stack([f.double().pow(2).mean().sqrt() for f in frames]).cpu().numpy()
+    assert np.max(np.abs(norms - g["norms"]) / g["norms"]) < 1e-5  # all 200 steps
+    graph_frames = FnoRollout(m).generate_many(b["inputs"], b["case_params"], b["mask"], steps)
+    for k in (0, 99, 199):
+        assert torch.equal(graph_frames[k], frames[k])

@@ -188,6 +188,49 @@ def test_multistep_inference_metrics(torch, tmp_path):
             assert abs(a[k] - b[k]) <= 1e-5 * abs(b[k]) + 1e-12, (k, a[k], b[k])
 
 
+def test_multistep_unet_in_train_mode_follows_the_reference_per_case(torch, tmp_path):
+    """the reference never calls model.eval() in test_multistep.py and rolls out ONE case at a time, so a U-Net's
+    BatchNorm normalises with that case's own statistics.  ``infer`` must not pool the statistics over the cases: with the
+    model in training mode its metrics equal the per-case formulation, and differ from a batched train-mode rollout; in
+    eval mode (no batch dependence left) the batched rollout is used and equals the per-case one as well."""
+    from cfdbench_amd.harness.data import SyntheticAutoDataset
+    from cfdbench_amd.harness.test_multistep import batch_dependent, get_metrics, infer, infer_case, prepare_cases
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    from cfdbench_amd.models.unet import UNet
+    torch.manual_seed(3)
+    model = UNet(2, 2, loss_name_to_fn("nmse"), 5, insert_case_params_at="input", bilinear=False, dim=2).cuda()
+    data = SyntheticAutoDataset(n_cases=3, n_frames=4, height=32, width=32, seed=6, border_mask=True)
+    steps = 3
+    feats, cps = prepare_cases(data, steps)
+
+    def per_case():
+        preds = [infer_case(model, f, c, steps) for f, c in zip(feats, cps)]
+        out = []
+        for s in range(steps):
+            ms = [get_metrics(preds[c][s][0][0] * feats[c][s][-1], feats[c][s][0] * feats[c][s][-1]) for c in range(3)]
+            out.append({k: float(np.mean([m[k] for m in ms])) for k in ms[0]})
+        return out
+
+    for mode in ("train", "eval"):
+        getattr(model, mode)()
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        assert batch_dependent(model) == (mode == "train")
+        got = infer(model, feats, cps, steps)
+        model.load_state_dict(state)  # train mode updates the running statistics: same start for the comparison run
+        ref = per_case()
+        model.load_state_dict(state)
+        for a, b in zip(got, ref):
+            for k in a:
+                assert abs(a[k] - b[k]) <= 1e-5 * abs(b[k]) + 1e-12, (mode, k, a[k], b[k])
+    model.train()
+    with torch.no_grad():  # what r1 did: all cases as one train-mode batch -> pooled BatchNorm statistics
+        start = torch.stack([f[0, :-1] for f in feats])
+        pooled = model.generate_many(inputs=start, case_params=torch.stack(list(cps)), mask=torch.stack([f[0, -1] for f in feats]),
+                                     steps=steps)
+        single = infer_case(model, feats[0], cps[0], steps)
+    assert not torch.allclose(pooled[-1][:1], single[-1], rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("name", ["rollout_small_64x64", "rollout_small_66x65"])
 def test_graph_rollout_matches_generate_many_and_reference_golden(torch, golden_dir, name):
     from cfdbench_amd.models.fno.fno2d import Fno2d

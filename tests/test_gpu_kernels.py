@@ -37,13 +37,11 @@ def test_mix_and_spectral_wgrad(be, B, Cin, Cout):
 
 @pytest.mark.parametrize("B,C,nwv,want_wg,fused", [(70, 32, "4", "256", "1"), (37, 20, "2", "36", "1"), (300, 20, "8", "80", "0"),
                                                    (256, 20, "0", "256", "1")])
-def test_mix_and_spectral_wgrad_kernel_routes(be, B, C, nwv, want_wg, fused, monkeypatch):
+def test_mix_and_spectral_wgrad_kernel_routes(be, B, C, nwv, want_wg, fused):
     """Every route of the mode-domain entry points at sizes the defaults would not pick: k_mix_lds workgroup shapes
-    (CFD_MIX_NWV, 0 = the lane = mode kernel), weight-gradient chunk sizes (CFD_WGRAD_WG), fused vs two launches."""
-    monkeypatch.setenv("CFD_MIX_NWV", nwv)
-    monkeypatch.setenv("CFD_WGRAD_WG", want_wg)
-    monkeypatch.setenv("CFD_FUSED_VARIANT", fused)
-    _assert_all(K.check_mix_wgrad(be, B, C, C))
+    (mix_nwv knob, 0 = the lane = mode kernel), weight-gradient chunk sizes (wgrad_wg), fused vs two launches (cfd_tune_set)."""
+    with K.tuned(be, mix_nwv=int(nwv), wgrad_wg=int(want_wg), fused_variant=int(fused)):
+        _assert_all(K.check_mix_wgrad(be, B, C, C))
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(5, 20, 20, 64, 64), (3, 6, 7, 32, 64), (2, 3, 5, 66, 65), (3, 32, 32, 64, 64), (2, 14, 9, 48, 64)])

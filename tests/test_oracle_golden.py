@@ -221,3 +221,85 @@ def test_auto_edeeponet_and_auto_ffn_forward(golden_dir, name):
     assert O.rel_nmse(fwd(P, x, cp, str(g["act"]), g["q"]), g["preds"]) < 1e-10
     full = fwd(P, x, cp, str(g["act"]))
     assert O.rel_nmse(full.reshape(g["preds_full"].shape), g["preds_full"]) < 1e-10
+
+
+# ---- full-size fixtures (oracle/make_golden_fullsize.py) and the CPU-baseline port -----------------------------------
+def _check_grad_fingerprints(g, grads, tol_vals=1e-8, tol_norm=1e-4):
+    n = 0
+    for key in g.files:
+        if key.startswith("gsum::") and key.endswith("::vals"):
+            k = key.split("::")[1]
+            got = np.ascontiguousarray(grads[k]).reshape(-1)[g[f"gsum::{k}::idx"]]
+            assert O.rel_nmse(got, g[key]) < tol_vals, k
+            nrm = np.sqrt(np.sum(np.abs(np.asarray(grads[k])) ** 2))
+            assert abs(nrm - abs(g[f"gsum::{k}::norm"])) <= tol_norm * max(nrm, 1e-30), k
+            n += 1
+    assert n > 0
+
+
+def test_fno_cylinder_p8(golden_dir):
+    """13 input features (the cylinder problem's 8 case parameters) through the lifting layer."""
+    g = np.load(golden_dir / "fno_cyl_p8_64x64.npz")
+    pseed, bseed, B, C, L, H, W, p = [int(v) for v in g["meta"]]
+    params = {k: v.astype(np.complex128 if np.iscomplexobj(v) else np.float64)
+              for k, v in synth.make_fno_params(pseed, C, L, 12, 12, p).items()}
+    batch = {k: v.astype(np.float64) for k, v in synth.make_batch(bseed, B, H, W, p).items()}
+    out = O.fno_forward(params, batch["inputs"], batch["case_params"], batch["mask"], batch["label"], L)
+    assert O.rel_nmse(out["preds"][:2], g["preds_first"]) < TOL64
+    assert abs(out["loss"]["nmse"] - float(g["loss_nmse"])) < 2e-6
+    grads = O.fno_backward(params, out["cache"], O.loss_grad_wrt_preds(out["cache"]["preds"], out["cache"]["label"], "nmse"), L)
+    _check_grad_fingerprints(g, grads)
+
+
+def test_auto_deeponet_66x65_w100_d8(golden_dir):
+    """BASELINE configs[3] network (branch 4295 -> 100 x 8, trunk 2 -> 100 x 8) on the tube grid."""
+    from oracle import deeponet_oracle as D
+    g = np.load(golden_dir / "auto_deeponet_66x65.npz")
+    pseed, bseed, B, H, W, width, depth, p = [int(v) for v in g["meta"]]
+    params = {k: v.astype(np.float64) for k, v in D.make_params(pseed, H * W + p, width, depth, depth).items()}
+    batch = {k: v.astype(np.float64) for k, v in synth.make_smooth_batch(bseed, B, H, W, p).items()}
+    out = D.auto_deeponet_forward(params, batch["inputs"], batch["case_params"], batch["label"], "relu")
+    assert O.rel_nmse(out["preds"], g["preds"]) < 1e-11
+    assert abs(out["loss"]["nmse"] - float(g["loss_nmse"])) <= 1e-5 * float(g["loss_nmse"])
+    grads = D.auto_deeponet_backward(params, out["cache"], O.loss_grad_wrt_preds(out["preds"], out["cache"]["labels"], "nmse"), "relu")
+    _check_grad_fingerprints(g, grads, tol_vals=1e-7)
+
+
+def test_rollout200_first_steps(golden_dir):
+    """The 200-step fixture's near-identity propagator: the fp64 oracle follows the reference's fp32 frames (the GPU test
+    checks the whole horizon; 20 steps keep this CPU test short)."""
+    g = np.load(golden_dir / "rollout200_c32_66x65.npz")
+    pseed, bseed, B, C, L, H, W, p, steps = [int(v) for v in g["meta"]]
+    eps, gain, decay = [float(v) for v in g["hyper"]]
+    params, batch = synth.make_rollout_case(pseed, bseed, B, C, L, H, W, p, eps, gain, decay)
+    p64 = {k: v.astype(np.complex128 if np.iscomplexobj(v) else np.float64) for k, v in params.items()}
+    b64 = {k: v.astype(np.float64) for k, v in batch.items()}
+    frames = O.generate_many(p64, b64["inputs"], b64["case_params"], b64["mask"], 20, L)
+    keep = [int(k) for k in g["keep"]]
+    for k in (0, 1, 4, 19):
+        assert O.rel_nmse(frames[k], g["frames"][keep.index(k)]) < 1e-9, k
+        assert abs(np.sqrt((frames[k] ** 2).mean()) - g["norms"][k]) < 1e-5 * g["norms"][k]
+    # the fixture is a genuine evolution, not a fixed point: the field moves by O(1) over the horizon and stays O(1)
+    assert 0.5 < g["norms"][-1] / g["norms"][0] < 2.0
+    assert O.rel_nmse(g["frames"][keep.index(199)], g["frames"][keep.index(0)]) > 0.1
+
+
+def test_torch_port_matches_the_oracle():
+    """oracle/torch_port.py (the ATen call sequence timed as bench.py's cpu_baseline) computes what the oracle computes."""
+    import torch
+    from oracle import torch_port as TP
+    C, L, B, p = 6, 2, 2, 5
+    params = synth.make_fno_params(9, C, L, 12, 12, p, spectral_gain=5.0)
+    batch = synth.make_batch(10, B, 64, 64, p, border_mask=True)
+    prm = {k: torch.from_numpy(v).requires_grad_(True) for k, v in params.items()}
+    preds, loss = TP.forward(prm, *[torch.from_numpy(batch[k]) for k in ("inputs", "case_params", "mask", "label")], L)
+    loss["nmse"].backward()
+    p64 = {k: v.astype(np.complex128 if np.iscomplexobj(v) else np.float64) for k, v in params.items()}
+    b64 = {k: v.astype(np.float64) for k, v in batch.items()}
+    ref = O.fno_forward(p64, b64["inputs"], b64["case_params"], b64["mask"], b64["label"], L)
+    assert O.rel_nmse(preds.detach().numpy(), ref["preds"]) < 1e-10
+    for k in ("mse", "mae", "nmse"):
+        assert abs(loss[k].item() - ref["loss"][k]) <= 2e-6 * abs(ref["loss"][k])
+    rg = O.fno_backward(p64, ref["cache"], O.loss_grad_wrt_preds(ref["cache"]["preds"], ref["cache"]["label"], "nmse"), L)
+    for k, t in prm.items():
+        assert O.rel_nmse(t.grad.numpy(), rg[k]) < 1e-8, k

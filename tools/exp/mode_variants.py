@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Dev experiment (GPU box): time the mode-domain kernels (mix, adjoint mix, spectral weight gradient) and the
-SpectralConv2d forward+backward pair under the dev switches of csrc/spectral.hip, all in one process.
+SpectralConv2d forward+backward pair under the dispatch knobs of csrc/tune.cpp (cfd_tune_set), all in one process.
 
     python tools/exp/mode_variants.py [--batch 256] [--reps 50]
 """
@@ -15,15 +15,15 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from cfdbench_amd import _lib  # noqa: E402
 
 CONFIGS = [
-    ("lane=mode mix, unfused", dict(CFD_MIX_NWV="0", CFD_FUSED_VARIANT="0")),
+    ("lane=mode mix, unfused", dict(mix_nwv=0, fused_variant=0)),
     ("default", dict()),
-    ("mix lds nwv1", dict(CFD_MIX_NWV="1")),
-    ("mix lds nwv2", dict(CFD_MIX_NWV="2")),
-    ("mix lds nwv4", dict(CFD_MIX_NWV="4")),
-    ("mix lds nwv8", dict(CFD_MIX_NWV="8")),
-    ("unfused", dict(CFD_FUSED_VARIANT="0")),
+    ("mix lds nwv1", dict(mix_nwv=1)),
+    ("mix lds nwv2", dict(mix_nwv=2)),
+    ("mix lds nwv4", dict(mix_nwv=4)),
+    ("mix lds nwv8", dict(mix_nwv=8)),
+    ("unfused", dict(fused_variant=0)),
 ]
-KEYS = ("CFD_WGRAD_WG", "CFD_MIX_NWV", "CFD_FUSED_VARIANT")
+KEYS = ("wgrad_wg", "mix_nwv", "fused_variant")
 
 
 def main():
@@ -60,8 +60,7 @@ def main():
     sel = [int(i) for i in args.configs.split(",") if i] or range(len(CONFIGS))
     for name, env in [CONFIGS[i] for i in sel]:
         for k in KEYS:
-            os.environ.pop(k, None)
-        os.environ.update(env)
+            api.call("cfd_tune_set", k.encode(), int(env.get(k, -1)))
         ws = torch.empty(api.size("cfd_spectral_conv2d_bwd_workspace_bytes", plan, B, C, C) + 256, dtype=torch.uint8, device=dev)
         cases = {
             "mix": lambda: api.call("cfd_spectral_mix", plan, P(xh), P(w1), P(w2), P(z), B, C, C, 0, st),
