@@ -8,11 +8,21 @@
 A step = forward + nMSE loss + backward + (N>1: RCCL all-reduce of the flat gradient) + Adam on one batch that is
 already resident in HBM.  Workload = BASELINE.json configs[1]: Fno2d(in=2,out=2,p=5,L=4,hidden=20,modes=12), B=256 per
 GPU, 64x64, fp32.  Weak scaling: every rank processes its own B frames; value = N*B*K / max-over-ranks time.
-Rank 0 prints ONE JSON line (with the `roofline` and `cpu_baseline` objects).
+Rank 0 prints ONE JSON line.  Beside the contract's keys it carries
+  roofline                  dominant kernel of the step: ALGORITHMIC bytes per launch / HIP-event time vs 8 TB/s
+  roofline_step             the whole step against the ideal-fusion byte count of SURVEY 8d (10.2 MB/frame at C=20, L=4)
+  roofline_spectral_conv2d  the north-star kernel group (SpectralConv2d fwd+bwd, 5N + 3Wb bytes)
+  kernels                   every kernel of the step: launches, average time, HBM fraction
+  exact_fp32                the same step with every contraction in exact fp32 (null until that route is built)
+  rollout / rollout_66x65   batched multi-step inference from one HIP graph (configs[4] horizon: 200 steps)
+  unet_cfg2 / auto_deeponet_cfg3   train steps of BASELINE configs[2] / configs[3] on one GPU
+  cpu_baseline              the reference's ATen call sequence on the host cores, at B = 256 and B = 32
+The extra legs run on rank 0 at N = 1 only.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -25,8 +35,12 @@ import torch.distributed as dist
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = fp32 vector peak
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_PEAK_TF = 157.3        # MI355X_MICROARCH.md: fp32 vector == f32-input MFMA peak
+BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+# kernels whose GEMM-shaped work runs as 3-term split-bf16 products on the bf16 matrix pipe (cfd_common.h): their
+# fp32-equivalent flops cost 3 bf16 MFMA flops each
+SPLIT_BF16 = ("k_dft_fwd", "k_idft", "k_block", "k_chan_wgrad", "k_head")
 
 
 def parse():
@@ -41,70 +55,231 @@ def parse():
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--n-case-params", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=32)
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward from a HIP graph")
     ap.add_argument("--no-rollout", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the U-Net / Auto-DeepONet / exact-fp32 legs")
     ap.add_argument("--rollout-batch", type=int, default=64)
     ap.add_argument("--rollout-steps", type=int, default=200)
     return ap.parse_args()
 
 
-def kernel_models(B, C, HW, L, M, head=128, co=2):
-    """Algorithmic HBM bytes and flops of ONE launch of each kernel."""
-    N = B * C * HW * 4          # one activation tensor
-    Mb = B * C * M * 8          # one kept-mode tensor (complex64)
-    Wb = 2 * C * C * (M // 2) * 8  # weights1+weights2 of one layer
-    px = B * HW
-    io = px * 4 * (2 + 1 + 2 + co)  # inputs, mask, label, preds of the head
-    return {
-        "k_stem_fwd": dict(bytes=px * 4 * 3 + N, flops=2 * px * C * 10),
-        "k_dft_fwd": dict(bytes=N + Mb, flops=2 * B * C * (36 * 64 * 32 + 64 * 32 * 32)),
-        "k_dft_fwd_act": dict(bytes=N + Mb, flops=2 * B * C * (36 * 64 * 32 + 64 * 32 * 32)),
-        "k_mix": dict(bytes=2 * Mb + Wb, flops=8 * B * C * C * M),
-        "k_mix_adj": dict(bytes=2 * Mb + Wb, flops=8 * B * C * C * M),
-        "k_chanmix": dict(bytes=2 * N, flops=2 * px * C * C),
-        "k_chanmix_act": dict(bytes=2 * N, flops=2 * px * C * C),
-        "k_chanmix_t": dict(bytes=2 * N, flops=2 * px * C * C),
-        "k_block_fwd": dict(bytes=2 * N + Mb, flops=2 * px * C * C + 2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
-        "k_block_fwd_act": dict(bytes=2 * N + Mb, flops=2 * px * C * C + 2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
-        "k_block_bwd": dict(bytes=2 * N + Mb, flops=2 * px * C * C + 2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
-        "k_block_bwd_dgelu": dict(bytes=3 * N + Mb, flops=2 * px * C * C + 2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
-        "k_idft": dict(bytes=N + Mb, flops=2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
-        "k_idft_add": dict(bytes=2 * N + Mb, flops=2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
-        "k_idft_add_dgelu": dict(bytes=3 * N + Mb, flops=2 * B * C * (28 * 32 * 64 + 24 * 64 * 64)),
-        "k_spec_wgrad_part": dict(bytes=2 * Mb + Wb, flops=8 * B * C * C * M),
-        "k_mixadj_wgrad": dict(bytes=3 * Mb + 2 * Wb, flops=16 * B * C * C * M),  # adjoint mix + weight gradient, one launch
-        "k_spec_wgrad_reduce": dict(bytes=2 * Wb, flops=0),
-        "k_chan_wgrad": dict(bytes=2 * N, flops=2 * px * C * C),
-        "k_chan_wgrad_stem": dict(bytes=N + px * 12, flops=2 * px * C * 10),
-        "k_wgrad_reduce": dict(bytes=0, flops=0),
-        "k_head_fwd": dict(bytes=N + io, flops=2 * px * (C * head + head * co)),
-        "k_head_bwd": dict(bytes=2 * N + io, flops=2 * px * (3 * C * head + 2 * head * co)),
-        "k_adam": dict(bytes=0, flops=0),
-    }
+# ----------------------------------------------------------------------------------------------------------------------
+# rooflines
+# ----------------------------------------------------------------------------------------------------------------------
+def read_prof(api):
+    """cfd_prof_end -> [(name, launches, total_ms, algorithmic_bytes, flops)], slowest first."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    api.call("cfd_prof_end", buf, len(buf))
+    rows = []
+    for line in buf.value.decode().splitlines():
+        f = line.split()
+        rows.append((f[0], int(f[1]), float(f[2]), float(f[3]), float(f[4])))
+    rows.sort(key=lambda r: -r[2])
+    return rows
 
 
-def roofline_of(name, avg_ms, model):
-    m = model.get(name)
-    if not m or avg_ms <= 0:
+def roofline_of(name, launches, total_ms, total_bytes, total_flops):
+    """the FNO / U-Net / DeepONet kernels are priced against HBM (algorithmic bytes of the launches, declared at
+    the launch sites, / their HIP-event time); a kernel whose matrix work would take LONGER than its bytes at the peak of the
+    pipe it issues on is priced against that pipe instead."""
+    if total_ms <= 0 or launches <= 0:
         return None
-    t = avg_ms * 1e-3
-    gbs = m["bytes"] / t / 1e9
-    tfs = m["flops"] / t / 1e12
-    t_hbm = m["bytes"] / (HBM_PEAK_GBS * 1e9)
-    t_mfma = m["flops"] / (FP32_MFMA_PEAK_TF * 1e12)
-    if t_mfma > t_hbm:
-        # fp32-equivalent flops of the kernel's GEMMs against the 157.3 TF fp32 ceiling (fp32 MFMA == VALU fp32 rate on
-        # gfx950, tools/exp/valu_rate.hip).  The head kernels run those GEMMs as 3-term split-bf16 MFMAs and are bound
-        # by the VALU work of GELU / gelu', which shares that ceiling.
-        return dict(kernel=name, bound="mfma", achieved=round(tfs, 3), peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s",
-                    frac=round(tfs / FP32_MFMA_PEAK_TF, 4), avg_us=round(avg_ms * 1e3, 2), traffic=None,
-                    note="fp32-equivalent GEMM flops vs the fp32 MFMA/VALU ceiling; GEMMs issue as split-bf16 MFMA, "
-                         "the kernel is VALU(GELU)-bound (profiles/*_step_busy_counters.txt)")
-    return dict(kernel=name, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(gbs / HBM_PEAK_GBS, 4), avg_us=round(avg_ms * 1e3, 2), traffic=None)
+    t = total_ms * 1e-3
+    split = name.startswith(SPLIT_BF16)
+    pipe_tf = BF16_MFMA_PEAK_TF / 3.0 if split else FP32_PEAK_TF  # fp32-equivalent flops per second of the pipe
+    t_hbm = total_bytes / (HBM_PEAK_GBS * 1e9)
+    t_pipe = total_flops / (pipe_tf * 1e12)
+    out = dict(kernel=name, avg_us=round(total_ms / launches * 1e3, 2), launches=launches,
+               algorithmic_bytes_per_launch=int(total_bytes / launches))
+    if total_bytes <= 0 and total_flops <= 0:
+        return dict(out, bound=None, frac=None, note="partial-sum reduction / data movement: no algorithmic bytes of its own")
+    if t_pipe > t_hbm:
+        tfs = total_flops / t / 1e12
+        return dict(out, bound="mfma", achieved=round(tfs, 2), peak=round(pipe_tf, 1), unit="TFLOP/s", frac=round(tfs / pipe_tf, 4),
+                    traffic=None, pipe="bf16 MFMA, 3-term split products (fp32-equivalent flops)" if split else "fp32 MFMA / VALU")
+    gbs = total_bytes / t / 1e9
+    return dict(out, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                fp32_equiv_tflops=round(total_flops / t / 1e12, 2))
+
+
+def latest_profile(pattern):
+    files = sorted((REPO / "profiles").glob(pattern))
+    return json.loads(files[-1].read_text()) if files else None
+
+
+def attach_pmc(rl, name, applies):
+    """HBM traffic per launch and unit-busy percentages of the dominant kernel from the committed rocprofv3 PMC passes of this
+    same command (tools/profile_step.sh, tools/pmc_step.sh: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE)."""
+    if not (rl and applies):
+        return
+    try:
+        pmc = latest_profile("r*_pmc_traffic.json") or {}
+        match = [v for k, v in pmc.items() if k.startswith(name + "<") or k == name]
+        if match:
+            rl["traffic"] = int(sum(m["traffic_bytes"] for m in match) / len(match))
+            rl["traffic_source"] = "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, per launch)"
+        busy = latest_profile("r*_step_busy.json") or {}
+        match = [v for k, v in busy.items() if k.startswith(name + "<") or k == name]
+        if match:
+            rl["busy_pct"] = {k: match[0][k] for k in ("mfma", "valu", "lds", "wait") if k in match[0]}
+            rl["busy_source"] = "profiles/ (rocprofv3 --pmc SQ_* busy counters of the same step)"
+    except Exception:  # noqa: BLE001
+        pass
+
+
+def fno_step_bytes_per_frame(C, L, HW, training=True):
+    """SURVEY.md 8(d) ideal fusion: every activation crosses HBM once per layer boundary, the 128-wide head never exists.
+    forward = inputs (3 ch) + [label (2)] + stem write A + L (read A + write A) + head read A + preds (2); backward ~ 2x."""
+    A = C * HW * 4
+    fwd = (2 * L + 2) * A + (3 + 2 + (2 if training else 0)) * HW * 4
+    return 3 * fwd if training else fwd
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# legs
+# ----------------------------------------------------------------------------------------------------------------------
+def time_steps(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def profiled(api, fn, steps):
+    api.call("cfd_prof_begin")
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return read_prof(api)
+
+
+def spectral_leg(api, _lib, dev, B, C, H, W, reps):
+    """North-star kernel group: SpectralConv2d forward+backward alone, algorithmic bytes 5N + 3Wb."""
+    plan = _lib.plan(H, W, 12, 12, dev.index)
+    x = torch.randn(B, C, H, W, device=dev)
+    gy = torch.randn(B, C, H, W, device=dev)
+    w1 = torch.view_as_real(torch.rand(C, C, 12, 12, dtype=torch.cfloat, device=dev) / (C * C)).contiguous()
+    w2 = torch.view_as_real(torch.rand(C, C, 12, 12, dtype=torch.cfloat, device=dev) / (C * C)).contiguous()
+    y, gx = torch.empty_like(x), torch.empty_like(x)
+    gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
+    xh = torch.empty(B, C, 24, 12, 2, device=dev)
+    z = torch.empty(B, C, 24, 12, 2, device=dev)
+    ws = torch.empty(api.size("cfd_spectral_conv2d_bwd_workspace_bytes", plan, B, C, C), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def spec():
+        api.call("cfd_spectral_conv2d_fwd", plan, x.data_ptr(), w1.data_ptr(), w2.data_ptr(), y.data_ptr(), xh.data_ptr(),
+                 z.data_ptr(), B, C, C, st)
+        api.call("cfd_spectral_conv2d_bwd", plan, gy.data_ptr(), xh.data_ptr(), w1.data_ptr(), w2.data_ptr(), gx.data_ptr(),
+                 gw1.data_ptr(), gw2.data_ptr(), ws.data_ptr(), B, C, C, st)
+
+    for _ in range(3):
+        spec()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        spec()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    alg = 5 * B * C * H * W * 4 + 3 * 2 * C * C * 144 * 8
+    gbs = alg / (us * 1e-6) / 1e9
+    return dict(what=f"SpectralConv2d fwd+bwd, B={B}, C={C}, {H}x{W}, modes 12 (dft, mix, idft | dft, adjoint mix + weight gradient, idft)",
+                bound="hbm", algorithmic_bytes=alg, avg_us=round(us, 2), achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None)
+
+
+def rollout_leg(model, B, steps, H, W, p, dev, reps=3, dtype="f32"):
+    from cfdbench_amd.rollout import FnoRollout
+    g = torch.Generator(device="cpu").manual_seed(99)
+    x0 = torch.randn(B, 2, H, W, generator=g).to(dev)
+    cp = torch.randn(B, p, generator=g).to(dev)
+    mask = torch.ones(B, 1, H, W, device=dev)
+    if (H, W) != (64, 64):  # tube / dam style border (SURVEY 8d)
+        mask[:, :, 0, :] = 0
+        mask[:, :, -1, :] = 0
+        mask[:, :, :, 0] = 0
+    kw = {} if dtype == "f32" else dict(dtype=dtype)
+    ro = FnoRollout(model, **kw)
+    ro.generate_frames(x0, cp, mask, steps)  # builds + captures the graph
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fr = ro.generate_frames(x0, cp, mask, steps)  # the graph's own frame buffer: no copies in the timed region
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    cfg = model.abi_config()
+    bpf = fno_step_bytes_per_frame(cfg["hidden"], cfg["num_layers"], H * W, training=False)
+    if dtype != "f32":
+        A = cfg["hidden"] * H * W * 4
+        bpf -= (2 * cfg["num_layers"] + 2) * A // 2  # activations stored in 2 bytes
+    fps = B * steps / dt
+    out = dict(what=f"FnoRollout: {B} cases x {steps} steps, Fno2d(hidden {cfg['hidden']}, L {cfg['num_layers']}), {H}x{W}, "
+                    f"{'fp32' if dtype == 'f32' else 'bf16 activation storage, fp32 accumulate'}, one HIP graph per horizon",
+               frames_per_s=round(fps, 1), ms_per_step=round(dt / steps * 1e3, 4),
+               roofline=dict(bound="hbm", bytes_per_frame=bpf, achieved=round(fps * bpf / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=round(fps * bpf / 1e9 / HBM_PEAK_GBS, 4)))
+    if dtype == "f32":
+        with torch.no_grad():
+            plain = model.generate_many(x0, cp, mask, 3)
+        out["bitwise_equal_to_generate_many"] = bool(all(torch.equal(a, b) for a, b in zip(plain, fr[1:4])))
+    return out, fr
+
+
+def unet_bytes_per_frame(dim, cin, H, W):
+    """Ideal fusion for the U-Net (conv + BatchNorm + ReLU as one pass, pooling / concat by addressing): every conv reads its
+    input and writes its output once in the forward pass; backward ~ 2x (unet.py:11-108)."""
+    e = 0
+    chans = [dim * 2 ** i for i in range(5)]
+    e += (cin + chans[0]) * H * W + 2 * chans[0] * H * W  # in_conv
+    for i in range(1, 5):
+        hw = (H >> i) * (W >> i)
+        e += (chans[i - 1] + chans[i]) * hw + 2 * chans[i] * hw
+    for i in range(4, 0, -1):
+        hw_lo, hw = (H >> i) * (W >> i), (H >> (i - 1)) * (W >> (i - 1))
+        e += chans[i] * hw_lo + chans[i - 1] * hw  # transposed conv
+        e += (chans[i] + chans[i - 1]) * hw + 2 * chans[i - 1] * hw  # double conv on the concatenation
+    e += (chans[0] + 2) * H * W
+    return 3 * e * 4
+
+
+def model_train_leg(api, name, model, batch, steps, warmup, frames, bytes_per_frame, what):
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+    from cfdbench_amd.graph import GraphedTrainStep
+
+    def eager():
+        out = model(**batch)
+        out["loss"]["nmse"].backward()
+        opt.step()
+        opt.zero_grad()
+
+    dt_eager = time_steps(eager, steps, warmup)
+    rows = profiled(api, eager, steps)
+    res = dict(what=what, frames_per_s=round(frames / dt_eager, 1), ms_per_step=round(dt_eager * 1e3, 3), mode="eager")
+    try:
+        gs = GraphedTrainStep(model, opt, batch)
+        dt_graph = time_steps(lambda: gs(**batch), steps, warmup)
+        if dt_graph < dt_eager:
+            res.update(frames_per_s=round(frames / dt_graph, 1), ms_per_step=round(dt_graph * 1e3, 3), mode="one HIP graph per step",
+                       eager_ms_per_step=round(dt_eager * 1e3, 3))
+    except Exception as e:  # noqa: BLE001
+        res["graph_error"] = str(e)[:200]
+    fps = res["frames_per_s"]
+    if bytes_per_frame:
+        res["roofline_step"] = dict(bound="hbm", bytes_per_frame=int(bytes_per_frame), achieved=round(fps * bytes_per_frame / 1e9, 1),
+                                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fps * bytes_per_frame / 1e9 / HBM_PEAK_GBS, 4))
+    tot = sum(r[2] for r in rows)
+    res["kernels"] = [dict(kernel=r[0], launches_per_step=r[1] // steps, us_per_step=round(r[2] / steps * 1e3, 1), share=round(r[2] / tot, 3))
+                      for r in rows[:8]]
+    dom = next((r for r in rows if r[3] > 0 or r[4] > 0), rows[0])
+    res["roofline"] = roofline_of(*dom)
+    return res
 
 
 def main():
@@ -131,6 +306,7 @@ def main():
     from cfdbench_amd.models.fno.fno2d import Fno2d
     from cfdbench_amd.models.loss import loss_name_to_fn
 
+    api = _lib.api()
     B, C, L, H, W, p = args.batch, args.hidden, args.layers, args.height, args.width, args.n_case_params
     torch.manual_seed(0)  # identical weights on every rank
     model = Fno2d(2, 2, p, loss_name_to_fn("nmse"), L, 12, 12, C).to(dev)
@@ -163,9 +339,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final = eng.scores()
+    fps = world * B * args.steps / elapsed
 
     result = {
-        "metric": "train frames/sec (64x64x2), Auto-FNO cavity", "value": round(world * B * args.steps / elapsed, 1),
+        "metric": "train frames/sec (64x64x2), Auto-FNO cavity", "value": round(fps, 1),
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -176,124 +353,103 @@ def main():
                    "global_batch": world * B, "parallelism": f"dp{world}", "graph": bool(args.graph)},
         "final_nmse": round(final["nmse"], 6),
     }
+    bpf = fno_step_bytes_per_frame(C, L, H * W)
+    per_gpu = fps / world
+    result["roofline_step"] = dict(bound="hbm", what="whole train step vs the ideal-fusion byte count of SURVEY.md 8(d)", bytes_per_frame=bpf,
+                                   achieved=round(per_gpu * bpf / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                   frac=round(per_gpu * bpf / 1e9 / HBM_PEAK_GBS, 4), frames_per_s_at_roofline=round(HBM_PEAK_GBS * 1e9 / bpf, 0))
 
     # ---- roofline leg: the same K steps again with per-kernel HIP events on the launch stream -------------------
     # EVERY rank runs these steps (they contain the gradient all-reduce, a collective); only rank 0 records events.
     if not args.no_roofline:
-        import ctypes
-        api = _lib.api()
         if rank == 0:
             api.call("cfd_prof_begin")
         for _ in range(args.steps):
             eng.train_step(inputs, label, cp, mask)
         torch.cuda.synchronize()
     if rank == 0 and not args.no_roofline:
-        buf = ctypes.create_string_buffer(1 << 16)
-        api.call("cfd_prof_end", buf, len(buf))
-        rows = []
-        for line in buf.value.decode().splitlines():
-            name, cnt, tot = line.split()
-            rows.append((name, int(cnt), float(tot)))
-        model_bytes = kernel_models(B, C, H * W, L, 2 * 12 * 12)
-        rows.sort(key=lambda r: -r[2])
+        rows = read_prof(api)
         tot_ms = sum(r[2] for r in rows)
         kern = []
-        for name, cnt, tot in rows:
-            rl = roofline_of(name, tot / cnt, model_bytes)
-            kern.append(dict(kernel=name, launches_per_step=cnt // args.steps, avg_us=round(tot / cnt * 1e3, 2),
-                             share=round(tot / tot_ms, 4), bound=rl and rl["bound"], frac=rl and rl["frac"]))
+        for r in rows:
+            rl = roofline_of(*r) or {}
+            kern.append(dict(kernel=r[0], launches_per_step=r[1] // args.steps, avg_us=round(r[2] / r[1] * 1e3, 2),
+                             share=round(r[2] / tot_ms, 4), bound=rl.get("bound"), frac=rl.get("frac")))
         result["kernels"] = kern
-        dom = rows[0]
-        result["roofline"] = roofline_of(dom[0], dom[2] / dom[1], model_bytes)
-        # HBM traffic per launch of the dominant kernel: rocprofv3 PMC passes of this same command
-        # (tools/profile_step.sh: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), committed under profiles/
+        result["kernel_time_ms_per_step"] = round(tot_ms / args.steps, 4)
+        result["roofline"] = roofline_of(*rows[0])
+        attach_pmc(result["roofline"], rows[0][0], B == 256 and C == 20 and (H, W) == (64, 64))
+        result["roofline_spectral_conv2d"] = spectral_leg(api, _lib, dev, B, C, H, W, max(args.steps, 20))
+
+    extra = rank == 0 and world == 1
+    # ---- rollout legs: batched multi-step inference from one HIP graph (the metric's "rollout" half; configs[4]) ----
+    if extra and not args.no_rollout:
+        result["rollout"], _ = rollout_leg(model, args.rollout_batch, args.rollout_steps, H, W, p, dev)
+        torch.manual_seed(0)
+        m32 = Fno2d(2, 2, p, loss_name_to_fn("nmse"), 4, 12, 12, 32).to(dev)  # the reference's default width (args.py:190)
+        result["rollout_66x65"], _ = rollout_leg(m32, args.rollout_batch, args.rollout_steps, 66, 65, p, dev)
         try:
-            pmc = json.loads(sorted((REPO / "profiles").glob("r*_pmc_traffic.json"))[-1].read_text())
-            match = [v for k, v in pmc.items() if k.startswith(dom[0] + "<") or k == dom[0]]
-            if match and B == 256 and C == 20:
-                result["roofline"]["traffic"] = int(sum(m["traffic_bytes"] for m in match) / len(match))
-                result["roofline"]["traffic_source"] = "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch)"
+            result["rollout_66x65_bf16"], _ = rollout_leg(m32, args.rollout_batch, args.rollout_steps, 66, 65, p, dev, dtype="bf16")
+        except TypeError:
+            result["rollout_66x65_bf16"] = None  # bf16 activation storage not built in this tree
+        del m32
+
+    # ---- the same step with exact-fp32 contractions (the split-bf16 trade on the record) ------------------------------
+    if extra and not args.no_extra:
+        try:
+            api.call("cfd_tune_set", b"exact_fp32", 1)
+            dt = time_steps(lambda: eng.train_step(inputs, label, cp, mask), args.steps, 3)
+            api.call("cfd_tune_set", b"exact_fp32", -1)
+            result["exact_fp32"] = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(B / dt, 1),
+                                        what="every contraction of the step on the exact-fp32 kernels (fp32 MFMA / FMA)")
         except Exception:  # noqa: BLE001
-            pass
-        # north-star kernel group: SpectralConv2d forward+backward alone, algorithmic bytes 5N + 3Wb
-        plan = _lib.plan(H, W, 12, 12, dev.index)
-        x = torch.randn(B, C, H, W, device=dev)
-        gy = torch.randn(B, C, H, W, device=dev)
-        w1 = torch.view_as_real(torch.rand(C, C, 12, 12, dtype=torch.cfloat, device=dev) / (C * C)).contiguous()
-        w2 = torch.view_as_real(torch.rand(C, C, 12, 12, dtype=torch.cfloat, device=dev) / (C * C)).contiguous()
-        y, gx = torch.empty_like(x), torch.empty_like(x)
-        gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
-        xh = torch.empty(B, C, 24, 12, 2, device=dev)
-        z = torch.empty(B, C, 24, 12, 2, device=dev)
-        ws = torch.empty(api.size("cfd_spectral_conv2d_bwd_workspace_bytes", plan, B, C, C), dtype=torch.uint8, device=dev)
-        st = torch.cuda.current_stream().cuda_stream
+            result["exact_fp32"] = None
 
-        def spec():
-            api.call("cfd_spectral_conv2d_fwd", plan, x.data_ptr(), w1.data_ptr(), w2.data_ptr(), y.data_ptr(), xh.data_ptr(),
-                     z.data_ptr(), B, C, C, st)
-            api.call("cfd_spectral_conv2d_bwd", plan, gy.data_ptr(), xh.data_ptr(), w1.data_ptr(), w2.data_ptr(), gx.data_ptr(),
-                     gw1.data_ptr(), gw2.data_ptr(), ws.data_ptr(), B, C, C, st)
-
-        for _ in range(3):
-            spec()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = max(args.steps, 20)
-        e0.record()
-        for _ in range(reps):
-            spec()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / reps * 1e3
-        Nb = B * C * H * W * 4
-        Wb = 2 * C * C * 144 * 8
-        alg = 5 * Nb + 3 * Wb
-        gbs = alg / (us * 1e-6) / 1e9
-        result["roofline_spectral_conv2d"] = dict(
-            what="SpectralConv2d fwd+bwd (dft, mix, idft | dft, mix_adj + wgrad in one launch, idft carrying the partial-sum reduction)", bound="hbm",
-            algorithmic_bytes=alg, avg_us=round(us, 2), achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-            frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None)
-
-    # ---- rollout leg (rank 0): batched multi-step inference from one HIP graph (BASELINE metric's "rollout" half) ---
-    if rank == 0 and world == 1 and not args.no_rollout:  # N=1 only: keeps the multi-rank runs short
-        from cfdbench_amd.rollout import FnoRollout
-        Br, steps_r = args.rollout_batch, args.rollout_steps
-        ro = FnoRollout(model)
-        x0 = inputs[:Br].contiguous()
-        fr = ro.generate_many(x0, cp[:Br].contiguous(), mask[:Br].contiguous(), steps_r)  # builds + captures the graph
-        torch.cuda.synchronize()
-        t0r = time.perf_counter()
-        reps_r = 3
-        for _ in range(reps_r):
-            fr = ro.generate_many(x0, cp[:Br].contiguous(), mask[:Br].contiguous(), steps_r)
-        torch.cuda.synchronize()
-        dtr = (time.perf_counter() - t0r) / reps_r
-        with torch.no_grad():
-            plain = model.generate_many(x0, cp[:Br].contiguous(), mask[:Br].contiguous(), 3)
-        result["rollout"] = dict(
-            what=f"FnoRollout.generate_many: {Br} cases x {steps_r} steps, {H}x{W}, fp32, one HIP graph per horizon",
-            frames_per_s=round(Br * steps_r / dtr, 1), ms_per_step=round(dtr / steps_r * 1e3, 4),
-            bitwise_equal_to_generate_many=bool(all(torch.equal(a, b) for a, b in zip(plain, fr[:3]))))
+    # ---- other model families of BASELINE.json (one GPU's share of configs[2] and configs[3]) -----------------------
+    if extra and not args.no_extra:
+        from cfdbench_amd.models.auto_deeponet import AutoDeepONet
+        from cfdbench_amd.models.unet import UNet
+        gg = torch.Generator(device="cpu").manual_seed(7)
+        Bu, pu = 128, 8
+        torch.manual_seed(0)
+        unet = UNet(2, 2, loss_name_to_fn("nmse"), pu, insert_case_params_at="input", dim=12).to(dev)
+        xu = torch.randn(Bu, 2, 64, 64, generator=gg).to(dev)
+        bu = dict(inputs=xu, label=(xu.cpu() + 0.1 * torch.randn(Bu, 2, 64, 64, generator=gg)).to(dev),
+                  case_params=torch.randn(Bu, pu, generator=gg).to(dev), mask=torch.ones(Bu, 1, 64, 64, device=dev))
+        result["unet_cfg2"] = model_train_leg(api, "unet", unet, bu, 10, 3, Bu, unet_bytes_per_frame(12, 2 + 1 + pu, 64, 64),
+                                              "BASELINE configs[2] per GPU: U-Net(dim 12, p=8) train step (fwd+nMSE+bwd+Adam), batch 128, 64x64, fp32")
+        del unet, bu
+        Bd, Hd, Wd = 512, 66, 65
+        torch.manual_seed(0)
+        don = AutoDeepONet(Hd * Wd + 5, 2, loss_name_to_fn("nmse"), branch_depth=8, trunk_depth=8, width=100, act_name="relu").to(dev)
+        xd = torch.randn(Bd, 2, Hd, Wd, generator=gg).to(dev)
+        bd = dict(inputs=xd, label=(xd.cpu() + 0.1 * torch.randn(Bd, 2, Hd, Wd, generator=gg)).to(dev),
+                  case_params=torch.randn(Bd, 5, generator=gg).to(dev), mask=torch.ones(Bd, 1, Hd, Wd, device=dev))
+        result["auto_deeponet_cfg3"] = model_train_leg(api, "auto_deeponet", don, bd, 10, 3, Bd, None,
+                                                       "BASELINE configs[3] per GPU: Auto-DeepONet(width 100, depth 8/8) train step, batch 512, 66x65, fp32")
+        del don, bd
 
     # ---- CPU baseline leg (rank 0, N=1): the reference's ATen call sequence on the host cores ------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if extra and not args.no_cpu_baseline:
         from oracle import torch_port
         ncpu = os.cpu_count() or 1
         # ATen's CPU kernels do not scale to every hardware thread at this size (256 threads on the 2x64-core GPU box is
-        # pathologically slow): probe two moderate thread counts with one timed step each, keep the faster, and stop
-        # probing as soon as ~20 s are spent so the default run stays within minutes.
+        # pathologically slow): probe two moderate thread counts with one timed step each at batch 32, keep the faster.
         cands = sorted({t for t in (16, 64) if t <= ncpu} or {ncpu})
         probe, t_probe0 = {}, time.perf_counter()
         for t in cands:
-            probe[t] = torch_port.time_train_steps(args.cpu_batch, 1, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=t)["frames_per_s"]
-            if time.perf_counter() - t_probe0 > 20.0:
+            probe[t] = torch_port.time_train_steps(32, 1, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=t)["frames_per_s"]
+            if time.perf_counter() - t_probe0 > 15.0:
                 break
         best_t = max(probe, key=probe.get)
-        cb = torch_port.time_train_steps(args.cpu_batch, args.cpu_steps, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=best_t)
+        cb32 = torch_port.time_train_steps(32, 5, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=best_t)
+        cb = torch_port.time_train_steps(B, args.cpu_steps, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=best_t)
         result["cpu_baseline"] = dict(
             value=round(cb["frames_per_s"], 1), unit="frames/s", cores=cb["threads"], kind="port",
-            sample=f"same train step (fwd+nMSE+bwd+Adam) via oracle/torch_port.py (PyTorch-CPU ATen ops, fp32), batch "
-                   f"{args.cpu_batch} x {args.cpu_steps} steps after 1 warm-up, median; best of thread counts "
-                   f"{ {t: round(v, 1) for t, v in probe.items()} } on {ncpu} host cores")
+            sample=f"the SAME workload (train step fwd+nMSE+bwd+Adam, batch {B}) via oracle/torch_port.py (PyTorch-CPU ATen ops, fp32; "
+                   f"checked against the oracle in tests/test_oracle_golden.py), {args.cpu_steps} steps after 1 warm-up, median; "
+                   f"thread count = best of { {t: round(v, 1) for t, v in probe.items()} } frames/s at batch 32, {ncpu} host cores",
+            value_batch32=round(cb32["frames_per_s"], 1))
 
     if rank == 0:
         print(json.dumps(result), flush=True)

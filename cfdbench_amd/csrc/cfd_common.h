@@ -38,12 +38,16 @@ int cfd_tune_get(int which);
 struct CfdProfScope {
     hipStream_t st;
     int idx;
-    CfdProfScope(const char* name, hipStream_t s);
+    CfdProfScope(const char* name, hipStream_t s, double bytes = 0.0, double flops = 0.0);
     ~CfdProfScope();
 };
 #define CFD_PROF_CAT2(a, b) a##b
 #define CFD_PROF_CAT(a, b) CFD_PROF_CAT2(a, b)
 #define CFD_PROF(name, st) CfdProfScope CFD_PROF_CAT(cfd_prof_scope_, __LINE__)(name, st)
+// the same with the launch's ALGORITHMIC HBM bytes (what must cross HBM once: inputs read + outputs written, DESIGN.md
+// section 4) and flops, so that bench.py's roofline of a kernel whose launches differ in shape is the sum over its launches
+#define CFD_PROF_W(name, st, bytes, flops) \
+    CfdProfScope CFD_PROF_CAT(cfd_prof_scope_, __LINE__)(name, st, (double)(bytes), (double)(flops))
 
 // Operator tables of one (H,W,m1,m2); all d_* pointers are device memory, fragment-major ([step][lane]).
 struct cfd_plan {

@@ -427,7 +427,8 @@ extern "C" int cfd_conv2d_fwd(const float* in, const float* w, const float* bias
     CFD_TRY(conv_check("cfd_conv2d_fwd", B, Ci, Co, H, W, ks));
     if (B == 0) return CFD_OK;
     const ConvGeom g{B, Ci, Co, H, W, ks};
-    CFD_PROF("k_conv_fwd", (hipStream_t)stream);
+    CFD_PROF_W("k_conv_fwd", (hipStream_t)stream, 4.0 * ((double)B * (Ci + Co) * H * W + (double)Co * Ci * ks * ks),
+               2.0 * B * H * W * (double)Co * Ci * ks * ks);
     return launch_conv_gather<false>(in, w, bias, out, g, (float*)ws, (hipStream_t)stream, "cfd_conv2d_fwd");
 }
 
@@ -804,7 +805,8 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
     if (gin) {
         float* ext = (float*)ws;
         {
-            CFD_PROF("k_conv_dgrad", st);
+            CFD_PROF_W("k_conv_dgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci * ks * ks),
+                       2.0 * B * HW * (double)Co * Ci * ks * ks);
             const size_t ext_bytes = cfd_align_up((size_t)B * Ci * (H + 2 * pad) * (W + 2 * pad) * sizeof(float), 256);
             float* split_ws = conv_split_bytes<true>(g) ? (float*)((char*)ws + ext_bytes) : nullptr;
             CFD_TRY(launch_conv_gather<true>(gout, w, nullptr, ext, g, split_ws, st, "cfd_conv2d_bwd(dgrad)"));
@@ -812,7 +814,7 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
         const long total = (long)B * Ci * HW;
         long blocks = (total + 255) / 256;
         if (blocks > 4096) blocks = 4096;
-        CFD_PROF("k_fold_pad", st);
+        CFD_PROF_W("k_fold_pad", st, 0.0, 0.0);  // pure data movement of the extended-grid formulation: no algorithmic bytes
         CFD_REQUIRE_I31(total, "cfd_conv2d_bwd");
         hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ext, gin, (unsigned)total, H, W,
                            pad, cfd_div_make((unsigned)HW), cfd_div_make((unsigned)W));
@@ -834,7 +836,8 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
                 const dim3 grid(groups, (Ci + CC - 1) / CC, ((Co + 15) / 16 + mtw - 1) / mtw);
                 // channel chunks / output groups that a workgroup does not own are written by the others; rows of a
                 // partially filled last chunk are covered because every (o, i) pair belongs to exactly one workgroup
-                CFD_PROF("k_conv_wgrad", st);
+                CFD_PROF_W("k_conv_wgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci * ks * ks),
+                           2.0 * B * HW * (double)Co * Ci * ks * ks);
 #define CW_T(K_, M_, C_)                                                                                                  \
     do {                                                                                                                  \
         static bool attr_set = false;                                                                                     \
@@ -854,7 +857,8 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
         wgrad_plan((long)B * HW, Co, J, chunk_px, nchunk);
         const dim3 grid(nchunk, (Co + 16 * CW_MT - 1) / (16 * CW_MT), (J + 16 * CW_NT - 1) / (16 * CW_NT));
         {
-            CFD_PROF("k_conv_wgrad", st);
+            CFD_PROF_W("k_conv_wgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci * ks * ks),
+                       2.0 * B * HW * (double)Co * Ci * ks * ks);
             CFD_REQUIRE_I31((long)B * HW, "cfd_conv2d_bwd");
             hipLaunchKernelGGL((k_conv_wgrad<false>), grid, dim3(64 * CV_WAVES), 0, st, gout, in, (float*)ws, g,
                                (unsigned)chunk_px, cfd_div_make((unsigned)HW), cfd_div_make((unsigned)W));
@@ -862,7 +866,7 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
         }
         CFD_LAUNCH_CHECK("cfd_conv2d_bwd(wgrad)");
         const long n = (long)Co * J;
-        CFD_PROF("k_part_reduce", st);
+        CFD_PROF_W("k_part_reduce", st, 0.0, 0.0);  // partial sums are an implementation detail
         launch_part_reduce((const float*)ws, gw, n, nchunk, st);
         CFD_LAUNCH_CHECK("cfd_conv2d_bwd(reduce)");
     }
@@ -1057,7 +1061,7 @@ extern "C" int cfd_batchnorm_fwd(const float* x, const float* gamma, const float
     float* part = (float*)ws;
     const float count = (float)((double)B * HW);
     if (training) {
-        CFD_PROF("k_bn_stats", st);
+        CFD_PROF_W("k_bn_stats", st, 4.0 * B * C * HW, 3.0 * B * C * HW);
         hipLaunchKernelGGL((k_bn_partial<3>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, part, B, C, HW, 0, cfd_div_make((unsigned)HW));
         hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 3, count, eps, momentum, save_mean,
@@ -1069,7 +1073,7 @@ extern "C" int cfd_batchnorm_fwd(const float* x, const float* gamma, const float
         CFD_LAUNCH_CHECK("cfd_batchnorm_fwd(eval stats)");
     }
     const long total = (long)B * C * HW;
-    CFD_PROF("k_bn_apply", st);
+    CFD_PROF_W("k_bn_apply", st, 8.0 * B * C * HW, 2.0 * B * C * HW);
     hipLaunchKernelGGL(k_bn_apply, dim3(ew_blocks(total)), dim3(256), 0, st, x, (const float*)save_mean,
                        (const float*)save_rstd, gamma, beta, y, (unsigned)total, C, relu, cfd_div_make((unsigned)HW),
                        cfd_div_make((unsigned)C));
@@ -1095,7 +1099,7 @@ extern "C" int cfd_batchnorm_bwd(const float* gy, const float* x, const float* g
     float* packed = part + (size_t)C * BN_SPLIT * 2;  // (mean, gamma, beta) for the relu mask inside the reduction
     hipLaunchKernelGGL(k_pack3, dim3((C + 255) / 256), dim3(256), 0, st, save_mean, gamma, beta, packed, C);
     {
-        CFD_PROF("k_bn_bwd_reduce", st);
+        CFD_PROF_W("k_bn_bwd_reduce", st, 8.0 * B * C * HW, 4.0 * B * C * HW);
         hipLaunchKernelGGL((k_bn_partial<2>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, gy, (const float*)packed, save_rstd,
                            part, B, C, HW, relu, cfd_div_make((unsigned)HW));
         hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 2, 1.f, 0.f, 0.f, (float*)nullptr,
@@ -1103,7 +1107,7 @@ extern "C" int cfd_batchnorm_bwd(const float* gy, const float* x, const float* g
     }
     CFD_LAUNCH_CHECK("cfd_batchnorm_bwd(reduce)");
     const long total = (long)B * C * HW;
-    CFD_PROF("k_bn_bwd_apply", st);
+    CFD_PROF_W("k_bn_bwd_apply", st, 12.0 * B * C * HW, 4.0 * B * C * HW);
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_blocks(total)), dim3(256), 0, st, x, gy, save_mean, save_rstd, gamma, beta,
                        (const float*)gbeta, (const float*)ggamma, gx, (unsigned)total, C, (float)(1.0 / ((double)B * HW)), relu,
                        training, cfd_div_make((unsigned)HW), cfd_div_make((unsigned)C));
@@ -1229,7 +1233,7 @@ extern "C" int cfd_convt2_fwd(const float* in, const float* w, const float* bias
     CFD_REQUIRE(in && w && out, CFD_ERR_INVALID_ARG, "cfd_convt2_fwd: NULL pointer");
     CFD_REQUIRE(B >= 0 && Ci >= 1 && Co >= 1 && H >= 1 && W >= 1, CFD_ERR_INVALID_ARG, "cfd_convt2_fwd: bad sizes");
     if (B == 0) return CFD_OK;
-    CFD_PROF("k_convt2_fwd", (hipStream_t)stream);
+    CFD_PROF_W("k_convt2_fwd", (hipStream_t)stream, 4.0 * B * H * W * ((double)Ci + 4.0 * Co), 8.0 * B * H * W * (double)Ci * Co);
     CFD_REQUIRE_I31((long)B * Co * 4 * H * W, "cfd_convt2_fwd");
     hipLaunchKernelGGL(k_convt2_fwd, dim3(ew_blocks((long)B * Co * 4 * H * W)), dim3(256), 0, (hipStream_t)stream, in, w, bias,
                        out, B, Ci, Co, H, W, cfd_div_make((unsigned)(2 * W)), cfd_div_make((unsigned)(2 * H)),
@@ -1254,7 +1258,7 @@ extern "C" int cfd_convt2_bwd(const float* gout, const float* in, const float* w
     CFD_REQUIRE_I31((long)B * (Ci > 4 * Co ? Ci : 4 * Co) * H * W, "cfd_convt2_bwd");
     hipStream_t st = (hipStream_t)stream;
     if (gin) {
-        CFD_PROF("k_convt2_bwd_in", st);
+        CFD_PROF_W("k_convt2_bwd_in", st, 4.0 * B * H * W * ((double)Ci + 4.0 * Co), 8.0 * B * H * W * (double)Ci * Co);
         hipLaunchKernelGGL(k_convt2_bwd_in, dim3(ew_blocks((long)B * Ci * H * W)), dim3(256), 0, st, gout, w, gin, B, Ci, Co, H, W,
                            cfd_div_make((unsigned)W), cfd_div_make((unsigned)H), cfd_div_make((unsigned)Ci));
         CFD_LAUNCH_CHECK("cfd_convt2_bwd(input)");
@@ -1267,7 +1271,7 @@ extern "C" int cfd_convt2_bwd(const float* gout, const float* in, const float* w
         const ConvGeom g{B, Ci, Co, H, W, 2};
         const dim3 grid(nchunk, (Ci + 16 * CW_MT - 1) / (16 * CW_MT), (J + 16 * CW_NT - 1) / (16 * CW_NT));
         {
-            CFD_PROF("k_convt2_wgrad", st);
+            CFD_PROF_W("k_convt2_wgrad", st, 4.0 * B * H * W * ((double)Ci + 4.0 * Co), 8.0 * B * H * W * (double)Ci * Co);
             hipLaunchKernelGGL((k_conv_wgrad<true>), grid, dim3(64 * CV_WAVES), 0, st, in, gout, (float*)ws, g,
                                (unsigned)chunk_px, cfd_div_make((unsigned)(H * W)), cfd_div_make((unsigned)W));
         }

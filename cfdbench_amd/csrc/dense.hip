@@ -210,7 +210,7 @@ static int launch_gemm(const float* A, const float* B, float* C, int M, int N, i
     float* Ck = splits > 1 ? (float*)ws : C;
     const int ldk = splits > 1 ? N : ldc;
     {
-        CFD_PROF("k_gemm", st);
+        CFD_PROF_W("k_gemm", st, 4.0 * ((double)M * K + (double)K * N + (double)M * N), 2.0 * M * (double)N * K);
         if (!at && !bt) hipLaunchKernelGGL((k_gemm<false, false>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);
         else if (!at && bt) hipLaunchKernelGGL((k_gemm<false, true>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);
         else if (at && !bt) hipLaunchKernelGGL((k_gemm<true, false>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);
@@ -218,7 +218,7 @@ static int launch_gemm(const float* A, const float* B, float* C, int M, int N, i
     }
     CFD_LAUNCH_CHECK(what);
     if (splits > 1) {
-        CFD_PROF("k_splitk_reduce", st);
+        CFD_PROF_W("k_splitk_reduce", st, 0.0, 0.0);  // split-K partials are an implementation detail
         size_t blocks = ((size_t)M * N + 255) / 256;
         if (blocks > 1024) blocks = 1024;
         hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, C, M, N, ldc, splits, epi);
@@ -454,7 +454,7 @@ extern "C" int cfd_normact_fwd(const float* x, float* y, float* stats, int S, lo
     CFD_REQUIRE(x && y && stats, CFD_ERR_INVALID_ARG, "cfd_normact_fwd: NULL pointer");
     CFD_REQUIRE(S >= 0 && L >= 2 && act >= 1 && act <= 4, CFD_ERR_INVALID_ARG, "cfd_normact_fwd: bad sizes / activation");
     if (S == 0) return CFD_OK;
-    CFD_PROF("k_normact_fwd", (hipStream_t)stream);
+    CFD_PROF_W("k_normact_fwd", (hipStream_t)stream, 8.0 * S * (double)L, 10.0 * S * (double)L);
     hipLaunchKernelGGL(k_normact_fwd, dim3(S), dim3(256), 0, (hipStream_t)stream, x, y, stats, L, act);
     CFD_LAUNCH_CHECK("cfd_normact_fwd");
     return CFD_OK;
@@ -465,7 +465,7 @@ extern "C" int cfd_normact_bwd(const float* x, const float* gy, const float* sta
     CFD_REQUIRE(x && gy && stats && gx, CFD_ERR_INVALID_ARG, "cfd_normact_bwd: NULL pointer");
     CFD_REQUIRE(S >= 0 && L >= 2 && act >= 1 && act <= 4, CFD_ERR_INVALID_ARG, "cfd_normact_bwd: bad sizes / activation");
     if (S == 0) return CFD_OK;
-    CFD_PROF("k_normact_bwd", (hipStream_t)stream);
+    CFD_PROF_W("k_normact_bwd", (hipStream_t)stream, 12.0 * S * (double)L, 14.0 * S * (double)L);
     hipLaunchKernelGGL(k_normact_bwd, dim3(S), dim3(256), 0, (hipStream_t)stream, x, gy, stats, gx, L, act);
     CFD_LAUNCH_CHECK("cfd_normact_bwd");
     return CFD_OK;

@@ -213,7 +213,7 @@ extern "C" int cfd_fno_head_fwd(const float* a, const float* mask, const float* 
     float* part = label ? (float*)ws : nullptr;
     const bool v4 = HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)preds % 16) == 0;
     {
-    CFD_PROF("k_head_fwd", st);
+    CFD_PROF_W("k_head_fwd", st, 4.0 * B * HW * ((double)C + 1 + (label ? 2 : 1) * Co), 2.0 * B * HW * (double)HEAD_HD * (C + Co));
 #define CFD_HF(V_, A_)                                                                                      \
     hipLaunchKernelGGL((k_head_fwd<V_, A_>), dim3(blocks), dim3(256), 0, st, a, mask, label, w1, b1, w2, b2, \
                        preds, part, B, C, Co, HW)
@@ -606,7 +606,7 @@ extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* 
     float* part = (float*)ws;
     const bool v4 = HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)ga % 16) == 0;
     {
-    CFD_PROF("k_head_bwd", st);
+    CFD_PROF_W("k_head_bwd", st, 4.0 * B * HW * (2.0 * C + 1 + 2.0 * Co), 2.0 * B * HW * (double)HEAD_HD * (3.0 * C + 2.0 * Co));
 #define CFD_HB(K_, V_, A_)                                                                                         \
     hipLaunchKernelGGL((k_head_bwd<K_, V_, A_>), dim3(blocks), dim3(256), 0, st, a, mask, label, preds, gpreds_ext, \
                        coef, w1, b1, w2, ga, part, B, C, Co, HW)
@@ -625,7 +625,7 @@ extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* 
     }
     CFD_LAUNCH_CHECK("cfd_fno_head_bwd");
     const int PS = (int)head_part_floats(C, Co);
-    CFD_PROF("k_head_reduce", st);
+    CFD_PROF_W("k_head_reduce", st, 0.0, 0.0);
     hipLaunchKernelGGL(k_head_reduce, dim3((PS + 3) / 4), dim3(256), 0, st, (const float*)part, blocks, PS, gw1,
                        gb1, gw2, gb2, C, Co);
     CFD_LAUNCH_CHECK("cfd_fno_head_bwd(reduce)");

@@ -126,7 +126,7 @@ extern "C" int cfd_fno_stem_fwd(const cfd_plan* p, const float* inputs, const fl
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
-    CFD_PROF("k_stem_fwd", st);
+    CFD_PROF_W("k_stem_fwd", st, 4.0 * B * p->H * p->W * ((double)in_chan + 1 + C), 2.0 * B * p->H * p->W * (double)C * (in_chan + 3 + P));
 #define CFD_STEM(CPV)                                                                                              \
     hipLaunchKernelGGL((k_stem_fwd<CPV>), dim3(blocks), dim3(256), 0, st, inputs, mask, case_params,               \
                        (const float*)p->d_gx, (const float*)p->d_gy, w, bias, out, B, in_chan, P, C, p->H, p->W)
@@ -228,7 +228,8 @@ static int launch_chanmix(const float* in, const float* w, const float* bias, fl
     const long total = (long)B * (HW / VEC);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    CFD_PROF(transpose ? "k_chanmix_t" : (act ? "k_chanmix_act" : "k_chanmix"), st);
+    CFD_PROF_W(transpose ? "k_chanmix_t" : (act ? "k_chanmix_act" : "k_chanmix"), st, 4.0 * B * HW * ((double)Ci + Co),
+               2.0 * B * HW * (double)Ci * Co);
     if (act)
         hipLaunchKernelGGL((k_chanmix<CPO, VEC, true>), dim3(blocks), dim3(256), 0, st, in, w, bias, out, B, Ci, Co, HW, transpose);
     else
@@ -491,7 +492,9 @@ static int launch_wgrad(const float* g, const float* in, StemSrc ss, float* gw, 
         else CFD_WG(M_, N_, false, false);             \
     } while (0)
     {
-    CFD_PROF(STEM ? "k_chan_wgrad_stem" : "k_chan_wgrad", st);
+    // stem: the gradient tensor + the raw input channels (features are generated); otherwise gradient + activation
+    CFD_PROF_W(STEM ? "k_chan_wgrad_stem" : "k_chan_wgrad", st, 4.0 * B * HW * ((double)Co + (STEM ? 3 : Ci)),
+               2.0 * B * HW * (double)Co * (Ci + 1));
     if (MT == 1 && NT == 1) CFD_WG_VA(1, 1);
     else if (MT == 1 && NT == 2) CFD_WG_VA(1, 2);
     else if (MT == 2 && NT == 1) CFD_WG_VA(2, 1);
@@ -510,7 +513,7 @@ static int launch_wgrad(const float* g, const float* in, StemSrc ss, float* gw, 
         *defer = ChanWgradTail{(const float*)part, gw, gb, blocks, Co, Ci};
         return CFD_OK;
     }
-    CFD_PROF("k_wgrad_reduce", st);
+    CFD_PROF_W("k_wgrad_reduce", st, 0.0, 0.0);  // partial sums are an implementation detail
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((Co * (Ci + 1) + 3) / 4), dim3(256), 0, st, (const float*)part, blocks,
                        gw, gb, Co, Ci);
     CFD_LAUNCH_CHECK("cfd_chan_wgrad(reduce)");
@@ -719,7 +722,7 @@ extern "C" int cfd_adam_flat(float* param, const float* grad, float* exp_avg, fl
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     size_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    CFD_PROF("k_adam", (hipStream_t)stream);
+    CFD_PROF_W("k_adam", (hipStream_t)stream, 28.0 * n, 12.0 * n);  // read p, g, m, v; write p, m, v
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)),
                        grad_scale);

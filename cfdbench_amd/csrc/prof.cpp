@@ -13,16 +13,17 @@ namespace {
 struct Rec {
     const char* name;
     hipEvent_t a, b;
+    double bytes, flops;  // algorithmic HBM bytes / flops this launch stands for (0 = not declared)
 };
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec> g_recs;
 }  // namespace
 
-CfdProfScope::CfdProfScope(const char* name, hipStream_t s) : st(s), idx(-1) {
+CfdProfScope::CfdProfScope(const char* name, hipStream_t s, double bytes, double flops) : st(s), idx(-1) {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    Rec r{name, nullptr, nullptr};
+    Rec r{name, nullptr, nullptr, bytes, flops};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
@@ -43,17 +44,20 @@ extern "C" int cfd_prof_begin(void) {
     return CFD_OK;
 }
 
-// Synchronises, writes one line per kernel "name count total_ms\n" into buf, disables profiling.
+// Synchronises, writes one line per kernel "name count total_ms total_bytes total_flops\n" into buf, disables profiling.
 extern "C" int cfd_prof_end(char* buf, size_t cap) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_on = false;
-    std::map<std::string, std::pair<int, double>> agg;
+    struct Agg { int n = 0; double ms = 0, bytes = 0, flops = 0; };
+    std::map<std::string, Agg> agg;
     for (auto& r : g_recs) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             auto& e = agg[r.name];
-            e.first += 1;
-            e.second += ms;
+            e.n += 1;
+            e.ms += ms;
+            e.bytes += r.bytes;
+            e.flops += r.flops;
         }
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -62,7 +66,8 @@ extern "C" int cfd_prof_end(char* buf, size_t cap) {
     std::string out;
     char line[256];
     for (auto& kv : agg) {
-        snprintf(line, sizeof(line), "%s %d %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        snprintf(line, sizeof(line), "%s %d %.6f %.0f %.0f\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.bytes,
+                 kv.second.flops);
         out += line;
     }
     if (buf && cap) {

@@ -374,7 +374,8 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64_b3(const float*
 
 template <int NJ, bool VEC4>
 static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, int act, hipStream_t st) {
-    CFD_PROF(act ? "k_dft_fwd_act" : "k_dft_fwd", st);
+    CFD_PROF_W(act ? "k_dft_fwd_act" : "k_dft_fwd", st, (double)nimg * (4.0 * p->H * p->W + 16.0 * p->m1 * p->m2),
+               (double)nimg * (4.0 * (p->m1 + 1) * (p->H / 2 + 1) * p->W + 8.0 * (p->m1 + 1) * p->W * p->m2));
     if constexpr (VEC4) {
         if (p->W == 64 && p->H == 64 && p->d_fwd_b3) {
             int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
@@ -715,7 +716,8 @@ extern "C" int cfd_spectral_mix(const cfd_plan* p, const float* xh, const float*
     if (B == 0) return CFD_OK;
     const int Cr = conj_t ? Cout : Cin, Cz = conj_t ? Cin : Cout;
     hipStream_t st = (hipStream_t)stream;
-    CFD_PROF(conj_t ? "k_mix_adj" : "k_mix", st);
+    CFD_PROF_W(conj_t ? "k_mix_adj" : "k_mix", st, 16.0 * p->m1 * p->m2 * ((double)B * (Cin + Cout) + (double)Cin * Cout),
+               16.0 * B * (double)Cin * Cout * p->m1 * p->m2);
     if (conj_t ? launch_mix_lds<true>((const float2*)xh, (const float2*)w1, (const float2*)w2, (float2*)z, B, Cr, Cz, Cout,
                                       p->m1, p->m2, st)
                : launch_mix_lds<false>((const float2*)xh, (const float2*)w1, (const float2*)w2, (float2*)z, B, Cr, Cz, Cout,
@@ -1029,7 +1031,8 @@ extern "C" int cfd_spectral_wgrad(const cfd_plan* p, const float* xh, const floa
     const long total = (long)Cin * Cout * M;
     hipStream_t st = (hipStream_t)stream;
     {
-        CFD_PROF("k_spec_wgrad_part", st);
+        CFD_PROF_W("k_spec_wgrad_part", st, 16.0 * p->m1 * p->m2 * ((double)B * (Cin + Cout) + (double)Cin * Cout),
+                   16.0 * B * (double)Cin * Cout * p->m1 * p->m2);
         // register-tiled kernel where the channel counts divide into its wave tiles (the FNO widths 10 / 20 / 40 ...),
         // lane = mode kernel otherwise
         const bool done = launch_spec_wgrad_tile<5, 10, 2>((const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M,
@@ -1038,7 +1041,7 @@ extern "C" int cfd_spectral_wgrad(const cfd_plan* p, const float* xh, const floa
             CFD_MIX_DISPATCH(launch_spec_wgrad, Cin, Cout, (const float2*)xh, (const float2*)gh, (float2*)ws, B, Cin, Cout, M, st);
     }
     CFD_LAUNCH_CHECK("cfd_spectral_wgrad(part)");
-    CFD_PROF("k_spec_wgrad_reduce", st);
+    CFD_PROF_W("k_spec_wgrad_reduce", st, 0.0, 0.0);
     hipLaunchKernelGGL(k_spec_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        (const float2*)ws, (float2*)gw1, (float2*)gw2, (const float*)p->d_clhw, nchunk, Cin * Cout,
                        p->m1, p->m2);
@@ -1086,7 +1089,7 @@ int cfd_int_spectral_mix_adj_wgrad(const cfd_plan* p, const float* xh, const flo
         // 5 x 5 accumulator tiles, 3-stage ring, two workgroups per (mode group, chunk): 122 registers, so two
         // workgroups per CU (measured: 19.1 us per launch against 20.9 / 22.8 us for 5 x 10 tiles with 2 / 4 stages)
         // width 32 (the reference's default --fno_hidden_dim): 4 x 8 tiles, four workgroups per (mode group, chunk)
-        CFD_PROF("k_mixadj_wgrad", st);
+        CFD_PROF_W("k_mixadj_wgrad", st, 16.0 * p->m1 * p->m2 * (3.0 * B * Cin + 2.0 * Cin * Cout), 32.0 * B * (double)Cin * Cout * p->m1 * p->m2);
         if (Cin == 20)
             launch_mixadj_wgrad<20, 5, 5, 3, 2>((const float2*)xh, (const float2*)gh, (const float2*)w1, (const float2*)w2,
                                                 (float2*)gz, (float2*)ws, B, p->m1, p->m2, &nchunk, st);
@@ -1101,7 +1104,7 @@ int cfd_int_spectral_mix_adj_wgrad(const cfd_plan* p, const float* xh, const flo
                                p->m1, p->m2};
         return CFD_OK;
     }
-    CFD_PROF("k_spec_wgrad_reduce", st);
+    CFD_PROF_W("k_spec_wgrad_reduce", st, 0.0, 0.0);
     hipLaunchKernelGGL(k_spec_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float2*)ws,
                        (float2*)gw1, (float2*)gw2, (const float*)p->d_clhw, nchunk, Cin * Cout, p->m1, p->m2);
     CFD_LAUNCH_CHECK("cfd_spectral_mix_adj_wgrad(reduce)");
@@ -1406,7 +1409,8 @@ static int launch_idft(const cfd_plan* p, const float* z, const float* addend, c
 #define CFD_IDFT64(E)                                                                                              \
     hipLaunchKernelGGL((k_idft64<E, false>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, z, addend, aprev, out,      \
                        (const bf16x8*)p->d_inv_b3, nimg, p->H, p->m1, p->m2, p->T, p->SA, p->SB, none)
-            CFD_PROF(epi == 0 ? "k_idft" : (epi == 1 ? "k_idft_add" : "k_idft_add_dgelu"), st);
+            CFD_PROF_W(epi == 0 ? "k_idft" : (epi == 1 ? "k_idft_add" : "k_idft_add_dgelu"), st,
+               (double)nimg * (4.0 * p->H * p->W * (1 + epi) + 16.0 * p->m1 * p->m2), (double)nimg * (8.0 * (p->m1 + 1) * p->W * p->m2 + 4.0 * p->H * p->W * p->m2));
             if (epi == 0 && tail && tail->nblk > 0)
                 hipLaunchKernelGGL((k_idft64<0, true>), dim3(blocks + tail->nblk), dim3(64 * CFD_WAVES), 0, st, z, addend,
                                    aprev, out, (const bf16x8*)p->d_inv_b3, nimg, p->H, p->m1, p->m2, p->T, p->SA, p->SB,
@@ -1422,7 +1426,8 @@ static int launch_idft(const cfd_plan* p, const float* z, const float* addend, c
 #define CFD_IDFT_LAUNCH(E)                                                                                         \
     hipLaunchKernelGGL((k_idft<NJ, VEC4, E>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, z, addend, aprev, out,     \
                        (const float*)p->d_inv, p->n_inv, nimg, p->H, p->W, p->m1, p->m2, p->T, p->SA, p->SB)
-    CFD_PROF(epi == 0 ? "k_idft" : (epi == 1 ? "k_idft_add" : "k_idft_add_dgelu"), st);
+    CFD_PROF_W(epi == 0 ? "k_idft" : (epi == 1 ? "k_idft_add" : "k_idft_add_dgelu"), st,
+               (double)nimg * (4.0 * p->H * p->W * (1 + epi) + 16.0 * p->m1 * p->m2), (double)nimg * (8.0 * (p->m1 + 1) * p->W * p->m2 + 4.0 * p->H * p->W * p->m2));
     if (epi == 0) CFD_IDFT_LAUNCH(0);
     else if (epi == 1) CFD_IDFT_LAUNCH(1);
     else CFD_IDFT_LAUNCH(2);
@@ -1755,7 +1760,8 @@ extern "C" int cfd_fno_block_fwd(const cfd_plan* p, const float* a, const float*
         CFD_TRY(cfd_chanmix(a, w0, b0, out, B, Cin, Cout, p->H * p->W, act_in, 0, stream));
         return cfd_spectral_idft(p, z, out, nullptr, out, B * Cout, 1, stream);
     }
-    CFD_PROF(act_in ? "k_block_fwd_act" : "k_block_fwd", st);
+    CFD_PROF_W(act_in ? "k_block_fwd_act" : "k_block_fwd", st, (double)B * (4.0 * p->H * p->W * (Cin + Cout) + 16.0 * p->m1 * p->m2 * Cout),
+               2.0 * B * p->H * p->W * (double)Cin * Cout);
     launch_block(p, a, z, w0, b0, nullptr, out, B, Cin, Cout, act_in, 0, 0, st);
     CFD_LAUNCH_CHECK("cfd_fno_block_fwd");
     return CFD_OK;
@@ -1769,14 +1775,14 @@ static int launch_reduce_tail_standalone(const CfdReduceTail* tail, hipStream_t 
     if (!tail || tail->nblk <= 0) return CFD_OK;
     if (tail->spec.part) {
         const long total = (long)tail->spec.CC * 2 * tail->spec.m1 * tail->spec.m2;
-        CFD_PROF("k_spec_wgrad_reduce", st);
+        CFD_PROF_W("k_spec_wgrad_reduce", st, 0.0, 0.0);
         hipLaunchKernelGGL(k_spec_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tail->spec.part,
                            tail->spec.gw1, tail->spec.gw2, tail->spec.clhw, tail->spec.nchunk, tail->spec.CC, tail->spec.m1,
                            tail->spec.m2);
         CFD_LAUNCH_CHECK("cfd_fno_block_bwd_input(spectral reduce)");
     }
     if (tail->chan.part) {
-        CFD_PROF("k_wgrad_reduce", st);
+        CFD_PROF_W("k_wgrad_reduce", st, 0.0, 0.0);
         hipLaunchKernelGGL(k_chan_reduce_standalone, dim3((tail->chan.Co * (tail->chan.Ci + 1) + 3) / 4), dim3(256), 0, st,
                            tail->chan);
         CFD_LAUNCH_CHECK("cfd_fno_block_bwd_input(1x1 reduce)");
@@ -1796,7 +1802,8 @@ int cfd_int_fno_block_bwd_input(const cfd_plan* p, const float* g, const float* 
         CFD_TRY(cfd_chanmix(g, w0, nullptr, gin, B, Cout, Cin, p->H * p->W, 0, 1, stream));
         return cfd_spectral_idft(p, gz, gin, aprev, gin, B * Cin, aprev ? 2 : 1, stream);
     }
-    CFD_PROF(aprev ? "k_block_bwd_dgelu" : "k_block_bwd", st);
+    CFD_PROF_W(aprev ? "k_block_bwd_dgelu" : "k_block_bwd", st,
+               (double)B * (4.0 * p->H * p->W * (Cin + Cout + (aprev ? Cin : 0)) + 16.0 * p->m1 * p->m2 * Cin), 2.0 * B * p->H * p->W * (double)Cin * Cout);
     launch_block(p, g, gz, w0, nullptr, aprev, gin, B, Cout, Cin, 0, 1, aprev ? 1 : 0, st, tail);
     CFD_LAUNCH_CHECK("cfd_fno_block_bwd_input");
     return CFD_OK;

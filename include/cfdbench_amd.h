@@ -48,7 +48,8 @@ const char* cfd_last_error(void);
 int cfd_tune_set(const char* name, int value);
 
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  cfd_prof_end synchronises and
- * writes "kernel_name launches total_ms\n" lines into buf.  Do not enable during stream capture.               */
+ * writes "kernel_name launches total_ms algorithmic_bytes flops\n" lines into buf (bytes / flops summed over the launches; 0 where a
+ * launch site declares none).  Do not enable during stream capture.               */
 int cfd_prof_begin(void);
 int cfd_prof_end(char* buf, size_t cap);
 

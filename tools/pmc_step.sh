@@ -5,7 +5,7 @@ TAG=${1:-busy}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-rollout"
+CMD="python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-rollout --no-extra"
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc -o p -- $CMD > /dev/null 2> $OUT/pmc.err; echo "rc=$?"
 python - <<PY > $OUT/busy.txt
 import csv, glob, collections
@@ -24,8 +24,13 @@ for k, cs in agg.items():
                  m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / simd / cyc, 4 * m.get("SQ_ACTIVE_INST_VALU", 0) / simd / cyc,
                  4 * m.get("SQ_ACTIVE_INST_LDS", 0) / simd / cyc,
                  m.get("SQ_WAIT_ANY", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1), m.get("SQ_WAIT_INST_ANY", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1)))
+import json
+js = {}
 for _, k, n, cyc, a, b, c, d, e in sorted(rows, reverse=True)[:30]:
     print(f"{k[:44]:44s} {n:4d} {cyc:9.0f} {100*a:6.1f} {100*b:6.1f} {100*c:6.1f} {100*d:6.1f} {100*e:6.1f}")
+    js[k] = dict(launches=n, cycles=round(cyc), mfma=round(100 * a, 1), valu=round(100 * b, 1), lds=round(100 * c, 1), wait=round(100 * d, 1),
+                 stall=round(100 * e, 1))
+json.dump(js, open("$OUT/step_busy.json", "w"), indent=1)
 PY
 cat $OUT/busy.txt
 find $OUT -name "*.csv" -size +2M -delete

@@ -5,7 +5,7 @@ TAG=${1:-prof}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-rollout"
+CMD="python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-rollout --no-extra"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o step -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err; echo "trace rc=$?"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $CMD > /dev/null 2> $OUT/pmc_fetch.err; echo "fetch rc=$?"
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $CMD > /dev/null 2> $OUT/pmc_write.err; echo "write rc=$?"
