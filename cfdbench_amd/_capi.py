@@ -106,6 +106,8 @@ _SIGS = {
     "cfd_dropout": (_I, [_P, _P, _Z, _F, C.c_ulonglong, _P]),
     "cfd_fno_workspace_bytes": (_Z, [_P, C.POINTER(FnoShape), _I]),
     "cfd_fno_forward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "cfd_fno_workspace_bytes_ex": (_Z, [_P, C.POINTER(FnoShape), _I, _I]),
+    "cfd_fno_forward_ex": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "cfd_fno_backward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),
                               _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cfd_fno_backward_phase": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),

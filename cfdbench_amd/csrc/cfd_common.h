@@ -8,7 +8,7 @@
 void cfd_set_error(const char* fmt, ...);
 
 // dispatch overrides (tune.cpp): environment read once per process, cfd_tune_set() afterwards; -1 = built-in choice
-enum { CFD_TUNE_MIX_NWV = 0, CFD_TUNE_WGRAD_WG, CFD_TUNE_FUSED_VARIANT, CFD_TUNE_BLOCK_FUSE, CFD_TUNE_COUNT };
+enum { CFD_TUNE_MIX_NWV = 0, CFD_TUNE_WGRAD_WG, CFD_TUNE_FUSED_VARIANT, CFD_TUNE_BLOCK_FUSE, CFD_TUNE_GENERAL_B3, CFD_TUNE_COUNT };
 int cfd_tune_get(int which);
 
 #define CFD_REQUIRE(cond, code, ...)      \
@@ -66,12 +66,43 @@ struct cfd_plan {
     void* d_inv_b3; // split-bf16 form of the inverse tables for the K = 32 MFMA (NULL unless T <= 4, SA <= 8, SB <= 8,
                     // NJ == 4): 16-byte vectors ta3[T][hi|lo][64 lanes] | tb3[NJ][hi|lo][64 lanes], element v of lane
                     // vector = table value of k-step v (zero beyond SA / SB)
+    // General-width split-bf16 tables (NULL unless H <= 70 and W <= 80): columns are dealt to lanes as y = 16 j + n (tile j of
+    // NJG = ceil(W/16), lane n) instead of the 64-wide kernels' y = 4 n + j, so any W works with coalesced scalar accesses.
+    void* d_fwd_g;  // 16-byte vectors [table][hi|lo][64 lanes]: T1C0, T1S0 (folded rows 4v+q), T1C1, T1S1 (rows 32+4v+q), then
+                    // T2C[h], T2S[h] for the NHG = ceil(NJG/2) column halves (k-slot (q, v = 4jj+r) = column 16(2h+jj)+4q+r)
+    void* d_inv_g;  // ta3[T][hi|lo][64] | tb3[NJG][hi|lo][64] with y = 16 j + n
+    int NJG, NHG, n_fwd_gv, n_inv_gv;  // vector counts of the two tables
     float* d_clhw;  // [m2]  c_l / (H*W)
     float* d_gx;    // [H]  np.linspace(0,1,H) as float32   (fno2d.py:251)
     float* d_gy;    // [W]
 };
 
 static inline size_t cfd_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Storage type of the activations between kernels: float everywhere, or __bf16 on the bf16-storage inference path
+// (BASELINE configs[4]; fp32 arithmetic and accumulation either way).  CFD_DT_* select it at the internal entry points.
+#define CFD_DT_F32 0
+#define CFD_DT_BF16 1
+template <typename TA>
+__device__ __forceinline__ float cfd_ld(const TA* p) { return (float)*p; }
+template <typename TA>
+__device__ __forceinline__ void cfd_st(TA* p, float v) { *p = (TA)v; }
+static inline size_t cfd_dt_size(int dt) { return dt == CFD_DT_BF16 ? 2 : 4; }
+
+// Internal (not exported) forms of the forward-path entry points with the activation storage type as an argument; dt =
+// CFD_DT_F32 is exactly the public function.  x / out / aprev / a point at activations of that type.  With bf16 storage the
+// 1x1 conv writes its (unrounded) result as fp32 and the inverse transform takes that fp32 addend, so a stored pre-activation
+// is rounded exactly once.
+int cfd_int_spectral_dft(const cfd_plan* p, const void* x, float* xh, int nimg, int act_in, int dt, void* stream);
+int cfd_int_spectral_idft(const cfd_plan* p, const float* z, const void* addend, const void* aprev, void* out, int nimg, int epi,
+                          int dt, void* stream);
+int cfd_int_chanmix(const void* in, const float* w, const float* bias, void* out, int B, int Ci, int Co, int HW, int act_in,
+                    int transpose, int dt, void* stream);
+int cfd_int_fno_stem_fwd(const cfd_plan* p, const float* inputs, const float* mask, const float* case_params, const float* w,
+                         const float* bias, void* out, int B, int in_chan, int P, int C, int dt, void* stream);
+int cfd_int_fno_head_fwd(const void* a, const float* mask, const float* label, const float* w1, const float* b1, const float* w2,
+                         const float* b2, float* preds, float* sums, void* ws, int B, int C, int Hd, int Co, int HW, int act_in,
+                         int dt, void* stream);
 
 #define CFD_SQRT1_2 0.70710678118654752440f
 #define CFD_INV_SQRT_2PI 0.39894228040143267794f

@@ -12,15 +12,16 @@ namespace {
 struct Layout {
     size_t n_act;    // floats of one (B,C,H,W) activation
     size_t n_modes;  // floats of one (B,C,2*m1,m2) complex tensor
-    size_t off_acts, off_xh, off_z, off_gA, off_gB, off_gh, off_scratch;
+    size_t off_acts, off_xh, off_z, off_gA, off_gB, off_gh, off_scratch, off_tmp;
     size_t scratch_bytes, total_bytes;
     int n_acts, n_xh;
 };
 
 size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
-Layout make_layout(const cfd_plan* p, const cfd_fno_shape* s, int training) {
+Layout make_layout(const cfd_plan* p, const cfd_fno_shape* s, int training, int dt = CFD_DT_F32) {
     Layout L{};
+    const size_t esz = cfd_dt_size(dt);  // bytes of one stored activation
     const size_t HW = (size_t)s->H * s->W;
     const int C = s->hidden, B = s->B;
     L.n_act = (size_t)B * C * HW;
@@ -29,9 +30,10 @@ Layout make_layout(const cfd_plan* p, const cfd_fno_shape* s, int training) {
     L.n_xh = training ? s->num_layers : 1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += cfd_align_up(bytes, 256); return o; };
-    L.off_acts = take(L.n_act * sizeof(float) * L.n_acts);
+    L.off_acts = take(L.n_act * esz * L.n_acts);
     L.off_xh = take(L.n_modes * sizeof(float) * L.n_xh);
     L.off_z = take(L.n_modes * sizeof(float));
+    L.off_tmp = dt == CFD_DT_BF16 ? take(L.n_act * sizeof(float)) : 0;  // fp32 result of the 1x1 conv (bf16 storage path)
     size_t scratch = cfd_fno_head_workspace_bytes(B, C, s->head, s->out_chan, (int)HW);
     if (training) {
         L.off_gA = take(L.n_act * sizeof(float));
@@ -68,30 +70,54 @@ extern "C" size_t cfd_fno_workspace_bytes(const cfd_plan* p, const cfd_fno_shape
     return make_layout(p, s, training).total_bytes;
 }
 
+extern "C" size_t cfd_fno_workspace_bytes_ex(const cfd_plan* p, const cfd_fno_shape* s, int training, int act_dtype) {
+    if (!p || !s || s->B < 1 || (act_dtype != CFD_DT_F32 && (act_dtype != CFD_DT_BF16 || training))) return 0;
+    return make_layout(p, s, training, act_dtype).total_bytes;
+}
+
 extern "C" int cfd_fno_forward(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm, const float* inputs,
                                const float* case_params, const float* mask, const float* label, float* preds,
                                float* sums, void* ws, int training, void* stream) {
+    return cfd_fno_forward_ex(p, s, prm, inputs, case_params, mask, label, preds, sums, ws, training, CFD_DT_F32, stream);
+}
+
+// bf16 activation storage (act_dtype = 1, inference only): the activations between kernels -- the lifting layer's output, every
+// FnoBlock's pre-activation -- are rounded to bf16 when stored and widened when loaded; inputs, predictions, kept modes,
+// weights and all arithmetic stay fp32.  Halves the activation traffic of a rollout step (3.3 -> 1.7 MB per frame).
+extern "C" int cfd_fno_forward_ex(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm, const float* inputs,
+                                  const float* case_params, const float* mask, const float* label, float* preds,
+                                  float* sums, void* ws, int training, int act_dtype, void* stream) {
     CFD_TRY(check_shape("cfd_fno_forward", p, s));
     CFD_REQUIRE(prm && inputs && preds && ws, CFD_ERR_INVALID_ARG, "cfd_fno_forward: NULL pointer");
     CFD_REQUIRE(!label || sums, CFD_ERR_INVALID_ARG, "cfd_fno_forward: label given without sums");
-    const Layout L = make_layout(p, s, training);
+    CFD_REQUIRE(act_dtype == CFD_DT_F32 || act_dtype == CFD_DT_BF16, CFD_ERR_INVALID_ARG, "cfd_fno_forward: act_dtype %d (0 = fp32, 1 = bf16)", act_dtype);
+    CFD_REQUIRE(act_dtype == CFD_DT_F32 || !training, CFD_ERR_UNSUPPORTED, "cfd_fno_forward: bf16 activation storage is an inference path (training = 0)");
+    const int dt = act_dtype;
+    const Layout L = make_layout(p, s, training, dt);
     char* base = (char*)ws;
     const int B = s->B, C = s->hidden, HW = s->H * s->W, NL = s->num_layers;
-    auto act_buf = [&](int l) { return (float*)(base + L.off_acts) + (size_t)(training ? l : (l & 1)) * L.n_act; };
+    const size_t esz = cfd_dt_size(dt);
+    auto act_buf = [&](int l) { return (void*)(base + L.off_acts + (size_t)(training ? l : (l & 1)) * L.n_act * esz); };
     auto xh_buf = [&](int l) { return (float*)(base + L.off_xh) + (size_t)(training ? l : 0) * L.n_modes; };
     float* z = (float*)(base + L.off_z);
     void* scratch = base + L.off_scratch;
 
-    CFD_TRY(cfd_fno_stem_fwd(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, act_buf(0), B, s->in_chan,
-                             s->n_case_params, C, stream));
+    CFD_TRY(cfd_int_fno_stem_fwd(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, act_buf(0), B, s->in_chan,
+                                 s->n_case_params, C, dt, stream));
     for (int l = 0; l < NL; ++l) {  // FnoBlock.forward, fno2d.py:106-112
         const int act = l > 0;
-        CFD_TRY(cfd_spectral_dft(p, act_buf(l), xh_buf(l), B * C, act, stream));
+        CFD_TRY(cfd_int_spectral_dft(p, act_buf(l), xh_buf(l), B * C, act, dt, stream));
         CFD_TRY(cfd_spectral_mix(p, xh_buf(l), prm->spec_w1[l], prm->spec_w2[l], z, B, C, C, 0, stream));
-        CFD_TRY(cfd_fno_block_fwd(p, act_buf(l), z, prm->w0_w[l], prm->w0_b[l], act_buf(l + 1), B, C, C, act, stream));
+        if (dt == CFD_DT_F32) {
+            CFD_TRY(cfd_fno_block_fwd(p, (const float*)act_buf(l), z, prm->w0_w[l], prm->w0_b[l], (float*)act_buf(l + 1), B, C, C, act, stream));
+        } else {  // bf16 storage: 1x1 conv into an fp32 scratch tensor, inverse transform added to it, ONE rounding on the store
+            float* tmp = (float*)(base + L.off_tmp);
+            CFD_TRY(cfd_int_chanmix(act_buf(l), prm->w0_w[l], prm->w0_b[l], tmp, B, C, C, HW, act, 0, dt, stream));
+            CFD_TRY(cfd_int_spectral_idft(p, z, tmp, nullptr, act_buf(l + 1), B * C, 1, dt, stream));
+        }
     }
-    CFD_TRY(cfd_fno_head_fwd(act_buf(NL), mask, label, prm->fc1_w, prm->fc1_b, prm->fc2_w, prm->fc2_b, preds, sums,
-                             scratch, B, C, s->head, s->out_chan, HW, NL > 0, stream));
+    CFD_TRY(cfd_int_fno_head_fwd(act_buf(NL), mask, label, prm->fc1_w, prm->fc1_b, prm->fc2_w, prm->fc2_b, preds, sums,
+                                 scratch, B, C, s->head, s->out_chan, HW, NL > 0, dt, stream));
     return CFD_OK;
 }
 

@@ -34,20 +34,20 @@ static int head_bwd_blocks(int B, int HW) {
 
 // Input tile in the K = 32 operand layout of v_mfma_f32_16x16x32_bf16: lane group q owns channels 8q .. 8q+7
 // (k-slot v <-> channel 8q + v, zero beyond C) of the lane's four pixels px .. px+3.
-template <bool VEC4, bool ACT>
-__device__ __forceinline__ void head_load_h8(const float* __restrict__ a, int b, int C, int HW, int px, int q,
+template <bool VEC4, bool ACT, typename TA = float>
+__device__ __forceinline__ void head_load_h8(const TA* __restrict__ a, int b, int C, int HW, int px, int q,
                                              float (&h)[8][4]) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int i = 8 * q + c;
-        const float* src = a + ((size_t)b * C + i) * HW + px;
-        if constexpr (VEC4) {
+        const TA* src = a + ((size_t)b * C + i) * HW + px;
+        if constexpr (VEC4 && sizeof(TA) == 4) {
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < C && px < HW) t = *reinterpret_cast<const float4*>(src);
             h[c][0] = t.x; h[c][1] = t.y; h[c][2] = t.z; h[c][3] = t.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h[c][j] = (i < C && px + j < HW) ? src[j] : 0.f;
+            for (int j = 0; j < 4; ++j) h[c][j] = (i < C && px + j < HW) ? cfd_ld(src + j) : 0.f;
         }
         if constexpr (ACT) cfd_gelu4(h[c][0], h[c][1], h[c][2], h[c][3]);
     }
@@ -67,8 +67,8 @@ __device__ __forceinline__ void head_build_w1f(bf16x8* s_hi, bf16x8* s_lo, const
     }
 }
 
-template <bool VEC4, bool ACT>
-__global__ __launch_bounds__(256, 2) void k_head_fwd(const float* __restrict__ a, const float* __restrict__ mask,
+template <bool VEC4, bool ACT, typename TA = float>
+__global__ __launch_bounds__(256, 2) void k_head_fwd(const TA* __restrict__ a, const float* __restrict__ mask,
                                                   const float* __restrict__ label, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                                   const float* __restrict__ b2, float* __restrict__ preds,
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void k_head_fwd(const float* __restrict__ a
         const int b = (int)(tile / tpb);
         const int px = (int)(tile - (long)b * tpb) * 64 + 4 * n;
         float h[8][4];
-        head_load_h8<VEC4, ACT>(a, b, C, HW, px, q, h);
+        head_load_h8<VEC4, ACT, TA>(a, b, C, HW, px, q, h);
         // The 4 pixel phases j run in a ROLLED loop (one 16-pixel sub-tile per trip keeps the live set at one
         // z tile); the phase being processed always sits in h[c][0] / lands in out*[3], registers rotate each trip.
         float out0[4] = {0.f, 0.f, 0.f, 0.f}, out1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -204,6 +204,13 @@ static int head_check(const char* fn, int B, int C, int Hd, int Co, int HW) {
 extern "C" int cfd_fno_head_fwd(const float* a, const float* mask, const float* label, const float* w1, const float* b1,
                                 const float* w2, const float* b2, float* preds, float* sums, void* ws, int B, int C,
                                 int Hd, int Co, int HW, int act_in, void* stream) {
+    return cfd_int_fno_head_fwd(a, mask, label, w1, b1, w2, b2, preds, sums, ws, B, C, Hd, Co, HW, act_in, CFD_DT_F32, stream);
+}
+
+int cfd_int_fno_head_fwd(const void* a_, const float* mask, const float* label, const float* w1, const float* b1, const float* w2,
+                         const float* b2, float* preds, float* sums, void* ws, int B, int C, int Hd, int Co, int HW, int act_in,
+                         int dt, void* stream) {
+    const float* a = (const float*)a_;
     CFD_REQUIRE(a && w1 && b1 && w2 && b2 && preds, CFD_ERR_INVALID_ARG, "cfd_fno_head_fwd: NULL pointer");
     CFD_REQUIRE(!label || (sums && ws), CFD_ERR_INVALID_ARG, "cfd_fno_head_fwd: label given without sums/workspace");
     CFD_TRY(head_check("cfd_fno_head_fwd", B, C, Hd, Co, HW));
@@ -211,9 +218,17 @@ extern "C" int cfd_fno_head_fwd(const float* a, const float* mask, const float* 
     hipStream_t st = (hipStream_t)stream;
     const int blocks = head_blocks(B, HW);
     float* part = label ? (float*)ws : nullptr;
-    const bool v4 = HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)preds % 16) == 0;
+    const bool v4 = dt == CFD_DT_F32 && HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)preds % 16) == 0;
     {
-    CFD_PROF_W("k_head_fwd", st, 4.0 * B * HW * ((double)C + 1 + (label ? 2 : 1) * Co), 2.0 * B * HW * (double)HEAD_HD * (C + Co));
+    CFD_PROF_W("k_head_fwd", st, B * HW * ((double)cfd_dt_size(dt) * C + 4.0 * (1 + (label ? 2 : 1) * Co)), 2.0 * B * HW * (double)HEAD_HD * (C + Co));
+    if (dt == CFD_DT_BF16) {
+        if (act_in)
+            hipLaunchKernelGGL((k_head_fwd<false, true, __bf16>), dim3(blocks), dim3(256), 0, st, (const __bf16*)a_, mask, label, w1, b1,
+                               w2, b2, preds, part, B, C, Co, HW);
+        else
+            hipLaunchKernelGGL((k_head_fwd<false, false, __bf16>), dim3(blocks), dim3(256), 0, st, (const __bf16*)a_, mask, label, w1, b1,
+                               w2, b2, preds, part, B, C, Co, HW);
+    } else {
 #define CFD_HF(V_, A_)                                                                                      \
     hipLaunchKernelGGL((k_head_fwd<V_, A_>), dim3(blocks), dim3(256), 0, st, a, mask, label, w1, b1, w2, b2, \
                        preds, part, B, C, Co, HW)
@@ -222,6 +237,7 @@ extern "C" int cfd_fno_head_fwd(const float* a, const float* mask, const float* 
     else if (act_in) CFD_HF(false, true);
     else CFD_HF(false, false);
 #undef CFD_HF
+    }
     }
     CFD_LAUNCH_CHECK("cfd_fno_head_fwd");
     if (label) {

@@ -171,6 +171,60 @@ extern "C" int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out) {
                 for (int v = 0; v < SB; ++v) put((size_t)(2 * T + 2 * j) * 64 + lane, v, tb[(v * NJ + j) * 64 + lane]);
     }
 
+    // ---- general-width split-bf16 tables (any W <= 80, H <= 70): y = 16 j + n column map ----
+    std::vector<unsigned short> fwdg, invg;
+    p->NJG = (W + 15) / 16;
+    p->NHG = (p->NJG + 1) / 2;
+    p->n_fwd_gv = p->n_inv_gv = 0;
+    if (H <= 70 && W <= 80 && SA <= 8 && SB <= 8 && T <= 8) {
+        const int NJG = p->NJG, NHG = p->NHG;
+        const int ntbl = 4 + 2 * NHG;
+        fwdg.assign((size_t)ntbl * 2 * 64 * 8, 0);
+        auto putg = [&](std::vector<unsigned short>& dst, size_t hivec, int v, double x) {
+            const float xf32 = (float)x;
+            const unsigned short hi = bf16_rne(xf32);
+            dst[hivec * 8 + v] = hi;
+            dst[(hivec + 64) * 8 + v] = bf16_rne(xf32 - bf16_to_float(hi));
+        };
+        for (int lane = 0; lane < 64; ++lane) {
+            const int q = lane >> 4, i = lane & 15;
+            for (int v = 0; v < 8; ++v) {
+                for (int b = 0; b < 2; ++b) {  // stage 1, B operand: lane (q, kap = i), folded row xf = 32 b + 4 v + q
+                    const int xf = 32 * b + 4 * v + q;
+                    if (i > m1 || xf > H / 2) continue;
+                    const bool paired = (xf != 0) && (2 * xf != H);
+                    const double th = PI2 * (double)((long)i * xf % H) / H;
+                    putg(fwdg, (size_t)(2 * (2 * b)) * 64 + lane, v, std::cos(th));
+                    putg(fwdg, (size_t)(2 * (2 * b + 1)) * 64 + lane, v, paired ? std::sin(th) : 0.0);
+                }
+                for (int h = 0; h < NHG; ++h) {  // stage 2, A operand: lane (q, l = i), column y = 16 (2h + jj) + 4q + r, v = 4jj + r
+                    const int tile = 2 * h + (v >> 2), y = 16 * tile + 4 * q + (v & 3);
+                    if (i >= m2 || tile >= NJG || y >= W) continue;
+                    const double ph = PI2 * (double)((long)i * y % W) / W;
+                    putg(fwdg, (size_t)(2 * (4 + h)) * 64 + lane, v, std::cos(ph));
+                    putg(fwdg, (size_t)(2 * (4 + NHG + h)) * 64 + lane, v, std::sin(ph));
+                }
+            }
+        }
+        invg.assign((size_t)(2 * T + 2 * NJG) * 64 * 8, 0);
+        for (int t = 0; t < T; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int v = 0; v < SA; ++v) putg(invg, (size_t)(2 * t) * 64 + lane, v, ta[(t * SA + v) * 64 + lane]);
+        for (int j = 0; j < NJG; ++j)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int v = 0; v < SB; ++v) {  // stage B, B operand: lane (q, n): c = 4 v + q, column y = 16 j + n
+                    const int c = 4 * v + (lane >> 4), y = 16 * j + (lane & 15);
+                    if (c >= 2 * m2 || y >= W) continue;
+                    const bool im = c >= m2;
+                    const int l = im ? c - m2 : c;
+                    const double cl = ((l == 0 || (W % 2 == 0 && l == W / 2)) ? 1.0 : 2.0) / ((double)H * W);
+                    const double ph = PI2 * (double)((long)l * y % W) / W;
+                    putg(invg, (size_t)(2 * T + 2 * j) * 64 + lane, v, im ? -cl * std::sin(ph) : cl * std::cos(ph));
+                }
+        p->n_fwd_gv = (int)(fwdg.size() / 8);
+        p->n_inv_gv = (int)(invg.size() / 8);
+    }
+
     p->n_fwd = (int)fwd.size();
     p->n_inv = (int)inv.size();
     int rc = upload(fwd, &p->d_fwd);
@@ -188,6 +242,16 @@ extern "C" int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out) {
         if (hipMalloc(&p->d_inv_b3, inv3.size() * 2) != hipSuccess ||
             hipMemcpy(p->d_inv_b3, inv3.data(), inv3.size() * 2, hipMemcpyHostToDevice) != hipSuccess) rc = CFD_ERR_HIP;
     }
+    p->d_fwd_g = nullptr;
+    p->d_inv_g = nullptr;
+    if (rc == CFD_OK && !fwdg.empty()) {
+        if (hipMalloc(&p->d_fwd_g, fwdg.size() * 2) != hipSuccess ||
+            hipMemcpy(p->d_fwd_g, fwdg.data(), fwdg.size() * 2, hipMemcpyHostToDevice) != hipSuccess) rc = CFD_ERR_HIP;
+    }
+    if (rc == CFD_OK && !invg.empty()) {
+        if (hipMalloc(&p->d_inv_g, invg.size() * 2) != hipSuccess ||
+            hipMemcpy(p->d_inv_g, invg.data(), invg.size() * 2, hipMemcpyHostToDevice) != hipSuccess) rc = CFD_ERR_HIP;
+    }
     if (rc != CFD_OK) {
         cfd_set_error("cfd_plan_create: device allocation/copy of operator tables failed");
         delete p;
@@ -203,6 +267,8 @@ extern "C" void cfd_plan_destroy(cfd_plan* p) {
     hipFree(p->d_inv);
     if (p->d_inv_b3) hipFree(p->d_inv_b3);
     if (p->d_fwd_b3) hipFree(p->d_fwd_b3);
+    if (p->d_fwd_g) hipFree(p->d_fwd_g);
+    if (p->d_inv_g) hipFree(p->d_inv_g);
     hipFree(p->d_clhw);
     hipFree(p->d_gx);
     hipFree(p->d_gy);

@@ -9,11 +9,11 @@
 // ------------------------------------------------------------------------------------------------------
 // stem: [u, v, mask, grid_x, grid_y, props...] -> fc0
 // ------------------------------------------------------------------------------------------------------
-template <int CP>
+template <int CP, typename TA>
 __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ inputs, const float* __restrict__ mask,
                                                   const float* __restrict__ cp, const float* __restrict__ gx,
                                                   const float* __restrict__ gy, const float* __restrict__ w,
-                                                  const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                  const float* __restrict__ bias, TA* __restrict__ out, int B,
                                                   int in_chan, int P, int C, int H, int W) {
     __shared__ float s_w[32 * CP];  // [feature][out], zero padded
     __shared__ float s_b[CP];
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ inpu
         for (int k = 0; k < P; ++k) add(in_chan + 3 + k, cp[(size_t)b * P + k]);
 #pragma unroll
         for (int o = 0; o < CP; ++o)
-            if (o < C) out[((size_t)b * C + o) * HW + p] = acc[o];
+            if (o < C) cfd_st(out + ((size_t)b * C + o) * HW + p, acc[o]);
     }
 }
 
@@ -117,6 +117,12 @@ __global__ __launch_bounds__(256) void k_stem_fwd4(const float* __restrict__ inp
 extern "C" int cfd_fno_stem_fwd(const cfd_plan* p, const float* inputs, const float* mask, const float* case_params,
                                 const float* w, const float* bias, float* out, int B, int in_chan, int P, int C,
                                 void* stream) {
+    return cfd_int_fno_stem_fwd(p, inputs, mask, case_params, w, bias, out, B, in_chan, P, C, CFD_DT_F32, stream);
+}
+
+int cfd_int_fno_stem_fwd(const cfd_plan* p, const float* inputs, const float* mask, const float* case_params, const float* w,
+                         const float* bias, void* out_, int B, int in_chan, int P, int C, int dt, void* stream) {
+    float* out = (float*)out_;
     CFD_REQUIRE(p && inputs && w && bias && out && (P == 0 || case_params), CFD_ERR_INVALID_ARG, "cfd_fno_stem_fwd: NULL pointer");
     CFD_REQUIRE(B >= 0 && in_chan >= 1 && P >= 0 && C >= 1, CFD_ERR_INVALID_ARG, "cfd_fno_stem_fwd: bad sizes");
     CFD_REQUIRE(in_chan + 3 + P <= 32 && C <= 32, CFD_ERR_UNSUPPORTED,
@@ -126,11 +132,18 @@ extern "C" int cfd_fno_stem_fwd(const cfd_plan* p, const float* inputs, const fl
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
-    CFD_PROF_W("k_stem_fwd", st, 4.0 * B * p->H * p->W * ((double)in_chan + 1 + C), 2.0 * B * p->H * p->W * (double)C * (in_chan + 3 + P));
+    CFD_PROF_W("k_stem_fwd", st, B * p->H * p->W * (4.0 * (in_chan + 1) + (double)cfd_dt_size(dt) * C),
+               2.0 * B * p->H * p->W * (double)C * (in_chan + 3 + P));
 #define CFD_STEM(CPV)                                                                                              \
-    hipLaunchKernelGGL((k_stem_fwd<CPV>), dim3(blocks), dim3(256), 0, st, inputs, mask, case_params,               \
-                       (const float*)p->d_gx, (const float*)p->d_gy, w, bias, out, B, in_chan, P, C, p->H, p->W)
-    const bool v4 = p->W % 4 == 0 && (((uintptr_t)inputs | (uintptr_t)mask | (uintptr_t)out | (uintptr_t)p->d_gy) % 16) == 0;
+    do {                                                                                                           \
+        if (dt == CFD_DT_BF16)                                                                                     \
+            hipLaunchKernelGGL((k_stem_fwd<CPV, __bf16>), dim3(blocks), dim3(256), 0, st, inputs, mask, case_params, \
+                               (const float*)p->d_gx, (const float*)p->d_gy, w, bias, (__bf16*)out_, B, in_chan, P, C, p->H, p->W); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_stem_fwd<CPV, float>), dim3(blocks), dim3(256), 0, st, inputs, mask, case_params, \
+                               (const float*)p->d_gx, (const float*)p->d_gy, w, bias, out, B, in_chan, P, C, p->H, p->W); \
+    } while (0)
+    const bool v4 = dt == CFD_DT_F32 && p->W % 4 == 0 && (((uintptr_t)inputs | (uintptr_t)mask | (uintptr_t)out | (uintptr_t)p->d_gy) % 16) == 0;
     if (v4) {
         const long quads = total / 4;
         int blocks4 = (int)((quads + 255) / 256);
@@ -156,9 +169,9 @@ extern "C" int cfd_fno_stem_fwd(const cfd_plan* p, const float* inputs, const fl
 // ------------------------------------------------------------------------------------------------------
 // 1x1 conv forward (and its input gradient with transpose=1)
 // ------------------------------------------------------------------------------------------------------
-template <int CPO, int VEC, bool ACT>
-__global__ __launch_bounds__(256) void k_chanmix(const float* __restrict__ in, const float* __restrict__ w,
-                                                 const float* __restrict__ bias, float* __restrict__ out, int B, int Ci,
+template <int CPO, int VEC, bool ACT, typename TA = float, typename TO = TA>
+__global__ __launch_bounds__(256) void k_chanmix(const TA* __restrict__ in, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, TO* __restrict__ out, int B, int Ci,
                                                  int Co, int HW, int transpose) {
     __shared__ float s_w[32 * CPO];  // [in][out], zero padded
     __shared__ float s_b[CPO];
@@ -182,8 +195,11 @@ __global__ __launch_bounds__(256) void k_chanmix(const float* __restrict__ in, c
             for (int k = 0; k < VEC; ++k) acc[o][k] = s_b[z0 + o];
         for (int ci = 0; ci < Ci; ++ci) {
             float v[VEC];
-            const float* src = in + ((size_t)b * Ci + ci) * HW + p;
-            if constexpr (VEC == 4) {
+            const TA* src = in + ((size_t)b * Ci + ci) * HW + p;
+            if constexpr (sizeof(TA) == 2) {  // bf16 storage: VEC consecutive 2-byte values
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v[k] = cfd_ld(src + k);
+            } else if constexpr (VEC == 4) {
                 const float4 t = *reinterpret_cast<const float4*>(src);
                 v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
             } else if constexpr (VEC == 2) {
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(256) void k_chanmix(const float* __restrict__ in, c
                 v[0] = t.x; v[1] = t.y;
             } else {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) v[k] = src[k];
+                for (int k = 0; k < VEC; ++k) v[k] = cfd_ld(src + k);
             }
             if constexpr (ACT) {
 #pragma unroll
@@ -208,14 +224,17 @@ __global__ __launch_bounds__(256) void k_chanmix(const float* __restrict__ in, c
 #pragma unroll
         for (int o = 0; o < CPO; ++o) {
             if (o < Co) {
-                float* dst = out + ((size_t)b * Co + o) * HW + p;
-                if constexpr (VEC == 4) {
+                TO* dst = out + ((size_t)b * Co + o) * HW + p;
+                if constexpr (sizeof(TO) == 2) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) cfd_st(dst + k, acc[o][k]);
+                } else if constexpr (VEC == 4) {
                     *reinterpret_cast<float4*>(dst) = make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
                 } else if constexpr (VEC == 2) {
                     *reinterpret_cast<float2*>(dst) = make_float2(acc[o][0], acc[o][1]);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) dst[k] = acc[o][k];
+                    for (int k = 0; k < VEC; ++k) cfd_st(dst + k, acc[o][k]);
                 }
             }
         }
@@ -235,6 +254,35 @@ static int launch_chanmix(const float* in, const float* w, const float* bias, fl
     else
         hipLaunchKernelGGL((k_chanmix<CPO, VEC, false>), dim3(blocks), dim3(256), 0, st, in, w, bias, out, B, Ci, Co, HW, transpose);
     CFD_LAUNCH_CHECK("cfd_chanmix");
+    return CFD_OK;
+}
+
+int cfd_int_chanmix(const void* in, const float* w, const float* bias, void* out, int B, int Ci, int Co, int HW, int act_in,
+                    int transpose, int dt, void* stream) {
+    if (dt == CFD_DT_F32) return cfd_chanmix((const float*)in, w, bias, (float*)out, B, Ci, Co, HW, act_in, transpose, stream);
+    CFD_REQUIRE(in && w && out && B >= 0 && Ci >= 1 && Co >= 1 && HW >= 1 && Ci <= 32 && Co <= 32, CFD_ERR_INVALID_ARG, "cfd_chanmix: bad arguments");
+    if (B == 0) return CFD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int VEC = HW % 2 == 0 ? 2 : 1;
+    const long total = (long)B * (HW / VEC);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    CFD_PROF_W(act_in ? "k_chanmix_act" : "k_chanmix", st, B * HW * (2.0 * Ci + 4.0 * Co), 2.0 * B * HW * (double)Ci * Co);
+#define CFD_CMB(CPV, VW, A_)                                                                                                  \
+    hipLaunchKernelGGL((k_chanmix<CPV, VW, A_, __bf16, float>), dim3(blocks), dim3(256), 0, st, (const __bf16*)in, w, bias, (float*)out, B, \
+                       Ci, Co, HW, transpose)
+#define CFD_CMB_VA(CPV)                                                    \
+    do {                                                                   \
+        if (VEC == 2) { if (act_in) CFD_CMB(CPV, 2, true); else CFD_CMB(CPV, 2, false); } \
+        else { if (act_in) CFD_CMB(CPV, 1, true); else CFD_CMB(CPV, 1, false); }          \
+    } while (0)
+    if (Co <= 8) CFD_CMB_VA(8);
+    else if (Co <= 16) CFD_CMB_VA(16);
+    else if (Co <= 24) CFD_CMB_VA(24);
+    else CFD_CMB_VA(32);
+#undef CFD_CMB_VA
+#undef CFD_CMB
+    CFD_LAUNCH_CHECK("cfd_chanmix(bf16 storage)");
     return CFD_OK;
 }
 

@@ -372,6 +372,173 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64_b3(const float*
     }
 }
 
+// General-width split-bf16 forward transform (any W <= 80, H <= 70: the 66 x 65 grids of the tube / dam problems).
+// Columns are dealt to lanes as y = 16 j + n (tile j, lane n), so every access of a wave is four runs of 16 consecutive
+// elements (one per lane group q = one row each) whatever W is -- the generic fp32 kernel above deals y = NJ n + j (a
+// stride-NJ gather) and pays 170 fp32 MFMAs (32 cycles each) per image.  Same contraction scheme as k_dft_fwd64_b3:
+//   stage 1  a1c/a1s[j] = sum over folded rows xf, K block 0: xf = 4v + q (0 .. 31), K block 1: xf = 32 + q (v = 0 only:
+//            rows 32 .. 35 cover H <= 70); data = A operand (lane (q, n): column 16 j + n, rows of its group q), so the
+//            accumulator of tile j holds Tc / Ts[kap = n][y = 16 j + 4q + r]
+//   stage 2  K = the columns, two tiles per K block (k-slot (q, v = 4jj + r) = column 16 (2h + jj) + 4q + r), accumulators
+//            feed the B operand as they are
+// One image per wave, persistent waves; the 18 row values of a tile are re-requested for the wave's NEXT image the moment they
+// have been folded (a rolling ring one image deep: ~17 KB in flight per wave).  TA = storage type of the activations
+// (float, or __bf16 for the bf16-storage inference path).
+template <int NJ, bool ACT, typename TA>
+__global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_dft_fwd_g(const TA* __restrict__ x, float2* __restrict__ xh,
+                                                                  const bf16x8* __restrict__ tabs3, int ntabv, int nimg, int H,
+                                                                  int W, int m1, int m2) {
+    constexpr int NH = (NJ + 1) / 2;
+    CFD_DYN_SHARED(bf16x8, s_dyn);
+    bf16x8* s_tab3 = s_dyn;                                              // [4 + 2 NH tables][hi|lo][64]
+    float2* s_out = reinterpret_cast<float2*>(s_dyn + (4 + 2 * NH) * 2 * 64);  // [CFD_WAVES][CFD_DFT_OS]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int stride = gridDim.x * CFD_WAVES;
+    int img = blockIdx.x * CFD_WAVES + wave;
+    const int HW = H * W, H2 = H / 2;
+    // row offsets of this lane group (elements): block 0 rows xf = 4v + q and their mirrors H - xf, block 1 row 32 + q
+    int offv[9], offu[9];
+    bool pair[9], valid[9];
+#pragma unroll
+    for (int v = 0; v < 9; ++v) {
+        const int xf = v < 8 ? 4 * v + q : 32 + q;
+        valid[v] = xf <= H2;
+        pair[v] = valid[v] && xf != 0 && 2 * xf != H;
+        offv[v] = valid[v] ? xf * W : 0;
+        offu[v] = pair[v] ? (H - xf) * W : 0;
+    }
+    int colc[NJ];  // this lane's column of tile j, clamped into the row (tables are zero beyond W)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) colc[j] = 16 * j + n < W ? 16 * j + n : W - 1;
+    float rv[NJ][9], ru[NJ][9];  // the rolling ring: tile j of the image being transformed, then of the next one
+    auto arm = [&](const TA* xi, int j) {
+#pragma unroll
+        for (int v = 0; v < 9; ++v) {
+            rv[j][v] = cfd_ld(xi + offv[v] + colc[j]);
+            ru[j][v] = cfd_ld(xi + offu[v] + colc[j]);
+        }
+    };
+    {
+        const TA* xi = x + (size_t)(img < nimg ? img : 0) * HW;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) arm(xi, j);
+    }
+    for (int i = threadIdx.x; i < ntabv; i += blockDim.x) s_tab3[i] = tabs3[i];
+    __syncthreads();
+    const int M = 2 * m1 * m2;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    while (img < nimg) {
+        const int nxt = img + stride;
+        const TA* xn = x + (size_t)(nxt < nimg ? nxt : img) * HW;  // no next image: re-read this one (values never used)
+        f32x4 a1c[NJ], a1s[NJ];
+        const int lo = cfd_opaque(lane);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float e8[8], o8[8], e1[8], o1[8];
+#pragma unroll
+            for (int v = 0; v < 9; ++v) {
+                float aa = valid[v] ? rv[j][v] : 0.f, bb = pair[v] ? ru[j][v] : 0.f;
+                if constexpr (ACT) { const cfd_f2 g2 = cfd_gelu2(cfd_f2{aa, bb}); aa = g2.x; bb = g2.y; }  // gelu(0) = 0
+                if (v < 8) { e8[v] = aa + bb; o8[v] = aa - bb; }
+                else { e1[0] = aa + bb; o1[0] = aa - bb; }
+            }
+#pragma unroll
+            for (int v = 1; v < 8; ++v) { e1[v] = 0.f; o1[v] = 0.f; }
+            cfd_sched_fence();
+            arm(xn, j);  // re-arm the slot with the same tile of the wave's next image
+            cfd_sched_fence();
+            const CfdSplit8 es = cfd_split8(e8), os = cfd_split8(o8), es1 = cfd_split8(e1), os1 = cfd_split8(o1);
+            const bf16x8 c0h = s_tab3[lo], c0l = s_tab3[64 + lo], s0h = s_tab3[128 + lo], s0l = s_tab3[192 + lo];
+            const bf16x8 c1h = s_tab3[256 + lo], c1l = s_tab3[320 + lo], s1h = s_tab3[384 + lo], s1l = s_tab3[448 + lo];
+            f32x4 c = cfd_mfma16x16x32_bf16(es.lo, c0h, zero);
+            f32x4 sn = cfd_mfma16x16x32_bf16(os.lo, s0h, zero);
+            c = cfd_mfma16x16x32_bf16(es.hi, c0l, c);
+            sn = cfd_mfma16x16x32_bf16(os.hi, s0l, sn);
+            c = cfd_mfma16x16x32_bf16(es1.lo, c1h, c);
+            sn = cfd_mfma16x16x32_bf16(os1.lo, s1h, sn);
+            c = cfd_mfma16x16x32_bf16(es1.hi, c1l, c);
+            sn = cfd_mfma16x16x32_bf16(os1.hi, s1l, sn);
+            c = cfd_mfma16x16x32_bf16(es1.hi, c1h, c);
+            sn = cfd_mfma16x16x32_bf16(os1.hi, s1h, sn);
+            c = cfd_mfma16x16x32_bf16(es.hi, c0h, c);
+            sn = cfd_mfma16x16x32_bf16(os.hi, s0h, sn);
+            a1c[j] = c;
+            a1s[j] = sn;
+        }
+        // ---- stage 2: sums over the columns, two tiles per K block ----
+        f32x4 Pc = zero, Ps = zero, Qc = zero, Qs = zero;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            float cv[8], sv[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cv[r] = a1c[2 * h][r];
+                sv[r] = a1s[2 * h][r];
+                cv[4 + r] = 2 * h + 1 < NJ ? a1c[2 * h + 1 < NJ ? 2 * h + 1 : 0][r] : 0.f;
+                sv[4 + r] = 2 * h + 1 < NJ ? a1s[2 * h + 1 < NJ ? 2 * h + 1 : 0][r] : 0.f;
+            }
+            const CfdSplit8 cs = cfd_split8(cv), ss = cfd_split8(sv);
+            const bf16x8 ch = s_tab3[(2 * (4 + h)) * 64 + lo], cl = s_tab3[(2 * (4 + h) + 1) * 64 + lo];
+            const bf16x8 sh = s_tab3[(2 * (4 + NH + h)) * 64 + lo], sl = s_tab3[(2 * (4 + NH + h) + 1) * 64 + lo];
+            Pc = cfd_mfma16x16x32_bf16(cl, cs.hi, Pc);
+            Ps = cfd_mfma16x16x32_bf16(sl, cs.hi, Ps);
+            Qc = cfd_mfma16x16x32_bf16(cl, ss.hi, Qc);
+            Qs = cfd_mfma16x16x32_bf16(sl, ss.hi, Qs);
+            Pc = cfd_mfma16x16x32_bf16(ch, cs.lo, Pc);
+            Ps = cfd_mfma16x16x32_bf16(sh, cs.lo, Ps);
+            Qc = cfd_mfma16x16x32_bf16(ch, ss.lo, Qc);
+            Qs = cfd_mfma16x16x32_bf16(sh, ss.lo, Qs);
+            Pc = cfd_mfma16x16x32_bf16(ch, cs.hi, Pc);
+            Ps = cfd_mfma16x16x32_bf16(sh, cs.hi, Ps);
+            Qc = cfd_mfma16x16x32_bf16(ch, ss.hi, Qc);
+            Qs = cfd_mfma16x16x32_bf16(sh, ss.hi, Qs);
+        }
+        // P*[r]: l = 4q + r, kap = n.  Modes -> this wave's LDS slice, then out in whole 512-byte runs
+        {
+            float2* so = s_out + wave * CFD_DFT_OS;
+            const int kap = n;
+            if (kap <= m1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int l = 4 * q + r;
+                    if (l < m2) {
+                        if (kap < m1) so[kap * m2 + l] = make_float2(Pc[r] - Qs[r], -(Ps[r] + Qc[r]));
+                        if (kap >= 1) so[(2 * m1 - kap) * m2 + l] = make_float2(Pc[r] + Qs[r], Qc[r] - Ps[r]);
+                    }
+                }
+            }
+            cfd_wave_lds_sync();
+            float2* o = xh + (size_t)img * M;
+            for (int i = lane; i < M; i += 64) o[i] = so[i];
+            cfd_wave_lds_sync();
+        }
+        img = nxt;
+    }
+}
+
+template <typename TA>
+static bool launch_dft_g(const cfd_plan* p, const TA* x, float* xh, int nimg, int act, hipStream_t st) {
+    if (!p->d_fwd_g || p->NJG < 1 || p->NJG > 5) return false;
+    int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
+    if (blocks > 2 * 256) blocks = 2 * 256;  // two resident workgroups per CU; the waves stride over the images
+    const size_t lds = (size_t)p->n_fwd_gv * sizeof(bf16x8) + (size_t)CFD_WAVES * CFD_DFT_OS * sizeof(float2);
+#define CFD_DFTG(NJ_, A_)                                                                                              \
+    hipLaunchKernelGGL((k_dft_fwd_g<NJ_, A_, TA>), dim3(blocks), dim3(64 * CFD_WAVES), lds, st, x, (float2*)xh,         \
+                       (const bf16x8*)p->d_fwd_g, p->n_fwd_gv, nimg, p->H, p->W, p->m1, p->m2)
+#define CFD_DFTG_A(NJ_) do { if (act) CFD_DFTG(NJ_, true); else CFD_DFTG(NJ_, false); } while (0)
+    switch (p->NJG) {
+        case 1: CFD_DFTG_A(1); break;
+        case 2: CFD_DFTG_A(2); break;
+        case 3: CFD_DFTG_A(3); break;
+        case 4: CFD_DFTG_A(4); break;
+        default: CFD_DFTG_A(5); break;
+    }
+#undef CFD_DFTG_A
+#undef CFD_DFTG
+    return true;
+}
+
 template <int NJ, bool VEC4>
 static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, int act, hipStream_t st) {
     CFD_PROF_W(act ? "k_dft_fwd_act" : "k_dft_fwd", st, (double)nimg * (4.0 * p->H * p->W + 16.0 * p->m1 * p->m2),
@@ -407,6 +574,10 @@ static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, in
             return CFD_OK;
         }
     }
+    if (cfd_tune_get(CFD_TUNE_GENERAL_B3) != 0 && launch_dft_g<float>(p, x, xh, nimg, act, st)) {
+        CFD_LAUNCH_CHECK("cfd_spectral_dft(general)");
+        return CFD_OK;
+    }
     int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
     if (blocks > 2048) blocks = 2048;
     if (act)
@@ -416,6 +587,19 @@ static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, in
         hipLaunchKernelGGL((k_dft_fwd<NJ, VEC4, false>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
                            (const float*)p->d_fwd, p->n_fwd, nimg, p->H, p->W, p->m1, p->m2, p->KX);
     CFD_LAUNCH_CHECK("cfd_spectral_dft");
+    return CFD_OK;
+}
+
+int cfd_int_spectral_dft(const cfd_plan* p, const void* x, float* xh, int nimg, int act_in, int dt, void* stream) {
+    if (dt == CFD_DT_F32) return cfd_spectral_dft(p, (const float*)x, xh, nimg, act_in, stream);
+    CFD_REQUIRE(p && x && xh && nimg >= 0, CFD_ERR_INVALID_ARG, "cfd_spectral_dft: NULL pointer or negative count");
+    if (nimg == 0) return CFD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    CFD_PROF_W(act_in ? "k_dft_fwd_act" : "k_dft_fwd", st, (double)nimg * (2.0 * p->H * p->W + 16.0 * p->m1 * p->m2),
+               (double)nimg * (4.0 * (p->m1 + 1) * (p->H / 2 + 1) * p->W + 8.0 * (p->m1 + 1) * p->W * p->m2));
+    CFD_REQUIRE(launch_dft_g<__bf16>(p, (const __bf16*)x, xh, nimg, act_in, st), CFD_ERR_UNSUPPORTED,
+                "cfd_spectral_dft: bf16 activation storage needs H <= 70 and W <= 80 (grid %dx%d)", p->H, p->W);
+    CFD_LAUNCH_CHECK("cfd_spectral_dft(bf16 storage)");
     return CFD_OK;
 }
 
@@ -1392,6 +1576,117 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __res
     }
 }
 
+// General-width split-bf16 inverse transform: k_idft64's scheme (stage A over the kept rows, stage B over the kept
+// columns, 6 + 3 NJ bf16 MFMAs per 16-row tile) with the columns dealt as y = 16 j + n, so the epilogue loads and the stores
+// of a wave are runs of 16 consecutive elements per output row whatever W is (66 x 65 grids: the fp32 kernel k_idft deals
+// y = NJ n + j and issues 14 + 8 NJ fp32 MFMAs of 32 cycles per tile).  Persistent waves, next image's modes prefetched.
+template <int NJ, int EPI, typename TA, typename TADD = TA>
+__global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_idft_g(const float* __restrict__ z, const TADD* addend,
+                                                               const TA* __restrict__ aprev, TA* out,
+                                                               const bf16x8* __restrict__ tabs3, int ntabv, int nimg, int H,
+                                                               int W, int m1, int m2, int T, int SA) {
+    CFD_DYN_SHARED(bf16x8, s_dyn);
+    bf16x8* s_tab3 = s_dyn;                                   // ta3[T][hi|lo][64] | tb3[NJ][hi|lo][64]
+    float* s_z = reinterpret_cast<float*>(s_dyn + ntabv);     // two mode slices per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int M2 = 4 * m1 * m2;
+    const int stride = gridDim.x * CFD_WAVES;
+    int img = blockIdx.x * CFD_WAVES + wave;
+    float* zs0 = s_z + wave * 2 * CFD_IDFT_ZMAX;
+    constexpr int ZR = (CFD_IDFT_ZMAX - 1 + 63) / 64;  // dwords per lane of one mode vector
+    float zr[ZR];
+    auto zfetch = [&](int im) {
+        const float* zi = z + (size_t)im * M2;
+#pragma unroll
+        for (int k = 0; k < ZR; ++k) zr[k] = zi[lane + 64 * k < M2 ? lane + 64 * k : 0];
+    };
+    auto zcommit = [&](float* zs) {
+#pragma unroll
+        for (int k = 0; k < ZR; ++k)
+            if (lane + 64 * k < M2) zs[lane + 64 * k] = zr[k];
+        if (lane == 0) zs[M2] = 0.f;
+    };
+    zfetch(img < nimg ? img : 0);
+    for (int i = threadIdx.x; i < ntabv; i += blockDim.x) s_tab3[i] = tabs3[i];
+    zcommit(zs0);
+    __syncthreads();
+    const bf16x8* tb3 = s_tab3 + 2 * T * 64;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    int colc[NJ];
+    bool cok[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { cok[j] = 16 * j + n < W; colc[j] = cok[j] ? 16 * j + n : W - 1; }
+    int cur = 0;
+    while (img < nimg) {
+        const int nxt = img + stride;
+        zfetch(nxt < nimg ? nxt : img);
+        cfd_sched_fence();
+        float va[2][8];
+        idft_gather(zs0 + cur * CFD_IDFT_ZMAX, m1, m2, SA, q, n, va);
+        const IdftSplitA sa = idft_split(va);
+        const size_t ibase = (size_t)img * H * W;
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            float ad[4][NJ], ap[4][NJ];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int xx = 16 * t + 4 * q + r;
+                const size_t rb = ibase + (size_t)(xx < H ? xx : H - 1) * W;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if constexpr (EPI >= 1) ad[r][j] = cfd_ld(addend + rb + colc[j]);
+                    if constexpr (EPI == 2) ap[r][j] = cfd_ld(aprev + rb + colc[j]);
+                }
+            }
+            f32x4 accB[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) accB[j] = zero;
+            idft_tile_b3<NJ>(sa, s_tab3 + 2 * t * 64, tb3, cfd_opaque(lane), accB);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int xx = 16 * t + 4 * q + r;
+                const size_t rb = ibase + (size_t)xx * W;
+#pragma unroll
+                for (int j = 0; j < NJ; j += 2) {
+                    cfd_f2 v = {accB[j][r], j + 1 < NJ ? accB[j + 1 < NJ ? j + 1 : j][r] : 0.f};
+                    if constexpr (EPI >= 1) v = v + cfd_f2{ad[r][j], j + 1 < NJ ? ad[r][j + 1 < NJ ? j + 1 : j] : 0.f};
+                    if constexpr (EPI == 2) v = v * cfd_gelu_grad2(cfd_f2{ap[r][j], j + 1 < NJ ? ap[r][j + 1 < NJ ? j + 1 : j] : 0.f});
+                    if (xx < H && cok[j]) cfd_st(out + rb + 16 * j + n, v.x);
+                    if (j + 1 < NJ && xx < H && cok[j + 1 < NJ ? j + 1 : j]) cfd_st(out + rb + 16 * (j + 1) + n, v.y);
+                }
+            }
+        }
+        cur ^= 1;
+        zcommit(zs0 + cur * CFD_IDFT_ZMAX);  // the other slice was last read one image ago (same wave: program order)
+        cfd_wave_lds_sync();
+        img = nxt;
+    }
+}
+
+template <typename TA, typename TADD = TA>
+static bool launch_idft_g(const cfd_plan* p, const float* z, const TADD* addend, const TA* aprev, TA* out, int nimg, int epi,
+                          hipStream_t st) {
+    if (!p->d_inv_g || p->NJG < 1 || p->NJG > 5) return false;
+    int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
+    if (blocks > 2 * 256) blocks = 2 * 256;
+    const size_t lds = (size_t)p->n_inv_gv * sizeof(bf16x8) + (size_t)CFD_WAVES * 2 * CFD_IDFT_ZMAX * sizeof(float);
+#define CFD_IDG(NJ_, E_)                                                                                             \
+    hipLaunchKernelGGL((k_idft_g<NJ_, E_, TA, TADD>), dim3(blocks), dim3(64 * CFD_WAVES), lds, st, z, addend, aprev, out,  \
+                       (const bf16x8*)p->d_inv_g, p->n_inv_gv, nimg, p->H, p->W, p->m1, p->m2, p->T, p->SA)
+#define CFD_IDG_E(NJ_) do { if (epi == 0) CFD_IDG(NJ_, 0); else if (epi == 1) CFD_IDG(NJ_, 1); else CFD_IDG(NJ_, 2); } while (0)
+    switch (p->NJG) {
+        case 1: CFD_IDG_E(1); break;
+        case 2: CFD_IDG_E(2); break;
+        case 3: CFD_IDG_E(3); break;
+        case 4: CFD_IDG_E(4); break;
+        default: CFD_IDG_E(5); break;
+    }
+#undef CFD_IDG_E
+#undef CFD_IDG
+    return true;
+}
+
 static bool idft64_applies(const cfd_plan* p) {
     return p->W == 64 && p->H % 16 == 0 && p->d_inv_b3 && 4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS;
 }
@@ -1423,6 +1718,14 @@ static int launch_idft(const cfd_plan* p, const float* z, const float* addend, c
             return CFD_OK;
         }
     }
+    if (cfd_tune_get(CFD_TUNE_GENERAL_B3) != 0 && p->d_inv_g && p->NJG <= 5) {
+        CFD_PROF_W(epi == 0 ? "k_idft" : (epi == 1 ? "k_idft_add" : "k_idft_add_dgelu"), st,
+                   (double)nimg * (4.0 * p->H * p->W * (1 + epi) + 16.0 * p->m1 * p->m2), (double)nimg * (8.0 * (p->m1 + 1) * p->W * p->m2 + 4.0 * p->H * p->W * p->m2));
+        if (launch_idft_g<float>(p, z, addend, aprev, out, nimg, epi, st)) {
+            CFD_LAUNCH_CHECK("cfd_spectral_idft(general)");
+            return CFD_OK;
+        }
+    }
 #define CFD_IDFT_LAUNCH(E)                                                                                         \
     hipLaunchKernelGGL((k_idft<NJ, VEC4, E>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, z, addend, aprev, out,     \
                        (const float*)p->d_inv, p->n_inv, nimg, p->H, p->W, p->m1, p->m2, p->T, p->SA, p->SB)
@@ -1433,6 +1736,21 @@ static int launch_idft(const cfd_plan* p, const float* z, const float* addend, c
     else CFD_IDFT_LAUNCH(2);
 #undef CFD_IDFT_LAUNCH
     CFD_LAUNCH_CHECK("cfd_spectral_idft");
+    return CFD_OK;
+}
+
+int cfd_int_spectral_idft(const cfd_plan* p, const float* z, const void* addend, const void* aprev, void* out, int nimg, int epi,
+                          int dt, void* stream) {
+    if (dt == CFD_DT_F32) return cfd_spectral_idft(p, z, (const float*)addend, (const float*)aprev, (float*)out, nimg, epi, stream);
+    CFD_REQUIRE(p && z && out && nimg >= 0 && epi >= 0 && epi <= 2 && (epi < 1 || addend) && (epi < 2 || aprev), CFD_ERR_INVALID_ARG,
+                "cfd_spectral_idft: bad arguments");
+    if (nimg == 0) return CFD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    CFD_PROF_W(epi == 0 ? "k_idft" : (epi == 1 ? "k_idft_add" : "k_idft_add_dgelu"), st,
+               (double)nimg * (2.0 * p->H * p->W * (1 + 2 * (epi >= 1) + (epi == 2)) + 16.0 * p->m1 * p->m2), (double)nimg * (8.0 * (p->m1 + 1) * p->W * p->m2 + 4.0 * p->H * p->W * p->m2));
+    CFD_REQUIRE((launch_idft_g<__bf16, float>(p, z, (const float*)addend, (const __bf16*)aprev, (__bf16*)out, nimg, epi, st)), CFD_ERR_UNSUPPORTED,
+                "cfd_spectral_idft: bf16 activation storage needs H <= 70 and W <= 80 (grid %dx%d)", p->H, p->W);
+    CFD_LAUNCH_CHECK("cfd_spectral_idft(bf16 storage)");
     return CFD_OK;
 }
 

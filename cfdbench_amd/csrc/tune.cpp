@@ -19,6 +19,7 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
     {"wgrad_wg", "CFD_WGRAD_WG", {-1}},          // workgroups the tiled spectral weight gradient aims at
     {"fused_variant", "CFD_FUSED_VARIANT", {-1}},  // 0 = adjoint mix and weight gradient as two launches
     {"block_fuse", "CFD_BLOCK_FUSE", {-1}},      // 0 = FnoBlock backward without the fused 1x1 weight gradient
+    {"general_b3", "CFD_GENERAL_B3", {-1}},      // 0 = grids other than 64 x 64 on the exact-fp32 generic transforms
 };
 std::once_flag g_once;
 void read_env() {

@@ -16,9 +16,20 @@ from ._capi import FnoShape
 from .functional import _creal, _param_struct
 
 
+ACT_DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+
+
 class FnoRollout:
-    def __init__(self, model):
+    """``dtype`` = storage type of the activations between kernels: "f32" (bitwise ``Fno2d.generate_many``) or "bf16"
+    (BASELINE.json configs[4]: the lifting layer's output and every FnoBlock's pre-activation are rounded to bf16 when
+    stored -- half the activation traffic; frames, weights, kept modes and all arithmetic stay fp32)."""
+
+    def __init__(self, model, dtype: str = "f32"):
+        if dtype not in ACT_DTYPES:
+            raise ValueError(f"dtype must be one of {sorted(ACT_DTYPES)}")
         self.model = model
+        self.dtype = dtype
+        self.act_dtype = ACT_DTYPES[dtype]
         self.api = _lib.api()
         self._cache: Dict[Tuple, dict] = {}
 
@@ -33,7 +44,7 @@ class FnoRollout:
                   frames=torch.empty((steps + 1, B, c, H, W), dtype=torch.float32, device=device),
                   cp=torch.empty((B, P), dtype=torch.float32, device=device),
                   mask=torch.empty((B, 1, H, W), dtype=torch.float32, device=device) if has_mask else None,
-                  ws=torch.empty(max(self.api.size("cfd_fno_workspace_bytes", plan, ctypes.byref(shape), 0), 16),
+                  ws=torch.empty(max(self.api.size("cfd_fno_workspace_bytes_ex", plan, ctypes.byref(shape), 0, self.act_dtype), 16),
                                  dtype=torch.uint8, device=device))
         # parameters are read through their current storage: re-capture if they are re-allocated (e.g. .to())
         flat = [(_creal(p.detach()) if p.is_complex() else p.detach().contiguous()) for p in self.model.abi_parameters()]
@@ -43,10 +54,10 @@ class FnoRollout:
         def run():
             s = torch.cuda.current_stream().cuda_stream
             for t in range(steps):
-                self.api.call("cfd_fno_forward", plan, ctypes.byref(shape), ctypes.byref(st["pstruct"]),
+                self.api.call("cfd_fno_forward_ex", plan, ctypes.byref(shape), ctypes.byref(st["pstruct"]),
                               st["frames"][t].data_ptr(), st["cp"].data_ptr(),
                               None if st["mask"] is None else st["mask"].data_ptr(), None,
-                              st["frames"][t + 1].data_ptr(), None, st["ws"].data_ptr(), 0, s)
+                              st["frames"][t + 1].data_ptr(), None, st["ws"].data_ptr(), 0, self.act_dtype, s)
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -42,7 +42,8 @@ const char* cfd_last_error(void);
 /* Dispatch overrides for tests and timing tools: which kernel variant a launch helper picks.  Knobs: "mix_nwv" (waves per
  * LDS-weight mixing workgroup, 0 = the lane = mode kernel), "wgrad_wg" (workgroups the tiled spectral weight gradient
  * aims at), "fused_variant" (0 = adjoint mix and spectral weight gradient as two launches), "block_fuse" (0 = the 1x1
- * weight gradient of a FnoBlock as its own kernel).  value -1 restores the built-in choice.  The environment variables
+ * weight gradient of a FnoBlock as its own kernel), "general_b3" (0 = grids other than 64 x 64 on the exact-fp32 generic
+ * transform kernels instead of the split-bf16 ones).  value -1 restores the built-in choice.  The environment variables
  * CFD_MIX_NWV / CFD_WGRAD_WG / CFD_FUSED_VARIANT / CFD_BLOCK_FUSE are read once per process, at the first launch.  Every
  * route computes the same function (the reference has no such switch: it has one ATen call per op).                */
 int cfd_tune_set(const char* name, int value);
@@ -303,6 +304,15 @@ size_t cfd_fno_workspace_bytes(const cfd_plan* plan, const cfd_fno_shape* shape,
 int cfd_fno_forward(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,
                     const float* inputs, const float* case_params, const float* mask, const float* label,
                     float* preds, float* sums, void* ws, int training, void* stream);
+
+/* The same forward pass with the storage type of the activations BETWEEN kernels as an argument (BASELINE.json configs[4]: the
+ * 200-step rollout of src/test_multistep.py:135-177 with bf16 storage): act_dtype 0 = fp32 (== cfd_fno_forward), 1 = bf16
+ * (the lifting layer's output and every FnoBlock's pre-activation are rounded to bf16 when stored; inputs, predictions, kept
+ * modes, weights, arithmetic and accumulation stay fp32).  bf16 is an inference path: training must be 0; grids up to 70 x 80. */
+size_t cfd_fno_workspace_bytes_ex(const cfd_plan* plan, const cfd_fno_shape* shape, int training, int act_dtype);
+int cfd_fno_forward_ex(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,
+                       const float* inputs, const float* case_params, const float* mask, const float* label,
+                       float* preds, float* sums, void* ws, int training, int act_dtype, void* stream);
 
 /* grads: same layout as params, every tensor overwritten.  coef/gpreds_ext as in cfd_fno_head_bwd.           */
 int cfd_fno_backward(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,

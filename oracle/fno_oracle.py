@@ -192,6 +192,14 @@ def mse_loss(preds: Array, labels: Array, normalize: bool = True) -> Dict[str, f
 # --------------------------------------------------------------------------------------
 # Fno2d forward / backward  (src/models/fno/fno2d.py:178-242)
 # --------------------------------------------------------------------------------------
+def bf16_round(x: Array) -> Array:
+    """Round to the nearest bfloat16 (ties to even) and return in x's dtype: what storing an activation as bf16 does."""
+    f = np.ascontiguousarray(x, dtype=np.float32)
+    u = f.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    return r.astype(x.dtype)
+
+
 def fno_forward(
     params: Dict[str, Array],
     inputs: Array,
@@ -202,8 +210,14 @@ def fno_forward(
     normalize: bool = True,
     use_fft: bool = True,
     keep_cache: bool = True,
+    act_store=None,
 ) -> Dict:
-    """``params`` uses the reference's state_dict key names (SURVEY.md 8b Checkpoint ABI)."""
+    """``params`` uses the reference's state_dict key names (SURVEY.md 8b Checkpoint ABI).
+    ``act_store`` (e.g. ``bf16_round``) is applied to every activation that the bf16-storage inference path keeps in
+    memory between kernels: the lifting layer's output and each FnoBlock's pre-activation (BASELINE configs[4]; the
+    reference itself has no reduced-precision path)."""
+    if act_store is None:
+        act_store = lambda a: a  # noqa: E731
     B, _, H, W = inputs.shape
     dt = inputs.dtype
     if mask is None:
@@ -214,13 +228,13 @@ def fno_forward(
     spec = spectral_conv2d_fwd if use_fft else spectral_conv2d_fwd_dft
     acts: List[Array] = []  # block inputs h_l
     pres: List[Array] = []  # pre-activations of block l
-    h = conv1x1(feats, params["fc0.weight"], params["fc0.bias"]).astype(dt)  # :217
+    h = act_store(conv1x1(feats, params["fc0.weight"], params["fc0.bias"]).astype(dt))  # :217
     for l in range(num_layers):  # :223, FnoBlock.forward :106-112
         acts.append(h)
         pre = spec(h, params[f"blocks.{l}.conv0.weights1"], params[f"blocks.{l}.conv0.weights2"]) + conv1x1(
             h, params[f"blocks.{l}.w0.weight"], params[f"blocks.{l}.w0.bias"]
         )
-        pre = pre.astype(dt)
+        pre = act_store(pre.astype(dt))
         pres.append(pre)
         h = gelu(pre)
     z1 = conv1x1(h, params["fc1.weight"], params["fc1.bias"]).astype(dt)  # :228
@@ -315,7 +329,7 @@ def adam_step(
 # --------------------------------------------------------------------------------------
 def generate_many(
     params: Dict[str, Array], inputs: Array, case_params: Array, mask: Array, steps: int,
-    num_layers: int = 4, use_fft: bool = True,
+    num_layers: int = 4, use_fft: bool = True, act_store=None,
 ) -> List[Array]:
     assert inputs.ndim == case_params.ndim + 2  # fno2d.py:280
     if inputs.ndim == 3:  # :281-285
@@ -324,7 +338,7 @@ def generate_many(
     out = []
     for _ in range(steps):  # :290-294
         cur = fno_forward(params, cur, case_params, mask, None, num_layers, use_fft=use_fft,
-                          keep_cache=False)["preds"]
+                          keep_cache=False, act_store=act_store)["preds"]
         out.append(cur)
     return out
 

@@ -65,27 +65,45 @@ def gen_fno_big(name, pseed, bseed, B, C, L, H, W, p):
 
 
 def gen_unet_big(name, seed, bseed, B, H, W, dim, p):
+    """Predictions, loss and running statistics from the reference in fp32 (its native precision); the gradient fingerprints
+    from the SAME module in fp64, because the fp32 gradients of this ReLU / train-mode-BatchNorm network are not a usable pin:
+    the reference's own fp32 backward deviates from its fp64 backward by up to ~2e-4 relative nMSE at this size (a
+    pre-activation next to zero lands on the other side of the ReLU kink).  That deviation is stored (``ref32_vs_64``) and
+    bounds what the test may ask of any fp32 implementation."""
     from models.unet import UNet  # reference
-    model = UNet(2, 2, MseLoss(normalize=True), p, insert_case_params_at="input", bilinear=False, dim=dim)
-    sd = synth.make_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed)
-    model.load_state_dict({k: _t(v) for k, v in sd.items()})
-    batch = synth.make_smooth_batch(bseed, B, H, W, p)
-    batch["mask"][:, :, 0, :] = 0
-    batch["mask"][:, :, :, 0] = 0
-    model.train()
-    out = model(inputs=_t(batch["inputs"]), case_params=_t(batch["case_params"]), mask=_t(batch["mask"]), label=_t(batch["label"]))
-    out["loss"]["nmse"].backward()
+
+    def run(dt):
+        model = UNet(2, 2, MseLoss(normalize=True), p, insert_case_params_at="input", bilinear=False, dim=dim)
+        sd = synth.make_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed)
+        model.load_state_dict({k: _t(v) for k, v in sd.items()})
+        model = model.to(dt)
+        batch = synth.make_smooth_batch(bseed, B, H, W, p)
+        batch["mask"][:, :, 0, :] = 0
+        batch["mask"][:, :, :, 0] = 0
+        tb = {k: _t(v).to(dt) for k, v in batch.items()}
+        model.train()
+        out = model(inputs=tb["inputs"], case_params=tb["case_params"], mask=tb["mask"], label=tb["label"])
+        out["loss"]["nmse"].backward()
+        return model, sd, tb, out
+
+    model, sd, tb, out = run(torch.float32)
+    m64, _, _, _ = run(torch.float64)
     save = dict(meta=np.array([seed, bseed, B, H, W, dim, p]), n_keys=np.array(len(sd)),
                 preds_train=out["preds"].detach().numpy(), **{f"loss_{k}": np.array(v.item()) for k, v in out["loss"].items()})
-    _grad_fingerprints(model, save, n=256)
+    _grad_fingerprints(m64, save, n=256)
+    g32 = {k: prm.grad.numpy() for k, prm in model.named_parameters()}
+    dev = [float(np.mean((g32[k] - prm.grad.numpy()) ** 2) / np.mean(prm.grad.numpy() ** 2))
+           for k, prm in m64.named_parameters() if float(prm.grad.abs().max()) > 1e-7]
+    save["ref32_vs_64"] = np.array(max(dev))
     for k, v in model.state_dict().items():
         if "running" in k:
             save[f"after::{k}"] = v.numpy()
+    model.load_state_dict({k: _t(v) for k, v in sd.items()})  # eval-mode outputs with the ORIGINAL running statistics
     model.eval()
     with torch.no_grad():
-        save["preds_eval"] = model(inputs=_t(batch["inputs"]), case_params=_t(batch["case_params"]), mask=_t(batch["mask"]))["preds"].numpy()
+        save["preds_eval"] = model(inputs=tb["inputs"], case_params=tb["case_params"], mask=tb["mask"])["preds"].numpy()
     np.savez_compressed(OUT / f"{name}.npz", **save)
-    print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
+    print(name, "ok", {k: float(v.detach()) for k, v in out["loss"].items()}, "fp32 vs fp64 reference gradients:", max(dev))
 
 
 def gen_auto_deeponet_big(name, pseed, bseed, B, H, W, width, depth, p):

@@ -419,6 +419,44 @@ def check_fno_vs_oracle(be, B, C, L, H, W, p=5, border=False, gain=4.0, pseed=7,
     return res
 
 
+def check_fno_bf16_storage(be, B, C, L, H, W, p=5, border=True, gain=4.0, pseed=17, bseed=18):
+    """cfd_fno_forward_ex with bf16 activation storage (BASELINE configs[4]) against the oracle with the SAME storage rule:
+    the lifting layer's output and every FnoBlock's pre-activation rounded to bf16 (RNE) where they are stored, everything
+    else fp32 / fp64.  An fp32 value that sits within round-off of a bf16 rounding boundary may fall to the other side than
+    the fp64 oracle's (one element in ~2e4, one bf16 ulp each), which bounds the agreement near 1e-9; ``vs_f32`` reports how
+    far the bf16-storage predictions are from the fp32 path (the price of the storage format, not an error)."""
+    api, P = be.api, be.ptr
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=gain)
+    batch = synth.make_batch(bseed, B, H, W, p, border_mask=border)
+    plan = api.plan_create(H, W, 12, 12)
+    try:
+        shape = FnoShape(B, H, W, 2, 2, p, C, L, 12, 12, 128)
+        pd = {k: be.dev(v) for k, v in params.items()}
+        ps = make_param_struct(be, pd, L)
+        di, dc, dm, dl = (be.dev(batch[k]) for k in ("inputs", "case_params", "mask", "label"))
+        out = {}
+        for name, dt in (("bf16", 1), ("f32", 0)):
+            nbytes = api.size("cfd_fno_workspace_bytes_ex", plan, ctypes.byref(shape), 0, dt)
+            assert nbytes > 0
+            ws = be.bytes(nbytes)
+            preds, sums = be.zeros((B, 2, H, W)), be.zeros((4,))
+            api.call("cfd_fno_forward_ex", plan, ctypes.byref(shape), ctypes.byref(ps), P(di), P(dc), P(dm), P(dl), P(preds),
+                     P(sums), P(ws), 0, dt, be.stream)
+            be.sync()
+            out[name] = (be.host(preds), be.host(sums))
+        assert api.size("cfd_fno_workspace_bytes_ex", plan, ctypes.byref(shape), 1, 1) == 0  # bf16 is an inference path
+        p64 = {k: v.astype(c128 if np.iscomplexobj(v) else f64) for k, v in params.items()}
+        b64 = {k: v.astype(f64) for k, v in batch.items()}
+        ref16 = O.fno_forward(p64, b64["inputs"], b64["case_params"], b64["mask"], b64["label"], L, act_store=O.bf16_round,
+                              keep_cache=False)
+        ref32 = O.fno_forward(p64, b64["inputs"], b64["case_params"], b64["mask"], b64["label"], L, keep_cache=False)
+        return {"bf16_vs_bf16_oracle": nm(out["bf16"][0], ref16["preds"]), "f32_vs_oracle": nm(out["f32"][0], ref32["preds"]),
+                "bf16_loss": abs(out["bf16"][1][0] / out["bf16"][1][2] - ref16["loss"]["nmse"]) / ref16["loss"]["nmse"],
+                "info:bf16_vs_f32": nm(out["bf16"][0], out["f32"][0]), "info:oracle_bf16_vs_f32": nm(ref16["preds"], ref32["preds"])}
+    finally:
+        api.plan_destroy(plan)
+
+
 # ---- dense layers of the DeepONet family (csrc/dense.hip) ---------------------------------------------------------
 def check_gemm(be, M, N, K, ta, tb, seed=21):
     api, P = be.api, be.ptr

@@ -52,6 +52,15 @@ def test_fused_block(be, B, Cin, Cout, H, W):
     _assert_all(K.check_block(be, B, Cin, Cout, H, W))
 
 
+def test_bf16_activation_storage_forward(be):
+    """cfd_fno_forward_ex(act_dtype = bf16) == the oracle with the same storage rule (one rounding per stored activation)."""
+    res = K.check_fno_bf16_storage(be, 1, 4, 1, 34, 33)
+    info = {k: v for k, v in res.items() if k.startswith("info:")}
+    assert res.pop("bf16_loss") < 1e-5  # fp32 loss sums
+    _assert_all({k: v for k, v in res.items() if not k.startswith("info:")}, tol=1e-7)
+    assert 1e-7 < info["info:bf16_vs_f32"] < 1e-3  # the storage format is visible, and small
+
+
 @pytest.mark.parametrize("H,W", [(64, 64), (66, 65)])
 def test_idft_epilogues(be, H, W):
     _assert_all(K.check_idft_epilogues(be, 3, H, W))

@@ -141,7 +141,11 @@ def test_unet_dim12_p8_64x64_vs_reference_golden(torch, golden_dir):
     assert O.rel_nmse(out["preds"].detach().cpu().numpy(), g["preds_train"]) < 1e-9
     assert abs(out["loss"]["nmse"].item() - float(g["loss_nmse"])) <= 1e-5 * float(g["loss_nmse"])
     out["loss"]["nmse"].backward()
-    _check_fingerprints(g, _named_grads(m), tol_vals=1e-6, tol_norm=1e-3)
+    # gradient fingerprints are the reference's fp64 backward; the reference's own fp32 backward is ref32_vs_64 (~2e-4) away
+    # from them (ReLU kinks), which bounds what an fp32 implementation can be asked to reproduce
+    noise = float(g["ref32_vs_64"])
+    assert 1e-6 < noise < 1e-2
+    _check_fingerprints(g, _named_grads(m), tol_vals=20 * noise, tol_norm=0.05)
     for k, v in m.state_dict().items():
         if "running" in k:
             assert O.rel_nmse(v.cpu().numpy(), g[f"after::{k}"]) < 1e-10, k

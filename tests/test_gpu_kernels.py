@@ -30,6 +30,16 @@ def test_spectral_fwd_bwd(be, B, Cin, Cout, H, W):
     _assert_all(K.check_spectral(be, B, Cin, Cout, H, W))
 
 
+@pytest.mark.parametrize("H,W", [(66, 65), (32, 64), (48, 64), (70, 80), (20, 24), (65, 33), (64, 64)])
+@pytest.mark.parametrize("general", [1, 0])
+def test_spectral_general_widths(be, H, W, general):
+    """Grids other than 64 x 64: the general-width split-bf16 transforms (columns dealt as y = 16 j + n) and, with the
+    general_b3 knob at 0, the exact-fp32 generic kernels they replace.  Many images per wave (persistent loop + ring)."""
+    with K.tuned(be, general_b3=general):
+        _assert_all(K.check_spectral(be, 23, 5, 4, H, W, m1=min(12, H // 2), m2=min(12, W // 2)))
+        _assert_all(K.check_idft_epilogues(be, 41, H, W, m1=min(12, H // 2), m2=min(12, W // 2)))
+
+
 @pytest.mark.parametrize("B,Cin,Cout", [(37, 20, 20), (9, 12, 7), (33, 24, 24), (70, 32, 32), (10, 5, 20), (256, 20, 20)])
 def test_mix_and_spectral_wgrad(be, B, Cin, Cout):
     _assert_all(K.check_mix_wgrad(be, B, Cin, Cout))
@@ -47,6 +57,18 @@ def test_mix_and_spectral_wgrad_kernel_routes(be, B, C, nwv, want_wg, fused):
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(5, 20, 20, 64, 64), (3, 6, 7, 32, 64), (2, 3, 5, 66, 65), (3, 32, 32, 64, 64), (2, 14, 9, 48, 64)])
 def test_fused_block(be, B, Cin, Cout, H, W):
     _assert_all(K.check_block(be, B, Cin, Cout, H, W))
+
+
+@pytest.mark.parametrize("B,C,L,H,W", [(3, 20, 2, 66, 65), (2, 32, 4, 66, 65), (2, 20, 4, 64, 64), (2, 8, 1, 48, 64)])
+def test_bf16_activation_storage_forward(be, B, C, L, H, W):
+    """BASELINE configs[4] storage format: cfd_fno_forward_ex(act_dtype = bf16) against the oracle with the same rule (the
+    lifting layer's output and every pre-activation rounded to bf16 once, where stored)."""
+    res = K.check_fno_bf16_storage(be, B, C, L, H, W)
+    info = {k: v for k, v in res.items() if k.startswith("info:")}
+    print(f"bf16 storage {B}x{C}x{H}x{W} L={L}:", {k: f"{v:.2e}" for k, v in res.items()})
+    assert res.pop("bf16_loss") < 1e-5  # fp32 loss sums
+    _assert_all({k: v for k, v in res.items() if not k.startswith("info:")}, tol=1e-7)
+    assert 1e-7 < info["info:bf16_vs_f32"] < 1e-3
 
 
 @pytest.mark.parametrize("H,W", [(64, 64), (66, 65)])

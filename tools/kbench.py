@@ -28,8 +28,12 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--json", type=str, default="")
+    ap.add_argument("--tune", type=str, default="", help="dispatch knobs, e.g. general_b3=0,fused_variant=0 (cfd_tune_set)")
     args = ap.parse_args()
     api = _lib.api()
+    for kv in [s for s in args.tune.split(",") if s]:
+        k, v = kv.split("=")
+        api.call("cfd_tune_set", k.encode(), int(v))
     dev = torch.device("cuda", 0)
     B, C, H, W = args.batch, args.hidden, args.height, args.width
     HW, m1, m2 = H * W, 12, 12
@@ -98,7 +102,12 @@ def main():
         "spectral_bwd": (lambda: api.call("cfd_spectral_conv2d_bwd", plan, P(g), P(xh), P(w1), P(w2), P(out), P(gw1), P(gw2),
                                           P(ws), B, C, C, st), 3 * N + 2 * Wb),
     }
+    def pair():
+        cases["spectral_fwd"][0]()
+        cases["spectral_bwd"][0]()
+    cases["spectral_fwd+bwd"] = (pair, 5 * N + 3 * Wb)
     only = [s for s in args.only.split(",") if s]
+    print(f"# B={B} C={C} {H}x{W} tune='{args.tune}'", flush=True)
     rows = {}
     for name, (fn, nbytes) in cases.items():
         if only and not any(name == o or name.startswith(o) for o in only):
