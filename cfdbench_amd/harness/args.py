@@ -6,7 +6,11 @@ the same attribute table drives ``argparse``.  Differences, all documented in SU
   * ``--data`` is an explicit alias of ``--data_name`` (README.md:179 uses it; argparse prefix matching would be ambiguous);
   * additions: ``infer_steps`` (test_multistep.py:198 hard-codes 20), ``fused`` (FnoTrainEngine instead of autograd+Adam),
     ``resume`` (continue from ``train_state.pt``: optimiser moments, schedule, epoch, RNG -- the reference saves weights only),
-    ``device_loader`` (frames resident in HBM, batches gathered on the device instead of DataLoader + collate_fn).
+    ``device_loader`` (frames resident in HBM, batches gathered on the device instead of DataLoader + collate_fn),
+    ``lr_scheduler`` (step = the reference's StepLR | plateau = ReduceLROnPlateau(lr_scheduler_factor, lr_scheduler_patience) |
+    cosine), ``early_stop`` (1: stop after early_stopping_patience evaluations without early_stopping_delta improvement),
+    ``gradient_accumulation_steps`` (args.py:323; micro-batches per optimiser step),
+    ``dtype`` (test_multistep only: "bf16" stores the FNO's activations between kernels as bf16 -- BASELINE configs[4]).
 Flags of models that are not built yet are carried so existing command lines and args.json files keep working.
 """
 from __future__ import annotations
@@ -35,7 +39,8 @@ _FLAGS: Dict[str, Any] = dict(
     # missing in the reference's Args but read by its trainers (train_auto.py:357, :188-189)
     lr_step_size=20, lr_gamma=0.9,
     # additions of this harness
-    infer_steps=20, fused=0, plot_interval=1, resume=0, device_loader=0,
+    infer_steps=20, fused=0, plot_interval=1, resume=0, device_loader=0, dtype="fp32",
+    lr_scheduler="step", early_stop=0, gradient_accumulation_steps=1,
 )
 
 

@@ -57,8 +57,10 @@ def batch_dependent(model) -> bool:
     return False
 
 
-def infer(model, all_features: List[Tensor], all_case_params: List[Tensor], infer_steps: int) -> List[Dict[str, float]]:
-    """test_multistep.py:135-177.  all_features[c]: (>=infer_steps, c+1, h, w) on the device.  The cases run as one batch
+def infer(model, all_features: List[Tensor], all_case_params: List[Tensor], infer_steps: int,
+          dtype: str = "fp32") -> List[Dict[str, float]]:
+    """test_multistep.py:135-177.  ``dtype`` = "bf16": the FNO rollout runs from one HIP graph with bf16 activation storage
+    (cfdbench_amd.rollout.FnoRollout; FNO only).  all_features[c]: (>=infer_steps, c+1, h, w) on the device.  The cases run as one batch
     unless the model is batch-dependent in its current mode (see the module docstring), in which case they run one by one
     exactly as in the reference."""
     n_cases = len(all_features)
@@ -69,6 +71,9 @@ def infer(model, all_features: List[Tensor], all_case_params: List[Tensor], infe
         per_case = [infer_case(model, f, cp, infer_steps) for f, cp in zip(all_features, all_case_params)]
         n_frames = len(per_case[0])
         preds = [torch.cat([pc[k] for pc in per_case], dim=0) for k in range(n_frames)]
+    elif dtype not in ("fp32", "f32", "float32"):
+        from ..rollout import FnoRollout
+        preds = FnoRollout(model, dtype=dtype).generate_many(start, cps, mask, infer_steps)
     else:
         with torch.no_grad():
             preds = model.generate_many(inputs=start, case_params=cps, mask=mask, steps=infer_steps)
@@ -114,7 +119,7 @@ def main(argv=None):
     model = init_model(args).cuda()
     output_dir = get_output_dir(args, is_auto=True)
     load_best_ckpt(model, output_dir)
-    all_metrics = infer(model, feats, cps, args.infer_steps)
+    all_metrics = infer(model, feats, cps, args.infer_steps, dtype=args.dtype)
     dump_json(all_metrics, output_dir / "multistep_metrics.json")
 
 

@@ -33,6 +33,7 @@ from ..models.fno.fno2d import Fno2d
 from .args import Args
 from .autoregressive import init_model
 from .common import dump_json, get_output_dir, load_best_ckpt, plot, plot_loss, plot_predictions
+from .schedule import EarlyStopping, LrSchedule
 from .dist_util import (average_buffers, broadcast_model_state, check_resume_state, init_distributed, rank_world,
                         shard_indices)
 
@@ -120,13 +121,18 @@ def test(model: AutoCfdModel, data, output_dir: Path, infer_steps: int = 200, pl
 def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epochs: int = 400, lr: float = 1e-3,
           lr_step_size: int = 1, lr_gamma: float = 0.9, batch_size: int = 2, eval_batch_size: int = 2,
           log_interval: int = 10, eval_interval: int = 2, measure_time: bool = False, fused: bool = False,
-          plot_interval: int = 1, resume: bool = False, device_loader: bool = False):
+          plot_interval: int = 1, resume: bool = False, device_loader: bool = False, lr_scheduler_kind: str = "step",
+          lr_scheduler_factor: float = 0.5, lr_scheduler_patience: int = 5, early_stopping_patience: int = 0,
+          early_stopping_delta: float = 1e-5, gradient_accumulation_steps: int = 1):
     """train_auto.py:181-313.  ``fused`` selects FnoTrainEngine (needs an Fno2d and the nmse loss).
 
     ``resume`` (the reference saves weights only, train_auto.py:301, and cannot continue a run): every
     checkpoint epoch also writes ``train_state.pt`` (optimiser moments / step, LR schedule, epoch, loss history, host RNG
     state); with ``resume`` a run that finds it reloads the weights of that checkpoint and continues with the NEXT epoch,
-    reproducing the uninterrupted run step for step (same shuffles, same Adam state)."""
+    reproducing the uninterrupted run step for step (same shuffles, same Adam state).
+
+    ``lr_scheduler_kind`` / ``early_stopping_patience`` / ``gradient_accumulation_steps``: the training options of this fork's
+    other trainers (harness/schedule.py; src/args.py:53-56,77-80,323) -- the defaults are the reference's benchmark loop."""
     rank, world = _rank_world()
     output_dir = Path(output_dir)
     if world > 1:  # shard the frames: every rank owns an equal, contiguous part of a fixed permutation (SURVEY.md 8e)
@@ -143,13 +149,20 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
     if rank == 0:
         output_dir.mkdir(exist_ok=True, parents=True)
     engine = None
+    accum = max(1, int(gradient_accumulation_steps))
     if fused:
         if not isinstance(model, Fno2d):
             raise NotImplementedError("--fused 1 needs the fno model")
+        if accum > 1:
+            raise NotImplementedError("--gradient_accumulation_steps > 1 needs the autograd path (--fused 0): the engine's "
+                                      "backward pass overwrites the flat gradient")
         engine = FnoTrainEngine(model, lr=lr, loss_name="nmse")
+        optimizer = None
     else:
         optimizer = Adam(model.parameters(), lr=lr)
-        scheduler = lr_scheduler.StepLR(optimizer, step_size=lr_step_size, gamma=lr_gamma)
+    schedule = LrSchedule(lr_scheduler_kind, lr, num_epochs, optimizer, lr_step_size=lr_step_size, lr_gamma=lr_gamma,
+                          factor=lr_scheduler_factor, patience=lr_scheduler_patience)
+    stopper = EarlyStopping(early_stopping_patience, early_stopping_delta)
     start_time = time.time()
     global_step = 0
     train_losses: List[float] = []
@@ -165,14 +178,16 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
             engine.load_state_dict(state["optimizer"])
         else:
             optimizer.load_state_dict(state["optimizer"])
-            scheduler.load_state_dict(state["scheduler"])
+        schedule.load_state_dict(state["scheduler"])
+        if state.get("early_stopping") is not None:
+            stopper.load_state_dict(state["early_stopping"])
         start_ep, global_step, train_losses = state["ep"] + 1, state["global_step"], list(state["train_losses"])
         torch.set_rng_state(state["rng"])  # the DataLoader draws its shuffles from the host generator
         if rank == 0:
             print(f"resuming after epoch {state['ep']} (step {global_step}) from {state_path}")
     for ep in range(start_ep, num_epochs):
         ep_start_time = time.time()
-        cur_lr = lr * lr_gamma ** (ep // lr_step_size)  # what StepLR(step_size, gamma) yields in epoch ep
+        cur_lr = schedule.lr
         ep_train_losses: List = []
         model.train()
         for step, batch in enumerate(train_loader):
@@ -187,11 +202,12 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
                 if step == 0 and not measure_time and rank == 0 and plot_interval > 0:
                     plot(batch["inputs"][0][0], batch["label"][0][0], outputs["preds"][0][0].detach(), Path("example.png"))
                 loss = outputs["loss"]
-                loss["nmse"].backward()  # train_auto.py:255
-                if world > 1:
-                    sync_gradients(list(model.parameters()))  # one flat all-reduce, DDP semantics
-                optimizer.step()
-                optimizer.zero_grad()
+                (loss["nmse"] / accum if accum > 1 else loss["nmse"]).backward()  # train_auto.py:255
+                if (step + 1) % accum == 0 or step + 1 == len(train_loader):
+                    if world > 1:
+                        sync_gradients(list(model.parameters()))  # one flat all-reduce, DDP semantics
+                    optimizer.step()
+                    optimizer.zero_grad()
                 ep_train_losses.append(loss["nmse"].item())  # train_auto.py:260
                 loss_mse, loss_nmse = loss["mse"], loss["nmse"]
             global_step += 1
@@ -205,8 +221,7 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
                            time=round(time.time() - start_time)))
         if engine is not None:
             ep_train_losses = torch.stack(ep_train_losses).tolist() if ep_train_losses else []
-        else:
-            scheduler.step()
+        schedule.epoch_end()
         if measure_time:
             print("Time usage:", time.time() - ep_start_time)
             return
@@ -231,15 +246,29 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
                            time=time.time() - ep_start_time), ckpt_dir / "scores.json")
             # full training state next to the reference's artefacts (written last, atomically: a crash mid-checkpoint
             # leaves the previous state in place)
+            dev_loss = float(np.mean(dev_scores["all"]["nmse"]))
+            schedule.validation(dev_loss)
+            stop = stopper.update(dev_loss)
             opt_state = engine.state_dict() if engine is not None else optimizer.state_dict()
             tmp = output_dir / "train_state.pt.tmp"
             torch.save(dict(ep=ep, global_step=global_step, train_losses=train_losses, ckpt=ckpt_dir.name,
-                            optimizer=opt_state, scheduler=None if engine is not None else scheduler.state_dict(),
+                            optimizer=opt_state, scheduler=schedule.state_dict(), early_stopping=stopper.state_dict(),
                             rng=torch.get_rng_state(), fused=engine is not None, world=world,
                             model_extra=model.extra_train_state() if hasattr(model, "extra_train_state") else None), tmp)
             tmp.replace(state_path)
-        if world > 1:
+        else:
+            stop = False
+        if world > 1:  # every rank follows rank 0's validation-driven decisions (plateau rate, early stop)
+            flags = torch.tensor([schedule.lr, float(stop)], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+            dist.broadcast(flags, 0)
+            for g_ in schedule.optimizer.param_groups:
+                g_["lr"] = float(flags[0])
+            stop = bool(flags[1] > 0.5)
             dist.barrier()
+        if stop:
+            if rank == 0:
+                print(f"early stopping after epoch {ep}: no improvement of {early_stopping_delta} in {early_stopping_patience} evaluations")
+            break
     if rank == 0:
         dump_json(train_losses, output_dir / "train_losses.json")
         plot_loss(train_losses, output_dir / "train_losses.png")
@@ -270,7 +299,10 @@ def main(argv=None):
               lr_step_size=args.lr_step_size, lr_gamma=args.lr_gamma, num_epochs=args.num_epochs,
               batch_size=args.batch_size, eval_batch_size=args.eval_batch_size, eval_interval=args.eval_interval,
               log_interval=args.log_interval, fused=bool(args.fused), plot_interval=args.plot_interval,
-              resume=bool(args.resume), device_loader=bool(args.device_loader))
+              resume=bool(args.resume), device_loader=bool(args.device_loader), lr_scheduler_kind=args.lr_scheduler,
+              lr_scheduler_factor=args.lr_scheduler_factor, lr_scheduler_patience=args.lr_scheduler_patience,
+              early_stopping_patience=args.early_stopping_patience if args.early_stop else 0,
+              early_stopping_delta=args.early_stopping_delta, gradient_accumulation_steps=args.gradient_accumulation_steps)
     if "test" in args.mode and rank == 0:  # the test split is small: rank 0 evaluates it alone
         args.save(str(output_dir / "test_args.json"))
         load_best_ckpt(model, output_dir)

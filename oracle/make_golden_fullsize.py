@@ -97,7 +97,7 @@ def gen_unet_big(name, seed, bseed, B, H, W, dim, p):
     save["ref32_vs_64"] = np.array(max(dev))
     for k, v in model.state_dict().items():
         if "running" in k:
-            save[f"after::{k}"] = v.numpy()
+            save[f"after::{k}"] = v.numpy().copy()
     model.load_state_dict({k: _t(v) for k, v in sd.items()})  # eval-mode outputs with the ORIGINAL running statistics
     model.eval()
     with torch.no_grad():

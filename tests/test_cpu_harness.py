@@ -141,3 +141,34 @@ def test_device_batch_loader_equals_dataloader_plus_collate():
     torch.manual_seed(5)
     again = torch.cat([b["inputs"] for b in DeviceBatchLoader(ds, 3, shuffle=True, drop_last=True, device="cpu", indices=idx)])
     assert torch.equal(seen, again)  # the permutation comes from the host generator: reproducible / resumable
+
+
+def test_lr_schedules_follow_torch_and_early_stopping():
+    """harness/schedule.py: the fused engine's shadow-optimizer schedule == the torch scheduler on a real optimizer."""
+    import torch
+    from cfdbench_amd.harness.schedule import EarlyStopping, LrSchedule
+    for kind in ("step", "cosine", "plateau"):
+        opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(3))], lr=2e-3)
+        a = LrSchedule(kind, 2e-3, 10, opt, lr_step_size=3, lr_gamma=0.9, factor=0.5, patience=1)
+        b = LrSchedule(kind, 2e-3, 10, None, lr_step_size=3, lr_gamma=0.9, factor=0.5, patience=1)
+        dev = [1.0, 0.9, 0.95, 0.97, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0]
+        seen = []
+        for ep in range(10):
+            assert a.lr == b.lr
+            seen.append(a.lr)
+            for s_ in (a, b):
+                s_.epoch_end()
+                s_.validation(dev[ep])
+        if kind == "step":
+            assert abs(seen[3] - 2e-3 * 0.9) < 1e-15 and abs(seen[9] - 2e-3 * 0.9 ** 3) < 1e-15
+        if kind == "cosine":
+            assert abs(seen[5] - 1e-3) < 1e-12
+        if kind == "plateau":
+            assert seen[0] == seen[2] == 2e-3 and seen[4] == 1e-3 and seen[-1] < 1e-3
+        st = b.state_dict()
+        c = LrSchedule(kind, 2e-3, 10, None, lr_step_size=3, lr_gamma=0.9, factor=0.5, patience=1)
+        c.load_state_dict(st)
+        assert c.lr == b.lr
+    es = EarlyStopping(patience=2, delta=0.01)
+    assert [es.update(v) for v in (1.0, 0.995, 0.5, 0.495, 0.499)] == [False, False, False, False, True]
+    assert not EarlyStopping(0).update(1.0)

@@ -78,11 +78,10 @@ def test_fno_whole_model_vs_reference_and_oracle(torch, golden_dir, name):
     for k in ("mse", "rmse", "mae", "nmse"):
         assert abs(out["loss"][k].item() - float(g[f"loss_{k}"])) <= 5e-6 * abs(float(g[f"loss_{k}"]))
     _check_fingerprints(g, grads, tol_vals=1e-7)
-    # -- the fp64 oracle.  The forward pass is per-sample, so every 16th sample of the batch pins the predictions
-    # (NumPy needs ~0.7 s per sample and pass); CFD_FULL_ORACLE=1 runs the whole batch through the oracle forward AND
-    # backward and compares every gradient entry (~3 min; its log is committed under profiles/).
+    # -- the fp64 oracle on the WHOLE batch: every prediction and every gradient entry (~10 s of NumPy on the GPU box's host;
+    # CFD_FAST_ORACLE=1 restricts it to the predictions of every 16th sample on slow hosts -- the forward pass is per sample)
     import os
-    full = os.environ.get("CFD_FULL_ORACLE") == "1" or B <= 16
+    full = os.environ.get("CFD_FAST_ORACLE") != "1" or B <= 16
     sel = slice(None) if full else slice(0, None, 16)
     p64 = {k: v.astype(np.complex128 if np.iscomplexobj(v) else np.float64) for k, v in params.items()}
     b64 = {k: v.astype(np.float64)[sel] for k, v in batch.items()}
@@ -204,3 +203,19 @@ def test_rollout_200_steps_c32_66x65_vs_reference_golden(torch, golden_dir):
     graph_frames = FnoRollout(m).generate_many(b["inputs"], b["case_params"], b["mask"], steps)
     for k in (0, 99, 199):
         assert torch.equal(graph_frames[k], frames[k])
+    # bf16 activation storage (BASELINE configs[4]).  The reference has no reduced-precision path, so the yardstick is the fp32
+    # rollout above; the stated per-step tolerance is  nMSE_k(bf16 vs fp32) <= 4e-5 * k^1.5  (k = step, averaged over the
+    # cases; measured 1.3e-5 at k = 1 and 4.1e-2 at k = 200 on this near-identity propagator, growth ~ k^1.44:
+    # profiles/r02g_rollout_bf16_study.txt) -- i.e. bf16 storage is OUTSIDE the 1e-5 budget of the fp32 path from the first
+    # step on and is offered as an explicit opt-in (FnoRollout(dtype="bf16"), test_multistep --dtype bf16).
+    b16 = FnoRollout(m, dtype="bf16").generate_many(b["inputs"], b["case_params"], b["mask"], steps)
+    errs16 = {k: O.rel_nmse(b16[k - 1].cpu().numpy(), frames[k - 1].cpu().numpy()) for k in (1, 2, 10, 50, 100, 200)}
+    print("bf16-storage rollout nMSE vs the fp32 rollout:", {k: f"{v:.1e}" for k, v in errs16.items()})
+    for k, e in errs16.items():
+        assert e <= 4e-5 * k ** 1.5, (k, e)
+    assert errs16[1] > 1e-7  # the storage format is really in use
+    # the same storage rule in the oracle: one rounding per stored activation (first step, where nothing has accumulated)
+    p64 = {k: v.astype(np.complex128 if np.iscomplexobj(v) else np.float64) for k, v in params.items()}
+    ref16 = O.fno_forward(p64, batch["inputs"].astype(np.float64), batch["case_params"].astype(np.float64),
+                          batch["mask"].astype(np.float64), None, L, act_store=O.bf16_round, keep_cache=False)["preds"]
+    assert O.rel_nmse(b16[0].cpu().numpy(), ref16) < 1e-7

@@ -161,6 +161,57 @@ def test_fused_and_autograd_paths_agree(torch, tmp_path):
         assert O.rel_nmse(bb.cpu().numpy(), a.cpu().numpy()) < 1e-9, k
 
 
+@pytest.mark.parametrize("fused", [0, 1])
+def test_training_options_schedules_and_early_stopping(torch, tmp_path, fused):
+    """SURVEY.md 8f-4 options: cosine / plateau learning-rate schedules on both training paths (the fused engine follows the
+    torch scheduler bit for bit through a shadow optimizer), early stopping on the validation loss, and (autograd path)
+    gradient accumulation == one step on the concatenated micro-batches' averaged gradients."""
+    from cfdbench_amd.harness.autoregressive import init_model
+    from cfdbench_amd.harness.common import get_output_dir
+    from cfdbench_amd.harness.data import SyntheticAutoDataset
+    from cfdbench_amd.harness.train_auto import train
+    tr = SyntheticAutoDataset(n_cases=4, n_frames=5, height=64, width=64, seed=0)
+    dev = SyntheticAutoDataset(n_cases=2, n_frames=3, height=64, width=64, seed=1)
+    finals = {}
+    for kind in ("cosine", "plateau"):
+        args = _args(tmp_path / kind, fused=fused)
+        out = get_output_dir(args, is_auto=True)
+        torch.manual_seed(0)
+        model = init_model(args).cuda()
+        losses = train(model, tr, dev, out, num_epochs=6, lr=5e-3, batch_size=4, eval_batch_size=4, eval_interval=1,
+                       fused=bool(fused), plot_interval=0, lr_scheduler_kind=kind, lr_scheduler_factor=0.5, lr_scheduler_patience=0,
+                       early_stopping_patience=2, early_stopping_delta=10.0)  # delta so large that nothing counts as improvement
+        # the first evaluation sets the best value, the next two are "no improvement" -> stop after epoch 2
+        assert len(losses) == 3 * (len(tr) // 4), (kind, len(losses))
+        state = torch.load(out / "train_state.pt", map_location="cpu", weights_only=False)
+        assert state["scheduler"]["kind"] == kind and state["early_stopping"]["bad"] == 2
+        if kind == "plateau":  # patience 0: the rate halves at every evaluation without improvement
+            assert abs(state["scheduler"]["lr"] - 5e-3 * 0.25) < 1e-12
+        else:
+            assert abs(state["scheduler"]["lr"] - 5e-3 * 0.5 * (1 + np.cos(np.pi * 3 / 6))) < 1e-9
+        finals[kind] = losses
+    if not fused:
+        from torch.utils.data import DataLoader
+        from cfdbench_amd.harness.train_auto import collate_fn
+        args = _args(tmp_path / "accum", fused=0)
+        n_micro = len(tr) // 4
+        assert n_micro >= 2
+        torch.manual_seed(0)
+        m1 = init_model(args).cuda()
+        train(m1, tr, dev, get_output_dir(args, is_auto=True), num_epochs=1, lr=1e-3, batch_size=4, eval_interval=10, plot_interval=0,
+              gradient_accumulation_steps=n_micro)
+        # by hand: ONE Adam step on the mean of the micro-batch gradients (same seed -> same initial weights, same shuffle)
+        torch.manual_seed(0)
+        m3 = init_model(args).cuda()
+        opt = torch.optim.Adam(m3.parameters(), lr=1e-3)
+        m3.train()
+        for batch in DataLoader(tr, batch_size=4, shuffle=True, collate_fn=collate_fn):
+            (m3(**batch)["loss"]["nmse"] / n_micro).backward()
+        opt.step()
+        for (k, a), b in zip(m1.state_dict().items(), m3.state_dict().values()):
+            assert torch.equal(a, b), k
+
+
 def test_multistep_inference_metrics(torch, tmp_path):
     from cfdbench_amd.harness.autoregressive import init_model
     from cfdbench_amd.harness.data import SyntheticAutoDataset
