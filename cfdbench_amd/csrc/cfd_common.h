@@ -8,7 +8,7 @@
 void cfd_set_error(const char* fmt, ...);
 
 // dispatch overrides (tune.cpp): environment read once per process, cfd_tune_set() afterwards; -1 = built-in choice
-enum { CFD_TUNE_MIX_NWV = 0, CFD_TUNE_WGRAD_WG, CFD_TUNE_FUSED_VARIANT, CFD_TUNE_BLOCK_FUSE, CFD_TUNE_GENERAL_B3, CFD_TUNE_COUNT };
+enum { CFD_TUNE_MIX_NWV = 0, CFD_TUNE_WGRAD_WG, CFD_TUNE_FUSED_VARIANT, CFD_TUNE_BLOCK_FUSE, CFD_TUNE_GENERAL_B3, CFD_TUNE_HEAD_BLOCKS, CFD_TUNE_COUNT };
 int cfd_tune_get(int which);
 
 #define CFD_REQUIRE(cond, code, ...)      \
@@ -111,9 +111,10 @@ int cfd_int_fno_head_fwd(const void* a, const float* mask, const float* label, c
 // Phi(x) = (1 + erf(x/sqrt 2))/2 with erf from Abramowitz & Stegun 7.1.26 (|err| <= 1.5e-7, i.e. fp32 round-off
 // class: nMSE vs the fp64 GELU on N(0,1) inputs 8e-15, ATen's own fp32 erff-based GELU 4e-15).  GELU is recomputed
 // on load by every consumer of an activation and is the VALU bottleneck of the head kernels, so it is evaluated on
-// PAIRS of values with packed fp32 math: 8 packed + 2 bit ops + rcp + exp2 per value instead of ~36 scalar VALU
-// instructions of libdevice erff.  The same exp(-x^2/2) serves erf and the density phi (derivative = 2 more ops).
-__device__ __forceinline__ void cfd_gelu_terms2(cfd_f2 x, cfd_f2& Phi, cfd_f2& e) {
+// PAIRS of values with packed fp32 math: 12 packed ops + 2 rcp + 2 exp2 per PAIR instead of ~36 scalar VALU
+// instructions per value of libdevice erff.  The same exp(-x^2/2) serves erf and the density phi (derivative = 2 more ops).
+// hc = erfc(|x| / sqrt 2) / 2 = Phi(-|x|) and e = exp(-x^2 / 2): the A&S polynomial with the 1/2 folded into its coefficients
+__device__ __forceinline__ void cfd_gelu_hc2(cfd_f2 x, cfd_f2& hc, cfd_f2& e) {
     const cfd_f2 d = cfd_fma2(cfd_abs2(x), (cfd_f2)(0.3275911f * CFD_SQRT1_2), (cfd_f2)(1.0f));
     cfd_f2 t;
     t.x = cfd_rcpf(d.x);
@@ -121,20 +122,25 @@ __device__ __forceinline__ void cfd_gelu_terms2(cfd_f2 x, cfd_f2& Phi, cfd_f2& e
     const cfd_f2 arg = (x * x) * (cfd_f2)(-0.72134752044448170368f);  // -x^2/2 * log2(e)
     e.x = cfd_exp2f(arg.x);  // exp(-x^2/2)
     e.y = cfd_exp2f(arg.y);
-    cfd_f2 p = cfd_fma2((cfd_f2)(1.061405429f), t, (cfd_f2)(-1.453152027f));
-    p = cfd_fma2(p, t, (cfd_f2)(1.421413741f));
-    p = cfd_fma2(p, t, (cfd_f2)(-0.284496736f));
-    p = cfd_fma2(p, t, (cfd_f2)(0.254829592f));
-    const cfd_f2 hc = ((p * t) * e) * (cfd_f2)(0.5f);  // erfc(|x|/sqrt 2) / 2
-    cfd_f2 s = (cfd_f2)(0.5f) - hc;                     // Phi(|x|) - 1/2 >= 0
+    cfd_f2 p = cfd_fma2((cfd_f2)(0.5f * 1.061405429f), t, (cfd_f2)(0.5f * -1.453152027f));
+    p = cfd_fma2(p, t, (cfd_f2)(0.5f * 1.421413741f));
+    p = cfd_fma2(p, t, (cfd_f2)(0.5f * -0.284496736f));
+    p = cfd_fma2(p, t, (cfd_f2)(0.5f * 0.254829592f));
+    hc = (p * t) * e;
+}
+__device__ __forceinline__ void cfd_gelu_terms2(cfd_f2 x, cfd_f2& Phi, cfd_f2& e) {
+    cfd_f2 hc;
+    cfd_gelu_hc2(x, hc, e);
+    cfd_f2 s = (cfd_f2)(0.5f) - hc;  // Phi(|x|) - 1/2 >= 0
     s.x = copysignf(s.x, x.x);
     s.y = copysignf(s.y, x.y);
     Phi = (cfd_f2)(0.5f) + s;
 }
+// gelu(x) = x Phi(x) = x/2 + |x| (1/2 - hc): no sign fix-up at all
 __device__ __forceinline__ cfd_f2 cfd_gelu2(cfd_f2 x) {
-    cfd_f2 Phi, e;
-    cfd_gelu_terms2(x, Phi, e);
-    return x * Phi;
+    cfd_f2 hc, e;
+    cfd_gelu_hc2(x, hc, e);
+    return cfd_fma2(cfd_abs2(x), (cfd_f2)(0.5f) - hc, x * (cfd_f2)(0.5f));
 }
 __device__ __forceinline__ cfd_f2 cfd_gelu_grad2(cfd_f2 x) {
     cfd_f2 Phi, e;

@@ -20,6 +20,17 @@ __device__ __forceinline__ f32x4 cfd_mfma16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4
 
 __device__ __forceinline__ float cfd_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 
+// Sum over the four 16-lane rows of a wave (every lane gets the total of the lanes with the same lane & 15): two VALU row
+// swaps (v_permlane16_swap / v_permlane32_swap, gfx950) instead of two ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ float cfd_row_sum4(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // [r0 r0 r2 r2], [r1 r1 r3 r3]
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned w = __float_as_uint(s);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);  // [lo lo], [hi hi]
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 __device__ __forceinline__ float cfd_wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -32,6 +43,23 @@ __device__ __forceinline__ void cfd_wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// "Retire fence" for a group of MFMAs: a real VALU read of the accumulator written by the LAST MFMA of the group, fenced on
+// both sides.  hipcc inserts the wait states an MFMA result needs before a VALU instruction may read it, the matrix pipe is in
+// order, so past this point every MFMA of the group has read its operands and written its result.  Needed before LDS / global
+// LOADS that follow MFMAs: the register allocator may make an MFMA out of place (dst != SrcC) and hand the freed SrcC
+// registers to such a load a fixed few wait states later, but an MFMA that depends on earlier MFMAs (or that sits behind
+// another wave's MFMAs on the same SIMD) reads SrcC when it actually STARTS -- under matrix-pipe contention the load's data
+// got there first (k_head_fwd beside another process' k_head_bwd: one phase of one tile wrong in ~10 % of the launches;
+// tools/det_kernels.py reproduces it, tools/scan_mfma_hazard.py finds the instruction pattern).
+__device__ __forceinline__ float cfd_mfma_retire(const f32x4& last) {
+    __builtin_amdgcn_sched_barrier(0);
+    int one = 0x3f800000;
+    asm volatile("" : "+v"(one));
+    const float t = __builtin_fmaf(last[3], __int_as_float(one), 0.f);  // not foldable: `one` is opaque
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
 }
 
 // Makes a value opaque to the optimiser (no instruction emitted).  Used on LDS table offsets inside a loop so the

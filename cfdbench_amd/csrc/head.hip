@@ -12,14 +12,15 @@
 #define HEAD_HD 128
 #define HEAD_MT 8
 #ifndef CFD_HEAD_FWD_BLOCKS
-#define CFD_HEAD_FWD_BLOCKS 768  // 3 resident workgroups per CU (138 VGPRs); 1024 leaves a quarter-filled second round (+5 %)
+#define CFD_HEAD_FWD_BLOCKS 1024  // 4 resident workgroups per CU (124 VGPRs)
 #endif
 #define HEAD_LD 17  // LDS row stride of the transposed tiles (16 pixels + 1 pad -> conflict-free column reads)
 
 static int head_blocks(int B, int HW) {
     const long tiles = (long)B * ((HW + 63) / 64);
     long blocks = (tiles + 7) / 8;  // >= 2 tiles per wave
-    if (blocks > CFD_HEAD_FWD_BLOCKS) blocks = CFD_HEAD_FWD_BLOCKS;
+    const int cap = cfd_tune_get(CFD_TUNE_HEAD_BLOCKS) > 0 ? cfd_tune_get(CFD_TUNE_HEAD_BLOCKS) : CFD_HEAD_FWD_BLOCKS;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
@@ -27,19 +28,27 @@ static int head_blocks(int B, int HW) {
 // backward: the four waves of a block share each tile (see k_head_bwd)
 static int head_bwd_blocks(int B, int HW) {
     const long tiles = (long)B * ((HW + 63) / 64);
-    long blocks = tiles < 512 ? tiles : 512;
+    const int cap = cfd_tune_get(CFD_TUNE_HEAD_BLOCKS) > 0 ? cfd_tune_get(CFD_TUNE_HEAD_BLOCKS) : 512;  // knob: tests reach the multi-tile loop
+    long blocks = tiles < cap ? tiles : cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
 
-// Input tile in the K = 32 operand layout of v_mfma_f32_16x16x32_bf16: lane group q owns channels 8q .. 8q+7
-// (k-slot v <-> channel 8q + v, zero beyond C) of the lane's four pixels px .. px+3.
+// Input tile in the K = 32 operand layout of v_mfma_f32_16x16x32_bf16: lane group q owns channels CQ q .. CQ q + CQ - 1 with
+// CQ = ceil(C / 4) (k-slot v <-> channel CQ q + v for v < CQ, zero otherwise) of the lane's four pixels px .. px+3.  Dealing
+// the channels evenly over the four lane groups (5 each at C = 20) instead of 8 per group keeps the GELU-on-load work at
+// C values per pixel: with 8 per group the groups q = 2, 3 evaluated GELU on 12 zero slots (37 % of the input GELUs, which
+// are half of all GELUs of the forward head).
 template <bool VEC4, bool ACT, typename TA = float>
-__device__ __forceinline__ void head_load_h8(const TA* __restrict__ a, int b, int C, int HW, int px, int q,
+__device__ __forceinline__ void head_load_h8(const TA* __restrict__ a, int b, int C, int CQ, int HW, int px, int q,
                                              float (&h)[8][4]) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const int i = 8 * q + c;
+        if (c >= CQ) {  // wave-uniform: no load, no GELU
+            h[c][0] = h[c][1] = h[c][2] = h[c][3] = 0.f;
+            continue;
+        }
+        const int i = CQ * q + c;
         const TA* src = a + ((size_t)b * C + i) * HW + px;
         if constexpr (VEC4 && sizeof(TA) == 4) {
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -53,14 +62,14 @@ __device__ __forceinline__ void head_load_h8(const TA* __restrict__ a, int b, in
     }
 }
 
-// split-bf16 A-operand fragments of fc1 for z = W1 h:  frag[mt][lane=(q,i)][v] = w1[16mt+i][8q+v]
-__device__ __forceinline__ void head_build_w1f(bf16x8* s_hi, bf16x8* s_lo, const float* __restrict__ w1, int C) {
+// split-bf16 A-operand fragments of fc1 for z = W1 h:  frag[mt][lane=(q,i)][v] = w1[16mt+i][CQ q + v]  (v < CQ)
+__device__ __forceinline__ void head_build_w1f(bf16x8* s_hi, bf16x8* s_lo, const float* __restrict__ w1, int C, int CQ) {
     for (int idx = threadIdx.x; idx < HEAD_MT * 64; idx += blockDim.x) {
         const int ln = idx & 63, mt = idx >> 6;
-        const int jh = 16 * mt + (ln & 15), c0 = 8 * (ln >> 4);
+        const int jh = 16 * mt + (ln & 15), c0 = CQ * (ln >> 4);
         float x[8];
 #pragma unroll
-        for (int v = 0; v < 8; ++v) x[v] = c0 + v < C ? w1[jh * C + c0 + v] : 0.f;
+        for (int v = 0; v < 8; ++v) x[v] = (v < CQ && c0 + v < C) ? w1[jh * C + c0 + v] : 0.f;
         const CfdSplit8 s = cfd_split8(x);
         s_hi[idx] = s.hi;
         s_lo[idx] = s.lo;
@@ -74,10 +83,11 @@ __global__ __launch_bounds__(256, 2) void k_head_fwd(const TA* __restrict__ a, c
                                                   const float* __restrict__ b2, float* __restrict__ preds,
                                                   float* __restrict__ part, int B, int C, int Co, int HW) {
     __shared__ bf16x8 s_w1hi[HEAD_MT * 64], s_w1lo[HEAD_MT * 64];
-    __shared__ float s_b1[HEAD_HD];
-    __shared__ cfd_f2 s_w2[HEAD_HD];  // (w2[0][jh], w2[1][jh]) pairs: one packed FMA updates both outputs
+    __shared__ __attribute__((aligned(16))) float s_b1[HEAD_HD];
+    __shared__ __attribute__((aligned(16))) cfd_f2 s_w2[HEAD_HD];  // (w2[0][jh], w2[1][jh]) pairs: one packed FMA updates both outputs
     __shared__ float s_red[12];
-    head_build_w1f(s_w1hi, s_w1lo, w1, C);
+    const int CQ = (C + 3) / 4;  // channels per lane group of the K = 32 operand
+    head_build_w1f(s_w1hi, s_w1lo, w1, C, CQ);
     for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x) s_b1[i] = b1[i];
     for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x) s_w2[i] = cfd_f2{w2[i], Co > 1 ? w2[HEAD_HD + i] : 0.f};
     __syncthreads();
@@ -91,13 +101,13 @@ __global__ __launch_bounds__(256, 2) void k_head_fwd(const TA* __restrict__ a, c
         const int b = (int)(tile / tpb);
         const int px = (int)(tile - (long)b * tpb) * 64 + 4 * n;
         float h[8][4];
-        head_load_h8<VEC4, ACT, TA>(a, b, C, HW, px, q, h);
+        head_load_h8<VEC4, ACT, TA>(a, b, C, CQ, HW, px, q, h);
         // The 4 pixel phases j run in a ROLLED loop (one 16-pixel sub-tile per trip keeps the live set at one
         // z tile); the phase being processed always sits in h[c][0] / lands in out*[3], registers rotate each trip.
         float out0[4] = {0.f, 0.f, 0.f, 0.f}, out1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int j = 0; j < 4; ++j) {
-            const int lo = cfd_opaque(lane), q4 = cfd_opaque(4 * q);  // keep the LDS table reads inside the loop
+            const int lo = cfd_opaque(lane), q4 = 4 * cfd_opaque(q);  // keep the LDS table reads inside the loop (q4: a visible multiple of 4)
             float xk[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) xk[c] = h[c][0];
@@ -106,17 +116,17 @@ __global__ __launch_bounds__(256, 2) void k_head_fwd(const TA* __restrict__ a, c
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt) {
                 const int jb = 16 * mt + q4;
-                z[mt] = f32x4{s_b1[jb], s_b1[jb + 1], s_b1[jb + 2], s_b1[jb + 3]};
+                const float4 bq = *reinterpret_cast<const float4*>(s_b1 + jb);  // one ds_read_b128 (16-byte aligned)
+                z[mt] = f32x4{bq.x, bq.y, bq.z, bq.w};
             }
-            // z += W1 h as w_lo*h_hi + w_hi*h_lo + w_hi*h_hi (term-major: consecutive MFMAs hit different accumulators)
+            // z += W1 h as w_lo*h_hi + w_hi*h_lo + w_hi*h_hi, strictly term-major: consecutive MFMAs hit different accumulators
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(s_w1lo[mt * 64 + lo], bs.hi, z[mt]);
 #pragma unroll
-            for (int mt = 0; mt < HEAD_MT; ++mt) {
-                const bf16x8 whi = s_w1hi[mt * 64 + lo];
-                z[mt] = cfd_mfma16x16x32_bf16(whi, bs.lo, z[mt]);
-                z[mt] = cfd_mfma16x16x32_bf16(whi, bs.hi, z[mt]);
-            }
+            for (int mt = 0; mt < HEAD_MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(s_w1hi[mt * 64 + lo], bs.lo, z[mt]);
+            cfd_sched_fence();
+#pragma unroll
+            for (int mt = 0; mt < HEAD_MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(s_w1hi[mt * 64 + cfd_opaque(lo)], bs.hi, z[mt]);
             cfd_f2 o01 = {0.f, 0.f};
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt)
@@ -124,12 +134,11 @@ __global__ __launch_bounds__(256, 2) void k_head_fwd(const TA* __restrict__ a, c
                 for (int r = 0; r < 4; r += 2) {
                     const int jh = 16 * mt + q4 + r;
                     const cfd_f2 gl = cfd_gelu2(cfd_f2{z[mt][r], z[mt][r + 1]});
-                    o01 = cfd_fma2(s_w2[jh], (cfd_f2)(gl.x), o01);
-                    o01 = cfd_fma2(s_w2[jh + 1], (cfd_f2)(gl.y), o01);
+                    const float4 wq = *reinterpret_cast<const float4*>(s_w2 + jh);  // (w2[0][jh], w2[1][jh], w2[0][jh+1], w2[1][jh+1])
+                    o01 = cfd_fma2(cfd_f2{wq.x, wq.y}, (cfd_f2)(gl.x), o01);
+                    o01 = cfd_fma2(cfd_f2{wq.z, wq.w}, (cfd_f2)(gl.y), o01);
                 }
-            float o0 = o01.x, o1 = o01.y;
-            o0 += cfd_shfl_xor(o0, 16); o0 += cfd_shfl_xor(o0, 32);
-            o1 += cfd_shfl_xor(o1, 16); o1 += cfd_shfl_xor(o1, 32);
+            const float o0 = cfd_row_sum4(o01.x), o1 = cfd_row_sum4(o01.y);  // sum over the four lane groups
             out0[0] = out0[1]; out0[1] = out0[2]; out0[2] = out0[3]; out0[3] = o0;
             out1[0] = out1[1]; out1[1] = out1[2]; out1[2] = out1[3]; out1[3] = o1;
 #pragma unroll
@@ -338,6 +347,8 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     const long total = (long)B * tpb;
     // ---- cooperative staging: element e = (channel e/16, pixel quad e%16) of a tile ----
     float4 raw[NST];
+    float4 gp_cur[NST], gp_next[NST];  // f'(a) of the tile being processed / of the tile just staged (ACT only): the GELU terms
+                                       // are evaluated ONCE per activation value, for f(a) at staging and f'(a) in the epilogue
     auto fetch = [&](long tile) {  // raw activations of `tile` -> registers (zeros past the end of the work / image)
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
@@ -367,7 +378,16 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
             const int i = e >> 4, n4 = e & 15;
             if (i < C) {
                 float4 v = raw[k];
-                if constexpr (ACT) cfd_gelu4(v.x, v.y, v.z, v.w);
+                if constexpr (ACT) {
+                    cfd_f2 P0, e0, P1, e1;
+                    const cfd_f2 x0 = {v.x, v.y}, x1 = {v.z, v.w};
+                    cfd_gelu_terms2(x0, P0, e0);
+                    cfd_gelu_terms2(x1, P1, e1);
+                    const cfd_f2 g0 = cfd_fma2(x0 * (cfd_f2)(CFD_INV_SQRT_2PI), e0, P0), g1 = cfd_fma2(x1 * (cfd_f2)(CFD_INV_SQRT_2PI), e1, P1);
+                    gp_next[k] = make_float4(g0.x, g0.y, g1.x, g1.y);
+                    const cfd_f2 f0 = x0 * P0, f1 = x1 * P1;
+                    v = make_float4(f0.x, f0.y, f1.x, f1.y);
+                }
                 const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -385,6 +405,8 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     __syncthreads();  // planes zeroed
     fetch(blockIdx.x);
     stage(0);
+#pragma unroll
+    for (int k = 0; k < NST; ++k) gp_cur[k] = gp_next[k];
     fetch((long)blockIdx.x + gridDim.x);
     __syncthreads();
     int buf = 0;
@@ -524,7 +546,10 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
         stage(buf ^ 1);
         fetch(tile + 2 * (long)gridDim.x);
         // ga[b][i][px0 .. px0+63] = (sum over the four hidden slices) * f'(a)
-        for (int e = threadIdx.x; e < C * 16; e += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            if (e >= C * 16) continue;
             const int i = e >> 4, n4 = e & 15;
             float4 v = s_red[i * 16 + n4];
 #pragma unroll
@@ -537,23 +562,25 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
             if constexpr (VEC4) {
                 if (p4 < HW) {
                     if constexpr (ACT) {
-                        float4 gg = *reinterpret_cast<const float4*>(a + off);
-                        cfd_gelu_grad4(gg.x, gg.y, gg.z, gg.w);
+                        const float4 gg = gp_cur[k];
                         v.x *= gg.x; v.y *= gg.y; v.z *= gg.z; v.w *= gg.w;
                     }
                     *reinterpret_cast<float4*>(ga + off) = v;
                 }
             } else {
                 const float vv[4] = {v.x, v.y, v.z, v.w};
+                const float gv[4] = {gp_cur[k].x, gp_cur[k].y, gp_cur[k].z, gp_cur[k].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (p4 + j < HW) {
                         float x = vv[j];
-                        if constexpr (ACT) x *= cfd_gelu_grad(a[off + j]);
+                        if constexpr (ACT) x *= gv[j];
                         ga[off + j] = x;
                     }
             }
         }
+#pragma unroll
+        for (int k = 0; k < NST; ++k) gp_cur[k] = gp_next[k];
         __syncthreads();
     }
     // ---- this block's partial parameter gradients: [gw1 128*C | gb1 128 | gw2 Co*128 | gb2 Co] ----

@@ -20,6 +20,7 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
     {"fused_variant", "CFD_FUSED_VARIANT", {-1}},  // 0 = adjoint mix and weight gradient as two launches
     {"block_fuse", "CFD_BLOCK_FUSE", {-1}},      // 0 = FnoBlock backward without the fused 1x1 weight gradient
     {"general_b3", "CFD_GENERAL_B3", {-1}},      // 0 = grids other than 64 x 64 on the exact-fp32 generic transforms
+    {"head_blocks", "CFD_HEAD_BLOCKS", {-1}},    // workgroup cap of the head kernels (tests: several tiles per workgroup at small sizes)
 };
 std::once_flag g_once;
 void read_env() {

@@ -69,6 +69,10 @@ class GradSync:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.n_buckets = max(1, n_buckets)
+        # RCCL ("nccl") reduces device buffers on its own stream, ordered by events: the asynchronous per-slice exchange below.
+        # Any other backend (gloo: the CPU tests, and the 2-process tests that share one GPU) gets device slices through an
+        # explicit, stream-ordered host staging in wait_all -- correct by construction, no overlap.
+        self.device_native = self.world > 1 and dist.get_backend(group) == "nccl"
 
     def bucket_slices(self, numel: int) -> List[Tuple[int, int]]:
         per = (numel + self.n_buckets - 1) // self.n_buckets
@@ -80,12 +84,19 @@ class GradSync:
         stream, running on the communicator's own stream); None when there is nothing to exchange."""
         if self.world == 1 or stop <= start:
             return None
+        if flat_grad.is_cuda and not self.device_native:
+            return ("host", flat_grad, start, stop)
         return dist.all_reduce(flat_grad[start:stop], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def wait_all(self, handles) -> float:
         """Make the current stream wait for the started reductions; returns the 1/world scale for Adam."""
         for h in handles:
-            if h is not None:
+            if isinstance(h, tuple):  # host-staged slice: D2H (ordered after every kernel enqueued so far), reduce, H2D
+                _, flat, a, b = h
+                t = flat[a:b].cpu()
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                flat[a:b].copy_(t)
+            elif h is not None:
                 h.wait()
         return 1.0 / self.world
 
@@ -93,11 +104,7 @@ class GradSync:
         """Returns the scale to apply to the reduced gradient (1/world)."""
         if self.world == 1:
             return 1.0
-        handles = [dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                   for a, b in self.bucket_slices(flat_grad.numel())]
-        for h in handles:
-            h.wait()
-        return 1.0 / self.world
+        return self.wait_all([self.reduce_slice_async(flat_grad, a, b) for a, b in self.bucket_slices(flat_grad.numel())])
 
 
 def backward_phase_slices(offsets: Sequence[int], numel: int, num_layers: int) -> List[Tuple[int, int]]:

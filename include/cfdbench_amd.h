@@ -43,7 +43,7 @@ const char* cfd_last_error(void);
  * LDS-weight mixing workgroup, 0 = the lane = mode kernel), "wgrad_wg" (workgroups the tiled spectral weight gradient
  * aims at), "fused_variant" (0 = adjoint mix and spectral weight gradient as two launches), "block_fuse" (0 = the 1x1
  * weight gradient of a FnoBlock as its own kernel), "general_b3" (0 = grids other than 64 x 64 on the exact-fp32 generic
- * transform kernels instead of the split-bf16 ones).  value -1 restores the built-in choice.  The environment variables
+ * transform kernels instead of the split-bf16 ones), "head_blocks" (workgroup cap of the projection-head kernels).  value -1 restores the built-in choice.  The environment variables
  * CFD_MIX_NWV / CFD_WGRAD_WG / CFD_FUSED_VARIANT / CFD_BLOCK_FUSE are read once per process, at the first launch.  Every
  * route computes the same function (the reference has no such switch: it has one ATen call per op).                */
 int cfd_tune_set(const char* name, int value);

@@ -56,6 +56,13 @@ inline float cfd_shfl_xor(float v, int mask) {
     return r;
 }
 
+inline float cfd_mfma_retire(const f32x4& last) { return last[3]; }
+
+inline float cfd_row_sum4(float v) {  // same association as the device form: (r0 + r1) + (r2 + r3) per lane & 15
+    const float s = v + cfd_shfl_xor(v, 16);
+    return s + cfd_shfl_xor(s, 32);
+}
+
 inline float cfd_wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += cfd_shfl_xor(v, m);
     return v;

@@ -84,6 +84,14 @@ def test_head(be, C, HW, act, which, ext):
     assert res["sums"] < 1e-5 and res["scores"] < 1e-5
 
 
+def test_head_several_tiles_per_workgroup(be):
+    """The head kernels' persistent loops (tile after tile per workgroup, staged planes / f'(a) handed from one tile to the
+    next): at small sizes every workgroup would get a single tile, so the workgroup count is capped through the knob."""
+    with K.tuned(be, head_blocks=2):
+        res = K.check_head(be, 3, 20, 192, True, "nmse", False)
+    _assert_all({k: v for k, v in res.items() if k not in ("sums", "scores")})
+
+
 def test_loss_and_adam(be):
     res = K.check_loss_and_adam(be)
     assert res["sums"] < 1e-5

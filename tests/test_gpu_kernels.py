@@ -96,6 +96,14 @@ def test_head(be, C, HW, act, which, ext):
     assert res["sums"] < 1e-5 and res["scores"] < 1e-5
 
 
+@pytest.mark.parametrize("cap", [1, 3, 16])
+def test_head_several_tiles_per_workgroup(be, cap):
+    """The head kernels' persistent loops (several tiles per workgroup: staged planes and f'(a) handed from tile to tile)."""
+    with K.tuned(be, head_blocks=cap):
+        res = K.check_head(be, 5, 20, 4096, True, "nmse", False)
+    _assert_all({k: v for k, v in res.items() if k not in ("sums", "scores")})
+
+
 def test_loss_and_adam(be):
     res = K.check_loss_and_adam(be, n=1_000_003)
     assert res["sums"] < 1e-5

@@ -83,9 +83,18 @@ def test_fno2d_forward_backward_vs_reference_golden(torch, golden_dir, name):
             err = O.rel_nmse(grads[k].grad.cpu().numpy(), g[key])
             assert err < 1e-8 and err < NORTH_STAR_TOL, (k, err)
         if key.startswith("gsum::") and key.endswith("::vals"):
+            # 32 sampled entries of the REFERENCE's fp32 gradient: its own round-off (sums over 32 768 pixels through four
+            # layers) is ~1e-7 on the small lifting-layer gradients, so this is a coarse check; the tight one follows
             k = key.split("::")[1]
             got = grads[k].grad.cpu().numpy().reshape(-1)[g[f"gsum::{k}::idx"]]
-            assert O.rel_nmse(got, g[key]) < 1e-7, k
+            assert O.rel_nmse(got, g[key]) < 1e-6, k
+    # every gradient entry against the fp64 oracle
+    p64 = {k: v.astype(np.complex128 if np.iscomplexobj(v) else np.float64) for k, v in params.items()}
+    b64 = {k: v.astype(np.float64) for k, v in batch.items()}
+    ref = O.fno_forward(p64, b64["inputs"], b64["case_params"], b64["mask"], b64["label"], L)
+    rg = O.fno_backward(p64, ref["cache"], O.loss_grad_wrt_preds(ref["cache"]["preds"], ref["cache"]["label"], "nmse"), L)
+    for k, prm in grads.items():
+        assert O.rel_nmse(prm.grad.cpu().numpy(), rg[k]) < 1e-8, k
 
 
 def test_forward_without_label_has_no_loss_and_3d_mask(torch):
