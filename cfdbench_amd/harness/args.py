@@ -77,7 +77,17 @@ class Args:
 
 
 def is_args_valid(args: Args) -> None:
-    """Validate argument values (src/args.py:372-378): asserts, like the reference; the model name is left to
-    ``init_model``."""
+    """Validate argument values (src/args.py:372-378): the reference's two asserts (the model name is left to
+    ``init_model``, like there), then this harness's own additions -- a flag combination that is not implemented is an
+    error, never silently ignored.  Called by every ``main`` right after parsing."""
     assert any(key in args.data_name for key in ["poiseuille", "cavity", "karman", "tube", "dam", "cylinder"])
     assert args.batch_size > 0
+    assert args.eval_batch_size > 0 and args.gradient_accumulation_steps >= 1
+    assert args.lr_scheduler in ("step", "plateau", "cosine"), args.lr_scheduler
+    assert args.dtype in ("fp32", "bf16"), args.dtype
+    if args.dtype == "bf16":  # bf16 activation STORAGE exists for FNO inference only (DESIGN.md section 7)
+        assert args.model == "fno", "--dtype bf16: FNO inference (test_multistep) only; the trainers reject it"
+    if args.fused:
+        assert args.model == "fno", "--fused 1 is the FnoTrainEngine path"
+        assert args.gradient_accumulation_steps == 1, "--fused 1 runs one fused optimiser step per batch"
+    assert args.unet_insert_case_params_at in ("input", "hidden")

@@ -22,7 +22,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
-from .args import Args
+from .args import Args, is_args_valid
 from .autoregressive import init_model
 from .common import dump_json, get_output_dir, load_best_ckpt
 
@@ -112,6 +112,7 @@ def prepare_cases(test_data, infer_steps: int, device="cuda"):
 def main(argv=None):
     from .data import get_auto_dataset
     args = Args().parse_args(argv)
+    is_args_valid(args)
     print(args)
     _, _, test_data = get_auto_dataset(data_dir=Path(args.data_dir), data_name=args.data_name, delta_time=args.delta_time,
                                        norm_props=bool(args.norm_props), norm_bc=bool(args.norm_bc), load_splits=["test"])

@@ -27,7 +27,7 @@ from ..models.base_model import CfdModel
 from ..models.deeponet import DeepONet
 from ..models.ffn import FfnModel
 from ..models.loss import loss_name_to_fn
-from .args import Args
+from .args import Args, is_args_valid
 from .common import dump_json, get_output_dir, load_best_ckpt, plot_loss, plot_predictions
 from .dist_util import (average_buffers, broadcast_model_state, check_resume_state, init_distributed, rank_world,
                         shard_indices)
@@ -221,6 +221,9 @@ def get_dataset(data_dir: Path, data_name: str, norm_props: bool, norm_bc: bool)
 
 def main(argv=None):
     args = Args().parse_args(argv)
+    is_args_valid(args)
+    if args.dtype != "fp32":
+        raise NotImplementedError("--dtype bf16 is an inference option (test_multistep); training stores fp32")
     rank, world = init_distributed()  # one process per GPU under torch.distributed.run; (0, 1) otherwise
     output_dir = get_output_dir(args)
     if rank == 0:

@@ -30,7 +30,7 @@ from torch.utils.data import DataLoader, Subset
 from ..engine import FnoTrainEngine, sync_gradients
 from ..models.base_model import AutoCfdModel
 from ..models.fno.fno2d import Fno2d
-from .args import Args
+from .args import Args, is_args_valid
 from .autoregressive import init_model
 from .common import dump_json, get_output_dir, load_best_ckpt, plot, plot_loss, plot_predictions
 from .schedule import EarlyStopping, LrSchedule
@@ -278,6 +278,9 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
 def main(argv=None):
     from .data import get_auto_dataset
     args = Args().parse_args(argv)
+    is_args_valid(args)
+    if args.dtype != "fp32":
+        raise NotImplementedError("--dtype bf16 is an inference option (test_multistep); training stores fp32")
     rank, world = init_distributed()  # one process per GPU under torch.distributed.run; (0, 1) otherwise
     output_dir = get_output_dir(args, is_auto=True)
     if rank == 0:

@@ -40,6 +40,21 @@ def test_cli_parsing_data_alias_and_save(tmp_path):
         Args().parse_args(["--dat", "x"])  # no prefix matching: --data_name / --data_dir would be ambiguous
 
 
+def test_is_args_valid_rejects_unimplemented_combinations():
+    """src/args.py:372-378 plus this harness's own flags: nothing unimplemented is silently ignored."""
+    from cfdbench_amd.harness.args import is_args_valid
+    is_args_valid(Args(model="fno", data_name="cavity_prop_bc_geo"))
+    is_args_valid(Args(model="fno", data_name="dam_prop", dtype="bf16"))
+    is_args_valid(Args(model="fno", data_name="dam_prop", fused=1, lr_scheduler="cosine"))
+    for bad in (dict(data_name="lid_driven"), dict(batch_size=0), dict(lr_scheduler="linear"), dict(dtype="fp16"),
+                dict(model="unet", dtype="bf16"), dict(model="unet", fused=1), dict(model="fno", fused=1, gradient_accumulation_steps=2),
+                dict(unet_insert_case_params_at="output"), dict(gradient_accumulation_steps=0)):
+        kw = dict(model="fno", data_name="cavity_prop_bc_geo")
+        kw.update(bad)
+        with pytest.raises(AssertionError):
+            is_args_valid(Args(**kw))
+
+
 def test_output_dir_scheme():
     a = Args(model="fno", data_name="cavity_bc", lr=0.001, fno_hidden_dim=20)
     assert str(get_output_dir(a, is_auto=True)) == "result/auto/cavity_bc/dt0.1/fno/lr0.001_d4_h20_m112_m212"
