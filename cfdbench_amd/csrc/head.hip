@@ -35,31 +35,36 @@ static int head_bwd_blocks(int B, int HW) {
 }
 
 // Input tile in the K = 32 operand layout of v_mfma_f32_16x16x32_bf16: lane group q owns channels CQ q .. CQ q + CQ - 1 with
-// CQ = ceil(C / 4) (k-slot v <-> channel CQ q + v for v < CQ, zero otherwise) of the lane's four pixels px .. px+3.  Dealing
+// CQ >= ceil(C / 4) a compile-time 2 / 5 / 8 (k-slot v <-> channel CQ q + v for v < CQ, zero otherwise) of the lane's four
+// pixels px .. px+3.  Dealing
 // the channels evenly over the four lane groups (5 each at C = 20) instead of 8 per group keeps the GELU-on-load work at
 // C values per pixel: with 8 per group the groups q = 2, 3 evaluated GELU on 12 zero slots (37 % of the input GELUs, which
 // are half of all GELUs of the forward head).
-template <bool VEC4, bool ACT, typename TA = float>
-__device__ __forceinline__ void head_load_h8(const TA* __restrict__ a, int b, int C, int CQ, int HW, int px, int q,
-                                             float (&h)[8][4]) {
+template <int CQ, bool VEC4, typename TA = float>
+__device__ __forceinline__ void head_load_raw(const TA* __restrict__ a, int b, int C, int HW, int px, int q,
+                                              float (&h)[CQ][4]) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        if (c >= CQ) {  // wave-uniform: no load, no GELU
-            h[c][0] = h[c][1] = h[c][2] = h[c][3] = 0.f;
-            continue;
-        }
+    for (int c = 0; c < CQ; ++c) {
+        h[c][0] = h[c][1] = h[c][2] = h[c][3] = 0.f;
+        if (b < 0) continue;  // wave-uniform: past the end of the work, no load
         const int i = CQ * q + c;
         const TA* src = a + ((size_t)b * C + i) * HW + px;
         if constexpr (VEC4 && sizeof(TA) == 4) {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < C && px < HW) t = *reinterpret_cast<const float4*>(src);
-            h[c][0] = t.x; h[c][1] = t.y; h[c][2] = t.z; h[c][3] = t.w;
+            if (i < C && px < HW) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                h[c][0] = t.x; h[c][1] = t.y; h[c][2] = t.z; h[c][3] = t.w;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) h[c][j] = (i < C && px + j < HW) ? cfd_ld(src + j) : 0.f;
         }
-        if constexpr (ACT) cfd_gelu4(h[c][0], h[c][1], h[c][2], h[c][3]);
     }
+}
+
+template <int CQ>
+__device__ __forceinline__ void head_act(float (&h)[CQ][4]) {
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) cfd_gelu4(h[c][0], h[c][1], h[c][2], h[c][3]);
 }
 
 // split-bf16 A-operand fragments of fc1 for z = W1 h:  frag[mt][lane=(q,i)][v] = w1[16mt+i][CQ q + v]  (v < CQ)
@@ -76,8 +81,8 @@ __device__ __forceinline__ void head_build_w1f(bf16x8* s_hi, bf16x8* s_lo, const
     }
 }
 
-template <bool VEC4, bool ACT, typename TA = float>
-__global__ __launch_bounds__(256, 2) void k_head_fwd(const TA* __restrict__ a, const float* __restrict__ mask,
+template <int CQ, bool VEC4, bool ACT, typename TA = float>
+__global__ __launch_bounds__(256, 3) void k_head_fwd(const TA* __restrict__ a, const float* __restrict__ mask,
                                                   const float* __restrict__ label, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                                   const float* __restrict__ b2, float* __restrict__ preds,
@@ -86,7 +91,6 @@ __global__ __launch_bounds__(256, 2) void k_head_fwd(const TA* __restrict__ a, c
     __shared__ __attribute__((aligned(16))) float s_b1[HEAD_HD];
     __shared__ __attribute__((aligned(16))) cfd_f2 s_w2[HEAD_HD];  // (w2[0][jh], w2[1][jh]) pairs: one packed FMA updates both outputs
     __shared__ float s_red[12];
-    const int CQ = (C + 3) / 4;  // channels per lane group of the K = 32 operand
     head_build_w1f(s_w1hi, s_w1lo, w1, C, CQ);
     for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x) s_b1[i] = b1[i];
     for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x) s_w2[i] = cfd_f2{w2[i], Co > 1 ? w2[HEAD_HD + i] : 0.f};
@@ -96,12 +100,48 @@ __global__ __launch_bounds__(256, 2) void k_head_fwd(const TA* __restrict__ a, c
     const int q = lane >> 4, n = lane & 15;
     float lsq = 0.f, labs = 0.f, ll2 = 0.f;
     const int tpb = (HW + 63) / 64;
-    const long total = (long)B * tpb;
-    for (long tile = (long)blockIdx.x * 4 + wave; tile < total; tile += (long)gridDim.x * 4) {
-        const int b = (int)(tile / tpb);
-        const int px = (int)(tile - (long)b * tpb) * 64 + 4 * n;
-        float h[8][4];
-        head_load_h8<VEC4, ACT, TA>(a, b, C, CQ, HW, px, q, h);
+    const int total = B * tpb;  // < 2^30 (checked by the launcher)
+    const int stride = (int)gridDim.x * 4;
+    // a wave's tiles: the raw activations, mask and label of tile k+1 are in flight while tile k is processed (each wave
+    // works alone on its tiles, so a load that is waited for right after its issue costs the wave a whole memory latency)
+    int tile = (int)blockIdx.x * 4 + wave;
+    int b = -1, px = 0;
+    auto locate = [&](int t, int& bb, int& pp) {
+        bb = -1;
+        pp = 0;
+        if (t < total) {
+            const unsigned ub = (unsigned)t / (unsigned)tpb;
+            bb = (int)ub;
+            pp = (int)((unsigned)t - ub * (unsigned)tpb) * 64 + 4 * n;
+        }
+    };
+    float hn[CQ][4];  // raw activations of the next tile
+    float mkn[4], lbn[4];  // mask / label (channel q) of the next tile's four pixels
+    auto fetch_io = [&](int bb, int pp) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = bb >= 0 && pp + j < HW;
+            mkn[j] = (ok && mask) ? mask[(size_t)bb * HW + pp + j] : 1.f;
+            lbn[j] = (ok && label && q < Co) ? label[((size_t)bb * Co + q) * HW + pp + j] : 0.f;
+        }
+    };
+    locate(tile, b, px);
+    head_load_raw<CQ, VEC4, TA>(a, b, C, HW, px, q, hn);
+    fetch_io(b, px);
+    for (; tile < total; tile += stride) {
+        float h[CQ][4], mk[4], lb[4];
+#pragma unroll
+        for (int c = 0; c < CQ; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[c][j] = hn[c][j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mk[j] = mkn[j]; lb[j] = lbn[j]; }
+        const int bc = b, pxc = px;
+        locate(tile + stride, b, px);
+        head_load_raw<CQ, VEC4, TA>(a, b, C, HW, px, q, hn);
+        fetch_io(b, px);
+        cfd_sched_fence();  // the prefetch stays here, ahead of this tile's arithmetic
+        if constexpr (ACT) head_act<CQ>(h);
         // The 4 pixel phases j run in a ROLLED loop (one 16-pixel sub-tile per trip keeps the live set at one
         // z tile); the phase being processed always sits in h[c][0] / lands in out*[3], registers rotate each trip.
         float out0[4] = {0.f, 0.f, 0.f, 0.f}, out1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -110,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void k_head_fwd(const TA* __restrict__ a, c
             const int lo = cfd_opaque(lane), q4 = 4 * cfd_opaque(q);  // keep the LDS table reads inside the loop (q4: a visible multiple of 4)
             float xk[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) xk[c] = h[c][0];
+            for (int c = 0; c < 8; ++c) xk[c] = c < CQ ? h[c < CQ ? c : 0][0] : 0.f;
             const CfdSplit8 bs = cfd_split8(xk);
             f32x4 z[HEAD_MT];
 #pragma unroll
@@ -142,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void k_head_fwd(const TA* __restrict__ a, c
             out0[0] = out0[1]; out0[1] = out0[2]; out0[2] = out0[3]; out0[3] = o0;
             out1[0] = out1[1]; out1[1] = out1[2]; out1[2] = out1[3]; out1[3] = o1;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { h[c][0] = h[c][1]; h[c][1] = h[c][2]; h[c][2] = h[c][3]; }
+            for (int c = 0; c < CQ; ++c) { h[c][0] = h[c][1]; h[c][1] = h[c][2]; h[c][2] = h[c][3]; }
         }
         if (q < Co) {  // lane group q stores output channel q
             const int c = q;
@@ -150,25 +190,23 @@ __global__ __launch_bounds__(256, 2) void k_head_fwd(const TA* __restrict__ a, c
             float pv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int pix = px + j;
-                const bool ok = pix < HW;
-                const float mk = (ok && mask) ? mask[(size_t)b * HW + pix] : 1.f;
-                pv[j] = ((c == 0 ? out0[j] : out1[j]) + bias) * mk;  // fno2d.py:233
+                const bool ok = pxc + j < HW;
+                pv[j] = ((c == 0 ? out0[j] : out1[j]) + bias) * mk[j];  // fno2d.py:233
                 if (label && ok) {
-                    const float lab = label[((size_t)b * Co + c) * HW + pix] * mk;  // fno2d.py:236
+                    const float lab = lb[j] * mk[j];  // fno2d.py:236
                     const float d = pv[j] - lab;
                     lsq = fmaf(d, d, lsq);
                     labs += fabsf(d);
                     ll2 = fmaf(lab, lab, ll2);
                 }
             }
-            float* dst = preds + ((size_t)b * Co + c) * HW + px;
+            float* dst = preds + ((size_t)bc * Co + c) * HW + pxc;
             if constexpr (VEC4) {
-                if (px < HW) *reinterpret_cast<float4*>(dst) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                if (pxc < HW) *reinterpret_cast<float4*>(dst) = make_float4(pv[0], pv[1], pv[2], pv[3]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (px + j < HW) dst[j] = pv[j];
+                    if (pxc + j < HW) dst[j] = pv[j];
             }
         }
     }
@@ -206,6 +244,8 @@ static int head_check(const char* fn, int B, int C, int Hd, int Co, int HW) {
     CFD_REQUIRE(B >= 0 && C >= 1 && HW >= 1, CFD_ERR_INVALID_ARG, "%s: bad sizes", fn);
     CFD_REQUIRE(Hd == HEAD_HD, CFD_ERR_UNSUPPORTED, "%s: head width %d unsupported (the reference hard-codes 128, fno2d.py:175)", fn, Hd);
     CFD_REQUIRE(C <= 32, CFD_ERR_UNSUPPORTED, "%s: hidden=%d (max 32) unsupported", fn, C);
+    CFD_REQUIRE((long)B * ((HW + 63) / 64) < (1L << 30), CFD_ERR_UNSUPPORTED, "%s: B * ceil(HW / 64) = %ld tiles (max 2^30)", fn,
+                (long)B * ((HW + 63) / 64));
     CFD_REQUIRE(Co >= 1 && Co <= 2, CFD_ERR_UNSUPPORTED, "%s: out_chan=%d (max 2) unsupported", fn, Co);
     return CFD_OK;
 }
@@ -230,23 +270,27 @@ int cfd_int_fno_head_fwd(const void* a_, const float* mask, const float* label, 
     const bool v4 = dt == CFD_DT_F32 && HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)preds % 16) == 0;
     {
     CFD_PROF_W("k_head_fwd", st, B * HW * ((double)cfd_dt_size(dt) * C + 4.0 * (1 + (label ? 2 : 1) * Co)), 2.0 * B * HW * (double)HEAD_HD * (C + Co));
-    if (dt == CFD_DT_BF16) {
-        if (act_in)
-            hipLaunchKernelGGL((k_head_fwd<false, true, __bf16>), dim3(blocks), dim3(256), 0, st, (const __bf16*)a_, mask, label, w1, b1,
-                               w2, b2, preds, part, B, C, Co, HW);
-        else
-            hipLaunchKernelGGL((k_head_fwd<false, false, __bf16>), dim3(blocks), dim3(256), 0, st, (const __bf16*)a_, mask, label, w1, b1,
-                               w2, b2, preds, part, B, C, Co, HW);
-    } else {
-#define CFD_HF(V_, A_)                                                                                      \
-    hipLaunchKernelGGL((k_head_fwd<V_, A_>), dim3(blocks), dim3(256), 0, st, a, mask, label, w1, b1, w2, b2, \
-                       preds, part, B, C, Co, HW)
-    if (v4 && act_in) CFD_HF(true, true);
-    else if (v4) CFD_HF(true, false);
-    else if (act_in) CFD_HF(false, true);
-    else CFD_HF(false, false);
+#define CFD_HF(Q_, V_, A_, T_)                                                                                            \
+    hipLaunchKernelGGL((k_head_fwd<Q_, V_, A_, T_>), dim3(blocks), dim3(256), 0, st, (const T_*)a_, mask, label, w1, b1, w2, \
+                       b2, preds, part, B, C, Co, HW)
+#define CFD_HF_Q(Q_)                                         \
+    do {                                                     \
+        if (dt == CFD_DT_BF16) {                             \
+            if (act_in) CFD_HF(Q_, false, true, __bf16);     \
+            else CFD_HF(Q_, false, false, __bf16);           \
+        } else if (v4) {                                     \
+            if (act_in) CFD_HF(Q_, true, true, float);       \
+            else CFD_HF(Q_, true, false, float);             \
+        } else {                                             \
+            if (act_in) CFD_HF(Q_, false, true, float);      \
+            else CFD_HF(Q_, false, false, float);            \
+        }                                                    \
+    } while (0)
+    if (C <= 8) CFD_HF_Q(2);  // channels per lane group of the K = 32 operand
+    else if (C <= 20) CFD_HF_Q(5);
+    else CFD_HF_Q(8);
+#undef CFD_HF_Q
 #undef CFD_HF
-    }
     }
     CFD_LAUNCH_CHECK("cfd_fno_head_fwd");
     if (label) {
@@ -293,7 +337,8 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     __shared__ __attribute__((aligned(16))) __bf16 s_ht[2][2][16 * MU * LDT];  // [buffer][hi/lo][channel][column]
     __shared__ __attribute__((aligned(16))) __bf16 s_x[4][2][32 * LDX];        // [wave][hi/lo][hidden][32 columns]
     __shared__ float4 s_red[4 * CP * 16];  // [wave][channel][16 x float4 = 64 pixels] partial d/dh
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ cfd_f2 s_gr[2][64];         // [buffer][column] upstream gradient on the raw head output, both channels
+    const int lane = threadIdx.x & 63, wave = cfd_uniform(threadIdx.x >> 6);
     const int q = lane >> 4, n = lane & 15;
     for (int i = threadIdx.x; i < 2 * 2 * 64 * LDK; i += blockDim.x) (&s_hk[0][0][0])[i] = (__bf16)0.f;
     for (int i = threadIdx.x; i < 2 * 2 * 16 * MU * LDT; i += blockDim.x) (&s_ht[0][0][0])[i] = (__bf16)0.f;
@@ -344,20 +389,70 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     }
     float gb2a0 = 0.f, gb2a1 = 0.f;
     const int tpb = (HW + 63) / 64;
-    const long total = (long)B * tpb;
+    const int total = B * tpb;  // < 2^30 (checked by the launcher)
+    // tile -> (batch entry, first pixel); b = -1 past the end of the work.  One division per trip of the tile loop: the
+    // coordinates of the tile being processed / staged / fetched are carried in t0 / t1 / t2.
+    struct TileAt { int b, px0; };
+    auto locate = [&](int tile) -> TileAt {
+        if (tile >= total) return TileAt{-1, 0};
+        const unsigned ub = (unsigned)tile / (unsigned)tpb;
+        return TileAt{(int)ub, (int)((unsigned)tile - ub * (unsigned)tpb) * 64};
+    };
     // ---- cooperative staging: element e = (channel e/16, pixel quad e%16) of a tile ----
     float4 raw[NST];
     float4 gp_cur[NST], gp_next[NST];  // f'(a) of the tile being processed / of the tile just staged (ACT only): the GELU terms
                                        // are evaluated ONCE per activation value, for f(a) at staging and f'(a) in the epilogue
-    auto fetch = [&](long tile) {  // raw activations of `tile` -> registers (zeros past the end of the work / image)
+    // upstream gradient of the tile's 64 pixels: wave 1 owns it (lane = pixel), fetched / staged with the activations.
+    // (The first version had every lane of every wave load mask / preds / label for its four pixels at the top of the
+    // tile and wait for them: 16x redundant, ~700 instructions and one exposed memory latency per tile.)
+    float rmk = 0.f, rpr[2] = {0.f, 0.f}, rlb[2] = {0.f, 0.f}, rge[2] = {0.f, 0.f};
+    bool rok = false;
+    auto fetch_gr = [&](const TileAt t) {
+        if (wave != 1) return;
+        const int pix = t.px0 + lane;
+        rok = t.b >= 0 && pix < HW;
+        rmk = 1.f;
+        rpr[0] = rpr[1] = rlb[0] = rlb[1] = rge[0] = rge[1] = 0.f;
+        if (rok) {
+            if (mask) rmk = mask[(size_t)t.b * HW + pix];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (c < Co) {
+                    const size_t off = ((size_t)t.b * Co + c) * HW + pix;
+                    if (gext) rge[c] = gext[off];
+                    if (label) { rpr[c] = preds[off]; rlb[c] = label[off]; }
+                }
+        }
+    };
+    auto stage_gr = [&](int buf) {
+        if (wave != 1) return;
+        float g[2] = {0.f, 0.f};
+        if (rok) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (c < Co) {
+                    float gp = rge[c];
+                    if (label) {
+                        const float d = rpr[c] - rlb[c] * rmk;
+                        const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                        gp += c0 * 2.f * d + c1 * sg;
+                    }
+                    g[c] = gp * rmk;
+                }
+        }
+        gb2a0 += g[0];
+        gb2a1 += g[1];
+        s_gr[buf][16 * (lane & 3) + (lane >> 2)] = cfd_f2{g[0], g[1]};  // pixel 4n + j -> column 16j + n
+    };
+    auto fetch = [&](const TileAt t) {  // raw activations of the tile -> registers (zeros past the end of the work / image)
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int e = threadIdx.x + 256 * k;
             const int i = e >> 4, n4 = e & 15;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tile < total && i < C) {
-                const int b = (int)(tile / tpb);
-                const int p4 = (int)(tile - (long)b * tpb) * 64 + 4 * n4;
+            if (t.b >= 0 && i < C) {
+                const int b = t.b;
+                const int p4 = t.px0 + 4 * n4;
                 const float* src = a + ((size_t)b * C + i) * HW + p4;
                 if constexpr (VEC4) {
                     if (p4 < HW) v = *reinterpret_cast<const float4*>(src);
@@ -403,48 +498,23 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
         }
     };
     __syncthreads();  // planes zeroed
-    fetch(blockIdx.x);
+    TileAt t0 = locate((int)blockIdx.x), t1 = locate((int)blockIdx.x + (int)gridDim.x);
+    fetch(t0);
+    fetch_gr(t0);
     stage(0);
+    stage_gr(0);
 #pragma unroll
     for (int k = 0; k < NST; ++k) gp_cur[k] = gp_next[k];
-    fetch((long)blockIdx.x + gridDim.x);
+    fetch(t1);
+    fetch_gr(t1);
     __syncthreads();
     int buf = 0;
-    for (long tile = blockIdx.x; tile < total; tile += gridDim.x, buf ^= 1) {  // all four waves walk the same tiles
-        const int b = (int)(tile / tpb);
-        const int px0 = (int)(tile - (long)b * tpb) * 64;
-        const int px = px0 + 4 * n;
-        // upstream gradient on the raw head output for this lane's 4 pixels (same for every q)
-        float gr0[4], gr1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pix = px + j;
-            gr0[j] = 0.f;
-            gr1[j] = 0.f;
-            if (pix < HW) {
-                const float mk = mask ? mask[(size_t)b * HW + pix] : 1.f;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    if (c < Co) {
-                        const size_t off = ((size_t)b * Co + c) * HW + pix;
-                        float gp = gext ? gext[off] : 0.f;
-                        if (label) {
-                            const float d = preds[off] - label[off] * mk;
-                            const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-                            gp += c0 * 2.f * d + c1 * sg;
-                        }
-                        if (c == 0) gr0[j] = gp * mk; else gr1[j] = gp * mk;
-                    }
-                }
-            }
-        }
-        if (wave == 0 && q == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { gb2a0 += gr0[j]; gb2a1 += gr1[j]; }
-        }
-        // The 4 pixel phases run in a ROLLED loop: the phase being processed sits in gr*[0], registers rotate each
-        // trip, which keeps the live set at one phase.
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x, buf ^= 1) {  // all four waves walk the same tiles
+        const int b = t0.b;
+        const int px0 = t0.px0;
+        // The 4 pixel phases run in a ROLLED loop, which keeps the live set at one phase.
         float* s_redf = reinterpret_cast<float*>(s_red);
+        const cfd_f2* grp = s_gr[buf];
         const __bf16* hk_hi = s_hk[buf][0];
         const __bf16* hk_lo = s_hk[buf][1];
         const __bf16* ht_hi = s_ht[buf][0];
@@ -466,7 +536,8 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
             for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].hi, hhi, z[t]);
             // 2. a1 = gelu(z) feeds the fc2 weight gradient; gz = (W2^T graw) * gelu'(z), k-slot 4t + r
             float gzv[8];
-            const cfd_f2 g0 = (cfd_f2)(gr0[0]), g1 = (cfd_f2)(gr1[0]);
+            const cfd_f2 grj = grp[col];
+            const cfd_f2 g0 = (cfd_f2)(grj.x), g1 = (cfd_f2)(grj.y);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -538,13 +609,14 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                     for (int mu = 0; mu < MU; ++mu) aw1[t][mu] = cfd_mfma16x16x32_bf16(ah[t], bh[mu], aw1[t][mu]);
                 cfd_wave_lds_sync();
             }
-            gr0[0] = gr0[1]; gr0[1] = gr0[2]; gr0[2] = gr0[3];
-            gr1[0] = gr1[1]; gr1[1] = gr1[2]; gr1[2] = gr1[3];
         }
         __syncthreads();
         // next tile's input planes (other buffer; its raw loads were issued one tile ago), then loads two tiles ahead
         stage(buf ^ 1);
-        fetch(tile + 2 * (long)gridDim.x);
+        stage_gr(buf ^ 1);
+        const TileAt t2 = locate(tile + 2 * (int)gridDim.x);
+        fetch(t2);
+        fetch_gr(t2);
         // ga[b][i][px0 .. px0+63] = (sum over the four hidden slices) * f'(a)
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
@@ -581,6 +653,8 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
         }
 #pragma unroll
         for (int k = 0; k < NST; ++k) gp_cur[k] = gp_next[k];
+        t0 = t1;
+        t1 = t2;
         __syncthreads();
     }
     // ---- this block's partial parameter gradients: [gw1 128*C | gb1 128 | gw2 Co*128 | gb2 Co] ----
@@ -608,7 +682,7 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                 if (Co > 1) dst[(size_t)(o_gw2 + HEAD_HD + jh) * nb] = sb;
             }
         }
-    if (wave == 0) {
+    if (wave == 1) {  // the wave that staged the upstream gradients summed them (tiles past the end contributed zeros)
         gb2a0 = cfd_wave_sum(gb2a0);
         gb2a1 = cfd_wave_sum(gb2a1);
         if (lane == 0) {
