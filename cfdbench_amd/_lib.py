@@ -13,7 +13,9 @@ from typing import Dict, Tuple
 
 from ._capi import CApi, CfdError
 
-_LIB_PATH = Path(__file__).resolve().parent / "_C" / "libcfdbench_amd.so"
+# CFDBENCH_AMD_LIB: explicit path of another build of the same library (kernel experiments: tools/build_variant.sh); there is
+# still no fallback -- a path that does not exist fails exactly like a missing default build
+_LIB_PATH = Path(os.environ.get("CFDBENCH_AMD_LIB") or Path(__file__).resolve().parent / "_C" / "libcfdbench_amd.so")
 _lock = threading.Lock()
 _api: CApi | None = None
 _plans: Dict[Tuple[int, int, int, int, int], int] = {}

@@ -183,14 +183,29 @@ __device__ __forceinline__ float cfd_gelu_grad(float x) {
 struct CfdSplit8 {
     bf16x8 hi, lo;
 };
+// hi = bf16(x), lo = bf16(x - hi), two values per v_cvt_pk_bf16_f32: the float value of hi is its bit pattern shifted
+// into the upper half, so a pair costs 2 conversions + 1 shift + 1 mask + 2 subtractions (written element by element the
+// compiler converted every value twice, once for the packed operand and once for 16-bit stores: 40 instead of 24 VALU
+// instructions per 8 values).
+typedef __bf16 cfd_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned cfd_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned cfd_pack_bf16(float a, float b) {
+    const cfd_bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
 __device__ __forceinline__ CfdSplit8 cfd_split8(const float (&x)[8]) {
-    CfdSplit8 s;
+    cfd_u32x4 h, l;
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
-        const __bf16 h = (__bf16)x[v];
-        s.hi[v] = h;
-        s.lo[v] = (__bf16)(x[v] - (float)h);
+    for (int k = 0; k < 4; ++k) {
+        const unsigned hk = cfd_pack_bf16(x[2 * k], x[2 * k + 1]);
+        const float h0 = __builtin_bit_cast(float, hk << 16), h1 = __builtin_bit_cast(float, hk & 0xffff0000u);
+        // opaque: a later 16-bit element extraction reads these packed words instead of re-converting the float
+        h[k] = (unsigned)cfd_opaque((int)hk);
+        l[k] = (unsigned)cfd_opaque((int)cfd_pack_bf16(x[2 * k] - h0, x[2 * k + 1] - h1));
     }
+    CfdSplit8 s;
+    s.hi = __builtin_bit_cast(bf16x8, h);
+    s.lo = __builtin_bit_cast(bf16x8, l);
     return s;
 }
 // D += A*B with both operands split

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--json", type=str, default="")
+    ap.add_argument("--dump-out", type=int, default=0, help="print the first N int64 words of the output tensor after one call of --only (kernel timestamp experiments)")
     ap.add_argument("--tune", type=str, default="", help="dispatch knobs, e.g. general_b3=0,fused_variant=0 (cfd_tune_set)")
     args = ap.parse_args()
     api = _lib.api()
@@ -126,6 +127,9 @@ def main():
             rows[name] = dict(us=round(us, 2), gbs=round(nbytes / us / 1e3, 1), frac_hbm=round(nbytes / us / 1e3 / 8000, 3))
             print(f"{name:18s} {us:9.2f} us   {nbytes / 1e6:8.1f} MB  {nbytes / us / 1e3:8.1f} GB/s  ({nbytes / us / 1e3 / 80:5.1f}% of 8 TB/s)",
                   flush=True)
+            if args.dump_out:
+                words = (preds if name.startswith('head_fwd') else out).reshape(-1)[:2 * args.dump_out].view(torch.int64).cpu().tolist()
+                print("dump:", " ".join(str(w) for w in words), flush=True)
         except Exception as e:  # noqa: BLE001
             print(f"{name:18s} FAILED: {e}", flush=True)
     if args.json:
