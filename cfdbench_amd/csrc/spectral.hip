@@ -1402,6 +1402,7 @@ __device__ __forceinline__ void idft_tile_b3(const IdftSplitA& sa, const bf16x8*
 #define CFD_B3_TABV ((2 * 4 + 2 * 4) * 64)  // 16-byte vectors of the split tables at T = 4, NJ = 4
 
 #define CFD_BLK_ZS 577  // floats of one staged mode vector: 2*M (m1 = m2 = 12) + the zero slot
+#define CFD_KB_ZS 580   // the same in k_block, rounded up to whole float4s (16-byte LDS stores)
 
 template <int V>
 struct CfdParity { static constexpr int value = V; };
@@ -1858,9 +1859,18 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     }
     constexpr int W = 64, NJ = 4;
     constexpr int WS = DPW <= 4 ? 4 : 8;              // floats per weight-table entry
+#ifdef CFD_BDIAG  // timing experiments only (tools/build_variant.sh): in-kernel timestamps of workgroup 0 / the last one
+    long long ts[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ts[k] = 0;
+    ts[0] = __builtin_readcyclecounter();
+#define CFD_BTS(k_) do { cfd_sched_fence(); ts[k_] = __builtin_readcyclecounter(); cfd_sched_fence(); } while (0)
+#else
+#define CFD_BTS(k_) do { } while (0)
+#endif
     __shared__ float4 s_src[2 * NW * 16 * 16];        // [buf][channel in chunk][row][float4 column]
     __shared__ bf16x8 s_tab3[CFD_B3_TABV];            // split-bf16 inverse tables: ta3 of every tile (T <= 4) | tb3
-    __shared__ float s_z[NW * DPW * CFD_BLK_ZS];      // kept modes of this wave's destination channels
+    __shared__ float s_z[NW * DPW * CFD_KB_ZS];      // kept modes of this wave's destination channels
     __shared__ float4 s_w[NW * NW * NCH * (WS / 4)];  // [wave][source channel] -> weights of the wave's DPW channels
     static_assert(NW * NCH <= 64, "one lane per source channel fills the weight table");
     static_assert(DPW <= 8, "weight-table entry holds at most 8 destination channels");
@@ -1891,27 +1901,61 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     };
     fetch(0, R[0]);
     fetch(1, R[1]);
-    // once per batch entry: operator tables, this wave's mixing weights and kept modes
-    for (int i = threadIdx.x; i < (2 * T + 2 * NJ) * 64; i += blockDim.x) s_tab3[i] = tabs3[i];
-    if (lane < NW * NCH) {
-        float wl[WS];
+    // once per batch entry: operator tables, this wave's mixing weights and kept modes.  ALL the global loads are issued
+    // before the first LDS store (the first version copied table, weights and each channel's modes one after the other:
+    // three to eleven dependent memory latencies, 13-18 k cycles = 13 % of the workgroup's life -- tools: CFD_BDIAG)
+    constexpr int NTV = (2 * 4 + 2 * NJ) * 64;                 // table vectors at T = 4 (T <= 4 is checked by the launcher)
+    constexpr int TPT = (NTV + 64 * NW - 1) / (64 * NW);       // per thread
+    const int ntab = (2 * T + 2 * NJ) * 64;
+    bf16x8 tv[TPT];
 #pragma unroll
-        for (int dd = 0; dd < WS; ++dd) {
-            const int d = wave + dd * NW;
-            wl[dd] = (dd < DPW && d < Cd && lane < Cs) ? (TRANS ? w[(size_t)lane * Cd + d] : w[(size_t)d * Cs + lane]) : 0.f;
-        }
+    for (int k = 0; k < TPT; ++k) {
+        const int i = threadIdx.x + k * 64 * NW;
+        tv[k] = tabs3[i < ntab ? i : 0];
+    }
+    float wl[WS];
 #pragma unroll
-        for (int h = 0; h < WS / 4; ++h)
-            s_w[(wave * (NW * NCH) + lane) * (WS / 4) + h] = make_float4(wl[4 * h], wl[4 * h + 1], wl[4 * h + 2], wl[4 * h + 3]);
+    for (int dd = 0; dd < WS; ++dd) {
+        const int d = wave + dd * NW;
+        wl[dd] = (lane < NW * NCH && dd < DPW && d < Cd && lane < Cs) ? (TRANS ? w[(size_t)lane * Cd + d] : w[(size_t)d * Cs + lane]) : 0.f;
     }
     float bv[DPW];
+    constexpr int ZV = (CFD_KB_ZS - 1 + 255) / 256;  // float4 rounds per channel (M2 <= CFD_KB_ZS - 1, a multiple of 4)
+    float4 zv[DPW][ZV];
 #pragma unroll
     for (int dd = 0; dd < DPW; ++dd) {
         const int d = wave + dd * NW;
         bv[dd] = (bias && d < Cd) ? bias[d] : 0.f;
-        if (d < Cd) idft_stage_z(z + ((size_t)b * Cd + d) * M2, s_z + (wave * DPW + dd) * CFD_BLK_ZS, M2, lane);
+        const float4* zi = reinterpret_cast<const float4*>(z + ((size_t)b * Cd + (d < Cd ? d : 0)) * M2);
+#pragma unroll
+        for (int k = 0; k < ZV; ++k) {
+            const int i = lane + 64 * k;
+            zv[dd][k] = zi[4 * i < M2 ? i : 0];
+        }
     }
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+        const int i = threadIdx.x + k * 64 * NW;
+        if (i < ntab) s_tab3[i] = tv[k];
+    }
+    if (lane < NW * NCH) {
+#pragma unroll
+        for (int h = 0; h < WS / 4; ++h)
+            s_w[(wave * (NW * NCH) + lane) * (WS / 4) + h] = make_float4(wl[4 * h], wl[4 * h + 1], wl[4 * h + 2], wl[4 * h + 3]);
+    }
+#pragma unroll
+    for (int dd = 0; dd < DPW; ++dd) {
+        float4* zs = reinterpret_cast<float4*>(s_z + (wave * DPW + dd) * CFD_KB_ZS);
+#pragma unroll
+        for (int k = 0; k < ZV; ++k) {
+            const int i = lane + 64 * k;
+            if (4 * i < M2) zs[i] = zv[dd][k];
+        }
+        if (lane == 0) s_z[(wave * DPW + dd) * CFD_KB_ZS + M2] = 0.f;  // the zero word every masked-out gather index points at
+    }
+    cfd_wave_lds_sync();
     const bf16x8* tb3 = s_tab3 + 2 * T * 64;
+    CFD_BTS(1);
     float4 AP[2][4];  // gelu'(aprev) operands of two destination channels in flight
     auto fetch_ap = [&](int t, int dd, float4 (&r)[4]) {
         const int d = wave + dd * NW;
@@ -1932,17 +1976,21 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
         for (int c = 0; c < NCH; ++c) {
             const int g = t * NCH + c;
             const int par = (PAR + c) & 1;
+            if (t == 1 && c == 0) CFD_BTS(6);
             commit(c, par, R[par]);
+            if (t == 1 && c == 0) CFD_BTS(7);
             __syncthreads();  // chunk g visible (first pass: also tables, weights); the other buffer is free again
+            if (t == 1 && c == 0) CFD_BTS(8);
             if (g + 2 < G) fetch(g + 2, R[par]);
             if constexpr (DGELU) {
                 if (c == NCH - 2) fetch_ap(t, 0, AP[0]);
                 if (c == NCH - 1) fetch_ap(t, 1, AP[1]);
             }
             // inverse transform of destination channel dd = c (spread over the chunks so MFMA and VALU work interleave)
+            if (t == 1 && c == 0) CFD_BTS(9);
             if (c < DPW && wave + c * NW < Cd) {
                 float va[2][8];
-                idft_gather(s_z + (wave * DPW + (c < DPW ? c : 0)) * CFD_BLK_ZS, m1, m2, SA, q, n, va);
+                idft_gather(s_z + (wave * DPW + (c < DPW ? c : 0)) * CFD_KB_ZS, m1, m2, SA, q, n, va);
                 idft_tile_b3<NJ>(idft_split(va), s_tab3 + 2 * t * 64, tb3, lane, acc[c < DPW ? c : 0]);
             }
             if constexpr (DPW > NCH) {  // more destination channels than chunks: the rest ride on the last chunk
@@ -1951,7 +1999,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                     for (int dd = NCH; dd < DPW; ++dd) {
                         if (wave + dd * NW < Cd) {
                             float va[2][8];
-                            idft_gather(s_z + (wave * DPW + dd) * CFD_BLK_ZS, m1, m2, SA, q, n, va);
+                            idft_gather(s_z + (wave * DPW + dd) * CFD_KB_ZS, m1, m2, SA, q, n, va);
                             idft_tile_b3<NJ>(idft_split(va), s_tab3 + 2 * t * 64, tb3, lane, acc[dd]);
                         }
                     }
@@ -1959,6 +2007,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
             }
             // channel mix of this chunk (dead channels hold zeros in LDS and get zero weights); the LDS reads of
             // source channel sl+1 are issued before the FMAs of channel sl
+            if (t == 1 && c == 0) CFD_BTS(10);
             {
                 float4 v[2][4], wq[2][WS / 4];
                 auto lds_fetch = [&](int sl, float4 (&vv)[4], float4 (&ww)[WS / 4]) {
@@ -1995,6 +2044,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
             }
         }
         // ---- tile epilogue: [* gelu'(aprev)], whole-float4 row stores ----
+        if (t == 1) CFD_BTS(11);
 #pragma unroll
         for (int dd = 0; dd < DPW; ++dd) {
             const int d = wave + dd * NW;
@@ -2022,17 +2072,28 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
 #pragma unroll 1
     for (int t = 0; t < T; t += 2) {
         tile(CfdParity<0>{}, t);
+        if (t == 0) CFD_BTS(2);
+        if (t == 2) CFD_BTS(4);
         if (t + 1 < T) {
             if constexpr (NCH % 2 == 1) tile(CfdParity<1>{}, t + 1);
             else tile(CfdParity<0>{}, t + 1);
         }
+        if (t == 0) CFD_BTS(3);
+        if (t == 2) CFD_BTS(5);
     }
+#ifdef CFD_BDIAG
+    if ((b == 0 || b == (int)gridDim.x - 1) && lane == 0 && (wave == 0 || wave == NW - 1)) {
+        long long* o = reinterpret_cast<long long*>(dst) + 16 * ((wave == 0 ? 0 : 1) + (b == 0 ? 0 : 2));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o[k] = ts[k];
+    }
+#endif
 }
 
-static bool block_fused_ok(const cfd_plan* p, int Cs, int Cd, const void* a, const void* b, const void* c) {
+static bool block_fused_ok(const cfd_plan* p, int Cs, int Cd, const void* a, const void* b, const void* c, const void* z) {
     const int cmax = Cs > Cd ? Cs : Cd;
-    return p->W == 64 && p->H % 16 == 0 && p->NJ == 4 && p->d_inv_b3 &&
-           4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS && cmax <= 32 &&
+    return p->W == 64 && p->H % 16 == 0 && p->NJ == 4 && p->d_inv_b3 &&  // d_inv_b3 exists for T <= 4 only (plan.cpp)
+           4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS && cmax <= 32 && ((uintptr_t)z % 16) == 0 &&
            ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && (!c || ((uintptr_t)c % 16) == 0);
 }
 
@@ -2060,7 +2121,9 @@ static void launch_block(const cfd_plan* p, const float* src, const float* z, co
     if (cmax <= 8) launch_block_cfg<4, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
     else if (cmax <= 16) launch_block_cfg<4, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
     else if (cmax <= 20) {  // measured at B=256, C=20 (us): (10,2,2) 61/73/60/97, (5,4,4) 69/79/67/82, (4,5,5) 77/84/74/83
-        if (dgelu) launch_block_cfg<5, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
+        // round 2, same box: (8,3,3) 52.8/59.3/53.5/62.2 against 49.4/60.9/50.9/66.8 -- two waves per SIMD, 3 + 2 destination
+        // channels per SIMD; (10,2,2) and (5,4,4) leave SIMDs with 3 vs 2 and 2 vs 1 waves
+        if (dgelu) launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
         else launch_block_cfg<10, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
     }
     else launch_block_cfg<8, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
@@ -2074,7 +2137,7 @@ extern "C" int cfd_fno_block_fwd(const cfd_plan* p, const float* a, const float*
                 "cfd_fno_block_fwd: channels (%d -> %d) unsupported (1..32)", Cin, Cout);
     if (B == 0) return CFD_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (!block_fused_ok(p, Cin, Cout, a, out, nullptr)) {  // general grids: two passes
+    if (!block_fused_ok(p, Cin, Cout, a, out, nullptr, z)) {  // general grids: two passes
         CFD_TRY(cfd_chanmix(a, w0, b0, out, B, Cin, Cout, p->H * p->W, act_in, 0, stream));
         return cfd_spectral_idft(p, z, out, nullptr, out, B * Cout, 1, stream);
     }
@@ -2115,7 +2178,7 @@ int cfd_int_fno_block_bwd_input(const cfd_plan* p, const float* g, const float* 
                 "cfd_fno_block_bwd_input: channels (%d -> %d) unsupported (1..32)", Cin, Cout);
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) return launch_reduce_tail_standalone(tail, st);
-    if (!block_fused_ok(p, Cout, Cin, g, gin, aprev)) {
+    if (!block_fused_ok(p, Cout, Cin, g, gin, aprev, gz)) {
         CFD_TRY(launch_reduce_tail_standalone(tail, st));
         CFD_TRY(cfd_chanmix(g, w0, nullptr, gin, B, Cout, Cin, p->H * p->W, 0, 1, stream));
         return cfd_spectral_idft(p, gz, gin, aprev, gin, B * Cin, aprev ? 2 : 1, stream);
