@@ -99,6 +99,8 @@ _SIGS = {
     "cfd_batchnorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfd_maxpool2_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "cfd_maxpool2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "cfd_upsample2_bilinear_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "cfd_upsample2_bilinear_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "cfd_convt2_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfd_convt2_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "cfd_convt2_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

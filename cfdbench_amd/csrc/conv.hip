@@ -1177,6 +1177,107 @@ extern "C" int cfd_maxpool2_bwd(const float* x, const float* gy, float* gx, int 
 }
 
 // ------------------------------------------------------------------------------------------------------
+// nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)  (src/models/unet.py:74-76, the bilinear=True up path)
+// ------------------------------------------------------------------------------------------------------
+// Source coordinate of output index o: s = o * (in - 1) / (out - 1) (align_corners), i0 = floor(s), i1 = min(i0 + 1, in - 1),
+// weights (1 - l, l) with l = s - i0 -- ATen's area_pixel_compute_source_index / compute_source_index_and_lambda in fp32.
+struct CfdLerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ CfdLerp cfd_lerp_src(int o, int n_in, float scale) {
+    const float s = scale * (float)o;
+    CfdLerp r;
+    r.i0 = (int)s;
+    if (r.i0 > n_in - 1) r.i0 = n_in - 1;
+    r.i1 = r.i0 + (r.i0 < n_in - 1 ? 1 : 0);
+    float l = s - (float)r.i0;
+    l = l < 0.f ? 0.f : (l > 1.f ? 1.f : l);
+    r.l1 = l;
+    r.l0 = 1.f - l;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_upsample2_fwd(const float* __restrict__ x, float* __restrict__ y, unsigned total,
+                                                       int H, int W, float sy, float sx, CfdDiv dHWo, CfdDiv dWo) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned img = cfd_div(e, dHWo);
+        const int p = (int)(e - img * (unsigned)(Ho * Wo)), yo = (int)cfd_div((unsigned)p, dWo), xo = p - yo * Wo;
+        const CfdLerp a = cfd_lerp_src(yo, H, sy), b = cfd_lerp_src(xo, W, sx);
+        const float* s = x + (size_t)img * H * W;
+        const float r0 = b.l0 * s[a.i0 * W + b.i0] + b.l1 * s[a.i0 * W + b.i1];
+        const float r1 = b.l0 * s[a.i1 * W + b.i0] + b.l1 * s[a.i1 * W + b.i1];
+        y[e] = a.l0 * r0 + a.l1 * r1;
+    }
+}
+
+// gx[i][j] = sum over the output pixels that read input (i, j) of their weight * gy: a gather over the (at most 4 x 4)
+// output rows / columns whose source interval touches the input pixel -- no atomics, fixed summation order.
+__global__ __launch_bounds__(256) void k_upsample2_bwd(const float* __restrict__ gy, float* __restrict__ gx, unsigned total,
+                                                       int H, int W, float sy, float sx, CfdDiv dHW, CfdDiv dW) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned img = cfd_div(e, dHW);
+        const int p = (int)(e - img * (unsigned)(H * W)), i = (int)cfd_div((unsigned)p, dW), j = p - i * W;
+        // candidate output rows 2i-2 .. 2i+3 (s = o (in-1)/(out-1) < o/2, so floor(s) = i needs o in (2i, 2i+3]; i1 = i one lower)
+        float wy[6], wx[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int yo = 2 * i - 2 + k, xo = 2 * j - 2 + k;
+            wy[k] = 0.f;
+            wx[k] = 0.f;
+            if (yo >= 0 && yo < Ho) {
+                const CfdLerp a = cfd_lerp_src(yo, H, sy);
+                wy[k] = (a.i0 == i ? a.l0 : 0.f) + (a.i1 == i ? a.l1 : 0.f);
+            }
+            if (xo >= 0 && xo < Wo) {
+                const CfdLerp b = cfd_lerp_src(xo, W, sx);
+                wx[k] = (b.i0 == j ? b.l0 : 0.f) + (b.i1 == j ? b.l1 : 0.f);
+            }
+        }
+        const float* g = gy + (size_t)img * Ho * Wo;
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 6; ++ky) {
+            const int yo = 2 * i - 2 + ky;
+            if (wy[ky] == 0.f) continue;
+            float row = 0.f;
+#pragma unroll
+            for (int kx = 0; kx < 6; ++kx) {
+                const int xo = 2 * j - 2 + kx;
+                if (wx[kx] != 0.f) row = fmaf(wx[kx], g[yo * Wo + xo], row);
+            }
+            acc = fmaf(wy[ky], row, acc);
+        }
+        gx[e] = acc;
+    }
+}
+
+static float upsample2_scale(int n) { return n > 0 ? (float)(n - 1) / (float)(2 * n - 1) : 0.f; }
+
+extern "C" int cfd_upsample2_bilinear_fwd(const float* x, float* y, int nimg, int H, int W, void* stream) {
+    CFD_REQUIRE(x && y && nimg >= 0 && H >= 1 && W >= 1, CFD_ERR_INVALID_ARG, "cfd_upsample2_bilinear_fwd: bad arguments");
+    if (nimg == 0) return CFD_OK;
+    CFD_REQUIRE_I31((long)nimg * 4 * H * W, "cfd_upsample2_bilinear_fwd");
+    const long total = (long)nimg * 4 * H * W;
+    CFD_PROF_W("k_upsample2_fwd", (hipStream_t)stream, 5.0 * nimg * H * W * 4.0, 6.0 * total);
+    hipLaunchKernelGGL(k_upsample2_fwd, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, (unsigned)total, H, W,
+                       upsample2_scale(H), upsample2_scale(W), cfd_div_make((unsigned)(4 * H * W)), cfd_div_make((unsigned)(2 * W)));
+    CFD_LAUNCH_CHECK("cfd_upsample2_bilinear_fwd");
+    return CFD_OK;
+}
+
+extern "C" int cfd_upsample2_bilinear_bwd(const float* gy, float* gx, int nimg, int H, int W, void* stream) {
+    CFD_REQUIRE(gy && gx && nimg >= 0 && H >= 1 && W >= 1, CFD_ERR_INVALID_ARG, "cfd_upsample2_bilinear_bwd: bad arguments");
+    if (nimg == 0) return CFD_OK;
+    CFD_REQUIRE_I31((long)nimg * 4 * H * W, "cfd_upsample2_bilinear_bwd");
+    const long total = (long)nimg * H * W;
+    CFD_PROF_W("k_upsample2_bwd", (hipStream_t)stream, 5.0 * nimg * H * W * 4.0, 2.0 * 16 * total);
+    hipLaunchKernelGGL(k_upsample2_bwd, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, gy, gx, (unsigned)total, H, W,
+                       upsample2_scale(H), upsample2_scale(W), cfd_div_make((unsigned)(H * W)), cfd_div_make((unsigned)W));
+    CFD_LAUNCH_CHECK("cfd_upsample2_bilinear_bwd");
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // ConvTranspose2d(kernel 2, stride 2)  (src/models/unet.py:80): out[b,o,2y+ky,2x+kx] = bias[o] + sum_i in[b,i,y,x] w[i,o,ky,kx]
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_convt2_fwd(const float* __restrict__ in, const float* __restrict__ w,

@@ -501,6 +501,27 @@ class MaxPool2Fn(torch.autograd.Function):
         return gx
 
 
+class UpsampleBilinear2xFn(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)  (src/models/unet.py:74-76)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        _require_cuda(x)
+        x = _f32c(x)
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        _lib.api().call("cfd_upsample2_bilinear_fwd", _ptr(x), _ptr(y), B * C, H, W, _stream())
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        B, C, H, W = ctx.shape
+        gx = torch.empty((B, C, H, W), dtype=torch.float32, device=gy.device)
+        _lib.api().call("cfd_upsample2_bilinear_bwd", _ptr(_f32c(gy)), _ptr(gx), B * C, H, W, _stream())
+        return gx
+
+
 class ConvTranspose2x2Fn(torch.autograd.Function):
     """nn.ConvTranspose2d(kernel_size=2, stride=2)."""
 

@@ -4,8 +4,10 @@ src/models/unet.py:11-263) on the gfx950 kernels of csrc/conv.hip.  The torch su
 nn.ConvTranspose2d) only hold parameters and buffers; the arithmetic runs in: implicit-GEMM replicate-padded conv (MFMA),
 fused BatchNorm+ReLU (batch statistics in training, running statistics in eval), 2x2 max-pool, 2x2/stride-2 transposed
 conv, 1x1 output conv and the (x + residual) * mask epilogue.  ``torch.cat`` / zero ``F.pad`` of skip connections are the
-only ATen calls (pure data movement).  ``bilinear=True`` is not built (init_model
-uses neither by default: src/utils/autoregressive.py:105-114, src/args.py:203)."""
+only ATen calls (pure data movement).  ``bilinear=True`` (unet.py:74-78: nn.Upsample(scale 2, bilinear, align_corners) +
+DoubleConv with in_channels // 2 mid channels, halved channel counts from down4 on) runs on ``cfd_upsample2_bilinear_*``;
+``init_model`` never passes it (src/utils/autoregressive.py:105-114), and like the reference it only composes with
+``insert_case_params_at="input"`` (the hidden Linear is sized dim * 16 while down4 then emits dim * 8 channels)."""
 from typing import List, Optional
 
 import torch
@@ -60,13 +62,19 @@ class Up(nn.Module):
 
     def __init__(self, in_channels, out_channels, bilinear=False):
         super().__init__()
-        if bilinear:
-            raise NotImplementedError("cfdbench_amd.UNet: bilinear=True is not built (init_model uses bilinear=False)")
-        self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
-        self.conv = DoubleConv(in_channels, out_channels)
+        self.bilinear = bilinear
+        if bilinear:  # plain convolutions reduce the channel count (unet.py:72-78)
+            self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)  # parameter-free; holds the reference's name
+            self.conv = DoubleConv(in_channels, out_channels, in_channels // 2)
+        else:
+            self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
+            self.conv = DoubleConv(in_channels, out_channels)
 
     def forward(self, x1, x2):
-        x1 = F_.ConvTranspose2x2Fn.apply(x1, self.up.weight, self.up.bias)
+        if self.bilinear:
+            x1 = F_.UpsampleBilinear2xFn.apply(x1)
+        else:
+            x1 = F_.ConvTranspose2x2Fn.apply(x1, self.up.weight, self.up.bias)
         diffY = x2.size()[2] - x1.size()[2]
         diffX = x2.size()[3] - x1.size()[3]
         if diffX or diffY:
@@ -102,10 +110,11 @@ class UNet(AutoCfdModel):
         self.down1 = Down(dim, dim * 2)
         self.down2 = Down(dim * 2, dim * 4)
         self.down3 = Down(dim * 4, dim * 8)
-        self.down4 = Down(dim * 8, dim * 16)
-        self.up1 = Up(dim * 16, dim * 8, bilinear)
-        self.up2 = Up(dim * 8, dim * 4, bilinear)
-        self.up3 = Up(dim * 4, dim * 2, bilinear)
+        factor = 2 if bilinear else 1  # unet.py:145-150
+        self.down4 = Down(dim * 8, dim * 16 // factor)
+        self.up1 = Up(dim * 16, dim * 8 // factor, bilinear)
+        self.up2 = Up(dim * 8, dim * 4 // factor, bilinear)
+        self.up3 = Up(dim * 4, dim * 2 // factor, bilinear)
         self.up4 = Up(dim * 2, dim, bilinear)
         self.out_conv = OutConv(dim, out_chan)
 

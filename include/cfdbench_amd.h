@@ -261,6 +261,11 @@ int cfd_batchnorm_bwd(const float* gy, const float* x, const float* gamma, const
 int cfd_maxpool2_fwd(const float* x, float* y, int nimg, int H, int W, void* stream);
 int cfd_maxpool2_bwd(const float* x, const float* gy, float* gx, int nimg, int H, int W, void* stream);
 
+/* nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) (unet.py:74-76, UNet(bilinear=True)) on nimg = B*C
+ * images: x (nimg,H,W) -> y (nimg,2H,2W); the backward is a gather (no atomics): gy (nimg,2H,2W) -> gx (nimg,H,W).  */
+int cfd_upsample2_bilinear_fwd(const float* x, float* y, int nimg, int H, int W, void* stream);
+int cfd_upsample2_bilinear_bwd(const float* gy, float* gx, int nimg, int H, int W, void* stream);
+
 /* nn.ConvTranspose2d(Ci, Co, kernel_size=2, stride=2) (unet.py:80): in (B,Ci,H,W), w (Ci,Co,2,2), out (B,Co,2H,2W). */
 int cfd_convt2_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int H, int W,
                    void* stream);

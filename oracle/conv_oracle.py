@@ -127,7 +127,42 @@ def convt2_bwd(g: Array, x: Array, w: Array):
     return gx, gw, g.sum(axis=(0, 2, 3))
 
 
-# ---- UNet.forward (src/models/unet.py:153-223), insert_case_params_at="input" | "hidden", bilinear=False ----
+def _lerp_tables(n_in: int, dtype):
+    """Source rows and weights of nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) along one axis
+    (ATen area_pixel_compute_source_index + compute_source_index_and_lambda; src/models/unet.py:74-76)."""
+    n_out = 2 * n_in
+    scale = (n_in - 1) / (n_out - 1) if n_out > 1 else 0.0
+    s = scale * np.arange(n_out, dtype=np.float64)
+    i0 = np.minimum(np.floor(s).astype(np.int64), n_in - 1)
+    i1 = i0 + (i0 < n_in - 1)
+    l1 = np.clip(s - i0, 0.0, 1.0).astype(dtype)
+    return i0, i1, (1 - l1).astype(dtype), l1
+
+
+def upsample2_bilinear(x: Array) -> Array:
+    B, C, H, W = x.shape
+    y0, y1, a0, a1 = _lerp_tables(H, x.dtype)
+    x0, x1, b0, b1 = _lerp_tables(W, x.dtype)
+    rows = x[:, :, y0, :] * a0[None, None, :, None] + x[:, :, y1, :] * a1[None, None, :, None]
+    return rows[:, :, :, x0] * b0[None, None, None, :] + rows[:, :, :, x1] * b1[None, None, None, :]
+
+
+def upsample2_bilinear_bwd(gy: Array) -> Array:
+    """Adjoint of upsample2_bilinear: gy (B,C,2H,2W) -> gx (B,C,H,W)."""
+    B, C, Ho, Wo = gy.shape
+    H, W = Ho // 2, Wo // 2
+    y0, y1, a0, a1 = _lerp_tables(H, gy.dtype)
+    x0, x1, b0, b1 = _lerp_tables(W, gy.dtype)
+    My = np.zeros((Ho, H), dtype=gy.dtype)
+    np.add.at(My, (np.arange(Ho), y0), a0)
+    np.add.at(My, (np.arange(Ho), y1), a1)
+    Mx = np.zeros((Wo, W), dtype=gy.dtype)
+    np.add.at(Mx, (np.arange(Wo), x0), b0)
+    np.add.at(Mx, (np.arange(Wo), x1), b1)
+    return np.einsum("bcyx,yi,xj->bcij", gy, My, Mx)
+
+
+# ---- UNet.forward (src/models/unet.py:153-223), insert_case_params_at="input" | "hidden", bilinear False | True ----
 def _double_conv(P, pre, x, training, stats):
     for j in (1, 2):
         x = conv2d(x, P[f"{pre}.conv{j}.0.weight"], P[f"{pre}.conv{j}.0.bias"])
@@ -158,8 +193,9 @@ def unet_forward(P: Dict[str, Array], inputs: Array, case_params: Array, mask: A
         # only ever consumed by up1 as its input, unet.py:206)
         conds = case_params @ P["case_params_fc.weight"].T + P["case_params_fc.bias"]
         cur = cur + conds[:, :, None, None]
+    bilinear = "up1.up.weight" not in P  # nn.Upsample holds no parameters (unet.py:74-78)
     for u, skip in zip((1, 2, 3, 4), (skips[3], skips[2], skips[1], skips[0])):
-        up = convt2(cur, P[f"up{u}.up.weight"], P[f"up{u}.up.bias"])
+        up = upsample2_bilinear(cur) if bilinear else convt2(cur, P[f"up{u}.up.weight"], P[f"up{u}.up.bias"])
         dy, dx = skip.shape[2] - up.shape[2], skip.shape[3] - up.shape[3]
         up = np.pad(up, ((0, 0), (0, 0), (dy // 2, dy - dy // 2), (dx // 2, dx - dx // 2)))
         cur = _double_conv(P, f"up{u}.conv", np.concatenate([skip, up], axis=1), training, stats)

@@ -204,12 +204,12 @@ def gen_auto_deeponet_cnn(name, seed, bseed, B, trunk_depth=2, p=5, steps=2, nq=
     print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
 
 
-def gen_unet(name, seed, bseed, B, H, W, dim, p=8, steps=2, insert="input"):
+def gen_unet(name, seed, bseed, B, H, W, dim, p=8, steps=2, insert="input", bilinear=False):
     """UNet (input-insert, ConvTranspose up path) train-mode forward/backward, running-stat update, eval forward and
     rollout from the reference module (src/models/unet.py).  The state_dict itself is stored (torch's init stream)."""
     from models.unet import UNet  # reference
     torch.manual_seed(seed)
-    model = UNet(2, 2, MseLoss(normalize=True), p, insert_case_params_at=insert, bilinear=False, dim=dim)
+    model = UNet(2, 2, MseLoss(normalize=True), p, insert_case_params_at=insert, bilinear=bilinear, dim=dim)
     with torch.no_grad():  # non-trivial BatchNorm affine parameters and running statistics
         g = torch.Generator().manual_seed(seed + 1)
         for k, v in model.state_dict().items():
@@ -235,7 +235,8 @@ def gen_unet(name, seed, bseed, B, H, W, dim, p=8, steps=2, insert="input"):
         save[f"grad::{k}"] = prm.grad.numpy()
     for k, v in model.state_dict().items():
         if "running" in k or "num_batches" in k:
-            save[f"after::{k}"] = v.numpy()
+            save[f"after::{k}"] = v.numpy().copy()
+    model.load_state_dict({k: _t(v) for k, v in sd0.items()})  # the eval outputs use the ORIGINAL running statistics (sd::*)
     model.eval()
     with torch.no_grad():
         save["preds_eval"] = model(inputs=_t(batch["inputs"]), case_params=_t(batch["case_params"]),
@@ -423,6 +424,9 @@ def gen_mseloss(name, seed):
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-unet-bilinear":  # added in round 2; the other fixtures are unchanged
+        gen_unet("unet_bilinear_dim4_32x48", 64, 74, 2, 32, 48, 4, p=5, bilinear=True)
+        return
     gen_spectral("spectral_64x64", 11, 2, 3, 4, 64, 64, 12, 12)
     gen_spectral("spectral_66x65", 12, 2, 4, 3, 66, 65, 12, 12)
     gen_spectral("spectral_c20_64x64", 13, 1, 20, 20, 64, 64, 12, 12)
@@ -437,6 +441,7 @@ def main():
     gen_unet("unet_dim4_32x32", 61, 71, 3, 32, 32, 4)
     gen_unet("unet_dim3_36x40", 62, 72, 2, 36, 40, 3, p=5)
     gen_unet("unet_hidden_dim2_32x32", 63, 73, 3, 32, 32, 2, p=5, insert="hidden")
+    gen_unet("unet_bilinear_dim4_32x48", 64, 74, 2, 32, 48, 4, p=5, bilinear=True)
     gen_resnet("resnet_h4_20x24", 81, 91, 2, 20, 24, 4, 1)
     gen_nonauto("deeponet_normact_relu", "deeponet", 101, 3, 37, 16, 18, 24, "relu", True)
     gen_nonauto("deeponet_plain_tanh", "deeponet", 102, 2, 50, 16, 18, 20, "tanh", False)

@@ -619,6 +619,26 @@ def check_pool_convt_resid(be, B, Ci, Co, H, W, seed=33):
     return res
 
 
+def check_upsample_bilinear(be, B, C, H, W, seed=35):
+    """cfd_upsample2_bilinear_fwd / _bwd against the oracle's restatement of nn.Upsample(2, bilinear, align_corners=True) and its
+    adjoint, plus the adjoint identity <up(x), g> == <x, up^T(g)> on the kernels themselves."""
+    from oracle import conv_oracle as CO
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    g = rng.standard_normal((B, C, 2 * H, 2 * W)).astype(np.float32)
+    dx, dg = be.dev(x), be.dev(g)
+    y, gx = be.zeros((B, C, 2 * H, 2 * W)), be.zeros((B, C, H, W))
+    api.call("cfd_upsample2_bilinear_fwd", P(dx), P(y), B * C, H, W, be.stream)
+    api.call("cfd_upsample2_bilinear_bwd", P(dg), P(gx), B * C, H, W, be.stream)
+    be.sync()
+    hy, hgx = be.host(y).astype(f64), be.host(gx).astype(f64)
+    res = {"up": nm(hy, CO.upsample2_bilinear(x.astype(f64))), "up_bwd": nm(hgx, CO.upsample2_bilinear_bwd(g.astype(f64)))}
+    lhs, rhs = float((hy * g).sum()), float((hgx * x).sum())
+    res["adjoint"] = (lhs - rhs) ** 2 / max(float((hy ** 2).sum() * (g.astype(f64) ** 2).sum()), 1e-300)
+    return res
+
+
 # ---- NormAct and the non-autoregressive DeepONet pieces (csrc/dense.hip) ---------------------------------------------
 def check_normact(be, S, shape, act, seed=41):
     from oracle import deeponet_oracle as D

@@ -154,6 +154,11 @@ def test_pool_convtranspose_residual(be, B, Ci, Co, H, W):
     _assert_all(res)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(1, 2, 5, 7), (1, 1, 1, 1), (2, 1, 4, 2)])
+def test_upsample_bilinear_align_corners(be, B, C, H, W):
+    _assert_all(K.check_upsample_bilinear(be, B, C, H, W))
+
+
 @pytest.mark.parametrize("S,shape,act", [(5, (24,), "relu"), (2, (7, 20), "tanh"), (3, (33,), "gelu"), (2, (5, 6), "swish")])
 def test_normact(be, S, shape, act):
     _assert_all(K.check_normact(be, S, shape, act))

@@ -189,6 +189,11 @@ def test_pool_convtranspose_residual(be, B, Ci, Co, H, W):
     _assert_all(res)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 96, 4, 4), (3, 12, 32, 32), (1, 5, 7, 9), (2, 3, 1, 1), (1, 2, 33, 2)])
+def test_upsample_bilinear_align_corners(be, B, C, H, W):
+    _assert_all(K.check_upsample_bilinear(be, B, C, H, W))
+
+
 @pytest.mark.parametrize("S,shape,act", [(8000, (100,), "relu"), (8, (1000, 100), "tanh"), (37, (333,), "gelu"), (5, (40, 24), "swish")])
 def test_normact(be, S, shape, act):
     _assert_all(K.check_normact(be, S, shape, act))

@@ -317,16 +317,16 @@ def test_auto_deeponet_vs_reference_golden(torch, golden_dir, name):
 
 
 # ---- U-Net drop-in (cfdbench_amd/models/unet.py) vs the reference module's golden outputs ---------------------------
-@pytest.mark.parametrize("name", ["unet_dim4_32x32", "unet_dim3_36x40", "unet_hidden_dim2_32x32"])
+@pytest.mark.parametrize("name", ["unet_dim4_32x32", "unet_dim3_36x40", "unet_hidden_dim2_32x32", "unet_bilinear_dim4_32x48"])
 def test_unet_vs_reference_golden(torch, golden_dir, name):
     from cfdbench_amd.models.loss import loss_name_to_fn
     from cfdbench_amd.models.unet import UNet
     g = np.load(golden_dir / f"{name}.npz")
     seed, bseed, B, H, W, dim, p, steps = [int(v) for v in g["meta"]]
     insert = "hidden" if "hidden" in name else "input"  # hidden: Linear(case_params) added to the bottleneck, unet.py:198-204
-    m = UNet(2, 2, loss_name_to_fn("nmse"), p, insert_case_params_at=insert, bilinear=False, dim=dim).cuda()
+    m = UNet(2, 2, loss_name_to_fn("nmse"), p, insert_case_params_at=insert, bilinear="bilinear" in name, dim=dim).cuda()
     sd = {k[len("sd::"):]: torch.from_numpy(np.ascontiguousarray(g[k])) for k in g.files if k.startswith("sd::")}
-    assert list(sd.keys()) == list(m.state_dict().keys())  # the reference's 136(+2)-tensor checkpoint layout
+    assert list(sd.keys()) == list(m.state_dict().keys())  # the reference's 136(+2)-tensor checkpoint layout (128 when bilinear)
     m.load_state_dict(sd)
     batch = synth.make_smooth_batch(bseed, B, H, W, p)
     batch["mask"][:, :, 0, :] = 0

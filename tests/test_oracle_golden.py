@@ -165,7 +165,22 @@ def test_auto_deeponet_forward_backward_rollout(golden_dir, name):
 
 
 # ---- U-Net (oracle/conv_oracle.py) against the reference module's outputs ------------------------------------------
-@pytest.mark.parametrize("name", ["unet_dim4_32x32", "unet_dim3_36x40", "unet_hidden_dim2_32x32"])
+def test_bilinear_upsample_oracle_matches_torch_and_its_adjoint():
+    """The restated nn.Upsample(scale_factor=2, bilinear, align_corners=True) against torch's own op and autograd."""
+    import torch
+    from oracle import conv_oracle as CO
+    rng = np.random.default_rng(5)
+    for shape in [(2, 3, 4, 4), (1, 2, 7, 9), (1, 1, 1, 1), (1, 2, 33, 2)]:
+        x = rng.standard_normal(shape)
+        g = rng.standard_normal(shape[:2] + (2 * shape[2], 2 * shape[3]))
+        t = torch.from_numpy(x).requires_grad_(True)
+        y = torch.nn.functional.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True)
+        y.backward(torch.from_numpy(g))
+        assert O.rel_nmse(CO.upsample2_bilinear(x), y.detach().numpy()) < 1e-24
+        assert O.rel_nmse(CO.upsample2_bilinear_bwd(g), t.grad.numpy()) < 1e-24
+
+
+@pytest.mark.parametrize("name", ["unet_dim4_32x32", "unet_dim3_36x40", "unet_hidden_dim2_32x32", "unet_bilinear_dim4_32x48"])
 def test_unet_forward_train_and_eval(golden_dir, name):
     from oracle import conv_oracle as CO
     g = np.load(golden_dir / f"{name}.npz")
