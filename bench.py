@@ -13,7 +13,7 @@ Rank 0 prints ONE JSON line.  Beside the contract's keys it carries
   roofline_step             the whole step against the ideal-fusion byte count of SURVEY 8d (10.2 MB/frame at C=20, L=4)
   roofline_spectral_conv2d  the north-star kernel group (SpectralConv2d fwd+bwd, 5N + 3Wb bytes)
   kernels                   every kernel of the step: launches, average time, HBM fraction
-  exact_fp32                the same step with every contraction in exact fp32 (null until that route is built)
+  exact_fp32                the same step and SpectralConv2d group with the transforms on the exact-fp32 kernels (cfd_tune_set("exact_fp32", 1))
   rollout / rollout_66x65   batched multi-step inference from one HIP graph (configs[4] horizon: 200 steps)
   unet_cfg2 / auto_deeponet_cfg3   train steps of BASELINE configs[2] / configs[3] on one GPU
   cpu_baseline              the reference's ATen call sequence on the host cores, at B = 256 and B = 32
@@ -398,10 +398,17 @@ def main():
     if extra and not args.no_extra:
         try:
             api.call("cfd_tune_set", b"exact_fp32", 1)
-            dt = time_steps(lambda: eng.train_step(inputs, label, cp, mask), args.steps, 3)
-            api.call("cfd_tune_set", b"exact_fp32", -1)
-            result["exact_fp32"] = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(B / dt, 1),
-                                        what="every contraction of the step on the exact-fp32 kernels (fp32 MFMA / FMA)")
+            try:
+                dt = time_steps(lambda: eng.train_step(inputs, label, cp, mask), args.steps, 3)
+                sp_exact = spectral_leg(api, _lib, dev, B, C, H, W, max(args.steps, 20))
+            finally:
+                api.call("cfd_tune_set", b"exact_fp32", -1)
+            result["exact_fp32"] = dict(
+                ms_per_step=round(dt * 1e3, 4), frames_per_s=round(B / dt, 1),
+                spectral_conv2d_us=sp_exact["avg_us"], spectral_conv2d_frac=sp_exact["frac"],
+                what="the same step / SpectralConv2d group with every DFT and inverse DFT on the exact-fp32 kernels (fp32 MFMA "
+                     "= the VALU's fp32 rate on gfx950) and the fused FnoBlock kernel replaced by its two exact passes; the "
+                     "1x1 weight gradient and the projection head have no exact-fp32 build and stay split-bf16")
         except Exception:  # noqa: BLE001
             result["exact_fp32"] = None
 

@@ -543,8 +543,9 @@ template <int NJ, bool VEC4>
 static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, int act, hipStream_t st) {
     CFD_PROF_W(act ? "k_dft_fwd_act" : "k_dft_fwd", st, (double)nimg * (4.0 * p->H * p->W + 16.0 * p->m1 * p->m2),
                (double)nimg * (4.0 * (p->m1 + 1) * (p->H / 2 + 1) * p->W + 8.0 * (p->m1 + 1) * p->W * p->m2));
+    const bool exact = cfd_tune_get(CFD_TUNE_EXACT_FP32) == 1;
     if constexpr (VEC4) {
-        if (p->W == 64 && p->H == 64 && p->d_fwd_b3) {
+        if (p->W == 64 && p->H == 64 && p->d_fwd_b3 && !exact) {
             int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
 #ifndef CFD_DFT_CAP
 #define CFD_DFT_CAP (3 * 256)
@@ -574,7 +575,7 @@ static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, in
             return CFD_OK;
         }
     }
-    if (cfd_tune_get(CFD_TUNE_GENERAL_B3) != 0 && launch_dft_g<float>(p, x, xh, nimg, act, st)) {
+    if (!exact && cfd_tune_get(CFD_TUNE_GENERAL_B3) != 0 && launch_dft_g<float>(p, x, xh, nimg, act, st)) {
         CFD_LAUNCH_CHECK("cfd_spectral_dft(general)");
         return CFD_OK;
     }
@@ -1689,7 +1690,8 @@ static bool launch_idft_g(const cfd_plan* p, const float* z, const TADD* addend,
 }
 
 static bool idft64_applies(const cfd_plan* p) {
-    return p->W == 64 && p->H % 16 == 0 && p->d_inv_b3 && 4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS;
+    return p->W == 64 && p->H % 16 == 0 && p->d_inv_b3 && 4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS &&
+           cfd_tune_get(CFD_TUNE_EXACT_FP32) != 1;
 }
 
 // `tail` (may be NULL): a partial-sum reduction to run as extra workgroups of this launch; only the 64-wide kernel with
@@ -1719,7 +1721,7 @@ static int launch_idft(const cfd_plan* p, const float* z, const float* addend, c
             return CFD_OK;
         }
     }
-    if (cfd_tune_get(CFD_TUNE_GENERAL_B3) != 0 && p->d_inv_g && p->NJG <= 5) {
+    if (cfd_tune_get(CFD_TUNE_EXACT_FP32) != 1 && cfd_tune_get(CFD_TUNE_GENERAL_B3) != 0 && p->d_inv_g && p->NJG <= 5) {
         CFD_PROF_W(epi == 0 ? "k_idft" : (epi == 1 ? "k_idft_add" : "k_idft_add_dgelu"), st,
                    (double)nimg * (4.0 * p->H * p->W * (1 + epi) + 16.0 * p->m1 * p->m2), (double)nimg * (8.0 * (p->m1 + 1) * p->W * p->m2 + 4.0 * p->H * p->W * p->m2));
         if (launch_idft_g<float>(p, z, addend, aprev, out, nimg, epi, st)) {
@@ -2092,7 +2094,8 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
 
 static bool block_fused_ok(const cfd_plan* p, int Cs, int Cd, const void* a, const void* b, const void* c, const void* z) {
     const int cmax = Cs > Cd ? Cs : Cd;
-    return p->W == 64 && p->H % 16 == 0 && p->NJ == 4 && p->d_inv_b3 &&  // d_inv_b3 exists for T <= 4 only (plan.cpp)
+    return cfd_tune_get(CFD_TUNE_EXACT_FP32) != 1 &&  // the fused kernel's inverse transform is split-bf16
+           p->W == 64 && p->H % 16 == 0 && p->NJ == 4 && p->d_inv_b3 &&  // d_inv_b3 exists for T <= 4 only (plan.cpp)
            4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS && cmax <= 32 && ((uintptr_t)z % 16) == 0 &&
            ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && (!c || ((uintptr_t)c % 16) == 0);
 }

@@ -21,6 +21,9 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
     {"block_fuse", "CFD_BLOCK_FUSE", {-1}},      // 0 = FnoBlock backward without the fused 1x1 weight gradient
     {"general_b3", "CFD_GENERAL_B3", {-1}},      // 0 = grids other than 64 x 64 on the exact-fp32 generic transforms
     {"head_blocks", "CFD_HEAD_BLOCKS", {-1}},    // workgroup cap of the head kernels (tests: several tiles per workgroup at small sizes)
+    {"exact_fp32", "CFD_EXACT_FP32", {-1}},      // 1 = every DFT / inverse DFT on the exact-fp32 kernels (fp32 MFMA / FMA), the fused
+                                                 // FnoBlock kernel replaced by its two exact passes: the price of the split-bf16 transforms
+                                                 // on the record (bench.py).  The 1x1 weight gradient and the head have no exact-fp32 build.
 };
 std::once_flag g_once;
 void read_env() {

@@ -120,6 +120,19 @@ def test_fno_whole_model_vs_oracle(be, B, C, L, H, W, border):
     assert max(res.values()) < K.NORTH_STAR_TOL
 
 
+@pytest.mark.parametrize("B,C,L,H,W", [(3, 20, 2, 64, 64), (2, 6, 2, 66, 65)])
+def test_exact_fp32_transform_route(be, B, C, L, H, W):
+    """cfd_tune_set("exact_fp32", 1): every DFT / inverse DFT on the exact-fp32 kernels, the fused FnoBlock replaced by its two
+    passes -- the route bench.py times beside the split-bf16 default.  Same oracle, and tighter where only transforms differ."""
+    with K.tuned(be, exact_fp32=1):
+        res = K.check_fno_vs_oracle(be, B, C, L, H, W, border=True)
+        assert res.pop("nmse_loss") < 1e-5
+        _assert_all(res, 1e-9)
+        sp = K.check_spectral(be, 5, 4, 3, H, W)
+        _assert_all(sp, 1e-12)
+        _assert_all(K.check_block(be, 3, C, C, H, W), 1e-12)
+
+
 def test_mfma_operand_layout_is_transpose_detecting(be):
     """A = I against an ASYMMETRIC second operand: a swapped row/column map in any of the chained MFMA stages would
     show up as a transposed spectrum (cdna_hip_programming.md section 3 'Always A=I-check with asymmetric B')."""
