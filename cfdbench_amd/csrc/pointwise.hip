@@ -241,6 +241,193 @@ __global__ __launch_bounds__(256) void k_chanmix(const TA* __restrict__ in, cons
     }
 }
 
+// ---- the same contraction on the matrix pipe (round 2) -------------------------------------------------------------
+// out[d][px] = bias[d] + sum_s W[d][s] f(in[s][px]) is ONE K = 32 split-bf16 MFMA step per 16 pixels and 16 output
+// channels (Ci, Co <= 32): 6 MFMAs where the VALU kernel above spends Ci * Co FMAs per pixel -- at Ci = Co = 32 that
+// kernel is VALU-bound (114 us at B = 256, 66 x 65: 31 % of HBM), this one streams.  Lane (n, q) of a wave loads four
+// consecutive pixels 4n .. 4n+3 of the eight channels 8q .. 8q+7 (the B operand of the four 16-pixel phases: pixel 4n + j
+// in phase j), the weight fragments are loop-invariant registers, and the accumulator rows d = 16 mt + 4q + r of the four
+// phases leave as one 16-byte store per row.  The next tile's loads are in flight during the arithmetic of this one.
+template <typename TA, int VEC>
+__device__ __forceinline__ void cfd_ld4px(const TA* __restrict__ p, int nvalid, float (&v)[4]) {
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (nvalid <= 0) return;
+    if constexpr (VEC == 4 && sizeof(TA) == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else if constexpr (VEC == 2 && sizeof(TA) == 4) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x; v[1] = t.y;
+        if (nvalid > 2) { const float2 u = *reinterpret_cast<const float2*>(p + 2); v[2] = u.x; v[3] = u.y; }
+    } else if constexpr (VEC == 4 && sizeof(TA) == 2) {  // four bf16 values in one 8-byte load
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        v[0] = __builtin_bit_cast(float, t.x << 16); v[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+        v[2] = __builtin_bit_cast(float, t.y << 16); v[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+    } else if constexpr (VEC == 2 && sizeof(TA) == 2) {
+        const unsigned t = *reinterpret_cast<const unsigned*>(p);
+        v[0] = __builtin_bit_cast(float, t << 16); v[1] = __builtin_bit_cast(float, t & 0xffff0000u);
+        if (nvalid > 2) {
+            const unsigned u = *reinterpret_cast<const unsigned*>(p + 2);
+            v[2] = __builtin_bit_cast(float, u << 16); v[3] = __builtin_bit_cast(float, u & 0xffff0000u);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nvalid) v[j] = cfd_ld(p + j);
+    }
+}
+
+template <int MT, int VEC, bool ACT, typename TA>
+__global__ __launch_bounds__(256, 2) void k_chanmix_b3(const TA* __restrict__ in, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                       int Ci, int Co, int HW, int transpose) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    // A operand: W[d = 16 mt + n][s = 8q + v] in THREE bf16 pieces (24 significant bits = the fp32 weight exactly): the
+    // weights are the same in every launch, so their rounding is a fixed perturbation of the operator that a 200-step rollout
+    // through a near-identity network accumulates coherently (2-piece weights: nMSE 3.0e-7 against the reference at step
+    // 200 of tests/golden/rollout200_c32_66x65, 3-piece: see DESIGN.md); the activations keep two pieces, whose rounding
+    // differs from value to value.  Five MFMAs per tile-step instead of three; the kernel is memory-bound either way.
+    CfdSplit8 wf[MT];
+    bf16x8 wlo2[MT];
+    float bz[MT][4];   // bias of accumulator row d = 16 mt + 4q + r
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float x[8];
+        const int d = 16 * mt + n;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int sc = 8 * q + v;
+            x[v] = (d < Co && sc < Ci) ? (transpose ? w[sc * Co + d] : w[d * Ci + sc]) : 0.f;
+        }
+        wf[mt] = cfd_split8(x);
+        float x3[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) x3[v] = (x[v] - (float)wf[mt].hi[v]) - (float)wf[mt].lo[v];  // exact: what two pieces miss
+        wlo2[mt] = cfd_split8(x3).hi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bz[mt][r] = (bias && 16 * mt + 4 * q + r < Co) ? bias[16 * mt + 4 * q + r] : 0.f;
+    }
+    const int tpb = (HW + 63) / 64;
+    const int total = B * tpb;  // < 2^30 (checked by the launcher)
+    const int stride = (int)gridDim.x * 4;
+    int tile = (int)blockIdx.x * 4 + wave;
+    int b = -1, px = 0;
+    auto locate = [&](int t) {
+        b = -1;
+        px = 0;
+        if (t < total) {
+            const unsigned ub = (unsigned)t / (unsigned)tpb;
+            b = (int)ub;
+            px = (int)((unsigned)t - ub * (unsigned)tpb) * 64 + 4 * n;
+        }
+    };
+    float hn[8][4];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int i = 8 * q + c;
+            const bool live = b >= 0 && i < Ci;
+            cfd_ld4px<TA, VEC>(in + ((size_t)(live ? b : 0) * Ci + (live ? i : 0)) * HW + (live ? px : 0), live ? HW - px : 0, hn[c]);
+        }
+    };
+    locate(tile);
+    fetch();
+    for (; tile < total; tile += stride) {
+        float h[8][4];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[c][j] = hn[c][j];
+        const int bc = b, pxc = px;
+        locate(tile + stride);
+        fetch();
+        cfd_sched_fence();  // the prefetch stays ahead of this tile's arithmetic
+        if constexpr (ACT) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) cfd_gelu4(h[c][0], h[c][1], h[c][2], h[c][3]);  // gelu(0) = 0: dead slots stay zero
+        }
+        float o[MT][4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float xk[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xk[c] = h[c][j];
+            const CfdSplit8 bs = cfd_split8(xk);
+            f32x4 z[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) z[mt] = f32x4{bz[mt][0], bz[mt][1], bz[mt][2], bz[mt][3]};
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wlo2[mt], bs.hi, z[mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wf[mt].lo, bs.lo, z[mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wf[mt].lo, bs.hi, z[mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wf[mt].hi, bs.lo, z[mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wf[mt].hi, bs.hi, z[mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[mt][r][j] = z[mt][r];
+        }
+        const int nvalid = HW - pxc;
+        if (nvalid > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = 16 * mt + 4 * q + r;
+                    if (d >= Co) continue;
+                    float* dst = out + ((size_t)bc * Co + d) * HW + pxc;
+                    if constexpr (VEC == 4) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(o[mt][r][0], o[mt][r][1], o[mt][r][2], o[mt][r][3]);
+                    } else if constexpr (VEC == 2) {
+                        *reinterpret_cast<float2*>(dst) = make_float2(o[mt][r][0], o[mt][r][1]);
+                        if (nvalid > 2) *reinterpret_cast<float2*>(dst + 2) = make_float2(o[mt][r][2], o[mt][r][3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < nvalid) dst[j] = o[mt][r][j];
+                    }
+                }
+        }
+    }
+}
+
+template <typename TA>
+static int launch_chanmix_b3(const TA* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int HW, int act,
+                             int transpose, hipStream_t st) {
+    CFD_REQUIRE((long)B * ((HW + 63) / 64) < (1L << 30), CFD_ERR_UNSUPPORTED, "cfd_chanmix: B * ceil(HW / 64) = %ld tiles (max 2^30)",
+                (long)B * ((HW + 63) / 64));
+    const long tiles = (long)B * ((HW + 63) / 64);
+    int blocks = (int)((tiles + 3) / 4);
+    if (blocks > 1024) blocks = 1024;
+    // widest access both tensors allow: the 4-pixel groups of a (b, channel) row start at multiples of 4 elements from a
+    // row start that is a multiple of HW elements
+    const size_t ea = sizeof(TA);
+    const int vec = (HW % 4 == 0 && ((uintptr_t)in % (4 * ea)) == 0 && ((uintptr_t)out % 16) == 0)   ? 4
+                    : (HW % 2 == 0 && ((uintptr_t)in % (2 * ea)) == 0 && ((uintptr_t)out % 8) == 0) ? 2
+                                                                                                    : 1;
+    CFD_PROF_W(transpose ? "k_chanmix_t" : (act ? "k_chanmix_act" : "k_chanmix"), st, B * HW * ((double)ea * Ci + 4.0 * Co),
+               2.0 * B * HW * (double)Ci * Co);
+#define CFD_CB3(M_, V_, A_) \
+    hipLaunchKernelGGL((k_chanmix_b3<M_, V_, A_, TA>), dim3(blocks), dim3(256), 0, st, in, w, bias, out, B, Ci, Co, HW, transpose)
+#define CFD_CB3_V(M_)                                                      \
+    do {                                                                   \
+        if (vec == 4) { if (act) CFD_CB3(M_, 4, true); else CFD_CB3(M_, 4, false); } \
+        else if (vec == 2) { if (act) CFD_CB3(M_, 2, true); else CFD_CB3(M_, 2, false); } \
+        else { if (act) CFD_CB3(M_, 1, true); else CFD_CB3(M_, 1, false); }  \
+    } while (0)
+    if (Co <= 16) CFD_CB3_V(1);
+    else CFD_CB3_V(2);
+#undef CFD_CB3_V
+#undef CFD_CB3
+    CFD_LAUNCH_CHECK("cfd_chanmix");
+    return CFD_OK;
+}
+
 template <int CPO, int VEC>
 static int launch_chanmix(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int HW,
                           int act, int transpose, hipStream_t st) {
@@ -263,6 +450,8 @@ int cfd_int_chanmix(const void* in, const float* w, const float* bias, void* out
     CFD_REQUIRE(in && w && out && B >= 0 && Ci >= 1 && Co >= 1 && HW >= 1 && Ci <= 32 && Co <= 32, CFD_ERR_INVALID_ARG, "cfd_chanmix: bad arguments");
     if (B == 0) return CFD_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (cfd_tune_get(CFD_TUNE_EXACT_FP32) != 1)
+        return launch_chanmix_b3<__bf16>((const __bf16*)in, w, bias, (float*)out, B, Ci, Co, HW, act_in, transpose, st);
     const int VEC = HW % 2 == 0 ? 2 : 1;
     const long total = (long)B * (HW / VEC);
     int blocks = (int)((total + 255) / 256);
@@ -293,6 +482,8 @@ extern "C" int cfd_chanmix(const float* in, const float* w, const float* bias, f
     CFD_REQUIRE(Ci <= 32 && Co <= 32, CFD_ERR_UNSUPPORTED, "cfd_chanmix: Ci=%d Co=%d (max 32) unsupported", Ci, Co);
     if (B == 0) return CFD_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (cfd_tune_get(CFD_TUNE_EXACT_FP32) != 1)  // split-bf16 MFMA form; the VALU kernel below is the exact-fp32 route
+        return launch_chanmix_b3<float>(in, w, bias, out, B, Ci, Co, HW, act_in, transpose, st);
     // pixels per thread: 4 (16-B accesses) while the accumulator tile stays small, 2 (8-B) for wide outputs
     const bool v4 = HW % 4 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0;
     const bool v2 = HW % 2 == 0 && ((uintptr_t)in % 8) == 0 && ((uintptr_t)out % 8) == 0;
