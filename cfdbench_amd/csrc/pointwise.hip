@@ -510,7 +510,35 @@ struct StemSrc {  // feature source for the fc0 weight gradient (features are ne
     int in_chan, P, W;
 };
 
-template <int MT, int NT, bool VEC4, bool ACT, bool STEM>
+// eight consecutive pixels of one row of a (b, channel) plane: two 16-byte, four 8-byte (HW even: 66 x 65 grids) or eight
+// 4-byte loads; pixels at or past `hw` read as zero (whole vectors: px and hw are multiples of the vector width)
+template <int VEC>
+__device__ __forceinline__ void cfd_ld8px(const float* __restrict__ src, int px, int hw, bool ok, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (!ok) return;
+    if constexpr (VEC == 4) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (px + 4 * k < hw) {
+                const float4 t = *reinterpret_cast<const float4*>(src + 4 * k);
+                v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+            }
+    } else if constexpr (VEC == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (px + 2 * k < hw) {
+                const float2 t = *reinterpret_cast<const float2*>(src + 2 * k);
+                v[2 * k] = t.x; v[2 * k + 1] = t.y;
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (px + j < hw) v[j] = src[j];
+    }
+}
+
+template <int MT, int NT, int VEC, bool ACT, bool STEM>
 __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g, const float* __restrict__ in,
                                                     StemSrc ss, float* __restrict__ part, int B, int Ci, int Co,
                                                     int HW) {
@@ -524,52 +552,34 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
 #pragma unroll
         for (int c = 0; c < NT; ++c) acc[a][c] = zero;
     const int cpb = (HW + 31) / 32;  // 32-pixel chunks per batch entry
-    const long total = (long)B * cpb;
+    const int total = B * cpb;       // < 2^30 (checked by the launcher): 32-bit index arithmetic
     const int CiIn = STEM ? ss.in_chan : Ci;  // channels physically present in `in`
     // One chunk = 32 pixels of every channel = ONE K = 32 step of the split-bf16 MFMA (cfd_common.h): lane (q, n) holds
     // pixels 8q .. 8q+7 of rows 16a + n (gradient) and 16c + n (input), straight from global memory in operand order.
     // load() only issues the global reads (raw values); GELU, the bf16 split and the MFMAs happen one iteration later,
     // so the next chunk's reads are in flight while this chunk is on the matrix pipe.
-    auto load = [&](long ch, float (&av)[MT][8], float (&bv)[NT][8]) {
-        const int b = (int)(ch / cpb);
-        const int px = (int)(ch - (long)b * cpb) * 32 + 8 * q;  // this lane's 8 pixels: px .. px+7
+    auto load = [&](int ch, float (&av)[MT][8], float (&bv)[NT][8]) {
+        const int b = (int)((unsigned)ch / (unsigned)cpb);
+        const int px = (ch - b * cpb) * 32 + 8 * q;  // this lane's 8 pixels: px .. px+7
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             const int o = 16 * a + n;
-            const float* src = g + ((size_t)b * Co + o) * HW + px;
-            if (VEC4) {
-                float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
-                if (o < Co && px < HW) t0 = *reinterpret_cast<const float4*>(src);
-                if (o < Co && px + 4 < HW) t1 = *reinterpret_cast<const float4*>(src + 4);
-                av[a][0] = t0.x; av[a][1] = t0.y; av[a][2] = t0.z; av[a][3] = t0.w;
-                av[a][4] = t1.x; av[a][5] = t1.y; av[a][6] = t1.z; av[a][7] = t1.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) av[a][j] = (o < Co && px + j < HW) ? src[j] : 0.f;
-            }
+            const float* src = g + ((size_t)b * Co + (o < Co ? o : 0)) * HW + px;
+            cfd_ld8px<VEC>(src, px, HW, o < Co, av[a]);
         }
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
             const int i = 16 * c + n;
             if (i < CiIn) {
                 const float* src = in + ((size_t)b * CiIn + i) * HW + px;
-                if (VEC4) {
-                    float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
-                    if (px < HW) t0 = *reinterpret_cast<const float4*>(src);
-                    if (px + 4 < HW) t1 = *reinterpret_cast<const float4*>(src + 4);
-                    bv[c][0] = t0.x; bv[c][1] = t0.y; bv[c][2] = t0.z; bv[c][3] = t0.w;
-                    bv[c][4] = t1.x; bv[c][5] = t1.y; bv[c][6] = t1.z; bv[c][7] = t1.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bv[c][j] = (px + j < HW) ? src[j] : 0.f;
-                }
+                cfd_ld8px<VEC>(src, px, HW, true, bv[c]);
             } else {
                 // generated columns: ones (bias gradient) and, for the stem, mask / grid_x / grid_y / case parameters.
                 // One row/column split per lane and chunk (px .. px+7 share a row whenever W % 8 == 0).
                 const int f = STEM ? i - ss.in_chan : -1;
                 const int row0 = STEM ? px / ss.W : 0, col0 = STEM ? px - row0 * ss.W : 0;
                 const bool same_row = STEM && (ss.W % 8 == 0);
-                if constexpr (STEM && VEC4) {
+                if constexpr (STEM && VEC == 4) {
                     // Fast path (W % 8 == 0: the lane's 8 pixels share a row, col0 is a multiple of 8): every generated
                     // column is either 8 contiguous floats (mask, grid_y) -> two 16-byte loads like the field channels,
                     // or one value for all 8 pixels (grid_x, case parameter, ones) -> one load.  The per-pixel form
@@ -597,32 +607,44 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
                         continue;
                     }
                 }
+                // any other grid (66 x 65: rows are not a multiple of 8 pixels).  Three lane classes instead of one branch
+                // per feature and pixel: a constant (ones, case parameter, absent mask), a plane read like a field channel
+                // (mask), or a table value per pixel (grid_x by row, grid_y by column, the row / column pair advanced
+                // without a division).
+                float cval = 0.f;
+                const float* plane = nullptr;
+                const float* tab = nullptr;
+                bool by_row = false;
+                if (i == Ci) cval = 1.f;
+                else if constexpr (STEM) {
+                    if (f == 0) { if (ss.mask) plane = ss.mask + (size_t)b * HW + px; else cval = 1.f; }
+                    else if (f == 1) { tab = ss.gx; by_row = true; }
+                    else if (f == 2) tab = ss.gy;
+                    else if (f < 3 + ss.P) cval = ss.cp[(size_t)b * ss.P + (f - 3)];
+                }
+                if (plane) {
+                    if (((uintptr_t)ss.mask % (4 * VEC)) == 0) cfd_ld8px<VEC>(plane, px, HW, true, bv[c]);
+                    else cfd_ld8px<1>(plane, px, HW, true, bv[c]);
+                } else if (tab) {
+                    int row = row0, col = col0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int pj = px + j;
-                    float v = 0.f;
-                    if (pj < HW) {
-                        if (i == Ci) v = 1.f;
-                        else if constexpr (STEM) {
-                            int row = row0, col = col0 + j;
-                            if (!same_row && col >= ss.W) { row = pj / ss.W; col = pj - row * ss.W; }
-                            if (f == 0) v = ss.mask ? ss.mask[(size_t)b * HW + pj] : 1.f;
-                            else if (f == 1) v = ss.gx[row];
-                            else if (f == 2) v = ss.gy[col];
-                            else if (f < 3 + ss.P) v = ss.cp[(size_t)b * ss.P + (f - 3)];
-                        }
+                    for (int j = 0; j < 8; ++j) {
+                        bv[c][j] = (px + j < HW) ? tab[by_row ? row : col] : 0.f;
+                        if (++col >= ss.W) { col = 0; ++row; }
                     }
-                    bv[c][j] = v;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bv[c][j] = (px + j < HW) ? cval : 0.f;
                 }
             }
         }
     };
-    const long stride = (long)gridDim.x * 4;
-    long ch = (long)blockIdx.x * 4 + wave;
+    const int stride = (int)gridDim.x * 4;
+    int ch = (int)blockIdx.x * 4 + wave;
     float av[MT][8], bv[NT][8], avn[MT][8], bvn[NT][8];
     if (ch < total) load(ch, av, bv);
     while (ch < total) {
-        const long nx = ch + stride;
+        const int nx = ch + stride;
         if (nx < total) load(nx, avn, bvn);
         cfd_sched_fence();
         if constexpr (ACT) {
@@ -717,18 +739,21 @@ template <bool STEM>
 static int launch_wgrad(const float* g, const float* in, StemSrc ss, float* gw, float* gb, void* ws, int B, int Ci,
                         int Co, int HW, int act, hipStream_t st, ChanWgradTail* defer = nullptr) {
     const int blocks = wgrad_blocks(B, HW);
+    CFD_REQUIRE((long)B * ((HW + 31) / 32) < (1L << 30), CFD_ERR_UNSUPPORTED, "cfd_chan_wgrad: B * ceil(HW / 32) = %ld chunks (max 2^30)",
+                (long)B * ((HW + 31) / 32));
     const int MT = (Co + 15) / 16, NT = (Ci + 1 + 15) / 16;
-    const bool v4 = HW % 4 == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)in % 16) == 0;
+    const int vec = (HW % 4 == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)in % 16) == 0)  ? 4
+                    : (HW % 2 == 0 && ((uintptr_t)g % 8) == 0 && ((uintptr_t)in % 8) == 0) ? 2
+                                                                                            : 1;
     float* part = (float*)ws;
 #define CFD_WG(M_, N_, V_, A_)                                                                                   \
     hipLaunchKernelGGL((k_chan_wgrad<M_, N_, V_, A_, STEM>), dim3(blocks), dim3(256), 0, st, g, in, ss, part, B, \
                        Ci, Co, HW)
-#define CFD_WG_VA(M_, N_)                              \
-    do {                                               \
-        if (v4 && act) CFD_WG(M_, N_, true, true);     \
-        else if (v4) CFD_WG(M_, N_, true, false);      \
-        else if (act) CFD_WG(M_, N_, false, true);     \
-        else CFD_WG(M_, N_, false, false);             \
+#define CFD_WG_VA(M_, N_)                                                                     \
+    do {                                                                                      \
+        if (vec == 4) { if (act) CFD_WG(M_, N_, 4, true); else CFD_WG(M_, N_, 4, false); }    \
+        else if (vec == 2) { if (act) CFD_WG(M_, N_, 2, true); else CFD_WG(M_, N_, 2, false); } \
+        else { if (act) CFD_WG(M_, N_, 1, true); else CFD_WG(M_, N_, 1, false); }             \
     } while (0)
     {
     // stem: the gradient tensor + the raw input channels (features are generated); otherwise gradient + activation
