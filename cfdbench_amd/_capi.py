@@ -64,11 +64,14 @@ _SIGS = {
     "cfd_fno_head_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "cfd_fno_head_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cfd_fno_head_bwd": (_I, [_P] * 15 + [_I, _I, _I, _I, _I, _I, _P]),
+    "cfd_fno_head_train": (_I, [_P] * 16 + [_I, _I, _I, _I, _I, _I, _P]),
     "cfd_loss_workspace_bytes": (_Z, [_Z]),
     "cfd_masked_loss_sums": (_I, [_P, _P, _P, _P, _Z, _P]),
     "cfd_loss_sums_bwd": (_I, [_P, _P, _P, _P, _P, _Z, _P]),
     "cfd_loss_scores": (_I, [_P, _P, _P]),
     "cfd_loss_coef": (_I, [_P, _P, _I, _F, _P]),
+    "cfd_label_energy_workspace_bytes": (_Z, []),
+    "cfd_label_energy_coef": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "cfd_gelu_fwd": (_I, [_P, _P, _Z, _P]),
     "cfd_gelu_bwd": (_I, [_P, _P, _P, _Z, _P]),
     "cfd_adam_flat": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P]),
@@ -110,6 +113,8 @@ _SIGS = {
     "cfd_fno_forward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "cfd_fno_workspace_bytes_ex": (_Z, [_P, C.POINTER(FnoShape), _I, _I]),
     "cfd_fno_forward_ex": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "cfd_fno_forward_train": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),
+                                   _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P]),
     "cfd_fno_backward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),
                               _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cfd_fno_backward_phase": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),

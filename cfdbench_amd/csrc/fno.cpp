@@ -121,6 +121,38 @@ extern "C" int cfd_fno_forward_ex(const cfd_plan* p, const cfd_fno_shape* s, con
     return CFD_OK;
 }
 
+// Training forward with the loss known in advance (FnoTrainEngine): everything of cfd_fno_forward(training = 1), but the
+// projection head runs ONCE for both directions -- predictions, loss sums, d loss / d a_L and the head's parameter
+// gradients leave the same kernel (head.hip, FUSE), so backward phase 0 is already done when this returns and the caller
+// continues with cfd_fno_backward_phase(1 .. L+1).  `which` = 0 mse, 1 nmse, 2 mae; `upstream` = d objective / d loss.
+extern "C" int cfd_fno_forward_train(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm,
+                                     const cfd_fno_params* g, const float* inputs, const float* case_params,
+                                     const float* mask, const float* label, float* preds, float* sums, float* coef, void* ws,
+                                     int which, float upstream, void* stream) {
+    CFD_TRY(check_shape("cfd_fno_forward_train", p, s));
+    CFD_REQUIRE(prm && g && inputs && label && preds && sums && coef && ws, CFD_ERR_INVALID_ARG, "cfd_fno_forward_train: NULL pointer");
+    const Layout L = make_layout(p, s, 1);
+    char* base = (char*)ws;
+    const int B = s->B, C = s->hidden, HW = s->H * s->W, NL = s->num_layers;
+    auto act_buf = [&](int l) { return (float*)(base + L.off_acts) + (size_t)l * L.n_act; };
+    auto xh_buf = [&](int l) { return (float*)(base + L.off_xh) + (size_t)l * L.n_modes; };
+    float* z = (float*)(base + L.off_z);
+    float* gA = (float*)(base + L.off_gA);
+    void* scratch = base + L.off_scratch;
+    // the label's energy and the gradient coefficients first: independent of the network (scratch is free until the head)
+    CFD_TRY(cfd_label_energy_coef(label, mask, sums, coef, scratch, B, s->out_chan, HW, which, upstream, stream));
+    CFD_TRY(cfd_fno_stem_fwd(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, act_buf(0), B, s->in_chan, s->n_case_params, C,
+                             stream));
+    for (int l = 0; l < NL; ++l) {  // FnoBlock.forward, fno2d.py:106-112
+        const int act = l > 0;
+        CFD_TRY(cfd_spectral_dft(p, act_buf(l), xh_buf(l), B * C, act, stream));
+        CFD_TRY(cfd_spectral_mix(p, xh_buf(l), prm->spec_w1[l], prm->spec_w2[l], z, B, C, C, 0, stream));
+        CFD_TRY(cfd_fno_block_fwd(p, act_buf(l), z, prm->w0_w[l], prm->w0_b[l], act_buf(l + 1), B, C, C, act, stream));
+    }
+    return cfd_fno_head_train(act_buf(NL), mask, label, coef, prm->fc1_w, prm->fc1_b, prm->fc2_w, prm->fc2_b, preds, sums, gA,
+                                  g->fc1_w, g->fc1_b, g->fc2_w, g->fc2_b, scratch, B, C, s->head, s->out_chan, HW, NL > 0, stream);
+}
+
 // One phase of the backward pass: 0 = projection head (+ loss gradient), 1 .. L = FnoBlock L-phase (the blocks in reverse
 // order), L+1 = lifting layer.  Phases must run in this order on one stream; the running input gradient alternates
 // between two workspace buffers, so a phase finds its operands from its index alone.  After phase k the gradients of

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64) void k_head_loss_final(const float* __restrict_
     if (lane == 0) { sums[0] = a; sums[1] = b; sums[2] = c; sums[3] = count; }
 }
 
-static size_t head_part_floats(int C, int Co) { return (size_t)HEAD_HD * C + HEAD_HD + (size_t)Co * HEAD_HD + Co; }
+static size_t head_part_floats(int C, int Co) { return (size_t)HEAD_HD * C + HEAD_HD + (size_t)Co * HEAD_HD + Co + 2; }  // + 2: fused loss sums
 
 extern "C" size_t cfd_fno_head_workspace_bytes(int B, int C, int Hd, int Co, int HW) {
     (void)Hd;
@@ -373,12 +373,20 @@ int cfd_int_fno_head_fwd(const void* a_, const float* mask, const float* label, 
 //               wave-private LDS plane pair (wave-level sync only)
 // d/dh sums over hidden units: each wave contributes its partial through LDS once per tile and the workgroup
 // finishes ga = d/dh * f'(a) with coalesced float4 stores.  Two workgroup barriers per tile.
-template <int KS, bool VEC4, bool ACT>
+// FUSE (training engine, round 2): the SAME pass also produces the forward results -- predictions and the loss sums -- so the
+// hidden layer's GELU is evaluated once per step instead of twice (k_head_fwd + this kernel).  Possible because the
+// derivative of mse / nmse / mae with respect to a prediction needs nothing of the forward pass but the prediction itself:
+// its coefficient (1 / n or 1 / sum label^2) is known from the labels before the head runs (k_label_energy, cfd_loss_coef).
+// Per pixel phase every wave adds its 32 hidden units' share of fc2 into LDS, one workgroup barrier later all four waves
+// read the sum, form the prediction and its loss gradient, and continue with the backward arithmetic on the GELU terms
+// they kept in registers.  `preds_w` / `b2` are used instead of `preds` / `gext`; the partial-sum block grows by
+// (sum d^2, sum |d|).
+template <int KS, bool VEC4, bool ACT, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void k_head_bwd(
     const float* __restrict__ a, const float* __restrict__ mask, const float* __restrict__ label,
     const float* __restrict__ preds, const float* __restrict__ gext, const float* __restrict__ coef,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, float* __restrict__ ga,
-    float* __restrict__ part, int B, int C, int Co, int HW) {
+    float* __restrict__ part, int B, int C, int Co, int HW, float* __restrict__ preds_w, const float* __restrict__ b2) {
     constexpr int CP = 4 * KS;          // padded channel count (rows of the d/dh exchange buffer)
     constexpr int MU = (CP + 15) / 16;  // 16-channel tiles
     constexpr int LDK = 40;             // bf16 row stride of s_hk: 32 channels + 8 pad (80 B: conflict-free b128 reads)
@@ -386,17 +394,22 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     constexpr int LDX = 40;             // bf16 row stride of the gz^T planes: 32 pixel columns + 8 pad
     constexpr int NST = (CP * 16 + 255) / 256;  // float4 staging loads per thread and tile
     __shared__ __attribute__((aligned(16))) __bf16 s_hk[2][2][64 * LDK];       // [buffer][hi/lo][column][channel]
-    __shared__ __attribute__((aligned(16))) __bf16 s_ht[2][2][16 * MU * LDT];  // [buffer][hi/lo][channel][column]
+    constexpr int HTR = CP + 1;  // rows of an s_ht plane: the CP channels + ONE zero row that every padding channel of the 16-wide
+                                 // MFMA tiles reads (16 MU rows would not leave room for two workgroups per CU in the fused kernel)
+    __shared__ __attribute__((aligned(16))) __bf16 s_ht[2][2][HTR * LDT];  // [buffer][hi/lo][channel][column]
     __shared__ __attribute__((aligned(16))) __bf16 s_x[4][2][32 * LDX];        // [wave][hi/lo][hidden][32 columns]
     __shared__ float4 s_red[4 * CP * 16];  // [wave][channel][16 x float4 = 64 pixels] partial d/dh
     __shared__ cfd_f2 s_gr[2][64];         // [buffer][column] upstream gradient on the raw head output, both channels
+                                           // (FUSE: label * mask of both channels; the gradient is formed in the phase)
+    __shared__ float s_mk[FUSE ? 2 : 1][64];       // FUSE: mask by column (0 past the end of the image / of the work)
+    __shared__ cfd_f2 s_pp[FUSE ? 2 : 1][4][16];   // FUSE: [phase parity][wave][pixel lane] partial fc2 sums of both outputs
     const int lane = threadIdx.x & 63, wave = cfd_uniform(threadIdx.x >> 6);
     const int q = lane >> 4, n = lane & 15;
 #if CFD_HDIAG & 1024
     const long long ts_entry = __builtin_readcyclecounter(), rt_entry = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
     for (int i = threadIdx.x; i < 2 * 2 * 64 * LDK; i += blockDim.x) (&s_hk[0][0][0])[i] = (__bf16)0.f;
-    for (int i = threadIdx.x; i < 2 * 2 * 16 * MU * LDT; i += blockDim.x) (&s_ht[0][0][0])[i] = (__bf16)0.f;
+    for (int i = threadIdx.x; i < 2 * 2 * HTR * LDT; i += blockDim.x) (&s_ht[0][0][0])[i] = (__bf16)0.f;
     __bf16* s_xhw = s_x[wave][0];
     __bf16* s_xlw = s_x[wave][1];
     // ---- loop-invariant fragments of this wave's hidden slice ----
@@ -443,6 +456,9 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
         for (int v = 0; v < 2; ++v) { acc2a[t][v] = cfd_f2{0.f, 0.f}; acc2b[t][v] = cfd_f2{0.f, 0.f}; accb1[t][v] = cfd_f2{0.f, 0.f}; }
     }
     float gb2a0 = 0.f, gb2a1 = 0.f;
+    float lsq = 0.f, labs = 0.f;                                   // FUSE: loss sums (wave 0, lane group 0)
+    float pv0[4] = {0.f, 0.f, 0.f, 0.f}, pv1[4] = {0.f, 0.f, 0.f, 0.f};  // FUSE: predictions of the lane's pixels 4n .. 4n+3
+    const float b2v0 = FUSE ? b2[0] : 0.f, b2v1 = (FUSE && Co > 1) ? b2[1] : 0.f;
     const int tpb = (HW + 63) / 64;
     const int total = B * tpb;  // < 2^30 (checked by the launcher)
     // tile -> (batch entry, first pixel); b = -1 past the end of the work.  One division per trip of the tile loop: the
@@ -474,13 +490,23 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
             for (int c = 0; c < 2; ++c)
                 if (c < Co) {
                     const size_t off = ((size_t)t.b * Co + c) * HW + pix;
-                    if (gext) rge[c] = gext[off];
-                    if (label) { rpr[c] = preds[off]; rlb[c] = label[off]; }
+                    if constexpr (FUSE) {
+                        rlb[c] = label[off];
+                    } else {
+                        if (gext) rge[c] = gext[off];
+                        if (label) { rpr[c] = preds[off]; rlb[c] = label[off]; }
+                    }
                 }
         }
     };
     auto stage_gr = [&](int buf) {
         if (wave != 1) return;
+        if constexpr (FUSE) {
+            const int colf = 16 * (lane & 3) + (lane >> 2);
+            s_gr[buf][colf] = rok ? cfd_f2{rlb[0] * rmk, rlb[1] * rmk} : cfd_f2{0.f, 0.f};  // fno2d.py:236
+            s_mk[buf][colf] = rok ? rmk : 0.f;
+            return;
+        }
         float g[2] = {0.f, 0.f};
         if (rok) {
 #pragma unroll
@@ -616,6 +642,57 @@ CFD_UNROLL(CFD_HB_UNROLL)
             // 2. a1 = gelu(z) feeds the fc2 weight gradient; gz = (W2^T graw) * gelu'(z), k-slot 4t + r
             if (j == 1) CFD_TS(9);
             float gzv[8];
+            if constexpr (FUSE) {
+                // forward half of the phase: GELU terms once, this wave's share of fc2, the workgroup's sum -> prediction,
+                // loss terms and the gradient on the raw output; then the backward half on the kept terms
+                cfd_f2 a1k[2][2], gdk[2][2];
+                cfd_f2 po0 = {0.f, 0.f}, po1 = {0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        const cfd_f2 zz = {z[t][2 * v], z[t][2 * v + 1]};
+                        cfd_f2 Phi, e;
+                        cfd_gelu_terms2(zz, Phi, e);
+                        a1k[t][v] = zz * Phi;
+                        gdk[t][v] = cfd_fma2(zz * (cfd_f2)(CFD_INV_SQRT_2PI), e, Phi);
+                        po0 = cfd_fma2(w2a[t][v], a1k[t][v], po0);
+                        po1 = cfd_fma2(w2b[t][v], a1k[t][v], po1);
+                    }
+                const float p0 = cfd_row_sum4(po0.x + po0.y), p1 = cfd_row_sum4(po1.x + po1.y);  // over the four lane groups
+                if (q == 0) s_pp[j & 1][wave][n] = cfd_f2{p0, p1};
+                __syncthreads();  // the other parity's slots are rewritten one phase later, after every wave has passed this point again
+                cfd_f2 sp = s_pp[j & 1][0][n];
+#pragma unroll
+                for (int wv = 1; wv < 4; ++wv) sp = sp + s_pp[j & 1][wv][n];
+                const float mk = s_mk[buf][col];
+                const cfd_f2 lab = grp[col];
+                const float pr0 = (sp.x + b2v0) * mk, pr1 = (sp.y + b2v1) * mk;  // fno2d.py:233
+                const float d0 = pr0 - lab.x, d1 = pr1 - lab.y;
+                const float sg0 = d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f), sg1 = d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f);
+                const float gp0 = (c0 * 2.f * d0 + c1 * sg0) * mk, gp1 = (c0 * 2.f * d1 + c1 * sg1) * mk;
+                pv0[0] = pv0[1]; pv0[1] = pv0[2]; pv0[2] = pv0[3]; pv0[3] = pr0;
+                pv1[0] = pv1[1]; pv1[1] = pv1[2]; pv1[2] = pv1[3]; pv1[3] = pr1;
+                if (wave == 0 && q == 0) {
+                    lsq = fmaf(d0, d0, fmaf(d1, d1, lsq));
+                    labs += fabsf(d0) + fabsf(d1);
+                    gb2a0 += gp0;
+                    gb2a1 += gp1;
+                }
+                const cfd_f2 g0 = (cfd_f2)(gp0), g1 = (cfd_f2)(gp1);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        acc2a[t][v] = cfd_fma2(g0, a1k[t][v], acc2a[t][v]);
+                        acc2b[t][v] = cfd_fma2(g1, a1k[t][v], acc2b[t][v]);
+                        const cfd_f2 ga1 = cfd_fma2(w2a[t][v], g0, w2b[t][v] * g1);
+                        const cfd_f2 gz = ga1 * gdk[t][v];
+                        accb1[t][v] = accb1[t][v] + gz;
+                        gzv[4 * t + 2 * v] = gz.x;
+                        gzv[4 * t + 2 * v + 1] = gz.y;
+                    }
+            } else {
             const cfd_f2 grj = grp[col];
             const cfd_f2 g0 = (cfd_f2)(grj.x), g1 = (cfd_f2)(grj.y);
 #pragma unroll
@@ -639,6 +716,7 @@ CFD_UNROLL(CFD_HB_UNROLL)
                     gzv[4 * t + 2 * v] = gz.x;
                     gzv[4 * t + 2 * v + 1] = gz.y;
                 }
+            }
             if (j == 1) CFD_TS(10);
 #if !(CFD_HDIAG & 16)
             const CfdSplit8 gs = cfd_split8(gzv);
@@ -694,7 +772,7 @@ CFD_UNROLL(CFD_HB_UNROLL)
                 }
 #pragma unroll
                 for (int mu = 0; mu < MU; ++mu) {
-                    const int o = (16 * mu + n) * LDT + 16 * (j - 1) + 8 * q;
+                    const int o = (16 * mu + n < CP ? 16 * mu + n : CP) * LDT + 16 * (j - 1) + 8 * q;
                     bh[mu] = *reinterpret_cast<const bf16x8*>(ht_hi + o);
                     bl[mu] = *reinterpret_cast<const bf16x8*>(ht_lo + o);
                 }
@@ -713,6 +791,24 @@ CFD_UNROLL(CFD_HB_UNROLL)
                 cfd_wave_lds_sync();
             }
             if (j == 1) CFD_TS(13);
+        }
+        if constexpr (FUSE) {
+            if (wave == 0 && q == 0) {  // predictions of the tile: pixels px0 + 4n .. 4n+3 of both output channels
+                const int p4 = px0 + 4 * n;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (c >= Co) continue;
+                    float* dstp = preds_w + ((size_t)b * Co + c) * HW + p4;
+                    const float* pv = c == 0 ? pv0 : pv1;
+                    if constexpr (VEC4) {
+                        if (p4 < HW) *reinterpret_cast<float4*>(dstp) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+                            if (p4 + jj < HW) dstp[jj] = pv[jj];
+                    }
+                }
+            }
         }
         CFD_TS(1);
         __syncthreads();
@@ -797,12 +893,20 @@ CFD_UNROLL(CFD_HB_UNROLL)
                 if (Co > 1) dst[(size_t)(o_gw2 + HEAD_HD + jh) * nb] = sb;
             }
         }
-    if (wave == 1) {  // the wave that staged the upstream gradients summed them (tiles past the end contributed zeros)
+    if (wave == (FUSE ? 0 : 1)) {  // the wave that formed / staged the upstream gradients summed them (tiles past the end: zeros)
         gb2a0 = cfd_wave_sum(gb2a0);
         gb2a1 = cfd_wave_sum(gb2a1);
         if (lane == 0) {
             dst[(size_t)o_gb2 * nb] = gb2a0;
             if (Co > 1) dst[(size_t)(o_gb2 + 1) * nb] = gb2a1;
+        }
+        if constexpr (FUSE) {  // two more rows of the partial-sum block: sum d^2, sum |d|  (MseLoss, loss.py:27-28)
+            lsq = cfd_wave_sum(lsq);
+            labs = cfd_wave_sum(labs);
+            if (lane == 0) {
+                dst[(size_t)(o_gb2 + Co) * nb] = lsq;
+                dst[(size_t)(o_gb2 + Co + 1) * nb] = labs;
+            }
         }
     }
 #if CFD_HDIAG & 1024
@@ -822,7 +926,8 @@ CFD_UNROLL(CFD_HB_UNROLL)
 // One wave per output element, whose per-block partials are one contiguous row (see k_wgrad_reduce).
 __global__ __launch_bounds__(256) void k_head_reduce(const float* __restrict__ part, int nblk, int PS,
                                                      float* __restrict__ gw1, float* __restrict__ gb1,
-                                                     float* __restrict__ gw2, float* __restrict__ gb2, int C, int Co) {
+                                                     float* __restrict__ gw2, float* __restrict__ gb2, int C, int Co,
+                                                     float* __restrict__ sums) {
     const int lane = threadIdx.x & 63;
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= PS) return;
@@ -832,7 +937,8 @@ __global__ __launch_bounds__(256) void k_head_reduce(const float* __restrict__ p
         if (e < o_gb1) gw1[e] = s;
         else if (e < o_gw2) gb1[e - o_gb1] = s;
         else if (e < o_gb2) gw2[e - o_gw2] = s;
-        else gb2[e - o_gb2] = s;
+        else if (e < o_gb2 + Co) gb2[e - o_gb2] = s;
+        else if (sums) sums[e - (o_gb2 + Co)] = s;  // fused head: sums[0] = sum d^2, sums[1] = sum |d|
     }
 }
 
@@ -852,8 +958,8 @@ extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* 
     {
     CFD_PROF_W("k_head_bwd", st, 4.0 * B * HW * (2.0 * C + 1 + 2.0 * Co), 2.0 * B * HW * (double)HEAD_HD * (3.0 * C + 2.0 * Co));
 #define CFD_HB(K_, V_, A_)                                                                                         \
-    hipLaunchKernelGGL((k_head_bwd<K_, V_, A_>), dim3(blocks), dim3(256), 0, st, a, mask, label, preds, gpreds_ext, \
-                       coef, w1, b1, w2, ga, part, B, C, Co, HW)
+    hipLaunchKernelGGL((k_head_bwd<K_, V_, A_, false>), dim3(blocks), dim3(256), 0, st, a, mask, label, preds, gpreds_ext, \
+                       coef, w1, b1, w2, ga, part, B, C, Co, HW, (float*)nullptr, (const float*)nullptr)
 #define CFD_HB_VA(K_)                              \
     do {                                           \
         if (v4 && act_in) CFD_HB(K_, true, true);  \
@@ -868,10 +974,53 @@ extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* 
 #undef CFD_HB
     }
     CFD_LAUNCH_CHECK("cfd_fno_head_bwd");
+    const int PS = (int)head_part_floats(C, Co) - 2;  // the two loss rows belong to the fused kernel
+    CFD_PROF_W("k_head_reduce", st, 0.0, 0.0);
+    hipLaunchKernelGGL(k_head_reduce, dim3((PS + 3) / 4), dim3(256), 0, st, (const float*)part, blocks, PS, gw1,
+                       gb1, gw2, gb2, C, Co, (float*)nullptr);
+    CFD_LAUNCH_CHECK("cfd_fno_head_bwd(reduce)");
+    return CFD_OK;
+}
+
+// Training head in ONE pass (k_head_bwd<FUSE>): predictions, loss sums (sums[0] = sum d^2, sums[1] = sum |d|; sums[2], sums[3] and
+// `coef` must already hold sum label^2, the element count and the loss-gradient coefficients -- cfd_label_energy +
+// cfd_loss_coef), d loss / d a and the four parameter gradients.  Replaces cfd_fno_head_fwd + cfd_loss_coef + cfd_fno_head_bwd
+// of a training step whose loss is one of mse / nmse / mae (fno2d.py:228-237, loss.py:22-37, train_auto.py:255).
+extern "C" int cfd_fno_head_train(const float* a, const float* mask, const float* label, const float* coef, const float* w1,
+                                  const float* b1, const float* w2, const float* b2, float* preds, float* sums, float* ga,
+                                  float* gw1, float* gb1, float* gw2, float* gb2, void* ws, int B, int C, int Hd, int Co,
+                                  int HW, int act_in, void* stream) {
+    CFD_REQUIRE(a && label && coef && w1 && b1 && w2 && b2 && preds && sums && ga && gw1 && gb1 && gw2 && gb2 && ws,
+                CFD_ERR_INVALID_ARG, "cfd_fno_head_train: NULL pointer");
+    CFD_TRY(head_check("cfd_fno_head_train", B, C, Hd, Co, HW));
+    CFD_REQUIRE(B >= 1, CFD_ERR_INVALID_ARG, "cfd_fno_head_train: empty batch");
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = head_bwd_blocks(B, HW);
+    float* part = (float*)ws;
+    const bool v4 = HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)ga % 16) == 0 && ((uintptr_t)preds % 16) == 0;
+    {
+    CFD_PROF_W("k_head_train", st, 4.0 * B * HW * (2.0 * C + 1 + 2.0 * Co), 2.0 * B * HW * (double)HEAD_HD * (3.0 * C + 3.0 * Co));
+#define CFD_HT(K_, V_, A_)                                                                                                \
+    hipLaunchKernelGGL((k_head_bwd<K_, V_, A_, true>), dim3(blocks), dim3(256), 0, st, a, mask, label, (const float*)nullptr, \
+                       (const float*)nullptr, coef, w1, b1, w2, ga, part, B, C, Co, HW, preds, b2)
+#define CFD_HT_VA(K_)                              \
+    do {                                           \
+        if (v4 && act_in) CFD_HT(K_, true, true);  \
+        else if (v4) CFD_HT(K_, true, false);      \
+        else if (act_in) CFD_HT(K_, false, true);  \
+        else CFD_HT(K_, false, false);             \
+    } while (0)
+    if (C <= 8) CFD_HT_VA(2);
+    else if (C <= 20) CFD_HT_VA(5);
+    else CFD_HT_VA(8);
+#undef CFD_HT_VA
+#undef CFD_HT
+    }
+    CFD_LAUNCH_CHECK("cfd_fno_head_train");
     const int PS = (int)head_part_floats(C, Co);
     CFD_PROF_W("k_head_reduce", st, 0.0, 0.0);
     hipLaunchKernelGGL(k_head_reduce, dim3((PS + 3) / 4), dim3(256), 0, st, (const float*)part, blocks, PS, gw1,
-                       gb1, gw2, gb2, C, Co);
-    CFD_LAUNCH_CHECK("cfd_fno_head_bwd(reduce)");
+                       gb1, gw2, gb2, C, Co, sums);
+    CFD_LAUNCH_CHECK("cfd_fno_head_train(reduce)");
     return CFD_OK;
 }

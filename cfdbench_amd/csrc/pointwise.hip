@@ -920,6 +920,67 @@ __global__ void k_loss_coef(const float* __restrict__ sums, float* __restrict__ 
     }
 }
 
+// sum (label * mask)^2 and the loss-gradient coefficients BEFORE the prediction exists: d mse / d p = 2 (p - l) / n,
+// d nmse / d p = 2 (p - l) / sum l^2, d mae / d p = sign(p - l) / n need nothing else from the forward pass (loss.py:27-35),
+// which is what lets the training head form predictions, loss sums and all gradients in one pass (head.hip, FUSE).
+// Two launches, fixed summation order: partial sums of 256 workgroups, then one workgroup finishes sums[2], sums[3], coef.
+__global__ __launch_bounds__(256) void k_label_energy_part(const float* __restrict__ label, const float* __restrict__ mask,
+                                                           float* __restrict__ part, unsigned planes, unsigned HW,
+                                                           CfdDiv dCo) {
+    __shared__ float s_red[4];
+    float acc = 0.f;
+    for (unsigned pl = blockIdx.x; pl < planes; pl += gridDim.x) {  // one (b, channel) plane at a time: the mask row is cfd_div(pl, Co)
+        const float* l = label + (size_t)pl * HW;
+        const float* m = mask ? mask + (size_t)cfd_div(pl, dCo) * HW : nullptr;
+        for (unsigned i = threadIdx.x; i < HW; i += blockDim.x) {
+            const float v = l[i] * (m ? m[i] : 1.f);
+            acc = fmaf(v, v, acc);
+        }
+    }
+    acc = cfd_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__global__ __launch_bounds__(64) void k_label_energy_coef(const float* __restrict__ part, int nblk, float count,
+                                                          float* __restrict__ sums, float* __restrict__ coef, int which,
+                                                          float upstream) {
+    float a = 0.f;
+    for (int k = threadIdx.x; k < nblk; k += 64) a += part[k];
+    a = cfd_wave_sum(a);
+    if (threadIdx.x == 0) {
+        sums[2] = a;
+        sums[3] = count;
+        float c0 = 0.f, c1 = 0.f;
+        if (which == 0) c0 = upstream / count;
+        else if (which == 1) c0 = upstream / a;
+        else c1 = upstream / count;
+        coef[0] = c0;
+        coef[1] = c1;
+    }
+}
+
+extern "C" size_t cfd_label_energy_workspace_bytes(void) { return 256 * sizeof(float); }
+
+extern "C" int cfd_label_energy_coef(const float* label, const float* mask, float* sums, float* coef, void* ws, int B, int Co,
+                                     int HW, int which, float upstream, void* stream) {
+    CFD_REQUIRE(label && sums && coef && ws, CFD_ERR_INVALID_ARG, "cfd_label_energy_coef: NULL pointer");
+    CFD_REQUIRE(B >= 1 && Co >= 1 && HW >= 1, CFD_ERR_INVALID_ARG, "cfd_label_energy_coef: bad sizes");
+    CFD_REQUIRE(which >= 0 && which <= 2, CFD_ERR_INVALID_ARG, "cfd_label_energy_coef: which must be 0 (mse), 1 (nmse), 2 (mae)");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned planes = (unsigned)B * Co;
+    const int blocks = planes < 256 ? (int)planes : 256;
+    CFD_PROF_W("k_label_energy", st, 4.0 * B * HW * (Co + 1.0), 2.0 * B * Co * HW);
+    hipLaunchKernelGGL(k_label_energy_part, dim3(blocks), dim3(256), 0, st, label, mask, (float*)ws, planes, (unsigned)HW,
+                       cfd_div_make((unsigned)Co));
+    CFD_LAUNCH_CHECK("cfd_label_energy_coef(part)");
+    hipLaunchKernelGGL(k_label_energy_coef, dim3(1), dim3(64), 0, st, (const float*)ws, blocks, (float)((double)B * Co * HW), sums,
+                       coef, which, upstream);
+    CFD_LAUNCH_CHECK("cfd_label_energy_coef");
+    return CFD_OK;
+}
+
 extern "C" int cfd_loss_coef(const float* sums, float* coef, int which, float upstream, void* stream) {
     CFD_REQUIRE(sums && coef, CFD_ERR_INVALID_ARG, "cfd_loss_coef: NULL pointer");
     CFD_REQUIRE(which >= 0 && which <= 2, CFD_ERR_INVALID_ARG, "cfd_loss_coef: which must be 0 (mse), 1 (nmse), 2 (mae)");

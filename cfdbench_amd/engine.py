@@ -153,7 +153,7 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 class FnoTrainEngine:
     def __init__(self, model, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, loss_name: str = "nmse", group=None, grad_buckets: int = 1,
-                 overlap: bool = True):
+                 overlap: bool = True, fused_head: bool = True):
         if loss_name not in _LOSS_IDS:
             raise ValueError(f"loss_name must be one of {sorted(_LOSS_IDS)}")
         self.api = _lib.api()
@@ -172,6 +172,9 @@ class FnoTrainEngine:
         self.step_count = 0
         self.sync = GradSync(group, grad_buckets)
         self.overlap = overlap  # DP: reduce each backward phase's gradients while the next phase computes
+        # the projection head in ONE pass for both directions (cfd_fno_forward_train: the loss is fixed, so its gradient's
+        # coefficient is known from the labels before the head runs); False = cfd_fno_forward + cfd_loss_coef + head backward
+        self.fused_head = fused_head
         self.pstruct = _param_struct(self.flat.ptrs(False), self.L)
         self.gstruct = _param_struct(self.flat.ptrs(True), self.L)
         self.sums = torch.zeros(4, dtype=torch.float32, device=self.device)
@@ -205,6 +208,15 @@ class FnoTrainEngine:
         st = torch.cuda.current_stream().cuda_stream
         a, sp = self.api, ctypes.byref(self.shape)
         mp = None if mask is None else mask.data_ptr()
+        if self.fused_head:
+            a.call("cfd_fno_forward_train", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
+                   inputs.data_ptr(), case_params.data_ptr(), mp, label.data_ptr(), self.preds.data_ptr(), self.sums.data_ptr(),
+                   self.coef.data_ptr(), self.ws.data_ptr(), self.loss_id, 1.0, st)
+            for phase in range(1, self.L + 2):  # phase 0 (the head) left the fused kernel already
+                a.call("cfd_fno_backward_phase", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
+                       inputs.data_ptr(), case_params.data_ptr(), mp, label.data_ptr(), self.preds.data_ptr(), None,
+                       self.coef.data_ptr(), self.ws.data_ptr(), phase, st)
+            return
         a.call("cfd_fno_forward", self.plan, sp, ctypes.byref(self.pstruct), inputs.data_ptr(), case_params.data_ptr(), mp,
                label.data_ptr(), self.preds.data_ptr(), self.sums.data_ptr(), self.ws.data_ptr(), 1, st)
         a.call("cfd_loss_coef", self.sums.data_ptr(), self.coef.data_ptr(), self.loss_id, 1.0, st)
@@ -233,14 +245,20 @@ class FnoTrainEngine:
         st = torch.cuda.current_stream().cuda_stream
         a, sp = self.api, ctypes.byref(self.shape)
         mp = None if mask is None else mask.data_ptr()
-        a.call("cfd_fno_forward", self.plan, sp, ctypes.byref(self.pstruct), inputs.data_ptr(), case_params.data_ptr(), mp,
-               label.data_ptr(), self.preds.data_ptr(), self.sums.data_ptr(), self.ws.data_ptr(), 1, st)
-        a.call("cfd_loss_coef", self.sums.data_ptr(), self.coef.data_ptr(), self.loss_id, 1.0, st)
+        if self.fused_head:
+            a.call("cfd_fno_forward_train", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
+                   inputs.data_ptr(), case_params.data_ptr(), mp, label.data_ptr(), self.preds.data_ptr(), self.sums.data_ptr(),
+                   self.coef.data_ptr(), self.ws.data_ptr(), self.loss_id, 1.0, st)
+        else:
+            a.call("cfd_fno_forward", self.plan, sp, ctypes.byref(self.pstruct), inputs.data_ptr(), case_params.data_ptr(), mp,
+                   label.data_ptr(), self.preds.data_ptr(), self.sums.data_ptr(), self.ws.data_ptr(), 1, st)
+            a.call("cfd_loss_coef", self.sums.data_ptr(), self.coef.data_ptr(), self.loss_id, 1.0, st)
         handles = []
         for phase, (s0, s1) in enumerate(self.phase_slices()):
-            a.call("cfd_fno_backward_phase", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
-                   inputs.data_ptr(), case_params.data_ptr(), mp, label.data_ptr(), self.preds.data_ptr(), None,
-                   self.coef.data_ptr(), self.ws.data_ptr(), phase, st)
+            if not (self.fused_head and phase == 0):  # the fused forward has produced the head's gradients already
+                a.call("cfd_fno_backward_phase", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
+                       inputs.data_ptr(), case_params.data_ptr(), mp, label.data_ptr(), self.preds.data_ptr(), None,
+                       self.coef.data_ptr(), self.ws.data_ptr(), phase, st)
             handles.append(self.sync.reduce_slice_async(self.flat.grad, s0, s1))
         return self.sync.wait_all(handles)
 

@@ -157,6 +157,15 @@ int cfd_fno_head_bwd(const float* a, const float* mask, const float* label, cons
                      float* ga, float* gw1, float* gb1, float* gw2, float* gb2, void* ws, int B, int C, int Hd, int Co,
                      int HW, int act_in, void* stream);
 
+/* Both directions of the head in ONE pass for a training step whose loss is mse / nmse / mae: preds, sums[0] = sum d^2,
+ * sums[1] = sum |d| (sums[2], sums[3] and coef are INPUTS here: cfd_label_energy_coef), ga and the four parameter
+ * gradients.  Same results as cfd_fno_head_fwd + cfd_loss_coef + cfd_fno_head_bwd up to summation order; the hidden
+ * layer's GELU is evaluated once instead of twice (fno2d.py:228-237 + the head part of train_auto.py:255).       */
+int cfd_fno_head_train(const float* a, const float* mask, const float* label, const float* coef, const float* w1,
+                       const float* b1, const float* w2, const float* b2, float* preds, float* sums, float* ga, float* gw1,
+                       float* gb1, float* gw2, float* gb2, void* ws, int B, int C, int Hd, int Co, int HW, int act_in,
+                       void* stream);
+
 /* MseLoss on arbitrary tensors (src/models/loss.py:22-37): sums = {sum (p-l)^2, sum |p-l|, sum l^2, n}.
  * ws: cfd_loss_workspace_bytes(n).                                                                         */
 size_t cfd_loss_workspace_bytes(size_t n);
@@ -169,6 +178,12 @@ int cfd_loss_sums_bwd(const float* preds, const float* labels, const float* gsum
 int cfd_loss_scores(const float* sums, float* scores, void* stream);
 /* coef for cfd_fno_head_bwd: which = 0 mse, 1 nmse, 2 mae; scaled by `upstream` (d objective / d loss).       */
 int cfd_loss_coef(const float* sums, float* coef, int which, float upstream, void* stream);
+/* The same coefficients BEFORE any prediction exists: d mse|nmse|mae / d preds need only the element count and
+ * sum (label * mask)^2 (loss.py:27-35), which this computes from the labels (sums[2], sums[3], coef[0..1]; mask (B,HW) may
+ * be NULL; ws: cfd_label_energy_workspace_bytes()).  Used by cfd_fno_forward_train.                              */
+size_t cfd_label_energy_workspace_bytes(void);
+int cfd_label_energy_coef(const float* label, const float* mask, float* sums, float* coef, void* ws, int B, int out_chan,
+                          int HW, int which, float upstream, void* stream);
 
 /* nn.GELU() (exact erf, fno2d.py:147) as a standalone pass -- only used by the stand-alone FnoBlock module;
  * inside Fno2d the activation is fused into the consumers.  bwd: gx = gy * gelu'(x).                          */
@@ -318,6 +333,16 @@ size_t cfd_fno_workspace_bytes_ex(const cfd_plan* plan, const cfd_fno_shape* sha
 int cfd_fno_forward_ex(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,
                        const float* inputs, const float* case_params, const float* mask, const float* label,
                        float* preds, float* sums, void* ws, int training, int act_dtype, void* stream);
+
+/* Training forward for a loss fixed in advance (`which` = 0 mse, 1 nmse, 2 mae; FnoTrainEngine): cfd_fno_forward(training = 1)
+ * with the projection head run ONCE for both directions -- preds, sums[0..3], coef, d loss / d a_L (workspace) and the
+ * gradients of fc1 / fc2 (grads) all leave one kernel, so the hidden layer's GELU is evaluated once per step instead of
+ * twice.  Replaces `model(**batch)` + the head part of `loss.backward()` (train_auto.py:233-255); continue with
+ * cfd_fno_backward_phase(1 .. num_layers + 1).                                                                 */
+int cfd_fno_forward_train(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,
+                          const cfd_fno_params* grads, const float* inputs, const float* case_params, const float* mask,
+                          const float* label, float* preds, float* sums, float* coef, void* ws, int which, float upstream,
+                          void* stream);
 
 /* grads: same layout as params, every tensor overwritten.  coef/gpreds_ext as in cfd_fno_head_bwd.           */
 int cfd_fno_backward(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,

@@ -316,6 +316,51 @@ def check_head(be, B, C, HW, act, which="nmse", with_ext=False, border=True, see
     return res
 
 
+def check_head_train(be, B, C, HW, act, which="nmse", border=True, seed=14):
+    """cfd_label_energy_coef + cfd_fno_head_train (both directions of the head in one pass) against the same fp64 references as
+    check_head: predictions, all four loss sums, d/da and the four parameter gradients."""
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    Hd, Co = 128, 2
+    a = rng.standard_normal((B, C, HW)).astype(np.float32)
+    mask = np.ones((B, 1, HW), np.float32)
+    if border:
+        mask[:, :, ::7] = 0
+    label = rng.standard_normal((B, Co, HW)).astype(np.float32)
+    w1 = (rng.standard_normal((Hd, C)) / np.sqrt(C)).astype(np.float32)
+    b1 = rng.standard_normal((Hd,)).astype(np.float32) * 0.1
+    w2 = (rng.standard_normal((Co, Hd)) / np.sqrt(Hd)).astype(np.float32)
+    b2 = rng.standard_normal((Co,)).astype(np.float32) * 0.1
+    A, M, Lb = a.astype(f64), mask.astype(f64), label.astype(f64)
+    h, z1, a1, preds_ref = _head_ref(A, M, Lb, w1.astype(f64), b1.astype(f64), w2.astype(f64), b2.astype(f64), act)
+    lab_m = Lb * M
+    da, dm, dl = be.dev(a), be.dev(mask), be.dev(label)
+    dw1, db1, dw2, db2 = be.dev(w1), be.dev(b1), be.dev(w2), be.dev(b2)
+    ws = be.bytes(max(api.size("cfd_fno_head_workspace_bytes", B, C, Hd, Co, HW), api.size("cfd_label_energy_workspace_bytes")))
+    preds, sums, coef = be.zeros((B, Co, HW)), be.zeros((4,)), be.zeros((2,))
+    ga = be.zeros((B, C, HW))
+    gw1, gb1, gw2, gb2 = be.zeros((Hd, C)), be.zeros((Hd,)), be.zeros((Co, Hd)), be.zeros((Co,))
+    wid = {"mse": 0, "nmse": 1, "mae": 2}[which]
+    api.call("cfd_label_energy_coef", P(dl), P(dm), P(sums), P(coef), P(ws), B, Co, HW, wid, 1.0, be.stream)
+    api.call("cfd_fno_head_train", P(da), P(dm), P(dl), P(coef), P(dw1), P(db1), P(dw2), P(db2), P(preds), P(sums), P(ga), P(gw1),
+             P(gb1), P(gw2), P(gb2), P(ws), B, C, Hd, Co, HW, int(act), be.stream)
+    be.sync()
+    res = {"preds": nm(be.host(preds), preds_ref)}
+    d = preds_ref - lab_m
+    sref = np.array([np.sum(d * d), np.sum(np.abs(d)), np.sum(lab_m * lab_m), d.size])
+    res["sums"] = float(np.max(np.abs(be.host(sums) - sref) / np.abs(sref)))
+    graw = O.loss_grad_wrt_preds(preds_ref, lab_m, which) * M
+    ga1 = np.einsum("cj,bcp->bjp", w2.astype(f64), graw)
+    gz = ga1 * O.gelu_grad(z1)
+    gh = np.einsum("ji,bjp->bip", w1.astype(f64), gz)
+    res["ga"] = nm(be.host(ga), gh * O.gelu_grad(A) if act else gh)
+    res["gw1"] = nm(be.host(gw1), np.einsum("bjp,bip->ji", gz, h))
+    res["gb1"] = nm(be.host(gb1), gz.sum(axis=(0, 2)))
+    res["gw2"] = nm(be.host(gw2), np.einsum("bcp,bjp->cj", graw, a1))
+    res["gb2"] = nm(be.host(gb2), graw.sum(axis=(0, 2)))
+    return res
+
+
 def check_loss_and_adam(be, n=10007, seed=5):
     api, P = be.api, be.ptr
     rng = np.random.default_rng(seed)

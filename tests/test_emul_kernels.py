@@ -84,6 +84,14 @@ def test_head(be, C, HW, act, which, ext):
     assert res["sums"] < 1e-5 and res["scores"] < 1e-5
 
 
+@pytest.mark.parametrize("C,HW,act,which,cap", [(20, 192, True, "nmse", 2), (6, 330, False, "mse", -1), (32, 128, True, "mae", -1)])
+def test_head_train_one_pass(be, C, HW, act, which, cap):
+    with K.tuned(be, head_blocks=cap):
+        res = K.check_head_train(be, 2, C, HW, act, which)
+    assert res.pop("sums") < 1e-5
+    _assert_all(res)
+
+
 def test_head_several_tiles_per_workgroup(be):
     """The head kernels' persistent loops (tile after tile per workgroup, staged planes / f'(a) handed from one tile to the
     next): at small sizes every workgroup would get a single tile, so the workgroup count is capped through the knob."""

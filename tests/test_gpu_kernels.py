@@ -96,6 +96,16 @@ def test_head(be, C, HW, act, which, ext):
     assert res["sums"] < 1e-5 and res["scores"] < 1e-5
 
 
+@pytest.mark.parametrize("C,HW,act,which,cap", [(20, 4096, True, "nmse", -1), (6, 4290, False, "mse", -1), (32, 4096, True, "mae", -1),
+                                                 (20, 4290, True, "nmse", 3), (8, 1000, True, "nmse", 1), (20, 64, True, "mse", -1)])
+def test_head_train_one_pass(be, C, HW, act, which, cap):
+    """Both directions of the head in one kernel (cfd_fno_head_train): the same references as test_head."""
+    with K.tuned(be, head_blocks=cap):
+        res = K.check_head_train(be, 3, C, HW, act, which)
+    assert res.pop("sums") < 1e-5
+    _assert_all(res)
+
+
 @pytest.mark.parametrize("cap", [1, 3, 16])
 def test_head_several_tiles_per_workgroup(be, cap):
     """The head kernels' persistent loops (several tiles per workgroup: staged planes and f'(a) handed from tile to tile)."""
