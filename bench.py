@@ -115,6 +115,7 @@ def attach_pmc(rl, name, applies):
     if not (rl and applies):
         return
     try:
+        name = {"k_head_train": "k_head_bwd"}.get(name, name)  # profiler label -> kernel symbol (the fused head is k_head_bwd<.., FUSE>)
         pmc = latest_profile("r*_pmc_traffic.json") or {}
         match = [v for k, v in pmc.items() if k.startswith(name + "<") or k == name]
         if match:

@@ -403,6 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                                            // (FUSE: label * mask of both channels; the gradient is formed in the phase)
     __shared__ float s_mk[FUSE ? 2 : 1][64];       // FUSE: mask by column (0 past the end of the image / of the work)
     __shared__ cfd_f2 s_pp[FUSE ? 2 : 1][4][16];   // FUSE: [phase parity][wave][pixel lane] partial fc2 sums of both outputs
+    __shared__ __attribute__((aligned(16))) float s_pv[2][FUSE ? 64 : 4];  // FUSE: the tile's predictions in pixel order (wave 0 only)
     const int lane = threadIdx.x & 63, wave = cfd_uniform(threadIdx.x >> 6);
     const int q = lane >> 4, n = lane & 15;
 #if CFD_HDIAG & 1024
@@ -457,7 +458,6 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     }
     float gb2a0 = 0.f, gb2a1 = 0.f;
     float lsq = 0.f, labs = 0.f;                                   // FUSE: loss sums (wave 0, lane group 0)
-    float pv0[4] = {0.f, 0.f, 0.f, 0.f}, pv1[4] = {0.f, 0.f, 0.f, 0.f};  // FUSE: predictions of the lane's pixels 4n .. 4n+3
     const float b2v0 = FUSE ? b2[0] : 0.f, b2v1 = (FUSE && Co > 1) ? b2[1] : 0.f;
     const int tpb = (HW + 63) / 64;
     const int total = B * tpb;  // < 2^30 (checked by the launcher)
@@ -669,11 +669,16 @@ CFD_UNROLL(CFD_HB_UNROLL)
                 const cfd_f2 lab = grp[col];
                 const float pr0 = (sp.x + b2v0) * mk, pr1 = (sp.y + b2v1) * mk;  // fno2d.py:233
                 const float d0 = pr0 - lab.x, d1 = pr1 - lab.y;
-                const float sg0 = d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f), sg1 = d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f);
-                const float gp0 = (c0 * 2.f * d0 + c1 * sg0) * mk, gp1 = (c0 * 2.f * d1 + c1 * sg1) * mk;
-                pv0[0] = pv0[1]; pv0[1] = pv0[2]; pv0[2] = pv0[3]; pv0[3] = pr0;
-                pv1[0] = pv1[1]; pv1[1] = pv1[2]; pv1[2] = pv1[3]; pv1[3] = pr1;
+                float gp0 = c0 * 2.f * d0, gp1 = c0 * 2.f * d1;
+                if (c1 != 0.f) {  // mae only (uniform)
+                    gp0 += c1 * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
+                    gp1 += c1 * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
+                }
+                gp0 *= mk;
+                gp1 *= mk;
                 if (wave == 0 && q == 0) {
+                    s_pv[0][4 * n + j] = pr0;
+                    s_pv[1][4 * n + j] = pr1;
                     lsq = fmaf(d0, d0, fmaf(d1, d1, lsq));
                     labs += fabsf(d0) + fabsf(d1);
                     gb2a0 += gp0;
@@ -793,20 +798,18 @@ CFD_UNROLL(CFD_HB_UNROLL)
             if (j == 1) CFD_TS(13);
         }
         if constexpr (FUSE) {
-            if (wave == 0 && q == 0) {  // predictions of the tile: pixels px0 + 4n .. 4n+3 of both output channels
+            if (wave == 0) cfd_wave_lds_sync();  // s_pv was written by this wave's lane group 0
+            if (wave == 0 && q < Co) {  // predictions of the tile: lane group q stores channel q, pixels px0 + 4n .. 4n+3
                 const int p4 = px0 + 4 * n;
+                const float4 pv = *reinterpret_cast<const float4*>(&s_pv[q][4 * n]);
+                float* dstp = preds_w + ((size_t)b * Co + q) * HW + p4;
+                if constexpr (VEC4) {
+                    if (p4 < HW) *reinterpret_cast<float4*>(dstp) = pv;
+                } else {
+                    const float pvv[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    if (c >= Co) continue;
-                    float* dstp = preds_w + ((size_t)b * Co + c) * HW + p4;
-                    const float* pv = c == 0 ? pv0 : pv1;
-                    if constexpr (VEC4) {
-                        if (p4 < HW) *reinterpret_cast<float4*>(dstp) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-                    } else {
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-                            if (p4 + jj < HW) dstp[jj] = pv[jj];
-                    }
+                    for (int jj = 0; jj < 4; ++jj)
+                        if (p4 + jj < HW) dstp[jj] = pvv[jj];
                 }
             }
         }

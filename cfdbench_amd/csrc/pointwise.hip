@@ -924,18 +924,40 @@ __global__ void k_loss_coef(const float* __restrict__ sums, float* __restrict__ 
 // d nmse / d p = 2 (p - l) / sum l^2, d mae / d p = sign(p - l) / n need nothing else from the forward pass (loss.py:27-35),
 // which is what lets the training head form predictions, loss sums and all gradients in one pass (head.hip, FUSE).
 // Two launches, fixed summation order: partial sums of 256 workgroups, then one workgroup finishes sums[2], sums[3], coef.
+template <int VEC>
 __global__ __launch_bounds__(256) void k_label_energy_part(const float* __restrict__ label, const float* __restrict__ mask,
-                                                           float* __restrict__ part, unsigned planes, unsigned HW,
-                                                           CfdDiv dCo) {
+                                                           float* __restrict__ part, unsigned total_units, unsigned HW,
+                                                           CfdDiv dU, CfdDiv dCo) {
+    // unit = VEC consecutive pixels of one (b, channel) plane; plane = unit / (HW / VEC), mask row = plane / Co
     __shared__ float s_red[4];
+    const unsigned U = HW / VEC;
     float acc = 0.f;
-    for (unsigned pl = blockIdx.x; pl < planes; pl += gridDim.x) {  // one (b, channel) plane at a time: the mask row is cfd_div(pl, Co)
-        const float* l = label + (size_t)pl * HW;
-        const float* m = mask ? mask + (size_t)cfd_div(pl, dCo) * HW : nullptr;
-        for (unsigned i = threadIdx.x; i < HW; i += blockDim.x) {
-            const float v = l[i] * (m ? m[i] : 1.f);
-            acc = fmaf(v, v, acc);
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned u0 = blockIdx.x * blockDim.x + threadIdx.x; u0 < total_units; u0 += 4 * stride) {
+        float lv[4][VEC], mv[4][VEC];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // four independent loads per operand in flight
+            const unsigned u = u0 + k * stride;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { lv[k][v] = 0.f; mv[k][v] = 1.f; }
+            if (u < total_units) {
+                const unsigned pl = cfd_div(u, dU), i = (u - pl * U) * VEC;
+                const float* l = label + (size_t)pl * HW + i;
+                const float* m = mask ? mask + (size_t)cfd_div(pl, dCo) * HW + i : nullptr;
+                if constexpr (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(l);
+                    lv[k][0] = t.x; lv[k][1] = t.y; lv[k][2] = t.z; lv[k][3] = t.w;
+                    if (m) { const float4 w = *reinterpret_cast<const float4*>(m); mv[k][0] = w.x; mv[k][1] = w.y; mv[k][2] = w.z; mv[k][3] = w.w; }
+                } else {
+                    lv[k][0] = l[0];
+                    if (m) mv[k][0] = m[0];
+                }
+            }
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { const float x = lv[k][v] * mv[k][v]; acc = fmaf(x, x, acc); }
     }
     acc = cfd_wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
@@ -969,11 +991,19 @@ extern "C" int cfd_label_energy_coef(const float* label, const float* mask, floa
     CFD_REQUIRE(B >= 1 && Co >= 1 && HW >= 1, CFD_ERR_INVALID_ARG, "cfd_label_energy_coef: bad sizes");
     CFD_REQUIRE(which >= 0 && which <= 2, CFD_ERR_INVALID_ARG, "cfd_label_energy_coef: which must be 0 (mse), 1 (nmse), 2 (mae)");
     hipStream_t st = (hipStream_t)stream;
-    const unsigned planes = (unsigned)B * Co;
-    const int blocks = planes < 256 ? (int)planes : 256;
+    CFD_REQUIRE_I31((long)B * Co * HW, "cfd_label_energy_coef");
+    const bool v4 = HW % 4 == 0 && ((uintptr_t)label % 16) == 0 && (!mask || ((uintptr_t)mask % 16) == 0);
+    const unsigned vec = v4 ? 4 : 1;
+    const unsigned units = (unsigned)((long)B * Co * HW / vec);
+    long want = ((long)units + 1023) / 1024;  // four units per thread
+    const int blocks = (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
     CFD_PROF_W("k_label_energy", st, 4.0 * B * HW * (Co + 1.0), 2.0 * B * Co * HW);
-    hipLaunchKernelGGL(k_label_energy_part, dim3(blocks), dim3(256), 0, st, label, mask, (float*)ws, planes, (unsigned)HW,
-                       cfd_div_make((unsigned)Co));
+    if (v4)
+        hipLaunchKernelGGL((k_label_energy_part<4>), dim3(blocks), dim3(256), 0, st, label, mask, (float*)ws, units, (unsigned)HW,
+                           cfd_div_make((unsigned)HW / 4), cfd_div_make((unsigned)Co));
+    else
+        hipLaunchKernelGGL((k_label_energy_part<1>), dim3(blocks), dim3(256), 0, st, label, mask, (float*)ws, units, (unsigned)HW,
+                           cfd_div_make((unsigned)HW), cfd_div_make((unsigned)Co));
     CFD_LAUNCH_CHECK("cfd_label_energy_coef(part)");
     hipLaunchKernelGGL(k_label_energy_coef, dim3(1), dim3(64), 0, st, (const float*)ws, blocks, (float)((double)B * Co * HW), sums,
                        coef, which, upstream);
