@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     __shared__ cfd_f2 s_gr[2][64];         // [buffer][column] upstream gradient on the raw head output, both channels
                                            // (FUSE: label * mask of both channels; the gradient is formed in the phase)
     __shared__ float s_mk[FUSE ? 2 : 1][64];       // FUSE: mask by column (0 past the end of the image / of the work)
-    __shared__ cfd_f2 s_pp[FUSE ? 2 : 1][4][16];   // FUSE: [phase parity][wave][pixel lane] partial fc2 sums of both outputs
+    __shared__ cfd_f2 s_pp[FUSE ? 4 : 1][4][16];   // FUSE: [phase parity][wave][pixel lane] partial fc2 sums of both outputs
     __shared__ __attribute__((aligned(16))) float s_pv[2][FUSE ? 64 : 4];  // FUSE: the tile's predictions in pixel order (wave 0 only)
     const int lane = threadIdx.x & 63, wave = cfd_uniform(threadIdx.x >> 6);
     const int q = lane >> 4, n = lane & 15;
@@ -618,14 +618,12 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
         const __bf16* hk_lo = s_hk[buf][1];
         const __bf16* ht_hi = s_ht[buf][0];
         const __bf16* ht_lo = s_ht[buf][1];
-CFD_UNROLL(CFD_HB_UNROLL)
-        for (int j = 0; j < 4; ++j) {
+        auto front = [&](int j, f32x4 (&z)[2]) {
             // 1. recompute this wave's slice of the hidden pre-activation z[hidden][pixel n]
             const int col = 16 * j + n;
             if (j == 1) CFD_TS(8);
             const bf16x8 hhi = *reinterpret_cast<const bf16x8*>(hk_hi + col * LDK + 8 * q);
             const bf16x8 hlo = *reinterpret_cast<const bf16x8*>(hk_lo + col * LDK + 8 * q);
-            f32x4 z[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) z[t] = f32x4{bz[t][0], bz[t][1], bz[t][2], bz[t][3]};
 #if !(CFD_HDIAG & 2)
@@ -639,89 +637,8 @@ CFD_UNROLL(CFD_HB_UNROLL)
 #pragma unroll
             for (int t = 0; t < 2; ++t) z[t][0] += (float)hhi[t] + (float)hlo[t];
 #endif
-            // 2. a1 = gelu(z) feeds the fc2 weight gradient; gz = (W2^T graw) * gelu'(z), k-slot 4t + r
-            if (j == 1) CFD_TS(9);
-            float gzv[8];
-            if constexpr (FUSE) {
-                // forward half of the phase: GELU terms once, this wave's share of fc2, the workgroup's sum -> prediction,
-                // loss terms and the gradient on the raw output; then the backward half on the kept terms
-                cfd_f2 a1k[2][2], gdk[2][2];
-                cfd_f2 po0 = {0.f, 0.f}, po1 = {0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int v = 0; v < 2; ++v) {
-                        const cfd_f2 zz = {z[t][2 * v], z[t][2 * v + 1]};
-                        cfd_f2 Phi, e;
-                        cfd_gelu_terms2(zz, Phi, e);
-                        a1k[t][v] = zz * Phi;
-                        gdk[t][v] = cfd_fma2(zz * (cfd_f2)(CFD_INV_SQRT_2PI), e, Phi);
-                        po0 = cfd_fma2(w2a[t][v], a1k[t][v], po0);
-                        po1 = cfd_fma2(w2b[t][v], a1k[t][v], po1);
-                    }
-                const float p0 = cfd_row_sum4(po0.x + po0.y), p1 = cfd_row_sum4(po1.x + po1.y);  // over the four lane groups
-                if (q == 0) s_pp[j & 1][wave][n] = cfd_f2{p0, p1};
-                __syncthreads();  // the other parity's slots are rewritten one phase later, after every wave has passed this point again
-                cfd_f2 sp = s_pp[j & 1][0][n];
-#pragma unroll
-                for (int wv = 1; wv < 4; ++wv) sp = sp + s_pp[j & 1][wv][n];
-                const float mk = s_mk[buf][col];
-                const cfd_f2 lab = grp[col];
-                const float pr0 = (sp.x + b2v0) * mk, pr1 = (sp.y + b2v1) * mk;  // fno2d.py:233
-                const float d0 = pr0 - lab.x, d1 = pr1 - lab.y;
-                float gp0 = c0 * 2.f * d0, gp1 = c0 * 2.f * d1;
-                if (c1 != 0.f) {  // mae only (uniform)
-                    gp0 += c1 * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
-                    gp1 += c1 * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
-                }
-                gp0 *= mk;
-                gp1 *= mk;
-                if (wave == 0 && q == 0) {
-                    s_pv[0][4 * n + j] = pr0;
-                    s_pv[1][4 * n + j] = pr1;
-                    lsq = fmaf(d0, d0, fmaf(d1, d1, lsq));
-                    labs += fabsf(d0) + fabsf(d1);
-                    gb2a0 += gp0;
-                    gb2a1 += gp1;
-                }
-                const cfd_f2 g0 = (cfd_f2)(gp0), g1 = (cfd_f2)(gp1);
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int v = 0; v < 2; ++v) {
-                        acc2a[t][v] = cfd_fma2(g0, a1k[t][v], acc2a[t][v]);
-                        acc2b[t][v] = cfd_fma2(g1, a1k[t][v], acc2b[t][v]);
-                        const cfd_f2 ga1 = cfd_fma2(w2a[t][v], g0, w2b[t][v] * g1);
-                        const cfd_f2 gz = ga1 * gdk[t][v];
-                        accb1[t][v] = accb1[t][v] + gz;
-                        gzv[4 * t + 2 * v] = gz.x;
-                        gzv[4 * t + 2 * v + 1] = gz.y;
-                    }
-            } else {
-            const cfd_f2 grj = grp[col];
-            const cfd_f2 g0 = (cfd_f2)(grj.x), g1 = (cfd_f2)(grj.y);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int v = 0; v < 2; ++v) {  // packed pairs of hidden units r = 2v, 2v+1
-                    const cfd_f2 zz = {z[t][2 * v], z[t][2 * v + 1]};
-                    cfd_f2 Phi, e;
-#if CFD_HDIAG & 1
-                    Phi = zz + (cfd_f2)(0.5f);
-                    e = zz;
-#else
-                    cfd_gelu_terms2(zz, Phi, e);
-#endif
-                    const cfd_f2 a1 = zz * Phi;
-                    acc2a[t][v] = cfd_fma2(g0, a1, acc2a[t][v]);
-                    acc2b[t][v] = cfd_fma2(g1, a1, acc2b[t][v]);
-                    const cfd_f2 ga1 = cfd_fma2(w2a[t][v], g0, w2b[t][v] * g1);
-                    const cfd_f2 gz = ga1 * cfd_fma2(zz * (cfd_f2)(CFD_INV_SQRT_2PI), e, Phi);
-                    accb1[t][v] = accb1[t][v] + gz;
-                    gzv[4 * t + 2 * v] = gz.x;
-                    gzv[4 * t + 2 * v + 1] = gz.y;
-                }
-            }
+        };
+        auto back = [&](int j, const float (&gzv)[8]) {
             if (j == 1) CFD_TS(10);
 #if !(CFD_HDIAG & 16)
             const CfdSplit8 gs = cfd_split8(gzv);
@@ -796,6 +713,128 @@ CFD_UNROLL(CFD_HB_UNROLL)
                 cfd_wave_lds_sync();
             }
             if (j == 1) CFD_TS(13);
+        };
+        if constexpr (FUSE) {
+            // Two pixel phases per workgroup barrier: both phases' forward halves (GELU terms kept in registers, this wave's share
+            // of fc2 into LDS), ONE barrier, then both backward halves.  Four slot pairs of s_pp rotate (pair parity x phase), so
+            // a fast wave's next writes never meet a slow wave's reads.
+            auto fwd_half = [&](int j, int slot, const f32x4 (&z)[2], cfd_f2 (&a1k)[2][2], cfd_f2 (&gdk)[2][2]) {
+                // forward half of the phase: GELU terms once, this wave's share of fc2, the workgroup's sum -> prediction,
+                // loss terms and the gradient on the raw output; then the backward half on the kept terms
+                cfd_f2 po0 = {0.f, 0.f}, po1 = {0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        const cfd_f2 zz = {z[t][2 * v], z[t][2 * v + 1]};
+                        cfd_f2 Phi, e;
+                        cfd_gelu_terms2(zz, Phi, e);
+                        a1k[t][v] = zz * Phi;
+                        gdk[t][v] = cfd_fma2(zz * (cfd_f2)(CFD_INV_SQRT_2PI), e, Phi);
+                        po0 = cfd_fma2(w2a[t][v], a1k[t][v], po0);
+                        po1 = cfd_fma2(w2b[t][v], a1k[t][v], po1);
+                    }
+                const float p0 = cfd_row_sum4(po0.x + po0.y), p1 = cfd_row_sum4(po1.x + po1.y);  // over the four lane groups
+                if (q == 0) s_pp[slot][wave][n] = cfd_f2{p0, p1};
+            };
+            auto bwd_half = [&](int j, int slot, const cfd_f2 (&a1k)[2][2], const cfd_f2 (&gdk)[2][2], float (&gzv)[8]) {
+                const int col = 16 * j + n;
+                cfd_f2 sp = s_pp[slot][0][n];
+#pragma unroll
+                for (int wv = 1; wv < 4; ++wv) sp = sp + s_pp[slot][wv][n];
+                const float mk = s_mk[buf][col];
+                const cfd_f2 lab = grp[col];
+                const float pr0 = (sp.x + b2v0) * mk, pr1 = (sp.y + b2v1) * mk;  // fno2d.py:233
+                const float d0 = pr0 - lab.x, d1 = pr1 - lab.y;
+                float gp0 = c0 * 2.f * d0, gp1 = c0 * 2.f * d1;
+                if (c1 != 0.f) {  // mae only (uniform)
+                    gp0 += c1 * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
+                    gp1 += c1 * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
+                }
+                gp0 *= mk;
+                gp1 *= mk;
+                if (wave == 0 && q == 0) {
+                    s_pv[0][4 * n + j] = pr0;
+                    s_pv[1][4 * n + j] = pr1;
+                    lsq = fmaf(d0, d0, fmaf(d1, d1, lsq));
+                    labs += fabsf(d0) + fabsf(d1);
+                    gb2a0 += gp0;
+                    gb2a1 += gp1;
+                }
+                const cfd_f2 g0 = (cfd_f2)(gp0), g1 = (cfd_f2)(gp1);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        acc2a[t][v] = cfd_fma2(g0, a1k[t][v], acc2a[t][v]);
+                        acc2b[t][v] = cfd_fma2(g1, a1k[t][v], acc2b[t][v]);
+                        const cfd_f2 ga1 = cfd_fma2(w2a[t][v], g0, w2b[t][v] * g1);
+                        const cfd_f2 gz = ga1 * gdk[t][v];
+                        accb1[t][v] = accb1[t][v] + gz;
+                        gzv[4 * t + 2 * v] = gz.x;
+                        gzv[4 * t + 2 * v + 1] = gz.y;
+                    }
+            };
+#pragma unroll 1
+            for (int jp = 0; jp < 4; jp += 2) {
+                cfd_f2 a1k0[2][2], gdk0[2][2], a1k1[2][2], gdk1[2][2];
+                const int slot0 = jp, slot1 = jp + 1;
+                {
+                    f32x4 z[2];
+                    front(jp, z);
+                    fwd_half(jp, slot0, z, a1k0, gdk0);
+                }
+                {
+                    f32x4 z[2];
+                    front(jp + 1, z);
+                    fwd_half(jp + 1, slot1, z, a1k1, gdk1);
+                }
+                __syncthreads();
+                {
+                    float gzv[8];
+                    bwd_half(jp, slot0, a1k0, gdk0, gzv);
+                    back(jp, gzv);
+                }
+                {
+                    float gzv[8];
+                    bwd_half(jp + 1, slot1, a1k1, gdk1, gzv);
+                    back(jp + 1, gzv);
+                }
+            }
+        } else {
+CFD_UNROLL(CFD_HB_UNROLL)
+            for (int j = 0; j < 4; ++j) {
+                f32x4 z[2];
+                front(j, z);
+                const int col = 16 * j + n;
+                // 2. a1 = gelu(z) feeds the fc2 weight gradient; gz = (W2^T graw) * gelu'(z), k-slot 4t + r
+                if (j == 1) CFD_TS(9);
+                float gzv[8];
+            const cfd_f2 grj = grp[col];
+            const cfd_f2 g0 = (cfd_f2)(grj.x), g1 = (cfd_f2)(grj.y);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {  // packed pairs of hidden units r = 2v, 2v+1
+                    const cfd_f2 zz = {z[t][2 * v], z[t][2 * v + 1]};
+                    cfd_f2 Phi, e;
+#if CFD_HDIAG & 1
+                    Phi = zz + (cfd_f2)(0.5f);
+                    e = zz;
+#else
+                    cfd_gelu_terms2(zz, Phi, e);
+#endif
+                    const cfd_f2 a1 = zz * Phi;
+                    acc2a[t][v] = cfd_fma2(g0, a1, acc2a[t][v]);
+                    acc2b[t][v] = cfd_fma2(g1, a1, acc2b[t][v]);
+                    const cfd_f2 ga1 = cfd_fma2(w2a[t][v], g0, w2b[t][v] * g1);
+                    const cfd_f2 gz = ga1 * cfd_fma2(zz * (cfd_f2)(CFD_INV_SQRT_2PI), e, Phi);
+                    accb1[t][v] = accb1[t][v] + gz;
+                    gzv[4 * t + 2 * v] = gz.x;
+                    gzv[4 * t + 2 * v + 1] = gz.y;
+                }
+                back(j, gzv);
+            }
         }
         if constexpr (FUSE) {
             if (wave == 0) cfd_wave_lds_sync();  // s_pv was written by this wave's lane group 0
