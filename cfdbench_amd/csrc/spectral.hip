@@ -1854,7 +1854,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                                                    const float* __restrict__ w, const float* __restrict__ bias,
                                                    const float* __restrict__ aprev, float* __restrict__ dst,
                                                    const bf16x8* __restrict__ tabs3, int Cs, int Cd, int H, int m1,
-                                                   int m2, int T, int SA, int SB, const CfdReduceTail tail) {
+                                                   int m2, int T, int SA, int SB, const CfdReduceTail tail, int SPL) {
     if (TAIL && (int)blockIdx.x < tail.nblk) {
         cfd_reduce_tail(tail, blockIdx.x);
         return;
@@ -1879,14 +1879,18 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     const int lane = threadIdx.x & 63;
     const int wave = cfd_uniform(threadIdx.x >> 6);
     const int q = lane >> 4, n = lane & 15;
-    const int b = TAIL ? (int)blockIdx.x - tail.nblk : (int)blockIdx.x;
+    // SPL workgroups share a batch entry by row tiles (SPL divides T): with fewer batch entries than CUs one workgroup per
+    // entry leaves most of the chip idle for the same ~45 us (B = 64: 44.9 us against 24.8 for the two-pass route); every
+    // tile is computed exactly as in the unsplit kernel, so a sample's result does not depend on the batch size
+    const int bi = TAIL ? (int)blockIdx.x - tail.nblk : (int)blockIdx.x;
+    const int b = bi / SPL, TPW = T / SPL, t0 = (bi - b * SPL) * TPW;
     const int HW = H * W;
     const int M2 = 4 * m1 * m2;
-    const int G = T * NCH;  // chunks of this batch entry, streamed tile after tile; chunk g lives in buffer g & 1
+    const int G = TPW * NCH;  // chunks of this workgroup's tiles, streamed tile after tile; chunk g lives in buffer g & 1
     // ---- this wave's slice of a source chunk: channel ((g % NCH)*NW + wave) of tile g / NCH, rows 4k+q ----
     float4 R[2][4];
     auto fetch = [&](int g, float4 (&r)[4]) {
-        const int t = g / NCH, ch = (g - t * NCH) * NW + wave;
+        const int tl = g / NCH, ch = (g - tl * NCH) * NW + wave, t = t0 + tl;
         const float* p = src + ((size_t)b * Cs + (ch < Cs ? ch : 0)) * HW + (size_t)(16 * t + q) * W + 4 * n;
 #pragma unroll
         for (int k = 0; k < 4; ++k) r[k] = *reinterpret_cast<const float4*>(p + (size_t)4 * k * W);
@@ -1967,8 +1971,9 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     };
     // One 16-row tile.  PAR = parity of the tile's first chunk index (compile time, so the prefetch registers and
     // LDS buffers are indexed statically even when NCH is odd).
-    auto tile = [&](auto par_c, int t) {
+    auto tile = [&](auto par_c, int tl) {
         constexpr int PAR = decltype(par_c)::value;
+        const int t = t0 + tl;
         f32x4 acc[DPW][NJ];
 #pragma unroll
         for (int dd = 0; dd < DPW; ++dd)
@@ -1976,7 +1981,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
             for (int j = 0; j < NJ; ++j) acc[dd][j] = f32x4{bv[dd], bv[dd], bv[dd], bv[dd]};
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int g = t * NCH + c;
+            const int g = tl * NCH + c;
             const int par = (PAR + c) & 1;
             if (t == 1 && c == 0) CFD_BTS(6);
             commit(c, par, R[par]);
@@ -2072,11 +2077,11 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
         }
     };
 #pragma unroll 1
-    for (int t = 0; t < T; t += 2) {
+    for (int t = 0; t < TPW; t += 2) {  // local tile index
         tile(CfdParity<0>{}, t);
         if (t == 0) CFD_BTS(2);
         if (t == 2) CFD_BTS(4);
-        if (t + 1 < T) {
+        if (t + 1 < TPW) {
             if constexpr (NCH % 2 == 1) tile(CfdParity<1>{}, t + 1);
             else tile(CfdParity<0>{}, t + 1);
         }
@@ -2106,10 +2111,13 @@ static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z
                              hipStream_t st, const CfdReduceTail* tail) {
     const bool ride = trans && tail && tail->nblk > 0;
     const CfdReduceTail tl = ride ? *tail : CfdReduceTail{};
-    const dim3 grid(B + tl.nblk), block(64 * NW);  // one workgroup per batch entry, tiles streamed inside
+    // one workgroup per batch entry, tiles streamed inside; below ~3/4 of the CU count the entries are split by row tiles
+    int spl = 1;
+    while (spl * 2 <= p->T && p->T % (spl * 2) == 0 && (long)B * spl * 2 <= 288) spl *= 2;
+    const dim3 grid(B * spl + tl.nblk), block(64 * NW);
 #define CFD_BLK(A_, T_, D_, R_)                                                                                  \
     hipLaunchKernelGGL((k_block<NW, DPW, NCH, A_, T_, D_, R_>), grid, block, 0, st, src, z, w, bias, aprev, dst, \
-                       (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB, tl)
+                       (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB, tl, spl)
     if (!trans) { if (act) CFD_BLK(true, false, false, false); else CFD_BLK(false, false, false, false); }
     else if (ride) { if (dgelu) CFD_BLK(false, true, true, true); else CFD_BLK(false, true, false, true); }
     else { if (dgelu) CFD_BLK(false, true, true, false); else CFD_BLK(false, true, false, false); }
