@@ -238,8 +238,14 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64(const float* __
 // slot is re-armed the moment its rows are folded, running on into the wave's next image); the folded values collect
 // in registers until the image's eight k-steps are in and the MFMAs issue in one burst.
 #define CFD_DFT3_TABV (7 * 2 * 64)  // 16-byte vectors of the split forward tables
+#ifndef CFD_DFT_RING
+#define CFD_DFT_RING 3  // row-quads in flight per wave (1, 3 or 9 = the whole image)
+#endif
+#ifndef CFD_DFT_OCC
+#define CFD_DFT_OCC 3  // workgroups per CU the forward kernel is compiled for
+#endif
 template <int D, bool ACT>
-__global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64_b3(const float* __restrict__ x, float2* __restrict__ xh,
+__global__ __launch_bounds__(64 * CFD_WAVES, CFD_DFT_OCC) void k_dft_fwd64_b3(const float* __restrict__ x, float2* __restrict__ xh,
                                                                      const bf16x8* __restrict__ tabs3, int nimg, int m1,
                                                                      int m2) {
     constexpr int H = 64, W = 64, NJ = 4, KXT = 9;
@@ -552,10 +558,10 @@ static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, in
 #endif
             if (blocks > CFD_DFT_CAP) blocks = CFD_DFT_CAP;  // 3 resident workgroups per CU; the waves stride over the images
             if (act)
-                hipLaunchKernelGGL((k_dft_fwd64_b3<3, true>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
+                hipLaunchKernelGGL((k_dft_fwd64_b3<CFD_DFT_RING, true>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
                                    (const bf16x8*)p->d_fwd_b3, nimg, p->m1, p->m2);
             else
-                hipLaunchKernelGGL((k_dft_fwd64_b3<3, false>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
+                hipLaunchKernelGGL((k_dft_fwd64_b3<CFD_DFT_RING, false>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
                                    (const bf16x8*)p->d_fwd_b3, nimg, p->m1, p->m2);
             CFD_LAUNCH_CHECK("cfd_spectral_dft");
             return CFD_OK;
