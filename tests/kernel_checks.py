@@ -155,6 +155,35 @@ def check_block(be, B, Cin, Cout, H, W, m1=12, m2=12, seed=12):
         api.plan_destroy(plan)
 
 
+def check_block_batch_split(be, Bbig, Bsmall, C, H, W, m1=12, m2=12, seed=13):
+    """The fused FnoBlock kernel splits batch entries over several workgroups (by row tiles) when there are fewer entries than
+    CUs: the first Bsmall entries computed alone (split) must equal, bit for bit, the same entries inside a batch of Bbig (one
+    workgroup per entry) -- forward with GELU on load and the gelu' input gradient."""
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((Bbig, C, H, W)).astype(np.float32)
+    g = rng.standard_normal((Bbig, C, H, W)).astype(np.float32)
+    z = (rng.standard_normal((Bbig, C, 2 * m1, m2)) + 1j * rng.standard_normal((Bbig, C, 2 * m1, m2))).astype(np.complex64)
+    w0 = rng.standard_normal((C, C)).astype(np.float32)
+    b0 = rng.standard_normal((C,)).astype(np.float32)
+    plan = api.plan_create(H, W, m1, m2)
+    try:
+        da, dg, dz, dw, db = be.dev(a), be.dev(g), be.dev(z), be.dev(w0), be.dev(b0)
+        res = {}
+        outs = []
+        for B in (Bbig, Bsmall):
+            out, gin = be.zeros((B, C, H, W)), be.zeros((B, C, H, W))
+            api.call("cfd_fno_block_fwd", plan, P(da), P(dz), P(dw), P(db), P(out), B, C, C, 1, be.stream)
+            api.call("cfd_fno_block_bwd_input", plan, P(dg), P(dz), P(dw), P(da), P(gin), B, C, C, be.stream)
+            be.sync()
+            outs.append((be.host(out), be.host(gin)))
+        res["fwd_bitwise"] = float(np.max(np.abs(outs[0][0][:Bsmall] - outs[1][0])))
+        res["bwd_bitwise"] = float(np.max(np.abs(outs[0][1][:Bsmall] - outs[1][1])))
+        return res
+    finally:
+        api.plan_destroy(plan)
+
+
 def check_idft_epilogues(be, nimg, H, W, m1=12, m2=12, seed=1):
     api, P = be.api, be.ptr
     rng = np.random.default_rng(seed)

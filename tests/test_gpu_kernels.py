@@ -59,6 +59,12 @@ def test_fused_block(be, B, Cin, Cout, H, W):
     _assert_all(K.check_block(be, B, Cin, Cout, H, W))
 
 
+@pytest.mark.parametrize("Bbig,Bsmall,C,H", [(160, 7, 20, 64), (150, 40, 8, 64), (148, 100, 32, 32)])
+def test_fused_block_batch_split_is_bitwise_neutral(be, Bbig, Bsmall, C, H):
+    res = K.check_block_batch_split(be, Bbig, Bsmall, C, H, 64)
+    assert res["fwd_bitwise"] == 0.0 and res["bwd_bitwise"] == 0.0, res
+
+
 @pytest.mark.parametrize("B,C,L,H,W", [(3, 20, 2, 66, 65), (2, 32, 4, 66, 65), (2, 20, 4, 64, 64), (2, 8, 1, 48, 64)])
 def test_bf16_activation_storage_forward(be, B, C, L, H, W):
     """BASELINE configs[4] storage format: cfd_fno_forward_ex(act_dtype = bf16) against the oracle with the same rule (the
