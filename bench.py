@@ -15,6 +15,7 @@ Rank 0 prints ONE JSON line.  Beside the contract's keys it carries
   kernels                   every kernel of the step: launches, average time, HBM fraction
   exact_fp32                the same step and SpectralConv2d group with the transforms on the exact-fp32 kernels (cfd_tune_set("exact_fp32", 1))
   rollout / rollout_66x65   batched multi-step inference from one HIP graph (configs[4] horizon: 200 steps)
+  train_66x65 / train_batch8  the same train step on the 66x65 grid (dam / tube / cylinder) and at the reference's default batch 8
   unet_cfg2 / auto_deeponet_cfg3   train steps of BASELINE configs[2] / configs[3] on one GPU
   cpu_baseline              the reference's ATen call sequence on the host cores, at B = 256 and B = 32
 The extra legs run on rank 0 at N = 1 only.
@@ -394,6 +395,28 @@ def main():
         except TypeError:
             result["rollout_66x65_bf16"] = None  # bf16 activation storage not built in this tree
         del m32
+
+    # ---- the training step on the 66 x 65 grid of the dam / tube / cylinder problems, and at the reference's default batch ----
+    if extra and not args.no_extra:
+        def train_leg(Bx, Hx, Wx, Cx, what):
+            torch.manual_seed(0)
+            mx = Fno2d(2, 2, p, loss_name_to_fn("nmse"), L, 12, 12, Cx).to(dev)
+            ex = FnoTrainEngine(mx, lr=1e-3, loss_name="nmse")
+            gx = torch.Generator(device="cpu").manual_seed(4321)
+            xi = torch.randn(Bx, 2, Hx, Wx, generator=gx).to(dev)
+            lb = (xi.cpu() + 0.1 * torch.randn(Bx, 2, Hx, Wx, generator=gx)).to(dev)
+            cpx = torch.randn(Bx, p, generator=gx).to(dev)
+            mk = torch.ones(Bx, 1, Hx, Wx, device=dev)
+            dt = time_steps(lambda: ex.train_step(xi, lb, cpx, mk), max(args.steps, 20), 10)
+            bpf = fno_step_bytes_per_frame(Cx, L, Hx * Wx)
+            return dict(what=what, ms_per_step=round(dt * 1e3, 4), frames_per_s=round(Bx / dt, 1),
+                        roofline_step=dict(bound="hbm", bytes_per_frame=bpf, achieved=round(Bx / dt * bpf / 1e9, 1), peak=HBM_PEAK_GBS,
+                                           unit="GB/s", frac=round(Bx / dt * bpf / 1e9 / HBM_PEAK_GBS, 4)))
+        try:
+            result["train_66x65"] = train_leg(B, 66, 65, C, f"the same train step on the 66x65 grid (general-width kernels), batch {B}, hidden {C}")
+            result["train_batch8"] = train_leg(8, H, W, C, f"the same train step at the reference's default batch size 8 (src/args.py:44), {H}x{W}, hidden {C}")
+        except Exception as e:  # noqa: BLE001
+            result["train_66x65"] = dict(error=str(e)[:200])
 
     # ---- the same step with exact-fp32 contractions (the split-bf16 trade on the record) ------------------------------
     if extra and not args.no_extra:
