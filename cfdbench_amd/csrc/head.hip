@@ -409,8 +409,6 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
 #if CFD_HDIAG & 1024
     const long long ts_entry = __builtin_readcyclecounter(), rt_entry = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    for (int i = threadIdx.x; i < 2 * 2 * 64 * LDK; i += blockDim.x) (&s_hk[0][0][0])[i] = (__bf16)0.f;
-    for (int i = threadIdx.x; i < 2 * 2 * HTR * LDT; i += blockDim.x) (&s_ht[0][0][0])[i] = (__bf16)0.f;
     __bf16* s_xhw = s_x[wave][0];
     __bf16* s_xlw = s_x[wave][1];
     // ---- loop-invariant fragments of this wave's hidden slice ----
@@ -418,33 +416,6 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     CfdSplit8 w1t[MU];  // A operand of d/dh = W1^T gz:  w1[32w + 16(v/4) + 4q + v%4][16mu + n]
     float bz[2][4];                // b1 at hidden unit 32w + 16t + 4q + r
     cfd_f2 w2a[2][2], w2b[2][2];   // w2[0], w2[1] at hidden units 32w + 16t + 4q + {2v, 2v+1}
-    {
-        float x[8];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int v = 0; v < 8; ++v) x[v] = (8 * q + v < C) ? w1[(32 * wave + 16 * t + n) * C + 8 * q + v] : 0.f;
-            w1f[t] = cfd_split8(x);
-        }
-#pragma unroll
-        for (int mu = 0; mu < MU; ++mu) {
-#pragma unroll
-            for (int v = 0; v < 8; ++v) {
-                const int jh = 32 * wave + 16 * (v >> 2) + 4 * q + (v & 3);
-                x[v] = (16 * mu + n < C) ? w1[jh * C + 16 * mu + n] : 0.f;
-            }
-            w1t[mu] = cfd_split8(x);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int jh = 32 * wave + 16 * t + 4 * q + r;
-            bz[t][r] = b1[jh];
-            w2a[t][r >> 1][r & 1] = w2[jh];
-            w2b[t][r >> 1][r & 1] = Co > 1 ? w2[HEAD_HD + jh] : 0.f;
-        }
     const float c0 = label ? coef[0] : 0.f, c1 = label ? coef[1] : 0.f;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 aw1[2][MU];
@@ -586,10 +557,41 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
             }
         }
     };
-    __syncthreads();  // planes zeroed
+    // prologue: the first tile's global loads go out FIRST; the LDS planes are zeroed and the weight fragments loaded while
+    // they are in flight (the first version did these one after the other: two exposed memory latencies per workgroup)
     TileAt t0 = locate((int)blockIdx.x), t1 = locate((int)blockIdx.x + (int)gridDim.x);
     fetch(t0);
     fetch_gr(t0);
+    for (int i = threadIdx.x; i < 2 * 2 * 64 * LDK; i += blockDim.x) (&s_hk[0][0][0])[i] = (__bf16)0.f;
+    for (int i = threadIdx.x; i < 2 * 2 * HTR * LDT; i += blockDim.x) (&s_ht[0][0][0])[i] = (__bf16)0.f;
+    {
+        float x[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) x[v] = (8 * q + v < C) ? w1[(32 * wave + 16 * t + n) * C + 8 * q + v] : 0.f;
+            w1f[t] = cfd_split8(x);
+        }
+#pragma unroll
+        for (int mu = 0; mu < MU; ++mu) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int jh = 32 * wave + 16 * (v >> 2) + 4 * q + (v & 3);
+                x[v] = (16 * mu + n < C) ? w1[jh * C + 16 * mu + n] : 0.f;
+            }
+            w1t[mu] = cfd_split8(x);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jh = 32 * wave + 16 * t + 4 * q + r;
+            bz[t][r] = b1[jh];
+            w2a[t][r >> 1][r & 1] = w2[jh];
+            w2b[t][r >> 1][r & 1] = Co > 1 ? w2[HEAD_HD + jh] : 0.f;
+        }
+    __syncthreads();  // planes zeroed
     stage(0);
     stage_gr(0);
 #pragma unroll
