@@ -142,7 +142,16 @@ def fno_step_bytes_per_frame(C, L, HW, training=True):
 # ----------------------------------------------------------------------------------------------------------------------
 # legs
 # ----------------------------------------------------------------------------------------------------------------------
+def settle():
+    """Between legs: collect the previous leg's engines / graphs NOW (their destruction -- hipGraphExecDestroy, pool frees -- is
+    host-synchronous and otherwise lands inside the next leg's timed loop: 3-ms outliers were observed) and drain the device."""
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+
+
 def time_steps(fn, steps, warmup):
+    settle()
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -181,6 +190,7 @@ def spectral_leg(api, _lib, dev, B, C, H, W, reps):
         api.call("cfd_spectral_conv2d_bwd", plan, gy.data_ptr(), xh.data_ptr(), w1.data_ptr(), w2.data_ptr(), gx.data_ptr(),
                  gw1.data_ptr(), gw2.data_ptr(), ws.data_ptr(), B, C, C, st)
 
+    settle()
     for _ in range(3):
         spec()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -210,7 +220,7 @@ def rollout_leg(model, B, steps, H, W, p, dev, reps=3, dtype="f32"):
     kw = {} if dtype == "f32" else dict(dtype=dtype)
     ro = FnoRollout(model, **kw)
     ro.generate_frames(x0, cp, mask, steps)  # builds + captures the graph
-    torch.cuda.synchronize()
+    settle()
     t0 = time.perf_counter()
     for _ in range(reps):
         fr = ro.generate_frames(x0, cp, mask, steps)  # the graph's own frame buffer: no copies in the timed region
