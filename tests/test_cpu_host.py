@@ -224,3 +224,25 @@ def test_uneven_frame_count_runs_in_lockstep_gloo_world2():
     assert res[0][1] == res[1][1] == 2  # 31 frames -> 16 kept -> 8 per rank -> 1 step per epoch
     assert res[0][2] == res[1][2] == 1.0 and res[0][3] == res[1][3] == 0.0  # rank 0's state everywhere
     assert res[0][4] == res[1][4] == 0.5 and res[0][5] == res[1][5] == 0
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """The newest profiles/r*_bench.json (a bench.py line measured on MI355X) carries every key of the bench contract, the
+    roofline object of the dominant kernel and the CPU baseline -- a guard against editing a key away."""
+    import json
+    files = sorted((REPO / "profiles").glob("r*_bench.json"))
+    assert files, "no committed bench line"
+    line = json.loads(files[-1].read_text().strip().splitlines()[-1])
+    for key, typ in dict(metric=str, value=(int, float), unit=str, n_gpus=int, steps=int, warmup=int, ms_per_step=(int, float),
+                         higher_is_better=bool, scaling=str, dtype=str, data=str, config=dict).items():
+        assert isinstance(line[key], typ), key
+    assert "vs_baseline" in line and line["scaling"] == "weak" and line["higher_is_better"] is True
+    assert "workload" in line["config"] and "model" not in line["config"]
+    base = json.loads((REPO / "BASELINE.json").read_text())
+    assert "train frames/sec" in base["metric"] and line["metric"].startswith("train frames/sec") and line["unit"] == "frames/s"
+    rl = line["roofline"]
+    assert rl["bound"] in ("hbm", "mfma") and rl["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3 and "traffic" in rl
+    cb = line["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
+    assert line["value"] > 1000 * cb["value"]  # a sanity bound, not a target: the GPU path is the product
