@@ -53,6 +53,8 @@ for B in (int(v) for v in os.environ.get("BATCHES", "4,37").split(",")):
         "stem_bwd": (lambda: api.call("cfd_fno_stem_bwd", plan, P(gg), P(inputs), P(mask), P(cp), P(gfc0w), P(gfc0b), P(ws), B, 2, 5, C, st), [gfc0w, gfc0b]),
         "head_fwd": (lambda: api.call("cfd_fno_head_fwd", P(a), P(mask), P(label), P(fc1w), P(fc1b), P(fc2w), P(fc2b), P(preds), P(sums), P(ws), B, C, 128, 2, HW, 1, st), [preds, sums]),
         "head_bwd": (lambda: api.call("cfd_fno_head_bwd", P(a), P(mask), P(label), P(preds), None, P(coef), P(fc1w), P(fc1b), P(fc2w), P(out), P(g1w), P(g1b), P(g2w), P(g2b), P(ws), B, C, 128, 2, HW, 1, st), [out, g1w, g1b, g2w, g2b]),
+        "chanmix_act": (lambda: api.call("cfd_chanmix", P(a), P(w0), P(b0), P(out), B, C, C, HW, 1, 0, st), [out]),
+        "chanmix_t": (lambda: api.call("cfd_chanmix", P(gg), P(w0), None, P(out), B, C, C, HW, 0, 1, st), [out]),
         "head_train": (lambda: (api.call("cfd_label_energy_coef", P(label), P(mask), P(sums), P(coef), P(ws), B, 2, HW, 1, 1.0, st),
                                 api.call("cfd_fno_head_train", P(a), P(mask), P(label), P(coef), P(fc1w), P(fc1b), P(fc2w), P(fc2b), P(preds), P(sums),
                                          P(out), P(g1w), P(g1b), P(g2w), P(g2b), P(ws), B, C, 128, 2, HW, 1, st)), [preds, sums, out, g1w, g1b, g2w, g2b]),
