@@ -45,23 +45,6 @@ __device__ __forceinline__ void cfd_wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// "Retire fence" for a group of MFMAs: a real VALU read of the accumulator written by the LAST MFMA of the group, fenced on
-// both sides.  hipcc inserts the wait states an MFMA result needs before a VALU instruction may read it, the matrix pipe is in
-// order, so past this point every MFMA of the group has read its operands and written its result.  Needed before LDS / global
-// LOADS that follow MFMAs: the register allocator may make an MFMA out of place (dst != SrcC) and hand the freed SrcC
-// registers to such a load a fixed few wait states later, but an MFMA that depends on earlier MFMAs (or that sits behind
-// another wave's MFMAs on the same SIMD) reads SrcC when it actually STARTS -- under matrix-pipe contention the load's data
-// got there first (k_head_fwd beside another process' k_head_bwd: one phase of one tile wrong in ~10 % of the launches;
-// tools/det_kernels.py reproduces it, tools/scan_mfma_hazard.py finds the instruction pattern).
-__device__ __forceinline__ float cfd_mfma_retire(const f32x4& last) {
-    __builtin_amdgcn_sched_barrier(0);
-    int one = 0x3f800000;
-    asm volatile("" : "+v"(one));
-    const float t = __builtin_fmaf(last[3], __int_as_float(one), 0.f);  // not foldable: `one` is opaque
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-
 // Makes a value opaque to the optimiser (no instruction emitted).  Used on LDS table offsets inside a loop so the
 // loop-invariant table reads are NOT hoisted into hundreds of live VGPRs (which costs occupancy or spills).
 __device__ __forceinline__ int cfd_opaque(int x) {
@@ -90,6 +73,16 @@ __device__ __forceinline__ float cfd_exp2f(float x) { return __builtin_amdgcn_ex
 typedef float cfd_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cfd_f2 cfd_fma2(cfd_f2 a, cfd_f2 b, cfd_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ cfd_f2 cfd_abs2(cfd_f2 a) { return __builtin_elementwise_abs(a); }
+
+// Sum of the two halves of a register pair as a SCALAR add.  Written as `v.x + v.y` hipcc emits
+// `v_pk_add_f32 d, v, v op_sel:[0,1] op_sel_hi:[1,0]` -- one of the packed-fp32 forms whose LOW result (src0.lo with src1.HI) is
+// wrong in lanes 48-63 while certain other kernels are resident on the GPU (tools/exp/pkfma_cotenancy.hip, DESIGN.md section 8;
+// tools/scan_pk_opsel.py keeps every such instruction out of the build).  The opaque copy keeps the add scalar.
+__device__ __forceinline__ float cfd_hsum2(cfd_f2 v) {
+    float a = v.x, b = v.y;
+    asm volatile("" : "+v"(b));
+    return a + b;
+}
 
 // Complex multiply-accumulate acc += x * w (cfd_cmla) and acc += conj(x) * w (cfd_cmla_conj) on (re, im) register
 // pairs: two v_pk_fma_f32 whose operand selects broadcast x.re / x.im and rotate w in the instruction itself.

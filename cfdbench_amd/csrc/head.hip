@@ -30,7 +30,55 @@
 #endif
 #define CFD_PRAGMA_(x) _Pragma(#x)
 #define CFD_UNROLL(n) CFD_PRAGMA_(unroll n)
+#if CFD_HDIAG & (2048 | 4096 | 8192)  // experiment (tools/det_session3.sh): k_head_fwd checks every broadcast LDS read of the fc2 weights / fc1 bias for
+                      // an exact zero (the tables hold random values) and records where it saw one
+__device__ unsigned cfd_dbg_count;
+__device__ unsigned cfd_dbg_rec[64][24];
+extern "C" int cfd_debug_fetch(unsigned* host) {  // host[0] = events seen, host[1 ..] = the first 64 records; resets the counter
+    unsigned zero = 0;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(cfd_dbg_count), sizeof(unsigned)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(host + 1, HIP_SYMBOL(cfd_dbg_rec), sizeof(unsigned) * 64 * 24) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(cfd_dbg_count), &zero, sizeof(unsigned)) != hipSuccess) return -1;
+    return 0;
+}
+__device__ __forceinline__ void cfd_dbg_check(int kind, const float4& v, const float* lds_addr, int tile, int j, int mt, int r) {
+    if (v.x == 0.f || v.y == 0.f || v.z == 0.f || v.w == 0.f) {
+        const volatile float* va = lds_addr;
+        const float4 again = make_float4(va[0], va[1], va[2], va[3]);
+        const unsigned slot = atomicAdd(&cfd_dbg_count, 1u);
+        if (slot < 64) {
+            unsigned* o = cfd_dbg_rec[slot];
+            o[0] = kind; o[1] = blockIdx.x; o[2] = threadIdx.x; o[3] = tile; o[4] = j; o[5] = mt; o[6] = r;
+            o[7] = __float_as_uint(v.x); o[8] = __float_as_uint(v.y); o[9] = __float_as_uint(v.z); o[10] = __float_as_uint(v.w);
+            o[11] = __float_as_uint(again.x); o[12] = __float_as_uint(again.y); o[13] = __float_as_uint(again.z); o[14] = __float_as_uint(again.w);
+            o[15] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+            o[16] = __builtin_amdgcn_s_getreg((31 << 11) | 5);   // GPR_ALLOC
+            o[17] = __builtin_amdgcn_s_getreg((31 << 11) | 6);   // LDS_ALLOC
+            o[18] = (unsigned)(size_t)lds_addr;
+            o[19] = (unsigned)__builtin_readcyclecounter();
+        }
+    }
+}
+// CFD_HDIAG & 4096: a wave notes when it finds itself on another hardware slot (HW_ID changed: it was context-saved and restored) or
+// when more than 10 us of wall clock passed between two consecutive pixel phases
+__device__ __forceinline__ void cfd_dbg_gap(unsigned hw_prev, unsigned hw_now, unsigned long long dt, int tile, int j) {
+    const unsigned slot = atomicAdd(&cfd_dbg_count, 1u);
+    if (slot < 64) {
+        unsigned* o = cfd_dbg_rec[slot];
+        o[0] = 3; o[1] = blockIdx.x; o[2] = threadIdx.x; o[3] = tile; o[4] = j; o[5] = hw_prev; o[6] = hw_now; o[7] = (unsigned)dt;
+        o[15] = hw_now;
+        o[16] = __builtin_amdgcn_s_getreg((31 << 11) | 5);
+        o[17] = __builtin_amdgcn_s_getreg((31 << 11) | 6);
+    }
+}
+#endif
 #define HEAD_LD 17  // LDS row stride of the transposed tiles (16 pixels + 1 pad -> conflict-free column reads)
+#ifndef CFD_HEAD_FWD_OCC
+#define CFD_HEAD_FWD_OCC 3
+#endif
+#ifndef CFD_HEAD_FWD_FORCE_SCRATCH
+#define CFD_HEAD_FWD_FORCE_SCRATCH 0
+#endif
 
 static int head_blocks(int B, int HW) {
     const long tiles = (long)B * ((HW + 63) / 64);
@@ -98,23 +146,33 @@ __device__ __forceinline__ void head_build_w1f(bf16x8* s_hi, bf16x8* s_lo, const
 }
 
 template <int CQ, bool VEC4, bool ACT, typename TA = float>
-__global__ __launch_bounds__(256, 3) void k_head_fwd(const TA* __restrict__ a, const float* __restrict__ mask,
+__global__ __launch_bounds__(256, CFD_HEAD_FWD_OCC) void k_head_fwd(const TA* __restrict__ a, const float* __restrict__ mask,
                                                   const float* __restrict__ label, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                                   const float* __restrict__ b2, float* __restrict__ preds,
                                                   float* __restrict__ part, int B, int C, int Co, int HW) {
     __shared__ bf16x8 s_w1hi[HEAD_MT * 64], s_w1lo[HEAD_MT * 64];
     __shared__ __attribute__((aligned(16))) float s_b1[HEAD_HD];
-    __shared__ __attribute__((aligned(16))) cfd_f2 s_w2[HEAD_HD];  // (w2[0][jh], w2[1][jh]) pairs: one packed FMA updates both outputs
+    // fc2 weights by PAIRS of hidden units: a packed FMA multiplies the GELU pair (g[jh], g[jh+1]) by (w2[c][jh], w2[c][jh+1]) with
+    // plain operands.  (Round 2 paired the two OUTPUTS instead and broadcast one g through the instruction's operand select,
+    // `v_pk_fma_f32 ... op_sel:[0,1,0]`: beside another process' k_head_bwd the low half of that form did not accumulate in lanes
+    // 48-63 -- profiles/r03_det_root_cause.md.)
+    __shared__ __attribute__((aligned(16))) cfd_f2 s_w2[HEAD_HD];
     __shared__ float s_red[12];
     head_build_w1f(s_w1hi, s_w1lo, w1, C, CQ);
     for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x) s_b1[i] = b1[i];
-    for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x) s_w2[i] = cfd_f2{w2[i], Co > 1 ? w2[HEAD_HD + i] : 0.f};
+    for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x)  // per PAIR of hidden units (2p, 2p+1): [w2[0][2p], w2[0][2p+1]], [w2[1][2p], w2[1][2p+1]]
+        s_w2[i] = (i & 1) ? (Co > 1 ? cfd_f2{w2[HEAD_HD + i - 1], w2[HEAD_HD + i]} : cfd_f2{0.f, 0.f}) : cfd_f2{w2[i], w2[i + 1]};
     __syncthreads();
     const float b2v0 = b2[0], b2v1 = Co > 1 ? b2[1] : 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
     float lsq = 0.f, labs = 0.f, ll2 = 0.f;
+#if CFD_HEAD_FWD_FORCE_SCRATCH  // experiment (tools/det_session.sh): one value parked in the private segment and re-read per tile
+    volatile int scratch_probe[2];  // reserves the private segment (offset 0); accessed with the spill code's own instructions below
+    scratch_probe[1] = 0;
+    asm volatile("scratch_store_dword off, %0, off" ::"v"(HW) : "memory");
+#endif
     const int tpb = (HW + 63) / 64;
     const int total = B * tpb;  // < 2^30 (checked by the launcher)
     const int stride = (int)gridDim.x * 4;
@@ -151,6 +209,10 @@ __global__ __launch_bounds__(256, 3) void k_head_fwd(const TA* __restrict__ a, c
     ts[14] = __builtin_readcyclecounter();
     const int tile_first = tile;
 #endif
+#if CFD_HDIAG & 4096
+    unsigned dbg_hw = 0;
+    unsigned long long dbg_t = 0;
+#endif
     for (; tile < total; tile += stride) {
 #if CFD_HDIAG & 1024
         const bool rec = tile == tile_first + 2 * stride;
@@ -165,7 +227,13 @@ __global__ __launch_bounds__(256, 3) void k_head_fwd(const TA* __restrict__ a, c
         for (int j = 0; j < 4; ++j) { mk[j] = mkn[j]; lb[j] = lbn[j]; }
         const int bc = b, pxc = px;
         locate(tile + stride, b, px);
+#if CFD_HEAD_FWD_FORCE_SCRATCH
+        int hw_reload;
+        asm volatile("scratch_load_dword %0, off, off\n\ts_waitcnt vmcnt(0)" : "=v"(hw_reload)::"memory");
+        head_load_raw<CQ, VEC4, TA>(a, b, C, hw_reload, px, q, hn);
+#else
         head_load_raw<CQ, VEC4, TA>(a, b, C, HW, px, q, hn);
+#endif
         fetch_io(b, px);
         cfd_sched_fence();  // the prefetch stays here, ahead of this tile's arithmetic
         CFD_TS(1);
@@ -177,6 +245,15 @@ __global__ __launch_bounds__(256, 3) void k_head_fwd(const TA* __restrict__ a, c
 CFD_UNROLL(CFD_HF_UNROLL)
         for (int j = 0; j < 4; ++j) {
             const int lo = cfd_opaque(lane), q4 = 4 * cfd_opaque(q);  // keep the LDS table reads inside the loop (q4: a visible multiple of 4)
+#if CFD_HDIAG & 4096
+            {
+                const unsigned hw_now = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+                const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+                if (dbg_t && (hw_now != dbg_hw || t_now - dbg_t > 1000ull) && (lane == 0)) cfd_dbg_gap(dbg_hw, hw_now, t_now - dbg_t, tile, j);
+                dbg_hw = hw_now;
+                dbg_t = t_now;
+            }
+#endif
             if (j == 1) CFD_TS(8);
             float xk[8];
 #pragma unroll
@@ -188,6 +265,9 @@ CFD_UNROLL(CFD_HF_UNROLL)
                 const int jb = 16 * mt + q4;
                 const float4 bq = *reinterpret_cast<const float4*>(s_b1 + jb);  // one ds_read_b128 (16-byte aligned)
                 z[mt] = f32x4{bq.x, bq.y, bq.z, bq.w};
+#if CFD_HDIAG & 2048
+                cfd_dbg_check(1, bq, s_b1 + jb, tile, j, mt, 0);
+#endif
             }
             // z += W1 h as w_lo*h_hi + w_hi*h_lo + w_hi*h_hi, strictly term-major: consecutive MFMAs hit different accumulators
 #if !(CFD_HDIAG & 2)
@@ -203,7 +283,7 @@ CFD_UNROLL(CFD_HF_UNROLL)
             for (int mt = 0; mt < HEAD_MT; ++mt) z[mt][0] += (float)bs.hi[mt & 7] + (float)bs.lo[mt & 7];
 #endif
             if (j == 1) CFD_TS(9);
-            cfd_f2 o01 = {0.f, 0.f};
+            cfd_f2 ox = {0.f, 0.f}, oy = {0.f, 0.f};  // outputs 0 / 1, partial sums over the even / odd hidden units of this lane
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt)
 #pragma unroll
@@ -214,12 +294,12 @@ CFD_UNROLL(CFD_HF_UNROLL)
 #else
                     const cfd_f2 gl = cfd_gelu2(cfd_f2{z[mt][r], z[mt][r + 1]});
 #endif
-                    const float4 wq = *reinterpret_cast<const float4*>(s_w2 + jh);  // (w2[0][jh], w2[1][jh], w2[0][jh+1], w2[1][jh+1])
-                    o01 = cfd_fma2(cfd_f2{wq.x, wq.y}, (cfd_f2)(gl.x), o01);
-                    o01 = cfd_fma2(cfd_f2{wq.z, wq.w}, (cfd_f2)(gl.y), o01);
+                    const float4 wq = *reinterpret_cast<const float4*>(s_w2 + jh);  // (w2[0][jh], w2[0][jh+1], w2[1][jh], w2[1][jh+1])
+                    ox = cfd_fma2(cfd_f2{wq.x, wq.y}, gl, ox);
+                    oy = cfd_fma2(cfd_f2{wq.z, wq.w}, gl, oy);
                 }
             if (j == 1) CFD_TS(10);
-            const float o0 = cfd_row_sum4(o01.x), o1 = cfd_row_sum4(o01.y);  // sum over the four lane groups
+            const float o0 = cfd_row_sum4(cfd_hsum2(ox)), o1 = cfd_row_sum4(cfd_hsum2(oy));  // sum over the four lane groups
             out0[0] = out0[1]; out0[1] = out0[2]; out0[2] = out0[3]; out0[3] = o0;
             out1[0] = out1[1]; out1[1] = out1[2]; out1[2] = out1[3]; out1[3] = o1;
 #pragma unroll
@@ -736,7 +816,7 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                         po0 = cfd_fma2(w2a[t][v], a1k[t][v], po0);
                         po1 = cfd_fma2(w2b[t][v], a1k[t][v], po1);
                     }
-                const float p0 = cfd_row_sum4(po0.x + po0.y), p1 = cfd_row_sum4(po1.x + po1.y);  // over the four lane groups
+                const float p0 = cfd_row_sum4(cfd_hsum2(po0)), p1 = cfd_row_sum4(cfd_hsum2(po1));  // over the four lane groups
                 if (q == 0) s_pp[slot][wave][n] = cfd_f2{p0, p1};
             };
             auto bwd_half = [&](int j, int slot, const cfd_f2 (&a1k)[2][2], const cfd_f2 (&gdk)[2][2], float (&gzv)[8]) {

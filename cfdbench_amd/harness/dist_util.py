@@ -35,12 +35,14 @@ def init_distributed(backend: str | None = None) -> Tuple[int, int]:
     return dist.get_rank(), dist.get_world_size()
 
 
-def shard_indices(n: int, rank: int, world: int, batch_size: int = 1, seed: int = 0) -> List[int]:
-    """Frames owned by ``rank``: a fixed permutation of range(n) cut to a multiple of world * batch_size (so that EVERY rank
+def shard_indices(n: int, rank: int, world: int, batch_size: int = 1, seed: int = 0, epoch: int = 0) -> List[int]:
+    """Frames owned by ``rank`` in ``epoch``: a permutation of range(n) seeded with seed + epoch (``DistributedSampler.set_epoch``
+    semantics: a rank meets different frames every epoch and all frames over time, although each epoch drops the remainder) cut
+    to a multiple of world * batch_size (so that EVERY rank
     sees the same number of frames and, with drop_last, runs the same number of steps -- a rank with one step more would
     pair its gradient all-reduce with the others' barrier) and split into contiguous, equal parts.  When n is smaller
     than world * batch_size only the multiple-of-world cut applies."""
-    perm = torch.randperm(n, generator=torch.Generator().manual_seed(seed)).tolist()
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(seed + epoch)).tolist()
     unit = world * batch_size
     keep = (n // unit) * unit if n >= unit else (n // world) * world
     per = keep // world

@@ -11,6 +11,13 @@ with the statistics of that ONE case and a ResNet's dropout stays active; batchi
 pool the statistics over the cases and change the metrics.  ``infer`` therefore falls back to the reference's per-case
 loop (``infer_case``) whenever the model holds BatchNorm / Dropout layers in training mode.  Metrics are reduced on the
 device and fetched once at the end instead of three ``.item()`` syncs per case and step.
+
+Multi-GPU: cases shard over the ranks of a ``torch.distributed`` launch (one process per GPU) -- rank r rolls
+out cases r, r + world, ... with NO collective on the data path; the per-step sums of the per-case metrics (a (steps, 3)
+fp64 tensor + the case count) are all-reduced ONCE at the end and rank 0 writes multistep_metrics.json:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        -m cfdbench_amd.harness.test_multistep --model fno --data dam_prop_bc_geo --infer_steps 200
 """
 from __future__ import annotations
 
@@ -57,13 +64,35 @@ def batch_dependent(model) -> bool:
     return False
 
 
-def infer(model, all_features: List[Tensor], all_case_params: List[Tensor], infer_steps: int,
-          dtype: str = "fp32") -> List[Dict[str, float]]:
-    """test_multistep.py:135-177.  ``dtype`` = "bf16": the FNO rollout runs from one HIP graph with bf16 activation storage
-    (cfdbench_amd.rollout.FnoRollout; FNO only).  all_features[c]: (>=infer_steps, c+1, h, w) on the device.  The cases run as one batch
-    unless the model is batch-dependent in its current mode (see the module docstring), in which case they run one by one
-    exactly as in the reference."""
+def rollout_frames(model, start: Tensor, cps: Tensor, mask: Tensor, infer_steps: int, dtype: str = "fp32"):
+    """``infer_steps`` predicted frames for a batch of cases.  An Fno2d rolls out from ONE HIP graph per horizon
+    (cfdbench_amd.rollout.FnoRollout: fp32 = bitwise ``generate_many``; "bf16" = bf16 activation storage); other models go through
+    their own ``generate_many``."""
+    from ..models.fno.fno2d import Fno2d
+    from ..rollout import ACT_DTYPES, FnoRollout
+    if isinstance(model, Fno2d) and start.is_cuda:
+        if dtype not in ACT_DTYPES:
+            raise ValueError(f"--dtype {dtype}: one of {sorted(ACT_DTYPES)}")
+        ro = getattr(model, "_multistep_rollout", None)
+        if ro is None or ro.dtype != dtype:
+            ro = FnoRollout(model, dtype=dtype)
+            object.__setattr__(model, "_multistep_rollout", ro)  # graph cache lives with the model (not a sub-module / parameter)
+        return ro.generate_frames(start, cps, mask, infer_steps)[1:]
+    if dtype not in ("fp32", "f32", "float32"):
+        raise ValueError(f"--dtype {dtype} is built for the FNO rollout only")
+    with torch.no_grad():
+        return model.generate_many(inputs=start, case_params=cps, mask=mask, steps=infer_steps)
+
+
+def case_metric_sums(model, all_features: List[Tensor], all_case_params: List[Tensor], infer_steps: int,
+                     dtype: str = "fp32") -> np.ndarray:
+    """(infer_steps, 3) fp64: for every step the SUM over the given cases of the per-case (mse, nmse, mae) -- the additive form
+    of test_multistep.py:160-174, so shards combine with one all-reduce.  all_features[c]: (>=infer_steps, c+1, h, w) on the
+    device.  The cases run as one batch unless the model is batch-dependent in its current mode (see the module docstring),
+    in which case they run one by one exactly as in the reference."""
     n_cases = len(all_features)
+    if n_cases == 0:
+        return np.zeros((infer_steps, 3), dtype=np.float64)
     start = torch.stack([f[0, :-1] for f in all_features])          # (n, c, h, w)
     mask = torch.stack([f[0, -1] for f in all_features])            # (n, h, w)
     cps = torch.stack(list(all_case_params))                        # (n, p)
@@ -71,12 +100,8 @@ def infer(model, all_features: List[Tensor], all_case_params: List[Tensor], infe
         per_case = [infer_case(model, f, cp, infer_steps) for f, cp in zip(all_features, all_case_params)]
         n_frames = len(per_case[0])
         preds = [torch.cat([pc[k] for pc in per_case], dim=0) for k in range(n_frames)]
-    elif dtype not in ("fp32", "f32", "float32"):
-        from ..rollout import FnoRollout
-        preds = FnoRollout(model, dtype=dtype).generate_many(start, cps, mask, infer_steps)
     else:
-        with torch.no_grad():
-            preds = model.generate_many(inputs=start, case_params=cps, mask=mask, steps=infer_steps)
+        preds = rollout_frames(model, start, cps, mask, infer_steps, dtype)
     sums = torch.empty(infer_steps, n_cases, 3, device=start.device)
     for step in range(infer_steps):
         lab = torch.stack([f[step, 0] * f[step, -1] for f in all_features])   # u channel of label frame `step`, masked
@@ -87,19 +112,43 @@ def infer(model, all_features: List[Tensor], all_case_params: List[Tensor], infe
         sums[step, :, 0] = (d * d).flatten(1).sum(1) / n
         sums[step, :, 1] = (lab * lab).flatten(1).sum(1) / n
         sums[step, :, 2] = d.abs().flatten(1).sum(1) / n
-    s = sums.double().cpu().numpy()
-    all_metrics = []
-    for step in range(infer_steps):
-        mse, l2, mae = s[step, :, 0], s[step, :, 1], s[step, :, 2]
-        all_metrics.append(dict(mse=float(np.mean(mse)), nmse=float(np.mean(mse / l2)), mae=float(np.mean(mae))))
-    return all_metrics
+    s = sums.double().cpu().numpy()  # the ONE device-to-host transfer of the rollout
+    return np.stack([s[:, :, 0].sum(1), (s[:, :, 0] / s[:, :, 1]).sum(1), s[:, :, 2].sum(1)], axis=1)
 
 
-def prepare_cases(test_data, infer_steps: int, device="cuda"):
+def shard_cases(n_cases: int, rank: int, world: int) -> List[int]:
+    """Cases owned by ``rank``: r, r + world, ... (round robin keeps long and short cases spread over the ranks)."""
+    return list(range(rank, n_cases, world))
+
+
+def infer(model, all_features: List[Tensor], all_case_params: List[Tensor], infer_steps: int,
+          dtype: str = "fp32", n_total_cases: int | None = None) -> List[Dict[str, float]]:
+    """test_multistep.py:135-177: per step, the mean over ALL test cases of the per-case metrics.  In a multi-process launch
+    ``all_features`` holds this rank's shard (``shard_cases``) and ``n_total_cases`` the global count; the shards' sums meet in
+    one all-reduce (the only collective of the rollout)."""
+    import torch.distributed as dist
+    local = case_metric_sums(model, all_features, all_case_params, infer_steps, dtype)
+    n = len(all_features) if n_total_cases is None else int(n_total_cases)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dev = all_features[0].device if len(all_features) else (torch.device("cuda", torch.cuda.current_device())
+                                                                if torch.cuda.is_available() else torch.device("cpu"))
+        if dist.get_backend() == "gloo":
+            dev = torch.device("cpu")
+        t = torch.cat([torch.from_numpy(local).flatten(), torch.tensor([float(len(all_features))], dtype=torch.float64)]).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t = t.cpu().numpy()
+        assert int(round(t[-1])) == n, f"the ranks hold {int(round(t[-1]))} cases, expected {n}"
+        local = t[:-1].reshape(infer_steps, 3)
+    return [dict(mse=float(local[k, 0] / n), nmse=float(local[k, 1] / n), mae=float(local[k, 2] / n)) for k in range(infer_steps)]
+
+
+def prepare_cases(test_data, infer_steps: int, device="cuda", only: List[int] | None = None):
     """Pad every case to >= infer_steps frames by repeating the last frame (steady state), move to the device
-    (test_multistep.py:201-218)."""
+    (test_multistep.py:201-218).  ``only``: indices of the cases to prepare (this rank's shard)."""
     feats, cps = [], []
-    for case_features, case_params in zip(test_data.all_features, test_data.case_params):
+    for ci, (case_features, case_params) in enumerate(zip(test_data.all_features, test_data.case_params)):
+        if only is not None and ci not in only:
+            continue
         case_features = np.asarray(case_features)
         if case_features.shape[0] < infer_steps:
             pad = np.repeat(case_features[-1:], infer_steps - case_features.shape[0], axis=0)
@@ -111,17 +160,27 @@ def prepare_cases(test_data, infer_steps: int, device="cuda"):
 
 def main(argv=None):
     from .data import get_auto_dataset
+    from .dist_util import init_distributed
     args = Args().parse_args(argv)
     is_args_valid(args)
-    print(args)
+    rank, world = init_distributed()  # one process per GPU; a plain start stays single-process
+    if rank == 0:
+        print(args)
     _, _, test_data = get_auto_dataset(data_dir=Path(args.data_dir), data_name=args.data_name, delta_time=args.delta_time,
                                        norm_props=bool(args.norm_props), norm_bc=bool(args.norm_bc), load_splits=["test"])
-    feats, cps = prepare_cases(test_data, args.infer_steps)
+    n_cases = len(test_data.all_features)
+    mine = shard_cases(n_cases, rank, world)
+    feats, cps = prepare_cases(test_data, args.infer_steps, only=set(mine))
     model = init_model(args).cuda()
     output_dir = get_output_dir(args, is_auto=True)
-    load_best_ckpt(model, output_dir)
-    all_metrics = infer(model, feats, cps, args.infer_steps, dtype=args.dtype)
-    dump_json(all_metrics, output_dir / "multistep_metrics.json")
+    load_best_ckpt(model, output_dir)  # every rank reads rank 0's checkpoint tree: identical replicas, no broadcast needed
+    all_metrics = infer(model, feats, cps, args.infer_steps, dtype=args.dtype, n_total_cases=n_cases)
+    if rank == 0:
+        dump_json(all_metrics, output_dir / "multistep_metrics.json")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -96,19 +96,30 @@ def test(model: CfdModel, data, output_dir: Path, plot_interval: int = 10, batch
 
 def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: int = 400, lr: float = 1e-3,
           lr_step_size: int = 1, lr_gamma: float = 0.9, batch_size: int = 64, log_interval: int = 50,
-          eval_interval: int = 2, measure_time: bool = False, plot_interval: int = 1, resume: bool = False):
+          eval_interval: int = 2, measure_time: bool = False, plot_interval: int = 1, resume: bool = False,
+          lr_scheduler_kind: str = "step", lr_scheduler_factor: float = 0.5, lr_scheduler_patience: int = 5,
+          early_stopping_patience: int = 0, early_stopping_delta: float = 1e-5, gradient_accumulation_steps: int = 1):
     """src/train.py:148-253: fwd -> ``loss["nmse"].backward()`` -> Adam -> zero_grad; StepLR per epoch.
-    ``resume``: continue from ``train_state.pt`` (see harness/train_auto.py:train)."""
+    ``resume``: continue from ``train_state.pt`` (see harness/train_auto.py:train).  ``lr_scheduler_kind`` /
+    ``early_stopping_patience`` / ``gradient_accumulation_steps``: the same options, with the same semantics, as
+    harness/train_auto.py:train (harness/schedule.py); the defaults are the reference's loop."""
     rank, world = _rank_world()
     output_dir = Path(output_dir)
-    if world > 1:  # equal shards: every rank runs the same number of steps
-        train_data = Subset(train_data, shard_indices(len(train_data), rank, world, batch_size))
+    if world > 1:
         broadcast_model_state(model)
-    loader = DataLoader(train_data, batch_size=batch_size, collate_fn=collate_fn, shuffle=True, drop_last=world > 1)
+
+    def make_loader(ep: int):  # equal shards, re-partitioned every epoch: every rank runs the same number of steps
+        data = Subset(train_data, shard_indices(len(train_data), rank, world, batch_size, epoch=ep)) if world > 1 else train_data
+        return DataLoader(data, batch_size=batch_size, collate_fn=collate_fn, shuffle=True, drop_last=world > 1)
+
+    loader = make_loader(0)
     if rank == 0:
         output_dir.mkdir(exist_ok=True, parents=True)
     optimizer = Adam(model.parameters(), lr=lr)
-    scheduler = lr_scheduler.StepLR(optimizer, step_size=lr_step_size, gamma=lr_gamma)
+    schedule = LrSchedule(lr_scheduler_kind, lr, num_epochs, optimizer, lr_step_size=lr_step_size, lr_gamma=lr_gamma,
+                          factor=lr_scheduler_factor, patience=lr_scheduler_patience)
+    stopper = EarlyStopping(early_stopping_patience, early_stopping_delta)
+    accum = max(1, int(gradient_accumulation_steps))
     start_time = time.time()
     global_step = 0
     all_train_losses: List[float] = []
@@ -119,7 +130,12 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
         check_resume_state(state, fused=False, world=world)
         model.load_state_dict(torch.load(output_dir / state["ckpt"] / "model.pt", map_location="cpu"))
         optimizer.load_state_dict(state["optimizer"])
-        scheduler.load_state_dict(state["scheduler"])
+        if "sched" in state["scheduler"]:
+            schedule.load_state_dict(state["scheduler"])
+        else:  # format 1 (round 2): the bare StepLR state
+            schedule.sched.load_state_dict(state["scheduler"])
+        if state.get("early_stopping") is not None:
+            stopper.load_state_dict(state["early_stopping"])
         start_ep, global_step, all_train_losses = state["ep"] + 1, state["global_step"], list(state["train_losses"])
         torch.set_rng_state(state["rng"])
         if rank == 0:
@@ -128,25 +144,32 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
         ep_start_time = time.time()
         ep_train_losses: List[float] = []
         model.train()
+        if world > 1 and ep > 0:
+            loader = make_loader(ep)
+        n_steps = len(loader)
+        n_full = (n_steps // accum) * accum
         for step, batch in enumerate(loader):
             loss = model(**batch)["loss"]["nmse"]
-            loss.backward()
-            if world > 1:
-                sync_gradients(list(model.parameters()))
-            optimizer.step()
-            optimizer.zero_grad()
+            group = accum if step < n_full else n_steps - n_full  # the epoch's trailing group may be shorter
+            (loss / group if group > 1 else loss).backward()
+            if (step + 1) % accum == 0 or step + 1 == n_steps:
+                if world > 1:
+                    sync_gradients(list(model.parameters()))
+                optimizer.step()
+                optimizer.zero_grad()
             ep_train_losses.append(loss.item())  # src/train.py:203
             global_step += 1
             if global_step % log_interval == 0 and not measure_time and rank == 0:
                 avg_loss = sum(ep_train_losses) / (len(ep_train_losses) + 1e-5)
-                print(dict(ep=ep, step=step, loss=f"{avg_loss:.3e}", lr=f"{scheduler.get_last_lr()[0]:.3e}",
+                print(dict(ep=ep, step=step, loss=f"{avg_loss:.3e}", lr=f"{schedule.lr:.3e}",
                            time=round(time.time() - start_time)))
         if measure_time:
             print("Time usage:", time.time() - ep_start_time)
             return all_train_losses + ep_train_losses
-        scheduler.step()
+        schedule.epoch_end()
         if world > 1 and (ep + 1) % eval_interval == 0:
             average_buffers(model)
+        stop = False
         if (ep + 1) % eval_interval == 0 and rank == 0:
             ckpt_dir = output_dir / f"ckpt-{ep}"
             ckpt_dir.mkdir(exist_ok=True, parents=True)
@@ -157,16 +180,28 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
             if ckpt_path.exists():
                 copyfile(ckpt_path, ckpt_dir / "backup_model.pt")
             torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, ckpt_path)
-            dump_json(dict(ep=ep, train_loss=float(np.mean(ep_train_losses)), dev_loss=float(np.mean(dev_scores["mean"]["nmse"])),
+            dev_loss = float(np.mean(dev_scores["mean"]["nmse"]))
+            dump_json(dict(ep=ep, train_loss=float(np.mean(ep_train_losses)), dev_loss=dev_loss,
                            time=time.time() - ep_start_time), ckpt_dir / "scores.json")
+            schedule.validation(dev_loss)
+            stop = stopper.update(dev_loss)
             tmp = output_dir / "train_state.pt.tmp"
-            torch.save(dict(ep=ep, global_step=global_step, train_losses=all_train_losses + ep_train_losses,
-                            ckpt=ckpt_dir.name, optimizer=optimizer.state_dict(), scheduler=scheduler.state_dict(),
-                            rng=torch.get_rng_state(), world=world), tmp)
+            torch.save(dict(format=2, ep=ep, global_step=global_step, train_losses=all_train_losses + ep_train_losses,
+                            ckpt=ckpt_dir.name, optimizer=optimizer.state_dict(), scheduler=schedule.state_dict(),
+                            early_stopping=stopper.state_dict(), rng=torch.get_rng_state(), world=world), tmp)
             tmp.replace(state_path)
-        if world > 1:
+        if world > 1:  # every rank follows rank 0's validation-driven decisions (plateau rate, early stop)
+            flags = torch.tensor([schedule.lr, float(stop)], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+            dist.broadcast(flags, 0)
+            for g_ in optimizer.param_groups:
+                g_["lr"] = float(flags[0])
+            stop = bool(flags[1] > 0.5)
             dist.barrier()
         all_train_losses += ep_train_losses
+        if stop:
+            if rank == 0:
+                print(f"early stopping after epoch {ep}: no improvement of {early_stopping_delta} in {early_stopping_patience} evaluations")
+            break
     if rank == 0:
         dump_json(all_train_losses, output_dir / "train_losses.json")
         plot_loss(all_train_losses, output_dir / "train_losses.png")
@@ -241,7 +276,10 @@ def main(argv=None):
         train(model, train_data, dev_data, output_dir, batch_size=args.batch_size, lr=args.lr,
               lr_step_size=args.lr_step_size, lr_gamma=args.lr_gamma, num_epochs=args.num_epochs,
               eval_interval=args.eval_interval, log_interval=args.log_interval, plot_interval=args.plot_interval,
-              resume=bool(args.resume))
+              resume=bool(args.resume), lr_scheduler_kind=args.lr_scheduler, lr_scheduler_factor=args.lr_scheduler_factor,
+              lr_scheduler_patience=args.lr_scheduler_patience,
+              early_stopping_patience=args.early_stopping_patience if args.early_stop else 0,
+              early_stopping_delta=args.early_stopping_delta, gradient_accumulation_steps=args.gradient_accumulation_steps)
     if "test" in args.mode and rank == 0:
         args.save(str(output_dir / "test_args.json"))
         load_best_ckpt(model, output_dir)

@@ -135,17 +135,22 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
     other trainers (harness/schedule.py; src/args.py:53-56,77-80,323) -- the defaults are the reference's benchmark loop."""
     rank, world = _rank_world()
     output_dir = Path(output_dir)
-    if world > 1:  # shard the frames: every rank owns an equal, contiguous part of a fixed permutation (SURVEY.md 8e)
-        train_data = Subset(train_data, shard_indices(len(train_data), rank, world, batch_size))
+    if world > 1:
         broadcast_model_state(model)  # identical replicas (weights, BatchNorm statistics) before the first step
-    if device_loader:  # SURVEY.md 8f-1: frames resident in HBM, batches gathered on the device (harness/data.py)
-        from .data import DeviceBatchLoader
-        base = train_data.dataset if isinstance(train_data, Subset) else train_data
-        train_loader = DeviceBatchLoader(base, batch_size, shuffle=True, drop_last=world > 1,
-                                         indices=train_data.indices if isinstance(train_data, Subset) else None)
-    else:
-        train_loader = DataLoader(train_data, batch_size=batch_size, shuffle=True, collate_fn=collate_fn,
-                                  drop_last=world > 1)
+
+    def make_loader(ep: int):
+        """The epoch's loader.  With several ranks the frames are re-partitioned EVERY epoch (``DistributedSampler.set_epoch``
+        semantics: shard_indices(..., epoch=ep) -- an equal part of that epoch's permutation per rank), so a
+        rank does not see the same 1/world of the data for the whole run."""
+        data = Subset(train_data, shard_indices(len(train_data), rank, world, batch_size, epoch=ep)) if world > 1 else train_data
+        if device_loader:  # SURVEY.md 8f-1: frames resident in HBM, batches gathered on the device (harness/data.py)
+            from .data import DeviceBatchLoader
+            base = data.dataset if isinstance(data, Subset) else data
+            return DeviceBatchLoader(base, batch_size, shuffle=True, drop_last=world > 1,
+                                     indices=data.indices if isinstance(data, Subset) else None)
+        return DataLoader(data, batch_size=batch_size, shuffle=True, collate_fn=collate_fn, drop_last=world > 1)
+
+    train_loader = make_loader(0)
     if rank == 0:
         output_dir.mkdir(exist_ok=True, parents=True)
     engine = None
@@ -178,7 +183,15 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
             engine.load_state_dict(state["optimizer"])
         else:
             optimizer.load_state_dict(state["optimizer"])
-        schedule.load_state_dict(state["scheduler"])
+        if state.get("scheduler") is None:
+            # train_state.pt of a round-2 fused run (format 1: the engine carried the rate, no scheduler state was written):
+            # replay the epoch-end steps of the schedule, which for step / cosine depends on the epoch count alone
+            if schedule.kind == "plateau":
+                raise RuntimeError("train_state.pt holds no scheduler state (written before format 2): a plateau schedule cannot be rebuilt")
+            for _ in range(state["ep"] + 1):
+                schedule.epoch_end()
+        else:
+            schedule.load_state_dict(state["scheduler"])
         if state.get("early_stopping") is not None:
             stopper.load_state_dict(state["early_stopping"])
         start_ep, global_step, train_losses = state["ep"] + 1, state["global_step"], list(state["train_losses"])
@@ -190,6 +203,10 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
         cur_lr = schedule.lr
         ep_train_losses: List = []
         model.train()
+        if world > 1 and ep > 0:
+            train_loader = make_loader(ep)
+        n_steps = len(train_loader)
+        n_full = (n_steps // accum) * accum  # micro-batches in complete accumulation groups; the rest form one short group
         for step, batch in enumerate(train_loader):
             if engine is not None:
                 engine.lr = cur_lr
@@ -202,8 +219,10 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
                 if step == 0 and not measure_time and rank == 0 and plot_interval > 0:
                     plot(batch["inputs"][0][0], batch["label"][0][0], outputs["preds"][0][0].detach(), Path("example.png"))
                 loss = outputs["loss"]
-                (loss["nmse"] / accum if accum > 1 else loss["nmse"]).backward()  # train_auto.py:255
-                if (step + 1) % accum == 0 or step + 1 == len(train_loader):
+                # mean over the micro-batches of THIS group: the trailing group of an epoch may be shorter than `accum`
+                group = accum if step < n_full else n_steps - n_full
+                (loss["nmse"] / group if group > 1 else loss["nmse"]).backward()  # train_auto.py:255
+                if (step + 1) % accum == 0 or step + 1 == n_steps:
                     if world > 1:
                         sync_gradients(list(model.parameters()))  # one flat all-reduce, DDP semantics
                     optimizer.step()
@@ -251,7 +270,7 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
             stop = stopper.update(dev_loss)
             opt_state = engine.state_dict() if engine is not None else optimizer.state_dict()
             tmp = output_dir / "train_state.pt.tmp"
-            torch.save(dict(ep=ep, global_step=global_step, train_losses=train_losses, ckpt=ckpt_dir.name,
+            torch.save(dict(format=2, ep=ep, global_step=global_step, train_losses=train_losses, ckpt=ckpt_dir.name,
                             optimizer=opt_state, scheduler=schedule.state_dict(), early_stopping=stopper.state_dict(),
                             rng=torch.get_rng_state(), fused=engine is not None, world=world,
                             model_extra=model.extra_train_state() if hasattr(model, "extra_train_state") else None), tmp)

@@ -56,8 +56,6 @@ inline float cfd_shfl_xor(float v, int mask) {
     return r;
 }
 
-inline float cfd_mfma_retire(const f32x4& last) { return last[3]; }
-
 inline float cfd_row_sum4(float v) {  // same association as the device form: (r0 + r1) + (r2 + r3) per lane & 15
     const float s = v + cfd_shfl_xor(v, 16);
     return s + cfd_shfl_xor(s, 32);
@@ -88,6 +86,7 @@ inline float cfd_exp2f(float x) { return exp2f(x); }
 typedef float cfd_f2 __attribute__((ext_vector_type(2)));
 inline cfd_f2 cfd_fma2(cfd_f2 a, cfd_f2 b, cfd_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 inline cfd_f2 cfd_abs2(cfd_f2 a) { return __builtin_elementwise_abs(a); }
+inline float cfd_hsum2(cfd_f2 v) { return v.x + v.y; }
 
 // complex multiply-accumulate, same rounding sequence as the device form (two fused steps per component)
 inline cfd_f2 cfd_cmla(cfd_f2 acc, cfd_f2 x, cfd_f2 w) {

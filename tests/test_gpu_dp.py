@@ -37,7 +37,7 @@ def _batch(torch, step, rank, world):
     return {k: torch.from_numpy(v[rank * B_RANK:(rank + 1) * B_RANK].copy()).cuda() for k, v in b.items()}
 
 
-def _worker(rank, world, port, overlap, q, lock):
+def _worker(rank, world, port, overlap, q):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -48,22 +48,11 @@ def _worker(rank, world, port, overlap, q, lock):
         from cfdbench_amd.engine import FnoTrainEngine
         eng = FnoTrainEngine(_make_model(torch), lr=1e-3, loss_name="nmse", overlap=overlap)
         assert eng.sync.world == world
-        # The two ranks of this test share ONE GPU.  Their forward / backward kernels are kept from running at the same time
-        # (a cross-process lock around the compute section, released where the gradient exchange starts): k_head_fwd is not
-        # reproducible while ANOTHER process runs k_head_bwd on the same GPU ("known issue"; tools/det_kernels.py
-        # reproduces it) -- a situation one-process-per-GPU training never creates, and not what this test is about.
-        wait_all = eng.sync.wait_all
-
-        def exchange(handles):
-            torch.cuda.synchronize()
-            lock.release()
-            return wait_all(handles)
-
-        eng.sync.wait_all = exchange
+        # The two ranks of this test share ONE GPU and run their kernels concurrently (round 2 had to serialise them with a
+        # cross-process lock: see tests/test_gpu_concurrency.py for what was wrong and how it is kept out of the library).
         grads = []
         for step in range(STEPS):
             b = _batch(torch, step, rank, world)
-            lock.acquire()
             eng.train_step(b["inputs"], b["label"], b["case_params"], b["mask"])
             torch.cuda.synchronize()
             grads.append(eng.flat.grad.cpu().numpy().copy())
@@ -76,9 +65,8 @@ def _run_world2(overlap):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    lock = ctx.Lock()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q, lock)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
