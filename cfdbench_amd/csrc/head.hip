@@ -30,70 +30,27 @@
 #endif
 #define CFD_PRAGMA_(x) _Pragma(#x)
 #define CFD_UNROLL(n) CFD_PRAGMA_(unroll n)
-#if CFD_HDIAG & (2048 | 4096 | 8192)  // experiment (tools/det_session3.sh): k_head_fwd checks every broadcast LDS read of the fc2 weights / fc1 bias for
-                      // an exact zero (the tables hold random values) and records where it saw one
-__device__ unsigned cfd_dbg_count;
-__device__ unsigned cfd_dbg_rec[64][24];
-extern "C" int cfd_debug_fetch(unsigned* host) {  // host[0] = events seen, host[1 ..] = the first 64 records; resets the counter
-    unsigned zero = 0;
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(cfd_dbg_count), sizeof(unsigned)) != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(host + 1, HIP_SYMBOL(cfd_dbg_rec), sizeof(unsigned) * 64 * 24) != hipSuccess) return -1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(cfd_dbg_count), &zero, sizeof(unsigned)) != hipSuccess) return -1;
-    return 0;
-}
-__device__ __forceinline__ void cfd_dbg_check(int kind, const float4& v, const float* lds_addr, int tile, int j, int mt, int r) {
-    if (v.x == 0.f || v.y == 0.f || v.z == 0.f || v.w == 0.f) {
-        const volatile float* va = lds_addr;
-        const float4 again = make_float4(va[0], va[1], va[2], va[3]);
-        const unsigned slot = atomicAdd(&cfd_dbg_count, 1u);
-        if (slot < 64) {
-            unsigned* o = cfd_dbg_rec[slot];
-            o[0] = kind; o[1] = blockIdx.x; o[2] = threadIdx.x; o[3] = tile; o[4] = j; o[5] = mt; o[6] = r;
-            o[7] = __float_as_uint(v.x); o[8] = __float_as_uint(v.y); o[9] = __float_as_uint(v.z); o[10] = __float_as_uint(v.w);
-            o[11] = __float_as_uint(again.x); o[12] = __float_as_uint(again.y); o[13] = __float_as_uint(again.z); o[14] = __float_as_uint(again.w);
-            o[15] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
-            o[16] = __builtin_amdgcn_s_getreg((31 << 11) | 5);   // GPR_ALLOC
-            o[17] = __builtin_amdgcn_s_getreg((31 << 11) | 6);   // LDS_ALLOC
-            o[18] = (unsigned)(size_t)lds_addr;
-            o[19] = (unsigned)__builtin_readcyclecounter();
-        }
-    }
-}
-// CFD_HDIAG & 4096: a wave notes when it finds itself on another hardware slot (HW_ID changed: it was context-saved and restored) or
-// when more than 10 us of wall clock passed between two consecutive pixel phases
-__device__ __forceinline__ void cfd_dbg_gap(unsigned hw_prev, unsigned hw_now, unsigned long long dt, int tile, int j) {
-    const unsigned slot = atomicAdd(&cfd_dbg_count, 1u);
-    if (slot < 64) {
-        unsigned* o = cfd_dbg_rec[slot];
-        o[0] = 3; o[1] = blockIdx.x; o[2] = threadIdx.x; o[3] = tile; o[4] = j; o[5] = hw_prev; o[6] = hw_now; o[7] = (unsigned)dt;
-        o[15] = hw_now;
-        o[16] = __builtin_amdgcn_s_getreg((31 << 11) | 5);
-        o[17] = __builtin_amdgcn_s_getreg((31 << 11) | 6);
-    }
-}
-#endif
 #define HEAD_LD 17  // LDS row stride of the transposed tiles (16 pixels + 1 pad -> conflict-free column reads)
-#ifndef CFD_HEAD_FWD_OCC
-#define CFD_HEAD_FWD_OCC 3
-#endif
-#ifndef CFD_HEAD_FWD_FORCE_SCRATCH
-#define CFD_HEAD_FWD_FORCE_SCRATCH 0
-#endif
 
-static int head_blocks(int B, int HW) {
+// Workgroup counts.  The `head_blocks` knob (tests: several tiles per workgroup at small sizes) can only LOWER them, and the
+// workspace is sized WITHOUT the knob (knob = false), so a knob changed after a workspace was sized and cached can never make a
+// launch write partial sums past its end.
+static int head_blocks(int B, int HW, bool knob = true) {
     const long tiles = (long)B * ((HW + 63) / 64);
     long blocks = (tiles + 7) / 8;  // >= 2 tiles per wave
-    const int cap = cfd_tune_get(CFD_TUNE_HEAD_BLOCKS) > 0 ? cfd_tune_get(CFD_TUNE_HEAD_BLOCKS) : CFD_HEAD_FWD_BLOCKS;
-    if (blocks > cap) blocks = cap;
+    if (blocks > CFD_HEAD_FWD_BLOCKS) blocks = CFD_HEAD_FWD_BLOCKS;
+    const int k = knob ? cfd_tune_get(CFD_TUNE_HEAD_BLOCKS) : -1;
+    if (k > 0 && blocks > k) blocks = k;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
 
 // backward: the four waves of a block share each tile (see k_head_bwd)
-static int head_bwd_blocks(int B, int HW) {
+static int head_bwd_blocks(int B, int HW, bool knob = true) {
     const long tiles = (long)B * ((HW + 63) / 64);
-    const int cap = cfd_tune_get(CFD_TUNE_HEAD_BLOCKS) > 0 ? cfd_tune_get(CFD_TUNE_HEAD_BLOCKS) : 512;  // knob: tests reach the multi-tile loop
-    long blocks = tiles < cap ? tiles : cap;
+    long blocks = tiles < 512 ? tiles : 512;
+    const int k = knob ? cfd_tune_get(CFD_TUNE_HEAD_BLOCKS) : -1;  // tests reach the multi-tile loop
+    if (k > 0 && blocks > k) blocks = k;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
@@ -146,7 +103,7 @@ __device__ __forceinline__ void head_build_w1f(bf16x8* s_hi, bf16x8* s_lo, const
 }
 
 template <int CQ, bool VEC4, bool ACT, typename TA = float>
-__global__ __launch_bounds__(256, CFD_HEAD_FWD_OCC) void k_head_fwd(const TA* __restrict__ a, const float* __restrict__ mask,
+__global__ __launch_bounds__(256, 3) void k_head_fwd(const TA* __restrict__ a, const float* __restrict__ mask,
                                                   const float* __restrict__ label, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                                   const float* __restrict__ b2, float* __restrict__ preds,
@@ -168,11 +125,6 @@ __global__ __launch_bounds__(256, CFD_HEAD_FWD_OCC) void k_head_fwd(const TA* __
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
     float lsq = 0.f, labs = 0.f, ll2 = 0.f;
-#if CFD_HEAD_FWD_FORCE_SCRATCH  // experiment (tools/det_session.sh): one value parked in the private segment and re-read per tile
-    volatile int scratch_probe[2];  // reserves the private segment (offset 0); accessed with the spill code's own instructions below
-    scratch_probe[1] = 0;
-    asm volatile("scratch_store_dword off, %0, off" ::"v"(HW) : "memory");
-#endif
     const int tpb = (HW + 63) / 64;
     const int total = B * tpb;  // < 2^30 (checked by the launcher)
     const int stride = (int)gridDim.x * 4;
@@ -209,10 +161,6 @@ __global__ __launch_bounds__(256, CFD_HEAD_FWD_OCC) void k_head_fwd(const TA* __
     ts[14] = __builtin_readcyclecounter();
     const int tile_first = tile;
 #endif
-#if CFD_HDIAG & 4096
-    unsigned dbg_hw = 0;
-    unsigned long long dbg_t = 0;
-#endif
     for (; tile < total; tile += stride) {
 #if CFD_HDIAG & 1024
         const bool rec = tile == tile_first + 2 * stride;
@@ -227,13 +175,7 @@ __global__ __launch_bounds__(256, CFD_HEAD_FWD_OCC) void k_head_fwd(const TA* __
         for (int j = 0; j < 4; ++j) { mk[j] = mkn[j]; lb[j] = lbn[j]; }
         const int bc = b, pxc = px;
         locate(tile + stride, b, px);
-#if CFD_HEAD_FWD_FORCE_SCRATCH
-        int hw_reload;
-        asm volatile("scratch_load_dword %0, off, off\n\ts_waitcnt vmcnt(0)" : "=v"(hw_reload)::"memory");
-        head_load_raw<CQ, VEC4, TA>(a, b, C, hw_reload, px, q, hn);
-#else
         head_load_raw<CQ, VEC4, TA>(a, b, C, HW, px, q, hn);
-#endif
         fetch_io(b, px);
         cfd_sched_fence();  // the prefetch stays here, ahead of this tile's arithmetic
         CFD_TS(1);
@@ -245,15 +187,6 @@ __global__ __launch_bounds__(256, CFD_HEAD_FWD_OCC) void k_head_fwd(const TA* __
 CFD_UNROLL(CFD_HF_UNROLL)
         for (int j = 0; j < 4; ++j) {
             const int lo = cfd_opaque(lane), q4 = 4 * cfd_opaque(q);  // keep the LDS table reads inside the loop (q4: a visible multiple of 4)
-#if CFD_HDIAG & 4096
-            {
-                const unsigned hw_now = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-                const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-                if (dbg_t && (hw_now != dbg_hw || t_now - dbg_t > 1000ull) && (lane == 0)) cfd_dbg_gap(dbg_hw, hw_now, t_now - dbg_t, tile, j);
-                dbg_hw = hw_now;
-                dbg_t = t_now;
-            }
-#endif
             if (j == 1) CFD_TS(8);
             float xk[8];
 #pragma unroll
@@ -265,9 +198,6 @@ CFD_UNROLL(CFD_HF_UNROLL)
                 const int jb = 16 * mt + q4;
                 const float4 bq = *reinterpret_cast<const float4*>(s_b1 + jb);  // one ds_read_b128 (16-byte aligned)
                 z[mt] = f32x4{bq.x, bq.y, bq.z, bq.w};
-#if CFD_HDIAG & 2048
-                cfd_dbg_check(1, bq, s_b1 + jb, tile, j, mt, 0);
-#endif
             }
             // z += W1 h as w_lo*h_hi + w_hi*h_lo + w_hi*h_hi, strictly term-major: consecutive MFMAs hit different accumulators
 #if !(CFD_HDIAG & 2)
@@ -367,8 +297,8 @@ static size_t head_part_floats(int C, int Co) { return (size_t)HEAD_HD * C + HEA
 extern "C" size_t cfd_fno_head_workspace_bytes(int B, int C, int Hd, int Co, int HW) {
     (void)Hd;
     if (B <= 0) return 0;
-    const size_t fwd = (size_t)head_blocks(B, HW) * 3 * sizeof(float);
-    const size_t bwd = (size_t)head_bwd_blocks(B, HW) * head_part_floats(C, Co) * sizeof(float);
+    const size_t fwd = (size_t)head_blocks(B, HW, false) * 3 * sizeof(float);
+    const size_t bwd = (size_t)head_bwd_blocks(B, HW, false) * head_part_floats(C, Co) * sizeof(float);
     return fwd > bwd ? fwd : bwd;
 }
 

@@ -33,6 +33,7 @@ void read_env() {
 }  // namespace
 
 int cfd_tune_get(int which) {
+    if (which < 0 || which >= CFD_TUNE_COUNT) return -1;
     std::call_once(g_once, read_env);
     return g_knobs[which].value.load(std::memory_order_relaxed);
 }

@@ -19,7 +19,7 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 import torch
 import torch.distributed as dist
-from torch.optim import Adam, lr_scheduler
+from torch.optim import Adam
 from torch.utils.data import DataLoader, Dataset, Subset
 
 from ..engine import sync_gradients
@@ -29,6 +29,7 @@ from ..models.ffn import FfnModel
 from ..models.loss import loss_name_to_fn
 from .args import Args, is_args_valid
 from .common import dump_json, get_output_dir, load_best_ckpt, plot_loss, plot_predictions
+from .schedule import EarlyStopping, LrSchedule
 from .dist_util import (average_buffers, broadcast_model_state, check_resume_state, init_distributed, rank_world,
                         shard_indices)
 
