@@ -16,9 +16,10 @@ Rank 0 prints ONE JSON line.  Beside the contract's keys it carries
   exact_fp32                the same step and SpectralConv2d group with the transforms on the exact-fp32 kernels (cfd_tune_set("exact_fp32", 1))
   rollout / rollout_66x65   batched multi-step inference from one HIP graph (configs[4] horizon: 200 steps)
   train_66x65 / train_batch8  the same train step on the 66x65 grid (dam / tube / cylinder) and at the reference's default batch 8
-  unet_cfg2 / auto_deeponet_cfg3   train steps of BASELINE configs[2] / configs[3] on one GPU
+  unet_cfg2 / auto_deeponet_cfg3 / resnet_b32   train steps of BASELINE configs[2] / configs[3] and of the ResNet baseline on one GPU
   cpu_baseline              the reference's ATen call sequence on the host cores, at B = 256 and B = 32
-The extra legs run on rank 0 at N = 1 only.
+The rollout / rollout_66x65 legs run on EVERY rank (cases shard over the ranks, `n_gpus` inside the leg); the other extra legs
+run on rank 0 at N = 1 only.
 """
 from __future__ import annotations
 
@@ -107,26 +108,53 @@ def roofline_of(name, launches, total_ms, total_bytes, total_flops):
 
 def latest_profile(pattern):
     files = sorted((REPO / "profiles").glob(pattern))
-    return json.loads(files[-1].read_text()) if files else None
+    return (json.loads(files[-1].read_text()), files[-1]) if files else (None, None)
+
+
+def profile_avg_us(tag, name):
+    """Average duration of kernel ``name`` in the rocprofv3 --stats summary committed with the same profile tag, or None."""
+    import csv
+    f = REPO / "profiles" / f"{tag}_step_kernel_stats.csv"
+    if not f.exists():
+        return None
+    tot, calls = 0.0, 0
+    for r in csv.DictReader(f.open()):
+        k = r["Name"].replace("void ", "")
+        if k.startswith(name + "<") or k.startswith(name + "("):
+            tot += float(r["TotalDurationNs"])
+            calls += int(r["Calls"])
+    return tot / calls / 1e3 if calls else None
 
 
 def attach_pmc(rl, name, applies):
     """HBM traffic per launch and unit-busy percentages of the dominant kernel from the committed rocprofv3 PMC passes of this
-    same command (tools/profile_step.sh, tools/pmc_step.sh: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE)."""
+    same command (tools/profile_step.sh, tools/pmc_step.sh: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE).  The
+    counters are NOT measured in this run: the line names the profile they come from, and they are dropped (null + reason) when
+    the kernel's time in this run is more than 15 % away from its time in that profile -- i.e. when the kernel has changed."""
     if not (rl and applies):
         return
     try:
-        name = {"k_head_train": "k_head_bwd"}.get(name, name)  # profiler label -> kernel symbol (the fused head is k_head_bwd<.., FUSE>)
-        pmc = latest_profile("r*_pmc_traffic.json") or {}
-        match = [v for k, v in pmc.items() if k.startswith(name + "<") or k == name]
+        sym = {"k_head_train": "k_head_bwd"}.get(name, name)  # profiler label -> kernel symbol (the fused head is k_head_bwd<.., FUSE>)
+        pmc, pf = latest_profile("r*_pmc_traffic.json")
+        if not pmc:
+            return
+        tag = pf.name.split("_pmc_traffic")[0]
+        ref_us = profile_avg_us(tag, sym)
+        rl["pmc_profile"] = dict(file=f"profiles/{pf.name}", kernel_avg_us_in_profile=None if ref_us is None else round(ref_us, 2))
+        if ref_us is None or abs(rl["avg_us"] - ref_us) > 0.15 * ref_us:
+            rl["traffic"] = None
+            rl["pmc_profile"]["dropped"] = ("kernel time in this run deviates > 15 % from the profiled build (or the profile has no row for it): "
+                                            "counters of another build are not attached")
+            return
+        match = [v for k, v in pmc.items() if k.startswith(sym + "<") or k == sym]
         if match:
             rl["traffic"] = int(sum(m["traffic_bytes"] for m in match) / len(match))
-            rl["traffic_source"] = "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, per launch)"
-        busy = latest_profile("r*_step_busy.json") or {}
-        match = [v for k, v in busy.items() if k.startswith(name + "<") or k == name]
-        if match:
+            rl["traffic_source"] = f"profiles/{pf.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, per launch)"
+        busy, bf = latest_profile("r*_step_busy.json")
+        match = [v for k, v in (busy or {}).items() if k.startswith(sym + "<") or k == sym]
+        if match and bf.name.startswith(tag):
             rl["busy_pct"] = {k: match[0][k] for k in ("mfma", "valu", "lds", "wait") if k in match[0]}
-            rl["busy_source"] = "profiles/ (rocprofv3 --pmc SQ_* busy counters of the same step)"
+            rl["busy_source"] = f"profiles/{bf.name} (rocprofv3 --pmc SQ_* busy counters of the same step)"
     except Exception:  # noqa: BLE001
         pass
 
@@ -207,9 +235,9 @@ def spectral_leg(api, _lib, dev, B, C, H, W, reps):
                 frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None)
 
 
-def rollout_leg(model, B, steps, H, W, p, dev, reps=3, dtype="f32"):
+def rollout_leg(model, B, steps, H, W, p, dev, reps=3, dtype="f32", seed=99):
     from cfdbench_amd.rollout import FnoRollout
-    g = torch.Generator(device="cpu").manual_seed(99)
+    g = torch.Generator(device="cpu").manual_seed(seed)
     x0 = torch.randn(B, 2, H, W, generator=g).to(dev)
     cp = torch.randn(B, p, generator=g).to(dev)
     mask = torch.ones(B, 1, H, W, device=dev)
@@ -357,7 +385,8 @@ def main():
         "metric": "train frames/sec (64x64x2), Auto-FNO cavity", "value": round(fps, 1),
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (storage and accumulation; DFT / 1x1-weight-gradient / head contractions as bf16x3 split products)",
+        "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: Auto-FNO train step (fwd+nMSE+bwd+Adam), Fno2d(L={L},hidden={C},modes=12,p={p}), "
                                f"{H}x{W}, batch {B}/GPU, fp32, random-init weights",
                    "precision": "fp32 storage and accumulation; DFT / 1x1-weight-gradient / head contractions as 3-term "
@@ -395,11 +424,32 @@ def main():
 
     extra = rank == 0 and world == 1
     # ---- rollout legs: batched multi-step inference from one HIP graph (the metric's "rollout" half; configs[4]) ----
-    if extra and not args.no_rollout:
-        result["rollout"], _ = rollout_leg(model, args.rollout_batch, args.rollout_steps, H, W, p, dev)
+    # Cases shard over the ranks with no collective on the data path (harness/test_multistep.py): EVERY rank rolls
+    # out its own `--rollout-batch` cases, the legs are bracketed by barriers and timed by the slowest rank (weak scaling).
+    def rollout_all_ranks(mdl, Hx, Wx, **kw):
+        barrier()
+        res, _ = rollout_leg(mdl, args.rollout_batch, args.rollout_steps, Hx, Wx, p, dev, seed=99 + rank, **kw)
+        if world > 1:
+            t = torch.tensor([res["ms_per_step"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t.item())
+            scale = res["ms_per_step"] / ms
+            res["ms_per_step"] = round(ms, 4)
+            res["frames_per_s"] = round(res["frames_per_s"] * scale * world, 1)  # whole job: all ranks' cases / the slowest rank's time
+            for k in ("achieved", "frac"):
+                res["roofline"][k] = round(res["roofline"][k] * scale, 4)  # per GPU
+        res["n_gpus"] = world
+        res["cases_per_gpu"] = args.rollout_batch
+        return res
+
+    if not args.no_rollout:
+        ro = rollout_all_ranks(model, H, W)
         torch.manual_seed(0)
         m32 = Fno2d(2, 2, p, loss_name_to_fn("nmse"), 4, 12, 12, 32).to(dev)  # the reference's default width (args.py:190)
-        result["rollout_66x65"], _ = rollout_leg(m32, args.rollout_batch, args.rollout_steps, 66, 65, p, dev)
+        ro32 = rollout_all_ranks(m32, 66, 65)
+        if rank == 0:
+            result["rollout"], result["rollout_66x65"] = ro, ro32
+    if extra and not args.no_rollout:
         try:
             result["rollout_66x65_bf16"], _ = rollout_leg(m32, args.rollout_batch, args.rollout_steps, 66, 65, p, dev, dtype="bf16")
         except TypeError:
@@ -469,6 +519,22 @@ def main():
         result["auto_deeponet_cfg3"] = model_train_leg(api, "auto_deeponet", don, bd, 10, 3, Bd, None,
                                                        "BASELINE configs[3] per GPU: Auto-DeepONet(width 100, depth 8/8) train step, batch 512, 66x65, fp32")
         del don, bd
+        # ResNet (SURVEY a-7: the one MFMA-bound path, 4.37 GFLOP per frame forward); training mode = dropout active
+        from cfdbench_amd.models.resnet import ResNet
+        Br = 32
+        torch.manual_seed(0)
+        rn = ResNet(2, 2, 5, loss_name_to_fn("nmse"), hidden_chan=16, num_blocks=4, kernel_size=7, padding=3).to(dev)
+        xr = torch.randn(Br, 2, 64, 64, generator=gg).to(dev)
+        br = dict(inputs=xr, label=(xr.cpu() + 0.1 * torch.randn(Br, 2, 64, 64, generator=gg)).to(dev),
+                  case_params=torch.randn(Br, 5, generator=gg).to(dev), mask=torch.ones(Br, 1, 64, 64, device=dev))
+        leg = model_train_leg(api, "resnet", rn, br, 5, 2, Br, None,
+                              "ResNet(hidden 16, depth 4, 7x7) train step (src/models/resnet.py:145-198), batch 32, 64x64, fp32")
+        fl = 3 * 4.37e9 * Br
+        tf = fl / (leg["ms_per_step"] * 1e-3) / 1e12
+        leg["roofline_step"] = dict(bound="mfma", flops_per_step=fl, achieved=round(tf, 2), peak=FP32_PEAK_TF, unit="TFLOP/s",
+                                    frac=round(tf / FP32_PEAK_TF, 4), pipe="fp32 MFMA / VALU (exact-fp32 implicit-GEMM convs)")
+        result["resnet_b32"] = leg
+        del rn, br
 
     # ---- CPU baseline leg (rank 0, N=1): the reference's ATen call sequence on the host cores ------------------
     if extra and not args.no_cpu_baseline:

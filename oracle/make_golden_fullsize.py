@@ -11,6 +11,7 @@ the tests from the NumPy streams of oracle/synth.py.
   unet_dim12_p8_64x64    UNet(dim 12, input-insert, p 8), 64x64, train-mode BatchNorm: configs[2]       unet.py:153-223
   auto_deeponet_66x65    AutoDeepONet(branch 4295, width 100, depth 8/8, relu), 66x65: configs[3]       auto_deeponet.py:76-147
   rollout200_c32_66x65   Fno2d(hidden 32, L 4) generate_many, 200 steps, 66x65, border mask: configs[4]  fno2d.py:269-295
+  resnet_h16_d4_64x64    ResNet(hidden 16, depth 4, kernel 7), 64x64, eval mode (dropout off): SURVEY a-7   resnet.py:145-236
 """
 from __future__ import annotations
 
@@ -140,12 +141,39 @@ def gen_rollout200(name, pseed, bseed, B, C, L, H, W, steps, p=5, eps=0.05, gain
     print(name, "ok", frames.shape, "rms of frames 0 / 99 / 199:", [float(np.sqrt((frames[k] ** 2).mean())) for k in (0, 99, steps - 1)])
 
 
+def gen_resnet_big(name, seed, bseed, B, H, W, hidden, depth, p=5, steps=2):
+    """ResNet at the size init_model builds it (src/utils/autoregressive.py:93-104: hidden_chan 16, num_blocks = resnet_depth 4,
+    kernel 7, padding 3), EVAL mode (torch's dropout stream is not reproducible): predictions in full, loss, gradient
+    fingerprints, a short rollout.  The weights are the reference's own initialisation under ``seed`` (stored)."""
+    from models.resnet import ResNet  # reference
+    torch.manual_seed(seed)
+    model = ResNet(2, 2, p, MseLoss(normalize=True), hidden_chan=hidden, num_blocks=depth, kernel_size=7, padding=3)
+    model.eval()
+    sd0 = {k: v.clone().numpy() for k, v in model.state_dict().items()}
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    batch["mask"][:, :, -1, :] = 0
+    x = _t(batch["inputs"]).requires_grad_(True)
+    out = model(inputs=x, case_params=_t(batch["case_params"]), mask=_t(batch["mask"]), label=_t(batch["label"]))
+    out["loss"]["nmse"].backward()
+    save = dict(meta=np.array([seed, bseed, B, H, W, hidden, depth, p, steps]), preds=out["preds"].detach().numpy(),
+                g_inputs=x.grad.numpy(), **{f"loss_{k}": np.array(v.item()) for k, v in out["loss"].items()})
+    for k, v in sd0.items():
+        save[f"sd::{k}"] = v
+    _grad_fingerprints(model, save, n=512)
+    with torch.no_grad():
+        frames = model.generate_many(_t(batch["inputs"][0]), _t(batch["case_params"][0]), steps, _t(batch["mask"][0]))
+    save["frames"] = np.stack([f.numpy() for f in frames])
+    np.savez_compressed(OUT / f"{name}.npz", **save)
+    print(name, "ok", {k: float(v) for k, v in out["loss"].items()}, save["frames"].shape)
+
+
 GENERATORS = {
     "fno_cfg2_b256": lambda: gen_fno_big("fno_cfg2_b256", 201, 211, 256, 20, 4, 64, 64, 5),
     "fno_cyl_p8_64x64": lambda: gen_fno_big("fno_cyl_p8_64x64", 202, 212, 3, 20, 4, 64, 64, 8),
     "unet_dim12_p8_64x64": lambda: gen_unet_big("unet_dim12_p8_64x64", 203, 213, 4, 64, 64, 12, 8),
     "auto_deeponet_66x65": lambda: gen_auto_deeponet_big("auto_deeponet_66x65", 204, 214, 8, 66, 65, 100, 8, 5),
     "rollout200_c32_66x65": lambda: gen_rollout200("rollout200_c32_66x65", 205, 215, 2, 32, 4, 66, 65, 200),
+    "resnet_h16_d4_64x64": lambda: gen_resnet_big("resnet_h16_d4_64x64", 206, 216, 4, 64, 64, 16, 4),
 }
 
 

@@ -171,6 +171,35 @@ def test_unet_dim12_p8_64x64_vs_reference_golden(torch, golden_dir):
     assert O.rel_nmse(ev.cpu().numpy(), g["preds_eval"]) < 1e-9
 
 
+def test_resnet_h16_d4_64x64_vs_reference_golden(torch, golden_dir):
+    """ResNet at the size init_model builds (hidden 16, depth 4, 7x7 kernels, 64x64: SURVEY a-7, 4.37 GFLOP per frame forward):
+    eval-mode predictions, loss, every gradient (fingerprints of the reference's backward) and a rollout."""
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    from cfdbench_amd.models.resnet import ResNet
+    g = np.load(golden_dir / "resnet_h16_d4_64x64.npz")
+    seed, bseed, B, H, W, hidden, depth, p, steps = [int(v) for v in g["meta"]]
+    m = ResNet(2, 2, p, loss_name_to_fn("nmse"), hidden_chan=hidden, num_blocks=depth, kernel_size=7, padding=3).cuda()
+    sd = {k[len("sd::"):]: torch.from_numpy(np.ascontiguousarray(g[k])) for k in g.files if k.startswith("sd::")}
+    assert list(sd.keys()) == list(m.state_dict().keys())
+    m.load_state_dict(sd)
+    m.eval()
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    batch["mask"][:, :, -1, :] = 0
+    b = _cuda(torch, batch)
+    x = b["inputs"].clone().requires_grad_(True)
+    out = m(inputs=x, case_params=b["case_params"], mask=b["mask"], label=b["label"])
+    assert O.rel_nmse(out["preds"].detach().cpu().numpy(), g["preds"]) < 1e-9
+    assert abs(out["loss"]["nmse"].item() - float(g["loss_nmse"])) <= 1e-5 * float(g["loss_nmse"])
+    out["loss"]["nmse"].backward()
+    _check_fingerprints(g, _named_grads(m), tol_vals=1e-7, tol_norm=2e-4)
+    assert O.rel_nmse(x.grad.cpu().numpy(), g["g_inputs"]) < 1e-7
+    with torch.no_grad():
+        frames = m.generate_many(b["inputs"][0], b["case_params"][0], steps, b["mask"][0])
+    assert len(frames) == steps + 1  # resnet.py:229
+    for t in range(steps + 1):
+        assert O.rel_nmse(frames[t].cpu().numpy(), g["frames"][t]) < 1e-8
+
+
 def test_auto_deeponet_66x65_w100_d8_vs_reference_golden(torch, golden_dir):
     from cfdbench_amd.models.auto_deeponet import AutoDeepONet
     from cfdbench_amd.models.loss import loss_name_to_fn

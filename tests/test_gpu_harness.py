@@ -1,6 +1,7 @@
 """MI355X: the harness end to end on a synthetic dataset (train both paths, checkpoint tree, test, multi-step inference)
 and the HIP-graph rollout against Fno2d.generate_many and the golden rollouts of the reference."""
 import json
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -237,6 +238,71 @@ def test_multistep_inference_metrics(torch, tmp_path):
     for a, b in zip(metrics, ref):
         for k in a:
             assert abs(a[k] - b[k]) <= 1e-5 * abs(b[k]) + 1e-12, (k, a[k], b[k])
+
+
+def _multistep_rank(rank, world, port, out_dir, steps, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # two ranks on the box's one GPU: host-side collective
+    try:
+        from cfdbench_amd.harness.autoregressive import init_model
+        from cfdbench_amd.harness.data import SyntheticAutoDataset
+        from cfdbench_amd.harness.test_multistep import infer, prepare_cases, shard_cases
+        args = _args(Path(out_dir))
+        torch.manual_seed(1)
+        model = init_model(args).cuda()
+        data = SyntheticAutoDataset(n_cases=5, n_frames=4, height=64, width=64, seed=5, border_mask=True)
+        mine = shard_cases(5, rank, world)
+        feats, cps = prepare_cases(data, steps, only=set(mine))
+        assert len(feats) == len(mine)
+        q.put((rank, mine, infer(model, feats, cps, steps, n_total_cases=5)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multistep_inference_sharded_over_two_ranks(torch, tmp_path):
+    """rollout inference shards the test cases over the ranks (r, r + world, ...), every rank rolls its cases out from one
+    HIP graph, and ONE all-reduce of the (steps, 3) metric sums gives the single-process metrics (src/test_multistep.py:135-177)."""
+    import socket
+    import torch.multiprocessing as mp
+    from cfdbench_amd.harness.autoregressive import init_model
+    from cfdbench_amd.harness.data import SyntheticAutoDataset
+    from cfdbench_amd.harness.test_multistep import infer, prepare_cases
+    steps = 6
+    args = _args(tmp_path)
+    torch.manual_seed(1)
+    model = init_model(args).cuda()
+    data = SyntheticAutoDataset(n_cases=5, n_frames=4, height=64, width=64, seed=5, border_mask=True)
+    feats, cps = prepare_cases(data, steps)
+    single = infer(model, feats, cps, steps)
+    with torch.no_grad():  # the graph rollout behind infer() is bitwise the step-by-step generate_many
+        start = torch.stack([f[0, :-1] for f in feats])
+        plain = model.generate_many(inputs=start, case_params=torch.stack(cps), mask=torch.stack([f[0, -1] for f in feats]), steps=steps)
+    from cfdbench_amd.harness.test_multistep import rollout_frames
+    graph = rollout_frames(model, start, torch.stack(cps), torch.stack([f[0, -1] for f in feats]), steps)
+    assert all(torch.equal(a, b) for a, b in zip(plain, graph))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_multistep_rank, args=(r, 2, port, str(tmp_path), steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3]
+    for _, _, got in res:
+        for a, b in zip(got, single):
+            for k in a:
+                assert abs(a[k] - b[k]) <= 1e-9 * abs(b[k]) + 1e-15, (k, a[k], b[k])
 
 
 def test_multistep_unet_in_train_mode_follows_the_reference_per_case(torch, tmp_path):
