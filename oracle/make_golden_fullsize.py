@@ -127,8 +127,8 @@ def gen_auto_deeponet_big(name, pseed, bseed, B, H, W, width, depth, p):
     print(name, "ok", {k: float(v) for k, v in out["loss"].items()})
 
 
-def gen_rollout200(name, pseed, bseed, B, C, L, H, W, steps, p=5, eps=0.05, gain=30.0, decay=0.04):
-    params, batch = synth.make_rollout_case(pseed, bseed, B, C, L, H, W, p, eps, gain, decay)
+def gen_rollout200(name, pseed, bseed, B, C, L, H, W, steps, p=5, eps=0.05, gain=30.0, decay=0.04, route="w0"):
+    params, batch = synth.make_rollout_case(pseed, bseed, B, C, L, H, W, p, eps, gain, decay, route=route)
     model = Fno2d(2, 2, p, MseLoss(normalize=True), L, 12, 12, C).eval()
     model.load_state_dict({k: _t(v) for k, v in params.items()})
     with torch.no_grad():
@@ -136,7 +136,7 @@ def gen_rollout200(name, pseed, bseed, B, C, L, H, W, steps, p=5, eps=0.05, gain
     frames = np.stack([f.numpy() for f in frames])  # (steps, B, 2, H, W)
     keep = [k for k in ROLLOUT_KEEP if k < steps]
     np.savez_compressed(OUT / f"{name}.npz", meta=np.array([pseed, bseed, B, C, L, H, W, p, steps]),
-                        hyper=np.array([eps, gain, decay]), keep=np.array(keep), frames=frames[keep],
+                        hyper=np.array([eps, gain, decay]), route=np.array(route), keep=np.array(keep), frames=frames[keep],
                         norms=np.sqrt((frames.astype(np.float64) ** 2).mean(axis=(1, 2, 3, 4))))
     print(name, "ok", frames.shape, "rms of frames 0 / 99 / 199:", [float(np.sqrt((frames[k] ** 2).mean())) for k in (0, 99, steps - 1)])
 
@@ -173,6 +173,8 @@ GENERATORS = {
     "unet_dim12_p8_64x64": lambda: gen_unet_big("unet_dim12_p8_64x64", 203, 213, 4, 64, 64, 12, 8),
     "auto_deeponet_66x65": lambda: gen_auto_deeponet_big("auto_deeponet_66x65", 204, 214, 8, 66, 65, 100, 8, 5),
     "rollout200_c32_66x65": lambda: gen_rollout200("rollout200_c32_66x65", 205, 215, 2, 32, 4, 66, 65, 200),
+    # the same horizon with the blocks' identity routed through SpectralConv2d (round 3: the transforms' fixed operands on the identity path)
+    "rollout200_spectral_c32_66x65": lambda: gen_rollout200("rollout200_spectral_c32_66x65", 207, 217, 2, 32, 4, 66, 65, 200, route="spectral"),
     "resnet_h16_d4_64x64": lambda: gen_resnet_big("resnet_h16_d4_64x64", 206, 216, 4, 64, 64, 16, 4),
 }
 

@@ -56,7 +56,7 @@ def make_fno_params(seed: int, C: int = 20, L: int = 4, m1: int = 12, m2: int = 
 
 def make_fno_propagator_params(seed: int, C: int = 20, L: int = 4, m1: int = 12, m2: int = 12, p: int = 5, eps: float = 0.05,
                                spectral_gain: float = 1.0, signal: float = 1.0, decay: float = 0.0,
-                               dtype=np.float32) -> Dict[str, np.ndarray]:
+                               dtype=np.float32, route: str = "w0") -> Dict[str, np.ndarray]:
     """Weights that make Fno2d a NEAR-IDENTITY map x_{t+1} = x_t + O(eps) -- a stand-in for a trained one-step propagator
     in rollout studies (random-init weights collapse every input to one fixed point within five steps, so a 200-step
     rollout of them exercises nothing).  Construction: gelu(x) - gelu(-x) = x exactly, so the pair of channels (+s u, -s u)
@@ -65,8 +65,13 @@ def make_fno_propagator_params(seed: int, C: int = 20, L: int = 4, m1: int = 12,
       w0 of blocks >= 1: ch0' = h0 - h1, ch1' = h1 - h0, ... ;  fc1: hidden 0..3 likewise;  fc2: u' = (1 - decay) (g0 - g1) / s
     (``decay`` balances the growth the random perturbation adds, so that 200-step rollouts stay O(1)).
     Every other weight (incl. all biases and the spectral weights, which couple the pixels) is the usual random init
-    scaled by ``eps``.  Needs C >= 4."""
-    assert C >= 4
+    scaled by ``eps``.  Needs C >= 4.
+    ``route`` = "spectral" (round 3): the blocks' identity goes through SpectralConv2d instead of the 1x1 conv -- the same pair
+    arithmetic written into weights1 / weights2 at EVERY kept mode, i.e. identity o the low-pass projector onto the kept modes,
+    which is the identity on the band-limited fields of ``make_smooth_batch`` (and removes the out-of-band harmonics GELU adds,
+    so the pair difference still returns the field exactly).  A 200-step rollout of this network sends all its energy through
+    DFT -> mode mixing -> inverse DFT in every layer: the fixture for the rounding of the transforms' fixed twiddle operands."""
+    assert C >= 4 and route in ("w0", "spectral")
     base = make_fno_params(seed, C, L, m1, m2, p, dtype=dtype, spectral_gain=spectral_gain)
     out = {k: (v * eps).astype(v.dtype) for k, v in base.items()}
     s = signal
@@ -77,10 +82,17 @@ def make_fno_propagator_params(seed: int, C: int = 20, L: int = 4, m1: int = 12,
     for l in range(L):
         w = out[f"blocks.{l}.w0.weight"]
         for c in range(4):
-            if l == 0:
+            pair = 2 * (c // 2)
+            if route == "spectral":  # weights{1,2}[in, out, k, l] (fno2d.py:54-57: einsum "bixy,ioxy->boxy")
+                for key in (f"blocks.{l}.conv0.weights1", f"blocks.{l}.conv0.weights2"):
+                    if l == 0:
+                        out[key][c, c] += 1.0
+                    else:
+                        out[key][pair, c] += sgn[c % 2]
+                        out[key][pair + 1, c] -= sgn[c % 2]
+            elif l == 0:
                 w[c, c, 0, 0] += 1.0
             else:
-                pair = 2 * (c // 2)
                 w[c, pair, 0, 0] += sgn[c % 2]
                 w[c, pair + 1, 0, 0] -= sgn[c % 2]
     for c in range(4):
@@ -134,10 +146,10 @@ def summarize(a: np.ndarray, idx_seed: int, n: int = 64) -> Dict[str, np.ndarray
 
 
 def make_rollout_case(pseed: int, bseed: int, B: int, C: int, L: int, H: int, W: int, p: int, eps: float, gain: float,
-                      decay: float):
+                      decay: float, route: str = "w0"):
     """Weights and start frame of the long-rollout fixtures / studies: the near-identity propagator above on a band-limited
     field with the tube / dam style border mask (zero top / bottom rows and left column)."""
-    params = make_fno_propagator_params(pseed, C, L, 12, 12, p, eps=eps, spectral_gain=gain, decay=decay)
+    params = make_fno_propagator_params(pseed, C, L, 12, 12, p, eps=eps, spectral_gain=gain, decay=decay, route=route)
     batch = make_smooth_batch(bseed, B, H, W, p)
     batch["mask"][:, :, 0, :] = 0
     batch["mask"][:, :, -1, :] = 0

@@ -223,6 +223,40 @@ def test_auto_deeponet_66x65_w100_d8_vs_reference_golden(torch, golden_dir):
         assert O.rel_nmse(frames[t].cpu().numpy(), g["frames"][t]) < 1e-8
 
 
+def test_rollout_200_steps_through_the_spectral_branch_vs_reference_golden(torch, golden_dir):
+    """The same 200-step horizon with the blocks' identity routed through SpectralConv2d (oracle/synth.py, route = "spectral"): all
+    the energy passes DFT -> mode mixing -> inverse DFT in every layer of every step, so the rounding of the transforms' FIXED
+    operands (the twiddle tables, two bf16 pieces each on the default route) sits on the identity path and any coherent bias
+    it had would accumulate over the 800 transforms.  Checked on the default (split-bf16) route and on
+    the exact-fp32 route against the reference's fp32 CPU rollout."""
+    from tests import kernel_checks as K
+    from tests.backends import TorchBackend
+    g = np.load(golden_dir / "rollout200_spectral_c32_66x65.npz")
+    pseed, bseed, B, C, L, H, W, p, steps = [int(v) for v in g["meta"]]
+    eps, gain, decay = [float(v) for v in g["hyper"]]
+    assert str(g["route"]) == "spectral"
+    params, batch = synth.make_rollout_case(pseed, bseed, B, C, L, H, W, p, eps, gain, decay, route="spectral")
+    m = _fno(torch, params, C, L, p).eval()
+    b = _cuda(torch, batch)
+    keep = [int(k) for k in g["keep"]]
+    out = {}
+    for route, knob in (("default (bf16x3 transforms)", -1), ("exact_fp32", 1)):
+        with K.tuned(TorchBackend(), exact_fp32=knob):
+            with torch.no_grad():
+                frames = m.generate_many(b["inputs"], b["case_params"], b["mask"], steps)
+        errs = {k: O.rel_nmse(frames[k].cpu().numpy(), g["frames"][i]) for i, k in enumerate(keep)}
+        print(f"spectral-branch rollout, {route}: nMSE vs the reference's fp32 frames:", {k: f"{v:.1e}" for k, v in errs.items()})
+        out[route] = errs
+        for k, e in errs.items():
+            assert e < 2e-7 and e < NORTH_STAR_TOL, (route, k, e)
+    # the frames really went through the spectral branch: with the spectral weights zeroed the rollout dies away
+    dead = {k: (np.zeros_like(v) if "conv0.weights" in k else v) for k, v in params.items()}
+    md = _fno(torch, dead, C, L, p).eval()
+    with torch.no_grad():
+        fd = md.generate_many(b["inputs"], b["case_params"], b["mask"], 3)
+    assert float(fd[2].double().pow(2).mean().sqrt()) < 0.05 * float(g["norms"][2])
+
+
 def test_rollout_200_steps_c32_66x65_vs_reference_golden(torch, golden_dir):
     """BASELINE configs[4] horizon: 200 autoregressive steps on the tube / dam grid at the reference's default width.  The
     fixture's network is a near-identity propagator (oracle/synth.py), so round-off is carried from step to step instead

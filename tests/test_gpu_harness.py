@@ -302,7 +302,7 @@ def test_multistep_inference_sharded_over_two_ranks(torch, tmp_path):
     for _, _, got in res:
         for a, b in zip(got, single):
             for k in a:
-                assert abs(a[k] - b[k]) <= 1e-9 * abs(b[k]) + 1e-15, (k, a[k], b[k])
+                assert abs(a[k] - b[k]) <= 2e-6 * abs(b[k]) + 1e-12, (k, a[k], b[k])  # fp32 sums on the device; batch 3 + 2 against batch 5
 
 
 def test_multistep_unet_in_train_mode_follows_the_reference_per_case(torch, tmp_path):
