@@ -115,6 +115,10 @@ _SIGS = {
     "cfd_fno_forward_ex": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "cfd_fno_forward_train": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),
                                    _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P]),
+    "cfd_fno_forward_train_ex": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),
+                                      _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _P]),
+    "cfd_fno_backward_phase_ex": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),
+                                       _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "cfd_fno_backward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),
                               _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cfd_fno_backward_phase": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),

@@ -88,6 +88,13 @@ __device__ __forceinline__ float cfd_ld(const TA* p) { return (float)*p; }
 template <typename TA>
 __device__ __forceinline__ void cfd_st(TA* p, float v) { *p = (TA)v; }
 static inline size_t cfd_dt_size(int dt) { return dt == CFD_DT_BF16 ? 2 : 4; }
+// four consecutive stored activations (16-byte aligned fp32 / 8-byte aligned bf16) as one vector load
+__device__ __forceinline__ float4 cfd_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 cfd_ld4(const __bf16* p) {
+    typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+    const bf16x4_ t = *reinterpret_cast<const bf16x4_*>(p);
+    return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+}
 
 // Internal (not exported) forms of the forward-path entry points with the activation storage type as an argument; dt =
 // CFD_DT_F32 is exactly the public function.  x / out / aprev / a point at activations of that type.  With bf16 storage the
@@ -96,6 +103,8 @@ static inline size_t cfd_dt_size(int dt) { return dt == CFD_DT_BF16 ? 2 : 4; }
 int cfd_int_spectral_dft(const cfd_plan* p, const void* x, float* xh, int nimg, int act_in, int dt, void* stream);
 int cfd_int_spectral_idft(const cfd_plan* p, const float* z, const void* addend, const void* aprev, void* out, int nimg, int epi,
                           int dt, void* stream);
+int cfd_int_spectral_idft_grad(const cfd_plan* p, const float* z, const float* addend, const void* aprev, float* out, int nimg,
+                               int dt, void* stream);
 int cfd_int_chanmix(const void* in, const float* w, const float* bias, void* out, int B, int Ci, int Co, int HW, int act_in,
                     int transpose, int dt, void* stream);
 int cfd_int_fno_stem_fwd(const cfd_plan* p, const float* inputs, const float* mask, const float* case_params, const float* w,
@@ -103,6 +112,10 @@ int cfd_int_fno_stem_fwd(const cfd_plan* p, const float* inputs, const float* ma
 int cfd_int_fno_head_fwd(const void* a, const float* mask, const float* label, const float* w1, const float* b1, const float* w2,
                          const float* b2, float* preds, float* sums, void* ws, int B, int C, int Hd, int Co, int HW, int act_in,
                          int dt, void* stream);
+
+int cfd_int_fno_head_train(const void* a, const float* mask, const float* label, const float* coef, const float* w1, const float* b1,
+                           const float* w2, const float* b2, float* preds, float* sums, float* ga, float* gw1, float* gb1,
+                           float* gw2, float* gb2, void* ws, int B, int C, int Hd, int Co, int HW, int act_in, int dt, void* stream);
 
 #define CFD_SQRT1_2 0.70710678118654752440f
 #define CFD_INV_SQRT_2PI 0.39894228040143267794f
@@ -183,6 +196,12 @@ __device__ __forceinline__ float cfd_gelu_grad(float x) {
 struct CfdSplit8 {
     bf16x8 hi, lo;
 };
+// FIXED operands -- the twiddle tables of the transforms -- are carried in CFD_TW = 3 bf16 pieces (hi + lo + lo2 = the fp32 value
+// exactly): the rounding of a fixed operand is the same in every step of a rollout, i.e. a coherent perturbation of the
+// operator that accumulates (200 steps through the spectral branch: nMSE 7e-7 with two pieces, 1e-9 with three --
+// tests/test_gpu_fullsize.py), while the activations' rounding averages out.  A product then takes FOUR bf16 MFMAs:
+// x_lo t_hi + x_hi t_lo + x_hi t_lo2 + x_hi t_hi.  Tables are stored piece-major: [table][piece][64 lanes] 16-byte vectors.
+#define CFD_TW 3
 // hi = bf16(x), lo = bf16(x - hi), two values per v_cvt_pk_bf16_f32: the float value of hi is its bit pattern shifted
 // into the upper half, so a pair costs 2 conversions + 1 shift + 1 mask + 2 subtractions (written element by element the
 // compiler converted every value twice, once for the packed operand and once for 16-bit stores: 40 instead of 24 VALU

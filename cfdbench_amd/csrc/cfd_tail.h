@@ -114,5 +114,7 @@ int cfd_int_spectral_mix_adj_wgrad(const cfd_plan* p, const float* xh, const flo
                                    SpecWgradTail* defer);
 int cfd_int_chan_wgrad(const float* g, const float* a, float* gw, float* gb, void* ws, int B, int Ci, int Co, int HW,
                        int act_in, void* stream, ChanWgradTail* defer);
+int cfd_int_chan_wgrad_dt(const float* g, const void* a, float* gw, float* gb, void* ws, int B, int Ci, int Co, int HW,
+                          int act_in, int dt, void* stream, ChanWgradTail* defer);
 int cfd_int_fno_block_bwd_input(const cfd_plan* p, const float* g, const float* gz, const float* w0, const float* aprev,
                                 float* gin, int B, int Cin, int Cout, void* stream, const CfdReduceTail* tail);

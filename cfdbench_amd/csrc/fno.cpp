@@ -71,7 +71,7 @@ extern "C" size_t cfd_fno_workspace_bytes(const cfd_plan* p, const cfd_fno_shape
 }
 
 extern "C" size_t cfd_fno_workspace_bytes_ex(const cfd_plan* p, const cfd_fno_shape* s, int training, int act_dtype) {
-    if (!p || !s || s->B < 1 || (act_dtype != CFD_DT_F32 && (act_dtype != CFD_DT_BF16 || training))) return 0;
+    if (!p || !s || s->B < 1 || (act_dtype != CFD_DT_F32 && act_dtype != CFD_DT_BF16)) return 0;
     return make_layout(p, s, training, act_dtype).total_bytes;
 }
 
@@ -129,28 +129,49 @@ extern "C" int cfd_fno_forward_train(const cfd_plan* p, const cfd_fno_shape* s, 
                                      const cfd_fno_params* g, const float* inputs, const float* case_params,
                                      const float* mask, const float* label, float* preds, float* sums, float* coef, void* ws,
                                      int which, float upstream, void* stream) {
+    return cfd_fno_forward_train_ex(p, s, prm, g, inputs, case_params, mask, label, preds, sums, coef, ws, which, upstream, CFD_DT_F32, stream);
+}
+
+// act_dtype = 1: bf16-storage TRAINING (the fork's other trainers offer mixed precision, src/args.py:77-80): the saved
+// activations a_0 .. a_L are rounded to bf16 when stored (half the bytes of everything the backward pass re-reads); parameters,
+// kept modes, gradients, accumulation and the optimiser stay fp32.  The backward pass differentiates the computation that was
+// actually run, i.e. it reads the ROUNDED activations (cfd_fno_backward_phase_ex with the same act_dtype).  Each FnoBlock runs as
+// 1x1 conv (fp32 scratch) + inverse transform with addend, so a stored pre-activation is rounded exactly once.
+extern "C" int cfd_fno_forward_train_ex(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm,
+                                        const cfd_fno_params* g, const float* inputs, const float* case_params,
+                                        const float* mask, const float* label, float* preds, float* sums, float* coef, void* ws,
+                                        int which, float upstream, int act_dtype, void* stream) {
     CFD_TRY(check_shape("cfd_fno_forward_train", p, s));
     CFD_REQUIRE(prm && g && inputs && label && preds && sums && coef && ws, CFD_ERR_INVALID_ARG, "cfd_fno_forward_train: NULL pointer");
-    const Layout L = make_layout(p, s, 1);
+    CFD_REQUIRE(act_dtype == CFD_DT_F32 || act_dtype == CFD_DT_BF16, CFD_ERR_INVALID_ARG, "cfd_fno_forward_train: act_dtype %d (0 = fp32, 1 = bf16)", act_dtype);
+    const int dt = act_dtype;
+    const Layout L = make_layout(p, s, 1, dt);
     char* base = (char*)ws;
     const int B = s->B, C = s->hidden, HW = s->H * s->W, NL = s->num_layers;
-    auto act_buf = [&](int l) { return (float*)(base + L.off_acts) + (size_t)l * L.n_act; };
+    const size_t esz = cfd_dt_size(dt);
+    auto act_buf = [&](int l) { return (void*)(base + L.off_acts + (size_t)l * L.n_act * esz); };
     auto xh_buf = [&](int l) { return (float*)(base + L.off_xh) + (size_t)l * L.n_modes; };
     float* z = (float*)(base + L.off_z);
     float* gA = (float*)(base + L.off_gA);
     void* scratch = base + L.off_scratch;
     // the label's energy and the gradient coefficients first: independent of the network (scratch is free until the head)
     CFD_TRY(cfd_label_energy_coef(label, mask, sums, coef, scratch, B, s->out_chan, HW, which, upstream, stream));
-    CFD_TRY(cfd_fno_stem_fwd(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, act_buf(0), B, s->in_chan, s->n_case_params, C,
-                             stream));
+    CFD_TRY(cfd_int_fno_stem_fwd(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, act_buf(0), B, s->in_chan, s->n_case_params, C,
+                                 dt, stream));
     for (int l = 0; l < NL; ++l) {  // FnoBlock.forward, fno2d.py:106-112
         const int act = l > 0;
-        CFD_TRY(cfd_spectral_dft(p, act_buf(l), xh_buf(l), B * C, act, stream));
+        CFD_TRY(cfd_int_spectral_dft(p, act_buf(l), xh_buf(l), B * C, act, dt, stream));
         CFD_TRY(cfd_spectral_mix(p, xh_buf(l), prm->spec_w1[l], prm->spec_w2[l], z, B, C, C, 0, stream));
-        CFD_TRY(cfd_fno_block_fwd(p, act_buf(l), z, prm->w0_w[l], prm->w0_b[l], act_buf(l + 1), B, C, C, act, stream));
+        if (dt == CFD_DT_F32) {
+            CFD_TRY(cfd_fno_block_fwd(p, (const float*)act_buf(l), z, prm->w0_w[l], prm->w0_b[l], (float*)act_buf(l + 1), B, C, C, act, stream));
+        } else {
+            float* tmp = (float*)(base + L.off_tmp);
+            CFD_TRY(cfd_int_chanmix(act_buf(l), prm->w0_w[l], prm->w0_b[l], tmp, B, C, C, HW, act, 0, dt, stream));
+            CFD_TRY(cfd_int_spectral_idft(p, z, tmp, nullptr, act_buf(l + 1), B * C, 1, dt, stream));
+        }
     }
-    return cfd_fno_head_train(act_buf(NL), mask, label, coef, prm->fc1_w, prm->fc1_b, prm->fc2_w, prm->fc2_b, preds, sums, gA,
-                                  g->fc1_w, g->fc1_b, g->fc2_w, g->fc2_b, scratch, B, C, s->head, s->out_chan, HW, NL > 0, stream);
+    return cfd_int_fno_head_train(act_buf(NL), mask, label, coef, prm->fc1_w, prm->fc1_b, prm->fc2_w, prm->fc2_b, preds, sums, gA,
+                                  g->fc1_w, g->fc1_b, g->fc2_w, g->fc2_b, scratch, B, C, s->head, s->out_chan, HW, NL > 0, dt, stream);
 }
 
 // One phase of the backward pass: 0 = projection head (+ loss gradient), 1 .. L = FnoBlock L-phase (the blocks in reverse
@@ -161,23 +182,37 @@ extern "C" int cfd_fno_backward_phase(const cfd_plan* p, const cfd_fno_shape* s,
                                       const cfd_fno_params* g, const float* inputs, const float* case_params,
                                       const float* mask, const float* label, const float* preds,
                                       const float* gpreds_ext, const float* coef, void* ws, int phase, void* stream) {
+    return cfd_fno_backward_phase_ex(p, s, prm, g, inputs, case_params, mask, label, preds, gpreds_ext, coef, ws, phase, CFD_DT_F32, stream);
+}
+
+// act_dtype = 1 continues cfd_fno_forward_train_ex(act_dtype = 1): phases 1 .. L+1 read the bf16 activations that pass stored.  (Phase 0,
+// the stand-alone head backward, exists for fp32 storage only: the bf16 path always runs the one-pass training head.)
+extern "C" int cfd_fno_backward_phase_ex(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm,
+                                         const cfd_fno_params* g, const float* inputs, const float* case_params,
+                                         const float* mask, const float* label, const float* preds,
+                                         const float* gpreds_ext, const float* coef, void* ws, int phase, int act_dtype, void* stream) {
     CFD_TRY(check_shape("cfd_fno_backward_phase", p, s));
     CFD_REQUIRE(prm && g && inputs && ws, CFD_ERR_INVALID_ARG, "cfd_fno_backward_phase: NULL pointer");
-    const Layout L = make_layout(p, s, 1);
+    CFD_REQUIRE(act_dtype == CFD_DT_F32 || act_dtype == CFD_DT_BF16, CFD_ERR_INVALID_ARG, "cfd_fno_backward_phase: act_dtype %d (0 = fp32, 1 = bf16)", act_dtype);
+    const int dt = act_dtype;
+    const Layout L = make_layout(p, s, 1, dt);
     char* base = (char*)ws;
     const int B = s->B, C = s->hidden, HW = s->H * s->W, NL = s->num_layers;
+    const size_t esz = cfd_dt_size(dt);
     CFD_REQUIRE(phase >= 0 && phase <= NL + 1, CFD_ERR_INVALID_ARG, "cfd_fno_backward_phase: phase %d outside 0..%d", phase, NL + 1);
-    auto act_buf = [&](int l) { return (float*)(base + L.off_acts) + (size_t)l * L.n_act; };
+    auto act_buf = [&](int l) { return (void*)(base + L.off_acts + (size_t)l * L.n_act * esz); };
     auto xh_buf = [&](int l) { return (float*)(base + L.off_xh) + (size_t)l * L.n_modes; };
     float* z = (float*)(base + L.off_z);
     float* gA = (float*)(base + L.off_gA);
     float* gB = (float*)(base + L.off_gB);
     float* gh = (float*)(base + L.off_gh);
     void* scratch = base + L.off_scratch;
-    if (phase == 0)
-        return cfd_fno_head_bwd(act_buf(NL), mask, label, preds, gpreds_ext, coef, prm->fc1_w, prm->fc1_b, prm->fc2_w, gA,
+    if (phase == 0) {
+        CFD_REQUIRE(dt == CFD_DT_F32, CFD_ERR_UNSUPPORTED, "cfd_fno_backward_phase: phase 0 with bf16 storage (the head ran in cfd_fno_forward_train_ex)");
+        return cfd_fno_head_bwd((const float*)act_buf(NL), mask, label, preds, gpreds_ext, coef, prm->fc1_w, prm->fc1_b, prm->fc2_w, gA,
                                 g->fc1_w, g->fc1_b, g->fc2_w, g->fc2_b, scratch, B, C, s->head, s->out_chan, HW, NL > 0,
                                 stream);
+    }
     const int done = phase - 1;  // blocks already processed: the gradient sits in gA after an even count
     float* gcur = (done & 1) ? gB : gA;
     float* gnext = (done & 1) ? gA : gB;
@@ -188,15 +223,25 @@ extern "C" int cfd_fno_backward_phase(const cfd_plan* p, const cfd_fno_shape* s,
     const int act = l > 0;
     // gcur = d loss / d a_{l+1}
     CFD_TRY(cfd_spectral_dft(p, gcur, gh, B * C, 0, stream));
+    char* scratch2 = (char*)scratch + cfd_align_up(cfd_spectral_wgrad_workspace_bytes(p, B, C, C), 256);
+    if (dt == CFD_DT_BF16) {
+        // two passes for the input gradient (1x1 conv transposed into the fp32 scratch tensor, inverse transform + addend
+        // [* gelu'(a_l), a_l read as bf16]); the weight-gradient producers reduce their own partial sums
+        float* tmp = (float*)(base + L.off_tmp);
+        CFD_TRY(cfd_int_spectral_mix_adj_wgrad(p, xh_buf(l), gh, prm->spec_w1[l], prm->spec_w2[l], z, g->spec_w1[l],
+                                               g->spec_w2[l], scratch, B, C, C, stream, nullptr));
+        CFD_TRY(cfd_int_chan_wgrad_dt(gcur, act_buf(l), g->w0_w[l], g->w0_b[l], scratch2, B, C, C, HW, act, dt, stream, nullptr));
+        CFD_TRY(cfd_chanmix(gcur, prm->w0_w[l], nullptr, tmp, B, C, C, HW, 0, 1, stream));
+        return cfd_int_spectral_idft_grad(p, z, tmp, act ? act_buf(l) : nullptr, gnext, B * C, dt, stream);
+    }
     // the reductions of both weight gradients ride in front of the input-gradient kernel's launch (cfd_tail.h); whatever
     // a producer could not defer it has already reduced itself
     CfdReduceTail tail{};
-    char* scratch2 = (char*)scratch + cfd_align_up(cfd_spectral_wgrad_workspace_bytes(p, B, C, C), 256);
     CFD_TRY(cfd_int_spectral_mix_adj_wgrad(p, xh_buf(l), gh, prm->spec_w1[l], prm->spec_w2[l], z, g->spec_w1[l],
                                            g->spec_w2[l], scratch, B, C, C, stream, &tail.spec));
-    CFD_TRY(cfd_int_chan_wgrad(gcur, act_buf(l), g->w0_w[l], g->w0_b[l], scratch2, B, C, C, HW, act, stream, &tail.chan));
+    CFD_TRY(cfd_int_chan_wgrad(gcur, (const float*)act_buf(l), g->w0_w[l], g->w0_b[l], scratch2, B, C, C, HW, act, stream, &tail.chan));
     tail.nblk = (tail.spec.part || tail.chan.part) ? 128 : 0;
-    return cfd_int_fno_block_bwd_input(p, gcur, z, prm->w0_w[l], act ? act_buf(l) : nullptr, gnext, B, C, C, stream, &tail);
+    return cfd_int_fno_block_bwd_input(p, gcur, z, prm->w0_w[l], act ? (const float*)act_buf(l) : nullptr, gnext, B, C, C, stream, &tail);
 }
 
 extern "C" int cfd_fno_backward(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm,

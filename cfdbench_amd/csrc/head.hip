@@ -391,9 +391,10 @@ int cfd_int_fno_head_fwd(const void* a_, const float* mask, const float* label, 
 // read the sum, form the prediction and its loss gradient, and continue with the backward arithmetic on the GELU terms
 // they kept in registers.  `preds_w` / `b2` are used instead of `preds` / `gext`; the partial-sum block grows by
 // (sum d^2, sum |d|).
-template <int KS, bool VEC4, bool ACT, bool FUSE = false>
+// TA: storage type of the activations `a` (float; __bf16 in bf16-storage training, FUSE only).
+template <int KS, bool VEC4, bool ACT, bool FUSE = false, typename TA = float>
 __global__ __launch_bounds__(256, 2) void k_head_bwd(
-    const float* __restrict__ a, const float* __restrict__ mask, const float* __restrict__ label,
+    const TA* __restrict__ a, const float* __restrict__ mask, const float* __restrict__ label,
     const float* __restrict__ preds, const float* __restrict__ gext, const float* __restrict__ coef,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, float* __restrict__ ga,
     float* __restrict__ part, int B, int C, int Co, int HW, float* __restrict__ preds_w, const float* __restrict__ b2) {
@@ -515,14 +516,14 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
             if (t.b >= 0 && i < C) {
                 const int b = t.b;
                 const int p4 = t.px0 + 4 * n4;
-                const float* src = a + ((size_t)b * C + i) * HW + p4;
+                const TA* src = a + ((size_t)b * C + i) * HW + p4;
                 if constexpr (VEC4) {
-                    if (p4 < HW) v = *reinterpret_cast<const float4*>(src);
+                    if (p4 < HW) v = cfd_ld4(src);
                 } else {
-                    if (p4 < HW) v.x = src[0];
-                    if (p4 + 1 < HW) v.y = src[1];
-                    if (p4 + 2 < HW) v.z = src[2];
-                    if (p4 + 3 < HW) v.w = src[3];
+                    if (p4 < HW) v.x = cfd_ld(src);
+                    if (p4 + 1 < HW) v.y = cfd_ld(src + 1);
+                    if (p4 + 2 < HW) v.z = cfd_ld(src + 2);
+                    if (p4 + 3 < HW) v.w = cfd_ld(src + 3);
                 }
             }
             raw[k] = v;
@@ -1044,6 +1045,14 @@ extern "C" int cfd_fno_head_train(const float* a, const float* mask, const float
                                   const float* b1, const float* w2, const float* b2, float* preds, float* sums, float* ga,
                                   float* gw1, float* gb1, float* gw2, float* gb2, void* ws, int B, int C, int Hd, int Co,
                                   int HW, int act_in, void* stream) {
+    return cfd_int_fno_head_train(a, mask, label, coef, w1, b1, w2, b2, preds, sums, ga, gw1, gb1, gw2, gb2, ws, B, C, Hd, Co, HW, act_in,
+                                  CFD_DT_F32, stream);
+}
+
+// `a` stored as dt (CFD_DT_BF16: bf16-storage training); everything else fp32
+int cfd_int_fno_head_train(const void* a, const float* mask, const float* label, const float* coef, const float* w1, const float* b1,
+                           const float* w2, const float* b2, float* preds, float* sums, float* ga, float* gw1, float* gb1,
+                           float* gw2, float* gb2, void* ws, int B, int C, int Hd, int Co, int HW, int act_in, int dt, void* stream) {
     CFD_REQUIRE(a && label && coef && w1 && b1 && w2 && b2 && preds && sums && ga && gw1 && gb1 && gw2 && gb2 && ws,
                 CFD_ERR_INVALID_ARG, "cfd_fno_head_train: NULL pointer");
     CFD_TRY(head_check("cfd_fno_head_train", B, C, Hd, Co, HW));
@@ -1053,16 +1062,21 @@ extern "C" int cfd_fno_head_train(const float* a, const float* mask, const float
     float* part = (float*)ws;
     const bool v4 = HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)ga % 16) == 0 && ((uintptr_t)preds % 16) == 0;
     {
-    CFD_PROF_W("k_head_train", st, 4.0 * B * HW * (2.0 * C + 1 + 2.0 * Co), 2.0 * B * HW * (double)HEAD_HD * (3.0 * C + 3.0 * Co));
-#define CFD_HT(K_, V_, A_)                                                                                                \
-    hipLaunchKernelGGL((k_head_bwd<K_, V_, A_, true>), dim3(blocks), dim3(256), 0, st, a, mask, label, (const float*)nullptr, \
+    CFD_PROF_W("k_head_train", st, B * HW * ((4.0 + cfd_dt_size(dt)) * C + 4.0 + 8.0 * Co), 2.0 * B * HW * (double)HEAD_HD * (3.0 * C + 3.0 * Co));
+#define CFD_HT(K_, V_, A_, T_)                                                                                            \
+    hipLaunchKernelGGL((k_head_bwd<K_, V_, A_, true, T_>), dim3(blocks), dim3(256), 0, st, (const T_*)a, mask, label, (const float*)nullptr, \
                        (const float*)nullptr, coef, w1, b1, w2, ga, part, B, C, Co, HW, preds, b2)
-#define CFD_HT_VA(K_)                              \
-    do {                                           \
-        if (v4 && act_in) CFD_HT(K_, true, true);  \
-        else if (v4) CFD_HT(K_, true, false);      \
-        else if (act_in) CFD_HT(K_, false, true);  \
-        else CFD_HT(K_, false, false);             \
+#define CFD_HT_VA(K_)                                                     \
+    do {                                                                  \
+        if (dt == CFD_DT_BF16) {                                          \
+            if (v4 && act_in) CFD_HT(K_, true, true, __bf16);             \
+            else if (v4) CFD_HT(K_, true, false, __bf16);                 \
+            else if (act_in) CFD_HT(K_, false, true, __bf16);             \
+            else CFD_HT(K_, false, false, __bf16);                        \
+        } else if (v4 && act_in) CFD_HT(K_, true, true, float);           \
+        else if (v4) CFD_HT(K_, true, false, float);                      \
+        else if (act_in) CFD_HT(K_, false, true, float);                  \
+        else CFD_HT(K_, false, false, float);                             \
     } while (0)
     if (C <= 8) CFD_HT_VA(2);
     else if (C <= 20) CFD_HT_VA(5);

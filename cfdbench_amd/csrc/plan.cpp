@@ -120,16 +120,20 @@ extern "C" int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out) {
     for (int i = 0; i < H; ++i) gx[i] = (i == H - 1) ? 1.0f : (float)((double)i * (1.0 / (double)(H - 1)));
     for (int i = 0; i < W; ++i) gy[i] = (i == W - 1) ? 1.0f : (float)((double)i * (1.0 / (double)(W - 1)));
 
+    // a table value in CFD_TW = 3 bf16 pieces (hi, lo, lo2: exact), written at 16-byte vector `vec` (+64, +128 for the later pieces)
+    auto put3 = [&](std::vector<unsigned short>& dst, size_t vec, int v, double x) {
+        float rem = (float)x;
+        for (int piece = 0; piece < CFD_TW; ++piece) {
+            const unsigned short b = bf16_rne(rem);
+            dst[(vec + 64 * (size_t)piece) * 8 + v] = b;
+            rem -= bf16_to_float(b);
+        }
+    };
     // ---- split-bf16 forward tables (64x64 grids): k-slot (q, v) of the K = 32 operand ----
     std::vector<unsigned short> fwd3;
     if (H == 64 && W == 64) {
-        fwd3.assign((size_t)7 * 2 * 64 * 8, 0);
-        auto putf = [&](int tbl, int lane, int v, double x) {
-            const float xf32 = (float)x;
-            const unsigned short hi = bf16_rne(xf32);
-            fwd3[((size_t)(2 * tbl) * 64 + lane) * 8 + v] = hi;
-            fwd3[((size_t)(2 * tbl + 1) * 64 + lane) * 8 + v] = bf16_rne(xf32 - bf16_to_float(hi));
-        };
+        fwd3.assign((size_t)7 * CFD_TW * 64 * 8, 0);
+        auto putf = [&](int tbl, int lane, int v, double x) { put3(fwd3, (size_t)(CFD_TW * tbl) * 64 + lane, v, x); };
         for (int lane = 0; lane < 64; ++lane) {
             const int q = lane >> 4, i = lane & 15;
             for (int v = 0; v < 8; ++v) {
@@ -157,18 +161,13 @@ extern "C" int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out) {
     // ---- split-bf16 inverse tables (K = 32 MFMA operand order: lane vector element v = k-step v) ----
     std::vector<unsigned short> inv3;
     if (T <= 4 && SA <= 8 && SB <= 8 && NJ == 4) {
-        inv3.assign((size_t)(2 * T + 2 * NJ) * 64 * 8, 0);
-        auto put = [&](size_t vec, int v, float x) {  // vec = index of the hi vector; the lo vector follows 64 later
-            const unsigned short hi = bf16_rne(x);
-            inv3[vec * 8 + v] = hi;
-            inv3[(vec + 64) * 8 + v] = bf16_rne(x - bf16_to_float(hi));
-        };
+        inv3.assign((size_t)(CFD_TW * T + CFD_TW * NJ) * 64 * 8, 0);
         for (int t = 0; t < T; ++t)
             for (int lane = 0; lane < 64; ++lane)
-                for (int v = 0; v < SA; ++v) put((size_t)(2 * t) * 64 + lane, v, ta[(t * SA + v) * 64 + lane]);
+                for (int v = 0; v < SA; ++v) put3(inv3, (size_t)(CFD_TW * t) * 64 + lane, v, ta[(t * SA + v) * 64 + lane]);
         for (int j = 0; j < NJ; ++j)
             for (int lane = 0; lane < 64; ++lane)
-                for (int v = 0; v < SB; ++v) put((size_t)(2 * T + 2 * j) * 64 + lane, v, tb[(v * NJ + j) * 64 + lane]);
+                for (int v = 0; v < SB; ++v) put3(inv3, (size_t)(CFD_TW * T + CFD_TW * j) * 64 + lane, v, tb[(v * NJ + j) * 64 + lane]);
     }
 
     // ---- general-width split-bf16 tables (any W <= 80, H <= 70): y = 16 j + n column map ----
@@ -179,13 +178,8 @@ extern "C" int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out) {
     if (H <= 70 && W <= 80 && SA <= 8 && SB <= 8 && T <= 8) {
         const int NJG = p->NJG, NHG = p->NHG;
         const int ntbl = 4 + 2 * NHG;
-        fwdg.assign((size_t)ntbl * 2 * 64 * 8, 0);
-        auto putg = [&](std::vector<unsigned short>& dst, size_t hivec, int v, double x) {
-            const float xf32 = (float)x;
-            const unsigned short hi = bf16_rne(xf32);
-            dst[hivec * 8 + v] = hi;
-            dst[(hivec + 64) * 8 + v] = bf16_rne(xf32 - bf16_to_float(hi));
-        };
+        fwdg.assign((size_t)ntbl * CFD_TW * 64 * 8, 0);
+        auto putg = put3;
         for (int lane = 0; lane < 64; ++lane) {
             const int q = lane >> 4, i = lane & 15;
             for (int v = 0; v < 8; ++v) {
@@ -194,22 +188,22 @@ extern "C" int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out) {
                     if (i > m1 || xf > H / 2) continue;
                     const bool paired = (xf != 0) && (2 * xf != H);
                     const double th = PI2 * (double)((long)i * xf % H) / H;
-                    putg(fwdg, (size_t)(2 * (2 * b)) * 64 + lane, v, std::cos(th));
-                    putg(fwdg, (size_t)(2 * (2 * b + 1)) * 64 + lane, v, paired ? std::sin(th) : 0.0);
+                    putg(fwdg, (size_t)(CFD_TW * (2 * b)) * 64 + lane, v, std::cos(th));
+                    putg(fwdg, (size_t)(CFD_TW * (2 * b + 1)) * 64 + lane, v, paired ? std::sin(th) : 0.0);
                 }
                 for (int h = 0; h < NHG; ++h) {  // stage 2, A operand: lane (q, l = i), column y = 16 (2h + jj) + 4q + r, v = 4jj + r
                     const int tile = 2 * h + (v >> 2), y = 16 * tile + 4 * q + (v & 3);
                     if (i >= m2 || tile >= NJG || y >= W) continue;
                     const double ph = PI2 * (double)((long)i * y % W) / W;
-                    putg(fwdg, (size_t)(2 * (4 + h)) * 64 + lane, v, std::cos(ph));
-                    putg(fwdg, (size_t)(2 * (4 + NHG + h)) * 64 + lane, v, std::sin(ph));
+                    putg(fwdg, (size_t)(CFD_TW * (4 + h)) * 64 + lane, v, std::cos(ph));
+                    putg(fwdg, (size_t)(CFD_TW * (4 + NHG + h)) * 64 + lane, v, std::sin(ph));
                 }
             }
         }
-        invg.assign((size_t)(2 * T + 2 * NJG) * 64 * 8, 0);
+        invg.assign((size_t)(CFD_TW * T + CFD_TW * NJG) * 64 * 8, 0);
         for (int t = 0; t < T; ++t)
             for (int lane = 0; lane < 64; ++lane)
-                for (int v = 0; v < SA; ++v) putg(invg, (size_t)(2 * t) * 64 + lane, v, ta[(t * SA + v) * 64 + lane]);
+                for (int v = 0; v < SA; ++v) putg(invg, (size_t)(CFD_TW * t) * 64 + lane, v, ta[(t * SA + v) * 64 + lane]);
         for (int j = 0; j < NJG; ++j)
             for (int lane = 0; lane < 64; ++lane)
                 for (int v = 0; v < SB; ++v) {  // stage B, B operand: lane (q, n): c = 4 v + q, column y = 16 j + n
@@ -219,7 +213,7 @@ extern "C" int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out) {
                     const int l = im ? c - m2 : c;
                     const double cl = ((l == 0 || (W % 2 == 0 && l == W / 2)) ? 1.0 : 2.0) / ((double)H * W);
                     const double ph = PI2 * (double)((long)l * y % W) / W;
-                    putg(invg, (size_t)(2 * T + 2 * j) * 64 + lane, v, im ? -cl * std::sin(ph) : cl * std::cos(ph));
+                    putg(invg, (size_t)(CFD_TW * T + CFD_TW * j) * 64 + lane, v, im ? -cl * std::sin(ph) : cl * std::cos(ph));
                 }
         p->n_fwd_gv = (int)(fwdg.size() / 8);
         p->n_inv_gv = (int)(invg.size() / 8);

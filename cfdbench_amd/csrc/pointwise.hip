@@ -538,8 +538,31 @@ __device__ __forceinline__ void cfd_ld8px(const float* __restrict__ src, int px,
     }
 }
 
-template <int MT, int NT, int VEC, bool ACT, bool STEM>
-__global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g, const float* __restrict__ in,
+// the same for a plane stored as bf16 (bf16-storage training): VEC = 4 -> ONE 16-byte load of the eight values
+template <int VEC>
+__device__ __forceinline__ void cfd_ld8px(const __bf16* __restrict__ src, int px, int hw, bool ok, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (!ok) return;
+    if constexpr (VEC == 4) {
+        if (px + 4 < hw) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(src);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+        } else if (px < hw) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (float)src[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (px + j < hw) v[j] = (float)src[j];
+    }
+}
+
+// TIN: storage type of `in` (float; __bf16 for the saved activations of bf16-storage training -- the gradient `g` is always fp32)
+template <int MT, int NT, int VEC, bool ACT, bool STEM, typename TIN = float>
+__global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g, const TIN* __restrict__ in,
                                                     StemSrc ss, float* __restrict__ part, int B, int Ci, int Co,
                                                     int HW) {
     __shared__ float s_red[4 * MT * NT * 4 * 64];
@@ -571,7 +594,7 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
         for (int c = 0; c < NT; ++c) {
             const int i = 16 * c + n;
             if (i < CiIn) {
-                const float* src = in + ((size_t)b * CiIn + i) * HW + px;
+                const TIN* src = in + ((size_t)b * CiIn + i) * HW + px;
                 cfd_ld8px<VEC>(src, px, HW, true, bv[c]);
             } else {
                 // generated columns: ones (bias gradient) and, for the stem, mask / grid_x / grid_y / case parameters.
@@ -738,29 +761,31 @@ extern "C" size_t cfd_chan_wgrad_workspace_bytes(int B, int Ci, int Co, int HW) 
 }
 
 // `defer` (may be NULL): leave the partial-sum reduction to a later launch (cfd_tail.h) instead of launching it here
-template <bool STEM>
-static int launch_wgrad(const float* g, const float* in, StemSrc ss, float* gw, float* gb, void* ws, int B, int Ci,
+template <bool STEM, typename TIN = float>
+static int launch_wgrad(const float* g, const TIN* in, StemSrc ss, float* gw, float* gb, void* ws, int B, int Ci,
                         int Co, int HW, int act, hipStream_t st, ChanWgradTail* defer = nullptr) {
     const int blocks = wgrad_blocks(B, HW);
     CFD_REQUIRE((long)B * ((HW + 31) / 32) < (1L << 30), CFD_ERR_UNSUPPORTED, "cfd_chan_wgrad: B * ceil(HW / 32) = %ld chunks (max 2^30)",
                 (long)B * ((HW + 31) / 32));
     const int MT = (Co + 15) / 16, NT = (Ci + 1 + 15) / 16;
-    const int vec = (HW % 4 == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)in % 16) == 0)  ? 4
+    // bf16 `in`: the 8-pixel groups are 16 bytes, so the vector path needs HW % 8 == 0 (64 x 64); other grids read element-wise
+    const int vec = sizeof(TIN) == 2 ? ((HW % 8 == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)in % 16) == 0) ? 4 : 1)
+                    : (HW % 4 == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)in % 16) == 0)  ? 4
                     : (HW % 2 == 0 && ((uintptr_t)g % 8) == 0 && ((uintptr_t)in % 8) == 0) ? 2
                                                                                             : 1;
     float* part = (float*)ws;
 #define CFD_WG(M_, N_, V_, A_)                                                                                   \
-    hipLaunchKernelGGL((k_chan_wgrad<M_, N_, V_, A_, STEM>), dim3(blocks), dim3(256), 0, st, g, in, ss, part, B, \
+    hipLaunchKernelGGL((k_chan_wgrad<M_, N_, V_, A_, STEM, TIN>), dim3(blocks), dim3(256), 0, st, g, in, ss, part, B, \
                        Ci, Co, HW)
 #define CFD_WG_VA(M_, N_)                                                                     \
     do {                                                                                      \
         if (vec == 4) { if (act) CFD_WG(M_, N_, 4, true); else CFD_WG(M_, N_, 4, false); }    \
-        else if (vec == 2) { if (act) CFD_WG(M_, N_, 2, true); else CFD_WG(M_, N_, 2, false); } \
+        else if (vec == 2) { if constexpr (sizeof(TIN) == 4) { if (act) CFD_WG(M_, N_, 2, true); else CFD_WG(M_, N_, 2, false); } } \
         else { if (act) CFD_WG(M_, N_, 1, true); else CFD_WG(M_, N_, 1, false); }             \
     } while (0)
     {
     // stem: the gradient tensor + the raw input channels (features are generated); otherwise gradient + activation
-    CFD_PROF_W(STEM ? "k_chan_wgrad_stem" : "k_chan_wgrad", st, 4.0 * B * HW * ((double)Co + (STEM ? 3 : Ci)),
+    CFD_PROF_W(STEM ? "k_chan_wgrad_stem" : "k_chan_wgrad", st, (double)B * HW * (4.0 * Co + sizeof(TIN) * (STEM ? 3 : Ci)),
                2.0 * B * HW * (double)Co * (Ci + 1));
     if (MT == 1 && NT == 1) CFD_WG_VA(1, 1);
     else if (MT == 1 && NT == 2) CFD_WG_VA(1, 2);
@@ -798,12 +823,20 @@ extern "C" int cfd_chan_wgrad(const float* g, const float* in, float* gw, float*
 
 int cfd_int_chan_wgrad(const float* g, const float* in, float* gw, float* gb, void* ws, int B, int Ci, int Co, int HW,
                        int act_in, void* stream, ChanWgradTail* defer) {
+    return cfd_int_chan_wgrad_dt(g, in, gw, gb, ws, B, Ci, Co, HW, act_in, CFD_DT_F32, stream, defer);
+}
+
+// `in` stored as dt (CFD_DT_BF16: the saved activations of bf16-storage training); the gradient and the results are fp32
+int cfd_int_chan_wgrad_dt(const float* g, const void* in, float* gw, float* gb, void* ws, int B, int Ci, int Co, int HW,
+                          int act_in, int dt, void* stream, ChanWgradTail* defer) {
     if (defer) defer->part = nullptr;
     CFD_REQUIRE(g && in && gw && ws, CFD_ERR_INVALID_ARG, "cfd_chan_wgrad: NULL pointer");
     CFD_REQUIRE(B >= 1 && Ci >= 1 && Co >= 1 && HW >= 1, CFD_ERR_INVALID_ARG, "cfd_chan_wgrad: bad sizes");
     CFD_REQUIRE(Ci <= 32 && Co <= 32, CFD_ERR_UNSUPPORTED, "cfd_chan_wgrad: Ci=%d Co=%d (max 32) unsupported", Ci, Co);
     StemSrc ss{};
-    return launch_wgrad<false>(g, in, ss, gw, gb, ws, B, Ci, Co, HW, act_in, (hipStream_t)stream, defer);
+    if (dt == CFD_DT_BF16)
+        return launch_wgrad<false, __bf16>(g, (const __bf16*)in, ss, gw, gb, ws, B, Ci, Co, HW, act_in, (hipStream_t)stream, defer);
+    return launch_wgrad<false>(g, (const float*)in, ss, gw, gb, ws, B, Ci, Co, HW, act_in, (hipStream_t)stream, defer);
 }
 
 extern "C" size_t cfd_fno_stem_bwd_workspace_bytes(const cfd_plan* p, int B, int in_chan, int P, int C) {

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64(const float* __
 // 36 + 24 bf16 MFMAs (~17 cycles) per image.  The rows stream through the same rolling ring as in k_dft_fwd64 (a
 // slot is re-armed the moment its rows are folded, running on into the wave's next image); the folded values collect
 // in registers until the image's eight k-steps are in and the MFMAs issue in one burst.
-#define CFD_DFT3_TABV (7 * 2 * 64)  // 16-byte vectors of the split forward tables
+#define CFD_DFT3_TABV (7 * CFD_TW * 64)  // 16-byte vectors of the split forward tables (three pieces per table)
 #ifndef CFD_DFT_RING
 #define CFD_DFT_RING 3  // row-quads in flight per wave (1, 3 or 9 = the whole image)
 #endif
@@ -308,19 +308,21 @@ __global__ __launch_bounds__(64 * CFD_WAVES, CFD_DFT_OCC) void k_dft_fwd64_b3(co
         f32x4 a1c[NJ], a1s[NJ];
         {
             const int lo = cfd_opaque(lane);
-            const bf16x8 tch = s_tab3[lo], tcl = s_tab3[64 + lo];
-            const bf16x8 tsh = s_tab3[128 + lo], tsl = s_tab3[192 + lo];
-            const bf16x8 tnh = s_tab3[256 + lo], tnl = s_tab3[320 + lo];
+            constexpr int TS = CFD_TW * 64;  // vectors per table
+            const bf16x8 tch = s_tab3[lo], tcl = s_tab3[64 + lo], tcl2 = s_tab3[128 + lo];
+            const bf16x8 tsh = s_tab3[TS + lo], tsl = s_tab3[TS + 64 + lo], tsl2 = s_tab3[TS + 128 + lo];
+            const bf16x8 tnh = s_tab3[2 * TS + lo];  // the Nyquist row's +-1 are exact in one piece
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const float nyv[8] = {ny[j], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 const CfdSplit8 es = cfd_split8(e8[j]), os = cfd_split8(o8[j]), ns = cfd_split8(nyv);
                 f32x4 c = cfd_mfma16x16x32_bf16(es.lo, tch, zero);
                 f32x4 s = cfd_mfma16x16x32_bf16(os.lo, tsh, zero);
+                c = cfd_mfma16x16x32_bf16(es.hi, tcl2, c);
+                s = cfd_mfma16x16x32_bf16(os.hi, tsl2, s);
                 c = cfd_mfma16x16x32_bf16(es.hi, tcl, c);
                 s = cfd_mfma16x16x32_bf16(os.hi, tsl, s);
                 c = cfd_mfma16x16x32_bf16(ns.lo, tnh, c);
-                c = cfd_mfma16x16x32_bf16(ns.hi, tnl, c);
                 c = cfd_mfma16x16x32_bf16(ns.hi, tnh, c);
                 c = cfd_mfma16x16x32_bf16(es.hi, tch, c);
                 s = cfd_mfma16x16x32_bf16(os.hi, tsh, s);
@@ -339,8 +341,12 @@ __global__ __launch_bounds__(64 * CFD_WAVES, CFD_DFT_OCC) void k_dft_fwd64_b3(co
                 const float sv[8] = {a1s[2 * h][0], a1s[2 * h][1], a1s[2 * h][2], a1s[2 * h][3],
                                      a1s[2 * h + 1][0], a1s[2 * h + 1][1], a1s[2 * h + 1][2], a1s[2 * h + 1][3]};
                 const CfdSplit8 cs = cfd_split8(cv), ss = cfd_split8(sv);
-                const bf16x8 ch = s_tab3[(2 * (3 + h)) * 64 + lo], cl = s_tab3[(2 * (3 + h) + 1) * 64 + lo];
-                const bf16x8 sh = s_tab3[(2 * (5 + h)) * 64 + lo], sl = s_tab3[(2 * (5 + h) + 1) * 64 + lo];
+                const bf16x8 ch = s_tab3[(CFD_TW * (3 + h)) * 64 + lo], cl = s_tab3[(CFD_TW * (3 + h) + 1) * 64 + lo], cl2 = s_tab3[(CFD_TW * (3 + h) + 2) * 64 + lo];
+                const bf16x8 sh = s_tab3[(CFD_TW * (5 + h)) * 64 + lo], sl = s_tab3[(CFD_TW * (5 + h) + 1) * 64 + lo], sl2 = s_tab3[(CFD_TW * (5 + h) + 2) * 64 + lo];
+                Pc = cfd_mfma16x16x32_bf16(cl2, cs.hi, Pc);
+                Ps = cfd_mfma16x16x32_bf16(sl2, cs.hi, Ps);
+                Qc = cfd_mfma16x16x32_bf16(cl2, ss.hi, Qc);
+                Qs = cfd_mfma16x16x32_bf16(sl2, ss.hi, Qs);
                 Pc = cfd_mfma16x16x32_bf16(cl, cs.hi, Pc);
                 Ps = cfd_mfma16x16x32_bf16(sl, cs.hi, Ps);
                 Qc = cfd_mfma16x16x32_bf16(cl, ss.hi, Qc);
@@ -396,8 +402,8 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_dft_fwd_g(const TA* __res
                                                                   int W, int m1, int m2) {
     constexpr int NH = (NJ + 1) / 2;
     CFD_DYN_SHARED(bf16x8, s_dyn);
-    bf16x8* s_tab3 = s_dyn;                                              // [4 + 2 NH tables][hi|lo][64]
-    float2* s_out = reinterpret_cast<float2*>(s_dyn + (4 + 2 * NH) * 2 * 64);  // [CFD_WAVES][CFD_DFT_OS]
+    bf16x8* s_tab3 = s_dyn;                                              // [4 + 2 NH tables][hi|lo|lo2][64]
+    float2* s_out = reinterpret_cast<float2*>(s_dyn + (4 + 2 * NH) * CFD_TW * 64);  // [CFD_WAVES][CFD_DFT_OS]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
     const int stride = gridDim.x * CFD_WAVES;
@@ -455,10 +461,17 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_dft_fwd_g(const TA* __res
             arm(xn, j);  // re-arm the slot with the same tile of the wave's next image
             cfd_sched_fence();
             const CfdSplit8 es = cfd_split8(e8), os = cfd_split8(o8), es1 = cfd_split8(e1), os1 = cfd_split8(o1);
-            const bf16x8 c0h = s_tab3[lo], c0l = s_tab3[64 + lo], s0h = s_tab3[128 + lo], s0l = s_tab3[192 + lo];
-            const bf16x8 c1h = s_tab3[256 + lo], c1l = s_tab3[320 + lo], s1h = s_tab3[384 + lo], s1l = s_tab3[448 + lo];
+            constexpr int TS = CFD_TW * 64;  // vectors per table
+            const bf16x8 c0h = s_tab3[lo], c0l = s_tab3[64 + lo], c0l2 = s_tab3[128 + lo];
+            const bf16x8 s0h = s_tab3[TS + lo], s0l = s_tab3[TS + 64 + lo], s0l2 = s_tab3[TS + 128 + lo];
+            const bf16x8 c1h = s_tab3[2 * TS + lo], c1l = s_tab3[2 * TS + 64 + lo], c1l2 = s_tab3[2 * TS + 128 + lo];
+            const bf16x8 s1h = s_tab3[3 * TS + lo], s1l = s_tab3[3 * TS + 64 + lo], s1l2 = s_tab3[3 * TS + 128 + lo];
             f32x4 c = cfd_mfma16x16x32_bf16(es.lo, c0h, zero);
             f32x4 sn = cfd_mfma16x16x32_bf16(os.lo, s0h, zero);
+            c = cfd_mfma16x16x32_bf16(es.hi, c0l2, c);
+            sn = cfd_mfma16x16x32_bf16(os.hi, s0l2, sn);
+            c = cfd_mfma16x16x32_bf16(es1.hi, c1l2, c);
+            sn = cfd_mfma16x16x32_bf16(os1.hi, s1l2, sn);
             c = cfd_mfma16x16x32_bf16(es.hi, c0l, c);
             sn = cfd_mfma16x16x32_bf16(os.hi, s0l, sn);
             c = cfd_mfma16x16x32_bf16(es1.lo, c1h, c);
@@ -485,8 +498,12 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_dft_fwd_g(const TA* __res
                 sv[4 + r] = 2 * h + 1 < NJ ? a1s[2 * h + 1 < NJ ? 2 * h + 1 : 0][r] : 0.f;
             }
             const CfdSplit8 cs = cfd_split8(cv), ss = cfd_split8(sv);
-            const bf16x8 ch = s_tab3[(2 * (4 + h)) * 64 + lo], cl = s_tab3[(2 * (4 + h) + 1) * 64 + lo];
-            const bf16x8 sh = s_tab3[(2 * (4 + NH + h)) * 64 + lo], sl = s_tab3[(2 * (4 + NH + h) + 1) * 64 + lo];
+            const bf16x8 ch = s_tab3[(CFD_TW * (4 + h)) * 64 + lo], cl = s_tab3[(CFD_TW * (4 + h) + 1) * 64 + lo], cl2 = s_tab3[(CFD_TW * (4 + h) + 2) * 64 + lo];
+            const bf16x8 sh = s_tab3[(CFD_TW * (4 + NH + h)) * 64 + lo], sl = s_tab3[(CFD_TW * (4 + NH + h) + 1) * 64 + lo], sl2 = s_tab3[(CFD_TW * (4 + NH + h) + 2) * 64 + lo];
+            Pc = cfd_mfma16x16x32_bf16(cl2, cs.hi, Pc);
+            Ps = cfd_mfma16x16x32_bf16(sl2, cs.hi, Ps);
+            Qc = cfd_mfma16x16x32_bf16(cl2, ss.hi, Qc);
+            Qs = cfd_mfma16x16x32_bf16(sl2, ss.hi, Qs);
             Pc = cfd_mfma16x16x32_bf16(cl, cs.hi, Pc);
             Ps = cfd_mfma16x16x32_bf16(sl, cs.hi, Ps);
             Qc = cfd_mfma16x16x32_bf16(cl, ss.hi, Qc);
@@ -1389,10 +1406,12 @@ template <int NJ>
 __device__ __forceinline__ void idft_tile_b3(const IdftSplitA& sa, const bf16x8* ta3, const bf16x8* tb3, int lane,
                                              f32x4 (&accB)[NJ]) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const bf16x8 th = ta3[lane], tl = ta3[64 + lane];
+    const bf16x8 th = ta3[lane], tl = ta3[64 + lane], tl2 = ta3[128 + lane];
     f32x4 accA[2];
     accA[0] = cfd_mfma16x16x32_bf16(sa.a[0].lo, th, zero);
     accA[1] = cfd_mfma16x16x32_bf16(sa.a[1].lo, th, zero);
+    accA[0] = cfd_mfma16x16x32_bf16(sa.a[0].hi, tl2, accA[0]);
+    accA[1] = cfd_mfma16x16x32_bf16(sa.a[1].hi, tl2, accA[1]);
     accA[0] = cfd_mfma16x16x32_bf16(sa.a[0].hi, tl, accA[0]);
     accA[1] = cfd_mfma16x16x32_bf16(sa.a[1].hi, tl, accA[1]);
     accA[0] = cfd_mfma16x16x32_bf16(sa.a[0].hi, th, accA[0]);
@@ -1400,13 +1419,15 @@ __device__ __forceinline__ void idft_tile_b3(const IdftSplitA& sa, const bf16x8*
     const float u[8] = {accA[0][0], accA[0][1], accA[0][2], accA[0][3], accA[1][0], accA[1][1], accA[1][2], accA[1][3]};
     const CfdSplit8 us = cfd_split8(u);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x32_bf16(us.lo, tb3[(2 * j) * 64 + lane], accB[j]);
+    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x32_bf16(us.lo, tb3[(CFD_TW * j) * 64 + lane], accB[j]);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x32_bf16(us.hi, tb3[(2 * j + 1) * 64 + lane], accB[j]);
+    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x32_bf16(us.hi, tb3[(CFD_TW * j + 2) * 64 + lane], accB[j]);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x32_bf16(us.hi, tb3[(2 * j) * 64 + lane], accB[j]);
+    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x32_bf16(us.hi, tb3[(CFD_TW * j + 1) * 64 + lane], accB[j]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x32_bf16(us.hi, tb3[(CFD_TW * j) * 64 + lane], accB[j]);
 }
-#define CFD_B3_TABV ((2 * 4 + 2 * 4) * 64)  // 16-byte vectors of the split tables at T = 4, NJ = 4
+#define CFD_B3_TABV ((CFD_TW * 4 + CFD_TW * 4) * 64)  // 16-byte vectors of the split tables at T = 4, NJ = 4 (three pieces each)
 
 #define CFD_BLK_ZS 577  // floats of one staged mode vector: 2*M (m1 = m2 = 12) + the zero slot
 #define CFD_KB_ZS 580   // the same in k_block, rounded up to whole float4s (16-byte LDS stores)
@@ -1538,10 +1559,10 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __res
         if (lane == 0) zs[M2] = 0.f;
     };
     zfetch(img < nimg ? img : 0);
-    for (int i = threadIdx.x; i < (2 * T + 2 * NJ) * 64; i += blockDim.x) s_tab3[i] = tabs3[i];
+    for (int i = threadIdx.x; i < (CFD_TW * T + CFD_TW * NJ) * 64; i += blockDim.x) s_tab3[i] = tabs3[i];
     zcommit(zs0);
     __syncthreads();
-    const bf16x8* tb3 = s_tab3 + 2 * T * 64;
+    const bf16x8* tb3 = s_tab3 + CFD_TW * T * 64;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     int cur = 0;
     while (img < nimg) {
@@ -1564,7 +1585,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __res
             f32x4 accB[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) accB[j] = zero;
-            idft_tile_b3<NJ>(sa, s_tab3 + 2 * t * 64, tb3, cfd_opaque(lane), accB);
+            idft_tile_b3<NJ>(sa, s_tab3 + CFD_TW * t * 64, tb3, cfd_opaque(lane), accB);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float4 v = make_float4(accB[0][r], accB[1][r], accB[2][r], accB[3][r]);
@@ -1588,9 +1609,11 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __res
 // columns, 6 + 3 NJ bf16 MFMAs per 16-row tile) with the columns dealt as y = 16 j + n, so the epilogue loads and the stores
 // of a wave are runs of 16 consecutive elements per output row whatever W is (66 x 65 grids: the fp32 kernel k_idft deals
 // y = NJ n + j and issues 14 + 8 NJ fp32 MFMAs of 32 cycles per tile).  Persistent waves, next image's modes prefetched.
-template <int NJ, int EPI, typename TA, typename TADD = TA>
+// TA / TADD / TPREV: storage types of `out`, `addend` and `aprev` (bf16 activation storage: the forward pass writes bf16 `out` from an
+// fp32 `addend`; the backward pass of bf16-storage TRAINING writes an fp32 gradient from an fp32 addend and a bf16 `aprev`).
+template <int NJ, int EPI, typename TA, typename TADD = TA, typename TPREV = TA>
 __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_idft_g(const float* __restrict__ z, const TADD* addend,
-                                                               const TA* __restrict__ aprev, TA* out,
+                                                               const TPREV* __restrict__ aprev, TA* out,
                                                                const bf16x8* __restrict__ tabs3, int ntabv, int nimg, int H,
                                                                int W, int m1, int m2, int T, int SA) {
     CFD_DYN_SHARED(bf16x8, s_dyn);
@@ -1619,7 +1642,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_idft_g(const float* __res
     for (int i = threadIdx.x; i < ntabv; i += blockDim.x) s_tab3[i] = tabs3[i];
     zcommit(zs0);
     __syncthreads();
-    const bf16x8* tb3 = s_tab3 + 2 * T * 64;
+    const bf16x8* tb3 = s_tab3 + CFD_TW * T * 64;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     int colc[NJ];
     bool cok[NJ];
@@ -1650,7 +1673,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_idft_g(const float* __res
             f32x4 accB[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) accB[j] = zero;
-            idft_tile_b3<NJ>(sa, s_tab3 + 2 * t * 64, tb3, cfd_opaque(lane), accB);
+            idft_tile_b3<NJ>(sa, s_tab3 + CFD_TW * t * 64, tb3, cfd_opaque(lane), accB);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int xx = 16 * t + 4 * q + r;
@@ -1672,15 +1695,15 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_idft_g(const float* __res
     }
 }
 
-template <typename TA, typename TADD = TA>
-static bool launch_idft_g(const cfd_plan* p, const float* z, const TADD* addend, const TA* aprev, TA* out, int nimg, int epi,
+template <typename TA, typename TADD = TA, typename TPREV = TA>
+static bool launch_idft_g(const cfd_plan* p, const float* z, const TADD* addend, const TPREV* aprev, TA* out, int nimg, int epi,
                           hipStream_t st) {
     if (!p->d_inv_g || p->NJG < 1 || p->NJG > 5) return false;
     int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
     if (blocks > 2 * 256) blocks = 2 * 256;
     const size_t lds = (size_t)p->n_inv_gv * sizeof(bf16x8) + (size_t)CFD_WAVES * 2 * CFD_IDFT_ZMAX * sizeof(float);
 #define CFD_IDG(NJ_, E_)                                                                                             \
-    hipLaunchKernelGGL((k_idft_g<NJ_, E_, TA, TADD>), dim3(blocks), dim3(64 * CFD_WAVES), lds, st, z, addend, aprev, out,  \
+    hipLaunchKernelGGL((k_idft_g<NJ_, E_, TA, TADD, TPREV>), dim3(blocks), dim3(64 * CFD_WAVES), lds, st, z, addend, aprev, out,  \
                        (const bf16x8*)p->d_inv_g, p->n_inv_gv, nimg, p->H, p->W, p->m1, p->m2, p->T, p->SA)
 #define CFD_IDG_E(NJ_) do { if (epi == 0) CFD_IDG(NJ_, 0); else if (epi == 1) CFD_IDG(NJ_, 1); else CFD_IDG(NJ_, 2); } while (0)
     switch (p->NJG) {
@@ -1760,6 +1783,22 @@ int cfd_int_spectral_idft(const cfd_plan* p, const float* z, const void* addend,
     CFD_REQUIRE((launch_idft_g<__bf16, float>(p, z, (const float*)addend, (const __bf16*)aprev, (__bf16*)out, nimg, epi, st)), CFD_ERR_UNSUPPORTED,
                 "cfd_spectral_idft: bf16 activation storage needs H <= 70 and W <= 80 (grid %dx%d)", p->H, p->W);
     CFD_LAUNCH_CHECK("cfd_spectral_idft(bf16 storage)");
+    return CFD_OK;
+}
+
+// Input-gradient form of bf16-storage training: out (fp32 gradient) = (idft(z) + addend (fp32)) [* gelu'(aprev), aprev stored as bf16].
+int cfd_int_spectral_idft_grad(const cfd_plan* p, const float* z, const float* addend, const void* aprev, float* out, int nimg,
+                               int dt, void* stream) {
+    const int epi = aprev ? 2 : 1;
+    if (dt == CFD_DT_F32) return cfd_spectral_idft(p, z, addend, (const float*)aprev, out, nimg, epi, stream);
+    CFD_REQUIRE(p && z && out && addend && nimg >= 0, CFD_ERR_INVALID_ARG, "cfd_spectral_idft(grad): bad arguments");
+    if (nimg == 0) return CFD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    CFD_PROF_W(epi == 1 ? "k_idft_add" : "k_idft_add_dgelu", st,
+               (double)nimg * (p->H * p->W * (8.0 + (epi == 2 ? 2.0 : 0.0)) + 16.0 * p->m1 * p->m2), (double)nimg * (8.0 * (p->m1 + 1) * p->W * p->m2 + 4.0 * p->H * p->W * p->m2));
+    CFD_REQUIRE((launch_idft_g<float, float, __bf16>(p, z, addend, (const __bf16*)aprev, out, nimg, epi, st)), CFD_ERR_UNSUPPORTED,
+                "cfd_spectral_idft(grad): bf16 activation storage needs H <= 70 and W <= 80 (grid %dx%d)", p->H, p->W);
+    CFD_LAUNCH_CHECK("cfd_spectral_idft(grad, bf16 storage)");
     return CFD_OK;
 }
 
@@ -1916,9 +1955,9 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     // once per batch entry: operator tables, this wave's mixing weights and kept modes.  ALL the global loads are issued
     // before the first LDS store (the first version copied table, weights and each channel's modes one after the other:
     // three to eleven dependent memory latencies, 13-18 k cycles = 13 % of the workgroup's life -- tools: CFD_BDIAG)
-    constexpr int NTV = (2 * 4 + 2 * NJ) * 64;                 // table vectors at T = 4 (T <= 4 is checked by the launcher)
+    constexpr int NTV = (CFD_TW * 4 + CFD_TW * NJ) * 64;       // table vectors at T = 4 (T <= 4 is checked by the launcher)
     constexpr int TPT = (NTV + 64 * NW - 1) / (64 * NW);       // per thread
-    const int ntab = (2 * T + 2 * NJ) * 64;
+    const int ntab = (CFD_TW * T + CFD_TW * NJ) * 64;
     bf16x8 tv[TPT];
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
@@ -1966,7 +2005,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
         if (lane == 0) s_z[(wave * DPW + dd) * CFD_KB_ZS + M2] = 0.f;  // the zero word every masked-out gather index points at
     }
     cfd_wave_lds_sync();
-    const bf16x8* tb3 = s_tab3 + 2 * T * 64;
+    const bf16x8* tb3 = s_tab3 + CFD_TW * T * 64;
     CFD_BTS(1);
     float4 AP[2][4];  // gelu'(aprev) operands of two destination channels in flight
     auto fetch_ap = [&](int t, int dd, float4 (&r)[4]) {
@@ -2004,7 +2043,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
             if (c < DPW && wave + c * NW < Cd) {
                 float va[2][8];
                 idft_gather(s_z + (wave * DPW + (c < DPW ? c : 0)) * CFD_KB_ZS, m1, m2, SA, q, n, va);
-                idft_tile_b3<NJ>(idft_split(va), s_tab3 + 2 * t * 64, tb3, lane, acc[c < DPW ? c : 0]);
+                idft_tile_b3<NJ>(idft_split(va), s_tab3 + CFD_TW * t * 64, tb3, lane, acc[c < DPW ? c : 0]);
             }
             if constexpr (DPW > NCH) {  // more destination channels than chunks: the rest ride on the last chunk
                 if (c == NCH - 1) {
@@ -2013,7 +2052,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                         if (wave + dd * NW < Cd) {
                             float va[2][8];
                             idft_gather(s_z + (wave * DPW + dd) * CFD_KB_ZS, m1, m2, SA, q, n, va);
-                            idft_tile_b3<NJ>(idft_split(va), s_tab3 + 2 * t * 64, tb3, lane, acc[dd]);
+                            idft_tile_b3<NJ>(idft_split(va), s_tab3 + CFD_TW * t * 64, tb3, lane, acc[dd]);
                         }
                     }
                 }
@@ -2107,7 +2146,7 @@ static bool block_fused_ok(const cfd_plan* p, int Cs, int Cd, const void* a, con
     const int cmax = Cs > Cd ? Cs : Cd;
     return cfd_tune_get(CFD_TUNE_EXACT_FP32) != 1 &&  // the fused kernel's inverse transform is split-bf16
            p->W == 64 && p->H % 16 == 0 && p->NJ == 4 && p->d_inv_b3 &&  // d_inv_b3 exists for T <= 4 only (plan.cpp)
-           4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS && cmax <= 32 && ((uintptr_t)z % 16) == 0 &&
+           4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS && cmax <= 24 && ((uintptr_t)z % 16) == 0 &&  // 25 .. 32 channels: see launch_block
            ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && (!c || ((uintptr_t)c % 16) == 0);
 }
 
@@ -2143,7 +2182,9 @@ static void launch_block(const cfd_plan* p, const float* src, const float* z, co
         if (dgelu) launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
         else launch_block_cfg<10, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
     }
-    else launch_block_cfg<8, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
+    // 21 .. 24 channels: (8,3,3).  25 .. 32 channels run as the two passes (block_fused_ok): with the tables in three pieces
+    // (CFD_TW) the (8,4,4) workgroup would need 168 KB of LDS (source chunks 64 + modes 74 + tables 24 + weights 4).
+    else launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
 }
 
 // out[b,o] = bias[o] + sum_i w0[o,i] f(a[b,i]) + idft(z[b,o])                       (FnoBlock.forward minus its GELU)

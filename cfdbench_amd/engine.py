@@ -20,6 +20,7 @@ from ._capi import FnoShape
 from .functional import _param_struct
 
 _LOSS_IDS = {"mse": 0, "nmse": 1, "mae": 2}
+_ACT_DTYPES = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 
 
 def flatten_layout(params: Sequence[Tensor], align: int = 4) -> Tuple[List[int], int]:
@@ -153,9 +154,18 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 class FnoTrainEngine:
     def __init__(self, model, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, loss_name: str = "nmse", group=None, grad_buckets: int = 1,
-                 overlap: bool = True, fused_head: bool = True):
+                 overlap: bool = True, fused_head: bool = True, act_dtype: str = "fp32"):
+        """``act_dtype`` = "bf16": bf16-storage training (src/args.py:77-80 of the fork's other trainers): the saved
+        activations a_0 .. a_L are rounded to bf16 when stored -- half the bytes of what the backward pass re-reads -- and the
+        backward pass reads those rounded values; master weights, gradients, accumulation and Adam stay fp32
+        (cfd_fno_forward_train_ex / cfd_fno_backward_phase_ex).  Needs the one-pass head (fused_head)."""
         if loss_name not in _LOSS_IDS:
             raise ValueError(f"loss_name must be one of {sorted(_LOSS_IDS)}")
+        if act_dtype not in _ACT_DTYPES:
+            raise ValueError(f"act_dtype must be one of {sorted(_ACT_DTYPES)}")
+        self.act_dtype = _ACT_DTYPES[act_dtype]
+        if self.act_dtype and not fused_head:
+            raise ValueError("bf16 activation storage runs the one-pass training head: fused_head must be True")
         self.api = _lib.api()
         self.model = model
         params = model.abi_parameters()
@@ -193,7 +203,9 @@ class FnoTrainEngine:
         self.plan = _lib.plan(H, W, c["modes1"], c["modes2"], self.device.index)
         self.shape = FnoShape(B, H, W, in_chan, c["out_chan"], case_params.shape[1], c["hidden"], self.L, c["modes1"],
                               c["modes2"], c["head"])
-        nbytes = self.api.size("cfd_fno_workspace_bytes", self.plan, ctypes.byref(self.shape), 1)
+        nbytes = self.api.size("cfd_fno_workspace_bytes_ex", self.plan, ctypes.byref(self.shape), 1, self.act_dtype)
+        if nbytes == 0:
+            raise RuntimeError("cfd_fno_workspace_bytes_ex returned 0 for this shape / activation type")
         self.ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
         self.preds = torch.empty((B, c["out_chan"], H, W), dtype=torch.float32, device=self.device)
         self._shape_key = key
@@ -209,13 +221,13 @@ class FnoTrainEngine:
         a, sp = self.api, ctypes.byref(self.shape)
         mp = None if mask is None else mask.data_ptr()
         if self.fused_head:
-            a.call("cfd_fno_forward_train", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
+            a.call("cfd_fno_forward_train_ex", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
                    inputs.data_ptr(), case_params.data_ptr(), mp, label.data_ptr(), self.preds.data_ptr(), self.sums.data_ptr(),
-                   self.coef.data_ptr(), self.ws.data_ptr(), self.loss_id, 1.0, st)
+                   self.coef.data_ptr(), self.ws.data_ptr(), self.loss_id, 1.0, self.act_dtype, st)
             for phase in range(1, self.L + 2):  # phase 0 (the head) left the fused kernel already
-                a.call("cfd_fno_backward_phase", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
+                a.call("cfd_fno_backward_phase_ex", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
                        inputs.data_ptr(), case_params.data_ptr(), mp, label.data_ptr(), self.preds.data_ptr(), None,
-                       self.coef.data_ptr(), self.ws.data_ptr(), phase, st)
+                       self.coef.data_ptr(), self.ws.data_ptr(), phase, self.act_dtype, st)
             return
         a.call("cfd_fno_forward", self.plan, sp, ctypes.byref(self.pstruct), inputs.data_ptr(), case_params.data_ptr(), mp,
                label.data_ptr(), self.preds.data_ptr(), self.sums.data_ptr(), self.ws.data_ptr(), 1, st)
@@ -246,9 +258,9 @@ class FnoTrainEngine:
         a, sp = self.api, ctypes.byref(self.shape)
         mp = None if mask is None else mask.data_ptr()
         if self.fused_head:
-            a.call("cfd_fno_forward_train", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
+            a.call("cfd_fno_forward_train_ex", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
                    inputs.data_ptr(), case_params.data_ptr(), mp, label.data_ptr(), self.preds.data_ptr(), self.sums.data_ptr(),
-                   self.coef.data_ptr(), self.ws.data_ptr(), self.loss_id, 1.0, st)
+                   self.coef.data_ptr(), self.ws.data_ptr(), self.loss_id, 1.0, self.act_dtype, st)
         else:
             a.call("cfd_fno_forward", self.plan, sp, ctypes.byref(self.pstruct), inputs.data_ptr(), case_params.data_ptr(), mp,
                    label.data_ptr(), self.preds.data_ptr(), self.sums.data_ptr(), self.ws.data_ptr(), 1, st)
@@ -256,9 +268,9 @@ class FnoTrainEngine:
         handles = []
         for phase, (s0, s1) in enumerate(self.phase_slices()):
             if not (self.fused_head and phase == 0):  # the fused forward has produced the head's gradients already
-                a.call("cfd_fno_backward_phase", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
+                a.call("cfd_fno_backward_phase_ex", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
                        inputs.data_ptr(), case_params.data_ptr(), mp, label.data_ptr(), self.preds.data_ptr(), None,
-                       self.coef.data_ptr(), self.ws.data_ptr(), phase, st)
+                       self.coef.data_ptr(), self.ws.data_ptr(), phase, self.act_dtype, st)
             handles.append(self.sync.reduce_slice_async(self.flat.grad, s0, s1))
         return self.sync.wait_all(handles)
 

@@ -10,7 +10,8 @@ the same attribute table drives ``argparse``.  Differences, all documented in SU
     ``lr_scheduler`` (step = the reference's StepLR | plateau = ReduceLROnPlateau(lr_scheduler_factor, lr_scheduler_patience) |
     cosine), ``early_stop`` (1: stop after early_stopping_patience evaluations without early_stopping_delta improvement),
     ``gradient_accumulation_steps`` (args.py:323; micro-batches per optimiser step),
-    ``dtype`` (test_multistep only: "bf16" stores the FNO's activations between kernels as bf16 -- BASELINE configs[4]).
+    ``dtype`` ("bf16": the FNO's activations between kernels are stored as bf16 -- test_multistep: BASELINE configs[4];
+    train_auto --fused 1: bf16-storage training with fp32 master weights, gradients and optimiser).
 Flags of models that are not built yet are carried so existing command lines and args.json files keep working.
 """
 from __future__ import annotations
@@ -85,8 +86,8 @@ def is_args_valid(args: Args) -> None:
     assert args.eval_batch_size > 0 and args.gradient_accumulation_steps >= 1
     assert args.lr_scheduler in ("step", "plateau", "cosine"), args.lr_scheduler
     assert args.dtype in ("fp32", "bf16"), args.dtype
-    if args.dtype == "bf16":  # bf16 activation STORAGE exists for FNO inference only
-        assert args.model == "fno", "--dtype bf16: FNO inference (test_multistep) only; the trainers reject it"
+    if args.dtype == "bf16":  # bf16 activation STORAGE: FNO inference (test_multistep) and the fused FNO trainer
+        assert args.model == "fno", "--dtype bf16 is built for the FNO (test_multistep, train_auto --fused 1)"
     if args.fused:
         assert args.model == "fno", "--fused 1 is the FnoTrainEngine path"
         assert args.gradient_accumulation_steps == 1, "--fused 1 runs one fused optimiser step per batch"

@@ -123,7 +123,7 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
           log_interval: int = 10, eval_interval: int = 2, measure_time: bool = False, fused: bool = False,
           plot_interval: int = 1, resume: bool = False, device_loader: bool = False, lr_scheduler_kind: str = "step",
           lr_scheduler_factor: float = 0.5, lr_scheduler_patience: int = 5, early_stopping_patience: int = 0,
-          early_stopping_delta: float = 1e-5, gradient_accumulation_steps: int = 1):
+          early_stopping_delta: float = 1e-5, gradient_accumulation_steps: int = 1, act_dtype: str = "fp32"):
     """train_auto.py:181-313.  ``fused`` selects FnoTrainEngine (needs an Fno2d and the nmse loss).
 
     ``resume`` (the reference saves weights only, train_auto.py:301, and cannot continue a run): every
@@ -161,7 +161,7 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
         if accum > 1:
             raise NotImplementedError("--gradient_accumulation_steps > 1 needs the autograd path (--fused 0): the engine's "
                                       "backward pass overwrites the flat gradient")
-        engine = FnoTrainEngine(model, lr=lr, loss_name="nmse")
+        engine = FnoTrainEngine(model, lr=lr, loss_name="nmse", act_dtype=act_dtype)
         optimizer = None
     else:
         optimizer = Adam(model.parameters(), lr=lr)
@@ -298,8 +298,8 @@ def main(argv=None):
     from .data import get_auto_dataset
     args = Args().parse_args(argv)
     is_args_valid(args)
-    if args.dtype != "fp32":
-        raise NotImplementedError("--dtype bf16 is an inference option (test_multistep); training stores fp32")
+    if args.dtype != "fp32" and not args.fused:
+        raise NotImplementedError("--dtype bf16 training is the fused FNO engine's option (--fused 1): the autograd path stores fp32")
     rank, world = init_distributed()  # one process per GPU under torch.distributed.run; (0, 1) otherwise
     output_dir = get_output_dir(args, is_auto=True)
     if rank == 0:
@@ -324,7 +324,8 @@ def main(argv=None):
               resume=bool(args.resume), device_loader=bool(args.device_loader), lr_scheduler_kind=args.lr_scheduler,
               lr_scheduler_factor=args.lr_scheduler_factor, lr_scheduler_patience=args.lr_scheduler_patience,
               early_stopping_patience=args.early_stopping_patience if args.early_stop else 0,
-              early_stopping_delta=args.early_stopping_delta, gradient_accumulation_steps=args.gradient_accumulation_steps)
+              early_stopping_delta=args.early_stopping_delta, gradient_accumulation_steps=args.gradient_accumulation_steps,
+              act_dtype=args.dtype)
     if "test" in args.mode and rank == 0:  # the test split is small: rank 0 evaluates it alone
         args.save(str(output_dir / "test_args.json"))
         load_best_ckpt(model, output_dir)

@@ -328,7 +328,8 @@ int cfd_fno_forward(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_
 /* The same forward pass with the storage type of the activations BETWEEN kernels as an argument (BASELINE.json configs[4]: the
  * 200-step rollout of src/test_multistep.py:135-177 with bf16 storage): act_dtype 0 = fp32 (== cfd_fno_forward), 1 = bf16
  * (the lifting layer's output and every FnoBlock's pre-activation are rounded to bf16 when stored; inputs, predictions, kept
- * modes, weights, arithmetic and accumulation stay fp32).  bf16 is an inference path: training must be 0; grids up to 70 x 80. */
+ * modes, weights, arithmetic and accumulation stay fp32).  cfd_fno_forward_ex(bf16) is the inference path (training must be 0);
+ * bf16-storage TRAINING goes through cfd_fno_forward_train_ex / cfd_fno_backward_phase_ex below.  Grids up to 70 x 80.       */
 size_t cfd_fno_workspace_bytes_ex(const cfd_plan* plan, const cfd_fno_shape* shape, int training, int act_dtype);
 int cfd_fno_forward_ex(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,
                        const float* inputs, const float* case_params, const float* mask, const float* label,
@@ -343,6 +344,21 @@ int cfd_fno_forward_train(const cfd_plan* plan, const cfd_fno_shape* shape, cons
                           const cfd_fno_params* grads, const float* inputs, const float* case_params, const float* mask,
                           const float* label, float* preds, float* sums, float* coef, void* ws, int which, float upstream,
                           void* stream);
+
+/* The training step with the storage type of the SAVED activations as an argument (the mixed-precision option of this
+ * fork's other trainers, src/args.py:77-80, src/train_gencast.py:324-340): act_dtype 0 = fp32 (== the functions without _ex),
+ * 1 = bf16 -- a_0 .. a_L are rounded to bf16 when stored and the backward pass reads those rounded values (it differentiates the
+ * computation that was run); parameters, kept modes, gradients, accumulation and the optimiser stay fp32.  Workspace:
+ * cfd_fno_workspace_bytes_ex(plan, shape, 1, act_dtype).  With act_dtype = 1 backward phase 0 does not exist (the head ran in
+ * cfd_fno_forward_train_ex); phases 1 .. num_layers + 1 as below.                                                           */
+int cfd_fno_forward_train_ex(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,
+                             const cfd_fno_params* grads, const float* inputs, const float* case_params, const float* mask,
+                             const float* label, float* preds, float* sums, float* coef, void* ws, int which, float upstream,
+                             int act_dtype, void* stream);
+int cfd_fno_backward_phase_ex(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,
+                              const cfd_fno_params* grads, const float* inputs, const float* case_params,
+                              const float* mask, const float* label, const float* preds, const float* gpreds_ext,
+                              const float* coef, void* ws, int phase, int act_dtype, void* stream);
 
 /* grads: same layout as params, every tensor overwritten.  coef/gpreds_ext as in cfd_fno_head_bwd.           */
 int cfd_fno_backward(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 echo "== env ==" > $OUT/env.log
 (rocminfo | grep -E "Marketing Name|gfx" | head -6; nproc; lscpu | grep "Model name"; python -c "import torch;print(torch.__version__, torch.cuda.get_device_name(0))") >> $OUT/env.log 2>&1
 echo "== pytest gpu =="
-timeout 1500 python -m pytest tests -m gpu -x -q --durations=15 "$@" > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -q --durations=15 "$@" > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
 tail -40 $OUT/pytest_gpu.log
 echo "== smoke =="
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/smoke.log
