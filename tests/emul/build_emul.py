@@ -27,14 +27,17 @@ def build(force: bool = False) -> Path:
     stamp = OUT / "stamp"
     if lib.exists() and stamp.exists() and stamp.read_text() == h.hexdigest() and not force:
         return lib
-    objs = []
-    for src in sources():
+    def compile_one(src: Path) -> str:
         obj = OUT / (src.name + ".o")
         cmd = [CLANG, "-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-Wno-unused-value",
                f"-I{HERE / 'include'}", f"-I{CSRC}", f"-I{REPO / 'include'}", "-DCFD_WGRAD_TILE_MIN_WGS=1", "-DCFD_CONV_TILE_MIN_WGS=2", "-c", str(src), "-o",
                str(obj)]
         subprocess.run(cmd, check=True)
-        objs.append(str(obj))
+        return str(obj)
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:  # one translation unit per core (was serial: 4 minutes)
+        objs = list(ex.map(compile_one, sources()))
     subprocess.run([CLANG, "-shared", "-pthread", "-o", str(lib)] + objs, check=True)
     stamp.write_text(h.hexdigest())
     return lib

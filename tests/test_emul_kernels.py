@@ -33,12 +33,12 @@ def test_spectral_fwd_bwd_fused_route(be):
     _assert_all(K.check_spectral(be, 1, 20, 20, 64, 64))
 
 
-@pytest.mark.parametrize("B,Cin,Cout", [(3, 20, 20), (9, 12, 7), (2, 24, 24), (5, 32, 32)])  # more shapes: test_gpu_kernels.py
+@pytest.mark.parametrize("B,Cin,Cout", [(3, 20, 20), (9, 12, 7), (2, 32, 32)])  # more shapes: test_gpu_kernels.py (the emulator runs one OS thread per lane: sizes kept small)
 def test_mix_and_spectral_wgrad(be, B, Cin, Cout):
     _assert_all(K.check_mix_wgrad(be, B, Cin, Cout))
 
 
-@pytest.mark.parametrize("want_wg,nwv,B,C", [("36", "2", 27, 20), ("256", "1", 5, 32)])
+@pytest.mark.parametrize("want_wg,nwv,B,C", [("36", "2", 27, 20), ("256", "1", 3, 32)])
 def test_mix_and_spectral_wgrad_multi_step(be, want_wg, nwv, B, C):
     """The batch-in-lanes kernels (k_mix_lds, k_spec_wgrad_tile, the fused k_mixadj_wgrad) at chunk sizes that reach
     the software-pipelined loops of the weight gradient (several 8-entry steps per workgroup, ragged last step) and
@@ -106,7 +106,7 @@ def test_loss_and_adam(be):
     assert res["adam_delta"] < 1e-9
 
 
-@pytest.mark.parametrize("C,L,H,W,border", [(8, 2, 64, 64, False), (6, 2, 34, 33, True)])
+@pytest.mark.parametrize("C,L,H,W,border", [(5, 1, 64, 64, False), (6, 2, 34, 33, True)])
 def test_fno_whole_model(be, C, L, H, W, border):
     res = K.check_fno_vs_oracle(be, 1, C, L, H, W, border=border)
     loss_err = res.pop("nmse_loss")
@@ -145,7 +145,7 @@ def test_deeponet_inner(be, B, P, Kq, HW, with_q):
     _assert_all(res)
 
 
-@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(1, 5, 7, 9, 10, 3), (1, 3, 18, 5, 4, 3), (1, 2, 3, 8, 9, 7), (2, 4, 4, 6, 6, 1), (1, 9, 20, 3, 32, 3)])  # wide-image tile kernel: more shapes in test_gpu_kernels.py
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(1, 5, 7, 9, 10, 3), (1, 3, 18, 5, 4, 3), (1, 2, 3, 8, 9, 7), (2, 4, 4, 6, 6, 1), (1, 5, 17, 3, 32, 3)])  # wide-image tile kernel: more shapes in test_gpu_kernels.py
 def test_conv2d_replicate(be, B, Ci, Co, H, W, ks):
     _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, ks))
 
