@@ -109,6 +109,9 @@ _SIGS = {
     "cfd_convt2_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfd_residual_mask": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfd_dropout": (_I, [_P, _P, _Z, _F, C.c_ulonglong, _P]),
+    "cfd_ffn_stack_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "cfd_ffn_stack_bwd_workspace_bytes": (_Z, [_I, _P, _I]),
+    "cfd_ffn_stack_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "cfd_fno_workspace_bytes": (_Z, [_P, C.POINTER(FnoShape), _I]),
     "cfd_fno_forward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "cfd_fno_workspace_bytes_ex": (_Z, [_P, C.POINTER(FnoShape), _I, _I]),

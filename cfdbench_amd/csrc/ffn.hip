@@ -1,0 +1,426 @@
+// A whole Linear(+activation) stack of the DeepONet family as ONE kernel per direction (Ffn, src/models/ffn.py:12-35):
+//   y_0 = x;   z_l = y_{l-1} W_l^T + b_l,   y_l = act(z_l)   (l = 1 .. L; no activation after the last layer unless act_last)
+// for stacks whose widths are all <= 128 (the reference's default width is 100, src/args.py:117-121).
+//
+// Why: at BASELINE configs[3] (Auto-DeepONet, width 100, depth 8 + 8, 512 x 4290) the layer-by-layer path issues 49 GEMM and 17
+// split-K-reduce launches per training step for 13 MB of HBM traffic -- 0.62 + 0.20 ms of kernels that are each at their launch /
+// latency floor.  Here a workgroup owns a tile of 64 rows and walks through ALL layers: the activations of the tile stay in LDS,
+// the next layer's 40-KB weight matrix is prefetched from L2 into registers while the current layer is on the matrix pipe, and
+// only what the backward pass needs crosses HBM (y_l, and z_l for gelu / swish).  The backward kernel walks the layers in
+// reverse with the running gradient tile in LDS: dZ = G * act', bias / weight gradient partials per workgroup (reduced by one
+// small kernel for the whole stack), G <- dZ W.  Arithmetic: exact fp32 on v_mfma_f32_16x16x4_f32 (the ReLU networks are not
+// safe on split-bf16 products: DESIGN.md section 4), k-ordered fma chains like the stand-alone GEMM (dense.hip).
+#include "cfd_common.h"
+
+#define FS_MAXL 16    // layers per stack
+#define FS_MAXD 128   // widest layer
+#define FS_ROWS 16    // rows per workgroup: one MFMA row tile; the four waves split the output column tiles
+#define FS_KSPLIT 8   // row slices of the batched weight-gradient kernel
+
+struct FfnStack {
+    const float* w[FS_MAXL];   // W_l (dims[l+1] x dims[l]), row-major (nn.Linear.weight)
+    const float* b[FS_MAXL];   // b_l (dims[l+1]) or NULL
+    float* y[FS_MAXL];         // y_l (R x dims[l+1])  -- forward: written; backward: read
+    float* z[FS_MAXL];         // z_l (R x dims[l+1]) for act >= 3 (gelu / swish), else NULL
+    int dims[FS_MAXL + 1];
+    int L, act, act_last;
+};
+
+__device__ __forceinline__ float fs_act(float z, int act) {
+    switch (act) {
+        case 1: return z > 0.f ? z : 0.f;
+        case 2: return tanhf(z);
+        case 3: return cfd_gelu(z);
+        case 4: return z * cfd_rcpf(1.f + cfd_expf(-z));
+        default: return z;
+    }
+}
+__device__ __forceinline__ float fs_act_grad(float y, float z, int act) {
+    switch (act) {
+        case 1: return y > 0.f ? 1.f : 0.f;
+        case 2: return 1.f - y * y;
+        case 3: return cfd_gelu_grad(z);
+        case 4: { const float s = cfd_rcpf(1.f + cfd_expf(-z)); return s * (1.f + z * (1.f - s)); }
+        default: return 1.f;
+    }
+}
+
+// A weight matrix (Dout x Din, row-major) staged by the whole workgroup: thread (tj = tid / 32, ti = tid % 32) owns the four
+// columns 4 ti .. 4 ti + 3 of rows tj, tj + 8, ...; registers first (the loads fly during the previous layer's MFMAs), LDS later.
+// TRANS = false: sW[j][i] = W[j][i];  TRANS = true: sW[i][j] = W[j][i] (the backward chain multiplies by W, not W^T).
+// Rows / columns up to the next multiple of 16 are written as zeros: they are MFMA padding.
+#define FS_WROWS (FS_MAXD / 8)
+struct FsWRegs { float4 v[FS_WROWS]; };
+__device__ __forceinline__ void fs_wfetch(const float* __restrict__ w, int Dout, int Din, FsWRegs& r) {
+    const int tj = threadIdx.x >> 5, c0 = 4 * (threadIdx.x & 31);
+    const bool vec = (Din & 3) == 0 && ((uintptr_t)w & 15) == 0;
+#pragma unroll
+    for (int k = 0; k < FS_WROWS; ++k) {
+        const int j = tj + 8 * k;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < Dout && c0 < Din) {
+            const float* p = w + (size_t)j * Din + c0;
+            if (vec) t = *reinterpret_cast<const float4*>(p);
+            else {
+                t.x = p[0];
+                if (c0 + 1 < Din) t.y = p[1];
+                if (c0 + 2 < Din) t.z = p[2];
+                if (c0 + 3 < Din) t.w = p[3];
+            }
+        }
+        r.v[k] = t;
+    }
+}
+template <bool TRANS>
+__device__ __forceinline__ void fs_wcommit(float* __restrict__ sW, int FS_LD, int Dout, int Din, const FsWRegs& r) {
+    const int tj = threadIdx.x >> 5, c0 = 4 * (threadIdx.x & 31);
+    const int Dop = (Dout + 15) & ~15, Dip = (Din + 15) & ~15;
+#pragma unroll
+    for (int k = 0; k < FS_WROWS; ++k) {
+        const int j = tj + 8 * k;
+        if (j < Dop && c0 < Dip) {
+            if constexpr (!TRANS) *reinterpret_cast<float4*>(sW + j * FS_LD + c0) = r.v[k];
+            else {
+                sW[(c0 + 0) * FS_LD + j] = r.v[k].x;
+                sW[(c0 + 1) * FS_LD + j] = r.v[k].y;
+                sW[(c0 + 2) * FS_LD + j] = r.v[k].z;
+                sW[(c0 + 3) * FS_LD + j] = r.v[k].w;
+            }
+        }
+    }
+}
+
+// out[16 rows][16 t + n] = sum_k sIn[row][k] sOp[16 t + n][k] for this wave's column tiles t = wave, wave + 4 (< NT), K padded to
+// NG groups of 16.  k-slot map of a group: MFMA step i of lane (q, n) carries k = 16 g + 4 q + i, so a lane's four steps are ONE
+// 16-byte LDS read per operand (the map is arbitrary as long as both operands use it).
+__device__ __forceinline__ void fs_tile_gemm(const float* __restrict__ sIn, const float* __restrict__ sOp, int FS_LD, int NG, int NT,
+                                              int wave, int q, int n, f32x4 (&acc)[2]) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    acc[0] = acc[1] = zero;
+    const bool t1 = wave + 4 < NT;
+    if (wave >= NT) return;
+    const float* ap = sIn + n * FS_LD + 4 * q;
+    const float* b0 = sOp + (16 * wave + n) * FS_LD + 4 * q;
+    const float* b1 = sOp + (16 * (t1 ? wave + 4 : wave) + n) * FS_LD + 4 * q;
+    float4 a = *reinterpret_cast<const float4*>(ap), x0 = *reinterpret_cast<const float4*>(b0), x1 = *reinterpret_cast<const float4*>(b1);
+    for (int g = 0; g < NG; ++g) {
+        const int gn = g + 1 < NG ? g + 1 : g;  // next group's operands are requested before this group's MFMAs
+        const float4 an = *reinterpret_cast<const float4*>(ap + 16 * gn);
+        const float4 y0 = *reinterpret_cast<const float4*>(b0 + 16 * gn), y1 = *reinterpret_cast<const float4*>(b1 + 16 * gn);
+        acc[0] = cfd_mfma16x16x4(a.x, x0.x, acc[0]);
+        acc[1] = cfd_mfma16x16x4(a.x, x1.x, acc[1]);
+        acc[0] = cfd_mfma16x16x4(a.y, x0.y, acc[0]);
+        acc[1] = cfd_mfma16x16x4(a.y, x1.y, acc[1]);
+        acc[0] = cfd_mfma16x16x4(a.z, x0.z, acc[0]);
+        acc[1] = cfd_mfma16x16x4(a.z, x1.z, acc[1]);
+        acc[0] = cfd_mfma16x16x4(a.w, x0.w, acc[0]);
+        acc[1] = cfd_mfma16x16x4(a.w, x1.w, acc[1]);
+        a = an; x0 = y0; x1 = y1;
+    }
+}
+
+// 16 rows of a (R x D) row-major matrix -> sT[row][col], zeros beyond R / D up to the next multiple of 16 columns
+__device__ __forceinline__ void fs_tile_load(const float* __restrict__ src, int R, int D, int row0, float* __restrict__ sT, int FS_LD) {
+    const int Dp = (D + 15) & ~15;
+    const int r = threadIdx.x >> 4, c = threadIdx.x & 15;  // 16 x 16 threads
+    for (int cc = c; cc < Dp; cc += 16) sT[r * FS_LD + cc] = (row0 + r < R && cc < D) ? src[(size_t)(row0 + r) * D + cc] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------
+// Dynamic LDS: row stride FS_LD = (widest layer rounded up to 16) + 4 floats (16-byte aligned rows, staggered banks);
+// [2][16][FS_LD] activations (ping-pong) | [widest][FS_LD] weights -- 67 KB at width 100, so two workgroups share a CU.
+__global__ __launch_bounds__(256, 2) void k_ffn_stack_fwd(const float* __restrict__ x, const FfnStack st, int R, int FS_LD) {
+    CFD_DYN_SHARED(float4, s_dyn4);
+    float* sA0 = reinterpret_cast<float*>(s_dyn4);
+    float* sA[2] = {sA0, sA0 + FS_ROWS * FS_LD};   // the tile's activations y_{l-1} / y_l (ping-pong)
+    float* sW = sA0 + 2 * FS_ROWS * FS_LD;         // W_l
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int row0 = blockIdx.x * FS_ROWS;
+    FsWRegs wr;
+    fs_wfetch(st.w[0], st.dims[1], st.dims[0], wr);
+    fs_tile_load(x, R, st.dims[0], row0, sA[0], FS_LD);
+    int cur = 0;
+    for (int l = 0; l < st.L; ++l, cur ^= 1) {
+        const int Din = st.dims[l], Dout = st.dims[l + 1];
+        const int NG = (Din + 15) >> 4, NT = (Dout + 15) >> 4;
+        __syncthreads();  // every wave is done with W_{l-1} and has written its columns of sA[cur]
+        fs_wcommit<false>(sW, FS_LD, Dout, Din, wr);
+        __syncthreads();
+        if (l + 1 < st.L) fs_wfetch(st.w[l + 1], st.dims[l + 2], st.dims[l + 1], wr);  // in flight during this layer's MFMAs
+        f32x4 acc[2];
+        fs_tile_gemm(sA[cur], sW, FS_LD, NG, NT, wave, q, n, acc);
+        // epilogue: bias, activation, store what backward needs, the tile's next input into the other sA buffer
+        const bool do_act = st.act != 0 && (l + 1 < st.L || st.act_last);
+        const float* bias = st.b[l];
+        float* yl = st.y[l];
+        float* zl = st.z[l];
+        float* sN = sA[cur ^ 1];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = wave + 4 * h;
+            if (t < NT) {
+                const int col = 16 * t + n;
+                const float bv = (bias && col < Dout) ? bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lr = 4 * q + r, row = row0 + lr;
+                    const float zv = acc[h][r] + bv;
+                    const float yv = do_act ? fs_act(zv, st.act) : zv;
+                    if (col < Dout && row < R) {
+                        yl[(size_t)row * Dout + col] = yv;
+                        if (zl && do_act) zl[(size_t)row * Dout + col] = zv;
+                    }
+                    sN[lr * FS_LD + col] = col < Dout ? yv : 0.f;  // k padding of the next layer reads zeros
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, part 1: the gradient chain  dZ_l = G_l * act'(y_l, z_l),  G_{l-1} = dZ_l W_l  (l = L .. 1), dZ_l stored for part 2
+// ------------------------------------------------------------------------------------------------------
+struct FfnStackBwd {
+    float* dz[FS_MAXL];    // dZ_l (R x dims[l+1]), workspace
+    int poff[FS_MAXL];     // offset (floats) of layer l's [gw (Dout x Din) | gb (Dout)] inside one partial slice
+    int pstride;           // floats per partial slice
+};
+
+__global__ __launch_bounds__(256, 2) void k_ffn_stack_bwd_chain(const float* __restrict__ gy, const FfnStack st, const FfnStackBwd bw,
+                                                                 float* __restrict__ gx, int R, int FS_LD) {
+    CFD_DYN_SHARED(float4, s_dyn4);
+    float* sG0 = reinterpret_cast<float*>(s_dyn4);
+    float* sG[2] = {sG0, sG0 + FS_ROWS * FS_LD};   // dZ_l of the tile / the next G (ping-pong)
+    float* sW = sG0 + 2 * FS_ROWS * FS_LD;         // W_l^T: sW[i][j]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int row0 = blockIdx.x * FS_ROWS;
+    FsWRegs wr;
+    fs_wfetch(st.w[st.L - 1], st.dims[st.L], st.dims[st.L - 1], wr);
+    fs_tile_load(gy, R, st.dims[st.L], row0, sG[0], FS_LD);
+    int cur = 0;
+    for (int l = st.L - 1; l >= 0; --l, cur ^= 1) {
+        const int Din = st.dims[l], Dout = st.dims[l + 1];
+        const bool do_act = st.act != 0 && (l + 1 < st.L || st.act_last);
+        const bool need_g = l > 0 || gx != nullptr;
+        __syncthreads();  // sG[cur] is complete; every wave is done with W_{l+1}
+        {   // dZ_l = G * act' in place (16 x 16 threads: one row, strided columns), stored for the weight-gradient kernel
+            const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+            const int Dp = (Dout + 15) & ~15;
+            float* g = sG[cur] + r * FS_LD;
+            const float* yl = st.y[l];
+            const float* zl = st.z[l];
+            float* dz = bw.dz[l];
+            for (int cc = c; cc < Dp; cc += 16) {
+                float v = g[cc];
+                if (row0 + r < R && cc < Dout) {
+                    const size_t o = (size_t)(row0 + r) * Dout + cc;
+                    if (do_act) v *= fs_act_grad(yl[o], zl ? zl[o] : 0.f, st.act);
+                    dz[o] = v;
+                    g[cc] = v;
+                }
+            }
+        }
+        if (need_g) fs_wcommit<true>(sW, FS_LD, Dout, Din, wr);
+        __syncthreads();
+        if (l > 0) fs_wfetch(st.w[l - 1], st.dims[l], st.dims[l - 1], wr);
+        if (!need_g) break;
+        // G_{l-1}[row][i] = sum_j dZ[row][j] W[j][i]: operand rows of sW are the output columns i, K = j
+        const int NG = (Dout + 15) >> 4, NT = (Din + 15) >> 4;
+        f32x4 acc[2];
+        fs_tile_gemm(sG[cur], sW, FS_LD, NG, NT, wave, q, n, acc);
+        float* sN = sG[cur ^ 1];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = wave + 4 * h;
+            if (t < NT) {
+                const int col = 16 * t + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lr = 4 * q + r;
+                    if (l > 0) sN[lr * FS_LD + col] = col < Din ? acc[h][r] : 0.f;
+                    else if (col < Din && row0 + lr < R) gx[(size_t)(row0 + lr) * Din + col] = acc[h][r];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, part 2: every layer's weight / bias gradient in ONE launch:  gW_l[j][i] = sum_r dZ_l[r][j] y_{l-1}[r][i], the bias
+// gradient as the extra input column i = Din whose value is 1.  Grid (tile, layer, row slice); one wave per 16 x 16 tile and
+// slice; partial tiles are summed by k_ffn_stack_reduce in a fixed order.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_ffn_stack_wgrad(const float* __restrict__ x, const FfnStack st, const FfnStackBwd bw,
+                                                         float* __restrict__ part, int R) {
+    const int l = blockIdx.y, slice = blockIdx.z;
+    const int Din = st.dims[l], Dout = st.dims[l + 1];
+    const int NTi = (Din + 1 + 15) >> 4, NTj = (Dout + 15) >> 4;
+    if ((int)blockIdx.x >= NTi * NTj) return;
+    const int tj = blockIdx.x / NTi, ti = blockIdx.x - tj * NTi;
+    const int lane = threadIdx.x, q = lane >> 4, n = lane & 15;
+    const float* dz = bw.dz[l];
+    const float* yin = l > 0 ? st.y[l - 1] : x;
+    const int per = ((R + FS_KSPLIT - 1) / FS_KSPLIT + 3) & ~3;
+    const int r0 = slice * per, r1 = r0 + per < R ? r0 + per : R;
+    const int j = 16 * tj + n, i = 16 * ti + n;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 + q; r < r1 + q; r += 4) {  // wave-uniform trip count; lanes past the slice contribute zeros
+        const bool ok = r < r1;
+        const float a = (ok && j < Dout) ? dz[(size_t)r * Dout + j] : 0.f;
+        const float b = !ok ? 0.f : (i < Din ? yin[(size_t)r * Din + i] : (i == Din ? 1.f : 0.f));
+        acc = cfd_mfma16x16x4(a, b, acc);
+    }
+    float* p = part + (size_t)slice * bw.pstride + bw.poff[l];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int jj = 16 * tj + 4 * q + r;
+        if (jj < Dout) {
+            if (i < Din) p[jj * Din + i] = acc[r];
+            else if (i == Din) p[Dout * Din + jj] = acc[r];
+        }
+    }
+}
+
+// gw_l / gb_l = sum over the row slices, fixed order (deterministic); one thread per output element
+struct FfnStackGrads {
+    float* gw[FS_MAXL];
+    float* gb[FS_MAXL];
+};
+__global__ __launch_bounds__(256) void k_ffn_stack_reduce(const float* __restrict__ part, const FfnStack st, const FfnStackBwd bw,
+                                                           const FfnStackGrads g) {
+    const int l = blockIdx.y;
+    const int Din = st.dims[l], Dout = st.dims[l + 1];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Dout * Din + Dout) return;
+    const float* p = part + bw.poff[l] + e;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < FS_KSPLIT; ++k) s += p[(size_t)k * bw.pstride];
+    if (e < Dout * Din) g.gw[l][e] = s;
+    else if (g.gb[l]) g.gb[l][e - Dout * Din] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------
+static int fs_check(const char* fn, int R, const int* dims, int L, int act) {
+    CFD_REQUIRE(dims && R >= 0 && L >= 1 && L <= FS_MAXL, CFD_ERR_INVALID_ARG, "%s: bad arguments (1 <= layers <= %d)", fn, FS_MAXL);
+    CFD_REQUIRE(act >= 0 && act <= 4, CFD_ERR_INVALID_ARG, "%s: activation %d (0 none, 1 relu, 2 tanh, 3 gelu, 4 swish)", fn, act);
+    for (int l = 0; l <= L; ++l)
+        CFD_REQUIRE(dims[l] >= 1 && dims[l] <= FS_MAXD, CFD_ERR_UNSUPPORTED, "%s: width %d of layer %d outside 1..%d", fn, dims[l], l, FS_MAXD);
+    return CFD_OK;
+}
+
+static int fs_ld(const int* dims, int L) {  // LDS row stride: widest layer rounded up to 16, + 4
+    int m = 16;
+    for (int l = 0; l <= L; ++l) { const int d = (dims[l] + 15) & ~15; if (d > m) m = d; }
+    return m + 4;
+}
+static size_t fs_lds_bytes(int ld) { return (size_t)(2 * FS_ROWS + (ld - 4)) * ld * sizeof(float); }
+
+static void fs_fill(FfnStack& st, const float* const* w, const float* const* b, float* const* y, float* const* z, const int* dims,
+                    int L, int act, int act_last) {
+    st.L = L; st.act = act; st.act_last = act_last;
+    for (int l = 0; l <= L; ++l) st.dims[l] = dims[l];
+    for (int l = 0; l < L; ++l) { st.w[l] = w[l]; st.b[l] = b ? b[l] : nullptr; st.y[l] = y[l]; st.z[l] = z ? z[l] : nullptr; }
+}
+
+extern "C" int cfd_ffn_stack_fwd(const float* x, const float* const* w, const float* const* b, float* const* y, float* const* z,
+                                 int R, const int* dims, int L, int act, int act_last, void* stream) {
+    CFD_TRY(fs_check("cfd_ffn_stack_fwd", R, dims, L, act));
+    CFD_REQUIRE(x && w && y, CFD_ERR_INVALID_ARG, "cfd_ffn_stack_fwd: NULL pointer");
+    for (int l = 0; l < L; ++l) {
+        CFD_REQUIRE(w[l] && y[l], CFD_ERR_INVALID_ARG, "cfd_ffn_stack_fwd: NULL weight / output of layer %d", l);
+        CFD_REQUIRE(act < 3 || !(l + 1 < L || act_last) || (z && z[l]), CFD_ERR_INVALID_ARG,
+                    "cfd_ffn_stack_fwd: gelu / swish need the pre-activation buffer of layer %d", l);
+    }
+    if (R == 0) return CFD_OK;
+    FfnStack st{};
+    fs_fill(st, w, b, y, z, dims, L, act, act_last);
+    hipStream_t s = (hipStream_t)stream;
+    double fl = 0.0, by = 4.0 * R * dims[0];
+    for (int l = 0; l < L; ++l) { fl += 2.0 * R * dims[l] * dims[l + 1]; by += 4.0 * R * dims[l + 1] + 4.0 * dims[l] * dims[l + 1]; }
+    CFD_PROF_W("k_ffn_stack_fwd", s, by, fl);
+    const int ld = fs_ld(dims, L);
+    hipLaunchKernelGGL(k_ffn_stack_fwd, dim3((R + FS_ROWS - 1) / FS_ROWS), dim3(256), fs_lds_bytes(ld), s, x, st, R, ld);
+    CFD_LAUNCH_CHECK("cfd_ffn_stack_fwd");
+    return CFD_OK;
+}
+
+// workspace: dZ_l for every layer (R x dims[l+1] floats each, 256-byte aligned), then FS_KSPLIT partial slices of all gradients
+static size_t fs_ws_layout(int R, const int* dims, int L, size_t* dz_off, int* poff, int* pstride) {
+    size_t off = 0;
+    for (int l = 0; l < L; ++l) {
+        if (dz_off) dz_off[l] = off;
+        off += cfd_align_up((size_t)R * dims[l + 1] * sizeof(float), 256);
+    }
+    int po = 0;
+    for (int l = 0; l < L; ++l) {
+        if (poff) poff[l] = po;
+        po += dims[l + 1] * dims[l] + dims[l + 1];
+    }
+    po = (po + 3) & ~3;
+    if (pstride) *pstride = po;
+    if (dz_off) dz_off[L] = off;
+    return off + (size_t)FS_KSPLIT * po * sizeof(float);
+}
+
+extern "C" size_t cfd_ffn_stack_bwd_workspace_bytes(int R, const int* dims, int L) {
+    if (!dims || R <= 0 || L < 1 || L > FS_MAXL) return 0;
+    return fs_ws_layout(R, dims, L, nullptr, nullptr, nullptr);
+}
+
+extern "C" int cfd_ffn_stack_bwd(const float* x, const float* gy, const float* const* w, float* const* y, float* const* z,
+                                 float* const* gw, float* const* gb, float* gx, void* ws, int R, const int* dims, int L, int act,
+                                 int act_last, void* stream) {
+    CFD_TRY(fs_check("cfd_ffn_stack_bwd", R, dims, L, act));
+    CFD_REQUIRE(x && gy && w && y && gw && ws, CFD_ERR_INVALID_ARG, "cfd_ffn_stack_bwd: NULL pointer");
+    CFD_REQUIRE(R >= 1, CFD_ERR_INVALID_ARG, "cfd_ffn_stack_bwd: empty batch");
+    for (int l = 0; l < L; ++l) {
+        CFD_REQUIRE(w[l] && y[l] && gw[l], CFD_ERR_INVALID_ARG, "cfd_ffn_stack_bwd: NULL weight / output / gradient of layer %d", l);
+        CFD_REQUIRE(act < 3 || !(l + 1 < L || act_last) || (z && z[l]), CFD_ERR_INVALID_ARG,
+                    "cfd_ffn_stack_bwd: gelu / swish need the pre-activation buffer of layer %d", l);
+    }
+    FfnStack st{};
+    FfnStackBwd bw{};
+    fs_fill(st, w, nullptr, y, z, dims, L, act, act_last);
+    size_t dz_off[FS_MAXL + 1];
+    fs_ws_layout(R, dims, L, dz_off, bw.poff, &bw.pstride);
+    for (int l = 0; l < L; ++l) bw.dz[l] = (float*)((char*)ws + dz_off[l]);
+    float* part = (float*)((char*)ws + dz_off[L]);
+    FfnStackGrads g{};
+    int emax = 0, tmax = 0;
+    for (int l = 0; l < L; ++l) {
+        g.gw[l] = gw[l];
+        g.gb[l] = gb ? gb[l] : nullptr;
+        const int e = dims[l + 1] * dims[l] + dims[l + 1];
+        const int t = ((dims[l] + 1 + 15) / 16) * ((dims[l + 1] + 15) / 16);
+        if (e > emax) emax = e;
+        if (t > tmax) tmax = t;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (R + FS_ROWS - 1) / FS_ROWS;
+    {
+        double fl = 0.0, by = 4.0 * R * (dims[0] + dims[L]);
+        for (int l = 0; l < L; ++l) { fl += 2.0 * R * dims[l] * dims[l + 1]; by += 8.0 * R * dims[l + 1] + 4.0 * dims[l] * dims[l + 1]; }
+        CFD_PROF_W("k_ffn_stack_bwd_chain", s, by, fl);
+        const int ld = fs_ld(dims, L);
+        hipLaunchKernelGGL(k_ffn_stack_bwd_chain, dim3(nblk), dim3(256), fs_lds_bytes(ld), s, gy, st, bw, gx, R, ld);
+    }
+    CFD_LAUNCH_CHECK("cfd_ffn_stack_bwd(chain)");
+    {
+        double fl = 0.0, by = 0.0;
+        for (int l = 0; l < L; ++l) { fl += 2.0 * R * dims[l] * dims[l + 1]; by += 4.0 * R * (dims[l] + dims[l + 1]) + 4.0 * dims[l] * dims[l + 1]; }
+        CFD_PROF_W("k_ffn_stack_wgrad", s, by, fl);
+        hipLaunchKernelGGL(k_ffn_stack_wgrad, dim3(tmax, L, FS_KSPLIT), dim3(64), 0, s, x, st, bw, part, R);
+    }
+    CFD_LAUNCH_CHECK("cfd_ffn_stack_bwd(wgrad)");
+    CFD_PROF_W("k_ffn_stack_reduce", s, 0.0, 0.0);
+    hipLaunchKernelGGL(k_ffn_stack_reduce, dim3((emax + 255) / 256, L), dim3(256), 0, s, (const float*)part, st, bw, g);
+    CFD_LAUNCH_CHECK("cfd_ffn_stack_bwd(reduce)");
+    return CFD_OK;
+}

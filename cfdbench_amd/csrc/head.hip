@@ -30,6 +30,9 @@
 #endif
 #define CFD_PRAGMA_(x) _Pragma(#x)
 #define CFD_UNROLL(n) CFD_PRAGMA_(unroll n)
+#ifndef CFD_HF_OCC8
+#define CFD_HF_OCC8 2  // workgroups per CU the 32-channel forward head is compiled for (3 = 168 VGPRs: 8-10 registers spilled)
+#endif
 #define HEAD_LD 17  // LDS row stride of the transposed tiles (16 pixels + 1 pad -> conflict-free column reads)
 
 // Workgroup counts.  The `head_blocks` knob (tests: several tiles per workgroup at small sizes) can only LOWER them, and the
@@ -103,7 +106,7 @@ __device__ __forceinline__ void head_build_w1f(bf16x8* s_hi, bf16x8* s_lo, const
 }
 
 template <int CQ, bool VEC4, bool ACT, typename TA = float>
-__global__ __launch_bounds__(256, 3) void k_head_fwd(const TA* __restrict__ a, const float* __restrict__ mask,
+__global__ __launch_bounds__(256, CQ == 8 ? CFD_HF_OCC8 : 3) void k_head_fwd(const TA* __restrict__ a, const float* __restrict__ mask,
                                                   const float* __restrict__ label, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                                   const float* __restrict__ b2, float* __restrict__ preds,

@@ -358,6 +358,74 @@ def linear_act(x: Tensor, w: Tensor, b: Optional[Tensor], act: Optional[str]) ->
     return LinearActFn.apply(x, w, b, ACT_CODES[act])
 
 
+FFN_STACK_MAX_WIDTH, FFN_STACK_MAX_LAYERS = 128, 16
+
+
+def _ptr_array(ts):
+    import ctypes
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+class FfnStackFn(torch.autograd.Function):
+    """A run of Linear(+activation) layers whose widths are all <= 128 as ONE kernel per direction (cfd_ffn_stack_fwd / _bwd,
+    csrc/ffn.hip): the rows' activations stay in LDS from layer to layer; only what backward needs is stored."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, act: int, act_last: bool, *wb: Tensor):
+        import ctypes
+        _require_cuda(x, *wb)
+        api = _lib.api()
+        L = len(wb) // 2
+        ws_ = [_f32c(t.detach()) for t in wb[0::2]]
+        bs_ = [None if t is None else _f32c(t.detach()) for t in wb[1::2]]
+        lead = x.shape[:-1]
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        R = x2.shape[0]
+        dims = [x2.shape[1]] + [w.shape[0] for w in ws_]
+        for l, w in enumerate(ws_):
+            if w.shape[1] != dims[l]:
+                raise RuntimeError(f"Ffn: layer {l} expects {w.shape[1]} features, got {dims[l]}")
+        ys = [torch.empty((R, d), dtype=torch.float32, device=x2.device) for d in dims[1:]]
+        zs = [torch.empty_like(y) if (act >= 3 and (l + 1 < L or act_last)) else None for l, y in enumerate(ys)]
+        cdims = (ctypes.c_int * (L + 1))(*dims)
+        api.call("cfd_ffn_stack_fwd", _ptr(x2), _ptr_array(ws_), _ptr_array(bs_), _ptr_array(ys), _ptr_array(zs), R, cdims, L, act,
+                 int(act_last), _stream())
+        ctx.save_for_backward(x2, *ws_, *ys, *[z for z in zs if z is not None])
+        ctx.meta = (L, dims, act, bool(act_last), lead, [b is not None for b in bs_], [z is not None for z in zs])
+        return ys[-1].reshape(*lead, dims[-1])
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        import ctypes
+        api = _lib.api()
+        L, dims, act, act_last, lead, has_b, has_z = ctx.meta
+        saved = ctx.saved_tensors
+        x2, ws_, ys = saved[0], list(saved[1:1 + L]), list(saved[1 + L:1 + 2 * L])
+        zi = iter(saved[1 + 2 * L:])
+        zs = [next(zi) if hz else None for hz in has_z]
+        R = x2.shape[0]
+        dev = x2.device
+        gy2 = _f32c(gy).reshape(R, dims[-1])
+        gws = [torch.empty_like(w) for w in ws_]
+        gbs = [torch.empty((w.shape[0],), dtype=torch.float32, device=dev) if hb else None for w, hb in zip(ws_, has_b)]
+        gx = torch.empty((R, dims[0]), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        cdims = (ctypes.c_int * (L + 1))(*dims)
+        ws = _bytes(api.size("cfd_ffn_stack_bwd_workspace_bytes", R, cdims, L), dev)
+        api.call("cfd_ffn_stack_bwd", _ptr(x2), _ptr(gy2), _ptr_array(ws_), _ptr_array(ys), _ptr_array(zs), _ptr_array(gws),
+                 _ptr_array(gbs), _ptr(gx), _ptr(ws), R, cdims, L, act, int(act_last), _stream())
+        grads = []
+        for gw, gb in zip(gws, gbs):
+            grads += [gw, gb]
+        return (gx.reshape(*lead, dims[0]) if gx is not None else None), None, None, *grads
+
+
+def ffn_stack(x: Tensor, weights, biases, act: Optional[str], act_last: bool) -> Tensor:
+    wb = []
+    for w, b in zip(weights, biases):
+        wb += [w, b]
+    return FfnStackFn.apply(x, ACT_CODES[act], bool(act_last), *wb)
+
+
 class DeepONetInnerFn(torch.autograd.Function):
     """preds[b,k] = <branch[b], trunk[k]> + bias + u[b, query k]  (auto_deeponet.py:129-135) as one GEMM."""
 

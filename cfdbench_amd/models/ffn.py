@@ -37,9 +37,42 @@ class Ffn(nn.Module):
             i += 1
         return self._run(z, i)
 
+    def _fusable_run(self, mods, i: int):
+        """(weights, biases, act name, act after the last layer, index behind the run) of the longest run of Linear[+plain
+        activation] layers from ``mods[i]`` on whose widths are all <= 128 -- the stack one kernel runs per direction
+        (functional.FfnStackFn, csrc/ffn.hip) -- or None when fewer than two layers qualify."""
+        ws, bs, act, j, last_act = [], [], None, i, False
+        while j < len(mods) and isinstance(mods[j], nn.Linear) and len(ws) < F_.FFN_STACK_MAX_LAYERS:
+            lin = mods[j]
+            if max(lin.in_features, lin.out_features) > F_.FFN_STACK_MAX_WIDTH:
+                break
+            nxt = mods[j + 1] if j + 1 < len(mods) else None
+            if isinstance(nxt, NormAct):
+                break  # statistics over the whole sample: not a per-row epilogue
+            if isinstance(nxt, _Act):
+                if act is not None and nxt.name != act:
+                    break
+                if ws and not last_act:
+                    break  # a layer without activation in the middle of the run ends it
+                act = nxt.name
+                ws.append(lin.weight); bs.append(lin.bias); last_act = True
+                j += 2
+            else:
+                if ws and not last_act:
+                    break
+                ws.append(lin.weight); bs.append(lin.bias); last_act = False
+                j += 1
+                break  # a Linear without activation can only close a run
+        return (ws, bs, act, last_act, j) if len(ws) >= 2 else None
+
     def _run(self, x: Tensor, i: int) -> Tensor:
         mods = list(self.layers)
         while i < len(mods):
+            run = self._fusable_run(mods, i) if x.is_cuda else None
+            if run is not None:
+                ws, bs, act, last_act, i = run
+                x = F_.ffn_stack(x, ws, bs, act, last_act)
+                continue
             lin = mods[i]
             act = None
             norm = None

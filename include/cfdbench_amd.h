@@ -230,6 +230,20 @@ int cfd_deeponet_inner_bwd(const float* gpreds, const float* branch, const float
 /* Stand-alone activation get_act_fn(name) (src/models/act_fn.py:8-18) on n contiguous floats; act 0 none, 1 relu, 2 tanh,
  * 3 gelu, 4 swish.  Backward: gx = gy * act'(x), reading y = act(x) for relu / tanh and x for gelu / swish (the other may
  * be NULL). */
+/* A whole stack of L <= 16 Linear(+activation) layers whose widths are all <= 128 as ONE kernel per direction (Ffn,
+ * src/models/ffn.py:12-35; Auto-DeepONet's branch / trunk nets, src/models/auto_deeponet.py:52-60): y_0 = x (R, dims[0]);
+ * z_l = y_{l-1} w_l^T + b_l, y_l = act(z_l), no activation after the last layer unless act_last.  w / b / y / z: host arrays of L
+ * device pointers (w_l: (dims[l+1], dims[l]) as nn.Linear.weight; b may be NULL or hold NULLs; y_l (R, dims[l+1]) is written by
+ * the forward pass and read by the backward pass; z_l the same for the pre-activations, needed for act = 3 gelu / 4 swish only).
+ * Backward: gy (R, dims[L]) -> gw_l, gb_l (overwritten) and, if gx != NULL, gx (R, dims[0]); ws: cfd_ffn_stack_bwd_workspace_bytes().
+ * Exact fp32 (v_mfma_f32_16x16x4_f32).                                                                                   */
+int cfd_ffn_stack_fwd(const float* x, const float* const* w, const float* const* b, float* const* y, float* const* z, int R,
+                      const int* dims, int L, int act, int act_last, void* stream);
+size_t cfd_ffn_stack_bwd_workspace_bytes(int R, const int* dims, int L);
+int cfd_ffn_stack_bwd(const float* x, const float* gy, const float* const* w, float* const* y, float* const* z,
+                      float* const* gw, float* const* gb, float* gx, void* ws, int R, const int* dims, int L, int act,
+                      int act_last, void* stream);
+
 int cfd_act_fwd(const float* x, float* y, size_t n, int act, void* stream);
 int cfd_act_bwd(const float* gy, const float* y, const float* x, float* gx, size_t n, int act, void* stream);
 

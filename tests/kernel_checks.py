@@ -573,6 +573,57 @@ def check_linear(be, M, K, N, act, seed=22):
     return res
 
 
+def check_ffn_stack(be, R, dims, act, act_last=False, with_gx=True, seed=29):
+    """cfd_ffn_stack_fwd / _bwd (a whole Linear+activation stack per kernel, csrc/ffn.hip) against the fp64 layer-by-layer
+    restatement of Ffn.forward (src/models/ffn.py:12-35) and its reverse pass."""
+    import ctypes
+    from oracle import deeponet_oracle as D
+    api, P = be.api, be.ptr
+    code = {"none": 0, "relu": 1, "tanh": 2, "gelu": 3, "swish": 4}[act]
+    rng = np.random.default_rng(seed)
+    L = len(dims) - 1
+    x = rng.standard_normal((R, dims[0])).astype(np.float32)
+    ws = [(rng.standard_normal((dims[l + 1], dims[l])) / np.sqrt(dims[l])).astype(np.float32) for l in range(L)]
+    bs = [(0.3 * rng.standard_normal((dims[l + 1],))).astype(np.float32) for l in range(L)]
+    gy = rng.standard_normal((R, dims[L])).astype(np.float32)
+    dx, dgy = be.dev(x), be.dev(gy)
+    dws, dbs = [be.dev(w) for w in ws], [be.dev(b) for b in bs]
+    ys = [be.zeros((R, d)) for d in dims[1:]]
+    acted = [code != 0 and (l + 1 < L or act_last) for l in range(L)]
+    zs = [be.zeros((R, dims[l + 1])) if (code >= 3 and acted[l]) else None for l in range(L)]
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[P(t) for t in ts])  # noqa: E731
+    cdims = (ctypes.c_int * (L + 1))(*dims)
+    api.call("cfd_ffn_stack_fwd", P(dx), arr(dws), arr(dbs), arr(ys), arr(zs), R, cdims, L, code, int(act_last), be.stream)
+    be.sync()
+    # fp64 restatement
+    h, zs64, ys64 = x.astype(f64), [], []
+    for l in range(L):
+        z = h @ ws[l].astype(f64).T + bs[l]
+        h = D.act(z, act) if acted[l] else z
+        zs64.append(z)
+        ys64.append(h)
+    res = {f"y{l}": nm(be.host(ys[l]), ys64[l]) for l in range(L)}
+    for l in range(L):
+        if zs[l] is not None:
+            res[f"z{l}"] = nm(be.host(zs[l]), zs64[l])
+    gws, gbs = [be.zeros(w.shape) for w in ws], [be.zeros(b.shape) for b in bs]
+    gx = be.zeros((R, dims[0])) if with_gx else None
+    wsb = be.bytes(api.size("cfd_ffn_stack_bwd_workspace_bytes", R, cdims, L))
+    api.call("cfd_ffn_stack_bwd", P(dx), P(dgy), arr(dws), arr(ys), arr(zs), arr(gws), arr(gbs), P(gx), P(wsb), R, cdims, L, code,
+             int(act_last), be.stream)
+    be.sync()
+    g = gy.astype(f64)
+    for l in reversed(range(L)):
+        gz = g * D.act_grad(zs64[l], act) if acted[l] else g
+        inp = ys64[l - 1] if l > 0 else x.astype(f64)
+        res[f"gw{l}"] = nm(be.host(gws[l]), gz.T @ inp)
+        res[f"gb{l}"] = nm(be.host(gbs[l]), gz.sum(axis=0))
+        g = gz @ ws[l].astype(f64)
+    if with_gx:
+        res["gx"] = nm(be.host(gx), g)
+    return res
+
+
 def check_deeponet_inner(be, B, P_, Kq, HW, with_q, seed=23):
     api, P = be.api, be.ptr
     rng = np.random.default_rng(seed)

@@ -133,6 +133,12 @@ def test_gemm(be, M, N, Kd, ta, tb):
     _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
 
 
+@pytest.mark.parametrize("R,dims,act,act_last,with_gx", [(70, [5, 12, 20, 7], "relu", False, True), (33, [3, 17, 9], "gelu", True, False)])
+def test_ffn_stack(be, R, dims, act, act_last, with_gx):
+    """A whole Linear(+activation) stack per kernel (cfd_ffn_stack_fwd / _bwd) against the fp64 layer-by-layer restatement."""
+    _assert_all(K.check_ffn_stack(be, R, dims, act, act_last, with_gx))
+
+
 @pytest.mark.parametrize("M,K_in,N,act", [(37, 21, 24, "relu"), (9, 130, 100, "tanh"), (20, 7, 5, "gelu"), (5, 3, 70, "swish"), (66, 2, 16, "none"), (24, 520, 20, "relu")])
 def test_linear_act(be, M, K_in, N, act):
     _assert_all(K.check_linear(be, M, K_in, N, act))

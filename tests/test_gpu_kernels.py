@@ -189,6 +189,14 @@ def test_gemm(be, M, N, Kd, ta, tb):
     _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
 
 
+@pytest.mark.parametrize("R,dims,act,act_last,with_gx", [(4290, [2, 100, 100, 100, 100, 100, 100, 100, 100], "relu", False, False), (512, [100] * 8, "relu", False, True),
+                                                            (70, [5, 12, 20, 7], "tanh", False, True), (333, [3, 128, 128, 1], "gelu", True, True), (65, [128, 64, 128], "swish", False, True),
+                                                            (1, [7, 9, 4], "none", False, True)])
+def test_ffn_stack(be, R, dims, act, act_last, with_gx):
+    """A whole Linear(+activation) stack per kernel (cfd_ffn_stack_fwd / _bwd) against the fp64 layer-by-layer restatement."""
+    _assert_all(K.check_ffn_stack(be, R, dims, act, act_last, with_gx))
+
+
 @pytest.mark.parametrize("M,K_in,N,act", [(512, 4295, 100, "relu"), (4290, 2, 100, "relu"), (4290, 100, 100, "tanh"), (300, 100, 100, "gelu"), (129, 33, 70, "swish"), (66, 100, 16, "none")])
 def test_linear_act(be, M, K_in, N, act):
     _assert_all(K.check_linear(be, M, K_in, N, act))
