@@ -20,14 +20,6 @@
 #ifndef CFD_HF_UNROLL
 #define CFD_HF_UNROLL 1
 #endif
-#ifndef CFD_HDIAG
-#define CFD_HDIAG 0  // timing diagnostics (never in the shipped build): bit 0 no hidden GELU, 1 no fc1 MFMAs, 2 no fc2 / d-dh MFMAs,
-#endif               // 3 no gw1 MFMAs, 4 no operand split + transposed stores
-#if CFD_HDIAG & 1024
-#define CFD_TS(k_) do { if (rec) { cfd_sched_fence(); ts[k_] = __builtin_readcyclecounter(); cfd_sched_fence(); } } while (0)
-#else
-#define CFD_TS(k_) do { } while (0)
-#endif
 #define CFD_PRAGMA_(x) _Pragma(#x)
 #define CFD_UNROLL(n) CFD_PRAGMA_(unroll n)
 #ifndef CFD_HF_OCC8
@@ -157,18 +149,7 @@ __global__ __launch_bounds__(256, CQ == 8 ? CFD_HF_OCC8 : 3) void k_head_fwd(con
     locate(tile, b, px);
     head_load_raw<CQ, VEC4, TA>(a, b, C, HW, px, q, hn);
     fetch_io(b, px);
-#if CFD_HDIAG & 1024
-    long long ts[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) ts[k] = 0;
-    ts[14] = __builtin_readcyclecounter();
-    const int tile_first = tile;
-#endif
     for (; tile < total; tile += stride) {
-#if CFD_HDIAG & 1024
-        const bool rec = tile == tile_first + 2 * stride;
-#endif
-        CFD_TS(0);
         float h[CQ][4], mk[4], lb[4];
 #pragma unroll
         for (int c = 0; c < CQ; ++c)
@@ -181,16 +162,13 @@ __global__ __launch_bounds__(256, CQ == 8 ? CFD_HF_OCC8 : 3) void k_head_fwd(con
         head_load_raw<CQ, VEC4, TA>(a, b, C, HW, px, q, hn);
         fetch_io(b, px);
         cfd_sched_fence();  // the prefetch stays here, ahead of this tile's arithmetic
-        CFD_TS(1);
         if constexpr (ACT) head_act<CQ>(h);
-        CFD_TS(2);
         // The 4 pixel phases j run in a ROLLED loop (one 16-pixel sub-tile per trip keeps the live set at one
         // z tile); the phase being processed always sits in h[c][0] / lands in out*[3], registers rotate each trip.
         float out0[4] = {0.f, 0.f, 0.f, 0.f}, out1[4] = {0.f, 0.f, 0.f, 0.f};
 CFD_UNROLL(CFD_HF_UNROLL)
         for (int j = 0; j < 4; ++j) {
             const int lo = cfd_opaque(lane), q4 = 4 * cfd_opaque(q);  // keep the LDS table reads inside the loop (q4: a visible multiple of 4)
-            if (j == 1) CFD_TS(8);
             float xk[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) xk[c] = c < CQ ? h[c < CQ ? c : 0][0] : 0.f;
@@ -203,7 +181,6 @@ CFD_UNROLL(CFD_HF_UNROLL)
                 z[mt] = f32x4{bq.x, bq.y, bq.z, bq.w};
             }
             // z += W1 h as w_lo*h_hi + w_hi*h_lo + w_hi*h_hi, strictly term-major: consecutive MFMAs hit different accumulators
-#if !(CFD_HDIAG & 2)
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(s_w1lo[mt * 64 + lo], bs.hi, z[mt]);
 #pragma unroll
@@ -211,35 +188,23 @@ CFD_UNROLL(CFD_HF_UNROLL)
             cfd_sched_fence();
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(s_w1hi[mt * 64 + cfd_opaque(lo)], bs.hi, z[mt]);
-#else
-#pragma unroll
-            for (int mt = 0; mt < HEAD_MT; ++mt) z[mt][0] += (float)bs.hi[mt & 7] + (float)bs.lo[mt & 7];
-#endif
-            if (j == 1) CFD_TS(9);
             cfd_f2 ox = {0.f, 0.f}, oy = {0.f, 0.f};  // outputs 0 / 1, partial sums over the even / odd hidden units of this lane
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {
                     const int jh = 16 * mt + q4 + r;
-#if CFD_HDIAG & 1
-                    const cfd_f2 gl = cfd_f2{z[mt][r], z[mt][r + 1]};
-#else
                     const cfd_f2 gl = cfd_gelu2(cfd_f2{z[mt][r], z[mt][r + 1]});
-#endif
                     const float4 wq = *reinterpret_cast<const float4*>(s_w2 + jh);  // (w2[0][jh], w2[0][jh+1], w2[1][jh], w2[1][jh+1])
                     ox = cfd_fma2(cfd_f2{wq.x, wq.y}, gl, ox);
                     oy = cfd_fma2(cfd_f2{wq.z, wq.w}, gl, oy);
                 }
-            if (j == 1) CFD_TS(10);
             const float o0 = cfd_row_sum4(cfd_hsum2(ox)), o1 = cfd_row_sum4(cfd_hsum2(oy));  // sum over the four lane groups
             out0[0] = out0[1]; out0[1] = out0[2]; out0[2] = out0[3]; out0[3] = o0;
             out1[0] = out1[1]; out1[1] = out1[2]; out1[2] = out1[3]; out1[3] = o1;
 #pragma unroll
             for (int c = 0; c < CQ; ++c) { h[c][0] = h[c][1]; h[c][1] = h[c][2]; h[c][2] = h[c][3]; }
-            if (j == 1) CFD_TS(11);
         }
-        CFD_TS(3);
         if (q < Co) {  // lane group q stores output channel q
             const int c = q;
             const float bias = c == 0 ? b2v0 : b2v1;
@@ -265,16 +230,7 @@ CFD_UNROLL(CFD_HF_UNROLL)
                     if (pxc + j < HW) dst[j] = pv[j];
             }
         }
-        CFD_TS(4);
     }
-#if CFD_HDIAG & 1024
-    ts[15] = __builtin_readcyclecounter();
-    if (blockIdx.x == 0 && lane == 0) {
-        long long* o = reinterpret_cast<long long*>(preds) + 16 * wave;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) o[k] = ts[k];
-    }
-#endif
     if (part) {
         lsq = cfd_wave_sum(lsq); labs = cfd_wave_sum(labs); ll2 = cfd_wave_sum(ll2);
         if (lane == 0) { s_red[wave] = lsq; s_red[4 + wave] = labs; s_red[8 + wave] = ll2; }
@@ -420,9 +376,6 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     __shared__ __attribute__((aligned(16))) float s_pv[2][FUSE ? 64 : 4];  // FUSE: the tile's predictions in pixel order (wave 0 only)
     const int lane = threadIdx.x & 63, wave = cfd_uniform(threadIdx.x >> 6);
     const int q = lane >> 4, n = lane & 15;
-#if CFD_HDIAG & 1024
-    const long long ts_entry = __builtin_readcyclecounter(), rt_entry = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
     __bf16* s_xhw = s_x[wave][0];
     __bf16* s_xlw = s_x[wave][1];
     // ---- loop-invariant fragments of this wave's hidden slice ----
@@ -542,12 +495,8 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                 if constexpr (ACT) {
                     cfd_f2 P0, e0, P1, e1;
                     const cfd_f2 x0 = {v.x, v.y}, x1 = {v.z, v.w};
-#if CFD_HDIAG & 32
-                    P0 = x0 + (cfd_f2)(0.5f); e0 = x0; P1 = x1 + (cfd_f2)(0.5f); e1 = x1;
-#else
                     cfd_gelu_terms2(x0, P0, e0);
                     cfd_gelu_terms2(x1, P1, e1);
-#endif
                     const cfd_f2 g0 = cfd_fma2(x0 * (cfd_f2)(CFD_INV_SQRT_2PI), e0, P0), g1 = cfd_fma2(x1 * (cfd_f2)(CFD_INV_SQRT_2PI), e1, P1);
                     gp_next[k] = make_float4(g0.x, g0.y, g1.x, g1.y);
                     const cfd_f2 f0 = x0 * P0, f1 = x1 * P1;
@@ -559,14 +508,10 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                     const __bf16 hi = (__bf16)vv[j];
                     const __bf16 lo = (__bf16)(vv[j] - (float)hi);
                     const int col = 16 * j + n4;
-#if CFD_HDIAG & 64
-                    if (j == 0) { s_hk[buf][0][col * LDK + i] = hi + lo; }
-#else
                     s_hk[buf][0][col * LDK + i] = hi;
                     s_hk[buf][1][col * LDK + i] = lo;
                     s_ht[buf][0][i * LDT + col] = hi;
                     s_ht[buf][1][i * LDT + col] = lo;
-#endif
                 }
             }
         }
@@ -614,17 +559,7 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     fetch_gr(t1);
     __syncthreads();
     int buf = 0;
-#if CFD_HDIAG & 1024
-    long long ts[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) ts[k] = 0;
-    ts[14] = __builtin_readcyclecounter();
-#endif
     for (int tile = blockIdx.x; tile < total; tile += gridDim.x, buf ^= 1) {  // all four waves walk the same tiles
-#if CFD_HDIAG & 1024
-        const bool rec = tile == (int)blockIdx.x + 5 * (int)gridDim.x;
-#endif
-        CFD_TS(0);
         const int b = t0.b;
         const int px0 = t0.px0;
         // The 4 pixel phases run in a ROLLED loop, which keeps the live set at one phase.
@@ -637,26 +572,18 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
         auto front = [&](int j, f32x4 (&z)[2]) {
             // 1. recompute this wave's slice of the hidden pre-activation z[hidden][pixel n]
             const int col = 16 * j + n;
-            if (j == 1) CFD_TS(8);
             const bf16x8 hhi = *reinterpret_cast<const bf16x8*>(hk_hi + col * LDK + 8 * q);
             const bf16x8 hlo = *reinterpret_cast<const bf16x8*>(hk_lo + col * LDK + 8 * q);
 #pragma unroll
             for (int t = 0; t < 2; ++t) z[t] = f32x4{bz[t][0], bz[t][1], bz[t][2], bz[t][3]};
-#if !(CFD_HDIAG & 2)
 #pragma unroll
             for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].lo, hhi, z[t]);
 #pragma unroll
             for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].hi, hlo, z[t]);
 #pragma unroll
             for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].hi, hhi, z[t]);
-#else
-#pragma unroll
-            for (int t = 0; t < 2; ++t) z[t][0] += (float)hhi[t] + (float)hlo[t];
-#endif
         };
         auto back = [&](int j, const float (&gzv)[8]) {
-            if (j == 1) CFD_TS(10);
-#if !(CFD_HDIAG & 16)
             const CfdSplit8 gs = cfd_split8(gzv);
             // 3. transposed gz planes of this wave: row = local hidden unit 16t + 4q + r, column 16(j&1) + n
             const int xcol = 16 * (j & 1) + n;
@@ -666,40 +593,24 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                 s_xhw[row * LDX + xcol] = gs.hi[v];
                 s_xlw[row * LDX + xcol] = gs.lo[v];
             }
-#else
-            CfdSplit8 gs;
-#pragma unroll
-            for (int v = 0; v < 8; ++v) { gs.hi[v] = __builtin_bit_cast(__bf16, (unsigned short)(__builtin_bit_cast(unsigned, gzv[v]) >> 16)); gs.lo[v] = gs.hi[v]; }
-#endif
             // 4. partial d/dh[channel][pixel] = sum over this wave's hidden units w1[jh][channel] gz[jh][pixel]
-            if (j == 1) CFD_TS(11);
             f32x4 ghc[MU];
-#if !(CFD_HDIAG & 4)
 #pragma unroll
             for (int mu = 0; mu < MU; ++mu) ghc[mu] = cfd_mfma16x16x32_bf16(w1t[mu].lo, gs.hi, zero);
 #pragma unroll
             for (int mu = 0; mu < MU; ++mu) ghc[mu] = cfd_mfma16x16x32_bf16(w1t[mu].hi, gs.lo, ghc[mu]);
 #pragma unroll
             for (int mu = 0; mu < MU; ++mu) ghc[mu] = cfd_mfma16x16x32_bf16(w1t[mu].hi, gs.hi, ghc[mu]);
-#else
-#pragma unroll
-            for (int mu = 0; mu < MU; ++mu) { ghc[mu] = zero; ghc[mu][0] = (float)gs.hi[mu] + (float)gs.lo[mu]; }
-#endif
             // this wave's partial d/dh of the tile: [channel][64 pixels], pixel = 4n + phase
 #pragma unroll
             for (int mu = 0; mu < MU; ++mu)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = 16 * mu + 4 * q + r;
-#if CFD_HDIAG & 256
-                    if (i < CP && r == 0) s_redf[((wave * CP + i) * 16 + n) * 4 + j] = ghc[mu][0] + ghc[mu][1] + ghc[mu][2] + ghc[mu][3];
-#else
                     if (i < CP) s_redf[((wave * CP + i) * 16 + n) * 4 + j] = ghc[mu][r];
-#endif
                 }
             // 5. after each pair of phases: gw1[hidden][channel] += sum over 32 pixels gz[hidden][px] h[channel][px]
-            if (j == 1) CFD_TS(12);
-            if ((j & 1) && !(CFD_HDIAG & 8)) {
+            if (j & 1) {
                 cfd_wave_lds_sync();
                 bf16x8 ah[2], al[2], bh[MU], bl[MU];
 #pragma unroll
@@ -728,7 +639,6 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                     for (int mu = 0; mu < MU; ++mu) aw1[t][mu] = cfd_mfma16x16x32_bf16(ah[t], bh[mu], aw1[t][mu]);
                 cfd_wave_lds_sync();
             }
-            if (j == 1) CFD_TS(13);
         };
         if constexpr (FUSE) {
             // Two pixel phases per workgroup barrier: both phases' forward halves (GELU terms kept in registers, this wave's share
@@ -824,7 +734,6 @@ CFD_UNROLL(CFD_HB_UNROLL)
                 front(j, z);
                 const int col = 16 * j + n;
                 // 2. a1 = gelu(z) feeds the fc2 weight gradient; gz = (W2^T graw) * gelu'(z), k-slot 4t + r
-                if (j == 1) CFD_TS(9);
                 float gzv[8];
             const cfd_f2 grj = grp[col];
             const cfd_f2 g0 = (cfd_f2)(grj.x), g1 = (cfd_f2)(grj.y);
@@ -834,12 +743,7 @@ CFD_UNROLL(CFD_HB_UNROLL)
                 for (int v = 0; v < 2; ++v) {  // packed pairs of hidden units r = 2v, 2v+1
                     const cfd_f2 zz = {z[t][2 * v], z[t][2 * v + 1]};
                     cfd_f2 Phi, e;
-#if CFD_HDIAG & 1
-                    Phi = zz + (cfd_f2)(0.5f);
-                    e = zz;
-#else
                     cfd_gelu_terms2(zz, Phi, e);
-#endif
                     const cfd_f2 a1 = zz * Phi;
                     acc2a[t][v] = cfd_fma2(g0, a1, acc2a[t][v]);
                     acc2b[t][v] = cfd_fma2(g1, a1, acc2b[t][v]);
@@ -868,17 +772,13 @@ CFD_UNROLL(CFD_HB_UNROLL)
                 }
             }
         }
-        CFD_TS(1);
         __syncthreads();
-        CFD_TS(2);
         // next tile's input planes (other buffer; its raw loads were issued one tile ago), then loads two tiles ahead
         stage(buf ^ 1);
         stage_gr(buf ^ 1);
-        CFD_TS(3);
         const TileAt t2 = locate(tile + 2 * (int)gridDim.x);
         fetch(t2);
         fetch_gr(t2);
-        CFD_TS(4);
         // ga[b][i][px0 .. px0+63] = (sum over the four hidden slices) * f'(a)
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
@@ -886,13 +786,11 @@ CFD_UNROLL(CFD_HB_UNROLL)
             if (e >= C * 16) continue;
             const int i = e >> 4, n4 = e & 15;
             float4 v = s_red[i * 16 + n4];
-#if !(CFD_HDIAG & 128)
 #pragma unroll
             for (int wv = 1; wv < 4; ++wv) {
                 const float4 u = s_red[(wv * CP + i) * 16 + n4];
                 v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
             }
-#endif
             const int p4 = px0 + 4 * n4;
             const size_t off = ((size_t)b * C + i) * HW + p4;
             if constexpr (VEC4) {
@@ -919,13 +817,8 @@ CFD_UNROLL(CFD_HB_UNROLL)
         for (int k = 0; k < NST; ++k) gp_cur[k] = gp_next[k];
         t0 = t1;
         t1 = t2;
-        CFD_TS(5);
         __syncthreads();
-        CFD_TS(6);
     }
-#if CFD_HDIAG & 1024
-    ts[15] = __builtin_readcyclecounter();
-#endif
     // ---- this block's partial parameter gradients: [gw1 128*C | gb1 128 | gw2 Co*128 | gb2 Co] ----
     const int o_gb1 = HEAD_HD * C, o_gw2 = o_gb1 + HEAD_HD, o_gb2 = o_gw2 + Co * HEAD_HD;
     // element-major partials part[element][block] (see k_head_reduce)
@@ -967,18 +860,6 @@ CFD_UNROLL(CFD_HB_UNROLL)
             }
         }
     }
-#if CFD_HDIAG & 1024
-    if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && lane == 0) {
-        long long* o = reinterpret_cast<long long*>(ga) + 16 * wave + (blockIdx.x == 0 ? 0 : 64);
-        ts[7] = __builtin_readcyclecounter();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) o[k] = ts[k];
-        if (blockIdx.x == 0) {
-            o[128 - 16 * wave + 4 + wave] = ts_entry;
-            if (wave == 0) { o[128] = (long long)__builtin_amdgcn_s_memrealtime(); o[129] = rt_entry; }
-        }
-    }
-#endif
 }
 
 // One wave per output element, whose per-block partials are one contiguous row (see k_wgrad_reduce).

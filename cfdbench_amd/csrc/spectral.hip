@@ -1906,15 +1906,6 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     }
     constexpr int W = 64, NJ = 4;
     constexpr int WS = DPW <= 4 ? 4 : 8;              // floats per weight-table entry
-#ifdef CFD_BDIAG  // timing experiments only (tools/build_variant.sh): in-kernel timestamps of workgroup 0 / the last one
-    long long ts[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) ts[k] = 0;
-    ts[0] = __builtin_readcyclecounter();
-#define CFD_BTS(k_) do { cfd_sched_fence(); ts[k_] = __builtin_readcyclecounter(); cfd_sched_fence(); } while (0)
-#else
-#define CFD_BTS(k_) do { } while (0)
-#endif
     __shared__ float4 s_src[2 * NW * 16 * 16];        // [buf][channel in chunk][row][float4 column]
     __shared__ bf16x8 s_tab3[CFD_B3_TABV];            // split-bf16 inverse tables: ta3 of every tile (T <= 4) | tb3
     __shared__ float s_z[NW * DPW * CFD_KB_ZS];      // kept modes of this wave's destination channels
@@ -2006,7 +1997,6 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     }
     cfd_wave_lds_sync();
     const bf16x8* tb3 = s_tab3 + CFD_TW * T * 64;
-    CFD_BTS(1);
     float4 AP[2][4];  // gelu'(aprev) operands of two destination channels in flight
     auto fetch_ap = [&](int t, int dd, float4 (&r)[4]) {
         const int d = wave + dd * NW;
@@ -2028,18 +2018,14 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
         for (int c = 0; c < NCH; ++c) {
             const int g = tl * NCH + c;
             const int par = (PAR + c) & 1;
-            if (t == 1 && c == 0) CFD_BTS(6);
             commit(c, par, R[par]);
-            if (t == 1 && c == 0) CFD_BTS(7);
             __syncthreads();  // chunk g visible (first pass: also tables, weights); the other buffer is free again
-            if (t == 1 && c == 0) CFD_BTS(8);
             if (g + 2 < G) fetch(g + 2, R[par]);
             if constexpr (DGELU) {
                 if (c == NCH - 2) fetch_ap(t, 0, AP[0]);
                 if (c == NCH - 1) fetch_ap(t, 1, AP[1]);
             }
             // inverse transform of destination channel dd = c (spread over the chunks so MFMA and VALU work interleave)
-            if (t == 1 && c == 0) CFD_BTS(9);
             if (c < DPW && wave + c * NW < Cd) {
                 float va[2][8];
                 idft_gather(s_z + (wave * DPW + (c < DPW ? c : 0)) * CFD_KB_ZS, m1, m2, SA, q, n, va);
@@ -2059,7 +2045,6 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
             }
             // channel mix of this chunk (dead channels hold zeros in LDS and get zero weights); the LDS reads of
             // source channel sl+1 are issued before the FMAs of channel sl
-            if (t == 1 && c == 0) CFD_BTS(10);
             {
                 float4 v[2][4], wq[2][WS / 4];
                 auto lds_fetch = [&](int sl, float4 (&vv)[4], float4 (&ww)[WS / 4]) {
@@ -2096,7 +2081,6 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
             }
         }
         // ---- tile epilogue: [* gelu'(aprev)], whole-float4 row stores ----
-        if (t == 1) CFD_BTS(11);
 #pragma unroll
         for (int dd = 0; dd < DPW; ++dd) {
             const int d = wave + dd * NW;
@@ -2124,22 +2108,11 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
 #pragma unroll 1
     for (int t = 0; t < TPW; t += 2) {  // local tile index
         tile(CfdParity<0>{}, t);
-        if (t == 0) CFD_BTS(2);
-        if (t == 2) CFD_BTS(4);
         if (t + 1 < TPW) {
             if constexpr (NCH % 2 == 1) tile(CfdParity<1>{}, t + 1);
             else tile(CfdParity<0>{}, t + 1);
         }
-        if (t == 0) CFD_BTS(3);
-        if (t == 2) CFD_BTS(5);
     }
-#ifdef CFD_BDIAG
-    if ((b == 0 || b == (int)gridDim.x - 1) && lane == 0 && (wave == 0 || wave == NW - 1)) {
-        long long* o = reinterpret_cast<long long*>(dst) + 16 * ((wave == 0 ? 0 : 1) + (b == 0 ? 0 : 2));
-#pragma unroll
-        for (int k = 0; k < 16; ++k) o[k] = ts[k];
-    }
-#endif
 }
 
 static bool block_fused_ok(const cfd_plan* p, int Cs, int Cd, const void* a, const void* b, const void* c, const void* z) {
