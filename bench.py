@@ -510,7 +510,8 @@ def main():
                 spectral_conv2d_us=sp_exact["avg_us"], spectral_conv2d_frac=sp_exact["frac"],
                 what="the same step / SpectralConv2d group with every DFT and inverse DFT on the exact-fp32 kernels (fp32 MFMA "
                      "= the VALU's fp32 rate on gfx950) and the fused FnoBlock kernel replaced by its two exact passes; the "
-                     "1x1 weight gradient and the projection head have no exact-fp32 build and stay split-bf16")
+                     "1x1 weight gradient and the projection head have no exact-fp32 build and stay split-bf16 -- i.e. the north star's 40 % "
+                     "SpectralConv2d target is met on the split-product route only (DESIGN.md section 5)")
         except Exception:  # noqa: BLE001
             result["exact_fp32"] = None
 
