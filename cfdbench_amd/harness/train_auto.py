@@ -59,13 +59,27 @@ _rank_world = rank_world
 
 
 def evaluate(model: AutoCfdModel, data, output_dir: Path, batch_size: int = 2, plot_interval: int = 1,
-             measure_time: bool = False, device_loader: bool = False):
-    """Single-step evaluation (train_auto.py:61-148): identity baseline + model scores per batch, predictions."""
+             measure_time: bool = False, device_loader: bool = False, sharded: bool = False):
+    """Single-step evaluation (train_auto.py:61-148): identity baseline + model scores per batch, predictions.
+
+    ``sharded`` (data-parallel runs; every rank must call): batch k of the evaluation order is evaluated by rank k % world -- the
+    SAME batches as the single-process loop, so the per-batch scores and the predictions are identical -- and rank 0 gathers
+    them back into order (one ``gather_object`` of the ranks' score tables and prediction blocks).  Rank 0 returns the result,
+    the other ranks None.  The reference evaluates on one process; with the training step at > 200 k frames/s the evaluation
+    every ``eval_interval`` epochs was the serial part of a multi-GPU run."""
+    rank, world = _rank_world() if sharded else (0, 1)
+    n_batches = (len(data) + batch_size - 1) // batch_size
+    mine = list(range(rank, n_batches, world))
+    own = None
+    if world > 1:  # the frames of this rank's batches, batch after batch (a short last batch is the last of its owner)
+        own = [i for k in mine for i in range(k * batch_size, min((k + 1) * batch_size, len(data)))]
     if device_loader:  # same batches, gathered on the device (harness/data.py)
         from .data import DeviceBatchLoader
-        loader = DeviceBatchLoader(data, batch_size, shuffle=False)
+        loader = DeviceBatchLoader(data, batch_size, shuffle=False, indices=own)
     else:
-        loader = DataLoader(data, batch_size=batch_size, shuffle=False, collate_fn=collate_fn)
+        dev = "cuda" if torch.cuda.is_available() else None
+        loader = DataLoader(data if own is None else Subset(data, own), batch_size=batch_size, shuffle=False,
+                            collate_fn=lambda b: collate_fn(b, device=dev))
     scores = {name: [] for name in model.loss_fn.get_score_names()}
     input_scores = deepcopy(scores)
     all_preds: List[Tensor] = []
@@ -87,13 +101,28 @@ def evaluate(model: AutoCfdModel, data, output_dir: Path, batch_size: int = 2, p
             for key in scores:
                 scores[key].append(loss[key].detach().reshape(()))
             all_preds.append(preds.detach())
-            if plot_interval > 0 and step % plot_interval == 0 and not measure_time:
+            gstep = mine[step] if world > 1 else step  # position in the evaluation order
+            if plot_interval > 0 and gstep % plot_interval == 0 and not measure_time and rank == 0:
                 plot_predictions(inp=inputs[0][0], label=labels[0][0], pred=preds[0][0], out_dir=Path(output_dir) / "images",
-                                 step=step)
+                                 step=gstep)
     for table in (scores, input_scores):
         for key in table:
             table[key] = torch.stack(table[key]).cpu().tolist() if table[key] else []
-    all_preds = [torch.cat(all_preds, dim=0).cpu()] if all_preds else []
+    pred_blocks = [p_.cpu() for p_ in all_preds]
+    if world > 1:
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object((mine, scores, input_scores, pred_blocks), gathered, dst=0)
+        if rank != 0:
+            return None
+        order = {}
+        for r_mine, r_scores, r_in, r_preds in gathered:
+            for pos, k in enumerate(r_mine):
+                order[k] = ({key: r_scores[key][pos] for key in r_scores}, {key: r_in[key][pos] for key in r_in}, r_preds[pos])
+        assert sorted(order) == list(range(n_batches)), "the ranks' evaluation shards do not tile the batches"
+        scores = {key: [order[k][0][key] for k in range(n_batches)] for key in scores}
+        input_scores = {key: [order[k][1][key] for k in range(n_batches)] for key in input_scores}
+        pred_blocks = [order[k][2] for k in range(n_batches)]
+    all_preds = [torch.cat(pred_blocks, dim=0)] if pred_blocks else []
     if measure_time:
         print(f"Time (ms) per step: {1000 * (time.time() - start_time) / max(len(loader), 1):.3f}")
     avg_scores = {}
@@ -247,11 +276,14 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
         train_losses += ep_train_losses
         if world > 1 and (ep + 1) % eval_interval == 0:
             average_buffers(model)  # BatchNorm running statistics of all shards go into the checkpoint
-        if (ep + 1) % eval_interval == 0 and rank == 0:
+        result = None
+        if (ep + 1) % eval_interval == 0:  # every rank evaluates its share of the dev batches; rank 0 gets the assembled result
             ckpt_dir = output_dir / f"ckpt-{ep}"
-            ckpt_dir.mkdir(exist_ok=True, parents=True)
+            if rank == 0:
+                ckpt_dir.mkdir(exist_ok=True, parents=True)
             result = evaluate(model, dev_data, ckpt_dir, batch_size=eval_batch_size, plot_interval=plot_interval,
-                              device_loader=device_loader)
+                              device_loader=device_loader, sharded=world > 1)
+        if (ep + 1) % eval_interval == 0 and rank == 0:
             dev_scores = result["scores"]
             dump_json(dev_scores, ckpt_dir / "dev_scores.json")
             dump_json(ep_train_losses, ckpt_dir / "train_loss.json")

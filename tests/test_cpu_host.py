@@ -332,6 +332,72 @@ def test_rollout_metrics_shard_over_ranks_gloo_world2(n_cases):
                 assert abs(got[k][name] - single[k][name]) <= 1e-12 * abs(single[k][name]), (k, name)
 
 
+class _ToyLoss:
+    def get_score_names(self):
+        return ["mse", "nmse"]
+
+    def __call__(self, preds, labels):
+        import torch
+        mse = torch.mean((preds - labels) ** 2)
+        return dict(mse=mse, nmse=mse / torch.mean(labels ** 2))
+
+
+class _ToyAutoModel:
+    """CPU stand-in for an AutoCfdModel (the product models run on the GPU only): preds = 0.9 u + 0.01 p_0, masked."""
+    loss_fn = _ToyLoss()
+
+    def eval(self):
+        return self
+
+    def __call__(self, inputs, label, case_params, mask):
+        preds = (0.9 * inputs[:, :1] + 0.01 * case_params[:, :1, None, None]) * mask
+        return dict(preds=preds, loss=self.loss_fn(preds=preds, labels=label[:, :1]))
+
+
+def _eval_worker(rank, world, port, n_cases, bs, out_dir, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cfdbench_amd.harness.data import SyntheticAutoDataset
+        from cfdbench_amd.harness.train_auto import evaluate
+        data = SyntheticAutoDataset(n_cases=n_cases, n_frames=4, height=8, width=9, seed=3)
+        got = evaluate(_ToyAutoModel(), data, Path(out_dir), batch_size=bs, plot_interval=0, sharded=True)
+        q.put((rank, None if got is None else (got["preds"].numpy(), got["scores"])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_cases,bs", [(3, 2), (1, 4), (4, 3)])
+def test_evaluate_shards_batches_over_ranks_gloo_world2(tmp_path, n_cases, bs):
+    """The periodic evaluation of a data-parallel run: batch k goes to rank k % world, rank 0 gets the single-process result back
+    (same batches, same order: per-batch score lists, their means and the prediction tensor are identical) -- odd batch counts,
+    a short last batch, and fewer batches than ranks."""
+    import torch.multiprocessing as mp
+    from cfdbench_amd.harness.data import SyntheticAutoDataset
+    from cfdbench_amd.harness.train_auto import evaluate
+    data = SyntheticAutoDataset(n_cases=n_cases, n_frames=4, height=8, width=9, seed=3)
+    (tmp_path / "single").mkdir()
+    (tmp_path / "dp").mkdir()
+    single = evaluate(_ToyAutoModel(), data, tmp_path / "single", batch_size=bs, plot_interval=0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, n_cases, bs, str(tmp_path / "dp"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] is None
+    preds, scores = res[0]
+    assert np.array_equal(preds, single["preds"].numpy())
+    assert scores == single["scores"]
+    assert len(scores["all"]["nmse"]) == (len(data) + bs - 1) // bs
+
+
 def test_shard_indices_reshuffle_per_epoch():
     """DistributedSampler.set_epoch semantics: the partition of the frames over the ranks changes with the epoch, stays a
     partition, keeps equal sizes, and is reproducible."""

@@ -263,6 +263,61 @@ def _multistep_rank(rank, world, port, out_dir, steps, q):
     finally:
         dist.destroy_process_group()
 
+def _evaluate_rank(rank, world, port, out_dir, device_loader, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cfdbench_amd.harness.autoregressive import init_model
+        from cfdbench_amd.harness.data import SyntheticAutoDataset
+        from cfdbench_amd.harness.train_auto import evaluate
+        torch.manual_seed(1)
+        model = init_model(_args(Path(out_dir))).cuda()
+        data = SyntheticAutoDataset(n_cases=3, n_frames=4, height=64, width=64, seed=5, border_mask=True)
+        got = evaluate(model, data, Path(out_dir), batch_size=2, plot_interval=0, device_loader=bool(device_loader), sharded=True)
+        q.put((rank, None if got is None else (got["preds"].numpy(), got["scores"])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("device_loader", [0, 1])
+def test_evaluate_sharded_over_two_ranks(torch, tmp_path, device_loader):
+    """The periodic evaluation of a data-parallel run (train_auto.py:61-148 is single-process): batch k on rank k % world, rank 0
+    assembles the single-process result -- bitwise, because every batch is the same launch on the same frames (5 batches of 2, 2, 2,
+    2, 1 frames over two ranks)."""
+    import socket
+    import torch.multiprocessing as mp
+    from cfdbench_amd.harness.autoregressive import init_model
+    from cfdbench_amd.harness.data import SyntheticAutoDataset
+    from cfdbench_amd.harness.train_auto import evaluate
+    torch.manual_seed(1)
+    model = init_model(_args(tmp_path)).cuda()
+    data = SyntheticAutoDataset(n_cases=3, n_frames=4, height=64, width=64, seed=5, border_mask=True)
+    single = evaluate(model, data, tmp_path, batch_size=2, plot_interval=0, device_loader=bool(device_loader))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_evaluate_rank, args=(r, 2, port, str(tmp_path), device_loader, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[1] is None
+    preds, scores = res[0]
+    assert len(scores["all"]["nmse"]) == 5
+    assert np.array_equal(preds, single["preds"].numpy())
+    assert scores == single["scores"]
+
+
 
 def test_multistep_inference_sharded_over_two_ranks(torch, tmp_path):
     """rollout inference shards the test cases over the ranks (r, r + world, ...), every rank rolls its cases out from one
