@@ -227,6 +227,40 @@ __device__ __forceinline__ CfdSplit8 cfd_split8(const float (&x)[8]) {
     s.lo = __builtin_bit_cast(bf16x8, l);
     return s;
 }
+// Three pieces, p[0] + p[1] + p[2] == x exactly (8 + 8 + 8 significant bits; both residuals are exact in fp32): the operand format
+// of the convolution stack (conv6.hip), whose ReLU / max-pool networks need fp32-exact products (a two-piece
+// product moves pre-activations across the ReLU kink).
+struct CfdSplit8x3 {
+    bf16x8 p[3];
+};
+__device__ __forceinline__ CfdSplit8x3 cfd_split8x3(const float (&x)[8]) {
+    cfd_u32x4 h, l, m;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned hk = cfd_pack_bf16(x[2 * k], x[2 * k + 1]);
+        const float r0 = x[2 * k] - __builtin_bit_cast(float, hk << 16), r1 = x[2 * k + 1] - __builtin_bit_cast(float, hk & 0xffff0000u);
+        const unsigned lk = cfd_pack_bf16(r0, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, lk << 16), s1 = r1 - __builtin_bit_cast(float, lk & 0xffff0000u);
+        h[k] = (unsigned)cfd_opaque((int)hk);
+        l[k] = (unsigned)cfd_opaque((int)lk);
+        m[k] = (unsigned)cfd_opaque((int)cfd_pack_bf16(s0, s1));
+    }
+    CfdSplit8x3 s;
+    s.p[0] = __builtin_bit_cast(bf16x8, h);
+    s.p[1] = __builtin_bit_cast(bf16x8, l);
+    s.p[2] = __builtin_bit_cast(bf16x8, m);
+    return s;
+}
+// D += A*B for two three-piece operands: the six products down to 2^-24 relative (a0 b0, a0 b1, a1 b0, a1 b1, a0 b2, a2 b0);
+// the dropped ones are <= 2^-32 of the product, below the rounding of the fp32 accumulation itself.  Small terms first.
+__device__ __forceinline__ f32x4 cfd_mfma_bf16x6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c) {
+    c = cfd_mfma16x16x32_bf16(a[2], b[0], c);
+    c = cfd_mfma16x16x32_bf16(a[0], b[2], c);
+    c = cfd_mfma16x16x32_bf16(a[1], b[1], c);
+    c = cfd_mfma16x16x32_bf16(a[1], b[0], c);
+    c = cfd_mfma16x16x32_bf16(a[0], b[1], c);
+    return cfd_mfma16x16x32_bf16(a[0], b[0], c);
+}
 // D += A*B with both operands split
 __device__ __forceinline__ f32x4 cfd_mfma_bf16x3(const CfdSplit8& a, const CfdSplit8& b, f32x4 c) {
     c = cfd_mfma16x16x32_bf16(a.lo, b.hi, c);

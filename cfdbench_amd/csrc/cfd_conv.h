@@ -1,0 +1,38 @@
+// Shared between conv.hip (exact-fp32 MFMA kernels, BatchNorm, pooling, the C ABI of the convolution stack) and conv6.hip (the
+// three-piece split-bf16 implicit-GEMM kernels for k = 3 and k = 7).
+#pragma once
+#include "cfd_common.h"
+
+struct ConvGeom {
+    int B, Ci, Co, H, W, ks;  // ks = kernel size (odd), pad = ks/2
+};
+
+struct ConvTile {
+    int TW, TH, NB;       // tile shape, NB*TH*TW <= 256
+    int tiles_x, tiles_y; // tiles per image
+    int LW, LH;           // LDS halo tile: (TH + ks - 1) x (TW + ks - 1) used, row stride LW
+    CfdDiv dUsed, dLH;    // magic-number dividers by the used halo width (TW + ks - 1) and by LH (staging index split)
+};
+
+// Destination tile shape of the LDS-tiled forward / input-gradient kernels for a Hd x Wd grid: the power-of-two shape, or the
+// shape with TW*TH <= 256 that needs the fewest workgroups per image (conv.hip).
+void cfd_conv_tile_shape(int Hd, int Wd, int B, int& TW, int& TH, int& NB);
+
+// out[e] = bias[channel(e)] + sum_z part[z][e] over split-K partial outputs (conv.hip)
+int cfd_conv_splitk_sum(const float* part, const float* bias, float* out, long n, int nz, int Cm, long HWd, hipStream_t st,
+                        const char* what);
+// out[e] = sum_chunk part[chunk][e] in a fixed order (conv.hip)
+void cfd_conv_part_reduce(const float* part, float* out, long n, int nchunk, hipStream_t st);
+
+// ---- conv6.hip: k = 3 / k = 7 on three-piece split-bf16 operands (fp32-exact pieces, six bf16 MFMAs per product) ----
+// forward (ext = false: dst (B,Co,H,W) = conv(src (B,Ci,H,W)) + bias) and the transposed-valid pass of the input gradient
+// (ext = true: dst (B,Ci,H+2p,W+2p) from src = gout (B,Co,H,W)).  ws: cfd_conv6_ws_bytes(); returns CFD_ERR_UNSUPPORTED when the
+// layer is not covered (the caller then uses the fp32 kernels).
+bool cfd_conv6_covers(const ConvGeom& g, bool ext);
+size_t cfd_conv6_ws_bytes(const ConvGeom& g, bool ext);
+int cfd_conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, bool ext,
+                  hipStream_t st, const char* what);
+// weight gradient gw (Co,Ci,ks,ks) = sum over (b, p) of gout[b][o][p] * in[b][i][clamp(p + tap)]
+bool cfd_conv6_wgrad_covers(const ConvGeom& g);
+size_t cfd_conv6_wgrad_ws_bytes(const ConvGeom& g);
+int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, void* ws, const ConvGeom& g, hipStream_t st, const char* what);

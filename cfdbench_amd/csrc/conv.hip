@@ -9,13 +9,9 @@
 //             V^T(g) is the same gather kernel on the (H+2pad) x (W+2pad) extended grid with zero outside g, and
 //             P^T folds the pad ring back onto the border pixels (k_fold_pad) -- deterministic, no atomics
 //   weight gradient: gw[o][(i,ky,kx)] = sum_p g[o][p] * in[i][clamp(...)]                    M = Cout, N = Cin*k*k, K = pixels
-#include "cfd_common.h"
+#include "cfd_conv.h"
 
 #define CV_WAVES 4
-
-struct ConvGeom {
-    int B, Ci, Co, H, W, ks;  // ks = kernel size (odd), pad = ks/2
-};
 
 // (i, ky, kx) of flat index k over Ci*ks*ks
 __device__ __forceinline__ void conv_split_k(int k, int ks, int& i, int& ky, int& kx) {
@@ -108,12 +104,6 @@ __global__ __launch_bounds__(64 * CV_WAVES) void k_conv_gather(const float* __re
 #ifndef CFD_CONV_TILE_MIN_WGS
 #define CFD_CONV_TILE_MIN_WGS 256  // fewer workgroups (after split-K) than this: use the gather kernel
 #endif
-struct ConvTile {
-    int TW, TH, NB;       // tile shape, NB*TH*TW == 256
-    int tiles_x, tiles_y; // tiles per image
-    int LW, LH;           // LDS halo tile: (TH + ks - 1) x (TW + ks - 1), row stride LW
-    CfdDiv dUsed, dLH;    // magic-number dividers by the used halo width (TW + ks - 1) and by LH (staging index split)
-};
 
 template <int KS, int MT, int CC, bool EXT>
 __global__ __launch_bounds__(256) void k_conv_tile(const float* __restrict__ src, const float* __restrict__ w,
@@ -242,6 +232,17 @@ __global__ __launch_bounds__(256) void k_splitk_sum(const float* __restrict__ pa
     }
 }
 
+int cfd_conv_splitk_sum(const float* part, const float* bias, float* out, long n, int nz, int Cm, long HWd, hipStream_t st,
+                        const char* what) {
+    CFD_REQUIRE_I31(n, what);
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)blocks), dim3(256), 0, st, part, bias, out, (unsigned)n, nz, Cm,
+                       cfd_div_make((unsigned)HWd), cfd_div_make((unsigned)Cm));
+    CFD_LAUNCH_CHECK(what);
+    return CFD_OK;
+}
+
 struct ConvTilePlan {
     ConvTile t;
     long ptiles;
@@ -250,15 +251,9 @@ struct ConvTilePlan {
     bool ok;
 };
 
-// Tile shape, output-channel grouping and split-K factor of the LDS-tiled kernel for one layer (shared by the launcher
-// and the workspace-size functions so that both always agree).
-template <int KS, int CC, bool EXT>
-static ConvTilePlan plan_conv_tile(const ConvGeom& g, bool allow_split) {
-    constexpr int PAD = KS / 2, KK = KS * KS, KSTEPS = (CC * KK + 3) / 4;
-    const int Hd = EXT ? g.H + 2 * PAD : g.H, Wd = EXT ? g.W + 2 * PAD : g.W;
-    const int Cm = EXT ? g.Ci : g.Co, Cs = EXT ? g.Co : g.Ci, MTall = (Cm + 15) / 16;
-    ConvTilePlan P{};
-    ConvTile& t = P.t;
+void cfd_conv_tile_shape(int Hd, int Wd, int B, int& TW_, int& TH_, int& NB_) {
+    struct { int TW, TH, NB; } t;
+    struct { int B; } g{B};
     t.TW = Wd >= 32 ? 32 : (Wd > 8 ? 16 : (Wd > 4 ? 8 : 4));
     int rows = 256 / t.TW;                       // rows available per workgroup
     t.TH = Hd < rows ? Hd : rows;
@@ -287,6 +282,21 @@ static ConvTilePlan plan_conv_tile(const ConvGeom& g, bool allow_split) {
         t.TH = bth;
         t.NB = 256 / (t.TW * t.TH);
     }
+    TW_ = t.TW;
+    TH_ = t.TH;
+    NB_ = t.NB;
+}
+
+// Tile shape, output-channel grouping and split-K factor of the LDS-tiled kernel for one layer (shared by the launcher
+// and the workspace-size functions so that both always agree).
+template <int KS, int CC, bool EXT>
+static ConvTilePlan plan_conv_tile(const ConvGeom& g, bool allow_split) {
+    constexpr int PAD = KS / 2, KK = KS * KS, KSTEPS = (CC * KK + 3) / 4;
+    const int Hd = EXT ? g.H + 2 * PAD : g.H, Wd = EXT ? g.W + 2 * PAD : g.W;
+    const int Cm = EXT ? g.Ci : g.Co, Cs = EXT ? g.Co : g.Ci, MTall = (Cm + 15) / 16;
+    ConvTilePlan P{};
+    ConvTile& t = P.t;
+    cfd_conv_tile_shape(Hd, Wd, g.B, t.TW, t.TH, t.NB);
     t.tiles_x = (Wd + t.TW - 1) / t.TW;
     t.tiles_y = (Hd + t.TH - 1) / t.TH;
     t.LH = t.TH + KS - 1;
@@ -351,15 +361,8 @@ static int launch_conv_tile(const float* src, const float* w, const float* bias,
 #undef CT_L
     CFD_LAUNCH_CHECK(what);
     if (P.ksplit > 1) {
-        const int Cm = EXT ? g.Ci : g.Co;
         const long HWd = EXT ? (long)(g.H + 2 * PAD) * (g.W + 2 * PAD) : (long)g.H * g.W;
-        const long n = (long)g.B * Cm * HWd;
-        CFD_REQUIRE_I31(n, what);
-        long blocks = (n + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)split_ws, bias, dst,
-                           (unsigned)n, P.ksplit, Cm, cfd_div_make((unsigned)HWd), cfd_div_make((unsigned)Cm));
-        CFD_LAUNCH_CHECK(what);
+        CFD_TRY(cfd_conv_splitk_sum(split_ws, bias, dst, (long)g.B * (EXT ? g.Ci : g.Co) * HWd, P.ksplit, EXT ? g.Ci : g.Co, HWd, st, what));
     }
     return CFD_OK;
 }
@@ -417,10 +420,12 @@ static int conv_check(const char* fn, int B, int Ci, int Co, int H, int W, int k
 extern "C" size_t cfd_conv2d_fwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks) {
     if (B <= 0 || Ci < 1 || Co < 1 || H < 1 || W < 1) return 0;
     const ConvGeom g{B, Ci, Co, H, W, ks};
+    if (cfd_conv6_covers(g, false)) return cfd_conv6_ws_bytes(g, false);  // weight fragments (+ split-K partials)
     return conv_split_bytes<false>(g);
 }
 
-// ws: cfd_conv2d_fwd_workspace_bytes() bytes, or NULL (then the deep, narrow layers run without split-K)
+// ws: cfd_conv2d_fwd_workspace_bytes() bytes, or NULL (then k = 3 / 7 run on the exact-fp32 MFMA kernels of this file instead of
+// the three-piece bf16 kernels of conv6.hip, and the deep, narrow layers without split-K)
 extern "C" int cfd_conv2d_fwd(const float* in, const float* w, const float* bias, float* out, void* ws, int B, int Ci, int Co,
                               int H, int W, int ks, void* stream) {
     CFD_REQUIRE(in && w && out, CFD_ERR_INVALID_ARG, "cfd_conv2d_fwd: NULL pointer");
@@ -429,6 +434,7 @@ extern "C" int cfd_conv2d_fwd(const float* in, const float* w, const float* bias
     const ConvGeom g{B, Ci, Co, H, W, ks};
     CFD_PROF_W("k_conv_fwd", (hipStream_t)stream, 4.0 * ((double)B * (Ci + Co) * H * W + (double)Co * Ci * ks * ks),
                2.0 * B * H * W * (double)Co * Ci * ks * ks);
+    if (ws && cfd_conv6_covers(g, false)) return cfd_conv6_run(in, w, bias, out, ws, g, false, (hipStream_t)stream, "cfd_conv2d_fwd");
     return launch_conv_gather<false>(in, w, bias, out, g, (float*)ws, (hipStream_t)stream, "cfd_conv2d_fwd");
 }
 
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(256) void k_part_reduce(const float* __restrict__ p
     }
 }
 
-static void launch_part_reduce(const float* part, float* out, long n, int nchunk, hipStream_t st) {
+void cfd_conv_part_reduce(const float* part, float* out, long n, int nchunk, hipStream_t st) {
     if (nchunk >= 128) {
         long blocks = (n + 15) / 16;
         if (blocks > 2048) blocks = 2048;
@@ -783,12 +789,16 @@ extern "C" size_t cfd_conv2d_bwd_workspace_bytes(int B, int Ci, int Co, int H, i
                                    : (ks == 7 ? wgrad_tile_plan<7, 4>(g, t, ptiles, groups, mtw, lds) : false);
         if (tiled && groups > nchunk) nchunk = groups;
     }
-    const size_t part = cfd_align_up((size_t)nchunk * Co * Ci * ks * ks * sizeof(float), 256);
+    size_t part = cfd_align_up((size_t)nchunk * Co * Ci * ks * ks * sizeof(float), 256);
+    {
+        const ConvGeom g{B, Ci, Co, H, W, ks};
+        if (cfd_conv6_wgrad_covers(g)) part = cfd_conv6_wgrad_ws_bytes(g);
+    }
     const size_t cs = chan_sum_ws_bytes(Co);
     // [extended input gradient | split-K partials of the input-gradient pass]; the weight-gradient partials and the
     // bias sums reuse the front of the buffer afterwards
     const ConvGeom gg{B, Ci, Co, H, W, ks};
-    const size_t dg = ext + conv_split_bytes<true>(gg);
+    const size_t dg = ext + (cfd_conv6_covers(gg, true) ? cfd_conv6_ws_bytes(gg, true) : conv_split_bytes<true>(gg));
     const size_t m = dg > part ? dg : part;
     return m > cs ? m : cs;
 }
@@ -808,8 +818,12 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
             CFD_PROF_W("k_conv_dgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci * ks * ks),
                        2.0 * B * HW * (double)Co * Ci * ks * ks);
             const size_t ext_bytes = cfd_align_up((size_t)B * Ci * (H + 2 * pad) * (W + 2 * pad) * sizeof(float), 256);
-            float* split_ws = conv_split_bytes<true>(g) ? (float*)((char*)ws + ext_bytes) : nullptr;
-            CFD_TRY(launch_conv_gather<true>(gout, w, nullptr, ext, g, split_ws, st, "cfd_conv2d_bwd(dgrad)"));
+            if (cfd_conv6_covers(g, true)) {
+                CFD_TRY(cfd_conv6_run(gout, w, nullptr, ext, (char*)ws + ext_bytes, g, true, st, "cfd_conv2d_bwd(dgrad)"));
+            } else {
+                float* split_ws = conv_split_bytes<true>(g) ? (float*)((char*)ws + ext_bytes) : nullptr;
+                CFD_TRY(launch_conv_gather<true>(gout, w, nullptr, ext, g, split_ws, st, "cfd_conv2d_bwd(dgrad)"));
+            }
         }
         const long total = (long)B * Ci * HW;
         long blocks = (total + 255) / 256;
@@ -820,7 +834,10 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
                            pad, cfd_div_make((unsigned)HW), cfd_div_make((unsigned)W));
         CFD_LAUNCH_CHECK("cfd_conv2d_bwd(fold)");
     }
-    if (gw) {
+    if (gw && cfd_conv6_wgrad_covers(g)) {
+        CFD_PROF_W("k_conv_wgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci * ks * ks), 2.0 * B * HW * (double)Co * Ci * ks * ks);
+        CFD_TRY(cfd_conv6_wgrad(gout, in, gw, ws, g, st, "cfd_conv2d_bwd(wgrad)"));
+    } else if (gw) {
         long chunk_px;
         int nchunk;
         const int J = Ci * ks * ks;
@@ -867,7 +884,7 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
         CFD_LAUNCH_CHECK("cfd_conv2d_bwd(wgrad)");
         const long n = (long)Co * J;
         CFD_PROF_W("k_part_reduce", st, 0.0, 0.0);  // partial sums are an implementation detail
-        launch_part_reduce((const float*)ws, gw, n, nchunk, st);
+        cfd_conv_part_reduce((const float*)ws, gw, n, nchunk, st);
         CFD_LAUNCH_CHECK("cfd_conv2d_bwd(reduce)");
     }
     if (gb) CFD_TRY(chan_sum(gout, gb, ws, B, Co, HW, st, "cfd_conv2d_bwd(bias)"));
@@ -1378,7 +1395,7 @@ extern "C" int cfd_convt2_bwd(const float* gout, const float* in, const float* w
         }
         CFD_LAUNCH_CHECK("cfd_convt2_bwd(wgrad)");
         const long n = (long)Ci * Co * 4;
-        launch_part_reduce((const float*)ws, gw, n, nchunk, st);
+        cfd_conv_part_reduce((const float*)ws, gw, n, nchunk, st);
         CFD_LAUNCH_CHECK("cfd_convt2_bwd(reduce)");
     }
     if (gb) CFD_TRY(chan_sum(gout, gb, ws, B, Co, 4 * H * W, st, "cfd_convt2_bwd(bias)"));

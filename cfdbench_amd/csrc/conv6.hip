@@ -1,0 +1,475 @@
+// k = 3 and k = 7 replicate-padded convolutions (src/models/unet.py:20-43, src/models/resnet.py:35-55) as implicit GEMMs on the
+// bf16 matrix pipe with THREE-PIECE operands: every fp32 value is carried as hi + lo + lo2 (8 + 8 + 8 significant bits, exact),
+// a product is six v_mfma_f32_16x16x32_bf16 (cfd_mfma_bf16x6: everything down to 2^-24 of the product, fp32 accumulation), so the
+// results are fp32-exact-class like the v_mfma_f32_16x16x4_f32 kernels of conv.hip they replace -- the ReLU / max-pool networks
+// need that (two-piece products move pre-activations across the ReLU kink) -- at 6 x 16 cycles per
+// 16x16x32 tile-step instead of 8 x 32.  What makes the matrix pipe the bound instead of the operand gathers:
+//   * an operand is split ONCE, on its way into LDS (weights: once per call by k_conv6_wprep into MFMA fragment order), and the
+//     k x k gather re-reads it from there as ONE ds_read_b128 per piece: the eight K slots of a lane are eight CHANNELS of one tap
+//     (forward / input gradient: LDS layout [pixel][channel]) or eight IMAGES of one pixel (weight gradient: layout
+//     [pixel][channel][image]), never eight neighbouring pixels -- a tap shift then moves whole 16-byte units and every read
+//     stays aligned;
+//   * forward / input gradient: workgroup = 256 destination pixels x 16 MT output channels, channel chunks of CC stream through
+//     LDS; a wave owns 4 pixel tiles so a weight fragment feeds 4 MFMA chains;
+//   * weight gradient: K = (8 images x 4 pixels) per step, M = output channels, N = (tap, channel) columns with the channel
+//     innermost, so a column tile is ONE tap and its B operand one aligned read; the four waves split the K steps of a 16-pixel
+//     tile and are summed through LDS at the end (fixed order).
+#include "cfd_conv.h"
+
+typedef cfd_u32x4 u4;
+
+#ifndef CFD_CONV6_MAX_LDS
+#define CFD_CONV6_MAX_LDS (80 * 1024)  // two workgroups per CU: one stages while the other feeds the matrix pipe
+#endif
+
+// ------------------------------------------------------------------------------------------------------
+// weight fragments: wfrag[(((chunk * KSTEPS + s) * MTall + mtile) * 3 + piece) * 64 + lane], lane (q, n):
+//   row m = 16 mtile + n, K slot j of step s = tap s * PPS + q / CH8, channel chunk * CC + 8 (q % CH8) + j
+//   (CH8 = CC / 8 channel octets per tap, PPS = 4 / CH8 taps per step).  EXT: A(m = i, (o, ky, kx)) = w[o][i][ky][kx].
+// ------------------------------------------------------------------------------------------------------
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_conv6_wprep(const float* __restrict__ w, u4* __restrict__ wfrag, ConvGeom g, int CC,
+                                                     int KSTEPS, int MTall, unsigned total) {
+    const int KK = g.ks * g.ks;
+    const int Cs = EXT ? g.Co : g.Ci, Cm = EXT ? g.Ci : g.Co;
+    const int CH8 = CC / 8, PPS = 4 / CH8;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63;
+        unsigned rest = idx >> 6;
+        const int mtile = rest % MTall;
+        rest /= MTall;
+        const int s = rest % KSTEPS, chunk = rest / KSTEPS;
+        const int q = lane >> 4, n = lane & 15;
+        const int m = 16 * mtile + n, pos = s * PPS + q / CH8, cb = chunk * CC + 8 * (q % CH8);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cb + j;
+            v[j] = (m < Cm && c < Cs && pos < KK) ? (EXT ? w[((size_t)c * g.Ci + m) * KK + pos] : w[((size_t)m * g.Ci + c) * KK + pos]) : 0.f;
+        }
+        const CfdSplit8x3 sp = cfd_split8x3(v);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) wfrag[((size_t)(idx >> 6) * 3 + pc) * 64 + lane] = __builtin_bit_cast(u4, sp.p[pc]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward / transposed-valid pass:  dst[b][m][p] = bias[m] + sum_k A(m, k) * src[b][c(k)][pos(p, k)]   (conv.hip has the algebra)
+// LDS (all dynamic, 16-byte carve offsets): [3 piece planes of NB * LH * LW halo pixels x CC bf16 | weight fragments of this
+// chunk and output group KSTEPS * MT * 3 * 64 x 16 B | tap offsets KSTEPS * 4 ints]
+// ------------------------------------------------------------------------------------------------------
+template <int KS, int MT, int CC, bool EXT>
+__global__ __launch_bounds__(256) void k_conv6(const float* __restrict__ src, const u4* __restrict__ wfrag,
+                                               const float* __restrict__ bias, float* __restrict__ dst, ConvGeom g, ConvTile t,
+                                               int MTall) {
+    constexpr int KK = KS * KS, PAD = KS / 2;
+    constexpr int CH8 = CC / 8, PPS = 4 / CH8, KSTEPS = (KK + PPS - 1) / PPS;
+    CFD_DYN_SHARED(u4, s_dyn);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int Cs = EXT ? g.Co : g.Ci, Cm = EXT ? g.Ci : g.Co;
+    const int Hd = EXT ? g.H + 2 * PAD : g.H, Wd = EXT ? g.W + 2 * PAD : g.W;
+    const int HWd = Hd * Wd, HWs = g.H * g.W;
+    const int halo = t.LH * t.LW, NPX = t.NB * halo;
+    const int plane = NPX * CH8;                       // 16-byte units per piece plane
+    u4* s_in = s_dyn;                                  // [piece][pixel][channel octet]
+    u4* s_w = s_dyn + 3 * plane;                       // [kstep][mt][piece][lane]
+    int* s_koff = (int*)(s_w + KSTEPS * MT * 3 * 64);  // [kstep][q]: 16-byte units from a pixel's own slot to its operand
+    const int mb = blockIdx.y * MT;                    // first output-channel tile of this workgroup
+    const int tpi = t.tiles_x * t.tiles_y;
+    const int bg = blockIdx.x / tpi, tr = blockIdx.x - bg * tpi;
+    const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
+    const int b0 = bg * t.NB;
+    for (int i = threadIdx.x; i < KSTEPS * 4; i += blockDim.x) {
+        const int s = i >> 2, qq = i & 3, pos = s * PPS + qq / CH8, ky = pos / KS, kx = pos - KS * ky;
+        s_koff[i] = pos < KK ? ((EXT ? (2 * PAD - ky) * t.LW + (2 * PAD - kx) : ky * t.LW + kx) * CH8 + qq % CH8) : qq % CH8;
+    }
+    // this wave's 4 pixel tiles: tile pixel pi = 64*wave + 16*tt + n -> (image bi, row, column)
+    int poff[4], pb[4], py[4], px[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const int pi = 64 * wave + 16 * tt + n;
+        const int bi = pi / (t.TH * t.TW), rem = pi - bi * (t.TH * t.TW);
+        const int r = rem / t.TW, c = rem - r * t.TW;
+        const bool on = bi < t.NB;  // NB*TH*TW may be < 256 (tile shapes that are not powers of two): idle lanes
+        pb[tt] = on ? b0 + bi : g.B; py[tt] = ty0 + r; px[tt] = tx0 + c;
+        poff[tt] = on ? (bi * halo + r * t.LW + c) * CH8 : 0;
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[mt][tt] = zero;
+    const int oy = EXT ? ty0 - 2 * PAD : ty0 - PAD, ox = EXT ? tx0 - 2 * PAD : tx0 - PAD;  // source coords of the halo origin
+    // split-K over blockIdx.z: a contiguous range of channel chunks, own partial output slice (summed by k_splitk_sum)
+    const int nch = (Cs + CC - 1) / CC, per = (nch + gridDim.z - 1) / gridDim.z;
+    const int chbeg = blockIdx.z * per, chend = (chbeg + per) < nch ? (chbeg + per) : nch;
+    const bool split = gridDim.z > 1;
+    if (split) dst += (size_t)blockIdx.z * g.B * Cm * HWd;
+    for (int ch = chbeg; ch < chend; ++ch) {
+        const int c0 = ch * CC;
+        __syncthreads();  // previous chunk fully consumed (first pass: s_koff written)
+        // halo pixels x channel octets: 8 channel values of one pixel -> three 16-byte pieces
+        for (int i = threadIdx.x; i < plane; i += blockDim.x) {
+            const int c8 = CH8 == 1 ? 0 : (i >= NPX ? 1 : 0), pxl = i - c8 * NPX;
+            const int r1 = (int)cfd_div((unsigned)pxl, t.dUsed), lx = pxl - r1 * t.LW;
+            const int bi = (int)cfd_div((unsigned)r1, t.dLH), ly = r1 - bi * t.LH;
+            int y = oy + ly, x = ox + lx;
+            bool ok = b0 + bi < g.B;
+            if constexpr (EXT) {
+                ok = ok && y >= 0 && y < g.H && x >= 0 && x < g.W;
+            } else {
+                y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
+                x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
+            }
+            const int cb = c0 + 8 * c8;
+            const float* sb = src + ((size_t)(ok ? b0 + bi : 0) * Cs + cb) * HWs + (ok ? y * g.W + x : 0);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (ok && cb + j < Cs) ? sb[(size_t)j * HWs] : 0.f;
+            const CfdSplit8x3 sp = cfd_split8x3(v);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) s_in[pc * plane + pxl * CH8 + c8] = __builtin_bit_cast(u4, sp.p[pc]);
+        }
+        // weight fragments of this chunk and output group: MT * 192 consecutive vectors per k-step
+        for (int i = threadIdx.x; i < KSTEPS * MT * 192; i += blockDim.x) {
+            const int s = i / (MT * 192), r = i - s * (MT * 192);
+            const u4 z4 = {0u, 0u, 0u, 0u};
+            s_w[i] = mb + r / 192 < MTall ? wfrag[((size_t)(ch * KSTEPS + s) * MTall + mb) * 192 + r] : z4;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int ko = s_koff[4 * s + q];
+            bf16x8 bv[4][3], av[MT][3];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) bv[tt][pc] = __builtin_bit_cast(bf16x8, s_in[pc * plane + poff[tt] + ko]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) av[mt][pc] = __builtin_bit_cast(bf16x8, s_w[((s * MT + mt) * 3 + pc) * 64 + lane]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[mt][tt] = cfd_mfma_bf16x6(av[mt], bv[tt], acc[mt][tt]);
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        if (pb[tt] < g.B && py[tt] < Hd && px[tt] < Wd) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * (mb + mt) + 4 * q + r;
+                    if (m < Cm)
+                        dst[((size_t)pb[tt] * Cm + m) * HWd + py[tt] * Wd + px[tt]] = acc[mt][tt][r] + ((bias && !split) ? bias[m] : 0.f);
+                }
+        }
+    }
+}
+
+struct Conv6Plan {
+    ConvTile t;
+    long ptiles;
+    int CC, KSTEPS, MTall, mtw, mgroups, ksplit, nch;
+    size_t lds, wfrag_bytes, split_bytes;
+    bool ok;
+};
+
+static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
+    Conv6Plan P{};
+    if (g.ks != 3 && g.ks != 7) return P;
+    const int KS = g.ks, PAD = KS / 2, KK = KS * KS;
+    const int Hd = ext ? g.H + 2 * PAD : g.H, Wd = ext ? g.W + 2 * PAD : g.W;
+    const int Cm = ext ? g.Ci : g.Co, Cs = ext ? g.Co : g.Ci;
+    P.CC = (KS == 7 || Cs <= 8) ? 8 : 16;  // k = 7: 13 k-steps of 4 taps x 8 channels keep two workgroups per CU
+    const int PPS = 32 / P.CC;
+    P.KSTEPS = (KK + PPS - 1) / PPS;
+    P.MTall = (Cm + 15) / 16;
+    P.nch = (Cs + P.CC - 1) / P.CC;
+    ConvTile& t = P.t;
+    cfd_conv_tile_shape(Hd, Wd, g.B, t.TW, t.TH, t.NB);
+    t.tiles_x = (Wd + t.TW - 1) / t.TW;
+    t.tiles_y = (Hd + t.TH - 1) / t.TH;
+    t.LH = t.TH + KS - 1;
+    t.LW = t.TW + KS - 1;
+    t.dUsed = cfd_div_make((unsigned)t.LW);
+    t.dLH = cfd_div_make((unsigned)t.LH);
+    P.ptiles = (long)((g.B + t.NB - 1) / t.NB) * t.tiles_x * t.tiles_y;
+    const auto lds_of = [&](int mtw) {
+        return (size_t)3 * t.NB * t.LH * t.LW * P.CC * 2 + (size_t)P.KSTEPS * mtw * 3 * 1024 + (size_t)P.KSTEPS * 16;
+    };
+    // two output-channel tiles per workgroup (a staged halo feeds twice the MFMAs) while two workgroups still fit a CU and the
+    // grid fills the chip
+    int mtw = P.MTall >= 2 ? 2 : 1;
+    if (mtw == 2 && (lds_of(2) > CFD_CONV6_MAX_LDS || P.ptiles * ((P.MTall + 1) / 2) < 256)) mtw = 1;
+    P.mtw = mtw;
+    P.mgroups = (P.MTall + mtw - 1) / mtw;
+    const long wgs = P.ptiles * P.mgroups;
+    P.ksplit = 1;
+    if (wgs < 256 && P.nch > 1) {  // deep, narrow levels: split the channel chunks over blockIdx.z
+        const long ks = (512 + wgs - 1) / wgs;
+        P.ksplit = (int)(ks < P.nch ? ks : P.nch);
+    }
+    P.lds = lds_of(mtw);
+    P.wfrag_bytes = cfd_align_up((size_t)P.nch * P.KSTEPS * P.MTall * 3 * 1024, 256);
+    P.split_bytes = P.ksplit > 1 ? cfd_align_up((size_t)P.ksplit * g.B * Cm * Hd * Wd * sizeof(float), 256) : 0;
+    P.ok = P.lds <= 150 * 1024 && (long)P.nch * P.KSTEPS * P.MTall * 64 < (1L << 31);
+    return P;
+}
+
+bool cfd_conv6_covers(const ConvGeom& g, bool ext) { return conv6_plan(g, ext).ok; }
+
+size_t cfd_conv6_ws_bytes(const ConvGeom& g, bool ext) {
+    const Conv6Plan P = conv6_plan(g, ext);
+    return P.ok ? P.wfrag_bytes + P.split_bytes : 0;
+}
+
+template <int KS, int CC, bool EXT>
+static void conv6_launch(const Conv6Plan& P, const float* src, const u4* wfrag, const float* bias, float* dst, const ConvGeom& g,
+                         hipStream_t st) {
+    const dim3 grid((unsigned)P.ptiles, P.mgroups, P.ksplit);
+#define C6_L(M_)                                                                                                                  \
+    do {                                                                                                                          \
+        static bool attr_set = false;                                                                                             \
+        if (!attr_set) {                                                                                                          \
+            (void)hipFuncSetAttribute((const void*)k_conv6<KS, M_, CC, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+            attr_set = true;                                                                                                      \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((k_conv6<KS, M_, CC, EXT>), grid, dim3(256), P.lds, st, src, wfrag, bias, dst, g, P.t, P.MTall);        \
+    } while (0)
+    if (P.mtw == 1) C6_L(1);
+    else C6_L(2);
+#undef C6_L
+}
+
+template <bool EXT>
+static int conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, hipStream_t st,
+                     const char* what) {
+    const Conv6Plan P = conv6_plan(g, EXT);
+    if (!P.ok) return CFD_ERR_UNSUPPORTED;
+    u4* wfrag = (u4*)ws;
+    float* split_ws = P.ksplit > 1 ? (float*)((char*)ws + P.wfrag_bytes) : nullptr;
+    {
+        const unsigned total = (unsigned)((long)P.nch * P.KSTEPS * P.MTall * 64);
+        unsigned blocks = (total + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL((k_conv6_wprep<EXT>), dim3(blocks), dim3(256), 0, st, w, wfrag, g, P.CC, P.KSTEPS, P.MTall, total);
+        CFD_LAUNCH_CHECK(what);
+    }
+    float* kdst = P.ksplit > 1 ? split_ws : dst;
+    if (g.ks == 3) {
+        if (P.CC == 8) conv6_launch<3, 8, EXT>(P, src, wfrag, bias, kdst, g, st);
+        else conv6_launch<3, 16, EXT>(P, src, wfrag, bias, kdst, g, st);
+    } else {
+        conv6_launch<7, 8, EXT>(P, src, wfrag, bias, kdst, g, st);
+    }
+    CFD_LAUNCH_CHECK(what);
+    if (P.ksplit > 1) {
+        const int PAD = g.ks / 2, Cm = EXT ? g.Ci : g.Co;
+        const long HWd = EXT ? (long)(g.H + 2 * PAD) * (g.W + 2 * PAD) : (long)g.H * g.W;
+        CFD_TRY(cfd_conv_splitk_sum(split_ws, bias, dst, (long)g.B * Cm * HWd, P.ksplit, Cm, HWd, st, what));
+    }
+    return CFD_OK;
+}
+
+int cfd_conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, bool ext,
+                  hipStream_t st, const char* what) {
+    return ext ? conv6_run<true>(src, w, bias, dst, ws, g, st, what) : conv6_run<false>(src, w, bias, dst, ws, g, st, what);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// weight gradient: gw[o][c][ky][kx] = sum_{b, y, x} g[b][o][y][x] * in[b][c][clamp(y + ky - pad)][clamp(x + kx - pad)]
+// Workgroup = one chunk of 16 input channels x 16 MT output channels x NKY tap rows (all KS columns); it walks tiles of
+// 8 images x 16 pixels (TH x TW) in a grid-stride loop.  LDS per tile: the replicate-clamped halo of the input
+// [piece][halo pixel][16 channels][8 images] and the upstream gradient [piece][16 pixels][16 MT channels][8 images], 16 bytes per
+// (pixel, channel) with the channel slot rotated by the pixel index ((c + pixel) & 15) so that the staging stores -- lanes =
+// consecutive pixels of one channel -- and the operand reads -- lanes = 16 channels of one pixel -- both spread over the banks.
+// MFMA view: K slot j of lane (q, n) = image j of pixel 4 wave + q; A row n = output channel; B column n = input channel of ONE
+// tap per column tile.  Accumulators stay in registers across the workgroup's tiles; one partial slice per pixel group.
+// ------------------------------------------------------------------------------------------------------
+struct Wg6Tile {
+    int TW, TH, tiles_x, tiles_y, LW, LH, HP;  // HP = LH * LW halo pixels
+    int tw_shift;
+    CfdDiv dHP, dLW;
+};
+
+template <int KS, int MT, int NKY>
+__global__ __launch_bounds__(256) void k_conv6_wgrad(const float* __restrict__ gout, const float* __restrict__ in,
+                                                     float* __restrict__ part, ConvGeom g, Wg6Tile t, int ntiles) {
+    constexpr int KK = KS * KS, PAD = KS / 2, NT = NKY * KS, NKG = KS / NKY;
+    CFD_DYN_SHARED(u4, s_dyn);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int HW = g.H * g.W;
+    u4* s_in = s_dyn;                    // [piece][halo pixel][16 slots]
+    u4* s_g = s_dyn + 3 * t.HP * 16;     // [piece][16 pixels][MT][16 slots]
+    const int c0 = blockIdx.y * 16;
+    const int mg = blockIdx.z / NKG, ky0 = (blockIdx.z - mg * NKG) * NKY;
+    const int mbase = mg * 16 * MT;
+    const int tpi = t.tiles_x * t.tiles_y;
+    const int pi = 4 * wave + q;                                       // this lane's pixel of the tile (its K step)
+    const int pbase = (pi >> t.tw_shift) * t.LW + (pi & (t.TW - 1));   // halo pixel of tap (0, 0)
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int bg = tile / tpi, tr = tile - bg * tpi;
+        const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
+        const int b0 = bg * 8;
+        const int oy = ty0 + ky0 - PAD, ox = tx0 - PAD;
+        __syncthreads();  // previous tile fully consumed
+        for (int i = threadIdx.x; i < t.HP * 16; i += blockDim.x) {
+            const int c = (int)cfd_div((unsigned)i, t.dHP), hp = i - c * t.HP;
+            const int ly = (int)cfd_div((unsigned)hp, t.dLW), lx = hp - ly * t.LW;
+            int y = oy + ly, x = ox + lx;
+            y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
+            x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
+            const bool cok = c0 + c < g.Ci;
+            const float* sb = in + ((size_t)b0 * g.Ci + (cok ? c0 + c : 0)) * HW + y * g.W + x;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (cok && b0 + j < g.B) ? sb[(size_t)j * g.Ci * HW] : 0.f;
+            const CfdSplit8x3 sp = cfd_split8x3(v);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) s_in[(pc * t.HP + hp) * 16 + ((c + hp) & 15)] = __builtin_bit_cast(u4, sp.p[pc]);
+        }
+        // upstream gradient of the tile's pixels (0 outside the image / batch / channel range: contributes nothing)
+        for (int i = threadIdx.x; i < 16 * 16 * MT; i += blockDim.x) {
+            const int o = i >> 4, p2 = i & 15;
+            const int y = ty0 + (p2 >> t.tw_shift), x = tx0 + (p2 & (t.TW - 1));
+            const bool ok = mbase + o < g.Co && y < g.H && x < g.W;
+            const float* sb = gout + ((size_t)b0 * g.Co + (ok ? mbase + o : 0)) * HW + (ok ? y * g.W + x : 0);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (ok && b0 + j < g.B) ? sb[(size_t)j * g.Co * HW] : 0.f;
+            const CfdSplit8x3 sp = cfd_split8x3(v);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                s_g[((pc * 16 + p2) * MT + (o >> 4)) * 16 + (((o & 15) + p2) & 15)] = __builtin_bit_cast(u4, sp.p[pc]);
+        }
+        __syncthreads();
+        bf16x8 av[MT][3];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) av[mt][pc] = __builtin_bit_cast(bf16x8, s_g[((pc * 16 + pi) * MT + mt) * 16 + ((n + pi) & 15)]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int P = pbase + (nt / KS) * t.LW + nt % KS;
+            bf16x8 bv[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bv[pc] = __builtin_bit_cast(bf16x8, s_in[(pc * t.HP + P) * 16 + ((n + P) & 15)]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = cfd_mfma_bf16x6(av[mt], bv, acc[mt][nt]);
+        }
+    }
+    // sum of the four waves (each owns 4 of the tile's 16 pixels) in a fixed order, one output-channel tile at a time
+    float* s_red = (float*)s_dyn;  // [wave][nt][r][lane]
+    float* dst = part + (size_t)blockIdx.x * g.Co * g.Ci * KK;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_red[((wave * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < NT * 256; e += blockDim.x) {
+            const int ln = e & 63, r = (e >> 6) & 3, nt = e >> 8;
+            const int o = mbase + 16 * mt + 4 * (ln >> 4) + r, c = c0 + (ln & 15);
+            if (o < g.Co && c < g.Ci) {
+                float sum = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) sum += s_red[((wv * NT + nt) * 4 + r) * 64 + ln];
+                dst[((size_t)o * g.Ci + c) * KK + (ky0 + nt / KS) * KS + nt % KS] = sum;
+            }
+        }
+    }
+}
+
+struct Wg6Plan {
+    Wg6Tile t;
+    int ntiles, groups, chunks, mtw, mgroups, nkg;
+    size_t lds, part_bytes;
+    bool ok;
+};
+
+static Wg6Plan wg6_plan(const ConvGeom& g) {
+    Wg6Plan P{};
+    if (g.ks != 3 && g.ks != 7) return P;
+    const int KS = g.ks, NKY = KS == 3 ? 3 : 1;
+    Wg6Tile& t = P.t;
+    t.TW = g.W >= 8 ? 8 : 4;
+    t.TH = 16 / t.TW;
+    t.tw_shift = t.TW == 8 ? 3 : 2;
+    t.tiles_x = (g.W + t.TW - 1) / t.TW;
+    t.tiles_y = (g.H + t.TH - 1) / t.TH;
+    t.LW = t.TW + KS - 1;
+    t.LH = t.TH + NKY - 1;
+    t.HP = t.LH * t.LW;
+    t.dHP = cfd_div_make((unsigned)t.HP);
+    t.dLW = cfd_div_make((unsigned)t.LW);
+    P.ntiles = ((g.B + 7) / 8) * t.tiles_x * t.tiles_y;
+    P.chunks = (g.Ci + 15) / 16;
+    const int MTall = (g.Co + 15) / 16;
+    P.mtw = MTall >= 3 ? 3 : MTall;
+    P.mgroups = (MTall + P.mtw - 1) / P.mtw;
+    P.nkg = KS / NKY;
+    // pixel groups: enough workgroups to fill the chip twice over, at most one per tile, partials capped at ~32 MB
+    long want = 2048 / ((long)P.chunks * P.mgroups * P.nkg);
+    if (want < 1) want = 1;
+    const long cap = (32L << 20) / ((long)g.Co * g.Ci * KS * KS * 4 + 1);
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    P.groups = (int)(want < P.ntiles ? want : P.ntiles);
+    const size_t stage = (size_t)3 * t.HP * 256 + (size_t)3 * 16 * P.mtw * 256;
+    const size_t red = (size_t)4 * NKY * KS * 256 * sizeof(float);
+    P.lds = stage > red ? stage : red;
+    P.part_bytes = cfd_align_up((size_t)P.groups * g.Co * g.Ci * KS * KS * sizeof(float), 256);
+    P.ok = P.lds <= 150 * 1024;
+    return P;
+}
+
+bool cfd_conv6_wgrad_covers(const ConvGeom& g) { return wg6_plan(g).ok; }
+
+size_t cfd_conv6_wgrad_ws_bytes(const ConvGeom& g) {
+    const Wg6Plan P = wg6_plan(g);
+    return P.ok ? P.part_bytes : 0;
+}
+
+int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, void* ws, const ConvGeom& g, hipStream_t st, const char* what) {
+    const Wg6Plan P = wg6_plan(g);
+    if (!P.ok) return CFD_ERR_UNSUPPORTED;
+    const dim3 grid(P.groups, P.chunks, P.mgroups * P.nkg);
+#define W6_L(K_, M_, Y_)                                                                                                          \
+    do {                                                                                                                          \
+        static bool attr_set = false;                                                                                             \
+        if (!attr_set) {                                                                                                          \
+            (void)hipFuncSetAttribute((const void*)k_conv6_wgrad<K_, M_, Y_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+            attr_set = true;                                                                                                      \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((k_conv6_wgrad<K_, M_, Y_>), grid, dim3(256), P.lds, st, gout, in, (float*)ws, g, P.t, P.ntiles);       \
+    } while (0)
+    if (g.ks == 3) {
+        if (P.mtw == 1) W6_L(3, 1, 3);
+        else if (P.mtw == 2) W6_L(3, 2, 3);
+        else W6_L(3, 3, 3);
+    } else {
+        if (P.mtw == 1) W6_L(7, 1, 1);
+        else if (P.mtw == 2) W6_L(7, 2, 1);
+        else W6_L(7, 3, 1);
+    }
+#undef W6_L
+    CFD_LAUNCH_CHECK(what);
+    cfd_conv_part_reduce((const float*)ws, gw, (long)g.Co * g.Ci * g.ks * g.ks, P.groups, st);
+    CFD_LAUNCH_CHECK(what);
+    return CFD_OK;
+}
