@@ -905,6 +905,7 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x, const float* __restrict__ aux,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     float* __restrict__ part, int B, int C, int HW, int relu,
                                                     CfdDiv dHW) {
     __shared__ float s_r[8];
@@ -913,6 +914,7 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
     const unsigned per = (n + BN_SPLIT - 1) / BN_SPLIT;
     const unsigned e0 = sp * per, e1 = e0 + per < n ? e0 + per : n;
     const float mu = MODE == 3 ? x[(size_t)c * HW] : (MODE >= 1 ? mean[c] : 0.f), rs = MODE == 2 ? rstd[c] : 0.f;
+    const float ga = (MODE == 2 && relu) ? gamma[c] : 0.f, be = (MODE == 2 && relu) ? beta[c] : 0.f;
     float s0 = 0.f, s1 = 0.f;
     auto item = [&](unsigned e, float v, float a) {
         (void)e;
@@ -924,7 +926,7 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x,
             const float xh = (v - mu) * rs;
             float gz = a;
             if (relu) {
-                const float yv = fmaf(xh, mean[C + c], mean[2 * C + c]);  // gamma, beta packed behind mean
+                const float yv = fmaf(xh, ga, be);
                 gz = yv > 0.f ? gz : 0.f;
             }
             s0 += gz;
@@ -1009,50 +1011,106 @@ static int chan_sum(const float* g, float* out, void* ws, int B, int C, int HW, 
     float* part = (float*)ws;
     float* dummy = part + (size_t)C * BN_SPLIT * 2;
     hipLaunchKernelGGL((k_bn_partial<0>), dim3(C, BN_SPLIT), dim3(256), 0, st, g, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, part, B, C, HW, 0, cfd_div_make((unsigned)HW));
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, B, C, HW,
+                       0, cfd_div_make((unsigned)HW));
     hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 2, 1.f, 0.f, 0.f, (float*)nullptr,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, out, dummy, C, (const float*)nullptr, 0);
     CFD_LAUNCH_CHECK(what);
     return CFD_OK;
 }
 
-__global__ __launch_bounds__(256) void k_bn_eval_stats(const float* __restrict__ run_mean, const float* __restrict__ run_var,
-                                                       float eps, float* __restrict__ mean, float* __restrict__ rstd, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) { mean[c] = run_mean[c]; rstd[c] = 1.0f / sqrtf(run_var[c] + eps); }
+// Sum of the BN_SPLIT partial pairs of channel c by wave 0 (the arithmetic of k_bn_final), broadcast through LDS.
+__device__ __forceinline__ void bn_partials(const float* __restrict__ part, int c, float* s_ab, float& a, float& b) {
+    if (threadIdx.x < 64) {
+        float pa = threadIdx.x < BN_SPLIT ? part[((size_t)c * BN_SPLIT + threadIdx.x) * 2] : 0.f;
+        float pb = threadIdx.x < BN_SPLIT ? part[((size_t)c * BN_SPLIT + threadIdx.x) * 2 + 1] : 0.f;
+        pa = cfd_wave_sum(pa);
+        pb = cfd_wave_sum(pb);
+        if (threadIdx.x == 0) { s_ab[0] = pa; s_ab[1] = pb; }
+    }
+    __syncthreads();
+    a = s_ab[0];
+    b = s_ab[1];
 }
 
-// y = [relu]((x - mean) * rstd * gamma + beta)
-__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ mean,
-                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                  const float* __restrict__ beta, float* __restrict__ y, unsigned total,
-                                                  int C, int relu, CfdDiv dHW, CfdDiv dC) {
-    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const unsigned row = cfd_div(e, dHW);
-        const int c = (int)(row - cfd_div(row, dC) * (unsigned)C);
-        float v = fmaf((x[e] - mean[c]) * rstd[c], gamma[c], beta[c]);
+// y = [relu]((x - mean) * rstd * gamma + beta) with the statistics finished in the same launch: workgroup (c, sp) sums the
+// channel's partial pairs of k_bn_partial<3> itself (training) or reads the running statistics (eval) and normalises slice sp
+// of the channel; slice 0 also writes save_mean / save_rstd and updates the running statistics.  (Round 2 had a one-workgroup
+// k_bn_final launch per reduction: 59 launches of ~4.5 us per U-Net step, 6 % of it.)
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ part,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                  float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                  float* __restrict__ y, int B, int C, int HW, float count, float eps,
+                                                  float momentum, int training, int relu, CfdDiv dHW) {
+    __shared__ float s_ab[2];
+    const int c = blockIdx.x, sp = blockIdx.y;
+    float mu, rs;
+    if (training) {
+        float a, b;
+        bn_partials(part, c, s_ab, a, b);
+        const float d = a / count;
+        mu = x[(size_t)c * HW] + d;
+        float m2 = b - a * d;  // sum (x - mean)^2 = sum (x-K)^2 - n (mean-K)^2
+        m2 = m2 > 0.f ? m2 : 0.f;
+        const float var = m2 / count;  // biased: what normalises (torch.nn.functional.batch_norm, training=True)
+        rs = 1.0f / sqrtf(var + eps);
+        if (sp == 0 && threadIdx.x == 0 && run_mean) {
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+            const float unb = count > 1.f ? m2 / (count - 1.f) : var;  // running_var tracks the unbiased estimate
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+        }
+    } else {
+        mu = run_mean[c];
+        rs = 1.0f / sqrtf(run_var[c] + eps);
+    }
+    if (sp == 0 && threadIdx.x == 0) { save_mean[c] = mu; save_rstd[c] = rs; }
+    const float ga = gamma[c], be = beta[c];
+    const unsigned n = (unsigned)B * HW;
+    const unsigned per = (n + gridDim.y - 1) / gridDim.y;
+    const unsigned e0 = sp * per, e1 = e0 + per < n ? e0 + per : n;
+    for (unsigned e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const unsigned b = cfd_div(e, dHW);
+        const size_t o = ((size_t)b * C + c) * HW + (e - b * (unsigned)HW);
+        float v = fmaf((x[o] - mu) * rs, ga, be);
         if (relu) v = v > 0.f ? v : 0.f;
-        y[e] = v;
+        y[o] = v;
     }
 }
 
-// gx = gamma * rstd * (gz - [gbeta/N + xhat * ggamma/N] if training)
+// gx = gamma * rstd * (gz - [gbeta/N + xhat * ggamma/N] if training); (gbeta, ggamma) = the sums of k_bn_partial<2>, finished here
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ gy,
-                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ gbeta, const float* __restrict__ ggamma,
-                                                      float* __restrict__ gx, unsigned total, int C, float inv_count,
-                                                      int relu, int training, CfdDiv dHW, CfdDiv dC) {
-    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const unsigned row = cfd_div(e, dHW);
-        const int c = (int)(row - cfd_div(row, dC) * (unsigned)C);
-        const float xh = (x[e] - mean[c]) * rstd[c];
-        float gz = gy[e];
-        if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.f)) gz = 0.f;
+                                                      const float* __restrict__ part, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ gbeta,
+                                                      float* __restrict__ ggamma, float* __restrict__ gx, int B, int C, int HW,
+                                                      float inv_count, int relu, int training, CfdDiv dHW) {
+    __shared__ float s_ab[2];
+    const int c = blockIdx.x, sp = blockIdx.y;
+    float gb, gg;
+    bn_partials(part, c, s_ab, gb, gg);
+    if (sp == 0 && threadIdx.x == 0) { gbeta[c] = gb; ggamma[c] = gg; }
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+    const unsigned n = (unsigned)B * HW;
+    const unsigned per = (n + gridDim.y - 1) / gridDim.y;
+    const unsigned e0 = sp * per, e1 = e0 + per < n ? e0 + per : n;
+    for (unsigned e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const unsigned b = cfd_div(e, dHW);
+        const size_t o = ((size_t)b * C + c) * HW + (e - b * (unsigned)HW);
+        const float xh = (x[o] - mu) * rs;
+        float gz = gy[o];
+        if (relu && !(fmaf(xh, ga, be) > 0.f)) gz = 0.f;
         float t = gz;
-        if (training) t -= (gbeta[c] + xh * ggamma[c]) * inv_count;
-        gx[e] = gamma[c] * rstd[c] * t;
+        if (training) t -= (gb + xh * gg) * inv_count;
+        gx[o] = ga * rs * t;
     }
+}
+
+// slices per channel of the normalising kernels: ~16 k elements each, enough workgroups to fill the chip
+static unsigned bn_slices(int B, int C, int HW) {
+    long per_c = (long)B * HW, s = (per_c + 16383) / 16384;
+    while (s * C < 1024 && s * 2048 < per_c) s *= 2;
+    return (unsigned)(s < 1 ? 1 : (s > 1024 ? 1024 : s));
 }
 
 static unsigned ew_blocks(long total) {
@@ -1080,27 +1138,16 @@ extern "C" int cfd_batchnorm_fwd(const float* x, const float* gamma, const float
     if (training) {
         CFD_PROF_W("k_bn_stats", st, 4.0 * B * C * HW, 3.0 * B * C * HW);
         hipLaunchKernelGGL((k_bn_partial<3>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, (const float*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, part, B, C, HW, 0, cfd_div_make((unsigned)HW));
-        hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 3, count, eps, momentum, save_mean,
-                           save_rstd, run_mean, run_var, (float*)nullptr, (float*)nullptr, C, x, HW);
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, B, C,
+                           HW, 0, cfd_div_make((unsigned)HW));
         CFD_LAUNCH_CHECK("cfd_batchnorm_fwd(stats)");
-    } else {
-        hipLaunchKernelGGL(k_bn_eval_stats, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)run_mean,
-                           (const float*)run_var, eps, save_mean, save_rstd, C);
-        CFD_LAUNCH_CHECK("cfd_batchnorm_fwd(eval stats)");
     }
-    const long total = (long)B * C * HW;
     CFD_PROF_W("k_bn_apply", st, 8.0 * B * C * HW, 2.0 * B * C * HW);
-    hipLaunchKernelGGL(k_bn_apply, dim3(ew_blocks(total)), dim3(256), 0, st, x, (const float*)save_mean,
-                       (const float*)save_rstd, gamma, beta, y, (unsigned)total, C, relu, cfd_div_make((unsigned)HW),
-                       cfd_div_make((unsigned)C));
+    hipLaunchKernelGGL(k_bn_apply, dim3(C, bn_slices(B, C, HW)), dim3(256), 0, st, x, (const float*)part, gamma, beta, run_mean,
+                       run_var, save_mean, save_rstd, y, B, C, HW, count, eps, momentum, training, relu,
+                       cfd_div_make((unsigned)HW));
     CFD_LAUNCH_CHECK("cfd_batchnorm_fwd(apply)");
     return CFD_OK;
-}
-
-__global__ __launch_bounds__(256) void k_pack3(const float* a, const float* b, const float* c, float* out, int C) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < C) { out[i] = a[i]; out[C + i] = b[i]; out[2 * C + i] = c[i]; }
 }
 
 // gx, ggamma, gbeta from gy (gradient on the [relu]'d output), the layer input x and the saved statistics.
@@ -1113,21 +1160,16 @@ extern "C" int cfd_batchnorm_bwd(const float* gy, const float* x, const float* g
     CFD_REQUIRE_I31((long)B * C * HW, "cfd_batchnorm_bwd");
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)ws;
-    float* packed = part + (size_t)C * BN_SPLIT * 2;  // (mean, gamma, beta) for the relu mask inside the reduction
-    hipLaunchKernelGGL(k_pack3, dim3((C + 255) / 256), dim3(256), 0, st, save_mean, gamma, beta, packed, C);
     {
         CFD_PROF_W("k_bn_bwd_reduce", st, 8.0 * B * C * HW, 4.0 * B * C * HW);
-        hipLaunchKernelGGL((k_bn_partial<2>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, gy, (const float*)packed, save_rstd,
-                           part, B, C, HW, relu, cfd_div_make((unsigned)HW));
-        hipLaunchKernelGGL(k_bn_final, dim3(C), dim3(64), 0, st, (const float*)part, 2, 1.f, 0.f, 0.f, (float*)nullptr,
-                           (float*)nullptr, (float*)nullptr, (float*)nullptr, gbeta, ggamma, C, (const float*)nullptr, 0);
+        hipLaunchKernelGGL((k_bn_partial<2>), dim3(C, BN_SPLIT), dim3(256), 0, st, x, gy, save_mean, save_rstd, gamma, beta, part,
+                           B, C, HW, relu, cfd_div_make((unsigned)HW));
     }
     CFD_LAUNCH_CHECK("cfd_batchnorm_bwd(reduce)");
-    const long total = (long)B * C * HW;
     CFD_PROF_W("k_bn_bwd_apply", st, 12.0 * B * C * HW, 4.0 * B * C * HW);
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_blocks(total)), dim3(256), 0, st, x, gy, save_mean, save_rstd, gamma, beta,
-                       (const float*)gbeta, (const float*)ggamma, gx, (unsigned)total, C, (float)(1.0 / ((double)B * HW)), relu,
-                       training, cfd_div_make((unsigned)HW), cfd_div_make((unsigned)C));
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(C, bn_slices(B, C, HW)), dim3(256), 0, st, x, gy, (const float*)part, save_mean,
+                       save_rstd, gamma, beta, gbeta, ggamma, gx, B, C, HW, (float)(1.0 / ((double)B * HW)), relu, training,
+                       cfd_div_make((unsigned)HW));
     CFD_LAUNCH_CHECK("cfd_batchnorm_bwd(apply)");
     return CFD_OK;
 }

@@ -18,6 +18,10 @@
 
 typedef cfd_u32x4 u4;
 
+#ifndef CFD_CONV6_GRID
+#define CFD_CONV6_GRID 512  // persistent workgroups per launch: two per CU (the CPU emulator build sets 2 so that small test shapes
+                            // walk several tiles per workgroup)
+#endif
 #ifndef CFD_CONV6_MAX_LDS
 #define CFD_CONV6_MAX_LDS (80 * 1024)  // two workgroups per CU: one stages while the other feeds the matrix pipe
 #endif
@@ -55,15 +59,21 @@ __global__ __launch_bounds__(256) void k_conv6_wprep(const float* __restrict__ w
 
 // ------------------------------------------------------------------------------------------------------
 // forward / transposed-valid pass:  dst[b][m][p] = bias[m] + sum_k A(m, k) * src[b][c(k)][pos(p, k)]   (conv.hip has the algebra)
+// Persistent workgroups: workgroup x of gridDim.x walks the pixel tiles x, x + gridDim.x, ... and, per tile, its range of channel
+// chunks.  The global loads of the NEXT (tile, chunk) -- NI halo items of 8 channel values and the chunk's weight fragments -- are
+// issued into registers right before the MFMA loop of the current one and land while it runs; splitting into pieces and the LDS
+// stores happen at the top of the next iteration.  (The first version staged global -> LDS in plain loops inside each
+// iteration: one exposed L2 round trip per loop trip, ~13 per chunk, 3x the MFMA time of a 12-channel layer.)
 // LDS (all dynamic, 16-byte carve offsets): [3 piece planes of NB * LH * LW halo pixels x CC bf16 | weight fragments of this
 // chunk and output group KSTEPS * MT * 3 * 64 x 16 B | tap offsets KSTEPS * 4 ints]
 // ------------------------------------------------------------------------------------------------------
-template <int KS, int MT, int CC, bool EXT>
+template <int KS, int MT, int CC, bool EXT, int NI>
 __global__ __launch_bounds__(256) void k_conv6(const float* __restrict__ src, const u4* __restrict__ wfrag,
                                                const float* __restrict__ bias, float* __restrict__ dst, ConvGeom g, ConvTile t,
-                                               int MTall) {
+                                               int MTall, int ptiles) {
     constexpr int KK = KS * KS, PAD = KS / 2;
     constexpr int CH8 = CC / 8, PPS = 4 / CH8, KSTEPS = (KK + PPS - 1) / PPS;
+    constexpr int WTOT = KSTEPS * MT * 192, NWV = (WTOT + 255) / 256;
     CFD_DYN_SHARED(u4, s_dyn);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
@@ -71,52 +81,55 @@ __global__ __launch_bounds__(256) void k_conv6(const float* __restrict__ src, co
     const int Hd = EXT ? g.H + 2 * PAD : g.H, Wd = EXT ? g.W + 2 * PAD : g.W;
     const int HWd = Hd * Wd, HWs = g.H * g.W;
     const int halo = t.LH * t.LW, NPX = t.NB * halo;
-    const int plane = NPX * CH8;                       // 16-byte units per piece plane
+    const int plane = NPX * CH8;                       // 16-byte units per piece plane (<= 256 NI)
     u4* s_in = s_dyn;                                  // [piece][pixel][channel octet]
     u4* s_w = s_dyn + 3 * plane;                       // [kstep][mt][piece][lane]
-    int* s_koff = (int*)(s_w + KSTEPS * MT * 3 * 64);  // [kstep][q]: 16-byte units from a pixel's own slot to its operand
+    int* s_koff = (int*)(s_w + WTOT);                  // [kstep][q]: 16-byte units from a pixel's own slot to its operand
     const int mb = blockIdx.y * MT;                    // first output-channel tile of this workgroup
     const int tpi = t.tiles_x * t.tiles_y;
-    const int bg = blockIdx.x / tpi, tr = blockIdx.x - bg * tpi;
-    const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
-    const int b0 = bg * t.NB;
     for (int i = threadIdx.x; i < KSTEPS * 4; i += blockDim.x) {
         const int s = i >> 2, qq = i & 3, pos = s * PPS + qq / CH8, ky = pos / KS, kx = pos - KS * ky;
         s_koff[i] = pos < KK ? ((EXT ? (2 * PAD - ky) * t.LW + (2 * PAD - kx) : ky * t.LW + kx) * CH8 + qq % CH8) : qq % CH8;
     }
-    // this wave's 4 pixel tiles: tile pixel pi = 64*wave + 16*tt + n -> (image bi, row, column)
-    int poff[4], pb[4], py[4], px[4];
+    // this wave's 4 pixel tiles: tile pixel pi = 64*wave + 16*tt + n -> (image bi, row, column) of the workgroup's tile
+    int poff[4], pbi[4], prow[4], pcol[4];
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
         const int pi = 64 * wave + 16 * tt + n;
         const int bi = pi / (t.TH * t.TW), rem = pi - bi * (t.TH * t.TW);
         const int r = rem / t.TW, c = rem - r * t.TW;
         const bool on = bi < t.NB;  // NB*TH*TW may be < 256 (tile shapes that are not powers of two): idle lanes
-        pb[tt] = on ? b0 + bi : g.B; py[tt] = ty0 + r; px[tt] = tx0 + c;
+        pbi[tt] = on ? bi : -1; prow[tt] = r; pcol[tt] = c;
         poff[tt] = on ? (bi * halo + r * t.LW + c) * CH8 : 0;
     }
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) acc[mt][tt] = zero;
-    const int oy = EXT ? ty0 - 2 * PAD : ty0 - PAD, ox = EXT ? tx0 - 2 * PAD : tx0 - PAD;  // source coords of the halo origin
     // split-K over blockIdx.z: a contiguous range of channel chunks, own partial output slice (summed by k_splitk_sum)
     const int nch = (Cs + CC - 1) / CC, per = (nch + gridDim.z - 1) / gridDim.z;
     const int chbeg = blockIdx.z * per, chend = (chbeg + per) < nch ? (chbeg + per) : nch;
+    const int nchw = chend - chbeg;
     const bool split = gridDim.z > 1;
     if (split) dst += (size_t)blockIdx.z * g.B * Cm * HWd;
-    for (int ch = chbeg; ch < chend; ++ch) {
+    const int ntile = ((int)blockIdx.x < ptiles) ? (ptiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nit = nchw > 0 ? ntile * nchw : 0;
+
+    float dr[NI][8];
+    u4 wr[NWV];
+    // global loads of iteration `it` (tile, chunk): halo pixels x channel octets, 8 channel values each; the chunk's fragments
+    const auto issue = [&](int it, bool with_w) {
+        const int tk = it / nchw, ch = chbeg + it - tk * nchw;
+        const int tile = blockIdx.x + tk * gridDim.x;
+        const int bg = tile / tpi, tr = tile - bg * tpi;
+        const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
+        const int b0 = bg * t.NB;
+        const int oy = EXT ? ty0 - 2 * PAD : ty0 - PAD, ox = EXT ? tx0 - 2 * PAD : tx0 - PAD;  // source coords of the halo origin
         const int c0 = ch * CC;
-        __syncthreads();  // previous chunk fully consumed (first pass: s_koff written)
-        // halo pixels x channel octets: 8 channel values of one pixel -> three 16-byte pieces
-        for (int i = threadIdx.x; i < plane; i += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int i = threadIdx.x + 256 * k;
             const int c8 = CH8 == 1 ? 0 : (i >= NPX ? 1 : 0), pxl = i - c8 * NPX;
             const int r1 = (int)cfd_div((unsigned)pxl, t.dUsed), lx = pxl - r1 * t.LW;
             const int bi = (int)cfd_div((unsigned)r1, t.dLH), ly = r1 - bi * t.LH;
             int y = oy + ly, x = ox + lx;
-            bool ok = b0 + bi < g.B;
+            bool ok = i < plane && b0 + bi < g.B;
             if constexpr (EXT) {
                 ok = ok && y >= 0 && y < g.H && x >= 0 && x < g.W;
             } else {
@@ -125,20 +138,48 @@ __global__ __launch_bounds__(256) void k_conv6(const float* __restrict__ src, co
             }
             const int cb = c0 + 8 * c8;
             const float* sb = src + ((size_t)(ok ? b0 + bi : 0) * Cs + cb) * HWs + (ok ? y * g.W + x : 0);
-            float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (ok && cb + j < Cs) ? sb[(size_t)j * HWs] : 0.f;
-            const CfdSplit8x3 sp = cfd_split8x3(v);
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) s_in[pc * plane + pxl * CH8 + c8] = __builtin_bit_cast(u4, sp.p[pc]);
+            for (int j = 0; j < 8; ++j) dr[k][j] = (ok && cb + j < Cs) ? sb[(size_t)j * HWs] : 0.f;
         }
-        // weight fragments of this chunk and output group: MT * 192 consecutive vectors per k-step
-        for (int i = threadIdx.x; i < KSTEPS * MT * 192; i += blockDim.x) {
-            const int s = i / (MT * 192), r = i - s * (MT * 192);
-            const u4 z4 = {0u, 0u, 0u, 0u};
-            s_w[i] = mb + r / 192 < MTall ? wfrag[((size_t)(ch * KSTEPS + s) * MTall + mb) * 192 + r] : z4;
+        if (with_w) {
+#pragma unroll
+            for (int k = 0; k < NWV; ++k) {
+                const int i = threadIdx.x + 256 * k;
+                const int s = i / (MT * 192), r = i - s * (MT * 192);
+                const u4 z4 = {0u, 0u, 0u, 0u};
+                wr[k] = (i < WTOT && mb + r / 192 < MTall) ? wfrag[((size_t)(ch * KSTEPS + s) * MTall + mb) * 192 + r] : z4;
+            }
+        }
+    };
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[mt][tt] = zero;
+    if (nit > 0) issue(0, true);
+    for (int it = 0; it < nit; ++it) {
+        __syncthreads();  // previous iteration's operands fully consumed (first pass: s_koff written)
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < plane) {
+                const int c8 = CH8 == 1 ? 0 : (i >= NPX ? 1 : 0), pxl = i - c8 * NPX;
+                const CfdSplit8x3 sp = cfd_split8x3(dr[k]);
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) s_in[pc * plane + pxl * CH8 + c8] = __builtin_bit_cast(u4, sp.p[pc]);
+            }
+        }
+        if (it == 0 || nchw > 1) {
+#pragma unroll
+            for (int k = 0; k < NWV; ++k) {
+                const int i = threadIdx.x + 256 * k;
+                if (i < WTOT) s_w[i] = wr[k];
+            }
         }
         __syncthreads();
+        if (it + 1 < nit) issue(it + 1, nchw > 1);
+        cfd_sched_fence();  // keep the loads above the MFMA loop: hipcc otherwise sinks them to their first use
 #pragma unroll 1
         for (int s = 0; s < KSTEPS; ++s) {
             const int ko = s_koff[4 * s + q];
@@ -156,18 +197,25 @@ __global__ __launch_bounds__(256) void k_conv6(const float* __restrict__ src, co
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) acc[mt][tt] = cfd_mfma_bf16x6(av[mt], bv[tt], acc[mt][tt]);
         }
-    }
+        const int tk = it / nchw;
+        if (it - tk * nchw == nchw - 1) {  // last chunk of the tile: store, start the next tile from zero
+            const int tile = blockIdx.x + tk * gridDim.x;
+            const int bg = tile / tpi, tr = tile - bg * tpi;
+            const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        if (pb[tt] < g.B && py[tt] < Hd && px[tt] < Wd) {
+            for (int tt = 0; tt < 4; ++tt) {
+                const int b = bg * t.NB + pbi[tt], y = ty0 + prow[tt], x = tx0 + pcol[tt];
+                const bool on = pbi[tt] >= 0 && b < g.B && y < Hd && x < Wd;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = 16 * (mb + mt) + 4 * q + r;
-                    if (m < Cm)
-                        dst[((size_t)pb[tt] * Cm + m) * HWd + py[tt] * Wd + px[tt]] = acc[mt][tt][r] + ((bias && !split) ? bias[m] : 0.f);
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = 16 * (mb + mt) + 4 * q + r;
+                        if (on && m < Cm) dst[((size_t)b * Cm + m) * HWd + y * Wd + x] = acc[mt][tt][r] + ((bias && !split) ? bias[m] : 0.f);
+                    }
+                    acc[mt][tt] = zero;
                 }
+            }
         }
     }
 }
@@ -175,7 +223,7 @@ __global__ __launch_bounds__(256) void k_conv6(const float* __restrict__ src, co
 struct Conv6Plan {
     ConvTile t;
     long ptiles;
-    int CC, KSTEPS, MTall, mtw, mgroups, ksplit, nch;
+    int CC, KSTEPS, MTall, mtw, mgroups, ksplit, nch, NI, gx;
     size_t lds, wfrag_bytes, split_bytes;
     bool ok;
 };
@@ -193,6 +241,8 @@ static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     P.nch = (Cs + P.CC - 1) / P.CC;
     ConvTile& t = P.t;
     cfd_conv_tile_shape(Hd, Wd, g.B, t.TW, t.TH, t.NB);
+    // a thread prefetches at most 5 halo items (8 channel values each) of the next tile: small images, many per workgroup
+    while (t.NB > 1 && t.NB * (t.TH + KS - 1) * (t.TW + KS - 1) * (P.CC / 8) > 5 * 256) --t.NB;
     t.tiles_x = (Wd + t.TW - 1) / t.TW;
     t.tiles_y = (Hd + t.TH - 1) / t.TH;
     t.LH = t.TH + KS - 1;
@@ -205,8 +255,11 @@ static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     };
     // two output-channel tiles per workgroup (a staged halo feeds twice the MFMAs) while two workgroups still fit a CU and the
     // grid fills the chip
+    const int plane = t.NB * t.LH * t.LW * (P.CC / 8);
+    P.NI = plane <= 3 * 256 ? 3 : 5;
     int mtw = P.MTall >= 2 ? 2 : 1;
-    if (mtw == 2 && (lds_of(2) > CFD_CONV6_MAX_LDS || P.ptiles * ((P.MTall + 1) / 2) < 256)) mtw = 1;
+    // (two tiles with 5 prefetch items per thread need > 256 registers: one wave per SIMD)
+    if (mtw == 2 && (lds_of(2) > CFD_CONV6_MAX_LDS || P.ptiles * ((P.MTall + 1) / 2) < 256 || P.NI == 5)) mtw = 1;
     P.mtw = mtw;
     P.mgroups = (P.MTall + mtw - 1) / mtw;
     const long wgs = P.ptiles * P.mgroups;
@@ -214,11 +267,17 @@ static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     if (wgs < 256 && P.nch > 1) {  // deep, narrow levels: split the channel chunks over blockIdx.z
         const long ks = (512 + wgs - 1) / wgs;
         P.ksplit = (int)(ks < P.nch ? ks : P.nch);
+        const int per = (P.nch + P.ksplit - 1) / P.ksplit;
+        P.ksplit = (P.nch + per - 1) / per;  // every slice owns at least one chunk (an empty one would leave its partial unwritten)
     }
     P.lds = lds_of(mtw);
+    // persistent workgroups: two per CU over the whole launch
+    long gx = CFD_CONV6_GRID / ((long)P.mgroups * P.ksplit);
+    if (gx < 1) gx = 1;
+    P.gx = (int)(gx < P.ptiles ? gx : P.ptiles);
     P.wfrag_bytes = cfd_align_up((size_t)P.nch * P.KSTEPS * P.MTall * 3 * 1024, 256);
     P.split_bytes = P.ksplit > 1 ? cfd_align_up((size_t)P.ksplit * g.B * Cm * Hd * Wd * sizeof(float), 256) : 0;
-    P.ok = P.lds <= 150 * 1024 && (long)P.nch * P.KSTEPS * P.MTall * 64 < (1L << 31);
+    P.ok = P.lds <= 150 * 1024 && plane <= 5 * 256 && (long)P.nch * P.KSTEPS * P.MTall * 64 < (1L << 31) && P.ptiles < (1L << 30);
     return P;
 }
 
@@ -232,18 +291,19 @@ size_t cfd_conv6_ws_bytes(const ConvGeom& g, bool ext) {
 template <int KS, int CC, bool EXT>
 static void conv6_launch(const Conv6Plan& P, const float* src, const u4* wfrag, const float* bias, float* dst, const ConvGeom& g,
                          hipStream_t st) {
-    const dim3 grid((unsigned)P.ptiles, P.mgroups, P.ksplit);
-#define C6_L(M_)                                                                                                                  \
+    const dim3 grid((unsigned)P.gx, P.mgroups, P.ksplit);
+#define C6_L(M_, N_)                                                                                                              \
     do {                                                                                                                          \
         static bool attr_set = false;                                                                                             \
         if (!attr_set) {                                                                                                          \
-            (void)hipFuncSetAttribute((const void*)k_conv6<KS, M_, CC, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+            (void)hipFuncSetAttribute((const void*)k_conv6<KS, M_, CC, EXT, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        hipLaunchKernelGGL((k_conv6<KS, M_, CC, EXT>), grid, dim3(256), P.lds, st, src, wfrag, bias, dst, g, P.t, P.MTall);        \
+        hipLaunchKernelGGL((k_conv6<KS, M_, CC, EXT, N_>), grid, dim3(256), P.lds, st, src, wfrag, bias, dst, g, P.t, P.MTall,    \
+                           (int)P.ptiles);                                                                                        \
     } while (0)
-    if (P.mtw == 1) C6_L(1);
-    else C6_L(2);
+    if (P.mtw == 1) { if (P.NI == 3) C6_L(1, 3); else C6_L(1, 5); }
+    else { if (P.NI == 3) C6_L(2, 3); else C6_L(2, 5); }
 #undef C6_L
 }
 
@@ -299,9 +359,10 @@ struct Wg6Tile {
 };
 
 template <int KS, int MT, int NKY>
-__global__ __launch_bounds__(256) void k_conv6_wgrad(const float* __restrict__ gout, const float* __restrict__ in,
+__global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict__ gout, const float* __restrict__ in,
                                                      float* __restrict__ part, ConvGeom g, Wg6Tile t, int ntiles) {
-    constexpr int KK = KS * KS, PAD = KS / 2, NT = NKY * KS, NKG = KS / NKY;
+    constexpr int KK = KS * KS, PAD = KS / 2, NT = NKY * KS, NKG = (KS + NKY - 1) / NKY;
+    constexpr int NIW = 3;  // halo items per thread: HP * 16 <= 768 (HP <= 40 for k = 3, 42 for k = 7 with NKY = 2)
     CFD_DYN_SHARED(u4, s_dyn);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
@@ -320,42 +381,63 @@ __global__ __launch_bounds__(256) void k_conv6_wgrad(const float* __restrict__ g
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // the next tile's global loads wait in registers while this tile's MFMAs run (see k_conv6)
+    float dri[NIW][8], drg[MT][8];
+    const auto issue = [&](int tile) {
         const int bg = tile / tpi, tr = tile - bg * tpi;
         const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
         const int b0 = bg * 8;
         const int oy = ty0 + ky0 - PAD, ox = tx0 - PAD;
-        __syncthreads();  // previous tile fully consumed
-        for (int i = threadIdx.x; i < t.HP * 16; i += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < NIW; ++k) {
+            const int i = threadIdx.x + 256 * k;
             const int c = (int)cfd_div((unsigned)i, t.dHP), hp = i - c * t.HP;
             const int ly = (int)cfd_div((unsigned)hp, t.dLW), lx = hp - ly * t.LW;
             int y = oy + ly, x = ox + lx;
             y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
             x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
-            const bool cok = c0 + c < g.Ci;
+            const bool cok = c < 16 && c0 + c < g.Ci;
             const float* sb = in + ((size_t)b0 * g.Ci + (cok ? c0 + c : 0)) * HW + y * g.W + x;
-            float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (cok && b0 + j < g.B) ? sb[(size_t)j * g.Ci * HW] : 0.f;
-            const CfdSplit8x3 sp = cfd_split8x3(v);
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) s_in[(pc * t.HP + hp) * 16 + ((c + hp) & 15)] = __builtin_bit_cast(u4, sp.p[pc]);
+            for (int j = 0; j < 8; ++j) dri[k][j] = (cok && b0 + j < g.B) ? sb[(size_t)j * g.Ci * HW] : 0.f;
         }
         // upstream gradient of the tile's pixels (0 outside the image / batch / channel range: contributes nothing)
-        for (int i = threadIdx.x; i < 16 * 16 * MT; i += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < MT; ++k) {
+            const int i = threadIdx.x + 256 * k;
             const int o = i >> 4, p2 = i & 15;
             const int y = ty0 + (p2 >> t.tw_shift), x = tx0 + (p2 & (t.TW - 1));
             const bool ok = mbase + o < g.Co && y < g.H && x < g.W;
             const float* sb = gout + ((size_t)b0 * g.Co + (ok ? mbase + o : 0)) * HW + (ok ? y * g.W + x : 0);
-            float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (ok && b0 + j < g.B) ? sb[(size_t)j * g.Co * HW] : 0.f;
-            const CfdSplit8x3 sp = cfd_split8x3(v);
+            for (int j = 0; j < 8; ++j) drg[k][j] = (ok && b0 + j < g.B) ? sb[(size_t)j * g.Co * HW] : 0.f;
+        }
+    };
+    if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int k = 0; k < NIW; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < t.HP * 16) {
+                const int c = (int)cfd_div((unsigned)i, t.dHP), hp = i - c * t.HP;
+                const CfdSplit8x3 sp = cfd_split8x3(dri[k]);
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) s_in[(pc * t.HP + hp) * 16 + ((c + hp) & 15)] = __builtin_bit_cast(u4, sp.p[pc]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MT; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            const int o = i >> 4, p2 = i & 15;
+            const CfdSplit8x3 sp = cfd_split8x3(drg[k]);
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc)
                 s_g[((pc * 16 + p2) * MT + (o >> 4)) * 16 + (((o & 15) + p2) & 15)] = __builtin_bit_cast(u4, sp.p[pc]);
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        cfd_sched_fence();
         bf16x8 av[MT][3];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -371,25 +453,31 @@ __global__ __launch_bounds__(256) void k_conv6_wgrad(const float* __restrict__ g
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = cfd_mfma_bf16x6(av[mt], bv, acc[mt][nt]);
         }
     }
-    // sum of the four waves (each owns 4 of the tile's 16 pixels) in a fixed order, one output-channel tile at a time
-    float* s_red = (float*)s_dyn;  // [wave][nt][r][lane]
+    // sum of the four waves (each owns 4 of the tile's 16 pixels) in a fixed order, RG column tiles of one output-channel tile at a
+    // time (the staging buffers are free by now)
+    constexpr int RG = KS == 3 ? 9 : 7;
+    static_assert(NT % RG == 0, "column tiles per reduction round");
+    float* s_red = (float*)s_dyn;  // [wave][RG][r][lane]
     float* dst = part + (size_t)blockIdx.x * g.Co * g.Ci * KK;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        __syncthreads();
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int n0 = 0; n0 < NT; n0 += RG) {
+            __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s_red[((wave * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
-        __syncthreads();
-        for (int e = threadIdx.x; e < NT * 256; e += blockDim.x) {
-            const int ln = e & 63, r = (e >> 6) & 3, nt = e >> 8;
-            const int o = mbase + 16 * mt + 4 * (ln >> 4) + r, c = c0 + (ln & 15);
-            if (o < g.Co && c < g.Ci) {
-                float sum = 0.f;
+            for (int nt = 0; nt < RG; ++nt)
 #pragma unroll
-                for (int wv = 0; wv < 4; ++wv) sum += s_red[((wv * NT + nt) * 4 + r) * 64 + ln];
-                dst[((size_t)o * g.Ci + c) * KK + (ky0 + nt / KS) * KS + nt % KS] = sum;
+                for (int r = 0; r < 4; ++r) s_red[((wave * RG + nt) * 4 + r) * 64 + lane] = acc[mt][n0 + nt][r];
+            __syncthreads();
+            for (int e = threadIdx.x; e < RG * 256; e += blockDim.x) {
+                const int ln = e & 63, r = (e >> 6) & 3, nt = e >> 8;
+                const int o = mbase + 16 * mt + 4 * (ln >> 4) + r, c = c0 + (ln & 15), ky = ky0 + (n0 + nt) / KS;
+                if (o < g.Co && c < g.Ci && ky < KS) {  // (the last tap-row group of k = 7 has a dummy row)
+                    float sum = 0.f;
+#pragma unroll
+                    for (int wv = 0; wv < 4; ++wv) sum += s_red[((wv * RG + nt) * 4 + r) * 64 + ln];
+                    dst[((size_t)o * g.Ci + c) * KK + ky * KS + (n0 + nt) % KS] = sum;
+                }
             }
         }
     }
@@ -405,7 +493,7 @@ struct Wg6Plan {
 static Wg6Plan wg6_plan(const ConvGeom& g) {
     Wg6Plan P{};
     if (g.ks != 3 && g.ks != 7) return P;
-    const int KS = g.ks, NKY = KS == 3 ? 3 : 1;
+    const int KS = g.ks, NKY = KS == 3 ? 3 : 2;  // k = 7: tap rows {0,1}, {2,3}, {4,5}, {6}: 14 column tiles per output-channel tile
     Wg6Tile& t = P.t;
     t.TW = g.W >= 8 ? 8 : 4;
     t.TH = 16 / t.TW;
@@ -420,18 +508,18 @@ static Wg6Plan wg6_plan(const ConvGeom& g) {
     P.ntiles = ((g.B + 7) / 8) * t.tiles_x * t.tiles_y;
     P.chunks = (g.Ci + 15) / 16;
     const int MTall = (g.Co + 15) / 16;
-    P.mtw = MTall >= 3 ? 3 : MTall;
+    P.mtw = MTall >= 2 ? 2 : 1;  // (three tiles would need > 256 registers with the prefetch: one wave per SIMD)
     P.mgroups = (MTall + P.mtw - 1) / P.mtw;
-    P.nkg = KS / NKY;
+    P.nkg = (KS + NKY - 1) / NKY;
     // pixel groups: enough workgroups to fill the chip twice over, at most one per tile, partials capped at ~32 MB
-    long want = 2048 / ((long)P.chunks * P.mgroups * P.nkg);
+    long want = 4 * CFD_CONV6_GRID / ((long)P.chunks * P.mgroups * P.nkg);
     if (want < 1) want = 1;
     const long cap = (32L << 20) / ((long)g.Co * g.Ci * KS * KS * 4 + 1);
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     P.groups = (int)(want < P.ntiles ? want : P.ntiles);
     const size_t stage = (size_t)3 * t.HP * 256 + (size_t)3 * 16 * P.mtw * 256;
-    const size_t red = (size_t)4 * NKY * KS * 256 * sizeof(float);
+    const size_t red = (size_t)4 * (KS == 3 ? 9 : 7) * 256 * sizeof(float);
     P.lds = stage > red ? stage : red;
     P.part_bytes = cfd_align_up((size_t)P.groups * g.Co * g.Ci * KS * KS * sizeof(float), 256);
     P.ok = P.lds <= 150 * 1024;
@@ -460,12 +548,10 @@ int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, void* ws, con
     } while (0)
     if (g.ks == 3) {
         if (P.mtw == 1) W6_L(3, 1, 3);
-        else if (P.mtw == 2) W6_L(3, 2, 3);
-        else W6_L(3, 3, 3);
+        else W6_L(3, 2, 3);
     } else {
-        if (P.mtw == 1) W6_L(7, 1, 1);
-        else if (P.mtw == 2) W6_L(7, 2, 1);
-        else W6_L(7, 3, 1);
+        if (P.mtw == 1) W6_L(7, 1, 2);
+        else W6_L(7, 2, 2);
     }
 #undef W6_L
     CFD_LAUNCH_CHECK(what);
