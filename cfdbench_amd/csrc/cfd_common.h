@@ -234,22 +234,39 @@ struct CfdSplit8x3 {
     bf16x8 p[3];
 };
 __device__ __forceinline__ CfdSplit8x3 cfd_split8x3(const float (&x)[8]) {
+    // Truncating pieces (hi = the upper 16 bits of x, lo = the upper 16 bits of x - hi, lo2 = x - hi - lo, 8 bits left: exact); a
+    // PAIR of values costs 4 masks + 2 packed subtractions + 3 byte permutes = 9 VALU instructions (the round-to-nearest form
+    // with v_cvt_pk_bf16_f32 took 13; the split is what the convolution kernels spend most of their VALU time on).
     cfd_u32x4 h, l, m;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const unsigned hk = cfd_pack_bf16(x[2 * k], x[2 * k + 1]);
-        const float r0 = x[2 * k] - __builtin_bit_cast(float, hk << 16), r1 = x[2 * k + 1] - __builtin_bit_cast(float, hk & 0xffff0000u);
-        const unsigned lk = cfd_pack_bf16(r0, r1);
-        const float s0 = r0 - __builtin_bit_cast(float, lk << 16), s1 = r1 - __builtin_bit_cast(float, lk & 0xffff0000u);
-        h[k] = (unsigned)cfd_opaque((int)hk);
-        l[k] = (unsigned)cfd_opaque((int)lk);
-        m[k] = (unsigned)cfd_opaque((int)cfd_pack_bf16(s0, s1));
+        // (scalars are bit-cast, never vector elements: __builtin_bit_cast of `v.y` read element 0 with this clang)
+        const float x0 = x[2 * k], x1 = x[2 * k + 1];
+        const unsigned h0 = __builtin_bit_cast(unsigned, x0) & 0xffff0000u, h1 = __builtin_bit_cast(unsigned, x1) & 0xffff0000u;
+        const cfd_f2 xv = {x0, x1}, hv = {__builtin_bit_cast(float, h0), __builtin_bit_cast(float, h1)};
+        const cfd_f2 r = xv - hv;
+        const float r0 = r.x, r1 = r.y;
+        const unsigned l0 = __builtin_bit_cast(unsigned, r0) & 0xffff0000u, l1 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+        const cfd_f2 lv = {__builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1)};
+        const cfd_f2 t = r - lv;
+        const float t0 = t.x, t1 = t.y;
+        h[k] = cfd_pack_hi16(h1, h0);
+        l[k] = cfd_pack_hi16(l1, l0);
+        m[k] = cfd_pack_hi16(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0));
     }
     CfdSplit8x3 s;
     s.p[0] = __builtin_bit_cast(bf16x8, h);
     s.p[1] = __builtin_bit_cast(bf16x8, l);
     s.p[2] = __builtin_bit_cast(bf16x8, m);
     return s;
+}
+// base[byte offset]: a wave-uniform base pointer plus a 32-bit per-lane BYTE offset compiles to the saddr + voffset addressing
+// form (no 64-bit address arithmetic in the VALU); the caller guarantees the tensor is smaller than 4 GB
+__device__ __forceinline__ float cfd_ldg_off(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void cfd_stg_off(float* base, unsigned byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 // D += A*B for two three-piece operands: the six products down to 2^-24 relative (a0 b0, a0 b1, a1 b0, a1 b1, a0 b2, a2 b0);
 // the dropped ones are <= 2^-32 of the product, below the rounding of the fp32 accumulation itself.  Small terms first.

@@ -52,6 +52,9 @@ __device__ __forceinline__ int cfd_opaque(int x) {
     return x;
 }
 
+// (hi & 0xffff0000) | (lo >> 16): the upper halves of two dwords as one (v_perm_b32) -- two truncated-to-bf16 floats as a pair
+__device__ __forceinline__ unsigned cfd_pack_hi16(unsigned hi, unsigned lo) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
 // Wave-uniform value -> SGPR (lets the compiler use scalar loads / scalar operands for per-wave indices).
 __device__ __forceinline__ int cfd_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 

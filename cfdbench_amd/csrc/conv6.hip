@@ -68,9 +68,9 @@ __global__ __launch_bounds__(256) void k_conv6_wprep(const float* __restrict__ w
 // chunk and output group KSTEPS * MT * 3 * 64 x 16 B | tap offsets KSTEPS * 4 ints]
 // ------------------------------------------------------------------------------------------------------
 template <int KS, int MT, int CC, bool EXT, int NI>
-__global__ __launch_bounds__(256) void k_conv6(const float* __restrict__ src, const u4* __restrict__ wfrag,
-                                               const float* __restrict__ bias, float* __restrict__ dst, ConvGeom g, ConvTile t,
-                                               int MTall, int ptiles) {
+__global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src, const u4* __restrict__ wfrag,
+                                                  const float* __restrict__ bias, float* __restrict__ dst, ConvGeom g, ConvTile t,
+                                                  int MTall, int ptiles) {
     constexpr int KK = KS * KS, PAD = KS / 2;
     constexpr int CH8 = CC / 8, PPS = 4 / CH8, KSTEPS = (KK + PPS - 1) / PPS;
     constexpr int WTOT = KSTEPS * MT * 192, NWV = (WTOT + 255) / 256;
@@ -81,26 +81,27 @@ __global__ __launch_bounds__(256) void k_conv6(const float* __restrict__ src, co
     const int Hd = EXT ? g.H + 2 * PAD : g.H, Wd = EXT ? g.W + 2 * PAD : g.W;
     const int HWd = Hd * Wd, HWs = g.H * g.W;
     const int halo = t.LH * t.LW, NPX = t.NB * halo;
-    const int plane = NPX * CH8;                       // 16-byte units per piece plane (<= 256 NI)
-    u4* s_in = s_dyn;                                  // [piece][pixel][channel octet]
+    const int plane = NPX * CH8;                       // (pixel, channel octet) units of the halo tile (<= 256 NI)
+    char* s_in = (char*)s_dyn;                         // [pixel][channel octet][piece] x 16 B
     u4* s_w = s_dyn + 3 * plane;                       // [kstep][mt][piece][lane]
-    int* s_koff = (int*)(s_w + WTOT);                  // [kstep][q]: 16-byte units from a pixel's own slot to its operand
+    int* s_koff = (int*)(s_w + WTOT);                  // [kstep][q]: BYTES from a pixel's own slot to its operand
     const int mb = blockIdx.y * MT;                    // first output-channel tile of this workgroup
     const int tpi = t.tiles_x * t.tiles_y;
     for (int i = threadIdx.x; i < KSTEPS * 4; i += blockDim.x) {
         const int s = i >> 2, qq = i & 3, pos = s * PPS + qq / CH8, ky = pos / KS, kx = pos - KS * ky;
-        s_koff[i] = pos < KK ? ((EXT ? (2 * PAD - ky) * t.LW + (2 * PAD - kx) : ky * t.LW + kx) * CH8 + qq % CH8) : qq % CH8;
+        s_koff[i] = 48 * (pos < KK ? ((EXT ? (2 * PAD - ky) * t.LW + (2 * PAD - kx) : ky * t.LW + kx) * CH8 + qq % CH8) : qq % CH8);
     }
     // this wave's 4 pixel tiles: tile pixel pi = 64*wave + 16*tt + n -> (image bi, row, column) of the workgroup's tile
-    int poff[4], pbi[4], prow[4], pcol[4];
+    int poff[4], pbi[4], ppix[4];
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
         const int pi = 64 * wave + 16 * tt + n;
         const int bi = pi / (t.TH * t.TW), rem = pi - bi * (t.TH * t.TW);
         const int r = rem / t.TW, c = rem - r * t.TW;
         const bool on = bi < t.NB;  // NB*TH*TW may be < 256 (tile shapes that are not powers of two): idle lanes
-        pbi[tt] = on ? bi : -1; prow[tt] = r; pcol[tt] = c;
-        poff[tt] = on ? (bi * halo + r * t.LW + c) * CH8 : 0;
+        pbi[tt] = on ? bi : -1;
+        ppix[tt] = r | (c << 16);
+        poff[tt] = on ? 48 * ((bi * halo + r * t.LW + c) * CH8) : 0;
     }
     // split-K over blockIdx.z: a contiguous range of channel chunks, own partial output slice (summed by k_splitk_sum)
     const int nch = (Cs + CC - 1) / CC, per = (nch + gridDim.z - 1) / gridDim.z;
@@ -111,9 +112,25 @@ __global__ __launch_bounds__(256) void k_conv6(const float* __restrict__ src, co
     const int ntile = ((int)blockIdx.x < ptiles) ? (ptiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int nit = nchw > 0 ? ntile * nchw : 0;
 
+    // this thread's NI halo items (pixel, channel octet): tile-invariant coordinates, packed lx | ly << 8 | bi << 16 | c8 << 24
+    unsigned ipk[NI], ilds[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int c8 = CH8 == 1 ? 0 : (i >= NPX ? 1 : 0), pxl = i - c8 * NPX;
+        const int r1 = (int)cfd_div((unsigned)pxl, t.dUsed), lx = pxl - r1 * t.LW;
+        const int bi = (int)cfd_div((unsigned)r1, t.dLH), ly = r1 - bi * t.LH;
+        ipk[k] = i < plane ? (unsigned)(lx | (ly << 8) | (bi << 16) | (c8 << 24)) : 0x80000000u;  // idle: item (0, 0, 0, 0), never committed
+        ilds[k] = 48u * (unsigned)(pxl * CH8 + c8);
+    }
     float dr[NI][8];
     u4 wr[NWV];
-    // global loads of iteration `it` (tile, chunk): halo pixels x channel octets, 8 channel values each; the chunk's fragments
+    bool dok[NI];
+    // global loads of iteration `it` (tile, chunk): 8 channel values per halo item, the chunk's weight fragments.  Every load is
+    // unconditional from a clamped (valid) address, a wave-uniform base pointer plus a 32-bit byte offset: channels beyond Cs
+    // meet zero weights, weight tiles beyond MTall feed rows that are never stored; only halo pixels outside the image (EXT) or
+    // the batch must become zeros, at commit time (`dok`).  (A `cond ? load : 0` form compiles to one branch per load, 64-bit
+    // per-lane addresses to ~5 VALU instructions per load: together 2/3 of the kernel's VALU time in the first version.)
     const auto issue = [&](int it, bool with_w) {
         const int tk = it / nchw, ch = chbeg + it - tk * nchw;
         const int tile = blockIdx.x + tk * gridDim.x;
@@ -122,35 +139,48 @@ __global__ __launch_bounds__(256) void k_conv6(const float* __restrict__ src, co
         const int b0 = bg * t.NB;
         const int oy = EXT ? ty0 - 2 * PAD : ty0 - PAD, ox = EXT ? tx0 - 2 * PAD : tx0 - PAD;  // source coords of the halo origin
         const int c0 = ch * CC;
+        const bool full = c0 + CC <= Cs;  // (uniform) every channel of the chunk exists: no per-channel clamping
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
-            const int i = threadIdx.x + 256 * k;
-            const int c8 = CH8 == 1 ? 0 : (i >= NPX ? 1 : 0), pxl = i - c8 * NPX;
-            const int r1 = (int)cfd_div((unsigned)pxl, t.dUsed), lx = pxl - r1 * t.LW;
-            const int bi = (int)cfd_div((unsigned)r1, t.dLH), ly = r1 - bi * t.LH;
+            const unsigned pk = ipk[k];
+            const int lx = pk & 255, ly = (pk >> 8) & 255, bi = (pk >> 16) & 255, c8 = (pk >> 24) & 1;
             int y = oy + ly, x = ox + lx;
-            bool ok = i < plane && b0 + bi < g.B;
-            if constexpr (EXT) {
-                ok = ok && y >= 0 && y < g.H && x >= 0 && x < g.W;
-            } else {
-                y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
-                x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
-            }
+            bool ok = b0 + bi < g.B;
+            if constexpr (EXT) ok = ok && y >= 0 && y < g.H && x >= 0 && x < g.W;
+            y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
+            x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
+            const int bsafe = b0 + bi < g.B ? b0 + bi : g.B - 1;
             const int cb = c0 + 8 * c8;
-            const float* sb = src + ((size_t)(ok ? b0 + bi : 0) * Cs + cb) * HWs + (ok ? y * g.W + x : 0);
+            const unsigned off = 4u * (unsigned)(bsafe * Cs * HWs + y * g.W + x);
+            if (full) {
+                const unsigned off2 = off + 4u * (unsigned)(cb * HWs);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dr[k][j] = (ok && cb + j < Cs) ? sb[(size_t)j * HWs] : 0.f;
+                for (int j = 0; j < 8; ++j) dr[k][j] = cfd_ldg_off(src + (size_t)j * HWs, off2);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dr[k][j] = cfd_ldg_off(src, off + 4u * (unsigned)((cb + j < Cs ? cb + j : Cs - 1) * HWs));
+            }
+            dok[k] = ok;
         }
         if (with_w) {
 #pragma unroll
             for (int k = 0; k < NWV; ++k) {
-                const int i = threadIdx.x + 256 * k;
-                const int s = i / (MT * 192), r = i - s * (MT * 192);
-                const u4 z4 = {0u, 0u, 0u, 0u};
-                wr[k] = (i < WTOT && mb + r / 192 < MTall) ? wfrag[((size_t)(ch * KSTEPS + s) * MTall + mb) * 192 + r] : z4;
+                int i = threadIdx.x + 256 * k;
+                i = i < WTOT ? i : WTOT - 1;
+                const int s = i / (MT * 192), r = i - s * (MT * 192), mt = r / 192;
+                const int mtile = mb + mt < MTall ? mb + mt : MTall - 1;
+                wr[k] = wfrag[((ch * KSTEPS + s) * MTall + mtile) * 192 + (r - mt * 192)];
             }
         }
     };
+    float bias_r[MT][4];  // this lane's output rows m = 16 (mb + mt) + 4 q + r
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 16 * (mb + mt) + 4 * q + r;
+            bias_r[mt][r] = (bias && !split && m < Cm) ? bias[m] : 0.f;
+        }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[MT][4];
 #pragma unroll
@@ -162,12 +192,14 @@ __global__ __launch_bounds__(256) void k_conv6(const float* __restrict__ src, co
         __syncthreads();  // previous iteration's operands fully consumed (first pass: s_koff written)
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
-            const int i = threadIdx.x + 256 * k;
-            if (i < plane) {
-                const int c8 = CH8 == 1 ? 0 : (i >= NPX ? 1 : 0), pxl = i - c8 * NPX;
+            if (!(ipk[k] >> 31)) {
+                if (!dok[k]) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dr[k][j] = 0.f;
+                }
                 const CfdSplit8x3 sp = cfd_split8x3(dr[k]);
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) s_in[pc * plane + pxl * CH8 + c8] = __builtin_bit_cast(u4, sp.p[pc]);
+                for (int pc = 0; pc < 3; ++pc) *(u4*)(s_in + ilds[k] + 16 * pc) = __builtin_bit_cast(u4, sp.p[pc]);
             }
         }
         if (it == 0 || nchw > 1) {
@@ -183,15 +215,16 @@ __global__ __launch_bounds__(256) void k_conv6(const float* __restrict__ src, co
 #pragma unroll 1
         for (int s = 0; s < KSTEPS; ++s) {
             const int ko = s_koff[4 * s + q];
+            const u4* wp = s_w + s * (MT * 192) + lane;
             bf16x8 bv[4][3], av[MT][3];
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) bv[tt][pc] = __builtin_bit_cast(bf16x8, s_in[pc * plane + poff[tt] + ko]);
+                for (int pc = 0; pc < 3; ++pc) bv[tt][pc] = __builtin_bit_cast(bf16x8, *(const u4*)(s_in + (poff[tt] + ko) + 16 * pc));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) av[mt][pc] = __builtin_bit_cast(bf16x8, s_w[((s * MT + mt) * 3 + pc) * 64 + lane]);
+                for (int pc = 0; pc < 3; ++pc) av[mt][pc] = __builtin_bit_cast(bf16x8, wp[(mt * 3 + pc) * 64]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -204,15 +237,15 @@ __global__ __launch_bounds__(256) void k_conv6(const float* __restrict__ src, co
             const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
-                const int b = bg * t.NB + pbi[tt], y = ty0 + prow[tt], x = tx0 + pcol[tt];
+                const int b = bg * t.NB + pbi[tt], y = ty0 + (ppix[tt] & 0xffff), x = tx0 + (ppix[tt] >> 16);
                 const bool on = pbi[tt] >= 0 && b < g.B && y < Hd && x < Wd;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
+                    const int m0 = 16 * (mb + mt) + 4 * q;
+                    const unsigned o = 4u * (unsigned)((b * Cm + m0) * HWd + y * Wd + x);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = 16 * (mb + mt) + 4 * q + r;
-                        if (on && m < Cm) dst[((size_t)b * Cm + m) * HWd + y * Wd + x] = acc[mt][tt][r] + ((bias && !split) ? bias[m] : 0.f);
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if (on && m0 + r < Cm) cfd_stg_off(dst + (size_t)r * HWd, o, acc[mt][tt][r] + bias_r[mt][r]);
                     acc[mt][tt] = zero;
                 }
             }
@@ -258,8 +291,7 @@ static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     const int plane = t.NB * t.LH * t.LW * (P.CC / 8);
     P.NI = plane <= 3 * 256 ? 3 : 5;
     int mtw = P.MTall >= 2 ? 2 : 1;
-    // (two tiles with 5 prefetch items per thread need > 256 registers: one wave per SIMD)
-    if (mtw == 2 && (lds_of(2) > CFD_CONV6_MAX_LDS || P.ptiles * ((P.MTall + 1) / 2) < 256 || P.NI == 5)) mtw = 1;
+    if (mtw == 2 && (lds_of(2) > CFD_CONV6_MAX_LDS || P.ptiles * ((P.MTall + 1) / 2) < 256)) mtw = 1;
     P.mtw = mtw;
     P.mgroups = (P.MTall + mtw - 1) / mtw;
     const long wgs = P.ptiles * P.mgroups;
@@ -277,7 +309,8 @@ static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     P.gx = (int)(gx < P.ptiles ? gx : P.ptiles);
     P.wfrag_bytes = cfd_align_up((size_t)P.nch * P.KSTEPS * P.MTall * 3 * 1024, 256);
     P.split_bytes = P.ksplit > 1 ? cfd_align_up((size_t)P.ksplit * g.B * Cm * Hd * Wd * sizeof(float), 256) : 0;
-    P.ok = P.lds <= 150 * 1024 && plane <= 5 * 256 && (long)P.nch * P.KSTEPS * P.MTall * 64 < (1L << 31) && P.ptiles < (1L << 30);
+    const bool small = (long)g.B * Cs * g.H * g.W < (1L << 30) && (long)g.B * Cm * Hd * Wd < (1L << 30);  // 32-bit byte offsets
+    P.ok = small && P.lds <= 150 * 1024 && plane <= 5 * 256 && (long)P.nch * P.KSTEPS * P.MTall * 64 < (1L << 31) && P.ptiles < (1L << 30);
     return P;
 }
 
@@ -360,15 +393,15 @@ struct Wg6Tile {
 
 template <int KS, int MT, int NKY>
 __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict__ gout, const float* __restrict__ in,
-                                                     float* __restrict__ part, ConvGeom g, Wg6Tile t, int ntiles) {
+                                                        float* __restrict__ part, ConvGeom g, Wg6Tile t, int ntiles) {
     constexpr int KK = KS * KS, PAD = KS / 2, NT = NKY * KS, NKG = (KS + NKY - 1) / NKY;
     constexpr int NIW = 3;  // halo items per thread: HP * 16 <= 768 (HP <= 40 for k = 3, 42 for k = 7 with NKY = 2)
     CFD_DYN_SHARED(u4, s_dyn);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
     const int HW = g.H * g.W;
-    u4* s_in = s_dyn;                    // [piece][halo pixel][16 slots]
-    u4* s_g = s_dyn + 3 * t.HP * 16;     // [piece][16 pixels][MT][16 slots]
+    char* s_in = (char*)s_dyn;                    // [halo pixel][16 slots][piece] x 16 B
+    char* s_g = (char*)(s_dyn + 3 * t.HP * 16);   // [16 pixels][MT][16 slots][piece] x 16 B
     const int c0 = blockIdx.y * 16;
     const int mg = blockIdx.z / NKG, ky0 = (blockIdx.z - mg * NKG) * NKY;
     const int mbase = mg * 16 * MT;
@@ -381,36 +414,64 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
-    // the next tile's global loads wait in registers while this tile's MFMAs run (see k_conv6)
+    // this thread's staging items: tile-invariant coordinates and LDS byte offsets
+    unsigned ipk[NIW], ilds[NIW];  // input halo items (pixel, channel): lx | ly << 8, channel offset folded into ich
+    unsigned ich[NIW];
+#pragma unroll
+    for (int k = 0; k < NIW; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int c = (int)cfd_div((unsigned)i, t.dHP), hp = i - c * t.HP;
+        const int ly = (int)cfd_div((unsigned)hp, t.dLW), lx = hp - ly * t.LW;
+        ipk[k] = c < 16 ? (unsigned)(lx | (ly << 8)) : 0x80000000u;  // idle: never committed
+        ich[k] = 4u * (unsigned)((c0 + c < g.Ci ? c0 + c : g.Ci - 1) * HW);
+        ilds[k] = 48u * (unsigned)(hp * 16 + ((c + hp) & 15));
+    }
+    unsigned gpk[MT], glds[MT], gch[MT];  // gradient items (pixel, output channel)
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int o = i >> 4, p2 = i & 15;
+        gpk[k] = (unsigned)((p2 & (t.TW - 1)) | ((p2 >> t.tw_shift) << 8));
+        gch[k] = 4u * (unsigned)((mbase + o < g.Co ? mbase + o : g.Co - 1) * HW);
+        glds[k] = 48u * (unsigned)((p2 * MT + (o >> 4)) * 16 + (((o & 15) + p2) & 15));
+    }
+    // the next tile's global loads wait in registers while this tile's MFMAs run (see k_conv6); all of them unconditional from
+    // clamped addresses (uniform image pointer + 32-bit byte offset)
     float dri[NIW][8], drg[MT][8];
+    int gok[MT];  // images of the gradient item that are real (0: pixel outside the image): the only operand that must be zeroed --
+                  // input values beside a zero gradient, input channels beyond Ci and output rows beyond Co never reach gw
     const auto issue = [&](int tile) {
         const int bg = tile / tpi, tr = tile - bg * tpi;
         const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
         const int b0 = bg * 8;
         const int oy = ty0 + ky0 - PAD, ox = tx0 - PAD;
+        const float* inb[8];
+        const float* gb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int b = b0 + j < g.B ? b0 + j : g.B - 1;
+            inb[j] = in + (size_t)b * g.Ci * HW;
+            gb[j] = gout + (size_t)b * g.Co * HW;
+        }
 #pragma unroll
         for (int k = 0; k < NIW; ++k) {
-            const int i = threadIdx.x + 256 * k;
-            const int c = (int)cfd_div((unsigned)i, t.dHP), hp = i - c * t.HP;
-            const int ly = (int)cfd_div((unsigned)hp, t.dLW), lx = hp - ly * t.LW;
-            int y = oy + ly, x = ox + lx;
+            int y = oy + (int)((ipk[k] >> 8) & 255), x = ox + (int)(ipk[k] & 255);
             y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
             x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
-            const bool cok = c < 16 && c0 + c < g.Ci;
-            const float* sb = in + ((size_t)b0 * g.Ci + (cok ? c0 + c : 0)) * HW + y * g.W + x;
+            const unsigned off = ich[k] + 4u * (unsigned)(y * g.W + x);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dri[k][j] = (cok && b0 + j < g.B) ? sb[(size_t)j * g.Ci * HW] : 0.f;
+            for (int j = 0; j < 8; ++j) dri[k][j] = cfd_ldg_off(inb[j], off);
         }
-        // upstream gradient of the tile's pixels (0 outside the image / batch / channel range: contributes nothing)
 #pragma unroll
         for (int k = 0; k < MT; ++k) {
-            const int i = threadIdx.x + 256 * k;
-            const int o = i >> 4, p2 = i & 15;
-            const int y = ty0 + (p2 >> t.tw_shift), x = tx0 + (p2 & (t.TW - 1));
-            const bool ok = mbase + o < g.Co && y < g.H && x < g.W;
-            const float* sb = gout + ((size_t)b0 * g.Co + (ok ? mbase + o : 0)) * HW + (ok ? y * g.W + x : 0);
+            int y = ty0 + (int)(gpk[k] >> 8), x = tx0 + (int)(gpk[k] & 255);
+            const bool ok = y < g.H && x < g.W;
+            y = y < g.H ? y : g.H - 1;
+            x = x < g.W ? x : g.W - 1;
+            const unsigned off = gch[k] + 4u * (unsigned)(y * g.W + x);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) drg[k][j] = (ok && b0 + j < g.B) ? sb[(size_t)j * g.Co * HW] : 0.f;
+            for (int j = 0; j < 8; ++j) drg[k][j] = cfd_ldg_off(gb[j], off);
+            gok[k] = ok ? g.B - b0 : 0;
         }
     };
     if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
@@ -418,22 +479,19 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
         __syncthreads();  // previous tile fully consumed
 #pragma unroll
         for (int k = 0; k < NIW; ++k) {
-            const int i = threadIdx.x + 256 * k;
-            if (i < t.HP * 16) {
-                const int c = (int)cfd_div((unsigned)i, t.dHP), hp = i - c * t.HP;
+            if (!(ipk[k] >> 31)) {
                 const CfdSplit8x3 sp = cfd_split8x3(dri[k]);
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) s_in[(pc * t.HP + hp) * 16 + ((c + hp) & 15)] = __builtin_bit_cast(u4, sp.p[pc]);
+                for (int pc = 0; pc < 3; ++pc) *(u4*)(s_in + ilds[k] + 16 * pc) = __builtin_bit_cast(u4, sp.p[pc]);
             }
         }
 #pragma unroll
         for (int k = 0; k < MT; ++k) {
-            const int i = threadIdx.x + 256 * k;
-            const int o = i >> 4, p2 = i & 15;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) drg[k][j] = j < gok[k] ? drg[k][j] : 0.f;
             const CfdSplit8x3 sp = cfd_split8x3(drg[k]);
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc)
-                s_g[((pc * 16 + p2) * MT + (o >> 4)) * 16 + (((o & 15) + p2) & 15)] = __builtin_bit_cast(u4, sp.p[pc]);
+            for (int pc = 0; pc < 3; ++pc) *(u4*)(s_g + glds[k] + 16 * pc) = __builtin_bit_cast(u4, sp.p[pc]);
         }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
@@ -442,13 +500,15 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) av[mt][pc] = __builtin_bit_cast(bf16x8, s_g[((pc * 16 + pi) * MT + mt) * 16 + ((n + pi) & 15)]);
+            for (int pc = 0; pc < 3; ++pc)
+                av[mt][pc] = __builtin_bit_cast(bf16x8, *(const u4*)(s_g + 48 * ((pi * MT + mt) * 16 + ((n + pi) & 15)) + 16 * pc));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int P = pbase + (nt / KS) * t.LW + nt % KS;
+            const char* bp = s_in + 48 * (P * 16 + ((n + P) & 15));
             bf16x8 bv[3];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) bv[pc] = __builtin_bit_cast(bf16x8, s_in[(pc * t.HP + P) * 16 + ((n + P) & 15)]);
+            for (int pc = 0; pc < 3; ++pc) bv[pc] = __builtin_bit_cast(bf16x8, *(const u4*)(bp + 16 * pc));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = cfd_mfma_bf16x6(av[mt], bv, acc[mt][nt]);
         }
@@ -522,7 +582,7 @@ static Wg6Plan wg6_plan(const ConvGeom& g) {
     const size_t red = (size_t)4 * (KS == 3 ? 9 : 7) * 256 * sizeof(float);
     P.lds = stage > red ? stage : red;
     P.part_bytes = cfd_align_up((size_t)P.groups * g.Co * g.Ci * KS * KS * sizeof(float), 256);
-    P.ok = P.lds <= 150 * 1024;
+    P.ok = P.lds <= 150 * 1024 && (long)g.B * g.Ci * g.H * g.W < (1L << 30) && (long)g.B * g.Co * g.H * g.W < (1L << 30);  // 32-bit byte offsets
     return P;
 }
 

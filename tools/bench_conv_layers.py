@@ -26,7 +26,8 @@ def main():
     shapes = [("unet", 128, ci, co, hw, 3) for ci, co, hw in
               [(10, 12, 64), (12, 12, 64), (12, 24, 32), (24, 24, 32), (24, 48, 16), (48, 48, 16), (48, 96, 8), (96, 96, 8),
                (96, 192, 4), (192, 192, 4), (192, 96, 8), (96, 48, 16), (48, 24, 32), (24, 12, 64)]]
-    shapes += [("resnet", 32, 10, 16, 64, 7), ("resnet", 32, 16, 16, 64, 7), ("resnet", 32, 16, 2, 64, 7)]
+    # ResidualBlock(in, out, hidden = 64): conv1 in -> 64, conv2 64 -> out (src/models/resnet.py:35-55)
+    shapes += [("resnet", 32, 8, 64, 64, 7), ("resnet", 32, 64, 16, 64, 7), ("resnet", 32, 16, 64, 64, 7), ("resnet", 32, 64, 2, 64, 7)]
     tot = [0.0, 0.0]
     if len(sys.argv) > 1:  # e.g. "1,5": only these rows (for counter collection)
         shapes = [shapes[int(i)] for i in sys.argv[1].split(",")]
