@@ -278,6 +278,23 @@ __device__ __forceinline__ f32x4 cfd_mfma_bf16x6(const bf16x8 (&a)[3], const bf1
     c = cfd_mfma16x16x32_bf16(a[0], b[1], c);
     return cfd_mfma16x16x32_bf16(a[0], b[0], c);
 }
+// The same for N independent accumulators sharing the A operand, product-major: consecutive MFMAs never depend on each other (a
+// chain of six dependent 16x16x32 MFMAs issues at about half rate: each waits for the previous result).
+template <int N>
+__device__ __forceinline__ void cfd_mfma_bf16x6_n(const bf16x8 (&a)[3], const bf16x8 (&b)[N][3], f32x4 (&c)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) c[i] = cfd_mfma16x16x32_bf16(a[2], b[i][0], c[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) c[i] = cfd_mfma16x16x32_bf16(a[0], b[i][2], c[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) c[i] = cfd_mfma16x16x32_bf16(a[1], b[i][1], c[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) c[i] = cfd_mfma16x16x32_bf16(a[1], b[i][0], c[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) c[i] = cfd_mfma16x16x32_bf16(a[0], b[i][1], c[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) c[i] = cfd_mfma16x16x32_bf16(a[0], b[i][0], c[i]);
+}
 // D += A*B with both operands split
 __device__ __forceinline__ f32x4 cfd_mfma_bf16x3(const CfdSplit8& a, const CfdSplit8& b, f32x4 c) {
     c = cfd_mfma16x16x32_bf16(a.lo, b.hi, c);

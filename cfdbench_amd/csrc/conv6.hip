@@ -187,6 +187,30 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) acc[mt][tt] = zero;
+    // A finished tile is stored one iteration LATER, after the next prefetch has been issued: vmcnt is one in-order counter for
+    // loads and stores and the stores are conditional, so the wait for the prefetched loads at the top of an iteration is a
+    // vmcnt(0) -- with the stores issued right before it, every iteration paid a full write-acknowledge latency (~4 us of the
+    // ~6 us per tile in the profile of the first version).
+    f32x4 outv[MT][4];
+    int out_tile = -1;
+    const auto store_tile = [&]() {
+        const int bg = out_tile / tpi, tr = out_tile - bg * tpi;
+        const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int b = bg * t.NB + pbi[tt], y = ty0 + (ppix[tt] & 0xffff), x = tx0 + (ppix[tt] >> 16);
+            const bool on = pbi[tt] >= 0 && b < g.B && y < Hd && x < Wd;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m0 = 16 * (mb + mt) + 4 * q;
+                const unsigned o = 4u * (unsigned)((b * Cm + m0) * HWd + y * Wd + x);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (on && m0 + r < Cm) cfd_stg_off(dst + (size_t)r * HWd, o, outv[mt][tt][r] + bias_r[mt][r]);
+            }
+        }
+        out_tile = -1;
+    };
     if (nit > 0) issue(0, true);
     for (int it = 0; it < nit; ++it) {
         __syncthreads();  // previous iteration's operands fully consumed (first pass: s_koff written)
@@ -211,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
         }
         __syncthreads();
         if (it + 1 < nit) issue(it + 1, nchw > 1);
+        if (out_tile >= 0) store_tile();
         cfd_sched_fence();  // keep the loads above the MFMA loop: hipcc otherwise sinks them to their first use
 #pragma unroll 1
         for (int s = 0; s < KSTEPS; ++s) {
@@ -226,31 +251,18 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) av[mt][pc] = __builtin_bit_cast(bf16x8, wp[(mt * 3 + pc) * 64]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) acc[mt][tt] = cfd_mfma_bf16x6(av[mt], bv[tt], acc[mt][tt]);
+            for (int mt = 0; mt < MT; ++mt) cfd_mfma_bf16x6_n<4>(av[mt], bv, acc[mt]);
         }
         const int tk = it / nchw;
-        if (it - tk * nchw == nchw - 1) {  // last chunk of the tile: store, start the next tile from zero
-            const int tile = blockIdx.x + tk * gridDim.x;
-            const int bg = tile / tpi, tr = tile - bg * tpi;
-            const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
+        if (it - tk * nchw == nchw - 1) {  // last chunk of the tile: hand the sums to the deferred store, start the next tile from zero
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int b = bg * t.NB + pbi[tt], y = ty0 + (ppix[tt] & 0xffff), x = tx0 + (ppix[tt] >> 16);
-                const bool on = pbi[tt] >= 0 && b < g.B && y < Hd && x < Wd;
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int m0 = 16 * (mb + mt) + 4 * q;
-                    const unsigned o = 4u * (unsigned)((b * Cm + m0) * HWd + y * Wd + x);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (on && m0 + r < Cm) cfd_stg_off(dst + (size_t)r * HWd, o, acc[mt][tt][r] + bias_r[mt][r]);
-                    acc[mt][tt] = zero;
-                }
-            }
+                for (int tt = 0; tt < 4; ++tt) { outv[mt][tt] = acc[mt][tt]; acc[mt][tt] = zero; }
+            out_tile = blockIdx.x + tk * gridDim.x;
         }
     }
+    if (out_tile >= 0) store_tile();
 }
 
 struct Conv6Plan {
@@ -502,15 +514,28 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc)
                 av[mt][pc] = __builtin_bit_cast(bf16x8, *(const u4*)(s_g + 48 * ((pi * MT + mt) * 16 + ((n + pi) & 15)) + 16 * pc));
+        // column tiles in groups of NG: their B operands are read together and the MFMAs run product-major over the group, so that
+        // consecutive MFMAs are independent
+        constexpr int NG = KS == 3 ? 3 : (MT == 1 ? 7 : 2);
+        static_assert(NT % NG == 0, "column tiles per MFMA group");
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // the six products of cfd_mfma_bf16x6, small terms first
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int P = pbase + (nt / KS) * t.LW + nt % KS;
-            const char* bp = s_in + 48 * (P * 16 + ((n + P) & 15));
-            bf16x8 bv[3];
+        for (int n0 = 0; n0 < NT; n0 += NG) {
+            bf16x8 bv[NG][3];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) bv[pc] = __builtin_bit_cast(bf16x8, *(const u4*)(bp + 16 * pc));
+            for (int i = 0; i < NG; ++i) {
+                const int nt = n0 + i, P = pbase + (nt / KS) * t.LW + nt % KS;
+                const char* bp = s_in + 48 * (P * 16 + ((n + P) & 15));
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = cfd_mfma_bf16x6(av[mt], bv, acc[mt][nt]);
+                for (int pc = 0; pc < 3; ++pc) bv[i][pc] = __builtin_bit_cast(bf16x8, *(const u4*)(bp + 16 * pc));
+            }
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < NG; ++i)
+                        acc[mt][n0 + i] = cfd_mfma16x16x32_bf16(av[mt][PA[p]], bv[i][PB[p]], acc[mt][n0 + i]);
         }
     }
     // sum of the four waves (each owns 4 of the tile's 16 pixels) in a fixed order, RG column tiles of one output-channel tile at a
