@@ -55,6 +55,14 @@ __device__ __forceinline__ int cfd_opaque(int x) {
 // (hi & 0xffff0000) | (lo >> 16): the upper halves of two dwords as one (v_perm_b32) -- two truncated-to-bf16 floats as a pair
 __device__ __forceinline__ unsigned cfd_pack_hi16(unsigned hi, unsigned lo) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
+// The same for a float.  Also the way to make the compiler WAIT for a global load where the value is produced: a value loaded before
+// a loop and first used inside it otherwise gets an s_waitcnt vmcnt(0) at that use in EVERY iteration (the pending-load state of the
+// loop entry is merged into the back edge), which drains all prefetches of the loop body.
+__device__ __forceinline__ float cfd_opaque_f(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // Wave-uniform value -> SGPR (lets the compiler use scalar loads / scalar operands for per-wave indices).
 __device__ __forceinline__ int cfd_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 

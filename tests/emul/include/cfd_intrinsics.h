@@ -69,6 +69,7 @@ inline float cfd_wave_sum(float v) {
 inline void cfd_wave_lds_sync() { cfd_emul::wave_sync(); }
 
 inline int cfd_opaque(int x) { return x; }
+inline float cfd_opaque_f(float x) { return x; }
 inline unsigned cfd_pack_hi16(unsigned hi, unsigned lo) { return (hi & 0xffff0000u) | (lo >> 16); }
 
 inline void cfd_sched_fence() {}
