@@ -43,6 +43,8 @@ BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 # kernels whose GEMM-shaped work runs as 3-term split-bf16 products on the bf16 matrix pipe (cfd_common.h): their
 # fp32-equivalent flops cost 3 bf16 MFMA flops each
 SPLIT_BF16 = ("k_dft_fwd", "k_idft", "k_block", "k_chan_wgrad", "k_head")
+# the k = 3 / k = 7 convolutions (conv6.hip): three-piece operands, SIX bf16 MFMAs per fp32-exact product
+SPLIT6_BF16 = ("k_conv_fwd", "k_conv_dgrad", "k_conv_wgrad")
 
 
 def parse():
@@ -89,8 +91,10 @@ def roofline_of(name, launches, total_ms, total_bytes, total_flops):
     if total_ms <= 0 or launches <= 0:
         return None
     t = total_ms * 1e-3
-    split = name.startswith(SPLIT_BF16)
-    pipe_tf = BF16_MFMA_PEAK_TF / 3.0 if split else FP32_PEAK_TF  # fp32-equivalent flops per second of the pipe
+    split, split6 = name.startswith(SPLIT_BF16), name.startswith(SPLIT6_BF16)
+    pipe_tf = BF16_MFMA_PEAK_TF / 3.0 if split else (BF16_MFMA_PEAK_TF / 6.0 if split6 else FP32_PEAK_TF)  # fp32-equivalent flops/s of the pipe
+    pipe = ("bf16 MFMA, 3-term split products (fp32-equivalent flops)" if split else
+            "bf16 MFMA, six products of three-piece (fp32-exact) operands (fp32-equivalent flops)" if split6 else "fp32 MFMA / VALU")
     t_hbm = total_bytes / (HBM_PEAK_GBS * 1e9)
     t_pipe = total_flops / (pipe_tf * 1e12)
     out = dict(kernel=name, avg_us=round(total_ms / launches * 1e3, 2), launches=launches,
@@ -100,7 +104,7 @@ def roofline_of(name, launches, total_ms, total_bytes, total_flops):
     if t_pipe > t_hbm:
         tfs = total_flops / t / 1e12
         return dict(out, bound="mfma", achieved=round(tfs, 2), peak=round(pipe_tf, 1), unit="TFLOP/s", frac=round(tfs / pipe_tf, 4),
-                    traffic=None, pipe="bf16 MFMA, 3-term split products (fp32-equivalent flops)" if split else "fp32 MFMA / VALU")
+                    traffic=None, pipe=pipe)
     gbs = total_bytes / t / 1e9
     return dict(out, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
                 fp32_equiv_tflops=round(total_flops / t / 1e12, 2))
@@ -550,8 +554,9 @@ def main():
                               "ResNet(hidden 16, depth 4, 7x7) train step (src/models/resnet.py:145-198), batch 32, 64x64, fp32")
         fl = 3 * 4.37e9 * Br
         tf = fl / (leg["ms_per_step"] * 1e-3) / 1e12
-        leg["roofline_step"] = dict(bound="mfma", flops_per_step=fl, achieved=round(tf, 2), peak=FP32_PEAK_TF, unit="TFLOP/s",
-                                    frac=round(tf / FP32_PEAK_TF, 4), pipe="fp32 MFMA / VALU (exact-fp32 implicit-GEMM convs)")
+        pk = round(BF16_MFMA_PEAK_TF / 6.0, 1)
+        leg["roofline_step"] = dict(bound="mfma", flops_per_step=fl, achieved=round(tf, 2), peak=pk, unit="TFLOP/s", frac=round(tf / pk, 4),
+                                    pipe="bf16 MFMA at six products per fp32-exact product (conv6.hip: three-piece operands): 2.5 PF / 6")
         result["resnet_b32"] = leg
         del rn, br
 

@@ -30,8 +30,10 @@ void cfd_conv_part_reduce(const float* part, float* out, long n, int nchunk, hip
 // layer is not covered (the caller then uses the fp32 kernels).
 bool cfd_conv6_covers(const ConvGeom& g, bool ext);
 size_t cfd_conv6_ws_bytes(const ConvGeom& g, bool ext);
-int cfd_conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, bool ext,
-                  hipStream_t st, const char* what);
+// ext with `gin` != NULL: extended positions that map one-to-one onto an interior pixel may be written straight to gin (B,Ci,H,W)
+// instead of dst; *direct then says so and the caller folds only the border pixels (k_fold_border) instead of every pixel.
+int cfd_conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, bool ext, float* gin,
+                  bool* direct, hipStream_t st, const char* what);
 // weight gradient gw (Co,Ci,ks,ks) = sum over (b, p) of gout[b][o][p] * in[b][i][clamp(p + tap)]
 bool cfd_conv6_wgrad_covers(const ConvGeom& g);
 size_t cfd_conv6_wgrad_ws_bytes(const ConvGeom& g);

@@ -34,6 +34,10 @@ extern "C" int cfd_dbg_c6_read(unsigned long long* out, int n) { return (int)hip
 #define CFD_CONV6_GRID 512  // persistent workgroups per launch: two per CU (the CPU emulator build sets 2 so that small test shapes
                             // walk several tiles per workgroup)
 #endif
+static int conv6_grid() {
+    const int t = cfd_tune_get(CFD_TUNE_CONV6_GRID);
+    return t > 0 ? t : CFD_CONV6_GRID;
+}
 #ifndef CFD_CONV6_MAX_LDS
 #define CFD_CONV6_MAX_LDS (80 * 1024)  // two workgroups per CU: one stages while the other feeds the matrix pipe
 #endif
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void k_conv6_wprep(const float* __restrict__ w
 template <int KS, int MT, int CC, bool EXT, int NI>
 __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src, const u4* __restrict__ wfrag,
                                                   const float* __restrict__ bias, float* __restrict__ dst, ConvGeom g, ConvTile t,
-                                                  int MTall, int ptiles) {
+                                                  int MTall, int ptiles, float* __restrict__ gin_direct) {
     constexpr int KK = KS * KS, PAD = KS / 2;
     constexpr int CH8 = CC / 8, PPS = 4 / CH8, KSTEPS = (KK + PPS - 1) / PPS;
     constexpr int WTOT = KSTEPS * MT * 192, NWV = (WTOT + 255) / 256;
@@ -215,10 +219,22 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int m0 = 16 * (mb + mt) + 4 * q;
-                const unsigned o = 4u * (unsigned)((b * Cm + m0) * HWd + y * Wd + x);
+                // input-gradient pass with `gin_direct`: extended positions that map one-to-one onto an interior pixel of the image
+                // go straight to gin; only the pad ring and the border rows / columns (whose pixels collect several extended
+                // positions) take the detour through the extended buffer and k_fold_border
+                const int yi = y - PAD, xi = x - PAD;
+                const bool direct = EXT && gin_direct != nullptr && yi >= 1 && yi <= g.H - 2 && xi >= 1 && xi <= g.W - 2;
+                if (direct) {
+                    const unsigned o = 4u * (unsigned)((b * Cm + m0) * HWs + yi * g.W + xi);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (on && m0 + r < Cm) cfd_stg_off(dst + (size_t)r * HWd, o, outv[mt][tt][r] + bias_r[mt][r]);
+                    for (int r = 0; r < 4; ++r)
+                        if (on && m0 + r < Cm) cfd_stg_off(gin_direct + (size_t)r * HWs, o, outv[mt][tt][r]);
+                } else {
+                    const unsigned o = 4u * (unsigned)((b * Cm + m0) * HWd + y * Wd + x);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (on && m0 + r < Cm) cfd_stg_off(dst + (size_t)r * HWd, o, outv[mt][tt][r] + bias_r[mt][r]);
+                }
             }
         }
         out_tile = -1;
@@ -335,7 +351,7 @@ static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     }
     P.lds = lds_of(mtw);
     // persistent workgroups: two per CU over the whole launch
-    long gx = CFD_CONV6_GRID / ((long)P.mgroups * P.ksplit);
+    long gx = conv6_grid() / ((long)P.mgroups * P.ksplit);
     if (gx < 1) gx = 1;
     P.gx = (int)(gx < P.ptiles ? gx : P.ptiles);
     P.wfrag_bytes = cfd_align_up((size_t)P.nch * P.KSTEPS * P.MTall * 3 * 1024, 256);
@@ -354,7 +370,7 @@ size_t cfd_conv6_ws_bytes(const ConvGeom& g, bool ext) {
 
 template <int KS, int CC, bool EXT>
 static void conv6_launch(const Conv6Plan& P, const float* src, const u4* wfrag, const float* bias, float* dst, const ConvGeom& g,
-                         hipStream_t st) {
+                         float* gin_direct, hipStream_t st) {
     const dim3 grid((unsigned)P.gx, P.mgroups, P.ksplit);
 #define C6_L(M_, N_)                                                                                                              \
     do {                                                                                                                          \
@@ -364,7 +380,7 @@ static void conv6_launch(const Conv6Plan& P, const float* src, const u4* wfrag, 
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
         hipLaunchKernelGGL((k_conv6<KS, M_, CC, EXT, N_>), grid, dim3(256), P.lds, st, src, wfrag, bias, dst, g, P.t, P.MTall,    \
-                           (int)P.ptiles);                                                                                        \
+                           (int)P.ptiles, gin_direct);                                                                            \
     } while (0)
     if (P.mtw == 1) { if (P.NI == 3) C6_L(1, 3); else C6_L(1, 5); }
     else { if (P.NI == 3) C6_L(2, 3); else C6_L(2, 5); }
@@ -372,8 +388,8 @@ static void conv6_launch(const Conv6Plan& P, const float* src, const u4* wfrag, 
 }
 
 template <bool EXT>
-static int conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, hipStream_t st,
-                     const char* what) {
+static int conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, float* gin,
+                     bool* direct, hipStream_t st, const char* what) {
     const Conv6Plan P = conv6_plan(g, EXT);
     if (!P.ok) return CFD_ERR_UNSUPPORTED;
     u4* wfrag = (u4*)ws;
@@ -386,11 +402,14 @@ static int conv6_run(const float* src, const float* w, const float* bias, float*
         CFD_LAUNCH_CHECK(what);
     }
     float* kdst = P.ksplit > 1 ? split_ws : dst;
+    // interior pixels of the input gradient straight to gin (no split-K partials, an interior exists, 32-bit offsets hold)
+    float* gd = (EXT && gin && P.ksplit == 1 && g.H >= 3 && g.W >= 3) ? gin : nullptr;
+    if (direct) *direct = gd != nullptr;
     if (g.ks == 3) {
-        if (P.CC == 8) conv6_launch<3, 8, EXT>(P, src, wfrag, bias, kdst, g, st);
-        else conv6_launch<3, 16, EXT>(P, src, wfrag, bias, kdst, g, st);
+        if (P.CC == 8) conv6_launch<3, 8, EXT>(P, src, wfrag, bias, kdst, g, gd, st);
+        else conv6_launch<3, 16, EXT>(P, src, wfrag, bias, kdst, g, gd, st);
     } else {
-        conv6_launch<7, 8, EXT>(P, src, wfrag, bias, kdst, g, st);
+        conv6_launch<7, 8, EXT>(P, src, wfrag, bias, kdst, g, gd, st);
     }
     CFD_LAUNCH_CHECK(what);
     if (P.ksplit > 1) {
@@ -401,9 +420,11 @@ static int conv6_run(const float* src, const float* w, const float* bias, float*
     return CFD_OK;
 }
 
-int cfd_conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, bool ext,
-                  hipStream_t st, const char* what) {
-    return ext ? conv6_run<true>(src, w, bias, dst, ws, g, st, what) : conv6_run<false>(src, w, bias, dst, ws, g, st, what);
+int cfd_conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, bool ext, float* gin,
+                  bool* direct, hipStream_t st, const char* what) {
+    if (direct) *direct = false;
+    return ext ? conv6_run<true>(src, w, bias, dst, ws, g, gin, direct, st, what)
+               : conv6_run<false>(src, w, bias, dst, ws, g, nullptr, nullptr, st, what);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -622,8 +643,11 @@ static Wg6Plan wg6_plan(const ConvGeom& g) {
     P.mtw = MTall >= 2 ? 2 : 1;  // (three tiles would need > 256 registers with the prefetch: one wave per SIMD)
     P.mgroups = (MTall + P.mtw - 1) / P.mtw;
     P.nkg = (KS + NKY - 1) / NKY;
-    // pixel groups: enough workgroups to fill the chip twice over, at most one per tile, partials capped at ~32 MB
-    long want = 4 * CFD_CONV6_GRID / ((long)P.chunks * P.mgroups * P.nkg);
+    // pixel groups: two workgroups per CU over the launch (measured: 2048 -> 1024 -> 512 workgroups took the ResNet weight
+    // gradients from 196 / 141 us to 147 / 115 to ~125 / 100: a workgroup's reduction epilogue and its partial slice are paid once
+    // per workgroup, not per tile), at most one per tile, partials capped at ~32 MB
+    const int mul = cfd_tune_get(CFD_TUNE_CONV6_WGRAD_MUL);
+    long want = (long)(mul > 0 ? mul : 1) * conv6_grid() / ((long)P.chunks * P.mgroups * P.nkg);
     if (want < 1) want = 1;
     const long cap = (32L << 20) / ((long)g.Co * g.Ci * KS * KS * 4 + 1);
     if (want > cap) want = cap;
