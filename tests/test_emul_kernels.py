@@ -151,7 +151,9 @@ def test_deeponet_inner(be, B, P, Kq, HW, with_q):
     _assert_all(res)
 
 
-@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(1, 5, 7, 9, 10, 3), (1, 3, 18, 5, 4, 3), (1, 2, 3, 8, 9, 7), (2, 4, 4, 6, 6, 1), (1, 5, 17, 3, 32, 3)])  # wide-image tile kernel: more shapes in test_gpu_kernels.py
+# conv6.hip (k = 3 / 7) with two persistent workgroups (the emulator build's CFD_CONV6_GRID): several tiles, two channel chunks
+# and ragged image groups per workgroup in the (40, 20, 18) case; more shapes in test_gpu_kernels.py
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(1, 5, 7, 9, 10, 3), (40, 20, 18, 5, 4, 3), (2, 2, 3, 8, 9, 7), (2, 4, 4, 6, 6, 1), (9, 3, 35, 2, 9, 7)])
 def test_conv2d_replicate(be, B, Ci, Co, H, W, ks):
     _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, ks))
 

@@ -214,6 +214,16 @@ def test_conv2d_replicate(be, B, Ci, Co, H, W, ks):
     _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, ks))
 
 
+@pytest.mark.parametrize("grid,B,Ci,Co,H,W,ks", [(2, 20, 12, 12, 64, 64, 3), (4, 37, 20, 40, 16, 16, 3), (2, 24, 8, 64, 30, 33, 7), (8, 11, 64, 16, 17, 16, 7),
+                                                  (1, 130, 192, 96, 4, 4, 3), (2, 9, 3, 5, 2, 3, 3)])
+def test_conv2d_persistent_workgroups_walk_many_tiles(be, grid, B, Ci, Co, H, W, ks):
+    """conv6.hip with a handful of persistent workgroups (the conv6_grid knob): every workgroup walks many (tile, chunk)
+    iterations -- register prefetch, deferred stores, accumulator hand-over, partial channel chunks, image groups of 8 with a
+    ragged last group, a grid without interior (2 x 3: the full fold) -- at the tolerance of the exact-fp32 kernels."""
+    with K.tuned(be, conv6_grid=grid):
+        _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, ks))
+
+
 @pytest.mark.parametrize("B,C,H,W,training,relu", [(4, 12, 64, 64, True, True), (3, 192, 4, 4, True, True), (2, 24, 33, 32, False, True), (3, 5, 7, 9, True, False)])
 def test_batchnorm_relu(be, B, C, H, W, training, relu):
     _assert_all(K.check_batchnorm(be, B, C, H, W, training, relu))
