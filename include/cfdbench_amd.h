@@ -266,7 +266,10 @@ int cfd_rowdot_bwd(const float* g, const float* branch, const float* trunk, floa
 /* ---- convolution stack of the U-Net / ResNet baselines (src/models/unet.py, src/models/resnet.py) ---------*/
 
 /* out (B,Co,H,W) = nn.Conv2d(Ci, Co, ks, padding=ks/2, padding_mode="replicate")(in); w (Co,Ci,ks,ks); ks odd <= 7
- * (unet.py:20-27 ks=3, resnet.py:35-41 ks=7, unet.py:105 ks=1); bias may be NULL.                              */
+ * (unet.py:20-27 ks=3, resnet.py:35-41 ks=7, unet.py:105 ks=1); bias may be NULL.  ws: cfd_conv2d_fwd_workspace_bytes()
+ * bytes (weight fragments and split-K partials of the k = 3 / 7 kernels; 0 for other kernel sizes), or NULL: k = 3 / 7 then run
+ * on the slower exact-fp32 gather kernel.  Both routes are fp32-exact class (the k = 3 / 7 kernels multiply three-piece bf16
+ * operands, six MFMAs per product).  The 2x2 transposed conv needs `out` / `gout` 8-byte aligned.                        */
 size_t cfd_conv2d_fwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);
 int cfd_conv2d_fwd(const float* in, const float* w, const float* bias, float* out, void* ws, int B, int Ci, int Co, int H,
                    int W, int ks, void* stream);
