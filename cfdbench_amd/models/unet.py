@@ -23,9 +23,7 @@ def _conv_bn_relu(seq: nn.Sequential, x: Tensor) -> Tensor:
     x = F_.Conv2dReplicateFn.apply(x, conv.weight, conv.bias)
     y = F_.BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, True, bn.eps,
                              bn.momentum)
-    if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
-    return y
+    return y  # (num_batches_tracked: one fused increment per forward, UNet.forward)
 
 
 class DoubleConv(nn.Module):
@@ -144,6 +142,11 @@ class UNet(AutoCfdModel):
         x = self.up3(x, x2)
         x = self.up4(x, x1)
         preds = F_.ResidualMaskFn.apply(self.out_conv(x), residual, mask)  # (out_conv + inputs[:, :out]) * mask
+        if self.training:  # nn.BatchNorm2d's step counters: ONE multi-tensor launch instead of 18 one-element increments
+            counters = [m.num_batches_tracked for m in self.modules()
+                        if isinstance(m, nn.BatchNorm2d) and m.training and m.num_batches_tracked is not None]
+            if counters:
+                torch._foreach_add_(counters, 1)
         if label is not None:
             label = F_.ResidualMaskFn.apply(label, None, mask)
             return dict(preds=preds, loss=self.loss_fn(labels=label, preds=preds))
