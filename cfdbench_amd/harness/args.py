@@ -10,6 +10,8 @@ the same attribute table drives ``argparse``.  Differences, all documented in SU
     ``lr_scheduler`` (step = the reference's StepLR | plateau = ReduceLROnPlateau(lr_scheduler_factor, lr_scheduler_patience) |
     cosine), ``early_stop`` (1: stop after early_stopping_patience evaluations without early_stopping_delta improvement),
     ``gradient_accumulation_steps`` (args.py:323; micro-batches per optimiser step),
+    ``graph`` (1: the autograd train step -- forward, loss, backward, Adam -- is captured once as a HIP graph and replayed per batch;
+    single process, no gradient accumulation, models without per-step host state, i.e. not the ResNet's dropout),
     ``dtype`` ("bf16": the FNO's activations between kernels are stored as bf16 -- test_multistep: BASELINE configs[4];
     train_auto --fused 1: bf16-storage training with fp32 master weights, gradients and optimiser).
 Flags of models that are not built yet are carried so existing command lines and args.json files keep working.
@@ -40,7 +42,7 @@ _FLAGS: Dict[str, Any] = dict(
     # missing in the reference's Args but read by its trainers (train_auto.py:357, :188-189)
     lr_step_size=20, lr_gamma=0.9,
     # additions of this harness
-    infer_steps=20, fused=0, plot_interval=1, resume=0, device_loader=0, dtype="fp32",
+    infer_steps=20, fused=0, plot_interval=1, resume=0, device_loader=0, dtype="fp32", graph=0,
     lr_scheduler="step", early_stop=0, gradient_accumulation_steps=1,
 )
 
@@ -91,4 +93,8 @@ def is_args_valid(args: Args) -> None:
     if args.fused:
         assert args.model == "fno", "--fused 1 is the FnoTrainEngine path"
         assert args.gradient_accumulation_steps == 1, "--fused 1 runs one fused optimiser step per batch"
+    if args.graph:
+        assert not args.fused, "--graph 1 captures the autograd step; the fused FNO engine has its own launch path"
+        assert args.gradient_accumulation_steps == 1, "--graph 1 captures one optimiser step per batch"
+        assert args.model != "resnet", "--graph 1: the ResNet's dropout takes a per-step host seed (not capturable)"
     assert args.unet_insert_case_params_at in ("input", "hidden")

@@ -60,7 +60,10 @@ class LrSchedule:
             raise RuntimeError(f"train_state.pt was written with --lr_scheduler {state['kind']}, this run uses {self.kind}")
         self.sched.load_state_dict(state["sched"])
         for g in self.optimizer.param_groups:
-            g["lr"] = state["lr"]
+            if torch.is_tensor(g["lr"]):  # capturable optimiser (train_auto --graph 1): the rate lives on the device
+                g["lr"].fill_(float(state["lr"]))
+            else:
+                g["lr"] = state["lr"]
 
 
 class EarlyStopping:

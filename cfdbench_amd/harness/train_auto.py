@@ -152,8 +152,15 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
           log_interval: int = 10, eval_interval: int = 2, measure_time: bool = False, fused: bool = False,
           plot_interval: int = 1, resume: bool = False, device_loader: bool = False, lr_scheduler_kind: str = "step",
           lr_scheduler_factor: float = 0.5, lr_scheduler_patience: int = 5, early_stopping_patience: int = 0,
-          early_stopping_delta: float = 1e-5, gradient_accumulation_steps: int = 1, act_dtype: str = "fp32"):
+          early_stopping_delta: float = 1e-5, gradient_accumulation_steps: int = 1, act_dtype: str = "fp32", graph: bool = False):
     """train_auto.py:181-313.  ``fused`` selects FnoTrainEngine (needs an Fno2d and the nmse loss).
+
+    ``graph`` (autograd path, one process): the step ``model(**batch) -> loss["nmse"].backward() -> Adam.step()`` is captured once
+    as a HIP graph (cfdbench_amd/graph.py) at the first full batch and replayed for every batch of that shape; a short last batch
+    runs eagerly on the same (capturable) optimiser.  Per-step losses stay on the device and are fetched once per epoch.  The
+    kernels are the same; what goes away is the per-operator host work of the eager loop (U-Net dim 12, B = 128: 5.2 -> 4.0 ms per
+    step; Auto-DeepONet B = 512: 1.8 -> 0.8 ms).  Adam runs in its capturable form (step count and rate on the device, fp32), so a
+    graph run follows an eager run to rounding, not to the bit.
 
     ``resume`` (the reference saves weights only, train_auto.py:301, and cannot continue a run): every
     checkpoint epoch also writes ``train_state.pt`` (optimiser moments / step, LR schedule, epoch, loss history, host RNG
@@ -192,8 +199,14 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
                                       "backward pass overwrites the flat gradient")
         engine = FnoTrainEngine(model, lr=lr, loss_name="nmse", act_dtype=act_dtype)
         optimizer = None
+    elif graph:
+        if world > 1 or accum > 1 or getattr(model, "graph_unsafe", False):
+            raise NotImplementedError("--graph 1 needs one process, gradient_accumulation_steps == 1 and a model without per-step "
+                                      "host state (the ResNet's dropout seed)")
+        optimizer = Adam(model.parameters(), lr=torch.tensor(float(lr), device="cuda"), capturable=True)
     else:
         optimizer = Adam(model.parameters(), lr=lr)
+    graphed = None
     schedule = LrSchedule(lr_scheduler_kind, lr, num_epochs, optimizer, lr_step_size=lr_step_size, lr_gamma=lr_gamma,
                           factor=lr_scheduler_factor, patience=lr_scheduler_patience)
     stopper = EarlyStopping(early_stopping_patience, early_stopping_delta)
@@ -212,6 +225,9 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
             engine.load_state_dict(state["optimizer"])
         else:
             optimizer.load_state_dict(state["optimizer"])
+            if graph:  # the rate of a capturable Adam is a device tensor (load_state_dict brought the saved copy)
+                for g_ in optimizer.param_groups:
+                    g_["lr"] = torch.tensor(float(g_["lr"]), device="cuda")
         if state.get("scheduler") is None:
             # train_state.pt of a round-2 fused run (format 1: the engine carried the rate, no scheduler state was written):
             # replay the epoch-end steps of the schedule, which for step / cosine depends on the epoch count alone
@@ -243,6 +259,23 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
                 # nmse = sum sq err / sum sq label; kept on the device, fetched once per epoch (no per-step host sync)
                 ep_train_losses.append((sums[0] / sums[2]).clone())
                 loss_mse = loss_nmse = None
+            elif graph:
+                from ..graph import GraphedTrainStep
+                if graphed is None and step + 1 < n_steps:  # capture on a full-size batch (never on a short last one)
+                    graphed = GraphedTrainStep(model, optimizer, batch, "nmse", restore_state=True)
+                if graphed is not None and graphed.matches(batch):
+                    loss = graphed(**batch)
+                    preds = graphed.preds
+                else:  # a batch of another shape: the same step, eagerly
+                    optimizer.zero_grad(set_to_none=False)
+                    outputs = model(**batch)
+                    loss, preds = outputs["loss"], outputs["preds"]
+                    loss["nmse"].backward()
+                    optimizer.step()
+                if step == 0 and not measure_time and rank == 0 and plot_interval > 0:
+                    plot(batch["inputs"][0][0], batch["label"][0][0], preds[0][0].detach(), Path("example.png"))
+                ep_train_losses.append(loss["nmse"].detach().clone())  # static tensor of the graph: cloned, fetched per epoch
+                loss_mse, loss_nmse = loss["mse"], loss["nmse"]
             else:
                 outputs = model(**batch)
                 if step == 0 and not measure_time and rank == 0 and plot_interval > 0:
@@ -267,7 +300,7 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
                     mse_v, nmse_v = loss_mse.item(), loss_nmse.item()
                 print(dict(ep=ep, step=step, mse=f"{mse_v:.3e}", nmse=f"{nmse_v:.3e}", lr=f"{cur_lr:.3e}",
                            time=round(time.time() - start_time)))
-        if engine is not None:
+        if engine is not None or graph:
             ep_train_losses = torch.stack(ep_train_losses).tolist() if ep_train_losses else []
         schedule.epoch_end()
         if measure_time:
@@ -357,7 +390,7 @@ def main(argv=None):
               lr_scheduler_factor=args.lr_scheduler_factor, lr_scheduler_patience=args.lr_scheduler_patience,
               early_stopping_patience=args.early_stopping_patience if args.early_stop else 0,
               early_stopping_delta=args.early_stopping_delta, gradient_accumulation_steps=args.gradient_accumulation_steps,
-              act_dtype=args.dtype)
+              act_dtype=args.dtype, graph=bool(args.graph))
     if "test" in args.mode and rank == 0:  # the test split is small: rank 0 evaluates it alone
         args.save(str(output_dir / "test_args.json"))
         load_best_ckpt(model, output_dir)

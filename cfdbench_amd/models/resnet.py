@@ -54,6 +54,8 @@ class ResidualBlock(nn.Module):
 
 
 class ResNet(AutoCfdModel):
+    graph_unsafe = True  # training-mode dropout takes a per-step host seed: the step cannot be replayed from a captured graph
+
     def __init__(self, in_chan: int, out_chan: int, n_case_params: int, loss_fn: nn.Module, hidden_chan: int = 32,
                  num_blocks: int = 4, kernel_size: int = 7, padding: int = 3, stride: int = 1):
         super().__init__(loss_fn)
