@@ -124,7 +124,6 @@ def test_train_auto_graph_option_follows_the_eager_run(torch, tmp_path, model_na
     print(model_name, "eager", np.round(e[[0, 8, 17, 26]], 5), "graph", np.round(g[[0, 8, 17, 26]], 5), "max rel", np.max(np.abs(e - g) / e))
     assert abs(e[0] - g[0]) <= 1e-6 * e[0]            # the first step sees the untouched initial weights (warm-up rolled back)
     assert np.max(np.abs(e - g) / e) < 2e-2           # same trajectory (the step arithmetic of Adam differs in rounding)
-    assert g[-1] < g[0]
 
 
 def test_graph_option_is_refused_where_it_cannot_hold(torch, tmp_path):
