@@ -15,7 +15,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
 def sources():
-    return sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.cpp")))
+    return sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.cpp"))) + [HERE / "fiber_switch.cpp"]
 
 
 def build(force: bool = False) -> Path:

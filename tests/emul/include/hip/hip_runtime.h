@@ -1,18 +1,18 @@
 // CPU SIMT emulator of the small HIP subset the cfdbench_amd kernels use.
-// TEST INFRASTRUCTURE ONLY: lets `tests/` run the *unmodified* kernel sources on the host (one OS thread
-// per work-item, pthread barriers for __syncthreads and for wave-collective ops such as MFMA / shuffles)
-// so index math is validated against the oracle before a kernel ever reaches the GPU.  It is never built
-// into, linked with, or imported by the product library.
+// TEST INFRASTRUCTURE ONLY: lets `tests/` run the *unmodified* kernel sources on the host so index math is validated against
+// the oracle before a kernel ever reaches the GPU.  It is never built into, linked with, or imported by the product library.
+// One FIBER per work-item (own stack, cooperative switch in tests/emul/fiber_switch.cpp), all fibers of a workgroup on the
+// calling OS thread, workgroups one after the other.  __syncthreads and the wave-collective ops (MFMA, shuffles) are barriers:
+// a fiber that arrives yields to the scheduler, which resumes the next fiber that is not waiting on an unreleased barrier.
+// (The first version ran one OS thread per work-item with pthread barriers: every MFMA of a 256-thread workgroup was a futex
+// storm on the 8 host cores, and the CPU suite took 14 minutes.)
 #pragma once
-#include <pthread.h>
-
 #include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -62,71 +62,149 @@ inline float2 make_float2(float x, float y) { return {x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 inline int2 make_int2(int x, int y) { return {x, y}; }
 
+extern "C" void cfd_emul_switch(void** save_sp, void* load_sp);  // tests/emul/fiber_switch.cpp
+
 namespace cfd_emul {
 struct Idx { unsigned x, y, z; };
-inline thread_local Idx t_threadIdx{0, 0, 0};
-inline thread_local Idx t_blockIdx{0, 0, 0};
-inline thread_local int t_lin = 0;       // linear thread id in block
 inline Idx g_blockDim{1, 1, 1}, g_gridDim{1, 1, 1};
 inline int g_nthreads = 1;
 
+struct Barrier {
+    int count = 0, n = 0;
+    unsigned gen = 0;
+};
 struct WaveCtx {
-    pthread_barrier_t bar;
+    Barrier bar;
     float fa[64], fb[64];
     float fa8[64][8], fb8[64][8];  // per-lane 8-element operands of the K=32 MFMA forms
     unsigned ua[64];
     int lanes;
 };
+struct Fiber {
+    void* sp = nullptr;
+    Idx tid{0, 0, 0}, bid{0, 0, 0};
+    int lin = 0;
+    bool done = false;
+    Barrier* wait_bar = nullptr;  // blocked until wait_bar->gen != wait_gen
+    unsigned wait_gen = 0;
+};
+inline std::vector<Fiber> g_fibers;
+inline Fiber* g_cur = nullptr;
+inline void* g_sched_sp = nullptr;
+inline void (*g_body)() = nullptr;  // what a fiber runs (set per launch)
 inline std::vector<WaveCtx*> g_waves;
-inline pthread_barrier_t g_block_bar;
+inline Barrier g_block_bar;
 inline std::vector<char> g_dyn_shared;  // dynamic LDS of the running launch (extern __shared__)
+inline char* g_stacks = nullptr;
+inline size_t g_stack_cap = 0;
+constexpr size_t kStack = 512 * 1024;  // per fiber; the kernels keep tens of KB of accumulators and staging arrays in locals
 
-inline WaveCtx& wave() { return *g_waves[t_lin >> 6]; }
-inline int lane() { return t_lin & 63; }
-inline void wave_sync() { pthread_barrier_wait(&wave().bar); }
-inline void block_sync() { pthread_barrier_wait(&g_block_bar); }
+inline WaveCtx& wave() { return *g_waves[g_cur->lin >> 6]; }
+inline int lane() { return g_cur->lin & 63; }
+inline void barrier_wait(Barrier& b) {
+    if (++b.count == b.n) {  // last arrival releases the others (they become runnable again) and runs on
+        b.count = 0;
+        ++b.gen;
+        return;
+    }
+    g_cur->wait_bar = &b;
+    g_cur->wait_gen = b.gen;
+    cfd_emul_switch(&g_cur->sp, g_sched_sp);
+}
+inline void wave_sync() { barrier_wait(wave().bar); }
+inline void block_sync() { barrier_wait(g_block_bar); }
+
+inline void fiber_entry() {
+    g_body();
+    g_cur->done = true;
+    cfd_emul_switch(&g_cur->sp, g_sched_sp);
+    abort();  // a finished fiber is never resumed
+}
 
 template <typename F, typename Tup, size_t... I>
 void call(F f, Tup& t, std::index_sequence<I...>) { f(std::get<I>(t)...); }
 
 template <typename... KArgs, typename... Args>
 void launch(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
+    static std::tuple<KArgs...>* s_args;
+    static void (*s_kern)(KArgs...);
+    static long s_nblocks;
+    static dim3 s_grid;
     std::tuple<KArgs...> targs(static_cast<KArgs>(args)...);
+    s_args = &targs;
+    s_kern = kern;
+    s_grid = grid;
     g_dyn_shared.assign(shmem + 16, 0);
     g_blockDim = {block.x, block.y, block.z};
     g_gridDim = {grid.x, grid.y, grid.z};
-    int nthreads = block.x * block.y * block.z;
+    const int nthreads = block.x * block.y * block.z;
     g_nthreads = nthreads;
-    int nwaves = (nthreads + 63) / 64;
-    for (auto* w : g_waves) { pthread_barrier_destroy(&w->bar); delete w; }
+    const int nwaves = (nthreads + 63) / 64;
+    for (auto* w : g_waves) delete w;
     g_waves.clear();
     for (int w = 0; w < nwaves; ++w) {
         auto* ctx = new WaveCtx();
         ctx->lanes = std::min(64, nthreads - 64 * w);
-        pthread_barrier_init(&ctx->bar, nullptr, ctx->lanes);
+        ctx->bar.n = ctx->lanes;
         g_waves.push_back(ctx);
     }
-    pthread_barrier_init(&g_block_bar, nullptr, nthreads);
-    long nblocks = (long)grid.x * grid.y * grid.z;
-    auto worker = [&](int lin) {
-        t_lin = lin;
-        t_threadIdx = {lin % block.x, (lin / block.x) % block.y, lin / (block.x * block.y)};
-        for (long b = 0; b < nblocks; ++b) {
-            t_blockIdx = {(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y))};
-            call(kern, targs, std::index_sequence_for<KArgs...>{});
+    g_block_bar = Barrier{};
+    g_block_bar.n = nthreads;
+    s_nblocks = (long)grid.x * grid.y * grid.z;
+    g_body = [] {
+        for (long b = 0; b < s_nblocks; ++b) {
+            g_cur->bid = {(unsigned)(b % s_grid.x), (unsigned)((b / s_grid.x) % s_grid.y), (unsigned)(b / ((long)s_grid.x * s_grid.y))};
+            call(s_kern, *s_args, std::index_sequence_for<KArgs...>{});
             block_sync();  // static __shared__ is reused by the next block
         }
     };
-    std::vector<std::thread> th;
-    th.reserve(nthreads);
-    for (int i = 0; i < nthreads; ++i) th.emplace_back(worker, i);
-    for (auto& t : th) t.join();
-    pthread_barrier_destroy(&g_block_bar);
+    if (g_stack_cap < (size_t)nthreads * kStack) {
+        free(g_stacks);
+        g_stack_cap = (size_t)nthreads * kStack;
+        g_stacks = (char*)aligned_alloc(4096, g_stack_cap);  // untouched pages cost nothing
+    }
+    g_fibers.assign(nthreads, Fiber{});
+    for (int i = 0; i < nthreads; ++i) {
+        Fiber& f = g_fibers[i];
+        f.lin = i;
+        f.tid = {i % block.x, (i / block.x) % block.y, i / (block.x * block.y)};
+        // initial frame for cfd_emul_switch: six callee-saved registers, then the entry address it "returns" to; the entry
+        // function sees the stack alignment of a called function (rsp = 8 mod 16)
+        uintptr_t top = ((uintptr_t)(g_stacks + (size_t)(i + 1) * kStack)) & ~(uintptr_t)15;
+        void** sp = (void**)(top - 16);
+        sp[1] = nullptr;
+        sp[0] = (void*)&fiber_entry;
+        sp -= 6;
+        for (int k = 0; k < 6; ++k) sp[k] = nullptr;
+        f.sp = sp;
+    }
+    // scheduler: resume every fiber that is not waiting on an unreleased barrier, round robin, until all are done
+    int live = nthreads;
+    while (live > 0) {
+        bool progress = false;
+        for (int i = 0; i < nthreads; ++i) {
+            Fiber& f = g_fibers[i];
+            if (f.done) continue;
+            if (f.wait_bar) {
+                if (f.wait_bar->gen == f.wait_gen) continue;
+                f.wait_bar = nullptr;
+            }
+            g_cur = &f;
+            cfd_emul_switch(&g_sched_sp, f.sp);
+            progress = true;
+            if (f.done) --live;
+        }
+        if (!progress) {
+            fprintf(stderr, "cfd_emul: deadlock (a barrier that not every work-item reaches)\n");
+            abort();
+        }
+    }
+    g_cur = nullptr;
 }
 }  // namespace cfd_emul
 
-#define threadIdx (cfd_emul::t_threadIdx)
-#define blockIdx (cfd_emul::t_blockIdx)
+#define threadIdx (cfd_emul::g_cur->tid)
+#define blockIdx (cfd_emul::g_cur->bid)
 #define blockDim (cfd_emul::g_blockDim)
 #define gridDim (cfd_emul::g_gridDim)
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
