@@ -153,7 +153,9 @@ def test_deeponet_inner(be, B, P, Kq, HW, with_q):
 
 # conv6.hip (k = 3 / 7) with two persistent workgroups (the emulator build's CFD_CONV6_GRID): several tiles, two channel chunks
 # and ragged image groups per workgroup in the (40, 20, 18) case; more shapes in test_gpu_kernels.py
-@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(1, 5, 7, 9, 10, 3), (40, 20, 18, 5, 4, 3), (2, 2, 3, 8, 9, 7), (2, 4, 4, 6, 6, 1), (9, 3, 35, 2, 9, 7)])
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(1, 5, 7, 9, 10, 3), (40, 20, 18, 5, 4, 3), (2, 2, 3, 8, 9, 7), (2, 4, 4, 6, 6, 1), (9, 3, 35, 2, 9, 7),
+                                            (3, 12, 12, 64, 64, 3), (2, 24, 12, 33, 32, 3), (20, 96, 40, 4, 4, 3), (2, 16, 64, 20, 21, 7),
+                                            (9, 64, 2, 17, 16, 7)])
 def test_conv2d_replicate(be, B, Ci, Co, H, W, ks):
     _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, ks))
 
