@@ -33,7 +33,7 @@ def test_spectral_fwd_bwd_fused_route(be):
     _assert_all(K.check_spectral(be, 1, 20, 20, 64, 64))
 
 
-@pytest.mark.parametrize("B,Cin,Cout", [(3, 20, 20), (9, 12, 7), (2, 32, 32)])  # more shapes: test_gpu_kernels.py (the emulator runs one OS thread per lane: sizes kept small)
+@pytest.mark.parametrize("B,Cin,Cout", [(3, 20, 20), (9, 12, 7), (2, 32, 32), (37, 20, 20), (16, 8, 24)])
 def test_mix_and_spectral_wgrad(be, B, Cin, Cout):
     _assert_all(K.check_mix_wgrad(be, B, Cin, Cout))
 
@@ -47,7 +47,8 @@ def test_mix_and_spectral_wgrad_multi_step(be, want_wg, nwv, B, C):
         _assert_all(K.check_mix_wgrad(be, B, C, C))
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 20, 20, 64, 64), (1, 6, 7, 32, 64), (1, 3, 5, 66, 65), (1, 32, 12, 32, 64)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 20, 20, 64, 64), (1, 6, 7, 32, 64), (1, 3, 5, 66, 65), (1, 32, 12, 32, 64), (5, 20, 20, 64, 64),
+                                            (3, 24, 21, 64, 64), (2, 20, 20, 66, 65), (3, 12, 16, 48, 64)])
 def test_fused_block(be, B, Cin, Cout, H, W):
     _assert_all(K.check_block(be, B, Cin, Cout, H, W))
 
@@ -66,7 +67,7 @@ def test_idft_epilogues(be, H, W):
     _assert_all(K.check_idft_epilogues(be, 3, H, W))
 
 
-@pytest.mark.parametrize("Ci,Co,HW,act", [(20, 20, 256, True), (6, 8, 66 * 5, False), (32, 32, 64, True)])
+@pytest.mark.parametrize("Ci,Co,HW,act", [(20, 20, 256, True), (6, 8, 66 * 5, False), (32, 32, 64, True), (20, 20, 4096, True), (32, 32, 4290, False)])
 def test_chanmix_and_wgrad(be, Ci, Co, HW, act):
     _assert_all(K.check_chanmix(be, 2, Ci, Co, HW, act))
 
@@ -106,7 +107,7 @@ def test_loss_and_adam(be):
     assert res["adam_delta"] < 1e-9
 
 
-@pytest.mark.parametrize("C,L,H,W,border", [(5, 1, 64, 64, False), (6, 2, 34, 33, True)])
+@pytest.mark.parametrize("C,L,H,W,border", [(5, 1, 64, 64, False), (6, 2, 34, 33, True), (20, 4, 64, 64, False), (32, 2, 66, 65, True)])
 def test_fno_whole_model(be, C, L, H, W, border):
     res = K.check_fno_vs_oracle(be, 1, C, L, H, W, border=border)
     loss_err = res.pop("nmse_loss")
@@ -133,7 +134,8 @@ def test_gemm(be, M, N, Kd, ta, tb):
     _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
 
 
-@pytest.mark.parametrize("R,dims,act,act_last,with_gx", [(70, [5, 12, 20, 7], "relu", False, True), (33, [3, 17, 9], "gelu", True, False)])
+@pytest.mark.parametrize("R,dims,act,act_last,with_gx", [(70, [5, 12, 20, 7], "relu", False, True), (33, [3, 17, 9], "gelu", True, False),
+                                                          (300, [100, 100, 100, 100, 100], "relu", False, True), (130, [7, 128, 64, 100], "tanh", True, True)])
 def test_ffn_stack(be, R, dims, act, act_last, with_gx):
     """A whole Linear(+activation) stack per kernel (cfd_ffn_stack_fwd / _bwd) against the fp64 layer-by-layer restatement."""
     _assert_all(K.check_ffn_stack(be, R, dims, act, act_last, with_gx))
@@ -160,12 +162,13 @@ def test_conv2d_replicate(be, B, Ci, Co, H, W, ks):
     _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, ks))
 
 
-@pytest.mark.parametrize("B,C,H,W,training,relu", [(2, 3, 6, 7, True, True), (2, 3, 4, 4, False, True), (3, 2, 5, 5, True, False)])
+@pytest.mark.parametrize("B,C,H,W,training,relu", [(2, 3, 6, 7, True, True), (2, 3, 4, 4, False, True), (3, 2, 5, 5, True, False), (4, 12, 64, 64, True, True),
+                                                    (9, 48, 4, 4, True, True)])
 def test_batchnorm_relu(be, B, C, H, W, training, relu):
     _assert_all(K.check_batchnorm(be, B, C, H, W, training, relu))
 
 
-@pytest.mark.parametrize("B,Ci,Co,H,W", [(1, 3, 5, 6, 8), (2, 2, 3, 5, 5)])
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(1, 3, 5, 6, 8), (2, 2, 3, 5, 5), (3, 24, 12, 16, 16), (2, 50, 7, 4, 4)])
 def test_pool_convtranspose_residual(be, B, Ci, Co, H, W):
     res = K.check_pool_convt_resid(be, B, Ci, Co, H, W)
     assert res.pop("pool") == 0.0 and res.pop("pool_bwd") == 0.0  # selections, not arithmetic: exact
