@@ -83,10 +83,8 @@ __device__ __forceinline__ void head_act(float (&h)[CQ][4]) {
     for (int c = 0; c < CQ; ++c) cfd_gelu4(h[c][0], h[c][1], h[c][2], h[c][3]);
 }
 
-// split-bf16 A-operand fragments of fc1 for z = W1 h:  frag[mt][lane=(q,i)][v] = w1[16mt+i][CQ q + v]  (v < CQ), in THREE pieces
-// (hi + lo + lo2 = the fp32 weight exactly): W1 is the same in every step of a rollout, so -- like the twiddle tables and the 1x1
-// weights (cfd_common.h: CFD_TW) -- its rounding would be a coherent perturbation of the operator, not noise
-__device__ __forceinline__ void head_build_w1f(bf16x8* s_hi, bf16x8* s_lo, bf16x8* s_lo2, const float* __restrict__ w1, int C, int CQ) {
+// split-bf16 A-operand fragments of fc1 for z = W1 h:  frag[mt][lane=(q,i)][v] = w1[16mt+i][CQ q + v]  (v < CQ)
+__device__ __forceinline__ void head_build_w1f(bf16x8* s_hi, bf16x8* s_lo, const float* __restrict__ w1, int C, int CQ) {
     for (int idx = threadIdx.x; idx < HEAD_MT * 64; idx += blockDim.x) {
         const int ln = idx & 63, mt = idx >> 6;
         const int jh = 16 * mt + (ln & 15), c0 = CQ * (ln >> 4);
@@ -96,10 +94,6 @@ __device__ __forceinline__ void head_build_w1f(bf16x8* s_hi, bf16x8* s_lo, bf16x
         const CfdSplit8 s = cfd_split8(x);
         s_hi[idx] = s.hi;
         s_lo[idx] = s.lo;
-        float x3[8];
-#pragma unroll
-        for (int v = 0; v < 8; ++v) x3[v] = (x[v] - (float)s.hi[v]) - (float)s.lo[v];  // exact: what two pieces miss
-        s_lo2[idx] = cfd_split8(x3).hi;
     }
 }
 
@@ -109,7 +103,7 @@ __global__ __launch_bounds__(256, CQ == 8 ? CFD_HF_OCC8 : 3) void k_head_fwd(con
                                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                                   const float* __restrict__ b2, float* __restrict__ preds,
                                                   float* __restrict__ part, int B, int C, int Co, int HW) {
-    __shared__ bf16x8 s_w1hi[HEAD_MT * 64], s_w1lo[HEAD_MT * 64], s_w1lo2[HEAD_MT * 64];
+    __shared__ bf16x8 s_w1hi[HEAD_MT * 64], s_w1lo[HEAD_MT * 64];
     __shared__ __attribute__((aligned(16))) float s_b1[HEAD_HD];
     // fc2 weights by PAIRS of hidden units: a packed FMA multiplies the GELU pair (g[jh], g[jh+1]) by (w2[c][jh], w2[c][jh+1]) with
     // plain operands.  (Round 2 paired the two OUTPUTS instead and broadcast one g through the instruction's operand select,
@@ -117,7 +111,7 @@ __global__ __launch_bounds__(256, CQ == 8 ? CFD_HF_OCC8 : 3) void k_head_fwd(con
     // 48-63 -- profiles/r03_det_root_cause.md.)
     __shared__ __attribute__((aligned(16))) cfd_f2 s_w2[HEAD_HD];
     __shared__ float s_red[12];
-    head_build_w1f(s_w1hi, s_w1lo, s_w1lo2, w1, C, CQ);
+    head_build_w1f(s_w1hi, s_w1lo, w1, C, CQ);
     for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x) s_b1[i] = b1[i];
     for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x)  // per PAIR of hidden units (2p, 2p+1): [w2[0][2p], w2[0][2p+1]], [w2[1][2p], w2[1][2p+1]]
         s_w2[i] = (i & 1) ? (Co > 1 ? cfd_f2{w2[HEAD_HD + i - 1], w2[HEAD_HD + i]} : cfd_f2{0.f, 0.f}) : cfd_f2{w2[i], w2[i + 1]};
@@ -186,9 +180,7 @@ CFD_UNROLL(CFD_HF_UNROLL)
                 const float4 bq = *reinterpret_cast<const float4*>(s_b1 + jb);  // one ds_read_b128 (16-byte aligned)
                 z[mt] = f32x4{bq.x, bq.y, bq.z, bq.w};
             }
-            // z += W1 h as w_lo2*h_hi + w_lo*h_hi + w_hi*h_lo + w_hi*h_hi, strictly term-major: consecutive MFMAs hit different accumulators
-#pragma unroll
-            for (int mt = 0; mt < HEAD_MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(s_w1lo2[mt * 64 + lo], bs.hi, z[mt]);
+            // z += W1 h as w_lo*h_hi + w_hi*h_lo + w_hi*h_hi, strictly term-major: consecutive MFMAs hit different accumulators
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(s_w1lo[mt * 64 + lo], bs.hi, z[mt]);
 #pragma unroll
