@@ -99,8 +99,10 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
           lr_step_size: int = 1, lr_gamma: float = 0.9, batch_size: int = 64, log_interval: int = 50,
           eval_interval: int = 2, measure_time: bool = False, plot_interval: int = 1, resume: bool = False,
           lr_scheduler_kind: str = "step", lr_scheduler_factor: float = 0.5, lr_scheduler_patience: int = 5,
-          early_stopping_patience: int = 0, early_stopping_delta: float = 1e-5, gradient_accumulation_steps: int = 1):
+          early_stopping_patience: int = 0, early_stopping_delta: float = 1e-5, gradient_accumulation_steps: int = 1,
+          graph: bool = False):
     """src/train.py:148-253: fwd -> ``loss["nmse"].backward()`` -> Adam -> zero_grad; StepLR per epoch.
+    ``graph``: the step replayed from one HIP graph (harness/train_auto.py:train has the semantics; one process, no accumulation).
     ``resume``: continue from ``train_state.pt`` (see harness/train_auto.py:train).  ``lr_scheduler_kind`` /
     ``early_stopping_patience`` / ``gradient_accumulation_steps``: the same options, with the same semantics, as
     harness/train_auto.py:train (harness/schedule.py); the defaults are the reference's loop."""
@@ -116,11 +118,17 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
     loader = make_loader(0)
     if rank == 0:
         output_dir.mkdir(exist_ok=True, parents=True)
-    optimizer = Adam(model.parameters(), lr=lr)
+    accum = max(1, int(gradient_accumulation_steps))
+    if graph:
+        if world > 1 or accum > 1:
+            raise NotImplementedError("--graph 1 needs one process and gradient_accumulation_steps == 1")
+        optimizer = Adam(model.parameters(), lr=torch.tensor(float(lr), device="cuda"), capturable=True)
+    else:
+        optimizer = Adam(model.parameters(), lr=lr)
+    graphed = None
     schedule = LrSchedule(lr_scheduler_kind, lr, num_epochs, optimizer, lr_step_size=lr_step_size, lr_gamma=lr_gamma,
                           factor=lr_scheduler_factor, patience=lr_scheduler_patience)
     stopper = EarlyStopping(early_stopping_patience, early_stopping_delta)
-    accum = max(1, int(gradient_accumulation_steps))
     start_time = time.time()
     global_step = 0
     all_train_losses: List[float] = []
@@ -131,6 +139,9 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
         check_resume_state(state, fused=False, world=world)
         model.load_state_dict(torch.load(output_dir / state["ckpt"] / "model.pt", map_location="cpu"))
         optimizer.load_state_dict(state["optimizer"])
+        if graph:  # the rate of a capturable Adam is a device tensor
+            for g_ in optimizer.param_groups:
+                g_["lr"] = torch.tensor(float(g_["lr"]), device="cuda")
         if "sched" in state["scheduler"]:
             schedule.load_state_dict(state["scheduler"])
         else:  # format 1 (round 2): the bare StepLR state
@@ -150,6 +161,20 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
         n_steps = len(loader)
         n_full = (n_steps // accum) * accum
         for step, batch in enumerate(loader):
+            if graph:
+                from ..graph import GraphedTrainStep
+                if graphed is None and step + 1 < n_steps:  # capture on a full-size batch
+                    graphed = GraphedTrainStep(model, optimizer, batch, "nmse", restore_state=True)
+                if graphed is not None and graphed.matches(batch):
+                    loss = graphed(**batch)["nmse"]
+                else:
+                    optimizer.zero_grad(set_to_none=False)
+                    loss = model(**batch)["loss"]["nmse"]
+                    loss.backward()
+                    optimizer.step()
+                ep_train_losses.append(loss.detach().clone())  # fetched once per epoch
+                global_step += 1
+                continue
             loss = model(**batch)["loss"]["nmse"]
             group = accum if step < n_full else n_steps - n_full  # the epoch's trailing group may be shorter
             (loss / group if group > 1 else loss).backward()
@@ -164,6 +189,8 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
                 avg_loss = sum(ep_train_losses) / (len(ep_train_losses) + 1e-5)
                 print(dict(ep=ep, step=step, loss=f"{avg_loss:.3e}", lr=f"{schedule.lr:.3e}",
                            time=round(time.time() - start_time)))
+        if graph:
+            ep_train_losses = torch.stack(ep_train_losses).tolist() if ep_train_losses else []
         if measure_time:
             print("Time usage:", time.time() - ep_start_time)
             return all_train_losses + ep_train_losses
@@ -280,7 +307,8 @@ def main(argv=None):
               resume=bool(args.resume), lr_scheduler_kind=args.lr_scheduler, lr_scheduler_factor=args.lr_scheduler_factor,
               lr_scheduler_patience=args.lr_scheduler_patience,
               early_stopping_patience=args.early_stopping_patience if args.early_stop else 0,
-              early_stopping_delta=args.early_stopping_delta, gradient_accumulation_steps=args.gradient_accumulation_steps)
+              early_stopping_delta=args.early_stopping_delta, gradient_accumulation_steps=args.gradient_accumulation_steps,
+              graph=bool(args.graph))
     if "test" in args.mode and rank == 0:
         args.save(str(output_dir / "test_args.json"))
         load_best_ckpt(model, output_dir)

@@ -126,6 +126,30 @@ def test_train_auto_graph_option_follows_the_eager_run(torch, tmp_path, model_na
     assert np.max(np.abs(e - g) / e) < 2e-2           # same trajectory (the step arithmetic of Adam differs in rounding)
 
 
+@pytest.mark.parametrize("model_name", ["deeponet", "ffn"])
+def test_nonauto_train_graph_option(torch, tmp_path, model_name):
+    """train.py --graph 1 (non-autoregressive DeepONet / FFN): the captured step draws fresh query points on every replay (torch's
+    CUDA generator is graph-safe), the loss falls and the artefacts are the eager loop's.  (No curve comparison: the warm-up
+    before the capture consumes random numbers, so the two runs see different query points.)"""
+    from cfdbench_amd.harness.args import Args
+    from cfdbench_amd.harness.common import get_output_dir, load_json
+    from cfdbench_amd.harness.train import SyntheticDataset, init_model, train
+    args = Args(model=model_name, data_name="cavity_prop_bc_geo", loss_name="nmse", deeponet_width=32, branch_depth=3,
+                trunk_depth=3, ffn_width=32, ffn_depth=3, lr=2e-3, output_dir=str(tmp_path), num_epochs=6, batch_size=4,
+                eval_interval=3, log_interval=5, plot_interval=0, graph=1)
+    out = get_output_dir(args)
+    tr, dev = SyntheticDataset(4, 6, 16, 16, seed=0), SyntheticDataset(2, 3, 16, 16, seed=1)
+    torch.manual_seed(0)
+    model = init_model(args).cuda()
+    model.num_label_samples = 200
+    losses = train(model, tr, dev, out, num_epochs=args.num_epochs, lr=args.lr, batch_size=args.batch_size,
+                   eval_interval=args.eval_interval, log_interval=args.log_interval, plot_interval=0, graph=True)
+    assert len(losses) == 6 * 6 and np.all(np.isfinite(losses))
+    assert len(set(np.round(losses[:6], 9))) == 6, "every replay must see freshly drawn query points"
+    assert np.mean(losses[-6:]) < np.mean(losses[:6]), "training does not reduce the nMSE"
+    assert (out / "ckpt-5" / "model.pt").exists() and set(load_json(out / "ckpt-5" / "scores.json")) == {"ep", "train_loss", "dev_loss", "time"}
+
+
 def test_graph_option_is_refused_where_it_cannot_hold(torch, tmp_path):
     from cfdbench_amd.harness.args import Args, is_args_valid
     for bad in (dict(model="resnet"), dict(model="fno", fused=1), dict(model="unet", gradient_accumulation_steps=2)):
