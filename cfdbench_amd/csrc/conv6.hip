@@ -627,7 +627,7 @@ static Wg6Plan wg6_plan(const ConvGeom& g) {
     if (g.ks != 3 && g.ks != 7) return P;
     const int KS = g.ks, NKY = KS == 3 ? 3 : 2;  // k = 7: tap rows {0,1}, {2,3}, {4,5}, {6}: 14 column tiles per output-channel tile
     Wg6Tile& t = P.t;
-    t.TW = g.W >= 8 ? 8 : 4;
+    t.TW = (g.W >= 8 || KS == 7) ? 8 : 4;  // (k = 7 on 4 x 4 tiles would stage a 5 x 10 halo: more than the three items per thread)
     t.TH = 16 / t.TW;
     t.tw_shift = t.TW == 8 ? 3 : 2;
     t.tiles_x = (g.W + t.TW - 1) / t.TW;
@@ -657,7 +657,7 @@ static Wg6Plan wg6_plan(const ConvGeom& g) {
     const size_t red = (size_t)4 * (KS == 3 ? 9 : 7) * 256 * sizeof(float);
     P.lds = stage > red ? stage : red;
     P.part_bytes = cfd_align_up((size_t)P.groups * g.Co * g.Ci * KS * KS * sizeof(float), 256);
-    P.ok = P.lds <= 150 * 1024 && (long)g.B * g.Ci * g.H * g.W < (1L << 30) && (long)g.B * g.Co * g.H * g.W < (1L << 30);  // 32-bit byte offsets
+    P.ok = P.lds <= 150 * 1024 && t.HP * 16 <= 3 * 256 && (long)g.B * g.Ci * g.H * g.W < (1L << 30) && (long)g.B * g.Co * g.H * g.W < (1L << 30);  // 32-bit byte offsets
     return P;
 }
 

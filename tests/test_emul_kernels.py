@@ -195,3 +195,36 @@ def test_broadcast_add_and_rowdot(be, B, Kq, P):
 @pytest.mark.parametrize("act", ["relu", "tanh", "gelu", "swish"])
 def test_standalone_activation(be, act):
     _assert_all(K.check_act(be, 1000, act))
+
+
+def test_conv2d_random_shapes(be):
+    """Seeded sweep over 45 random (batch, channels, image, kernel size, persistent-grid) combinations of the k = 3 / 7 convolution
+    kernels (conv6.hip), degenerate images included (1 x W, H x 1, smaller than the kernel, fewer images than a group of 8).
+    Found in round 3: the k = 7 weight gradient on 4 x 4 tiles staged a halo larger than its per-thread item budget."""
+    import random
+    rnd = random.Random(20260927)
+    shapes = [(8, 16, 40, 1, 4, 7, 1), (3, 24, 40, 2, 1, 7, 2), (2, 17, 16, 3, 1, 7, 8)]  # the three cases that exposed it
+    while len(shapes) < 45:
+        shapes.append((rnd.choice([1, 2, 3, 5, 8, 9, 17]), rnd.choice([1, 2, 5, 8, 9, 16, 17, 24, 33]), rnd.choice([1, 2, 7, 12, 16, 17, 31, 40]),
+                       rnd.choice([1, 2, 3, 4, 5, 8, 13, 16, 33]), rnd.choice([1, 2, 3, 4, 7, 8, 9, 17, 32, 40]), rnd.choice([3, 3, 7]),
+                       rnd.choice([-1, 1, 2, 3, 8])))
+    for i, (B, Ci, Co, H, W, ks, grid) in enumerate(shapes):
+        with K.tuned(be, conv6_grid=grid):
+            res = K.check_conv2d(be, B, Ci, Co, H, W, ks, seed=100 + i)
+        bad = {k: v for k, v in res.items() if not (v < 1e-10)}
+        assert not bad, ((B, Ci, Co, H, W, ks, grid), bad)
+
+
+def test_dense_and_norm_kernels_random_shapes(be):
+    """The same kind of sweep for BatchNorm, the fused Linear stacks, the GEMM and the 1x1 conv / its weight gradient."""
+    import random
+    rnd = random.Random(7)
+    R = rnd.choice
+    for it in range(10):
+        B, C, H, W = R([1, 2, 3, 5, 9]), R([1, 2, 3, 7, 12, 17, 24, 33, 48]), R([1, 2, 3, 4, 6, 9, 16]), R([1, 2, 3, 4, 5, 8, 9, 16])
+        _assert_all(K.check_batchnorm(be, B, C, H, W, R([True, False]), R([True, False]), seed=it))
+        dims = [R([1, 2, 3, 7, 16, 33, 100, 128]) for _ in range(R([2, 3, 4, 6]))]
+        _assert_all(K.check_ffn_stack(be, R([1, 5, 16, 17, 33, 70, 129]), dims, R(["relu", "gelu", "tanh"]), R([True, False]), R([True, False]), seed=it))
+        _assert_all(K.check_gemm(be, R([1, 5, 16, 17, 40, 100]), R([1, 3, 16, 21, 64, 100]), R([1, 2, 5, 19, 37, 130]), R([0, 1]), R([0, 1]), seed=it))
+        _assert_all(K.check_chanmix(be, B, R([1, 2, 6, 8, 9, 16, 20, 24, 32]), R([1, 3, 8, 9, 16, 20, 25, 32]), R([1, 2, 5, 63, 64, 65, 130, 330]),
+                                    R([True, False]), seed=it))
