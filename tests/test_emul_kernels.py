@@ -228,3 +228,19 @@ def test_dense_and_norm_kernels_random_shapes(be):
         _assert_all(K.check_gemm(be, R([1, 5, 16, 17, 40, 100]), R([1, 3, 16, 21, 64, 100]), R([1, 2, 5, 19, 37, 130]), R([0, 1]), R([0, 1]), seed=it))
         _assert_all(K.check_chanmix(be, B, R([1, 2, 6, 8, 9, 16, 20, 24, 32]), R([1, 3, 8, 9, 16, 20, 25, 32]), R([1, 2, 5, 63, 64, 65, 130, 330]),
                                     R([True, False]), seed=it))
+
+
+def test_fno_kernels_random_shapes(be):
+    """Seeded sweep over grids (16 .. 70 x 16 .. 80, the 64-wide and the general-width kernels), kept modes and channel counts for the
+    transforms, the mode-domain kernels, the FnoBlock and the inverse-transform epilogues."""
+    import random
+    rnd = random.Random(11)
+    R = rnd.choice
+    for it in range(6):
+        H, W = R([16, 24, 32, 33, 48, 64, 65, 66, 70]), R([16, 17, 32, 33, 48, 64, 65, 72, 80])
+        m1, m2 = min(R([1, 2, 4, 7, 8, 12]), H // 2), min(R([1, 2, 5, 8, 12]), W // 2)
+        B, Ci, Co = R([1, 2, 3, 5]), R([1, 3, 8, 12, 20, 21, 24, 32]), R([1, 2, 7, 16, 20, 25, 32])
+        _assert_all(K.check_spectral(be, B, Ci, Co, H, W, m1, m2, seed=it), 1e-9)
+        _assert_all(K.check_block(be, B, Ci, Co, H, W, m1, m2, seed=it), 1e-9)
+        _assert_all(K.check_idft_epilogues(be, 3 * B, H, W, m1, m2, seed=it), 1e-9)
+        _assert_all(K.check_mix_wgrad(be, R([1, 3, 9, 17, 30]), Ci, Co, m1, m2, H, W, seed=it), 1e-9)
