@@ -294,7 +294,7 @@ def unet_bytes_per_frame(dim, cin, H, W):
 
 
 def model_train_leg(api, name, model, batch, steps, warmup, frames, bytes_per_frame, what):
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True)  # torch's single-kernel multi-tensor Adam
     from cfdbench_amd.graph import GraphedTrainStep
 
     def eager():

@@ -203,7 +203,9 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
         if world > 1 or accum > 1 or getattr(model, "graph_unsafe", False):
             raise NotImplementedError("--graph 1 needs one process, gradient_accumulation_steps == 1 and a model without per-step "
                                       "host state (the ResNet's dropout seed)")
-        optimizer = Adam(model.parameters(), lr=torch.tensor(float(lr), device="cuda"), capturable=True)
+        # fused: ONE multi-tensor kernel per step (the capturable foreach form with a device-resident rate takes ~2.7 ms for the U-Net's
+        # 136 tensors, tools/exp/adam_fused_ab.py); same formula, results within rounding of the foreach form
+        optimizer = Adam(model.parameters(), lr=torch.tensor(float(lr), device="cuda"), capturable=True, fused=True)
     else:
         optimizer = Adam(model.parameters(), lr=lr)
     graphed = None

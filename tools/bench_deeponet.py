@@ -27,7 +27,7 @@ def main():
     H, W, p, B = 66, 65, 5, a.batch
     torch.manual_seed(0)
     m = AutoDeepONet(H * W + p, 2, loss_name_to_fn("nmse"), branch_depth=8, trunk_depth=8, width=100).cuda()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=a.graph)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=a.graph, fused=True)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, 2, H, W, generator=g).cuda()
     y = (x.cpu() + 0.1 * torch.randn(B, 2, H, W, generator=g)).cuda()

@@ -26,7 +26,7 @@ def main():
     H, W, p, B = 64, 64, 8, a.batch
     torch.manual_seed(0)
     m = UNet(2, 2, loss_name_to_fn("nmse"), p, insert_case_params_at="input", dim=12).cuda()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=a.graph)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=a.graph, fused=True)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, 2, H, W, generator=g).cuda()
     y = (x.cpu() + 0.1 * torch.randn(B, 2, H, W, generator=g)).cuda()

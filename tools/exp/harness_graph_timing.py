@@ -1,0 +1,33 @@
+"""GPU box: wall time per training step of harness/train_auto.py:train on the U-Net (dim 12, B = 128, 64x64), eager vs --graph 1."""
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
+from cfdbench_amd.harness.args import Args  # noqa: E402
+from cfdbench_amd.harness.autoregressive import init_model  # noqa: E402
+from cfdbench_amd.harness.data import SyntheticAutoDataset  # noqa: E402
+from cfdbench_amd.harness.train_auto import train  # noqa: E402
+
+model_name = sys.argv[1] if len(sys.argv) > 1 else "unet"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+tr = SyntheticAutoDataset(n_cases=B // 4 + 1, n_frames=21, height=64, width=64, seed=0)  # >= 5 B frames
+dev = SyntheticAutoDataset(n_cases=2, n_frames=3, height=64, width=64, seed=1)
+for graph in (0, 1):
+    with tempfile.TemporaryDirectory() as td:
+        args = Args(model=model_name, data_name="cavity_bc", loss_name="nmse", output_dir=td, batch_size=B, graph=graph, unet_dim=12)
+        torch.manual_seed(0)
+        model = init_model(args).cuda()
+        n_steps = len(tr) // B
+        train(model, tr, dev, Path(td) / "w", num_epochs=1, lr=1e-3, batch_size=B, eval_interval=100, log_interval=10 ** 9, plot_interval=0,
+              graph=bool(graph), device_loader=True)  # warm-up epoch (capture included)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        train(model, tr, dev, Path(td) / "t", num_epochs=3, lr=1e-3, batch_size=B, eval_interval=100, log_interval=10 ** 9, plot_interval=0,
+              graph=bool(graph), device_loader=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"{model_name} B={B} graph={graph}: {dt / (3 * ((len(tr) + B - 1) // B)) * 1e3:.2f} ms per step (wall, incl. loader, {3 * ((len(tr) + B - 1) // B)} steps)")
