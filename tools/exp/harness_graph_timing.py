@@ -14,7 +14,7 @@ from cfdbench_amd.harness.train_auto import train  # noqa: E402
 
 model_name = sys.argv[1] if len(sys.argv) > 1 else "unet"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-tr = SyntheticAutoDataset(n_cases=B // 4 + 1, n_frames=21, height=64, width=64, seed=0)  # >= 5 B frames
+tr = SyntheticAutoDataset(n_cases=B // 2, n_frames=61, height=64, width=64, seed=0)  # 30 B frames: 30 steps per epoch
 dev = SyntheticAutoDataset(n_cases=2, n_frames=3, height=64, width=64, seed=1)
 for graph in (0, 1):
     with tempfile.TemporaryDirectory() as td:
