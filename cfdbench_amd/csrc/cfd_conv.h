@@ -22,7 +22,7 @@ void cfd_conv_tile_shape(int Hd, int Wd, int B, int& TW, int& TH, int& NB);
 int cfd_conv_splitk_sum(const float* part, const float* bias, float* out, long n, int nz, int Cm, long HWd, hipStream_t st,
                         const char* what);
 // out[e] = sum_chunk part[chunk][e] in a fixed order (conv.hip)
-void cfd_conv_part_reduce(const float* part, float* out, long n, int nchunk, hipStream_t st);
+void cfd_conv_part_reduce(const float* part, float* out, long n, int nchunk, hipStream_t st, float* out2 = nullptr, long n1 = 0);
 
 // ---- conv6.hip: k = 3 / k = 7 on three-piece split-bf16 operands (fp32-exact pieces, six bf16 MFMAs per product) ----
 // forward (ext = false: dst (B,Co,H,W) = conv(src (B,Ci,H,W)) + bias) and the transposed-valid pass of the input gradient
@@ -37,4 +37,6 @@ int cfd_conv6_run(const float* src, const float* w, const float* bias, float* ds
 // weight gradient gw (Co,Ci,ks,ks) = sum over (b, p) of gout[b][o][p] * in[b][i][clamp(p + tap)]
 bool cfd_conv6_wgrad_covers(const ConvGeom& g);
 size_t cfd_conv6_wgrad_ws_bytes(const ConvGeom& g);
-int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, void* ws, const ConvGeom& g, hipStream_t st, const char* what);
+// gb != NULL: the bias gradient gb (Co) = sum over (b, p) of gout rides in the same launches (the gradient tile is staged anyway)
+int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, float* gb, void* ws, const ConvGeom& g, hipStream_t st,
+                    const char* what);

@@ -373,7 +373,8 @@ static void wgrad_plan(long total_px, int R, int J, long& chunk_px, int& nchunk)
 // weight tensor and ~1000 partial slices (the wide, shallow U-Net levels) would otherwise leave each of a handful of
 // threads a serial chain of 1000 dependent-latency loads (measured 60 us for 1296 outputs).
 template <int G>
-__global__ __launch_bounds__(256) void k_part_reduce(const float* __restrict__ part, float* __restrict__ out, long n, int nchunk) {
+__global__ __launch_bounds__(256) void k_part_reduce(const float* __restrict__ part, float* __restrict__ out, long n, int nchunk,
+                                                     float* __restrict__ out2, long n1) {
     constexpr int E = 256 / G;
     __shared__ float s_p[256];
     const int el = threadIdx.x % E, grp = threadIdx.x / E;
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256) void k_part_reduce(const float* __restrict__ p
             for (; c < nchunk; c += G) s += part[(size_t)c * n + e];
         }
         if (G == 1) {
-            if (e < n) out[e] = s;
+            if (e < n) { if (e < n1) out[e] = s; else out2[e - n1] = s; }
         } else {
             s_p[threadIdx.x] = s;
             __syncthreads();
@@ -398,26 +399,29 @@ __global__ __launch_bounds__(256) void k_part_reduce(const float* __restrict__ p
                 float tot = 0.f;
 #pragma unroll
                 for (int k = 0; k < G; ++k) tot += s_p[k * E + el];
-                out[e] = tot;
+                if (e < n1) out[e] = tot; else out2[e - n1] = tot;
             }
             __syncthreads();
         }
     }
 }
 
-void cfd_conv_part_reduce(const float* part, float* out, long n, int nchunk, hipStream_t st) {
+// elements [0, n1) of a partial slice go to out, elements [n1, n) to out2 (the conv6 weight gradient carries the bias gradient behind
+// the weights); out2 == NULL: n1 = n
+void cfd_conv_part_reduce(const float* part, float* out, long n, int nchunk, hipStream_t st, float* out2, long n1) {
+    if (!out2) n1 = n;
     if (nchunk >= 128) {
         long blocks = (n + 15) / 16;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL((k_part_reduce<16>), dim3((unsigned)blocks), dim3(256), 0, st, part, out, n, nchunk);
+        hipLaunchKernelGGL((k_part_reduce<16>), dim3((unsigned)blocks), dim3(256), 0, st, part, out, n, nchunk, out2, n1);
     } else if (nchunk >= 24) {
         long blocks = (n + 63) / 64;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL((k_part_reduce<4>), dim3((unsigned)blocks), dim3(256), 0, st, part, out, n, nchunk);
+        hipLaunchKernelGGL((k_part_reduce<4>), dim3((unsigned)blocks), dim3(256), 0, st, part, out, n, nchunk, out2, n1);
     } else {
         long blocks = (n + 255) / 256;
         if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL((k_part_reduce<1>), dim3((unsigned)blocks), dim3(256), 0, st, part, out, n, nchunk);
+        hipLaunchKernelGGL((k_part_reduce<1>), dim3((unsigned)blocks), dim3(256), 0, st, part, out, n, nchunk, out2, n1);
     }
 }
 
@@ -488,7 +492,8 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
     }
     if (gw && cfd_conv6_wgrad_covers(g)) {
         CFD_PROF_W("k_conv_wgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci * ks * ks), 2.0 * B * HW * (double)Co * Ci * ks * ks);
-        CFD_TRY(cfd_conv6_wgrad(gout, in, gw, ws, g, st, "cfd_conv2d_bwd(wgrad)"));
+        CFD_TRY(cfd_conv6_wgrad(gout, in, gw, gb, ws, g, st, "cfd_conv2d_bwd(wgrad)"));
+        gb = nullptr;  // done in the same launches
     } else if (gw) {
         long chunk_px;
         int nchunk;

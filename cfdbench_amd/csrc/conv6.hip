@@ -445,7 +445,7 @@ struct Wg6Tile {
 
 template <int KS, int MT, int NKY>
 __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict__ gout, const float* __restrict__ in,
-                                                        float* __restrict__ part, ConvGeom g, Wg6Tile t, int ntiles) {
+                                                        float* __restrict__ part, ConvGeom g, Wg6Tile t, int ntiles, int want_gb) {
     constexpr int KK = KS * KS, PAD = KS / 2, NT = NKY * KS, NKG = (KS + NKY - 1) / NKY;
     constexpr int NIW = 3;  // halo items per thread: HP * 16 <= 768 (HP <= 40 for k = 3, 42 for k = 7 with NKY = 2)
     CFD_DYN_SHARED(u4, s_dyn);
@@ -487,6 +487,12 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
         gch[k] = 4u * (unsigned)((mbase + o < g.Co ? mbase + o : g.Co - 1) * HW);
         glds[k] = 48u * (unsigned)((p2 * MT + (o >> 4)) * 16 + (((o & 15) + p2) & 15));
     }
+    // bias gradient gb[o] = sum over (b, p) of gout[b][o][p]: the workgroups of the first channel chunk and tap-row group add up the
+    // gradient items they stage anyway (one item = 8 images of one pixel; the 16 pixels of a channel sit in 16 consecutive lanes)
+    const bool do_gb = want_gb && blockIdx.y == 0 && ky0 == 0;
+    float gbacc[MT];
+#pragma unroll
+    for (int k = 0; k < MT; ++k) gbacc[k] = 0.f;
     // the next tile's global loads wait in registers while this tile's MFMAs run (see k_conv6); all of them unconditional from
     // clamped addresses (uniform image pointer + 32-bit byte offset)
     float dri[NIW][8], drg[MT][8];
@@ -544,6 +550,14 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
         for (int k = 0; k < MT; ++k) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) drg[k][j] = j < gok[k] ? drg[k][j] : 0.f;
+            if (do_gb) {  // (uniform per workgroup)
+                float sg = ((drg[k][0] + drg[k][1]) + (drg[k][2] + drg[k][3])) + ((drg[k][4] + drg[k][5]) + (drg[k][6] + drg[k][7]));
+                sg += cfd_shfl_xor(sg, 1);
+                sg += cfd_shfl_xor(sg, 2);
+                sg += cfd_shfl_xor(sg, 4);
+                sg += cfd_shfl_xor(sg, 8);
+                gbacc[k] += sg;
+            }
             const CfdSplit8x3 sp = cfd_split8x3(drg[k]);
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) *(u4*)(s_g + glds[k] + 16 * pc) = __builtin_bit_cast(u4, sp.p[pc]);
@@ -590,7 +604,15 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
     constexpr int RG = KS == 3 ? 9 : 7;
     static_assert(NT % RG == 0, "column tiles per reduction round");
     float* s_red = (float*)s_dyn;  // [wave][RG][r][lane]
-    float* dst = part + (size_t)blockIdx.x * g.Co * g.Ci * KK;
+    const size_t n1 = (size_t)g.Co * g.Ci * KK;
+    float* dst = part + (size_t)blockIdx.x * (n1 + (want_gb ? g.Co : 0));
+    if (do_gb) {
+#pragma unroll
+        for (int k = 0; k < MT; ++k) {
+            const int i = threadIdx.x + 256 * k, o = mbase + (i >> 4);
+            if ((i & 15) == 0 && o < g.Co) dst[n1 + o] = gbacc[k];
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -656,7 +678,7 @@ static Wg6Plan wg6_plan(const ConvGeom& g) {
     const size_t stage = (size_t)3 * t.HP * 256 + (size_t)3 * 16 * P.mtw * 256;
     const size_t red = (size_t)4 * (KS == 3 ? 9 : 7) * 256 * sizeof(float);
     P.lds = stage > red ? stage : red;
-    P.part_bytes = cfd_align_up((size_t)P.groups * g.Co * g.Ci * KS * KS * sizeof(float), 256);
+    P.part_bytes = cfd_align_up((size_t)P.groups * ((size_t)g.Co * g.Ci * KS * KS + g.Co) * sizeof(float), 256);  // (+ bias-gradient row)
     P.ok = P.lds <= 150 * 1024 && t.HP * 16 <= 3 * 256 && (long)g.B * g.Ci * g.H * g.W < (1L << 30) && (long)g.B * g.Co * g.H * g.W < (1L << 30);  // 32-bit byte offsets
     return P;
 }
@@ -668,7 +690,8 @@ size_t cfd_conv6_wgrad_ws_bytes(const ConvGeom& g) {
     return P.ok ? P.part_bytes : 0;
 }
 
-int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, void* ws, const ConvGeom& g, hipStream_t st, const char* what) {
+int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, float* gb, void* ws, const ConvGeom& g, hipStream_t st,
+                    const char* what) {
     const Wg6Plan P = wg6_plan(g);
     if (!P.ok) return CFD_ERR_UNSUPPORTED;
     const dim3 grid(P.groups, P.chunks, P.mgroups * P.nkg);
@@ -679,7 +702,8 @@ int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, void* ws, con
             (void)hipFuncSetAttribute((const void*)k_conv6_wgrad<K_, M_, Y_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        hipLaunchKernelGGL((k_conv6_wgrad<K_, M_, Y_>), grid, dim3(256), P.lds, st, gout, in, (float*)ws, g, P.t, P.ntiles);       \
+        hipLaunchKernelGGL((k_conv6_wgrad<K_, M_, Y_>), grid, dim3(256), P.lds, st, gout, in, (float*)ws, g, P.t, P.ntiles,        \
+                           gb ? 1 : 0);                                                                                           \
     } while (0)
     if (g.ks == 3) {
         if (P.mtw == 1) W6_L(3, 1, 3);
@@ -690,7 +714,8 @@ int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, void* ws, con
     }
 #undef W6_L
     CFD_LAUNCH_CHECK(what);
-    cfd_conv_part_reduce((const float*)ws, gw, (long)g.Co * g.Ci * g.ks * g.ks, P.groups, st);
+    const long n1 = (long)g.Co * g.Ci * g.ks * g.ks;
+    cfd_conv_part_reduce((const float*)ws, gw, n1 + (gb ? g.Co : 0), P.groups, st, gb, n1);
     CFD_LAUNCH_CHECK(what);
     return CFD_OK;
 }
