@@ -338,7 +338,10 @@ static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     const int plane = t.NB * t.LH * t.LW * (P.CC / 8);
     P.NI = plane <= 3 * 256 ? 3 : 5;
     int mtw = P.MTall >= 2 ? 2 : 1;
-    if (mtw == 2 && (lds_of(2) > CFD_CONV6_MAX_LDS || P.ptiles * ((P.MTall + 1) / 2) < 256)) mtw = 1;
+#ifndef CFD_CONV6_MT2_MIN_WGS
+#define CFD_CONV6_MT2_MIN_WGS 64  // (256 -> 64: -1.4 % on the U-Net step; split-K supplies the workgroups of the deep levels)
+#endif
+    if (mtw == 2 && (lds_of(2) > CFD_CONV6_MAX_LDS || P.ptiles * ((P.MTall + 1) / 2) < CFD_CONV6_MT2_MIN_WGS)) mtw = 1;
     P.mtw = mtw;
     P.mgroups = (P.MTall + mtw - 1) / mtw;
     const long wgs = P.ptiles * P.mgroups;
