@@ -32,8 +32,10 @@ bool cfd_conv6_covers(const ConvGeom& g, bool ext);
 size_t cfd_conv6_ws_bytes(const ConvGeom& g, bool ext);
 // ext with `gin` != NULL: extended positions that map one-to-one onto an interior pixel may be written straight to gin (B,Ci,H,W)
 // instead of dst; *direct then says so and the caller folds only the border pixels (k_fold_border) instead of every pixel.
+// forward with `stats` != NULL ((Co, cfd_conv6_stats_slots(), 2) floats): per-channel partial sums of (out - bias) and its square.
 int cfd_conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, bool ext, float* gin,
-                  bool* direct, hipStream_t st, const char* what);
+                  bool* direct, hipStream_t st, const char* what, float* stats = nullptr);
+int cfd_conv6_stats_slots(const ConvGeom& g);
 // weight gradient gw (Co,Ci,ks,ks) = sum over (b, p) of gout[b][o][p] * in[b][i][clamp(p + tap)]
 bool cfd_conv6_wgrad_covers(const ConvGeom& g);
 size_t cfd_conv6_wgrad_ws_bytes(const ConvGeom& g);

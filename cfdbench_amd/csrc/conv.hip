@@ -212,6 +212,28 @@ extern "C" int cfd_conv2d_fwd(const float* in, const float* w, const float* bias
     return launch_conv_gather<false>(in, w, bias, out, g, (hipStream_t)stream, "cfd_conv2d_fwd");
 }
 
+// The same forward, also emitting per-channel partial sums for the training-mode BatchNorm that follows the conv:
+// stats (Co, slots, 2) = sums of (out - bias) and (out - bias)^2 over disjoint pixel sets, slots = cfd_conv2d_fwd_stats_slots()
+// (0: this layer cannot emit them -- use cfd_conv2d_fwd and cfd_batchnorm_fwd).  cfd_batchnorm_fwd_stats consumes them.
+extern "C" int cfd_conv2d_fwd_stats_slots(int B, int Ci, int Co, int H, int W, int ks) {
+    if (B <= 0 || Ci < 1 || Co < 1 || H < 1 || W < 1) return 0;
+    const ConvGeom g{B, Ci, Co, H, W, ks};
+    return cfd_conv6_covers(g, false) ? cfd_conv6_stats_slots(g) : 0;
+}
+
+extern "C" int cfd_conv2d_fwd_stats(const float* in, const float* w, const float* bias, float* out, void* ws, float* stats, int B,
+                                    int Ci, int Co, int H, int W, int ks, void* stream) {
+    CFD_REQUIRE(in && w && out && ws && stats, CFD_ERR_INVALID_ARG, "cfd_conv2d_fwd_stats: NULL pointer");
+    CFD_TRY(conv_check("cfd_conv2d_fwd_stats", B, Ci, Co, H, W, ks));
+    CFD_REQUIRE(B >= 1, CFD_ERR_INVALID_ARG, "cfd_conv2d_fwd_stats: empty batch");
+    const ConvGeom g{B, Ci, Co, H, W, ks};
+    CFD_REQUIRE(cfd_conv2d_fwd_stats_slots(B, Ci, Co, H, W, ks) > 0, CFD_ERR_UNSUPPORTED,
+                "cfd_conv2d_fwd_stats: this layer emits no statistics (cfd_conv2d_fwd_stats_slots() == 0)");
+    CFD_PROF_W("k_conv_fwd", (hipStream_t)stream, 4.0 * ((double)B * (Ci + Co) * H * W + (double)Co * Ci * ks * ks),
+               2.0 * B * H * W * (double)Co * Ci * ks * ks);
+    return cfd_conv6_run(in, w, bias, out, ws, g, false, nullptr, nullptr, (hipStream_t)stream, "cfd_conv2d_fwd_stats", stats);
+}
+
 // gin[b][i][y][x] = sum over the extended positions that replicate padding maps to (y, x)
 __global__ __launch_bounds__(256) void k_fold_pad(const float* __restrict__ ext, float* __restrict__ gin, unsigned total,
                                                   int H, int W, int pad, CfdDiv dHW, CfdDiv dW) {
@@ -646,10 +668,14 @@ static int chan_sum(const float* g, float* out, void* ws, int B, int C, int HW, 
 }
 
 // Sum of the BN_SPLIT partial pairs of channel c by wave 0 (the arithmetic of k_bn_final), broadcast through LDS.
-__device__ __forceinline__ void bn_partials(const float* __restrict__ part, int c, float* s_ab, float& a, float& b) {
+__device__ __forceinline__ void bn_partials(const float* __restrict__ part, int c, float* s_ab, float& a, float& b,
+                                            int nsplit = BN_SPLIT) {
     if (threadIdx.x < 64) {
-        float pa = threadIdx.x < BN_SPLIT ? part[((size_t)c * BN_SPLIT + threadIdx.x) * 2] : 0.f;
-        float pb = threadIdx.x < BN_SPLIT ? part[((size_t)c * BN_SPLIT + threadIdx.x) * 2 + 1] : 0.f;
+        float pa = 0.f, pb = 0.f;
+        for (int i = threadIdx.x; i < nsplit; i += 64) {  // (nsplit == BN_SPLIT: one pair per lane, the arithmetic of k_bn_final)
+            pa += part[((size_t)c * nsplit + i) * 2];
+            pb += part[((size_t)c * nsplit + i) * 2 + 1];
+        }
         pa = cfd_wave_sum(pa);
         pb = cfd_wave_sum(pb);
         if (threadIdx.x == 0) { s_ab[0] = pa; s_ab[1] = pb; }
@@ -668,15 +694,18 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
                                                   float* __restrict__ run_mean, float* __restrict__ run_var,
                                                   float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                   float* __restrict__ y, int B, int C, int HW, float count, float eps,
-                                                  float momentum, int training, int relu, CfdDiv dHW) {
+                                                  float momentum, int training, int relu, CfdDiv dHW, int nsplit,
+                                                  const float* __restrict__ kbase, int kstride) {
     __shared__ float s_ab[2];
     const int c = blockIdx.x, sp = blockIdx.y;
     float mu, rs;
     if (training) {
         float a, b;
-        bn_partials(part, c, s_ab, a, b);
+        bn_partials(part, c, s_ab, a, b, nsplit);
         const float d = a / count;
-        mu = x[(size_t)c * HW] + d;
+        // the partials are sums of (x - K) and (x - K)^2; K = the channel's first element (k_bn_partial<3>) or, when the conv that
+        // produced x emitted them (cfd_conv2d_fwd_stats), its bias
+        mu = (kbase ? kbase[(size_t)c * kstride] : 0.f) + d;
         float m2 = b - a * d;  // sum (x - mean)^2 = sum (x-K)^2 - n (mean-K)^2
         m2 = m2 > 0.f ? m2 : 0.f;
         const float var = m2 / count;  // biased: what normalises (torch.nn.functional.batch_norm, training=True)
@@ -771,8 +800,25 @@ extern "C" int cfd_batchnorm_fwd(const float* x, const float* gamma, const float
     CFD_PROF_W("k_bn_apply", st, 8.0 * B * C * HW, 2.0 * B * C * HW);
     hipLaunchKernelGGL(k_bn_apply, dim3(C, bn_slices(B, C, HW)), dim3(256), 0, st, x, (const float*)part, gamma, beta, run_mean,
                        run_var, save_mean, save_rstd, y, B, C, HW, count, eps, momentum, training, relu,
-                       cfd_div_make((unsigned)HW));
+                       cfd_div_make((unsigned)HW), BN_SPLIT, x, HW);
     CFD_LAUNCH_CHECK("cfd_batchnorm_fwd(apply)");
+    return CFD_OK;
+}
+
+// Training-mode forward from partial sums that the producer of x emitted (cfd_conv2d_fwd_stats): stats (C, slots, 2) = sums of
+// (x - shift[c]) and its square over disjoint pixel sets (shift NULL: 0).  One launch; otherwise cfd_batchnorm_fwd(training = 1).
+extern "C" int cfd_batchnorm_fwd_stats(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                                       float* y, float* save_mean, float* save_rstd, const float* stats, int slots,
+                                       const float* shift, int B, int C, int HW, float eps, float momentum, int relu, void* stream) {
+    CFD_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && stats, CFD_ERR_INVALID_ARG, "cfd_batchnorm_fwd_stats: NULL pointer");
+    CFD_REQUIRE(B >= 1 && C >= 1 && HW >= 1 && slots >= 1, CFD_ERR_INVALID_ARG, "cfd_batchnorm_fwd_stats: bad sizes");
+    CFD_REQUIRE_I31((long)B * C * HW, "cfd_batchnorm_fwd_stats");
+    hipStream_t st = (hipStream_t)stream;
+    CFD_PROF_W("k_bn_apply", st, 8.0 * B * C * HW, 2.0 * B * C * HW);
+    hipLaunchKernelGGL(k_bn_apply, dim3(C, bn_slices(B, C, HW)), dim3(256), 0, st, x, stats, gamma, beta, run_mean, run_var,
+                       save_mean, save_rstd, y, B, C, HW, (float)((double)B * HW), eps, momentum, 1, relu, cfd_div_make((unsigned)HW),
+                       slots, shift, 1);
+    CFD_LAUNCH_CHECK("cfd_batchnorm_fwd_stats");
     return CFD_OK;
 }
 

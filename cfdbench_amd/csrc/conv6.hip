@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void k_conv6_wprep(const float* __restrict__ w
 template <int KS, int MT, int CC, bool EXT, int NI>
 __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src, const u4* __restrict__ wfrag,
                                                   const float* __restrict__ bias, float* __restrict__ dst, ConvGeom g, ConvTile t,
-                                                  int MTall, int ptiles, float* __restrict__ gin_direct) {
+                                                  int MTall, int ptiles, float* __restrict__ gin_direct,
+                                                  float* __restrict__ stats) {
     constexpr int KK = KS * KS, PAD = KS / 2;
     constexpr int CH8 = CC / 8, PPS = 4 / CH8, KSTEPS = (KK + PPS - 1) / PPS;
     constexpr int WTOT = KSTEPS * MT * 192, NWV = (WTOT + 255) / 256;
@@ -209,6 +210,13 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
     // ~6 us per tile in the profile of the first version).
     f32x4 outv[MT][4];
     int out_tile = -1;
+    // forward with `stats`: per-channel sums of (out - bias) and (out - bias)^2 over this workgroup's pixels -- the BatchNorm that
+    // follows the conv takes its batch statistics from these partials (shift = the conv bias) instead of re-reading `out`
+    float st1[MT][4], st2[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st1[mt][r] = st2[mt][r] = 0.f;
     const auto store_tile = [&]() {
         const int bg = out_tile / tpi, tr = out_tile - bg * tpi;
         const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
@@ -234,6 +242,12 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (on && m0 + r < Cm) cfd_stg_off(dst + (size_t)r * HWd, o, outv[mt][tt][r] + bias_r[mt][r]);
+                    if constexpr (!EXT && NI == 3) {  // (the 5-item variants serve the small deep levels, which split their chunks)
+                        if (stats && on) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { st1[mt][r] += outv[mt][tt][r]; st2[mt][r] = fmaf(outv[mt][tt][r], outv[mt][tt][r], st2[mt][r]); }
+                        }
+                    }
                 }
             }
         }
@@ -298,6 +312,32 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
         }
     }
     if (out_tile >= 0) store_tile();
+    if constexpr (!EXT && NI == 3) {
+        if (stats) {  // (uniform) 16 pixel lanes -> one value per (wave, channel), then the four waves through LDS, fixed order
+            __syncthreads();
+            float* s_st = (float*)s_dyn;  // [wave][mt][q][r][2]
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = st1[mt][r], c2 = st2[mt][r];
+#pragma unroll
+                    for (int sh = 1; sh < 16; sh <<= 1) { a += cfd_shfl_xor(a, sh); c2 += cfd_shfl_xor(c2, sh); }
+                    if (n == 0) { s_st[(((wave * MT + mt) * 4 + q) * 4 + r) * 2] = a; s_st[(((wave * MT + mt) * 4 + q) * 4 + r) * 2 + 1] = c2; }
+                }
+            __syncthreads();
+            for (int e = threadIdx.x; e < MT * 16 * 2; e += blockDim.x) {
+                const int which = e & 1, ch = e >> 1, mt = ch >> 4, qr = ch & 15;
+                const int c = 16 * (mb + mt) + qr;
+                if (c < Cm) {
+                    float tot = 0.f;
+#pragma unroll
+                    for (int wv = 0; wv < 4; ++wv) tot += s_st[((wv * MT + mt) * 16 + qr) * 2 + which];
+                    stats[((size_t)c * gridDim.x + blockIdx.x) * 2 + which] = tot;
+                }
+            }
+        }
+    }
 }
 
 struct Conv6Plan {
@@ -373,7 +413,7 @@ size_t cfd_conv6_ws_bytes(const ConvGeom& g, bool ext) {
 
 template <int KS, int CC, bool EXT>
 static void conv6_launch(const Conv6Plan& P, const float* src, const u4* wfrag, const float* bias, float* dst, const ConvGeom& g,
-                         float* gin_direct, hipStream_t st) {
+                         float* gin_direct, float* stats, hipStream_t st) {
     const dim3 grid((unsigned)P.gx, P.mgroups, P.ksplit);
 #define C6_L(M_, N_)                                                                                                              \
     do {                                                                                                                          \
@@ -383,7 +423,7 @@ static void conv6_launch(const Conv6Plan& P, const float* src, const u4* wfrag, 
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
         hipLaunchKernelGGL((k_conv6<KS, M_, CC, EXT, N_>), grid, dim3(256), P.lds, st, src, wfrag, bias, dst, g, P.t, P.MTall,    \
-                           (int)P.ptiles, gin_direct);                                                                            \
+                           (int)P.ptiles, gin_direct, stats);                                                                     \
     } while (0)
     if (P.mtw == 1) { if (P.NI == 3) C6_L(1, 3); else C6_L(1, 5); }
     else { if (P.NI == 3) C6_L(2, 3); else C6_L(2, 5); }
@@ -392,7 +432,7 @@ static void conv6_launch(const Conv6Plan& P, const float* src, const u4* wfrag, 
 
 template <bool EXT>
 static int conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, float* gin,
-                     bool* direct, hipStream_t st, const char* what) {
+                     bool* direct, float* stats, hipStream_t st, const char* what) {
     const Conv6Plan P = conv6_plan(g, EXT);
     if (!P.ok) return CFD_ERR_UNSUPPORTED;
     u4* wfrag = (u4*)ws;
@@ -408,11 +448,12 @@ static int conv6_run(const float* src, const float* w, const float* bias, float*
     // interior pixels of the input gradient straight to gin (no split-K partials, an interior exists, 32-bit offsets hold)
     float* gd = (EXT && gin && P.ksplit == 1 && g.H >= 3 && g.W >= 3) ? gin : nullptr;
     if (direct) *direct = gd != nullptr;
+    if (stats && (EXT || P.ksplit > 1 || P.NI != 3)) return CFD_ERR_UNSUPPORTED;  // (callers ask cfd_conv6_stats_slots first)
     if (g.ks == 3) {
-        if (P.CC == 8) conv6_launch<3, 8, EXT>(P, src, wfrag, bias, kdst, g, gd, st);
-        else conv6_launch<3, 16, EXT>(P, src, wfrag, bias, kdst, g, gd, st);
+        if (P.CC == 8) conv6_launch<3, 8, EXT>(P, src, wfrag, bias, kdst, g, gd, stats, st);
+        else conv6_launch<3, 16, EXT>(P, src, wfrag, bias, kdst, g, gd, stats, st);
     } else {
-        conv6_launch<7, 8, EXT>(P, src, wfrag, bias, kdst, g, gd, st);
+        conv6_launch<7, 8, EXT>(P, src, wfrag, bias, kdst, g, gd, stats, st);
     }
     CFD_LAUNCH_CHECK(what);
     if (P.ksplit > 1) {
@@ -424,10 +465,17 @@ static int conv6_run(const float* src, const float* w, const float* bias, float*
 }
 
 int cfd_conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, bool ext, float* gin,
-                  bool* direct, hipStream_t st, const char* what) {
+                  bool* direct, hipStream_t st, const char* what, float* stats) {
     if (direct) *direct = false;
-    return ext ? conv6_run<true>(src, w, bias, dst, ws, g, gin, direct, st, what)
-               : conv6_run<false>(src, w, bias, dst, ws, g, nullptr, nullptr, st, what);
+    return ext ? conv6_run<true>(src, w, bias, dst, ws, g, gin, direct, nullptr, st, what)
+               : conv6_run<false>(src, w, bias, dst, ws, g, nullptr, nullptr, stats, st, what);
+}
+
+// partial (sum, sum of squares) pairs per output channel the forward kernel can emit for the BatchNorm that follows (0: not on
+// this layer -- not a conv6 layer, or its channel chunks are split over workgroups)
+int cfd_conv6_stats_slots(const ConvGeom& g) {
+    const Conv6Plan P = conv6_plan(g, false);
+    return (P.ok && P.ksplit == 1 && P.NI == 3) ? P.gx : 0;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -549,6 +549,68 @@ class BatchNormFn(torch.autograd.Function):
         return gx, gg, gb, None, None, None, None, None, None
 
 
+class ConvBnReluFn(torch.autograd.Function):
+    """[ReLU](BatchNorm2d(Conv2d(x))) in TRAINING mode (unet.py:20-30) as one autograd node: where the conv kernel can emit the
+    per-channel partial sums of its output (cfd_conv2d_fwd_stats), the BatchNorm takes its batch statistics from them and runs as
+    ONE launch instead of a statistics pass plus a normalising pass; otherwise the two stand-alone calls.  The backward pass is
+    BatchNormFn's followed by Conv2dReplicateFn's."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor], gamma: Tensor, beta: Tensor, run_mean: Optional[Tensor],
+                run_var: Optional[Tensor], relu: bool, eps: float, momentum: float):
+        _require_cuda(x, w, b, gamma, beta, run_mean, run_var)
+        api = _lib.api()
+        x, w = _f32c(x), _f32c(w.detach())
+        b = _f32c(b.detach()) if b is not None else None
+        gamma, beta = _f32c(gamma.detach()), _f32c(beta.detach())
+        B, Ci, H, W = x.shape
+        Co, Ci_w, ks, ks2 = w.shape
+        if Ci_w != Ci or ks != ks2:
+            raise RuntimeError(f"conv2d: input has {Ci} channels, weight is {tuple(w.shape)}")
+        y0 = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+        z = torch.empty_like(y0)
+        sm = torch.empty(Co, dtype=torch.float32, device=x.device)
+        sr = torch.empty(Co, dtype=torch.float32, device=x.device)
+        nws = api.size("cfd_conv2d_fwd_workspace_bytes", B, Ci, Co, H, W, ks)
+        ws = _bytes(nws, x.device) if nws else None
+        slots = api.size("cfd_conv2d_fwd_stats_slots", B, Ci, Co, H, W, ks) if ws is not None else 0
+        if slots > 0:
+            stats = torch.empty((Co, slots, 2), dtype=torch.float32, device=x.device)
+            api.call("cfd_conv2d_fwd_stats", _ptr(x), _ptr(w), _ptr(b), _ptr(y0), _ptr(ws), _ptr(stats), B, Ci, Co, H, W, ks, _stream())
+            api.call("cfd_batchnorm_fwd_stats", _ptr(y0), _ptr(gamma), _ptr(beta), _ptr(run_mean), _ptr(run_var), _ptr(z), _ptr(sm),
+                     _ptr(sr), _ptr(stats), slots, _ptr(b), B, Co, H * W, float(eps), float(momentum), int(relu), _stream())
+        else:
+            api.call("cfd_conv2d_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y0), _ptr(ws), B, Ci, Co, H, W, ks, _stream())
+            bws = _bytes(api.size("cfd_batchnorm_workspace_bytes", Co), x.device)
+            api.call("cfd_batchnorm_fwd", _ptr(y0), _ptr(gamma), _ptr(beta), _ptr(run_mean), _ptr(run_var), _ptr(z), _ptr(sm),
+                     _ptr(sr), _ptr(bws), B, Co, H * W, float(eps), float(momentum), 1, int(relu), _stream())
+        ctx.save_for_backward(x, w, y0, gamma, beta, sm, sr)
+        ctx.meta = (b is not None, bool(relu))
+        return z
+
+    @staticmethod
+    def backward(ctx, gz: Tensor):
+        api = _lib.api()
+        x, w, y0, gamma, beta, sm, sr = ctx.saved_tensors
+        has_b, relu = ctx.meta
+        B, Ci, H, W = x.shape
+        Co, _, ks, _ = w.shape
+        gz = _f32c(gz)
+        gy0 = torch.empty_like(y0)
+        gg = torch.empty(Co, dtype=torch.float32, device=x.device)
+        gbeta = torch.empty(Co, dtype=torch.float32, device=x.device)
+        bws = _bytes(api.size("cfd_batchnorm_workspace_bytes", Co), x.device)
+        api.call("cfd_batchnorm_bwd", _ptr(gz), _ptr(y0), _ptr(gamma), _ptr(beta), _ptr(sm), _ptr(sr), _ptr(gy0), _ptr(gg),
+                 _ptr(gbeta), _ptr(bws), B, Co, H * W, 1, int(relu), _stream())
+        gin = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w)
+        gb = torch.empty(Co, dtype=torch.float32, device=x.device) if has_b else None
+        ws = _bytes(api.size("cfd_conv2d_bwd_workspace_bytes", B, Ci, Co, H, W, ks), x.device)
+        api.call("cfd_conv2d_bwd", _ptr(gy0), _ptr(x), _ptr(w), _ptr(gin), _ptr(gw), _ptr(gb), _ptr(ws), B, Ci, Co, H, W, ks,
+                 _stream())
+        return gin, gw, gb, gg, gbeta, None, None, None, None, None
+
+
 class MaxPool2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor):

@@ -20,6 +20,9 @@ from .base_model import AutoCfdModel
 
 def _conv_bn_relu(seq: nn.Sequential, x: Tensor) -> Tensor:
     conv, bn = seq[0], seq[1]
+    if bn.training and x.is_cuda:  # one node: the conv emits the BatchNorm's batch statistics where it can (functional.ConvBnReluFn)
+        return F_.ConvBnReluFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, bn.eps,
+                                     bn.momentum)
     x = F_.Conv2dReplicateFn.apply(x, conv.weight, conv.bias)
     y = F_.BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, True, bn.eps,
                              bn.momentum)

@@ -273,6 +273,13 @@ int cfd_rowdot_bwd(const float* g, const float* branch, const float* trunk, floa
 size_t cfd_conv2d_fwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);
 int cfd_conv2d_fwd(const float* in, const float* w, const float* bias, float* out, void* ws, int B, int Ci, int Co, int H,
                    int W, int ks, void* stream);
+/* The same forward, also emitting per-channel partial sums for the training-mode BatchNorm that follows the conv (unet.py:20-30:
+ * Conv2d -> BatchNorm2d): stats (Co, slots, 2) floats = sums of (out - bias) and (out - bias)^2 over disjoint pixel sets, slots =
+ * cfd_conv2d_fwd_stats_slots() (0: this layer cannot emit them).  Consumed by cfd_batchnorm_fwd_stats (one launch instead of the
+ * statistics pass + the normalising pass).                                                                               */
+int cfd_conv2d_fwd_stats_slots(int B, int Ci, int Co, int H, int W, int ks);
+int cfd_conv2d_fwd_stats(const float* in, const float* w, const float* bias, float* out, void* ws, float* stats, int B, int Ci,
+                         int Co, int H, int W, int ks, void* stream);
 /* gin (B,Ci,H,W), gw (Co,Ci,ks,ks), gb (Co) from gout; any output may be NULL.  ws: cfd_conv2d_bwd_workspace_bytes(). */
 size_t cfd_conv2d_bwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);
 int cfd_conv2d_bwd(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws, int B,
@@ -285,6 +292,10 @@ size_t cfd_batchnorm_workspace_bytes(int C);
 int cfd_batchnorm_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float* y,
                       float* save_mean, float* save_rstd, void* ws, int B, int C, int HW, float eps, float momentum,
                       int training, int relu, void* stream);
+/* training-mode forward from the partial sums of cfd_conv2d_fwd_stats: stats (C, slots, 2), shift (C) = the conv bias or NULL */
+int cfd_batchnorm_fwd_stats(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float* y,
+                            float* save_mean, float* save_rstd, const float* stats, int slots, const float* shift, int B, int C,
+                            int HW, float eps, float momentum, int relu, void* stream);
 int cfd_batchnorm_bwd(const float* gy, const float* x, const float* gamma, const float* beta, const float* save_mean,
                       const float* save_rstd, float* gx, float* ggamma, float* gbeta, void* ws, int B, int C, int HW,
                       int training, int relu, void* stream);

@@ -679,6 +679,35 @@ def check_conv2d(be, B, Ci, Co, H, W, ks, seed=31):
     return res
 
 
+def check_conv_bn_stats(be, B, Ci, Co, H, W, ks, relu=True, seed=36):
+    """cfd_conv2d_fwd_stats + cfd_batchnorm_fwd_stats (the conv emits the BatchNorm's batch statistics) against the oracle's
+    conv -> training-mode BatchNorm; returns None when the layer cannot emit statistics."""
+    from oracle import conv_oracle as CO
+    api, P = be.api, be.ptr
+    slots = api.size("cfd_conv2d_fwd_stats_slots", B, Ci, Co, H, W, ks)
+    if slots <= 0:
+        return None
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, Ci, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, ks, ks)) / np.sqrt(Ci * ks * ks)).astype(np.float32)
+    b = (rng.standard_normal((Co,)) * 0.2 + 3.0 * rng.standard_normal((Co,))).astype(np.float32)  # |mean| >> std in some channels
+    gamma = (1 + 0.3 * rng.standard_normal(Co)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(Co)).astype(np.float32)
+    rm = (0.5 * rng.standard_normal(Co)).astype(np.float32)
+    rv = (1 + rng.random(Co)).astype(np.float32)
+    dx, dw, db, dga, dbe, drm, drv = be.dev(x), be.dev(w), be.dev(b), be.dev(gamma), be.dev(beta), be.dev(rm), be.dev(rv)
+    out, y, sm, sr = be.zeros((B, Co, H, W)), be.zeros((B, Co, H, W)), be.zeros((Co,)), be.zeros((Co,))
+    stats = be.zeros((Co, slots, 2))
+    ws = be.bytes(api.size("cfd_conv2d_fwd_workspace_bytes", B, Ci, Co, H, W, ks))
+    api.call("cfd_conv2d_fwd_stats", P(dx), P(dw), P(db), P(out), P(ws), P(stats), B, Ci, Co, H, W, ks, be.stream)
+    api.call("cfd_batchnorm_fwd_stats", P(out), P(dga), P(dbe), P(drm), P(drv), P(y), P(sm), P(sr), P(stats), slots, P(db), B, Co,
+             H * W, 1e-5, 0.1, int(relu), be.stream)
+    be.sync()
+    r0 = CO.conv2d(x.astype(f64), w.astype(f64), b.astype(f64))
+    ry, cache, nrm, nrv = CO.batchnorm(r0, gamma.astype(f64), beta.astype(f64), rm.astype(f64), rv.astype(f64), True, relu=relu)
+    return {"out": nm(be.host(out), r0), "y": nm(be.host(y), ry), "run_mean": nm(be.host(drm), nrm), "run_var": nm(be.host(drv), nrv)}
+
+
 def check_batchnorm(be, B, C, H, W, training, relu, seed=32):
     from oracle import conv_oracle as CO
     api, P = be.api, be.ptr

@@ -162,6 +162,15 @@ def test_conv2d_replicate(be, B, Ci, Co, H, W, ks):
     _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, ks))
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(3, 12, 12, 64, 64, 3), (9, 5, 20, 9, 10, 3), (2, 8, 40, 20, 21, 7), (5, 12, 18, 16, 16, 3)])
+def test_conv_emits_batchnorm_statistics(be, B, Ci, Co, H, W, ks):
+    """conv forward with the statistics epilogue + the one-launch BatchNorm that consumes them (several tiles per workgroup)."""
+    with K.tuned(be, conv6_grid=3):
+        res = K.check_conv_bn_stats(be, B, Ci, Co, H, W, ks)
+    assert res is not None
+    _assert_all(res)
+
+
 @pytest.mark.parametrize("B,C,H,W,training,relu", [(2, 3, 6, 7, True, True), (2, 3, 4, 4, False, True), (3, 2, 5, 5, True, False), (4, 12, 64, 64, True, True),
                                                     (9, 48, 4, 4, True, True)])
 def test_batchnorm_relu(be, B, C, H, W, training, relu):
