@@ -670,15 +670,25 @@ static int chan_sum(const float* g, float* out, void* ws, int B, int C, int HW, 
 // Sum of the BN_SPLIT partial pairs of channel c by wave 0 (the arithmetic of k_bn_final), broadcast through LDS.
 __device__ __forceinline__ void bn_partials(const float* __restrict__ part, int c, float* s_ab, float& a, float& b,
                                             int nsplit = BN_SPLIT) {
-    if (threadIdx.x < 64) {
-        float pa = 0.f, pb = 0.f;
-        for (int i = threadIdx.x; i < nsplit; i += 64) {  // (nsplit == BN_SPLIT: one pair per lane, the arithmetic of k_bn_final)
-            pa += part[((size_t)c * nsplit + i) * 2];
-            pb += part[((size_t)c * nsplit + i) * 2 + 1];
-        }
-        pa = cfd_wave_sum(pa);
-        pb = cfd_wave_sum(pb);
-        if (threadIdx.x == 0) { s_ab[0] = pa; s_ab[1] = pb; }
+    // every thread takes the pairs t, t + 256, ... (all loads in flight at once: a one-wave loop over 512 conv-emitted pairs cost
+    // eight dependent memory latencies, +5 us per launch), then wave sums and the four waves in a fixed order.  With
+    // nsplit == BN_SPLIT wave 0 holds one pair per lane and the others add zeros: the arithmetic of k_bn_final.
+    float pa = 0.f, pb = 0.f;
+    for (int i = threadIdx.x; i < nsplit; i += blockDim.x) {
+        const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)c * nsplit + i) * 2);
+        pa += v.x;
+        pb += v.y;
+    }
+    pa = cfd_wave_sum(pa);
+    pb = cfd_wave_sum(pb);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_ab[2 + 2 * wave] = pa; s_ab[3 + 2 * wave] = pb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ta = s_ab[2], tb = s_ab[3];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { ta += s_ab[2 + 2 * w]; tb += s_ab[3 + 2 * w]; }
+        s_ab[0] = ta;
+        s_ab[1] = tb;
     }
     __syncthreads();
     a = s_ab[0];
@@ -696,7 +706,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
                                                   float* __restrict__ y, int B, int C, int HW, float count, float eps,
                                                   float momentum, int training, int relu, CfdDiv dHW, int nsplit,
                                                   const float* __restrict__ kbase, int kstride) {
-    __shared__ float s_ab[2];
+    __shared__ float s_ab[10];
     const int c = blockIdx.x, sp = blockIdx.y;
     float mu, rs;
     if (training) {
@@ -740,7 +750,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ beta, float* __restrict__ gbeta,
                                                       float* __restrict__ ggamma, float* __restrict__ gx, int B, int C, int HW,
                                                       float inv_count, int relu, int training, CfdDiv dHW) {
-    __shared__ float s_ab[2];
+    __shared__ float s_ab[10];
     const int c = blockIdx.x, sp = blockIdx.y;
     float gb, gg;
     bn_partials(part, c, s_ab, gb, gg);
