@@ -34,6 +34,18 @@ extern "C" int cfd_dbg_c6_read(unsigned long long* out, int n) { return (int)hip
 #define CFD_CONV6_GRID 512  // persistent workgroups per launch: two per CU (the CPU emulator build sets 2 so that small test shapes
                             // walk several tiles per workgroup)
 #endif
+// Tiles of a persistent workgroup: a CONTIGUOUS range (row-major neighbours share halo columns and, a tile row later, halo rows), and
+// the workgroups of one XCD (launch order p, p + 8, ...: round-robin over the 8 XCDs) own neighbouring ranges, so that a halo line
+// fetched for one tile is still in that XCD's L2 for the next.  (With the strided assignment tile = p + k G the weight gradient of a
+// 12-channel 64x64 layer fetched 254 MB from HBM for 50 MB of operands: 2.5x halo x 2x from 40-byte runs in 64-byte lines, every
+// one of them a miss -- profiles/r03y_unet_pmc_traffic.json.)
+__device__ __forceinline__ void conv6_tile_range(int ntiles, int& tbeg, int& tend) {
+    const int G = gridDim.x, p = blockIdx.x;
+    const int pp = (G % 8 == 0) ? (p % 8) * (G / 8) + p / 8 : p;
+    tbeg = (int)((long)ntiles * pp / G);
+    tend = (int)((long)ntiles * (pp + 1) / G);
+}
+
 static int conv6_grid() {
     const int t = cfd_tune_get(CFD_TUNE_CONV6_GRID);
     return t > 0 ? t : CFD_CONV6_GRID;
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(256) void k_conv6_wprep(const float* __restrict__ w
 
 // ------------------------------------------------------------------------------------------------------
 // forward / transposed-valid pass:  dst[b][m][p] = bias[m] + sum_k A(m, k) * src[b][c(k)][pos(p, k)]   (conv.hip has the algebra)
-// Persistent workgroups: workgroup x of gridDim.x walks the pixel tiles x, x + gridDim.x, ... and, per tile, its range of channel
+// Persistent workgroups: a workgroup walks its contiguous range of pixel tiles (conv6_tile_range) and, per tile, its range of channel
 // chunks.  The global loads of the NEXT (tile, chunk) -- NI halo items of 8 channel values and the chunk's weight fragments -- are
 // issued into registers right before the MFMA loop of the current one and land while it runs; splitting into pieces and the LDS
 // stores happen at the top of the next iteration.  (The first version staged global -> LDS in plain loops inside each
@@ -126,7 +138,9 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
     const int nchw = chend - chbeg;
     const bool split = gridDim.z > 1;
     if (split) dst += (size_t)blockIdx.z * g.B * Cm * HWd;
-    const int ntile = ((int)blockIdx.x < ptiles) ? (ptiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    int tbeg, tend;
+    conv6_tile_range(ptiles, tbeg, tend);
+    const int ntile = tend - tbeg;
     const int nit = nchw > 0 ? ntile * nchw : 0;
 
     // this thread's NI halo items (pixel, channel octet): tile-invariant coordinates, packed lx | ly << 8 | bi << 16 | c8 << 24
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
     // per-lane addresses to ~5 VALU instructions per load: together 2/3 of the kernel's VALU time in the first version.)
     const auto issue = [&](int it, bool with_w) {
         const int tk = it / nchw, ch = chbeg + it - tk * nchw;
-        const int tile = blockIdx.x + tk * gridDim.x;
+        const int tile = tbeg + tk;
         const int bg = tile / tpi, tr = tile - bg * tpi;
         const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
         const int b0 = bg * t.NB;
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) { outv[mt][tt] = acc[mt][tt]; acc[mt][tt] = zero; }
-            out_tile = blockIdx.x + tk * gridDim.x;
+            out_tile = tbeg + tk;
         }
     }
     if (out_tile >= 0) store_tile();
@@ -583,9 +597,11 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
             gok[k] = ok ? g.B - b0 : 0;
         }
     };
-    if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
+    int tbeg, tend;
+    conv6_tile_range(ntiles, tbeg, tend);
+    if (tbeg < tend) issue(tbeg);
     [[maybe_unused]] int it = 0;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+    for (int tile = tbeg; tile < tend; ++tile, ++it) {
         C6_TS(0);
         __syncthreads();  // previous tile fully consumed
         C6_TS(1);
@@ -616,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
         C6_TS(2);
         __syncthreads();
         C6_TS(3);
-        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        if (tile + 1 < tend) issue(tile + 1);
         cfd_sched_fence();
         C6_TS(4);
         bf16x8 av[MT][3];
