@@ -126,6 +126,38 @@ def test_train_auto_graph_option_follows_the_eager_run(torch, tmp_path, model_na
     assert np.max(np.abs(e - g) / e) < 2e-2           # same trajectory (the step arithmetic of Adam differs in rounding)
 
 
+def test_resume_with_graph_option_reproduces_the_uninterrupted_run(torch, tmp_path):
+    """--graph 1 + --resume 1 (U-Net): the capture's warm-up steps are rolled back over the LOADED optimiser state and BatchNorm
+    buffers, so 4 epochs in one go == 2 epochs, restart, resume to 4 -- bitwise (the replayed graph is deterministic)."""
+    from cfdbench_amd.harness.args import Args
+    from cfdbench_amd.harness.autoregressive import init_model
+    from cfdbench_amd.harness.data import SyntheticAutoDataset
+    from cfdbench_amd.harness.train_auto import train
+    tr = SyntheticAutoDataset(n_cases=5, n_frames=5, height=64, width=64, seed=0)  # 20 frames: 5 full batches of 4
+    dev = SyntheticAutoDataset(n_cases=1, n_frames=4, height=64, width=64, seed=1)
+
+    def run(out, num_epochs, resume):
+        args = Args(model="unet", data_name="cavity_bc", loss_name="nmse", unet_dim=4, lr=2e-3, output_dir=str(out), graph=1)
+        torch.manual_seed(0)
+        model = init_model(args).cuda()
+        if resume:
+            torch.manual_seed(123)
+            for p_ in model.parameters():
+                p_.data.mul_(0.5)
+        losses = train(model, tr, dev, out, num_epochs=num_epochs, lr=args.lr, lr_step_size=1, lr_gamma=0.8, batch_size=4,
+                       eval_batch_size=4, log_interval=100, eval_interval=2, plot_interval=0, resume=resume, graph=True)
+        return model, losses
+
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    ma, la = run(tmp_path / "a", 4, False)
+    run(tmp_path / "b", 2, False)
+    mb, lb = run(tmp_path / "b", 4, True)
+    assert la == lb
+    for (k, pa), (_, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        assert torch.equal(pa, pb), k
+
+
 @pytest.mark.parametrize("model_name", ["deeponet", "ffn"])
 def test_nonauto_train_graph_option(torch, tmp_path, model_name):
     """train.py --graph 1 (non-autoregressive DeepONet / FFN): the captured step draws fresh query points on every replay (torch's
