@@ -1,6 +1,7 @@
 """U-Net with the reference's module tree, constructor and ``state_dict`` (136 tensors incl. BatchNorm buffers under
 ``in_conv.conv{1,2}.{0,1}.*``, ``down{1-4}.maxpool_conv.1.*``, ``up{1-4}.{up,conv}.*``, ``out_conv.conv.*``;
-src/models/unet.py:11-263) on the gfx950 kernels of csrc/conv.hip.  The torch sub-modules (nn.Conv2d, nn.BatchNorm2d,
+src/models/unet.py:11-263) on the gfx950 kernels of csrc/conv6.hip (3x3 convs: three-piece split-bf16 implicit GEMMs, fp32-exact class)
+and csrc/conv.hip.  The torch sub-modules (nn.Conv2d, nn.BatchNorm2d,
 nn.ConvTranspose2d) only hold parameters and buffers; the arithmetic runs in: implicit-GEMM replicate-padded conv (MFMA),
 fused BatchNorm+ReLU (batch statistics in training, running statistics in eval), 2x2 max-pool, 2x2/stride-2 transposed
 conv, 1x1 output conv and the (x + residual) * mask epilogue.  ``torch.cat`` / zero ``F.pad`` of skip connections are the
