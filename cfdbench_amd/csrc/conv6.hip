@@ -18,17 +18,6 @@
 
 typedef cfd_u32x4 u4;
 
-#ifdef CFD_C6DIAG  // experiment builds only (tools/build_variant.sh): s_memtime stamps of workgroup 0, wave 0 at the phase boundaries
-__device__ unsigned long long c6_ts[1024];
-extern "C" int cfd_dbg_c6_read(unsigned long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c6_ts), (size_t)n * 8); }
-#define C6_TS(slot)                                                                                     \
-    do {                                                                                                \
-        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && it < 16)      \
-            c6_ts[it * 8 + (slot)] = __builtin_readcyclecounter();                                      \
-    } while (0)
-#else
-#define C6_TS(slot) do { } while (0)
-#endif
 
 #ifndef CFD_CONV6_GRID
 #define CFD_CONV6_GRID 512  // persistent workgroups per launch: two per CU (the CPU emulator build sets 2 so that small test shapes
@@ -270,9 +259,7 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
     };
     if (nit > 0) issue(0, true);
     for (int it = 0; it < nit; ++it) {
-        C6_TS(0);
         __syncthreads();  // previous iteration's operands fully consumed (first pass: s_koff written)
-        C6_TS(1);
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             if (!(ipk[k] >> 31)) {
@@ -292,14 +279,10 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
                 if (i < WTOT) s_w[i] = wr[k];
             }
         }
-        C6_TS(2);
         __syncthreads();
-        C6_TS(3);
         if (it + 1 < nit) issue(it + 1, nchw > 1);
-        C6_TS(4);
         if (out_tile >= 0) store_tile();
         cfd_sched_fence();  // keep the loads above the MFMA loop: hipcc otherwise sinks them to their first use
-        C6_TS(5);
 #pragma unroll 1
         for (int s = 0; s < KSTEPS; ++s) {
             const int ko = s_koff[4 * s + q];
@@ -316,7 +299,6 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) cfd_mfma_bf16x6_n<4>(av[mt], bv, acc[mt]);
         }
-        C6_TS(6);
         const int tk = it / nchw;
         if (it - tk * nchw == nchw - 1) {  // last chunk of the tile: hand the sums to the deferred store, start the next tile from zero
 #pragma unroll
@@ -601,11 +583,8 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
     int tbeg, tend;
     conv6_tile_range(ntiles, tbeg, tend);
     if (tbeg < tend) issue(tbeg);
-    [[maybe_unused]] int it = 0;
-    for (int tile = tbeg; tile < tend; ++tile, ++it) {
-        C6_TS(0);
+    for (int tile = tbeg; tile < tend; ++tile) {
         __syncthreads();  // previous tile fully consumed
-        C6_TS(1);
 #pragma unroll
         for (int k = 0; k < NIW; ++k) {
             if (!(ipk[k] >> 31)) {
@@ -630,12 +609,9 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) *(u4*)(s_g + glds[k] + 16 * pc) = __builtin_bit_cast(u4, sp.p[pc]);
         }
-        C6_TS(2);
         __syncthreads();
-        C6_TS(3);
         if (tile + 1 < tend) issue(tile + 1);
         cfd_sched_fence();
-        C6_TS(4);
         bf16x8 av[MT][3];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -665,7 +641,6 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
                     for (int i = 0; i < NG; ++i)
                         acc[mt][n0 + i] = cfd_mfma16x16x32_bf16(av[mt][PA[p]], bv[i][PB[p]], acc[mt][n0 + i]);
         }
-        C6_TS(5);
     }
     // sum of the four waves (each owns 4 of the tile's 16 pixels) in a fixed order, RG column tiles of one output-channel tile at a
     // time (the staging buffers are free by now)

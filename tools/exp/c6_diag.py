@@ -1,4 +1,7 @@
-"""GPU box: phase timestamps of k_conv6 (variant build with -DCFD_C6DIAG, CFDBENCH_AMD_LIB pointing at it)."""
+"""GPU box: phase timestamps of k_conv6 / k_conv6_wgrad (variant build with -DCFD_C6DIAG, CFDBENCH_AMD_LIB pointing at it).
+The C6_TS(slot) stamps were taken out of csrc/conv6.hip after the measurements (profiles/r03w_conv6_phase_timestamps.txt); they
+live in the history: `git show 4bb9d6d:cfdbench_amd/csrc/conv6.hip` has them (s_memtime of workgroup 0 / wave 0 into a __device__
+array read back through cfd_dbg_c6_read)."""
 import ctypes
 import sys
 from pathlib import Path
