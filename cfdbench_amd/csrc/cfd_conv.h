@@ -25,16 +25,16 @@ int cfd_conv_splitk_sum(const float* part, const float* bias, float* out, long n
 void cfd_conv_part_reduce(const float* part, float* out, long n, int nchunk, hipStream_t st, float* out2 = nullptr, long n1 = 0);
 
 // ---- conv6.hip: k = 3 / k = 7 on three-piece split-bf16 operands (fp32-exact pieces, six bf16 MFMAs per product) ----
-// forward (ext = false: dst (B,Co,H,W) = conv(src (B,Ci,H,W)) + bias) and the input gradient (ext = true: dst = gin (B,Ci,H,W) from
-// src = gout (B,Co,H,W)).  ws: cfd_conv6_ws_bytes(); returns CFD_ERR_UNSUPPORTED when the
+// forward (ext = false: dst (B,Co,H,W) = conv(src (B,Ci,H,W)) + bias) and the transposed-valid pass of the input gradient
+// (ext = true: dst (B,Ci,H+2p,W+2p) from src = gout (B,Co,H,W)).  ws: cfd_conv6_ws_bytes(); returns CFD_ERR_UNSUPPORTED when the
 // layer is not covered (the caller then uses the fp32 kernels).
 bool cfd_conv6_covers(const ConvGeom& g, bool ext);
 size_t cfd_conv6_ws_bytes(const ConvGeom& g, bool ext);
-// ext = true: dst = gin (B,Ci,H,W), complete: the H x W window of the extended grid on the MFMA kernel plus the pad ring added onto
-// the border pixels by k_conv6_ring (no extended buffer, no fold).
+// ext with `gin` != NULL: extended positions that map one-to-one onto an interior pixel may be written straight to gin (B,Ci,H,W)
+// instead of dst; *direct then says so and the caller folds only the border pixels (k_fold_border) instead of every pixel.
 // forward with `stats` != NULL ((Co, cfd_conv6_stats_slots(), 2) floats): per-channel partial sums of (out - bias) and its square.
-int cfd_conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, bool ext,
-                  hipStream_t st, const char* what, float* stats = nullptr);
+int cfd_conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, bool ext, float* gin,
+                  bool* direct, hipStream_t st, const char* what, float* stats = nullptr);
 int cfd_conv6_stats_slots(const ConvGeom& g);
 // weight gradient gw (Co,Ci,ks,ks) = sum over (b, p) of gout[b][o][p] * in[b][i][clamp(p + tap)]
 bool cfd_conv6_wgrad_covers(const ConvGeom& g);

@@ -207,7 +207,8 @@ extern "C" int cfd_conv2d_fwd(const float* in, const float* w, const float* bias
     const ConvGeom g{B, Ci, Co, H, W, ks};
     CFD_PROF_W("k_conv_fwd", (hipStream_t)stream, 4.0 * ((double)B * (Ci + Co) * H * W + (double)Co * Ci * ks * ks),
                2.0 * B * H * W * (double)Co * Ci * ks * ks);
-    if (ws && cfd_conv6_covers(g, false)) return cfd_conv6_run(in, w, bias, out, ws, g, false, (hipStream_t)stream, "cfd_conv2d_fwd");
+    if (ws && cfd_conv6_covers(g, false))
+        return cfd_conv6_run(in, w, bias, out, ws, g, false, nullptr, nullptr, (hipStream_t)stream, "cfd_conv2d_fwd");
     return launch_conv_gather<false>(in, w, bias, out, g, (hipStream_t)stream, "cfd_conv2d_fwd");
 }
 
@@ -230,7 +231,7 @@ extern "C" int cfd_conv2d_fwd_stats(const float* in, const float* w, const float
                 "cfd_conv2d_fwd_stats: this layer emits no statistics (cfd_conv2d_fwd_stats_slots() == 0)");
     CFD_PROF_W("k_conv_fwd", (hipStream_t)stream, 4.0 * ((double)B * (Ci + Co) * H * W + (double)Co * Ci * ks * ks),
                2.0 * B * H * W * (double)Co * Ci * ks * ks);
-    return cfd_conv6_run(in, w, bias, out, ws, g, false, (hipStream_t)stream, "cfd_conv2d_fwd_stats", stats);
+    return cfd_conv6_run(in, w, bias, out, ws, g, false, nullptr, nullptr, (hipStream_t)stream, "cfd_conv2d_fwd_stats", stats);
 }
 
 // gin[b][i][y][x] = sum over the extended positions that replicate padding maps to (y, x)
@@ -247,6 +248,30 @@ __global__ __launch_bounds__(256) void k_fold_pad(const float* __restrict__ ext,
         for (int yy = y0; yy <= y1; ++yy)
             for (int xx = x0; xx <= x1; ++xx) acc += s[yy * We + xx];
         gin[e] = acc;
+    }
+}
+
+// The same for the border pixels only (top and bottom rows, then the left and right columns without their corners): the interior
+// of gin was written by the input-gradient kernel itself (conv6.hip, `gin_direct`), so the fold touches 2 (H + W) - 4 pixels per
+// image instead of H * W and the extended buffer is read along its rim only.
+__global__ __launch_bounds__(256) void k_fold_border(const float* __restrict__ ext, float* __restrict__ gin, unsigned total, int H,
+                                                     int W, int pad, CfdDiv dNB) {
+    const int He = H + 2 * pad, We = W + 2 * pad, nb = 2 * W + 2 * (H - 2);
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned img = cfd_div(e, dNB);
+        const int j = (int)(e - img * (unsigned)nb);
+        int y, x;
+        if (j < W) { y = 0; x = j; }
+        else if (j < 2 * W) { y = H - 1; x = j - W; }
+        else if (j < 2 * W + H - 2) { y = 1 + (j - 2 * W); x = 0; }
+        else { y = 1 + (j - 2 * W - (H - 2)); x = W - 1; }
+        const int y0 = y == 0 ? 0 : y + pad, y1 = y == H - 1 ? He - 1 : y + pad;
+        const int x0 = x == 0 ? 0 : x + pad, x1 = x == W - 1 ? We - 1 : x + pad;
+        const float* s = ext + (size_t)img * He * We;
+        float acc = 0.f;
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) acc += s[yy * We + xx];
+        gin[(size_t)img * H * W + y * W + x] = acc;
     }
 }
 
@@ -442,7 +467,7 @@ extern "C" size_t cfd_conv2d_bwd_workspace_bytes(int B, int Ci, int Co, int H, i
     // [extended input gradient | weight fragments and split-K partials of the input-gradient pass (conv6.hip)]; the
     // weight-gradient partials and the bias sums reuse the front of the buffer afterwards
     const ConvGeom gg{B, Ci, Co, H, W, ks};
-    const size_t dg = cfd_conv6_covers(gg, true) ? cfd_conv6_ws_bytes(gg, true) : ext;  // conv6: no extended buffer
+    const size_t dg = ext + (cfd_conv6_covers(gg, true) ? cfd_conv6_ws_bytes(gg, true) : 0);
     const size_t m = dg > part ? dg : part;
     return m > cs ? m : cs;
 }
@@ -456,23 +481,35 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
     hipStream_t st = (hipStream_t)stream;
     const ConvGeom g{B, Ci, Co, H, W, ks};
     const int HW = H * W, pad = ks / 2;
-    if (gin && cfd_conv6_covers(g, true)) {  // window of the extended grid on the MFMA kernel + the pad ring (conv6.hip): straight into gin
-        CFD_PROF_W("k_conv_dgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci * ks * ks), 2.0 * B * HW * (double)Co * Ci * ks * ks);
-        CFD_TRY(cfd_conv6_run(gout, w, nullptr, gin, ws, g, true, st, "cfd_conv2d_bwd(dgrad)"));
-    } else if (gin) {
+    if (gin) {
         float* ext = (float*)ws;
+        bool direct = false;
         {
             CFD_PROF_W("k_conv_dgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci * ks * ks),
                        2.0 * B * HW * (double)Co * Ci * ks * ks);
-            CFD_TRY(launch_conv_gather<true>(gout, w, nullptr, ext, g, st, "cfd_conv2d_bwd(dgrad)"));
+            const size_t ext_bytes = cfd_align_up((size_t)B * Ci * (H + 2 * pad) * (W + 2 * pad) * sizeof(float), 256);
+            if (cfd_conv6_covers(g, true)) {
+                CFD_TRY(cfd_conv6_run(gout, w, nullptr, ext, (char*)ws + ext_bytes, g, true, gin, &direct, st, "cfd_conv2d_bwd(dgrad)"));
+            } else {
+                CFD_TRY(launch_conv_gather<true>(gout, w, nullptr, ext, g, st, "cfd_conv2d_bwd(dgrad)"));
+            }
         }
         CFD_PROF_W("k_fold_pad", st, 0.0, 0.0);  // pure data movement of the extended-grid formulation: no algorithmic bytes
-        const long total = (long)B * Ci * HW;
-        long blocks = (total + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        CFD_REQUIRE_I31(total, "cfd_conv2d_bwd");
-        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ext, gin, (unsigned)total, H, W,
-                           pad, cfd_div_make((unsigned)HW), cfd_div_make((unsigned)W));
+        if (direct) {
+            const long total = (long)B * Ci * (2 * W + 2 * (H - 2));
+            CFD_REQUIRE_I31(total, "cfd_conv2d_bwd");
+            long blocks = (total + 255) / 256;
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(k_fold_border, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ext, gin, (unsigned)total, H, W, pad,
+                               cfd_div_make((unsigned)(2 * W + 2 * (H - 2))));
+        } else {
+            const long total = (long)B * Ci * HW;
+            long blocks = (total + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            CFD_REQUIRE_I31(total, "cfd_conv2d_bwd");
+            hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ext, gin, (unsigned)total, H, W,
+                               pad, cfd_div_make((unsigned)HW), cfd_div_make((unsigned)W));
+        }
         CFD_LAUNCH_CHECK("cfd_conv2d_bwd(fold)");
     }
     if (gw && cfd_conv6_wgrad_covers(g)) {

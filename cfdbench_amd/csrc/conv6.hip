@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void k_conv6_wprep(const float* __restrict__ w
 template <int KS, int MT, int CC, bool EXT, int NI>
 __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src, const u4* __restrict__ wfrag,
                                                   const float* __restrict__ bias, float* __restrict__ dst, ConvGeom g, ConvTile t,
-                                                  int MTall, int ptiles, float* __restrict__ stats) {
+                                                  int MTall, int ptiles, float* __restrict__ gin_direct,
+                                                  float* __restrict__ stats) {
     constexpr int KK = KS * KS, PAD = KS / 2;
     constexpr int CH8 = CC / 8, PPS = 4 / CH8, KSTEPS = (KK + PPS - 1) / PPS;
     constexpr int WTOT = KSTEPS * MT * 192, NWV = (WTOT + 255) / 256;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
     const int Cs = EXT ? g.Co : g.Ci, Cm = EXT ? g.Ci : g.Co;
-    const int Hd = g.H, Wd = g.W;  // (EXT: the H x W window of the extended grid; its ring is k_conv6_ring's)
+    const int Hd = EXT ? g.H + 2 * PAD : g.H, Wd = EXT ? g.W + 2 * PAD : g.W;
     const int HWd = Hd * Wd, HWs = g.H * g.W;
     const int halo = t.LH * t.LW, NPX = t.NB * halo;
     const int plane = NPX * CH8;                       // (pixel, channel octet) units of the halo tile (<= 256 NI)
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
         const int bg = tile / tpi, tr = tile - bg * tpi;
         const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
         const int b0 = bg * t.NB;
-        const int oy = ty0 - PAD, ox = tx0 - PAD;  // source coords of the halo origin (EXT: pixel (y, x) reads (y + PAD - ky, x + PAD - kx))
+        const int oy = EXT ? ty0 - 2 * PAD : ty0 - PAD, ox = EXT ? tx0 - 2 * PAD : tx0 - PAD;  // source coords of the halo origin
         const int c0 = ch * CC;
         const bool full = c0 + CC <= Cs;  // (uniform) every channel of the chunk exists: no per-channel clamping
 #pragma unroll
@@ -230,7 +231,17 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int m0 = 16 * (mb + mt) + 4 * q;
-                {
+                // input-gradient pass with `gin_direct`: extended positions that map one-to-one onto an interior pixel of the image
+                // go straight to gin; only the pad ring and the border rows / columns (whose pixels collect several extended
+                // positions) take the detour through the extended buffer and k_fold_border
+                const int yi = y - PAD, xi = x - PAD;
+                const bool direct = EXT && gin_direct != nullptr && yi >= 1 && yi <= g.H - 2 && xi >= 1 && xi <= g.W - 2;
+                if (direct) {
+                    const unsigned o = 4u * (unsigned)((b * Cm + m0) * HWs + yi * g.W + xi);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (on && m0 + r < Cm) cfd_stg_off(gin_direct + (size_t)r * HWs, o, outv[mt][tt][r]);
+                } else {
                     const unsigned o = 4u * (unsigned)((b * Cm + m0) * HWd + y * Wd + x);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -338,7 +349,7 @@ static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     Conv6Plan P{};
     if (g.ks != 3 && g.ks != 7) return P;
     const int KS = g.ks, PAD = KS / 2, KK = KS * KS;
-    const int Hd = g.H, Wd = g.W;  // (input gradient: the H x W window of the extended grid)
+    const int Hd = ext ? g.H + 2 * PAD : g.H, Wd = ext ? g.W + 2 * PAD : g.W;
     const int Cm = ext ? g.Ci : g.Co, Cs = ext ? g.Co : g.Ci;
     P.CC = (KS == 7 || Cs <= 8) ? 8 : 16;  // k = 7: 13 k-steps of 4 taps x 8 channels keep two workgroups per CU
     const int PPS = 32 / P.CC;
@@ -399,7 +410,7 @@ size_t cfd_conv6_ws_bytes(const ConvGeom& g, bool ext) {
 
 template <int KS, int CC, bool EXT>
 static void conv6_launch(const Conv6Plan& P, const float* src, const u4* wfrag, const float* bias, float* dst, const ConvGeom& g,
-                         float* stats, hipStream_t st) {
+                         float* gin_direct, float* stats, hipStream_t st) {
     const dim3 grid((unsigned)P.gx, P.mgroups, P.ksplit);
 #define C6_L(M_, N_)                                                                                                              \
     do {                                                                                                                          \
@@ -409,67 +420,16 @@ static void conv6_launch(const Conv6Plan& P, const float* src, const u4* wfrag, 
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
         hipLaunchKernelGGL((k_conv6<KS, M_, CC, EXT, N_>), grid, dim3(256), P.lds, st, src, wfrag, bias, dst, g, P.t, P.MTall,    \
-                           (int)P.ptiles, stats);                                                                                 \
+                           (int)P.ptiles, gin_direct, stats);                                                                     \
     } while (0)
     if (P.mtw == 1) { if (P.NI == 3) C6_L(1, 3); else C6_L(1, 5); }
     else { if (P.NI == 3) C6_L(2, 3); else C6_L(2, 5); }
 #undef C6_L
 }
 
-// ------------------------------------------------------------------------------------------------------
-// Ring of the input gradient.  gin = P^T V^T g (conv.hip): k_conv6<EXT> computes V^T g on the H x W WINDOW of the (H+2p) x (W+2p)
-// extended grid straight into gin -- for a pixel off the border that is all of it.  A border pixel q also collects the extended
-// positions P of the pad ring that replicate padding maps onto it (clamp(P - p) == q, P != q + p):
-//   gin[b][i][q] += sum_P sum_o sum_{ky, kx: 0 <= P - (ky, kx) < (H, W)} w[o][i][ky][kx] * g[b][o][P_y - ky][P_x - kx]
-// One thread per (image, input channel, border pixel); 2 (H + W) - 4 pixels per image, 3 Co (k = 3) .. ~100 Co (k = 7 corner)
-// multiply-adds each: ~2 % of the layer's work at 64 x 64 (k = 3), done on the VALU in exact fp32.  (Round 3 first ran the whole
-// extended grid through the MFMA kernel and folded it: +20 % pixels at 64 x 64 with k = 7, +56 % at 8 x 8, +125 % at 4 x 4.)
-// ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_conv6_ring(const float* __restrict__ gout, const float* __restrict__ w, float* __restrict__ gin,
-                                                    ConvGeom g, unsigned total, int nb, CfdDiv dNB, CfdDiv dCi) {
-    const int KS = g.ks, PAD = KS / 2, KK = KS * KS, H = g.H, W = g.W, HW = H * W;
-    const int nrow = H > 1 ? 2 * W : W;           // top row, then the bottom row if it is another one
-    const int ncol = W > 1 ? 2 : 1;               // left column, then the right column if it is another one (rows 1 .. H-2)
-    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const unsigned img = cfd_div(e, dNB);     // b * Ci + i
-        const int j = (int)(e - img * (unsigned)nb);
-        const unsigned b = cfd_div(img, dCi);
-        const int i = (int)(img - b * (unsigned)g.Ci);
-        int y, x;
-        if (j < W) { y = 0; x = j; }
-        else if (j < nrow) { y = H - 1; x = j - W; }
-        else { const int r = j - nrow; y = 1 + r / ncol; x = (r % ncol) ? W - 1 : 0; }
-        const int y0 = y == 0 ? 0 : y + PAD, y1 = y == H - 1 ? H - 1 + 2 * PAD : y + PAD;   // extended rows mapped onto y
-        const int x0 = x == 0 ? 0 : x + PAD, x1 = x == W - 1 ? W - 1 + 2 * PAD : x + PAD;
-        const float* gb = gout + (size_t)b * g.Co * HW;
-        const float* wi = w + (size_t)i * KK;
-        float acc = 0.f;
-        for (int Py = y0; Py <= y1; ++Py)
-            for (int Px = x0; Px <= x1; ++Px) {
-                if (Py == y + PAD && Px == x + PAD) continue;  // the window position: k_conv6's
-                const int kyl = Py - (H - 1) > 0 ? Py - (H - 1) : 0, kyh = Py < KS - 1 ? Py : KS - 1;
-                const int kxl = Px - (W - 1) > 0 ? Px - (W - 1) : 0, kxh = Px < KS - 1 ? Px : KS - 1;
-                for (int ky = kyl; ky <= kyh; ++ky)
-                    for (int kx = kxl; kx <= kxh; ++kx) {
-                        const float* gp = gb + (Py - ky) * W + (Px - kx);
-                        const float* wp = wi + ky * KS + kx;
-                        float a0 = 0.f, a1 = 0.f;  // two chains over the output channels
-                        int o = 0;
-                        for (; o + 1 < g.Co; o += 2) {
-                            a0 = fmaf(gp[(size_t)o * HW], wp[(size_t)o * g.Ci * KK], a0);
-                            a1 = fmaf(gp[(size_t)(o + 1) * HW], wp[(size_t)(o + 1) * g.Ci * KK], a1);
-                        }
-                        if (o < g.Co) a0 = fmaf(gp[(size_t)o * HW], wp[(size_t)o * g.Ci * KK], a0);
-                        acc += a0 + a1;
-                    }
-            }
-        gin[(size_t)img * HW + y * W + x] += acc;
-    }
-}
-
 template <bool EXT>
-static int conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, float* stats,
-                     hipStream_t st, const char* what) {
+static int conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, float* gin,
+                     bool* direct, float* stats, hipStream_t st, const char* what) {
     const Conv6Plan P = conv6_plan(g, EXT);
     if (!P.ok) return CFD_ERR_UNSUPPORTED;
     u4* wfrag = (u4*)ws;
@@ -482,34 +442,30 @@ static int conv6_run(const float* src, const float* w, const float* bias, float*
         CFD_LAUNCH_CHECK(what);
     }
     float* kdst = P.ksplit > 1 ? split_ws : dst;
+    // interior pixels of the input gradient straight to gin (no split-K partials, an interior exists, 32-bit offsets hold)
+    float* gd = (EXT && gin && P.ksplit == 1 && g.H >= 3 && g.W >= 3) ? gin : nullptr;
+    if (direct) *direct = gd != nullptr;
     if (stats && (EXT || P.ksplit > 1 || P.NI != 3)) return CFD_ERR_UNSUPPORTED;  // (callers ask cfd_conv6_stats_slots first)
     if (g.ks == 3) {
-        if (P.CC == 8) conv6_launch<3, 8, EXT>(P, src, wfrag, bias, kdst, g, stats, st);
-        else conv6_launch<3, 16, EXT>(P, src, wfrag, bias, kdst, g, stats, st);
+        if (P.CC == 8) conv6_launch<3, 8, EXT>(P, src, wfrag, bias, kdst, g, gd, stats, st);
+        else conv6_launch<3, 16, EXT>(P, src, wfrag, bias, kdst, g, gd, stats, st);
     } else {
-        conv6_launch<7, 8, EXT>(P, src, wfrag, bias, kdst, g, stats, st);
+        conv6_launch<7, 8, EXT>(P, src, wfrag, bias, kdst, g, gd, stats, st);
     }
     CFD_LAUNCH_CHECK(what);
-    const int Cm = EXT ? g.Ci : g.Co;
-    const long HWd = (long)g.H * g.W;
-    if (P.ksplit > 1) CFD_TRY(cfd_conv_splitk_sum(split_ws, bias, dst, (long)g.B * Cm * HWd, P.ksplit, Cm, HWd, st, what));
-    if (EXT) {  // the pad ring, added onto the border pixels
-        const int nb = (g.H > 1 ? 2 * g.W : g.W) + (g.H > 2 ? (g.H - 2) * (g.W > 1 ? 2 : 1) : 0);
-        const long total = (long)g.B * g.Ci * nb;
-        CFD_REQUIRE_I31(total, what);
-        long blocks = (total + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(k_conv6_ring, dim3((unsigned)blocks), dim3(256), 0, st, src, w, dst, g, (unsigned)total, nb,
-                           cfd_div_make((unsigned)nb), cfd_div_make((unsigned)g.Ci));
-        CFD_LAUNCH_CHECK(what);
+    if (P.ksplit > 1) {
+        const int PAD = g.ks / 2, Cm = EXT ? g.Ci : g.Co;
+        const long HWd = EXT ? (long)(g.H + 2 * PAD) * (g.W + 2 * PAD) : (long)g.H * g.W;
+        CFD_TRY(cfd_conv_splitk_sum(split_ws, bias, dst, (long)g.B * Cm * HWd, P.ksplit, Cm, HWd, st, what));
     }
     return CFD_OK;
 }
 
-// ext: dst = gin (B,Ci,H,W), complete (window + ring)
-int cfd_conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, bool ext,
-                  hipStream_t st, const char* what, float* stats) {
-    return ext ? conv6_run<true>(src, w, bias, dst, ws, g, nullptr, st, what) : conv6_run<false>(src, w, bias, dst, ws, g, stats, st, what);
+int cfd_conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, bool ext, float* gin,
+                  bool* direct, hipStream_t st, const char* what, float* stats) {
+    if (direct) *direct = false;
+    return ext ? conv6_run<true>(src, w, bias, dst, ws, g, gin, direct, nullptr, st, what)
+               : conv6_run<false>(src, w, bias, dst, ws, g, nullptr, nullptr, stats, st, what);
 }
 
 // partial (sum, sum of squares) pairs per output channel the forward kernel can emit for the BatchNorm that follows (0: not on
