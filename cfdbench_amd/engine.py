@@ -9,6 +9,7 @@ key names, complex64 spectral weights) always reflects the trained weights and c
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -68,12 +69,17 @@ class GradSync:
 
     def __init__(self, group=None, n_buckets: int = 1):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        live = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if live else 1
         self.n_buckets = max(1, n_buckets)
+        # A one-rank group has nothing to exchange and skips the collectives -- unless CFDBENCH_DP_ALWAYS_EXCHANGE=1 asks for them:
+        # that is how a one-GPU box runs the RCCL path itself (communicator stream, event ordering, slices of the flat buffer
+        # reduced while later backward phases still write it; tests/test_gpu_dp.py).  A SUM over one rank is the identity.
+        self.exchange = self.world > 1 or (live and os.environ.get("CFDBENCH_DP_ALWAYS_EXCHANGE", "0") == "1")
         # RCCL ("nccl") reduces device buffers on its own stream, ordered by events: the asynchronous per-slice exchange below.
         # Any other backend (gloo: the CPU tests, and the 2-process tests that share one GPU) gets device slices through an
         # explicit, stream-ordered host staging in wait_all -- correct by construction, no overlap.
-        self.device_native = self.world > 1 and dist.get_backend(group) == "nccl"
+        self.device_native = self.exchange and dist.get_backend(group) == "nccl"
 
     def bucket_slices(self, numel: int) -> List[Tuple[int, int]]:
         per = (numel + self.n_buckets - 1) // self.n_buckets
@@ -83,7 +89,7 @@ class GradSync:
     def reduce_slice_async(self, flat_grad: Tensor, start: int, stop: int):
         """Start the SUM all-reduce of flat_grad[start:stop] (ordered after the work already enqueued on the current
         stream, running on the communicator's own stream); None when there is nothing to exchange."""
-        if self.world == 1 or stop <= start:
+        if not self.exchange or stop <= start:
             return None
         if flat_grad.is_cuda and not self.device_native:
             return ("host", flat_grad, start, stop)
@@ -103,7 +109,7 @@ class GradSync:
 
     def all_reduce(self, flat_grad: Tensor) -> float:
         """Returns the scale to apply to the reduced gradient (1/world)."""
-        if self.world == 1:
+        if not self.exchange:
             return 1.0
         return self.wait_all([self.reduce_slice_async(flat_grad, a, b) for a, b in self.bucket_slices(flat_grad.numel())])
 
@@ -283,7 +289,7 @@ class FnoTrainEngine:
     def train_step(self, inputs: Tensor, label: Tensor, case_params: Tensor, mask: Optional[Tensor] = None) -> Tensor:
         """One optimisation step; returns the device tensor [sum sq err, sum abs err, sum sq label, n] of THIS rank's
         batch (no host sync -- read it with .tolist() only when logging)."""
-        if self.sync.world > 1 and self.overlap:
+        if self.sync.exchange and self.overlap:
             scale = self.forward_backward_overlapped(inputs, label, case_params, mask)
         else:
             self.forward_backward(inputs, label, case_params, mask)

@@ -135,6 +135,38 @@ def test_data_parallel_gradient_exchange_gloo_world2():
     assert not np.allclose(res[0][2], res[1][2])  # the ranks really had different shards
 
 
+def _alone_worker(port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from cfdbench_amd.engine import GradSync
+        quiet = GradSync(None, n_buckets=3)
+        os.environ["CFDBENCH_DP_ALWAYS_EXCHANGE"] = "1"
+        forced = GradSync(None, n_buckets=3)
+        t = torch.arange(1000, dtype=torch.float32)
+        handles = [forced.reduce_slice_async(t, a, b) for a, b in forced.bucket_slices(t.numel())]
+        q.put((quiet.exchange, forced.exchange, quiet.reduce_slice_async(t, 0, 10) is None, sum(h is not None for h in handles),
+               forced.wait_all(handles), bool(torch.equal(t, torch.arange(1000, dtype=torch.float32)))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_group_runs_the_collectives_only_when_asked():
+    """CFDBENCH_DP_ALWAYS_EXCHANGE=1: a one-rank group still issues its all-reduces (how the RCCL branch is exercised on a one-GPU
+    box, tests/test_gpu_dp.py); by default it skips them."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_alone_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert res == (False, True, True, 3, 1.0, True)
+
+
 def _sync_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist

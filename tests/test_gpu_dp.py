@@ -109,3 +109,55 @@ def test_engine_train_step_world2_equals_ddp_emulation(overlap):
     assert np.array_equal(res[0][1], res[1][1]), "replicas diverged"
     assert np.array_equal(res[0][1], final)
     assert not np.array_equal(parts[0].cpu().numpy(), parts[1].cpu().numpy())  # the ranks really had different shards
+
+
+def _rccl_worker(port, overlap, graph, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CFDBENCH_DP_ALWAYS_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      NCCL_SOCKET_IFNAME="lo")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from cfdbench_amd.engine import FnoTrainEngine
+        eng = FnoTrainEngine(_make_model(torch), lr=1e-3, loss_name="nmse", overlap=overlap, grad_buckets=3)
+        assert eng.sync.exchange and eng.sync.device_native
+        grads = []
+        for step in range(STEPS):
+            b = _batch(torch, step, 0, 1)
+            (eng.train_step_graph if graph else eng.train_step)(b["inputs"], b["label"], b["case_params"], b["mask"])
+            torch.cuda.synchronize()
+            grads.append(eng.flat.grad.cpu().numpy().copy())
+        q.put((eng.flat.data.cpu().numpy().copy(), grads))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap,graph", [(True, False), (False, False), (False, True)])
+def test_engine_train_step_over_rccl_one_rank_group(overlap, graph):
+    """The RCCL branch of GradSync itself (backend "nccl": asynchronous all-reduce of slices of the flat gradient on the
+    communicator's stream, ordered by events, while later backward phases are still being enqueued) on the one GPU this box
+    has: a one-rank group whose collectives are forced on (CFDBENCH_DP_ALWAYS_EXCHANGE=1).  A SUM over one rank is the
+    identity, so gradients and parameters must equal the plain single-process engine's bit for bit -- any missing
+    stream dependency between the kernels and the collective shows up as a torn slice."""
+    import torch
+    import torch.multiprocessing as mp
+    from cfdbench_amd.engine import FnoTrainEngine
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_rccl_worker, args=(_free_port(), overlap, graph, q))
+    proc.start()
+    try:
+        params, grads = q.get(timeout=300)
+    finally:
+        proc.join(timeout=120)
+        if proc.is_alive():
+            proc.kill()
+    assert proc.exitcode == 0
+    eng = FnoTrainEngine(_make_model(torch), lr=1e-3, loss_name="nmse")
+    for step in range(STEPS):
+        b = _batch(torch, step, 0, 1)
+        eng.train_step(b["inputs"], b["label"], b["case_params"], b["mask"])
+        torch.cuda.synchronize()
+        assert np.array_equal(grads[step], eng.flat.grad.cpu().numpy()), f"step {step}: gradient after the RCCL exchange differs"
+    assert np.array_equal(params, eng.flat.data.cpu().numpy())
