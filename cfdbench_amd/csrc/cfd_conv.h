@@ -33,8 +33,13 @@ size_t cfd_conv6_ws_bytes(const ConvGeom& g, bool ext);
 // ext with `gin` != NULL: extended positions that map one-to-one onto an interior pixel may be written straight to gin (B,Ci,H,W)
 // instead of dst; *direct then says so and the caller folds only the border pixels (k_fold_border) instead of every pixel.
 // forward with `stats` != NULL ((Co, cfd_conv6_stats_slots(), 2) floats): per-channel partial sums of (out - bias) and its square.
+// `wfrag` != NULL: the weights' fragments made earlier by cfd_conv6_wprep_batch (cfd_conv6_wfrag_bytes() bytes for this
+// (Ci, Co, ks, ext)); the call then skips its own preparation launch.
 int cfd_conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, bool ext, float* gin,
-                  bool* direct, hipStream_t st, const char* what, float* stats = nullptr);
+                  bool* direct, hipStream_t st, const char* what, float* stats = nullptr, const void* wfrag = nullptr);
+size_t cfd_conv6_wfrag_bytes(int Ci, int Co, int ks, bool ext);  // 0: no fragment form (kernel size other than 3 / 7)
+int cfd_conv6_wprep_batch(int n, const float* const* w, void* const* wfrag, const int* Ci, const int* Co, const int* ks, const int* ext,
+                          hipStream_t st, const char* what);
 int cfd_conv6_stats_slots(const ConvGeom& g);
 // weight gradient gw (Co,Ci,ks,ks) = sum over (b, p) of gout[b][o][p] * in[b][i][clamp(p + tap)]
 bool cfd_conv6_wgrad_covers(const ConvGeom& g);

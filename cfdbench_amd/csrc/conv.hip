@@ -197,21 +197,6 @@ extern "C" size_t cfd_conv2d_fwd_workspace_bytes(int B, int Ci, int Co, int H, i
     return 0;
 }
 
-// ws: cfd_conv2d_fwd_workspace_bytes() bytes, or NULL (then k = 3 / 7 run on the exact-fp32 gather kernel of this file instead of
-// the three-piece bf16 kernels of conv6.hip)
-extern "C" int cfd_conv2d_fwd(const float* in, const float* w, const float* bias, float* out, void* ws, int B, int Ci, int Co,
-                              int H, int W, int ks, void* stream) {
-    CFD_REQUIRE(in && w && out, CFD_ERR_INVALID_ARG, "cfd_conv2d_fwd: NULL pointer");
-    CFD_TRY(conv_check("cfd_conv2d_fwd", B, Ci, Co, H, W, ks));
-    if (B == 0) return CFD_OK;
-    const ConvGeom g{B, Ci, Co, H, W, ks};
-    CFD_PROF_W("k_conv_fwd", (hipStream_t)stream, 4.0 * ((double)B * (Ci + Co) * H * W + (double)Co * Ci * ks * ks),
-               2.0 * B * H * W * (double)Co * Ci * ks * ks);
-    if (ws && cfd_conv6_covers(g, false))
-        return cfd_conv6_run(in, w, bias, out, ws, g, false, nullptr, nullptr, (hipStream_t)stream, "cfd_conv2d_fwd");
-    return launch_conv_gather<false>(in, w, bias, out, g, (hipStream_t)stream, "cfd_conv2d_fwd");
-}
-
 // The same forward, also emitting per-channel partial sums for the training-mode BatchNorm that follows the conv:
 // stats (Co, slots, 2) = sums of (out - bias) and (out - bias)^2 over disjoint pixel sets, slots = cfd_conv2d_fwd_stats_slots()
 // (0: this layer cannot emit them -- use cfd_conv2d_fwd and cfd_batchnorm_fwd).  cfd_batchnorm_fwd_stats consumes them.
@@ -221,17 +206,57 @@ extern "C" int cfd_conv2d_fwd_stats_slots(int B, int Ci, int Co, int H, int W, i
     return cfd_conv6_covers(g, false) ? cfd_conv6_stats_slots(g) : 0;
 }
 
-extern "C" int cfd_conv2d_fwd_stats(const float* in, const float* w, const float* bias, float* out, void* ws, float* stats, int B,
-                                    int Ci, int Co, int H, int W, int ks, void* stream) {
-    CFD_REQUIRE(in && w && out && ws && stats, CFD_ERR_INVALID_ARG, "cfd_conv2d_fwd_stats: NULL pointer");
-    CFD_TRY(conv_check("cfd_conv2d_fwd_stats", B, Ci, Co, H, W, ks));
-    CFD_REQUIRE(B >= 1, CFD_ERR_INVALID_ARG, "cfd_conv2d_fwd_stats: empty batch");
+// Fragments of the weights made ahead of the calls that use them (conv6.hip: the form depends on (Ci, Co, ks, transposed) only):
+// cfd_conv2d_wprep_batch fills the buffers of any number of layers in ONE launch; cfd_conv2d_fwd_ex / cfd_conv2d_bwd_ex take them
+// and skip their own preparation launch.  transposed = 0: the forward pass; 1: the input-gradient pass.
+extern "C" size_t cfd_conv2d_wfrag_bytes(int Ci, int Co, int ks, int transposed) {
+    if (Ci < 1 || Co < 1 || Ci > 192 || Co > 192) return 0;
+    return cfd_conv6_wfrag_bytes(Ci, Co, ks, transposed != 0);
+}
+
+extern "C" int cfd_conv2d_wprep_batch(int n, const float* const* w, void* const* wfrag, const int* Ci, const int* Co, const int* ks,
+                                      const int* transposed, void* stream) {
+    CFD_REQUIRE(n >= 0, CFD_ERR_INVALID_ARG, "cfd_conv2d_wprep_batch: negative count");
+    if (n == 0) return CFD_OK;
+    CFD_REQUIRE(w && wfrag && Ci && Co && ks && transposed, CFD_ERR_INVALID_ARG, "cfd_conv2d_wprep_batch: NULL table");
+    for (int i = 0; i < n; ++i)
+        CFD_REQUIRE(cfd_conv2d_wfrag_bytes(Ci[i], Co[i], ks[i], transposed[i]) > 0, CFD_ERR_UNSUPPORTED,
+                    "cfd_conv2d_wprep_batch: item %d (%d -> %d channels, kernel size %d) has no fragment form", i, Ci[i], Co[i], ks[i]);
+    CFD_PROF_W("k_conv_wprep", (hipStream_t)stream, 0.0, 0.0);  // (an implementation detail of the k = 3 / 7 kernels: no algorithmic bytes)
+    return cfd_conv6_wprep_batch(n, w, wfrag, Ci, Co, ks, transposed, (hipStream_t)stream, "cfd_conv2d_wprep_batch");
+}
+
+// ws: cfd_conv2d_fwd_workspace_bytes() bytes, or NULL (then k = 3 / 7 run on the exact-fp32 gather kernel of this file instead of
+// the three-piece bf16 kernels of conv6.hip).  stats: NULL or the (Co, slots, 2) partial sums above.  wfrag: NULL or the weights'
+// forward fragments (cfd_conv2d_wprep_batch); ignored where the layer does not run on the fragment kernels.
+extern "C" int cfd_conv2d_fwd_ex(const float* in, const float* w, const float* bias, float* out, void* ws, float* stats,
+                                 const void* wfrag, int B, int Ci, int Co, int H, int W, int ks, void* stream) {
+    CFD_REQUIRE(in && w && out, CFD_ERR_INVALID_ARG, "cfd_conv2d_fwd: NULL pointer");
+    CFD_TRY(conv_check("cfd_conv2d_fwd", B, Ci, Co, H, W, ks));
+    if (stats) {
+        CFD_REQUIRE(ws, CFD_ERR_INVALID_ARG, "cfd_conv2d_fwd: statistics need the workspace");
+        CFD_REQUIRE(B >= 1, CFD_ERR_INVALID_ARG, "cfd_conv2d_fwd: statistics of an empty batch");
+        CFD_REQUIRE(cfd_conv2d_fwd_stats_slots(B, Ci, Co, H, W, ks) > 0, CFD_ERR_UNSUPPORTED,
+                    "cfd_conv2d_fwd: this layer emits no statistics (cfd_conv2d_fwd_stats_slots() == 0)");
+    }
+    if (B == 0) return CFD_OK;
     const ConvGeom g{B, Ci, Co, H, W, ks};
-    CFD_REQUIRE(cfd_conv2d_fwd_stats_slots(B, Ci, Co, H, W, ks) > 0, CFD_ERR_UNSUPPORTED,
-                "cfd_conv2d_fwd_stats: this layer emits no statistics (cfd_conv2d_fwd_stats_slots() == 0)");
     CFD_PROF_W("k_conv_fwd", (hipStream_t)stream, 4.0 * ((double)B * (Ci + Co) * H * W + (double)Co * Ci * ks * ks),
                2.0 * B * H * W * (double)Co * Ci * ks * ks);
-    return cfd_conv6_run(in, w, bias, out, ws, g, false, nullptr, nullptr, (hipStream_t)stream, "cfd_conv2d_fwd_stats", stats);
+    if (ws && cfd_conv6_covers(g, false))
+        return cfd_conv6_run(in, w, bias, out, ws, g, false, nullptr, nullptr, (hipStream_t)stream, "cfd_conv2d_fwd", stats, wfrag);
+    return launch_conv_gather<false>(in, w, bias, out, g, (hipStream_t)stream, "cfd_conv2d_fwd");
+}
+
+extern "C" int cfd_conv2d_fwd(const float* in, const float* w, const float* bias, float* out, void* ws, int B, int Ci, int Co,
+                              int H, int W, int ks, void* stream) {
+    return cfd_conv2d_fwd_ex(in, w, bias, out, ws, nullptr, nullptr, B, Ci, Co, H, W, ks, stream);
+}
+
+extern "C" int cfd_conv2d_fwd_stats(const float* in, const float* w, const float* bias, float* out, void* ws, float* stats, int B,
+                                    int Ci, int Co, int H, int W, int ks, void* stream) {
+    CFD_REQUIRE(stats, CFD_ERR_INVALID_ARG, "cfd_conv2d_fwd_stats: NULL pointer");
+    return cfd_conv2d_fwd_ex(in, w, bias, out, ws, stats, nullptr, B, Ci, Co, H, W, ks, stream);
 }
 
 // gin[b][i][y][x] = sum over the extended positions that replicate padding maps to (y, x)
@@ -472,9 +497,18 @@ extern "C" size_t cfd_conv2d_bwd_workspace_bytes(int B, int Ci, int Co, int H, i
     return m > cs ? m : cs;
 }
 
-// gin (B,Ci,H,W), gw (Co,Ci,ks,ks), gb (Co) from gout (B,Co,H,W); any of gin / gw / gb may be NULL.
+// gin (B,Ci,H,W), gw (Co,Ci,ks,ks), gb (Co) from gout (B,Co,H,W); any of gin / gw / gb may be NULL.  wfrag_t: NULL or the weights'
+// input-gradient fragments (cfd_conv2d_wprep_batch, transposed = 1).
+extern "C" int cfd_conv2d_bwd_ex(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws,
+                                 const void* wfrag_t, int B, int Ci, int Co, int H, int W, int ks, void* stream);
+
 extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws,
                               int B, int Ci, int Co, int H, int W, int ks, void* stream) {
+    return cfd_conv2d_bwd_ex(gout, in, w, gin, gw, gb, ws, nullptr, B, Ci, Co, H, W, ks, stream);
+}
+
+extern "C" int cfd_conv2d_bwd_ex(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws,
+                                 const void* wfrag_t, int B, int Ci, int Co, int H, int W, int ks, void* stream) {
     CFD_REQUIRE(gout && in && w && ws, CFD_ERR_INVALID_ARG, "cfd_conv2d_bwd: NULL pointer");
     CFD_TRY(conv_check("cfd_conv2d_bwd", B, Ci, Co, H, W, ks));
     CFD_REQUIRE(B >= 1, CFD_ERR_INVALID_ARG, "cfd_conv2d_bwd: empty batch");
@@ -489,7 +523,8 @@ extern "C" int cfd_conv2d_bwd(const float* gout, const float* in, const float* w
                        2.0 * B * HW * (double)Co * Ci * ks * ks);
             const size_t ext_bytes = cfd_align_up((size_t)B * Ci * (H + 2 * pad) * (W + 2 * pad) * sizeof(float), 256);
             if (cfd_conv6_covers(g, true)) {
-                CFD_TRY(cfd_conv6_run(gout, w, nullptr, ext, (char*)ws + ext_bytes, g, true, gin, &direct, st, "cfd_conv2d_bwd(dgrad)"));
+                CFD_TRY(cfd_conv6_run(gout, w, nullptr, ext, (char*)ws + ext_bytes, g, true, gin, &direct, st, "cfd_conv2d_bwd(dgrad)",
+                                      nullptr, wfrag_t));
             } else {
                 CFD_TRY(launch_conv_gather<true>(gout, w, nullptr, ext, g, st, "cfd_conv2d_bwd(dgrad)"));
             }

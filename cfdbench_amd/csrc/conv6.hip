@@ -49,12 +49,12 @@ static int conv6_grid() {
 //   (CH8 = CC / 8 channel octets per tap, PPS = 4 / CH8 taps per step).  EXT: A(m = i, (o, ky, kx)) = w[o][i][ky][kx].
 // ------------------------------------------------------------------------------------------------------
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_conv6_wprep(const float* __restrict__ w, u4* __restrict__ wfrag, ConvGeom g, int CC,
-                                                     int KSTEPS, int MTall, unsigned total) {
-    const int KK = g.ks * g.ks;
-    const int Cs = EXT ? g.Co : g.Ci, Cm = EXT ? g.Ci : g.Co;
+__device__ __forceinline__ void conv6_wprep_body(const float* __restrict__ w, u4* __restrict__ wfrag, int Ci, int Co, int ks, int CC,
+                                                 int KSTEPS, int MTall, unsigned total, unsigned first, unsigned stride) {
+    const int KK = ks * ks;
+    const int Cs = EXT ? Co : Ci, Cm = EXT ? Ci : Co;
     const int CH8 = CC / 8, PPS = 4 / CH8;
-    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    for (unsigned idx = first; idx < total; idx += stride) {
         const int lane = idx & 63;
         unsigned rest = idx >> 6;
         const int mtile = rest % MTall;
@@ -66,12 +66,43 @@ __global__ __launch_bounds__(256) void k_conv6_wprep(const float* __restrict__ w
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = cb + j;
-            v[j] = (m < Cm && c < Cs && pos < KK) ? (EXT ? w[((size_t)c * g.Ci + m) * KK + pos] : w[((size_t)m * g.Ci + c) * KK + pos]) : 0.f;
+            v[j] = (m < Cm && c < Cs && pos < KK) ? (EXT ? w[((size_t)c * Ci + m) * KK + pos] : w[((size_t)m * Ci + c) * KK + pos]) : 0.f;
         }
         const CfdSplit8x3 sp = cfd_split8x3(v);
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) wfrag[((size_t)(idx >> 6) * 3 + pc) * 64 + lane] = __builtin_bit_cast(u4, sp.p[pc]);
     }
+}
+
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_conv6_wprep(const float* __restrict__ w, u4* __restrict__ wfrag, ConvGeom g, int CC,
+                                                     int KSTEPS, int MTall, unsigned total) {
+    conv6_wprep_body<EXT>(w, wfrag, g.Ci, g.Co, g.ks, CC, KSTEPS, MTall, total, blockIdx.x * blockDim.x + threadIdx.x,
+                          gridDim.x * blockDim.x);
+}
+
+// The fragments of MANY weight tensors in one launch (cfd_conv2d_wprep_batch: a model prepares every layer's weights once per
+// forward pass instead of one ~4 us launch in front of each convolution and each input gradient -- 35 launches of a U-Net step).
+// Workgroups [blk0, blk0 + nblk) belong to item i; the table travels as the kernel argument.
+#define CFD_WPREP_MAX 32
+struct WprepItem {
+    const float* w;
+    u4* frag;
+    int Ci, Co, ks, CC, KSTEPS, MTall, ext;
+    unsigned total, blk0, nblk;
+};
+struct WprepBatch {
+    int n;
+    WprepItem it[CFD_WPREP_MAX];
+};
+
+__global__ __launch_bounds__(256) void k_conv6_wprep_batch(const WprepBatch b) {
+    int i = 0;
+    while (i + 1 < b.n && blockIdx.x >= b.it[i + 1].blk0) ++i;
+    const WprepItem& e = b.it[i];
+    const unsigned first = (blockIdx.x - e.blk0) * blockDim.x + threadIdx.x, stride = e.nblk * blockDim.x;
+    if (e.ext) conv6_wprep_body<true>(e.w, e.frag, e.Ci, e.Co, e.ks, e.CC, e.KSTEPS, e.MTall, e.total, first, stride);
+    else conv6_wprep_body<false>(e.w, e.frag, e.Ci, e.Co, e.ks, e.CC, e.KSTEPS, e.MTall, e.total, first, stride);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -345,17 +376,39 @@ struct Conv6Plan {
     bool ok;
 };
 
+// The fragment form of a weight tensor depends on (Ci, Co, ks, ext) only -- not on the batch or the grid -- so fragments made once
+// serve every call of the layer.
+struct Conv6Frag {
+    int CC, KSTEPS, MTall, nch;
+    size_t bytes;
+    bool ok;
+};
+
+static Conv6Frag conv6_frag(int Ci, int Co, int ks, bool ext) {
+    Conv6Frag F{};
+    if ((ks != 3 && ks != 7) || Ci < 1 || Co < 1) return F;
+    const int Cm = ext ? Ci : Co, Cs = ext ? Co : Ci;
+    F.CC = (ks == 7 || Cs <= 8) ? 8 : 16;  // k = 7: 13 k-steps of 4 taps x 8 channels keep two workgroups per CU
+    const int PPS = 32 / F.CC;
+    F.KSTEPS = (ks * ks + PPS - 1) / PPS;
+    F.MTall = (Cm + 15) / 16;
+    F.nch = (Cs + F.CC - 1) / F.CC;
+    F.bytes = cfd_align_up((size_t)F.nch * F.KSTEPS * F.MTall * 3 * 1024, 256);
+    F.ok = (long)F.nch * F.KSTEPS * F.MTall * 64 < (1L << 31);
+    return F;
+}
+
 static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     Conv6Plan P{};
     if (g.ks != 3 && g.ks != 7) return P;
-    const int KS = g.ks, PAD = KS / 2, KK = KS * KS;
+    const int KS = g.ks, PAD = KS / 2;
     const int Hd = ext ? g.H + 2 * PAD : g.H, Wd = ext ? g.W + 2 * PAD : g.W;
     const int Cm = ext ? g.Ci : g.Co, Cs = ext ? g.Co : g.Ci;
-    P.CC = (KS == 7 || Cs <= 8) ? 8 : 16;  // k = 7: 13 k-steps of 4 taps x 8 channels keep two workgroups per CU
-    const int PPS = 32 / P.CC;
-    P.KSTEPS = (KK + PPS - 1) / PPS;
-    P.MTall = (Cm + 15) / 16;
-    P.nch = (Cs + P.CC - 1) / P.CC;
+    const Conv6Frag F = conv6_frag(g.Ci, g.Co, g.ks, ext);
+    P.CC = F.CC;
+    P.KSTEPS = F.KSTEPS;
+    P.MTall = F.MTall;
+    P.nch = F.nch;
     ConvTile& t = P.t;
     cfd_conv_tile_shape(Hd, Wd, g.B, t.TW, t.TH, t.NB);
     // a thread prefetches at most 5 halo items (8 channel values each) of the next tile: small images, many per workgroup
@@ -394,10 +447,10 @@ static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     long gx = conv6_grid() / ((long)P.mgroups * P.ksplit);
     if (gx < 1) gx = 1;
     P.gx = (int)(gx < P.ptiles ? gx : P.ptiles);
-    P.wfrag_bytes = cfd_align_up((size_t)P.nch * P.KSTEPS * P.MTall * 3 * 1024, 256);
+    P.wfrag_bytes = F.bytes;
     P.split_bytes = P.ksplit > 1 ? cfd_align_up((size_t)P.ksplit * g.B * Cm * Hd * Wd * sizeof(float), 256) : 0;
     const bool small = (long)g.B * Cs * g.H * g.W < (1L << 30) && (long)g.B * Cm * Hd * Wd < (1L << 30);  // 32-bit byte offsets
-    P.ok = small && P.lds <= 150 * 1024 && plane <= 5 * 256 && (long)P.nch * P.KSTEPS * P.MTall * 64 < (1L << 31) && P.ptiles < (1L << 30);
+    P.ok = small && P.lds <= 150 * 1024 && plane <= 5 * 256 && F.ok && P.ptiles < (1L << 30);
     return P;
 }
 
@@ -429,16 +482,16 @@ static void conv6_launch(const Conv6Plan& P, const float* src, const u4* wfrag, 
 
 template <bool EXT>
 static int conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, float* gin,
-                     bool* direct, float* stats, hipStream_t st, const char* what) {
+                     bool* direct, float* stats, const void* wfrag_ready, hipStream_t st, const char* what) {
     const Conv6Plan P = conv6_plan(g, EXT);
     if (!P.ok) return CFD_ERR_UNSUPPORTED;
-    u4* wfrag = (u4*)ws;
+    const u4* wfrag = wfrag_ready ? (const u4*)wfrag_ready : (const u4*)ws;
     float* split_ws = P.ksplit > 1 ? (float*)((char*)ws + P.wfrag_bytes) : nullptr;
-    {
+    if (!wfrag_ready) {
         const unsigned total = (unsigned)((long)P.nch * P.KSTEPS * P.MTall * 64);
         unsigned blocks = (total + 255) / 256;
         if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL((k_conv6_wprep<EXT>), dim3(blocks), dim3(256), 0, st, w, wfrag, g, P.CC, P.KSTEPS, P.MTall, total);
+        hipLaunchKernelGGL((k_conv6_wprep<EXT>), dim3(blocks), dim3(256), 0, st, w, (u4*)ws, g, P.CC, P.KSTEPS, P.MTall, total);
         CFD_LAUNCH_CHECK(what);
     }
     float* kdst = P.ksplit > 1 ? split_ws : dst;
@@ -462,10 +515,44 @@ static int conv6_run(const float* src, const float* w, const float* bias, float*
 }
 
 int cfd_conv6_run(const float* src, const float* w, const float* bias, float* dst, void* ws, const ConvGeom& g, bool ext, float* gin,
-                  bool* direct, hipStream_t st, const char* what, float* stats) {
+                  bool* direct, hipStream_t st, const char* what, float* stats, const void* wfrag) {
     if (direct) *direct = false;
-    return ext ? conv6_run<true>(src, w, bias, dst, ws, g, gin, direct, nullptr, st, what)
-               : conv6_run<false>(src, w, bias, dst, ws, g, nullptr, nullptr, stats, st, what);
+    return ext ? conv6_run<true>(src, w, bias, dst, ws, g, gin, direct, nullptr, wfrag, st, what)
+               : conv6_run<false>(src, w, bias, dst, ws, g, nullptr, nullptr, stats, wfrag, st, what);
+}
+
+size_t cfd_conv6_wfrag_bytes(int Ci, int Co, int ks, bool ext) {
+    const Conv6Frag F = conv6_frag(Ci, Co, ks, ext);
+    return F.ok ? F.bytes : 0;
+}
+
+int cfd_conv6_wprep_batch(int n, const float* const* w, void* const* wfrag, const int* Ci, const int* Co, const int* ks,
+                          const int* ext, hipStream_t st, const char* what) {
+    for (int base = 0; base < n; base += CFD_WPREP_MAX) {
+        WprepBatch b{};
+        b.n = n - base < CFD_WPREP_MAX ? n - base : CFD_WPREP_MAX;
+        unsigned blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            const int k = base + i;
+            const Conv6Frag F = conv6_frag(Ci[k], Co[k], ks[k], ext[k] != 0);
+            if (!F.ok || !w[k] || !wfrag[k]) {
+                cfd_set_error("%s: item %d (Ci %d, Co %d, ks %d) has no fragment form or a NULL pointer", what, k, Ci[k], Co[k], ks[k]);
+                return CFD_ERR_INVALID_ARG;
+            }
+            WprepItem& e = b.it[i];
+            e.w = w[k];
+            e.frag = (u4*)wfrag[k];
+            e.Ci = Ci[k], e.Co = Co[k], e.ks = ks[k], e.CC = F.CC, e.KSTEPS = F.KSTEPS, e.MTall = F.MTall, e.ext = ext[k] != 0;
+            e.total = (unsigned)((long)F.nch * F.KSTEPS * F.MTall * 64);
+            e.nblk = (e.total + 255) / 256;
+            if (e.nblk > 256) e.nblk = 256;
+            e.blk0 = blocks;
+            blocks += e.nblk;
+        }
+        hipLaunchKernelGGL(k_conv6_wprep_batch, dim3(blocks), dim3(256), 0, st, b);
+        CFD_LAUNCH_CHECK(what);
+    }
+    return CFD_OK;
 }
 
 // partial (sum, sum of squares) pairs per output channel the forward kernel can emit for the BatchNorm that follows (0: not on

@@ -26,7 +26,7 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
                                                  // on the record (bench.py).  The 1x1 weight gradient and the head have no exact-fp32 build.
     {"conv6_grid", "CFD_CONV6_GRID", {-1}},      // persistent workgroups of a conv6 forward / input-gradient launch (default 512 = two per CU;
                                                  // tests: 2, so that small shapes walk several tiles per workgroup)
-    {"conv6_wgrad_mul", "CFD_CONV6_WGRAD_MUL", {-1}},  // workgroups of a conv6 weight-gradient launch in units of conv6_grid (default 2)
+    {"conv6_wgrad_mul", "CFD_CONV6_WGRAD_MUL", {-1}},  // workgroups of a conv6 weight-gradient launch in units of conv6_grid (default 1)
 };
 std::once_flag g_once;
 void read_env() {

@@ -477,11 +477,80 @@ class DeepONetInnerFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------------
 # Convolution stack of the U-Net / ResNet baselines  (src/models/unet.py, src/models/resnet.py)
 # ----------------------------------------------------------------------------------------------------
+class PreparedConvWeights:
+    """The MFMA fragments of a model's k = 3 / 7 convolution weights, made by ONE launch per forward pass
+    (cfd_conv2d_wprep_batch) instead of one small launch in front of every convolution and every input gradient
+    (35 per U-Net step, 26 per ResNet step).  ``refresh`` is called at the top of the model's forward; each layer then hands
+    ``frags(conv)`` to Conv2dReplicateFn / ConvBnReluFn.  The fragments are a pure function of the weights, so they are
+    trusted only while the weight's autograd version is the one they were made from (an optimizer step or a
+    ``load_state_dict`` in between sends the layer back to preparing its own) -- and a forward always starts with a refresh.
+    CFDBENCH_CONV_PREP=0 turns the whole thing off (timing comparisons)."""
+
+    def __init__(self, convs):
+        import os
+        self.convs = [c for c in convs if c.kernel_size in ((3, 3), (7, 7))]
+        self.enabled = os.environ.get("CFDBENCH_CONV_PREP", "1") != "0"
+        self._key = {}
+        self._tables = {}
+        for c in self.convs:
+            c._cfd_wfrag = None
+
+    def _build(self, api, transposed: bool):
+        import ctypes
+        items = []
+        for c in self.convs:
+            w = c.weight
+            Co, Ci, ks, _ = w.shape
+            for tr in ((0, 1) if transposed else (0,)):
+                n = api.size("cfd_conv2d_wfrag_bytes", Ci, Co, ks, tr)
+                if n == 0:
+                    continue
+                buf = getattr(c, "_cfd_wfrag_buf", {})
+                if tr not in buf or buf[tr].device != w.device:
+                    buf[tr] = torch.empty(n, dtype=torch.uint8, device=w.device)
+                c._cfd_wfrag_buf = buf
+                items.append((w.data_ptr(), buf[tr].data_ptr(), Ci, Co, ks, tr))
+        n = len(items)
+        col = lambda j, ty: (ty * n)(*[it[j] for it in items])
+        self._tables[transposed] = (n, col(0, ctypes.c_void_p), col(1, ctypes.c_void_p), col(2, ctypes.c_int), col(3, ctypes.c_int),
+                                    col(4, ctypes.c_int), col(5, ctypes.c_int))
+
+    def refresh(self, transposed: bool) -> None:
+        """Remake every layer's fragments from the current weights (``transposed``: also the input-gradient form)."""
+        ws = [c.weight for c in self.convs]
+        if not self.enabled or not all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() for w in ws):
+            for c in self.convs:
+                c._cfd_wfrag = None
+            return
+        api = _lib.api()
+        transposed = bool(transposed)
+        key = tuple(w.data_ptr() for w in ws)
+        if self._key.get(transposed) != key:
+            self._build(api, transposed)
+            self._key[transposed] = key
+        n, wp, fp, ci, co, ks, tr = self._tables[transposed]
+        if n == 0:
+            return
+        api.call("cfd_conv2d_wprep_batch", n, wp, fp, ci, co, ks, tr, _stream())
+        for c in self.convs:
+            buf = c._cfd_wfrag_buf
+            c._cfd_wfrag = (buf.get(0), buf.get(1) if transposed else None, c.weight._version)
+
+
+def conv_frags(conv):
+    """(forward fragments, input-gradient fragments) of a layer registered with PreparedConvWeights, or (None, None) when
+    there are none or the weights changed since they were made."""
+    st = getattr(conv, "_cfd_wfrag", None)
+    if st is None or st[2] != conv.weight._version:
+        return None, None
+    return st[0], st[1]
+
+
 class Conv2dReplicateFn(torch.autograd.Function):
     """nn.Conv2d(k, padding=k//2, padding_mode='replicate') as an implicit GEMM on the matrix pipe."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor]):
+    def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor], wfrag: Optional[Tensor] = None, wfrag_t: Optional[Tensor] = None):
         _require_cuda(x, w, b)
         api = _lib.api()
         x, w = _f32c(x), _f32c(w.detach())
@@ -493,9 +562,10 @@ class Conv2dReplicateFn(torch.autograd.Function):
         out = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
         nws = api.size("cfd_conv2d_fwd_workspace_bytes", B, Ci, Co, H, W, ks)  # split-K partials of narrow, deep layers
         ws = _bytes(nws, x.device) if nws else None
-        api.call("cfd_conv2d_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(out), _ptr(ws), B, Ci, Co, H, W, ks, _stream())
+        api.call("cfd_conv2d_fwd_ex", _ptr(x), _ptr(w), _ptr(b), _ptr(out), _ptr(ws), None, _ptr(wfrag), B, Ci, Co, H, W, ks, _stream())
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
+        ctx.wfrag_t = wfrag_t  # (PreparedConvWeights: made from these very weights at the top of this forward pass)
         return out
 
     @staticmethod
@@ -509,9 +579,9 @@ class Conv2dReplicateFn(torch.autograd.Function):
         gw = torch.empty_like(w)
         gb = torch.empty(Co, dtype=torch.float32, device=g.device) if ctx.has_b else None
         ws = _bytes(api.size("cfd_conv2d_bwd_workspace_bytes", B, Ci, Co, H, W, ks), g.device)
-        api.call("cfd_conv2d_bwd", _ptr(g), _ptr(x), _ptr(w), _ptr(gin), _ptr(gw), _ptr(gb), _ptr(ws), B, Ci, Co, H, W, ks,
-                 _stream())
-        return gin, gw, gb
+        api.call("cfd_conv2d_bwd_ex", _ptr(g), _ptr(x), _ptr(w), _ptr(gin), _ptr(gw), _ptr(gb), _ptr(ws), _ptr(ctx.wfrag_t), B, Ci, Co,
+                 H, W, ks, _stream())
+        return gin, gw, gb, None, None
 
 
 class BatchNormFn(torch.autograd.Function):
@@ -557,7 +627,8 @@ class ConvBnReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor], gamma: Tensor, beta: Tensor, run_mean: Optional[Tensor],
-                run_var: Optional[Tensor], relu: bool, eps: float, momentum: float):
+                run_var: Optional[Tensor], relu: bool, eps: float, momentum: float, wfrag: Optional[Tensor] = None,
+                wfrag_t: Optional[Tensor] = None):
         _require_cuda(x, w, b, gamma, beta, run_mean, run_var)
         api = _lib.api()
         x, w = _f32c(x), _f32c(w.detach())
@@ -576,16 +647,18 @@ class ConvBnReluFn(torch.autograd.Function):
         slots = api.size("cfd_conv2d_fwd_stats_slots", B, Ci, Co, H, W, ks) if ws is not None else 0
         if slots > 0:
             stats = torch.empty((Co, slots, 2), dtype=torch.float32, device=x.device)
-            api.call("cfd_conv2d_fwd_stats", _ptr(x), _ptr(w), _ptr(b), _ptr(y0), _ptr(ws), _ptr(stats), B, Ci, Co, H, W, ks, _stream())
+            api.call("cfd_conv2d_fwd_ex", _ptr(x), _ptr(w), _ptr(b), _ptr(y0), _ptr(ws), _ptr(stats), _ptr(wfrag), B, Ci, Co, H, W, ks,
+                     _stream())
             api.call("cfd_batchnorm_fwd_stats", _ptr(y0), _ptr(gamma), _ptr(beta), _ptr(run_mean), _ptr(run_var), _ptr(z), _ptr(sm),
                      _ptr(sr), _ptr(stats), slots, _ptr(b), B, Co, H * W, float(eps), float(momentum), int(relu), _stream())
         else:
-            api.call("cfd_conv2d_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y0), _ptr(ws), B, Ci, Co, H, W, ks, _stream())
+            api.call("cfd_conv2d_fwd_ex", _ptr(x), _ptr(w), _ptr(b), _ptr(y0), _ptr(ws), None, _ptr(wfrag), B, Ci, Co, H, W, ks, _stream())
             bws = _bytes(api.size("cfd_batchnorm_workspace_bytes", Co), x.device)
             api.call("cfd_batchnorm_fwd", _ptr(y0), _ptr(gamma), _ptr(beta), _ptr(run_mean), _ptr(run_var), _ptr(z), _ptr(sm),
                      _ptr(sr), _ptr(bws), B, Co, H * W, float(eps), float(momentum), 1, int(relu), _stream())
         ctx.save_for_backward(x, w, y0, gamma, beta, sm, sr)
         ctx.meta = (b is not None, bool(relu))
+        ctx.wfrag_t = wfrag_t
         return z
 
     @staticmethod
@@ -606,9 +679,9 @@ class ConvBnReluFn(torch.autograd.Function):
         gw = torch.empty_like(w)
         gb = torch.empty(Co, dtype=torch.float32, device=x.device) if has_b else None
         ws = _bytes(api.size("cfd_conv2d_bwd_workspace_bytes", B, Ci, Co, H, W, ks), x.device)
-        api.call("cfd_conv2d_bwd", _ptr(gy0), _ptr(x), _ptr(w), _ptr(gin), _ptr(gw), _ptr(gb), _ptr(ws), B, Ci, Co, H, W, ks,
-                 _stream())
-        return gin, gw, gb, gg, gbeta, None, None, None, None, None
+        api.call("cfd_conv2d_bwd_ex", _ptr(gy0), _ptr(x), _ptr(w), _ptr(gin), _ptr(gw), _ptr(gb), _ptr(ws), _ptr(ctx.wfrag_t), B, Ci,
+                 Co, H, W, ks, _stream())
+        return gin, gw, gb, gg, gbeta, None, None, None, None, None, None, None
 
 
 class MaxPool2Fn(torch.autograd.Function):

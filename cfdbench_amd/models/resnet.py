@@ -43,13 +43,13 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         residual = x if self.res_conv is None else F_.Conv2dReplicateFn.apply(x, self.res_conv.weight, self.res_conv.bias)
-        x = F_.Conv2dReplicateFn.apply(x, self.conv1.weight, self.conv1.bias)
+        x = F_.Conv2dReplicateFn.apply(x, self.conv1.weight, self.conv1.bias, *F_.conv_frags(self.conv1))
         if self.training and self.dropout.p > 0:
             seed = self._mix64(self._mix64(torch.initial_seed()) + 0x9E3779B97F4A7C15 * (self.block_idx + 1)
                                + self.drop_step) & 0xFFFFFFFFFFFF
             x = F_.DropoutFn.apply(x, self.dropout.p, seed)
         x = F_.GeluFn.apply(x)
-        x = F_.Conv2dReplicateFn.apply(x, self.conv2.weight, self.conv2.bias)
+        x = F_.Conv2dReplicateFn.apply(x, self.conv2.weight, self.conv2.bias, *F_.conv_frags(self.conv2))
         return F_.AddFn.apply(x, residual)
 
 
@@ -71,6 +71,8 @@ class ResNet(AutoCfdModel):
         for i, blk in enumerate(self.blocks):
             blk.block_idx = i
         self._train_steps = 0  # training-mode forwards so far: the dropout stream's step counter
+        # MFMA fragments of all 7x7 weights, remade by one launch at the top of every forward pass (functional.PreparedConvWeights)
+        self._prep = F_.PreparedConvWeights([m for m in self.modules() if isinstance(m, nn.Conv2d)])
 
     def forward(self, inputs: Tensor, case_params: Tensor, mask: Optional[Tensor] = None, label: Optional[Tensor] = None) -> dict:
         """inputs (B,c,h,w), case_params (B,p), mask (B,h,w)|(B,1,h,w), label (B,c,h,w)  (resnet.py:145-198)."""
@@ -81,6 +83,8 @@ class ResNet(AutoCfdModel):
         elif mask.dim() == 3:
             mask = mask.unsqueeze(1)
         cp = case_params.unsqueeze(-1).unsqueeze(-1).expand(-1, -1, height, width)
+        if inputs.is_cuda:
+            self._prep.refresh(torch.is_grad_enabled())
         if self.training:
             self._train_steps += 1
             for blk in self.blocks:

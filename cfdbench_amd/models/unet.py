@@ -23,8 +23,8 @@ def _conv_bn_relu(seq: nn.Sequential, x: Tensor) -> Tensor:
     conv, bn = seq[0], seq[1]
     if bn.training and x.is_cuda:  # one node: the conv emits the BatchNorm's batch statistics where it can (functional.ConvBnReluFn)
         return F_.ConvBnReluFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, bn.eps,
-                                     bn.momentum)
-    x = F_.Conv2dReplicateFn.apply(x, conv.weight, conv.bias)
+                                     bn.momentum, *F_.conv_frags(conv))
+    x = F_.Conv2dReplicateFn.apply(x, conv.weight, conv.bias, *F_.conv_frags(conv))
     y = F_.BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, True, bn.eps,
                              bn.momentum)
     return y  # (num_batches_tracked: one fused increment per forward, UNet.forward)
@@ -119,6 +119,8 @@ class UNet(AutoCfdModel):
         self.up3 = Up(dim * 4, dim * 2 // factor, bilinear)
         self.up4 = Up(dim * 2, dim, bilinear)
         self.out_conv = OutConv(dim, out_chan)
+        # MFMA fragments of all 3x3 weights, remade by one launch at the top of every forward pass (functional.PreparedConvWeights)
+        self._prep = F_.PreparedConvWeights([m for m in self.modules() if isinstance(m, nn.Conv2d)])
 
     def forward(self, inputs: Tensor, case_params: Tensor, mask: Optional[Tensor] = None, label: Optional[Tensor] = None):
         """inputs (B,c,h,w), mask (B,h,w)|(B,1,h,w), label (B,c,h,w), case_params (b,p)  (unet.py:153-223)."""
@@ -128,6 +130,8 @@ class UNet(AutoCfdModel):
             mask = torch.ones((batch_size, 1, height, width), device=inputs.device)
         elif mask.dim() == 3:
             mask = mask.unsqueeze(1)
+        if inputs.is_cuda:
+            self._prep.refresh(torch.is_grad_enabled())
         if self.insert_case_params_at == "input":
             cp = case_params.unsqueeze(2).unsqueeze(3).expand(-1, -1, height, width)
             x = torch.cat([inputs, mask, cp], dim=1)

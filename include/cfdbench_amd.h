@@ -280,10 +280,25 @@ int cfd_conv2d_fwd(const float* in, const float* w, const float* bias, float* ou
 int cfd_conv2d_fwd_stats_slots(int B, int Ci, int Co, int H, int W, int ks);
 int cfd_conv2d_fwd_stats(const float* in, const float* w, const float* bias, float* out, void* ws, float* stats, int B, int Ci,
                          int Co, int H, int W, int ks, void* stream);
+/* Weights prepared ahead of the calls that use them.  The k = 3 / 7 kernels read a layer's weights as MFMA fragments of three bf16
+ * pieces; cfd_conv2d_fwd / cfd_conv2d_bwd make them with a small launch of their own in every call.  A model that runs many
+ * layers per step (unet.py:153-223: 18 convolutions, resnet.py:145-198: 14) makes them for ALL layers in one launch instead:
+ * wfrag[i] = cfd_conv2d_wfrag_bytes(Ci[i], Co[i], ks[i], transposed[i]) bytes (0: the layer has no fragment form -- kernel size
+ * other than 3 / 7), transposed = 0 for the forward pass, 1 for the input-gradient pass; the form depends on neither batch nor
+ * grid size.  The fragments are a pure function of the weights: remake them after every change of the weights (optimizer step,
+ * load_state_dict).  cfd_conv2d_fwd_ex / cfd_conv2d_bwd_ex are the calls above with the optional extras spelled out -- stats (NULL
+ * or as in cfd_conv2d_fwd_stats) and wfrag / wfrag_t (NULL or the prepared fragments; ignored on layers that run elsewhere).  */
+size_t cfd_conv2d_wfrag_bytes(int Ci, int Co, int ks, int transposed);
+int cfd_conv2d_wprep_batch(int n, const float* const* w, void* const* wfrag, const int* Ci, const int* Co, const int* ks,
+                           const int* transposed, void* stream);
+int cfd_conv2d_fwd_ex(const float* in, const float* w, const float* bias, float* out, void* ws, float* stats, const void* wfrag,
+                      int B, int Ci, int Co, int H, int W, int ks, void* stream);
 /* gin (B,Ci,H,W), gw (Co,Ci,ks,ks), gb (Co) from gout; any output may be NULL.  ws: cfd_conv2d_bwd_workspace_bytes(). */
 size_t cfd_conv2d_bwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);
 int cfd_conv2d_bwd(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws, int B,
                    int Ci, int Co, int H, int W, int ks, void* stream);
+int cfd_conv2d_bwd_ex(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws,
+                      const void* wfrag_t, int B, int Ci, int Co, int H, int W, int ks, void* stream);
 
 /* y = [relu](nn.BatchNorm2d(x)) (unet.py:28-30).  training: batch statistics, saved in save_mean / save_rstd for the
  * backward pass, running_mean / running_var updated in place (momentum; unbiased variance) when non-NULL;

@@ -679,6 +679,54 @@ def check_conv2d(be, B, Ci, Co, H, W, ks, seed=31):
     return res
 
 
+def check_conv_prepared(be, layers, seed=37):
+    """cfd_conv2d_wprep_batch + cfd_conv2d_fwd_ex / cfd_conv2d_bwd_ex: the fragments of ALL `layers` = [(B, Ci, Co, H, W, ks), ...]
+    made by one call (forward and input-gradient forms interleaved), then every layer run with them -- must equal the calls that
+    prepare their own weights BIT FOR BIT (same fragments, same kernels).  Returns the number of values that differ."""
+    import ctypes
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    data, items = [], []
+    for (B, Ci, Co, H, W, ks) in layers:
+        x = be.dev(rng.standard_normal((B, Ci, H, W)).astype(np.float32))
+        w = be.dev((rng.standard_normal((Co, Ci, ks, ks)) / np.sqrt(Ci * ks * ks)).astype(np.float32))
+        b = be.dev(rng.standard_normal((Co,)).astype(np.float32) * 0.2)
+        g = be.dev(rng.standard_normal((B, Co, H, W)).astype(np.float32))
+        fr = []
+        for tr in (0, 1):
+            n = api.size("cfd_conv2d_wfrag_bytes", Ci, Co, ks, tr)
+            assert n > 0, (Ci, Co, ks, tr)
+            fr.append(be.bytes(n))
+            items.append((P(w), P(fr[-1]), Ci, Co, ks, tr))
+        data.append((x, w, b, g, fr))
+    n = len(items)
+    col = lambda j, ty: (ty * n)(*[it[j] for it in items])
+    api.call("cfd_conv2d_wprep_batch", n, col(0, ctypes.c_void_p), col(1, ctypes.c_void_p), col(2, ctypes.c_int), col(3, ctypes.c_int),
+             col(4, ctypes.c_int), col(5, ctypes.c_int), be.stream)
+    be.sync()
+    bad = 0
+    for (B, Ci, Co, H, W, ks), (x, w, b, g, fr) in zip(layers, data):
+        outs = []
+        for prepared in (False, True):
+            out = be.zeros((B, Co, H, W))
+            nws = api.size("cfd_conv2d_fwd_workspace_bytes", B, Ci, Co, H, W, ks)
+            assert nws > 0
+            fws = be.bytes(nws)
+            slots = api.size("cfd_conv2d_fwd_stats_slots", B, Ci, Co, H, W, ks)
+            stats = be.zeros((Co, max(slots, 1), 2))
+            api.call("cfd_conv2d_fwd_ex", P(x), P(w), P(b), P(out), P(fws), P(stats) if slots > 0 else None,
+                     P(fr[0]) if prepared else None, B, Ci, Co, H, W, ks, be.stream)
+            ws = be.bytes(api.size("cfd_conv2d_bwd_workspace_bytes", B, Ci, Co, H, W, ks))
+            gin, gw, gb = be.zeros((B, Ci, H, W)), be.zeros((Co, Ci, ks, ks)), be.zeros((Co,))
+            api.call("cfd_conv2d_bwd_ex", P(g), P(x), P(w), P(gin), P(gw), P(gb), P(ws), P(fr[1]) if prepared else None, B, Ci, Co, H, W,
+                     ks, be.stream)
+            be.sync()
+            outs.append([be.host(t).copy() for t in (out, stats, gin, gw, gb)])
+        for a, c in zip(*outs):
+            bad += int(np.count_nonzero(a != c))
+    return bad
+
+
 def check_conv_bn_stats(be, B, Ci, Co, H, W, ks, relu=True, seed=36):
     """cfd_conv2d_fwd_stats + cfd_batchnorm_fwd_stats (the conv emits the BatchNorm's batch statistics) against the oracle's
     conv -> training-mode BatchNorm; returns None when the layer cannot emit statistics."""

@@ -171,6 +171,15 @@ def test_conv_emits_batchnorm_statistics(be, B, Ci, Co, H, W, ks):
     _assert_all(res)
 
 
+def test_conv_weights_prepared_in_one_batch(be):
+    """fragments of several layers (k = 3 and 7, narrow and wide, forward and input-gradient forms) made by one
+    cfd_conv2d_wprep_batch launch: the layers then compute bit for bit what they compute preparing their own"""
+    layers = [(2, 3, 12, 16, 16, 3), (3, 12, 24, 9, 10, 3), (2, 40, 20, 8, 8, 3), (1, 8, 16, 12, 13, 7), (2, 17, 5, 20, 21, 7)]
+    assert K.check_conv_prepared(be, layers) == 0
+    assert K.check_conv_prepared(be, [(1, 3 + i % 3, 4 + i % 5, 6, 6, 3) for i in range(17)], seed=38) == 0  # 34 items: two launches
+    assert be.api.size("cfd_conv2d_wfrag_bytes", 12, 12, 5, 0) == 0 and be.api.size("cfd_conv2d_wfrag_bytes", 12, 2, 1, 1) == 0
+
+
 @pytest.mark.parametrize("B,C,H,W,training,relu", [(2, 3, 6, 7, True, True), (2, 3, 4, 4, False, True), (3, 2, 5, 5, True, False), (4, 12, 64, 64, True, True),
                                                     (9, 48, 4, 4, True, True)])
 def test_batchnorm_relu(be, B, C, H, W, training, relu):

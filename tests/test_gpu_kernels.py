@@ -234,6 +234,16 @@ def test_conv_emits_batchnorm_statistics(be, grid, B, Ci, Co, H, W, ks):
     _assert_all(res)
 
 
+def test_conv_weights_prepared_in_one_batch(be):
+    """cfd_conv2d_wprep_batch: the fragments of all 18 3x3 layers of the configs[2] U-Net (both forms) and of ResNet's 7x7 layers
+    from single launches; every layer then computes bit for bit what it computes preparing its own weights."""
+    unet = [(16, 11, 12, 64, 64), (16, 12, 12, 64, 64), (16, 12, 24, 32, 32), (16, 24, 24, 32, 32), (16, 24, 48, 16, 16),
+            (16, 48, 48, 16, 16), (16, 48, 96, 8, 8), (16, 96, 96, 8, 8), (16, 96, 192, 4, 4), (16, 192, 192, 4, 4), (16, 192, 96, 8, 8),
+            (16, 96, 48, 16, 16), (16, 48, 24, 32, 32), (16, 24, 12, 64, 64)]
+    assert K.check_conv_prepared(be, [(B, Ci, Co, H, W, 3) for B, Ci, Co, H, W in unet]) == 0
+    assert K.check_conv_prepared(be, [(4, 11, 64, 64, 64, 7), (4, 64, 16, 64, 64, 7), (4, 16, 64, 33, 31, 7), (4, 64, 2, 64, 64, 7)], seed=39) == 0
+
+
 @pytest.mark.parametrize("B,C,H,W,training,relu", [(4, 12, 64, 64, True, True), (3, 192, 4, 4, True, True), (2, 24, 33, 32, False, True), (3, 5, 7, 9, True, False)])
 def test_batchnorm_relu(be, B, C, H, W, training, relu):
     _assert_all(K.check_batchnorm(be, B, C, H, W, training, relu))

@@ -361,6 +361,34 @@ def test_unet_vs_reference_golden(torch, golden_dir, name):
             assert O.rel_nmse(frames[t].cpu().numpy(), g["frames"][t]) < 1e-8
 
 
+def test_prepared_conv_weights_follow_the_weights(torch):
+    """functional.PreparedConvWeights: the fragments made at the top of a forward pass are those of the CURRENT weights -- three Adam
+    steps equal the run that prepares inside every call bit for bit -- and a layer called on its own after an optimizer step
+    (no model-level refresh in between) does not pick up the fragments of the old weights."""
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    from cfdbench_amd.models.unet import UNet
+    b = _cuda(torch, synth.make_smooth_batch(77, 6, 32, 32, 3))
+    runs = []
+    for prepared in (True, False):
+        torch.manual_seed(5)
+        m = UNet(2, 2, loss_name_to_fn("nmse"), 3, insert_case_params_at="input", dim=4).cuda().train()
+        m._prep.enabled = prepared
+        opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+        for _ in range(3):
+            opt.zero_grad()
+            m(inputs=b["inputs"], case_params=b["case_params"], mask=b["mask"], label=b["label"])["loss"]["nmse"].backward()
+            opt.step()
+        x = torch.cat([b["inputs"], b["mask"], b["case_params"][:, :, None, None].expand(-1, -1, 32, 32)], dim=1)
+        alone = m.in_conv(x).detach().clone()  # straight after opt.step(): any fragments at hand are those of the old weights
+        with torch.no_grad():
+            ev = m.eval()(inputs=b["inputs"], case_params=b["case_params"], mask=b["mask"])["preds"].clone()
+        runs.append(([p.detach().clone() for p in m.parameters()], alone, ev))
+        assert (m.in_conv.conv1[0]._cfd_wfrag is not None) == prepared
+    for a, c in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, c)
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+
+
 # ---- ResNet drop-in (cfdbench_amd/models/resnet.py) vs the reference module's golden outputs (eval mode) ------------
 def test_resnet_vs_reference_golden(torch, golden_dir):
     from cfdbench_amd.models.loss import loss_name_to_fn
