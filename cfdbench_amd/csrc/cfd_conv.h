@@ -47,3 +47,16 @@ size_t cfd_conv6_wgrad_ws_bytes(const ConvGeom& g);
 // gb != NULL: the bias gradient gb (Co) = sum over (b, p) of gout rides in the same launches (the gradient tile is staged anyway)
 int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, float* gb, void* ws, const ConvGeom& g, hipStream_t st,
                     const char* what);
+
+// ---- convt6.hip: ConvTranspose2d(2, stride 2) on three-piece split-bf16 operands (fp32-exact pieces, six bf16 MFMAs per product) ----
+bool cfd_convt6_covers(int B, int Ci, int Co, int H, int W);
+int cfd_convt6_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int H, int W, hipStream_t st,
+                   const char* what);
+int cfd_convt6_bwd_in(const float* gout, const float* w, float* gin, int B, int Ci, int Co, int H, int W, hipStream_t st,
+                      const char* what);
+// weight gradient gw (Ci,Co,2,2) and, when gb != NULL, the bias gradient gb (Co) in the same launches; needs W % 4 == 0, H W % 8 == 0 and 16-byte
+// aligned tensors (CFD_ERR_UNSUPPORTED otherwise: the caller keeps the fp32 kernel).  ws: cfd_convt6_wgrad_ws_bytes().
+bool cfd_convt6_wgrad_covers(int B, int Ci, int Co, int H, int W);
+size_t cfd_convt6_wgrad_ws_bytes(int B, int Ci, int Co, int H, int W);
+int cfd_convt6_wgrad(const float* gout, const float* in, float* gw, float* gb, void* ws, int B, int Ci, int Co, int H, int W,
+                     hipStream_t st, const char* what);

@@ -62,6 +62,12 @@ __device__ __forceinline__ float cfd_opaque_f(float x) {
     asm volatile("" : "+v"(x));
     return x;
 }
+// The same for a whole 16-byte vector (the destination of one global_load_dwordx4 stays one register tuple: four scalar opaque
+// values made the compiler copy every component out right behind the load, with a full wait each).
+__device__ __forceinline__ f32x4 cfd_opaque_f4(f32x4 x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 
 // Wave-uniform value -> SGPR (lets the compiler use scalar loads / scalar operands for per-wave indices).
 __device__ __forceinline__ int cfd_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }

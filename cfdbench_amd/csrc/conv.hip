@@ -1154,6 +1154,8 @@ extern "C" int cfd_convt2_fwd(const float* in, const float* w, const float* bias
     if (B == 0) return CFD_OK;
     CFD_PROF_W("k_convt2_fwd", (hipStream_t)stream, 4.0 * B * H * W * ((double)Ci + 4.0 * Co), 8.0 * B * H * W * (double)Ci * Co);
     CFD_REQUIRE_I31((long)B * Co * 4 * H * W, "cfd_convt2_fwd");
+    if (cfd_tune_get(CFD_TUNE_CONVT_MFMA) != 0 && cfd_convt6_covers(B, Ci, Co, H, W))
+        return cfd_convt6_fwd(in, w, bias, out, B, Ci, Co, H, W, (hipStream_t)stream, "cfd_convt2_fwd");
     {
         const long px = (long)B * H * W;
         long bx = (px + 255) / 256;
@@ -1171,7 +1173,9 @@ extern "C" size_t cfd_convt2_bwd_workspace_bytes(int B, int Ci, int Co, int H, i
     long chunk_px;
     int nchunk;
     wgrad_plan((long)B * H * W, Ci, Co * 4, chunk_px, nchunk);
-    const size_t a = cfd_align_up((size_t)nchunk * Ci * Co * 4 * sizeof(float), 256), b = chan_sum_ws_bytes(Co);
+    size_t a = cfd_align_up((size_t)nchunk * Ci * Co * 4 * sizeof(float), 256);
+    const size_t b = chan_sum_ws_bytes(Co), c = cfd_convt6_wgrad_ws_bytes(B, Ci, Co, H, W);
+    if (c > a) a = c;
     return a > b ? a : b;
 }
 
@@ -1187,9 +1191,18 @@ extern "C" int cfd_convt2_bwd(const float* gout, const float* in, const float* w
         const long px = (long)B * H * W;
         long bx = (px + 255) / 256;
         if (bx > 2048) bx = 2048;
+        if (cfd_tune_get(CFD_TUNE_CONVT_MFMA) != 0 && cfd_convt6_covers(B, Ci, Co, H, W) && !((size_t)w & 15))  // (weight rows as float4)
+            CFD_TRY(cfd_convt6_bwd_in(gout, w, gin, B, Ci, Co, H, W, st, "cfd_convt2_bwd(input)"));
+        else
         hipLaunchKernelGGL(k_convt2_bwd_in, dim3((unsigned)bx, (Ci + CT_OB - 1) / CT_OB), dim3(256), (size_t)Co * CT_OB * sizeof(float4),
                            st, gout, w, gin, B, Ci, Co, H, W, cfd_div_make((unsigned)(H * W)), cfd_div_make((unsigned)W));
         CFD_LAUNCH_CHECK("cfd_convt2_bwd(input)");
+    }
+    if (gw && cfd_tune_get(CFD_TUNE_CONVT_MFMA) != 0 && cfd_convt6_wgrad_covers(B, Ci, Co, H, W) && !((size_t)in & 15) &&
+        !((size_t)gout & 15)) {
+        CFD_PROF_W("k_convt2_wgrad", st, 4.0 * B * H * W * ((double)Ci + 4.0 * Co), 8.0 * B * H * W * (double)Ci * Co);
+        CFD_TRY(cfd_convt6_wgrad(gout, in, gw, gb, ws, B, Ci, Co, H, W, st, "cfd_convt2_bwd(wgrad)"));
+        gw = nullptr, gb = nullptr;  // (the bias gradient rode in the same launches)
     }
     if (gw) {
         long chunk_px;

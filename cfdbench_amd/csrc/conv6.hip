@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_conv6_wprep(const float* __restrict__ w
 // The fragments of MANY weight tensors in one launch (cfd_conv2d_wprep_batch: a model prepares every layer's weights once per
 // forward pass instead of one ~4 us launch in front of each convolution and each input gradient -- 35 launches of a U-Net step).
 // Workgroups [blk0, blk0 + nblk) belong to item i; the table travels as the kernel argument.
-#define CFD_WPREP_MAX 32
+#define CFD_WPREP_MAX 48  // (the kernel argument block holds 4 KB: 48 items of 56 bytes)
 struct WprepItem {
     const float* w;
     u4* frag;

@@ -27,6 +27,7 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
     {"conv6_grid", "CFD_CONV6_GRID", {-1}},      // persistent workgroups of a conv6 forward / input-gradient launch (default 512 = two per CU;
                                                  // tests: 2, so that small shapes walk several tiles per workgroup)
     {"conv6_wgrad_mul", "CFD_CONV6_WGRAD_MUL", {-1}},  // workgroups of a conv6 weight-gradient launch in units of conv6_grid (default 1)
+    {"convt_mfma", "CFD_CONVT_MFMA", {-1}},      // 0 = ConvTranspose2d(2, 2) on the fp32 VALU kernels of conv.hip instead of convt6.hip
 };
 std::once_flag g_once;
 void read_env() {

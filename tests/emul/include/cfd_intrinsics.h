@@ -70,6 +70,7 @@ inline void cfd_wave_lds_sync() { cfd_emul::wave_sync(); }
 
 inline int cfd_opaque(int x) { return x; }
 inline float cfd_opaque_f(float x) { return x; }
+inline f32x4 cfd_opaque_f4(f32x4 x) { return x; }
 inline unsigned cfd_pack_hi16(unsigned hi, unsigned lo) { return (hi & 0xffff0000u) | (lo >> 16); }
 
 inline void cfd_sched_fence() {}

@@ -784,6 +784,30 @@ def check_batchnorm(be, B, C, H, W, training, relu, seed=32):
     return res
 
 
+def check_convt(be, B, Ci, Co, H, W, seed=34, x=None, rng=None):
+    """cfd_convt2_fwd / cfd_convt2_bwd (ConvTranspose2d(2, stride 2), unet.py:80) against the oracle"""
+    from oracle import conv_oracle as CO
+    api, P = be.api, be.ptr
+    rng = rng if rng is not None else np.random.default_rng(seed)
+    if x is None:
+        x = np.maximum(rng.standard_normal((B, Ci, H, W)), 0).astype(np.float32)
+    dx = be.dev(x)
+    w = (rng.standard_normal((Ci, Co, 2, 2)) / np.sqrt(Ci)).astype(np.float32)
+    b = rng.standard_normal((Co,)).astype(np.float32) * 0.1
+    g = rng.standard_normal((B, Co, 2 * H, 2 * W)).astype(np.float32)
+    dw, db, dg = be.dev(w), be.dev(b), be.dev(g)
+    out = be.zeros((B, Co, 2 * H, 2 * W))
+    api.call("cfd_convt2_fwd", P(dx), P(dw), P(db), P(out), B, Ci, Co, H, W, be.stream)
+    ws = be.bytes(api.size("cfd_convt2_bwd_workspace_bytes", B, Ci, Co, H, W))
+    gin, gw, gb = be.zeros((B, Ci, H, W)), be.zeros((Ci, Co, 2, 2)), be.zeros((Co,))
+    api.call("cfd_convt2_bwd", P(dg), P(dx), P(dw), P(gin), P(gw), P(gb), P(ws), B, Ci, Co, H, W, be.stream)
+    be.sync()
+    res = {"convt": nm(be.host(out), CO.convt2(x.astype(f64), w.astype(f64), b.astype(f64)))}
+    rgx, rgw, rgb = CO.convt2_bwd(g.astype(f64), x.astype(f64), w.astype(f64))
+    res["convt_gin"], res["convt_gw"], res["convt_gb"] = nm(be.host(gin), rgx), nm(be.host(gw), rgw), nm(be.host(gb), rgb)
+    return res
+
+
 def check_pool_convt_resid(be, B, Ci, Co, H, W, seed=33):
     from oracle import conv_oracle as CO
     api, P = be.api, be.ptr
@@ -799,19 +823,7 @@ def check_pool_convt_resid(be, B, Ci, Co, H, W, seed=33):
     be.sync()
     res = {"pool": float(np.abs(be.host(y) - CO.maxpool2(x)).max()),
            "pool_bwd": float(np.abs(be.host(gx) - CO.maxpool2_bwd(x, gy)).max())}
-    w = (rng.standard_normal((Ci, Co, 2, 2)) / np.sqrt(Ci)).astype(np.float32)
-    b = rng.standard_normal((Co,)).astype(np.float32) * 0.1
-    g = rng.standard_normal((B, Co, 2 * H, 2 * W)).astype(np.float32)
-    dw, db, dg = be.dev(w), be.dev(b), be.dev(g)
-    out = be.zeros((B, Co, 2 * H, 2 * W))
-    api.call("cfd_convt2_fwd", P(dx), P(dw), P(db), P(out), B, Ci, Co, H, W, be.stream)
-    ws = be.bytes(api.size("cfd_convt2_bwd_workspace_bytes", B, Ci, Co, H, W))
-    gin, gw, gb = be.zeros((B, Ci, H, W)), be.zeros((Ci, Co, 2, 2)), be.zeros((Co,))
-    api.call("cfd_convt2_bwd", P(dg), P(dx), P(dw), P(gin), P(gw), P(gb), P(ws), B, Ci, Co, H, W, be.stream)
-    be.sync()
-    res["convt"] = nm(be.host(out), CO.convt2(x.astype(f64), w.astype(f64), b.astype(f64)))
-    rgx, rgw, rgb = CO.convt2_bwd(g.astype(f64), x.astype(f64), w.astype(f64))
-    res["convt_gin"], res["convt_gw"], res["convt_gb"] = nm(be.host(gin), rgx), nm(be.host(gw), rgw), nm(be.host(gb), rgb)
+    res.update(check_convt(be, B, Ci, Co, H, W, x=x, rng=rng))
     C2 = min(2, Ci)
     mask = (rng.random((B, H * W)) > 0.2).astype(np.float32)
     xs = rng.standard_normal((B, C2, H * W)).astype(np.float32)

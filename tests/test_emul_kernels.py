@@ -176,7 +176,7 @@ def test_conv_weights_prepared_in_one_batch(be):
     cfd_conv2d_wprep_batch launch: the layers then compute bit for bit what they compute preparing their own"""
     layers = [(2, 3, 12, 16, 16, 3), (3, 12, 24, 9, 10, 3), (2, 40, 20, 8, 8, 3), (1, 8, 16, 12, 13, 7), (2, 17, 5, 20, 21, 7)]
     assert K.check_conv_prepared(be, layers) == 0
-    assert K.check_conv_prepared(be, [(1, 3 + i % 3, 4 + i % 5, 6, 6, 3) for i in range(17)], seed=38) == 0  # 34 items: two launches
+    assert K.check_conv_prepared(be, [(1, 3 + i % 3, 4 + i % 5, 6, 6, 3) for i in range(25)], seed=38) == 0  # 50 items: two launches
     assert be.api.size("cfd_conv2d_wfrag_bytes", 12, 12, 5, 0) == 0 and be.api.size("cfd_conv2d_wfrag_bytes", 12, 2, 1, 1) == 0
 
 
@@ -231,6 +231,25 @@ def test_conv2d_random_shapes(be):
             res = K.check_conv2d(be, B, Ci, Co, H, W, ks, seed=100 + i)
         bad = {k: v for k, v in res.items() if not (v < 1e-10)}
         assert not bad, ((B, Ci, Co, H, W, ks, grid), bad)
+
+
+def test_convtranspose_random_shapes(be):
+    """Seeded sweep over the ConvTranspose2d(2, 2) kernels of convt6.hip: pixel counts that are no multiple of a 16-pixel tile or a
+    32-pixel k-step, several row / column groups, several k-step ranges per launch, widths the MFMA weight gradient does not take
+    (W % 8 != 0: fp32 kernel) -- and every shape again on the fp32 VALU kernels (convt_mfma = 0)."""
+    import random
+    rnd = random.Random(31)
+    R = rnd.choice
+    shapes = [(3, 20, 9, 1, 8), (4, 20, 9, 16, 16), (2, 50, 26, 8, 8), (1, 100, 3, 2, 16), (2, 3, 50, 4, 8), (8, 24, 12, 16, 32)]
+    while len(shapes) < 20:
+        shapes.append((R([1, 2, 3, 5]), R([1, 2, 7, 16, 17, 24, 48, 49, 96]), R([1, 2, 3, 4, 5, 12, 13, 24, 48]), R([1, 2, 3, 4, 8, 9]),
+                       R([1, 3, 4, 8, 8, 16, 24])))
+    for i, (B, Ci, Co, H, W) in enumerate(shapes):
+        for mfma in (-1, 0) if i < 8 else (-1,):
+            with K.tuned(be, convt_mfma=mfma):
+                res = K.check_convt(be, B, Ci, Co, H, W, seed=200 + i)
+            bad = {k: v for k, v in res.items() if not (v < 1e-10)}
+            assert not bad, ((B, Ci, Co, H, W, mfma), bad)
 
 
 def test_dense_and_norm_kernels_random_shapes(be):

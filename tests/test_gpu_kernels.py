@@ -256,6 +256,16 @@ def test_pool_convtranspose_residual(be, B, Ci, Co, H, W):
     _assert_all(res)
 
 
+@pytest.mark.parametrize("mfma", [-1, 0])
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(128, 24, 12, 32, 32), (128, 48, 24, 16, 16), (128, 96, 48, 8, 8), (128, 192, 96, 4, 4), (3, 50, 26, 9, 24),
+                                         (5, 7, 3, 6, 5)])
+def test_convtranspose_full_size(be, B, Ci, Co, H, W, mfma):
+    """ConvTranspose2d(2, 2) forward / input gradient / weight + bias gradient at the four up-path levels of the configs[2] U-Net
+    (batch 128) and two odd shapes, on the matrix-pipe kernels (convt6.hip) and on the fp32 VALU kernels they replace."""
+    with K.tuned(be, convt_mfma=mfma):
+        _assert_all(K.check_convt(be, B, Ci, Co, H, W))
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 96, 4, 4), (3, 12, 32, 32), (1, 5, 7, 9), (2, 3, 1, 1), (1, 2, 33, 2)])
 def test_upsample_bilinear_align_corners(be, B, C, H, W):
     _assert_all(K.check_upsample_bilinear(be, B, C, H, W))
