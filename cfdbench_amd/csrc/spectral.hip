@@ -1955,11 +1955,14 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
         const int i = threadIdx.x + k * 64 * NW;
         tv[k] = tabs3[i < ntab ? i : 0];
     }
+    // (every load below comes from a clamped, always valid address and is zeroed / skipped only after ALL of them are in flight:
+    // `inside ? w[..] : 0` and a clamped load whose only use sits under an `if` both compile to a branch around the load with a full
+    // wait inside -- five serialized memory round trips at the start of every workgroup in the first version)
     float wl[WS];
 #pragma unroll
     for (int dd = 0; dd < WS; ++dd) {
-        const int d = wave + dd * NW;
-        wl[dd] = (lane < NW * NCH && dd < DPW && d < Cd && lane < Cs) ? (TRANS ? w[(size_t)lane * Cd + d] : w[(size_t)d * Cs + lane]) : 0.f;
+        const int d = wave + dd * NW, dc = d < Cd ? d : Cd - 1, lc = lane < Cs ? lane : Cs - 1;
+        wl[dd] = dd < DPW ? (TRANS ? w[(size_t)lc * Cd + dc] : w[(size_t)dc * Cs + lc]) : 0.f;
     }
     float bv[DPW];
     constexpr int ZV = (CFD_KB_ZS - 1 + 255) / 256;  // float4 rounds per channel (M2 <= CFD_KB_ZS - 1, a multiple of 4)
@@ -1967,12 +1970,29 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
 #pragma unroll
     for (int dd = 0; dd < DPW; ++dd) {
         const int d = wave + dd * NW;
-        bv[dd] = (bias && d < Cd) ? bias[d] : 0.f;
+        bv[dd] = bias ? bias[d < Cd ? d : Cd - 1] : 0.f;
         const float4* zi = reinterpret_cast<const float4*>(z + ((size_t)b * Cd + (d < Cd ? d : 0)) * M2);
 #pragma unroll
         for (int k = 0; k < ZV; ++k) {
             const int i = lane + 64 * k;
             zv[dd][k] = zi[4 * i < M2 ? i : 0];
+        }
+    }
+#pragma unroll
+    for (int dd = 0; dd < WS; ++dd) {
+        const int d = wave + dd * NW;
+        wl[dd] = cfd_opaque_f(wl[dd]);
+        wl[dd] = (lane < NW * NCH && dd < DPW && d < Cd && lane < Cs) ? wl[dd] : 0.f;
+    }
+#pragma unroll
+    for (int dd = 0; dd < DPW; ++dd) {
+        bv[dd] = cfd_opaque_f(bv[dd]);
+        bv[dd] = wave + dd * NW < Cd ? bv[dd] : 0.f;
+#pragma unroll
+        for (int k = 0; k < ZV; ++k) {
+            f32x4 t = {zv[dd][k].x, zv[dd][k].y, zv[dd][k].z, zv[dd][k].w};
+            t = cfd_opaque_f4(t);
+            zv[dd][k] = make_float4(t[0], t[1], t[2], t[3]);
         }
     }
 #pragma unroll
