@@ -71,9 +71,37 @@ __device__ __forceinline__ void head_load_raw(const TA* __restrict__ a, int b, i
                 h[c][0] = t.x; h[c][1] = t.y; h[c][2] = t.z; h[c][3] = t.w;
             }
         } else {
+            // Unconditional loads from clamped addresses: the caller zeroes what lies outside (head_mask_raw) when it takes the
+            // values over, a tile later.  (`inside ? load : 0` compiles to a branch with a full wait per element: 32 serialized round
+            // trips per tile in the bf16-storage head, which was slower than the fp32 one.)
+            const TA* row = a + ((size_t)b * C + (i < C ? i : C - 1)) * HW;
+            if (sizeof(TA) == 2 && (HW & 1) == 0) {  // pixel pairs: px is a multiple of 4 and the row starts on a 4-byte boundary
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h[c][j] = (i < C && px + j < HW) ? cfd_ld(src + j) : 0.f;
+                for (int k = 0; k < 2; ++k) {
+                    const int pk = px + 2 * k < HW ? px + 2 * k : (px < HW ? px : 0);
+                    const unsigned t = *reinterpret_cast<const unsigned*>(row + pk);
+                    h[c][2 * k] = __builtin_bit_cast(float, t << 16);
+                    h[c][2 * k + 1] = __builtin_bit_cast(float, t & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[c][j] = cfd_ld(row + (px + j < HW ? px + j : HW - 1));
+            }
         }
+    }
+}
+
+// zero the slots of head_load_raw's scalar path that lie outside the tensor (b, px: the tile the values were loaded for)
+template <int CQ, bool VEC4, typename TA = float>
+__device__ __forceinline__ void head_mask_raw(float (&h)[CQ][4], int b, int C, int HW, int px, int q) {
+    if constexpr (!(VEC4 && sizeof(TA) == 4)) {
+#pragma unroll
+        for (int c = 0; c < CQ; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = cfd_opaque_f(h[c][j]);
+                h[c][j] = (b >= 0 && CQ * q + c < C && px + j < HW) ? v : 0.f;
+            }
     }
 }
 
@@ -155,6 +183,7 @@ __global__ __launch_bounds__(256, CQ == 8 ? CFD_HF_OCC8 : 3) void k_head_fwd(con
         for (int c = 0; c < CQ; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) h[c][j] = hn[c][j];
+        head_mask_raw<CQ, VEC4, TA>(h, b, C, HW, px, q);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { mk[j] = mkn[j]; lb[j] = lbn[j]; }
         const int bc = b, pxc = px;
