@@ -18,11 +18,24 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ inpu
     __shared__ float s_w[32 * CP];  // [feature][out], zero padded
     __shared__ float s_b[CP];
     const int F = in_chan + 3 + P;
-    for (int i = threadIdx.x; i < 32 * CP; i += blockDim.x) {
-        const int f = i / CP, o = i % CP;
-        s_w[i] = (f < F && o < C) ? w[o * F + f] : 0.f;
+    {   // (loads from clamped addresses first, zeroing afterwards: `inside ? w[..] : 0` is a branch with a full wait per load)
+        constexpr int NV = (32 * CP + 255) / 256;
+        float wv[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = threadIdx.x + 256 * k, f = i / CP, o = i % CP;
+            wv[k] = w[(o < C ? o : C - 1) * F + (f < F ? f : F - 1)];
+        }
+        float bv = bias[(int)threadIdx.x < C ? threadIdx.x : C - 1];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = threadIdx.x + 256 * k, f = i / CP, o = i % CP;
+            wv[k] = cfd_opaque_f(wv[k]);
+            if (i < 32 * CP) s_w[i] = (f < F && o < C) ? wv[k] : 0.f;
+        }
+        bv = cfd_opaque_f(bv);
+        if (threadIdx.x < CP) s_b[threadIdx.x] = (int)threadIdx.x < C ? bv : 0.f;
     }
-    for (int i = threadIdx.x; i < CP; i += blockDim.x) s_b[i] = i < C ? bias[i] : 0.f;
     __syncthreads();
     const int HW = H * W;
     const long total = (long)B * HW;
@@ -37,11 +50,38 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ inpu
 #pragma unroll
             for (int o = 0; o < CP; ++o) acc[o] = fmaf(s_w[z0 + f * CP + o], v, acc[o]);
         };
-        for (int c = 0; c < in_chan; ++c) add(c, inputs[((size_t)b * in_chan + c) * HW + p]);
-        add(in_chan, mask ? mask[(size_t)b * HW + p] : 1.f);  // fno2d.py:189-195
-        add(in_chan + 1, gx[row]);                              // grid_x varies along rows, fno2d.py:251-252
-        add(in_chan + 2, gy[col]);
-        for (int k = 0; k < P; ++k) add(in_chan + 3 + k, cp[(size_t)b * P + k]);
+        // every operand of the pixel is requested before the first one is used (the loops below waited for each load in turn: ten
+        // exposed memory round trips per pixel, which is what a 64-case rollout step paid 16 us for)
+        constexpr int MC = 4, MP = 8;
+        if (in_chan <= MC && P <= MP) {
+            float vin[MC], cpv[MP];
+#pragma unroll
+            for (int c = 0; c < MC; ++c) vin[c] = inputs[((size_t)b * in_chan + (c < in_chan ? c : in_chan - 1)) * HW + p];
+            float vm = mask ? mask[(size_t)b * HW + p] : 1.f;
+            float gxv = gx[row], gyv = gy[col];
+#pragma unroll
+            for (int k = 0; k < MP; ++k) cpv[k] = P > 0 ? cp[(size_t)b * P + (k < P ? k : P - 1)] : 0.f;
+#pragma unroll
+            for (int c = 0; c < MC; ++c) vin[c] = cfd_opaque_f(vin[c]);
+            vm = cfd_opaque_f(vm), gxv = cfd_opaque_f(gxv), gyv = cfd_opaque_f(gyv);
+#pragma unroll
+            for (int k = 0; k < MP; ++k) cpv[k] = cfd_opaque_f(cpv[k]);
+#pragma unroll
+            for (int c = 0; c < MC; ++c)
+                if (c < in_chan) add(c, vin[c]);
+            add(in_chan, vm);        // fno2d.py:189-195
+            add(in_chan + 1, gxv);   // grid_x varies along rows, fno2d.py:251-252
+            add(in_chan + 2, gyv);
+#pragma unroll
+            for (int k = 0; k < MP; ++k)
+                if (k < P) add(in_chan + 3 + k, cpv[k]);
+        } else {
+            for (int c = 0; c < in_chan; ++c) add(c, inputs[((size_t)b * in_chan + c) * HW + p]);
+            add(in_chan, mask ? mask[(size_t)b * HW + p] : 1.f);
+            add(in_chan + 1, gx[row]);
+            add(in_chan + 2, gy[col]);
+            for (int k = 0; k < P; ++k) add(in_chan + 3 + k, cp[(size_t)b * P + k]);
+        }
 #pragma unroll
         for (int o = 0; o < CP; ++o)
             if (o < C) cfd_st(out + ((size_t)b * C + o) * HW + p, acc[o]);
@@ -61,11 +101,24 @@ __global__ __launch_bounds__(256) void k_stem_fwd4(const float* __restrict__ inp
     __shared__ __attribute__((aligned(16))) float s_w[32 * CP];  // [feature][out], zero padded
     __shared__ __attribute__((aligned(16))) float s_b[CP];
     const int F = in_chan + 3 + P;
-    for (int i = threadIdx.x; i < 32 * CP; i += blockDim.x) {
-        const int f = i / CP, o = i % CP;
-        s_w[i] = (f < F && o < C) ? w[o * F + f] : 0.f;
+    {   // (loads from clamped addresses first, zeroing afterwards: `inside ? w[..] : 0` is a branch with a full wait per load)
+        constexpr int NV = (32 * CP + 255) / 256;
+        float wv[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = threadIdx.x + 256 * k, f = i / CP, o = i % CP;
+            wv[k] = w[(o < C ? o : C - 1) * F + (f < F ? f : F - 1)];
+        }
+        float bv = bias[(int)threadIdx.x < C ? threadIdx.x : C - 1];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = threadIdx.x + 256 * k, f = i / CP, o = i % CP;
+            wv[k] = cfd_opaque_f(wv[k]);
+            if (i < 32 * CP) s_w[i] = (f < F && o < C) ? wv[k] : 0.f;
+        }
+        bv = cfd_opaque_f(bv);
+        if (threadIdx.x < CP) s_b[threadIdx.x] = (int)threadIdx.x < C ? bv : 0.f;
     }
-    for (int i = threadIdx.x; i < CP; i += blockDim.x) s_b[i] = i < C ? bias[i] : 0.f;
     __syncthreads();
     const int HW = H * W, Q = HW / 4;
     const long total = (long)B * Q;
@@ -98,15 +151,44 @@ __global__ __launch_bounds__(256) void k_stem_fwd4(const float* __restrict__ inp
                 }
             }
         };
-        for (int c = 0; c < in_chan; ++c)
-            add(c, *reinterpret_cast<const float4*>(inputs + ((size_t)b * in_chan + c) * HW + p));
-        add(in_chan, mask ? *reinterpret_cast<const float4*>(mask + (size_t)b * HW + p) : make_float4(1.f, 1.f, 1.f, 1.f));
-        const float gxv = gx[row];
-        add(in_chan + 1, make_float4(gxv, gxv, gxv, gxv));
-        add(in_chan + 2, *reinterpret_cast<const float4*>(gy + col));
-        for (int k = 0; k < P; ++k) {
-            const float c1 = cp[(size_t)b * P + k];
-            add(in_chan + 3 + k, make_float4(c1, c1, c1, c1));
+        constexpr int MC = 4, MP = 8;
+        if (in_chan <= MC && P <= MP) {  // (all operands requested before the first use: see k_stem_fwd)
+            f32x4 vin[MC], vm = {1.f, 1.f, 1.f, 1.f}, gyv;
+            float cpv[MP];
+#pragma unroll
+            for (int c = 0; c < MC; ++c)
+                vin[c] = *reinterpret_cast<const f32x4*>(inputs + ((size_t)b * in_chan + (c < in_chan ? c : in_chan - 1)) * HW + p);
+            if (mask) vm = *reinterpret_cast<const f32x4*>(mask + (size_t)b * HW + p);
+            float gxv = gx[row];
+            gyv = *reinterpret_cast<const f32x4*>(gy + col);
+#pragma unroll
+            for (int k = 0; k < MP; ++k) cpv[k] = P > 0 ? cp[(size_t)b * P + (k < P ? k : P - 1)] : 0.f;
+#pragma unroll
+            for (int c = 0; c < MC; ++c) vin[c] = cfd_opaque_f4(vin[c]);
+            vm = cfd_opaque_f4(vm), gyv = cfd_opaque_f4(gyv), gxv = cfd_opaque_f(gxv);
+#pragma unroll
+            for (int k = 0; k < MP; ++k) cpv[k] = cfd_opaque_f(cpv[k]);
+            const auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
+#pragma unroll
+            for (int c = 0; c < MC; ++c)
+                if (c < in_chan) add(c, f4(vin[c]));
+            add(in_chan, f4(vm));
+            add(in_chan + 1, make_float4(gxv, gxv, gxv, gxv));
+            add(in_chan + 2, f4(gyv));
+#pragma unroll
+            for (int k = 0; k < MP; ++k)
+                if (k < P) add(in_chan + 3 + k, make_float4(cpv[k], cpv[k], cpv[k], cpv[k]));
+        } else {
+            for (int c = 0; c < in_chan; ++c)
+                add(c, *reinterpret_cast<const float4*>(inputs + ((size_t)b * in_chan + c) * HW + p));
+            add(in_chan, mask ? *reinterpret_cast<const float4*>(mask + (size_t)b * HW + p) : make_float4(1.f, 1.f, 1.f, 1.f));
+            const float gxv = gx[row];
+            add(in_chan + 1, make_float4(gxv, gxv, gxv, gxv));
+            add(in_chan + 2, *reinterpret_cast<const float4*>(gy + col));
+            for (int k = 0; k < P; ++k) {
+                const float c1 = cp[(size_t)b * P + k];
+                add(in_chan + 3 + k, make_float4(c1, c1, c1, c1));
+            }
         }
 #pragma unroll
         for (int o = 0; o < CP; ++o)
