@@ -495,6 +495,11 @@ class PreparedConvWeights:
         for c in self.convs:
             c._cfd_wfrag = None
 
+    def __getstate__(self):  # copy.deepcopy / pickle of the owning model: the pointer tables are per-process caches, rebuilt on demand
+        d = self.__dict__.copy()
+        d["_key"], d["_tables"] = {}, {}
+        return d
+
     def _build(self, api, transposed: bool):
         import ctypes
         items = []

@@ -384,6 +384,10 @@ def test_prepared_conv_weights_follow_the_weights(torch):
             ev = m.eval()(inputs=b["inputs"], case_params=b["case_params"], mask=b["mask"])["preds"].clone()
         runs.append(([p.detach().clone() for p in m.parameters()], alone, ev))
         assert (m.in_conv.conv1[0]._cfd_wfrag is not None) == prepared
+        import copy
+        twin = copy.deepcopy(m)  # (the pointer tables of the fragment cache are not copied: rebuilt on the twin's first forward)
+        with torch.no_grad():
+            assert torch.equal(twin(inputs=b["inputs"], case_params=b["case_params"], mask=b["mask"])["preds"], ev)
     for a, c in zip(runs[0][0], runs[1][0]):
         assert torch.equal(a, c)
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
