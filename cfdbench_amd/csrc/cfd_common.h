@@ -260,6 +260,13 @@ __device__ __forceinline__ CfdSplit8x3 cfd_split8x3(const float (&x)[8]) {
     s.p[2] = __builtin_bit_cast(bf16x8, m);
     return s;
 }
+// counter-based hash of (seed, element index): the keep mask of nn.Dropout (conv.hip k_dropout, pointwise.hip k_dropout_gelu)
+__device__ __forceinline__ unsigned cfd_hash32(unsigned long long v) {
+    v ^= v >> 33; v *= 0xff51afd7ed558ccdULL;
+    v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL;
+    v ^= v >> 33;
+    return (unsigned)v;
+}
 // base[byte offset]: a wave-uniform base pointer plus a 32-bit per-lane BYTE offset compiles to the saddr + voffset addressing
 // form (no 64-bit address arithmetic in the VALU); the caller guarantees the tensor is smaller than 4 GB
 __device__ __forceinline__ float cfd_ldg_off(const float* base, unsigned byte_off) {

@@ -1260,13 +1260,6 @@ extern "C" int cfd_residual_mask(const float* x, const float* resid, const float
 // ResNet is therefore tested in eval mode (dropout = identity), and the training path is tested for its statistics
 // and for forward/backward consistency (the backward pass regenerates the same mask from the same seed).
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned cfd_hash32(unsigned long long v) {
-    v ^= v >> 33; v *= 0xff51afd7ed558ccdULL;
-    v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL;
-    v ^= v >> 33;
-    return (unsigned)v;
-}
-
 __global__ __launch_bounds__(256) void k_dropout(const float* __restrict__ x, float* __restrict__ y, size_t n, float p,
                                                  unsigned long long seed) {
     const float scale = 1.0f / (1.0f - p);

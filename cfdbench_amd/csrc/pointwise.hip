@@ -1147,6 +1147,59 @@ __global__ __launch_bounds__(256) void k_gelu(const float* __restrict__ x, const
         out[i] = BWD ? gy[i] * cfd_gelu_grad(x[i]) : cfd_gelu(x[i]);
 }
 
+// gelu(dropout(x)) and its gradient as ONE pass each (ResidualBlock.forward, src/models/resnet.py:70-77: conv1 -> dropout -> GELU):
+// the keep mask is the hash of (seed, index) of k_dropout, regenerated in the backward pass; value for value the two stand-alone
+// passes (same roundings), which cost the ResNet step two launches and two trips through HBM per block and direction.
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_dropout_gelu(const float* __restrict__ x, const float* __restrict__ gy,
+                                                      float* __restrict__ out, size_t n4, float p, unsigned long long seed) {
+    const float scale = 1.0f / (1.0f - p);
+    const unsigned thresh = (unsigned)((double)p * 4294967296.0);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (BWD) gv = reinterpret_cast<const float4*>(gy)[i];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool keep = cfd_hash32(seed * 0x9E3779B97F4A7C15ULL + (4 * i + j)) >= thresh;
+            const float d = keep ? xs[j] * scale : 0.f;
+            if constexpr (BWD) {
+                const float t = gs[j] * cfd_gelu_grad(d);
+                o[j] = keep ? t * scale : 0.f;
+            } else {
+                o[j] = cfd_gelu(d);
+            }
+        }
+        reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+static int launch_dropout_gelu(const float* x, const float* gy, float* out, size_t n, float p, unsigned long long seed, bool bwd,
+                               hipStream_t st, const char* what) {
+    CFD_REQUIRE(x && out && (!bwd || gy), CFD_ERR_INVALID_ARG, "%s: NULL pointer", what);
+    CFD_REQUIRE(p >= 0.f && p < 1.f, CFD_ERR_INVALID_ARG, "%s: p must be in [0, 1)", what);
+    CFD_REQUIRE(n % 4 == 0 && !(((size_t)x | (size_t)out | (size_t)gy) & 15), CFD_ERR_UNSUPPORTED,
+                "%s: needs a multiple of four elements and 16-byte aligned tensors (use cfd_dropout + cfd_gelu_* otherwise)", what);
+    if (n == 0) return CFD_OK;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (bwd) hipLaunchKernelGGL((k_dropout_gelu<true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gy, out, n / 4, p, seed);
+    else hipLaunchKernelGGL((k_dropout_gelu<false>), dim3((unsigned)blocks), dim3(256), 0, st, x, gy, out, n / 4, p, seed);
+    CFD_LAUNCH_CHECK(what);
+    return CFD_OK;
+}
+
+extern "C" int cfd_dropout_gelu_fwd(const float* x, float* y, size_t n, float p, unsigned long long seed, void* stream) {
+    return launch_dropout_gelu(x, nullptr, y, n, p, seed, false, (hipStream_t)stream, "cfd_dropout_gelu_fwd");
+}
+
+extern "C" int cfd_dropout_gelu_bwd(const float* x, const float* gy, float* gx, size_t n, float p, unsigned long long seed,
+                                    void* stream) {
+    return launch_dropout_gelu(x, gy, gx, n, p, seed, true, (hipStream_t)stream, "cfd_dropout_gelu_bwd");
+}
+
 extern "C" int cfd_gelu_fwd(const float* x, float* y, size_t n, void* stream) {
     CFD_REQUIRE(x && y, CFD_ERR_INVALID_ARG, "cfd_gelu_fwd: NULL pointer");
     if (n == 0) return CFD_OK;

@@ -860,6 +860,55 @@ class DropoutFn(torch.autograd.Function):
         return gx, None, None
 
 
+class DropoutGeluFn(torch.autograd.Function):
+    """gelu(dropout(x)) as one pass per direction (ResidualBlock: conv1 -> nn.Dropout -> nn.GELU, resnet.py:70-77); p = 0 (eval
+    mode) is the plain GELU.  Value for value GeluFn(DropoutFn(x)); falls back to the two passes for tensors the fused kernel does
+    not take (element count not a multiple of four)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, p: float, seed: int):
+        _require_cuda(x)
+        x = _f32c(x)
+        ctx.fused = x.numel() % 4 == 0 and x.data_ptr() % 16 == 0
+        ctx.meta = (float(p), int(seed))
+        y = torch.empty_like(x)
+        api = _lib.api()
+        if ctx.fused:
+            api.call("cfd_dropout_gelu_fwd", _ptr(x), _ptr(y), x.numel(), float(p), int(seed), _stream())
+            ctx.save_for_backward(x)
+        else:
+            d = x
+            if p > 0:
+                d = torch.empty_like(x)
+                api.call("cfd_dropout", _ptr(x), _ptr(d), x.numel(), float(p), int(seed), _stream())
+            api.call("cfd_gelu_fwd", _ptr(d), _ptr(y), x.numel(), _stream())
+            ctx.save_for_backward(d)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        (x,) = ctx.saved_tensors
+        p, seed = ctx.meta
+        gy = _f32c(gy)
+        gx = torch.empty_like(x)
+        api = _lib.api()
+        if ctx.fused and gy.data_ptr() % 16 == 0:
+            api.call("cfd_dropout_gelu_bwd", _ptr(x), _ptr(gy), _ptr(gx), x.numel(), p, seed, _stream())
+            return gx, None, None
+        if ctx.fused:  # (the saved tensor is x, not dropout(x))
+            d = x
+            if p > 0:
+                d = torch.empty_like(x)
+                api.call("cfd_dropout", _ptr(x), _ptr(d), x.numel(), p, seed, _stream())
+            x = d
+        api.call("cfd_gelu_bwd", _ptr(x), _ptr(gy), _ptr(gx), x.numel(), _stream())
+        if p > 0:
+            g2 = torch.empty_like(gx)
+            api.call("cfd_dropout", _ptr(gx), _ptr(g2), gx.numel(), p, seed, _stream())
+            gx = g2
+        return gx, None, None
+
+
 class AddFn(torch.autograd.Function):
     """x + y for equal shapes (the skip connection of a ResidualBlock, resnet.py:79)."""
 

@@ -44,11 +44,12 @@ class ResidualBlock(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         residual = x if self.res_conv is None else F_.Conv2dReplicateFn.apply(x, self.res_conv.weight, self.res_conv.bias)
         x = F_.Conv2dReplicateFn.apply(x, self.conv1.weight, self.conv1.bias, *F_.conv_frags(self.conv1))
+        p_drop, seed = 0.0, 0
         if self.training and self.dropout.p > 0:
+            p_drop = self.dropout.p
             seed = self._mix64(self._mix64(torch.initial_seed()) + 0x9E3779B97F4A7C15 * (self.block_idx + 1)
                                + self.drop_step) & 0xFFFFFFFFFFFF
-            x = F_.DropoutFn.apply(x, self.dropout.p, seed)
-        x = F_.GeluFn.apply(x)
+        x = F_.DropoutGeluFn.apply(x, p_drop, seed)  # dropout (training) and GELU in one pass per direction
         x = F_.Conv2dReplicateFn.apply(x, self.conv2.weight, self.conv2.bias, *F_.conv_frags(self.conv2))
         return F_.AddFn.apply(x, residual)
 

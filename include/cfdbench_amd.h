@@ -338,6 +338,11 @@ int cfd_residual_mask(const float* x, const float* resid, const float* mask, flo
 /* nn.Dropout (resnet.py:45,76): y = x * keep / (1-p) with keep from a counter-based hash of (seed, index).  The same
  * call with the upstream gradient as x is the backward pass.  (torch's Philox stream is not reproducible here.)  */
 int cfd_dropout(const float* x, float* y, size_t n, float p, unsigned long long seed, void* stream);
+/* y = gelu(dropout(x)) and gx = d/dx of it applied to gy, one pass each (resnet.py:70-77: conv1 -> nn.Dropout -> nn.GELU); p = 0 is
+ * the plain GELU.  Value for value cfd_dropout followed by cfd_gelu_fwd / cfd_gelu_bwd followed by cfd_dropout.  n % 4 == 0 and
+ * 16-byte aligned tensors, else CFD_ERR_UNSUPPORTED.                                                                        */
+int cfd_dropout_gelu_fwd(const float* x, float* y, size_t n, float p, unsigned long long seed, void* stream);
+int cfd_dropout_gelu_bwd(const float* x, const float* gy, float* gx, size_t n, float p, unsigned long long seed, void* stream);
 
 /* ---- whole Auto-FNO (Fno2d.forward, fno2d.py:178-242; loss.backward() at train_auto.py:255) ---------------*/
 typedef struct {

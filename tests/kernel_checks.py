@@ -913,3 +913,27 @@ def check_act(be, n, act, seed=43):
     api.call("cfd_act_bwd", P(dg), P(y), P(dx), P(gx), n, code, be.stream)
     be.sync()
     return {"y": nm(be.host(y), D.act(x.astype(f64), act)), "gx": nm(be.host(gx), g.astype(f64) * D.act_grad(x.astype(f64), act))}
+
+
+def check_dropout_gelu(be, n, p, seed=5):
+    """cfd_dropout_gelu_fwd / _bwd against cfd_dropout + cfd_gelu_fwd / cfd_gelu_bwd + cfd_dropout: the same values bit for bit, and
+    against the exact-erf GELU of numpy on the kept elements.  Returns (values that differ, nMSE of the forward vs numpy)."""
+    import math
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    x = (2.5 * rng.standard_normal(n)).astype(np.float32)
+    g = rng.standard_normal(n).astype(np.float32)
+    dx, dg = be.dev(x), be.dev(g)
+    y1, gx1, d, y2, t, gx2 = (be.zeros((n,)) for _ in range(6))
+    api.call("cfd_dropout_gelu_fwd", P(dx), P(y1), n, p, 1234, be.stream)
+    api.call("cfd_dropout_gelu_bwd", P(dx), P(dg), P(gx1), n, p, 1234, be.stream)
+    api.call("cfd_dropout", P(dx), P(d), n, p, 1234, be.stream)
+    api.call("cfd_gelu_fwd", P(d), P(y2), n, be.stream)
+    api.call("cfd_gelu_bwd", P(d), P(dg), P(t), n, be.stream)
+    api.call("cfd_dropout", P(t), P(gx2), n, p, 1234, be.stream)
+    be.sync()
+    bad = int(np.count_nonzero(be.host(y1) != be.host(y2))) + int(np.count_nonzero(be.host(gx1) != be.host(gx2)))
+    dh = be.host(d).astype(f64)
+    from scipy.special import erf
+    ref = 0.5 * dh * (1.0 + erf(dh / math.sqrt(2.0)))
+    return bad, nm(be.host(y1), ref)

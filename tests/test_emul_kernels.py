@@ -252,6 +252,13 @@ def test_convtranspose_random_shapes(be):
             assert not bad, ((B, Ci, Co, H, W, mfma), bad)
 
 
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_dropout_gelu_one_pass(be, p):
+    """gelu(dropout(x)) and its gradient in one pass each == the stand-alone passes bit for bit (p = 0: the plain GELU)"""
+    bad, err = K.check_dropout_gelu(be, 4 * 1031, p)
+    assert bad == 0 and err < 1e-12
+
+
 def test_dense_and_norm_kernels_random_shapes(be):
     """The same kind of sweep for BatchNorm, the fused Linear stacks, the GEMM and the 1x1 conv / its weight gradient."""
     import random

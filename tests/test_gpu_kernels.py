@@ -266,6 +266,13 @@ def test_convtranspose_full_size(be, B, Ci, Co, H, W, mfma):
         _assert_all(K.check_convt(be, B, Ci, Co, H, W))
 
 
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_dropout_gelu_one_pass(be, p):
+    """gelu(dropout(x)) and its gradient in one pass each == the stand-alone passes bit for bit (p = 0: the plain GELU)"""
+    bad, err = K.check_dropout_gelu(be, 32 * 64 * 64 * 64, p)
+    assert bad == 0 and err < 1e-12
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 96, 4, 4), (3, 12, 32, 32), (1, 5, 7, 9), (2, 3, 1, 1), (1, 2, 33, 2)])
 def test_upsample_bilinear_align_corners(be, B, C, H, W):
     _assert_all(K.check_upsample_bilinear(be, B, C, H, W))
