@@ -23,6 +23,16 @@ int cfd_conv_splitk_sum(const float* part, const float* bias, float* out, long n
                         const char* what);
 // out[e] = sum_chunk part[chunk][e] in a fixed order (conv.hip)
 void cfd_conv_part_reduce(const float* part, float* out, long n, int nchunk, hipStream_t st, float* out2 = nullptr, long n1 = 0);
+// The same reduction as a job that rides in the first `nblk` workgroups of a LATER launch of the same call (k_fold_border carries the
+// weight-gradient reduction of cfd_conv2d_bwd: one ~5-us launch less per convolution and backward pass; same code, same order).
+struct CfdPartReduceJob {
+    const float* part;  // NULL: no job
+    float* out;
+    float* out2;
+    long n, n1;
+    int nchunk, nblk, G;
+};
+CfdPartReduceJob cfd_conv_part_reduce_job(const float* part, float* out, long n, int nchunk, float* out2, long n1);
 
 // ---- conv6.hip: k = 3 / k = 7 on three-piece split-bf16 operands (fp32-exact pieces, six bf16 MFMAs per product) ----
 // forward (ext = false: dst (B,Co,H,W) = conv(src (B,Ci,H,W)) + bias) and the transposed-valid pass of the input gradient
@@ -45,8 +55,9 @@ int cfd_conv6_stats_slots(const ConvGeom& g);
 bool cfd_conv6_wgrad_covers(const ConvGeom& g);
 size_t cfd_conv6_wgrad_ws_bytes(const ConvGeom& g);
 // gb != NULL: the bias gradient gb (Co) = sum over (b, p) of gout rides in the same launches (the gradient tile is staged anyway)
+// defer != NULL: the reduction of the partial slices is not launched but described in *defer for a later launch to carry
 int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, float* gb, void* ws, const ConvGeom& g, hipStream_t st,
-                    const char* what);
+                    const char* what, CfdPartReduceJob* defer = nullptr);
 
 // ---- convt6.hip: ConvTranspose2d(2, stride 2) on three-piece split-bf16 operands (fp32-exact pieces, six bf16 MFMAs per product) ----
 bool cfd_convt6_covers(int B, int Ci, int Co, int H, int W);

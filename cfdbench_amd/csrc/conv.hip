@@ -276,30 +276,6 @@ __global__ __launch_bounds__(256) void k_fold_pad(const float* __restrict__ ext,
     }
 }
 
-// The same for the border pixels only (top and bottom rows, then the left and right columns without their corners): the interior
-// of gin was written by the input-gradient kernel itself (conv6.hip, `gin_direct`), so the fold touches 2 (H + W) - 4 pixels per
-// image instead of H * W and the extended buffer is read along its rim only.
-__global__ __launch_bounds__(256) void k_fold_border(const float* __restrict__ ext, float* __restrict__ gin, unsigned total, int H,
-                                                     int W, int pad, CfdDiv dNB) {
-    const int He = H + 2 * pad, We = W + 2 * pad, nb = 2 * W + 2 * (H - 2);
-    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const unsigned img = cfd_div(e, dNB);
-        const int j = (int)(e - img * (unsigned)nb);
-        int y, x;
-        if (j < W) { y = 0; x = j; }
-        else if (j < 2 * W) { y = H - 1; x = j - W; }
-        else if (j < 2 * W + H - 2) { y = 1 + (j - 2 * W); x = 0; }
-        else { y = 1 + (j - 2 * W - (H - 2)); x = W - 1; }
-        const int y0 = y == 0 ? 0 : y + pad, y1 = y == H - 1 ? He - 1 : y + pad;
-        const int x0 = x == 0 ? 0 : x + pad, x1 = x == W - 1 ? We - 1 : x + pad;
-        const float* s = ext + (size_t)img * He * We;
-        float acc = 0.f;
-        for (int yy = y0; yy <= y1; ++yy)
-            for (int xx = x0; xx <= x1; ++xx) acc += s[yy * We + xx];
-        gin[(size_t)img * H * W + y * W + x] = acc;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------
 // weight gradient: gw[o][j] = sum_{b,p} g[b][o][p] * in[b][i(j)][clamp(p + (ky,kx)(j) - pad)],  j over Ci*ks*ks
 // Workgroup = one 32 x 64 block of the (o, j) plane x one chunk of pixels; partials are reduced in a fixed order.
@@ -420,12 +396,11 @@ static void wgrad_plan(long total_px, int R, int J, long& chunk_px, int& nchunk)
 // weight tensor and ~1000 partial slices (the wide, shallow U-Net levels) would otherwise leave each of a handful of
 // threads a serial chain of 1000 dependent-latency loads (measured 60 us for 1296 outputs).
 template <int G>
-__global__ __launch_bounds__(256) void k_part_reduce(const float* __restrict__ part, float* __restrict__ out, long n, int nchunk,
-                                                     float* __restrict__ out2, long n1) {
+__device__ __forceinline__ void part_reduce_body(const float* __restrict__ part, float* __restrict__ out, long n, int nchunk,
+                                                 float* __restrict__ out2, long n1, int blk, int nblk, float* s_p) {
     constexpr int E = 256 / G;
-    __shared__ float s_p[256];
     const int el = threadIdx.x % E, grp = threadIdx.x / E;
-    for (long e0 = (long)blockIdx.x * E; e0 < n; e0 += (long)gridDim.x * E) {
+    for (long e0 = (long)blk * E; e0 < n; e0 += (long)nblk * E) {
         const long e = e0 + el;
         float s = 0.f;
         if (e < n) {
@@ -453,23 +428,68 @@ __global__ __launch_bounds__(256) void k_part_reduce(const float* __restrict__ p
     }
 }
 
+template <int G>
+__global__ __launch_bounds__(256) void k_part_reduce(const float* __restrict__ part, float* __restrict__ out, long n, int nchunk,
+                                                     float* __restrict__ out2, long n1) {
+    __shared__ float s_p[256];
+    part_reduce_body<G>(part, out, n, nchunk, out2, n1, blockIdx.x, gridDim.x, s_p);
+}
+
+// workgroup `blk` of job.nblk (256 threads) of a carried reduction
+__device__ __forceinline__ void cfd_part_reduce_job_run(const CfdPartReduceJob& j, int blk, float* s_p) {
+    if (j.G == 16) part_reduce_body<16>(j.part, j.out, j.n, j.nchunk, j.out2, j.n1, blk, j.nblk, s_p);
+    else if (j.G == 4) part_reduce_body<4>(j.part, j.out, j.n, j.nchunk, j.out2, j.n1, blk, j.nblk, s_p);
+    else part_reduce_body<1>(j.part, j.out, j.n, j.nchunk, j.out2, j.n1, blk, j.nblk, s_p);
+}
+
+// The same for the border pixels only (top and bottom rows, then the left and right columns without their corners): the interior
+// of gin was written by the input-gradient kernel itself (conv6.hip, `gin_direct`), so the fold touches 2 (H + W) - 4 pixels per
+// image instead of H * W and the extended buffer is read along its rim only.  The first job.nblk workgroups of the launch run a
+// carried partial-sum reduction instead (the weight gradient of the same cfd_conv2d_bwd call).
+__global__ __launch_bounds__(256) void k_fold_border(const float* __restrict__ ext, float* __restrict__ gin, unsigned total, int H,
+                                                     int W, int pad, CfdDiv dNB, const CfdPartReduceJob job) {
+    __shared__ float s_p[256];
+    if ((int)blockIdx.x < job.nblk) {
+        cfd_part_reduce_job_run(job, blockIdx.x, s_p);
+        return;
+    }
+    const unsigned blk = blockIdx.x - job.nblk, nblk = gridDim.x - job.nblk;
+    const int He = H + 2 * pad, We = W + 2 * pad, nb = 2 * W + 2 * (H - 2);
+    for (unsigned e = blk * blockDim.x + threadIdx.x; e < total; e += nblk * blockDim.x) {
+        const unsigned img = cfd_div(e, dNB);
+        const int j = (int)(e - img * (unsigned)nb);
+        int y, x;
+        if (j < W) { y = 0; x = j; }
+        else if (j < 2 * W) { y = H - 1; x = j - W; }
+        else if (j < 2 * W + H - 2) { y = 1 + (j - 2 * W); x = 0; }
+        else { y = 1 + (j - 2 * W - (H - 2)); x = W - 1; }
+        const int y0 = y == 0 ? 0 : y + pad, y1 = y == H - 1 ? He - 1 : y + pad;
+        const int x0 = x == 0 ? 0 : x + pad, x1 = x == W - 1 ? We - 1 : x + pad;
+        const float* s = ext + (size_t)img * He * We;
+        float acc = 0.f;
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) acc += s[yy * We + xx];
+        gin[(size_t)img * H * W + y * W + x] = acc;
+    }
+}
+
 // elements [0, n1) of a partial slice go to out, elements [n1, n) to out2 (the conv6 weight gradient carries the bias gradient behind
 // the weights); out2 == NULL: n1 = n
+CfdPartReduceJob cfd_conv_part_reduce_job(const float* part, float* out, long n, int nchunk, float* out2, long n1) {
+    CfdPartReduceJob j{part, out, out2, n, out2 ? n1 : n, nchunk, 0, 1};
+    long blocks;
+    if (nchunk >= 128) { j.G = 16; blocks = (n + 15) / 16; if (blocks > 2048) blocks = 2048; }
+    else if (nchunk >= 24) { j.G = 4; blocks = (n + 63) / 64; if (blocks > 2048) blocks = 2048; }
+    else { j.G = 1; blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024; }
+    j.nblk = (int)blocks;
+    return j;
+}
+
 void cfd_conv_part_reduce(const float* part, float* out, long n, int nchunk, hipStream_t st, float* out2, long n1) {
-    if (!out2) n1 = n;
-    if (nchunk >= 128) {
-        long blocks = (n + 15) / 16;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL((k_part_reduce<16>), dim3((unsigned)blocks), dim3(256), 0, st, part, out, n, nchunk, out2, n1);
-    } else if (nchunk >= 24) {
-        long blocks = (n + 63) / 64;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL((k_part_reduce<4>), dim3((unsigned)blocks), dim3(256), 0, st, part, out, n, nchunk, out2, n1);
-    } else {
-        long blocks = (n + 255) / 256;
-        if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL((k_part_reduce<1>), dim3((unsigned)blocks), dim3(256), 0, st, part, out, n, nchunk, out2, n1);
-    }
+    const CfdPartReduceJob j = cfd_conv_part_reduce_job(part, out, n, nchunk, out2, n1);
+    if (j.G == 16) hipLaunchKernelGGL((k_part_reduce<16>), dim3((unsigned)j.nblk), dim3(256), 0, st, part, out, n, nchunk, out2, j.n1);
+    else if (j.G == 4) hipLaunchKernelGGL((k_part_reduce<4>), dim3((unsigned)j.nblk), dim3(256), 0, st, part, out, n, nchunk, out2, j.n1);
+    else hipLaunchKernelGGL((k_part_reduce<1>), dim3((unsigned)j.nblk), dim3(256), 0, st, part, out, n, nchunk, out2, j.n1);
 }
 
 // per-channel sum over (B, HW) in two parallel stages (defined next to the BatchNorm reductions it shares)
@@ -493,7 +513,9 @@ extern "C" size_t cfd_conv2d_bwd_workspace_bytes(int B, int Ci, int Co, int H, i
     // weight-gradient partials and the bias sums reuse the front of the buffer afterwards
     const ConvGeom gg{B, Ci, Co, H, W, ks};
     const size_t dg = ext + (cfd_conv6_covers(gg, true) ? cfd_conv6_ws_bytes(gg, true) : 0);
-    const size_t m = dg > part ? dg : part;
+    // conv6 route: the weight-gradient partials live BEHIND the input-gradient region (their reduction rides in the border-fold
+    // launch, which still reads the extended buffer)
+    const size_t m = (cfd_conv6_covers(gg, true) && cfd_conv6_wgrad_covers(gg)) ? dg + part : (dg > part ? dg : part);
     return m > cs ? m : cs;
 }
 
@@ -529,14 +551,27 @@ extern "C" int cfd_conv2d_bwd_ex(const float* gout, const float* in, const float
                 CFD_TRY(launch_conv_gather<true>(gout, w, nullptr, ext, g, st, "cfd_conv2d_bwd(dgrad)"));
             }
         }
+        // conv6 route with a direct interior: the weight gradient runs BEFORE the border fold and leaves its partial-sum reduction to
+        // the fold launch's first workgroups (one launch less; the partials sit behind the input-gradient region of ws)
+        CfdPartReduceJob job{};
+        if (direct && gw && cfd_conv6_wgrad_covers(g)) {
+            const size_t ext_bytes = cfd_align_up((size_t)B * Ci * (H + 2 * pad) * (W + 2 * pad) * sizeof(float), 256);
+            void* wws = (char*)ws + ext_bytes + cfd_conv6_ws_bytes(g, true);
+            {
+                CFD_PROF_W("k_conv_wgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci * ks * ks),
+                           2.0 * B * HW * (double)Co * Ci * ks * ks);
+                CFD_TRY(cfd_conv6_wgrad(gout, in, gw, gb, wws, g, st, "cfd_conv2d_bwd(wgrad)", &job));
+            }
+            gw = nullptr, gb = nullptr;  // final once the fold launch below has run
+        }
         CFD_PROF_W("k_fold_pad", st, 0.0, 0.0);  // pure data movement of the extended-grid formulation: no algorithmic bytes
         if (direct) {
             const long total = (long)B * Ci * (2 * W + 2 * (H - 2));
             CFD_REQUIRE_I31(total, "cfd_conv2d_bwd");
             long blocks = (total + 255) / 256;
             if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(k_fold_border, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ext, gin, (unsigned)total, H, W, pad,
-                               cfd_div_make((unsigned)(2 * W + 2 * (H - 2))));
+            hipLaunchKernelGGL(k_fold_border, dim3((unsigned)(blocks + job.nblk)), dim3(256), 0, st, (const float*)ext, gin, (unsigned)total,
+                               H, W, pad, cfd_div_make((unsigned)(2 * W + 2 * (H - 2))), job);
         } else {
             const long total = (long)B * Ci * HW;
             long blocks = (total + 255) / 256;

@@ -821,7 +821,7 @@ size_t cfd_conv6_wgrad_ws_bytes(const ConvGeom& g) {
 }
 
 int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, float* gb, void* ws, const ConvGeom& g, hipStream_t st,
-                    const char* what) {
+                    const char* what, CfdPartReduceJob* defer) {
     const Wg6Plan P = wg6_plan(g);
     if (!P.ok) return CFD_ERR_UNSUPPORTED;
     const dim3 grid(P.groups, P.chunks, P.mgroups * P.nkg);
@@ -845,6 +845,10 @@ int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, float* gb, vo
 #undef W6_L
     CFD_LAUNCH_CHECK(what);
     const long n1 = (long)g.Co * g.Ci * g.ks * g.ks;
+    if (defer) {
+        *defer = cfd_conv_part_reduce_job((const float*)ws, gw, n1 + (gb ? g.Co : 0), P.groups, gb, n1);
+        return CFD_OK;
+    }
     cfd_conv_part_reduce((const float*)ws, gw, n1 + (gb ? g.Co : 0), P.groups, st, gb, n1);
     CFD_LAUNCH_CHECK(what);
     return CFD_OK;
