@@ -176,6 +176,10 @@ int cfd_loss_sums_bwd(const float* preds, const float* labels, const float* gsum
                       void* stream);
 /* scores[0..3] = {mse, rmse, mae, nmse} from sums (loss.py:27-35).                                           */
 int cfd_loss_scores(const float* sums, float* scores, void* stream);
+/* gsums[4] = d(scores)/d(sums) applied to the upstream gradients of mse / rmse / mae / nmse (device scalars; NULL = no gradient):
+ * the backward pass of cfd_loss_scores in one launch, with autograd's fp32 operation order for loss.py:27-35.  gsums[3] = 0.   */
+int cfd_loss_scores_bwd(const float* sums, const float* g_mse, const float* g_rmse, const float* g_mae, const float* g_nmse,
+                        float* gsums, void* stream);
 /* coef for cfd_fno_head_bwd: which = 0 mse, 1 nmse, 2 mae; scaled by `upstream` (d objective / d loss).       */
 int cfd_loss_coef(const float* sums, float* coef, int which, float upstream, void* stream);
 /* The same coefficients BEFORE any prediction exists: d mse|nmse|mae / d preds need only the element count and

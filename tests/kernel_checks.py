@@ -937,3 +937,32 @@ def check_dropout_gelu(be, n, p, seed=5):
     from scipy.special import erf
     ref = 0.5 * dh * (1.0 + erf(dh / math.sqrt(2.0)))
     return bad, nm(be.host(y1), ref)
+
+
+def check_loss_scores_bwd(be, seed=6):
+    """cfd_loss_scores / cfd_loss_scores_bwd against the formulas of loss.py:27-35 and their derivatives in float64; returns the
+    largest relative error over the scores and over d(score)/d(sums) for each score alone and for all four together."""
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for _ in range(5):
+        n = float(rng.integers(10, 100000))
+        sums = np.array([rng.random() * n, rng.random() * n, (0.5 + rng.random()) * n, n], np.float32)
+        g = rng.standard_normal(4).astype(np.float32)
+        ds, scores = be.dev(sums), be.zeros((4,))
+        api.call("cfd_loss_scores", P(ds), P(scores), be.stream)
+        s0, s1, s2, nn = (float(v) for v in sums)
+        ref = np.array([s0 / nn, np.sqrt(s0 / nn), s1 / nn, s0 / s2])
+        be.sync()
+        worst = max(worst, float(np.abs(be.host(scores) - ref).max() / np.abs(ref).max()))
+        jac = np.array([[1 / nn, 0, 0], [0.5 / np.sqrt(s0 / nn) / nn, 0, 0], [0, 1 / nn, 0], [1 / s2, 0, -s0 / s2 ** 2]])  # d score_i / d sums_j
+        for pick in ([0], [1], [2], [3], [0, 1, 2, 3]):
+            gd = [be.dev(g[i:i + 1]) if i in pick else None for i in range(4)]
+            out = be.zeros((4,))
+            api.call("cfd_loss_scores_bwd", P(ds), *[P(t) if t is not None else None for t in gd], P(out), be.stream)
+            be.sync()
+            want = sum(g[i] * jac[i] for i in pick)
+            got = be.host(out)
+            assert got[3] == 0.0
+            worst = max(worst, float(np.abs(got[:3] - want).max() / max(np.abs(want).max(), 1e-30)))
+    return worst

@@ -252,6 +252,11 @@ def test_convtranspose_random_shapes(be):
             assert not bad, ((B, Ci, Co, H, W, mfma), bad)
 
 
+def test_loss_scores_and_their_gradient(be):
+    """(mse, rmse, mae, nmse) from the sums tensor and d(scores)/d(sums), one launch each"""
+    assert K.check_loss_scores_bwd(be) < 1e-6
+
+
 @pytest.mark.parametrize("p", [0.0, 0.2])
 def test_dropout_gelu_one_pass(be, p):
     """gelu(dropout(x)) and its gradient in one pass each == the stand-alone passes bit for bit (p = 0: the plain GELU)"""

@@ -154,6 +154,28 @@ def test_mseloss_vs_reference_golden(torch, golden_dir):
         loss_name_to_fn("l1")
 
 
+def test_loss_scores_node_equals_the_scalar_formulas(torch):
+    """functional.LossScoresFn == loss.py:27-35 written with torch scalar ops on the sums tensor: scores bit for bit, gradients of
+    every score w.r.t. the sums to fp32 rounding."""
+    from cfdbench_amd.functional import LossScoresFn
+    gen = torch.Generator().manual_seed(3)
+    for _ in range(4):
+        n = float(torch.randint(100, 1000000, (1,), generator=gen))
+        sums = (torch.rand(4, generator=gen) * n).cuda()
+        sums[3] = n
+        a = sums.clone().requires_grad_(True)
+        b = sums.clone().requires_grad_(True)
+        ours = LossScoresFn.apply(a)
+        nn_ = b[3]
+        mse = b[0] / nn_
+        theirs = (mse, torch.sqrt(mse), b[1] / nn_, mse / (b[2] / nn_))
+        for i in range(4):
+            assert torch.equal(ours[i], theirs[i]), i
+            (ga,) = torch.autograd.grad(ours[i], a, retain_graph=True)
+            (gb,) = torch.autograd.grad(theirs[i], b, retain_graph=True)
+            assert ga[3] == 0 and torch.allclose(ga[:3], gb[:3], rtol=1e-6, atol=0), (i, ga, gb)
+
+
 def test_fno_block_module(torch):
     from cfdbench_amd.models.fno.fno2d import FnoBlock
     import torch.nn as nn
