@@ -294,7 +294,8 @@ def unet_bytes_per_frame(dim, cin, H, W):
 
 
 def model_train_leg(api, name, model, batch, steps, warmup, frames, bytes_per_frame, what):
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True)  # torch's single-kernel multi-tensor Adam
+    from cfdbench_amd.optim import Adam as MultiTensorAdam
+    opt = MultiTensorAdam(model.parameters(), lr=1e-3)  # torch.optim.Adam's update as one launch per 80 tensors (cfd_adam_multi)
     from cfdbench_amd.graph import GraphedTrainStep
 
     def eager():

@@ -76,6 +76,7 @@ _SIGS = {
     "cfd_gelu_fwd": (_I, [_P, _P, _Z, _P]),
     "cfd_gelu_bwd": (_I, [_P, _P, _P, _Z, _P]),
     "cfd_adam_flat": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P]),
+    "cfd_adam_multi": (_I, [_I, _P, _P, _P, _P, _P, _P, _F, _P, _F, _F, _F, _F, _F, _F, _P]),
     "cfd_gemm_workspace_bytes": (_Z, [_I, _I, _I]),
     "cfd_gemm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfd_linear_fwd_workspace_bytes": (_Z, [_I, _I, _I]),

@@ -352,8 +352,20 @@ extern "C" int cfd_deeponet_inner_fwd(const float* branch, const float* trunk, c
 
 __global__ __launch_bounds__(256) void k_sum_all(const float* __restrict__ g, size_t n, float* __restrict__ part) {
     __shared__ float s_r[4];
-    float a = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a += g[i];
+    // eight loads in flight per thread, eight running sums combined in a fixed order (one load per trip was a chain of 67 exposed
+    // memory round trips for the 2.2 M gradients of the Auto-DeepONet bias: 17 us)
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (; i + 7 * stride < n; i += 8 * stride) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = g[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+    for (; i < n; i += stride) acc[0] += g[i];
+    float a = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     a = cfd_wave_sum(a);
     if ((threadIdx.x & 63) == 0) s_r[threadIdx.x >> 6] = a;
     __syncthreads();

@@ -205,8 +205,12 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
                                       "host state (the ResNet's dropout seed)")
         # fused: ONE multi-tensor kernel per step (the capturable foreach form with a device-resident rate takes ~2.7 ms for the U-Net's
         # 136 tensors, tools/exp/adam_fused_ab.py); same formula, results within rounding of the foreach form
-        optimizer = Adam(model.parameters(), lr=torch.tensor(float(lr), device="cuda"), capturable=True,
-                         fused=not any(p_.is_complex() for p_ in model.parameters()))  # (torch's fused form takes real parameters only)
+        from ..optim import Adam as MultiTensorAdam
+        if MultiTensorAdam.supports(list(model.parameters())):  # one launch per 80 tensors (cfd_adam_multi; torch's fused form: 3 x 31 us)
+            optimizer = MultiTensorAdam(model.parameters(), lr=torch.tensor(float(lr), device="cuda"))
+        else:
+            optimizer = Adam(model.parameters(), lr=torch.tensor(float(lr), device="cuda"), capturable=True,
+                             fused=not any(p_.is_complex() for p_ in model.parameters()))  # (torch's fused form takes real parameters only)
     else:
         optimizer = Adam(model.parameters(), lr=lr)
     graphed = None

@@ -198,6 +198,12 @@ int cfd_gelu_bwd(const float* x, const float* gy, float* gx, size_t n, void* str
  * torch's view_as_real handling).  step >= 1.                                                               */
 int cfd_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* The same step for n parameter tensors in one launch per 80 tensors (host tables of device pointers and element counts).  lr_dev /
+ * step_dev: NULL, or device scalars that override lr / step (torch.optim.Adam(capturable=True) keeps both on the device, so that a
+ * captured HIP graph replays with the current values); bias corrections in fp32.  fp32 real tensors only.                      */
+int cfd_adam_multi(int n, float* const* param, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
+                   const size_t* numel, const float* lr_dev, float lr, const float* step_dev, float step, float beta1, float beta2,
+                   float eps, float weight_decay, float grad_scale, void* stream);
 
 /* ---- dense layers of the DeepONet family (fp32 MFMA GEMMs) ----------------------------------------------*/
 

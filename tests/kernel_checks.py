@@ -966,3 +966,25 @@ def check_loss_scores_bwd(be, seed=6):
             assert got[3] == 0.0
             worst = max(worst, float(np.abs(got[:3] - want).max() / max(np.abs(want).max(), 1e-30)))
     return worst
+
+
+def check_adam_multi(be, sizes=(7, 1025, 300, 1), steps=3, seed=8):
+    """cfd_adam_multi (many tensors, one launch, step count and rate from device scalars) against cfd_adam_flat tensor by tensor:
+    the same update up to the fp32 rounding of the bias corrections.  Returns the largest relative difference of the parameters."""
+    import ctypes
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    p0 = [rng.standard_normal(n).astype(np.float32) for n in sizes]
+    pa, ma, va = [be.dev(t) for t in p0], [be.zeros((n,)) for n in sizes], [be.zeros((n,)) for n in sizes]
+    pb, mb, vb = [be.dev(t) for t in p0], [be.zeros((n,)) for n in sizes], [be.zeros((n,)) for n in sizes]
+    lr = be.dev(np.array([2e-3], np.float32))
+    col = lambda ts: (ctypes.c_void_p * len(ts))(*[P(t) for t in ts])
+    for k in range(1, steps + 1):
+        g = [be.dev(rng.standard_normal(n).astype(np.float32)) for n in sizes]
+        stp = be.dev(np.array([float(k)], np.float32))
+        api.call("cfd_adam_multi", len(sizes), col(pa), col(g), col(ma), col(va), (ctypes.c_size_t * len(sizes))(*sizes), P(lr), 0.0, P(stp), 0.0,
+                 0.9, 0.999, 1e-8, 0.01, 1.0, be.stream)
+        for t in range(len(sizes)):
+            api.call("cfd_adam_flat", P(pb[t]), P(g[t]), P(mb[t]), P(vb[t]), sizes[t], 2e-3, 0.9, 0.999, 1e-8, 0.01, k, 1.0, be.stream)
+        be.sync()
+    return max(float(np.abs(be.host(a) - be.host(b)).max() / np.abs(be.host(b)).max()) for a, b in zip(pa, pb))

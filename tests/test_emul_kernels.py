@@ -252,6 +252,10 @@ def test_convtranspose_random_shapes(be):
             assert not bad, ((B, Ci, Co, H, W, mfma), bad)
 
 
+def test_adam_for_many_tensors_in_one_launch(be):
+    assert K.check_adam_multi(be, sizes=(7, 1025, 300, 1)) < 2e-6
+
+
 def test_loss_scores_and_their_gradient(be):
     """(mse, rmse, mae, nmse) from the sums tensor and d(scores)/d(sums), one launch each"""
     assert K.check_loss_scores_bwd(be) < 1e-6

@@ -266,6 +266,10 @@ def test_convtranspose_full_size(be, B, Ci, Co, H, W, mfma):
         _assert_all(K.check_convt(be, B, Ci, Co, H, W))
 
 
+def test_adam_for_many_tensors_in_one_launch(be):
+    assert K.check_adam_multi(be, sizes=tuple([3, 700, 100000, 12] * 25)) < 2e-6
+
+
 def test_loss_scores_and_their_gradient(be):
     """(mse, rmse, mae, nmse) from the sums tensor and d(scores)/d(sums), one launch each"""
     assert K.check_loss_scores_bwd(be) < 1e-6

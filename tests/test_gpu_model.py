@@ -176,6 +176,60 @@ def test_loss_scores_node_equals_the_scalar_formulas(torch):
             assert ga[3] == 0 and torch.allclose(ga[:3], gb[:3], rtol=1e-6, atol=0), (i, ga, gb)
 
 
+def test_multi_tensor_adam_follows_torch_adam(torch):
+    """cfdbench_amd.optim.Adam == torch.optim.Adam on 90 tensors of odd sizes (two launches), with weight decay, a device-resident
+    rate that changes between steps, and a state_dict round trip in the middle; then the same step replayed from a HIP graph."""
+    from cfdbench_amd.optim import Adam
+    gen = torch.Generator().manual_seed(9)
+    shapes = [(int(torch.randint(1, 40, (1,), generator=gen)), int(torch.randint(1, 50, (1,), generator=gen))) for _ in range(89)] + [(300, 1111)]
+    init = [torch.randn(s, generator=gen) for s in shapes]
+    grads = [[torch.randn(s, generator=gen) for s in shapes] for _ in range(6)]
+    pa = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    pb = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    lr_a, lr_b = torch.tensor(3e-3, device="cuda"), torch.tensor(3e-3, device="cuda")
+    oa = Adam(pa, lr=lr_a, betas=(0.8, 0.95), eps=1e-7, weight_decay=0.01)
+    ob = torch.optim.Adam(pb, lr=lr_b, betas=(0.8, 0.95), eps=1e-7, weight_decay=0.01, capturable=True)
+    for k in range(6):
+        if k == 3:  # a scheduler step and a checkpoint round trip
+            lr_a.mul_(0.5), lr_b.mul_(0.5)
+            sd = oa.state_dict()
+            oa = Adam(pa, lr=lr_a, betas=(0.8, 0.95), eps=1e-7, weight_decay=0.01)
+            oa.load_state_dict(sd)
+        for p, q, g in zip(pa, pb, grads[k]):
+            p.grad, q.grad = g.cuda(), g.cuda()
+        oa.step(), ob.step()
+    for p, q in zip(pa, pb):
+        assert torch.allclose(p, q, rtol=2e-5, atol=1e-7)
+    assert float(oa.state[pa[0]]["step"]) == 6.0 and set(oa.state[pa[0]].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    # graph replay: static gradient buffers, two replays == two eager steps
+    pc = [torch.nn.Parameter(t.clone().cuda()) for t in init[:5]]
+    pd = [torch.nn.Parameter(t.clone().cuda()) for t in init[:5]]
+    oc, od = Adam(pc, lr=1e-2), Adam(pd, lr=1e-2)
+    for p in pc:
+        p.grad = torch.zeros_like(p)
+    oc.step()  # state created outside the capture
+    for p, q in zip(pc, pd):
+        q.grad = torch.zeros_like(q)
+    od.step()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        oc.step()
+    torch.cuda.current_stream().wait_stream(side)
+    od.step()
+    with torch.cuda.graph(graph):
+        oc.step()
+    for k in range(2):
+        for p, q, g in zip(pc, pd, grads[k][:5]):
+            p.grad.copy_(g.cuda())
+            q.grad = g.cuda()
+        graph.replay()
+        od.step()
+    for p, q in zip(pc, pd):
+        assert torch.equal(p, q)
+
+
 def test_fno_block_module(torch):
     from cfdbench_amd.models.fno.fno2d import FnoBlock
     import torch.nn as nn

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of cfdbench_amd.optim.Adam")
     a = ap.parse_args()
     from cfdbench_amd import _lib
     from cfdbench_amd.models.auto_deeponet import AutoDeepONet
@@ -27,7 +28,8 @@ def main():
     H, W, p, B = 66, 65, 5, a.batch
     torch.manual_seed(0)
     m = AutoDeepONet(H * W + p, 2, loss_name_to_fn("nmse"), branch_depth=8, trunk_depth=8, width=100).cuda()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=a.graph, fused=True)
+    from cfdbench_amd.optim import Adam as MultiTensorAdam
+    opt = MultiTensorAdam(m.parameters(), lr=1e-3) if not a.torch_adam else torch.optim.Adam(m.parameters(), lr=1e-3, capturable=a.graph, fused=True)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, 2, H, W, generator=g).cuda()
     y = (x.cpu() + 0.1 * torch.randn(B, 2, H, W, generator=g)).cuda()

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of cfdbench_amd.optim.Adam")
     a = ap.parse_args()
     from cfdbench_amd import _lib
     from cfdbench_amd.models.loss import loss_name_to_fn
@@ -26,7 +27,8 @@ def main():
     H, W, p, B = 64, 64, 8, a.batch
     torch.manual_seed(0)
     m = UNet(2, 2, loss_name_to_fn("nmse"), p, insert_case_params_at="input", dim=12).cuda()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=a.graph, fused=True)
+    from cfdbench_amd.optim import Adam as MultiTensorAdam
+    opt = MultiTensorAdam(m.parameters(), lr=1e-3) if not a.torch_adam else torch.optim.Adam(m.parameters(), lr=1e-3, capturable=a.graph, fused=True)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, 2, H, W, generator=g).cuda()
     y = (x.cpu() + 0.1 * torch.randn(B, 2, H, W, generator=g)).cuda()
