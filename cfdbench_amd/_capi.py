@@ -84,6 +84,7 @@ _SIGS = {
     "cfd_linear_bwd_workspace_bytes": (_Z, [_I, _I, _I]),
     "cfd_linear_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfd_deeponet_inner_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cfd_deeponet_inner_fwd_ex": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "cfd_deeponet_inner_bwd_workspace_bytes": (_Z, [_I, _I, _I]),
     "cfd_deeponet_inner_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cfd_act_fwd": (_I, [_P, _P, _Z, _I, _P]),

@@ -339,15 +339,23 @@ extern "C" int cfd_linear_bwd(const float* gy, const float* x, const float* w, c
 // DeepONet inner product + bias + residual  (auto_deeponet.py:127-135)
 // ------------------------------------------------------------------------------------------------------
 // preds[b][k] = sum_p branch[b][p] trunk[k][p] + bias[0] + (u ? u[b*HW + (qidx ? qidx[k] : k)] : 0)
-extern "C" int cfd_deeponet_inner_fwd(const float* branch, const float* trunk, const float* bias, const float* u,
-                                      const int* qidx, float* preds, int B, int P, int Kq, int HW, void* stream) {
+// ldu: row stride of u in floats (>= HW) -- the residual field may be the leading HW columns of the branch net's input matrix
+// [u.flatten(), case_params] (auto_deeponet.py:111-116), which then needs no copy of its own.
+extern "C" int cfd_deeponet_inner_fwd_ex(const float* branch, const float* trunk, const float* bias, const float* u, int ldu,
+                                         const int* qidx, float* preds, int B, int P, int Kq, int HW, void* stream) {
     CFD_REQUIRE(branch && trunk && bias && preds, CFD_ERR_INVALID_ARG, "cfd_deeponet_inner_fwd: NULL pointer");
     CFD_REQUIRE(B >= 0 && P >= 1 && Kq >= 0, CFD_ERR_INVALID_ARG, "cfd_deeponet_inner_fwd: bad sizes");
     CFD_REQUIRE(u || !qidx, CFD_ERR_INVALID_ARG, "cfd_deeponet_inner_fwd: query indices without a residual field");
     CFD_REQUIRE(!u || qidx || Kq <= HW, CFD_ERR_INVALID_ARG, "cfd_deeponet_inner_fwd: more queries than lattice points");
+    CFD_REQUIRE(!u || ldu >= HW, CFD_ERR_INVALID_ARG, "cfd_deeponet_inner_fwd: row stride of u smaller than a row");
     GemmEpi epi{};
-    epi.mode = 2; epi.bias = bias; epi.resid = u; epi.qidx = qidx; epi.ldr = HW;  // u == NULL: bias only (deeponet.py:205)
+    epi.mode = 2; epi.bias = bias; epi.resid = u; epi.qidx = qidx; epi.ldr = ldu;  // u == NULL: bias only (deeponet.py:205)
     return launch_gemm(branch, trunk, preds, B, Kq, P, P, P, Kq, 0, 1, epi, nullptr, (hipStream_t)stream, "cfd_deeponet_inner_fwd");
+}
+
+extern "C" int cfd_deeponet_inner_fwd(const float* branch, const float* trunk, const float* bias, const float* u,
+                                      const int* qidx, float* preds, int B, int P, int Kq, int HW, void* stream) {
+    return cfd_deeponet_inner_fwd_ex(branch, trunk, bias, u, HW, qidx, preds, B, P, Kq, HW, stream);
 }
 
 __global__ __launch_bounds__(256) void k_sum_all(const float* __restrict__ g, size_t n, float* __restrict__ part) {

@@ -459,12 +459,15 @@ class DeepONetInnerFn(torch.autograd.Function):
         branch, trunk, bias = _f32c(branch), _f32c(trunk), _f32c(bias.detach())
         B, P = branch.shape
         Kq = trunk.shape[0]
-        u2 = _f32c(u).reshape(B, -1) if u is not None else None
+        if u is not None and u.dim() == 2 and u.dtype == torch.float32 and u.stride(1) == 1 and u.stride(0) >= u.shape[1]:
+            u2 = u  # rows with a stride (the leading columns of the branch input matrix): read in place
+        else:
+            u2 = _f32c(u).reshape(B, -1) if u is not None else None
         HW = u2.shape[1] if u2 is not None else 0
         qi = qidx.to(torch.int32).contiguous() if qidx is not None else None
         preds = torch.empty((B, Kq), dtype=torch.float32, device=branch.device)
-        api.call("cfd_deeponet_inner_fwd", _ptr(branch), _ptr(trunk), _ptr(bias), _ptr(u2), _ptr(qi), _ptr(preds), B, P, Kq,
-                 HW, _stream())
+        api.call("cfd_deeponet_inner_fwd_ex", _ptr(branch), _ptr(trunk), _ptr(bias), _ptr(u2), u2.stride(0) if u2 is not None else 0,
+                 _ptr(qi), _ptr(preds), B, P, Kq, HW, _stream())
         ctx.save_for_backward(branch, trunk)
         ctx.has_u = u is not None
         ctx.u_shape = None if u is None else tuple(u.shape)

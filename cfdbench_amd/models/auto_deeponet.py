@@ -63,8 +63,13 @@ class AutoDeepONet(AutoCfdModel):
         """inputs (b,c,h,w), case_params (b,p), label (b,c,h,w), query_idxs (k,2) -> preds (b,k) + loss if label, else
         preds (b,1,h,w)   (auto_deeponet.py:76-147)."""
         batch_size, num_chan, height, width = inputs.shape
-        u = inputs[:, 0]                                        # only the u channel (:109)
-        flat_inputs = torch.cat([u.reshape(batch_size, -1), case_params], dim=1)  # (:111-116)
+        # branch input [u.flatten(), case_params] (:109-116) assembled by two copies straight into one matrix (the reshape of the
+        # strided channel view + torch.cat copied the field twice); its leading H*W columns double as the residual field below
+        hw, n_p = height * width, case_params.shape[1]
+        flat_inputs = torch.empty((batch_size, hw + n_p), dtype=inputs.dtype, device=inputs.device)
+        flat_inputs[:, :hw].view(batch_size, height, width).copy_(inputs[:, 0])
+        flat_inputs[:, hw:].copy_(case_params)
+        u = flat_inputs[:, :hw]
         x_branch = self.branch_net(flat_inputs)
         full = query_idxs is None
         if full:

@@ -232,6 +232,10 @@ int cfd_linear_bwd(const float* gy, const float* x, const float* w, const float*
  * lattice indices row*W+col of the query points, NULL = the full lattice in row-major order.                  */
 int cfd_deeponet_inner_fwd(const float* branch, const float* trunk, const float* bias, const float* u, const int* qidx,
                            float* preds, int B, int P, int Kq, int HW, void* stream);
+/* The same with a row stride for u (ldu >= HW floats): the residual field read in place from the leading columns of the branch
+ * net's input matrix [u.flatten(), case_params] (auto_deeponet.py:111-116).                                          */
+int cfd_deeponet_inner_fwd_ex(const float* branch, const float* trunk, const float* bias, const float* u, int ldu, const int* qidx,
+                              float* preds, int B, int P, int Kq, int HW, void* stream);
 /* gbranch (B,P) = g trunk; gtrunk (Kq,P) = g^T branch; gbias (1) = sum g.  Any output may be NULL.             */
 size_t cfd_deeponet_inner_bwd_workspace_bytes(int B, int P, int Kq);
 int cfd_deeponet_inner_bwd(const float* gpreds, const float* branch, const float* trunk, float* gbranch, float* gtrunk,
