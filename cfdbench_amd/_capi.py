@@ -117,6 +117,8 @@ _SIGS = {
     "cfd_convt2_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfd_convt2_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "cfd_convt2_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cfd_convt2_fwd_ex": (_I, [_P, _P, _P, _P, C.c_long, _I, _I, _I, _I, _I, _P]),
+    "cfd_convt2_bwd_ex": (_I, [_P, C.c_long, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfd_residual_mask": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfd_dropout": (_I, [_P, _P, _Z, _F, C.c_ulonglong, _P]),
     "cfd_dropout_gelu_fwd": (_I, [_P, _P, _Z, _F, C.c_ulonglong, _P]),

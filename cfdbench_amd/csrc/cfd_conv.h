@@ -60,14 +60,15 @@ int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, float* gb, vo
                     const char* what, CfdPartReduceJob* defer = nullptr);
 
 // ---- convt6.hip: ConvTranspose2d(2, stride 2) on three-piece split-bf16 operands (fp32-exact pieces, six bf16 MFMAs per product) ----
-bool cfd_convt6_covers(int B, int Ci, int Co, int H, int W);
+// *_bstride: elements between consecutive images of the 2H x 2W tensor (0 = dense): the tensor as a channel slice of a wider one
+bool cfd_convt6_covers(int B, int Ci, int Co, int H, int W, long fine_bstride = 0);
 int cfd_convt6_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int H, int W, hipStream_t st,
-                   const char* what);
+                   const char* what, long out_bstride = 0);
 int cfd_convt6_bwd_in(const float* gout, const float* w, float* gin, int B, int Ci, int Co, int H, int W, hipStream_t st,
-                      const char* what);
+                      const char* what, long gout_bstride = 0);
 // weight gradient gw (Ci,Co,2,2) and, when gb != NULL, the bias gradient gb (Co) in the same launches; needs W % 4 == 0, H W % 8 == 0 and 16-byte
 // aligned tensors (CFD_ERR_UNSUPPORTED otherwise: the caller keeps the fp32 kernel).  ws: cfd_convt6_wgrad_ws_bytes().
 bool cfd_convt6_wgrad_covers(int B, int Ci, int Co, int H, int W);
 size_t cfd_convt6_wgrad_ws_bytes(int B, int Ci, int Co, int H, int W);
 int cfd_convt6_wgrad(const float* gout, const float* in, float* gw, float* gb, void* ws, int B, int Ci, int Co, int H, int W,
-                     hipStream_t st, const char* what);
+                     hipStream_t st, const char* what, long gout_bstride = 0);

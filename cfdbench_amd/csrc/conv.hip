@@ -1260,6 +1260,44 @@ extern "C" int cfd_convt2_bwd(const float* gout, const float* in, const float* w
     return CFD_OK;
 }
 
+// The same two calls with the 2H x 2W tensor addressed as a channel slice of a wider one: `out` / `gout` point at the slice's first
+// channel of image 0, *_bstride is the number of elements between consecutive images (>= Co 4 H W).  The U-Net's up path writes the
+// transposed convolution straight into the second half of its skip concatenation and reads the gradient from there (unet.py:80-88:
+// torch.cat([x2, x1])), which saves a pass over x1 in each direction.  Matrix-pipe kernels only (convt6.hip): CFD_ERR_UNSUPPORTED
+// where they do not apply -- the caller then uses the dense calls and a concatenation of its own.
+extern "C" int cfd_convt2_fwd_ex(const float* in, const float* w, const float* bias, float* out, long out_bstride, int B, int Ci, int Co,
+                                 int H, int W, void* stream) {
+    if (out_bstride == 0 || out_bstride == (long)Co * 4 * H * W) return cfd_convt2_fwd(in, w, bias, out, B, Ci, Co, H, W, stream);
+    CFD_REQUIRE(in && w && out, CFD_ERR_INVALID_ARG, "cfd_convt2_fwd_ex: NULL pointer");
+    CFD_REQUIRE(B >= 1 && Ci >= 1 && Co >= 1 && H >= 1 && W >= 1, CFD_ERR_INVALID_ARG, "cfd_convt2_fwd_ex: bad sizes");
+    CFD_REQUIRE(((size_t)out & 7) == 0 && out_bstride % 2 == 0, CFD_ERR_INVALID_ARG, "cfd_convt2_fwd_ex: out must be 8-byte aligned");
+    CFD_REQUIRE(cfd_tune_get(CFD_TUNE_CONVT_MFMA) != 0 && cfd_convt6_covers(B, Ci, Co, H, W, out_bstride), CFD_ERR_UNSUPPORTED,
+                "cfd_convt2_fwd_ex: a strided output needs the matrix-pipe kernel, which does not take this shape");
+    CFD_PROF_W("k_convt2_fwd", (hipStream_t)stream, 4.0 * B * H * W * ((double)Ci + 4.0 * Co), 8.0 * B * H * W * (double)Ci * Co);
+    return cfd_convt6_fwd(in, w, bias, out, B, Ci, Co, H, W, (hipStream_t)stream, "cfd_convt2_fwd_ex", out_bstride);
+}
+
+extern "C" int cfd_convt2_bwd_ex(const float* gout, long gout_bstride, const float* in, const float* w, float* gin, float* gw, float* gb,
+                                 void* ws, int B, int Ci, int Co, int H, int W, void* stream) {
+    if (gout_bstride == 0 || gout_bstride == (long)Co * 4 * H * W) return cfd_convt2_bwd(gout, in, w, gin, gw, gb, ws, B, Ci, Co, H, W, stream);
+    CFD_REQUIRE(gout && in && w && ws, CFD_ERR_INVALID_ARG, "cfd_convt2_bwd_ex: NULL pointer");
+    CFD_REQUIRE(B >= 1 && Ci >= 1 && Co >= 1 && H >= 1 && W >= 1, CFD_ERR_INVALID_ARG, "cfd_convt2_bwd_ex: bad sizes");
+    CFD_REQUIRE(!gb || gw, CFD_ERR_UNSUPPORTED, "cfd_convt2_bwd_ex: the bias gradient rides in the weight-gradient launches (ask for both)");
+    const bool ok = cfd_tune_get(CFD_TUNE_CONVT_MFMA) != 0 && cfd_convt6_covers(B, Ci, Co, H, W, gout_bstride) && !((size_t)gout & 15) &&
+                    gout_bstride % 4 == 0 && (!gin || !((size_t)w & 15)) && (!gw || (cfd_convt6_wgrad_covers(B, Ci, Co, H, W) && !((size_t)in & 15)));
+    CFD_REQUIRE(ok, CFD_ERR_UNSUPPORTED, "cfd_convt2_bwd_ex: a strided gradient needs the matrix-pipe kernels, which do not take this shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (gin) {
+        CFD_PROF_W("k_convt2_bwd_in", st, 4.0 * B * H * W * ((double)Ci + 4.0 * Co), 8.0 * B * H * W * (double)Ci * Co);
+        CFD_TRY(cfd_convt6_bwd_in(gout, w, gin, B, Ci, Co, H, W, st, "cfd_convt2_bwd_ex(input)", gout_bstride));
+    }
+    if (gw) {
+        CFD_PROF_W("k_convt2_wgrad", st, 4.0 * B * H * W * ((double)Ci + 4.0 * Co), 8.0 * B * H * W * (double)Ci * Co);
+        CFD_TRY(cfd_convt6_wgrad(gout, in, gw, gb, ws, B, Ci, Co, H, W, st, "cfd_convt2_bwd_ex(wgrad)", gout_bstride));
+    }
+    return CFD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // output epilogue of the conv baselines: preds = (x + residual) * mask  (src/models/unet.py:206-208)
 // ------------------------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@ typedef cfd_u32x4 u4;
 template <bool BWD, int MT, int NT, bool KSPL>
 __global__ __launch_bounds__(256) void k_convt6(const float* __restrict__ src, const float* __restrict__ w,
                                                 const float* __restrict__ bias, float* __restrict__ dst, int Ci, int Co, int H, int W,
-                                                unsigned total, CfdDiv dHW, CfdDiv dW) {
+                                                unsigned total, CfdDiv dHW, CfdDiv dW, unsigned fbs) {
     const int lane = threadIdx.x & 63, wave = cfd_uniform(threadIdx.x >> 6);
     const int q = lane >> 4, n = lane & 15;
     const int HW = H * W, C4 = 4 * Co;
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void k_convt6(const float* __restrict__ src, c
         live[u] = p < total;
         const unsigned pc = live[u] ? p : total - 1;
         const unsigned b = cfd_div(pc, dHW), rem = pc - b * (unsigned)HW, y = cfd_div(rem, dW), x = rem - y * (unsigned)W;
-        const unsigned fine = b * (unsigned)(Co * 4 * HW) + (2 * y) * (unsigned)(2 * W) + 2 * x, coarse = b * (unsigned)(Ci * HW) + rem;
+        const unsigned fine = b * fbs + (2 * y) * (unsigned)(2 * W) + 2 * x,  // fbs: batch stride of the 2H x 2W tensor (>= Co 4 HW)
+                        coarse = b * (unsigned)(Ci * HW) + rem;
         sbase[u] = BWD ? fine : coarse;
         dbase[u] = BWD ? coarse : fine;
     }
@@ -184,15 +185,18 @@ __global__ __launch_bounds__(256) void k_convt6(const float* __restrict__ src, c
     }
 }
 
-static bool convt6_small(int B, int Ci, int Co, int H, int W) {  // 32-bit element offsets
-    return (long)B * Ci * H * W < (1L << 31) && (long)B * Co * 4 * H * W < (1L << 31);
+// fine_bstride: elements between consecutive images of the 2H x 2W tensor (0 = Co 4 H W: dense); a larger stride addresses the
+// tensor as a channel slice of a wider one (the U-Net's skip concatenation, unet.py:80-88)
+static bool convt6_small(int B, int Ci, int Co, int H, int W, long fine_bstride = 0) {  // 32-bit element offsets
+    const long fbs = fine_bstride > 0 ? fine_bstride : (long)Co * 4 * H * W;
+    return (long)B * Ci * H * W < (1L << 31) && (long)B * fbs < (1L << 31) && fbs >= (long)Co * 4 * H * W;
 }
 
-bool cfd_convt6_covers(int B, int Ci, int Co, int H, int W) { return B >= 1 && convt6_small(B, Ci, Co, H, W); }
+bool cfd_convt6_covers(int B, int Ci, int Co, int H, int W, long fine_bstride) { return B >= 1 && convt6_small(B, Ci, Co, H, W, fine_bstride); }
 
 template <bool BWD>
 static int convt6_launch(const float* src, const float* w, const float* bias, float* dst, int B, int Ci, int Co, int H, int W,
-                         hipStream_t st, const char* what) {
+                         long fine_bstride, hipStream_t st, const char* what) {
     constexpr int MT = 3;
     const unsigned total = (unsigned)((long)B * H * W);
     const int M = BWD ? Ci : 4 * Co, mgroups = ((M + 15) / 16 + MT - 1) / MT;
@@ -205,25 +209,27 @@ static int convt6_launch(const float* src, const float* w, const float* bias, fl
     const CfdDiv dHW = cfd_div_make((unsigned)(H * W)), dW = cfd_div_make((unsigned)W);
     if (wg4 >= CFD_CONVT6_NT4_MIN_WGS) {
         const dim3 grid((unsigned)(((long)total + 255) / 256), mgroups);
-        hipLaunchKernelGGL((k_convt6<BWD, MT, 4, false>), grid, dim3(256), 0, st, src, w, bias, dst, Ci, Co, H, W, total, dHW, dW);
+        hipLaunchKernelGGL((k_convt6<BWD, MT, 4, false>), grid, dim3(256), 0, st, src, w, bias, dst, Ci, Co, H, W, total, dHW, dW,
+                           (unsigned)fine_bstride);
     } else {  // one 16-pixel tile per workgroup, the K steps dealt to its four waves
         const dim3 grid((unsigned)(((long)total + 15) / 16), mgroups);
-        hipLaunchKernelGGL((k_convt6<BWD, MT, 1, true>), grid, dim3(256), 0, st, src, w, bias, dst, Ci, Co, H, W, total, dHW, dW);
+        hipLaunchKernelGGL((k_convt6<BWD, MT, 1, true>), grid, dim3(256), 0, st, src, w, bias, dst, Ci, Co, H, W, total, dHW, dW,
+                           (unsigned)fine_bstride);
     }
     CFD_LAUNCH_CHECK(what);
     return CFD_OK;
 }
 
 int cfd_convt6_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int H, int W, hipStream_t st,
-                   const char* what) {
-    if (!cfd_convt6_covers(B, Ci, Co, H, W)) return CFD_ERR_UNSUPPORTED;
-    return convt6_launch<false>(in, w, bias, out, B, Ci, Co, H, W, st, what);
+                   const char* what, long out_bstride) {
+    if (!cfd_convt6_covers(B, Ci, Co, H, W, out_bstride)) return CFD_ERR_UNSUPPORTED;
+    return convt6_launch<false>(in, w, bias, out, B, Ci, Co, H, W, out_bstride > 0 ? out_bstride : (long)Co * 4 * H * W, st, what);
 }
 
 int cfd_convt6_bwd_in(const float* gout, const float* w, float* gin, int B, int Ci, int Co, int H, int W, hipStream_t st,
-                      const char* what) {
-    if (!cfd_convt6_covers(B, Ci, Co, H, W)) return CFD_ERR_UNSUPPORTED;
-    return convt6_launch<true>(gout, w, nullptr, gin, B, Ci, Co, H, W, st, what);
+                      const char* what, long gout_bstride) {
+    if (!cfd_convt6_covers(B, Ci, Co, H, W, gout_bstride)) return CFD_ERR_UNSUPPORTED;
+    return convt6_launch<true>(gout, w, nullptr, gin, B, Ci, Co, H, W, gout_bstride > 0 ? gout_bstride : (long)Co * 4 * H * W, st, what);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -238,7 +244,7 @@ int cfd_convt6_bwd_in(const float* gout, const float* w, float* gin, int B, int 
 template <int MTG, int NTG>
 __global__ __launch_bounds__(256) void k_convt6_wgrad(const float* __restrict__ in, const float* __restrict__ gout,
                                                       float* __restrict__ part, int Ci, int Co, int H, int W, unsigned total,
-                                                      int ksteps, int per, int want_gb, CfdDiv dHW, CfdDiv dW) {
+                                                      int ksteps, int per, int want_gb, CfdDiv dHW, CfdDiv dW, unsigned gbs) {
     __shared__ float s_red[4 * (MTG * NTG * 256 + NTG * 16)];
     const int lane = threadIdx.x & 63, wave = cfd_uniform(threadIdx.x >> 6);
     const int q = lane >> 4, n = lane & 15;
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(256) void k_convt6_wgrad(const float* __restrict__ 
 #pragma unroll
         for (int nt = 0; nt < NTG; ++nt) {
             const int c = 16 * (nb + nt) + n, o = c >> 2, dy = (c >> 1) & 1;
-            const float* gplane = gout + (size_t)(b * (unsigned)Co + (o < Co ? o : Co - 1)) * (4 * HW);
+            const float* gplane = gout + (size_t)b * gbs + (size_t)(o < Co ? o : Co - 1) * (4 * HW);  // gbs: batch stride of gout
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f32x4* gp = reinterpret_cast<const f32x4*>(gplane + (size_t)(2 * yq[h] + dy) * (2 * W) + 2 * xq[h]);
@@ -361,9 +367,9 @@ struct Convt6WgPlan {
     bool ok;
 };
 
-static Convt6WgPlan convt6_wg_plan(int B, int Ci, int Co, int H, int W) {
+static Convt6WgPlan convt6_wg_plan(int B, int Ci, int Co, int H, int W, long gout_bstride = 0) {
     Convt6WgPlan P{};
-    if (B < 1 || W % 4 != 0 || (H * W) % 8 != 0 || !convt6_small(B, Ci, Co, H, W)) return P;
+    if (B < 1 || W % 4 != 0 || (H * W) % 8 != 0 || !convt6_small(B, Ci, Co, H, W, gout_bstride) || gout_bstride % 4 != 0) return P;
     const long px = (long)B * H * W;
     P.ksteps = (int)((px + 31) / 32);
     P.mgroups = ((Ci + 15) / 16 + 2) / 3;
@@ -388,12 +394,13 @@ bool cfd_convt6_wgrad_covers(int B, int Ci, int Co, int H, int W) { return convt
 size_t cfd_convt6_wgrad_ws_bytes(int B, int Ci, int Co, int H, int W) { return convt6_wg_plan(B, Ci, Co, H, W).bytes; }
 
 int cfd_convt6_wgrad(const float* gout, const float* in, float* gw, float* gb, void* ws, int B, int Ci, int Co, int H, int W,
-                     hipStream_t st, const char* what) {
-    const Convt6WgPlan P = convt6_wg_plan(B, Ci, Co, H, W);
+                     hipStream_t st, const char* what, long gout_bstride) {
+    const Convt6WgPlan P = convt6_wg_plan(B, Ci, Co, H, W, gout_bstride);
     if (!P.ok || ((size_t)in & 15) || ((size_t)gout & 15)) return CFD_ERR_UNSUPPORTED;
     const dim3 grid(P.groups, P.mgroups, P.ngroups);
     hipLaunchKernelGGL((k_convt6_wgrad<3, 3>), grid, dim3(256), 0, st, in, gout, (float*)ws, Ci, Co, H, W, (unsigned)((long)B * H * W),
-                       P.ksteps, P.per, gb ? 1 : 0, cfd_div_make((unsigned)(H * W)), cfd_div_make((unsigned)W));
+                       P.ksteps, P.per, gb ? 1 : 0, cfd_div_make((unsigned)(H * W)), cfd_div_make((unsigned)W),
+                       (unsigned)(gout_bstride > 0 ? gout_bstride : (long)Co * 4 * H * W));
     CFD_LAUNCH_CHECK(what);
     const long n1 = (long)Ci * 4 * Co;
     cfd_conv_part_reduce((const float*)ws, gw, n1 + (gb ? Co : 0), P.groups, st, gb, n1);

@@ -787,6 +787,55 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         return gin, gw, gb
 
 
+class ConvTransposeCatFn(torch.autograd.Function):
+    """torch.cat([skip, ConvTranspose2d(2, 2)(x)], dim=1) (unet.py:80-88) with the transposed convolution writing straight into the
+    second half of the concatenation and its gradient read from there (cfd_convt2_fwd_ex / cfd_convt2_bwd_ex): a pass over the
+    up-sampled tensor less in each direction.  ``supported`` tells whether the strided kernels take the shape; otherwise the caller
+    uses ConvTranspose2x2Fn + torch.cat."""
+
+    @staticmethod
+    def supported(x: Tensor, w: Tensor, skip: Tensor) -> bool:
+        import os
+        B, Ci, H, W = x.shape
+        return (x.is_cuda and skip.is_cuda and skip.dtype == torch.float32 and x.dtype == torch.float32 and w.dtype == torch.float32
+                and tuple(skip.shape[2:]) == (2 * H, 2 * W) and skip.shape[0] == B and W % 4 == 0 and (H * W) % 8 == 0
+                and w.data_ptr() % 16 == 0 and w.is_contiguous() and os.environ.get("CFD_CONVT_MFMA", "1") != "0")
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor], skip: Tensor):
+        _require_cuda(x, w, b, skip)
+        x, w = _f32c(x), _f32c(w.detach())
+        b = _f32c(b.detach()) if b is not None else None
+        B, Ci, H, W = x.shape
+        Co, C2 = w.shape[1], skip.shape[1]
+        out = torch.empty((B, C2 + Co, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        out[:, :C2].copy_(skip)
+        plane = 4 * H * W
+        _lib.api().call("cfd_convt2_fwd_ex", _ptr(x), _ptr(w), _ptr(b), out.data_ptr() + 4 * C2 * plane, (C2 + Co) * plane, B, Ci, Co, H, W,
+                        _stream())
+        ctx.save_for_backward(x, w)
+        ctx.meta = (b is not None, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        api = _lib.api()
+        x, w = ctx.saved_tensors
+        has_b, C2 = ctx.meta
+        B, Ci, H, W = x.shape
+        Co = w.shape[1]
+        g = _f32c(g)
+        plane = 4 * H * W
+        gin = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w)
+        gb = torch.empty(Co, dtype=torch.float32, device=g.device) if has_b else None
+        ws = _bytes(api.size("cfd_convt2_bwd_workspace_bytes", B, Ci, Co, H, W), g.device)
+        api.call("cfd_convt2_bwd_ex", g.data_ptr() + 4 * C2 * plane, (C2 + Co) * plane, _ptr(x), _ptr(w), _ptr(gin), _ptr(gw), _ptr(gb),
+                 _ptr(ws), B, Ci, Co, H, W, _stream())
+        gskip = g[:, :C2].contiguous() if ctx.needs_input_grad[3] else None
+        return gin, gw, gb, gskip
+
+
 class ResidualMaskFn(torch.autograd.Function):
     """(x + resid[:, :C]) * mask  (unet.py:206-208).  resid and mask are data (no gradient is taken for them)."""
 

@@ -73,6 +73,9 @@ class Up(nn.Module):
             self.conv = DoubleConv(in_channels, out_channels)
 
     def forward(self, x1, x2):
+        if not self.bilinear and F_.ConvTransposeCatFn.supported(x1, self.up.weight, x2):
+            # the transposed convolution writes behind the skip tensor inside the concatenation (no separate pass over its output)
+            return self.conv(F_.ConvTransposeCatFn.apply(x1, self.up.weight, self.up.bias, x2))
         if self.bilinear:
             x1 = F_.UpsampleBilinear2xFn.apply(x1)
         else:

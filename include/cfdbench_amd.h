@@ -344,6 +344,14 @@ int cfd_convt2_fwd(const float* in, const float* w, const float* bias, float* ou
 size_t cfd_convt2_bwd_workspace_bytes(int B, int Ci, int Co, int H, int W);
 int cfd_convt2_bwd(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws, int B,
                    int Ci, int Co, int H, int W, void* stream);
+/* The same with the 2H x 2W tensor addressed as a channel slice of a wider one (out / gout = the slice's first channel of image 0,
+ * *_bstride = elements between consecutive images, 0 = dense): unet.py:80-88 concatenates the transposed convolution's output behind
+ * the skip tensor -- written there directly and its gradient read from there, a pass over it is saved in each direction.  Strided
+ * tensors run on the matrix-pipe kernels only: CFD_ERR_UNSUPPORTED where those do not apply (W % 4, H W % 8, alignment).        */
+int cfd_convt2_fwd_ex(const float* in, const float* w, const float* bias, float* out, long out_bstride, int B, int Ci, int Co, int H,
+                      int W, void* stream);
+int cfd_convt2_bwd_ex(const float* gout, long gout_bstride, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws,
+                      int B, int Ci, int Co, int H, int W, void* stream);
 
 /* out = (x + resid[:, :C]) * mask (unet.py:206-208): x, out (B,C,HW); resid (B,Cr,HW) or NULL; mask (B,HW) or NULL. */
 int cfd_residual_mask(const float* x, const float* resid, const float* mask, float* out, int B, int C, int Cr, int HW,

@@ -988,3 +988,34 @@ def check_adam_multi(be, sizes=(7, 1025, 300, 1), steps=3, seed=8):
             api.call("cfd_adam_flat", P(pb[t]), P(g[t]), P(mb[t]), P(vb[t]), sizes[t], 2e-3, 0.9, 0.999, 1e-8, 0.01, k, 1.0, be.stream)
         be.sync()
     return max(float(np.abs(be.host(a) - be.host(b)).max() / np.abs(be.host(b)).max()) for a, b in zip(pa, pb))
+
+
+def check_convt_strided(be, B, Ci, Co, H, W, C2=3, seed=40):
+    """cfd_convt2_fwd_ex / cfd_convt2_bwd_ex with the 2H x 2W tensor as the trailing Co channels of a (C2 + Co)-channel one: the same
+    values as the dense calls, bit for bit, and the leading C2 channels untouched.  Returns the number of values that differ."""
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, Ci, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Ci, Co, 2, 2)) / np.sqrt(Ci)).astype(np.float32)
+    b = rng.standard_normal((Co,)).astype(np.float32) * 0.1
+    gwide = rng.standard_normal((B, C2 + Co, 2 * H, 2 * W)).astype(np.float32)
+    dx, dw, db = be.dev(x), be.dev(w), be.dev(b)
+    plane = 4 * H * W
+    out = be.zeros((B, Co, 2 * H, 2 * W))
+    api.call("cfd_convt2_fwd", P(dx), P(dw), P(db), P(out), B, Ci, Co, H, W, be.stream)
+    wide = be.dev(np.full((B, C2 + Co, 2 * H, 2 * W), 7.0, np.float32))
+    api.call("cfd_convt2_fwd_ex", P(dx), P(dw), P(db), P(wide) + 4 * C2 * plane, (C2 + Co) * plane, B, Ci, Co, H, W, be.stream)
+    ws = be.bytes(api.size("cfd_convt2_bwd_workspace_bytes", B, Ci, Co, H, W))
+    dg = be.dev(np.ascontiguousarray(gwide[:, C2:]))
+    gin, gw, gb = be.zeros((B, Ci, H, W)), be.zeros((Ci, Co, 2, 2)), be.zeros((Co,))
+    api.call("cfd_convt2_bwd", P(dg), P(dx), P(dw), P(gin), P(gw), P(gb), P(ws), B, Ci, Co, H, W, be.stream)
+    dgw = be.dev(gwide)
+    gin2, gw2, gb2 = be.zeros((B, Ci, H, W)), be.zeros((Ci, Co, 2, 2)), be.zeros((Co,))
+    api.call("cfd_convt2_bwd_ex", P(dgw) + 4 * C2 * plane, (C2 + Co) * plane, P(dx), P(dw), P(gin2), P(gw2), P(gb2), P(ws), B, Ci, Co, H, W,
+             be.stream)
+    be.sync()
+    hw = be.host(wide)
+    bad = int(np.count_nonzero(hw[:, C2:] != be.host(out))) + int(np.count_nonzero(hw[:, :C2] != 7.0))
+    for a, c in ((gin, gin2), (gw, gw2), (gb, gb2)):
+        bad += int(np.count_nonzero(be.host(a) != be.host(c)))
+    return bad

@@ -252,6 +252,12 @@ def test_convtranspose_random_shapes(be):
             assert not bad, ((B, Ci, Co, H, W, mfma), bad)
 
 
+def test_convtranspose_into_a_channel_slice(be):
+    """the transposed convolution written into / its gradient read from the trailing channels of a wider tensor == the dense calls"""
+    for B, Ci, Co, H, W in [(2, 20, 9, 4, 8), (3, 50, 26, 8, 8), (1, 7, 3, 2, 4)]:
+        assert K.check_convt_strided(be, B, Ci, Co, H, W) == 0, (B, Ci, Co, H, W)
+
+
 def test_adam_for_many_tensors_in_one_launch(be):
     assert K.check_adam_multi(be, sizes=(7, 1025, 300, 1)) < 2e-6
 

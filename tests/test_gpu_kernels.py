@@ -266,6 +266,12 @@ def test_convtranspose_full_size(be, B, Ci, Co, H, W, mfma):
         _assert_all(K.check_convt(be, B, Ci, Co, H, W))
 
 
+def test_convtranspose_into_a_channel_slice(be):
+    """the transposed convolution written into / its gradient read from the trailing channels of a wider tensor == the dense calls"""
+    for B, Ci, Co, H, W in [(128, 24, 12, 32, 32), (128, 192, 96, 4, 4), (16, 48, 24, 16, 16), (3, 7, 5, 6, 12)]:
+        assert K.check_convt_strided(be, B, Ci, Co, H, W) == 0, (B, Ci, Co, H, W)
+
+
 def test_adam_for_many_tensors_in_one_launch(be):
     assert K.check_adam_multi(be, sizes=tuple([3, 700, 100000, 12] * 25)) < 2e-6
 
