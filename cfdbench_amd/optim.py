@@ -5,7 +5,9 @@ where the data would need ~3 us.  Same update rule, same state layout (``step`` 
 ``exp_avg_sq``), so ``state_dict`` / ``load_state_dict``, LR schedulers and ``graph.GraphedTrainStep`` work unchanged; bias
 corrections are formed in fp32 on the device like torch's capturable path.  One difference: the parameters of a group that receive
 a gradient share ONE step count (the first one's) -- they do in every model here, where a parameter either always or never has one.  Real fp32 CUDA parameters only (the FNO's complex
-weights stay with torch's Adam or the fused engine's flat one)."""
+weights stay with torch's Adam or the fused engine's flat one).  Meant for captured steps (`--graph 1`, bench legs): in an eager
+loop its per-step Python (136 parameters: checks, pointer-table lookup) costs more host time than torch's C++ fused path saves on
+the GPU -- measured 6.50 vs 6.15 ms per eager U-Net step on a slow-host box -- so the eager default keeps the stock optimizer."""
 from __future__ import annotations
 
 import ctypes
