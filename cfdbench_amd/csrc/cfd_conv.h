@@ -72,3 +72,14 @@ bool cfd_convt6_wgrad_covers(int B, int Ci, int Co, int H, int W);
 size_t cfd_convt6_wgrad_ws_bytes(int B, int Ci, int Co, int H, int W);
 int cfd_convt6_wgrad(const float* gout, const float* in, float* gw, float* gb, void* ws, int B, int Ci, int Co, int H, int W,
                      hipStream_t st, const char* what, long gout_bstride = 0);
+
+// ---- conv1.hip: 1x1 convolutions as streamed three-piece bf16 GEMMs over the pixels (off unless the conv1_mfma knob is 1) ----
+bool cfd_conv1_covers(int B, int Ci, int Co, int HW);
+int cfd_conv1_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Ci, int Co, int HW, hipStream_t st,
+                  const char* what);
+int cfd_conv1_dgrad(const float* gout, const float* w, float* gin, int B, int Ci, int Co, int HW, hipStream_t st, const char* what);
+// needs H W % 8 == 0 and 16-byte aligned tensors (CFD_ERR_UNSUPPORTED otherwise); gb rides in the same launches
+bool cfd_conv1_wgrad_covers(int B, int Ci, int Co, int HW);
+size_t cfd_conv1_wgrad_ws_bytes(int B, int Ci, int Co, int HW);
+int cfd_conv1_wgrad(const float* gout, const float* in, float* gw, float* gb, void* ws, int B, int Ci, int Co, int HW, hipStream_t st,
+                    const char* what);

@@ -245,6 +245,8 @@ extern "C" int cfd_conv2d_fwd_ex(const float* in, const float* w, const float* b
                2.0 * B * H * W * (double)Co * Ci * ks * ks);
     if (ws && cfd_conv6_covers(g, false))
         return cfd_conv6_run(in, w, bias, out, ws, g, false, nullptr, nullptr, (hipStream_t)stream, "cfd_conv2d_fwd", stats, wfrag);
+    if (ks == 1 && cfd_tune_get(CFD_TUNE_CONV1_MFMA) == 1 && cfd_conv1_covers(B, Ci, Co, H * W))
+        return cfd_conv1_fwd(in, w, bias, out, B, Ci, Co, H * W, (hipStream_t)stream, "cfd_conv2d_fwd");
     return launch_conv_gather<false>(in, w, bias, out, g, (hipStream_t)stream, "cfd_conv2d_fwd");
 }
 
@@ -508,6 +510,10 @@ extern "C" size_t cfd_conv2d_bwd_workspace_bytes(int B, int Ci, int Co, int H, i
         const ConvGeom g{B, Ci, Co, H, W, ks};
         if (cfd_conv6_wgrad_covers(g)) part = cfd_conv6_wgrad_ws_bytes(g);
     }
+    if (ks == 1) {
+        const size_t c1 = cfd_conv1_wgrad_ws_bytes(B, Ci, Co, H * W);
+        if (c1 > part) part = c1;
+    }
     const size_t cs = chan_sum_ws_bytes(Co);
     // [extended input gradient | weight fragments and split-K partials of the input-gradient pass (conv6.hip)]; the
     // weight-gradient partials and the bias sums reuse the front of the buffer afterwards
@@ -537,6 +543,18 @@ extern "C" int cfd_conv2d_bwd_ex(const float* gout, const float* in, const float
     hipStream_t st = (hipStream_t)stream;
     const ConvGeom g{B, Ci, Co, H, W, ks};
     const int HW = H * W, pad = ks / 2;
+    if (ks == 1 && cfd_tune_get(CFD_TUNE_CONV1_MFMA) == 1 && cfd_conv1_covers(B, Ci, Co, HW)) {  // conv1.hip: no extended grid, no fold
+        if (gin) {
+            CFD_PROF_W("k_conv_dgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci), 2.0 * B * HW * (double)Co * Ci);
+            CFD_TRY(cfd_conv1_dgrad(gout, w, gin, B, Ci, Co, HW, st, "cfd_conv2d_bwd(dgrad)"));
+            gin = nullptr;
+        }
+        if (gw && cfd_conv1_wgrad_covers(B, Ci, Co, HW) && !((size_t)in & 15) && !((size_t)gout & 15)) {
+            CFD_PROF_W("k_conv_wgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci), 2.0 * B * HW * (double)Co * Ci);
+            CFD_TRY(cfd_conv1_wgrad(gout, in, gw, gb, ws, B, Ci, Co, HW, st, "cfd_conv2d_bwd(wgrad)"));
+            gw = nullptr, gb = nullptr;
+        }
+    }
     if (gin) {
         float* ext = (float*)ws;
         bool direct = false;

@@ -28,6 +28,8 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
                                                  // tests: 2, so that small shapes walk several tiles per workgroup)
     {"conv6_wgrad_mul", "CFD_CONV6_WGRAD_MUL", {-1}},  // workgroups of a conv6 weight-gradient launch in units of conv6_grid (default 1)
     {"convt_mfma", "CFD_CONVT_MFMA", {-1}},      // 0 = ConvTranspose2d(2, 2) on the fp32 VALU kernels of conv.hip instead of convt6.hip
+    {"conv1_mfma", "CFD_CONV1_MFMA", {-1}},      // 1 = 1x1 convolutions on the streamed matrix-pipe kernels of conv1.hip (end of round 3: parity
+                                                 // green, one timing -0.8 % on the U-Net step; off by default until the full suite ran with it)
 };
 std::once_flag g_once;
 void read_env() {

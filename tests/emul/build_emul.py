@@ -30,7 +30,7 @@ def build(force: bool = False) -> Path:
     def compile_one(src: Path) -> str:
         obj = OUT / (src.name + ".o")
         cmd = [CLANG, "-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-Wno-unused-value",
-               f"-I{HERE / 'include'}", f"-I{CSRC}", f"-I{REPO / 'include'}", "-DCFD_CONV6_GRID=2", "-DCFD_CONVT6_NT4_MIN_WGS=2", "-c", str(src), "-o",
+               f"-I{HERE / 'include'}", f"-I{CSRC}", f"-I{REPO / 'include'}", "-DCFD_CONV6_GRID=2", "-DCFD_CONVT6_NT4_MIN_WGS=2", "-DCFD_CONV1_NT4_MIN_WGS=2", "-c", str(src), "-o",
                str(obj)]
         subprocess.run(cmd, check=True)
         return str(obj)

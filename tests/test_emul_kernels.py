@@ -233,6 +233,24 @@ def test_conv2d_random_shapes(be):
         assert not bad, ((B, Ci, Co, H, W, ks, grid), bad)
 
 
+def test_conv1x1_on_the_matrix_pipe(be):
+    """1x1 convolutions (U-Net OutConv, ResNet res_conv) on the streamed kernels of conv1.hip (conv1_mfma = 1; off by default until
+    measured) and on the general kernels: forward, input gradient, weight + bias gradient against the oracle -- pixel counts that are no
+    multiple of a tile or a k-step, several row / column groups, several k-step ranges, H W % 8 != 0 (weight gradient falls back)."""
+    import random
+    rnd = random.Random(41)
+    R = rnd.choice
+    shapes = [(3, 12, 2, 8, 8), (2, 11, 64, 4, 8), (1, 64, 2, 16, 16), (2, 50, 50, 2, 8), (5, 3, 7, 3, 5), (4, 16, 100, 4, 4), (8, 12, 2, 16, 32)]
+    while len(shapes) < 16:
+        shapes.append((R([1, 2, 3, 5]), R([1, 2, 7, 16, 17, 33, 64, 100]), R([1, 2, 3, 16, 17, 49, 64]), R([1, 2, 3, 4, 8]), R([1, 3, 4, 8, 16])))
+    for i, (B, Ci, Co, H, W) in enumerate(shapes):
+        for knob in (1, -1) if i < 7 else (1,):
+            with K.tuned(be, conv1_mfma=knob):
+                res = K.check_conv2d(be, B, Ci, Co, H, W, 1, seed=300 + i)
+            bad = {k: v for k, v in res.items() if not (v < 1e-10)}
+            assert not bad, ((B, Ci, Co, H, W, knob), bad)
+
+
 def test_convtranspose_random_shapes(be):
     """Seeded sweep over the ConvTranspose2d(2, 2) kernels of convt6.hip: pixel counts that are no multiple of a 16-pixel tile or a
     32-pixel k-step, several row / column groups, several k-step ranges per launch, widths the MFMA weight gradient does not take

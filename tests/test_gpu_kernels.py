@@ -266,6 +266,15 @@ def test_convtranspose_full_size(be, B, Ci, Co, H, W, mfma):
         _assert_all(K.check_convt(be, B, Ci, Co, H, W))
 
 
+@pytest.mark.parametrize("knob", [1, -1])
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(128, 12, 2, 64, 64), (32, 11, 64, 64, 64), (32, 64, 2, 64, 64), (3, 50, 26, 9, 24), (5, 7, 3, 6, 5)])
+def test_conv1x1_both_routes(be, B, Ci, Co, H, W, knob):
+    """1x1 convolutions (U-Net OutConv, ResNet res_conv shapes + two odd ones): the streamed matrix-pipe kernels of conv1.hip
+    (conv1_mfma = 1) and the general kernels (default) against the oracle."""
+    with K.tuned(be, conv1_mfma=knob):
+        _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, 1))
+
+
 def test_convtranspose_into_a_channel_slice(be):
     """the transposed convolution written into / its gradient read from the trailing channels of a wider tensor == the dense calls"""
     for B, Ci, Co, H, W in [(128, 24, 12, 32, 32), (128, 192, 96, 4, 4), (16, 48, 24, 16, 16), (3, 7, 5, 6, 12)]:
