@@ -2,8 +2,9 @@
 """Headline benchmark: Auto-FNO training frames/s on synthetic (B,2,64,64) batches (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # starts its own N ranks (one process per GPU, RCCL over xGMI)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # or under an external launcher: WORLD_SIZE set => this process is a rank
 
 A step = forward + nMSE loss + backward + (N>1: RCCL all-reduce of the flat gradient) + Adam on one batch that is
 already resident in HBM.  Workload = BASELINE.json configs[1]: Fno2d(in=2,out=2,p=5,L=4,hidden=20,modes=12), B=256 per
@@ -66,7 +67,52 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the U-Net / Auto-DeepONet / exact-fp32 legs")
     ap.add_argument("--rollout-batch", type=int, default=64)
     ap.add_argument("--rollout-steps", type=int, default=200)
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend of the N > 1 job: nccl = RCCL over xGMI (the product); gloo only with --dry-dp")
+    ap.add_argument("--dry-dp", action="store_true",
+                    help="no GPU: run ONLY the data-parallel skeleton of the step (rank launch, rendezvous, GradSync's per-phase "
+                         "exchange of the model's flat gradient buffer, barrier / max-over-ranks timing, the JSON line) on host "
+                         "tensors -- what tests/test_cpu_host.py drives; the line is marked dry_dp and is not a measurement")
     return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts its own N ranks (one process per GPU)
+# ----------------------------------------------------------------------------------------------------------------------
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """Called when --gpus N > 1 and no rendezvous environment is set (i.e. not under torch.distributed.run): start the N ranks
+    of this same command line ourselves -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT, exactly
+    what torchrun would export -- inherit stdout (rank 0 prints the one JSON line), and return the worst exit code.  If a rank
+    dies the others are terminated by PID (they would otherwise sit in the rendezvous or a collective until its timeout)."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CFDBENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on these hosts
+        env.setdefault("OMP_NUM_THREADS", "8")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env))
+    rc, live = 0, list(procs)
+    while live:
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in live:  # exact PIDs of our own children
+                    other.terminate()
+        time.sleep(0.05)
+    return rc
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -327,16 +373,83 @@ def model_train_leg(api, name, model, batch, steps, warmup, frames, bytes_per_fr
     return res
 
 
+def dry_dp(args, rank, world):
+    """--dry-dp: the step's data-parallel skeleton on host tensors (module docstring of parse()).  The flat gradient buffer has
+    the layout of the benchmark's Fno2d (engine.flatten_layout / backward_phase_slices), every rank fills it with its own
+    values, and each 'step' runs GradSync's per-phase asynchronous exchange in backward-phase order followed by the 1/world
+    scale -- the same calls FnoTrainEngine.forward_backward_overlapped makes between its kernels."""
+    from cfdbench_amd.engine import GradSync, backward_phase_slices, flatten_layout
+    from cfdbench_amd.models.fno.fno2d import Fno2d
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend if args.backend == "gloo" or torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+    B, C, L, p = args.batch, args.hidden, args.layers, args.n_case_params
+    torch.manual_seed(0)
+    model = Fno2d(2, 2, p, loss_name_to_fn("nmse"), L, 12, 12, C)
+    offs, numel = flatten_layout(model.abi_parameters())
+    slices = backward_phase_slices(offs, numel, L)
+    sync = GradSync(None)
+    g = torch.Generator().manual_seed(1234 + rank)
+    mine = torch.randn(numel, generator=g)
+    flat = torch.empty_like(mine)
+
+    def step():
+        flat.copy_(mine)
+        scale = sync.wait_all([sync.reduce_slice_async(flat, a, b) for a, b in slices])
+        flat.mul_(scale)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    # every rank must now hold the mean of all ranks' buffers: checked against an all-gather of the originals
+    ok = True
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        ok = bool(torch.allclose(flat, torch.stack(parts).sum(0) / world, rtol=1e-6, atol=1e-7))
+    elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "train frames/sec (64x64x2), Auto-FNO cavity", "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_dp": True,
+            "config": {"workload": "DRY RUN of the data-parallel skeleton (no kernels, no GPU): launcher + rendezvous + per-phase gradient "
+                                   "exchange of the Fno2d flat gradient buffer on host tensors; not a measurement",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "backend": dist.get_backend() if world > 1 else None,
+                       "flat_gradient_floats": numel, "exchange_slices": len(slices), "self_launched": os.environ.get("CFDBENCH_SELF_LAUNCHED") == "1"},
+            "gradient_mean_ok": ok}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(4)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))  # plain `python bench.py --gpus N`: one process per GPU, started here
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running the {world} ranks the launcher started", file=sys.stderr)
+    if args.dry_dp:
+        return dry_dp(args, rank, world)
+    if args.backend != "nccl":
+        print("bench.py: --backend gloo is for --dry-dp only; the measured job exchanges gradients over RCCL", file=sys.stderr)
+        sys.exit(1)
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback", file=sys.stderr)
         sys.exit(1)

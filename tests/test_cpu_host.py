@@ -465,3 +465,50 @@ def test_committed_bench_line_keeps_the_driver_contract():
     cb = line["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
     assert line["value"] > 1000 * cb["value"]  # a sanity bound, not a target: the GPU path is the product
+
+
+def _run_bench(*flags, env=None, timeout=600):
+    import json
+    import subprocess
+    import sys
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "bench.py"), *flags], env=e, capture_output=True,
+                       text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO torchrun and no rendezvous environment: bench.py spawns its two ranks, they meet over
+    gloo, exchange the model's flat gradient buffer the way the engine does, and rank 0 alone prints the one JSON line."""
+    r, lines = _run_bench("--gpus", "2", "--backend", "gloo", "--dry-dp", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["dry_dp"] is True
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 512
+    assert d["config"]["backend"] == "gloo" and d["config"]["self_launched"] is True
+    assert d["gradient_mean_ok"] is True and d["config"]["exchange_slices"] == 6
+
+
+def test_bench_under_an_external_launcher_does_not_spawn():
+    """With WORLD_SIZE in the environment (torch.distributed.run's contract) the process IS a rank: a one-rank dry run prints its
+    line with dp1 and never re-launches itself."""
+    r, lines = _run_bench("--gpus", "1", "--dry-dp", "--steps", "2", "--warmup", "0",
+                          env=dict(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1 and lines[0]["config"]["parallelism"] == "dp1"
+    assert lines[0]["config"]["self_launched"] is False
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """A rank that dies takes the job down with a non-zero exit code instead of leaving its peers in the rendezvous: without a GPU
+    the measured (non --dry-dp) path exits 1 in every rank, and the launcher hands that code back."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without GPUs")
+    r, lines = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", timeout=300)
+    assert r.returncode == 1 and not lines
+    assert "no CPU fallback" in r.stderr
