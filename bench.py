@@ -348,12 +348,14 @@ def model_train_leg(api, name, model, batch, steps, warmup, frames, bytes_per_fr
         out = model(**batch)
         out["loss"]["nmse"].backward()
         opt.step()
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=False)  # keep the gradient tensors: the multi-tensor Adam's pointer table stays valid
 
     dt_eager = time_steps(eager, steps, warmup)
     rows = profiled(api, eager, steps)
     res = dict(what=what, frames_per_s=round(frames / dt_eager, 1), ms_per_step=round(dt_eager * 1e3, 3), mode="eager")
     try:
+        if getattr(model, "graph_unsafe", False):  # per-step HOST state (the ResNet's dropout seed / step counter): a replayed graph
+            raise RuntimeError("model is graph_unsafe: eager launches only")  # would reuse one frozen dropout mask -- not a training step
         gs = GraphedTrainStep(model, opt, batch)
         dt_graph = time_steps(lambda: gs(**batch), steps, warmup)
         if dt_graph < dt_eager:

@@ -94,6 +94,11 @@ class DeviceBatchLoader:
         keys = [k for k in data.case_params[0].keys() if k not in ("rotated", "dx", "dy")]
         table = torch.tensor([[float(cp[k]) for k in keys] for cp in data.case_params], dtype=torch.float32)
         self.case_params = table[torch.as_tensor(data.case_ids, dtype=torch.long)].to(device)
+        self.set_indices(indices)
+
+    def set_indices(self, indices=None) -> None:
+        """Restrict the loader to ``indices`` (None = every frame) WITHOUT touching the resident tensors: a data-parallel run
+        re-partitions the frames every epoch, and only this index list changes -- the corpus is uploaded once."""
         n = len(self.inputs)
         self.indices = torch.arange(n) if indices is None else torch.as_tensor(indices, dtype=torch.long)
 

@@ -102,13 +102,17 @@ def evaluate(model: AutoCfdModel, data, output_dir: Path, batch_size: int = 2, p
                 scores[key].append(loss[key].detach().reshape(()))
             all_preds.append(preds.detach())
             gstep = mine[step] if world > 1 else step  # position in the evaluation order
-            if plot_interval > 0 and gstep % plot_interval == 0 and not measure_time and rank == 0:
+            # every rank plots the batches it owns (the file names carry the GLOBAL step, all ranks write into the same images/
+            # directory): the output tree of an N-rank run is the single-process one
+            if plot_interval > 0 and gstep % plot_interval == 0 and not measure_time:
                 plot_predictions(inp=inputs[0][0], label=labels[0][0], pred=preds[0][0], out_dir=Path(output_dir) / "images",
                                  step=gstep)
     for table in (scores, input_scores):
         for key in table:
             table[key] = torch.stack(table[key]).cpu().tolist() if table[key] else []
-    pred_blocks = [p_.cpu() for p_ in all_preds]
+    # ONE device-to-host copy for all predictions of this rank, split back into its batches on the host
+    sizes = [int(p_.shape[0]) for p_ in all_preds]
+    pred_blocks = list(torch.cat(all_preds, dim=0).cpu().split(sizes)) if all_preds else []
     if world > 1:
         gathered = [None] * world if rank == 0 else None
         dist.gather_object((mine, scores, input_scores, pred_blocks), gathered, dst=0)
@@ -178,14 +182,18 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
         """The epoch's loader.  With several ranks the frames are re-partitioned EVERY epoch (``DistributedSampler.set_epoch``
         semantics: shard_indices(..., epoch=ep) -- an equal part of that epoch's permutation per rank), so a
         rank does not see the same 1/world of the data for the whole run."""
-        data = Subset(train_data, shard_indices(len(train_data), rank, world, batch_size, epoch=ep)) if world > 1 else train_data
+        shard = shard_indices(len(train_data), rank, world, batch_size, epoch=ep) if world > 1 else None
         if device_loader:  # SURVEY.md 8f-1: frames resident in HBM, batches gathered on the device (harness/data.py)
             from .data import DeviceBatchLoader
-            base = data.dataset if isinstance(data, Subset) else data
-            return DeviceBatchLoader(base, batch_size, shuffle=True, drop_last=world > 1,
-                                     indices=data.indices if isinstance(data, Subset) else None)
+            if resident:  # the split is uploaded ONCE; an epoch's re-partition only swaps the index list
+                resident[0].set_indices(shard)
+            else:
+                resident.append(DeviceBatchLoader(train_data, batch_size, shuffle=True, drop_last=world > 1, indices=shard))
+            return resident[0]
+        data = Subset(train_data, shard) if world > 1 else train_data
         return DataLoader(data, batch_size=batch_size, shuffle=True, collate_fn=collate_fn, drop_last=world > 1)
 
+    resident: List = []
     train_loader = make_loader(0)
     if rank == 0:
         output_dir.mkdir(exist_ok=True, parents=True)
