@@ -154,8 +154,10 @@ extern "C" int cfd_fno_forward_train_ex(const cfd_plan* p, const cfd_fno_shape* 
     float* z = (float*)(base + L.off_z);
     float* gA = (float*)(base + L.off_gA);
     void* scratch = base + L.off_scratch;
-    // the label's energy and the gradient coefficients first: independent of the network (scratch is free until the head)
-    CFD_TRY(cfd_label_energy_coef(label, mask, sums, coef, scratch, B, s->out_chan, HW, which, upstream, stream));
+    // the label's energy and the gradient coefficients: independent of the network (scratch is free until the head), so they
+    // run beside the lifting layer on the side stream and join in front of the head
+    hipStream_t side = cfd_side_fork((hipStream_t)stream);
+    CFD_TRY(cfd_label_energy_coef(label, mask, sums, coef, scratch, B, s->out_chan, HW, which, upstream, side));
     CFD_TRY(cfd_int_fno_stem_fwd(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, act_buf(0), B, s->in_chan, s->n_case_params, C,
                                  dt, stream));
     for (int l = 0; l < NL; ++l) {  // FnoBlock.forward, fno2d.py:106-112
@@ -170,6 +172,7 @@ extern "C" int cfd_fno_forward_train_ex(const cfd_plan* p, const cfd_fno_shape* 
             CFD_TRY(cfd_int_spectral_idft(p, z, tmp, nullptr, act_buf(l + 1), B * C, 1, dt, stream));
         }
     }
+    CFD_TRY(cfd_side_join((hipStream_t)stream, side));
     return cfd_int_fno_head_train(act_buf(NL), mask, label, coef, prm->fc1_w, prm->fc1_b, prm->fc2_w, prm->fc2_b, preds, sums, gA,
                                   g->fc1_w, g->fc1_b, g->fc2_w, g->fc2_b, scratch, B, C, s->head, s->out_chan, HW, NL > 0, dt, stream);
 }
@@ -222,7 +225,6 @@ extern "C" int cfd_fno_backward_phase_ex(const cfd_plan* p, const cfd_fno_shape*
     const int l = NL - phase;
     const int act = l > 0;
     // gcur = d loss / d a_{l+1}
-    CFD_TRY(cfd_spectral_dft(p, gcur, gh, B * C, 0, stream));
     char* scratch2 = (char*)scratch + cfd_align_up(cfd_spectral_wgrad_workspace_bytes(p, B, C, C), 256);
     if (dt == CFD_DT_BF16) {
         // two passes for the input gradient (1x1 conv transposed into the fp32 scratch tensor, inverse transform + addend
@@ -235,11 +237,15 @@ extern "C" int cfd_fno_backward_phase_ex(const cfd_plan* p, const cfd_fno_shape*
         return cfd_int_spectral_idft_grad(p, z, tmp, act ? act_buf(l) : nullptr, gnext, B * C, dt, stream);
     }
     // the reductions of both weight gradients ride in front of the input-gradient kernel's launch (cfd_tail.h); whatever
-    // a producer could not defer it has already reduced itself
+    // a producer could not defer it has already reduced itself.  The 1x1 weight gradient needs only gcur and a_l: it streams
+    // them on the side stream (side.cpp) beside the transform and the latency-bound mode-domain kernel.
+    hipStream_t side = cfd_side_fork((hipStream_t)stream);
     CfdReduceTail tail{};
+    CFD_TRY(cfd_int_chan_wgrad(gcur, (const float*)act_buf(l), g->w0_w[l], g->w0_b[l], scratch2, B, C, C, HW, act, side, &tail.chan));
+    CFD_TRY(cfd_spectral_dft(p, gcur, gh, B * C, 0, stream));
     CFD_TRY(cfd_int_spectral_mix_adj_wgrad(p, xh_buf(l), gh, prm->spec_w1[l], prm->spec_w2[l], z, g->spec_w1[l],
                                            g->spec_w2[l], scratch, B, C, C, stream, &tail.spec));
-    CFD_TRY(cfd_int_chan_wgrad(gcur, (const float*)act_buf(l), g->w0_w[l], g->w0_b[l], scratch2, B, C, C, HW, act, stream, &tail.chan));
+    CFD_TRY(cfd_side_join((hipStream_t)stream, side));  // the block kernel reduces the 1x1 partial sums
     tail.nblk = (tail.spec.part || tail.chan.part) ? 128 : 0;
     return cfd_int_fno_block_bwd_input(p, gcur, z, prm->w0_w[l], act ? (const float*)act_buf(l) : nullptr, gnext, B, C, C, stream, &tail);
 }

@@ -36,6 +36,8 @@ CfdProfScope::~CfdProfScope() {
     (void)hipEventRecord(g_recs[idx].b, st);
 }
 
+bool cfd_prof_active() { return g_on; }
+
 extern "C" int cfd_prof_begin(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
