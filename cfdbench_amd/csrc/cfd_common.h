@@ -35,7 +35,7 @@ int cfd_tune_get(int which);
     } while (0)
 
 // side.cpp: fork / join onto the library's per-device side stream (independent kernels of one call beside each other)
-hipStream_t cfd_side_fork(hipStream_t main);
+hipStream_t cfd_side_fork(hipStream_t main, int use);
 int cfd_side_join(hipStream_t main, hipStream_t side);
 bool cfd_prof_active();  // prof.cpp: the per-kernel event profiler is recording
 

@@ -156,7 +156,7 @@ extern "C" int cfd_fno_forward_train_ex(const cfd_plan* p, const cfd_fno_shape* 
     void* scratch = base + L.off_scratch;
     // the label's energy and the gradient coefficients: independent of the network (scratch is free until the head), so they
     // run beside the lifting layer on the side stream and join in front of the head
-    hipStream_t side = cfd_side_fork((hipStream_t)stream);
+    hipStream_t side = cfd_side_fork((hipStream_t)stream, 1);
     CFD_TRY(cfd_label_energy_coef(label, mask, sums, coef, scratch, B, s->out_chan, HW, which, upstream, side));
     CFD_TRY(cfd_int_fno_stem_fwd(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, act_buf(0), B, s->in_chan, s->n_case_params, C,
                                  dt, stream));
@@ -230,6 +230,7 @@ extern "C" int cfd_fno_backward_phase_ex(const cfd_plan* p, const cfd_fno_shape*
         // two passes for the input gradient (1x1 conv transposed into the fp32 scratch tensor, inverse transform + addend
         // [* gelu'(a_l), a_l read as bf16]); the weight-gradient producers reduce their own partial sums
         float* tmp = (float*)(base + L.off_tmp);
+        CFD_TRY(cfd_spectral_dft(p, gcur, gh, B * C, 0, stream));
         CFD_TRY(cfd_int_spectral_mix_adj_wgrad(p, xh_buf(l), gh, prm->spec_w1[l], prm->spec_w2[l], z, g->spec_w1[l],
                                                g->spec_w2[l], scratch, B, C, C, stream, nullptr));
         CFD_TRY(cfd_int_chan_wgrad_dt(gcur, act_buf(l), g->w0_w[l], g->w0_b[l], scratch2, B, C, C, HW, act, dt, stream, nullptr));
@@ -237,9 +238,11 @@ extern "C" int cfd_fno_backward_phase_ex(const cfd_plan* p, const cfd_fno_shape*
         return cfd_int_spectral_idft_grad(p, z, tmp, act ? act_buf(l) : nullptr, gnext, B * C, dt, stream);
     }
     // the reductions of both weight gradients ride in front of the input-gradient kernel's launch (cfd_tail.h); whatever
-    // a producer could not defer it has already reduced itself.  The 1x1 weight gradient needs only gcur and a_l: it streams
-    // them on the side stream (side.cpp) beside the transform and the latency-bound mode-domain kernel.
-    hipStream_t side = cfd_side_fork((hipStream_t)stream);
+    // a producer could not defer it has already reduced itself.  The 1x1 weight gradient needs only gcur and a_l; with
+    // side_stream bit 2 it runs on the side stream (side.cpp) beside the transform and the mode-domain kernel.  OFF by default:
+    // measured (profiles/r04a_side_stream_ab.txt) the two do run concurrently, but the latency-bound mode-domain kernel then
+    // takes 53 us instead of 26 -- it needs the wave slots the streaming kernel occupies -- and the phase is no shorter.
+    hipStream_t side = cfd_side_fork((hipStream_t)stream, 2);
     CfdReduceTail tail{};
     CFD_TRY(cfd_int_chan_wgrad(gcur, (const float*)act_buf(l), g->w0_w[l], g->w0_b[l], scratch2, B, C, C, HW, act, side, &tail.chan));
     CFD_TRY(cfd_spectral_dft(p, gcur, gh, B * C, 0, stream));

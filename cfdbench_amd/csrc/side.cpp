@@ -1,8 +1,7 @@
 // Fork / join onto a library-owned side stream: independent kernels of one C-ABI call run beside each other instead of in
-// launch order.  The FNO backward phase is a chain dft -> adjoint mix + spectral weight gradient -> fused block kernel with ONE
-// off-chain member, the 1x1-conv weight gradient (it needs only d loss / d a_{l+1} and a_l, both complete when the phase
-// starts): on the caller's stream it sat between the mode-domain kernel -- latency-bound, HBM nearly idle for ~25 us -- and the
-// block kernel; on the side stream it streams its two activations through that window.
+// launch order.  Users: the label-energy pass of the training forward (beside the lifting layer; on by default) and the 1x1-conv
+// weight gradient of a backward phase (beside the transform and the mode-domain kernel; measured no gain, off by default --
+// fno.cpp).
 //
 // Semantics: cfd_side_fork(main) returns a stream on which work is ordered after everything enqueued on `main` so far;
 // cfd_side_join(main, side) orders everything enqueued on `main` afterwards behind the side stream's work.  Both are plain
@@ -48,8 +47,11 @@ Side* side_of_current_device() {
 }
 }  // namespace
 
-hipStream_t cfd_side_fork(hipStream_t main) {
-    if (cfd_tune_get(CFD_TUNE_SIDE_STREAM) == 0 || cfd_prof_active()) return main;
+// `use`: which user asks (bit 1 = label energy beside the lifting layer, bit 2 = 1x1 weight gradient beside the mode-domain
+// kernels); the side_stream knob is a mask of the enabled users, default 1.
+hipStream_t cfd_side_fork(hipStream_t main, int use) {
+    const int knob = cfd_tune_get(CFD_TUNE_SIDE_STREAM);
+    if ((((knob < 0) ? 1 : knob) & use) == 0 || cfd_prof_active()) return main;
     std::lock_guard<std::mutex> lk(g_mu);
     Side* s = side_of_current_device();
     if (!s) return main;

@@ -30,7 +30,7 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
     {"convt_mfma", "CFD_CONVT_MFMA", {-1}},      // 0 = ConvTranspose2d(2, 2) on the fp32 VALU kernels of conv.hip instead of convt6.hip
     {"conv1_mfma", "CFD_CONV1_MFMA", {-1}},      // 1 = 1x1 convolutions on the streamed matrix-pipe kernels of conv1.hip (end of round 3: parity
                                                  // green, one timing -0.8 % on the U-Net step; off by default until the full suite ran with it)
-    {"side_stream", "CFD_SIDE_STREAM", {-1}},    // 0 = every kernel of a call on the caller's stream, in launch order (side.cpp)
+    {"side_stream", "CFD_SIDE_STREAM", {-1}},    // mask of the side-stream users (side.cpp): 1 = label energy (default), 2 = 1x1 weight gradient, 0 = none
 };
 std::once_flag g_once;
 void read_env() {
