@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the U-Net / Auto-DeepONet / exact-fp32 legs")
     ap.add_argument("--rollout-batch", type=int, default=64)
     ap.add_argument("--rollout-steps", type=int, default=200)
+    ap.add_argument("--only", default=None,
+                    help="run ONE extra leg and print {leg: result} (what the rocprofv3 --pmc passes of tools/pmc_traffic.sh profile): "
+                         "spectral | unet | auto_deeponet | resnet | deeponet | auto_edeeponet | auto_ffn | auto_deeponet_cnn")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend of the N > 1 job: nccl = RCCL over xGMI (the product); gloo only with --dry-dp")
     ap.add_argument("--dry-dp", action="store_true",
@@ -205,6 +208,35 @@ def attach_pmc(rl, name, applies):
         if match and bf.name.startswith(tag):
             rl["busy_pct"] = {k: match[0][k] for k in ("mfma", "valu", "lds", "wait") if k in match[0]}
             rl["busy_source"] = f"profiles/{bf.name} (rocprofv3 --pmc SQ_* busy counters of the same step)"
+    except Exception:  # noqa: BLE001
+        pass
+
+
+def attach_leg_traffic(rl, leg, kernel=None):
+    """Counter-based HBM traffic of a leg's roofline object from the committed rocprofv3 --pmc passes of `bench.py --only LEG`
+    (tools/pmc_traffic.sh -> profiles/r*_LEG_pmc_traffic.json; FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE).
+    kernel = None: the whole leg is one kernel GROUP (SpectralConv2d forward+backward): bytes of all launches of the profiled
+    command / its number of group calls.  Not measured in this run -- the line names the file."""
+    if not rl:
+        return
+    pmc, pf = latest_profile(f"r*_{leg}_pmc_traffic.json")
+    if not pmc:
+        return
+    try:
+        if kernel is None:
+            calls = pmc.get("k_mixadj_wgrad", {}).get("launches", 0)
+            if calls:
+                rl["traffic"] = int(sum(v["traffic_bytes"] * v["launches"] for k, v in pmc.items() if isinstance(v, dict) and k.startswith("k_")) / calls)
+        else:
+            # profiler label -> (symbol prefix, required template-argument substring)
+            sym, need = {"k_head_train": ("k_head_bwd", ""), "k_conv_dgrad": ("k_conv6", ", true, "), "k_conv_fwd": ("k_conv6", ", false, "),
+                         "k_conv_wgrad": ("k_conv6_wgrad", "")}.get(kernel, (kernel, ""))
+            match = [v for k, v in pmc.items() if isinstance(v, dict) and (k == sym or k.startswith(sym + "<")) and need in k]
+            n = sum(m["launches"] for m in match)
+            if n:
+                rl["traffic"] = int(sum(m["traffic_bytes"] * m["launches"] for m in match) / n)
+        if rl.get("traffic"):
+            rl["traffic_source"] = f"profiles/{pf.name} (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE passes of `bench.py --only {leg}`, per launch)"
     except Exception:  # noqa: BLE001
         pass
 
@@ -372,7 +404,125 @@ def model_train_leg(api, name, model, batch, steps, warmup, frames, bytes_per_fr
                       for r in rows[:8]]
     dom = next((r for r in rows if r[3] > 0 or r[4] > 0), rows[0])
     res["roofline"] = roofline_of(*dom)
+    attach_leg_traffic(res["roofline"], name, dom[0])
     return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# train-step legs of the other model families (rank 0, N = 1); each also runs alone under `--only NAME`
+# ----------------------------------------------------------------------------------------------------------------------
+def _fields(B, H, W, p, gen, dev, border=False):
+    x = torch.randn(B, 2, H, W, generator=gen).to(dev)
+    mask = torch.ones(B, 1, H, W, device=dev)
+    if border:
+        mask[:, :, 0, :] = 0
+        mask[:, :, -1, :] = 0
+        mask[:, :, :, 0] = 0
+    return dict(inputs=x, label=(x.cpu() + 0.1 * torch.randn(B, 2, H, W, generator=gen)).to(dev),
+                case_params=torch.randn(B, p, generator=gen).to(dev), mask=mask)
+
+
+def leg_unet(api, dev):
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    from cfdbench_amd.models.unet import UNet
+    Bu, pu = 128, 8
+    torch.manual_seed(0)
+    unet = UNet(2, 2, loss_name_to_fn("nmse"), pu, insert_case_params_at="input", dim=12).to(dev)
+    bu = _fields(Bu, 64, 64, pu, torch.Generator(device="cpu").manual_seed(7), dev)
+    return model_train_leg(api, "unet", unet, bu, 10, 3, Bu, unet_bytes_per_frame(12, 2 + 1 + pu, 64, 64),
+                           "BASELINE configs[2] per GPU: U-Net(dim 12, p=8) train step (fwd+nMSE+bwd+Adam), batch 128, 64x64, fp32")
+
+
+def ffn_stack_bytes(rows, widths):
+    """Ideal fusion of a Linear(+activation) stack over `rows` rows (ffn.py:12-35): the input rows are read once, the output rows
+    written once and every weight matrix read once in the forward pass; backward ~ 2x (the same streams + their gradients)."""
+    w = sum(a * b + b for a, b in zip(widths[:-1], widths[1:]))
+    return 3 * 4 * (rows * (widths[0] + widths[-1]) + w)
+
+
+def leg_auto_deeponet(api, dev):
+    from cfdbench_amd.models.auto_deeponet import AutoDeepONet
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    Bd, Hd, Wd, w, d = 512, 66, 65, 100, 8
+    torch.manual_seed(0)
+    don = AutoDeepONet(Hd * Wd + 5, 2, loss_name_to_fn("nmse"), branch_depth=d, trunk_depth=d, width=w, act_name="relu").to(dev)
+    bd = _fields(Bd, Hd, Wd, 5, torch.Generator(device="cpu").manual_seed(8), dev)
+    # SURVEY 8(a-8) ideal fusion: the branch stack over B rows of H*W+p inputs, the trunk stack over the k = H*W query points, and the
+    # inner product reading both (B + k) x w outputs, the residual u and the label and writing the (B, k) predictions -- never (B, k, w)
+    k = Hd * Wd
+    step_bytes = ffn_stack_bytes(Bd, [k + 5] + [w] * d) + ffn_stack_bytes(k, [2] + [w] * d) + 3 * 4 * ((Bd + k) * w + 3 * Bd * k)
+    return model_train_leg(api, "auto_deeponet", don, bd, 10, 3, Bd, step_bytes / Bd,
+                           "BASELINE configs[3] per GPU: Auto-DeepONet(width 100, depth 8/8) train step, batch 512, 66x65, fp32")
+
+
+def leg_resnet(api, dev):
+    # ResNet (SURVEY a-7: the one MFMA-bound path, 4.37 GFLOP per frame forward); training mode = dropout active
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    from cfdbench_amd.models.resnet import ResNet
+    Br = 32
+    torch.manual_seed(0)
+    rn = ResNet(2, 2, 5, loss_name_to_fn("nmse"), hidden_chan=16, num_blocks=4, kernel_size=7, padding=3).to(dev)
+    br = _fields(Br, 64, 64, 5, torch.Generator(device="cpu").manual_seed(9), dev)
+    leg = model_train_leg(api, "resnet", rn, br, 5, 2, Br, None,
+                          "ResNet(hidden 16, depth 4, 7x7) train step (src/models/resnet.py:145-198), batch 32, 64x64, fp32")
+    fl = 3 * 4.37e9 * Br
+    tf = fl / (leg["ms_per_step"] * 1e-3) / 1e12
+    pk = round(BF16_MFMA_PEAK_TF / 6.0, 1)
+    leg["roofline_step"] = dict(bound="mfma", flops_per_step=fl, achieved=round(tf, 2), peak=pk, unit="TFLOP/s", frac=round(tf / pk, 4),
+                                pipe="bf16 MFMA at six products per fp32-exact product (conv6.hip: three-piece operands): 2.5 PF / 6")
+    return leg
+
+
+def leg_deeponet(api, dev):
+    """the NON-autoregressive DeepONet of train.py (src/models/deeponet.py:153-223): branch over the case parameters,
+    trunk over (t, x, y) for k = 1000 random lattice points per step, NormAct activations."""
+    from cfdbench_amd.harness.args import Args
+    from cfdbench_amd.harness.train import init_model
+    B, H, W, k = 256, 64, 64, 1000
+    torch.manual_seed(0)
+    m = init_model(Args(model="deeponet", data_name="cavity_prop_bc_geo", loss_name="nmse")).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(10)
+    batch = dict(case_params=torch.randn(B, 5, generator=g).to(dev), t=torch.rand(B, 1, generator=g).to(dev),
+                 label=torch.randn(B, 3, H, W, generator=g).to(dev),
+                 query_idxs=torch.stack([torch.randint(0, H, (k,), generator=g), torch.randint(0, W, (k,), generator=g)], -1).to(dev))
+    w, d = 100, 8
+    # ideal fusion: the trunk stack runs over B*k rows whose FIRST layer input is built in-kernel from (b, p) + (k, p) rows; only the
+    # (B, k) predictions / sampled labels and the parameters cross HBM
+    step_bytes = 3 * 4 * (2 * B * k + (B + k) * w) + ffn_stack_bytes(0, [w] * (d + 1)) + ffn_stack_bytes(B, [5] + [w] * d)
+    leg = model_train_leg(api, "deeponet", m, batch, 10, 3, B, step_bytes / B,
+                          f"DeepONet (non-autoregressive, train.py) train step: batch {B} x {k} query points, width 100, depth 8/8, NormAct, fp32")
+    fl = 3 * 2.0 * B * k * (d - 0) * w * w  # the trunk stack over B*k rows dominates: 2 * rows * w * w per layer, fwd + 2x bwd
+    leg["fp32_equiv_tflops_step"] = round(fl / (leg["ms_per_step"] * 1e-3) / 1e12, 2)
+    return leg
+
+
+def _auto_leg(api, dev, name, B, what, **flags):
+    from cfdbench_amd.harness.args import Args
+    from cfdbench_amd.harness.autoregressive import init_model
+    torch.manual_seed(0)
+    m = init_model(Args(model=name, data_name="cavity_prop_bc_geo", loss_name="nmse", **flags)).to(dev)
+    batch = _fields(B, 64, 64, 5, torch.Generator(device="cpu").manual_seed(11), dev)
+    return model_train_leg(api, name, m, batch, 10, 3, B, None, what)
+
+
+def leg_auto_edeeponet(api, dev):
+    return _auto_leg(api, dev, "auto_edeeponet", 128, "SURVEY 8f-3: Auto-EDeepONet (two branches x trunk, width 100, depth 8) train step, batch 128, 64x64, fp32")
+
+
+def leg_auto_ffn(api, dev):
+    return _auto_leg(api, dev, "auto_ffn", 32, "SURVEY 8f-3: Auto-FFN (width 200, depth 8; first Linear split over [frame | query]) train step, batch 32, 64x64, fp32")
+
+
+def leg_auto_deeponet_cnn(api, dev):
+    return _auto_leg(api, dev, "auto_deeponet_cnn", 32, "SURVEY 8f-3: Auto-DeepONet-CNN (5x5 conv branch, 512-wide output FFN) train step, batch 32, 64x64, fp32")
+
+
+# leg name -> (key in the JSON line, function)
+MODEL_LEGS = {
+    "unet": ("unet_cfg2", leg_unet), "auto_deeponet": ("auto_deeponet_cfg3", leg_auto_deeponet), "resnet": ("resnet_b32", leg_resnet),
+    "deeponet": ("deeponet_nonauto", leg_deeponet), "auto_edeeponet": ("auto_edeeponet", leg_auto_edeeponet),
+    "auto_ffn": ("auto_ffn", leg_auto_ffn), "auto_deeponet_cnn": ("auto_deeponet_cnn", leg_auto_deeponet_cnn),
+}
 
 
 def dry_dp(args, rank, world):
@@ -468,6 +618,16 @@ def main():
 
     api = _lib.api()
     B, C, L, H, W, p = args.batch, args.hidden, args.layers, args.height, args.width, args.n_case_params
+    if args.only:  # one leg alone (profiling target); not the benchmark line
+        if args.only == "spectral":
+            out = {"roofline_spectral_conv2d": spectral_leg(api, _lib, dev, B, C, H, W, max(args.steps, 20))}
+        elif args.only in MODEL_LEGS:
+            out = {MODEL_LEGS[args.only][0]: MODEL_LEGS[args.only][1](api, dev)}
+        else:
+            print(f"bench.py: unknown --only {args.only!r}", file=sys.stderr)
+            sys.exit(1)
+        print(json.dumps(out), flush=True)
+        return
     torch.manual_seed(0)  # identical weights on every rank
     model = Fno2d(2, 2, p, loss_name_to_fn("nmse"), L, 12, 12, C).to(dev)
     eng = FnoTrainEngine(model, lr=1e-3, loss_name="nmse")
@@ -541,6 +701,8 @@ def main():
         result["roofline"] = roofline_of(*rows[0])
         attach_pmc(result["roofline"], rows[0][0], B == 256 and C == 20 and (H, W) == (64, 64))
         result["roofline_spectral_conv2d"] = spectral_leg(api, _lib, dev, B, C, H, W, max(args.steps, 20))
+        if B == 256 and C == 20 and (H, W) == (64, 64):
+            attach_leg_traffic(result["roofline_spectral_conv2d"], "spectral")
 
     extra = rank == 0 and world == 1
     # ---- rollout legs: batched multi-step inference from one HIP graph (the metric's "rollout" half; configs[4]) ----
@@ -635,46 +797,13 @@ def main():
         except Exception:  # noqa: BLE001
             result["exact_fp32"] = None
 
-    # ---- other model families of BASELINE.json (one GPU's share of configs[2] and configs[3]) -----------------------
+    # ---- other model families of BASELINE.json (one GPU's share of configs[2] and configs[3]) and of SURVEY 8 a-9 / f-3 ----
     if extra and not args.no_extra:
-        from cfdbench_amd.models.auto_deeponet import AutoDeepONet
-        from cfdbench_amd.models.unet import UNet
-        gg = torch.Generator(device="cpu").manual_seed(7)
-        Bu, pu = 128, 8
-        torch.manual_seed(0)
-        unet = UNet(2, 2, loss_name_to_fn("nmse"), pu, insert_case_params_at="input", dim=12).to(dev)
-        xu = torch.randn(Bu, 2, 64, 64, generator=gg).to(dev)
-        bu = dict(inputs=xu, label=(xu.cpu() + 0.1 * torch.randn(Bu, 2, 64, 64, generator=gg)).to(dev),
-                  case_params=torch.randn(Bu, pu, generator=gg).to(dev), mask=torch.ones(Bu, 1, 64, 64, device=dev))
-        result["unet_cfg2"] = model_train_leg(api, "unet", unet, bu, 10, 3, Bu, unet_bytes_per_frame(12, 2 + 1 + pu, 64, 64),
-                                              "BASELINE configs[2] per GPU: U-Net(dim 12, p=8) train step (fwd+nMSE+bwd+Adam), batch 128, 64x64, fp32")
-        del unet, bu
-        Bd, Hd, Wd = 512, 66, 65
-        torch.manual_seed(0)
-        don = AutoDeepONet(Hd * Wd + 5, 2, loss_name_to_fn("nmse"), branch_depth=8, trunk_depth=8, width=100, act_name="relu").to(dev)
-        xd = torch.randn(Bd, 2, Hd, Wd, generator=gg).to(dev)
-        bd = dict(inputs=xd, label=(xd.cpu() + 0.1 * torch.randn(Bd, 2, Hd, Wd, generator=gg)).to(dev),
-                  case_params=torch.randn(Bd, 5, generator=gg).to(dev), mask=torch.ones(Bd, 1, Hd, Wd, device=dev))
-        result["auto_deeponet_cfg3"] = model_train_leg(api, "auto_deeponet", don, bd, 10, 3, Bd, None,
-                                                       "BASELINE configs[3] per GPU: Auto-DeepONet(width 100, depth 8/8) train step, batch 512, 66x65, fp32")
-        del don, bd
-        # ResNet (SURVEY a-7: the one MFMA-bound path, 4.37 GFLOP per frame forward); training mode = dropout active
-        from cfdbench_amd.models.resnet import ResNet
-        Br = 32
-        torch.manual_seed(0)
-        rn = ResNet(2, 2, 5, loss_name_to_fn("nmse"), hidden_chan=16, num_blocks=4, kernel_size=7, padding=3).to(dev)
-        xr = torch.randn(Br, 2, 64, 64, generator=gg).to(dev)
-        br = dict(inputs=xr, label=(xr.cpu() + 0.1 * torch.randn(Br, 2, 64, 64, generator=gg)).to(dev),
-                  case_params=torch.randn(Br, 5, generator=gg).to(dev), mask=torch.ones(Br, 1, 64, 64, device=dev))
-        leg = model_train_leg(api, "resnet", rn, br, 5, 2, Br, None,
-                              "ResNet(hidden 16, depth 4, 7x7) train step (src/models/resnet.py:145-198), batch 32, 64x64, fp32")
-        fl = 3 * 4.37e9 * Br
-        tf = fl / (leg["ms_per_step"] * 1e-3) / 1e12
-        pk = round(BF16_MFMA_PEAK_TF / 6.0, 1)
-        leg["roofline_step"] = dict(bound="mfma", flops_per_step=fl, achieved=round(tf, 2), peak=pk, unit="TFLOP/s", frac=round(tf / pk, 4),
-                                    pipe="bf16 MFMA at six products per fp32-exact product (conv6.hip: three-piece operands): 2.5 PF / 6")
-        result["resnet_b32"] = leg
-        del rn, br
+        for leg in MODEL_LEGS:
+            try:
+                result[MODEL_LEGS[leg][0]] = MODEL_LEGS[leg][1](api, dev)
+            except Exception as e:  # noqa: BLE001
+                result[MODEL_LEGS[leg][0]] = dict(error=f"{type(e).__name__}: {str(e)[:300]}")
 
     # ---- CPU baseline leg (rank 0, N=1): the reference's ATen call sequence on the host cores ------------------
     if extra and not args.no_cpu_baseline:
