@@ -778,24 +778,28 @@ def main():
         except Exception as e:  # noqa: BLE001
             result["train_66x65"] = dict(error=str(e)[:200])
 
-    # ---- the same step with exact-fp32 contractions (the split-bf16 trade on the record) ------------------------------
+    # ---- the same step on the fp32-exact-class route (the default route's split-product trade on the record) ------------------
     if extra and not args.no_extra:
-        try:
-            api.call("cfd_tune_set", b"exact_fp32", 1)
+        def timed_route(knob, value):
+            api.call("cfd_tune_set", knob, value)
             try:
-                dt = time_steps(lambda: eng.train_step(inputs, label, cp, mask), args.steps, 3)
-                sp_exact = spectral_leg(api, _lib, dev, B, C, H, W, max(args.steps, 20))
+                dt = min(time_steps(lambda: eng.train_step(inputs, label, cp, mask), args.steps, 3) for _ in range(2))
+                sp = min((spectral_leg(api, _lib, dev, B, C, H, W, max(args.steps, 20)) for _ in range(2)), key=lambda r: r["avg_us"])  # best of two, like dt
             finally:
-                api.call("cfd_tune_set", b"exact_fp32", -1)
+                api.call("cfd_tune_set", knob, -1)
+            return dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(B / dt, 1), spectral_conv2d_us=sp["avg_us"], spectral_conv2d_frac=sp["frac"])
+        try:
             result["exact_fp32"] = dict(
-                ms_per_step=round(dt * 1e3, 4), frames_per_s=round(B / dt, 1),
-                spectral_conv2d_us=sp_exact["avg_us"], spectral_conv2d_frac=sp_exact["frac"],
-                what="the same step / SpectralConv2d group with every DFT and inverse DFT on the exact-fp32 kernels (fp32 MFMA "
-                     "= the VALU's fp32 rate on gfx950) and the fused FnoBlock kernel replaced by its two exact passes; the "
-                     "1x1 weight gradient and the projection head have no exact-fp32 build and stay split-bf16 -- i.e. the north star's 40 % "
-                     "SpectralConv2d target is met on the split-product route only (DESIGN.md section 5)")
-        except Exception:  # noqa: BLE001
-            result["exact_fp32"] = None
+                timed_route(b"act_pieces", 3),
+                what="the same step / SpectralConv2d group on the fp32-exact-class route (cfd_tune_set('act_pieces', 3)): the activation operand of every "
+                     "transform, of the fused FnoBlock's inverse transform, of the 1x1 conv and of the 1x1 weight gradient in THREE bf16 pieces against "
+                     "three-piece fixed operands, six MFMAs per product -- every term down to 2^-24, measured nMSE vs the fp64 oracle 6e-15 .. 5e-14 per "
+                     "kernel (profiles/r04b_err_act3.json); mode mixing / spectral weight gradient / channel mix inside k_block are exact fp32 FMAs on "
+                     "both routes; the projection head keeps two-piece operands (whole-model predictions 3e-12)",
+                fp32_mfma_route=dict(timed_route(b"exact_fp32", 1),
+                                     what="round 1-3's exact route: every DFT / inverse DFT on v_mfma_f32_16x16x4_f32 kernels, the FnoBlock as two passes"))
+        except Exception as e:  # noqa: BLE001
+            result["exact_fp32"] = dict(error=str(e)[:300])
 
     # ---- other model families of BASELINE.json (one GPU's share of configs[2] and configs[3]) and of SURVEY 8 a-9 / f-3 ----
     if extra and not args.no_extra:

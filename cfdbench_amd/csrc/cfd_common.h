@@ -8,7 +8,7 @@
 void cfd_set_error(const char* fmt, ...);
 
 // dispatch overrides (tune.cpp): environment read once per process, cfd_tune_set() afterwards; -1 = built-in choice
-enum { CFD_TUNE_MIX_NWV = 0, CFD_TUNE_WGRAD_WG, CFD_TUNE_FUSED_VARIANT, CFD_TUNE_BLOCK_FUSE, CFD_TUNE_GENERAL_B3, CFD_TUNE_HEAD_BLOCKS, CFD_TUNE_EXACT_FP32, CFD_TUNE_CONV6_GRID, CFD_TUNE_CONV6_WGRAD_MUL, CFD_TUNE_CONVT_MFMA, CFD_TUNE_CONV1_MFMA, CFD_TUNE_SIDE_STREAM, CFD_TUNE_COUNT };
+enum { CFD_TUNE_MIX_NWV = 0, CFD_TUNE_WGRAD_WG, CFD_TUNE_FUSED_VARIANT, CFD_TUNE_BLOCK_FUSE, CFD_TUNE_GENERAL_B3, CFD_TUNE_HEAD_BLOCKS, CFD_TUNE_EXACT_FP32, CFD_TUNE_CONV6_GRID, CFD_TUNE_CONV6_WGRAD_MUL, CFD_TUNE_CONVT_MFMA, CFD_TUNE_CONV1_MFMA, CFD_TUNE_SIDE_STREAM, CFD_TUNE_ACT_PIECES, CFD_TUNE_COUNT };
 int cfd_tune_get(int which);
 
 #define CFD_REQUIRE(cond, code, ...)      \
@@ -307,6 +307,78 @@ __device__ __forceinline__ void cfd_mfma_bf16x6_n(const bf16x8 (&a)[3], const bf
 #pragma unroll
     for (int i = 0; i < N; ++i) c[i] = cfd_mfma16x16x32_bf16(a[0], b[i][0], c[i]);
 }
+// ---- activation operands of the FNO contractions (transforms, 1x1 conv, 1x1 weight gradient) ---------------------------------
+// AP = pieces the ACTIVATION operand is carried in (template parameter of the kernels, chosen per launch by the act_pieces knob):
+//   AP = 2 (default): hi = bf16(x), lo = bf16(x - hi); a product against a three-piece fixed operand takes four bf16 MFMAs
+//           (x_lo t_hi + x_hi t_lo2 + x_hi t_lo + x_hi t_hi): relative error <= ~2^-16 per product, measured nMSE against the fp64
+//           oracle 2e-11 .. 5e-11 -- the round-3 arithmetic.
+//   AP = 3 (round 4, `cfd_tune_set("act_pieces", 3)`): three truncating pieces (cfd_split8x3: p[0] + p[1] + p[2] == x exactly) and
+//           the six MFMAs of cfd_mfma_bf16x6 -- every term down to 2^-24 of the product, i.e. fp32-exact class like the convolution
+//           stack: measured nMSE 6e-15 .. 5e-14 on every transform / FnoBlock / 1x1 kernel (profiles/r04b_err_act3.json).  Costs
+//           3 more VALU instructions per pair of values and two more MFMAs per product: +6.7 % on the train step, which is why it
+//           is the selectable route (it replaces the exact-fp32 MFMA kernels as bench.py's `exact_fp32` leg) and not the default.
+template <int AP>
+struct CfdAct8 {
+    bf16x8 p[AP];
+};
+template <int AP>
+__device__ __forceinline__ CfdAct8<AP> cfd_act_split8(const float (&x)[8]) {
+    CfdAct8<AP> r;
+    if constexpr (AP == 3) {
+        const CfdSplit8x3 s = cfd_split8x3(x);
+        r.p[0] = s.p[0]; r.p[1] = s.p[1]; r.p[2] = s.p[2];
+    } else {
+        const CfdSplit8 s = cfd_split8(x);
+        r.p[0] = s.hi; r.p[1] = s.lo;
+    }
+    return r;
+}
+// the same for a vector whose ONLY non-zero element is element 0 (the Nyquist row of the 64-wide forward transform): a handful of
+// scalar instructions instead of a full eight-value split
+template <int AP>
+__device__ __forceinline__ CfdAct8<AP> cfd_act_split1(float x) {
+    if constexpr (AP == 3) {
+        const unsigned h = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+        const float r = x - __builtin_bit_cast(float, h);
+        const unsigned l = __builtin_bit_cast(unsigned, r) & 0xffff0000u;
+        const float t = r - __builtin_bit_cast(float, l);
+        CfdAct8<AP> o;
+        o.p[0] = __builtin_bit_cast(bf16x8, cfd_u32x4{h >> 16, 0u, 0u, 0u});
+        o.p[1] = __builtin_bit_cast(bf16x8, cfd_u32x4{l >> 16, 0u, 0u, 0u});
+        o.p[2] = __builtin_bit_cast(bf16x8, cfd_u32x4{__builtin_bit_cast(unsigned, t) >> 16, 0u, 0u, 0u});
+        return o;
+    } else {
+        const float v[8] = {x, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        return cfd_act_split8<AP>(v);
+    }
+}
+// the (activation piece, table piece) pairs of a product against a three-piece fixed operand, smallest terms first
+__host__ __device__ constexpr int cfd_nterm(int ap) { return ap == 3 ? 6 : 4; }
+__host__ __device__ constexpr int cfd_term_a(int ap, int k) { return ap == 3 ? (k == 0 ? 2 : (k == 2 || k == 3) ? 1 : 0) : (k == 0 ? 1 : 0); }
+__host__ __device__ constexpr int cfd_term_t(int ap, int k) { return ap == 3 ? (k == 1 ? 2 : (k == 2 || k == 4) ? 1 : 0) : (k == 1 ? 2 : k == 2 ? 1 : 0); }
+// activation x activation (1x1 weight gradient): 3 pieces: the six of cfd_mfma_bf16x6; 2 pieces: lo*hi, hi*lo, hi*hi
+__host__ __device__ constexpr int cfd_nterm_aa(int ap) { return ap == 3 ? 6 : 3; }
+__host__ __device__ constexpr int cfd_term_aa_a(int ap, int k) { return ap == 3 ? cfd_term_a(3, k) : (k == 0 ? 1 : 0); }
+__host__ __device__ constexpr int cfd_term_aa_b(int ap, int k) { return ap == 3 ? cfd_term_t(3, k) : (k == 1 ? 1 : 0); }
+// three pieces of a fixed operand (piece-major tables: [piece][64 lanes] vectors behind `t`)
+struct CfdTab3 {
+    bf16x8 p[3];
+};
+__device__ __forceinline__ CfdTab3 cfd_tab3(const bf16x8* t, int lane) {
+    CfdTab3 r;
+    r.p[0] = t[lane]; r.p[1] = t[64 + lane]; r.p[2] = t[128 + lane];
+    return r;
+}
+// term k of  acc += activation x table  with the activation as the A operand (ACTA) or as the B operand.  With the table as
+// the A operand the two-piece route walks its four terms in the order the round-3 kernels used (hi*lo2, hi*lo, lo*hi, hi*hi), so
+// that the default route's results stay bit-identical to round 3.
+template <bool ACTA, int AP>
+__device__ __forceinline__ f32x4 cfd_term(const CfdAct8<AP>& x, const CfdTab3& t, int k, f32x4 c) {
+    if constexpr (ACTA) return cfd_mfma16x16x32_bf16(x.p[cfd_term_a(AP, k)], t.p[cfd_term_t(AP, k)], c);
+    else if constexpr (AP == 2) return cfd_mfma16x16x32_bf16(t.p[k == 0 ? 2 : k == 1 ? 1 : 0], x.p[k == 2 ? 1 : 0], c);
+    else return cfd_mfma16x16x32_bf16(t.p[cfd_term_t(AP, k)], x.p[cfd_term_a(AP, k)], c);
+}
+int cfd_act_pieces();  // tune.cpp: 2 or 3 (act_pieces knob)
 // D += A*B with both operands split
 __device__ __forceinline__ f32x4 cfd_mfma_bf16x3(const CfdSplit8& a, const CfdSplit8& b, f32x4 c) {
     c = cfd_mfma16x16x32_bf16(a.lo, b.hi, c);

@@ -359,7 +359,7 @@ __device__ __forceinline__ void cfd_ld4px(const TA* __restrict__ p, int nvalid, 
     }
 }
 
-template <int MT, int VEC, bool ACT, typename TA>
+template <int MT, int VEC, bool ACT, typename TA, int AP>
 __global__ __launch_bounds__(256, 2) void k_chanmix_b3(const TA* __restrict__ in, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, int B,
                                                        int Ci, int Co, int HW, int transpose) {
@@ -370,8 +370,7 @@ __global__ __launch_bounds__(256, 2) void k_chanmix_b3(const TA* __restrict__ in
     // through a near-identity network accumulates coherently (2-piece weights: nMSE 3.0e-7 against the reference at step
     // 200 of tests/golden/rollout200_c32_66x65, 3-piece: see DESIGN.md); the activations keep two pieces, whose rounding
     // differs from value to value.  Five MFMAs per tile-step instead of three; the kernel is memory-bound either way.
-    CfdSplit8 wf[MT];
-    bf16x8 wlo2[MT];
+    CfdTab3 wf[MT];    // (round 4: the activations carry AP = 2 or 3 pieces -- five or six MFMAs per tile-step, cfd_common.h)
     float bz[MT][4];   // bias of accumulator row d = 16 mt + 4q + r
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -382,11 +381,12 @@ __global__ __launch_bounds__(256, 2) void k_chanmix_b3(const TA* __restrict__ in
             const int sc = 8 * q + v;
             x[v] = (d < Co && sc < Ci) ? (transpose ? w[sc * Co + d] : w[d * Ci + sc]) : 0.f;
         }
-        wf[mt] = cfd_split8(x);
+        // round-to-nearest pieces as in rounds 2-3 (hi, lo, then the bf16 of what two pieces miss): the default route's results stay bit-identical
+        const CfdSplit8 w2 = cfd_split8(x);
         float x3[8];
 #pragma unroll
-        for (int v = 0; v < 8; ++v) x3[v] = (x[v] - (float)wf[mt].hi[v]) - (float)wf[mt].lo[v];  // exact: what two pieces miss
-        wlo2[mt] = cfd_split8(x3).hi;
+        for (int v = 0; v < 8; ++v) x3[v] = (x[v] - (float)w2.hi[v]) - (float)w2.lo[v];  // exact
+        wf[mt].p[0] = w2.hi; wf[mt].p[1] = w2.lo; wf[mt].p[2] = cfd_split8(x3).hi;
 #pragma unroll
         for (int r = 0; r < 4; ++r) bz[mt][r] = (bias && 16 * mt + 4 * q + r < Co) ? bias[16 * mt + 4 * q + r] : 0.f;
     }
@@ -435,20 +435,27 @@ __global__ __launch_bounds__(256, 2) void k_chanmix_b3(const TA* __restrict__ in
             float xk[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) xk[c] = h[c][j];
-            const CfdSplit8 bs = cfd_split8(xk);
+            const CfdAct8<AP> bs = cfd_act_split8<AP>(xk);
             f32x4 z[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) z[mt] = f32x4{bz[mt][0], bz[mt][1], bz[mt][2], bz[mt][3]};
+            if constexpr (AP == 2) {  // five terms in the round-3 order (w_lo2 x_hi, w_lo x_lo, w_lo x_hi, w_hi x_lo, w_hi x_hi)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wlo2[mt], bs.hi, z[mt]);
+                for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wf[mt].p[2], bs.p[0], z[mt]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wf[mt].lo, bs.lo, z[mt]);
+                for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wf[mt].p[1], bs.p[1], z[mt]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wf[mt].lo, bs.hi, z[mt]);
+                for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wf[mt].p[1], bs.p[0], z[mt]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wf[mt].hi, bs.lo, z[mt]);
+                for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wf[mt].p[0], bs.p[1], z[mt]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wf[mt].hi, bs.hi, z[mt]);
+                for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(wf[mt].p[0], bs.p[0], z[mt]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < cfd_nterm(AP); ++k)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) z[mt] = cfd_term<false, AP>(bs, wf[mt], k, z[mt]);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -494,8 +501,14 @@ static int launch_chanmix_b3(const TA* in, const float* w, const float* bias, fl
                                                                                                     : 1;
     CFD_PROF_W(transpose ? "k_chanmix_t" : (act ? "k_chanmix_act" : "k_chanmix"), st, B * HW * ((double)ea * Ci + 4.0 * Co),
                2.0 * B * HW * (double)Ci * Co);
-#define CFD_CB3(M_, V_, A_) \
-    hipLaunchKernelGGL((k_chanmix_b3<M_, V_, A_, TA>), dim3(blocks), dim3(256), 0, st, in, w, bias, out, B, Ci, Co, HW, transpose)
+    const bool ap3 = sizeof(TA) == 4 && cfd_act_pieces() == 3;  // bf16 storage keeps two pieces
+#define CFD_CB3_P(M_, V_, A_, P_) \
+    hipLaunchKernelGGL((k_chanmix_b3<M_, V_, A_, TA, P_>), dim3(blocks), dim3(256), 0, st, in, w, bias, out, B, Ci, Co, HW, transpose)
+#define CFD_CB3(M_, V_, A_)                                                                   \
+    do {                                                                                      \
+        if constexpr (sizeof(TA) == 4) { if (ap3) CFD_CB3_P(M_, V_, A_, 3); else CFD_CB3_P(M_, V_, A_, 2); } \
+        else CFD_CB3_P(M_, V_, A_, 2);                                                        \
+    } while (0)
 #define CFD_CB3_V(M_)                                                      \
     do {                                                                   \
         if (vec == 4) { if (act) CFD_CB3(M_, 4, true); else CFD_CB3(M_, 4, false); } \
@@ -506,6 +519,7 @@ static int launch_chanmix_b3(const TA* in, const float* w, const float* bias, fl
     else CFD_CB3_V(2);
 #undef CFD_CB3_V
 #undef CFD_CB3
+#undef CFD_CB3_P
     CFD_LAUNCH_CHECK("cfd_chanmix");
     return CFD_OK;
 }
@@ -643,7 +657,7 @@ __device__ __forceinline__ void cfd_ld8px(const __bf16* __restrict__ src, int px
 }
 
 // TIN: storage type of `in` (float; __bf16 for the saved activations of bf16-storage training -- the gradient `g` is always fp32)
-template <int MT, int NT, int VEC, bool ACT, bool STEM, typename TIN = float>
+template <int MT, int NT, int VEC, bool ACT, bool STEM, typename TIN, int AP>
 __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g, const TIN* __restrict__ in,
                                                     StemSrc ss, float* __restrict__ part, int B, int Ci, int Co,
                                                     int HW) {
@@ -761,24 +775,20 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
                 }
         }
         {
-            CfdSplit8 as[MT], bs[NT];
+            // both operands are activations, AP pieces each (3: the six products of cfd_mfma_bf16x6; 2: lo*hi, hi*lo, hi*hi),
+            // term-major so that consecutive MFMAs hit different accumulators
+            CfdAct8<AP> as[MT], bs[NT];
 #pragma unroll
-            for (int a = 0; a < MT; ++a) as[a] = cfd_split8(av[a]);
+            for (int a = 0; a < MT; ++a) as[a] = cfd_act_split8<AP>(av[a]);
 #pragma unroll
-            for (int c = 0; c < NT; ++c) bs[c] = cfd_split8(bv[c]);
-            // term-major: consecutive MFMAs hit different accumulators
+            for (int c = 0; c < NT; ++c) bs[c] = cfd_act_split8<AP>(bv[c]);
 #pragma unroll
-            for (int a = 0; a < MT; ++a)
+            for (int k = 0; k < cfd_nterm_aa(AP); ++k)
 #pragma unroll
-                for (int c = 0; c < NT; ++c) acc[a][c] = cfd_mfma16x16x32_bf16(as[a].lo, bs[c].hi, acc[a][c]);
+                for (int a = 0; a < MT; ++a)
 #pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int c = 0; c < NT; ++c) acc[a][c] = cfd_mfma16x16x32_bf16(as[a].hi, bs[c].lo, acc[a][c]);
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int c = 0; c < NT; ++c) acc[a][c] = cfd_mfma16x16x32_bf16(as[a].hi, bs[c].hi, acc[a][c]);
+                    for (int c = 0; c < NT; ++c)
+                        acc[a][c] = cfd_mfma16x16x32_bf16(as[a].p[cfd_term_aa_a(AP, k)], bs[c].p[cfd_term_aa_b(AP, k)], acc[a][c]);
         }
         cfd_sched_fence();
 #pragma unroll
@@ -856,9 +866,15 @@ static int launch_wgrad(const float* g, const TIN* in, StemSrc ss, float* gw, fl
                     : (HW % 2 == 0 && ((uintptr_t)g % 8) == 0 && ((uintptr_t)in % 8) == 0) ? 2
                                                                                             : 1;
     float* part = (float*)ws;
-#define CFD_WG(M_, N_, V_, A_)                                                                                   \
-    hipLaunchKernelGGL((k_chan_wgrad<M_, N_, V_, A_, STEM, TIN>), dim3(blocks), dim3(256), 0, st, g, in, ss, part, B, \
+    const bool ap3 = sizeof(TIN) == 4 && cfd_act_pieces() == 3;  // bf16 storage keeps two pieces
+#define CFD_WG_P(M_, N_, V_, A_, P_)                                                                             \
+    hipLaunchKernelGGL((k_chan_wgrad<M_, N_, V_, A_, STEM, TIN, P_>), dim3(blocks), dim3(256), 0, st, g, in, ss, part, B, \
                        Ci, Co, HW)
+#define CFD_WG(M_, N_, V_, A_)                                                                \
+    do {                                                                                      \
+        if constexpr (sizeof(TIN) == 4) { if (ap3) CFD_WG_P(M_, N_, V_, A_, 3); else CFD_WG_P(M_, N_, V_, A_, 2); } \
+        else CFD_WG_P(M_, N_, V_, A_, 2);                                                     \
+    } while (0)
 #define CFD_WG_VA(M_, N_)                                                                     \
     do {                                                                                      \
         if (vec == 4) { if (act) CFD_WG(M_, N_, 4, true); else CFD_WG(M_, N_, 4, false); }    \
@@ -882,6 +898,7 @@ static int launch_wgrad(const float* g, const TIN* in, StemSrc ss, float* gw, fl
     }
 #undef CFD_WG_VA
 #undef CFD_WG
+#undef CFD_WG_P
     CFD_LAUNCH_CHECK("cfd_chan_wgrad");
     if (defer) {
         *defer = ChanWgradTail{(const float*)part, gw, gb, blocks, Co, Ci};

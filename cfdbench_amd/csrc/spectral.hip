@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64(const float* __
 #ifndef CFD_DFT_OCC
 #define CFD_DFT_OCC 3  // workgroups per CU the forward kernel is compiled for
 #endif
-template <int D, bool ACT>
+template <int D, bool ACT, int AP>
 __global__ __launch_bounds__(64 * CFD_WAVES, CFD_DFT_OCC) void k_dft_fwd64_b3(const float* __restrict__ x, float2* __restrict__ xh,
                                                                      const bf16x8* __restrict__ tabs3, int nimg, int m1,
                                                                      int m2) {
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, CFD_DFT_OCC) void k_dft_fwd64_b3(co
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     float aa = a[j], bb = is_paired(s) ? b[j] : 0.f;
-                    if constexpr (ACT) { const cfd_f2 g2 = cfd_gelu2(cfd_f2{aa, bb}); aa = g2.x; bb = g2.y; }  // gelu(0) = 0
+                    if constexpr (ACT) { const cfd_f2 g2 = cfd_gelu2(cfd_f2{aa, bb}); aa = cfd_opaque_f(g2.x); bb = cfd_opaque_f(g2.y); }  // gelu(0) = 0; opaque: see k_dft_fwd_g
                     if (s < KXT - 1) { e8[j][s < 8 ? s : 0] = aa + bb; o8[j][s < 8 ? s : 0] = aa - bb; }
                     else ny[j] = q == 0 ? aa : 0.f;  // k-step 8: only row H/2 (lanes q == 0), cosine sums only
                 }
@@ -309,23 +309,21 @@ __global__ __launch_bounds__(64 * CFD_WAVES, CFD_DFT_OCC) void k_dft_fwd64_b3(co
         {
             const int lo = cfd_opaque(lane);
             constexpr int TS = CFD_TW * 64;  // vectors per table
-            const bf16x8 tch = s_tab3[lo], tcl = s_tab3[64 + lo], tcl2 = s_tab3[128 + lo];
-            const bf16x8 tsh = s_tab3[TS + lo], tsl = s_tab3[TS + 64 + lo], tsl2 = s_tab3[TS + 128 + lo];
+            const CfdTab3 tc = cfd_tab3(s_tab3, lo), ts = cfd_tab3(s_tab3 + TS, lo);
             const bf16x8 tnh = s_tab3[2 * TS + lo];  // the Nyquist row's +-1 are exact in one piece
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const float nyv[8] = {ny[j], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                const CfdSplit8 es = cfd_split8(e8[j]), os = cfd_split8(o8[j]), ns = cfd_split8(nyv);
-                f32x4 c = cfd_mfma16x16x32_bf16(es.lo, tch, zero);
-                f32x4 s = cfd_mfma16x16x32_bf16(os.lo, tsh, zero);
-                c = cfd_mfma16x16x32_bf16(es.hi, tcl2, c);
-                s = cfd_mfma16x16x32_bf16(os.hi, tsl2, s);
-                c = cfd_mfma16x16x32_bf16(es.hi, tcl, c);
-                s = cfd_mfma16x16x32_bf16(os.hi, tsl, s);
-                c = cfd_mfma16x16x32_bf16(ns.lo, tnh, c);
-                c = cfd_mfma16x16x32_bf16(ns.hi, tnh, c);
-                c = cfd_mfma16x16x32_bf16(es.hi, tch, c);
-                s = cfd_mfma16x16x32_bf16(os.hi, tsh, s);
+                const CfdAct8<AP> es = cfd_act_split8<AP>(e8[j]), os = cfd_act_split8<AP>(o8[j]), ns = cfd_act_split1<AP>(ny[j]);
+                f32x4 c = zero, s = zero;
+#pragma unroll
+                for (int k = 0; k < cfd_nterm(AP); ++k) {  // term-major: consecutive MFMAs hit different accumulators
+                    c = cfd_term<true, AP>(es, tc, k, c);
+                    s = cfd_term<true, AP>(os, ts, k, s);
+                    if (k == cfd_nterm(AP) - 2) {  // the Nyquist row: every activation piece against the exact +-1
+#pragma unroll
+                        for (int pc = AP - 1; pc >= 0; --pc) c = cfd_mfma16x16x32_bf16(ns.p[pc], tnh, c);
+                    }
+                }
                 a1c[j] = c;
                 a1s[j] = s;
             }
@@ -340,25 +338,15 @@ __global__ __launch_bounds__(64 * CFD_WAVES, CFD_DFT_OCC) void k_dft_fwd64_b3(co
                                      a1c[2 * h + 1][0], a1c[2 * h + 1][1], a1c[2 * h + 1][2], a1c[2 * h + 1][3]};
                 const float sv[8] = {a1s[2 * h][0], a1s[2 * h][1], a1s[2 * h][2], a1s[2 * h][3],
                                      a1s[2 * h + 1][0], a1s[2 * h + 1][1], a1s[2 * h + 1][2], a1s[2 * h + 1][3]};
-                const CfdSplit8 cs = cfd_split8(cv), ss = cfd_split8(sv);
-                const bf16x8 ch = s_tab3[(CFD_TW * (3 + h)) * 64 + lo], cl = s_tab3[(CFD_TW * (3 + h) + 1) * 64 + lo], cl2 = s_tab3[(CFD_TW * (3 + h) + 2) * 64 + lo];
-                const bf16x8 sh = s_tab3[(CFD_TW * (5 + h)) * 64 + lo], sl = s_tab3[(CFD_TW * (5 + h) + 1) * 64 + lo], sl2 = s_tab3[(CFD_TW * (5 + h) + 2) * 64 + lo];
-                Pc = cfd_mfma16x16x32_bf16(cl2, cs.hi, Pc);
-                Ps = cfd_mfma16x16x32_bf16(sl2, cs.hi, Ps);
-                Qc = cfd_mfma16x16x32_bf16(cl2, ss.hi, Qc);
-                Qs = cfd_mfma16x16x32_bf16(sl2, ss.hi, Qs);
-                Pc = cfd_mfma16x16x32_bf16(cl, cs.hi, Pc);
-                Ps = cfd_mfma16x16x32_bf16(sl, cs.hi, Ps);
-                Qc = cfd_mfma16x16x32_bf16(cl, ss.hi, Qc);
-                Qs = cfd_mfma16x16x32_bf16(sl, ss.hi, Qs);
-                Pc = cfd_mfma16x16x32_bf16(ch, cs.lo, Pc);
-                Ps = cfd_mfma16x16x32_bf16(sh, cs.lo, Ps);
-                Qc = cfd_mfma16x16x32_bf16(ch, ss.lo, Qc);
-                Qs = cfd_mfma16x16x32_bf16(sh, ss.lo, Qs);
-                Pc = cfd_mfma16x16x32_bf16(ch, cs.hi, Pc);
-                Ps = cfd_mfma16x16x32_bf16(sh, cs.hi, Ps);
-                Qc = cfd_mfma16x16x32_bf16(ch, ss.hi, Qc);
-                Qs = cfd_mfma16x16x32_bf16(sh, ss.hi, Qs);
+                const CfdAct8<AP> cs = cfd_act_split8<AP>(cv), ss = cfd_act_split8<AP>(sv);
+                const CfdTab3 ct = cfd_tab3(s_tab3 + (CFD_TW * (3 + h)) * 64, lo), st = cfd_tab3(s_tab3 + (CFD_TW * (5 + h)) * 64, lo);
+#pragma unroll
+                for (int k = 0; k < cfd_nterm(AP); ++k) {
+                    Pc = cfd_term<false, AP>(cs, ct, k, Pc);
+                    Ps = cfd_term<false, AP>(cs, st, k, Ps);
+                    Qc = cfd_term<false, AP>(ss, ct, k, Qc);
+                    Qs = cfd_term<false, AP>(ss, st, k, Qs);
+                }
             }
         }
         // modes -> this wave's LDS slice (scattered 8-byte writes are cheap there), then out in whole 512-byte runs
@@ -396,7 +384,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, CFD_DFT_OCC) void k_dft_fwd64_b3(co
 // One image per wave, persistent waves; the 18 row values of a tile are re-requested for the wave's NEXT image the moment they
 // have been folded (a rolling ring one image deep: ~17 KB in flight per wave).  TA = storage type of the activations
 // (float, or __bf16 for the bf16-storage inference path).
-template <int NJ, bool ACT, typename TA>
+template <int NJ, bool ACT, typename TA, int AP>
 __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_dft_fwd_g(const TA* __restrict__ x, float2* __restrict__ xh,
                                                                   const bf16x8* __restrict__ tabs3, int ntabv, int nimg, int H,
                                                                   int W, int m1, int m2) {
@@ -451,7 +439,8 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_dft_fwd_g(const TA* __res
 #pragma unroll
             for (int v = 0; v < 9; ++v) {
                 float aa = valid[v] ? rv[j][v] : 0.f, bb = pair[v] ? ru[j][v] : 0.f;
-                if constexpr (ACT) { const cfd_f2 g2 = cfd_gelu2(cfd_f2{aa, bb}); aa = g2.x; bb = g2.y; }  // gelu(0) = 0
+                // (opaque: the fold below must not become one v_pk_add_f32 on the GELU's register pair with op_sel:[0,1] -- build.py's lint)
+                if constexpr (ACT) { const cfd_f2 g2 = cfd_gelu2(cfd_f2{aa, bb}); aa = cfd_opaque_f(g2.x); bb = cfd_opaque_f(g2.y); }  // gelu(0) = 0
                 if (v < 8) { e8[v] = aa + bb; o8[v] = aa - bb; }
                 else { e1[0] = aa + bb; o1[0] = aa - bb; }
             }
@@ -460,28 +449,36 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_dft_fwd_g(const TA* __res
             cfd_sched_fence();
             arm(xn, j);  // re-arm the slot with the same tile of the wave's next image
             cfd_sched_fence();
-            const CfdSplit8 es = cfd_split8(e8), os = cfd_split8(o8), es1 = cfd_split8(e1), os1 = cfd_split8(o1);
+            const CfdAct8<AP> es = cfd_act_split8<AP>(e8), os = cfd_act_split8<AP>(o8), es1 = cfd_act_split8<AP>(e1), os1 = cfd_act_split8<AP>(o1);
             constexpr int TS = CFD_TW * 64;  // vectors per table
-            const bf16x8 c0h = s_tab3[lo], c0l = s_tab3[64 + lo], c0l2 = s_tab3[128 + lo];
-            const bf16x8 s0h = s_tab3[TS + lo], s0l = s_tab3[TS + 64 + lo], s0l2 = s_tab3[TS + 128 + lo];
-            const bf16x8 c1h = s_tab3[2 * TS + lo], c1l = s_tab3[2 * TS + 64 + lo], c1l2 = s_tab3[2 * TS + 128 + lo];
-            const bf16x8 s1h = s_tab3[3 * TS + lo], s1l = s_tab3[3 * TS + 64 + lo], s1l2 = s_tab3[3 * TS + 128 + lo];
-            f32x4 c = cfd_mfma16x16x32_bf16(es.lo, c0h, zero);
-            f32x4 sn = cfd_mfma16x16x32_bf16(os.lo, s0h, zero);
-            c = cfd_mfma16x16x32_bf16(es.hi, c0l2, c);
-            sn = cfd_mfma16x16x32_bf16(os.hi, s0l2, sn);
-            c = cfd_mfma16x16x32_bf16(es1.hi, c1l2, c);
-            sn = cfd_mfma16x16x32_bf16(os1.hi, s1l2, sn);
-            c = cfd_mfma16x16x32_bf16(es.hi, c0l, c);
-            sn = cfd_mfma16x16x32_bf16(os.hi, s0l, sn);
-            c = cfd_mfma16x16x32_bf16(es1.lo, c1h, c);
-            sn = cfd_mfma16x16x32_bf16(os1.lo, s1h, sn);
-            c = cfd_mfma16x16x32_bf16(es1.hi, c1l, c);
-            sn = cfd_mfma16x16x32_bf16(os1.hi, s1l, sn);
-            c = cfd_mfma16x16x32_bf16(es1.hi, c1h, c);
-            sn = cfd_mfma16x16x32_bf16(os1.hi, s1h, sn);
-            c = cfd_mfma16x16x32_bf16(es.hi, c0h, c);
-            sn = cfd_mfma16x16x32_bf16(os.hi, s0h, sn);
+            const CfdTab3 c0 = cfd_tab3(s_tab3, lo), s0 = cfd_tab3(s_tab3 + TS, lo), c1 = cfd_tab3(s_tab3 + 2 * TS, lo), s1 = cfd_tab3(s_tab3 + 3 * TS, lo);
+            f32x4 c = zero, sn = zero;
+            if constexpr (AP == 2) {  // the round-3 term order (row block 1 between the terms of block 0): bit-identical results
+                c = cfd_mfma16x16x32_bf16(es.p[1], c0.p[0], c);
+                sn = cfd_mfma16x16x32_bf16(os.p[1], s0.p[0], sn);
+                c = cfd_mfma16x16x32_bf16(es.p[0], c0.p[2], c);
+                sn = cfd_mfma16x16x32_bf16(os.p[0], s0.p[2], sn);
+                c = cfd_mfma16x16x32_bf16(es1.p[0], c1.p[2], c);
+                sn = cfd_mfma16x16x32_bf16(os1.p[0], s1.p[2], sn);
+                c = cfd_mfma16x16x32_bf16(es.p[0], c0.p[1], c);
+                sn = cfd_mfma16x16x32_bf16(os.p[0], s0.p[1], sn);
+                c = cfd_mfma16x16x32_bf16(es1.p[1], c1.p[0], c);
+                sn = cfd_mfma16x16x32_bf16(os1.p[1], s1.p[0], sn);
+                c = cfd_mfma16x16x32_bf16(es1.p[0], c1.p[1], c);
+                sn = cfd_mfma16x16x32_bf16(os1.p[0], s1.p[1], sn);
+                c = cfd_mfma16x16x32_bf16(es1.p[0], c1.p[0], c);
+                sn = cfd_mfma16x16x32_bf16(os1.p[0], s1.p[0], sn);
+                c = cfd_mfma16x16x32_bf16(es.p[0], c0.p[0], c);
+                sn = cfd_mfma16x16x32_bf16(os.p[0], s0.p[0], sn);
+            } else {
+#pragma unroll
+                for (int k = 0; k < cfd_nterm(AP); ++k) {
+                    c = cfd_term<true, AP>(es, c0, k, c);
+                    sn = cfd_term<true, AP>(os, s0, k, sn);
+                    c = cfd_term<true, AP>(es1, c1, k, c);
+                    sn = cfd_term<true, AP>(os1, s1, k, sn);
+                }
+            }
             a1c[j] = c;
             a1s[j] = sn;
         }
@@ -497,25 +494,15 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_dft_fwd_g(const TA* __res
                 cv[4 + r] = 2 * h + 1 < NJ ? a1c[2 * h + 1 < NJ ? 2 * h + 1 : 0][r] : 0.f;
                 sv[4 + r] = 2 * h + 1 < NJ ? a1s[2 * h + 1 < NJ ? 2 * h + 1 : 0][r] : 0.f;
             }
-            const CfdSplit8 cs = cfd_split8(cv), ss = cfd_split8(sv);
-            const bf16x8 ch = s_tab3[(CFD_TW * (4 + h)) * 64 + lo], cl = s_tab3[(CFD_TW * (4 + h) + 1) * 64 + lo], cl2 = s_tab3[(CFD_TW * (4 + h) + 2) * 64 + lo];
-            const bf16x8 sh = s_tab3[(CFD_TW * (4 + NH + h)) * 64 + lo], sl = s_tab3[(CFD_TW * (4 + NH + h) + 1) * 64 + lo], sl2 = s_tab3[(CFD_TW * (4 + NH + h) + 2) * 64 + lo];
-            Pc = cfd_mfma16x16x32_bf16(cl2, cs.hi, Pc);
-            Ps = cfd_mfma16x16x32_bf16(sl2, cs.hi, Ps);
-            Qc = cfd_mfma16x16x32_bf16(cl2, ss.hi, Qc);
-            Qs = cfd_mfma16x16x32_bf16(sl2, ss.hi, Qs);
-            Pc = cfd_mfma16x16x32_bf16(cl, cs.hi, Pc);
-            Ps = cfd_mfma16x16x32_bf16(sl, cs.hi, Ps);
-            Qc = cfd_mfma16x16x32_bf16(cl, ss.hi, Qc);
-            Qs = cfd_mfma16x16x32_bf16(sl, ss.hi, Qs);
-            Pc = cfd_mfma16x16x32_bf16(ch, cs.lo, Pc);
-            Ps = cfd_mfma16x16x32_bf16(sh, cs.lo, Ps);
-            Qc = cfd_mfma16x16x32_bf16(ch, ss.lo, Qc);
-            Qs = cfd_mfma16x16x32_bf16(sh, ss.lo, Qs);
-            Pc = cfd_mfma16x16x32_bf16(ch, cs.hi, Pc);
-            Ps = cfd_mfma16x16x32_bf16(sh, cs.hi, Ps);
-            Qc = cfd_mfma16x16x32_bf16(ch, ss.hi, Qc);
-            Qs = cfd_mfma16x16x32_bf16(sh, ss.hi, Qs);
+            const CfdAct8<AP> cs = cfd_act_split8<AP>(cv), ss = cfd_act_split8<AP>(sv);
+            const CfdTab3 ct = cfd_tab3(s_tab3 + (CFD_TW * (4 + h)) * 64, lo), st = cfd_tab3(s_tab3 + (CFD_TW * (4 + NH + h)) * 64, lo);
+#pragma unroll
+            for (int k = 0; k < cfd_nterm(AP); ++k) {
+                Pc = cfd_term<false, AP>(cs, ct, k, Pc);
+                Ps = cfd_term<false, AP>(cs, st, k, Ps);
+                Qc = cfd_term<false, AP>(ss, ct, k, Qc);
+                Qs = cfd_term<false, AP>(ss, st, k, Qs);
+            }
         }
         // P*[r]: l = 4q + r, kap = n.  Modes -> this wave's LDS slice, then out in whole 512-byte runs
         {
@@ -546,9 +533,16 @@ static bool launch_dft_g(const cfd_plan* p, const TA* x, float* xh, int nimg, in
     int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
     if (blocks > 2 * 256) blocks = 2 * 256;  // two resident workgroups per CU; the waves stride over the images
     const size_t lds = (size_t)p->n_fwd_gv * sizeof(bf16x8) + (size_t)CFD_WAVES * CFD_DFT_OS * sizeof(float2);
-#define CFD_DFTG(NJ_, A_)                                                                                              \
-    hipLaunchKernelGGL((k_dft_fwd_g<NJ_, A_, TA>), dim3(blocks), dim3(64 * CFD_WAVES), lds, st, x, (float2*)xh,         \
+    // fp32 storage honours the act_pieces knob; the bf16-storage route keeps two pieces (its values have 8 significant bits)
+    const bool ap3 = sizeof(TA) == 4 && cfd_act_pieces() == 3;
+#define CFD_DFTG_P(NJ_, A_, P_)                                                                                        \
+    hipLaunchKernelGGL((k_dft_fwd_g<NJ_, A_, TA, P_>), dim3(blocks), dim3(64 * CFD_WAVES), lds, st, x, (float2*)xh,     \
                        (const bf16x8*)p->d_fwd_g, p->n_fwd_gv, nimg, p->H, p->W, p->m1, p->m2)
+#define CFD_DFTG(NJ_, A_)                                                             \
+    do {                                                                              \
+        if constexpr (sizeof(TA) == 4) { if (ap3) CFD_DFTG_P(NJ_, A_, 3); else CFD_DFTG_P(NJ_, A_, 2); } \
+        else CFD_DFTG_P(NJ_, A_, 2);                                                  \
+    } while (0)
 #define CFD_DFTG_A(NJ_) do { if (act) CFD_DFTG(NJ_, true); else CFD_DFTG(NJ_, false); } while (0)
     switch (p->NJG) {
         case 1: CFD_DFTG_A(1); break;
@@ -559,6 +553,7 @@ static bool launch_dft_g(const cfd_plan* p, const TA* x, float* xh, int nimg, in
     }
 #undef CFD_DFTG_A
 #undef CFD_DFTG
+#undef CFD_DFTG_P
     return true;
 }
 
@@ -574,12 +569,12 @@ static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, in
 #define CFD_DFT_CAP (3 * 256)
 #endif
             if (blocks > CFD_DFT_CAP) blocks = CFD_DFT_CAP;  // 3 resident workgroups per CU; the waves stride over the images
-            if (act)
-                hipLaunchKernelGGL((k_dft_fwd64_b3<CFD_DFT_RING, true>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
-                                   (const bf16x8*)p->d_fwd_b3, nimg, p->m1, p->m2);
-            else
-                hipLaunchKernelGGL((k_dft_fwd64_b3<CFD_DFT_RING, false>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
-                                   (const bf16x8*)p->d_fwd_b3, nimg, p->m1, p->m2);
+#define CFD_DFT64(A_, P_)                                                                                                  \
+    hipLaunchKernelGGL((k_dft_fwd64_b3<CFD_DFT_RING, A_, P_>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh, \
+                       (const bf16x8*)p->d_fwd_b3, nimg, p->m1, p->m2)
+            if (cfd_act_pieces() == 3) { if (act) CFD_DFT64(true, 3); else CFD_DFT64(false, 3); }
+            else { if (act) CFD_DFT64(true, 2); else CFD_DFT64(false, 2); }
+#undef CFD_DFT64
             CFD_LAUNCH_CHECK("cfd_spectral_dft");
             return CFD_OK;
         }
@@ -1393,39 +1388,36 @@ __device__ __forceinline__ void idft_tile(const float (&va)[2][8], const float* 
 // -- 6 + 12 bf16 MFMAs (~17 cycles) instead of 14 + 24 fp32 ones (32 cycles).  k-slot (q, v) of the K = 32 operand
 // is (k-step v, k index q) of the fp32 form, so va[mu][0..7] and the stage-A accumulators feed the A operands as they
 // are; ta3 / tb3 point at the hi vectors of this tile's / column group's table (lo = +64 vectors).
+template <int AP>
 struct IdftSplitA {
-    CfdSplit8 a[2];
+    CfdAct8<AP> a[2];
 };
-__device__ __forceinline__ IdftSplitA idft_split(const float (&va)[2][8]) {
-    IdftSplitA s;
-    s.a[0] = cfd_split8(va[0]);
-    s.a[1] = cfd_split8(va[1]);
+template <int AP>
+__device__ __forceinline__ IdftSplitA<AP> idft_split(const float (&va)[2][8]) {
+    IdftSplitA<AP> s;
+    s.a[0] = cfd_act_split8<AP>(va[0]);
+    s.a[1] = cfd_act_split8<AP>(va[1]);
     return s;
 }
-template <int NJ>
-__device__ __forceinline__ void idft_tile_b3(const IdftSplitA& sa, const bf16x8* ta3, const bf16x8* tb3, int lane,
+template <int NJ, int AP>
+__device__ __forceinline__ void idft_tile_b3(const IdftSplitA<AP>& sa, const bf16x8* ta3, const bf16x8* tb3, int lane,
                                              f32x4 (&accB)[NJ]) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const bf16x8 th = ta3[lane], tl = ta3[64 + lane], tl2 = ta3[128 + lane];
-    f32x4 accA[2];
-    accA[0] = cfd_mfma16x16x32_bf16(sa.a[0].lo, th, zero);
-    accA[1] = cfd_mfma16x16x32_bf16(sa.a[1].lo, th, zero);
-    accA[0] = cfd_mfma16x16x32_bf16(sa.a[0].hi, tl2, accA[0]);
-    accA[1] = cfd_mfma16x16x32_bf16(sa.a[1].hi, tl2, accA[1]);
-    accA[0] = cfd_mfma16x16x32_bf16(sa.a[0].hi, tl, accA[0]);
-    accA[1] = cfd_mfma16x16x32_bf16(sa.a[1].hi, tl, accA[1]);
-    accA[0] = cfd_mfma16x16x32_bf16(sa.a[0].hi, th, accA[0]);
-    accA[1] = cfd_mfma16x16x32_bf16(sa.a[1].hi, th, accA[1]);
+    const CfdTab3 ta = cfd_tab3(ta3, lane);
+    f32x4 accA[2] = {zero, zero};
+#pragma unroll
+    for (int k = 0; k < cfd_nterm(AP); ++k) {
+        accA[0] = cfd_term<true, AP>(sa.a[0], ta, k, accA[0]);
+        accA[1] = cfd_term<true, AP>(sa.a[1], ta, k, accA[1]);
+    }
     const float u[8] = {accA[0][0], accA[0][1], accA[0][2], accA[0][3], accA[1][0], accA[1][1], accA[1][2], accA[1][3]};
-    const CfdSplit8 us = cfd_split8(u);
+    const CfdAct8<AP> us = cfd_act_split8<AP>(u);
+    // (the table pieces are read where they are used: NJ x 3 resident vectors would cost the fused block kernel 48 VGPRs)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x32_bf16(us.lo, tb3[(CFD_TW * j) * 64 + lane], accB[j]);
+    for (int k = 0; k < cfd_nterm(AP); ++k)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x32_bf16(us.hi, tb3[(CFD_TW * j + 2) * 64 + lane], accB[j]);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x32_bf16(us.hi, tb3[(CFD_TW * j + 1) * 64 + lane], accB[j]);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) accB[j] = cfd_mfma16x16x32_bf16(us.hi, tb3[(CFD_TW * j) * 64 + lane], accB[j]);
+        for (int j = 0; j < NJ; ++j)
+            accB[j] = cfd_mfma16x16x32_bf16(us.p[cfd_term_a(AP, k)], tb3[(CFD_TW * j + cfd_term_t(AP, k)) * 64 + lane], accB[j]);
 }
 #define CFD_B3_TABV ((CFD_TW * 4 + CFD_TW * 4) * 64)  // 16-byte vectors of the split tables at T = 4, NJ = 4 (three pieces each)
 
@@ -1525,7 +1517,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES) void k_idft(const float* __restrict
 // TAIL: the first tail.nblk workgroups of the launch do not transform anything -- they sum the partial spectral weight
 // gradients of the preceding launch (cfd_reduce_tail, cfd_tail.h).  That reduction is a ~0.5-us job which as a kernel
 // of its own costs the ~4.5-us dispatch floor plus a launch gap; here it rides in front of the resident transform waves.
-template <int EPI, bool TAIL>
+template <int EPI, bool TAIL, int AP>
 __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __restrict__ z, const float* addend,
                                                                const float* __restrict__ aprev, float* out,
                                                                const bf16x8* __restrict__ tabs3, int nimg,
@@ -1571,7 +1563,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __res
         cfd_sched_fence();
         float va[2][8];
         idft_gather(zs0 + cur * CFD_BLK_ZS, m1, m2, SA, q, n, va);
-        const IdftSplitA sa = idft_split(va);  // once per image: the stage-A data does not depend on the row tile
+        const IdftSplitA<AP> sa = idft_split<AP>(va);  // once per image: the stage-A data does not depend on the row tile
         const size_t ibase = (size_t)img * H * W + 4 * n;
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
@@ -1585,7 +1577,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __res
             f32x4 accB[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) accB[j] = zero;
-            idft_tile_b3<NJ>(sa, s_tab3 + CFD_TW * t * 64, tb3, cfd_opaque(lane), accB);
+            idft_tile_b3<NJ, AP>(sa, s_tab3 + CFD_TW * t * 64, tb3, cfd_opaque(lane), accB);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float4 v = make_float4(accB[0][r], accB[1][r], accB[2][r], accB[3][r]);
@@ -1611,7 +1603,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __res
 // y = NJ n + j and issues 14 + 8 NJ fp32 MFMAs of 32 cycles per tile).  Persistent waves, next image's modes prefetched.
 // TA / TADD / TPREV: storage types of `out`, `addend` and `aprev` (bf16 activation storage: the forward pass writes bf16 `out` from an
 // fp32 `addend`; the backward pass of bf16-storage TRAINING writes an fp32 gradient from an fp32 addend and a bf16 `aprev`).
-template <int NJ, int EPI, typename TA, typename TADD = TA, typename TPREV = TA>
+template <int NJ, int EPI, typename TA, typename TADD, typename TPREV, int AP>
 __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_idft_g(const float* __restrict__ z, const TADD* addend,
                                                                const TPREV* __restrict__ aprev, TA* out,
                                                                const bf16x8* __restrict__ tabs3, int ntabv, int nimg, int H,
@@ -1655,7 +1647,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_idft_g(const float* __res
         cfd_sched_fence();
         float va[2][8];
         idft_gather(zs0 + cur * CFD_IDFT_ZMAX, m1, m2, SA, q, n, va);
-        const IdftSplitA sa = idft_split(va);
+        const IdftSplitA<AP> sa = idft_split<AP>(va);
         const size_t ibase = (size_t)img * H * W;
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
@@ -1673,7 +1665,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_idft_g(const float* __res
             f32x4 accB[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) accB[j] = zero;
-            idft_tile_b3<NJ>(sa, s_tab3 + CFD_TW * t * 64, tb3, cfd_opaque(lane), accB);
+            idft_tile_b3<NJ, AP>(sa, s_tab3 + CFD_TW * t * 64, tb3, cfd_opaque(lane), accB);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int xx = 16 * t + 4 * q + r;
@@ -1702,9 +1694,16 @@ static bool launch_idft_g(const cfd_plan* p, const float* z, const TADD* addend,
     int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
     if (blocks > 2 * 256) blocks = 2 * 256;
     const size_t lds = (size_t)p->n_inv_gv * sizeof(bf16x8) + (size_t)CFD_WAVES * 2 * CFD_IDFT_ZMAX * sizeof(float);
-#define CFD_IDG(NJ_, E_)                                                                                             \
-    hipLaunchKernelGGL((k_idft_g<NJ_, E_, TA, TADD, TPREV>), dim3(blocks), dim3(64 * CFD_WAVES), lds, st, z, addend, aprev, out,  \
+    constexpr bool all_f32 = sizeof(TA) == 4 && sizeof(TADD) == 4 && sizeof(TPREV) == 4;
+    const bool ap3 = all_f32 && cfd_act_pieces() == 3;
+#define CFD_IDG_P(NJ_, E_, P_)                                                                                       \
+    hipLaunchKernelGGL((k_idft_g<NJ_, E_, TA, TADD, TPREV, P_>), dim3(blocks), dim3(64 * CFD_WAVES), lds, st, z, addend, aprev, out,  \
                        (const bf16x8*)p->d_inv_g, p->n_inv_gv, nimg, p->H, p->W, p->m1, p->m2, p->T, p->SA)
+#define CFD_IDG(NJ_, E_)                                                              \
+    do {                                                                              \
+        if constexpr (all_f32) { if (ap3) CFD_IDG_P(NJ_, E_, 3); else CFD_IDG_P(NJ_, E_, 2); } \
+        else CFD_IDG_P(NJ_, E_, 2);                                                   \
+    } while (0)
 #define CFD_IDG_E(NJ_) do { if (epi == 0) CFD_IDG(NJ_, 0); else if (epi == 1) CFD_IDG(NJ_, 1); else CFD_IDG(NJ_, 2); } while (0)
     switch (p->NJG) {
         case 1: CFD_IDG_E(1); break;
@@ -1715,6 +1714,7 @@ static bool launch_idft_g(const cfd_plan* p, const float* z, const TADD* addend,
     }
 #undef CFD_IDG_E
 #undef CFD_IDG
+#undef CFD_IDG_P
     return true;
 }
 
@@ -1733,19 +1733,26 @@ static int launch_idft(const cfd_plan* p, const float* z, const float* addend, c
         if (idft64_applies(p)) {
             if (blocks > CFD_DFT_CAP) blocks = CFD_DFT_CAP;  // resident workgroups; waves stride over the images
             CfdReduceTail none{};
-#define CFD_IDFT64(E)                                                                                              \
-    hipLaunchKernelGGL((k_idft64<E, false>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, z, addend, aprev, out,      \
+            const bool ap3 = cfd_act_pieces() == 3;
+#define CFD_IDFT64_P(E, P_)                                                                                        \
+    hipLaunchKernelGGL((k_idft64<E, false, P_>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, z, addend, aprev, out,  \
                        (const bf16x8*)p->d_inv_b3, nimg, p->H, p->m1, p->m2, p->T, p->SA, p->SB, none)
+#define CFD_IDFT64(E) do { if (ap3) CFD_IDFT64_P(E, 3); else CFD_IDFT64_P(E, 2); } while (0)
             CFD_PROF_W(epi == 0 ? "k_idft" : (epi == 1 ? "k_idft_add" : "k_idft_add_dgelu"), st,
                (double)nimg * (4.0 * p->H * p->W * (1 + epi) + 16.0 * p->m1 * p->m2), (double)nimg * (8.0 * (p->m1 + 1) * p->W * p->m2 + 4.0 * p->H * p->W * p->m2));
-            if (epi == 0 && tail && tail->nblk > 0)
-                hipLaunchKernelGGL((k_idft64<0, true>), dim3(blocks + tail->nblk), dim3(64 * CFD_WAVES), 0, st, z, addend,
-                                   aprev, out, (const bf16x8*)p->d_inv_b3, nimg, p->H, p->m1, p->m2, p->T, p->SA, p->SB,
-                                   *tail);
+            if (epi == 0 && tail && tail->nblk > 0) {
+                if (ap3)
+                    hipLaunchKernelGGL((k_idft64<0, true, 3>), dim3(blocks + tail->nblk), dim3(64 * CFD_WAVES), 0, st, z, addend,
+                                       aprev, out, (const bf16x8*)p->d_inv_b3, nimg, p->H, p->m1, p->m2, p->T, p->SA, p->SB, *tail);
+                else
+                    hipLaunchKernelGGL((k_idft64<0, true, 2>), dim3(blocks + tail->nblk), dim3(64 * CFD_WAVES), 0, st, z, addend,
+                                       aprev, out, (const bf16x8*)p->d_inv_b3, nimg, p->H, p->m1, p->m2, p->T, p->SA, p->SB, *tail);
+            }
             else if (epi == 0) CFD_IDFT64(0);
             else if (epi == 1) CFD_IDFT64(1);
             else CFD_IDFT64(2);
 #undef CFD_IDFT64
+#undef CFD_IDFT64_P
             CFD_LAUNCH_CHECK("cfd_spectral_idft");
             return CFD_OK;
         }
@@ -1894,7 +1901,7 @@ extern "C" int cfd_spectral_conv2d_bwd(const cfd_plan* p, const float* gy, const
 // source chunks.  NW = 4 (one wave per SIMD) wherever the channel count allows.
 // TAIL (backward only): the first tail.nblk workgroups of the launch run the reductions of this FnoBlock's two weight
 // gradients (cfd_tail.h) instead of a batch entry -- two kernel launches less per block and backward pass.
-template <int NW, int DPW, int NCH, bool ACT, bool TRANS, bool DGELU, bool TAIL>
+template <int NW, int DPW, int NCH, bool ACT, bool TRANS, bool DGELU, bool TAIL, int AP>
 __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src, const float* __restrict__ z,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
                                                    const float* __restrict__ aprev, float* __restrict__ dst,
@@ -2017,7 +2024,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     }
     cfd_wave_lds_sync();
     const bf16x8* tb3 = s_tab3 + CFD_TW * T * 64;
-    float4 AP[2][4];  // gelu'(aprev) operands of two destination channels in flight
+    float4 APV[2][4];  // gelu'(aprev) operands of two destination channels in flight
     auto fetch_ap = [&](int t, int dd, float4 (&r)[4]) {
         const int d = wave + dd * NW;
         const float* p = aprev + ((size_t)b * Cd + (d < Cd ? d : 0)) * HW + (size_t)(16 * t + 4 * q) * W + 4 * n;
@@ -2042,14 +2049,14 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
             __syncthreads();  // chunk g visible (first pass: also tables, weights); the other buffer is free again
             if (g + 2 < G) fetch(g + 2, R[par]);
             if constexpr (DGELU) {
-                if (c == NCH - 2) fetch_ap(t, 0, AP[0]);
-                if (c == NCH - 1) fetch_ap(t, 1, AP[1]);
+                if (c == NCH - 2) fetch_ap(t, 0, APV[0]);
+                if (c == NCH - 1) fetch_ap(t, 1, APV[1]);
             }
             // inverse transform of destination channel dd = c (spread over the chunks so MFMA and VALU work interleave)
             if (c < DPW && wave + c * NW < Cd) {
                 float va[2][8];
                 idft_gather(s_z + (wave * DPW + (c < DPW ? c : 0)) * CFD_KB_ZS, m1, m2, SA, q, n, va);
-                idft_tile_b3<NJ>(idft_split(va), s_tab3 + CFD_TW * t * 64, tb3, lane, acc[c < DPW ? c : 0]);
+                idft_tile_b3<NJ, AP>(idft_split<AP>(va), s_tab3 + CFD_TW * t * 64, tb3, lane, acc[c < DPW ? c : 0]);
             }
             if constexpr (DPW > NCH) {  // more destination channels than chunks: the rest ride on the last chunk
                 if (c == NCH - 1) {
@@ -2058,7 +2065,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                         if (wave + dd * NW < Cd) {
                             float va[2][8];
                             idft_gather(s_z + (wave * DPW + dd) * CFD_KB_ZS, m1, m2, SA, q, n, va);
-                            idft_tile_b3<NJ>(idft_split(va), s_tab3 + CFD_TW * t * 64, tb3, lane, acc[dd]);
+                            idft_tile_b3<NJ, AP>(idft_split<AP>(va), s_tab3 + CFD_TW * t * 64, tb3, lane, acc[dd]);
                         }
                     }
                 }
@@ -2107,8 +2114,8 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
             float4 ap[4];
             if constexpr (DGELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ap[r] = AP[dd & 1][r];
-                if (dd + 2 < DPW) fetch_ap(t, dd + 2, AP[dd & 1]);
+                for (int r = 0; r < 4; ++r) ap[r] = APV[dd & 1][r];
+                if (dd + 2 < DPW) fetch_ap(t, dd + 2, APV[dd & 1]);
             }
             if (d < Cd) {
                 float* o = dst + ((size_t)b * Cd + d) * HW + (size_t)(16 * t + 4 * q) * W + 4 * n;
@@ -2153,13 +2160,16 @@ static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z
     int spl = 1;
     while (spl * 2 <= p->T && p->T % (spl * 2) == 0 && (long)B * spl * 2 <= 288) spl *= 2;
     const dim3 grid(B * spl + tl.nblk), block(64 * NW);
-#define CFD_BLK(A_, T_, D_, R_)                                                                                  \
-    hipLaunchKernelGGL((k_block<NW, DPW, NCH, A_, T_, D_, R_>), grid, block, 0, st, src, z, w, bias, aprev, dst, \
+    const bool ap3 = cfd_act_pieces() == 3;
+#define CFD_BLK_P(A_, T_, D_, R_, P_)                                                                                \
+    hipLaunchKernelGGL((k_block<NW, DPW, NCH, A_, T_, D_, R_, P_>), grid, block, 0, st, src, z, w, bias, aprev, dst, \
                        (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB, tl, spl)
+#define CFD_BLK(A_, T_, D_, R_) do { if (ap3) CFD_BLK_P(A_, T_, D_, R_, 3); else CFD_BLK_P(A_, T_, D_, R_, 2); } while (0)
     if (!trans) { if (act) CFD_BLK(true, false, false, false); else CFD_BLK(false, false, false, false); }
     else if (ride) { if (dgelu) CFD_BLK(false, true, true, true); else CFD_BLK(false, true, false, true); }
     else { if (dgelu) CFD_BLK(false, true, true, false); else CFD_BLK(false, true, false, false); }
 #undef CFD_BLK
+#undef CFD_BLK_P
 }
 
 // (waves, destination channels per wave, source chunks): waves*DPW >= Cd and waves*NCH >= Cs

@@ -31,6 +31,8 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
     {"conv1_mfma", "CFD_CONV1_MFMA", {-1}},      // 1 = 1x1 convolutions on the streamed matrix-pipe kernels of conv1.hip (end of round 3: parity
                                                  // green, one timing -0.8 % on the U-Net step; off by default until the full suite ran with it)
     {"side_stream", "CFD_SIDE_STREAM", {-1}},    // mask of the side-stream users (side.cpp): 1 = label energy (default), 2 = 1x1 weight gradient, 0 = none
+    {"act_pieces", "CFD_ACT_PIECES", {-1}},      // bf16 pieces of the ACTIVATION operand of the FNO contractions: 2 (default, 2^-16 per product) or 3
+                                                 // (fp32-exact class, six MFMAs per product; cfd_common.h)
 };
 std::once_flag g_once;
 void read_env() {
@@ -44,6 +46,8 @@ int cfd_tune_get(int which) {
     std::call_once(g_once, read_env);
     return g_knobs[which].value.load(std::memory_order_relaxed);
 }
+
+int cfd_act_pieces() { return cfd_tune_get(CFD_TUNE_ACT_PIECES) == 3 ? 3 : 2; }
 
 extern "C" int cfd_tune_set(const char* name, int value) {
     CFD_REQUIRE(name != nullptr, CFD_ERR_INVALID_ARG, "cfd_tune_set: NULL name");

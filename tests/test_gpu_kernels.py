@@ -354,3 +354,28 @@ def test_backward_phase_argument_checks(be):
                             None, None, None, phase, be.stream)
     finally:
         be.api.plan_destroy(plan)
+
+
+# fp32-exact class: every contraction kernel with the activation operand in THREE bf16 pieces (act_pieces = 3, cfd_common.h)
+EXACT_TOL = 2e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(64, 64), (66, 65)])
+def test_three_piece_activations_spectral_and_block(be, H, W):
+    """act_pieces = 3: six-MFMA products in the transforms, the fused FnoBlock / its two-pass form and the 1x1 kernels hold the
+    fp64 oracle to fp32 round-off (the default two-piece route: ~2e-11 .. 5e-11)."""
+    with K.tuned(be, act_pieces=3):
+        _assert_all(K.check_spectral(be, 2, 20 if W == 64 else 5, 20 if W == 64 else 5, H, W), EXACT_TOL)
+        _assert_all(K.check_block(be, 1, 20, 20, H, W), EXACT_TOL)
+        _assert_all(K.check_chanmix(be, 2, 20, 20, H * W, 1), EXACT_TOL)
+        _assert_all(K.check_idft_epilogues(be, 3, H, W), EXACT_TOL)
+
+
+@pytest.mark.gpu
+def test_three_piece_activations_whole_model(be):
+    """The whole model on the act_pieces = 3 route: what is left is the projection head's two-piece fc1 (preds ~1e-12)."""
+    with K.tuned(be, act_pieces=3):
+        res = K.check_fno_vs_oracle(be, 2, 20, 2, 64, 64)
+        assert res.pop("nmse_loss") < 1e-5  # a ratio of fp32 sums
+        _assert_all(res, 1e-10)
