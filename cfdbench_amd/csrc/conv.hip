@@ -245,7 +245,7 @@ extern "C" int cfd_conv2d_fwd_ex(const float* in, const float* w, const float* b
                2.0 * B * H * W * (double)Co * Ci * ks * ks);
     if (ws && cfd_conv6_covers(g, false))
         return cfd_conv6_run(in, w, bias, out, ws, g, false, nullptr, nullptr, (hipStream_t)stream, "cfd_conv2d_fwd", stats, wfrag);
-    if (ks == 1 && cfd_tune_get(CFD_TUNE_CONV1_MFMA) == 1 && cfd_conv1_covers(B, Ci, Co, H * W))
+    if (ks == 1 && cfd_tune_get(CFD_TUNE_CONV1_MFMA) != 0 && cfd_conv1_covers(B, Ci, Co, H * W))
         return cfd_conv1_fwd(in, w, bias, out, B, Ci, Co, H * W, (hipStream_t)stream, "cfd_conv2d_fwd");
     return launch_conv_gather<false>(in, w, bias, out, g, (hipStream_t)stream, "cfd_conv2d_fwd");
 }
@@ -543,7 +543,7 @@ extern "C" int cfd_conv2d_bwd_ex(const float* gout, const float* in, const float
     hipStream_t st = (hipStream_t)stream;
     const ConvGeom g{B, Ci, Co, H, W, ks};
     const int HW = H * W, pad = ks / 2;
-    if (ks == 1 && cfd_tune_get(CFD_TUNE_CONV1_MFMA) == 1 && cfd_conv1_covers(B, Ci, Co, HW)) {  // conv1.hip: no extended grid, no fold
+    if (ks == 1 && cfd_tune_get(CFD_TUNE_CONV1_MFMA) != 0 && cfd_conv1_covers(B, Ci, Co, HW)) {  // conv1.hip: no extended grid, no fold
         if (gin) {
             CFD_PROF_W("k_conv_dgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci), 2.0 * B * HW * (double)Co * Ci);
             CFD_TRY(cfd_conv1_dgrad(gout, w, gin, B, Ci, Co, HW, st, "cfd_conv2d_bwd(dgrad)"));

@@ -288,7 +288,85 @@ extern "C" int cfd_act_bwd(const float* gy, const float* y, const float* x, floa
     return CFD_OK;
 }
 
-// out[n] = sum_m g[m][n]: one wave per column, lanes stride over rows, fixed shuffle tree (deterministic)
+// out[n] = sum_m g[m][n] (bias gradient of a Linear layer), two deterministic stages.  Stage 1: workgroup c of `nchunk` owns rows
+// [c * rpc, (c+1) * rpc); its 256 threads are 4 row groups x 64 column lanes, so a wave reads 64 consecutive columns of one row
+// (round 3's kernel gave each LANE its own row: 64 cache lines per load instruction -- 544 us for the 256 000 x 100 trunk
+// activations of the non-autoregressive DeepONet, half of its train step); a thread keeps ceil(N / 64) <= 8 running sums, the four
+// row groups meet in LDS.  Stage 2: one thread per column adds the nchunk partial rows in order.
+#define CFD_COLSUM_MAXCHUNK 512
+static int colsum_chunks(int M) {
+    long c = ((long)M + 63) / 64;  // >= 64 rows per workgroup
+    return (int)(c < 1 ? 1 : (c > CFD_COLSUM_MAXCHUNK ? CFD_COLSUM_MAXCHUNK : c));
+}
+__global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ g, float* __restrict__ part, int M, int N, int rpc) {
+    __shared__ float s_p[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * rpc, r1 = r0 + rpc < M ? r0 + rpc : M;
+    for (int c0 = 0; c0 < N; c0 += 512) {  // N <= 512 in every model of the benchmark: one pass
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int nk = (N - c0 + 63) / 64 < 8 ? (N - c0 + 63) / 64 : 8;  // live column groups of this pass (uniform)
+        int m = r0 + ty;
+        // eight rows per trip: all of a trip's loads are issued before the first add (one row per trip left ~2 loads in flight per
+        // wave: 290 us for 102 MB); rows are added in row order, so the sum does not depend on the trip structure
+        for (; m + 28 < r1; m += 32) {
+            float v[8][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < nk) { const int c = c0 + 64 * k + tx; v[j][k] = c < N ? g[(size_t)(m + 4 * j) * N + c] : 0.f; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < nk) acc[k] += v[j][k];
+        }
+        for (; m < r1; m += 4) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = c0 + 64 * k + tx;
+                if (k < nk && c < N) acc[k] += g[(size_t)m * N + c];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (c0 + 64 * k >= N) break;  // uniform
+            __syncthreads();
+            s_p[ty][tx] = acc[k];
+            __syncthreads();
+            const int c = c0 + 64 * k + tx;
+            if (ty == 0 && c < N) part[(size_t)blockIdx.x * N + c] = (s_p[0][tx] + s_p[1][tx]) + (s_p[2][tx] + s_p[3][tx]);
+        }
+    }
+}
+// stage 2: workgroup = 64 columns x 16 chunk groups; a thread adds chunks ty, ty + 16, ... (eight loads in flight), the 16 groups meet
+// in LDS in a fixed order.  (One thread per column walking 1024 partial rows one dependent load at a time took ~250 us.)
+__global__ __launch_bounds__(1024) void k_colsum_final(const float* __restrict__ part, float* __restrict__ out, int nchunk, int N) {
+    __shared__ float s_p[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (c < N) {
+        int k = ty;
+        for (; k + 7 * 16 < nchunk; k += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(k + 16 * j) * N + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; k < nchunk; k += 16) s += part[(size_t)k * N + c];
+    }
+    s_p[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += s_p[j][tx];
+        out[c] = t;
+    }
+}
+// small matrices: one wave per column, lanes stride over rows, fixed shuffle tree (one launch, no workspace)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, float* __restrict__ out, int M, int N) {
     const int lane = threadIdx.x & 63, col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= N) return;
@@ -297,12 +375,13 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, flo
     s = cfd_wave_sum(s);
     if (lane == 0) out[col] = s;
 }
+static size_t colsum_ws_bytes(int M, int N) { return M >= 2048 ? cfd_align_up((size_t)colsum_chunks(M) * N * sizeof(float), 256) : 0; }
 
 extern "C" size_t cfd_linear_bwd_workspace_bytes(int M, int K, int N) {
     if (M <= 0) return 0;
     const size_t gz = cfd_align_up((size_t)M * N * sizeof(float), 256);
     const size_t a = gemm_ws_bytes(M, K, N), b = gemm_ws_bytes(N, K, M);  // input gradient, weight gradient
-    return gz + (a > b ? a : b);
+    return gz + (a > b ? a : b) + colsum_ws_bytes(M, N);  // + the bias gradient's partial rows (behind the GEMM workspace)
 }
 
 // gx (M,K) = gz w;  gw (N,K) = gz^T x;  gb (N) = column sums of gz;  gz = gy * act'.  gx / gb may be NULL.
@@ -329,7 +408,16 @@ extern "C" int cfd_linear_bwd(const float* gy, const float* x, const float* w, c
     if (gx) CFD_TRY(launch_gemm(gz, w, gx, M, K, N, N, K, K, 0, 0, epi, skws, st, "cfd_linear_bwd(gx)"));
     CFD_TRY(launch_gemm(gz, x, gw, N, K, M, N, K, K, 1, 0, epi, skws, st, "cfd_linear_bwd(gw)"));
     if (gb) {
-        hipLaunchKernelGGL(k_colsum, dim3((N + 3) / 4), dim3(256), 0, st, gz, gb, M, N);
+        if (colsum_ws_bytes(M, N)) {
+            const size_t a = gemm_ws_bytes(M, K, N), b = gemm_ws_bytes(N, K, M);
+            float* part = (float*)((char*)skws + (a > b ? a : b));
+            const int nchunk = colsum_chunks(M), rpc = (M + nchunk - 1) / nchunk;
+            CFD_PROF_W("k_colsum", st, 4.0 * M * (double)N, (double)M * N);
+            hipLaunchKernelGGL(k_colsum_part, dim3(nchunk), dim3(256), 0, st, gz, part, M, N, rpc);
+            hipLaunchKernelGGL(k_colsum_final, dim3((N + 63) / 64), dim3(1024), 0, st, (const float*)part, gb, (M + rpc - 1) / rpc, N);
+        } else {
+            hipLaunchKernelGGL(k_colsum, dim3((N + 3) / 4), dim3(256), 0, st, gz, gb, M, N);
+        }
         CFD_LAUNCH_CHECK("cfd_linear_bwd(gb)");
     }
     return CFD_OK;
@@ -416,57 +504,111 @@ extern "C" int cfd_deeponet_inner_bwd(const float* gpreds, const float* branch, 
 // NormAct  (src/models/act_fn.py:21-47): per sample (everything but dim 0), x^ = (x - mean) / std (unbiased std, no eps),
 // y = act(x^) * std + mean.  One workgroup per sample; statistics in two passes (mean, then centred sum of squares).
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float block_sum_256(float v, float* s_r) {
+// (round 4) 1024 threads per sample, 16-byte loads with four in flight per thread, statistics in ONE pass: sums of (x - K) and
+// (x - K)^2 around K = the mean of the sample's first <= 1024 values (within a few percent of a standard deviation of the true
+// mean, so sum (x-K)^2 - (sum (x-K))^2 / L loses no digits).  Round 3's kernels walked a 400-KB sample three times with 256 threads
+// and one 4-byte load per loop trip: 165 / 197 us per launch at the non-autoregressive DeepONet's 256 x (1000 x 100) trunk activations
+// (1.2 TB/s), a quarter of its train step.
+#define NA_T 1024
+__device__ __forceinline__ float block_sum_na(float v, float* s_r) {
     v = cfd_wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) s_r[threadIdx.x >> 6] = v;
     __syncthreads();
-    return (s_r[0] + s_r[1]) + (s_r[2] + s_r[3]);
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NA_T / 64; ++w) t += s_r[w];
+    return t;
+}
+// f(x_i) for i in this thread's share of [0, L): four float4 loads in flight when the sample is 16-byte aligned and L % 4 == 0
+template <typename F>
+__device__ __forceinline__ void na_for_each(const float* __restrict__ xs, long L, bool vec, F&& f) {
+    if (vec) {
+        const float4* x4 = reinterpret_cast<const float4*>(xs);
+        const long n4 = L >> 2;
+        long i = threadIdx.x;
+        for (; i + 3 * NA_T < n4; i += 4 * NA_T) {
+            const float4 a = x4[i], b = x4[i + NA_T], c = x4[i + 2 * NA_T], d = x4[i + 3 * NA_T];
+            f(4 * i, a); f(4 * (i + NA_T), b); f(4 * (i + 2 * NA_T), c); f(4 * (i + 3 * NA_T), d);
+        }
+        for (; i < n4; i += NA_T) f(4 * i, x4[i]);
+    } else {
+        for (long i = threadIdx.x; i < L; i += NA_T) f(i, make_float4(xs[i], 0.f, 0.f, 0.f));
+    }
 }
 
-__global__ __launch_bounds__(256) void k_normact_fwd(const float* __restrict__ x, float* __restrict__ y,
-                                                     float* __restrict__ stats, long L, int act) {
-    __shared__ float s_r[4];
+__global__ __launch_bounds__(NA_T) void k_normact_fwd(const float* __restrict__ x, float* __restrict__ y,
+                                                      float* __restrict__ stats, long L, int act) {
+    __shared__ float s_r[NA_T / 64];
     const float* xs = x + (size_t)blockIdx.x * L;
     float* ys = y + (size_t)blockIdx.x * L;
-    float a = 0.f;
-    for (long i = threadIdx.x; i < L; i += blockDim.x) a += xs[i];
-    const float mean = block_sum_256(a, s_r) / (float)L;
-    float q = 0.f;
-    for (long i = threadIdx.x; i < L; i += blockDim.x) { const float d = xs[i] - mean; q = fmaf(d, d, q); }
-    const float sd = sqrtf(block_sum_256(q, s_r) / (float)(L - 1));
+    const bool vec = (L & 3) == 0 && ((uintptr_t)xs & 15) == 0 && ((uintptr_t)ys & 15) == 0;
+    const long nk = L < NA_T ? L : NA_T;
+    const float K = block_sum_na((long)threadIdx.x < nk ? xs[threadIdx.x] : 0.f, s_r) / (float)nk;
+    float a = 0.f, q = 0.f;
+    if (vec) na_for_each(xs, L, true, [&](long, const float4 v) {
+        const float d0 = v.x - K, d1 = v.y - K, d2 = v.z - K, d3 = v.w - K;
+        a += (d0 + d1) + (d2 + d3);
+        q = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, q))));
+    });
+    else na_for_each(xs, L, false, [&](long, const float4 v) { const float d = v.x - K; a += d; q = fmaf(d, d, q); });
+    a = block_sum_na(a, s_r);
+    q = block_sum_na(q, s_r);
+    const float mean = K + a / (float)L;
+    float m2 = q - a * (a / (float)L);
+    m2 = m2 > 0.f ? m2 : 0.f;
+    const float sd = sqrtf(m2 / (float)(L - 1));
     const float inv = 1.0f / sd;
-    for (long i = threadIdx.x; i < L; i += blockDim.x) ys[i] = fmaf(cfd_act((xs[i] - mean) * inv, act), sd, mean);
+    if (vec) na_for_each(xs, L, true, [&](long i, const float4 v) {
+        float4 o;
+        o.x = fmaf(cfd_act((v.x - mean) * inv, act), sd, mean);
+        o.y = fmaf(cfd_act((v.y - mean) * inv, act), sd, mean);
+        o.z = fmaf(cfd_act((v.z - mean) * inv, act), sd, mean);
+        o.w = fmaf(cfd_act((v.w - mean) * inv, act), sd, mean);
+        *reinterpret_cast<float4*>(ys + i) = o;
+    });
+    else na_for_each(xs, L, false, [&](long i, const float4 v) { ys[i] = fmaf(cfd_act((v.x - mean) * inv, act), sd, mean); });
     if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = sd; }
 }
 
 // gx_i = gu_i / sd + Gmu / L + Gsd * u_i / (L - 1),  u = x^, gu = g * sd * act'(u),
 // Gmu = sum g - sum gu / sd,  Gsd = sum g * act(u) - sum gu * u / sd
-__global__ __launch_bounds__(256) void k_normact_bwd(const float* __restrict__ x, const float* __restrict__ g,
-                                                     const float* __restrict__ stats, float* __restrict__ gx, long L, int act) {
-    __shared__ float s_r[4];
+__global__ __launch_bounds__(NA_T) void k_normact_bwd(const float* __restrict__ x, const float* __restrict__ g,
+                                                      const float* __restrict__ stats, float* __restrict__ gx, long L, int act) {
+    __shared__ float s_r[NA_T / 64];
     const float* xs = x + (size_t)blockIdx.x * L;
     const float* gs = g + (size_t)blockIdx.x * L;
     float* os = gx + (size_t)blockIdx.x * L;
+    const bool vec = (L & 3) == 0 && ((uintptr_t)xs & 15) == 0 && ((uintptr_t)gs & 15) == 0 && ((uintptr_t)os & 15) == 0;
     const float mean = stats[2 * blockIdx.x], sd = stats[2 * blockIdx.x + 1], inv = 1.0f / sd;
     float s_g = 0.f, s_gu = 0.f, s_ga = 0.f, s_guu = 0.f;
-    for (long i = threadIdx.x; i < L; i += blockDim.x) {
-        const float u = (xs[i] - mean) * inv, gi = gs[i];
+    auto acc1 = [&](float xv, float gi) {
+        const float u = (xv - mean) * inv;
         const float av = cfd_act(u, act);
         const float gu = gi * sd * cfd_act_grad(av, u, act);
         s_g += gi; s_gu += gu; s_ga = fmaf(gi, av, s_ga); s_guu = fmaf(gu, u, s_guu);
-    }
-    s_g = block_sum_256(s_g, s_r);
-    s_gu = block_sum_256(s_gu, s_r);
-    s_ga = block_sum_256(s_ga, s_r);
-    s_guu = block_sum_256(s_guu, s_r);
+    };
+    if (vec) na_for_each(xs, L, true, [&](long i, const float4 v) {
+        const float4 gv = *reinterpret_cast<const float4*>(gs + i);
+        acc1(v.x, gv.x); acc1(v.y, gv.y); acc1(v.z, gv.z); acc1(v.w, gv.w);
+    });
+    else na_for_each(xs, L, false, [&](long i, const float4 v) { acc1(v.x, gs[i]); });
+    s_g = block_sum_na(s_g, s_r);
+    s_gu = block_sum_na(s_gu, s_r);
+    s_ga = block_sum_na(s_ga, s_r);
+    s_guu = block_sum_na(s_guu, s_r);
     const float Gmu = s_g - s_gu * inv, Gsd = s_ga - s_guu * inv;
     const float c0 = Gmu / (float)L, c1 = Gsd / (float)(L - 1);
-    for (long i = threadIdx.x; i < L; i += blockDim.x) {
-        const float u = (xs[i] - mean) * inv;
-        const float gu = gs[i] * sd * cfd_act_grad(cfd_act(u, act), u, act);
-        os[i] = fmaf(gu, inv, fmaf(c1, u, c0));
-    }
+    auto out1 = [&](float xv, float gi) {
+        const float u = (xv - mean) * inv;
+        const float gu = gi * sd * cfd_act_grad(cfd_act(u, act), u, act);
+        return fmaf(gu, inv, fmaf(c1, u, c0));
+    };
+    if (vec) na_for_each(xs, L, true, [&](long i, const float4 v) {
+        const float4 gv = *reinterpret_cast<const float4*>(gs + i);
+        *reinterpret_cast<float4*>(os + i) = make_float4(out1(v.x, gv.x), out1(v.y, gv.y), out1(v.z, gv.z), out1(v.w, gv.w));
+    });
+    else na_for_each(xs, L, false, [&](long i, const float4 v) { os[i] = out1(v.x, gs[i]); });
 }
 
 // y (S,L) = NormAct(x); stats (S,2) receives (mean, std) for the backward pass.  act as in cfd_linear_fwd (1..4).
@@ -475,7 +617,7 @@ extern "C" int cfd_normact_fwd(const float* x, float* y, float* stats, int S, lo
     CFD_REQUIRE(S >= 0 && L >= 2 && act >= 1 && act <= 4, CFD_ERR_INVALID_ARG, "cfd_normact_fwd: bad sizes / activation");
     if (S == 0) return CFD_OK;
     CFD_PROF_W("k_normact_fwd", (hipStream_t)stream, 8.0 * S * (double)L, 10.0 * S * (double)L);
-    hipLaunchKernelGGL(k_normact_fwd, dim3(S), dim3(256), 0, (hipStream_t)stream, x, y, stats, L, act);
+    hipLaunchKernelGGL(k_normact_fwd, dim3(S), dim3(NA_T), 0, (hipStream_t)stream, x, y, stats, L, act);
     CFD_LAUNCH_CHECK("cfd_normact_fwd");
     return CFD_OK;
 }
@@ -486,7 +628,7 @@ extern "C" int cfd_normact_bwd(const float* x, const float* gy, const float* sta
     CFD_REQUIRE(S >= 0 && L >= 2 && act >= 1 && act <= 4, CFD_ERR_INVALID_ARG, "cfd_normact_bwd: bad sizes / activation");
     if (S == 0) return CFD_OK;
     CFD_PROF_W("k_normact_bwd", (hipStream_t)stream, 12.0 * S * (double)L, 14.0 * S * (double)L);
-    hipLaunchKernelGGL(k_normact_bwd, dim3(S), dim3(256), 0, (hipStream_t)stream, x, gy, stats, gx, L, act);
+    hipLaunchKernelGGL(k_normact_bwd, dim3(S), dim3(NA_T), 0, (hipStream_t)stream, x, gy, stats, gx, L, act);
     CFD_LAUNCH_CHECK("cfd_normact_bwd");
     return CFD_OK;
 }

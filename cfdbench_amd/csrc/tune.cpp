@@ -28,8 +28,8 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
                                                  // tests: 2, so that small shapes walk several tiles per workgroup)
     {"conv6_wgrad_mul", "CFD_CONV6_WGRAD_MUL", {-1}},  // workgroups of a conv6 weight-gradient launch in units of conv6_grid (default 1)
     {"convt_mfma", "CFD_CONVT_MFMA", {-1}},      // 0 = ConvTranspose2d(2, 2) on the fp32 VALU kernels of conv.hip instead of convt6.hip
-    {"conv1_mfma", "CFD_CONV1_MFMA", {-1}},      // 1 = 1x1 convolutions on the streamed matrix-pipe kernels of conv1.hip (end of round 3: parity
-                                                 // green, one timing -0.8 % on the U-Net step; off by default until the full suite ran with it)
+    {"conv1_mfma", "CFD_CONV1_MFMA", {-1}},      // 0 = 1x1 convolutions on the general gather kernels instead of the streamed matrix-pipe kernels of conv1.hip
+                                                 // (on by default since round 4: full GPU suite green with it, U-Net step -1 %: profiles/r04c_conv1_mfma.txt)
     {"side_stream", "CFD_SIDE_STREAM", {-1}},    // mask of the side-stream users (side.cpp): 1 = label energy (default), 2 = 1x1 weight gradient, 0 = none
     {"act_pieces", "CFD_ACT_PIECES", {-1}},      // bf16 pieces of the ACTIVATION operand of the FNO contractions: 2 (default, 2^-16 per product) or 3
                                                  // (fp32-exact class, six MFMAs per product; cfd_common.h)

@@ -197,7 +197,8 @@ def test_ffn_stack(be, R, dims, act, act_last, with_gx):
     _assert_all(K.check_ffn_stack(be, R, dims, act, act_last, with_gx))
 
 
-@pytest.mark.parametrize("M,K_in,N,act", [(512, 4295, 100, "relu"), (4290, 2, 100, "relu"), (4290, 100, 100, "tanh"), (300, 100, 100, "gelu"), (129, 33, 70, "swish"), (66, 100, 16, "none")])
+@pytest.mark.parametrize("M,K_in,N,act", [(512, 4295, 100, "relu"), (4290, 2, 100, "relu"), (4290, 100, 100, "tanh"), (300, 100, 100, "gelu"), (129, 33, 70, "swish"), (66, 100, 16, "none"),
+                                          (70001, 9, 100, "relu"), (2050, 5, 530, "none")])  # two-stage bias gradient: > 1024 chunks of rows; N > 512
 def test_linear_act(be, M, K_in, N, act):
     _assert_all(K.check_linear(be, M, K_in, N, act))
 
@@ -266,11 +267,11 @@ def test_convtranspose_full_size(be, B, Ci, Co, H, W, mfma):
         _assert_all(K.check_convt(be, B, Ci, Co, H, W))
 
 
-@pytest.mark.parametrize("knob", [1, -1])
+@pytest.mark.parametrize("knob", [-1, 0])
 @pytest.mark.parametrize("B,Ci,Co,H,W", [(128, 12, 2, 64, 64), (32, 11, 64, 64, 64), (32, 64, 2, 64, 64), (3, 50, 26, 9, 24), (5, 7, 3, 6, 5)])
 def test_conv1x1_both_routes(be, B, Ci, Co, H, W, knob):
     """1x1 convolutions (U-Net OutConv, ResNet res_conv shapes + two odd ones): the streamed matrix-pipe kernels of conv1.hip
-    (conv1_mfma = 1) and the general kernels (default) against the oracle."""
+    (the default since round 4) and the general kernels (conv1_mfma = 0) against the oracle."""
     with K.tuned(be, conv1_mfma=knob):
         _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, 1))
 
