@@ -154,8 +154,9 @@ extern "C" int cfd_fno_forward_train_ex(const cfd_plan* p, const cfd_fno_shape* 
     float* z = (float*)(base + L.off_z);
     float* gA = (float*)(base + L.off_gA);
     void* scratch = base + L.off_scratch;
-    // the label's energy and the gradient coefficients: independent of the network (scratch is free until the head), so they
-    // run beside the lifting layer on the side stream and join in front of the head
+    // the label's energy and the gradient coefficients: independent of the network (scratch is free until the head); with
+    // side_stream bit 1 they run beside the lifting layer on the side stream and join in front of the head (off by default:
+    // the fork / join pair costs more than the 16 us it hides -- side.cpp)
     hipStream_t side = cfd_side_fork((hipStream_t)stream, 1);
     CFD_TRY(cfd_label_energy_coef(label, mask, sums, coef, scratch, B, s->out_chan, HW, which, upstream, side));
     CFD_TRY(cfd_int_fno_stem_fwd(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, act_buf(0), B, s->in_chan, s->n_case_params, C,

@@ -1,7 +1,10 @@
 // Fork / join onto a library-owned side stream: independent kernels of one C-ABI call run beside each other instead of in
-// launch order.  Users: the label-energy pass of the training forward (beside the lifting layer; on by default) and the 1x1-conv
-// weight gradient of a backward phase (beside the transform and the mode-domain kernel; measured no gain, off by default --
-// fno.cpp).
+// launch order.  Users: the label-energy pass of the training forward (beside the lifting layer) and the 1x1-conv weight gradient
+// of a backward phase (beside the transform and the mode-domain kernel).  BOTH ARE OFF BY DEFAULT: measured on MI355X
+// (profiles/r04a_side_stream_ab.txt) a fork / join pair costs ~25-30 us of cross-queue signalling per use -- more than the 16 us
+// of label-energy kernels it hides (step 1.146 ms off / 1.162 ms on at batch 256, 0.301 / 0.334 ms at batch 8) -- and the weight
+// gradient does run beside the mode-domain kernel but slows it from 26 to 53 us (both want the same wave slots).  The knob
+// (side_stream = mask of users) keeps the experiment reproducible.
 //
 // Semantics: cfd_side_fork(main) returns a stream on which work is ordered after everything enqueued on `main` so far;
 // cfd_side_join(main, side) orders everything enqueued on `main` afterwards behind the side stream's work.  Both are plain
@@ -48,10 +51,10 @@ Side* side_of_current_device() {
 }  // namespace
 
 // `use`: which user asks (bit 1 = label energy beside the lifting layer, bit 2 = 1x1 weight gradient beside the mode-domain
-// kernels); the side_stream knob is a mask of the enabled users, default 1.
+// kernels); the side_stream knob is a mask of the enabled users, default 0 = none (measured: profiles/r04a_side_stream_ab.txt).
 hipStream_t cfd_side_fork(hipStream_t main, int use) {
     const int knob = cfd_tune_get(CFD_TUNE_SIDE_STREAM);
-    if ((((knob < 0) ? 1 : knob) & use) == 0 || cfd_prof_active()) return main;
+    if ((((knob < 0) ? 0 : knob) & use) == 0 || cfd_prof_active()) return main;
     std::lock_guard<std::mutex> lk(g_mu);
     Side* s = side_of_current_device();
     if (!s) return main;

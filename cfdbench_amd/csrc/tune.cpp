@@ -30,7 +30,7 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
     {"convt_mfma", "CFD_CONVT_MFMA", {-1}},      // 0 = ConvTranspose2d(2, 2) on the fp32 VALU kernels of conv.hip instead of convt6.hip
     {"conv1_mfma", "CFD_CONV1_MFMA", {-1}},      // 0 = 1x1 convolutions on the general gather kernels instead of the streamed matrix-pipe kernels of conv1.hip
                                                  // (on by default since round 4: full GPU suite green with it, U-Net step -1 %: profiles/r04c_conv1_mfma.txt)
-    {"side_stream", "CFD_SIDE_STREAM", {-1}},    // mask of the side-stream users (side.cpp): 1 = label energy (default), 2 = 1x1 weight gradient, 0 = none
+    {"side_stream", "CFD_SIDE_STREAM", {-1}},    // mask of the side-stream users (side.cpp): 1 = label energy, 2 = 1x1 weight gradient; default 0 = none (measured a net loss)
     {"act_pieces", "CFD_ACT_PIECES", {-1}},      // bf16 pieces of the ACTIVATION operand of the FNO contractions: 2 (default, 2^-16 per product) or 3
                                                  // (fp32-exact class, six MFMAs per product; cfd_common.h)
 };
