@@ -665,12 +665,13 @@ def main():
         "metric": "train frames/sec (64x64x2), Auto-FNO cavity", "value": round(fps, 1),
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (storage and accumulation; DFT / 1x1-weight-gradient / head contractions as bf16x3 split products)",
+        "vs_baseline": None, "dtype": "f32 (storage and accumulation; DFT / 1x1 / head contractions as split-bf16 products: activations in 2 pieces, fixed operands in 3, rel. 2^-16 per product; the fp32-exact-class build of the whole step is the exact_fp32 leg)",
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: Auto-FNO train step (fwd+nMSE+bwd+Adam), Fno2d(L={L},hidden={C},modes=12,p={p}), "
                                f"{H}x{W}, batch {B}/GPU, fp32, random-init weights",
-                   "precision": "fp32 storage and accumulation; DFT / 1x1-weight-gradient / head contractions as 3-term "
-                                "split-bf16 MFMA products (rel. error <= 2^-16, measured nMSE vs fp64 oracle <= 5e-11)",
+                   "precision": "fp32 storage and accumulation; DFT / 1x1-weight-gradient / head contractions as split-bf16 MFMA products "
+                                "(rel. error <= 2^-16 per product, measured nMSE vs the fp64 oracle <= 5e-11 per kernel, 3e-12 whole-model predictions); "
+                                "cfd_tune_set('act_pieces', 3) selects the fp32-exact-class build of every contraction (exact_fp32 leg)",
                    "global_batch": world * B, "parallelism": f"dp{world}", "graph": bool(args.graph)},
         "final_nmse": round(final["nmse"], 6),
     }
@@ -791,11 +792,11 @@ def main():
         try:
             result["exact_fp32"] = dict(
                 timed_route(b"act_pieces", 3),
-                what="the same step / SpectralConv2d group on the fp32-exact-class route (cfd_tune_set('act_pieces', 3)): the activation operand of every "
-                     "transform, of the fused FnoBlock's inverse transform, of the 1x1 conv and of the 1x1 weight gradient in THREE bf16 pieces against "
-                     "three-piece fixed operands, six MFMAs per product -- every term down to 2^-24, measured nMSE vs the fp64 oracle 6e-15 .. 5e-14 per "
-                     "kernel (profiles/r04b_err_act3.json); mode mixing / spectral weight gradient / channel mix inside k_block are exact fp32 FMAs on "
-                     "both routes; the projection head keeps two-piece operands (whole-model predictions 3e-12)",
+                what="the same step / SpectralConv2d group on the fp32-exact-class route (cfd_tune_set('act_pieces', 3)): EVERY contraction of the step "
+                     "-- transforms, the fused FnoBlock's inverse transform, 1x1 conv, 1x1 weight gradient, all three GEMMs of the projection head -- with "
+                     "both operands in THREE bf16 pieces and six MFMAs per product (every term down to 2^-24); mode mixing / spectral weight gradient / "
+                     "channel mix inside k_block are exact fp32 FMAs on both routes.  Measured nMSE vs the fp64 oracle: 1e-14 .. 5e-14 per kernel, whole "
+                     "model 4e-14 (predictions) / <= 2e-12 (gradients) -- profiles/r04d_err_act3.json",
                 fp32_mfma_route=dict(timed_route(b"exact_fp32", 1),
                                      what="round 1-3's exact route: every DFT / inverse DFT on v_mfma_f32_16x16x4_f32 kernels, the FnoBlock as two passes"))
         except Exception as e:  # noqa: BLE001

@@ -112,26 +112,28 @@ __device__ __forceinline__ void head_act(float (&h)[CQ][4]) {
 }
 
 // split-bf16 A-operand fragments of fc1 for z = W1 h:  frag[mt][lane=(q,i)][v] = w1[16mt+i][CQ q + v]  (v < CQ)
-__device__ __forceinline__ void head_build_w1f(bf16x8* s_hi, bf16x8* s_lo, const float* __restrict__ w1, int C, int CQ) {
+// AP pieces per value (cfd_common.h: 2 = the default split products, 3 = fp32-exact class); piece p of fragment idx at s_w[p * HEAD_MT * 64 + idx]
+template <int AP>
+__device__ __forceinline__ void head_build_w1f(bf16x8* s_w, const float* __restrict__ w1, int C, int CQ) {
     for (int idx = threadIdx.x; idx < HEAD_MT * 64; idx += blockDim.x) {
         const int ln = idx & 63, mt = idx >> 6;
         const int jh = 16 * mt + (ln & 15), c0 = CQ * (ln >> 4);
         float x[8];
 #pragma unroll
         for (int v = 0; v < 8; ++v) x[v] = (v < CQ && c0 + v < C) ? w1[jh * C + c0 + v] : 0.f;
-        const CfdSplit8 s = cfd_split8(x);
-        s_hi[idx] = s.hi;
-        s_lo[idx] = s.lo;
+        const CfdAct8<AP> s = cfd_act_split8<AP>(x);
+#pragma unroll
+        for (int pc = 0; pc < AP; ++pc) s_w[pc * HEAD_MT * 64 + idx] = s.p[pc];
     }
 }
 
-template <int CQ, bool VEC4, bool ACT, typename TA = float>
+template <int CQ, bool VEC4, bool ACT, typename TA, int AP>
 __global__ __launch_bounds__(256, CQ == 8 ? CFD_HF_OCC8 : 3) void k_head_fwd(const TA* __restrict__ a, const float* __restrict__ mask,
                                                   const float* __restrict__ label, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                                   const float* __restrict__ b2, float* __restrict__ preds,
                                                   float* __restrict__ part, int B, int C, int Co, int HW) {
-    __shared__ bf16x8 s_w1hi[HEAD_MT * 64], s_w1lo[HEAD_MT * 64];
+    __shared__ bf16x8 s_w1[AP * HEAD_MT * 64];  // [piece][M tile][lane]
     __shared__ __attribute__((aligned(16))) float s_b1[HEAD_HD];
     // fc2 weights by PAIRS of hidden units: a packed FMA multiplies the GELU pair (g[jh], g[jh+1]) by (w2[c][jh], w2[c][jh+1]) with
     // plain operands.  (Round 2 paired the two OUTPUTS instead and broadcast one g through the instruction's operand select,
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256, CQ == 8 ? CFD_HF_OCC8 : 3) void k_head_fwd(con
     // 48-63 -- profiles/r03_det_root_cause.md.)
     __shared__ __attribute__((aligned(16))) cfd_f2 s_w2[HEAD_HD];
     __shared__ float s_red[12];
-    head_build_w1f(s_w1hi, s_w1lo, w1, C, CQ);
+    head_build_w1f<AP>(s_w1, w1, C, CQ);
     for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x) s_b1[i] = b1[i];
     for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x)  // per PAIR of hidden units (2p, 2p+1): [w2[0][2p], w2[0][2p+1]], [w2[1][2p], w2[1][2p+1]]
         s_w2[i] = (i & 1) ? (Co > 1 ? cfd_f2{w2[HEAD_HD + i - 1], w2[HEAD_HD + i]} : cfd_f2{0.f, 0.f}) : cfd_f2{w2[i], w2[i + 1]};
@@ -201,7 +203,7 @@ CFD_UNROLL(CFD_HF_UNROLL)
             float xk[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) xk[c] = c < CQ ? h[c < CQ ? c : 0][0] : 0.f;
-            const CfdSplit8 bs = cfd_split8(xk);
+            const CfdAct8<AP> bs = cfd_act_split8<AP>(xk);
             f32x4 z[HEAD_MT];
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt) {
@@ -209,14 +211,16 @@ CFD_UNROLL(CFD_HF_UNROLL)
                 const float4 bq = *reinterpret_cast<const float4*>(s_b1 + jb);  // one ds_read_b128 (16-byte aligned)
                 z[mt] = f32x4{bq.x, bq.y, bq.z, bq.w};
             }
-            // z += W1 h as w_lo*h_hi + w_hi*h_lo + w_hi*h_hi, strictly term-major: consecutive MFMAs hit different accumulators
+            // z += W1 h, both operands in AP pieces (2: w_lo*h_hi + w_hi*h_lo + w_hi*h_hi; 3: the six products of cfd_mfma_bf16x6),
+            // strictly term-major: consecutive MFMAs hit different accumulators
 #pragma unroll
-            for (int mt = 0; mt < HEAD_MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(s_w1lo[mt * 64 + lo], bs.hi, z[mt]);
+            for (int k = 0; k < cfd_nterm_aa(AP); ++k) {
+                if (AP == 2 && k == 2) cfd_sched_fence();
 #pragma unroll
-            for (int mt = 0; mt < HEAD_MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(s_w1hi[mt * 64 + lo], bs.lo, z[mt]);
-            cfd_sched_fence();
-#pragma unroll
-            for (int mt = 0; mt < HEAD_MT; ++mt) z[mt] = cfd_mfma16x16x32_bf16(s_w1hi[mt * 64 + cfd_opaque(lo)], bs.hi, z[mt]);
+                for (int mt = 0; mt < HEAD_MT; ++mt)
+                    z[mt] = cfd_mfma16x16x32_bf16(s_w1[(cfd_term_aa_a(AP, k) * HEAD_MT + mt) * 64 + ((AP == 2 && k == 2) ? cfd_opaque(lo) : lo)],
+                                                  bs.p[cfd_term_aa_b(AP, k)], z[mt]);
+            }
             cfd_f2 ox = {0.f, 0.f}, oy = {0.f, 0.f};  // outputs 0 / 1, partial sums over the even / odd hidden units of this lane
 #pragma unroll
             for (int mt = 0; mt < HEAD_MT; ++mt)
@@ -320,9 +324,15 @@ int cfd_int_fno_head_fwd(const void* a_, const float* mask, const float* label, 
     const bool v4 = dt == CFD_DT_F32 && HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)preds % 16) == 0;
     {
     CFD_PROF_W("k_head_fwd", st, B * HW * ((double)cfd_dt_size(dt) * C + 4.0 * (1 + (label ? 2 : 1) * Co)), 2.0 * B * HW * (double)HEAD_HD * (C + Co));
-#define CFD_HF(Q_, V_, A_, T_)                                                                                            \
-    hipLaunchKernelGGL((k_head_fwd<Q_, V_, A_, T_>), dim3(blocks), dim3(256), 0, st, (const T_*)a_, mask, label, w1, b1, w2, \
+    const bool ap3 = dt == CFD_DT_F32 && cfd_act_pieces() == 3;  // fp32-exact-class route (bf16 storage keeps two pieces)
+#define CFD_HF_P(Q_, V_, A_, T_, P_)                                                                                      \
+    hipLaunchKernelGGL((k_head_fwd<Q_, V_, A_, T_, P_>), dim3(blocks), dim3(256), 0, st, (const T_*)a_, mask, label, w1, b1, w2, \
                        b2, preds, part, B, C, Co, HW)
+#define CFD_HF(Q_, V_, A_, T_)                                                                        \
+    do {                                                                                              \
+        if constexpr (sizeof(T_) == 4) { if (ap3) CFD_HF_P(Q_, V_, A_, T_, 3); else CFD_HF_P(Q_, V_, A_, T_, 2); } \
+        else CFD_HF_P(Q_, V_, A_, T_, 2);                                                             \
+    } while (0)
 #define CFD_HF_Q(Q_)                                         \
     do {                                                     \
         if (dt == CFD_DT_BF16) {                             \
@@ -341,6 +351,7 @@ int cfd_int_fno_head_fwd(const void* a_, const float* mask, const float* label, 
     else CFD_HF_Q(8);
 #undef CFD_HF_Q
 #undef CFD_HF
+#undef CFD_HF_P
     }
     CFD_LAUNCH_CHECK("cfd_fno_head_fwd");
     if (label) {
@@ -380,7 +391,10 @@ int cfd_int_fno_head_fwd(const void* a_, const float* mask, const float* label, 
 // they kept in registers.  `preds_w` / `b2` are used instead of `preds` / `gext`; the partial-sum block grows by
 // (sum d^2, sum |d|).
 // TA: storage type of the activations `a` (float; __bf16 in bf16-storage training, FUSE only).
-template <int KS, bool VEC4, bool ACT, bool FUSE = false, typename TA = float>
+// AP: bf16 pieces per operand value (2 = default; 3 = fp32-exact class, input planes single-buffered so that two workgroups still fit
+// a CU -- the second buffer was never needed for correctness: a tile's planes are staged between the two tile-end barriers, after
+// every wave has finished reading the previous tile's).
+template <int KS, bool VEC4, bool ACT, bool FUSE, typename TA, int AP>
 __global__ __launch_bounds__(256, 2) void k_head_bwd(
     const TA* __restrict__ a, const float* __restrict__ mask, const float* __restrict__ label,
     const float* __restrict__ preds, const float* __restrict__ gext, const float* __restrict__ coef,
@@ -392,11 +406,12 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     constexpr int LDT = 72;             // bf16 row stride of s_ht: 64 pixel columns + 8 pad (144 B)
     constexpr int LDX = 40;             // bf16 row stride of the gz^T planes: 32 pixel columns + 8 pad
     constexpr int NST = (CP * 16 + 255) / 256;  // float4 staging loads per thread and tile
-    __shared__ __attribute__((aligned(16))) __bf16 s_hk[2][2][64 * LDK];       // [buffer][hi/lo][column][channel]
+    constexpr int NBUF = AP == 3 ? 1 : 2;  // input-plane buffers (see above)
+    __shared__ __attribute__((aligned(16))) __bf16 s_hk[NBUF][AP][64 * LDK];   // [buffer][piece][column][channel]
     constexpr int HTR = CP + 1;  // rows of an s_ht plane: the CP channels + ONE zero row that every padding channel of the 16-wide
                                  // MFMA tiles reads (16 MU rows would not leave room for two workgroups per CU in the fused kernel)
-    __shared__ __attribute__((aligned(16))) __bf16 s_ht[2][2][HTR * LDT];  // [buffer][hi/lo][channel][column]
-    __shared__ __attribute__((aligned(16))) __bf16 s_x[4][2][32 * LDX];        // [wave][hi/lo][hidden][32 columns]
+    __shared__ __attribute__((aligned(16))) __bf16 s_ht[NBUF][AP][HTR * LDT];  // [buffer][piece][channel][column]
+    __shared__ __attribute__((aligned(16))) __bf16 s_x[4][AP][32 * LDX];       // [wave][piece][hidden][32 columns]
     __shared__ float4 s_red[4 * CP * 16];  // [wave][channel][16 x float4 = 64 pixels] partial d/dh
     __shared__ cfd_f2 s_gr[2][64];         // [buffer][column] upstream gradient on the raw head output, both channels
                                            // (FUSE: label * mask of both channels; the gradient is formed in the phase)
@@ -405,11 +420,10 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     __shared__ __attribute__((aligned(16))) float s_pv[2][FUSE ? 64 : 4];  // FUSE: the tile's predictions in pixel order (wave 0 only)
     const int lane = threadIdx.x & 63, wave = cfd_uniform(threadIdx.x >> 6);
     const int q = lane >> 4, n = lane & 15;
-    __bf16* s_xhw = s_x[wave][0];
-    __bf16* s_xlw = s_x[wave][1];
+    __bf16* s_xw = s_x[wave][0];  // piece pc of this wave's gz^T plane at s_xw + pc * 32 * LDX
     // ---- loop-invariant fragments of this wave's hidden slice ----
-    CfdSplit8 w1f[2];   // A operand of z = W1 h:        w1[32w + 16t + n][8q + v]
-    CfdSplit8 w1t[MU];  // A operand of d/dh = W1^T gz:  w1[32w + 16(v/4) + 4q + v%4][16mu + n]
+    CfdAct8<AP> w1f[2];   // A operand of z = W1 h:        w1[32w + 16t + n][8q + v]
+    CfdAct8<AP> w1t[MU];  // A operand of d/dh = W1^T gz:  w1[32w + 16(v/4) + 4q + v%4][16mu + n]
     float bz[2][4];                // b1 at hidden unit 32w + 16t + 4q + r
     cfd_f2 w2a[2][2], w2b[2][2];   // w2[0], w2[1] at hidden units 32w + 16t + 4q + {2v, 2v+1}
     const float c0 = label ? coef[0] : 0.f, c1 = label ? coef[1] : 0.f;
@@ -534,13 +548,25 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                 const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const __bf16 hi = (__bf16)vv[j];
-                    const __bf16 lo = (__bf16)(vv[j] - (float)hi);
                     const int col = 16 * j + n4;
-                    s_hk[buf][0][col * LDK + i] = hi;
-                    s_hk[buf][1][col * LDK + i] = lo;
-                    s_ht[buf][0][i * LDT + col] = hi;
-                    s_ht[buf][1][i * LDT + col] = lo;
+                    if constexpr (AP == 3) {  // truncating pieces: pc0 + pc1 + pc2 == the value exactly
+                        float r = vv[j];
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) {
+                            const unsigned hb = __builtin_bit_cast(unsigned, r) & 0xffff0000u;
+                            const __bf16 pv = __builtin_bit_cast(__bf16, (unsigned short)(hb >> 16));
+                            s_hk[buf][pc][col * LDK + i] = pv;
+                            s_ht[buf][pc][i * LDT + col] = pv;
+                            r -= __builtin_bit_cast(float, hb);
+                        }
+                    } else {
+                        const __bf16 hi = (__bf16)vv[j];
+                        const __bf16 lo = (__bf16)(vv[j] - (float)hi);
+                        s_hk[buf][0][col * LDK + i] = hi;
+                        s_hk[buf][1][col * LDK + i] = lo;
+                        s_ht[buf][0][i * LDT + col] = hi;
+                        s_ht[buf][1][i * LDT + col] = lo;
+                    }
                 }
             }
         }
@@ -550,15 +576,15 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     TileAt t0 = locate((int)blockIdx.x), t1 = locate((int)blockIdx.x + (int)gridDim.x);
     fetch(t0);
     fetch_gr(t0);
-    for (int i = threadIdx.x; i < 2 * 2 * 64 * LDK; i += blockDim.x) (&s_hk[0][0][0])[i] = (__bf16)0.f;
-    for (int i = threadIdx.x; i < 2 * 2 * HTR * LDT; i += blockDim.x) (&s_ht[0][0][0])[i] = (__bf16)0.f;
+    for (int i = threadIdx.x; i < NBUF * AP * 64 * LDK; i += blockDim.x) (&s_hk[0][0][0])[i] = (__bf16)0.f;
+    for (int i = threadIdx.x; i < NBUF * AP * HTR * LDT; i += blockDim.x) (&s_ht[0][0][0])[i] = (__bf16)0.f;
     {
         float x[8];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int v = 0; v < 8; ++v) x[v] = (8 * q + v < C) ? w1[(32 * wave + 16 * t + n) * C + 8 * q + v] : 0.f;
-            w1f[t] = cfd_split8(x);
+            w1f[t] = cfd_act_split8<AP>(x);
         }
 #pragma unroll
         for (int mu = 0; mu < MU; ++mu) {
@@ -567,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                 const int jh = 32 * wave + 16 * (v >> 2) + 4 * q + (v & 3);
                 x[v] = (16 * mu + n < C) ? w1[jh * C + 16 * mu + n] : 0.f;
             }
-            w1t[mu] = cfd_split8(x);
+            w1t[mu] = cfd_act_split8<AP>(x);
         }
     }
 #pragma unroll
@@ -588,48 +614,45 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     fetch_gr(t1);
     __syncthreads();
     int buf = 0;
-    for (int tile = blockIdx.x; tile < total; tile += gridDim.x, buf ^= 1) {  // all four waves walk the same tiles
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x, buf ^= (NBUF - 1)) {  // all four waves walk the same tiles
         const int b = t0.b;
         const int px0 = t0.px0;
         // The 4 pixel phases run in a ROLLED loop, which keeps the live set at one phase.
         float* s_redf = reinterpret_cast<float*>(s_red);
         const cfd_f2* grp = s_gr[buf];
-        const __bf16* hk_hi = s_hk[buf][0];
-        const __bf16* hk_lo = s_hk[buf][1];
-        const __bf16* ht_hi = s_ht[buf][0];
-        const __bf16* ht_lo = s_ht[buf][1];
+        const __bf16* hk = s_hk[buf][0];  // piece pc at + pc * 64 * LDK
+        const __bf16* ht = s_ht[buf][0];  // piece pc at + pc * HTR * LDT
         auto front = [&](int j, f32x4 (&z)[2]) {
             // 1. recompute this wave's slice of the hidden pre-activation z[hidden][pixel n]
             const int col = 16 * j + n;
-            const bf16x8 hhi = *reinterpret_cast<const bf16x8*>(hk_hi + col * LDK + 8 * q);
-            const bf16x8 hlo = *reinterpret_cast<const bf16x8*>(hk_lo + col * LDK + 8 * q);
+            bf16x8 hp[AP];
+#pragma unroll
+            for (int pc = 0; pc < AP; ++pc) hp[pc] = *reinterpret_cast<const bf16x8*>(hk + pc * 64 * LDK + col * LDK + 8 * q);
 #pragma unroll
             for (int t = 0; t < 2; ++t) z[t] = f32x4{bz[t][0], bz[t][1], bz[t][2], bz[t][3]};
 #pragma unroll
-            for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].lo, hhi, z[t]);
+            for (int k = 0; k < cfd_nterm_aa(AP); ++k)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].hi, hlo, z[t]);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].hi, hhi, z[t]);
+                for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].p[cfd_term_aa_a(AP, k)], hp[cfd_term_aa_b(AP, k)], z[t]);
         };
         auto back = [&](int j, const float (&gzv)[8]) {
-            const CfdSplit8 gs = cfd_split8(gzv);
+            const CfdAct8<AP> gs = cfd_act_split8<AP>(gzv);
             // 3. transposed gz planes of this wave: row = local hidden unit 16t + 4q + r, column 16(j&1) + n
             const int xcol = 16 * (j & 1) + n;
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
                 const int row = 16 * (v >> 2) + 4 * q + (v & 3);
-                s_xhw[row * LDX + xcol] = gs.hi[v];
-                s_xlw[row * LDX + xcol] = gs.lo[v];
+#pragma unroll
+                for (int pc = 0; pc < AP; ++pc) s_xw[pc * 32 * LDX + row * LDX + xcol] = gs.p[pc][v];
             }
             // 4. partial d/dh[channel][pixel] = sum over this wave's hidden units w1[jh][channel] gz[jh][pixel]
             f32x4 ghc[MU];
 #pragma unroll
-            for (int mu = 0; mu < MU; ++mu) ghc[mu] = cfd_mfma16x16x32_bf16(w1t[mu].lo, gs.hi, zero);
+            for (int mu = 0; mu < MU; ++mu) ghc[mu] = zero;
 #pragma unroll
-            for (int mu = 0; mu < MU; ++mu) ghc[mu] = cfd_mfma16x16x32_bf16(w1t[mu].hi, gs.lo, ghc[mu]);
+            for (int k = 0; k < cfd_nterm_aa(AP); ++k)
 #pragma unroll
-            for (int mu = 0; mu < MU; ++mu) ghc[mu] = cfd_mfma16x16x32_bf16(w1t[mu].hi, gs.hi, ghc[mu]);
+                for (int mu = 0; mu < MU; ++mu) ghc[mu] = cfd_mfma16x16x32_bf16(w1t[mu].p[cfd_term_aa_a(AP, k)], gs.p[cfd_term_aa_b(AP, k)], ghc[mu]);
             // this wave's partial d/dh of the tile: [channel][64 pixels], pixel = 4n + phase
 #pragma unroll
             for (int mu = 0; mu < MU; ++mu)
@@ -641,31 +664,26 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
             // 5. after each pair of phases: gw1[hidden][channel] += sum over 32 pixels gz[hidden][px] h[channel][px]
             if (j & 1) {
                 cfd_wave_lds_sync();
-                bf16x8 ah[2], al[2], bh[MU], bl[MU];
+                bf16x8 ap[2][AP], bp[MU][AP];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int o = (16 * t + n) * LDX + 8 * q;
-                    ah[t] = *reinterpret_cast<const bf16x8*>(s_xhw + o);
-                    al[t] = *reinterpret_cast<const bf16x8*>(s_xlw + o);
+#pragma unroll
+                    for (int pc = 0; pc < AP; ++pc) ap[t][pc] = *reinterpret_cast<const bf16x8*>(s_xw + pc * 32 * LDX + o);
                 }
 #pragma unroll
                 for (int mu = 0; mu < MU; ++mu) {
                     const int o = (16 * mu + n < CP ? 16 * mu + n : CP) * LDT + 16 * (j - 1) + 8 * q;
-                    bh[mu] = *reinterpret_cast<const bf16x8*>(ht_hi + o);
-                    bl[mu] = *reinterpret_cast<const bf16x8*>(ht_lo + o);
+#pragma unroll
+                    for (int pc = 0; pc < AP; ++pc) bp[mu][pc] = *reinterpret_cast<const bf16x8*>(ht + pc * HTR * LDT + o);
                 }
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int k = 0; k < cfd_nterm_aa(AP); ++k)
 #pragma unroll
-                    for (int mu = 0; mu < MU; ++mu) aw1[t][mu] = cfd_mfma16x16x32_bf16(al[t], bh[mu], aw1[t][mu]);
+                    for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int mu = 0; mu < MU; ++mu) aw1[t][mu] = cfd_mfma16x16x32_bf16(ah[t], bl[mu], aw1[t][mu]);
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int mu = 0; mu < MU; ++mu) aw1[t][mu] = cfd_mfma16x16x32_bf16(ah[t], bh[mu], aw1[t][mu]);
+                        for (int mu = 0; mu < MU; ++mu)
+                            aw1[t][mu] = cfd_mfma16x16x32_bf16(ap[t][cfd_term_aa_a(AP, k)], bp[mu][cfd_term_aa_b(AP, k)], aw1[t][mu]);
                 cfd_wave_lds_sync();
             }
         };
@@ -803,8 +821,8 @@ CFD_UNROLL(CFD_HB_UNROLL)
         }
         __syncthreads();
         // next tile's input planes (other buffer; its raw loads were issued one tile ago), then loads two tiles ahead
-        stage(buf ^ 1);
-        stage_gr(buf ^ 1);
+        stage(buf ^ (NBUF - 1));  // the other buffer -- or, single-buffered, the planes every wave has finished reading (barrier above)
+        stage_gr(buf ^ (NBUF - 1));
         const TileAt t2 = locate(tile + 2 * (int)gridDim.x);
         fetch(t2);
         fetch_gr(t2);
@@ -925,9 +943,11 @@ extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* 
     const bool v4 = HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)ga % 16) == 0;
     {
     CFD_PROF_W("k_head_bwd", st, 4.0 * B * HW * (2.0 * C + 1 + 2.0 * Co), 2.0 * B * HW * (double)HEAD_HD * (3.0 * C + 2.0 * Co));
-#define CFD_HB(K_, V_, A_)                                                                                         \
-    hipLaunchKernelGGL((k_head_bwd<K_, V_, A_, false>), dim3(blocks), dim3(256), 0, st, a, mask, label, preds, gpreds_ext, \
+    const bool ap3 = cfd_act_pieces() == 3;
+#define CFD_HB_P(K_, V_, A_, P_)                                                                                   \
+    hipLaunchKernelGGL((k_head_bwd<K_, V_, A_, false, float, P_>), dim3(blocks), dim3(256), 0, st, a, mask, label, preds, gpreds_ext, \
                        coef, w1, b1, w2, ga, part, B, C, Co, HW, (float*)nullptr, (const float*)nullptr)
+#define CFD_HB(K_, V_, A_) do { if (ap3) CFD_HB_P(K_, V_, A_, 3); else CFD_HB_P(K_, V_, A_, 2); } while (0)
 #define CFD_HB_VA(K_)                              \
     do {                                           \
         if (v4 && act_in) CFD_HB(K_, true, true);  \
@@ -940,6 +960,7 @@ extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* 
     else CFD_HB_VA(8);
 #undef CFD_HB_VA
 #undef CFD_HB
+#undef CFD_HB_P
     }
     CFD_LAUNCH_CHECK("cfd_fno_head_bwd");
     const int PS = (int)head_part_floats(C, Co) - 2;  // the two loss rows belong to the fused kernel
@@ -976,9 +997,15 @@ int cfd_int_fno_head_train(const void* a, const float* mask, const float* label,
     const bool v4 = HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)ga % 16) == 0 && ((uintptr_t)preds % 16) == 0;
     {
     CFD_PROF_W("k_head_train", st, B * HW * ((4.0 + cfd_dt_size(dt)) * C + 4.0 + 8.0 * Co), 2.0 * B * HW * (double)HEAD_HD * (3.0 * C + 3.0 * Co));
-#define CFD_HT(K_, V_, A_, T_)                                                                                            \
-    hipLaunchKernelGGL((k_head_bwd<K_, V_, A_, true, T_>), dim3(blocks), dim3(256), 0, st, (const T_*)a, mask, label, (const float*)nullptr, \
+    const bool ap3 = dt == CFD_DT_F32 && cfd_act_pieces() == 3;
+#define CFD_HT_P(K_, V_, A_, T_, P_)                                                                                      \
+    hipLaunchKernelGGL((k_head_bwd<K_, V_, A_, true, T_, P_>), dim3(blocks), dim3(256), 0, st, (const T_*)a, mask, label, (const float*)nullptr, \
                        (const float*)nullptr, coef, w1, b1, w2, ga, part, B, C, Co, HW, preds, b2)
+#define CFD_HT(K_, V_, A_, T_)                                                                        \
+    do {                                                                                              \
+        if constexpr (sizeof(T_) == 4) { if (ap3) CFD_HT_P(K_, V_, A_, T_, 3); else CFD_HT_P(K_, V_, A_, T_, 2); } \
+        else CFD_HT_P(K_, V_, A_, T_, 2);                                                             \
+    } while (0)
 #define CFD_HT_VA(K_)                                                     \
     do {                                                                  \
         if (dt == CFD_DT_BF16) {                                          \
@@ -996,6 +1023,7 @@ int cfd_int_fno_head_train(const void* a, const float* mask, const float* label,
     else CFD_HT_VA(8);
 #undef CFD_HT_VA
 #undef CFD_HT
+#undef CFD_HT_P
     }
     CFD_LAUNCH_CHECK("cfd_fno_head_train");
     const int PS = (int)head_part_floats(C, Co);
