@@ -8,7 +8,7 @@
 void cfd_set_error(const char* fmt, ...);
 
 // dispatch overrides (tune.cpp): environment read once per process, cfd_tune_set() afterwards; -1 = built-in choice
-enum { CFD_TUNE_MIX_NWV = 0, CFD_TUNE_WGRAD_WG, CFD_TUNE_FUSED_VARIANT, CFD_TUNE_BLOCK_FUSE, CFD_TUNE_GENERAL_B3, CFD_TUNE_HEAD_BLOCKS, CFD_TUNE_EXACT_FP32, CFD_TUNE_CONV6_GRID, CFD_TUNE_CONV6_WGRAD_MUL, CFD_TUNE_CONVT_MFMA, CFD_TUNE_CONV1_MFMA, CFD_TUNE_SIDE_STREAM, CFD_TUNE_ACT_PIECES, CFD_TUNE_COUNT };
+enum { CFD_TUNE_MIX_NWV = 0, CFD_TUNE_WGRAD_WG, CFD_TUNE_FUSED_VARIANT, CFD_TUNE_BLOCK_FUSE, CFD_TUNE_GENERAL_B3, CFD_TUNE_HEAD_BLOCKS, CFD_TUNE_EXACT_FP32, CFD_TUNE_CONV6_GRID, CFD_TUNE_CONV6_WGRAD_MUL, CFD_TUNE_CONVT_MFMA, CFD_TUNE_CONV1_MFMA, CFD_TUNE_SIDE_STREAM, CFD_TUNE_ACT_PIECES, CFD_TUNE_BLOCK_GEN, CFD_TUNE_COUNT };
 int cfd_tune_get(int which);
 
 #define CFD_REQUIRE(cond, code, ...)      \
@@ -54,6 +54,7 @@ struct CfdProfScope {
 #define CFD_PROF_W(name, st, bytes, flops) \
     CfdProfScope CFD_PROF_CAT(cfd_prof_scope_, __LINE__)(name, st, (double)(bytes), (double)(flops))
 
+#define CFD_KB_TMAX 5  // row tiles of 16 the 64-column kernels walk at most (H <= 80)
 // Operator tables of one (H,W,m1,m2); all d_* pointers are device memory, fragment-major ([step][lane]).
 struct cfd_plan {
     int H, W, m1, m2;
@@ -68,9 +69,11 @@ struct cfd_plan {
     void* d_fwd_b3; // split-bf16 forward tables for the K = 32 MFMA (NULL unless H == 64, W == 64): 16-byte vectors
                     // [table][hi|lo][64 lanes], tables T1C, T1S, T1N (stage 1: rows 4v+q | Nyquist row), T2C0, T2C1,
                     // T2S0, T2S1 (stage 2: columns 4(4q+r)+2h+jj, v = 4jj+r)
-    void* d_inv_b3; // split-bf16 form of the inverse tables for the K = 32 MFMA (NULL unless T <= 4, SA <= 8, SB <= 8,
-                    // NJ == 4): 16-byte vectors ta3[T][hi|lo][64 lanes] | tb3[NJ][hi|lo][64 lanes], element v of lane
-                    // vector = table value of k-step v (zero beyond SA / SB)
+    void* d_inv_b3; // split-bf16 form of the inverse tables for the K = 32 MFMA with the column map y = 4 n + j (NULL unless T <=
+                    // CFD_KB_TMAX, SA <= 8, SB <= 8, 64 <= W <= 68): 16-byte vectors ta3[T][piece][64 lanes] | tb3[4][piece][64
+                    // lanes], element v of lane vector = table value of k-step v (zero beyond SA / SB, beyond H / W)
+    int E;          // tail columns W - 64 of the 64-column kernels (0 when W == 64 or d_inv_b3 == NULL)
+    float* d_tail;  // [4][32] stage-B factors of the tail columns (fp32; NULL when d_inv_b3 == NULL)
     // General-width split-bf16 tables (NULL unless H <= 70 and W <= 80): columns are dealt to lanes as y = 16 j + n (tile j of
     // NJG = ceil(W/16), lane n) instead of the 64-wide kernels' y = 4 n + j, so any W works with coalesced scalar accesses.
     void* d_fwd_g;  // 16-byte vectors [table][hi|lo][64 lanes]: T1C0, T1S0 (folded rows 4v+q), T1C1, T1S1 (rows 32+4v+q), then

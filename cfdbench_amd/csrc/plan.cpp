@@ -159,15 +159,34 @@ extern "C" int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out) {
         }
     }
     // ---- split-bf16 inverse tables (K = 32 MFMA operand order: lane vector element v = k-step v) ----
+    // Built for every grid the 64-column kernels (k_idft64, k_block) can walk: W = 64 exactly, or -- round 4, the fused FnoBlock on
+    // the 66 x 65 grids of the tube / dam / cylinder problems -- 64 < W <= 68 with the columns 64 .. W-1 handled as a "tail" on the
+    // VALU (tail table below); up to 5 row tiles (H <= 80; rows past H meet zero table entries).  Column map y = 4 n + j (j < 4).
     std::vector<unsigned short> inv3;
-    if (T <= 4 && SA <= 8 && SB <= 8 && NJ == 4) {
-        inv3.assign((size_t)(CFD_TW * T + CFD_TW * NJ) * 64 * 8, 0);
+    std::vector<float> tail;  // [e = y - 64][c = 0 .. 31]: stage-B factor of U'[.][c] for tail column y (c < m2: cl cos, c - m2 < m2: -cl sin)
+    p->E = 0;
+    if (T <= CFD_KB_TMAX && SA <= 8 && SB <= 8 && W >= 64 && W <= 68) {
+        const int NJ4 = 4;
+        p->E = W - 64;
+        auto tbval = [&](int c, int y) -> double {
+            if (c >= 2 * m2 || y >= W) return 0.0;
+            const bool im = c >= m2;
+            const int l = im ? c - m2 : c;
+            const double cl = ((l == 0 || (W % 2 == 0 && l == W / 2)) ? 1.0 : 2.0) / ((double)H * W);
+            const double ph = PI2 * (double)((long)l * y % W) / W;
+            return im ? -cl * std::sin(ph) : cl * std::cos(ph);
+        };
+        inv3.assign((size_t)(CFD_TW * T + CFD_TW * NJ4) * 64 * 8, 0);
         for (int t = 0; t < T; ++t)
             for (int lane = 0; lane < 64; ++lane)
                 for (int v = 0; v < SA; ++v) put3(inv3, (size_t)(CFD_TW * t) * 64 + lane, v, ta[(t * SA + v) * 64 + lane]);
-        for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ4; ++j)
             for (int lane = 0; lane < 64; ++lane)
-                for (int v = 0; v < SB; ++v) put3(inv3, (size_t)(CFD_TW * T + CFD_TW * j) * 64 + lane, v, tb[(v * NJ + j) * 64 + lane]);
+                for (int v = 0; v < SB; ++v)  // stage B, B operand: lane (q, n): c = 4 v + q, column y = 4 n + j  (== tb[] when W == 64)
+                    put3(inv3, (size_t)(CFD_TW * T + CFD_TW * j) * 64 + lane, v, (double)(float)tbval(4 * v + (lane >> 4), NJ4 * (lane & 15) + j));
+        tail.assign(4 * 32, 0.f);
+        for (int e = 0; e < p->E; ++e)
+            for (int c = 0; c < 32; ++c) tail[e * 32 + c] = (float)tbval(c, 64 + e);
     }
 
     // ---- general-width split-bf16 tables (any W <= 80, H <= 70): y = 16 j + n column map ----
@@ -236,6 +255,8 @@ extern "C" int cfd_plan_create(int H, int W, int m1, int m2, cfd_plan** out) {
         if (hipMalloc(&p->d_inv_b3, inv3.size() * 2) != hipSuccess ||
             hipMemcpy(p->d_inv_b3, inv3.data(), inv3.size() * 2, hipMemcpyHostToDevice) != hipSuccess) rc = CFD_ERR_HIP;
     }
+    p->d_tail = nullptr;
+    if (rc == CFD_OK && !tail.empty()) rc = upload(tail, &p->d_tail);
     p->d_fwd_g = nullptr;
     p->d_inv_g = nullptr;
     if (rc == CFD_OK && !fwdg.empty()) {
@@ -263,6 +284,7 @@ extern "C" void cfd_plan_destroy(cfd_plan* p) {
     if (p->d_fwd_b3) hipFree(p->d_fwd_b3);
     if (p->d_fwd_g) hipFree(p->d_fwd_g);
     if (p->d_inv_g) hipFree(p->d_inv_g);
+    if (p->d_tail) hipFree(p->d_tail);
     hipFree(p->d_clhw);
     hipFree(p->d_gx);
     hipFree(p->d_gy);

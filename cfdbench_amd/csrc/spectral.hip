@@ -1399,9 +1399,12 @@ __device__ __forceinline__ IdftSplitA<AP> idft_split(const float (&va)[2][8]) {
     s.a[1] = cfd_act_split8<AP>(va[1]);
     return s;
 }
+// `tw` (may be NULL): fp32 stage-B factors [4][32] of the tail columns 64 .. 64+E-1 (plan.d_tail, in LDS); *tailv then receives this
+// lane's value of tail column e = lane >> 4 for row 16t + (lane & 15): the stage-A result U'[x][c] times tw[e][c], summed over c with
+// exact fp32 FMAs (a lane holds the eight c = 4 (4 mu + r) + q of its group q; the four groups of a row meet in cfd_row_sum4).
 template <int NJ, int AP>
 __device__ __forceinline__ void idft_tile_b3(const IdftSplitA<AP>& sa, const bf16x8* ta3, const bf16x8* tb3, int lane,
-                                             f32x4 (&accB)[NJ]) {
+                                             f32x4 (&accB)[NJ], const float* tw = nullptr, int E = 0, float* tailv = nullptr) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const CfdTab3 ta = cfd_tab3(ta3, lane);
     f32x4 accA[2] = {zero, zero};
@@ -1409,6 +1412,20 @@ __device__ __forceinline__ void idft_tile_b3(const IdftSplitA<AP>& sa, const bf1
     for (int k = 0; k < cfd_nterm(AP); ++k) {
         accA[0] = cfd_term<true, AP>(sa.a[0], ta, k, accA[0]);
         accA[1] = cfd_term<true, AP>(sa.a[1], ta, k, accA[1]);
+    }
+    if (tw) {
+        const int qq = lane >> 4;
+        float mine = 0.f;
+        for (int e = 0; e < E; ++e) {
+            float pe = 0.f;
+#pragma unroll
+            for (int mu = 0; mu < 2; ++mu)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pe = fmaf(accA[mu][r], tw[e * 32 + 4 * (4 * mu + r) + qq], pe);
+            pe = cfd_row_sum4(pe);
+            if (e == qq) mine = pe;
+        }
+        *tailv = mine;
     }
     const float u[8] = {accA[0][0], accA[0][1], accA[0][2], accA[0][3], accA[1][0], accA[1][1], accA[1][2], accA[1][3]};
     const CfdAct8<AP> us = cfd_act_split8<AP>(u);
@@ -1419,7 +1436,7 @@ __device__ __forceinline__ void idft_tile_b3(const IdftSplitA<AP>& sa, const bf1
         for (int j = 0; j < NJ; ++j)
             accB[j] = cfd_mfma16x16x32_bf16(us.p[cfd_term_a(AP, k)], tb3[(CFD_TW * j + cfd_term_t(AP, k)) * 64 + lane], accB[j]);
 }
-#define CFD_B3_TABV ((CFD_TW * 4 + CFD_TW * 4) * 64)  // 16-byte vectors of the split tables at T = 4, NJ = 4 (three pieces each)
+#define CFD_B3_TABV ((CFD_TW * CFD_KB_TMAX + CFD_TW * 4) * 64)  // 16-byte vectors of the split tables at T = CFD_KB_TMAX, NJ = 4 (three pieces each)
 
 #define CFD_BLK_ZS 577  // floats of one staged mode vector: 2*M (m1 = m2 = 12) + the zero slot
 #define CFD_KB_ZS 580   // the same in k_block, rounded up to whole float4s (16-byte LDS stores)
@@ -1901,12 +1918,30 @@ extern "C" int cfd_spectral_conv2d_bwd(const cfd_plan* p, const float* gy, const
 // source chunks.  NW = 4 (one wave per SIMD) wherever the channel count allows.
 // TAIL (backward only): the first tail.nblk workgroups of the launch run the reductions of this FnoBlock's two weight
 // gradients (cfd_tail.h) instead of a batch entry -- two kernel launches less per block and backward pass.
-template <int NW, int DPW, int NCH, bool ACT, bool TRANS, bool DGELU, bool TAIL, int AP>
+// GEN (round 4): any grid with 64 <= W <= 68 and H <= 80 -- the 66 x 65 grids of the tube / dam / cylinder problems.  Rows have the
+// pitch W (so a lane's four columns are a 16-byte access from a 4-byte-aligned address: cfd_f4u, measured at 94 % of the aligned
+// rate), the row tiles cover ceil(H / 16) * 16 rows with the rows past H clamped on load and masked on store, and the E = W - 64
+// tail columns ride beside the 64 MFMA columns on the VALU: their source values sit in a small LDS plane per chunk (lane n < 4 of a
+// group fetches the tail of row 4n + q), lane (q = e, i = row) accumulates the channel mix of tail column e for its row, and the
+// inverse transform's contribution comes from the stage-A accumulators (idft_tile_b3's tail sums).
+struct __attribute__((packed, aligned(4))) cfd_f4u { float x, y, z, w; };
+template <bool GEN>
+__device__ __forceinline__ float4 cfd_ldrow4(const float* p) {
+    if constexpr (GEN) { const cfd_f4u v = *reinterpret_cast<const cfd_f4u*>(p); return make_float4(v.x, v.y, v.z, v.w); }
+    else return *reinterpret_cast<const float4*>(p);
+}
+template <bool GEN>
+__device__ __forceinline__ void cfd_strow4(float* p, float4 v) {
+    if constexpr (GEN) *reinterpret_cast<cfd_f4u*>(p) = cfd_f4u{v.x, v.y, v.z, v.w};
+    else *reinterpret_cast<float4*>(p) = v;
+}
+template <int NW, int DPW, int NCH, bool ACT, bool TRANS, bool DGELU, bool TAIL, int AP, bool GEN>
 __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src, const float* __restrict__ z,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
                                                    const float* __restrict__ aprev, float* __restrict__ dst,
                                                    const bf16x8* __restrict__ tabs3, int Cs, int Cd, int H, int m1,
-                                                   int m2, int T, int SA, int SB, const CfdReduceTail tail, int SPL) {
+                                                   int m2, int T, int SA, int SB, const CfdReduceTail tail, int SPL,
+                                                   int pitch, const float* __restrict__ tailtab) {
     if (TAIL && (int)blockIdx.x < tail.nblk) {
         cfd_reduce_tail(tail, blockIdx.x);
         return;
@@ -1917,6 +1952,8 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     __shared__ bf16x8 s_tab3[CFD_B3_TABV];            // split-bf16 inverse tables: ta3 of every tile (T <= 4) | tb3
     __shared__ float s_z[NW * DPW * CFD_KB_ZS];      // kept modes of this wave's destination channels
     __shared__ float4 s_w[NW * NW * NCH * (WS / 4)];  // [wave][source channel] -> weights of the wave's DPW channels
+    __shared__ float s_tail[GEN ? 2 * NW * 16 * 4 : 4];  // GEN: [buf][channel in chunk][row][tail column e] source values
+    __shared__ float s_tw[GEN ? 4 * 32 : 4];             // GEN: stage-B factors of the tail columns (plan.d_tail)
     static_assert(NW * NCH <= 64, "one lane per source channel fills the weight table");
     static_assert(DPW <= 8, "weight-table entry holds at most 8 destination channels");
     const int lane = threadIdx.x & 63;
@@ -1926,19 +1963,30 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     // entry leaves most of the chip idle for the same ~45 us (B = 64: 44.9 us against 24.8 for the two-pass route); every
     // tile is computed exactly as in the unsplit kernel, so a sample's result does not depend on the batch size
     const int bi = TAIL ? (int)blockIdx.x - tail.nblk : (int)blockIdx.x;
-    const int b = bi / SPL, TPW = T / SPL, t0 = (bi - b * SPL) * TPW;
-    const int HW = H * W;
+    // (round 4: SPL need not divide T -- five row tiles at 66 x 65: the last workgroup of an entry takes what is left)
+    const int b = bi / SPL, TPWmax = (T + SPL - 1) / SPL, t0 = (bi - b * SPL) * TPWmax;
+    const int TPW = T - t0 < TPWmax ? T - t0 : TPWmax;  // >= 1: the launcher sizes SPL as ceil(T / TPWmax)
+    const int P = GEN ? pitch : W;  // row pitch in floats
+    const int E = GEN ? pitch - W : 0;  // tail columns
+    const int HW = H * P;
     const int M2 = 4 * m1 * m2;
     const int G = TPW * NCH;  // chunks of this workgroup's tiles, streamed tile after tile; chunk g lives in buffer g & 1
+    auto rowc = [&](int x) { return GEN ? (x < H ? x : H - 1) : x; };  // rows past H: clamped on load (their results are never stored)
     // ---- this wave's slice of a source chunk: channel ((g % NCH)*NW + wave) of tile g / NCH, rows 4k+q ----
     float4 R[2][4];
-    auto fetch = [&](int g, float4 (&r)[4]) {
+    float RT[2][GEN ? 4 : 1];  // GEN: tail values of row 4n + q (lanes n < 4), chunk parity as R
+    auto fetch = [&](int g, float4 (&r)[4], float (&rt)[GEN ? 4 : 1]) {
         const int tl = g / NCH, ch = (g - tl * NCH) * NW + wave, t = t0 + tl;
-        const float* p = src + ((size_t)b * Cs + (ch < Cs ? ch : 0)) * HW + (size_t)(16 * t + q) * W + 4 * n;
+        const float* pl = src + ((size_t)b * Cs + (ch < Cs ? ch : 0)) * HW;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = *reinterpret_cast<const float4*>(p + (size_t)4 * k * W);
+        for (int k = 0; k < 4; ++k) r[k] = cfd_ldrow4<GEN>(pl + (size_t)rowc(16 * t + q + 4 * k) * P + 4 * n);
+        if constexpr (GEN) {
+            const float* pt = pl + (size_t)rowc(16 * t + q + 4 * (n & 3)) * P + W;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rt[e] = pt[e < E ? e : 0];  // (clamped index: always inside the row)
+        }
     };
-    auto commit = [&](int c, int buf, const float4 (&r)[4]) {
+    auto commit = [&](int c, int buf, const float4 (&r)[4], const float (&rt)[GEN ? 4 : 1]) {
         const bool live = c * NW + wave < Cs;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1947,13 +1995,24 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
             if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
             s_src[((buf * NW + wave) * 16 + 4 * k + q) * 16 + n] = v;
         }
+        if constexpr (GEN) {
+            if (n < 4) {
+                float4 v = make_float4(rt[0], rt[1], rt[2], rt[3]);
+                if constexpr (ACT) cfd_gelu4(v.x, v.y, v.z, v.w);
+                if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (E < 4) v.w = 0.f;
+                if (E < 3) v.z = 0.f;
+                if (E < 2) v.y = 0.f;
+                *reinterpret_cast<float4*>(&s_tail[((buf * NW + wave) * 16 + 4 * n + q) * 4]) = v;
+            }
+        }
     };
-    fetch(0, R[0]);
-    fetch(1, R[1]);
+    fetch(0, R[0], RT[0]);
+    fetch(1, R[1], RT[1]);
     // once per batch entry: operator tables, this wave's mixing weights and kept modes.  ALL the global loads are issued
     // before the first LDS store (the first version copied table, weights and each channel's modes one after the other:
     // three to eleven dependent memory latencies, 13-18 k cycles = 13 % of the workgroup's life -- tools: CFD_BDIAG)
-    constexpr int NTV = (CFD_TW * 4 + CFD_TW * NJ) * 64;       // table vectors at T = 4 (T <= 4 is checked by the launcher)
+    constexpr int NTV = (CFD_TW * CFD_KB_TMAX + CFD_TW * NJ) * 64;  // table vectors at T = CFD_KB_TMAX (checked by the launcher)
     constexpr int TPT = (NTV + 64 * NW - 1) / (64 * NW);       // per thread
     const int ntab = (CFD_TW * T + CFD_TW * NJ) * 64;
     bf16x8 tv[TPT];
@@ -2012,6 +2071,9 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
         for (int h = 0; h < WS / 4; ++h)
             s_w[(wave * (NW * NCH) + lane) * (WS / 4) + h] = make_float4(wl[4 * h], wl[4 * h + 1], wl[4 * h + 2], wl[4 * h + 3]);
     }
+    if constexpr (GEN) {
+        if (threadIdx.x < 4 * 32) s_tw[threadIdx.x] = tailtab[threadIdx.x];
+    }
 #pragma unroll
     for (int dd = 0; dd < DPW; ++dd) {
         float4* zs = reinterpret_cast<float4*>(s_z + (wave * DPW + dd) * CFD_KB_ZS);
@@ -2027,9 +2089,9 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     float4 APV[2][4];  // gelu'(aprev) operands of two destination channels in flight
     auto fetch_ap = [&](int t, int dd, float4 (&r)[4]) {
         const int d = wave + dd * NW;
-        const float* p = aprev + ((size_t)b * Cd + (d < Cd ? d : 0)) * HW + (size_t)(16 * t + 4 * q) * W + 4 * n;
+        const float* pl = aprev + ((size_t)b * Cd + (d < Cd ? d : 0)) * HW;
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) r[r4] = *reinterpret_cast<const float4*>(p + (size_t)r4 * W);
+        for (int r4 = 0; r4 < 4; ++r4) r[r4] = cfd_ldrow4<GEN>(pl + (size_t)rowc(16 * t + 4 * q + r4) * P + 4 * n);
     };
     // One 16-row tile.  PAR = parity of the tile's first chunk index (compile time, so the prefetch registers and
     // LDS buffers are indexed statically even when NCH is odd).
@@ -2037,17 +2099,20 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
         constexpr int PAR = decltype(par_c)::value;
         const int t = t0 + tl;
         f32x4 acc[DPW][NJ];
+        float tacc[GEN ? DPW : 1], ttail[GEN ? DPW : 1];  // GEN: tail column e = q of row 16t + n: channel mix (+ bias) | inverse transform
 #pragma unroll
-        for (int dd = 0; dd < DPW; ++dd)
+        for (int dd = 0; dd < DPW; ++dd) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[dd][j] = f32x4{bv[dd], bv[dd], bv[dd], bv[dd]};
+            if constexpr (GEN) { tacc[dd] = bv[dd]; ttail[dd] = 0.f; }
+        }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int g = tl * NCH + c;
             const int par = (PAR + c) & 1;
-            commit(c, par, R[par]);
+            commit(c, par, R[par], RT[par]);
             __syncthreads();  // chunk g visible (first pass: also tables, weights); the other buffer is free again
-            if (g + 2 < G) fetch(g + 2, R[par]);
+            if (g + 2 < G) fetch(g + 2, R[par], RT[par]);
             if constexpr (DGELU) {
                 if (c == NCH - 2) fetch_ap(t, 0, APV[0]);
                 if (c == NCH - 1) fetch_ap(t, 1, APV[1]);
@@ -2056,7 +2121,8 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
             if (c < DPW && wave + c * NW < Cd) {
                 float va[2][8];
                 idft_gather(s_z + (wave * DPW + (c < DPW ? c : 0)) * CFD_KB_ZS, m1, m2, SA, q, n, va);
-                idft_tile_b3<NJ, AP>(idft_split<AP>(va), s_tab3 + CFD_TW * t * 64, tb3, lane, acc[c < DPW ? c : 0]);
+                idft_tile_b3<NJ, AP>(idft_split<AP>(va), s_tab3 + CFD_TW * t * 64, tb3, lane, acc[c < DPW ? c : 0], GEN ? s_tw : nullptr, E,
+                                     GEN ? &ttail[c < DPW ? c : 0] : nullptr);
             }
             if constexpr (DPW > NCH) {  // more destination channels than chunks: the rest ride on the last chunk
                 if (c == NCH - 1) {
@@ -2065,7 +2131,8 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                         if (wave + dd * NW < Cd) {
                             float va[2][8];
                             idft_gather(s_z + (wave * DPW + dd) * CFD_KB_ZS, m1, m2, SA, q, n, va);
-                            idft_tile_b3<NJ, AP>(idft_split<AP>(va), s_tab3 + CFD_TW * t * 64, tb3, lane, acc[dd]);
+                            idft_tile_b3<NJ, AP>(idft_split<AP>(va), s_tab3 + CFD_TW * t * 64, tb3, lane, acc[dd], GEN ? s_tw : nullptr, E,
+                                                 GEN ? &ttail[dd] : nullptr);
                         }
                     }
                 }
@@ -2100,6 +2167,11 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                             acc[dd][3][r] = fmaf(wd[dd], v[0][r].w, acc[dd][3][r]);
                         }
                     }
+                    if constexpr (GEN) {  // tail column e = q of row 16t + n, source channel sl of this chunk
+                        const float tv = s_tail[((par * NW + sl) * 16 + n) * 4 + q];
+#pragma unroll
+                        for (int dd = 0; dd < DPW; ++dd) tacc[dd] = fmaf(wd[dd], tv, tacc[dd]);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[0][r] = v[1][r];
 #pragma unroll
@@ -2118,7 +2190,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                 if (dd + 2 < DPW) fetch_ap(t, dd + 2, APV[dd & 1]);
             }
             if (d < Cd) {
-                float* o = dst + ((size_t)b * Cd + d) * HW + (size_t)(16 * t + 4 * q) * W + 4 * n;
+                float* o = dst + ((size_t)b * Cd + d) * HW + (size_t)(16 * t + 4 * q) * P + 4 * n;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float4 v = make_float4(acc[dd][0][r], acc[dd][1][r], acc[dd][2][r], acc[dd][3][r]);
@@ -2127,7 +2199,16 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                         cfd_gelu_grad4(gg.x, gg.y, gg.z, gg.w);
                         v.x *= gg.x; v.y *= gg.y; v.z *= gg.z; v.w *= gg.w;
                     }
-                    *reinterpret_cast<float4*>(o + (size_t)r * W) = v;
+                    if (!GEN || 16 * t + 4 * q + r < H) cfd_strow4<GEN>(o + (size_t)r * P, v);
+                }
+                if constexpr (GEN) {  // tail column e = q of row 16t + n
+                    const int x = 16 * t + n;
+                    if (q < E && x < H) {
+                        const size_t off = ((size_t)b * Cd + d) * HW + (size_t)x * P + W + q;
+                        float v = tacc[dd] + ttail[dd];
+                        if constexpr (DGELU) v *= cfd_gelu_grad(aprev[off]);
+                        dst[off] = v;
+                    }
                 }
             }
         }
@@ -2142,12 +2223,14 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     }
 }
 
+static bool block_is_gen(const cfd_plan* p) { return p->W != 64 || p->H % 16 != 0; }  // pitch != 64 or a ragged last row tile
 static bool block_fused_ok(const cfd_plan* p, int Cs, int Cd, const void* a, const void* b, const void* c, const void* z) {
     const int cmax = Cs > Cd ? Cs : Cd;
-    return cfd_tune_get(CFD_TUNE_EXACT_FP32) != 1 &&  // the fused kernel's inverse transform is split-bf16
-           p->W == 64 && p->H % 16 == 0 && p->NJ == 4 && p->d_inv_b3 &&  // d_inv_b3 exists for T <= 4 only (plan.cpp)
-           4 * p->m1 * p->m2 + 1 <= CFD_BLK_ZS && cmax <= 24 && ((uintptr_t)z % 16) == 0 &&  // 25 .. 32 channels: see launch_block
-           ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && (!c || ((uintptr_t)c % 16) == 0);
+    if (cfd_tune_get(CFD_TUNE_EXACT_FP32) == 1 || !p->d_inv_b3 || p->T > CFD_KB_TMAX) return false;  // (the fused kernel's inverse transform is split-bf16)
+    if (4 * p->m1 * p->m2 + 1 > CFD_BLK_ZS || cmax > 24 || ((uintptr_t)z % 16) != 0) return false;    // 25 .. 32 channels: see launch_block
+    if (block_is_gen(p))  // round 4: 64 <= W <= 68 (d_inv_b3 exists), any H <= 80; 4-byte aligned planes; built for two-piece activations
+        return cfd_tune_get(CFD_TUNE_BLOCK_GEN) != 0 && cfd_act_pieces() == 2 && p->d_tail;
+    return ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && (!c || ((uintptr_t)c % 16) == 0);
 }
 
 template <int NW, int DPW, int NCH>
@@ -2159,12 +2242,23 @@ static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z
     // one workgroup per batch entry, tiles streamed inside; below ~3/4 of the CU count the entries are split by row tiles
     int spl = 1;
     while (spl * 2 <= p->T && p->T % (spl * 2) == 0 && (long)B * spl * 2 <= 288) spl *= 2;
+    if (p->T % 2 != 0) {  // an odd tile count (five at 66 x 65): the most workgroups per entry that still fit one round, no empty ones
+        int want = 1;
+        while (want < p->T && (long)B * (want + 1) <= 288) ++want;
+        const int tpw = (p->T + want - 1) / want;
+        spl = (p->T + tpw - 1) / tpw;
+    }
     const dim3 grid(B * spl + tl.nblk), block(64 * NW);
-    const bool ap3 = cfd_act_pieces() == 3;
-#define CFD_BLK_P(A_, T_, D_, R_, P_)                                                                                \
-    hipLaunchKernelGGL((k_block<NW, DPW, NCH, A_, T_, D_, R_, P_>), grid, block, 0, st, src, z, w, bias, aprev, dst, \
-                       (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB, tl, spl)
-#define CFD_BLK(A_, T_, D_, R_) do { if (ap3) CFD_BLK_P(A_, T_, D_, R_, 3); else CFD_BLK_P(A_, T_, D_, R_, 2); } while (0)
+    const bool ap3 = cfd_act_pieces() == 3, gen = block_is_gen(p);
+#define CFD_BLK_P(A_, T_, D_, R_, P_, G_)                                                                                \
+    hipLaunchKernelGGL((k_block<NW, DPW, NCH, A_, T_, D_, R_, P_, G_>), grid, block, 0, st, src, z, w, bias, aprev, dst, \
+                       (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB, tl, spl, p->W, (const float*)p->d_tail)
+#define CFD_BLK(A_, T_, D_, R_)                                                      \
+    do {                                                                             \
+        if (gen) { if constexpr (NW != 10) CFD_BLK_P(A_, T_, D_, R_, 2, true); }  /* block_fused_ok: two pieces; launch_block: never (10,2,2) */ \
+        else if (ap3) CFD_BLK_P(A_, T_, D_, R_, 3, false);                           \
+        else CFD_BLK_P(A_, T_, D_, R_, 2, false);                                    \
+    } while (0)
     if (!trans) { if (act) CFD_BLK(true, false, false, false); else CFD_BLK(false, false, false, false); }
     else if (ride) { if (dgelu) CFD_BLK(false, true, true, true); else CFD_BLK(false, true, false, true); }
     else { if (dgelu) CFD_BLK(false, true, true, false); else CFD_BLK(false, true, false, false); }
@@ -2182,7 +2276,8 @@ static void launch_block(const cfd_plan* p, const float* src, const float* z, co
     else if (cmax <= 20) {  // measured at B=256, C=20 (us): (10,2,2) 61/73/60/97, (5,4,4) 69/79/67/82, (4,5,5) 77/84/74/83
         // round 2, same box: (8,3,3) 52.8/59.3/53.5/62.2 against 49.4/60.9/50.9/66.8 -- two waves per SIMD, 3 + 2 destination
         // channels per SIMD; (10,2,2) and (5,4,4) leave SIMDs with 3 vs 2 and 2 vs 1 waves
-        if (dgelu) launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
+        // general grids (pitch != 64, five row tiles): (10,2,2) would need 161 KB of LDS with the fifth tile's tables and the tail planes
+        if (dgelu || block_is_gen(p)) launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
         else launch_block_cfg<10, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
     }
     // 21 .. 24 channels: (8,3,3).  25 .. 32 channels run as the two passes (block_fused_ok): with the tables in three pieces

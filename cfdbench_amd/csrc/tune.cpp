@@ -33,6 +33,7 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
     {"side_stream", "CFD_SIDE_STREAM", {-1}},    // mask of the side-stream users (side.cpp): 1 = label energy, 2 = 1x1 weight gradient; default 0 = none (measured a net loss)
     {"act_pieces", "CFD_ACT_PIECES", {-1}},      // bf16 pieces of the ACTIVATION operand of the FNO contractions: 2 (default, 2^-16 per product) or 3
                                                  // (fp32-exact class, six MFMAs per product; cfd_common.h)
+    {"block_gen", "CFD_BLOCK_GEN", {-1}},        // 0 = the FnoBlock of grids other than 64-wide / H % 16 == 0 (66 x 65) as two passes instead of the fused kernel
 };
 std::once_flag g_once;
 void read_env() {

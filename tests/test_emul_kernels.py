@@ -48,9 +48,27 @@ def test_mix_and_spectral_wgrad_multi_step(be, want_wg, nwv, B, C):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 20, 20, 64, 64), (1, 6, 7, 32, 64), (1, 3, 5, 66, 65), (1, 32, 12, 32, 64), (5, 20, 20, 64, 64),
-                                            (3, 24, 21, 64, 64), (2, 20, 20, 66, 65), (3, 12, 16, 48, 64)])
+                                            (3, 24, 21, 64, 64), (2, 20, 20, 66, 65), (3, 12, 16, 48, 64),
+                                            # round 4, the general fused kernel: row pitch != 64, tail columns (E = W - 64 = 1 .. 4), a ragged
+                                            # last row tile, five row tiles; every (waves, channels) configuration
+                                            (2, 6, 7, 50, 64), (1, 20, 20, 66, 67), (1, 5, 4, 70, 68), (2, 12, 20, 80, 65), (1, 16, 9, 33, 66)])
 def test_fused_block(be, B, Cin, Cout, H, W):
     _assert_all(K.check_block(be, B, Cin, Cout, H, W))
+
+
+def test_general_fused_block_splits_entries_unevenly(be):
+    """Five row tiles at 66 x 65 do not divide: few batch entries are split over ceil(5 / tiles-per-workgroup) workgroups, and an
+    entry's result must not depend on that (290 entries: one workgroup each; 2 entries: five workgroups each)."""
+    with K.tuned(be, block_gen=1):
+        res = K.check_block_batch_split(be, 290, 2, 3, 66, 65)
+    assert res["fwd_bitwise"] == 0.0 and res["bwd_bitwise"] == 0.0, res
+
+
+def test_general_fused_block_equals_its_two_passes(be):
+    """block_gen = 0 routes the 66 x 65 FnoBlock through k_chanmix_b3 + k_idft_g; both routes hold the oracle (above) and differ from
+    each other by rounding only."""
+    with K.tuned(be, block_gen=0):
+        _assert_all(K.check_block(be, 2, 20, 20, 66, 65))
 
 
 def test_bf16_activation_storage_forward(be):

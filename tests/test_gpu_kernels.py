@@ -54,14 +54,24 @@ def test_mix_and_spectral_wgrad_kernel_routes(be, B, C, nwv, want_wg, fused):
         _assert_all(K.check_mix_wgrad(be, B, C, C))
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(5, 20, 20, 64, 64), (3, 6, 7, 32, 64), (2, 3, 5, 66, 65), (3, 32, 32, 64, 64), (2, 14, 9, 48, 64)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(5, 20, 20, 64, 64), (3, 6, 7, 32, 64), (2, 3, 5, 66, 65), (3, 32, 32, 64, 64), (2, 14, 9, 48, 64),
+                                            # round 4, the general fused kernel (pitch != 64, tail columns, ragged / five row tiles)
+                                            (7, 20, 20, 66, 65), (300, 20, 20, 66, 65), (2, 6, 7, 50, 64), (3, 20, 20, 66, 67), (2, 5, 4, 70, 68),
+                                            (2, 12, 20, 80, 65), (3, 16, 9, 33, 66), (2, 24, 24, 66, 65)])
 def test_fused_block(be, B, Cin, Cout, H, W):
     _assert_all(K.check_block(be, B, Cin, Cout, H, W))
 
 
-@pytest.mark.parametrize("Bbig,Bsmall,C,H", [(160, 7, 20, 64), (150, 40, 8, 64), (148, 100, 32, 32)])
-def test_fused_block_batch_split_is_bitwise_neutral(be, Bbig, Bsmall, C, H):
-    res = K.check_block_batch_split(be, Bbig, Bsmall, C, H, 64)
+def test_general_fused_block_equals_its_two_passes(be):
+    """block_gen = 0 routes the 66 x 65 FnoBlock through k_chanmix_b3 + k_idft_g; both routes hold the oracle."""
+    with K.tuned(be, block_gen=0):
+        _assert_all(K.check_block(be, 2, 20, 20, 66, 65))
+
+
+@pytest.mark.parametrize("Bbig,Bsmall,C,H,W", [(160, 7, 20, 64, 64), (150, 40, 8, 64, 64), (148, 100, 32, 32, 64),
+                                               (300, 64, 20, 66, 65), (300, 17, 20, 66, 65), (290, 100, 6, 50, 66)])  # five / odd tile counts: uneven splits
+def test_fused_block_batch_split_is_bitwise_neutral(be, Bbig, Bsmall, C, H, W):
+    res = K.check_block_batch_split(be, Bbig, Bsmall, C, H, W)
     assert res["fwd_bitwise"] == 0.0 and res["bwd_bitwise"] == 0.0, res
 
 

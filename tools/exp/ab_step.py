@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--hw", type=int, nargs=2, default=(64, 64))
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--prof", action="store_true", help="per-kernel HIP-event times of the first config (cfd_prof)")
     a = ap.parse_args()
     from cfdbench_amd import _lib
     from cfdbench_amd.engine import FnoTrainEngine
@@ -68,6 +69,22 @@ def main():
     for c, v in res.items():
         print(f"{c or '(defaults)':40s} best {min(v):.4f} ms  median {statistics.median(v):.4f} ms  all {[round(t, 4) for t in v]}", flush=True)
     print("nmse", eng.scores()["nmse"])
+    if a.prof:
+        import ctypes
+        apply(a.configs[0])
+        api.call("cfd_prof_begin")
+        for _ in range(10):
+            eng.train_step(x, y, cp, mask)
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 16)
+        api.call("cfd_prof_end", buf, len(buf))
+        rows = [ln.split() for ln in buf.value.decode().splitlines()]
+        tot = sum(float(r[2]) for r in rows)
+        print(f"# per-kernel times, config {a.configs[0]!r}: {tot / 10 * 1e3:.1f} us of kernels per step")
+        for r in sorted(rows, key=lambda r: -float(r[2])):
+            n = int(r[1])
+            gbs = float(r[3]) / (float(r[2]) * 1e-3) / 1e9 if float(r[2]) > 0 else 0
+            print(f"  {r[0]:22s} {n // 10:3d}/step {float(r[2]) / n * 1e3:8.2f} us  {gbs:7.0f} GB/s  {float(r[2]) / tot * 100:5.1f} %")
 
 
 if __name__ == "__main__":
