@@ -104,6 +104,16 @@ __device__ __forceinline__ float4 cfd_ld4(const __bf16* p) {
     return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
 }
 
+// Four consecutive floats from / to an address that is only 4-byte aligned, as ONE 16-byte access (global_load / store_dwordx4; gfx950
+// runs them at 94 % of the aligned rate: tools/exp/unaligned_x4.hip).  The planes of the 66 x 65 grids (4290 floats) start on 8-byte
+// boundaries and their rows on 4-byte ones; rounds 1-3 read them with 8- or 4-byte accesses.
+struct __attribute__((packed, aligned(4))) cfd_f4u { float x, y, z, w; };
+__device__ __forceinline__ float4 cfd_ld4u(const float* p) {
+    const cfd_f4u v = *reinterpret_cast<const cfd_f4u*>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void cfd_st4u(float* p, float4 v) { *reinterpret_cast<cfd_f4u*>(p) = cfd_f4u{v.x, v.y, v.z, v.w}; }
+
 // Internal (not exported) forms of the forward-path entry points with the activation storage type as an argument; dt =
 // CFD_DT_F32 is exactly the public function.  x / out / aprev / a point at activations of that type.  With bf16 storage the
 // 1x1 conv writes its (unrounded) result as fp32 and the inverse transform takes that fp32 addend, so a stored pre-activation

@@ -59,6 +59,19 @@ static int head_bwd_blocks(int B, int HW, bool knob = true) {
 template <int CQ, bool VEC4, typename TA = float>
 __device__ __forceinline__ void head_load_raw(const TA* __restrict__ a, int b, int C, int HW, int px, int q,
                                               float (&h)[CQ][4]) {
+    if constexpr (!VEC4 && sizeof(TA) == 4) {
+        // planes that are not 16-byte aligned (66 x 65): ONE branch for the lane's four pixels -- inside the plane: an unaligned
+        // 16-byte load per channel, all issued back to back; across the plane's end: clamped scalars (head_mask_raw zeroes the rest)
+        if (b >= 0 && px + 3 < HW) {
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) {
+                const int i = CQ * q + c;
+                const float4 t = cfd_ld4u(reinterpret_cast<const float*>(a) + ((size_t)b * C + (i < C ? i : C - 1)) * HW + px);
+                h[c][0] = t.x; h[c][1] = t.y; h[c][2] = t.z; h[c][3] = t.w;
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int c = 0; c < CQ; ++c) {
         h[c][0] = h[c][1] = h[c][2] = h[c][3] = 0.f;
@@ -257,6 +270,8 @@ CFD_UNROLL(CFD_HF_UNROLL)
             float* dst = preds + ((size_t)bc * Co + c) * HW + pxc;
             if constexpr (VEC4) {
                 if (pxc < HW) *reinterpret_cast<float4*>(dst) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            } else if (pxc + 3 < HW) {
+                cfd_st4u(dst, make_float4(pv[0], pv[1], pv[2], pv[3]));
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -518,6 +533,8 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                 const TA* src = a + ((size_t)b * C + i) * HW + p4;
                 if constexpr (VEC4) {
                     if (p4 < HW) v = cfd_ld4(src);
+                } else if (sizeof(TA) == 4 && p4 + 3 < HW) {
+                    v = cfd_ld4u(reinterpret_cast<const float*>(src));
                 } else {
                     if (p4 < HW) v.x = cfd_ld(src);
                     if (p4 + 1 < HW) v.y = cfd_ld(src + 1);
@@ -811,6 +828,8 @@ CFD_UNROLL(CFD_HB_UNROLL)
                 float* dstp = preds_w + ((size_t)b * Co + q) * HW + p4;
                 if constexpr (VEC4) {
                     if (p4 < HW) *reinterpret_cast<float4*>(dstp) = pv;
+                } else if (p4 + 3 < HW) {
+                    cfd_st4u(dstp, pv);
                 } else {
                     const float pvv[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
@@ -848,6 +867,12 @@ CFD_UNROLL(CFD_HB_UNROLL)
                     }
                     *reinterpret_cast<float4*>(ga + off) = v;
                 }
+            } else if (p4 + 3 < HW) {
+                if constexpr (ACT) {
+                    const float4 gg = gp_cur[k];
+                    v.x *= gg.x; v.y *= gg.y; v.z *= gg.z; v.w *= gg.w;
+                }
+                cfd_st4u(ga + off, v);
             } else {
                 const float vv[4] = {v.x, v.y, v.z, v.w};
                 const float gv[4] = {gp_cur[k].x, gp_cur[k].y, gp_cur[k].z, gp_cur[k].w};

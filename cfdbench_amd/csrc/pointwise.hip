@@ -406,6 +406,8 @@ __global__ __launch_bounds__(256, 2) void k_chanmix_b3(const TA* __restrict__ in
     };
     float hn[8][4];
     auto fetch = [&]() {
+        // (round 4: unaligned 16-byte loads were tried here for the 66 x 65 planes and measured SLOWER than the 8-byte pairs -- 29.5 vs
+        // 25.9 us at C = 32, 64 cases -- unlike in k_chan_wgrad and the head kernels, where they win)
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int i = 8 * q + c;
@@ -620,17 +622,18 @@ __device__ __forceinline__ void cfd_ld8px(const float* __restrict__ src, int px,
                 const float4 t = *reinterpret_cast<const float4*>(src + 4 * k);
                 v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
             }
-    } else if constexpr (VEC == 2) {
+    } else {  // VEC = 2 / 1 (planes not 16-byte aligned, 66 x 65): unaligned 16-byte loads, scalars across a plane's end
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (px + 2 * k < hw) {
-                const float2 t = *reinterpret_cast<const float2*>(src + 2 * k);
-                v[2 * k] = t.x; v[2 * k + 1] = t.y;
+        for (int k = 0; k < 2; ++k) {
+            if (px + 4 * k + 3 < hw) {
+                const float4 t = cfd_ld4u(src + 4 * k);
+                v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (px + 4 * k + j < hw) v[4 * k + j] = src[4 * k + j];
             }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (px + j < hw) v[j] = src[j];
+        }
     }
 }
 

@@ -1924,15 +1924,14 @@ extern "C" int cfd_spectral_conv2d_bwd(const cfd_plan* p, const float* gy, const
 // tail columns ride beside the 64 MFMA columns on the VALU: their source values sit in a small LDS plane per chunk (lane n < 4 of a
 // group fetches the tail of row 4n + q), lane (q = e, i = row) accumulates the channel mix of tail column e for its row, and the
 // inverse transform's contribution comes from the stage-A accumulators (idft_tile_b3's tail sums).
-struct __attribute__((packed, aligned(4))) cfd_f4u { float x, y, z, w; };
 template <bool GEN>
 __device__ __forceinline__ float4 cfd_ldrow4(const float* p) {
-    if constexpr (GEN) { const cfd_f4u v = *reinterpret_cast<const cfd_f4u*>(p); return make_float4(v.x, v.y, v.z, v.w); }
+    if constexpr (GEN) return cfd_ld4u(p);
     else return *reinterpret_cast<const float4*>(p);
 }
 template <bool GEN>
 __device__ __forceinline__ void cfd_strow4(float* p, float4 v) {
-    if constexpr (GEN) *reinterpret_cast<cfd_f4u*>(p) = cfd_f4u{v.x, v.y, v.z, v.w};
+    if constexpr (GEN) cfd_st4u(p, v);
     else *reinterpret_cast<float4*>(p) = v;
 }
 template <int NW, int DPW, int NCH, bool ACT, bool TRANS, bool DGELU, bool TAIL, int AP, bool GEN>
