@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle", type=int, default=30,
+                    help="untimed steps BEFORE the W warm-up steps (part of set-up, like building the model): the first ~25 steps after a cold "
+                         "start run 2-4 %% slower (clock ramp, first touch of the 1.3-GB workspace); the timed region is still exactly K steps "
+                         "after W warm-up steps, bracketed by barriers")
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (BASELINE configs[1]: 256)")
     ap.add_argument("--hidden", type=int, default=20)
     ap.add_argument("--layers", type=int, default=4)
@@ -159,8 +163,12 @@ def roofline_of(name, launches, total_ms, total_bytes, total_flops):
                 fp32_equiv_tflops=round(total_flops / t / 1e12, 2))
 
 
-def latest_profile(pattern):
-    files = sorted((REPO / "profiles").glob(pattern))
+def latest_profile(suffix):
+    """Newest profiles/r<round><letters>_<suffix> (e.g. suffix "pmc_traffic.json" = the step's counters, "unet_pmc_traffic.json" = a
+    leg's): the round tag is matched exactly, so a leg's file never passes for another leg's or for the step's."""
+    import re
+    pat = re.compile(r"^r\d+[a-z]*_" + re.escape(suffix) + "$")
+    files = sorted(f for f in (REPO / "profiles").iterdir() if pat.match(f.name))
     return (json.loads(files[-1].read_text()), files[-1]) if files else (None, None)
 
 
@@ -188,7 +196,7 @@ def attach_pmc(rl, name, applies):
         return
     try:
         sym = {"k_head_train": "k_head_bwd"}.get(name, name)  # profiler label -> kernel symbol (the fused head is k_head_bwd<.., FUSE>)
-        pmc, pf = latest_profile("r*_pmc_traffic.json")
+        pmc, pf = latest_profile("pmc_traffic.json")
         if not pmc:
             return
         tag = pf.name.split("_pmc_traffic")[0]
@@ -203,7 +211,7 @@ def attach_pmc(rl, name, applies):
         if match:
             rl["traffic"] = int(sum(m["traffic_bytes"] for m in match) / len(match))
             rl["traffic_source"] = f"profiles/{pf.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, per launch)"
-        busy, bf = latest_profile("r*_step_busy.json")
+        busy, bf = latest_profile("step_busy.json")
         match = [v for k, v in (busy or {}).items() if k.startswith(sym + "<") or k == sym]
         if match and bf.name.startswith(tag):
             rl["busy_pct"] = {k: match[0][k] for k in ("mfma", "valu", "lds", "wait") if k in match[0]}
@@ -219,12 +227,12 @@ def attach_leg_traffic(rl, leg, kernel=None):
     command / its number of group calls.  Not measured in this run -- the line names the file."""
     if not rl:
         return
-    pmc, pf = latest_profile(f"r*_{leg}_pmc_traffic.json")
+    pmc, pf = latest_profile(f"{leg}_pmc_traffic.json")
     if not pmc:
         return
     try:
         if kernel is None:
-            calls = pmc.get("k_mixadj_wgrad", {}).get("launches", 0)
+            calls = sum(v["launches"] for k, v in pmc.items() if isinstance(v, dict) and k.startswith("k_mixadj_wgrad"))  # one per group call
             if calls:
                 rl["traffic"] = int(sum(v["traffic_bytes"] * v["launches"] for k, v in pmc.items() if isinstance(v, dict) and k.startswith("k_")) / calls)
         else:
@@ -642,7 +650,7 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    for _ in range(args.settle + args.warmup):
         step(inputs, label, cp, mask)
     torch.cuda.synchronize()
     barrier()
@@ -672,7 +680,7 @@ def main():
                    "precision": "fp32 storage and accumulation; DFT / 1x1-weight-gradient / head contractions as split-bf16 MFMA products "
                                 "(rel. error <= 2^-16 per product, measured nMSE vs the fp64 oracle <= 5e-11 per kernel, 3e-12 whole-model predictions); "
                                 "cfd_tune_set('act_pieces', 3) selects the fp32-exact-class build of every contraction (exact_fp32 leg)",
-                   "global_batch": world * B, "parallelism": f"dp{world}", "graph": bool(args.graph)},
+                   "global_batch": world * B, "parallelism": f"dp{world}", "graph": bool(args.graph), "settle_steps": args.settle},
         "final_nmse": round(final["nmse"], 6),
     }
     bpf = fno_step_bytes_per_frame(C, L, H * W)
