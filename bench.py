@@ -497,10 +497,14 @@ def leg_deeponet(api, dev):
     # ideal fusion: the trunk stack runs over B*k rows whose FIRST layer input is built in-kernel from (b, p) + (k, p) rows; only the
     # (B, k) predictions / sampled labels and the parameters cross HBM
     step_bytes = 3 * 4 * (2 * B * k + (B + k) * w) + ffn_stack_bytes(0, [w] * (d + 1)) + ffn_stack_bytes(B, [5] + [w] * d)
-    leg = model_train_leg(api, "deeponet", m, batch, 10, 3, B, step_bytes / B,
+    leg = model_train_leg(api, "deeponet", m, batch, 10, 3, B, None,
                           f"DeepONet (non-autoregressive, train.py) train step: batch {B} x {k} query points, width 100, depth 8/8, NormAct, fp32")
-    fl = 3 * 2.0 * B * k * (d - 0) * w * w  # the trunk stack over B*k rows dominates: 2 * rows * w * w per layer, fwd + 2x bwd
-    leg["fp32_equiv_tflops_step"] = round(fl / (leg["ms_per_step"] * 1e-3) / 1e12, 2)
+    # the trunk stack over B*k rows dominates (2 * rows * w * w per w x w layer, forward + 2x backward); its GEMMs are exact fp32 MFMA
+    fl = 3 * 2.0 * B * k * (d - 1) * w * w
+    tf = fl / (leg["ms_per_step"] * 1e-3) / 1e12
+    leg["roofline_step"] = dict(bound="mfma", flops_per_step=fl, achieved=round(tf, 2), peak=FP32_PEAK_TF, unit="TFLOP/s", frac=round(tf / FP32_PEAK_TF, 4),
+                                pipe="fp32 MFMA (exact-fp32 GEMMs: ReLU / NormAct kinks, DESIGN.md section 4)",
+                                ideal_fusion_bytes_per_step=int(step_bytes))
     return leg
 
 
@@ -792,7 +796,7 @@ def main():
         def timed_route(knob, value):
             api.call("cfd_tune_set", knob, value)
             try:
-                dt = min(time_steps(lambda: eng.train_step(inputs, label, cp, mask), args.steps, 3) for _ in range(2))
+                dt = min(time_steps(lambda: eng.train_step(inputs, label, cp, mask), args.steps, 10) for _ in range(2))
                 sp = min((spectral_leg(api, _lib, dev, B, C, H, W, max(args.steps, 20)) for _ in range(2)), key=lambda r: r["avg_us"])  # best of two, like dt
             finally:
                 api.call("cfd_tune_set", knob, -1)
