@@ -47,7 +47,7 @@ __device__ __forceinline__ float fs_act_grad(float y, float z, int act) {
 
 // A weight matrix (Dout x Din, row-major) staged by the whole workgroup: thread (tj = tid / 32, ti = tid % 32) owns the four
 // columns 4 ti .. 4 ti + 3 of rows tj, tj + 8, ...; registers first (the loads fly during the previous layer's MFMAs), LDS later.
-// TRANS = false: sW[j][i] = W[j][i];  TRANS = true: sW[i][j] = W[j][i] (the backward chain multiplies by W, not W^T).
+// sW[j][i] = W[j][i] in both directions (the backward chain, which multiplies by W and not W^T, reads it transposed: fs_tile_gemm_t).
 // Rows / columns up to the next multiple of 16 are written as zeros: they are MFMA padding.
 #define FS_WROWS (FS_MAXD / 8)
 struct FsWRegs { float4 v[FS_WROWS]; };
@@ -71,28 +71,50 @@ __device__ __forceinline__ void fs_wfetch(const float* __restrict__ w, int Dout,
         r.v[k] = t;
     }
 }
-template <bool TRANS>
 __device__ __forceinline__ void fs_wcommit(float* __restrict__ sW, int FS_LD, int Dout, int Din, const FsWRegs& r) {
     const int tj = threadIdx.x >> 5, c0 = 4 * (threadIdx.x & 31);
     const int Dop = (Dout + 15) & ~15, Dip = (Din + 15) & ~15;
 #pragma unroll
     for (int k = 0; k < FS_WROWS; ++k) {
         const int j = tj + 8 * k;
-        if (j < Dop && c0 < Dip) {
-            if constexpr (!TRANS) *reinterpret_cast<float4*>(sW + j * FS_LD + c0) = r.v[k];
-            else {
-                sW[(c0 + 0) * FS_LD + j] = r.v[k].x;
-                sW[(c0 + 1) * FS_LD + j] = r.v[k].y;
-                sW[(c0 + 2) * FS_LD + j] = r.v[k].z;
-                sW[(c0 + 3) * FS_LD + j] = r.v[k].w;
-            }
-        }
+        if (j < Dop && c0 < Dip) *reinterpret_cast<float4*>(sW + j * FS_LD + c0) = r.v[k];
     }
 }
 
 // out[16 rows][16 t + n] = sum_k sIn[row][k] sOp[16 t + n][k] for this wave's column tiles t = wave, wave + 4 (< NT), K padded to
 // NG groups of 16.  k-slot map of a group: MFMA step i of lane (q, n) carries k = 16 g + 4 q + i, so a lane's four steps are ONE
 // 16-byte LDS read per operand (the map is arbitrary as long as both operands use it).
+// fs_tile_gemm_t: the operand matrix is stored TRANSPOSED to what the product needs (the backward chain multiplies by W, whose LDS image is the
+// forward's sW[j][i]): out[row][16 t + n] = sum_k sIn[row][k] sOp[k][16 t + n]; a lane's four steps are then four 4-byte reads
+// (conflict-free: the 16 lanes of a group read 16 consecutive floats).  Round 3 stored W^T instead, with scalar LDS stores whose
+// addresses a thread's rows put 4 FS_LD floats apart -- 16 mod 32 banks, a 16-way conflict on each of 64 stores per thread and layer:
+// SQ_LDS_BANK_CONFLICT was 87 % of the kernel's LDS cycles (profiles/r04e_ffn_bwd_lds.txt).
+__device__ __forceinline__ void fs_tile_gemm_t(const float* __restrict__ sIn, const float* __restrict__ sOp, int FS_LD, int NG, int NT,
+                                                int wave, int q, int n, f32x4 (&acc)[2]) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    acc[0] = acc[1] = zero;
+    const bool t1 = wave + 4 < NT;
+    if (wave >= NT) return;
+    const float* ap = sIn + n * FS_LD + 4 * q;
+    const float* b0 = sOp + (4 * q) * FS_LD + 16 * wave + n;
+    const float* b1 = sOp + (4 * q) * FS_LD + 16 * (t1 ? wave + 4 : wave) + n;
+    auto ldb = [&](const float* b, int g) { return make_float4(b[(16 * g) * FS_LD], b[(16 * g + 1) * FS_LD], b[(16 * g + 2) * FS_LD], b[(16 * g + 3) * FS_LD]); };
+    float4 a = *reinterpret_cast<const float4*>(ap), x0 = ldb(b0, 0), x1 = ldb(b1, 0);
+    for (int g = 0; g < NG; ++g) {
+        const int gn = g + 1 < NG ? g + 1 : g;  // next group's operands are requested before this group's MFMAs
+        const float4 an = *reinterpret_cast<const float4*>(ap + 16 * gn);
+        const float4 y0 = ldb(b0, gn), y1 = ldb(b1, gn);
+        acc[0] = cfd_mfma16x16x4(a.x, x0.x, acc[0]);
+        acc[1] = cfd_mfma16x16x4(a.x, x1.x, acc[1]);
+        acc[0] = cfd_mfma16x16x4(a.y, x0.y, acc[0]);
+        acc[1] = cfd_mfma16x16x4(a.y, x1.y, acc[1]);
+        acc[0] = cfd_mfma16x16x4(a.z, x0.z, acc[0]);
+        acc[1] = cfd_mfma16x16x4(a.z, x1.z, acc[1]);
+        acc[0] = cfd_mfma16x16x4(a.w, x0.w, acc[0]);
+        acc[1] = cfd_mfma16x16x4(a.w, x1.w, acc[1]);
+        a = an; x0 = y0; x1 = y1;
+    }
+}
 __device__ __forceinline__ void fs_tile_gemm(const float* __restrict__ sIn, const float* __restrict__ sOp, int FS_LD, int NG, int NT,
                                               int wave, int q, int n, f32x4 (&acc)[2]) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -147,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_ffn_stack_fwd(const float* __restric
         const int Din = st.dims[l], Dout = st.dims[l + 1];
         const int NG = (Din + 15) >> 4, NT = (Dout + 15) >> 4;
         __syncthreads();  // every wave is done with W_{l-1} and has written its columns of sA[cur]
-        fs_wcommit<false>(sW, FS_LD, Dout, Din, wr);
+        fs_wcommit(sW, FS_LD, Dout, Din, wr);
         __syncthreads();
         if (l + 1 < st.L) fs_wfetch(st.w[l + 1], st.dims[l + 2], st.dims[l + 1], wr);  // in flight during this layer's MFMAs
         f32x4 acc[2];
@@ -194,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void k_ffn_stack_bwd_chain(const float* __r
     CFD_DYN_SHARED(float4, s_dyn4);
     float* sG0 = reinterpret_cast<float*>(s_dyn4);
     float* sG[2] = {sG0, sG0 + FS_ROWS * FS_LD};   // dZ_l of the tile / the next G (ping-pong)
-    float* sW = sG0 + 2 * FS_ROWS * FS_LD;         // W_l^T: sW[i][j]
+    float* sW = sG0 + 2 * FS_ROWS * FS_LD;         // W_l: sW[j][i] (rows = this layer's outputs j = the chain's K)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
     const int row0 = blockIdx.x * FS_ROWS;
@@ -224,14 +246,14 @@ __global__ __launch_bounds__(256, 2) void k_ffn_stack_bwd_chain(const float* __r
                 }
             }
         }
-        if (need_g) fs_wcommit<true>(sW, FS_LD, Dout, Din, wr);
+        if (need_g) fs_wcommit(sW, FS_LD, Dout, Din, wr);  // sW[j][i] = W[j][i], 16-byte stores (fs_tile_gemm_t reads it transposed)
         __syncthreads();
         if (l > 0) fs_wfetch(st.w[l - 1], st.dims[l], st.dims[l - 1], wr);
         if (!need_g) break;
         // G_{l-1}[row][i] = sum_j dZ[row][j] W[j][i]: operand rows of sW are the output columns i, K = j
         const int NG = (Dout + 15) >> 4, NT = (Din + 15) >> 4;
         f32x4 acc[2];
-        fs_tile_gemm(sG[cur], sW, FS_LD, NG, NT, wave, q, n, acc);
+        fs_tile_gemm_t(sG[cur], sW, FS_LD, NG, NT, wave, q, n, acc);
         float* sN = sG[cur ^ 1];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
