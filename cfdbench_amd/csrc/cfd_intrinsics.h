@@ -85,6 +85,26 @@ __device__ __forceinline__ float cfd_rcpf(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ unsigned cfd_umulhi(unsigned a, unsigned b) { return __umulhi(a, b); }
 __device__ __forceinline__ float cfd_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32, no range fix-up
 
+// Raw buffer resource over [base, base + bytes), bytes <= 2^31: `buffer_load / buffer_store v, voffset, s[rsrc], soffset offen`.
+// The address is base + voffset (per lane, VGPR) + soffset (wave-uniform, SGPR) -- no 64-bit address arithmetic in the VALU, which
+// is what hipcc turns `uniform pointer + 32-bit lane offset` into as soon as it reshapes the address expression (conv6.hip: one
+// v_lshl_add_u64 per 4-byte load) -- and the hardware range check replaces predication: a lane whose voffset is CFD_BUF_OOB (>= bytes)
+// loads 0 and its store is dropped, with no exec-mask region and no branch around the instruction (hipcc emits one per conditional
+// store).  Callers keep voffset + soffset + 4 <= bytes for every live lane.
+typedef __amdgpu_buffer_rsrc_t CfdBuf;
+#define CFD_BUF_OOB 0x80000000u
+__device__ __forceinline__ CfdBuf cfd_buf(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);  // raw, 32-bit data format
+}
+__device__ __forceinline__ float cfd_buf_ld(CfdBuf b, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void cfd_buf_st(CfdBuf b, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b, (int)voff, (int)soff, 0);
+}
+// true in every lane of the wave when `p` holds in any of them (a wave-uniform branch condition)
+__device__ __forceinline__ bool cfd_wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 // Two fp32 values in one 64-bit register pair: +, -, * and cfd_fma2 on it compile to the packed VALU instructions
 // (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), which retire two lanes' worth of fp32 math per issue slot.
 typedef float cfd_f2 __attribute__((ext_vector_type(2)));

@@ -18,6 +18,23 @@
 
 typedef cfd_u32x4 u4;
 
+#ifdef CFD_C6DIAG  // experiment builds only (tools/build_variant.sh c6diag conv6.hip -DCFD_C6DIAG, tools/exp/c6_diag.py): s_memtime
+                   // stamps of workgroup 0 / wave 0 at the phase boundaries of its first 16 iterations
+__device__ unsigned long long c6_ts[1024];
+extern "C" int cfd_dbg_c6_read(unsigned long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c6_ts), (size_t)n * 8); }
+extern "C" int cfd_dbg_c6_clear() {
+    static unsigned long long z[1024];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(c6_ts), z, sizeof(z));
+}
+#define C6_TS(slot)                                                                                     \
+    do {                                                                                                \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && it < 16)      \
+            c6_ts[it * 8 + (slot)] = __builtin_readcyclecounter();                                      \
+    } while (0)
+#else
+#define C6_TS(slot) do { } while (0)
+#endif
+
 
 #ifndef CFD_CONV6_GRID
 #define CFD_CONV6_GRID 512  // persistent workgroups per launch: two per CU (the CPU emulator build sets 2 so that small test shapes
@@ -164,25 +181,36 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
     const int ntile = ((int)blockIdx.x < ptiles) ? (ptiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int nit = nchw > 0 ? ntile * nchw : 0;
 
-    // this thread's NI halo items (pixel, channel octet): tile-invariant coordinates, packed lx | ly << 8 | bi << 16 | c8 << 24
-    unsigned ipk[NI], ilds[NI];
+    // this thread's NI halo items (pixel, channel octet): tile-invariant coordinates, packed lx | ly << 8 | bi << 16.  The items of
+    // channel octet 1 start at a multiple of 64, so that an item's octet is uniform per wave and its channels are wave-uniform
+    // buffer offsets (conv6_plan counts the slots the same way).
+    const int NPXp = (NPX + 63) & ~63;
+    unsigned ipk[NI], ilds[NI], ibase[NI];
+    int ic8[NI];
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         const int i = threadIdx.x + 256 * k;
-        const int c8 = CH8 == 1 ? 0 : (i >= NPX ? 1 : 0), pxl = i - c8 * NPX;
+        const int c8 = CH8 == 1 ? 0 : cfd_uniform(i >= NPXp ? 1 : 0);
+        const bool live = i - c8 * NPXp < NPX;
+        const int pxl = live ? i - c8 * NPXp : 0;
         const int r1 = (int)cfd_div((unsigned)pxl, t.dUsed), lx = pxl - r1 * t.LW;
         const int bi = (int)cfd_div((unsigned)r1, t.dLH), ly = r1 - bi * t.LH;
-        ipk[k] = i < plane ? (unsigned)(lx | (ly << 8) | (bi << 16) | (c8 << 24)) : 0x80000000u;  // idle: item (0, 0, 0, 0), never committed
+        ipk[k] = live ? (unsigned)(lx | (ly << 8) | (bi << 16)) : 0x80000000u;  // idle: loads nothing, never committed
         ilds[k] = 48u * (unsigned)(pxl * CH8 + c8);
+        ibase[k] = 4u * (unsigned)(bi * Cs * HWs);
+        ic8[k] = c8;
     }
     float dr[NI][8];
     u4 wr[NWV];
-    bool dok[NI];
+    // Operand loads and result stores go through raw buffer resources (cfd_intrinsics.h): per-lane 32-bit offset + wave-uniform
+    // offset, out-of-range lanes dropped by the hardware.  (Written as `uniform pointer + lane offset` / `if (ok) store`, hipcc made
+    // a 64-bit VALU address for every 4-byte access and an exec-mask region with its own branch for every store: ~70 VALU
+    // instructions per halo item and ~100 branches per tile in an instruction-issue-bound loop.)
+    const CfdBuf bsrc = cfd_buf(src, 4u * (unsigned)(g.B * Cs * HWs));
     // global loads of iteration `it` (tile, chunk): 8 channel values per halo item, the chunk's weight fragments.  Every load is
-    // unconditional from a clamped (valid) address, a wave-uniform base pointer plus a 32-bit byte offset: channels beyond Cs
-    // meet zero weights, weight tiles beyond MTall feed rows that are never stored; only halo pixels outside the image (EXT) or
-    // the batch must become zeros, at commit time (`dok`).  (A `cond ? load : 0` form compiles to one branch per load, 64-bit
-    // per-lane addresses to ~5 VALU instructions per load: together 2/3 of the kernel's VALU time in the first version.)
+    // unconditional: halo pixels outside the image (EXT) or the batch carry the out-of-range offset and come back as zeros,
+    // channels beyond Cs meet zero weights, weight tiles beyond MTall feed rows that are never stored.  (A `cond ? load : 0` form
+    // compiles to one branch per load.)
     const auto issue = [&](int it, bool with_w) {
         const int tk = it / nchw, ch = chbeg + it - tk * nchw;
         const int tile = blockIdx.x + tk * gridDim.x;
@@ -190,29 +218,26 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
         const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
         const int b0 = bg * t.NB;
         const int oy = EXT ? ty0 - 2 * PAD : ty0 - PAD, ox = EXT ? tx0 - 2 * PAD : tx0 - PAD;  // source coords of the halo origin
-        const int c0 = ch * CC;
-        const bool full = c0 + CC <= Cs;  // (uniform) every channel of the chunk exists: no per-channel clamping
+        const int c0 = ch * CC, nbv = g.B - b0;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const unsigned pk = ipk[k];
-            const int lx = pk & 255, ly = (pk >> 8) & 255, bi = (pk >> 16) & 255, c8 = (pk >> 24) & 1;
+            const int lx = pk & 255, ly = (pk >> 8) & 255, bi = (pk >> 16) & 255;
             int y = oy + ly, x = ox + lx;
-            bool ok = b0 + bi < g.B;
-            if constexpr (EXT) ok = ok && y >= 0 && y < g.H && x >= 0 && x < g.W;
-            y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
-            x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
-            const int bsafe = b0 + bi < g.B ? b0 + bi : g.B - 1;
-            const int cb = c0 + 8 * c8;
-            const unsigned off = 4u * (unsigned)(bsafe * Cs * HWs + y * g.W + x);
-            if (full) {
-                const unsigned off2 = off + 4u * (unsigned)(cb * HWs);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dr[k][j] = cfd_ldg_off(src + (size_t)j * HWs, off2);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dr[k][j] = cfd_ldg_off(src, off + 4u * (unsigned)((cb + j < Cs ? cb + j : Cs - 1) * HWs));
+            bool ok = !(pk >> 31) && bi < nbv;
+            if constexpr (EXT) {  // outside the image: zeros
+                ok = ok && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+            } else {              // replicate padding
+                y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
+                x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
             }
-            dok[k] = ok;
+            const unsigned vo = ok ? ibase[k] + 4u * (unsigned)(y * g.W + x) : CFD_BUF_OOB;
+            const int cb = c0 + 8 * ic8[k];  // (uniform) channels beyond Cs meet zero weights: any finite value of this image will do
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = cb + j < Cs ? cb + j : Cs - 1;
+                dr[k][j] = cfd_buf_ld(bsrc, vo, 4u * (unsigned)((b0 * Cs + c) * HWs));
+            }
         }
         if (with_w) {
 #pragma unroll
@@ -252,6 +277,32 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) st1[mt][r] = st2[mt][r] = 0.f;
+    // rows m = 16 (mb + mt) + 4 q + r of this lane exist while r < rlim[mt]
+    int rlim[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rlim[mt] = Cm - 16 * (mb + mt) - 4 * q;
+    const bool c4 = (Cm & 3) == 0;  // (uniform) a lane's four rows of a tile exist together
+    const CfdBuf bdst = cfd_buf(dst, 4u * (unsigned)(g.B * Cm * HWd));
+    const CfdBuf bgin = cfd_buf(gin_direct ? gin_direct : dst, 4u * (unsigned)(g.B * Cm * (gin_direct ? HWs : HWd)));
+    // the MT x 4 values of pixel tile tt to rows of `hw` floats: `o` = the lane's offset of row 16 mb + 4 q, or out of range
+    const auto put = [&](const CfdBuf& bf, unsigned o, int hw, int tt, bool with_bias) {
+        if (c4) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned om = rlim[mt] > 0 ? o : CFD_BUF_OOB;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cfd_buf_st(bf, om, 4u * (unsigned)((16 * mt + r) * hw), with_bias ? outv[mt][tt][r] + bias_r[mt][r] : outv[mt][tt][r]);
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cfd_buf_st(bf, r < rlim[mt] ? o : CFD_BUF_OOB, 4u * (unsigned)((16 * mt + r) * hw),
+                               with_bias ? outv[mt][tt][r] + bias_r[mt][r] : outv[mt][tt][r]);
+        }
+    };
     const auto store_tile = [&]() {
         const int bg = out_tile / tpi, tr = out_tile - bg * tpi;
         const int ty0 = (tr / t.tiles_x) * t.TH, tx0 = (tr % t.tiles_x) * t.TW;
@@ -259,29 +310,24 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
         for (int tt = 0; tt < 4; ++tt) {
             const int b = bg * t.NB + pbi[tt], y = ty0 + (ppix[tt] & 0xffff), x = tx0 + (ppix[tt] >> 16);
             const bool on = pbi[tt] >= 0 && b < g.B && y < Hd && x < Wd;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int m0 = 16 * (mb + mt) + 4 * q;
+            const int row0 = b * Cm + 16 * mb + 4 * q;
+            if constexpr (EXT) {
                 // input-gradient pass with `gin_direct`: extended positions that map one-to-one onto an interior pixel of the image
                 // go straight to gin; only the pad ring and the border rows / columns (whose pixels collect several extended
                 // positions) take the detour through the extended buffer and k_fold_border
                 const int yi = y - PAD, xi = x - PAD;
-                const bool direct = EXT && gin_direct != nullptr && yi >= 1 && yi <= g.H - 2 && xi >= 1 && xi <= g.W - 2;
-                if (direct) {
-                    const unsigned o = 4u * (unsigned)((b * Cm + m0) * HWs + yi * g.W + xi);
+                const bool direct = gin_direct != nullptr && yi >= 1 && yi <= g.H - 2 && xi >= 1 && xi <= g.W - 2;
+                if (gin_direct) put(bgin, on && direct ? 4u * (unsigned)(row0 * HWs + yi * g.W + xi) : CFD_BUF_OOB, HWs, tt, false);
+                if (cfd_wave_any(on && !direct))  // (interior tiles have no such lane)
+                    put(bdst, on && !direct ? 4u * (unsigned)(row0 * HWd + y * Wd + x) : CFD_BUF_OOB, HWd, tt, true);
+            } else {
+                put(bdst, on ? 4u * (unsigned)(row0 * HWd + y * Wd + x) : CFD_BUF_OOB, HWd, tt, true);
+                if constexpr (NI == 3) {  // (the 5-item variants serve the small deep levels, which split their chunks)
+                    if (stats && on) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (on && m0 + r < Cm) cfd_stg_off(gin_direct + (size_t)r * HWs, o, outv[mt][tt][r]);
-                } else {
-                    const unsigned o = 4u * (unsigned)((b * Cm + m0) * HWd + y * Wd + x);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (on && m0 + r < Cm) cfd_stg_off(dst + (size_t)r * HWd, o, outv[mt][tt][r] + bias_r[mt][r]);
-                    if constexpr (!EXT && NI == 3) {  // (the 5-item variants serve the small deep levels, which split their chunks)
-                        if (stats && on) {
+                        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { st1[mt][r] += outv[mt][tt][r]; st2[mt][r] = fmaf(outv[mt][tt][r], outv[mt][tt][r], st2[mt][r]); }
-                        }
                     }
                 }
             }
@@ -290,14 +336,12 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
     };
     if (nit > 0) issue(0, true);
     for (int it = 0; it < nit; ++it) {
+        C6_TS(0);
         __syncthreads();  // previous iteration's operands fully consumed (first pass: s_koff written)
+        C6_TS(1);
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             if (!(ipk[k] >> 31)) {
-                if (!dok[k]) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) dr[k][j] = 0.f;
-                }
                 const CfdSplit8x3 sp = cfd_split8x3(dr[k]);
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) *(u4*)(s_in + ilds[k] + 16 * pc) = __builtin_bit_cast(u4, sp.p[pc]);
@@ -310,10 +354,14 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
                 if (i < WTOT) s_w[i] = wr[k];
             }
         }
+        C6_TS(2);
         __syncthreads();
+        C6_TS(3);
         if (it + 1 < nit) issue(it + 1, nchw > 1);
+        C6_TS(4);
         if (out_tile >= 0) store_tile();
         cfd_sched_fence();  // keep the loads above the MFMA loop: hipcc otherwise sinks them to their first use
+        C6_TS(5);
 #pragma unroll 1
         for (int s = 0; s < KSTEPS; ++s) {
             const int ko = s_koff[4 * s + q];
@@ -330,6 +378,7 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) cfd_mfma_bf16x6_n<4>(av[mt], bv, acc[mt]);
         }
+        C6_TS(6);
         const int tk = it / nchw;
         if (it - tk * nchw == nchw - 1) {  // last chunk of the tile: hand the sums to the deferred store, start the next tile from zero
 #pragma unroll
@@ -411,8 +460,13 @@ static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     P.nch = F.nch;
     ConvTile& t = P.t;
     cfd_conv_tile_shape(Hd, Wd, g.B, t.TW, t.TH, t.NB);
-    // a thread prefetches at most 5 halo items (8 channel values each) of the next tile: small images, many per workgroup
-    while (t.NB > 1 && t.NB * (t.TH + KS - 1) * (t.TW + KS - 1) * (P.CC / 8) > 5 * 256) --t.NB;
+    // a thread prefetches at most 5 halo items (8 channel values each) of the next tile: small images, many per workgroup.
+    // Item slots of a tile: its halo pixels once per channel octet, the second octet starting at a multiple of 64 (k_conv6).
+    const auto slots_of = [&](int nb) {
+        const int npx = nb * (t.TH + KS - 1) * (t.TW + KS - 1);
+        return P.CC == 8 ? npx : ((npx + 63) & ~63) + npx;
+    };
+    while (t.NB > 1 && slots_of(t.NB) > 5 * 256) --t.NB;
     t.tiles_x = (Wd + t.TW - 1) / t.TW;
     t.tiles_y = (Hd + t.TH - 1) / t.TH;
     t.LH = t.TH + KS - 1;
@@ -425,7 +479,7 @@ static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     };
     // two output-channel tiles per workgroup (a staged halo feeds twice the MFMAs) while two workgroups still fit a CU and the
     // grid fills the chip
-    const int plane = t.NB * t.LH * t.LW * (P.CC / 8);
+    const int plane = slots_of(t.NB);
     P.NI = plane <= 3 * 256 ? 3 : 5;
     int mtw = P.MTall >= 2 ? 2 : 1;
 #ifndef CFD_CONV6_MT2_MIN_WGS
@@ -449,7 +503,7 @@ static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     P.gx = (int)(gx < P.ptiles ? gx : P.ptiles);
     P.wfrag_bytes = F.bytes;
     P.split_bytes = P.ksplit > 1 ? cfd_align_up((size_t)P.ksplit * g.B * Cm * Hd * Wd * sizeof(float), 256) : 0;
-    const bool small = (long)g.B * Cs * g.H * g.W < (1L << 30) && (long)g.B * Cm * Hd * Wd < (1L << 30);  // 32-bit byte offsets
+    const bool small = (long)g.B * Cs * g.H * g.W <= (1L << 29) && (long)g.B * Cm * Hd * Wd <= (1L << 29);  // buffer resources: <= 2^31 bytes
     P.ok = small && P.lds <= 150 * 1024 && plane <= 5 * 256 && F.ok && P.ptiles < (1L << 30);
     return P;
 }

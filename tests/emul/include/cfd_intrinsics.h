@@ -86,6 +86,40 @@ inline float cfd_rcpf(float x) { return 1.0f / x; }
 inline unsigned cfd_umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline float cfd_exp2f(float x) { return exp2f(x); }
 
+// raw buffer resource: the hardware drops lanes whose voffset is out of range (loads return 0); a LIVE lane that reaches beyond the
+// resource is a kernel bug the hardware would not report -- the emulator aborts on it
+struct CfdBuf { char* base; unsigned bytes; };
+#define CFD_BUF_OOB 0x80000000u
+inline CfdBuf cfd_buf(const void* base, unsigned bytes) { return CfdBuf{const_cast<char*>(static_cast<const char*>(base)), bytes}; }
+inline void cfd_buf_check(const CfdBuf& b, unsigned voff, unsigned soff) {
+    if ((unsigned long long)voff + soff + 4ull > b.bytes) {
+        fprintf(stderr, "emulator: buffer access at voffset %u + soffset %u beyond a %u-byte resource\n", voff, soff, b.bytes);
+        abort();
+    }
+}
+inline float cfd_buf_ld(CfdBuf b, unsigned voff, unsigned soff) {
+    if (voff >= b.bytes) return 0.f;
+    cfd_buf_check(b, voff, soff);
+    float v;
+    memcpy(&v, b.base + voff + soff, 4);
+    return v;
+}
+inline void cfd_buf_st(CfdBuf b, unsigned voff, unsigned soff, float v) {
+    if (voff >= b.bytes) return;
+    cfd_buf_check(b, voff, soff);
+    memcpy(b.base + voff + soff, &v, 4);
+}
+inline bool cfd_wave_any(bool p) {
+    auto& w = cfd_emul::wave();
+    const int l = cfd_emul::lane();
+    w.fa[l] = p ? 1.f : 0.f;
+    cfd_emul::wave_sync();
+    bool any = false;
+    for (int i = 0; i < 64; ++i) any = any || w.fa[i] != 0.f;
+    cfd_emul::wave_sync();
+    return any;
+}
+
 typedef float cfd_f2 __attribute__((ext_vector_type(2)));
 inline cfd_f2 cfd_fma2(cfd_f2 a, cfd_f2 b, cfd_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 inline cfd_f2 cfd_abs2(cfd_f2 a) { return __builtin_elementwise_abs(a); }
