@@ -8,9 +8,8 @@
 // prefetched into registers while the previous slab is on the matrix pipe.
 #include "cfd_common.h"
 
-#define GT 64   // block tile edge (M and N)
+#define GT 64   // block tile edge (M and N) of the small-problem kernel: 4 waves x (2 x 2) MFMA tiles
 #define GK 16   // K slab
-#define GLD 68  // LDS row stride in floats (64 + 4: keeps 16-B alignment for ds_write_b128, staggers banks)
 
 struct GemmEpi {
     int mode;             // 0: store; 1: + bias[n], activation; 2: + bias[0] (+ resid[m*ldr + (qidx ? qidx[n] : n)])
@@ -43,61 +42,81 @@ __device__ __forceinline__ float cfd_act_grad(float y, float z, int act) {
     }
 }
 
-// One 64 x 16 slab of op(X) into registers.  KCONT: the source is k-contiguous (X stored [rows][K]); else it is
-// row-contiguous (X stored [K][rows]).  Either way s[k][row] is what lands in LDS.
-template <bool KCONT>
+// One (16 WT*2) x 16 slab of op(X) -- the rows [row0, row0 + 32 WT) of a block tile -- into registers, 64 rows per float4 round.
+// KCONT: the source is k-contiguous (X stored [rows][K]); else it is row-contiguous (X stored [K][rows]).  Either way s[k][row] is
+// what lands in LDS (row stride LD floats).
+template <bool KCONT, int WT>
 struct SlabRegs {
-    float v[4];
+    static constexpr int NR = WT / 2;  // rounds of 64 rows
+    float v[NR][4];
     __device__ __forceinline__ void load(const float* __restrict__ X, int ld, int rows, int K, int row0, int k0, int tid) {
-        if constexpr (KCONT) {
-            const int row = row0 + (tid >> 2), k = k0 + (tid & 3) * 4;
-            const float* p = X + (size_t)row * ld + k;
-            if (row < rows && k + 3 < K && ((((uintptr_t)p) & 15) == 0)) {
-                const float4 t = *reinterpret_cast<const float4*>(p);
-                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (row < rows && k + j < K) ? p[j] : 0.f;
-            }
-        } else {
-            const int k = k0 + (tid >> 4), row = row0 + (tid & 15) * 4;
-            const float* p = X + (size_t)k * ld + row;
-            if (k < K && row + 3 < rows && ((((uintptr_t)p) & 15) == 0)) {
-                const float4 t = *reinterpret_cast<const float4*>(p);
-                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            } else {
+        for (int h = 0; h < NR; ++h) {
+            if constexpr (KCONT) {
+                const int row = row0 + 64 * h + (tid >> 2), k = k0 + (tid & 3) * 4;
+                const float* p = X + (size_t)row * ld + k;
+                if (row < rows && k + 3 < K && ((((uintptr_t)p) & 15) == 0)) {
+                    const float4 t = *reinterpret_cast<const float4*>(p);
+                    v[h][0] = t.x; v[h][1] = t.y; v[h][2] = t.z; v[h][3] = t.w;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (k < K && row + j < rows) ? p[j] : 0.f;
+                    for (int j = 0; j < 4; ++j) v[h][j] = (row < rows && k + j < K) ? p[j] : 0.f;
+                }
+            } else {
+                const int k = k0 + (tid >> 4), row = row0 + 64 * h + (tid & 15) * 4;
+                const float* p = X + (size_t)k * ld + row;
+                if (k < K && row + 3 < rows && ((((uintptr_t)p) & 15) == 0)) {
+                    const float4 t = *reinterpret_cast<const float4*>(p);
+                    v[h][0] = t.x; v[h][1] = t.y; v[h][2] = t.z; v[h][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[h][j] = (k < K && row + j < rows) ? p[j] : 0.f;
+                }
             }
         }
     }
+    template <int LD>
     __device__ __forceinline__ void store(float* s, int tid) const {
-        if constexpr (KCONT) {
-            const int row = tid >> 2, k = (tid & 3) * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s[(k + j) * GLD + row] = v[j];
-        } else {
-            const int k = tid >> 4, row = (tid & 15) * 4;
-            *reinterpret_cast<float4*>(s + k * GLD + row) = make_float4(v[0], v[1], v[2], v[3]);
+        for (int h = 0; h < NR; ++h) {
+            if constexpr (KCONT) {
+                const int row = 64 * h + (tid >> 2), k = (tid & 3) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[(k + j) * LD + row] = v[h][j];
+            } else {
+                const int k = tid >> 4, row = 64 * h + (tid & 15) * 4;
+                *reinterpret_cast<float4*>(s + k * LD + row) = make_float4(v[h][0], v[h][1], v[h][2], v[h][3]);
+            }
         }
     }
 };
 
 // C[M][N] = epi( sum_k opA(m,k) opB(k,n) );  AT: A stored [K][M] (else [M][K]);  BT: B stored [N][K] (else [K][N]).
-template <bool AT, bool BT>
-__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, const float* __restrict__ B,
-                                              float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
-                                              GemmEpi epi, int slabs_per_split) {
-    __shared__ __attribute__((aligned(16))) float s_a[2][GK * GLD];
-    __shared__ __attribute__((aligned(16))) float s_b[2][GK * GLD];
+// WT x WT MFMA tiles per wave, block tile 32 WT square.  WT = 2 (64 x 64: round 1's kernel) makes 16 MFMAs between two barriers
+// with one ds_read_b32 per MFMA operand and ran the 131 k x 200 x 200 Linear layers of the DeepONet family at a quarter of the fp32
+// matrix pipe's rate; WT = 4 (128 x 128) makes 64 MFMAs per barrier from 32 operand reads and half the operand traffic per flop:
+// launch_gemm picks it whenever the 128-tiles still fill the chip.
+template <bool AT, bool BT, int WT>
+__global__ __launch_bounds__(256, 2) void k_gemm(const float* __restrict__ A, const float* __restrict__ B,
+                                                 float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
+                                                 GemmEpi epi, int slabs_per_split) {
+    constexpr int BT_ = 32 * WT;                  // block tile edge
+    constexpr int LD = BT_ + (WT == 2 ? 4 : 16);  // LDS row stride in floats: 16-B aligned rows; the 128-wide tile's four k rows of
+                                                  // one MFMA step (lanes q) sit 16 banks apart: its operand reads are conflict-free
+    __shared__ __attribute__((aligned(16))) float s_a[2][GK * LD];
+    __shared__ __attribute__((aligned(16))) float s_b[2][GK * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, n = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
-    SlabRegs<!AT> ra;  // A is k-contiguous unless transposed
-    SlabRegs<BT> rb;   // B is k-contiguous only when stored transposed
+    const int m0 = blockIdx.y * BT_, n0 = blockIdx.x * BT_;
+    SlabRegs<!AT, WT> ra;  // A is k-contiguous unless transposed
+    SlabRegs<BT, WT> rb;   // B is k-contiguous only when stored transposed
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc[2][2] = {{zero, zero}, {zero, zero}};
+    f32x4 acc[WT][WT];
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[i][j] = zero;
     // split-K: blockIdx.z owns slabs [s0, s1) and writes its partial tile to C + z*M*ldc (epilogue in k_splitk_reduce)
     const int nslab_all = (K + GK - 1) / GK;
     const int s0 = blockIdx.z * slabs_per_split;
@@ -105,8 +124,8 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, const
     C += (size_t)blockIdx.z * M * ldc;
     ra.load(A, lda, M, K, m0, s0 * GK, tid);
     rb.load(B, ldb, N, K, n0, s0 * GK, tid);
-    ra.store(s_a[0], tid);
-    rb.store(s_b[0], tid);
+    ra.template store<LD>(s_a[0], tid);
+    rb.template store<LD>(s_b[0], tid);
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
         const int cur = s & 1;
@@ -118,32 +137,32 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, const
         const float* sb = s_b[cur];
 #pragma unroll
         for (int kk = 0; kk < GK / 4; ++kk) {
-            float av[2], bv[2];
+            float av[WT], bv[WT];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                av[i] = sa[(4 * kk + q) * GLD + 32 * wm + 16 * i + n];
-                bv[i] = sb[(4 * kk + q) * GLD + 32 * wn + 16 * i + n];
+            for (int i = 0; i < WT; ++i) {
+                av[i] = sa[(4 * kk + q) * LD + 16 * WT * wm + 16 * i + n];
+                bv[i] = sb[(4 * kk + q) * LD + 16 * WT * wn + 16 * i + n];
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < WT; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = cfd_mfma16x16x4(av[i], bv[j], acc[i][j]);
+                for (int j = 0; j < WT; ++j) acc[i][j] = cfd_mfma16x16x4(av[i], bv[j], acc[i][j]);
         }
         if (s + 1 < nslab) {
-            ra.store(s_a[cur ^ 1], tid);  // the other buffer was last read before the previous barrier
-            rb.store(s_b[cur ^ 1], tid);
+            ra.template store<LD>(s_a[cur ^ 1], tid);  // the other buffer was last read before the previous barrier
+            rb.template store<LD>(s_b[cur ^ 1], tid);
         }
         __syncthreads();
     }
-    // acc[i][j][r] = C[m0 + 32wm + 16i + 4q + r][n0 + 32wn + 16j + n]
+    // acc[i][j][r] = C[m0 + 16 WT wm + 16i + 4q + r][n0 + 16 WT wn + 16j + n]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + 32 * wn + 16 * j + n;
+        for (int j = 0; j < WT; ++j) {
+            const int col = n0 + 16 * WT * wn + 16 * j + n;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + 32 * wm + 16 * i + 4 * q + r;
+                const int row = m0 + 16 * WT * wm + 16 * i + 4 * q + r;
                 if (row < M && col < N) {
                     float v = acc[i][j][r];
                     if (epi.mode == 1) {
@@ -186,15 +205,26 @@ static int gemm_splits(int M, int N, int K) {
     const long tiles = (long)((M + GT - 1) / GT) * ((N + GT - 1) / GT);
     const int nslab = (K + GK - 1) / GK;
     if (tiles >= 128 || nslab < 8) return 1;
-    long s = (256 + tiles - 1) / tiles;
+    // four workgroups per CU: with one (256 in all: round 1's target) every SIMD holds a single wave and nothing hides its LDS and
+    // barrier latencies -- the 200 x 200 weight gradients over 131 k rows of the Auto-FFN ran at 30 % of the matrix pipe, half the
+    // rate of the forward product of the same size (profiles/r04g_gemm_counters.txt)
+    long s = (1024 + tiles - 1) / tiles;
     if (s > nslab / 4) s = nslab / 4;  // at least 4 slabs (64 k) per split
-    if (s > 64) s = 64;
+    if (s > 128) s = 128;
     return s < 1 ? 1 : (int)s;
 }
 
 static size_t gemm_ws_bytes(int M, int N, int K) {
     const int s = gemm_splits(M, N, K);
     return s > 1 ? cfd_align_up((size_t)s * M * N * sizeof(float), 256) : 0;
+}
+
+// 128 x 128 block tiles (WT = 4) when they alone give every CU a workgroup and no split-K is wanted; else the 64 x 64 kernel
+static bool gemm_big_tiles(int M, int N, int splits) {
+    const int t = cfd_tune_get(CFD_TUNE_GEMM_TILE);
+    if (t == 64) return false;
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    return splits == 1 && (t == 128 || tiles >= 256);
 }
 
 static int launch_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int at,
@@ -204,17 +234,25 @@ static int launch_gemm(const float* A, const float* B, float* C, int M, int N, i
     const int nslab = (K + GK - 1) / GK;
     const int per = (nslab + splits - 1) / splits;
     splits = (nslab + per - 1) / per;
-    const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, splits);
+    const bool big = gemm_big_tiles(M, N, splits);
+    const int bt_ = big ? 128 : GT;
+    const dim3 grid((N + bt_ - 1) / bt_, (M + bt_ - 1) / bt_, splits);
     GemmEpi e0{};
     const GemmEpi& ek = splits > 1 ? e0 : epi;
     float* Ck = splits > 1 ? (float*)ws : C;
     const int ldk = splits > 1 ? N : ldc;
     {
         CFD_PROF_W("k_gemm", st, 4.0 * ((double)M * K + (double)K * N + (double)M * N), 2.0 * M * (double)N * K);
-        if (!at && !bt) hipLaunchKernelGGL((k_gemm<false, false>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);
-        else if (!at && bt) hipLaunchKernelGGL((k_gemm<false, true>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);
-        else if (at && !bt) hipLaunchKernelGGL((k_gemm<true, false>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);
-        else hipLaunchKernelGGL((k_gemm<true, true>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);
+#define GEMM_L(AT_, BT_)                                                                                                          \
+    do {                                                                                                                          \
+        if (big) hipLaunchKernelGGL((k_gemm<AT_, BT_, 4>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);     \
+        else hipLaunchKernelGGL((k_gemm<AT_, BT_, 2>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);        \
+    } while (0)
+        if (!at && !bt) GEMM_L(false, false);
+        else if (!at && bt) GEMM_L(false, true);
+        else if (at && !bt) GEMM_L(true, false);
+        else GEMM_L(true, true);
+#undef GEMM_L
     }
     CFD_LAUNCH_CHECK(what);
     if (splits > 1) {

@@ -152,6 +152,20 @@ def test_gemm(be, M, N, Kd, ta, tb):
     _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
 
 
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("M,N,Kd,ta,tb", [(150, 45, 37, 0, 0), (33, 140, 19, 0, 1), (130, 21, 66, 1, 0), (17, 18, 5, 1, 1)])
+def test_gemm_both_block_tiles(be, M, N, Kd, ta, tb, tile):
+    """The 64 x 64 and the 128 x 128 block tile of k_gemm on every storage form, whatever launch_gemm would pick for the shape."""
+    with K.tuned(be, gemm_tile=tile):
+        _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
+
+
+@pytest.mark.parametrize("M,K_in,N,act", [(137, 21, 24, "relu"), (20, 7, 5, "gelu")])
+def test_linear_act_on_128_tiles(be, M, K_in, N, act):
+    with K.tuned(be, gemm_tile=128):
+        _assert_all(K.check_linear(be, M, K_in, N, act))
+
+
 @pytest.mark.parametrize("R,dims,act,act_last,with_gx", [(70, [5, 12, 20, 7], "relu", False, True), (33, [3, 17, 9], "gelu", True, False),
                                                           (300, [100, 100, 100, 100, 100], "relu", False, True), (130, [7, 128, 64, 100], "tanh", True, True)])
 def test_ffn_stack(be, R, dims, act, act_last, with_gx):
