@@ -99,6 +99,10 @@ __device__ __forceinline__ CfdBuf cfd_buf(const void* base, unsigned bytes) {
 __device__ __forceinline__ float cfd_buf_ld(CfdBuf b, unsigned voff, unsigned soff) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b, (int)voff, (int)soff, 0));
 }
+// 16 bytes per lane from a 4-byte-aligned offset; callers keep the whole access inside the resource or mark it out of range
+__device__ __forceinline__ f32x4 cfd_buf_ld4(CfdBuf b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, 0));
+}
 __device__ __forceinline__ void cfd_buf_st(CfdBuf b, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b, (int)voff, (int)soff, 0);
 }

@@ -42,127 +42,166 @@ __device__ __forceinline__ float cfd_act_grad(float y, float z, int act) {
     }
 }
 
-// One (16 WT*2) x 16 slab of op(X) -- the rows [row0, row0 + 32 WT) of a block tile -- into registers, 64 rows per float4 round.
-// KCONT: the source is k-contiguous (X stored [rows][K]); else it is row-contiguous (X stored [K][rows]).  Either way s[k][row] is
-// what lands in LDS (row stride LD floats).
-template <bool KCONT, int WT>
+// One (64 NR) x 16 slab of op(X) -- the rows [row0, row0 + 64 NR) of a block tile, the reduction indices [k0, k0 + 16) -- in
+// registers and its place in LDS.  KCONT: X is stored [rows][K] (k-contiguous), LDS layout [row][24] (16 k + 8 floats of padding:
+// the operand fetch is ONE conflict-free ds_read_b128 per MFMA tile and slab, the staging store one ds_write_b128); else X is
+// stored [K][rows], LDS layout [k][64 NR + 4] (staging: ds_write_b128 along the rows; operand fetch: ds_read_b32, the four k rows
+// of an MFMA step 16 banks apart).  MFMA step kk of a slab contracts the reduction indices 4 q + kk of its lanes (q = lane / 16) --
+// any assignment works as long as both operands use the same one, and this one makes a k-contiguous operand's four values of a
+// lane one 16-byte unit.  Global loads are raw buffer loads of 16 bytes (4 bytes when the row length is not a multiple of four):
+// out-of-range rows / reduction indices carry CFD_BUF_OOB and come back as zeros, no branch per lane.
+template <bool KCONT, int NR>
 struct SlabRegs {
-    static constexpr int NR = WT / 2;  // rounds of 64 rows
-    float v[NR][4];
-    __device__ __forceinline__ void load(const float* __restrict__ X, int ld, int rows, int K, int row0, int k0, int tid) {
+    static constexpr int ROWS = 64 * NR;  // one 16-byte unit per thread and round of 64 rows
+    static constexpr int LD = KCONT ? 24 : ROWS + 4;
+    static constexpr int FLOATS = KCONT ? ROWS * 24 : GK * (ROWS + 4);
+    f32x4 v[NR];
+    __device__ __forceinline__ void load(const float* __restrict__ X, int ld, int rows, int K, int row0, int k0, int tid, bool vec) {
+        // resource from the slab's first element to the last element of the matrix (clamped to 2^31 bytes: lane offsets stay below
+        // ROWS * ld * 4, launch_gemm bounds ld)
+        const float* base = KCONT ? X + (size_t)row0 * ld + k0 : X + (size_t)k0 * ld + row0;
+        const long ext = KCONT ? (long)(rows - row0 - 1) * ld + (K - k0) : (long)(K - k0 - 1) * ld + (rows - row0);
+        const CfdBuf bf = cfd_buf(base, ext <= 0 ? 0u : (ext >= (1L << 29) ? 0x80000000u : (unsigned)(4 * ext)));
 #pragma unroll
         for (int h = 0; h < NR; ++h) {
-            if constexpr (KCONT) {
-                const int row = row0 + 64 * h + (tid >> 2), k = k0 + (tid & 3) * 4;
-                const float* p = X + (size_t)row * ld + k;
-                if (row < rows && k + 3 < K && ((((uintptr_t)p) & 15) == 0)) {
-                    const float4 t = *reinterpret_cast<const float4*>(p);
-                    v[h][0] = t.x; v[h][1] = t.y; v[h][2] = t.z; v[h][3] = t.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[h][j] = (row < rows && k + j < K) ? p[j] : 0.f;
-                }
+            // (r, c): row within the block tile and reduction index within the slab of this thread's unit; the unit runs along k
+            // (KCONT) or along the rows
+            const int r = KCONT ? 64 * h + (tid >> 2) : 64 * h + (tid & 15) * 4;
+            const int c = KCONT ? (tid & 3) * 4 : tid >> 4;
+            const bool ok = row0 + r < rows && k0 + c < K;
+            const unsigned off = 4u * (unsigned)(KCONT ? r * ld + c : c * ld + r);
+            if (vec) {
+                v[h] = cfd_buf_ld4(bf, ok ? off : CFD_BUF_OOB, 0);
             } else {
-                const int k = k0 + (tid >> 4), row = row0 + 64 * h + (tid & 15) * 4;
-                const float* p = X + (size_t)k * ld + row;
-                if (k < K && row + 3 < rows && ((((uintptr_t)p) & 15) == 0)) {
-                    const float4 t = *reinterpret_cast<const float4*>(p);
-                    v[h][0] = t.x; v[h][1] = t.y; v[h][2] = t.z; v[h][3] = t.w;
-                } else {
+                const int left = KCONT ? K - (k0 + c) : rows - (row0 + r);  // elements of the unit inside the matrix
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[h][j] = (k < K && row + j < rows) ? p[j] : 0.f;
-                }
+                for (int j = 0; j < 4; ++j) v[h][j] = cfd_buf_ld(bf, ok && j < left ? off + 4u * j : CFD_BUF_OOB, 0);
             }
         }
     }
-    template <int LD>
     __device__ __forceinline__ void store(float* s, int tid) const {
 #pragma unroll
         for (int h = 0; h < NR; ++h) {
-            if constexpr (KCONT) {
-                const int row = 64 * h + (tid >> 2), k = (tid & 3) * 4;
+            if constexpr (KCONT) *reinterpret_cast<f32x4*>(s + (64 * h + (tid >> 2)) * 24 + (tid & 3) * 4) = v[h];
+            else *reinterpret_cast<f32x4*>(s + (tid >> 4) * LD + 64 * h + (tid & 15) * 4) = v[h];
+        }
+    }
+    // this lane's operand values of 16-row tile `tile` for the four MFMA steps of the slab
+    __device__ static __forceinline__ f32x4 fetch(const float* s, int tile, int q, int n) {
+        if constexpr (KCONT) {
+            return *reinterpret_cast<const f32x4*>(s + (16 * tile + n) * 24 + 4 * q);
+        } else {
+            f32x4 f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s[(k + j) * LD + row] = v[h][j];
-            } else {
-                const int k = tid >> 4, row = 64 * h + (tid & 15) * 4;
-                *reinterpret_cast<float4*>(s + k * LD + row) = make_float4(v[h][0], v[h][1], v[h][2], v[h][3]);
-            }
+            for (int kk = 0; kk < 4; ++kk) f[kk] = s[(4 * q + kk) * LD + 16 * tile + n];
+            return f;
         }
     }
 };
 
 // C[M][N] = epi( sum_k opA(m,k) opB(k,n) );  AT: A stored [K][M] (else [M][K]);  BT: B stored [N][K] (else [K][N]).
-// WT x WT MFMA tiles per wave, block tile 32 WT square.  WT = 2 (64 x 64: round 1's kernel) makes 16 MFMAs between two barriers
-// with one ds_read_b32 per MFMA operand and ran the 131 k x 200 x 200 Linear layers of the DeepONet family at a quarter of the fp32
-// matrix pipe's rate; WT = 4 (128 x 128) makes 64 MFMAs per barrier from 32 operand reads and half the operand traffic per flop:
-// launch_gemm picks it whenever the 128-tiles still fill the chip.
-template <bool AT, bool BT, int WT>
+// Four waves as a WGM x WGN grid, WTM x WTN MFMA tiles per wave: block tile (16 WTM WGM) x (16 WTN WGN).  Shapes built:
+//   2 x 2 waves of 2 x 2 tiles:   64 x 64   THE DEFAULT: 85 registers, 21-25 KB of LDS, five to seven blocks per CU
+//   2 x 2 waves of 4 x 4 tiles:  128 x 128  (gemm_tile = 128) half the operand reads per flop
+//   4 x 1 waves of 2 x 8 / 2 x 16 tiles: 128 rows x ALL columns up to 128 / 256 (gemm_tile = 1): A read once, 13 column tiles for N = 200
+//     where the square blocks cover 16
+// The two large shapes are SLOWER on every product of the benchmark (131 k x 200 x 200 of the Auto-FFN: 64 x 64 3.41 ms of k_gemm per
+// step, 128 x 128 3.83-3.97, all-columns 3.62-5.10; profiles/r04g_gemm_counters.txt): the kernel's time is the SUM of its parts -- the
+// MFMAs, the global loads, the epilogue, the LDS / barrier skeleton, measured by taking each out -- not their maximum, and only many
+// small blocks per CU overlap them; they stay in the build behind the knob, with their tests.  Row / column tiles beyond M / N are
+// skipped.
+// K in slabs of 16 through a three-deep pipeline: while slab s is on the matrix pipe, slab s + 1 -- loaded during slab s - 1 -- goes
+// from registers to the other LDS buffer (the stores are issued in front of the MFMAs and complete beside them) and slab s + 2 is
+// on its way from memory; one barrier per slab.
+template <bool AT, bool BT, int WGM, int WTM, int WTN>
 __global__ __launch_bounds__(256, 2) void k_gemm(const float* __restrict__ A, const float* __restrict__ B,
                                                  float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
-                                                 GemmEpi epi, int slabs_per_split) {
-    constexpr int BT_ = 32 * WT;                  // block tile edge
-    constexpr int LD = BT_ + (WT == 2 ? 4 : 16);  // LDS row stride in floats: 16-B aligned rows; the 128-wide tile's four k rows of
-                                                  // one MFMA step (lanes q) sit 16 banks apart: its operand reads are conflict-free
-    __shared__ __attribute__((aligned(16))) float s_a[2][GK * LD];
-    __shared__ __attribute__((aligned(16))) float s_b[2][GK * LD];
+                                                 GemmEpi epi, int slabs_per_split, int nbx, int nby, int nbz) {
+    constexpr int WGN = 4 / WGM;
+    constexpr int BM = 16 * WTM * WGM, BN = 16 * WTN * WGN;  // block tile
+    using RA = SlabRegs<!AT, BM / 64>;  // A is k-contiguous unless transposed
+    using RB = SlabRegs<BT, BN / 64>;   // B is k-contiguous only when stored transposed
+    CFD_DYN_SHARED(f32x4, s_dyn);  // (the all-columns tile holds 72 KB: beyond the static limit)
+    float* const s_a[2] = {(float*)s_dyn, (float*)s_dyn + RA::FLOATS};
+    float* const s_b[2] = {(float*)s_dyn + 2 * RA::FLOATS, (float*)s_dyn + 2 * RA::FLOATS + RB::FLOATS};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, n = lane & 15;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BT_, n0 = blockIdx.x * BT_;
-    SlabRegs<!AT, WT> ra;  // A is k-contiguous unless transposed
-    SlabRegs<BT, WT> rb;   // B is k-contiguous only when stored transposed
+    const int wm = wave / WGN, wn = wave % WGN;
+    // Block -> tile map.  Workgroups are dealt to the 8 XCDs round robin in launch order and each XCD has its own L2, so the blocks
+    // that read the same operand rows -- the column blocks of one row tile; with split-K all tiles of one K range -- are made
+    // CONSECUTIVE ON ONE XCD instead of consecutive in launch order.  Groups of `gs` blocks; group g = 8 (l / gs) + XCD for the
+    // XCD's l-th block; the grid is padded to a multiple of 8 groups.  (Measured: no change on MI355X -- the re-reads of a plain
+    // (x, y, z) grid are served by the memory-side cache -- kept because it halves the HBM fetches.)
+    const int gs = nbz > 1 ? nbx * nby : nbx, ngroups = nbz > 1 ? nbz : nby;
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int grp = 8 * (l / gs) + xcd, t = l % gs;
+    if (grp >= ngroups) return;
+    const int bx = t % nbx, by = nbz > 1 ? t / nbx : grp, bz = nbz > 1 ? grp : 0;
+    const int m0 = by * BM, n0 = bx * BN;
+    // (uniform) this wave's row / column tiles that hold an element of C: the others are skipped -- with several blocks per SIMD the
+    // matrix-pipe time a wave does not use goes to its neighbours (N = 200 on 64-wide blocks: 13 live column tiles of 16)
+    const int ntm = (M - m0 - 16 * WTM * wm + 15) / 16, ntn = (N - n0 - 16 * WTN * wn + 15) / 16;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc[WT][WT];
+    f32x4 acc[WTM][WTN];
 #pragma unroll
-    for (int i = 0; i < WT; ++i)
+    for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < WT; ++j) acc[i][j] = zero;
-    // split-K: blockIdx.z owns slabs [s0, s1) and writes its partial tile to C + z*M*ldc (epilogue in k_splitk_reduce)
+        for (int j = 0; j < WTN; ++j) acc[i][j] = zero;
+    // split-K: block bz owns slabs [s0, s1) and writes its partial tile to C + bz*M*ldc (epilogue in k_splitk_reduce)
     const int nslab_all = (K + GK - 1) / GK;
-    const int s0 = blockIdx.z * slabs_per_split;
+    const int s0 = bz * slabs_per_split;
     const int nslab = (s0 + slabs_per_split < nslab_all ? s0 + slabs_per_split : nslab_all) - s0;
-    C += (size_t)blockIdx.z * M * ldc;
-    ra.load(A, lda, M, K, m0, s0 * GK, tid);
-    rb.load(B, ldb, N, K, n0, s0 * GK, tid);
-    ra.template store<LD>(s_a[0], tid);
-    rb.template store<LD>(s_b[0], tid);
-    __syncthreads();
-    for (int s = 0; s < nslab; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < nslab) {  // next slab's global reads fly during this slab's MFMAs
-            ra.load(A, lda, M, K, m0, (s0 + s + 1) * GK, tid);
-            rb.load(B, ldb, N, K, n0, (s0 + s + 1) * GK, tid);
-        }
-        const float* sa = s_a[cur];
-        const float* sb = s_b[cur];
+    C += (size_t)bz * M * ldc;
+    const bool va = ((AT ? M : K) & 3) == 0, vb = ((BT ? K : N) & 3) == 0;  // (uniform) 16-byte units never straddle a row end
+    RA ra0, ra1;
+    RB rb0, rb1;
+    const auto load = [&](RA& ra, RB& rb, int slab) {
+        ra.load(A, lda, M, K, m0, (s0 + slab) * GK, tid, va);
+        rb.load(B, ldb, N, K, n0, (s0 + slab) * GK, tid, vb);
+    };
+    const auto mma = [&](const float* sa, const float* sb) {
+        f32x4 fa[WTM];
 #pragma unroll
-        for (int kk = 0; kk < GK / 4; ++kk) {
-            float av[WT], bv[WT];
+        for (int i = 0; i < WTM; ++i) fa[i] = RA::fetch(sa, WTM * wm + i, q, n);
 #pragma unroll
-            for (int i = 0; i < WT; ++i) {
-                av[i] = sa[(4 * kk + q) * LD + 16 * WT * wm + 16 * i + n];
-                bv[i] = sb[(4 * kk + q) * LD + 16 * WT * wn + 16 * i + n];
+        for (int j = 0; j < WTN; ++j) {
+            if (j >= ntn) break;
+            const f32x4 fb = RB::fetch(sb, WTN * wn + j, q, n);
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) {
+                if (i >= ntm) break;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc[i][j] = cfd_mfma16x16x4(fa[i][kk], fb[kk], acc[i][j]);
             }
-#pragma unroll
-            for (int i = 0; i < WT; ++i)
-#pragma unroll
-                for (int j = 0; j < WT; ++j) acc[i][j] = cfd_mfma16x16x4(av[i], bv[j], acc[i][j]);
         }
-        if (s + 1 < nslab) {
-            ra.template store<LD>(s_a[cur ^ 1], tid);  // the other buffer was last read before the previous barrier
-            rb.template store<LD>(s_b[cur ^ 1], tid);
-        }
+    };
+    load(ra0, rb0, 0);
+    if (nslab > 1) load(ra1, rb1, 1);
+    ra0.store(s_a[0], tid);
+    rb0.store(s_b[0], tid);
+    __syncthreads();
+    for (int s = 0; s < nslab; s += 2) {
+        // slab s from buffer 0; slab s + 1 waits in (ra1, rb1)
+        if (s + 1 < nslab) { ra1.store(s_a[1], tid); rb1.store(s_b[1], tid); }  // (buffer 1 was last read before the previous barrier)
+        if (s + 2 < nslab) load(ra0, rb0, s + 2);
+        mma(s_a[0], s_b[0]);
+        __syncthreads();
+        if (s + 1 >= nslab) break;
+        // slab s + 1 from buffer 1; slab s + 2 waits in (ra0, rb0)
+        if (s + 2 < nslab) { ra0.store(s_a[0], tid); rb0.store(s_b[0], tid); }
+        if (s + 3 < nslab) load(ra1, rb1, s + 3);
+        mma(s_a[1], s_b[1]);
         __syncthreads();
     }
-    // acc[i][j][r] = C[m0 + 16 WT wm + 16i + 4q + r][n0 + 16 WT wn + 16j + n]
+    // acc[i][j][r] = C[m0 + 16 (WTM wm + i) + 4q + r][n0 + 16 (WTN wn + j) + n]
 #pragma unroll
-    for (int i = 0; i < WT; ++i)
+    for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < WT; ++j) {
-            const int col = n0 + 16 * WT * wn + 16 * j + n;
+        for (int j = 0; j < WTN; ++j) {
+            const int col = n0 + 16 * (WTN * wn + j) + n;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + 16 * WT * wm + 16 * i + 4 * q + r;
+                const int row = m0 + 16 * (WTM * wm + i) + 4 * q + r;
                 if (row < M && col < N) {
                     float v = acc[i][j][r];
                     if (epi.mode == 1) {
@@ -219,40 +258,62 @@ static size_t gemm_ws_bytes(int M, int N, int K) {
     return s > 1 ? cfd_align_up((size_t)s * M * N * sizeof(float), 256) : 0;
 }
 
-// 128 x 128 block tiles (WT = 4) when they alone give every CU a workgroup and no split-K is wanted; else the 64 x 64 kernel
-static bool gemm_big_tiles(int M, int N, int splits) {
+// Block tile of a product: 64 x 64 unless the gemm_tile knob asks for 128 x 128 or (1) 128 rows x all columns (see k_gemm).
+static int gemm_tile_kind(int M, int N, int splits) {
     const int t = cfd_tune_get(CFD_TUNE_GEMM_TILE);
-    if (t == 64) return false;
-    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-    return splits == 1 && (t == 128 || tiles >= 256);
+    if (t == 64) return 64;
+    if (t == 128) return 128;
+    if (t == 1) return N <= 128 ? 1 : 2;  // (the all-columns kernels on any shape; N > 256 takes several column blocks)
+    (void)M; (void)splits;
+    return 64;
 }
 
 static int launch_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int at,
                        int bt, const GemmEpi& epi, void* ws, hipStream_t st, const char* what) {
     if (M == 0 || N == 0) return CFD_OK;
+    CFD_REQUIRE(lda < (1 << 22) && ldb < (1 << 22), CFD_ERR_UNSUPPORTED, "%s: leading dimensions beyond 2^22 (lda %d, ldb %d)", what, lda, ldb);
     int splits = ws ? gemm_splits(M, N, K) : 1;
     const int nslab = (K + GK - 1) / GK;
     const int per = (nslab + splits - 1) / splits;
     splits = (nslab + per - 1) / per;
-    const bool big = gemm_big_tiles(M, N, splits);
-    const int bt_ = big ? 128 : GT;
-    const dim3 grid((N + bt_ - 1) / bt_, (M + bt_ - 1) / bt_, splits);
+    const int kind = gemm_tile_kind(M, N, splits);
+    const int bm = kind == 64 ? 64 : 128, bn = kind == 64 ? 64 : (kind == 1 ? 128 : (kind == 2 ? 256 : 128));
+    const int nbx = (N + bn - 1) / bn, nby = (M + bm - 1) / bm;
+    const long ngroups = splits > 1 ? splits : nby, gsz = splits > 1 ? (long)nbx * nby : nbx;
+    const long nblocks = ((ngroups + 7) / 8) * 8 * gsz;  // (see k_gemm: block -> tile map)
+    CFD_REQUIRE(nblocks < (1L << 31), CFD_ERR_UNSUPPORTED, "%s: %ld blocks", what, nblocks);
+    const dim3 grid((unsigned)nblocks);
     GemmEpi e0{};
     const GemmEpi& ek = splits > 1 ? e0 : epi;
     float* Ck = splits > 1 ? (float*)ws : C;
     const int ldk = splits > 1 ? N : ldc;
     {
         CFD_PROF_W("k_gemm", st, 4.0 * ((double)M * K + (double)K * N + (double)M * N), 2.0 * M * (double)N * K);
-#define GEMM_L(AT_, BT_)                                                                                                          \
-    do {                                                                                                                          \
-        if (big) hipLaunchKernelGGL((k_gemm<AT_, BT_, 4>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);     \
-        else hipLaunchKernelGGL((k_gemm<AT_, BT_, 2>), grid, dim3(256), 0, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per);        \
+#define GEMM_K(AT_, BT_, G_, TM_, TN_)                                                                                                     \
+    do {                                                                                                                                  \
+        constexpr int bm_ = 16 * TM_ * G_, bn_ = 16 * TN_ * (4 / G_);                                                                     \
+        constexpr size_t lds_ = 2 * sizeof(float) * (SlabRegs<!AT_, bm_ / 64>::FLOATS + SlabRegs<BT_, bn_ / 64>::FLOATS);                \
+        static bool attr_set = false;                                                                                                     \
+        if (!attr_set) {                                                                                                                  \
+            (void)hipFuncSetAttribute((const void*)k_gemm<AT_, BT_, G_, TM_, TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+            attr_set = true;                                                                                                              \
+        }                                                                                                                                 \
+        hipLaunchKernelGGL((k_gemm<AT_, BT_, G_, TM_, TN_>), grid, dim3(256), lds_, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per, nbx,   \
+                           nby, splits);                                                                                                  \
+    } while (0)
+#define GEMM_L(AT_, BT_)                                  \
+    do {                                                  \
+        if (kind == 64) GEMM_K(AT_, BT_, 2, 2, 2);        \
+        else if (kind == 128) GEMM_K(AT_, BT_, 2, 4, 4);  \
+        else if (kind == 1) GEMM_K(AT_, BT_, 4, 2, 8);    \
+        else GEMM_K(AT_, BT_, 4, 2, 16);                  \
     } while (0)
         if (!at && !bt) GEMM_L(false, false);
         else if (!at && bt) GEMM_L(false, true);
         else if (at && !bt) GEMM_L(true, false);
         else GEMM_L(true, true);
 #undef GEMM_L
+#undef GEMM_K
     }
     CFD_LAUNCH_CHECK(what);
     if (splits > 1) {

@@ -104,6 +104,13 @@ inline float cfd_buf_ld(CfdBuf b, unsigned voff, unsigned soff) {
     memcpy(&v, b.base + voff + soff, 4);
     return v;
 }
+inline f32x4 cfd_buf_ld4(CfdBuf b, unsigned voff, unsigned soff) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (voff >= b.bytes) return v;
+    cfd_buf_check(b, voff + 12, soff);  // a live access lies inside the resource as a whole
+    memcpy(&v, b.base + voff + soff, 16);
+    return v;
+}
 inline void cfd_buf_st(CfdBuf b, unsigned voff, unsigned soff, float v) {
     if (voff >= b.bytes) return;
     cfd_buf_check(b, voff, soff);

@@ -152,17 +152,19 @@ def test_gemm(be, M, N, Kd, ta, tb):
     _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
 
 
-@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("tile", [64, 128, 1])
 @pytest.mark.parametrize("M,N,Kd,ta,tb", [(150, 45, 37, 0, 0), (33, 140, 19, 0, 1), (130, 21, 66, 1, 0), (17, 18, 5, 1, 1)])
 def test_gemm_both_block_tiles(be, M, N, Kd, ta, tb, tile):
-    """The 64 x 64 and the 128 x 128 block tile of k_gemm on every storage form, whatever launch_gemm would pick for the shape."""
+    """Every block tile of k_gemm (64 x 64, 128 x 128, 1 = 128 rows x all columns) on every storage form, whatever launch_gemm would
+    pick for the shape."""
     with K.tuned(be, gemm_tile=tile):
         _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
 
 
 @pytest.mark.parametrize("M,K_in,N,act", [(137, 21, 24, "relu"), (20, 7, 5, "gelu")])
-def test_linear_act_on_128_tiles(be, M, K_in, N, act):
-    with K.tuned(be, gemm_tile=128):
+@pytest.mark.parametrize("tile", [128, 1])
+def test_linear_act_on_the_large_tiles(be, M, K_in, N, act, tile):
+    with K.tuned(be, gemm_tile=tile):
         _assert_all(K.check_linear(be, M, K_in, N, act))
 
 

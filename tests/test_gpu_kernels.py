@@ -199,17 +199,19 @@ def test_gemm(be, M, N, Kd, ta, tb):
     _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
 
 
-@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("tile", [64, 128, 1])
 @pytest.mark.parametrize("M,N,Kd,ta,tb", [(4290, 100, 100, 0, 0), (70001, 200, 200, 0, 1), (300, 515, 4000, 1, 0), (130, 129, 77, 1, 1), (70, 45, 37, 0, 0)])
 def test_gemm_both_block_tiles(be, M, N, Kd, ta, tb, tile):
-    """The 64 x 64 and the 128 x 128 block tile of k_gemm on every storage form, whatever launch_gemm would pick for the shape."""
+    """Every block tile of k_gemm (64 x 64, 128 x 128, 1 = 128 rows x all columns) on every storage form, whatever launch_gemm would
+    pick for the shape."""
     with K.tuned(be, gemm_tile=tile):
         _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
 
 
-@pytest.mark.parametrize("M,K_in,N,act", [(131072, 200, 200, "tanh"), (4290, 100, 100, "relu"), (129, 33, 70, "swish"), (2050, 5, 530, "none")]  # (the Auto-FFN layer with a smooth activation: among 26 M pre-activations a handful sit within an fp32 rounding of the ReLU kink))
-def test_linear_act_on_128_tiles(be, M, K_in, N, act):
-    with K.tuned(be, gemm_tile=128):
+@pytest.mark.parametrize("M,K_in,N,act", [(131072, 200, 200, "tanh"), (4290, 100, 100, "relu"), (129, 33, 70, "swish"), (2050, 5, 530, "none")])  # (the Auto-FFN layer with a smooth activation: among 26 M pre-activations a handful sit within an fp32 rounding of the ReLU kink)
+@pytest.mark.parametrize("tile", [128, 1])
+def test_linear_act_on_the_large_tiles(be, M, K_in, N, act, tile):
+    with K.tuned(be, gemm_tile=tile):
         _assert_all(K.check_linear(be, M, K_in, N, act))
 
 

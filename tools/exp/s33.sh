@@ -1,9 +1,8 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_kernels.py -q -x -k "gemm or linear_act or deeponet_inner or ffn" 2>&1 | tail -2
-for t in 64 -1; do
+for t in 64 128 1; do
   export CFD_GEMM_TILE=$t
   echo "== CFD_GEMM_TILE=$t"
-  for leg in deeponet auto_ffn auto_deeponet_cnn auto_deeponet auto_edeeponet; do
+  for leg in deeponet auto_ffn auto_deeponet_cnn; do
   python bench.py --only $leg 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=list(json.load(sys.stdin).values())[0]
