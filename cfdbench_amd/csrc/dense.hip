@@ -248,6 +248,8 @@ static int gemm_splits(int M, int N, int K) {
     // barrier latencies -- the 200 x 200 weight gradients over 131 k rows of the Auto-FFN ran at 30 % of the matrix pipe, half the
     // rate of the forward product of the same size (profiles/r04g_gemm_counters.txt)
     long s = (1024 + tiles - 1) / tiles;
+    const long smax = nslab / 16 > 256 / tiles ? nslab / 16 : (256 + tiles - 1) / tiles;  // beyond one block per CU: >= 16 slabs (256 k) per split
+    if (s > smax) s = smax;
     if (s > nslab / 4) s = nslab / 4;  // at least 4 slabs (64 k) per split
     if (s > 128) s = 128;
     return s < 1 ? 1 : (int)s;
