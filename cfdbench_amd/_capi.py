@@ -31,6 +31,14 @@ class FnoParams(C.Structure):
     ]
 
 
+class FfnStackArgs(C.Structure):
+    """``cfd_ffn_stack_args`` (include/cfdbench_amd.h): one Linear(+activation) stack of a multi-stack launch; w / b / y / z / gw / gb point
+    at host arrays of ``L`` device pointers, ``dims`` at ``L + 1`` ints."""
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("R", C.c_int),
+                ("dims", C.c_void_p), ("L", C.c_int), ("act", C.c_int), ("act_last", C.c_int),
+                ("gy", C.c_void_p), ("gw", C.c_void_p), ("gb", C.c_void_p), ("gx", C.c_void_p), ("ws", C.c_void_p)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -125,6 +133,8 @@ _SIGS = {
     "cfd_dropout_gelu_bwd": (_I, [_P, _P, _P, _Z, _F, C.c_ulonglong, _P]),
     "cfd_ffn_stack_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "cfd_ffn_stack_bwd_workspace_bytes": (_Z, [_I, _P, _I]),
+    "cfd_ffn_stacks_fwd": (_I, [_I, C.POINTER(FfnStackArgs), _P]),
+    "cfd_ffn_stacks_bwd": (_I, [_I, C.POINTER(FfnStackArgs), _P]),
     "cfd_ffn_stack_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "cfd_fno_workspace_bytes": (_Z, [_P, C.POINTER(FnoShape), _I]),
     "cfd_fno_forward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), _P, _P, _P, _P, _P, _P, _P, _I, _P]),

@@ -26,6 +26,18 @@ struct FfnStack {
     int L, act, act_last;
 };
 
+// Several independent stacks in ONE launch per direction (the branch and trunk nets of the DeepONet variants: 32 + 269 row tiles
+// at BASELINE configs[3], each too few to fill 256 CUs and each at its latency floor): workgroups [blk0[s], blk0[s+1]) walk stack s.
+#define FS_MAXS 3
+struct FfnStackSet {
+    FfnStack st[FS_MAXS];
+    const float* x[FS_MAXS];
+    int R[FS_MAXS];
+    int blk0[FS_MAXS + 1];   // first workgroup (forward / chain) of each stack
+    int lay0[FS_MAXS + 1];   // first (stack, layer) index of each stack in the weight-gradient / reduction grids
+    int ns;
+};
+
 __device__ __forceinline__ float fs_act(float z, int act) {
     switch (act) {
         case 1: return z > 0.f ? z : 0.f;
@@ -153,14 +165,19 @@ __device__ __forceinline__ void fs_tile_load(const float* __restrict__ src, int 
 // ------------------------------------------------------------------------------------------------------
 // Dynamic LDS: row stride FS_LD = (widest layer rounded up to 16) + 4 floats (16-byte aligned rows, staggered banks);
 // [2][16][FS_LD] activations (ping-pong) | [widest][FS_LD] weights -- 67 KB at width 100, so two workgroups share a CU.
-__global__ __launch_bounds__(256, 2) void k_ffn_stack_fwd(const float* __restrict__ x, const FfnStack st, int R, int FS_LD) {
+__global__ __launch_bounds__(256, 2) void k_ffn_stack_fwd(const FfnStackSet set, int FS_LD) {
     CFD_DYN_SHARED(float4, s_dyn4);
+    int si = 0;
+    while (si + 1 < set.ns && (int)blockIdx.x >= set.blk0[si + 1]) ++si;
+    const FfnStack& st = set.st[si];
+    const float* __restrict__ x = set.x[si];
+    const int R = set.R[si];
     float* sA0 = reinterpret_cast<float*>(s_dyn4);
     float* sA[2] = {sA0, sA0 + FS_ROWS * FS_LD};   // the tile's activations y_{l-1} / y_l (ping-pong)
     float* sW = sA0 + 2 * FS_ROWS * FS_LD;         // W_l
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
-    const int row0 = blockIdx.x * FS_ROWS;
+    const int row0 = ((int)blockIdx.x - set.blk0[si]) * FS_ROWS;
     FsWRegs wr;
     fs_wfetch(st.w[0], st.dims[1], st.dims[0], wr);
     fs_tile_load(x, R, st.dims[0], row0, sA[0], FS_LD);
@@ -211,15 +228,28 @@ struct FfnStackBwd {
     int pstride;           // floats per partial slice
 };
 
-__global__ __launch_bounds__(256, 2) void k_ffn_stack_bwd_chain(const float* __restrict__ gy, const FfnStack st, const FfnStackBwd bw,
-                                                                 float* __restrict__ gx, int R, int FS_LD) {
+struct FfnStackBwdSet {
+    FfnStackBwd bw[FS_MAXS];
+    const float* gy[FS_MAXS];
+    float* gx[FS_MAXS];
+    float* part[FS_MAXS];   // FS_KSPLIT partial slices of the stack's gradients
+};
+
+__global__ __launch_bounds__(256, 2) void k_ffn_stack_bwd_chain(const FfnStackSet set, const FfnStackBwdSet bset, int FS_LD) {
     CFD_DYN_SHARED(float4, s_dyn4);
+    int si = 0;
+    while (si + 1 < set.ns && (int)blockIdx.x >= set.blk0[si + 1]) ++si;
+    const FfnStack& st = set.st[si];
+    const FfnStackBwd& bw = bset.bw[si];
+    const float* __restrict__ gy = bset.gy[si];
+    float* __restrict__ gx = bset.gx[si];
+    const int R = set.R[si];
     float* sG0 = reinterpret_cast<float*>(s_dyn4);
     float* sG[2] = {sG0, sG0 + FS_ROWS * FS_LD};   // dZ_l of the tile / the next G (ping-pong)
     float* sW = sG0 + 2 * FS_ROWS * FS_LD;         // W_l: sW[j][i] (rows = this layer's outputs j = the chain's K)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
-    const int row0 = blockIdx.x * FS_ROWS;
+    const int row0 = ((int)blockIdx.x - set.blk0[si]) * FS_ROWS;
     FsWRegs wr;
     fs_wfetch(st.w[st.L - 1], st.dims[st.L], st.dims[st.L - 1], wr);
     fs_tile_load(gy, R, st.dims[st.L], row0, sG[0], FS_LD);
@@ -276,9 +306,15 @@ __global__ __launch_bounds__(256, 2) void k_ffn_stack_bwd_chain(const float* __r
 // gradient as the extra input column i = Din whose value is 1.  Grid (tile, layer, row slice); one wave per 16 x 16 tile and
 // slice; partial tiles are summed by k_ffn_stack_reduce in a fixed order.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_ffn_stack_wgrad(const float* __restrict__ x, const FfnStack st, const FfnStackBwd bw,
-                                                         float* __restrict__ part, int R) {
-    const int l = blockIdx.y, slice = blockIdx.z;
+__global__ __launch_bounds__(64) void k_ffn_stack_wgrad(const FfnStackSet set, const FfnStackBwdSet bset) {
+    int si = 0;
+    while (si + 1 < set.ns && (int)blockIdx.y >= set.lay0[si + 1]) ++si;
+    const FfnStack& st = set.st[si];
+    const FfnStackBwd& bw = bset.bw[si];
+    const float* __restrict__ x = set.x[si];
+    float* __restrict__ part = bset.part[si];
+    const int R = set.R[si];
+    const int l = (int)blockIdx.y - set.lay0[si], slice = blockIdx.z;
     const int Din = st.dims[l], Dout = st.dims[l + 1];
     const int NTi = (Din + 1 + 15) >> 4, NTj = (Dout + 15) >> 4;
     if ((int)blockIdx.x >= NTi * NTj) return;
@@ -290,11 +326,34 @@ __global__ __launch_bounds__(64) void k_ffn_stack_wgrad(const float* __restrict_
     const int r0 = slice * per, r1 = r0 + per < R ? r0 + per : R;
     const int j = 16 * tj + n, i = 16 * ti + n;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0 + q; r < r1 + q; r += 4) {  // wave-uniform trip count; lanes past the slice contribute zeros
+    // Eight MFMA steps (32 rows) per trip, all sixteen loads of a trip issued before its first MFMA: with one step per trip every
+    // step waited for its own two loads -- 134 exposed L2 latencies per wave at the trunk net's 536 rows per slice, 32 us per launch
+    // for 0.7 GFLOP.  Unconditional loads from clamped addresses (a `cond ? load : 0` is a branch and a full wait per element), zeroed
+    // afterwards; the products are added in row order as before: the sums do not depend on the trip structure.
+    const int jc = j < Dout ? j : Dout - 1, ic = i < Din ? i : Din - 1;
+    const float bconst = i == Din ? 1.f : 0.f;  // the bias gradient's column of ones
+    int r = r0 + q;
+    for (; r + 28 < r1 + q; r += 32) {  // (wave-uniform) all eight steps start inside [r0 + q, r1 + q)
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int rr = r + 4 * u, rc = rr < r1 ? rr : r1 - 1;
+            a[u] = dz[(size_t)rc * Dout + jc];
+            b[u] = yin[(size_t)rc * Din + ic];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = r + 4 * u < r1;
+            const float av = (ok && j < Dout) ? a[u] : 0.f;
+            const float bv = !ok ? 0.f : (i < Din ? b[u] : bconst);
+            acc = cfd_mfma16x16x4(av, bv, acc);
+        }
+    }
+    for (; r < r1 + q; r += 4) {  // wave-uniform trip count; lanes past the slice contribute zeros
         const bool ok = r < r1;
-        const float a = (ok && j < Dout) ? dz[(size_t)r * Dout + j] : 0.f;
-        const float b = !ok ? 0.f : (i < Din ? yin[(size_t)r * Din + i] : (i == Din ? 1.f : 0.f));
-        acc = cfd_mfma16x16x4(a, b, acc);
+        const int rc = ok ? r : r1 - 1;
+        const float a = dz[(size_t)rc * Dout + jc], b = yin[(size_t)rc * Din + ic];
+        acc = cfd_mfma16x16x4((ok && j < Dout) ? a : 0.f, !ok ? 0.f : (i < Din ? b : bconst), acc);
     }
     float* p = part + (size_t)slice * bw.pstride + bw.poff[l];
 #pragma unroll
@@ -312,9 +371,15 @@ struct FfnStackGrads {
     float* gw[FS_MAXL];
     float* gb[FS_MAXL];
 };
-__global__ __launch_bounds__(256) void k_ffn_stack_reduce(const float* __restrict__ part, const FfnStack st, const FfnStackBwd bw,
-                                                           const FfnStackGrads g) {
-    const int l = blockIdx.y;
+struct FfnStackGradsSet { FfnStackGrads g[FS_MAXS]; };
+__global__ __launch_bounds__(256) void k_ffn_stack_reduce(const FfnStackSet set, const FfnStackBwdSet bset, const FfnStackGradsSet gset) {
+    int si = 0;
+    while (si + 1 < set.ns && (int)blockIdx.y >= set.lay0[si + 1]) ++si;
+    const FfnStack& st = set.st[si];
+    const FfnStackBwd& bw = bset.bw[si];
+    const FfnStackGrads& g = gset.g[si];
+    const float* __restrict__ part = bset.part[si];
+    const int l = (int)blockIdx.y - set.lay0[si];
     const int Din = st.dims[l], Dout = st.dims[l + 1];
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= Dout * Din + Dout) return;
@@ -351,26 +416,56 @@ static void fs_fill(FfnStack& st, const float* const* w, const float* const* b, 
     for (int l = 0; l < L; ++l) { st.w[l] = w[l]; st.b[l] = b ? b[l] : nullptr; st.y[l] = y[l]; st.z[l] = z ? z[l] : nullptr; }
 }
 
+static int fs_check_fwd(const char* fn, const cfd_ffn_stack_args& a) {
+    CFD_TRY(fs_check(fn, a.R, a.dims, a.L, a.act));
+    CFD_REQUIRE(a.x && a.w && a.y, CFD_ERR_INVALID_ARG, "%s: NULL pointer", fn);
+    for (int l = 0; l < a.L; ++l) {
+        CFD_REQUIRE(a.w[l] && a.y[l], CFD_ERR_INVALID_ARG, "%s: NULL weight / output of layer %d", fn, l);
+        CFD_REQUIRE(a.act < 3 || !(l + 1 < a.L || a.act_last) || (a.z && a.z[l]), CFD_ERR_INVALID_ARG,
+                    "%s: gelu / swish need the pre-activation buffer of layer %d", fn, l);
+    }
+    return CFD_OK;
+}
+
+static int fs_fwd(const char* fn, int n, const cfd_ffn_stack_args* a, hipStream_t s) {
+    CFD_REQUIRE(a && n >= 1 && n <= FS_MAXS, CFD_ERR_INVALID_ARG, "%s: 1 .. %d stacks per call", fn, FS_MAXS);
+    FfnStackSet set{};
+    int ld = 0, blocks = 0;
+    double fl = 0.0, by = 0.0;
+    for (int i = 0; i < n; ++i) {
+        CFD_TRY(fs_check_fwd(fn, a[i]));
+        if (a[i].R == 0) continue;  // an empty stack takes no workgroup
+        const int k = set.ns++;
+        fs_fill(set.st[k], a[i].w, a[i].b, a[i].y, a[i].z, a[i].dims, a[i].L, a[i].act, a[i].act_last);
+        set.x[k] = a[i].x;
+        set.R[k] = a[i].R;
+        set.blk0[k] = blocks;
+        blocks += (a[i].R + FS_ROWS - 1) / FS_ROWS;
+        const int l_ = fs_ld(a[i].dims, a[i].L);
+        if (l_ > ld) ld = l_;
+        by += 4.0 * a[i].R * a[i].dims[0];
+        for (int l = 0; l < a[i].L; ++l) {
+            fl += 2.0 * a[i].R * a[i].dims[l] * a[i].dims[l + 1];
+            by += 4.0 * a[i].R * a[i].dims[l + 1] + 4.0 * a[i].dims[l] * a[i].dims[l + 1];
+        }
+    }
+    if (set.ns == 0) return CFD_OK;
+    set.blk0[set.ns] = blocks;
+    CFD_PROF_W("k_ffn_stack_fwd", s, by, fl);
+    hipLaunchKernelGGL(k_ffn_stack_fwd, dim3(blocks), dim3(256), fs_lds_bytes(ld), s, set, ld);
+    CFD_LAUNCH_CHECK(fn);
+    return CFD_OK;
+}
+
+extern "C" int cfd_ffn_stacks_fwd(int n, const cfd_ffn_stack_args* stacks, void* stream) {
+    return fs_fwd("cfd_ffn_stacks_fwd", n, stacks, (hipStream_t)stream);
+}
+
 extern "C" int cfd_ffn_stack_fwd(const float* x, const float* const* w, const float* const* b, float* const* y, float* const* z,
                                  int R, const int* dims, int L, int act, int act_last, void* stream) {
-    CFD_TRY(fs_check("cfd_ffn_stack_fwd", R, dims, L, act));
-    CFD_REQUIRE(x && w && y, CFD_ERR_INVALID_ARG, "cfd_ffn_stack_fwd: NULL pointer");
-    for (int l = 0; l < L; ++l) {
-        CFD_REQUIRE(w[l] && y[l], CFD_ERR_INVALID_ARG, "cfd_ffn_stack_fwd: NULL weight / output of layer %d", l);
-        CFD_REQUIRE(act < 3 || !(l + 1 < L || act_last) || (z && z[l]), CFD_ERR_INVALID_ARG,
-                    "cfd_ffn_stack_fwd: gelu / swish need the pre-activation buffer of layer %d", l);
-    }
-    if (R == 0) return CFD_OK;
-    FfnStack st{};
-    fs_fill(st, w, b, y, z, dims, L, act, act_last);
-    hipStream_t s = (hipStream_t)stream;
-    double fl = 0.0, by = 4.0 * R * dims[0];
-    for (int l = 0; l < L; ++l) { fl += 2.0 * R * dims[l] * dims[l + 1]; by += 4.0 * R * dims[l + 1] + 4.0 * dims[l] * dims[l + 1]; }
-    CFD_PROF_W("k_ffn_stack_fwd", s, by, fl);
-    const int ld = fs_ld(dims, L);
-    hipLaunchKernelGGL(k_ffn_stack_fwd, dim3((R + FS_ROWS - 1) / FS_ROWS), dim3(256), fs_lds_bytes(ld), s, x, st, R, ld);
-    CFD_LAUNCH_CHECK("cfd_ffn_stack_fwd");
-    return CFD_OK;
+    cfd_ffn_stack_args a{};
+    a.x = x; a.w = w; a.b = b; a.y = y; a.z = z; a.R = R; a.dims = dims; a.L = L; a.act = act; a.act_last = act_last;
+    return fs_fwd("cfd_ffn_stack_fwd", 1, &a, (hipStream_t)stream);
 }
 
 // workspace: dZ_l for every layer (R x dims[l+1] floats each, 256-byte aligned), then FS_KSPLIT partial slices of all gradients
@@ -396,53 +491,79 @@ extern "C" size_t cfd_ffn_stack_bwd_workspace_bytes(int R, const int* dims, int 
     return fs_ws_layout(R, dims, L, nullptr, nullptr, nullptr);
 }
 
+static int fs_bwd(const char* fn, int n, const cfd_ffn_stack_args* a, hipStream_t s) {
+    CFD_REQUIRE(a && n >= 1 && n <= FS_MAXS, CFD_ERR_INVALID_ARG, "%s: 1 .. %d stacks per call", fn, FS_MAXS);
+    FfnStackSet set{};
+    FfnStackBwdSet bset{};
+    FfnStackGradsSet gset{};
+    int ld = 0, blocks = 0, layers = 0, emax = 0, tmax = 0;
+    double fl = 0.0, by_chain = 0.0, by_wg = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const cfd_ffn_stack_args& t = a[i];
+        CFD_TRY(fs_check(fn, t.R, t.dims, t.L, t.act));
+        CFD_REQUIRE(t.x && t.gy && t.w && t.y && t.gw && t.ws, CFD_ERR_INVALID_ARG, "%s: NULL pointer (stack %d)", fn, i);
+        CFD_REQUIRE(t.R >= 1, CFD_ERR_INVALID_ARG, "%s: empty batch (stack %d)", fn, i);
+        for (int l = 0; l < t.L; ++l) {
+            CFD_REQUIRE(t.w[l] && t.y[l] && t.gw[l], CFD_ERR_INVALID_ARG, "%s: NULL weight / output / gradient of layer %d", fn, l);
+            CFD_REQUIRE(t.act < 3 || !(l + 1 < t.L || t.act_last) || (t.z && t.z[l]), CFD_ERR_INVALID_ARG,
+                        "%s: gelu / swish need the pre-activation buffer of layer %d", fn, l);
+        }
+        const int k = set.ns++;
+        fs_fill(set.st[k], t.w, nullptr, t.y, t.z, t.dims, t.L, t.act, t.act_last);
+        set.x[k] = t.x;
+        set.R[k] = t.R;
+        set.blk0[k] = blocks;
+        set.lay0[k] = layers;
+        blocks += (t.R + FS_ROWS - 1) / FS_ROWS;
+        layers += t.L;
+        size_t dz_off[FS_MAXL + 1];
+        fs_ws_layout(t.R, t.dims, t.L, dz_off, bset.bw[k].poff, &bset.bw[k].pstride);
+        for (int l = 0; l < t.L; ++l) bset.bw[k].dz[l] = (float*)((char*)t.ws + dz_off[l]);
+        bset.part[k] = (float*)((char*)t.ws + dz_off[t.L]);
+        bset.gy[k] = t.gy;
+        bset.gx[k] = t.gx;
+        const int l_ = fs_ld(t.dims, t.L);
+        if (l_ > ld) ld = l_;
+        by_chain += 4.0 * t.R * (t.dims[0] + t.dims[t.L]);
+        for (int l = 0; l < t.L; ++l) {
+            gset.g[k].gw[l] = t.gw[l];
+            gset.g[k].gb[l] = t.gb ? t.gb[l] : nullptr;
+            const int e = t.dims[l + 1] * t.dims[l] + t.dims[l + 1];
+            const int tt = ((t.dims[l] + 1 + 15) / 16) * ((t.dims[l + 1] + 15) / 16);
+            if (e > emax) emax = e;
+            if (tt > tmax) tmax = tt;
+            fl += 2.0 * t.R * t.dims[l] * t.dims[l + 1];
+            by_chain += 8.0 * t.R * t.dims[l + 1] + 4.0 * t.dims[l] * t.dims[l + 1];
+            by_wg += 4.0 * t.R * (t.dims[l] + t.dims[l + 1]) + 4.0 * t.dims[l] * t.dims[l + 1];
+        }
+    }
+    set.blk0[set.ns] = blocks;
+    set.lay0[set.ns] = layers;
+    {
+        CFD_PROF_W("k_ffn_stack_bwd_chain", s, by_chain, fl);
+        hipLaunchKernelGGL(k_ffn_stack_bwd_chain, dim3(blocks), dim3(256), fs_lds_bytes(ld), s, set, bset, ld);
+    }
+    CFD_LAUNCH_CHECK(fn);
+    {
+        CFD_PROF_W("k_ffn_stack_wgrad", s, by_wg, fl);
+        hipLaunchKernelGGL(k_ffn_stack_wgrad, dim3(tmax, layers, FS_KSPLIT), dim3(64), 0, s, set, bset);
+    }
+    CFD_LAUNCH_CHECK(fn);
+    CFD_PROF_W("k_ffn_stack_reduce", s, 0.0, 0.0);
+    hipLaunchKernelGGL(k_ffn_stack_reduce, dim3((emax + 255) / 256, layers), dim3(256), 0, s, set, bset, gset);
+    CFD_LAUNCH_CHECK(fn);
+    return CFD_OK;
+}
+
+extern "C" int cfd_ffn_stacks_bwd(int n, const cfd_ffn_stack_args* stacks, void* stream) {
+    return fs_bwd("cfd_ffn_stacks_bwd", n, stacks, (hipStream_t)stream);
+}
+
 extern "C" int cfd_ffn_stack_bwd(const float* x, const float* gy, const float* const* w, float* const* y, float* const* z,
                                  float* const* gw, float* const* gb, float* gx, void* ws, int R, const int* dims, int L, int act,
                                  int act_last, void* stream) {
-    CFD_TRY(fs_check("cfd_ffn_stack_bwd", R, dims, L, act));
-    CFD_REQUIRE(x && gy && w && y && gw && ws, CFD_ERR_INVALID_ARG, "cfd_ffn_stack_bwd: NULL pointer");
-    CFD_REQUIRE(R >= 1, CFD_ERR_INVALID_ARG, "cfd_ffn_stack_bwd: empty batch");
-    for (int l = 0; l < L; ++l) {
-        CFD_REQUIRE(w[l] && y[l] && gw[l], CFD_ERR_INVALID_ARG, "cfd_ffn_stack_bwd: NULL weight / output / gradient of layer %d", l);
-        CFD_REQUIRE(act < 3 || !(l + 1 < L || act_last) || (z && z[l]), CFD_ERR_INVALID_ARG,
-                    "cfd_ffn_stack_bwd: gelu / swish need the pre-activation buffer of layer %d", l);
-    }
-    FfnStack st{};
-    FfnStackBwd bw{};
-    fs_fill(st, w, nullptr, y, z, dims, L, act, act_last);
-    size_t dz_off[FS_MAXL + 1];
-    fs_ws_layout(R, dims, L, dz_off, bw.poff, &bw.pstride);
-    for (int l = 0; l < L; ++l) bw.dz[l] = (float*)((char*)ws + dz_off[l]);
-    float* part = (float*)((char*)ws + dz_off[L]);
-    FfnStackGrads g{};
-    int emax = 0, tmax = 0;
-    for (int l = 0; l < L; ++l) {
-        g.gw[l] = gw[l];
-        g.gb[l] = gb ? gb[l] : nullptr;
-        const int e = dims[l + 1] * dims[l] + dims[l + 1];
-        const int t = ((dims[l] + 1 + 15) / 16) * ((dims[l + 1] + 15) / 16);
-        if (e > emax) emax = e;
-        if (t > tmax) tmax = t;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    const int nblk = (R + FS_ROWS - 1) / FS_ROWS;
-    {
-        double fl = 0.0, by = 4.0 * R * (dims[0] + dims[L]);
-        for (int l = 0; l < L; ++l) { fl += 2.0 * R * dims[l] * dims[l + 1]; by += 8.0 * R * dims[l + 1] + 4.0 * dims[l] * dims[l + 1]; }
-        CFD_PROF_W("k_ffn_stack_bwd_chain", s, by, fl);
-        const int ld = fs_ld(dims, L);
-        hipLaunchKernelGGL(k_ffn_stack_bwd_chain, dim3(nblk), dim3(256), fs_lds_bytes(ld), s, gy, st, bw, gx, R, ld);
-    }
-    CFD_LAUNCH_CHECK("cfd_ffn_stack_bwd(chain)");
-    {
-        double fl = 0.0, by = 0.0;
-        for (int l = 0; l < L; ++l) { fl += 2.0 * R * dims[l] * dims[l + 1]; by += 4.0 * R * (dims[l] + dims[l + 1]) + 4.0 * dims[l] * dims[l + 1]; }
-        CFD_PROF_W("k_ffn_stack_wgrad", s, by, fl);
-        hipLaunchKernelGGL(k_ffn_stack_wgrad, dim3(tmax, L, FS_KSPLIT), dim3(64), 0, s, x, st, bw, part, R);
-    }
-    CFD_LAUNCH_CHECK("cfd_ffn_stack_bwd(wgrad)");
-    CFD_PROF_W("k_ffn_stack_reduce", s, 0.0, 0.0);
-    hipLaunchKernelGGL(k_ffn_stack_reduce, dim3((emax + 255) / 256, L), dim3(256), 0, s, (const float*)part, st, bw, g);
-    CFD_LAUNCH_CHECK("cfd_ffn_stack_bwd(reduce)");
-    return CFD_OK;
+    cfd_ffn_stack_args a{};
+    a.x = x; a.w = w; a.y = y; a.z = z; a.R = R; a.dims = dims; a.L = L; a.act = act; a.act_last = act_last;
+    a.gy = gy; a.gw = gw; a.gb = gb; a.gx = gx; a.ws = ws;
+    return fs_bwd("cfd_ffn_stack_bwd", 1, &a, (hipStream_t)stream);
 }

@@ -442,6 +442,110 @@ class FfnStackFn(torch.autograd.Function):
         return (gx.reshape(*lead, dims[0]) if gx is not None else None), None, None, *grads
 
 
+class FfnStacksFn(torch.autograd.Function):
+    """Up to three independent Linear(+activation) stacks -- the branch and trunk nets of a DeepONet variant -- as ONE kernel launch
+    per direction (cfd_ffn_stacks_fwd / _bwd): a stack of 512 rows is 32 workgroups, one of 4290 rows 269, and each launch sits at
+    its latency floor.  apply(meta, *tensors): meta = ((act code, act_last, number of layers), ...) per stack, tensors = per stack
+    [x, w_0, b_0, w_1, b_1, ...]; returns one output per stack."""
+
+    @staticmethod
+    def _args(api, n):
+        from ._capi import FfnStackArgs
+        return (FfnStackArgs * n)()
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        import ctypes
+        api = _lib.api()
+        n = len(meta)
+        args = FfnStacksFn._args(api, n)
+        keep, per, outs, pos = [], [], [], 0
+        for i, (act, act_last, L) in enumerate(meta):
+            x = tensors[pos]
+            wb = tensors[pos + 1:pos + 1 + 2 * L]
+            pos += 1 + 2 * L
+            _require_cuda(x, *wb)
+            ws_ = [_f32c(t.detach()) for t in wb[0::2]]
+            bs_ = [None if t is None else _f32c(t.detach()) for t in wb[1::2]]
+            lead = x.shape[:-1]
+            x2 = _f32c(x).reshape(-1, x.shape[-1])
+            R = x2.shape[0]
+            dims = [x2.shape[1]] + [w.shape[0] for w in ws_]
+            for l, w in enumerate(ws_):
+                if w.shape[1] != dims[l]:
+                    raise RuntimeError(f"Ffn: layer {l} expects {w.shape[1]} features, got {dims[l]}")
+            ys = [torch.empty((R, d), dtype=torch.float32, device=x2.device) for d in dims[1:]]
+            zs = [torch.empty_like(y) if (act >= 3 and (l + 1 < L or act_last)) else None for l, y in enumerate(ys)]
+            arrs = (_ptr_array(ws_), _ptr_array(bs_), _ptr_array(ys), _ptr_array(zs), (ctypes.c_int * (L + 1))(*dims))
+            keep.append(arrs)
+            a = args[i]
+            a.x, a.R, a.L, a.act, a.act_last = _ptr(x2), R, L, act, int(act_last)
+            a.w, a.b, a.y, a.z, a.dims = (ctypes.addressof(t) for t in arrs)
+            per.append((x2, ws_, ys, zs, dims, lead, [b is not None for b in bs_]))
+            outs.append(ys[-1].reshape(*lead, dims[-1]))
+        api.call("cfd_ffn_stacks_fwd", n, args, _stream())
+        saved, layout = [], []
+        for x2, ws_, ys, zs, dims, lead, has_b in per:
+            layout.append((len(saved), dims, lead, has_b, [z is not None for z in zs]))
+            saved += [x2, *ws_, *ys, *[z for z in zs if z is not None]]
+        ctx.save_for_backward(*saved)
+        ctx.meta, ctx.layout = meta, layout
+        # which x need a gradient: tensors[...] positions of the inputs
+        ctx.x_pos = []
+        pos = 0
+        for (_, _, L) in meta:
+            ctx.x_pos.append(pos + 1)  # (+1: `meta` is argument 0 of apply)
+            pos += 1 + 2 * L
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        import ctypes
+        api = _lib.api()
+        n = len(ctx.meta)
+        args = FfnStacksFn._args(api, n)
+        saved = ctx.saved_tensors
+        keep, grads = [], [None]
+        for i, ((act, act_last, L), (s0, dims, lead, has_b, has_z)) in enumerate(zip(ctx.meta, ctx.layout)):
+            x2 = saved[s0]
+            ws_ = list(saved[s0 + 1:s0 + 1 + L])
+            ys = list(saved[s0 + 1 + L:s0 + 1 + 2 * L])
+            zi = iter(saved[s0 + 1 + 2 * L:s0 + 1 + 2 * L + sum(has_z)])
+            zs = [next(zi) if hz else None for hz in has_z]
+            R, dev = x2.shape[0], x2.device
+            gy = gys[i]
+            gy2 = _f32c(gy).reshape(R, dims[-1]) if gy is not None else torch.zeros((R, dims[-1]), dtype=torch.float32, device=dev)
+            gws = [torch.empty_like(w) for w in ws_]
+            gbs = [torch.empty((w.shape[0],), dtype=torch.float32, device=dev) if hb else None for w, hb in zip(ws_, has_b)]
+            gx = torch.empty((R, dims[0]), dtype=torch.float32, device=dev) if ctx.needs_input_grad[ctx.x_pos[i]] else None
+            cdims = (ctypes.c_int * (L + 1))(*dims)
+            ws = _bytes(api.size("cfd_ffn_stack_bwd_workspace_bytes", R, cdims, L), dev)
+            arrs = (_ptr_array(ws_), _ptr_array(ys), _ptr_array(zs), _ptr_array(gws), _ptr_array(gbs), cdims)
+            keep.append((arrs, gy2, ws))
+            a = args[i]
+            a.x, a.gy, a.gx, a.ws, a.R, a.L, a.act, a.act_last = _ptr(x2), _ptr(gy2), _ptr(gx), _ptr(ws), R, L, act, int(act_last)
+            a.w, a.y, a.z, a.gw, a.gb, a.dims = (ctypes.addressof(t) for t in arrs)
+            grads.append(gx.reshape(*lead, dims[0]) if gx is not None else None)
+            for gw, gb in zip(gws, gbs):
+                grads += [gw, gb]
+        api.call("cfd_ffn_stacks_bwd", n, args, _stream())
+        return tuple(grads)
+
+
+FFN_STACKS_MAX = 3
+
+
+def ffn_stacks(runs):
+    """runs: [(x, weights, biases, act name, act_last), ...] (at most FFN_STACKS_MAX) -> the stacks' outputs, one launch per direction."""
+    meta, tensors = [], []
+    for x, weights, biases, act, act_last in runs:
+        meta.append((ACT_CODES[act], bool(act_last), len(weights)))
+        tensors.append(x)
+        for w, b in zip(weights, biases):
+            tensors += [w, b]
+    return list(FfnStacksFn.apply(tuple(meta), *tensors))
+
+
 def ffn_stack(x: Tensor, weights, biases, act: Optional[str], act_last: bool) -> Tensor:
     wb = []
     for w, b in zip(weights, biases):

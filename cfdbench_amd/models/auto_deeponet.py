@@ -14,7 +14,7 @@ from torch import Tensor, nn
 from .. import functional as F_
 from .act_fn import get_act_fn
 from .base_model import AutoCfdModel
-from .ffn import Ffn
+from .ffn import Ffn, run_ffns_together
 from .loss import MseLoss
 
 
@@ -70,11 +70,15 @@ class AutoDeepONet(AutoCfdModel):
         flat_inputs[:, :hw].view(batch_size, height, width).copy_(inputs[:, 0])
         flat_inputs[:, hw:].copy_(case_params)
         u = flat_inputs[:, :hw]
-        x_branch = self.branch_net(flat_inputs)
         full = query_idxs is None
         if full:
             query_idxs = self._full_lattice(height, width, inputs.device)
-        x_trunk = self._trunk(query_idxs, full)
+        if torch.is_grad_enabled() and flat_inputs.is_cuda:
+            # training: the two nets are independent until the inner product -- their Linear stacks share one launch per direction
+            x_branch, x_trunk = run_ffns_together([self.branch_net, self.trunk_net], [flat_inputs, (query_idxs.float() - 50) / 100])
+        else:
+            x_branch = self.branch_net(flat_inputs)
+            x_trunk = self._trunk(query_idxs, full)
         qflat = None if full else (query_idxs[:, 0] * width + query_idxs[:, 1])
         preds = F_.DeepONetInnerFn.apply(x_branch, x_trunk, self.bias, u, qflat)  # (:129-135)
         if label is not None:

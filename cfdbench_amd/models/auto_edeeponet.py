@@ -11,7 +11,7 @@ from .. import functional as F_
 from .act_fn import get_act_fn
 from .auto_deeponet import AutoDeepONet
 from .base_model import AutoCfdModel
-from .ffn import Ffn
+from .ffn import Ffn, run_ffns_together
 from .loss import MseLoss
 
 
@@ -50,11 +50,17 @@ class AutoEDeepONet(AutoCfdModel):
         Without a label the reference returns the (b, k) predictions un-reshaped (its ``.view`` result is dropped, :130)."""
         batch_size, num_chan, height, width = inputs.shape
         u = inputs[:, 0]
-        x_branch = self.branch1(u.reshape(batch_size, -1)) * self.branch2(case_params)  # (:91-93)
         full = query_idxs is None
         if full:
             query_idxs = self._full_lattice(height, width, inputs.device)
-        x_trunk = self._trunk(query_idxs, full)                                        # (:103-105)
+        if torch.is_grad_enabled() and inputs.is_cuda:
+            # training: three independent nets, their Linear stacks in one launch per direction
+            b1, b2, x_trunk = run_ffns_together([self.branch1, self.branch2, self.trunk_net],
+                                                [u.reshape(batch_size, -1), case_params, (query_idxs.float() - 50) / 100])
+            x_branch = b1 * b2                                                           # (:91-93)
+        else:
+            x_branch = self.branch1(u.reshape(batch_size, -1)) * self.branch2(case_params)  # (:91-93)
+            x_trunk = self._trunk(query_idxs, full)                                        # (:103-105)
         qflat = None if full else (query_idxs[:, 0] * width + query_idxs[:, 1])
         preds = F_.DeepONetInnerFn.apply(x_branch, x_trunk, self.bias, u, qflat)         # (:107-112)
         if label is not None:

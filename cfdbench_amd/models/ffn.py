@@ -89,6 +89,40 @@ class Ffn(nn.Module):
         return x
 
 
+def run_ffns_together(ffns, xs):
+    """``[ffn(x) for ffn, x in zip(ffns, xs)]`` for INDEPENDENT nets (a DeepONet's branch and trunk), with the fusable runs of different
+    nets sharing one kernel launch per direction (functional.ffn_stacks): each net first runs the layers that no stack kernel takes
+    (a first Linear wider than 128), then the nets that stand at a fusable run go together, then each finishes on its own."""
+    states = []  # [net, module index, tensor]
+    for net, x in zip(ffns, xs):
+        mods = list(net.layers)
+        i = 0
+        while i < len(mods) and x.is_cuda and net._fusable_run(mods, i) is None:  # the single-layer prefix of Ffn._run
+            lin, act, norm = mods[i], None, None
+            if i + 1 < len(mods) and isinstance(mods[i + 1], _Act):
+                act = mods[i + 1].name
+                i += 1
+            elif i + 1 < len(mods) and isinstance(mods[i + 1], NormAct):
+                norm = mods[i + 1]
+                i += 1
+            x = F_.linear_act(x, lin.weight, lin.bias, act)
+            if norm is not None:
+                x = norm(x)
+            i += 1
+        states.append([net, i, x])
+    ready = [k for k, (net, i, x) in enumerate(states) if x.is_cuda and i < len(list(net.layers))]
+    if 2 <= len(ready) <= F_.FFN_STACKS_MAX:
+        runs = []
+        for k in ready:
+            net, i, x = states[k]
+            ws, bs, act, last_act, j = net._fusable_run(list(net.layers), i)
+            runs.append((x, ws, bs, act, last_act))
+            states[k][1] = j
+        for k, y in zip(ready, F_.ffn_stacks(runs)):
+            states[k][2] = y
+    return [net._run(x, i) for net, i, x in states]
+
+
 class FfnModel(CfdModel):
     """Non-autoregressive FFN baseline (src/models/ffn.py:38-181): one Ffn over [case params, x, y, t] rows."""
 

@@ -258,6 +258,29 @@ int cfd_ffn_stack_bwd(const float* x, const float* gy, const float* const* w, fl
                       float* const* gw, float* const* gb, float* gx, void* ws, int R, const int* dims, int L, int act,
                       int act_last, void* stream);
 
+/* Up to 3 independent stacks in ONE launch per direction (the branch and trunk nets of a DeepONet variant -- src/models/auto_deeponet.py:52-60,
+ * auto_edeeponet.py:37-39 -- are 32 + 269 row tiles at BASELINE configs[3]: each too small to fill the GPU, each at its latency floor).
+ * One element per stack, fields as the arguments of cfd_ffn_stack_fwd / _bwd (gy .. ws are read by cfd_ffn_stacks_bwd only; ws:
+ * cfd_ffn_stack_bwd_workspace_bytes(R, dims, L) bytes per stack).  Same arithmetic and summation orders as the single-stack calls,
+ * which are these with n = 1. */
+typedef struct cfd_ffn_stack_args {
+    const float* x;
+    const float* const* w;
+    const float* const* b;
+    float* const* y;
+    float* const* z;
+    int R;
+    const int* dims;
+    int L, act, act_last;
+    const float* gy;
+    float* const* gw;
+    float* const* gb;
+    float* gx;
+    void* ws;
+} cfd_ffn_stack_args;
+int cfd_ffn_stacks_fwd(int n, const cfd_ffn_stack_args* stacks, void* stream);
+int cfd_ffn_stacks_bwd(int n, const cfd_ffn_stack_args* stacks, void* stream);
+
 int cfd_act_fwd(const float* x, float* y, size_t n, int act, void* stream);
 int cfd_act_bwd(const float* gy, const float* y, const float* x, float* gx, size_t n, int act, void* stream);
 

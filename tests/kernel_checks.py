@@ -624,6 +624,62 @@ def check_ffn_stack(be, R, dims, act, act_last=False, with_gx=True, seed=29):
     return res
 
 
+def check_ffn_stacks(be, specs, seed=31):
+    """cfd_ffn_stacks_fwd / _bwd: several stacks in one launch per direction must give BITWISE what the single-stack calls give (same
+    kernels, same per-stack work decomposition).  specs: [(R, dims, act name, act_last, with_gx), ...].  Returns the number of
+    differing elements per output (all zero) -- the single-stack calls themselves are pinned against the fp64 restatement above."""
+    import ctypes
+    from cfdbench_amd._capi import FfnStackArgs
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    codes = {"none": 0, "relu": 1, "tanh": 2, "gelu": 3, "swish": 4}
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[P(t) for t in ts])  # noqa: E731
+    n = len(specs)
+    data, keep = [], []
+    for R, dims, act, act_last, with_gx in specs:
+        L, code = len(dims) - 1, codes[act]
+        d = dict(R=R, dims=dims, L=L, code=code, act_last=act_last, with_gx=with_gx,
+                 x=be.dev(rng.standard_normal((R, dims[0])).astype(np.float32)), gy=be.dev(rng.standard_normal((R, dims[L])).astype(np.float32)),
+                 w=[be.dev((rng.standard_normal((dims[l + 1], dims[l])) / np.sqrt(dims[l])).astype(np.float32)) for l in range(L)],
+                 b=[be.dev((0.3 * rng.standard_normal((dims[l + 1],))).astype(np.float32)) for l in range(L)],
+                 cdims=(ctypes.c_int * (L + 1))(*dims))
+        acted = [code != 0 and (l + 1 < L or act_last) for l in range(L)]
+        for tag in ("one", "many"):  # outputs of the single-stack calls / of the joint call
+            d[tag] = dict(y=[be.zeros((R, dd)) for dd in dims[1:]],
+                          z=[be.zeros((R, dims[l + 1])) if (code >= 3 and acted[l]) else None for l in range(L)],
+                          gw=[be.zeros((dims[l + 1], dims[l])) for l in range(L)], gb=[be.zeros((dims[l + 1],)) for l in range(L)],
+                          gx=be.zeros((R, dims[0])) if with_gx else None,
+                          ws=be.bytes(api.size("cfd_ffn_stack_bwd_workspace_bytes", R, d["cdims"], L)))
+        data.append(d)
+    for d in data:
+        o = d["one"]
+        api.call("cfd_ffn_stack_fwd", P(d["x"]), arr(d["w"]), arr(d["b"]), arr(o["y"]), arr(o["z"]), d["R"], d["cdims"], d["L"], d["code"],
+                 int(d["act_last"]), be.stream)
+        api.call("cfd_ffn_stack_bwd", P(d["x"]), P(d["gy"]), arr(d["w"]), arr(o["y"]), arr(o["z"]), arr(o["gw"]), arr(o["gb"]), P(o["gx"]),
+                 P(o["ws"]), d["R"], d["cdims"], d["L"], d["code"], int(d["act_last"]), be.stream)
+    args = (FfnStackArgs * n)()
+    for a, d in zip(args, data):
+        o = d["many"]
+        arrs = [arr(d["w"]), arr(d["b"]), arr(o["y"]), arr(o["z"]), arr(o["gw"]), arr(o["gb"])]
+        keep.append(arrs)
+        a.x, a.gy, a.gx, a.ws = P(d["x"]), P(d["gy"]), P(o["gx"]), P(o["ws"])
+        a.R, a.L, a.act, a.act_last = d["R"], d["L"], d["code"], int(d["act_last"])
+        a.w, a.b, a.y, a.z, a.gw, a.gb = (ctypes.addressof(t) for t in arrs)
+        a.dims = ctypes.addressof(d["cdims"])
+    api.call("cfd_ffn_stacks_fwd", n, args, be.stream)
+    api.call("cfd_ffn_stacks_bwd", n, args, be.stream)
+    be.sync()
+    res = {}
+    for i, d in enumerate(data):
+        for key in ("y", "z", "gw", "gb"):
+            for l in range(d["L"]):
+                if d["one"][key][l] is not None:
+                    res[f"s{i}.{key}{l}"] = int(np.count_nonzero(be.host(d["one"][key][l]) != be.host(d["many"][key][l])))
+        if d["with_gx"]:
+            res[f"s{i}.gx"] = int(np.count_nonzero(be.host(d["one"]["gx"]) != be.host(d["many"]["gx"])))
+    return res
+
+
 def check_deeponet_inner(be, B, P_, Kq, HW, with_q, seed=23):
     api, P = be.api, be.ptr
     rng = np.random.default_rng(seed)

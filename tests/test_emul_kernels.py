@@ -161,6 +161,14 @@ def test_gemm_both_block_tiles(be, M, N, Kd, ta, tb, tile):
         _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
 
 
+@pytest.mark.parametrize("specs", [[(70, [5, 12, 20, 7], "relu", False, True), (33, [3, 17, 9], "gelu", True, False)], [(20, [4, 100, 100], "relu", False, True), (50, [100, 100, 100], "relu", False, True), (17, [2, 33, 100], "tanh", True, False)]])
+def test_ffn_stacks_in_one_launch_equal_the_single_calls(be, specs):
+    """cfd_ffn_stacks_fwd / _bwd (the branch and trunk stacks of a DeepONet variant as one launch per direction) == the single-stack
+    calls, bit for bit."""
+    res = K.check_ffn_stacks(be, specs)
+    assert all(v == 0 for v in res.values()), {k: v for k, v in res.items() if v}
+
+
 @pytest.mark.parametrize("M,K_in,N,act", [(137, 21, 24, "relu"), (20, 7, 5, "gelu")])
 @pytest.mark.parametrize("tile", [128, 1])
 def test_linear_act_on_the_large_tiles(be, M, K_in, N, act, tile):

@@ -208,6 +208,14 @@ def test_gemm_both_block_tiles(be, M, N, Kd, ta, tb, tile):
         _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
 
 
+@pytest.mark.parametrize("specs", [[(512, [100] * 8, "relu", False, True), (4290, [2] + [100] * 8, "relu", False, False)], [(128, [100] * 8, "relu", True, True), (128, [100] * 8, "relu", True, True), (4096, [2] + [100] * 8, "relu", False, False)], [(70, [5, 12, 20, 7], "swish", False, True), (333, [3, 128, 128, 1], "gelu", True, True)]])
+def test_ffn_stacks_in_one_launch_equal_the_single_calls(be, specs):
+    """cfd_ffn_stacks_fwd / _bwd (the branch and trunk stacks of a DeepONet variant as one launch per direction) == the single-stack
+    calls, bit for bit."""
+    res = K.check_ffn_stacks(be, specs)
+    assert all(v == 0 for v in res.values()), {k: v for k, v in res.items() if v}
+
+
 @pytest.mark.parametrize("M,K_in,N,act", [(131072, 200, 200, "tanh"), (4290, 100, 100, "relu"), (129, 33, 70, "swish"), (2050, 5, 530, "none")])  # (the Auto-FFN layer with a smooth activation: among 26 M pre-activations a handful sit within an fp32 rounding of the ReLU kink)
 @pytest.mark.parametrize("tile", [128, 1])
 def test_linear_act_on_the_large_tiles(be, M, K_in, N, act, tile):
