@@ -47,13 +47,23 @@ class AutoDeepONet(AutoCfdModel):
             self._lattice[key] = torch.tensor(list(product(range(height), range(width))), dtype=torch.long, device=device)
         return self._lattice[key]
 
+    def _trunk_input(self, query_idxs: Tensor, full: bool) -> Tensor:
+        """(idx - 50) / 100 (auto_deeponet.py:127-128); for the full lattice a constant of the grid: made once, not by three
+        elementwise launches per step (4 % of the configs[3] train step)."""
+        if not full:
+            return (query_idxs.float() - 50) / 100
+        key = ("trunk_in", query_idxs.data_ptr())
+        if key not in self._lattice:
+            self._lattice[key] = (query_idxs.float() - 50) / 100
+        return self._lattice[key]
+
     def _trunk(self, query_idxs: Tensor, full: bool) -> Tensor:
         """trunk_net((idx - 50) / 100), cached in eval mode for the full lattice (weights are frozen then)."""
         ver = tuple(p._version for p in self.trunk_net.parameters())
         if full and not self.training and not torch.is_grad_enabled() and self._trunk_cache is not None \
                 and self._trunk_cache[0] == (query_idxs.data_ptr(), ver):
             return self._trunk_cache[1]
-        x_trunk = self.trunk_net((query_idxs.float() - 50) / 100)  # auto_deeponet.py:127-128
+        x_trunk = self.trunk_net(self._trunk_input(query_idxs, full))  # auto_deeponet.py:127-128
         if full and not self.training and not torch.is_grad_enabled():
             self._trunk_cache = ((query_idxs.data_ptr(), ver), x_trunk)
         return x_trunk
@@ -75,7 +85,7 @@ class AutoDeepONet(AutoCfdModel):
             query_idxs = self._full_lattice(height, width, inputs.device)
         if torch.is_grad_enabled() and flat_inputs.is_cuda:
             # training: the two nets are independent until the inner product -- their Linear stacks share one launch per direction
-            x_branch, x_trunk = run_ffns_together([self.branch_net, self.trunk_net], [flat_inputs, (query_idxs.float() - 50) / 100])
+            x_branch, x_trunk = run_ffns_together([self.branch_net, self.trunk_net], [flat_inputs, self._trunk_input(query_idxs, full)])
         else:
             x_branch = self.branch_net(flat_inputs)
             x_trunk = self._trunk(query_idxs, full)

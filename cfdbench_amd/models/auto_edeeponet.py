@@ -43,6 +43,7 @@ class AutoEDeepONet(AutoCfdModel):
 
     _full_lattice = AutoDeepONet._full_lattice
     _trunk = AutoDeepONet._trunk
+    _trunk_input = AutoDeepONet._trunk_input
 
     def forward(self, inputs: Tensor, case_params: Tensor, label: Optional[Tensor] = None,
                 mask: Optional[Tensor] = None, query_idxs: Optional[Tensor] = None) -> Dict[str, Tensor]:
@@ -56,7 +57,7 @@ class AutoEDeepONet(AutoCfdModel):
         if torch.is_grad_enabled() and inputs.is_cuda:
             # training: three independent nets, their Linear stacks in one launch per direction
             b1, b2, x_trunk = run_ffns_together([self.branch1, self.branch2, self.trunk_net],
-                                                [u.reshape(batch_size, -1), case_params, (query_idxs.float() - 50) / 100])
+                                                [u.reshape(batch_size, -1), case_params, self._trunk_input(query_idxs, full)])
             x_branch = b1 * b2                                                           # (:91-93)
         else:
             x_branch = self.branch1(u.reshape(batch_size, -1)) * self.branch2(case_params)  # (:91-93)
