@@ -392,6 +392,35 @@ def test_auto_deeponet_vs_reference_golden(torch, golden_dir, name):
         assert O.rel_nmse(sub.cpu().numpy(), full[:, idx].cpu().numpy()) < 1e-10
 
 
+def test_deeponet_nets_in_one_launch_equal_the_separate_runs(torch):
+    """Training runs the branch and trunk nets' Linear stacks as ONE launch per direction (models/ffn.py: run_ffns_together,
+    cfd_ffn_stacks_fwd / _bwd); the loss and every gradient are BITWISE those of the nets run one after the other."""
+    import cfdbench_amd.models.auto_deeponet as AD
+    import cfdbench_amd.models.auto_edeeponet as AE
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    B, H, W, p = 6, 18, 17, 3
+    batch = _cuda(torch, synth.make_smooth_batch(5, B, H, W, p))
+    torch.manual_seed(3)
+    models = [AD.AutoDeepONet(H * W + p, 2, loss_name_to_fn("nmse"), branch_depth=4, trunk_depth=5, width=40, act_name="relu").cuda(),
+              AE.AutoEDeepONet(H * W, p, 2, loss_name_to_fn("nmse"), branch_depth=3, trunk_depth=4, width=36, act_name="tanh").cuda()]  # (dim_branch1, dim_branch2, trunk_dim, loss)
+    separately = lambda nets, xs: [net(x) for net, x in zip(nets, xs)]  # noqa: E731
+    for m, mod in zip(models, (AD, AE)):
+        got = []
+        for fn in (mod.run_ffns_together, separately):
+            saved, mod.run_ffns_together = mod.run_ffns_together, fn
+            try:
+                m.zero_grad(set_to_none=True)
+                out = m(inputs=batch["inputs"], case_params=batch["case_params"], label=batch["label"], mask=batch["mask"])
+                out["loss"]["nmse"].backward()
+                got.append((out["loss"]["nmse"].item(), out["preds"].detach().clone(), {k: v.grad.clone() for k, v in m.named_parameters()}))
+            finally:
+                mod.run_ffns_together = saved
+        assert got[0][0] == got[1][0]
+        assert torch.equal(got[0][1], got[1][1])
+        for k in got[0][2]:
+            assert torch.equal(got[0][2][k], got[1][2][k]), k
+
+
 # ---- U-Net drop-in (cfdbench_amd/models/unet.py) vs the reference module's golden outputs ---------------------------
 @pytest.mark.parametrize("name", ["unet_dim4_32x32", "unet_dim3_36x40", "unet_hidden_dim2_32x32", "unet_bilinear_dim4_32x48"])
 def test_unet_vs_reference_golden(torch, golden_dir, name):
