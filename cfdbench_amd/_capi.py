@@ -120,6 +120,7 @@ _SIGS = {
     "cfd_batchnorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfd_maxpool2_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "cfd_maxpool2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "cfd_maxpool2_bwd_add": (_I, [_P, _P, _P, _Z, _P, _I, _I, _I, _I, _P]),
     "cfd_upsample2_bilinear_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "cfd_upsample2_bilinear_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "cfd_convt2_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -962,9 +962,12 @@ __global__ __launch_bounds__(256) void k_maxpool2(const float* __restrict__ x, f
     }
 }
 
+// `add` (optional): a second gradient of the pooled tensor's INPUT, (B, C, H, W) with batch stride add_bs floats -- the skip
+// connection's share, read in place from the gradient of the decoder's concatenation (unet.py:80-88) -- summed in the same pass
+// instead of a contiguous copy of the slice + autograd's add kernel.
 __global__ __launch_bounds__(256) void k_maxpool2_bwd(const float* __restrict__ x, const float* __restrict__ gy,
                                                       float* __restrict__ gx, unsigned total, int H, int W, CfdDiv dHW,
-                                                      CfdDiv dW) {
+                                                      CfdDiv dW, const float* __restrict__ add, unsigned add_bs, int C, CfdDiv dC) {
     const int Ho = H / 2, Wo = W / 2;
     for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const unsigned img = cfd_div(e, dHW);
@@ -979,6 +982,10 @@ __global__ __launch_bounds__(256) void k_maxpool2_bwd(const float* __restrict__ 
             if (s[W] > m) { m = s[W]; arg = 2; }
             if (s[W + 1] > m) { m = s[W + 1]; arg = 3; }
             if (arg == (yy - 2 * yo) * 2 + (xx - 2 * xo)) g = gy[(size_t)img * Ho * Wo + yo * Wo + xo];
+        }
+        if (add) {
+            const unsigned b = cfd_div(img, dC), c = img - b * (unsigned)C;
+            g += add[(size_t)b * add_bs + (size_t)c * (H * W) + p];
         }
         gx[e] = g;
     }
@@ -1000,8 +1007,24 @@ extern "C" int cfd_maxpool2_bwd(const float* x, const float* gy, float* gx, int 
     if (nimg == 0) return CFD_OK;
     CFD_REQUIRE_I31((long)nimg * H * W, "cfd_maxpool2_bwd");
     hipLaunchKernelGGL(k_maxpool2_bwd, dim3(ew_blocks((long)nimg * H * W)), dim3(256), 0, (hipStream_t)stream, x, gy, gx,
-                       (unsigned)((long)nimg * H * W), H, W, cfd_div_make((unsigned)(H * W)), cfd_div_make((unsigned)W));
+                       (unsigned)((long)nimg * H * W), H, W, cfd_div_make((unsigned)(H * W)), cfd_div_make((unsigned)W), (const float*)nullptr,
+                       0u, 1, cfd_div_make(1u));
     CFD_LAUNCH_CHECK("cfd_maxpool2_bwd");
+    return CFD_OK;
+}
+
+extern "C" int cfd_maxpool2_bwd_add(const float* x, const float* gy, const float* add, size_t add_batch_stride, float* gx, int B, int C,
+                                    int H, int W, void* stream) {
+    CFD_REQUIRE(x && gy && add && gx && B >= 0 && C >= 1 && H >= 2 && W >= 2, CFD_ERR_INVALID_ARG, "cfd_maxpool2_bwd_add: bad arguments");
+    CFD_REQUIRE(add_batch_stride >= (size_t)C * H * W && add_batch_stride < (1ul << 31), CFD_ERR_INVALID_ARG,
+                "cfd_maxpool2_bwd_add: batch stride %zu of the second gradient", add_batch_stride);
+    if (B == 0) return CFD_OK;
+    const long total = (long)B * C * H * W;
+    CFD_REQUIRE_I31(total, "cfd_maxpool2_bwd_add");
+    hipLaunchKernelGGL(k_maxpool2_bwd, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, gy, gx, (unsigned)total, H, W,
+                       cfd_div_make((unsigned)(H * W)), cfd_div_make((unsigned)W), add, (unsigned)add_batch_stride, C,
+                       cfd_div_make((unsigned)C));
+    CFD_LAUNCH_CHECK("cfd_maxpool2_bwd_add");
     return CFD_OK;
 }
 

@@ -839,6 +839,39 @@ class MaxPool2Fn(torch.autograd.Function):
         return gx
 
 
+class MaxPoolSkipFn(torch.autograd.Function):
+    """``(MaxPool2d(2)(x), x)`` for an encoder output that also feeds a skip connection (unet.py:179-196: x1 .. x4 go to the next
+    Down block AND to an Up block's concatenation).  The second output is x itself; taking both gradients here lets the backward
+    pass add the skip connection's share inside the max-pool gradient kernel -- read in place from the gradient of the decoder's
+    concatenation (a channel slice with a batch stride) -- instead of a contiguous copy of that slice + autograd's add kernel."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        _require_cuda(x)
+        x = _f32c(x)
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        _lib.api().call("cfd_maxpool2_fwd", _ptr(x), _ptr(y), B * C, H, W, _stream())
+        ctx.save_for_backward(x)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy: Optional[Tensor], gskip: Optional[Tensor]):
+        (x,) = ctx.saved_tensors
+        B, C, H, W = x.shape
+        if gy is None:
+            return gskip
+        gx = torch.empty_like(x)
+        api = _lib.api()
+        if gskip is None:
+            api.call("cfd_maxpool2_bwd", _ptr(x), _ptr(_f32c(gy)), _ptr(gx), B * C, H, W, _stream())
+            return gx
+        if not (gskip.dtype == torch.float32 and gskip.stride()[1:] == (H * W, W, 1) and gskip.stride(0) >= C * H * W):
+            gskip = _f32c(gskip)
+        api.call("cfd_maxpool2_bwd_add", _ptr(x), _ptr(_f32c(gy)), _ptr(gskip), gskip.stride(0), _ptr(gx), B, C, H, W, _stream())
+        return gx
+
+
 class UpsampleBilinear2xFn(torch.autograd.Function):
     """nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)  (src/models/unet.py:74-76)."""
 
@@ -936,7 +969,8 @@ class ConvTransposeCatFn(torch.autograd.Function):
         ws = _bytes(api.size("cfd_convt2_bwd_workspace_bytes", B, Ci, Co, H, W), g.device)
         api.call("cfd_convt2_bwd_ex", g.data_ptr() + 4 * C2 * plane, (C2 + Co) * plane, _ptr(x), _ptr(w), _ptr(gin), _ptr(gw), _ptr(gb),
                  _ptr(ws), B, Ci, Co, H, W, _stream())
-        gskip = g[:, :C2].contiguous() if ctx.needs_input_grad[3] else None
+        # the skip connection's share stays a view of g: MaxPoolSkipFn reads it in place (any other consumer takes the strided tensor)
+        gskip = g[:, :C2] if ctx.needs_input_grad[3] else None
         return gin, gw, gb, gskip
 
 

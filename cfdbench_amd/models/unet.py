@@ -58,6 +58,12 @@ class Down(nn.Module):
     def forward(self, x):
         return self.maxpool_conv[1](F_.MaxPool2Fn.apply(x))
 
+    def forward_with_skip(self, x):
+        """(this block's output, x as the skip connection's input): the pooling node hands x on, so that its backward pass takes
+        the skip connection's gradient too (functional.MaxPoolSkipFn)."""
+        pooled, skip = F_.MaxPoolSkipFn.apply(x)
+        return self.maxpool_conv[1](pooled), skip
+
 
 class Up(nn.Module):
     """Upscaling then double conv (unet.py:66-99)."""
@@ -141,10 +147,16 @@ class UNet(AutoCfdModel):
         else:
             x = torch.cat([inputs, mask], dim=1)
         x1 = self.in_conv(x)
-        x2 = self.down1(x1)
-        x3 = self.down2(x2)
-        x4 = self.down3(x3)
-        x5 = self.down4(x4)
+        if x1.is_cuda:
+            x2, x1 = self.down1.forward_with_skip(x1)
+            x3, x2 = self.down2.forward_with_skip(x2)
+            x4, x3 = self.down3.forward_with_skip(x3)
+            x5, x4 = self.down4.forward_with_skip(x4)
+        else:
+            x2 = self.down1(x1)
+            x3 = self.down2(x2)
+            x4 = self.down3(x3)
+            x5 = self.down4(x4)
         if self.insert_case_params_at == "hidden":  # x5 + Linear(case_params)[:, :, None, None]  (unet.py:198-204)
             conds = F_.linear_act(case_params, self.case_params_fc.weight, self.case_params_fc.bias, None)
             x5 = F_.ChannelBiasAddFn.apply(x5, conds)

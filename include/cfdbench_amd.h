@@ -355,6 +355,10 @@ int cfd_batchnorm_bwd(const float* gy, const float* x, const float* gamma, const
 /* nn.MaxPool2d(2) (unet.py:59) on nimg = B*C images; the gradient goes to the first maximum of each window.     */
 int cfd_maxpool2_fwd(const float* x, float* y, int nimg, int H, int W, void* stream);
 int cfd_maxpool2_bwd(const float* x, const float* gy, float* gx, int nimg, int H, int W, void* stream);
+/* The same with a second gradient of x summed in: add (B, C, H, W) with a batch stride of add_batch_stride floats (the skip
+ * connection's share of the decoder concatenation's gradient, unet.py:80-88, read in place). */
+int cfd_maxpool2_bwd_add(const float* x, const float* gy, const float* add, size_t add_batch_stride, float* gx, int B, int C, int H,
+                         int W, void* stream);
 
 /* nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) (unet.py:74-76, UNet(bilinear=True)) on nimg = B*C
  * images: x (nimg,H,W) -> y (nimg,2H,2W); the backward is a gather (no atomics): gy (nimg,2H,2W) -> gx (nimg,H,W).  */

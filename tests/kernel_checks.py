@@ -879,6 +879,12 @@ def check_pool_convt_resid(be, B, Ci, Co, H, W, seed=33):
     be.sync()
     res = {"pool": float(np.abs(be.host(y) - CO.maxpool2(x)).max()),
            "pool_bwd": float(np.abs(be.host(gx) - CO.maxpool2_bwd(x, gy)).max())}
+    # the same with the skip connection's gradient summed in: a channel slice (first Ci of Ci + 3 channels) of a larger tensor
+    gcat = rng.standard_normal((B, Ci + 3, H, W)).astype(np.float32)
+    dgcat, gx2 = be.dev(gcat), be.zeros((B, Ci, H, W))
+    api.call("cfd_maxpool2_bwd_add", P(dx), P(dgy), P(dgcat), (Ci + 3) * H * W, P(gx2), B, Ci, H, W, be.stream)
+    be.sync()
+    res["pool_bwd_add"] = float(np.abs(be.host(gx2) - (be.host(gx) + gcat[:, :Ci])).max())  # one fp32 add: exact
     res.update(check_convt(be, B, Ci, Co, H, W, x=x, rng=rng))
     C2 = min(2, Ci)
     mask = (rng.random((B, H * W)) > 0.2).astype(np.float32)
