@@ -3,7 +3,8 @@
 // a product is six v_mfma_f32_16x16x32_bf16 (cfd_mfma_bf16x6: everything down to 2^-24 of the product, fp32 accumulation), so the
 // results are fp32-exact-class like the v_mfma_f32_16x16x4_f32 kernels of conv.hip they replace -- the ReLU / max-pool networks
 // need that (two-piece products move pre-activations across the ReLU kink) -- at 6 x 16 cycles per
-// 16x16x32 tile-step instead of 8 x 32.  What makes the matrix pipe the bound instead of the operand gathers:
+// 16x16x32 tile-step instead of 8 x 32.  What keeps the operand gathers cheap (the MFMA phase of a tile then runs at the pipe's
+// rate; the staging phases around it do not overlap it -- profiles/r04f_conv6_phases.txt):
 //   * an operand is split ONCE, on its way into LDS (weights: once per call by k_conv6_wprep into MFMA fragment order), and the
 //     k x k gather re-reads it from there as ONE ds_read_b128 per piece: the eight K slots of a lane are eight CHANNELS of one tap
 //     (forward / input gradient: LDS layout [pixel][channel]) or eight IMAGES of one pixel (weight gradient: layout
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
     // Operand loads and result stores go through raw buffer resources (cfd_intrinsics.h): per-lane 32-bit offset + wave-uniform
     // offset, out-of-range lanes dropped by the hardware.  (Written as `uniform pointer + lane offset` / `if (ok) store`, hipcc made
     // a 64-bit VALU address for every 4-byte access and an exec-mask region with its own branch for every store: ~70 VALU
-    // instructions per halo item and ~100 branches per tile in an instruction-issue-bound loop.)
+    // instructions per halo item and ~100 branches per tile.  Removing them did NOT shorten the staging phases -- they are bound by
+    // the CU's vector-memory and LDS paths, not by instruction issue: profiles/r04f_conv6_phases.txt.)
     const CfdBuf bsrc = cfd_buf(src, 4u * (unsigned)(g.B * Cs * HWs));
     // global loads of iteration `it` (tile, chunk): 8 channel values per halo item, the chunk's weight fragments.  Every load is
     // unconditional: halo pixels outside the image (EXT) or the batch carry the out-of-range offset and come back as zeros,
