@@ -394,8 +394,8 @@ def model_train_leg(api, name, model, batch, steps, warmup, frames, bytes_per_fr
     rows = profiled(api, eager, steps)
     res = dict(what=what, frames_per_s=round(frames / dt_eager, 1), ms_per_step=round(dt_eager * 1e3, 3), mode="eager")
     try:
-        if getattr(model, "graph_unsafe", False):  # per-step HOST state (the ResNet's dropout seed / step counter): a replayed graph
-            raise RuntimeError("model is graph_unsafe: eager launches only")  # would reuse one frozen dropout mask -- not a training step
+        if getattr(model, "graph_unsafe", False):  # per-step HOST state a replayed graph would freeze (no model of this tree since the ResNet's
+            raise RuntimeError("model is graph_unsafe: eager launches only")  # dropout step counter moved to the device, round 4)
         gs = GraphedTrainStep(model, opt, batch)
         dt_graph = time_steps(lambda: gs(**batch), steps, warmup)
         if dt_graph < dt_eager:

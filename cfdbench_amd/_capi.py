@@ -132,6 +132,8 @@ _SIGS = {
     "cfd_dropout": (_I, [_P, _P, _Z, _F, C.c_ulonglong, _P]),
     "cfd_dropout_gelu_fwd": (_I, [_P, _P, _Z, _F, C.c_ulonglong, _P]),
     "cfd_dropout_gelu_bwd": (_I, [_P, _P, _P, _Z, _F, C.c_ulonglong, _P]),
+    "cfd_dropout_gelu_fwd_step": (_I, [_P, _P, _Z, _F, C.c_ulonglong, _P, _P]),
+    "cfd_dropout_gelu_bwd_step": (_I, [_P, _P, _P, _Z, _F, C.c_ulonglong, _P, _P]),
     "cfd_ffn_stack_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "cfd_ffn_stack_bwd_workspace_bytes": (_Z, [_I, _P, _I]),
     "cfd_ffn_stacks_fwd": (_I, [_I, C.POINTER(FfnStackArgs), _P]),

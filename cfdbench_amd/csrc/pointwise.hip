@@ -1217,9 +1217,19 @@ __global__ __launch_bounds__(256) void k_gelu(const float* __restrict__ x, const
 // gelu(dropout(x)) and its gradient as ONE pass each (ResidualBlock.forward, src/models/resnet.py:70-77: conv1 -> dropout -> GELU):
 // the keep mask is the hash of (seed, index) of k_dropout, regenerated in the backward pass; value for value the two stand-alone
 // passes (same roundings), which cost the ResNet step two launches and two trips through HBM per block and direction.
+// `step` (optional): the stream's step counter in DEVICE memory; the seed is then mix(seed + *step) & 2^48 - 1 with the splitmix64
+// finaliser -- what the host computed per step before (models/resnet.py) -- so that a training step replayed from a captured graph
+// draws a new mask every time (the counter is incremented inside the graph).
+__device__ __forceinline__ unsigned long long cfd_mix64(unsigned long long v) {
+    v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    v = (v ^ (v >> 27)) * 0x94D049BB133111EBULL;
+    return v ^ (v >> 31);
+}
 template <bool BWD>
 __global__ __launch_bounds__(256) void k_dropout_gelu(const float* __restrict__ x, const float* __restrict__ gy,
-                                                      float* __restrict__ out, size_t n4, float p, unsigned long long seed) {
+                                                      float* __restrict__ out, size_t n4, float p, unsigned long long seed,
+                                                      const unsigned long long* __restrict__ step) {
+    if (step) seed = cfd_mix64(seed + *step) & 0xFFFFFFFFFFFFULL;
     const float scale = 1.0f / (1.0f - p);
     const unsigned thresh = (unsigned)((double)p * 4294967296.0);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -1243,7 +1253,8 @@ __global__ __launch_bounds__(256) void k_dropout_gelu(const float* __restrict__ 
     }
 }
 
-static int launch_dropout_gelu(const float* x, const float* gy, float* out, size_t n, float p, unsigned long long seed, bool bwd,
+static int launch_dropout_gelu(const float* x, const float* gy, float* out, size_t n, float p, unsigned long long seed,
+                               const unsigned long long* step, bool bwd,
                                hipStream_t st, const char* what) {
     CFD_REQUIRE(x && out && (!bwd || gy), CFD_ERR_INVALID_ARG, "%s: NULL pointer", what);
     CFD_REQUIRE(p >= 0.f && p < 1.f, CFD_ERR_INVALID_ARG, "%s: p must be in [0, 1)", what);
@@ -1252,19 +1263,31 @@ static int launch_dropout_gelu(const float* x, const float* gy, float* out, size
     if (n == 0) return CFD_OK;
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    if (bwd) hipLaunchKernelGGL((k_dropout_gelu<true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gy, out, n / 4, p, seed);
-    else hipLaunchKernelGGL((k_dropout_gelu<false>), dim3((unsigned)blocks), dim3(256), 0, st, x, gy, out, n / 4, p, seed);
+    if (bwd) hipLaunchKernelGGL((k_dropout_gelu<true>), dim3((unsigned)blocks), dim3(256), 0, st, x, gy, out, n / 4, p, seed, step);
+    else hipLaunchKernelGGL((k_dropout_gelu<false>), dim3((unsigned)blocks), dim3(256), 0, st, x, gy, out, n / 4, p, seed, step);
     CFD_LAUNCH_CHECK(what);
     return CFD_OK;
 }
 
 extern "C" int cfd_dropout_gelu_fwd(const float* x, float* y, size_t n, float p, unsigned long long seed, void* stream) {
-    return launch_dropout_gelu(x, nullptr, y, n, p, seed, false, (hipStream_t)stream, "cfd_dropout_gelu_fwd");
+    return launch_dropout_gelu(x, nullptr, y, n, p, seed, nullptr, false, (hipStream_t)stream, "cfd_dropout_gelu_fwd");
+}
+
+extern "C" int cfd_dropout_gelu_fwd_step(const float* x, float* y, size_t n, float p, unsigned long long base,
+                                         const unsigned long long* step, void* stream) {
+    CFD_REQUIRE(step, CFD_ERR_INVALID_ARG, "cfd_dropout_gelu_fwd_step: NULL step counter");
+    return launch_dropout_gelu(x, nullptr, y, n, p, base, step, false, (hipStream_t)stream, "cfd_dropout_gelu_fwd_step");
+}
+
+extern "C" int cfd_dropout_gelu_bwd_step(const float* x, const float* gy, float* gx, size_t n, float p, unsigned long long base,
+                                         const unsigned long long* step, void* stream) {
+    CFD_REQUIRE(step, CFD_ERR_INVALID_ARG, "cfd_dropout_gelu_bwd_step: NULL step counter");
+    return launch_dropout_gelu(x, gy, gx, n, p, base, step, true, (hipStream_t)stream, "cfd_dropout_gelu_bwd_step");
 }
 
 extern "C" int cfd_dropout_gelu_bwd(const float* x, const float* gy, float* gx, size_t n, float p, unsigned long long seed,
                                     void* stream) {
-    return launch_dropout_gelu(x, gy, gx, n, p, seed, true, (hipStream_t)stream, "cfd_dropout_gelu_bwd");
+    return launch_dropout_gelu(x, gy, gx, n, p, seed, nullptr, true, (hipStream_t)stream, "cfd_dropout_gelu_bwd");
 }
 
 extern "C" int cfd_gelu_fwd(const float* x, float* y, size_t n, void* stream) {

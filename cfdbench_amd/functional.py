@@ -1079,14 +1079,30 @@ class DropoutGeluFn(torch.autograd.Function):
     not take (element count not a multiple of four)."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, p: float, seed: int):
+    def _mix64(v: int) -> int:  # splitmix64 finaliser (csrc/pointwise.hip: cfd_mix64)
+        v &= 0xFFFFFFFFFFFFFFFF
+        v = ((v ^ (v >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        v = ((v ^ (v >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return v ^ (v >> 31)
+
+    @staticmethod
+    def forward(ctx, x: Tensor, p: float, seed: int, step: Optional[Tensor] = None):
+        """``step`` (a 0-d int64 CUDA tensor): the stream's step counter on the device; the mask's seed is then
+        mix64(seed + step) & (2^48 - 1), formed by the kernel -- a captured train step draws a new mask on every replay."""
         _require_cuda(x)
         x = _f32c(x)
         ctx.fused = x.numel() % 4 == 0 and x.data_ptr() % 16 == 0
+        ctx.step = step if (step is not None and p > 0) else None
+        if ctx.step is not None and not ctx.fused:  # (the two-pass fallback takes a host seed: one synchronisation, not capturable)
+            seed = DropoutGeluFn._mix64(int(seed) + int(step.item())) & 0xFFFFFFFFFFFF
+            ctx.step = None
         ctx.meta = (float(p), int(seed))
         y = torch.empty_like(x)
         api = _lib.api()
-        if ctx.fused:
+        if ctx.fused and ctx.step is not None:
+            api.call("cfd_dropout_gelu_fwd_step", _ptr(x), _ptr(y), x.numel(), float(p), int(seed), _ptr(ctx.step), _stream())
+            ctx.save_for_backward(x)
+        elif ctx.fused:
             api.call("cfd_dropout_gelu_fwd", _ptr(x), _ptr(y), x.numel(), float(p), int(seed), _stream())
             ctx.save_for_backward(x)
         else:
@@ -1105,9 +1121,14 @@ class DropoutGeluFn(torch.autograd.Function):
         gy = _f32c(gy)
         gx = torch.empty_like(x)
         api = _lib.api()
+        if ctx.step is not None:
+            if gy.data_ptr() % 16 != 0:
+                gy = gy.clone()  # (a fresh allocation is 16-byte aligned)
+            api.call("cfd_dropout_gelu_bwd_step", _ptr(x), _ptr(gy), _ptr(gx), x.numel(), p, seed, _ptr(ctx.step), _stream())
+            return gx, None, None, None
         if ctx.fused and gy.data_ptr() % 16 == 0:
             api.call("cfd_dropout_gelu_bwd", _ptr(x), _ptr(gy), _ptr(gx), x.numel(), p, seed, _stream())
-            return gx, None, None
+            return gx, None, None, None
         if ctx.fused:  # (the saved tensor is x, not dropout(x))
             d = x
             if p > 0:
@@ -1119,7 +1140,7 @@ class DropoutGeluFn(torch.autograd.Function):
             g2 = torch.empty_like(gx)
             api.call("cfd_dropout", _ptr(gx), _ptr(g2), gx.numel(), p, seed, _stream())
             gx = g2
-        return gx, None, None
+        return gx, None, None, None
 
 
 class AddFn(torch.autograd.Function):

@@ -28,11 +28,13 @@ class ResidualBlock(nn.Module):
         self.conv2 = nn.Conv2d(hidden_chan, out_chan, kernel_size, stride, padding, bias=bias, padding_mode="replicate")
         self.bn2 = nn.BatchNorm2d(out_chan)
         self.res_conv = nn.Conv2d(in_chan, out_chan, kernel_size=1, stride=stride, padding=0, bias=bias) if use_1x1conv else None
-        # Dropout stream: seed = mix(torch.initial_seed(), block index, step).  ResNet sets block_idx at construction and
-        # drop_step before every training forward; both are reproducible from --seed and the step counter is part of the
-        # saved training state (harness: train_state.pt), so a resumed run draws the masks the uninterrupted run would.
+        # Dropout stream: seed = mix(mix(torch.initial_seed()) + phi * (block index + 1) + step).  ResNet sets block_idx at
+        # construction and hands its step counter -- a DEVICE scalar, incremented once per training forward -- to every block; both
+        # are reproducible from --seed and the counter is part of the saved training state (harness: train_state.pt), so a resumed
+        # run draws the masks the uninterrupted run would.  The kernel forms the seed from the device counter (round 4): a train
+        # step replayed from a captured graph advances the stream like an eager one.
         self.block_idx = 0
-        self.drop_step = 0
+        self.drop_step = None  # the owner's step counter (0-d int64 tensor); None: step 0
 
     @staticmethod
     def _mix64(x: int) -> int:  # splitmix64 finaliser
@@ -44,18 +46,21 @@ class ResidualBlock(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         residual = x if self.res_conv is None else F_.Conv2dReplicateFn.apply(x, self.res_conv.weight, self.res_conv.bias)
         x = F_.Conv2dReplicateFn.apply(x, self.conv1.weight, self.conv1.bias, *F_.conv_frags(self.conv1))
-        p_drop, seed = 0.0, 0
+        p_drop, seed, step = 0.0, 0, None
         if self.training and self.dropout.p > 0:
             p_drop = self.dropout.p
-            seed = self._mix64(self._mix64(torch.initial_seed()) + 0x9E3779B97F4A7C15 * (self.block_idx + 1)
-                               + self.drop_step) & 0xFFFFFFFFFFFF
-        x = F_.DropoutGeluFn.apply(x, p_drop, seed)  # dropout (training) and GELU in one pass per direction
+            base = (self._mix64(torch.initial_seed()) + 0x9E3779B97F4A7C15 * (self.block_idx + 1)) & 0xFFFFFFFFFFFFFFFF
+            if self.drop_step is not None and self.drop_step.is_cuda:
+                seed, step = base, self.drop_step  # seed = mix64(base + step) & (2^48 - 1), formed on the device
+            else:
+                seed = self._mix64(base + (int(self.drop_step) if self.drop_step is not None else 0)) & 0xFFFFFFFFFFFF
+        x = F_.DropoutGeluFn.apply(x, p_drop, seed, step)  # dropout (training) and GELU in one pass per direction
         x = F_.Conv2dReplicateFn.apply(x, self.conv2.weight, self.conv2.bias, *F_.conv_frags(self.conv2))
         return F_.AddFn.apply(x, residual)
 
 
 class ResNet(AutoCfdModel):
-    graph_unsafe = True  # training-mode dropout takes a per-step host seed: the step cannot be replayed from a captured graph
+    graph_unsafe = False  # (round 4) the dropout stream's step counter lives on the device and is advanced inside the step
 
     def __init__(self, in_chan: int, out_chan: int, n_case_params: int, loss_fn: nn.Module, hidden_chan: int = 32,
                  num_blocks: int = 4, kernel_size: int = 7, padding: int = 3, stride: int = 1):
@@ -71,7 +76,9 @@ class ResNet(AutoCfdModel):
         self.blocks = nn.Sequential(*blocks)
         for i, blk in enumerate(self.blocks):
             blk.block_idx = i
-        self._train_steps = 0  # training-mode forwards so far: the dropout stream's step counter
+        # training-mode forwards so far = the dropout stream's step counter: a non-persistent buffer (follows .to() / .cuda(), restored
+        # by graph.GraphedTrainStep(restore_state=True) after its warm-up steps, NOT in the state_dict: the reference's keys stay)
+        self.register_buffer("_drop_step", torch.zeros((), dtype=torch.int64), persistent=False)
         # MFMA fragments of all 7x7 weights, remade by one launch at the top of every forward pass (functional.PreparedConvWeights)
         self._prep = F_.PreparedConvWeights([m for m in self.modules() if isinstance(m, nn.Conv2d)])
 
@@ -87,9 +94,10 @@ class ResNet(AutoCfdModel):
         if inputs.is_cuda:
             self._prep.refresh(torch.is_grad_enabled())
         if self.training:
-            self._train_steps += 1
+            with torch.no_grad():
+                self._drop_step.add_(1)
             for blk in self.blocks:
-                blk.drop_step = self._train_steps
+                blk.drop_step = self._drop_step
         x = self.blocks(torch.cat([inputs, mask, cp], dim=1))
         preds = F_.ResidualMaskFn.apply(x, residual, mask)  # (blocks + inputs[:, :out_chan]) * mask
         if label is not None:
@@ -99,10 +107,11 @@ class ResNet(AutoCfdModel):
 
     # ---- training state beyond the state_dict (kept out of it: the reference's checkpoint keys must not change) ----
     def extra_train_state(self) -> dict:
-        return dict(train_steps=int(self._train_steps))
+        return dict(train_steps=int(self._drop_step.item()))
 
     def load_extra_train_state(self, state: dict) -> None:
-        self._train_steps = int(state.get("train_steps", 0))
+        with torch.no_grad():
+            self._drop_step.fill_(int(state.get("train_steps", 0)))
 
     def generate(self, inputs: Tensor, case_params: Tensor, mask: Optional[Tensor] = None):
         return self.forward(inputs, case_params=case_params, mask=mask)["preds"]

@@ -392,6 +392,13 @@ int cfd_dropout(const float* x, float* y, size_t n, float p, unsigned long long 
  * 16-byte aligned tensors, else CFD_ERR_UNSUPPORTED.                                                                        */
 int cfd_dropout_gelu_fwd(const float* x, float* y, size_t n, float p, unsigned long long seed, void* stream);
 int cfd_dropout_gelu_bwd(const float* x, const float* gy, float* gx, size_t n, float p, unsigned long long seed, void* stream);
+/* The same with the stream's step counter in DEVICE memory: seed = splitmix64(base + *step) & (2^48 - 1), computed by the kernel, so
+ * that a train step replayed from a captured graph (which increments *step inside the graph) draws a new mask each time.  With the
+ * host computing the same expression and passing it as `seed` above, the masks are identical. */
+int cfd_dropout_gelu_fwd_step(const float* x, float* y, size_t n, float p, unsigned long long base, const unsigned long long* step,
+                              void* stream);
+int cfd_dropout_gelu_bwd_step(const float* x, const float* gy, float* gx, size_t n, float p, unsigned long long base,
+                              const unsigned long long* step, void* stream);
 
 /* ---- whole Auto-FNO (Fno2d.forward, fno2d.py:178-242; loss.backward() at train_auto.py:255) ---------------*/
 typedef struct {
