@@ -758,16 +758,55 @@ __global__ __launch_bounds__(256) void k_bcast_add(const float* __restrict__ ft,
     }
 }
 
-// gft[b,p] = sum_k g[b,k,p] (which = 0) or gfxy[k,p] = sum_b g[b,k,p] (which = 1): thread per output, coalesced along p
-__global__ __launch_bounds__(256) void k_bcast_add_bwd(const float* __restrict__ g, float* __restrict__ out, int B, int K, int P,
-                                                       int which) {
-    const long total = which == 0 ? (long)B * P : (long)K * P;
+// out[b,p] = sum_k w[b,k] g[b,k,p] (w == NULL: 1): one workgroup of 1024 threads per sample b -- 8 row groups x 128 column lanes,
+// eight rows per trip with their loads issued before the first add, the row groups summed through LDS in a fixed order.  (Rounds
+// 1-3: one THREAD per output walking all K rows with one dependent load per trip -- 100 workgroups, 230-290 us for the 102 MB of the
+// non-autoregressive DeepONet's 256 x 1000 x 100 trunk activations, three such launches = 16 % of its train step.)
+__global__ __launch_bounds__(1024) void k_rows_wsum(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ out,
+                                                    int K, int P) {
+    __shared__ float s_p[8][128];
+    const int b = blockIdx.x, tx = threadIdx.x & 127, ty = threadIdx.x >> 7;
+    const float* gb = g + (size_t)b * K * P;
+    const float* wb = w ? w + (size_t)b * K : nullptr;
+    for (int p0 = 0; p0 < P; p0 += 128) {
+        const int p = p0 + tx, pc = p < P ? p : P - 1;
+        float s = 0.f;
+        int k = ty;
+        for (; k + 56 < K; k += 64) {  // rows k, k + 8, ..., k + 56 of this row group
+            float v[8], c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v[u] = gb[(size_t)(k + 8 * u) * P + pc]; c[u] = wb ? wb[k + 8 * u] : 1.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = fmaf(c[u], v[u], s);
+        }
+        for (; k < K; k += 8) s = fmaf(wb ? wb[k] : 1.f, gb[(size_t)k * P + pc], s);
+        s_p[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && p < P) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += s_p[j][tx];
+            out[(size_t)b * P + p] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// gfxy[k,p] = sum_b g[b,k,p]: thread per output (coalesced along p), eight samples per trip
+__global__ __launch_bounds__(256) void k_bcast_add_bwd_b(const float* __restrict__ g, float* __restrict__ out, int B, int K, int P) {
+    const long total = (long)K * P;
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
-    const int p = (int)(e % P), o = (int)(e / P);
     float s = 0.f;
-    if (which == 0) for (int k = 0; k < K; ++k) s += g[((size_t)o * K + k) * P + p];
-    else for (int b = 0; b < B; ++b) s += g[((size_t)b * K + o) * P + p];
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = g[(size_t)(b + u) * total + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < B; ++b) s += g[(size_t)b * total + e];
     out[e] = s;
 }
 
@@ -784,8 +823,8 @@ extern "C" int cfd_bcast_add_fwd(const float* ft, const float* fxy, float* out, 
 
 extern "C" int cfd_bcast_add_bwd(const float* g, float* gft, float* gfxy, int B, int K, int P, void* stream) {
     CFD_REQUIRE(g && B >= 1 && K >= 1 && P >= 1, CFD_ERR_INVALID_ARG, "cfd_bcast_add_bwd: bad arguments");
-    if (gft) hipLaunchKernelGGL(k_bcast_add_bwd, dim3((unsigned)(((long)B * P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, gft, B, K, P, 0);
-    if (gfxy) hipLaunchKernelGGL(k_bcast_add_bwd, dim3((unsigned)(((long)K * P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, gfxy, B, K, P, 1);
+    if (gft) hipLaunchKernelGGL(k_rows_wsum, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, g, (const float*)nullptr, gft, K, P);
+    if (gfxy) hipLaunchKernelGGL(k_bcast_add_bwd_b, dim3((unsigned)(((long)K * P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, gfxy, B, K, P);
     CFD_LAUNCH_CHECK("cfd_bcast_add_bwd");
     return CFD_OK;
 }
@@ -815,16 +854,7 @@ __global__ __launch_bounds__(256) void k_rowdot_bwd_trunk(const float* __restric
     }
 }
 
-// gbranch[b,p] = sum_k g[b,k] * trunk[b,k,p]: thread per (b,p), coalesced along p
-__global__ __launch_bounds__(256) void k_rowdot_bwd_branch(const float* __restrict__ g, const float* __restrict__ trunk,
-                                                           float* __restrict__ gbranch, int B, int K, int P) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (long)B * P) return;
-    const int p = (int)(e % P), b = (int)(e / P);
-    float s = 0.f;
-    for (int k = 0; k < K; ++k) s = fmaf(g[(size_t)b * K + k], trunk[((size_t)b * K + k) * P + p], s);
-    gbranch[e] = s;
-}
+// gbranch[b,p] = sum_k g[b,k] * trunk[b,k,p]: k_rows_wsum with the weights g[b,:]
 
 // preds (B,K) = per-sample dot of branch (B,P) with trunk (B,K,P), + bias[0]
 extern "C" int cfd_rowdot_fwd(const float* branch, const float* trunk, const float* bias, float* preds, int B, int K, int P,
@@ -844,7 +874,7 @@ extern "C" int cfd_rowdot_bwd(const float* g, const float* branch, const float* 
                               float* gbias, void* ws, int B, int K, int P, void* stream) {
     CFD_REQUIRE(g && branch && trunk && B >= 1 && K >= 1 && P >= 1, CFD_ERR_INVALID_ARG, "cfd_rowdot_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (gbranch) hipLaunchKernelGGL(k_rowdot_bwd_branch, dim3((unsigned)(((long)B * P + 255) / 256)), dim3(256), 0, st, g, trunk, gbranch, B, K, P);
+    if (gbranch) hipLaunchKernelGGL(k_rows_wsum, dim3((unsigned)B), dim3(1024), 0, st, trunk, g, gbranch, K, P);
     if (gtrunk) {
         long blocks = ((long)B * K * P + 255) / 256;
         hipLaunchKernelGGL(k_rowdot_bwd_trunk, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, g, branch, gtrunk, B, K, P);

@@ -247,7 +247,7 @@ def test_normact(be, S, shape, act):
     _assert_all(K.check_normact(be, S, shape, act))
 
 
-@pytest.mark.parametrize("B,Kq,P", [(2, 9, 20), (3, 5, 7)])
+@pytest.mark.parametrize("B,Kq,P", [(2, 9, 20), (3, 5, 7), (2, 150, 130)])  # (eight-row trips of every row group; two passes of 128 columns)
 def test_broadcast_add_and_rowdot(be, B, Kq, P):
     res = K.check_bcast_rowdot(be, B, Kq, P)
     assert res.pop("gbias") < 1e-5

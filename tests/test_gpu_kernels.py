@@ -342,7 +342,7 @@ def test_normact(be, S, shape, act):
     _assert_all(K.check_normact(be, S, shape, act))
 
 
-@pytest.mark.parametrize("B,Kq,P", [(8, 1000, 100), (3, 37, 24)])
+@pytest.mark.parametrize("B,Kq,P", [(8, 1000, 100), (3, 37, 24), (5, 300, 200), (20, 77, 129)])
 def test_broadcast_add_and_rowdot(be, B, Kq, P):
     res = K.check_bcast_rowdot(be, B, Kq, P)
     assert res.pop("gbias") < 1e-5
