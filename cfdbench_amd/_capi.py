@@ -91,6 +91,7 @@ _SIGS = {
     "cfd_linear_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfd_linear_bwd_workspace_bytes": (_Z, [_I, _I, _I]),
     "cfd_linear_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cfd_linear_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "cfd_deeponet_inner_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfd_deeponet_inner_fwd_ex": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "cfd_deeponet_inner_bwd_workspace_bytes": (_Z, [_I, _I, _I]),

@@ -12,13 +12,16 @@
 #define GK 16   // K slab
 
 struct GemmEpi {
-    int mode;             // 0: store; 1: + bias[n], activation; 2: + bias[0] (+ resid[m*ldr + (qidx ? qidx[n] : n)])
+    int mode;             // 0: store; 1: + bias[n], activation; 2: + bias[0] (+ resid[m*ldr + (qidx ? qidx[n] : n)]);
+                          // 3: * act'(resid[m*ldr + n] as the layer output, gz_z[m*ldr + n] as its pre-activation): the input gradient of
+                          //    a Linear layer leaves the GEMM as the PREVIOUS layer's dZ (no separate activation-gradient pass)
     int act;              // mode 1: 0 none, 1 relu, 2 tanh, 3 gelu (exact erf), 4 swish
     const float* bias;
     float* preact;        // mode 1: pre-activation copy (needed by the gelu / swish derivative), may be NULL
     const float* resid;
     const int* qidx;
     int ldr;
+    const float* gz_z;    // mode 3: pre-activations (gelu / swish), else NULL
 };
 
 __device__ __forceinline__ float cfd_act(float z, int act) {
@@ -211,6 +214,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const float* __restrict__ A, co
                     } else if (epi.mode == 2) {
                         v += epi.bias[0];
                         if (epi.resid) v += epi.resid[(size_t)row * epi.ldr + (epi.qidx ? epi.qidx[col] : col)];
+                    } else if (epi.mode == 3) {
+                        const size_t o = (size_t)row * epi.ldr + col;
+                        v *= cfd_act_grad(epi.resid[o], epi.gz_z ? epi.gz_z[o] : 0.f, epi.act);
                     }
                     C[(size_t)row * ldc + col] = v;
                 }
@@ -243,6 +249,9 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
         } else if (epi.mode == 2) {
             v += epi.bias[0];
             if (epi.resid) v += epi.resid[(size_t)row * epi.ldr + (epi.qidx ? epi.qidx[col] : col)];
+        } else if (epi.mode == 3) {
+            const size_t o = (size_t)row * epi.ldr + col;
+            v *= cfd_act_grad(epi.resid[o], epi.gz_z ? epi.gz_z[o] : 0.f, epi.act);
         }
         C[(size_t)row * ldc + col] = v;
     }
@@ -496,8 +505,26 @@ extern "C" size_t cfd_linear_bwd_workspace_bytes(int M, int K, int N) {
 }
 
 // gx (M,K) = gz w;  gw (N,K) = gz^T x;  gb (N) = column sums of gz;  gz = gy * act'.  gx / gb may be NULL.
+// in_act != 0: x is the OUTPUT of a layer with that activation (in_preact: its pre-activations for gelu / swish) and gx leaves as that
+// layer's dZ = (gz w) * in_act'(x) -- the caller then runs that layer's backward with act = 0.
+static int linear_bwd(const float* gy, const float* x, const float* w, const float* y, const float* preact, float* gx, float* gw,
+                      float* gb, void* ws, int M, int K, int N, int act, int in_act, const float* in_preact, void* stream);
+
 extern "C" int cfd_linear_bwd(const float* gy, const float* x, const float* w, const float* y, const float* preact,
                               float* gx, float* gw, float* gb, void* ws, int M, int K, int N, int act, void* stream) {
+    return linear_bwd(gy, x, w, y, preact, gx, gw, gb, ws, M, K, N, act, 0, nullptr, stream);
+}
+
+extern "C" int cfd_linear_bwd_ex(const float* gy, const float* x, const float* w, const float* y, const float* preact, float* gx,
+                                 float* gw, float* gb, void* ws, int M, int K, int N, int act, int in_act, const float* in_preact,
+                                 void* stream) {
+    CFD_REQUIRE(in_act >= 0 && in_act <= 4, CFD_ERR_INVALID_ARG, "cfd_linear_bwd_ex: bad in_act");
+    CFD_REQUIRE(in_act < 3 || in_preact, CFD_ERR_INVALID_ARG, "cfd_linear_bwd_ex: gelu / swish need the input layer's pre-activation");
+    return linear_bwd(gy, x, w, y, preact, gx, gw, gb, ws, M, K, N, act, in_act, in_preact, stream);
+}
+
+static int linear_bwd(const float* gy, const float* x, const float* w, const float* y, const float* preact, float* gx, float* gw,
+                      float* gb, void* ws, int M, int K, int N, int act, int in_act, const float* in_preact, void* stream) {
     CFD_REQUIRE(gy && x && w && gw, CFD_ERR_INVALID_ARG, "cfd_linear_bwd: NULL pointer");
     CFD_REQUIRE(M >= 1 && K >= 1 && N >= 1, CFD_ERR_INVALID_ARG, "cfd_linear_bwd: bad sizes");
     CFD_REQUIRE(act >= 0 && act <= 4, CFD_ERR_INVALID_ARG, "cfd_linear_bwd: bad act");
@@ -516,7 +543,11 @@ extern "C" int cfd_linear_bwd(const float* gy, const float* x, const float* w, c
     }
     GemmEpi epi{};
     void* skws = (char*)ws + cfd_align_up((size_t)M * N * sizeof(float), 256);
-    if (gx) CFD_TRY(launch_gemm(gz, w, gx, M, K, N, N, K, K, 0, 0, epi, skws, st, "cfd_linear_bwd(gx)"));
+    if (gx) {
+        GemmEpi ex{};
+        if (in_act != 0) { ex.mode = 3; ex.act = in_act; ex.resid = x; ex.ldr = K; ex.gz_z = in_preact; }
+        CFD_TRY(launch_gemm(gz, w, gx, M, K, N, N, K, K, 0, 0, ex, skws, st, "cfd_linear_bwd(gx)"));
+    }
     CFD_TRY(launch_gemm(gz, x, gw, N, K, M, N, K, K, 1, 0, epi, skws, st, "cfd_linear_bwd(gw)"));
     if (gb) {
         if (colsum_ws_bytes(M, N)) {

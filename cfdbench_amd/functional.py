@@ -348,6 +348,74 @@ class LinearActFn(torch.autograd.Function):
         return (gx.reshape(*lead, K) if gx is not None else None), gw, gb, None
 
 
+class LinearChainFn(torch.autograd.Function):
+    """A run of Linear(+activation) layers too wide for the stack kernel (FfnStackFn: widths <= 128) as ONE autograd node: the same
+    GEMM launches per layer as LinearActFn, but in the backward pass a layer's input gradient leaves its GEMM already multiplied by the
+    previous layer's activation derivative (cfd_linear_bwd_ex), so the separate activation-gradient pass over every (rows, width)
+    gradient disappears (8 x 51 us per Auto-FFN train step).  apply(x, acts, *[w_0, b_0, w_1, b_1, ...]), acts = activation code per layer."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, acts, *wb: Tensor):
+        _require_cuda(x, *wb)
+        api = _lib.api()
+        L = len(wb) // 2
+        ws_ = [_f32c(t.detach()) for t in wb[0::2]]
+        bs_ = [None if t is None else _f32c(t.detach()) for t in wb[1::2]]
+        lead = x.shape[:-1]
+        h = _f32c(x).reshape(-1, x.shape[-1])
+        x2, M = h, h.shape[0]
+        ys, pres = [], []
+        for l in range(L):
+            N, K = ws_[l].shape
+            if h.shape[1] != K:
+                raise RuntimeError(f"Linear: input has {h.shape[1]} features, weight expects {K}")
+            y = torch.empty((M, N), dtype=torch.float32, device=h.device)
+            pre = torch.empty_like(y) if acts[l] >= 3 else None
+            nws = api.size("cfd_linear_fwd_workspace_bytes", M, K, N)
+            ws = _bytes(nws, h.device) if nws else None
+            api.call("cfd_linear_fwd", _ptr(h), _ptr(ws_[l]), _ptr(bs_[l]), _ptr(y), _ptr(pre), _ptr(ws), M, K, N, acts[l], _stream())
+            ys.append(y)
+            pres.append(pre)
+            h = y
+        ctx.save_for_backward(x2, *ws_, *ys, *[p for p in pres if p is not None])
+        ctx.meta = (L, tuple(acts), lead, [b is not None for b in bs_], [p is not None for p in pres])
+        return h.reshape(*lead, h.shape[1])
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        api = _lib.api()
+        L, acts, lead, has_b, has_p = ctx.meta
+        saved = ctx.saved_tensors
+        x2, ws_, ys = saved[0], list(saved[1:1 + L]), list(saved[1 + L:1 + 2 * L])
+        pi = iter(saved[1 + 2 * L:])
+        pres = [next(pi) if hp else None for hp in has_p]
+        M, dev = x2.shape[0], x2.device
+        g = _f32c(gy).reshape(M, ws_[-1].shape[0])
+        grads = [None] * (2 * L)
+        for l in reversed(range(L)):
+            N, K = ws_[l].shape
+            xin = ys[l - 1] if l > 0 else x2
+            need_gx = l > 0 or ctx.needs_input_grad[0]
+            gx = torch.empty((M, K), dtype=torch.float32, device=dev) if need_gx else None
+            gw = torch.empty((N, K), dtype=torch.float32, device=dev)
+            gb = torch.empty((N,), dtype=torch.float32, device=dev) if has_b[l] else None
+            ws = _bytes(api.size("cfd_linear_bwd_workspace_bytes", M, K, N), dev)
+            act = acts[l] if l == L - 1 else 0  # (below the last layer g already is dZ_l: the layer above folded act_l' into its GEMM)
+            in_act = acts[l - 1] if l > 0 else 0
+            api.call("cfd_linear_bwd_ex", _ptr(g), _ptr(xin), _ptr(ws_[l]), _ptr(ys[l]), _ptr(pres[l]), _ptr(gx), _ptr(gw), _ptr(gb),
+                     _ptr(ws), M, K, N, act, in_act, _ptr(pres[l - 1]) if l > 0 else None, _stream())
+            grads[2 * l], grads[2 * l + 1] = gw, gb
+            g = gx
+        return (g.reshape(*lead, x2.shape[1]) if g is not None else None), None, *grads
+
+
+def linear_chain(x: Tensor, weights, biases, acts) -> Tensor:
+    wb = []
+    for w, b in zip(weights, biases):
+        wb += [w, b]
+    return LinearChainFn.apply(x, tuple(ACT_CODES[a] for a in acts), *wb)
+
+
 class ActFn(torch.autograd.Function):
     """y = act(x) elementwise (get_act_fn(name), act_fn.py:8-18) for tensors that are not a GEMM output."""
 

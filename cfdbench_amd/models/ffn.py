@@ -65,6 +65,27 @@ class Ffn(nn.Module):
                 break  # a Linear without activation can only close a run
         return (ws, bs, act, last_act, j) if len(ws) >= 2 else None
 
+    def _chain_run(self, mods, i: int):
+        """(weights, biases, activation name per layer, index behind the run) of the longest run of Linear[+plain activation] layers
+        from ``mods[i]`` on (any width; a NormAct ends it: its statistics span the whole sample; so does the start of a run the stack
+        kernel takes) -- one autograd node whose backward
+        pass folds each activation derivative into the GEMM above it (functional.LinearChainFn) -- or None for fewer than two."""
+        ws, bs, acts, j = [], [], [], i
+        while j < len(mods) and isinstance(mods[j], nn.Linear):
+            if j > i and self._fusable_run(mods, j) is not None:
+                break  # the narrow layers behind a wide first one belong to the stack kernel
+            nxt = mods[j + 1] if j + 1 < len(mods) else None
+            if isinstance(nxt, NormAct):
+                break
+            ws.append(mods[j].weight); bs.append(mods[j].bias)
+            if isinstance(nxt, _Act):
+                acts.append(nxt.name)
+                j += 2
+            else:
+                acts.append(None)
+                j += 1
+        return (ws, bs, acts, j) if len(ws) >= 2 else None
+
     def _run(self, x: Tensor, i: int) -> Tensor:
         mods = list(self.layers)
         while i < len(mods):
@@ -72,6 +93,11 @@ class Ffn(nn.Module):
             if run is not None:
                 ws, bs, act, last_act, i = run
                 x = F_.ffn_stack(x, ws, bs, act, last_act)
+                continue
+            chain = self._chain_run(mods, i) if x.is_cuda else None
+            if chain is not None:
+                ws, bs, acts, i = chain
+                x = F_.linear_chain(x, ws, bs, acts)
                 continue
             lin = mods[i]
             act = None

@@ -225,6 +225,11 @@ int cfd_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
 size_t cfd_linear_bwd_workspace_bytes(int M, int K, int N);
 int cfd_linear_bwd(const float* gy, const float* x, const float* w, const float* y, const float* preact, float* gx,
                    float* gw, float* gb, void* ws, int M, int K, int N, int act, void* stream);
+/* The same; with in_act != 0, x is the OUTPUT of a layer with that activation (in_preact: its pre-activations, gelu / swish only) and
+ * gx leaves as that layer's dZ = (gz w) * in_act'(x): the caller runs that layer's backward with act = 0 and this dZ as its gy -- one
+ * pass over the (M, K) gradient less per layer of a Linear chain (src/models/ffn.py:12-35). */
+int cfd_linear_bwd_ex(const float* gy, const float* x, const float* w, const float* y, const float* preact, float* gx, float* gw,
+                      float* gb, void* ws, int M, int K, int N, int act, int in_act, const float* in_preact, void* stream);
 
 /* DeepONet output (src/models/auto_deeponet.py:127-135, src/models/deeponet.py:204-205):
  *   preds[b,k] = sum_p branch[b,p] trunk[k,p] + bias[0] + (u ? u[b*HW + (qidx ? qidx[k] : k)] : 0)

@@ -624,6 +624,31 @@ def check_ffn_stack(be, R, dims, act, act_last=False, with_gx=True, seed=29):
     return res
 
 
+def check_linear_chain_bwd(be, M, K, N, in_act, seed=37):
+    """cfd_linear_bwd_ex with in_act: the input gradient leaves the GEMM as the previous layer's dZ = (gz w) * in_act'(x) -- against
+    the fp64 product and, bit for bit, against cfd_linear_bwd followed by cfd_act_bwd (one fp32 multiply after the same GEMM)."""
+    from oracle import deeponet_oracle as D
+    api, P = be.api, be.ptr
+    code = {"relu": 1, "tanh": 2, "gelu": 3, "swish": 4}[in_act]
+    rng = np.random.default_rng(seed)
+    zin = rng.standard_normal((M, K)).astype(np.float32)           # the previous layer's pre-activation ...
+    x = D.act(zin.astype(f64), in_act).astype(np.float32)          # ... and its output = this layer's input
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    gz = rng.standard_normal((M, N)).astype(np.float32)
+    dx, dz, dw, dg = be.dev(x), be.dev(zin), be.dev(w), be.dev(gz)
+    gx1, gw1, gb1 = be.zeros((M, K)), be.zeros((N, K)), be.zeros((N,))
+    ws = be.bytes(api.size("cfd_linear_bwd_workspace_bytes", M, K, N))
+    api.call("cfd_linear_bwd_ex", P(dg), P(dx), P(dw), None, None, P(gx1), P(gw1), P(gb1), P(ws), M, K, N, 0, code,
+             P(dz) if code >= 3 else None, be.stream)
+    gx0, gw0, gb0, gx2 = be.zeros((M, K)), be.zeros((N, K)), be.zeros((N,)), be.zeros((M, K))
+    api.call("cfd_linear_bwd", P(dg), P(dx), P(dw), None, None, P(gx0), P(gw0), P(gb0), P(ws), M, K, N, 0, be.stream)
+    api.call("cfd_act_bwd", P(gx0), P(dx), P(dz), P(gx2), M * K, code, be.stream)
+    be.sync()
+    ref = (gz.astype(f64) @ w.astype(f64)) * D.act_grad(zin.astype(f64), in_act)
+    return {"gz_prev": nm(be.host(gx1), ref), "differs_from_two_passes": float(np.count_nonzero(be.host(gx1) != be.host(gx2))),
+            "gw_differs": float(np.count_nonzero(be.host(gw1) != be.host(gw0)))}
+
+
 def check_ffn_stacks(be, specs, seed=31):
     """cfd_ffn_stacks_fwd / _bwd: several stacks in one launch per direction must give BITWISE what the single-stack calls give (same
     kernels, same per-stack work decomposition).  specs: [(R, dims, act name, act_last, with_gx), ...].  Returns the number of

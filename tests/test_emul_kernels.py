@@ -161,6 +161,13 @@ def test_gemm_both_block_tiles(be, M, N, Kd, ta, tb, tile):
         _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
 
 
+@pytest.mark.parametrize("M,K_in,N,in_act", [(37, 21, 24, "relu"), (70, 130, 9, "gelu"), (20, 7, 5, "tanh")])
+def test_linear_input_gradient_leaves_as_the_previous_layers_dz(be, M, K_in, N, in_act):
+    res = K.check_linear_chain_bwd(be, M, K_in, N, in_act)
+    assert res.pop("differs_from_two_passes") == 0 and res.pop("gw_differs") == 0
+    _assert_all(res)
+
+
 @pytest.mark.parametrize("specs", [[(70, [5, 12, 20, 7], "relu", False, True), (33, [3, 17, 9], "gelu", True, False)], [(20, [4, 100, 100], "relu", False, True), (50, [100, 100, 100], "relu", False, True), (17, [2, 33, 100], "tanh", True, False)]])
 def test_ffn_stacks_in_one_launch_equal_the_single_calls(be, specs):
     """cfd_ffn_stacks_fwd / _bwd (the branch and trunk stacks of a DeepONet variant as one launch per direction) == the single-stack

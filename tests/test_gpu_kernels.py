@@ -208,6 +208,13 @@ def test_gemm_both_block_tiles(be, M, N, Kd, ta, tb, tile):
         _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
 
 
+@pytest.mark.parametrize("M,K_in,N,in_act", [(4290, 200, 200, "relu"), (300, 100, 100, "gelu"), (129, 33, 70, "swish"), (2050, 5, 530, "tanh")])
+def test_linear_input_gradient_leaves_as_the_previous_layers_dz(be, M, K_in, N, in_act):
+    res = K.check_linear_chain_bwd(be, M, K_in, N, in_act)
+    assert res.pop("differs_from_two_passes") == 0 and res.pop("gw_differs") == 0
+    _assert_all(res)
+
+
 @pytest.mark.parametrize("specs", [[(512, [100] * 8, "relu", False, True), (4290, [2] + [100] * 8, "relu", False, False)], [(128, [100] * 8, "relu", True, True), (128, [100] * 8, "relu", True, True), (4096, [2] + [100] * 8, "relu", False, False)], [(70, [5, 12, 20, 7], "swish", False, True), (333, [3, 128, 128, 1], "gelu", True, True)]])
 def test_ffn_stacks_in_one_launch_equal_the_single_calls(be, specs):
     """cfd_ffn_stacks_fwd / _bwd (the branch and trunk stacks of a DeepONet variant as one launch per direction) == the single-stack
