@@ -1,5 +1,5 @@
 // Shared between conv.hip (exact-fp32 MFMA kernels, BatchNorm, pooling, the C ABI of the convolution stack) and conv6.hip (the
-// three-piece split-bf16 implicit-GEMM kernels for k = 3 and k = 7).
+// three-piece split-bf16 implicit-GEMM kernels for k = 3, 5 and 7).
 #pragma once
 #include "cfd_common.h"
 

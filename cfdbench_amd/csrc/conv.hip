@@ -1,4 +1,4 @@
-// Convolution stack of the U-Net / ResNet baselines on the CDNA4 matrix pipe.  k = 3 and k = 7 run on the three-piece split-bf16
+// Convolution stack of the U-Net / ResNet baselines on the CDNA4 matrix pipe.  k = 3, 5 and 7 run on the three-piece split-bf16
 // kernels of conv6.hip; this file holds the C ABI, the general gather kernels (any odd k <= 7, exact-fp32
 // v_mfma_f32_16x16x4_f32: k = 1 / 5, and k = 3 / 7 when no workspace is given), BatchNorm, pooling and the transposed conv:
 //   nn.Conv2d(k, padding=k/2, padding_mode="replicate")   src/models/unet.py:20-43 (k=3), src/models/resnet.py:35-55 (k=7)

@@ -1,4 +1,4 @@
-// k = 3 and k = 7 replicate-padded convolutions (src/models/unet.py:20-43, src/models/resnet.py:35-55) as implicit GEMMs on the
+// k = 3, 5 and 7 replicate-padded convolutions (src/models/unet.py:20-43, auto_deeponet_cnn.py:17-33, resnet.py:35-55) as implicit GEMMs on the
 // bf16 matrix pipe with THREE-PIECE operands: every fp32 value is carried as hi + lo + lo2 (8 + 8 + 8 significant bits, exact),
 // a product is six v_mfma_f32_16x16x32_bf16 (cfd_mfma_bf16x6: everything down to 2^-24 of the product, fp32 accumulation), so the
 // results are fp32-exact-class like the v_mfma_f32_16x16x4_f32 kernels of conv.hip they replace -- the ReLU / max-pool networks
@@ -437,9 +437,9 @@ struct Conv6Frag {
 
 static Conv6Frag conv6_frag(int Ci, int Co, int ks, bool ext) {
     Conv6Frag F{};
-    if ((ks != 3 && ks != 7) || Ci < 1 || Co < 1) return F;
+    if ((ks != 3 && ks != 5 && ks != 7) || Ci < 1 || Co < 1) return F;
     const int Cm = ext ? Ci : Co, Cs = ext ? Co : Ci;
-    F.CC = (ks == 7 || Cs <= 8) ? 8 : 16;  // k = 7: 13 k-steps of 4 taps x 8 channels keep two workgroups per CU
+    F.CC = (ks >= 5 || Cs <= 8) ? 8 : 16;  // k = 5 / 7: 7 / 13 k-steps of 4 taps x 8 channels keep two workgroups per CU
     const int PPS = 32 / F.CC;
     F.KSTEPS = (ks * ks + PPS - 1) / PPS;
     F.MTall = (Cm + 15) / 16;
@@ -451,7 +451,7 @@ static Conv6Frag conv6_frag(int Ci, int Co, int ks, bool ext) {
 
 static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     Conv6Plan P{};
-    if (g.ks != 3 && g.ks != 7) return P;
+    if (g.ks != 3 && g.ks != 5 && g.ks != 7) return P;
     const int KS = g.ks, PAD = KS / 2;
     const int Hd = ext ? g.H + 2 * PAD : g.H, Wd = ext ? g.W + 2 * PAD : g.W;
     const int Cm = ext ? g.Ci : g.Co, Cs = ext ? g.Co : g.Ci;
@@ -558,6 +558,8 @@ static int conv6_run(const float* src, const float* w, const float* bias, float*
     if (g.ks == 3) {
         if (P.CC == 8) conv6_launch<3, 8, EXT>(P, src, wfrag, bias, kdst, g, gd, stats, st);
         else conv6_launch<3, 16, EXT>(P, src, wfrag, bias, kdst, g, gd, stats, st);
+    } else if (g.ks == 5) {  // (round 4: the 5 x 5 convolutions of the Auto-DeepONet-CNN branch, src/models/auto_deeponet_cnn.py:17-33)
+        conv6_launch<5, 8, EXT>(P, src, wfrag, bias, kdst, g, gd, stats, st);
     } else {
         conv6_launch<7, 8, EXT>(P, src, wfrag, bias, kdst, g, gd, stats, st);
     }
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
                 av[mt][pc] = __builtin_bit_cast(bf16x8, *(const u4*)(s_g + 48 * ((pi * MT + mt) * 16 + ((n + pi) & 15)) + 16 * pc));
         // column tiles in groups of NG: their B operands are read together and the MFMAs run product-major over the group, so that
         // consecutive MFMAs are independent
-        constexpr int NG = KS == 3 ? 3 : (MT == 1 ? 7 : 2);
+        constexpr int NG = KS == 3 ? 3 : (MT == 1 ? KS : 2);  // (k = 5 / 7: NT = 10 / 14 column tiles)
         static_assert(NT % NG == 0, "column tiles per MFMA group");
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // the six products of cfd_mfma_bf16x6, small terms first
 #pragma unroll
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
     }
     // sum of the four waves (each owns 4 of the tile's 16 pixels) in a fixed order, RG column tiles of one output-channel tile at a
     // time (the staging buffers are free by now)
-    constexpr int RG = KS == 3 ? 9 : 7;
+    constexpr int RG = KS == 3 ? 9 : KS;
     static_assert(NT % RG == 0, "column tiles per reduction round");
     float* s_red = (float*)s_dyn;  // [wave][RG][r][lane]
     const size_t n1 = (size_t)g.Co * g.Ci * KK;
@@ -832,10 +834,10 @@ struct Wg6Plan {
 
 static Wg6Plan wg6_plan(const ConvGeom& g) {
     Wg6Plan P{};
-    if (g.ks != 3 && g.ks != 7) return P;
-    const int KS = g.ks, NKY = KS == 3 ? 3 : 2;  // k = 7: tap rows {0,1}, {2,3}, {4,5}, {6}: 14 column tiles per output-channel tile
+    if (g.ks != 3 && g.ks != 5 && g.ks != 7) return P;
+    const int KS = g.ks, NKY = KS == 3 ? 3 : 2;  // k = 7: tap rows {0,1}, {2,3}, {4,5}, {6}: 14 column tiles per output-channel tile; k = 5: {0,1}, {2,3}, {4}: 10
     Wg6Tile& t = P.t;
-    t.TW = (g.W >= 8 || KS == 7) ? 8 : 4;  // (k = 7 on 4 x 4 tiles would stage a 5 x 10 halo: more than the three items per thread)
+    t.TW = (g.W >= 8 || KS >= 5) ? 8 : 4;  // (k = 7 on 4 x 4 tiles would stage a 5 x 10 halo: more than the three items per thread)
     t.TH = 16 / t.TW;
     t.tw_shift = t.TW == 8 ? 3 : 2;
     t.tiles_x = (g.W + t.TW - 1) / t.TW;
@@ -862,7 +864,7 @@ static Wg6Plan wg6_plan(const ConvGeom& g) {
     if (want < 1) want = 1;
     P.groups = (int)(want < P.ntiles ? want : P.ntiles);
     const size_t stage = (size_t)3 * t.HP * 256 + (size_t)3 * 16 * P.mtw * 256;
-    const size_t red = (size_t)4 * (KS == 3 ? 9 : 7) * 256 * sizeof(float);
+    const size_t red = (size_t)4 * (KS == 3 ? 9 : KS) * 256 * sizeof(float);
     P.lds = stage > red ? stage : red;
     P.part_bytes = cfd_align_up((size_t)P.groups * ((size_t)g.Co * g.Ci * KS * KS + g.Co) * sizeof(float), 256);  // (+ bias-gradient row)
     P.ok = P.lds <= 150 * 1024 && t.HP * 16 <= 3 * 256 && (long)g.B * g.Ci * g.H * g.W < (1L << 30) && (long)g.B * g.Co * g.H * g.W < (1L << 30);  // 32-bit byte offsets
@@ -894,6 +896,9 @@ int cfd_conv6_wgrad(const float* gout, const float* in, float* gw, float* gb, vo
     if (g.ks == 3) {
         if (P.mtw == 1) W6_L(3, 1, 3);
         else W6_L(3, 2, 3);
+    } else if (g.ks == 5) {
+        if (P.mtw == 1) W6_L(5, 1, 2);
+        else W6_L(5, 2, 2);
     } else {
         if (P.mtw == 1) W6_L(7, 1, 2);
         else W6_L(7, 2, 2);

@@ -205,7 +205,7 @@ def test_deeponet_inner(be, B, P, Kq, HW, with_q):
 
 # conv6.hip (k = 3 / 7) with two persistent workgroups (the emulator build's CFD_CONV6_GRID): several tiles, two channel chunks
 # and ragged image groups per workgroup in the (40, 20, 18) case; more shapes in test_gpu_kernels.py
-@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(1, 5, 7, 9, 10, 3), (40, 20, 18, 5, 4, 3), (2, 2, 3, 8, 9, 7), (2, 4, 4, 6, 6, 1), (9, 3, 35, 2, 9, 7),
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(1, 5, 7, 9, 10, 3), (40, 20, 18, 5, 4, 3), (2, 2, 3, 8, 9, 7), (2, 4, 4, 6, 6, 1), (9, 3, 35, 2, 9, 7), (2, 5, 20, 9, 10, 5), (3, 32, 7, 6, 5, 5),
                                             (3, 12, 12, 64, 64, 3), (2, 24, 12, 33, 32, 3), (20, 96, 40, 4, 4, 3), (2, 16, 64, 20, 21, 7),
                                             (9, 64, 2, 17, 16, 7)])
 def test_conv2d_replicate(be, B, Ci, Co, H, W, ks):
@@ -222,12 +222,12 @@ def test_conv_emits_batchnorm_statistics(be, B, Ci, Co, H, W, ks):
 
 
 def test_conv_weights_prepared_in_one_batch(be):
-    """fragments of several layers (k = 3 and 7, narrow and wide, forward and input-gradient forms) made by one
+    """fragments of several layers (k = 3, 5 and 7, narrow and wide, forward and input-gradient forms) made by one
     cfd_conv2d_wprep_batch launch: the layers then compute bit for bit what they compute preparing their own"""
-    layers = [(2, 3, 12, 16, 16, 3), (3, 12, 24, 9, 10, 3), (2, 40, 20, 8, 8, 3), (1, 8, 16, 12, 13, 7), (2, 17, 5, 20, 21, 7)]
+    layers = [(2, 3, 12, 16, 16, 3), (3, 12, 24, 9, 10, 3), (2, 40, 20, 8, 8, 3), (1, 8, 16, 12, 13, 7), (2, 17, 5, 20, 21, 7), (2, 9, 32, 10, 11, 5)]
     assert K.check_conv_prepared(be, layers) == 0
     assert K.check_conv_prepared(be, [(1, 3 + i % 3, 4 + i % 5, 6, 6, 3) for i in range(25)], seed=38) == 0  # 50 items: two launches
-    assert be.api.size("cfd_conv2d_wfrag_bytes", 12, 12, 5, 0) == 0 and be.api.size("cfd_conv2d_wfrag_bytes", 12, 2, 1, 1) == 0
+    assert be.api.size("cfd_conv2d_wfrag_bytes", 12, 12, 9, 0) == 0 and be.api.size("cfd_conv2d_wfrag_bytes", 12, 2, 1, 1) == 0
 
 
 @pytest.mark.parametrize("B,C,H,W,training,relu", [(2, 3, 6, 7, True, True), (2, 3, 4, 4, False, True), (3, 2, 5, 5, True, False), (4, 12, 64, 64, True, True),

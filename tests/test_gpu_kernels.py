@@ -251,7 +251,7 @@ def test_deeponet_inner(be, B, P, Kq, HW, with_q):
     _assert_all(res)
 
 
-@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(3, 11, 12, 64, 64, 3), (2, 24, 12, 33, 32, 3), (2, 96, 192, 5, 4, 3), (2, 192, 96, 8, 8, 3), (1, 8, 64, 20, 21, 7), (1, 64, 16, 17, 16, 7), (2, 12, 2, 16, 16, 1)])
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(3, 11, 12, 64, 64, 3), (2, 24, 12, 33, 32, 3), (2, 96, 192, 5, 4, 3), (2, 192, 96, 8, 8, 3), (1, 8, 64, 20, 21, 7), (1, 64, 16, 17, 16, 7), (2, 12, 2, 16, 16, 1), (32, 32, 32, 36, 36, 5), (4, 8, 32, 68, 68, 5), (3, 32, 32, 8, 8, 5)])
 def test_conv2d_replicate(be, B, Ci, Co, H, W, ks):
     _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, ks))
 

@@ -13,7 +13,7 @@ rnd = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 bad = 0
 for it in range(n):
-    ks = rnd.choice([3, 3, 7])
+    ks = rnd.choice([3, 3, 5, 7])
     B = rnd.choice([1, 2, 3, 5, 8, 9, 17, 33, 128])
     Ci, Co = rnd.choice([1, 2, 5, 8, 9, 12, 16, 17, 24, 33, 48, 96, 192]), rnd.choice([1, 2, 7, 12, 16, 17, 31, 40, 64, 96, 192])
     H, W = rnd.choice([1, 2, 3, 4, 5, 8, 13, 16, 32, 33, 64]), rnd.choice([1, 2, 3, 4, 7, 8, 9, 16, 17, 32, 40, 64, 65])
