@@ -108,7 +108,9 @@ struct SlabRegs {
 //   2 x 2 waves of 4 x 4 tiles:  128 x 128  (gemm_tile = 128) half the operand reads per flop
 //   4 x 1 waves of 2 x 8 / 2 x 16 tiles: 128 rows x ALL columns up to 128 / 256 (gemm_tile = 1): A read once, 13 column tiles for N = 200
 //     where the square blocks cover 16
-// The two large shapes are SLOWER on every product of the benchmark (131 k x 200 x 200 of the Auto-FFN: 64 x 64 3.41 ms of k_gemm per
+//   4 x 2 waves (EIGHT waves, the first four stage) of 2 x 2 tiles: 128 x 64 (gemm_tile = 8): 25 % fewer operand loads per flop at the
+//     64 x 64 kernel's registers per wave: +1 .. +6 % slower
+// The large shapes are SLOWER on every product of the benchmark (131 k x 200 x 200 of the Auto-FFN: 64 x 64 3.41 ms of k_gemm per
 // step, 128 x 128 3.83-3.97, all-columns 3.62-5.10; profiles/r04g_gemm_counters.txt): the kernel's time is the SUM of its parts -- the
 // MFMAs, the global loads, the epilogue, the LDS / barrier skeleton, measured by taking each out -- not their maximum, and only many
 // small blocks per CU overlap them; they stay in the build behind the knob, with their tests.  Row / column tiles beyond M / N are
@@ -116,11 +118,11 @@ struct SlabRegs {
 // K in slabs of 16 through a three-deep pipeline: while slab s is on the matrix pipe, slab s + 1 -- loaded during slab s - 1 -- goes
 // from registers to the other LDS buffer (the stores are issued in front of the MFMAs and complete beside them) and slab s + 2 is
 // on its way from memory; one barrier per slab.
-template <bool AT, bool BT, int WGM, int WTM, int WTN>
-__global__ __launch_bounds__(256, 2) void k_gemm(const float* __restrict__ A, const float* __restrict__ B,
+template <bool AT, bool BT, int WGM, int WTM, int WTN, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void k_gemm(const float* __restrict__ A, const float* __restrict__ B,
                                                  float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
                                                  GemmEpi epi, int slabs_per_split, int nbx, int nby, int nbz) {
-    constexpr int WGN = 4 / WGM;
+    constexpr int WGN = NW / WGM;  // (NW = 8: the first four waves stage the slabs, all eight feed the matrix pipe)
     constexpr int BM = 16 * WTM * WGM, BN = 16 * WTN * WGN;  // block tile
     using RA = SlabRegs<!AT, BM / 64>;  // A is k-contiguous unless transposed
     using RB = SlabRegs<BT, BN / 64>;   // B is k-contiguous only when stored transposed
@@ -158,9 +160,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const float* __restrict__ A, co
     const bool va = ((AT ? M : K) & 3) == 0, vb = ((BT ? K : N) & 3) == 0;  // (uniform) 16-byte units never straddle a row end
     RA ra0, ra1;
     RB rb0, rb1;
+    const bool stager = NW == 4 || tid < 256;  // (wave-uniform)
     const auto load = [&](RA& ra, RB& rb, int slab) {
+        if (!stager) return;
         ra.load(A, lda, M, K, m0, (s0 + slab) * GK, tid, va);
         rb.load(B, ldb, N, K, n0, (s0 + slab) * GK, tid, vb);
+    };
+    const auto commit = [&](const RA& ra, const RB& rb, int buf) {
+        if (!stager) return;
+        ra.store(s_a[buf], tid);
+        rb.store(s_b[buf], tid);
     };
     const auto mma = [&](const float* sa, const float* sb) {
         f32x4 fa[WTM];
@@ -180,18 +189,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const float* __restrict__ A, co
     };
     load(ra0, rb0, 0);
     if (nslab > 1) load(ra1, rb1, 1);
-    ra0.store(s_a[0], tid);
-    rb0.store(s_b[0], tid);
+    commit(ra0, rb0, 0);
     __syncthreads();
     for (int s = 0; s < nslab; s += 2) {
         // slab s from buffer 0; slab s + 1 waits in (ra1, rb1)
-        if (s + 1 < nslab) { ra1.store(s_a[1], tid); rb1.store(s_b[1], tid); }  // (buffer 1 was last read before the previous barrier)
+        if (s + 1 < nslab) commit(ra1, rb1, 1);  // (buffer 1 was last read before the previous barrier)
         if (s + 2 < nslab) load(ra0, rb0, s + 2);
         mma(s_a[0], s_b[0]);
         __syncthreads();
         if (s + 1 >= nslab) break;
         // slab s + 1 from buffer 1; slab s + 2 waits in (ra0, rb0)
-        if (s + 2 < nslab) { ra0.store(s_a[0], tid); rb0.store(s_b[0], tid); }
+        if (s + 2 < nslab) commit(ra0, rb0, 0);
         if (s + 3 < nslab) load(ra1, rb1, s + 3);
         mma(s_a[1], s_b[1]);
         __syncthreads();
@@ -285,6 +293,7 @@ static int gemm_tile_kind(int M, int N, int splits) {
     if (t == 64) return 64;
     if (t == 128) return 128;
     if (t == 1) return N <= 128 ? 1 : 2;  // (the all-columns kernels on any shape; N > 256 takes several column blocks)
+    if (t == 8) return 8;                 // 128 x 64 blocks of eight waves
     (void)M; (void)splits;
     return 64;
 }
@@ -298,7 +307,7 @@ static int launch_gemm(const float* A, const float* B, float* C, int M, int N, i
     const int per = (nslab + splits - 1) / splits;
     splits = (nslab + per - 1) / per;
     const int kind = gemm_tile_kind(M, N, splits);
-    const int bm = kind == 64 ? 64 : 128, bn = kind == 64 ? 64 : (kind == 1 ? 128 : (kind == 2 ? 256 : 128));
+    const int bm = kind == 64 ? 64 : 128, bn = (kind == 64 || kind == 8) ? 64 : (kind == 1 ? 128 : (kind == 2 ? 256 : 128));
     const int nbx = (N + bn - 1) / bn, nby = (M + bm - 1) / bm;
     const long ngroups = splits > 1 ? splits : nby, gsz = splits > 1 ? (long)nbx * nby : nbx;
     const long nblocks = ((ngroups + 7) / 8) * 8 * gsz;  // (see k_gemm: block -> tile map)
@@ -310,24 +319,25 @@ static int launch_gemm(const float* A, const float* B, float* C, int M, int N, i
     const int ldk = splits > 1 ? N : ldc;
     {
         CFD_PROF_W("k_gemm", st, 4.0 * ((double)M * K + (double)K * N + (double)M * N), 2.0 * M * (double)N * K);
-#define GEMM_K(AT_, BT_, G_, TM_, TN_)                                                                                                     \
+#define GEMM_K(AT_, BT_, G_, TM_, TN_, NW_)                                                                                                \
     do {                                                                                                                                  \
-        constexpr int bm_ = 16 * TM_ * G_, bn_ = 16 * TN_ * (4 / G_);                                                                     \
+        constexpr int bm_ = 16 * TM_ * G_, bn_ = 16 * TN_ * (NW_ / G_);                                                                   \
         constexpr size_t lds_ = 2 * sizeof(float) * (SlabRegs<!AT_, bm_ / 64>::FLOATS + SlabRegs<BT_, bn_ / 64>::FLOATS);                \
         static bool attr_set = false;                                                                                                     \
         if (!attr_set) {                                                                                                                  \
-            (void)hipFuncSetAttribute((const void*)k_gemm<AT_, BT_, G_, TM_, TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+            (void)hipFuncSetAttribute((const void*)k_gemm<AT_, BT_, G_, TM_, TN_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
             attr_set = true;                                                                                                              \
         }                                                                                                                                 \
-        hipLaunchKernelGGL((k_gemm<AT_, BT_, G_, TM_, TN_>), grid, dim3(256), lds_, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per, nbx,   \
+        hipLaunchKernelGGL((k_gemm<AT_, BT_, G_, TM_, TN_, NW_>), grid, dim3(64 * NW_), lds_, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per, nbx,   \
                            nby, splits);                                                                                                  \
     } while (0)
 #define GEMM_L(AT_, BT_)                                  \
     do {                                                  \
-        if (kind == 64) GEMM_K(AT_, BT_, 2, 2, 2);        \
-        else if (kind == 128) GEMM_K(AT_, BT_, 2, 4, 4);  \
-        else if (kind == 1) GEMM_K(AT_, BT_, 4, 2, 8);    \
-        else GEMM_K(AT_, BT_, 4, 2, 16);                  \
+        if (kind == 64) GEMM_K(AT_, BT_, 2, 2, 2, 4);        \
+        else if (kind == 128) GEMM_K(AT_, BT_, 2, 4, 4, 4);  \
+        else if (kind == 8) GEMM_K(AT_, BT_, 4, 2, 2, 8);    \
+        else if (kind == 1) GEMM_K(AT_, BT_, 4, 2, 8, 4);    \
+        else GEMM_K(AT_, BT_, 4, 2, 16, 4);                  \
     } while (0)
         if (!at && !bt) GEMM_L(false, false);
         else if (!at && bt) GEMM_L(false, true);

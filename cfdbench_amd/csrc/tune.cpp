@@ -34,8 +34,8 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
     {"act_pieces", "CFD_ACT_PIECES", {-1}},      // bf16 pieces of the ACTIVATION operand of the FNO contractions: 2 (default, 2^-16 per product) or 3
                                                  // (fp32-exact class, six MFMAs per product; cfd_common.h)
     {"block_gen", "CFD_BLOCK_GEN", {-1}},        // 0 = the FnoBlock of grids other than 64-wide / H % 16 == 0 (66 x 65) as two passes instead of the fused kernel
-    {"gemm_tile", "CFD_GEMM_TILE", {-1}},        // block tile of the fp32 GEMM (dense.hip): 128 = 128 x 128, 1 = 128 rows x all columns; default 64 x 64 (the fastest
-                                                 // on every product of the benchmark)
+    {"gemm_tile", "CFD_GEMM_TILE", {-1}},        // block tile of the fp32 GEMM (dense.hip): 128 = 128 x 128, 1 = 128 rows x all columns, 8 = 128 x 64 on eight waves;
+                                                 // default 64 x 64 (the fastest on every product of the benchmark)
 };
 std::once_flag g_once;
 void read_env() {

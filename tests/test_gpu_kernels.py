@@ -199,10 +199,10 @@ def test_gemm(be, M, N, Kd, ta, tb):
     _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
 
 
-@pytest.mark.parametrize("tile", [64, 128, 1])
+@pytest.mark.parametrize("tile", [64, 128, 1, 8])
 @pytest.mark.parametrize("M,N,Kd,ta,tb", [(4290, 100, 100, 0, 0), (70001, 200, 200, 0, 1), (300, 515, 4000, 1, 0), (130, 129, 77, 1, 1), (70, 45, 37, 0, 0)])
 def test_gemm_both_block_tiles(be, M, N, Kd, ta, tb, tile):
-    """Every block tile of k_gemm (64 x 64, 128 x 128, 1 = 128 rows x all columns) on every storage form, whatever launch_gemm would
+    """Every block tile of k_gemm (64 x 64, 128 x 128, 1 = 128 rows x all columns, 8 = 128 x 64 on eight waves) on every storage form, whatever launch_gemm would
     pick for the shape."""
     with K.tuned(be, gemm_tile=tile):
         _assert_all(K.check_gemm(be, M, N, Kd, ta, tb))
