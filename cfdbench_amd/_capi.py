@@ -115,6 +115,9 @@ _SIGS = {
     "cfd_conv2d_wprep_batch": (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
     "cfd_conv2d_fwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cfd_conv2d_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cfd_conv2d_zeropad_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "cfd_conv2d_zeropad_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cfd_conv2d_zeropad_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cfd_batchnorm_workspace_bytes": (_Z, [_I]),
     "cfd_batchnorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _P]),
     "cfd_batchnorm_fwd_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _F, _F, _I, _P]),

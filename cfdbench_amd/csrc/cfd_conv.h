@@ -5,6 +5,7 @@
 
 struct ConvGeom {
     int B, Ci, Co, H, W, ks;  // ks = kernel size (odd), pad = ks/2
+    int zpad;                 // 1: ZERO padding (nn.Conv2d's default, src/models/auto_deeponet_cnn.py:17-33) on the conv6 kernels; 0: replicate
 };
 
 struct ConvTile {
@@ -39,6 +40,7 @@ CfdPartReduceJob cfd_conv_part_reduce_job(const float* part, float* out, long n,
 // (ext = true: dst (B,Ci,H+2p,W+2p) from src = gout (B,Co,H,W)).  ws: cfd_conv6_ws_bytes(); returns CFD_ERR_UNSUPPORTED when the
 // layer is not covered (the caller then uses the fp32 kernels).
 bool cfd_conv6_covers(const ConvGeom& g, bool ext);
+bool cfd_conv6_zeropad_covers(const ConvGeom& g);
 size_t cfd_conv6_ws_bytes(const ConvGeom& g, bool ext);
 // ext with `gin` != NULL: extended positions that map one-to-one onto an interior pixel may be written straight to gin (B,Ci,H,W)
 // instead of dst; *direct then says so and the caller folds only the border pixels (k_fold_border) instead of every pixel.

@@ -261,6 +261,57 @@ extern "C" int cfd_conv2d_fwd_stats(const float* in, const float* w, const float
     return cfd_conv2d_fwd_ex(in, w, bias, out, ws, stats, nullptr, B, Ci, Co, H, W, ks, stream);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// nn.Conv2d(k, padding = k / 2) with ZERO padding (the CNN branch of src/models/auto_deeponet_cnn.py:17-33) on the conv6 kernels: the
+// halo outside the image loads as zeros instead of the clamped pixel; the input gradient has nothing to fold -- every image pixel is
+// one position of the extended grid and is written straight to gin.  (Until round 4 the model zero-padded its input by k / 2 with
+// F.pad, ran the replicate kernel on the larger grid and cropped: ~6 extra launches per convolution and direction.)
+// ------------------------------------------------------------------------------------------------------
+static int chan_sum(const float* g, float* out, void* ws, int B, int C, int HW, hipStream_t st, const char* what);  // (defined below)
+extern "C" int cfd_conv2d_zeropad_supported(int B, int Ci, int Co, int H, int W, int ks) {
+    if (B < 1 || Ci < 1 || Co < 1 || H < 1 || W < 1) return 0;
+    const ConvGeom g{B, Ci, Co, H, W, ks, 1};
+    return cfd_conv6_zeropad_covers(g) ? 1 : 0;
+}
+
+extern "C" int cfd_conv2d_zeropad_fwd(const float* in, const float* w, const float* bias, float* out, void* ws, int B, int Ci, int Co,
+                                      int H, int W, int ks, void* stream) {
+    CFD_REQUIRE(in && w && out && ws, CFD_ERR_INVALID_ARG, "cfd_conv2d_zeropad_fwd: NULL pointer");
+    CFD_TRY(conv_check("cfd_conv2d_zeropad_fwd", B, Ci, Co, H, W, ks));
+    CFD_REQUIRE(cfd_conv2d_zeropad_supported(B, Ci, Co, H, W, ks), CFD_ERR_UNSUPPORTED,
+                "cfd_conv2d_zeropad_fwd: shape outside the conv6 kernels (cfd_conv2d_zeropad_supported() == 0)");
+    const ConvGeom g{B, Ci, Co, H, W, ks, 1};
+    CFD_PROF_W("k_conv_fwd", (hipStream_t)stream, 4.0 * ((double)B * (Ci + Co) * H * W + (double)Co * Ci * ks * ks),
+               2.0 * B * H * W * (double)Co * Ci * ks * ks);
+    return cfd_conv6_run(in, w, bias, out, ws, g, false, nullptr, nullptr, (hipStream_t)stream, "cfd_conv2d_zeropad_fwd", nullptr, nullptr);
+}
+
+extern "C" int cfd_conv2d_zeropad_bwd(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws,
+                                      int B, int Ci, int Co, int H, int W, int ks, void* stream) {
+    CFD_REQUIRE(gout && in && w && ws, CFD_ERR_INVALID_ARG, "cfd_conv2d_zeropad_bwd: NULL pointer");
+    CFD_TRY(conv_check("cfd_conv2d_zeropad_bwd", B, Ci, Co, H, W, ks));
+    CFD_REQUIRE(cfd_conv2d_zeropad_supported(B, Ci, Co, H, W, ks), CFD_ERR_UNSUPPORTED,
+                "cfd_conv2d_zeropad_bwd: shape outside the conv6 kernels (cfd_conv2d_zeropad_supported() == 0)");
+    hipStream_t st = (hipStream_t)stream;
+    const ConvGeom g{B, Ci, Co, H, W, ks, 1};
+    const int HW = H * W, pad = ks / 2;
+    const size_t ext_bytes = cfd_align_up((size_t)B * Ci * (H + 2 * pad) * (W + 2 * pad) * sizeof(float), 256);
+    if (gin) {  // (ws layout of cfd_conv2d_bwd: [extended grid -- unused here | fragments of the input-gradient pass | weight-gradient partials])
+        bool direct = false;
+        CFD_PROF_W("k_conv_dgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci * ks * ks), 2.0 * B * HW * (double)Co * Ci * ks * ks);
+        CFD_TRY(cfd_conv6_run(gout, w, nullptr, (float*)ws, (char*)ws + ext_bytes, g, true, gin, &direct, st, "cfd_conv2d_zeropad_bwd(dgrad)",
+                              nullptr, nullptr));
+    }
+    if (gw) {
+        void* wws = (char*)ws + ext_bytes + cfd_conv6_ws_bytes(g, true);
+        CFD_PROF_W("k_conv_wgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci * ks * ks), 2.0 * B * HW * (double)Co * Ci * ks * ks);
+        CFD_TRY(cfd_conv6_wgrad(gout, in, gw, gb, wws, g, st, "cfd_conv2d_zeropad_bwd(wgrad)", nullptr));
+    } else if (gb) {
+        CFD_TRY(chan_sum(gout, gb, ws, B, Co, HW, st, "cfd_conv2d_zeropad_bwd(bias)"));
+    }
+    return CFD_OK;
+}
+
 // gin[b][i][y][x] = sum over the extended positions that replicate padding maps to (y, x)
 __global__ __launch_bounds__(256) void k_fold_pad(const float* __restrict__ ext, float* __restrict__ gin, unsigned total,
                                                   int H, int W, int pad, CfdDiv dHW, CfdDiv dW) {

@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
             bool ok = !(pk >> 31) && bi < nbv;
             if constexpr (EXT) {  // outside the image: zeros
                 ok = ok && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
-            } else {              // replicate padding
+            } else {              // replicate padding (zero padding: the clamped position is never loaded)
+                if (g.zpad) ok = ok && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
                 y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
                 x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
             }
@@ -317,10 +318,11 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
                 // input-gradient pass with `gin_direct`: extended positions that map one-to-one onto an interior pixel of the image
                 // go straight to gin; only the pad ring and the border rows / columns (whose pixels collect several extended
                 // positions) take the detour through the extended buffer and k_fold_border
-                const int yi = y - PAD, xi = x - PAD;
-                const bool direct = gin_direct != nullptr && yi >= 1 && yi <= g.H - 2 && xi >= 1 && xi <= g.W - 2;
+                // (zero padding: EVERY image pixel is one extended position -- all direct, the pad ring is dropped, nothing to fold)
+                const int yi = y - PAD, xi = x - PAD, rim = g.zpad ? 0 : 1;
+                const bool direct = gin_direct != nullptr && yi >= rim && yi <= g.H - 1 - rim && xi >= rim && xi <= g.W - 1 - rim;
                 if (gin_direct) put(bgin, on && direct ? 4u * (unsigned)(row0 * HWs + yi * g.W + xi) : CFD_BUF_OOB, HWs, tt, false);
-                if (cfd_wave_any(on && !direct))  // (interior tiles have no such lane)
+                if (!g.zpad && cfd_wave_any(on && !direct))  // (interior tiles have no such lane)
                     put(bdst, on && !direct ? 4u * (unsigned)(row0 * HWd + y * Wd + x) : CFD_BUF_OOB, HWd, tt, true);
             } else {
                 put(bdst, on ? 4u * (unsigned)(row0 * HWd + y * Wd + x) : CFD_BUF_OOB, HWd, tt, true);
@@ -512,6 +514,13 @@ static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
 
 bool cfd_conv6_covers(const ConvGeom& g, bool ext) { return conv6_plan(g, ext).ok; }
 
+// zero padding runs on these kernels only: forward, the input gradient with every pixel written directly (no split-K partials, an
+// image of at least 3 x 3) and the weight gradient must all be covered
+bool cfd_conv6_zeropad_covers(const ConvGeom& g) {
+    const Conv6Plan Pe = conv6_plan(g, true);
+    return conv6_plan(g, false).ok && Pe.ok && Pe.ksplit == 1 && g.H >= 3 && g.W >= 3 && cfd_conv6_wgrad_covers(g);
+}
+
 size_t cfd_conv6_ws_bytes(const ConvGeom& g, bool ext) {
     const Conv6Plan P = conv6_plan(g, ext);
     return P.ok ? P.wfrag_bytes + P.split_bytes : 0;
@@ -554,6 +563,7 @@ static int conv6_run(const float* src, const float* w, const float* bias, float*
     // interior pixels of the input gradient straight to gin (no split-K partials, an interior exists, 32-bit offsets hold)
     float* gd = (EXT && gin && P.ksplit == 1 && g.H >= 3 && g.W >= 3) ? gin : nullptr;
     if (direct) *direct = gd != nullptr;
+    if (EXT && g.zpad && !gd) return CFD_ERR_UNSUPPORTED;  // (zero padding has no fold pass: callers ask cfd_conv6_zeropad_covers first)
     if (stats && (EXT || P.ksplit > 1 || P.NI != 3)) return CFD_ERR_UNSUPPORTED;  // (callers ask cfd_conv6_stats_slots first)
     if (g.ks == 3) {
         if (P.CC == 8) conv6_launch<3, 8, EXT>(P, src, wfrag, bias, kdst, g, gd, stats, st);
@@ -689,6 +699,7 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
     // the next tile's global loads wait in registers while this tile's MFMAs run (see k_conv6); all of them unconditional from
     // clamped addresses (uniform image pointer + 32-bit byte offset)
     float dri[NIW][8], drg[MT][8];
+    bool iok[NIW];  // zero padding: the halo pixel lies inside the image (outside: the operand is zero, not the clamped pixel)
     int gok[MT];  // images of the gradient item that are real (0: pixel outside the image): the only operand that must be zeroed --
                   // input values beside a zero gradient, input channels beyond Ci and output rows beyond Co never reach gw
     const auto issue = [&](int tile) {
@@ -707,6 +718,7 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < NIW; ++k) {
             int y = oy + (int)((ipk[k] >> 8) & 255), x = ox + (int)(ipk[k] & 255);
+            iok[k] = !g.zpad || ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W);
             y = y < 0 ? 0 : (y >= g.H ? g.H - 1 : y);
             x = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
             const unsigned off = ich[k] + 4u * (unsigned)(y * g.W + x);
@@ -733,6 +745,10 @@ __global__ __launch_bounds__(256, 2) void k_conv6_wgrad(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < NIW; ++k) {
             if (!(ipk[k] >> 31)) {
+                if (!iok[k]) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dri[k][j] = 0.f;
+                }
                 const CfdSplit8x3 sp = cfd_split8x3(dri[k]);
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) *(u4*)(s_in + ilds[k] + 16 * pc) = __builtin_bit_cast(u4, sp.p[pc]);

@@ -822,6 +822,48 @@ class BatchNormFn(torch.autograd.Function):
         return gx, gg, gb, None, None, None, None, None, None
 
 
+class Conv2dZeroPadFn(torch.autograd.Function):
+    """nn.Conv2d(k, padding=k // 2) with its default ZERO padding (the CNN branch of auto_deeponet_cnn.py:17-33) on the three-piece bf16
+    kernels (cfd_conv2d_zeropad_fwd / _bwd).  ``supported`` tells whether the kernels take the shape; otherwise the caller zero-pads,
+    runs the replicate-padding kernel on the larger grid and crops."""
+
+    @staticmethod
+    def supported(x: Tensor, w: Tensor) -> bool:
+        if not (x.is_cuda and x.dim() == 4 and w.dim() == 4 and w.shape[2] == w.shape[3] and w.shape[1] == x.shape[1]):
+            return False
+        B, Ci, H, W = x.shape
+        return _lib.api().size("cfd_conv2d_zeropad_supported", B, Ci, w.shape[0], H, W, w.shape[2]) == 1
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor]):
+        _require_cuda(x, w, b)
+        api = _lib.api()
+        x, w = _f32c(x), _f32c(w.detach())
+        b = _f32c(b.detach()) if b is not None else None
+        B, Ci, H, W = x.shape
+        Co, _, ks, _ = w.shape
+        y = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+        ws = _bytes(api.size("cfd_conv2d_fwd_workspace_bytes", B, Ci, Co, H, W, ks), x.device)
+        api.call("cfd_conv2d_zeropad_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(ws), B, Ci, Co, H, W, ks, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        api = _lib.api()
+        x, w = ctx.saved_tensors
+        B, Ci, H, W = x.shape
+        Co, _, ks, _ = w.shape
+        gy = _f32c(gy)
+        gin = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w)
+        gb = torch.empty(Co, dtype=torch.float32, device=x.device) if ctx.has_b else None
+        ws = _bytes(api.size("cfd_conv2d_bwd_workspace_bytes", B, Ci, Co, H, W, ks), x.device)
+        api.call("cfd_conv2d_zeropad_bwd", _ptr(gy), _ptr(x), _ptr(w), _ptr(gin), _ptr(gw), _ptr(gb), _ptr(ws), B, Ci, Co, H, W, ks, _stream())
+        return gin, gw, gb
+
+
 class ConvBnReluFn(torch.autograd.Function):
     """[ReLU](BatchNorm2d(Conv2d(x))) in TRAINING mode (unet.py:20-30) as one autograd node: where the conv kernel can emit the
     per-channel partial sums of its output (cfd_conv2d_fwd_stats), the BatchNorm takes its batch statistics from them and runs as

@@ -22,7 +22,10 @@ from .loss import MseLoss
 
 
 def zero_padded_conv(x: Tensor, conv: nn.Conv2d) -> Tensor:
-    """nn.Conv2d(k, padding=k//2) (zero padding) through the replicate-padding implicit-GEMM kernel."""
+    """nn.Conv2d(k, padding=k//2) (zero padding): on the zero-padding form of the implicit-GEMM kernels where they take the shape
+    (functional.Conv2dZeroPadFn, round 4), else through the replicate-padding kernel on a zero-padded input, cropped."""
+    if F_.Conv2dZeroPadFn.supported(x, conv.weight):
+        return F_.Conv2dZeroPadFn.apply(x, conv.weight, conv.bias)
     p = conv.kernel_size[0] // 2
     y = F_.Conv2dReplicateFn.apply(torch.nn.functional.pad(x, (p, p, p, p)), conv.weight, conv.bias)
     return y[:, :, p:-p, p:-p]

@@ -341,6 +341,14 @@ int cfd_conv2d_bwd(const float* gout, const float* in, const float* w, float* gi
                    int Ci, int Co, int H, int W, int ks, void* stream);
 int cfd_conv2d_bwd_ex(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws,
                       const void* wfrag_t, int B, int Ci, int Co, int H, int W, int ks, void* stream);
+/* nn.Conv2d(k, padding = k / 2) with ZERO padding (the CNN branch of src/models/auto_deeponet_cnn.py:17-33), k = 3 / 5 / 7, for the
+ * shapes cfd_conv2d_zeropad_supported() accepts (others: zero-pad the input by k / 2, run cfd_conv2d_fwd on the larger grid, crop).
+ * ws: cfd_conv2d_fwd_workspace_bytes() / cfd_conv2d_bwd_workspace_bytes() of the same shape. */
+int cfd_conv2d_zeropad_supported(int B, int Ci, int Co, int H, int W, int ks);
+int cfd_conv2d_zeropad_fwd(const float* in, const float* w, const float* bias, float* out, void* ws, int B, int Ci, int Co, int H, int W,
+                           int ks, void* stream);
+int cfd_conv2d_zeropad_bwd(const float* gout, const float* in, const float* w, float* gin, float* gw, float* gb, void* ws, int B,
+                           int Ci, int Co, int H, int W, int ks, void* stream);
 
 /* y = [relu](nn.BatchNorm2d(x)) (unet.py:28-30).  training: batch statistics, saved in save_mean / save_rstd for the
  * backward pass, running_mean / running_var updated in place (momentum; unbiased variance) when non-NULL;

@@ -760,6 +760,35 @@ def check_conv2d(be, B, Ci, Co, H, W, ks, seed=31):
     return res
 
 
+def check_conv2d_zeropad(be, B, Ci, Co, H, W, ks, seed=41):
+    """cfd_conv2d_zeropad_fwd / _bwd (nn.Conv2d's default zero padding on the conv6 kernels) against the fp64 oracle: the oracle's
+    replicate-padded convolution of the input zero-padded by k / 2, cropped -- the construction the model used before -- and its
+    reverse pass (gradient of the crop = zero-padding the upstream gradient; gradient of the pad = cropping)."""
+    from oracle import conv_oracle as CO
+    api, P = be.api, be.ptr
+    if api.size("cfd_conv2d_zeropad_supported", B, Ci, Co, H, W, ks) != 1:
+        return None  # (the caller zero-pads and crops around the replicate kernel: models/auto_deeponet_cnn.py)
+    rng = np.random.default_rng(seed)
+    p = ks // 2
+    x = rng.standard_normal((B, Ci, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, ks, ks)) / np.sqrt(Ci * ks * ks)).astype(np.float32)
+    b = rng.standard_normal((Co,)).astype(np.float32) * 0.2
+    g = rng.standard_normal((B, Co, H, W)).astype(np.float32)
+    dx, dw, db, dg = be.dev(x), be.dev(w), be.dev(b), be.dev(g)
+    out = be.zeros((B, Co, H, W))
+    fws = be.bytes(api.size("cfd_conv2d_fwd_workspace_bytes", B, Ci, Co, H, W, ks))
+    api.call("cfd_conv2d_zeropad_fwd", P(dx), P(dw), P(db), P(out), P(fws), B, Ci, Co, H, W, ks, be.stream)
+    ws = be.bytes(api.size("cfd_conv2d_bwd_workspace_bytes", B, Ci, Co, H, W, ks))
+    gin, gw, gb = be.zeros((B, Ci, H, W)), be.zeros((Co, Ci, ks, ks)), be.zeros((Co,))
+    api.call("cfd_conv2d_zeropad_bwd", P(dg), P(dx), P(dw), P(gin), P(gw), P(gb), P(ws), B, Ci, Co, H, W, ks, be.stream)
+    be.sync()
+    pad4 = ((0, 0), (0, 0), (p, p), (p, p))
+    xp, gp = np.pad(x.astype(f64), pad4), np.pad(g.astype(f64), pad4)
+    ref = CO.conv2d(xp, w.astype(f64), b.astype(f64))[:, :, p:-p, p:-p]
+    rgx, rgw, rgb = CO.conv2d_bwd(gp, xp, w.astype(f64))
+    return {"out": nm(be.host(out), ref), "gin": nm(be.host(gin), rgx[:, :, p:-p, p:-p]), "gw": nm(be.host(gw), rgw), "gb": nm(be.host(gb), rgb)}
+
+
 def check_conv_prepared(be, layers, seed=37):
     """cfd_conv2d_wprep_batch + cfd_conv2d_fwd_ex / cfd_conv2d_bwd_ex: the fragments of ALL `layers` = [(B, Ci, Co, H, W, ks), ...]
     made by one call (forward and input-gradient forms interleaved), then every layer run with them -- must equal the calls that

@@ -221,6 +221,13 @@ def test_conv_emits_batchnorm_statistics(be, B, Ci, Co, H, W, ks):
     _assert_all(res)
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(2, 5, 8, 9, 10, 5), (3, 8, 7, 6, 5, 3), (2, 3, 8, 8, 9, 7), (20, 12, 12, 16, 16, 3)])
+def test_conv2d_zero_padding(be, B, Ci, Co, H, W, ks):
+    """(one channel chunk per pass: with the emulator build's two persistent workgroups a second chunk would be split over workgroups,
+    which the zero-padding route does not take -- cfd_conv2d_zeropad_supported)"""
+    _assert_all(K.check_conv2d_zeropad(be, B, Ci, Co, H, W, ks))
+
+
 def test_conv_weights_prepared_in_one_batch(be):
     """fragments of several layers (k = 3, 5 and 7, narrow and wide, forward and input-gradient forms) made by one
     cfd_conv2d_wprep_batch launch: the layers then compute bit for bit what they compute preparing their own"""

@@ -276,6 +276,16 @@ def test_conv_emits_batchnorm_statistics(be, grid, B, Ci, Co, H, W, ks):
     _assert_all(res)
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(32, 8, 32, 64, 64, 5), (32, 32, 32, 32, 32, 5), (8, 32, 32, 4, 4, 5), (3, 11, 12, 33, 32, 3), (2, 16, 64, 20, 21, 7)])
+def test_conv2d_zero_padding(be, B, Ci, Co, H, W, ks):
+    res = K.check_conv2d_zeropad(be, B, Ci, Co, H, W, ks)
+    if res is None:  # few pixel tiles: the input-gradient pass would split its channel chunks over workgroups -- route not taken
+        assert (B, H) != (32, 64) and (B, H) != (3, 33)  # (the branch's first layers and a mid-size k = 3 layer must be covered)
+        assert be.api.size("cfd_conv2d_zeropad_supported", B, Ci, Co, H, W, ks) == 0
+    else:
+        _assert_all(res)
+
+
 def test_conv_weights_prepared_in_one_batch(be):
     """cfd_conv2d_wprep_batch: the fragments of all 18 3x3 layers of the configs[2] U-Net (both forms) and of ResNet's 7x7 layers
     from single launches; every layer then computes bit for bit what it computes preparing its own weights."""
