@@ -22,6 +22,8 @@ struct GemmEpi {
     const int* qidx;
     int ldr;
     const float* gz_z;    // mode 3: pre-activations (gelu / swish), else NULL
+    int ones1;            // != 0: column ones1 - 1 of C is VIRTUAL -- opB has a row of ones there (the column sums of opA^T: a Linear layer's
+    float* out2;          //       bias gradient rides in its weight-gradient product) -- and goes to out2[m] instead of C (ldc = N - 1)
 };
 
 __device__ __forceinline__ float cfd_act(float z, int act) {
@@ -59,7 +61,9 @@ struct SlabRegs {
     static constexpr int LD = KCONT ? 24 : ROWS + 4;
     static constexpr int FLOATS = KCONT ? ROWS * 24 : GK * (ROWS + 4);
     f32x4 v[NR];
-    __device__ __forceinline__ void load(const float* __restrict__ X, int ld, int rows, int K, int row0, int k0, int tid, bool vec) {
+    // ones: index of a virtual row of ones behind the matrix' rows (rows <= ones), or -1
+    __device__ __forceinline__ void load(const float* __restrict__ X, int ld, int rows, int K, int row0, int k0, int tid, bool vec,
+                                         int ones = -1) {
         // resource from the slab's first element to the last element of the matrix (clamped to 2^31 bytes: lane offsets stay below
         // ROWS * ld * 4, launch_gemm bounds ld)
         const float* base = KCONT ? X + (size_t)row0 * ld + k0 : X + (size_t)k0 * ld + row0;
@@ -79,6 +83,14 @@ struct SlabRegs {
                 const int left = KCONT ? K - (k0 + c) : rows - (row0 + r);  // elements of the unit inside the matrix
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[h][j] = cfd_buf_ld(bf, ok && j < left ? off + 4u * j : CFD_BUF_OOB, 0);
+            }
+            if constexpr (!KCONT) {
+                if (ones >= 0) {  // (uniform)
+                    const float one = k0 + c < K ? 1.f : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (row0 + r + j == ones) v[h][j] = one;
+                }
             }
         }
     }
@@ -118,7 +130,7 @@ struct SlabRegs {
 // K in slabs of 16 through a three-deep pipeline: while slab s is on the matrix pipe, slab s + 1 -- loaded during slab s - 1 -- goes
 // from registers to the other LDS buffer (the stores are issued in front of the MFMAs and complete beside them) and slab s + 2 is
 // on its way from memory; one barrier per slab.
-template <bool AT, bool BT, int WGM, int WTM, int WTN, int NW = 4>
+template <bool AT, bool BT, int WGM, int WTM, int WTN, int NW = 4, bool ONES = false>
 __global__ __launch_bounds__(64 * NW, 2) void k_gemm(const float* __restrict__ A, const float* __restrict__ B,
                                                  float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
                                                  GemmEpi epi, int slabs_per_split, int nbx, int nby, int nbz) {
@@ -157,14 +169,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm(const float* __restrict__ A
     const int s0 = bz * slabs_per_split;
     const int nslab = (s0 + slabs_per_split < nslab_all ? s0 + slabs_per_split : nslab_all) - s0;
     C += (size_t)bz * M * ldc;
-    const bool va = ((AT ? M : K) & 3) == 0, vb = ((BT ? K : N) & 3) == 0;  // (uniform) 16-byte units never straddle a row end
+    // the virtual column of C / row of ones of opB: its own instantiation (ONES) -- the patch in the operand loader costs registers,
+    // and this kernel lives on its five to seven blocks per CU
+    const int ones = ONES ? epi.ones1 - 1 : -1;
+    const int Nb = ones >= 0 ? N - 1 : N;      // opB's real extent
+    const bool va = ((AT ? M : K) & 3) == 0, vb = ((BT ? K : Nb) & 3) == 0;  // (uniform) 16-byte units never straddle a row end
     RA ra0, ra1;
     RB rb0, rb1;
     const bool stager = NW == 4 || tid < 256;  // (wave-uniform)
     const auto load = [&](RA& ra, RB& rb, int slab) {
         if (!stager) return;
         ra.load(A, lda, M, K, m0, (s0 + slab) * GK, tid, va);
-        rb.load(B, ldb, N, K, n0, (s0 + slab) * GK, tid, vb);
+        rb.load(B, ldb, Nb, K, n0, (s0 + slab) * GK, tid, vb, ones);
     };
     const auto commit = [&](const RA& ra, const RB& rb, int buf) {
         if (!stager) return;
@@ -226,7 +242,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm(const float* __restrict__ A
                         const size_t o = (size_t)row * epi.ldr + col;
                         v *= cfd_act_grad(epi.resid[o], epi.gz_z ? epi.gz_z[o] : 0.f, epi.act);
                     }
-                    C[(size_t)row * ldc + col] = v;
+                    if (ONES && epi.out2 && col == epi.ones1 - 1) epi.out2[row] = v;  // (split-K partials keep the column: out2 == NULL)
+                    else C[(size_t)row * ldc + col] = v;
                 }
             }
         }
@@ -261,7 +278,8 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
             const size_t o = (size_t)row * epi.ldr + col;
             v *= cfd_act_grad(epi.resid[o], epi.gz_z ? epi.gz_z[o] : 0.f, epi.act);
         }
-        C[(size_t)row * ldc + col] = v;
+        if (epi.out2 && col == epi.ones1 - 1) epi.out2[row] = v;
+        else C[(size_t)row * ldc + col] = v;
     }
 }
 
@@ -314,6 +332,7 @@ static int launch_gemm(const float* A, const float* B, float* C, int M, int N, i
     CFD_REQUIRE(nblocks < (1L << 31), CFD_ERR_UNSUPPORTED, "%s: %ld blocks", what, nblocks);
     const dim3 grid((unsigned)nblocks);
     GemmEpi e0{};
+    e0.ones1 = epi.ones1;  // (the split kernels still load the row of ones; their partial tiles keep its column)
     const GemmEpi& ek = splits > 1 ? e0 : epi;
     float* Ck = splits > 1 ? (float*)ws : C;
     const int ldk = splits > 1 ? N : ldc;
@@ -339,7 +358,13 @@ static int launch_gemm(const float* A, const float* B, float* C, int M, int N, i
         else if (kind == 1) GEMM_K(AT_, BT_, 4, 2, 8, 4);    \
         else GEMM_K(AT_, BT_, 4, 2, 16, 4);                  \
     } while (0)
-        if (!at && !bt) GEMM_L(false, false);
+        if (ek.ones1) {  // (the weight-gradient form with its bias column: 64 x 64 blocks only)
+            CFD_REQUIRE(at && !bt && kind == 64, CFD_ERR_UNSUPPORTED, "%s: the ones column rides in the A^T B form on 64 x 64 blocks only", what);
+            constexpr size_t lds1 = 2 * sizeof(float) * (SlabRegs<false, 1>::FLOATS + SlabRegs<false, 1>::FLOATS);
+            hipLaunchKernelGGL((k_gemm<true, false, 2, 2, 2, 4, true>), grid, dim3(256), lds1, st, A, B, Ck, M, N, K, lda, ldb, ldk, ek, per, nbx,
+                               nby, splits);
+        }
+        else if (!at && !bt) GEMM_L(false, false);
         else if (!at && bt) GEMM_L(false, true);
         else if (at && !bt) GEMM_L(true, false);
         else GEMM_L(true, true);
@@ -510,8 +535,8 @@ static size_t colsum_ws_bytes(int M, int N) { return M >= 2048 ? cfd_align_up((s
 extern "C" size_t cfd_linear_bwd_workspace_bytes(int M, int K, int N) {
     if (M <= 0) return 0;
     const size_t gz = cfd_align_up((size_t)M * N * sizeof(float), 256);
-    const size_t a = gemm_ws_bytes(M, K, N), b = gemm_ws_bytes(N, K, M);  // input gradient, weight gradient
-    return gz + (a > b ? a : b) + colsum_ws_bytes(M, N);  // + the bias gradient's partial rows (behind the GEMM workspace)
+    const size_t a = gemm_ws_bytes(M, K, N), b = gemm_ws_bytes(N, K + 1, M);  // input gradient, weight gradient (+ the bias gradient's column)
+    return gz + (a > b ? a : b) + colsum_ws_bytes(M, N);  // (+ room for the stand-alone column sum's partial rows: rounds 3-4, kept in the size)
 }
 
 // gx (M,K) = gz w;  gw (N,K) = gz^T x;  gb (N) = column sums of gz;  gz = gy * act'.  gx / gb may be NULL.
@@ -558,10 +583,15 @@ static int linear_bwd(const float* gy, const float* x, const float* w, const flo
         if (in_act != 0) { ex.mode = 3; ex.act = in_act; ex.resid = x; ex.ldr = K; ex.gz_z = in_preact; }
         CFD_TRY(launch_gemm(gz, w, gx, M, K, N, N, K, K, 0, 0, ex, skws, st, "cfd_linear_bwd(gx)"));
     }
-    CFD_TRY(launch_gemm(gz, x, gw, N, K, M, N, K, K, 1, 0, epi, skws, st, "cfd_linear_bwd(gw)"));
-    if (gb) {
+    // gw = gz^T x, and gb = gz^T 1 as one more column of the same product (a row of ones behind x's K columns): no separate pass
+    // over gz for the bias gradient (k_colsum_part + k_colsum_final: 38 us per 256 k x 100 layer)
+    GemmEpi ew{};
+    const bool gb_rides = gb && (K % 64) != 0 && cfd_tune_get(CFD_TUNE_GEMM_TILE) <= 0;  // (K a multiple of 64: the column would add a column block)
+    if (gb_rides) { ew.ones1 = K + 1; ew.out2 = gb; }
+    CFD_TRY(launch_gemm(gz, x, gw, N, gb_rides ? K + 1 : K, M, N, K, K, 1, 0, ew, skws, st, "cfd_linear_bwd(gw)"));
+    if (gb && !gb_rides) {
         if (colsum_ws_bytes(M, N)) {
-            const size_t a = gemm_ws_bytes(M, K, N), b = gemm_ws_bytes(N, K, M);
+            const size_t a = gemm_ws_bytes(M, K, N), b = gemm_ws_bytes(N, K + 1, M);
             float* part = (float*)((char*)skws + (a > b ? a : b));
             const int nchunk = colsum_chunks(M), rpc = (M + nchunk - 1) / nchunk;
             CFD_PROF_W("k_colsum", st, 4.0 * M * (double)N, (double)M * N);
