@@ -189,11 +189,19 @@ __global__ __launch_bounds__(256, 2) void k_ffn_stack_fwd(const FfnStackSet set,
         fs_wcommit(sW, FS_LD, Dout, Din, wr);
         __syncthreads();
         if (l + 1 < st.L) fs_wfetch(st.w[l + 1], st.dims[l + 2], st.dims[l + 1], wr);  // in flight during this layer's MFMAs
+        // (the bias values of this lane's two column tiles are requested BEFORE the MFMAs: loaded in the epilogue they cost one exposed
+        // L2 latency per layer of a kernel that is a chain of such latencies)
+        const float* bias = st.b[l];
+        float bvs[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int col = 16 * (wave + 4 * h) + n;
+            bvs[h] = (bias && col < Dout) ? bias[col] : 0.f;
+        }
         f32x4 acc[2];
         fs_tile_gemm(sA[cur], sW, FS_LD, NG, NT, wave, q, n, acc);
         // epilogue: bias, activation, store what backward needs, the tile's next input into the other sA buffer
         const bool do_act = st.act != 0 && (l + 1 < st.L || st.act_last);
-        const float* bias = st.b[l];
         float* yl = st.y[l];
         float* zl = st.z[l];
         float* sN = sA[cur ^ 1];
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void k_ffn_stack_fwd(const FfnStackSet set,
             const int t = wave + 4 * h;
             if (t < NT) {
                 const int col = 16 * t + n;
-                const float bv = (bias && col < Dout) ? bias[col] : 0.f;
+                const float bv = bvs[h];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int lr = 4 * q + r, row = row0 + lr;
@@ -266,13 +274,27 @@ __global__ __launch_bounds__(256, 2) void k_ffn_stack_bwd_chain(const FfnStackSe
             const float* yl = st.y[l];
             const float* zl = st.z[l];
             float* dz = bw.dz[l];
-            for (int cc = c; cc < Dp; cc += 16) {
-                float v = g[cc];
-                if (row0 + r < R && cc < Dout) {
-                    const size_t o = (size_t)(row0 + r) * Dout + cc;
-                    if (do_act) v *= fs_act_grad(yl[o], zl ? zl[o] : 0.f, st.act);
-                    dz[o] = v;
-                    g[cc] = v;
+            // all of a thread's y / z values are requested before the first is used (one element per trip: up to eight exposed L2
+            // latencies per layer -- the largest single term of this kernel's time); widths <= 128: eight columns per thread
+            float yv[FS_MAXD / 16], zv[FS_MAXD / 16];
+            const bool rowok = row0 + r < R;
+            const size_t ro = (size_t)(rowok ? row0 + r : 0) * Dout;
+#pragma unroll
+            for (int u = 0; u < FS_MAXD / 16; ++u) {
+                const int cc = c + 16 * u, ccl = cc < Dout ? cc : 0;
+                yv[u] = do_act ? yl[ro + ccl] : 0.f;
+                zv[u] = (do_act && zl) ? zl[ro + ccl] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < FS_MAXD / 16; ++u) {
+                const int cc = c + 16 * u;
+                if (cc < Dp) {
+                    float v = g[cc];
+                    if (rowok && cc < Dout) {
+                        if (do_act) v *= fs_act_grad(yv[u], zv[u], st.act);
+                        dz[ro + cc] = v;
+                        g[cc] = v;
+                    }
                 }
             }
         }
