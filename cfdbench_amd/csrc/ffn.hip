@@ -12,6 +12,18 @@
 // safe on split-bf16 products: DESIGN.md section 4), k-ordered fma chains like the stand-alone GEMM (dense.hip).
 #include "cfd_common.h"
 
+#ifdef CFD_FSDIAG  // experiment builds only (tools/build_variant.sh fsdiag ffn.hip -DCFD_FSDIAG, tools/exp/fs_diag.py): s_memtime stamps of
+                   // the LAST workgroup's wave 0 at the phase boundaries of every layer of k_ffn_stack_fwd
+__device__ unsigned long long fs_ts[256];
+extern "C" int cfd_dbg_fs_read(unsigned long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fs_ts), (size_t)n * 8); }
+#define FS_TS(l, slot)                                                                                      \
+    do {                                                                                                    \
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && (l) < 16) fs_ts[(l) * 8 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define FS_TS(l, slot) do { } while (0)
+#endif
+
 #define FS_MAXL 16    // layers per stack
 #define FS_MAXD 128   // widest layer
 #define FS_ROWS 16    // rows per workgroup: one MFMA row tile; the four waves split the output column tiles
@@ -63,24 +75,28 @@ __device__ __forceinline__ float fs_act_grad(float y, float z, int act) {
 // Rows / columns up to the next multiple of 16 are written as zeros: they are MFMA padding.
 #define FS_WROWS (FS_MAXD / 8)
 struct FsWRegs { float4 v[FS_WROWS]; };
+// Raw buffer loads: rows / columns outside the matrix carry the out-of-range offset and come back as zeros.  (Written as `if (inside)
+// load`, each of a thread's 16 loads sat in its own branch with a wait behind it: the phase stamps of k_ffn_stack_fwd showed 3.2-5.7 k
+// cycles for ISSUING one layer's weight loads where the loads were meant to fly beside the MFMAs; 1.6-3.4 k now:
+// tools/exp/fs_diag.py, profiles/r04i_ffn_stack_phases.txt.)
 __device__ __forceinline__ void fs_wfetch(const float* __restrict__ w, int Dout, int Din, FsWRegs& r) {
     const int tj = threadIdx.x >> 5, c0 = 4 * (threadIdx.x & 31);
-    const bool vec = (Din & 3) == 0 && ((uintptr_t)w & 15) == 0;
+    const bool vec = (Din & 3) == 0;  // (uniform) a 16-byte unit never straddles a row end
+    const CfdBuf bf = cfd_buf(w, 4u * (unsigned)(Dout * Din));
 #pragma unroll
     for (int k = 0; k < FS_WROWS; ++k) {
         const int j = tj + 8 * k;
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < Dout && c0 < Din) {
-            const float* p = w + (size_t)j * Din + c0;
-            if (vec) t = *reinterpret_cast<const float4*>(p);
-            else {
-                t.x = p[0];
-                if (c0 + 1 < Din) t.y = p[1];
-                if (c0 + 2 < Din) t.z = p[2];
-                if (c0 + 3 < Din) t.w = p[3];
-            }
+        const bool ok = j < Dout && c0 < Din;
+        const unsigned off = 4u * (unsigned)(j * Din + c0);
+        if (vec) {
+            const f32x4 t = cfd_buf_ld4(bf, ok ? off : CFD_BUF_OOB, 0);
+            r.v[k] = make_float4(t[0], t[1], t[2], t[3]);
+        } else {
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = cfd_buf_ld(bf, ok && c0 + e < Din ? off + 4u * e : CFD_BUF_OOB, 0);
+            r.v[k] = make_float4(t[0], t[1], t[2], t[3]);
         }
-        r.v[k] = t;
     }
 }
 __device__ __forceinline__ void fs_wcommit(float* __restrict__ sW, int FS_LD, int Dout, int Din, const FsWRegs& r) {
@@ -185,10 +201,15 @@ __global__ __launch_bounds__(256, 2) void k_ffn_stack_fwd(const FfnStackSet set,
     for (int l = 0; l < st.L; ++l, cur ^= 1) {
         const int Din = st.dims[l], Dout = st.dims[l + 1];
         const int NG = (Din + 15) >> 4, NT = (Dout + 15) >> 4;
+        FS_TS(l, 0);
         __syncthreads();  // every wave is done with W_{l-1} and has written its columns of sA[cur]
+        FS_TS(l, 1);
         fs_wcommit(sW, FS_LD, Dout, Din, wr);
+        FS_TS(l, 2);
         __syncthreads();
+        FS_TS(l, 3);
         if (l + 1 < st.L) fs_wfetch(st.w[l + 1], st.dims[l + 2], st.dims[l + 1], wr);  // in flight during this layer's MFMAs
+        FS_TS(l, 4);
         // (the bias values of this lane's two column tiles are requested BEFORE the MFMAs: loaded in the epilogue they cost one exposed
         // L2 latency per layer of a kernel that is a chain of such latencies)
         const float* bias = st.b[l];
@@ -200,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void k_ffn_stack_fwd(const FfnStackSet set,
         }
         f32x4 acc[2];
         fs_tile_gemm(sA[cur], sW, FS_LD, NG, NT, wave, q, n, acc);
+        FS_TS(l, 5);
         // epilogue: bias, activation, store what backward needs, the tile's next input into the other sA buffer
         const bool do_act = st.act != 0 && (l + 1 < st.L || st.act_last);
         float* yl = st.y[l];
