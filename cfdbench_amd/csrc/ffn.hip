@@ -14,7 +14,7 @@
 
 #ifdef CFD_FSDIAG  // experiment builds only (tools/build_variant.sh fsdiag ffn.hip -DCFD_FSDIAG, tools/exp/fs_diag.py): s_memtime stamps of
                    // the LAST workgroup's wave 0 at the phase boundaries of every layer of k_ffn_stack_fwd
-__device__ unsigned long long fs_ts[256];
+__device__ unsigned long long fs_ts[256];  // [0..7][8]: forward, [8..15][8]: backward chain
 extern "C" int cfd_dbg_fs_read(unsigned long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fs_ts), (size_t)n * 8); }
 #define FS_TS(l, slot)                                                                                      \
     do {                                                                                                    \
@@ -284,32 +284,41 @@ __global__ __launch_bounds__(256, 2) void k_ffn_stack_bwd_chain(const FfnStackSe
     fs_wfetch(st.w[st.L - 1], st.dims[st.L], st.dims[st.L - 1], wr);
     fs_tile_load(gy, R, st.dims[st.L], row0, sG[0], FS_LD);
     int cur = 0;
+    // The y / z values a thread needs for dZ_l = G * act'(y_l, z_l) do not depend on the chain: they are requested one layer AHEAD (beside
+    // the weight loads, in flight during the previous layer's MFMAs) -- loaded inside the dZ pass, the pass took 4.3-5.8 k of a layer's
+    // ~15 k cycles (phase stamps, profiles/r04i_ffn_stack_phases.txt).  Thread (r, c): row r of the tile, columns c, c + 16, ...
+    float yv[FS_MAXD / 16], zv[FS_MAXD / 16];
+    const int dr = threadIdx.x >> 4, dc = threadIdx.x & 15;
+    const bool rowok = row0 + dr < R;
+    const auto yfetch = [&](int l) {
+        const int Dout = st.dims[l + 1];
+        const bool act_l = st.act != 0 && (l + 1 < st.L || st.act_last);
+        const float* yl = st.y[l];
+        const float* zl = st.z[l];
+        const size_t ro = (size_t)(rowok ? row0 + dr : 0) * Dout;
+#pragma unroll
+        for (int u = 0; u < FS_MAXD / 16; ++u) {
+            const int cc = dc + 16 * u, ccl = cc < Dout ? cc : 0;  // (clamped: unconditional loads)
+            yv[u] = act_l ? yl[ro + ccl] : 0.f;
+            zv[u] = (act_l && zl) ? zl[ro + ccl] : 0.f;
+        }
+    };
+    yfetch(st.L - 1);
     for (int l = st.L - 1; l >= 0; --l, cur ^= 1) {
         const int Din = st.dims[l], Dout = st.dims[l + 1];
         const bool do_act = st.act != 0 && (l + 1 < st.L || st.act_last);
         const bool need_g = l > 0 || gx != nullptr;
+        FS_TS(8 + (st.L - 1 - l), 0);  // (rows 8.. of the stamp table: the chain kernel, layers in its own order)
         __syncthreads();  // sG[cur] is complete; every wave is done with W_{l+1}
+        FS_TS(8 + (st.L - 1 - l), 1);
         {   // dZ_l = G * act' in place (16 x 16 threads: one row, strided columns), stored for the weight-gradient kernel
-            const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
             const int Dp = (Dout + 15) & ~15;
-            float* g = sG[cur] + r * FS_LD;
-            const float* yl = st.y[l];
-            const float* zl = st.z[l];
+            float* g = sG[cur] + dr * FS_LD;
             float* dz = bw.dz[l];
-            // all of a thread's y / z values are requested before the first is used (one element per trip: up to eight exposed L2
-            // latencies per layer -- the largest single term of this kernel's time); widths <= 128: eight columns per thread
-            float yv[FS_MAXD / 16], zv[FS_MAXD / 16];
-            const bool rowok = row0 + r < R;
-            const size_t ro = (size_t)(rowok ? row0 + r : 0) * Dout;
+            const size_t ro = (size_t)(rowok ? row0 + dr : 0) * Dout;
 #pragma unroll
             for (int u = 0; u < FS_MAXD / 16; ++u) {
-                const int cc = c + 16 * u, ccl = cc < Dout ? cc : 0;
-                yv[u] = do_act ? yl[ro + ccl] : 0.f;
-                zv[u] = (do_act && zl) ? zl[ro + ccl] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < FS_MAXD / 16; ++u) {
-                const int cc = c + 16 * u;
+                const int cc = dc + 16 * u;
                 if (cc < Dp) {
                     float v = g[cc];
                     if (rowok && cc < Dout) {
@@ -320,14 +329,21 @@ __global__ __launch_bounds__(256, 2) void k_ffn_stack_bwd_chain(const FfnStackSe
                 }
             }
         }
+        FS_TS(8 + (st.L - 1 - l), 2);
         if (need_g) fs_wcommit(sW, FS_LD, Dout, Din, wr);  // sW[j][i] = W[j][i], 16-byte stores (fs_tile_gemm_t reads it transposed)
+        FS_TS(8 + (st.L - 1 - l), 3);
         __syncthreads();
-        if (l > 0) fs_wfetch(st.w[l - 1], st.dims[l], st.dims[l - 1], wr);
+        if (l > 0) {
+            fs_wfetch(st.w[l - 1], st.dims[l], st.dims[l - 1], wr);
+            yfetch(l - 1);  // (this layer's values were consumed by the dZ pass above)
+        }
+        FS_TS(8 + (st.L - 1 - l), 4);
         if (!need_g) break;
         // G_{l-1}[row][i] = sum_j dZ[row][j] W[j][i]: operand rows of sW are the output columns i, K = j
         const int NG = (Dout + 15) >> 4, NT = (Din + 15) >> 4;
         f32x4 acc[2];
         fs_tile_gemm_t(sG[cur], sW, FS_LD, NG, NT, wave, q, n, acc);
+        FS_TS(8 + (st.L - 1 - l), 5);
         float* sN = sG[cur ^ 1];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {

@@ -16,9 +16,11 @@ ws = [torch.randn(dims[l + 1], dims[l], device="cuda") / dims[l] ** 0.5 for l in
 bs = [torch.zeros(dims[l + 1], device="cuda") for l in range(L)]
 x = torch.randn(R, 2, device="cuda")
 xb = torch.randn(512, wdt, device="cuda")
+for w in ws:
+    w.requires_grad_(True)
 for _ in range(3):
-    with torch.no_grad():
-        F_.ffn_stacks([(xb, ws[1:], bs[1:], "relu", False), (x, ws, bs, "relu", False)])
+    yb, yt = F_.ffn_stacks([(xb, ws[1:], bs[1:], "relu", False), (x, ws, bs, "relu", False)])
+    (yb.sum() + yt.sum()).backward()
 torch.cuda.synchronize()
 lib = ctypes.CDLL(str(_lib._LIB_PATH))
 buf = (ctypes.c_ulonglong * 128)()
@@ -30,3 +32,10 @@ for l in range(L):
     nxt = ts[l + 1, 0] - ts[l, 5] if l + 1 < L else 0
     print(l, dict(zip(names, d.tolist())), "epilogue->next", int(nxt))
 print("total cycles", int(ts[L - 1, 5] - ts[0, 0]))
+names2 = ["barrier1", "dZ pass", "commit", "barrier2+fetch_issue", "gemm_t"]
+print("backward chain (layers L-1 .. 0):")
+for l in range(L):
+    d = np.diff(ts[8 + l, :6])
+    nxt = ts[8 + l + 1, 0] - ts[8 + l, 5] if l + 1 < L else 0
+    print(l, dict(zip(names2, d.tolist())), "epilogue->next", int(nxt))
+print("total cycles", int(ts[8 + L - 1, 5] - ts[8, 0]))
