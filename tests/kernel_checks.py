@@ -1055,6 +1055,33 @@ def check_dropout_gelu(be, n, p, seed=5):
     return bad, nm(be.host(y1), ref)
 
 
+def check_dropout_step(be, n, p, base, step, seed=7):
+    """cfd_dropout_gelu_fwd_step / _bwd_step (the stream's step counter in device memory, the seed formed by the kernel) against the
+    host-seeded calls with seed = splitmix64(base + step) & (2^48 - 1): the same values bit for bit.  Returns the number that differ."""
+    api, P = be.api, be.ptr
+
+    def mix64(v):
+        v &= 0xFFFFFFFFFFFFFFFF
+        v = ((v ^ (v >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        v = ((v ^ (v >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return v ^ (v >> 31)
+    rng = np.random.default_rng(seed)
+    x = (2.5 * rng.standard_normal(n)).astype(np.float32)
+    g = rng.standard_normal(n).astype(np.float32)
+    dx, dg = be.dev(x), be.dev(g)
+    dstep = be.dev(np.array([step], dtype=np.int64))
+    y1, gx1, y2, gx2 = (be.zeros((n,)) for _ in range(4))
+    host_seed = mix64(base + step) & 0xFFFFFFFFFFFF
+    api.call("cfd_dropout_gelu_fwd_step", P(dx), P(y1), n, p, base, P(dstep), be.stream)
+    api.call("cfd_dropout_gelu_bwd_step", P(dx), P(dg), P(gx1), n, p, base, P(dstep), be.stream)
+    api.call("cfd_dropout_gelu_fwd", P(dx), P(y2), n, p, host_seed, be.stream)
+    api.call("cfd_dropout_gelu_bwd", P(dx), P(dg), P(gx2), n, p, host_seed, be.stream)
+    be.sync()
+    kept = float(np.count_nonzero(be.host(y1))) / n
+    assert abs(kept - (1.0 - p)) < 0.05, kept
+    return int(np.count_nonzero(be.host(y1) != be.host(y2))) + int(np.count_nonzero(be.host(gx1) != be.host(gx2)))
+
+
 def check_loss_scores_bwd(be, seed=6):
     """cfd_loss_scores / cfd_loss_scores_bwd against the formulas of loss.py:27-35 and their derivatives in float64; returns the
     largest relative error over the scores and over d(score)/d(sums) for each score alone and for all four together."""

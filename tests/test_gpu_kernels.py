@@ -342,6 +342,12 @@ def test_loss_scores_and_their_gradient(be):
     assert K.check_loss_scores_bwd(be) < 1e-6
 
 
+@pytest.mark.parametrize("step", [0, 7, 123456789])
+def test_dropout_seed_formed_on_the_device(be, step):
+    """the dropout stream's step counter read from device memory gives the masks of the host-side seed formula (models/resnet.py)"""
+    assert K.check_dropout_step(be, 4 * 1031, 0.2, 0x1234567890ABCDEF, step) == 0
+
+
 @pytest.mark.parametrize("p", [0.0, 0.2])
 def test_dropout_gelu_one_pass(be, p):
     """gelu(dropout(x)) and its gradient in one pass each == the stand-alone passes bit for bit (p = 0: the plain GELU)"""
