@@ -512,3 +512,51 @@ def test_bench_launcher_reports_a_failed_rank():
     r, lines = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", timeout=300)
     assert r.returncode == 1 and not lines
     assert "no CPU fallback" in r.stderr
+
+
+def test_ffn_routes_its_layers_to_the_stack_and_chain_kernels():
+    """Host logic of models/ffn.py: which runs of Linear(+activation) layers go to the fused stack kernel (all widths <= 128), which to
+    the Linear-chain node (wider runs of >= 2 layers), which stay single calls -- the partition the DeepONet variants rely on."""
+    import torch
+    from cfdbench_amd.models.act_fn import get_act_fn
+    from cfdbench_amd.models.ffn import Ffn
+
+    def partition(dims, act_norm=False, act_on_output=False):
+        f = Ffn(dims, act_fn=get_act_fn("relu", act_norm), act_on_output=act_on_output)
+        mods, i, out = list(f.layers), 0, []
+        while i < len(mods):
+            run = f._fusable_run(mods, i)
+            if run is not None:
+                out.append(("stack", len(run[0])))
+                i = run[4]
+                continue
+            chain = f._chain_run(mods, i)
+            if chain is not None:
+                out.append(("chain", len(chain[0])))
+                i = chain[3]
+                continue
+            out.append(("single", 1))
+            i += 2 if i + 1 < len(mods) and not isinstance(mods[i + 1], torch.nn.Linear) else 1
+        return out
+
+    assert partition([4295] + [100] * 8) == [("single", 1), ("stack", 7)]         # Auto-DeepONet branch: a wide first layer, then the stack
+    assert partition([2] + [100] * 8) == [("stack", 8)]                            # its trunk
+    assert partition([4101] + [200] * 8 + [1]) == [("chain", 9)]                   # Auto-FFN: wider than the stack kernel takes
+    assert partition([512] * 3 + [1]) == [("chain", 3)]                            # the CNN variant's output FFN
+    assert partition([300, 300, 100, 100, 100]) == [("chain", 2), ("stack", 2)]    # the narrow tail of a wide run belongs to the stack kernel
+    assert partition([100, 100, 100], act_norm=True) == [("single", 1), ("single", 1)]  # NormAct: statistics over the sample, no fusion
+    assert partition([64, 1]) == [("single", 1)]
+
+
+def test_resnet_dropout_step_counter_is_training_state_not_a_checkpoint_key():
+    """The ResNet's dropout step counter (a non-persistent buffer since round 4: it follows .to(), GraphedTrainStep restores it, the
+    kernels read it on the device) stays out of the state_dict -- the reference's checkpoint keys -- and round-trips through the
+    harness's extra training state."""
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    from cfdbench_amd.models.resnet import ResNet
+    m = ResNet(2, 2, 3, loss_name_to_fn("nmse"), hidden_chan=4, num_blocks=1, kernel_size=7, padding=3)
+    assert not any("drop_step" in k for k in m.state_dict())
+    assert any(b is m._drop_step for b in m.buffers()) and not getattr(m, "graph_unsafe", False)
+    assert m.extra_train_state() == dict(train_steps=0)
+    m.load_extra_train_state(dict(train_steps=41))
+    assert m.extra_train_state() == dict(train_steps=41) and int(m._drop_step) == 41
