@@ -197,9 +197,10 @@ extern "C" size_t cfd_conv2d_fwd_workspace_bytes(int B, int Ci, int Co, int H, i
     return 0;
 }
 
-// The same forward, also emitting per-channel partial sums for the training-mode BatchNorm that follows the conv:
-// stats (Co, slots, 2) = sums of (out - bias) and (out - bias)^2 over disjoint pixel sets, slots = cfd_conv2d_fwd_stats_slots()
-// (0: this layer cannot emit them -- use cfd_conv2d_fwd and cfd_batchnorm_fwd).  cfd_batchnorm_fwd_stats consumes them.
+// The same forward, also emitting per-channel records for the training-mode BatchNorm that follows the conv:
+// stats (Co, slots, 4) = (m, m2, n, -) = mean of out - bias, sum of squared deviations from it and pixel count of each slot (disjoint
+// pixel sets), slots = cfd_conv2d_fwd_stats_slots() (0: this layer cannot emit them -- use cfd_conv2d_fwd and cfd_batchnorm_fwd).
+// cfd_batchnorm_fwd_stats consumes them.
 extern "C" int cfd_conv2d_fwd_stats_slots(int B, int Ci, int Co, int H, int W, int ks) {
     if (B <= 0 || Ci < 1 || Co < 1 || H < 1 || W < 1) return 0;
     const ConvGeom g{B, Ci, Co, H, W, ks};
@@ -227,7 +228,7 @@ extern "C" int cfd_conv2d_wprep_batch(int n, const float* const* w, void* const*
 }
 
 // ws: cfd_conv2d_fwd_workspace_bytes() bytes, or NULL (then k = 3 / 7 run on the exact-fp32 gather kernel of this file instead of
-// the three-piece bf16 kernels of conv6.hip).  stats: NULL or the (Co, slots, 2) partial sums above.  wfrag: NULL or the weights'
+// the three-piece bf16 kernels of conv6.hip).  stats: NULL or the (Co, slots, 4) records above.  wfrag: NULL or the weights'
 // forward fragments (cfd_conv2d_wprep_batch); ignored where the layer does not run on the fragment kernels.
 extern "C" int cfd_conv2d_fwd_ex(const float* in, const float* w, const float* bias, float* out, void* ws, float* stats,
                                  const void* wfrag, int B, int Ci, int Co, int H, int W, int ks, void* stream) {
@@ -834,6 +835,48 @@ __device__ __forceinline__ void bn_partials(const float* __restrict__ part, int 
     b = s_ab[1];
 }
 
+// Block sums of two per-thread values: wave sums, then the four waves in a fixed order through s_ab (10 floats).
+__device__ __forceinline__ void bn_block_sum2(float pa, float pb, float* s_ab, float& a, float& b) {
+    pa = cfd_wave_sum(pa);
+    pb = cfd_wave_sum(pb);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_ab[2 + 2 * wave] = pa; s_ab[3 + 2 * wave] = pb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ta = s_ab[2], tb = s_ab[3];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { ta += s_ab[2 + 2 * w]; tb += s_ab[3 + 2 * w]; }
+        s_ab[0] = ta;
+        s_ab[1] = tb;
+    }
+    __syncthreads();
+    a = s_ab[0];
+    b = s_ab[1];
+}
+
+// Mean and sum of squared deviations of channel c from per-slot records (m, m2, n, -) = mean of x - shift, sum of squared deviations
+// from it and element count of the slot (cfd_conv2d_fwd_stats).  Pairwise combination:
+//   mean - shift = sum_s n_s m_s / N;   sum (x - mean)^2 = sum_s [m2_s + n_s (m_s - (mean - shift))^2]
+// -- no difference of two large sums anywhere, whatever |mean| / std is.  Returns d = mean - shift and m2.
+__device__ __forceinline__ void bn_slot_stats(const float* __restrict__ rec, int c, float* s_ab, int nslots, float count, float& d,
+                                              float& m2) {
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(rec) + (size_t)c * nslots;
+    float t = 0.f, unused = 0.f;
+    for (int i = threadIdx.x; i < nslots; i += blockDim.x) {
+        const f32x4 v = r4[i];
+        t = fmaf(v[2], v[0], t);
+    }
+    float tot, z;
+    bn_block_sum2(t, unused, s_ab, tot, z);
+    d = tot / count;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nslots; i += blockDim.x) {
+        const f32x4 v = r4[i];
+        const float e = v[0] - d;
+        m += fmaf(v[2] * e, e, v[1]);
+    }
+    bn_block_sum2(m, unused, s_ab, m2, z);
+}
+
 // y = [relu]((x - mean) * rstd * gamma + beta) with the statistics finished in the same launch: workgroup (c, sp) sums the
 // channel's partial pairs of k_bn_partial<3> itself (training) or reads the running statistics (eval) and normalises slice sp
 // of the channel; slice 0 also writes save_mean / save_rstd and updates the running statistics.  (Round 2 had a one-workgroup
@@ -849,13 +892,17 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
     const int c = blockIdx.x, sp = blockIdx.y;
     float mu, rs;
     if (training) {
-        float a, b;
-        bn_partials(part, c, s_ab, a, b, nsplit);
-        const float d = a / count;
-        // the partials are sums of (x - K) and (x - K)^2; K = the channel's first element (k_bn_partial<3>) or, when the conv that
-        // produced x emitted them (cfd_conv2d_fwd_stats), its bias
-        mu = (kbase ? kbase[(size_t)c * kstride] : 0.f) + d;
-        float m2 = b - a * d;  // sum (x - mean)^2 = sum (x-K)^2 - n (mean-K)^2
+        float d, m2;
+        if (kstride == 0) {  // per-slot records of the conv that produced x (cfd_conv2d_fwd_stats); kbase = its bias
+            bn_slot_stats(part, c, s_ab, nsplit, count, d, m2);
+            mu = (kbase ? kbase[c] : 0.f) + d;
+        } else {  // sums of (x - K) and (x - K)^2, K = the channel's first element (k_bn_partial<3>)
+            float a, b;
+            bn_partials(part, c, s_ab, a, b, nsplit);
+            d = a / count;
+            mu = (kbase ? kbase[(size_t)c * kstride] : 0.f) + d;
+            m2 = b - a * d;  // sum (x - mean)^2 = sum (x-K)^2 - n (mean-K)^2
+        }
         m2 = m2 > 0.f ? m2 : 0.f;
         const float var = m2 / count;  // biased: what normalises (torch.nn.functional.batch_norm, training=True)
         rs = 1.0f / sqrtf(var + eps);
@@ -954,8 +1001,10 @@ extern "C" int cfd_batchnorm_fwd(const float* x, const float* gamma, const float
     return CFD_OK;
 }
 
-// Training-mode forward from partial sums that the producer of x emitted (cfd_conv2d_fwd_stats): stats (C, slots, 2) = sums of
-// (x - shift[c]) and its square over disjoint pixel sets (shift NULL: 0).  One launch; otherwise cfd_batchnorm_fwd(training = 1).
+// Training-mode forward from the records that the producer of x emitted (cfd_conv2d_fwd_stats): stats (C, slots, 4) = (m, m2,
+// n, -) = mean of x - shift[c], sum of squared deviations from it and element count of each slot (disjoint sets covering the channel;
+// shift NULL: 0).
+// One launch; otherwise cfd_batchnorm_fwd(training = 1).
 extern "C" int cfd_batchnorm_fwd_stats(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var,
                                        float* y, float* save_mean, float* save_rstd, const float* stats, int slots,
                                        const float* shift, int B, int C, int HW, float eps, float momentum, int relu, void* stream) {
@@ -966,7 +1015,7 @@ extern "C" int cfd_batchnorm_fwd_stats(const float* x, const float* gamma, const
     CFD_PROF_W("k_bn_apply", st, 8.0 * B * C * HW, 2.0 * B * C * HW);
     hipLaunchKernelGGL(k_bn_apply, dim3(C, bn_slices(B, C, HW)), dim3(256), 0, st, x, stats, gamma, beta, run_mean, run_var,
                        save_mean, save_rstd, y, B, C, HW, (float)((double)B * HW), eps, momentum, 1, relu, cfd_div_make((unsigned)HW),
-                       slots, shift, 1);
+                       slots, shift, 0);
     CFD_LAUNCH_CHECK("cfd_batchnorm_fwd_stats");
     return CFD_OK;
 }

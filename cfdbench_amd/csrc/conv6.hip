@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_conv6_wprep_batch(const WprepBatch b) {
 // LDS (all dynamic, 16-byte carve offsets): [3 piece planes of NB * LH * LW halo pixels x CC bf16 | weight fragments of this
 // chunk and output group KSTEPS * MT * 3 * 64 x 16 B | tap offsets KSTEPS * 4 ints]
 // ------------------------------------------------------------------------------------------------------
-template <int KS, int MT, int CC, bool EXT, int NI>
+template <int KS, int MT, int CC, bool EXT, int NI, bool ST = false>  // ST: the forward that also emits `stats` (k = 3, NI == 3)
 __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src, const u4* __restrict__ wfrag,
                                                   const float* __restrict__ bias, float* __restrict__ dst, ConvGeom g, ConvTile t,
                                                   int MTall, int ptiles, float* __restrict__ gin_direct,
@@ -273,9 +273,11 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
     // ~6 us per tile in the profile of the first version).
     f32x4 outv[MT][4];
     int out_tile = -1;
-    // forward with `stats`: per-channel sums of (out - bias) and (out - bias)^2 over this workgroup's pixels -- the BatchNorm that
-    // follows the conv takes its batch statistics from these partials (shift = the conv bias) instead of re-reading `out`
-    float st1[MT][4], st2[MT][4];
+    // forward with `stats`: per channel, each lane's running mean and sum of squared deviations of (out - bias) over its pixels
+    // (Welford's update: no fixed shift, so nothing cancels when |mean| >> std; the same two registers per channel as plain sums,
+    // plus the lane's pixel count) -- the BatchNorm that follows the conv takes its batch statistics from the merged records
+    // instead of re-reading `out`
+    float st1[MT][4], st2[MT][4], stn = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -326,12 +328,18 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
                     put(bdst, on && !direct ? 4u * (unsigned)(row0 * HWd + y * Wd + x) : CFD_BUF_OOB, HWd, tt, true);
             } else {
                 put(bdst, on ? 4u * (unsigned)(row0 * HWd + y * Wd + x) : CFD_BUF_OOB, HWd, tt, true);
-                if constexpr (NI == 3) {  // (the 5-item variants serve the small deep levels, which split their chunks)
-                    if (stats && on) {
+                if constexpr (ST) {
+                    if (on) {
+                        stn += 1.f;
+                        const float rn = cfd_rcpf(stn);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { st1[mt][r] += outv[mt][tt][r]; st2[mt][r] = fmaf(outv[mt][tt][r], outv[mt][tt][r], st2[mt][r]); }
+                            for (int r = 0; r < 4; ++r) {
+                                const float v = outv[mt][tt][r], d = v - st1[mt][r];
+                                st1[mt][r] = fmaf(d, rn, st1[mt][r]);
+                                st2[mt][r] = fmaf(d, v - st1[mt][r], st2[mt][r]);
+                            }
                     }
                 }
             }
@@ -393,30 +401,38 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
         }
     }
     if (out_tile >= 0) store_tile();
-    if constexpr (!EXT && NI == 3) {
-        if (stats) {  // (uniform) 16 pixel lanes -> one value per (wave, channel), then the four waves through LDS, fixed order
-            __syncthreads();
-            float* s_st = (float*)s_dyn;  // [wave][mt][q][r][2]
+    if constexpr (ST) {
+        {  // the 16 pixel lanes of a row group merge pairwise -> one record (mean, m2, pixels) per (channel, wave)
+            const size_t slot = 4 * (size_t)blockIdx.x + wave, nslots = 4 * (size_t)gridDim.x;
+            float cn = stn, w_hi[4], w_prod[4];  // per merge round: n_b / (n_a + n_b) and n_a n_b / (n_a + n_b), the same for every channel
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float nb = cfd_shfl_xor(cn, 1 << k), nn = cn + nb, rn = nn > 0.f ? 1.f / nn : 0.f;
+                w_hi[k] = nb * rn;
+                w_prod[k] = cn * nb * rn;
+                cn = nn;
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float a = st1[mt][r], c2 = st2[mt][r];
+                    float m = st1[mt][r], m2 = st2[mt][r];
 #pragma unroll
-                    for (int sh = 1; sh < 16; sh <<= 1) { a += cfd_shfl_xor(a, sh); c2 += cfd_shfl_xor(c2, sh); }
-                    if (n == 0) { s_st[(((wave * MT + mt) * 4 + q) * 4 + r) * 2] = a; s_st[(((wave * MT + mt) * 4 + q) * 4 + r) * 2 + 1] = c2; }
+                    for (int k = 0; k < 4; ++k) {
+                        // (both lanes of a pair compute the same merged values: each takes "its own" as a and the partner as b, and
+                        //  m_a + (m_b - m_a) n_b / n  ==  the partner's expression only up to rounding -- so the lower lane's result
+                        //  is the one both keep)
+                        const bool low = !((lane >> k) & 1);
+                        const float mo = cfd_shfl_xor(m, 1 << k), m2o = cfd_shfl_xor(m2, 1 << k);
+                        const float wo = cfd_shfl_xor(w_hi[k], 1 << k);
+                        const float ma = low ? m : mo, mb_ = low ? mo : m, wh = low ? w_hi[k] : wo;
+                        const float dl = mb_ - ma;
+                        m = fmaf(dl, wh, ma);
+                        m2 = (m2 + m2o) + dl * dl * w_prod[k];
+                    }
+                    const int c = 16 * (mb + mt) + 4 * q + r;
+                    if (n == 0 && c < Cm) *(f32x4*)(stats + ((size_t)c * nslots + slot) * 4) = f32x4{m, m2, cn, 0.f};
                 }
-            __syncthreads();
-            for (int e = threadIdx.x; e < MT * 16 * 2; e += blockDim.x) {
-                const int which = e & 1, ch = e >> 1, mt = ch >> 4, qr = ch & 15;
-                const int c = 16 * (mb + mt) + qr;
-                if (c < Cm) {
-                    float tot = 0.f;
-#pragma unroll
-                    for (int wv = 0; wv < 4; ++wv) tot += s_st[((wv * MT + mt) * 16 + qr) * 2 + which];
-                    stats[((size_t)c * gridDim.x + blockIdx.x) * 2 + which] = tot;
-                }
-            }
         }
     }
 }
@@ -530,18 +546,24 @@ template <int KS, int CC, bool EXT>
 static void conv6_launch(const Conv6Plan& P, const float* src, const u4* wfrag, const float* bias, float* dst, const ConvGeom& g,
                          float* gin_direct, float* stats, hipStream_t st) {
     const dim3 grid((unsigned)P.gx, P.mgroups, P.ksplit);
-#define C6_L(M_, N_)                                                                                                              \
+#define C6_L(M_, N_, S_)                                                                                                          \
     do {                                                                                                                          \
         static bool attr_set = false;                                                                                             \
         if (!attr_set) {                                                                                                          \
-            (void)hipFuncSetAttribute((const void*)k_conv6<KS, M_, CC, EXT, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+            (void)hipFuncSetAttribute((const void*)k_conv6<KS, M_, CC, EXT, N_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        hipLaunchKernelGGL((k_conv6<KS, M_, CC, EXT, N_>), grid, dim3(256), P.lds, st, src, wfrag, bias, dst, g, P.t, P.MTall,    \
+        hipLaunchKernelGGL((k_conv6<KS, M_, CC, EXT, N_, S_>), grid, dim3(256), P.lds, st, src, wfrag, bias, dst, g, P.t, P.MTall, \
                            (int)P.ptiles, gin_direct, stats);                                                                     \
     } while (0)
-    if (P.mtw == 1) { if (P.NI == 3) C6_L(1, 3); else C6_L(1, 5); }
-    else { if (P.NI == 3) C6_L(2, 3); else C6_L(2, 5); }
+    if constexpr (!EXT && KS == 3) {
+        if (stats) {  // (conv6_run: NI == 3, one pass)
+            if (P.mtw == 1) C6_L(1, 3, true); else C6_L(2, 3, true);
+            return;
+        }
+    }
+    if (P.mtw == 1) { if (P.NI == 3) C6_L(1, 3, false); else C6_L(1, 5, false); }
+    else { if (P.NI == 3) C6_L(2, 3, false); else C6_L(2, 5, false); }
 #undef C6_L
 }
 
@@ -564,7 +586,7 @@ static int conv6_run(const float* src, const float* w, const float* bias, float*
     float* gd = (EXT && gin && P.ksplit == 1 && g.H >= 3 && g.W >= 3) ? gin : nullptr;
     if (direct) *direct = gd != nullptr;
     if (EXT && g.zpad && !gd) return CFD_ERR_UNSUPPORTED;  // (zero padding has no fold pass: callers ask cfd_conv6_zeropad_covers first)
-    if (stats && (EXT || P.ksplit > 1 || P.NI != 3)) return CFD_ERR_UNSUPPORTED;  // (callers ask cfd_conv6_stats_slots first)
+    if (stats && (EXT || g.ks != 3 || P.ksplit > 1 || P.NI != 3)) return CFD_ERR_UNSUPPORTED;  // (callers ask cfd_conv6_stats_slots first)
     if (g.ks == 3) {
         if (P.CC == 8) conv6_launch<3, 8, EXT>(P, src, wfrag, bias, kdst, g, gd, stats, st);
         else conv6_launch<3, 16, EXT>(P, src, wfrag, bias, kdst, g, gd, stats, st);
@@ -627,7 +649,7 @@ int cfd_conv6_wprep_batch(int n, const float* const* w, void* const* wfrag, cons
 // this layer -- not a conv6 layer, or its channel chunks are split over workgroups)
 int cfd_conv6_stats_slots(const ConvGeom& g) {
     const Conv6Plan P = conv6_plan(g, false);
-    return (P.ok && P.ksplit == 1 && P.NI == 3) ? P.gx : 0;
+    return (P.ok && g.ks == 3 && P.ksplit == 1 && P.NI == 3) ? 4 * P.gx : 0;  // one record per wave of the launch
 }
 
 // ------------------------------------------------------------------------------------------------------

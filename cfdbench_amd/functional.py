@@ -891,7 +891,7 @@ class ConvBnReluFn(torch.autograd.Function):
         ws = _bytes(nws, x.device) if nws else None
         slots = api.size("cfd_conv2d_fwd_stats_slots", B, Ci, Co, H, W, ks) if ws is not None else 0
         if slots > 0:
-            stats = torch.empty((Co, slots, 2), dtype=torch.float32, device=x.device)
+            stats = torch.empty((Co, slots, 4), dtype=torch.float32, device=x.device)
             api.call("cfd_conv2d_fwd_ex", _ptr(x), _ptr(w), _ptr(b), _ptr(y0), _ptr(ws), _ptr(stats), _ptr(wfrag), B, Ci, Co, H, W, ks,
                      _stream())
             api.call("cfd_batchnorm_fwd_stats", _ptr(y0), _ptr(gamma), _ptr(beta), _ptr(run_mean), _ptr(run_var), _ptr(z), _ptr(sm),

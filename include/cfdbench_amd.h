@@ -315,8 +315,9 @@ int cfd_rowdot_bwd(const float* g, const float* branch, const float* trunk, floa
 size_t cfd_conv2d_fwd_workspace_bytes(int B, int Ci, int Co, int H, int W, int ks);
 int cfd_conv2d_fwd(const float* in, const float* w, const float* bias, float* out, void* ws, int B, int Ci, int Co, int H,
                    int W, int ks, void* stream);
-/* The same forward, also emitting per-channel partial sums for the training-mode BatchNorm that follows the conv (unet.py:20-30:
- * Conv2d -> BatchNorm2d): stats (Co, slots, 2) floats = sums of (out - bias) and (out - bias)^2 over disjoint pixel sets, slots =
+/* The same forward, also emitting per-channel records for the training-mode BatchNorm that follows the conv (unet.py:20-30:
+ * Conv2d -> BatchNorm2d): stats (Co, slots, 4) floats = (m, m2, n, -) = mean of out - bias, sum of squared deviations from it and
+ * pixel count of each slot (disjoint pixel sets; running-mean updates, so that nothing cancels when |mean| >> std), slots =
  * cfd_conv2d_fwd_stats_slots() (0: this layer cannot emit them).  Consumed by cfd_batchnorm_fwd_stats (one launch instead of the
  * statistics pass + the normalising pass).                                                                               */
 int cfd_conv2d_fwd_stats_slots(int B, int Ci, int Co, int H, int W, int ks);
@@ -357,7 +358,7 @@ size_t cfd_batchnorm_workspace_bytes(int C);
 int cfd_batchnorm_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float* y,
                       float* save_mean, float* save_rstd, void* ws, int B, int C, int HW, float eps, float momentum,
                       int training, int relu, void* stream);
-/* training-mode forward from the partial sums of cfd_conv2d_fwd_stats: stats (C, slots, 2), shift (C) = the conv bias or NULL */
+/* training-mode forward from the records of cfd_conv2d_fwd_stats: stats (C, slots, 4), shift (C) = the conv bias or NULL */
 int cfd_batchnorm_fwd_stats(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float* y,
                             float* save_mean, float* save_rstd, const float* stats, int slots, const float* shift, int B, int C,
                             int HW, float eps, float momentum, int relu, void* stream);

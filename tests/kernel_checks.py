@@ -823,7 +823,7 @@ def check_conv_prepared(be, layers, seed=37):
             assert nws > 0
             fws = be.bytes(nws)
             slots = api.size("cfd_conv2d_fwd_stats_slots", B, Ci, Co, H, W, ks)
-            stats = be.zeros((Co, max(slots, 1), 2))
+            stats = be.zeros((Co, max(slots, 1), 4))
             api.call("cfd_conv2d_fwd_ex", P(x), P(w), P(b), P(out), P(fws), P(stats) if slots > 0 else None,
                      P(fr[0]) if prepared else None, B, Ci, Co, H, W, ks, be.stream)
             ws = be.bytes(api.size("cfd_conv2d_bwd_workspace_bytes", B, Ci, Co, H, W, ks))
@@ -837,17 +837,20 @@ def check_conv_prepared(be, layers, seed=37):
     return bad
 
 
-def check_conv_bn_stats(be, B, Ci, Co, H, W, ks, relu=True, seed=36):
+def check_conv_bn_stats(be, B, Ci, Co, H, W, ks, relu=True, seed=36, offset=0.0, spread=1.0):
     """cfd_conv2d_fwd_stats + cfd_batchnorm_fwd_stats (the conv emits the BatchNorm's batch statistics) against the oracle's
-    conv -> training-mode BatchNorm; returns None when the layer cannot emit statistics."""
+    conv -> training-mode BatchNorm; returns None when the layer cannot emit statistics.  `offset` / `spread`: input = offset +
+    spread * noise under all-positive weights -- output channels whose mean is far from the bias and |mean| >> std."""
     from oracle import conv_oracle as CO
     api, P = be.api, be.ptr
     slots = api.size("cfd_conv2d_fwd_stats_slots", B, Ci, Co, H, W, ks)
     if slots <= 0:
         return None
     rng = np.random.default_rng(seed)
-    x = rng.standard_normal((B, Ci, H, W)).astype(np.float32)
+    x = (offset + spread * rng.standard_normal((B, Ci, H, W))).astype(np.float32)
     w = (rng.standard_normal((Co, Ci, ks, ks)) / np.sqrt(Ci * ks * ks)).astype(np.float32)
+    if offset != 0.0:
+        w = np.abs(w)
     b = (rng.standard_normal((Co,)) * 0.2 + 3.0 * rng.standard_normal((Co,))).astype(np.float32)  # |mean| >> std in some channels
     gamma = (1 + 0.3 * rng.standard_normal(Co)).astype(np.float32)
     beta = (0.2 * rng.standard_normal(Co)).astype(np.float32)
@@ -855,7 +858,7 @@ def check_conv_bn_stats(be, B, Ci, Co, H, W, ks, relu=True, seed=36):
     rv = (1 + rng.random(Co)).astype(np.float32)
     dx, dw, db, dga, dbe, drm, drv = be.dev(x), be.dev(w), be.dev(b), be.dev(gamma), be.dev(beta), be.dev(rm), be.dev(rv)
     out, y, sm, sr = be.zeros((B, Co, H, W)), be.zeros((B, Co, H, W)), be.zeros((Co,)), be.zeros((Co,))
-    stats = be.zeros((Co, slots, 2))
+    stats = be.zeros((Co, slots, 4))
     ws = be.bytes(api.size("cfd_conv2d_fwd_workspace_bytes", B, Ci, Co, H, W, ks))
     api.call("cfd_conv2d_fwd_stats", P(dx), P(dw), P(db), P(out), P(ws), P(stats), B, Ci, Co, H, W, ks, be.stream)
     api.call("cfd_batchnorm_fwd_stats", P(out), P(dga), P(dbe), P(drm), P(drv), P(y), P(sm), P(sr), P(stats), slots, P(db), B, Co,

@@ -212,13 +212,24 @@ def test_conv2d_replicate(be, B, Ci, Co, H, W, ks):
     _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, ks))
 
 
-@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(3, 12, 12, 64, 64, 3), (9, 5, 20, 9, 10, 3), (2, 8, 40, 20, 21, 7), (5, 12, 18, 16, 16, 3)])
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(3, 12, 12, 64, 64, 3), (9, 5, 20, 9, 10, 3), (2, 8, 40, 20, 21, 3), (5, 12, 18, 16, 16, 3)])
 def test_conv_emits_batchnorm_statistics(be, B, Ci, Co, H, W, ks):
     """conv forward with the statistics epilogue + the one-launch BatchNorm that consumes them (several tiles per workgroup)."""
     with K.tuned(be, conv6_grid=3):
         res = K.check_conv_bn_stats(be, B, Ci, Co, H, W, ks)
     assert res is not None
     _assert_all(res)
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(3, 12, 12, 64, 64, 3), (9, 5, 20, 9, 10, 3)])
+def test_conv_batchnorm_statistics_with_mean_far_from_bias(be, B, Ci, Co, H, W, ks):
+    """Output channels with |mean - bias| ~ 100 std: the statistics records carry a per-slot sample as their shift, so the variance
+    does not come out of a cancelling difference (with the bias as the only shift y missed by ~3e-4 relative here)."""
+    with K.tuned(be, conv6_grid=3):
+        res = K.check_conv_bn_stats(be, B, Ci, Co, H, W, ks, offset=5.0, spread=0.1)
+    assert res is not None
+    # (y itself is bounded by the fp32 rounding of `out`, ~1e-7 of a mean that is 100 std: nMSE ~1e-8 whatever the statistics do)
+    assert res["run_mean"] < 1e-10 and res["run_var"] < 1e-10 and res["out"] < 1e-10 and res["y"] < 1e-6, res
 
 
 @pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(2, 5, 8, 9, 10, 5), (3, 8, 7, 6, 5, 3), (2, 3, 8, 8, 9, 7), (20, 12, 12, 16, 16, 3)])

@@ -266,14 +266,24 @@ def test_conv2d_persistent_workgroups_walk_many_tiles(be, grid, B, Ci, Co, H, W,
         _assert_all(K.check_conv2d(be, B, Ci, Co, H, W, ks))
 
 
-@pytest.mark.parametrize("grid,B,Ci,Co,H,W,ks", [(-1, 128, 12, 12, 64, 64, 3), (4, 64, 24, 48, 32, 32, 3), (-1, 32, 8, 64, 64, 64, 7), (-1, 3, 5, 7, 9, 10, 3)])
+@pytest.mark.parametrize("grid,B,Ci,Co,H,W,ks", [(-1, 128, 12, 12, 64, 64, 3), (4, 64, 24, 48, 32, 32, 3), (-1, 32, 8, 64, 64, 64, 3), (-1, 3, 5, 7, 9, 10, 3)])
 def test_conv_emits_batchnorm_statistics(be, grid, B, Ci, Co, H, W, ks):
     """cfd_conv2d_fwd_stats + cfd_batchnorm_fwd_stats against the oracle's conv -> training-mode BatchNorm (running statistics
-    included), at a full-size U-Net layer, with few persistent workgroups, at 7x7 and at a tiny layer."""
+    included), at a full-size U-Net layer, with few persistent workgroups, at a wide layer and at a tiny one (k = 3: the kernel sizes the
+    reference follows with a BatchNorm, src/models/unet.py:20-30)."""
     with K.tuned(be, conv6_grid=grid):
         res = K.check_conv_bn_stats(be, B, Ci, Co, H, W, ks)
     assert res is not None
     _assert_all(res)
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(128, 12, 12, 64, 64, 3), (64, 24, 48, 32, 32, 3)])
+def test_conv_batchnorm_statistics_with_mean_far_from_bias(be, B, Ci, Co, H, W, ks):
+    """Output channels with |mean - bias| ~ 100 std: per-slot shifted records, no cancelling difference in the variance."""
+    res = K.check_conv_bn_stats(be, B, Ci, Co, H, W, ks, offset=5.0, spread=0.1)
+    assert res is not None
+    # (y itself is bounded by the fp32 rounding of `out`, ~1e-7 of a mean that is 100 std: nMSE ~1e-8 whatever the statistics do)
+    assert res["run_mean"] < 1e-10 and res["run_var"] < 1e-10 and res["out"] < 1e-10 and res["y"] < 1e-6, res
 
 
 @pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(32, 8, 32, 64, 64, 5), (32, 32, 32, 32, 32, 5), (8, 32, 32, 4, 4, 5), (3, 11, 12, 33, 32, 3), (2, 16, 64, 20, 21, 7)])
