@@ -854,27 +854,27 @@ __device__ __forceinline__ void bn_block_sum2(float pa, float pb, float* s_ab, f
 }
 
 // Mean and sum of squared deviations of channel c from per-slot records (m, m2, n, -) = mean of x - shift, sum of squared deviations
-// from it and element count of the slot (cfd_conv2d_fwd_stats).  Pairwise combination:
-//   mean - shift = sum_s n_s m_s / N;   sum (x - mean)^2 = sum_s [m2_s + n_s (m_s - (mean - shift))^2]
-// -- no difference of two large sums anywhere, whatever |mean| / std is.  Returns d = mean - shift and m2.
+// from it and element count of the slot (cfd_conv2d_fwd_stats).  With r = the first slot's mean as the common reference:
+//   A = sum_s n_s (m_s - r),  Q = sum_s [m2_s + n_s (m_s - r)^2];   mean - shift = r + A / N,  sum (x - mean)^2 = Q - A^2 / N
+// -- the slot means scatter around r by no more than the data do, so Q - A^2 / N is a difference of comparable numbers only when the
+// variance really is that small against the scatter (one pass and one block reduction, like the plain sums).  Returns d = mean - shift
+// and m2.
 __device__ __forceinline__ void bn_slot_stats(const float* __restrict__ rec, int c, float* s_ab, int nslots, float count, float& d,
                                               float& m2) {
     const f32x4* r4 = reinterpret_cast<const f32x4*>(rec) + (size_t)c * nslots;
-    float t = 0.f, unused = 0.f;
+    const float r = r4[0][0];
+    float pa = 0.f, pq = 0.f;
     for (int i = threadIdx.x; i < nslots; i += blockDim.x) {
         const f32x4 v = r4[i];
-        t = fmaf(v[2], v[0], t);
+        const float e = v[0] - r, ne = v[2] * e;
+        pa += ne;
+        pq += fmaf(ne, e, v[1]);
     }
-    float tot, z;
-    bn_block_sum2(t, unused, s_ab, tot, z);
-    d = tot / count;
-    float m = 0.f;
-    for (int i = threadIdx.x; i < nslots; i += blockDim.x) {
-        const f32x4 v = r4[i];
-        const float e = v[0] - d;
-        m += fmaf(v[2] * e, e, v[1]);
-    }
-    bn_block_sum2(m, unused, s_ab, m2, z);
+    float a, qq;
+    bn_block_sum2(pa, pq, s_ab, a, qq);
+    const float da = a / count;
+    d = r + da;
+    m2 = qq - a * da;
 }
 
 // y = [relu]((x - mean) * rstd * gamma + beta) with the statistics finished in the same launch: workgroup (c, sp) sums the

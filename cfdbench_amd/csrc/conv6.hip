@@ -402,37 +402,54 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
     }
     if (out_tile >= 0) store_tile();
     if constexpr (ST) {
-        {  // the 16 pixel lanes of a row group merge pairwise -> one record (mean, m2, pixels) per (channel, wave)
-            const size_t slot = 4 * (size_t)blockIdx.x + wave, nslots = 4 * (size_t)gridDim.x;
-            float cn = stn, w_hi[4], w_prod[4];  // per merge round: n_b / (n_a + n_b) and n_a n_b / (n_a + n_b), the same for every channel
+        // the 16 pixel lanes of a row group merge pairwise, then the four waves through LDS in a fixed order -> one record
+        // (mean, m2, pixels) per (channel, workgroup)
+        float cn = stn, w_hi[4], w_prod[4];  // per merge round: n_b / (n_a + n_b) and n_a n_b / (n_a + n_b), the same for every channel
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float nb = cfd_shfl_xor(cn, 1 << k), nn = cn + nb, rn = nn > 0.f ? 1.f / nn : 0.f;
-                w_hi[k] = nb * rn;
-                w_prod[k] = cn * nb * rn;
-                cn = nn;
-            }
+        for (int k = 0; k < 4; ++k) {
+            const float nb = cfd_shfl_xor(cn, 1 << k), nn = cn + nb, rn = nn > 0.f ? 1.f / nn : 0.f;
+            w_hi[k] = nb * rn;
+            w_prod[k] = cn * nb * rn;
+            cn = nn;
+        }
+        __syncthreads();
+        float* s_st = (float*)s_dyn;  // [wave][mt][q][r][4]
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float m = st1[mt][r], m2 = st2[mt][r];
+            for (int r = 0; r < 4; ++r) {
+                float m = st1[mt][r], m2 = st2[mt][r];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        // (both lanes of a pair compute the same merged values: each takes "its own" as a and the partner as b, and
-                        //  m_a + (m_b - m_a) n_b / n  ==  the partner's expression only up to rounding -- so the lower lane's result
-                        //  is the one both keep)
-                        const bool low = !((lane >> k) & 1);
-                        const float mo = cfd_shfl_xor(m, 1 << k), m2o = cfd_shfl_xor(m2, 1 << k);
-                        const float wo = cfd_shfl_xor(w_hi[k], 1 << k);
-                        const float ma = low ? m : mo, mb_ = low ? mo : m, wh = low ? w_hi[k] : wo;
-                        const float dl = mb_ - ma;
-                        m = fmaf(dl, wh, ma);
-                        m2 = (m2 + m2o) + dl * dl * w_prod[k];
-                    }
-                    const int c = 16 * (mb + mt) + 4 * q + r;
-                    if (n == 0 && c < Cm) *(f32x4*)(stats + ((size_t)c * nslots + slot) * 4) = f32x4{m, m2, cn, 0.f};
+                for (int k = 0; k < 4; ++k) {
+                    // (m_a + (m_b - m_a) n_b / n is the partner's expression only up to rounding: both lanes of a pair evaluate the
+                    //  LOWER lane's form, so all 16 end up with the same bits)
+                    const bool low = !((lane >> k) & 1);
+                    const float mo = cfd_shfl_xor(m, 1 << k), m2o = cfd_shfl_xor(m2, 1 << k);
+                    const float wo = cfd_shfl_xor(w_hi[k], 1 << k);
+                    const float ma = low ? m : mo, mb_ = low ? mo : m, wh = low ? w_hi[k] : wo;
+                    const float dl = mb_ - ma;
+                    m = fmaf(dl, wh, ma);
+                    m2 = (m2 + m2o) + dl * dl * w_prod[k];
                 }
+                if (n == 0) *(f32x4*)(s_st + (((wave * MT + mt) * 4 + q) * 4 + r) * 4) = f32x4{m, m2, cn, 0.f};
+            }
+        __syncthreads();
+        for (int e = threadIdx.x; e < MT * 16; e += blockDim.x) {
+            const int mt = e >> 4, qr = e & 15, c = 16 * (mb + mt) + qr;
+            if (c < Cm) {
+                float m = 0.f, m2 = 0.f, cnt = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) {
+                    const f32x4 b = *(const f32x4*)(s_st + ((wv * MT + mt) * 16 + qr) * 4);
+                    if (b[2] > 0.f) {
+                        const float nn = cnt + b[2], wh = b[2] / nn, dl = b[0] - m;
+                        m = fmaf(dl, wh, m);
+                        m2 = (m2 + b[1]) + dl * dl * (cnt * wh);
+                        cnt = nn;
+                    }
+                }
+                *(f32x4*)(stats + ((size_t)c * gridDim.x + blockIdx.x) * 4) = f32x4{m, m2, cnt, 0.f};
+            }
         }
     }
 }
@@ -649,7 +666,7 @@ int cfd_conv6_wprep_batch(int n, const float* const* w, void* const* wfrag, cons
 // this layer -- not a conv6 layer, or its channel chunks are split over workgroups)
 int cfd_conv6_stats_slots(const ConvGeom& g) {
     const Conv6Plan P = conv6_plan(g, false);
-    return (P.ok && g.ks == 3 && P.ksplit == 1 && P.NI == 3) ? 4 * P.gx : 0;  // one record per wave of the launch
+    return (P.ok && g.ks == 3 && P.ksplit == 1 && P.NI == 3) ? P.gx : 0;  // one record per workgroup of the launch
 }
 
 // ------------------------------------------------------------------------------------------------------
