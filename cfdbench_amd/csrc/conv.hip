@@ -835,6 +835,7 @@ __device__ __forceinline__ void bn_partials(const float* __restrict__ part, int 
     b = s_ab[1];
 }
 
+#define BN_EW 4  // elements per thread and trip of the normalising kernels (their loads in flight together)
 // Block sums of two per-thread values: wave sums, then the four waves in a fixed order through s_ab (10 floats).
 __device__ __forceinline__ void bn_block_sum2(float pa, float pb, float* s_ab, float& a, float& b) {
     pa = cfd_wave_sum(pa);
@@ -862,7 +863,9 @@ __device__ __forceinline__ void bn_block_sum2(float pa, float pb, float* s_ab, f
 __device__ __forceinline__ void bn_slot_stats(const float* __restrict__ rec, int c, float* s_ab, int nslots, float count, float& d,
                                               float& m2) {
     const f32x4* r4 = reinterpret_cast<const f32x4*>(rec) + (size_t)c * nslots;
-    const float r = r4[0][0];
+    // (a per-lane load on purpose: as a scalar load of a uniform address the compiler waits for it before it issues the record loads
+    //  below -- one more trip to memory)
+    const float r = rec[((size_t)c * nslots + cfd_opaque(0)) * 4];
     float pa = 0.f, pq = 0.f;
     for (int i = threadIdx.x; i < nslots; i += blockDim.x) {
         const f32x4 v = r4[i];
@@ -890,19 +893,41 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
                                                   const float* __restrict__ kbase, int kstride) {
     __shared__ float s_ab[10];
     const int c = blockIdx.x, sp = blockIdx.y;
+    // Everything that does not depend on the statistics is REQUESTED first -- the per-channel parameters and the slice's first batch
+    // of elements: each of them behind the reduction was one more trip to memory during which the whole grid (every workgroup runs
+    // the same prologue at the same time) had nothing in flight (gamma / beta as scalar loads behind the last barrier: +2.8 us on a
+    // 15 us launch).
+    const float ga = gamma[c], be = beta[c];
+    const float kb = (training && kbase) ? kbase[(size_t)c * (kstride ? kstride : 1)] : 0.f;
+    const unsigned n = (unsigned)B * HW;
+    const unsigned per = (n + gridDim.y - 1) / gridDim.y;
+    const unsigned e0 = sp * per, e1 = e0 + per < n ? e0 + per : n;
+    const bool any = e0 < e1;
+    size_t o[BN_EW];
+    float xv[BN_EW];
+    const auto fetch = [&](unsigned eb) {  // elements eb + k blockDim.x (clamped into the slice: no conditional loads)
+#pragma unroll
+        for (int k = 0; k < BN_EW; ++k) {
+            unsigned e = eb + k * blockDim.x;
+            e = e < e1 ? e : e1 - 1;
+            const unsigned b = cfd_div(e, dHW);
+            o[k] = ((size_t)b * C + c) * HW + (e - b * (unsigned)HW);
+            xv[k] = x[o[k]];
+        }
+    };
+    if (any) fetch(e0 + threadIdx.x);
     float mu, rs;
     if (training) {
         float d, m2;
         if (kstride == 0) {  // per-slot records of the conv that produced x (cfd_conv2d_fwd_stats); kbase = its bias
             bn_slot_stats(part, c, s_ab, nsplit, count, d, m2);
-            mu = (kbase ? kbase[c] : 0.f) + d;
         } else {  // sums of (x - K) and (x - K)^2, K = the channel's first element (k_bn_partial<3>)
             float a, b;
             bn_partials(part, c, s_ab, a, b, nsplit);
             d = a / count;
-            mu = (kbase ? kbase[(size_t)c * kstride] : 0.f) + d;
             m2 = b - a * d;  // sum (x - mean)^2 = sum (x-K)^2 - n (mean-K)^2
         }
+        mu = kb + d;
         m2 = m2 > 0.f ? m2 : 0.f;
         const float var = m2 / count;  // biased: what normalises (torch.nn.functional.batch_norm, training=True)
         rs = 1.0f / sqrtf(var + eps);
@@ -916,16 +941,17 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
         rs = 1.0f / sqrtf(run_var[c] + eps);
     }
     if (sp == 0 && threadIdx.x == 0) { save_mean[c] = mu; save_rstd[c] = rs; }
-    const float ga = gamma[c], be = beta[c];
-    const unsigned n = (unsigned)B * HW;
-    const unsigned per = (n + gridDim.y - 1) / gridDim.y;
-    const unsigned e0 = sp * per, e1 = e0 + per < n ? e0 + per : n;
-    for (unsigned e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-        const unsigned b = cfd_div(e, dHW);
-        const size_t o = ((size_t)b * C + c) * HW + (e - b * (unsigned)HW);
-        float v = fmaf((x[o] - mu) * rs, ga, be);
-        if (relu) v = v > 0.f ? v : 0.f;
-        y[o] = v;
+    if (!any) return;
+    for (unsigned eb = e0 + threadIdx.x;;) {
+#pragma unroll
+        for (int k = 0; k < BN_EW; ++k) {
+            float v = fmaf((xv[k] - mu) * rs, ga, be);
+            if (relu) v = v > 0.f ? v : 0.f;
+            if (eb + k * blockDim.x < e1) y[o[k]] = v;
+        }
+        eb += BN_EW * blockDim.x;
+        if (eb - threadIdx.x >= e1) break;  // (uniform)
+        fetch(eb);
     }
 }
 
@@ -938,22 +964,43 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       float inv_count, int relu, int training, CfdDiv dHW) {
     __shared__ float s_ab[10];
     const int c = blockIdx.x, sp = blockIdx.y;
-    float gb, gg;
-    bn_partials(part, c, s_ab, gb, gg);
-    if (sp == 0 && threadIdx.x == 0) { gbeta[c] = gb; ggamma[c] = gg; }
+    // (parameters and the slice's first batch requested ahead of the reduction, as in k_bn_apply)
     const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
     const unsigned n = (unsigned)B * HW;
     const unsigned per = (n + gridDim.y - 1) / gridDim.y;
     const unsigned e0 = sp * per, e1 = e0 + per < n ? e0 + per : n;
-    for (unsigned e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-        const unsigned b = cfd_div(e, dHW);
-        const size_t o = ((size_t)b * C + c) * HW + (e - b * (unsigned)HW);
-        const float xh = (x[o] - mu) * rs;
-        float gz = gy[o];
-        if (relu && !(fmaf(xh, ga, be) > 0.f)) gz = 0.f;
-        float t = gz;
-        if (training) t -= (gb + xh * gg) * inv_count;
-        gx[o] = ga * rs * t;
+    const bool any = e0 < e1;
+    size_t o[BN_EW];
+    float xv[BN_EW], gv[BN_EW];
+    const auto fetch = [&](unsigned eb) {
+#pragma unroll
+        for (int k = 0; k < BN_EW; ++k) {
+            unsigned e = eb + k * blockDim.x;
+            e = e < e1 ? e : e1 - 1;
+            const unsigned b = cfd_div(e, dHW);
+            o[k] = ((size_t)b * C + c) * HW + (e - b * (unsigned)HW);
+            xv[k] = x[o[k]];
+            gv[k] = gy[o[k]];
+        }
+    };
+    if (any) fetch(e0 + threadIdx.x);
+    float gb, gg;
+    bn_partials(part, c, s_ab, gb, gg);
+    if (sp == 0 && threadIdx.x == 0) { gbeta[c] = gb; ggamma[c] = gg; }
+    if (!any) return;
+    for (unsigned eb = e0 + threadIdx.x;;) {
+#pragma unroll
+        for (int k = 0; k < BN_EW; ++k) {
+            const float xh = (xv[k] - mu) * rs;
+            float gz = gv[k];
+            if (relu && !(fmaf(xh, ga, be) > 0.f)) gz = 0.f;
+            float t = gz;
+            if (training) t -= (gb + xh * gg) * inv_count;
+            if (eb + k * blockDim.x < e1) gx[o[k]] = ga * rs * t;
+        }
+        eb += BN_EW * blockDim.x;
+        if (eb - threadIdx.x >= e1) break;  // (uniform)
+        fetch(eb);
     }
 }
 

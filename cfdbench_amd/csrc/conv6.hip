@@ -407,9 +407,9 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
         float cn = stn, w_hi[4], w_prod[4];  // per merge round: n_b / (n_a + n_b) and n_a n_b / (n_a + n_b), the same for every channel
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float nb = cfd_shfl_xor(cn, 1 << k), nn = cn + nb, rn = nn > 0.f ? 1.f / nn : 0.f;
+            const float nb = cfd_shfl_xor(cn, 1 << k), nn = cn + nb, rn = nn > 0.f ? cfd_rcpf(nn) : 0.f;
             w_hi[k] = nb * rn;
-            w_prod[k] = cn * nb * rn;
+            w_prod[k] = cn * w_hi[k];
             cn = nn;
         }
         __syncthreads();
@@ -418,18 +418,15 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                // (every lane merges "its own" with its partner's: the two lanes of a pair agree up to rounding only, and only what
+                //  reaches lane n == 0 is written -- any of these roundings is a valid merge, and the same one on every run)
                 float m = st1[mt][r], m2 = st2[mt][r];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    // (m_a + (m_b - m_a) n_b / n is the partner's expression only up to rounding: both lanes of a pair evaluate the
-                    //  LOWER lane's form, so all 16 end up with the same bits)
-                    const bool low = !((lane >> k) & 1);
                     const float mo = cfd_shfl_xor(m, 1 << k), m2o = cfd_shfl_xor(m2, 1 << k);
-                    const float wo = cfd_shfl_xor(w_hi[k], 1 << k);
-                    const float ma = low ? m : mo, mb_ = low ? mo : m, wh = low ? w_hi[k] : wo;
-                    const float dl = mb_ - ma;
-                    m = fmaf(dl, wh, ma);
-                    m2 = (m2 + m2o) + dl * dl * w_prod[k];
+                    const float dl = mo - m;
+                    m = fmaf(dl, w_hi[k], m);
+                    m2 = fmaf(dl * dl, w_prod[k], m2 + m2o);
                 }
                 if (n == 0) *(f32x4*)(s_st + (((wave * MT + mt) * 4 + q) * 4 + r) * 4) = f32x4{m, m2, cn, 0.f};
             }
@@ -442,9 +439,9 @@ __global__ __launch_bounds__(256, 2) void k_conv6(const float* __restrict__ src,
                 for (int wv = 0; wv < 4; ++wv) {
                     const f32x4 b = *(const f32x4*)(s_st + ((wv * MT + mt) * 16 + qr) * 4);
                     if (b[2] > 0.f) {
-                        const float nn = cnt + b[2], wh = b[2] / nn, dl = b[0] - m;
+                        const float nn = cnt + b[2], wh = b[2] * cfd_rcpf(nn), dl = b[0] - m;
                         m = fmaf(dl, wh, m);
-                        m2 = (m2 + b[1]) + dl * dl * (cnt * wh);
+                        m2 = fmaf(dl * dl, cnt * wh, m2 + b[1]);
                         cnt = nn;
                     }
                 }
