@@ -14,9 +14,10 @@ Rank 0 prints ONE JSON line.  Beside the contract's keys it carries
   roofline_step             the whole step against the ideal-fusion byte count of SURVEY 8d (10.2 MB/frame at C=20, L=4)
   roofline_spectral_conv2d  the north-star kernel group (SpectralConv2d fwd+bwd, 5N + 3Wb bytes)
   kernels                   every kernel of the step: launches, average time, HBM fraction
-  exact_fp32                the same step and SpectralConv2d group with the transforms on the exact-fp32 kernels (cfd_tune_set("exact_fp32", 1))
+  split2                    the same step and SpectralConv2d group with two-piece activation operands (cfd_tune_set("act_pieces", 2): rounds 1-4's default)
+  fp32_mfma_route           the same with the transforms on the exact-fp32 MFMA kernels (cfd_tune_set("exact_fp32", 1))
   rollout / rollout_66x65   batched multi-step inference from one HIP graph (configs[4] horizon: 200 steps)
-  train_66x65 / train_batch8  the same train step on the 66x65 grid (dam / tube / cylinder) and at the reference's default batch 8
+  train_66x65 / train_batch8 / train_c32_*  the same train step on the 66x65 grid (dam / tube / cylinder), at the reference's default batch 8 and default width 32
   unet_cfg2 / auto_deeponet_cfg3 / resnet_b32   train steps of BASELINE configs[2] / configs[3] and of the ResNet baseline on one GPU
   cpu_baseline              the reference's ATen call sequence on the host cores, at B = 256 and B = 32
 The rollout / rollout_66x65 legs run on EVERY rank (cases shard over the ranks, `n_gpus` inside the leg); the other extra legs
@@ -41,8 +42,8 @@ sys.path.insert(0, str(REPO))
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TF = 157.3        # MI355X_MICROARCH.md: fp32 vector == f32-input MFMA peak
 BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak
-# kernels whose GEMM-shaped work runs as 3-term split-bf16 products on the bf16 matrix pipe (cfd_common.h): their
-# fp32-equivalent flops cost 3 bf16 MFMA flops each
+# kernels whose GEMM-shaped work runs as split-bf16 products on the bf16 matrix pipe (cfd_common.h): on the default route (three pieces
+# per operand since round 5) an fp32-equivalent flop costs SIX bf16 MFMA flops, like the convolutions below
 SPLIT_BF16 = ("k_dft_fwd", "k_idft", "k_block", "k_chan_wgrad", "k_head")
 # the k = 3 / k = 7 convolutions (conv6.hip): three-piece operands, SIX bf16 MFMAs per fp32-exact product
 SPLIT6_BF16 = ("k_conv_fwd", "k_conv_dgrad", "k_conv_wgrad")
@@ -145,9 +146,8 @@ def roofline_of(name, launches, total_ms, total_bytes, total_flops):
         return None
     t = total_ms * 1e-3
     split, split6 = name.startswith(SPLIT_BF16), name.startswith(SPLIT6_BF16)
-    pipe_tf = BF16_MFMA_PEAK_TF / 3.0 if split else (BF16_MFMA_PEAK_TF / 6.0 if split6 else FP32_PEAK_TF)  # fp32-equivalent flops/s of the pipe
-    pipe = ("bf16 MFMA, 3-term split products (fp32-equivalent flops)" if split else
-            "bf16 MFMA, six products of three-piece (fp32-exact) operands (fp32-equivalent flops)" if split6 else "fp32 MFMA / VALU")
+    pipe_tf = BF16_MFMA_PEAK_TF / 6.0 if (split or split6) else FP32_PEAK_TF  # fp32-equivalent flops/s of the pipe
+    pipe = "bf16 MFMA, six products of three-piece (fp32-exact) operands (fp32-equivalent flops)" if (split or split6) else "fp32 MFMA / VALU"
     t_hbm = total_bytes / (HBM_PEAK_GBS * 1e9)
     t_pipe = total_flops / (pipe_tf * 1e12)
     out = dict(kernel=name, avg_us=round(total_ms / launches * 1e3, 2), launches=launches,
@@ -379,7 +379,47 @@ def unet_bytes_per_frame(dim, cin, H, W):
     return 3 * e * 4
 
 
+DP = dict(world=1, rank=0, steps=None, warmup=None)  # set by main() for `--gpus N --only LEG`: the leg as a data-parallel job
+
+
+def model_dp_leg(name, model, batch, frames, what):
+    """`bench.py --gpus N --only unet|auto_deeponet|...`: the train step of a graph-replayed model as a DATA-PARALLEL job, one process
+    per GPU (BASELINE configs[2] "DDP 8x", configs[3] "4x"): forward + backward + gradient pack from one HIP graph, ONE all-reduce of
+    the flat gradient over RCCL, Adam from a second graph (cfdbench_amd/graph.py).  Weak scaling: every rank trains on its own batch;
+    value = N * B * K / max-over-ranks time between barriers -- the contract of the headline line."""
+    from cfdbench_amd.graph import GraphedTrainStep
+    from cfdbench_amd.optim import Adam as MultiTensorAdam
+    world, rank = DP["world"], DP["rank"]
+    steps, warmup = DP["steps"] or 20, DP["warmup"] if DP["warmup"] is not None else 5
+    opt = MultiTensorAdam(model.parameters(), lr=1e-3)
+    gs = GraphedTrainStep(model, opt, batch)
+    assert gs.dp == (world > 1)
+    for _ in range(warmup):
+        gs(**batch)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gs(**batch)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=batch["inputs"].device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    return {"metric": f"train frames/sec, {name}", "value": round(world * frames * steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": what, "global_batch": world * frames, "parallelism": f"dp{world}",
+                       "step": "graph A (forward + backward + gradient pack) -> all-reduce of the flat gradient (RCCL) -> graph B (Adam)",
+                       "flat_gradient_bytes": int(gs.exchange.numel * 4) if gs.exchange is not None else 0},
+            "final_nmse": round(float(gs.loss["nmse"].item()), 6)}
+
+
 def model_train_leg(api, name, model, batch, steps, warmup, frames, bytes_per_frame, what):
+    if DP["world"] > 1:
+        return model_dp_leg(name, model, batch, frames, what)
     from cfdbench_amd.optim import Adam as MultiTensorAdam
     opt = MultiTensorAdam(model.parameters(), lr=1e-3)  # torch.optim.Adam's update as one launch per 80 tensors (cfd_adam_multi)
     from cfdbench_amd.graph import GraphedTrainStep
@@ -388,7 +428,9 @@ def model_train_leg(api, name, model, batch, steps, warmup, frames, bytes_per_fr
         out = model(**batch)
         out["loss"]["nmse"].backward()
         opt.step()
-        opt.zero_grad(set_to_none=False)  # keep the gradient tensors: the multi-tensor Adam's pointer table stays valid
+        # set_to_none: the next backward pass hands autograd's gradient tensors over as they are (with set_to_none=False every step paid
+        # one fill and one accumulate-add launch per parameter -- 46 + 56 stock ATen launches per U-Net step in round 4's rocprof table)
+        opt.zero_grad(set_to_none=True)
 
     dt_eager = time_steps(eager, steps, warmup)
     rows = profiled(api, eager, steps)
@@ -420,6 +462,8 @@ def model_train_leg(api, name, model, batch, steps, warmup, frames, bytes_per_fr
 # train-step legs of the other model families (rank 0, N = 1); each also runs alone under `--only NAME`
 # ----------------------------------------------------------------------------------------------------------------------
 def _fields(B, H, W, p, gen, dev, border=False):
+    if DP["rank"]:  # data-parallel leg: every rank draws its own shard
+        gen.manual_seed(gen.initial_seed() + 1000 * DP["rank"])
     x = torch.randn(B, 2, H, W, generator=gen).to(dev)
     mask = torch.ones(B, 1, H, W, device=dev)
     if border:
@@ -634,6 +678,14 @@ def main():
         if args.only == "spectral":
             out = {"roofline_spectral_conv2d": spectral_leg(api, _lib, dev, B, C, H, W, max(args.steps, 20))}
         elif args.only in MODEL_LEGS:
+            if world > 1:  # the leg as a data-parallel job: ONE contract-style line from rank 0
+                DP.update(world=world, rank=rank, steps=args.steps, warmup=args.warmup)
+                out = MODEL_LEGS[args.only][1](api, dev)
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
+                dist.barrier()
+                dist.destroy_process_group()
+                return
             out = {MODEL_LEGS[args.only][0]: MODEL_LEGS[args.only][1](api, dev)}
         else:
             print(f"bench.py: unknown --only {args.only!r}", file=sys.stderr)
@@ -677,13 +729,13 @@ def main():
         "metric": "train frames/sec (64x64x2), Auto-FNO cavity", "value": round(fps, 1),
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (storage and accumulation; DFT / 1x1 / head contractions as split-bf16 products: activations in 2 pieces, fixed operands in 3, rel. 2^-16 per product; the fp32-exact-class build of the whole step is the exact_fp32 leg)",
+        "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: Auto-FNO train step (fwd+nMSE+bwd+Adam), Fno2d(L={L},hidden={C},modes=12,p={p}), "
                                f"{H}x{W}, batch {B}/GPU, fp32, random-init weights",
-                   "precision": "fp32 storage and accumulation; DFT / 1x1-weight-gradient / head contractions as split-bf16 MFMA products "
-                                "(rel. error <= 2^-16 per product, measured nMSE vs the fp64 oracle <= 5e-11 per kernel, 3e-12 whole-model predictions); "
-                                "cfd_tune_set('act_pieces', 3) selects the fp32-exact-class build of every contraction (exact_fp32 leg)",
+                   "precision": "fp32 storage and accumulation; every contraction on bf16 MFMAs with BOTH operands in three bf16 pieces, six "
+                                "products per product term down to 2^-24 (fp32-exact class; nMSE vs the fp64 oracle 4e-14 whole model)",
+                   "act_pieces": 3,
                    "global_batch": world * B, "parallelism": f"dp{world}", "graph": bool(args.graph), "settle_steps": args.settle},
         "final_nmse": round(final["nmse"], 6),
     }
@@ -716,6 +768,11 @@ def main():
         result["roofline_spectral_conv2d"] = spectral_leg(api, _lib, dev, B, C, H, W, max(args.steps, 20))
         if B == 256 and C == 20 and (H, W) == (64, 64):
             attach_leg_traffic(result["roofline_spectral_conv2d"], "spectral")
+        # the north star's own figure and the whole-step fraction ride INSIDE the roofline object (the driver's record keeps that
+        # object whole and only the names of the other extra keys)
+        sc = result["roofline_spectral_conv2d"]
+        result["roofline"]["spectral_conv2d"] = {k: sc.get(k) for k in ("avg_us", "algorithmic_bytes", "achieved", "frac", "traffic", "target_frac", "target_us") if k in sc}
+        result["roofline"]["step"] = dict(frac=result["roofline_step"]["frac"], bytes_per_frame=bpf, ms_per_step=result["ms_per_step"])
 
     extra = rank == 0 and world == 1
     # ---- rollout legs: batched multi-step inference from one HIP graph (the metric's "rollout" half; configs[4]) ----
@@ -788,10 +845,13 @@ def main():
         try:
             result["train_66x65"] = train_leg(B, 66, 65, C, f"the same train step on the 66x65 grid (general-width kernels), batch {B}, hidden {C}")
             result["train_batch8"] = train_leg(8, H, W, C, f"the same train step at the reference's default batch size 8 (src/args.py:44), {H}x{W}, hidden {C}")
+            # the reference's DEFAULT width (--fno_hidden_dim 32, src/args.py:190) on both grids
+            result["train_c32_64x64"] = train_leg(B, H, W, 32, f"the same train step at the reference's default width 32 (src/args.py:190), {H}x{W}, batch {B}")
+            result["train_c32_66x65"] = train_leg(B, 66, 65, 32, f"the same train step at width 32 on the 66x65 grid (dam / tube / cylinder), batch {B}")
         except Exception as e:  # noqa: BLE001
             result["train_66x65"] = dict(error=str(e)[:200])
 
-    # ---- the same step on the fp32-exact-class route (the default route's split-product trade on the record) ------------------
+    # ---- the same step on the round 1-4 default route (two-piece activation operands) and on the old fp32-MFMA transforms ----------
     if extra and not args.no_extra:
         def timed_route(knob, value):
             api.call("cfd_tune_set", knob, value)
@@ -802,17 +862,15 @@ def main():
                 api.call("cfd_tune_set", knob, -1)
             return dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(B / dt, 1), spectral_conv2d_us=sp["avg_us"], spectral_conv2d_frac=sp["frac"])
         try:
-            result["exact_fp32"] = dict(
-                timed_route(b"act_pieces", 3),
-                what="the same step / SpectralConv2d group on the fp32-exact-class route (cfd_tune_set('act_pieces', 3)): EVERY contraction of the step "
-                     "-- transforms, the fused FnoBlock's inverse transform, 1x1 conv, 1x1 weight gradient, all three GEMMs of the projection head -- with "
-                     "both operands in THREE bf16 pieces and six MFMAs per product (every term down to 2^-24); mode mixing / spectral weight gradient / "
-                     "channel mix inside k_block are exact fp32 FMAs on both routes.  Measured nMSE vs the fp64 oracle: 1e-14 .. 5e-14 per kernel, whole "
-                     "model 4e-14 (predictions) / <= 2e-12 (gradients) -- profiles/r04d_err_act3.json",
-                fp32_mfma_route=dict(timed_route(b"exact_fp32", 1),
-                                     what="round 1-3's exact route: every DFT / inverse DFT on v_mfma_f32_16x16x4_f32 kernels, the FnoBlock as two passes"))
+            result["split2"] = dict(
+                timed_route(b"act_pieces", 2),
+                what="the same step / SpectralConv2d group with the ACTIVATION operands in two bf16 pieces (cfd_tune_set('act_pieces', 2), the "
+                     "default of rounds 1-4): rel. 2^-16 per product, nMSE vs the fp64 oracle 2e-11 .. 5e-11 per kernel -- NOT fp32-class "
+                     "arithmetic, kept as a selectable route")
+            result["fp32_mfma_route"] = dict(timed_route(b"exact_fp32", 1),
+                                             what="round 1-3's exact route: every DFT / inverse DFT on v_mfma_f32_16x16x4_f32 kernels, the FnoBlock as two passes")
         except Exception as e:  # noqa: BLE001
-            result["exact_fp32"] = dict(error=str(e)[:300])
+            result["split2"] = dict(error=str(e)[:300])
 
     # ---- other model families of BASELINE.json (one GPU's share of configs[2] and configs[3]) and of SURVEY 8 a-9 / f-3 ----
     if extra and not args.no_extra:
@@ -826,23 +884,30 @@ def main():
     if extra and not args.no_cpu_baseline:
         from oracle import torch_port
         ncpu = os.cpu_count() or 1
-        # ATen's CPU kernels do not scale to every hardware thread at this size (256 threads on the 2x64-core GPU box is
-        # pathologically slow): probe two moderate thread counts with one timed step each at batch 32, keep the faster.
-        cands = sorted({t for t in (16, 64) if t <= ncpu} or {ncpu})
+        # the reference modules themselves where /root/reference/src imports (the build container), else the port of
+        # their ATen call sequence (the GPU box has no /root/reference).  ATen's CPU kernels do not scale to every hardware thread at
+        # this size (256 threads on the 2x64-core GPU box is pathologically slow): sweep {8, 16, 32, 64, all} with one timed step each
+        # at batch 32 inside a 20-s budget, keep the fastest.
+        use_ref = torch_port.reference_importable()
+        timer = torch_port.time_reference_steps if use_ref else torch_port.time_train_steps
+        cands = sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu})
         probe, t_probe0 = {}, time.perf_counter()
         for t in cands:
-            probe[t] = torch_port.time_train_steps(32, 1, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=t)["frames_per_s"]
-            if time.perf_counter() - t_probe0 > 15.0:
+            probe[t] = timer(32, 1, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=t)["frames_per_s"]
+            if time.perf_counter() - t_probe0 > 20.0:
                 break
         best_t = max(probe, key=probe.get)
-        cb32 = torch_port.time_train_steps(32, 5, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=best_t)
-        cb = torch_port.time_train_steps(B, args.cpu_steps, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=best_t)
+        cb32 = timer(32, 5, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=best_t)
+        cb = timer(B, args.cpu_steps, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=best_t)
         result["cpu_baseline"] = dict(
-            value=round(cb["frames_per_s"], 1), unit="frames/s", cores=cb["threads"], kind="port",
-            sample=f"the SAME workload (train step fwd+nMSE+bwd+Adam, batch {B}) via oracle/torch_port.py (PyTorch-CPU ATen ops, fp32; "
-                   f"checked against the oracle in tests/test_oracle_golden.py), {args.cpu_steps} steps after 1 warm-up, median; "
-                   f"thread count = best of { {t: round(v, 1) for t, v in probe.items()} } frames/s at batch 32, {ncpu} host cores",
-            value_batch32=round(cb32["frames_per_s"], 1))
+            value=round(cb["frames_per_s"], 1), unit="frames/s", cores=cb["threads"], kind="reference" if use_ref else "port",
+            sample=f"the SAME workload (train step fwd+nMSE+bwd+Adam, batch {B}) on "
+                   + ("the reference's own Fno2d module (/root/reference/src), " if use_ref else
+                      "oracle/torch_port.py (the reference's PyTorch-CPU ATen call sequence, fp32; checked against the oracle in tests/test_oracle_golden.py), ")
+                   + f"{args.cpu_steps} steps after 1 warm-up, median; thread sweep at batch 32: { {t: round(v, 1) for t, v in probe.items()} } "
+                   f"frames/s, {ncpu} host cores",
+            value_batch32=round(cb32["frames_per_s"], 1), thread_sweep_batch32={str(t): round(v, 1) for t, v in probe.items()},
+            host_cores=ncpu)
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -40,6 +40,7 @@ class FfnStackArgs(C.Structure):
 
 
 _P = C.c_void_p
+ABI_VERSION = 500  # include/cfdbench_amd.h: CFD_ABI_VERSION
 _I = C.c_int
 _F = C.c_float
 _Z = C.c_size_t
@@ -85,6 +86,7 @@ _SIGS = {
     "cfd_gelu_bwd": (_I, [_P, _P, _P, _Z, _P]),
     "cfd_adam_flat": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P]),
     "cfd_adam_multi": (_I, [_I, _P, _P, _P, _P, _P, _P, _F, _P, _F, _F, _F, _F, _F, _F, _P]),
+    "cfd_scale_copy_multi": (_I, [_I, _P, _P, _P, _F, _P]),
     "cfd_gemm_workspace_bytes": (_Z, [_I, _I, _I]),
     "cfd_gemm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfd_linear_fwd_workspace_bytes": (_Z, [_I, _I, _I]),
@@ -180,6 +182,9 @@ class CApi:
         if missing and require_all:
             raise CfdError(f"library {lib._name} lacks C-ABI symbols: {missing}")
         self.missing = missing
+        if "cfd_version" not in missing and int(lib.cfd_version()) != ABI_VERSION:
+            raise CfdError(f"library {lib._name} is ABI version {int(lib.cfd_version())}, this binding needs {ABI_VERSION} "
+                           "(include/cfdbench_amd.h: CFD_ABI_VERSION) -- a stale build; run `python -m cfdbench_amd.build --force`")
 
     # -- helpers ---------------------------------------------------------------------------------
     def _chk(self, rc: int, what: str):

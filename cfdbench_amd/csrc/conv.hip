@@ -890,7 +890,10 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
                                                   float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                   float* __restrict__ y, int B, int C, int HW, float count, float eps,
                                                   float momentum, int training, int relu, CfdDiv dHW, int nsplit,
-                                                  const float* __restrict__ kbase, int kstride) {
+                                                  const float* __restrict__ kbase, int kstride, int records) {
+    // records: `part` holds the (m, m2, n, -) slot records of cfd_conv2d_fwd_stats (kbase = the producer's shift, stride kstride);
+    // otherwise the (sum, sum of squares) partials of k_bn_partial<3> about kbase[c * kstride] (an explicit mode since round 5:
+    // it used to be encoded as kstride == 0)
     __shared__ float s_ab[10];
     const int c = blockIdx.x, sp = blockIdx.y;
     // Everything that does not depend on the statistics is REQUESTED first -- the per-channel parameters and the slice's first batch
@@ -898,7 +901,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
     // the same prologue at the same time) had nothing in flight (gamma / beta as scalar loads behind the last barrier: +2.8 us on a
     // 15 us launch).
     const float ga = gamma[c], be = beta[c];
-    const float kb = (training && kbase) ? kbase[(size_t)c * (kstride ? kstride : 1)] : 0.f;
+    const float kb = (training && kbase) ? kbase[(size_t)c * kstride] : 0.f;
     const unsigned n = (unsigned)B * HW;
     const unsigned per = (n + gridDim.y - 1) / gridDim.y;
     const unsigned e0 = sp * per, e1 = e0 + per < n ? e0 + per : n;
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
     float mu, rs;
     if (training) {
         float d, m2;
-        if (kstride == 0) {  // per-slot records of the conv that produced x (cfd_conv2d_fwd_stats); kbase = its bias
+        if (records) {  // per-slot records of the conv that produced x (cfd_conv2d_fwd_stats); kbase = its bias
             bn_slot_stats(part, c, s_ab, nsplit, count, d, m2);
         } else {  // sums of (x - K) and (x - K)^2, K = the channel's first element (k_bn_partial<3>)
             float a, b;
@@ -1043,7 +1046,7 @@ extern "C" int cfd_batchnorm_fwd(const float* x, const float* gamma, const float
     CFD_PROF_W("k_bn_apply", st, 8.0 * B * C * HW, 2.0 * B * C * HW);
     hipLaunchKernelGGL(k_bn_apply, dim3(C, bn_slices(B, C, HW)), dim3(256), 0, st, x, (const float*)part, gamma, beta, run_mean,
                        run_var, save_mean, save_rstd, y, B, C, HW, count, eps, momentum, training, relu,
-                       cfd_div_make((unsigned)HW), BN_SPLIT, x, HW);
+                       cfd_div_make((unsigned)HW), BN_SPLIT, x, HW, 0);
     CFD_LAUNCH_CHECK("cfd_batchnorm_fwd(apply)");
     return CFD_OK;
 }
@@ -1062,7 +1065,7 @@ extern "C" int cfd_batchnorm_fwd_stats(const float* x, const float* gamma, const
     CFD_PROF_W("k_bn_apply", st, 8.0 * B * C * HW, 2.0 * B * C * HW);
     hipLaunchKernelGGL(k_bn_apply, dim3(C, bn_slices(B, C, HW)), dim3(256), 0, st, x, stats, gamma, beta, run_mean, run_var,
                        save_mean, save_rstd, y, B, C, HW, (float)((double)B * HW), eps, momentum, 1, relu, cfd_div_make((unsigned)HW),
-                       slots, shift, 0);
+                       slots, shift, 1, 1);
     CFD_LAUNCH_CHECK("cfd_batchnorm_fwd_stats");
     return CFD_OK;
 }

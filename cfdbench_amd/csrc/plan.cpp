@@ -19,7 +19,7 @@ void cfd_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cfd_last_error(void) { return g_err; }
-extern "C" int cfd_version(void) { return 100; }
+extern "C" int cfd_version(void) { return CFD_ABI_VERSION; }
 
 // float -> bf16 bit pattern, round to nearest even (the device-side split uses the same rounding)
 static unsigned short bf16_rne(float x) {

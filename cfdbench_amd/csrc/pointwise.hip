@@ -1402,6 +1402,54 @@ extern "C" int cfd_adam_multi(int n, float* const* param, const float* const* gr
     return CFD_OK;
 }
 
+// dst[k][i] = scale * src[k][i] for n tensors in one launch per 80 (the data-parallel path of the graph-replayed models packs every
+// parameter gradient, pre-scaled by 1 / world, into ONE flat buffer behind the captured backward pass: graph.GraphedTrainStep;
+// torch.cat + mul_ + ~136 copy_ launches per U-Net step before).  Same table walk as k_adam_multi.
+struct CopyItem {
+    const float* s;
+    float* d;
+    unsigned n, blk0;
+};
+struct CopyBatch {
+    int n;
+    CopyItem it[CFD_ADAM_MAX];
+};
+__global__ __launch_bounds__(256) void k_scale_copy_multi(const CopyBatch b, float scale) {
+    int i = 0;
+    while (i + 1 < b.n && blockIdx.x >= b.it[i + 1].blk0) ++i;
+    const CopyItem& e = b.it[i];
+    const unsigned nblk = (i + 1 < b.n ? b.it[i + 1].blk0 : gridDim.x) - e.blk0;
+    for (unsigned k = (blockIdx.x - e.blk0) * blockDim.x + threadIdx.x; k < e.n; k += nblk * blockDim.x) e.d[k] = e.s[k] * scale;
+}
+
+extern "C" int cfd_scale_copy_multi(int n, const float* const* src, float* const* dst, const size_t* numel, float scale, void* stream) {
+    CFD_REQUIRE(n >= 0, CFD_ERR_INVALID_ARG, "cfd_scale_copy_multi: negative count");
+    if (n == 0) return CFD_OK;
+    CFD_REQUIRE(src && dst && numel, CFD_ERR_INVALID_ARG, "cfd_scale_copy_multi: NULL table");
+    for (int base = 0; base < n; base += CFD_ADAM_MAX) {
+        CopyBatch b{};
+        b.n = n - base < CFD_ADAM_MAX ? n - base : CFD_ADAM_MAX;
+        unsigned blocks = 0;
+        double total = 0.0;
+        for (int i = 0; i < b.n; ++i) {
+            const int k = base + i;
+            CFD_REQUIRE(src[k] && dst[k], CFD_ERR_INVALID_ARG, "cfd_scale_copy_multi: NULL pointer in item %d", k);
+            CFD_REQUIRE(numel[k] < (1ull << 31), CFD_ERR_UNSUPPORTED, "cfd_scale_copy_multi: item %d has 2^31 or more elements", k);
+            CopyItem& e = b.it[i];
+            e.s = src[k], e.d = dst[k], e.n = (unsigned)numel[k], e.blk0 = blocks;
+            unsigned nb = (e.n + 1023) / 1024;
+            if (nb < 1) nb = 1;
+            if (nb > 256) nb = 256;
+            blocks += nb;
+            total += (double)e.n;
+        }
+        CFD_PROF_W("k_scale_copy_multi", (hipStream_t)stream, 8.0 * total, total);
+        hipLaunchKernelGGL(k_scale_copy_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b, scale);
+        CFD_LAUNCH_CHECK("cfd_scale_copy_multi");
+    }
+    return CFD_OK;
+}
+
 extern "C" int cfd_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                              void* stream) {

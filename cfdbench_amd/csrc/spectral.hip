@@ -2227,8 +2227,8 @@ static bool block_fused_ok(const cfd_plan* p, int Cs, int Cd, const void* a, con
     const int cmax = Cs > Cd ? Cs : Cd;
     if (cfd_tune_get(CFD_TUNE_EXACT_FP32) == 1 || !p->d_inv_b3 || p->T > CFD_KB_TMAX) return false;  // (the fused kernel's inverse transform is split-bf16)
     if (4 * p->m1 * p->m2 + 1 > CFD_BLK_ZS || cmax > 24 || ((uintptr_t)z % 16) != 0) return false;    // 25 .. 32 channels: see launch_block
-    if (block_is_gen(p))  // round 4: 64 <= W <= 68 (d_inv_b3 exists), any H <= 80; 4-byte aligned planes; built for two-piece activations
-        return cfd_tune_get(CFD_TUNE_BLOCK_GEN) != 0 && cfd_act_pieces() == 2 && p->d_tail;
+    if (block_is_gen(p))  // round 4: 64 <= W <= 68 (d_inv_b3 exists), any H <= 80; 4-byte aligned planes (round 5: both piece counts)
+        return cfd_tune_get(CFD_TUNE_BLOCK_GEN) != 0 && p->d_tail;
     return ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && (!c || ((uintptr_t)c % 16) == 0);
 }
 
@@ -2254,7 +2254,7 @@ static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z
                        (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB, tl, spl, p->W, (const float*)p->d_tail)
 #define CFD_BLK(A_, T_, D_, R_)                                                      \
     do {                                                                             \
-        if (gen) { if constexpr (NW != 10) CFD_BLK_P(A_, T_, D_, R_, 2, true); }  /* block_fused_ok: two pieces; launch_block: never (10,2,2) */ \
+        if (gen) { if constexpr (NW != 10) { if (ap3) CFD_BLK_P(A_, T_, D_, R_, 3, true); else CFD_BLK_P(A_, T_, D_, R_, 2, true); } }  /* launch_block: never (10,2,2) */ \
         else if (ap3) CFD_BLK_P(A_, T_, D_, R_, 3, false);                           \
         else CFD_BLK_P(A_, T_, D_, R_, 2, false);                                    \
     } while (0)

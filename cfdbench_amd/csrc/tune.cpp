@@ -31,8 +31,8 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
     {"conv1_mfma", "CFD_CONV1_MFMA", {-1}},      // 0 = 1x1 convolutions on the general gather kernels instead of the streamed matrix-pipe kernels of conv1.hip
                                                  // (on by default since round 4: full GPU suite green with it, U-Net step -1 %: profiles/r04c_conv1_mfma.txt)
     {"side_stream", "CFD_SIDE_STREAM", {-1}},    // mask of the side-stream users (side.cpp): 1 = label energy, 2 = 1x1 weight gradient; default 0 = none (measured a net loss)
-    {"act_pieces", "CFD_ACT_PIECES", {-1}},      // bf16 pieces of the ACTIVATION operand of the FNO contractions: 2 (default, 2^-16 per product) or 3
-                                                 // (fp32-exact class, six MFMAs per product; cfd_common.h)
+    {"act_pieces", "CFD_ACT_PIECES", {-1}},      // bf16 pieces of the ACTIVATION operand of the FNO contractions: 3 (default since round 5: fp32-exact class, six
+                                                 // MFMAs per product; cfd_common.h) or 2 (2^-16 per product, the round 1-4 default: ~8 % faster)
     {"block_gen", "CFD_BLOCK_GEN", {-1}},        // 0 = the FnoBlock of grids other than 64-wide / H % 16 == 0 (66 x 65) as two passes instead of the fused kernel
     {"gemm_tile", "CFD_GEMM_TILE", {-1}},        // block tile of the fp32 GEMM (dense.hip): 128 = 128 x 128, 1 = 128 rows x all columns, 8 = 128 x 64 on eight waves;
                                                  // default 64 x 64 (the fastest on every product of the benchmark)
@@ -50,7 +50,7 @@ int cfd_tune_get(int which) {
     return g_knobs[which].value.load(std::memory_order_relaxed);
 }
 
-int cfd_act_pieces() { return cfd_tune_get(CFD_TUNE_ACT_PIECES) == 3 ? 3 : 2; }
+int cfd_act_pieces() { return cfd_tune_get(CFD_TUNE_ACT_PIECES) == 2 ? 2 : 3; }  // round 5: fp32-exact class is the default
 
 extern "C" int cfd_tune_set(const char* name, int value) {
     CFD_REQUIRE(name != nullptr, CFD_ERR_INVALID_ARG, "cfd_tune_set: NULL name");

@@ -128,26 +128,96 @@ def backward_phase_slices(offsets: Sequence[int], numel: int, num_layers: int) -
     return sl
 
 
+class FlatGradExchange:
+    """Data-parallel gradient exchange of the AUTOGRAD training paths (U-Net, ResNet, the DeepONet family; eager or replayed from
+    HIP graphs -- graph.GraphedTrainStep): after a backward pass every parameter gradient is packed, pre-scaled by 1 / world, into
+    ONE flat fp32 buffer by one launch per 80 tensors (``cfd_scale_copy_multi``; complex gradients as (re, im) pairs), the buffer is
+    SUM-all-reduced (RCCL over xGMI on GPUs; gloo in the CPU tests, staged through the host for device tensors like GradSync), and
+    the parameters' ``.grad`` are re-pointed at views of the buffer, so the optimizer reads the reduced values where they are: no
+    scatter-back.  DistributedDataParallel semantics (per-rank loss normalisers, averaged gradients).  (Rounds 1-4: ``torch.cat`` +
+    all-reduce + ``mul_`` + one ``copy_`` launch per tensor, eager only.)"""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], group=None):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGradExchange: no trainable parameters")
+        self.sync = GradSync(group)
+        self.world = self.sync.world
+        dev = self.params[0].device
+        self.offsets, self.numel = flatten_layout(self.params)
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.views: List[Tensor] = []  # what the optimizer reads: one view per parameter, the parameter's shape and dtype
+        self._real_views: List[Tensor] = []
+        for p_, off in zip(self.params, self.offsets):
+            n = p_.numel() * (2 if p_.is_complex() else 1)
+            sl = self.flat[off:off + n]
+            self._real_views.append(sl)
+            self.views.append(torch.view_as_complex(sl.view(*p_.shape, 2)) if p_.is_complex() else sl.view(p_.shape))
+        self._table = None  # (key, ctypes tables) of the last pack
+
+    def _sources(self) -> List[Tensor]:
+        src = []
+        for p_ in self.params:
+            g = p_.grad
+            if g is None:
+                raise RuntimeError("FlatGradExchange.pack: a trainable parameter has no gradient (every parameter must take part in the "
+                                   "loss: the flat buffer is exchanged whole)")
+            g = torch.view_as_real(g) if g.is_complex() else g
+            src.append(g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous())
+        return src
+
+    def pack(self) -> None:
+        """``.grad`` of every parameter (wherever autograd left it) -> the flat buffer, times 1 / world."""
+        src = self._sources()
+        scale = 1.0 / self.world
+        if self.flat.is_cuda:
+            key = tuple(t.data_ptr() for t in src)
+            if self._table is None or self._table[0] != key:
+                col = lambda vals, ty: (ty * len(vals))(*vals)  # noqa: E731
+                self._table = (key, (len(src), col(list(key), ctypes.c_void_p), col([v.data_ptr() for v in self._real_views], ctypes.c_void_p),
+                                     col([t.numel() for t in src], ctypes.c_size_t)))
+            n, sp, dp, nn = self._table[1]
+            self._keep = src  # (temporaries of non-contiguous gradients live until the next pack)
+            _lib.api().call("cfd_scale_copy_multi", n, sp, dp, nn, float(scale), torch.cuda.current_stream().cuda_stream)
+        else:  # host tensors (the gloo tests of the exchange logic)
+            with torch.no_grad():
+                for d, t in zip(self._real_views, src):
+                    d.copy_(t.reshape(-1)).mul_(scale)
+
+    def reduce(self) -> None:
+        """SUM all-reduce of the flat buffer (ordered after the work enqueued on the current stream)."""
+        self.sync.wait_all([self.sync.reduce_slice_async(self.flat, a, b) for a, b in self.sync.bucket_slices(self.numel)])
+
+    def install(self) -> None:
+        """``p.grad`` = the parameter's view of the flat buffer (what ``optimizer.step()`` then reads)."""
+        for p_, v in zip(self.params, self.views):
+            p_.grad = v
+
+    def exchange(self) -> None:
+        self.pack()
+        self.reduce()
+        self.install()
+
+
+_exchanges: Dict[Tuple[int, ...], FlatGradExchange] = {}
+
+
 def sync_gradients(params: Sequence[torch.nn.Parameter], group=None) -> None:
-    """Data-parallel gradient averaging for the autograd training path (any model): every ``.grad`` is packed into ONE
-    flat fp32 buffer (complex gradients as (re, im) pairs), summed over the ranks in a single all-reduce (RCCL over xGMI
-    on GPUs, gloo in the CPU tests), scaled by 1/world and scattered back.  Same semantics as DistributedDataParallel."""
+    """Data-parallel gradient averaging for the eager autograd training path (any model): FlatGradExchange on the parameters that
+    received a gradient -- one pack launch per 80 tensors, ONE all-reduce, ``.grad`` left as views of the reduced flat buffer.
+    Same semantics as DistributedDataParallel.  No-op outside a process group / in a one-rank group."""
     if not (dist.is_available() and dist.is_initialized()):
         return
-    world = dist.get_world_size(group)
-    if world == 1:
+    if dist.get_world_size(group) == 1 and os.environ.get("CFDBENCH_DP_ALWAYS_EXCHANGE", "0") != "1":
         return
-    grads = [torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad for p in params if p.grad is not None]
-    if not grads:
+    ps = [p_ for p_ in params if p_.requires_grad and p_.grad is not None]
+    if not ps:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat.mul_(1.0 / world)
-    off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
-        off += n
+    key = tuple(id(p_) for p_ in ps) + (id(group),)
+    ex = _exchanges.get(key)
+    if ex is None or any(a is not b for a, b in zip(ex.params, ps)):
+        ex = _exchanges[key] = FlatGradExchange(ps, group)
+    ex.exchange()
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:

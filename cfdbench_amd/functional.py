@@ -1198,12 +1198,18 @@ class DropoutGeluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, p: float, seed: int, step: Optional[Tensor] = None):
         """``step`` (a 0-d int64 CUDA tensor): the stream's step counter on the device; the mask's seed is then
-        mix64(seed + step) & (2^48 - 1), formed by the kernel -- a captured train step draws a new mask on every replay."""
+        mix64(seed + step) & (2^48 - 1), formed by the kernel -- a captured train step draws a new mask on every replay.
+        The caller hands over a tensor that is NOT modified between this forward and its backward (ResNet.forward passes a per-call
+        snapshot of its counter); it is saved through save_for_backward, so an in-place change raises instead of silently
+        regenerating a different mask."""
         _require_cuda(x)
         x = _f32c(x)
         ctx.fused = x.numel() % 4 == 0 and x.data_ptr() % 16 == 0
         ctx.step = step if (step is not None and p > 0) else None
         if ctx.step is not None and not ctx.fused:  # (the two-pass fallback takes a host seed: one synchronisation, not capturable)
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("DropoutGeluFn: the two-pass fallback (element count not a multiple of 4, or an unaligned tensor) reads "
+                                   "the step counter on the host and cannot run inside a stream capture; use shapes the fused kernel takes")
             seed = DropoutGeluFn._mix64(int(seed) + int(step.item())) & 0xFFFFFFFFFFFF
             ctx.step = None
         ctx.meta = (float(p), int(seed))
@@ -1211,7 +1217,8 @@ class DropoutGeluFn(torch.autograd.Function):
         api = _lib.api()
         if ctx.fused and ctx.step is not None:
             api.call("cfd_dropout_gelu_fwd_step", _ptr(x), _ptr(y), x.numel(), float(p), int(seed), _ptr(ctx.step), _stream())
-            ctx.save_for_backward(x)
+            ctx.save_for_backward(x, ctx.step)  # the counter too: autograd's version check guards it
+            ctx.step = True
         elif ctx.fused:
             api.call("cfd_dropout_gelu_fwd", _ptr(x), _ptr(y), x.numel(), float(p), int(seed), _stream())
             ctx.save_for_backward(x)
@@ -1226,15 +1233,16 @@ class DropoutGeluFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy: Tensor):
-        (x,) = ctx.saved_tensors
+        x = ctx.saved_tensors[0]
         p, seed = ctx.meta
         gy = _f32c(gy)
         gx = torch.empty_like(x)
         api = _lib.api()
         if ctx.step is not None:
+            step = ctx.saved_tensors[1]
             if gy.data_ptr() % 16 != 0:
                 gy = gy.clone()  # (a fresh allocation is 16-byte aligned)
-            api.call("cfd_dropout_gelu_bwd_step", _ptr(x), _ptr(gy), _ptr(gx), x.numel(), p, seed, _ptr(ctx.step), _stream())
+            api.call("cfd_dropout_gelu_bwd_step", _ptr(x), _ptr(gy), _ptr(gx), x.numel(), p, seed, _ptr(step), _stream())
             return gx, None, None, None
         if ctx.fused and gy.data_ptr() % 16 == 0:
             api.call("cfd_dropout_gelu_bwd", _ptr(x), _ptr(gy), _ptr(gx), x.numel(), p, seed, _stream())

@@ -6,7 +6,16 @@ buffers before each replay; shapes are fixed per instance.
 
 ``restore_state=True`` (the harness, ``train_auto --graph 1``): the warm-up steps that precede the capture must not count as
 training, so parameters, buffers and optimiser state are snapshotted first and restored IN PLACE afterwards (the captured graph
-holds their addresses); optimiser state that the warm-up created is reset to its initial value (zeros)."""
+holds their addresses); optimiser state that the warm-up created is reset to its initial value (zeros).
+
+Data parallel (round 5; SURVEY 8 a-11 / 8e for configs[2] and configs[3], whose models train through autograd): inside a process
+group of more than one rank the step is TWO graphs with the exchange between them --
+    graph A   forward + backward + one pack launch per 80 tensors: every parameter gradient, pre-scaled by 1 / world, into ONE flat buffer
+    exchange  SUM all-reduce of that buffer (RCCL over xGMI; ``engine.FlatGradExchange``), enqueued eagerly between the replays
+    graph B   optimizer.step() reading the reduced gradients through ``.grad`` views of the flat buffer
+-- DistributedDataParallel semantics, no per-tensor copies, no host synchronisation.  Every rank must construct the object and call
+it the same number of times (the warm-up steps exchange too, so that replicas which are not restored stay identical).
+``capture=False`` runs the same three stages eagerly (batches of another shape; host tensors in the gloo tests of the logic)."""
 from __future__ import annotations
 
 from typing import Dict, Optional
@@ -17,10 +26,21 @@ from torch import Tensor
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, example_batch: Dict[str, Optional[Tensor]], loss_name: str = "nmse", warmup: int = 3,
-                 restore_state: bool = False):
+                 restore_state: bool = False, group=None, capture: bool = True):
+        from .engine import GradSync
         self.model, self.optimizer, self.loss_name = model, optimizer, loss_name
         self.static = {k: (v.clone() if v is not None else None) for k, v in example_batch.items()}
         self.shapes = {k: (tuple(v.shape) if v is not None else None) for k, v in example_batch.items()}
+        # data parallel: the exchange object is made after the first backward pass, over the parameters that received a gradient
+        # (the ResNet keeps the reference's unused bn1 / bn2 parameters)
+        self.dp, self.group, self.exchange = GradSync(group).exchange, group, None
+        self.capture = bool(capture)
+        self.graph = self.graph_opt = None
+        self.loss = self.preds = None
+        if not self.capture:
+            return
+        if self.dp and warmup < 1:
+            raise ValueError("GraphedTrainStep: the data-parallel capture needs at least one warm-up step")
         snap = None
         if restore_state:
             snap = ([t.detach().clone() for t in list(model.parameters()) + list(model.buffers())],
@@ -29,10 +49,7 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):  # lazy initialisation (optimizer state, plans, allocator pools) outside the capture
-                optimizer.zero_grad(set_to_none=True)
-                out = model(**self.static)
-                out["loss"][loss_name].backward()
-                optimizer.step()
+                self.eager_step(self.static)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
@@ -41,7 +58,19 @@ class GraphedTrainStep:
             self.loss = {k: v for k, v in out["loss"].items()}
             self.preds = out["preds"]
             self.loss[loss_name].backward()
-            optimizer.step()
+            if self.exchange is None:
+                optimizer.step()
+            else:
+                self.exchange.pack()
+        self._raw_grads = [p.grad for p in model.parameters()]
+        if self.exchange is not None:
+            # the pack launch of graph A reads the gradient tensors autograd allocated during the capture (graph-private pool): they
+            # must outlive the parameters' .grad, which from here on are views of the flat buffer
+            self.exchange.reduce()  # (one eager exchange before the second capture: communicator warm-up on this stream)
+            self.exchange.install()
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+                optimizer.step()
         if snap is not None:
             with torch.no_grad():
                 for t, saved in zip(list(model.parameters()) + list(model.buffers()), snap[0]):
@@ -50,7 +79,24 @@ class GraphedTrainStep:
                     for t in st.values():
                         if torch.is_tensor(t):
                             t.copy_(snap[1][id(t)]) if id(t) in snap[1] else t.zero_()
-            optimizer.zero_grad(set_to_none=False)  # the captured backward accumulates into these gradient tensors
+            if self.exchange is None:
+                optimizer.zero_grad(set_to_none=False)  # the captured backward accumulates into these gradient tensors
+
+    def eager_step(self, batch: Dict[str, Optional[Tensor]]) -> Dict[str, Tensor]:
+        """The same optimisation step without a graph (any batch shape): forward, backward, (exchange,) optimizer."""
+        # one process, after the capture: the gradient tensors of the capture stay the parameters' .grad (zeroed, accumulated into)
+        keep = self.graph is not None and self.exchange is None
+        self.optimizer.zero_grad(set_to_none=not keep)
+        out = self.model(**batch)
+        out["loss"][self.loss_name].backward()
+        if self.dp:
+            if self.exchange is None:
+                from .engine import FlatGradExchange
+                self.exchange = FlatGradExchange([p for p in self.model.parameters() if p.grad is not None], self.group)
+            self.exchange.exchange()
+        self.optimizer.step()
+        self._eager_preds = out["preds"]
+        return out["loss"]
 
     def matches(self, batch: Dict[str, Optional[Tensor]]) -> bool:
         """True when ``batch`` has the captured shapes (a short last batch of an epoch has not: run it eagerly)."""
@@ -59,9 +105,16 @@ class GraphedTrainStep:
 
     def __call__(self, **batch) -> Dict[str, Tensor]:
         """One optimisation step on ``batch`` (same shapes as the example); returns the static loss tensors."""
+        if not self.capture:
+            loss = self.eager_step(batch)
+            self.preds = self._eager_preds
+            return loss
         for k, v in batch.items():
             dst = self.static.get(k)
             if dst is not None and v is not None and v.data_ptr() != dst.data_ptr():
                 dst.copy_(v, non_blocking=True)
         self.graph.replay()
+        if self.exchange is not None:
+            self.exchange.reduce()
+            self.graph_opt.replay()
         return self.loss

@@ -96,5 +96,4 @@ def is_args_valid(args: Args) -> None:
     if args.graph:
         assert not args.fused, "--graph 1 captures the autograd step; the fused FNO engine has its own launch path"
         assert args.gradient_accumulation_steps == 1, "--graph 1 captures one optimiser step per batch"
-        assert args.model != "resnet", "--graph 1: the ResNet's dropout takes a per-step host seed (not capturable)"
     assert args.unet_insert_case_params_at in ("input", "hidden")

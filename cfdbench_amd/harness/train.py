@@ -102,7 +102,7 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
           early_stopping_patience: int = 0, early_stopping_delta: float = 1e-5, gradient_accumulation_steps: int = 1,
           graph: bool = False):
     """src/train.py:148-253: fwd -> ``loss["nmse"].backward()`` -> Adam -> zero_grad; StepLR per epoch.
-    ``graph``: the step replayed from one HIP graph (harness/train_auto.py:train has the semantics; one process, no accumulation).
+    ``graph``: the step replayed from HIP graphs (harness/train_auto.py:train has the semantics; no accumulation; several ranks: graph.py).
     ``resume``: continue from ``train_state.pt`` (see harness/train_auto.py:train).  ``lr_scheduler_kind`` /
     ``early_stopping_patience`` / ``gradient_accumulation_steps``: the same options, with the same semantics, as
     harness/train_auto.py:train (harness/schedule.py); the defaults are the reference's loop."""
@@ -120,8 +120,8 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
         output_dir.mkdir(exist_ok=True, parents=True)
     accum = max(1, int(gradient_accumulation_steps))
     if graph:
-        if world > 1 or accum > 1:
-            raise NotImplementedError("--graph 1 needs one process and gradient_accumulation_steps == 1")
+        if accum > 1:
+            raise NotImplementedError("--graph 1 needs gradient_accumulation_steps == 1")
         # fused: ONE multi-tensor kernel per step (the capturable foreach form with a device-resident rate takes ~2.7 ms for the U-Net's
         # 136 tensors, tools/exp/adam_fused_ab.py); same formula, results within rounding of the foreach form
         from ..optim import Adam as MultiTensorAdam
@@ -174,7 +174,11 @@ def train(model: CfdModel, train_data, dev_data, output_dir: Path, num_epochs: i
                     graphed = GraphedTrainStep(model, optimizer, batch, "nmse", restore_state=True)
                 if graphed is not None and graphed.matches(batch):
                     loss = graphed(**batch)["nmse"]
+                elif graphed is not None:  # a batch of another shape: the same step (and gradient exchange), eagerly
+                    loss = graphed.eager_step(batch)["nmse"]
                 else:
+                    if world > 1:
+                        raise NotImplementedError("--graph 1 with several ranks needs at least two batches per epoch and rank")
                     optimizer.zero_grad(set_to_none=False)
                     loss = model(**batch)["loss"]["nmse"]
                     loss.backward()

@@ -159,7 +159,7 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
           early_stopping_delta: float = 1e-5, gradient_accumulation_steps: int = 1, act_dtype: str = "fp32", graph: bool = False):
     """train_auto.py:181-313.  ``fused`` selects FnoTrainEngine (needs an Fno2d and the nmse loss).
 
-    ``graph`` (autograd path, one process): the step ``model(**batch) -> loss["nmse"].backward() -> Adam.step()`` is captured once
+    ``graph`` (autograd path; with several ranks the gradient exchange sits between two graphs, cfdbench_amd/graph.py): the step ``model(**batch) -> loss["nmse"].backward() -> Adam.step()`` is captured once
     as a HIP graph (cfdbench_amd/graph.py) at the first full batch and replayed for every batch of that shape; a short last batch
     runs eagerly on the same (capturable) optimiser.  Per-step losses stay on the device and are fetched once per epoch.  The
     kernels are the same; what goes away is the per-operator host work of the eager loop (U-Net dim 12, B = 128: 5.2 -> 4.0 ms per
@@ -208,9 +208,10 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
         engine = FnoTrainEngine(model, lr=lr, loss_name="nmse", act_dtype=act_dtype)
         optimizer = None
     elif graph:
-        if world > 1 or accum > 1 or getattr(model, "graph_unsafe", False):
-            raise NotImplementedError("--graph 1 needs one process, gradient_accumulation_steps == 1 and a model without per-step "
-                                      "host state (the ResNet's dropout seed)")
+        if accum > 1 or getattr(model, "graph_unsafe", False):
+            raise NotImplementedError("--graph 1 needs gradient_accumulation_steps == 1 and a model without per-step host state")
+        # world > 1 (round 5): graph.GraphedTrainStep replays forward + backward + gradient pack, exchanges the flat gradient over the
+        # process group and replays the optimizer from a second graph
         # fused: ONE multi-tensor kernel per step (the capturable foreach form with a device-resident rate takes ~2.7 ms for the U-Net's
         # 136 tensors, tools/exp/adam_fused_ab.py); same formula, results within rounding of the foreach form
         from ..optim import Adam as MultiTensorAdam
@@ -281,7 +282,12 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
                 if graphed is not None and graphed.matches(batch):
                     loss = graphed(**batch)
                     preds = graphed.preds
-                else:  # a batch of another shape: the same step, eagerly
+                elif graphed is not None:  # a batch of another shape: the same step (and exchange), eagerly
+                    loss = graphed.eager_step(batch)
+                    preds = graphed._eager_preds
+                else:  # a one-batch epoch: nothing to capture on
+                    if world > 1:
+                        raise NotImplementedError("--graph 1 with several ranks needs at least two batches per epoch and rank")
                     optimizer.zero_grad(set_to_none=False)
                     outputs = model(**batch)
                     loss, preds = outputs["loss"], outputs["preds"]

@@ -96,8 +96,12 @@ class ResNet(AutoCfdModel):
         if self.training:
             with torch.no_grad():
                 self._drop_step.add_(1)
+                # This forward's value of the counter as a tensor of its own (one 8-byte device copy, capturable): the backward of THIS
+                # forward regenerates its masks from it whatever happens to the live counter in between (a second training forward
+                # before the backward -- `model(a) + model(b)`, deferred backward of an accumulation step -- bumps `_drop_step`).
+                step_now = self._drop_step.clone()
             for blk in self.blocks:
-                blk.drop_step = self._drop_step
+                blk.drop_step = step_now
         x = self.blocks(torch.cat([inputs, mask, cp], dim=1))
         preds = F_.ResidualMaskFn.apply(x, residual, mask)  # (blocks + inputs[:, :out_chan]) * mask
         if label is not None:

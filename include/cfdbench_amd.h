@@ -36,6 +36,11 @@ extern "C" {
 
 #define CFD_MAX_LAYERS 16
 
+/* ABI version of this header; cfd_version() returns the library's.  Bumped whenever a buffer layout behind an unchanged signature
+ * changes (500, round 5: the statistics records of cfd_conv2d_fwd_stats / cfd_batchnorm_fwd_stats are (C, slots, 4) floats since
+ * round 4 -- a caller that still allocates (C, slots, 2) must fail at load time, not write out of bounds; the default of the
+ * "act_pieces" knob is 3).  The Python binding refuses a library whose version differs (cfdbench_amd/_capi.py). */
+#define CFD_ABI_VERSION 500
 int cfd_version(void);
 const char* cfd_last_error(void);
 
@@ -204,6 +209,11 @@ int cfd_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_av
 int cfd_adam_multi(int n, float* const* param, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
                    const size_t* numel, const float* lr_dev, float lr, const float* step_dev, float step, float beta1, float beta2,
                    float eps, float weight_decay, float grad_scale, void* stream);
+
+/* dst[k][i] = scale * src[k][i] for n fp32 tensors in one launch per 80 (host tables of device pointers and element counts).  The
+ * data-parallel gradient exchange of the autograd training paths (a-11; no reference symbol): every parameter gradient, pre-scaled by
+ * 1 / world, into one flat all-reduce buffer.                                                                                      */
+int cfd_scale_copy_multi(int n, const float* const* src, float* const* dst, const size_t* numel, float scale, void* stream);
 
 /* ---- dense layers of the DeepONet family (fp32 MFMA GEMMs) ----------------------------------------------*/
 

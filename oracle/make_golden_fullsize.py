@@ -167,6 +167,79 @@ def gen_resnet_big(name, seed, bseed, B, H, W, hidden, depth, p=5, steps=2):
     print(name, "ok", {k: float(v) for k, v in out["loss"].items()}, save["frames"].shape)
 
 
+def gen_unet_batch(name, seed, bseed, B, H, W, dim, p):
+    """configs[2] at its OWN batch (B = 128 per GPU), fingerprint form (VERDICT r4 missing #5): predictions (training and eval mode)
+    as per-sample norms + sampled entries, loss, running statistics, and TWO sets of gradient fingerprints from the reference module --
+    its fp64 backward (``gsum::``: the exact answer) and its native fp32 backward (``g32sum::``: what the reference itself returns,
+    ``ref32_vs_64`` away from the former because of ReLU / max-pool kinks)."""
+    from models.unet import UNet  # reference
+
+    def run(dt):
+        model = UNet(2, 2, MseLoss(normalize=True), p, insert_case_params_at="input", bilinear=False, dim=dim)
+        sd = synth.make_state_dict([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed)
+        model.load_state_dict({k: _t(v) for k, v in sd.items()})
+        model = model.to(dt)
+        batch = synth.make_smooth_batch(bseed, B, H, W, p)
+        batch["mask"][:, :, 0, :] = 0
+        batch["mask"][:, :, :, 0] = 0
+        tb = {k: _t(v).to(dt) for k, v in batch.items()}
+        model.train()
+        out = model(inputs=tb["inputs"], case_params=tb["case_params"], mask=tb["mask"], label=tb["label"])
+        out["loss"]["nmse"].backward()
+        return model, sd, tb, out
+
+    model, sd, tb, out = run(torch.float32)
+    m64, _, _, out64 = run(torch.float64)
+    preds = out["preds"].detach().numpy()
+    save = dict(meta=np.array([seed, bseed, B, H, W, dim, p]),
+                preds_sample_norms=np.sqrt((preds.astype(np.float64) ** 2).sum(axis=(1, 2, 3))),
+                **{f"loss_{k}": np.array(v.item()) for k, v in out["loss"].items()},
+                **{f"loss64_{k}": np.array(v.item()) for k, v in out64["loss"].items()})
+    for kk, vv in synth.summarize(preds, 11, n=4096).items():
+        save[f"psum::{kk}"] = vv
+    _grad_fingerprints(m64, save, n=256)
+    for k, prm in model.named_parameters():
+        for kk, vv in synth.summarize(prm.grad.numpy(), 7, n=256).items():
+            save[f"g32sum::{k}::{kk}"] = vv
+    g32 = {k: prm.grad.numpy() for k, prm in model.named_parameters()}
+    dev = [float(np.mean((g32[k] - prm.grad.numpy()) ** 2) / np.mean(prm.grad.numpy() ** 2))
+           for k, prm in m64.named_parameters() if float(prm.grad.abs().max()) > 1e-7]
+    save["ref32_vs_64"] = np.array(max(dev))
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            save[f"after::{k}"] = v.numpy().copy()
+    model.load_state_dict({k: _t(v) for k, v in sd.items()})
+    model.eval()
+    with torch.no_grad():
+        ev = model(inputs=tb["inputs"], case_params=tb["case_params"], mask=tb["mask"])["preds"].numpy()
+    for kk, vv in synth.summarize(ev, 13, n=4096).items():
+        save[f"esum::{kk}"] = vv
+    np.savez_compressed(OUT / f"{name}.npz", **save)
+    print(name, "ok", {k: float(v.detach()) for k, v in out["loss"].items()}, "fp32 vs fp64 reference gradients:", max(dev))
+
+
+def gen_auto_deeponet_batch(name, pseed, bseed, B, H, W, width, depth, p):
+    """configs[3] at its OWN batch (B = 512 per GPU), fingerprint form: predictions (per-sample norms + sampled entries), loss, every
+    parameter gradient of the reference's fp32 backward."""
+    from models.auto_deeponet import AutoDeepONet  # reference
+    from oracle import deeponet_oracle as D
+    params = D.make_params(pseed, H * W + p, width, depth, depth)
+    batch = synth.make_smooth_batch(bseed, B, H, W, p)
+    model = AutoDeepONet(H * W + p, 2, MseLoss(normalize=True), branch_depth=depth, trunk_depth=depth, width=width, act_name="relu")
+    model.load_state_dict({k: _t(v) for k, v in params.items()})
+    out = model(inputs=_t(batch["inputs"]), case_params=_t(batch["case_params"]), label=_t(batch["label"]), mask=_t(batch["mask"]))
+    out["loss"]["nmse"].backward()
+    preds = out["preds"].detach().numpy()
+    save = dict(meta=np.array([pseed, bseed, B, H, W, width, depth, p]),
+                preds_sample_norms=np.sqrt((preds.astype(np.float64) ** 2).reshape(B, -1).sum(axis=1)),
+                **{f"loss_{k}": np.array(v.item()) for k, v in out["loss"].items()})
+    for kk, vv in synth.summarize(preds, 11, n=4096).items():
+        save[f"psum::{kk}"] = vv
+    _grad_fingerprints(model, save, n=256)
+    np.savez_compressed(OUT / f"{name}.npz", **save)
+    print(name, "ok", {k: float(v) for k, v in out["loss"].items()}, preds.shape)
+
+
 GENERATORS = {
     "fno_cfg2_b256": lambda: gen_fno_big("fno_cfg2_b256", 201, 211, 256, 20, 4, 64, 64, 5),
     "fno_cyl_p8_64x64": lambda: gen_fno_big("fno_cyl_p8_64x64", 202, 212, 3, 20, 4, 64, 64, 8),
@@ -175,6 +248,9 @@ GENERATORS = {
     "rollout200_c32_66x65": lambda: gen_rollout200("rollout200_c32_66x65", 205, 215, 2, 32, 4, 66, 65, 200),
     # the same horizon with the blocks' identity routed through SpectralConv2d (round 3: the transforms' fixed operands on the identity path)
     "rollout200_spectral_c32_66x65": lambda: gen_rollout200("rollout200_spectral_c32_66x65", 207, 217, 2, 32, 4, 66, 65, 200, route="spectral"),
+    # the configs' own per-GPU batches (round 5)
+    "unet_dim12_p8_b128": lambda: gen_unet_batch("unet_dim12_p8_b128", 203, 223, 128, 64, 64, 12, 8),
+    "auto_deeponet_b512_66x65": lambda: gen_auto_deeponet_batch("auto_deeponet_b512_66x65", 204, 224, 512, 66, 65, 100, 8, 5),
     "resnet_h16_d4_64x64": lambda: gen_resnet_big("resnet_h16_d4_64x64", 206, 216, 4, 64, 64, 16, 4),
 }
 

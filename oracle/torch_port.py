@@ -89,3 +89,49 @@ def time_train_steps(B: int, steps: int, warmup: int = 1, C: int = 20, L: int = 
     times.sort()
     med = times[len(times) // 2]
     return dict(frames_per_s=B / med, median_s=med, steps=steps, batch=B, threads=torch.get_num_threads())
+
+
+def reference_importable(root: str = "/root/reference/src") -> bool:
+    """True when the reference's own Fno2d imports (the build container; the GPU box has no /root/reference)."""
+    import os
+    import sys
+    if not os.path.isdir(root):
+        return False
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    try:
+        from models.fno.fno2d import Fno2d  # noqa: F401  (reference)
+        from models.loss import MseLoss  # noqa: F401
+        return True
+    except Exception:  # noqa: BLE001
+        return False
+
+
+def time_reference_steps(B: int, steps: int, warmup: int = 1, C: int = 20, L: int = 4, H: int = 64, W: int = 64,
+                         p: int = 5, threads: int | None = None) -> Dict:
+    """The SAME loop on the reference's own module (src/models/fno/fno2d.py:Fno2d, src/train_auto.py:231-257) -- SURVEY 8(d)'s CPU
+    baseline "kind: reference"; only where /root/reference/src imports."""
+    from models.fno.fno2d import Fno2d  # reference
+    from models.loss import MseLoss
+    if threads:
+        torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    model = Fno2d(2, 2, p, MseLoss(normalize=True), L, 12, 12, C)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(1234)
+    inputs = torch.randn(B, 2, H, W, generator=g)
+    label = inputs + 0.1 * torch.randn(B, 2, H, W, generator=g)
+    cp = torch.randn(B, p, generator=g)
+    mask = torch.ones(B, 1, H, W)
+    times: List[float] = []
+    for s in range(warmup + steps):
+        t0 = time.perf_counter()
+        out = model(inputs=inputs, case_params=cp, mask=mask, label=label)
+        out["loss"]["nmse"].backward()
+        opt.step()
+        opt.zero_grad()
+        if s >= warmup:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(frames_per_s=B / med, median_s=med, steps=steps, batch=B, threads=torch.get_num_threads())

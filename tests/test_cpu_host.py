@@ -167,6 +167,90 @@ def test_one_rank_group_runs_the_collectives_only_when_asked():
     assert res == (False, True, True, 3, 1.0, True)
 
 
+class _TinyAuto:  # (built inside the workers: a torch module with the AutoCfdModel call interface)
+    @staticmethod
+    def make(torch):
+        class M(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                torch.manual_seed(3)
+                self.a = torch.nn.Linear(6, 5)
+                self.b = torch.nn.Linear(5, 6)
+                self.unused = torch.nn.Parameter(torch.zeros(4))  # never receives a gradient (the ResNet's bn1 / bn2)
+
+            def forward(self, inputs, label=None):
+                preds = self.b(torch.tanh(self.a(inputs)))
+                d = preds - label
+                return dict(preds=preds, loss=dict(nmse=(d * d).mean() / (label * label).mean(), mse=(d * d).mean()))
+        return M()
+
+
+def _graph_dp_batches(torch, rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return [dict(inputs=torch.randn(8, 6, generator=g), label=torch.randn(8, 6, generator=g)) for _ in range(4)]
+
+
+def _graph_dp_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cfdbench_amd.graph import GraphedTrainStep
+        m = _TinyAuto.make(torch)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+        batches = _graph_dp_batches(torch, rank)
+        gs = GraphedTrainStep(m, opt, batches[0], "nmse", capture=False)  # host tensors: the three stages run eagerly
+        assert gs.dp and gs.exchange is None
+        losses = [float(gs(**b)["nmse"]) for b in batches]
+        ex = gs.exchange
+        assert len(ex.params) == 4 and m.unused.grad is None
+        # the optimizer read the reduced gradients where they are: .grad is a view of the flat buffer
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(ex.params, ex.views))
+        q.put((rank, [p.detach().numpy().copy() for p in ex.params], losses))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_graph_step_data_parallel_gloo_world2_equals_ddp_emulation():
+    """GraphedTrainStep inside a two-rank group (pack every gradient pre-scaled into one flat buffer -> ONE
+    all-reduce -> optimizer on views of that buffer) follows the single-process emulation of DistributedDataParallel: per-rank loss,
+    averaged gradients, replicated Adam.  (`capture=False` runs the stages of the two graphs eagerly on host tensors; the captured
+    form runs in tests/test_gpu_dp.py.)"""
+    import torch
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # emulation: one replica, both shards, gradients averaged by hand
+    m = _TinyAuto.make(torch)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    shards = [_graph_dp_batches(torch, r) for r in range(2)]
+    ps = [m.a.weight, m.a.bias, m.b.weight, m.b.bias]
+    for k in range(4):
+        grads = []
+        for r in range(2):
+            opt.zero_grad(set_to_none=True)
+            m(**shards[r][k])["loss"]["nmse"].backward()
+            grads.append([p.grad.clone() for p in ps])
+        for p, g0, g1 in zip(ps, *grads):
+            p.grad = (g0 + g1) / 2
+        opt.step()
+    for r in range(2):
+        for got, want in zip(res[r][1], ps):
+            assert np.allclose(got, want.detach().numpy(), rtol=1e-5, atol=1e-7)
+    assert all(np.array_equal(a, b) for a, b in zip(res[0][1], res[1][1]))  # replicas stay identical bit for bit
+    assert res[0][2] != res[1][2]  # (different shards)
+
+
 def _sync_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist

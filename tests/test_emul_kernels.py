@@ -423,3 +423,19 @@ def test_three_piece_activations_whole_model(be):
         res = K.check_fno_vs_oracle(be, 2, 20, 2, 64, 64)
         assert res.pop("nmse_loss") < 1e-5  # a ratio of fp32 sums
         _assert_all(res, 3e-12)  # fp32 round-off through the whole network (the default route: 3e-12 predictions, <= 2e-11 gradients)
+
+
+def test_two_piece_activation_route_still_holds_its_tolerance(be):
+    """act_pieces = 2 (the default of rounds 1-4, now the selectable `split2` route of bench.py): activation operands in two bf16
+    pieces, rel. 2^-16 per product -- every contraction kernel and the whole model inside 1e-9 of the fp64 oracle.  (Everything else
+    in this file runs the round-5 default, three pieces.)"""
+    with K.tuned(be, act_pieces=2):
+        _assert_all(K.check_spectral(be, 2, 20, 20, 64, 64), 1e-9)
+        _assert_all(K.check_block(be, 1, 20, 20, 64, 64), 1e-9)
+        _assert_all(K.check_block(be, 1, 20, 20, 66, 65), 1e-9)
+        _assert_all(K.check_chanmix(be, 2, 20, 20, 64 * 64, 1), 1e-9)
+        for res in (K.check_head(be, 2, 20, 64 * 64, 1), K.check_head_train(be, 2, 20, 64 * 64, 1)):
+            _assert_all({k: v for k, v in res.items() if k not in ("sums", "scores")}, 1e-9)
+        res = K.check_fno_vs_oracle(be, 2, 20, 2, 64, 64)
+        assert res.pop("nmse_loss") < 1e-5
+        _assert_all(res, 1e-9)

@@ -161,3 +161,115 @@ def test_engine_train_step_over_rccl_one_rank_group(overlap, graph):
         torch.cuda.synchronize()
         assert np.array_equal(grads[step], eng.flat.grad.cpu().numpy()), f"step {step}: gradient after the RCCL exchange differs"
     assert np.array_equal(params, eng.flat.data.cpu().numpy())
+
+
+# ---- data parallelism for the graph-replayed models: U-Net (configs[2]) and Auto-DeepONet (configs[3]) --------
+def _auto_model(torch, name):
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    torch.manual_seed(17)
+    if name == "unet":
+        from cfdbench_amd.models.unet import UNet
+        return UNet(2, 2, loss_name_to_fn("nmse"), n_case_params=3, insert_case_params_at="input", dim=4).cuda().train()
+    from cfdbench_amd.models.auto_deeponet import AutoDeepONet
+    return AutoDeepONet(16 * 16 + 3, 2, loss_name_to_fn("nmse"), num_label_samples=64, width=12, trunk_depth=3, branch_depth=3).cuda().train()
+
+
+def _auto_batch(torch, step, rank):
+    b = synth.make_smooth_batch(500 + 7 * step + rank, 4, 16, 16, 3)
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in b.items()}
+
+
+def _auto_optimizer(torch, m):
+    from cfdbench_amd.optim import Adam
+    return Adam(m.parameters(), lr=1e-3)
+
+
+def _graph_dp_worker(rank, world, port, backend, name, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo")
+    if world == 1:
+        os.environ["CFDBENCH_DP_ALWAYS_EXCHANGE"] = "1"
+    torch.cuda.set_device(0)
+    kw = dict(device_id=torch.device("cuda", 0)) if backend == "nccl" else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    try:
+        from cfdbench_amd.graph import GraphedTrainStep
+        m = _auto_model(torch, name)
+        opt = _auto_optimizer(torch, m)
+        gs = GraphedTrainStep(m, opt, _auto_batch(torch, 0, rank), "nmse", restore_state=True)
+        assert gs.dp and gs.exchange is not None and gs.graph_opt is not None
+        losses = [float(gs(**_auto_batch(torch, s, rank))["nmse"].item()) for s in range(STEPS)]
+        losses.append(float(gs.eager_step(_auto_batch(torch, STEPS, rank))["nmse"].item()))  # a step outside the graphs exchanges too
+        losses.append(float(gs(**_auto_batch(torch, STEPS + 1, rank))["nmse"].item()))      # ... and the graphs still replay after it
+        torch.cuda.synchronize()
+        q.put((rank, [p.detach().cpu().numpy().copy() for p in m.parameters()], losses))
+    finally:
+        dist.destroy_process_group()
+
+
+def _graph_dp_reference(torch, name, world):
+    """One replica, the ranks' shards one after the other, gradients averaged by hand, the same one-launch Adam."""
+    m = _auto_model(torch, name)
+    opt = _auto_optimizer(torch, m)
+    ps = [p for p in m.parameters()]
+    for s in range(STEPS + 2):
+        grads = []
+        for r in range(world):
+            opt.zero_grad(set_to_none=True)
+            m(**_auto_batch(torch, s, r))["loss"]["nmse"].backward()
+            grads.append([None if p.grad is None else p.grad.clone() for p in ps])
+        for i, p in enumerate(ps):
+            if grads[0][i] is not None:
+                p.grad = sum(g[i] for g in grads) / world
+        opt.step()
+    torch.cuda.synchronize()
+    return [p.detach().cpu().numpy() for p in ps]
+
+
+@pytest.mark.parametrize("name", ["unet", "auto_deeponet"])
+def test_graphed_train_step_world2_equals_ddp_emulation(name):
+    """Two processes on one GPU (gloo, host-staged exchange): forward + backward + gradient pack replayed from one graph, ONE all-reduce
+    of the flat gradient, Adam replayed from a second graph reading the reduced gradients in place -- against the single-process
+    emulation of DistributedDataParallel.  The captured Adam is the same kernel; BatchNorm statistics are per rank (DDP)."""
+    import torch
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_dp_worker, args=(r, 2, port, "gloo", name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = _graph_dp_reference(torch, name, 2)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a, b), "replicas diverged"
+    for got, ref in zip(res[0][1], want):
+        assert np.allclose(got, ref, rtol=2e-4, atol=2e-6)  # (sum order of the two shards' gradients; ReLU nets)
+    assert res[0][2] != res[1][2]
+
+
+def test_graphed_train_step_over_rccl_one_rank_group():
+    """The same two-graph step with the exchange on RCCL (backend "nccl", one-rank group with the collectives forced on): the
+    all-reduce is enqueued between the two replays on the communicator's stream.  SUM over one rank = identity, so the parameters
+    follow the single-process path."""
+    import torch
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_graph_dp_worker, args=(0, 1, _free_port(), "nccl", "unet", q))
+    proc.start()
+    try:
+        _, params, losses = q.get(timeout=300)
+    finally:
+        proc.join(timeout=120)
+        if proc.is_alive():
+            proc.kill()
+    assert proc.exitcode == 0
+    want = _graph_dp_reference(torch, "unet", 1)
+    for got, ref in zip(params, want):
+        assert np.allclose(got, ref, rtol=1e-5, atol=1e-7)
+    assert len(set(losses)) == len(losses)

@@ -184,9 +184,11 @@ def test_nonauto_train_graph_option(torch, tmp_path, model_name):
 
 def test_graph_option_is_refused_where_it_cannot_hold(torch, tmp_path):
     from cfdbench_amd.harness.args import Args, is_args_valid
-    for bad in (dict(model="resnet"), dict(model="fno", fused=1), dict(model="unet", gradient_accumulation_steps=2)):
+    for bad in (dict(model="fno", fused=1), dict(model="unet", gradient_accumulation_steps=2)):
         with pytest.raises(AssertionError):
             is_args_valid(Args(data_name="cavity_bc", graph=1, **bad))
+    # (round 5) the ResNet's dropout stream counter lives on the device since round 4: its step is capturable and no longer refused
+    is_args_valid(Args(data_name="cavity_bc", graph=1, model="resnet"))
 
 
 def test_train_with_device_batch_loader(torch, tmp_path):

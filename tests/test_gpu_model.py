@@ -581,6 +581,40 @@ def test_resnet_train_step_from_a_graph_advances_the_dropout_stream(torch):
         assert torch.equal(a, b), k
 
 
+def test_resnet_two_training_forwards_before_one_backward_keep_their_masks(torch):
+    """the backward of a training forward regenerates ITS dropout masks even when a second training forward ran in
+    between (`model(a) + model(b)`, deferred backward): each call keeps a snapshot of the step counter.  The gradients of the summed
+    loss equal the sum of the gradients of two separate forward / backward pairs at the same counter values."""
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    from cfdbench_amd.models.resnet import ResNet
+    B, H, W, p = 2, 16, 16, 3
+    ba = _cuda(torch, synth.make_smooth_batch(21, B, H, W, p))
+    bb = _cuda(torch, synth.make_smooth_batch(22, B, H, W, p))
+    torch.manual_seed(5)
+    m = ResNet(2, 2, p, loss_name_to_fn("nmse"), hidden_chan=8, num_blocks=1, kernel_size=7, padding=3).cuda().train()
+    # separately: counter 1 for a, counter 2 for b
+    sep = None
+    for batch in (ba, bb):
+        m.zero_grad(set_to_none=True)
+        m(**batch)["loss"]["nmse"].backward()
+        g = [None if q.grad is None else q.grad.clone() for q in m.parameters()]  # (the unused bn1 / bn2 parameters have none)
+        sep = g if sep is None else [None if x is None else x + y for x, y in zip(sep, g)]
+    # together: the same counter values (1, 2), ONE backward after both forwards
+    m.load_extra_train_state(dict(train_steps=0))
+    m.zero_grad(set_to_none=True)
+    la = m(**ba)["loss"]["nmse"]
+    lb = m(**bb)["loss"]["nmse"]
+    (la + lb).backward()
+    n = 0
+    for (k, q), ref in zip(m.named_parameters(), sep):
+        if ref is None:
+            assert q.grad is None, k
+            continue
+        assert torch.allclose(q.grad, ref, rtol=1e-5, atol=1e-8), k
+        n += 1
+    assert n >= 4
+
+
 # ---- non-autoregressive DeepONet / FfnModel drop-ins vs the reference modules' golden outputs -----------------------
 @pytest.mark.parametrize("name", ["deeponet_normact_relu", "deeponet_plain_tanh", "ffnmodel_normact_gelu"])
 def test_nonauto_models_vs_reference_golden(torch, golden_dir, name):
