@@ -9,7 +9,7 @@ void cfd_set_error(const char* fmt, ...);
 
 // dispatch overrides (tune.cpp): environment read once per process, cfd_tune_set() afterwards; -1 = built-in choice
 enum { CFD_TUNE_MIX_NWV = 0, CFD_TUNE_WGRAD_WG, CFD_TUNE_FUSED_VARIANT, CFD_TUNE_BLOCK_FUSE, CFD_TUNE_GENERAL_B3, CFD_TUNE_HEAD_BLOCKS, CFD_TUNE_EXACT_FP32, CFD_TUNE_CONV6_GRID, CFD_TUNE_CONV6_WGRAD_MUL, CFD_TUNE_CONVT_MFMA, CFD_TUNE_CONV1_MFMA, CFD_TUNE_SIDE_STREAM, CFD_TUNE_ACT_PIECES, CFD_TUNE_BLOCK_GEN,
-    CFD_TUNE_GEMM_TILE, CFD_TUNE_COUNT };
+    CFD_TUNE_GEMM_TILE, CFD_TUNE_GEMM_SPLITS, CFD_TUNE_BLOCK_WIDE, CFD_TUNE_COUNT };
 int cfd_tune_get(int which);
 
 #define CFD_REQUIRE(cond, code, ...)      \
@@ -420,6 +420,39 @@ __device__ __forceinline__ float cfd_row_sum(const float* __restrict__ row, int 
         for (int k = lane; k < n; k += 64) s += row[k];
     }
     return cfd_wave_sum(s);
+}
+
+// Sum over `nrec` BLOCK-MAJOR partial records (part[rec * stride + e]: what a producer workgroup writes with coalesced stores) of the 16
+// consecutive elements e0 .. e0 + 15.  Every thread of the workgroup takes part (blockDim.x a multiple of 64, <= 1024).  lane = (record
+// subset bq = lane >> 4, element el = lane & 15): a wave's load instruction reads four 64-byte runs; wave w adds the records
+// (4 w + bq) + k (4 waves) in that order, eight loads in flight; the four subsets of a wave meet in cfd_row_sum4, the waves through
+// `scratch` (>= 16 * waves floats of LDS) in wave order -- the result depends on nothing but the records and the workgroup size.
+// Returns the total of element e0 + threadIdx.x in the threads with threadIdx.x < 16.  (Rounds 1-4 kept such partials ELEMENT-major --
+// contiguous rows for the reduction, but every producer store a 4-byte transaction of its own: 1.5 M per head launch, 0.43 M per 1x1
+// weight-gradient launch; the head's counter-based write traffic was 1.58x its algorithmic bytes and the kernel 13 us slower.)
+__device__ __forceinline__ float cfd_record_sum16(const float* __restrict__ part, int nrec, int stride, int e0, int nelem, float* scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int bq = lane >> 4, el = lane & 15;
+    const float* src = part + (e0 + el < nelem ? e0 + el : nelem - 1);
+    const int step = 4 * nw;
+    float s = 0.f;
+    int r = 4 * wave + bq;
+    for (; r + 7 * step < nrec; r += 8 * step) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(r + u * step) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; r < nrec; r += step) s += src[(size_t)r * stride];
+    s = cfd_row_sum4(s);
+    __syncthreads();  // (the readers of a previous call are done with `scratch`)
+    if (lane < 16) scratch[wave * 16 + lane] = s;
+    __syncthreads();
+    float tot = 0.f;
+    if (threadIdx.x < 16)
+        for (int w = 0; w < nw; ++w) tot += scratch[w * 16 + threadIdx.x];
+    return tot;
 }
 
 // ---- division of 31-bit indices by a launch-invariant divisor --------------------------------------------------

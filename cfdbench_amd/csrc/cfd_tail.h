@@ -14,8 +14,7 @@ struct SpecWgradTail {
     const float* clhw;
     int nchunk, CC, m1, m2;
 };
-// 1x1-conv weight / bias gradient: one output element per wave, its per-block partials are one contiguous row
-// (k_wgrad_reduce)
+// 1x1-conv weight / bias gradient: block-major partial records part[block][Co (Ci + 1)] (k_chan_wgrad), nrow = blocks
 struct ChanWgradTail {
     const float* part;  // NULL: no such job
     float* gw;
@@ -75,12 +74,14 @@ __device__ __forceinline__ void spec_wgrad_reduce_one(const long gid, const floa
     spec_wgrad_reduce_multi<1>(gid, 0, gid + 1, part, gw1, gw2, clhw, nchunk, CC, m1, m2);
 }
 
-__device__ __forceinline__ void chan_wgrad_reduce_one(const int e, const int lane, const float* __restrict__ part,
-                                                      int nrow, float* __restrict__ gw, float* __restrict__ gb, int Co,
-                                                      int Ci) {
-    const int NW = Ci + 1;
-    const float s = cfd_row_sum(part + (size_t)e * nrow, nrow, lane);
-    if (lane == 0) {
+// 1x1-conv weight / bias gradient elements [16 grp, 16 grp + 16) from the block-major partial records of k_chan_wgrad (cfd_record_sum16;
+// every thread of the workgroup calls it, `scratch` >= 16 floats per wave)
+__device__ __forceinline__ void chan_wgrad_reduce_group(const int grp, const float* __restrict__ part, int nrow, float* __restrict__ gw,
+                                                        float* __restrict__ gb, int Co, int Ci, float* scratch) {
+    const int NW = Ci + 1, total = Co * NW;
+    const float s = cfd_record_sum16(part, nrow, total, 16 * grp, total, scratch);
+    const int e = 16 * grp + (int)threadIdx.x;
+    if (threadIdx.x < 16 && e < total) {
         const int o = e / NW, i = e - o * NW;
         if (i < Ci) gw[o * Ci + i] = s;
         else if (gb) gb[o] = s;
@@ -88,8 +89,8 @@ __device__ __forceinline__ void chan_wgrad_reduce_one(const int e, const int lan
 }
 
 // Workgroup `blk` of `t.nblk` (any workgroup size that is a multiple of 64): thread-strided over the spectral elements,
-// wave-strided over the 1x1-conv elements.
-__device__ __forceinline__ void cfd_reduce_tail(const CfdReduceTail& t, int blk) {
+// workgroup-strided over the groups of 16 1x1-conv elements.  `scratch`: LDS of the carrying kernel, >= 16 floats per wave.
+__device__ __forceinline__ void cfd_reduce_tail(const CfdReduceTail& t, int blk, float* scratch) {
     if (t.spec.part) {
         const long total = (long)t.spec.CC * 2 * t.spec.m1 * t.spec.m2;
         // three elements per thread and round: at 128 workgroups of 320 threads the 115 200 elements of C = 20 are ONE
@@ -100,10 +101,9 @@ __device__ __forceinline__ void cfd_reduce_tail(const CfdReduceTail& t, int blk)
                                        t.spec.CC, t.spec.m1, t.spec.m2);
     }
     if (t.chan.part) {
-        const int wpb = blockDim.x >> 6, lane = threadIdx.x & 63;
-        const int total = t.chan.Co * (t.chan.Ci + 1);
-        for (int e = blk * wpb + (threadIdx.x >> 6); e < total; e += t.nblk * wpb)  // whole waves together
-            chan_wgrad_reduce_one(e, lane, t.chan.part, t.chan.nrow, t.chan.gw, t.chan.gb, t.chan.Co, t.chan.Ci);
+        const int ngroups = (t.chan.Co * (t.chan.Ci + 1) + 15) / 16;
+        for (int grp = blk; grp < ngroups; grp += t.nblk)  // (uniform per workgroup)
+            chan_wgrad_reduce_group(grp, t.chan.part, t.chan.nrow, t.chan.gw, t.chan.gb, t.chan.Co, t.chan.Ci, scratch);
     }
 }
 

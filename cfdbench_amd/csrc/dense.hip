@@ -288,6 +288,12 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
 static int gemm_splits(int M, int N, int K) {
     const long tiles = (long)((M + GT - 1) / GT) * ((N + GT - 1) / GT);
     const int nslab = (K + GK - 1) / GK;
+    const int forced = cfd_tune_get(CFD_TUNE_GEMM_SPLITS);
+    if (forced > 0) return forced < nslab ? forced : nslab;
+    // (round 5) 128 .. 255 tiles still leave every CU with a single four-wave block: with K >= 512 the split pays there too -- the
+    // first-layer weight gradient of the Auto-DeepONet branch net (100 x 4295 over K = 512: 136 tiles) 39.8 -> 22.3 us at 8 splits,
+    // tools/exp/gemm_shapes.py
+    if (tiles >= 128 && tiles < 256 && nslab >= 32) return 8 < nslab / 4 ? 8 : nslab / 4;
     if (tiles >= 128 || nslab < 8) return 1;
     // four workgroups per CU: with one (256 in all: round 1's target) every SIMD holds a single wave and nothing hides its LDS and
     // barrier latencies -- the 200 x 200 weight gradients over 131 k rows of the Auto-FFN ran at 30 % of the matrix pipe, half the

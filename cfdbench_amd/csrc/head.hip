@@ -300,6 +300,7 @@ __global__ __launch_bounds__(64) void k_head_loss_final(const float* __restrict_
 }
 
 static size_t head_part_floats(int C, int Co) { return (size_t)HEAD_HD * C + HEAD_HD + (size_t)Co * HEAD_HD + Co + 2; }  // + 2: fused loss sums
+__device__ __forceinline__ size_t head_part_floats_dev(int C, int Co) { return (size_t)HEAD_HD * C + HEAD_HD + (size_t)Co * HEAD_HD + Co + 2; }
 
 extern "C" size_t cfd_fno_head_workspace_bytes(int B, int C, int Hd, int Co, int HW) {
     (void)Hd;
@@ -893,9 +894,11 @@ CFD_UNROLL(CFD_HB_UNROLL)
     }
     // ---- this block's partial parameter gradients: [gw1 128*C | gb1 128 | gw2 Co*128 | gb2 Co] ----
     const int o_gb1 = HEAD_HD * C, o_gw2 = o_gb1 + HEAD_HD, o_gb2 = o_gw2 + Co * HEAD_HD;
-    // element-major partials part[element][block] (see k_head_reduce)
-    float* dst = part + blockIdx.x;
-    const size_t nb = gridDim.x;
+    // block-major partials part[block][element] (round 5): a wave's stores are 64-byte runs of consecutive elements.  (Rounds 1-4 wrote
+    // them element-major, stride gridDim.x: 2948 x 512 scattered 4-byte stores = 1.5 M write transactions per launch, the kernel's
+    // counter-based write traffic was 1.58x its algorithmic bytes -- profiles/r04z_pmc_traffic.json; k_head_reduce walks the blocks.)
+    float* dst = part + (size_t)blockIdx.x * (head_part_floats_dev(C, Co));
+    const size_t nb = 1;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -934,16 +937,16 @@ CFD_UNROLL(CFD_HB_UNROLL)
     }
 }
 
-// One wave per output element, whose per-block partials are one contiguous row (see k_wgrad_reduce).
-__global__ __launch_bounds__(256) void k_head_reduce(const float* __restrict__ part, int nblk, int PS,
+// Sum of the per-block partial records part[block][PSTR] (block-major): workgroup = 16 consecutive elements (cfd_record_sum16: every
+// load instruction reads 64-byte runs, fixed summation order, deterministic).
+__global__ __launch_bounds__(256) void k_head_reduce(const float* __restrict__ part, int nblk, int PS, int PSTR,
                                                      float* __restrict__ gw1, float* __restrict__ gb1,
                                                      float* __restrict__ gw2, float* __restrict__ gb2, int C, int Co,
                                                      float* __restrict__ sums) {
-    const int lane = threadIdx.x & 63;
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (e >= PS) return;
-    const float s = cfd_row_sum(part + (size_t)e * nblk, nblk, lane);
-    if (lane == 0) {
+    __shared__ float s_scr[64];
+    const float s = cfd_record_sum16(part, nblk, PSTR, 16 * (int)blockIdx.x, PS, s_scr);
+    const int e = 16 * (int)blockIdx.x + (int)threadIdx.x;
+    if (threadIdx.x < 16 && e < PS) {
         const int o_gb1 = HEAD_HD * C, o_gw2 = o_gb1 + HEAD_HD, o_gb2 = o_gw2 + Co * HEAD_HD;
         if (e < o_gb1) gw1[e] = s;
         else if (e < o_gw2) gb1[e - o_gb1] = s;
@@ -990,7 +993,7 @@ extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* 
     CFD_LAUNCH_CHECK("cfd_fno_head_bwd");
     const int PS = (int)head_part_floats(C, Co) - 2;  // the two loss rows belong to the fused kernel
     CFD_PROF_W("k_head_reduce", st, 0.0, 0.0);
-    hipLaunchKernelGGL(k_head_reduce, dim3((PS + 3) / 4), dim3(256), 0, st, (const float*)part, blocks, PS, gw1,
+    hipLaunchKernelGGL(k_head_reduce, dim3((PS + 15) / 16), dim3(256), 0, st, (const float*)part, blocks, PS, (int)head_part_floats(C, Co), gw1,
                        gb1, gw2, gb2, C, Co, (float*)nullptr);
     CFD_LAUNCH_CHECK("cfd_fno_head_bwd(reduce)");
     return CFD_OK;
@@ -1053,7 +1056,7 @@ int cfd_int_fno_head_train(const void* a, const float* mask, const float* label,
     CFD_LAUNCH_CHECK("cfd_fno_head_train");
     const int PS = (int)head_part_floats(C, Co);
     CFD_PROF_W("k_head_reduce", st, 0.0, 0.0);
-    hipLaunchKernelGGL(k_head_reduce, dim3((PS + 3) / 4), dim3(256), 0, st, (const float*)part, blocks, PS, gw1,
+    hipLaunchKernelGGL(k_head_reduce, dim3((PS + 15) / 16), dim3(256), 0, st, (const float*)part, blocks, PS, PS, gw1,
                        gb1, gw2, gb2, C, Co, sums);
     CFD_LAUNCH_CHECK("cfd_fno_head_train(reduce)");
     return CFD_OK;

@@ -812,11 +812,12 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
 #pragma unroll
             for (int r = 0; r < 4; ++r) s_red[((wave * MT * NT + a * NT + c) * 4 + r) * 64 + lane] = acc[a][c][r];
     __syncthreads();
-    // partials are stored element-major, part[element][block]: the scattered 4-byte stores cost the producer nothing
-    // (fire and forget) and the reduction reads whole contiguous rows
+    // partials are stored BLOCK-major, part[block][Co (Ci + 1)] (round 5): a wave's stores are runs of consecutive elements.  (Rounds 1-4:
+    // element-major, "the scattered 4-byte stores cost the producer nothing" -- they were 0.43 M write transactions per launch, 13 MB of
+    // counted write traffic for 1.7 MB of partial sums; cfd_record_sum16 has the numbers.)
     const int NW = Ci + 1;
-    float* dst = part + blockIdx.x;
-    const size_t nb = gridDim.x;
+    float* dst = part + (size_t)blockIdx.x * Co * NW;
+    const size_t nb = 1;
     for (int e = threadIdx.x; e < MT * NT * 4 * 64; e += blockDim.x) {
         const int ln = e & 63, r = (e >> 6) & 3, tile = e >> 8;
         const int a = tile / NT, c = tile % NT;
@@ -830,13 +831,11 @@ __global__ __launch_bounds__(256) void k_chan_wgrad(const float* __restrict__ g,
     }
 }
 
-// One wave per output element: its row of per-block partials is contiguous (part[element][block]); fixed summation
-// order (lane-strided float4 chunks, then a shuffle tree), so the result is deterministic.
+// Workgroup = 16 consecutive output elements of the block-major partial records (cfd_record_sum16): fixed summation order, deterministic.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int nblk, float* __restrict__ gw,
                                                       float* __restrict__ gb, int Co, int Ci) {
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (e >= Co * (Ci + 1)) return;  // whole wave exits together
-    chan_wgrad_reduce_one(e, threadIdx.x & 63, part, nblk, gw, gb, Co, Ci);
+    __shared__ float s_scr[64];
+    chan_wgrad_reduce_group(blockIdx.x, part, nblk, gw, gb, Co, Ci, s_scr);
 }
 
 static int wgrad_blocks(int B, int HW) {
@@ -908,7 +907,7 @@ static int launch_wgrad(const float* g, const TIN* in, StemSrc ss, float* gw, fl
         return CFD_OK;
     }
     CFD_PROF_W("k_wgrad_reduce", st, 0.0, 0.0);  // partial sums are an implementation detail
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((Co * (Ci + 1) + 3) / 4), dim3(256), 0, st, (const float*)part, blocks,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((Co * (Ci + 1) + 15) / 16), dim3(256), 0, st, (const float*)part, blocks,
                        gw, gb, Co, Ci);
     CFD_LAUNCH_CHECK("cfd_chan_wgrad(reduce)");
     return CFD_OK;

@@ -1183,9 +1183,8 @@ __global__ __launch_bounds__(512) void k_mixadj_wgrad(const float2* __restrict__
 
 // the 1x1-conv reduction as a kernel of its own (only where a deferred one cannot ride, see cfd_int_fno_block_bwd_input)
 __global__ __launch_bounds__(256) void k_chan_reduce_standalone(const ChanWgradTail t) {
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (e >= t.Co * (t.Ci + 1)) return;
-    chan_wgrad_reduce_one(e, threadIdx.x & 63, t.part, t.nrow, t.gw, t.gb, t.Co, t.Ci);
+    __shared__ float s_scr[64];
+    chan_wgrad_reduce_group(blockIdx.x, t.part, t.nrow, t.gw, t.gb, t.Co, t.Ci, s_scr);
 }
 
 __global__ __launch_bounds__(256) void k_spec_wgrad_reduce(const float2* __restrict__ part, float2* __restrict__ gw1,
@@ -1545,7 +1544,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __res
     __shared__ float s_z[CFD_WAVES * 2 * CFD_BLK_ZS];    // two slices per wave
     const int nskip = TAIL ? tail.nblk : 0;
     if (TAIL && (int)blockIdx.x < nskip) {
-        cfd_reduce_tail(tail, blockIdx.x);
+        cfd_reduce_tail(tail, blockIdx.x, s_z);
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1940,16 +1939,16 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                                                    const float* __restrict__ aprev, float* __restrict__ dst,
                                                    const bf16x8* __restrict__ tabs3, int Cs, int Cd, int H, int m1,
                                                    int m2, int T, int SA, int SB, const CfdReduceTail tail, int SPL,
-                                                   int pitch, const float* __restrict__ tailtab) {
-    if (TAIL && (int)blockIdx.x < tail.nblk) {
-        cfd_reduce_tail(tail, blockIdx.x);
-        return;
-    }
+                                                   int pitch, const float* __restrict__ tailtab, int ND, int NENT) {
     constexpr int W = 64, NJ = 4;
     constexpr int WS = DPW <= 4 ? 4 : 8;              // floats per weight-table entry
     __shared__ float4 s_src[2 * NW * 16 * 16];        // [buf][channel in chunk][row][float4 column]
     __shared__ bf16x8 s_tab3[CFD_B3_TABV];            // split-bf16 inverse tables: ta3 of every tile (T <= 4) | tb3
     __shared__ float s_z[NW * DPW * CFD_KB_ZS];      // kept modes of this wave's destination channels
+    if (TAIL && (int)blockIdx.x < tail.nblk) {
+        cfd_reduce_tail(tail, blockIdx.x, s_z);  // (s_z: scratch of the 1x1 partial-record sums)
+        return;
+    }
     __shared__ float4 s_w[NW * NW * NCH * (WS / 4)];  // [wave][source channel] -> weights of the wave's DPW channels
     __shared__ float s_tail[GEN ? 2 * NW * 16 * 4 : 4];  // GEN: [buf][channel in chunk][row][tail column e] source values
     __shared__ float s_tw[GEN ? 4 * 32 : 4];             // GEN: stage-B factors of the tail columns (plan.d_tail)
@@ -1961,9 +1960,21 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     // SPL workgroups share a batch entry by row tiles (SPL divides T): with fewer batch entries than CUs one workgroup per
     // entry leaves most of the chip idle for the same ~45 us (B = 64: 44.9 us against 24.8 for the two-pass route); every
     // tile is computed exactly as in the unsplit kernel, so a sample's result does not depend on the batch size
-    const int bi = TAIL ? (int)blockIdx.x - tail.nblk : (int)blockIdx.x;
+    const int bi0 = TAIL ? (int)blockIdx.x - tail.nblk : (int)blockIdx.x;
+    // ND > 1 (round 5: 25 .. 32 channels, the reference's default width): the destination channels of an entry are dealt to ND
+    // workgroups of NW * DPW channels each (all of a wide entry's modes do not fit one workgroup's LDS); every one streams ALL the
+    // source channels, so the source is read ND times -- the ND workgroups of one (entry, row split) sit 8 block indices apart, i.e.
+    // on the same XCD (workgroups are dealt to the XCDs round robin), and the second read is served by that XCD's L2.
+    int bi = bi0, dg = 0;
+    if (ND > 1) {
+        const int xcd = bi0 & 7, l = bi0 >> 3;
+        dg = l % ND;
+        bi = (l / ND) * 8 + xcd;
+    }
+    const int dbase = dg * NW * DPW;  // first destination channel of this workgroup
     // (round 4: SPL need not divide T -- five row tiles at 66 x 65: the last workgroup of an entry takes what is left)
     const int b = bi / SPL, TPWmax = (T + SPL - 1) / SPL, t0 = (bi - b * SPL) * TPWmax;
+    if (bi >= NENT) return;  // (NENT = batch entries x row splits; with ND > 1 the grid is padded to whole groups of 8 * ND)
     const int TPW = T - t0 < TPWmax ? T - t0 : TPWmax;  // >= 1: the launcher sizes SPL as ceil(T / TPWmax)
     const int P = GEN ? pitch : W;  // row pitch in floats
     const int E = GEN ? pitch - W : 0;  // tail columns
@@ -2026,7 +2037,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     float wl[WS];
 #pragma unroll
     for (int dd = 0; dd < WS; ++dd) {
-        const int d = wave + dd * NW, dc = d < Cd ? d : Cd - 1, lc = lane < Cs ? lane : Cs - 1;
+        const int d = dbase + wave + dd * NW, dc = d < Cd ? d : Cd - 1, lc = lane < Cs ? lane : Cs - 1;
         wl[dd] = dd < DPW ? (TRANS ? w[(size_t)lc * Cd + dc] : w[(size_t)dc * Cs + lc]) : 0.f;
     }
     float bv[DPW];
@@ -2034,7 +2045,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     float4 zv[DPW][ZV];
 #pragma unroll
     for (int dd = 0; dd < DPW; ++dd) {
-        const int d = wave + dd * NW;
+        const int d = dbase + wave + dd * NW;
         bv[dd] = bias ? bias[d < Cd ? d : Cd - 1] : 0.f;
         const float4* zi = reinterpret_cast<const float4*>(z + ((size_t)b * Cd + (d < Cd ? d : 0)) * M2);
 #pragma unroll
@@ -2045,14 +2056,14 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     }
 #pragma unroll
     for (int dd = 0; dd < WS; ++dd) {
-        const int d = wave + dd * NW;
+        const int d = dbase + wave + dd * NW;
         wl[dd] = cfd_opaque_f(wl[dd]);
         wl[dd] = (lane < NW * NCH && dd < DPW && d < Cd && lane < Cs) ? wl[dd] : 0.f;
     }
 #pragma unroll
     for (int dd = 0; dd < DPW; ++dd) {
         bv[dd] = cfd_opaque_f(bv[dd]);
-        bv[dd] = wave + dd * NW < Cd ? bv[dd] : 0.f;
+        bv[dd] = dbase + wave + dd * NW < Cd ? bv[dd] : 0.f;
 #pragma unroll
         for (int k = 0; k < ZV; ++k) {
             f32x4 t = {zv[dd][k].x, zv[dd][k].y, zv[dd][k].z, zv[dd][k].w};
@@ -2087,7 +2098,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     const bf16x8* tb3 = s_tab3 + CFD_TW * T * 64;
     float4 APV[2][4];  // gelu'(aprev) operands of two destination channels in flight
     auto fetch_ap = [&](int t, int dd, float4 (&r)[4]) {
-        const int d = wave + dd * NW;
+        const int d = dbase + wave + dd * NW;
         const float* pl = aprev + ((size_t)b * Cd + (d < Cd ? d : 0)) * HW;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) r[r4] = cfd_ldrow4<GEN>(pl + (size_t)rowc(16 * t + 4 * q + r4) * P + 4 * n);
@@ -2117,7 +2128,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                 if (c == NCH - 1) fetch_ap(t, 1, APV[1]);
             }
             // inverse transform of destination channel dd = c (spread over the chunks so MFMA and VALU work interleave)
-            if (c < DPW && wave + c * NW < Cd) {
+            if (c < DPW && dbase + wave + c * NW < Cd) {
                 float va[2][8];
                 idft_gather(s_z + (wave * DPW + (c < DPW ? c : 0)) * CFD_KB_ZS, m1, m2, SA, q, n, va);
                 idft_tile_b3<NJ, AP>(idft_split<AP>(va), s_tab3 + CFD_TW * t * 64, tb3, lane, acc[c < DPW ? c : 0], GEN ? s_tw : nullptr, E,
@@ -2127,7 +2138,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                 if (c == NCH - 1) {
 #pragma unroll
                     for (int dd = NCH; dd < DPW; ++dd) {
-                        if (wave + dd * NW < Cd) {
+                        if (dbase + wave + dd * NW < Cd) {
                             float va[2][8];
                             idft_gather(s_z + (wave * DPW + dd) * CFD_KB_ZS, m1, m2, SA, q, n, va);
                             idft_tile_b3<NJ, AP>(idft_split<AP>(va), s_tab3 + CFD_TW * t * 64, tb3, lane, acc[dd], GEN ? s_tw : nullptr, E,
@@ -2181,7 +2192,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
         // ---- tile epilogue: [* gelu'(aprev)], whole-float4 row stores ----
 #pragma unroll
         for (int dd = 0; dd < DPW; ++dd) {
-            const int d = wave + dd * NW;
+            const int d = dbase + wave + dd * NW;
             float4 ap[4];
             if constexpr (DGELU) {
 #pragma unroll
@@ -2226,7 +2237,15 @@ static bool block_is_gen(const cfd_plan* p) { return p->W != 64 || p->H % 16 != 
 static bool block_fused_ok(const cfd_plan* p, int Cs, int Cd, const void* a, const void* b, const void* c, const void* z) {
     const int cmax = Cs > Cd ? Cs : Cd;
     if (cfd_tune_get(CFD_TUNE_EXACT_FP32) == 1 || !p->d_inv_b3 || p->T > CFD_KB_TMAX) return false;  // (the fused kernel's inverse transform is split-bf16)
-    if (4 * p->m1 * p->m2 + 1 > CFD_BLK_ZS || cmax > 24 || ((uintptr_t)z % 16) != 0) return false;    // 25 .. 32 channels: see launch_block
+    if (4 * p->m1 * p->m2 + 1 > CFD_BLK_ZS || cmax > 32 || ((uintptr_t)z % 16) != 0) return false;
+    // 25 .. 32 channels (two workgroups per entry, see launch_block): measured at B = 256 / width 32 (profiles/r05b_block_c32.txt) the
+    // split kernel re-reads every source value from LDS twice as often per output as the (8,4,4) shape would and only beats the two
+    // passes where they are slowest -- the input gradient with gelu' on the general grids (66 x 65: 157 us against 84 + 101); forward
+    // (146 against 86 + 59) and the 64-wide grids (123 against 46 + 76) stay on the two passes.  "block_wide" = 1 forces it everywhere.
+    if (cmax > 24) {
+        const int wide = cfd_tune_get(CFD_TUNE_BLOCK_WIDE);
+        if (wide == 0 || (wide != 1 && !(c && block_is_gen(p)))) return false;
+    }
     if (block_is_gen(p))  // round 4: 64 <= W <= 68 (d_inv_b3 exists), any H <= 80; 4-byte aligned planes (round 5: both piece counts)
         return cfd_tune_get(CFD_TUNE_BLOCK_GEN) != 0 && p->d_tail;
     return ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && (!c || ((uintptr_t)c % 16) == 0);
@@ -2238,20 +2257,24 @@ static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z
                              hipStream_t st, const CfdReduceTail* tail) {
     const bool ride = trans && tail && tail->nblk > 0;
     const CfdReduceTail tl = ride ? *tail : CfdReduceTail{};
-    // one workgroup per batch entry, tiles streamed inside; below ~3/4 of the CU count the entries are split by row tiles
+    // destination groups per entry (k_block: ND): one unless the entry's destination channels exceed what a workgroup owns
+    const int nd = (Cd + NW * DPW - 1) / (NW * DPW);
+    // one workgroup per batch entry (and destination group), tiles streamed inside; below ~3/4 of the CU count the entries are split by row tiles
     int spl = 1;
-    while (spl * 2 <= p->T && p->T % (spl * 2) == 0 && (long)B * spl * 2 <= 288) spl *= 2;
+    while (spl * 2 <= p->T && p->T % (spl * 2) == 0 && (long)B * nd * spl * 2 <= 288) spl *= 2;
     if (p->T % 2 != 0) {  // an odd tile count (five at 66 x 65): the most workgroups per entry that still fit one round, no empty ones
         int want = 1;
-        while (want < p->T && (long)B * (want + 1) <= 288) ++want;
+        while (want < p->T && (long)B * nd * (want + 1) <= 288) ++want;
         const int tpw = (p->T + want - 1) / want;
         spl = (p->T + tpw - 1) / tpw;
     }
-    const dim3 grid(B * spl + tl.nblk), block(64 * NW);
+    long nwg = (long)B * spl;
+    if (nd > 1) nwg = (nwg + 7) / 8 * 8 * nd;  // whole groups of 8 * nd block indices (the kernel drops the padding)
+    const dim3 grid((unsigned)(nwg + tl.nblk)), block(64 * NW);
     const bool ap3 = cfd_act_pieces() == 3, gen = block_is_gen(p);
 #define CFD_BLK_P(A_, T_, D_, R_, P_, G_)                                                                                \
     hipLaunchKernelGGL((k_block<NW, DPW, NCH, A_, T_, D_, R_, P_, G_>), grid, block, 0, st, src, z, w, bias, aprev, dst, \
-                       (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB, tl, spl, p->W, (const float*)p->d_tail)
+                       (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB, tl, spl, p->W, (const float*)p->d_tail, nd, B * spl)
 #define CFD_BLK(A_, T_, D_, R_)                                                      \
     do {                                                                             \
         if (gen) { if constexpr (NW != 10) { if (ap3) CFD_BLK_P(A_, T_, D_, R_, 3, true); else CFD_BLK_P(A_, T_, D_, R_, 2, true); } }  /* launch_block: never (10,2,2) */ \
@@ -2279,9 +2302,12 @@ static void launch_block(const cfd_plan* p, const float* src, const float* z, co
         if (dgelu || block_is_gen(p)) launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
         else launch_block_cfg<10, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
     }
-    // 21 .. 24 channels: (8,3,3).  25 .. 32 channels run as the two passes (block_fused_ok): with the tables in three pieces
-    // (CFD_TW) the (8,4,4) workgroup would need 168 KB of LDS (source chunks 64 + modes 74 + tables 24 + weights 4).
-    else launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
+    // 21 .. 24 channels: (8,3,3).
+    else if (cmax <= 24) launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
+    // 25 .. 32 channels (round 5; the reference's default width 32, src/args.py:190): with the tables in three pieces (CFD_TW) an
+    // (8,4,4) workgroup would need 168 KB of LDS (source chunks 64 + modes 74 + tables 24 + weights 4), so the entry's destination
+    // channels are dealt to TWO (8,2,4) workgroups of 16 channels (modes 37 KB: 133 KB), each streaming all the source channels.
+    else launch_block_cfg<8, 2, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
 }
 
 // out[b,o] = bias[o] + sum_i w0[o,i] f(a[b,i]) + idft(z[b,o])                       (FnoBlock.forward minus its GELU)
@@ -2319,7 +2345,7 @@ static int launch_reduce_tail_standalone(const CfdReduceTail* tail, hipStream_t 
     }
     if (tail->chan.part) {
         CFD_PROF_W("k_wgrad_reduce", st, 0.0, 0.0);
-        hipLaunchKernelGGL(k_chan_reduce_standalone, dim3((tail->chan.Co * (tail->chan.Ci + 1) + 3) / 4), dim3(256), 0, st,
+        hipLaunchKernelGGL(k_chan_reduce_standalone, dim3((tail->chan.Co * (tail->chan.Ci + 1) + 15) / 16), dim3(256), 0, st,
                            tail->chan);
         CFD_LAUNCH_CHECK("cfd_fno_block_bwd_input(1x1 reduce)");
     }

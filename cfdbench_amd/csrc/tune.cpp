@@ -36,6 +36,9 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
     {"block_gen", "CFD_BLOCK_GEN", {-1}},        // 0 = the FnoBlock of grids other than 64-wide / H % 16 == 0 (66 x 65) as two passes instead of the fused kernel
     {"gemm_tile", "CFD_GEMM_TILE", {-1}},        // block tile of the fp32 GEMM (dense.hip): 128 = 128 x 128, 1 = 128 rows x all columns, 8 = 128 x 64 on eight waves;
                                                  // default 64 x 64 (the fastest on every product of the benchmark)
+    {"block_wide", "CFD_BLOCK_WIDE", {-1}},      // fused FnoBlock at 25 .. 32 channels (two workgroups per entry): 1 = wherever the shape allows (tests),
+                                                 // 0 = never; default: only the gelu' input gradient on the general grids, where it beats the two passes
+    {"gemm_splits", "CFD_GEMM_SPLITS", {-1}},    // > 0: forced split-K count of every fp32 GEMM that takes a workspace (timing sweeps: tools/exp/gemm_shapes.py)
 };
 std::once_flag g_once;
 void read_env() {

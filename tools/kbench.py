@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--json", type=str, default="")
     ap.add_argument("--dump-out", type=int, default=0, help="print the first N int64 words of the output tensor after one call of --only (kernel timestamp experiments)")
+    ap.add_argument("--zeros", action="store_true", help="all-zero activations / gradients / labels (DVFS probe: the same instruction stream at "
+                                                         "the lowest switching power; MI355X_MICROARCH.md)")
     ap.add_argument("--tune", type=str, default="", help="dispatch knobs, e.g. general_b3=0,fused_variant=0 (cfd_tune_set)")
     args = ap.parse_args()
     api = _lib.api()
@@ -41,7 +43,7 @@ def main():
     M = 2 * m1 * m2
     plan = _lib.plan(H, W, m1, m2, 0)
     st = torch.cuda.current_stream().cuda_stream
-    f = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
+    f = (lambda *s: torch.zeros(*s, device=dev)) if args.zeros else (lambda *s: torch.randn(*s, device=dev))  # noqa: E731
     a, a2, g, out = f(B, C, H, W), f(B, C, H, W), f(B, C, H, W), f(B, C, H, W)
     xh, gh, z = f(B, C, 2 * m1, m2, 2), f(B, C, 2 * m1, m2, 2), f(B, C, 2 * m1, m2, 2)
     w1, w2 = f(C, C, m1, m2, 2) / (C * C), f(C, C, m1, m2, 2) / (C * C)
@@ -98,6 +100,8 @@ def main():
         "head_bwd": (lambda: api.call("cfd_fno_head_bwd", P(a), P(mask), P(label), P(preds), None, P(coef), P(fc1w), P(fc1b),
                                       P(fc2w), P(out), P(g1w), P(g1b), P(g2w), P(g2b), P(ws), B, C, 128, 2, HW, 1, st),
                      2 * N + px * 28),
+        "head_train": (lambda: api.call("cfd_fno_head_train", P(a), P(mask), P(label), P(coef), P(fc1w), P(fc1b), P(fc2w), P(fc2b), P(preds),
+                                        P(sums), P(out), P(g1w), P(g1b), P(g2w), P(g2b), P(ws), B, C, 128, 2, HW, 1, st), 2 * N + px * 28),
         "spectral_fwd": (lambda: api.call("cfd_spectral_conv2d_fwd", plan, P(a), P(w1), P(w2), P(out), P(xh), P(z), B, C, C, st),
                          2 * N + Wb),
         "spectral_bwd": (lambda: api.call("cfd_spectral_conv2d_bwd", plan, P(g), P(xh), P(w1), P(w2), P(out), P(gw1), P(gw2),
