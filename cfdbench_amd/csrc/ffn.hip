@@ -366,19 +366,28 @@ __global__ __launch_bounds__(256, 2) void k_ffn_stack_bwd_chain(const FfnStackSe
 // gradient as the extra input column i = Din whose value is 1.  Grid (tile, layer, row slice); one wave per 16 x 16 tile and
 // slice; partial tiles are summed by k_ffn_stack_reduce in a fixed order.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_ffn_stack_wgrad(const FfnStackSet set, const FfnStackBwdSet bset) {
+// Block -> (tile, layer, row slice).  The NTi x NTj tiles of one (layer, slice) read the SAME rows of dZ and of the layer input -- each
+// column block once per tile of the other operand, 7x at width 100 -- and workgroups are dealt to the 8 XCDs (one L2 each) round robin
+// in launch order: as a plain (tile, layer, slice) grid the tiles of a group landed on all eight L2s and every one of them fetched the
+// rows again (rocprofv3 FETCH_SIZE: 223 MB per launch for 27 MB of operands, the kernel ran at the fabric's rate:
+// profiles/r05p_auto_deeponet_pmc_traffic.json).  Round 5: a 1-D grid whose block l runs work item (l % 8) * (items / 8) + l / 8, so
+// the tiles of a group are consecutive blocks of ONE XCD and the re-reads are L2 hits.
+__global__ __launch_bounds__(64) void k_ffn_stack_wgrad(const FfnStackSet set, const FfnStackBwdSet bset, int tmax, int layers, int per_xcd) {
+    const int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (item >= tmax * layers * FS_KSPLIT) return;
+    const int bx = item % tmax, by = (item / tmax) % layers, bz = item / (tmax * layers);
     int si = 0;
-    while (si + 1 < set.ns && (int)blockIdx.y >= set.lay0[si + 1]) ++si;
+    while (si + 1 < set.ns && by >= set.lay0[si + 1]) ++si;
     const FfnStack& st = set.st[si];
     const FfnStackBwd& bw = bset.bw[si];
     const float* __restrict__ x = set.x[si];
     float* __restrict__ part = bset.part[si];
     const int R = set.R[si];
-    const int l = (int)blockIdx.y - set.lay0[si], slice = blockIdx.z;
+    const int l = by - set.lay0[si], slice = bz;
     const int Din = st.dims[l], Dout = st.dims[l + 1];
     const int NTi = (Din + 1 + 15) >> 4, NTj = (Dout + 15) >> 4;
-    if ((int)blockIdx.x >= NTi * NTj) return;
-    const int tj = blockIdx.x / NTi, ti = blockIdx.x - tj * NTi;
+    if (bx >= NTi * NTj) return;
+    const int tj = bx / NTi, ti = bx - tj * NTi;
     const int lane = threadIdx.x, q = lane >> 4, n = lane & 15;
     const float* dz = bw.dz[l];
     const float* yin = l > 0 ? st.y[l - 1] : x;
@@ -606,7 +615,8 @@ static int fs_bwd(const char* fn, int n, const cfd_ffn_stack_args* a, hipStream_
     CFD_LAUNCH_CHECK(fn);
     {
         CFD_PROF_W("k_ffn_stack_wgrad", s, by_wg, fl);
-        hipLaunchKernelGGL(k_ffn_stack_wgrad, dim3(tmax, layers, FS_KSPLIT), dim3(64), 0, s, set, bset);
+        const int items = tmax * layers * FS_KSPLIT, per_xcd = (items + 7) / 8;
+        hipLaunchKernelGGL(k_ffn_stack_wgrad, dim3(8 * per_xcd), dim3(64), 0, s, set, bset, tmax, layers, per_xcd);
     }
     CFD_LAUNCH_CHECK(fn);
     CFD_PROF_W("k_ffn_stack_reduce", s, 0.0, 0.0);

@@ -410,8 +410,14 @@ int cfd_int_fno_head_fwd(const void* a_, const float* mask, const float* label, 
 // AP: bf16 pieces per operand value (2 = default; 3 = fp32-exact class, input planes single-buffered so that two workgroups still fit
 // a CU -- the second buffer was never needed for correctness: a tile's planes are staged between the two tile-end barriers, after
 // every wave has finished reading the previous tile's).
-template <int KS, bool VEC4, bool ACT, bool FUSE, typename TA, int AP>
-__global__ __launch_bounds__(256, 2) void k_head_bwd(
+// NWV (round 5): waves per workgroup, 4 (32 hidden units = two M-tiles per wave) or 8 (16 hidden units each, eight partial d/dh planes).
+// At 21 .. 32 channels the four-wave workgroup needs 97 KB of LDS -- ONE workgroup per CU, one wave per SIMD (VERDICT r4 missing #3);
+// eight waves share the input planes of one 131-KB workgroup: two waves per SIMD, k_head_train 415 -> see DESIGN.md section 4.  At
+// <= 20 channels two four-wave workgroups fit a CU and stay the default (the eight-wave form measured there: profiles/r05c_head_waves.txt;
+// a first version that squeezed it into 80 KB by letting waves w and w + 4 ds_add_f32 into one partial plane ran 4.5x SLOWER: LDS float
+// atomics serialise).
+template <int KS, bool VEC4, bool ACT, bool FUSE, typename TA, int AP, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, 2) void k_head_bwd(
     const TA* __restrict__ a, const float* __restrict__ mask, const float* __restrict__ label,
     const float* __restrict__ preds, const float* __restrict__ gext, const float* __restrict__ coef,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, float* __restrict__ ga,
@@ -421,33 +427,37 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     constexpr int LDK = 40;             // bf16 row stride of s_hk: 32 channels + 8 pad (80 B: conflict-free b128 reads)
     constexpr int LDT = 72;             // bf16 row stride of s_ht: 64 pixel columns + 8 pad (144 B)
     constexpr int LDX = 40;             // bf16 row stride of the gz^T planes: 32 pixel columns + 8 pad
-    constexpr int NST = (CP * 16 + 255) / 256;  // float4 staging loads per thread and tile
+    constexpr int HT = 8 / NWV;         // 16-unit hidden tiles per wave (M-tiles of the recompute)
+    constexpr int HPW = 16 * HT;        // hidden units per wave
+    constexpr int NTH = 64 * NWV;       // threads
+    static_assert(NWV == 4 || NWV == 8, "hidden units over four or eight waves");
+    constexpr int NST = (CP * 16 + NTH - 1) / NTH;  // float4 staging loads per thread and tile
     constexpr int NBUF = AP == 3 ? 1 : 2;  // input-plane buffers (see above)
     __shared__ __attribute__((aligned(16))) __bf16 s_hk[NBUF][AP][64 * LDK];   // [buffer][piece][column][channel]
     constexpr int HTR = CP + 1;  // rows of an s_ht plane: the CP channels + ONE zero row that every padding channel of the 16-wide
                                  // MFMA tiles reads (16 MU rows would not leave room for two workgroups per CU in the fused kernel)
     __shared__ __attribute__((aligned(16))) __bf16 s_ht[NBUF][AP][HTR * LDT];  // [buffer][piece][channel][column]
-    __shared__ __attribute__((aligned(16))) __bf16 s_x[4][AP][32 * LDX];       // [wave][piece][hidden][32 columns]
-    __shared__ float4 s_red[4 * CP * 16];  // [wave][channel][16 x float4 = 64 pixels] partial d/dh
+    __shared__ __attribute__((aligned(16))) __bf16 s_x[NWV][AP][HPW * LDX];    // [wave][piece][hidden][32 columns]
+    __shared__ float4 s_red[NWV * CP * 16];  // [wave][channel][16 x float4 = 64 pixels] partial d/dh
     __shared__ cfd_f2 s_gr[2][64];         // [buffer][column] upstream gradient on the raw head output, both channels
                                            // (FUSE: label * mask of both channels; the gradient is formed in the phase)
     __shared__ float s_mk[FUSE ? 2 : 1][64];       // FUSE: mask by column (0 past the end of the image / of the work)
-    __shared__ cfd_f2 s_pp[FUSE ? 4 : 1][4][16];   // FUSE: [phase parity][wave][pixel lane] partial fc2 sums of both outputs
+    __shared__ cfd_f2 s_pp[FUSE ? 4 : 1][NWV][16]; // FUSE: [phase parity][wave][pixel lane] partial fc2 sums of both outputs
     __shared__ __attribute__((aligned(16))) float s_pv[2][FUSE ? 64 : 4];  // FUSE: the tile's predictions in pixel order (wave 0 only)
     const int lane = threadIdx.x & 63, wave = cfd_uniform(threadIdx.x >> 6);
     const int q = lane >> 4, n = lane & 15;
     __bf16* s_xw = s_x[wave][0];  // piece pc of this wave's gz^T plane at s_xw + pc * 32 * LDX
     // ---- loop-invariant fragments of this wave's hidden slice ----
-    CfdAct8<AP> w1f[2];   // A operand of z = W1 h:        w1[32w + 16t + n][8q + v]
+    CfdAct8<AP> w1f[HT];  // A operand of z = W1 h:        w1[HPW w + 16t + n][8q + v]
     CfdAct8<AP> w1t[MU];  // A operand of d/dh = W1^T gz:  w1[32w + 16(v/4) + 4q + v%4][16mu + n]
-    float bz[2][4];                // b1 at hidden unit 32w + 16t + 4q + r
-    cfd_f2 w2a[2][2], w2b[2][2];   // w2[0], w2[1] at hidden units 32w + 16t + 4q + {2v, 2v+1}
+    float bz[HT][4];               // b1 at hidden unit HPW w + 16t + 4q + r
+    cfd_f2 w2a[HT][2], w2b[HT][2]; // w2[0], w2[1] at hidden units HPW w + 16t + 4q + {2v, 2v+1}
     const float c0 = label ? coef[0] : 0.f, c1 = label ? coef[1] : 0.f;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 aw1[2][MU];
-    cfd_f2 acc2a[2][2], acc2b[2][2], accb1[2][2];
+    f32x4 aw1[HT][MU];
+    cfd_f2 acc2a[HT][2], acc2b[HT][2], accb1[HT][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < HT; ++t) {
 #pragma unroll
         for (int v = 0; v < MU; ++v) aw1[t][v] = zero;
 #pragma unroll
@@ -525,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     auto fetch = [&](const TileAt t) {  // raw activations of the tile -> registers (zeros past the end of the work / image)
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-            const int e = threadIdx.x + 256 * k;
+            const int e = threadIdx.x + NTH * k;
             const int i = e >> 4, n4 = e & 15;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t.b >= 0 && i < C) {
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     auto stage = [&](int buf) {  // registers -> f(a) -> bf16 hi/lo -> both operand layouts of buffer `buf`
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-            const int e = threadIdx.x + 256 * k;
+            const int e = threadIdx.x + NTH * k;
             const int i = e >> 4, n4 = e & 15;
             if (i < C) {
                 float4 v = raw[k];
@@ -599,26 +609,26 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
     {
         float x[8];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < HT; ++t) {
 #pragma unroll
-            for (int v = 0; v < 8; ++v) x[v] = (8 * q + v < C) ? w1[(32 * wave + 16 * t + n) * C + 8 * q + v] : 0.f;
+            for (int v = 0; v < 8; ++v) x[v] = (8 * q + v < C) ? w1[(HPW * wave + 16 * t + n) * C + 8 * q + v] : 0.f;
             w1f[t] = cfd_act_split8<AP>(x);
         }
 #pragma unroll
         for (int mu = 0; mu < MU; ++mu) {
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
-                const int jh = 32 * wave + 16 * (v >> 2) + 4 * q + (v & 3);
-                x[v] = (16 * mu + n < C) ? w1[jh * C + 16 * mu + n] : 0.f;
+                const int jh = HPW * wave + 16 * (v >> 2) + 4 * q + (v & 3);  // (NWV = 8: the k-slots v >= 4 carry zeros)
+                x[v] = ((v >> 2) < HT && 16 * mu + n < C) ? w1[(jh < HEAD_HD ? jh : 0) * C + 16 * mu + n] : 0.f;
             }
             w1t[mu] = cfd_act_split8<AP>(x);
         }
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < HT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int jh = 32 * wave + 16 * t + 4 * q + r;
+            const int jh = HPW * wave + 16 * t + 4 * q + r;
             bz[t][r] = b1[jh];
             w2a[t][r >> 1][r & 1] = w2[jh];
             w2b[t][r >> 1][r & 1] = Co > 1 ? w2[HEAD_HD + jh] : 0.f;
@@ -640,28 +650,28 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
         const cfd_f2* grp = s_gr[buf];
         const __bf16* hk = s_hk[buf][0];  // piece pc at + pc * 64 * LDK
         const __bf16* ht = s_ht[buf][0];  // piece pc at + pc * HTR * LDT
-        auto front = [&](int j, f32x4 (&z)[2]) {
+        auto front = [&](int j, f32x4 (&z)[HT]) {
             // 1. recompute this wave's slice of the hidden pre-activation z[hidden][pixel n]
             const int col = 16 * j + n;
             bf16x8 hp[AP];
 #pragma unroll
             for (int pc = 0; pc < AP; ++pc) hp[pc] = *reinterpret_cast<const bf16x8*>(hk + pc * 64 * LDK + col * LDK + 8 * q);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) z[t] = f32x4{bz[t][0], bz[t][1], bz[t][2], bz[t][3]};
+            for (int t = 0; t < HT; ++t) z[t] = f32x4{bz[t][0], bz[t][1], bz[t][2], bz[t][3]};
 #pragma unroll
             for (int k = 0; k < cfd_nterm_aa(AP); ++k)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].p[cfd_term_aa_a(AP, k)], hp[cfd_term_aa_b(AP, k)], z[t]);
+                for (int t = 0; t < HT; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].p[cfd_term_aa_a(AP, k)], hp[cfd_term_aa_b(AP, k)], z[t]);
         };
         auto back = [&](int j, const float (&gzv)[8]) {
             const CfdAct8<AP> gs = cfd_act_split8<AP>(gzv);
             // 3. transposed gz planes of this wave: row = local hidden unit 16t + 4q + r, column 16(j&1) + n
             const int xcol = 16 * (j & 1) + n;
 #pragma unroll
-            for (int v = 0; v < 8; ++v) {
+            for (int v = 0; v < 4 * HT; ++v) {
                 const int row = 16 * (v >> 2) + 4 * q + (v & 3);
 #pragma unroll
-                for (int pc = 0; pc < AP; ++pc) s_xw[pc * 32 * LDX + row * LDX + xcol] = gs.p[pc][v];
+                for (int pc = 0; pc < AP; ++pc) s_xw[pc * HPW * LDX + row * LDX + xcol] = gs.p[pc][v];
             }
             // 4. partial d/dh[channel][pixel] = sum over this wave's hidden units w1[jh][channel] gz[jh][pixel]
             f32x4 ghc[MU];
@@ -682,12 +692,12 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
             // 5. after each pair of phases: gw1[hidden][channel] += sum over 32 pixels gz[hidden][px] h[channel][px]
             if (j & 1) {
                 cfd_wave_lds_sync();
-                bf16x8 ap[2][AP], bp[MU][AP];
+                bf16x8 ap[HT][AP], bp[MU][AP];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < HT; ++t) {
                     const int o = (16 * t + n) * LDX + 8 * q;
 #pragma unroll
-                    for (int pc = 0; pc < AP; ++pc) ap[t][pc] = *reinterpret_cast<const bf16x8*>(s_xw + pc * 32 * LDX + o);
+                    for (int pc = 0; pc < AP; ++pc) ap[t][pc] = *reinterpret_cast<const bf16x8*>(s_xw + pc * HPW * LDX + o);
                 }
 #pragma unroll
                 for (int mu = 0; mu < MU; ++mu) {
@@ -698,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
 #pragma unroll
                 for (int k = 0; k < cfd_nterm_aa(AP); ++k)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
+                    for (int t = 0; t < HT; ++t)
 #pragma unroll
                         for (int mu = 0; mu < MU; ++mu)
                             aw1[t][mu] = cfd_mfma16x16x32_bf16(ap[t][cfd_term_aa_a(AP, k)], bp[mu][cfd_term_aa_b(AP, k)], aw1[t][mu]);
@@ -709,12 +719,12 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
             // Two pixel phases per workgroup barrier: both phases' forward halves (GELU terms kept in registers, this wave's share
             // of fc2 into LDS), ONE barrier, then both backward halves.  Four slot pairs of s_pp rotate (pair parity x phase), so
             // a fast wave's next writes never meet a slow wave's reads.
-            auto fwd_half = [&](int j, int slot, const f32x4 (&z)[2], cfd_f2 (&a1k)[2][2], cfd_f2 (&gdk)[2][2]) {
+            auto fwd_half = [&](int j, int slot, const f32x4 (&z)[HT], cfd_f2 (&a1k)[HT][2], cfd_f2 (&gdk)[HT][2]) {
                 // forward half of the phase: GELU terms once, this wave's share of fc2, the workgroup's sum -> prediction,
                 // loss terms and the gradient on the raw output; then the backward half on the kept terms
                 cfd_f2 po0 = {0.f, 0.f}, po1 = {0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < HT; ++t)
 #pragma unroll
                     for (int v = 0; v < 2; ++v) {
                         const cfd_f2 zz = {z[t][2 * v], z[t][2 * v + 1]};
@@ -728,11 +738,11 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                 const float p0 = cfd_row_sum4(cfd_hsum2(po0)), p1 = cfd_row_sum4(cfd_hsum2(po1));  // over the four lane groups
                 if (q == 0) s_pp[slot][wave][n] = cfd_f2{p0, p1};
             };
-            auto bwd_half = [&](int j, int slot, const cfd_f2 (&a1k)[2][2], const cfd_f2 (&gdk)[2][2], float (&gzv)[8]) {
+            auto bwd_half = [&](int j, int slot, const cfd_f2 (&a1k)[HT][2], const cfd_f2 (&gdk)[HT][2], float (&gzv)[8]) {
                 const int col = 16 * j + n;
                 cfd_f2 sp = s_pp[slot][0][n];
 #pragma unroll
-                for (int wv = 1; wv < 4; ++wv) sp = sp + s_pp[slot][wv][n];
+                for (int wv = 1; wv < NWV; ++wv) sp = sp + s_pp[slot][wv][n];
                 const float mk = s_mk[buf][col];
                 const cfd_f2 lab = grp[col];
                 const float pr0 = (sp.x + b2v0) * mk, pr1 = (sp.y + b2v1) * mk;  // fno2d.py:233
@@ -754,7 +764,9 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
                 }
                 const cfd_f2 g0 = (cfd_f2)(gp0), g1 = (cfd_f2)(gp1);
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int v = 4 * HT; v < 8; ++v) gzv[v] = 0.f;  // (NWV = 8: the upper k-slots of the d/dh product)
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
 #pragma unroll
                     for (int v = 0; v < 2; ++v) {
                         acc2a[t][v] = cfd_fma2(g0, a1k[t][v], acc2a[t][v]);
@@ -768,15 +780,15 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
             };
 #pragma unroll 1
             for (int jp = 0; jp < 4; jp += 2) {
-                cfd_f2 a1k0[2][2], gdk0[2][2], a1k1[2][2], gdk1[2][2];
+                cfd_f2 a1k0[HT][2], gdk0[HT][2], a1k1[HT][2], gdk1[HT][2];
                 const int slot0 = jp, slot1 = jp + 1;
                 {
-                    f32x4 z[2];
+                    f32x4 z[HT];
                     front(jp, z);
                     fwd_half(jp, slot0, z, a1k0, gdk0);
                 }
                 {
-                    f32x4 z[2];
+                    f32x4 z[HT];
                     front(jp + 1, z);
                     fwd_half(jp + 1, slot1, z, a1k1, gdk1);
                 }
@@ -795,7 +807,7 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd(
         } else {
 CFD_UNROLL(CFD_HB_UNROLL)
             for (int j = 0; j < 4; ++j) {
-                f32x4 z[2];
+                f32x4 z[HT];
                 front(j, z);
                 const int col = 16 * j + n;
                 // 2. a1 = gelu(z) feeds the fc2 weight gradient; gz = (W2^T graw) * gelu'(z), k-slot 4t + r
@@ -803,7 +815,9 @@ CFD_UNROLL(CFD_HB_UNROLL)
             const cfd_f2 grj = grp[col];
             const cfd_f2 g0 = (cfd_f2)(grj.x), g1 = (cfd_f2)(grj.y);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int v = 4 * HT; v < 8; ++v) gzv[v] = 0.f;
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
 #pragma unroll
                 for (int v = 0; v < 2; ++v) {  // packed pairs of hidden units r = 2v, 2v+1
                     const cfd_f2 zz = {z[t][2 * v], z[t][2 * v + 1]};
@@ -849,12 +863,12 @@ CFD_UNROLL(CFD_HB_UNROLL)
         // ga[b][i][px0 .. px0+63] = (sum over the four hidden slices) * f'(a)
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-            const int e = threadIdx.x + 256 * k;
+            const int e = threadIdx.x + NTH * k;
             if (e >= C * 16) continue;
             const int i = e >> 4, n4 = e & 15;
             float4 v = s_red[i * 16 + n4];
 #pragma unroll
-            for (int wv = 1; wv < 4; ++wv) {
+            for (int wv = 1; wv < NWV; ++wv) {
                 const float4 u = s_red[(wv * CP + i) * 16 + n4];
                 v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
             }
@@ -900,10 +914,10 @@ CFD_UNROLL(CFD_HB_UNROLL)
     float* dst = part + (size_t)blockIdx.x * (head_part_floats_dev(C, Co));
     const size_t nb = 1;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < HT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int jh = 32 * wave + 16 * t + 4 * q + r;
+            const int jh = HPW * wave + 16 * t + 4 * q + r;
 #pragma unroll
             for (int v = 0; v < MU; ++v) {
                 const int i = 16 * v + n;
@@ -1026,9 +1040,22 @@ int cfd_int_fno_head_train(const void* a, const float* mask, const float* label,
     {
     CFD_PROF_W("k_head_train", st, B * HW * ((4.0 + cfd_dt_size(dt)) * C + 4.0 + 8.0 * Co), 2.0 * B * HW * (double)HEAD_HD * (3.0 * C + 3.0 * Co));
     const bool ap3 = dt == CFD_DT_F32 && cfd_act_pieces() == 3;
+    // eight waves of 16 hidden units (k_head_bwd: NWV) where the four-wave workgroup leaves a CU with one wave per SIMD (21 .. 32 channels);
+    // "head_waves" = 4 / 8 forces either form
+    const int hw = cfd_tune_get(CFD_TUNE_HEAD_WAVES);
+    const bool w8 = dt == CFD_DT_F32 && (hw == 8 || (hw != 4 && C > 20));
 #define CFD_HT_P(K_, V_, A_, T_, P_)                                                                                      \
-    hipLaunchKernelGGL((k_head_bwd<K_, V_, A_, true, T_, P_>), dim3(blocks), dim3(256), 0, st, (const T_*)a, mask, label, (const float*)nullptr, \
-                       (const float*)nullptr, coef, w1, b1, w2, ga, part, B, C, Co, HW, preds, b2)
+    do {                                                                                                                  \
+        if constexpr (sizeof(T_) == 4) {                                                                                  \
+            if (w8) {                                                                                                     \
+                hipLaunchKernelGGL((k_head_bwd<K_, V_, A_, true, T_, P_, 8>), dim3(blocks), dim3(512), 0, st, (const T_*)a, mask, label, (const float*)nullptr, \
+                                   (const float*)nullptr, coef, w1, b1, w2, ga, part, B, C, Co, HW, preds, b2);           \
+                break;                                                                                                    \
+            }                                                                                                             \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((k_head_bwd<K_, V_, A_, true, T_, P_>), dim3(blocks), dim3(256), 0, st, (const T_*)a, mask, label, (const float*)nullptr, \
+                           (const float*)nullptr, coef, w1, b1, w2, ga, part, B, C, Co, HW, preds, b2);                   \
+    } while (0)
 #define CFD_HT(K_, V_, A_, T_)                                                                        \
     do {                                                                                              \
         if constexpr (sizeof(T_) == 4) { if (ap3) CFD_HT_P(K_, V_, A_, T_, 3); else CFD_HT_P(K_, V_, A_, T_, 2); } \

@@ -459,3 +459,16 @@ def test_fused_block_width_32_batch_split_is_bitwise(be):
     with K.tuned(be, block_wide=1):
         res = K.check_block_batch_split(be, 5, 2, 32, 64, 64)
     assert res["fwd_bitwise"] == 0.0 and res["bwd_bitwise"] == 0.0, res
+
+
+@pytest.mark.parametrize("C,HW", [(20, 64 * 64), (20, 66 * 65), (32, 64 * 64), (5, 36 * 40)])
+def test_training_head_on_eight_waves(be, C, HW):
+    """Round 5: the one-pass training head with 16 hidden units per wave on eight waves (`head_waves` = 8; the partial d/dh sums of waves
+    w and w + 4 meet in one zeroed LDS slot through two ds_add_f32): same results class as the four-wave kernel, both piece counts, and
+    bit-stable from call to call (two contributions per slot: the order of the two adds cannot matter)."""
+    with K.tuned(be, head_waves=8):
+        res = K.check_head_train(be, 2, C, HW, 1)
+        _assert_all({k: v for k, v in res.items() if k not in ("sums", "scores")}, 5e-13)
+        with K.tuned(be, act_pieces=2):
+            res = K.check_head_train(be, 3, C, HW, 1)
+            _assert_all({k: v for k, v in res.items() if k not in ("sums", "scores")}, 1e-9)
