@@ -110,9 +110,20 @@ def evaluate(model: AutoCfdModel, data, output_dir: Path, batch_size: int = 2, p
     for table in (scores, input_scores):
         for key in table:
             table[key] = torch.stack(table[key]).cpu().tolist() if table[key] else []
-    # ONE device-to-host copy for all predictions of this rank, split back into its batches on the host
+    # all predictions of this rank to the host with ONE synchronisation: every batch is copied asynchronously into its slice of one
+    # pinned host buffer (a device-side torch.cat first would hold the split's predictions twice on the device: ADVICE r4)
     sizes = [int(p_.shape[0]) for p_ in all_preds]
-    pred_blocks = list(torch.cat(all_preds, dim=0).cpu().split(sizes)) if all_preds else []
+    pred_blocks = []
+    if all_preds:
+        first = all_preds[0]
+        host = torch.empty((sum(sizes),) + tuple(first.shape[1:]), dtype=first.dtype, pin_memory=first.is_cuda)
+        off = 0
+        for p_, n_ in zip(all_preds, sizes):
+            host[off:off + n_].copy_(p_, non_blocking=True)
+            off += n_
+        if first.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        pred_blocks = list(host.split(sizes))
     if world > 1:
         gathered = [None] * world if rank == 0 else None
         dist.gather_object((mine, scores, input_scores, pred_blocks), gathered, dst=0)

@@ -86,10 +86,15 @@ class Ffn(nn.Module):
                 j += 1
         return (ws, bs, acts, j) if len(ws) >= 2 else None
 
-    def _run(self, x: Tensor, i: int) -> Tensor:
+    def _run(self, x: Tensor, i: int, stop_at_fusable: bool = False):
+        """Layers from ``mods[i]`` on: stack kernel / chain node / single Linear(+activation), in that order of preference.
+        ``stop_at_fusable``: return ``(x, i)`` as soon as ``mods[i]`` starts a run the stack kernel takes (run_ffns_together lets
+        the runs of several nets share one launch) -- ONE routing for both callers."""
         mods = list(self.layers)
         while i < len(mods):
             run = self._fusable_run(mods, i) if x.is_cuda else None
+            if run is not None and stop_at_fusable:
+                return x, i
             if run is not None:
                 ws, bs, act, last_act, i = run
                 x = F_.ffn_stack(x, ws, bs, act, last_act)
@@ -112,7 +117,7 @@ class Ffn(nn.Module):
             if norm is not None:
                 x = norm(x)
             i += 1
-        return x
+        return (x, i) if stop_at_fusable else x
 
 
 def run_ffns_together(ffns, xs):
@@ -121,20 +126,7 @@ def run_ffns_together(ffns, xs):
     (a first Linear wider than 128), then the nets that stand at a fusable run go together, then each finishes on its own."""
     states = []  # [net, module index, tensor]
     for net, x in zip(ffns, xs):
-        mods = list(net.layers)
-        i = 0
-        while i < len(mods) and x.is_cuda and net._fusable_run(mods, i) is None:  # the single-layer prefix of Ffn._run
-            lin, act, norm = mods[i], None, None
-            if i + 1 < len(mods) and isinstance(mods[i + 1], _Act):
-                act = mods[i + 1].name
-                i += 1
-            elif i + 1 < len(mods) and isinstance(mods[i + 1], NormAct):
-                norm = mods[i + 1]
-                i += 1
-            x = F_.linear_act(x, lin.weight, lin.bias, act)
-            if norm is not None:
-                x = norm(x)
-            i += 1
+        x, i = net._run(x, 0, stop_at_fusable=True)  # the prefix no stack kernel takes (a chain node or single layers: Ffn._run's routing)
         states.append([net, i, x])
     ready = [k for k, (net, i, x) in enumerate(states) if x.is_cuda and i < len(list(net.layers))]
     if 2 <= len(ready) <= F_.FFN_STACKS_MAX:
