@@ -897,16 +897,20 @@ def main():
             probe[t] = timer(32, 1, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=t)["frames_per_s"]
             if time.perf_counter() - t_probe0 > 20.0 or (len(probe) > 1 and probe[t] < 0.8 * max(probe.values())):
                 break
-        best_t = max(probe, key=probe.get)
+        # the batch-32 ranking does not carry over to the full batch (8 threads win at 32, 16 at 256 on the 2 x EPYC 9575F box): the two
+        # best probe counts are both timed on the real workload, the faster one is reported
+        top = sorted(probe, key=probe.get, reverse=True)[:2]
+        runs = {t: timer(B, max(2, args.cpu_steps - 1), warmup=1, C=C, L=L, H=H, W=W, p=p, threads=t) for t in top}
+        best_t = max(runs, key=lambda t: runs[t]["frames_per_s"])
+        cb = runs[best_t]
         cb32 = timer(32, 5, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=best_t)
-        cb = timer(B, args.cpu_steps, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=best_t)
         result["cpu_baseline"] = dict(
             value=round(cb["frames_per_s"], 1), unit="frames/s", cores=cb["threads"], kind="reference" if use_ref else "port",
             sample=f"the SAME workload (train step fwd+nMSE+bwd+Adam, batch {B}) on "
                    + ("the reference's own Fno2d module (/root/reference/src), " if use_ref else
                       "oracle/torch_port.py (the reference's PyTorch-CPU ATen call sequence, fp32; checked against the oracle in tests/test_oracle_golden.py), ")
-                   + f"{args.cpu_steps} steps after 1 warm-up, median; thread sweep at batch 32: { {t: round(v, 1) for t, v in probe.items()} } "
-                   f"frames/s, {ncpu} host cores",
+                   + f"{cb['steps']} steps after 1 warm-up, median, best of the thread counts { {t: round(r['frames_per_s'], 1) for t, r in runs.items()} }; "
+                   f"thread sweep at batch 32: { {t: round(v, 1) for t, v in probe.items()} } frames/s, {ncpu} host cores",
             value_batch32=round(cb32["frames_per_s"], 1), thread_sweep_batch32={str(t): round(v, 1) for t, v in probe.items()},
             host_cores=ncpu)
 
