@@ -802,6 +802,10 @@ def main():
         if rank == 0:
             result["rollout"], result["rollout_66x65"] = ro, ro32
     if extra and not args.no_rollout:
+        try:  # the same horizon with four times the cases in flight (the general-grid kernels are latency-bound at 64 cases)
+            result["rollout_66x65_256cases"], _ = rollout_leg(m32, 4 * args.rollout_batch, args.rollout_steps, 66, 65, p, dev)
+        except Exception as e:  # noqa: BLE001
+            result["rollout_66x65_256cases"] = dict(error=str(e)[:200])
         try:
             result["rollout_66x65_bf16"], _ = rollout_leg(m32, args.rollout_batch, args.rollout_steps, 66, 65, p, dev, dtype="bf16")
         except TypeError:
