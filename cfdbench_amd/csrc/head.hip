@@ -30,10 +30,16 @@
 // Workgroup counts.  The `head_blocks` knob (tests: several tiles per workgroup at small sizes) can only LOWER them, and the
 // workspace is sized WITHOUT the knob (knob = false), so a knob changed after a workspace was sized and cached can never make a
 // launch write partial sums past its end.
-static int head_blocks(int B, int HW, bool knob = true) {
+static int head_blocks(int B, int HW, bool knob = true, int C = 20) {
     const long tiles = (long)B * ((HW + 63) / 64);
     long blocks = (tiles + 7) / 8;  // >= 2 tiles per wave
     if (blocks > CFD_HEAD_FWD_BLOCKS) blocks = CFD_HEAD_FWD_BLOCKS;
+    // Whole rounds of resident workgroups (round 5): the waves stride over the tiles, so 536 workgroups on the 512 slots of the
+    // 32-channel kernel (two per CU) ran a second, nearly empty round -- 54.6 us against 46.6 at 512 (64 rollout cases at 66 x 65);
+    // 1024 on the 768 slots of the narrower kernels likewise.  (Fewer workgroups than slots: unchanged.)
+    // (C <= 0: the workspace query -- no rounding, an upper bound of every rounded count)
+    const long slots = 256L * (C > 20 ? CFD_HF_OCC8 : 3);
+    if (C > 0 && blocks > slots) blocks = slots * (blocks / slots);
     const int k = knob ? cfd_tune_get(CFD_TUNE_HEAD_BLOCKS) : -1;
     if (k > 0 && blocks > k) blocks = k;
     if (blocks < 1) blocks = 1;
@@ -305,7 +311,7 @@ __device__ __forceinline__ size_t head_part_floats_dev(int C, int Co) { return (
 extern "C" size_t cfd_fno_head_workspace_bytes(int B, int C, int Hd, int Co, int HW) {
     (void)Hd;
     if (B <= 0) return 0;
-    const size_t fwd = (size_t)head_blocks(B, HW, false) * 3 * sizeof(float);
+    const size_t fwd = (size_t)head_blocks(B, HW, false, 0) * 3 * sizeof(float);
     const size_t bwd = (size_t)head_bwd_blocks(B, HW, false) * head_part_floats(C, Co) * sizeof(float);
     return fwd > bwd ? fwd : bwd;
 }
@@ -335,7 +341,7 @@ int cfd_int_fno_head_fwd(const void* a_, const float* mask, const float* label, 
     CFD_TRY(head_check("cfd_fno_head_fwd", B, C, Hd, Co, HW));
     if (B == 0) return CFD_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int blocks = head_blocks(B, HW);
+    const int blocks = head_blocks(B, HW, true, C);
     float* part = label ? (float*)ws : nullptr;
     const bool v4 = dt == CFD_DT_F32 && HW % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)preds % 16) == 0;
     {
