@@ -21,6 +21,19 @@ struct ChanWgradTail {
     float* gb;
     int nrow, Co, Ci;
 };
+// Lifting-layer (fc0) gradient sums emitted by the input-gradient kernel of FnoBlock 0 (k_block<.., STEMG>, round 5): the kernel holds
+// g_0 = dL/da_0 tile by tile in its accumulators; instead of storing it (84 MB at B = 256) for a weight-gradient pass that reads it back,
+// it adds, per (batch entry [x row split], channel c), the six sums  S = sum_px g_0 * {1, u, v, mask, grid_x(row), grid_y(col)}
+// -- all the fc0 gradient needs: the case parameters are constant per entry (sum g_0 * cp[b,k] = cp[b,k] * S[0]) -- into
+// part[entry][c][6]; k_stem_grad_combine finishes gw / gb.  inputs: (B, in_chan <= 2, H, W); mask: (B, H, W) or NULL (= ones).
+struct CfdStemG {
+    const float* inputs;  // NULL: not used (the kernel stores g_0 as usual)
+    const float* mask;
+    const float* gx;
+    const float* gy;
+    float* part;
+    int in_chan;
+};
 struct CfdReduceTail {
     SpecWgradTail spec;
     ChanWgradTail chan;
@@ -116,5 +129,11 @@ int cfd_int_chan_wgrad(const float* g, const float* a, float* gw, float* gb, voi
                        int act_in, void* stream, ChanWgradTail* defer);
 int cfd_int_chan_wgrad_dt(const float* g, const void* a, float* gw, float* gb, void* ws, int B, int Ci, int Co, int HW,
                           int act_in, int dt, void* stream, ChanWgradTail* defer);
+// stemg (may be NULL): emit the lifting layer's sums instead of storing the input gradient (only valid where cfd_int_stemg_ok holds and
+// the call is the plain input gradient, aprev == NULL)
 int cfd_int_fno_block_bwd_input(const cfd_plan* p, const float* g, const float* gz, const float* w0, const float* aprev,
-                                float* gin, int B, int Cin, int Cout, void* stream, const CfdReduceTail* tail);
+                                float* gin, int B, int Cin, int Cout, void* stream, const CfdReduceTail* tail, const CfdStemG* stemg);
+bool cfd_int_stemg_ok(const cfd_plan* p, int B, int C, int in_chan, int P, const void* inputs, const void* mask, const void* z);
+size_t cfd_int_stemg_part_bytes(const cfd_plan* p, int B, int C);
+int cfd_int_stemg_combine(const cfd_plan* p, const float* part, const float* cp, float* gw, float* gb, int B, int C, int in_chan, int P,
+                          void* stream);

@@ -19,6 +19,12 @@ struct Layout {
 
 size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
+// byte offset of the lifting layer's sum records inside the scratch region (behind the spectral and the 1x1 weight-gradient partials,
+// which the tail workgroups of the same launch are still reading)
+size_t stemg_offset(const cfd_plan* p, int B, int C, int HW) {
+    return cfd_align_up(cfd_align_up(cfd_spectral_wgrad_workspace_bytes(p, B, C, C), 256) + cfd_chan_wgrad_workspace_bytes(B, C, C, HW), 256);
+}
+
 Layout make_layout(const cfd_plan* p, const cfd_fno_shape* s, int training, int dt = CFD_DT_F32) {
     Layout L{};
     const size_t esz = cfd_dt_size(dt);  // bytes of one stored activation
@@ -44,6 +50,8 @@ Layout make_layout(const cfd_plan* p, const cfd_fno_shape* s, int training, int 
         scratch = max2(scratch, cfd_align_up(cfd_spectral_wgrad_workspace_bytes(p, B, C, C), 256) +
                                     cfd_chan_wgrad_workspace_bytes(B, C, C, (int)HW));
         scratch = max2(scratch, cfd_fno_stem_bwd_workspace_bytes(p, B, s->in_chan, s->n_case_params, C));
+        // the lifting layer's sums of k_block<.., STEMG> live behind the two weight-gradient partial regions of the last block phase
+        scratch = max2(scratch, stemg_offset(p, B, C, (int)HW) + cfd_int_stemg_part_bytes(p, B, C));
     }
     L.scratch_bytes = scratch;
     L.off_scratch = take(scratch);
@@ -220,9 +228,18 @@ extern "C" int cfd_fno_backward_phase_ex(const cfd_plan* p, const cfd_fno_shape*
     const int done = phase - 1;  // blocks already processed: the gradient sits in gA after an even count
     float* gcur = (done & 1) ? gB : gA;
     float* gnext = (done & 1) ? gA : gB;
-    if (phase == NL + 1)
+    // Round 5: where the fused FnoBlock kernel runs the last block phase (l = 0), it emits the six per-(entry, channel) sums the lifting
+    // layer's gradient needs instead of storing g_0 for a pass that reads it back (cfd_tail.h: CfdStemG): one activation-sized write and
+    // the k_chan_wgrad_stem launch less.  Both phases evaluate the same predicate.
+    const bool stemg = dt == CFD_DT_F32 && NL >= 1 &&
+                       cfd_int_stemg_ok(p, B, C, s->in_chan, s->n_case_params, inputs, mask, z);
+    float* stem_part = (float*)((char*)scratch + stemg_offset(p, B, C, HW));
+    if (phase == NL + 1) {
+        if (stemg)
+            return cfd_int_stemg_combine(p, stem_part, case_params, g->fc0_w, g->fc0_b, B, C, s->in_chan, s->n_case_params, stream);
         return cfd_fno_stem_bwd(p, gcur, inputs, mask, case_params, g->fc0_w, g->fc0_b, scratch, B, s->in_chan,
                                 s->n_case_params, C, stream);
+    }
     const int l = NL - phase;
     const int act = l > 0;
     // gcur = d loss / d a_{l+1}
@@ -251,7 +268,8 @@ extern "C" int cfd_fno_backward_phase_ex(const cfd_plan* p, const cfd_fno_shape*
                                            g->spec_w2[l], scratch, B, C, C, stream, &tail.spec));
     CFD_TRY(cfd_side_join((hipStream_t)stream, side));  // the block kernel reduces the 1x1 partial sums
     tail.nblk = (tail.spec.part || tail.chan.part) ? 128 : 0;
-    return cfd_int_fno_block_bwd_input(p, gcur, z, prm->w0_w[l], act ? (const float*)act_buf(l) : nullptr, gnext, B, C, C, stream, &tail);
+    const CfdStemG sg{(l == 0 && stemg) ? inputs : nullptr, mask, p->d_gx, p->d_gy, stem_part, s->in_chan};
+    return cfd_int_fno_block_bwd_input(p, gcur, z, prm->w0_w[l], act ? (const float*)act_buf(l) : nullptr, gnext, B, C, C, stream, &tail, &sg);
 }
 
 extern "C" int cfd_fno_backward(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm,

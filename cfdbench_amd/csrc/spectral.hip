@@ -1933,13 +1933,14 @@ __device__ __forceinline__ void cfd_strow4(float* p, float4 v) {
     if constexpr (GEN) cfd_st4u(p, v);
     else *reinterpret_cast<float4*>(p) = v;
 }
-template <int NW, int DPW, int NCH, bool ACT, bool TRANS, bool DGELU, bool TAIL, int AP, bool GEN>
+template <int NW, int DPW, int NCH, bool ACT, bool TRANS, bool DGELU, bool TAIL, int AP, bool GEN, bool STEMG = false>
 __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src, const float* __restrict__ z,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
                                                    const float* __restrict__ aprev, float* __restrict__ dst,
                                                    const bf16x8* __restrict__ tabs3, int Cs, int Cd, int H, int m1,
                                                    int m2, int T, int SA, int SB, const CfdReduceTail tail, int SPL,
-                                                   int pitch, const float* __restrict__ tailtab, int ND, int NENT) {
+                                                   int pitch, const float* __restrict__ tailtab, int ND, int NENT, const CfdStemG sg) {
+    static_assert(!STEMG || (TRANS && !DGELU && !GEN && !ACT), "the lifting-layer sums ride in the plain input-gradient kernel of 64-wide grids");
     constexpr int W = 64, NJ = 4;
     constexpr int WS = DPW <= 4 ? 4 : 8;              // floats per weight-table entry
     __shared__ float4 s_src[2 * NW * 16 * 16];        // [buf][channel in chunk][row][float4 column]
@@ -2096,7 +2097,32 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     }
     cfd_wave_lds_sync();
     const bf16x8* tb3 = s_tab3 + CFD_TW * T * 64;
-    float4 APV[2][4];  // gelu'(aprev) operands of two destination channels in flight
+    float4 APV[2][4];  // gelu'(aprev) operands of two destination channels in flight; STEMG: the tile's u / v rows (in_chan planes)
+    float4 SMK[STEMG ? 4 : 1];  // STEMG: the tile's mask rows
+    float SG[STEMG ? DPW : 1][6];  // STEMG: this lane's share of sum g_0 * {1, u, v, mask, grid_x, grid_y} of its destination channels
+    float gyv[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (STEMG) {
+#pragma unroll
+        for (int dd = 0; dd < DPW; ++dd)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) SG[dd][k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gyv[j] = sg.gy[4 * n + j];
+    }
+    auto fetch_feat = [&](int t, int which) {  // which: 0 = u, 1 = v, 2 = mask rows 16t + 4q + r, columns 4n .. 4n+3
+        if constexpr (STEMG) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const size_t off = (size_t)(16 * t + 4 * q + r4) * W + 4 * n;
+                if (which < 2) {
+                    const int ch = which < sg.in_chan ? which : 0;
+                    APV[which][r4] = *reinterpret_cast<const float4*>(sg.inputs + ((size_t)b * sg.in_chan + ch) * HW + off);
+                } else {
+                    SMK[r4] = sg.mask ? *reinterpret_cast<const float4*>(sg.mask + (size_t)b * HW + off) : make_float4(1.f, 1.f, 1.f, 1.f);
+                }
+            }
+        }
+    };
     auto fetch_ap = [&](int t, int dd, float4 (&r)[4]) {
         const int d = dbase + wave + dd * NW;
         const float* pl = aprev + ((size_t)b * Cd + (d < Cd ? d : 0)) * HW;
@@ -2126,6 +2152,10 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
             if constexpr (DGELU) {
                 if (c == NCH - 2) fetch_ap(t, 0, APV[0]);
                 if (c == NCH - 1) fetch_ap(t, 1, APV[1]);
+            }
+            if constexpr (STEMG) {  // the tile's feature rows, requested while the last chunks are mixed
+                if (c == NCH - 2) { fetch_feat(t, 0); fetch_feat(t, 1); }
+                if (c == NCH - 1) fetch_feat(t, 2);
             }
             // inverse transform of destination channel dd = c (spread over the chunks so MFMA and VALU work interleave)
             if (c < DPW && dbase + wave + c * NW < Cd) {
@@ -2199,6 +2229,22 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                 for (int r = 0; r < 4; ++r) ap[r] = APV[dd & 1][r];
                 if (dd + 2 < DPW) fetch_ap(t, dd + 2, APV[dd & 1]);
             }
+            if constexpr (STEMG) {
+                // g_0 is not stored: its products with the lifting layer's features are summed (dead channels hold zeros)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float g0 = acc[dd][0][r], g1 = acc[dd][1][r], g2 = acc[dd][2][r], g3 = acc[dd][3][r];
+                    const float gs = (g0 + g1) + (g2 + g3);
+                    const float4 uu = APV[0][r], vv = APV[1][r], mm = SMK[r];
+                    SG[dd][0] += gs;
+                    SG[dd][1] += fmaf(g0, uu.x, g1 * uu.y) + fmaf(g2, uu.z, g3 * uu.w);
+                    SG[dd][2] += fmaf(g0, vv.x, g1 * vv.y) + fmaf(g2, vv.z, g3 * vv.w);
+                    SG[dd][3] += fmaf(g0, mm.x, g1 * mm.y) + fmaf(g2, mm.z, g3 * mm.w);
+                    SG[dd][4] = fmaf(gs, sg.gx[16 * t + 4 * q + r], SG[dd][4]);
+                    SG[dd][5] += fmaf(g0, gyv[0], g1 * gyv[1]) + fmaf(g2, gyv[2], g3 * gyv[3]);
+                }
+                continue;
+            }
             if (d < Cd) {
                 float* o = dst + ((size_t)b * Cd + d) * HW + (size_t)(16 * t + 4 * q) * P + 4 * n;
 #pragma unroll
@@ -2231,6 +2277,17 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
             else tile(CfdParity<0>{}, t + 1);
         }
     }
+    if constexpr (STEMG) {  // one record per (entry [x row split], destination channel): the wave's six sums
+#pragma unroll
+        for (int dd = 0; dd < DPW; ++dd) {
+            const int d = dbase + wave + dd * NW;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float tot = cfd_wave_sum(SG[dd][k]);
+                if (lane == 0 && d < Cd) sg.part[((size_t)bi * Cd + d) * 6 + k] = tot;
+            }
+        }
+    }
 }
 
 static bool block_is_gen(const cfd_plan* p) { return p->W != 64 || p->H % 16 != 0; }  // pitch != 64 or a ragged last row tile
@@ -2251,15 +2308,9 @@ static bool block_fused_ok(const cfd_plan* p, int Cs, int Cd, const void* a, con
     return ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && (!c || ((uintptr_t)c % 16) == 0);
 }
 
-template <int NW, int DPW, int NCH>
-static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z, const float* w, const float* bias,
-                             const float* aprev, float* dst, int B, int Cs, int Cd, int act, int trans, int dgelu,
-                             hipStream_t st, const CfdReduceTail* tail) {
-    const bool ride = trans && tail && tail->nblk > 0;
-    const CfdReduceTail tl = ride ? *tail : CfdReduceTail{};
-    // destination groups per entry (k_block: ND): one unless the entry's destination channels exceed what a workgroup owns
-    const int nd = (Cd + NW * DPW - 1) / (NW * DPW);
-    // one workgroup per batch entry (and destination group), tiles streamed inside; below ~3/4 of the CU count the entries are split by row tiles
+// one workgroup per batch entry (and destination group), tiles streamed inside; below ~3/4 of the CU count the entries are split by row
+// tiles: workgroups per (entry, destination group)
+static int block_row_splits(const cfd_plan* p, int B, int nd) {
     int spl = 1;
     while (spl * 2 <= p->T && p->T % (spl * 2) == 0 && (long)B * nd * spl * 2 <= 288) spl *= 2;
     if (p->T % 2 != 0) {  // an odd tile count (five at 66 x 65): the most workgroups per entry that still fit one round, no empty ones
@@ -2268,13 +2319,38 @@ static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z
         const int tpw = (p->T + want - 1) / want;
         spl = (p->T + tpw - 1) / tpw;
     }
+    return spl;
+}
+
+template <int NW, int DPW, int NCH>
+static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z, const float* w, const float* bias,
+                             const float* aprev, float* dst, int B, int Cs, int Cd, int act, int trans, int dgelu,
+                             hipStream_t st, const CfdReduceTail* tail, const CfdStemG* stemg = nullptr) {
+    const bool ride = trans && tail && tail->nblk > 0;
+    const CfdReduceTail tl = ride ? *tail : CfdReduceTail{};
+    // destination groups per entry (k_block: ND): one unless the entry's destination channels exceed what a workgroup owns
+    const int nd = (Cd + NW * DPW - 1) / (NW * DPW);
+    const int spl = block_row_splits(p, B, nd);
     long nwg = (long)B * spl;
     if (nd > 1) nwg = (nwg + 7) / 8 * 8 * nd;  // whole groups of 8 * nd block indices (the kernel drops the padding)
     const dim3 grid((unsigned)(nwg + tl.nblk)), block(64 * NW);
     const bool ap3 = cfd_act_pieces() == 3, gen = block_is_gen(p);
+    const CfdStemG sg0{};
 #define CFD_BLK_P(A_, T_, D_, R_, P_, G_)                                                                                \
     hipLaunchKernelGGL((k_block<NW, DPW, NCH, A_, T_, D_, R_, P_, G_>), grid, block, 0, st, src, z, w, bias, aprev, dst, \
-                       (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB, tl, spl, p->W, (const float*)p->d_tail, nd, B * spl)
+                       (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB, tl, spl, p->W, (const float*)p->d_tail, nd, B * spl, sg0)
+    // the lifting-layer sums (k_block<.., STEMG>): plain input gradient of a 64-wide grid, one destination group, at most 24 channels
+    if (stemg && stemg->inputs && trans && !dgelu && !act && !gen && nd == 1) {
+        if constexpr (NW * NCH <= 24 && NW != 10) {  // (not the wide (8,2,4) shape: two destination groups; not ten waves: registers)
+#define CFD_BLK_S(R_, P_)                                                                                                       \
+    hipLaunchKernelGGL((k_block<NW, DPW, NCH, false, true, false, R_, P_, false, true>), grid, block, 0, st, src, z, w, bias, aprev, dst, \
+                       (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB, tl, spl, p->W, (const float*)p->d_tail, nd, B * spl, *stemg)
+            if (ride) { if (ap3) CFD_BLK_S(true, 3); else CFD_BLK_S(true, 2); }
+            else { if (ap3) CFD_BLK_S(false, 3); else CFD_BLK_S(false, 2); }
+#undef CFD_BLK_S
+            return;
+        }
+    }
 #define CFD_BLK(A_, T_, D_, R_)                                                      \
     do {                                                                             \
         if (gen) { if constexpr (NW != 10) { if (ap3) CFD_BLK_P(A_, T_, D_, R_, 3, true); else CFD_BLK_P(A_, T_, D_, R_, 2, true); } }  /* launch_block: never (10,2,2) */ \
@@ -2291,19 +2367,20 @@ static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z
 // (waves, destination channels per wave, source chunks): waves*DPW >= Cd and waves*NCH >= Cs
 static void launch_block(const cfd_plan* p, const float* src, const float* z, const float* w, const float* bias,
                          const float* aprev, float* dst, int B, int Cs, int Cd, int act, int trans, int dgelu,
-                         hipStream_t st, const CfdReduceTail* tail = nullptr) {
+                         hipStream_t st, const CfdReduceTail* tail = nullptr, const CfdStemG* stemg = nullptr) {
     const int cmax = Cs > Cd ? Cs : Cd;
-    if (cmax <= 8) launch_block_cfg<4, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
-    else if (cmax <= 16) launch_block_cfg<4, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
+    if (cmax <= 8) launch_block_cfg<4, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
+    else if (cmax <= 16) launch_block_cfg<4, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
     else if (cmax <= 20) {  // measured at B=256, C=20 (us): (10,2,2) 61/73/60/97, (5,4,4) 69/79/67/82, (4,5,5) 77/84/74/83
         // round 2, same box: (8,3,3) 52.8/59.3/53.5/62.2 against 49.4/60.9/50.9/66.8 -- two waves per SIMD, 3 + 2 destination
         // channels per SIMD; (10,2,2) and (5,4,4) leave SIMDs with 3 vs 2 and 2 vs 1 waves
         // general grids (pitch != 64, five row tiles): (10,2,2) would need 161 KB of LDS with the fifth tile's tables and the tail planes
-        if (dgelu || block_is_gen(p)) launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
-        else launch_block_cfg<10, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
+        // (the lifting-layer sums need ~60 more registers: ten waves -- three per SIMD, 168 registers -- would spill 69 of them)
+        if (dgelu || block_is_gen(p) || (stemg && stemg->inputs)) launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
+        else launch_block_cfg<10, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
     }
     // 21 .. 24 channels: (8,3,3).
-    else if (cmax <= 24) launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
+    else if (cmax <= 24) launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
     // 25 .. 32 channels (round 5; the reference's default width 32, src/args.py:190): with the tables in three pieces (CFD_TW) an
     // (8,4,4) workgroup would need 168 KB of LDS (source chunks 64 + modes 74 + tables 24 + weights 4), so the entry's destination
     // channels are dealt to TWO (8,2,4) workgroups of 16 channels (modes 37 KB: 133 KB), each streaming all the source channels.
@@ -2352,26 +2429,93 @@ static int launch_reduce_tail_standalone(const CfdReduceTail* tail, hipStream_t 
     return CFD_OK;
 }
 
+// ---- lifting-layer gradient from the sums of k_block<.., STEMG> (cfd_tail.h: CfdStemG) ------------------------------------------
+// gw[c][f], f = (in_chan field channels, mask, grid_x, grid_y, P case parameters), and gb[c] from part[rec][c][6], rec = batch entry x row
+// split: one workgroup per channel, thread-strided over the records in a fixed order, LDS tree; the case-parameter columns are
+// sum_b cp[b][k] * S0[b][c] (a case parameter is constant over an entry's pixels).
+__global__ __launch_bounds__(256) void k_stem_grad_combine(const float* __restrict__ part, int nrec, int spl, const float* __restrict__ cp,
+                                                           int P, int in_chan, int C, float* __restrict__ gw, float* __restrict__ gb) {
+    constexpr int NA = 6 + 8;  // the six sums + up to eight case-parameter columns
+    __shared__ float s_r[NA][256];
+    const int c = blockIdx.x;
+    float a[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) a[k] = 0.f;
+    for (int r = threadIdx.x; r < nrec; r += 256) {
+        const float* q = part + ((size_t)r * C + c) * 6;
+        float v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = q[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a[k] += v[k];
+        const float* cpb = cp + (size_t)(r / spl) * P;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < P) a[6 + k] = fmaf(cpb[k], v[0], a[6 + k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NA; ++k) s_r[k][threadIdx.x] = a[k];
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+#pragma unroll
+            for (int k = 0; k < NA; ++k) s_r[k][threadIdx.x] += s_r[k][threadIdx.x + h];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int F = in_chan + 3 + P;
+        float* row = gw + (size_t)c * F;
+        for (int i = 0; i < in_chan; ++i) row[i] = s_r[1 + i][0];
+        row[in_chan] = s_r[3][0];
+        row[in_chan + 1] = s_r[4][0];
+        row[in_chan + 2] = s_r[5][0];
+        for (int k = 0; k < P; ++k) row[in_chan + 3 + k] = s_r[6 + k][0];
+        gb[c] = s_r[0][0];
+    }
+}
+
+// whether the input gradient of FnoBlock 0 can emit the lifting layer's sums instead of storing g_0 (same predicate in both phases)
+bool cfd_int_stemg_ok(const cfd_plan* p, int B, int C, int in_chan, int P, const void* inputs, const void* mask, const void* z) {
+    if (cfd_tune_get(CFD_TUNE_STEM_FUSE) == 0) return false;
+    if (!p || block_is_gen(p) || C > 24 || in_chan < 1 || in_chan > 2 || P > 8 || B < 1) return false;
+    if (cfd_tune_get(CFD_TUNE_EXACT_FP32) == 1 || !p->d_inv_b3 || p->T > CFD_KB_TMAX || 4 * p->m1 * p->m2 + 1 > CFD_BLK_ZS) return false;
+    return ((uintptr_t)inputs % 16) == 0 && (!mask || ((uintptr_t)mask % 16) == 0) && ((uintptr_t)z % 16) == 0;
+}
+size_t cfd_int_stemg_part_bytes(const cfd_plan* p, int B, int C) { return (size_t)B * (p ? p->T : 1) * C * 6 * sizeof(float); }
+
+int cfd_int_stemg_combine(const cfd_plan* p, const float* part, const float* cp, float* gw, float* gb, int B, int C, int in_chan, int P,
+                          void* stream) {
+    const int spl = block_row_splits(p, B, 1);
+    CFD_PROF_W("k_stem_grad_combine", (hipStream_t)stream, 0.0, 0.0);
+    hipLaunchKernelGGL(k_stem_grad_combine, dim3(C), dim3(256), 0, (hipStream_t)stream, part, B * spl, spl, cp, P, in_chan, C, gw, gb);
+    CFD_LAUNCH_CHECK("cfd_fno_stem_bwd(combine)");
+    return CFD_OK;
+}
+
 int cfd_int_fno_block_bwd_input(const cfd_plan* p, const float* g, const float* gz, const float* w0, const float* aprev,
-                                float* gin, int B, int Cin, int Cout, void* stream, const CfdReduceTail* tail) {
+                                float* gin, int B, int Cin, int Cout, void* stream, const CfdReduceTail* tail, const CfdStemG* stemg) {
     CFD_REQUIRE(p && g && gz && w0 && gin, CFD_ERR_INVALID_ARG, "cfd_fno_block_bwd_input: NULL pointer");
     CFD_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && Cin <= 32 && Cout <= 32, CFD_ERR_UNSUPPORTED,
                 "cfd_fno_block_bwd_input: channels (%d -> %d) unsupported (1..32)", Cin, Cout);
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) return launch_reduce_tail_standalone(tail, st);
     if (!block_fused_ok(p, Cout, Cin, g, gin, aprev, gz)) {
+        CFD_REQUIRE(!(stemg && stemg->inputs), CFD_ERR_UNSUPPORTED, "cfd_fno_block_bwd_input: the lifting-layer sums need the fused kernel (cfd_int_stemg_ok)");
         CFD_TRY(launch_reduce_tail_standalone(tail, st));
         CFD_TRY(cfd_chanmix(g, w0, nullptr, gin, B, Cout, Cin, p->H * p->W, 0, 1, stream));
         return cfd_spectral_idft(p, gz, gin, aprev, gin, B * Cin, aprev ? 2 : 1, stream);
     }
-    CFD_PROF_W(aprev ? "k_block_bwd_dgelu" : "k_block_bwd", st,
-               (double)B * (4.0 * p->H * p->W * (Cin + Cout + (aprev ? Cin : 0)) + 16.0 * p->m1 * p->m2 * Cin), 2.0 * B * p->H * p->W * (double)Cin * Cout);
-    launch_block(p, g, gz, w0, nullptr, aprev, gin, B, Cout, Cin, 0, 1, aprev ? 1 : 0, st, tail);
+    CFD_REQUIRE(!(stemg && stemg->inputs && aprev), CFD_ERR_INVALID_ARG, "cfd_fno_block_bwd_input: the lifting-layer sums ride in the plain input gradient");
+    const bool sums = stemg && stemg->inputs;  // (reads g and the entry's feature planes, writes no gradient tensor)
+    CFD_PROF_W(sums ? "k_block_bwd_stem" : (aprev ? "k_block_bwd_dgelu" : "k_block_bwd"), st,
+               (double)B * (4.0 * p->H * p->W * ((sums ? 3 : Cin) + Cout + (aprev ? Cin : 0)) + 16.0 * p->m1 * p->m2 * Cin), 2.0 * B * p->H * p->W * (double)Cin * Cout);
+    launch_block(p, g, gz, w0, nullptr, aprev, gin, B, Cout, Cin, 0, 1, aprev ? 1 : 0, st, tail, stemg);
     CFD_LAUNCH_CHECK("cfd_fno_block_bwd_input");
     return CFD_OK;
 }
 
 extern "C" int cfd_fno_block_bwd_input(const cfd_plan* p, const float* g, const float* gz, const float* w0,
                                        const float* aprev, float* gin, int B, int Cin, int Cout, void* stream) {
-    return cfd_int_fno_block_bwd_input(p, g, gz, w0, aprev, gin, B, Cin, Cout, stream, nullptr);
+    return cfd_int_fno_block_bwd_input(p, g, gz, w0, aprev, gin, B, Cin, Cout, stream, nullptr, nullptr);
 }
