@@ -401,7 +401,9 @@ class FnoTrainEngine:
             self.forward_backward(*self._static)  # warm-up outside capture
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        from .graph import CAPTURE_MODE
+        torch.cuda.synchronize()  # (no collective of an earlier step in flight: see graph.CAPTURE_MODE)
+        with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
             self.forward_backward(*self._static)
         self._graph = g
 

@@ -24,6 +24,14 @@ import torch
 from torch import Tensor
 
 
+# Stream captures in this package run in "thread_local" error mode: in the default ("global") mode ANY thread's potentially unsafe HIP call
+# fails while a capture is open -- and inside a process group the RCCL watchdog thread polls hipEventQuery on the collectives it still
+# tracks.  A capture that began before the watchdog had retired the last all-reduce of the warm-up steps killed the process ("operation
+# not permitted when stream is capturing", one run in four of tests/test_gpu_dp.py on the GPU box).  The capturing thread itself keeps
+# the strict checks.
+CAPTURE_MODE = "thread_local"
+
+
 class GraphedTrainStep:
     def __init__(self, model, optimizer, example_batch: Dict[str, Optional[Tensor]], loss_name: str = "nmse", warmup: int = 3,
                  restore_state: bool = False, group=None, capture: bool = True):
@@ -52,8 +60,10 @@ class GraphedTrainStep:
                 self.eager_step(self.static)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
+        if self.dp:
+            torch.cuda.synchronize()  # the warm-up steps' collectives have completed before the capture opens
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
             out = model(**self.static)
             self.loss = {k: v for k, v in out["loss"].items()}
             self.preds = out["preds"]
@@ -67,9 +77,10 @@ class GraphedTrainStep:
             # the pack launch of graph A reads the gradient tensors autograd allocated during the capture (graph-private pool): they
             # must outlive the parameters' .grad, which from here on are views of the flat buffer
             self.exchange.reduce()  # (one eager exchange before the second capture: communicator warm-up on this stream)
+            torch.cuda.synchronize()
             self.exchange.install()
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), capture_error_mode=CAPTURE_MODE):
                 optimizer.step()
         if snap is not None:
             with torch.no_grad():

@@ -69,7 +69,8 @@ class FnoRollout:
             run()  # warm-up outside capture (plan tables, module load)
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        from .graph import CAPTURE_MODE
+        with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
             run()
         st["graph"] = g
         return st
