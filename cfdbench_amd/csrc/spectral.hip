@@ -1940,7 +1940,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                                                    const bf16x8* __restrict__ tabs3, int Cs, int Cd, int H, int m1,
                                                    int m2, int T, int SA, int SB, const CfdReduceTail tail, int SPL,
                                                    int pitch, const float* __restrict__ tailtab, int ND, int NENT, const CfdStemG sg) {
-    static_assert(!STEMG || (TRANS && !DGELU && !GEN && !ACT), "the lifting-layer sums ride in the plain input-gradient kernel of 64-wide grids");
+    static_assert(!STEMG || (TRANS && !DGELU && !ACT), "the lifting-layer sums ride in the plain input-gradient kernel");
     constexpr int W = 64, NJ = 4;
     constexpr int WS = DPW <= 4 ? 4 : 8;              // floats per weight-table entry
     __shared__ float4 s_src[2 * NW * 16 * 16];        // [buf][channel in chunk][row][float4 column]
@@ -2113,12 +2113,12 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
         if constexpr (STEMG) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const size_t off = (size_t)(16 * t + 4 * q + r4) * W + 4 * n;
+                const size_t off = (size_t)rowc(16 * t + 4 * q + r4) * P + 4 * n;  // (GEN: rows past H clamped; their products are skipped)
                 if (which < 2) {
                     const int ch = which < sg.in_chan ? which : 0;
-                    APV[which][r4] = *reinterpret_cast<const float4*>(sg.inputs + ((size_t)b * sg.in_chan + ch) * HW + off);
+                    APV[which][r4] = cfd_ldrow4<GEN>(sg.inputs + ((size_t)b * sg.in_chan + ch) * HW + off);
                 } else {
-                    SMK[r4] = sg.mask ? *reinterpret_cast<const float4*>(sg.mask + (size_t)b * HW + off) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    SMK[r4] = sg.mask ? cfd_ldrow4<GEN>(sg.mask + (size_t)b * HW + off) : make_float4(1.f, 1.f, 1.f, 1.f);
                 }
             }
         }
@@ -2233,15 +2233,31 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                 // g_0 is not stored: its products with the lifting layer's features are summed (dead channels hold zeros)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float g0 = acc[dd][0][r], g1 = acc[dd][1][r], g2 = acc[dd][2][r], g3 = acc[dd][3][r];
+                    const bool live = !GEN || 16 * t + 4 * q + r < H;  // (GEN: the last row tile is ragged)
+                    const float g0 = live ? acc[dd][0][r] : 0.f, g1 = live ? acc[dd][1][r] : 0.f, g2 = live ? acc[dd][2][r] : 0.f,
+                                g3 = live ? acc[dd][3][r] : 0.f;
                     const float gs = (g0 + g1) + (g2 + g3);
                     const float4 uu = APV[0][r], vv = APV[1][r], mm = SMK[r];
                     SG[dd][0] += gs;
                     SG[dd][1] += fmaf(g0, uu.x, g1 * uu.y) + fmaf(g2, uu.z, g3 * uu.w);
                     SG[dd][2] += fmaf(g0, vv.x, g1 * vv.y) + fmaf(g2, vv.z, g3 * vv.w);
                     SG[dd][3] += fmaf(g0, mm.x, g1 * mm.y) + fmaf(g2, mm.z, g3 * mm.w);
-                    SG[dd][4] = fmaf(gs, sg.gx[16 * t + 4 * q + r], SG[dd][4]);
+                    SG[dd][4] = fmaf(gs, sg.gx[rowc(16 * t + 4 * q + r)], SG[dd][4]);  // (clamped: a row past H must not read beyond the table -- 0 * NaN)
                     SG[dd][5] += fmaf(g0, gyv[0], g1 * gyv[1]) + fmaf(g2, gyv[2], g3 * gyv[3]);
+                }
+                if constexpr (GEN) {  // tail column e = q of row 16t + n (this lane's value of the 65th .. 68th column)
+                    const int x = 16 * t + n;
+                    if (q < E && x < H) {
+                        const float gv = tacc[dd] + ttail[dd];
+                        const size_t off = (size_t)x * P + W + q;
+                        const float* pin = sg.inputs + (size_t)b * sg.in_chan * HW;
+                        SG[dd][0] += gv;
+                        SG[dd][1] = fmaf(gv, pin[off], SG[dd][1]);
+                        SG[dd][2] = fmaf(gv, pin[(sg.in_chan > 1 ? (size_t)HW : 0) + off], SG[dd][2]);
+                        SG[dd][3] = fmaf(gv, sg.mask ? sg.mask[(size_t)b * HW + off] : 1.f, SG[dd][3]);
+                        SG[dd][4] = fmaf(gv, sg.gx[x], SG[dd][4]);
+                        SG[dd][5] = fmaf(gv, sg.gy[W + q], SG[dd][5]);
+                    }
                 }
                 continue;
             }
@@ -2340,13 +2356,15 @@ static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z
     hipLaunchKernelGGL((k_block<NW, DPW, NCH, A_, T_, D_, R_, P_, G_>), grid, block, 0, st, src, z, w, bias, aprev, dst, \
                        (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB, tl, spl, p->W, (const float*)p->d_tail, nd, B * spl, sg0)
     // the lifting-layer sums (k_block<.., STEMG>): plain input gradient of a 64-wide grid, one destination group, at most 24 channels
-    if (stemg && stemg->inputs && trans && !dgelu && !act && !gen && nd == 1) {
+    if (stemg && stemg->inputs && trans && !dgelu && !act && nd == 1) {
         if constexpr (NW * NCH <= 24 && NW != 10) {  // (not the wide (8,2,4) shape: two destination groups; not ten waves: registers)
-#define CFD_BLK_S(R_, P_)                                                                                                       \
-    hipLaunchKernelGGL((k_block<NW, DPW, NCH, false, true, false, R_, P_, false, true>), grid, block, 0, st, src, z, w, bias, aprev, dst, \
+#define CFD_BLK_S(R_, P_, G_)                                                                                                   \
+    hipLaunchKernelGGL((k_block<NW, DPW, NCH, false, true, false, R_, P_, G_, true>), grid, block, 0, st, src, z, w, bias, aprev, dst, \
                        (const bf16x8*)p->d_inv_b3, Cs, Cd, p->H, p->m1, p->m2, p->T, p->SA, p->SB, tl, spl, p->W, (const float*)p->d_tail, nd, B * spl, *stemg)
-            if (ride) { if (ap3) CFD_BLK_S(true, 3); else CFD_BLK_S(true, 2); }
-            else { if (ap3) CFD_BLK_S(false, 3); else CFD_BLK_S(false, 2); }
+#define CFD_BLK_SG(R_, P_) do { if (gen) CFD_BLK_S(R_, P_, true); else CFD_BLK_S(R_, P_, false); } while (0)
+            if (ride) { if (ap3) CFD_BLK_SG(true, 3); else CFD_BLK_SG(true, 2); }
+            else { if (ap3) CFD_BLK_SG(false, 3); else CFD_BLK_SG(false, 2); }
+#undef CFD_BLK_SG
 #undef CFD_BLK_S
             return;
         }
@@ -2478,9 +2496,14 @@ __global__ __launch_bounds__(256) void k_stem_grad_combine(const float* __restri
 // whether the input gradient of FnoBlock 0 can emit the lifting layer's sums instead of storing g_0 (same predicate in both phases)
 bool cfd_int_stemg_ok(const cfd_plan* p, int B, int C, int in_chan, int P, const void* inputs, const void* mask, const void* z) {
     if (cfd_tune_get(CFD_TUNE_STEM_FUSE) == 0) return false;
-    if (!p || block_is_gen(p) || C > 24 || in_chan < 1 || in_chan > 2 || P > 8 || B < 1) return false;
+    if (!p || C > 24 || in_chan < 1 || in_chan > 2 || P > 8 || B < 1) return false;
     if (cfd_tune_get(CFD_TUNE_EXACT_FP32) == 1 || !p->d_inv_b3 || p->T > CFD_KB_TMAX || 4 * p->m1 * p->m2 + 1 > CFD_BLK_ZS) return false;
-    return ((uintptr_t)inputs % 16) == 0 && (!mask || ((uintptr_t)mask % 16) == 0) && ((uintptr_t)z % 16) == 0;
+    if (((uintptr_t)z % 16) != 0) return false;
+    if (block_is_gen(p))  // general grids (66 x 65): built and tested, but OFF unless stem_fuse = 3 -- with the ragged tile and the tail column
+                          // the (8,3,3) general kernel spills and takes 122 us against 75 + 40 for the plain kernel + the weight-gradient
+                          // pass (train step 1.637 against 1.617 ms at 66 x 65, B = 256)
+        return cfd_tune_get(CFD_TUNE_STEM_FUSE) == 3 && cfd_tune_get(CFD_TUNE_BLOCK_GEN) != 0 && p->d_tail;
+    return ((uintptr_t)inputs % 16) == 0 && (!mask || ((uintptr_t)mask % 16) == 0);
 }
 size_t cfd_int_stemg_part_bytes(const cfd_plan* p, int B, int C) { return (size_t)B * (p ? p->T : 1) * C * 6 * sizeof(float); }
 

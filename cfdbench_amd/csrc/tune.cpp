@@ -43,7 +43,7 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
     {CFD_TUNE_BLOCK_WIDE, "block_wide", "CFD_BLOCK_WIDE", {-1}},      // fused FnoBlock at 25 .. 32 channels (two workgroups per entry): 1 = wherever the shape allows (tests),
                                                  // 0 = never; default: only the gelu' input gradient on the general grids, where it beats the two passes
     {CFD_TUNE_HEAD_WAVES, "head_waves", "CFD_HEAD_WAVES", {-1}},      // waves per workgroup of the one-pass training head (k_head_bwd<.., NWV>): 4 or 8; default: 8 at 21 .. 32 channels, else 4
-    {CFD_TUNE_STEM_FUSE, "stem_fuse", "CFD_STEM_FUSE", {-1}},        // 0 = the lifting layer's gradient as its own pass over a stored g_0 (k_chan_wgrad_stem) instead of sums emitted by FnoBlock 0's input-gradient kernel
+    {CFD_TUNE_STEM_FUSE, "stem_fuse", "CFD_STEM_FUSE", {-1}},        // 0 = the lifting layer's gradient as its own pass over a stored g_0 (k_chan_wgrad_stem) instead of sums emitted by FnoBlock 0's input-gradient kernel; 3 = the sums on the general grids (66 x 65) too (slower there: off by default)
 };
 std::once_flag g_once;
 void read_env() {

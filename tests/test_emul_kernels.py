@@ -474,15 +474,17 @@ def test_training_head_on_eight_waves(be, C, HW):
             _assert_all({k: v for k, v in res.items() if k not in ("sums", "scores")}, 1e-9)
 
 
+@pytest.mark.parametrize("H,W", [(64, 64), (66, 65)])
 @pytest.mark.parametrize("B,C", [(2, 20), (3, 8), (1, 24)])
-def test_lifting_layer_gradient_from_the_block_kernels_sums(be, B, C):
+def test_lifting_layer_gradient_from_the_block_kernels_sums(be, B, C, H, W):
     """Round 5: the input-gradient kernel of FnoBlock 0 emits the six per-(entry, channel) sums the fc0 gradient needs instead of storing
     g_0 (k_block<.., STEMG> + k_stem_grad_combine) -- whole model against the fp64 oracle with the fusion (default) and without it
     (`stem_fuse` = 0: the stored g_0 and the k_chan_wgrad_stem pass), several batch / width combinations (row splits, both wave shapes)."""
-    res = K.check_fno_vs_oracle(be, B, C, 2, 64, 64, border=B == 3)  # (B = 3: a mask with zero rows / column)
+    with K.tuned(be, stem_fuse=3 if W != 64 else -1):  # (on the general grids the sums are built but off by default: slower there)
+        res = K.check_fno_vs_oracle(be, B, C, 2, H, W, border=B == 3)  # (B = 3: a mask with zero rows / column; 66 x 65: ragged tile, tail column)
     assert res.pop("nmse_loss") < 1e-5
     _assert_all(res, 3e-12)
     with K.tuned(be, stem_fuse=0):
-        res0 = K.check_fno_vs_oracle(be, B, C, 2, 64, 64, border=B == 3)
+        res0 = K.check_fno_vs_oracle(be, B, C, 2, H, W, border=B == 3)
         assert res0.pop("nmse_loss") < 1e-5
         _assert_all(res0, 3e-12)
