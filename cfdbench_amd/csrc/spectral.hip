@@ -2100,7 +2100,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     float4 APV[2][4];  // gelu'(aprev) operands of two destination channels in flight; STEMG: the tile's u / v rows (in_chan planes)
     float4 SMK[STEMG ? 4 : 1];  // STEMG: the tile's mask rows
     float SG[STEMG ? DPW : 1][6];  // STEMG: this lane's share of sum g_0 * {1, u, v, mask, grid_x, grid_y} of its destination channels
-    float gyv[4] = {0.f, 0.f, 0.f, 0.f};
+    float gyv[4] = {0.f, 0.f, 0.f, 0.f}, gxr[4] = {0.f, 0.f, 0.f, 0.f};  // grid_y of the lane's columns; grid_x of the tile's rows 4q + r
     if constexpr (STEMG) {
 #pragma unroll
         for (int dd = 0; dd < DPW; ++dd)
@@ -2119,6 +2119,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                     APV[which][r4] = cfd_ldrow4<GEN>(sg.inputs + ((size_t)b * sg.in_chan + ch) * HW + off);
                 } else {
                     SMK[r4] = sg.mask ? cfd_ldrow4<GEN>(sg.mask + (size_t)b * HW + off) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    gxr[r4] = sg.gx[rowc(16 * t + 4 * q + r4)];  // (clamped: a row past H must not read beyond the table -- 0 * NaN)
                 }
             }
         }
@@ -2242,7 +2243,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                     SG[dd][1] += fmaf(g0, uu.x, g1 * uu.y) + fmaf(g2, uu.z, g3 * uu.w);
                     SG[dd][2] += fmaf(g0, vv.x, g1 * vv.y) + fmaf(g2, vv.z, g3 * vv.w);
                     SG[dd][3] += fmaf(g0, mm.x, g1 * mm.y) + fmaf(g2, mm.z, g3 * mm.w);
-                    SG[dd][4] = fmaf(gs, sg.gx[rowc(16 * t + 4 * q + r)], SG[dd][4]);  // (clamped: a row past H must not read beyond the table -- 0 * NaN)
+                    SG[dd][4] = fmaf(gs, gxr[r], SG[dd][4]);
                     SG[dd][5] += fmaf(g0, gyv[0], g1 * gyv[1]) + fmaf(g2, gyv[2], g3 * gyv[3]);
                 }
                 if constexpr (GEN) {  // tail column e = q of row 16t + n (this lane's value of the 65th .. 68th column)
