@@ -379,7 +379,7 @@ def unet_bytes_per_frame(dim, cin, H, W):
     return 3 * e * 4
 
 
-DP = dict(world=1, rank=0, steps=None, warmup=None)  # set by main() for `--gpus N --only LEG`: the leg as a data-parallel job
+DP = dict(world=1, rank=0, steps=None, warmup=None, force=False)  # set by main() for `--gpus N --only LEG`: the leg as a data-parallel job
 
 
 def model_dp_leg(name, model, batch, frames, what):
@@ -393,7 +393,7 @@ def model_dp_leg(name, model, batch, frames, what):
     steps, warmup = DP["steps"] or 20, DP["warmup"] if DP["warmup"] is not None else 5
     opt = MultiTensorAdam(model.parameters(), lr=1e-3)
     gs = GraphedTrainStep(model, opt, batch)
-    assert gs.dp == (world > 1)
+    assert gs.dp == (world > 1 or DP["force"])
     for _ in range(warmup):
         gs(**batch)
     torch.cuda.synchronize()
@@ -418,7 +418,7 @@ def model_dp_leg(name, model, batch, frames, what):
 
 
 def model_train_leg(api, name, model, batch, steps, warmup, frames, bytes_per_frame, what):
-    if DP["world"] > 1:
+    if DP["world"] > 1 or DP["force"]:
         return model_dp_leg(name, model, batch, frames, what)
     from cfdbench_amd.optim import Adam as MultiTensorAdam
     opt = MultiTensorAdam(model.parameters(), lr=1e-3)  # torch.optim.Adam's update as one launch per 80 tensors (cfd_adam_multi)
@@ -663,8 +663,13 @@ def main():
         sys.exit(1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # CFDBENCH_DP_ALWAYS_EXCHANGE=1 with --only LEG on ONE GPU: the leg's data-parallel form over a one-rank RCCL group whose collectives
+    # are forced on (engine.GradSync) -- how a 1-GPU box exercises that code path (tests/test_gpu_dp.py); not a measurement of scaling
+    force_dp = world == 1 and args.only in MODEL_LEGS and os.environ.get("CFDBENCH_DP_ALWAYS_EXCHANGE", "0") == "1"
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dp:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from cfdbench_amd import _lib
@@ -678,8 +683,8 @@ def main():
         if args.only == "spectral":
             out = {"roofline_spectral_conv2d": spectral_leg(api, _lib, dev, B, C, H, W, max(args.steps, 20))}
         elif args.only in MODEL_LEGS:
-            if world > 1:  # the leg as a data-parallel job: ONE contract-style line from rank 0
-                DP.update(world=world, rank=rank, steps=args.steps, warmup=args.warmup)
+            if world > 1 or force_dp:  # the leg as a data-parallel job: ONE contract-style line from rank 0
+                DP.update(world=world, rank=rank, steps=args.steps, warmup=args.warmup, force=force_dp)
                 out = MODEL_LEGS[args.only][1](api, dev)
                 if rank == 0:
                     print(json.dumps(out), flush=True)

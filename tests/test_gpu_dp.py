@@ -273,3 +273,23 @@ def test_graphed_train_step_over_rccl_one_rank_group():
     for got, ref in zip(params, want):
         assert np.allclose(got, ref, rtol=1e-5, atol=1e-7)
     assert len(set(losses)) == len(losses)
+
+
+def test_bench_only_leg_as_a_data_parallel_job_over_a_one_rank_rccl_group():
+    """`bench.py --only unet` in its data-parallel form (graph A -> all-reduce of the flat gradient over RCCL -> graph B), on the one GPU
+    of this box as a one-rank group with the collectives forced on: the contract-style line of `--gpus N --only LEG`."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, CFDBENCH_DP_ALWAYS_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(repo / "bench.py"), "--only", "unet", "--steps", "5", "--warmup", "2"], env=env, cwd=repo,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["config"]["parallelism"] == "dp1"
+    assert line["config"]["flat_gradient_bytes"] >= 4 * 1095362  # the U-Net's 1.1 M parameters (each tensor padded to 16 bytes)
+    assert 0 < line["ms_per_step"] < 50 and line["value"] > 0 and np.isfinite(line["final_nmse"])
