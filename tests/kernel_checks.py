@@ -1136,6 +1136,30 @@ def check_adam_multi(be, sizes=(7, 1025, 300, 1), steps=3, seed=8):
     return max(float(np.abs(be.host(a) - be.host(b)).max() / np.abs(be.host(b)).max()) for a, b in zip(pa, pb))
 
 
+def check_scale_copy_multi(be, sizes=(7, 1025, 300, 1, 70001), scale=0.25, seed=9):
+    """cfd_scale_copy_multi (the gradient pack of the data-parallel autograd paths): dst[k] = scale * src[k] for many tensors in one
+    launch per 80, written into ONE flat buffer at 4-float-aligned offsets; exact (a power-of-two scale), the gaps untouched.
+    Returns the number of wrong values."""
+    import ctypes
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    src = [rng.standard_normal(n).astype(np.float32) for n in sizes]
+    offs, off = [], 0
+    for n in sizes:
+        offs.append(off)
+        off += (n + 3) // 4 * 4
+    flat = be.dev(np.full((off,), 7.0, np.float32))
+    dsrc = [be.dev(t) for t in src]
+    api.call("cfd_scale_copy_multi", len(sizes), (ctypes.c_void_p * len(sizes))(*[P(t) for t in dsrc]),
+             (ctypes.c_void_p * len(sizes))(*[P(flat) + 4 * o for o in offs]), (ctypes.c_size_t * len(sizes))(*sizes), float(scale), be.stream)
+    be.sync()
+    got = be.host(flat)
+    want = np.full((off,), 7.0, np.float32)
+    for t, o in zip(src, offs):
+        want[o:o + t.size] = t * np.float32(scale)
+    return int((got != want).sum())
+
+
 def check_convt_strided(be, B, Ci, Co, H, W, C2=3, seed=40):
     """cfd_convt2_fwd_ex / cfd_convt2_bwd_ex with the 2H x 2W tensor as the trailing Co channels of a (C2 + Co)-channel one: the same
     values as the dense calls, bit for bit, and the leading C2 channels untouched.  Returns the number of values that differ."""

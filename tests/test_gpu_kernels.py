@@ -516,3 +516,9 @@ def test_lifting_layer_gradient_from_the_block_kernels_sums(be, B, C, H, W):
         res0 = K.check_fno_vs_oracle(be, B, C, 2, H, W, border=B == 3)
         assert res0.pop("nmse_loss") < 1e-5
         _assert_all(res0, 3e-12)
+
+
+def test_scale_copy_multi_packs_many_tensors_into_one_buffer(be):
+    """cfd_scale_copy_multi: the data-parallel gradient pack (engine.FlatGradExchange) -- 5 tensors and 170 tensors (three launches of <= 80)."""
+    assert K.check_scale_copy_multi(be) == 0
+    assert K.check_scale_copy_multi(be, sizes=tuple(1 + (37 * i) % 500 for i in range(170)), scale=0.125) == 0
