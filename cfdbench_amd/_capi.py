@@ -79,6 +79,8 @@ _SIGS = {
     "cfd_loss_sums_bwd": (_I, [_P, _P, _P, _P, _P, _Z, _P]),
     "cfd_loss_scores": (_I, [_P, _P, _P]),
     "cfd_loss_scores_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P]),
+    "cfd_mse_loss_fwd": (_I, [_P, _P, _P, _P, _P, _Z, _P]),
+    "cfd_mse_loss_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "cfd_loss_coef": (_I, [_P, _P, _I, _F, _P]),
     "cfd_label_energy_workspace_bytes": (_Z, []),
     "cfd_label_energy_coef": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),

@@ -1093,6 +1093,74 @@ extern "C" int cfd_loss_scores_bwd(const float* sums, const float* g_mse, const 
     return CFD_OK;
 }
 
+// ---- MseLoss as ONE autograd node (round 5): sums + scores from two launches, the whole backward pass from one -----------------------
+// cfd_mse_loss_fwd = cfd_masked_loss_sums whose final one-workgroup launch also writes the four scores (k_loss_final + k_loss_scores);
+// cfd_mse_loss_bwd = cfd_loss_scores_bwd folded into cfd_loss_sums_bwd: every thread forms the three sum gradients from the sums and the
+// upstream score gradients (a dozen scalar operations, the same fp32 order as k_loss_scores_bwd) and applies them to its elements.
+// Five launches per training step of every autograd model become three (each ~4.7 us at its dispatch floor: 3 % of an Auto-DeepONet step).
+__global__ __launch_bounds__(64) void k_loss_final_scores(const float* __restrict__ part, int nblk, float count, float* __restrict__ sums,
+                                                          float* __restrict__ scores) {
+    const int lane = threadIdx.x;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int k = lane; k < nblk; k += 64) { a += part[k * 3]; b += part[k * 3 + 1]; c += part[k * 3 + 2]; }
+    a = cfd_wave_sum(a); b = cfd_wave_sum(b); c = cfd_wave_sum(c);
+    if (lane == 0) {
+        sums[0] = a; sums[1] = b; sums[2] = c; sums[3] = count;
+        const float mse = a / count;           // loss.py:27
+        scores[0] = mse;
+        scores[1] = sqrtf(mse);                // loss.py:31
+        scores[2] = b / count;                 // loss.py:28
+        scores[3] = mse / (c / count);         // loss.py:35
+    }
+}
+
+extern "C" int cfd_mse_loss_fwd(const float* preds, const float* labels, float* sums, float* scores, void* ws, size_t n, void* stream) {
+    CFD_REQUIRE(preds && labels && sums && scores && ws, CFD_ERR_INVALID_ARG, "cfd_mse_loss_fwd: NULL pointer");
+    CFD_REQUIRE(n >= 1, CFD_ERR_INVALID_ARG, "cfd_mse_loss_fwd: empty tensors (mean of nothing)");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_loss_part, dim3(CFD_LOSS_BLOCKS), dim3(256), 0, st, preds, labels, n, (float*)ws);
+    CFD_LAUNCH_CHECK("cfd_mse_loss_fwd(part)");
+    hipLaunchKernelGGL(k_loss_final_scores, dim3(1), dim3(64), 0, st, (const float*)ws, CFD_LOSS_BLOCKS, (float)n, sums, scores);
+    CFD_LAUNCH_CHECK("cfd_mse_loss_fwd(final)");
+    return CFD_OK;
+}
+
+__global__ __launch_bounds__(256) void k_mse_loss_bwd(const float* __restrict__ p, const float* __restrict__ l, const float* __restrict__ sums,
+                                                      const float* __restrict__ g_mse, const float* __restrict__ g_rmse,
+                                                      const float* __restrict__ g_mae, const float* __restrict__ g_nmse,
+                                                      float* __restrict__ gp, float* __restrict__ gl, size_t n) {
+    // d(scores)/d(sums): k_loss_scores_bwd's operations, once per thread
+    const float cnt = sums[3];
+    const float mse = sums[0] / cnt, den = sums[2] / cnt;
+    float gm = g_mse ? g_mse[0] : 0.f;
+    if (g_rmse) gm += g_rmse[0] / (2.f * sqrtf(mse));
+    float gden = 0.f;
+    if (g_nmse) {
+        gm += g_nmse[0] / den;
+        gden = -g_nmse[0] * mse / (den * den);
+    }
+    const float g0 = gm / cnt, g1 = g_mae ? g_mae[0] / cnt : 0.f, g2 = gden / cnt;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float lv = l[i], d = p[i] - lv;
+        const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        const float g = g0 * 2.f * d + g1 * sg;
+        if (gp) gp[i] = g;
+        if (gl) gl[i] = g2 * 2.f * lv - g;
+    }
+}
+
+extern "C" int cfd_mse_loss_bwd(const float* preds, const float* labels, const float* sums, const float* g_mse, const float* g_rmse,
+                                const float* g_mae, const float* g_nmse, float* gp, float* gl, size_t n, void* stream) {
+    CFD_REQUIRE(preds && labels && sums, CFD_ERR_INVALID_ARG, "cfd_mse_loss_bwd: NULL pointer");
+    if (n == 0 || (!gp && !gl)) return CFD_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_mse_loss_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, preds, labels, sums, g_mse, g_rmse, g_mae,
+                       g_nmse, gp, gl, n);
+    CFD_LAUNCH_CHECK("cfd_mse_loss_bwd");
+    return CFD_OK;
+}
+
 __global__ void k_loss_coef(const float* __restrict__ sums, float* __restrict__ coef, int which, float upstream) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float c0 = 0.f, c1 = 0.f;

@@ -207,6 +207,45 @@ class LossScoresFn(torch.autograd.Function):
         return gsums
 
 
+class MseLossFn(torch.autograd.Function):
+    """(mse, rmse, mae, nmse) of MseLoss.forward (loss.py:22-37) as ONE autograd node: LossSumsFn + LossScoresFn took five launches per
+    training step (partial sums, final sum, scores | score gradients, element gradients), this one takes three (cfd_mse_loss_fwd /
+    cfd_mse_loss_bwd: the same fp32 operations in the same order).  Every autograd model's loss goes through it."""
+
+    @staticmethod
+    def forward(ctx, preds: Tensor, labels: Tensor):
+        _require_cuda(preds, labels)
+        api = _lib.api()
+        if preds.shape != labels.shape:
+            raise RuntimeError(f"MseLoss: preds {tuple(preds.shape)} vs labels {tuple(labels.shape)}")
+        p, l = _f32c(preds), _f32c(labels)
+        n = p.numel()
+        sums = torch.empty(4, dtype=torch.float32, device=p.device)
+        scores = torch.empty(4, dtype=torch.float32, device=p.device)
+        ws = _bytes(api.size("cfd_loss_workspace_bytes", n), p.device)
+        api.call("cfd_mse_loss_fwd", _ptr(p), _ptr(l), _ptr(sums), _ptr(scores), _ptr(ws), n, _stream())
+        ctx.save_for_backward(p, l, sums)
+        ctx.set_materialize_grads(False)
+        return scores[0], scores[1], scores[2], scores[3]
+
+    @staticmethod
+    def backward(ctx, g_mse, g_rmse, g_mae, g_nmse):
+        p, l, sums = ctx.saved_tensors
+        gs = [None if g is None else _f32c(g) for g in (g_mse, g_rmse, g_mae, g_nmse)]
+        gp = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        gl = torch.empty_like(l) if ctx.needs_input_grad[1] else None
+        _lib.api().call("cfd_mse_loss_bwd", _ptr(p), _ptr(l), _ptr(sums), *[_ptr(g) for g in gs], _ptr(gp), _ptr(gl), p.numel(), _stream())
+        return gp, gl
+
+
+def mse_loss_scores(preds: Tensor, labels: Tensor, normalize: bool) -> dict:
+    mse, rmse, mae, nmse = MseLossFn.apply(preds, labels)
+    out = dict(mse=mse, rmse=rmse, mae=mae)
+    if normalize:
+        out["nmse"] = nmse
+    return out
+
+
 def scores_from_sums(sums: Tensor, normalize: bool) -> dict:
     """loss.py:27-35 on the 4-float sums tensor (differentiable w.r.t. sums)."""
     mse, rmse, mae, nmse = LossScoresFn.apply(sums)

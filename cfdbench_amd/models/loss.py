@@ -1,10 +1,11 @@
 """``MseLoss`` / ``loss_name_to_fn`` with the reference's names and semantics (src/models/loss.py:8-50); the three
-full-tensor reductions run as ONE fused HIP pass (cfd_masked_loss_sums) instead of F.mse_loss + F.l1_loss + mean."""
+full-tensor reductions run as ONE fused HIP pass instead of F.mse_loss + F.l1_loss + mean, the whole loss as one autograd node
+(functional.MseLossFn: cfd_mse_loss_fwd / cfd_mse_loss_bwd)."""
 from typing import List
 
 from torch import Tensor, nn
 
-from ..functional import LossSumsFn, scores_from_sums
+from ..functional import mse_loss_scores
 
 
 class MseLoss(nn.Module):
@@ -20,7 +21,7 @@ class MseLoss(nn.Module):
         return names
 
     def forward(self, preds: Tensor, labels: Tensor) -> dict:  # loss.py:22-37
-        return scores_from_sums(LossSumsFn.apply(preds, labels), self.normalize)
+        return mse_loss_scores(preds, labels, self.normalize)
 
 
 def loss_name_to_fn(name: str, masked: bool = False) -> MseLoss:  # loss.py:40-50

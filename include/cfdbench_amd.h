@@ -185,6 +185,12 @@ int cfd_loss_scores(const float* sums, float* scores, void* stream);
  * the backward pass of cfd_loss_scores in one launch, with autograd's fp32 operation order for loss.py:27-35.  gsums[3] = 0.   */
 int cfd_loss_scores_bwd(const float* sums, const float* g_mse, const float* g_rmse, const float* g_mae, const float* g_nmse,
                         float* gsums, void* stream);
+/* MseLoss.forward / its backward as one autograd node (src/models/loss.py:22-37): sums (4 floats, as cfd_masked_loss_sums) AND scores
+ * (mse, rmse, mae, nmse) from two launches; the gradients on preds / labels (either may be NULL) from the upstream gradients of the four
+ * scores (device scalars or NULL) in ONE launch.  Same fp32 operations as the four entry points above in the same order.              */
+int cfd_mse_loss_fwd(const float* preds, const float* labels, float* sums, float* scores, void* ws, size_t n, void* stream);
+int cfd_mse_loss_bwd(const float* preds, const float* labels, const float* sums, const float* g_mse, const float* g_rmse,
+                     const float* g_mae, const float* g_nmse, float* gp, float* gl, size_t n, void* stream);
 /* coef for cfd_fno_head_bwd: which = 0 mse, 1 nmse, 2 mae; scaled by `upstream` (d objective / d loss).       */
 int cfd_loss_coef(const float* sums, float* coef, int which, float upstream, void* stream);
 /* The same coefficients BEFORE any prediction exists: d mse|nmse|mae / d preds need only the element count and

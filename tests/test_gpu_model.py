@@ -154,6 +154,26 @@ def test_mseloss_vs_reference_golden(torch, golden_dir):
         loss_name_to_fn("l1")
 
 
+def test_mse_loss_single_node_equals_the_two_node_path(torch):
+    """functional.MseLossFn (round 5: three launches per step) == LossSumsFn + LossScoresFn (five): the four scores and the gradients
+    on predictions AND labels for each score, bit for bit -- the kernels run the same fp32 operations in the same order."""
+    from cfdbench_amd.functional import LossSumsFn, MseLossFn, scores_from_sums
+    gen = torch.Generator().manual_seed(9)
+    for n in (5, 4099, 200001):
+        p0 = torch.randn(n, generator=gen).cuda()
+        l0 = torch.randn(n, generator=gen).cuda()
+        for k, name in enumerate(("mse", "rmse", "mae", "nmse")):
+            pa, la = p0.clone().requires_grad_(True), l0.clone().requires_grad_(True)
+            pb, lb = p0.clone().requires_grad_(True), l0.clone().requires_grad_(True)
+            one = MseLossFn.apply(pa, la)
+            two = scores_from_sums(LossSumsFn.apply(pb, lb), True)
+            for i, nm_ in enumerate(("mse", "rmse", "mae", "nmse")):
+                assert torch.equal(one[i], two[nm_]), (n, nm_)
+            one[k].backward()
+            two[name].backward()
+            assert torch.equal(pa.grad, pb.grad) and torch.equal(la.grad, lb.grad), (n, name)
+
+
 def test_loss_scores_node_equals_the_scalar_formulas(torch):
     """functional.LossScoresFn == loss.py:27-35 written with torch scalar ops on the sums tensor: scores bit for bit, gradients of
     every score w.r.t. the sums to fp32 rounding."""
