@@ -881,6 +881,55 @@ def main():
         except Exception as e:  # noqa: BLE001
             result["split2"] = dict(error=str(e)[:300])
 
+    # ---- the PCIe-inclusive rate: the same step fed from PINNED HOST batches (never `value`: the C ABI takes device pointers and the
+    # harness keeps the data set resident, harness/data.py:DeviceBatchLoader; this is what a caller that hands over host batches gets) ----
+    if extra and not args.no_extra:
+        try:
+            dev_t = (inputs, label, cp, mask)
+            hb = [tuple(t.cpu().pin_memory() for t in dev_t) for _ in range(2)]
+            db = [tuple(torch.empty_like(t) for t in dev_t) for _ in range(2)]
+            nbytes = sum(t.numel() * t.element_size() for t in dev_t)
+            turn = [0]
+
+            def serial_step():  # upload on the step's own stream, then the step
+                k = turn[0] & 1
+                turn[0] += 1
+                for d, h in zip(db[k], hb[k]):
+                    d.copy_(h, non_blocking=True)
+                eng.train_step(*db[k])
+            dt_ser = min(time_steps(serial_step, args.steps, 5) for _ in range(2))
+            cur, side = torch.cuda.current_stream(), torch.cuda.Stream()
+            ready, free = [torch.cuda.Event() for _ in range(2)], [torch.cuda.Event() for _ in range(2)]
+            for e in free:
+                e.record(cur)
+
+            def upload(k):  # batch k: host -> its device buffers on the copy stream, once the step that last read them has finished
+                side.wait_event(free[k])
+                with torch.cuda.stream(side):
+                    for d, h in zip(db[k], hb[k]):
+                        d.copy_(h, non_blocking=True)
+                ready[k].record(side)
+            turn[0] = 0
+            upload(0)
+
+            def overlapped_step():  # step i on buffer set i & 1 while set (i + 1) & 1 is uploaded behind it
+                k = turn[0] & 1
+                turn[0] += 1
+                upload(k ^ 1)
+                cur.wait_event(ready[k])
+                eng.train_step(*db[k])
+                free[k].record(cur)
+            dt_ov = min(time_steps(overlapped_step, args.steps, 5) for _ in range(2))
+            result["train_host_batches"] = dict(
+                what=f"the headline step fed from pinned host batches (inputs, label, mask, case parameters: {nbytes / 1e6:.1f} MB per step over PCIe)",
+                serial_ms_per_step=round(dt_ser * 1e3, 4), serial_frames_per_s=round(B / dt_ser, 1),
+                overlapped_ms_per_step=round(dt_ov * 1e3, 4), overlapped_frames_per_s=round(B / dt_ov, 1),
+                h2d_bytes_per_step=nbytes, serial_h2d_share_ms=round((dt_ser - elapsed / args.steps) * 1e3, 4),
+                note="serial: uploads on the step's stream; overlapped: two buffer sets, the next batch uploaded on a copy stream during the step")
+            del hb, db
+        except Exception as e:  # noqa: BLE001
+            result["train_host_batches"] = dict(error=f"{type(e).__name__}: {str(e)[:300]}")
+
     # ---- other model families of BASELINE.json (one GPU's share of configs[2] and configs[3]) and of SURVEY 8 a-9 / f-3 ----
     if extra and not args.no_extra:
         for leg in MODEL_LEGS:
