@@ -898,7 +898,9 @@ def main():
                     d.copy_(h, non_blocking=True)
                 eng.train_step(*db[k])
             dt_ser = min(time_steps(serial_step, args.steps, 5) for _ in range(2))
-            cur, side = torch.cuda.current_stream(), torch.cuda.Stream()
+            from cfdbench_amd.harness.data import overlapping_copy_stream
+            cur = torch.cuda.current_stream()
+            side, side_overlaps = overlapping_copy_stream(dev)  # (one stream in four shares the step's hardware queue and cannot overlap it)
             ready, free = [torch.cuda.Event() for _ in range(2)], [torch.cuda.Event() for _ in range(2)]
             for e in free:
                 e.record(cur)
@@ -925,7 +927,10 @@ def main():
                 serial_ms_per_step=round(dt_ser * 1e3, 4), serial_frames_per_s=round(B / dt_ser, 1),
                 overlapped_ms_per_step=round(dt_ov * 1e3, 4), overlapped_frames_per_s=round(B / dt_ov, 1),
                 h2d_bytes_per_step=nbytes, serial_h2d_share_ms=round((dt_ser - elapsed / args.steps) * 1e3, 4),
-                note="serial: uploads on the step's stream; overlapped: two buffer sets, the next batch uploaded on a copy stream during the step")
+                copy_stream_overlaps=bool(side_overlaps),
+                note="serial: hipMemcpyAsync on the step's stream; overlapped: two buffer sets, the next batch's copies on a second stream during the "
+                     "step (a stream probed not to share the step's hardware queue: harness/data.py:overlapping_copy_stream).  An upload KERNEL "
+                     "reading the pinned pages does not overlap on any stream (tools/exp/host_batches.py)")
             del hb, db
         except Exception as e:  # noqa: BLE001
             result["train_host_batches"] = dict(error=f"{type(e).__name__}: {str(e)[:300]}")

@@ -117,3 +117,38 @@ class DeviceBatchLoader:
             y = self.labels.index_select(0, idx)
             yield dict(inputs=x[:, :-1].contiguous(), label=y[:, :-1].contiguous(), mask=x[:, -1:].contiguous(),
                        case_params=self.case_params.index_select(0, idx))
+
+
+def overlapping_copy_stream(device=None, tries: int = 8, work_passes: int = 40):
+    """A stream whose host-to-device copies run WHILE the kernels of the current stream execute -- for callers that own pinned HOST
+    batches and upload batch i + 1 during step i (bench.py's ``train_host_batches`` leg; the resident ``DeviceBatchLoader`` needs none).
+
+    Not every stream can: HIP maps its streams round-robin onto a few hardware queues (four here), and a stream that shares the
+    current stream's queue executes behind it -- on MI355X every fourth ``torch.cuda.Stream()`` serialises with the default stream
+    (measured, tools/exp/host_batches.py: step 1.29 ms with the upload hidden on 33 of 40 fresh streams, 1.69 ms = step + copy on the
+    other 7).  So candidates are probed: ~2 ms of kernels on the current stream, a small pinned copy on the candidate behind the same
+    start event, and the candidate is taken when its copy finished in under half the kernels' time.  Returns ``(stream, overlaps)``;
+    ``overlaps`` is False when no candidate passed (the last one is returned)."""
+    cur = torch.cuda.current_stream(device)
+    dev = cur.device
+    x = torch.empty(32 << 20, dtype=torch.float32, device=dev)
+    h = torch.zeros(1024, dtype=torch.float32).pin_memory()
+    d = torch.empty(1024, dtype=torch.float32, device=dev)
+    d.copy_(h)  # (first touch of the freshly pinned page)
+    cand = None
+    for _ in range(tries):
+        cand = torch.cuda.Stream(dev)
+        start, k_end, c_end = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        torch.cuda.synchronize(dev)
+        start.record(cur)
+        for _ in range(work_passes):
+            x.mul_(1.0)
+        k_end.record(cur)
+        cand.wait_event(start)
+        with torch.cuda.stream(cand):
+            d.copy_(h, non_blocking=True)
+        c_end.record(cand)
+        torch.cuda.synchronize(dev)
+        if start.elapsed_time(c_end) < 0.5 * start.elapsed_time(k_end):
+            return cand, True
+    return cand, False
