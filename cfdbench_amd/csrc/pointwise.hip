@@ -1380,19 +1380,41 @@ extern "C" int cfd_gelu_bwd(const float* x, const float* gy, float* gx, size_t n
 // ------------------------------------------------------------------------------------------------------
 // Adam  (torch.optim.Adam defaults: amsgrad=False, maximize=False; train_auto.py:213)
 // ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps, float wd,
+                                            float bc1, float rsqrt_bc2, float gscale) {
+    float gi = g * gscale;
+    if (wd != 0.f) gi = fmaf(wd, p, gi);
+    m = fmaf(1.f - b1, gi - m, m);                 // m.lerp_(g, 1-b1)
+    v = fmaf(b2, v, (1.f - b2) * gi * gi);         // v.mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = sqrtf(v) * rsqrt_bc2 + eps;  // sqrt(v)/sqrt(bc2) + eps
+    p = p - (lr / bc1) * (m / denom);
+}
+// VEC: the four buffers are 16-byte aligned -- a thread owns four consecutive elements per trip (one 16-byte load per buffer: the
+// flat buffer of the FNO engine, 926 k elements, is ONE trip of 905 workgroups instead of two trips of 2048); the last n % 4 elements
+// go to the first threads of the grid one by one.
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
                                               float wd, float bc1, float rsqrt_bc2, float gscale) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float gi = g[i] * gscale;
-        const float pi = p[i];
-        if (wd != 0.f) gi = fmaf(wd, pi, gi);
-        const float mi = fmaf(1.f - b1, gi - m[i], m[i]);           // m.lerp_(g, 1-b1)
-        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);       // v.mul_(b2).addcmul_(g, g, 1-b2)
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;              // sqrt(v)/sqrt(bc2) + eps
-        p[i] = pi - (lr / bc1) * (mi / denom);
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    if constexpr (VEC) {
+        const size_t n4 = n >> 2;
+        for (size_t i = t0; i < n4; i += nt) {
+            f32x4 pi = reinterpret_cast<const f32x4*>(p)[i], mi = reinterpret_cast<const f32x4*>(m)[i], vi = reinterpret_cast<const f32x4*>(v)[i];
+            const f32x4 gi = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pj = pi[j], mj = mi[j], vj = vi[j];
+                adam_update(pj, gi[j], mj, vj, lr, b1, b2, eps, wd, bc1, rsqrt_bc2, gscale);
+                pi[j] = pj, mi[j] = mj, vi[j] = vj;
+            }
+            reinterpret_cast<f32x4*>(m)[i] = mi;
+            reinterpret_cast<f32x4*>(v)[i] = vi;
+            reinterpret_cast<f32x4*>(p)[i] = pi;
+        }
+        for (size_t i = 4 * n4 + t0; i < n; i += nt) adam_update(p[i], g[i], m[i], v[i], lr, b1, b2, eps, wd, bc1, rsqrt_bc2, gscale);
+    } else {
+        for (size_t i = t0; i < n; i += nt) adam_update(p[i], g[i], m[i], v[i], lr, b1, b2, eps, wd, bc1, rsqrt_bc2, gscale);
     }
 }
 
@@ -1402,6 +1424,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 // workgroups [blk0, blk0 + nblk) belong to item i.  Learning rate and step count come from device scalars when given (a captured
 // HIP graph replays with the values of the moment), bias corrections are formed in fp32 like torch's capturable path.
 #define CFD_ADAM_MAX 80
+#define CFD_MULTI_MAX_BLOCKS 2048u  // workgroups per tensor of the multi-tensor launches (beyond: several trips per thread)
 struct AdamItem {
     float* p;
     const float* g;
@@ -1417,24 +1440,49 @@ struct AdamBatch {
 __global__ __launch_bounds__(256) void k_adam_multi(const AdamBatch b, const float* __restrict__ lr_dev, float lr,
                                                     const float* __restrict__ step_dev, float step, float b1, float b2, float eps,
                                                     float wd, float gscale) {
-    int i = 0;
-    while (i + 1 < b.n && blockIdx.x >= b.it[i + 1].blk0) ++i;
+    // this workgroup's item: the last one whose first workgroup is <= blockIdx.x.  Bisection -- seven dependent scalar loads of the
+    // kernel-argument table at most; the linear walk of rounds 3-4 cost the last items' workgroups up to 79 of them
+    int i = 0, hi = b.n;
+    while (hi - i > 1) {
+        const int mid = (i + hi) >> 1;
+        if (blockIdx.x >= b.it[mid].blk0) i = mid;
+        else hi = mid;
+    }
     const AdamItem& e = b.it[i];
     const unsigned nblk = (i + 1 < b.n ? b.it[i + 1].blk0 : gridDim.x) - e.blk0;
     if (lr_dev) lr = lr_dev[0];
     if (step_dev) step = step_dev[0];
-    const float bc1 = 1.f - powf(b1, step), rsqrt_bc2 = 1.f / sqrtf(1.f - powf(b2, step));
-    for (unsigned k = (blockIdx.x - e.blk0) * blockDim.x + threadIdx.x; k < e.n; k += nblk * blockDim.x) {
-        float gi = e.g[k] * gscale;
-        const float pi = e.p[k];
-        if (wd != 0.f) gi = fmaf(wd, pi, gi);
-        const float mi = fmaf(1.f - b1, gi - e.m[k], e.m[k]);
-        const float vi = fmaf(b2, e.v[k], (1.f - b2) * gi * gi);
-        e.m[k] = mi;
-        e.v[k] = vi;
-        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
-        e.p[k] = pi - (lr / bc1) * (mi / denom);
+    // the bias corrections once per workgroup (wave 0), not once per wave: two powf are ~300 VALU instructions, and with one element per
+    // thread they were most of the kernel's issue time
+    __shared__ float s_bc[2];
+    if (threadIdx.x < 64) {
+        const float c1 = 1.f - powf(b1, step), c2 = 1.f / sqrtf(1.f - powf(b2, step));
+        if (threadIdx.x == 0) s_bc[0] = c1, s_bc[1] = c2;
     }
+    __syncthreads();
+    const float bc1 = s_bc[0], rsqrt_bc2 = s_bc[1];
+    // (bit 31 of n: the item's four buffers are 16-byte aligned -- a thread owns four consecutive elements per trip, the last n % 4
+    // elements go one by one to the item's first threads)
+    const unsigned n = e.n & 0x7fffffffu, t0 = (blockIdx.x - e.blk0) * blockDim.x + threadIdx.x, nt = nblk * blockDim.x;
+    unsigned first = 0;
+    if (e.n >> 31) {
+        const unsigned n4 = n >> 2;
+        for (unsigned k = t0; k < n4; k += nt) {
+            f32x4 pi = reinterpret_cast<const f32x4*>(e.p)[k], mi = reinterpret_cast<const f32x4*>(e.m)[k], vi = reinterpret_cast<const f32x4*>(e.v)[k];
+            const f32x4 gi = reinterpret_cast<const f32x4*>(e.g)[k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pj = pi[j], mj = mi[j], vj = vi[j];
+                adam_update(pj, gi[j], mj, vj, lr, b1, b2, eps, wd, bc1, rsqrt_bc2, gscale);
+                pi[j] = pj, mi[j] = mj, vi[j] = vj;
+            }
+            reinterpret_cast<f32x4*>(e.m)[k] = mi;
+            reinterpret_cast<f32x4*>(e.v)[k] = vi;
+            reinterpret_cast<f32x4*>(e.p)[k] = pi;
+        }
+        first = 4 * n4;
+    }
+    for (unsigned k = first + t0; k < n; k += nt) adam_update(e.p[k], e.g[k], e.m[k], e.v[k], lr, b1, b2, eps, wd, bc1, rsqrt_bc2, gscale);
 }
 
 extern "C" int cfd_adam_multi(int n, float* const* param, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
@@ -1455,11 +1503,17 @@ extern "C" int cfd_adam_multi(int n, float* const* param, const float* const* gr
             CFD_REQUIRE(numel[k] < (1ull << 31), CFD_ERR_UNSUPPORTED, "cfd_adam_multi: item %d has 2^31 or more elements", k);
             AdamItem& e = b.it[i];
             e.p = param[k], e.g = grad[k], e.m = exp_avg[k], e.v = exp_avg_sq[k], e.n = (unsigned)numel[k], e.blk0 = blocks;
-            unsigned nb = (e.n + 1023) / 1024;  // four elements per thread and trip
+            // ONE trip per thread up to 2048 workgroups per tensor, four elements in 16-byte units where the buffers allow: a thread that
+            // walks several trips pays one memory latency per trip (the Auto-DeepONet's 430 k-element first-layer weight: 7 trips on 256
+            // workgroups), and one element per thread takes more workgroups than the chip holds at once (2300 for that model: two
+            // rounds of the whole latency chain -- table lookup, step / rate scalars, bias corrections, loads)
+            const bool vec = e.n >= 4 && ((((uintptr_t)e.p | (uintptr_t)e.g | (uintptr_t)e.m | (uintptr_t)e.v) & 15) == 0);
+            unsigned nb = ((vec ? e.n / 4 : e.n) + 255) / 256;
+            if (vec) e.n |= 0x80000000u;
             if (nb < 1) nb = 1;
-            if (nb > 256) nb = 256;
+            if (nb > CFD_MULTI_MAX_BLOCKS) nb = CFD_MULTI_MAX_BLOCKS;
             blocks += nb;
-            total += (double)e.n;
+            total += (double)(e.n & 0x7fffffffu);
         }
         CFD_PROF_W("k_adam", (hipStream_t)stream, 28.0 * total, 12.0 * total);
         hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b, lr_dev, lr, step_dev, step, beta1, beta2,
@@ -1482,8 +1536,12 @@ struct CopyBatch {
     CopyItem it[CFD_ADAM_MAX];
 };
 __global__ __launch_bounds__(256) void k_scale_copy_multi(const CopyBatch b, float scale) {
-    int i = 0;
-    while (i + 1 < b.n && blockIdx.x >= b.it[i + 1].blk0) ++i;
+    int i = 0, hi = b.n;  // (bisection, as k_adam_multi)
+    while (hi - i > 1) {
+        const int mid = (i + hi) >> 1;
+        if (blockIdx.x >= b.it[mid].blk0) i = mid;
+        else hi = mid;
+    }
     const CopyItem& e = b.it[i];
     const unsigned nblk = (i + 1 < b.n ? b.it[i + 1].blk0 : gridDim.x) - e.blk0;
     for (unsigned k = (blockIdx.x - e.blk0) * blockDim.x + threadIdx.x; k < e.n; k += nblk * blockDim.x) e.d[k] = e.s[k] * scale;
@@ -1504,9 +1562,9 @@ extern "C" int cfd_scale_copy_multi(int n, const float* const* src, float* const
             CFD_REQUIRE(numel[k] < (1ull << 31), CFD_ERR_UNSUPPORTED, "cfd_scale_copy_multi: item %d has 2^31 or more elements", k);
             CopyItem& e = b.it[i];
             e.s = src[k], e.d = dst[k], e.n = (unsigned)numel[k], e.blk0 = blocks;
-            unsigned nb = (e.n + 1023) / 1024;
+            unsigned nb = (e.n + 255) / 256;  // (as cfd_adam_multi: one element per thread up to CFD_MULTI_MAX_BLOCKS workgroups per tensor)
             if (nb < 1) nb = 1;
-            if (nb > 256) nb = 256;
+            if (nb > CFD_MULTI_MAX_BLOCKS) nb = CFD_MULTI_MAX_BLOCKS;
             blocks += nb;
             total += (double)e.n;
         }
@@ -1524,12 +1582,16 @@ extern "C" int cfd_adam_flat(float* param, const float* grad, float* exp_avg, fl
     CFD_REQUIRE(step >= 1, CFD_ERR_INVALID_ARG, "cfd_adam_flat: step must be >= 1");
     if (n == 0) return CFD_OK;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    size_t blocks = (n + 255) / 256;
+    const bool vec = ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0) && n >= 4;
+    size_t blocks = ((vec ? n / 4 : n) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     CFD_PROF_W("k_adam", (hipStream_t)stream, 28.0 * n, 12.0 * n);  // read p, g, m, v; write p, m, v
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)),
-                       grad_scale);
+    if (vec)
+        hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                           beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+    else
+        hipLaunchKernelGGL(k_adam<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                           beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
     CFD_LAUNCH_CHECK("cfd_adam_flat");
     return CFD_OK;
 }

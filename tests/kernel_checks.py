@@ -1114,26 +1114,50 @@ def check_loss_scores_bwd(be, seed=6):
     return worst
 
 
-def check_adam_multi(be, sizes=(7, 1025, 300, 1), steps=3, seed=8):
+def check_adam_multi(be, sizes=(7, 1025, 300, 1), steps=3, seed=8, shift_odd=False):
     """cfd_adam_multi (many tensors, one launch, step count and rate from device scalars) against cfd_adam_flat tensor by tensor:
-    the same update up to the fp32 rounding of the bias corrections.  Returns the largest relative difference of the parameters."""
+    the same update up to the fp32 rounding of the bias corrections.  ``shift_odd``: every second tensor's four buffers start one
+    element off the 16-byte grid (the one-element-per-thread path beside the 16-byte-unit one in ONE launch).  Returns the largest
+    relative difference of the parameters."""
     import ctypes
     api, P = be.api, be.ptr
     rng = np.random.default_rng(seed)
+    sh = [1 if (shift_odd and t % 2) else 0 for t in range(len(sizes))]
+    pad = lambda a, s_: np.concatenate([np.zeros(s_, np.float32), a])
     p0 = [rng.standard_normal(n).astype(np.float32) for n in sizes]
-    pa, ma, va = [be.dev(t) for t in p0], [be.zeros((n,)) for n in sizes], [be.zeros((n,)) for n in sizes]
+    pa, ma, va = ([be.dev(pad(t, s_)) for t, s_ in zip(p0, sh)], [be.zeros((n + s_,)) for n, s_ in zip(sizes, sh)],
+                  [be.zeros((n + s_,)) for n, s_ in zip(sizes, sh)])
     pb, mb, vb = [be.dev(t) for t in p0], [be.zeros((n,)) for n in sizes], [be.zeros((n,)) for n in sizes]
     lr = be.dev(np.array([2e-3], np.float32))
-    col = lambda ts: (ctypes.c_void_p * len(ts))(*[P(t) for t in ts])
+    col = lambda ts: (ctypes.c_void_p * len(ts))(*[P(t) + 4 * s_ for t, s_ in zip(ts, sh)])
     for k in range(1, steps + 1):
-        g = [be.dev(rng.standard_normal(n).astype(np.float32)) for n in sizes]
+        gh = [rng.standard_normal(n).astype(np.float32) for n in sizes]
+        ga, g = [be.dev(pad(t, s_)) for t, s_ in zip(gh, sh)], [be.dev(t) for t in gh]
         stp = be.dev(np.array([float(k)], np.float32))
-        api.call("cfd_adam_multi", len(sizes), col(pa), col(g), col(ma), col(va), (ctypes.c_size_t * len(sizes))(*sizes), P(lr), 0.0, P(stp), 0.0,
+        api.call("cfd_adam_multi", len(sizes), col(pa), col(ga), col(ma), col(va), (ctypes.c_size_t * len(sizes))(*sizes), P(lr), 0.0, P(stp), 0.0,
                  0.9, 0.999, 1e-8, 0.01, 1.0, be.stream)
         for t in range(len(sizes)):
             api.call("cfd_adam_flat", P(pb[t]), P(g[t]), P(mb[t]), P(vb[t]), sizes[t], 2e-3, 0.9, 0.999, 1e-8, 0.01, k, 1.0, be.stream)
         be.sync()
-    return max(float(np.abs(be.host(a) - be.host(b)).max() / np.abs(be.host(b)).max()) for a, b in zip(pa, pb))
+    return max(float(np.abs(be.host(a)[s_:] - be.host(b)).max() / np.abs(be.host(b)).max()) for a, b, s_ in zip(pa, pb, sh))
+
+
+def check_adam_flat_unaligned(be, n=1003, seed=10):
+    """cfd_adam_flat on buffers that are NOT 16-byte aligned (element offset 1: the one-element-per-thread kernel) against the same
+    update on aligned buffers (16-byte units, four elements per thread + a scalar tail).  Returns the number of differing values."""
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    host = [rng.standard_normal(n).astype(np.float32) for _ in range(2)] + [np.abs(rng.standard_normal(n)).astype(np.float32) * 1e-3 for _ in range(2)]
+    al = [be.dev(t) for t in host]                                         # p, g, m, v
+    un = [be.dev(np.concatenate([np.zeros(1, np.float32), t])) for t in host]
+    api.call("cfd_adam_flat", P(al[0]), P(al[1]), P(al[2]), P(al[3]), n, 1e-3, 0.9, 0.999, 1e-8, 0.01, 2, 0.5, be.stream)
+    api.call("cfd_adam_flat", P(un[0]) + 4, P(un[1]) + 4, P(un[2]) + 4, P(un[3]) + 4, n, 1e-3, 0.9, 0.999, 1e-8, 0.01, 2, 0.5, be.stream)
+    be.sync()
+    bad = 0
+    for a, u, h in zip(al, un, host):
+        got = be.host(u)
+        bad += int(np.sum(got[1:] != be.host(a))) + int(got[0] != 0.0)
+    return bad + int(np.array_equal(be.host(al[0]), host[0]))  # (and the update did change the parameters)
 
 
 def check_scale_copy_multi(be, sizes=(7, 1025, 300, 1, 70001), scale=0.25, seed=9):

@@ -349,6 +349,15 @@ def test_adam_for_many_tensors_in_one_launch(be):
     assert K.check_adam_multi(be, sizes=(7, 1025, 300, 1)) < 2e-6
 
 
+def test_adam_for_many_tensors_aligned_and_unaligned_in_one_launch(be):
+    assert K.check_adam_multi(be, sizes=(7, 1025, 300, 1, 9, 64), shift_odd=True) < 2e-6
+
+
+def test_adam_flat_on_unaligned_buffers(be):
+    """the 16-byte-unit Adam kernel and its one-element-per-thread form (buffers off the 16-byte grid) make the same update, bit for bit"""
+    assert K.check_adam_flat_unaligned(be) == 0
+
+
 def test_loss_scores_and_their_gradient(be):
     """(mse, rmse, mae, nmse) from the sums tensor and d(scores)/d(sums), one launch each"""
     assert K.check_loss_scores_bwd(be) < 1e-6

@@ -347,6 +347,22 @@ def test_adam_for_many_tensors_in_one_launch(be):
     assert K.check_adam_multi(be, sizes=tuple([3, 700, 100000, 12] * 25)) < 2e-6
 
 
+def test_adam_for_many_tensors_aligned_and_unaligned_in_one_launch(be):
+    assert K.check_adam_multi(be, sizes=(7, 1025, 300, 1, 9, 64), shift_odd=True) < 2e-6
+
+
+def test_adam_flat_on_unaligned_buffers(be):
+    """the 16-byte-unit Adam kernel and its one-element-per-thread form (buffers off the 16-byte grid) make the same update, bit for bit"""
+    assert K.check_adam_flat_unaligned(be) == 0
+    assert K.check_adam_flat_unaligned(be, n=926446) == 0  # the FNO engine's flat buffer: one trip of 905 workgroups / two of 2048
+
+
+def test_multi_tensor_launches_beyond_the_workgroup_cap(be):
+    """a tensor of more than 2048 x 256 elements: several trips per thread in cfd_adam_multi / cfd_scale_copy_multi"""
+    assert K.check_adam_multi(be, sizes=(600001, 5, 2048 * 256 + 1)) < 2e-6
+    assert K.check_scale_copy_multi(be, sizes=(600001, 3, 2048 * 256 + 1), scale=0.5) == 0
+
+
 def test_loss_scores_and_their_gradient(be):
     """(mse, rmse, mae, nmse) from the sums tensor and d(scores)/d(sums), one launch each"""
     assert K.check_loss_scores_bwd(be) < 1e-6
