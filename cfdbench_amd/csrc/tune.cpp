@@ -44,6 +44,9 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
                                                  // 0 = never; default: only the gelu' input gradient on the general grids, where it beats the two passes
     {CFD_TUNE_HEAD_WAVES, "head_waves", "CFD_HEAD_WAVES", {-1}},      // waves per workgroup of the one-pass training head (k_head_bwd<.., NWV>): 4 or 8; default: 8 at 21 .. 32 channels, else 4
     {CFD_TUNE_STEM_FUSE, "stem_fuse", "CFD_STEM_FUSE", {-1}},        // 0 = the lifting layer's gradient as its own pass over a stored g_0 (k_chan_wgrad_stem) instead of sums emitted by FnoBlock 0's input-gradient kernel; 3 = the sums on the general grids (66 x 65) too (slower there: off by default)
+    {CFD_TUNE_MODE_MFMA, "mode_mfma", "CFD_MODE_MFMA", {-1}},        // mode mixing / adjoint / spectral weight gradient on the fp32 matrix pipe (modes.hip, round 6): 0 = never (the batch-in-lanes
+                                                 // VALU kernels of spectral.hip), 1 = wherever the shape allows (tests: small batches); default: 20 channels and >= 128 entries
+    {CFD_TUNE_MODE_BC, "mode_bc", "CFD_MODE_BC", {-1}},            // batch entries per chunk of the modes.hip kernels (tests: several chunks and ragged stages at small batches)
 };
 std::once_flag g_once;
 void read_env() {

@@ -43,8 +43,16 @@ def test_mix_and_spectral_wgrad_multi_step(be, want_wg, nwv, B, C):
     """The batch-in-lanes kernels (k_mix_lds, k_spec_wgrad_tile, the fused k_mixadj_wgrad) at chunk sizes that reach
     the software-pipelined loops of the weight gradient (several 8-entry steps per workgroup, ragged last step) and
     several workgroup shapes of the mixing kernel, with a small batch."""
-    with K.tuned(be, mix_nwv=int(nwv), wgrad_wg=int(want_wg)):
+    with K.tuned(be, mix_nwv=int(nwv), wgrad_wg=int(want_wg), mode_mfma=0):
         _assert_all(K.check_mix_wgrad(be, B, C, C))
+
+
+@pytest.mark.parametrize("B,bc", [(3, -1), (37, -1), (45, 16), (21, 5)])
+def test_mix_and_spectral_wgrad_on_the_matrix_pipe(be, B, bc):
+    """modes.hip (round 6): the three mode-domain contractions of 20 channels as real GEMMs on the fp32 matrix pipe; forced at small
+    batches (mode_mfma = 1), mode_bc shrinks the chunk: several chunks, ragged last stage, a last K-step that is partly zeros."""
+    with K.tuned(be, mode_mfma=1, mode_bc=bc):
+        _assert_all(K.check_mix_wgrad(be, B, 20, 20))
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 20, 20, 64, 64), (1, 6, 7, 32, 64), (1, 3, 5, 66, 65), (1, 32, 12, 32, 64), (5, 20, 20, 64, 64),

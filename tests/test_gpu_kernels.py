@@ -50,8 +50,27 @@ def test_mix_and_spectral_wgrad(be, B, Cin, Cout):
 def test_mix_and_spectral_wgrad_kernel_routes(be, B, C, nwv, want_wg, fused):
     """Every route of the mode-domain entry points at sizes the defaults would not pick: k_mix_lds workgroup shapes
     (mix_nwv knob, 0 = the lane = mode kernel), weight-gradient chunk sizes (wgrad_wg), fused vs two launches (cfd_tune_set)."""
-    with K.tuned(be, mix_nwv=int(nwv), wgrad_wg=int(want_wg), fused_variant=int(fused)):
+    with K.tuned(be, mix_nwv=int(nwv), wgrad_wg=int(want_wg), fused_variant=int(fused), mode_mfma=0):
         _assert_all(K.check_mix_wgrad(be, B, C, C))
+
+
+@pytest.mark.parametrize("B,bc", [(256, -1), (300, -1), (128, 16), (37, -1), (200, 24), (21, 5), (512, -1)])
+def test_mix_and_spectral_wgrad_on_the_matrix_pipe(be, B, bc):
+    """modes.hip (round 6): mixing, adjoint and spectral weight gradient of 20 channels as real GEMMs on v_mfma_f32_16x16x4_f32 --
+    the default from 128 entries, forced here at every size (mode_mfma = 1); mode_bc shrinks the chunk so that small batches reach
+    several chunks, ragged last stages and chunks whose last K-step is partly zeros."""
+    with K.tuned(be, mode_mfma=1, mode_bc=bc):
+        _assert_all(K.check_mix_wgrad(be, B, 20, 20))
+
+
+def test_matrix_pipe_mode_kernels_agree_with_the_valu_kernels(be):
+    """Both routes are fp32-exact class: their results differ only in summation order (1e-13 relative)."""
+    with K.tuned(be, mode_mfma=1):
+        a = K.check_mix_wgrad(be, 256, 20, 20, seed=3)
+    with K.tuned(be, mode_mfma=0):
+        b = K.check_mix_wgrad(be, 256, 20, 20, seed=3)
+    _assert_all(a)
+    _assert_all(b)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(5, 20, 20, 64, 64), (3, 6, 7, 32, 64), (2, 3, 5, 66, 65), (3, 32, 32, 64, 64), (2, 14, 9, 48, 64),
