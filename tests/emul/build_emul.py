@@ -27,12 +27,21 @@ def build(force: bool = False) -> Path:
     stamp = OUT / "stamp"
     if lib.exists() and stamp.exists() and stamp.read_text() == h.hexdigest() and not force:
         return lib
+    hdr = hashlib.sha1()
+    for f in sorted(CSRC.glob("*.h")) + sorted((HERE / "include").rglob("*.h")) + [REPO / "include" / "cfdbench_amd.h"]:
+        hdr.update(f.read_bytes())
+
     def compile_one(src: Path) -> str:
         obj = OUT / (src.name + ".o")
+        ostamp = OUT / (src.name + ".stamp")  # per-object stamp: one edited kernel file recompiles alone
+        odig = hashlib.sha1(hdr.digest() + src.read_bytes()).hexdigest()
+        if obj.exists() and ostamp.exists() and ostamp.read_text() == odig and not force:
+            return str(obj)
         cmd = [CLANG, "-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-Wno-unused-value",
                f"-I{HERE / 'include'}", f"-I{CSRC}", f"-I{REPO / 'include'}", "-DCFD_CONV6_GRID=2", "-DCFD_CONVT6_NT4_MIN_WGS=2", "-DCFD_CONV1_NT4_MIN_WGS=2", "-c", str(src), "-o",
                str(obj)]
         subprocess.run(cmd, check=True)
+        ostamp.write_text(odig)
         return str(obj)
 
     from concurrent.futures import ThreadPoolExecutor
