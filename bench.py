@@ -47,6 +47,14 @@ BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 SPLIT_BF16 = ("k_dft_fwd", "k_idft", "k_block", "k_chan_wgrad", "k_head")
 # the k = 3 / k = 7 convolutions (conv6.hip): three-piece operands, SIX bf16 MFMAs per fp32-exact product
 SPLIT6_BF16 = ("k_conv_fwd", "k_conv_dgrad", "k_conv_wgrad")
+# profiler label (cfd_prof, what `roofline.kernel` and the `kernels` table name) -> the symbol rocprofv3's kernel trace shows for it
+ROCPROF_SYMBOL = {"k_head_train": "k_head_bwd<5, true, true, true, float, 3, 4> (head.hip: the FUSE instantiation = forward + loss + backward in one pass)",
+                  "k_head_bwd": "k_head_bwd<..., false, ...>", "k_block_bwd_dgelu": "k_block<8, 3, 3, false, true, true, true, 3, false, false>",
+                  "k_block_fwd_act": "k_block<10, 2, 2, true, false, false, false, 3, false, false>",
+                  "k_block_fwd": "k_block<10, 2, 2, false, false, false, false, 3, false, false>",
+                  "k_block_bwd_stem": "k_block<8, 3, 3, false, true, false, true, 3, false, true>",
+                  "k_mix": "k_modes_mfma<20, false, false, 2>", "k_mixadj_wgrad": "k_modes_mfma<20, true, true, 3>",
+                  "k_dft_fwd": "k_dft_fwd64_b3<3, false, 3>", "k_dft_fwd_act": "k_dft_fwd64_b3<3, true, 3>"}
 
 
 def parse():
@@ -65,7 +73,7 @@ def parse():
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--n-case-params", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed steps of the cpu_baseline leg (SURVEY 8d: >= 10 after 3 warm-up steps)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward from a HIP graph")
     ap.add_argument("--no-rollout", action="store_true")
@@ -778,6 +786,12 @@ def main():
         sc = result["roofline_spectral_conv2d"]
         result["roofline"]["spectral_conv2d"] = {k: sc.get(k) for k in ("avg_us", "algorithmic_bytes", "achieved", "frac", "traffic", "target_frac", "target_us") if k in sc}
         result["roofline"]["step"] = dict(frac=result["roofline_step"]["frac"], bytes_per_frame=bpf, ms_per_step=result["ms_per_step"])
+        # ... and once more as SCALAR keys (round 6: the driver's parse of round 5 kept only the scalar members of `roofline`)
+        result["roofline"].update(
+            kernel_symbol=ROCPROF_SYMBOL.get(result["roofline"]["kernel"], result["roofline"]["kernel"]),
+            spectral_conv2d_us=sc.get("avg_us"), spectral_conv2d_frac=sc.get("frac"), spectral_conv2d_achieved_gbs=sc.get("achieved"),
+            spectral_conv2d_bytes=sc.get("algorithmic_bytes"), spectral_conv2d_traffic=sc.get("traffic"),
+            step_frac=result["roofline_step"]["frac"], step_bytes_per_frame=bpf, step_ms=result["ms_per_step"])
 
     extra = rank == 0 and world == 1
     # ---- rollout legs: batched multi-step inference from one HIP graph (the metric's "rollout" half; configs[4]) ----
@@ -943,17 +957,17 @@ def main():
             except Exception as e:  # noqa: BLE001
                 result[MODEL_LEGS[leg][0]] = dict(error=f"{type(e).__name__}: {str(e)[:300]}")
 
-    # ---- CPU baseline leg (rank 0, N=1): the reference's ATen call sequence on the host cores ------------------
+    # ---- CPU baseline leg (rank 0, N=1): the reference's ATen call sequence on the host cores, SURVEY 8(d) protocol -----------
     if extra and not args.no_cpu_baseline:
         from oracle import torch_port
         ncpu = os.cpu_count() or 1
-        # the reference modules themselves where /root/reference/src imports (the build container), else the port of
-        # their ATen call sequence (the GPU box has no /root/reference).  ATen's CPU kernels do not scale to every hardware thread at
-        # this size: sweep {8, 16, 32, 64} with one timed step each at batch 32 inside a 20-s budget, keep the fastest.
-        use_ref = torch_port.reference_importable()
-        timer = torch_port.time_reference_steps if use_ref else torch_port.time_train_steps
-        # (never ALL hardware threads: one batch-32 step on the GPU box's 256 threads took 28 MINUTES in round 5's first full run --
-        # the sweep stops at 64 and at the first count that is slower than its predecessor)
+        # kind "port" = oracle/torch_port.py, the reference's PyTorch-CPU call sequence: the reference is Python and cannot travel to
+        # the GPU box in any form.  Where /root/reference/src exists (never on a GPU box) the reference's own module is timed too, in a
+        # child process, and reported beside the port (`reference_frames_per_s`) -- `value` is the port on every box, so it compares.
+        # ATen's CPU kernels do not scale to every hardware thread at this size (one batch-32 step on the GPU box's 256 threads took
+        # 28 MINUTES in round 5): sweep {8, 16, 32, 64} with one timed step each at batch 32 inside a 20-s budget, stop at the first
+        # count that is slower than its predecessor.
+        timer = torch_port.time_train_steps
         cands = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} or {ncpu})
         probe, t_probe0 = {}, time.perf_counter()
         for t in cands:
@@ -961,21 +975,32 @@ def main():
             if time.perf_counter() - t_probe0 > 20.0 or (len(probe) > 1 and probe[t] < 0.8 * max(probe.values())):
                 break
         # the batch-32 ranking does not carry over to the full batch (8 threads win at 32, 16 at 256 on the 2 x EPYC 9575F box): the two
-        # best probe counts are both timed on the real workload, the faster one is reported
+        # best probe counts get two steps each on the real workload, the faster one runs the protocol: 3 warm-up + >= 10 timed steps, median
         top = sorted(probe, key=probe.get, reverse=True)[:2]
-        runs = {t: timer(B, max(2, args.cpu_steps - 1), warmup=1, C=C, L=L, H=H, W=W, p=p, threads=t) for t in top}
-        best_t = max(runs, key=lambda t: runs[t]["frames_per_s"])
-        cb = runs[best_t]
+        pick = {t: timer(B, 2, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=t)["frames_per_s"] for t in top}
+        best_t = max(pick, key=pick.get)
+        cb = timer(B, max(10, args.cpu_steps), warmup=3, C=C, L=L, H=H, W=W, p=p, threads=best_t)
         cb32 = timer(32, 5, warmup=1, C=C, L=L, H=H, W=W, p=p, threads=best_t)
+        ref = None
+        if torch_port.reference_importable():
+            try:
+                ref = torch_port.time_reference_steps(B, max(10, args.cpu_steps), warmup=3, C=C, L=L, H=H, W=W, p=p, threads=best_t)
+            except RuntimeError:
+                ref = None
         result["cpu_baseline"] = dict(
-            value=round(cb["frames_per_s"], 1), unit="frames/s", cores=cb["threads"], kind="reference" if use_ref else "port",
-            sample=f"the SAME workload (train step fwd+nMSE+bwd+Adam, batch {B}) on "
-                   + ("the reference's own Fno2d module (/root/reference/src), " if use_ref else
-                      "oracle/torch_port.py (the reference's PyTorch-CPU ATen call sequence, fp32; checked against the oracle in tests/test_oracle_golden.py), ")
-                   + f"{cb['steps']} steps after 1 warm-up, median, best of the thread counts { {t: round(r['frames_per_s'], 1) for t, r in runs.items()} }; "
-                   f"thread sweep at batch 32: { {t: round(v, 1) for t, v in probe.items()} } frames/s, {ncpu} host cores",
+            value=round(cb["frames_per_s"], 1), unit="frames/s", cores=cb["threads"], kind="port",
+            sample=f"the SAME workload (train step fwd+nMSE+bwd+Adam, batch {B}, synthetic inputs of SURVEY 8d) on oracle/torch_port.py (the "
+                   f"reference's PyTorch-CPU ATen call sequence, fp32; checked against the oracle in tests/test_oracle_golden.py): {cb['steps']} timed "
+                   f"steps after 3 warm-up steps, median; thread count = the faster of { {t: round(v, 1) for t, v in pick.items()} } (two steps "
+                   f"each), candidates from a batch-32 sweep { {t: round(v, 1) for t, v in probe.items()} } frames/s; {ncpu} host threads on the box",
+            steps=cb["steps"], warmup=3, median_s=round(cb["median_s"], 4), min_s=round(cb["min_s"], 4), max_s=round(cb["max_s"], 4),
+            spread=round((cb["max_s"] - cb["min_s"]) / cb["median_s"], 4),
+            cpu_model=torch_port.cpu_model(), host_cores=ncpu,
             value_batch32=round(cb32["frames_per_s"], 1), thread_sweep_batch32={str(t): round(v, 1) for t, v in probe.items()},
-            host_cores=ncpu)
+            reference_frames_per_s=None if ref is None else round(ref["frames_per_s"], 1),
+            reference_note=("the reference's own Fno2d (src/models/fno/fno2d.py) timed by the same protocol in a child process" if ref else
+                            "the reference is Python source and may not travel to the GPU box: not timed here (in the build container, batch 8 on "
+                            "8 threads, the port ran 105 and the reference module 118 frames/s)"))
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -323,14 +323,13 @@ __device__ __forceinline__ void cfd_mfma_bf16x6_n(const bf16x8 (&a)[3], const bf
 }
 // ---- activation operands of the FNO contractions (transforms, 1x1 conv, 1x1 weight gradient) ---------------------------------
 // AP = pieces the ACTIVATION operand is carried in (template parameter of the kernels, chosen per launch by the act_pieces knob):
-//   AP = 2 (default): hi = bf16(x), lo = bf16(x - hi); a product against a three-piece fixed operand takes four bf16 MFMAs
-//           (x_lo t_hi + x_hi t_lo2 + x_hi t_lo + x_hi t_hi): relative error <= ~2^-16 per product, measured nMSE against the fp64
-//           oracle 2e-11 .. 5e-11 -- the round-3 arithmetic.
-//   AP = 3 (round 4, `cfd_tune_set("act_pieces", 3)`): three truncating pieces (cfd_split8x3: p[0] + p[1] + p[2] == x exactly) and
-//           the six MFMAs of cfd_mfma_bf16x6 -- every term down to 2^-24 of the product, i.e. fp32-exact class like the convolution
-//           stack: measured nMSE 6e-15 .. 5e-14 on every transform / FnoBlock / 1x1 kernel (profiles/r04b_err_act3.json).  Costs
-//           3 more VALU instructions per pair of values and two more MFMAs per product: +6.7 % on the train step, which is why it
-//           is the selectable route (it replaces the exact-fp32 MFMA kernels as bench.py's `exact_fp32` leg) and not the default.
+//   AP = 3 (the default since round 5, tune.cpp: cfd_act_pieces()): three truncating pieces (cfd_split8x3: p[0] + p[1] + p[2] == x
+//           exactly) and the six MFMAs of cfd_mfma_bf16x6 -- every term down to 2^-24 of the product, i.e. fp32-exact class like the
+//           convolution stack: measured nMSE 6e-15 .. 5e-14 on every transform / FnoBlock / 1x1 kernel (profiles/r04d_err_act3.json).
+//           Against two pieces it costs 3 more VALU instructions per pair of values and two more MFMAs per product: +8 % on the step.
+//   AP = 2 (`cfd_tune_set("act_pieces", 2)`, the default of rounds 1-4, bench.py's `split2` leg): hi = bf16(x), lo = bf16(x - hi); a
+//           product against a three-piece fixed operand takes four bf16 MFMAs (x_lo t_hi + x_hi t_lo2 + x_hi t_lo + x_hi t_hi):
+//           relative error <= ~2^-16 per product, measured nMSE against the fp64 oracle 2e-11 .. 5e-11.
 template <int AP>
 struct CfdAct8 {
     bf16x8 p[AP];

@@ -285,6 +285,7 @@ bool cfd_int_modes_mfma_ok(const cfd_plan* p, int B, int Cin, int Cout, const vo
 }
 
 size_t cfd_int_modes_mfma_chunks(const cfd_plan* p, int B) {  // partial-sum chunks the weight gradient may write
+    if ((p->m1 * p->m2) % CFD_MM_T != 0 || B < 1) return 0;    // (never dispatched for such plans: cfd_int_modes_mfma_ok)
     int BC, nchunk;
     cfd_mm_geometry(B, p->m1 * p->m2 * 2 / CFD_MM_T, true, &BC, &nchunk);
     return (size_t)nchunk;

@@ -2352,8 +2352,10 @@ static int block_row_splits(const cfd_plan* p, int B, int nd) {
     return spl;
 }
 
+// Returns true when the lifting-layer-sum instantiation (STEMG) was the one launched: the caller REQUIRES that whenever it asked for
+// the sums (the plain kernel would store g_0 and leave the sum records unwritten -- garbage fc0 gradients, no error).
 template <int NW, int DPW, int NCH>
-static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z, const float* w, const float* bias,
+static bool launch_block_cfg(const cfd_plan* p, const float* src, const float* z, const float* w, const float* bias,
                              const float* aprev, float* dst, int B, int Cs, int Cd, int act, int trans, int dgelu,
                              hipStream_t st, const CfdReduceTail* tail, const CfdStemG* stemg = nullptr) {
     const bool ride = trans && tail && tail->nblk > 0;
@@ -2380,7 +2382,7 @@ static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z
             else { if (ap3) CFD_BLK_SG(false, 3); else CFD_BLK_SG(false, 2); }
 #undef CFD_BLK_SG
 #undef CFD_BLK_S
-            return;
+            return true;
         }
     }
 #define CFD_BLK(A_, T_, D_, R_)                                                      \
@@ -2394,29 +2396,30 @@ static void launch_block_cfg(const cfd_plan* p, const float* src, const float* z
     else { if (dgelu) CFD_BLK(false, true, true, false); else CFD_BLK(false, true, false, false); }
 #undef CFD_BLK
 #undef CFD_BLK_P
+    return false;
 }
 
 // (waves, destination channels per wave, source chunks): waves*DPW >= Cd and waves*NCH >= Cs
-static void launch_block(const cfd_plan* p, const float* src, const float* z, const float* w, const float* bias,
+static bool launch_block(const cfd_plan* p, const float* src, const float* z, const float* w, const float* bias,
                          const float* aprev, float* dst, int B, int Cs, int Cd, int act, int trans, int dgelu,
                          hipStream_t st, const CfdReduceTail* tail = nullptr, const CfdStemG* stemg = nullptr) {
     const int cmax = Cs > Cd ? Cs : Cd;
-    if (cmax <= 8) launch_block_cfg<4, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
-    else if (cmax <= 16) launch_block_cfg<4, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
+    if (cmax <= 8) return launch_block_cfg<4, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
+    else if (cmax <= 16) return launch_block_cfg<4, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
     else if (cmax <= 20) {  // measured at B=256, C=20 (us): (10,2,2) 61/73/60/97, (5,4,4) 69/79/67/82, (4,5,5) 77/84/74/83
         // round 2, same box: (8,3,3) 52.8/59.3/53.5/62.2 against 49.4/60.9/50.9/66.8 -- two waves per SIMD, 3 + 2 destination
         // channels per SIMD; (10,2,2) and (5,4,4) leave SIMDs with 3 vs 2 and 2 vs 1 waves
         // general grids (pitch != 64, five row tiles): (10,2,2) would need 161 KB of LDS with the fifth tile's tables and the tail planes
         // (the lifting-layer sums need ~60 more registers: ten waves -- three per SIMD, 168 registers -- would spill 69 of them)
-        if (dgelu || block_is_gen(p) || (stemg && stemg->inputs)) launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
-        else launch_block_cfg<10, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
+        if (dgelu || block_is_gen(p) || (stemg && stemg->inputs)) return launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
+        else return launch_block_cfg<10, 2, 2>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
     }
     // 21 .. 24 channels: (8,3,3).
-    else if (cmax <= 24) launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
+    else if (cmax <= 24) return launch_block_cfg<8, 3, 3>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail, stemg);
     // 25 .. 32 channels (round 5; the reference's default width 32, src/args.py:190): with the tables in three pieces (CFD_TW) an
     // (8,4,4) workgroup would need 168 KB of LDS (source chunks 64 + modes 74 + tables 24 + weights 4), so the entry's destination
     // channels are dealt to TWO (8,2,4) workgroups of 16 channels (modes 37 KB: 133 KB), each streaming all the source channels.
-    else launch_block_cfg<8, 2, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
+    else return launch_block_cfg<8, 2, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
 }
 
 // out[b,o] = bias[o] + sum_i w0[o,i] f(a[b,i]) + idft(z[b,o])                       (FnoBlock.forward minus its GELU)
@@ -2547,8 +2550,10 @@ int cfd_int_fno_block_bwd_input(const cfd_plan* p, const float* g, const float* 
     const bool sums = stemg && stemg->inputs;  // (reads g and the entry's feature planes, writes no gradient tensor)
     CFD_PROF_W(sums ? "k_block_bwd_stem" : (aprev ? "k_block_bwd_dgelu" : "k_block_bwd"), st,
                (double)B * (4.0 * p->H * p->W * ((sums ? 3 : Cin) + Cout + (aprev ? Cin : 0)) + 16.0 * p->m1 * p->m2 * Cin), 2.0 * B * p->H * p->W * (double)Cin * Cout);
-    launch_block(p, g, gz, w0, nullptr, aprev, gin, B, Cout, Cin, 0, 1, aprev ? 1 : 0, st, tail, stemg);
+    const bool emitted = launch_block(p, g, gz, w0, nullptr, aprev, gin, B, Cout, Cin, 0, 1, aprev ? 1 : 0, st, tail, stemg);
     CFD_LAUNCH_CHECK("cfd_fno_block_bwd_input");
+    CFD_REQUIRE(emitted == sums, CFD_ERR_UNSUPPORTED, "cfd_fno_block_bwd_input: the lifting-layer sums were requested but this shape (Cin %d, Cout %d) has no "
+                "k_block<.., STEMG> instantiation -- cfd_int_stemg_ok and the launch table are out of step", Cin, Cout);
     return CFD_OK;
 }
 

@@ -199,9 +199,6 @@ class FlatGradExchange:
         self.install()
 
 
-_exchanges: Dict[Tuple[int, ...], FlatGradExchange] = {}
-
-
 def sync_gradients(params: Sequence[torch.nn.Parameter], group=None) -> None:
     """Data-parallel gradient averaging for the eager autograd training path (any model): FlatGradExchange on the parameters that
     received a gradient -- one pack launch per 80 tensors, ONE all-reduce, ``.grad`` left as views of the reduced flat buffer.
@@ -213,10 +210,17 @@ def sync_gradients(params: Sequence[torch.nn.Parameter], group=None) -> None:
     ps = [p_ for p_ in params if p_.requires_grad and p_.grad is not None]
     if not ps:
         return
-    key = tuple(id(p_) for p_ in ps) + (id(group),)
-    ex = _exchanges.get(key)
-    if ex is None or any(a is not b for a, b in zip(ex.params, ps)):
-        ex = _exchanges[key] = FlatGradExchange(ps, group)
+    # One exchange object per (parameter set, group, world, backend), hung off the FIRST parameter so that it dies with the model
+    # (a module-global dict kept every model's parameters and a model-sized flat buffer alive: ADVICE r5), and re-validated against
+    # the live process group: after destroy_process_group + a new init in the same process a cached object would carry a stale
+    # world size, backend and 1 / world scale.
+    world, backend = dist.get_world_size(group), dist.get_backend(group)
+    key = tuple(id(p_) for p_ in ps) + (id(group), world, backend)
+    slot = getattr(ps[0], "_cfd_grad_exchange", None)
+    ex = slot[1] if slot is not None and slot[0] == key else None
+    if ex is None or any(a is not b for a, b in zip(ex.params, ps)) or ex.sync.world != world:
+        ex = FlatGradExchange(ps, group)
+        ps[0]._cfd_grad_exchange = (key, ex)
     ex.exchange()
 
 

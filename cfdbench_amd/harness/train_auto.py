@@ -116,14 +116,23 @@ def evaluate(model: AutoCfdModel, data, output_dir: Path, batch_size: int = 2, p
     pred_blocks = []
     if all_preds:
         first = all_preds[0]
-        host = torch.empty((sum(sizes),) + tuple(first.shape[1:]), dtype=first.dtype, pin_memory=first.is_cuda)
+        shape = (sum(sizes),) + tuple(first.shape[1:])
+        nbytes = first.element_size() * int(torch.tensor(shape).prod())
+        # pinned only while the split is small (<= 256 MB): a multi-GB hipHostMalloc is slow, can fail where pageable memory would
+        # not, and stays pinned in the caching host allocator afterwards; pageable copies are synchronous but correct
+        pin = first.is_cuda and nbytes <= (256 << 20)
+        try:
+            host = torch.empty(shape, dtype=first.dtype, pin_memory=pin)
+        except RuntimeError:
+            host, pin = torch.empty(shape, dtype=first.dtype), False
         off = 0
         for p_, n_ in zip(all_preds, sizes):
-            host[off:off + n_].copy_(p_, non_blocking=True)
+            host[off:off + n_].copy_(p_, non_blocking=pin)
             off += n_
         if first.is_cuda:
             torch.cuda.current_stream().synchronize()
-        pred_blocks = list(host.split(sizes))
+        # (clones under a process group: gather_object pickles every view together with the WHOLE storage it points into)
+        pred_blocks = [b_.clone() for b_ in host.split(sizes)] if world > 1 else list(host.split(sizes))
     if world > 1:
         gathered = [None] * world if rank == 0 else None
         dist.gather_object((mine, scores, input_scores, pred_blocks), gathered, dst=0)

@@ -65,18 +65,28 @@ def forward(prm, inputs, case_params, mask, label, L: int):
     return preds, dict(mse=mse, mae=F.l1_loss(preds, lab), nmse=mse / torch.square(lab).mean())
 
 
+def _summary(times: List[float], B: int, steps: int) -> Dict:
+    ts = sorted(times)
+    med = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
+    return dict(frames_per_s=B / med, median_s=med, min_s=ts[0], max_s=ts[-1], steps=steps, batch=B, threads=torch.get_num_threads())
+
+
+def _synthetic(B: int, H: int, W: int, p: int):
+    g = torch.Generator().manual_seed(1234)  # SURVEY 8(d)
+    inputs = torch.randn(B, 2, H, W, generator=g)
+    label = inputs + 0.1 * torch.randn(B, 2, H, W, generator=g)
+    return inputs, label, torch.randn(B, p, generator=g), torch.ones(B, 1, H, W)
+
+
 def time_train_steps(B: int, steps: int, warmup: int = 1, C: int = 20, L: int = 4, H: int = 64, W: int = 64,
                      p: int = 5, threads: int | None = None) -> Dict:
-    """train_auto.py:231-257 on synthetic data: forward -> loss['nmse'].backward() -> Adam.step() -> zero_grad()."""
+    """train_auto.py:231-257 on synthetic data: forward -> loss['nmse'].backward() -> Adam.step() -> zero_grad().  Returns the
+    median (and min / max) of ``steps`` timed steps after ``warmup`` untimed ones (3 + >= 10)."""
     if threads:
         torch.set_num_threads(threads)
     prm = init_params(C, L, 12, 12, p)
     opt = torch.optim.Adam(list(prm.values()), lr=1e-3)
-    g = torch.Generator().manual_seed(1234)
-    inputs = torch.randn(B, 2, H, W, generator=g)
-    label = inputs + 0.1 * torch.randn(B, 2, H, W, generator=g)
-    cp = torch.randn(B, p, generator=g)
-    mask = torch.ones(B, 1, H, W)
+    inputs, label, cp, mask = _synthetic(B, H, W, p)
     times: List[float] = []
     for s in range(warmup + steps):
         t0 = time.perf_counter()
@@ -86,52 +96,87 @@ def time_train_steps(B: int, steps: int, warmup: int = 1, C: int = 20, L: int = 
         opt.zero_grad()
         if s >= warmup:
             times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return dict(frames_per_s=B / med, median_s=med, steps=steps, batch=B, threads=torch.get_num_threads())
+    return _summary(times, B, steps)
+
+
+def cpu_model() -> str:
+    """The host CPU's model string (/proc/cpuinfo) -- SURVEY 8(d): state the core count AND the CPU model beside the baseline."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+# The reference's own modules are timed in a CHILD process: they are untrusted code whose top-level packages (models, utils, args,
+# dataset, train) would otherwise shadow anything of the same name for the rest of the calling process (ADVICE r5).  The child
+# gets /root/reference/src on ITS sys.path only.  The Python reference cannot travel to the GPU box in any form, so there
+# reference_importable() is False and bench.py's cpu_baseline is kind "port" (this file's ATen call sequence).
+_REF_CHILD = r"""
+import json, sys, time
+sys.path.insert(0, sys.argv[1])
+a = json.loads(sys.argv[2])
+import torch
+from models.fno.fno2d import Fno2d
+from models.loss import MseLoss
+if a["threads"]:
+    torch.set_num_threads(a["threads"])
+if a["probe"]:
+    print(json.dumps({"ok": True})); sys.exit(0)
+B, H, W, p = a["B"], a["H"], a["W"], a["p"]
+torch.manual_seed(0)
+model = Fno2d(2, 2, p, MseLoss(normalize=True), a["L"], 12, 12, a["C"])
+opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+g = torch.Generator().manual_seed(1234)
+inputs = torch.randn(B, 2, H, W, generator=g)
+label = inputs + 0.1 * torch.randn(B, 2, H, W, generator=g)
+cp = torch.randn(B, p, generator=g)
+mask = torch.ones(B, 1, H, W)
+times = []
+for s in range(a["warmup"] + a["steps"]):
+    t0 = time.perf_counter()
+    out = model(inputs=inputs, case_params=cp, mask=mask, label=label)
+    out["loss"]["nmse"].backward()
+    opt.step()
+    opt.zero_grad()
+    if s >= a["warmup"]:
+        times.append(time.perf_counter() - t0)
+print(json.dumps({"times": times, "threads": torch.get_num_threads()}))
+"""
+
+
+def _ref_child(root: str, **a):
+    import json
+    import os
+    import subprocess
+    import sys
+    if not os.path.isdir(root):
+        return None
+    r = subprocess.run([sys.executable, "-c", _REF_CHILD, root, json.dumps(a)], capture_output=True, text=True, cwd="/tmp")
+    if r.returncode != 0:
+        return None
+    try:
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return None
 
 
 def reference_importable(root: str = "/root/reference/src") -> bool:
-    """True when the reference's own Fno2d imports (the build container; the GPU box has no /root/reference)."""
-    import os
-    import sys
-    if not os.path.isdir(root):
-        return False
-    if root not in sys.path:
-        sys.path.insert(0, root)
-    try:
-        from models.fno.fno2d import Fno2d  # noqa: F401  (reference)
-        from models.loss import MseLoss  # noqa: F401
-        return True
-    except Exception:  # noqa: BLE001
-        return False
+    """True when the reference's own Fno2d imports in a child process (the build container; the GPU box has no /root/reference)."""
+    return bool(_ref_child(root, probe=True, threads=0))
 
 
 def time_reference_steps(B: int, steps: int, warmup: int = 1, C: int = 20, L: int = 4, H: int = 64, W: int = 64,
-                         p: int = 5, threads: int | None = None) -> Dict:
+                         p: int = 5, threads: int | None = None, root: str = "/root/reference/src") -> Dict:
     """The SAME loop on the reference's own module (src/models/fno/fno2d.py:Fno2d, src/train_auto.py:231-257) -- SURVEY 8(d)'s CPU
-    baseline "kind: reference"; only where /root/reference/src imports."""
-    from models.fno.fno2d import Fno2d  # reference
-    from models.loss import MseLoss
-    if threads:
-        torch.set_num_threads(threads)
-    torch.manual_seed(0)
-    model = Fno2d(2, 2, p, MseLoss(normalize=True), L, 12, 12, C)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    g = torch.Generator().manual_seed(1234)
-    inputs = torch.randn(B, 2, H, W, generator=g)
-    label = inputs + 0.1 * torch.randn(B, 2, H, W, generator=g)
-    cp = torch.randn(B, p, generator=g)
-    mask = torch.ones(B, 1, H, W)
-    times: List[float] = []
-    for s in range(warmup + steps):
-        t0 = time.perf_counter()
-        out = model(inputs=inputs, case_params=cp, mask=mask, label=label)
-        out["loss"]["nmse"].backward()
-        opt.step()
-        opt.zero_grad()
-        if s >= warmup:
-            times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return dict(frames_per_s=B / med, median_s=med, steps=steps, batch=B, threads=torch.get_num_threads())
+    baseline "kind: reference"; only where /root/reference/src exists, and in a child process (see above)."""
+    res = _ref_child(root, probe=False, B=B, steps=steps, warmup=warmup, C=C, L=L, H=H, W=W, p=p, threads=threads or 0)
+    if not res:
+        raise RuntimeError(f"the reference modules under {root} could not be timed")
+    out = _summary(res["times"], B, steps)
+    out["threads"] = res["threads"]
+    return out
