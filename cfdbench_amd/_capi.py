@@ -40,7 +40,7 @@ class FfnStackArgs(C.Structure):
 
 
 _P = C.c_void_p
-ABI_VERSION = 500  # include/cfdbench_amd.h: CFD_ABI_VERSION
+ABI_VERSION = 600  # include/cfdbench_amd.h: CFD_ABI_VERSION
 _I = C.c_int
 _F = C.c_float
 _Z = C.c_size_t
@@ -157,6 +157,12 @@ _SIGS = {
                                       _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _P]),
     "cfd_fno_backward_phase_ex": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),
                                        _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "cfd_fno_forward_train_f": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),
+                                     _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _P]),
+    "cfd_fno_backward_phase_f": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),
+                                      _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cfd_fno_adam_step": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams), _P, _P, _P, _P, _P,
+                               _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _I, _I, _I, _P]),
     "cfd_fno_backward": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),
                               _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cfd_fno_backward_phase": (_I, [_P, C.POINTER(FnoShape), C.POINTER(FnoParams), C.POINTER(FnoParams),

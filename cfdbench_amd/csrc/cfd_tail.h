@@ -34,9 +34,24 @@ struct CfdStemG {
     float* part;
     int in_chan;
 };
+// Projection head (k_head_bwd): block-major partial records part[block][PSTR] -> fc1 / fc2 gradients and, from the one-pass training head,
+// the loss sums.  Round 6: in the fused training step this reduction rides in backward phase 1's block kernel instead of being a launch of
+// its own behind the head (~5 us of dispatch floor; CFD_TRAIN_DEFER_HEAD).
+#define CFD_HEAD_HD 128  // fno2d.py:175 (head.hip: HEAD_HD)
+struct HeadTail {
+    const float* part;  // NULL: no such job
+    float* gw1;
+    float* gb1;
+    float* gw2;
+    float* gb2;
+    float* sums;   // may be NULL (stand-alone backward: no loss rows)
+    int nrec, PS, PSTR, C, Co;
+    float count;   // > 0 (deferred nMSE normaliser, CFD_TRAIN_DEFER_SCALE): row 2 of the loss rows is sum (label*mask)^2 -> sums[2], sums[3] = count
+};
 struct CfdReduceTail {
     SpecWgradTail spec;
     ChanWgradTail chan;
+    HeadTail head;
     int nblk;  // workgroups of the carrying launch that run the jobs (0: none)
 };
 
@@ -101,6 +116,70 @@ __device__ __forceinline__ void chan_wgrad_reduce_group(const int grp, const flo
     }
 }
 
+// Elements [16 grp, 16 grp + 16) of the head's partial records (k_head_reduce's body; every thread of the workgroup calls it)
+__device__ __forceinline__ void head_reduce_group(const int grp, const HeadTail& t, float* scratch) {
+    const float s = cfd_record_sum16(t.part, t.nrec, t.PSTR, 16 * grp, t.PS, scratch);
+    const int e = 16 * grp + (int)threadIdx.x;
+    if (threadIdx.x < 16 && e < t.PS) {
+        const int o_gb1 = CFD_HEAD_HD * t.C, o_gw2 = o_gb1 + CFD_HEAD_HD, o_gb2 = o_gw2 + t.Co * CFD_HEAD_HD;
+        if (e < o_gb1) t.gw1[e] = s;
+        else if (e < o_gw2) t.gb1[e - o_gb1] = s;
+        else if (e < o_gb2) t.gw2[e - o_gw2] = s;
+        else if (e < o_gb2 + t.Co) t.gb2[e - o_gb2] = s;
+        else if (t.sums) {  // one-pass head: sums[0] = sum d^2, sums[1] = sum |d| (, sums[2] = sum (label*mask)^2, sums[3] = n)
+            const int k = e - (o_gb2 + t.Co);
+            t.sums[k] = s;
+            if (k == 2) t.sums[3] = t.count;
+        }
+    }
+}
+
+// Lifting-layer gradient of channel c from the sums of k_block<.., STEMG> (CfdStemG): gw[c][f], f = (in_chan field channels, mask,
+// grid_x, grid_y, P case parameters), and gb[c] from part[rec][c][6], rec = batch entry x row split -- thread-strided over the records in
+// a fixed order, LDS tree; the case-parameter columns are sum_b cp[b][k] * S0[b][c] (a case parameter is constant over an entry's
+// pixels).  256 threads; afterwards (barrier inside) s_r[k][0] holds: k = 0 bias, 1 .. 5 the five field sums, 6 + k case parameter k.
+#define CFD_STEMG_NA (6 + 8)
+__device__ __forceinline__ void stem_combine_channel(const float* __restrict__ part, int nrec, int spl, const float* __restrict__ cp, int P,
+                                                     int C, int c, float (&s_r)[CFD_STEMG_NA][256]) {
+    constexpr int NA = CFD_STEMG_NA;
+    float a[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) a[k] = 0.f;
+    for (int r = threadIdx.x; r < nrec; r += 256) {
+        const float* q = part + ((size_t)r * C + c) * 6;
+        float v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = q[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a[k] += v[k];
+        const float* cpb = cp + (size_t)(r / spl) * P;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < P) a[6 + k] = fmaf(cpb[k], v[0], a[6 + k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NA; ++k) s_r[k][threadIdx.x] = a[k];
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+#pragma unroll
+            for (int k = 0; k < NA; ++k) s_r[k][threadIdx.x] += s_r[k][threadIdx.x + h];
+        }
+        __syncthreads();
+    }
+}
+// feature f of the fc0 weight row (fno2d.py:189-217 channel order: fields, mask, grid_x, grid_y, case parameters) -> index into s_r
+__device__ __forceinline__ int stem_feature_slot(int f, int in_chan) {
+    return f < in_chan ? 1 + f : (f < in_chan + 3 ? 3 + (f - in_chan) : 6 + (f - in_chan - 3));
+}
+// The job as cfd_fno_adam_step carries it (CFD_TRAIN_DEFER_STEM): workgroup c < C finishes channel c and applies Adam to its row itself
+struct StemAdamJob {
+    const float* part;  // NULL: no such job
+    const float* cp;
+    int nrec, spl, P, in_chan, C;
+    long w_off, b_off;  // element offsets of fc0.weight / fc0.bias inside the flat parameter buffer
+};
+
 // Workgroup `blk` of `t.nblk` (any workgroup size that is a multiple of 64): thread-strided over the spectral elements,
 // workgroup-strided over the groups of 16 1x1-conv elements.  `scratch`: LDS of the carrying kernel, >= 16 floats per wave.
 __device__ __forceinline__ void cfd_reduce_tail(const CfdReduceTail& t, int blk, float* scratch) {
@@ -118,6 +197,10 @@ __device__ __forceinline__ void cfd_reduce_tail(const CfdReduceTail& t, int blk,
         for (int grp = blk; grp < ngroups; grp += t.nblk)  // (uniform per workgroup)
             chan_wgrad_reduce_group(grp, t.chan.part, t.chan.nrow, t.chan.gw, t.chan.gb, t.chan.Co, t.chan.Ci, scratch);
     }
+    if (t.head.part) {
+        const int ngroups = (t.head.PS + 15) / 16;
+        for (int grp = blk; grp < ngroups; grp += t.nblk) head_reduce_group(grp, t.head, scratch);
+    }
 }
 
 // Internal (not exported through include/cfdbench_amd.h) entry points of the FNO backward phase: the weight-gradient
@@ -133,7 +216,22 @@ int cfd_int_chan_wgrad_dt(const float* g, const void* a, float* gw, float* gb, v
 // the call is the plain input gradient, aprev == NULL)
 int cfd_int_fno_block_bwd_input(const cfd_plan* p, const float* g, const float* gz, const float* w0, const float* aprev,
                                 float* gin, int B, int Cin, int Cout, void* stream, const CfdReduceTail* tail, const CfdStemG* stemg);
+// one-pass training head with its reduction optionally left to the caller (*defer filled, no reduce launch); c0v / c1v: the loss-gradient
+// coefficients by value when coef == NULL (deferred nMSE normaliser); count > 0: also reduce sum (label*mask)^2 into sums[2], sums[3] = count
+int cfd_int_fno_head_train_f(const void* a, const float* mask, const float* label, const float* coef, float c0v, float c1v, float count,
+                             const float* w1, const float* b1, const float* w2, const float* b2, float* preds, float* sums, float* ga,
+                             float* gw1, float* gb1, float* gw2, float* gb2, void* ws, int B, int C, int Hd, int Co, int HW, int act_in,
+                             int dt, void* stream, HeadTail* defer);
+HeadTail cfd_int_head_tail(const void* ws, float* gw1, float* gb1, float* gw2, float* gb2, float* sums, int B, int C, int Co, int HW, float count);
+bool cfd_int_block_bwd_fused(const cfd_plan* p, int C, const void* g, const void* gin, const void* aprev, const void* gz);
 bool cfd_int_stemg_ok(const cfd_plan* p, int B, int C, int in_chan, int P, const void* inputs, const void* mask, const void* z);
 size_t cfd_int_stemg_part_bytes(const cfd_plan* p, int B, int C);
+int cfd_int_stemg_splits(const cfd_plan* p, int B);
 int cfd_int_stemg_combine(const cfd_plan* p, const float* part, const float* cp, float* gw, float* gb, int B, int C, int in_chan, int P,
                           void* stream);
+
+// Adam on the flat parameter buffer with the deferred work of the fused training step (fno.cpp: cfd_fno_adam_step): `sums` != NULL:
+// every gradient is multiplied by sums[3] / sums[2] on top of grad_scale (deferred nMSE normaliser); job.part != NULL: workgroup c < C
+// finishes the lifting layer's gradient row c from the block kernel's sum records, stores it and applies Adam to it.
+int cfd_int_adam_flat_f(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int step, float grad_scale, const float* sums, const StemAdamJob* job, void* stream);

@@ -13,6 +13,7 @@ struct Layout {
     size_t n_act;    // floats of one (B,C,H,W) activation
     size_t n_modes;  // floats of one (B,C,2*m1,m2) complex tensor
     size_t off_acts, off_xh, off_z, off_gA, off_gB, off_gh, off_scratch, off_tmp;
+    size_t head_off;  // byte offset of the training head's partial records inside the scratch region (0 in inference)
     size_t scratch_bytes, total_bytes;
     int n_acts, n_xh;
 };
@@ -52,6 +53,10 @@ Layout make_layout(const cfd_plan* p, const cfd_fno_shape* s, int training, int 
         scratch = max2(scratch, cfd_fno_stem_bwd_workspace_bytes(p, B, s->in_chan, s->n_case_params, C));
         // the lifting layer's sums of k_block<.., STEMG> live behind the two weight-gradient partial regions of the last block phase
         scratch = max2(scratch, stemg_offset(p, B, C, (int)HW) + cfd_int_stemg_part_bytes(p, B, C));
+        // round 6: the training head's partial records behind everything a block phase writes -- with CFD_TRAIN_DEFER_HEAD they are read
+        // by backward phase 1's block kernel, AFTER that phase's weight-gradient producers have written their partials into the regions above
+        L.head_off = cfd_align_up(stemg_offset(p, B, C, (int)HW) + cfd_int_stemg_part_bytes(p, B, C), 256);
+        scratch = max2(scratch, L.head_off + cfd_fno_head_workspace_bytes(B, C, s->head, s->out_chan, (int)HW));
     }
     L.scratch_bytes = scratch;
     L.off_scratch = take(scratch);
@@ -69,6 +74,26 @@ int check_shape(const char* fn, const cfd_plan* p, const cfd_fno_shape* s) {
                 s->num_layers, CFD_MAX_LAYERS);
     CFD_REQUIRE(s->hidden >= 1 && s->hidden <= 32, CFD_ERR_UNSUPPORTED, "%s: hidden=%d (max 32)", fn, s->hidden);
     return CFD_OK;
+}
+
+// Which deferrals of `flags` apply to this shape (the forward call, every backward phase and cfd_fno_adam_step evaluate the same thing).
+struct Deferred {
+    bool scale, head, stem;
+};
+Deferred deferred(const cfd_plan* p, const cfd_fno_shape* s, const Layout& L, char* base, int which, int dt, int flags, const void* inputs,
+                  const void* mask) {
+    const int B = s->B, C = s->hidden, NL = s->num_layers;
+    Deferred d{};
+    d.scale = (flags & CFD_TRAIN_DEFER_SCALE) && which == 1;
+    const float* gA = (const float*)(base + L.off_gA);
+    const float* gB = (const float*)(base + L.off_gB);
+    const float* z = (const float*)(base + L.off_z);
+    // backward phase 1 = FnoBlock NL-1: gcur = gA, gnext = gB, aprev = a_{NL-1} when NL > 1
+    const void* aprev = NL > 1 ? (const void*)(base + L.off_acts + (size_t)(NL - 1) * L.n_act * cfd_dt_size(dt)) : nullptr;
+    d.head = (flags & CFD_TRAIN_DEFER_HEAD) && dt == CFD_DT_F32 && NL >= 1 && cfd_int_block_bwd_fused(p, C, gA, gB, aprev, z);
+    d.stem = (flags & CFD_TRAIN_DEFER_STEM) && dt == CFD_DT_F32 && NL >= 1 &&
+             cfd_int_stemg_ok(p, B, C, s->in_chan, s->n_case_params, inputs, mask, z);
+    return d;
 }
 
 }  // namespace
@@ -149,8 +174,18 @@ extern "C" int cfd_fno_forward_train_ex(const cfd_plan* p, const cfd_fno_shape* 
                                         const cfd_fno_params* g, const float* inputs, const float* case_params,
                                         const float* mask, const float* label, float* preds, float* sums, float* coef, void* ws,
                                         int which, float upstream, int act_dtype, void* stream) {
+    return cfd_fno_forward_train_f(p, s, prm, g, inputs, case_params, mask, label, preds, sums, coef, ws, which, upstream, act_dtype, 0, stream);
+}
+
+// flags: CFD_TRAIN_DEFER_* (include/cfdbench_amd.h) -- the single-GPU training step with its three tiny launches folded into others
+extern "C" int cfd_fno_forward_train_f(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm,
+                                       const cfd_fno_params* g, const float* inputs, const float* case_params,
+                                       const float* mask, const float* label, float* preds, float* sums, float* coef, void* ws,
+                                       int which, float upstream, int act_dtype, int flags, void* stream) {
     CFD_TRY(check_shape("cfd_fno_forward_train", p, s));
-    CFD_REQUIRE(prm && g && inputs && label && preds && sums && coef && ws, CFD_ERR_INVALID_ARG, "cfd_fno_forward_train: NULL pointer");
+    CFD_REQUIRE(which >= 0 && which <= 2, CFD_ERR_INVALID_ARG, "cfd_fno_forward_train: which must be 0 (mse), 1 (nmse), 2 (mae)");
+    CFD_REQUIRE(prm && g && inputs && label && preds && sums && ws && (coef || ((flags & CFD_TRAIN_DEFER_SCALE) && which == 1)), CFD_ERR_INVALID_ARG,
+                "cfd_fno_forward_train: NULL pointer");
     CFD_REQUIRE(act_dtype == CFD_DT_F32 || act_dtype == CFD_DT_BF16, CFD_ERR_INVALID_ARG, "cfd_fno_forward_train: act_dtype %d (0 = fp32, 1 = bf16)", act_dtype);
     const int dt = act_dtype;
     const Layout L = make_layout(p, s, 1, dt);
@@ -165,8 +200,9 @@ extern "C" int cfd_fno_forward_train_ex(const cfd_plan* p, const cfd_fno_shape* 
     // the label's energy and the gradient coefficients: independent of the network (scratch is free until the head); with
     // side_stream bit 1 they run beside the lifting layer on the side stream and join in front of the head (off by default:
     // the fork / join pair costs more than the 16 us it hides -- side.cpp)
-    hipStream_t side = cfd_side_fork((hipStream_t)stream, 1);
-    CFD_TRY(cfd_label_energy_coef(label, mask, sums, coef, scratch, B, s->out_chan, HW, which, upstream, side));
+    const Deferred df = deferred(p, s, L, base, which, dt, flags, inputs, mask);
+    hipStream_t side = cfd_side_fork((hipStream_t)stream, df.scale ? 0 : 1);
+    if (!df.scale) CFD_TRY(cfd_label_energy_coef(label, mask, sums, coef, scratch, B, s->out_chan, HW, which, upstream, side));
     CFD_TRY(cfd_int_fno_stem_fwd(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, act_buf(0), B, s->in_chan, s->n_case_params, C,
                                  dt, stream));
     for (int l = 0; l < NL; ++l) {  // FnoBlock.forward, fno2d.py:106-112
@@ -182,8 +218,12 @@ extern "C" int cfd_fno_forward_train_ex(const cfd_plan* p, const cfd_fno_shape* 
         }
     }
     CFD_TRY(cfd_side_join((hipStream_t)stream, side));
-    return cfd_int_fno_head_train(act_buf(NL), mask, label, coef, prm->fc1_w, prm->fc1_b, prm->fc2_w, prm->fc2_b, preds, sums, gA,
-                                  g->fc1_w, g->fc1_b, g->fc2_w, g->fc2_b, scratch, B, C, s->head, s->out_chan, HW, NL > 0, dt, stream);
+    // deferred normaliser: the mse coefficient by value, sum (label*mask)^2 and the count leave the head's reduction (sums[2], sums[3])
+    const float count = (float)((double)B * s->out_chan * HW);
+    HeadTail ht{};
+    return cfd_int_fno_head_train_f(act_buf(NL), mask, label, df.scale ? nullptr : coef, upstream / count, 0.f, df.scale ? count : 0.f,
+                                    prm->fc1_w, prm->fc1_b, prm->fc2_w, prm->fc2_b, preds, sums, gA, g->fc1_w, g->fc1_b, g->fc2_w, g->fc2_b,
+                                    (char*)scratch + L.head_off, B, C, s->head, s->out_chan, HW, NL > 0, dt, stream, df.head ? &ht : nullptr);
 }
 
 // One phase of the backward pass: 0 = projection head (+ loss gradient), 1 .. L = FnoBlock L-phase (the blocks in reverse
@@ -203,6 +243,16 @@ extern "C" int cfd_fno_backward_phase_ex(const cfd_plan* p, const cfd_fno_shape*
                                          const cfd_fno_params* g, const float* inputs, const float* case_params,
                                          const float* mask, const float* label, const float* preds,
                                          const float* gpreds_ext, const float* coef, void* ws, int phase, int act_dtype, void* stream) {
+    return cfd_fno_backward_phase_f(p, s, prm, g, inputs, case_params, mask, label, preds, gpreds_ext, coef, nullptr, ws, phase, 0, act_dtype, 0, stream);
+}
+
+// flags (CFD_TRAIN_DEFER_*): phase 1 carries the head's reduction left behind by cfd_fno_forward_train_f (which needs `sums` and `which`
+// again: the head job writes the loss sums); phase L + 1 launches nothing when cfd_fno_adam_step finishes the lifting layer's gradient.
+extern "C" int cfd_fno_backward_phase_f(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm,
+                                        const cfd_fno_params* g, const float* inputs, const float* case_params,
+                                        const float* mask, const float* label, const float* preds,
+                                        const float* gpreds_ext, const float* coef, float* sums, void* ws, int phase, int which,
+                                        int act_dtype, int flags, void* stream) {
     CFD_TRY(check_shape("cfd_fno_backward_phase", p, s));
     CFD_REQUIRE(prm && g && inputs && ws, CFD_ERR_INVALID_ARG, "cfd_fno_backward_phase: NULL pointer");
     CFD_REQUIRE(act_dtype == CFD_DT_F32 || act_dtype == CFD_DT_BF16, CFD_ERR_INVALID_ARG, "cfd_fno_backward_phase: act_dtype %d (0 = fp32, 1 = bf16)", act_dtype);
@@ -234,7 +284,10 @@ extern "C" int cfd_fno_backward_phase_ex(const cfd_plan* p, const cfd_fno_shape*
     const bool stemg = dt == CFD_DT_F32 && NL >= 1 &&
                        cfd_int_stemg_ok(p, B, C, s->in_chan, s->n_case_params, inputs, mask, z);
     float* stem_part = (float*)((char*)scratch + stemg_offset(p, B, C, HW));
+    const Deferred df = deferred(p, s, L, base, which, dt, flags, inputs, mask);
+    CFD_REQUIRE(!df.head || sums, CFD_ERR_INVALID_ARG, "cfd_fno_backward_phase: CFD_TRAIN_DEFER_HEAD needs the `sums` of the forward call");
     if (phase == NL + 1) {
+        if (stemg && df.stem) return CFD_OK;  // cfd_fno_adam_step's launch finishes the lifting layer's gradient
         if (stemg)
             return cfd_int_stemg_combine(p, stem_part, case_params, g->fc0_w, g->fc0_b, B, C, s->in_chan, s->n_case_params, stream);
         return cfd_fno_stem_bwd(p, gcur, inputs, mask, case_params, g->fc0_w, g->fc0_b, scratch, B, s->in_chan,
@@ -267,7 +320,10 @@ extern "C" int cfd_fno_backward_phase_ex(const cfd_plan* p, const cfd_fno_shape*
     CFD_TRY(cfd_int_spectral_mix_adj_wgrad(p, xh_buf(l), gh, prm->spec_w1[l], prm->spec_w2[l], z, g->spec_w1[l],
                                            g->spec_w2[l], scratch, B, C, C, stream, &tail.spec));
     CFD_TRY(cfd_side_join((hipStream_t)stream, side));  // the block kernel reduces the 1x1 partial sums
-    tail.nblk = (tail.spec.part || tail.chan.part) ? 128 : 0;
+    if (df.head && phase == 1)  // the reduction cfd_fno_forward_train_f left behind (records at head_off: nothing of this phase touched them)
+        tail.head = cfd_int_head_tail((char*)scratch + L.head_off, g->fc1_w, g->fc1_b, g->fc2_w, g->fc2_b, sums, B, C, s->out_chan, HW,
+                                      df.scale ? (float)((double)B * s->out_chan * HW) : 0.f);
+    tail.nblk = (tail.spec.part || tail.chan.part || tail.head.part) ? 128 : 0;
     const CfdStemG sg{(l == 0 && stemg) ? inputs : nullptr, mask, p->d_gx, p->d_gy, stem_part, s->in_chan};
     return cfd_int_fno_block_bwd_input(p, gcur, z, prm->w0_w[l], act ? (const float*)act_buf(l) : nullptr, gnext, B, C, C, stream, &tail, &sg);
 }
@@ -281,4 +337,36 @@ extern "C" int cfd_fno_backward(const cfd_plan* p, const cfd_fno_shape* s, const
         CFD_TRY(cfd_fno_backward_phase(p, s, prm, g, inputs, case_params, mask, label, preds, gpreds_ext, coef, ws, phase,
                                        stream));
     return CFD_OK;
+}
+
+// The optimiser launch of the fused training step: Adam over the flat buffers, the deferred nMSE normaliser (sums[3] / sums[2] on top of
+// grad_scale) and the lifting layer's gradient rows (see include/cfdbench_amd.h).  `params` / `grads` point into `param` / `grad`.
+extern "C" int cfd_fno_adam_step(const cfd_plan* p, const cfd_fno_shape* s, const cfd_fno_params* prm, const cfd_fno_params* g,
+                                 const float* inputs, const float* case_params, const float* mask, const float* sums, void* ws,
+                                 float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int step, float grad_scale, int which, int act_dtype,
+                                 int flags, void* stream) {
+    CFD_TRY(check_shape("cfd_fno_adam_step", p, s));
+    CFD_REQUIRE(prm && g && ws && param && grad, CFD_ERR_INVALID_ARG, "cfd_fno_adam_step: NULL pointer");
+    CFD_REQUIRE(act_dtype == CFD_DT_F32 || act_dtype == CFD_DT_BF16, CFD_ERR_INVALID_ARG, "cfd_fno_adam_step: act_dtype %d", act_dtype);
+    const Layout L = make_layout(p, s, 1, act_dtype);
+    char* base = (char*)ws;
+    const Deferred df = deferred(p, s, L, base, which, act_dtype, flags, inputs, mask);
+    CFD_REQUIRE(!df.scale || sums, CFD_ERR_INVALID_ARG, "cfd_fno_adam_step: CFD_TRAIN_DEFER_SCALE needs the `sums` of the forward call");
+    StemAdamJob job{};
+    if (df.stem) {
+        const int B = s->B, C = s->hidden, HW = s->H * s->W;
+        CFD_REQUIRE(case_params || s->n_case_params == 0, CFD_ERR_INVALID_ARG, "cfd_fno_adam_step: NULL case_params");
+        const float* gw = (const float*)g->fc0_w;
+        const float* gb = (const float*)g->fc0_b;
+        CFD_REQUIRE(gw >= grad && gb >= grad && (size_t)(gw - grad) < n && (size_t)(gb - grad) < n, CFD_ERR_INVALID_ARG,
+                    "cfd_fno_adam_step: grads->fc0 does not point into the flat gradient buffer");
+        CFD_REQUIRE((const float*)prm->fc0_w - param == gw - grad && (const float*)prm->fc0_b - param == gb - grad, CFD_ERR_INVALID_ARG,
+                    "cfd_fno_adam_step: params and grads are laid out differently");
+        const int spl = cfd_int_stemg_splits(p, B);
+        job = StemAdamJob{(const float*)(base + L.off_scratch + stemg_offset(p, B, C, HW)), case_params, B * spl, spl, s->n_case_params,
+                          s->in_chan, C, (long)(gw - grad), (long)(gb - grad)};
+    }
+    return cfd_int_adam_flat_f(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                               df.scale ? sums : nullptr, df.stem ? &job : nullptr, stream);
 }

@@ -8,6 +8,7 @@
 // step at B=256), and fp32 MFMA on gfx950 only matches the VALU's fp32 rate without overlapping it, so the GEMMs run
 // as split-bf16 3-term products on v_mfma_f32_16x16x32_bf16 (cfd_common.h, relative error ~2^-16, fp32 accumulate).
 #include "cfd_common.h"
+#include "cfd_tail.h"
 
 #define HEAD_HD 128
 #define HEAD_MT 8
@@ -305,8 +306,10 @@ __global__ __launch_bounds__(64) void k_head_loss_final(const float* __restrict_
     if (lane == 0) { sums[0] = a; sums[1] = b; sums[2] = c; sums[3] = count; }
 }
 
-static size_t head_part_floats(int C, int Co) { return (size_t)HEAD_HD * C + HEAD_HD + (size_t)Co * HEAD_HD + Co + 2; }  // + 2: fused loss sums
-__device__ __forceinline__ size_t head_part_floats_dev(int C, int Co) { return (size_t)HEAD_HD * C + HEAD_HD + (size_t)Co * HEAD_HD + Co + 2; }
+#define HEAD_LOSS_ROWS 3  // rows of the one-pass head behind the parameter gradients: sum d^2, sum |d|, sum (label * mask)^2
+static size_t head_part_floats(int C, int Co) { return (size_t)HEAD_HD * C + HEAD_HD + (size_t)Co * HEAD_HD + Co + HEAD_LOSS_ROWS; }
+__device__ __forceinline__ size_t head_part_floats_dev(int C, int Co) { return (size_t)HEAD_HD * C + HEAD_HD + (size_t)Co * HEAD_HD + Co + HEAD_LOSS_ROWS; }
+static_assert(HEAD_HD == CFD_HEAD_HD, "cfd_tail.h's head_reduce_group assumes the same hidden width");
 
 extern "C" size_t cfd_fno_head_workspace_bytes(int B, int C, int Hd, int Co, int HW) {
     (void)Hd;
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_head_bwd(
     const TA* __restrict__ a, const float* __restrict__ mask, const float* __restrict__ label,
     const float* __restrict__ preds, const float* __restrict__ gext, const float* __restrict__ coef,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, float* __restrict__ ga,
-    float* __restrict__ part, int B, int C, int Co, int HW, float* __restrict__ preds_w, const float* __restrict__ b2) {
+    float* __restrict__ part, int B, int C, int Co, int HW, float* __restrict__ preds_w, const float* __restrict__ b2, float c0v, float c1v) {
     constexpr int CP = 4 * KS;          // padded channel count (rows of the d/dh exchange buffer)
     constexpr int MU = (CP + 15) / 16;  // 16-channel tiles
     constexpr int LDK = 40;             // bf16 row stride of s_hk: 32 channels + 8 pad (80 B: conflict-free b128 reads)
@@ -458,7 +461,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_head_bwd(
     CfdAct8<AP> w1t[MU];  // A operand of d/dh = W1^T gz:  w1[32w + 16(v/4) + 4q + v%4][16mu + n]
     float bz[HT][4];               // b1 at hidden unit HPW w + 16t + 4q + r
     cfd_f2 w2a[HT][2], w2b[HT][2]; // w2[0], w2[1] at hidden units HPW w + 16t + 4q + {2v, 2v+1}
-    const float c0 = label ? coef[0] : 0.f, c1 = label ? coef[1] : 0.f;
+    // loss-gradient coefficients: from device memory (cfd_loss_coef / cfd_label_energy_coef), or by value when coef == NULL (round 6: the
+    // deferred nMSE normaliser -- the head runs with the mse coefficient and cfd_fno_adam_step rescales every gradient)
+    const float c0 = label ? (coef ? coef[0] : c0v) : 0.f, c1 = label ? (coef ? coef[1] : c1v) : 0.f;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 aw1[HT][MU];
     cfd_f2 acc2a[HT][2], acc2b[HT][2], accb1[HT][2];
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_head_bwd(
         for (int v = 0; v < 2; ++v) { acc2a[t][v] = cfd_f2{0.f, 0.f}; acc2b[t][v] = cfd_f2{0.f, 0.f}; accb1[t][v] = cfd_f2{0.f, 0.f}; }
     }
     float gb2a0 = 0.f, gb2a1 = 0.f;
-    float lsq = 0.f, labs = 0.f;                                   // FUSE: loss sums (wave 0, lane group 0)
+    float lsq = 0.f, labs = 0.f, lab2 = 0.f;                       // FUSE: loss sums and sum (label * mask)^2 (wave 0, lane group 0)
     const float b2v0 = FUSE ? b2[0] : 0.f, b2v1 = (FUSE && Co > 1) ? b2[1] : 0.f;
     const int tpb = (HW + 63) / 64;
     const int total = B * tpb;  // < 2^30 (checked by the launcher)
@@ -765,6 +770,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_head_bwd(
                     s_pv[1][4 * n + j] = pr1;
                     lsq = fmaf(d0, d0, fmaf(d1, d1, lsq));
                     labs += fabsf(d0) + fabsf(d1);
+                    lab2 = fmaf(lab.x, lab.x, fmaf(lab.y, lab.y, lab2));
                     gb2a0 += gp0;
                     gb2a1 += gp1;
                 }
@@ -946,12 +952,14 @@ CFD_UNROLL(CFD_HB_UNROLL)
             dst[(size_t)o_gb2 * nb] = gb2a0;
             if (Co > 1) dst[(size_t)(o_gb2 + 1) * nb] = gb2a1;
         }
-        if constexpr (FUSE) {  // two more rows of the partial-sum block: sum d^2, sum |d|  (MseLoss, loss.py:27-28)
+        if constexpr (FUSE) {  // three more rows of the partial-sum block: sum d^2, sum |d|, sum (label*mask)^2  (MseLoss, loss.py:27-35)
             lsq = cfd_wave_sum(lsq);
             labs = cfd_wave_sum(labs);
+            lab2 = cfd_wave_sum(lab2);
             if (lane == 0) {
                 dst[(size_t)(o_gb2 + Co) * nb] = lsq;
                 dst[(size_t)(o_gb2 + Co + 1) * nb] = labs;
+                dst[(size_t)(o_gb2 + Co + 2) * nb] = lab2;
             }
         }
     }
@@ -959,21 +967,16 @@ CFD_UNROLL(CFD_HB_UNROLL)
 
 // Sum of the per-block partial records part[block][PSTR] (block-major): workgroup = 16 consecutive elements (cfd_record_sum16: every
 // load instruction reads 64-byte runs, fixed summation order, deterministic).
-__global__ __launch_bounds__(256) void k_head_reduce(const float* __restrict__ part, int nblk, int PS, int PSTR,
-                                                     float* __restrict__ gw1, float* __restrict__ gb1,
-                                                     float* __restrict__ gw2, float* __restrict__ gb2, int C, int Co,
-                                                     float* __restrict__ sums) {
+__global__ __launch_bounds__(256) void k_head_reduce(const HeadTail t) {
     __shared__ float s_scr[64];
-    const float s = cfd_record_sum16(part, nblk, PSTR, 16 * (int)blockIdx.x, PS, s_scr);
-    const int e = 16 * (int)blockIdx.x + (int)threadIdx.x;
-    if (threadIdx.x < 16 && e < PS) {
-        const int o_gb1 = HEAD_HD * C, o_gw2 = o_gb1 + HEAD_HD, o_gb2 = o_gw2 + Co * HEAD_HD;
-        if (e < o_gb1) gw1[e] = s;
-        else if (e < o_gw2) gb1[e - o_gb1] = s;
-        else if (e < o_gb2) gw2[e - o_gw2] = s;
-        else if (e < o_gb2 + Co) gb2[e - o_gb2] = s;
-        else if (sums) sums[e - (o_gb2 + Co)] = s;  // fused head: sums[0] = sum d^2, sums[1] = sum |d|
-    }
+    head_reduce_group(blockIdx.x, t, s_scr);
+}
+
+HeadTail cfd_int_head_tail(const void* ws, float* gw1, float* gb1, float* gw2, float* gb2, float* sums, int B, int C, int Co, int HW, float count) {
+    const int pstr = (int)head_part_floats(C, Co);
+    // rows reduced: parameter gradients; + sum d^2, sum |d| for the one-pass head (sums != NULL); + sum (label*mask)^2 when count > 0
+    const int ps = pstr - HEAD_LOSS_ROWS + (sums ? (count > 0.f ? 3 : 2) : 0);
+    return HeadTail{(const float*)ws, gw1, gb1, gw2, gb2, sums, head_bwd_blocks(B, HW), ps, pstr, C, Co, count};
 }
 
 extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* label, const float* preds,
@@ -994,7 +997,7 @@ extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* 
     const bool ap3 = cfd_act_pieces() == 3;
 #define CFD_HB_P(K_, V_, A_, P_)                                                                                   \
     hipLaunchKernelGGL((k_head_bwd<K_, V_, A_, false, float, P_>), dim3(blocks), dim3(256), 0, st, a, mask, label, preds, gpreds_ext, \
-                       coef, w1, b1, w2, ga, part, B, C, Co, HW, (float*)nullptr, (const float*)nullptr)
+                       coef, w1, b1, w2, ga, part, B, C, Co, HW, (float*)nullptr, (const float*)nullptr, 0.f, 0.f)
 #define CFD_HB(K_, V_, A_) do { if (ap3) CFD_HB_P(K_, V_, A_, 3); else CFD_HB_P(K_, V_, A_, 2); } while (0)
 #define CFD_HB_VA(K_)                              \
     do {                                           \
@@ -1011,10 +1014,9 @@ extern "C" int cfd_fno_head_bwd(const float* a, const float* mask, const float* 
 #undef CFD_HB_P
     }
     CFD_LAUNCH_CHECK("cfd_fno_head_bwd");
-    const int PS = (int)head_part_floats(C, Co) - 2;  // the two loss rows belong to the fused kernel
+    const HeadTail ht = cfd_int_head_tail(part, gw1, gb1, gw2, gb2, nullptr, B, C, Co, HW, 0.f);  // (the loss rows belong to the one-pass kernel)
     CFD_PROF_W("k_head_reduce", st, 0.0, 0.0);
-    hipLaunchKernelGGL(k_head_reduce, dim3((PS + 15) / 16), dim3(256), 0, st, (const float*)part, blocks, PS, (int)head_part_floats(C, Co), gw1,
-                       gb1, gw2, gb2, C, Co, (float*)nullptr);
+    hipLaunchKernelGGL(k_head_reduce, dim3((ht.PS + 15) / 16), dim3(256), 0, st, ht);
     CFD_LAUNCH_CHECK("cfd_fno_head_bwd(reduce)");
     return CFD_OK;
 }
@@ -1035,7 +1037,17 @@ extern "C" int cfd_fno_head_train(const float* a, const float* mask, const float
 int cfd_int_fno_head_train(const void* a, const float* mask, const float* label, const float* coef, const float* w1, const float* b1,
                            const float* w2, const float* b2, float* preds, float* sums, float* ga, float* gw1, float* gb1,
                            float* gw2, float* gb2, void* ws, int B, int C, int Hd, int Co, int HW, int act_in, int dt, void* stream) {
-    CFD_REQUIRE(a && label && coef && w1 && b1 && w2 && b2 && preds && sums && ga && gw1 && gb1 && gw2 && gb2 && ws,
+    CFD_REQUIRE(coef, CFD_ERR_INVALID_ARG, "cfd_fno_head_train: NULL pointer");
+    return cfd_int_fno_head_train_f(a, mask, label, coef, 0.f, 0.f, 0.f, w1, b1, w2, b2, preds, sums, ga, gw1, gb1, gw2, gb2, ws, B, C, Hd, Co, HW,
+                                    act_in, dt, stream, nullptr);
+}
+
+int cfd_int_fno_head_train_f(const void* a, const float* mask, const float* label, const float* coef, float c0v, float c1v, float count,
+                             const float* w1, const float* b1, const float* w2, const float* b2, float* preds, float* sums, float* ga,
+                             float* gw1, float* gb1, float* gw2, float* gb2, void* ws, int B, int C, int Hd, int Co, int HW, int act_in,
+                             int dt, void* stream, HeadTail* defer) {
+    if (defer) defer->part = nullptr;
+    CFD_REQUIRE(a && label && w1 && b1 && w2 && b2 && preds && sums && ga && gw1 && gb1 && gw2 && gb2 && ws,
                 CFD_ERR_INVALID_ARG, "cfd_fno_head_train: NULL pointer");
     CFD_TRY(head_check("cfd_fno_head_train", B, C, Hd, Co, HW));
     CFD_REQUIRE(B >= 1, CFD_ERR_INVALID_ARG, "cfd_fno_head_train: empty batch");
@@ -1055,12 +1067,12 @@ int cfd_int_fno_head_train(const void* a, const float* mask, const float* label,
         if constexpr (sizeof(T_) == 4) {                                                                                  \
             if (w8) {                                                                                                     \
                 hipLaunchKernelGGL((k_head_bwd<K_, V_, A_, true, T_, P_, 8>), dim3(blocks), dim3(512), 0, st, (const T_*)a, mask, label, (const float*)nullptr, \
-                                   (const float*)nullptr, coef, w1, b1, w2, ga, part, B, C, Co, HW, preds, b2);           \
+                                   (const float*)nullptr, coef, w1, b1, w2, ga, part, B, C, Co, HW, preds, b2, c0v, c1v); \
                 break;                                                                                                    \
             }                                                                                                             \
         }                                                                                                                 \
         hipLaunchKernelGGL((k_head_bwd<K_, V_, A_, true, T_, P_>), dim3(blocks), dim3(256), 0, st, (const T_*)a, mask, label, (const float*)nullptr, \
-                           (const float*)nullptr, coef, w1, b1, w2, ga, part, B, C, Co, HW, preds, b2);                   \
+                           (const float*)nullptr, coef, w1, b1, w2, ga, part, B, C, Co, HW, preds, b2, c0v, c1v);         \
     } while (0)
 #define CFD_HT(K_, V_, A_, T_)                                                                        \
     do {                                                                                              \
@@ -1087,10 +1099,13 @@ int cfd_int_fno_head_train(const void* a, const float* mask, const float* label,
 #undef CFD_HT_P
     }
     CFD_LAUNCH_CHECK("cfd_fno_head_train");
-    const int PS = (int)head_part_floats(C, Co);
+    const HeadTail ht = cfd_int_head_tail(part, gw1, gb1, gw2, gb2, sums, B, C, Co, HW, count);
+    if (defer) {  // the caller's next carrying launch reduces the records (cfd_tail.h)
+        *defer = ht;
+        return CFD_OK;
+    }
     CFD_PROF_W("k_head_reduce", st, 0.0, 0.0);
-    hipLaunchKernelGGL(k_head_reduce, dim3((PS + 15) / 16), dim3(256), 0, st, (const float*)part, blocks, PS, PS, gw1,
-                       gb1, gw2, gb2, C, Co, sums);
+    hipLaunchKernelGGL(k_head_reduce, dim3((ht.PS + 15) / 16), dim3(256), 0, st, ht);
     CFD_LAUNCH_CHECK("cfd_fno_head_train(reduce)");
     return CFD_OK;
 }

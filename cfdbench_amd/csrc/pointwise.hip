@@ -1418,6 +1418,86 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     }
 }
 
+// Round 6, the fused training step's optimiser launch (cfd_fno_adam_step): the flat Adam above PLUS the work that used to be launches of
+// its own in front of it -- (a) the nMSE normaliser: the head ran with the mse coefficient upstream / n, so every gradient still lacks the
+// factor n / sum (label*mask)^2 = sums[3] / sums[2] (both left by the head's reduction; k_label_energy_part + _coef: two launches, 10 us);
+// (b) the lifting layer's gradient: workgroup c < job.C finishes row c of fc0 from the sum records of k_block<.., STEMG>, stores it (in
+// the same, still unscaled units as every other gradient) and applies Adam to it; the flat part skips those two ranges.
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_adam_f(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float rsqrt_bc2,
+                                                float gscale, const float* __restrict__ sums, const StemAdamJob job) {
+    __shared__ float s_r[CFD_STEMG_NA][256];
+    if (sums) gscale *= sums[3] / sums[2];
+    const int njob = job.part ? job.C : 0;
+    const int F = job.in_chan + 3 + job.P;
+    if ((int)blockIdx.x < njob) {
+        const int c = blockIdx.x;
+        stem_combine_channel(job.part, job.nrec, job.spl, job.cp, job.P, job.C, c, s_r);
+        if ((int)threadIdx.x <= F) {
+            const bool bias = (int)threadIdx.x == F;
+            const float gv = bias ? s_r[0][0] : s_r[stem_feature_slot(threadIdx.x, job.in_chan)][0];
+            const size_t i = bias ? (size_t)job.b_off + c : (size_t)job.w_off + (size_t)c * F + threadIdx.x;
+            g[i] = gv;
+            adam_update(p[i], gv, m[i], v[i], lr, b1, b2, eps, wd, bc1, rsqrt_bc2, gscale);
+        }
+        return;
+    }
+    const size_t jw0 = (size_t)job.w_off, jw1 = jw0 + (size_t)job.C * F, jb0 = (size_t)job.b_off, jb1 = jb0 + job.C;
+    auto mine = [&](size_t e) { return !(njob && ((e >= jw0 && e < jw1) || (e >= jb0 && e < jb1))); };
+    const size_t t0 = (size_t)(blockIdx.x - njob) * blockDim.x + threadIdx.x, nt = (size_t)(gridDim.x - njob) * blockDim.x;
+    if constexpr (VEC) {
+        const size_t n4 = n >> 2;
+        const size_t jlo = jw0 < jb0 ? jw0 : jb0, jhi = jw1 > jb1 ? jw1 : jb1;
+        for (size_t i = t0; i < n4; i += nt) {
+            if (njob && 4 * i < jhi && 4 * i + 4 > jlo) {  // a unit that touches the lifting layer's ranges: element by element
+                for (size_t e = 4 * i; e < 4 * i + 4; ++e)
+                    if (mine(e)) adam_update(p[e], g[e], m[e], v[e], lr, b1, b2, eps, wd, bc1, rsqrt_bc2, gscale);
+                continue;
+            }
+            f32x4 pi = reinterpret_cast<const f32x4*>(p)[i], mi = reinterpret_cast<const f32x4*>(m)[i], vi = reinterpret_cast<const f32x4*>(v)[i];
+            const f32x4 gi = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pj = pi[j], mj = mi[j], vj = vi[j];
+                adam_update(pj, gi[j], mj, vj, lr, b1, b2, eps, wd, bc1, rsqrt_bc2, gscale);
+                pi[j] = pj, mi[j] = mj, vi[j] = vj;
+            }
+            reinterpret_cast<f32x4*>(m)[i] = mi;
+            reinterpret_cast<f32x4*>(v)[i] = vi;
+            reinterpret_cast<f32x4*>(p)[i] = pi;
+        }
+        for (size_t i = 4 * n4 + t0; i < n; i += nt)
+            if (mine(i)) adam_update(p[i], g[i], m[i], v[i], lr, b1, b2, eps, wd, bc1, rsqrt_bc2, gscale);
+    } else {
+        for (size_t i = t0; i < n; i += nt)
+            if (mine(i)) adam_update(p[i], g[i], m[i], v[i], lr, b1, b2, eps, wd, bc1, rsqrt_bc2, gscale);
+    }
+}
+
+int cfd_int_adam_flat_f(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int step, float grad_scale, const float* sums, const StemAdamJob* job, void* stream) {
+    CFD_REQUIRE(param && grad && exp_avg && exp_avg_sq, CFD_ERR_INVALID_ARG, "cfd_fno_adam_step: NULL pointer");
+    CFD_REQUIRE(step >= 1, CFD_ERR_INVALID_ARG, "cfd_fno_adam_step: step must be >= 1");
+    if (n == 0) return CFD_OK;
+    const StemAdamJob jb = job ? *job : StemAdamJob{};
+    CFD_REQUIRE(!jb.part || (jb.P <= 8 && jb.in_chan + 3 + jb.P < 256), CFD_ERR_UNSUPPORTED, "cfd_fno_adam_step: lifting layer with %d case parameters", jb.P);
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const bool vec = ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0) && n >= 4;
+    size_t blocks = ((vec ? n / 4 : n) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    blocks += jb.part ? jb.C : 0;
+    CFD_PROF_W("k_adam", (hipStream_t)stream, 28.0 * n, 12.0 * n);  // read p, g, m, v; write p, m, v
+    if (vec)
+        hipLaunchKernelGGL(k_adam_f<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                           beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, sums, jb);
+    else
+        hipLaunchKernelGGL(k_adam_f<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                           beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, sums, jb);
+    CFD_LAUNCH_CHECK("cfd_fno_adam_step");
+    return CFD_OK;
+}
+
 // The same step for MANY parameter tensors in one launch (the autograd training paths of the U-Net / ResNet / DeepONet families keep
 // torch's per-tensor parameters: 136 / 28 / 33 tensors).  torch's fused multi-tensor Adam took 3 x 31 us for the U-Net's 4.4 MB and
 // 40 us for the Auto-DeepONet's 2.3 MB -- 7 % of that model's step.  The (p, g, m, v, n) table travels as the kernel argument;

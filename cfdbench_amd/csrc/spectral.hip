@@ -1196,6 +1196,11 @@ __global__ __launch_bounds__(256) void k_chan_reduce_standalone(const ChanWgradT
     chan_wgrad_reduce_group(blockIdx.x, t.part, t.nrow, t.gw, t.gb, t.Co, t.Ci, s_scr);
 }
 
+__global__ __launch_bounds__(256) void k_head_reduce_standalone(const HeadTail t) {  // (only where a deferred one cannot ride)
+    __shared__ float s_scr[64];
+    head_reduce_group(blockIdx.x, t, s_scr);
+}
+
 __global__ __launch_bounds__(256) void k_spec_wgrad_reduce(const float2* __restrict__ part, float2* __restrict__ gw1,
                                                            float2* __restrict__ gw2, const float* __restrict__ clhw,
                                                            int nchunk, int CC, int m1, int m2) {
@@ -2461,7 +2466,17 @@ static int launch_reduce_tail_standalone(const CfdReduceTail* tail, hipStream_t 
                            tail->chan);
         CFD_LAUNCH_CHECK("cfd_fno_block_bwd_input(1x1 reduce)");
     }
+    if (tail->head.part) {
+        CFD_PROF_W("k_head_reduce", st, 0.0, 0.0);
+        hipLaunchKernelGGL(k_head_reduce_standalone, dim3((tail->head.PS + 15) / 16), dim3(256), 0, st, tail->head);
+        CFD_LAUNCH_CHECK("cfd_fno_block_bwd_input(head reduce)");
+    }
     return CFD_OK;
+}
+
+// whether cfd_int_fno_block_bwd_input will run the fused kernel (the one that carries tail jobs) for this plan / width / buffers
+bool cfd_int_block_bwd_fused(const cfd_plan* p, int C, const void* g, const void* gin, const void* aprev, const void* gz) {
+    return block_fused_ok(p, C, C, g, gin, aprev, gz);
 }
 
 // ---- lifting-layer gradient from the sums of k_block<.., STEMG> (cfd_tail.h: CfdStemG) ------------------------------------------
@@ -2470,44 +2485,12 @@ static int launch_reduce_tail_standalone(const CfdReduceTail* tail, hipStream_t 
 // sum_b cp[b][k] * S0[b][c] (a case parameter is constant over an entry's pixels).
 __global__ __launch_bounds__(256) void k_stem_grad_combine(const float* __restrict__ part, int nrec, int spl, const float* __restrict__ cp,
                                                            int P, int in_chan, int C, float* __restrict__ gw, float* __restrict__ gb) {
-    constexpr int NA = 6 + 8;  // the six sums + up to eight case-parameter columns
-    __shared__ float s_r[NA][256];
+    __shared__ float s_r[CFD_STEMG_NA][256];
     const int c = blockIdx.x;
-    float a[NA];
-#pragma unroll
-    for (int k = 0; k < NA; ++k) a[k] = 0.f;
-    for (int r = threadIdx.x; r < nrec; r += 256) {
-        const float* q = part + ((size_t)r * C + c) * 6;
-        float v[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] = q[k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) a[k] += v[k];
-        const float* cpb = cp + (size_t)(r / spl) * P;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (k < P) a[6 + k] = fmaf(cpb[k], v[0], a[6 + k]);
-    }
-#pragma unroll
-    for (int k = 0; k < NA; ++k) s_r[k][threadIdx.x] = a[k];
-    __syncthreads();
-    for (int h = 128; h >= 1; h >>= 1) {
-        if ((int)threadIdx.x < h) {
-#pragma unroll
-            for (int k = 0; k < NA; ++k) s_r[k][threadIdx.x] += s_r[k][threadIdx.x + h];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const int F = in_chan + 3 + P;
-        float* row = gw + (size_t)c * F;
-        for (int i = 0; i < in_chan; ++i) row[i] = s_r[1 + i][0];
-        row[in_chan] = s_r[3][0];
-        row[in_chan + 1] = s_r[4][0];
-        row[in_chan + 2] = s_r[5][0];
-        for (int k = 0; k < P; ++k) row[in_chan + 3 + k] = s_r[6 + k][0];
-        gb[c] = s_r[0][0];
-    }
+    stem_combine_channel(part, nrec, spl, cp, P, C, c, s_r);  // (cfd_tail.h: shared with cfd_fno_adam_step's carrying kernel)
+    const int F = in_chan + 3 + P;
+    if ((int)threadIdx.x < F) gw[(size_t)c * F + threadIdx.x] = s_r[stem_feature_slot(threadIdx.x, in_chan)][0];
+    if (threadIdx.x == 0) gb[c] = s_r[0][0];
 }
 
 // whether the input gradient of FnoBlock 0 can emit the lifting layer's sums instead of storing g_0 (same predicate in both phases)
@@ -2523,6 +2506,8 @@ bool cfd_int_stemg_ok(const cfd_plan* p, int B, int C, int in_chan, int P, const
     return ((uintptr_t)inputs % 16) == 0 && (!mask || ((uintptr_t)mask % 16) == 0);
 }
 size_t cfd_int_stemg_part_bytes(const cfd_plan* p, int B, int C) { return (size_t)B * (p ? p->T : 1) * C * 6 * sizeof(float); }
+
+int cfd_int_stemg_splits(const cfd_plan* p, int B) { return block_row_splits(p, B, 1); }  // records per batch entry
 
 int cfd_int_stemg_combine(const cfd_plan* p, const float* part, const float* cp, float* gw, float* gb, int B, int C, int in_chan, int P,
                           void* stream) {

@@ -267,6 +267,11 @@ class FnoTrainEngine:
         self.fused_head = fused_head
         self.pstruct = _param_struct(self.flat.ptrs(False), self.L)
         self.gstruct = _param_struct(self.flat.ptrs(True), self.L)
+        # Round 6: the single-GPU step folds its three tiny launches into launches that exist anyway (include/cfdbench_amd.h,
+        # CFD_TRAIN_DEFER_*: the nMSE normaliser into Adam, the head's reduction into backward phase 1, the fc0 combine into Adam's
+        # launch).  Data-parallel steps keep them: a rank's gradients must be final and normalised by ITS labels before the all-reduce.
+        # With the flags, `flat.grad` after train_step holds the gradients of sum d^2 * upstream / n (nmse); `gradients()` rescales.
+        self.defer_flags = 0 if (self.sync.exchange or not fused_head) else 7
         self.sums = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.coef = torch.zeros(2, dtype=torch.float32, device=self.device)
         self.scores_buf = torch.zeros(4, dtype=torch.float32, device=self.device)
@@ -291,8 +296,9 @@ class FnoTrainEngine:
         self._shape_key = key
         self._graph = None
 
-    def forward_backward(self, inputs: Tensor, label: Tensor, case_params: Tensor, mask: Optional[Tensor] = None):
-        """Enqueue forward + loss + backward into the flat gradient buffer (every gradient is overwritten)."""
+    def forward_backward(self, inputs: Tensor, label: Tensor, case_params: Tensor, mask: Optional[Tensor] = None, flags: int = 0):
+        """Enqueue forward + loss + backward into the flat gradient buffer (every gradient is overwritten).  ``flags`` =
+        CFD_TRAIN_DEFER_* (train_step passes ``defer_flags``): the gradients are then complete only after ``optimizer_step``'s launch."""
         for t in (inputs, label, case_params, mask):
             if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
                 raise RuntimeError("FnoTrainEngine expects contiguous float32 CUDA tensors")
@@ -300,15 +306,18 @@ class FnoTrainEngine:
         st = torch.cuda.current_stream().cuda_stream
         a, sp = self.api, ctypes.byref(self.shape)
         mp = None if mask is None else mask.data_ptr()
+        self._last = (inputs, case_params, mask, flags)  # optimizer_step finishes what the flags deferred
         if self.fused_head:
-            a.call("cfd_fno_forward_train_ex", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
+            a.call("cfd_fno_forward_train_f", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
                    inputs.data_ptr(), case_params.data_ptr(), mp, label.data_ptr(), self.preds.data_ptr(), self.sums.data_ptr(),
-                   self.coef.data_ptr(), self.ws.data_ptr(), self.loss_id, 1.0, self.act_dtype, st)
+                   self.coef.data_ptr(), self.ws.data_ptr(), self.loss_id, 1.0, self.act_dtype, flags, st)
             for phase in range(1, self.L + 2):  # phase 0 (the head) left the fused kernel already
-                a.call("cfd_fno_backward_phase_ex", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
+                a.call("cfd_fno_backward_phase_f", self.plan, sp, ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
                        inputs.data_ptr(), case_params.data_ptr(), mp, label.data_ptr(), self.preds.data_ptr(), None,
-                       self.coef.data_ptr(), self.ws.data_ptr(), phase, self.act_dtype, st)
+                       self.coef.data_ptr(), self.sums.data_ptr(), self.ws.data_ptr(), phase, self.loss_id, self.act_dtype, flags, st)
             return
+        if flags:
+            raise RuntimeError("FnoTrainEngine: the deferred training step needs the one-pass head (fused_head)")
         a.call("cfd_fno_forward", self.plan, sp, ctypes.byref(self.pstruct), inputs.data_ptr(), case_params.data_ptr(), mp,
                label.data_ptr(), self.preds.data_ptr(), self.sums.data_ptr(), self.ws.data_ptr(), 1, st)
         a.call("cfd_loss_coef", self.sums.data_ptr(), self.coef.data_ptr(), self.loss_id, 1.0, st)
@@ -356,9 +365,27 @@ class FnoTrainEngine:
 
     def optimizer_step(self, grad_scale: float = 1.0):
         self.step_count += 1
+        inputs, case_params, mask, flags = getattr(self, "_last", (None, None, None, 0))
+        if flags:  # the pass left work to this launch: nMSE normaliser from sums[2:4], the lifting layer's gradient rows
+            self.api.call("cfd_fno_adam_step", self.plan, ctypes.byref(self.shape), ctypes.byref(self.pstruct), ctypes.byref(self.gstruct),
+                          inputs.data_ptr(), case_params.data_ptr(), None if mask is None else mask.data_ptr(), self.sums.data_ptr(),
+                          self.ws.data_ptr(), self.flat.data.data_ptr(), self.flat.grad.data_ptr(), self.exp_avg.data_ptr(),
+                          self.exp_avg_sq.data_ptr(), self.flat.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                          self.step_count, grad_scale, self.loss_id, self.act_dtype, flags, torch.cuda.current_stream().cuda_stream)
+            self._last = (inputs, case_params, mask, 0)  # (a second optimizer_step on the same gradients must not redo the deferred work)
+            self._grad_pending_scale = bool(flags & 1) and self.loss_id == _LOSS_IDS["nmse"]
+            return
+        self._grad_pending_scale = False
         self.api.call("cfd_adam_flat", self.flat.data.data_ptr(), self.flat.grad.data_ptr(), self.exp_avg.data_ptr(),
                       self.exp_avg_sq.data_ptr(), self.flat.numel, self.lr, self.betas[0], self.betas[1], self.eps,
                       self.weight_decay, self.step_count, grad_scale, torch.cuda.current_stream().cuda_stream)
+
+    def gradients(self) -> Tensor:
+        """The flat gradient of the last step in the loss's own units.  After a deferred train_step (``defer_flags``) the buffer holds the
+        gradients of sum d^2 / n -- this returns them times n / sum (label*mask)^2 (what Adam applied); otherwise the buffer itself."""
+        if getattr(self, "_grad_pending_scale", False):
+            return self.flat.grad * (self.sums[3] / self.sums[2])
+        return self.flat.grad
 
     def train_step(self, inputs: Tensor, label: Tensor, case_params: Tensor, mask: Optional[Tensor] = None) -> Tensor:
         """One optimisation step; returns the device tensor [sum sq err, sum abs err, sum sq label, n] of THIS rank's
@@ -366,7 +393,7 @@ class FnoTrainEngine:
         if self.sync.exchange and self.overlap:
             scale = self.forward_backward_overlapped(inputs, label, case_params, mask)
         else:
-            self.forward_backward(inputs, label, case_params, mask)
+            self.forward_backward(inputs, label, case_params, mask, self.defer_flags)
             scale = self.sync.all_reduce(self.flat.grad)
         self.optimizer_step(scale)
         return self.sums
@@ -402,13 +429,13 @@ class FnoTrainEngine:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self.forward_backward(*self._static)  # warm-up outside capture
+            self.forward_backward(*self._static, flags=self.defer_flags)  # warm-up outside capture
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
         from .graph import CAPTURE_MODE
         torch.cuda.synchronize()  # (no collective of an earlier step in flight: see graph.CAPTURE_MODE)
         with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
-            self.forward_backward(*self._static)
+            self.forward_backward(*self._static, flags=self.defer_flags)
         self._graph = g
 
     def train_step_graph(self, inputs: Tensor, label: Tensor, case_params: Tensor, mask: Optional[Tensor] = None) -> Tensor:
@@ -420,6 +447,7 @@ class FnoTrainEngine:
             if dst is not None and src is not dst:
                 dst.copy_(src, non_blocking=True)
         self._graph.replay()
+        self._last = (self._static[0], self._static[2], self._static[3], self.defer_flags)  # (the replayed pass used the static buffers)
         scale = self.sync.all_reduce(self.flat.grad)
         self.optimizer_step(scale)
         return self.sums

@@ -40,7 +40,7 @@ extern "C" {
  * changes (500, round 5: the statistics records of cfd_conv2d_fwd_stats / cfd_batchnorm_fwd_stats are (C, slots, 4) floats since
  * round 4 -- a caller that still allocates (C, slots, 2) must fail at load time, not write out of bounds; the default of the
  * "act_pieces" knob is 3).  The Python binding refuses a library whose version differs (cfdbench_amd/_capi.py). */
-#define CFD_ABI_VERSION 500
+#define CFD_ABI_VERSION 600
 int cfd_version(void);
 const char* cfd_last_error(void);
 
@@ -493,6 +493,38 @@ int cfd_fno_backward_phase_ex(const cfd_plan* plan, const cfd_fno_shape* shape, 
                               const cfd_fno_params* grads, const float* inputs, const float* case_params,
                               const float* mask, const float* label, const float* preds, const float* gpreds_ext,
                               const float* coef, void* ws, int phase, int act_dtype, void* stream);
+
+/* Round 6 -- the fused SINGLE-GPU training step with deferred work (FnoTrainEngine.train_step; the reference's loop is
+ * src/train_auto.py:231-257: model(**batch) -> loss["nmse"].backward() -> Adam.step()).  Three tiny launches of the step above --
+ * the label-energy pair in front of the head, the head's partial-sum reduction behind it, the lifting layer's combine in front of
+ * Adam -- each cost ~5 us of dispatch floor for microseconds of work; with `flags` they ride in launches that exist anyway:
+ *   CFD_TRAIN_DEFER_SCALE  nmse only: the head runs with the mse coefficient upstream / n (passed by value, `coef` unused) and ALSO sums
+ *                          (label * mask)^2; every gradient of the pass is then short of the factor n / sum (label*mask)^2, which
+ *                          cfd_fno_adam_step applies from sums[2], sums[3] (every gradient is linear in that scalar).  Until then the
+ *                          gradient buffers hold the gradients of sum d^2 * upstream / n.
+ *   CFD_TRAIN_DEFER_HEAD   the head's reduction rides in backward phase 1's FnoBlock kernel (fc1 / fc2 gradients and sums[] are final
+ *                          after phase 1 instead of after the forward call)
+ *   CFD_TRAIN_DEFER_STEM   backward phase num_layers + 1 launches nothing; cfd_fno_adam_step finishes the fc0 gradient in its own launch
+ * A flag whose precondition does not hold for the shape (other widths / grids, bf16 storage, no FnoBlock) is ignored -- by all three
+ * calls alike, they evaluate the same predicates -- so the caller passes the same `flags` to the forward, to every phase and to
+ * cfd_fno_adam_step.  flags = 0 is exactly cfd_fno_forward_train_ex / cfd_fno_backward_phase_ex / cfd_adam_flat.  Data-parallel
+ * training keeps flags = 0: a rank's gradients must be final and normalised by ITS labels before they are all-reduced.
+ * cfd_fno_adam_step: param / grad / exp_avg / exp_avg_sq = the flat buffers (n floats) that `params` / `grads` point into.       */
+#define CFD_TRAIN_DEFER_SCALE 1
+#define CFD_TRAIN_DEFER_HEAD 2
+#define CFD_TRAIN_DEFER_STEM 4
+int cfd_fno_forward_train_f(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,
+                            const cfd_fno_params* grads, const float* inputs, const float* case_params, const float* mask,
+                            const float* label, float* preds, float* sums, float* coef, void* ws, int which, float upstream,
+                            int act_dtype, int flags, void* stream);
+int cfd_fno_backward_phase_f(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,
+                             const cfd_fno_params* grads, const float* inputs, const float* case_params,
+                             const float* mask, const float* label, const float* preds, const float* gpreds_ext,
+                             const float* coef, float* sums, void* ws, int phase, int which, int act_dtype, int flags, void* stream);
+int cfd_fno_adam_step(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params, const cfd_fno_params* grads,
+                      const float* inputs, const float* case_params, const float* mask, const float* sums, void* ws, float* param,
+                      float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int step, float grad_scale, int which, int act_dtype, int flags, void* stream);
 
 /* grads: same layout as params, every tensor overwritten.  coef/gpreds_ext as in cfd_fno_head_bwd.           */
 int cfd_fno_backward(const cfd_plan* plan, const cfd_fno_shape* shape, const cfd_fno_params* params,

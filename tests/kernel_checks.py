@@ -477,6 +477,90 @@ def run_fno(be, params, batch, L, C, H, W, p, with_label=True, which="nmse"):
         api.plan_destroy(plan)
 
 
+def _flat_struct(be, flat, layout, L):
+    """cfd_fno_params whose tensors are slices of one flat float32 buffer (the training engine's layout)."""
+    base = be.ptr(flat)
+
+    class _V:  # (make_param_struct only needs be.ptr of each entry)
+        def __init__(self, off):
+            self.off = off
+    s = FnoParams()
+    at = lambda k: base + 4 * layout[k][0]  # noqa: E731
+    s.fc0_w, s.fc0_b = at("fc0.weight"), at("fc0.bias")
+    for l in range(L):
+        s.spec_w1[l], s.spec_w2[l] = at(f"blocks.{l}.conv0.weights1"), at(f"blocks.{l}.conv0.weights2")
+        s.w0_w[l], s.w0_b[l] = at(f"blocks.{l}.w0.weight"), at(f"blocks.{l}.w0.bias")
+    s.fc1_w, s.fc1_b, s.fc2_w, s.fc2_b = at("fc1.weight"), at("fc1.bias"), at("fc2.weight"), at("fc2.bias")
+    return s
+
+
+def check_fno_train_step_deferred(be, B, C, L, H, W, p=5, which="nmse", flags=7, steps=2, border=True, pseed=27, bseed=28):
+    """Round 6: the fused single-GPU training step with its three tiny launches folded into others (CFD_TRAIN_DEFER_*:
+    cfd_fno_forward_train_f / cfd_fno_backward_phase_f / cfd_fno_adam_step) against the same calls with flags = 0 (the label-energy pair,
+    the head's own reduction, the fc0 combine, cfd_adam_flat) -- parameters after `steps` Adam steps, predictions, loss sums, and the
+    first step's gradient (rescaled by n / sum (label*mask)^2 where the normaliser was deferred) against the fp64 oracle."""
+    api, P = be.api, be.ptr
+    wid = {"mse": 0, "nmse": 1, "mae": 2}[which]
+    params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=4.0)
+    batch = synth.make_batch(bseed, B, H, W, p, border_mask=border)
+    names = ["fc0.weight", "fc0.bias"] + [f"blocks.{l}.{t}" for l in range(L) for t in ("conv0.weights1", "conv0.weights2", "w0.weight", "w0.bias")] \
+        + ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
+    layout, off = {}, 0
+    for k in names:
+        n = params[k].size * (2 if np.iscomplexobj(params[k]) else 1)
+        layout[k] = (off, n)
+        off += (n + 3) // 4 * 4
+    numel = off
+    flat0 = np.zeros(numel, np.float32)
+    for k in names:
+        v = params[k]
+        flat0[layout[k][0]:layout[k][0] + layout[k][1]] = (np.stack([v.real, v.imag], -1) if np.iscomplexobj(v) else v).reshape(-1)
+    plan = api.plan_create(H, W, 12, 12)
+    try:
+        shape = FnoShape(B, H, W, 2, 2, p, C, L, 12, 12, 128)
+        di, dc, dm, dl = be.dev(batch["inputs"]), be.dev(batch["case_params"]), be.dev(batch["mask"]), be.dev(batch["label"])
+        out = {}
+        for fl in (0, flags):
+            flat, grad = be.dev(flat0), be.zeros((numel,))
+            m, v = be.zeros((numel,)), be.zeros((numel,))
+            ps, gs = _flat_struct(be, flat, layout, L), _flat_struct(be, grad, layout, L)
+            ws = be.bytes(api.size("cfd_fno_workspace_bytes", plan, ctypes.byref(shape), 1))
+            preds, sums, coef = be.zeros((B, 2, H, W)), be.zeros((4,)), be.zeros((2,))
+            g1 = None
+            for step in range(1, steps + 1):
+                api.call("cfd_fno_forward_train_f", plan, ctypes.byref(shape), ctypes.byref(ps), ctypes.byref(gs), P(di), P(dc), P(dm), P(dl),
+                         P(preds), P(sums), P(coef), P(ws), wid, 1.0, 0, fl, be.stream)
+                for phase in range(1, L + 2):
+                    api.call("cfd_fno_backward_phase_f", plan, ctypes.byref(shape), ctypes.byref(ps), ctypes.byref(gs), P(di), P(dc), P(dm),
+                             P(dl), P(preds), None, P(coef), P(sums), P(ws), phase, wid, 0, fl, be.stream)
+                api.call("cfd_fno_adam_step", plan, ctypes.byref(shape), ctypes.byref(ps), ctypes.byref(gs), P(di), P(dc), P(dm), P(sums), P(ws),
+                         P(flat), P(grad), P(m), P(v), numel, 1e-3, 0.9, 0.999, 1e-8, 0.0, step, 1.0, wid, 0, fl, be.stream)
+                be.sync()
+                if step == 1:
+                    g1 = be.host(grad).copy()
+                    s1 = be.host(sums).copy()
+                    if (fl & 1) and which == "nmse":
+                        g1 = g1 * (s1[3] / s1[2])
+                    out[fl] = dict(g1=g1, sums1=s1, preds1=be.host(preds).copy())
+            out[fl]["flat"] = be.host(flat).copy()
+        a, b = out[0], out[flags]
+        res = {"params": nm(b["flat"], a["flat"]), "preds": nm(b["preds1"], a["preds1"]), "grad_vs_immediate": nm(b["g1"], a["g1"]),
+               "sums": float(np.max(np.abs(b["sums1"] - a["sums1"]) / np.abs(a["sums1"])))}
+        # the deferred step's first gradient against the oracle
+        p64 = {k: v.astype(c128 if np.iscomplexobj(v) else f64) for k, v in params.items()}
+        b64 = {k: v.astype(f64) for k, v in batch.items()}
+        ref = O.fno_forward(p64, b64["inputs"], b64["case_params"], b64["mask"], b64["label"], L)
+        rg = O.fno_backward(p64, ref["cache"], O.loss_grad_wrt_preds(ref["cache"]["preds"], ref["cache"]["label"], which), L)
+        for k in ("fc0.weight", "fc0.bias", "fc1.weight", "fc2.bias", f"blocks.{L - 1}.conv0.weights1" if L else "fc1.bias"):
+            got = b["g1"][layout[k][0]:layout[k][0] + layout[k][1]]
+            want = rg[k]
+            want = (np.stack([want.real, want.imag], -1) if np.iscomplexobj(want) else want).reshape(-1)
+            res["oracle:" + k] = nm(got, want)
+        return res
+    finally:
+        api.plan_destroy(plan)
+
+
 def check_fno_vs_oracle(be, B, C, L, H, W, p=5, border=False, gain=4.0, pseed=7, bseed=8):
     params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=gain)
     batch = synth.make_batch(bseed, B, H, W, p, border_mask=border)

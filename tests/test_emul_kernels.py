@@ -511,3 +511,14 @@ def test_scale_copy_multi_packs_many_tensors_into_one_buffer(be):
     """cfd_scale_copy_multi: the data-parallel gradient pack (engine.FlatGradExchange) -- 5 tensors and 170 tensors (three launches of <= 80)."""
     assert K.check_scale_copy_multi(be) == 0
     assert K.check_scale_copy_multi(be, sizes=tuple(1 + (37 * i) % 500 for i in range(170)), scale=0.125) == 0
+
+
+@pytest.mark.parametrize("kw", [dict(B=2, C=20, L=2, H=64, W=64), dict(B=1, C=8, L=1, H=64, W=64, which="mae"),
+                                dict(B=2, C=20, L=1, H=64, W=64, which="mse", flags=6), dict(B=1, C=20, L=1, H=66, W=65)])
+def test_fused_train_step_with_deferred_launches(be, kw):
+    """Round 6 (CFD_TRAIN_DEFER_*): the nMSE normaliser applied by Adam, the head's reduction riding in backward phase 1's block kernel, the
+    fc0 combine riding in Adam's launch -- same parameters after two steps as the step with those five launches (fp32 round-off), same
+    predictions bit for bit, and the (rescaled) gradient holds the oracle."""
+    res = K.check_fno_train_step_deferred(be, **kw)
+    assert res.pop("sums") < 1e-6 and res.pop("preds") == 0.0
+    _assert_all(res, 1e-11)

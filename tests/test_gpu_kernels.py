@@ -557,3 +557,15 @@ def test_scale_copy_multi_packs_many_tensors_into_one_buffer(be):
     """cfd_scale_copy_multi: the data-parallel gradient pack (engine.FlatGradExchange) -- 5 tensors and 170 tensors (three launches of <= 80)."""
     assert K.check_scale_copy_multi(be) == 0
     assert K.check_scale_copy_multi(be, sizes=tuple(1 + (37 * i) % 500 for i in range(170)), scale=0.125) == 0
+
+
+@pytest.mark.parametrize("kw", [dict(B=4, C=20, L=4, H=64, W=64), dict(B=3, C=8, L=1, H=64, W=64, which="mae"), dict(B=300, C=20, L=2, H=64, W=64, steps=1),
+                                dict(B=3, C=20, L=2, H=64, W=64, which="mse", flags=6), dict(B=2, C=20, L=2, H=66, W=65), dict(B=2, C=32, L=2, H=64, W=64),
+                                dict(B=5, C=20, L=2, H=64, W=64, flags=1), dict(B=5, C=20, L=2, H=64, W=64, flags=2), dict(B=5, C=20, L=2, H=64, W=64, flags=4)])
+def test_fused_train_step_with_deferred_launches(be, kw):
+    """Round 6 (CFD_TRAIN_DEFER_*): the nMSE normaliser applied by Adam, the head's reduction riding in backward phase 1's block kernel, the
+    fc0 combine riding in Adam's launch -- same parameters after two steps as the step with those five launches (fp32 round-off), same
+    predictions bit for bit, and the (rescaled) gradient holds the oracle.  Every flag alone and all together."""
+    res = K.check_fno_train_step_deferred(be, **kw)
+    assert res.pop("sums") < 1e-6 and res.pop("preds") == 0.0
+    _assert_all(res, 1e-11)

@@ -755,3 +755,40 @@ def test_auto_deeponet_cnn_vs_reference_golden(torch, golden_dir):
     with torch.no_grad():
         frames = m.generate_many(x.detach()[:1], cp[:1], mask[:1, 0], steps)
         assert O.rel_nmse(torch.stack(frames).cpu().numpy(), g["frames"]) < 1e-8
+
+
+def test_train_engine_deferred_step_equals_the_step_with_its_own_launches(torch):
+    """FnoTrainEngine.train_step folds three tiny launches into others on one GPU (engine.defer_flags = 7): same trajectory as with
+    defer_flags = 0 (fp32 round-off of one extra multiply per gradient), `gradients()` = the immediate gradients, eager and graph replay."""
+    from cfdbench_amd.engine import FnoTrainEngine
+    from cfdbench_amd.models.fno.fno2d import Fno2d
+    from cfdbench_amd.models.loss import loss_name_to_fn
+    from oracle import fno_oracle as O
+    from oracle import synth
+    B, C, L, H, W, p = 6, 20, 3, 64, 64, 5
+    params = synth.make_fno_params(5, C, L, 12, 12, p, spectral_gain=4.0)
+    b = {k: torch.from_numpy(v).cuda() for k, v in synth.make_batch(6, B, H, W, p, border_mask=True).items()}
+
+    def run(flags, graph):
+        m = Fno2d(2, 2, p, loss_name_to_fn("nmse"), L, 12, 12, C).cuda()
+        m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()})
+        eng = FnoTrainEngine(m, lr=1e-3, loss_name="nmse")
+        assert eng.defer_flags == 7  # one process, no exchange
+        eng.defer_flags = flags
+        step = eng.train_step_graph if graph else eng.train_step
+        grads, sums = [], []
+        for _ in range(3):
+            s = step(b["inputs"], b["label"], b["case_params"], b["mask"])
+            torch.cuda.synchronize()
+            grads.append(eng.gradients().cpu().numpy().copy())
+            sums.append(s.cpu().numpy().copy())
+        return eng.flat.data.cpu().numpy().copy(), grads, sums
+
+    ref = run(0, False)
+    for flags, graph in ((7, False), (7, True), (5, False)):
+        got = run(flags, graph)
+        assert O.rel_nmse(got[0], ref[0]) < 1e-12, (flags, graph)
+        for g, r in zip(got[1], ref[1]):
+            assert O.rel_nmse(g, r) < 1e-11
+        for s_, r_ in zip(got[2], ref[2]):
+            assert np.allclose(s_, r_, rtol=2e-6, atol=0)
