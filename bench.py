@@ -387,7 +387,7 @@ def unet_bytes_per_frame(dim, cin, H, W):
     return 3 * e * 4
 
 
-DP = dict(world=1, rank=0, steps=None, warmup=None, force=False)  # set by main() for `--gpus N --only LEG`: the leg as a data-parallel job
+DP = dict(world=1, rank=0, steps=None, warmup=None, force=False, comm_stream_overlaps=None)  # set by main() for `--gpus N --only LEG`: the leg as a data-parallel job
 
 
 def model_dp_leg(name, model, batch, frames, what):
@@ -420,8 +420,10 @@ def model_dp_leg(name, model, batch, frames, what):
             "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": what, "global_batch": world * frames, "parallelism": f"dp{world}",
-                       "step": "graph A (forward + backward + gradient pack) -> all-reduce of the flat gradient (RCCL) -> graph B (Adam)",
-                       "flat_gradient_bytes": int(gs.exchange.numel * 4) if gs.exchange is not None else 0},
+                       "step": "ONE HIP graph per step: forward + backward + gradient pack -> all-reduce of the flat gradient (RCCL, captured) -> Adam "
+                               "(CFDBENCH_DP_ONE_GRAPH=0: graph A -> eager all-reduce -> graph B, the round-5 form)",
+                       "flat_gradient_bytes": int(gs.exchange.numel * 4) if gs.exchange is not None else 0,
+                       "collective_in_graph": bool(gs.one_graph), "comm_stream_overlaps": DP["comm_stream_overlaps"]},
             "final_nmse": round(float(gs.loss["nmse"].item()), 6)}
 
 
@@ -679,6 +681,10 @@ def main():
         if force_dp:
             os.environ.setdefault("MASTER_PORT", str(free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # the communicator's stream must not share the compute stream's hardware queue (one pool entry in four does): probe, and
+        # take a fresh group until one overlaps (harness/dist_util.py); the verdict travels in the line
+        from cfdbench_amd.harness.dist_util import steer_comm_stream
+        DP["comm_stream_overlaps"] = steer_comm_stream()
 
     from cfdbench_amd import _lib
     from cfdbench_amd.engine import FnoTrainEngine
@@ -737,6 +743,26 @@ def main():
         elapsed = float(t.item())
     final = eng.scores()
     fps = world * B * args.steps / elapsed
+    dp_info = None
+    if eng.sync.exchange and not args.graph:
+        # what the exchange costs this rank per step: the same K steps with the collectives switched off (same kernels: a data-parallel
+        # engine keeps the step's five own launches), between the same barriers.  On N GPUs this is the exposed (un-hidden) part of the
+        # all-reduces plus their host calls; it explains the scaling curve the driver computes from the per-N values.
+        eng.sync.exchange = False
+        for _ in range(3):
+            step(inputs, label, cp, mask)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(inputs, label, cp, mask)
+        torch.cuda.synchronize()
+        t_no = (time.perf_counter() - t1) / args.steps
+        barrier()
+        eng.sync.exchange = True
+        dp_info = dict(comm_stream_overlaps=DP["comm_stream_overlaps"], step_ms_without_exchange=round(t_no * 1e3, 4),
+                       exposed_comm_us=round((elapsed / args.steps - t_no) * 1e6, 1), rank=rank,
+                       flat_gradient_bytes=int(eng.flat.numel * 4), buckets="one per backward phase (head, FnoBlocks, lifting layer)")
 
     result = {
         "metric": "train frames/sec (64x64x2), Auto-FNO cavity", "value": round(fps, 1),
@@ -752,6 +778,8 @@ def main():
                    "global_batch": world * B, "parallelism": f"dp{world}", "graph": bool(args.graph), "settle_steps": args.settle},
         "final_nmse": round(final["nmse"], 6),
     }
+    if dp_info:
+        result["dp"] = dp_info
     bpf = fno_step_bytes_per_frame(C, L, H * W)
     per_gpu = fps / world
     result["roofline_step"] = dict(bound="hbm", what="whole train step vs the ideal-fusion byte count of SURVEY.md 8(d)", bytes_per_frame=bpf,

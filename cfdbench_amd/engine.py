@@ -62,14 +62,36 @@ class FlatParams:
         return [(g if grad else v).data_ptr() for v, g in zip(self.views, self.grad_views)]
 
 
+# The process group the data-parallel exchanges use when none is given: the default group, or the one
+# harness/dist_util.overlapping_comm_group picked (a communicator whose stream really overlaps the compute stream).
+_dp_group = None
+
+
+def set_default_group(group) -> None:
+    global _dp_group
+    _dp_group = group
+
+
+def _resolve_group(group):
+    if group is not None or _dp_group is None:
+        return group
+    try:  # (a group of a process group that has been destroyed since is forgotten)
+        dist.get_world_size(_dp_group)
+        return _dp_group
+    except Exception:  # noqa: BLE001
+        set_default_group(None)
+        return None
+
+
 class GradSync:
     """Data-parallel gradient exchange: SUM all-reduce of the flat gradient buffer (RCCL over xGMI on GPUs, gloo in
     the CPU tests) in ``n_buckets`` contiguous slices; the 1/world_size factor is folded into the Adam kernel.
     Semantics = DistributedDataParallel's (per-rank loss normalisers, averaged gradients)."""
 
     def __init__(self, group=None, n_buckets: int = 1):
-        self.group = group
         live = dist.is_available() and dist.is_initialized()
+        group = _resolve_group(group) if live else group
+        self.group = group
         self.world = dist.get_world_size(group) if live else 1
         self.n_buckets = max(1, n_buckets)
         # A one-rank group has nothing to exchange and skips the collectives -- unless CFDBENCH_DP_ALWAYS_EXCHANGE=1 asks for them:
@@ -205,7 +227,7 @@ def sync_gradients(params: Sequence[torch.nn.Parameter], group=None) -> None:
     Same semantics as DistributedDataParallel.  No-op outside a process group / in a one-rank group."""
     if not (dist.is_available() and dist.is_initialized()):
         return
-    if dist.get_world_size(group) == 1 and os.environ.get("CFDBENCH_DP_ALWAYS_EXCHANGE", "0") != "1":
+    if dist.get_world_size(_resolve_group(group)) == 1 and os.environ.get("CFDBENCH_DP_ALWAYS_EXCHANGE", "0") != "1":
         return
     ps = [p_ for p_ in params if p_.requires_grad and p_.grad is not None]
     if not ps:
@@ -214,6 +236,7 @@ def sync_gradients(params: Sequence[torch.nn.Parameter], group=None) -> None:
     # (a module-global dict kept every model's parameters and a model-sized flat buffer alive: ADVICE r5), and re-validated against
     # the live process group: after destroy_process_group + a new init in the same process a cached object would carry a stale
     # world size, backend and 1 / world scale.
+    group = _resolve_group(group)
     world, backend = dist.get_world_size(group), dist.get_backend(group)
     key = tuple(id(p_) for p_ in ps) + (id(group), world, backend)
     slot = getattr(ps[0], "_cfd_grad_exchange", None)
@@ -434,8 +457,15 @@ class FnoTrainEngine:
         g = torch.cuda.CUDAGraph()
         from .graph import CAPTURE_MODE
         torch.cuda.synchronize()  # (no collective of an earlier step in flight: see graph.CAPTURE_MODE)
+        # Round 6: over RCCL the per-phase all-reduces are captured with the pass (forked onto the communicator's stream and joined back
+        # by events), so a replayed data-parallel step makes no host call into the process group; host-staged backends reduce after it.
+        self._graph_exchanges = bool(self.sync.exchange and self.sync.device_native and self.overlap
+                                     and os.environ.get("CFDBENCH_DP_ONE_GRAPH", "1") != "0")
         with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
-            self.forward_backward(*self._static, flags=self.defer_flags)
+            if self._graph_exchanges:
+                self._graph_scale = self.forward_backward_overlapped(*self._static)
+            else:
+                self.forward_backward(*self._static, flags=self.defer_flags)
         self._graph = g
 
     def train_step_graph(self, inputs: Tensor, label: Tensor, case_params: Tensor, mask: Optional[Tensor] = None) -> Tensor:
@@ -448,6 +478,6 @@ class FnoTrainEngine:
                 dst.copy_(src, non_blocking=True)
         self._graph.replay()
         self._last = (self._static[0], self._static[2], self._static[3], self.defer_flags)  # (the replayed pass used the static buffers)
-        scale = self.sync.all_reduce(self.flat.grad)
+        scale = self._graph_scale if self._graph_exchanges else self.sync.all_reduce(self.flat.grad)
         self.optimizer_step(scale)
         return self.sums

@@ -13,7 +13,11 @@ group of more than one rank the step is TWO graphs with the exchange between the
     graph A   forward + backward + one pack launch per 80 tensors: every parameter gradient, pre-scaled by 1 / world, into ONE flat buffer
     exchange  SUM all-reduce of that buffer (RCCL over xGMI; ``engine.FlatGradExchange``), enqueued eagerly between the replays
     graph B   optimizer.step() reading the reduced gradients through ``.grad`` views of the flat buffer
--- DistributedDataParallel semantics, no per-tensor copies, no host synchronisation.  Every rank must construct the object and call
+-- DistributedDataParallel semantics, no per-tensor copies, no host synchronisation.  Round 6: over RCCL (backend "nccl") the collective
+is CAPTURED with the rest (``one_graph``, the default there; CFDBENCH_DP_ONE_GRAPH=0 restores the two graphs): a step is ONE replay --
+forward, backward, pack, all-reduce on the communicator's stream (forked from and joined to the capture by events), optimizer -- and no
+host call per step touches the process group.  Host-staged backends (gloo: the CPU tests, two processes on one GPU) keep the two graphs.
+Every rank must construct the object and call
 it the same number of times (the warm-up steps exchange too, so that replicas which are not restored stay identical).
 ``capture=False`` runs the same three stages eagerly (batches of another shape; host tensors in the gloo tests of the logic)."""
 from __future__ import annotations
@@ -34,9 +38,15 @@ CAPTURE_MODE = "thread_local"
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, example_batch: Dict[str, Optional[Tensor]], loss_name: str = "nmse", warmup: int = 3,
-                 restore_state: bool = False, group=None, capture: bool = True):
+                 restore_state: bool = False, group=None, capture: bool = True, one_graph: Optional[bool] = None):
+        import os
         from .engine import GradSync
         self.model, self.optimizer, self.loss_name = model, optimizer, loss_name
+        sync = GradSync(group)
+        # the all-reduce inside the graph: only where the backend reduces device buffers on its own stream (RCCL)
+        self.one_graph = sync.device_native and os.environ.get("CFDBENCH_DP_ONE_GRAPH", "1") != "0" if one_graph is None else bool(one_graph)
+        if self.one_graph and not sync.device_native:
+            raise ValueError("GraphedTrainStep: one_graph needs a backend that reduces device buffers on its own stream (nccl)")
         self.static = {k: (v.clone() if v is not None else None) for k, v in example_batch.items()}
         self.shapes = {k: (tuple(v.shape) if v is not None else None) for k, v in example_batch.items()}
         # data parallel: the exchange object is made after the first backward pass, over the parameters that received a gradient
@@ -72,8 +82,14 @@ class GraphedTrainStep:
                 optimizer.step()
             else:
                 self.exchange.pack()
-        self._raw_grads = [p.grad for p in model.parameters()]
-        if self.exchange is not None:
+                if self.one_graph:  # the collective and the optimizer in the same capture
+                    self._raw_grads = [p.grad for p in model.parameters()]  # (the pack launch reads these on every replay)
+                    self.exchange.reduce()
+                    self.exchange.install()
+                    optimizer.step()
+        if not (self.exchange is not None and self.one_graph):
+            self._raw_grads = [p.grad for p in model.parameters()]
+        if self.exchange is not None and not self.one_graph:
             # the pack launch of graph A reads the gradient tensors autograd allocated during the capture (graph-private pool): they
             # must outlive the parameters' .grad, which from here on are views of the flat buffer
             self.exchange.reduce()  # (one eager exchange before the second capture: communicator warm-up on this stream)
@@ -125,7 +141,7 @@ class GraphedTrainStep:
             if dst is not None and v is not None and v.data_ptr() != dst.data_ptr():
                 dst.copy_(v, non_blocking=True)
         self.graph.replay()
-        if self.exchange is not None:
+        if self.graph_opt is not None:  # two-graph form: the exchange between the replays
             self.exchange.reduce()
             self.graph_opt.replay()
         return self.loss

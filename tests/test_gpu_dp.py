@@ -133,7 +133,7 @@ def _rccl_worker(port, overlap, graph, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap,graph", [(True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("overlap,graph", [(True, False), (False, False), (False, True), (True, True)])  # (True, True): the per-phase all-reduces captured in the graph (round 6)
 def test_engine_train_step_over_rccl_one_rank_group(overlap, graph):
     """The RCCL branch of GradSync itself (backend "nccl": asynchronous all-reduce of slices of the flat gradient on the
     communicator's stream, ordered by events, while later backward phases are still being enqueued) on the one GPU this box
@@ -155,6 +155,7 @@ def test_engine_train_step_over_rccl_one_rank_group(overlap, graph):
             proc.kill()
     assert proc.exitcode == 0
     eng = FnoTrainEngine(_make_model(torch), lr=1e-3, loss_name="nmse")
+    eng.defer_flags = 0  # (a data-parallel engine keeps the step's five own launches: bitwise the same kernels as this one)
     for step in range(STEPS):
         b = _batch(torch, step, 0, 1)
         eng.train_step(b["inputs"], b["label"], b["case_params"], b["mask"])
@@ -198,7 +199,10 @@ def _graph_dp_worker(rank, world, port, backend, name, q):
         m = _auto_model(torch, name)
         opt = _auto_optimizer(torch, m)
         gs = GraphedTrainStep(m, opt, _auto_batch(torch, 0, rank), "nmse", restore_state=True)
-        assert gs.dp and gs.exchange is not None and gs.graph_opt is not None
+        assert gs.dp and gs.exchange is not None
+        # round 6: over RCCL the all-reduce is captured with the rest (ONE graph per step); host-staged backends keep the two graphs
+        assert gs.one_graph == (backend == "nccl" and os.environ.get("CFDBENCH_DP_ONE_GRAPH", "1") != "0")
+        assert (gs.graph_opt is None) == gs.one_graph
         losses = [float(gs(**_auto_batch(torch, s, rank))["nmse"].item()) for s in range(STEPS)]
         losses.append(float(gs.eager_step(_auto_batch(torch, STEPS, rank))["nmse"].item()))  # a step outside the graphs exchanges too
         losses.append(float(gs(**_auto_batch(torch, STEPS + 1, rank))["nmse"].item()))      # ... and the graphs still replay after it
@@ -273,6 +277,65 @@ def test_graphed_train_step_over_rccl_one_rank_group():
     for got, ref in zip(params, want):
         assert np.allclose(got, ref, rtol=1e-5, atol=1e-7)
     assert len(set(losses)) == len(losses)
+
+
+def test_graphed_train_step_two_graphs_over_rccl_still_work(monkeypatch):
+    """CFDBENCH_DP_ONE_GRAPH=0: the round-5 form (graph A, eager all-reduce, graph B) stays selectable."""
+    import torch
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("CFDBENCH_DP_ONE_GRAPH", "0")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_graph_dp_worker, args=(0, 1, _free_port(), "nccl", "auto_deeponet", q))
+    proc.start()
+    try:
+        _, params, losses = q.get(timeout=300)
+    finally:
+        proc.join(timeout=120)
+        if proc.is_alive():
+            proc.kill()
+    assert proc.exitcode == 0
+    want = _graph_dp_reference(torch, "auto_deeponet", 1)
+    for got, ref in zip(params, want):
+        assert np.allclose(got, ref, rtol=1e-5, atol=1e-7)
+
+
+def _comm_probe_worker(port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from cfdbench_amd.harness.dist_util import comm_stream_overlaps, overlapping_comm_group
+        first = comm_stream_overlaps(None)
+        grp, ok = overlapping_comm_group(None)
+        t = torch.arange(8, dtype=torch.float32, device="cuda")
+        dist.all_reduce(t, group=grp)
+        torch.cuda.synchronize()
+        q.put((bool(first), bool(ok), t.cpu().tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_communicator_stream_is_probed_and_steered_onto_an_overlapping_queue():
+    """harness/dist_util.overlapping_comm_group: HIP deals streams onto four hardware queues and the communicator's stream is drawn from
+    the same pool -- one placement in four would serialise every gradient all-reduce behind the backward pass.  The probe times a small
+    all-reduce beside 2 ms of kernels; a group whose stream does not overlap is replaced by a fresh one (next pool entry) until one does."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_comm_probe_worker, args=(_free_port(), q))
+    proc.start()
+    try:
+        first, ok, vals = q.get(timeout=300)
+    finally:
+        proc.join(timeout=120)
+        if proc.is_alive():
+            proc.kill()
+    assert proc.exitcode == 0
+    assert ok, f"no overlapping communicator stream found (the first group's verdict was {first})"
+    assert vals == [float(i) for i in range(8)]
 
 
 def test_bench_only_leg_as_a_data_parallel_job_over_a_one_rank_rccl_group():
