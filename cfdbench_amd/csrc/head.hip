@@ -15,6 +15,11 @@
 #ifndef CFD_HEAD_FWD_BLOCKS
 #define CFD_HEAD_FWD_BLOCKS 1024  // 4 resident workgroups per CU (124 VGPRs)
 #endif
+#ifndef CFD_HEAD_EXP
+#define CFD_HEAD_EXP 0  // timing experiments on the one-pass training head (tools/build_variant.sh -DCFD_HEAD_EXP=..; results are WRONG):
+                        // 1 no mid-pair barrier, 2 no tile-end barriers, 4 trivial GELU terms, 8 no fc1 MFMAs, 16 no d/dh + gw1 MFMAs,
+                        // 32 one-piece split of gz, 64 no transposed gz stores
+#endif
 #ifndef CFD_HB_UNROLL
 #define CFD_HB_UNROLL 1  // phases of k_head_bwd's rolled loop per trip (experiments: tools/build_variant.sh)
 #endif
@@ -672,7 +677,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_head_bwd(
 #pragma unroll
             for (int k = 0; k < cfd_nterm_aa(AP); ++k)
 #pragma unroll
-                for (int t = 0; t < HT; ++t) z[t] = cfd_mfma16x16x32_bf16(w1f[t].p[cfd_term_aa_a(AP, k)], hp[cfd_term_aa_b(AP, k)], z[t]);
+                for (int t = 0; t < HT; ++t) {
+                    if constexpr (CFD_HEAD_EXP & 8) z[t][k & 3] += (float)hp[cfd_term_aa_b(AP, k)][t];
+                    else z[t] = cfd_mfma16x16x32_bf16(w1f[t].p[cfd_term_aa_a(AP, k)], hp[cfd_term_aa_b(AP, k)], z[t]);
+                }
         };
         auto back = [&](int j, const float (&gzv)[8]) {
             const CfdAct8<AP> gs = cfd_act_split8<AP>(gzv);
@@ -682,7 +690,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_head_bwd(
             for (int v = 0; v < 4 * HT; ++v) {
                 const int row = 16 * (v >> 2) + 4 * q + (v & 3);
 #pragma unroll
-                for (int pc = 0; pc < AP; ++pc) s_xw[pc * HPW * LDX + row * LDX + xcol] = gs.p[pc][v];
+                for (int pc = 0; pc < AP; ++pc)
+                    if (!(CFD_HEAD_EXP & 64) || (v == 0 && gzv[0] == 1.2345f)) s_xw[pc * HPW * LDX + row * LDX + xcol] = gs.p[pc][v];
             }
             // 4. partial d/dh[channel][pixel] = sum over this wave's hidden units w1[jh][channel] gz[jh][pixel]
             f32x4 ghc[MU];
@@ -691,7 +700,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_head_bwd(
 #pragma unroll
             for (int k = 0; k < cfd_nterm_aa(AP); ++k)
 #pragma unroll
-                for (int mu = 0; mu < MU; ++mu) ghc[mu] = cfd_mfma16x16x32_bf16(w1t[mu].p[cfd_term_aa_a(AP, k)], gs.p[cfd_term_aa_b(AP, k)], ghc[mu]);
+                for (int mu = 0; mu < MU; ++mu) {
+                    if constexpr (CFD_HEAD_EXP & 16) ghc[mu][k & 3] += (float)gs.p[cfd_term_aa_b(AP, k)][mu];
+                    else ghc[mu] = cfd_mfma16x16x32_bf16(w1t[mu].p[cfd_term_aa_a(AP, k)], gs.p[cfd_term_aa_b(AP, k)], ghc[mu]);
+                }
             // this wave's partial d/dh of the tile: [channel][64 pixels], pixel = 4n + phase
 #pragma unroll
             for (int mu = 0; mu < MU; ++mu)
@@ -721,8 +733,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_head_bwd(
 #pragma unroll
                     for (int t = 0; t < HT; ++t)
 #pragma unroll
-                        for (int mu = 0; mu < MU; ++mu)
-                            aw1[t][mu] = cfd_mfma16x16x32_bf16(ap[t][cfd_term_aa_a(AP, k)], bp[mu][cfd_term_aa_b(AP, k)], aw1[t][mu]);
+                        for (int mu = 0; mu < MU; ++mu) {
+                            if constexpr (CFD_HEAD_EXP & 16) aw1[t][mu][k & 3] += (float)ap[t][cfd_term_aa_a(AP, k)][mu] * (float)bp[mu][cfd_term_aa_b(AP, k)][t];
+                            else aw1[t][mu] = cfd_mfma16x16x32_bf16(ap[t][cfd_term_aa_a(AP, k)], bp[mu][cfd_term_aa_b(AP, k)], aw1[t][mu]);
+                        }
                 cfd_wave_lds_sync();
             }
         };
@@ -740,7 +754,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_head_bwd(
                     for (int v = 0; v < 2; ++v) {
                         const cfd_f2 zz = {z[t][2 * v], z[t][2 * v + 1]};
                         cfd_f2 Phi, e;
-                        cfd_gelu_terms2(zz, Phi, e);
+                        if constexpr (CFD_HEAD_EXP & 4) { Phi = zz; e = zz; } else cfd_gelu_terms2(zz, Phi, e);
                         a1k[t][v] = zz * Phi;
                         gdk[t][v] = cfd_fma2(zz * (cfd_f2)(CFD_INV_SQRT_2PI), e, Phi);
                         po0 = cfd_fma2(w2a[t][v], a1k[t][v], po0);
@@ -804,7 +818,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void k_head_bwd(
                     front(jp + 1, z);
                     fwd_half(jp + 1, slot1, z, a1k1, gdk1);
                 }
-                __syncthreads();
+                if (!(CFD_HEAD_EXP & 1)) __syncthreads();
                 {
                     float gzv[8];
                     bwd_half(jp, slot0, a1k0, gdk0, gzv);
@@ -865,7 +879,7 @@ CFD_UNROLL(CFD_HB_UNROLL)
                 }
             }
         }
-        __syncthreads();
+        if (!(CFD_HEAD_EXP & 2)) __syncthreads();
         // next tile's input planes (other buffer; its raw loads were issued one tile ago), then loads two tiles ahead
         stage(buf ^ (NBUF - 1));  // the other buffer -- or, single-buffered, the planes every wave has finished reading (barrier above)
         stage_gr(buf ^ (NBUF - 1));
@@ -916,7 +930,7 @@ CFD_UNROLL(CFD_HB_UNROLL)
         for (int k = 0; k < NST; ++k) gp_cur[k] = gp_next[k];
         t0 = t1;
         t1 = t2;
-        __syncthreads();
+        if (!(CFD_HEAD_EXP & 2)) __syncthreads();
     }
     // ---- this block's partial parameter gradients: [gw1 128*C | gb1 128 | gw2 Co*128 | gb2 Co] ----
     const int o_gb1 = HEAD_HD * C, o_gw2 = o_gb1 + HEAD_HD, o_gb2 = o_gw2 + Co * HEAD_HD;

@@ -346,9 +346,13 @@ def test_full_size_properties_b256(torch):
         # linearity, to the accuracy of the split-bf16 (3-term) inverse transform: ~2^-16 per product, nMSE ~1e-10
         # (the parity budget of BASELINE.json is 1e-5)
         assert lin.item() < 1e-9
-        # batch independence: the first 8 samples alone give the same rows
+        # batch independence: a sub-batch alone gives the same rows -- bit for bit while it takes the same mode-mixing kernel (round 6: from
+        # 128 entries the contraction runs as fmaf chains on the fp32 matrix pipe, modes.hip, below on the VALU kernels: both exact-fp32
+        # class, different summation order), to fp32 round-off across the two
+        f128 = F_.spectral_conv2d(x[:128].contiguous(), w1, w2)
+        assert torch.equal(f128, fx[:128])
         f8 = F_.spectral_conv2d(x[:8].contiguous(), w1, w2)
-        assert torch.equal(f8, fx[:8])
+        assert ((f8 - fx[:8]).pow(2).mean() / fx[:8].pow(2).mean()).item() < 1e-12
     # adjoint identity <f(x), y> == <x, f^T(y)> through the backward kernels
     xr = x.clone().requires_grad_(True)
     out = F_.spectral_conv2d(xr, w1, w2)
