@@ -610,6 +610,10 @@ extern "C" int cfd_conv2d_bwd_ex(const float* gout, const float* in, const float
     if (gin) {
         float* ext = (float*)ws;
         bool direct = false;
+        // side_stream bit 4 (round 6 experiment): the weight gradient on the library's side stream BESIDE the input gradient -- neither
+        // depends on the other, and on the deep U-Net levels (16 x 16 and below) neither fills the chip; forked BEFORE the input gradient
+        // is enqueued, joined in front of the fold launch that carries the weight gradient's partial-sum reduction
+        hipStream_t side = (gw && cfd_conv6_wgrad_covers(g)) ? cfd_side_fork(st, 4) : st;
         {
             CFD_PROF_W("k_conv_dgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci * ks * ks),
                        2.0 * B * HW * (double)Co * Ci * ks * ks);
@@ -630,10 +634,11 @@ extern "C" int cfd_conv2d_bwd_ex(const float* gout, const float* in, const float
             {
                 CFD_PROF_W("k_conv_wgrad", st, 4.0 * ((double)B * (Ci + Co) * HW + (double)Co * Ci * ks * ks),
                            2.0 * B * HW * (double)Co * Ci * ks * ks);
-                CFD_TRY(cfd_conv6_wgrad(gout, in, gw, gb, wws, g, st, "cfd_conv2d_bwd(wgrad)", &job));
+                CFD_TRY(cfd_conv6_wgrad(gout, in, gw, gb, wws, g, side, "cfd_conv2d_bwd(wgrad)", &job));
             }
             gw = nullptr, gb = nullptr;  // final once the fold launch below has run
         }
+        CFD_TRY(cfd_side_join(st, side));
         CFD_PROF_W("k_fold_pad", st, 0.0, 0.0);  // pure data movement of the extended-grid formulation: no algorithmic bytes
         if (direct) {
             const long total = (long)B * Ci * (2 * W + 2 * (H - 2));
