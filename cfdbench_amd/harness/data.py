@@ -78,7 +78,7 @@ class DeviceBatchLoader:
     ``collate_fn`` stacks the frames, rebuilds the case-parameter table from Python floats and copies four tensors to the
     GPU (src/train_auto.py:33-58) -- which tops out at a few thousand frames/s, two orders of magnitude below the
     training step.  Here the stacked frames ``data.inputs`` / ``data.labels`` (N, 3, h, w) and the per-frame parameter
-    table live on the device once; a batch is three ``index_select`` gathers with the epoch's permutation, and the
+    table live on the device once; a batch is four ``index_select`` gathers with the epoch's permutation, and the
     yielded dict is exactly ``collate_fn``'s: ``inputs`` = channels [:-1], ``mask`` = the last channel, ``label`` =
     channels [:-1] of the next frame, ``case_params`` = every case.json key except rotated / dx / dy, in key order.
 
@@ -89,8 +89,13 @@ class DeviceBatchLoader:
     def __init__(self, data, batch_size: int, shuffle: bool = True, drop_last: bool = False, device: str = "cuda",
                  indices=None, generator=None):
         self.batch_size, self.shuffle, self.drop_last, self.generator = int(batch_size), shuffle, drop_last, generator
-        self.inputs = data.inputs.to(device)
-        self.labels = data.labels.to(device)
+        # resident planes, split the way a batch is consumed: fields (N, c, h, w), mask (N, 1, h, w), next frame's fields (N, c, h, w).
+        # (Round 6: one gather per batch tensor and no `.contiguous()` of channel slices -- three copy launches less per batch; the labels'
+        # mask channel, which no consumer reads, is not kept.)
+        self.inputs = data.inputs[:, :-1].contiguous().to(device)
+        self.mask = data.inputs[:, -1:].contiguous().to(device)
+        self.labels = data.labels[:, :-1].contiguous().to(device)
+        self._bound = None
         keys = [k for k in data.case_params[0].keys() if k not in ("rotated", "dx", "dy")]
         table = torch.tensor([[float(cp[k]) for k in keys] for cp in data.case_params], dtype=torch.float32)
         self.case_params = table[torch.as_tensor(data.case_ids, dtype=torch.long)].to(device)
@@ -113,10 +118,27 @@ class DeviceBatchLoader:
         order = order.to(self.inputs.device)
         for k in range(len(self)):
             idx = order[k * self.batch_size:(k + 1) * self.batch_size]
-            x = self.inputs.index_select(0, idx)
-            y = self.labels.index_select(0, idx)
-            yield dict(inputs=x[:, :-1].contiguous(), label=y[:, :-1].contiguous(), mask=x[:, -1:].contiguous(),
-                       case_params=self.case_params.index_select(0, idx))
+            src = dict(inputs=self.inputs, label=self.labels, mask=self.mask, case_params=self.case_params)
+            out = self._bound
+            if out is not None and len(idx) == out["inputs"].shape[0]:
+                # gathered STRAIGHT into the buffers a captured training step reads (graph.GraphedTrainStep.static): the step then finds
+                # its own tensors in the batch and copies nothing (four device-to-device copies per step before)
+                for name, t in src.items():
+                    torch.index_select(t, 0, idx, out=out[name])
+                yield dict(out)
+            else:
+                yield {name: t.index_select(0, idx) for name, t in src.items()}
+
+    def bind(self, buffers) -> None:
+        """Gather every full-size batch into ``buffers`` (a dict with inputs / label / mask / case_params tensors of one batch's shapes and
+        this loader's device, e.g. ``GraphedTrainStep.static``) instead of fresh tensors; ``None`` unbinds.  The yielded dict then holds
+        those very tensors -- valid until the next batch is drawn."""
+        if buffers is not None:
+            for name, ref in dict(inputs=self.inputs, label=self.labels, mask=self.mask, case_params=self.case_params).items():
+                b = buffers.get(name)
+                if b is None or b.shape[1:] != ref.shape[1:] or b.dtype != ref.dtype or b.device != ref.device or not b.is_contiguous():
+                    raise ValueError(f"DeviceBatchLoader.bind: buffer '{name}' does not match the resident tensor")
+        self._bound = buffers
 
 
 def overlapping_copy_stream(device=None, tries: int = 8, work_passes: int = 40):

@@ -299,6 +299,8 @@ def train(model: AutoCfdModel, train_data, dev_data, output_dir: Path, num_epoch
                 from ..graph import GraphedTrainStep
                 if graphed is None and step + 1 < n_steps:  # capture on a full-size batch (never on a short last one)
                     graphed = GraphedTrainStep(model, optimizer, batch, "nmse", restore_state=True)
+                    if hasattr(train_loader, "bind"):  # the resident loader gathers the next batches straight into the step's buffers
+                        train_loader.bind(graphed.static)
                 if graphed is not None and graphed.matches(batch):
                     loss = graphed(**batch)
                     preds = graphed.preds

@@ -158,6 +158,26 @@ def test_device_batch_loader_equals_dataloader_plus_collate():
     assert torch.equal(seen, again)  # the permutation comes from the host generator: reproducible / resumable
 
 
+def test_device_batch_loader_gathers_into_bound_buffers():
+    """DeviceBatchLoader.bind (round 6): full-size batches are gathered straight into the buffers of a captured training step
+    (GraphedTrainStep.static) -- the yielded tensors ARE those buffers, with the same values an unbound loader yields; a short last batch
+    comes as fresh tensors."""
+    from cfdbench_amd.harness.data import DeviceBatchLoader
+    ds = SyntheticAutoDataset(n_cases=3, n_frames=5, height=8, width=9, seed=4, border_mask=True)  # 12 frames: batches of 5, 5, 2
+    plain = list(DeviceBatchLoader(ds, 5, shuffle=False, device="cpu"))
+    ld = DeviceBatchLoader(ds, 5, shuffle=False, device="cpu")
+    static = {k: torch.full_like(v, -1.0) for k, v in plain[0].items()}
+    ld.bind(static)
+    for i, b in enumerate(ld):
+        for k in b:
+            assert torch.equal(b[k], plain[i][k]), (i, k)
+            assert (b[k].data_ptr() == static[k].data_ptr()) == (i < 2), (i, k)  # the short last batch is not the bound buffer
+    with pytest.raises(ValueError):
+        ld.bind({k: v[:, :0] if v.dim() > 1 else v for k, v in static.items()})
+    ld.bind(None)
+    assert next(iter(ld))["inputs"].data_ptr() != static["inputs"].data_ptr()
+
+
 def test_lr_schedules_follow_torch_and_early_stopping():
     """harness/schedule.py: the fused engine's shadow-optimizer schedule == the torch scheduler on a real optimizer."""
     import torch
