@@ -223,7 +223,7 @@ int cfd_int_fno_head_train_f(const void* a, const float* mask, const float* labe
                              float* gw1, float* gb1, float* gw2, float* gb2, void* ws, int B, int C, int Hd, int Co, int HW, int act_in,
                              int dt, void* stream, HeadTail* defer);
 HeadTail cfd_int_head_tail(const void* ws, float* gw1, float* gb1, float* gw2, float* gb2, float* sums, int B, int C, int Co, int HW, float count);
-bool cfd_int_block_bwd_fused(const cfd_plan* p, int C, const void* g, const void* gin, const void* aprev, const void* gz);
+bool cfd_int_block_bwd_fused(const cfd_plan* p, int B, int C, const void* g, const void* gin, const void* aprev, const void* gz);
 bool cfd_int_stemg_ok(const cfd_plan* p, int B, int C, int in_chan, int P, const void* inputs, const void* mask, const void* z);
 size_t cfd_int_stemg_part_bytes(const cfd_plan* p, int B, int C);
 int cfd_int_stemg_splits(const cfd_plan* p, int B);

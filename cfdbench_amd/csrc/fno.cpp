@@ -90,7 +90,7 @@ Deferred deferred(const cfd_plan* p, const cfd_fno_shape* s, const Layout& L, ch
     const float* z = (const float*)(base + L.off_z);
     // backward phase 1 = FnoBlock NL-1: gcur = gA, gnext = gB, aprev = a_{NL-1} when NL > 1
     const void* aprev = NL > 1 ? (const void*)(base + L.off_acts + (size_t)(NL - 1) * L.n_act * cfd_dt_size(dt)) : nullptr;
-    d.head = (flags & CFD_TRAIN_DEFER_HEAD) && dt == CFD_DT_F32 && NL >= 1 && cfd_int_block_bwd_fused(p, C, gA, gB, aprev, z);
+    d.head = (flags & CFD_TRAIN_DEFER_HEAD) && dt == CFD_DT_F32 && NL >= 1 && cfd_int_block_bwd_fused(p, B, C, gA, gB, aprev, z);
     d.stem = (flags & CFD_TRAIN_DEFER_STEM) && dt == CFD_DT_F32 && NL >= 1 &&
              cfd_int_stemg_ok(p, B, C, s->in_chan, s->n_case_params, inputs, mask, z);
     return d;

@@ -1961,7 +1961,12 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
     static_assert(!STEMG || (TRANS && !DGELU && !ACT), "the lifting-layer sums ride in the plain input-gradient kernel");
     constexpr int W = 64, NJ = 4;
     constexpr int WS = DPW <= 4 ? 4 : 8;              // floats per weight-table entry
-    __shared__ float4 s_src[2 * NW * 16 * 16];        // [buf][channel in chunk][row][float4 column]
+    // SBUF (round 6, the (8,4,4) shape = 25 .. 32 channels in ONE workgroup per entry): a single source-chunk buffer -- the
+    // second one is what pushed this shape to 168 KB of LDS; the price is a second workgroup barrier per chunk (all waves done with
+    // the chunk before the next one is committed), the prefetch two chunks ahead in registers stays
+    constexpr bool SBUF = NW == 8 && DPW == 4 && NCH == 4;
+    constexpr int NBUF = SBUF ? 1 : 2;
+    __shared__ float4 s_src[NBUF * NW * 16 * 16];     // [buf][channel in chunk][row][float4 column]
     __shared__ bf16x8 s_tab3[CFD_B3_TABV];            // split-bf16 inverse tables: ta3 of every tile (T <= 4) | tb3
     __shared__ float s_z[NW * DPW * CFD_KB_ZS];      // kept modes of this wave's destination channels
     if (TAIL && (int)blockIdx.x < tail.nblk) {
@@ -1969,7 +1974,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
         return;
     }
     __shared__ float4 s_w[NW * NW * NCH * (WS / 4)];  // [wave][source channel] -> weights of the wave's DPW channels
-    __shared__ float s_tail[GEN ? 2 * NW * 16 * 4 : 4];  // GEN: [buf][channel in chunk][row][tail column e] source values
+    __shared__ float s_tail[GEN ? NBUF * NW * 16 * 4 : 4];  // GEN: [buf][channel in chunk][row][tail column e] source values
     __shared__ float s_tw[GEN ? 4 * 32 : 4];             // GEN: stage-B factors of the tail columns (plan.d_tail)
     static_assert(NW * NCH <= 64, "one lane per source channel fills the weight table");
     static_assert(DPW <= 8, "weight-table entry holds at most 8 destination channels");
@@ -2165,7 +2170,9 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
         for (int c = 0; c < NCH; ++c) {
             const int g = tl * NCH + c;
             const int par = (PAR + c) & 1;
-            commit(c, par, R[par], RT[par]);
+            const int lb = SBUF ? 0 : par;  // LDS buffer of this chunk
+            if constexpr (SBUF) __syncthreads();  // every wave is done with the previous chunk
+            commit(c, lb, R[par], RT[par]);
             __syncthreads();  // chunk g visible (first pass: also tables, weights); the other buffer is free again
             if (g + 2 < G) fetch(g + 2, R[par], RT[par]);
             if constexpr (DGELU) {
@@ -2202,7 +2209,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                 float4 v[2][4], wq[2][WS / 4];
                 auto lds_fetch = [&](int sl, float4 (&vv)[4], float4 (&ww)[WS / 4]) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) vv[r] = s_src[((par * NW + sl) * 16 + 4 * q + r) * 16 + n];
+                    for (int r = 0; r < 4; ++r) vv[r] = s_src[((lb * NW + sl) * 16 + 4 * q + r) * 16 + n];
 #pragma unroll
                     for (int h = 0; h < WS / 4; ++h) ww[h] = s_w[(wave * (NW * NCH) + c * NW + sl) * (WS / 4) + h];
                 };
@@ -2227,7 +2234,7 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
                         }
                     }
                     if constexpr (GEN) {  // tail column e = q of row 16t + n, source channel sl of this chunk
-                        const float tv = s_tail[((par * NW + sl) * 16 + n) * 4 + q];
+                        const float tv = s_tail[((lb * NW + sl) * 16 + n) * 4 + q];
 #pragma unroll
                         for (int dd = 0; dd < DPW; ++dd) tacc[dd] = fmaf(wd[dd], tv, tacc[dd]);
                     }
@@ -2326,17 +2333,25 @@ __global__ __launch_bounds__(64 * NW) void k_block(const float* __restrict__ src
 }
 
 static bool block_is_gen(const cfd_plan* p) { return p->W != 64 || p->H % 16 != 0; }  // pitch != 64 or a ragged last row tile
-static bool block_fused_ok(const cfd_plan* p, int Cs, int Cd, const void* a, const void* b, const void* c, const void* z) {
+// B = batch entries, bwd = the input-gradient direction (c != NULL: with gelu')
+static bool block_fused_ok(const cfd_plan* p, int Cs, int Cd, const void* a, const void* b, const void* c, const void* z, int B, bool bwd) {
     const int cmax = Cs > Cd ? Cs : Cd;
     if (cfd_tune_get(CFD_TUNE_EXACT_FP32) == 1 || !p->d_inv_b3 || p->T > CFD_KB_TMAX) return false;  // (the fused kernel's inverse transform is split-bf16)
     if (4 * p->m1 * p->m2 + 1 > CFD_BLK_ZS || cmax > 32 || ((uintptr_t)z % 16) != 0) return false;
-    // 25 .. 32 channels (two workgroups per entry, see launch_block): measured at B = 256 / width 32 (profiles/r05b_block_c32.txt) the
-    // split kernel re-reads every source value from LDS twice as often per output as the (8,4,4) shape would and only beats the two
-    // passes where they are slowest -- the input gradient with gelu' on the general grids (66 x 65: 157 us against 84 + 101); forward
-    // (146 against 86 + 59) and the 64-wide grids (123 against 46 + 76) stay on the two passes.  "block_wide" = 1 forces it everywhere.
+    // 25 .. 32 channels (the reference's default width 32).  Round 5: two (8,2,4) workgroups per entry re-read every source value from
+    // LDS twice as often per output as one workgroup would and only beat the two passes for the gelu' input gradient on the general
+    // grids.  Round 6: ONE (8,4,4) workgroup per entry with a SINGLE source-chunk buffer (138 KB instead of 168; k_block: SBUF) -- measured
+    // against the two passes (kbench, us, width 32; fwd+gelu / input gradient / input gradient with gelu'):
+    //   64 x 64   B = 256: 110 / 88 / 107 against 106 / 102 / 128     B = 64: 31 / 28 / 31 against 37 / 32 / 40
+    //   66 x 65   B = 256: 139 / 109 / 162 against 146 / 143 / 174    B = 64: 50 / 43 / 58 against 44 / 41 / 49
+    // and inside the train step (HBM-cold) the fused forward wins at B = 256 too: width-32 step at 64 x 64 2.20 ms on two passes, 2.07 with
+    // only the backward fused, 1.98 with both.  So: 64-wide grids always, general grids from 128 entries (a 64-case rollout step at 66 x 65:
+    // 357 us on two passes, 374 fused).  "block_wide": 0 = never, 1 = the round-5 pair of workgroups everywhere, 2 = the single one everywhere.
     if (cmax > 24) {
         const int wide = cfd_tune_get(CFD_TUNE_BLOCK_WIDE);
-        if (wide == 0 || (wide != 1 && !(c && block_is_gen(p)))) return false;
+        if (wide == 0) return false;
+        if (wide != 1 && wide != 2 && block_is_gen(p) && B < 128) return false;
+        (void)bwd;
     }
     if (block_is_gen(p))  // round 4: 64 <= W <= 68 (d_inv_b3 exists), any H <= 80; 4-byte aligned planes (round 5: both piece counts)
         return cfd_tune_get(CFD_TUNE_BLOCK_GEN) != 0 && p->d_tail;
@@ -2424,7 +2439,9 @@ static bool launch_block(const cfd_plan* p, const float* src, const float* z, co
     // 25 .. 32 channels (round 5; the reference's default width 32, src/args.py:190): with the tables in three pieces (CFD_TW) an
     // (8,4,4) workgroup would need 168 KB of LDS (source chunks 64 + modes 74 + tables 24 + weights 4), so the entry's destination
     // channels are dealt to TWO (8,2,4) workgroups of 16 channels (modes 37 KB: 133 KB), each streaming all the source channels.
-    else return launch_block_cfg<8, 2, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
+    // round 6: ONE (8,4,4) workgroup per entry with a single source-chunk buffer (138 KB); block_wide = 1: the round-5 pair
+    else if (cfd_tune_get(CFD_TUNE_BLOCK_WIDE) == 1) return launch_block_cfg<8, 2, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
+    else return launch_block_cfg<8, 4, 4>(p, src, z, w, bias, aprev, dst, B, Cs, Cd, act, trans, dgelu, st, tail);
 }
 
 // out[b,o] = bias[o] + sum_i w0[o,i] f(a[b,i]) + idft(z[b,o])                       (FnoBlock.forward minus its GELU)
@@ -2435,7 +2452,7 @@ extern "C" int cfd_fno_block_fwd(const cfd_plan* p, const float* a, const float*
                 "cfd_fno_block_fwd: channels (%d -> %d) unsupported (1..32)", Cin, Cout);
     if (B == 0) return CFD_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (!block_fused_ok(p, Cin, Cout, a, out, nullptr, z)) {  // general grids: two passes
+    if (!block_fused_ok(p, Cin, Cout, a, out, nullptr, z, B, false)) {  // general grids: two passes
         CFD_TRY(cfd_chanmix(a, w0, b0, out, B, Cin, Cout, p->H * p->W, act_in, 0, stream));
         return cfd_spectral_idft(p, z, out, nullptr, out, B * Cout, 1, stream);
     }
@@ -2475,8 +2492,8 @@ static int launch_reduce_tail_standalone(const CfdReduceTail* tail, hipStream_t 
 }
 
 // whether cfd_int_fno_block_bwd_input will run the fused kernel (the one that carries tail jobs) for this plan / width / buffers
-bool cfd_int_block_bwd_fused(const cfd_plan* p, int C, const void* g, const void* gin, const void* aprev, const void* gz) {
-    return block_fused_ok(p, C, C, g, gin, aprev, gz);
+bool cfd_int_block_bwd_fused(const cfd_plan* p, int B, int C, const void* g, const void* gin, const void* aprev, const void* gz) {
+    return block_fused_ok(p, C, C, g, gin, aprev, gz, B, true);
 }
 
 // ---- lifting-layer gradient from the sums of k_block<.., STEMG> (cfd_tail.h: CfdStemG) ------------------------------------------
@@ -2525,7 +2542,7 @@ int cfd_int_fno_block_bwd_input(const cfd_plan* p, const float* g, const float* 
                 "cfd_fno_block_bwd_input: channels (%d -> %d) unsupported (1..32)", Cin, Cout);
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) return launch_reduce_tail_standalone(tail, st);
-    if (!block_fused_ok(p, Cout, Cin, g, gin, aprev, gz)) {
+    if (!block_fused_ok(p, Cout, Cin, g, gin, aprev, gz, B, true)) {
         CFD_REQUIRE(!(stemg && stemg->inputs), CFD_ERR_UNSUPPORTED, "cfd_fno_block_bwd_input: the lifting-layer sums need the fused kernel (cfd_int_stemg_ok)");
         CFD_TRY(launch_reduce_tail_standalone(tail, st));
         CFD_TRY(cfd_chanmix(g, w0, nullptr, gin, B, Cout, Cin, p->H * p->W, 0, 1, stream));

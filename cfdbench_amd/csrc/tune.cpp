@@ -40,8 +40,9 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
     {CFD_TUNE_GEMM_TILE, "gemm_tile", "CFD_GEMM_TILE", {-1}},        // block tile of the fp32 GEMM (dense.hip): 128 = 128 x 128, 1 = 128 rows x all columns, 8 = 128 x 64 on eight waves;
                                                  // default 64 x 64 (the fastest on every product of the benchmark)
     {CFD_TUNE_GEMM_SPLITS, "gemm_splits", "CFD_GEMM_SPLITS", {-1}},    // > 0: forced split-K count of every fp32 GEMM that takes a workspace (timing sweeps: tools/exp/gemm_shapes.py)
-    {CFD_TUNE_BLOCK_WIDE, "block_wide", "CFD_BLOCK_WIDE", {-1}},      // fused FnoBlock at 25 .. 32 channels (two workgroups per entry): 1 = wherever the shape allows (tests),
-                                                 // 0 = never; default: only the gelu' input gradient on the general grids, where it beats the two passes
+    {CFD_TUNE_BLOCK_WIDE, "block_wide", "CFD_BLOCK_WIDE", {-1}},      // fused FnoBlock at 25 .. 32 channels: 0 = never (two passes), 1 = the round-5 pair of (8,2,4) workgroups per entry wherever
+                                                 // the shape allows, 2 = the round-6 single (8,4,4) workgroup (one source-chunk buffer) wherever the shape allows; default: the
+                                                 // single workgroup where it beats the two passes (64-wide grids always; general grids from 128 entries)
     {CFD_TUNE_HEAD_WAVES, "head_waves", "CFD_HEAD_WAVES", {-1}},      // waves per workgroup of the one-pass training head (k_head_bwd<.., NWV>): 4 or 8; default: 8 at 21 .. 32 channels, else 4
     {CFD_TUNE_STEM_FUSE, "stem_fuse", "CFD_STEM_FUSE", {-1}},        // 0 = the lifting layer's gradient as its own pass over a stored g_0 (k_chan_wgrad_stem) instead of sums emitted by FnoBlock 0's input-gradient kernel; 3 = the sums on the general grids (66 x 65) too (slower there: off by default)
     {CFD_TUNE_MODE_MFMA, "mode_mfma", "CFD_MODE_MFMA", {-1}},        // mode mixing / adjoint / spectral weight gradient on the fp32 matrix pipe (modes.hip, round 6): 0 = never (the batch-in-lanes

@@ -458,22 +458,26 @@ def test_two_piece_activation_route_still_holds_its_tolerance(be):
         _assert_all(res, 1e-9)
 
 
+@pytest.mark.parametrize("wide", [1, 2])
 @pytest.mark.parametrize("H,W", [(64, 64), (66, 65)])
 @pytest.mark.parametrize("Ci,Co", [(32, 32), (28, 25), (32, 20), (20, 32)])
-def test_fused_block_for_25_to_32_channels(be, H, W, Ci, Co):
-    """Round 5: the fused FnoBlock kernel at the reference's default width 32 (src/args.py:190) -- the destination channels of an
-    entry are dealt to two workgroups of 16 (k_block: ND = 2), both directions, both piece counts; B = 3 leaves padding workgroups in
-    the grid of 8 * ND block groups."""
-    with K.tuned(be, block_wide=1):  # (by default only the gelu' input gradient of the general grids takes the fused kernel at these widths)
+def test_fused_block_for_25_to_32_channels(be, H, W, Ci, Co, wide):
+    """The fused FnoBlock kernel at the reference's default width 32 (src/args.py:190), both directions, both piece counts.  block_wide = 1
+    (round 5): the destination channels of an entry dealt to two workgroups of 16 (k_block: ND = 2; B = 3 leaves padding workgroups in the
+    grid of 8 * ND block groups).  block_wide = 2 (round 6): ONE (8,4,4) workgroup per entry with a single source-chunk buffer -- the
+    default where it beats the two passes."""
+    with K.tuned(be, block_wide=wide):
         _assert_all(K.check_block(be, 3, Ci, Co, H, W), EXACT_TOL)
         with K.tuned(be, act_pieces=2):
             _assert_all(K.check_block(be, 1, Ci, Co, H, W), 1e-9)
     _assert_all(K.check_block(be, 2, Ci, Co, H, W), EXACT_TOL)  # the default dispatch
 
 
-def test_fused_block_width_32_batch_split_is_bitwise(be):
-    """Width 32: a sample's result does not depend on the batch it sits in (entries split by row tiles AND by destination group)."""
-    with K.tuned(be, block_wide=1):
+@pytest.mark.parametrize("wide", [1, 2])
+def test_fused_block_width_32_batch_split_is_bitwise(be, wide):
+    """Width 32: a sample's result does not depend on the batch it sits in (entries split by row tiles AND, with block_wide = 1, by
+    destination group) -- as long as the same kernel runs: the DEFAULT dispatch picks by batch size (block_fused_ok)."""
+    with K.tuned(be, block_wide=wide):
         res = K.check_block_batch_split(be, 5, 2, 32, 64, 64)
     assert res["fwd_bitwise"] == 0.0 and res["bwd_bitwise"] == 0.0, res
 
