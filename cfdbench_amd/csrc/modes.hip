@@ -24,22 +24,22 @@
 #define CFD_MM_T 8    // modes per tile = waves per workgroup
 #define CFD_MM_CP 18  // floats of one (entry, channel) piece in LDS: 16 data + 2 pad
 
-static inline int cfd_mm_rmax(bool wgrad) { return wgrad ? 40 : 32; }  // LDS rows (batch entries) of one chunk
 template <int C>
 static constexpr int cfd_mm_bp() { return C * CFD_MM_CP + 4; }  // row pitch in floats
+// RMAX = LDS rows (batch entries) of one chunk: 32 for the mix alone at 20 channels (72 KB: two workgroups per CU), 40 with the weight
+// gradient (142 KB), 37 for the mix alone at 32 channels (156 KB: 256 / 7 entries per chunk = 252 workgroups, one per CU)
 template <int C>
-static size_t cfd_mm_lds_bytes(bool wgrad) {
-    return ((size_t)(wgrad ? 2 : 1) * cfd_mm_rmax(wgrad) * cfd_mm_bp<C>() + (size_t)C * C * CFD_MM_CP) * sizeof(float);
+static size_t cfd_mm_lds_bytes(bool wgrad, int rmax) {
+    return ((size_t)(wgrad ? 2 : 1) * rmax * cfd_mm_bp<C>() + (size_t)C * C * CFD_MM_CP) * sizeof(float);
 }
 
 // xin: the contracted operand of the mix (forward: xh, adjoint: gh); xw (WGRAD): xh, the conjugated side of the weight gradient.
-template <int C, bool CONJT, bool WGRAD, int NST>
+template <int C, bool CONJT, bool WGRAD, int NST, int RMAX>
 __global__ __launch_bounds__(512) void k_modes_mfma(const float* __restrict__ xin, const float* __restrict__ xw,
                                                     const float* __restrict__ w1, const float* __restrict__ w2,
                                                     float* __restrict__ z, float* __restrict__ part, int B, int BC, int M, int half,
                                                     int ntile, int npair, int nchunk) {
     constexpr int BP = cfd_mm_bp<C>(), CP = CFD_MM_CP;
-    constexpr int RMAX = WGRAD ? 40 : 32;
     constexpr int NT = (2 * C + 15) / 16;              // 16-wide tiles of the (channel, re/im) index
     constexpr int KS = C / 2;                          // K = 2C in steps of 4
     constexpr int SF4 = 16 * 4 * C;                    // 16-byte vectors of one stage of one operand
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(512) void k_modes_mfma(const float* __restrict__ xi
     constexpr int NWL = (WF4 + 511) / 512;
     static_assert(C % 4 == 0, "k_modes_mfma: channels in K-steps of four");
     static_assert(16 * NST >= RMAX, "k_modes_mfma: stages cover the LDS rows");
+    static_assert(!WGRAD || RMAX % 4 == 0, "k_modes_mfma: the weight gradient walks the rows in K-steps of four");
     CFD_DYN_SHARED(f32x4, smem4);  // (declared in 16-byte units: the weight rows move as whole vectors)
     float* smem = reinterpret_cast<float*>(smem4);
     float* GS = smem;                                  // rows of the mix operand (results written back in place)
@@ -253,14 +254,13 @@ __global__ __launch_bounds__(512) void k_modes_mfma(const float* __restrict__ xi
     }
 }
 
-// Chunk geometry.  Forward / adjoint alone: 32 entries per chunk (two stages, 72 KB of LDS: two workgroups per CU).  With the weight
-// gradient: about one workgroup per CU (142 KB of LDS) and at most 40 entries per chunk.  The mode_bc knob overrides the rows.
-static void cfd_mm_geometry(int B, int ntile, bool wgrad, int* BC, int* nchunk) {
-    const int rmax = cfd_mm_rmax(wgrad);
+// Chunk geometry.  rmax = LDS rows of the instantiation; spread = aim at about one workgroup per CU (the shapes whose LDS allows only
+// one: with the weight gradient, or 32 channels) instead of filling the rows.  The mode_bc knob overrides the rows.
+static void cfd_mm_geometry(int B, int ntile, int rmax, bool spread, int* BC, int* nchunk) {
     int bc;
     const int knob = cfd_tune_get(CFD_TUNE_MODE_BC);
     if (knob >= 1) bc = knob < rmax ? knob : rmax;
-    else if (!wgrad) bc = rmax;
+    else if (!spread) bc = rmax;
     else {
         int want = 256 / ntile;
         if (want < 1) want = 1;
@@ -272,11 +272,13 @@ static void cfd_mm_geometry(int B, int ntile, bool wgrad, int* BC, int* nchunk) 
     *nchunk = (B + bc - 1) / bc;
 }
 
-bool cfd_int_modes_mfma_ok(const cfd_plan* p, int B, int Cin, int Cout, const void* a, const void* b, const void* c) {
+bool cfd_int_modes_mfma_ok(const cfd_plan* p, int B, int Cin, int Cout, const void* a, const void* b, const void* c, bool wgrad) {
     const int knob = cfd_tune_get(CFD_TUNE_MODE_MFMA);
     if (knob == 0) return false;
     const int M = 2 * p->m1 * p->m2, half = p->m1 * p->m2;
-    if (Cin != Cout || Cin != 20) return false;            // the channel count is a template parameter
+    // the channel count is a template parameter: 20 (mix, adjoint, weight gradient) and 32 (mix / adjoint alone: two 32-channel operand
+    // chunks plus the weights do not fit the LDS beside each other, the weight gradient stays on the VALU kernel there)
+    if (Cin != Cout || !(Cin == 20 || (Cin == 32 && !wgrad))) return false;
     if (half % CFD_MM_T != 0) return false;                  // a tile never straddles weights1 / weights2
     if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) % 16) return false;
     (void)M;
@@ -287,22 +289,22 @@ bool cfd_int_modes_mfma_ok(const cfd_plan* p, int B, int Cin, int Cout, const vo
 size_t cfd_int_modes_mfma_chunks(const cfd_plan* p, int B) {  // partial-sum chunks the weight gradient may write
     if ((p->m1 * p->m2) % CFD_MM_T != 0 || B < 1) return 0;    // (never dispatched for such plans: cfd_int_modes_mfma_ok)
     int BC, nchunk;
-    cfd_mm_geometry(B, p->m1 * p->m2 * 2 / CFD_MM_T, true, &BC, &nchunk);
+    cfd_mm_geometry(B, p->m1 * p->m2 * 2 / CFD_MM_T, 40, true, &BC, &nchunk);
     return (size_t)nchunk;
 }
 
-template <int C, bool CONJT, bool WGRAD, int NST>
+template <int C, bool CONJT, bool WGRAD, int NST, int RMAX>
 static int mm_launch(const float* xin, const float* xw, const float* w1, const float* w2, float* z, float* part, int B, int BC,
                      int nchunk, int M, int half, hipStream_t st) {
     const int ntile = M / CFD_MM_T, npair = (ntile + 1) / 2;
     const unsigned grid = (unsigned)((npair * nchunk + 7) / 8) * 16u;
-    const size_t lds = cfd_mm_lds_bytes<C>(WGRAD);
+    const size_t lds = cfd_mm_lds_bytes<C>(WGRAD, RMAX);
     static bool attr_set = false;  // > 64 KB of dynamic LDS needs the attribute once per kernel
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_modes_mfma<C, CONJT, WGRAD, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_modes_mfma<C, CONJT, WGRAD, NST, RMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_modes_mfma<C, CONJT, WGRAD, NST>), dim3(grid), dim3(512), lds, st, xin, xw, w1, w2, z, part, B, BC, M, half,
+    hipLaunchKernelGGL((k_modes_mfma<C, CONJT, WGRAD, NST, RMAX>), dim3(grid), dim3(512), lds, st, xin, xw, w1, w2, z, part, B, BC, M, half,
                        ntile, npair, nchunk);
     return CFD_OK;
 }
@@ -312,11 +314,16 @@ int cfd_int_modes_mix(const cfd_plan* p, const float* xin, const float* w1, cons
                       void* stream) {
     const int M = 2 * p->m1 * p->m2, half = p->m1 * p->m2;
     int BC, nchunk;
-    cfd_mm_geometry(B, M / CFD_MM_T, false, &BC, &nchunk);
     hipStream_t st = (hipStream_t)stream;
-    (void)C;
-    if (conj_t) mm_launch<20, true, false, 2>(xin, nullptr, w1, w2, z, nullptr, B, BC, nchunk, M, half, st);
-    else mm_launch<20, false, false, 2>(xin, nullptr, w1, w2, z, nullptr, B, BC, nchunk, M, half, st);
+    if (C == 32) {
+        cfd_mm_geometry(B, M / CFD_MM_T, 37, true, &BC, &nchunk);
+        if (conj_t) mm_launch<32, true, false, 3, 37>(xin, nullptr, w1, w2, z, nullptr, B, BC, nchunk, M, half, st);
+        else mm_launch<32, false, false, 3, 37>(xin, nullptr, w1, w2, z, nullptr, B, BC, nchunk, M, half, st);
+    } else {
+        cfd_mm_geometry(B, M / CFD_MM_T, 32, false, &BC, &nchunk);
+        if (conj_t) mm_launch<20, true, false, 2, 32>(xin, nullptr, w1, w2, z, nullptr, B, BC, nchunk, M, half, st);
+        else mm_launch<20, false, false, 2, 32>(xin, nullptr, w1, w2, z, nullptr, B, BC, nchunk, M, half, st);
+    }
     CFD_LAUNCH_CHECK("cfd_spectral_mix(mfma)");
     return CFD_OK;
 }
@@ -326,9 +333,9 @@ int cfd_int_modes_mixadj_wgrad(const cfd_plan* p, const float* xh, const float* 
                                float* part, int B, int C, int* nchunk_out, void* stream) {
     const int M = 2 * p->m1 * p->m2, half = p->m1 * p->m2;
     int BC, nchunk;
-    cfd_mm_geometry(B, M / CFD_MM_T, true, &BC, &nchunk);
+    cfd_mm_geometry(B, M / CFD_MM_T, 40, true, &BC, &nchunk);
     (void)C;
-    mm_launch<20, true, true, 3>(gh, xh, w1, w2, gz, part, B, BC, nchunk, M, half, (hipStream_t)stream);
+    mm_launch<20, true, true, 3, 40>(gh, xh, w1, w2, gz, part, B, BC, nchunk, M, half, (hipStream_t)stream);
     CFD_LAUNCH_CHECK("cfd_spectral_mix_adj_wgrad(mfma)");
     *nchunk_out = nchunk;
     return CFD_OK;

@@ -643,9 +643,9 @@ extern "C" int cfd_spectral_dft(const cfd_plan* p, const float* x, float* xh, in
 // owns one channel of the NON-contracted side and keeps its CR complex weights (mix) or CR complex accumulators
 // (weight gradient) in registers for a whole chunk of the batch.  The contracted-side modes of SB batch entries
 // are staged once per workgroup in LDS (double buffered, next stage prefetched into registers during the math).
-// Round 6: at 20 channels and >= 128 batch entries the three contractions run on the fp32 matrix pipe (modes.hip); the kernels below
+// Round 6: at 20 channels (at 32: the mix alone) and >= 128 batch entries the contractions run on the fp32 matrix pipe (modes.hip); the kernels below
 // remain for the other widths, small batches and as the mode_mfma = 0 route of the tests.
-bool cfd_int_modes_mfma_ok(const cfd_plan* p, int B, int Cin, int Cout, const void* a, const void* b, const void* c);
+bool cfd_int_modes_mfma_ok(const cfd_plan* p, int B, int Cin, int Cout, const void* a, const void* b, const void* c, bool wgrad);
 size_t cfd_int_modes_mfma_chunks(const cfd_plan* p, int B);
 int cfd_int_modes_mix(const cfd_plan* p, const float* xin, const float* w1, const float* w2, float* z, int B, int C, int conj_t, void* stream);
 int cfd_int_modes_mixadj_wgrad(const cfd_plan* p, const float* xh, const float* gh, const float* w1, const float* w2, float* gz, float* part,
@@ -928,7 +928,7 @@ extern "C" int cfd_spectral_mix(const cfd_plan* p, const float* xh, const float*
     hipStream_t st = (hipStream_t)stream;
     CFD_PROF_W(conj_t ? "k_mix_adj" : "k_mix", st, 16.0 * p->m1 * p->m2 * ((double)B * (Cin + Cout) + (double)Cin * Cout),
                16.0 * B * (double)Cin * Cout * p->m1 * p->m2);
-    if (cfd_int_modes_mfma_ok(p, B, Cin, Cout, xh, z, w1) && ((uintptr_t)w2 % 16) == 0)
+    if (cfd_int_modes_mfma_ok(p, B, Cin, Cout, xh, z, w1, false) && ((uintptr_t)w2 % 16) == 0)
         return cfd_int_modes_mix(p, xh, w1, w2, z, B, Cin, conj_t, stream);
     if (conj_t ? launch_mix_lds<true>((const float2*)xh, (const float2*)w1, (const float2*)w2, (float2*)z, B, Cr, Cz, Cout,
                                       p->m1, p->m2, st)
@@ -1308,7 +1308,7 @@ int cfd_int_spectral_mix_adj_wgrad(const cfd_plan* p, const float* xh, const flo
         // workgroups per CU (measured: 19.1 us per launch against 20.9 / 22.8 us for 5 x 10 tiles with 2 / 4 stages)
         // width 32 (the reference's default --fno_hidden_dim): 4 x 8 tiles, four workgroups per (mode group, chunk)
         CFD_PROF_W("k_mixadj_wgrad", st, 16.0 * p->m1 * p->m2 * (3.0 * B * Cin + 2.0 * Cin * Cout), 32.0 * B * (double)Cin * Cout * p->m1 * p->m2);
-        if (cfd_int_modes_mfma_ok(p, B, Cin, Cout, xh, gh, gz) && (((uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)ws) % 16) == 0)
+        if (cfd_int_modes_mfma_ok(p, B, Cin, Cout, xh, gh, gz, true) && (((uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)ws) % 16) == 0)
             CFD_TRY(cfd_int_modes_mixadj_wgrad(p, xh, gh, w1, w2, gz, (float*)ws, B, Cin, &nchunk, stream));
         else if (Cin == 20)
             launch_mixadj_wgrad<20, 5, 5, 3, 2>((const float2*)xh, (const float2*)gh, (const float2*)w1, (const float2*)w2,

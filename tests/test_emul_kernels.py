@@ -47,12 +47,12 @@ def test_mix_and_spectral_wgrad_multi_step(be, want_wg, nwv, B, C):
         _assert_all(K.check_mix_wgrad(be, B, C, C))
 
 
-@pytest.mark.parametrize("B,bc", [(3, -1), (37, -1), (45, 16), (21, 5)])
-def test_mix_and_spectral_wgrad_on_the_matrix_pipe(be, B, bc):
+@pytest.mark.parametrize("B,bc,C", [(3, -1, 20), (37, -1, 20), (45, 16, 20), (21, 5, 20), (38, -1, 32), (9, 4, 32)])
+def test_mix_and_spectral_wgrad_on_the_matrix_pipe(be, B, bc, C):
     """modes.hip (round 6): the three mode-domain contractions of 20 channels as real GEMMs on the fp32 matrix pipe; forced at small
     batches (mode_mfma = 1), mode_bc shrinks the chunk: several chunks, ragged last stage, a last K-step that is partly zeros."""
-    with K.tuned(be, mode_mfma=1, mode_bc=bc):
-        _assert_all(K.check_mix_wgrad(be, B, 20, 20))
+    with K.tuned(be, mode_mfma=1, mode_bc=bc):  # (32 channels: mix and adjoint only -- the weight gradient stays on the VALU kernels there)
+        _assert_all(K.check_mix_wgrad(be, B, C, C))
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 20, 20, 64, 64), (1, 6, 7, 32, 64), (1, 3, 5, 66, 65), (1, 32, 12, 32, 64), (5, 20, 20, 64, 64),

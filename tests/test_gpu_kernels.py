@@ -54,13 +54,14 @@ def test_mix_and_spectral_wgrad_kernel_routes(be, B, C, nwv, want_wg, fused):
         _assert_all(K.check_mix_wgrad(be, B, C, C))
 
 
-@pytest.mark.parametrize("B,bc", [(256, -1), (300, -1), (128, 16), (37, -1), (200, 24), (21, 5), (512, -1)])
-def test_mix_and_spectral_wgrad_on_the_matrix_pipe(be, B, bc):
+@pytest.mark.parametrize("B,bc,C", [(256, -1, 20), (300, -1, 20), (128, 16, 20), (37, -1, 20), (200, 24, 20), (21, 5, 20), (512, -1, 20),
+                                    (256, -1, 32), (130, -1, 32), (41, 9, 32)])
+def test_mix_and_spectral_wgrad_on_the_matrix_pipe(be, B, bc, C):
     """modes.hip (round 6): mixing, adjoint and spectral weight gradient of 20 channels as real GEMMs on v_mfma_f32_16x16x4_f32 --
     the default from 128 entries, forced here at every size (mode_mfma = 1); mode_bc shrinks the chunk so that small batches reach
     several chunks, ragged last stages and chunks whose last K-step is partly zeros."""
-    with K.tuned(be, mode_mfma=1, mode_bc=bc):
-        _assert_all(K.check_mix_wgrad(be, B, 20, 20))
+    with K.tuned(be, mode_mfma=1, mode_bc=bc):  # (32 channels: mix and adjoint only -- the weight gradient stays on the VALU kernels there)
+        _assert_all(K.check_mix_wgrad(be, B, C, C))
 
 
 def test_matrix_pipe_mode_kernels_agree_with_the_valu_kernels(be):
