@@ -53,7 +53,7 @@ ROCPROF_SYMBOL = {"k_head_train": "k_head_bwd<5, true, true, true, float, 3, 4> 
                   "k_block_fwd_act": "k_block<10, 2, 2, true, false, false, false, 3, false, false>",
                   "k_block_fwd": "k_block<10, 2, 2, false, false, false, false, 3, false, false>",
                   "k_block_bwd_stem": "k_block<8, 3, 3, false, true, false, true, 3, false, true>",
-                  "k_mix": "k_modes_mfma<20, false, false, 2>", "k_mixadj_wgrad": "k_modes_mfma<20, true, true, 3>",
+                  "k_mix": "k_modes_mfma<20, false, false, 2, 32>", "k_mixadj_wgrad": "k_modes_mfma<20, true, true, 3, 40>", "k_adam": "k_adam_f<true>",
                   "k_dft_fwd": "k_dft_fwd64_b3<3, false, 3>", "k_dft_fwd_act": "k_dft_fwd64_b3<3, true, 3>"}
 
 
@@ -240,7 +240,9 @@ def attach_leg_traffic(rl, leg, kernel=None):
         return
     try:
         if kernel is None:
-            calls = sum(v["launches"] for k, v in pmc.items() if isinstance(v, dict) and k.startswith("k_mixadj_wgrad"))  # one per group call
+            # one adjoint-mix + weight-gradient launch per group call (round 6: k_modes_mfma<C, CONJT = true, WGRAD = true, ..>)
+            calls = sum(v["launches"] for k, v in pmc.items() if isinstance(v, dict) and
+                        (k.startswith("k_mixadj_wgrad") or (k.startswith("k_modes_mfma<") and ", true, true," in k)))
             if calls:
                 rl["traffic"] = int(sum(v["traffic_bytes"] * v["launches"] for k, v in pmc.items() if isinstance(v, dict) and k.startswith("k_")) / calls)
         else:
