@@ -546,8 +546,13 @@ def test_committed_bench_line_keeps_the_driver_contract():
     rl = line["roofline"]
     assert rl["bound"] in ("hbm", "mfma") and rl["unit"] in ("GB/s", "TFLOP/s")
     assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3 and "traffic" in rl
+    # round 6: the north-star figure and the step fraction as SCALAR members of `roofline` (the driver's record keeps scalars only)
+    for key in ("spectral_conv2d_us", "spectral_conv2d_frac", "step_frac", "step_ms"):
+        assert isinstance(rl[key], (int, float)), key
+    assert isinstance(rl["kernel_symbol"], str) and abs(rl["spectral_conv2d_frac"] - line["roofline_spectral_conv2d"]["frac"]) < 1e-9
     cb = line["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
+    assert cb["steps"] >= 10 and cb["warmup"] >= 3 and isinstance(cb["cpu_model"], str) and cb["min_s"] <= cb["median_s"] <= cb["max_s"]
     assert line["value"] > 1000 * cb["value"]  # a sanity bound, not a target: the GPU path is the product
 
 
