@@ -919,6 +919,8 @@ def main():
         try:
             result["split2"] = dict(
                 timed_route(b"act_pieces", 2),
+                priced="spectral_conv2d_frac is bytes / time / 8 TB/s (HBM); no matrix-pipe ceiling is applied to this leg (with two activation "
+                       "pieces a product costs four bf16 MFMAs, not the six `roofline_of` assumes for the default route)",
                 what="the same step / SpectralConv2d group with the ACTIVATION operands in two bf16 pieces (cfd_tune_set('act_pieces', 2), the "
                      "default of rounds 1-4): rel. 2^-16 per product, nMSE vs the fp64 oracle 2e-11 .. 5e-11 per kernel -- NOT fp32-class "
                      "arithmetic, kept as a selectable route")

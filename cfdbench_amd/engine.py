@@ -366,6 +366,7 @@ class FnoTrainEngine:
             if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
                 raise RuntimeError("FnoTrainEngine expects contiguous float32 CUDA tensors")
         self._prepare(inputs, case_params)
+        self._last = (inputs, case_params, mask, 0)  # (a data-parallel pass defers nothing: optimizer_step runs the plain flat Adam)
         st = torch.cuda.current_stream().cuda_stream
         a, sp = self.api, ctypes.byref(self.shape)
         mp = None if mask is None else mask.data_ptr()

@@ -480,10 +480,6 @@ def run_fno(be, params, batch, L, C, H, W, p, with_label=True, which="nmse"):
 def _flat_struct(be, flat, layout, L):
     """cfd_fno_params whose tensors are slices of one flat float32 buffer (the training engine's layout)."""
     base = be.ptr(flat)
-
-    class _V:  # (make_param_struct only needs be.ptr of each entry)
-        def __init__(self, off):
-            self.off = off
     s = FnoParams()
     at = lambda k: base + 4 * layout[k][0]  # noqa: E731
     s.fc0_w, s.fc0_b = at("fc0.weight"), at("fc0.bias")
