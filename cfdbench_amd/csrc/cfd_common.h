@@ -9,7 +9,7 @@ void cfd_set_error(const char* fmt, ...);
 
 // dispatch overrides (tune.cpp): environment read once per process, cfd_tune_set() afterwards; -1 = built-in choice
 enum { CFD_TUNE_MIX_NWV = 0, CFD_TUNE_WGRAD_WG, CFD_TUNE_FUSED_VARIANT, CFD_TUNE_BLOCK_FUSE, CFD_TUNE_GENERAL_B3, CFD_TUNE_HEAD_BLOCKS, CFD_TUNE_EXACT_FP32, CFD_TUNE_CONV6_GRID, CFD_TUNE_CONV6_WGRAD_MUL, CFD_TUNE_CONVT_MFMA, CFD_TUNE_CONV1_MFMA, CFD_TUNE_SIDE_STREAM, CFD_TUNE_ACT_PIECES, CFD_TUNE_BLOCK_GEN,
-    CFD_TUNE_GEMM_TILE, CFD_TUNE_GEMM_SPLITS, CFD_TUNE_BLOCK_WIDE, CFD_TUNE_HEAD_WAVES, CFD_TUNE_STEM_FUSE, CFD_TUNE_MODE_MFMA, CFD_TUNE_MODE_BC, CFD_TUNE_COUNT };
+    CFD_TUNE_GEMM_TILE, CFD_TUNE_GEMM_SPLITS, CFD_TUNE_BLOCK_WIDE, CFD_TUNE_HEAD_WAVES, CFD_TUNE_STEM_FUSE, CFD_TUNE_MODE_MFMA, CFD_TUNE_MODE_BC, CFD_TUNE_STEM_DFT, CFD_TUNE_COUNT };
 int cfd_tune_get(int which);
 
 #define CFD_REQUIRE(cond, code, ...)      \
@@ -120,6 +120,9 @@ __device__ __forceinline__ void cfd_st4u(float* p, float4 v) { *reinterpret_cast
 // 1x1 conv writes its (unrounded) result as fp32 and the inverse transform takes that fp32 addend, so a stored pre-activation
 // is rounded exactly once.
 int cfd_int_spectral_dft(const cfd_plan* p, const void* x, float* xh, int nimg, int act_in, int dt, void* stream);
+bool cfd_int_dft_stem_ok(const cfd_plan* p, int B, int in_chan, int P, int C, const void* inputs, const void* mask, const void* a0);
+int cfd_int_spectral_dft_stem(const cfd_plan* p, const float* inputs, const float* mask, const float* cp, const float* w, const float* bias,
+                              float* a0, float* xh, int B, int P, int C, void* stream);
 int cfd_int_spectral_idft(const cfd_plan* p, const float* z, const void* addend, const void* aprev, void* out, int nimg, int epi,
                           int dt, void* stream);
 int cfd_int_spectral_idft_grad(const cfd_plan* p, const float* z, const float* addend, const void* aprev, float* out, int nimg,

@@ -135,11 +135,18 @@ extern "C" int cfd_fno_forward_ex(const cfd_plan* p, const cfd_fno_shape* s, con
     float* z = (float*)(base + L.off_z);
     void* scratch = base + L.off_scratch;
 
-    CFD_TRY(cfd_int_fno_stem_fwd(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, act_buf(0), B, s->in_chan,
-                                 s->n_case_params, C, dt, stream));
+    // round 6: on 64 x 64 the lifting layer rides in the first forward transform (one launch, one activation-sized read less)
+    const bool sd = dt == CFD_DT_F32 && NL >= 1 && cfd_int_dft_stem_ok(p, B, s->in_chan, s->n_case_params, C, inputs, mask, act_buf(0));
+    if (!sd)
+        CFD_TRY(cfd_int_fno_stem_fwd(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, act_buf(0), B, s->in_chan,
+                                     s->n_case_params, C, dt, stream));
     for (int l = 0; l < NL; ++l) {  // FnoBlock.forward, fno2d.py:106-112
         const int act = l > 0;
-        CFD_TRY(cfd_int_spectral_dft(p, act_buf(l), xh_buf(l), B * C, act, dt, stream));
+        if (l == 0 && sd)
+            CFD_TRY(cfd_int_spectral_dft_stem(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, (float*)act_buf(0), xh_buf(0), B,
+                                              s->n_case_params, C, stream));
+        else
+            CFD_TRY(cfd_int_spectral_dft(p, act_buf(l), xh_buf(l), B * C, act, dt, stream));
         CFD_TRY(cfd_spectral_mix(p, xh_buf(l), prm->spec_w1[l], prm->spec_w2[l], z, B, C, C, 0, stream));
         if (dt == CFD_DT_F32) {
             CFD_TRY(cfd_fno_block_fwd(p, (const float*)act_buf(l), z, prm->w0_w[l], prm->w0_b[l], (float*)act_buf(l + 1), B, C, C, act, stream));
@@ -203,11 +210,17 @@ extern "C" int cfd_fno_forward_train_f(const cfd_plan* p, const cfd_fno_shape* s
     const Deferred df = deferred(p, s, L, base, which, dt, flags, inputs, mask);
     hipStream_t side = cfd_side_fork((hipStream_t)stream, df.scale ? 0 : 1);
     if (!df.scale) CFD_TRY(cfd_label_energy_coef(label, mask, sums, coef, scratch, B, s->out_chan, HW, which, upstream, side));
-    CFD_TRY(cfd_int_fno_stem_fwd(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, act_buf(0), B, s->in_chan, s->n_case_params, C,
-                                 dt, stream));
+    const bool sd = dt == CFD_DT_F32 && NL >= 1 && cfd_int_dft_stem_ok(p, B, s->in_chan, s->n_case_params, C, inputs, mask, act_buf(0));
+    if (!sd)
+        CFD_TRY(cfd_int_fno_stem_fwd(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, act_buf(0), B, s->in_chan, s->n_case_params, C,
+                                     dt, stream));
     for (int l = 0; l < NL; ++l) {  // FnoBlock.forward, fno2d.py:106-112
         const int act = l > 0;
-        CFD_TRY(cfd_int_spectral_dft(p, act_buf(l), xh_buf(l), B * C, act, dt, stream));
+        if (l == 0 && sd)
+            CFD_TRY(cfd_int_spectral_dft_stem(p, inputs, mask, case_params, prm->fc0_w, prm->fc0_b, (float*)act_buf(0), xh_buf(0), B,
+                                              s->n_case_params, C, stream));
+        else
+            CFD_TRY(cfd_int_spectral_dft(p, act_buf(l), xh_buf(l), B * C, act, dt, stream));
         CFD_TRY(cfd_spectral_mix(p, xh_buf(l), prm->spec_w1[l], prm->spec_w2[l], z, B, C, C, 0, stream));
         if (dt == CFD_DT_F32) {
             CFD_TRY(cfd_fno_block_fwd(p, (const float*)act_buf(l), z, prm->w0_w[l], prm->w0_b[l], (float*)act_buf(l + 1), B, C, C, act, stream));

@@ -244,13 +244,32 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64(const float* __
 #ifndef CFD_DFT_OCC
 #define CFD_DFT_OCC 3  // workgroups per CU the forward kernel is compiled for
 #endif
-template <int D, bool ACT, int AP>
-__global__ __launch_bounds__(64 * CFD_WAVES, CFD_DFT_OCC) void k_dft_fwd64_b3(const float* __restrict__ x, float2* __restrict__ xh,
+// STEM (round 6): the LIFTING LAYER fused into the first forward transform (Fno2d.forward, fno2d.py:189-217 + :62).  The wave of image
+// (b, c) builds a_0[b, c] = fc0(features)[c] row by row from the entry's u / v / mask planes (shared by the C waves of an entry: L2 hits),
+// the coordinate tables and the case parameters -- the same fmaf chain, feature by feature, as k_stem_fwd4, so a_0 is bit for bit the
+// stand-alone kernel's -- folds it into the transform AND stores it (the FnoBlock kernel and the backward pass read a_0): one launch and
+// one activation-sized read (84 MB at B = 256) less per forward pass.  in_chan == 2, P <= 8; ring depth 1 (three planes per row quad).
+struct CfdStemIn {
+    const float* inputs;  // (B, 2, 64, 64)
+    const float* mask;    // (B, 64, 64) or NULL (= ones)
+    const float* cp;      // (B, P)
+    const float* w;       // (C, 5 + P)
+    const float* bias;    // (C)
+    const float* gx;      // [64]  (plan.d_gx)
+    const float* gy;      // [64]
+    float* a0;            // (B, C, 64, 64): written
+    int P, C;
+};
+template <int D, bool ACT, int AP, bool STEM = false>
+__global__ __launch_bounds__(64 * CFD_WAVES, STEM ? 2 : CFD_DFT_OCC) void k_dft_fwd64_b3(const float* __restrict__ x, float2* __restrict__ xh,
                                                                      const bf16x8* __restrict__ tabs3, int nimg, int m1,
-                                                                     int m2) {
+                                                                     int m2, const CfdStemIn si) {
     constexpr int H = 64, W = 64, NJ = 4, KXT = 9;
+    constexpr int NF = STEM ? 3 : 1;  // planes behind one row quad: the activation itself, or u / v / mask
+    static_assert(!(STEM && ACT), "the lifting layer's output enters the first FnoBlock without GELU");
     __shared__ bf16x8 s_tab3[CFD_DFT3_TABV];
     __shared__ float2 s_out[CFD_WAVES * CFD_DFT_OS];
+    __shared__ float s_gx[STEM ? H : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
     const int stride = gridDim.x * CFD_WAVES;
@@ -259,34 +278,92 @@ __global__ __launch_bounds__(64 * CFD_WAVES, CFD_DFT_OCC) void k_dft_fwd64_b3(co
     // Rolling prefetch exactly as k_dft_fwd64: k-step s holds rows xf = 4s+q (valid while xf <= H/2) and their mirror
     // rows H-xf (only for 0 < xf < H/2); the ring slot of step s is re-armed with step s+D (running on into the wave's
     // next image) the moment its rows have been folded.
-    float4 v[D], u[D];
+    float4 v[D][NF], u[D][NF];
     const int lv = q * W + 4 * n;
     const int lu = (H - q) * W + 4 * n;
     auto off_v = [&](int s) { return (s < KXT - 1 || q == 0) ? 4 * s * W + lv : 4 * n; };
     auto off_u = [&](int s) { return (s == 0 ? q != 0 : s < KXT - 1) ? lu - 4 * s * W : 4 * n; };
     auto is_paired = [&](int s) { return s == 0 ? q != 0 : s < KXT - 1; };
+    // the NF planes behind element offset `off` of image `im`
+    auto ld = [&](int im, int off, float4 (&dst)[NF]) {
+        if constexpr (STEM) {
+            const int b = cfd_uniform(im) / si.C;
+            const float* pin = si.inputs + (size_t)b * 2 * H * W + off;
+            dst[0] = *reinterpret_cast<const float4*>(pin);
+            dst[1] = *reinterpret_cast<const float4*>(pin + H * W);
+            dst[2] = si.mask ? *reinterpret_cast<const float4*>(si.mask + (size_t)b * H * W + off) : make_float4(1.f, 1.f, 1.f, 1.f);
+        } else {
+            dst[0] = *reinterpret_cast<const float4*>(x + (size_t)im * H * W + off);
+        }
+    };
     {
-        const float* xi = x + (size_t)(img < nimg ? img : 0) * H * W;
+        const int im0 = img < nimg ? img : 0;
 #pragma unroll
         for (int s = 0; s < D; ++s) {
-            v[s] = *reinterpret_cast<const float4*>(xi + off_v(s));
-            u[s] = *reinterpret_cast<const float4*>(xi + off_u(s));
+            ld(im0, off_v(s), v[s]);
+            ld(im0, off_u(s), u[s]);
         }
     }
     for (int i = threadIdx.x; i < CFD_DFT3_TABV; i += blockDim.x) s_tab3[i] = tabs3[i];
+    float gyl[4] = {0.f, 0.f, 0.f, 0.f};  // STEM: grid_y of the lane's four columns
+    if constexpr (STEM) {
+        if (threadIdx.x < H) s_gx[threadIdx.x] = si.gx[threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gyl[j] = si.gy[4 * n + j];
+    }
     __syncthreads();
     const int M = 2 * m1 * m2;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     while (img < nimg) {
         const int nxt = img + stride;
-        const float* xn = x + (size_t)(nxt < nimg ? nxt : img) * H * W;
+        const int imn = nxt < nimg ? nxt : img;
+        // STEM: this image's row of the lifting layer -- fc0.weight[c][0 .. 4 + P], fc0.bias[c], the entry's case parameters (wave-uniform)
+        float sw[5 + 8], sb = 0.f, scp[8];
+        if constexpr (STEM) {
+            const int iu = cfd_uniform(img), bb = iu / si.C, c = iu - bb * si.C, F = 5 + si.P;
+            sb = si.bias[c];
+#pragma unroll
+            for (int f = 0; f < 5 + 8; ++f) sw[f] = si.w[c * F + (f < F ? f : F - 1)];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) scp[k] = si.P > 0 ? si.cp[(size_t)bb * si.P + (k < si.P ? k : si.P - 1)] : 0.f;
+        }
+        // a_0 of four pixels of row `row`: bias, then one fmaf per feature in k_stem_fwd4's order (u, v, mask, grid_x, grid_y, case parameters)
+        auto lift = [&](const float4 (&r)[NF], int row, float (&out)[4]) {
+            if constexpr (STEM) {
+                const float gxv = s_gx[row];
+                const float uu[4] = {r[0].x, r[0].y, r[0].z, r[0].w}, vv[4] = {r[1].x, r[1].y, r[1].z, r[1].w},
+                            mm[4] = {r[NF - 1].x, r[NF - 1].y, r[NF - 1].z, r[NF - 1].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float acc = sb;
+                    acc = fmaf(sw[0], uu[j], acc);
+                    acc = fmaf(sw[1], vv[j], acc);
+                    acc = fmaf(sw[2], mm[j], acc);
+                    acc = fmaf(sw[3], gxv, acc);
+                    acc = fmaf(sw[4], gyl[j], acc);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k < si.P) acc = fmaf(sw[5 + k], scp[k], acc);
+                    out[j] = acc;
+                }
+            } else {
+                out[0] = r[0].x; out[1] = r[0].y; out[2] = r[0].z; out[3] = r[0].w;
+            }
+        };
         // ---- fold the rows into the K = 32 operands: slot v of lane group q is k-step v, i.e. row xf = 4v + q ----
         float e8[NJ][8], o8[NJ][8], ny[NJ];
 #pragma unroll
         for (int s = 0; s < KXT; ++s) {
             {
-                float a[4] = {v[s % D].x, v[s % D].y, v[s % D].z, v[s % D].w};
-                float b[4] = {u[s % D].x, u[s % D].y, u[s % D].z, u[s % D].w};
+                float a[4], b[4];
+                const int rowv = (s < KXT - 1 || q == 0) ? 4 * s + q : 0, rowu = is_paired(s) ? H - q - 4 * s : 0;
+                lift(v[s % D], rowv, a);
+                lift(u[s % D], rowu, b);
+                if constexpr (STEM) {  // every row of the image passes here exactly once: a_0 goes out as whole float4 row quads
+                    float* ao = si.a0 + (size_t)img * H * W;
+                    if (s < KXT - 1 || q == 0) *reinterpret_cast<float4*>(ao + off_v(s)) = make_float4(a[0], a[1], a[2], a[3]);
+                    if (is_paired(s)) *reinterpret_cast<float4*>(ao + off_u(s)) = make_float4(b[0], b[1], b[2], b[3]);
+                }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     float aa = a[j], bb = is_paired(s) ? b[j] : 0.f;
@@ -296,11 +373,11 @@ __global__ __launch_bounds__(64 * CFD_WAVES, CFD_DFT_OCC) void k_dft_fwd64_b3(co
                 }
             }
             {   // re-arm the slot with k-step s+D: of this image while one remains, else of the wave's next image
-                const float* src = s + D < KXT ? x + (size_t)img * H * W : xn;
+                const int ims = s + D < KXT ? img : imn;
                 const int sn = (s + D) % KXT;
                 cfd_sched_fence();
-                v[s % D] = *reinterpret_cast<const float4*>(src + off_v(sn));
-                u[s % D] = *reinterpret_cast<const float4*>(src + off_u(sn));
+                ld(ims, off_v(sn), v[s % D]);
+                ld(ims, off_u(sn), u[s % D]);
                 cfd_sched_fence();
             }
         }
@@ -571,7 +648,7 @@ static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, in
             if (blocks > CFD_DFT_CAP) blocks = CFD_DFT_CAP;  // 3 resident workgroups per CU; the waves stride over the images
 #define CFD_DFT64(A_, P_)                                                                                                  \
     hipLaunchKernelGGL((k_dft_fwd64_b3<CFD_DFT_RING, A_, P_>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh, \
-                       (const bf16x8*)p->d_fwd_b3, nimg, p->m1, p->m2)
+                       (const bf16x8*)p->d_fwd_b3, nimg, p->m1, p->m2, CfdStemIn{})
             if (cfd_act_pieces() == 3) { if (act) CFD_DFT64(true, 3); else CFD_DFT64(false, 3); }
             else { if (act) CFD_DFT64(true, 2); else CFD_DFT64(false, 2); }
 #undef CFD_DFT64
@@ -606,6 +683,39 @@ static int launch_dft(const cfd_plan* p, const float* x, float* xh, int nimg, in
         hipLaunchKernelGGL((k_dft_fwd<NJ, VEC4, false>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, x, (float2*)xh,
                            (const float*)p->d_fwd, p->n_fwd, nimg, p->H, p->W, p->m1, p->m2, p->KX);
     CFD_LAUNCH_CHECK("cfd_spectral_dft");
+    return CFD_OK;
+}
+
+// The lifting layer fused into the first forward transform (k_dft_fwd64_b3<.., STEM>): whether it applies, and the launch.  a0 = the
+// lifting layer's output (B, C, 64, 64), written; xh = its kept modes.  "stem_dft" = 0 keeps the two launches (tests, A/B).
+bool cfd_int_dft_stem_ok(const cfd_plan* p, int B, int in_chan, int P, int C, const void* inputs, const void* mask, const void* a0) {
+    // Measured (round 6): the fused launch takes 44 us at B = 256 against 25.5 + 22.4 for the two it replaces (ring depth 1 at two
+    // workgroups per CU: nine dependent L2 round trips per image) -- step 1.227 against 1.224 ms, no gain -- but a 64-case rollout step
+    // goes from 196.4 to 191.6 us.  Default: below 128 entries; "stem_dft" = 1 everywhere, 0 never.
+    const int knob = cfd_tune_get(CFD_TUNE_STEM_DFT);
+    if (knob == 0 || B < 1 || (knob != 1 && B >= 128)) return false;
+    if (!(p->W == 64 && p->H == 64 && p->NJ == 4 && p->d_fwd_b3) || cfd_tune_get(CFD_TUNE_EXACT_FP32) == 1) return false;
+    if (in_chan != 2 || P < 0 || P > 8 || C < 1 || C > 32) return false;
+    return (((uintptr_t)inputs | (uintptr_t)mask | (uintptr_t)a0 | (uintptr_t)p->d_gy) % 16) == 0;
+}
+
+int cfd_int_spectral_dft_stem(const cfd_plan* p, const float* inputs, const float* mask, const float* cp, const float* w, const float* bias,
+                              float* a0, float* xh, int B, int P, int C, void* stream) {
+    CFD_REQUIRE(p && inputs && w && bias && a0 && xh && (P == 0 || cp), CFD_ERR_INVALID_ARG, "cfd_fno_stem_dft: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int nimg = B * C;
+    CFD_PROF_W("k_dft_fwd_stem", st, (double)B * p->H * p->W * (4.0 * 3 + 4.0 * C) + (double)nimg * 16.0 * p->m1 * p->m2,
+               (double)nimg * (4.0 * (p->m1 + 1) * (p->H / 2 + 1) * p->W + 8.0 * (p->m1 + 1) * p->W * p->m2) + 2.0 * B * p->H * p->W * (double)C * (5 + P));
+    int blocks = (nimg + CFD_WAVES - 1) / CFD_WAVES;
+    if (blocks > 2 * 256) blocks = 2 * 256;  // two resident workgroups per CU (the lifting layer's row weights cost ~40 registers)
+    const CfdStemIn si{inputs, mask, cp, w, bias, (const float*)p->d_gx, (const float*)p->d_gy, a0, P, C};
+    if (cfd_act_pieces() == 3)
+        hipLaunchKernelGGL((k_dft_fwd64_b3<1, false, 3, true>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, (const float*)nullptr, (float2*)xh,
+                           (const bf16x8*)p->d_fwd_b3, nimg, p->m1, p->m2, si);
+    else
+        hipLaunchKernelGGL((k_dft_fwd64_b3<1, false, 2, true>), dim3(blocks), dim3(64 * CFD_WAVES), 0, st, (const float*)nullptr, (float2*)xh,
+                           (const bf16x8*)p->d_fwd_b3, nimg, p->m1, p->m2, si);
+    CFD_LAUNCH_CHECK("cfd_fno_stem_dft");
     return CFD_OK;
 }
 

@@ -48,6 +48,7 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
     {CFD_TUNE_MODE_MFMA, "mode_mfma", "CFD_MODE_MFMA", {-1}},        // mode mixing / adjoint / spectral weight gradient on the fp32 matrix pipe (modes.hip, round 6): 0 = never (the batch-in-lanes
                                                  // VALU kernels of spectral.hip), 1 = wherever the shape allows (tests: small batches); default: 20 channels and >= 128 entries
     {CFD_TUNE_MODE_BC, "mode_bc", "CFD_MODE_BC", {-1}},            // batch entries per chunk of the modes.hip kernels (tests: several chunks and ragged stages at small batches)
+    {CFD_TUNE_STEM_DFT, "stem_dft", "CFD_STEM_DFT", {-1}},          // the lifting layer fused into the first forward transform (k_dft_fwd64_b3<.., STEM>, round 6; 64 x 64, in_chan 2): default below 128 batch entries (rollouts), 1 = always, 0 = never
 };
 std::once_flag g_once;
 void read_env() {

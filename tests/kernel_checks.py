@@ -557,6 +557,21 @@ def check_fno_train_step_deferred(be, B, C, L, H, W, p=5, which="nmse", flags=7,
         api.plan_destroy(plan)
 
 
+def check_stem_dft_fusion(be, B, C, L, p, border, seed=61):
+    """Round 6: the lifting layer fused into the first forward transform (stem_dft = 1) against the two launches (stem_dft = 0): predictions
+    (training and inference workspaces) and every gradient bit for bit -- a_0 is built by the same fmaf chain and stored for the consumers."""
+    params = synth.make_fno_params(seed, C, L, 12, 12, p, spectral_gain=4.0)
+    batch = synth.make_batch(seed + 1, B, 64, 64, p, border_mask=border)
+    with tuned(be, stem_dft=1):
+        a = run_fno(be, params, batch, L, C, 64, 64, p)
+    with tuned(be, stem_dft=0):
+        b = run_fno(be, params, batch, L, C, 64, 64, p)
+    res = {"preds": float(np.max(np.abs(a["preds"] - b["preds"]))), "preds_infer": float(np.max(np.abs(a["preds_infer"] - b["preds_infer"])))}
+    for k in a["grads"]:
+        res["g:" + k] = float(np.max(np.abs(a["grads"][k] - b["grads"][k])))
+    return res
+
+
 def check_fno_vs_oracle(be, B, C, L, H, W, p=5, border=False, gain=4.0, pseed=7, bseed=8):
     params = synth.make_fno_params(pseed, C, L, 12, 12, p, spectral_gain=gain)
     batch = synth.make_batch(bseed, B, H, W, p, border_mask=border)

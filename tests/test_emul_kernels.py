@@ -526,3 +526,12 @@ def test_fused_train_step_with_deferred_launches(be, kw):
     res = K.check_fno_train_step_deferred(be, **kw)
     assert res.pop("sums") < 1e-6 and res.pop("preds") == 0.0
     _assert_all(res, 1e-11)
+
+
+@pytest.mark.parametrize("B,C,L,p,border", [(2, 20, 2, 5, False), (3, 8, 1, 8, True), (1, 32, 1, 0, True)])
+def test_lifting_layer_fused_into_the_first_transform_is_bitwise(be, B, C, L, p, border):
+    """k_dft_fwd64_b3<.., STEM> (round 6; default below 128 entries at 64 x 64): the wave of image (b, c) builds a_0[b, c] from the entry's
+    u / v / mask planes, tables and case parameters by k_stem_fwd4's fmaf chain, folds it into the transform and stores it -- the whole
+    model's predictions and gradients equal the two-launch route bit for bit."""
+    res = K.check_stem_dft_fusion(be, B, C, L, p, border)
+    assert all(v == 0.0 for v in res.values()), res

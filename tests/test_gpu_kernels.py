@@ -581,3 +581,12 @@ def test_width_32_block_default_dispatch_at_full_size(be, B, H, W):
     """Width 32 at the sizes where the default dispatch switches between the single-workgroup fused kernel and the two passes
     (66 x 65: fused from 128 entries, two passes below; 64 x 64: always fused): both sides hold the oracle."""
     _assert_all(K.check_block(be, B, 32, 32, H, W))
+
+
+@pytest.mark.parametrize("B,C,L,p,border", [(2, 20, 2, 5, False), (70, 20, 4, 5, True), (256, 20, 1, 5, False), (5, 32, 2, 8, True), (9, 12, 1, 0, True)])
+def test_lifting_layer_fused_into_the_first_transform_is_bitwise(be, B, C, L, p, border):
+    """k_dft_fwd64_b3<.., STEM> (round 6; default below 128 entries at 64 x 64): the wave of image (b, c) builds a_0[b, c] from the entry's
+    u / v / mask planes, tables and case parameters by k_stem_fwd4's fmaf chain, folds it into the transform and stores it -- the whole
+    model's predictions and gradients equal the two-launch route bit for bit."""
+    res = K.check_stem_dft_fusion(be, B, C, L, p, border)
+    assert all(v == 0.0 for v in res.values()), res
