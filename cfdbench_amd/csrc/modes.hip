@@ -282,8 +282,9 @@ bool cfd_int_modes_mfma_ok(const cfd_plan* p, int B, int Cin, int Cout, const vo
     if (half % CFD_MM_T != 0) return false;                  // a tile never straddles weights1 / weights2
     if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) % 16) return false;
     (void)M;
-    // below ~128 entries the lane = mode kernels of spectral.hip win (few workgroups here, each paying the weight fill)
-    return knob == 1 || B >= 128;
+    // below ~128 entries the lane = mode kernels of spectral.hip win at 20 channels (few workgroups here, each paying the weight fill:
+    // 64-case rollout step 191.6 against 193.8 us); at 32 channels the matrix pipe already wins at 64 (66 x 65: 359.4 -> 348.4 us)
+    return knob == 1 || B >= (Cin == 32 ? 64 : 128);
 }
 
 size_t cfd_int_modes_mfma_chunks(const cfd_plan* p, int B) {  // partial-sum chunks the weight gradient may write
