@@ -282,6 +282,27 @@ __device__ __forceinline__ CfdSplit8x3 cfd_split8x3(const float (&x)[8]) {
     s.p[2] = __builtin_bit_cast(bf16x8, m);
     return s;
 }
+// Workgroup copy of n elements (16-byte vectors or floats) from global memory into LDS with up to EIGHT loads per thread in flight before
+// the first store.  Written as `for (i = tid; i < n; i += blockDim.x) dst[i] = src[i]` with a run-time n, hipcc emits load / s_waitcnt
+// vmcnt(0) / ds_write per trip: one exposed L2 round trip per 4 KB (256 threads) -- 6-8 of them, 4-5 us, in front of every workgroup of
+// the general-grid transforms and of k_idft64 (round 6; found in the ISA of k_idft_g).
+template <typename V>
+__device__ __forceinline__ void cfd_stage_lds(V* dst, const V* __restrict__ src, int n) {
+    const int step = (int)blockDim.x;
+    for (int i0 = (int)threadIdx.x; i0 < n; i0 += 8 * step) {
+        V r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * step;
+            r[k] = src[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * step;
+            if (i < n) dst[i] = r[k];
+        }
+    }
+}
 // counter-based hash of (seed, element index): the keep mask of nn.Dropout (conv.hip k_dropout, pointwise.hip k_dropout_gelu)
 __device__ __forceinline__ unsigned cfd_hash32(unsigned long long v) {
     v ^= v >> 33; v *= 0xff51afd7ed558ccdULL;

@@ -140,7 +140,10 @@ __device__ __forceinline__ void head_act(float (&h)[CQ][4]) {
 // AP pieces per value (cfd_common.h: 2 = the default split products, 3 = fp32-exact class); piece p of fragment idx at s_w[p * HEAD_MT * 64 + idx]
 template <int AP>
 __device__ __forceinline__ void head_build_w1f(bf16x8* s_w, const float* __restrict__ w1, int C, int CQ) {
-    for (int idx = threadIdx.x; idx < HEAD_MT * 64; idx += blockDim.x) {
+#pragma unroll
+    for (int i0 = 0; i0 < HEAD_MT * 64; i0 += 256) {  // (workgroups of 256 threads: compile-time trips, every trip's loads issued together)
+        const int idx = i0 + (int)threadIdx.x;
+        if (idx >= HEAD_MT * 64) break;
         const int ln = idx & 63, mt = idx >> 6;
         const int jh = 16 * mt + (ln & 15), c0 = CQ * (ln >> 4);
         float x[8];
@@ -166,12 +169,6 @@ __global__ __launch_bounds__(256, CQ == 8 ? CFD_HF_OCC8 : 3) void k_head_fwd(con
     // 48-63 -- profiles/r03_det_root_cause.md.)
     __shared__ __attribute__((aligned(16))) cfd_f2 s_w2[HEAD_HD];
     __shared__ float s_red[12];
-    head_build_w1f<AP>(s_w1, w1, C, CQ);
-    for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x) s_b1[i] = b1[i];
-    for (int i = threadIdx.x; i < HEAD_HD; i += blockDim.x)  // per PAIR of hidden units (2p, 2p+1): [w2[0][2p], w2[0][2p+1]], [w2[1][2p], w2[1][2p+1]]
-        s_w2[i] = (i & 1) ? (Co > 1 ? cfd_f2{w2[HEAD_HD + i - 1], w2[HEAD_HD + i]} : cfd_f2{0.f, 0.f}) : cfd_f2{w2[i], w2[i + 1]};
-    __syncthreads();
-    const float b2v0 = b2[0], b2v1 = Co > 1 ? b2[1] : 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, n = lane & 15;
     float lsq = 0.f, labs = 0.f, ll2 = 0.f;
@@ -204,6 +201,21 @@ __global__ __launch_bounds__(256, CQ == 8 ? CFD_HF_OCC8 : 3) void k_head_fwd(con
     locate(tile, b, px);
     head_load_raw<CQ, VEC4, TA>(a, b, C, HW, px, q, hn);
     fetch_io(b, px);
+    // The weights go to LDS AFTER the first tile has been requested, in trips of a compile-time 256 threads (round 6: with `i += blockDim.x`
+    // the three copy loops stayed rolled -- load, s_waitcnt vmcnt(0), ds_write per trip -- and the first tile was requested behind them:
+    // five dependent round trips in front of a wave's only tile at 64 rollout cases).
+    head_build_w1f<AP>(s_w1, w1, C, CQ);
+#pragma unroll
+    for (int i0 = 0; i0 < HEAD_HD; i0 += 256) {
+        const int i = i0 + (int)threadIdx.x;
+        if (i < HEAD_HD) {
+            s_b1[i] = b1[i];
+            // per PAIR of hidden units (2p, 2p+1): [w2[0][2p], w2[0][2p+1]], [w2[1][2p], w2[1][2p+1]]
+            s_w2[i] = (i & 1) ? (Co > 1 ? cfd_f2{w2[HEAD_HD + i - 1], w2[HEAD_HD + i]} : cfd_f2{0.f, 0.f}) : cfd_f2{w2[i], w2[i + 1]};
+        }
+    }
+    const float b2v0 = b2[0], b2v1 = Co > 1 ? b2[1] : 0.f;
+    __syncthreads();
     for (; tile < total; tile += stride) {
         float h[CQ][4], mk[4], lb[4];
 #pragma unroll

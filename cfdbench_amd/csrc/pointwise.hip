@@ -370,26 +370,6 @@ __global__ __launch_bounds__(256, 2) void k_chanmix_b3(const TA* __restrict__ in
     // through a near-identity network accumulates coherently (2-piece weights: nMSE 3.0e-7 against the reference at step
     // 200 of tests/golden/rollout200_c32_66x65, 3-piece: see DESIGN.md); the activations keep two pieces, whose rounding
     // differs from value to value.  Five MFMAs per tile-step instead of three; the kernel is memory-bound either way.
-    CfdTab3 wf[MT];    // (round 4: the activations carry AP = 2 or 3 pieces -- five or six MFMAs per tile-step, cfd_common.h)
-    float bz[MT][4];   // bias of accumulator row d = 16 mt + 4q + r
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        float x[8];
-        const int d = 16 * mt + n;
-#pragma unroll
-        for (int v = 0; v < 8; ++v) {
-            const int sc = 8 * q + v;
-            x[v] = (d < Co && sc < Ci) ? (transpose ? w[sc * Co + d] : w[d * Ci + sc]) : 0.f;
-        }
-        // round-to-nearest pieces as in rounds 2-3 (hi, lo, then the bf16 of what two pieces miss): the default route's results stay bit-identical
-        const CfdSplit8 w2 = cfd_split8(x);
-        float x3[8];
-#pragma unroll
-        for (int v = 0; v < 8; ++v) x3[v] = (x[v] - (float)w2.hi[v]) - (float)w2.lo[v];  // exact
-        wf[mt].p[0] = w2.hi; wf[mt].p[1] = w2.lo; wf[mt].p[2] = cfd_split8(x3).hi;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bz[mt][r] = (bias && 16 * mt + 4 * q + r < Co) ? bias[16 * mt + 4 * q + r] : 0.f;
-    }
     const int tpb = (HW + 63) / 64;
     const int total = B * tpb;  // < 2^30 (checked by the launcher)
     const int stride = (int)gridDim.x * 4;
@@ -416,7 +396,27 @@ __global__ __launch_bounds__(256, 2) void k_chanmix_b3(const TA* __restrict__ in
         }
     };
     locate(tile);
-    fetch();
+    fetch();  // (round 6: requested BEFORE the weight prologue -- with one tile per wave, as at 64 rollout cases, the two round trips ran one after the other)
+    CfdTab3 wf[MT];    // (round 4: the activations carry AP = 2 or 3 pieces -- five or six MFMAs per tile-step, cfd_common.h)
+    float bz[MT][4];   // bias of accumulator row d = 16 mt + 4q + r
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float x[8];
+        const int d = 16 * mt + n;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int sc = 8 * q + v;
+            x[v] = (d < Co && sc < Ci) ? (transpose ? w[sc * Co + d] : w[d * Ci + sc]) : 0.f;
+        }
+        // round-to-nearest pieces as in rounds 2-3 (hi, lo, then the bf16 of what two pieces miss): the default route's results stay bit-identical
+        const CfdSplit8 w2 = cfd_split8(x);
+        float x3[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) x3[v] = (x[v] - (float)w2.hi[v]) - (float)w2.lo[v];  // exact
+        wf[mt].p[0] = w2.hi; wf[mt].p[1] = w2.lo; wf[mt].p[2] = cfd_split8(x3).hi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bz[mt][r] = (bias && 16 * mt + 4 * q + r < Co) ? bias[16 * mt + 4 * q + r] : 0.f;
+    }
     for (; tile < total; tile += stride) {
         float h[8][4];
 #pragma unroll

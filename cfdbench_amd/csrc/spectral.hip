@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES) void k_dft_fwd(const float* __restr
                                                              int H, int W, int m1, int m2, int KX) {
     __shared__ float s_tab[(2 * 17 + 8 * NJ) * 64];
     __shared__ float2 s_out[CFD_WAVES * CFD_DFT_OS];
-    for (int i = threadIdx.x; i < ntab; i += blockDim.x) s_tab[i] = tabs[i];
+    cfd_stage_lds(s_tab, tabs, ntab);
     __syncthreads();
     const float* t1c = s_tab;
     const float* t1s = t1c + KX * 64;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_dft_fwd64(const float* __
             u[s] = *reinterpret_cast<const float4*>(xi + off_u(s));
         }
     }
-    for (int i = threadIdx.x; i < ntab; i += blockDim.x) s_tab[i] = tabs[i];
+    cfd_stage_lds(s_tab, tabs, ntab);
     __syncthreads();
     const float* t1c = s_tab;
     const float* t1s = t1c + KXT * 64;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_dft_fwd_g(const TA* __res
 #pragma unroll
         for (int j = 0; j < NJ; ++j) arm(xi, j);
     }
-    for (int i = threadIdx.x; i < ntabv; i += blockDim.x) s_tab3[i] = tabs3[i];
+    cfd_stage_lds(s_tab3, tabs3, ntabv);
     __syncthreads();
     const int M = 2 * m1 * m2;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -1587,7 +1587,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES) void k_idft(const float* __restrict
     const int M2 = 4 * m1 * m2;
     float* zs = s_z + wave * CFD_IDFT_ZMAX;
     if (live) idft_stage_z(z + (size_t)img * M2, zs, M2, lane);
-    for (int i = threadIdx.x; i < ntab; i += blockDim.x) s_tab[i] = tabs[i];
+    cfd_stage_lds(s_tab, tabs, ntab);
     __syncthreads();
     if (!live) return;
     const float* ta = s_tab;
@@ -1695,7 +1695,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 3) void k_idft64(const float* __res
         if (lane == 0) zs[M2] = 0.f;
     };
     zfetch(img < nimg ? img : 0);
-    for (int i = threadIdx.x; i < (CFD_TW * T + CFD_TW * NJ) * 64; i += blockDim.x) s_tab3[i] = tabs3[i];
+    cfd_stage_lds(s_tab3, tabs3, (CFD_TW * T + CFD_TW * NJ) * 64);
     zcommit(zs0);
     __syncthreads();
     const bf16x8* tb3 = s_tab3 + CFD_TW * T * 64;
@@ -1775,7 +1775,7 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_idft_g(const float* __res
         if (lane == 0) zs[M2] = 0.f;
     };
     zfetch(img < nimg ? img : 0);
-    for (int i = threadIdx.x; i < ntabv; i += blockDim.x) s_tab3[i] = tabs3[i];
+    cfd_stage_lds(s_tab3, tabs3, ntabv);
     zcommit(zs0);
     __syncthreads();
     const bf16x8* tb3 = s_tab3 + CFD_TW * T * 64;
@@ -1784,28 +1784,41 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_idft_g(const float* __res
     bool cok[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) { cok[j] = 16 * j + n < W; colc[j] = cok[j] ? 16 * j + n : W - 1; }
-    int cur = 0;
-    while (img < nimg) {
-        const int nxt = img + stride;
-        zfetch(nxt < nimg ? nxt : img);
-        cfd_sched_fence();
-        float va[2][8];
-        idft_gather(zs0 + cur * CFD_IDFT_ZMAX, m1, m2, SA, q, n, va);
-        const IdftSplitA<AP> sa = idft_split<AP>(va);
-        const size_t ibase = (size_t)img * H * W;
-#pragma unroll 1
-        for (int t = 0; t < T; ++t) {
-            float ad[4][NJ], ap[4][NJ];
+    // One (image, row tile) per trip.  The addend / gelu' source rows of the NEXT trip are requested before this trip's MFMAs and stores
+    // (round 6): vmcnt counts loads and stores in order, so loads issued after a tile's stores were waited for together with the stores'
+    // write acknowledges -- two exposed memory latencies per row tile, ~3.9 us of a tile's ~4 at 64 rollout cases (66 x 65, 32 channels:
+    // 19.6 us per launch for 70 MB).
+    int cur = 0, t = 0;
+    float ad[4][NJ], ap[4][NJ], adn[4][NJ], apn[4][NJ];
+    auto ldtile = [&](int im, int tt, float (&a_)[4][NJ], float (&p_)[4][NJ]) {
+        const size_t ib = (size_t)im * H * W;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int xx = 16 * t + 4 * q + r;
-                const size_t rb = ibase + (size_t)(xx < H ? xx : H - 1) * W;
+        for (int r = 0; r < 4; ++r) {
+            const int xx = 16 * tt + 4 * q + r;
+            const size_t rb = ib + (size_t)(xx < H ? xx : H - 1) * W;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    if constexpr (EPI >= 1) ad[r][j] = cfd_ld(addend + rb + colc[j]);
-                    if constexpr (EPI == 2) ap[r][j] = cfd_ld(aprev + rb + colc[j]);
-                }
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (EPI >= 1) a_[r][j] = cfd_ld(addend + rb + colc[j]);
+                if constexpr (EPI == 2) p_[r][j] = cfd_ld(aprev + rb + colc[j]);
             }
+        }
+    };
+    if (img < nimg) ldtile(img, 0, ad, ap);
+    IdftSplitA<AP> sa;
+    while (img < nimg) {
+        if (t == 0) {  // (uniform) a new image: its modes were staged one image ago; request the next image's
+            const int nxt = img + stride;
+            zfetch(nxt < nimg ? nxt : img);
+            float va[2][8];
+            idft_gather(zs0 + cur * CFD_IDFT_ZMAX, m1, m2, SA, q, n, va);
+            sa = idft_split<AP>(va);
+        }
+        int nt = t + 1, nimg_ = img;
+        if (nt == T) { nt = 0; nimg_ = img + stride; }
+        if (nimg_ < nimg) ldtile(nimg_, nt, adn, apn);
+        cfd_sched_fence();
+        const size_t ibase = (size_t)img * H * W;
+        {
             f32x4 accB[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) accB[j] = zero;
@@ -1824,10 +1837,21 @@ __global__ __launch_bounds__(64 * CFD_WAVES, 2) void k_idft_g(const float* __res
                 }
             }
         }
-        cur ^= 1;
-        zcommit(zs0 + cur * CFD_IDFT_ZMAX);  // the other slice was last read one image ago (same wave: program order)
-        cfd_wave_lds_sync();
-        img = nxt;
+        cfd_sched_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (EPI >= 1) ad[r][j] = adn[r][j];
+                if constexpr (EPI == 2) ap[r][j] = apn[r][j];
+            }
+        if (nt == 0) {
+            cur ^= 1;
+            zcommit(zs0 + cur * CFD_IDFT_ZMAX);  // the other slice was last read one image ago (same wave: program order)
+            cfd_wave_lds_sync();
+        }
+        img = nimg_;
+        t = nt;
     }
 }
 
