@@ -138,7 +138,11 @@ void cfd_conv_tile_shape(int Hd, int Wd, int B, int& TW, int& TH, int& NB) {
     int btw = TW, bth = TH;
     for (int tw = 4; tw <= 64 && tw <= Wd; ++tw)
         for (int thh = 1; thh * tw <= 256 && thh <= Hd; ++thh) {
-            if (tw * thh < 128) continue;  // at least half of the lanes busy
+            // at least half of the lanes busy -- or the tile is the WHOLE image and several images share the workgroup (round 6: the
+            // 10 x 10 and 6 x 6 extended grids of the 8 x 8 / 4 x 4 U-Net levels fell back to one 16 x 16 / four 8 x 8 tiles per workgroup,
+            // 39 % / 56 % of the lanes, where two 10 x 10 / seven 6 x 6 images fill 78 % / 98 %; thin tiles of many images are not
+            // admitted: their halo is three times their area)
+            if (tw * thh < 128 && !(tw == Wd && thh == Hd)) continue;
             const double c = cost(tw, thh);
             if (c < best - 1e-9 || (c < best + 1e-9 && tw > btw)) { best = c; btw = tw; bth = thh; }
         }

@@ -524,15 +524,29 @@ static Conv6Plan conv6_plan(const ConvGeom& g, bool ext) {
     P.mgroups = (P.MTall + mtw - 1) / mtw;
     const long wgs = P.ptiles * P.mgroups;
     P.ksplit = 1;
-    if (wgs < 256 && P.nch > 1) {  // deep, narrow levels: split the channel chunks over blockIdx.z
-        const long ks = (512 + wgs - 1) / wgs;
-        P.ksplit = (int)(ks < P.nch ? ks : P.nch);
-        const int per = (P.nch + P.ksplit - 1) / P.ksplit;
-        P.ksplit = (P.nch + per - 1) / per;  // every slice owns at least one chunk (an empty one would leave its partial unwritten)
+    const long slots = conv6_grid();  // resident workgroups of a launch (two per CU)
+    long gx = slots / P.mgroups;
+    if (wgs < 256 && P.nch > 1) {
+        // deep, narrow levels: the channel chunks split over blockIdx.z.  Round 6: (splits, workgroups per slice) chosen together for the
+        // fewest (tile, chunk) trips of the slowest workgroup while the whole grid stays resident -- the fixed rule (512 / wgs splits, then
+        // gx = 512 / (groups x splits)) left e.g. the 4 x 4 U-Net level with 8 tiles on 7 workgroups x 6 splits: one workgroup walked two
+        // tiles while the rest idled.  Ties go to fewer splits (less partial-sum traffic for k_splitk_sum).
+        long best_trips = -1;
+        const int ksmax = P.nch < 16 ? P.nch : 16;
+        for (int ks = 1; ks <= ksmax; ++ks) {
+            const int per = (P.nch + ks - 1) / ks, kse = (P.nch + per - 1) / per;  // every slice owns at least one chunk
+            if (kse != ks) continue;
+            long g1 = slots / ((long)P.mgroups * ks);
+            if (g1 < 1) g1 = 1;
+            if (g1 > P.ptiles) g1 = P.ptiles;
+            const long trips = ((P.ptiles + g1 - 1) / g1) * per;
+            if (best_trips < 0 || trips < best_trips) { best_trips = trips; P.ksplit = ks; gx = g1; }
+        }
+    } else if (P.ksplit == 1) {
+        gx = slots / P.mgroups;
     }
     P.lds = lds_of(mtw);
     // persistent workgroups: two per CU over the whole launch
-    long gx = conv6_grid() / ((long)P.mgroups * P.ksplit);
     if (gx < 1) gx = 1;
     P.gx = (int)(gx < P.ptiles ? gx : P.ptiles);
     P.wfrag_bytes = F.bytes;
