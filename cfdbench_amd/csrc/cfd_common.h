@@ -9,7 +9,7 @@ void cfd_set_error(const char* fmt, ...);
 
 // dispatch overrides (tune.cpp): environment read once per process, cfd_tune_set() afterwards; -1 = built-in choice
 enum { CFD_TUNE_MIX_NWV = 0, CFD_TUNE_WGRAD_WG, CFD_TUNE_FUSED_VARIANT, CFD_TUNE_BLOCK_FUSE, CFD_TUNE_GENERAL_B3, CFD_TUNE_HEAD_BLOCKS, CFD_TUNE_EXACT_FP32, CFD_TUNE_CONV6_GRID, CFD_TUNE_CONV6_WGRAD_MUL, CFD_TUNE_CONVT_MFMA, CFD_TUNE_CONV1_MFMA, CFD_TUNE_SIDE_STREAM, CFD_TUNE_ACT_PIECES, CFD_TUNE_BLOCK_GEN,
-    CFD_TUNE_GEMM_TILE, CFD_TUNE_GEMM_SPLITS, CFD_TUNE_BLOCK_WIDE, CFD_TUNE_HEAD_WAVES, CFD_TUNE_STEM_FUSE, CFD_TUNE_MODE_MFMA, CFD_TUNE_MODE_BC, CFD_TUNE_STEM_DFT, CFD_TUNE_COUNT };
+    CFD_TUNE_GEMM_TILE, CFD_TUNE_GEMM_SPLITS, CFD_TUNE_BLOCK_WIDE, CFD_TUNE_HEAD_WAVES, CFD_TUNE_STEM_FUSE, CFD_TUNE_MODE_MFMA, CFD_TUNE_MODE_BC, CFD_TUNE_STEM_DFT, CFD_TUNE_GEMM_B3, CFD_TUNE_COUNT };
 int cfd_tune_get(int which);
 
 #define CFD_REQUIRE(cond, code, ...)      \

@@ -106,6 +106,13 @@ __device__ __forceinline__ f32x4 cfd_buf_ld4(CfdBuf b, unsigned voff, unsigned s
 __device__ __forceinline__ void cfd_buf_st(CfdBuf b, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b, (int)voff, (int)soff, 0);
 }
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4, gfx950): the destination is the WAVE-UNIFORM `lds_wave_base`
+// + 16 * lane -- no per-lane scatter -- the source address is per lane.  Counted by vmcnt like any load; hipcc drains it (vmcnt(0)) in
+// front of the next __syncthreads().
+__device__ __forceinline__ void cfd_glds16(const void* g_lane, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned*)g_lane,
+                                     (__attribute__((address_space(3))) unsigned*)lds_wave_base, 16, 0, 0);
+}
 // true in every lane of the wave when `p` holds in any of them (a wave-uniform branch condition)
 __device__ __forceinline__ bool cfd_wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 

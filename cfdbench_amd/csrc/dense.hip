@@ -7,6 +7,7 @@
 // one LDS-tiled kernel C = epi(op(A) op(B)): 64x64 block tile, 4 waves x (2x2) MFMA tiles, K in slabs of 16 that are
 // prefetched into registers while the previous slab is on the matrix pipe.
 #include "cfd_common.h"
+#include <type_traits>
 
 #define GT 64   // block tile edge (M and N) of the small-problem kernel: 4 waves x (2 x 2) MFMA tiles
 #define GK 16   // K slab
@@ -388,6 +389,203 @@ static int launch_gemm(const float* A, const float* B, float* C, int M, int N, i
     return CFD_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Tall products C[M][N] = epi(A[M][K] Bw) with a SMALL second operand (a Linear layer's weights: N, K <= 1024) on the bf16 matrix pipe
+// with THREE-PIECE operands (round 6; cfd_common.h: six v_mfma_f32_16x16x32_bf16 per product term, everything down to 2^-24 -- the
+// fp32-exact class the convolution stack runs on, so the ReLU networks see no kink crossings).  The 131 k x 200 x 200 products of the
+// Auto-FFN ran at 42 % of the fp32 matrix pipe (167 us; the pipe's own time is 67 us); six 16-cycle MFMAs replace eight 32-cycle ones and
+// the product becomes memory-bound (210 MB).
+//   * Bw is split ONCE per call into MFMA fragment order by k_rowgemm6_prep: frag[((ks * NTall + nt) * 3 + piece) * 64 + lane],
+//     lane (q, n): column 16 nt + n, reduction indices 32 ks + 8 q .. + 7.  TRANS: Bw[k][col] stored [k][col] (the input gradient gz w),
+//     else stored [col][k] (the forward x w^T).
+//   * workgroup = 128 rows (four waves x two 16-row tiles) x ALL columns in passes of R6_NT column tiles; per K slab of 32 the pass's
+//     fragments go global -> registers -> LDS (double-buffered, one barrier per slab) and feed both row tiles of every wave; the A rows
+//     come straight from global memory in operand order (a lane's eight reduction indices are 32 contiguous bytes) and are split in
+//     registers.  The next slab's loads are in flight during this slab's MFMAs.
+// ------------------------------------------------------------------------------------------------------
+#define R6_NT 13
+#ifndef CFD_R6_EXP
+#define CFD_R6_EXP 0  // timing experiments (results WRONG): 1 no MFMAs, 2 no A loads, 4 no fragment loads, 8 no stores
+#endif
+#define R6_RT 2
+typedef cfd_u32x4 r6_u4;
+
+template <bool TRANS>
+__global__ __launch_bounds__(256) void k_rowgemm6_prep(const float* __restrict__ W, int ldw, r6_u4* __restrict__ frag, int N, int K,
+                                                       int NTall, int nks) {
+    const unsigned total = (unsigned)nks * NTall * 64;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, q = lane >> 4, n = lane & 15;
+        const unsigned rest = idx >> 6;
+        const int nt = rest % NTall, ks = rest / NTall;
+        const int col = 16 * nt + n, k0 = 32 * ks + 8 * q;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = (col < N && k0 + j < K) ? (TRANS ? W[(size_t)(k0 + j) * ldw + col] : W[(size_t)col * ldw + k0 + j]) : 0.f;
+        const CfdSplit8x3 sp = cfd_split8x3(v);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) frag[((size_t)rest * 3 + pc) * 64 + lane] = __builtin_bit_cast(r6_u4, sp.p[pc]);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_rowgemm6(const float* __restrict__ A, int lda, const r6_u4* __restrict__ frag,
+                                                     float* __restrict__ C, int ldc, int M, int N, int K, GemmEpi epi, int NTall,
+                                                     int nks) {
+    constexpr int NT = R6_NT, RT = R6_RT, FB = NT * 192;  // 16-byte units of one pass's fragments per slab
+    CFD_DYN_SHARED(f32x4, s_dyn);                         // (one extern array type per translation unit) [2][FB] 16-byte units
+    r6_u4* const s_frag = reinterpret_cast<r6_u4*>(s_dyn);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int row0 = (int)blockIdx.x * (64 * RT) + wave * (16 * RT);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // A rows of this lane (clamped: rows past M feed accumulator rows that are never stored)
+    const float* arow[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int r = row0 + 16 * rt + n;
+        arow[rt] = A + (size_t)(r < M ? r : M - 1) * lda;
+    }
+    for (int nt0 = 0; nt0 < NTall; nt0 += NT) {
+        const int ntp = NTall - nt0 < NT ? NTall - nt0 : NT;  // (uniform) live column tiles of this pass
+        const int fcount = ntp * 192;
+        f32x4 acc[RT][NT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = zero;
+        f32x4 ar[RT][2];
+        // loads of slab ks: the A rows unconditional from clamped addresses (a 16-byte unit past K is zeroed after the load: K % 4 == 0);
+        // the pass's fragments straight into LDS buffer ks & 1 (cfd_glds16: 1 KB per wave instruction, no registers -- through
+        // registers the 40 VGPRs of the fragment units spilled the kernel), rows of 64 units dealt to the four waves
+        const auto issue = [&](int ks) {
+            const int k0 = 32 * ks + 8 * q;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = k0 + 4 * h;
+                    if constexpr (CFD_R6_EXP & 2) ar[rt][h] = f32x4{(float)k, 1.f, 2.f, (float)ks};
+                    else ar[rt][h] = *reinterpret_cast<const f32x4*>(arow[rt] + (k < K ? k : K - 4));  // (zeroed at its use: a select here waits for the load)
+                }
+            const r6_u4* fb = frag + ((size_t)ks * NTall + nt0) * 192;
+            r6_u4* sbn = s_frag + (ks & 1) * FB;
+            if constexpr (!(CFD_R6_EXP & 4))
+            for (int u = wave; u < 3 * ntp; u += 4) cfd_glds16(fb + 64 * u + lane, sbn + 64 * u);
+        };
+        issue(0);
+        for (int ks = 0; ks < nks; ++ks) {
+            const r6_u4* sb = s_frag + (ks & 1) * FB;
+            CfdSplit8x3 as[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const bool in0 = 32 * ks + 8 * q < K, in1 = 32 * ks + 8 * q + 4 < K;  // 16-byte units past K (last slab) are zeros
+                const float x[8] = {in0 ? ar[rt][0][0] : 0.f, in0 ? ar[rt][0][1] : 0.f, in0 ? ar[rt][0][2] : 0.f, in0 ? ar[rt][0][3] : 0.f,
+                                    in1 ? ar[rt][1][0] : 0.f, in1 ? ar[rt][1][1] : 0.f, in1 ? ar[rt][1][2] : 0.f, in1 ? ar[rt][1][3] : 0.f};
+                as[rt] = cfd_split8x3(x);
+            }
+            __syncthreads();  // this slab's fragments have landed (requested one slab ago); the other buffer's readers are done
+            if (ks + 1 < nks) issue(ks + 1);
+            cfd_sched_fence();
+            // fully unrolled with uniform guards (a `break` kept the loop rolled and the accumulators in scratch memory); the fragments of
+            // column tile nt + 1 are requested before tile nt's MFMAs (the LDS latency of a tile's three reads was exposed per tile)
+            bf16x8 bq[2][3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bq[0][pc] = __builtin_bit_cast(bf16x8, sb[pc * 64 + lane]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (nt < ntp) {
+                    {   // unconditional (the last live tile re-reads itself): a guarded read joins the MFMAs behind a full lgkmcnt(0)
+                        const int nn = nt + 1 < ntp ? nt + 1 : nt;
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) bq[(nt + 1) & 1][pc] = __builtin_bit_cast(bf16x8, sb[(nn * 3 + pc) * 64 + lane]);
+                    }
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // cfd_mfma_bf16x6's products, small terms first
+#pragma unroll
+                    for (int p = 0; p < 6; ++p)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            if constexpr (CFD_R6_EXP & 1) acc[rt][nt][p & 3] += (float)as[rt].p[PA[p]][rt] * (float)bq[nt & 1][PB[p]][p];
+                            else acc[rt][nt] = cfd_mfma16x16x32_bf16(as[rt].p[PA[p]], bq[nt & 1][PB[p]], acc[rt][nt]);
+                        }
+                }
+            }
+        }
+        __syncthreads();  // the next pass refills buffer 0
+        // acc[rt][nt][r] = C[row0 + 16 rt + 4 q + r][16 (nt0 + nt) + n].  Stores through a raw buffer resource (32-bit offsets, rows / columns
+        // past the matrix dropped by the range check: no branch and no 64-bit address per element -- 104 elements per lane and pass), the
+        // bias once per column tile.
+        const CfdBuf bC = cfd_buf(C, 4u * (unsigned)((size_t)(M - 1) * ldc + N));
+        const CfdBuf bP = cfd_buf(epi.preact ? epi.preact : C, 4u * (unsigned)((size_t)(M - 1) * ldc + N));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt >= ntp) continue;
+            const int col = 16 * (nt0 + nt) + n;
+            const bool cok = col < N;
+            const float bv = (epi.mode == 1 && epi.bias && cok) ? epi.bias[col] : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + 16 * rt + 4 * q + r;
+                    const bool ok = cok && row < M;
+                    const unsigned off = ok ? 4u * (unsigned)(row * ldc + col) : CFD_BUF_OOB;
+                    float v = acc[rt][nt][r];
+                    if (epi.mode == 1) {
+                        v += bv;
+                        if (epi.preact) cfd_buf_st(bP, off, 0, v);
+                        v = cfd_act(v, epi.act);
+                    } else if (epi.mode == 3) {
+                        const size_t o = (size_t)(ok ? row : 0) * epi.ldr + (ok ? col : 0);
+                        v *= cfd_act_grad(epi.resid[o], epi.gz_z ? epi.gz_z[o] : 0.f, epi.act);
+                    }
+                    if (!(CFD_R6_EXP & 8) || v == 1.2345f) cfd_buf_st(bC, off, 0, v);
+                }
+        }
+    }
+}
+
+static size_t rowgemm6_frag_bytes(int N, int K) {
+    const long NTall = (N + 15) / 16, nks = (K + 31) / 32;
+    return cfd_align_up((size_t)(nks * NTall * 3 * 64) * sizeof(r6_u4), 256);
+}
+// (A: M x K row-major with row stride lda; trans: see k_rowgemm6_prep)
+static bool rowgemm6_covers(int M, int N, int K, const float* A, int lda, const GemmEpi& epi) {
+    const int knob = cfd_tune_get(CFD_TUNE_GEMM_B3);  // 0 = never, 2 = at any row count (tests)
+    if (knob == 0 || cfd_tune_get(CFD_TUNE_EXACT_FP32) == 1) return false;
+    // tall, small second operand; by default from 160 columns / reduction indices (measured inside the legs, HBM-cold: 131 k x 200 x 200
+    // 130 against 160-167 us, 131 k x 512 x 512 465 against 690 us, but 256 k x 100 x 100 109 against 87 / 102 us: the pass machinery is
+    // sized for 13 column tiles and K = 100 pads its last 32-slab by 28 %)
+    const int lo = knob == 2 ? 16 : 160;
+    if (M < (knob == 2 ? 1 : 4096) || N < lo || N > 1024 || K < lo || K > 1024) return false;
+    if ((K & 3) || (lda & 3) || ((uintptr_t)A & 15)) return false;           // 16-byte units along a row
+    if (epi.mode == 2 || epi.ones1 || epi.out2) return false;
+    if ((size_t)M * (N > K ? N : K) * 4 >= (1ull << 31)) return false;  // 32-bit byte offsets into C (ldc <= max(N, K) at both call sites)
+    return true;
+}
+static int rowgemm6_run(const float* A, int lda, const float* W, int ldw, bool trans, float* C, int ldc, int M, int N, int K,
+                        const GemmEpi& epi, void* frag_ws, hipStream_t st, const char* what) {
+    const int NTall = (N + 15) / 16, nks = (K + 31) / 32;
+    const unsigned total = (unsigned)nks * NTall * 64;
+    unsigned pb = (total + 255) / 256;
+    if (pb > 512) pb = 512;
+    if (trans) hipLaunchKernelGGL((k_rowgemm6_prep<true>), dim3(pb), dim3(256), 0, st, W, ldw, (r6_u4*)frag_ws, N, K, NTall, nks);
+    else hipLaunchKernelGGL((k_rowgemm6_prep<false>), dim3(pb), dim3(256), 0, st, W, ldw, (r6_u4*)frag_ws, N, K, NTall, nks);
+    CFD_LAUNCH_CHECK(what);
+    constexpr size_t lds = 2 * (size_t)R6_NT * 192 * sizeof(r6_u4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_rowgemm6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    CFD_PROF_W("k_rowgemm6", st, 4.0 * ((double)M * K + (double)K * N + (double)M * N), 2.0 * M * (double)N * K);
+    hipLaunchKernelGGL(k_rowgemm6, dim3((unsigned)((M + 64 * R6_RT - 1) / (64 * R6_RT))), dim3(256), lds, st, A, lda, (const r6_u4*)frag_ws, C,
+                       ldc, M, N, K, epi, NTall, nks);
+    CFD_LAUNCH_CHECK(what);
+    return CFD_OK;
+}
+
 extern "C" size_t cfd_gemm_workspace_bytes(int M, int N, int K) { return gemm_ws_bytes(M, N, K); }
 
 extern "C" int cfd_gemm(const float* a, const float* b, float* c, void* ws, int M, int N, int K, int lda, int ldb, int ldc,
@@ -401,7 +599,10 @@ extern "C" int cfd_gemm(const float* a, const float* b, float* c, void* ws, int 
 // ------------------------------------------------------------------------------------------------------
 // nn.Linear + activation  (ffn.py:23-31): y = act(x w^T + b), x (M,K), w (N,K), y (M,N)
 // ------------------------------------------------------------------------------------------------------
-extern "C" size_t cfd_linear_fwd_workspace_bytes(int M, int K, int N) { return gemm_ws_bytes(M, N, K); }
+extern "C" size_t cfd_linear_fwd_workspace_bytes(int M, int K, int N) {
+    const size_t a = gemm_ws_bytes(M, N, K), b = rowgemm6_frag_bytes(N, K);  // split-K partials or the weights' fragments (k_rowgemm6)
+    return a > b ? a : b;
+}
 
 extern "C" int cfd_linear_fwd(const float* x, const float* w, const float* bias, float* y, float* preact, void* ws, int M,
                               int K, int N, int act, void* stream) {
@@ -411,6 +612,8 @@ extern "C" int cfd_linear_fwd(const float* x, const float* w, const float* bias,
     CFD_REQUIRE(act < 3 || preact, CFD_ERR_INVALID_ARG, "cfd_linear_fwd: gelu / swish need the pre-activation buffer");
     GemmEpi epi{};
     epi.mode = 1; epi.act = act; epi.bias = bias; epi.preact = preact;
+    if (ws && M > 0 && rowgemm6_covers(M, N, K, x, K, epi))
+        return rowgemm6_run(x, K, w, K, false, y, N, M, N, K, epi, ws, (hipStream_t)stream, "cfd_linear_fwd");
     return launch_gemm(x, w, y, M, N, K, K, K, N, 0, 1, epi, ws, (hipStream_t)stream, "cfd_linear_fwd");
 }
 
@@ -541,7 +744,9 @@ static size_t colsum_ws_bytes(int M, int N) { return M >= 2048 ? cfd_align_up((s
 extern "C" size_t cfd_linear_bwd_workspace_bytes(int M, int K, int N) {
     if (M <= 0) return 0;
     const size_t gz = cfd_align_up((size_t)M * N * sizeof(float), 256);
-    const size_t a = gemm_ws_bytes(M, K, N), b = gemm_ws_bytes(N, K + 1, M);  // input gradient, weight gradient (+ the bias gradient's column)
+    size_t a = gemm_ws_bytes(M, K, N);
+    const size_t b = gemm_ws_bytes(N, K + 1, M);  // input gradient, weight gradient (+ the bias gradient's column)
+    if (rowgemm6_frag_bytes(K, N) > a) a = rowgemm6_frag_bytes(K, N);  // (the input gradient on k_rowgemm6: w's fragments)
     return gz + (a > b ? a : b) + colsum_ws_bytes(M, N);  // (+ room for the stand-alone column sum's partial rows: rounds 3-4, kept in the size)
 }
 
@@ -587,7 +792,8 @@ static int linear_bwd(const float* gy, const float* x, const float* w, const flo
     if (gx) {
         GemmEpi ex{};
         if (in_act != 0) { ex.mode = 3; ex.act = in_act; ex.resid = x; ex.ldr = K; ex.gz_z = in_preact; }
-        CFD_TRY(launch_gemm(gz, w, gx, M, K, N, N, K, K, 0, 0, ex, skws, st, "cfd_linear_bwd(gx)"));
+        if (rowgemm6_covers(M, K, N, gz, N, ex)) CFD_TRY(rowgemm6_run(gz, N, w, K, true, gx, K, M, K, N, ex, skws, st, "cfd_linear_bwd(gx)"));
+        else CFD_TRY(launch_gemm(gz, w, gx, M, K, N, N, K, K, 0, 0, ex, skws, st, "cfd_linear_bwd(gx)"));
     }
     // gw = gz^T x, and gb = gz^T 1 as one more column of the same product (a row of ones behind x's K columns): no separate pass
     // over gz for the bias gradient (k_colsum_part + k_colsum_final: 38 us per 256 k x 100 layer)
@@ -597,7 +803,9 @@ static int linear_bwd(const float* gy, const float* x, const float* w, const flo
     CFD_TRY(launch_gemm(gz, x, gw, N, gb_rides ? K + 1 : K, M, N, K, K, 1, 0, ew, skws, st, "cfd_linear_bwd(gw)"));
     if (gb && !gb_rides) {
         if (colsum_ws_bytes(M, N)) {
-            const size_t a = gemm_ws_bytes(M, K, N), b = gemm_ws_bytes(N, K + 1, M);
+            size_t a = gemm_ws_bytes(M, K, N);
+            const size_t b = gemm_ws_bytes(N, K + 1, M);
+            if (rowgemm6_frag_bytes(K, N) > a) a = rowgemm6_frag_bytes(K, N);
             float* part = (float*)((char*)skws + (a > b ? a : b));
             const int nchunk = colsum_chunks(M), rpc = (M + nchunk - 1) / nchunk;
             CFD_PROF_W("k_colsum", st, 4.0 * M * (double)N, (double)M * N);

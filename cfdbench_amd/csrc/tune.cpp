@@ -49,6 +49,7 @@ Knob g_knobs[CFD_TUNE_COUNT] = {
                                                  // VALU kernels of spectral.hip), 1 = wherever the shape allows (tests: small batches); default: 20 channels and >= 128 entries
     {CFD_TUNE_MODE_BC, "mode_bc", "CFD_MODE_BC", {-1}},            // batch entries per chunk of the modes.hip kernels (tests: several chunks and ragged stages at small batches)
     {CFD_TUNE_STEM_DFT, "stem_dft", "CFD_STEM_DFT", {-1}},          // the lifting layer fused into the first forward transform (k_dft_fwd64_b3<.., STEM>, round 6; 64 x 64, in_chan 2): default below 128 batch entries (rollouts), 1 = always, 0 = never
+    {CFD_TUNE_GEMM_B3, "gemm_b3", "CFD_GEMM_B3", {-1}},            // 0 = tall Linear products (M >= 4096, N, K <= 1024) stay on the fp32 MFMA kernel k_gemm instead of the three-piece bf16 kernel k_rowgemm6 (round 6); 2 = k_rowgemm6 at any row count (tests)
 };
 std::once_flag g_once;
 void read_env() {

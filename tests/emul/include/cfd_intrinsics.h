@@ -1,6 +1,7 @@
 // Emulator twin of cfdbench_amd/csrc/cfd_intrinsics.h (same function names, host semantics).
 // TEST INFRASTRUCTURE ONLY.
 #pragma once
+#include <cstring>
 #include <hip/hip_runtime.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -67,6 +68,9 @@ inline float cfd_wave_sum(float v) {
 }
 
 inline void cfd_wave_lds_sync() { cfd_emul::wave_sync(); }
+
+// global -> LDS copy of 16 bytes per lane: destination = wave-uniform base + 16 * lane (global_load_lds_dwordx4)
+inline void cfd_glds16(const void* g_lane, void* lds_wave_base) { std::memcpy((char*)lds_wave_base + 16 * cfd_emul::lane(), g_lane, 16); }
 
 inline int cfd_opaque(int x) { return x; }
 inline float cfd_opaque_f(float x) { return x; }

@@ -719,6 +719,47 @@ def check_ffn_stack(be, R, dims, act, act_last=False, with_gx=True, seed=29):
     return res
 
 
+def check_linear_rowgemm6(be, M, K, N, act, in_act=None, seed=41, force=True):
+    """Round 6: a Linear layer's forward product and input gradient on k_rowgemm6 (three-piece bf16 operands, the weights pre-split
+    into MFMA fragments; tall products, M >= 4096 by default -- `force`: gemm_b3 = 2 runs it at any row count) against the fp64 layer,
+    and against the fp32-MFMA kernel (gemm_b3 = 0): both are fp32-exact-class, they differ by accumulation order only."""
+    from oracle import deeponet_oracle as D
+    api, P = be.api, be.ptr
+    code = {"none": 0, "relu": 1, "tanh": 2, "gelu": 3, "swish": 4}
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal((N,)).astype(np.float32) * 0.3
+    gy = rng.standard_normal((M, N)).astype(np.float32)
+    xin = x
+    xpre = None
+    if in_act:  # x is the output of a previous layer with activation in_act (the input gradient leaves as that layer's dZ)
+        xpre = x
+        xin = D.act(x.astype(f64), in_act).astype(np.float32)
+    outs = {}
+    for knob in ((2 if force else -1), 0):
+        with tuned(be, gemm_b3=knob):
+            dx, dw, db, dgy = be.dev(xin), be.dev(w), be.dev(b), be.dev(gy)
+            dxpre = be.dev(xpre) if xpre is not None else None
+            y, pre = be.zeros((M, N)), be.zeros((M, N))
+            wsf = be.bytes(api.size("cfd_linear_fwd_workspace_bytes", M, K, N))
+            api.call("cfd_linear_fwd", P(dx), P(dw), P(db), P(y), P(pre), P(wsf), M, K, N, code[act], be.stream)
+            gx, gw, gb = be.zeros((M, K)), be.zeros((N, K)), be.zeros((N,))
+            wsb = be.bytes(api.size("cfd_linear_bwd_workspace_bytes", M, K, N))
+            api.call("cfd_linear_bwd_ex", P(dgy), P(dx), P(dw), P(y), P(pre), P(gx), P(gw), P(gb), P(wsb), M, K, N, code[act],
+                     code[in_act] if in_act else 0, P(dxpre) if dxpre is not None else None, be.stream)
+            be.sync()
+            outs[knob] = (be.host(y), be.host(pre), be.host(gx), be.host(gw), be.host(gb))
+    z = xin.astype(f64) @ w.astype(f64).T + b
+    gz = gy.astype(f64) * D.act_grad(z, act)
+    gx_ref = gz @ w.astype(f64)
+    if in_act:
+        gx_ref = gx_ref * D.act_grad(xpre.astype(f64), in_act)
+    a, c = outs[2 if force else -1], outs[0]
+    return {"y": nm(a[0], D.act(z, act)), "pre": nm(a[1], z), "gx": nm(a[2], gx_ref), "gw": nm(a[3], gz.T @ xin.astype(f64)),
+            "gb": nm(a[4], gz.sum(0)), "y_vs_fp32_kernel": nm(a[0], c[0].astype(f64)), "gx_vs_fp32_kernel": nm(a[2], c[2].astype(f64))}
+
+
 def check_linear_chain_bwd(be, M, K, N, in_act, seed=37):
     """cfd_linear_bwd_ex with in_act: the input gradient leaves the GEMM as the previous layer's dZ = (gz w) * in_act'(x) -- against
     the fp64 product and, bit for bit, against cfd_linear_bwd followed by cfd_act_bwd (one fp32 multiply after the same GEMM)."""

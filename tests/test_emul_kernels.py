@@ -535,3 +535,14 @@ def test_lifting_layer_fused_into_the_first_transform_is_bitwise(be, B, C, L, p,
     model's predictions and gradients equal the two-launch route bit for bit."""
     res = K.check_stem_dft_fusion(be, B, C, L, p, border)
     assert all(v == 0.0 for v in res.values()), res
+
+
+@pytest.mark.parametrize("M,K_in,N,act,in_act", [(300, 40, 24, "relu", None), (150, 100, 100, "gelu", "relu"), (260, 36, 230, "tanh", "tanh"), (129, 16, 16, "none", None), (70, 200, 52, "swish", "gelu")])
+def test_linear_on_three_piece_bf16_operands(be, M, K_in, N, act, in_act):
+    """k_rowgemm6 (round 6): forward product with bias / activation / pre-activation copy and the input gradient with the previous layer's
+    activation derivative in the epilogue, weights pre-split into fragments; row counts that are no multiples of 128, column counts with a
+    ragged last tile and a second pass (N > 208), K with a ragged last slab.  fp64 layer to the kernel-test tolerance; 1e-12 of the fp32-MFMA
+    kernel's result."""
+    res = K.check_linear_rowgemm6(be, M, K_in, N, act, in_act)
+    assert res.pop("y_vs_fp32_kernel") < 1e-12 and res.pop("gx_vs_fp32_kernel") < 1e-12
+    _assert_all(res)
