@@ -586,6 +586,189 @@ static int rowgemm6_run(const float* A, int lda, const float* W, int ldw, bool t
     return CFD_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// The weight gradient of a tall Linear layer on the same operands: gw[n][k] = sum_m gz[m][n] x[m][k] (M rows, N, K <= 1024), and the
+// bias gradient gb[n] = sum_m gz[m][n] as a virtual column K of ones behind x's columns (Kx = K + 1) when K is no multiple of 128.
+// Both MFMA operands are COLUMNS of row-major matrices -- eight consecutive rows m of one column per lane -- so the blocks are
+// transposed on their way into LDS: a staging item is (8 rows, 4 columns): eight 16-byte loads, regrouped in registers into four
+// column octets, split into three bf16 pieces and written as whole fragment units [tile][piece][lane].
+// Workgroup (256 threads) = a chunk of rows x up to 13 n-tiles (208 columns of gz) x 8 k-tiles (128 columns of x); wave w owns k-tiles
+// 2 w, 2 w + 1 and all n-tiles: 26 accumulator tiles; per step of 32 rows 45 fragment reads feed 156 MFMAs per wave.  The next step's
+// loads wait in registers while this step's MFMAs run.  Partial sums per chunk: part[chunk][n][Kx], reduced by k_splitk_reduce.
+// ------------------------------------------------------------------------------------------------------
+#define W6_NT 13  // n-tiles per workgroup
+#define W6_KT 8   // k-tiles per workgroup (two per wave)
+__global__ __launch_bounds__(256, 2) void k_rowwgrad6(const float* __restrict__ gz, const float* __restrict__ x, float* __restrict__ part,
+                                                      int M, int N, int K, int Kx, int rows_per_chunk) {
+    CFD_DYN_SHARED(f32x4, s_dyn);  // [A fragments W6_NT x 3 x 64 | B fragments W6_KT x 3 x 64] 16-byte units
+    r6_u4* const s_a = reinterpret_cast<r6_u4*>(s_dyn);
+    r6_u4* const s_b = s_a + W6_NT * 192;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = (int)blockIdx.z * (16 * W6_NT), k0 = (int)blockIdx.y * (16 * W6_KT);
+    const int ntl = (N - n0 + 15) / 16 < W6_NT ? (N - n0 + 15) / 16 : W6_NT;     // (uniform) live n-tiles
+    const int ktl = (Kx - k0 + 15) / 16 < W6_KT ? (Kx - k0 + 15) / 16 : W6_KT;   // live k-tiles
+    const int m_beg = (int)blockIdx.x * rows_per_chunk;
+    const int m_end = m_beg + rows_per_chunk < M ? m_beg + rows_per_chunk : M;
+    // staging items of this thread: slot 0 = item tid, slot 1 = item tid + 256.  Items [0, 208): gz, (row octet o = i / 52, column group
+    // cg = i % 52); items [208, 336): x, (o = j / 32, cg = j % 32) with j = i - 208.  A column group is four consecutive columns.
+    constexpr int NA = 4 * (4 * W6_NT), NB = 4 * (4 * W6_KT);
+    int it_oct[2], it_col[2], it_unit[2];  // row octet, first column (matrix coordinates), first LDS unit of the item's four columns
+    int it_kind[2];                        // 0 gz, 1 x, 2 the column of ones, -1 none
+    const float* it_base[2];
+    int it_ld[2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int i = tid + 256 * sl;
+        it_kind[sl] = -1; it_oct[sl] = 0; it_col[sl] = 0; it_unit[sl] = 0; it_base[sl] = gz; it_ld[sl] = N;
+        if (i < NA) {
+            const int o = i / (4 * W6_NT), cg = i - o * (4 * W6_NT), col = n0 + 4 * cg;
+            if (col < N) { it_kind[sl] = 0; it_oct[sl] = o; it_col[sl] = col; it_unit[sl] = ((4 * cg) >> 4) * 192 + o * 16 + ((4 * cg) & 15); }
+        } else if (i < NA + NB) {
+            const int j = i - NA, o = j / (4 * W6_KT), cg = j - o * (4 * W6_KT), col = k0 + 4 * cg;
+            if (col < Kx) {
+                it_kind[sl] = col < K ? 1 : 2; it_oct[sl] = o; it_col[sl] = col; it_base[sl] = x; it_ld[sl] = K;
+                it_unit[sl] = W6_NT * 192 + ((4 * cg) >> 4) * 192 + o * 16 + ((4 * cg) & 15);
+            }
+        }
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[W6_NT][2];
+#pragma unroll
+    for (int nt = 0; nt < W6_NT; ++nt) acc[nt][0] = acc[nt][1] = zero;
+    f32x4 rg[2][8];  // raw rows of the two items: rg[slot][row of the octet] = four consecutive columns
+    const auto issue = [&](int m0) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            if (it_kind[sl] == 0 || it_kind[sl] == 1) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int row = m0 + 8 * it_oct[sl] + r;
+                    rg[sl][r] = *reinterpret_cast<const f32x4*>(it_base[sl] + (size_t)(row < m_end ? row : m_end - 1) * it_ld[sl] + it_col[sl]);
+                }
+            }
+        }
+    };
+    if (m_beg < m_end) issue(m_beg);
+    for (int m0 = m_beg; m0 < m_end; m0 += 32) {
+        __syncthreads();  // the previous step's fragments are consumed
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            if (it_kind[sl] < 0) continue;
+            // four columns x eight rows -> four column octets (rows past the chunk are zeros; the virtual column: ones)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const bool in = m0 + 8 * it_oct[sl] + r < m_end;
+                    v[r] = !in ? 0.f : (it_kind[sl] == 2 ? (c == 0 ? 1.f : 0.f) : rg[sl][r][c]);
+                }
+                const CfdSplit8x3 sp = cfd_split8x3(v);
+                r6_u4* dst = s_a + it_unit[sl] + c;  // (columns of one group stay inside one 16-column tile: 4 | 16)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) dst[pc * 64] = __builtin_bit_cast(r6_u4, sp.p[pc]);
+            }
+        }
+        __syncthreads();
+        if (m0 + 32 < m_end) issue(m0 + 32);
+        cfd_sched_fence();
+        bf16x8 bq[2][3];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int kt = 2 * wave + kk < ktl ? 2 * wave + kk : 0;  // (a dead k-tile re-reads tile 0: its accumulators are never stored)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bq[kk][pc] = __builtin_bit_cast(bf16x8, s_b[(kt * 3 + pc) * 64 + lane]);
+        }
+        bf16x8 aq[2][3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) aq[0][pc] = __builtin_bit_cast(bf16x8, s_a[pc * 64 + lane]);
+#pragma unroll
+        for (int nt = 0; nt < W6_NT; ++nt) {
+            if (nt < ntl) {
+                {
+                    const int nn = nt + 1 < ntl ? nt + 1 : nt;
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) aq[(nt + 1) & 1][pc] = __builtin_bit_cast(bf16x8, s_a[(nn * 3 + pc) * 64 + lane]);
+                }
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) acc[nt][kk] = cfd_mfma16x16x32_bf16(aq[nt & 1][PA[p]], bq[kk][PB[p]], acc[nt][kk]);
+            }
+        }
+    }
+    // acc[nt][kk][r] = gw[n0 + 16 nt + 4 q + r][k0 + 16 (2 wave + kk) + n]
+    const int q = lane >> 4, n = lane & 15;
+    float* dst = part + (size_t)blockIdx.x * N * Kx;
+#pragma unroll
+    for (int nt = 0; nt < W6_NT; ++nt) {
+        if (nt >= ntl) continue;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int col = k0 + 16 * (2 * wave + kk) + n;
+            if (2 * wave + kk >= ktl || col >= Kx) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = n0 + 16 * nt + 4 * q + r;
+                if (row < N) dst[(size_t)row * Kx + col] = acc[nt][kk][r];
+            }
+        }
+    }
+}
+
+static bool gb_rides6(int K) { return (K % (16 * W6_KT)) != 0; }  // (else the column of ones would open a k-group of its own)
+static int roww6_chunks(int M, int N, int Kx) {
+    const long groups = (long)((Kx + 16 * W6_KT - 1) / (16 * W6_KT)) * ((N + 16 * W6_NT - 1) / (16 * W6_NT));
+    long chunks = (512 + groups - 1) / groups;  // two workgroups per CU
+    const long maxc = (M + 255) / 256;          // at least 256 rows (8 steps) per chunk
+    if (chunks > maxc) chunks = maxc;
+    return chunks < 1 ? 1 : (int)chunks;
+}
+static size_t roww6_ws_bytes(int M, int N, int K) {  // with or without the column of ones (the chunk count depends on it): the larger
+    const size_t a = (size_t)roww6_chunks(M, N, K) * N * K, b = (size_t)roww6_chunks(M, N, K + 1) * N * (K + 1);
+    return cfd_align_up((a > b ? a : b) * sizeof(float), 256);
+}
+static bool roww6_covers(int M, int N, int K, const float* gz, const float* x) {
+    const int knob = cfd_tune_get(CFD_TUNE_GEMM_B3);
+    if (knob == 0 || cfd_tune_get(CFD_TUNE_EXACT_FP32) == 1) return false;
+    const int lo = knob == 2 ? 16 : 160;
+    if (M < (knob == 2 ? 1 : 4096) || N < lo || N > 1024 || K < lo || K > 1024) return false;
+    if ((N & 3) || (K & 3) || (((uintptr_t)gz | (uintptr_t)x) & 15)) return false;
+    return true;
+}
+// gw (N, K) and, if gb != NULL and it can ride, gb (N); returns whether gb was produced
+static int roww6_run(const float* gz, const float* x, float* gw, float* gb, void* ws, int M, int N, int K, bool* gb_done, hipStream_t st,
+                     const char* what) {
+    const bool ride = gb && gb_rides6(K);
+    const int Kx = ride ? K + 1 : K;
+    const int chunks = roww6_chunks(M, N, Kx);
+    int rpc = (M + chunks - 1) / chunks;
+    rpc = (rpc + 31) / 32 * 32;
+    const int nchunk = (M + rpc - 1) / rpc;
+    CFD_REQUIRE(nchunk <= chunks, CFD_ERR_WORKSPACE, "%s: %d row chunks planned, %d launched", what, chunks, nchunk);  // (the workspace is sized by `chunks`)
+    const dim3 grid((unsigned)nchunk, (unsigned)((Kx + 16 * W6_KT - 1) / (16 * W6_KT)), (unsigned)((N + 16 * W6_NT - 1) / (16 * W6_NT)));
+    constexpr size_t lds = (size_t)(W6_NT + W6_KT) * 192 * sizeof(r6_u4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_rowwgrad6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    CFD_PROF_W("k_rowwgrad6", st, 4.0 * ((double)M * K + (double)M * N + (double)N * K), 2.0 * M * (double)N * K);
+    hipLaunchKernelGGL(k_rowwgrad6, grid, dim3(256), lds, st, gz, x, (float*)ws, M, N, K, Kx, rpc);
+    CFD_LAUNCH_CHECK(what);
+    GemmEpi epi{};
+    if (ride) { epi.ones1 = K + 1; epi.out2 = gb; }
+    CFD_PROF_W("k_splitk_reduce", st, 0.0, 0.0);
+    size_t blocks = ((size_t)N * Kx + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, gw, N, Kx, K, nchunk, epi);
+    CFD_LAUNCH_CHECK(what);
+    *gb_done = ride;
+    return CFD_OK;
+}
+
 extern "C" size_t cfd_gemm_workspace_bytes(int M, int N, int K) { return gemm_ws_bytes(M, N, K); }
 
 extern "C" int cfd_gemm(const float* a, const float* b, float* c, void* ws, int M, int N, int K, int lda, int ldb, int ldc,
@@ -745,8 +928,9 @@ extern "C" size_t cfd_linear_bwd_workspace_bytes(int M, int K, int N) {
     if (M <= 0) return 0;
     const size_t gz = cfd_align_up((size_t)M * N * sizeof(float), 256);
     size_t a = gemm_ws_bytes(M, K, N);
-    const size_t b = gemm_ws_bytes(N, K + 1, M);  // input gradient, weight gradient (+ the bias gradient's column)
+    size_t b = gemm_ws_bytes(N, K + 1, M);  // input gradient, weight gradient (+ the bias gradient's column)
     if (rowgemm6_frag_bytes(K, N) > a) a = rowgemm6_frag_bytes(K, N);  // (the input gradient on k_rowgemm6: w's fragments)
+    if (roww6_ws_bytes(M, N, K) > b) b = roww6_ws_bytes(M, N, K);      // (the weight gradient on k_rowwgrad6: partial sums per row chunk)
     return gz + (a > b ? a : b) + colsum_ws_bytes(M, N);  // (+ room for the stand-alone column sum's partial rows: rounds 3-4, kept in the size)
 }
 
@@ -798,14 +982,19 @@ static int linear_bwd(const float* gy, const float* x, const float* w, const flo
     // gw = gz^T x, and gb = gz^T 1 as one more column of the same product (a row of ones behind x's K columns): no separate pass
     // over gz for the bias gradient (k_colsum_part + k_colsum_final: 38 us per 256 k x 100 layer)
     GemmEpi ew{};
-    const bool gb_rides = gb && (K % 64) != 0 && cfd_tune_get(CFD_TUNE_GEMM_TILE) <= 0;  // (K a multiple of 64: the column would add a column block)
-    if (gb_rides) { ew.ones1 = K + 1; ew.out2 = gb; }
-    CFD_TRY(launch_gemm(gz, x, gw, N, gb_rides ? K + 1 : K, M, N, K, K, 1, 0, ew, skws, st, "cfd_linear_bwd(gw)"));
+    bool gb_rides = gb && (K % 64) != 0 && cfd_tune_get(CFD_TUNE_GEMM_TILE) <= 0;  // (K a multiple of 64: the column would add a column block)
+    if (roww6_covers(M, N, K, gz, x)) {  // tall layers: the three-piece bf16 kernel (round 6)
+        CFD_TRY(roww6_run(gz, x, gw, gb, skws, M, N, K, &gb_rides, st, "cfd_linear_bwd(gw)"));
+    } else {
+        if (gb_rides) { ew.ones1 = K + 1; ew.out2 = gb; }
+        CFD_TRY(launch_gemm(gz, x, gw, N, gb_rides ? K + 1 : K, M, N, K, K, 1, 0, ew, skws, st, "cfd_linear_bwd(gw)"));
+    }
     if (gb && !gb_rides) {
         if (colsum_ws_bytes(M, N)) {
             size_t a = gemm_ws_bytes(M, K, N);
-            const size_t b = gemm_ws_bytes(N, K + 1, M);
+            size_t b = gemm_ws_bytes(N, K + 1, M);
             if (rowgemm6_frag_bytes(K, N) > a) a = rowgemm6_frag_bytes(K, N);
+            if (roww6_ws_bytes(M, N, K) > b) b = roww6_ws_bytes(M, N, K);
             float* part = (float*)((char*)skws + (a > b ? a : b));
             const int nchunk = colsum_chunks(M), rpc = (M + nchunk - 1) / nchunk;
             CFD_PROF_W("k_colsum", st, 4.0 * M * (double)N, (double)M * N);

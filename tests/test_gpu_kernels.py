@@ -603,9 +603,17 @@ def test_linear_on_three_piece_bf16_operands(be, M, K_in, N, act, in_act):
     _assert_all(res)
 
 
-@pytest.mark.parametrize("M,K_in,N,act,in_act", [(8192, 200, 200, "relu", "relu"), (4100, 160, 176, "gelu", None), (5000, 512, 512, "relu", "relu")])
+@pytest.mark.parametrize("M,K_in,N,act,in_act", [(8192, 200, 200, "relu", "relu"), (4100, 160, 176, "gelu", None), (5000, 512, 512, "tanh", "tanh")])
 def test_tall_linear_products_run_on_the_three_piece_kernel_by_default(be, M, K_in, N, act, in_act):
     """The shapes of the Auto-FFN / DeepONet / Auto-DeepONet-CNN layers (>= 4096 rows) take k_rowgemm6 without any knob."""
     res = K.check_linear_rowgemm6(be, M, K_in, N, act, in_act, force=False)
+    assert res.pop("y_vs_fp32_kernel") < 1e-12 and res.pop("gx_vs_fp32_kernel") < 1e-12
+    _assert_all(res)
+
+
+def test_tall_linear_layer_at_the_cnn_models_row_count(be):
+    """131072 x 512 x 512 (the Auto-DeepONet-CNN's output FFN): the weight gradient's row chunks are planned WITHOUT the column of ones here
+    (K % 128 == 0) -- the workspace was once sized for the plan with it (fewer chunks): a write past its end."""
+    res = K.check_linear_rowgemm6(be, 131072, 512, 512, "tanh", "tanh", force=False)  # (smooth activations: at 67 M pre-activations a ReLU mask differs between the fp64 layer and any fp32 kernel in a few elements)
     assert res.pop("y_vs_fp32_kernel") < 1e-12 and res.pop("gx_vs_fp32_kernel") < 1e-12
     _assert_all(res)
