@@ -733,7 +733,7 @@ static size_t roww6_ws_bytes(int M, int N, int K) {  // with or without the colu
 static bool roww6_covers(int M, int N, int K, const float* gz, const float* x) {
     const int knob = cfd_tune_get(CFD_TUNE_GEMM_B3);
     if (knob == 0 || cfd_tune_get(CFD_TUNE_EXACT_FP32) == 1) return false;
-    const int lo = knob == 2 ? 16 : 160;
+    const int lo = knob == 2 ? 16 : 96;  // (the weight gradient wins from width ~100: 256 k x 100 x 100 69.5 us against 135.7; DeepONet leg 3.74 -> 3.39 ms)
     if (M < (knob == 2 ? 1 : 4096) || N < lo || N > 1024 || K < lo || K > 1024) return false;
     if ((N & 3) || (K & 3) || (((uintptr_t)gz | (uintptr_t)x) & 15)) return false;
     return true;
