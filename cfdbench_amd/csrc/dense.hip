@@ -430,10 +430,14 @@ __global__ __launch_bounds__(256) void k_rowgemm6_prep(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_rowgemm6(const float* __restrict__ A, int lda, const r6_u4* __restrict__ frag,
+// <NT, RT>: column tiles per pass, 16-row tiles per wave.  <13, 2>: up to 208 columns per pass on 128-row workgroups, two per CU;
+// <7, 1>: layers of at most 112 columns (the DeepONets' width 100) on 64-row workgroups of ~100 registers, four per CU -- such a product
+// is memory-bound (204 MB for 0.5 GFLOP-class work per layer) and needs the occupancy more than the fragment reuse
+template <int NT, int RT>
+__global__ __launch_bounds__(256, RT == 1 ? 4 : 2) void k_rowgemm6(const float* __restrict__ A, int lda, const r6_u4* __restrict__ frag,
                                                      float* __restrict__ C, int ldc, int M, int N, int K, GemmEpi epi, int NTall,
                                                      int nks) {
-    constexpr int NT = R6_NT, RT = R6_RT, FB = NT * 192;  // 16-byte units of one pass's fragments per slab
+    constexpr int FB = NT * 192;  // 16-byte units of one pass's fragments per slab
     CFD_DYN_SHARED(f32x4, s_dyn);                         // (one extern array type per translation unit) [2][FB] 16-byte units
     r6_u4* const s_frag = reinterpret_cast<r6_u4*>(s_dyn);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -554,10 +558,11 @@ static size_t rowgemm6_frag_bytes(int N, int K) {
 static bool rowgemm6_covers(int M, int N, int K, const float* A, int lda, const GemmEpi& epi) {
     const int knob = cfd_tune_get(CFD_TUNE_GEMM_B3);  // 0 = never, 2 = at any row count (tests)
     if (knob == 0 || cfd_tune_get(CFD_TUNE_EXACT_FP32) == 1) return false;
-    // tall, small second operand; by default from 160 columns / reduction indices (measured inside the legs, HBM-cold: 131 k x 200 x 200
-    // 130 against 160-167 us, 131 k x 512 x 512 465 against 690 us, but 256 k x 100 x 100 109 against 87 / 102 us: the pass machinery is
-    // sized for 13 column tiles and K = 100 pads its last 32-slab by 28 %)
-    const int lo = knob == 2 ? 16 : 160;
+    // tall, small second operand; by default from 160 columns / reduction indices on the <13, 2> shape (measured inside the legs, HBM-cold:
+    // 131 k x 200 x 200 130 against 160-167 us, 131 k x 512 x 512 465 against 690 us; 256 k x 100 x 100 109 against 87 / 102 us there: the
+    // pass machinery is sized for 13 column tiles and K = 100 pads its last 32-slab by 28 %), width ~100 on the light <7, 1> shape
+    const bool narrow = N >= 96 && N <= 112 && K >= 96;  // the <7, 1> shape (DeepONet width 100: 75.9 us against 87 / 102 on k_gemm)
+    const int lo = knob == 2 ? 16 : (narrow ? 96 : 160);
     if (M < (knob == 2 ? 1 : 4096) || N < lo || N > 1024 || K < lo || K > 1024) return false;
     if ((K & 3) || (lda & 3) || ((uintptr_t)A & 15)) return false;           // 16-byte units along a row
     if (epi.mode == 2 || epi.ones1 || epi.out2) return false;
@@ -573,15 +578,21 @@ static int rowgemm6_run(const float* A, int lda, const float* W, int ldw, bool t
     if (trans) hipLaunchKernelGGL((k_rowgemm6_prep<true>), dim3(pb), dim3(256), 0, st, W, ldw, (r6_u4*)frag_ws, N, K, NTall, nks);
     else hipLaunchKernelGGL((k_rowgemm6_prep<false>), dim3(pb), dim3(256), 0, st, W, ldw, (r6_u4*)frag_ws, N, K, NTall, nks);
     CFD_LAUNCH_CHECK(what);
-    constexpr size_t lds = 2 * (size_t)R6_NT * 192 * sizeof(r6_u4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_rowgemm6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     CFD_PROF_W("k_rowgemm6", st, 4.0 * ((double)M * K + (double)K * N + (double)M * N), 2.0 * M * (double)N * K);
-    hipLaunchKernelGGL(k_rowgemm6, dim3((unsigned)((M + 64 * R6_RT - 1) / (64 * R6_RT))), dim3(256), lds, st, A, lda, (const r6_u4*)frag_ws, C,
-                       ldc, M, N, K, epi, NTall, nks);
+#define R6_LAUNCH(NT_, RT_)                                                                                                              \
+    do {                                                                                                                                 \
+        constexpr size_t lds = 2 * (size_t)NT_ * 192 * sizeof(r6_u4);                                                                    \
+        static bool attr_set = false;                                                                                                    \
+        if (!attr_set) {                                                                                                                 \
+            (void)hipFuncSetAttribute((const void*)k_rowgemm6<NT_, RT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+            attr_set = true;                                                                                                             \
+        }                                                                                                                                \
+        hipLaunchKernelGGL((k_rowgemm6<NT_, RT_>), dim3((unsigned)((M + 64 * RT_ - 1) / (64 * RT_))), dim3(256), lds, st, A, lda,        \
+                           (const r6_u4*)frag_ws, C, ldc, M, N, K, epi, NTall, nks);                                                     \
+    } while (0)
+    if (NTall <= 7) R6_LAUNCH(7, 1);
+    else R6_LAUNCH(R6_NT, R6_RT);
+#undef R6_LAUNCH
     CFD_LAUNCH_CHECK(what);
     return CFD_OK;
 }

@@ -603,7 +603,7 @@ def test_linear_on_three_piece_bf16_operands(be, M, K_in, N, act, in_act):
     _assert_all(res)
 
 
-@pytest.mark.parametrize("M,K_in,N,act,in_act", [(8192, 200, 200, "relu", "relu"), (4100, 160, 176, "gelu", None), (5000, 512, 512, "tanh", "tanh"), (6000, 100, 100, "tanh", "tanh")])
+@pytest.mark.parametrize("M,K_in,N,act,in_act", [(8192, 200, 200, "relu", "relu"), (4100, 160, 176, "gelu", None), (5000, 512, 512, "tanh", "tanh"), (6000, 100, 100, "tanh", "tanh"), (4500, 100, 112, "gelu", "tanh")])
 def test_tall_linear_products_run_on_the_three_piece_kernel_by_default(be, M, K_in, N, act, in_act):
     """The shapes of the Auto-FFN / DeepONet / Auto-DeepONet-CNN layers (>= 4096 rows) take k_rowgemm6 without any knob."""
     res = K.check_linear_rowgemm6(be, M, K_in, N, act, in_act, force=False)
