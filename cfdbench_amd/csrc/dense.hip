@@ -399,16 +399,15 @@ static int launch_gemm(const float* A, const float* B, float* C, int M, int N, i
 //   * Bw is split ONCE per call into MFMA fragment order by k_rowgemm6_prep: frag[((ks * NTall + nt) * 3 + piece) * 64 + lane],
 //     lane (q, n): column 16 nt + n, reduction indices 32 ks + 8 q .. + 7.  TRANS: Bw[k][col] stored [k][col] (the input gradient gz w),
 //     else stored [col][k] (the forward x w^T).
-//   * workgroup = 128 rows (four waves x two 16-row tiles) x ALL columns in passes of R6_NT column tiles; per K slab of 32 the pass's
-//     fragments go global -> registers -> LDS (double-buffered, one barrier per slab) and feed both row tiles of every wave; the A rows
-//     come straight from global memory in operand order (a lane's eight reduction indices are 32 contiguous bytes) and are split in
-//     registers.  The next slab's loads are in flight during this slab's MFMAs.
+//   * workgroup = 64 rows (four waves x one 16-row tile) x ALL columns in passes of R6_NT column tiles; per K slab of 32 the pass's
+//     fragments go global -> LDS directly (cfd_glds16) and the A rows come straight from global memory in operand order (a lane's eight
+//     reduction indices are 32 contiguous bytes), split in registers.  The next slab's A loads are in flight during this slab's MFMAs;
+//     four workgroups per CU cover each other's barriers and fragment loads.
 // ------------------------------------------------------------------------------------------------------
 #define R6_NT 13
 #ifndef CFD_R6_EXP
 #define CFD_R6_EXP 0  // timing experiments (results WRONG): 1 no MFMAs, 2 no A loads, 4 no fragment loads, 8 no stores
 #endif
-#define R6_RT 2
 typedef cfd_u32x4 r6_u4;
 
 template <bool TRANS>
@@ -433,7 +432,9 @@ __global__ __launch_bounds__(256) void k_rowgemm6_prep(const float* __restrict__
 // <NT, RT>: column tiles per pass, 16-row tiles per wave.  <13, 2>: up to 208 columns per pass on 128-row workgroups, two per CU;
 // <7, 1>: layers of at most 112 columns (the DeepONets' width 100) on 64-row workgroups of ~100 registers, four per CU -- such a product
 // is memory-bound (204 MB for 0.5 GFLOP-class work per layer) and needs the occupancy more than the fragment reuse
-template <int NT, int RT>
+// NBUF: LDS buffers of a pass's fragments.  2: the next slab's fragments land while this slab's MFMAs run (one barrier per slab); 1: they are
+// requested behind a second barrier -- half the LDS (39 KB at 13 column tiles), so that four light workgroups share a CU
+template <int NT, int RT, int NBUF = 2>
 __global__ __launch_bounds__(256, RT == 1 ? 4 : 2) void k_rowgemm6(const float* __restrict__ A, int lda, const r6_u4* __restrict__ frag,
                                                      float* __restrict__ C, int ldc, int M, int N, int K, GemmEpi epi, int NTall,
                                                      int nks) {
@@ -463,6 +464,12 @@ __global__ __launch_bounds__(256, RT == 1 ? 4 : 2) void k_rowgemm6(const float* 
         // loads of slab ks: the A rows unconditional from clamped addresses (a 16-byte unit past K is zeroed after the load: K % 4 == 0);
         // the pass's fragments straight into LDS buffer ks & 1 (cfd_glds16: 1 KB per wave instruction, no registers -- through
         // registers the 40 VGPRs of the fragment units spilled the kernel), rows of 64 units dealt to the four waves
+        const auto issue_b = [&](int ks) {
+            const r6_u4* fb = frag + ((size_t)ks * NTall + nt0) * 192;
+            r6_u4* sbn = s_frag + (NBUF == 2 ? (ks & 1) * FB : 0);
+            if constexpr (!(CFD_R6_EXP & 4))
+            for (int u = wave; u < 3 * ntp; u += 4) cfd_glds16(fb + 64 * u + lane, sbn + 64 * u);
+        };
         const auto issue = [&](int ks) {
             const int k0 = 32 * ks + 8 * q;
 #pragma unroll
@@ -473,14 +480,12 @@ __global__ __launch_bounds__(256, RT == 1 ? 4 : 2) void k_rowgemm6(const float* 
                     if constexpr (CFD_R6_EXP & 2) ar[rt][h] = f32x4{(float)k, 1.f, 2.f, (float)ks};
                     else ar[rt][h] = *reinterpret_cast<const f32x4*>(arow[rt] + (k < K ? k : K - 4));  // (zeroed at its use: a select here waits for the load)
                 }
-            const r6_u4* fb = frag + ((size_t)ks * NTall + nt0) * 192;
-            r6_u4* sbn = s_frag + (ks & 1) * FB;
-            if constexpr (!(CFD_R6_EXP & 4))
-            for (int u = wave; u < 3 * ntp; u += 4) cfd_glds16(fb + 64 * u + lane, sbn + 64 * u);
+            if constexpr (NBUF == 2) issue_b(ks);
         };
         issue(0);
+        if constexpr (NBUF == 1) issue_b(0);
         for (int ks = 0; ks < nks; ++ks) {
-            const r6_u4* sb = s_frag + (ks & 1) * FB;
+            const r6_u4* sb = s_frag + (NBUF == 2 ? (ks & 1) * FB : 0);
             CfdSplit8x3 as[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -513,6 +518,12 @@ __global__ __launch_bounds__(256, RT == 1 ? 4 : 2) void k_rowgemm6(const float* 
                             if constexpr (CFD_R6_EXP & 1) acc[rt][nt][p & 3] += (float)as[rt].p[PA[p]][rt] * (float)bq[nt & 1][PB[p]][p];
                             else acc[rt][nt] = cfd_mfma16x16x32_bf16(as[rt].p[PA[p]], bq[nt & 1][PB[p]], acc[rt][nt]);
                         }
+                }
+            }
+            if constexpr (NBUF == 1) {
+                if (ks + 1 < nks) {
+                    __syncthreads();  // every wave has read this slab's fragments
+                    issue_b(ks + 1);
                 }
             }
         }
@@ -579,19 +590,21 @@ static int rowgemm6_run(const float* A, int lda, const float* W, int ldw, bool t
     else hipLaunchKernelGGL((k_rowgemm6_prep<false>), dim3(pb), dim3(256), 0, st, W, ldw, (r6_u4*)frag_ws, N, K, NTall, nks);
     CFD_LAUNCH_CHECK(what);
     CFD_PROF_W("k_rowgemm6", st, 4.0 * ((double)M * K + (double)K * N + (double)M * N), 2.0 * M * (double)N * K);
-#define R6_LAUNCH(NT_, RT_)                                                                                                              \
+#define R6_LAUNCH(NT_, RT_, NB_)                                                                                                         \
     do {                                                                                                                                 \
-        constexpr size_t lds = 2 * (size_t)NT_ * 192 * sizeof(r6_u4);                                                                    \
+        constexpr size_t lds = NB_ * (size_t)NT_ * 192 * sizeof(r6_u4);                                                                  \
         static bool attr_set = false;                                                                                                    \
         if (!attr_set) {                                                                                                                 \
-            (void)hipFuncSetAttribute((const void*)k_rowgemm6<NT_, RT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+            (void)hipFuncSetAttribute((const void*)k_rowgemm6<NT_, RT_, NB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
             attr_set = true;                                                                                                             \
         }                                                                                                                                \
-        hipLaunchKernelGGL((k_rowgemm6<NT_, RT_>), dim3((unsigned)((M + 64 * RT_ - 1) / (64 * RT_))), dim3(256), lds, st, A, lda,        \
+        hipLaunchKernelGGL((k_rowgemm6<NT_, RT_, NB_>), dim3((unsigned)((M + 64 * RT_ - 1) / (64 * RT_))), dim3(256), lds, st, A, lda,        \
                            (const r6_u4*)frag_ws, C, ldc, M, N, K, epi, NTall, nks);                                                     \
     } while (0)
-    if (NTall <= 7) R6_LAUNCH(7, 1);
-    else R6_LAUNCH(R6_NT, R6_RT);
+    // light shapes (one row tile per wave, four workgroups per CU): the product is memory-bound and its phases do not overlap inside a
+    // workgroup -- 131 k x 200 x 200: 86 us on <13, 1, 1> against 118 on the first shape (two row tiles per wave, 235 VGPRs, two per CU)
+    if (NTall <= 7) R6_LAUNCH(7, 1, 2);
+    else R6_LAUNCH(R6_NT, 1, 1);
 #undef R6_LAUNCH
     CFD_LAUNCH_CHECK(what);
     return CFD_OK;
