@@ -745,7 +745,10 @@ __global__ __launch_bounds__(256, 2) void k_rowwgrad6(const float* __restrict__ 
 static bool gb_rides6(int K) { return (K % (16 * W6_KT)) != 0; }  // (else the column of ones would open a k-group of its own)
 static int roww6_chunks(int M, int N, int Kx) {
     const long groups = (long)((Kx + 16 * W6_KT - 1) / (16 * W6_KT)) * ((N + 16 * W6_NT - 1) / (16 * W6_NT));
-    long chunks = (512 + groups - 1) / groups;  // two workgroups per CU
+#ifndef CFD_W6_WGS
+#define CFD_W6_WGS 512  // workgroups aimed at (two per CU); measured (tools/build_variant.sh -DCFD_W6_WGS=..): 256 / 384 / 512: DeepONet leg 3.30 / 3.23 / 3.13 ms, Auto-FFN 2.90 / 2.88 / 2.70
+#endif
+    long chunks = (CFD_W6_WGS + groups - 1) / groups;
     const long maxc = (M + 255) / 256;          // at least 256 rows (8 steps) per chunk
     if (chunks > maxc) chunks = maxc;
     return chunks < 1 ? 1 : (int)chunks;
