@@ -40,7 +40,7 @@ class FfnStackArgs(C.Structure):
 
 
 _P = C.c_void_p
-ABI_VERSION = 600  # include/cfdbench_amd.h: CFD_ABI_VERSION
+ABI_VERSION = 601  # include/cfdbench_amd.h: CFD_ABI_VERSION
 _I = C.c_int
 _F = C.c_float
 _Z = C.c_size_t
@@ -81,6 +81,8 @@ _SIGS = {
     "cfd_loss_scores_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "cfd_mse_loss_fwd": (_I, [_P, _P, _P, _P, _P, _Z, _P]),
     "cfd_mse_loss_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "cfd_mse_loss_fwd_ld": (_I, [_P, _P, _P, _P, _P, _Z, _Z, _Z, _P]),
+    "cfd_mse_loss_bwd_ld": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _Z, _Z, _P]),
     "cfd_loss_coef": (_I, [_P, _P, _I, _F, _P]),
     "cfd_label_energy_workspace_bytes": (_Z, []),
     "cfd_label_energy_coef": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),

@@ -1161,6 +1161,98 @@ extern "C" int cfd_mse_loss_bwd(const float* preds, const float* labels, const f
     return CFD_OK;
 }
 
+// ---- the same with STRIDED label rows (round 6): labels (rows, cols) with row stride ldl >= cols -- a channel slice label[:, 0] of a
+// (B, C, H, W) tensor viewed as (B, H W) -- so that the caller need not make it contiguous first (one copy launch and 2 n floats of traffic
+// per Auto-DeepONet step).  preds, gp: contiguous (rows, cols).  Same operations per element in the same order as the contiguous kernels
+// (the element -> (row, column) split is the only difference); n < 2^31.
+__global__ __launch_bounds__(256) void k_loss_part_ld(const float* __restrict__ p, const float* __restrict__ l, unsigned n, CfdDiv dcols,
+                                                      unsigned cols, unsigned ldl, float* __restrict__ part) {
+    __shared__ float s_r[3 * 4];
+    const unsigned stride = gridDim.x * blockDim.x;
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const auto lab = [&](unsigned e) {
+        const unsigned r = cfd_div(e, dcols);
+        return l[(size_t)r * ldl + (e - r * cols)];
+    };
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (; (size_t)i + 3 * (size_t)stride < n; i += 4 * stride) {
+        float pv[4], lv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pv[k] = p[i + k * stride]; lv[k] = lab(i + k * stride); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d = pv[k] - lv[k];
+            a = fmaf(d, d, a);
+            b += fabsf(d);
+            c = fmaf(lv[k], lv[k], c);
+        }
+    }
+    for (; i < n; i += stride) {
+        const float lv = lab(i), d = p[i] - lv;
+        a = fmaf(d, d, a);
+        b += fabsf(d);
+        c = fmaf(lv, lv, c);
+    }
+    a = cfd_wave_sum(a); b = cfd_wave_sum(b); c = cfd_wave_sum(c);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_r[wave] = a; s_r[4 + wave] = b; s_r[8 + wave] = c; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float* s = s_r + 4 * threadIdx.x;
+        part[blockIdx.x * 3 + threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+    }
+}
+
+extern "C" int cfd_mse_loss_fwd_ld(const float* preds, const float* labels, float* sums, float* scores, void* ws, size_t rows, size_t cols,
+                                   size_t ldl, void* stream) {
+    CFD_REQUIRE(preds && labels && sums && scores && ws, CFD_ERR_INVALID_ARG, "cfd_mse_loss_fwd_ld: NULL pointer");
+    CFD_REQUIRE(rows >= 1 && cols >= 1 && ldl >= cols, CFD_ERR_INVALID_ARG, "cfd_mse_loss_fwd_ld: bad shape (rows %zu, cols %zu, ldl %zu)", rows, cols, ldl);
+    const size_t n = rows * cols;
+    if (ldl == cols) return cfd_mse_loss_fwd(preds, labels, sums, scores, ws, n, stream);
+    CFD_REQUIRE(n < (1ull << 31) && ldl < (1ull << 31), CFD_ERR_UNSUPPORTED, "cfd_mse_loss_fwd_ld: %zu elements (max 2^31 - 1)", n);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_loss_part_ld, dim3(CFD_LOSS_BLOCKS), dim3(256), 0, st, preds, labels, (unsigned)n, cfd_div_make((unsigned)cols),
+                       (unsigned)cols, (unsigned)ldl, (float*)ws);
+    CFD_LAUNCH_CHECK("cfd_mse_loss_fwd_ld(part)");
+    hipLaunchKernelGGL(k_loss_final_scores, dim3(1), dim3(64), 0, st, (const float*)ws, CFD_LOSS_BLOCKS, (float)n, sums, scores);
+    CFD_LAUNCH_CHECK("cfd_mse_loss_fwd_ld(final)");
+    return CFD_OK;
+}
+
+__global__ __launch_bounds__(256) void k_mse_loss_bwd_ld(const float* __restrict__ p, const float* __restrict__ l, const float* __restrict__ sums,
+                                                         const float* __restrict__ g_mse, const float* __restrict__ g_rmse,
+                                                         const float* __restrict__ g_mae, const float* __restrict__ g_nmse,
+                                                         float* __restrict__ gp, unsigned n, CfdDiv dcols, unsigned cols, unsigned ldl) {
+    const float cnt = sums[3];
+    const float mse = sums[0] / cnt, den = sums[2] / cnt;
+    float gm = g_mse ? g_mse[0] : 0.f;
+    if (g_rmse) gm += g_rmse[0] / (2.f * sqrtf(mse));
+    if (g_nmse) gm += g_nmse[0] / den;
+    const float g0 = gm / cnt, g1 = g_mae ? g_mae[0] / cnt : 0.f;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned r = cfd_div(i, dcols);
+        const float lv = l[(size_t)r * ldl + (i - r * cols)], d = p[i] - lv;
+        const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        gp[i] = g0 * 2.f * d + g1 * sg;
+    }
+}
+
+extern "C" int cfd_mse_loss_bwd_ld(const float* preds, const float* labels, const float* sums, const float* g_mse, const float* g_rmse,
+                                   const float* g_mae, const float* g_nmse, float* gp, size_t rows, size_t cols, size_t ldl, void* stream) {
+    CFD_REQUIRE(preds && labels && sums, CFD_ERR_INVALID_ARG, "cfd_mse_loss_bwd_ld: NULL pointer");
+    CFD_REQUIRE(cols >= 1 && ldl >= cols, CFD_ERR_INVALID_ARG, "cfd_mse_loss_bwd_ld: bad shape");
+    const size_t n = rows * cols;
+    if (n == 0 || !gp) return CFD_OK;
+    if (ldl == cols) return cfd_mse_loss_bwd(preds, labels, sums, g_mse, g_rmse, g_mae, g_nmse, gp, nullptr, n, stream);
+    CFD_REQUIRE(n < (1ull << 31) && ldl < (1ull << 31), CFD_ERR_UNSUPPORTED, "cfd_mse_loss_bwd_ld: %zu elements (max 2^31 - 1)", n);
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_mse_loss_bwd_ld, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, preds, labels, sums, g_mse, g_rmse, g_mae,
+                       g_nmse, gp, (unsigned)n, cfd_div_make((unsigned)cols), (unsigned)cols, (unsigned)ldl);
+    CFD_LAUNCH_CHECK("cfd_mse_loss_bwd_ld");
+    return CFD_OK;
+}
+
 __global__ void k_loss_coef(const float* __restrict__ sums, float* __restrict__ coef, int which, float upstream) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float c0 = 0.f, c1 = 0.f;

@@ -207,6 +207,17 @@ class LossScoresFn(torch.autograd.Function):
         return gsums
 
 
+def _row_strided(t: Tensor):
+    """(rows, cols, row stride) if `t` is a float32 NON-contiguous tensor whose rows t[i] are contiguous blocks at a uniform stride (a channel
+    slice x[:, 0] of a contiguous (B, C, H, W) tensor, or its (B, H W) view) -- else None."""
+    if t.dtype != torch.float32 or t.dim() < 2 or t.is_contiguous() or t.shape[0] < 1 or t.numel() == 0:
+        return None
+    cols = t.numel() // t.shape[0]
+    if not t[0].is_contiguous() or t.stride(0) < cols:
+        return None
+    return int(t.shape[0]), int(cols), int(t.stride(0))
+
+
 class MseLossFn(torch.autograd.Function):
     """(mse, rmse, mae, nmse) of MseLoss.forward (loss.py:22-37) as ONE autograd node: LossSumsFn + LossScoresFn took five launches per
     training step (partial sums, final sum, scores | score gradients, element gradients), this one takes three (cfd_mse_loss_fwd /
@@ -218,12 +229,22 @@ class MseLossFn(torch.autograd.Function):
         api = _lib.api()
         if preds.shape != labels.shape:
             raise RuntimeError(f"MseLoss: preds {tuple(preds.shape)} vs labels {tuple(labels.shape)}")
-        p, l = _f32c(preds), _f32c(labels)
+        p = _f32c(preds)
         n = p.numel()
         sums = torch.empty(4, dtype=torch.float32, device=p.device)
         scores = torch.empty(4, dtype=torch.float32, device=p.device)
         ws = _bytes(api.size("cfd_loss_workspace_bytes", n), p.device)
-        api.call("cfd_mse_loss_fwd", _ptr(p), _ptr(l), _ptr(sums), _ptr(scores), _ptr(ws), n, _stream())
+        # labels as strided rows (a channel slice label[:, 0] viewed as (B, H W): cfd_mse_loss_fwd_ld) -- no contiguous copy
+        ld = _row_strided(labels)
+        if ld is not None and not labels.requires_grad and n < 2 ** 31:
+            rows, cols, ldl = ld
+            l = labels.detach()
+            api.call("cfd_mse_loss_fwd_ld", _ptr(p), _ptr(l), _ptr(sums), _ptr(scores), _ptr(ws), rows, cols, ldl, _stream())
+            ctx.ld = ld
+        else:
+            l = _f32c(labels)
+            api.call("cfd_mse_loss_fwd", _ptr(p), _ptr(l), _ptr(sums), _ptr(scores), _ptr(ws), n, _stream())
+            ctx.ld = None
         ctx.save_for_backward(p, l, sums)
         ctx.set_materialize_grads(False)
         return scores[0], scores[1], scores[2], scores[3]
@@ -233,6 +254,10 @@ class MseLossFn(torch.autograd.Function):
         p, l, sums = ctx.saved_tensors
         gs = [None if g is None else _f32c(g) for g in (g_mse, g_rmse, g_mae, g_nmse)]
         gp = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        if ctx.ld is not None:
+            rows, cols, ldl = ctx.ld
+            _lib.api().call("cfd_mse_loss_bwd_ld", _ptr(p), _ptr(l), _ptr(sums), *[_ptr(g) for g in gs], _ptr(gp), rows, cols, ldl, _stream())
+            return gp, None
         gl = torch.empty_like(l) if ctx.needs_input_grad[1] else None
         _lib.api().call("cfd_mse_loss_bwd", _ptr(p), _ptr(l), _ptr(sums), *[_ptr(g) for g in gs], _ptr(gp), _ptr(gl), p.numel(), _stream())
         return gp, gl

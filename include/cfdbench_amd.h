@@ -40,7 +40,7 @@ extern "C" {
  * changes (500, round 5: the statistics records of cfd_conv2d_fwd_stats / cfd_batchnorm_fwd_stats are (C, slots, 4) floats since
  * round 4 -- a caller that still allocates (C, slots, 2) must fail at load time, not write out of bounds; the default of the
  * "act_pieces" knob is 3).  The Python binding refuses a library whose version differs (cfdbench_amd/_capi.py). */
-#define CFD_ABI_VERSION 600
+#define CFD_ABI_VERSION 601
 int cfd_version(void);
 const char* cfd_last_error(void);
 
@@ -191,6 +191,13 @@ int cfd_loss_scores_bwd(const float* sums, const float* g_mse, const float* g_rm
 int cfd_mse_loss_fwd(const float* preds, const float* labels, float* sums, float* scores, void* ws, size_t n, void* stream);
 int cfd_mse_loss_bwd(const float* preds, const float* labels, const float* sums, const float* g_mse, const float* g_rmse,
                      const float* g_mae, const float* g_nmse, float* gp, float* gl, size_t n, void* stream);
+/* The same with STRIDED label rows (ABI 601): labels (rows, cols) with row stride ldl >= cols elements -- the channel slice label[:, 0] of a
+ * (B, C, H, W) tensor viewed as (B, H W), which MseLoss receives from the Auto-DeepONet family (src/models/auto_deeponet.py:137-142) -- so
+ * that no contiguous copy is made first.  preds and gp are contiguous (rows, cols); the label gradient is not produced.  rows cols < 2^31. */
+int cfd_mse_loss_fwd_ld(const float* preds, const float* labels, float* sums, float* scores, void* ws, size_t rows, size_t cols, size_t ldl,
+                        void* stream);
+int cfd_mse_loss_bwd_ld(const float* preds, const float* labels, const float* sums, const float* g_mse, const float* g_rmse,
+                        const float* g_mae, const float* g_nmse, float* gp, size_t rows, size_t cols, size_t ldl, void* stream);
 /* coef for cfd_fno_head_bwd: which = 0 mse, 1 nmse, 2 mae; scaled by `upstream` (d objective / d loss).       */
 int cfd_loss_coef(const float* sums, float* coef, int which, float upstream, void* stream);
 /* The same coefficients BEFORE any prediction exists: d mse|nmse|mae / d preds need only the element count and

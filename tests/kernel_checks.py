@@ -719,6 +719,36 @@ def check_ffn_stack(be, R, dims, act, act_last=False, with_gx=True, seed=29):
     return res
 
 
+def check_mse_loss_strided_labels(be, rows, cols, ldl, seed=71):
+    """cfd_mse_loss_fwd_ld / _bwd_ld (ABI 601): labels as rows at stride ldl against the contiguous entry points on a contiguous copy -- sums,
+    scores and the prediction gradient bit for bit (the element -> (row, column) split is the only difference) -- and against fp64."""
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    preds = rng.standard_normal((rows, cols)).astype(np.float32)
+    big = rng.standard_normal((rows, ldl)).astype(np.float32)
+    lab = np.ascontiguousarray(big[:, :cols])
+    g = [np.array([v], np.float32) for v in (0.3, -0.2, 0.7, 1.1)]
+    dp, dbig, dlab = be.dev(preds), be.dev(big), be.dev(lab)
+    dg = [be.dev(v) for v in g]
+    out = {}
+    for name in ("ld", "contig"):
+        sums, scores, gp = be.zeros((4,)), be.zeros((4,)), be.zeros((rows, cols))
+        ws = be.bytes(api.size("cfd_loss_workspace_bytes", rows * cols))
+        if name == "ld":
+            api.call("cfd_mse_loss_fwd_ld", P(dp), P(dbig), P(sums), P(scores), P(ws), rows, cols, ldl, be.stream)
+            api.call("cfd_mse_loss_bwd_ld", P(dp), P(dbig), P(sums), *[P(v) for v in dg], P(gp), rows, cols, ldl, be.stream)
+        else:
+            api.call("cfd_mse_loss_fwd", P(dp), P(dlab), P(sums), P(scores), P(ws), rows * cols, be.stream)
+            api.call("cfd_mse_loss_bwd", P(dp), P(dlab), P(sums), *[P(v) for v in dg], P(gp), None, rows * cols, be.stream)
+        be.sync()
+        out[name] = (be.host(sums), be.host(scores), be.host(gp))
+    d = preds.astype(f64) - lab.astype(f64)
+    mse, den = float((d * d).mean()), float((lab.astype(f64) ** 2).mean())
+    ref = np.array([mse, np.sqrt(mse), np.abs(d).mean(), mse / den])
+    return {"sums_differ": float(np.max(np.abs(out["ld"][0] - out["contig"][0]))), "scores_differ": float(np.max(np.abs(out["ld"][1] - out["contig"][1]))),
+            "gp_differ": float(np.max(np.abs(out["ld"][2] - out["contig"][2]))), "scores_rel": float(np.max(np.abs(out["ld"][1] - ref) / ref))}
+
+
 def check_linear_rowgemm6(be, M, K, N, act, in_act=None, seed=41, force=True):
     """Round 6: a Linear layer's forward product and input gradient on k_rowgemm6 (three-piece bf16 operands, the weights pre-split
     into MFMA fragments; tall products, M >= 4096 by default -- `force`: gemm_b3 = 2 runs it at any row count) against the fp64 layer,

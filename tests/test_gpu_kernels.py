@@ -617,3 +617,12 @@ def test_tall_linear_layer_at_the_cnn_models_row_count(be):
     res = K.check_linear_rowgemm6(be, 131072, 512, 512, "tanh", "tanh", force=False)  # (smooth activations: at 67 M pre-activations a ReLU mask differs between the fp64 layer and any fp32 kernel in a few elements)
     assert res.pop("y_vs_fp32_kernel") < 1e-12 and res.pop("gx_vs_fp32_kernel") < 1e-12
     _assert_all(res)
+
+
+@pytest.mark.parametrize("rows,cols,ldl", [(7, 130, 260), (33, 4290, 8580), (1, 50, 77), (300, 3, 5)])
+def test_mse_loss_with_strided_label_rows(be, rows, cols, ldl):
+    """ABI 601: the loss entry points on label rows at a stride (a channel slice of a (B, C, H, W) label viewed as (B, H W)) == the contiguous
+    entry points on a copy, bit for bit; scores to fp32 round-off of the fp64 values."""
+    res = K.check_mse_loss_strided_labels(be, rows, cols, ldl)
+    assert res.pop("sums_differ") == 0.0 and res.pop("scores_differ") == 0.0 and res.pop("gp_differ") == 0.0
+    assert res["scores_rel"] < 1e-5

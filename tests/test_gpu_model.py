@@ -796,3 +796,23 @@ def test_train_engine_deferred_step_equals_the_step_with_its_own_launches(torch)
             assert O.rel_nmse(g, r) < 1e-11
         for s_, r_ in zip(got[2], ref[2]):
             assert np.allclose(s_, r_, rtol=2e-6, atol=0)
+
+
+@pytest.mark.gpu
+def test_mse_loss_takes_a_channel_slice_of_the_label_without_a_copy():
+    """functional.MseLossFn on label[:, 0] viewed as (B, H W) (what the Auto-DeepONet family passes): the strided entry points, results equal
+    to the contiguous path bit for bit, gradients included."""
+    import torch
+    from cfdbench_amd import functional as F_
+    g = torch.Generator().manual_seed(3)
+    label = torch.randn(6, 2, 11, 13, generator=g).cuda()
+    preds = torch.randn(6, 11 * 13, generator=g).cuda().requires_grad_(True)
+    strided = label[:, 0].reshape(6, -1)
+    assert not strided.is_contiguous() and F_._row_strided(strided) == (6, 143, 286)
+    out_s = F_.MseLossFn.apply(preds, strided)
+    (out_s[3] + 0.5 * out_s[0]).backward()
+    gs = preds.grad.clone()
+    preds.grad = None
+    out_c = F_.MseLossFn.apply(preds, strided.contiguous())
+    (out_c[3] + 0.5 * out_c[0]).backward()
+    assert all(torch.equal(a, b) for a, b in zip(out_s, out_c)) and torch.equal(gs, preds.grad)
