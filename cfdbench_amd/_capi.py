@@ -83,6 +83,7 @@ _SIGS = {
     "cfd_mse_loss_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "cfd_mse_loss_fwd_ld": (_I, [_P, _P, _P, _P, _P, _Z, _Z, _Z, _P]),
     "cfd_mse_loss_bwd_ld": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _Z, _Z, _P]),
+    "cfd_rows_concat2": (_I, [_P, _Z, _Z, _P, _Z, _Z, _P, _Z, _P]),
     "cfd_loss_coef": (_I, [_P, _P, _I, _F, _P]),
     "cfd_label_energy_workspace_bytes": (_Z, []),
     "cfd_label_energy_coef": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),

@@ -207,6 +207,17 @@ class LossScoresFn(torch.autograd.Function):
         return gsums
 
 
+def rows_concat2(a: Tensor, b: Tensor) -> Tensor:
+    """[a | b] along dim 1 for 2-D float32 CUDA tensors whose rows are contiguous (any row stride: a channel slice viewed as (B, H W)) in one
+    launch (cfd_rows_concat2); no autograd (the Auto-DeepONet family's branch input is assembled from tensors without gradients)."""
+    _require_cuda(a, b)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0] or a.stride(1) != 1 or b.stride(1) != 1 or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise RuntimeError("rows_concat2: (rows, ka) and (rows, kb) float32 tensors with unit inner stride")
+    out = torch.empty((a.shape[0], a.shape[1] + b.shape[1]), dtype=torch.float32, device=a.device)
+    _lib.api().call("cfd_rows_concat2", _ptr(a), a.stride(0), a.shape[1], _ptr(b), b.stride(0), b.shape[1], _ptr(out), a.shape[0], _stream())
+    return out
+
+
 def _row_strided(t: Tensor):
     """(rows, cols, row stride) if `t` is a float32 NON-contiguous tensor whose rows t[i] are contiguous blocks at a uniform stride (a channel
     slice x[:, 0] of a contiguous (B, C, H, W) tensor, or its (B, H W) view) -- else None."""

@@ -76,9 +76,15 @@ class AutoDeepONet(AutoCfdModel):
         # branch input [u.flatten(), case_params] (:109-116) assembled by two copies straight into one matrix (the reshape of the
         # strided channel view + torch.cat copied the field twice); its leading H*W columns double as the residual field below
         hw, n_p = height * width, case_params.shape[1]
-        flat_inputs = torch.empty((batch_size, hw + n_p), dtype=inputs.dtype, device=inputs.device)
-        flat_inputs[:, :hw].view(batch_size, height, width).copy_(inputs[:, 0])
-        flat_inputs[:, hw:].copy_(case_params)
+        u0 = inputs[:, 0]
+        if (inputs.is_cuda and inputs.dtype == torch.float32 and case_params.dtype == torch.float32 and n_p >= 1 and u0[0].is_contiguous()
+                and case_params.stride(-1) == 1 and not inputs.requires_grad and not case_params.requires_grad):
+            # one launch (cfd_rows_concat2) from the channel slice viewed as (B, H W) and the case parameters
+            flat_inputs = F_.rows_concat2(u0.reshape(batch_size, hw) if batch_size > 1 else u0.reshape(1, hw), case_params)
+        else:
+            flat_inputs = torch.empty((batch_size, hw + n_p), dtype=inputs.dtype, device=inputs.device)
+            flat_inputs[:, :hw].view(batch_size, height, width).copy_(u0)
+            flat_inputs[:, hw:].copy_(case_params)
         u = flat_inputs[:, :hw]
         full = query_idxs is None
         if full:

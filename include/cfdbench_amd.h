@@ -198,6 +198,10 @@ int cfd_mse_loss_fwd_ld(const float* preds, const float* labels, float* sums, fl
                         void* stream);
 int cfd_mse_loss_bwd_ld(const float* preds, const float* labels, const float* sums, const float* g_mse, const float* g_rmse,
                         const float* g_mae, const float* g_nmse, float* gp, size_t rows, size_t cols, size_t ldl, void* stream);
+/* out (rows, ka + kb) = [a | b] with a (rows, ka) at row stride lda and b (rows, kb) at row stride ldb (ABI 601): the branch input
+ * [u.flatten(), case_params] of the Auto-DeepONet family (src/models/auto_deeponet.py:109-116) from the field's channel slice and the case
+ * parameters in one launch.  rows (ka + kb) < 2^31.                                                                                   */
+int cfd_rows_concat2(const float* a, size_t lda, size_t ka, const float* b, size_t ldb, size_t kb, float* out, size_t rows, void* stream);
 /* coef for cfd_fno_head_bwd: which = 0 mse, 1 nmse, 2 mae; scaled by `upstream` (d objective / d loss).       */
 int cfd_loss_coef(const float* sums, float* coef, int which, float upstream, void* stream);
 /* The same coefficients BEFORE any prediction exists: d mse|nmse|mae / d preds need only the element count and

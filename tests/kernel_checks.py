@@ -719,6 +719,18 @@ def check_ffn_stack(be, R, dims, act, act_last=False, with_gx=True, seed=29):
     return res
 
 
+def check_rows_concat2(be, rows, ka, lda, kb, ldb, seed=73):
+    """cfd_rows_concat2: [a | b] from rows at strides lda / ldb, exactly."""
+    api, P = be.api, be.ptr
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((rows, lda)).astype(np.float32)
+    Bm = rng.standard_normal((rows, ldb)).astype(np.float32)
+    dA, dB, out = be.dev(A), be.dev(Bm), be.zeros((rows, ka + kb))
+    api.call("cfd_rows_concat2", P(dA), lda, ka, P(dB), ldb, kb, P(out), rows, be.stream)
+    be.sync()
+    return {"differs": float(np.max(np.abs(be.host(out) - np.concatenate([A[:, :ka], Bm[:, :kb]], axis=1))))}
+
+
 def check_mse_loss_strided_labels(be, rows, cols, ldl, seed=71):
     """cfd_mse_loss_fwd_ld / _bwd_ld (ABI 601): labels as rows at stride ldl against the contiguous entry points on a contiguous copy -- sums,
     scores and the prediction gradient bit for bit (the element -> (row, column) split is the only difference) -- and against fp64."""

@@ -555,3 +555,8 @@ def test_mse_loss_with_strided_label_rows(be, rows, cols, ldl):
     res = K.check_mse_loss_strided_labels(be, rows, cols, ldl)
     assert res.pop("sums_differ") == 0.0 and res.pop("scores_differ") == 0.0 and res.pop("gp_differ") == 0.0
     assert res["scores_rel"] < 1e-5
+
+
+@pytest.mark.parametrize("rows,ka,lda,kb,ldb", [(5, 130, 260, 5, 5), (33, 4290, 8580, 8, 8), (1, 7, 7, 3, 9)])
+def test_rows_concat2(be, rows, ka, lda, kb, ldb):
+    assert K.check_rows_concat2(be, rows, ka, lda, kb, ldb)["differs"] == 0.0
